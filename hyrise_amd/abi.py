@@ -1,0 +1,134 @@
+"""ctypes mirror of include/hyrise_amd.h -- the C ABI of the MI355X hot path.
+
+Python is plumbing only (tests, bench, multi-GPU launch); the product is libhyrise_amd.so.  Loading fails loudly when
+the HIP library has not been built: there is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhyrise_amd.so")
+
+# enums ---------------------------------------------------------------------------------------------------------------
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_CAPACITY = 0, 1, 2, 3, 4
+TYPE_NULL, TYPE_INT, TYPE_LONG, TYPE_FLOAT, TYPE_DOUBLE, TYPE_STRING = range(6)
+(PRED_EQUALS, PRED_NOT_EQUALS, PRED_LESS_THAN, PRED_LESS_THAN_EQUALS, PRED_GREATER_THAN, PRED_GREATER_THAN_EQUALS,
+ PRED_BETWEEN_INCLUSIVE, PRED_BETWEEN_LOWER_EXCLUSIVE, PRED_BETWEEN_UPPER_EXCLUSIVE, PRED_BETWEEN_EXCLUSIVE,
+ PRED_IN, PRED_NOT_IN, PRED_LIKE, PRED_NOT_LIKE, PRED_LIKE_INSENSITIVE, PRED_NOT_LIKE_INSENSITIVE,
+ PRED_IS_NULL, PRED_IS_NOT_NULL) = range(18)
+(JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL_OUTER, JOIN_CROSS, JOIN_SEMI, JOIN_ANTI_NULL_AS_TRUE,
+ JOIN_ANTI_NULL_AS_FALSE) = range(8)
+AGG_MIN, AGG_MAX, AGG_SUM, AGG_AVG, AGG_COUNT, AGG_COUNT_DISTINCT, AGG_STDDEV_SAMP, AGG_ANY = range(8)
+ENC_UNENCODED, ENC_DICTIONARY, ENC_FRAME_OF_REFERENCE, ENC_REFERENCE = range(4)
+MEM_HOST, MEM_DEVICE = 0, 1
+CHUNK_SCANNED, CHUNK_ALL_MATCH, CHUNK_NONE_MATCH = 0, 1, 2
+INVALID_VALUE_ID = 0xFFFFFFFF
+INVALID_CHUNK_ID = 0xFFFFFFFF
+FOR_BLOCK_SIZE = 2048
+SCAN_MATERIALIZE_ALL_MATCH = 1
+CHUNK_DEFAULT_SIZE = 65535  # Chunk::DEFAULT_SIZE, storage/chunk.hpp:52
+
+
+class RowID(C.Structure):
+    _fields_ = [("chunk_id", C.c_uint32), ("chunk_offset", C.c_uint32)]
+
+
+class Segment(C.Structure):
+    _fields_ = [("encoding", C.c_uint32), ("data_type", C.c_uint32), ("size", C.c_uint32), ("width", C.c_uint32),
+                ("data", C.c_void_p), ("aux", C.c_void_p), ("aux_size", C.c_uint32), ("ref_chunk_id", C.c_uint32),
+                ("nulls", C.c_void_p), ("ref", C.c_void_p)]
+
+
+class Value(C.Union):
+    _fields_ = [("i32", C.c_int32), ("i64", C.c_int64), ("f32", C.c_float), ("f64", C.c_double),
+                ("value_id", C.c_uint32)]
+
+
+class Predicate(C.Structure):
+    _fields_ = [("condition", C.c_uint32), ("value_type", C.c_uint32), ("value", Value), ("value2", Value),
+                ("per_chunk_lower", C.c_void_p), ("per_chunk_upper", C.c_void_p), ("per_chunk_found", C.c_void_p),
+                ("column_is_nullable", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ScanResult(C.Structure):
+    _fields_ = [("mem", C.c_uint32), ("flags", C.c_uint32), ("matches", C.c_void_p), ("capacity", C.c_uint64),
+                ("offsets", C.c_void_p), ("counts", C.c_void_p), ("chunk_state", C.c_void_p),
+                ("total_matches", C.c_uint64)]
+
+
+class JoinResult(C.Structure):
+    _fields_ = [("mem", C.c_uint32), ("radix_bits", C.c_uint32), ("left_pos", C.c_void_p), ("right_pos", C.c_void_p),
+                ("capacity", C.c_uint64), ("slice_offsets", C.c_void_p), ("slice_capacity", C.c_uint32),
+                ("n_slices", C.c_uint32), ("n_pairs", C.c_uint64), ("left_is_build", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class AggregateSpec(C.Structure):
+    _fields_ = [("function", C.c_uint32), ("column", C.c_void_p)]
+
+
+class AggregateColumn(C.Structure):
+    _fields_ = [("data_type", C.c_uint32), ("reserved", C.c_uint32), ("values", C.c_void_p), ("is_null", C.c_void_p)]
+
+
+class AggregateResult(C.Structure):
+    _fields_ = [("mem", C.c_uint32), ("group_capacity", C.c_uint32), ("n_groups", C.c_uint32),
+                ("reserved", C.c_uint32), ("group_row_ids", C.c_void_p), ("columns", C.POINTER(AggregateColumn))]
+
+
+# every symbol include/hyrise_amd.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("hy_abi_version", C.c_int32, []),
+    ("hy_init", C.c_int32, [C.c_int32]),
+    ("hy_shutdown", C.c_int32, []),
+    ("hy_last_error", C.c_char_p, []),
+    ("hy_set_stream", C.c_int32, [C.c_void_p]),
+    ("hy_synchronize", C.c_int32, []),
+    ("hy_device_malloc", C.c_int32, [C.POINTER(C.c_void_p), C.c_size_t]),
+    ("hy_device_free", C.c_int32, [C.c_void_p]),
+    ("hy_memcpy_h2d", C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("hy_memcpy_d2h", C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("hy_device_count", C.c_int32, [C.POINTER(C.c_int32)]),
+    ("hy_column_create", C.c_int32, [C.POINTER(Segment), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("hy_column_destroy", C.c_int32, [C.c_void_p]),
+    ("hy_column_row_count", C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("hy_column_chunk_count", C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("hy_table_scan", C.c_int32, [C.c_void_p, C.POINTER(Predicate), C.c_void_p, C.c_uint32, C.POINTER(ScanResult)]),
+    ("hy_table_scan_columns", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ScanResult)]),
+    ("hy_join_hash", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinResult)]),
+    ("hy_join_hash_radix_bits", C.c_int32, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),
+    ("hy_join_hash_count", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("hy_aggregate_hash", C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(AggregateSpec), C.c_uint32,
+                                      C.POINTER(AggregateResult)]),
+]
+
+
+class HyriseAmdError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"hyrise_amd status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libhyrise_amd.so (built by __graft_entry__.build()); raises if it is missing -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). hyrise_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OK:
+        raise HyriseAmdError(status, load_library().hy_last_error().decode("utf-8", "replace"))

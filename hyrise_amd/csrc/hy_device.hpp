@@ -1,0 +1,108 @@
+// hy_device.hpp -- internal declarations shared by the HIP translation units behind include/hyrise_amd.h.
+// gfx950 (MI355X / CDNA4) only: wave64, 256 CUs in 8 XCDs, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hyrise_amd.h"
+
+namespace hy {
+
+// ---- device-side view of one segment (48 bytes, read through the scalar/L2 path by every workgroup) ---------------
+struct DevSegment {
+  const void* data;            // values | attribute vector | FoR offsets | pos list (hy_row_id)
+  const void* aux;             // dictionary | block minima
+  const uint64_t* nulls;       // null bitmap or nullptr
+  const DevSegment* ref;       // REFERENCE: segments of the referenced column
+  uint32_t size;
+  uint32_t aux_size;
+  uint32_t ref_chunk_id;
+  uint8_t encoding;
+  uint8_t data_type;
+  uint8_t width;
+  uint8_t flags;               // SEG_*
+};
+enum : uint8_t { SEG_UNALIGNED = 1 };
+
+// A contiguous run of at most SLICE_ROWS rows of one chunk: the unit of work of the scan / materialise kernels.
+struct Slice {
+  uint32_t chunk;
+  uint32_t row_begin;
+  uint32_t row_count;
+  uint32_t first_of_chunk;     // 1 if row_begin == 0
+};
+
+constexpr uint32_t WG_THREADS = 256;
+constexpr uint32_t ROWS_PER_THREAD = 32;
+constexpr uint32_t SLICE_ROWS = WG_THREADS * ROWS_PER_THREAD;   // 8192
+
+}  // namespace hy
+
+// The opaque ABI type.
+struct hy_column {
+  uint32_t n_chunks = 0;
+  uint32_t data_type = HY_TYPE_NULL;
+  uint64_t rows = 0;
+  bool is_reference = false;
+  bool multi_chunk_reference = false;       // some pos list spans several referenced chunks
+  bool has_dictionary_without_values = false;
+  const hy_column* ref = nullptr;
+  std::vector<hy_segment> host_segments;    // caller's descriptors (pointers patched to device addresses)
+  std::vector<uint64_t> row_base;           // [n_chunks + 1] prefix sum of sizes
+  hy::DevSegment* d_segments = nullptr;
+  hy::Slice* d_slices = nullptr;
+  uint32_t n_slices = 0;
+  std::vector<void*> owned;                 // device allocations freed with the column
+};
+
+namespace hy {
+
+// ---- errors ---------------------------------------------------------------------------------------------------------
+hy_status fail(hy_status code, const char* fmt, ...);
+#define HY_HIP(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t err__ = (expr);                                                                            \
+    if (err__ != hipSuccess)                                                                              \
+      return ::hy::fail(HY_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), __FILE__, __LINE__); \
+  } while (0)
+#define HY_TRY(expr)                    \
+  do {                                  \
+    hy_status st__ = (expr);            \
+    if (st__ != HY_OK) return st__;     \
+  } while (0)
+
+hipStream_t current_stream();
+
+// ---- per-thread scratch (status words for decoupled look-back, job tables, temporaries) ----------------------------
+// Every operator call of a thread reuses one growing arena; thread-safe because it is thread-local, as are streams.
+struct Scratch {
+  void* base = nullptr;
+  size_t capacity = 0;
+  size_t used = 0;
+  uint32_t* ticket = nullptr;     // monotonically increasing work-ticket counter (never reset: base passed per launch)
+  uint32_t ticket_base = 0;
+  uint32_t epoch = 0;             // tag of the current launch in look-back status words (30 bits, never 0)
+  uint64_t* status = nullptr;     // look-back status words; used for NOTHING else, so stale words carry older epochs
+  size_t status_capacity = 0;
+  hy_status reserve(size_t bytes);   // ensure capacity (may reallocate: only call before carving)
+  hy_status begin_launch(size_t status_words, uint32_t tickets);  // new epoch; returns with status/ticket_base valid
+  void* carve(size_t bytes);         // 256-byte aligned sub-allocation of the arena
+  void reset() { used = 0; }
+};
+Scratch& scratch();
+
+template <typename T>
+inline T* carve(Scratch& s, size_t count) {
+  return static_cast<T*>(s.carve(sizeof(T) * (count ? count : 1)));
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace hy

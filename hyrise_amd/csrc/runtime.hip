@@ -1,0 +1,338 @@
+// runtime.hip -- process/device runtime behind the C ABI: device selection, thread-local stream + error text,
+// the per-thread scratch arena, and the residency cache (hy_column) that makes encoded segments device-visible once.
+// One process per GPU (hy_init(device)); every ABI call is thread-safe and re-entrant: the only shared mutable state
+// is thread-local (reference threading contract: scan_chunk is invoked concurrently from many workers,
+// table_scan.cpp:129-131 -- here one call covers all chunks, and concurrent calls come from different threads).
+#include "hy_device.hpp"
+
+#include <cstring>
+
+namespace hy {
+
+static thread_local std::string t_error;
+static thread_local hipStream_t t_stream = nullptr;
+static thread_local Scratch t_scratch;
+
+hy_status fail(hy_status code, const char* fmt, ...) {
+  char buffer[1024];
+  va_list args;
+  va_start(args, fmt);
+  vsnprintf(buffer, sizeof(buffer), fmt, args);
+  va_end(args);
+  t_error = buffer;
+  return code;
+}
+
+hipStream_t current_stream() { return t_stream; }
+
+Scratch& scratch() { return t_scratch; }
+
+hy_status Scratch::reserve(size_t bytes) {
+  bytes = align_up(bytes + 4096, 1 << 20);
+  if (!ticket) {
+    HY_HIP(hipMalloc(reinterpret_cast<void**>(&ticket), 256));
+    HY_HIP(hipMemset(ticket, 0, 256));
+    ticket_base = 0;
+    epoch = 0;
+  }
+  if (bytes > capacity) {
+    if (base) {
+      HY_HIP(hipStreamSynchronize(t_stream));
+      HY_HIP(hipFree(base));
+      base = nullptr;
+      capacity = 0;
+    }
+    HY_HIP(hipMalloc(&base, bytes));
+    capacity = bytes;
+  }
+  used = 0;
+  return HY_OK;
+}
+
+// Starts a new look-back epoch.  Status words are tagged {state:2, epoch:30, value:32}; the buffer holds nothing but
+// status words, so anything left from earlier launches carries an older epoch and reads as "not yet published".
+// The ticket counter is never reset either: the launch subtracts ticket_base.
+hy_status Scratch::begin_launch(size_t status_words, uint32_t tickets) {
+  if (status_words > status_capacity) {
+    if (status) {
+      HY_HIP(hipStreamSynchronize(t_stream));
+      HY_HIP(hipFree(status));
+      status = nullptr;
+    }
+    status_capacity = align_up(status_words + 1024, 4096);
+    HY_HIP(hipMalloc(reinterpret_cast<void**>(&status), status_capacity * sizeof(uint64_t)));
+    HY_HIP(hipMemsetAsync(status, 0, status_capacity * sizeof(uint64_t), t_stream));
+  }
+  if (epoch >= (1u << 30) - 2 || ticket_base > 0xF0000000u - tickets) {
+    HY_HIP(hipMemsetAsync(status, 0, status_capacity * sizeof(uint64_t), t_stream));
+    HY_HIP(hipMemsetAsync(ticket, 0, 256, t_stream));
+    epoch = 0;
+    ticket_base = 0;
+  }
+  ++epoch;
+  return HY_OK;
+}
+
+void* Scratch::carve(size_t bytes) {
+  const size_t offset = align_up(used, 256);
+  if (offset + bytes > capacity) return nullptr;
+  used = offset + bytes;
+  return static_cast<char*>(base) + offset;
+}
+
+}  // namespace hy
+
+using namespace hy;
+
+extern "C" {
+
+int32_t hy_abi_version(void) { return HY_ABI_VERSION; }
+
+const char* hy_last_error(void) { return t_error.c_str(); }
+
+hy_status hy_device_count(int32_t* count) {
+  if (!count) return fail(HY_ERR_INVALID, "hy_device_count: null argument");
+  int n = 0;
+  hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess) {
+    *count = 0;
+    return fail(HY_ERR_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(err));
+  }
+  *count = n;
+  return HY_OK;
+}
+
+hy_status hy_init(int32_t device) {
+  int n = 0;
+  HY_HIP(hipGetDeviceCount(&n));
+  if (n <= 0) return fail(HY_ERR_DEVICE, "hy_init: no HIP device visible -- the MI355X path has no CPU fallback");
+  if (device < 0 || device >= n) return fail(HY_ERR_INVALID, "hy_init: device %d out of range [0,%d)", device, n);
+  HY_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HY_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("HY_ALLOW_ANY_ARCH")) {
+    return fail(HY_ERR_DEVICE, "hy_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                prop.gcnArchName);
+  }
+  return HY_OK;
+}
+
+hy_status hy_shutdown(void) {
+  Scratch& s = scratch();
+  if (s.base) (void)hipFree(s.base);
+  if (s.ticket) (void)hipFree(s.ticket);
+  if (s.status) (void)hipFree(s.status);
+  s = Scratch{};
+  return HY_OK;
+}
+
+hy_status hy_set_stream(void* hip_stream) {
+  t_stream = static_cast<hipStream_t>(hip_stream);
+  return HY_OK;
+}
+
+hy_status hy_synchronize(void) {
+  HY_HIP(hipStreamSynchronize(t_stream));
+  return HY_OK;
+}
+
+hy_status hy_device_malloc(void** ptr, size_t bytes) {
+  if (!ptr) return fail(HY_ERR_INVALID, "hy_device_malloc: null argument");
+  HY_HIP(hipMalloc(ptr, bytes ? bytes : 256));
+  return HY_OK;
+}
+
+hy_status hy_device_free(void* ptr) {
+  if (ptr) HY_HIP(hipFree(ptr));
+  return HY_OK;
+}
+
+hy_status hy_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  if (bytes) HY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, t_stream));
+  HY_HIP(hipStreamSynchronize(t_stream));
+  return HY_OK;
+}
+
+hy_status hy_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  if (bytes) HY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t_stream));
+  HY_HIP(hipStreamSynchronize(t_stream));
+  return HY_OK;
+}
+
+// ---- residency cache -------------------------------------------------------------------------------------------------
+
+static size_t type_width(uint32_t data_type) {
+  switch (data_type) {
+    case HY_TYPE_INT: return 4;
+    case HY_TYPE_LONG: return 8;
+    case HY_TYPE_FLOAT: return 4;
+    case HY_TYPE_DOUBLE: return 8;
+    default: return 0;
+  }
+}
+
+static hy_status validate_segment(const hy_segment& s, uint32_t chunk, uint32_t column_type) {
+  if (s.data_type != column_type) return fail(HY_ERR_INVALID, "chunk %u: data type %u differs from chunk 0's %u", chunk, s.data_type, column_type);
+  if (s.data_type < HY_TYPE_INT || s.data_type > HY_TYPE_STRING) return fail(HY_ERR_INVALID, "chunk %u: bad data type %u", chunk, s.data_type);
+  switch (s.encoding) {
+    case HY_ENC_UNENCODED:
+      if (s.data_type == HY_TYPE_STRING) return fail(HY_ERR_UNSUPPORTED, "chunk %u: unencoded string segments stay on the CPU path", chunk);
+      if (s.width != type_width(s.data_type)) return fail(HY_ERR_INVALID, "chunk %u: value width %u does not match type %u", chunk, s.width, s.data_type);
+      if (s.size && !s.data) return fail(HY_ERR_INVALID, "chunk %u: null data pointer", chunk);
+      break;
+    case HY_ENC_DICTIONARY:
+      if (s.width != 1 && s.width != 2 && s.width != 4) return fail(HY_ERR_INVALID, "chunk %u: attribute vector width %u", chunk, s.width);
+      if (s.size && !s.data) return fail(HY_ERR_INVALID, "chunk %u: null attribute vector", chunk);
+      if (s.data_type != HY_TYPE_STRING && s.aux_size && !s.aux) return fail(HY_ERR_INVALID, "chunk %u: dictionary missing", chunk);
+      break;
+    case HY_ENC_FRAME_OF_REFERENCE:
+      if (s.data_type != HY_TYPE_INT) return fail(HY_ERR_INVALID, "chunk %u: FrameOfReference is int32 only", chunk);
+      if (s.width != 1 && s.width != 2 && s.width != 4) return fail(HY_ERR_INVALID, "chunk %u: offset width %u", chunk, s.width);
+      if (s.size && (!s.data || !s.aux)) return fail(HY_ERR_INVALID, "chunk %u: FrameOfReference buffers missing", chunk);
+      if (s.aux_size != (s.size + HY_FOR_BLOCK_SIZE - 1) / HY_FOR_BLOCK_SIZE) return fail(HY_ERR_INVALID, "chunk %u: %u block minima for %u rows", chunk, s.aux_size, s.size);
+      break;
+    case HY_ENC_REFERENCE:
+      if (!s.ref) return fail(HY_ERR_INVALID, "chunk %u: reference segment without referenced column", chunk);
+      if (s.ref->is_reference) return fail(HY_ERR_INVALID, "chunk %u: reference segments must not reference reference segments (table_scan.cpp:140-148)", chunk);
+      if (!s.data && s.ref_chunk_id >= s.ref->n_chunks) return fail(HY_ERR_INVALID, "chunk %u: EntireChunkPosList chunk id out of range", chunk);
+      if (s.data && s.ref_chunk_id != 0xFFFFFFFFu && s.ref_chunk_id >= s.ref->n_chunks) return fail(HY_ERR_INVALID, "chunk %u: common chunk id out of range", chunk);
+      break;
+    default: return fail(HY_ERR_UNSUPPORTED, "chunk %u: encoding %u stays on the CPU path", chunk, s.encoding);
+  }
+  return HY_OK;
+}
+
+static size_t data_bytes(const hy_segment& s) {
+  return s.encoding == HY_ENC_REFERENCE ? (s.data ? size_t{8} * s.size : 0) : size_t{s.width} * s.size;
+}
+static size_t aux_bytes(const hy_segment& s) {
+  if (s.encoding == HY_ENC_DICTIONARY) return s.aux ? type_width(s.data_type) * s.aux_size : 0;
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) return size_t{4} * s.aux_size;
+  return 0;
+}
+static size_t null_bytes(const hy_segment& s) {
+  return (s.nulls && s.encoding != HY_ENC_REFERENCE) ? size_t{8} * ((s.size + 63) / 64) : 0;
+}
+
+hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32_t mem, hy_column** out) {
+  if (!out) return fail(HY_ERR_INVALID, "hy_column_create: null output");
+  *out = nullptr;
+  if (n_chunks && !segments) return fail(HY_ERR_INVALID, "hy_column_create: null segments");
+  if (mem != HY_MEM_HOST && mem != HY_MEM_DEVICE) return fail(HY_ERR_INVALID, "hy_column_create: bad memory space %u", mem);
+  const uint32_t column_type = n_chunks ? segments[0].data_type : HY_TYPE_INT;
+  for (uint32_t c = 0; c < n_chunks; ++c) HY_TRY(validate_segment(segments[c], c, column_type));
+
+  auto column = new hy_column();
+  column->n_chunks = n_chunks;
+  column->data_type = column_type;
+  column->host_segments.assign(segments, segments + n_chunks);
+  column->row_base.resize(size_t{n_chunks} + 1, 0);
+  auto cleanup = [&](hy_status st) {
+    hy_column_destroy(column);
+    return st;
+  };
+
+  // One arena for every buffer of the column: 916 chunks x 3 buffers would otherwise be ~2.7k hipMallocs.
+  size_t arena_bytes = 0;
+  if (mem == HY_MEM_HOST) {
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      const hy_segment& s = segments[c];
+      // +16: vector loads of the last partial group never leave the allocation
+      arena_bytes += align_up(data_bytes(s) + 16, 256) + align_up(aux_bytes(s) + 16, 256) + align_up(null_bytes(s) + 16, 256);
+    }
+  }
+  char* arena = nullptr;
+  if (arena_bytes) {
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&arena), arena_bytes);
+    if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "hipMalloc(%zu) failed: %s", arena_bytes, hipGetErrorString(err)));
+    column->owned.push_back(arena);
+  }
+  size_t cursor = 0;
+  auto upload = [&](const void* src, size_t bytes, const void** dst) -> hipError_t {
+    *dst = nullptr;
+    if (!src || !bytes) return hipSuccess;
+    char* target = arena + cursor;
+    cursor += align_up(bytes + 16, 256);
+    *dst = target;
+    return hipMemcpy(target, src, bytes, hipMemcpyHostToDevice);
+  };
+
+  std::vector<DevSegment> dev(n_chunks ? n_chunks : 1);
+  std::vector<Slice> slices;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    hy_segment& s = column->host_segments[c];
+    DevSegment& d = dev[c];
+    std::memset(&d, 0, sizeof(d));
+    if (mem == HY_MEM_HOST) {
+      const void *p_data = nullptr, *p_aux = nullptr, *p_nulls = nullptr;
+      hipError_t err = upload(s.data, data_bytes(s), &p_data);
+      if (err == hipSuccess) err = upload(s.aux, aux_bytes(s), &p_aux);
+      if (err == hipSuccess) err = upload(s.nulls, null_bytes(s), &p_nulls);
+      if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "chunk %u upload failed: %s", c, hipGetErrorString(err)));
+      s.data = p_data;
+      s.aux = p_aux;
+      s.nulls = static_cast<const uint64_t*>(p_nulls);
+    }
+    d.data = s.data;
+    d.aux = s.aux;
+    d.nulls = s.encoding == HY_ENC_REFERENCE ? nullptr : s.nulls;
+    d.size = s.size;
+    d.aux_size = s.aux_size;
+    d.ref_chunk_id = s.ref_chunk_id;
+    d.encoding = static_cast<uint8_t>(s.encoding);
+    d.data_type = static_cast<uint8_t>(s.data_type);
+    d.width = static_cast<uint8_t>(s.width);
+    d.flags = 0;
+    if (reinterpret_cast<uintptr_t>(s.data) % 16 != 0 || reinterpret_cast<uintptr_t>(s.nulls) % 8 != 0) d.flags |= SEG_UNALIGNED;
+    if (s.encoding == HY_ENC_REFERENCE) {
+      column->is_reference = true;
+      if (column->ref && column->ref != s.ref) return cleanup(fail(HY_ERR_INVALID, "chunk %u references a different table than chunk 0", c));
+      column->ref = s.ref;
+      d.ref = s.ref->d_segments;
+      if (s.data && s.ref_chunk_id == 0xFFFFFFFFu) column->multi_chunk_reference = true;
+    } else if (column->is_reference) {
+      return cleanup(fail(HY_ERR_INVALID, "chunk %u: data and reference segments mixed in one column", c));
+    }
+    if (s.encoding == HY_ENC_DICTIONARY && !s.aux && s.aux_size) column->has_dictionary_without_values = true;
+    column->row_base[c + 1] = column->row_base[c] + s.size;
+    uint32_t begin = 0;
+    do {
+      const uint32_t count = (s.size - begin < SLICE_ROWS) ? s.size - begin : SLICE_ROWS;
+      slices.push_back(Slice{c, begin, count, begin == 0 ? 1u : 0u});
+      begin += count;
+    } while (begin < s.size);
+  }
+  column->rows = column->row_base[n_chunks];
+  column->n_slices = static_cast<uint32_t>(slices.size());
+
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&column->d_segments), sizeof(DevSegment) * dev.size());
+  if (err == hipSuccess) err = hipMemcpy(column->d_segments, dev.data(), sizeof(DevSegment) * dev.size(), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_slices), sizeof(Slice) * (slices.size() + 1));
+  if (err == hipSuccess && !slices.empty()) err = hipMemcpy(column->d_slices, slices.data(), sizeof(Slice) * slices.size(), hipMemcpyHostToDevice);
+  if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "descriptor upload failed: %s", hipGetErrorString(err)));
+  *out = column;
+  return HY_OK;
+}
+
+hy_status hy_column_destroy(hy_column* column) {
+  if (!column) return HY_OK;
+  for (void* p : column->owned) (void)hipFree(p);
+  if (column->d_segments) (void)hipFree(column->d_segments);
+  if (column->d_slices) (void)hipFree(column->d_slices);
+  delete column;
+  return HY_OK;
+}
+
+hy_status hy_column_row_count(const hy_column* column, uint64_t* rows) {
+  if (!column || !rows) return fail(HY_ERR_INVALID, "hy_column_row_count: null argument");
+  *rows = column->rows;
+  return HY_OK;
+}
+
+hy_status hy_column_chunk_count(const hy_column* column, uint32_t* chunks) {
+  if (!column || !chunks) return fail(HY_ERR_INVALID, "hy_column_chunk_count: null argument");
+  *chunks = column->n_chunks;
+  return HY_OK;
+}
+
+}  // extern "C"

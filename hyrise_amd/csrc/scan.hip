@@ -1,0 +1,889 @@
+// scan.hip -- TableScan on MI355X: ColumnVsValue / ColumnBetween / ColumnIsNull / ColumnVsColumn over Value,
+// Dictionary and FrameOfReference segments (and reference segments through their pos lists).
+//
+// What it replaces (reference, CPU):
+//   TableScan::_on_execute's per-chunk JobTask fan-out                     operators/table_scan.cpp:97-240
+//   AbstractTableScanImpl::_scan_with_iterators (the hot loop)             table_scan/abstract_table_scan_impl.hpp:44-242
+//   ColumnVsValue / ColumnBetween / ColumnIsNull / ColumnVsColumn impls    table_scan/column_*_table_scan_impl.cpp
+//
+// Device design (one launch for ALL chunks of a column; a chunk is ~128 KiB, far too small for a launch of its own):
+//   prepare_jobs  one thread per data chunk: the two dictionary binary searches and the all/none early-outs of the
+//                 reference (column_vs_value_table_scan_impl.cpp:211-272, column_between_table_scan_impl.cpp:112-170)
+//                 collapse every predicate into ONE normalised per-chunk test:
+//                     integers / value ids:  ((u)(x - lo) <= span) ^ invert        (type_comparison.hpp:120-132)
+//                     float / double:        lower/upper compares with inclusive flags, ^ invert
+//                     null test:             bitmap bit / value id == null id
+//   scan_slices   one workgroup per slice (<= 8192 consecutive rows of one chunk).  Each lane streams 4 x 8 rows with
+//                 16-byte loads (8 rows of a 2-byte attribute vector per load, 1 KiB per wave instruction), builds a
+//                 32-bit match mask, the wave does one packed prefix sum, the workgroup's total goes through a
+//                 single-pass decoupled look-back (epoch-tagged 8-byte status words, agent-scope relaxed atomics: the
+//                 word IS the flag) to obtain its global output offset, matches are compacted through LDS and written
+//                 as coalesced 8-byte RowIDs.  PosLists therefore come out back to back, per chunk, ascending --
+//                 bit-identical to what the CPU loop appends -- with the column read exactly once.
+//   finalize      per-chunk counts / states.
+// HBM-bound integer work: no MFMA anywhere.
+#include "hy_device.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace hy {
+
+// ---- per-chunk normalised predicate ---------------------------------------------------------------------------------
+enum : uint32_t { JOB_SCAN = 0, JOB_ALL = 1, JOB_NONE = 2 };
+enum : uint32_t { KIND_U32 = 0, KIND_I64 = 1, KIND_F32 = 2, KIND_F64 = 3, KIND_NULLTEST = 4 };
+enum : uint32_t { JF_INVERT = 1, JF_LOWER_INCL = 2, JF_UPPER_INCL = 4, JF_NEVER = 8 };
+
+struct ScanJob {
+  uint32_t mode;       // JOB_*
+  uint32_t kind;       // KIND_*
+  uint32_t flags;      // JF_*
+  uint32_t null_vid;   // dictionary: value id that encodes NULL (aux_size); else 0xFFFFFFFF
+  uint64_t lo;         // integer lower bound (bit pattern) | float/double lower bound bits
+  uint64_t span;       // integer hi - lo                   | float/double upper bound bits
+};
+
+struct PredicateArgs {
+  uint32_t condition;
+  uint32_t value_type;
+  hy_value value;
+  hy_value value2;
+  const uint32_t* per_chunk_lower;
+  const uint32_t* per_chunk_upper;
+  const uint8_t* per_chunk_found;
+  uint32_t column_is_nullable;
+  uint32_t materialize_all;
+};
+
+__device__ __forceinline__ bool is_between(uint32_t c) { return c >= HY_PRED_BETWEEN_INCLUSIVE && c <= HY_PRED_BETWEEN_EXCLUSIVE; }
+__device__ __forceinline__ bool lower_inclusive(uint32_t c) { return c == HY_PRED_BETWEEN_INCLUSIVE || c == HY_PRED_BETWEEN_UPPER_EXCLUSIVE; }
+__device__ __forceinline__ bool upper_inclusive(uint32_t c) { return c == HY_PRED_BETWEEN_INCLUSIVE || c == HY_PRED_BETWEEN_LOWER_EXCLUSIVE; }
+
+template <typename T>
+__device__ uint32_t dict_lower_bound(const T* dict, uint32_t d, T value) {
+  uint32_t lo = 0, hi = d;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (dict[mid] < value) lo = mid + 1; else hi = mid;
+  }
+  return lo == d ? HY_INVALID_VALUE_ID : lo;
+}
+template <typename T>
+__device__ uint32_t dict_upper_bound(const T* dict, uint32_t d, T value) {
+  uint32_t lo = 0, hi = d;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (!(value < dict[mid])) lo = mid + 1; else hi = mid;
+  }
+  return lo == d ? HY_INVALID_VALUE_ID : lo;
+}
+
+template <typename T>
+__device__ void dict_bounds(const DevSegment& s, T v, uint32_t* lower, uint32_t* upper, bool* found) {
+  const T* dict = static_cast<const T*>(s.aux);
+  *lower = dict_lower_bound(dict, s.aux_size, v);
+  *upper = dict_upper_bound(dict, s.aux_size, v);
+  *found = *lower != HY_INVALID_VALUE_ID && dict[*lower] == v;
+}
+
+__device__ void set_value_id_range(ScanJob& job, uint32_t lo, uint32_t hi_inclusive, bool invert) {
+  job.kind = KIND_U32;
+  job.lo = lo;
+  job.span = hi_inclusive - lo;
+  job.flags = invert ? JF_INVERT : 0;
+}
+
+// Signed integer predicate -> [lo, hi] in a wider type; returns false for an empty range.
+template <typename Wide>
+__device__ bool integer_range(uint32_t cond, Wide v, Wide v2, Wide tmin, Wide tmax, Wide* lo, Wide* hi, bool* invert) {
+  *invert = false;
+  switch (cond) {
+    case HY_PRED_EQUALS: *lo = v; *hi = v; break;
+    case HY_PRED_NOT_EQUALS: *lo = v; *hi = v; *invert = true; break;
+    case HY_PRED_LESS_THAN: *lo = tmin; *hi = v - 1; break;
+    case HY_PRED_LESS_THAN_EQUALS: *lo = tmin; *hi = v; break;
+    case HY_PRED_GREATER_THAN: *lo = v + 1; *hi = tmax; break;
+    case HY_PRED_GREATER_THAN_EQUALS: *lo = v; *hi = tmax; break;
+    default:  // between: column_between_table_scan_impl.cpp:86-94 + type_comparison.hpp:120-132
+      *lo = lower_inclusive(cond) ? v : v + 1;
+      *hi = upper_inclusive(cond) ? v2 : v2 - 1;
+      break;
+  }
+  return *lo <= *hi;
+}
+
+// One thread per DATA chunk of the scanned column (for reference columns: of the referenced column).
+__global__ void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, PredicateArgs p, ScanJob* jobs) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  const DevSegment s = segments[c];
+  ScanJob job;
+  job.mode = JOB_SCAN;
+  job.kind = KIND_U32;
+  job.flags = 0;
+  job.null_vid = 0xFFFFFFFFu;
+  job.lo = 0;
+  job.span = 0;
+  const uint32_t cond = p.condition;
+
+  if (cond == HY_PRED_IS_NULL || cond == HY_PRED_IS_NOT_NULL) {
+    const bool is_null = cond == HY_PRED_IS_NULL;
+    if (s.encoding == HY_ENC_DICTIONARY) {  // column_is_null_table_scan_impl.cpp:167-195
+      const bool all = is_null ? s.aux_size == 0 : s.aux_size == s.size;
+      const bool none = is_null ? s.aux_size == s.size : s.aux_size == 0;
+      if (all) job.mode = JOB_ALL;
+      else if (none) job.mode = JOB_NONE;
+      set_value_id_range(job, s.aux_size, s.aux_size, !is_null);
+    } else {                                // :197-251 (nullable == has a null vector)
+      if (!s.nulls) job.mode = is_null ? JOB_NONE : JOB_ALL;
+      job.kind = KIND_NULLTEST;
+      job.flags = is_null ? 0 : JF_INVERT;
+    }
+    jobs[c] = job;
+    return;
+  }
+
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    const uint32_t d = s.aux_size;
+    job.null_vid = d;
+    uint32_t lower = 0, upper = 0, lower2 = 0, upper2 = 0;
+    bool found = false, found2 = false;
+    if (s.aux && s.data_type != HY_TYPE_STRING) {
+      switch (s.data_type) {
+        case HY_TYPE_INT: dict_bounds<int32_t>(s, p.value.i32, &lower, &upper, &found); dict_bounds<int32_t>(s, p.value2.i32, &lower2, &upper2, &found2); break;
+        case HY_TYPE_LONG: dict_bounds<int64_t>(s, p.value.i64, &lower, &upper, &found); dict_bounds<int64_t>(s, p.value2.i64, &lower2, &upper2, &found2); break;
+        case HY_TYPE_FLOAT: dict_bounds<float>(s, p.value.f32, &lower, &upper, &found); dict_bounds<float>(s, p.value2.f32, &lower2, &upper2, &found2); break;
+        default: dict_bounds<double>(s, p.value.f64, &lower, &upper, &found); dict_bounds<double>(s, p.value2.f64, &lower2, &upper2, &found2); break;
+      }
+    } else {  // caller-resolved value ids (string dictionaries)
+      lower = p.per_chunk_lower[c];
+      upper = p.per_chunk_upper[c];
+      found = p.per_chunk_found ? p.per_chunk_found[c] != 0 : false;
+    }
+    if (is_between(cond)) {  // column_between_table_scan_impl.cpp:112-193
+      uint32_t lower_vid, upper_vid;
+      if (s.aux && s.data_type != HY_TYPE_STRING) {
+        lower_vid = lower_inclusive(cond) ? lower : upper;
+        upper_vid = upper_inclusive(cond) ? upper2 : lower2;
+      } else {
+        lower_vid = lower;  // caller applied the inclusive/exclusive rule
+        upper_vid = upper;
+      }
+      if (lower_vid == 0 && upper_vid == HY_INVALID_VALUE_ID) {
+        if (p.column_is_nullable) {
+          if (d == 0) job.flags = JF_NEVER; else set_value_id_range(job, 0, d - 1, false);
+        } else {
+          job.mode = JOB_ALL;
+        }
+      } else if (lower_vid == HY_INVALID_VALUE_ID || lower_vid >= upper_vid) {
+        job.mode = JOB_NONE;
+      } else {
+        if (upper_vid == HY_INVALID_VALUE_ID) upper_vid = d;
+        set_value_id_range(job, lower_vid, upper_vid - 1, false);
+      }
+    } else {                 // column_vs_value_table_scan_impl.cpp:89-272
+      const bool use_upper = cond == HY_PRED_LESS_THAN_EQUALS || cond == HY_PRED_GREATER_THAN;
+      const uint32_t search = use_upper ? upper : lower;
+      bool all = false, none = false;
+      switch (cond) {
+        case HY_PRED_EQUALS: all = found && d == 1; none = !found; break;
+        case HY_PRED_NOT_EQUALS: all = !found; none = found && d == 1; break;
+        case HY_PRED_LESS_THAN:
+        case HY_PRED_LESS_THAN_EQUALS: all = search == HY_INVALID_VALUE_ID; none = search == 0; break;
+        default: all = search == 0; none = search == HY_INVALID_VALUE_ID; break;
+      }
+      if (all) {
+        if (p.column_is_nullable) {  // still filter NULLs (:125-132)
+          if (d == 0) job.flags = JF_NEVER; else set_value_id_range(job, 0, d - 1, false);
+        } else {
+          job.mode = JOB_ALL;
+        }
+      } else if (none) {
+        job.mode = JOB_NONE;
+      } else {
+        switch (cond) {  // .hpp:57-81; NULL (== d) is outside every range below
+          case HY_PRED_EQUALS: set_value_id_range(job, search, search, false); break;
+          case HY_PRED_NOT_EQUALS: set_value_id_range(job, search, search, true); break;  // + explicit NULL check
+          case HY_PRED_LESS_THAN:
+          case HY_PRED_LESS_THAN_EQUALS: set_value_id_range(job, 0, search - 1, false); break;
+          default: set_value_id_range(job, search, d - 1, false); break;
+        }
+      }
+    }
+    jobs[c] = job;
+    return;
+  }
+
+  // Value / FrameOfReference segments: decode + typed compare with NULL check (_scan_generic_segment).
+  switch (s.data_type) {
+    case HY_TYPE_INT: {
+      int64_t lo, hi;
+      bool invert;
+      if (!integer_range<int64_t>(cond, p.value.i32, p.value2.i32, INT32_MIN, INT32_MAX, &lo, &hi, &invert)) {
+        job.flags = JF_NEVER;
+      } else {
+        job.kind = KIND_U32;
+        job.lo = static_cast<uint32_t>(static_cast<int32_t>(lo));
+        job.span = static_cast<uint32_t>(static_cast<uint64_t>(hi - lo));
+        job.flags = invert ? JF_INVERT : 0;
+      }
+      break;
+    }
+    case HY_TYPE_LONG: {
+      __int128 lo, hi;
+      bool invert;
+      if (!integer_range<__int128>(cond, p.value.i64, p.value2.i64, INT64_MIN, INT64_MAX, &lo, &hi, &invert)) {
+        job.flags = JF_NEVER;
+      } else {
+        job.kind = KIND_I64;
+        job.lo = static_cast<uint64_t>(static_cast<int64_t>(lo));
+        job.span = static_cast<uint64_t>(hi - lo);
+        job.flags = invert ? JF_INVERT : 0;
+      }
+      break;
+    }
+    case HY_TYPE_FLOAT:
+    case HY_TYPE_DOUBLE: {
+      const bool is_f32 = s.data_type == HY_TYPE_FLOAT;
+      double a, b;
+      uint32_t flags = 0;
+      const double v = is_f32 ? static_cast<double>(p.value.f32) : p.value.f64;
+      const double v2 = is_f32 ? static_cast<double>(p.value2.f32) : p.value2.f64;
+      const double inf = INFINITY;
+      switch (cond) {
+        case HY_PRED_EQUALS: a = v; b = v; flags = JF_LOWER_INCL | JF_UPPER_INCL; break;
+        case HY_PRED_NOT_EQUALS: a = v; b = v; flags = JF_LOWER_INCL | JF_UPPER_INCL | JF_INVERT; break;
+        case HY_PRED_LESS_THAN: a = -inf; b = v; flags = JF_LOWER_INCL; break;
+        case HY_PRED_LESS_THAN_EQUALS: a = -inf; b = v; flags = JF_LOWER_INCL | JF_UPPER_INCL; break;
+        case HY_PRED_GREATER_THAN: a = v; b = inf; flags = JF_UPPER_INCL; break;
+        case HY_PRED_GREATER_THAN_EQUALS: a = v; b = inf; flags = JF_LOWER_INCL | JF_UPPER_INCL; break;
+        default:
+          a = v; b = v2;
+          flags = (lower_inclusive(cond) ? JF_LOWER_INCL : 0) | (upper_inclusive(cond) ? JF_UPPER_INCL : 0);
+          break;
+      }
+      if (is_f32) {
+        job.kind = KIND_F32;
+        job.lo = __float_as_uint(static_cast<float>(a));
+        job.span = __float_as_uint(static_cast<float>(b));
+      } else {
+        job.kind = KIND_F64;
+        job.lo = static_cast<uint64_t>(__double_as_longlong(a));
+        job.span = static_cast<uint64_t>(__double_as_longlong(b));
+      }
+      job.flags = flags;
+      break;
+    }
+    default: job.mode = JOB_NONE; break;
+  }
+  jobs[c] = job;
+}
+
+// ---- row evaluation ---------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t load_compressed(const void* data, uint32_t width, uint32_t i) {
+  if (width == 1) return static_cast<const uint8_t*>(data)[i];
+  if (width == 2) return static_cast<const uint16_t*>(data)[i];
+  return static_cast<const uint32_t*>(data)[i];
+}
+
+__device__ __forceinline__ bool float_in_range(float x, const ScanJob& job) {
+  const float a = __uint_as_float(static_cast<uint32_t>(job.lo)), b = __uint_as_float(static_cast<uint32_t>(job.span));
+  const bool lower_ok = (job.flags & JF_LOWER_INCL) ? x >= a : x > a;
+  const bool upper_ok = (job.flags & JF_UPPER_INCL) ? x <= b : x < b;
+  return lower_ok && upper_ok;
+}
+__device__ __forceinline__ bool double_in_range(double x, const ScanJob& job) {
+  const double a = __longlong_as_double(static_cast<long long>(job.lo)), b = __longlong_as_double(static_cast<long long>(job.span));
+  const bool lower_ok = (job.flags & JF_LOWER_INCL) ? x >= a : x > a;
+  const bool upper_ok = (job.flags & JF_UPPER_INCL) ? x <= b : x < b;
+  return lower_ok && upper_ok;
+}
+
+// Scalar evaluation of one row of a DATA segment: tails, unaligned buffers and pos-list gathers.
+__device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) {
+  if (job.mode == JOB_ALL) return true;
+  if (job.mode == JOB_NONE || (job.flags & JF_NEVER)) return false;
+  const bool invert = job.flags & JF_INVERT;
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    const uint32_t vid = load_compressed(s.data, s.width, row);
+    const bool in = (vid - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+    return (in != invert) && vid != job.null_vid;   // null_vid is 0xFFFFFFFF for the NULL test itself
+  }
+  const bool is_null = s.nulls ? ((s.nulls[row >> 6] >> (row & 63)) & 1) != 0 : false;
+  if (job.kind == KIND_NULLTEST) return is_null != invert;
+  if (is_null) return false;
+  bool in;
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+    const uint32_t x = load_compressed(s.data, s.width, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]);
+    in = (x - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+  } else {
+    switch (job.kind) {
+      case KIND_U32: in = (static_cast<const uint32_t*>(s.data)[row] - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span); break;
+      case KIND_I64: in = (static_cast<const uint64_t*>(s.data)[row] - job.lo) <= job.span; break;
+      case KIND_F32: in = float_in_range(static_cast<const float*>(s.data)[row], job); break;
+      default: in = double_in_range(static_cast<const double*>(s.data)[row], job); break;
+    }
+  }
+  return in != invert;
+}
+
+// 8 consecutive rows starting at row0 (multiple of 8), all valid, buffers 16-byte aligned: vector loads.
+template <int WIDTH>
+__device__ __forceinline__ void load8(const void* data, uint32_t row0, uint32_t (&x)[8]) {
+  if constexpr (WIDTH == 1) {
+    const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(data) + row0);
+    x[0] = v.x & 0xFF; x[1] = (v.x >> 8) & 0xFF; x[2] = (v.x >> 16) & 0xFF; x[3] = v.x >> 24;
+    x[4] = v.y & 0xFF; x[5] = (v.y >> 8) & 0xFF; x[6] = (v.y >> 16) & 0xFF; x[7] = v.y >> 24;
+  } else if constexpr (WIDTH == 2) {
+    const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(data) + row0);
+    x[0] = v.x & 0xFFFF; x[1] = v.x >> 16; x[2] = v.y & 0xFFFF; x[3] = v.y >> 16;
+    x[4] = v.z & 0xFFFF; x[5] = v.z >> 16; x[6] = v.w & 0xFFFF; x[7] = v.w >> 16;
+  } else {
+    const uint4 v0 = *reinterpret_cast<const uint4*>(static_cast<const uint32_t*>(data) + row0);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(static_cast<const uint32_t*>(data) + row0 + 4);
+    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+  }
+}
+
+template <int WIDTH>
+__device__ __forceinline__ uint32_t eval8_u32(const DevSegment& s, const ScanJob& job, uint32_t row0, uint32_t bias) {
+  uint32_t x[8];
+  load8<WIDTH>(s.data, row0, x);
+  const uint32_t lo = static_cast<uint32_t>(job.lo) - bias, span = static_cast<uint32_t>(job.span);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bits |= ((x[j] - lo) <= span ? 1u : 0u) << j;
+  return bits;
+}
+
+// Match bits of 8 rows [row0, row0+8) of a data segment; rows >= size are masked off by the caller.
+__device__ __forceinline__ uint32_t eval8(const DevSegment& s, const ScanJob& job, uint32_t row0, uint32_t valid) {
+  if (valid < 8 || (s.flags & SEG_UNALIGNED)) {
+    uint32_t bits = 0;
+    for (uint32_t j = 0; j < valid; ++j) bits |= (eval_row(s, job, row0 + j) ? 1u : 0u) << j;
+    return bits;
+  }
+  const uint32_t inv = (job.flags & JF_INVERT) ? 0xFFu : 0u;
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    uint32_t bits, nullbits = 0;
+    uint32_t x[8];
+    const uint32_t lo = static_cast<uint32_t>(job.lo), span = static_cast<uint32_t>(job.span);
+    if (s.width == 2) load8<2>(s.data, row0, x);
+    else if (s.width == 1) load8<1>(s.data, row0, x);
+    else load8<4>(s.data, row0, x);
+    bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bits |= ((x[j] - lo) <= span ? 1u : 0u) << j;
+    if (inv) {  // != : NULL never matches (column_vs_value_table_scan_impl.cpp:171-177); 0xFFFFFFFF for IS NOT NULL
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nullbits |= (x[j] == job.null_vid ? 1u : 0u) << j;
+    }
+    return (bits ^ inv) & ~nullbits;
+  }
+  const uint32_t nullbits = s.nulls ? reinterpret_cast<const uint8_t*>(s.nulls)[row0 >> 3] : 0u;
+  if (job.kind == KIND_NULLTEST) return (nullbits ^ inv) & 0xFFu;
+  uint32_t bits = 0;
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+    // value = offset + block minimum; test (offset + min - lo) <= span, i.e. compare offsets against (lo - min)
+    const uint32_t bias = static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row0 / HY_FOR_BLOCK_SIZE]);
+    if (s.width == 2) bits = eval8_u32<2>(s, job, row0, bias);
+    else if (s.width == 1) bits = eval8_u32<1>(s, job, row0, bias);
+    else bits = eval8_u32<4>(s, job, row0, bias);
+  } else if (job.kind == KIND_U32) {
+    bits = eval8_u32<4>(s, job, row0, 0);
+  } else if (job.kind == KIND_I64) {
+    const uint4* p = reinterpret_cast<const uint4*>(static_cast<const uint64_t*>(s.data) + row0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = p[q];
+      const uint64_t a = (static_cast<uint64_t>(v.y) << 32) | v.x, b = (static_cast<uint64_t>(v.w) << 32) | v.z;
+      bits |= ((a - job.lo) <= job.span ? 1u : 0u) << (2 * q);
+      bits |= ((b - job.lo) <= job.span ? 1u : 0u) << (2 * q + 1);
+    }
+  } else if (job.kind == KIND_F32) {
+    const uint4* p = reinterpret_cast<const uint4*>(static_cast<const float*>(s.data) + row0);
+    const uint4 v0 = p[0], v1 = p[1];
+    const uint32_t raw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bits |= (float_in_range(__uint_as_float(raw[j]), job) ? 1u : 0u) << j;
+  } else {
+    const uint4* p = reinterpret_cast<const uint4*>(static_cast<const double*>(s.data) + row0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = p[q];
+      const double a = __longlong_as_double((static_cast<long long>(v.y) << 32) | v.x);
+      const double b = __longlong_as_double((static_cast<long long>(v.w) << 32) | v.z);
+      bits |= (double_in_range(a, job) ? 1u : 0u) << (2 * q);
+      bits |= (double_in_range(b, job) ? 1u : 0u) << (2 * q + 1);
+    }
+  }
+  return (bits ^ inv) & ~nullbits & 0xFFu;
+}
+
+// Decoded numeric value of one row of a DATA segment (ColumnVsColumn), as the widest carrier of its class.
+struct Cell {
+  bool is_null;
+  int64_t i;
+  double f;
+};
+__device__ Cell load_cell(const DevSegment& s, uint32_t row) {
+  Cell c{false, 0, 0.0};
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    const uint32_t vid = load_compressed(s.data, s.width, row);
+    if (vid >= s.aux_size) { c.is_null = true; return c; }
+    switch (s.data_type) {
+      case HY_TYPE_INT: c.i = static_cast<const int32_t*>(s.aux)[vid]; break;
+      case HY_TYPE_LONG: c.i = static_cast<const int64_t*>(s.aux)[vid]; break;
+      case HY_TYPE_FLOAT: c.f = static_cast<const float*>(s.aux)[vid]; break;
+      default: c.f = static_cast<const double*>(s.aux)[vid]; break;
+    }
+    return c;
+  }
+  if (s.nulls && ((s.nulls[row >> 6] >> (row & 63)) & 1)) { c.is_null = true; return c; }
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+    c.i = static_cast<int32_t>(load_compressed(s.data, s.width, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]));
+    return c;
+  }
+  switch (s.data_type) {
+    case HY_TYPE_INT: c.i = static_cast<const int32_t*>(s.data)[row]; break;
+    case HY_TYPE_LONG: c.i = static_cast<const int64_t*>(s.data)[row]; break;
+    case HY_TYPE_FLOAT: c.f = static_cast<const float*>(s.data)[row]; break;
+    default: c.f = static_cast<const double*>(s.data)[row]; break;
+  }
+  return c;
+}
+
+template <typename T>
+__device__ __forceinline__ bool compare(uint32_t cond, T a, T b) {
+  switch (cond) {
+    case HY_PRED_EQUALS: return a == b;
+    case HY_PRED_NOT_EQUALS: return a != b;
+    case HY_PRED_LESS_THAN: return a < b;
+    case HY_PRED_LESS_THAN_EQUALS: return a <= b;
+    case HY_PRED_GREATER_THAN: return a > b;
+    default: return a >= b;
+  }
+}
+
+// Row `row` of chunk `chunk` of a column that may consist of reference segments.
+__device__ Cell column_cell(const DevSegment* segments, uint32_t chunk, uint32_t row, uint32_t* type) {
+  const DevSegment& s = segments[chunk];
+  *type = s.data_type;
+  if (s.encoding != HY_ENC_REFERENCE) return load_cell(s, row);
+  hy_row_id r;
+  if (s.data) r = static_cast<const hy_row_id*>(s.data)[row];
+  else { r.chunk_id = s.ref_chunk_id; r.chunk_offset = row; }
+  if (r.chunk_offset == 0xFFFFFFFFu) return Cell{true, 0, 0.0};
+  return load_cell(s.ref[r.chunk_id], r.chunk_offset);
+}
+
+// C++ usual arithmetic conversions of `left OP right` (column_vs_column_table_scan_impl.cpp:169-184).
+__device__ bool compare_cells(uint32_t cond, const Cell& l, uint32_t lt, const Cell& r, uint32_t rt) {
+  const bool lf = lt == HY_TYPE_FLOAT || lt == HY_TYPE_DOUBLE, rf = rt == HY_TYPE_FLOAT || rt == HY_TYPE_DOUBLE;
+  if (!lf && !rf) return compare<int64_t>(cond, l.i, r.i);
+  if (lt == HY_TYPE_DOUBLE || rt == HY_TYPE_DOUBLE) return compare<double>(cond, lf ? l.f : static_cast<double>(l.i), rf ? r.f : static_cast<double>(r.i));
+  return compare<float>(cond, lf ? static_cast<float>(l.f) : static_cast<float>(l.i), rf ? static_cast<float>(r.f) : static_cast<float>(r.i));
+}
+
+// ---- the scan kernel ----------------------------------------------------------------------------------------------------
+
+constexpr uint64_t ST_AGGREGATE = 1ull << 62;
+constexpr uint64_t ST_PREFIX = 2ull << 62;
+__device__ __forceinline__ uint64_t make_status(uint64_t state, uint32_t epoch, uint32_t value) {
+  return state | (static_cast<uint64_t>(epoch) << 32) | value;
+}
+
+struct ScanArgs {
+  const DevSegment* segments;      // scanned column
+  const DevSegment* right;         // ColumnVsColumn: right column, else nullptr
+  const Slice* slices;
+  const ScanJob* jobs;             // per DATA chunk (of the referenced column for reference columns)
+  uint32_t n_slices;
+  uint32_t n_chunks;
+  uint32_t condition;              // ColumnVsColumn
+  uint32_t materialize_all;
+  uint32_t is_null_scan;           // IS NULL on reference columns: NULL_ROW_IDs match
+  uint32_t epoch;
+  uint32_t ticket_base;
+  uint32_t* ticket;
+  uint64_t* status;
+  hy_row_id* matches;
+  uint64_t capacity;
+  uint64_t* offsets;               // [n_chunks + 1]
+  uint32_t* overflow;              // set to 1 if capacity was exceeded
+};
+
+__device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v, uint32_t lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up(v, d, 64);
+    if (lane >= static_cast<uint32_t>(d)) v += t;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void scan_slices(ScanArgs a) {
+  __shared__ uint32_t s_ticket;
+  __shared__ uint32_t s_wave_total[4];
+  __shared__ uint32_t s_exclusive;
+  __shared__ uint16_t s_rows[SLICE_ROWS];
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u) - a.ticket_base;
+  __syncthreads();
+  const uint32_t slice_id = s_ticket;
+  const Slice slice = a.slices[slice_id];
+  const DevSegment seg = a.segments[slice.chunk];
+
+  // ---- 1. evaluate 4 x 8 rows per lane: wave w owns rows [w*2048, (w+1)*2048) of the slice, k-th load 512 rows ----
+  uint32_t mask = 0;       // bit (8k + j) <-> row  wave*2048 + k*512 + lane*8 + j  of the slice
+  uint32_t mode = JOB_SCAN;
+  if (a.right) {
+    // ColumnVsColumn: both sides decoded per row (no SIMD path in the reference either, abstract_table_scan_impl.hpp:61-66)
+#pragma unroll 1
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+      for (uint32_t j = 0; j < 8 && r0 + j < slice.row_count; ++j) {
+        const uint32_t row = slice.row_begin + r0 + j;
+        uint32_t lt, rt;
+        const Cell l = column_cell(a.segments, slice.chunk, row, &lt);
+        const Cell r = column_cell(a.right, slice.chunk, row, &rt);
+        if (!l.is_null && !r.is_null && compare_cells(a.condition, l, lt, r, rt)) mask |= 1u << (8 * k + j);
+      }
+    }
+  } else if (seg.encoding == HY_ENC_REFERENCE) {
+    const bool single = seg.ref_chunk_id != 0xFFFFFFFFu;
+    if (single) mode = a.jobs[seg.ref_chunk_id].mode;
+    if (mode == JOB_SCAN || (mode == JOB_ALL && a.materialize_all)) {
+#pragma unroll 1
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+        for (uint32_t j = 0; j < 8 && r0 + j < slice.row_count; ++j) {
+          const uint32_t row = slice.row_begin + r0 + j;
+          hy_row_id r;
+          if (seg.data) r = static_cast<const hy_row_id*>(seg.data)[row];
+          else { r.chunk_id = seg.ref_chunk_id; r.chunk_offset = row; }
+          bool m;
+          if (r.chunk_offset == 0xFFFFFFFFu) m = a.is_null_scan != 0;   // NULL_ROW_ID: only IS NULL matches
+          else m = eval_row(seg.ref[r.chunk_id], a.jobs[r.chunk_id], r.chunk_offset);
+          if (m) mask |= 1u << (8 * k + j);
+        }
+      }
+    }
+  } else {
+    const ScanJob job = a.jobs[slice.chunk];
+    mode = job.mode;
+    if (mode == JOB_SCAN && !(job.flags & JF_NEVER)) {
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+        if (r0 < slice.row_count) {
+          const uint32_t valid = (slice.row_count - r0 < 8) ? slice.row_count - r0 : 8;
+          mask |= eval8(seg, job, slice.row_begin + r0, valid) << (8 * k);
+        }
+      }
+    } else if (mode == JOB_ALL && a.materialize_all) {
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+        if (r0 < slice.row_count) {
+          const uint32_t valid = (slice.row_count - r0 < 8) ? slice.row_count - r0 : 8;
+          mask |= ((1u << valid) - 1u) << (8 * k);
+        }
+      }
+    }
+  }
+
+  // ---- 2. positions: one packed wave scan over the four per-load counts (16 bits each) -------------------------------
+  const uint64_t packed = static_cast<uint64_t>(__popc(mask & 0xFFu)) | (static_cast<uint64_t>(__popc(mask & 0xFF00u)) << 16) |
+                          (static_cast<uint64_t>(__popc(mask & 0xFF0000u)) << 32) | (static_cast<uint64_t>(__popc(mask >> 24)) << 48);
+  const uint64_t inclusive = wave_inclusive_scan(packed, lane);
+  const uint64_t totals = __shfl(inclusive, 63, 64);       // per-load totals of this wave
+  const uint64_t exclusive = inclusive - packed;
+  const uint32_t t0 = totals & 0xFFFF, t1 = (totals >> 16) & 0xFFFF, t2 = (totals >> 32) & 0xFFFF, t3 = totals >> 48;
+  const uint32_t wave_total = t0 + t1 + t2 + t3;
+  if (lane == 0) s_wave_total[wave] = wave_total;
+  __syncthreads();
+  uint32_t wave_base = 0, block_total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 4; ++w) {
+    const uint32_t t = s_wave_total[w];
+    if (w < wave) wave_base += t;
+    block_total += t;
+  }
+
+  // ---- 3. decoupled look-back over the slices before this one (wave 0) ------------------------------------------------
+  if (wave == 0) {
+    if (lane == 0) __hip_atomic_store(&a.status[slice_id], make_status(slice_id == 0 ? ST_PREFIX : ST_AGGREGATE, a.epoch, block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t exclusive_prefix = 0;
+    int64_t window_end = static_cast<int64_t>(slice_id) - 1;   // newest predecessor not yet summed
+    while (window_end >= 0) {
+      const int64_t idx = window_end - lane;
+      uint64_t word = 0;
+      bool ready;
+      do {  // every lane polls its own predecessor until it carries this launch's epoch
+        ready = true;
+        if (idx >= 0) {
+          word = __hip_atomic_load(&a.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ready = (static_cast<uint32_t>(word >> 32) & 0x3FFFFFFFu) == a.epoch && (word >> 62) != 0;
+        }
+        if (!__all(ready)) __builtin_amdgcn_s_sleep(1);
+      } while (!__all(ready));
+      const bool is_prefix = idx >= 0 && (word >> 62) == 2;
+      const uint64_t prefix_lanes = __ballot(is_prefix);
+      const uint32_t first_prefix = prefix_lanes ? static_cast<uint32_t>(__ffsll(static_cast<long long>(prefix_lanes)) - 1) : 64u;
+      uint32_t contribution = (idx >= 0 && lane <= first_prefix) ? static_cast<uint32_t>(word) : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) contribution += __shfl_xor(contribution, d, 64);
+      exclusive_prefix += contribution;
+      if (prefix_lanes) break;
+      window_end -= 64;
+    }
+    if (lane == 0) {
+      if (slice_id != 0) __hip_atomic_store(&a.status[slice_id], make_status(ST_PREFIX, a.epoch, exclusive_prefix + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_exclusive = exclusive_prefix;
+      if (slice.first_of_chunk) a.offsets[slice.chunk] = exclusive_prefix;
+      if (slice_id == a.n_slices - 1) a.offsets[a.n_chunks] = static_cast<uint64_t>(exclusive_prefix) + block_total;
+    }
+  }
+
+  // ---- 4. compact row numbers through LDS, then coalesced 8-byte RowID stores -----------------------------------------
+  if (block_total != 0) {
+    const uint32_t e0 = exclusive & 0xFFFF, e1 = (exclusive >> 16) & 0xFFFF, e2 = (exclusive >> 32) & 0xFFFF, e3 = exclusive >> 48;
+    const uint32_t base_k[4] = {wave_base + e0, wave_base + t0 + e1, wave_base + t0 + t1 + e2, wave_base + t0 + t1 + t2 + e3};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      uint32_t m = (mask >> (8 * k)) & 0xFFu;
+      uint32_t p = base_k[k];
+      const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+      while (m) {
+        const uint32_t j = __ffs(m) - 1;
+        m &= m - 1;
+        s_rows[p++] = static_cast<uint16_t>(r0 + j);
+      }
+    }
+  }
+  __syncthreads();
+  if (block_total != 0) {
+    const uint64_t out_base = s_exclusive;
+    if (out_base + block_total > a.capacity) {
+      if (tid == 0) *a.overflow = 1;
+    } else {
+      uint2* out = reinterpret_cast<uint2*>(a.matches + out_base);
+      for (uint32_t i = tid; i < block_total; i += WG_THREADS) out[i] = make_uint2(slice.chunk, slice.row_begin + s_rows[i]);
+    }
+  }
+}
+
+struct FinalizeArgs {
+  const DevSegment* segments;
+  const ScanJob* jobs;
+  uint32_t n_chunks;
+  uint32_t materialize_all;
+  uint32_t columns_scan;
+  const uint32_t* excluded;   // sorted chunk ids or nullptr
+  uint32_t n_excluded;
+  const uint64_t* offsets;
+  uint32_t* counts;
+  uint8_t* chunk_state;
+};
+
+__global__ void finalize_scan(FinalizeArgs a) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.n_chunks) return;
+  const DevSegment s = a.segments[c];
+  uint32_t mode = JOB_SCAN;
+  if (!a.columns_scan) {
+    if (s.encoding != HY_ENC_REFERENCE) mode = a.jobs[c].mode;
+    else if (s.ref_chunk_id != 0xFFFFFFFFu && s.size > 0) mode = a.jobs[s.ref_chunk_id].mode;
+  }
+  const uint32_t written = static_cast<uint32_t>(a.offsets[c + 1] - a.offsets[c]);
+  a.counts[c] = (mode == JOB_ALL) ? s.size : written;
+  a.chunk_state[c] = mode == JOB_ALL ? HY_CHUNK_ALL_MATCH : mode == JOB_NONE ? HY_CHUNK_NONE_MATCH : HY_CHUNK_SCANNED;
+}
+
+__global__ void exclude_chunks(ScanJob* jobs, const uint32_t* excluded, uint32_t n_excluded) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_excluded) jobs[excluded[i]].mode = JOB_NONE;
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+
+static hy_status validate_predicate(const hy_column* column, const hy_predicate* p) {
+  const uint32_t c = p->condition;
+  const bool null_test = c == HY_PRED_IS_NULL || c == HY_PRED_IS_NOT_NULL;
+  if (!(c <= HY_PRED_BETWEEN_EXCLUSIVE || null_test)) return fail(HY_ERR_UNSUPPORTED, "predicate condition %u stays on the CPU path (Like/In/ExpressionEvaluator)", c);
+  const hy_column* data_column = column->is_reference ? column->ref : column;
+  if (!null_test) {
+    if (data_column && data_column->has_dictionary_without_values) {
+      if (!p->per_chunk_lower || !p->per_chunk_upper) return fail(HY_ERR_INVALID, "string dictionary scan needs per-chunk value ids (hy_predicate.per_chunk_lower/upper)");
+    } else if (column->data_type == HY_TYPE_STRING) {
+      // dictionary<string> with no dictionary buffers at all (every chunk NULL-only) still needs resolved ids
+      if (!p->per_chunk_lower || !p->per_chunk_upper) return fail(HY_ERR_INVALID, "string column scan needs per-chunk value ids");
+    } else if (p->value_type != column->data_type) {
+      // ColumnVsValueTableScanImpl asserts equal types (column_vs_value_table_scan_impl.cpp:34-36)
+      return fail(HY_ERR_INVALID, "literal type %u differs from column type %u: use the lossless predicate cast first", p->value_type, column->data_type);
+    }
+  }
+  return HY_OK;
+}
+
+static hy_status run_scan(const hy_column* column, const hy_column* right, const hy_predicate* predicate, uint32_t condition,
+                          const uint32_t* excluded, uint32_t n_excluded, hy_scan_result* result) {
+  const uint32_t n_chunks = column->n_chunks;
+  const hy_column* data_column = column->is_reference ? column->ref : column;
+  const uint32_t n_data_chunks = data_column ? data_column->n_chunks : 0;
+  const bool host_result = result->mem == HY_MEM_HOST;
+  if (!result->offsets || !result->counts || !result->chunk_state) return fail(HY_ERR_INVALID, "scan result arrays missing");
+  if (result->capacity && !result->matches) return fail(HY_ERR_INVALID, "scan result: matches buffer missing");
+  hipStream_t stream = current_stream();
+  Scratch& sc = scratch();
+
+  // Scratch: jobs | per_chunk arrays | excluded | overflow flag | (host results) device copies of the outputs
+  const uint64_t device_capacity = host_result ? column->rows : result->capacity;
+  size_t need = sizeof(ScanJob) * (n_data_chunks + 1) + 3 * 4 * (size_t{n_data_chunks} + 64) + 4 * (size_t{n_excluded} + 64) + 1024;
+  if (host_result) need += sizeof(hy_row_id) * (device_capacity + 1) + 8 * (size_t{n_chunks} + 2) + 4 * (size_t{n_chunks} + 1) + n_chunks + 4096;
+  HY_TRY(sc.reserve(need + 16 * 256));
+  ScanJob* d_jobs = carve<ScanJob>(sc, n_data_chunks + 1);
+  uint32_t* d_overflow = carve<uint32_t>(sc, 64);
+  HY_HIP(hipMemsetAsync(d_overflow, 0, 4, stream));
+
+  PredicateArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.materialize_all = (result->flags & HY_SCAN_MATERIALIZE_ALL_MATCH) ? 1 : 0;
+  if (predicate) {
+    pa.condition = predicate->condition;
+    pa.value_type = predicate->value_type;
+    pa.value = predicate->value;
+    pa.value2 = predicate->value2;
+    pa.column_is_nullable = predicate->column_is_nullable;
+    auto stage = [&](const void* host, size_t bytes, const void** dev) -> hy_status {
+      *dev = nullptr;
+      if (!host) return HY_OK;
+      void* d = sc.carve(bytes ? bytes : 4);
+      HY_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, stream));
+      *dev = d;
+      return HY_OK;
+    };
+    const void* d;
+    HY_TRY(stage(predicate->per_chunk_lower, 4 * size_t{n_data_chunks}, &d)); pa.per_chunk_lower = static_cast<const uint32_t*>(d);
+    HY_TRY(stage(predicate->per_chunk_upper, 4 * size_t{n_data_chunks}, &d)); pa.per_chunk_upper = static_cast<const uint32_t*>(d);
+    HY_TRY(stage(predicate->per_chunk_found, size_t{n_data_chunks}, &d)); pa.per_chunk_found = static_cast<const uint8_t*>(d);
+    if (n_data_chunks) {
+      hipLaunchKernelGGL(prepare_jobs, dim3((n_data_chunks + 255) / 256), dim3(256), 0, stream, data_column->d_segments, n_data_chunks, pa, d_jobs);
+    }
+  }
+  uint32_t* d_excluded = nullptr;
+  if (n_excluded) {
+    if (column->is_reference) return fail(HY_ERR_INVALID, "excluded chunks apply to data tables only");
+    d_excluded = carve<uint32_t>(sc, n_excluded);
+    HY_HIP(hipMemcpyAsync(d_excluded, excluded, 4 * size_t{n_excluded}, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(exclude_chunks, dim3((n_excluded + 255) / 256), dim3(256), 0, stream, d_jobs, d_excluded, n_excluded);
+  }
+
+  hy_row_id* d_matches = result->matches;
+  uint64_t* d_offsets = result->offsets;
+  uint32_t* d_counts = result->counts;
+  uint8_t* d_state = result->chunk_state;
+  if (host_result) {
+    d_matches = carve<hy_row_id>(sc, device_capacity + 1);
+    d_offsets = carve<uint64_t>(sc, size_t{n_chunks} + 2);
+    d_counts = carve<uint32_t>(sc, size_t{n_chunks} + 1);
+    d_state = carve<uint8_t>(sc, size_t{n_chunks} + 1);
+    if (!d_matches || !d_offsets || !d_counts || !d_state) return fail(HY_ERR_DEVICE, "scratch arena exhausted");
+  }
+
+  if (n_chunks == 0) {
+    HY_HIP(hipMemsetAsync(d_offsets, 0, 8, stream));
+  } else {
+    HY_TRY(sc.begin_launch(column->n_slices, column->n_slices));
+    ScanArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.segments = column->d_segments;
+    a.right = right ? right->d_segments : nullptr;
+    a.slices = column->d_slices;
+    a.jobs = d_jobs;
+    a.n_slices = column->n_slices;
+    a.n_chunks = n_chunks;
+    a.condition = condition;
+    a.materialize_all = pa.materialize_all;
+    a.is_null_scan = predicate && predicate->condition == HY_PRED_IS_NULL;
+    a.epoch = sc.epoch;
+    a.ticket_base = sc.ticket_base;
+    a.ticket = sc.ticket;
+    a.status = sc.status;
+    a.matches = d_matches;
+    a.capacity = device_capacity;
+    a.offsets = d_offsets;
+    a.overflow = d_overflow;
+    sc.ticket_base += column->n_slices;
+    hipLaunchKernelGGL(scan_slices, dim3(column->n_slices), dim3(WG_THREADS), 0, stream, a);
+    FinalizeArgs f;
+    f.segments = column->d_segments;
+    f.jobs = d_jobs;
+    f.n_chunks = n_chunks;
+    f.materialize_all = pa.materialize_all;
+    f.columns_scan = right ? 1 : 0;
+    f.excluded = d_excluded;
+    f.n_excluded = n_excluded;
+    f.offsets = d_offsets;
+    f.counts = d_counts;
+    f.chunk_state = d_state;
+    hipLaunchKernelGGL(finalize_scan, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, f);
+  }
+  HY_HIP(hipGetLastError());
+
+  if (host_result) {
+    uint32_t overflow = 0;
+    HY_HIP(hipMemcpyAsync(result->offsets, d_offsets, 8 * (size_t{n_chunks} + 1), hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipMemcpyAsync(result->counts, d_counts, 4 * size_t{n_chunks}, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipMemcpyAsync(result->chunk_state, d_state, size_t{n_chunks}, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipStreamSynchronize(stream));
+    const uint64_t total = result->offsets[n_chunks];
+    result->total_matches = total;
+    if (overflow || total > result->capacity) return fail(HY_ERR_CAPACITY, "scan produced %llu RowIDs, capacity is %llu", static_cast<unsigned long long>(total), static_cast<unsigned long long>(result->capacity));
+    if (total) HY_HIP(hipMemcpyAsync(result->matches, d_matches, sizeof(hy_row_id) * total, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipStreamSynchronize(stream));
+  } else {
+    result->total_matches = 0;
+  }
+  return HY_OK;
+}
+
+}  // namespace hy
+
+using namespace hy;
+
+extern "C" {
+
+hy_status hy_table_scan(const hy_column* column, const hy_predicate* predicate, const uint32_t* excluded_chunks,
+                        uint32_t n_excluded, hy_scan_result* result) {
+  if (!column || !predicate || !result) return fail(HY_ERR_INVALID, "hy_table_scan: null argument");
+  if (n_excluded && !excluded_chunks) return fail(HY_ERR_INVALID, "hy_table_scan: excluded chunk list missing");
+  for (uint32_t i = 0; i < n_excluded; ++i) {
+    if (excluded_chunks[i] >= column->n_chunks) return fail(HY_ERR_INVALID, "excluded chunk id %u out of range", excluded_chunks[i]);
+  }
+  HY_TRY(validate_predicate(column, predicate));
+  if (column->multi_chunk_reference) {
+    return fail(HY_ERR_UNSUPPORTED, "pos lists spanning several chunks are reordered by referenced chunk on the CPU path "
+                                    "(abstract_dereferenced_column_table_scan_impl.cpp:49-86)");
+  }
+  return run_scan(column, nullptr, predicate, 0, excluded_chunks, n_excluded, result);
+}
+
+hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, uint32_t condition,
+                                hy_scan_result* result) {
+  if (!left || !right || !result) return fail(HY_ERR_INVALID, "hy_table_scan_columns: null argument");
+  if (condition > HY_PRED_GREATER_THAN_EQUALS) return fail(HY_ERR_INVALID, "ColumnVsColumn supports binary comparisons only");
+  if (left->n_chunks != right->n_chunks) return fail(HY_ERR_INVALID, "columns of one table must have the same chunk count");
+  for (uint32_t c = 0; c < left->n_chunks; ++c) {
+    if (left->host_segments[c].size != right->host_segments[c].size) return fail(HY_ERR_INVALID, "chunk %u: segment sizes differ", c);
+  }
+  if (left->data_type == HY_TYPE_STRING || right->data_type == HY_TYPE_STRING) return fail(HY_ERR_UNSUPPORTED, "string ColumnVsColumn scans stay on the CPU path");
+  return run_scan(left, right, nullptr, condition, nullptr, 0, result);
+}
+
+}  // extern "C"

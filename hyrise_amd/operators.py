@@ -1,0 +1,84 @@
+"""Thin Python callers of the C ABI (tests / bench plumbing).  Every function here ends in a call into
+libhyrise_amd.so; nothing is computed in Python."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+def make_predicate(condition, data_type=abi.TYPE_INT, value=None, value2=None, nullable=False, per_chunk_lower=None,
+                   per_chunk_upper=None, per_chunk_found=None):
+    p = abi.Predicate()
+    p.condition = condition
+    p.value_type = data_type
+    for field, v in (("value", value), ("value2", value2)):
+        if v is None:
+            continue
+        u = getattr(p, field)
+        if data_type == abi.TYPE_INT:
+            u.i32 = int(v)
+        elif data_type == abi.TYPE_LONG:
+            u.i64 = int(v)
+        elif data_type == abi.TYPE_FLOAT:
+            u.f32 = float(v)
+        elif data_type == abi.TYPE_DOUBLE:
+            u.f64 = float(v)
+    p.column_is_nullable = 1 if nullable else 0
+    keep = []
+    for name, arr, dt in (("per_chunk_lower", per_chunk_lower, np.uint32), ("per_chunk_upper", per_chunk_upper, np.uint32),
+                          ("per_chunk_found", per_chunk_found, np.uint8)):
+        if arr is not None:
+            arr = np.ascontiguousarray(arr, dtype=dt)
+            keep.append(arr)
+            setattr(p, name, arr.ctypes.data)
+    p._keepalive = keep
+    return p
+
+
+class HostScanResult:
+    """Scan result in host memory, numpy views."""
+
+    def __init__(self, n_chunks, capacity, flags=0):
+        self.matches = np.zeros((max(1, capacity), 2), dtype=np.uint32)
+        self.offsets = np.zeros(n_chunks + 1, dtype=np.uint64)
+        self.counts = np.zeros(max(1, n_chunks), dtype=np.uint32)
+        self.chunk_state = np.zeros(max(1, n_chunks), dtype=np.uint8)
+        self.n_chunks = n_chunks
+        r = abi.ScanResult()
+        r.mem = abi.MEM_HOST
+        r.flags = flags
+        r.matches = self.matches.ctypes.data
+        r.capacity = capacity
+        r.offsets = self.offsets.ctypes.data
+        r.counts = self.counts.ctypes.data
+        r.chunk_state = self.chunk_state.ctypes.data
+        self.c = r
+
+    def pos_list(self, chunk):
+        return self.matches[int(self.offsets[chunk]):int(self.offsets[chunk + 1])]
+
+    @property
+    def total(self):
+        return int(self.offsets[self.n_chunks])
+
+
+def table_scan(column, predicate, excluded_chunks=None, flags=0, capacity=None):
+    """hy_table_scan with a host-memory result."""
+    lib = abi.load_library()
+    result = HostScanResult(column.n_chunks, column.rows if capacity is None else capacity, flags)
+    excluded = None
+    n_excluded = 0
+    if excluded_chunks is not None and len(excluded_chunks):
+        excluded = np.ascontiguousarray(excluded_chunks, dtype=np.uint32)
+        n_excluded = len(excluded)
+    abi.check(lib.hy_table_scan(column.handle, C.byref(predicate), excluded.ctypes.data if excluded is not None else None,
+                                n_excluded, C.byref(result.c)))
+    return result
+
+
+def table_scan_columns(left, right, condition, capacity=None):
+    lib = abi.load_library()
+    result = HostScanResult(left.n_chunks, left.rows if capacity is None else capacity)
+    abi.check(lib.hy_table_scan_columns(left.handle, right.handle, condition, C.byref(result.c)))
+    return result

@@ -1,0 +1,250 @@
+/*
+ * hyrise_amd.h -- C ABI of the MI355X-native execution hot path for Hyrise.
+ *
+ * This is the drop-in boundary: the three read-only operators whose `_on_execute()` bodies
+ * (reference: src/lib/operators/abstract_read_only_operator.hpp:20-22) are replaced call these
+ * entry points with plain pointers and sizes.  No C++ types, no torch types, no exceptions cross
+ * this line.  Every function returns an `hy_status`; a non-zero status has a message retrievable
+ * through `hy_last_error()` (the Hyrise adapter turns it into `Fail(...)`, i.e. std::logic_error,
+ * reference: src/lib/utils/assert.hpp:48-70).  `HY_ERR_UNSUPPORTED` means "shape not handled on
+ * the device; run the stock CPU operator" and is never an execution failure.
+ *
+ * Layout contract (all restated from the reference):
+ *   RowID            {u32 chunk_id, u32 chunk_offset}, NULL_ROW_ID = {~0u, ~0u}   types.hpp:97-117,150
+ *   ValueSegment<T>  T values[n] (+ optional null bitmap)                        value_segment.hpp:84-85
+ *   DictionarySegment<T>  sorted unique T dictionary[d]; attribute vector of value ids as
+ *                    u8/u16/u32 (FixedWidthInteger); NULL == value id d           dictionary_segment.hpp:88-90
+ *   FrameOfReferenceSegment<int32>  i32 block_minima[ceil(n/2048)], offsets as u8/u16/u32,
+ *                    optional null bitmap; value = (i32)offset + minimum           frame_of_reference_segment.hpp:49,94-97
+ *   null bitmap      libstdc++ vector<bool> words: bit (i % 64) of u64 word (i / 64)
+ *   ReferenceSegment pos list of RowIDs into the chunks of another column          reference_segment.hpp:20-48
+ */
+#ifndef HYRISE_AMD_H_
+#define HYRISE_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HY_ABI_VERSION 1
+
+typedef int32_t hy_status;
+enum {
+  HY_OK = 0,
+  HY_ERR_INVALID = 1,     /* malformed argument: the adapter raises std::logic_error            */
+  HY_ERR_UNSUPPORTED = 2, /* shape not handled on the device: adapter runs the stock CPU path    */
+  HY_ERR_DEVICE = 3,      /* HIP runtime failure (message carries the hipError string)            */
+  HY_ERR_CAPACITY = 4     /* caller-provided output buffer too small                              */
+};
+
+/* Mirrors hyrise::DataType (all_type_variant.hpp:34-39,52). */
+enum { HY_TYPE_NULL = 0, HY_TYPE_INT = 1, HY_TYPE_LONG = 2, HY_TYPE_FLOAT = 3, HY_TYPE_DOUBLE = 4, HY_TYPE_STRING = 5 };
+
+/* Mirrors hyrise::PredicateCondition, same numeric order (types.hpp:160-179). */
+enum {
+  HY_PRED_EQUALS = 0, HY_PRED_NOT_EQUALS = 1, HY_PRED_LESS_THAN = 2, HY_PRED_LESS_THAN_EQUALS = 3,
+  HY_PRED_GREATER_THAN = 4, HY_PRED_GREATER_THAN_EQUALS = 5,
+  HY_PRED_BETWEEN_INCLUSIVE = 6, HY_PRED_BETWEEN_LOWER_EXCLUSIVE = 7, HY_PRED_BETWEEN_UPPER_EXCLUSIVE = 8,
+  HY_PRED_BETWEEN_EXCLUSIVE = 9,
+  HY_PRED_IN = 10, HY_PRED_NOT_IN = 11, HY_PRED_LIKE = 12, HY_PRED_NOT_LIKE = 13, HY_PRED_LIKE_INSENSITIVE = 14,
+  HY_PRED_NOT_LIKE_INSENSITIVE = 15, HY_PRED_IS_NULL = 16, HY_PRED_IS_NOT_NULL = 17
+};
+
+/* Mirrors hyrise::JoinMode, same numeric order (types.hpp:210). */
+enum {
+  HY_JOIN_INNER = 0, HY_JOIN_LEFT = 1, HY_JOIN_RIGHT = 2, HY_JOIN_FULL_OUTER = 3, HY_JOIN_CROSS = 4, HY_JOIN_SEMI = 5,
+  HY_JOIN_ANTI_NULL_AS_TRUE = 6, HY_JOIN_ANTI_NULL_AS_FALSE = 7
+};
+
+/* Aggregate functions handled by AggregateHash (window_function_traits.hpp:11-77). */
+enum {
+  HY_AGG_MIN = 0, HY_AGG_MAX = 1, HY_AGG_SUM = 2, HY_AGG_AVG = 3, HY_AGG_COUNT = 4, HY_AGG_COUNT_DISTINCT = 5,
+  HY_AGG_STDDEV_SAMP = 6, HY_AGG_ANY = 7
+};
+
+enum { HY_ENC_UNENCODED = 0, HY_ENC_DICTIONARY = 1, HY_ENC_FRAME_OF_REFERENCE = 2, HY_ENC_REFERENCE = 3 };
+
+/* Where the pointers of a descriptor / result live. */
+enum { HY_MEM_HOST = 0, HY_MEM_DEVICE = 1 };
+
+#define HY_INVALID_VALUE_ID 0xFFFFFFFFu /* "not found" (types.hpp:152), NOT the NULL value id */
+#define HY_FOR_BLOCK_SIZE 2048u         /* frame_of_reference_segment.hpp:49 */
+#define HY_INVALID_COLUMN 0xFFFFu       /* COUNT(*) argument (INVALID_COLUMN_ID)                      */
+
+typedef struct hy_row_id {
+  uint32_t chunk_id;
+  uint32_t chunk_offset;
+} hy_row_id;
+
+typedef struct hy_column hy_column; /* opaque: one column of a table, chunk by chunk, resident on the device */
+
+/*
+ * One segment (= one column of one chunk).  Plain views of what Hyrise keeps in pmr_vectors.
+ *   UNENCODED          data = T values[size]                       width = sizeof(T)
+ *   DICTIONARY         data = attribute vector (value ids)          width = 1|2|4
+ *                      aux  = T dictionary[aux_size] sorted unique; may be NULL for HY_TYPE_STRING
+ *                      (then comparisons must be passed as pre-resolved value ids, see hy_predicate)
+ *   FRAME_OF_REFERENCE data = offset values                         width = 1|2|4
+ *                      aux  = int32 block_minima[aux_size]
+ *   REFERENCE          data = hy_row_id pos_list[size]  (NULL => EntireChunkPosList{ref_chunk_id,size})
+ *                      ref  = the referenced column (data segments only; reference_segment.hpp:36-38)
+ * nulls: optional bitmap (see header comment); NULL when the segment stores no NULLs.
+ * Dictionary segments carry NULLs as value id == aux_size instead (dictionary_segment.cpp:139-141).
+ */
+typedef struct hy_segment {
+  uint32_t encoding;   /* HY_ENC_* */
+  uint32_t data_type;  /* HY_TYPE_* of the logical column */
+  uint32_t size;       /* rows in this chunk */
+  uint32_t width;      /* bytes per element of `data` */
+  const void* data;
+  const void* aux;
+  uint32_t aux_size;
+  uint32_t ref_chunk_id;     /* REFERENCE: common chunk id if the pos list references a single chunk, else ~0u */
+  const uint64_t* nulls;
+  const hy_column* ref;      /* REFERENCE only */
+} hy_segment;
+
+/* A literal as the scan implementations receive it after the lossless cast (table_scan.cpp:312-452). */
+typedef union hy_value {
+  int32_t i32;
+  int64_t i64;
+  float f32;
+  double f64;
+  uint32_t value_id;
+} hy_value;
+
+/*
+ * Predicate of ColumnVsValue / ColumnBetween / ColumnIsNull scans.
+ *   condition   HY_PRED_*; two-sided (between) conditions use value and value2.
+ *   value_type  HY_TYPE_* of value/value2; must equal the column type (ColumnVsValueTableScanImpl asserts this,
+ *               column_vs_value_table_scan_impl.cpp:34-36).
+ *   Dictionary segments whose dictionary is not on the device (strings): the caller resolves the literal per chunk
+ *   exactly as column_vs_value_table_scan_impl.cpp:211-226 / column_between_table_scan_impl.cpp:112-124 do and passes
+ *   per_chunk_lower / per_chunk_upper (value ids, HY_INVALID_VALUE_ID = past the end) plus, for =/!=,
+ *   per_chunk_found (1 if dictionary[lower] == literal).  Arrays have one entry per chunk of the column.
+ */
+typedef struct hy_predicate {
+  uint32_t condition;
+  uint32_t value_type;
+  hy_value value;
+  hy_value value2;
+  const uint32_t* per_chunk_lower;
+  const uint32_t* per_chunk_upper;
+  const uint8_t* per_chunk_found;
+  uint32_t column_is_nullable; /* Table::column_is_nullable(); matters for dictionary "matches all" early-outs */
+  uint32_t reserved;
+} hy_predicate;
+
+/* Per-chunk classification the scan reports (TableScan::PerformanceData counters, table_scan.hpp:56-69). */
+enum {
+  HY_CHUNK_SCANNED = 0,      /* PosList materialised in `matches`                                              */
+  HY_CHUNK_ALL_MATCH = 1,    /* every row matches: count == size, NO RowIDs written (EntireChunkPosList)        */
+  HY_CHUNK_NONE_MATCH = 2    /* early-out, count == 0                                                           */
+};
+
+/*
+ * Result of a scan.  `matches` holds the PosLists of all chunks back to back, in input-chunk order; chunk c owns
+ * matches[offsets[c] .. offsets[c+1]).  Positions are relative to the *input* chunk (scan_chunk() contract,
+ * abstract_dereferenced_column_table_scan_impl.cpp:75-80), ascending, bit-identical to the CPU operator's PosList.
+ * All arrays are caller-allocated, in the memory space `mem`.
+ */
+typedef struct hy_scan_result {
+  uint32_t mem;            /* HY_MEM_HOST | HY_MEM_DEVICE */
+  uint32_t flags;          /* HY_SCAN_* */
+  hy_row_id* matches;      /* capacity RowIDs */
+  uint64_t capacity;
+  uint64_t* offsets;       /* [n_chunks + 1] */
+  uint32_t* counts;        /* [n_chunks] matches per chunk (== size for ALL_MATCH chunks) */
+  uint8_t* chunk_state;    /* [n_chunks] HY_CHUNK_* */
+  uint64_t total_matches;  /* filled for HY_MEM_HOST results; for device results read offsets[n_chunks] */
+} hy_scan_result;
+
+#define HY_SCAN_MATERIALIZE_ALL_MATCH 1u /* also write RowIDs for ALL_MATCH chunks (what the CPU impl does internally) */
+
+/* ---- runtime -------------------------------------------------------------------------------------------------- */
+int32_t hy_abi_version(void);
+hy_status hy_init(int32_t device);            /* selects the HIP device for the calling process (one process per GPU) */
+hy_status hy_shutdown(void);
+const char* hy_last_error(void);              /* thread-local message of the last non-OK status */
+hy_status hy_set_stream(void* hip_stream);    /* thread-local stream used for all launches; NULL = default stream     */
+hy_status hy_synchronize(void);
+hy_status hy_device_malloc(void** ptr, size_t bytes);
+hy_status hy_device_free(void* ptr);
+hy_status hy_memcpy_h2d(void* dst, const void* src, size_t bytes);
+hy_status hy_memcpy_d2h(void* dst, const void* src, size_t bytes);
+hy_status hy_device_count(int32_t* count);
+
+/* ---- residency cache: a column made device-visible once (encoded segments are immutable,
+ *      abstract_encoded_segment.hpp:12-17) ------------------------------------------------------------------------ */
+/* mem == HY_MEM_HOST: segment buffers are copied to HBM and owned by the hy_column.
+ * mem == HY_MEM_DEVICE: pointers are device pointers and stay owned by the caller. */
+hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32_t mem, hy_column** out);
+hy_status hy_column_destroy(hy_column* column);
+hy_status hy_column_row_count(const hy_column* column, uint64_t* rows);
+hy_status hy_column_chunk_count(const hy_column* column, uint32_t* chunks);
+
+/* ---- TableScan (replaces TableScan::_on_execute's per-chunk scan_chunk() fan-out, table_scan.cpp:97-240) --------- */
+/* ColumnVsValue / ColumnBetween / ColumnIsNull (column_vs_value_table_scan_impl.cpp, column_between_table_scan_impl.cpp,
+ * column_is_null_table_scan_impl.cpp), over data or reference columns.  excluded_chunks may be NULL. */
+hy_status hy_table_scan(const hy_column* column, const hy_predicate* predicate, const uint32_t* excluded_chunks,
+                        uint32_t n_excluded, hy_scan_result* result);
+/* ColumnVsColumn (column_vs_column_table_scan_impl.cpp:36-187): left <condition> right, both columns of one table. */
+hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, uint32_t condition,
+                                hy_scan_result* result);
+
+/* ---- JoinHash (replaces JoinHash::_on_execute, join_hash.cpp:116-225,270-572) ----------------------------------- */
+typedef struct hy_join_result {
+  uint32_t mem;
+  uint32_t radix_bits;            /* in: 0xFFFFFFFF = derive like JoinHash::calculate_radix_bits; out: value used      */
+  hy_row_id* left_pos;            /* [capacity] RowIDs into the LEFT input (unused for Semi/Anti*: may be NULL)        */
+  hy_row_id* right_pos;           /* [capacity] RowIDs into the RIGHT input                                            */
+  uint64_t capacity;
+  uint64_t* slice_offsets;        /* [slice_capacity + 1] boundaries of the per-probe-slice PosLists                   */
+  uint32_t slice_capacity;
+  uint32_t n_slices;              /* out */
+  uint64_t n_pairs;               /* out */
+  uint32_t left_is_build;         /* out: JoinHash::PerformanceData::left_input_is_build_side                          */
+  uint32_t reserved;
+} hy_join_result;
+
+/* Equi-join of two int32/int64 columns.  Pair order == the CPU operator's concatenated probe() output
+ * (join_hash_steps.hpp:624-792): by radix partition, then probe row, then build-side insertion order. */
+hy_status hy_join_hash(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result);
+hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint32_t* radix_bits);
+/* Upper bound for result->capacity without running the join (Semi/Anti: probe rows; others: exact pair count). */
+hy_status hy_join_hash_count(const hy_column* left, const hy_column* right, uint32_t mode, uint64_t* n_pairs);
+
+/* ---- AggregateHash (replaces AggregateHash::_on_execute, aggregate_hash.cpp:1180-1372) -------------------------- */
+typedef struct hy_aggregate_spec {
+  uint32_t function;              /* HY_AGG_* */
+  const hy_column* column;        /* NULL for COUNT(*) */
+} hy_aggregate_spec;
+
+typedef struct hy_aggregate_column {
+  uint32_t data_type;             /* out: HY_TYPE_* of the result column (window_function_traits.hpp)                 */
+  uint32_t reserved;
+  void* values;                   /* [group_capacity] int64 / double / int32 / float                                   */
+  uint8_t* is_null;               /* [group_capacity] 1 = NULL (a group that saw only NULLs)                           */
+} hy_aggregate_column;
+
+typedef struct hy_aggregate_result {
+  uint32_t mem;
+  uint32_t group_capacity;
+  uint32_t n_groups;              /* out */
+  uint32_t reserved;
+  hy_row_id* group_row_ids;       /* [group_capacity] representative row per group (write_groupby_output)              */
+  hy_aggregate_column* columns;   /* [n_aggregates] */
+} hy_aggregate_result;
+
+/* Group order == the CPU operator's: first occurrence, or ascending key under the immediate-key shortcut
+ * (aggregate_hash.cpp:388-401, 770-804). */
+hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby,
+                            const hy_aggregate_spec* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYRISE_AMD_H_ */

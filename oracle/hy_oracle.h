@@ -1,0 +1,78 @@
+/*
+ * hy_oracle.h -- CPU restatement of the Hyrise hot path (TableScan / JoinHash / AggregateHash).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load liboracle.so, and only as the checker / reported CPU baseline.
+ *
+ * The reference (C++23 + Boost + oneTBB + 18 absent submodules) cannot be compiled in this environment
+ * (SURVEY.md section 0), so this is a restatement that follows the reference function by function; every function
+ * cites the file:line it follows.  It is pinned against the reference's own fixtures and known-answer tests
+ * (tests/golden/, see tests/test_oracle_*.py); what those tests do NOT pin (PosList order, join pair order,
+ * group order) is defined by the cited reference code only -- see DESIGN.md section 5.
+ *
+ * Descriptors are the product ABI's plain structs (include/hyrise_amd.h) with HOST pointers; `hy_segment.ref`
+ * points to an `hyo_column` here.
+ */
+#ifndef HY_ORACLE_H_
+#define HY_ORACLE_H_
+
+#include "../include/hyrise_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hyo_column {
+  const hy_segment* segments;
+  uint32_t n_chunks;
+} hyo_column;
+
+/* ---- encoders (dictionary_encoder.hpp:33-103, frame_of_reference_encoder.hpp:25-122,
+ *      fixed_width_integer_compressor.cpp:33-57) ---------------------------------------------------------------- */
+/* values: T[n] (NULL slots ignored), nulls: byte-per-row or NULL.  dict_out capacity n.  Returns dictionary size;
+ * *width_out = 1|2|4 (attribute vector element width), av_out capacity n*4 bytes. */
+uint32_t hyo_encode_dictionary(uint32_t data_type, const void* values, const uint8_t* nulls, uint32_t n,
+                               void* dict_out, void* av_out, uint32_t* width_out);
+/* int32 only.  minima_out capacity ceil(n/2048); offsets_out capacity n*4 bytes.  Returns width (1|2|4);
+ * *has_nulls_out = whether the segment keeps a null vector. */
+uint32_t hyo_encode_frame_of_reference(const int32_t* values, const uint8_t* nulls, uint32_t n, int32_t* minima_out,
+                                       void* offsets_out, uint32_t* has_nulls_out);
+/* byte-per-row null flags -> libstdc++ vector<bool> words. */
+void hyo_pack_nulls(const uint8_t* nulls, uint32_t n, uint64_t* words_out);
+
+/* ---- TableScan ------------------------------------------------------------------------------------------------ */
+/* AbstractDereferencedColumnTableScanImpl::scan_chunk for ColumnVsValue / ColumnBetween / ColumnIsNull.
+ * matches capacity = segment size.  Returns match count, -1 on unsupported input.  state_out (may be NULL) receives
+ * HY_CHUNK_ALL_MATCH / HY_CHUNK_NONE_MATCH when the reference takes an early-out, else HY_CHUNK_SCANNED. */
+int64_t hyo_scan_chunk(const hyo_column* column, uint32_t chunk_id, const hy_predicate* predicate, hy_row_id* matches,
+                       uint8_t* state_out);
+/* ColumnVsColumnTableScanImpl::scan_chunk. */
+int64_t hyo_scan_chunk_columns(const hyo_column* left, const hyo_column* right, uint32_t chunk_id, uint32_t condition,
+                               hy_row_id* matches);
+/* Whole-column driver with the ABI's result layout (host memory), single thread or `threads` pthreads over chunks
+ * (JobTask fan-out, table_scan.cpp:223-229). */
+int32_t hyo_table_scan(const hyo_column* column, const hy_predicate* predicate, hy_scan_result* result, int threads);
+int32_t hyo_table_scan_columns(const hyo_column* left, const hyo_column* right, uint32_t condition,
+                               hy_scan_result* result, int threads);
+
+/* ---- JoinHash ------------------------------------------------------------------------------------------------- */
+int32_t hyo_join_hash(const hyo_column* left, const hyo_column* right, uint32_t mode, hy_join_result* result,
+                      int threads);
+uint32_t hyo_calculate_radix_bits(uint64_t build_rows, uint64_t probe_rows);
+/* Step-level entry points pinned by join_hash_steps_test.cpp. */
+/* materialize_input: writes (row_id,value) elements of one column in chunk order; returns element count.
+ * bloom_in may be NULL (all-true); bloom_out 2^20 bits = 16384 u64 words (zeroed by the caller).
+ * histograms_out [n_chunks << radix_bits] */
+uint64_t hyo_join_materialize(const hyo_column* column, int keep_nulls, uint32_t radix_bits, const uint64_t* bloom_in,
+                              uint64_t* bloom_out, hy_row_id* row_ids_out, int64_t* values_out, uint8_t* nulls_out,
+                              uint64_t* chunk_element_counts_out, uint64_t* histograms_out);
+
+/* ---- AggregateHash -------------------------------------------------------------------------------------------- */
+int32_t hyo_aggregate_hash(const hyo_column* const* groupby_columns, uint32_t n_groupby,
+                           const uint32_t* functions, const hyo_column* const* aggregate_columns, uint32_t n_aggregates,
+                           hy_aggregate_result* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

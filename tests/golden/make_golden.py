@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Copies the reference's own test fixtures for the hot path into tests/golden/ (they are test DATA, not source), and
+records provenance.  Run in the build container where /root/reference is mounted:  python tests/golden/make_golden.py
+
+The expected values that the reference keeps inline in its gtest sources (explicit multisets in table_scan_test.cpp,
+index lists in table_scan_between_test.cpp, Bloom/histogram known answers in join_hash_steps_test.cpp) are restated
+with file:line citations in tests/golden/known_answers.py.
+"""
+import hashlib
+import json
+import os
+import shutil
+
+REF = "/root/reference/resources/test_data/tbl"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+FILES = [
+    # TableScan fixtures (src/test/lib/operators/table_scan_test.cpp, table_scan_between_test.cpp)
+    "int_float.tbl", "int_float2.tbl", "int_float_filtered.tbl", "int_float_filtered2.tbl", "int_float_with_null.tbl",
+    "int_int_shuffled.tbl", "int_int_shuffled_2.tbl", "int_sorted.tbl", "int_int_w_null_8_rows.tbl",
+    "int_int3.tbl", "int_int_int.tbl", "int_string_like.tbl", "int_float_null_1.tbl", "int_float_null_2.tbl",
+    "int_float4.tbl", "int_float_double_string.tbl", "float_int.tbl", "int.tbl", "int2.tbl", "int3.tbl",
+    # JoinHash: differential-testing inputs (src/test/lib/operators/join_test_runner.cpp:656-791)
+    "join_test_runner/input_table_left_0.tbl", "join_test_runner/input_table_left_10.tbl",
+    "join_test_runner/input_table_left_15.tbl", "join_test_runner/input_table_right_0.tbl",
+    "join_test_runner/input_table_right_10.tbl", "join_test_runner/input_table_right_15.tbl",
+    # realistic inputs (join_hash_test.cpp:24-31)
+    "tpch/sf-0.001/lineitem.tbl", "tpch/sf-0.001/orders.tbl",
+]
+
+
+def main():
+    manifest = {}
+    names = list(FILES)
+    # AggregateHash: every input/expected pair (src/test/lib/operators/aggregate_test.cpp:290-852)
+    for root, _, files in os.walk(os.path.join(REF, "aggregateoperator")):
+        for f in sorted(files):
+            names.append(os.path.relpath(os.path.join(root, f), REF))
+    for name in names:
+        src = os.path.join(REF, name)
+        if not os.path.exists(src):
+            print("missing in reference:", name)
+            continue
+        dst = os.path.join(HERE, "tbl", name)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copyfile(src, dst)
+        with open(src, "rb") as fh:
+            manifest[name] = {"source": "resources/test_data/tbl/" + name, "sha256": hashlib.sha256(fh.read()).hexdigest()}
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+    print(len(manifest), "fixtures copied")
+
+
+if __name__ == "__main__":
+    main()

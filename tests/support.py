@@ -1,0 +1,235 @@
+"""Test support: the CPU oracle binding (oracle/liboracle.so -- TEST INFRASTRUCTURE, never imported by the product),
+the reference's `.tbl` text-table format, and helpers to run one predicate through oracle and device."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hyrise_amd import abi, storage
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "tbl")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class OracleColumn(C.Structure):
+    _fields_ = [("segments", C.POINTER(abi.Segment)), ("n_chunks", C.c_uint32)]
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is not None:
+        return _oracle
+    if not os.path.exists(ORACLE_PATH):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+    lib = C.CDLL(ORACLE_PATH)
+    lib.hyo_encode_dictionary.restype = C.c_uint32
+    lib.hyo_encode_dictionary.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_uint32)]
+    lib.hyo_encode_frame_of_reference.restype = C.c_uint32
+    lib.hyo_encode_frame_of_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                  C.POINTER(C.c_uint32)]
+    lib.hyo_pack_nulls.restype = None
+    lib.hyo_pack_nulls.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.hyo_scan_chunk.restype = C.c_int64
+    lib.hyo_scan_chunk.argtypes = [C.POINTER(OracleColumn), C.c_uint32, C.POINTER(abi.Predicate), C.c_void_p, C.c_void_p]
+    lib.hyo_scan_chunk_columns.restype = C.c_int64
+    lib.hyo_scan_chunk_columns.argtypes = [C.POINTER(OracleColumn), C.POINTER(OracleColumn), C.c_uint32, C.c_uint32,
+                                           C.c_void_p]
+    lib.hyo_table_scan.restype = C.c_int32
+    lib.hyo_table_scan.argtypes = [C.POINTER(OracleColumn), C.POINTER(abi.Predicate), C.POINTER(abi.ScanResult), C.c_int]
+    lib.hyo_table_scan_columns.restype = C.c_int32
+    lib.hyo_table_scan_columns.argtypes = [C.POINTER(OracleColumn), C.POINTER(OracleColumn), C.c_uint32,
+                                           C.POINTER(abi.ScanResult), C.c_int]
+    _oracle = lib
+    return lib
+
+
+class OracleCol:
+    """hyo_column over a HostColumn (host pointers)."""
+
+    def __init__(self, host_column):
+        self.host = host_column
+        self._ref_cols = {}
+
+        def resolve(ref_host):
+            col = self._ref_cols.get(id(ref_host))
+            if col is None:
+                col = OracleCol(ref_host)
+                self._ref_cols[id(ref_host)] = col
+            return C.addressof(col.c)
+
+        self._descriptors = host_column.descriptors(resolve)
+        self.c = OracleColumn(self._descriptors, host_column.n_chunks)
+
+
+def oracle_scan(host_column, predicate, flags=0, threads=1):
+    """hyo_table_scan -> same result layout as the ABI (host numpy arrays)."""
+    from hyrise_amd.operators import HostScanResult
+    col = OracleCol(host_column)
+    result = HostScanResult(host_column.n_chunks, host_column.rows, flags)
+    status = oracle().hyo_table_scan(C.byref(col.c), C.byref(predicate), C.byref(result.c), threads)
+    assert status == 0, f"oracle scan failed with {status}"
+    return result
+
+
+def oracle_scan_columns(left, right, condition, threads=1):
+    from hyrise_amd.operators import HostScanResult
+    lcol, rcol = OracleCol(left), OracleCol(right)
+    result = HostScanResult(left.n_chunks, left.rows)
+    status = oracle().hyo_table_scan_columns(C.byref(lcol.c), C.byref(rcol.c), condition, C.byref(result.c), threads)
+    assert status == 0, f"oracle scan failed with {status}"
+    return result
+
+
+# ---- .tbl text tables (src/lib/utils/load_table.cpp:22-96) -----------------------------------------------------------
+TBL_TYPES = {"int": abi.TYPE_INT, "long": abi.TYPE_LONG, "float": abi.TYPE_FLOAT, "double": abi.TYPE_DOUBLE,
+             "string": abi.TYPE_STRING}
+
+
+class TblTable:
+    def __init__(self, names, types, nullable, columns, nulls):
+        self.names, self.types, self.nullable, self.columns, self.nulls = names, types, nullable, columns, nulls
+
+    @property
+    def rows(self):
+        return len(self.columns[0]) if self.columns else 0
+
+    def column(self, name_or_index):
+        i = self.names.index(name_or_index) if isinstance(name_or_index, str) else name_or_index
+        return self.columns[i], (self.nulls[i] if self.nullable[i] else None)
+
+
+def load_tbl(path):
+    """Line 1: column names, line 2: types ('int', 'float_null', ...), then '|'-separated rows; 'null' in a nullable
+    column is NULL."""
+    if not os.path.isabs(path):
+        path = os.path.join(GOLDEN, path)
+    with open(path) as fh:
+        lines = fh.read().split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    names = lines[0].split("|")
+    type_specs = lines[1].split("|")
+    types, nullable = [], []
+    for spec in type_specs:
+        parts = spec.split("_")
+        types.append(TBL_TYPES[parts[0]])
+        nullable.append(len(parts) > 1 and parts[1] == "null")
+    raw = [line.split("|") for line in lines[2:]]
+    columns, nulls = [], []
+    for c, t in enumerate(types):
+        cells = [row[c] for row in raw]
+        is_null = np.array([nullable[c] and cell == "null" for cell in cells], dtype=bool)
+        if t == abi.TYPE_STRING:
+            values = np.array([("" if n else cell) for cell, n in zip(cells, is_null)], dtype=object)
+        else:
+            np_type = storage.NP_TYPES[t]
+            if t in (abi.TYPE_INT, abi.TYPE_LONG):
+                values = np.array([0 if n else int(cell) for cell, n in zip(cells, is_null)], dtype=np_type)
+            else:
+                values = np.array([0 if n else float(cell) for cell, n in zip(cells, is_null)], dtype=np_type)
+        columns.append(values)
+        nulls.append(is_null)
+    return TblTable(names, types, nullable, columns, nulls)
+
+
+def decode_rows(host_column, rows):
+    """Values (None for NULL) at (chunk_id, chunk_offset) RowIDs of a DATA HostColumn -- test-side decoding."""
+    out = []
+    for chunk_id, offset in rows:
+        seg = host_column.segments[int(chunk_id)]
+        offset = int(offset)
+        if seg.encoding == abi.ENC_DICTIONARY:
+            vid = int(seg.data[offset])
+            out.append(None if vid == seg.aux_size else seg.aux[vid].item())
+        elif seg.encoding == abi.ENC_FRAME_OF_REFERENCE:
+            is_null = seg.nulls is not None and (int(seg.nulls[offset // 64]) >> (offset % 64)) & 1
+            out.append(None if is_null else int(seg.data[offset]) + int(seg.aux[offset // abi.FOR_BLOCK_SIZE]))
+        else:
+            is_null = seg.nulls is not None and (int(seg.nulls[offset // 64]) >> (offset % 64)) & 1
+            out.append(None if is_null else seg.data[offset].item())
+    return out
+
+
+def assert_scan_equal(device_result, oracle_result, context=""):
+    """Bit-exact comparison of two scan results (offsets, counts, states, RowIDs)."""
+    n = oracle_result.n_chunks
+    np.testing.assert_array_equal(device_result.counts[:n], oracle_result.counts[:n], err_msg=f"counts {context}")
+    np.testing.assert_array_equal(device_result.chunk_state[:n], oracle_result.chunk_state[:n], err_msg=f"states {context}")
+    np.testing.assert_array_equal(device_result.offsets, oracle_result.offsets, err_msg=f"offsets {context}")
+    total = oracle_result.total
+    assert device_result.matches[:total].tobytes() == oracle_result.matches[:total].tobytes(), f"PosLists differ {context}"
+
+
+def gpu_available():
+    try:
+        lib = abi.load_library()
+    except (ImportError, OSError):
+        return False
+    count = C.c_int32(0)
+    return lib.hy_device_count(C.byref(count)) == 0 and count.value > 0
+
+
+def build_column(values, nulls, chunk_size, encodings, nullable=None):
+    """Column with per-chunk encodings (int or list; chunks past the list stay unencoded, like the reference's
+    partly-compressed test tables)."""
+    values = np.ascontiguousarray(values)
+    n = len(values)
+    nullable = (nulls is not None) if nullable is None else nullable
+    segments = []
+    for c, begin in enumerate(range(0, n, chunk_size)):
+        end = min(n, begin + chunk_size)
+        enc = encodings if isinstance(encodings, int) else (encodings[c] if c < len(encodings) else abi.ENC_UNENCODED)
+        if enc == abi.ENC_FRAME_OF_REFERENCE and values.dtype != np.int32:
+            enc = abi.ENC_UNENCODED  # encoding_supports_data_type(): fall back like load_and_encode_table
+        chunk_nulls = None
+        if nulls is not None:
+            chunk_nulls = np.asarray(nulls[begin:end], dtype=bool)
+        elif nullable and enc == abi.ENC_UNENCODED:
+            chunk_nulls = np.zeros(end - begin, dtype=bool)
+        segments.append(storage.encode_segment(values[begin:end], chunk_nulls, enc))
+    return storage.HostColumn(segments, storage.TYPE_OF_NP[values.dtype])
+
+
+def brute_force_scan(values, nulls, condition, value=None, value2=None):
+    """Independent numpy evaluation of a predicate (SQL semantics: NULL never matches a comparison)."""
+    valid = ~nulls if nulls is not None else np.ones(len(values), dtype=bool)
+    v = values
+    if condition == abi.PRED_IS_NULL:
+        return ~valid
+    if condition == abi.PRED_IS_NOT_NULL:
+        return valid
+    t = values.dtype.type
+    a = t(value)
+    ops = {abi.PRED_EQUALS: v == a, abi.PRED_NOT_EQUALS: v != a, abi.PRED_LESS_THAN: v < a,
+           abi.PRED_LESS_THAN_EQUALS: v <= a, abi.PRED_GREATER_THAN: v > a, abi.PRED_GREATER_THAN_EQUALS: v >= a}
+    if condition in ops:
+        return ops[condition] & valid
+    b = t(value2)
+    lower = (v >= a) if condition in (abi.PRED_BETWEEN_INCLUSIVE, abi.PRED_BETWEEN_UPPER_EXCLUSIVE) else (v > a)
+    upper = (v <= b) if condition in (abi.PRED_BETWEEN_INCLUSIVE, abi.PRED_BETWEEN_LOWER_EXCLUSIVE) else (v < b)
+    return lower & upper & valid
+
+
+def expected_result_from_mask(mask, chunk_size):
+    """(chunk_id, chunk_offset) pairs, ascending, for a boolean row mask of a data table."""
+    rows = np.nonzero(mask)[0]
+    return np.stack([rows // chunk_size, rows % chunk_size], axis=1).astype(np.uint32)
+
+
+def result_rows(result):
+    """All matching (chunk_id, chunk_offset) RowIDs of a scan result, expanding ALL_MATCH chunks (for which the ABI
+    writes no RowIDs: the adapter emits an EntireChunkPosList, table_scan.cpp:201-205)."""
+    rows = []
+    for c in range(result.n_chunks):
+        if result.chunk_state[c] == abi.CHUNK_ALL_MATCH and result.offsets[c + 1] == result.offsets[c]:
+            rows.extend((c, i) for i in range(int(result.counts[c])))
+        else:
+            rows.extend(map(tuple, result.pos_list(c).tolist()))
+    return rows

@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: the library builds, loads, and exports every symbol the header declares."""
+import os
+import re
+
+import pytest
+
+from hyrise_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "hyrise_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hy_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built():
+    assert os.path.exists(abi.LIB_PATH), "libhyrise_amd.so missing: run __graft_entry__.build()"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = abi.load_library()
+    declared = header_functions()
+    bound = sorted(name for name, _, _ in abi.SYMBOLS)
+    assert declared == bound, f"header and abi.py disagree: {set(declared) ^ set(bound)}"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+
+
+def test_abi_version_and_struct_sizes():
+    lib = abi.load_library()
+    assert lib.hy_abi_version() == 1
+    import ctypes as C
+    assert C.sizeof(abi.RowID) == 8          # types.hpp:97-117
+    assert C.sizeof(abi.Segment) == 56
+    assert C.sizeof(abi.Value) == 8
+
+
+def test_calls_without_a_device_fail_loudly():
+    """No GPU in the build container: the product path must say so instead of computing anything on the CPU."""
+    import ctypes as C
+    lib = abi.load_library()
+    count = C.c_int32(-1)
+    lib.hy_device_count(C.byref(count))
+    if count.value > 0:
+        pytest.skip("a GPU is visible")
+    status = lib.hy_init(0)
+    assert status == abi.ERR_DEVICE
+    assert lib.hy_last_error()

@@ -1,0 +1,208 @@
+"""Parity of the HIP TableScan with the CPU oracle: PosLists, per-chunk offsets/counts and early-out states must be
+bit-identical.  Every call goes through the C ABI (hy_table_scan / hy_table_scan_columns)."""
+import numpy as np
+import pytest
+
+from golden import known_answers as KA
+from hyrise_amd import abi, storage
+from hyrise_amd.operators import make_predicate, table_scan, table_scan_columns
+from hyrise_amd.storage import DeviceColumn
+from support import (assert_scan_equal, build_column, decode_rows, load_tbl, oracle_scan, oracle_scan_columns,
+                     result_rows)
+
+pytestmark = pytest.mark.gpu
+
+ENCODINGS = [abi.ENC_UNENCODED, abi.ENC_DICTIONARY, abi.ENC_FRAME_OF_REFERENCE]
+CONDITIONS = [abi.PRED_EQUALS, abi.PRED_NOT_EQUALS, abi.PRED_LESS_THAN, abi.PRED_LESS_THAN_EQUALS,
+              abi.PRED_GREATER_THAN, abi.PRED_GREATER_THAN_EQUALS, abi.PRED_BETWEEN_INCLUSIVE,
+              abi.PRED_BETWEEN_LOWER_EXCLUSIVE, abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.PRED_BETWEEN_EXCLUSIVE,
+              abi.PRED_IS_NULL, abi.PRED_IS_NOT_NULL]
+
+
+def check(host_column, predicate, device_column=None, flags=0, excluded=None, context=""):
+    dev = device_column or DeviceColumn(host_column)
+    got = table_scan(dev, predicate, excluded_chunks=excluded, flags=flags)
+    if excluded is None:
+        want = oracle_scan(host_column, predicate, flags=flags)
+        assert_scan_equal(got, want, context)
+    return got
+
+
+@pytest.mark.parametrize("np_type", [np.int32, np.int64, np.float32, np.float64])
+@pytest.mark.parametrize("with_nulls", [False, True])
+def test_scan_matches_oracle_small(device, np_type, with_nulls):
+    rng = np.random.default_rng(3)
+    data_type = storage.TYPE_OF_NP[np.dtype(np_type)]
+    for n, chunk in ((5000, 777), (20000, 8200), (1, 10), (8192, 8192), (8193, 65535)):
+        values = rng.integers(-50, 50, n).astype(np_type)
+        nulls = (rng.random(n) < 0.1) if with_nulls else None
+        for encoding in ENCODINGS:
+            if encoding == abi.ENC_FRAME_OF_REFERENCE and np_type != np.int32:
+                continue
+            host = build_column(values, nulls, chunk, encoding, nullable=with_nulls)
+            dev = DeviceColumn(host)
+            for condition in CONDITIONS:
+                for value, value2 in ((-7, 12), (3, 3), (12, -7), (-1000, 1000), (49, 49), (-50, -50)):
+                    for flags in (0, abi.SCAN_MATERIALIZE_ALL_MATCH):
+                        p = make_predicate(condition, data_type, value, value2, nullable=with_nulls)
+                        check(host, p, dev, flags, context=f"type {np_type.__name__} enc {encoding} cond {condition} "
+                                                           f"lit {value},{value2} n {n} chunk {chunk} flags {flags}")
+
+
+@pytest.mark.parametrize("width_values", [200, 3000, 70000])
+def test_scan_attribute_vector_widths(device, width_values):
+    """u8 / u16 / u32 attribute vectors and FoR offsets (fixed_width_integer_compressor.cpp:33-44)."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    values = rng.integers(0, width_values, n).astype(np.int32)
+    nulls = rng.random(n) < 0.02
+    for encoding in (abi.ENC_DICTIONARY, abi.ENC_FRAME_OF_REFERENCE):
+        for with_nulls in (False, True):
+            host = build_column(values, nulls if with_nulls else None, 65535, encoding, nullable=with_nulls)
+            expected_width = 1 if width_values <= 255 else 2 if width_values <= 65535 else 4
+            assert host.segments[0].width == expected_width
+            dev = DeviceColumn(host)
+            for condition in CONDITIONS:
+                p = make_predicate(condition, abi.TYPE_INT, width_values // 3, 2 * width_values // 3, nullable=with_nulls)
+                check(host, p, dev, context=f"enc {encoding} cond {condition} width {expected_width}")
+
+
+def test_reference_fixtures_on_device(device):
+    """The reference's inline known answers (table_scan_test.cpp:407-431,486-534) through the HIP path."""
+    for encoding in ENCODINGS:
+        for path, chunk in (("int_int_shuffled.tbl", 7), ("int_int_shuffled_2.tbl", 5)):
+            t = load_tbl(path)
+            a = build_column(t.columns[0], None, chunk, [encoding, encoding])
+            b = build_column(t.columns[1], None, chunk, [encoding, encoding])
+            dev = DeviceColumn(a)
+            for answers, literal in ((KA.SCAN_ON_COMPRESSED_SEGMENTS, 6), (KA.SCAN_VALUE_GREATER_THAN_MAX, 30),
+                                     (KA.SCAN_VALUE_LESS_THAN_MIN, -10)):
+                for condition, expected in answers.items():
+                    got = check(a, make_predicate(condition, abi.TYPE_INT, literal), dev)
+                    assert sorted(decode_rows(b, result_rows(got))) == sorted(expected)
+
+
+def test_scan_for_null_values_on_device(device):
+    t = load_tbl("int_int_w_null_8_rows.tbl")
+    for encoding in ENCODINGS:
+        a = build_column(t.columns[0], t.nulls[0], 4, encoding)
+        b = build_column(t.columns[1], t.nulls[1], 4, encoding)
+        for condition, expected in KA.SCAN_FOR_NULL_VALUES.items():
+            got = check(b, make_predicate(condition, abi.TYPE_INT, nullable=True))
+            values = decode_rows(a, result_rows(got))
+            assert sorted(values, key=lambda v: (v is None, v)) == sorted(expected, key=lambda v: (v is None, v))
+
+
+def test_wide_dictionary_on_device(device):
+    for entries, literal, expected_rows in KA.WIDE_DICTIONARY:
+        host = build_column(np.arange(entries + 1, dtype=np.int32), None, 100_000, abi.ENC_DICTIONARY)
+        got = check(host, make_predicate(abi.PRED_GREATER_THAN, abi.TYPE_INT, literal))
+        assert got.total == expected_rows
+
+
+def test_scan_reference_segments_single_chunk(device):
+    """Reference tables as a first TableScan (or Validate's EntireChunkPosList, validate.cpp:275) produces them:
+    every pos list references one chunk (fast path, abstract_dereferenced_column_table_scan_impl.cpp:38-46)."""
+    rng = np.random.default_rng(9)
+    n, chunk = 100_000, 20_000
+    values = rng.integers(0, 1000, n).astype(np.int32)
+    nulls = rng.random(n) < 0.05
+    for encoding in ENCODINGS:
+        base = build_column(values, nulls, chunk, encoding)
+        first = oracle_scan(base, make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 700, nullable=True),
+                            flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
+        pos_lists, single = [], []
+        for c in range(base.n_chunks):
+            pos_lists.append(first.pos_list(c).copy())
+            single.append(c)
+        pos_lists.append(2)  # EntireChunkPosList over chunk 2
+        single.append(2)
+        ref_host = storage.make_reference_column(base, pos_lists, single)
+        base_dev = DeviceColumn(base)
+        ref_dev = DeviceColumn(ref_host, refs={id(base): base_dev})
+        for condition in CONDITIONS:
+            p = make_predicate(condition, abi.TYPE_INT, 100, 400, nullable=True)
+            check(ref_host, p, ref_dev, context=f"reference enc {encoding} cond {condition}")
+
+
+def test_multi_chunk_pos_list_is_reported_unsupported(device):
+    """Multi-chunk pos lists are reordered by referenced chunk on the CPU path for now: the ABI must say UNSUPPORTED
+    (adapter falls back), never return a differently ordered PosList."""
+    t = load_tbl("int_int_shuffled_2.tbl")
+    a = build_column(t.columns[0], None, 5, abi.ENC_DICTIONARY)
+    ref = storage.make_reference_column(a, [np.array(KA.WEIRD_POS_LIST, dtype=np.uint32)], [None])
+    base_dev = DeviceColumn(a)
+    ref_dev = DeviceColumn(ref, refs={id(a): base_dev})
+    with pytest.raises(abi.HyriseAmdError) as err:
+        table_scan(ref_dev, make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, 10))
+    assert err.value.status == abi.ERR_UNSUPPORTED
+
+
+def test_column_vs_column(device):
+    rng = np.random.default_rng(13)
+    n, chunk = 70_000, 9_000
+    left = rng.integers(0, 20, n).astype(np.int32)
+    rights = [rng.integers(0, 20, n).astype(np.int32), rng.integers(0, 20, n).astype(np.int64),
+              (rng.integers(0, 20, n) + 0.5 * (rng.random(n) < 0.5)).astype(np.float32),
+              (rng.integers(0, 20, n) + 0.5 * (rng.random(n) < 0.5)).astype(np.float64)]
+    lnull, rnull = rng.random(n) < 0.1, rng.random(n) < 0.1
+    for right in rights:
+        for lenc in ENCODINGS:
+            for renc in (abi.ENC_UNENCODED, abi.ENC_DICTIONARY):
+                lcol, rcol = build_column(left, lnull, chunk, lenc), build_column(right, rnull, chunk, renc)
+                ldev, rdev = DeviceColumn(lcol), DeviceColumn(rcol)
+                for condition in CONDITIONS[:6]:
+                    got = table_scan_columns(ldev, rdev, condition)
+                    want = oracle_scan_columns(lcol, rcol, condition)
+                    assert_scan_equal(got, want, f"col-vs-col {right.dtype} lenc {lenc} renc {renc} cond {condition}")
+
+
+def test_excluded_chunks(device):
+    rng = np.random.default_rng(17)
+    values = rng.integers(0, 100, 50_000).astype(np.int32)
+    host = build_column(values, None, 5000, abi.ENC_DICTIONARY)
+    dev = DeviceColumn(host)
+    p = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 50)
+    full = oracle_scan(host, p)
+    got = table_scan(dev, p, excluded_chunks=[1, 4, 9])
+    for c in range(host.n_chunks):
+        if c in (1, 4, 9):
+            assert got.counts[c] == 0
+        else:
+            np.testing.assert_array_equal(got.pos_list(c), full.pos_list(c))
+
+
+def test_capacity_error(device):
+    values = np.arange(10_000, dtype=np.int32)
+    dev = DeviceColumn(build_column(values, None, 1000, abi.ENC_UNENCODED))
+    with pytest.raises(abi.HyriseAmdError) as err:
+        table_scan(dev, make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 5000), capacity=100)
+    assert err.value.status == abi.ERR_CAPACITY
+
+
+def test_type_mismatch_is_rejected(device):
+    dev = DeviceColumn(build_column(np.arange(10, dtype=np.int32), None, 5, abi.ENC_UNENCODED))
+    with pytest.raises(abi.HyriseAmdError) as err:
+        table_scan(dev, make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, 3.5))
+    assert err.value.status == abi.ERR_INVALID
+
+
+def test_large_scan_lineitem_shape(device):
+    """l_shipdate-shaped column at 1/10 of SF10 (6M rows, 92 chunks, u16 attribute vectors): oracle parity plus
+    size-independent properties (a predicate and its complement partition the rows; results are ascending)."""
+    rng = np.random.default_rng(42)
+    n = 6_000_000
+    days = (rng.integers(0, 2406, n) + rng.integers(1, 122, n)).astype(np.int32)
+    host = build_column(days, None, abi.CHUNK_DEFAULT_SIZE, abi.ENC_DICTIONARY)
+    assert host.segments[0].width == 2
+    dev = DeviceColumn(host)
+    total = 0
+    for condition, v, v2 in ((abi.PRED_LESS_THAN_EQUALS, 2436, None), (abi.PRED_GREATER_THAN, 2436, None),
+                             (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, 731, 1096), (abi.PRED_EQUALS, 1263, None)):
+        got = check(host, make_predicate(condition, abi.TYPE_INT, v, v2), dev)
+        if condition in (abi.PRED_LESS_THAN_EQUALS, abi.PRED_GREATER_THAN):
+            total += sum(int(c) for c in got.counts)
+        rows = got.matches[:got.total].astype(np.int64)
+        key = rows[:, 0] * (1 << 32) + rows[:, 1]
+        assert np.all(np.diff(key) > 0)
+    assert total == n
