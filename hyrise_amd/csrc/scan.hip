@@ -87,7 +87,7 @@ __device__ void dict_bounds(const DevSegment& s, T v, uint32_t* lower, uint32_t*
   *found = *lower != HY_INVALID_VALUE_ID && dict[*lower] == v;
 }
 
-__device__ void set_value_id_range(ScanJob& job, uint32_t lo, uint32_t hi_inclusive, bool invert) {
+__device__ __forceinline__ void set_value_id_range(ScanJob& job, uint32_t lo, uint32_t hi_inclusive, bool invert) {
   job.kind = KIND_U32;
   job.lo = lo;
   job.span = hi_inclusive - lo;
@@ -202,13 +202,18 @@ __global__ void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, Pred
       } else if (none) {
         job.mode = JOB_NONE;
       } else {
-        switch (cond) {  // .hpp:57-81; NULL (== d) is outside every range below
-          case HY_PRED_EQUALS: set_value_id_range(job, search, search, false); break;
-          case HY_PRED_NOT_EQUALS: set_value_id_range(job, search, search, true); break;  // + explicit NULL check
-          case HY_PRED_LESS_THAN:
-          case HY_PRED_LESS_THAN_EQUALS: set_value_id_range(job, 0, search - 1, false); break;
-          default: set_value_id_range(job, search, d - 1, false); break;
+        // .hpp:57-81; NULL (== d) is outside every range below
+        uint32_t range_lo = search, range_hi = search;
+        bool invert = false;
+        if (cond == HY_PRED_NOT_EQUALS) {
+          invert = true;   // + explicit NULL check in the kernel
+        } else if (cond == HY_PRED_LESS_THAN || cond == HY_PRED_LESS_THAN_EQUALS) {
+          range_lo = 0;
+          range_hi = search - 1;
+        } else if (cond == HY_PRED_GREATER_THAN || cond == HY_PRED_GREATER_THAN_EQUALS) {
+          range_hi = d - 1;
         }
+        set_value_id_range(job, range_lo, range_hi, invert);
       }
     }
     jobs[c] = job;

@@ -56,9 +56,10 @@ def test_scan_attribute_vector_widths(device, width_values):
     n = 300_000
     values = rng.integers(0, width_values, n).astype(np.int32)
     nulls = rng.random(n) < 0.02
+    chunk = 65535 if width_values <= 65535 else 290_000   # > 65536 distinct values need a bigger chunk
     for encoding in (abi.ENC_DICTIONARY, abi.ENC_FRAME_OF_REFERENCE):
         for with_nulls in (False, True):
-            host = build_column(values, nulls if with_nulls else None, 65535, encoding, nullable=with_nulls)
+            host = build_column(values, nulls if with_nulls else None, chunk, encoding, nullable=with_nulls)
             expected_width = 1 if width_values <= 255 else 2 if width_values <= 65535 else 4
             assert host.segments[0].width == expected_width
             dev = DeviceColumn(host)
