@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the MI355X hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload at every N: config 2 of BASELINE.json -- TableScan ColumnVsValue on a TPC-H SF10 lineitem `l_shipdate`
+column (59 986 052 rows, 916 chunks of 65 535, DictionarySegment<int32> + FixedWidthInteger u16 attribute vectors),
+predicate `l_shipdate < 1995-01-01` (the reference's own micro-benchmark predicate,
+src/benchmark/tpch_data_micro_benchmark.cpp:65-67).  One step = one hy_table_scan over the whole column with the
+column resident in HBM and the PosLists written to HBM.  With N GPUs every rank scans its own SF10-shaped shard of an
+N x SF10 table (chunks shard naturally, no data-path collective: SURVEY.md section 8(e)) -> weak scaling.
+
+Prints ONE JSON line on rank 0: rows/s over the whole job, plus `roofline` (scan_slices kernel: algorithmic bytes /
+HIP-event duration vs. the 8 TB/s HBM peak) and `cpu_baseline` (the CPU restatement of the Hyrise operator on the
+host cores, rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=0, help="override row count (debug); 0 = SF10 lineitem")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cases", action="store_true", help="also time the Q1/Q6/point predicates (extra JSON field)")
+    return ap.parse_args()
+
+
+def cpu_baseline(host_column, predicate, rows, budget_s=12.0):
+    """CPU restatement of the Hyrise TableScan (oracle/, kind 'port'), all host cores, one job per chunk range
+    (table_scan.cpp:223-229).  The ONLY place bench.py touches the oracle: a reported baseline, never the product."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import support
+    cores = os.cpu_count() or 1
+    times = []
+    t_end = time.perf_counter() + budget_s
+    support.oracle_scan(host_column, predicate, threads=cores)  # warm-up (page-in, thread start)
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 15):
+        t0 = time.perf_counter()
+        support.oracle_scan(host_column, predicate, threads=cores)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    median = times[len(times) // 2]
+    return {"value": rows / median, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": f"full {rows}-row l_shipdate column, same predicate, median of {len(times)} runs "
+                      f"({median * 1e3:.1f} ms each), CPU restatement of Hyrise's TableScan (not Hyrise itself)"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    from hyrise_amd import abi, tpch
+    from hyrise_amd.operators import make_predicate
+    from hyrise_amd.storage import DeviceColumn
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    lib = abi.load_library()          # raises if the HIP library is missing: no fallback
+    abi.check(lib.hy_init(local_rank))
+    stream = torch.cuda.current_stream()
+    abi.check(lib.hy_set_stream(C.c_void_p(stream.cuda_stream)))
+
+    # ---- data: this rank's SF10-shaped shard (seed differs per rank), encoded like Hyrise, uploaded once -------------
+    rows = args.rows or tpch.LINEITEM_ROWS_SF10
+    days, host_column = tpch.shipdate_column(rows, seed=42 + rank)
+    column = DeviceColumn(host_column)
+    n_chunks = host_column.n_chunks
+    predicate = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
+
+    dev = torch.device("cuda", local_rank)
+    matches = torch.empty((rows, 2), dtype=torch.int32, device=dev)
+    offsets = torch.zeros(n_chunks + 1, dtype=torch.int64, device=dev)
+    counts = torch.zeros(n_chunks, dtype=torch.int32, device=dev)
+    states = torch.zeros(n_chunks, dtype=torch.uint8, device=dev)
+    result = abi.ScanResult()
+    result.mem = abi.MEM_DEVICE
+    result.matches, result.capacity = matches.data_ptr(), rows
+    result.offsets, result.counts, result.chunk_state = offsets.data_ptr(), counts.data_ptr(), states.data_ptr()
+
+    def step(pred=predicate):
+        abi.check(lib.hy_table_scan(column.handle, C.byref(pred), None, 0, C.byref(result)))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    abi.check(lib.hy_set_profiling(1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = C.c_float(0), C.c_uint32(0)
+    abi.check(lib.hy_profile_read(C.byref(kernel_ms), C.byref(launches)))
+    abi.check(lib.hy_set_profiling(0))
+
+    n_matches = int(offsets[-1].item())
+    expected = int((days < tpch.DAY_1995_01_01).sum())
+    if n_matches != expected:
+        raise SystemExit(f"rank {rank}: scan produced {n_matches} matches, numpy says {expected}")
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_rows = rows * world
+    value = total_rows / (elapsed / args.steps)
+
+    # roofline of the dominant kernel (scan_slices): algorithmic bytes per launch = attribute vector + RowIDs written
+    width = host_column.segments[0].width
+    algorithmic_bytes = rows * width + n_matches * 8
+    kernel_s = (kernel_ms.value / max(1, launches.value)) * 1e-3
+    achieved = algorithmic_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+
+    extra_cases = None
+    if args.cases and rank == 0:
+        extra_cases = {}
+        for name, pred in (("q1_le_1998-09-02", make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, tpch.DAY_1998_09_02)),
+                           ("q6_between_1994", make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, tpch.DAY_1994_01_01, tpch.DAY_1995_01_01)),
+                           ("point_eq_1995-06-17", make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, tpch.CURRENT_DATE))):
+            for _ in range(3):
+                step(pred)
+            abi.check(lib.hy_set_profiling(1))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step(pred)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / args.steps
+            km, ln = C.c_float(0), C.c_uint32(0)
+            abi.check(lib.hy_profile_read(C.byref(km), C.byref(ln)))
+            abi.check(lib.hy_set_profiling(0))
+            m = int(offsets[-1].item())
+            bytes_case = rows * width + m * 8
+            extra_cases[name] = {"rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "matches": m,
+                                 "kernel_ms": km.value / max(1, ln.value),
+                                 "kernel_GBps": bytes_case / (km.value / max(1, ln.value) * 1e-3) / 1e9}
+
+    if rank == 0:
+        line = {
+            "metric": "rows/sec TableScan (ColumnVsValue, l_shipdate < 1995-01-01) on TPC-H SF10 lineitem",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "configs[1]: TableScan ColumnVsValue, SF10 lineitem l_shipdate, DictionarySegment<int32> "
+                                   "+ u16 attribute vectors, 916 chunks x 65535 rows, column and PosLists resident in HBM",
+                       "rows_per_gpu": rows, "chunks_per_gpu": n_chunks, "selectivity": n_matches / rows,
+                       "parallelism": f"chunk-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "scan_slices",
+                         "algorithmic_bytes_per_launch": algorithmic_bytes,
+                         "kernel_ms": kernel_s * 1e3, "launches_timed": int(launches.value)},
+        }
+        if extra_cases:
+            line["cases"] = extra_cases
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host_column, predicate, rows)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,10 @@ hy_status fail(hy_status code, const char* fmt, ...);
 
 hipStream_t current_stream();
 
+// Optional HIP-event bracket around the dominant kernel of an operator call (hy_set_profiling / hy_last_kernel_ms).
+void profile_begin(hipStream_t stream);
+void profile_end(hipStream_t stream);
+
 // ---- per-thread scratch (status words for decoupled look-back, job tables, temporaries) ----------------------------
 // Every operator call of a thread reuses one growing arena; thread-safe because it is thread-local, as are streams.
 struct Scratch {

@@ -25,6 +25,33 @@ hy_status fail(hy_status code, const char* fmt, ...) {
 
 hipStream_t current_stream() { return t_stream; }
 
+struct Profile {
+  bool enabled = false;
+  std::vector<hipEvent_t> events;   // start/stop pairs, reused across profiling sessions
+  size_t used = 0;
+};
+static thread_local Profile t_profile;
+
+static hipEvent_t next_event() {
+  Profile& p = t_profile;
+  if (p.used == p.events.size()) {
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    p.events.push_back(e);
+  }
+  return p.events[p.used++];
+}
+
+void profile_begin(hipStream_t stream) {
+  if (!t_profile.enabled || t_profile.used >= 16384) return;
+  (void)hipEventRecord(next_event(), stream);
+}
+
+void profile_end(hipStream_t stream) {
+  if (!t_profile.enabled || (t_profile.used & 1) == 0) return;
+  (void)hipEventRecord(next_event(), stream);
+}
+
 Scratch& scratch() { return t_scratch; }
 
 hy_status Scratch::reserve(size_t bytes) {
@@ -114,6 +141,30 @@ hy_status hy_init(int32_t device) {
     return fail(HY_ERR_DEVICE, "hy_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                 prop.gcnArchName);
   }
+  return HY_OK;
+}
+
+hy_status hy_set_profiling(int32_t enabled) {
+  t_profile.enabled = enabled != 0;
+  t_profile.used = 0;
+  return HY_OK;
+}
+
+hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches) {
+  if (!total_milliseconds || !launches) return fail(HY_ERR_INVALID, "hy_profile_read: null argument");
+  Profile& p = t_profile;
+  float total = 0.f;
+  uint32_t count = 0;
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    float ms = 0.f;
+    HY_HIP(hipEventSynchronize(p.events[i + 1]));
+    HY_HIP(hipEventElapsedTime(&ms, p.events[i], p.events[i + 1]));
+    total += ms;
+    ++count;
+  }
+  *total_milliseconds = total;
+  *launches = count;
+  p.used = 0;
   return HY_OK;
 }
 

@@ -824,7 +824,9 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     a.offsets = d_offsets;
     a.overflow = d_overflow;
     sc.ticket_base += column->n_slices;
+    profile_begin(stream);
     hipLaunchKernelGGL(scan_slices, dim3(column->n_slices), dim3(WG_THREADS), 0, stream, a);
+    profile_end(stream);
     FinalizeArgs f;
     f.segments = column->d_segments;
     f.jobs = d_jobs;

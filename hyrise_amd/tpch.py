@@ -1,0 +1,87 @@
+"""TPC-H lineitem / orders shaped synthetic columns (numpy, seeded) -- the inputs of bench.py and of the large tests.
+
+The reference generates TPC-H with its vendored dbgen (src/benchmarklib/tpch/tpch_table_generator.cpp:141-316), which
+cannot travel to the GPU box; this module follows the TPC-H specification's column distributions (the same ones
+dbgen implements) so that value ranges, dictionary sizes and vector-compression widths match what Hyrise would hold:
+  o_orderkey   sparse keys: 8 of every 32 integers (dbgen MK_SPARSE), ascending, unique   -> unencoded int32
+  o_orderdate  uniform in [1992-01-01, 1998-08-02]
+  lineitems    1..7 per order (mean 4)                                                     -> l_orderkey FoR, u16 offsets
+  l_shipdate   o_orderdate + uniform[1,121]; l_commitdate +[30,90]; l_receiptdate = ship + [1,30]
+  l_quantity   uniform[1,50]; l_discount uniform[0.00,0.10]; l_tax uniform[0.00,0.08]
+  l_extendedprice  quantity * retail price of a uniformly chosen part
+  l_returnflag 'R'/'A' if receiptdate <= 1995-06-17 else 'N'; l_linestatus 'O' if shipdate > 1995-06-17 else 'F'
+Dates are int32 days since 1992-01-01 (the "int" twin of SURVEY.md section 8: a dictionary scan only ever sees value
+ids, so DictionarySegment<int32> of day numbers and DictionarySegment<pmr_string> of ISO dates run the same kernel).
+"""
+import numpy as np
+
+from . import abi, storage
+
+ORDERS_PER_SF = 1_500_000
+LINEITEM_ROWS_SF10 = 59_986_052          # dbgen row count at SF 10 (tpch_table_generator.cpp:155-166)
+LAST_ORDERDATE = 2405                    # 1998-08-02 as days since 1992-01-01
+CURRENT_DATE = 1263                      # 1995-06-17
+DAY_1995_01_01 = 1096
+DAY_1994_01_01 = 731
+DAY_1998_09_02 = 2436
+
+
+def sparse_orderkeys(n):
+    """dbgen mk_sparse: ((i >> 3) << 5) | (i & 7) for i = 1..n."""
+    i = np.arange(1, n + 1, dtype=np.int64)
+    return (((i >> 3) << 5) | (i & 7)).astype(np.int32)
+
+
+class TpchData:
+    """Raw (unencoded) numpy columns of orders and lineitem at `scale_factor`."""
+
+    def __init__(self, scale_factor=10.0, seed=42, lineitem_rows=None):
+        rng = np.random.default_rng(seed)
+        n_orders = int(round(ORDERS_PER_SF * scale_factor))
+        self.o_orderkey = sparse_orderkeys(n_orders)
+        self.o_orderdate = rng.integers(0, LAST_ORDERDATE + 1, n_orders, dtype=np.int32)
+        counts = rng.integers(1, 8, n_orders, dtype=np.int32)
+        if lineitem_rows is None and abs(scale_factor - 10.0) < 1e-9:
+            lineitem_rows = LINEITEM_ROWS_SF10
+        if lineitem_rows is not None:   # pin the row count (dbgen's differs from ours only by its fixed seeds)
+            diff = int(counts.sum()) - lineitem_rows
+            idx = 0
+            while diff != 0:
+                c = counts[idx]
+                if diff > 0 and c > 1:
+                    step = min(diff, c - 1)
+                    counts[idx] -= step
+                    diff -= step
+                elif diff < 0 and c < 7:
+                    step = min(-diff, 7 - c)
+                    counts[idx] += step
+                    diff += step
+                idx += 1
+        self.lineitems_per_order = counts
+        n = int(counts.sum())
+        order_index = np.repeat(np.arange(n_orders, dtype=np.int32), counts)
+        self.l_orderkey = self.o_orderkey[order_index]
+        orderdate = self.o_orderdate[order_index]
+        self.l_shipdate = (orderdate + rng.integers(1, 122, n, dtype=np.int32)).astype(np.int32)
+        self.l_commitdate = (orderdate + rng.integers(30, 91, n, dtype=np.int32)).astype(np.int32)
+        self.l_receiptdate = (self.l_shipdate + rng.integers(1, 31, n, dtype=np.int32)).astype(np.int32)
+        self.l_quantity = rng.integers(1, 51, n).astype(np.float32)
+        self.l_discount = (rng.integers(0, 11, n) / 100.0).astype(np.float32)
+        self.l_tax = (rng.integers(0, 9, n) / 100.0).astype(np.float32)
+        partkey = rng.integers(1, int(200_000 * scale_factor) + 1, n)
+        retail = (90000 + (partkey // 10) % 20001 + 100 * (partkey % 1000)) / 100.0
+        self.l_extendedprice = (self.l_quantity * retail).astype(np.float32)
+        returned = rng.integers(0, 2, n).astype(np.uint8)
+        # single-character strings as their byte (the AggregateHash key of a <5-char string is 2 + byte,
+        # aggregate_hash.cpp:852-900)
+        self.l_returnflag = np.where(self.l_receiptdate <= CURRENT_DATE, np.where(returned == 1, ord("R"), ord("A")),
+                                     ord("N")).astype(np.int32)
+        self.l_linestatus = np.where(self.l_shipdate > CURRENT_DATE, ord("O"), ord("F")).astype(np.int32)
+        self.n_orders, self.n_lineitems = n_orders, n
+
+
+def shipdate_column(n_rows=LINEITEM_ROWS_SF10, seed=42, chunk_size=abi.CHUNK_DEFAULT_SIZE):
+    """Just l_shipdate (config 2), dictionary-encoded per chunk like Hyrise's "Automatic" encoding of that column."""
+    rng = np.random.default_rng(seed)
+    days = (rng.integers(0, LAST_ORDERDATE + 1, n_rows, dtype=np.int32) + rng.integers(1, 122, n_rows, dtype=np.int32))
+    return days.astype(np.int32), storage.make_column(days.astype(np.int32), None, abi.ENC_DICTIONARY, chunk_size)
