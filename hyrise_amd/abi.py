@@ -26,6 +26,7 @@ INVALID_VALUE_ID = 0xFFFFFFFF
 INVALID_CHUNK_ID = 0xFFFFFFFF
 FOR_BLOCK_SIZE = 2048
 SCAN_MATERIALIZE_ALL_MATCH = 1
+SCAN_CHUNK_REGIONS = 2
 CHUNK_DEFAULT_SIZE = 65535  # Chunk::DEFAULT_SIZE, storage/chunk.hpp:52
 
 

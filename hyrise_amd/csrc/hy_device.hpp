@@ -39,6 +39,21 @@ struct Slice {
   uint32_t first_of_chunk;     // 1 if row_begin == 0
 };
 
+// A part: at most PART_SLICES consecutive slices of ONE chunk -- the unit a scan workgroup owns.  A Hyrise chunk
+// (<= 65 535 rows) is exactly one part, so its PosList is produced by one workgroup without any inter-workgroup traffic.
+struct Part {
+  uint32_t first_slice;
+  uint32_t n_slices;
+  uint32_t chunk;
+  uint32_t part_in_chunk;
+  uint32_t parts_in_chunk;
+  uint32_t first_part;          // index of the chunk's part 0
+  uint32_t first_row;           // chunk offset of the part's first row
+  uint32_t reserved;
+  uint64_t region_base;         // first RowID slot of the chunk's output region (= rows in all chunks before it)
+};
+constexpr uint32_t PART_SLICES = 8;   // upper bound (LDS sizing); the actual part length is chosen per column
+
 constexpr uint32_t WG_THREADS = 256;
 constexpr uint32_t ROWS_PER_THREAD = 32;
 constexpr uint32_t SLICE_ROWS = WG_THREADS * ROWS_PER_THREAD;   // 8192
@@ -53,12 +68,15 @@ struct hy_column {
   bool is_reference = false;
   bool multi_chunk_reference = false;       // some pos list spans several referenced chunks
   bool has_dictionary_without_values = false;
+  uint32_t stream_width = 0;                // 1|2|4 if every segment is an aligned W-byte id/offset/int32 vector, else 0
   const hy_column* ref = nullptr;
   std::vector<hy_segment> host_segments;    // caller's descriptors (pointers patched to device addresses)
   std::vector<uint64_t> row_base;           // [n_chunks + 1] prefix sum of sizes
   hy::DevSegment* d_segments = nullptr;
   hy::Slice* d_slices = nullptr;
   uint32_t n_slices = 0;
+  hy::Part* d_parts = nullptr;
+  uint32_t n_parts = 0;
   std::vector<void*> owned;                 // device allocations freed with the column
 };
 

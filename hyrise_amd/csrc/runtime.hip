@@ -310,6 +310,11 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
 
   std::vector<DevSegment> dev(n_chunks ? n_chunks : 1);
   std::vector<Slice> slices;
+  std::vector<Part> parts;
+  uint32_t part_slices = PART_SLICES;   // slices per part: one Hyrise chunk (65 535 rows) = one part = one workgroup
+  if (const char* env = getenv("HY_PART_SLICES")) part_slices = static_cast<uint32_t>(atoi(env));
+  if (part_slices < 1) part_slices = 1;
+  if (part_slices > PART_SLICES) part_slices = PART_SLICES;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     hy_segment& s = column->host_segments[c];
     DevSegment& d = dev[c];
@@ -347,19 +352,43 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     if (s.encoding == HY_ENC_DICTIONARY && !s.aux && s.aux_size) column->has_dictionary_without_values = true;
     column->row_base[c + 1] = column->row_base[c] + s.size;
     uint32_t begin = 0;
+    const uint32_t first_slice_of_chunk = static_cast<uint32_t>(slices.size());
     do {
       const uint32_t count = (s.size - begin < SLICE_ROWS) ? s.size - begin : SLICE_ROWS;
       slices.push_back(Slice{c, begin, count, begin == 0 ? 1u : 0u});
       begin += count;
     } while (begin < s.size);
+    const uint32_t chunk_slices = static_cast<uint32_t>(slices.size()) - first_slice_of_chunk;
+    const uint32_t chunk_parts = (chunk_slices + part_slices - 1) / part_slices;
+    const uint32_t first_part = static_cast<uint32_t>(parts.size());
+    for (uint32_t p = 0; p < chunk_parts; ++p) {
+      const uint32_t first = first_slice_of_chunk + p * part_slices;
+      const uint32_t n = (chunk_slices - p * part_slices < part_slices) ? chunk_slices - p * part_slices : part_slices;
+      parts.push_back(Part{first, n, c, p, chunk_parts, first_part, p * part_slices * SLICE_ROWS, 0, column->row_base[c]});
+    }
   }
+  // Streaming instantiation of the scan kernel: one common element width, aligned buffers, 32-bit comparisons.
+  uint32_t stream_width = 0;
+  bool streamable = n_chunks > 0 && !column->is_reference;
+  for (uint32_t c = 0; c < n_chunks && streamable; ++c) {
+    const hy_segment& s = column->host_segments[c];
+    const bool kind_ok = s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE ||
+                         (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT);
+    if (!kind_ok || (dev[c].flags & SEG_UNALIGNED)) streamable = false;
+    else if (stream_width == 0) stream_width = s.width;
+    else if (stream_width != s.width) streamable = false;
+  }
+  column->stream_width = streamable ? stream_width : 0;
   column->rows = column->row_base[n_chunks];
   column->n_slices = static_cast<uint32_t>(slices.size());
+  column->n_parts = static_cast<uint32_t>(parts.size());
 
   hipError_t err = hipMalloc(reinterpret_cast<void**>(&column->d_segments), sizeof(DevSegment) * dev.size());
   if (err == hipSuccess) err = hipMemcpy(column->d_segments, dev.data(), sizeof(DevSegment) * dev.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_slices), sizeof(Slice) * (slices.size() + 1));
   if (err == hipSuccess && !slices.empty()) err = hipMemcpy(column->d_slices, slices.data(), sizeof(Slice) * slices.size(), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_parts), sizeof(Part) * (parts.size() + 1));
+  if (err == hipSuccess && !parts.empty()) err = hipMemcpy(column->d_parts, parts.data(), sizeof(Part) * parts.size(), hipMemcpyHostToDevice);
   if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "descriptor upload failed: %s", hipGetErrorString(err)));
   *out = column;
   return HY_OK;
@@ -370,6 +399,7 @@ hy_status hy_column_destroy(hy_column* column) {
   for (void* p : column->owned) (void)hipFree(p);
   if (column->d_segments) (void)hipFree(column->d_segments);
   if (column->d_slices) (void)hipFree(column->d_slices);
+  if (column->d_parts) (void)hipFree(column->d_parts);
   delete column;
   return HY_OK;
 }

@@ -114,8 +114,9 @@ __device__ bool integer_range(uint32_t cond, Wide v, Wide v2, Wide tmin, Wide tm
 }
 
 // One thread per DATA chunk of the scanned column (for reference columns: of the referenced column).
-__global__ void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, PredicateArgs p, ScanJob* jobs) {
+__global__ void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, PredicateArgs p, ScanJob* jobs, uint32_t* overflow) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) *overflow = 0;
   if (c >= n_chunks) return;
   const DevSegment s = segments[c];
   ScanJob job;
@@ -494,30 +495,26 @@ __device__ bool compare_cells(uint32_t cond, const Cell& l, uint32_t lt, const C
 
 // ---- the scan kernel ----------------------------------------------------------------------------------------------------
 
-constexpr uint64_t ST_AGGREGATE = 1ull << 62;
-constexpr uint64_t ST_PREFIX = 2ull << 62;
-__device__ __forceinline__ uint64_t make_status(uint64_t state, uint32_t epoch, uint32_t value) {
-  return state | (static_cast<uint64_t>(epoch) << 32) | value;
-}
-
 struct ScanArgs {
   const DevSegment* segments;      // scanned column
   const DevSegment* right;         // ColumnVsColumn: right column, else nullptr
   const Slice* slices;
   const ScanJob* jobs;             // per DATA chunk (of the referenced column for reference columns)
   uint32_t n_slices;
+  uint32_t n_parts;
   uint32_t n_chunks;
   uint32_t condition;              // ColumnVsColumn
   uint32_t materialize_all;
   uint32_t is_null_scan;           // IS NULL on reference columns: NULL_ROW_IDs match
   uint32_t epoch;
-  uint32_t ticket_base;
-  uint32_t* ticket;
-  uint64_t* status;
-  hy_row_id* matches;
+  uint64_t* status;                // [n_parts] epoch-tagged part totals (only touched by multi-part chunks)
+  hy_row_id* matches;              // chunk regions
   uint64_t capacity;
-  uint64_t* offsets;               // [n_chunks + 1]
+  uint64_t* offsets;               // [n_chunks + 1] region starts
+  uint32_t* counts;                // [n_chunks] or nullptr
+  uint8_t* chunk_state;            // [n_chunks] or nullptr
   uint32_t* overflow;              // set to 1 if capacity was exceeded
+  uint64_t* trace;                 // debug: 4 wall-clock stamps per workgroup (HY_SCAN_TRACE), else nullptr
 };
 
 __device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v, uint32_t lane) {
@@ -529,22 +526,73 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v, uint32_t lan
   return v;
 }
 
-__global__ __launch_bounds__(256) void scan_slices(ScanArgs a) {
-  __shared__ uint32_t s_ticket;
-  __shared__ uint32_t s_wave_total[4];
-  __shared__ uint32_t s_exclusive;
-  __shared__ uint16_t s_rows[SLICE_ROWS];
+// Match bits of 8 already-loaded 32-bit lanes.
+__device__ __forceinline__ uint32_t range_bits8(const uint32_t (&x)[8], uint32_t lo, uint32_t span) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bits |= ((x[j] - lo) <= span ? 1u : 0u) << j;
+  return bits;
+}
 
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u) - a.ticket_base;
-  __syncthreads();
-  const uint32_t slice_id = s_ticket;
-  const Slice slice = a.slices[slice_id];
-  const DevSegment seg = a.segments[slice.chunk];
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int W>
+struct RawGroup;   // 8 rows of W-byte elements as loaded from HBM
+template <> struct RawGroup<1> { u32x2 v; };
+template <> struct RawGroup<2> { u32x4 v; };
+template <> struct RawGroup<4> { u32x4 v0, v1; };
 
-  // ---- 1. evaluate 4 x 8 rows per lane: wave w owns rows [w*2048, (w+1)*2048) of the slice, k-th load 512 rows ----
+// Segment buffers are always global memory: say so, or the compiler emits flat loads (which also tick lgkmcnt).
+#define HY_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const HY_GLOBAL T* as_global(const void* p) {
+  return (const HY_GLOBAL T*)(p);
+}
+
+template <int W>
+__device__ __forceinline__ RawGroup<W> load_group(const void* data, uint32_t row0) {
+  RawGroup<W> g;
+  const HY_GLOBAL uint8_t* base = as_global<uint8_t>(data) + static_cast<size_t>(row0) * W;
+  if constexpr (W == 1) {
+    g.v = *(const HY_GLOBAL u32x2*)(base);
+  } else if constexpr (W == 2) {
+    g.v = *(const HY_GLOBAL u32x4*)(base);
+  } else {
+    g.v0 = *(const HY_GLOBAL u32x4*)(base);
+    g.v1 = *(const HY_GLOBAL u32x4*)(base + 16);
+  }
+  return g;
+}
+
+template <int W>
+__device__ __forceinline__ void unpack_group(const RawGroup<W>& g, uint32_t (&x)[8]) {
+  if constexpr (W == 1) {
+    x[0] = g.v.x & 0xFF; x[1] = (g.v.x >> 8) & 0xFF; x[2] = (g.v.x >> 16) & 0xFF; x[3] = g.v.x >> 24;
+    x[4] = g.v.y & 0xFF; x[5] = (g.v.y >> 8) & 0xFF; x[6] = (g.v.y >> 16) & 0xFF; x[7] = g.v.y >> 24;
+  } else if constexpr (W == 2) {
+    x[0] = g.v.x & 0xFFFF; x[1] = g.v.x >> 16; x[2] = g.v.y & 0xFFFF; x[3] = g.v.y >> 16;
+    x[4] = g.v.z & 0xFFFF; x[5] = g.v.z >> 16; x[6] = g.v.w & 0xFFFF; x[7] = g.v.w >> 16;
+  } else {
+    x[0] = g.v0.x; x[1] = g.v0.y; x[2] = g.v0.z; x[3] = g.v0.w; x[4] = g.v1.x; x[5] = g.v1.y; x[6] = g.v1.z; x[7] = g.v1.w;
+  }
+}
+
+// Persistent two-pass kernel.  gridDim.x workgroups, all co-resident; workgroup b owns the CONTIGUOUS slice range
+// [b * per_wg, (b+1) * per_wg) of each round (a round = gridDim.x * per_wg slices; SF10 lineitem is one round).
+//   pass 1  stream the range once: 32-bit match mask per lane and slice -> LDS (1 KiB per slice) plus the match count
+//           of every (slice, wave).  In the streaming instantiations (W = 1/2/4: every segment of the column is a
+//           W-byte attribute vector / FoR offset vector / int32 value vector) the loads of slice s+1 are issued before
+//           slice s is evaluated, so every lane keeps 8 x 16 B in flight.
+//   exchange  publish the workgroup total as ONE epoch-tagged 8-byte word (agent-scope relaxed atomic: the word is the
+//           flag, no fence), then all 256 threads read the totals of the workgroups before it in parallel -- one
+//           L2 round trip instead of a serial look-back chain -- and reduce them to the global output offset
+//   pass 2  barrier-free: wave w owns rows [w*2048, (w+1)*2048) of every slice, i.e. a contiguous piece of the
+//           output; it derives its output offset from the (slice, wave) counts, expands its masks with one packed
+//           prefix sum, compacts row numbers through its private 4 KiB of LDS and writes coalesced 8-byte RowIDs.
+// The column is read from HBM exactly once and every RowID is written exactly once.  Output order is slice order,
+// i.e. (chunk, row) ascending: bit-identical to the CPU loop's appends.
+__device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slice& slice, const DevSegment& seg, uint32_t wave, uint32_t lane) {
   uint32_t mask = 0;       // bit (8k + j) <-> row  wave*2048 + k*512 + lane*8 + j  of the slice
-  uint32_t mode = JOB_SCAN;
   if (a.right) {
     // ColumnVsColumn: both sides decoded per row (no SIMD path in the reference either, abstract_table_scan_impl.hpp:61-66)
 #pragma unroll 1
@@ -559,8 +607,8 @@ __global__ __launch_bounds__(256) void scan_slices(ScanArgs a) {
       }
     }
   } else if (seg.encoding == HY_ENC_REFERENCE) {
-    const bool single = seg.ref_chunk_id != 0xFFFFFFFFu;
-    if (single) mode = a.jobs[seg.ref_chunk_id].mode;
+    uint32_t mode = JOB_SCAN;
+    if (seg.ref_chunk_id != 0xFFFFFFFFu) mode = a.jobs[seg.ref_chunk_id].mode;
     if (mode == JOB_SCAN || (mode == JOB_ALL && a.materialize_all)) {
 #pragma unroll 1
       for (uint32_t k = 0; k < 4; ++k) {
@@ -579,8 +627,7 @@ __global__ __launch_bounds__(256) void scan_slices(ScanArgs a) {
     }
   } else {
     const ScanJob job = a.jobs[slice.chunk];
-    mode = job.mode;
-    if (mode == JOB_SCAN && !(job.flags & JF_NEVER)) {
+    if (job.mode == JOB_SCAN && !(job.flags & JF_NEVER)) {
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
@@ -589,7 +636,7 @@ __global__ __launch_bounds__(256) void scan_slices(ScanArgs a) {
           mask |= eval8(seg, job, slice.row_begin + r0, valid) << (8 * k);
         }
       }
-    } else if (mode == JOB_ALL && a.materialize_all) {
+    } else if (job.mode == JOB_ALL && a.materialize_all) {
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
@@ -600,121 +647,312 @@ __global__ __launch_bounds__(256) void scan_slices(ScanArgs a) {
       }
     }
   }
+  return mask;
+}
 
-  // ---- 2. positions: one packed wave scan over the four per-load counts (16 bits each) -------------------------------
-  const uint64_t packed = static_cast<uint64_t>(__popc(mask & 0xFFu)) | (static_cast<uint64_t>(__popc(mask & 0xFF00u)) << 16) |
-                          (static_cast<uint64_t>(__popc(mask & 0xFF0000u)) << 32) | (static_cast<uint64_t>(__popc(mask >> 24)) << 48);
-  const uint64_t inclusive = wave_inclusive_scan(packed, lane);
-  const uint64_t totals = __shfl(inclusive, 63, 64);       // per-load totals of this wave
-  const uint64_t exclusive = inclusive - packed;
-  const uint32_t t0 = totals & 0xFFFF, t1 = (totals >> 16) & 0xFFFF, t2 = (totals >> 32) & 0xFFFF, t3 = totals >> 48;
-  const uint32_t wave_total = t0 + t1 + t2 + t3;
-  if (lane == 0) s_wave_total[wave] = wave_total;
-  __syncthreads();
-  uint32_t wave_base = 0, block_total = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < 4; ++w) {
-    const uint32_t t = s_wave_total[w];
-    if (w < wave) wave_base += t;
-    block_total += t;
+
+// Slim scalar evaluation for the streaming instantiations (the one partial 8-row group at the end of a chunk).
+__device__ __forceinline__ bool eval_row_u32(const DevSegment& s, const ScanJob& job, uint32_t row) {
+  const bool invert = job.flags & JF_INVERT;
+  const uint32_t raw = load_compressed(s.data, s.width, row);
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    const bool in = (raw - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+    return (in != invert) && raw != job.null_vid;
   }
+  const bool is_null = s.nulls ? ((s.nulls[row >> 6] >> (row & 63)) & 1) != 0 : false;
+  if (job.kind == KIND_NULLTEST) return is_null != invert;
+  if (is_null) return false;
+  const uint32_t bias = s.encoding == HY_ENC_FRAME_OF_REFERENCE ? static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]) : 0u;
+  const bool in = (raw + bias - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+  return in != invert;
+}
 
-  // ---- 3. decoupled look-back over the slices before this one (wave 0) ------------------------------------------------
-  if (wave == 0) {
-    if (lane == 0) __hip_atomic_store(&a.status[slice_id], make_status(slice_id == 0 ? ST_PREFIX : ST_AGGREGATE, a.epoch, block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t exclusive_prefix = 0;
-    int64_t window_end = static_cast<int64_t>(slice_id) - 1;   // newest predecessor not yet summed
-    while (window_end >= 0) {
-      const int64_t idx = window_end - lane;
-      uint64_t word = 0;
-      bool ready;
-      do {  // every lane polls its own predecessor until it carries this launch's epoch
-        ready = true;
-        if (idx >= 0) {
-          word = __hip_atomic_load(&a.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ready = (static_cast<uint32_t>(word >> 32) & 0x3FFFFFFFu) == a.epoch && (word >> 62) != 0;
-        }
-        if (!__all(ready)) __builtin_amdgcn_s_sleep(1);
-      } while (!__all(ready));
-      const bool is_prefix = idx >= 0 && (word >> 62) == 2;
-      const uint64_t prefix_lanes = __ballot(is_prefix);
-      const uint32_t first_prefix = prefix_lanes ? static_cast<uint32_t>(__ffsll(static_cast<long long>(prefix_lanes)) - 1) : 64u;
-      uint32_t contribution = (idx >= 0 && lane <= first_prefix) ? static_cast<uint32_t>(word) : 0u;
+template <int W>
+struct SliceLoad {
+  RawGroup<W> raw[4];
+  uint32_t null_byte[4];
+  uint32_t bias[4];
+};
+
+template <int W>
+__device__ __forceinline__ void issue_loads(SliceLoad<W>& ld, const DevSegment& seg, const ScanJob& job, const Slice& slice, uint32_t wave, uint32_t lane) {
+  const bool wanted = job.mode == JOB_SCAN && !(job.flags & JF_NEVER);
+  const bool is_for = seg.encoding == HY_ENC_FRAME_OF_REFERENCE;
+  const bool has_bitmap = seg.nulls != nullptr && seg.encoding != HY_ENC_DICTIONARY;
 #pragma unroll
-      for (int d = 32; d > 0; d >>= 1) contribution += __shfl_xor(contribution, d, 64);
-      exclusive_prefix += contribution;
-      if (prefix_lanes) break;
-      window_end -= 64;
-    }
-    if (lane == 0) {
-      if (slice_id != 0) __hip_atomic_store(&a.status[slice_id], make_status(ST_PREFIX, a.epoch, exclusive_prefix + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_exclusive = exclusive_prefix;
-      if (slice.first_of_chunk) a.offsets[slice.chunk] = exclusive_prefix;
-      if (slice_id == a.n_slices - 1) a.offsets[a.n_chunks] = static_cast<uint64_t>(exclusive_prefix) + block_total;
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+    const uint32_t row = slice.row_begin + r0;
+    ld.null_byte[k] = 0;
+    ld.bias[k] = 0;
+    if (wanted && r0 + 8 <= slice.row_count) {
+      ld.raw[k] = load_group<W>(seg.data, row);
+      if (has_bitmap) ld.null_byte[k] = as_global<uint8_t>(seg.nulls)[row >> 3];
+      if (is_for) ld.bias[k] = static_cast<uint32_t>(as_global<int32_t>(seg.aux)[row / HY_FOR_BLOCK_SIZE]);
     }
   }
+}
 
-  // ---- 4. compact row numbers through LDS, then coalesced 8-byte RowID stores -----------------------------------------
-  if (block_total != 0) {
-    const uint32_t e0 = exclusive & 0xFFFF, e1 = (exclusive >> 16) & 0xFFFF, e2 = (exclusive >> 32) & 0xFFFF, e3 = exclusive >> 48;
-    const uint32_t base_k[4] = {wave_base + e0, wave_base + t0 + e1, wave_base + t0 + t1 + e2, wave_base + t0 + t1 + t2 + e3};
+template <int W>
+__device__ __forceinline__ uint32_t evaluate_loaded(const SliceLoad<W>& ld, const DevSegment& seg, const ScanJob& job, const Slice& slice,
+                                                    uint32_t materialize_all, uint32_t wave, uint32_t lane) {
+  uint32_t mask = 0;
+  if (job.mode == JOB_SCAN && !(job.flags & JF_NEVER)) {
+    const uint32_t inv = (job.flags & JF_INVERT) ? 0xFFu : 0u;
+    const uint32_t lo = static_cast<uint32_t>(job.lo), span = static_cast<uint32_t>(job.span);
+    const bool is_dict = seg.encoding == HY_ENC_DICTIONARY;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
-      uint32_t m = (mask >> (8 * k)) & 0xFFu;
-      uint32_t p = base_k[k];
       const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
-      while (m) {
-        const uint32_t j = __ffs(m) - 1;
-        m &= m - 1;
-        s_rows[p++] = static_cast<uint16_t>(r0 + j);
+      uint32_t bits = 0;
+      if (r0 + 8 <= slice.row_count) {
+        if (job.kind == KIND_NULLTEST) {
+          bits = (ld.null_byte[k] ^ inv) & 0xFFu;
+        } else {
+          uint32_t x[8];
+          unpack_group<W>(ld.raw[k], x);
+          bits = range_bits8(x, lo - ld.bias[k], span) ^ inv;
+          if (is_dict) {
+            if (inv) {   // != : NULL (value id == dictionary size) never matches
+              uint32_t nullbits = 0;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) nullbits |= (x[j] == job.null_vid ? 1u : 0u) << j;
+              bits &= ~nullbits;
+            }
+          } else {
+            bits &= ~ld.null_byte[k];
+          }
+          bits &= 0xFFu;
+        }
+      } else if (r0 < slice.row_count) {   // the one partial group at the end of a chunk
+        for (uint32_t j = 0; r0 + j < slice.row_count; ++j) bits |= (eval_row_u32(seg, job, slice.row_begin + r0 + j) ? 1u : 0u) << j;
+      }
+      mask |= bits << (8 * k);
+    }
+  } else if (job.mode == JOB_ALL && materialize_all) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+      if (r0 < slice.row_count) {
+        const uint32_t valid = (slice.row_count - r0 < 8) ? slice.row_count - r0 : 8;
+        mask |= ((1u << valid) - 1u) << (8 * k);
       }
     }
   }
-  __syncthreads();
-  if (block_total != 0) {
-    const uint64_t out_base = s_exclusive;
-    if (out_base + block_total > a.capacity) {
-      if (tid == 0) *a.overflow = 1;
-    } else {
-      uint2* out = reinterpret_cast<uint2*>(a.matches + out_base);
-      for (uint32_t i = tid; i < block_total; i += WG_THREADS) out[i] = make_uint2(slice.chunk, slice.row_begin + s_rows[i]);
+  return mask;
+}
+
+// W = 0: generic instantiation (mixed widths, 64-bit / floating point value segments, reference segments,
+// ColumnVsColumn); W = 1 | 2 | 4: streaming instantiation.
+//
+// One workgroup owns one PART at a time (<= 8 slices = 65 536 rows of ONE chunk; parts b, b + gridDim.x, ...):
+//   P1  stream the part once: 32-bit match mask per lane and slice -> LDS (1 KiB per slice) plus the match count of
+//       every (slice, wave).  Streaming instantiations issue the loads of slice s+1 (also across parts) before slice s
+//       is evaluated, so every lane keeps 8 x 16 B in flight.
+//   P2  barrier-free: wave w owns rows [w*2048, (w+1)*2048) of every slice, i.e. a contiguous piece of the output; it
+//       derives its offset from the (slice, wave) counts, expands its masks with one packed prefix sum, compacts row
+//       numbers through its private 4 KiB of LDS and writes coalesced 8-byte RowIDs into the chunk's output region.
+// A Hyrise chunk (<= 65 535 rows) is one part: NO inter-workgroup communication at all.  Only chunks larger than a
+// part chain their parts: a part publishes its total as one epoch-tagged 8-byte word (agent-scope relaxed atomic; the
+// word is the flag) and reads the totals of the earlier parts of its chunk in parallel (they belong to workgroups
+// that are resident and never wait for later parts, so this cannot deadlock as long as the grid is co-resident).
+// The column is read from HBM exactly once and every RowID is written exactly once, in (chunk, row) order.
+template <int W>
+__global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict__ segments_in, const DevSegment* __restrict__ right_in,
+                                                   const Slice* __restrict__ slices_in, const ScanJob* __restrict__ jobs_in,
+                                                   const Part* __restrict__ parts, ScanArgs a) {
+  // The descriptor tables are read-only and never alias the outputs: as __restrict__ kernel parameters their
+  // (wave-uniform) loads become scalar loads instead of vector loads with waits.
+  a.segments = segments_in;
+  a.right = right_in;
+  a.slices = slices_in;
+  a.jobs = jobs_in;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* s_rows = reinterpret_cast<uint16_t*>(smem);                              // [4 waves][2048] compaction buffers
+  uint32_t* s_masks = reinterpret_cast<uint32_t*>(smem + SLICE_ROWS * 2);            // [PART_SLICES][256]
+  uint32_t* s_wave_count = s_masks + PART_SLICES * WG_THREADS;                       // [PART_SLICES][4]
+  uint32_t* s_small = s_wave_count + PART_SLICES * 4;                                // [16] reductions
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64();
+
+  // streaming state: loads of the next slice to evaluate (possibly of the next part)
+  SliceLoad<(W == 0 ? 1 : W)> next;
+  Slice slice{0, 0, 0, 0};
+  DevSegment seg;
+  ScanJob job;
+  if constexpr (W != 0) {
+    if (blockIdx.x < a.n_parts) {
+      slice = a.slices[parts[blockIdx.x].first_slice];
+      seg = a.segments[slice.chunk];
+      job = a.jobs[slice.chunk];
+      issue_loads<W>(next, seg, job, slice, wave, lane);
     }
   }
-}
 
-struct FinalizeArgs {
-  const DevSegment* segments;
-  const ScanJob* jobs;
-  uint32_t n_chunks;
-  uint32_t materialize_all;
-  uint32_t columns_scan;
-  const uint32_t* excluded;   // sorted chunk ids or nullptr
-  uint32_t n_excluded;
-  const uint64_t* offsets;
-  uint32_t* counts;
-  uint8_t* chunk_state;
-};
+  for (uint32_t part_id = blockIdx.x; part_id < a.n_parts; part_id += gridDim.x) {
+    const Part part = parts[part_id];
+    const uint32_t begin = part.first_slice, end = part.first_slice + part.n_slices;
 
-__global__ void finalize_scan(FinalizeArgs a) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.n_chunks) return;
-  const DevSegment s = a.segments[c];
-  uint32_t mode = JOB_SCAN;
-  if (!a.columns_scan) {
-    if (s.encoding != HY_ENC_REFERENCE) mode = a.jobs[c].mode;
-    else if (s.ref_chunk_id != 0xFFFFFFFFu && s.size > 0) mode = a.jobs[s.ref_chunk_id].mode;
+    // ---- P1: evaluate, keep the masks in LDS ----------------------------------------------------------------------------
+    for (uint32_t s = begin; s < end; ++s) {
+      uint32_t mask;
+      if constexpr (W == 0) {
+        const Slice this_slice = a.slices[s];
+        const DevSegment this_seg = a.segments[this_slice.chunk];
+        mask = evaluate_slice(a, this_slice, this_seg, wave, lane);
+      } else {
+        const SliceLoad<W> current = next;
+        const Slice current_slice = slice;
+        const DevSegment current_seg = seg;
+        const ScanJob current_job = job;
+        uint32_t upcoming = s + 1;
+        if (upcoming == end) upcoming = part_id + gridDim.x < a.n_parts ? parts[part_id + gridDim.x].first_slice : a.n_slices;
+        if (upcoming < a.n_slices) {
+          slice = a.slices[upcoming];
+          seg = a.segments[slice.chunk];
+          job = a.jobs[slice.chunk];
+          issue_loads<W>(next, seg, job, slice, wave, lane);
+        }
+        mask = evaluate_loaded<W>(current, current_seg, current_job, current_slice, a.materialize_all, wave, lane);
+      }
+      s_masks[(s - begin) * WG_THREADS + tid] = mask;
+      uint32_t count = __popc(mask);
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d, 64);
+      if (lane == 0) s_wave_count[(s - begin) * 4 + wave] = count;
+    }
+    __syncthreads();
+    uint32_t part_total = 0;
+    for (uint32_t i = 0; i < part.n_slices * 4; ++i) part_total += s_wave_count[i];
+    if (a.trace && tid == 0 && part_id == blockIdx.x) a.trace[blockIdx.x * 4 + 1] = wall_clock64();
+
+    // ---- chunks larger than one part: matches in the earlier parts of the same chunk -------------------------------------
+    uint32_t before = 0;
+    if (part.parts_in_chunk > 1) {
+      if (tid == 0) __hip_atomic_store(&a.status[part_id], (static_cast<uint64_t>(a.epoch) << 32) | part_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t i = part.first_part + tid; i < part_id; i += WG_THREADS) {
+        uint64_t word;
+        do {
+          word = __hip_atomic_load(&a.status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (static_cast<uint32_t>(word >> 32) != a.epoch) __builtin_amdgcn_s_sleep(1);
+        } while (static_cast<uint32_t>(word >> 32) != a.epoch);
+        before += static_cast<uint32_t>(word);
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+      if (lane == 0) s_small[4 + wave] = before;
+      __syncthreads();
+      before = s_small[4] + s_small[5] + s_small[6] + s_small[7];
+    }
+    if (a.trace && tid == 0 && part_id == blockIdx.x) a.trace[blockIdx.x * 4 + 2] = wall_clock64();
+
+    // ---- per-chunk outputs ------------------------------------------------------------------------------------------------
+    if (tid == 0) {
+      uint32_t mode = JOB_SCAN;
+      const DevSegment chunk_seg = a.segments[part.chunk];
+      if (!a.right) {
+        if (chunk_seg.encoding != HY_ENC_REFERENCE) mode = a.jobs[part.chunk].mode;
+        else if (chunk_seg.ref_chunk_id != 0xFFFFFFFFu && chunk_seg.size > 0) mode = a.jobs[chunk_seg.ref_chunk_id].mode;
+      }
+      if (part.part_in_chunk == 0) {
+        a.offsets[part.chunk] = part.region_base;
+        if (a.chunk_state) a.chunk_state[part.chunk] = mode == JOB_ALL ? HY_CHUNK_ALL_MATCH : mode == JOB_NONE ? HY_CHUNK_NONE_MATCH : HY_CHUNK_SCANNED;
+        if (part.chunk + 1 == a.n_chunks) a.offsets[a.n_chunks] = part.region_base + chunk_seg.size;
+      }
+      if (part.part_in_chunk + 1 == part.parts_in_chunk && a.counts) a.counts[part.chunk] = mode == JOB_ALL ? chunk_seg.size : before + part_total;
+    }
+
+    // ---- P2 (no workgroup barriers): every wave expands its own rows ----------------------------------------------------
+    uint64_t offset = part.region_base + before;
+    uint16_t* my_rows = s_rows + wave * 2048;
+    for (uint32_t s = begin; s < end && part_total != 0; ++s) {
+      const uint32_t* counts = s_wave_count + (s - begin) * 4;
+      const uint32_t c0 = counts[0], c1 = counts[1], c2 = counts[2], c3 = counts[3];
+      const uint32_t slice_total = c0 + c1 + c2 + c3;
+      const uint32_t my_total = wave == 0 ? c0 : wave == 1 ? c1 : wave == 2 ? c2 : c3;
+      const uint64_t my_offset = offset + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+      if (my_total != 0) {
+        const uint32_t row_begin = part.first_row + (s - begin) * SLICE_ROWS;
+        const uint32_t mask = s_masks[(s - begin) * WG_THREADS + tid];
+        const uint64_t packed = static_cast<uint64_t>(__popc(mask & 0xFFu)) | (static_cast<uint64_t>(__popc(mask & 0xFF00u)) << 16) |
+                                (static_cast<uint64_t>(__popc(mask & 0xFF0000u)) << 32) | (static_cast<uint64_t>(__popc(mask >> 24)) << 48);
+        const uint64_t inclusive = wave_inclusive_scan(packed, lane);
+        const uint64_t totals = __shfl(inclusive, 63, 64);       // per-load totals of this wave
+        const uint64_t exclusive = inclusive - packed;
+        const uint32_t t0 = totals & 0xFFFF, t1 = (totals >> 16) & 0xFFFF, t2 = (totals >> 32) & 0xFFFF;
+        const uint32_t e0 = exclusive & 0xFFFF, e1 = (exclusive >> 16) & 0xFFFF, e2 = (exclusive >> 32) & 0xFFFF, e3 = exclusive >> 48;
+        const uint32_t base_k[4] = {e0, t0 + e1, t0 + t1 + e2, t0 + t1 + t2 + e3};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+          uint32_t m = (mask >> (8 * k)) & 0xFFu;
+          uint32_t p = base_k[k];
+          const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+          while (m) {
+            const uint32_t j = __ffs(m) - 1;
+            m &= m - 1;
+            my_rows[p++] = static_cast<uint16_t>(r0 + j);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order; this only stops reordering
+        if (my_offset + my_total > a.capacity) {
+          if (lane == 0) *a.overflow = 1;
+        } else {
+          uint2* out = reinterpret_cast<uint2*>(a.matches + my_offset);
+          for (uint32_t i = lane; i < my_total; i += 64) out[i] = make_uint2(part.chunk, row_begin + my_rows[i]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      offset += slice_total;
+    }
+    __syncthreads();   // s_masks / s_wave_count / s_small are reused by the next part
   }
-  const uint32_t written = static_cast<uint32_t>(a.offsets[c + 1] - a.offsets[c]);
-  a.counts[c] = (mode == JOB_ALL) ? s.size : written;
-  a.chunk_state[c] = mode == JOB_ALL ? HY_CHUNK_ALL_MATCH : mode == JOB_NONE ? HY_CHUNK_NONE_MATCH : HY_CHUNK_SCANNED;
+  if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 3] = wall_clock64();
 }
+
+uint64_t* g_trace_buffer = nullptr;
+uint32_t g_trace_grid = 0;
 
 __global__ void exclude_chunks(ScanJob* jobs, const uint32_t* excluded, uint32_t n_excluded) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_excluded) jobs[excluded[i]].mode = JOB_NONE;
 }
 
+// Host results only: copy every chunk's region into the back-to-back layout (one workgroup per chunk).
+__global__ void compact_regions(const hy_row_id* regions, const uint64_t* region_offsets, const uint64_t* dense_offsets, hy_row_id* dense, uint32_t n_chunks) {
+  const uint32_t c = blockIdx.x;
+  if (c >= n_chunks) return;
+  const uint64_t count = dense_offsets[c + 1] - dense_offsets[c];
+  const uint2* src = reinterpret_cast<const uint2*>(regions + region_offsets[c]);
+  uint2* dst = reinterpret_cast<uint2*>(dense + dense_offsets[c]);
+  for (uint64_t i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
+
+// Launch shape of the persistent scan kernel: min(parts, CUs x resident workgroups per CU).  Workgroups of a chunk
+// that spans several parts wait for each other, so the grid must be co-resident: stay one below what the occupancy
+// query admits (ROCm 7.2 over-reports by one for SGPR-heavy 256-thread kernels, MI355X_MICROARCH.md "Residency and
+// cooperative launch").
+using ScanKernel = void (*)(const DevSegment*, const DevSegment*, const Slice*, const ScanJob*, const Part*, ScanArgs);
+constexpr size_t SCAN_LDS_BYTES = SLICE_ROWS * 2 + PART_SLICES * (WG_THREADS * 4 + 16) + 64;
+
+static uint32_t scan_grid(ScanKernel kernel, uint32_t n_parts) {
+  int device = 0, cus = 256;
+  (void)hipGetDevice(&device);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  int want = 8;
+  if (const char* env = getenv("HY_SCAN_WGS_PER_CU")) want = atoi(env);
+  int per_cu = 0;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WG_THREADS, SCAN_LDS_BYTES);
+  // The over-report only happens where SGPRs are the limiter (API 7-8 blocks per CU); a VGPR- or LDS-limited answer
+  // (<= 5) is exact.
+  if (per_cu >= 6) per_cu -= 1;
+  int use = per_cu < want ? per_cu : want;
+  if (use < 1) use = 1;
+  const uint32_t resident_max = static_cast<uint32_t>(cus * use);
+  return n_parts < resident_max ? (n_parts ? n_parts : 1) : resident_max;
+}
 
 static hy_status validate_predicate(const hy_column* column, const hy_predicate* p) {
   const uint32_t c = p->condition;
@@ -741,19 +979,21 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   const hy_column* data_column = column->is_reference ? column->ref : column;
   const uint32_t n_data_chunks = data_column ? data_column->n_chunks : 0;
   const bool host_result = result->mem == HY_MEM_HOST;
-  if (!result->offsets || !result->counts || !result->chunk_state) return fail(HY_ERR_INVALID, "scan result arrays missing");
+  if (!result->offsets) return fail(HY_ERR_INVALID, "scan result: offsets array missing");
+  if (host_result && (!result->counts || !result->chunk_state)) return fail(HY_ERR_INVALID, "scan result: host results need counts and chunk_state");
+  if (!host_result && !(result->flags & HY_SCAN_CHUNK_REGIONS)) return fail(HY_ERR_INVALID, "scan result: device results use the chunk-region layout; set HY_SCAN_CHUNK_REGIONS");
+  if (!host_result && result->capacity < column->rows) return fail(HY_ERR_CAPACITY, "scan result: chunk regions need capacity >= %llu rows", static_cast<unsigned long long>(column->rows));
   if (result->capacity && !result->matches) return fail(HY_ERR_INVALID, "scan result: matches buffer missing");
   hipStream_t stream = current_stream();
   Scratch& sc = scratch();
 
-  // Scratch: jobs | per_chunk arrays | excluded | overflow flag | (host results) device copies of the outputs
-  const uint64_t device_capacity = host_result ? column->rows : result->capacity;
+  // Scratch: jobs | per_chunk arrays | excluded | overflow flag | (host results) regions + dense copy + per-chunk arrays
   size_t need = sizeof(ScanJob) * (n_data_chunks + 1) + 3 * 4 * (size_t{n_data_chunks} + 64) + 4 * (size_t{n_excluded} + 64) + 1024;
-  if (host_result) need += sizeof(hy_row_id) * (device_capacity + 1) + 8 * (size_t{n_chunks} + 2) + 4 * (size_t{n_chunks} + 1) + n_chunks + 4096;
+  if (host_result) need += 2 * sizeof(hy_row_id) * (column->rows + 1) + 3 * 8 * (size_t{n_chunks} + 2) + 4 * (size_t{n_chunks} + 1) + n_chunks + 8192;
   HY_TRY(sc.reserve(need + 16 * 256));
   ScanJob* d_jobs = carve<ScanJob>(sc, n_data_chunks + 1);
   uint32_t* d_overflow = carve<uint32_t>(sc, 64);
-  HY_HIP(hipMemsetAsync(d_overflow, 0, 4, stream));
+  if (!predicate || n_data_chunks == 0) HY_HIP(hipMemsetAsync(d_overflow, 0, 4, stream));   // else prepare_jobs zeroes it
 
   PredicateArgs pa;
   std::memset(&pa, 0, sizeof(pa));
@@ -777,13 +1017,12 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     HY_TRY(stage(predicate->per_chunk_upper, 4 * size_t{n_data_chunks}, &d)); pa.per_chunk_upper = static_cast<const uint32_t*>(d);
     HY_TRY(stage(predicate->per_chunk_found, size_t{n_data_chunks}, &d)); pa.per_chunk_found = static_cast<const uint8_t*>(d);
     if (n_data_chunks) {
-      hipLaunchKernelGGL(prepare_jobs, dim3((n_data_chunks + 255) / 256), dim3(256), 0, stream, data_column->d_segments, n_data_chunks, pa, d_jobs);
+      hipLaunchKernelGGL(prepare_jobs, dim3((n_data_chunks + 255) / 256), dim3(256), 0, stream, data_column->d_segments, n_data_chunks, pa, d_jobs, d_overflow);
     }
   }
-  uint32_t* d_excluded = nullptr;
   if (n_excluded) {
     if (column->is_reference) return fail(HY_ERR_INVALID, "excluded chunks apply to data tables only");
-    d_excluded = carve<uint32_t>(sc, n_excluded);
+    uint32_t* d_excluded = carve<uint32_t>(sc, n_excluded);
     HY_HIP(hipMemcpyAsync(d_excluded, excluded, 4 * size_t{n_excluded}, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(exclude_chunks, dim3((n_excluded + 255) / 256), dim3(256), 0, stream, d_jobs, d_excluded, n_excluded);
   }
@@ -792,7 +1031,9 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   uint64_t* d_offsets = result->offsets;
   uint32_t* d_counts = result->counts;
   uint8_t* d_state = result->chunk_state;
+  uint64_t device_capacity = result->capacity;
   if (host_result) {
+    device_capacity = column->rows;
     d_matches = carve<hy_row_id>(sc, device_capacity + 1);
     d_offsets = carve<uint64_t>(sc, size_t{n_chunks} + 2);
     d_counts = carve<uint32_t>(sc, size_t{n_chunks} + 1);
@@ -803,7 +1044,12 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   if (n_chunks == 0) {
     HY_HIP(hipMemsetAsync(d_offsets, 0, 8, stream));
   } else {
-    HY_TRY(sc.begin_launch(column->n_slices, column->n_slices));
+    ScanKernel kernel = scan_slices<0>;
+    if (!right && column->stream_width == 1) kernel = scan_slices<1>;
+    else if (!right && column->stream_width == 2) kernel = scan_slices<2>;
+    else if (!right && column->stream_width == 4) kernel = scan_slices<4>;
+    const uint32_t grid = scan_grid(kernel, column->n_parts);
+    HY_TRY(sc.begin_launch(column->n_parts, 0));
     ScanArgs a;
     std::memset(&a, 0, sizeof(a));
     a.segments = column->d_segments;
@@ -811,49 +1057,59 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     a.slices = column->d_slices;
     a.jobs = d_jobs;
     a.n_slices = column->n_slices;
+    a.n_parts = column->n_parts;
     a.n_chunks = n_chunks;
     a.condition = condition;
     a.materialize_all = pa.materialize_all;
     a.is_null_scan = predicate && predicate->condition == HY_PRED_IS_NULL;
     a.epoch = sc.epoch;
-    a.ticket_base = sc.ticket_base;
-    a.ticket = sc.ticket;
     a.status = sc.status;
     a.matches = d_matches;
     a.capacity = device_capacity;
     a.offsets = d_offsets;
+    a.counts = d_counts;
+    a.chunk_state = d_state;
     a.overflow = d_overflow;
-    sc.ticket_base += column->n_slices;
+    a.trace = nullptr;
+    if (getenv("HY_SCAN_TRACE")) {
+      static uint64_t* trace_buffer = nullptr;
+      if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 4 * 4096);
+      a.trace = trace_buffer;
+      g_trace_buffer = trace_buffer;
+      g_trace_grid = grid;
+    }
     profile_begin(stream);
-    hipLaunchKernelGGL(scan_slices, dim3(column->n_slices), dim3(WG_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(WG_THREADS), SCAN_LDS_BYTES, stream, a.segments, a.right, a.slices, a.jobs, column->d_parts, a);
     profile_end(stream);
-    FinalizeArgs f;
-    f.segments = column->d_segments;
-    f.jobs = d_jobs;
-    f.n_chunks = n_chunks;
-    f.materialize_all = pa.materialize_all;
-    f.columns_scan = right ? 1 : 0;
-    f.excluded = d_excluded;
-    f.n_excluded = n_excluded;
-    f.offsets = d_offsets;
-    f.counts = d_counts;
-    f.chunk_state = d_state;
-    hipLaunchKernelGGL(finalize_scan, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, f);
   }
   HY_HIP(hipGetLastError());
 
   if (host_result) {
     uint32_t overflow = 0;
-    HY_HIP(hipMemcpyAsync(result->offsets, d_offsets, 8 * (size_t{n_chunks} + 1), hipMemcpyDeviceToHost, stream));
     HY_HIP(hipMemcpyAsync(result->counts, d_counts, 4 * size_t{n_chunks}, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipMemcpyAsync(result->chunk_state, d_state, size_t{n_chunks}, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
-    const uint64_t total = result->offsets[n_chunks];
+    if (overflow) return fail(HY_ERR_DEVICE, "scan overflowed its own region buffer (internal error)");
+    // back-to-back layout for the host: offsets[c+1] - offsets[c] = RowIDs written for chunk c
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      result->offsets[c] = total;
+      const bool elided = result->chunk_state[c] == HY_CHUNK_ALL_MATCH && !pa.materialize_all;
+      total += elided ? 0 : result->counts[c];
+    }
+    result->offsets[n_chunks] = total;
     result->total_matches = total;
-    if (overflow || total > result->capacity) return fail(HY_ERR_CAPACITY, "scan produced %llu RowIDs, capacity is %llu", static_cast<unsigned long long>(total), static_cast<unsigned long long>(result->capacity));
-    if (total) HY_HIP(hipMemcpyAsync(result->matches, d_matches, sizeof(hy_row_id) * total, hipMemcpyDeviceToHost, stream));
-    HY_HIP(hipStreamSynchronize(stream));
+    if (total > result->capacity) return fail(HY_ERR_CAPACITY, "scan produced %llu RowIDs, capacity is %llu", static_cast<unsigned long long>(total), static_cast<unsigned long long>(result->capacity));
+    if (total) {
+      uint64_t* d_dense_offsets = carve<uint64_t>(sc, size_t{n_chunks} + 2);
+      hy_row_id* d_dense = carve<hy_row_id>(sc, total);
+      if (!d_dense_offsets || !d_dense) return fail(HY_ERR_DEVICE, "scratch arena exhausted");
+      HY_HIP(hipMemcpyAsync(d_dense_offsets, result->offsets, 8 * (size_t{n_chunks} + 1), hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(compact_regions, dim3(n_chunks), dim3(256), 0, stream, d_matches, d_offsets, d_dense_offsets, d_dense, n_chunks);
+      HY_HIP(hipMemcpyAsync(result->matches, d_dense, sizeof(hy_row_id) * total, hipMemcpyDeviceToHost, stream));
+      HY_HIP(hipStreamSynchronize(stream));
+    }
   } else {
     result->total_matches = 0;
   }
@@ -865,6 +1121,15 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
 using namespace hy;
 
 extern "C" {
+
+// debug only (HY_SCAN_TRACE): copies the per-workgroup phase stamps of the last scan; not part of the public header
+int hy_debug_scan_trace(uint64_t* out, uint32_t capacity_wgs) {
+  if (!g_trace_buffer) return 0;
+  const uint32_t n = g_trace_grid < capacity_wgs ? g_trace_grid : capacity_wgs;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(out, g_trace_buffer, size_t{n} * 32, hipMemcpyDeviceToHost);
+  return static_cast<int>(n);
+}
 
 hy_status hy_table_scan(const hy_column* column, const hy_predicate* predicate, const uint32_t* excluded_chunks,
                         uint32_t n_excluded, hy_scan_result* result) {

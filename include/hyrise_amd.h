@@ -163,6 +163,11 @@ typedef struct hy_scan_result {
 } hy_scan_result;
 
 #define HY_SCAN_MATERIALIZE_ALL_MATCH 1u /* also write RowIDs for ALL_MATCH chunks (what the CPU impl does internally) */
+/* Layout of `matches`.  Host results are always back to back: offsets[c+1] == offsets[c] + RowIDs written for chunk c.
+ * Device results use CHUNK REGIONS (the flag must be set to acknowledge it): chunk c's PosList starts at
+ * offsets[c] = number of rows in all chunks before c and holds counts[c] RowIDs (none for an elided ALL_MATCH chunk);
+ * offsets[n_chunks] = total rows; capacity must be >= total rows.  The kernel then needs no global prefix sum at all. */
+#define HY_SCAN_CHUNK_REGIONS 2u
 
 /* ---- runtime -------------------------------------------------------------------------------------------------- */
 int32_t hy_abi_version(void);
