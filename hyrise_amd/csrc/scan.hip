@@ -7,7 +7,7 @@
 //   ColumnVsValue / ColumnBetween / ColumnIsNull / ColumnVsColumn impls    table_scan/column_*_table_scan_impl.cpp
 //
 // Device design (one launch for ALL chunks of a column; a chunk is ~128 KiB, far too small for a launch of its own):
-//   prepare_jobs  one thread per data chunk: the two dictionary binary searches and the all/none early-outs of the
+//   prepare_jobs  one workgroup per data chunk: the dictionary bound searches (cooperative 64-ary) and the all/none early-outs of the
 //                 reference (column_vs_value_table_scan_impl.cpp:211-272, column_between_table_scan_impl.cpp:112-170)
 //                 collapse every predicate into ONE normalised per-chunk test:
 //                     integers / value ids:  ((u)(x - lo) <= span) ^ invert        (type_comparison.hpp:120-132)
@@ -60,31 +60,39 @@ __device__ __forceinline__ bool is_between(uint32_t c) { return c >= HY_PRED_BET
 __device__ __forceinline__ bool lower_inclusive(uint32_t c) { return c == HY_PRED_BETWEEN_INCLUSIVE || c == HY_PRED_BETWEEN_UPPER_EXCLUSIVE; }
 __device__ __forceinline__ bool upper_inclusive(uint32_t c) { return c == HY_PRED_BETWEEN_INCLUSIVE || c == HY_PRED_BETWEEN_LOWER_EXCLUSIVE; }
 
+// Wave-cooperative 64-ary search in a sorted dictionary: first index whose element is NOT (< value) [upper == false]
+// or NOT (<= value) [upper == true]; d if there is none.  Two dependent loads for d <= 4096, three up to 262 144.
 template <typename T>
-__device__ uint32_t dict_lower_bound(const T* dict, uint32_t d, T value) {
+__device__ uint32_t wave_bound(const T* dict, uint32_t d, T value, bool upper, uint32_t lane) {
   uint32_t lo = 0, hi = d;
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if (dict[mid] < value) lo = mid + 1; else hi = mid;
+  while (hi > lo) {
+    const uint32_t span = hi - lo;
+    const uint32_t step = (span + 63) / 64;
+    const uint64_t idx = static_cast<uint64_t>(lo) + static_cast<uint64_t>(lane) * step;
+    bool before = false;
+    if (idx < hi) {
+      const T e = dict[idx];
+      before = upper ? !(value < e) : (e < value);
+    }
+    const uint32_t n = __popcll(__ballot(before));   // the probes that satisfy the predicate form a prefix
+    if (n == 0) { hi = lo; break; }
+    const uint64_t new_hi = static_cast<uint64_t>(lo) + static_cast<uint64_t>(n) * step;
+    lo = lo + (n - 1) * step + 1;
+    hi = new_hi < hi ? static_cast<uint32_t>(new_hi) : hi;
   }
-  return lo == d ? HY_INVALID_VALUE_ID : lo;
-}
-template <typename T>
-__device__ uint32_t dict_upper_bound(const T* dict, uint32_t d, T value) {
-  uint32_t lo = 0, hi = d;
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if (!(value < dict[mid])) lo = mid + 1; else hi = mid;
-  }
-  return lo == d ? HY_INVALID_VALUE_ID : lo;
+  return lo;
 }
 
 template <typename T>
-__device__ void dict_bounds(const DevSegment& s, T v, uint32_t* lower, uint32_t* upper, bool* found) {
+__device__ uint32_t wave_search(const DevSegment& s, T v, T v2, uint32_t which, uint32_t lane) {
   const T* dict = static_cast<const T*>(s.aux);
-  *lower = dict_lower_bound(dict, s.aux_size, v);
-  *upper = dict_upper_bound(dict, s.aux_size, v);
-  *found = *lower != HY_INVALID_VALUE_ID && dict[*lower] == v;
+  const uint32_t r = wave_bound<T>(dict, s.aux_size, (which & 2) ? v2 : v, (which & 1) != 0, lane);
+  return r == s.aux_size ? HY_INVALID_VALUE_ID : r;
+}
+
+template <typename T>
+__device__ bool dict_equals(const DevSegment& s, uint32_t vid, T v) {
+  return vid != HY_INVALID_VALUE_ID && static_cast<const T*>(s.aux)[vid] == v;
 }
 
 __device__ __forceinline__ void set_value_id_range(ScanJob& job, uint32_t lo, uint32_t hi_inclusive, bool invert) {
@@ -113,11 +121,33 @@ __device__ bool integer_range(uint32_t cond, Wide v, Wide v2, Wide tmin, Wide tm
   return *lo <= *hi;
 }
 
-// One thread per DATA chunk of the scanned column (for reference columns: of the referenced column).
-__global__ void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, PredicateArgs p, ScanJob* jobs, uint32_t* overflow) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0) *overflow = 0;
+// One 256-thread workgroup per DATA chunk of the scanned column (for reference columns: of the referenced column).
+// Wave w runs one of the (up to) four dictionary searches -- lower/upper bound of value and of value2 -- as a
+// cooperative 64-ary search, so a chunk costs two or three dependent loads instead of ~50.
+__global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, PredicateArgs p, ScanJob* jobs, uint32_t* overflow) {
+  __shared__ uint32_t s_bound[4];
+  const uint32_t c = blockIdx.x;
+  if (c == 0 && threadIdx.x == 0) *overflow = 0;
   if (c >= n_chunks) return;
+  {
+    const DevSegment seg = segments[c];
+    const uint32_t cond0 = p.condition;
+    const bool searchable = seg.encoding == HY_ENC_DICTIONARY && seg.aux && seg.data_type != HY_TYPE_STRING &&
+                            cond0 != HY_PRED_IS_NULL && cond0 != HY_PRED_IS_NOT_NULL;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (searchable && (wave < 2 || is_between(cond0))) {
+      uint32_t r;
+      switch (seg.data_type) {
+        case HY_TYPE_INT: r = wave_search<int32_t>(seg, p.value.i32, p.value2.i32, wave, lane); break;
+        case HY_TYPE_LONG: r = wave_search<int64_t>(seg, p.value.i64, p.value2.i64, wave, lane); break;
+        case HY_TYPE_FLOAT: r = wave_search<float>(seg, p.value.f32, p.value2.f32, wave, lane); break;
+        default: r = wave_search<double>(seg, p.value.f64, p.value2.f64, wave, lane); break;
+      }
+      if (lane == 0) s_bound[wave] = r;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   const DevSegment s = segments[c];
   ScanJob job;
   job.mode = JOB_SCAN;
@@ -149,13 +179,14 @@ __global__ void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, Pred
     const uint32_t d = s.aux_size;
     job.null_vid = d;
     uint32_t lower = 0, upper = 0, lower2 = 0, upper2 = 0;
-    bool found = false, found2 = false;
+    bool found = false;
     if (s.aux && s.data_type != HY_TYPE_STRING) {
+      lower = s_bound[0]; upper = s_bound[1]; lower2 = s_bound[2]; upper2 = s_bound[3];
       switch (s.data_type) {
-        case HY_TYPE_INT: dict_bounds<int32_t>(s, p.value.i32, &lower, &upper, &found); dict_bounds<int32_t>(s, p.value2.i32, &lower2, &upper2, &found2); break;
-        case HY_TYPE_LONG: dict_bounds<int64_t>(s, p.value.i64, &lower, &upper, &found); dict_bounds<int64_t>(s, p.value2.i64, &lower2, &upper2, &found2); break;
-        case HY_TYPE_FLOAT: dict_bounds<float>(s, p.value.f32, &lower, &upper, &found); dict_bounds<float>(s, p.value2.f32, &lower2, &upper2, &found2); break;
-        default: dict_bounds<double>(s, p.value.f64, &lower, &upper, &found); dict_bounds<double>(s, p.value2.f64, &lower2, &upper2, &found2); break;
+        case HY_TYPE_INT: found = dict_equals<int32_t>(s, lower, p.value.i32); break;
+        case HY_TYPE_LONG: found = dict_equals<int64_t>(s, lower, p.value.i64); break;
+        case HY_TYPE_FLOAT: found = dict_equals<float>(s, lower, p.value.f32); break;
+        default: found = dict_equals<double>(s, lower, p.value.f64); break;
       }
     } else {  // caller-resolved value ids (string dictionaries)
       lower = p.per_chunk_lower[c];
@@ -1017,7 +1048,7 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     HY_TRY(stage(predicate->per_chunk_upper, 4 * size_t{n_data_chunks}, &d)); pa.per_chunk_upper = static_cast<const uint32_t*>(d);
     HY_TRY(stage(predicate->per_chunk_found, size_t{n_data_chunks}, &d)); pa.per_chunk_found = static_cast<const uint8_t*>(d);
     if (n_data_chunks) {
-      hipLaunchKernelGGL(prepare_jobs, dim3((n_data_chunks + 255) / 256), dim3(256), 0, stream, data_column->d_segments, n_data_chunks, pa, d_jobs, d_overflow);
+      hipLaunchKernelGGL(prepare_jobs, dim3(n_data_chunks), dim3(256), 0, stream, data_column->d_segments, n_data_chunks, pa, d_jobs, d_overflow);
     }
   }
   if (n_excluded) {
