@@ -209,8 +209,9 @@ hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, u
 typedef struct hy_join_result {
   uint32_t mem;
   uint32_t radix_bits;            /* in: 0xFFFFFFFF = derive like JoinHash::calculate_radix_bits; out: value used      */
-  hy_row_id* left_pos;            /* [capacity] RowIDs into the LEFT input (unused for Semi/Anti*: may be NULL)        */
-  hy_row_id* right_pos;           /* [capacity] RowIDs into the RIGHT input                                            */
+  hy_row_id* left_pos;            /* [capacity] RowIDs into the LEFT input                                             */
+  hy_row_id* right_pos;           /* [capacity] RowIDs into the RIGHT input (Semi/Anti*: unused, may be NULL -- the     *
+                                   *  probe side of those modes is the LEFT input and only left_pos is written)       */
   uint64_t capacity;
   uint64_t* slice_offsets;        /* [slice_capacity + 1] boundaries of the per-probe-slice PosLists                   */
   uint32_t slice_capacity;

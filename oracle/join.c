@@ -1,0 +1,494 @@
+/*
+ * join.c -- restatement of JoinHash (radix-partitioned hash join).  TEST INFRASTRUCTURE ONLY (see hy_oracle.h).
+ *
+ * Follows, step by step:
+ *   JoinHash::calculate_radix_bits                    operators/join_hash.cpp:70-114
+ *   JoinHash::_on_execute (side selection)            join_hash.cpp:139-183
+ *   JoinHashImpl::_on_execute (NULL policy, Bloom
+ *     filter order, AntiNullAsTrue early exit)        join_hash.cpp:270-572
+ *   materialize_input                                 join_hash/join_hash_steps.hpp:274-420
+ *   partition_by_radix                                join_hash_steps.hpp:509-617
+ *   build + PosHashTable                              join_hash_steps.hpp:97-236, 426-507
+ *   probe / probe_semi_anti                           join_hash_steps.hpp:624-922
+ * Integer keys only (int32/int64): std::hash is the identity there (pinned by join_hash_steps_test.cpp:169-188);
+ * std::hash<float/double> is implementation-defined, so float-keyed joins stay on the CPU path.
+ * Secondary predicates are not part of the device ABI and therefore not restated.
+ *
+ * Result: the concatenation of probe()'s per-slice PosLists, in the order the slices are created
+ * (partition, then 131 070-element slice), plus the slice boundaries; write_output_chunks
+ * (join_helper/join_output_writing.cpp:205-340) only groups / merges slices and is host-side bookkeeping.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hy_oracle.h"
+
+#define BLOOM_BITS (1u << 20)       /* join_hash_steps.hpp:252 */
+#define BLOOM_MASK (BLOOM_BITS - 1)
+#define BLOOM_WORDS (BLOOM_BITS / 64)
+#define PROBE_SIZE_PER_CHUNK (65535u * 2u) /* join_hash_steps.hpp:47 */
+
+typedef struct {
+  hy_row_id row_id;
+  int64_t value;
+} element_t;
+
+typedef struct {
+  element_t* elements;
+  uint8_t* nulls; /* byte per element, only with keep_nulls */
+  uint64_t size;
+} partition_t;
+
+static inline uint32_t load_compressed(const void* data, uint32_t width, uint32_t i) {
+  if (width == 1) return ((const uint8_t*)data)[i];
+  if (width == 2) return ((const uint16_t*)data)[i];
+  return ((const uint32_t*)data)[i];
+}
+
+/* value of row i of a DATA segment; returns 1 if NULL */
+static int data_value(const hy_segment* s, uint32_t i, int64_t* out) {
+  *out = 0;
+  switch (s->encoding) {
+    case HY_ENC_UNENCODED:
+      if (s->nulls && ((s->nulls[i / 64] >> (i % 64)) & 1)) return 1;
+      *out = s->data_type == HY_TYPE_INT ? ((const int32_t*)s->data)[i] : ((const int64_t*)s->data)[i];
+      return 0;
+    case HY_ENC_DICTIONARY: {
+      const uint32_t vid = load_compressed(s->data, s->width, i);
+      if (vid >= s->aux_size) return 1;
+      *out = s->data_type == HY_TYPE_INT ? ((const int32_t*)s->aux)[vid] : ((const int64_t*)s->aux)[vid];
+      return 0;
+    }
+    case HY_ENC_FRAME_OF_REFERENCE:
+      if (s->nulls && ((s->nulls[i / 64] >> (i % 64)) & 1)) return 1;
+      *out = (int32_t)(load_compressed(s->data, s->width, i) + (uint32_t)((const int32_t*)s->aux)[i / HY_FOR_BLOCK_SIZE]);
+      return 0;
+    default: return 1;
+  }
+}
+
+/* value of row i of chunk c of a column that may be made of reference segments */
+static int column_value(const hyo_column* col, uint32_t c, uint32_t i, int64_t* out) {
+  const hy_segment* s = &col->segments[c];
+  if (s->encoding != HY_ENC_REFERENCE) return data_value(s, i, out);
+  const hyo_column* referenced = (const hyo_column*)s->ref;
+  hy_row_id r;
+  if (s->data) r = ((const hy_row_id*)s->data)[i];
+  else { r.chunk_id = s->ref_chunk_id; r.chunk_offset = i; }
+  *out = 0;
+  if (r.chunk_offset == 0xFFFFFFFFu) return 1;
+  return data_value(&referenced->segments[r.chunk_id], r.chunk_offset, out);
+}
+
+static inline int bloom_get(const uint64_t* bloom, uint64_t hash) {
+  const uint32_t bit = (uint32_t)(hash & BLOOM_MASK);
+  return (int)((bloom[bit / 64] >> (bit % 64)) & 1);
+}
+static inline void bloom_set(uint64_t* bloom, uint64_t hash) {
+  const uint32_t bit = (uint32_t)(hash & BLOOM_MASK);
+  bloom[bit / 64] |= (uint64_t)1 << (bit % 64);
+}
+
+uint32_t hyo_calculate_radix_bits(uint64_t build_rows, uint64_t probe_rows) {
+  (void)probe_rows;
+  const double l2_cache_max_usable = 1024000 * 0.75;                             /* join_hash.cpp:95-96 */
+  const double complete_hash_map_size = (double)build_rows * (double)sizeof(uint32_t) / 0.8; /* :101-105 */
+  double cluster_count = complete_hash_map_size / l2_cache_max_usable;
+  if (cluster_count < 1.0) cluster_count = 1.0;
+  const double bits = ceil(log2(cluster_count));
+  return bits > 8.0 ? 8u : (uint32_t)bits;                                       /* :113 */
+}
+
+/* materialize_input<T, HashedType, keep_null_values> for one chunk (join_hash_steps.hpp:306-410). */
+static void materialize_chunk(const hyo_column* col, uint32_t chunk_id, int keep_nulls, uint32_t radix_bits,
+                              const uint64_t* bloom_in, uint64_t* bloom_out, partition_t* out, uint64_t* histogram) {
+  const uint32_t n = col->segments[chunk_id].size;
+  const uint64_t radix_mask = ((uint64_t)1 << radix_bits) - 1;
+  out->elements = (element_t*)malloc(sizeof(element_t) * (n ? n : 1));
+  out->nulls = keep_nulls ? (uint8_t*)calloc(n ? n : 1, 1) : NULL;
+  uint64_t count = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    int64_t value;
+    const int is_null = column_value(col, chunk_id, i, &value);
+    if (is_null && !keep_nulls) continue;
+    const uint64_t hash = (uint64_t)value; /* std::hash<integral> is the identity */
+    if (!is_null && bloom_in && !bloom_get(bloom_in, hash) && !keep_nulls) continue; /* :354-358 */
+    bloom_set(bloom_out, hash);                                                      /* :362 */
+    out->elements[count].row_id.chunk_id = chunk_id;  /* reference segments: index in the segment (:364-371) */
+    out->elements[count].row_id.chunk_offset = i;
+    out->elements[count].value = value;
+    if (keep_nulls) out->nulls[count] = (uint8_t)is_null;
+    ++count;
+    if (radix_bits > 0) ++histogram[hash & radix_mask];
+  }
+  out->size = count;
+}
+
+uint64_t hyo_join_materialize(const hyo_column* column, int keep_nulls, uint32_t radix_bits, const uint64_t* bloom_in,
+                              uint64_t* bloom_out, hy_row_id* row_ids_out, int64_t* values_out, uint8_t* nulls_out,
+                              uint64_t* chunk_element_counts_out, uint64_t* histograms_out) {
+  const uint64_t partitions = (uint64_t)1 << radix_bits;
+  uint64_t total = 0;
+  for (uint32_t c = 0; c < column->n_chunks; ++c) {
+    partition_t p;
+    uint64_t* hist = (uint64_t*)calloc(partitions, sizeof(uint64_t));
+    materialize_chunk(column, c, keep_nulls, radix_bits, bloom_in, bloom_out, &p, hist);
+    for (uint64_t i = 0; i < p.size; ++i) {
+      row_ids_out[total + i] = p.elements[i].row_id;
+      values_out[total + i] = p.elements[i].value;
+      if (nulls_out) nulls_out[total + i] = p.nulls ? p.nulls[i] : 0;
+    }
+    if (chunk_element_counts_out) chunk_element_counts_out[c] = p.size;
+    if (histograms_out) memcpy(histograms_out + (uint64_t)c * partitions, hist, sizeof(uint64_t) * partitions);
+    total += p.size;
+    free(hist); free(p.elements); free(p.nulls);
+  }
+  return total;
+}
+
+/* ---- tiny parallel-for (JobTask fan-out) ---------------------------------------------------------------------- */
+typedef void (*job_fn)(void* ctx, uint64_t index);
+typedef struct { job_fn fn; void* ctx; uint64_t n; volatile uint64_t* next; } pool_t;
+static void* pool_worker(void* arg) {
+  pool_t* p = (pool_t*)arg;
+  for (;;) {
+    const uint64_t i = __atomic_fetch_add(p->next, 1, __ATOMIC_RELAXED);
+    if (i >= p->n) return NULL;
+    p->fn(p->ctx, i);
+  }
+}
+static void parallel_for(uint64_t n, job_fn fn, void* ctx, int threads) {
+  if (threads <= 1 || n <= 1) { for (uint64_t i = 0; i < n; ++i) fn(ctx, i); return; }
+  volatile uint64_t next = 0;
+  pool_t pool = {fn, ctx, n, &next};
+  if ((uint64_t)threads > n) threads = (int)n;
+  pthread_t* tids = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+  for (int t = 0; t < threads; ++t) pthread_create(&tids[t], NULL, pool_worker, &pool);
+  for (int t = 0; t < threads; ++t) pthread_join(tids[t], NULL);
+  free(tids);
+}
+
+/* ---- PosHashTable (join_hash_steps.hpp:97-236): key -> dense id in insertion order; id -> RowIDs in insertion order */
+typedef struct {
+  int64_t* keys; uint32_t* ids; uint8_t* used; uint64_t capacity; /* open addressing */
+  uint32_t distinct;
+  uint64_t* offsets;   /* [distinct + 1] into pos_list (finalize()) */
+  hy_row_id* pos_list;
+  int exists;
+} hash_table_t;
+
+static uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; return x; }
+
+static uint32_t table_find(const hash_table_t* t, int64_t key) {
+  if (!t->exists || t->capacity == 0) return 0xFFFFFFFFu;
+  uint64_t slot = mix((uint64_t)key) & (t->capacity - 1);
+  while (t->used[slot]) {
+    if (t->keys[slot] == key) return t->ids[slot];
+    slot = (slot + 1) & (t->capacity - 1);
+  }
+  return 0xFFFFFFFFu;
+}
+
+static void table_build(hash_table_t* t, const partition_t* parts, uint32_t n_parts, const uint64_t* probe_bloom,
+                        int all_positions) {
+  uint64_t total = 0;
+  for (uint32_t p = 0; p < n_parts; ++p) total += parts[p].size;
+  uint64_t cap = 16;
+  while (cap < total * 2) cap <<= 1;
+  t->capacity = cap;
+  t->keys = (int64_t*)malloc(sizeof(int64_t) * cap);
+  t->ids = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+  t->used = (uint8_t*)calloc(cap, 1);
+  t->distinct = 0;
+  t->exists = 1;
+  uint32_t* element_ids = (uint32_t*)malloc(sizeof(uint32_t) * (total ? total : 1));
+  uint32_t* counts = (uint32_t*)calloc(total ? total : 1, sizeof(uint32_t));
+  uint64_t e = 0;
+  for (uint32_t p = 0; p < n_parts; ++p) {
+    for (uint64_t i = 0; i < parts[p].size; ++i, ++e) {
+      const int64_t key = parts[p].elements[i].value;
+      element_ids[e] = 0xFFFFFFFFu;
+      if (!bloom_get(probe_bloom, (uint64_t)key)) continue;   /* :476-479 */
+      uint64_t slot = mix((uint64_t)key) & (cap - 1);
+      while (t->used[slot] && t->keys[slot] != key) slot = (slot + 1) & (cap - 1);
+      if (!t->used[slot]) { t->used[slot] = 1; t->keys[slot] = key; t->ids[slot] = t->distinct++; }
+      element_ids[e] = t->ids[slot];
+      counts[t->ids[slot]]++;
+    }
+  }
+  if (all_positions) { /* finalize(): concatenate the per-id lists, each in insertion order (:147-175) */
+    t->offsets = (uint64_t*)malloc(sizeof(uint64_t) * ((uint64_t)t->distinct + 1));
+    uint64_t sum = 0;
+    for (uint32_t id = 0; id < t->distinct; ++id) { t->offsets[id] = sum; sum += counts[id]; }
+    t->offsets[t->distinct] = sum;
+    t->pos_list = (hy_row_id*)malloc(sizeof(hy_row_id) * (sum ? sum : 1));
+    uint64_t* cursor = (uint64_t*)malloc(sizeof(uint64_t) * ((uint64_t)t->distinct + 1));
+    memcpy(cursor, t->offsets, sizeof(uint64_t) * ((uint64_t)t->distinct + 1));
+    e = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+      for (uint64_t i = 0; i < parts[p].size; ++i, ++e) {
+        if (element_ids[e] != 0xFFFFFFFFu) t->pos_list[cursor[element_ids[e]]++] = parts[p].elements[i].row_id;
+      }
+    }
+    free(cursor);
+  }
+  free(element_ids); free(counts);
+}
+
+static void table_free(hash_table_t* t) {
+  free(t->keys); free(t->ids); free(t->used); free(t->offsets); free(t->pos_list);
+  memset(t, 0, sizeof(*t));
+}
+
+/* ---- pipeline -------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const hyo_column* column; int keep_nulls; uint32_t radix_bits; const uint64_t* bloom_in;
+  uint64_t** local_blooms; partition_t* chunks; uint64_t* histograms; uint64_t partitions;
+} materialize_ctx_t;
+
+static void materialize_job(void* arg, uint64_t c) {
+  materialize_ctx_t* m = (materialize_ctx_t*)arg;
+  m->local_blooms[c] = (uint64_t*)calloc(BLOOM_WORDS, sizeof(uint64_t));
+  materialize_chunk(m->column, (uint32_t)c, m->keep_nulls, m->radix_bits, m->bloom_in, m->local_blooms[c], &m->chunks[c],
+                    m->histograms + c * m->partitions);
+}
+
+static partition_t* materialize(const hyo_column* col, int keep_nulls, uint32_t radix_bits, const uint64_t* bloom_in,
+                                uint64_t* bloom_out, uint64_t** histograms_out, int threads) {
+  const uint64_t partitions = (uint64_t)1 << radix_bits;
+  partition_t* chunks = (partition_t*)calloc(col->n_chunks ? col->n_chunks : 1, sizeof(partition_t));
+  uint64_t* hist = (uint64_t*)calloc((uint64_t)(col->n_chunks ? col->n_chunks : 1) * partitions, sizeof(uint64_t));
+  uint64_t** local = (uint64_t**)calloc(col->n_chunks ? col->n_chunks : 1, sizeof(uint64_t*));
+  materialize_ctx_t ctx = {col, keep_nulls, radix_bits, bloom_in, local, chunks, hist, partitions};
+  parallel_for(col->n_chunks, materialize_job, &ctx, threads);
+  for (uint32_t c = 0; c < col->n_chunks; ++c) { /* output_bloom_filter |= local (:405-409) */
+    for (uint32_t w = 0; w < BLOOM_WORDS; ++w) bloom_out[w] |= local[c][w];
+    free(local[c]);
+  }
+  free(local);
+  *histograms_out = hist;
+  return chunks;
+}
+
+/* partition_by_radix (:509-617): stable scatter, offsets = prefix over input partitions per radix value. */
+static partition_t* partition_by_radix(const partition_t* in, uint32_t n_in, const uint64_t* histograms,
+                                       uint32_t radix_bits, int keep_nulls) {
+  const uint64_t partitions = (uint64_t)1 << radix_bits;
+  const uint64_t mask = partitions - 1;
+  partition_t* out = (partition_t*)calloc(partitions, sizeof(partition_t));
+  uint64_t* offsets = (uint64_t*)malloc(sizeof(uint64_t) * (uint64_t)(n_in ? n_in : 1) * partitions);
+  for (uint64_t r = 0; r < partitions; ++r) {
+    uint64_t size = 0;
+    for (uint32_t c = 0; c < n_in; ++c) { offsets[(uint64_t)c * partitions + r] = size; size += histograms[(uint64_t)c * partitions + r]; }
+    out[r].elements = (element_t*)malloc(sizeof(element_t) * (size ? size : 1));
+    out[r].nulls = keep_nulls ? (uint8_t*)malloc(size ? size : 1) : NULL;
+    out[r].size = size;
+  }
+  for (uint32_t c = 0; c < n_in; ++c) {
+    for (uint64_t i = 0; i < in[c].size; ++i) {
+      const uint64_t r = (uint64_t)in[c].elements[i].value & mask;
+      const uint64_t idx = offsets[(uint64_t)c * partitions + r]++;
+      out[r].elements[idx] = in[c].elements[i];
+      if (keep_nulls) out[r].nulls[idx] = in[c].nulls[i];
+    }
+  }
+  free(offsets);
+  return out;
+}
+
+static void free_partitions(partition_t* p, uint64_t n) {
+  if (!p) return;
+  for (uint64_t i = 0; i < n; ++i) { free(p[i].elements); free(p[i].nulls); }
+  free(p);
+}
+
+typedef struct { hy_row_id* build; hy_row_id* probe; uint64_t size, capacity; } pos_pair_t;
+static void pair_push(pos_pair_t* p, hy_row_id b, hy_row_id r, int with_build) {
+  if (p->size == p->capacity) {
+    p->capacity = p->capacity ? p->capacity * 2 : 64;
+    p->probe = (hy_row_id*)realloc(p->probe, sizeof(hy_row_id) * p->capacity);
+    if (with_build) p->build = (hy_row_id*)realloc(p->build, sizeof(hy_row_id) * p->capacity);
+  }
+  p->probe[p->size] = r;
+  if (with_build) p->build[p->size] = b;
+  p->size++;
+}
+
+typedef struct {
+  const partition_t* probe_partitions; const hash_table_t* tables; uint32_t n_tables; uint32_t mode; int keep_nulls;
+  uint64_t build_rows;
+  struct { uint32_t partition; uint64_t begin, end; } * slices;
+  pos_pair_t* out;
+} probe_ctx_t;
+
+static const hy_row_id NULL_ROW = {0xFFFFFFFFu, 0xFFFFFFFFu};
+
+static void probe_job(void* arg, uint64_t s) {
+  probe_ctx_t* p = (probe_ctx_t*)arg;
+  const partition_t* part = &p->probe_partitions[p->slices[s].partition];
+  const hash_table_t* table = NULL;
+  if (p->n_tables) {
+    const uint32_t idx = p->n_tables > 1 ? p->slices[s].partition : 0;
+    if (p->tables[idx].exists) table = &p->tables[idx];
+  }
+  pos_pair_t* out = &p->out[s];
+  const uint32_t mode = p->mode;
+  const int semi_anti = mode == HY_JOIN_SEMI || mode == HY_JOIN_ANTI_NULL_AS_TRUE || mode == HY_JOIN_ANTI_NULL_AS_FALSE;
+  for (uint64_t i = p->slices[s].begin; i < p->slices[s].end; ++i) {
+    const element_t* e = &part->elements[i];
+    const int is_null = p->keep_nulls && part->nulls[i];
+    if (!semi_anti) { /* probe() :690-777 */
+      if (!table) { if (p->keep_nulls) pair_push(out, NULL_ROW, e->row_id, 1); continue; }
+      if (mode == HY_JOIN_INNER && e->row_id.chunk_offset == 0xFFFFFFFFu) continue;
+      const uint32_t id = table_find(table, e->value);
+      if (id != 0xFFFFFFFFu) {
+        if (is_null) { pair_push(out, NULL_ROW, e->row_id, 1); continue; }
+        for (uint64_t m = table->offsets[id]; m < table->offsets[id + 1]; ++m) pair_push(out, table->pos_list[m], e->row_id, 1);
+      } else if (p->keep_nulls) {
+        pair_push(out, NULL_ROW, e->row_id, 1);
+      }
+    } else { /* probe_semi_anti() :844-908 */
+      if (!table) {
+        if (mode == HY_JOIN_ANTI_NULL_AS_FALSE) pair_push(out, NULL_ROW, e->row_id, 0);
+        else if (mode == HY_JOIN_ANTI_NULL_AS_TRUE && !(is_null && p->build_rows != 0)) pair_push(out, NULL_ROW, e->row_id, 0);
+        continue;
+      }
+      if (mode == HY_JOIN_SEMI) { if (e->row_id.chunk_offset == 0xFFFFFFFFu) continue; }
+      else if (mode == HY_JOIN_ANTI_NULL_AS_FALSE) { if (is_null) { pair_push(out, NULL_ROW, e->row_id, 0); continue; } }
+      else if (is_null) continue;
+      const int matches = table_find(table, e->value) != 0xFFFFFFFFu;
+      if ((mode == HY_JOIN_SEMI && matches) || (mode != HY_JOIN_SEMI && !matches)) pair_push(out, NULL_ROW, e->row_id, 0);
+    }
+  }
+}
+
+typedef struct { hash_table_t* tables; const partition_t* build_partitions; const uint64_t* probe_bloom; int all_positions; } build_ctx_t;
+static void build_job(void* arg, uint64_t r) {
+  build_ctx_t* b = (build_ctx_t*)arg;
+  if (b->build_partitions[r].size == 0) return; /* :458-460 */
+  table_build(&b->tables[r], &b->build_partitions[r], 1, b->probe_bloom, b->all_positions);
+}
+
+int32_t hyo_join_hash(const hyo_column* left, const hyo_column* right, uint32_t mode, hy_join_result* result,
+                      int threads) {
+  if (mode == HY_JOIN_FULL_OUTER || mode == HY_JOIN_CROSS || mode > HY_JOIN_ANTI_NULL_AS_FALSE) return HY_ERR_UNSUPPORTED;
+  uint64_t left_rows = 0, right_rows = 0;
+  for (uint32_t c = 0; c < left->n_chunks; ++c) left_rows += left->segments[c].size;
+  for (uint32_t c = 0; c < right->n_chunks; ++c) right_rows += right->segments[c].size;
+  /* join_hash.cpp:139-155 */
+  const int build_right = mode == HY_JOIN_LEFT || mode == HY_JOIN_ANTI_NULL_AS_TRUE || mode == HY_JOIN_ANTI_NULL_AS_FALSE ||
+                          mode == HY_JOIN_SEMI || (mode == HY_JOIN_INNER && left_rows > right_rows);
+  const hyo_column* build = build_right ? right : left;
+  const hyo_column* probe = build_right ? left : right;
+  const uint64_t build_rows = build_right ? right_rows : left_rows, probe_rows = build_right ? left_rows : right_rows;
+  uint32_t radix_bits = result->radix_bits == 0xFFFFFFFFu ? hyo_calculate_radix_bits(build_rows, probe_rows) : result->radix_bits;
+  result->radix_bits = radix_bits;
+  result->left_is_build = (uint32_t)!build_right;
+  const uint64_t partitions = (uint64_t)1 << radix_bits;
+  const int keep_nulls_build = mode == HY_JOIN_ANTI_NULL_AS_TRUE;                          /* :284-286 */
+  const int keep_nulls_probe = mode == HY_JOIN_LEFT || mode == HY_JOIN_RIGHT || mode == HY_JOIN_ANTI_NULL_AS_TRUE ||
+                               mode == HY_JOIN_ANTI_NULL_AS_FALSE;
+  const int semi_anti = mode == HY_JOIN_SEMI || mode == HY_JOIN_ANTI_NULL_AS_TRUE || mode == HY_JOIN_ANTI_NULL_AS_FALSE;
+
+  uint64_t* build_bloom = (uint64_t*)calloc(BLOOM_WORDS, sizeof(uint64_t));
+  uint64_t* probe_bloom = (uint64_t*)calloc(BLOOM_WORDS, sizeof(uint64_t));
+  uint64_t *hist_build = NULL, *hist_probe = NULL;
+  partition_t *mat_build, *mat_probe;
+  if (build_rows < probe_rows) { /* :365-381 */
+    mat_build = materialize(build, keep_nulls_build, radix_bits, NULL, build_bloom, &hist_build, threads);
+    mat_probe = materialize(probe, keep_nulls_probe, radix_bits, build_bloom, probe_bloom, &hist_probe, threads);
+  } else {
+    mat_probe = materialize(probe, keep_nulls_probe, radix_bits, NULL, probe_bloom, &hist_probe, threads);
+    mat_build = materialize(build, keep_nulls_build, radix_bits, probe_bloom, build_bloom, &hist_build, threads);
+  }
+  partition_t *radix_build, *radix_probe;
+  uint64_t n_build_parts, n_probe_parts;
+  if (radix_bits > 0) { /* :398-435 */
+    radix_build = build->n_chunks ? partition_by_radix(mat_build, build->n_chunks, hist_build, radix_bits, keep_nulls_build) : NULL;
+    radix_probe = probe->n_chunks ? partition_by_radix(mat_probe, probe->n_chunks, hist_probe, radix_bits, keep_nulls_probe) : NULL;
+    n_build_parts = build->n_chunks ? partitions : 0;   /* empty radix_container stays empty (:512-514) */
+    n_probe_parts = probe->n_chunks ? partitions : 0;
+    free_partitions(mat_build, build->n_chunks ? build->n_chunks : 1);
+    free_partitions(mat_probe, probe->n_chunks ? probe->n_chunks : 1);
+  } else {
+    radix_build = mat_build; radix_probe = mat_probe;
+    n_build_parts = build->n_chunks; n_probe_parts = probe->n_chunks;
+  }
+  free(hist_build); free(hist_probe);
+
+  /* build (:426-507) */
+  const int all_positions = !semi_anti;
+  uint32_t n_tables = 0;
+  hash_table_t* tables = NULL;
+  if (n_build_parts > 0) {
+    if (radix_bits == 0) {
+      n_tables = 1;
+      tables = (hash_table_t*)calloc(1, sizeof(hash_table_t));
+      table_build(&tables[0], radix_build, (uint32_t)n_build_parts, probe_bloom, all_positions);
+    } else {
+      n_tables = (uint32_t)n_build_parts;
+      tables = (hash_table_t*)calloc(n_tables, sizeof(hash_table_t));
+      build_ctx_t bctx = {tables, radix_build, probe_bloom, all_positions};
+      parallel_for(n_tables, build_job, &bctx, threads);
+    }
+  }
+
+  int32_t status = HY_OK;
+  result->n_slices = 0;
+  result->n_pairs = 0;
+  int early_out = 0;
+  if (mode == HY_JOIN_ANTI_NULL_AS_TRUE) { /* :483-494 */
+    for (uint64_t p = 0; p < n_build_parts && !early_out; ++p)
+      for (uint64_t i = 0; i < radix_build[p].size; ++i) if (radix_build[p].nulls[i]) { early_out = 1; break; }
+  }
+  if (!early_out) {
+    /* probe (:641-660): one slice per PROBE_SIZE_PER_CHUNK elements of every non-empty partition */
+    uint64_t n_slices = 0;
+    for (uint64_t p = 0; p < n_probe_parts; ++p) n_slices += (radix_probe[p].size + PROBE_SIZE_PER_CHUNK - 1) / PROBE_SIZE_PER_CHUNK;
+    probe_ctx_t pctx;
+    memset(&pctx, 0, sizeof(pctx));
+    pctx.probe_partitions = radix_probe; pctx.tables = tables; pctx.n_tables = n_tables; pctx.mode = mode;
+    pctx.keep_nulls = keep_nulls_probe; pctx.build_rows = build_rows;
+    pctx.slices = malloc(sizeof(*pctx.slices) * (n_slices ? n_slices : 1));
+    pctx.out = (pos_pair_t*)calloc(n_slices ? n_slices : 1, sizeof(pos_pair_t));
+    uint64_t s = 0;
+    for (uint64_t p = 0; p < n_probe_parts; ++p)
+      for (uint64_t b = 0; b < radix_probe[p].size; b += PROBE_SIZE_PER_CHUNK, ++s) {
+        pctx.slices[s].partition = (uint32_t)p;
+        pctx.slices[s].begin = b;
+        pctx.slices[s].end = b + PROBE_SIZE_PER_CHUNK < radix_probe[p].size ? b + PROBE_SIZE_PER_CHUNK : radix_probe[p].size;
+      }
+    parallel_for(n_slices, probe_job, &pctx, threads);
+    uint64_t total = 0;
+    for (s = 0; s < n_slices; ++s) total += pctx.out[s].size;
+    if (n_slices > result->slice_capacity || total > result->capacity) status = HY_ERR_CAPACITY;
+    else {
+      uint64_t cursor = 0;
+      for (s = 0; s < n_slices; ++s) {
+        result->slice_offsets[s] = cursor;
+        if (pctx.out[s].size) {
+          hy_row_id* build_out = result->left_is_build ? result->left_pos : result->right_pos;
+          hy_row_id* probe_out = result->left_is_build ? result->right_pos : result->left_pos;
+          memcpy(probe_out + cursor, pctx.out[s].probe, sizeof(hy_row_id) * pctx.out[s].size);
+          if (!semi_anti && build_out) memcpy(build_out + cursor, pctx.out[s].build, sizeof(hy_row_id) * pctx.out[s].size);
+        }
+        cursor += pctx.out[s].size;
+      }
+      result->slice_offsets[n_slices] = cursor;
+      result->n_slices = (uint32_t)n_slices;
+      result->n_pairs = total;
+    }
+    for (s = 0; s < n_slices; ++s) { free(pctx.out[s].build); free(pctx.out[s].probe); }
+    free(pctx.out); free(pctx.slices);
+  } else {
+    result->slice_offsets[0] = 0;
+  }
+  for (uint32_t t = 0; t < n_tables; ++t) table_free(&tables[t]);
+  free(tables);
+  free_partitions(radix_build, n_build_parts ? n_build_parts : 1);
+  free_partitions(radix_probe, n_probe_parts ? n_probe_parts : 1);
+  free(build_bloom); free(probe_bloom);
+  return status;
+}

@@ -233,3 +233,138 @@ def result_rows(result):
         else:
             rows.extend(map(tuple, result.pos_list(c).tolist()))
     return rows
+
+
+# ---- JoinHash -------------------------------------------------------------------------------------------------------
+class HostJoinResult:
+    def __init__(self, capacity, slice_capacity, radix_bits=None, mem=abi.MEM_HOST):
+        self.left = np.zeros((max(1, capacity), 2), dtype=np.uint32)
+        self.right = np.zeros((max(1, capacity), 2), dtype=np.uint32)
+        self.slice_offsets = np.zeros(slice_capacity + 2, dtype=np.uint64)
+        r = abi.JoinResult()
+        r.mem = mem
+        r.radix_bits = 0xFFFFFFFF if radix_bits is None else radix_bits
+        r.left_pos, r.right_pos = self.left.ctypes.data, self.right.ctypes.data
+        r.capacity = capacity
+        r.slice_offsets = self.slice_offsets.ctypes.data
+        r.slice_capacity = slice_capacity
+        self.c = r
+
+    @property
+    def n_pairs(self):
+        return int(self.c.n_pairs)
+
+    def pairs(self):
+        n = self.n_pairs
+        return self.left[:n], self.right[:n]
+
+
+def _bind_join(lib):
+    lib.hyo_join_hash.restype = C.c_int32
+    lib.hyo_join_hash.argtypes = [C.POINTER(OracleColumn), C.POINTER(OracleColumn), C.c_uint32, C.POINTER(abi.JoinResult), C.c_int]
+    lib.hyo_calculate_radix_bits.restype = C.c_uint32
+    lib.hyo_calculate_radix_bits.argtypes = [C.c_uint64, C.c_uint64]
+    lib.hyo_join_materialize.restype = C.c_uint64
+    lib.hyo_join_materialize.argtypes = [C.POINTER(OracleColumn), C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def oracle_join(left, right, mode, radix_bits=None, threads=1, capacity=None):
+    lib = oracle()
+    _bind_join(lib)
+    lcol, rcol = OracleCol(left), OracleCol(right)
+    if capacity is None:
+        capacity = max(left.rows, right.rows, 1) * 4 + 1024
+    slice_capacity = (max(left.rows, right.rows) // 131070) + 600
+    while True:
+        result = HostJoinResult(capacity, slice_capacity, radix_bits)
+        status = lib.hyo_join_hash(C.byref(lcol.c), C.byref(rcol.c), mode, C.byref(result.c), threads)
+        if status == abi.ERR_CAPACITY:
+            capacity *= 8
+            continue
+        assert status == 0, f"oracle join failed with {status}"
+        return result
+
+
+def column_values(host_column):
+    """(values list with None for NULL) of a HostColumn, row order, decoding data or reference segments."""
+    out = []
+    for c, seg in enumerate(host_column.segments):
+        if seg.encoding == abi.ENC_REFERENCE:
+            if seg.data is None:
+                rows = [(seg.ref_chunk_id, i) for i in range(seg.size)]
+            else:
+                rows = [tuple(r) for r in seg.data.tolist()]
+            for r in rows:
+                out.append(None if r[1] == 0xFFFFFFFF else decode_rows(seg.ref, [r])[0])
+        else:
+            out.extend(decode_rows(host_column, [(c, i) for i in range(seg.size)]))
+    return out
+
+
+def row_ids_of(host_column):
+    rows = []
+    for c, seg in enumerate(host_column.segments):
+        rows.extend((c, i) for i in range(seg.size))
+    return rows
+
+
+def verification_join(left, right, mode):
+    """Nested-loop reference of the join semantics (JoinVerification, operators/join_verification.cpp:60-184), as a
+    sorted multiset of ((left chunk, left offset) | None, (right chunk, right offset) | None)."""
+    lv, rv = column_values(left), column_values(right)
+    lrows, rrows = row_ids_of(left), row_ids_of(right)
+    out = []
+    if mode == abi.JOIN_INNER:
+        index = {}
+        for j, v in enumerate(rv):
+            if v is not None:
+                index.setdefault(v, []).append(j)
+        for i, v in enumerate(lv):
+            for j in index.get(v, []) if v is not None else []:
+                out.append((lrows[i], rrows[j]))
+    elif mode in (abi.JOIN_LEFT, abi.JOIN_RIGHT):
+        outer_v, outer_rows, inner_v, inner_rows = (lv, lrows, rv, rrows) if mode == abi.JOIN_LEFT else (rv, rrows, lv, lrows)
+        index = {}
+        for j, v in enumerate(inner_v):
+            if v is not None:
+                index.setdefault(v, []).append(j)
+        for i, v in enumerate(outer_v):
+            matches = index.get(v, []) if v is not None else []
+            for j in matches:
+                out.append((outer_rows[i], inner_rows[j]) if mode == abi.JOIN_LEFT else (inner_rows[j], outer_rows[i]))
+            if not matches:
+                out.append((outer_rows[i], None) if mode == abi.JOIN_LEFT else (None, outer_rows[i]))
+    else:
+        rset = set(v for v in rv if v is not None)
+        right_has_null = any(v is None for v in rv)
+        for i, v in enumerate(lv):
+            if mode == abi.JOIN_SEMI:
+                keep = v is not None and v in rset
+            elif mode == abi.JOIN_ANTI_NULL_AS_FALSE:
+                keep = v is None or v not in rset
+            else:  # AntiNullAsTrue: NULL comparisons count as matches
+                if len(rv) == 0:
+                    keep = True
+                elif v is None or right_has_null:
+                    keep = False
+                else:
+                    keep = v not in rset
+            if keep:
+                out.append((lrows[i], None))
+    return sorted(out, key=lambda p: (p[0] is None, p[0] or (0, 0), p[1] is None, p[1] or (0, 0)))
+
+
+def join_result_multiset(result, mode):
+    n = result.n_pairs
+    semi = mode in (abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_ANTI_NULL_AS_FALSE)
+    out = []
+    for k in range(n):
+        l = tuple(int(x) for x in result.left[k])
+        left_id = None if l[1] == 0xFFFFFFFF else l
+        if semi:
+            out.append((left_id, None))
+        else:
+            r = tuple(int(x) for x in result.right[k])
+            out.append((left_id, None if r[1] == 0xFFFFFFFF else r))
+    return sorted(out, key=lambda p: (p[0] is None, p[0] or (0, 0), p[1] is None, p[1] or (0, 0)))

@@ -1,0 +1,138 @@
+"""Pins the CPU oracle's JoinHash: the reference's step-level known answers (join_hash_steps_test.cpp,
+join_hash_test.cpp), differential testing against a nested-loop JoinVerification on the reference's own
+join_test_runner inputs (join_test_runner.cpp:656-791), and the ordering contract of probe()."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hyrise_amd import abi, storage
+from support import (OracleCol, _bind_join, build_column, column_values, join_result_multiset, load_tbl, oracle,
+                     oracle_join, verification_join)
+
+MODES = [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE,
+         abi.JOIN_ANTI_NULL_AS_FALSE]
+MODE_IDS = ["Inner", "Left", "Right", "Semi", "AntiNullAsTrue", "AntiNullAsFalse"]
+
+
+def test_radix_bit_calculation():
+    """join_hash_test.cpp:122-129 + the SF10 value derived in SURVEY.md 8(a) A10."""
+    lib = oracle()
+    _bind_join(lib)
+    assert lib.hyo_calculate_radix_bits(1, 0) == 0
+    assert lib.hyo_calculate_radix_bits(0, 1) == 0
+    assert lib.hyo_calculate_radix_bits(0, 0) == 0
+    assert lib.hyo_calculate_radix_bits(1, 1) == 0
+    assert lib.hyo_calculate_radix_bits(2**64 - 1, 2**64 - 1) > 0
+    assert lib.hyo_calculate_radix_bits(15_000_000, 59_986_052) == 7
+
+
+def materialize(column, keep_nulls, radix_bits, bloom_in=None):
+    lib = oracle()
+    _bind_join(lib)
+    col = OracleCol(column)
+    n = column.rows
+    rows = np.zeros((max(1, n), 2), dtype=np.uint32)
+    values = np.zeros(max(1, n), dtype=np.int64)
+    nulls = np.zeros(max(1, n), dtype=np.uint8)
+    counts = np.zeros(max(1, column.n_chunks), dtype=np.uint64)
+    hist = np.zeros(max(1, column.n_chunks) << radix_bits, dtype=np.uint64)
+    bloom_out = np.zeros(16384, dtype=np.uint64)
+    total = lib.hyo_join_materialize(C.byref(col.c), int(keep_nulls), radix_bits,
+                                     bloom_in.ctypes.data if bloom_in is not None else None, bloom_out.ctypes.data,
+                                     rows.ctypes.data, values.ctypes.data, nulls.ctypes.data, counts.ctypes.data,
+                                     hist.ctypes.data)
+    return rows[:total], values[:total], nulls[:total], counts, hist.reshape(max(1, column.n_chunks), -1), bloom_out
+
+
+def bloom_bits(words):
+    return set(np.nonzero(np.unpackbits(words.view(np.uint8), bitorder="little"))[0].tolist())
+
+
+def test_materialize_bloom_filters():
+    """join_hash_steps_test.cpp:169-220 on int_int4_with_null.tbl (chunk size 10)."""
+    values = np.array([18, 7, 7, 9, 6, 0, 13, 0, 9, 7, 0], dtype=np.int32)      # column a, NULLs at rows 5 and 7
+    nulls = np.zeros(11, dtype=bool)
+    nulls[[5, 7]] = True
+    column = build_column(values, nulls, 10, abi.ENC_UNENCODED)
+    _, _, _, _, _, bloom = materialize(column, False, 1)
+    assert bloom_bits(bloom) == {0, 6, 7, 9, 13, 18}                             # :169-188
+    bloom_in = np.zeros(16384, dtype=np.uint64)
+    for v in (6, 7, 9):
+        bloom_in[v // 64] |= np.uint64(1) << np.uint64(v % 64)
+    rows, vals, _, _, _, _ = materialize(column, False, 1, bloom_in)
+    assert vals.tolist() == [7, 7, 9, 6, 9, 7]                                   # :190-220
+    assert rows[:, 1].tolist() == [1, 2, 3, 4, 8, 9]
+
+
+def test_materialize_histograms():
+    """join_hash_steps_test.cpp:222-263: 1000 rows of i % 2 in chunks of 10."""
+    column = build_column((np.arange(1000) % 2).astype(np.int32), None, 10, abi.ENC_UNENCODED)
+    _, _, _, _, hist, _ = materialize(column, False, 1)
+    assert hist.shape == (100, 2) and np.all(hist == 5)
+    _, _, _, _, hist2, _ = materialize(column, False, 2)
+    assert np.all((hist2 == 5) | (hist2 == 0)) and int((hist2 == 0).sum()) == 200
+
+
+def runner_tables(size, chunk):
+    left = load_tbl(f"join_test_runner/input_table_left_{size}.tbl")
+    right = load_tbl(f"join_test_runner/input_table_right_{size}.tbl")
+    return left, right
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_join_against_verification_on_runner_tables(mode):
+    """join_test_runner.cpp: every join mode x table sizes {0,10,15} x chunk sizes {10,3,1} x nullable int columns,
+    several radix settings; results compared as multisets like the reference does (:786-791)."""
+    for lsize in (0, 10, 15):
+        for rsize in (0, 10, 15):
+            lt, rt = runner_tables(lsize, 0)[0], runner_tables(rsize, 0)[1]
+            for column_name in ("int", "int_null", "long", "long_null"):
+                lvals, lnull = lt.column("l_" + column_name)
+                rvals, rnull = rt.column("r_" + column_name)
+                for chunk in (10, 3, 1):
+                    for encoding in (abi.ENC_UNENCODED, abi.ENC_DICTIONARY):
+                        left = build_column(lvals, lnull, chunk, encoding)
+                        right = build_column(rvals, rnull, chunk, encoding)
+                        for radix_bits in (None, 0, 1, 2, 5):
+                            got = oracle_join(left, right, mode, radix_bits)
+                            assert join_result_multiset(got, mode) == verification_join(left, right, mode), \
+                                f"{column_name} sizes {lsize},{rsize} chunk {chunk} enc {encoding} radix {radix_bits}"
+
+
+def test_join_order_contract():
+    """What no reference test pins but the reference code defines (join_hash_steps.hpp:541-591,655-760): pairs come
+    partition by partition (low radix bits of the key), inside a partition by probe row, inside a probe row by build
+    row (insertion order)."""
+    rng = np.random.default_rng(5)
+    build_values = rng.integers(0, 50, 400).astype(np.int32)
+    probe_values = rng.integers(0, 60, 3000).astype(np.int32)
+    left = build_column(build_values, None, 64, abi.ENC_UNENCODED)      # smaller -> build side
+    right = build_column(probe_values, None, 500, abi.ENC_UNENCODED)
+    for radix_bits in (0, 3):
+        got = oracle_join(left, right, abi.JOIN_INNER, radix_bits)
+        assert got.c.left_is_build == 1
+        build_ids, probe_ids = got.pairs()
+        keys = [(int(probe_values[c * 500 + o]) & ((1 << radix_bits) - 1), int(c), int(o), int(bc), int(bo))
+                for (bc, bo), (c, o) in zip(build_ids.tolist(), probe_ids.tolist())]
+        assert keys == sorted(keys)
+        assert got.n_pairs == sum(int((build_values == v).sum()) for v in probe_values)
+
+
+def test_probe_slices_of_131070_elements():
+    """probe() cuts every partition into slices of PROBE_SIZE_PER_CHUNK = 2 * 65535 materialised probe elements
+    (join_hash_steps.hpp:47,655-660)."""
+    n = 300_000
+    probe_values = (np.arange(n) % 1000).astype(np.int32)
+    build_values = np.arange(0, 1000, 2, dtype=np.int32)
+    got = oracle_join(build_column(build_values, None, 1000, abi.ENC_UNENCODED),
+                      build_column(probe_values, None, 65535, abi.ENC_UNENCODED), abi.JOIN_INNER, 0)
+    # radix_bits 0: partitions == probe chunks (65535 rows each => one slice per chunk)
+    assert got.c.n_slices == 5
+    got1 = oracle_join(build_column(build_values, None, 1000, abi.ENC_UNENCODED),
+                       build_column(probe_values, None, 65535, abi.ENC_UNENCODED), abi.JOIN_INNER, 1)
+    # the probe side is filtered by the build side's Bloom filter (only even values survive): all 150 000 elements fall
+    # into partition 0 => 2 slices
+    assert got1.c.n_slices == 2
+    offsets = got1.slice_offsets[:3].tolist()
+    assert offsets == [0, 131070, 150000]
