@@ -82,3 +82,40 @@ def table_scan_columns(left, right, condition, capacity=None):
     result = HostScanResult(left.n_chunks, left.rows if capacity is None else capacity)
     abi.check(lib.hy_table_scan_columns(left.handle, right.handle, condition, C.byref(result.c)))
     return result
+
+
+class HostJoinResult:
+    """Join result in host memory (numpy views): pairs[k] = (left RowID, right RowID), slice boundaries."""
+
+    def __init__(self, capacity, slice_capacity, radix_bits=None):
+        self.left = np.zeros((max(1, capacity), 2), dtype=np.uint32)
+        self.right = np.zeros((max(1, capacity), 2), dtype=np.uint32)
+        self.slice_offsets = np.zeros(slice_capacity + 2, dtype=np.uint64)
+        r = abi.JoinResult()
+        r.mem = abi.MEM_HOST
+        r.radix_bits = 0xFFFFFFFF if radix_bits is None else radix_bits
+        r.left_pos, r.right_pos = self.left.ctypes.data, self.right.ctypes.data
+        r.capacity = capacity
+        r.slice_offsets = self.slice_offsets.ctypes.data
+        r.slice_capacity = slice_capacity
+        self.c = r
+
+    @property
+    def n_pairs(self):
+        return int(self.c.n_pairs)
+
+
+def join_hash_count(left, right, mode):
+    lib = abi.load_library()
+    n = C.c_uint64(0)
+    abi.check(lib.hy_join_hash_count(left.handle, right.handle, mode, C.byref(n)))
+    return int(n.value)
+
+
+def join_hash(left, right, mode, radix_bits=None):
+    """hy_join_hash with a host-memory result sized by hy_join_hash_count."""
+    lib = abi.load_library()
+    n_pairs = join_hash_count(left, right, mode)
+    result = HostJoinResult(n_pairs, max(left.rows, right.rows) // 131070 + max(left.n_chunks, right.n_chunks) + 600, radix_bits)
+    abi.check(lib.hy_join_hash(left.handle, right.handle, mode, C.byref(result.c)))
+    return result
