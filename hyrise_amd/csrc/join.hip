@@ -33,7 +33,8 @@ namespace hy {
 constexpr uint32_t JOIN_TILE = 2048;                 // rows per workgroup tile (8 per lane)
 constexpr uint32_t PROBE_SIZE_PER_CHUNK = 65535u * 2u;  // join_hash_steps.hpp:47
 constexpr uint32_t BLOOM_BITS = 1u << 20;            // join_hash_steps.hpp:252
-constexpr uint32_t BLOOM_WORDS = BLOOM_BITS / 32;
+// The device keeps the filter as one BYTE per bit: setting a bit is a plain store (no atomics, races are benign), and
+// the 1 MiB array stays L2-resident for the probe.
 constexpr uint32_t INVALID_PARTITION = 0x1FF;
 
 // ---- decoding ---------------------------------------------------------------------------------------------------------
@@ -72,9 +73,8 @@ __device__ __forceinline__ bool column_key(const DevSegment* segments, uint32_t 
   return data_key(s.ref[r.chunk_id], r.chunk_offset, key);
 }
 
-__device__ __forceinline__ bool bloom_test(const uint32_t* bloom, uint64_t hash) {
-  const uint32_t bit = static_cast<uint32_t>(hash) & (BLOOM_BITS - 1);
-  return (bloom[bit >> 5] >> (bit & 31)) & 1;
+__device__ __forceinline__ bool bloom_test(const uint8_t* bloom, uint64_t hash) {
+  return bloom[static_cast<uint32_t>(hash) & (BLOOM_BITS - 1)] != 0;
 }
 
 // ---- build side: materialise -------------------------------------------------------------------------------------------
@@ -85,8 +85,8 @@ struct MaterializeArgs {
   const Slice* slices;
   uint32_t n_slices;
   uint32_t keep_nulls;
-  const uint32_t* bloom_in;       // nullptr = every bit set
-  uint32_t* bloom_out;            // may be nullptr
+  const uint8_t* bloom_in;        // nullptr = every bit set
+  uint8_t* bloom_out;             // may be nullptr
   uint32_t* slice_counts;         // [n_slices]
   const uint64_t* slice_offsets;  // MODE 1
   uint64_t* keys;                 // MODE 1: sign-extended key bits
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void join_materialize(MaterializeArgs a) {
       a.keys[pos] = static_cast<uint64_t>(key);
       a.row_ids[pos] = hy_row_id{slice.chunk, slice.row_begin + r};
       if (is_null && a.any_null) *a.any_null = 1;
-      if (a.bloom_out) atomicOr(&a.bloom_out[(static_cast<uint32_t>(key) & (BLOOM_BITS - 1)) >> 5], 1u << (static_cast<uint32_t>(key) & 31));
+      if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(key) & (BLOOM_BITS - 1)] = 1;
     }
   }
 }
@@ -160,17 +160,29 @@ __global__ __launch_bounds__(1024) void scan_counts(const uint32_t* counts, uint
   for (uint32_t i = begin; i < end; ++i) { offsets[i] = run; run += counts[i]; }
 }
 
-// keys sorted ascending (unsigned bit order)?  Also OR-reduces all keys (significant bits for the radix sort).
-__global__ void check_sorted(const uint64_t* keys, uint64_t n, uint32_t* unsorted, unsigned long long* key_or) {
+// keys sorted ascending (unsigned bit order)?  Also OR-reduces all keys (significant bytes for the radix sort):
+// one atomic per 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void check_sorted(const uint64_t* keys, uint64_t n, uint32_t* unsorted, unsigned long long* key_or) {
+  __shared__ uint64_t s_bits[16];
+  __shared__ uint32_t s_unsorted;
+  if (threadIdx.x == 0) s_unsorted = 0;
+  __syncthreads();
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   uint64_t bits = 0;
   if (i < n) {
     bits = keys[i];
-    if (i + 1 < n && keys[i] > keys[i + 1]) *unsorted = 1;
+    if (i + 1 < n && bits > keys[i + 1]) s_unsorted = 1;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) bits |= __shfl_xor(bits, d, 64);
-  if ((threadIdx.x & 63) == 0 && bits) atomicOr(key_or, static_cast<unsigned long long>(bits));
+  if ((threadIdx.x & 63) == 0) s_bits[threadIdx.x >> 6] = bits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t all = 0;
+    for (uint32_t w = 0; w < 16; ++w) all |= s_bits[w];
+    if (all) atomicOr(key_or, static_cast<unsigned long long>(all));
+    if (s_unsorted) *unsorted = 1;
+  }
 }
 
 // ---- stable LSD radix sort of (key, RowID) pairs, 8 bits per pass ---------------------------------------------------
@@ -371,7 +383,7 @@ struct ProbeArgs {
   uint32_t radix_bits;
   uint32_t keep_nulls;            // probe side keeps NULLs (Left/Right/Anti*)
   uint32_t build_rows_zero;       // build table has no rows (AntiNullAsTrue special case)
-  const uint32_t* build_bloom;    // filter applied to the probe side, or nullptr
+  const uint8_t* build_bloom;     // filter applied to the probe side, or nullptr
   Directory dir;
   // pass 1 out / pass 2 in
   uint32_t* hist_elements;        // [P][n_tiles]  (P = 1 << radix_bits, or 1)
@@ -553,13 +565,39 @@ static uint32_t calculate_radix_bits(uint64_t build_rows) {   // join_hash.cpp:7
 struct DeviceBuffer;
 static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t stream);
 
+// Temporary device buffers come from a per-thread pool of power-of-two blocks that is reused across calls
+// (hipMalloc/hipFree cost ~100 us each and synchronise the device).
+struct BufferPool {
+  std::vector<std::pair<size_t, void*>> free_blocks;
+  ~BufferPool() { for (auto& b : free_blocks) (void)hipFree(b.second); }
+};
+static thread_local BufferPool t_pool;
+
 struct DeviceBuffer {
   void* ptr = nullptr;
+  size_t capacity = 0;
   hy_status alloc(size_t bytes) {
-    hipError_t err = hipMalloc(&ptr, bytes ? bytes : 256);
-    return err == hipSuccess ? HY_OK : fail(HY_ERR_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    size_t rounded = 4096;
+    while (rounded < bytes) rounded <<= 1;
+    for (size_t i = 0; i < t_pool.free_blocks.size(); ++i) {
+      if (t_pool.free_blocks[i].first == rounded) {
+        ptr = t_pool.free_blocks[i].second;
+        capacity = rounded;
+        t_pool.free_blocks.erase(t_pool.free_blocks.begin() + i);
+        return HY_OK;
+      }
+    }
+    hipError_t err = hipMalloc(&ptr, rounded);
+    if (err != hipSuccess) {   // release the pool and retry once
+      for (auto& b : t_pool.free_blocks) (void)hipFree(b.second);
+      t_pool.free_blocks.clear();
+      err = hipMalloc(&ptr, rounded);
+    }
+    if (err != hipSuccess) { ptr = nullptr; return fail(HY_ERR_DEVICE, "hipMalloc(%zu) failed: %s", rounded, hipGetErrorString(err)); }
+    capacity = rounded;
+    return HY_OK;
   }
-  ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+  ~DeviceBuffer() { if (ptr) t_pool.free_blocks.emplace_back(capacity, ptr); }
   template <typename T> T* as() const { return static_cast<T*>(ptr); }
 };
 
@@ -598,8 +636,8 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   HY_TRY(b.flags.alloc(64));
   HY_HIP(hipMemsetAsync(b.flags.ptr, 0, 64, stream));
   if (want_bloom) {
-    HY_TRY(b.bloom.alloc(BLOOM_WORDS * 4));
-    HY_HIP(hipMemsetAsync(b.bloom.ptr, 0, BLOOM_WORDS * 4, stream));
+    HY_TRY(b.bloom.alloc(BLOOM_BITS));
+    HY_HIP(hipMemsetAsync(b.bloom.ptr, 0, BLOOM_BITS, stream));
   }
   MaterializeArgs m{};
   m.segments = build->d_segments;
@@ -607,7 +645,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   m.n_slices = n_slices;
   m.keep_nulls = keep_nulls;
   m.bloom_in = nullptr;
-  m.bloom_out = want_bloom ? b.bloom.as<uint32_t>() : nullptr;
+  m.bloom_out = want_bloom ? b.bloom.as<uint8_t>() : nullptr;
   m.slice_counts = counts.as<uint32_t>();
   m.any_null = b.flags.as<uint32_t>() + 2;
   uint64_t total = 0;
@@ -627,7 +665,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     hipLaunchKernelGGL(join_materialize<1>, dim3(n_slices), dim3(256), 0, stream, m);
     uint32_t* unsorted = b.flags.as<uint32_t>();
     unsigned long long* key_or = reinterpret_cast<unsigned long long*>(b.flags.as<uint32_t>() + 4);
-    hipLaunchKernelGGL(check_sorted, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, stream, b.keys.as<uint64_t>(), total, unsorted, key_or);
+    hipLaunchKernelGGL(check_sorted, dim3(static_cast<uint32_t>((total + 1023) / 1024)), dim3(1024), 0, stream, b.keys.as<uint64_t>(), total, unsorted, key_or);
     uint32_t host_flags[8];
     HY_HIP(hipMemcpyAsync(host_flags, b.flags.ptr, 32, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
@@ -655,7 +693,9 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       }
       if (src_keys != b.keys.as<uint64_t>()) {
         std::swap(b.keys.ptr, b.keys_tmp.ptr);
+        std::swap(b.keys.capacity, b.keys_tmp.capacity);
         std::swap(b.rows.ptr, b.rows_tmp.ptr);
+        std::swap(b.rows.capacity, b.rows_tmp.capacity);
       }
     }
   }
@@ -741,7 +781,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.radix_bits = radix_bits;
   a.keep_nulls = keep_nulls_probe;
   a.build_rows_zero = build->rows == 0;
-  a.build_bloom = probe_filtered ? b.bloom.as<uint32_t>() : nullptr;
+  a.build_bloom = probe_filtered ? b.bloom.as<uint8_t>() : nullptr;
   a.dir = b.directory;
   a.hist_elements = hist_e.as<uint32_t>();
   a.hist_pairs = hist_p.as<uint32_t>();

@@ -53,3 +53,50 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def extract_aggregate_cases():
+    """Restates the (input table, aggregates, GROUP BY columns, expected .tbl) tuples of every `test_output<TypeParam>`
+    call in src/test/lib/operators/aggregate_test.cpp (with the line it comes from) into aggregate_cases.json."""
+    import re
+    src_path = "/root/reference/src/test/lib/operators/aggregate_test.cpp"
+    text = open(src_path).read()
+    wrappers = {}
+    for m in re.finditer(r"(_table_wrapper_\w+) = std::make_shared<TableWrapper>\(\s*load_table\(\"resources/test_data/tbl/([^\"]+)\", ChunkOffset\{(\d+)\}\)\)", text):
+        wrappers[m.group(1)] = {"input": m.group(2), "chunk_size": int(m.group(3)), "encoded": False}
+    # dictionary-encoded variants are built from a local `test_table`
+    wrappers["_table_wrapper_1_1_dict"] = {"input": "aggregateoperator/groupby_int_1gb_1agg/input.tbl", "chunk_size": 2, "encoded": True}
+    wrappers["_table_wrapper_1_1_null_dict"] = {"input": "aggregateoperator/groupby_int_1gb_1agg/input_null.tbl", "chunk_size": 2, "encoded": True}
+    cases = []
+    for m in re.finditer(r"test_output<TypeParam>\(", text):
+        end = text.index(");", m.end())
+        call = text[m.end():end]
+        # split top-level arguments
+        args, depth, cur = [], 0, ""
+        for ch in call:
+            if ch in "{(":
+                depth += 1
+            elif ch in "})":
+                depth -= 1
+            if ch == "," and depth == 0:
+                args.append(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+        args.append(cur.strip())
+        wrapper = args[0].replace("this->", "")
+        if wrapper not in wrappers or len(args) < 4:
+            continue
+        aggregates = [(int(a), f) for a, f in re.findall(r"\{ColumnID\{(\d+)\}, WindowFunction::(\w+)\}", args[1])]
+        aggregates += [(None, f) for f in re.findall(r"\{INVALID_COLUMN_ID, WindowFunction::(\w+)\}", args[1])]
+        groupby = [int(g) for g in re.findall(r"ColumnID\{(\d+)\}", args[2])]
+        expected = re.search(r"resources/test_data/tbl/([^\"]+)", args[3]).group(1)
+        line = text[:m.start()].count("\n") + 1
+        cases.append({"line": line, **wrappers[wrapper], "aggregates": aggregates, "groupby": groupby, "expected": expected})
+    with open(os.path.join(HERE, "aggregate_cases.json"), "w") as fh:
+        json.dump({"source": "src/test/lib/operators/aggregate_test.cpp", "cases": cases}, fh, indent=1)
+    print(len(cases), "aggregate cases restated")
+
+
+if __name__ == "__main__":
+    extract_aggregate_cases()

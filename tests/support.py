@@ -368,3 +368,58 @@ def join_result_multiset(result, mode):
             r = tuple(int(x) for x in result.right[k])
             out.append((left_id, None if r[1] == 0xFFFFFFFF else r))
     return sorted(out, key=lambda p: (p[0] is None, p[0] or (0, 0), p[1] is None, p[1] or (0, 0)))
+
+
+# ---- AggregateHash --------------------------------------------------------------------------------------------------
+AGG_BY_NAME = {"Min": abi.AGG_MIN, "Max": abi.AGG_MAX, "Sum": abi.AGG_SUM, "Avg": abi.AGG_AVG, "Count": abi.AGG_COUNT,
+               "CountDistinct": abi.AGG_COUNT_DISTINCT, "StandardDeviationSample": abi.AGG_STDDEV_SAMP, "Any": abi.AGG_ANY}
+_RESULT_NP = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}
+
+
+class HostAggregateResult:
+    def __init__(self, n_aggregates, group_capacity, mem=abi.MEM_HOST):
+        self.row_ids = np.zeros((max(1, group_capacity), 2), dtype=np.uint32)
+        self.raw = [np.zeros(max(1, group_capacity), dtype=np.uint64) for _ in range(n_aggregates)]
+        self.nulls = [np.zeros(max(1, group_capacity), dtype=np.uint8) for _ in range(n_aggregates)]
+        self.columns = (abi.AggregateColumn * max(1, n_aggregates))()
+        for a in range(n_aggregates):
+            self.columns[a].values = self.raw[a].ctypes.data
+            self.columns[a].is_null = self.nulls[a].ctypes.data
+        r = abi.AggregateResult()
+        r.mem = mem
+        r.group_capacity = group_capacity
+        r.group_row_ids = self.row_ids.ctypes.data
+        r.columns = self.columns
+        self.c = r
+        self.n_aggregates = n_aggregates
+
+    @property
+    def n_groups(self):
+        return int(self.c.n_groups)
+
+    def column(self, a):
+        """values (python list, None for NULL) of aggregate a."""
+        t = _RESULT_NP[self.columns[a].data_type]
+        n = self.n_groups
+        values = self.raw[a].view(np.uint8)[: 8 * len(self.raw[a])].view(t)[:n] if t in (np.int64, np.float64) else \
+            np.frombuffer(self.raw[a].tobytes(), dtype=t)[:n]
+        return [None if self.nulls[a][i] else values[i].item() for i in range(n)]
+
+
+def oracle_aggregate(groupby_columns, aggregates, group_capacity=None):
+    """aggregates: list of (function, HostColumn or None)."""
+    lib = oracle()
+    lib.hyo_aggregate_hash.restype = C.c_int32
+    lib.hyo_aggregate_hash.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_uint32,
+                                       C.POINTER(abi.AggregateResult)]
+    gcols = [OracleCol(c) for c in groupby_columns]
+    acols = [OracleCol(c) if c is not None else None for _, c in aggregates]
+    garr = (C.c_void_p * max(1, len(gcols)))(*[C.addressof(c.c) for c in gcols])
+    aarr = (C.c_void_p * max(1, len(acols)))(*[C.addressof(c.c) if c is not None else None for c in acols])
+    farr = (C.c_uint32 * max(1, len(aggregates)))(*[f for f, _ in aggregates])
+    rows = (groupby_columns[0] if groupby_columns else next(c for _, c in aggregates if c is not None)).rows
+    result = HostAggregateResult(len(aggregates), (rows + 1) if group_capacity is None else group_capacity)
+    status = lib.hyo_aggregate_hash(garr, len(gcols), farr, aarr, len(aggregates), C.byref(result.c))
+    assert status == 0, f"oracle aggregate failed with {status}"
+    result._keep = (gcols, acols)
+    return result

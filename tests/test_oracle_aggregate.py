@@ -1,0 +1,104 @@
+"""Pins the CPU oracle's AggregateHash on the reference's own input/expected .tbl pairs
+(src/test/lib/operators/aggregate_test.cpp, restated in tests/golden/aggregate_cases.json by make_golden.py), compared
+like EXPECT_TABLE_EQ_UNORDERED with the reference's float tolerance (check_table_equal.cpp:34,109-115), plus the
+group-order contract that only the reference code defines."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from hyrise_amd import abi
+from support import AGG_BY_NAME, GOLDEN, build_column, column_values, load_tbl, oracle_aggregate
+
+CASES = json.load(open(os.path.join(os.path.dirname(GOLDEN), "aggregate_cases.json")))["cases"]
+NUMERIC_CASES = [c for c in CASES if "string" not in c["input"]]
+
+
+def cells_equal(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    if isinstance(a, float) or isinstance(b, float):
+        return abs(a - b) < max(1e-4, abs(b) * 1e-4)
+    return a == b
+
+
+def rows_match_unordered(got_rows, want_rows):
+    remaining = list(want_rows)
+    for row in got_rows:
+        for i, cand in enumerate(remaining):
+            if len(cand) == len(row) and all(cells_equal(x, y) for x, y in zip(row, cand)):
+                remaining.pop(i)
+                break
+        else:
+            return False
+    return not remaining
+
+
+def run_case(case, run):
+    table = load_tbl(case["input"])
+    encoding = abi.ENC_DICTIONARY if case["encoded"] else abi.ENC_UNENCODED
+    columns = [build_column(table.columns[i], table.nulls[i] if table.nullable[i] else None, case["chunk_size"], encoding)
+               for i in range(len(table.names))]
+    groupby = [columns[g] for g in case["groupby"]]
+    aggregates = [(AGG_BY_NAME[f], columns[c] if c is not None else None) for c, f in case["aggregates"]]
+    if not groupby and not any(c is not None for _, c in aggregates):
+        return None
+    result = run(groupby, aggregates)
+    # output table: GROUP BY columns (values of the representative rows), then one column per aggregate
+    rows = []
+    group_values = [column_values(g) for g in groupby]
+    flat_index = {}
+    offset = 0
+    for chunk, seg in enumerate(columns[0].segments):
+        for i in range(seg.size):
+            flat_index[(chunk, i)] = offset + i
+        offset += seg.size
+    for g in range(result.n_groups):
+        rid = tuple(int(x) for x in result.row_ids[g])
+        row = [gv[flat_index[rid]] for gv in group_values]
+        rows.append(row)
+    for a in range(len(aggregates)):
+        for g, v in enumerate(result.column(a)):
+            rows[g].append(v)
+    expected = load_tbl(case["expected"])
+    want = [[None if (expected.nullable[c] and expected.nulls[c][r]) else expected.columns[c][r].item()
+             for c in range(len(expected.names))] for r in range(expected.rows)]
+    assert rows_match_unordered(rows, want), f"aggregate_test.cpp:{case['line']}: got {rows} want {want}"
+    return result
+
+
+@pytest.mark.parametrize("case", NUMERIC_CASES, ids=[f"L{c['line']}" for c in NUMERIC_CASES])
+def test_reference_aggregate_fixture(case):
+    run_case(case, oracle_aggregate)
+
+
+def test_group_order_is_first_occurrence():
+    """aggregate_hash.cpp:388-401: result ids are handed out in first-occurrence order (no key-range shortcut here:
+    the keys are spread over more than 1.2 x rows)."""
+    keys = np.array([9_000_000, -5, 70_000, -5, 9_000_000, 123, 70_000, 0], dtype=np.int32)
+    values = np.arange(8, dtype=np.int32)
+    result = oracle_aggregate([build_column(keys, None, 3, abi.ENC_UNENCODED)], [(abi.AGG_SUM, build_column(values, None, 3, abi.ENC_UNENCODED))])
+    assert [tuple(r) for r in result.row_ids[:result.n_groups].tolist()] == [(0, 0), (0, 1), (0, 2), (1, 2), (2, 1)]
+    assert result.column(0) == [0 + 4, 1 + 3, 2 + 6, 5, 7]
+
+
+def test_immediate_key_shortcut_orders_by_key_with_null_first():
+    """aggregate_hash.cpp:770-804, 364-369: one int32 GROUP BY column with a dense key range => results ordered by key
+    (NULL first) and the representative row is the group's LAST row."""
+    keys = np.array([5, 3, 0, 4, 3, 0, 5, 3], dtype=np.int32)
+    nulls = np.array([0, 0, 1, 0, 0, 0, 0, 0], dtype=bool)
+    result = oracle_aggregate([build_column(keys, nulls, 3, abi.ENC_UNENCODED)], [(abi.AGG_COUNT, None)])
+    assert result.column(0) == [1, 1, 3, 1, 2]            # NULL, 0, 3, 4, 5
+    assert [tuple(r) for r in result.row_ids[:5].tolist()] == [(0, 2), (1, 2), (2, 1), (1, 0), (2, 0)]
+
+
+def test_float_sum_is_sequential_double_addition():
+    rng = np.random.default_rng(1)
+    v = (rng.random(10000) * 1e6).astype(np.float32)
+    result = oracle_aggregate([], [(abi.AGG_SUM, build_column(v, None, 1000, abi.ENC_UNENCODED)), (abi.AGG_AVG, build_column(v, None, 1000, abi.ENC_UNENCODED))])
+    acc = 0.0
+    for x in v.tolist():
+        acc += x
+    assert result.column(0)[0] == acc and result.column(1)[0] == acc / len(v)
