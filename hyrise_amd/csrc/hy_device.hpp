@@ -77,6 +77,7 @@ struct hy_column {
   uint32_t n_slices = 0;
   hy::Part* d_parts = nullptr;
   uint32_t n_parts = 0;
+  uint64_t* d_row_base = nullptr;           // [n_chunks + 1] device copy of row_base
   std::vector<void*> owned;                 // device allocations freed with the column
 };
 

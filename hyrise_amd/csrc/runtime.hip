@@ -387,6 +387,8 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   if (err == hipSuccess) err = hipMemcpy(column->d_segments, dev.data(), sizeof(DevSegment) * dev.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_slices), sizeof(Slice) * (slices.size() + 1));
   if (err == hipSuccess && !slices.empty()) err = hipMemcpy(column->d_slices, slices.data(), sizeof(Slice) * slices.size(), hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_row_base), 8 * (size_t{n_chunks} + 1));
+  if (err == hipSuccess) err = hipMemcpy(column->d_row_base, column->row_base.data(), 8 * (size_t{n_chunks} + 1), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_parts), sizeof(Part) * (parts.size() + 1));
   if (err == hipSuccess && !parts.empty()) err = hipMemcpy(column->d_parts, parts.data(), sizeof(Part) * parts.size(), hipMemcpyHostToDevice);
   if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "descriptor upload failed: %s", hipGetErrorString(err)));
@@ -400,6 +402,7 @@ hy_status hy_column_destroy(hy_column* column) {
   if (column->d_segments) (void)hipFree(column->d_segments);
   if (column->d_slices) (void)hipFree(column->d_slices);
   if (column->d_parts) (void)hipFree(column->d_parts);
+  if (column->d_row_base) (void)hipFree(column->d_row_base);
   delete column;
   return HY_OK;
 }

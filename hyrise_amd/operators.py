@@ -119,3 +119,47 @@ def join_hash(left, right, mode, radix_bits=None):
     result = HostJoinResult(n_pairs, max(left.rows, right.rows) // 131070 + max(left.n_chunks, right.n_chunks) + 600, radix_bits)
     abi.check(lib.hy_join_hash(left.handle, right.handle, mode, C.byref(result.c)))
     return result
+
+
+class HostAggregateResult:
+    """Aggregate result in host memory.  values of aggregate a: .column(a) (None = NULL)."""
+    _NP = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}
+
+    def __init__(self, n_aggregates, group_capacity):
+        self.row_ids = np.zeros((max(1, group_capacity), 2), dtype=np.uint32)
+        self.raw = [np.zeros(max(1, group_capacity), dtype=np.uint64) for _ in range(n_aggregates)]
+        self.nulls = [np.zeros(max(1, group_capacity), dtype=np.uint8) for _ in range(n_aggregates)]
+        self.columns = (abi.AggregateColumn * max(1, n_aggregates))()
+        for a in range(n_aggregates):
+            self.columns[a].values = self.raw[a].ctypes.data
+            self.columns[a].is_null = self.nulls[a].ctypes.data
+        r = abi.AggregateResult()
+        r.mem = abi.MEM_HOST
+        r.group_capacity = group_capacity
+        r.group_row_ids = self.row_ids.ctypes.data
+        r.columns = self.columns
+        self.c = r
+
+    @property
+    def n_groups(self):
+        return int(self.c.n_groups)
+
+    def column(self, a):
+        t = self._NP[self.columns[a].data_type]
+        n = self.n_groups
+        values = np.frombuffer(self.raw[a].tobytes(), dtype=t)[:n]
+        return [None if self.nulls[a][i] else values[i].item() for i in range(n)]
+
+
+def aggregate_hash(groupby_columns, aggregates, group_capacity=None):
+    """aggregates: list of (HY_AGG_*, DeviceColumn or None for COUNT(*))."""
+    lib = abi.load_library()
+    garr = (C.c_void_p * max(1, len(groupby_columns)))(*[c.handle for c in groupby_columns])
+    specs = (abi.AggregateSpec * max(1, len(aggregates)))()
+    for i, (function, column) in enumerate(aggregates):
+        specs[i].function = function
+        specs[i].column = column.handle if column is not None else None
+    shape = groupby_columns[0] if groupby_columns else next(c for _, c in aggregates if c is not None)
+    result = HostAggregateResult(len(aggregates), (shape.rows + 1) if group_capacity is None else group_capacity)
+    abi.check(lib.hy_aggregate_hash(garr, len(groupby_columns), specs, len(aggregates), C.byref(result.c)))
+    return result

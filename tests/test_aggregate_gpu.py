@@ -1,0 +1,116 @@
+"""Parity of the HIP AggregateHash with the CPU oracle: same groups in the same order, same representative rows,
+integer results identical; SUM/AVG over float/double within 1e-9 relative (parallel f64 atomics vs. the reference's
+sequential double additions -- its own tests only ask for 1e-4, check_table_equal.cpp:34,109-115)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from hyrise_amd import abi, storage, tpch
+from hyrise_amd.operators import aggregate_hash
+from hyrise_amd.storage import DeviceColumn
+from support import AGG_BY_NAME, GOLDEN, build_column, load_tbl, oracle_aggregate
+
+pytestmark = pytest.mark.gpu
+FLOAT_TOLERANCE = 1e-9
+CASES = [c for c in json.load(open(os.path.join(os.path.dirname(GOLDEN), "aggregate_cases.json")))["cases"] if "string" not in c["input"]]
+UNSUPPORTED = {"CountDistinct", "StandardDeviationSample"}
+
+
+def assert_aggregate_equal(got, want, n_aggregates, context=""):
+    assert got.n_groups == want.n_groups, f"group count {context}"
+    n = want.n_groups
+    np.testing.assert_array_equal(got.row_ids[:n], want.row_ids[:n], err_msg=f"group order / representative rows {context}")
+    for a in range(n_aggregates):
+        g, w = got.column(a), want.column(a)
+        for x, y in zip(g, w):
+            if x is None or y is None:
+                assert x is None and y is None, f"NULL mismatch aggregate {a} {context}"
+            elif isinstance(y, float):
+                assert abs(x - y) <= FLOAT_TOLERANCE * max(1.0, abs(y)), f"aggregate {a}: {x} vs {y} {context}"
+            else:
+                assert x == y, f"aggregate {a}: {x} vs {y} {context}"
+
+
+def run_both(groupby_hosts, aggregate_hosts, context=""):
+    cache = {}
+
+    def dev(col):
+        if id(col) not in cache:
+            cache[id(col)] = DeviceColumn(col)
+        return cache[id(col)]
+
+    got = aggregate_hash([dev(c) for c in groupby_hosts], [(f, dev(c) if c is not None else None) for f, c in aggregate_hosts])
+    want = oracle_aggregate(groupby_hosts, aggregate_hosts)
+    assert_aggregate_equal(got, want, len(aggregate_hosts), context)
+    return got
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"L{c['line']}" for c in CASES])
+def test_reference_aggregate_fixture_on_device(device, case):
+    table = load_tbl(case["input"])
+    encoding = abi.ENC_DICTIONARY if case["encoded"] else abi.ENC_UNENCODED
+    columns = [build_column(table.columns[i], table.nulls[i] if table.nullable[i] else None, case["chunk_size"], encoding)
+               for i in range(len(table.names))]
+    groupby = [columns[g] for g in case["groupby"]]
+    aggregates = [(AGG_BY_NAME[f], columns[c] if c is not None else None) for c, f in case["aggregates"]]
+    if any(f in UNSUPPORTED for _, f in case["aggregates"]):
+        devs = [DeviceColumn(c) for c in columns]
+        with pytest.raises(abi.HyriseAmdError) as err:
+            aggregate_hash([devs[g] for g in case["groupby"]], [(AGG_BY_NAME[f], devs[c] if c is not None else None) for c, f in case["aggregates"]])
+        assert err.value.status == abi.ERR_UNSUPPORTED
+        return
+    run_both(groupby, aggregates, f"aggregate_test.cpp:{case['line']}")
+
+
+def test_group_order_and_immediate_key(device):
+    keys = np.array([9_000_000, -5, 70_000, -5, 9_000_000, 123, 70_000, 0], dtype=np.int32)
+    values = np.arange(8, dtype=np.int32)
+    run_both([build_column(keys, None, 3, abi.ENC_UNENCODED)], [(abi.AGG_SUM, build_column(values, None, 3, abi.ENC_UNENCODED))])
+    dense = np.array([5, 3, 0, 4, 3, 0, 5, 3], dtype=np.int32)
+    nulls = np.array([0, 0, 1, 0, 0, 0, 0, 0], dtype=bool)
+    got = run_both([build_column(dense, nulls, 3, abi.ENC_UNENCODED)], [(abi.AGG_COUNT, None)])
+    assert got.column(0) == [1, 1, 3, 1, 2]
+
+
+@pytest.mark.parametrize("n_groups", [3, 700, 40_000])
+def test_random_groups(device, n_groups):
+    """Few groups (all in the LDS tables), more groups than LDS slots, and many groups (global table, retry path)."""
+    rng = np.random.default_rng(n_groups)
+    n, chunk = 300_000, 65535
+    k1 = rng.integers(0, n_groups, n).astype(np.int32) * 7919           # sparse keys: no immediate-key shortcut
+    k2 = rng.integers(0, 3, n).astype(np.int64)
+    k1_null = rng.random(n) < 0.01
+    ints = rng.integers(-1000, 1000, n).astype(np.int32)
+    longs = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    floats = (rng.random(n) * 1000).astype(np.float32)
+    doubles = rng.random(n) * 1e6
+    vnull = rng.random(n) < 0.05
+    g1 = build_column(k1, k1_null, chunk, abi.ENC_DICTIONARY)
+    g2 = build_column(k2, None, chunk, abi.ENC_UNENCODED)
+    ci = build_column(ints, vnull, chunk, abi.ENC_FRAME_OF_REFERENCE)
+    cl = build_column(longs, None, chunk, abi.ENC_UNENCODED)
+    cf = build_column(floats, vnull, chunk, abi.ENC_DICTIONARY)
+    cd = build_column(doubles, None, chunk, abi.ENC_UNENCODED)
+    aggregates = [(abi.AGG_SUM, ci), (abi.AGG_MIN, ci), (abi.AGG_MAX, cl), (abi.AGG_SUM, cf), (abi.AGG_AVG, cd), (abi.AGG_COUNT, ci),
+                  (abi.AGG_COUNT, None), (abi.AGG_MIN, cf)]
+    run_both([g1], aggregates, f"{n_groups} groups, 1 key")
+    run_both([g1, g2], aggregates[:5] + [(abi.AGG_ANY, g2)], f"{n_groups} groups, 2 keys")
+    run_both([], aggregates, "no GROUP BY")
+    run_both([g2, g1], [], "DISTINCT")
+
+
+def test_tpch_q1_core(device):
+    """Q1 core (config 4 of BASELINE.json, SF 0.05): GROUP BY l_returnflag, l_linestatus (1-character strings, passed as
+    their AggregateKey names) with SUM / AVG / COUNT over dictionary-encoded float columns."""
+    data = tpch.TpchData(scale_factor=0.05, seed=3)
+    flag = storage.make_column(data.l_returnflag, None, abi.ENC_DICTIONARY)
+    status = storage.make_column(data.l_linestatus, None, abi.ENC_DICTIONARY)
+    qty = storage.make_column(data.l_quantity, None, abi.ENC_DICTIONARY)
+    price = storage.make_column(data.l_extendedprice, None, abi.ENC_DICTIONARY)
+    disc = storage.make_column(data.l_discount, None, abi.ENC_DICTIONARY)
+    got = run_both([flag, status], [(abi.AGG_SUM, qty), (abi.AGG_SUM, price), (abi.AGG_AVG, qty), (abi.AGG_AVG, price), (abi.AGG_AVG, disc),
+                                    (abi.AGG_COUNT, None)], "Q1 core")
+    assert got.n_groups == 4
+    assert sum(got.column(5)) == data.n_lineitems
