@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=0, help="override row count (debug); 0 = SF10 lineitem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cases", action="store_true", help="also time the Q1/Q6/point predicates (extra JSON field)")
+    ap.add_argument("--no-join", action="store_true", help="skip the JoinHash orders x lineitem leg (extra JSON field)")
     return ap.parse_args()
 
 
@@ -57,6 +58,56 @@ def cpu_baseline(host_column, predicate, rows, budget_s=12.0):
     return {"value": rows / median, "unit": "rows/s", "cores": cores, "kind": "port",
             "sample": f"full {rows}-row l_shipdate column, same predicate, median of {len(times)} runs "
                       f"({median * 1e3:.1f} ms each), CPU restatement of Hyrise's TableScan (not Hyrise itself)"}
+
+
+def committed_traffic():
+    """HBM bytes per scan_slices launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as
+    the gfx950 guide prescribes, + WRITE_SIZE; collected by tools/profile_scan.sh on the same command).  None when no
+    profile of this round is committed."""
+    path = os.path.join(ROOT, "profiles", "scan_pmc.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as fh:
+            return json.load(fh).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def join_leg(lib, torch, dev, steps):
+    """Config 3 of BASELINE.json: JoinHash(orders, lineitem) on the order key, SF10 -- o_orderkey unencoded int32 (build),
+    l_orderkey FrameOfReference + u16 offsets (probe); PosList pairs written to HBM.  Reported beside the scan."""
+    from hyrise_amd import abi, storage, tpch
+    from hyrise_amd.storage import DeviceColumn
+    data = tpch.TpchData(scale_factor=10.0, seed=42)
+    orders = DeviceColumn(storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED))
+    lineitem = DeviceColumn(storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE))
+    n = data.n_lineitems
+    left = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    right = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    slice_offsets = torch.zeros(4096, dtype=torch.int64, device=dev)
+    r = abi.JoinResult()
+    r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
+    r.left_pos, r.right_pos, r.capacity = left.data_ptr(), right.data_ptr(), n
+    r.slice_offsets, r.slice_capacity = slice_offsets.data_ptr(), 4000
+    steps = max(3, min(steps, 10))
+    for _ in range(2):
+        abi.check(lib.hy_join_hash(orders.handle, lineitem.handle, abi.JOIN_INNER, C.byref(r)))
+    abi.check(lib.hy_set_profiling(1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        abi.check(lib.hy_join_hash(orders.handle, lineitem.handle, abi.JOIN_INNER, C.byref(r)))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    km, ln = C.c_float(0), C.c_uint32(0)
+    abi.check(lib.hy_profile_read(C.byref(km), C.byref(ln)))
+    abi.check(lib.hy_set_profiling(0))
+    algorithmic = data.n_orders * 4 + n * 2 + int(r.n_pairs) * 16      # SURVEY.md 8(d): build keys + probe keys + 16 B/pair
+    return {"workload": "configs[2]: JoinHash orders x lineitem on the order key, SF10, Inner", "rows_per_s": (data.n_orders + n) / dt,
+            "ms_per_join": dt * 1e3, "pairs": int(r.n_pairs), "radix_bits": int(r.radix_bits), "output_pos_lists": int(r.n_slices),
+            "algorithmic_bytes": algorithmic, "achieved_GBps_whole_join": algorithmic / dt / 1e9,
+            "probe_scatter_kernel_ms": km.value / max(1, ln.value)}
 
 
 def main():
@@ -166,6 +217,10 @@ def main():
                                  "kernel_ms": km.value / max(1, ln.value),
                                  "kernel_GBps": bytes_case / (km.value / max(1, ln.value) * 1e-3) / 1e9}
 
+    join_info = None
+    if rank == 0 and not args.no_join and not args.rows:
+        join_info = join_leg(lib, torch, dev, args.steps)
+
     if rank == 0:
         line = {
             "metric": "rows/sec TableScan (ColumnVsValue, l_shipdate < 1995-01-01) on TPC-H SF10 lineitem",
@@ -183,6 +238,9 @@ def main():
         }
         if extra_cases:
             line["cases"] = extra_cases
+        if join_info:
+            line["join"] = join_info
+        line["roofline"]["traffic"] = committed_traffic()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_column, predicate, rows)
         print(json.dumps(line))
