@@ -1,0 +1,913 @@
+// hyrise_host.hpp -- C++ mirror of the slice of Hyrise's operator/storage interface that the hot path touches, written
+// against the C ABI (include/hyrise_amd.h).  Hyrise itself cannot be built in this environment;
+// this header lets the three operators be driven -- and tested -- exactly the way the reference's own tests drive them:
+//
+//     auto table   = load_table("int_float.tbl", ChunkOffset{2});            src/lib/utils/load_table.cpp:57-96
+//     ChunkEncoder::encode_all_chunks(table, EncodingType::Dictionary);      src/lib/storage/chunk_encoder.hpp
+//     auto wrapper = std::make_shared<TableWrapper>(table); wrapper->execute();
+//     auto scan    = std::make_shared<TableScan>(wrapper, ColumnID{0}, PredicateCondition::GreaterThanEquals, 1234);
+//     scan->execute();  scan->get_output();                                  operators/abstract_operator.hpp:133,143
+//
+// Names, argument meaning and error behaviour follow the reference: operators derive from AbstractReadOnlyOperator and
+// implement `_on_execute()` (abstract_read_only_operator.hpp:20-22); scans and joins return TableType::References
+// tables whose segments share PosLists (table_scan.cpp:207-210); failures throw std::logic_error (utils/assert.hpp:48-70).
+// There is NO CPU implementation behind these classes: what the device library reports as HY_ERR_UNSUPPORTED (the
+// shapes for which the real adapter keeps Hyrise's stock operator) surfaces as std::logic_error here.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <optional>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "../../include/hyrise_amd.h"
+
+namespace hyrise_amd {
+
+// ---- types.hpp / all_type_variant.hpp ---------------------------------------------------------------------------------
+using ChunkID = uint32_t;
+using ChunkOffset = uint32_t;
+using ColumnID = uint16_t;
+constexpr ColumnID INVALID_COLUMN_ID = 0xFFFF;
+
+enum class DataType : uint8_t { Null, Int, Long, Float, Double, String };
+enum class PredicateCondition : uint8_t {
+  Equals, NotEquals, LessThan, LessThanEquals, GreaterThan, GreaterThanEquals, BetweenInclusive, BetweenLowerExclusive,
+  BetweenUpperExclusive, BetweenExclusive, In, NotIn, Like, NotLike, LikeInsensitive, NotLikeInsensitive, IsNull, IsNotNull
+};
+enum class JoinMode : uint8_t { Inner, Left, Right, FullOuter, Cross, Semi, AntiNullAsTrue, AntiNullAsFalse };
+enum class WindowFunction : uint8_t { Min, Max, Sum, Avg, Count, CountDistinct, StandardDeviationSample, Any };
+enum class EncodingType : uint8_t { Unencoded, Dictionary, FrameOfReference };
+enum class TableType : uint8_t { Data, References };
+
+struct NullValue {};
+using AllTypeVariant = std::variant<NullValue, int32_t, int64_t, float, double, std::string>;
+inline bool variant_is_null(const AllTypeVariant& v) { return v.index() == 0; }
+inline DataType data_type_from_all_type_variant(const AllTypeVariant& v) { return static_cast<DataType>(v.index()); }
+
+struct RowID {
+  ChunkID chunk_id;
+  ChunkOffset chunk_offset;
+  bool is_null() const { return chunk_offset == 0xFFFFFFFFu; }
+  bool operator==(const RowID& o) const { return chunk_id == o.chunk_id && chunk_offset == o.chunk_offset; }
+};
+static_assert(sizeof(RowID) == sizeof(hy_row_id), "RowID must be the ABI's 8-byte {chunk_id, chunk_offset}");
+constexpr RowID NULL_ROW_ID{0xFFFFFFFFu, 0xFFFFFFFFu};
+
+[[noreturn]] inline void Fail(const std::string& message) { throw std::logic_error(message); }
+inline void Assert(bool condition, const std::string& message) { if (!condition) Fail(message); }
+inline void check_status(hy_status status) { if (status != HY_OK) Fail(std::string("hyrise_amd: ") + hy_last_error()); }
+
+// ---- storage ---------------------------------------------------------------------------------------------------------
+class AbstractPosList {
+ public:
+  virtual ~AbstractPosList() = default;
+  virtual size_t size() const = 0;
+  virtual RowID operator[](size_t index) const = 0;
+  virtual bool references_single_chunk() const = 0;
+  virtual ChunkID common_chunk_id() const = 0;
+};
+
+class RowIDPosList : public AbstractPosList {   // pos_lists/row_id_pos_list.hpp:22-143
+ public:
+  RowIDPosList() = default;
+  explicit RowIDPosList(std::vector<RowID> init) : rows(std::move(init)) {}
+  size_t size() const override { return rows.size(); }
+  RowID operator[](size_t index) const override { return rows[index]; }
+  void guarantee_single_chunk() { _single = true; }
+  bool references_single_chunk() const override { return _single; }
+  ChunkID common_chunk_id() const override { return rows.empty() ? 0xFFFFFFFFu : rows[0].chunk_id; }
+  std::vector<RowID> rows;
+
+ private:
+  bool _single = false;
+};
+
+class EntireChunkPosList : public AbstractPosList {   // pos_lists/entire_chunk_pos_list.hpp:8-44
+ public:
+  EntireChunkPosList(ChunkID chunk_id, ChunkOffset size) : _chunk_id(chunk_id), _size(size) {}
+  size_t size() const override { return _size; }
+  RowID operator[](size_t index) const override { return RowID{_chunk_id, static_cast<ChunkOffset>(index)}; }
+  bool references_single_chunk() const override { return true; }
+  ChunkID common_chunk_id() const override { return _chunk_id; }
+
+ private:
+  ChunkID _chunk_id;
+  ChunkOffset _size;
+};
+
+class Table;
+
+class AbstractSegment {
+ public:
+  explicit AbstractSegment(DataType type) : _data_type(type) {}
+  virtual ~AbstractSegment() = default;
+  virtual ChunkOffset size() const = 0;
+  virtual AllTypeVariant operator[](ChunkOffset offset) const = 0;   // slow, test-side access like the reference's
+  DataType data_type() const { return _data_type; }
+
+ private:
+  DataType _data_type;
+};
+
+template <typename T> constexpr DataType data_type_of() {
+  if constexpr (std::is_same_v<T, int32_t>) return DataType::Int;
+  else if constexpr (std::is_same_v<T, int64_t>) return DataType::Long;
+  else if constexpr (std::is_same_v<T, float>) return DataType::Float;
+  else if constexpr (std::is_same_v<T, double>) return DataType::Double;
+  else return DataType::String;
+}
+
+inline std::vector<uint64_t> pack_null_words(const std::vector<bool>& nulls) {   // libstdc++ vector<bool> word order
+  std::vector<uint64_t> words((nulls.size() + 63) / 64, 0);
+  for (size_t i = 0; i < nulls.size(); ++i) if (nulls[i]) words[i / 64] |= uint64_t{1} << (i % 64);
+  return words;
+}
+
+template <typename T>
+class ValueSegment : public AbstractSegment {   // storage/value_segment.hpp:15-90
+ public:
+  ValueSegment(std::vector<T> values, std::optional<std::vector<bool>> nulls) : AbstractSegment(data_type_of<T>()), _values(std::move(values)), _nulls(std::move(nulls)) {
+    if (_nulls) _null_words = pack_null_words(*_nulls);
+  }
+  ChunkOffset size() const override { return static_cast<ChunkOffset>(_values.size()); }
+  bool is_nullable() const { return _nulls.has_value(); }
+  const std::vector<T>& values() const { return _values; }
+  const std::vector<uint64_t>& null_words() const { return _null_words; }
+  bool is_null(ChunkOffset offset) const { return _nulls && (*_nulls)[offset]; }
+  AllTypeVariant operator[](ChunkOffset offset) const override { if (is_null(offset)) return NullValue{}; return _values[offset]; }
+
+ private:
+  std::vector<T> _values;
+  std::optional<std::vector<bool>> _nulls;
+  std::vector<uint64_t> _null_words;
+};
+
+// FixedWidthIntegerVector<u8/u16/u32> (fixed_width_integer_compressor.cpp:33-44)
+struct CompressedVector {
+  uint32_t width = 4;
+  std::vector<uint8_t> bytes;
+  static CompressedVector compress(const std::vector<uint32_t>& values, uint32_t max_value) {
+    CompressedVector out;
+    out.width = max_value <= 0xFF ? 1 : max_value <= 0xFFFF ? 2 : 4;
+    out.bytes.resize(values.size() * out.width + 16);
+    for (size_t i = 0; i < values.size(); ++i) std::memcpy(out.bytes.data() + i * out.width, &values[i], out.width);
+    return out;
+  }
+  uint32_t get(size_t i) const { uint32_t v = 0; std::memcpy(&v, bytes.data() + i * width, width); return v; }
+};
+
+template <typename T>
+class DictionarySegment : public AbstractSegment {   // storage/dictionary_segment.hpp:19-91
+ public:
+  DictionarySegment(std::vector<T> dictionary, CompressedVector attribute_vector, ChunkOffset size)
+      : AbstractSegment(data_type_of<T>()), _dictionary(std::move(dictionary)), _attribute_vector(std::move(attribute_vector)), _size(size) {}
+  ChunkOffset size() const override { return _size; }
+  const std::vector<T>& dictionary() const { return _dictionary; }
+  const CompressedVector& attribute_vector() const { return _attribute_vector; }
+  uint32_t unique_values_count() const { return static_cast<uint32_t>(_dictionary.size()); }
+  uint32_t lower_bound(const T& value) const {   // dictionary_segment.cpp:94-106
+    const auto it = std::lower_bound(_dictionary.begin(), _dictionary.end(), value);
+    return it == _dictionary.end() ? HY_INVALID_VALUE_ID : static_cast<uint32_t>(it - _dictionary.begin());
+  }
+  uint32_t upper_bound(const T& value) const {   // :108-119
+    const auto it = std::upper_bound(_dictionary.begin(), _dictionary.end(), value);
+    return it == _dictionary.end() ? HY_INVALID_VALUE_ID : static_cast<uint32_t>(it - _dictionary.begin());
+  }
+  AllTypeVariant operator[](ChunkOffset offset) const override {
+    const auto vid = _attribute_vector.get(offset);
+    if (vid >= _dictionary.size()) return NullValue{};
+    return _dictionary[vid];
+  }
+
+ private:
+  std::vector<T> _dictionary;
+  CompressedVector _attribute_vector;
+  ChunkOffset _size;
+};
+
+class FrameOfReferenceSegment : public AbstractSegment {   // storage/frame_of_reference_segment.hpp:37-98
+ public:
+  FrameOfReferenceSegment(std::vector<int32_t> minima, CompressedVector offsets, std::optional<std::vector<bool>> nulls, ChunkOffset size)
+      : AbstractSegment(DataType::Int), _minima(std::move(minima)), _offsets(std::move(offsets)), _nulls(std::move(nulls)), _size(size) {
+    if (_nulls) _null_words = pack_null_words(*_nulls);
+  }
+  ChunkOffset size() const override { return _size; }
+  const std::vector<int32_t>& block_minima() const { return _minima; }
+  const CompressedVector& offset_values() const { return _offsets; }
+  bool has_nulls() const { return _nulls.has_value(); }
+  const std::vector<uint64_t>& null_words() const { return _null_words; }
+  AllTypeVariant operator[](ChunkOffset offset) const override {
+    if (_nulls && (*_nulls)[offset]) return NullValue{};
+    return static_cast<int32_t>(_offsets.get(offset) + static_cast<uint32_t>(_minima[offset / HY_FOR_BLOCK_SIZE]));
+  }
+
+ private:
+  std::vector<int32_t> _minima;
+  CompressedVector _offsets;
+  std::optional<std::vector<bool>> _nulls;
+  std::vector<uint64_t> _null_words;
+  ChunkOffset _size;
+};
+
+class ReferenceSegment : public AbstractSegment {   // storage/reference_segment.hpp:20-48
+ public:
+  ReferenceSegment(std::shared_ptr<const Table> table, ColumnID column_id, std::shared_ptr<const AbstractPosList> pos_list);
+  ChunkOffset size() const override { return static_cast<ChunkOffset>(_pos_list->size()); }
+  const std::shared_ptr<const Table>& referenced_table() const { return _table; }
+  ColumnID referenced_column_id() const { return _column_id; }
+  const std::shared_ptr<const AbstractPosList>& pos_list() const { return _pos_list; }
+  AllTypeVariant operator[](ChunkOffset offset) const override;
+
+ private:
+  std::shared_ptr<const Table> _table;
+  ColumnID _column_id;
+  std::shared_ptr<const AbstractPosList> _pos_list;
+};
+
+using Segments = std::vector<std::shared_ptr<AbstractSegment>>;
+
+class Chunk {   // storage/chunk.hpp:38-218
+ public:
+  static constexpr ChunkOffset DEFAULT_SIZE = 65535;
+  explicit Chunk(Segments segments) : _segments(std::move(segments)) {}
+  ChunkOffset size() const { return _segments.empty() ? 0 : _segments[0]->size(); }
+  const std::shared_ptr<AbstractSegment>& get_segment(ColumnID column_id) const { return _segments.at(column_id); }
+  void replace_segment(ColumnID column_id, std::shared_ptr<AbstractSegment> segment) { _segments.at(column_id) = std::move(segment); }
+  ColumnID column_count() const { return static_cast<ColumnID>(_segments.size()); }
+
+ private:
+  Segments _segments;
+};
+
+struct TableColumnDefinition {
+  std::string name;
+  DataType data_type;
+  bool nullable;
+};
+using TableColumnDefinitions = std::vector<TableColumnDefinition>;
+
+struct ColumnCache;   // device-resident columns of one table (residency cache)
+
+class Table : public std::enable_shared_from_this<Table> {   // storage/table.hpp
+ public:
+  Table(TableColumnDefinitions definitions, TableType type, ChunkOffset target_chunk_size = Chunk::DEFAULT_SIZE)
+      : _definitions(std::move(definitions)), _type(type), _target_chunk_size(target_chunk_size) {}
+  Table(TableColumnDefinitions definitions, TableType type, std::vector<std::shared_ptr<Chunk>> chunks)
+      : _definitions(std::move(definitions)), _type(type), _target_chunk_size(Chunk::DEFAULT_SIZE), _chunks(std::move(chunks)) {}
+  ~Table();
+  const TableColumnDefinitions& column_definitions() const { return _definitions; }
+  ColumnID column_count() const { return static_cast<ColumnID>(_definitions.size()); }
+  DataType column_data_type(ColumnID id) const { return _definitions.at(id).data_type; }
+  bool column_is_nullable(ColumnID id) const { return _definitions.at(id).nullable; }
+  const std::string& column_name(ColumnID id) const { return _definitions.at(id).name; }
+  TableType type() const { return _type; }
+  ChunkID chunk_count() const { return static_cast<ChunkID>(_chunks.size()); }
+  const std::shared_ptr<Chunk>& get_chunk(ChunkID id) const { return _chunks.at(id); }
+  uint64_t row_count() const { uint64_t n = 0; for (const auto& c : _chunks) n += c->size(); return n; }
+  void append_chunk(Segments segments) { _chunks.push_back(std::make_shared<Chunk>(std::move(segments))); }
+  // Table::append(row): rows are collected and cut into ValueSegments of target_chunk_size rows by finalize().
+  void append(std::vector<AllTypeVariant> row) { _pending.push_back(std::move(row)); if (_pending.size() == _target_chunk_size) finalize(); }
+  void finalize();
+  AllTypeVariant get_value(ColumnID column_id, uint64_t row) const {
+    for (const auto& chunk : _chunks) { if (row < chunk->size()) return (*chunk->get_segment(column_id))[static_cast<ChunkOffset>(row)]; row -= chunk->size(); }
+    Fail("row index out of range");
+  }
+  std::vector<std::vector<AllTypeVariant>> get_rows() const {
+    std::vector<std::vector<AllTypeVariant>> rows;
+    for (const auto& chunk : _chunks)
+      for (ChunkOffset r = 0; r < chunk->size(); ++r) {
+        std::vector<AllTypeVariant> row;
+        for (ColumnID c = 0; c < column_count(); ++c) row.push_back((*chunk->get_segment(c))[r]);
+        rows.push_back(std::move(row));
+      }
+    return rows;
+  }
+  mutable std::shared_ptr<ColumnCache> device_columns;
+
+ private:
+  TableColumnDefinitions _definitions;
+  TableType _type;
+  ChunkOffset _target_chunk_size;
+  std::vector<std::shared_ptr<Chunk>> _chunks;
+  std::vector<std::vector<AllTypeVariant>> _pending;
+};
+
+inline ReferenceSegment::ReferenceSegment(std::shared_ptr<const Table> table, ColumnID column_id, std::shared_ptr<const AbstractPosList> pos_list)
+    : AbstractSegment(table->column_data_type(column_id)), _table(std::move(table)), _column_id(column_id), _pos_list(std::move(pos_list)) {
+  Assert(_table->type() == TableType::Data, "ReferenceSegments must not reference reference tables (table_scan.cpp:140-148)");
+}
+inline AllTypeVariant ReferenceSegment::operator[](ChunkOffset offset) const {
+  const RowID row = (*_pos_list)[offset];
+  if (row.is_null()) return NullValue{};
+  return (*_table->get_chunk(row.chunk_id)->get_segment(_column_id))[row.chunk_offset];
+}
+
+template <typename T>
+std::shared_ptr<AbstractSegment> make_value_segment(const std::vector<std::vector<AllTypeVariant>>& rows, ColumnID column, bool nullable) {
+  std::vector<T> values;
+  std::vector<bool> nulls;
+  for (const auto& row : rows) {
+    const bool is_null = variant_is_null(row[column]);
+    Assert(!is_null || nullable, "NULL in a non-nullable column");
+    nulls.push_back(is_null);
+    values.push_back(is_null ? T{} : std::get<T>(row[column]));
+  }
+  return std::make_shared<ValueSegment<T>>(std::move(values), nullable ? std::optional<std::vector<bool>>(std::move(nulls)) : std::nullopt);
+}
+
+inline void Table::finalize() {
+  if (_pending.empty()) return;
+  Segments segments;
+  for (ColumnID c = 0; c < column_count(); ++c) {
+    switch (_definitions[c].data_type) {
+      case DataType::Int: segments.push_back(make_value_segment<int32_t>(_pending, c, _definitions[c].nullable)); break;
+      case DataType::Long: segments.push_back(make_value_segment<int64_t>(_pending, c, _definitions[c].nullable)); break;
+      case DataType::Float: segments.push_back(make_value_segment<float>(_pending, c, _definitions[c].nullable)); break;
+      case DataType::Double: segments.push_back(make_value_segment<double>(_pending, c, _definitions[c].nullable)); break;
+      default: segments.push_back(make_value_segment<std::string>(_pending, c, _definitions[c].nullable)); break;
+    }
+  }
+  _chunks.push_back(std::make_shared<Chunk>(std::move(segments)));
+  _pending.clear();
+}
+
+// ---- load_table (utils/load_table.cpp:22-96) ----------------------------------------------------------------------------
+inline std::vector<std::string> split_string_by_delimiter(const std::string& line, char delimiter) {
+  std::vector<std::string> out;
+  std::stringstream stream(line);
+  std::string cell;
+  while (std::getline(stream, cell, delimiter)) out.push_back(cell);
+  if (!line.empty() && line.back() == delimiter) out.emplace_back();
+  return out;
+}
+
+inline std::shared_ptr<Table> load_table(const std::string& file_name, ChunkOffset chunk_size = Chunk::DEFAULT_SIZE) {
+  std::ifstream infile(file_name);
+  Assert(infile.is_open(), "load_table: Could not find file '" + file_name + "'.");
+  std::string line;
+  std::getline(infile, line);
+  const auto names = split_string_by_delimiter(line, '|');
+  std::getline(infile, line);
+  const auto types = split_string_by_delimiter(line, '|');
+  TableColumnDefinitions definitions;
+  for (size_t i = 0; i < names.size(); ++i) {
+    const auto parts = split_string_by_delimiter(types[i], '_');
+    const bool nullable = parts.size() > 1 && parts[1] == "null";
+    DataType type;
+    if (parts[0] == "int") type = DataType::Int;
+    else if (parts[0] == "long") type = DataType::Long;
+    else if (parts[0] == "float") type = DataType::Float;
+    else if (parts[0] == "double") type = DataType::Double;
+    else if (parts[0] == "string") type = DataType::String;
+    else Fail("Invalid data type '" + parts[0] + "' for column '" + names[i] + "'.");
+    definitions.push_back({names[i], type, nullable});
+  }
+  auto table = std::make_shared<Table>(definitions, TableType::Data, chunk_size);
+  while (std::getline(infile, line)) {
+    auto cells = split_string_by_delimiter(line, '|');
+    cells.resize(definitions.size());
+    std::vector<AllTypeVariant> row;
+    for (size_t c = 0; c < definitions.size(); ++c) {
+      if (definitions[c].nullable && cells[c] == "null") { row.emplace_back(NullValue{}); continue; }
+      switch (definitions[c].data_type) {
+        case DataType::Int: row.emplace_back(static_cast<int32_t>(std::stol(cells[c]))); break;
+        case DataType::Long: row.emplace_back(static_cast<int64_t>(std::stoll(cells[c]))); break;
+        case DataType::Float: row.emplace_back(std::stof(cells[c])); break;
+        case DataType::Double: row.emplace_back(std::stod(cells[c])); break;
+        default: row.emplace_back(cells[c]); break;
+      }
+    }
+    table->append(std::move(row));
+  }
+  table->finalize();
+  return table;
+}
+
+// ---- ChunkEncoder (dictionary_encoder.hpp:33-103, frame_of_reference_encoder.hpp:25-122) --------------------------------
+struct ChunkEncoder {
+  template <typename T>
+  static std::shared_ptr<AbstractSegment> encode_dictionary(const ValueSegment<T>& segment) {
+    std::vector<T> dictionary;
+    for (ChunkOffset i = 0; i < segment.size(); ++i) if (!segment.is_null(i)) dictionary.push_back(segment.values()[i]);
+    std::sort(dictionary.begin(), dictionary.end());
+    dictionary.erase(std::unique(dictionary.begin(), dictionary.end()), dictionary.end());
+    const auto null_value_id = static_cast<uint32_t>(dictionary.size());
+    std::vector<uint32_t> ids(segment.size());
+    for (ChunkOffset i = 0; i < segment.size(); ++i) {
+      ids[i] = segment.is_null(i) ? null_value_id
+                                  : static_cast<uint32_t>(std::lower_bound(dictionary.begin(), dictionary.end(), segment.values()[i]) - dictionary.begin());
+    }
+    return std::make_shared<DictionarySegment<T>>(std::move(dictionary), CompressedVector::compress(ids, null_value_id), segment.size());
+  }
+  static std::shared_ptr<AbstractSegment> encode_frame_of_reference(const ValueSegment<int32_t>& segment) {
+    const auto n = segment.size();
+    std::vector<int32_t> minima;
+    std::vector<uint32_t> offsets(n);
+    std::vector<bool> nulls(n, false);
+    bool any_null = false;
+    uint32_t max_offset = 0;
+    for (ChunkOffset begin = 0; begin < n; begin += HY_FOR_BLOCK_SIZE) {
+      const auto end = std::min<ChunkOffset>(n, begin + HY_FOR_BLOCK_SIZE);
+      int32_t minimum = INT32_MAX;
+      for (auto i = begin; i < end; ++i) {
+        nulls[i] = segment.is_null(i);
+        any_null |= nulls[i];
+        if (!nulls[i]) minimum = std::min(minimum, segment.values()[i]);
+      }
+      minima.push_back(minimum);
+      for (auto i = begin; i < end; ++i) {
+        const int32_t value = nulls[i] ? minimum : segment.values()[i];
+        offsets[i] = static_cast<uint32_t>(value) - static_cast<uint32_t>(minimum);
+        max_offset = std::max(max_offset, offsets[i]);
+      }
+    }
+    return std::make_shared<FrameOfReferenceSegment>(std::move(minima), CompressedVector::compress(offsets, max_offset),
+                                                     any_null ? std::optional<std::vector<bool>>(std::move(nulls)) : std::nullopt, n);
+  }
+  // encode_all_chunks(table, SegmentEncodingSpec{type}); unsupported (type, data type) pairs stay unencoded like
+  // load_and_encode_table in table_scan_test.cpp:63-75.
+  static void encode_all_chunks(const std::shared_ptr<Table>& table, EncodingType type) {
+    if (type == EncodingType::Unencoded) return;
+    for (ChunkID chunk_id = 0; chunk_id < table->chunk_count(); ++chunk_id) {
+      const auto& chunk = table->get_chunk(chunk_id);
+      for (ColumnID c = 0; c < table->column_count(); ++c) {
+        const auto segment = chunk->get_segment(c);
+        std::shared_ptr<AbstractSegment> encoded;
+        if (type == EncodingType::FrameOfReference) {
+          if (const auto* ints = dynamic_cast<const ValueSegment<int32_t>*>(segment.get())) encoded = encode_frame_of_reference(*ints);
+        } else if (const auto* i32 = dynamic_cast<const ValueSegment<int32_t>*>(segment.get())) encoded = encode_dictionary(*i32);
+        else if (const auto* i64 = dynamic_cast<const ValueSegment<int64_t>*>(segment.get())) encoded = encode_dictionary(*i64);
+        else if (const auto* f32 = dynamic_cast<const ValueSegment<float>*>(segment.get())) encoded = encode_dictionary(*f32);
+        else if (const auto* f64 = dynamic_cast<const ValueSegment<double>*>(segment.get())) encoded = encode_dictionary(*f64);
+        else if (const auto* str = dynamic_cast<const ValueSegment<std::string>*>(segment.get())) encoded = encode_dictionary(*str);
+        if (encoded) chunk->replace_segment(c, encoded);
+      }
+    }
+  }
+};
+
+// ---- marshalling into the C ABI (what INTEGRATION.md section 1 does inside Hyrise) --------------------------------------
+struct DeviceColumn {
+  hy_column* handle = nullptr;
+  std::vector<hy_segment> descriptors;
+  std::vector<std::vector<int64_t>> key_names;   // string GROUP BY columns: AggregateKeyEntry names per chunk
+  ~DeviceColumn() { if (handle) hy_column_destroy(handle); }
+};
+
+struct ColumnCache {
+  std::map<std::pair<ColumnID, bool>, std::shared_ptr<DeviceColumn>> columns;
+};
+inline Table::~Table() = default;
+
+template <typename T> constexpr uint32_t abi_type() { return static_cast<uint32_t>(data_type_of<T>()); }
+
+// AggregateKeyEntry name of a string (aggregate_hash.cpp:852-914); strings of 5+ characters get map ids from 5e9 on.
+inline int64_t string_key_name(const std::string& s, std::map<std::string, int64_t>& long_strings) {
+  const auto byte = [&](size_t i) { return static_cast<int64_t>(static_cast<uint8_t>(s[i])); };
+  switch (s.size()) {
+    case 0: return 1;
+    case 1: return 2 + byte(0);
+    case 2: return 258 + (byte(1) << 8) + byte(0);
+    case 3: return 65794 + (byte(2) << 16) + (byte(1) << 8) + byte(0);
+    case 4: return 16843010ll + (byte(3) << 24) + (byte(2) << 16) + (byte(1) << 8) + byte(0);
+    default: {
+      const auto it = long_strings.emplace(s, 5000000000ll + static_cast<int64_t>(long_strings.size())).first;
+      return it->second;
+    }
+  }
+}
+
+// `as_key_names`: present string dictionary columns as dictionaries of int64 AggregateKey names (GROUP BY).
+inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const Table>& table, ColumnID column_id, bool as_key_names = false) {
+  if (!table->device_columns) table->device_columns = std::make_shared<ColumnCache>();
+  auto& slot = table->device_columns->columns[{column_id, as_key_names}];
+  if (slot) return slot;
+  auto column = std::make_shared<DeviceColumn>();
+  const auto chunk_count = table->chunk_count();
+  column->descriptors.assign(chunk_count, hy_segment{});
+  column->key_names.resize(chunk_count);
+  std::map<std::string, int64_t> long_strings;
+  std::shared_ptr<DeviceColumn> referenced;
+  for (ChunkID chunk_id = 0; chunk_id < chunk_count; ++chunk_id) {
+    const auto segment = table->get_chunk(chunk_id)->get_segment(column_id);
+    hy_segment& d = column->descriptors[chunk_id];
+    d.size = segment->size();
+    d.data_type = static_cast<uint32_t>(segment->data_type());
+    d.ref_chunk_id = 0xFFFFFFFFu;
+    bool ok = false;
+    const auto describe_value = [&](auto* typed) {
+      using T = std::decay_t<decltype(typed->values()[0])>;
+      d.encoding = HY_ENC_UNENCODED; d.width = sizeof(T); d.data = typed->values().data();
+      d.nulls = typed->is_nullable() ? typed->null_words().data() : nullptr;
+      ok = true;
+    };
+    const auto describe_dictionary = [&](auto* typed) {
+      d.encoding = HY_ENC_DICTIONARY; d.width = typed->attribute_vector().width; d.data = typed->attribute_vector().bytes.data();
+      d.aux = typed->dictionary().data(); d.aux_size = typed->unique_values_count();
+      ok = true;
+    };
+    if (const auto* s = dynamic_cast<const ValueSegment<int32_t>*>(segment.get())) describe_value(s);
+    else if (const auto* s = dynamic_cast<const ValueSegment<int64_t>*>(segment.get())) describe_value(s);
+    else if (const auto* s = dynamic_cast<const ValueSegment<float>*>(segment.get())) describe_value(s);
+    else if (const auto* s = dynamic_cast<const ValueSegment<double>*>(segment.get())) describe_value(s);
+    else if (const auto* s = dynamic_cast<const DictionarySegment<int32_t>*>(segment.get())) describe_dictionary(s);
+    else if (const auto* s = dynamic_cast<const DictionarySegment<int64_t>*>(segment.get())) describe_dictionary(s);
+    else if (const auto* s = dynamic_cast<const DictionarySegment<float>*>(segment.get())) describe_dictionary(s);
+    else if (const auto* s = dynamic_cast<const DictionarySegment<double>*>(segment.get())) describe_dictionary(s);
+    else if (const auto* s = dynamic_cast<const DictionarySegment<std::string>*>(segment.get())) {
+      d.encoding = HY_ENC_DICTIONARY; d.width = s->attribute_vector().width; d.data = s->attribute_vector().bytes.data();
+      d.aux_size = s->unique_values_count();
+      if (as_key_names) {   // GROUP BY: the dictionary becomes the int64 key names
+        for (const auto& entry : s->dictionary()) column->key_names[chunk_id].push_back(string_key_name(entry, long_strings));
+        d.aux = column->key_names[chunk_id].data();
+        d.data_type = HY_TYPE_LONG;
+      } else {
+        d.aux = nullptr;   // scans compare value ids; literals are resolved per chunk by the caller
+      }
+      ok = true;
+    } else if (const auto* s = dynamic_cast<const FrameOfReferenceSegment*>(segment.get())) {
+      d.encoding = HY_ENC_FRAME_OF_REFERENCE; d.width = s->offset_values().width; d.data = s->offset_values().bytes.data();
+      d.aux = s->block_minima().data(); d.aux_size = static_cast<uint32_t>(s->block_minima().size());
+      d.nulls = s->has_nulls() ? s->null_words().data() : nullptr;
+      ok = true;
+    } else if (const auto* s = dynamic_cast<const ReferenceSegment*>(segment.get())) {
+      if (!referenced) referenced = device_column(s->referenced_table(), s->referenced_column_id(), as_key_names);
+      d.encoding = HY_ENC_REFERENCE; d.width = 8; d.ref = referenced->handle;
+      if (as_key_names && s->data_type() == DataType::String) d.data_type = HY_TYPE_LONG;
+      if (const auto* entire = dynamic_cast<const EntireChunkPosList*>(s->pos_list().get())) {
+        d.data = nullptr; d.ref_chunk_id = entire->common_chunk_id();
+      } else {
+        const auto& rows = static_cast<const RowIDPosList&>(*s->pos_list());
+        d.data = rows.rows.data();
+        d.ref_chunk_id = rows.references_single_chunk() && rows.size() ? rows.common_chunk_id() : 0xFFFFFFFFu;
+      }
+      ok = true;
+    }
+    if (!ok) Fail("segment kind not handled by the device path (the Hyrise adapter keeps the stock operator here)");
+  }
+  check_status(hy_column_create(column->descriptors.data(), chunk_count, HY_MEM_HOST, &column->handle));
+  slot = column;
+  return column;
+}
+
+// ---- operators ---------------------------------------------------------------------------------------------------------
+class AbstractOperator {   // operators/abstract_operator.hpp
+ public:
+  AbstractOperator(std::shared_ptr<const AbstractOperator> left = nullptr, std::shared_ptr<const AbstractOperator> right = nullptr)
+      : _left_input(std::move(left)), _right_input(std::move(right)) {}
+  virtual ~AbstractOperator() = default;
+  virtual const std::string& name() const = 0;
+  void execute() {   // abstract_operator.cpp:78-136
+    Assert(!_executed, "Operator has already been executed.");
+    _output = _on_execute();
+    _executed = true;
+  }
+  std::shared_ptr<const Table> get_output() const { Assert(_executed, "Operator has not been executed."); return _output; }
+  std::shared_ptr<const Table> left_input_table() const { return _left_input->get_output(); }
+  std::shared_ptr<const Table> right_input_table() const { return _right_input->get_output(); }
+  void never_clear_output() {}
+
+ protected:
+  virtual std::shared_ptr<const Table> _on_execute() = 0;
+  std::shared_ptr<const AbstractOperator> _left_input, _right_input;
+  std::shared_ptr<const Table> _output;
+  bool _executed = false;
+};
+using AbstractReadOnlyOperator = AbstractOperator;   // abstract_read_only_operator.hpp:18-22: ignores the transaction context
+
+class TableWrapper : public AbstractReadOnlyOperator {   // operators/table_wrapper.hpp
+ public:
+  explicit TableWrapper(std::shared_ptr<const Table> table) : _table(std::move(table)) {}
+  const std::string& name() const override { static const std::string n = "TableWrapper"; return n; }
+
+ protected:
+  std::shared_ptr<const Table> _on_execute() override { return _table; }
+  std::shared_ptr<const Table> _table;
+};
+
+inline hy_value to_hy_value(const AllTypeVariant& v) {
+  hy_value out{};
+  switch (v.index()) {
+    case 1: out.i32 = std::get<int32_t>(v); break;
+    case 2: out.i64 = std::get<int64_t>(v); break;
+    case 3: out.f32 = std::get<float>(v); break;
+    case 4: out.f64 = std::get<double>(v); break;
+    default: break;
+  }
+  return out;
+}
+
+inline bool is_between(PredicateCondition c) { return c >= PredicateCondition::BetweenInclusive && c <= PredicateCondition::BetweenExclusive; }
+
+// TableScan over `column <condition> value [AND value2]` / `column IS [NOT] NULL` / `column <condition> column2`
+// (the shapes create_impl maps to ColumnVsValue / ColumnBetween / ColumnIsNull / ColumnVsColumn, table_scan.cpp:312-452).
+class TableScan : public AbstractReadOnlyOperator {
+ public:
+  TableScan(std::shared_ptr<const AbstractOperator> in, ColumnID column_id, PredicateCondition condition, AllTypeVariant value = NullValue{},
+            std::optional<AllTypeVariant> value2 = std::nullopt)
+      : AbstractReadOnlyOperator(std::move(in)), _column_id(column_id), _condition(condition), _value(std::move(value)), _value2(std::move(value2)) {}
+  TableScan(std::shared_ptr<const AbstractOperator> in, ColumnID left_column, PredicateCondition condition, ColumnID right_column, bool /*column_vs_column*/)
+      : AbstractReadOnlyOperator(std::move(in)), _column_id(left_column), _condition(condition), _right_column_id(right_column) {}
+  const std::string& name() const override { static const std::string n = "TableScan"; return n; }
+  std::vector<ChunkID> excluded_chunk_ids;
+  size_t num_chunks_with_early_out = 0, num_chunks_with_all_rows_matching = 0;   // TableScan::PerformanceData (table_scan.hpp:56-69)
+
+ protected:
+  std::shared_ptr<const Table> _on_execute() override {
+    const auto in_table = left_input_table();
+    const auto chunk_count = in_table->chunk_count();
+    const auto column = device_column(in_table, _column_id);
+    std::vector<RowID> matches(std::max<uint64_t>(1, in_table->row_count()));
+    std::vector<uint64_t> offsets(chunk_count + 1);
+    std::vector<uint32_t> counts(std::max<ChunkID>(1, chunk_count));
+    std::vector<uint8_t> states(std::max<ChunkID>(1, chunk_count));
+    hy_scan_result result{};
+    result.mem = HY_MEM_HOST;
+    result.matches = reinterpret_cast<hy_row_id*>(matches.data());
+    result.capacity = in_table->row_count();
+    result.offsets = offsets.data();
+    result.counts = counts.data();
+    result.chunk_state = states.data();
+    if (_right_column_id) {
+      check_status(hy_table_scan_columns(column->handle, device_column(in_table, *_right_column_id)->handle, static_cast<uint32_t>(_condition), &result));
+    } else {
+      hy_predicate predicate{};
+      predicate.condition = static_cast<uint32_t>(_condition);
+      predicate.column_is_nullable = in_table->column_is_nullable(_column_id);
+      const bool null_test = _condition == PredicateCondition::IsNull || _condition == PredicateCondition::IsNotNull;
+      std::vector<uint32_t> lower, upper;
+      std::vector<uint8_t> found;
+      if (!null_test) {
+        // ColumnVsValueTableScanImpl asserts matching types (column_vs_value_table_scan_impl.cpp:34-36)
+        Assert(data_type_from_all_type_variant(_value) == in_table->column_data_type(_column_id), "Cannot scan: column and value data type do not match.");
+        predicate.value_type = static_cast<uint32_t>(data_type_from_all_type_variant(_value));
+        predicate.value = to_hy_value(_value);
+        if (_value2) predicate.value2 = to_hy_value(*_value2);
+        if (in_table->column_data_type(_column_id) == DataType::String) resolve_string_literal(in_table, lower, upper, found, predicate);
+      }
+      check_status(hy_table_scan(column->handle, &predicate, excluded_chunk_ids.data(), static_cast<uint32_t>(excluded_chunk_ids.size()), &result));
+    }
+    // ---- output assembly, table_scan.cpp:129-220 ----
+    std::vector<std::shared_ptr<Chunk>> output_chunks;
+    for (ChunkID chunk_id = 0; chunk_id < chunk_count; ++chunk_id) {
+      if (states[chunk_id] == HY_CHUNK_NONE_MATCH) ++num_chunks_with_early_out;
+      if (states[chunk_id] == HY_CHUNK_ALL_MATCH) ++num_chunks_with_all_rows_matching;
+      if (counts[chunk_id] == 0) continue;   // :132-134
+      const auto chunk_in = in_table->get_chunk(chunk_id);
+      const bool all = counts[chunk_id] == chunk_in->size();
+      Segments out_segments;
+      if (in_table->type() == TableType::References) {
+        if (all) {   // forward the chunk (:151-156)
+          for (ColumnID c = 0; c < in_table->column_count(); ++c) out_segments.push_back(chunk_in->get_segment(c));
+        } else {     // translate through every distinct input pos list once (:158-196)
+          std::map<const AbstractPosList*, std::shared_ptr<RowIDPosList>> filtered;
+          for (ColumnID c = 0; c < in_table->column_count(); ++c) {
+            const auto ref = std::static_pointer_cast<ReferenceSegment>(chunk_in->get_segment(c));
+            auto& list = filtered[ref->pos_list().get()];
+            if (!list) {
+              list = std::make_shared<RowIDPosList>();
+              for (uint64_t m = offsets[chunk_id]; m < offsets[chunk_id + 1]; ++m) list->rows.push_back((*ref->pos_list())[matches[m].chunk_offset]);
+              if (ref->pos_list()->references_single_chunk()) list->guarantee_single_chunk();
+            }
+            out_segments.push_back(std::make_shared<ReferenceSegment>(ref->referenced_table(), ref->referenced_column_id(), list));
+          }
+        }
+      } else {
+        std::shared_ptr<AbstractPosList> pos_list;
+        if (all) pos_list = std::make_shared<EntireChunkPosList>(chunk_id, chunk_in->size());   // :201-205
+        else {
+          auto rows = std::make_shared<RowIDPosList>(std::vector<RowID>(matches.begin() + offsets[chunk_id], matches.begin() + offsets[chunk_id + 1]));
+          rows->guarantee_single_chunk();
+          pos_list = rows;
+        }
+        for (ColumnID c = 0; c < in_table->column_count(); ++c) out_segments.push_back(std::make_shared<ReferenceSegment>(in_table, c, pos_list));
+      }
+      output_chunks.push_back(std::make_shared<Chunk>(std::move(out_segments)));
+    }
+    return std::make_shared<Table>(in_table->column_definitions(), TableType::References, std::move(output_chunks));
+  }
+
+ private:
+  // DictionarySegment<pmr_string>: resolve the literal per chunk like _get_search_value_id
+  // (column_vs_value_table_scan_impl.cpp:211-226) and column_between_table_scan_impl.cpp:112-124.
+  void resolve_string_literal(const std::shared_ptr<const Table>& in_table, std::vector<uint32_t>& lower, std::vector<uint32_t>& upper,
+                              std::vector<uint8_t>& found, hy_predicate& predicate) const {
+    auto data_table = in_table;
+    auto column_id = _column_id;
+    if (in_table->type() == TableType::References && in_table->chunk_count()) {
+      const auto ref = std::static_pointer_cast<ReferenceSegment>(in_table->get_chunk(0)->get_segment(_column_id));
+      data_table = ref->referenced_table();
+      column_id = ref->referenced_column_id();
+    }
+    const auto& value = std::get<std::string>(_value);
+    for (ChunkID c = 0; c < data_table->chunk_count(); ++c) {
+      const auto* dict = dynamic_cast<const DictionarySegment<std::string>*>(data_table->get_chunk(c)->get_segment(column_id).get());
+      Assert(dict, "unencoded string segments stay on the CPU path");
+      if (is_between(_condition)) {
+        const auto& value2 = std::get<std::string>(*_value2);
+        const bool lower_inclusive = _condition == PredicateCondition::BetweenInclusive || _condition == PredicateCondition::BetweenUpperExclusive;
+        const bool upper_inclusive = _condition == PredicateCondition::BetweenInclusive || _condition == PredicateCondition::BetweenLowerExclusive;
+        lower.push_back(lower_inclusive ? dict->lower_bound(value) : dict->upper_bound(value));
+        upper.push_back(upper_inclusive ? dict->upper_bound(value2) : dict->lower_bound(value2));
+        found.push_back(0);
+      } else {
+        const auto lb = dict->lower_bound(value);
+        lower.push_back(lb);
+        upper.push_back(dict->upper_bound(value));
+        found.push_back(lb != HY_INVALID_VALUE_ID && dict->dictionary()[lb] == value);
+      }
+    }
+    predicate.value_type = HY_TYPE_STRING;
+    predicate.per_chunk_lower = lower.data();
+    predicate.per_chunk_upper = upper.data();
+    predicate.per_chunk_found = found.data();
+  }
+
+  ColumnID _column_id;
+  PredicateCondition _condition;
+  AllTypeVariant _value;
+  std::optional<AllTypeVariant> _value2;
+  std::optional<ColumnID> _right_column_id;
+};
+
+using ColumnIDPair = std::pair<ColumnID, ColumnID>;
+
+class JoinHash : public AbstractReadOnlyOperator {   // operators/join_hash.hpp:33-36 (primary predicate: Equals)
+ public:
+  JoinHash(std::shared_ptr<const AbstractOperator> left, std::shared_ptr<const AbstractOperator> right, JoinMode mode, ColumnIDPair column_ids,
+           std::optional<size_t> radix_bits = std::nullopt)
+      : AbstractReadOnlyOperator(std::move(left), std::move(right)), _mode(mode), _column_ids(column_ids), _radix_bits(radix_bits) {}
+  const std::string& name() const override { static const std::string n = "JoinHash"; return n; }
+  size_t radix_bits = 0;
+  bool left_input_is_build_side = false;   // JoinHash::PerformanceData
+
+ protected:
+  std::shared_ptr<const Table> _on_execute() override {
+    const auto left = left_input_table(), right = right_input_table();
+    const auto left_column = device_column(left, _column_ids.first), right_column = device_column(right, _column_ids.second);
+    uint64_t pair_count = 0;
+    check_status(hy_join_hash_count(left_column->handle, right_column->handle, static_cast<uint32_t>(_mode), &pair_count));
+    std::vector<RowID> left_positions(std::max<uint64_t>(1, pair_count)), right_positions(std::max<uint64_t>(1, pair_count));
+    const uint32_t slice_capacity = static_cast<uint32_t>(std::max(left->row_count(), right->row_count()) / 131070 + std::max(left->chunk_count(), right->chunk_count()) + 300);
+    std::vector<uint64_t> slice_offsets(slice_capacity + 2);
+    hy_join_result result{};
+    result.mem = HY_MEM_HOST;
+    result.radix_bits = _radix_bits ? static_cast<uint32_t>(*_radix_bits) : 0xFFFFFFFFu;
+    result.left_pos = reinterpret_cast<hy_row_id*>(left_positions.data());
+    result.right_pos = reinterpret_cast<hy_row_id*>(right_positions.data());
+    result.capacity = pair_count;
+    result.slice_offsets = slice_offsets.data();
+    result.slice_capacity = slice_capacity;
+    check_status(hy_join_hash(left_column->handle, right_column->handle, static_cast<uint32_t>(_mode), &result));
+    radix_bits = result.radix_bits;
+    left_input_is_build_side = result.left_is_build;
+    const bool semi_anti = _mode == JoinMode::Semi || _mode == JoinMode::AntiNullAsTrue || _mode == JoinMode::AntiNullAsFalse;
+    // Output: one chunk per non-empty probe slice (write_output_chunks, join_output_writing.cpp:205-340; the 1000/4000
+    // merge of small PosLists is not applied here).  Columns: left input's, then right input's (Semi/Anti: left only).
+    TableColumnDefinitions definitions = left->column_definitions();
+    if (!semi_anti) for (const auto& d : right->column_definitions()) definitions.push_back({d.name, d.data_type, d.nullable || _mode == JoinMode::Left});
+    if (_mode == JoinMode::Right) for (ColumnID c = 0; c < left->column_count(); ++c) definitions[c].nullable = true;
+    std::vector<std::shared_ptr<Chunk>> chunks;
+    for (uint32_t s = 0; s < result.n_slices; ++s) {
+      const auto begin = slice_offsets[s], end = slice_offsets[s + 1];
+      if (begin == end) continue;
+      Segments segments;
+      append_side(segments, left, std::vector<RowID>(left_positions.begin() + begin, left_positions.begin() + end));
+      if (!semi_anti) append_side(segments, right, std::vector<RowID>(right_positions.begin() + begin, right_positions.begin() + end));
+      chunks.push_back(std::make_shared<Chunk>(std::move(segments)));
+    }
+    return std::make_shared<Table>(definitions, TableType::References, std::move(chunks));
+  }
+
+ private:
+  // write_output_segments (join_output_writing.cpp:95-200): reference inputs are dereferenced through their pos lists.
+  static void append_side(Segments& segments, const std::shared_ptr<const Table>& input, std::vector<RowID> positions) {
+    if (input->type() == TableType::Data) {
+      const auto pos_list = std::make_shared<RowIDPosList>(std::move(positions));
+      for (ColumnID c = 0; c < input->column_count(); ++c) segments.push_back(std::make_shared<ReferenceSegment>(input, c, pos_list));
+      return;
+    }
+    std::map<std::vector<const AbstractPosList*>, std::shared_ptr<RowIDPosList>> cache;
+    for (ColumnID c = 0; c < input->column_count(); ++c) {
+      std::vector<const AbstractPosList*> lists;
+      for (ChunkID k = 0; k < input->chunk_count(); ++k) lists.push_back(std::static_pointer_cast<ReferenceSegment>(input->get_chunk(k)->get_segment(c))->pos_list().get());
+      auto& resolved = cache[lists];
+      if (!resolved) {
+        resolved = std::make_shared<RowIDPosList>();
+        for (const auto& row : positions) resolved->rows.push_back(row.is_null() ? NULL_ROW_ID : (*lists[row.chunk_id])[row.chunk_offset]);
+      }
+      const auto first = std::static_pointer_cast<ReferenceSegment>(input->get_chunk(0)->get_segment(c));
+      segments.push_back(std::make_shared<ReferenceSegment>(first->referenced_table(), first->referenced_column_id(), resolved));
+    }
+  }
+
+  JoinMode _mode;
+  ColumnIDPair _column_ids;
+  std::optional<size_t> _radix_bits;
+};
+
+struct AggregateDefinition {   // WindowFunctionExpression over a PQPColumnExpression (INVALID_COLUMN_ID: COUNT(*))
+  ColumnID column_id;
+  WindowFunction function;
+};
+
+class AggregateHash : public AbstractReadOnlyOperator {   // operators/aggregate_hash.hpp:139-141
+ public:
+  AggregateHash(std::shared_ptr<const AbstractOperator> in, std::vector<AggregateDefinition> aggregates, std::vector<ColumnID> groupby_column_ids)
+      : AbstractReadOnlyOperator(std::move(in)), _aggregates(std::move(aggregates)), _groupby(std::move(groupby_column_ids)) {}
+  const std::string& name() const override { static const std::string n = "AggregateHash"; return n; }
+
+ protected:
+  std::shared_ptr<const Table> _on_execute() override {
+    const auto input = left_input_table();
+    std::vector<std::shared_ptr<DeviceColumn>> keep;
+    std::vector<const hy_column*> groupby;
+    for (const auto id : _groupby) { keep.push_back(device_column(input, id, input->column_data_type(id) == DataType::String)); groupby.push_back(keep.back()->handle); }
+    std::vector<hy_aggregate_spec> specs;
+    for (const auto& aggregate : _aggregates) {
+      hy_aggregate_spec spec{};
+      spec.function = static_cast<uint32_t>(aggregate.function);
+      if (aggregate.column_id != INVALID_COLUMN_ID) {
+        // SUM / AVG / STDDEV_SAMP of strings are invalid (aggregate_test.cpp:232-262 expects std::logic_error)
+        const bool arithmetic = aggregate.function == WindowFunction::Sum || aggregate.function == WindowFunction::Avg || aggregate.function == WindowFunction::StandardDeviationSample;
+        Assert(!(arithmetic && input->column_data_type(aggregate.column_id) == DataType::String), "Aggregate function not available for strings.");
+        keep.push_back(device_column(input, aggregate.column_id));
+        spec.column = keep.back()->handle;
+      } else {
+        Assert(aggregate.function == WindowFunction::Count, "Only COUNT may have an invalid ColumnID.");   // aggregate_hash.cpp:1002
+      }
+      specs.push_back(spec);
+    }
+    const uint32_t capacity = static_cast<uint32_t>(input->row_count() + 1);
+    std::vector<RowID> group_rows(capacity);
+    std::vector<std::vector<uint64_t>> values(specs.size(), std::vector<uint64_t>(capacity));
+    std::vector<std::vector<uint8_t>> nulls(specs.size(), std::vector<uint8_t>(capacity));
+    std::vector<hy_aggregate_column> columns(std::max<size_t>(1, specs.size()));
+    for (size_t a = 0; a < specs.size(); ++a) { columns[a].values = values[a].data(); columns[a].is_null = nulls[a].data(); }
+    hy_aggregate_result result{};
+    result.mem = HY_MEM_HOST;
+    result.group_capacity = capacity;
+    result.group_row_ids = reinterpret_cast<hy_row_id*>(group_rows.data());
+    result.columns = columns.data();
+    std::vector<hy_aggregate_spec> call_specs = specs;
+    if (groupby.empty() && std::all_of(specs.begin(), specs.end(), [](const auto& s) { return !s.column; })) {
+      // a lone COUNT(*): pass the table's first column as an (ignored) ANY so that the library knows the chunk layout
+      keep.push_back(device_column(input, ColumnID{0}));
+      hy_aggregate_spec lone_spec{};
+      lone_spec.function = HY_AGG_ANY;
+      lone_spec.column = keep.back()->handle;
+      call_specs.push_back(lone_spec);
+      columns.push_back(hy_aggregate_column{});
+      values.emplace_back(capacity);
+      nulls.emplace_back(capacity);
+      columns.back().values = values.back().data();
+      columns.back().is_null = nulls.back().data();
+      result.columns = columns.data();
+    }
+    check_status(hy_aggregate_hash(groupby.data(), static_cast<uint32_t>(groupby.size()), call_specs.data(), static_cast<uint32_t>(call_specs.size()), &result));
+    // ---- output (aggregate_hash.cpp:1301-1361): GROUP BY columns reference the input through the representative
+    // rows, aggregate columns are ValueSegments; here both are materialised into one Data table of value segments.
+    TableColumnDefinitions definitions;
+    for (const auto id : _groupby) definitions.push_back(input->column_definitions()[id]);
+    static const char* names[] = {"MIN", "MAX", "SUM", "AVG", "COUNT", "COUNT DISTINCT", "STDDEV_SAMP", "ANY"};
+    for (size_t a = 0; a < specs.size(); ++a) {
+      const auto& aggregate = _aggregates[a];
+      const std::string argument = aggregate.column_id == INVALID_COLUMN_ID ? "*" : input->column_name(aggregate.column_id);
+      const bool needs_null = aggregate.function != WindowFunction::Count && aggregate.function != WindowFunction::CountDistinct;
+      definitions.push_back({std::string(names[static_cast<int>(aggregate.function)]) + "(" + argument + ")", static_cast<DataType>(columns[a].data_type), needs_null});
+    }
+    auto output = std::make_shared<Table>(definitions, TableType::Data, Chunk::DEFAULT_SIZE);
+    for (uint32_t g = 0; g < result.n_groups; ++g) {
+      std::vector<AllTypeVariant> row;
+      for (const auto id : _groupby) row.push_back((*input->get_chunk(group_rows[g].chunk_id)->get_segment(id))[group_rows[g].chunk_offset]);
+      for (size_t a = 0; a < specs.size(); ++a) {
+        if (nulls[a][g]) { row.emplace_back(NullValue{}); continue; }
+        switch (static_cast<DataType>(columns[a].data_type)) {
+          case DataType::Int: row.emplace_back(reinterpret_cast<const int32_t*>(values[a].data())[g]); break;
+          case DataType::Long: row.emplace_back(reinterpret_cast<const int64_t*>(values[a].data())[g]); break;
+          case DataType::Float: row.emplace_back(reinterpret_cast<const float*>(values[a].data())[g]); break;
+          default: row.emplace_back(reinterpret_cast<const double*>(values[a].data())[g]); break;
+        }
+      }
+      output->append(std::move(row));
+    }
+    output->finalize();
+    return output;
+  }
+
+ private:
+  std::vector<AggregateDefinition> _aggregates;
+  std::vector<ColumnID> _groupby;
+};
+
+}  // namespace hyrise_amd

@@ -1,0 +1,256 @@
+// host_tests.cpp -- the reference's operator tests, re-stated against the C++ mirror of the operator interface
+// (hyrise_amd/host/hyrise_host.hpp) and therefore running on the HIP library through the C ABI.  Sources mirrored:
+//   src/test/lib/operators/table_scan_test.cpp   (ScanOnCompressedSegments :407-431, ScanOnReferencedCompressedSegments
+//                                                 :433-463, out-of-range literals :486-534, SingleScan :296-302,
+//                                                 DoubleScan, ScanForNullValues :661-684, string scans)
+//   src/test/lib/operators/join_test_runner.cpp  (differential test against a nested-loop join, :656-791)
+//   src/test/lib/operators/aggregate_test.cpp    (input/expected .tbl pairs, EXPECT_TABLE_EQ_UNORDERED)
+// Usage: host_tests <tests/golden/tbl directory>.  Prints one line per test, exits non-zero on the first failure.
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <iostream>
+
+#include "../../hyrise_amd/host/hyrise_host.hpp"
+
+using namespace hyrise_amd;
+
+static std::string g_tbl;
+static int g_failures = 0;
+
+#define EXPECT_TRUE(cond)                                                                      \
+  do {                                                                                         \
+    if (!(cond)) { std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++g_failures; } \
+  } while (0)
+
+static bool cells_equal(const AllTypeVariant& a, const AllTypeVariant& b) {   // check_table_equal.cpp:34,109-115 (lenient types)
+  if (variant_is_null(a) || variant_is_null(b)) return variant_is_null(a) && variant_is_null(b);
+  if (a.index() == 5 || b.index() == 5) return a.index() == b.index() && std::get<std::string>(a) == std::get<std::string>(b);
+  const auto as_double = [](const AllTypeVariant& v) {
+    switch (v.index()) { case 1: return static_cast<double>(std::get<int32_t>(v)); case 2: return static_cast<double>(std::get<int64_t>(v));
+                         case 3: return static_cast<double>(std::get<float>(v)); default: return std::get<double>(v); }
+  };
+  const double x = as_double(a), y = as_double(b);
+  return std::fabs(x - y) < std::max(1e-4, std::fabs(y) * 1e-4);
+}
+
+static bool tables_equal_unordered(const std::shared_ptr<const Table>& got, const std::shared_ptr<const Table>& want) {
+  auto a = got->get_rows(), b = want->get_rows();
+  if (a.size() != b.size()) { std::printf("  row counts differ: %zu vs %zu\n", a.size(), b.size()); return false; }
+  for (const auto& row : a) {
+    bool matched = false;
+    for (size_t i = 0; i < b.size() && !matched; ++i) {
+      if (b[i].size() != row.size()) continue;
+      bool equal = true;
+      for (size_t c = 0; c < row.size() && equal; ++c) equal = cells_equal(row[c], b[i][c]);
+      if (equal) { b.erase(b.begin() + i); matched = true; }
+    }
+    if (!matched) return false;
+  }
+  return true;
+}
+
+static std::vector<int32_t> column_ints(const std::shared_ptr<const Table>& table, ColumnID column) {
+  std::vector<int32_t> out;
+  for (const auto& row : table->get_rows()) out.push_back(std::get<int32_t>(row[column]));
+  std::sort(out.begin(), out.end());
+  return out;
+}
+
+static std::shared_ptr<TableWrapper> wrap(std::shared_ptr<Table> table) {
+  auto wrapper = std::make_shared<TableWrapper>(std::move(table));
+  wrapper->execute();
+  return wrapper;
+}
+
+static std::shared_ptr<TableWrapper> load_and_encode(const std::string& file, ChunkOffset chunk_size, EncodingType encoding) {
+  auto table = load_table(g_tbl + "/" + file, chunk_size);
+  ChunkEncoder::encode_all_chunks(table, encoding);
+  return wrap(table);
+}
+
+static void run(const char* name, const std::function<void()>& test) {
+  const int before = g_failures;
+  try { test(); } catch (const std::exception& e) { std::printf("  EXCEPTION: %s\n", e.what()); ++g_failures; }
+  std::printf("[%s] %s\n", g_failures == before ? "  OK  " : "FAILED", name);
+}
+
+static const EncodingType ENCODINGS[] = {EncodingType::Unencoded, EncodingType::Dictionary, EncodingType::FrameOfReference};
+
+static void test_scan_on_compressed_segments() {   // table_scan_test.cpp:407-431, 486-534
+  using PC = PredicateCondition;
+  const std::vector<int32_t> all{100, 100, 102, 102, 104, 104, 106, 106, 108, 108, 110, 110, 112, 112};
+  struct Case { int32_t literal; std::map<PC, std::vector<int32_t>> expected; };
+  const std::vector<Case> cases = {
+      {6, {{PC::Equals, {106, 106}}, {PC::NotEquals, {100, 100, 102, 102, 104, 104, 108, 108, 110, 110, 112, 112}}, {PC::LessThan, {100, 100, 102, 102, 104, 104}},
+           {PC::LessThanEquals, {100, 100, 102, 102, 104, 104, 106, 106}}, {PC::GreaterThan, {108, 108, 110, 110, 112, 112}},
+           {PC::GreaterThanEquals, {106, 106, 108, 108, 110, 110, 112, 112}}, {PC::IsNull, {}}, {PC::IsNotNull, all}}},
+      {30, {{PC::Equals, {}}, {PC::NotEquals, all}, {PC::LessThan, all}, {PC::LessThanEquals, all}, {PC::GreaterThan, {}}, {PC::GreaterThanEquals, {}}}},
+      {-10, {{PC::Equals, {}}, {PC::NotEquals, all}, {PC::LessThan, {}}, {PC::LessThanEquals, {}}, {PC::GreaterThan, all}, {PC::GreaterThanEquals, all}}}};
+  for (const auto encoding : ENCODINGS) {
+    for (const auto& [file, chunk] : std::vector<std::pair<std::string, ChunkOffset>>{{"int_int_shuffled.tbl", 7}, {"int_int_shuffled_2.tbl", 5}}) {
+      const auto wrapper = load_and_encode(file, chunk, encoding);
+      for (const auto& c : cases) {
+        for (const auto& [condition, expected] : c.expected) {
+          auto scan = std::make_shared<TableScan>(wrapper, ColumnID{0}, condition, AllTypeVariant{c.literal});
+          scan->execute();
+          EXPECT_TRUE(column_ints(scan->get_output(), ColumnID{1}) == expected);
+        }
+      }
+    }
+  }
+}
+
+static void test_scan_on_referenced_segments() {   // table_scan_test.cpp:433-463
+  using PC = PredicateCondition;
+  const std::map<PC, std::vector<int32_t>> expected = {{PC::Equals, {104, 104}}, {PC::NotEquals, {100, 100, 102, 102, 106, 106}}, {PC::LessThan, {100, 100, 102, 102}},
+      {PC::LessThanEquals, {100, 100, 102, 102, 104, 104}}, {PC::GreaterThan, {106, 106}}, {PC::GreaterThanEquals, {104, 104, 106, 106}}, {PC::IsNull, {}},
+      {PC::IsNotNull, {100, 100, 102, 102, 104, 104, 106, 106}}};
+  for (const auto encoding : ENCODINGS) {
+    const auto wrapper = load_and_encode("int_int_shuffled.tbl", 7, encoding);
+    for (const auto& [condition, values] : expected) {
+      auto scan1 = std::make_shared<TableScan>(wrapper, ColumnID{1}, PC::LessThan, AllTypeVariant{int32_t{108}});
+      scan1->execute();
+      auto scan2 = std::make_shared<TableScan>(scan1, ColumnID{0}, condition, AllTypeVariant{int32_t{4}});
+      scan2->execute();
+      EXPECT_TRUE(column_ints(scan2->get_output(), ColumnID{1}) == values);
+    }
+  }
+}
+
+static void test_single_and_double_scan() {   // table_scan_test.cpp:296-302 and DoubleScan
+  for (const auto encoding : ENCODINGS) {
+    const auto wrapper = load_and_encode("int_float.tbl", 2, encoding);
+    auto scan = std::make_shared<TableScan>(wrapper, ColumnID{0}, PredicateCondition::GreaterThanEquals, AllTypeVariant{int32_t{1234}});
+    scan->execute();
+    EXPECT_TRUE(tables_equal_unordered(scan->get_output(), load_table(g_tbl + "/int_float_filtered2.tbl", 1)));
+    auto scan2 = std::make_shared<TableScan>(scan, ColumnID{1}, PredicateCondition::LessThan, AllTypeVariant{457.9f});
+    scan2->execute();
+    EXPECT_TRUE(tables_equal_unordered(scan2->get_output(), load_table(g_tbl + "/int_float_filtered.tbl", 1)));
+    auto between = std::make_shared<TableScan>(wrapper, ColumnID{0}, PredicateCondition::BetweenInclusive, AllTypeVariant{int32_t{1234}}, AllTypeVariant{int32_t{20000}});
+    between->execute();
+    EXPECT_TRUE(tables_equal_unordered(between->get_output(), load_table(g_tbl + "/int_float_filtered2.tbl", 1)));
+  }
+}
+
+static void test_scan_for_null_values() {   // table_scan_test.cpp:661-684
+  for (const auto encoding : ENCODINGS) {
+    const auto wrapper = load_and_encode("int_int_w_null_8_rows.tbl", 4, encoding);
+    auto is_null = std::make_shared<TableScan>(wrapper, ColumnID{1}, PredicateCondition::IsNull);
+    is_null->execute();
+    EXPECT_TRUE(column_ints(is_null->get_output(), ColumnID{0}) == (std::vector<int32_t>{12, 123}));
+    auto not_null = std::make_shared<TableScan>(wrapper, ColumnID{1}, PredicateCondition::IsNotNull);
+    not_null->execute();
+    EXPECT_TRUE(not_null->get_output()->row_count() == 6);
+  }
+}
+
+static void test_string_dictionary_scan() {   // the l_shipdate case: DictionarySegment<pmr_string>, value ids resolved per chunk
+  const auto wrapper = load_and_encode("int_string_like.tbl", 2, EncodingType::Dictionary);
+  const auto rows = wrapper->get_output()->get_rows();
+  for (const auto condition : {PredicateCondition::Equals, PredicateCondition::NotEquals, PredicateCondition::LessThan, PredicateCondition::GreaterThanEquals}) {
+    const std::string literal = std::get<std::string>(rows[2][1]);
+    auto scan = std::make_shared<TableScan>(wrapper, ColumnID{1}, condition, AllTypeVariant{literal});
+    scan->execute();
+    size_t expected = 0;
+    for (const auto& row : rows) {
+      if (variant_is_null(row[1])) continue;   // NULL never matches a comparison
+      const auto& v = std::get<std::string>(row[1]);
+      expected += condition == PredicateCondition::Equals ? v == literal : condition == PredicateCondition::NotEquals ? v != literal
+                : condition == PredicateCondition::LessThan ? v < literal : v >= literal;
+    }
+    EXPECT_TRUE(scan->get_output()->row_count() == expected);
+  }
+}
+
+static void test_type_mismatch_throws() {   // table_scan_test.cpp:383-405 (EXPECT_THROW std::logic_error)
+  const auto wrapper = load_and_encode("int_float.tbl", 2, EncodingType::Unencoded);
+  auto scan = std::make_shared<TableScan>(wrapper, ColumnID{0}, PredicateCondition::Equals, AllTypeVariant{std::string("x")});
+  bool thrown = false;
+  try { scan->execute(); } catch (const std::logic_error&) { thrown = true; }
+  EXPECT_TRUE(thrown);
+}
+
+static void test_join_against_nested_loop() {   // join_test_runner.cpp:656-791 (Inner / Semi / AntiNullAsFalse on int columns)
+  for (const auto chunk : {ChunkOffset{10}, ChunkOffset{3}}) {
+    for (const auto encoding : {EncodingType::Unencoded, EncodingType::Dictionary}) {
+      const auto left = load_and_encode("join_test_runner/input_table_left_15.tbl", chunk, encoding);
+      const auto right = load_and_encode("join_test_runner/input_table_right_10.tbl", chunk, encoding);
+      const auto lrows = left->get_output()->get_rows(), rrows = right->get_output()->get_rows();
+      for (const ColumnID column : {ColumnID{0}, ColumnID{1}}) {   // int, int_null
+        size_t inner = 0, semi = 0, anti = 0;
+        for (const auto& l : lrows) {
+          bool any = false;
+          for (const auto& r : rrows) {
+            if (!variant_is_null(l[column]) && !variant_is_null(r[column]) && std::get<int32_t>(l[column]) == std::get<int32_t>(r[column])) { ++inner; any = true; }
+          }
+          semi += any;
+          anti += !any;
+        }
+        auto join = std::make_shared<JoinHash>(left, right, JoinMode::Inner, ColumnIDPair{column, column});
+        join->execute();
+        EXPECT_TRUE(join->get_output()->row_count() == inner);
+        for (const auto& row : join->get_output()->get_rows()) EXPECT_TRUE(cells_equal(row[column], row[lrows[0].size() + column]));
+        auto semi_join = std::make_shared<JoinHash>(left, right, JoinMode::Semi, ColumnIDPair{column, column}, 2);
+        semi_join->execute();
+        EXPECT_TRUE(semi_join->get_output()->row_count() == semi);
+        auto anti_join = std::make_shared<JoinHash>(left, right, JoinMode::AntiNullAsFalse, ColumnIDPair{column, column});
+        anti_join->execute();
+        EXPECT_TRUE(anti_join->get_output()->row_count() == anti);
+        auto left_join = std::make_shared<JoinHash>(left, right, JoinMode::Left, ColumnIDPair{column, column});
+        left_join->execute();
+        EXPECT_TRUE(left_join->get_output()->row_count() == inner + anti);
+      }
+    }
+  }
+}
+
+static void test_aggregates_against_fixtures() {   // aggregate_test.cpp: test_output<>(input, aggregates, group by, expected)
+  struct Case { std::string input; std::vector<AggregateDefinition> aggregates; std::vector<ColumnID> groupby; std::string expected; };
+  const std::string d1 = "aggregateoperator/groupby_int_1gb_1agg/", d2 = "aggregateoperator/groupby_int_1gb_2agg/", d21 = "aggregateoperator/groupby_int_2gb_1agg/";
+  const std::vector<Case> cases = {
+      {d1 + "input.tbl", {{1, WindowFunction::Max}}, {0}, d1 + "max.tbl"},      {d1 + "input.tbl", {{1, WindowFunction::Min}}, {0}, d1 + "min.tbl"},
+      {d1 + "input.tbl", {{1, WindowFunction::Sum}}, {0}, d1 + "sum.tbl"},      {d1 + "input.tbl", {{1, WindowFunction::Avg}}, {0}, d1 + "avg.tbl"},
+      {d1 + "input.tbl", {{1, WindowFunction::Count}}, {0}, d1 + "count.tbl"},  {d1 + "input_null.tbl", {{1, WindowFunction::Sum}}, {0}, d1 + "sum_null.tbl"},
+      {d1 + "input_null.tbl", {{1, WindowFunction::Avg}}, {0}, d1 + "avg_null.tbl"}, {d1 + "input_null.tbl", {{INVALID_COLUMN_ID, WindowFunction::Count}}, {0}, d1 + "count_star_null.tbl"},
+      {d2 + "input.tbl", {{1, WindowFunction::Max}, {2, WindowFunction::Avg}}, {0}, d2 + "max_avg.tbl"},
+      {d2 + "input.tbl", {{1, WindowFunction::Sum}, {2, WindowFunction::Sum}}, {0}, d2 + "sum_sum.tbl"},
+      {d21 + "input.tbl", {{2, WindowFunction::Max}}, {0, 1}, d21 + "max.tbl"}, {d21 + "input.tbl", {{2, WindowFunction::Sum}}, {0, 1}, d21 + "sum.tbl"},
+      {"aggregateoperator/groupby_string_1gb_1agg/input.tbl", {{1, WindowFunction::Sum}}, {0}, "aggregateoperator/groupby_string_1gb_1agg/sum.tbl"},
+      {"aggregateoperator/groupby_string_1gb_1agg/input.tbl", {{1, WindowFunction::Avg}}, {0}, "aggregateoperator/groupby_string_1gb_1agg/avg.tbl"},
+  };
+  for (const auto encoding : {EncodingType::Unencoded, EncodingType::Dictionary}) {
+    for (const auto& c : cases) {
+      if (encoding == EncodingType::Unencoded && c.input.find("string") != std::string::npos) continue;   // unencoded strings: CPU path
+      const auto wrapper = load_and_encode(c.input, 2, encoding);
+      auto aggregate = std::make_shared<AggregateHash>(wrapper, c.aggregates, c.groupby);
+      aggregate->execute();
+      const bool ok = tables_equal_unordered(aggregate->get_output(), load_table(g_tbl + "/" + c.expected, 100));
+      if (!ok) std::printf("  case %s -> %s\n", c.input.c_str(), c.expected.c_str());
+      EXPECT_TRUE(ok);
+    }
+  }
+  // CannotSumStringColumns (aggregate_test.cpp:232-241)
+  const auto strings = load_and_encode("aggregateoperator/groupby_string_1gb_1agg/input.tbl", 2, EncodingType::Dictionary);
+  bool thrown = false;
+  try { auto a = std::make_shared<AggregateHash>(strings, std::vector<AggregateDefinition>{{0, WindowFunction::Sum}}, std::vector<ColumnID>{0}); a->execute(); }
+  catch (const std::logic_error&) { thrown = true; }
+  EXPECT_TRUE(thrown);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: host_tests <tbl directory>\n"); return 2; }
+  g_tbl = argv[1];
+  check_status(hy_init(0));
+  run("TableScan.ScanOnCompressedSegments (+ out-of-range literals)", test_scan_on_compressed_segments);
+  run("TableScan.ScanOnReferencedCompressedSegments", test_scan_on_referenced_segments);
+  run("TableScan.SingleScan / DoubleScan / Between", test_single_and_double_scan);
+  run("TableScan.ScanForNullValues", test_scan_for_null_values);
+  run("TableScan.DictionarySegment<string>", test_string_dictionary_scan);
+  run("TableScan.TypeMismatchThrowsLogicError", test_type_mismatch_throws);
+  run("JoinHash vs nested loop (Inner/Semi/AntiNullAsFalse/Left)", test_join_against_nested_loop);
+  run("AggregateHash vs .tbl fixtures (+ CannotSumStringColumns)", test_aggregates_against_fixtures);
+  hy_shutdown();
+  std::printf("%s\n", g_failures ? "HOST TESTS FAILED" : "HOST TESTS PASSED");
+  return g_failures ? 1 : 0;
+}
