@@ -538,6 +538,7 @@ struct ScanArgs {
   uint32_t materialize_all;
   uint32_t is_null_scan;           // IS NULL on reference columns: NULL_ROW_IDs match
   uint32_t epoch;
+  uint32_t debug;
   uint64_t* status;                // [n_parts] epoch-tagged part totals (only touched by multi-part chunks)
   hy_row_id* matches;              // chunk regions
   uint64_t capacity;
@@ -773,21 +774,50 @@ __device__ __forceinline__ uint32_t evaluate_loaded(const SliceLoad<W>& ld, cons
   return mask;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS traffic, unlike __shfl_up's ds_bpermute):
+// four row_shr steps scan each 16-lane row, row_bcast:15 / row_bcast:31 carry the row totals across rows.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xF, 0xF, false));   // row_shr:1
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xF, 0xF, false));   // row_shr:2
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xF, 0xF, false));   // row_shr:4
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xF, 0xF, false));   // row_shr:8
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+constexpr uint32_t ROW_PAD = 16;   // slack of a wave's compaction buffer: its output range starts anywhere inside a 128-byte line
+
+__device__ __forceinline__ Slice part_slice(const Part& part, const DevSegment& seg, uint32_t i) {
+  Slice slice;
+  slice.chunk = part.chunk;
+  slice.row_begin = part.first_row + i * SLICE_ROWS;
+  slice.row_count = seg.size - slice.row_begin < SLICE_ROWS ? seg.size - slice.row_begin : SLICE_ROWS;
+  slice.first_of_chunk = slice.row_begin == 0;
+  return slice;
+}
+
 // W = 0: generic instantiation (mixed widths, 64-bit / floating point value segments, reference segments,
 // ColumnVsColumn); W = 1 | 2 | 4: streaming instantiation.
 //
-// One workgroup owns one PART at a time (<= 8 slices = 65 536 rows of ONE chunk; parts b, b + gridDim.x, ...):
-//   P1  stream the part once: 32-bit match mask per lane and slice -> LDS (1 KiB per slice) plus the match count of
-//       every (slice, wave).  Streaming instantiations issue the loads of slice s+1 (also across parts) before slice s
-//       is evaluated, so every lane keeps 8 x 16 B in flight.
-//   P2  barrier-free: wave w owns rows [w*2048, (w+1)*2048) of every slice, i.e. a contiguous piece of the output; it
-//       derives its offset from the (slice, wave) counts, expands its masks with one packed prefix sum, compacts row
-//       numbers through its private 4 KiB of LDS and writes coalesced 8-byte RowIDs into the chunk's output region.
+// One workgroup owns one PART at a time (<= 8 slices = 65 536 rows of ONE chunk; parts b, b + gridDim.x, ...) and walks
+// its slices ONCE, in row order.  Per slice (8192 rows; lane l of wave w owns 4 groups of 8 consecutive rows):
+//   evaluate  the slice's loads were issued one slice earlier (also across parts), so every lane keeps 8 x 16 B in
+//             flight while it evaluates; the 32-bit match mask stays in a register
+//   count     per-group popcounts packed into one 64-bit word, ONE DPP prefix scan per half gives every lane its four
+//             output positions inside the wave and the wave its total; the four wave totals meet in LDS (the only
+//             workgroup barrier of the slice)
+//   emit      wave w owns rows [w*2048, (w+1)*2048), i.e. a contiguous piece of the output: it compacts its row numbers
+//             through its private 4 KiB of LDS and writes coalesced 8-byte RowIDs at the running offset of the chunk's
+//             output region.
+// Reads of slice s+1, the ALU work of slice s and the writes of slice s overlap inside every workgroup, and the
+// descriptors of a part (Part, DevSegment, ScanJob) are scalar-loaded one part ahead, off the critical path.
 // A Hyrise chunk (<= 65 535 rows) is one part: NO inter-workgroup communication at all.  Only chunks larger than a
-// part chain their parts: a part publishes its total as one epoch-tagged 8-byte word (agent-scope relaxed atomic; the
-// word is the flag) and reads the totals of the earlier parts of its chunk in parallel (they belong to workgroups
-// that are resident and never wait for later parts, so this cannot deadlock as long as the grid is co-resident).
-// The column is read from HBM exactly once and every RowID is written exactly once, in (chunk, row) order.
+// part chain their parts: such a part first counts its matches (a second, cache-resident read of its rows), publishes
+// the total as one epoch-tagged 8-byte word (agent-scope relaxed atomic; the word is the flag) and reads the totals of
+// the earlier parts of its chunk in parallel (they belong to workgroups that are resident and never wait for later
+// parts, so this cannot deadlock as long as the grid is co-resident).
+// Every RowID is written exactly once, in (chunk, row) order: bit-identical to the CPU loop's appends.
 template <int W>
 __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict__ segments_in, const DevSegment* __restrict__ right_in,
                                                    const Slice* __restrict__ slices_in, const ScanJob* __restrict__ jobs_in,
@@ -799,68 +829,58 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
   a.slices = slices_in;
   a.jobs = jobs_in;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t* s_rows = reinterpret_cast<uint16_t*>(smem);                              // [4 waves][2048] compaction buffers
-  uint32_t* s_masks = reinterpret_cast<uint32_t*>(smem + SLICE_ROWS * 2);            // [PART_SLICES][256]
-  uint32_t* s_wave_count = s_masks + PART_SLICES * WG_THREADS;                       // [PART_SLICES][4]
-  uint32_t* s_small = s_wave_count + PART_SLICES * 4;                                // [16] reductions
+  uint16_t* s_rows = reinterpret_cast<uint16_t*>(smem);                              // [4 waves][2048 + ROW_PAD] compaction buffers
+  uint32_t* s_wave_count = reinterpret_cast<uint32_t*>(smem + (SLICE_ROWS + 4 * ROW_PAD) * 2);   // [2][4] wave totals, double buffered
+  uint32_t* s_small = s_wave_count + 8;                                              // [16] reductions
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64();
 
-  // streaming state: loads of the next slice to evaluate (possibly of the next part)
-  SliceLoad<(W == 0 ? 1 : W)> next;
-  Slice slice{0, 0, 0, 0};
-  DevSegment seg;
-  ScanJob job;
-  if constexpr (W != 0) {
-    if (blockIdx.x < a.n_parts) {
-      slice = a.slices[parts[blockIdx.x].first_slice];
-      seg = a.segments[slice.chunk];
-      job = a.jobs[slice.chunk];
-      issue_loads<W>(next, seg, job, slice, wave, lane);
+  constexpr int LW = W == 0 ? 1 : W;
+  SliceLoad<LW> next;   // streaming state: loads of the next slice to evaluate (possibly of the next part)
+  uint32_t part_id = blockIdx.x;
+  Part part{};
+  DevSegment seg{};
+  ScanJob job{};
+  if (part_id < a.n_parts) {
+    part = parts[part_id];
+    seg = a.segments[part.chunk];
+    if constexpr (W != 0) {
+      job = a.jobs[part.chunk];
+      issue_loads<W>(next, seg, job, part_slice(part, seg, 0), wave, lane);
     }
   }
 
-  for (uint32_t part_id = blockIdx.x; part_id < a.n_parts; part_id += gridDim.x) {
-    const Part part = parts[part_id];
-    const uint32_t begin = part.first_slice, end = part.first_slice + part.n_slices;
-
-    // ---- P1: evaluate, keep the masks in LDS ----------------------------------------------------------------------------
-    for (uint32_t s = begin; s < end; ++s) {
-      uint32_t mask;
-      if constexpr (W == 0) {
-        const Slice this_slice = a.slices[s];
-        const DevSegment this_seg = a.segments[this_slice.chunk];
-        mask = evaluate_slice(a, this_slice, this_seg, wave, lane);
-      } else {
-        const SliceLoad<W> current = next;
-        const Slice current_slice = slice;
-        const DevSegment current_seg = seg;
-        const ScanJob current_job = job;
-        uint32_t upcoming = s + 1;
-        if (upcoming == end) upcoming = part_id + gridDim.x < a.n_parts ? parts[part_id + gridDim.x].first_slice : a.n_slices;
-        if (upcoming < a.n_slices) {
-          slice = a.slices[upcoming];
-          seg = a.segments[slice.chunk];
-          job = a.jobs[slice.chunk];
-          issue_loads<W>(next, seg, job, slice, wave, lane);
-        }
-        mask = evaluate_loaded<W>(current, current_seg, current_job, current_slice, a.materialize_all, wave, lane);
-      }
-      s_masks[(s - begin) * WG_THREADS + tid] = mask;
-      uint32_t count = __popc(mask);
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d, 64);
-      if (lane == 0) s_wave_count[(s - begin) * 4 + wave] = count;
+  uint32_t parity = 0;
+  while (part_id < a.n_parts) {
+    const uint32_t next_part_id = part_id + gridDim.x;
+    Part next_part = part;
+    DevSegment next_seg = seg;
+    ScanJob next_job = job;
+    if (next_part_id < a.n_parts) {   // one part ahead: these scalar loads complete long before they are needed
+      next_part = parts[next_part_id];
+      next_seg = a.segments[next_part.chunk];
+      if constexpr (W != 0) next_job = a.jobs[next_part.chunk];
     }
-    __syncthreads();
-    uint32_t part_total = 0;
-    for (uint32_t i = 0; i < part.n_slices * 4; ++i) part_total += s_wave_count[i];
-    if (a.trace && tid == 0 && part_id == blockIdx.x) a.trace[blockIdx.x * 4 + 1] = wall_clock64();
 
     // ---- chunks larger than one part: matches in the earlier parts of the same chunk -------------------------------------
     uint32_t before = 0;
     if (part.parts_in_chunk > 1) {
+      uint32_t mine = 0;
+      for (uint32_t i = 0; i < part.n_slices; ++i) {
+        const Slice slice = part_slice(part, seg, i);
+        if constexpr (W == 0) {
+          mine += __popc(evaluate_slice(a, slice, seg, wave, lane));
+        } else {
+          SliceLoad<W> again;
+          issue_loads<W>(again, seg, job, slice, wave, lane);
+          mine += __popc(evaluate_loaded<W>(again, seg, job, slice, a.materialize_all, wave, lane));
+        }
+      }
+      mine = __builtin_amdgcn_readlane(wave_inclusive_scan_u32(mine), 63);
+      if (lane == 0) s_small[wave] = mine;
+      __syncthreads();
+      const uint32_t part_total = s_small[0] + s_small[1] + s_small[2] + s_small[3];
       if (tid == 0) __hip_atomic_store(&a.status[part_id], (static_cast<uint64_t>(a.epoch) << 32) | part_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (uint32_t i = part.first_part + tid; i < part_id; i += WG_THREADS) {
         uint64_t word;
@@ -870,53 +890,66 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
         } while (static_cast<uint32_t>(word >> 32) != a.epoch);
         before += static_cast<uint32_t>(word);
       }
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+      before = __builtin_amdgcn_readlane(wave_inclusive_scan_u32(before), 63);
       if (lane == 0) s_small[4 + wave] = before;
       __syncthreads();
       before = s_small[4] + s_small[5] + s_small[6] + s_small[7];
     }
-    if (a.trace && tid == 0 && part_id == blockIdx.x) a.trace[blockIdx.x * 4 + 2] = wall_clock64();
 
     // ---- per-chunk outputs ------------------------------------------------------------------------------------------------
-    if (tid == 0) {
-      uint32_t mode = JOB_SCAN;
-      const DevSegment chunk_seg = a.segments[part.chunk];
-      if (!a.right) {
-        if (chunk_seg.encoding != HY_ENC_REFERENCE) mode = a.jobs[part.chunk].mode;
-        else if (chunk_seg.ref_chunk_id != 0xFFFFFFFFu && chunk_seg.size > 0) mode = a.jobs[chunk_seg.ref_chunk_id].mode;
-      }
-      if (part.part_in_chunk == 0) {
-        a.offsets[part.chunk] = part.region_base;
-        if (a.chunk_state) a.chunk_state[part.chunk] = mode == JOB_ALL ? HY_CHUNK_ALL_MATCH : mode == JOB_NONE ? HY_CHUNK_NONE_MATCH : HY_CHUNK_SCANNED;
-        if (part.chunk + 1 == a.n_chunks) a.offsets[a.n_chunks] = part.region_base + chunk_seg.size;
-      }
-      if (part.part_in_chunk + 1 == part.parts_in_chunk && a.counts) a.counts[part.chunk] = mode == JOB_ALL ? chunk_seg.size : before + part_total;
+    uint32_t mode = JOB_SCAN;
+    if (!a.right) {
+      if (seg.encoding != HY_ENC_REFERENCE) mode = a.jobs[part.chunk].mode;
+      else if (seg.ref_chunk_id != 0xFFFFFFFFu && seg.size > 0) mode = a.jobs[seg.ref_chunk_id].mode;
+    }
+    if (tid == 0 && part.part_in_chunk == 0) {
+      a.offsets[part.chunk] = part.region_base;
+      if (a.chunk_state) a.chunk_state[part.chunk] = mode == JOB_ALL ? HY_CHUNK_ALL_MATCH : mode == JOB_NONE ? HY_CHUNK_NONE_MATCH : HY_CHUNK_SCANNED;
+      if (part.chunk + 1 == a.n_chunks) a.offsets[a.n_chunks] = part.region_base + seg.size;
     }
 
-    // ---- P2 (no workgroup barriers): every wave expands its own rows ----------------------------------------------------
-    uint64_t offset = part.region_base + before;
-    uint16_t* my_rows = s_rows + wave * 2048;
-    for (uint32_t s = begin; s < end && part_total != 0; ++s) {
-      const uint32_t* counts = s_wave_count + (s - begin) * 4;
-      const uint32_t c0 = counts[0], c1 = counts[1], c2 = counts[2], c3 = counts[3];
-      const uint32_t slice_total = c0 + c1 + c2 + c3;
-      const uint32_t my_total = wave == 0 ? c0 : wave == 1 ? c1 : wave == 2 ? c2 : c3;
-      const uint64_t my_offset = offset + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+    // ---- the slices of the part, in row order -----------------------------------------------------------------------------
+    uint32_t emitted = before;   // matches of this chunk before the current slice
+    uint16_t* my_rows = s_rows + wave * (2048 + ROW_PAD);
+    for (uint32_t i = 0; i < part.n_slices; ++i) {
+      const Slice slice = part_slice(part, seg, i);
+      uint32_t mask;
+      if constexpr (W == 0) {
+        mask = evaluate_slice(a, slice, seg, wave, lane);
+      } else {
+        const SliceLoad<W> current = next;
+        if (i + 1 < part.n_slices) issue_loads<W>(next, seg, job, part_slice(part, seg, i + 1), wave, lane);
+        else if (next_part_id < a.n_parts) issue_loads<W>(next, next_seg, next_job, part_slice(next_part, next_seg, 0), wave, lane);
+        mask = evaluate_loaded<W>(current, seg, job, slice, a.materialize_all, wave, lane);
+      }
+      // positions: fields of 16 bits, group k of the lane in field k (a wave holds at most 512 matches per group)
+      const uint32_t packed_lo = __popc(mask & 0xFFu) | (__popc(mask & 0xFF00u) << 16);
+      const uint32_t packed_hi = __popc(mask & 0xFF0000u) | (__popc(mask >> 24) << 16);
+      const uint32_t inclusive_lo = wave_inclusive_scan_u32(packed_lo), inclusive_hi = wave_inclusive_scan_u32(packed_hi);
+      const uint32_t totals_lo = __builtin_amdgcn_readlane(inclusive_lo, 63), totals_hi = __builtin_amdgcn_readlane(inclusive_hi, 63);
+      const uint32_t t0 = totals_lo & 0xFFFF, t1 = totals_lo >> 16, t2 = totals_hi & 0xFFFF, t3 = totals_hi >> 16;
+      const uint32_t my_total = t0 + t1 + t2 + t3;
+      uint32_t* counts = s_wave_count + parity * 4;
+      parity ^= 1;
+      if (lane == 0) counts[wave] = my_total;
+      __syncthreads();
+      const uint32_t c0 = __builtin_amdgcn_readfirstlane(counts[0]), c1 = __builtin_amdgcn_readfirstlane(counts[1]),
+                     c2 = __builtin_amdgcn_readfirstlane(counts[2]), c3 = __builtin_amdgcn_readfirstlane(counts[3]);
+      const uint32_t my_offset = emitted + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+      emitted += c0 + c1 + c2 + c3;
       if (my_total != 0) {
-        const uint32_t row_begin = part.first_row + (s - begin) * SLICE_ROWS;
-        const uint32_t mask = s_masks[(s - begin) * WG_THREADS + tid];
-        const uint64_t packed = static_cast<uint64_t>(__popc(mask & 0xFFu)) | (static_cast<uint64_t>(__popc(mask & 0xFF00u)) << 16) |
-                                (static_cast<uint64_t>(__popc(mask & 0xFF0000u)) << 32) | (static_cast<uint64_t>(__popc(mask >> 24)) << 48);
-        const uint64_t inclusive = wave_inclusive_scan(packed, lane);
-        const uint64_t totals = __shfl(inclusive, 63, 64);       // per-load totals of this wave
-        const uint64_t exclusive = inclusive - packed;
-        const uint32_t t0 = totals & 0xFFFF, t1 = (totals >> 16) & 0xFFFF, t2 = (totals >> 32) & 0xFFFF;
-        const uint32_t e0 = exclusive & 0xFFFF, e1 = (exclusive >> 16) & 0xFFFF, e2 = (exclusive >> 32) & 0xFFFF, e3 = exclusive >> 48;
-        const uint32_t base_k[4] = {e0, t0 + e1, t0 + t1 + e2, t0 + t1 + t2 + e3};
+        // The wave's RowIDs go to elements [first, first + my_total) of the output.  The compaction buffer is laid out so
+        // that LDS slot q is output element  line + q,  line = first rounded down to a 128-byte line (16 RowIDs):
+        // every store instruction of the body then writes 64 x 16 B = 8 whole, aligned lines.
+        const uint64_t first = part.region_base + my_offset;
+        const uint32_t skew = static_cast<uint32_t>(first) & 15u;
+        const uint32_t exclusive_lo = inclusive_lo - packed_lo, exclusive_hi = inclusive_hi - packed_hi;
+        const uint32_t base_k[4] = {skew + (exclusive_lo & 0xFFFF), skew + t0 + (exclusive_lo >> 16), skew + t0 + t1 + (exclusive_hi & 0xFFFF),
+                                    skew + t0 + t1 + t2 + (exclusive_hi >> 16)};
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
           uint32_t m = (mask >> (8 * k)) & 0xFFu;
+          if (a.debug & 2) m = 0;
           uint32_t p = base_k[k];
           const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
           while (m) {
@@ -926,17 +959,36 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
           }
         }
         __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order; this only stops reordering
-        if (my_offset + my_total > a.capacity) {
+        if (first + my_total > a.capacity) {
           if (lane == 0) *a.overflow = 1;
-        } else {
-          uint2* out = reinterpret_cast<uint2*>(a.matches + my_offset);
-          for (uint32_t i = lane; i < my_total; i += 64) out[i] = make_uint2(part.chunk, row_begin + my_rows[i]);
+        } else if (!(a.debug & 1)) {
+          // RowIDs are written once and not read again by this kernel: nontemporal, 16 bytes (two RowIDs) per lane
+          HY_GLOBAL u32x4* out = (HY_GLOBAL u32x4*)(a.matches + (first - skew));
+          const uint32_t* pairs = reinterpret_cast<const uint32_t*>(my_rows);
+          const uint32_t end = skew + my_total;
+          for (uint32_t q = lane; 2 * q < end; q += 64) {
+            const uint32_t two = pairs[q];
+            const uint32_t row_a = slice.row_begin + (two & 0xFFFFu), row_b = slice.row_begin + (two >> 16);
+            if (2 * q >= skew && 2 * q + 1 < end) {
+              const u32x4 v = {part.chunk, row_a, part.chunk, row_b};
+              __builtin_nontemporal_store(v, out + q);
+            } else {   // the (at most two) pairs that straddle the ends of the wave's range
+              HY_GLOBAL u32x2* single = (HY_GLOBAL u32x2*)(out + q);
+              if (2 * q >= skew) { const u32x2 v = {part.chunk, row_a}; __builtin_nontemporal_store(v, single); }
+              if (2 * q + 1 >= skew && 2 * q + 1 < end) { const u32x2 v = {part.chunk, row_b}; __builtin_nontemporal_store(v, single + 1); }
+            }
+          }
         }
         __builtin_amdgcn_wave_barrier();
       }
-      offset += slice_total;
     }
-    __syncthreads();   // s_masks / s_wave_count / s_small are reused by the next part
+    if (tid == 0 && part.part_in_chunk + 1 == part.parts_in_chunk && a.counts) a.counts[part.chunk] = mode == JOB_ALL ? seg.size : emitted;
+    if (a.trace && tid == 0 && part_id == blockIdx.x) a.trace[blockIdx.x * 4 + 1] = wall_clock64();
+
+    part_id = next_part_id;
+    part = next_part;
+    seg = next_seg;
+    job = next_job;
   }
   if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 3] = wall_clock64();
 }
@@ -966,7 +1018,7 @@ __global__ void compact_regions(const hy_row_id* regions, const uint64_t* region
 // query admits (ROCm 7.2 over-reports by one for SGPR-heavy 256-thread kernels, MI355X_MICROARCH.md "Residency and
 // cooperative launch").
 using ScanKernel = void (*)(const DevSegment*, const DevSegment*, const Slice*, const ScanJob*, const Part*, ScanArgs);
-constexpr size_t SCAN_LDS_BYTES = SLICE_ROWS * 2 + PART_SLICES * (WG_THREADS * 4 + 16) + 64;
+constexpr size_t SCAN_LDS_BYTES = (SLICE_ROWS + 4 * ROW_PAD) * 2 + 8 * 4 + 16 * 4;   // compaction buffers | wave totals | reductions
 
 static uint32_t scan_grid(ScanKernel kernel, uint32_t n_parts) {
   int device = 0, cus = 256;
@@ -1094,6 +1146,7 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     a.materialize_all = pa.materialize_all;
     a.is_null_scan = predicate && predicate->condition == HY_PRED_IS_NULL;
     a.epoch = sc.epoch;
+    a.debug = getenv("HY_SCAN_DEBUG") ? atoi(getenv("HY_SCAN_DEBUG")) : 0;
     a.status = sc.status;
     a.matches = d_matches;
     a.capacity = device_capacity;
