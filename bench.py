@@ -25,6 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROFILE_EVERY = 4               # every 4th scan of the timed region carries the HIP event pair (a timed launch costs ~7 us of stream time)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -162,7 +163,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    abi.check(lib.hy_set_profiling(1))
+    abi.check(lib.hy_set_profiling(0 if os.environ.get("HY_BENCH_NO_EVENTS") else PROFILE_EVERY))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -201,7 +202,7 @@ def main():
                            ("point_eq_1995-06-17", make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, tpch.CURRENT_DATE))):
             for _ in range(3):
                 step(pred)
-            abi.check(lib.hy_set_profiling(1))
+            abi.check(lib.hy_set_profiling(PROFILE_EVERY))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):

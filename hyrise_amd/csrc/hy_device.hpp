@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -102,6 +103,7 @@ hipStream_t current_stream();
 // Optional HIP-event bracket around the dominant kernel of an operator call (hy_set_profiling / hy_last_kernel_ms).
 void profile_begin(hipStream_t stream);
 void profile_end(hipStream_t stream);
+bool profile_events(hipEvent_t* start, hipEvent_t* stop);   // per-kernel pair for hipExtLaunchKernelGGL
 
 // ---- per-thread scratch (status words for decoupled look-back, job tables, temporaries) ----------------------------
 // Every operator call of a thread reuses one growing arena; thread-safe because it is thread-local, as are streams.

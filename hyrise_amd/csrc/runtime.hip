@@ -27,6 +27,9 @@ hipStream_t current_stream() { return t_stream; }
 
 struct Profile {
   bool enabled = false;
+  uint32_t period = 1;              // every period-th bracket is timed (timed launches cost ~7 us of stream time each)
+  uint32_t counter = 0;
+  bool open = false;                // profile_begin recorded, profile_end pending
   std::vector<hipEvent_t> events;   // start/stop pairs, reused across profiling sessions
   size_t used = 0;
 };
@@ -42,14 +45,31 @@ static hipEvent_t next_event() {
   return p.events[p.used++];
 }
 
+static bool sampled() {
+  Profile& p = t_profile;
+  if (!p.enabled || p.used >= 16384) return false;
+  return p.counter++ % p.period == 0;
+}
+
 void profile_begin(hipStream_t stream) {
-  if (!t_profile.enabled || t_profile.used >= 16384) return;
-  (void)hipEventRecord(next_event(), stream);
+  t_profile.open = sampled();
+  if (t_profile.open) (void)hipEventRecord(next_event(), stream);
 }
 
 void profile_end(hipStream_t stream) {
-  if (!t_profile.enabled || (t_profile.used & 1) == 0) return;
+  if (!t_profile.open) return;
+  t_profile.open = false;
   (void)hipEventRecord(next_event(), stream);
+}
+
+// A start/stop pair for ONE kernel: handed to hipExtLaunchKernelGGL, which stamps them from the dispatch packet itself
+// (no extra barrier packets on the stream, unlike hipEventRecord before and after the launch).
+bool profile_events(hipEvent_t* start, hipEvent_t* stop) {
+  *start = *stop = nullptr;
+  if (!sampled()) return false;
+  *start = next_event();
+  *stop = next_event();
+  return true;
 }
 
 Scratch& scratch() { return t_scratch; }
@@ -145,7 +165,10 @@ hy_status hy_init(int32_t device) {
 }
 
 hy_status hy_set_profiling(int32_t enabled) {
-  t_profile.enabled = enabled != 0;
+  t_profile.enabled = enabled > 0;
+  t_profile.period = enabled > 1 ? static_cast<uint32_t>(enabled) : 1;
+  t_profile.counter = 0;
+  t_profile.open = false;
   t_profile.used = 0;
   return HY_OK;
 }

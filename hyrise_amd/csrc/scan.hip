@@ -13,14 +13,13 @@
 //                     integers / value ids:  ((u)(x - lo) <= span) ^ invert        (type_comparison.hpp:120-132)
 //                     float / double:        lower/upper compares with inclusive flags, ^ invert
 //                     null test:             bitmap bit / value id == null id
-//   scan_slices   one workgroup per slice (<= 8192 consecutive rows of one chunk).  Each lane streams 4 x 8 rows with
-//                 16-byte loads (8 rows of a 2-byte attribute vector per load, 1 KiB per wave instruction), builds a
-//                 32-bit match mask, the wave does one packed prefix sum, the workgroup's total goes through a
-//                 single-pass decoupled look-back (epoch-tagged 8-byte status words, agent-scope relaxed atomics: the
-//                 word IS the flag) to obtain its global output offset, matches are compacted through LDS and written
-//                 as coalesced 8-byte RowIDs.  PosLists therefore come out back to back, per chunk, ascending --
+//   scan_slices   persistent; one workgroup per PART (<= 8 slices of 8192 rows of ONE chunk -- a Hyrise chunk is one part).
+//                 Per slice: 16-byte loads issued one slice ahead, a packed two-rows-per-instruction range test, one
+//                 DPP prefix scan, compaction of the row numbers through LDS and line-aligned nontemporal 16-byte
+//                 stores of RowID pairs into the chunk's own output region (region c starts at row_base[c], so no
+//                 global prefix sum and no inter-workgroup traffic).  PosLists come out per chunk, ascending --
 //                 bit-identical to what the CPU loop appends -- with the column read exactly once.
-//   finalize      per-chunk counts / states.
+//   compact_regions  (host results only) packs the regions back to back.
 // HBM-bound integer work: no MFMA anywhere.
 #include "hy_device.hpp"
 
@@ -121,35 +120,28 @@ __device__ bool integer_range(uint32_t cond, Wide v, Wide v2, Wide tmin, Wide tm
   return *lo <= *hi;
 }
 
-// One 256-thread workgroup per DATA chunk of the scanned column (for reference columns: of the referenced column).
-// Wave w runs one of the (up to) four dictionary searches -- lower/upper bound of value and of value2 -- as a
-// cooperative 64-ary search, so a chunk costs two or three dependent loads instead of ~50.
-__global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, PredicateArgs p, ScanJob* jobs, uint32_t* overflow) {
-  __shared__ uint32_t s_bound[4];
-  const uint32_t c = blockIdx.x;
-  if (c == 0 && threadIdx.x == 0) *overflow = 0;
-  if (c >= n_chunks) return;
-  {
-    const DevSegment seg = segments[c];
-    const uint32_t cond0 = p.condition;
-    const bool searchable = seg.encoding == HY_ENC_DICTIONARY && seg.aux && seg.data_type != HY_TYPE_STRING &&
-                            cond0 != HY_PRED_IS_NULL && cond0 != HY_PRED_IS_NOT_NULL;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (searchable && (wave < 2 || is_between(cond0))) {
-      uint32_t r;
-      switch (seg.data_type) {
-        case HY_TYPE_INT: r = wave_search<int32_t>(seg, p.value.i32, p.value2.i32, wave, lane); break;
-        case HY_TYPE_LONG: r = wave_search<int64_t>(seg, p.value.i64, p.value2.i64, wave, lane); break;
-        case HY_TYPE_FLOAT: r = wave_search<float>(seg, p.value.f32, p.value2.f32, wave, lane); break;
-        default: r = wave_search<double>(seg, p.value.f64, p.value2.f64, wave, lane); break;
-      }
-      if (lane == 0) s_bound[wave] = r;
-    }
+// ---- predicate -> ScanJob of one chunk --------------------------------------------------------------------------------------
+// (Deriving the job at the head of each part inside scan_slices instead was measured: the four dependent loads cost the
+// scan kernel what the separate launch costs the stream, ~4 us either way, so the separate kernel stays.)
+//   job_search   wave w runs one of the (up to) four dictionary searches -- lower/upper bound of value and of value2 -- as a
+//                cooperative 64-ary search, so a chunk costs two or three dependent loads instead of ~50
+//   finish_job   the scalar rules of the reference's scan implementations on the four bounds
+__device__ __forceinline__ bool job_searches(const DevSegment& seg, uint32_t cond, uint32_t wave) {
+  const bool searchable = seg.encoding == HY_ENC_DICTIONARY && seg.aux && seg.data_type != HY_TYPE_STRING &&
+                          cond != HY_PRED_IS_NULL && cond != HY_PRED_IS_NOT_NULL;
+  return searchable && (wave < 2 || is_between(cond));
+}
+
+__device__ __forceinline__ uint32_t job_search(const DevSegment& seg, const PredicateArgs& p, uint32_t wave, uint32_t lane) {
+  switch (seg.data_type) {
+    case HY_TYPE_INT: return wave_search<int32_t>(seg, p.value.i32, p.value2.i32, wave, lane);
+    case HY_TYPE_LONG: return wave_search<int64_t>(seg, p.value.i64, p.value2.i64, wave, lane);
+    case HY_TYPE_FLOAT: return wave_search<float>(seg, p.value.f32, p.value2.f32, wave, lane);
+    default: return wave_search<double>(seg, p.value.f64, p.value2.f64, wave, lane);
   }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  const DevSegment s = segments[c];
-  ScanJob job;
+}
+
+__device__ __forceinline__ void finish_job(const DevSegment& s, uint32_t c, const PredicateArgs& p, const uint32_t* s_bound, ScanJob& job) {
   job.mode = JOB_SCAN;
   job.kind = KIND_U32;
   job.flags = 0;
@@ -171,7 +163,6 @@ __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, 
       job.kind = KIND_NULLTEST;
       job.flags = is_null ? 0 : JF_INVERT;
     }
-    jobs[c] = job;
     return;
   }
 
@@ -248,7 +239,6 @@ __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, 
         set_value_id_range(job, range_lo, range_hi, invert);
       }
     }
-    jobs[c] = job;
     return;
   }
 
@@ -314,6 +304,24 @@ __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, 
     }
     default: job.mode = JOB_NONE; break;
   }
+}
+
+// One 256-thread workgroup per DATA chunk of the scanned column (for reference columns: of the referenced column).
+__global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, PredicateArgs p, ScanJob* jobs, uint32_t* overflow) {
+  __shared__ uint32_t s_bound[4];
+  const uint32_t c = blockIdx.x;
+  if (c == 0 && threadIdx.x == 0) *overflow = 0;
+  if (c >= n_chunks) return;
+  const DevSegment seg = segments[c];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (job_searches(seg, p.condition, wave)) {
+    const uint32_t r = job_search(seg, p, wave, lane);
+    if (lane == 0) s_bound[wave] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  ScanJob job;
+  finish_job(seg, c, p, s_bound, job);
   jobs[c] = job;
 }
 
@@ -545,7 +553,7 @@ struct ScanArgs {
   uint64_t* offsets;               // [n_chunks + 1] region starts
   uint32_t* counts;                // [n_chunks] or nullptr
   uint8_t* chunk_state;            // [n_chunks] or nullptr
-  uint32_t* overflow;              // set to 1 if capacity was exceeded
+  uint32_t* overflow;              // set to 1 if capacity was exceeded (a persistent, normally-zero word of the scratch)
   uint64_t* trace;                 // debug: 4 wall-clock stamps per workgroup (HY_SCAN_TRACE), else nullptr
 };
 
@@ -683,106 +691,161 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
 }
 
 
-// Slim scalar evaluation for the streaming instantiations (the one partial 8-row group at the end of a chunk).
-__device__ __forceinline__ bool eval_row_u32(const DevSegment& s, const ScanJob& job, uint32_t row) {
-  const bool invert = job.flags & JF_INVERT;
-  const uint32_t raw = load_compressed(s.data, s.width, row);
-  if (s.encoding == HY_ENC_DICTIONARY) {
-    const bool in = (raw - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
-    return (in != invert) && raw != job.null_vid;
-  }
-  const bool is_null = s.nulls ? ((s.nulls[row >> 6] >> (row & 63)) & 1) != 0 : false;
-  if (job.kind == KIND_NULLTEST) return is_null != invert;
-  if (is_null) return false;
-  const uint32_t bias = s.encoding == HY_ENC_FRAME_OF_REFERENCE ? static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]) : 0u;
-  const bool in = (raw + bias - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
-  return in != invert;
-}
-
+// ---- streaming instantiations (W = 1 | 2 | 4): every segment of the column is a W-byte attribute vector, FoR offset vector
+// or int32 value vector.  Lane l of wave w owns, per slice, the four 8-row groups  w*2048 + k*512 + l*8  (k = 0..3).
+// A group is always loaded whole (one aligned 8*W-byte access): a group that holds at least one row of the segment lies
+// in the same page as that row, so the bytes past the end of the last group are readable; they are masked out below.
 template <int W>
 struct SliceLoad {
   RawGroup<W> raw[4];
   uint32_t null_byte[4];
-  uint32_t bias[4];
+  uint32_t bias;          // FrameOfReference: minimum of the wave's 2048-row block (a wave's rows never straddle blocks)
 };
 
 template <int W>
 __device__ __forceinline__ void issue_loads(SliceLoad<W>& ld, const DevSegment& seg, const ScanJob& job, const Slice& slice, uint32_t wave, uint32_t lane) {
-  const bool wanted = job.mode == JOB_SCAN && !(job.flags & JF_NEVER);
-  const bool is_for = seg.encoding == HY_ENC_FRAME_OF_REFERENCE;
+  ld.bias = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) ld.null_byte[k] = 0;
+  if (job.mode != JOB_SCAN || (job.flags & JF_NEVER) || slice.row_count == 0) return;
   const bool has_bitmap = seg.nulls != nullptr && seg.encoding != HY_ENC_DICTIONARY;
+  const uint32_t last_group = (slice.row_count - 1) & ~7u;
 #pragma unroll
   for (uint32_t k = 0; k < 4; ++k) {
-    const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+    uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+    if (slice.row_count != SLICE_ROWS) r0 = r0 < last_group ? r0 : last_group;   // groups past the end re-read the last one
     const uint32_t row = slice.row_begin + r0;
-    ld.null_byte[k] = 0;
-    ld.bias[k] = 0;
-    if (wanted && r0 + 8 <= slice.row_count) {
-      ld.raw[k] = load_group<W>(seg.data, row);
-      if (has_bitmap) ld.null_byte[k] = as_global<uint8_t>(seg.nulls)[row >> 3];
-      if (is_for) ld.bias[k] = static_cast<uint32_t>(as_global<int32_t>(seg.aux)[row / HY_FOR_BLOCK_SIZE]);
-    }
+    ld.raw[k] = load_group<W>(seg.data, row);
+    if (has_bitmap) ld.null_byte[k] = as_global<uint8_t>(seg.nulls)[row >> 3];
   }
+  if (seg.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+    uint32_t r0 = __builtin_amdgcn_readfirstlane(wave) * 2048;
+    r0 = r0 < last_group ? r0 : last_group;
+    ld.bias = static_cast<uint32_t>(as_global<int32_t>(seg.aux)[(slice.row_begin + r0) / HY_FOR_BLOCK_SIZE]);
+  }
+}
+
+// Packed 16-bit range test of two rows at once: 1 in a half  <=>  that row is OUTSIDE [lo, lo + span].
+// (inline assembly: written with builtins the compiler turns the saturating subtract back into compares + selects)
+__device__ __forceinline__ uint32_t pk_outside(uint32_t two_rows, uint32_t lo2, uint32_t span2, uint32_t one2) {
+  uint32_t x, t, r;
+  asm("v_pk_sub_u16 %0, %1, %2" : "=v"(x) : "v"(two_rows), "v"(lo2));
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(t) : "v"(x), "v"(span2));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(t), "v"(one2));
+  return r;
+}
+// 1 in a half  <=>  that row differs from `value`
+__device__ __forceinline__ uint32_t pk_differs(uint32_t two_rows, uint32_t value2, uint32_t one2) {
+  uint32_t x, r;
+  asm("v_pk_sub_u16 %0, %1, %2" : "=v"(x) : "v"(two_rows), "v"(value2));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(one2));
+  return r;
+}
+
+// Rows of a group as four dwords of two 16-bit lanes each (row 2i in the low half of dword i).
+template <int W>
+__device__ __forceinline__ void packed_rows(const RawGroup<W>& g, uint32_t (&d)[4]) {
+  if constexpr (W == 2) {
+    d[0] = g.v.x; d[1] = g.v.y; d[2] = g.v.z; d[3] = g.v.w;
+  } else {
+    static_assert(W == 1, "packed evaluation is for 8- and 16-bit elements");
+    d[0] = __builtin_amdgcn_perm(g.v.x, g.v.x, 0x0c010c00u); d[1] = __builtin_amdgcn_perm(g.v.x, g.v.x, 0x0c030c02u);
+    d[2] = __builtin_amdgcn_perm(g.v.y, g.v.y, 0x0c010c00u); d[3] = __builtin_amdgcn_perm(g.v.y, g.v.y, 0x0c030c02u);
+  }
+}
+
+// Per-row flags of two groups: bit (8*g + r) <-> row r of group g.  `flag(dword)` returns 0/1 in each 16-bit half.
+template <int W, typename Flag>
+__device__ __forceinline__ uint32_t two_groups(const RawGroup<W>& g0, const RawGroup<W>& g1, Flag flag) {
+  uint32_t d0[4], d1[4];
+  packed_rows<W>(g0, d0);
+  packed_rows<W>(g1, d1);
+  uint32_t acc = 0;   // even rows collect in bits 0..15, odd rows 16 higher
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc |= (flag(d0[i]) << (2 * i)) | (flag(d1[i]) << (8 + 2 * i));
+  return (acc | (acc >> 15)) & 0xFFFFu;
 }
 
 template <int W>
 __device__ __forceinline__ uint32_t evaluate_loaded(const SliceLoad<W>& ld, const DevSegment& seg, const ScanJob& job, const Slice& slice,
                                                     uint32_t materialize_all, uint32_t wave, uint32_t lane) {
-  uint32_t mask = 0;
-  if (job.mode == JOB_SCAN && !(job.flags & JF_NEVER)) {
-    const uint32_t inv = (job.flags & JF_INVERT) ? 0xFFu : 0u;
-    const uint32_t lo = static_cast<uint32_t>(job.lo), span = static_cast<uint32_t>(job.span);
-    const bool is_dict = seg.encoding == HY_ENC_DICTIONARY;
+  uint32_t valid = 0xFFFFFFFFu;   // rows of the lane's groups that exist
+  if (slice.row_count != SLICE_ROWS) {
+    valid = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
       const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
-      uint32_t bits = 0;
-      if (r0 + 8 <= slice.row_count) {
-        if (job.kind == KIND_NULLTEST) {
-          bits = (ld.null_byte[k] ^ inv) & 0xFFu;
-        } else {
-          uint32_t x[8];
-          unpack_group<W>(ld.raw[k], x);
-          bits = range_bits8(x, lo - ld.bias[k], span) ^ inv;
-          if (is_dict) {
-            if (inv) {   // != : NULL (value id == dictionary size) never matches
-              uint32_t nullbits = 0;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) nullbits |= (x[j] == job.null_vid ? 1u : 0u) << j;
-              bits &= ~nullbits;
-            }
-          } else {
-            bits &= ~ld.null_byte[k];
-          }
-          bits &= 0xFFu;
-        }
-      } else if (r0 < slice.row_count) {   // the one partial group at the end of a chunk
-        for (uint32_t j = 0; r0 + j < slice.row_count; ++j) bits |= (eval_row_u32(seg, job, slice.row_begin + r0 + j) ? 1u : 0u) << j;
-      }
-      mask |= bits << (8 * k);
-    }
-  } else if (job.mode == JOB_ALL && materialize_all) {
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-      const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
-      if (r0 < slice.row_count) {
-        const uint32_t valid = (slice.row_count - r0 < 8) ? slice.row_count - r0 : 8;
-        mask |= ((1u << valid) - 1u) << (8 * k);
-      }
+      const uint32_t rows = r0 >= slice.row_count ? 0u : (slice.row_count - r0 < 8 ? slice.row_count - r0 : 8u);
+      valid |= ((1u << rows) - 1u) << (8 * k);
     }
   }
-  return mask;
+  if (job.mode == JOB_ALL) return materialize_all ? valid : 0u;
+  if (job.mode != JOB_SCAN || (job.flags & JF_NEVER)) return 0u;
+
+  const bool invert = job.flags & JF_INVERT;
+  const uint32_t null_bits = ld.null_byte[0] | (ld.null_byte[1] << 8) | (ld.null_byte[2] << 16) | (ld.null_byte[3] << 24);   // 0 for dictionaries
+  if (job.kind == KIND_NULLTEST) return (invert ? ~null_bits : null_bits) & valid;
+
+  const bool is_dict = seg.encoding == HY_ENC_DICTIONARY;
+  uint32_t inside;   // rows whose value lies in [lo, lo + span]
+  uint32_t not_null = ~null_bits;
+  if constexpr (W == 4) {
+    const uint32_t lo = static_cast<uint32_t>(job.lo) - ld.bias, span = static_cast<uint32_t>(job.span);
+    inside = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      uint32_t x[8];
+      unpack_group<W>(ld.raw[k], x);
+      inside |= range_bits8(x, lo, span) << (8 * k);
+      if (is_dict && invert) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) not_null &= ~((x[j] == job.null_vid ? 1u : 0u) << (8 * k + j));
+      }
+    }
+  } else {
+    // The stored elements are < 2^(8W): clip the range to that domain once per wave and compare two rows per
+    // instruction.  In terms of the stored element x the predicate is  lo - bias <= x <= lo - bias + span.
+    constexpr int64_t max_element = (int64_t{1} << (8 * W)) - 1;
+    const int64_t low = static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(job.lo))) - static_cast<int32_t>(ld.bias);
+    const int64_t high = low + static_cast<int64_t>(static_cast<uint32_t>(job.span));
+    const int64_t clipped_low = low < 0 ? 0 : low, clipped_high = high > max_element ? max_element : high;
+    if (clipped_low > clipped_high) {
+      inside = 0;
+    } else {
+      const uint32_t one2 = 0x00010001u;
+      const uint32_t lo2 = static_cast<uint32_t>(clipped_low) * 0x00010001u, span2 = static_cast<uint32_t>(clipped_high - clipped_low) * 0x00010001u;
+      auto outside = [&](uint32_t d) { return pk_outside(d, lo2, span2, one2); };
+      inside = ~(two_groups<W>(ld.raw[0], ld.raw[1], outside) | (two_groups<W>(ld.raw[2], ld.raw[3], outside) << 16));
+    }
+    if (is_dict && invert && job.null_vid <= static_cast<uint32_t>(max_element)) {   // != : NULL (value id == dictionary size) never matches
+      const uint32_t one2 = 0x00010001u, null2 = job.null_vid * 0x00010001u;
+      auto differs = [&](uint32_t d) { return pk_differs(d, null2, one2); };
+      not_null = two_groups<W>(ld.raw[0], ld.raw[1], differs) | (two_groups<W>(ld.raw[2], ld.raw[3], differs) << 16);
+    }
+  }
+  return (invert ? ~inside : inside) & not_null & valid;
 }
 
-// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS traffic, unlike __shfl_up's ds_bpermute):
-// four row_shr steps scan each 16-lane row, row_bcast:15 / row_bcast:31 carry the row totals across rows.
+// Inclusive prefix sum over the 64 lanes of a wave, six DPP adds (no LDS traffic, unlike __shfl_up's ds_bpermute):
+// four row_shr steps scan each 16-lane row (bound_ctrl: lanes without a source add 0), row_bcast:15 / row_bcast:31 carry
+// the row totals into the later rows.  Inline assembly because the compiler splits every update_dpp + add into
+// v_mov + v_mov_dpp + v_add; the s_nops are the VALU-write -> DPP-read wait states the assembler does not insert.
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xF, 0xF, false));   // row_shr:1
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xF, 0xF, false));   // row_shr:2
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xF, 0xF, false));   // row_shr:4
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xF, 0xF, false));   // row_shr:8
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  asm volatile(
+      "s_nop 4\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(v));
   return v;
 }
 
@@ -803,13 +866,14 @@ __device__ __forceinline__ Slice part_slice(const Part& part, const DevSegment& 
 // One workgroup owns one PART at a time (<= 8 slices = 65 536 rows of ONE chunk; parts b, b + gridDim.x, ...) and walks
 // its slices ONCE, in row order.  Per slice (8192 rows; lane l of wave w owns 4 groups of 8 consecutive rows):
 //   evaluate  the slice's loads were issued one slice earlier (also across parts), so every lane keeps 8 x 16 B in
-//             flight while it evaluates; the 32-bit match mask stays in a register
-//   count     per-group popcounts packed into one 64-bit word, ONE DPP prefix scan per half gives every lane its four
-//             output positions inside the wave and the wave its total; the four wave totals meet in LDS (the only
-//             workgroup barrier of the slice)
+//             flight while it evaluates two rows per instruction (packed 16-bit range test); the 32-bit match mask stays
+//             in a register
+//   count     the masks are transposed inside the wave (256 bytes of LDS) so that lane L holds 32 CONSECUTIVE rows; one
+//             DPP prefix scan over the popcounts gives every lane its output position inside the wave and the wave its
+//             total; the four wave totals meet in LDS (the only workgroup barrier of the slice)
 //   emit      wave w owns rows [w*2048, (w+1)*2048), i.e. a contiguous piece of the output: it compacts its row numbers
-//             through its private 4 KiB of LDS and writes coalesced 8-byte RowIDs at the running offset of the chunk's
-//             output region.
+//             through its private 4 KiB of LDS and writes RowID pairs with line-aligned, nontemporal 16-byte stores at
+//             the running offset of the chunk's output region.
 // Reads of slice s+1, the ALU work of slice s and the writes of slice s overlap inside every workgroup, and the
 // descriptors of a part (Part, DevSegment, ScanJob) are scalar-loaded one part ahead, off the critical path.
 // A Hyrise chunk (<= 65 535 rows) is one part: NO inter-workgroup communication at all.  Only chunks larger than a
@@ -832,9 +896,10 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
   uint16_t* s_rows = reinterpret_cast<uint16_t*>(smem);                              // [4 waves][2048 + ROW_PAD] compaction buffers
   uint32_t* s_wave_count = reinterpret_cast<uint32_t*>(smem + (SLICE_ROWS + 4 * ROW_PAD) * 2);   // [2][4] wave totals, double buffered
   uint32_t* s_small = s_wave_count + 8;                                              // [16] reductions
+  uint8_t* s_bytes = reinterpret_cast<uint8_t*>(s_small + 16);                       // [4 waves][256] mask transposition
 
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64();
+  if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64();   // (reading HW_ID here with s_getreg makes the register allocator spill)
 
   constexpr int LW = W == 0 ? 1 : W;
   SliceLoad<LW> next;   // streaming state: loads of the next slice to evaluate (possibly of the next part)
@@ -898,7 +963,9 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
 
     // ---- per-chunk outputs ------------------------------------------------------------------------------------------------
     uint32_t mode = JOB_SCAN;
-    if (!a.right) {
+    if constexpr (W != 0) {
+      mode = job.mode;
+    } else if (!a.right) {
       if (seg.encoding != HY_ENC_REFERENCE) mode = a.jobs[part.chunk].mode;
       else if (seg.ref_chunk_id != 0xFFFFFFFFu && seg.size > 0) mode = a.jobs[seg.ref_chunk_id].mode;
     }
@@ -911,6 +978,7 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
     // ---- the slices of the part, in row order -----------------------------------------------------------------------------
     uint32_t emitted = before;   // matches of this chunk before the current slice
     uint16_t* my_rows = s_rows + wave * (2048 + ROW_PAD);
+    uint8_t* my_bytes = s_bytes + wave * 256;
     for (uint32_t i = 0; i < part.n_slices; ++i) {
       const Slice slice = part_slice(part, seg, i);
       uint32_t mask;
@@ -922,13 +990,19 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
         else if (next_part_id < a.n_parts) issue_loads<W>(next, next_seg, next_job, part_slice(next_part, next_seg, 0), wave, lane);
         mask = evaluate_loaded<W>(current, seg, job, slice, a.materialize_all, wave, lane);
       }
-      // positions: fields of 16 bits, group k of the lane in field k (a wave holds at most 512 matches per group)
-      const uint32_t packed_lo = __popc(mask & 0xFFu) | (__popc(mask & 0xFF00u) << 16);
-      const uint32_t packed_hi = __popc(mask & 0xFF0000u) | (__popc(mask >> 24) << 16);
-      const uint32_t inclusive_lo = wave_inclusive_scan_u32(packed_lo), inclusive_hi = wave_inclusive_scan_u32(packed_hi);
-      const uint32_t totals_lo = __builtin_amdgcn_readlane(inclusive_lo, 63), totals_hi = __builtin_amdgcn_readlane(inclusive_hi, 63);
-      const uint32_t t0 = totals_lo & 0xFFFF, t1 = totals_lo >> 16, t2 = totals_hi & 0xFFFF, t3 = totals_hi >> 16;
-      const uint32_t my_total = t0 + t1 + t2 + t3;
+      // Transpose the masks inside the wave so that lane L holds the 32 CONSECUTIVE rows [32 L, 32 L + 32) of the wave's
+      // 2048: byte k of lane l goes to byte k*64 + l of the wave's 256-byte scratch, lane L reads dword L.  A lane's
+      // matches are then one contiguous run of the output, and one prefix sum over the popcounts places them.
+      my_bytes[lane] = static_cast<uint8_t>(mask);
+      my_bytes[64 + lane] = static_cast<uint8_t>(mask >> 8);
+      my_bytes[128 + lane] = static_cast<uint8_t>(mask >> 16);
+      my_bytes[192 + lane] = static_cast<uint8_t>(mask >> 24);
+      __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order; this only stops reordering
+      uint32_t run = reinterpret_cast<const uint32_t*>(my_bytes)[lane];
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t run_count = __popc(run);
+      const uint32_t inclusive = wave_inclusive_scan_u32(run_count);
+      const uint32_t my_total = __builtin_amdgcn_readlane(inclusive, 63);
       uint32_t* counts = s_wave_count + parity * 4;
       parity ^= 1;
       if (lane == 0) counts[wave] = my_total;
@@ -943,41 +1017,35 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
         // every store instruction of the body then writes 64 x 16 B = 8 whole, aligned lines.
         const uint64_t first = part.region_base + my_offset;
         const uint32_t skew = static_cast<uint32_t>(first) & 15u;
-        const uint32_t exclusive_lo = inclusive_lo - packed_lo, exclusive_hi = inclusive_hi - packed_hi;
-        const uint32_t base_k[4] = {skew + (exclusive_lo & 0xFFFF), skew + t0 + (exclusive_lo >> 16), skew + t0 + t1 + (exclusive_hi & 0xFFFF),
-                                    skew + t0 + t1 + t2 + (exclusive_hi >> 16)};
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-          uint32_t m = (mask >> (8 * k)) & 0xFFu;
-          if (a.debug & 2) m = 0;
-          uint32_t p = base_k[k];
-          const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
-          while (m) {
-            const uint32_t j = __ffs(m) - 1;
-            m &= m - 1;
-            my_rows[p++] = static_cast<uint16_t>(r0 + j);
+        const uint32_t end = skew + my_total;
+        {
+          uint16_t* slot = my_rows + skew + (inclusive - run_count);
+          const uint32_t row0 = wave * 2048 + lane * 32;
+          if (a.debug & 2) run = 0;
+          while (run) {
+            const uint32_t j = __ffs(run) - 1;
+            run &= run - 1;
+            *slot++ = static_cast<uint16_t>(row0 + j);
           }
         }
-        __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order; this only stops reordering
+        __builtin_amdgcn_wave_barrier();
         if (first + my_total > a.capacity) {
           if (lane == 0) *a.overflow = 1;
         } else if (!(a.debug & 1)) {
-          // RowIDs are written once and not read again by this kernel: nontemporal, 16 bytes (two RowIDs) per lane
+          // RowIDs are written once and not read again by this kernel: nontemporal, 16 bytes (two RowIDs) per lane.
+          // Pairs [pair_begin, pair_end) lie completely inside the wave's range; the slot before and the slot after
+          // them are written on their own.
           HY_GLOBAL u32x4* out = (HY_GLOBAL u32x4*)(a.matches + (first - skew));
           const uint32_t* pairs = reinterpret_cast<const uint32_t*>(my_rows);
-          const uint32_t end = skew + my_total;
-          for (uint32_t q = lane; 2 * q < end; q += 64) {
+          const uint32_t pair_begin = (skew + 1) / 2, pair_end = end / 2;
+          for (uint32_t q = lane < pair_begin ? lane + 64 : lane; q < pair_end; q += 64) {
             const uint32_t two = pairs[q];
-            const uint32_t row_a = slice.row_begin + (two & 0xFFFFu), row_b = slice.row_begin + (two >> 16);
-            if (2 * q >= skew && 2 * q + 1 < end) {
-              const u32x4 v = {part.chunk, row_a, part.chunk, row_b};
-              __builtin_nontemporal_store(v, out + q);
-            } else {   // the (at most two) pairs that straddle the ends of the wave's range
-              HY_GLOBAL u32x2* single = (HY_GLOBAL u32x2*)(out + q);
-              if (2 * q >= skew) { const u32x2 v = {part.chunk, row_a}; __builtin_nontemporal_store(v, single); }
-              if (2 * q + 1 >= skew && 2 * q + 1 < end) { const u32x2 v = {part.chunk, row_b}; __builtin_nontemporal_store(v, single + 1); }
-            }
+            const u32x4 v = {part.chunk, slice.row_begin + (two & 0xFFFFu), part.chunk, slice.row_begin + (two >> 16)};
+            __builtin_nontemporal_store(v, out + q);
           }
+          HY_GLOBAL u32x2* single = (HY_GLOBAL u32x2*)out;
+          if (lane == 0 && (skew & 1)) { const u32x2 v = {part.chunk, slice.row_begin + my_rows[skew]}; __builtin_nontemporal_store(v, single + skew); }
+          if (lane == 1 && (end & 1)) { const u32x2 v = {part.chunk, slice.row_begin + my_rows[end - 1]}; __builtin_nontemporal_store(v, single + (end - 1)); }
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -1018,7 +1086,7 @@ __global__ void compact_regions(const hy_row_id* regions, const uint64_t* region
 // query admits (ROCm 7.2 over-reports by one for SGPR-heavy 256-thread kernels, MI355X_MICROARCH.md "Residency and
 // cooperative launch").
 using ScanKernel = void (*)(const DevSegment*, const DevSegment*, const Slice*, const ScanJob*, const Part*, ScanArgs);
-constexpr size_t SCAN_LDS_BYTES = (SLICE_ROWS + 4 * ROW_PAD) * 2 + 8 * 4 + 16 * 4;   // compaction buffers | wave totals | reductions
+constexpr size_t SCAN_LDS_BYTES = (SLICE_ROWS + 4 * ROW_PAD) * 2 + 8 * 4 + 16 * 4 + 4 * 256;   // compaction buffers | wave totals | reductions
 
 static uint32_t scan_grid(ScanKernel kernel, uint32_t n_parts) {
   int device = 0, cus = 256;
@@ -1075,8 +1143,11 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   if (host_result) need += 2 * sizeof(hy_row_id) * (column->rows + 1) + 3 * 8 * (size_t{n_chunks} + 2) + 4 * (size_t{n_chunks} + 1) + n_chunks + 8192;
   HY_TRY(sc.reserve(need + 16 * 256));
   ScanJob* d_jobs = carve<ScanJob>(sc, n_data_chunks + 1);
-  uint32_t* d_overflow = carve<uint32_t>(sc, 64);
-  if (!predicate || n_data_chunks == 0) HY_HIP(hipMemsetAsync(d_overflow, 0, 4, stream));   // else prepare_jobs zeroes it
+  uint32_t* d_overflow = sc.ticket + 16;   // persistent word, zero unless a scan overflowed (an internal error)
+  ScanKernel kernel = scan_slices<0>;
+  if (!right && column->stream_width == 1) kernel = scan_slices<1>;
+  else if (!right && column->stream_width == 2) kernel = scan_slices<2>;
+  else if (!right && column->stream_width == 4) kernel = scan_slices<4>;
 
   PredicateArgs pa;
   std::memset(&pa, 0, sizeof(pa));
@@ -1127,10 +1198,6 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   if (n_chunks == 0) {
     HY_HIP(hipMemsetAsync(d_offsets, 0, 8, stream));
   } else {
-    ScanKernel kernel = scan_slices<0>;
-    if (!right && column->stream_width == 1) kernel = scan_slices<1>;
-    else if (!right && column->stream_width == 2) kernel = scan_slices<2>;
-    else if (!right && column->stream_width == 4) kernel = scan_slices<4>;
     const uint32_t grid = scan_grid(kernel, column->n_parts);
     HY_TRY(sc.begin_launch(column->n_parts, 0));
     ScanArgs a;
@@ -1162,9 +1229,10 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
       g_trace_buffer = trace_buffer;
       g_trace_grid = grid;
     }
-    profile_begin(stream);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(WG_THREADS), SCAN_LDS_BYTES, stream, a.segments, a.right, a.slices, a.jobs, column->d_parts, a);
-    profile_end(stream);
+    hipEvent_t started = nullptr, stopped = nullptr;
+    profile_events(&started, &stopped);
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(WG_THREADS), SCAN_LDS_BYTES, stream, started, stopped, 0, a.segments, a.right, a.slices, a.jobs,
+                          column->d_parts, a);
   }
   HY_HIP(hipGetLastError());
 
@@ -1174,7 +1242,10 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     HY_HIP(hipMemcpyAsync(result->chunk_state, d_state, size_t{n_chunks}, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
-    if (overflow) return fail(HY_ERR_DEVICE, "scan overflowed its own region buffer (internal error)");
+    if (overflow) {
+      (void)hipMemsetAsync(d_overflow, 0, 4, stream);
+      return fail(HY_ERR_DEVICE, "scan overflowed its own region buffer (internal error)");
+    }
     // back-to-back layout for the host: offsets[c+1] - offsets[c] = RowIDs written for chunk c
     uint64_t total = 0;
     for (uint32_t c = 0; c < n_chunks; ++c) {

@@ -181,9 +181,10 @@ hy_status hy_device_free(void* ptr);
 hy_status hy_memcpy_h2d(void* dst, const void* src, size_t bytes);
 hy_status hy_memcpy_d2h(void* dst, const void* src, size_t bytes);
 hy_status hy_device_count(int32_t* count);
-/* Measurement hook: when enabled, every operator call brackets its dominant kernel (scan_slices, join probe,
- * aggregate accumulate) with a pair of HIP events on the launch stream.  hy_profile_read() waits for the recorded
- * events and returns the summed elapsed time and the number of brackets since profiling was (re-)enabled. */
+/* Measurement hook: when enabled (> 0), operator calls time their dominant kernel (scan_slices, join probe, aggregate
+ * accumulate) with a pair of HIP events on the launch stream; enabled = n > 1 times every n-th call only (a timed
+ * launch costs several microseconds of stream time).  hy_profile_read() waits for the recorded events and returns the
+ * summed elapsed time and the number of timed launches since profiling was (re-)enabled. */
 hy_status hy_set_profiling(int32_t enabled);
 hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches);
 

@@ -14,11 +14,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // Each workgroup: rows_per_wg rows of 2 B read, out_per_wg RowIDs of 8 B written.
 template <int MODE>   // bit 0: 16-byte stores, bit 1: nontemporal stores, bit 2: nontemporal loads
 __global__ __launch_bounds__(256) void mix(const u32x4* __restrict__ in, uint2* __restrict__ out, unsigned rows_per_wg, unsigned out_per_wg,
-                                            unsigned n_parts, unsigned* __restrict__ sink) {
+                                            unsigned n_parts, unsigned* __restrict__ sink, unsigned region_stride) {
   unsigned acc = 0;
   for (unsigned part = blockIdx.x; part < n_parts; part += gridDim.x) {
     const u32x4* src = in + static_cast<size_t>(part) * (rows_per_wg / 8);
-    uint2* dst = out + static_cast<size_t>(part) * rows_per_wg;   // chunk regions, like the scan
+    uint2* dst = out + static_cast<size_t>(part) * region_stride;   // chunk regions, like the scan
     const unsigned loads = rows_per_wg / 8, stores = out_per_wg;
     const unsigned steps = 8;
     for (unsigned s = 0; s < steps; ++s) {
@@ -47,31 +47,33 @@ __global__ __launch_bounds__(256) void mix(const u32x4* __restrict__ in, uint2* 
 
 int main(int argc, char** argv) {
   const unsigned n_parts = 916, rows = 65536;
-  const double selectivities[] = {0.0, 0.0004, 0.15, 0.43, 0.986, 1.0};
+  const double selectivities[] = {0.15, 0.43};
   u32x4* in;
   uint2* out;
   unsigned* sink;
   CHECK(hipMalloc(&in, size_t{n_parts} * rows * 2));
-  CHECK(hipMalloc(&out, size_t{n_parts} * rows * 8));
+  CHECK(hipMalloc(&out, size_t{n_parts + 1} * (rows + 4096) * 8));
   CHECK(hipMalloc(&sink, 4));
   CHECK(hipMemset(in, 1, size_t{n_parts} * rows * 2));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  typedef void (*Kernel)(const u32x4*, uint2*, unsigned, unsigned, unsigned, unsigned*);
+  typedef void (*Kernel)(const u32x4*, uint2*, unsigned, unsigned, unsigned, unsigned*, unsigned);
   const Kernel kernels[8] = {mix<0>, mix<1>, mix<2>, mix<3>, mix<4>, mix<5>, mix<6>, mix<7>};
-  for (unsigned mode = 0; mode < 8; ++mode) {
+  for (unsigned stride : {65536u, 65535u, 65536u + 1040u, 65536u - 2064u, 28192u, 32768u + 1040u})
+  for (unsigned mode : {3u}) {
     const unsigned grid = 916;
+    printf("region stride %u RowIDs\n", stride);
     const Kernel mix = kernels[mode];
     for (double sel : selectivities) {
       const unsigned out_per_wg = static_cast<unsigned>(rows * sel) / 8 * 8;
-      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(mix, dim3(grid > n_parts ? n_parts : grid), dim3(256), 0, 0, in, out, rows, out_per_wg, n_parts, sink);
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(mix, dim3(grid > n_parts ? n_parts : grid), dim3(256), 0, 0, in, out, rows, out_per_wg, n_parts, sink, stride);
       CHECK(hipDeviceSynchronize());
       float best = 1e9f, sum = 0;
       const int reps = 30;
       for (int i = 0; i < reps; ++i) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(mix, dim3(grid > n_parts ? n_parts : grid), dim3(256), 0, 0, in, out, rows, out_per_wg, n_parts, sink);
+        hipLaunchKernelGGL(mix, dim3(grid > n_parts ? n_parts : grid), dim3(256), 0, 0, in, out, rows, out_per_wg, n_parts, sink, stride);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
