@@ -30,7 +30,14 @@
 
 namespace hy {
 
-constexpr uint32_t JOIN_TILE = 2048;                 // rows per workgroup tile (8 per lane)
+constexpr uint32_t JOIN_TILE = 4096;                 // probe rows per workgroup tile: half a slice
+constexpr uint32_t JOIN_THREADS = 512;
+constexpr uint32_t JOIN_WAVES = JOIN_THREADS / 64;
+constexpr uint32_t JOIN_WAVE_ROWS = JOIN_TILE / JOIN_WAVES;   // consecutive rows of a wave
+constexpr uint32_t JOIN_ROUNDS = JOIN_WAVE_ROWS / 64;
+constexpr uint32_t JOIN_STAGE = JOIN_TILE + 256;     // pairs a tile can stage in LDS before it falls back to direct writes
+constexpr uint32_t MAX_PARTITIONS = 256;             // radix_bits <= 8
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 constexpr uint32_t PROBE_SIZE_PER_CHUNK = 65535u * 2u;  // join_hash_steps.hpp:47
 constexpr uint32_t BLOOM_BITS = 1u << 20;            // join_hash_steps.hpp:252
 // The device keeps the filter as one BYTE per bit: setting a bit is a plain store (no atomics, races are benign), and
@@ -161,18 +168,20 @@ __global__ __launch_bounds__(1024) void scan_counts(const uint32_t* counts, uint
 }
 
 // keys sorted ascending (unsigned bit order)?  Also OR-reduces all keys (significant bytes for the radix sort):
-// one atomic per 1024-thread workgroup.
+// one atomic per 1024-thread workgroup, at most 1024 workgroups (atomics on one word retire at ~88 per microsecond).
 __global__ __launch_bounds__(1024) void check_sorted(const uint64_t* keys, uint64_t n, uint32_t* unsorted, unsigned long long* key_or) {
   __shared__ uint64_t s_bits[16];
   __shared__ uint32_t s_unsorted;
   if (threadIdx.x == 0) s_unsorted = 0;
   __syncthreads();
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   uint64_t bits = 0;
-  if (i < n) {
-    bits = keys[i];
-    if (i + 1 < n && bits > keys[i + 1]) s_unsorted = 1;
+  bool unsorted_here = false;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t key = keys[i];
+    bits |= key;
+    if (i + 1 < n && key > keys[i + 1]) unsorted_here = true;
   }
+  if (unsorted_here) s_unsorted = 1;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) bits |= __shfl_xor(bits, d, 64);
   if ((threadIdx.x & 63) == 0) s_bits[threadIdx.x >> 6] = bits;
@@ -200,6 +209,26 @@ __global__ __launch_bounds__(256) void sort_histogram(const uint64_t* keys, uint
   }
   __syncthreads();
   hist[static_cast<size_t>(tid) * n_tiles + blockIdx.x] = s_hist[tid];
+}
+
+// Inclusive prefix sum over the lanes of a wave (DPP; see scan.hip).
+__device__ __forceinline__ uint32_t join_wave_inclusive_scan(uint32_t v) {
+  asm volatile(
+      "s_nop 4\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(v));
+  return v;
 }
 
 // Wave-level match-any on an 8-bit digit: mask of the lanes (among `valid`) holding the same digit.
@@ -348,13 +377,26 @@ __global__ void directory_fill(const uint64_t* keys, uint64_t n, uint64_t key_mi
   }
 }
 
-// (start, count) of `key` in the sorted build keys.
+// (start, count) of `key` in the sorted build keys.  Buckets of up to four keys (the directory is sized for ~one key
+// per bucket) are probed with four independent loads instead of a dependent binary search chain.
 __device__ __forceinline__ void directory_lookup(const Directory& d, uint64_t key, uint32_t* start, uint32_t* count) {
   *start = 0;
   *count = 0;
   if (d.n == 0 || key < d.key_min || key > d.key_max) return;
   const uint64_t bucket = (key - d.key_min) >> d.shift;
   uint32_t lo = d.dir[bucket], hi = d.dir[bucket + 1];
+  if (hi - lo <= 4) {
+    const uint32_t last = static_cast<uint32_t>(d.n - 1);
+    const uint64_t k0 = d.keys[lo < last ? lo : last], k1 = d.keys[lo + 1 < last ? lo + 1 : last], k2 = d.keys[lo + 2 < last ? lo + 2 : last],
+                   k3 = d.keys[lo + 3 < last ? lo + 3 : last];
+    const uint32_t size = hi - lo;
+    const uint32_t equal = (size > 0 && k0 == key ? 1u : 0u) | (size > 1 && k1 == key ? 2u : 0u) | (size > 2 && k2 == key ? 4u : 0u) | (size > 3 && k3 == key ? 8u : 0u);
+    if (equal) {   // equal keys are adjacent
+      *start = lo + (__ffs(equal) - 1);
+      *count = __popc(equal);
+    }
+    return;
+  }
   const uint32_t bucket_end = hi;
   while (lo < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
@@ -395,6 +437,7 @@ struct ProbeArgs {
   hy_row_id* build_out;           // may be nullptr (Semi/Anti)
   hy_row_id* probe_out;
   uint64_t* slice_offsets;
+  uint32_t* error;                // set when a probe row matches >= 2^22 build rows (the staging record cannot hold it)
 };
 
 struct ProbeRow {
@@ -403,6 +446,22 @@ struct ProbeRow {
   uint32_t start;       // first build position (emit real partners) -- unused when null_partner
   bool null_partner;    // emit NULL_ROW_ID as the build side
 };
+
+// Output pairs of one probe row per join mode (probe / probe_semi_anti, join_hash_steps.hpp:575-922).
+__device__ __forceinline__ uint32_t pairs_of(const ProbeArgs& a, bool is_null, uint32_t count, bool* null_partner) {
+  *null_partner = false;
+  switch (a.mode) {
+    case HY_JOIN_INNER: return count;
+    case HY_JOIN_LEFT:
+    case HY_JOIN_RIGHT:
+      if (is_null || count == 0) { *null_partner = true; return 1; }
+      return count;
+    case HY_JOIN_SEMI: return count > 0 ? 1 : 0;
+    case HY_JOIN_ANTI_NULL_AS_FALSE: return (is_null || count == 0) ? 1 : 0;
+    default:  // AntiNullAsTrue
+      return is_null ? (a.build_rows_zero ? 1 : 0) : (count == 0 ? 1 : 0);
+  }
+}
 
 __device__ __forceinline__ ProbeRow probe_row(const ProbeArgs& a, uint32_t chunk, uint32_t row) {
   ProbeRow out{INVALID_PARTITION, 0, 0, false};
@@ -415,47 +474,206 @@ __device__ __forceinline__ ProbeRow probe_row(const ProbeArgs& a, uint32_t chunk
   uint32_t start = 0, count = 0;
   if (!is_null) directory_lookup(a.dir, hash, &start, &count);
   out.start = start;
-  switch (a.mode) {
-    case HY_JOIN_INNER: out.emit = count; break;
-    case HY_JOIN_LEFT:
-    case HY_JOIN_RIGHT:
-      if (is_null || count == 0) { out.emit = 1; out.null_partner = true; } else out.emit = count;
-      break;
-    case HY_JOIN_SEMI: out.emit = count > 0 ? 1 : 0; break;
-    case HY_JOIN_ANTI_NULL_AS_FALSE: out.emit = (is_null || count == 0) ? 1 : 0; break;
-    default:  // AntiNullAsTrue
-      out.emit = is_null ? (a.build_rows_zero ? 1 : 0) : (count == 0 ? 1 : 0);
-      break;
-  }
+  out.emit = pairs_of(a, is_null, count, &out.null_partner);
   return out;
 }
 
+// ---- batched evaluation: the JOIN_ROUNDS rows of a lane, phase by phase --------------------------------------------------
+// A probe is a chain of dependent loads (key -> Bloom byte -> directory entry -> build keys).  Evaluating the lane's rows
+// one after the other would pay that latency JOIN_ROUNDS times; here every phase issues the loads of all rows first.
+template <typename T>
+__device__ __forceinline__ void load_rows(const void* data, const uint32_t (&row)[JOIN_ROUNDS], const bool (&in)[JOIN_ROUNDS], T (&out)[JOIN_ROUNDS]) {
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) out[k] = in[k] ? static_cast<const T*>(data)[row[k]] : T{};
+}
+
+__device__ __forceinline__ void load_compressed_rows(const void* data, uint32_t width, const uint32_t (&row)[JOIN_ROUNDS], const bool (&in)[JOIN_ROUNDS],
+                                                     uint32_t (&out)[JOIN_ROUNDS]) {
+  if (width == 1) {
+    uint8_t v[JOIN_ROUNDS];
+    load_rows<uint8_t>(data, row, in, v);
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) out[k] = v[k];
+  } else if (width == 2) {
+    uint16_t v[JOIN_ROUNDS];
+    load_rows<uint16_t>(data, row, in, v);
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) out[k] = v[k];
+  } else {
+    load_rows<uint32_t>(data, row, in, out);
+  }
+}
+
+// meta[k] = emit << 10 | null_partner << 9 | partition (INVALID_PARTITION: not materialised); start[k] = first build position
+__device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
+                                              uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&start)[JOIN_ROUNDS]) {
+  uint32_t row[JOIN_ROUNDS];
+  bool in[JOIN_ROUNDS], is_null[JOIN_ROUNDS];
+  int64_t key[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    const uint32_t r = wave * JOIN_WAVE_ROWS + k * 64 + lane;
+    in[k] = r < row_count;
+    row[k] = row_begin + r;
+    is_null[k] = false;
+    key[k] = 0;
+    meta[k] = INVALID_PARTITION;
+    start[k] = 0;
+  }
+  // ---- phase 1: keys
+  const DevSegment s = a.segments[chunk];
+  if (s.encoding == HY_ENC_REFERENCE) {
+#pragma unroll 1
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+      if (in[k]) is_null[k] = column_key(a.segments, chunk, row[k], &key[k]);
+    }
+  } else if (s.encoding == HY_ENC_DICTIONARY) {
+    uint32_t vid[JOIN_ROUNDS];
+    load_compressed_rows(s.data, s.width, row, in, vid);
+    bool has[JOIN_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+      is_null[k] = in[k] && vid[k] >= s.aux_size;
+      has[k] = in[k] && !is_null[k];
+    }
+    if (s.data_type == HY_TYPE_INT) {
+      int32_t v[JOIN_ROUNDS];
+      load_rows<int32_t>(s.aux, vid, has, v);
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = v[k];
+    } else {
+      load_rows<int64_t>(s.aux, vid, has, key);
+    }
+  } else {
+    if (s.nulls) {
+      uint32_t word[JOIN_ROUNDS];
+      uint64_t bits[JOIN_ROUNDS];
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) word[k] = row[k] >> 6;
+      load_rows<uint64_t>(s.nulls, word, in, bits);
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) is_null[k] = in[k] && ((bits[k] >> (row[k] & 63)) & 1);
+    }
+    if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+      uint32_t raw[JOIN_ROUNDS], block[JOIN_ROUNDS];
+      int32_t bias[JOIN_ROUNDS];
+      load_compressed_rows(s.data, s.width, row, in, raw);
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) block[k] = row[k] / HY_FOR_BLOCK_SIZE;
+      load_rows<int32_t>(s.aux, block, in, bias);
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = static_cast<int32_t>(raw[k] + static_cast<uint32_t>(bias[k]));
+    } else if (s.data_type == HY_TYPE_INT) {
+      int32_t v[JOIN_ROUNDS];
+      load_rows<int32_t>(s.data, row, in, v);
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = v[k];
+    } else {
+      load_rows<int64_t>(s.data, row, in, key);
+    }
+  }
+  // ---- phase 2: which rows are materialised (join_hash_steps.hpp:354-358): NULL policy, the build side's Bloom filter
+  bool valid[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    if (is_null[k]) key[k] = 0;   // a kept NULL hashes like 0 (it lands in partition 0)
+    valid[k] = in[k] && !(is_null[k] && !a.keep_nulls);
+  }
+  if (a.build_bloom && !a.keep_nulls) {
+    uint32_t index[JOIN_ROUNDS];
+    uint8_t hit[JOIN_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) index[k] = static_cast<uint32_t>(key[k]) & (BLOOM_BITS - 1);
+    load_rows<uint8_t>(a.build_bloom, index, valid, hit);
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) valid[k] = valid[k] && hit[k] != 0;
+  }
+  // ---- phase 3: directory entries
+  const Directory& d = a.dir;
+  bool look[JOIN_ROUNDS];
+  uint32_t lo[JOIN_ROUNDS], hi[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    const uint64_t hash = static_cast<uint64_t>(key[k]);
+    look[k] = valid[k] && !is_null[k] && d.n != 0 && hash >= d.key_min && hash <= d.key_max;
+    const uint64_t bucket = look[k] ? (hash - d.key_min) >> d.shift : 0;
+    lo[k] = look[k] ? d.dir[bucket] : 0;
+    hi[k] = look[k] ? d.dir[bucket + 1] : 0;
+  }
+  // ---- phase 4: the bucket's keys (four at a time; longer buckets fall back to a binary search)
+  uint32_t count[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t half = 0; half < JOIN_ROUNDS; half += JOIN_ROUNDS / 2) {
+    uint64_t probe[JOIN_ROUNDS / 2][4];
+    const uint32_t last = d.n ? static_cast<uint32_t>(d.n - 1) : 0;
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS / 2; ++k) {
+      const bool wanted = look[half + k] && hi[half + k] > lo[half + k] && hi[half + k] - lo[half + k] <= 4;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t at = lo[half + k] + j < last ? lo[half + k] + j : last;
+        probe[k][j] = wanted ? d.keys[at] : 0;
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS / 2; ++k) {
+      const uint32_t i = half + k;
+      const uint64_t hash = static_cast<uint64_t>(key[i]);
+      const uint32_t size = hi[i] - lo[i];
+      count[i] = 0;
+      if (look[i] && size != 0) {
+        if (size <= 4) {
+          const uint32_t equal = (probe[k][0] == hash ? 1u : 0u) | (size > 1 && probe[k][1] == hash ? 2u : 0u) | (size > 2 && probe[k][2] == hash ? 4u : 0u) |
+                                 (size > 3 && probe[k][3] == hash ? 8u : 0u);
+          if (equal) {   // equal keys are adjacent
+            start[i] = lo[i] + (__ffs(equal) - 1);
+            count[i] = __popc(equal);
+          }
+        } else {
+          directory_lookup(d, hash, &start[i], &count[i]);
+        }
+      }
+    }
+  }
+  // ---- phase 5: pairs per mode
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    if (!valid[k]) continue;
+    const uint32_t partition = a.radix_bits ? static_cast<uint32_t>(static_cast<uint64_t>(key[k]) & ((1u << a.radix_bits) - 1)) : 0;
+    bool null_partner = false;
+    uint32_t emit = pairs_of(a, is_null[k], count[k], &null_partner);
+    if (emit >= (1u << 22)) { *a.error = 1; emit = (1u << 22) - 1; }
+    meta[k] = (emit << 10) | (null_partner ? 0x200u : 0u) | partition;
+  }
+}
+
 __device__ __forceinline__ void tile_rows(const ProbeArgs& a, uint32_t tile, uint32_t* chunk, uint32_t* row_begin, uint32_t* row_count) {
-  const Slice slice = a.slices[tile >> 2];
-  const uint32_t offset = (tile & 3) * JOIN_TILE;
+  const Slice slice = a.slices[tile / (SLICE_ROWS / JOIN_TILE)];
+  const uint32_t offset = (tile % (SLICE_ROWS / JOIN_TILE)) * JOIN_TILE;
   *chunk = slice.chunk;
   *row_begin = slice.row_begin + offset;
   *row_count = slice.row_count > offset ? (slice.row_count - offset < JOIN_TILE ? slice.row_count - offset : JOIN_TILE) : 0;
 }
 
-__global__ __launch_bounds__(256) void probe_histogram(ProbeArgs a) {
-  __shared__ uint32_t s_elements[256];
-  __shared__ uint32_t s_pairs[256];
-  const uint32_t tid = threadIdx.x;
+// Pass 1: per tile (4096 consecutive probe rows) and radix partition, the number of materialised probe elements and of
+// output pairs.  Wave w owns rows [w*512, (w+1)*512) of the tile, 64 consecutive rows per round.
+__global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
+  __shared__ uint32_t s_elements[MAX_PARTITIONS];
+  __shared__ uint32_t s_pairs[MAX_PARTITIONS];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t partitions = 1u << a.radix_bits;
-  s_elements[tid] = 0;
-  s_pairs[tid] = 0;
+  if (tid < MAX_PARTITIONS) { s_elements[tid] = 0; s_pairs[tid] = 0; }
   __syncthreads();
   uint32_t chunk, row_begin, row_count;
   tile_rows(a, blockIdx.x, &chunk, &row_begin, &row_count);
-  for (uint32_t k = 0; k < JOIN_TILE / 256; ++k) {
-    const uint32_t r = k * 256 + tid;
-    if (r < row_count) {
-      const ProbeRow p = probe_row(a, chunk, row_begin + r);
-      if (p.partition != INVALID_PARTITION) {
-        atomicAdd(&s_elements[p.partition], 1u);
-        if (p.emit) atomicAdd(&s_pairs[p.partition], p.emit);
-      }
+  uint32_t meta[JOIN_ROUNDS], start[JOIN_ROUNDS];
+  evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
+#pragma unroll
+  for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
+    const uint32_t partition = meta[round] & 0x1FF;
+    if (partition != INVALID_PARTITION) {
+      atomicAdd(&s_elements[partition], 1u);
+      if (meta[round] >> 10) atomicAdd(&s_pairs[partition], meta[round] >> 10);
     }
   }
   __syncthreads();
@@ -465,91 +683,168 @@ __global__ __launch_bounds__(256) void probe_histogram(ProbeArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void probe_scatter(ProbeArgs a) {
-  __shared__ uint16_t s_meta[JOIN_TILE];     // partition | null_partner << 15
-  __shared__ uint32_t s_emit[JOIN_TILE];
-  __shared__ uint32_t s_start[JOIN_TILE];
-  __shared__ uint32_t s_run_elements[4][256];
-  __shared__ uint32_t s_run_pairs[4][256];
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// LDS of probe_emit, in 4-byte words: per-row lookup results | staged pairs | per-(wave, partition) running counters |
+// per-partition offsets inside the tile | global bases of the tile's cells.
+__host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
+  return 2 * size_t{JOIN_TILE} + 2 * size_t{JOIN_STAGE} + 2 * size_t{JOIN_WAVES} * partitions + (partitions + 1) + 4 * size_t{partitions} + 8;
+}
+
+// Pass 2: every tile knows, from the scanned histograms, where its pairs of every partition go.  The tile is evaluated
+// once (lookup results parked in LDS), a wave-level match-any ranking gives every row its stable rank inside
+// (partition, tile), and the pairs are first laid out partition by partition in LDS and then copied out, so that a run of
+// consecutive lanes writes a run of consecutive RowIDs: a (tile, partition) cell is one contiguous piece of the output.
+// Tiles whose pairs do not fit the staging buffer (build keys with many duplicates) write their pairs directly.
+__global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
   const uint32_t partitions = 1u << a.radix_bits;
-  for (uint32_t w = 0; w < 4; ++w) { s_run_elements[w][tid] = 0; s_run_pairs[w][tid] = 0; }
+  uint32_t* s_start = join_smem;                                     // [JOIN_TILE] first build position of the row's matches
+  uint32_t* s_meta = s_start + JOIN_TILE;                            // [JOIN_TILE] emit << 10 | null_partner << 9 | partition
+  uint32_t* s_stage = s_meta + JOIN_TILE;                            // [JOIN_STAGE][2] row | partition << 12 | null << 21 , build position
+  uint32_t* s_run_elements = s_stage + 2 * JOIN_STAGE;               // [JOIN_WAVES][partitions]
+  uint32_t* s_run_pairs = s_run_elements + JOIN_WAVES * partitions;  // [JOIN_WAVES][partitions]
+  uint32_t* s_tile_offset = s_run_pairs + JOIN_WAVES * partitions;   // [partitions + 1] first staged slot of every partition
+  uint64_t* s_base_pairs = reinterpret_cast<uint64_t*>(s_tile_offset + partitions + 1 + ((partitions + 1) & 1));   // [partitions]
+  uint64_t* s_base_elements = s_base_pairs + partitions;             // [partitions]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint32_t i = tid; i < 2 * JOIN_WAVES * partitions; i += JOIN_THREADS) s_run_elements[i] = 0;
   __syncthreads();
   uint32_t chunk, row_begin, row_count;
   tile_rows(a, blockIdx.x, &chunk, &row_begin, &row_count);
 
-  // (a) evaluate every row once: wave w owns rows [w*512, (w+1)*512), round = 64 consecutive rows
-  for (uint32_t round = 0; round < 8; ++round) {
-    const uint32_t r = wave * 512 + round * 64 + lane;
-    ProbeRow p{INVALID_PARTITION, 0, 0, false};
-    if (r < row_count) p = probe_row(a, chunk, row_begin + r);
-    s_meta[r] = static_cast<uint16_t>(p.partition | (p.null_partner ? 0x8000u : 0u));
-    s_emit[r] = p.emit;
-    s_start[r] = p.start;
-    if (p.partition != INVALID_PARTITION) {
-      atomicAdd(&s_run_elements[wave][p.partition], 1u);
-      if (p.emit) atomicAdd(&s_run_pairs[wave][p.partition], p.emit);
+  // (a) evaluate every row once
+  {
+    uint32_t meta[JOIN_ROUNDS], start[JOIN_ROUNDS];
+    evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
+#pragma unroll
+    for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
+      const uint32_t r = wave * JOIN_WAVE_ROWS + round * 64 + lane;
+      s_start[r] = start[round];
+      s_meta[r] = meta[round];
+      const uint32_t partition = meta[round] & 0x1FF;
+      if (partition != INVALID_PARTITION) {
+        atomicAdd(&s_run_elements[wave * partitions + partition], 1u);
+        if (meta[round] >> 10) atomicAdd(&s_run_pairs[wave * partitions + partition], meta[round] >> 10);
+      }
     }
   }
   __syncthreads();
-  // (b) thread = partition: exclusive prefix over the waves
+  // (b) thread = partition: exclusive prefix over the waves, tile totals, global bases of the tile's cells
   if (tid < partitions) {
     uint32_t run_e = 0, run_p = 0;
-    for (uint32_t w = 0; w < 4; ++w) {
-      const uint32_t e = s_run_elements[w][tid], p = s_run_pairs[w][tid];
-      s_run_elements[w][tid] = run_e;
-      s_run_pairs[w][tid] = run_p;
+    for (uint32_t w = 0; w < JOIN_WAVES; ++w) {
+      const uint32_t e = s_run_elements[w * partitions + tid], p = s_run_pairs[w * partitions + tid];
+      s_run_elements[w * partitions + tid] = run_e;
+      s_run_pairs[w * partitions + tid] = run_p;
       run_e += e;
       run_p += p;
     }
+    s_tile_offset[tid] = run_p;   // totals for now
+    const size_t cell = static_cast<size_t>(tid) * a.n_tiles + blockIdx.x;
+    s_base_pairs[tid] = a.base_pairs[cell];
+    s_base_elements[tid] = a.base_elements[cell];
   }
   __syncthreads();
-  // (c) stable ranking inside the wave, round by round
+  // (c) wave 0: exclusive prefix over the partitions -> first staged slot of every partition
+  if (wave == 0) {
+    const uint32_t per_lane = (partitions + 63) / 64;
+    uint32_t mine = 0;
+    for (uint32_t i = 0; i < per_lane; ++i) {
+      const uint32_t q = lane * per_lane + i;
+      if (q < partitions) mine += s_tile_offset[q];
+    }
+    const uint32_t inclusive = join_wave_inclusive_scan(mine);
+    uint32_t running = inclusive - mine;
+    for (uint32_t i = 0; i < per_lane; ++i) {
+      const uint32_t q = lane * per_lane + i;
+      if (q < partitions) {
+        const uint32_t total = s_tile_offset[q];
+        s_tile_offset[q] = running;
+        running += total;
+      }
+    }
+    if (lane == 63) s_tile_offset[partitions] = inclusive;
+  }
+  __syncthreads();
+  const uint32_t tile_pairs = s_tile_offset[partitions];
+  const bool staged = tile_pairs <= JOIN_STAGE;
+
+  // (d) stable ranking inside the wave, round by round
   const hy_row_id null_row{0xFFFFFFFFu, 0xFFFFFFFFu};
-  for (uint32_t round = 0; round < 8; ++round) {
-    const uint32_t round_base = wave * 512 + round * 64;
+  for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
+    const uint32_t round_base = wave * JOIN_WAVE_ROWS + round * 64;
     const uint32_t r = round_base + lane;
     const uint32_t meta = s_meta[r];
     const uint32_t partition = meta & 0x1FF;
+    const uint32_t emit = meta >> 10;
     const bool valid = partition != INVALID_PARTITION;
     const uint64_t peers = match_any(partition, valid, a.radix_bits);
+    const uint64_t lower = peers & ((1ull << lane) - 1);
+    const uint64_t many = __ballot(emit > 1), one = __ballot(emit == 1);
     uint32_t pairs_before = 0, pairs_total = 0;
     if (valid) {
-      uint64_t lower = peers & ((1ull << lane) - 1);
-      while (lower) {
-        const uint32_t j = __ffsll(static_cast<long long>(lower)) - 1;
-        lower &= lower - 1;
-        pairs_before += s_emit[round_base + j];
+      if (many == 0) {
+        pairs_before = __popcll(lower & one);
+        pairs_total = __popcll(peers & one);
+      } else {
+        uint64_t rest = peers;
+        while (rest) {
+          const uint32_t j = __ffsll(static_cast<long long>(rest)) - 1;
+          rest &= rest - 1;
+          const uint32_t e = s_meta[round_base + j] >> 10;
+          if (j < lane) pairs_before += e;
+          pairs_total += e;
+        }
       }
-      const uint32_t emit = s_emit[r];
-      pairs_total = pairs_before + emit;
-      const uint32_t element_rank = s_run_elements[wave][partition] + __popcll(peers & ((1ull << lane) - 1));
-      const uint32_t pair_rank = s_run_pairs[wave][partition] + pairs_before;
-      const size_t cell = static_cast<size_t>(partition) * a.n_tiles + blockIdx.x;
-      const uint64_t pair_pos = a.base_pairs[cell] + pair_rank;
+      const uint32_t element_rank = s_run_elements[wave * partitions + partition] + __popcll(lower);
+      const uint32_t pair_rank = s_run_pairs[wave * partitions + partition] + pairs_before;
+      const uint64_t pair_pos = s_base_pairs[partition] + pair_rank;
       // 131 070-element cuts (join_hash_steps.hpp:655-660)
       const uint64_t origin = a.radix_bits ? a.partition_element_origin[partition] : a.partition_element_origin[chunk];
-      const uint64_t element_in_partition = a.base_elements[cell] + element_rank - origin;
+      const uint64_t element_in_partition = s_base_elements[partition] + element_rank - origin;
       if (element_in_partition % PROBE_SIZE_PER_CHUNK == 0) {
         const uint32_t slice_base = a.radix_bits ? a.partition_slice_base[partition] : a.partition_slice_base[chunk];
         a.slice_offsets[slice_base + element_in_partition / PROBE_SIZE_PER_CHUNK] = pair_pos;
       }
       if (emit) {
-        const hy_row_id probe_id{chunk, row_begin + r};
-        const bool null_partner = meta & 0x8000u;
+        const bool null_partner = meta & 0x200u;
         const uint32_t start = s_start[r];
-        for (uint32_t t = 0; t < emit; ++t) {
-          a.probe_out[pair_pos + t] = probe_id;
-          if (a.build_out) a.build_out[pair_pos + t] = null_partner ? null_row : a.dir.row_ids[start + t];
+        if (staged) {
+          const uint32_t slot = s_tile_offset[partition] + pair_rank;
+          const uint32_t tag = r | (partition << 12) | (null_partner ? 1u << 21 : 0u);
+          for (uint32_t t = 0; t < emit; ++t) {
+            s_stage[2 * (slot + t)] = tag;
+            s_stage[2 * (slot + t) + 1] = start + t;
+          }
+        } else {
+          const hy_row_id probe_id{chunk, row_begin + r};
+          for (uint32_t t = 0; t < emit; ++t) {
+            a.probe_out[pair_pos + t] = probe_id;
+            if (a.build_out) a.build_out[pair_pos + t] = null_partner ? null_row : a.dir.row_ids[start + t];
+          }
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
     if (valid && (peers >> lane) >> 1 == 0) {   // highest peer advances the running counters of its partition
-      s_run_elements[wave][partition] += static_cast<uint32_t>(__popcll(peers));
-      s_run_pairs[wave][partition] += pairs_total;
+      s_run_elements[wave * partitions + partition] += static_cast<uint32_t>(__popcll(peers));
+      s_run_pairs[wave * partitions + partition] += pairs_total;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (!staged) return;
+  __syncthreads();
+  // (e) copy out: slot s of partition p is pair  base_pairs[p][tile] + (s - first slot of p)
+  for (uint32_t s = tid; s < tile_pairs; s += JOIN_THREADS) {
+    const uint32_t tag = s_stage[2 * s], position = s_stage[2 * s + 1];
+    const uint32_t partition = (tag >> 12) & 0x1FF;
+    const uint64_t pair_pos = s_base_pairs[partition] + (s - s_tile_offset[partition]);
+    const u32x2_t probe_id = {chunk, row_begin + (tag & 0xFFFu)};
+    __builtin_nontemporal_store(probe_id, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
+    if (a.build_out) {
+      u32x2_t build_id = {0xFFFFFFFFu, 0xFFFFFFFFu};
+      if (!(tag & (1u << 21))) build_id = reinterpret_cast<const u32x2_t*>(a.dir.row_ids)[position];
+      __builtin_nontemporal_store(build_id, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+    }
   }
 }
 
@@ -665,7 +960,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     hipLaunchKernelGGL(join_materialize<1>, dim3(n_slices), dim3(256), 0, stream, m);
     uint32_t* unsorted = b.flags.as<uint32_t>();
     unsigned long long* key_or = reinterpret_cast<unsigned long long*>(b.flags.as<uint32_t>() + 4);
-    hipLaunchKernelGGL(check_sorted, dim3(static_cast<uint32_t>((total + 1023) / 1024)), dim3(1024), 0, stream, b.keys.as<uint64_t>(), total, unsorted, key_or);
+    hipLaunchKernelGGL(check_sorted, dim3(static_cast<uint32_t>(std::min<uint64_t>((total + 1023) / 1024, 1024))), dim3(1024), 0, stream, b.keys.as<uint64_t>(), total, unsorted, key_or);
     uint32_t host_flags[8];
     HY_HIP(hipMemcpyAsync(host_flags, b.flags.ptr, 32, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
@@ -712,7 +1007,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     HY_HIP(hipMemcpyAsync(&d.key_max, d.keys + (total - 1), 8, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
     uint32_t buckets = 1;
-    while (buckets < total / 8 && buckets < (1u << 26)) buckets <<= 1;   // ~8 keys per bucket on uniform keys
+    while (buckets < total && buckets < (1u << 27)) buckets <<= 1;   // 1-2 keys per bucket on uniform keys: one probe of four keys
     const uint64_t range = d.key_max - d.key_min;
     uint32_t shift = 0;
     while (shift < 64 && (range >> shift) >= buckets) ++shift;
@@ -765,7 +1060,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   }
 
   // probe pass 1
-  const uint32_t n_tiles = probe->n_slices * 4;
+  const uint32_t n_tiles = probe->n_slices * (SLICE_ROWS / JOIN_TILE);
   const uint32_t partitions = 1u << radix_bits;
   const size_t cells = size_t{partitions} * n_tiles;
   DeviceBuffer hist_e, hist_p, base_e, base_p;
@@ -785,6 +1080,10 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.dir = b.directory;
   a.hist_elements = hist_e.as<uint32_t>();
   a.hist_pairs = hist_p.as<uint32_t>();
+  DeviceBuffer d_error;
+  HY_TRY(d_error.alloc(256));
+  HY_HIP(hipMemsetAsync(d_error.ptr, 0, 4, stream));
+  a.error = d_error.as<uint32_t>();
   // Which scanned positions the host needs: the start of every partition (radix) or of every probe chunk
   // (radix_bits == 0: "partitions" are the probe chunks), plus the grand totals.
   const uint32_t n_groups = radix_bits ? partitions : probe->n_chunks;
@@ -796,7 +1095,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     for (uint32_t c = 0; c < probe->n_chunks; ++c) {
       const uint32_t chunk_slices = (probe->host_segments[c].size + SLICE_ROWS - 1) / SLICE_ROWS;
       group_first_cell[c] = tile;
-      tile += (chunk_slices ? chunk_slices : 1) * 4;   // the 4 tiles of each of its slices, consecutive
+      tile += (chunk_slices ? chunk_slices : 1) * (SLICE_ROWS / JOIN_TILE);   // the tiles of each of its slices, consecutive
     }
     group_first_cell[n_groups] = tile;
   }
@@ -806,7 +1105,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   HY_TRY(d_index.alloc(8 * (size_t{n_groups} + 1)));
   HY_TRY(d_origin.alloc(8 * (size_t{n_groups} + 1)));
   if (n_tiles) {
-    hipLaunchKernelGGL(probe_histogram, dim3(n_tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(probe_count, dim3(n_tiles), dim3(JOIN_THREADS), 0, stream, a);
     HY_TRY(exclusive_scan(hist_e.as<uint32_t>(), base_e.as<uint64_t>(), uint64_t{cells}, stream));
     HY_TRY(exclusive_scan(hist_p.as<uint32_t>(), base_p.as<uint64_t>(), uint64_t{cells}, stream));
     HY_HIP(hipMemcpyAsync(d_index.ptr, group_first_cell.data(), 8 * (size_t{n_groups} + 1), hipMemcpyHostToDevice, stream));
@@ -857,8 +1156,14 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.probe_out = dev_probe;
   a.slice_offsets = dev_slice_offsets;
   if (n_tiles) {
+    const size_t lds_bytes = 4 * probe_emit_lds_words(partitions);
+    static bool lds_raised = false;
+    if (!lds_raised) {
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
+      lds_raised = true;
+    }
     profile_begin(stream);
-    hipLaunchKernelGGL(probe_scatter, dim3(n_tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(probe_emit, dim3(n_tiles), dim3(JOIN_THREADS), lds_bytes, stream, a);
     profile_end(stream);
   }
   HY_HIP(hipMemcpyAsync(dev_slice_offsets + n_slices, &result->n_pairs, 8, hipMemcpyHostToDevice, stream));
@@ -870,7 +1175,10 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     }
     HY_HIP(hipMemcpyAsync(result->slice_offsets, dev_slice_offsets, 8 * (n_slices + 1), hipMemcpyDeviceToHost, stream));
   }
+  uint32_t probe_error = 0;
+  HY_HIP(hipMemcpyAsync(&probe_error, d_error.ptr, 4, hipMemcpyDeviceToHost, stream));
   HY_HIP(hipStreamSynchronize(stream));   // the temporaries above are freed on return
+  if (probe_error) return fail(HY_ERR_UNSUPPORTED, "a probe row matches more than 4 194 303 build rows");
   return HY_OK;
 }
 

@@ -1,5 +1,5 @@
 import sys, os, time, ctypes as C
-sys.path.insert(0,'.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hyrise_amd import abi, tpch, storage
 from hyrise_amd.storage import DeviceColumn
