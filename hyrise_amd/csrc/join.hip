@@ -38,6 +38,7 @@ constexpr uint32_t JOIN_ROUNDS = JOIN_WAVE_ROWS / 64;
 constexpr uint32_t JOIN_STAGE = JOIN_TILE + 256;     // pairs a tile can stage in LDS before it falls back to direct writes
 constexpr uint32_t MAX_PARTITIONS = 256;             // radix_bits <= 8
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 constexpr uint32_t PROBE_SIZE_PER_CHUNK = 65535u * 2u;  // join_hash_steps.hpp:47
 constexpr uint32_t BLOOM_BITS = 1u << 20;            // join_hash_steps.hpp:252
 // The device keeps the filter as one BYTE per bit: setting a bit is a plain store (no atomics, races are benign), and
@@ -357,6 +358,7 @@ __global__ void gather_u64(const uint64_t* src, const uint64_t* index, uint64_t*
 // ---- bucket directory over the sorted build keys ------------------------------------------------------------------------
 struct Directory {
   const uint64_t* keys;      // sorted (unsigned order of the sign-extended bits)
+  const uint32_t* keys32;    // int32 build columns: the low halves of `keys` (same order), padded by four entries; else nullptr
   const hy_row_id* row_ids;  // same order
   const uint32_t* dir;       // [n_buckets + 1] first position of every bucket
   uint64_t n;
@@ -375,6 +377,11 @@ __global__ void directory_fill(const uint64_t* keys, uint64_t n, uint64_t key_mi
   if (i + 1 == n) {
     for (uint64_t b = bucket + 1; b <= n_buckets; ++b) dir[b] = static_cast<uint32_t>(n);
   }
+}
+
+__global__ void narrow_keys(const uint64_t* keys, uint64_t n, uint32_t* keys32) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n + 4) keys32[i] = i < n ? static_cast<uint32_t>(keys[i]) : 0u;
 }
 
 // (start, count) of `key` in the sorted build keys.  Buckets of up to four keys (the directory is sized for ~one key
@@ -481,26 +488,27 @@ __device__ __forceinline__ ProbeRow probe_row(const ProbeArgs& a, uint32_t chunk
 // ---- batched evaluation: the JOIN_ROUNDS rows of a lane, phase by phase --------------------------------------------------
 // A probe is a chain of dependent loads (key -> Bloom byte -> directory entry -> build keys).  Evaluating the lane's rows
 // one after the other would pay that latency JOIN_ROUNDS times; here every phase issues the loads of all rows first.
+// All loads are unconditional (indices of rows that do not exist are clamped to an existing row and the results masked
+// afterwards): straight-line code, every phase's loads back to back, no exec-mask juggling around each load.
 template <typename T>
-__device__ __forceinline__ void load_rows(const void* data, const uint32_t (&row)[JOIN_ROUNDS], const bool (&in)[JOIN_ROUNDS], T (&out)[JOIN_ROUNDS]) {
+__device__ __forceinline__ void load_rows(const void* data, const uint32_t (&index)[JOIN_ROUNDS], T (&out)[JOIN_ROUNDS]) {
 #pragma unroll
-  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) out[k] = in[k] ? static_cast<const T*>(data)[row[k]] : T{};
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) out[k] = static_cast<const T*>(data)[index[k]];
 }
 
-__device__ __forceinline__ void load_compressed_rows(const void* data, uint32_t width, const uint32_t (&row)[JOIN_ROUNDS], const bool (&in)[JOIN_ROUNDS],
-                                                     uint32_t (&out)[JOIN_ROUNDS]) {
+__device__ __forceinline__ void load_compressed_rows(const void* data, uint32_t width, const uint32_t (&index)[JOIN_ROUNDS], uint32_t (&out)[JOIN_ROUNDS]) {
   if (width == 1) {
     uint8_t v[JOIN_ROUNDS];
-    load_rows<uint8_t>(data, row, in, v);
+    load_rows<uint8_t>(data, index, v);
 #pragma unroll
     for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) out[k] = v[k];
   } else if (width == 2) {
     uint16_t v[JOIN_ROUNDS];
-    load_rows<uint16_t>(data, row, in, v);
+    load_rows<uint16_t>(data, index, v);
 #pragma unroll
     for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) out[k] = v[k];
   } else {
-    load_rows<uint32_t>(data, row, in, out);
+    load_rows<uint32_t>(data, index, out);
   }
 }
 
@@ -514,12 +522,13 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
   for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
     const uint32_t r = wave * JOIN_WAVE_ROWS + k * 64 + lane;
     in[k] = r < row_count;
-    row[k] = row_begin + r;
+    row[k] = row_begin + (in[k] ? r : 0);   // row_count > 0: the tile's first row exists
     is_null[k] = false;
     key[k] = 0;
     meta[k] = INVALID_PARTITION;
     start[k] = 0;
   }
+  if (row_count == 0) return;
   // ---- phase 1: keys
   const DevSegment s = a.segments[chunk];
   if (s.encoding == HY_ENC_REFERENCE) {
@@ -529,20 +538,21 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
     }
   } else if (s.encoding == HY_ENC_DICTIONARY) {
     uint32_t vid[JOIN_ROUNDS];
-    load_compressed_rows(s.data, s.width, row, in, vid);
-    bool has[JOIN_ROUNDS];
+    load_compressed_rows(s.data, s.width, row, vid);
 #pragma unroll
     for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
-      is_null[k] = in[k] && vid[k] >= s.aux_size;
-      has[k] = in[k] && !is_null[k];
+      is_null[k] = vid[k] >= s.aux_size;
+      if (is_null[k]) vid[k] = 0;
     }
-    if (s.data_type == HY_TYPE_INT) {
-      int32_t v[JOIN_ROUNDS];
-      load_rows<int32_t>(s.aux, vid, has, v);
+    if (s.aux_size != 0) {
+      if (s.data_type == HY_TYPE_INT) {
+        int32_t v[JOIN_ROUNDS];
+        load_rows<int32_t>(s.aux, vid, v);
 #pragma unroll
-      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = v[k];
-    } else {
-      load_rows<int64_t>(s.aux, vid, has, key);
+        for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = v[k];
+      } else {
+        load_rows<int64_t>(s.aux, vid, key);
+      }
     }
   } else {
     if (s.nulls) {
@@ -550,89 +560,122 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
       uint64_t bits[JOIN_ROUNDS];
 #pragma unroll
       for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) word[k] = row[k] >> 6;
-      load_rows<uint64_t>(s.nulls, word, in, bits);
+      load_rows<uint64_t>(s.nulls, word, bits);
 #pragma unroll
-      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) is_null[k] = in[k] && ((bits[k] >> (row[k] & 63)) & 1);
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) is_null[k] = (bits[k] >> (row[k] & 63)) & 1;
     }
     if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
       uint32_t raw[JOIN_ROUNDS], block[JOIN_ROUNDS];
       int32_t bias[JOIN_ROUNDS];
-      load_compressed_rows(s.data, s.width, row, in, raw);
+      load_compressed_rows(s.data, s.width, row, raw);
 #pragma unroll
       for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) block[k] = row[k] / HY_FOR_BLOCK_SIZE;
-      load_rows<int32_t>(s.aux, block, in, bias);
+      load_rows<int32_t>(s.aux, block, bias);
 #pragma unroll
       for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = static_cast<int32_t>(raw[k] + static_cast<uint32_t>(bias[k]));
     } else if (s.data_type == HY_TYPE_INT) {
       int32_t v[JOIN_ROUNDS];
-      load_rows<int32_t>(s.data, row, in, v);
+      load_rows<int32_t>(s.data, row, v);
 #pragma unroll
       for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = v[k];
     } else {
-      load_rows<int64_t>(s.data, row, in, key);
+      load_rows<int64_t>(s.data, row, key);
     }
   }
-  // ---- phase 2: which rows are materialised (join_hash_steps.hpp:354-358): NULL policy, the build side's Bloom filter
+  // ---- phase 2: which rows are materialised by the NULL policy (the Bloom filter follows the lookup, see phase 4)
   bool valid[JOIN_ROUNDS];
 #pragma unroll
   for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
     if (is_null[k]) key[k] = 0;   // a kept NULL hashes like 0 (it lands in partition 0)
     valid[k] = in[k] && !(is_null[k] && !a.keep_nulls);
   }
-  if (a.build_bloom && !a.keep_nulls) {
-    uint32_t index[JOIN_ROUNDS];
-    uint8_t hit[JOIN_ROUNDS];
-#pragma unroll
-    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) index[k] = static_cast<uint32_t>(key[k]) & (BLOOM_BITS - 1);
-    load_rows<uint8_t>(a.build_bloom, index, valid, hit);
-#pragma unroll
-    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) valid[k] = valid[k] && hit[k] != 0;
-  }
-  // ---- phase 3: directory entries
+  // ---- phase 3: directory entries (dir[bucket], dir[bucket + 1] in one 8-byte load)
   const Directory& d = a.dir;
   bool look[JOIN_ROUNDS];
-  uint32_t lo[JOIN_ROUNDS], hi[JOIN_ROUNDS];
+  uint32_t lo[JOIN_ROUNDS], hi[JOIN_ROUNDS], count[JOIN_ROUNDS];
 #pragma unroll
   for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
-    const uint64_t hash = static_cast<uint64_t>(key[k]);
-    look[k] = valid[k] && !is_null[k] && d.n != 0 && hash >= d.key_min && hash <= d.key_max;
-    const uint64_t bucket = look[k] ? (hash - d.key_min) >> d.shift : 0;
-    lo[k] = look[k] ? d.dir[bucket] : 0;
-    hi[k] = look[k] ? d.dir[bucket + 1] : 0;
+    look[k] = false;
+    lo[k] = hi[k] = count[k] = 0;
   }
-  // ---- phase 4: the bucket's keys (four at a time; longer buckets fall back to a binary search)
-  uint32_t count[JOIN_ROUNDS];
+  if (d.n != 0) {
 #pragma unroll
-  for (uint32_t half = 0; half < JOIN_ROUNDS; half += JOIN_ROUNDS / 2) {
-    uint64_t probe[JOIN_ROUNDS / 2][4];
-    const uint32_t last = d.n ? static_cast<uint32_t>(d.n - 1) : 0;
-#pragma unroll
-    for (uint32_t k = 0; k < JOIN_ROUNDS / 2; ++k) {
-      const bool wanted = look[half + k] && hi[half + k] > lo[half + k] && hi[half + k] - lo[half + k] <= 4;
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j) {
-        const uint32_t at = lo[half + k] + j < last ? lo[half + k] + j : last;
-        probe[k][j] = wanted ? d.keys[at] : 0;
-      }
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+      const uint64_t hash = static_cast<uint64_t>(key[k]);
+      look[k] = valid[k] && !is_null[k] && hash >= d.key_min && hash <= d.key_max;
+      const uint64_t bucket = look[k] ? (hash - d.key_min) >> d.shift : 0;
+      const u32x2_t entry = *reinterpret_cast<const u32x2_t __attribute__((aligned(4)))*>(d.dir + bucket);
+      lo[k] = entry.x;
+      hi[k] = entry.y;
     }
+    // ---- phase 4: the bucket's keys, four at a time (longer buckets fall back to a binary search)
+    if (d.keys32) {   // int32 build keys: one 16-byte load per row (the array is padded by four entries)
+      u32x4_t probe[JOIN_ROUNDS];
 #pragma unroll
-    for (uint32_t k = 0; k < JOIN_ROUNDS / 2; ++k) {
-      const uint32_t i = half + k;
-      const uint64_t hash = static_cast<uint64_t>(key[i]);
-      const uint32_t size = hi[i] - lo[i];
-      count[i] = 0;
-      if (look[i] && size != 0) {
-        if (size <= 4) {
-          const uint32_t equal = (probe[k][0] == hash ? 1u : 0u) | (size > 1 && probe[k][1] == hash ? 2u : 0u) | (size > 2 && probe[k][2] == hash ? 4u : 0u) |
-                                 (size > 3 && probe[k][3] == hash ? 8u : 0u);
-          if (equal) {   // equal keys are adjacent
-            start[i] = lo[i] + (__ffs(equal) - 1);
-            count[i] = __popc(equal);
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) probe[k] = *reinterpret_cast<const u32x4_t __attribute__((aligned(4)))*>(d.keys32 + lo[k]);
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+        const uint32_t size = hi[k] - lo[k];
+        const bool fits = key[k] == static_cast<int64_t>(static_cast<int32_t>(key[k]));   // outside int32: no partner
+        const uint32_t want = static_cast<uint32_t>(key[k]);
+        const uint32_t equal = (size > 0 && probe[k].x == want ? 1u : 0u) | (size > 1 && probe[k].y == want ? 2u : 0u) | (size > 2 && probe[k].z == want ? 4u : 0u) |
+                               (size > 3 && probe[k].w == want ? 8u : 0u);
+        if (look[k] && fits) {
+          if (size <= 4) {
+            if (equal) {   // equal keys are adjacent
+              start[k] = lo[k] + (__ffs(equal) - 1);
+              count[k] = __popc(equal);
+            }
+          } else {
+            directory_lookup(d, static_cast<uint64_t>(key[k]), &start[k], &count[k]);
           }
-        } else {
-          directory_lookup(d, hash, &start[i], &count[i]);
         }
       }
+    } else {
+      const uint32_t last = static_cast<uint32_t>(d.n - 1);
+#pragma unroll
+      for (uint32_t half = 0; half < JOIN_ROUNDS; half += JOIN_ROUNDS / 2) {
+        uint64_t probe[JOIN_ROUNDS / 2][4];
+#pragma unroll
+        for (uint32_t k = 0; k < JOIN_ROUNDS / 2; ++k) {
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) probe[k][j] = d.keys[lo[half + k] + j < last ? lo[half + k] + j : last];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < JOIN_ROUNDS / 2; ++k) {
+          const uint32_t i = half + k;
+          const uint64_t hash = static_cast<uint64_t>(key[i]);
+          const uint32_t size = hi[i] - lo[i];
+          const uint32_t equal = (size > 0 && probe[k][0] == hash ? 1u : 0u) | (size > 1 && probe[k][1] == hash ? 2u : 0u) | (size > 2 && probe[k][2] == hash ? 4u : 0u) |
+                                 (size > 3 && probe[k][3] == hash ? 8u : 0u);
+          if (look[i]) {
+            if (size <= 4) {
+              if (equal) {
+                start[i] = lo[i] + (__ffs(equal) - 1);
+                count[i] = __popc(equal);
+              }
+            } else {
+              directory_lookup(d, hash, &start[i], &count[i]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // The build side's Bloom filter decides which probe rows count as materialised (join_hash_steps.hpp:354-358).  Every
+  // build key is in the filter, so only rows WITHOUT a partner need the test: usually none of a wave's rows.
+  if (a.build_bloom && !a.keep_nulls) {
+    bool any = false;
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) any = any || (valid[k] && count[k] == 0);
+    if (__any(any)) {
+      uint32_t index[JOIN_ROUNDS];
+      uint8_t hit[JOIN_ROUNDS];
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) index[k] = static_cast<uint32_t>(key[k]) & (BLOOM_BITS - 1);
+      load_rows<uint8_t>(a.build_bloom, index, hit);
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) valid[k] = valid[k] && !(count[k] == 0 && hit[k] == 0);
     }
   }
   // ---- phase 5: pairs per mode
@@ -686,7 +729,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
 // LDS of probe_emit, in 4-byte words: per-row lookup results | staged pairs | per-(wave, partition) running counters |
 // per-partition offsets inside the tile | global bases of the tile's cells.
 __host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
-  return 2 * size_t{JOIN_TILE} + 2 * size_t{JOIN_STAGE} + 2 * size_t{JOIN_WAVES} * partitions + (partitions + 1) + 4 * size_t{partitions} + 8;
+  return 2 * size_t{JOIN_TILE} + 2 * size_t{JOIN_STAGE} + 2 * size_t{JOIN_WAVES} * partitions + (partitions + 1) + 6 * size_t{partitions} + 8;
 }
 
 // Pass 2: every tile knows, from the scanned histograms, where its pairs of every partition go.  The tile is evaluated
@@ -704,7 +747,8 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
   uint32_t* s_run_pairs = s_run_elements + JOIN_WAVES * partitions;  // [JOIN_WAVES][partitions]
   uint32_t* s_tile_offset = s_run_pairs + JOIN_WAVES * partitions;   // [partitions + 1] first staged slot of every partition
   uint64_t* s_base_pairs = reinterpret_cast<uint64_t*>(s_tile_offset + partitions + 1 + ((partitions + 1) & 1));   // [partitions]
-  uint64_t* s_base_elements = s_base_pairs + partitions;             // [partitions]
+  uint32_t* s_cut_rank = reinterpret_cast<uint32_t*>(s_base_pairs + partitions);   // [partitions] rank (in the tile) of the element that starts a new output PosList
+  uint32_t* s_cut_slice = s_cut_rank + partitions;                   // [partitions] ... and the index of that PosList
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (uint32_t i = tid; i < 2 * JOIN_WAVES * partitions; i += JOIN_THREADS) s_run_elements[i] = 0;
   __syncthreads();
@@ -741,7 +785,14 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
     s_tile_offset[tid] = run_p;   // totals for now
     const size_t cell = static_cast<size_t>(tid) * a.n_tiles + blockIdx.x;
     s_base_pairs[tid] = a.base_pairs[cell];
-    s_base_elements[tid] = a.base_elements[cell];
+    // 131 070-element cuts (join_hash_steps.hpp:655-660): the one element of this cell, if any, whose index inside its
+    // partition (radix_bits == 0: inside its probe chunk) is a multiple of PROBE_SIZE_PER_CHUNK
+    const uint32_t group = a.radix_bits ? tid : chunk;
+    const uint64_t first_element = a.base_elements[cell] - a.partition_element_origin[group];
+    const uint64_t next_cut = (first_element + PROBE_SIZE_PER_CHUNK - 1) / PROBE_SIZE_PER_CHUNK;
+    const uint64_t cut_rank = next_cut * PROBE_SIZE_PER_CHUNK - first_element;
+    s_cut_rank[tid] = cut_rank < run_e ? static_cast<uint32_t>(cut_rank) : 0xFFFFFFFFu;
+    s_cut_slice[tid] = a.partition_slice_base[group] + static_cast<uint32_t>(next_cut);
   }
   __syncthreads();
   // (c) wave 0: exclusive prefix over the partitions -> first staged slot of every partition
@@ -798,13 +849,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
       const uint32_t element_rank = s_run_elements[wave * partitions + partition] + __popcll(lower);
       const uint32_t pair_rank = s_run_pairs[wave * partitions + partition] + pairs_before;
       const uint64_t pair_pos = s_base_pairs[partition] + pair_rank;
-      // 131 070-element cuts (join_hash_steps.hpp:655-660)
-      const uint64_t origin = a.radix_bits ? a.partition_element_origin[partition] : a.partition_element_origin[chunk];
-      const uint64_t element_in_partition = s_base_elements[partition] + element_rank - origin;
-      if (element_in_partition % PROBE_SIZE_PER_CHUNK == 0) {
-        const uint32_t slice_base = a.radix_bits ? a.partition_slice_base[partition] : a.partition_slice_base[chunk];
-        a.slice_offsets[slice_base + element_in_partition / PROBE_SIZE_PER_CHUNK] = pair_pos;
-      }
+      if (element_rank == s_cut_rank[partition]) a.slice_offsets[s_cut_slice[partition]] = pair_pos;
       if (emit) {
         const bool null_partner = meta & 0x200u;
         const uint32_t start = s_start[r];
@@ -915,7 +960,7 @@ static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, h
 static bool is_integer_column(const hy_column* c) { return c->data_type == HY_TYPE_INT || c->data_type == HY_TYPE_LONG; }
 
 struct BuildSide {
-  DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags;
+  DeviceBuffer keys, rows, keys_tmp, rows_tmp, keys32, dir, bloom, flags;
   uint64_t n = 0;
   Directory directory{};
   bool any_null = false;
@@ -997,8 +1042,14 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   // directory
   Directory& d = b.directory;
   d.keys = b.keys.as<uint64_t>();
+  d.keys32 = nullptr;
   d.row_ids = b.rows.as<hy_row_id>();
   d.n = total;
+  if (total && build->data_type == HY_TYPE_INT) {
+    HY_TRY(b.keys32.alloc(4 * (total + 4)));
+    hipLaunchKernelGGL(narrow_keys, dim3(static_cast<uint32_t>((total + 4 + 255) / 256)), dim3(256), 0, stream, d.keys, total, b.keys32.as<uint32_t>());
+    d.keys32 = b.keys32.as<uint32_t>();
+  }
   d.key_min = d.key_max = 0;
   d.shift = 0;
   d.n_buckets = 1;
