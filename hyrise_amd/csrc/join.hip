@@ -444,6 +444,8 @@ struct ProbeArgs {
   hy_row_id* build_out;           // may be nullptr (Semi/Anti)
   hy_row_id* probe_out;
   uint64_t* slice_offsets;
+  uint32_t* row_cache;            // [n_tiles][JOIN_TILE] pass 1 -> pass 2 (see cached_rows), or nullptr
+  uint32_t* tile_uncached;        // [n_tiles] set by pass 1 when a tile's rows do not fit the cache word
   uint32_t* error;                // set when a probe row matches >= 2^22 build rows (the staging record cannot hold it)
 };
 
@@ -512,12 +514,9 @@ __device__ __forceinline__ void load_compressed_rows(const void* data, uint32_t 
   }
 }
 
-// meta[k] = emit << 10 | null_partner << 9 | partition (INVALID_PARTITION: not materialised); start[k] = first build position
-__device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
-                                              uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&start)[JOIN_ROUNDS]) {
-  uint32_t row[JOIN_ROUNDS];
-  bool in[JOIN_ROUNDS], is_null[JOIN_ROUNDS];
-  int64_t key[JOIN_ROUNDS];
+// Phase 1 of a probe: the keys of the lane's JOIN_ROUNDS rows (NULL rows: key 0, a kept NULL lands in partition 0).
+__device__ __forceinline__ void decode_keys(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
+                                            uint32_t (&row)[JOIN_ROUNDS], bool (&in)[JOIN_ROUNDS], bool (&is_null)[JOIN_ROUNDS], int64_t (&key)[JOIN_ROUNDS]) {
 #pragma unroll
   for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
     const uint32_t r = wave * JOIN_WAVE_ROWS + k * 64 + lane;
@@ -525,11 +524,7 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
     row[k] = row_begin + (in[k] ? r : 0);   // row_count > 0: the tile's first row exists
     is_null[k] = false;
     key[k] = 0;
-    meta[k] = INVALID_PARTITION;
-    start[k] = 0;
   }
-  if (row_count == 0) return;
-  // ---- phase 1: keys
   const DevSegment s = a.segments[chunk];
   if (s.encoding == HY_ENC_REFERENCE) {
 #pragma unroll 1
@@ -582,13 +577,55 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
       load_rows<int64_t>(s.data, row, key);
     }
   }
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    if (is_null[k]) key[k] = 0;
+  }
+}
+
+// The probe's second pass re-reads what the first pass found: one word per probe row,
+//   [31] materialised  [30] one output pair  [29] its partner is NULL_ROW_ID  [28:0] build position of the partner.
+// A tile with a row that does not fit (several partners, a position >= 2^29) is flagged and evaluated again instead.
+constexpr uint32_t CACHE_MATERIALISED = 1u << 31, CACHE_EMIT = 1u << 30, CACHE_NULL_PARTNER = 1u << 29, CACHE_POSITION = (1u << 29) - 1;
+
+__device__ __forceinline__ void cached_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
+                                            uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&start)[JOIN_ROUNDS]) {
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) { meta[k] = INVALID_PARTITION; start[k] = 0; }
+  if (row_count == 0) return;
+  uint32_t row[JOIN_ROUNDS], word[JOIN_ROUNDS], index[JOIN_ROUNDS];
+  bool in[JOIN_ROUNDS], is_null[JOIN_ROUNDS];
+  int64_t key[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    const uint32_t r = wave * JOIN_WAVE_ROWS + k * 64 + lane;
+    index[k] = r < row_count ? r : 0;
+  }
+  load_rows<uint32_t>(a.row_cache + static_cast<size_t>(blockIdx.x) * JOIN_TILE, index, word);
+  decode_keys(a, chunk, row_begin, row_count, wave, lane, row, in, is_null, key);
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    if (!in[k] || !(word[k] & CACHE_MATERIALISED)) continue;
+    const uint32_t partition = a.radix_bits ? static_cast<uint32_t>(static_cast<uint64_t>(key[k]) & ((1u << a.radix_bits) - 1)) : 0;
+    meta[k] = ((word[k] & CACHE_EMIT) ? 1u << 10 : 0u) | ((word[k] & CACHE_NULL_PARTNER) ? 0x200u : 0u) | partition;
+    start[k] = word[k] & CACHE_POSITION;
+  }
+}
+
+// meta[k] = emit << 10 | null_partner << 9 | partition (INVALID_PARTITION: not materialised); start[k] = first build position
+__device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
+                                              uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&start)[JOIN_ROUNDS]) {
+  uint32_t row[JOIN_ROUNDS];
+  bool in[JOIN_ROUNDS], is_null[JOIN_ROUNDS];
+  int64_t key[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) { meta[k] = INVALID_PARTITION; start[k] = 0; }
+  if (row_count == 0) return;
+  decode_keys(a, chunk, row_begin, row_count, wave, lane, row, in, is_null, key);
   // ---- phase 2: which rows are materialised by the NULL policy (the Bloom filter follows the lookup, see phase 4)
   bool valid[JOIN_ROUNDS];
 #pragma unroll
-  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
-    if (is_null[k]) key[k] = 0;   // a kept NULL hashes like 0 (it lands in partition 0)
-    valid[k] = in[k] && !(is_null[k] && !a.keep_nulls);
-  }
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) valid[k] = in[k] && !(is_null[k] && !a.keep_nulls);
   // ---- phase 3: directory entries (dir[bucket], dir[bucket + 1] in one 8-byte load)
   const Directory& d = a.dir;
   bool look[JOIN_ROUNDS];
@@ -701,7 +738,7 @@ __device__ __forceinline__ void tile_rows(const ProbeArgs& a, uint32_t tile, uin
 // Pass 1: per tile (4096 consecutive probe rows) and radix partition, the number of materialised probe elements and of
 // output pairs.  Wave w owns rows [w*512, (w+1)*512) of the tile, 64 consecutive rows per round.
 __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
-  __shared__ uint32_t s_elements[MAX_PARTITIONS];
+  __shared__ uint32_t s_elements[MAX_PARTITIONS + 1];   // + 1: "a row of this tile does not fit the cache word"
   __shared__ uint32_t s_pairs[MAX_PARTITIONS];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t partitions = 1u << a.radix_bits;
@@ -711,15 +748,31 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
   tile_rows(a, blockIdx.x, &chunk, &row_begin, &row_count);
   uint32_t meta[JOIN_ROUNDS], start[JOIN_ROUNDS];
   evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
+  bool fits = true;
 #pragma unroll
   for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
     const uint32_t partition = meta[round] & 0x1FF;
+    const uint32_t emit = meta[round] >> 10;
     if (partition != INVALID_PARTITION) {
       atomicAdd(&s_elements[partition], 1u);
-      if (meta[round] >> 10) atomicAdd(&s_pairs[partition], meta[round] >> 10);
+      if (emit) atomicAdd(&s_pairs[partition], emit);
+    }
+    if (a.row_cache) {
+      const uint32_t r = wave * JOIN_WAVE_ROWS + round * 64 + lane;
+      fits = fits && emit <= 1 && start[round] <= CACHE_POSITION;
+      const uint32_t word = partition == INVALID_PARTITION ? 0u
+                                                           : CACHE_MATERIALISED | (emit ? CACHE_EMIT : 0u) | ((meta[round] & 0x200u) ? CACHE_NULL_PARTNER : 0u) | (start[round] & CACHE_POSITION);
+      if (r < row_count) __builtin_nontemporal_store(word, a.row_cache + static_cast<size_t>(blockIdx.x) * JOIN_TILE + r);
     }
   }
+  if (a.row_cache) {
+    const bool all_fit = __all(fits);
+    if (tid == 0) s_elements[MAX_PARTITIONS] = 0;
+    __syncthreads();
+    if (!all_fit && lane == 0) s_elements[MAX_PARTITIONS] = 1;
+  }
   __syncthreads();
+  if (a.row_cache && tid == 0) a.tile_uncached[blockIdx.x] = s_elements[MAX_PARTITIONS];
   if (tid < partitions) {
     a.hist_elements[static_cast<size_t>(tid) * a.n_tiles + blockIdx.x] = s_elements[tid];
     a.hist_pairs[static_cast<size_t>(tid) * a.n_tiles + blockIdx.x] = s_pairs[tid];
@@ -754,11 +807,22 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
   __syncthreads();
   uint32_t chunk, row_begin, row_count;
   tile_rows(a, blockIdx.x, &chunk, &row_begin, &row_count);
+  // thread = partition: the cell's global bases, requested now and used after the tile has been evaluated
+  uint64_t cell_base_pairs = 0, cell_first_element = 0;
+  uint32_t cell_slice_base = 0;
+  if (tid < partitions) {
+    const size_t cell = static_cast<size_t>(tid) * a.n_tiles + blockIdx.x;
+    const uint32_t group = a.radix_bits ? tid : chunk;
+    cell_base_pairs = a.base_pairs[cell];
+    cell_first_element = a.base_elements[cell] - a.partition_element_origin[group];
+    cell_slice_base = a.partition_slice_base[group];
+  }
 
   // (a) evaluate every row once
   {
     uint32_t meta[JOIN_ROUNDS], start[JOIN_ROUNDS];
-    evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
+    if (a.row_cache && a.tile_uncached[blockIdx.x] == 0) cached_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
+    else evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
 #pragma unroll
     for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
       const uint32_t r = wave * JOIN_WAVE_ROWS + round * 64 + lane;
@@ -783,16 +847,13 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
       run_p += p;
     }
     s_tile_offset[tid] = run_p;   // totals for now
-    const size_t cell = static_cast<size_t>(tid) * a.n_tiles + blockIdx.x;
-    s_base_pairs[tid] = a.base_pairs[cell];
+    s_base_pairs[tid] = cell_base_pairs;
     // 131 070-element cuts (join_hash_steps.hpp:655-660): the one element of this cell, if any, whose index inside its
     // partition (radix_bits == 0: inside its probe chunk) is a multiple of PROBE_SIZE_PER_CHUNK
-    const uint32_t group = a.radix_bits ? tid : chunk;
-    const uint64_t first_element = a.base_elements[cell] - a.partition_element_origin[group];
-    const uint64_t next_cut = (first_element + PROBE_SIZE_PER_CHUNK - 1) / PROBE_SIZE_PER_CHUNK;
-    const uint64_t cut_rank = next_cut * PROBE_SIZE_PER_CHUNK - first_element;
+    const uint64_t next_cut = (cell_first_element + PROBE_SIZE_PER_CHUNK - 1) / PROBE_SIZE_PER_CHUNK;
+    const uint64_t cut_rank = next_cut * PROBE_SIZE_PER_CHUNK - cell_first_element;
     s_cut_rank[tid] = cut_rank < run_e ? static_cast<uint32_t>(cut_rank) : 0xFFFFFFFFu;
-    s_cut_slice[tid] = a.partition_slice_base[group] + static_cast<uint32_t>(next_cut);
+    s_cut_slice[tid] = cell_slice_base + static_cast<uint32_t>(next_cut);
   }
   __syncthreads();
   // (c) wave 0: exclusive prefix over the partitions -> first staged slot of every partition
@@ -1131,6 +1192,13 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.dir = b.directory;
   a.hist_elements = hist_e.as<uint32_t>();
   a.hist_pairs = hist_p.as<uint32_t>();
+  DeviceBuffer d_cache, d_uncached;
+  if (!count_only && n_tiles) {   // pass 2 follows: let pass 1 leave its lookup results behind (4 B per probe row)
+    HY_TRY(d_cache.alloc(4 * size_t{n_tiles} * JOIN_TILE));
+    HY_TRY(d_uncached.alloc(4 * size_t{n_tiles}));
+    a.row_cache = d_cache.as<uint32_t>();
+    a.tile_uncached = d_uncached.as<uint32_t>();
+  }
   DeviceBuffer d_error;
   HY_TRY(d_error.alloc(256));
   HY_HIP(hipMemsetAsync(d_error.ptr, 0, 4, stream));
