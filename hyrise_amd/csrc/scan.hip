@@ -1061,6 +1061,75 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
   if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 3] = wall_clock64();
 }
 
+// ---- pos lists that reference several chunks --------------------------------------------------------------------------
+// The reference splits such a pos list by referenced chunk (split_pos_list_by_chunk_id.cpp:13-59), scans sub-list by
+// sub-list and appends the matches in that order (abstract_dereferenced_column_table_scan_impl.cpp:49-106): the chunk's
+// output is its matches ordered by (referenced chunk id, position), NULL_ROW_IDs last.  scan_slices produced them in
+// position order; one wave per such chunk re-orders its region with a stable LSD radix sort on the referenced chunk id
+// (8 bits per pass; a slow path in the reference as well).
+__device__ __forceinline__ uint32_t referenced_chunk_of(const hy_row_id* pos_list, uint32_t position, uint32_t n_referenced_chunks) {
+  const hy_row_id r = pos_list[position];
+  return r.chunk_offset == 0xFFFFFFFFu || r.chunk_id > n_referenced_chunks ? n_referenced_chunks : r.chunk_id;
+}
+
+__global__ __launch_bounds__(64) void reorder_by_referenced_chunk(const DevSegment* __restrict__ segments, hy_row_id* matches, const uint64_t* __restrict__ offsets,
+                                                                  const uint32_t* __restrict__ counts, hy_row_id* temp, uint32_t n_referenced_chunks) {
+  __shared__ uint32_t s_bin[256];
+  const uint32_t chunk = blockIdx.x, lane = threadIdx.x;
+  const DevSegment seg = segments[chunk];
+  if (seg.encoding != HY_ENC_REFERENCE || !seg.data || seg.ref_chunk_id != 0xFFFFFFFFu) return;
+  const uint32_t n = counts[chunk];
+  if (n < 2) return;
+  const hy_row_id* pos_list = static_cast<const hy_row_id*>(seg.data);
+  hy_row_id* src = matches + offsets[chunk];
+  hy_row_id* dst = temp + offsets[chunk];
+  uint32_t passes = 0;
+  for (uint32_t shift = 0; shift < 32 && (n_referenced_chunks >> shift) != 0; shift += 8) {
+    for (uint32_t b = lane; b < 256; b += 64) s_bin[b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < n; i += 64) atomicAdd(&s_bin[(referenced_chunk_of(pos_list, src[i].chunk_offset, n_referenced_chunks) >> shift) & 0xFF], 1u);
+    __builtin_amdgcn_wave_barrier();
+    // exclusive prefix over the 256 bins: four consecutive bins per lane
+    const uint32_t b0 = s_bin[4 * lane], b1 = s_bin[4 * lane + 1], b2 = s_bin[4 * lane + 2], b3 = s_bin[4 * lane + 3];
+    const uint32_t sum = b0 + b1 + b2 + b3;
+    const uint32_t before = wave_inclusive_scan_u32(sum) - sum;
+    s_bin[4 * lane] = before;
+    s_bin[4 * lane + 1] = before + b0;
+    s_bin[4 * lane + 2] = before + b0 + b1;
+    s_bin[4 * lane + 3] = before + b0 + b1 + b2;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < n; base += 64) {   // 64 consecutive matches per round keep the order stable
+      const uint32_t i = base + lane;
+      const bool valid = i < n;
+      hy_row_id row{0, 0};
+      uint32_t digit = 0;
+      if (valid) {
+        row = src[i];
+        digit = (referenced_chunk_of(pos_list, row.chunk_offset, n_referenced_chunks) >> shift) & 0xFF;
+      }
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (uint32_t b = 0; b < 8; ++b) {
+        const bool bit = (digit >> b) & 1;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      if (valid) dst[s_bin[digit] + __popcll(peers & ((1ull << lane) - 1))] = row;
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (peers >> lane) >> 1 == 0) s_bin[digit] += static_cast<uint32_t>(__popcll(peers));   // highest peer advances the bin
+      __builtin_amdgcn_wave_barrier();
+    }
+    hy_row_id* swap = src;
+    src = dst;
+    dst = swap;
+    ++passes;
+    __threadfence();   // the next pass reads what this one wrote
+  }
+  if (passes & 1) {
+    for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+  }
+}
+
 uint64_t* g_trace_buffer = nullptr;
 uint32_t g_trace_grid = 0;
 
@@ -1140,6 +1209,7 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
 
   // Scratch: jobs | per_chunk arrays | excluded | overflow flag | (host results) regions + dense copy + per-chunk arrays
   size_t need = sizeof(ScanJob) * (n_data_chunks + 1) + 3 * 4 * (size_t{n_data_chunks} + 64) + 4 * (size_t{n_excluded} + 64) + 1024;
+  if (column->multi_chunk_reference) need += sizeof(hy_row_id) * (column->rows + 1) + 256;
   if (host_result) need += 2 * sizeof(hy_row_id) * (column->rows + 1) + 3 * 8 * (size_t{n_chunks} + 2) + 4 * (size_t{n_chunks} + 1) + n_chunks + 8192;
   HY_TRY(sc.reserve(need + 16 * 256));
   ScanJob* d_jobs = carve<ScanJob>(sc, n_data_chunks + 1);
@@ -1234,6 +1304,11 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(WG_THREADS), SCAN_LDS_BYTES, stream, started, stopped, 0, a.segments, a.right, a.slices, a.jobs,
                           column->d_parts, a);
   }
+  if (column->multi_chunk_reference && predicate && n_chunks && d_counts) {
+    hy_row_id* d_temp = carve<hy_row_id>(sc, column->rows + 1);
+    if (!d_temp) return fail(HY_ERR_DEVICE, "scratch arena exhausted");
+    hipLaunchKernelGGL(reorder_by_referenced_chunk, dim3(n_chunks), dim3(64), 0, stream, column->d_segments, d_matches, d_offsets, d_counts, d_temp, n_data_chunks);
+  }
   HY_HIP(hipGetLastError());
 
   if (host_result) {
@@ -1294,9 +1369,8 @@ hy_status hy_table_scan(const hy_column* column, const hy_predicate* predicate, 
     if (excluded_chunks[i] >= column->n_chunks) return fail(HY_ERR_INVALID, "excluded chunk id %u out of range", excluded_chunks[i]);
   }
   HY_TRY(validate_predicate(column, predicate));
-  if (column->multi_chunk_reference) {
-    return fail(HY_ERR_UNSUPPORTED, "pos lists spanning several chunks are reordered by referenced chunk on the CPU path "
-                                    "(abstract_dereferenced_column_table_scan_impl.cpp:49-86)");
+  if (column->multi_chunk_reference && result->mem == HY_MEM_DEVICE && !result->counts) {
+    return fail(HY_ERR_INVALID, "scans of pos lists that span several chunks need result->counts (their matches are re-ordered by referenced chunk)");
   }
   return run_scan(column, nullptr, predicate, 0, excluded_chunks, n_excluded, result);
 }

@@ -126,17 +126,38 @@ def test_scan_reference_segments_single_chunk(device):
             check(ref_host, p, ref_dev, context=f"reference enc {encoding} cond {condition}")
 
 
-def test_multi_chunk_pos_list_is_reported_unsupported(device):
-    """Multi-chunk pos lists are reordered by referenced chunk on the CPU path for now: the ABI must say UNSUPPORTED
-    (adapter falls back), never return a differently ordered PosList."""
+def test_multi_chunk_pos_lists(device):
+    """Pos lists that reference several chunks (a scan on a join's output): the reference splits them by referenced
+    chunk and appends the matches sub-list by sub-list (abstract_dereferenced_column_table_scan_impl.cpp:49-106,
+    split_pos_list_by_chunk_id.cpp:13-59) -- matches come out ordered by (referenced chunk, position), NULL_ROW_IDs
+    last.  The reference's own weird-pos-list test (operators/table_scan_test.cpp) plus random shuffled pos lists with
+    NULL_ROW_IDs over every encoding."""
     t = load_tbl("int_int_shuffled_2.tbl")
     a = build_column(t.columns[0], None, 5, abi.ENC_DICTIONARY)
     ref = storage.make_reference_column(a, [np.array(KA.WEIRD_POS_LIST, dtype=np.uint32)], [None])
     base_dev = DeviceColumn(a)
     ref_dev = DeviceColumn(ref, refs={id(a): base_dev})
-    with pytest.raises(abi.HyriseAmdError) as err:
-        table_scan(ref_dev, make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, 10))
-    assert err.value.status == abi.ERR_UNSUPPORTED
+    for condition in CONDITIONS:
+        check(ref, make_predicate(condition, abi.TYPE_INT, 10, 100, nullable=True), ref_dev, context=f"weird pos list cond {condition}")
+
+    rng = np.random.default_rng(17)
+    n, chunk = 200_000, 700   # 286 referenced chunks: two radix passes
+    values = rng.integers(0, 1000, n).astype(np.int32)
+    nulls = rng.random(n) < 0.05
+    for encoding in ENCODINGS:
+        base = build_column(values, nulls, chunk, encoding)
+        base_dev = DeviceColumn(base)
+        pos_lists = []
+        for size in (0, 1, 63, 64, 65, 30_000, 65_535):
+            rows = rng.integers(0, n, size)
+            pos = np.stack([rows // chunk, rows % chunk], axis=1).astype(np.uint32)
+            pos[rng.random(size) < 0.03] = 0xFFFFFFFF   # NULL_ROW_IDs (outer joins)
+            pos_lists.append(pos)
+        ref_host = storage.make_reference_column(base, pos_lists, [None] * len(pos_lists))
+        ref_dev = DeviceColumn(ref_host, refs={id(base): base_dev})
+        for condition in CONDITIONS:
+            p = make_predicate(condition, abi.TYPE_INT, 100, 400, nullable=True)
+            check(ref_host, p, ref_dev, context=f"multi-chunk pos list enc {encoding} cond {condition}")
 
 
 def test_column_vs_column(device):
