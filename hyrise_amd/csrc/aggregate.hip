@@ -31,6 +31,7 @@ namespace hy {
 constexpr uint32_t MAX_GROUPBY = 4;
 constexpr uint32_t MAX_AGGREGATES = 8;
 constexpr uint32_t LDS_SLOTS = 256;
+constexpr uint32_t DENSE_GROUPS = 4;   // slices with at most this many groups accumulate in thread-private LDS cells
 constexpr uint32_t TAG_EMPTY = 0, TAG_LOCKED = 1;   // ready tags have bit 31 set
 
 struct AggColumn {
@@ -112,14 +113,38 @@ __device__ __forceinline__ int64_t ordered_bits(double d) {
   return b < 0 ? b ^ 0x7FFFFFFFFFFFFFFFll : b;
 }
 
+// Hash of a GROUP BY tuple: two independent 32-bit multiplicative mixes (64-bit multiplies cost ~10 instructions each
+// on this hardware and the hash is computed per row).  Only the placement in the hash tables depends on it.
 __device__ __forceinline__ uint64_t hash_tuple(const uint64_t* tuple, uint32_t words) {
-  uint64_t h = 0x9E3779B97F4A7C15ull;
+  uint32_t h1 = 0x9E3779B9u, h2 = 0x85EBCA6Bu;
   for (uint32_t w = 0; w < words; ++w) {
-    h ^= tuple[w] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-    h *= 0xff51afd7ed558ccdull;
-    h ^= h >> 33;
+    const uint32_t lo = static_cast<uint32_t>(tuple[w]), hi = static_cast<uint32_t>(tuple[w] >> 32);
+    h1 = (h1 ^ lo) * 0x9E3779B1u;
+    h1 = (h1 ^ (h1 >> 15) ^ hi) * 0x85EBCA77u;
+    h2 = (h2 ^ hi) * 0xC2B2AE3Du;
+    h2 = (h2 ^ (h2 >> 13) ^ lo) * 0x27D4EB2Fu;
   }
-  return h;
+  h1 ^= h1 >> 16;
+  h2 ^= h2 >> 15;
+  return (static_cast<uint64_t>(h2) << 32) | h1;
+}
+
+// the same function with a compile-time loop bound (tuples that live in registers must not be indexed dynamically)
+__device__ __forceinline__ uint64_t hash_tuple_static(const uint64_t (&tuple)[MAX_GROUPBY + 1], uint32_t words) {
+  uint32_t h1 = 0x9E3779B9u, h2 = 0x85EBCA6Bu;
+#pragma unroll
+  for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) {
+    if (w < words) {
+      const uint32_t lo = static_cast<uint32_t>(tuple[w]), hi = static_cast<uint32_t>(tuple[w] >> 32);
+      h1 = (h1 ^ lo) * 0x9E3779B1u;
+      h1 = (h1 ^ (h1 >> 15) ^ hi) * 0x85EBCA77u;
+      h2 = (h2 ^ hi) * 0xC2B2AE3Du;
+      h2 = (h2 ^ (h2 >> 13) ^ lo) * 0x27D4EB2Fu;
+    }
+  }
+  h1 ^= h1 >> 16;
+  h2 ^= h2 >> 15;
+  return (static_cast<uint64_t>(h2) << 32) | h1;
 }
 
 __device__ __forceinline__ uint64_t initial_value(uint32_t function) {
@@ -192,8 +217,191 @@ __device__ __forceinline__ void merge_global(const AggArgs& a, uint32_t slot, ui
   atomicAdd(reinterpret_cast<unsigned long long*>(&a.counts[static_cast<size_t>(slot) * a.n_aggregates + g]), static_cast<unsigned long long>(count));
 }
 
-// LDS layout (dynamic): tags[LDS_SLOTS] u32 | keys[LDS_SLOTS][words] u64 | first[LDS_SLOTS] u64 | last[LDS_SLOTS] u64 |
-//                       values[LDS_SLOTS][A] u64 | counts[LDS_SLOTS][A] u32
+// ---- batched decoding: B rows of one column per call, the loads of all rows issued before any is used ----------------
+// bits[i]: the value as int64 (integer columns) or as the bits of a double (float/double columns); null bit i set for NULL.
+template <int B>
+__device__ __forceinline__ void decode_rows(const DevSegment* segments, uint32_t chunk, const uint32_t (&row)[B], uint32_t valid, uint64_t (&bits)[B], uint32_t* nulls) {
+  const DevSegment s = segments[chunk];
+  *nulls = 0;
+  if (s.encoding == HY_ENC_REFERENCE) {
+#pragma unroll 1
+    for (int i = 0; i < B; ++i) {
+      bits[i] = 0;
+      if (!((valid >> i) & 1)) continue;
+      const Value v = column_value(segments, chunk, row[i]);
+      const bool is_float = s.data_type == HY_TYPE_FLOAT || s.data_type == HY_TYPE_DOUBLE;
+      if (v.is_null) *nulls |= 1u << i;
+      else bits[i] = is_float ? static_cast<uint64_t>(__double_as_longlong(v.f)) : static_cast<uint64_t>(v.i);
+    }
+    return;
+  }
+  const void* values = s.data;
+  uint32_t index[B];
+#pragma unroll
+  for (int i = 0; i < B; ++i) index[i] = row[i];
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    if (s.width == 1) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) index[i] = static_cast<const uint8_t*>(s.data)[row[i]];
+    } else if (s.width == 2) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) index[i] = static_cast<const uint16_t*>(s.data)[row[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < B; ++i) index[i] = static_cast<const uint32_t*>(s.data)[row[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      if (index[i] >= s.aux_size) { *nulls |= 1u << i; index[i] = 0; }
+    }
+    values = s.aux;
+    if (s.aux_size == 0) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = 0;
+      return;
+    }
+  } else if (s.nulls) {
+    uint64_t word[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) word[i] = s.nulls[row[i] >> 6];
+#pragma unroll
+    for (int i = 0; i < B; ++i) *nulls |= static_cast<uint32_t>((word[i] >> (row[i] & 63)) & 1) << i;
+  }
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+    uint32_t raw[B];
+    int32_t bias[B];
+    if (s.width == 1) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) raw[i] = static_cast<const uint8_t*>(s.data)[row[i]];
+    } else if (s.width == 2) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) raw[i] = static_cast<const uint16_t*>(s.data)[row[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < B; ++i) raw[i] = static_cast<const uint32_t*>(s.data)[row[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) bias[i] = static_cast<const int32_t*>(s.aux)[row[i] / HY_FOR_BLOCK_SIZE];
+#pragma unroll
+    for (int i = 0; i < B; ++i) bits[i] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(raw[i] + static_cast<uint32_t>(bias[i]))));
+    return;
+  }
+  switch (s.data_type) {
+    case HY_TYPE_INT: {
+      int32_t v[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) v[i] = static_cast<const int32_t*>(values)[index[i]];
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = static_cast<uint64_t>(static_cast<int64_t>(v[i]));
+      break;
+    }
+    case HY_TYPE_LONG:
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = static_cast<const uint64_t*>(values)[index[i]];
+      break;
+    case HY_TYPE_FLOAT: {
+      float v[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) v[i] = static_cast<const float*>(values)[index[i]];
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(v[i])));
+      break;
+    }
+    default:
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = static_cast<const uint64_t*>(values)[index[i]];
+      break;
+  }
+}
+
+// accumulator (+)= contribution, as plain arithmetic on 64-bit words (the atomics below do the same on shared cells)
+__device__ __forceinline__ uint64_t combine(const AggColumn& c, uint64_t accumulator, uint64_t contribution) {
+  switch (c.function) {
+    case HY_AGG_MIN: return static_cast<uint64_t>(min(static_cast<long long>(accumulator), static_cast<long long>(contribution)));
+    case HY_AGG_MAX: return static_cast<uint64_t>(max(static_cast<long long>(accumulator), static_cast<long long>(contribution)));
+    case HY_AGG_SUM:
+    case HY_AGG_AVG:
+      if (c.is_float || c.function == HY_AGG_AVG) {
+        return static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(accumulator)) + __longlong_as_double(static_cast<long long>(contribution))));
+      }
+      return accumulator + contribution;
+    default: return accumulator;
+  }
+}
+
+// decoded value -> the word the accumulators of this aggregate work on
+__device__ __forceinline__ uint64_t contribution_from(const AggColumn& c, uint64_t bits) {
+  switch (c.function) {
+    case HY_AGG_MIN:
+    case HY_AGG_MAX: return c.is_float ? static_cast<uint64_t>(ordered_bits(__longlong_as_double(static_cast<long long>(bits)))) : bits;
+    case HY_AGG_SUM: return bits;
+    case HY_AGG_AVG: return c.is_float ? bits : static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<int64_t>(bits))));
+    default: return 0;
+  }
+}
+
+__device__ __forceinline__ void accumulate_lds(const AggColumn& c, uint64_t* target, uint64_t contribution) {
+  switch (c.function) {
+    case HY_AGG_MIN: atomicMin(reinterpret_cast<long long*>(target), static_cast<long long>(contribution)); break;
+    case HY_AGG_MAX: atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(contribution)); break;
+    case HY_AGG_SUM:
+    case HY_AGG_AVG:
+      if (c.is_float || c.function == HY_AGG_AVG) atomicAdd(reinterpret_cast<double*>(target), __longlong_as_double(static_cast<long long>(contribution)));
+      else atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(contribution));
+      break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ uint64_t wave_combine(const AggColumn& c, uint64_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = combine(c, v, static_cast<uint64_t>(__shfl_xor(static_cast<long long>(v), d, 64)));
+  return v;
+}
+
+// Aggregate input of one row (generic, one row at a time): false for NULL (NULL inputs leave the aggregate unchanged,
+// aggregate_hash.cpp:627-637).
+__device__ __forceinline__ bool contribution_of(const AggColumn& c, uint32_t chunk, uint32_t row, uint64_t* contribution) {
+  *contribution = 0;
+  if (!c.segments) return true;   // COUNT(*)
+  const Value v = column_value(c.segments, chunk, row);
+  if (v.is_null) return false;
+  const uint64_t bits = c.is_float ? static_cast<uint64_t>(__double_as_longlong(c.data_type == HY_TYPE_FLOAT ? static_cast<double>(static_cast<float>(v.f)) : v.f))
+                                   : static_cast<uint64_t>(v.i);
+  *contribution = contribution_from(c, bits);
+  return true;
+}
+
+// GROUP BY tuple of one row (generic, one row at a time): word 0 = NULL mask, then the raw values (0 for NULL)
+__device__ __forceinline__ void row_tuple(const AggArgs& a, uint32_t chunk, uint32_t row, uint64_t (&tuple)[MAX_GROUPBY + 1]) {
+  tuple[0] = 0;
+  for (uint32_t g = 0; g < a.n_groupby; ++g) {
+    const Value v = column_value(a.groupby[g].segments, chunk, row);
+    uint64_t bits = 0;
+    if (v.is_null) tuple[0] |= 1ull << g;
+    else if (a.groupby[g].is_float) {
+      const double d = a.groupby[g].data_type == HY_TYPE_FLOAT ? static_cast<double>(static_cast<float>(v.f)) : v.f;
+      bits = d == 0.0 ? 0ull : static_cast<uint64_t>(__double_as_longlong(d));
+    } else bits = static_cast<uint64_t>(v.i);
+    tuple[g + 1] = bits;
+  }
+  for (uint32_t g = a.n_groupby; g < MAX_GROUPBY; ++g) tuple[g + 1] = 0;
+}
+
+// LDS layout (dynamic): keys[LDS_SLOTS][words] u64 | first[LDS_SLOTS] u64 | last[LDS_SLOTS] u64 | values[LDS_SLOTS][A] u64 |
+//                       counts[LDS_SLOTS][A] u32 | tags[LDS_SLOTS] u32 | dense index of a slot [LDS_SLOTS] u32 |
+//                       slot of a dense index [DENSE_GROUPS] u32 | number of groups u32 | slot of every row [SLICE_ROWS] u8
+//
+// One workgroup per 8192-row slice, 32 rows per thread (row k*256 + tid of the slice):
+//   pass 1  GROUP BY: the thread's rows are decoded 8 at a time (all loads of a column first), every tuple is looked up /
+//           inserted in the workgroup's LDS hash table, and the row's slot is remembered.  A new group also gets a dense
+//           index (its arrival number).
+//   pass 2  aggregate by aggregate, 16 rows at a time: rows of the first DENSE_GROUPS groups of the slice (TPC-H Q1 has 4
+//           in total) accumulate in registers, one accumulator per dense group; a wave reduction and one LDS atomic per wave
+//           and group fold them into the table.  (256 threads doing LDS atomics on 4 cells serialise completely.)
+//   pass 3  only if the slice has more groups: the remaining rows use LDS atomics per row -- the more groups, the fewer
+//           conflicts -- and rows whose group does not fit the LDS table go to the global table directly.
+//   merge   the slice's groups go to the global table with agent-scope atomics.
 __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t words = a.n_groupby + 1;
@@ -201,9 +409,13 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   uint64_t* s_first = s_keys + LDS_SLOTS * words;
   uint64_t* s_last = s_first + LDS_SLOTS;
   uint64_t* s_values = s_last + LDS_SLOTS;
-  uint32_t* s_counts = reinterpret_cast<uint32_t*>(s_values + LDS_SLOTS * a.n_aggregates);
+  uint32_t* s_counts = reinterpret_cast<uint32_t*>(s_values + LDS_SLOTS * a.n_aggregates);   // [LDS_SLOTS][A]
   uint32_t* s_tags = s_counts + LDS_SLOTS * a.n_aggregates;
-  const uint32_t tid = threadIdx.x;
+  uint32_t* s_dense_of_slot = s_tags + LDS_SLOTS;                                            // [LDS_SLOTS]
+  uint32_t* s_slot_of_dense = s_dense_of_slot + LDS_SLOTS;                                   // [DENSE_GROUPS]
+  uint32_t* s_n_groups = s_slot_of_dense + DENSE_GROUPS;
+  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_n_groups + 4);                          // [SLICE_ROWS]
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
   for (uint32_t s = tid; s < LDS_SLOTS; s += 256) {
     s_tags[s] = TAG_EMPTY;
     s_first[s] = ~0ull;
@@ -213,41 +425,67 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       s_counts[s * a.n_aggregates + g] = 0;
     }
   }
+  if (tid == 0) *s_n_groups = 0;
   __syncthreads();
 
   const Slice slice = a.slices[blockIdx.x];
   const uint64_t chunk_base = a.row_base[slice.chunk];
-  for (uint32_t k = 0; k < SLICE_ROWS / 256; ++k) {
-    const uint32_t r = k * 256 + tid;
-    if (r >= slice.row_count) continue;
-    const uint32_t row = slice.row_begin + r;
-    const uint64_t global_row = chunk_base + row;
-    // GROUP BY tuple: word 0 = NULL mask, then the raw values (0 for NULL)
-    uint64_t tuple[MAX_GROUPBY + 1];
-    tuple[0] = 0;
-    for (uint32_t g = 0; g < a.n_groupby; ++g) {
-      const Value v = column_value(a.groupby[g].segments, slice.chunk, row);
-      uint64_t bits = 0;
-      if (v.is_null) tuple[0] |= 1ull << g;
-      else if (a.groupby[g].is_float) {
-        const double d = a.groupby[g].data_type == HY_TYPE_FLOAT ? static_cast<double>(static_cast<float>(v.f)) : v.f;
-        bits = d == 0.0 ? 0ull : static_cast<uint64_t>(__double_as_longlong(d));
-      } else bits = static_cast<uint64_t>(v.i);
-      tuple[g + 1] = bits;
+  constexpr uint32_t ROWS = SLICE_ROWS / 256;
+  if (slice.row_count == 0) return;
+  uint32_t in_table = 0;   // bit k: row k found its group in the LDS table
+
+  // ---- pass 1: group lookup, 8 rows at a time -----------------------------------------------------------------------------
+  constexpr int GB = 4;
+#pragma unroll 1
+  for (uint32_t block = 0; block < ROWS / GB; ++block) {
+    uint32_t row[GB], valid = 0;
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const uint32_t r = (block * GB + i) * 256 + tid;
+      if (r < slice.row_count) valid |= 1u << i;
+      row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
     }
-    const uint64_t hash = hash_tuple(tuple, words);
-    // workgroup-private table in LDS (same lock discipline as global_slot)
-    const uint32_t ready = 0x80000000u | static_cast<uint32_t>(hash >> 33);
-    uint32_t slot = static_cast<uint32_t>(hash) & (LDS_SLOTS - 1);
-    bool found = false;
-    {
+    uint64_t tuple[GB][MAX_GROUPBY + 1];
+#pragma unroll
+    for (int i = 0; i < GB; ++i) tuple[i][0] = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+      if (g >= a.n_groupby) {
+#pragma unroll
+        for (int i = 0; i < GB; ++i) tuple[i][g + 1] = 0;
+        continue;
+      }
+      uint64_t bits[GB];
+      uint32_t nulls;
+      decode_rows<GB>(a.groupby[g].segments, slice.chunk, row, valid, bits, &nulls);
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        uint64_t word = bits[i];
+        if (a.groupby[g].is_float && __longlong_as_double(static_cast<long long>(word)) == 0.0) word = 0;   // -0.0 groups with 0.0
+        if ((nulls >> i) & 1) { tuple[i][0] |= 1ull << g; word = 0; }
+        tuple[i][g + 1] = word;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      if (!((valid >> i) & 1)) continue;
+      const uint32_t k = block * GB + i;
+      const uint64_t hash = hash_tuple_static(tuple[i], words);
+      // workgroup-private table in LDS (same lock discipline as global_slot)
+      const uint32_t ready = 0x80000000u | static_cast<uint32_t>(hash >> 33);
+      uint32_t slot = static_cast<uint32_t>(hash) & (LDS_SLOTS - 1);
+      bool found = false;
       uint32_t probes = 0;
       bool done = false;
       while (!done) {
         const uint32_t tag = atomicAdd(&s_tags[slot], 0u);
         if (tag == TAG_EMPTY) {
           if (atomicCAS(&s_tags[slot], TAG_EMPTY, TAG_LOCKED) == TAG_EMPTY) {
-            for (uint32_t w = 0; w < words; ++w) s_keys[slot * words + w] = tuple[w];
+#pragma unroll
+            for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) { if (w < words) s_keys[slot * words + w] = tuple[i][w]; }
+            const uint32_t dense = atomicAdd(s_n_groups, 1u);
+            s_dense_of_slot[slot] = dense;
+            if (dense < DENSE_GROUPS) s_slot_of_dense[dense] = slot;
             __threadfence_block();
             atomicExch(&s_tags[slot], ready);
             found = true;
@@ -256,7 +494,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         } else if (tag != TAG_LOCKED) {
           bool equal = tag == ready;
           if (equal) {
-            for (uint32_t w = 0; w < words; ++w) equal &= s_keys[slot * words + w] == tuple[w];
+#pragma unroll
+            for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) { if (w < words) equal &= s_keys[slot * words + w] == tuple[i][w]; }
           }
           if (equal) {
             found = true;
@@ -267,45 +506,187 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
           }
         }
       }
+      if (found) in_table |= 1u << k;
+      s_row_slot[k * 256 + tid] = static_cast<uint8_t>(slot);
     }
-    uint32_t gslot = 0xFFFFFFFFu;
-    if (!found) {   // more groups in this slice than LDS slots: this row goes to the global table directly
-      gslot = global_slot(a, tuple, words, hash);
-      if (gslot == 0xFFFFFFFFu) { *a.overflow = 1; continue; }
-      atomicMin(reinterpret_cast<unsigned long long*>(&a.first_row[gslot]), static_cast<unsigned long long>(global_row));
-      atomicMax(reinterpret_cast<unsigned long long*>(&a.last_row[gslot]), static_cast<unsigned long long>(global_row));
-    } else {
-      atomicMin(reinterpret_cast<unsigned long long*>(&s_first[slot]), static_cast<unsigned long long>(global_row));
-      atomicMax(reinterpret_cast<unsigned long long*>(&s_last[slot]), static_cast<unsigned long long>(global_row));
-    }
-    for (uint32_t g = 0; g < a.n_aggregates; ++g) {
-      const AggColumn& c = a.aggregates[g];
-      uint64_t contribution = 0;
-      if (c.segments) {
-        const Value v = column_value(c.segments, slice.chunk, row);
-        if (v.is_null) continue;   // NULL inputs leave the aggregate unchanged (aggregate_hash.cpp:627-637)
-        const double as_double = c.is_float ? (c.data_type == HY_TYPE_FLOAT ? static_cast<double>(static_cast<float>(v.f)) : v.f) : static_cast<double>(v.i);
-        switch (c.function) {
-          case HY_AGG_MIN:
-          case HY_AGG_MAX: contribution = static_cast<uint64_t>(c.is_float ? ordered_bits(as_double) : v.i); break;
-          case HY_AGG_SUM: contribution = c.is_float ? static_cast<uint64_t>(__double_as_longlong(as_double)) : static_cast<uint64_t>(v.i); break;
-          case HY_AGG_AVG: contribution = static_cast<uint64_t>(__double_as_longlong(as_double)); break;
-          default: break;
+  }
+  __syncthreads();
+  const uint32_t n_groups = *s_n_groups;
+  const uint32_t n_dense = n_groups < DENSE_GROUPS ? n_groups : DENSE_GROUPS;
+
+  // ---- pass 2: rows of the dense groups, registers --------------------------------------------------------------------------
+  uint32_t dense_lo = 0, dense_hi = 0;   // dense index of every row, two bits per row (rows 0-15 | 16-31); 3 = not dense when n_dense < 4 ...
+  uint32_t is_dense = 0;                 // ... so the membership is kept separately
+  {
+    uint32_t first[DENSE_GROUPS], last[DENSE_GROUPS];
+#pragma unroll
+    for (uint32_t j = 0; j < DENSE_GROUPS; ++j) { first[j] = 0xFFFFFFFFu; last[j] = 0; }
+#pragma unroll
+    for (uint32_t k = 0; k < ROWS; ++k) {
+      const uint32_t r = k * 256 + tid;
+      if (r < slice.row_count && ((in_table >> k) & 1)) {
+        const uint32_t dense = s_dense_of_slot[s_row_slot[r]];
+        if (dense < DENSE_GROUPS) {
+          is_dense |= 1u << k;
+          if (k < 16) dense_lo |= dense << (2 * k); else dense_hi |= dense << (2 * (k - 16));
+#pragma unroll
+          for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+            if (dense == j) { first[j] = min(first[j], r); last[j] = max(last[j], r); }
+          }
         }
       }
-      if (!found) { merge_global(a, gslot, g, contribution, 1); continue; }
-      uint64_t* target = &s_values[slot * a.n_aggregates + g];
-      switch (c.function) {
-        case HY_AGG_MIN: atomicMin(reinterpret_cast<long long*>(target), static_cast<long long>(contribution)); break;
-        case HY_AGG_MAX: atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(contribution)); break;
-        case HY_AGG_SUM:
-        case HY_AGG_AVG:
-          if (c.is_float || c.function == HY_AGG_AVG) atomicAdd(reinterpret_cast<double*>(target), __longlong_as_double(static_cast<long long>(contribution)));
-          else atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(contribution));
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {   // representative rows: smallest / largest row of the group
+      if (j >= n_dense) break;
+      uint32_t lowest = first[j], highest = last[j];
+      const bool any = lowest != 0xFFFFFFFFu;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        lowest = min(lowest, static_cast<uint32_t>(__shfl_xor(static_cast<int>(lowest), d, 64)));
+        highest = max(highest, static_cast<uint32_t>(__shfl_xor(static_cast<int>(highest), d, 64)));
+      }
+      if (__any(any) && lane == 0) {
+        const uint32_t slot = s_slot_of_dense[j];
+        atomicMin(reinterpret_cast<unsigned long long*>(&s_first[slot]), static_cast<unsigned long long>(chunk_base + slice.row_begin + lowest));
+        atomicMax(reinterpret_cast<unsigned long long*>(&s_last[slot]), static_cast<unsigned long long>(chunk_base + slice.row_begin + highest));
+      }
+    }
+  }
+  constexpr int AB = 16;
+#pragma unroll 1
+  for (uint32_t g = 0; g < a.n_aggregates; ++g) {
+    const AggColumn c = a.aggregates[g];
+    // what the accumulators do, decided once per aggregate (not per row)
+    enum : uint32_t { ACC_NONE, ACC_MIN, ACC_MAX, ACC_ADD_INT, ACC_ADD_DOUBLE };
+    uint32_t kind = ACC_NONE;
+    if (c.function == HY_AGG_MIN) kind = ACC_MIN;
+    else if (c.function == HY_AGG_MAX) kind = ACC_MAX;
+    else if (c.function == HY_AGG_SUM) kind = c.is_float ? ACC_ADD_DOUBLE : ACC_ADD_INT;
+    else if (c.function == HY_AGG_AVG) kind = ACC_ADD_DOUBLE;
+    const bool to_ordered = (kind == ACC_MIN || kind == ACC_MAX) && c.is_float;   // MIN/MAX of doubles on order-preserving int64
+    const bool int_to_double = c.function == HY_AGG_AVG && !c.is_float;
+    uint64_t accumulator[DENSE_GROUPS];
+    uint32_t counts = 0;   // rows accumulated per dense group, 8 bits each (a thread has 32 rows)
+#pragma unroll
+    for (uint32_t j = 0; j < DENSE_GROUPS; ++j) accumulator[j] = initial_value(c.function);
+#pragma unroll 1
+    for (uint32_t half = 0; half < ROWS / AB; ++half) {
+      const uint32_t members = (is_dense >> (half * AB)) & 0xFFFFu;
+      const uint32_t dense_bits = half == 0 ? dense_lo : dense_hi;
+      uint64_t bits[AB];
+      uint32_t nulls = 0;
+      if (c.segments) {
+        uint32_t row[AB];
+#pragma unroll
+        for (int i = 0; i < AB; ++i) {
+          const uint32_t r = (half * AB + i) * 256 + tid;
+          row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
+        }
+        decode_rows<AB>(c.segments, slice.chunk, row, members, bits, &nulls);
+        if (to_ordered) {
+#pragma unroll
+          for (int i = 0; i < AB; ++i) bits[i] = static_cast<uint64_t>(ordered_bits(__longlong_as_double(static_cast<long long>(bits[i]))));
+        } else if (int_to_double) {
+#pragma unroll
+          for (int i = 0; i < AB; ++i) bits[i] = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<int64_t>(bits[i]))));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < AB; ++i) bits[i] = 0;   // COUNT(*)
+      }
+      const uint32_t take = members & ~nulls;
+#pragma unroll
+      for (int i = 0; i < AB; ++i) {
+        if ((take >> i) & 1) counts += 1u << (8 * ((dense_bits >> (2 * i)) & 3));
+      }
+      switch (kind) {
+        case ACC_MIN:
+#pragma unroll
+          for (int i = 0; i < AB; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+              if (((take >> i) & 1) && ((dense_bits >> (2 * i)) & 3) == j) accumulator[j] = static_cast<uint64_t>(min(static_cast<long long>(accumulator[j]), static_cast<long long>(bits[i])));
+            }
+          }
+          break;
+        case ACC_MAX:
+#pragma unroll
+          for (int i = 0; i < AB; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+              if (((take >> i) & 1) && ((dense_bits >> (2 * i)) & 3) == j) accumulator[j] = static_cast<uint64_t>(max(static_cast<long long>(accumulator[j]), static_cast<long long>(bits[i])));
+            }
+          }
+          break;
+        case ACC_ADD_INT:
+#pragma unroll
+          for (int i = 0; i < AB; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+              if (((take >> i) & 1) && ((dense_bits >> (2 * i)) & 3) == j) accumulator[j] += bits[i];
+            }
+          }
+          break;
+        case ACC_ADD_DOUBLE:
+#pragma unroll
+          for (int i = 0; i < AB; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+              if (((take >> i) & 1) && ((dense_bits >> (2 * i)) & 3) == j) {
+                accumulator[j] = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(accumulator[j])) + __longlong_as_double(static_cast<long long>(bits[i]))));
+              }
+            }
+          }
           break;
         default: break;
       }
-      atomicAdd(&s_counts[slot * a.n_aggregates + g], 1u);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+      if (j >= n_dense) break;
+      const uint64_t value = wave_combine(c, accumulator[j]);
+      uint32_t count = (counts >> (8 * j)) & 0xFF;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d, 64);
+      if (lane == 0 && count != 0) {
+        const uint32_t slot = s_slot_of_dense[j];
+        accumulate_lds(c, &s_values[slot * a.n_aggregates + g], value);
+        atomicAdd(&s_counts[slot * a.n_aggregates + g], count);
+      }
+    }
+  }
+
+  // ---- pass 3: rows of the other groups (slices with more than DENSE_GROUPS groups only) ----------------------------------
+  if (n_groups > DENSE_GROUPS) {
+#pragma unroll 1
+    for (uint32_t k = 0; k < ROWS; ++k) {
+      const uint32_t r = k * 256 + tid;
+      if (r >= slice.row_count || ((is_dense >> k) & 1)) continue;
+      const uint32_t row = slice.row_begin + r;
+      const uint64_t global_row = chunk_base + row;
+      const bool found = (in_table >> k) & 1;
+      const uint32_t slot = s_row_slot[r];
+      uint32_t gslot = 0xFFFFFFFFu;
+      if (!found) {
+        uint64_t tuple[MAX_GROUPBY + 1];
+        row_tuple(a, slice.chunk, row, tuple);
+        gslot = global_slot(a, tuple, words, hash_tuple(tuple, words));
+        if (gslot == 0xFFFFFFFFu) { *a.overflow = 1; continue; }
+        atomicMin(reinterpret_cast<unsigned long long*>(&a.first_row[gslot]), static_cast<unsigned long long>(global_row));
+        atomicMax(reinterpret_cast<unsigned long long*>(&a.last_row[gslot]), static_cast<unsigned long long>(global_row));
+      } else {
+        atomicMin(reinterpret_cast<unsigned long long*>(&s_first[slot]), static_cast<unsigned long long>(global_row));
+        atomicMax(reinterpret_cast<unsigned long long*>(&s_last[slot]), static_cast<unsigned long long>(global_row));
+      }
+      for (uint32_t g = 0; g < a.n_aggregates; ++g) {
+        const AggColumn& c = a.aggregates[g];
+        uint64_t contribution;
+        if (!contribution_of(c, slice.chunk, row, &contribution)) continue;
+        if (!found) { merge_global(a, gslot, g, contribution, 1); continue; }
+        accumulate_lds(c, &s_values[slot * a.n_aggregates + g], contribution);
+        atomicAdd(&s_counts[slot * a.n_aggregates + g], 1u);
+      }
     }
   }
   __syncthreads();
@@ -348,16 +729,6 @@ __global__ void gather_values(const DevSegment* segments, const hy_row_id* rows,
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-struct PooledBuffer {   // small RAII wrapper; aggregate temporaries are modest, plain hipMalloc is fine here
-  void* ptr = nullptr;
-  hy_status alloc(size_t bytes) {
-    hipError_t err = hipMalloc(&ptr, bytes ? bytes : 256);
-    return err == hipSuccess ? HY_OK : fail(HY_ERR_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
-  }
-  ~PooledBuffer() { if (ptr) (void)hipFree(ptr); }
-  template <typename T> T* as() const { return static_cast<T*>(ptr); }
-};
-
 static uint32_t result_type(uint32_t function, uint32_t input_type) {   // window_function_traits.hpp:11-77
   const bool is_float = input_type == HY_TYPE_FLOAT || input_type == HY_TYPE_DOUBLE;
   switch (function) {
@@ -419,7 +790,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   a.row_base = shape->d_row_base;
   hipStream_t stream = current_stream();
   const uint32_t words = n_groupby + 1;
-  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4) + 64;
+  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + SLICE_ROWS;
 
   std::vector<uint64_t> h_keys, h_first, h_last, h_values, h_counts;
   uint32_t n_groups = 0;
@@ -429,7 +800,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     if (attempt == 1) { capacity = 1u << 22; }
     if (attempt == 2) { capacity = 1024; while (capacity < 2 * shape->rows + 1024) capacity <<= 1; }
     if (capacity > (1ull << 31)) return fail(HY_ERR_UNSUPPORTED, "too many rows for the device group table");
-    PooledBuffer tags, keys, first, last, values, counts, flags;
+    DeviceBuffer tags, keys, first, last, values, counts, flags;
     HY_TRY(tags.alloc(4 * capacity));
     HY_TRY(keys.alloc(8 * capacity * words));
     HY_TRY(first.alloc(8 * capacity));
@@ -454,7 +825,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     }
     uint32_t host_flags[2] = {0, 0};
     // count groups, then compact
-    PooledBuffer c_keys, c_first, c_last, c_values, c_counts;
+    DeviceBuffer c_keys, c_first, c_last, c_values, c_counts;
     const uint32_t out_capacity = static_cast<uint32_t>(std::min<uint64_t>(capacity, shape->rows + 1));
     HY_TRY(c_keys.alloc(8 * size_t{out_capacity} * words));
     HY_TRY(c_first.alloc(8 * size_t{out_capacity}));
@@ -528,7 +899,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     std::vector<uint64_t> any_bits;
     std::vector<uint8_t> any_null;
     if (function == HY_AGG_ANY && n_groups) {
-      PooledBuffer d_rows, d_bits, d_null;
+      DeviceBuffer d_rows, d_bits, d_null;
       HY_TRY(d_rows.alloc(8 * size_t{n_groups}));
       HY_TRY(d_bits.alloc(8 * size_t{n_groups}));
       HY_TRY(d_null.alloc(n_groups));

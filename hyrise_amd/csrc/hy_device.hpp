@@ -130,4 +130,18 @@ inline T* carve(Scratch& s, size_t count) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+
+// Temporary device buffers come from a per-thread pool of power-of-two blocks that is reused across calls
+// (hipMalloc/hipFree cost ~100 us each and synchronise the device).
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t capacity = 0;
+  hy_status alloc(size_t bytes);
+  ~DeviceBuffer();
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  template <typename T> T* as() const { return static_cast<T*>(ptr); }
+};
+
 }  // namespace hy

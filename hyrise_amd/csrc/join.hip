@@ -963,44 +963,7 @@ static uint32_t calculate_radix_bits(uint64_t build_rows) {   // join_hash.cpp:7
   return static_cast<uint32_t>(std::min<size_t>(8, static_cast<size_t>(std::ceil(std::log2(cluster_count)))));
 }
 
-struct DeviceBuffer;
 static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t stream);
-
-// Temporary device buffers come from a per-thread pool of power-of-two blocks that is reused across calls
-// (hipMalloc/hipFree cost ~100 us each and synchronise the device).
-struct BufferPool {
-  std::vector<std::pair<size_t, void*>> free_blocks;
-  ~BufferPool() { for (auto& b : free_blocks) (void)hipFree(b.second); }
-};
-static thread_local BufferPool t_pool;
-
-struct DeviceBuffer {
-  void* ptr = nullptr;
-  size_t capacity = 0;
-  hy_status alloc(size_t bytes) {
-    size_t rounded = 4096;
-    while (rounded < bytes) rounded <<= 1;
-    for (size_t i = 0; i < t_pool.free_blocks.size(); ++i) {
-      if (t_pool.free_blocks[i].first == rounded) {
-        ptr = t_pool.free_blocks[i].second;
-        capacity = rounded;
-        t_pool.free_blocks.erase(t_pool.free_blocks.begin() + i);
-        return HY_OK;
-      }
-    }
-    hipError_t err = hipMalloc(&ptr, rounded);
-    if (err != hipSuccess) {   // release the pool and retry once
-      for (auto& b : t_pool.free_blocks) (void)hipFree(b.second);
-      t_pool.free_blocks.clear();
-      err = hipMalloc(&ptr, rounded);
-    }
-    if (err != hipSuccess) { ptr = nullptr; return fail(HY_ERR_DEVICE, "hipMalloc(%zu) failed: %s", rounded, hipGetErrorString(err)); }
-    capacity = rounded;
-    return HY_OK;
-  }
-  ~DeviceBuffer() { if (ptr) t_pool.free_blocks.emplace_back(capacity, ptr); }
-  template <typename T> T* as() const { return static_cast<T*>(ptr); }
-};
 
 // out[0..n) = exclusive prefix sums of in, out[n] = total
 static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t stream) {

@@ -72,6 +72,37 @@ bool profile_events(hipEvent_t* start, hipEvent_t* stop) {
   return true;
 }
 
+
+struct BufferPool {
+  std::vector<std::pair<size_t, void*>> free_blocks;
+  ~BufferPool() { for (auto& b : free_blocks) (void)hipFree(b.second); }
+};
+static thread_local BufferPool t_pool;
+
+hy_status DeviceBuffer::alloc(size_t bytes) {
+  size_t rounded = 4096;
+  while (rounded < bytes) rounded <<= 1;
+  for (size_t i = 0; i < t_pool.free_blocks.size(); ++i) {
+    if (t_pool.free_blocks[i].first == rounded) {
+      ptr = t_pool.free_blocks[i].second;
+      capacity = rounded;
+      t_pool.free_blocks.erase(t_pool.free_blocks.begin() + i);
+      return HY_OK;
+    }
+  }
+  hipError_t err = hipMalloc(&ptr, rounded);
+  if (err != hipSuccess) {   // release the pool and retry once
+    for (auto& b : t_pool.free_blocks) (void)hipFree(b.second);
+    t_pool.free_blocks.clear();
+    err = hipMalloc(&ptr, rounded);
+  }
+  if (err != hipSuccess) { ptr = nullptr; return fail(HY_ERR_DEVICE, "hipMalloc(%zu) failed: %s", rounded, hipGetErrorString(err)); }
+  capacity = rounded;
+  return HY_OK;
+}
+
+DeviceBuffer::~DeviceBuffer() { if (ptr) t_pool.free_blocks.emplace_back(capacity, ptr); }
+
 Scratch& scratch() { return t_scratch; }
 
 hy_status Scratch::reserve(size_t bytes) {

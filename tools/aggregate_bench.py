@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Ad-hoc timing of the TPC-H Q1 core on one GPU (config 4 of BASELINE.json): GROUP BY l_returnflag, l_linestatus with
+SUM / AVG / COUNT(*) over SF10 lineitem (debug aid; bench.py reports the headline)."""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from hyrise_amd import abi, storage, tpch
+from hyrise_amd.operators import aggregate_hash
+from hyrise_amd.storage import DeviceColumn
+
+lib = abi.load_library()
+abi.check(lib.hy_init(0))
+sf = float(os.environ.get("SF", "10"))
+data = tpch.TpchData(scale_factor=sf, seed=42)
+n = data.n_lineitems
+cols = {
+    "l_returnflag": storage.make_column(data.l_returnflag, None, abi.ENC_DICTIONARY),
+    "l_linestatus": storage.make_column(data.l_linestatus, None, abi.ENC_DICTIONARY),
+    "l_quantity": storage.make_column(data.l_quantity, None, abi.ENC_UNENCODED),
+    "l_extendedprice": storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED),
+    "l_discount": storage.make_column(data.l_discount, None, abi.ENC_UNENCODED),
+}
+dev = {k: DeviceColumn(v) for k, v in cols.items()}
+aggregates = [(abi.AGG_SUM, dev["l_quantity"]), (abi.AGG_SUM, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_quantity"]),
+              (abi.AGG_AVG, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_discount"]), (abi.AGG_COUNT, None)]
+bytes_per_row = 1 + 1 + 4 + 4 + 4
+for i in range(4):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    result = aggregate_hash([dev["l_returnflag"], dev["l_linestatus"]], aggregates, group_capacity=64)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    print(f"aggregate ms {dt * 1e3:.3f} groups {result.n_groups} rows/s {n / dt:.3g} algorithmic GB/s {n * bytes_per_row / dt / 1e9:.0f}")
