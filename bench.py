@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cases", action="store_true", help="also time the Q1/Q6/point predicates (extra JSON field)")
     ap.add_argument("--no-join", action="store_true", help="skip the JoinHash orders x lineitem leg (extra JSON field)")
+    ap.add_argument("--no-aggregate", action="store_true", help="skip the AggregateHash Q1-core leg (extra JSON field)")
     return ap.parse_args()
 
 
@@ -108,7 +109,42 @@ def join_leg(lib, torch, dev, steps):
     return {"workload": "configs[2]: JoinHash orders x lineitem on the order key, SF10, Inner", "rows_per_s": (data.n_orders + n) / dt,
             "ms_per_join": dt * 1e3, "pairs": int(r.n_pairs), "radix_bits": int(r.radix_bits), "output_pos_lists": int(r.n_slices),
             "algorithmic_bytes": algorithmic, "achieved_GBps_whole_join": algorithmic / dt / 1e9,
-            "probe_scatter_kernel_ms": km.value / max(1, ln.value)}
+            "probe_emit_kernel_ms": km.value / max(1, ln.value)}
+
+
+def aggregate_leg(lib, torch, steps):
+    """Config 4 of BASELINE.json on one GPU: AggregateHash, TPC-H Q1 core -- GROUP BY l_returnflag, l_linestatus (dictionary
+    segments, u8 attribute vectors) with SUM / AVG over l_quantity, l_extendedprice, l_discount (float value segments) and
+    COUNT(*), SF10 lineitem.  Reported beside the scan."""
+    from hyrise_amd import abi, storage, tpch
+    from hyrise_amd.operators import aggregate_hash
+    from hyrise_amd.storage import DeviceColumn
+    data = tpch.TpchData(scale_factor=10.0, seed=42)
+    n = data.n_lineitems
+    flag = DeviceColumn(storage.make_column(data.l_returnflag, None, abi.ENC_DICTIONARY))
+    status = DeviceColumn(storage.make_column(data.l_linestatus, None, abi.ENC_DICTIONARY))
+    quantity = DeviceColumn(storage.make_column(data.l_quantity, None, abi.ENC_UNENCODED))
+    price = DeviceColumn(storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED))
+    discount = DeviceColumn(storage.make_column(data.l_discount, None, abi.ENC_UNENCODED))
+    aggregates = [(abi.AGG_SUM, quantity), (abi.AGG_SUM, price), (abi.AGG_AVG, quantity), (abi.AGG_AVG, price), (abi.AGG_AVG, discount),
+                  (abi.AGG_COUNT, None)]
+    steps = max(3, min(steps, 10))
+    for _ in range(2):
+        result = aggregate_hash([flag, status], aggregates, group_capacity=64)
+    abi.check(lib.hy_set_profiling(1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        result = aggregate_hash([flag, status], aggregates, group_capacity=64)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    km, ln = C.c_float(0), C.c_uint32(0)
+    abi.check(lib.hy_profile_read(C.byref(km), C.byref(ln)))
+    abi.check(lib.hy_set_profiling(0))
+    algorithmic = n * (1 + 1 + 4 + 4 + 4)   # two u8 attribute vectors + three float columns, each read once
+    return {"workload": "configs[3] on one GPU: AggregateHash Q1 core, GROUP BY l_returnflag, l_linestatus, SF10 lineitem",
+            "rows_per_s": n / dt, "ms_per_aggregate": dt * 1e3, "groups": int(result.n_groups), "algorithmic_bytes": algorithmic,
+            "achieved_GBps_whole_operator": algorithmic / dt / 1e9, "aggregate_rows_kernel_ms": km.value / max(1, ln.value)}
 
 
 def main():
@@ -222,6 +258,10 @@ def main():
     if rank == 0 and not args.no_join and not args.rows:
         join_info = join_leg(lib, torch, dev, args.steps)
 
+    aggregate_info = None
+    if rank == 0 and not args.no_aggregate and not args.rows:
+        aggregate_info = aggregate_leg(lib, torch, args.steps)
+
     if rank == 0:
         line = {
             "metric": "rows/sec TableScan (ColumnVsValue, l_shipdate < 1995-01-01) on TPC-H SF10 lineitem",
@@ -241,6 +281,8 @@ def main():
             line["cases"] = extra_cases
         if join_info:
             line["join"] = join_info
+        if aggregate_info:
+            line["aggregate"] = aggregate_info
         line["roofline"]["traffic"] = committed_traffic()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_column, predicate, rows)
