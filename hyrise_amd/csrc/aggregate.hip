@@ -1,5 +1,5 @@
 // aggregate.hip -- AggregateHash on MI355X: GROUP BY over up to 4 integer (or dictionary-named) columns with
-// MIN / MAX / SUM / AVG / COUNT / COUNT(*) / ANY aggregates.
+// MIN / MAX / SUM / AVG / COUNT / COUNT(*) / COUNT(DISTINCT) / STDDEV_SAMP / ANY aggregates.
 //
 // What it replaces (reference, CPU):
 //   AggregateHash::_on_execute / _aggregate             operators/aggregate_hash.cpp:950-1372
@@ -23,7 +23,9 @@
 #include "hy_device.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <map>
 #include <vector>
 
 namespace hy {
@@ -33,6 +35,7 @@ constexpr uint32_t MAX_AGGREGATES = 8;
 constexpr uint32_t LDS_SLOTS = 256;
 constexpr uint32_t DENSE_GROUPS = 4;   // slices with at most this many groups accumulate in thread-private LDS cells
 constexpr uint32_t TAG_EMPTY = 0, TAG_LOCKED = 1;   // ready tags have bit 31 set
+constexpr uint32_t AGG_SUM_SQUARES = 100;           // device-internal: sum of x*x as double (second accumulator of STDDEV_SAMP)
 
 struct AggColumn {
   const DevSegment* segments;
@@ -209,7 +212,8 @@ __device__ __forceinline__ void merge_global(const AggArgs& a, uint32_t slot, ui
     case HY_AGG_MAX: atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(value)); break;
     case HY_AGG_SUM:
     case HY_AGG_AVG:
-      if (c.is_float || c.function == HY_AGG_AVG) atomicAdd(reinterpret_cast<double*>(target), __longlong_as_double(static_cast<long long>(value)));
+    case AGG_SUM_SQUARES:
+      if (c.is_float || c.function != HY_AGG_SUM) atomicAdd(reinterpret_cast<double*>(target), __longlong_as_double(static_cast<long long>(value)));
       else atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(value));
       break;
     default: break;
@@ -321,7 +325,8 @@ __device__ __forceinline__ uint64_t combine(const AggColumn& c, uint64_t accumul
     case HY_AGG_MAX: return static_cast<uint64_t>(max(static_cast<long long>(accumulator), static_cast<long long>(contribution)));
     case HY_AGG_SUM:
     case HY_AGG_AVG:
-      if (c.is_float || c.function == HY_AGG_AVG) {
+    case AGG_SUM_SQUARES:
+      if (c.is_float || c.function != HY_AGG_SUM) {
         return static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(accumulator)) + __longlong_as_double(static_cast<long long>(contribution))));
       }
       return accumulator + contribution;
@@ -336,6 +341,10 @@ __device__ __forceinline__ uint64_t contribution_from(const AggColumn& c, uint64
     case HY_AGG_MAX: return c.is_float ? static_cast<uint64_t>(ordered_bits(__longlong_as_double(static_cast<long long>(bits)))) : bits;
     case HY_AGG_SUM: return bits;
     case HY_AGG_AVG: return c.is_float ? bits : static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<int64_t>(bits))));
+    case AGG_SUM_SQUARES: {
+      const double x = c.is_float ? __longlong_as_double(static_cast<long long>(bits)) : static_cast<double>(static_cast<int64_t>(bits));
+      return static_cast<uint64_t>(__double_as_longlong(x * x));
+    }
     default: return 0;
   }
 }
@@ -346,7 +355,8 @@ __device__ __forceinline__ void accumulate_lds(const AggColumn& c, uint64_t* tar
     case HY_AGG_MAX: atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(contribution)); break;
     case HY_AGG_SUM:
     case HY_AGG_AVG:
-      if (c.is_float || c.function == HY_AGG_AVG) atomicAdd(reinterpret_cast<double*>(target), __longlong_as_double(static_cast<long long>(contribution)));
+    case AGG_SUM_SQUARES:
+      if (c.is_float || c.function != HY_AGG_SUM) atomicAdd(reinterpret_cast<double*>(target), __longlong_as_double(static_cast<long long>(contribution)));
       else atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(contribution));
       break;
     default: break;
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     if (c.function == HY_AGG_MIN) kind = ACC_MIN;
     else if (c.function == HY_AGG_MAX) kind = ACC_MAX;
     else if (c.function == HY_AGG_SUM) kind = c.is_float ? ACC_ADD_DOUBLE : ACC_ADD_INT;
-    else if (c.function == HY_AGG_AVG) kind = ACC_ADD_DOUBLE;
+    else if (c.function == HY_AGG_AVG || c.function == AGG_SUM_SQUARES) kind = ACC_ADD_DOUBLE;
     const bool to_ordered = (kind == ACC_MIN || kind == ACC_MAX) && c.is_float;   // MIN/MAX of doubles on order-preserving int64
     const bool int_to_double = c.function == HY_AGG_AVG && !c.is_float;
     uint64_t accumulator[DENSE_GROUPS];
@@ -590,6 +600,9 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         } else if (int_to_double) {
 #pragma unroll
           for (int i = 0; i < AB; ++i) bits[i] = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<int64_t>(bits[i]))));
+        } else if (c.function == AGG_SUM_SQUARES) {
+#pragma unroll
+          for (int i = 0; i < AB; ++i) bits[i] = contribution_from(c, bits[i]);
         }
       } else {
 #pragma unroll
@@ -747,53 +760,19 @@ static hy_row_id row_id_of(const hy_column* shape, uint64_t global_row) {
   return hy_row_id{chunk, static_cast<uint32_t>(global_row - shape->row_base[chunk])};
 }
 
-static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_groupby, const hy_aggregate_spec* specs, uint32_t n_aggregates,
-                               hy_aggregate_result* result) {
-  if (n_groupby > MAX_GROUPBY) return fail(HY_ERR_UNSUPPORTED, "more than %u GROUP BY columns stay on the CPU path", MAX_GROUPBY);
-  if (n_aggregates > MAX_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "more than %u aggregates stay on the CPU path", MAX_AGGREGATES);
-  const hy_column* shape = n_groupby ? groupby[0] : nullptr;
-  for (uint32_t g = 0; g < n_aggregates && !shape; ++g) shape = specs[g].column;
-  if (!shape) return fail(HY_ERR_INVALID, "hy_aggregate_hash needs at least one column (pass any column of the table for a lone COUNT(*))");
-  auto same_shape = [&](const hy_column* c) {
-    if (c->n_chunks != shape->n_chunks) return false;
-    for (uint32_t k = 0; k < c->n_chunks; ++k) if (c->host_segments[k].size != shape->host_segments[k].size) return false;
-    return true;
-  };
-  AggArgs a;
-  std::memset(&a, 0, sizeof(a));
-  a.n_groupby = n_groupby;
-  a.n_aggregates = n_aggregates;
-  for (uint32_t g = 0; g < n_groupby; ++g) {
-    if (!groupby[g] || !same_shape(groupby[g])) return fail(HY_ERR_INVALID, "GROUP BY column %u does not have the table's chunk layout", g);
-    if (groupby[g]->data_type == HY_TYPE_STRING) return fail(HY_ERR_UNSUPPORTED, "string GROUP BY columns must be passed as dictionary segments of int64 key names (INTEGRATION.md)");
-    a.groupby[g].segments = groupby[g]->d_segments;
-    a.groupby[g].data_type = groupby[g]->data_type;
-    a.groupby[g].is_float = groupby[g]->data_type == HY_TYPE_FLOAT || groupby[g]->data_type == HY_TYPE_DOUBLE;
-  }
-  for (uint32_t g = 0; g < n_aggregates; ++g) {
-    const hy_aggregate_spec& spec = specs[g];
-    if (spec.function == HY_AGG_COUNT_DISTINCT || spec.function == HY_AGG_STDDEV_SAMP) return fail(HY_ERR_UNSUPPORTED, "COUNT(DISTINCT) / STDDEV_SAMP stay on the CPU path");
-    if (spec.function > HY_AGG_ANY) return fail(HY_ERR_INVALID, "unknown aggregate function %u", spec.function);
-    if (!spec.column && spec.function != HY_AGG_COUNT) return fail(HY_ERR_INVALID, "only COUNT may omit its column (aggregate_hash.cpp:1002)");
-    if (spec.column) {
-      if (!same_shape(spec.column)) return fail(HY_ERR_INVALID, "aggregate column %u does not have the table's chunk layout", g);
-      if (spec.column->data_type == HY_TYPE_STRING && spec.function != HY_AGG_COUNT) return fail(HY_ERR_UNSUPPORTED, "string aggregates stay on the CPU path");
-      a.aggregates[g].segments = spec.column->d_segments;
-      a.aggregates[g].data_type = spec.column->data_type;
-      a.aggregates[g].is_float = spec.column->data_type == HY_TYPE_FLOAT || spec.column->data_type == HY_TYPE_DOUBLE;
-    } else {
-      a.aggregates[g].data_type = HY_TYPE_LONG;
-    }
-    a.aggregates[g].function = spec.function;
-  }
-  a.slices = shape->d_slices;
-  a.row_base = shape->d_row_base;
-  hipStream_t stream = current_stream();
-  const uint32_t words = n_groupby + 1;
-  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + SLICE_ROWS;
-
-  std::vector<uint64_t> h_keys, h_first, h_last, h_values, h_counts;
+// What the device table holds after one pass over the table: the groups' tuples, first / last rows and accumulators.
+struct DeviceGroups {
   uint32_t n_groups = 0;
+  std::vector<uint64_t> keys, first, last, values, counts;
+};
+
+// Runs aggregate_rows + compact_groups for the columns wired into `a` (GROUP BY and device accumulators), retrying with a
+// larger global table when it overflows.
+static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out) {
+  hipStream_t stream = current_stream();
+  const uint32_t words = a.n_groupby + 1;
+  const uint32_t n_aggregates = a.n_aggregates;
+  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + SLICE_ROWS;
   uint64_t capacity = 1u << 16;
   while (capacity < 2 * uint64_t{LDS_SLOTS}) capacity <<= 1;
   for (int attempt = 0; attempt < 3; ++attempt) {
@@ -837,23 +816,113 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     HY_HIP(hipMemcpyAsync(host_flags, flags.ptr, 8, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
     if (host_flags[0]) continue;   // table overflow: retry with a larger one
-    n_groups = host_flags[1];
-    h_keys.resize(size_t{n_groups} * words);
-    h_first.resize(n_groups);
-    h_last.resize(n_groups);
-    h_values.resize(size_t{n_groups} * (n_aggregates ? n_aggregates : 1));
-    h_counts.resize(size_t{n_groups} * (n_aggregates ? n_aggregates : 1));
+    const uint32_t n_groups = host_flags[1];
+    out.n_groups = n_groups;
+    out.keys.resize(size_t{n_groups} * words);
+    out.first.resize(n_groups);
+    out.last.resize(n_groups);
+    out.values.resize(size_t{n_groups} * (n_aggregates ? n_aggregates : 1));
+    out.counts.resize(size_t{n_groups} * (n_aggregates ? n_aggregates : 1));
     if (n_groups) {
-      HY_HIP(hipMemcpyAsync(h_keys.data(), c_keys.ptr, 8 * h_keys.size(), hipMemcpyDeviceToHost, stream));
-      HY_HIP(hipMemcpyAsync(h_first.data(), c_first.ptr, 8 * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
-      HY_HIP(hipMemcpyAsync(h_last.data(), c_last.ptr, 8 * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
+      HY_HIP(hipMemcpyAsync(out.keys.data(), c_keys.ptr, 8 * out.keys.size(), hipMemcpyDeviceToHost, stream));
+      HY_HIP(hipMemcpyAsync(out.first.data(), c_first.ptr, 8 * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
+      HY_HIP(hipMemcpyAsync(out.last.data(), c_last.ptr, 8 * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
       if (n_aggregates) {
-        HY_HIP(hipMemcpyAsync(h_values.data(), c_values.ptr, 8 * h_values.size(), hipMemcpyDeviceToHost, stream));
-        HY_HIP(hipMemcpyAsync(h_counts.data(), c_counts.ptr, 8 * h_counts.size(), hipMemcpyDeviceToHost, stream));
+        HY_HIP(hipMemcpyAsync(out.values.data(), c_values.ptr, 8 * out.values.size(), hipMemcpyDeviceToHost, stream));
+        HY_HIP(hipMemcpyAsync(out.counts.data(), c_counts.ptr, 8 * out.counts.size(), hipMemcpyDeviceToHost, stream));
       }
       HY_HIP(hipStreamSynchronize(stream));
     }
-    break;
+    return HY_OK;
+  }
+  return fail(HY_ERR_DEVICE, "the device group table overflowed at every size (internal error)");
+}
+
+static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_groupby, const hy_aggregate_spec* specs, uint32_t n_aggregates,
+                               hy_aggregate_result* result) {
+  if (n_groupby > MAX_GROUPBY) return fail(HY_ERR_UNSUPPORTED, "more than %u GROUP BY columns stay on the CPU path", MAX_GROUPBY);
+  if (n_aggregates > MAX_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "more than %u aggregates stay on the CPU path", MAX_AGGREGATES);
+  const hy_column* shape = n_groupby ? groupby[0] : nullptr;
+  for (uint32_t g = 0; g < n_aggregates && !shape; ++g) shape = specs[g].column;
+  if (!shape) return fail(HY_ERR_INVALID, "hy_aggregate_hash needs at least one column (pass any column of the table for a lone COUNT(*))");
+  auto same_shape = [&](const hy_column* c) {
+    if (c->n_chunks != shape->n_chunks) return false;
+    for (uint32_t k = 0; k < c->n_chunks; ++k) if (c->host_segments[k].size != shape->host_segments[k].size) return false;
+    return true;
+  };
+  auto wire = [](AggColumn& slot, const hy_column* column, uint32_t function) {
+    slot.segments = column ? column->d_segments : nullptr;
+    slot.data_type = column ? column->data_type : static_cast<uint32_t>(HY_TYPE_LONG);
+    slot.is_float = column && (column->data_type == HY_TYPE_FLOAT || column->data_type == HY_TYPE_DOUBLE);
+    slot.function = function;
+  };
+  AggArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n_groupby = n_groupby;
+  for (uint32_t g = 0; g < n_groupby; ++g) {
+    if (!groupby[g] || !same_shape(groupby[g])) return fail(HY_ERR_INVALID, "GROUP BY column %u does not have the table's chunk layout", g);
+    if (groupby[g]->data_type == HY_TYPE_STRING) return fail(HY_ERR_UNSUPPORTED, "string GROUP BY columns must be passed as dictionary segments of int64 key names (INTEGRATION.md)");
+    wire(a.groupby[g], groupby[g], 0);
+  }
+  // Device accumulators.  STDDEV_SAMP takes two (sum as double + count, sum of squares); COUNT(DISTINCT) takes none: it
+  // is a second grouping by (GROUP BY columns, aggregate column) whose groups are counted per outer group.
+  std::vector<int> primary(n_aggregates, -1), secondary(n_aggregates, -1);
+  uint32_t n_device = 0;
+  for (uint32_t g = 0; g < n_aggregates; ++g) {
+    const hy_aggregate_spec& spec = specs[g];
+    if (spec.function > HY_AGG_ANY) return fail(HY_ERR_INVALID, "unknown aggregate function %u", spec.function);
+    if (!spec.column && spec.function != HY_AGG_COUNT) return fail(HY_ERR_INVALID, "only COUNT may omit its column (aggregate_hash.cpp:1002)");
+    if (spec.column) {
+      if (!same_shape(spec.column)) return fail(HY_ERR_INVALID, "aggregate column %u does not have the table's chunk layout", g);
+      if (spec.column->data_type == HY_TYPE_STRING && spec.function != HY_AGG_COUNT) return fail(HY_ERR_UNSUPPORTED, "string aggregates stay on the CPU path");
+    }
+    if (spec.function == HY_AGG_COUNT_DISTINCT) {
+      if (n_groupby + 1 > MAX_GROUPBY) return fail(HY_ERR_UNSUPPORTED, "COUNT(DISTINCT) with %u GROUP BY columns stays on the CPU path", n_groupby);
+      continue;
+    }
+    const uint32_t wanted = spec.function == HY_AGG_STDDEV_SAMP ? 2 : 1;
+    if (n_device + wanted > MAX_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "more than %u device accumulators stay on the CPU path", MAX_AGGREGATES);
+    primary[g] = static_cast<int>(n_device);
+    wire(a.aggregates[n_device++], spec.column, spec.function == HY_AGG_STDDEV_SAMP ? static_cast<uint32_t>(HY_AGG_AVG) : spec.function);
+    if (spec.function == HY_AGG_STDDEV_SAMP) {
+      secondary[g] = static_cast<int>(n_device);
+      wire(a.aggregates[n_device++], spec.column, AGG_SUM_SQUARES);
+    }
+  }
+  a.n_aggregates = n_device;
+  a.slices = shape->d_slices;
+  a.row_base = shape->d_row_base;
+  hipStream_t stream = current_stream();
+  const uint32_t words = n_groupby + 1;
+
+  DeviceGroups main_groups;
+  HY_TRY(device_groups(a, shape, main_groups));
+  const uint32_t n_groups = main_groups.n_groups;
+  const std::vector<uint64_t>&h_keys = main_groups.keys, &h_first = main_groups.first, &h_last = main_groups.last, &h_values = main_groups.values,
+                             &h_counts = main_groups.counts;
+
+  // COUNT(DISTINCT column): groups of (GROUP BY columns, column) with a non-NULL column value, counted per outer group
+  std::vector<std::vector<uint64_t>> distinct_counts(n_aggregates);
+  for (uint32_t g = 0; g < n_aggregates; ++g) {
+    if (specs[g].function != HY_AGG_COUNT_DISTINCT) continue;
+    AggArgs inner = a;
+    inner.n_groupby = n_groupby + 1;
+    inner.n_aggregates = 0;
+    wire(inner.groupby[n_groupby], specs[g].column, 0);
+    DeviceGroups combos;
+    HY_TRY(device_groups(inner, shape, combos));
+    std::map<std::vector<uint64_t>, uint32_t> group_of_key;
+    for (uint32_t i = 0; i < n_groups; ++i) group_of_key.emplace(std::vector<uint64_t>(h_keys.begin() + size_t{i} * words, h_keys.begin() + size_t{i + 1} * words), i);
+    distinct_counts[g].assign(n_groups, 0);
+    const uint32_t inner_words = words + 1;
+    for (uint32_t i = 0; i < combos.n_groups; ++i) {
+      const uint64_t* tuple = combos.keys.data() + size_t{i} * inner_words;
+      if ((tuple[0] >> n_groupby) & 1) continue;   // the aggregate column is NULL in this combination
+      std::vector<uint64_t> outer(tuple, tuple + words);
+      outer[0] &= (1ull << n_groupby) - 1;
+      const auto it = group_of_key.find(outer);
+      if (it != group_of_key.end()) distinct_counts[g][it->second] += 1;
+    }
   }
 
   // ---- order of the result rows (aggregate_hash.cpp:388-401, 770-804) ---------------------------------------------------
@@ -914,13 +983,25 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     }
     for (uint32_t o = 0; o < out_groups; ++o) {
       const bool have = o < n_groups;
-      const uint64_t bits = have ? h_values[size_t{order[o]} * n_aggregates + g] : 0;
-      const uint64_t count = have ? h_counts[size_t{order[o]} * n_aggregates + g] : 0;
+      const uint64_t bits = have && primary[g] >= 0 ? h_values[size_t{order[o]} * n_device + primary[g]] : 0;
+      const uint64_t count = have && primary[g] >= 0 ? h_counts[size_t{order[o]} * n_device + primary[g]] : 0;
       bool is_null = false;
       int64_t vi = 0;
       double vf = 0.0;
       switch (function) {
         case HY_AGG_COUNT: vi = static_cast<int64_t>(count); break;
+        case HY_AGG_COUNT_DISTINCT: vi = have ? static_cast<int64_t>(distinct_counts[g][order[o]]) : 0; break;
+        case HY_AGG_STDDEV_SAMP:   // abstract_aggregate_operator.hpp:83-113 (Welford there; sums here: float tolerance)
+          is_null = count <= 1;
+          if (count > 1) {
+            double sum, squares;
+            std::memcpy(&sum, &bits, 8);
+            std::memcpy(&squares, &h_values[size_t{order[o]} * n_device + secondary[g]], 8);
+            const double n = static_cast<double>(count);
+            const double variance = (squares - sum * sum / n) / (n - 1.0);
+            vf = variance > 0.0 ? std::sqrt(variance) : 0.0;
+          }
+          break;
         case HY_AGG_SUM:
           is_null = count == 0;
           if (is_float) std::memcpy(&vf, &bits, 8); else vi = static_cast<int64_t>(bits);

@@ -15,7 +15,6 @@ from support import AGG_BY_NAME, GOLDEN, build_column, load_tbl, oracle_aggregat
 pytestmark = pytest.mark.gpu
 FLOAT_TOLERANCE = 1e-9
 CASES = [c for c in json.load(open(os.path.join(os.path.dirname(GOLDEN), "aggregate_cases.json")))["cases"] if "string" not in c["input"]]
-UNSUPPORTED = {"CountDistinct", "StandardDeviationSample"}
 
 
 def assert_aggregate_equal(got, want, n_aggregates, context=""):
@@ -55,12 +54,6 @@ def test_reference_aggregate_fixture_on_device(device, case):
                for i in range(len(table.names))]
     groupby = [columns[g] for g in case["groupby"]]
     aggregates = [(AGG_BY_NAME[f], columns[c] if c is not None else None) for c, f in case["aggregates"]]
-    if any(f in UNSUPPORTED for _, f in case["aggregates"]):
-        devs = [DeviceColumn(c) for c in columns]
-        with pytest.raises(abi.HyriseAmdError) as err:
-            aggregate_hash([devs[g] for g in case["groupby"]], [(AGG_BY_NAME[f], devs[c] if c is not None else None) for c, f in case["aggregates"]])
-        assert err.value.status == abi.ERR_UNSUPPORTED
-        return
     run_both(groupby, aggregates, f"aggregate_test.cpp:{case['line']}")
 
 
@@ -114,3 +107,28 @@ def test_tpch_q1_core(device):
                                     (abi.AGG_COUNT, None)], "Q1 core")
     assert got.n_groups == 4
     assert sum(got.column(5)) == data.n_lineitems
+
+
+def test_count_distinct_and_stddev(device):
+    """COUNT(DISTINCT) = groups of (GROUP BY columns, column) counted per outer group; STDDEV_SAMP from n, sum, sum of
+    squares (the reference runs Welford's recurrence, abstract_aggregate_operator.hpp:83-113): 1e-9 relative."""
+    rng = np.random.default_rng(77)
+    n = 150_000
+    key_a = rng.integers(0, 7, n).astype(np.int32)
+    key_b = rng.integers(-3, 3, n).astype(np.int32)
+    ints = rng.integers(0, 400, n).astype(np.int32)
+    floats = (rng.integers(0, 50, n) / 4.0).astype(np.float32)
+    doubles = rng.normal(1000.0, 25.0, n)
+    int_nulls = rng.random(n) < 0.1
+    key_nulls = rng.random(n) < 0.02
+    for chunk, encoding in ((65535, abi.ENC_DICTIONARY), (9000, abi.ENC_UNENCODED)):
+        ka = build_column(key_a, key_nulls, chunk, encoding)
+        kb = build_column(key_b, None, chunk, encoding)
+        ci = build_column(ints, int_nulls, chunk, encoding)
+        cf = build_column(floats, None, chunk, encoding)
+        cd = build_column(doubles, None, chunk, abi.ENC_UNENCODED)
+        aggregates = [(abi.AGG_COUNT_DISTINCT, ci), (abi.AGG_STDDEV_SAMP, ci), (abi.AGG_COUNT_DISTINCT, cf), (abi.AGG_STDDEV_SAMP, cd),
+                      (abi.AGG_SUM, ci), (abi.AGG_COUNT, None)]
+        run_both([ka, kb], aggregates, f"distinct/stddev chunk {chunk} enc {encoding}")
+        run_both([ka], aggregates[:4], f"distinct/stddev one key chunk {chunk} enc {encoding}")
+        run_both([], aggregates[:4], f"distinct/stddev no GROUP BY chunk {chunk} enc {encoding}")
