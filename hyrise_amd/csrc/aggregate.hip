@@ -11,11 +11,13 @@
 // (or ascending key under the immediate-key shortcut).  Device design:
 //   aggregate_rows   one workgroup per 8192-row slice.  Every row's GROUP BY tuple (NULL mask + raw 64-bit values) is
 //                    looked up in a workgroup-private open-addressed hash table staged in LDS (tag word = lock,
-//                    ds_cmpswap to claim a slot); the aggregates accumulate with LDS atomics (ds_add_u64 / ds_add_f64
-//                    / ds_min / ds_max), together with the smallest and largest global row number of the group.  At
-//                    the end the (few) occupied LDS slots are merged into a global open-addressed table with
-//                    agent-scope atomics -- for TPC-H Q1 that is 4 groups x 6 aggregates per workgroup instead of 8192
-//                    x 6 global atomics.  Tiles whose groups do not fit the LDS table go to the global table directly.
+//                    ds_cmpswap to claim a slot).  Rows of the slice's first four groups accumulate in registers,
+//                    aggregate by aggregate, and reach the table through a wave reduction + one LDS atomic per wave;
+//                    rows of further groups use LDS atomics (ds_add_u64 / ds_add_f64 / ds_min / ds_max).  The smallest
+//                    and largest global row number of every group ride along.  At the end the (few) occupied LDS
+//                    slots are merged into a global open-addressed table with agent-scope atomics -- for TPC-H Q1 that
+//                    is 4 groups x 6 aggregates per workgroup instead of 8192 x 6 global atomics.  Rows whose group
+//                    does not fit the LDS table go to the global table directly.
 //   compact_groups   occupied global slots -> dense arrays.
 // The host then orders the groups exactly like the reference (first-row rank, or key order) and derives AVG.
 // SUM/AVG over float/double columns use f64 atomics: the additions happen in a different order than the reference's
