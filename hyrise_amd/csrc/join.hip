@@ -148,6 +148,40 @@ __global__ __launch_bounds__(256) void join_materialize(MaterializeArgs a) {
   }
 }
 
+// Build columns that cannot hold NULLs (value / FrameOfReference segments without a null vector): every row is
+// materialised at its own row number -- no counting, no ballots, eight rows of a lane in flight at a time.
+__global__ __launch_bounds__(256) void join_materialize_dense(MaterializeArgs a) {
+  const uint32_t tid = threadIdx.x;
+  const Slice slice = a.slices[blockIdx.x];
+  const DevSegment s = a.segments[slice.chunk];
+  const uint64_t base = a.slice_offsets[blockIdx.x];
+  constexpr uint32_t BATCH = 8;
+#pragma unroll 1
+  for (uint32_t block = 0; block < SLICE_ROWS / 256 / BATCH; ++block) {
+    uint32_t r[BATCH];
+    int64_t key[BATCH];
+#pragma unroll
+    for (uint32_t i = 0; i < BATCH; ++i) {
+      r[i] = (block * BATCH + i) * 256 + tid;
+      const uint32_t row = slice.row_begin + (r[i] < slice.row_count ? r[i] : 0);
+      if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+        key[i] = static_cast<int32_t>(jload_compressed(s.data, s.width, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]));
+      } else if (s.data_type == HY_TYPE_INT) {
+        key[i] = static_cast<const int32_t*>(s.data)[row];
+      } else {
+        key[i] = static_cast<const int64_t*>(s.data)[row];
+      }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < BATCH; ++i) {
+      if (r[i] >= slice.row_count) continue;
+      a.keys[base + r[i]] = static_cast<uint64_t>(key[i]);
+      a.row_ids[base + r[i]] = hy_row_id{slice.chunk, slice.row_begin + r[i]};
+      if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(key[i]) & (BLOOM_BITS - 1)] = 1;
+    }
+  }
+}
+
 // Single-workgroup exclusive scan of u32 counts into u64 offsets (n is a few thousand); offsets[n] = total.
 __global__ __launch_bounds__(1024) void scan_counts(const uint32_t* counts, uint64_t* offsets, uint32_t n) {
   __shared__ uint64_t s_partial[1024];
@@ -368,20 +402,19 @@ struct Directory {
   uint32_t n_buckets;
 };
 
-__global__ void directory_fill(const uint64_t* keys, uint64_t n, uint64_t key_min, uint32_t shift, uint32_t n_buckets, uint32_t* dir) {
+__global__ void directory_fill(const uint64_t* keys, uint64_t n, uint64_t key_min, uint32_t shift, uint32_t n_buckets, uint32_t* dir, uint32_t* keys32) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (keys32) {   // int32 build columns: the low halves, same order, padded by four entries
+    keys32[i] = static_cast<uint32_t>(keys[i]);
+    if (i + 1 == n) { keys32[n] = 0; keys32[n + 1] = 0; keys32[n + 2] = 0; keys32[n + 3] = 0; }
+  }
   const uint64_t bucket = (keys[i] - key_min) >> shift;
   const int64_t previous = i == 0 ? -1 : static_cast<int64_t>((keys[i - 1] - key_min) >> shift);
   for (int64_t b = previous + 1; b <= static_cast<int64_t>(bucket); ++b) dir[b] = static_cast<uint32_t>(i);
   if (i + 1 == n) {
     for (uint64_t b = bucket + 1; b <= n_buckets; ++b) dir[b] = static_cast<uint32_t>(n);
   }
-}
-
-__global__ void narrow_keys(const uint64_t* keys, uint64_t n, uint32_t* keys32) {
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n + 4) keys32[i] = i < n ? static_cast<uint32_t>(keys[i]) : 0u;
 }
 
 // (start, count) of `key` in the sorted build keys.  Buckets of up to four keys (the directory is sized for ~one key
@@ -779,24 +812,27 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
   }
 }
 
-// LDS of probe_emit, in 4-byte words: per-row lookup results | staged pairs | per-(wave, partition) running counters |
-// per-partition offsets inside the tile | global bases of the tile's cells.
+// LDS of probe_emit, in 4-byte words: staged pairs | the pair counts of a wave's current round | per-(wave, partition)
+// running counters | per-partition offsets inside the tile | global bases of the tile's cells.
 __host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
-  return 2 * size_t{JOIN_TILE} + 2 * size_t{JOIN_STAGE} + 2 * size_t{JOIN_WAVES} * partitions + (partitions + 1) + 6 * size_t{partitions} + 8;
+  return 2 * size_t{JOIN_STAGE} + JOIN_THREADS + 2 * size_t{JOIN_WAVES} * partitions + (partitions + 1) + 6 * size_t{partitions} + 8;
 }
 
-// Pass 2: every tile knows, from the scanned histograms, where its pairs of every partition go.  The tile is evaluated
-// once (lookup results parked in LDS), a wave-level match-any ranking gives every row its stable rank inside
+// Pass 2: every tile knows, from the scanned histograms, where its pairs of every partition go.  A lane keeps the lookup
+// results of its eight rows in registers (CACHED: re-read from pass 1's word per row; otherwise -- tiles whose rows did
+// not fit that word -- evaluated again by a second launch of this kernel, so that the common instantiation needs few
+// enough registers for three workgroups per CU), a wave-level match-any ranking gives every row its stable rank inside
 // (partition, tile), and the pairs are first laid out partition by partition in LDS and then copied out, so that a run of
 // consecutive lanes writes a run of consecutive RowIDs: a (tile, partition) cell is one contiguous piece of the output.
 // Tiles whose pairs do not fit the staging buffer (build keys with many duplicates) write their pairs directly.
-__global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
+template <bool CACHED>
+__global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void probe_emit(ProbeArgs a) {
+  if ((a.tile_uncached[blockIdx.x] == 0) != CACHED) return;   // the other instantiation's tile
   extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
   const uint32_t partitions = 1u << a.radix_bits;
-  uint32_t* s_start = join_smem;                                     // [JOIN_TILE] first build position of the row's matches
-  uint32_t* s_meta = s_start + JOIN_TILE;                            // [JOIN_TILE] emit << 10 | null_partner << 9 | partition
-  uint32_t* s_stage = s_meta + JOIN_TILE;                            // [JOIN_STAGE][2] row | partition << 12 | null << 21 , build position
-  uint32_t* s_run_elements = s_stage + 2 * JOIN_STAGE;               // [JOIN_WAVES][partitions]
+  uint32_t* s_stage = join_smem;                                     // [JOIN_STAGE][2] row | partition << 12 | null << 21 , build position
+  uint32_t* s_round_emit = s_stage + 2 * JOIN_STAGE;                 // [JOIN_WAVES][64] pairs of the rows of a wave's current round
+  uint32_t* s_run_elements = s_round_emit + JOIN_THREADS;            // [JOIN_WAVES][partitions]
   uint32_t* s_run_pairs = s_run_elements + JOIN_WAVES * partitions;  // [JOIN_WAVES][partitions]
   uint32_t* s_tile_offset = s_run_pairs + JOIN_WAVES * partitions;   // [partitions + 1] first staged slot of every partition
   uint64_t* s_base_pairs = reinterpret_cast<uint64_t*>(s_tile_offset + partitions + 1 + ((partitions + 1) & 1));   // [partitions]
@@ -818,21 +854,16 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
     cell_slice_base = a.partition_slice_base[group];
   }
 
-  // (a) evaluate every row once
-  {
-    uint32_t meta[JOIN_ROUNDS], start[JOIN_ROUNDS];
-    if (a.row_cache && a.tile_uncached[blockIdx.x] == 0) cached_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
-    else evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
+  // (a) the lookup results of the lane's rows (row  wave*512 + round*64 + lane  <->  index round)
+  uint32_t row_meta[JOIN_ROUNDS], row_start[JOIN_ROUNDS];
+  if constexpr (CACHED) cached_rows(a, chunk, row_begin, row_count, wave, lane, row_meta, row_start);
+  else evaluate_rows(a, chunk, row_begin, row_count, wave, lane, row_meta, row_start);
 #pragma unroll
-    for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
-      const uint32_t r = wave * JOIN_WAVE_ROWS + round * 64 + lane;
-      s_start[r] = start[round];
-      s_meta[r] = meta[round];
-      const uint32_t partition = meta[round] & 0x1FF;
-      if (partition != INVALID_PARTITION) {
-        atomicAdd(&s_run_elements[wave * partitions + partition], 1u);
-        if (meta[round] >> 10) atomicAdd(&s_run_pairs[wave * partitions + partition], meta[round] >> 10);
-      }
+  for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
+    const uint32_t partition = row_meta[round] & 0x1FF;
+    if (partition != INVALID_PARTITION) {
+      atomicAdd(&s_run_elements[wave * partitions + partition], 1u);
+      if (row_meta[round] >> 10) atomicAdd(&s_run_pairs[wave * partitions + partition], row_meta[round] >> 10);
     }
   }
   __syncthreads();
@@ -882,16 +913,21 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
 
   // (d) stable ranking inside the wave, round by round
   const hy_row_id null_row{0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
   for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
     const uint32_t round_base = wave * JOIN_WAVE_ROWS + round * 64;
     const uint32_t r = round_base + lane;
-    const uint32_t meta = s_meta[r];
+    const uint32_t meta = row_meta[round];
     const uint32_t partition = meta & 0x1FF;
     const uint32_t emit = meta >> 10;
     const bool valid = partition != INVALID_PARTITION;
     const uint64_t peers = match_any(partition, valid, a.radix_bits);
     const uint64_t lower = peers & ((1ull << lane) - 1);
     const uint64_t many = __ballot(emit > 1), one = __ballot(emit == 1);
+    if (many != 0) {   // rows with several partners: the peers' pair counts are read from LDS
+      s_round_emit[wave * 64 + lane] = emit;
+      __builtin_amdgcn_wave_barrier();
+    }
     uint32_t pairs_before = 0, pairs_total = 0;
     if (valid) {
       if (many == 0) {
@@ -899,10 +935,11 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
         pairs_total = __popcll(peers & one);
       } else {
         uint64_t rest = peers;
+#pragma unroll 1
         while (rest) {
           const uint32_t j = __ffsll(static_cast<long long>(rest)) - 1;
           rest &= rest - 1;
-          const uint32_t e = s_meta[round_base + j] >> 10;
+          const uint32_t e = s_round_emit[wave * 64 + j];
           if (j < lane) pairs_before += e;
           pairs_total += e;
         }
@@ -913,16 +950,16 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
       if (element_rank == s_cut_rank[partition]) a.slice_offsets[s_cut_slice[partition]] = pair_pos;
       if (emit) {
         const bool null_partner = meta & 0x200u;
-        const uint32_t start = s_start[r];
+        const uint32_t start = row_start[round];
         if (staged) {
           const uint32_t slot = s_tile_offset[partition] + pair_rank;
           const uint32_t tag = r | (partition << 12) | (null_partner ? 1u << 21 : 0u);
-          for (uint32_t t = 0; t < emit; ++t) {
-            s_stage[2 * (slot + t)] = tag;
-            s_stage[2 * (slot + t) + 1] = start + t;
-          }
+          reinterpret_cast<u32x2_t*>(s_stage)[slot] = u32x2_t{tag, start};
+#pragma unroll 1
+          for (uint32_t t = 1; t < emit; ++t) reinterpret_cast<u32x2_t*>(s_stage)[slot + t] = u32x2_t{tag, start + t};   // several partners: rare
         } else {
           const hy_row_id probe_id{chunk, row_begin + r};
+#pragma unroll 1
           for (uint32_t t = 0; t < emit; ++t) {
             a.probe_out[pair_pos + t] = probe_id;
             if (a.build_out) a.build_out[pair_pos + t] = null_partner ? null_row : a.dir.row_ids[start + t];
@@ -941,7 +978,8 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit(ProbeArgs a) {
   __syncthreads();
   // (e) copy out: slot s of partition p is pair  base_pairs[p][tile] + (s - first slot of p)
   for (uint32_t s = tid; s < tile_pairs; s += JOIN_THREADS) {
-    const uint32_t tag = s_stage[2 * s], position = s_stage[2 * s + 1];
+    const u32x2_t record = reinterpret_cast<const u32x2_t*>(s_stage)[s];
+    const uint32_t tag = record.x, position = record.y;
     const uint32_t partition = (tag >> 12) & 0x1FF;
     const uint64_t pair_pos = s_base_pairs[partition] + (s - s_tile_offset[partition]);
     const u32x2_t probe_id = {chunk, row_begin + (tag & 0xFFFu)};
@@ -988,6 +1026,7 @@ struct BuildSide {
   uint64_t n = 0;
   Directory directory{};
   bool any_null = false;
+  std::vector<uint64_t> host_slice_offsets;   // source of an asynchronous upload: lives as long as the join
 };
 
 // Materialise + (sort) + directory.  `bloom_in` (device) filters the build side (no observable effect, kept for the
@@ -1013,27 +1052,55 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   m.slice_counts = counts.as<uint32_t>();
   m.any_null = b.flags.as<uint32_t>() + 2;
   uint64_t total = 0;
-  if (n_slices) {
+  // A column whose segments cannot hold NULLs (value / FrameOfReference segments without a null vector) materialises
+  // every row: slice offsets are row numbers, no counting pass and no host round trip.
+  bool dense = true;
+  for (uint32_t c = 0; c < build->n_chunks && dense; ++c) {
+    const hy_segment& seg = build->host_segments[c];
+    dense = (seg.encoding == HY_ENC_UNENCODED || seg.encoding == HY_ENC_FRAME_OF_REFERENCE) && seg.nulls == nullptr;
+  }
+  if (n_slices && dense) {
+    std::vector<uint64_t>& slice_offsets = b.host_slice_offsets;
+    slice_offsets.clear();
+    slice_offsets.reserve(size_t{n_slices} + 1);
+    for (uint32_t c = 0; c < build->n_chunks; ++c) {
+      uint32_t begin = 0;
+      do {   // the same cuts as hy_column_create
+        slice_offsets.push_back(build->row_base[c] + begin);
+        begin += SLICE_ROWS;
+      } while (begin < build->host_segments[c].size);
+    }
+    slice_offsets.push_back(build->rows);
+    if (slice_offsets.size() != size_t{n_slices} + 1) return fail(HY_ERR_DEVICE, "slice table mismatch (internal error)");
+    HY_HIP(hipMemcpyAsync(offsets.ptr, slice_offsets.data(), 8 * slice_offsets.size(), hipMemcpyHostToDevice, stream));
+    total = build->rows;
+  } else if (n_slices) {
     hipLaunchKernelGGL(join_materialize<0>, dim3(n_slices), dim3(256), 0, stream, m);
     hipLaunchKernelGGL(scan_counts, dim3(1), dim3(1024), 0, stream, counts.as<uint32_t>(), offsets.as<uint64_t>(), n_slices);
     HY_HIP(hipMemcpyAsync(&total, offsets.as<uint64_t>() + n_slices, 8, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
   }
   b.n = total;
+  uint64_t first_key = 0, last_key = 0;
+  bool keys_were_sorted = false;
   HY_TRY(b.keys.alloc(8 * total));
   HY_TRY(b.rows.alloc(8 * total));
   if (total) {
     m.slice_offsets = offsets.as<uint64_t>();
     m.keys = b.keys.as<uint64_t>();
     m.row_ids = b.rows.as<hy_row_id>();
-    hipLaunchKernelGGL(join_materialize<1>, dim3(n_slices), dim3(256), 0, stream, m);
+    if (dense) hipLaunchKernelGGL(join_materialize_dense, dim3(n_slices), dim3(256), 0, stream, m);
+    else hipLaunchKernelGGL(join_materialize<1>, dim3(n_slices), dim3(256), 0, stream, m);
     uint32_t* unsorted = b.flags.as<uint32_t>();
     unsigned long long* key_or = reinterpret_cast<unsigned long long*>(b.flags.as<uint32_t>() + 4);
     hipLaunchKernelGGL(check_sorted, dim3(static_cast<uint32_t>(std::min<uint64_t>((total + 1023) / 1024, 1024))), dim3(1024), 0, stream, b.keys.as<uint64_t>(), total, unsorted, key_or);
     uint32_t host_flags[8];
     HY_HIP(hipMemcpyAsync(host_flags, b.flags.ptr, 32, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipMemcpyAsync(&first_key, b.keys.ptr, 8, hipMemcpyDeviceToHost, stream));   // min / max if the keys are already sorted
+    HY_HIP(hipMemcpyAsync(&last_key, b.keys.as<uint64_t>() + (total - 1), 8, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
     b.any_null = host_flags[2] != 0;
+    keys_were_sorted = host_flags[0] == 0;
     if (host_flags[0]) {   // not sorted: stable LSD radix sort, only over the bytes that are not constant zero
       uint64_t key_bits;
       std::memcpy(&key_bits, &host_flags[4], 8);
@@ -1071,16 +1138,20 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   d.n = total;
   if (total && build->data_type == HY_TYPE_INT) {
     HY_TRY(b.keys32.alloc(4 * (total + 4)));
-    hipLaunchKernelGGL(narrow_keys, dim3(static_cast<uint32_t>((total + 4 + 255) / 256)), dim3(256), 0, stream, d.keys, total, b.keys32.as<uint32_t>());
-    d.keys32 = b.keys32.as<uint32_t>();
+    d.keys32 = b.keys32.as<uint32_t>();   // filled by directory_fill
   }
   d.key_min = d.key_max = 0;
   d.shift = 0;
   d.n_buckets = 1;
   if (total) {
-    HY_HIP(hipMemcpyAsync(&d.key_min, d.keys, 8, hipMemcpyDeviceToHost, stream));
-    HY_HIP(hipMemcpyAsync(&d.key_max, d.keys + (total - 1), 8, hipMemcpyDeviceToHost, stream));
-    HY_HIP(hipStreamSynchronize(stream));
+    if (keys_were_sorted) {
+      d.key_min = first_key;
+      d.key_max = last_key;
+    } else {
+      HY_HIP(hipMemcpyAsync(&d.key_min, d.keys, 8, hipMemcpyDeviceToHost, stream));
+      HY_HIP(hipMemcpyAsync(&d.key_max, d.keys + (total - 1), 8, hipMemcpyDeviceToHost, stream));
+      HY_HIP(hipStreamSynchronize(stream));
+    }
     uint32_t buckets = 1;
     while (buckets < total && buckets < (1u << 27)) buckets <<= 1;   // 1-2 keys per bucket on uniform keys: one probe of four keys
     const uint64_t range = d.key_max - d.key_min;
@@ -1092,7 +1163,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   HY_TRY(b.dir.alloc(4 * (size_t{d.n_buckets} + 2)));
   d.dir = b.dir.as<uint32_t>();
   if (total) {
-    hipLaunchKernelGGL(directory_fill, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, stream, d.keys, total, d.key_min, d.shift, d.n_buckets, b.dir.as<uint32_t>());
+    hipLaunchKernelGGL(directory_fill, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, stream, d.keys, total, d.key_min, d.shift, d.n_buckets, b.dir.as<uint32_t>(), const_cast<uint32_t*>(d.keys32));
   } else {
     HY_HIP(hipMemsetAsync(b.dir.ptr, 0, 4 * (size_t{d.n_buckets} + 2), stream));
   }
@@ -1241,12 +1312,14 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     const size_t lds_bytes = 4 * probe_emit_lds_words(partitions);
     static bool lds_raised = false;
     if (!lds_raised) {
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
       lds_raised = true;
     }
     profile_begin(stream);
-    hipLaunchKernelGGL(probe_emit, dim3(n_tiles), dim3(JOIN_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL(probe_emit<true>, dim3(n_tiles), dim3(JOIN_THREADS), lds_bytes, stream, a);
     profile_end(stream);
+    hipLaunchKernelGGL(probe_emit<false>, dim3(n_tiles), dim3(JOIN_THREADS), lds_bytes, stream, a);   // tiles pass 1 flagged (rare)
   }
   HY_HIP(hipMemcpyAsync(dev_slice_offsets + n_slices, &result->n_pairs, 8, hipMemcpyHostToDevice, stream));
   HY_HIP(hipGetLastError());
