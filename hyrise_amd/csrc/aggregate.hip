@@ -134,22 +134,22 @@ __device__ __forceinline__ uint64_t hash_tuple(const uint64_t* tuple, uint32_t w
   return (static_cast<uint64_t>(h2) << 32) | h1;
 }
 
-// the same function with a compile-time loop bound (tuples that live in registers must not be indexed dynamically)
-__device__ __forceinline__ uint64_t hash_tuple_static(const uint64_t (&tuple)[MAX_GROUPBY + 1], uint32_t words) {
-  uint32_t h1 = 0x9E3779B9u, h2 = 0x85EBCA6Bu;
+// Hash for the workgroup's LDS table only (computed for every row): fold the words with rotates and xors, then two
+// multiplies -- 32-bit multiplies run at quarter rate, the per-word mixing of hash_tuple costs more than the lookup itself.
+// Structured tuples may collide here; that costs probes in a 256-slot table, never correctness.
+__device__ __forceinline__ uint64_t hash_local(const uint64_t (&tuple)[MAX_GROUPBY + 1], uint32_t words) {
+  uint32_t lo = 0x9E3779B9u, hi = 0x85EBCA6Bu;
 #pragma unroll
   for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) {
     if (w < words) {
-      const uint32_t lo = static_cast<uint32_t>(tuple[w]), hi = static_cast<uint32_t>(tuple[w] >> 32);
-      h1 = (h1 ^ lo) * 0x9E3779B1u;
-      h1 = (h1 ^ (h1 >> 15) ^ hi) * 0x85EBCA77u;
-      h2 = (h2 ^ hi) * 0xC2B2AE3Du;
-      h2 = (h2 ^ (h2 >> 13) ^ lo) * 0x27D4EB2Fu;
+      lo = ((lo << 7) | (lo >> 25)) ^ static_cast<uint32_t>(tuple[w]);
+      hi = ((hi << 11) | (hi >> 21)) + static_cast<uint32_t>(tuple[w] >> 32);
     }
   }
-  h1 ^= h1 >> 16;
-  h2 ^= h2 >> 15;
-  return (static_cast<uint64_t>(h2) << 32) | h1;
+  uint32_t h1 = (lo ^ (hi * 0x9E3779B1u)) * 0x85EBCA77u;
+  h1 ^= h1 >> 15;
+  const uint32_t h2 = (h1 ^ lo) * 0xC2B2AE3Du;
+  return (static_cast<uint64_t>(h2 ^ (h2 >> 13)) << 32) | h1;
 }
 
 __device__ __forceinline__ uint64_t initial_value(uint32_t function) {
@@ -405,12 +405,16 @@ __device__ __forceinline__ void row_tuple(const AggArgs& a, uint32_t chunk, uint
 //                       slot of a dense index [DENSE_GROUPS] u32 | number of groups u32 | slot of every row [SLICE_ROWS] u8
 //
 // One workgroup per 8192-row slice, 32 rows per thread (row k*256 + tid of the slice):
-//   pass 1  GROUP BY: the thread's rows are decoded 8 at a time (all loads of a column first), every tuple is looked up /
-//           inserted in the workgroup's LDS hash table, and the row's slot is remembered.  A new group also gets a dense
-//           index (its arrival number).
+//   pass 1  GROUP BY, four rows of a thread at a time: every tuple is looked up / inserted in the workgroup's LDS table and
+//           the row's slot is remembered.  Dictionary columns are keyed by their VALUE IDS inside the slice (one chunk) and
+//           translated to values only when the slice's groups are merged into the global table; when every GROUP BY
+//           column is a dictionary segment and the product of (dictionary size + 1) fits the table, the combined value-id
+//           code IS the slot (no hash, no probing, no key comparison: TPC-H Q1).  A new group also gets a dense index
+//           (its arrival number).
 //   pass 2  aggregate by aggregate, 16 rows at a time: rows of the first DENSE_GROUPS groups of the slice (TPC-H Q1 has 4
-//           in total) accumulate in registers, one accumulator per dense group; a wave reduction and one LDS atomic per wave
-//           and group fold them into the table.  (256 threads doing LDS atomics on 4 cells serialise completely.)
+//           in total) accumulate in thread-private LDS cells (one per dense group and thread: LDS atomics that never
+//           conflict and whose results nobody waits for); a wave reduction and one LDS atomic per wave and group fold the
+//           cells into the table.  (256 threads doing LDS atomics on 4 shared cells serialise completely.)
 //   pass 3  only if the slice has more groups: the remaining rows use LDS atomics per row -- the more groups, the fewer
 //           conflicts -- and rows whose group does not fit the LDS table go to the global table directly.
 //   merge   the slice's groups go to the global table with agent-scope atomics.
@@ -426,7 +430,9 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   uint32_t* s_dense_of_slot = s_tags + LDS_SLOTS;                                            // [LDS_SLOTS]
   uint32_t* s_slot_of_dense = s_dense_of_slot + LDS_SLOTS;                                   // [DENSE_GROUPS]
   uint32_t* s_n_groups = s_slot_of_dense + DENSE_GROUPS;
-  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_n_groups + 4);                          // [SLICE_ROWS]
+  uint64_t* s_cell_value = reinterpret_cast<uint64_t*>(s_n_groups + 4);                     // [DENSE_GROUPS][256] thread-private accumulators
+  uint32_t* s_cell_count = reinterpret_cast<uint32_t*>(s_cell_value + DENSE_GROUPS * 256);   // [DENSE_GROUPS][256]
+  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_cell_count + DENSE_GROUPS * 256);       // [SLICE_ROWS]
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   for (uint32_t s = tid; s < LDS_SLOTS; s += 256) {
     s_tags[s] = TAG_EMPTY;
@@ -446,7 +452,26 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   if (slice.row_count == 0) return;
   uint32_t in_table = 0;   // bit k: row k found its group in the LDS table
 
-  // ---- pass 1: group lookup, 8 rows at a time -----------------------------------------------------------------------------
+  uint32_t local_keys = 0;   // bit g: GROUP BY column g is a dictionary segment in this chunk (keyed by value id inside the slice)
+  for (uint32_t g = 0; g < a.n_groupby; ++g) {
+    if (a.groupby[g].segments[slice.chunk].encoding == HY_ENC_DICTIONARY) local_keys |= 1u << g;
+  }
+  // direct-mapped table?
+  uint32_t direct_size[MAX_GROUPBY] = {1, 1, 1, 1}, direct_stride[MAX_GROUPBY] = {0, 0, 0, 0};
+  bool direct = a.n_groupby > 0 && local_keys == (1u << a.n_groupby) - 1;
+  {
+    uint64_t product = 1;
+#pragma unroll
+    for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+      if (g < a.n_groupby && direct) {
+        direct_size[g] = a.groupby[g].segments[slice.chunk].aux_size + 1;   // + 1: NULL
+        direct_stride[g] = static_cast<uint32_t>(product);
+        product *= direct_size[g];
+        if (product > LDS_SLOTS) direct = false;
+      }
+    }
+  }
+  // ---- pass 1: group lookup, 4 rows at a time -----------------------------------------------------------------------------
   constexpr int GB = 4;
 #pragma unroll 1
   for (uint32_t block = 0; block < ROWS / GB; ++block) {
@@ -457,14 +482,35 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       if (r < slice.row_count) valid |= 1u << i;
       row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
     }
+    // Inside a slice (one chunk) a dictionary column's VALUE ID identifies the value, so dictionary columns are keyed by
+    // their value ids here and translated to values only when the slice's groups are merged into the global table:
+    // pass 1 never touches the dictionaries.  The attribute-vector loads of all dictionary columns are issued first.
     uint64_t tuple[GB][MAX_GROUPBY + 1];
 #pragma unroll
     for (int i = 0; i < GB; ++i) tuple[i][0] = 0;
+    uint32_t vid[MAX_GROUPBY][GB];
+#pragma unroll
+    for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+      if (g >= a.n_groupby || !((local_keys >> g) & 1)) continue;
+      const DevSegment& seg = a.groupby[g].segments[slice.chunk];
+#pragma unroll
+      for (int i = 0; i < GB; ++i) vid[g][i] = aload_compressed(seg.data, seg.width, row[i]);
+    }
 #pragma unroll
     for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
       if (g >= a.n_groupby) {
 #pragma unroll
         for (int i = 0; i < GB; ++i) tuple[i][g + 1] = 0;
+        continue;
+      }
+      if ((local_keys >> g) & 1) {
+        const uint32_t dictionary_size = a.groupby[g].segments[slice.chunk].aux_size;
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+          const bool is_null = vid[g][i] >= dictionary_size;
+          if (is_null) tuple[i][0] |= 1ull << g;
+          tuple[i][g + 1] = is_null ? 0 : vid[g][i];
+        }
         continue;
       }
       uint64_t bits[GB];
@@ -478,11 +524,39 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         tuple[i][g + 1] = word;
       }
     }
+    if (direct) {
+      // every GROUP BY column is a dictionary segment and the product of (dictionary size + 1) fits the table: the
+      // combined value-id code IS the slot -- no hash, no probing, no key comparison
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        if (!((valid >> i) & 1)) continue;
+        const uint32_t k = block * GB + i;
+        uint32_t slot = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+          if (g < a.n_groupby) slot += (((tuple[i][0] >> g) & 1) ? direct_size[g] - 1 : static_cast<uint32_t>(tuple[i][g + 1])) * direct_stride[g];
+        }
+        if (__hip_atomic_load(&s_tags[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == TAG_EMPTY) {
+          if (atomicCAS(&s_tags[slot], TAG_EMPTY, TAG_LOCKED) == TAG_EMPTY) {   // first row of this group in the slice
+#pragma unroll
+            for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) { if (w < words) s_keys[slot * words + w] = tuple[i][w]; }
+            const uint32_t dense = atomicAdd(s_n_groups, 1u);
+            s_dense_of_slot[slot] = dense;
+            if (dense < DENSE_GROUPS) s_slot_of_dense[dense] = slot;
+            __threadfence_block();
+            atomicExch(&s_tags[slot], 0x80000000u);
+          }
+        }
+        in_table |= 1u << k;
+        s_row_slot[k * 256 + tid] = static_cast<uint8_t>(slot);
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
       if (!((valid >> i) & 1)) continue;
       const uint32_t k = block * GB + i;
-      const uint64_t hash = hash_tuple_static(tuple[i], words);
+      const uint64_t hash = hash_local(tuple[i], words);
       // workgroup-private table in LDS (same lock discipline as global_slot)
       const uint32_t ready = 0x80000000u | static_cast<uint32_t>(hash >> 33);
       uint32_t slot = static_cast<uint32_t>(hash) & (LDS_SLOTS - 1);
@@ -490,7 +564,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       uint32_t probes = 0;
       bool done = false;
       while (!done) {
-        const uint32_t tag = atomicAdd(&s_tags[slot], 0u);
+        const uint32_t tag = __hip_atomic_load(&s_tags[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);   // a plain ds_read: 256 threads reading 4 hot tags with an atomic RMW serialise
         if (tag == TAG_EMPTY) {
           if (atomicCAS(&s_tags[slot], TAG_EMPTY, TAG_LOCKED) == TAG_EMPTY) {
 #pragma unroll
@@ -578,10 +652,13 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     else if (c.function == HY_AGG_AVG || c.function == AGG_SUM_SQUARES) kind = ACC_ADD_DOUBLE;
     const bool to_ordered = (kind == ACC_MIN || kind == ACC_MAX) && c.is_float;   // MIN/MAX of doubles on order-preserving int64
     const bool int_to_double = c.function == HY_AGG_AVG && !c.is_float;
-    uint64_t accumulator[DENSE_GROUPS];
-    uint32_t counts = 0;   // rows accumulated per dense group, 8 bits each (a thread has 32 rows)
+    // One private cell per (dense group, thread): the LDS read-modify-write instructions below never conflict, a row
+    // costs one ds_add / ds_min / ds_max on the value cell and one ds_add on the count cell.
 #pragma unroll
-    for (uint32_t j = 0; j < DENSE_GROUPS; ++j) accumulator[j] = initial_value(c.function);
+    for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+      s_cell_value[j * 256 + tid] = initial_value(c.function);
+      s_cell_count[j * 256 + tid] = 0;
+    }
 #pragma unroll 1
     for (uint32_t half = 0; half < ROWS / AB; ++half) {
       const uint32_t members = (is_dense >> (half * AB)) & 0xFFFFu;
@@ -611,48 +688,30 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         for (int i = 0; i < AB; ++i) bits[i] = 0;   // COUNT(*)
       }
       const uint32_t take = members & ~nulls;
+      // The cells are private to the thread, yet LDS atomics (no return value, nothing waits for them) beat a plain
+      // read-modify-write here: the latter makes every row of a group wait for the previous row's LDS round trip.
+      uint32_t cell[AB];
 #pragma unroll
       for (int i = 0; i < AB; ++i) {
-        if ((take >> i) & 1) counts += 1u << (8 * ((dense_bits >> (2 * i)) & 3));
+        cell[i] = ((dense_bits >> (2 * i)) & 3) * 256 + tid;
+        if ((take >> i) & 1) atomicAdd(&s_cell_count[cell[i]], 1u);
       }
-      switch (kind) {
+      switch (kind) {   // one loop per kind: the row loop itself stays free of scalar branches
         case ACC_MIN:
 #pragma unroll
-          for (int i = 0; i < AB; ++i) {
-#pragma unroll
-            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
-              if (((take >> i) & 1) && ((dense_bits >> (2 * i)) & 3) == j) accumulator[j] = static_cast<uint64_t>(min(static_cast<long long>(accumulator[j]), static_cast<long long>(bits[i])));
-            }
-          }
+          for (int i = 0; i < AB; ++i) if ((take >> i) & 1) atomicMin(reinterpret_cast<long long*>(&s_cell_value[cell[i]]), static_cast<long long>(bits[i]));
           break;
         case ACC_MAX:
 #pragma unroll
-          for (int i = 0; i < AB; ++i) {
-#pragma unroll
-            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
-              if (((take >> i) & 1) && ((dense_bits >> (2 * i)) & 3) == j) accumulator[j] = static_cast<uint64_t>(max(static_cast<long long>(accumulator[j]), static_cast<long long>(bits[i])));
-            }
-          }
+          for (int i = 0; i < AB; ++i) if ((take >> i) & 1) atomicMax(reinterpret_cast<long long*>(&s_cell_value[cell[i]]), static_cast<long long>(bits[i]));
           break;
         case ACC_ADD_INT:
 #pragma unroll
-          for (int i = 0; i < AB; ++i) {
-#pragma unroll
-            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
-              if (((take >> i) & 1) && ((dense_bits >> (2 * i)) & 3) == j) accumulator[j] += bits[i];
-            }
-          }
+          for (int i = 0; i < AB; ++i) if ((take >> i) & 1) atomicAdd(reinterpret_cast<unsigned long long*>(&s_cell_value[cell[i]]), static_cast<unsigned long long>(bits[i]));
           break;
         case ACC_ADD_DOUBLE:
 #pragma unroll
-          for (int i = 0; i < AB; ++i) {
-#pragma unroll
-            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
-              if (((take >> i) & 1) && ((dense_bits >> (2 * i)) & 3) == j) {
-                accumulator[j] = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(accumulator[j])) + __longlong_as_double(static_cast<long long>(bits[i]))));
-              }
-            }
-          }
+          for (int i = 0; i < AB; ++i) if ((take >> i) & 1) atomicAdd(reinterpret_cast<double*>(&s_cell_value[cell[i]]), __longlong_as_double(static_cast<long long>(bits[i])));
           break;
         default: break;
       }
@@ -660,8 +719,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
 #pragma unroll
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
       if (j >= n_dense) break;
-      const uint64_t value = wave_combine(c, accumulator[j]);
-      uint32_t count = (counts >> (8 * j)) & 0xFF;
+      const uint64_t value = wave_combine(c, s_cell_value[j * 256 + tid]);
+      uint32_t count = s_cell_count[j * 256 + tid];
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d, 64);
       if (lane == 0 && count != 0) {
@@ -710,6 +769,20 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     if (s_tags[s] == TAG_EMPTY) continue;
     uint64_t tuple[MAX_GROUPBY + 1];
     for (uint32_t w = 0; w < words; ++w) tuple[w] = s_keys[s * words + w];
+    for (uint32_t g = 0; g < a.n_groupby; ++g) {   // value ids -> values
+      if (!((local_keys >> g) & 1) || ((tuple[0] >> g) & 1)) continue;
+      const DevSegment& seg = a.groupby[g].segments[slice.chunk];
+      const uint32_t id = static_cast<uint32_t>(tuple[g + 1]);
+      uint64_t bits;
+      switch (seg.data_type) {
+        case HY_TYPE_INT: bits = static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int32_t*>(seg.aux)[id])); break;
+        case HY_TYPE_LONG: bits = static_cast<const uint64_t*>(seg.aux)[id]; break;
+        case HY_TYPE_FLOAT: bits = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<const float*>(seg.aux)[id]))); break;
+        default: bits = static_cast<const uint64_t*>(seg.aux)[id]; break;
+      }
+      if (a.groupby[g].is_float && __longlong_as_double(static_cast<long long>(bits)) == 0.0) bits = 0;
+      tuple[g + 1] = bits;
+    }
     const uint32_t gslot = global_slot(a, tuple, words, hash_tuple(tuple, words));
     if (gslot == 0xFFFFFFFFu) { *a.overflow = 1; continue; }
     atomicMin(reinterpret_cast<unsigned long long*>(&a.first_row[gslot]), static_cast<unsigned long long>(s_first[s]));
@@ -774,7 +847,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   hipStream_t stream = current_stream();
   const uint32_t words = a.n_groupby + 1;
   const uint32_t n_aggregates = a.n_aggregates;
-  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + SLICE_ROWS;
+  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + size_t{DENSE_GROUPS} * 256 * 12 + SLICE_ROWS;
   uint64_t capacity = 1u << 16;
   while (capacity < 2 * uint64_t{LDS_SLOTS}) capacity <<= 1;
   for (int attempt = 0; attempt < 3; ++attempt) {

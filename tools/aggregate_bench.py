@@ -28,6 +28,8 @@ cols = {
 dev = {k: DeviceColumn(v) for k, v in cols.items()}
 aggregates = [(abi.AGG_SUM, dev["l_quantity"]), (abi.AGG_SUM, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_quantity"]),
               (abi.AGG_AVG, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_discount"]), (abi.AGG_COUNT, None)]
+n_aggs = int(os.environ.get("AGGS", str(len(aggregates))))
+aggregates = aggregates[:n_aggs] if n_aggs else [(abi.AGG_COUNT, None)]
 bytes_per_row = 1 + 1 + 4 + 4 + 4
 for i in range(4):
     torch.cuda.synchronize()
