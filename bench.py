@@ -161,11 +161,19 @@ def main():
     from hyrise_amd.operators import make_predicate
     from hyrise_amd.storage import DeviceColumn
 
+    # HY_BENCH_SHARE_GPU=1 (debug): several ranks on ONE GPU with the gloo backend, to exercise the N > 1 control flow on
+    # a single-GPU box; the real thing is one rank per GPU over RCCL.
+    share_gpu = bool(os.environ.get("HY_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     lib = abi.load_library()          # raises if the HIP library is missing: no fallback
     abi.check(lib.hy_init(local_rank))
@@ -216,7 +224,7 @@ def main():
         raise SystemExit(f"rank {rank}: scan produced {n_matches} matches, numpy says {expected}")
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
