@@ -546,7 +546,6 @@ struct ScanArgs {
   uint32_t materialize_all;
   uint32_t is_null_scan;           // IS NULL on reference columns: NULL_ROW_IDs match
   uint32_t epoch;
-  uint32_t debug;
   uint64_t* status;                // [n_parts] epoch-tagged part totals (only touched by multi-part chunks)
   hy_row_id* matches;              // chunk regions
   uint64_t capacity;
@@ -1021,7 +1020,6 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
         {
           uint16_t* slot = my_rows + skew + (inclusive - run_count);
           const uint32_t row0 = wave * 2048 + lane * 32;
-          if (a.debug & 2) run = 0;
           while (run) {
             const uint32_t j = __ffs(run) - 1;
             run &= run - 1;
@@ -1031,7 +1029,7 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
         __builtin_amdgcn_wave_barrier();
         if (first + my_total > a.capacity) {
           if (lane == 0) *a.overflow = 1;
-        } else if (!(a.debug & 1)) {
+        } else {
           // RowIDs are written once and not read again by this kernel: nontemporal, 16 bytes (two RowIDs) per lane.
           // Pairs [pair_begin, pair_end) lie completely inside the wave's range; the slot before and the slot after
           // them are written on their own.
@@ -1283,7 +1281,6 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     a.materialize_all = pa.materialize_all;
     a.is_null_scan = predicate && predicate->condition == HY_PRED_IS_NULL;
     a.epoch = sc.epoch;
-    a.debug = getenv("HY_SCAN_DEBUG") ? atoi(getenv("HY_SCAN_DEBUG")) : 0;
     a.status = sc.status;
     a.matches = d_matches;
     a.capacity = device_capacity;
