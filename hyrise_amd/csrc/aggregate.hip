@@ -921,7 +921,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   for (uint32_t g = 0; g < n_aggregates && !shape; ++g) shape = specs[g].column;
   if (!shape) return fail(HY_ERR_INVALID, "hy_aggregate_hash needs at least one column (pass any column of the table for a lone COUNT(*))");
   auto same_shape = [&](const hy_column* c) {
-    if (c->n_chunks != shape->n_chunks) return false;
+    if (c->n_chunks != shape->n_chunks || c->is_mvcc || (c->ref && c->ref->is_mvcc)) return false;
     for (uint32_t k = 0; k < c->n_chunks; ++k) if (c->host_segments[k].size != shape->host_segments[k].size) return false;
     return true;
   };

@@ -67,6 +67,7 @@ struct hy_column {
   uint32_t data_type = HY_TYPE_NULL;
   uint64_t rows = 0;
   bool is_reference = false;
+  bool is_mvcc = false;                     // HY_ENC_MVCC segments: a table's MvccData, only hy_validate reads it
   bool multi_chunk_reference = false;       // some pos list spans several referenced chunks
   bool has_dictionary_without_values = false;
   uint32_t stream_width = 0;                // 1|2|4 if every segment is an aligned W-byte id/offset/int32 vector, else 0

@@ -1019,7 +1019,7 @@ static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, h
   return HY_OK;
 }
 
-static bool is_integer_column(const hy_column* c) { return c->data_type == HY_TYPE_INT || c->data_type == HY_TYPE_LONG; }
+static bool is_integer_column(const hy_column* c) { return (c->data_type == HY_TYPE_INT || c->data_type == HY_TYPE_LONG) && !c->is_mvcc && !(c->ref && c->ref->is_mvcc); }
 
 struct BuildSide {
   DeviceBuffer keys, rows, keys_tmp, rows_tmp, keys32, dir, bloom, flags;

@@ -296,6 +296,10 @@ static hy_status validate_segment(const hy_segment& s, uint32_t chunk, uint32_t 
       if (s.size && (!s.data || !s.aux)) return fail(HY_ERR_INVALID, "chunk %u: FrameOfReference buffers missing", chunk);
       if (s.aux_size != (s.size + HY_FOR_BLOCK_SIZE - 1) / HY_FOR_BLOCK_SIZE) return fail(HY_ERR_INVALID, "chunk %u: %u block minima for %u rows", chunk, s.aux_size, s.size);
       break;
+    case HY_ENC_MVCC:
+      if (s.width != 4 || s.data_type != HY_TYPE_INT) return fail(HY_ERR_INVALID, "chunk %u: MVCC segments are three uint32 arrays (width 4, HY_TYPE_INT)", chunk);
+      if (s.size && (!s.data || !s.aux || !s.nulls)) return fail(HY_ERR_INVALID, "chunk %u: MVCC arrays missing (tids, begin cids, end cids)", chunk);
+      break;
     case HY_ENC_REFERENCE:
       if (!s.ref) return fail(HY_ERR_INVALID, "chunk %u: reference segment without referenced column", chunk);
       if (s.ref->is_reference) return fail(HY_ERR_INVALID, "chunk %u: reference segments must not reference reference segments (table_scan.cpp:140-148)", chunk);
@@ -313,9 +317,11 @@ static size_t data_bytes(const hy_segment& s) {
 static size_t aux_bytes(const hy_segment& s) {
   if (s.encoding == HY_ENC_DICTIONARY) return s.aux ? type_width(s.data_type) * s.aux_size : 0;
   if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) return size_t{4} * s.aux_size;
+  if (s.encoding == HY_ENC_MVCC) return size_t{4} * s.size;
   return 0;
 }
 static size_t null_bytes(const hy_segment& s) {
+  if (s.encoding == HY_ENC_MVCC) return size_t{4} * s.size;   // the end commit ids travel in the `nulls` slot
   return (s.nulls && s.encoding != HY_ENC_REFERENCE) ? size_t{8} * ((s.size + 63) / 64) : 0;
 }
 
@@ -404,6 +410,8 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
       return cleanup(fail(HY_ERR_INVALID, "chunk %u: data and reference segments mixed in one column", c));
     }
     if (s.encoding == HY_ENC_DICTIONARY && !s.aux && s.aux_size) column->has_dictionary_without_values = true;
+    if (s.encoding == HY_ENC_MVCC) column->is_mvcc = true;
+    else if (column->is_mvcc) return cleanup(fail(HY_ERR_INVALID, "chunk %u: MVCC and data segments mixed in one column", c));
     column->row_base[c + 1] = column->row_base[c] + s.size;
     uint32_t begin = 0;
     const uint32_t first_slice_of_chunk = static_cast<uint32_t>(slices.size());

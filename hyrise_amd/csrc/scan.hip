@@ -31,7 +31,8 @@ namespace hy {
 
 // ---- per-chunk normalised predicate ---------------------------------------------------------------------------------
 enum : uint32_t { JOB_SCAN = 0, JOB_ALL = 1, JOB_NONE = 2 };
-enum : uint32_t { KIND_U32 = 0, KIND_I64 = 1, KIND_F32 = 2, KIND_F64 = 3, KIND_NULLTEST = 4 };
+enum : uint32_t { KIND_U32 = 0, KIND_I64 = 1, KIND_F32 = 2, KIND_F64 = 3, KIND_NULLTEST = 4,
+                  KIND_VISIBLE = 5 /* Validate: lo = snapshot commit id, span = our transaction id */ };
 enum : uint32_t { JF_INVERT = 1, JF_LOWER_INCL = 2, JF_UPPER_INCL = 4, JF_NEVER = 8 };
 
 struct ScanJob {
@@ -325,6 +326,25 @@ __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, 
   jobs[c] = job;
 }
 
+// Validate: one job per chunk of the MVCC column.  Entirely visible chunks (validate.cpp:57-68) need no row test.
+__global__ void prepare_visibility_jobs(const DevSegment* segments, uint32_t n_chunks, uint32_t our_tid, uint32_t snapshot, uint32_t can_use_chunk_shortcut,
+                                        ScanJob* jobs, uint32_t* overflow) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) *overflow = 0;
+  if (c >= n_chunks) return;
+  const DevSegment s = segments[c];
+  ScanJob job;
+  job.kind = KIND_VISIBLE;
+  job.flags = 0;
+  job.null_vid = 0xFFFFFFFFu;
+  job.lo = snapshot;
+  job.span = our_tid;
+  const bool is_mutable = (s.ref_chunk_id >> 31) != 0;
+  const uint32_t invalid_rows = s.ref_chunk_id & 0x7FFFFFFFu, max_begin_cid = s.aux_size;
+  job.mode = (can_use_chunk_shortcut && !is_mutable && snapshot >= max_begin_cid && invalid_rows == 0) ? JOB_ALL : JOB_SCAN;
+  jobs[c] = job;
+}
+
 // ---- row evaluation ---------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint32_t load_compressed(const void* data, uint32_t width, uint32_t i) {
@@ -350,6 +370,12 @@ __device__ __forceinline__ bool double_in_range(double x, const ScanJob& job) {
 __device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) {
   if (job.mode == JOB_ALL) return true;
   if (job.mode == JOB_NONE || (job.flags & JF_NEVER)) return false;
+  if (s.encoding == HY_ENC_MVCC) {   // Validate::is_row_visible (validate.cpp:47-55)
+    const uint32_t snapshot = static_cast<uint32_t>(job.lo), our_tid = static_cast<uint32_t>(job.span);
+    const uint32_t tid = static_cast<const uint32_t*>(s.data)[row], begin = static_cast<const uint32_t*>(s.aux)[row];
+    const uint32_t end = reinterpret_cast<const uint32_t*>(s.nulls)[row];
+    return snapshot < end && ((snapshot >= begin) != (tid == our_tid));
+  }
   const bool invert = job.flags & JF_INVERT;
   if (s.encoding == HY_ENC_DICTIONARY) {
     const uint32_t vid = load_compressed(s.data, s.width, row);
@@ -408,6 +434,17 @@ __device__ __forceinline__ uint32_t eval8(const DevSegment& s, const ScanJob& jo
   if (valid < 8 || (s.flags & SEG_UNALIGNED)) {
     uint32_t bits = 0;
     for (uint32_t j = 0; j < valid; ++j) bits |= (eval_row(s, job, row0 + j) ? 1u : 0u) << j;
+    return bits;
+  }
+  if (s.encoding == HY_ENC_MVCC) {   // eight rows: 2 x 16 B of each of the three arrays
+    const uint32_t snapshot = static_cast<uint32_t>(job.lo), our_tid = static_cast<uint32_t>(job.span);
+    uint32_t tid[8], begin[8], end[8];
+    load8<4>(s.data, row0, tid);
+    load8<4>(s.aux, row0, begin);
+    load8<4>(s.nulls, row0, end);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bits |= ((snapshot < end[j] && ((snapshot >= begin[j]) != (tid[j] == our_tid))) ? 1u : 0u) << j;
     return bits;
   }
   const uint32_t inv = (job.flags & JF_INVERT) ? 0xFFu : 0u;
@@ -1191,8 +1228,12 @@ static hy_status validate_predicate(const hy_column* column, const hy_predicate*
   return HY_OK;
 }
 
+struct VisibilityArgs {   // hy_validate
+  uint32_t our_tid, snapshot, can_use_chunk_shortcut;
+};
+
 static hy_status run_scan(const hy_column* column, const hy_column* right, const hy_predicate* predicate, uint32_t condition,
-                          const uint32_t* excluded, uint32_t n_excluded, hy_scan_result* result) {
+                          const uint32_t* excluded, uint32_t n_excluded, hy_scan_result* result, const VisibilityArgs* visibility = nullptr) {
   const uint32_t n_chunks = column->n_chunks;
   const hy_column* data_column = column->is_reference ? column->ref : column;
   const uint32_t n_data_chunks = data_column ? data_column->n_chunks : 0;
@@ -1220,6 +1261,10 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   PredicateArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.materialize_all = (result->flags & HY_SCAN_MATERIALIZE_ALL_MATCH) ? 1 : 0;
+  if (visibility && n_data_chunks) {
+    hipLaunchKernelGGL(prepare_visibility_jobs, dim3((n_data_chunks + 255) / 256), dim3(256), 0, stream, data_column->d_segments, n_data_chunks, visibility->our_tid,
+                       visibility->snapshot, visibility->can_use_chunk_shortcut, d_jobs, d_overflow);
+  }
   if (predicate) {
     pa.condition = predicate->condition;
     pa.value_type = predicate->value_type;
@@ -1301,7 +1346,7 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(WG_THREADS), SCAN_LDS_BYTES, stream, started, stopped, 0, a.segments, a.right, a.slices, a.jobs,
                           column->d_parts, a);
   }
-  if (column->multi_chunk_reference && predicate && n_chunks && d_counts) {
+  if (column->multi_chunk_reference && predicate && n_chunks && d_counts) {   // (Validate keeps position order, validate.cpp:236-253)
     hy_row_id* d_temp = carve<hy_row_id>(sc, column->rows + 1);
     if (!d_temp) return fail(HY_ERR_DEVICE, "scratch arena exhausted");
     hipLaunchKernelGGL(reorder_by_referenced_chunk, dim3(n_chunks), dim3(64), 0, stream, column->d_segments, d_matches, d_offsets, d_counts, d_temp, n_data_chunks);
@@ -1365,6 +1410,7 @@ hy_status hy_table_scan(const hy_column* column, const hy_predicate* predicate, 
   for (uint32_t i = 0; i < n_excluded; ++i) {
     if (excluded_chunks[i] >= column->n_chunks) return fail(HY_ERR_INVALID, "excluded chunk id %u out of range", excluded_chunks[i]);
   }
+  if (column->is_mvcc || (column->ref && column->ref->is_mvcc)) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
   HY_TRY(validate_predicate(column, predicate));
   if (column->multi_chunk_reference && result->mem == HY_MEM_DEVICE && !result->counts) {
     return fail(HY_ERR_INVALID, "scans of pos lists that span several chunks need result->counts (their matches are re-ordered by referenced chunk)");
@@ -1372,9 +1418,18 @@ hy_status hy_table_scan(const hy_column* column, const hy_predicate* predicate, 
   return run_scan(column, nullptr, predicate, 0, excluded_chunks, n_excluded, result);
 }
 
+hy_status hy_validate(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut, hy_scan_result* result) {
+  if (!mvcc || !result) return fail(HY_ERR_INVALID, "hy_validate: null argument");
+  const hy_column* data = mvcc->is_reference ? mvcc->ref : mvcc;
+  if (!data || !data->is_mvcc) return fail(HY_ERR_INVALID, "hy_validate needs a column of HY_ENC_MVCC segments (or reference segments into one)");
+  const VisibilityArgs visibility{our_tid, snapshot_commit_id, can_use_chunk_shortcut};
+  return run_scan(mvcc, nullptr, nullptr, 0, nullptr, 0, result, &visibility);
+}
+
 hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, uint32_t condition,
                                 hy_scan_result* result) {
   if (!left || !right || !result) return fail(HY_ERR_INVALID, "hy_table_scan_columns: null argument");
+  if (left->is_mvcc || right->is_mvcc || (left->ref && left->ref->is_mvcc) || (right->ref && right->ref->is_mvcc)) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
   if (condition > HY_PRED_GREATER_THAN_EQUALS) return fail(HY_ERR_INVALID, "ColumnVsColumn supports binary comparisons only");
   if (left->n_chunks != right->n_chunks) return fail(HY_ERR_INVALID, "columns of one table must have the same chunk count");
   for (uint32_t c = 0; c < left->n_chunks; ++c) {

@@ -84,6 +84,14 @@ def table_scan_columns(left, right, condition, capacity=None):
     return result
 
 
+def validate(mvcc, our_tid, snapshot_commit_id, can_use_chunk_shortcut=True, flags=0):
+    """Validate (MVCC visibility) over a DeviceColumn of MVCC segments or of reference segments into one."""
+    lib = abi.load_library()
+    result = HostScanResult(mvcc.n_chunks, mvcc.rows, flags)
+    abi.check(lib.hy_validate(mvcc.handle, our_tid, snapshot_commit_id, 1 if can_use_chunk_shortcut else 0, C.byref(result.c)))
+    return result
+
+
 class HostJoinResult:
     """Join result in host memory (numpy views): pairs[k] = (left RowID, right RowID), slice boundaries."""
 

@@ -152,6 +152,31 @@ def auto_encoding(data_type, unique):
     return abi.ENC_DICTIONARY
 
 
+MVCC_MUTABLE = 1 << 31
+MAX_COMMIT_ID = 0xFFFFFFFF - 1   # MvccData::MAX_COMMIT_ID (mvcc_data.hpp): "not yet invalidated"
+
+
+def make_mvcc_column(tids, begin_cids, end_cids, chunk_size=abi.CHUNK_DEFAULT_SIZE, mutable_chunks=(), invalid_row_counts=None):
+    """A table's MvccData as a column of HY_ENC_MVCC segments (see hy_validate in include/hyrise_amd.h): per chunk the
+    transaction ids, begin and end commit ids, max_begin_cid and the invalid-row counter (default: rows whose end_cid
+    is set), bit 31 of which marks the chunk as still mutable."""
+    tids, begin_cids, end_cids = (np.ascontiguousarray(a, dtype=np.uint32) for a in (tids, begin_cids, end_cids))
+    n = len(tids)
+    segments = []
+    for chunk_id, begin in enumerate(range(0, n, chunk_size)):
+        end = min(n, begin + chunk_size)
+        b, e = begin_cids[begin:end].copy(), end_cids[begin:end].copy()
+        committed = b[b < MAX_COMMIT_ID]
+        max_begin = int(committed.max()) if len(committed) else 0
+        if np.any(b >= MAX_COMMIT_ID):   # an uncommitted insert keeps max_begin_cid at its initial MAX_COMMIT_ID
+            max_begin = MAX_COMMIT_ID
+        invalid = int(np.sum(e < MAX_COMMIT_ID)) if invalid_row_counts is None else int(invalid_row_counts[chunk_id])
+        flags = invalid | (MVCC_MUTABLE if chunk_id in mutable_chunks else 0)
+        segments.append(HostSegment(abi.ENC_MVCC, abi.TYPE_INT, end - begin, 4, tids[begin:end].copy(), aux=b, aux_size=max_begin, nulls=e,
+                                    ref_chunk_id=flags))
+    return HostColumn(segments, abi.TYPE_INT)
+
+
 def make_reference_column(referenced, pos_lists, single_chunk_ids=None):
     """Reference segments over `referenced` (a HostColumn of data segments).
     pos_lists: per chunk either an (n,2) uint32 array of (chunk_id, chunk_offset) RowIDs, or an int k meaning

@@ -65,7 +65,8 @@ enum {
   HY_AGG_STDDEV_SAMP = 6, HY_AGG_ANY = 7
 };
 
-enum { HY_ENC_UNENCODED = 0, HY_ENC_DICTIONARY = 1, HY_ENC_FRAME_OF_REFERENCE = 2, HY_ENC_REFERENCE = 3 };
+enum { HY_ENC_UNENCODED = 0, HY_ENC_DICTIONARY = 1, HY_ENC_FRAME_OF_REFERENCE = 2, HY_ENC_REFERENCE = 3,
+       HY_ENC_MVCC = 4 /* not a column encoding: a chunk's MvccData, see hy_validate */ };
 
 /* Where the pointers of a descriptor / result live. */
 enum { HY_MEM_HOST = 0, HY_MEM_DEVICE = 1 };
@@ -205,6 +206,22 @@ hy_status hy_table_scan(const hy_column* column, const hy_predicate* predicate, 
 /* ColumnVsColumn (column_vs_column_table_scan_impl.cpp:36-187): left <condition> right, both columns of one table. */
 hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, uint32_t condition,
                                 hy_scan_result* result);
+
+/* ---- Validate (replaces Validate::_on_execute / _validate_chunks, validate.cpp:32-55,87-314) ----
+ * The MVCC visibility filter that sits in front of every TableScan of an SQL-driven plan.  The table's MvccData
+ * (storage/mvcc_data.hpp) is passed as one "column" of HY_ENC_MVCC segments, one per chunk:
+ *     data  = transaction ids  (uint32_t[size])       aux   = begin commit ids (uint32_t[size])
+ *     nulls = END commit ids   (uint32_t[size], cast) aux_size = the chunk's max_begin_cid
+ *     ref_chunk_id = the chunk's invalid_row_count, bit 31 set while the chunk is still mutable
+ *     width = 4, data_type = HY_TYPE_INT
+ * or, for a reference table, as a column of HY_ENC_REFERENCE segments whose `ref` is such an MVCC column.
+ * A row is visible iff  snapshot < end_cid && ((snapshot >= begin_cid) != (row_tid == our_tid))   (validate.cpp:47-55).
+ * Chunks that are entirely visible (immutable, snapshot >= max_begin_cid, no invalid rows, and the transaction has no
+ * in-flight Delete: can_use_chunk_shortcut, validate.cpp:57-68,116-127) are reported as HY_CHUNK_ALL_MATCH (the adapter
+ * emits an EntireChunkPosList / reuses the input pos list, validate.cpp:207-211,282-284).  The result has the layout of
+ * hy_table_scan: positions inside the input chunks, in position order. */
+hy_status hy_validate(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut,
+                      hy_scan_result* result);
 
 /* ---- JoinHash (replaces JoinHash::_on_execute, join_hash.cpp:116-225,270-572) ----------------------------------- */
 typedef struct hy_join_result {

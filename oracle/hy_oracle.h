@@ -52,6 +52,9 @@ int64_t hyo_scan_chunk_columns(const hyo_column* left, const hyo_column* right, 
 /* Whole-column driver with the ABI's result layout (host memory), single thread or `threads` pthreads over chunks
  * (JobTask fan-out, table_scan.cpp:223-229). */
 int32_t hyo_table_scan(const hyo_column* column, const hy_predicate* predicate, hy_scan_result* result, int threads);
+/* Validate (validate.c): visible positions per input chunk, same result layout as hyo_table_scan. */
+int32_t hyo_validate(const hyo_column* column, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut,
+                     hy_scan_result* result);
 int32_t hyo_table_scan_columns(const hyo_column* left, const hyo_column* right, uint32_t condition,
                                hy_scan_result* result, int threads);
 

@@ -43,6 +43,8 @@ def oracle():
                                            C.c_void_p]
     lib.hyo_table_scan.restype = C.c_int32
     lib.hyo_table_scan.argtypes = [C.POINTER(OracleColumn), C.POINTER(abi.Predicate), C.POINTER(abi.ScanResult), C.c_int]
+    lib.hyo_validate.restype = C.c_int32
+    lib.hyo_validate.argtypes = [C.POINTER(OracleColumn), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(abi.ScanResult)]
     lib.hyo_table_scan_columns.restype = C.c_int32
     lib.hyo_table_scan_columns.argtypes = [C.POINTER(OracleColumn), C.POINTER(OracleColumn), C.c_uint32,
                                            C.POINTER(abi.ScanResult), C.c_int]
@@ -75,6 +77,15 @@ def oracle_scan(host_column, predicate, flags=0, threads=1):
     result = HostScanResult(host_column.n_chunks, host_column.rows, flags)
     status = oracle().hyo_table_scan(C.byref(col.c), C.byref(predicate), C.byref(result.c), threads)
     assert status == 0, f"oracle scan failed with {status}"
+    return result
+
+
+def oracle_validate(host_column, our_tid, snapshot_commit_id, can_use_chunk_shortcut=True, flags=0):
+    from hyrise_amd.operators import HostScanResult
+    col = OracleCol(host_column)
+    result = HostScanResult(host_column.n_chunks, host_column.rows, flags)
+    status = oracle().hyo_validate(C.byref(col.c), our_tid, snapshot_commit_id, 1 if can_use_chunk_shortcut else 0, C.byref(result.c))
+    assert status == 0, f"oracle validate failed with {status}"
     return result
 
 
