@@ -236,10 +236,36 @@ class ReferenceSegment : public AbstractSegment {   // storage/reference_segment
 
 using Segments = std::vector<std::shared_ptr<AbstractSegment>>;
 
+using TransactionID = uint32_t;
+using CommitID = uint32_t;
+constexpr CommitID MAX_COMMIT_ID = 0xFFFFFFFFu - 1;        // storage/mvcc_data.hpp
+constexpr TransactionID INVALID_TRANSACTION_ID = 0;
+
+struct MvccData {   // storage/mvcc_data.hpp: three arrays, one entry per row of the chunk
+  explicit MvccData(size_t size, CommitID begin_commit_id = MAX_COMMIT_ID)
+      : tids(size, INVALID_TRANSACTION_ID), begin_cids(size, begin_commit_id), end_cids(size, MAX_COMMIT_ID), max_begin_cid(begin_commit_id) {}
+  TransactionID get_tid(ChunkOffset row) const { return tids[row]; }
+  CommitID get_begin_cid(ChunkOffset row) const { return begin_cids[row]; }
+  CommitID get_end_cid(ChunkOffset row) const { return end_cids[row]; }
+  void set_tid(ChunkOffset row, TransactionID tid) { tids[row] = tid; }
+  void set_begin_cid(ChunkOffset row, CommitID cid) { begin_cids[row] = cid; }
+  void set_end_cid(ChunkOffset row, CommitID cid) { end_cids[row] = cid; }
+  std::vector<TransactionID> tids;
+  std::vector<CommitID> begin_cids, end_cids;
+  CommitID max_begin_cid;
+};
+
 class Chunk {   // storage/chunk.hpp:38-218
  public:
   static constexpr ChunkOffset DEFAULT_SIZE = 65535;
   explicit Chunk(Segments segments) : _segments(std::move(segments)) {}
+  Chunk(Segments segments, std::shared_ptr<MvccData> mvcc_data) : _segments(std::move(segments)), _mvcc_data(std::move(mvcc_data)) {}
+  bool has_mvcc_data() const { return _mvcc_data != nullptr; }
+  const std::shared_ptr<MvccData>& mvcc_data() const { return _mvcc_data; }
+  bool is_mutable() const { return _is_mutable; }
+  void set_immutable() { _is_mutable = false; }
+  uint32_t invalid_row_count() const { return _invalid_row_count; }
+  void increase_invalid_row_count(uint32_t count) { _invalid_row_count += count; }
   ChunkOffset size() const { return _segments.empty() ? 0 : _segments[0]->size(); }
   const std::shared_ptr<AbstractSegment>& get_segment(ColumnID column_id) const { return _segments.at(column_id); }
   void replace_segment(ColumnID column_id, std::shared_ptr<AbstractSegment> segment) { _segments.at(column_id) = std::move(segment); }
@@ -247,6 +273,9 @@ class Chunk {   // storage/chunk.hpp:38-218
 
  private:
   Segments _segments;
+  std::shared_ptr<MvccData> _mvcc_data;
+  bool _is_mutable = true;
+  uint32_t _invalid_row_count = 0;
 };
 
 struct TableColumnDefinition {
@@ -275,6 +304,7 @@ class Table : public std::enable_shared_from_this<Table> {   // storage/table.hp
   const std::shared_ptr<Chunk>& get_chunk(ChunkID id) const { return _chunks.at(id); }
   uint64_t row_count() const { uint64_t n = 0; for (const auto& c : _chunks) n += c->size(); return n; }
   void append_chunk(Segments segments) { _chunks.push_back(std::make_shared<Chunk>(std::move(segments))); }
+  void append_chunk(Segments segments, std::shared_ptr<MvccData> mvcc_data) { _chunks.push_back(std::make_shared<Chunk>(std::move(segments), std::move(mvcc_data))); }
   // Table::append(row): rows are collected and cut into ValueSegments of target_chunk_size rows by finalize().
   void append(std::vector<AllTypeVariant> row) { _pending.push_back(std::move(row)); if (_pending.size() == _target_chunk_size) finalize(); }
   void finalize();
@@ -738,6 +768,129 @@ class TableScan : public AbstractReadOnlyOperator {
   AllTypeVariant _value;
   std::optional<AllTypeVariant> _value2;
   std::optional<ColumnID> _right_column_id;
+};
+
+// ---- Validate (operators/validate.hpp, validate.cpp:87-314) -------------------------------------------------------------
+struct TransactionContext {   // concurrency/transaction_context.hpp: what Validate reads of it
+  TransactionContext(TransactionID transaction_id, CommitID snapshot_commit_id, bool has_in_flight_delete = false)
+      : _tid(transaction_id), _snapshot(snapshot_commit_id), _delete(has_in_flight_delete) {}
+  TransactionID transaction_id() const { return _tid; }
+  CommitID snapshot_commit_id() const { return _snapshot; }
+  bool has_in_flight_delete() const { return _delete; }   // read_write_operators() contains a Delete (validate.cpp:116-127)
+
+ private:
+  TransactionID _tid;
+  CommitID _snapshot;
+  bool _delete;
+};
+
+// The MvccData of a data table as a column of HY_ENC_MVCC segments.  Mutable chunks change under writers, so this column is
+// rebuilt per call (the Hyrise adapter caches the immutable chunks).
+inline std::shared_ptr<DeviceColumn> mvcc_column(const std::shared_ptr<const Table>& table) {
+  auto column = std::make_shared<DeviceColumn>();
+  const auto chunk_count = table->chunk_count();
+  column->descriptors.assign(chunk_count, hy_segment{});
+  for (ChunkID chunk_id = 0; chunk_id < chunk_count; ++chunk_id) {
+    const auto& chunk = table->get_chunk(chunk_id);
+    Assert(chunk->has_mvcc_data(), "Trying to use Validate on a table that has no MVCC data.");
+    const auto& mvcc = *chunk->mvcc_data();
+    hy_segment& d = column->descriptors[chunk_id];
+    d.encoding = HY_ENC_MVCC; d.data_type = HY_TYPE_INT; d.size = chunk->size(); d.width = 4;
+    d.data = mvcc.tids.data(); d.aux = mvcc.begin_cids.data(); d.nulls = reinterpret_cast<const uint64_t*>(mvcc.end_cids.data());
+    d.aux_size = mvcc.max_begin_cid;
+    d.ref_chunk_id = chunk->invalid_row_count() | (chunk->is_mutable() ? 1u << 31 : 0u);
+  }
+  check_status(hy_column_create(column->descriptors.data(), chunk_count, HY_MEM_HOST, &column->handle));
+  return column;
+}
+
+class Validate : public AbstractReadOnlyOperator {
+ public:
+  explicit Validate(std::shared_ptr<const AbstractOperator> in) : AbstractReadOnlyOperator(std::move(in)) {}
+  const std::string& name() const override { static const std::string n = "Validate"; return n; }
+  void set_transaction_context(std::shared_ptr<TransactionContext> context) { _context = std::move(context); }
+  static bool is_row_visible(TransactionID our_tid, CommitID snapshot_commit_id, TransactionID row_tid, CommitID begin_cid, CommitID end_cid) {
+    return snapshot_commit_id < end_cid && ((snapshot_commit_id >= begin_cid) != (row_tid == our_tid));   // validate.cpp:47-55
+  }
+
+ protected:
+  std::shared_ptr<const Table> _on_execute() override {
+    if (!_context) Fail("Validate cannot be called without a transaction context.");   // validate.cpp:87-89
+    const auto in_table = left_input_table();
+    const auto chunk_count = in_table->chunk_count();
+    // the table that owns the MvccData: the input itself or the table its reference segments point to (:186-199)
+    auto mvcc_table = in_table;
+    if (in_table->type() == TableType::References && chunk_count) {
+      mvcc_table = std::static_pointer_cast<ReferenceSegment>(in_table->get_chunk(0)->get_segment(0))->referenced_table();
+    }
+    const auto mvcc = mvcc_column(mvcc_table);
+    std::shared_ptr<DeviceColumn> input = mvcc;
+    if (in_table->type() == TableType::References) {   // the input's pos lists over the MVCC column
+      input = std::make_shared<DeviceColumn>();
+      input->descriptors.assign(chunk_count, hy_segment{});
+      for (ChunkID chunk_id = 0; chunk_id < chunk_count; ++chunk_id) {
+        const auto ref = std::static_pointer_cast<ReferenceSegment>(in_table->get_chunk(chunk_id)->get_segment(0));
+        hy_segment& d = input->descriptors[chunk_id];
+        d.encoding = HY_ENC_REFERENCE; d.data_type = HY_TYPE_INT; d.size = ref->size(); d.width = 8; d.ref = mvcc->handle;
+        if (const auto* entire = dynamic_cast<const EntireChunkPosList*>(ref->pos_list().get())) {
+          d.data = nullptr; d.ref_chunk_id = entire->common_chunk_id();
+        } else {
+          const auto& rows = static_cast<const RowIDPosList&>(*ref->pos_list());
+          d.data = rows.rows.data();
+          d.ref_chunk_id = rows.references_single_chunk() && rows.size() ? rows.common_chunk_id() : 0xFFFFFFFFu;
+        }
+      }
+      check_status(hy_column_create(input->descriptors.data(), chunk_count, HY_MEM_HOST, &input->handle));
+    }
+    std::vector<RowID> matches(std::max<uint64_t>(1, in_table->row_count()));
+    std::vector<uint64_t> offsets(chunk_count + 1);
+    std::vector<uint32_t> counts(std::max<ChunkID>(1, chunk_count));
+    std::vector<uint8_t> states(std::max<ChunkID>(1, chunk_count));
+    hy_scan_result result{};
+    result.mem = HY_MEM_HOST;
+    result.matches = reinterpret_cast<hy_row_id*>(matches.data());
+    result.capacity = in_table->row_count();
+    result.offsets = offsets.data();
+    result.counts = counts.data();
+    result.chunk_state = states.data();
+    check_status(hy_validate(input->handle, _context->transaction_id(), _context->snapshot_commit_id(), _context->has_in_flight_delete() ? 0 : 1, &result));
+    // ---- output assembly, validate.cpp:256-311 ----
+    std::vector<std::shared_ptr<Chunk>> output_chunks;
+    for (ChunkID chunk_id = 0; chunk_id < chunk_count; ++chunk_id) {
+      if (counts[chunk_id] == 0) continue;   // :299
+      const auto chunk_in = in_table->get_chunk(chunk_id);
+      const bool entirely_visible = states[chunk_id] == HY_CHUNK_ALL_MATCH;
+      Segments out_segments;
+      if (in_table->type() == TableType::References) {
+        const auto first = std::static_pointer_cast<ReferenceSegment>(chunk_in->get_segment(0));
+        std::shared_ptr<const AbstractPosList> pos_list = first->pos_list();   // reused when entirely visible (:207-211)
+        if (!entirely_visible) {
+          auto visible = std::make_shared<RowIDPosList>();
+          for (uint64_t m = offsets[chunk_id]; m < offsets[chunk_id + 1]; ++m) visible->rows.push_back((*first->pos_list())[matches[m].chunk_offset]);
+          if (first->pos_list()->references_single_chunk()) visible->guarantee_single_chunk();
+          pos_list = visible;
+        }
+        for (ColumnID c = 0; c < in_table->column_count(); ++c) {
+          const auto ref = std::static_pointer_cast<ReferenceSegment>(chunk_in->get_segment(c));
+          out_segments.push_back(std::make_shared<ReferenceSegment>(ref->referenced_table(), ref->referenced_column_id(), pos_list));
+        }
+      } else {
+        std::shared_ptr<AbstractPosList> pos_list;
+        if (entirely_visible) pos_list = std::make_shared<EntireChunkPosList>(chunk_id, chunk_in->size());   // :282-284
+        else {
+          auto rows = std::make_shared<RowIDPosList>(std::vector<RowID>(matches.begin() + offsets[chunk_id], matches.begin() + offsets[chunk_id + 1]));
+          rows->guarantee_single_chunk();
+          pos_list = rows;
+        }
+        for (ColumnID c = 0; c < in_table->column_count(); ++c) out_segments.push_back(std::make_shared<ReferenceSegment>(in_table, c, pos_list));
+      }
+      output_chunks.push_back(std::make_shared<Chunk>(std::move(out_segments)));
+    }
+    return std::make_shared<Table>(in_table->column_definitions(), TableType::References, std::move(output_chunks));
+  }
+
+ private:
+  std::shared_ptr<TransactionContext> _context;
 };
 
 using ColumnIDPair = std::pair<ColumnID, ColumnID>;

@@ -238,6 +238,57 @@ static void test_aggregates_against_fixtures() {   // aggregate_test.cpp: test_o
   EXPECT_TRUE(thrown);
 }
 
+static void test_validate_visibility() {   // validate_visibility_test.cpp:45-131 (our_tid 2, snapshot 2) + a scan on its output
+  struct Case { const char* name; TransactionID tid; CommitID begin, end; uint64_t rows; };
+  const Case cases[] = {{"Impossible", 2, 2, 2, 0}, {"PastDelete", 42, 2, 2, 0}, {"Impossible2", 2, 4, 1, 0}, {"OwnDeleteUncommitted", 2, 1, 6, 0},
+                        {"Impossible3", 50, 3, 1, 0}, {"OwnInsert", 2, 3, 3, 1}, {"PastInsertOrFutureDelete", 99, 2, 3, 1},
+                        {"UncommittedInsertOrFutureInsert", 99, 3, 3, 0}};
+  const auto make_table = [](size_t rows) {
+    auto table = std::make_shared<Table>(TableColumnDefinitions{{"a", DataType::Int, false}, {"b", DataType::Int, false}}, TableType::Data, ChunkOffset{10});
+    std::vector<int32_t> a(rows), b(rows);
+    for (size_t i = 0; i < rows; ++i) { a[i] = 123 + static_cast<int32_t>(i); b[i] = 456; }
+    table->append_chunk({std::make_shared<ValueSegment<int32_t>>(a, std::nullopt), std::make_shared<ValueSegment<int32_t>>(b, std::nullopt)}, std::make_shared<MvccData>(rows));
+    return table;
+  };
+  for (const auto& c : cases) {
+    const auto table = make_table(1);
+    const auto& mvcc = table->get_chunk(0)->mvcc_data();
+    mvcc->set_tid(0, c.tid); mvcc->set_begin_cid(0, c.begin); mvcc->set_end_cid(0, c.end);
+    auto validate = std::make_shared<Validate>(wrap(table));
+    validate->set_transaction_context(std::make_shared<TransactionContext>(2, 2));
+    validate->execute();
+    EXPECT_TRUE(validate->get_output()->row_count() == c.rows);
+  }
+  // all eight rows in one chunk: rows 5 and 6 survive; a TableScan runs on Validate's reference output
+  const auto table = make_table(8);
+  for (ChunkOffset i = 0; i < 8; ++i) {
+    const auto& mvcc = table->get_chunk(0)->mvcc_data();
+    mvcc->set_tid(i, cases[i].tid); mvcc->set_begin_cid(i, cases[i].begin); mvcc->set_end_cid(i, cases[i].end);
+  }
+  auto validate = std::make_shared<Validate>(wrap(table));
+  validate->set_transaction_context(std::make_shared<TransactionContext>(2, 2));
+  validate->execute();
+  EXPECT_TRUE(column_ints(validate->get_output(), ColumnID{0}) == (std::vector<int32_t>{128, 129}));
+  auto scan = std::make_shared<TableScan>(validate, ColumnID{0}, PredicateCondition::GreaterThan, AllTypeVariant{int32_t{128}});
+  scan->execute();
+  EXPECT_TRUE(column_ints(scan->get_output(), ColumnID{0}) == (std::vector<int32_t>{129}));
+  // Validate on a reference table (the scan's output) and the entirely-visible shortcut on an immutable, committed chunk
+  auto again = std::make_shared<Validate>(scan);
+  again->set_transaction_context(std::make_shared<TransactionContext>(2, 2));
+  again->execute();
+  EXPECT_TRUE(column_ints(again->get_output(), ColumnID{0}) == (std::vector<int32_t>{129}));
+  const auto old_table = make_table(5);
+  for (ChunkOffset i = 0; i < 5; ++i) old_table->get_chunk(0)->mvcc_data()->set_begin_cid(i, 1);
+  old_table->get_chunk(0)->mvcc_data()->max_begin_cid = 1;
+  old_table->get_chunk(0)->set_immutable();
+  auto shortcut = std::make_shared<Validate>(wrap(old_table));
+  shortcut->set_transaction_context(std::make_shared<TransactionContext>(7, 3));
+  shortcut->execute();
+  EXPECT_TRUE(shortcut->get_output()->row_count() == 5);
+  const auto out_segment = std::static_pointer_cast<ReferenceSegment>(shortcut->get_output()->get_chunk(0)->get_segment(0));
+  EXPECT_TRUE(dynamic_cast<const EntireChunkPosList*>(out_segment->pos_list().get()) != nullptr);   // validate.cpp:282-284
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: host_tests <tbl directory>\n"); return 2; }
   g_tbl = argv[1];
@@ -248,6 +299,7 @@ int main(int argc, char** argv) {
   run("TableScan.ScanForNullValues", test_scan_for_null_values);
   run("TableScan.DictionarySegment<string>", test_string_dictionary_scan);
   run("TableScan.TypeMismatchThrowsLogicError", test_type_mismatch_throws);
+  run("Validate.Visibility truth table, reference input, chunk shortcut", test_validate_visibility);
   run("JoinHash vs nested loop (Inner/Semi/AntiNullAsFalse/Left)", test_join_against_nested_loop);
   run("AggregateHash vs .tbl fixtures (+ CannotSumStringColumns)", test_aggregates_against_fixtures);
   hy_shutdown();
