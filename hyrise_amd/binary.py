@@ -1,0 +1,235 @@
+"""Hyrise binary tables (`.bin`): reader and writer for the layouts this library consumes.
+
+Format: src/lib/import_export/binary/binary_writer.hpp:24-215 (header, chunk header, one record per segment), written by
+BinaryWriter::write (binary_writer.cpp) and read by BinaryParser (binary_parser.cpp).  A table exported by a Hyrise that
+runs elsewhere -- exact dictionaries, attribute-vector widths, FrameOfReference blocks -- becomes `HostColumn`s whose
+buffers go to the device unchanged (`storage.DeviceColumn`), and columns encoded here can be written back byte-identically.
+
+Handled: Unencoded (ValueSegment), Dictionary and FrameOfReference segments with FixedWidthInteger attribute / offset
+vectors, all five data types (string columns: parsed; only their dictionary-encoded form is scannable on the device).
+RunLength, FixedStringDictionary, LZ4 and BitPacking vectors raise UnsupportedSegment (the adapter keeps such columns
+on the CPU path).
+"""
+import struct
+
+import numpy as np
+
+from . import abi
+from .storage import HostColumn, HostSegment, pack_nulls
+
+ENCODING_UNENCODED, ENCODING_DICTIONARY, ENCODING_RUN_LENGTH, ENCODING_FIXED_STRING, ENCODING_FRAME_OF_REFERENCE, ENCODING_LZ4 = range(6)  # encoding_type.hpp:26
+VECTOR_BIT_PACKING, VECTOR_FIXED_1, VECTOR_FIXED_2, VECTOR_FIXED_4 = range(4)   # compressed_vector_type.hpp:28-33
+TYPE_NAMES = {"int": abi.TYPE_INT, "long": abi.TYPE_LONG, "float": abi.TYPE_FLOAT, "double": abi.TYPE_DOUBLE, "string": abi.TYPE_STRING}
+NAME_OF_TYPE = {v: k for k, v in TYPE_NAMES.items()}
+NUMPY_OF_TYPE = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}
+WIDTH_OF_VECTOR = {VECTOR_FIXED_1: 1, VECTOR_FIXED_2: 2, VECTOR_FIXED_4: 4}
+UINT_OF_WIDTH = {1: np.uint8, 2: np.uint16, 4: np.uint32}
+
+
+class UnsupportedSegment(Exception):
+    pass
+
+
+class BinaryTable:
+    """names / types (HY_TYPE_*) / nullable per column, target chunk size, and one HostColumn per column.  String
+    columns keep their values as Python lists next to the HostColumn (`strings[column][chunk]`: dictionary or values)."""
+
+    def __init__(self, names, types, nullable, chunk_size, columns, strings, null_masks, sort_definitions=None):
+        self.names, self.types, self.nullable, self.chunk_size = names, types, nullable, chunk_size
+        self.columns, self.strings, self.null_masks = columns, strings, null_masks
+        self.sort_definitions = sort_definitions or []   # per chunk: list of (column id, sort mode) -- Chunk::individually_sorted_by
+
+    @property
+    def chunk_count(self):
+        return self.columns[0].n_chunks if self.columns else 0
+
+
+class _Reader:
+    def __init__(self, data):
+        self.data, self.pos = data, 0
+
+    def take(self, fmt):
+        size = struct.calcsize(fmt)
+        values = struct.unpack_from("<" + fmt, self.data, self.pos)
+        self.pos += size
+        return values if len(values) > 1 else values[0]
+
+    def array(self, dtype, count):
+        out = np.frombuffer(self.data, dtype=dtype, count=count, offset=self.pos).copy()
+        self.pos += out.nbytes
+        return out
+
+    def strings(self, count):   # export_string_values (binary_writer.cpp:48-76): size_t lengths, then the bytes back to back
+        lengths = self.array(np.uint64, count)
+        out = []
+        for n in lengths:
+            out.append(self.data[self.pos:self.pos + int(n)].decode("utf-8", errors="surrogateescape"))
+            self.pos += int(n)
+        return out
+
+
+def read_table(path):
+    with open(path, "rb") as fh:
+        r = _Reader(fh.read())
+    chunk_size, chunk_count, column_count = r.take("I"), r.take("I"), r.take("H")
+    types = [TYPE_NAMES[t] for t in r.strings(column_count)]
+    nullable = [bool(b) for b in r.array(np.uint8, column_count)]
+    names = r.strings(column_count)
+    segments = [[] for _ in range(column_count)]
+    strings = [[] for _ in range(column_count)]
+    null_masks = [[] for _ in range(column_count)]
+    sort_definitions = []
+    for _ in range(chunk_count):
+        rows = r.take("I")
+        sort_definitions.append([r.take("HB") for _ in range(r.take("I"))])   # SortColumnDefinition: ColumnID (2) + SortMode (1)
+        for c in range(column_count):
+            segment, text, nulls = _read_segment(r, types[c], nullable[c], rows)
+            segments[c].append(segment)
+            strings[c].append(text)
+            null_masks[c].append(nulls)
+    if r.pos != len(r.data):
+        raise ValueError(f"{path}: {len(r.data) - r.pos} trailing bytes")
+    columns = [HostColumn(segments[c], types[c]) for c in range(column_count)]
+    return BinaryTable(names, types, nullable, chunk_size, columns, strings, null_masks, sort_definitions)
+
+
+def _read_segment(r, data_type, column_nullable, rows):
+    encoding = r.take("B")
+    is_string = data_type == abi.TYPE_STRING
+    if encoding == ENCODING_UNENCODED:                   # binary_writer.hpp:56-76
+        nulls = None
+        if column_nullable and r.take("B"):
+            nulls = r.array(np.uint8, rows).astype(bool)
+        if is_string:
+            values = r.strings(rows)
+            return HostSegment(abi.ENC_UNENCODED, data_type, rows, 0, None), values, nulls
+        values = r.array(NUMPY_OF_TYPE[data_type], rows)
+        words = pack_nulls(nulls) if nulls is not None else None
+        return HostSegment(abi.ENC_UNENCODED, data_type, rows, values.dtype.itemsize, values, nulls=words), None, nulls
+    if encoding == ENCODING_DICTIONARY:                  # binary_writer.hpp:98-120
+        vector_type = r.take("B")
+        dictionary_size = r.take("I")
+        text = None
+        if is_string:
+            text = r.strings(dictionary_size)
+            dictionary = None
+        else:
+            dictionary = r.array(NUMPY_OF_TYPE[data_type], dictionary_size)
+        if vector_type not in WIDTH_OF_VECTOR:
+            raise UnsupportedSegment("BitPacking attribute vector")
+        width = WIDTH_OF_VECTOR[vector_type]
+        attribute_vector = r.array(UINT_OF_WIDTH[width], rows)
+        nulls = attribute_vector == dictionary_size     # NULL value id (dictionary_segment.cpp:139-141)
+        return (HostSegment(abi.ENC_DICTIONARY, data_type, rows, width, attribute_vector, aux=dictionary, aux_size=dictionary_size), text,
+                nulls if nulls.any() else None)
+    if encoding == ENCODING_FRAME_OF_REFERENCE:          # binary_writer.hpp:168-190
+        vector_type = r.take("B")
+        blocks = r.take("I")
+        minima = r.array(np.int32, blocks)
+        nulls = r.array(np.uint8, rows).astype(bool) if r.take("B") else None
+        if vector_type not in WIDTH_OF_VECTOR:
+            raise UnsupportedSegment("BitPacking offset vector")
+        width = WIDTH_OF_VECTOR[vector_type]
+        offsets = r.array(UINT_OF_WIDTH[width], rows)
+        words = pack_nulls(nulls) if nulls is not None else None
+        return HostSegment(abi.ENC_FRAME_OF_REFERENCE, data_type, rows, width, offsets, aux=minima, aux_size=blocks, nulls=words), None, nulls
+    raise UnsupportedSegment({ENCODING_RUN_LENGTH: "RunLength", ENCODING_FIXED_STRING: "FixedStringDictionary", ENCODING_LZ4: "LZ4"}.get(encoding, f"encoding {encoding}"))
+
+
+def _write_strings(out, values):
+    raw = [v.encode("utf-8", errors="surrogateescape") for v in values]
+    out.append(np.array([len(v) for v in raw], dtype=np.uint64).tobytes())
+    out.extend(raw)
+
+
+def write_table(path, table):
+    """Serialises a BinaryTable exactly like BinaryWriter::write: tables parsed from a file, or built from columns that
+    this package encoded, come out byte-identical to what Hyrise writes."""
+    out = [struct.pack("<IIH", table.chunk_size, table.chunk_count, len(table.names))]
+    _write_strings(out, [NAME_OF_TYPE[t] for t in table.types])
+    out.append(bytes(int(n) for n in table.nullable))
+    _write_strings(out, table.names)
+    for chunk in range(table.chunk_count):
+        rows = table.columns[0].segments[chunk].size
+        sorted_by = table.sort_definitions[chunk] if chunk < len(table.sort_definitions) else []
+        out.append(struct.pack("<II", rows, len(sorted_by)))
+        for column_id, mode in sorted_by:
+            out.append(struct.pack("<HB", column_id, mode))
+        for c, column in enumerate(table.columns):
+            s = column.segments[chunk]
+            text = table.strings[c][chunk] if table.strings[c] else None
+            nulls = table.null_masks[c][chunk] if table.null_masks[c] else None
+            if s.encoding == abi.ENC_UNENCODED:
+                out.append(struct.pack("<B", ENCODING_UNENCODED))
+                if table.nullable[c]:
+                    # a nullable column's ValueSegment is nullable itself (value_segment.hpp), even without NULLs
+                    mask = nulls if nulls is not None else np.zeros(rows, dtype=bool)
+                    out.append(struct.pack("<B", 1))
+                    out.append(mask.astype(np.uint8).tobytes())
+                if table.types[c] == abi.TYPE_STRING:
+                    _write_strings(out, text)
+                else:
+                    out.append(np.ascontiguousarray(s.data).tobytes())
+            elif s.encoding == abi.ENC_DICTIONARY:
+                out.append(struct.pack("<BBI", ENCODING_DICTIONARY, {1: VECTOR_FIXED_1, 2: VECTOR_FIXED_2, 4: VECTOR_FIXED_4}[s.width], s.aux_size))
+                if table.types[c] == abi.TYPE_STRING:
+                    _write_strings(out, text)
+                else:
+                    out.append(np.ascontiguousarray(s.aux).tobytes())
+                out.append(np.ascontiguousarray(s.data).tobytes())
+            elif s.encoding == abi.ENC_FRAME_OF_REFERENCE:
+                out.append(struct.pack("<BBI", ENCODING_FRAME_OF_REFERENCE, {1: VECTOR_FIXED_1, 2: VECTOR_FIXED_2, 4: VECTOR_FIXED_4}[s.width], s.aux_size))
+                out.append(np.ascontiguousarray(s.aux).tobytes())
+                out.append(struct.pack("<B", 1 if nulls is not None else 0))
+                if nulls is not None:
+                    out.append(nulls.astype(np.uint8).tobytes())
+                out.append(np.ascontiguousarray(s.data).tobytes())
+            else:
+                raise UnsupportedSegment(f"encoding {s.encoding}")
+    data = b"".join(out)
+    with open(path, "wb") as fh:
+        fh.write(data)
+    return data
+
+
+def decode_column(table, column):
+    """(values, null mask) of a numeric column over all chunks, decoded on the host (for tests)."""
+    values, masks = [], []
+    for chunk, s in enumerate(table.columns[column].segments):
+        nulls = table.null_masks[column][chunk]
+        mask = nulls if nulls is not None else np.zeros(s.size, dtype=bool)
+        if s.encoding == abi.ENC_UNENCODED:
+            v = s.data.copy()
+        elif s.encoding == abi.ENC_DICTIONARY:
+            padded = np.concatenate([s.aux, np.zeros(1, dtype=s.aux.dtype)])
+            v = padded[np.minimum(s.data.astype(np.int64), s.aux_size)]
+        else:
+            v = (s.data.astype(np.int64) + np.repeat(s.aux.astype(np.int64), abi.FOR_BLOCK_SIZE)[:s.size]).astype(np.int32)
+        v = v.copy()
+        v[mask] = 0
+        values.append(v)
+        masks.append(mask)
+    if not values:
+        return np.zeros(0, dtype=NUMPY_OF_TYPE[table.types[column]]), np.zeros(0, dtype=bool)
+    return np.concatenate(values), np.concatenate(masks)
+
+
+def table_from_columns(names, nullable, chunk_size, columns, nulls=None):
+    """BinaryTable over HostColumns encoded by storage.make_column (numeric columns).  nulls[c]: the column's bool array
+    or None.  The per-chunk NULL masks are what the writer needs beside the segments: a nullable column's ValueSegment
+    always carries its null vector, a FrameOfReferenceSegment only if the chunk holds a NULL."""
+    nulls = nulls or [None] * len(columns)
+    masks = []
+    for c, column in enumerate(columns):
+        per_chunk, begin = [], 0
+        for s in column.segments:
+            mask = np.asarray(nulls[c][begin:begin + s.size], dtype=bool) if nulls[c] is not None else None
+            begin += s.size
+            if s.encoding == abi.ENC_UNENCODED:
+                per_chunk.append(mask if mask is not None else (np.zeros(s.size, dtype=bool) if nullable[c] else None))
+            elif s.encoding == abi.ENC_FRAME_OF_REFERENCE:
+                per_chunk.append(mask if s.nulls is not None else None)
+            else:
+                per_chunk.append(mask if mask is not None and mask.any() else None)
+        masks.append(per_chunk)
+    return BinaryTable(list(names), [c.data_type for c in columns], list(nullable), chunk_size, list(columns), [[] for _ in columns], masks)

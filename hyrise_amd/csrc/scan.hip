@@ -128,7 +128,8 @@ __device__ bool integer_range(uint32_t cond, Wide v, Wide v2, Wide tmin, Wide tm
 //                cooperative 64-ary search, so a chunk costs two or three dependent loads instead of ~50
 //   finish_job   the scalar rules of the reference's scan implementations on the four bounds
 __device__ __forceinline__ bool job_searches(const DevSegment& seg, uint32_t cond, uint32_t wave) {
-  const bool searchable = seg.encoding == HY_ENC_DICTIONARY && seg.aux && seg.data_type != HY_TYPE_STRING &&
+  // (an EMPTY dictionary -- every row NULL -- has no buffer either, but nothing to resolve: it is searched, and finds nothing)
+  const bool searchable = seg.encoding == HY_ENC_DICTIONARY && (seg.aux || seg.aux_size == 0) && seg.data_type != HY_TYPE_STRING &&
                           cond != HY_PRED_IS_NULL && cond != HY_PRED_IS_NOT_NULL;
   return searchable && (wave < 2 || is_between(cond));
 }
@@ -172,7 +173,7 @@ __device__ __forceinline__ void finish_job(const DevSegment& s, uint32_t c, cons
     job.null_vid = d;
     uint32_t lower = 0, upper = 0, lower2 = 0, upper2 = 0;
     bool found = false;
-    if (s.aux && s.data_type != HY_TYPE_STRING) {
+    if ((s.aux || s.aux_size == 0) && s.data_type != HY_TYPE_STRING) {
       lower = s_bound[0]; upper = s_bound[1]; lower2 = s_bound[2]; upper2 = s_bound[3];
       switch (s.data_type) {
         case HY_TYPE_INT: found = dict_equals<int32_t>(s, lower, p.value.i32); break;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void finish_job(const DevSegment& s, uint32_t c, cons
     }
     if (is_between(cond)) {  // column_between_table_scan_impl.cpp:112-193
       uint32_t lower_vid, upper_vid;
-      if (s.aux && s.data_type != HY_TYPE_STRING) {
+      if ((s.aux || s.aux_size == 0) && s.data_type != HY_TYPE_STRING) {
         lower_vid = lower_inclusive(cond) ? lower : upper;
         upper_vid = upper_inclusive(cond) ? upper2 : lower2;
       } else {

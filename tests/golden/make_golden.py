@@ -29,8 +29,35 @@ FILES = [
 ]
 
 
+# Binary tables written by Hyrise itself (src/test/lib/import_export/binary/binary_writer_test.cpp compares its output
+# byte by byte with these files): real DictionarySegment / FrameOfReferenceSegment / ValueSegment layouts.
+BIN_REF = "/root/reference/resources/test_data/bin"
+BIN_FILES = ["SingleChunkFrameOfReferenceSegment.bin", "MultipleChunksFrameOfReferenceSegment.bin", "NullValuesFrameOfReferenceSegment.bin",
+             "AllNullFrameOfReferenceSegment.bin", "SortColumnDefinitions.bin", "TwoColumnsNoValues.bin", "float.bin", "int_float.bin",
+             "int_float_deleted.bin", "int_string2.bin", "FixedStringDictionarySingleChunk.bin"]
+BIN_DIRS = ["AllTypesAllNullValues", "AllTypesMixColumn", "AllTypesNullValues", "AllTypesSegmentSorted", "AllTypesSegmentUnsorted",
+            "EmptyStringsSegment", "MultipleChunkSingleFloatColumn", "RepeatedInt", "RunNullValues", "SingleChunkSingleFloatColumn", "StringSegment"]
+
+
+def copy_binary_tables(manifest):
+    names = list(BIN_FILES)
+    for directory in BIN_DIRS:
+        names += [f"{directory}/{encoding}.bin" for encoding in ("Unencoded", "Dictionary", "RunLength")]
+    for name in names:
+        src = os.path.join(BIN_REF, name)
+        if not os.path.exists(src):
+            print("missing in reference:", name)
+            continue
+        dst = os.path.join(HERE, "bin", name)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copyfile(src, dst)
+        with open(src, "rb") as fh:
+            manifest["bin/" + name] = {"source": "resources/test_data/bin/" + name, "sha256": hashlib.sha256(fh.read()).hexdigest()}
+
+
 def main():
     manifest = {}
+    copy_binary_tables(manifest)
     names = list(FILES)
     # AggregateHash: every input/expected pair (src/test/lib/operators/aggregate_test.cpp:290-852)
     for root, _, files in os.walk(os.path.join(REF, "aggregateoperator")):
