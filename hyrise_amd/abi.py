@@ -19,7 +19,7 @@ TYPE_NULL, TYPE_INT, TYPE_LONG, TYPE_FLOAT, TYPE_DOUBLE, TYPE_STRING = range(6)
 (JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL_OUTER, JOIN_CROSS, JOIN_SEMI, JOIN_ANTI_NULL_AS_TRUE,
  JOIN_ANTI_NULL_AS_FALSE) = range(8)
 AGG_MIN, AGG_MAX, AGG_SUM, AGG_AVG, AGG_COUNT, AGG_COUNT_DISTINCT, AGG_STDDEV_SAMP, AGG_ANY = range(8)
-ENC_UNENCODED, ENC_DICTIONARY, ENC_FRAME_OF_REFERENCE, ENC_REFERENCE, ENC_MVCC = range(5)
+ENC_UNENCODED, ENC_DICTIONARY, ENC_FRAME_OF_REFERENCE, ENC_REFERENCE, ENC_MVCC, ENC_RUN_LENGTH = range(6)
 MEM_HOST, MEM_DEVICE = 0, 1
 CHUNK_SCANNED, CHUNK_ALL_MATCH, CHUNK_NONE_MATCH = 0, 1, 2
 INVALID_VALUE_ID = 0xFFFFFFFF

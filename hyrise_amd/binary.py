@@ -6,8 +6,8 @@ runs elsewhere -- exact dictionaries, attribute-vector widths, FrameOfReference 
 buffers go to the device unchanged (`storage.DeviceColumn`), and columns encoded here can be written back byte-identically.
 
 Handled: Unencoded (ValueSegment), Dictionary and FrameOfReference segments with FixedWidthInteger attribute / offset
-vectors, all five data types (string columns: parsed; only their dictionary-encoded form is scannable on the device).
-RunLength, FixedStringDictionary, LZ4 and BitPacking vectors raise UnsupportedSegment (the adapter keeps such columns
+vectors and numeric RunLength segments, all five data types (string columns: parsed; only their dictionary-encoded form is
+scannable on the device).  FixedStringDictionary, LZ4 and BitPacking vectors raise UnsupportedSegment (the adapter keeps such columns
 on the CPU path).
 """
 import struct
@@ -133,6 +133,17 @@ def _read_segment(r, data_type, column_nullable, rows):
         offsets = r.array(UINT_OF_WIDTH[width], rows)
         words = pack_nulls(nulls) if nulls is not None else None
         return HostSegment(abi.ENC_FRAME_OF_REFERENCE, data_type, rows, width, offsets, aux=minima, aux_size=blocks, nulls=words), None, nulls
+    if encoding == ENCODING_RUN_LENGTH:                  # binary_writer.hpp:146-160
+        runs = r.take("I")
+        text = r.strings(runs) if is_string else None
+        run_values = None if is_string else r.array(NUMPY_OF_TYPE[data_type], runs)
+        run_nulls = r.array(np.uint8, runs)
+        run_ends = r.array(np.uint32, runs)
+        lengths = np.diff(np.concatenate([[-1], run_ends.astype(np.int64)]))
+        nulls = np.repeat(run_nulls.astype(bool), lengths)
+        width = 0 if is_string else run_values.dtype.itemsize
+        return (HostSegment(abi.ENC_RUN_LENGTH, data_type, rows, width, run_values, aux=run_ends, aux_size=runs, nulls=run_nulls), text,
+                nulls if nulls.any() else None)
     raise UnsupportedSegment({ENCODING_RUN_LENGTH: "RunLength", ENCODING_FIXED_STRING: "FixedStringDictionary", ENCODING_LZ4: "LZ4"}.get(encoding, f"encoding {encoding}"))
 
 
@@ -184,6 +195,14 @@ def write_table(path, table):
                 if nulls is not None:
                     out.append(nulls.astype(np.uint8).tobytes())
                 out.append(np.ascontiguousarray(s.data).tobytes())
+            elif s.encoding == abi.ENC_RUN_LENGTH:
+                out.append(struct.pack("<BI", ENCODING_RUN_LENGTH, s.aux_size))
+                if table.types[c] == abi.TYPE_STRING:
+                    _write_strings(out, text)
+                else:
+                    out.append(np.ascontiguousarray(s.data).tobytes())
+                out.append(np.ascontiguousarray(s.nulls, dtype=np.uint8).tobytes())
+                out.append(np.ascontiguousarray(s.aux, dtype=np.uint32).tobytes())
             else:
                 raise UnsupportedSegment(f"encoding {s.encoding}")
     data = b"".join(out)
@@ -200,6 +219,8 @@ def decode_column(table, column):
         mask = nulls if nulls is not None else np.zeros(s.size, dtype=bool)
         if s.encoding == abi.ENC_UNENCODED:
             v = s.data.copy()
+        elif s.encoding == abi.ENC_RUN_LENGTH:
+            v = np.repeat(s.data, np.diff(np.concatenate([[-1], s.aux.astype(np.int64)])))
         elif s.encoding == abi.ENC_DICTIONARY:
             padded = np.concatenate([s.aux, np.zeros(1, dtype=s.aux.dtype)])
             v = padded[np.minimum(s.data.astype(np.int64), s.aux_size)]

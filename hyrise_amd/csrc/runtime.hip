@@ -296,6 +296,11 @@ static hy_status validate_segment(const hy_segment& s, uint32_t chunk, uint32_t 
       if (s.size && (!s.data || !s.aux)) return fail(HY_ERR_INVALID, "chunk %u: FrameOfReference buffers missing", chunk);
       if (s.aux_size != (s.size + HY_FOR_BLOCK_SIZE - 1) / HY_FOR_BLOCK_SIZE) return fail(HY_ERR_INVALID, "chunk %u: %u block minima for %u rows", chunk, s.aux_size, s.size);
       break;
+    case HY_ENC_RUN_LENGTH:
+      if (s.data_type == HY_TYPE_STRING) return fail(HY_ERR_UNSUPPORTED, "chunk %u: run-length encoded strings stay on the CPU path", chunk);
+      if (s.width != type_width(s.data_type)) return fail(HY_ERR_INVALID, "chunk %u: run value width %u does not match type %u", chunk, s.width, s.data_type);
+      if (s.size && (!s.data || !s.aux || !s.aux_size)) return fail(HY_ERR_INVALID, "chunk %u: run-length buffers missing", chunk);
+      break;
     case HY_ENC_MVCC:
       if (s.width != 4 || s.data_type != HY_TYPE_INT) return fail(HY_ERR_INVALID, "chunk %u: MVCC segments are three uint32 arrays (width 4, HY_TYPE_INT)", chunk);
       if (s.size && (!s.data || !s.aux || !s.nulls)) return fail(HY_ERR_INVALID, "chunk %u: MVCC arrays missing (tids, begin cids, end cids)", chunk);
@@ -342,6 +347,41 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     hy_column_destroy(column);
     return st;
   };
+
+  // RunLengthSegments are expanded once, here: the kernels see a ValueSegment (values + null bitmap).  The expansion of
+  // RunLengthSegmentIterable (run_length_segment_iterable.hpp): row r belongs to the first run whose end position >= r.
+  std::vector<std::vector<unsigned char>> expanded_values(n_chunks);
+  std::vector<std::vector<uint64_t>> expanded_nulls(n_chunks);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    hy_segment& s = column->host_segments[c];
+    if (s.encoding != HY_ENC_RUN_LENGTH) continue;
+    if (mem != HY_MEM_HOST) return cleanup(fail(HY_ERR_UNSUPPORTED, "chunk %u: run-length segments are expanded on upload (HY_MEM_HOST only)", c));
+    const auto* run_values = static_cast<const unsigned char*>(s.data);
+    const auto* run_ends = static_cast<const uint32_t*>(s.aux);
+    const auto* run_nulls = reinterpret_cast<const uint8_t*>(s.nulls);
+    auto& values = expanded_values[c];
+    auto& nulls = expanded_nulls[c];
+    values.assign(size_t{s.width} * s.size, 0);
+    bool any_null = false;
+    for (uint32_t run = 0; run < s.aux_size && run_nulls; ++run) any_null = any_null || run_nulls[run] != 0;
+    if (any_null) nulls.assign((size_t{s.size} + 63) / 64, 0);
+    uint32_t row = 0;
+    for (uint32_t run = 0; run < s.aux_size; ++run) {
+      if (run_ends[run] >= s.size || run_ends[run] < row) return cleanup(fail(HY_ERR_INVALID, "chunk %u: run %u ends at %u (rows: %u)", c, run, run_ends[run], s.size));
+      const bool is_null = run_nulls && run_nulls[run] != 0;
+      for (; row <= run_ends[run]; ++row) {
+        if (is_null) nulls[row >> 6] |= 1ull << (row & 63);
+        else std::memcpy(&values[size_t{row} * s.width], run_values + size_t{run} * s.width, s.width);
+      }
+    }
+    if (row != s.size) return cleanup(fail(HY_ERR_INVALID, "chunk %u: runs cover %u of %u rows", c, row, s.size));
+    s.encoding = HY_ENC_UNENCODED;
+    s.data = values.data();
+    s.aux = nullptr;
+    s.aux_size = 0;
+    s.nulls = any_null ? nulls.data() : nullptr;
+  }
+  segments = column->host_segments.data();   // from here on: the expanded descriptors
 
   // One arena for every buffer of the column: 916 chunks x 3 buffers would otherwise be ~2.7k hipMallocs.
   size_t arena_bytes = 0;

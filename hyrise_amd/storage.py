@@ -152,6 +152,43 @@ def auto_encoding(data_type, unique):
     return abi.ENC_DICTIONARY
 
 
+def encode_run_length(values, nulls=None):
+    """RunLengthSegment<T> of one chunk (run_length_encoder.hpp): one run per stretch of equal values / NULLs; end positions
+    are inclusive.  The NULL flags travel as one byte per run."""
+    values = np.ascontiguousarray(values)
+    n = len(values)
+    mask = np.asarray(nulls, dtype=bool) if nulls is not None else np.zeros(n, dtype=bool)
+    if n == 0:
+        return HostSegment(abi.ENC_RUN_LENGTH, TYPE_OF_NP[values.dtype], 0, values.dtype.itemsize, values[:0].copy(), aux=np.zeros(0, np.uint32),
+                           aux_size=0, nulls=np.zeros(0, np.uint8))
+    clean = values.copy()
+    clean[mask] = 0
+    change = np.ones(n, dtype=bool)
+    change[1:] = (clean[1:] != clean[:-1]) | (mask[1:] != mask[:-1])
+    starts = np.flatnonzero(change)
+    ends = np.concatenate([starts[1:] - 1, [n - 1]]).astype(np.uint32)
+    return HostSegment(abi.ENC_RUN_LENGTH, TYPE_OF_NP[values.dtype], n, values.dtype.itemsize, clean[starts].copy(), aux=ends, aux_size=len(starts),
+                       nulls=mask[starts].astype(np.uint8))
+
+
+def expand_run_length(host_column):
+    """The same column with every RunLength segment replaced by the ValueSegment it decodes to (what the residency cache
+    does on upload; the CPU oracle reads plain segments only)."""
+    if not any(s.encoding == abi.ENC_RUN_LENGTH for s in host_column.segments):
+        return host_column
+    segments = []
+    for s in host_column.segments:
+        if s.encoding != abi.ENC_RUN_LENGTH:
+            segments.append(s)
+            continue
+        lengths = np.diff(np.concatenate([[-1], np.asarray(s.aux, dtype=np.int64)]))
+        mask = np.repeat(np.asarray(s.nulls, dtype=bool), lengths)
+        values = np.repeat(s.data, lengths)
+        values[mask] = 0
+        segments.append(HostSegment(abi.ENC_UNENCODED, s.data_type, s.size, s.width, values, nulls=pack_nulls(mask) if mask.any() else None))
+    return HostColumn(segments, host_column.data_type)
+
+
 MVCC_MUTABLE = 1 << 31
 MAX_COMMIT_ID = 0xFFFFFFFF - 1   # MvccData::MAX_COMMIT_ID (mvcc_data.hpp): "not yet invalidated"
 

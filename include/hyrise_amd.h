@@ -66,7 +66,10 @@ enum {
 };
 
 enum { HY_ENC_UNENCODED = 0, HY_ENC_DICTIONARY = 1, HY_ENC_FRAME_OF_REFERENCE = 2, HY_ENC_REFERENCE = 3,
-       HY_ENC_MVCC = 4 /* not a column encoding: a chunk's MvccData, see hy_validate */ };
+       HY_ENC_MVCC = 4 /* not a column encoding: a chunk's MvccData, see hy_validate */,
+       HY_ENC_RUN_LENGTH = 5 /* RunLengthSegment<T> (run_length_segment.hpp): data = run values (T[aux_size]), aux = inclusive end
+                              * positions (uint32_t[aux_size]), nulls = per-run NULL flags as BYTES (uint8_t[aux_size], cast), width =
+                              * sizeof(T).  HY_MEM_HOST only: the residency cache expands the runs once, on upload. */ };
 
 /* Where the pointers of a descriptor / result live. */
 enum { HY_MEM_HOST = 0, HY_MEM_DEVICE = 1 };

@@ -56,6 +56,8 @@ class OracleCol:
     """hyo_column over a HostColumn (host pointers)."""
 
     def __init__(self, host_column):
+        from hyrise_amd.storage import expand_run_length
+        host_column = expand_run_length(host_column)   # the oracle reads Value / Dictionary / FrameOfReference segments
         self.host = host_column
         self._ref_cols = {}
 

@@ -13,7 +13,7 @@ from support import GOLDEN
 
 BIN = os.path.join(os.path.dirname(GOLDEN), "bin")
 FILES = sorted(p for p in glob.glob(os.path.join(BIN, "**", "*.bin"), recursive=True))
-UNSUPPORTED = ("RunLength.bin", "FixedStringDictionarySingleChunk.bin")
+UNSUPPORTED = ("FixedStringDictionarySingleChunk.bin",)
 
 
 def supported(path):
@@ -98,3 +98,25 @@ def test_known_table_contents():
     np.testing.assert_allclose(floats, [458.7, 456.7, 457.7], rtol=1e-6)
     empty = binary.read_table(os.path.join(BIN, "TwoColumnsNoValues.bin"))
     assert empty.names == ["FirstColumn", "SecondColumn"] and empty.chunk_count == 0
+
+
+@pytest.mark.parametrize("directory", ["AllTypesAllNullValues", "AllTypesMixColumn", "AllTypesNullValues", "AllTypesSegmentSorted", "AllTypesSegmentUnsorted",
+                                       "RepeatedInt", "RunNullValues", "SingleChunkSingleFloatColumn"])
+def test_run_length_encoder_reproduces_hyrise_bytes(directory):
+    """Same game for RunLengthSegment: runs, NULL runs and inclusive end positions as Hyrise's RunLengthEncoder wrote them."""
+    plain = binary.read_table(os.path.join(BIN, directory, "Unencoded.bin"))
+    encoded = binary.read_table(os.path.join(BIN, directory, "RunLength.bin"))
+    for c in numeric_columns(plain):
+        values, nulls = binary.decode_column(plain, c)
+        their_values, their_nulls = binary.decode_column(encoded, c)
+        np.testing.assert_array_equal(values, their_values)
+        np.testing.assert_array_equal(nulls, their_nulls)
+        begin = 0
+        for theirs in encoded.columns[c].segments:
+            if theirs.encoding == abi.ENC_RUN_LENGTH:
+                ours = storage.encode_run_length(values[begin:begin + theirs.size], nulls[begin:begin + theirs.size])
+                assert ours.aux_size == theirs.aux_size, (directory, c)
+                np.testing.assert_array_equal(ours.aux, theirs.aux)
+                np.testing.assert_array_equal(ours.nulls, theirs.nulls)
+                np.testing.assert_array_equal(ours.data[ours.nulls == 0], theirs.data[theirs.nulls == 0])   # a NULL run's value is unspecified
+            begin += theirs.size

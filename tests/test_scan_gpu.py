@@ -258,3 +258,28 @@ def test_scan_hyrise_binary_tables(device):
                 scanned += 1
             dev.close()
     assert scanned > 300
+
+
+def test_run_length_segments(device):
+    """RunLengthSegment<T> columns (expanded once by the residency cache) behave like the ValueSegments they decode to:
+    scans, a join and an aggregate over long runs with NULL runs."""
+    from hyrise_amd.operators import aggregate_hash, join_hash
+    from support import oracle_aggregate, oracle_join
+    rng = np.random.default_rng(23)
+    n, chunk = 200_000, 30_000
+    values = np.repeat(rng.integers(0, 50, n // 40 + 1), 40)[:n].astype(np.int32)
+    nulls = np.repeat(rng.random(n // 25 + 1) < 0.1, 25)[:n]
+    segments = [storage.encode_run_length(values[b:b + chunk], nulls[b:b + chunk]) for b in range(0, n, chunk)]
+    host = storage.HostColumn(segments, abi.TYPE_INT)
+    assert segments[0].aux_size < chunk // 10
+    dev = DeviceColumn(host)
+    for condition in CONDITIONS:
+        check(host, make_predicate(condition, abi.TYPE_INT, 10, 30, nullable=True), dev, context=f"run length cond {condition}")
+    other_host = build_column(rng.integers(0, 60, 3_000).astype(np.int32), None, 1_000, abi.ENC_DICTIONARY)
+    other = DeviceColumn(other_host)
+    got, want = join_hash(other, dev, abi.JOIN_INNER), oracle_join(other_host, host, abi.JOIN_INNER)
+    assert got.n_pairs == want.n_pairs and got.left[:got.n_pairs].tobytes() == want.left[:want.n_pairs].tobytes()
+    assert got.right[:got.n_pairs].tobytes() == want.right[:want.n_pairs].tobytes()
+    sums = aggregate_hash([dev], [(abi.AGG_COUNT, None), (abi.AGG_SUM, dev)])
+    expected = oracle_aggregate([host], [(abi.AGG_COUNT, None), (abi.AGG_SUM, host)])
+    assert sums.n_groups == expected.n_groups and sums.column(0) == expected.column(0) and sums.column(1) == expected.column(1)
