@@ -7,7 +7,8 @@ buffers go to the device unchanged (`storage.DeviceColumn`), and columns encoded
 
 Handled: Unencoded (ValueSegment), Dictionary and FrameOfReference segments with FixedWidthInteger attribute / offset
 vectors and numeric RunLength segments, all five data types (string columns: parsed; only their dictionary-encoded form is
-scannable on the device).  FixedStringDictionary, LZ4 and BitPacking vectors raise UnsupportedSegment (the adapter keeps such columns
+scannable on the device; FixedStringDictionary segments are string dictionaries for it).  LZ4 and BitPacking vectors
+raise UnsupportedSegment (the adapter keeps such columns
 on the CPU path).
 """
 import struct
@@ -28,6 +29,14 @@ UINT_OF_WIDTH = {1: np.uint8, 2: np.uint16, 4: np.uint32}
 
 class UnsupportedSegment(Exception):
     pass
+
+
+class FixedStrings(list):
+    """Dictionary of a FixedStringDictionarySegment: the strings plus the fixed slot length they are stored with."""
+
+    def __init__(self, values, length):
+        super().__init__(values)
+        self.length = length
 
 
 class BinaryTable:
@@ -122,6 +131,19 @@ def _read_segment(r, data_type, column_nullable, rows):
         nulls = attribute_vector == dictionary_size     # NULL value id (dictionary_segment.cpp:139-141)
         return (HostSegment(abi.ENC_DICTIONARY, data_type, rows, width, attribute_vector, aux=dictionary, aux_size=dictionary_size), text,
                 nulls if nulls.any() else None)
+    if encoding == ENCODING_FIXED_STRING:                # binary_writer.hpp:122-144: a dictionary of fixed-length char slots
+        vector_type = r.take("B")
+        dictionary_size, length = r.take("I"), r.take("I")
+        raw = r.data[r.pos:r.pos + dictionary_size * length]
+        r.pos += dictionary_size * length
+        text = FixedStrings([raw[i * length:(i + 1) * length].rstrip(b"\0").decode("utf-8", errors="surrogateescape") for i in range(dictionary_size)], length)
+        if vector_type not in WIDTH_OF_VECTOR:
+            raise UnsupportedSegment("BitPacking attribute vector")
+        width = WIDTH_OF_VECTOR[vector_type]
+        attribute_vector = r.array(UINT_OF_WIDTH[width], rows)
+        nulls = attribute_vector == dictionary_size
+        # for the device this IS a string dictionary segment: scans compare value ids the caller resolved
+        return HostSegment(abi.ENC_DICTIONARY, data_type, rows, width, attribute_vector, aux=None, aux_size=dictionary_size), text, nulls if nulls.any() else None
     if encoding == ENCODING_FRAME_OF_REFERENCE:          # binary_writer.hpp:168-190
         vector_type = r.take("B")
         blocks = r.take("I")
@@ -181,6 +203,10 @@ def write_table(path, table):
                     _write_strings(out, text)
                 else:
                     out.append(np.ascontiguousarray(s.data).tobytes())
+            elif s.encoding == abi.ENC_DICTIONARY and isinstance(text, FixedStrings):
+                out.append(struct.pack("<BBII", ENCODING_FIXED_STRING, {1: VECTOR_FIXED_1, 2: VECTOR_FIXED_2, 4: VECTOR_FIXED_4}[s.width], s.aux_size, text.length))
+                out.extend(v.encode("utf-8", errors="surrogateescape").ljust(text.length, b"\0") for v in text)
+                out.append(np.ascontiguousarray(s.data).tobytes())
             elif s.encoding == abi.ENC_DICTIONARY:
                 out.append(struct.pack("<BBI", ENCODING_DICTIONARY, {1: VECTOR_FIXED_1, 2: VECTOR_FIXED_2, 4: VECTOR_FIXED_4}[s.width], s.aux_size))
                 if table.types[c] == abi.TYPE_STRING:

@@ -34,7 +34,8 @@ FILES = [
 BIN_REF = "/root/reference/resources/test_data/bin"
 BIN_FILES = ["SingleChunkFrameOfReferenceSegment.bin", "MultipleChunksFrameOfReferenceSegment.bin", "NullValuesFrameOfReferenceSegment.bin",
              "AllNullFrameOfReferenceSegment.bin", "SortColumnDefinitions.bin", "TwoColumnsNoValues.bin", "float.bin", "int_float.bin",
-             "int_float_deleted.bin", "int_string2.bin", "FixedStringDictionarySingleChunk.bin"]
+             "int_float_deleted.bin", "int_string2.bin", "FixedStringDictionarySingleChunk.bin", "FixedStringDictionaryNullValue.bin",
+             "FixedStringDictionaryMultipleChunks.bin"]
 BIN_DIRS = ["AllTypesAllNullValues", "AllTypesMixColumn", "AllTypesNullValues", "AllTypesSegmentSorted", "AllTypesSegmentUnsorted",
             "EmptyStringsSegment", "MultipleChunkSingleFloatColumn", "RepeatedInt", "RunNullValues", "SingleChunkSingleFloatColumn", "StringSegment"]
 
@@ -42,7 +43,7 @@ BIN_DIRS = ["AllTypesAllNullValues", "AllTypesMixColumn", "AllTypesNullValues", 
 def copy_binary_tables(manifest):
     names = list(BIN_FILES)
     for directory in BIN_DIRS:
-        names += [f"{directory}/{encoding}.bin" for encoding in ("Unencoded", "Dictionary", "RunLength")]
+        names += [f"{directory}/{encoding}.bin" for encoding in ("Unencoded", "Dictionary", "RunLength", "LZ4")]
     for name in names:
         src = os.path.join(BIN_REF, name)
         if not os.path.exists(src):

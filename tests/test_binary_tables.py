@@ -13,7 +13,7 @@ from support import GOLDEN
 
 BIN = os.path.join(os.path.dirname(GOLDEN), "bin")
 FILES = sorted(p for p in glob.glob(os.path.join(BIN, "**", "*.bin"), recursive=True))
-UNSUPPORTED = ("FixedStringDictionarySingleChunk.bin",)
+UNSUPPORTED = ("LZ4.bin",)
 
 
 def supported(path):
@@ -86,6 +86,15 @@ def test_frame_of_reference_encoder_reproduces_hyrise_bytes(name, chunk_size, nu
     got_values, got_nulls = binary.decode_column(parsed, 0)
     np.testing.assert_array_equal(got_values, values)
     np.testing.assert_array_equal(got_nulls, nulls if nulls is not None else np.zeros(len(rows), dtype=bool))
+
+
+def test_fixed_string_dictionary():
+    """binary_writer_test.cpp FixedStringDictionarySingleChunk: "This", "is", "a", "test" in a FixedStringDictionarySegment."""
+    table = binary.read_table(os.path.join(BIN, "FixedStringDictionarySingleChunk.bin"))
+    segment, dictionary = table.columns[0].segments[0], table.strings[0][0]
+    assert list(dictionary) == ["This", "a", "is", "test"] and dictionary.length == 4
+    assert [dictionary[i] for i in segment.data] == ["This", "is", "a", "test"]
+    assert segment.encoding == abi.ENC_DICTIONARY and segment.aux is None and segment.aux_size == 4
 
 
 def test_known_table_contents():
