@@ -64,6 +64,13 @@ class JoinResult(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+ARITH_ADD, ARITH_SUB, ARITH_MUL, ARITH_DIV, ARITH_MOD = range(5)
+
+
+class Operand(C.Structure):
+    _fields_ = [("column", C.c_void_p), ("literal_type", C.c_uint32), ("literal", Value)]
+
+
 class AggregateSpec(C.Structure):
     _fields_ = [("function", C.c_uint32), ("column", C.c_void_p)]
 
@@ -98,6 +105,10 @@ SYMBOLS = [
     ("hy_column_chunk_count", C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("hy_table_scan", C.c_int32, [C.c_void_p, C.POINTER(Predicate), C.c_void_p, C.c_uint32, C.POINTER(ScanResult)]),
     ("hy_table_scan_columns", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ScanResult)]),
+    ("hy_projection_arithmetic", C.c_int32, [C.c_uint32, C.POINTER(Operand), C.POINTER(Operand), C.POINTER(C.c_void_p)]),
+    ("hy_column_read_chunk", C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("hy_column_data_type", C.c_uint32, [C.c_void_p]),
+    ("hy_column_chunk_rows", C.c_uint32, [C.c_void_p, C.c_uint32]),
     ("hy_validate", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ScanResult)]),
     ("hy_join_hash", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinResult)]),
     ("hy_join_hash_radix_bits", C.c_int32, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),

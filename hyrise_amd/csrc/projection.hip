@@ -1,0 +1,281 @@
+// projection.hip -- the arithmetic a Projection evaluates.
+//
+// What it replaces (reference, CPU):
+//   Projection::_on_execute -> ExpressionEvaluator::evaluate_expression_to_segment     operators/projection.cpp, expression/evaluation/expression_evaluator.cpp
+//   _evaluate_arithmetic_expression + the functors of                                   expression/evaluation/expression_functors.hpp:127-213
+//   expression_common_type                                                              expression/expression_utils.cpp:172-204
+//
+// The reference interprets the expression tree per chunk and materialises one ExpressionResult vector per node.  Here one
+// kernel evaluates  left <op> right  for all chunks of a table (one workgroup per 8192-row slice, a lane per row, both
+// operands decoded in place -- data or reference segments of any supported encoding, or a literal) and writes a
+// device-resident column of unencoded value segments + null bitmap that the next operator consumes directly: for TPC-H Q6
+// / Q1 the products never leave HBM.  HBM-bound: bytes in (operand widths) + bytes out (result width) per row.
+#include "hy_device.hpp"
+#include "hy_decode.hpp"
+
+#include <cstring>
+#include <vector>
+
+namespace hy {
+
+struct Operand {
+  const DevSegment* segments;   // nullptr: literal
+  uint32_t type;                // HY_TYPE_*
+  hy_value literal;
+};
+
+struct ProjectionArgs {
+  Operand left, right;
+  uint32_t op;
+  uint32_t result_type;
+  const Slice* slices;
+  const uint64_t* row_base;     // first global row of every chunk
+  void* values;                 // [rows] of the result type, chunk after chunk (chunk c at row_base[c], 16-byte padded per chunk: see value_base)
+  const uint64_t* value_base;   // byte offset of every chunk's values
+  uint64_t* nulls;              // bitmap words, chunk after chunk
+  const uint64_t* null_base;    // word offset of every chunk's bitmap
+};
+
+__device__ __forceinline__ bool is_float_type(uint32_t t) { return t == HY_TYPE_FLOAT || t == HY_TYPE_DOUBLE; }
+
+// usual arithmetic conversions of the two C++ operand types (std::common_type_t)
+__device__ __forceinline__ uint32_t cxx_common_type(uint32_t a, uint32_t b) {
+  if (a == HY_TYPE_DOUBLE || b == HY_TYPE_DOUBLE) return HY_TYPE_DOUBLE;
+  if (a == HY_TYPE_FLOAT || b == HY_TYPE_FLOAT) return HY_TYPE_FLOAT;
+  if (a == HY_TYPE_LONG || b == HY_TYPE_LONG) return HY_TYPE_LONG;
+  return HY_TYPE_INT;
+}
+
+__device__ __forceinline__ Value operand_value(const Operand& o, uint32_t chunk, uint32_t row) {
+  if (o.segments) {
+    Value v = column_value(o.segments, chunk, row);
+    if (o.type == HY_TYPE_FLOAT) v.f = static_cast<double>(static_cast<float>(v.f));
+    return v;
+  }
+  Value v{o.type == HY_TYPE_NULL, 0, 0.0};
+  switch (o.type) {
+    case HY_TYPE_INT: v.i = o.literal.i32; break;
+    case HY_TYPE_LONG: v.i = o.literal.i64; break;
+    case HY_TYPE_FLOAT: v.f = static_cast<double>(o.literal.f32); break;
+    case HY_TYPE_DOUBLE: v.f = o.literal.f64; break;
+    default: break;
+  }
+  return v;
+}
+
+// value of type `from` (Value convention: .i for integers, .f for float / double) as type `to`
+__device__ __forceinline__ Value convert(const Value& v, uint32_t from, uint32_t to) {
+  Value out{false, 0, 0.0};
+  if (is_float_type(to)) {
+    double d = is_float_type(from) ? v.f : static_cast<double>(v.i);
+    if (to == HY_TYPE_FLOAT) d = static_cast<double>(static_cast<float>(d));
+    out.f = d;
+  } else {
+    int64_t i = is_float_type(from) ? static_cast<int64_t>(v.f) : v.i;
+    if (to == HY_TYPE_INT) i = static_cast<int64_t>(static_cast<int32_t>(i));
+    out.i = i;
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(256) void projection_rows(ProjectionArgs a) {
+  const Slice slice = a.slices[blockIdx.x];
+  const uint32_t lane = threadIdx.x & 63;
+  char* values = static_cast<char*>(a.values) + a.value_base[slice.chunk];
+  uint64_t* nulls = a.nulls + a.null_base[slice.chunk];
+  const uint32_t width = (a.result_type == HY_TYPE_INT || a.result_type == HY_TYPE_FLOAT) ? 4 : 8;
+  for (uint32_t k = 0; k < SLICE_ROWS / 256; ++k) {
+    const uint32_t r = k * 256 + threadIdx.x;
+    const bool in = r < slice.row_count;
+    const uint32_t row = slice.row_begin + r;
+    bool is_null = false;
+    Value result{false, 0, 0.0};
+    if (in) {
+      const Value x = operand_value(a.left, slice.chunk, row), y = operand_value(a.right, slice.chunk, row);
+      is_null = x.is_null || y.is_null;
+      if (!is_null) {
+        const uint32_t at = a.left.type, bt = a.right.type, rt = a.result_type;
+        if (a.op == HY_ARITH_DIV || a.op == HY_ARITH_MOD) {
+          is_null = is_float_type(bt) ? y.f == 0.0 : y.i == 0;   // division by zero is NULL (expression_functors.hpp:174,205)
+        }
+        if (!is_null) {
+          if (a.op == HY_ARITH_DIV) {          // computed in the result type
+            const Value p = convert(x, at, rt), q = convert(y, bt, rt);
+            if (rt == HY_TYPE_DOUBLE) result.f = p.f / q.f;
+            else if (rt == HY_TYPE_FLOAT) result.f = static_cast<double>(static_cast<float>(p.f) / static_cast<float>(q.f));
+            else if (rt == HY_TYPE_INT) result.i = q.i == -1 ? static_cast<int64_t>(static_cast<int32_t>(0u - static_cast<uint32_t>(p.i)))
+                                                             : static_cast<int64_t>(static_cast<int32_t>(p.i) / static_cast<int32_t>(q.i));
+            else result.i = q.i == -1 ? static_cast<int64_t>(0ull - static_cast<uint64_t>(p.i)) : p.i / q.i;
+          } else if (a.op == HY_ARITH_MOD) {
+            uint32_t computed = rt;
+            if (!is_float_type(at) && !is_float_type(bt)) {
+              computed = cxx_common_type(at, bt);
+              result.i = y.i == -1 ? 0 : (computed == HY_TYPE_INT ? static_cast<int64_t>(static_cast<int32_t>(x.i) % static_cast<int32_t>(y.i)) : x.i % y.i);
+            } else if (at == HY_TYPE_FLOAT && bt == HY_TYPE_FLOAT) {
+              computed = HY_TYPE_FLOAT;
+              result.f = static_cast<double>(fmodf(static_cast<float>(x.f), static_cast<float>(y.f)));
+            } else {   // std::fmod with an integral or double argument: in double
+              computed = HY_TYPE_DOUBLE;
+              result.f = fmod(is_float_type(at) ? x.f : static_cast<double>(x.i), is_float_type(bt) ? y.f : static_cast<double>(y.i));
+            }
+            result = convert(result, computed, rt);
+          } else {                              // + - * : computed in the common C++ type, cast to the result type
+            const uint32_t c = cxx_common_type(at, bt);
+            const Value p = convert(x, at, c), q = convert(y, bt, c);
+            if (c == HY_TYPE_DOUBLE) {
+              result.f = a.op == HY_ARITH_ADD ? p.f + q.f : a.op == HY_ARITH_SUB ? p.f - q.f : p.f * q.f;
+            } else if (c == HY_TYPE_FLOAT) {
+              const float pf = static_cast<float>(p.f), qf = static_cast<float>(q.f);
+              // separate statements: the compiler must not contract a float multiply-add across the two roundings
+              const float rf = a.op == HY_ARITH_ADD ? __fadd_rn(pf, qf) : a.op == HY_ARITH_SUB ? __fsub_rn(pf, qf) : __fmul_rn(pf, qf);
+              result.f = static_cast<double>(rf);
+            } else if (c == HY_TYPE_LONG) {
+              const uint64_t pu = static_cast<uint64_t>(p.i), qu = static_cast<uint64_t>(q.i);
+              result.i = static_cast<int64_t>(a.op == HY_ARITH_ADD ? pu + qu : a.op == HY_ARITH_SUB ? pu - qu : pu * qu);
+            } else {
+              const uint32_t pu = static_cast<uint32_t>(p.i), qu = static_cast<uint32_t>(q.i);
+              result.i = static_cast<int64_t>(static_cast<int32_t>(a.op == HY_ARITH_ADD ? pu + qu : a.op == HY_ARITH_SUB ? pu - qu : pu * qu));
+            }
+            result = convert(result, c, rt);
+          }
+        }
+      }
+      // NULL cells hold T{} (value_segment.hpp)
+      switch (a.result_type) {
+        case HY_TYPE_INT: reinterpret_cast<int32_t*>(values)[row] = is_null ? 0 : static_cast<int32_t>(result.i); break;
+        case HY_TYPE_LONG: reinterpret_cast<int64_t*>(values)[row] = is_null ? 0 : result.i; break;
+        case HY_TYPE_FLOAT: reinterpret_cast<float*>(values)[row] = is_null ? 0.f : static_cast<float>(result.f); break;
+        default: reinterpret_cast<double*>(values)[row] = is_null ? 0.0 : result.f; break;
+      }
+    }
+    (void)width;
+    const uint64_t null_lanes = __ballot(in && is_null);   // 64 consecutive rows = one bitmap word (slices start at multiples of 8192)
+    if (lane == 0 && r < ((slice.row_count + 63) & ~63u)) nulls[row >> 6] = null_lanes;
+  }
+}
+
+static uint32_t expression_common_type(uint32_t lhs, uint32_t rhs) {   // expression_utils.cpp:172-204
+  if (lhs == HY_TYPE_NULL) return rhs;
+  if (rhs == HY_TYPE_NULL) return lhs;
+  if (lhs == HY_TYPE_DOUBLE || rhs == HY_TYPE_DOUBLE) return HY_TYPE_DOUBLE;
+  if (lhs == HY_TYPE_LONG) return rhs == HY_TYPE_FLOAT ? HY_TYPE_DOUBLE : HY_TYPE_LONG;
+  if (rhs == HY_TYPE_LONG) return lhs == HY_TYPE_FLOAT ? HY_TYPE_DOUBLE : HY_TYPE_LONG;
+  if (lhs == HY_TYPE_FLOAT || rhs == HY_TYPE_FLOAT) return HY_TYPE_FLOAT;
+  return HY_TYPE_INT;
+}
+
+static bool numeric(uint32_t t) { return t >= HY_TYPE_INT && t <= HY_TYPE_DOUBLE; }
+
+}  // namespace hy
+
+using namespace hy;
+
+extern "C" {
+
+hy_status hy_projection_arithmetic(uint32_t op, const hy_operand* left, const hy_operand* right, hy_column** out) {
+  if (!left || !right || !out) return fail(HY_ERR_INVALID, "hy_projection_arithmetic: null argument");
+  *out = nullptr;
+  if (op > HY_ARITH_MOD) return fail(HY_ERR_INVALID, "unknown arithmetic operator %u", op);
+  const hy_column* shape = left->column ? left->column : right->column;
+  if (!shape) return fail(HY_ERR_INVALID, "hy_projection_arithmetic: at least one operand must be a column");
+  for (const hy_operand* o : {left, right}) {
+    if (o->column) {
+      if (o->column->is_mvcc || (o->column->ref && o->column->ref->is_mvcc)) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
+      if (!numeric(o->column->data_type)) return fail(HY_ERR_UNSUPPORTED, "string expressions stay on the CPU path");
+      if (o->column->n_chunks != shape->n_chunks) return fail(HY_ERR_INVALID, "operand columns do not belong to one table (chunk counts differ)");
+      for (uint32_t c = 0; c < shape->n_chunks; ++c) {
+        if (o->column->host_segments[c].size != shape->host_segments[c].size) return fail(HY_ERR_INVALID, "operand columns do not belong to one table (chunk %u)", c);
+      }
+    } else if (o->literal_type != HY_TYPE_NULL && !numeric(o->literal_type)) {
+      return fail(HY_ERR_UNSUPPORTED, "string expressions stay on the CPU path");
+    }
+  }
+  const uint32_t left_type = left->column ? left->column->data_type : left->literal_type;
+  const uint32_t right_type = right->column ? right->column->data_type : right->literal_type;
+  if (left_type == HY_TYPE_NULL && right_type == HY_TYPE_NULL) return fail(HY_ERR_INVALID, "Cannot deduce common type if both sides are NULL.");
+  const uint32_t result_type = expression_common_type(left_type, right_type);
+  const uint32_t width = (result_type == HY_TYPE_INT || result_type == HY_TYPE_FLOAT) ? 4 : 8;
+  hipStream_t stream = current_stream();
+
+  // result buffers: one allocation, chunk c's values at value_base[c] (256-byte aligned), then all bitmaps
+  const uint32_t n_chunks = shape->n_chunks;
+  std::vector<uint64_t> value_base(n_chunks + 1, 0), null_base(n_chunks + 1, 0);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const uint64_t rows = shape->host_segments[c].size;
+    value_base[c + 1] = value_base[c] + ((rows * width + 16 + 255) & ~uint64_t{255});
+    null_base[c + 1] = null_base[c] + ((rows + 63) / 64 + 31) / 32 * 32;   // 256-byte aligned bitmaps
+  }
+  const uint64_t values_bytes = value_base[n_chunks], null_words = null_base[n_chunks];
+  const uint64_t tables_bytes = 16 * (uint64_t{n_chunks} + 1);
+  char* arena = nullptr;
+  HY_HIP(hipMalloc(reinterpret_cast<void**>(&arena), values_bytes + 8 * null_words + tables_bytes + 256));
+  uint64_t* d_nulls = reinterpret_cast<uint64_t*>(arena + values_bytes);
+  uint64_t* d_value_base = reinterpret_cast<uint64_t*>(arena + values_bytes + 8 * null_words);
+  uint64_t* d_null_base = d_value_base + n_chunks + 1;
+  auto release = [&](hy_status status) { (void)hipFree(arena); return status; };
+  if (hipMemcpyAsync(d_value_base, value_base.data(), 8 * (size_t{n_chunks} + 1), hipMemcpyHostToDevice, stream) != hipSuccess ||
+      hipMemcpyAsync(d_null_base, null_base.data(), 8 * (size_t{n_chunks} + 1), hipMemcpyHostToDevice, stream) != hipSuccess) {
+    return release(fail(HY_ERR_DEVICE, "projection: upload of the chunk tables failed"));
+  }
+  ProjectionArgs a{};
+  a.left = Operand{left->column ? left->column->d_segments : nullptr, left_type, left->literal};
+  a.right = Operand{right->column ? right->column->d_segments : nullptr, right_type, right->literal};
+  a.op = op;
+  a.result_type = result_type;
+  a.slices = shape->d_slices;
+  a.row_base = shape->d_row_base;
+  a.values = arena;
+  a.value_base = d_value_base;
+  a.nulls = d_nulls;
+  a.null_base = d_null_base;
+  if (shape->n_slices && shape->rows) {
+    profile_begin(stream);
+    hipLaunchKernelGGL(projection_rows, dim3(shape->n_slices), dim3(256), 0, stream, a);
+    profile_end(stream);
+  }
+  if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) return release(fail(HY_ERR_DEVICE, "projection kernel failed"));
+
+  // the result as a column over the device buffers (HY_MEM_DEVICE: nothing is copied), which then owns them
+  std::vector<hy_segment> segments(n_chunks ? n_chunks : 1);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    hy_segment& s = segments[c];
+    std::memset(&s, 0, sizeof(s));
+    s.encoding = HY_ENC_UNENCODED;
+    s.data_type = result_type;
+    s.size = shape->host_segments[c].size;
+    s.width = width;
+    s.data = arena + value_base[c];
+    s.nulls = d_nulls + null_base[c];
+    s.ref_chunk_id = 0xFFFFFFFFu;
+  }
+  hy_column* column = nullptr;
+  const hy_status status = hy_column_create(segments.data(), n_chunks, HY_MEM_DEVICE, &column);
+  if (status != HY_OK) return release(status);
+  column->owned.push_back(arena);
+  *out = column;
+  return HY_OK;
+}
+
+hy_status hy_column_read_chunk(const hy_column* column, uint32_t chunk, void* values, uint64_t* null_words) {
+  if (!column || !values) return fail(HY_ERR_INVALID, "hy_column_read_chunk: null argument");
+  if (chunk >= column->n_chunks) return fail(HY_ERR_INVALID, "chunk %u out of range", chunk);
+  const hy_segment& s = column->host_segments[chunk];
+  if (s.encoding != HY_ENC_UNENCODED) return fail(HY_ERR_UNSUPPORTED, "hy_column_read_chunk reads unencoded value segments");
+  hipStream_t stream = current_stream();
+  if (s.size) HY_HIP(hipMemcpyAsync(values, s.data, size_t{s.width} * s.size, hipMemcpyDeviceToHost, stream));
+  if (null_words) {
+    const size_t words = (size_t{s.size} + 63) / 64;
+    if (s.nulls && words) HY_HIP(hipMemcpyAsync(null_words, s.nulls, 8 * words, hipMemcpyDeviceToHost, stream));
+    else std::memset(null_words, 0, 8 * words);
+  }
+  HY_HIP(hipStreamSynchronize(stream));
+  return HY_OK;
+}
+
+uint32_t hy_column_data_type(const hy_column* column) { return column ? column->data_type : static_cast<uint32_t>(HY_TYPE_NULL); }
+
+uint32_t hy_column_chunk_rows(const hy_column* column, uint32_t chunk) {
+  return column && chunk < column->n_chunks ? column->host_segments[chunk].size : 0;
+}
+
+}  // extern "C"

@@ -92,6 +92,76 @@ def validate(mvcc, our_tid, snapshot_commit_id, can_use_chunk_shortcut=True, fla
     return result
 
 
+class ResultColumn:
+    """A device-resident column produced by an operator (hy_projection_arithmetic): usable wherever a DeviceColumn is."""
+
+    def __init__(self, handle):
+        self.lib = abi.load_library()
+        self.handle = handle
+        rows, chunks = C.c_uint64(0), C.c_uint32(0)
+        abi.check(self.lib.hy_column_row_count(handle, C.byref(rows)))
+        abi.check(self.lib.hy_column_chunk_count(handle, C.byref(chunks)))
+        self.rows, self.n_chunks = int(rows.value), int(chunks.value)
+        self.data_type = int(self.lib.hy_column_data_type(handle))
+
+    def read(self):
+        """(values, null mask) of the whole column, copied back to the host."""
+        from .storage import NP_TYPES
+        values, nulls = [], []
+        for chunk in range(self.n_chunks):
+            rows = int(self.lib.hy_column_chunk_rows(self.handle, chunk))
+            v = np.zeros(rows, dtype=NP_TYPES[self.data_type])
+            words = np.zeros((rows + 63) // 64, dtype=np.uint64)
+            abi.check(self.lib.hy_column_read_chunk(self.handle, chunk, v.ctypes.data, words.ctypes.data))
+            values.append(v)
+            nulls.append(np.unpackbits(words.view(np.uint8), bitorder="little")[:rows].astype(bool))
+        if not values:
+            return np.zeros(0, dtype=NP_TYPES[self.data_type]), np.zeros(0, dtype=bool)
+        return np.concatenate(values), np.concatenate(nulls)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hy_column_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _operand(x):
+    """DeviceColumn / ResultColumn, or a literal: (HY_TYPE_*, value) / None for a NULL literal."""
+    o = abi.Operand()
+    if hasattr(x, "handle"):
+        o.column = x.handle
+        return o
+    o.column = None
+    if x is None:
+        o.literal_type = abi.TYPE_NULL
+        return o
+    o.literal_type, value = x
+    if o.literal_type == abi.TYPE_INT:
+        o.literal.i32 = int(value)
+    elif o.literal_type == abi.TYPE_LONG:
+        o.literal.i64 = int(value)
+    elif o.literal_type == abi.TYPE_FLOAT:
+        o.literal.f32 = float(value)
+    else:
+        o.literal.f64 = float(value)
+    return o
+
+
+def projection_arithmetic(op, left, right):
+    """left <op> right (abi.ARITH_*), operands: columns or literals -> ResultColumn (stays on the device)."""
+    lib = abi.load_library()
+    handle = C.c_void_p()
+    lo, ro = _operand(left), _operand(right)
+    abi.check(lib.hy_projection_arithmetic(op, C.byref(lo), C.byref(ro), C.byref(handle)))
+    return ResultColumn(handle)
+
+
 class HostJoinResult:
     """Join result in host memory (numpy views): pairs[k] = (left RowID, right RowID), slice boundaries."""
 

@@ -226,6 +226,32 @@ hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, u
 hy_status hy_validate(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut,
                       hy_scan_result* result);
 
+/* ---- Projection arithmetic (the ArithmeticExpressions a Projection evaluates through the
+ * ExpressionEvaluator, operators/projection.cpp + expression/evaluation/expression_functors.hpp:127-213) -------------------
+ * result = left <op> right, element-wise over a table's rows; an operand is a column of the table (data or reference
+ * segments, any supported encoding) or a literal.  Same numeric order as hyrise::ArithmeticOperator
+ * (expression/arithmetic_expression.hpp).  Semantics of the reference:
+ *   result type  expression_common_type (expression_utils.cpp:172-204): Double if either is Double; Long with Float -> Double;
+ *                Long with Int -> Long; Float if either is Float; else Int
+ *   + - *        computed in std::common_type_t of the operand types, then cast to the result type; NULL if an operand is NULL
+ *   /            NULL if an operand is NULL or the divisor is 0; computed in the result type (integers truncate)
+ *   %            NULL as for /; `%` for two integral operands, std::fmod otherwise
+ * The result is a new device-resident column of unencoded value segments (result type, chunked like the column operand(s),
+ * with a null vector) that the following operator -- typically hy_aggregate_hash: Q1/Q6 never materialise the expression
+ * on the host -- takes like any other column; hy_column_read_chunk copies a chunk back.  Destroy it with hy_column_destroy. */
+enum { HY_ARITH_ADD = 0, HY_ARITH_SUB = 1, HY_ARITH_MUL = 2, HY_ARITH_DIV = 3, HY_ARITH_MOD = 4 };
+typedef struct hy_operand {
+  const hy_column* column;   /* NULL: the operand is `literal` */
+  uint32_t literal_type;     /* HY_TYPE_INT / LONG / FLOAT / DOUBLE, or HY_TYPE_NULL for a NULL literal */
+  hy_value literal;
+} hy_operand;
+hy_status hy_projection_arithmetic(uint32_t op, const hy_operand* left, const hy_operand* right, hy_column** result);
+/* Copies one chunk of an unencoded device-resident column to host memory: values[rows] of the column's type and, if
+ * null_words is not NULL, the null bitmap (bit i of word i/64; rows/64 rounded up words). */
+hy_status hy_column_read_chunk(const hy_column* column, uint32_t chunk, void* values, uint64_t* null_words);
+uint32_t hy_column_data_type(const hy_column* column);
+uint32_t hy_column_chunk_rows(const hy_column* column, uint32_t chunk);
+
 /* ---- JoinHash (replaces JoinHash::_on_execute, join_hash.cpp:116-225,270-572) ----------------------------------- */
 typedef struct hy_join_result {
   uint32_t mem;

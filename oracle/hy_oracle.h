@@ -52,6 +52,11 @@ int64_t hyo_scan_chunk_columns(const hyo_column* left, const hyo_column* right, 
 /* Whole-column driver with the ABI's result layout (host memory), single thread or `threads` pthreads over chunks
  * (JobTask fan-out, table_scan.cpp:223-229). */
 int32_t hyo_table_scan(const hyo_column* column, const hy_predicate* predicate, hy_scan_result* result, int threads);
+/* Projection arithmetic (projection.c). */
+uint32_t hyo_expression_common_type(uint32_t lhs, uint32_t rhs);
+int hyo_arithmetic_cell(uint32_t op, uint32_t a_type, const void* a, int a_null, uint32_t b_type, const void* b, int b_null, void* result);
+uint32_t hyo_arithmetic(uint32_t op, uint32_t a_type, const void* a, const uint8_t* a_nulls, uint32_t a_stride, uint32_t b_type, const void* b,
+                        const uint8_t* b_nulls, uint32_t b_stride, uint64_t n, void* result, uint8_t* result_nulls);
 /* Validate (validate.c): visible positions per input chunk, same result layout as hyo_table_scan. */
 int32_t hyo_validate(const hyo_column* column, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut,
                      hy_scan_result* result);

@@ -26,6 +26,8 @@ FILES = [
     "join_test_runner/input_table_right_10.tbl", "join_test_runner/input_table_right_15.tbl",
     # realistic inputs (join_hash_test.cpp:24-31)
     "tpch/sf-0.001/lineitem.tbl", "tpch/sf-0.001/orders.tbl",
+    # Projection arithmetic: the ExpressionEvaluator's series tests (src/test/lib/expression/expression_evaluator_to_values_test.cpp:38,244-256)
+    "expression_evaluator/input_a.tbl",
 ]
 
 

@@ -43,6 +43,11 @@ def oracle():
                                            C.c_void_p]
     lib.hyo_table_scan.restype = C.c_int32
     lib.hyo_table_scan.argtypes = [C.POINTER(OracleColumn), C.POINTER(abi.Predicate), C.POINTER(abi.ScanResult), C.c_int]
+    lib.hyo_arithmetic.restype = C.c_uint32
+    lib.hyo_arithmetic.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                   C.c_void_p, C.c_void_p]
+    lib.hyo_expression_common_type.restype = C.c_uint32
+    lib.hyo_expression_common_type.argtypes = [C.c_uint32, C.c_uint32]
     lib.hyo_validate.restype = C.c_int32
     lib.hyo_validate.argtypes = [C.POINTER(OracleColumn), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(abi.ScanResult)]
     lib.hyo_table_scan_columns.restype = C.c_int32
@@ -89,6 +94,31 @@ def oracle_validate(host_column, our_tid, snapshot_commit_id, can_use_chunk_shor
     status = oracle().hyo_validate(C.byref(col.c), our_tid, snapshot_commit_id, 1 if can_use_chunk_shortcut else 0, C.byref(result.c))
     assert status == 0, f"oracle validate failed with {status}"
     return result
+
+
+def oracle_arithmetic(op, left, right, n=None):
+    """left / right: (numpy values, bool nulls or None) for a column, (HY_TYPE_*, value) for a literal, None for a NULL
+    literal.  Returns (values, nulls) as the reference's ExpressionEvaluator produces them."""
+    def operand(x):
+        if x is None:
+            return abi.TYPE_NULL, np.zeros(1, dtype=np.int32), np.ones(1, dtype=np.uint8), 0
+        if isinstance(x[0], np.ndarray):
+            values = np.ascontiguousarray(x[0])
+            nulls = np.ascontiguousarray(x[1], dtype=np.uint8) if x[1] is not None else None
+            return storage.TYPE_OF_NP[values.dtype], values, nulls, 1
+        data_type, value = x
+        return data_type, np.array([value], dtype=storage.NP_TYPES[data_type]), None, 0
+    lt, lv, ln, ls = operand(left)
+    rt, rv, rn, rs = operand(right)
+    if n is None:
+        n = len(lv) if ls else len(rv)
+    result_type = oracle().hyo_expression_common_type(lt, rt)
+    out = np.zeros(n, dtype=storage.NP_TYPES[result_type])
+    out_nulls = np.zeros(n, dtype=np.uint8)
+    got = oracle().hyo_arithmetic(op, lt, lv.ctypes.data, ln.ctypes.data if ln is not None else None, ls, rt, rv.ctypes.data,
+                                  rn.ctypes.data if rn is not None else None, rs, n, out.ctypes.data, out_nulls.ctypes.data)
+    assert got == result_type
+    return out, out_nulls.astype(bool)
 
 
 def oracle_scan_columns(left, right, condition, threads=1):

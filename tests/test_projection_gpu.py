@@ -1,0 +1,121 @@
+"""Parity of hy_projection_arithmetic with the CPU restatement of the ExpressionEvaluator's arithmetic: bit-identical
+values (the float operations are single IEEE operations in the type the reference computes in) and NULLs, for every
+operator x operand type pair x encoding, literals on either side, reference-segment inputs; and TPC-H Q6 end to end --
+three scans, the product, the sum -- without leaving the device."""
+import numpy as np
+import pytest
+
+from hyrise_amd import abi, storage, tpch
+from hyrise_amd.operators import aggregate_hash, make_predicate, projection_arithmetic, table_scan
+from hyrise_amd.storage import DeviceColumn
+from support import build_column, load_tbl, oracle_arithmetic
+
+pytestmark = pytest.mark.gpu
+OPS = [abi.ARITH_ADD, abi.ARITH_SUB, abi.ARITH_MUL, abi.ARITH_DIV, abi.ARITH_MOD]
+NP = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}
+
+
+def assert_same(got, want, context):
+    values, nulls = got.read()
+    want_values, want_nulls = want
+    assert values.dtype == want_values.dtype, context
+    np.testing.assert_array_equal(nulls, want_nulls, err_msg=f"NULLs {context}")
+    keep = ~nulls
+    assert values[keep].tobytes() == want_values[keep].tobytes(), f"values {context}"
+    assert not values[nulls].any(), f"NULL cells hold T{{}} {context}"
+
+
+def test_reference_series_on_device(device):   # expression_evaluator_to_values_test.cpp:244-256
+    t = load_tbl("expression_evaluator/input_a.tbl")
+    cols = {name: build_column(*t.column(name), 3, abi.ENC_UNENCODED) for name in "abc"}
+    dev = {name: DeviceColumn(c) for name, c in cols.items()}
+    values, nulls = projection_arithmetic(abi.ARITH_MUL, dev["a"], dev["b"]).read()
+    assert values.tolist() == [2, 6, 12, 20] and not nulls.any()
+    values, nulls = projection_arithmetic(abi.ARITH_MOD, dev["a"], dev["c"]).read()
+    assert [None if n else v for v, n in zip(values.tolist(), nulls)] == [1, None, 3, None]
+    inner = projection_arithmetic(abi.ARITH_ADD, dev["b"], dev["c"])           # a + (b + c): a result column as an operand
+    values, nulls = projection_arithmetic(abi.ARITH_ADD, dev["a"], inner).read()
+    assert [None if n else v for v, n in zip(values.tolist(), nulls)] == [36, None, 41, None]
+    values, nulls = projection_arithmetic(abi.ARITH_ADD, dev["a"], None).read()
+    assert nulls.all()
+
+
+def test_all_type_pairs(device):
+    rng = np.random.default_rng(61)
+    n, chunk = 40_000, 9_000
+    raw = {abi.TYPE_INT: rng.integers(-50, 50, n).astype(np.int32), abi.TYPE_LONG: (rng.integers(-5, 5, n) * 3_000_000_000).astype(np.int64),
+           abi.TYPE_FLOAT: (rng.integers(-400, 400, n) / 7.0).astype(np.float32), abi.TYPE_DOUBLE: rng.normal(0, 1000, n)}
+    raw[abi.TYPE_INT][::11] = 0                      # zero divisors
+    raw[abi.TYPE_FLOAT][::13] = 0.0
+    raw[abi.TYPE_INT][5] = np.iinfo(np.int32).max    # int32 wrap-around
+    nulls = {t: (rng.random(n) < 0.1) for t in raw}
+    hosts, devs = {}, {}
+    for t, values in raw.items():
+        encoding = abi.ENC_DICTIONARY if t in (abi.TYPE_INT, abi.TYPE_FLOAT) else abi.ENC_UNENCODED
+        hosts[t] = build_column(values, nulls[t], chunk, encoding)
+        devs[t] = DeviceColumn(hosts[t])
+    literal = {abi.TYPE_INT: 3, abi.TYPE_LONG: 5_000_000_000, abi.TYPE_FLOAT: 2.5, abi.TYPE_DOUBLE: 0.1}
+    for op in OPS:
+        for lt in raw:
+            for rt in raw:
+                got = projection_arithmetic(op, devs[lt], devs[rt])
+                assert_same(got, oracle_arithmetic(op, (raw[lt], nulls[lt]), (raw[rt], nulls[rt])), f"op {op} types {lt},{rt}")
+            for rt, value in literal.items():
+                assert_same(projection_arithmetic(op, devs[lt], (rt, value)), oracle_arithmetic(op, (raw[lt], nulls[lt]), (rt, value)), f"op {op} {lt} x literal {rt}")
+                assert_same(projection_arithmetic(op, (rt, value), devs[lt]), oracle_arithmetic(op, (rt, value), (raw[lt], nulls[lt])), f"op {op} literal {rt} x {lt}")
+    # FrameOfReference input and reference segments (a scan's output, gathered)
+    for_host = build_column(raw[abi.TYPE_INT], None, chunk, abi.ENC_FRAME_OF_REFERENCE)
+    for_dev = DeviceColumn(for_host)
+    assert_same(projection_arithmetic(abi.ARITH_MUL, for_dev, devs[abi.TYPE_DOUBLE]),
+                oracle_arithmetic(abi.ARITH_MUL, (raw[abi.TYPE_INT], None), (raw[abi.TYPE_DOUBLE], nulls[abi.TYPE_DOUBLE])), "FrameOfReference x double")
+    rows = rng.integers(0, n, 12_345)
+    pos = np.stack([rows // chunk, rows % chunk], axis=1).astype(np.uint32)
+    refs = []
+    for t in (abi.TYPE_FLOAT, abi.TYPE_LONG):
+        ref_host = storage.make_reference_column(hosts[t], [pos], [None])
+        refs.append(DeviceColumn(ref_host, refs={id(hosts[t]): devs[t]}))
+    assert_same(projection_arithmetic(abi.ARITH_SUB, refs[0], refs[1]),
+                oracle_arithmetic(abi.ARITH_SUB, (raw[abi.TYPE_FLOAT][rows], nulls[abi.TYPE_FLOAT][rows]), (raw[abi.TYPE_LONG][rows], nulls[abi.TYPE_LONG][rows])),
+                "reference segments float - long")
+
+
+def test_tpch_q6_pipeline_stays_on_device(device):
+    """SELECT SUM(l_extendedprice * l_discount) FROM lineitem WHERE l_shipdate >= 1994-01-01 AND l_shipdate < 1995-01-01
+    AND l_discount BETWEEN 0.05 AND 0.07 AND l_quantity < 24 -- scans chained through reference segments (PosLists), the
+    product over the survivors, the sum: every intermediate is a device column; the check is plain numpy."""
+    data = tpch.TpchData(scale_factor=0.05, seed=7)
+    n, chunk = data.n_lineitems, 20_000
+    hosts = {"shipdate": storage.make_column(data.l_shipdate, None, abi.ENC_DICTIONARY, chunk_size=chunk),
+             "discount": storage.make_column(data.l_discount, None, abi.ENC_DICTIONARY, chunk_size=chunk),
+             "quantity": storage.make_column(data.l_quantity, None, abi.ENC_UNENCODED, chunk_size=chunk),
+             "price": storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED, chunk_size=chunk)}
+    devs = {k: DeviceColumn(v) for k, v in hosts.items()}
+
+    def pos_lists(result, previous=None):
+        """A scan's output as reference segments over the base table (one pos list per non-empty input chunk)."""
+        lists = []
+        for c in range(result.n_chunks):
+            rows = result.pos_list(c) if result.chunk_state[c] != abi.CHUNK_ALL_MATCH else None
+            if rows is None:
+                size = previous[c].shape[0] if previous is not None else hosts["shipdate"].segments[c].size
+                rows = np.stack([np.full(size, c, dtype=np.uint32), np.arange(size, dtype=np.uint32)], axis=1)
+            lists.append(previous[c][rows[:, 1]] if previous is not None else rows.astype(np.uint32))
+        return lists
+
+    def reference(name, lists):
+        host = storage.make_reference_column(hosts[name], lists, [None] * len(lists))
+        return DeviceColumn(host, refs={id(hosts[name]): devs[name]})
+
+    first = table_scan(devs["shipdate"], make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, tpch.DAY_1994_01_01, tpch.DAY_1995_01_01))
+    lists = pos_lists(first)
+    second = table_scan(reference("discount", lists), make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, np.float32(0.05), np.float32(0.07)))
+    lists = pos_lists(second, lists)
+    third = table_scan(reference("quantity", lists), make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, 24.0))
+    lists = pos_lists(third, lists)
+    revenue = projection_arithmetic(abi.ARITH_MUL, reference("price", lists), reference("discount", lists))
+    total = aggregate_hash([], [(abi.AGG_SUM, revenue), (abi.AGG_COUNT, None)], group_capacity=4)
+    keep = (data.l_shipdate >= tpch.DAY_1994_01_01) & (data.l_shipdate < tpch.DAY_1995_01_01) & (data.l_discount >= np.float32(0.05)) & \
+           (data.l_discount <= np.float32(0.07)) & (data.l_quantity < 24)
+    products = data.l_extendedprice[keep] * data.l_discount[keep]            # float32 products, like the reference
+    assert total.column(1)[0] == int(keep.sum()) > 100
+    assert abs(total.column(0)[0] - float(products.astype(np.float64).sum())) <= 1e-9 * abs(float(products.astype(np.float64).sum()))
