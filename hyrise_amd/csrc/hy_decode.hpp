@@ -52,4 +52,101 @@ __device__ inline Value column_value(const DevSegment* segments, uint32_t chunk,
   return data_value(s.ref[r.chunk_id], r.chunk_offset);
 }
 
+// ---- batched decoding: B rows of one column per call, the loads of all rows issued before any is used ----------------
+// bits[i]: the value as int64 (integer columns) or as the bits of a double (float/double columns); null bit i set for NULL.
+template <int B>
+__device__ __forceinline__ void decode_rows(const DevSegment* segments, uint32_t chunk, const uint32_t (&row)[B], uint32_t valid, uint64_t (&bits)[B], uint32_t* nulls) {
+  const DevSegment s = segments[chunk];
+  *nulls = 0;
+  if (s.encoding == HY_ENC_REFERENCE) {
+#pragma unroll 1
+    for (int i = 0; i < B; ++i) {
+      bits[i] = 0;
+      if (!((valid >> i) & 1)) continue;
+      const Value v = column_value(segments, chunk, row[i]);
+      const bool is_float = s.data_type == HY_TYPE_FLOAT || s.data_type == HY_TYPE_DOUBLE;
+      if (v.is_null) *nulls |= 1u << i;
+      else bits[i] = is_float ? static_cast<uint64_t>(__double_as_longlong(v.f)) : static_cast<uint64_t>(v.i);
+    }
+    return;
+  }
+  const void* values = s.data;
+  uint32_t index[B];
+#pragma unroll
+  for (int i = 0; i < B; ++i) index[i] = row[i];
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    if (s.width == 1) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) index[i] = static_cast<const uint8_t*>(s.data)[row[i]];
+    } else if (s.width == 2) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) index[i] = static_cast<const uint16_t*>(s.data)[row[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < B; ++i) index[i] = static_cast<const uint32_t*>(s.data)[row[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      if (index[i] >= s.aux_size) { *nulls |= 1u << i; index[i] = 0; }
+    }
+    values = s.aux;
+    if (s.aux_size == 0) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = 0;
+      return;
+    }
+  } else if (s.nulls) {
+    uint64_t word[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) word[i] = s.nulls[row[i] >> 6];
+#pragma unroll
+    for (int i = 0; i < B; ++i) *nulls |= static_cast<uint32_t>((word[i] >> (row[i] & 63)) & 1) << i;
+  }
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+    uint32_t raw[B];
+    int32_t bias[B];
+    if (s.width == 1) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) raw[i] = static_cast<const uint8_t*>(s.data)[row[i]];
+    } else if (s.width == 2) {
+#pragma unroll
+      for (int i = 0; i < B; ++i) raw[i] = static_cast<const uint16_t*>(s.data)[row[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < B; ++i) raw[i] = static_cast<const uint32_t*>(s.data)[row[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) bias[i] = static_cast<const int32_t*>(s.aux)[row[i] / HY_FOR_BLOCK_SIZE];
+#pragma unroll
+    for (int i = 0; i < B; ++i) bits[i] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(raw[i] + static_cast<uint32_t>(bias[i]))));
+    return;
+  }
+  switch (s.data_type) {
+    case HY_TYPE_INT: {
+      int32_t v[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) v[i] = static_cast<const int32_t*>(values)[index[i]];
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = static_cast<uint64_t>(static_cast<int64_t>(v[i]));
+      break;
+    }
+    case HY_TYPE_LONG:
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = static_cast<const uint64_t*>(values)[index[i]];
+      break;
+    case HY_TYPE_FLOAT: {
+      float v[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) v[i] = static_cast<const float*>(values)[index[i]];
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(v[i])));
+      break;
+    }
+    default:
+#pragma unroll
+      for (int i = 0; i < B; ++i) bits[i] = static_cast<const uint64_t*>(values)[index[i]];
+      break;
+  }
+}
+
 }  // namespace hy

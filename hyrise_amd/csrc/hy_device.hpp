@@ -81,6 +81,7 @@ struct hy_column {
   uint32_t n_parts = 0;
   uint64_t* d_row_base = nullptr;           // [n_chunks + 1] device copy of row_base
   std::vector<void*> owned;                 // device allocations freed with the column
+  std::vector<std::pair<size_t, void*>> pooled;   // ... or handed back to the buffer pool (operator results)
 };
 
 namespace hy {
@@ -134,6 +135,10 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Temporary device buffers come from a per-thread pool of power-of-two blocks that is reused across calls
 // (hipMalloc/hipFree cost ~100 us each and synchronise the device).
+// Pool of power-of-two device blocks (per thread): acquire / release without hipMalloc / hipFree in the steady state.
+hy_status pool_acquire(size_t bytes, void** ptr, size_t* capacity);
+void pool_release(void* ptr, size_t capacity);
+
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t capacity = 0;

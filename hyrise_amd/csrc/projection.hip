@@ -46,20 +46,31 @@ __device__ __forceinline__ uint32_t cxx_common_type(uint32_t a, uint32_t b) {
   return HY_TYPE_INT;
 }
 
-__device__ __forceinline__ Value operand_value(const Operand& o, uint32_t chunk, uint32_t row) {
+// B rows of an operand as (bits, NULL mask): bits = int64 value or the bits of a double (float columns widened), like
+// decode_rows; a literal is broadcast.
+template <int B>
+__device__ __forceinline__ void operand_rows(const Operand& o, uint32_t chunk, const uint32_t (&row)[B], uint32_t valid, uint64_t (&bits)[B], uint32_t* nulls) {
   if (o.segments) {
-    Value v = column_value(o.segments, chunk, row);
-    if (o.type == HY_TYPE_FLOAT) v.f = static_cast<double>(static_cast<float>(v.f));
-    return v;
+    decode_rows<B>(o.segments, chunk, row, valid, bits, nulls);
+    return;
   }
-  Value v{o.type == HY_TYPE_NULL, 0, 0.0};
+  uint64_t literal = 0;
   switch (o.type) {
-    case HY_TYPE_INT: v.i = o.literal.i32; break;
-    case HY_TYPE_LONG: v.i = o.literal.i64; break;
-    case HY_TYPE_FLOAT: v.f = static_cast<double>(o.literal.f32); break;
-    case HY_TYPE_DOUBLE: v.f = o.literal.f64; break;
+    case HY_TYPE_INT: literal = static_cast<uint64_t>(static_cast<int64_t>(o.literal.i32)); break;
+    case HY_TYPE_LONG: literal = static_cast<uint64_t>(o.literal.i64); break;
+    case HY_TYPE_FLOAT: literal = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(o.literal.f32))); break;
+    case HY_TYPE_DOUBLE: literal = static_cast<uint64_t>(__double_as_longlong(o.literal.f64)); break;
     default: break;
   }
+#pragma unroll
+  for (int i = 0; i < B; ++i) bits[i] = literal;
+  *nulls = o.type == HY_TYPE_NULL ? 0xFFFFFFFFu : 0u;
+}
+
+__device__ __forceinline__ Value as_value(uint64_t bits, uint32_t type) {
+  Value v{false, 0, 0.0};
+  if (is_float_type(type)) v.f = __longlong_as_double(static_cast<long long>(bits));
+  else v.i = static_cast<int64_t>(bits);
   return v;
 }
 
@@ -78,79 +89,95 @@ __device__ __forceinline__ Value convert(const Value& v, uint32_t from, uint32_t
   return out;
 }
 
+// one cell: returns true if the result is NULL (division / modulo by zero)
+__device__ __forceinline__ bool arithmetic_cell(uint32_t op, uint32_t at, uint32_t bt, uint32_t rt, const Value& x, const Value& y, Value* out) {
+  Value result{false, 0, 0.0};
+  if (op == HY_ARITH_DIV || op == HY_ARITH_MOD) {
+    if (is_float_type(bt) ? y.f == 0.0 : y.i == 0) return true;   // expression_functors.hpp:174,205
+  }
+  if (op == HY_ARITH_DIV) {          // computed in the result type
+    const Value p = convert(x, at, rt), q = convert(y, bt, rt);
+    if (rt == HY_TYPE_DOUBLE) result.f = p.f / q.f;
+    else if (rt == HY_TYPE_FLOAT) result.f = static_cast<double>(static_cast<float>(p.f) / static_cast<float>(q.f));
+    else if (rt == HY_TYPE_INT) result.i = q.i == -1 ? static_cast<int64_t>(static_cast<int32_t>(0u - static_cast<uint32_t>(p.i)))
+                                                     : static_cast<int64_t>(static_cast<int32_t>(p.i) / static_cast<int32_t>(q.i));
+    else result.i = q.i == -1 ? static_cast<int64_t>(0ull - static_cast<uint64_t>(p.i)) : p.i / q.i;
+  } else if (op == HY_ARITH_MOD) {
+    uint32_t computed = rt;
+    if (!is_float_type(at) && !is_float_type(bt)) {
+      computed = cxx_common_type(at, bt);
+      result.i = y.i == -1 ? 0 : (computed == HY_TYPE_INT ? static_cast<int64_t>(static_cast<int32_t>(x.i) % static_cast<int32_t>(y.i)) : x.i % y.i);
+    } else if (at == HY_TYPE_FLOAT && bt == HY_TYPE_FLOAT) {
+      computed = HY_TYPE_FLOAT;
+      result.f = static_cast<double>(fmodf(static_cast<float>(x.f), static_cast<float>(y.f)));
+    } else {   // std::fmod with an integral or double argument: in double
+      computed = HY_TYPE_DOUBLE;
+      result.f = fmod(is_float_type(at) ? x.f : static_cast<double>(x.i), is_float_type(bt) ? y.f : static_cast<double>(y.i));
+    }
+    result = convert(result, computed, rt);
+  } else {                              // + - * : computed in the common C++ type, cast to the result type
+    const uint32_t c = cxx_common_type(at, bt);
+    const Value p = convert(x, at, c), q = convert(y, bt, c);
+    if (c == HY_TYPE_DOUBLE) {
+      result.f = op == HY_ARITH_ADD ? __dadd_rn(p.f, q.f) : op == HY_ARITH_SUB ? __dsub_rn(p.f, q.f) : __dmul_rn(p.f, q.f);
+    } else if (c == HY_TYPE_FLOAT) {
+      const float pf = static_cast<float>(p.f), qf = static_cast<float>(q.f);
+      // single IEEE operations: the compiler must not contract them with neighbouring operations
+      const float rf = op == HY_ARITH_ADD ? __fadd_rn(pf, qf) : op == HY_ARITH_SUB ? __fsub_rn(pf, qf) : __fmul_rn(pf, qf);
+      result.f = static_cast<double>(rf);
+    } else if (c == HY_TYPE_LONG) {
+      const uint64_t pu = static_cast<uint64_t>(p.i), qu = static_cast<uint64_t>(q.i);
+      result.i = static_cast<int64_t>(op == HY_ARITH_ADD ? pu + qu : op == HY_ARITH_SUB ? pu - qu : pu * qu);
+    } else {
+      const uint32_t pu = static_cast<uint32_t>(p.i), qu = static_cast<uint32_t>(q.i);
+      result.i = static_cast<int64_t>(static_cast<int32_t>(op == HY_ARITH_ADD ? pu + qu : op == HY_ARITH_SUB ? pu - qu : pu * qu));
+    }
+    result = convert(result, c, rt);
+  }
+  *out = result;
+  return false;
+}
+
+// One workgroup per 8192-row slice; a thread owns rows k*256 + tid (k = 0..31), decoded eight at a time (the loads of both
+// operands first).  Row r of a wave's round lands in bit (r % 64) of one bitmap word: the null words are one ballot each.
 __global__ __launch_bounds__(256) void projection_rows(ProjectionArgs a) {
   const Slice slice = a.slices[blockIdx.x];
   const uint32_t lane = threadIdx.x & 63;
   char* values = static_cast<char*>(a.values) + a.value_base[slice.chunk];
   uint64_t* nulls = a.nulls + a.null_base[slice.chunk];
-  const uint32_t width = (a.result_type == HY_TYPE_INT || a.result_type == HY_TYPE_FLOAT) ? 4 : 8;
-  for (uint32_t k = 0; k < SLICE_ROWS / 256; ++k) {
-    const uint32_t r = k * 256 + threadIdx.x;
-    const bool in = r < slice.row_count;
-    const uint32_t row = slice.row_begin + r;
-    bool is_null = false;
-    Value result{false, 0, 0.0};
-    if (in) {
-      const Value x = operand_value(a.left, slice.chunk, row), y = operand_value(a.right, slice.chunk, row);
-      is_null = x.is_null || y.is_null;
-      if (!is_null) {
-        const uint32_t at = a.left.type, bt = a.right.type, rt = a.result_type;
-        if (a.op == HY_ARITH_DIV || a.op == HY_ARITH_MOD) {
-          is_null = is_float_type(bt) ? y.f == 0.0 : y.i == 0;   // division by zero is NULL (expression_functors.hpp:174,205)
-        }
-        if (!is_null) {
-          if (a.op == HY_ARITH_DIV) {          // computed in the result type
-            const Value p = convert(x, at, rt), q = convert(y, bt, rt);
-            if (rt == HY_TYPE_DOUBLE) result.f = p.f / q.f;
-            else if (rt == HY_TYPE_FLOAT) result.f = static_cast<double>(static_cast<float>(p.f) / static_cast<float>(q.f));
-            else if (rt == HY_TYPE_INT) result.i = q.i == -1 ? static_cast<int64_t>(static_cast<int32_t>(0u - static_cast<uint32_t>(p.i)))
-                                                             : static_cast<int64_t>(static_cast<int32_t>(p.i) / static_cast<int32_t>(q.i));
-            else result.i = q.i == -1 ? static_cast<int64_t>(0ull - static_cast<uint64_t>(p.i)) : p.i / q.i;
-          } else if (a.op == HY_ARITH_MOD) {
-            uint32_t computed = rt;
-            if (!is_float_type(at) && !is_float_type(bt)) {
-              computed = cxx_common_type(at, bt);
-              result.i = y.i == -1 ? 0 : (computed == HY_TYPE_INT ? static_cast<int64_t>(static_cast<int32_t>(x.i) % static_cast<int32_t>(y.i)) : x.i % y.i);
-            } else if (at == HY_TYPE_FLOAT && bt == HY_TYPE_FLOAT) {
-              computed = HY_TYPE_FLOAT;
-              result.f = static_cast<double>(fmodf(static_cast<float>(x.f), static_cast<float>(y.f)));
-            } else {   // std::fmod with an integral or double argument: in double
-              computed = HY_TYPE_DOUBLE;
-              result.f = fmod(is_float_type(at) ? x.f : static_cast<double>(x.i), is_float_type(bt) ? y.f : static_cast<double>(y.i));
-            }
-            result = convert(result, computed, rt);
-          } else {                              // + - * : computed in the common C++ type, cast to the result type
-            const uint32_t c = cxx_common_type(at, bt);
-            const Value p = convert(x, at, c), q = convert(y, bt, c);
-            if (c == HY_TYPE_DOUBLE) {
-              result.f = a.op == HY_ARITH_ADD ? p.f + q.f : a.op == HY_ARITH_SUB ? p.f - q.f : p.f * q.f;
-            } else if (c == HY_TYPE_FLOAT) {
-              const float pf = static_cast<float>(p.f), qf = static_cast<float>(q.f);
-              // separate statements: the compiler must not contract a float multiply-add across the two roundings
-              const float rf = a.op == HY_ARITH_ADD ? __fadd_rn(pf, qf) : a.op == HY_ARITH_SUB ? __fsub_rn(pf, qf) : __fmul_rn(pf, qf);
-              result.f = static_cast<double>(rf);
-            } else if (c == HY_TYPE_LONG) {
-              const uint64_t pu = static_cast<uint64_t>(p.i), qu = static_cast<uint64_t>(q.i);
-              result.i = static_cast<int64_t>(a.op == HY_ARITH_ADD ? pu + qu : a.op == HY_ARITH_SUB ? pu - qu : pu * qu);
-            } else {
-              const uint32_t pu = static_cast<uint32_t>(p.i), qu = static_cast<uint32_t>(q.i);
-              result.i = static_cast<int64_t>(static_cast<int32_t>(a.op == HY_ARITH_ADD ? pu + qu : a.op == HY_ARITH_SUB ? pu - qu : pu * qu));
-            }
-            result = convert(result, c, rt);
-          }
-        }
-      }
-      // NULL cells hold T{} (value_segment.hpp)
-      switch (a.result_type) {
-        case HY_TYPE_INT: reinterpret_cast<int32_t*>(values)[row] = is_null ? 0 : static_cast<int32_t>(result.i); break;
-        case HY_TYPE_LONG: reinterpret_cast<int64_t*>(values)[row] = is_null ? 0 : result.i; break;
-        case HY_TYPE_FLOAT: reinterpret_cast<float*>(values)[row] = is_null ? 0.f : static_cast<float>(result.f); break;
-        default: reinterpret_cast<double*>(values)[row] = is_null ? 0.0 : result.f; break;
-      }
+  const uint32_t at = a.left.type, bt = a.right.type, rt = a.result_type;
+  constexpr int B = 8;
+#pragma unroll 1
+  for (uint32_t block = 0; block < SLICE_ROWS / 256 / B; ++block) {
+    uint32_t row[B], valid = 0;
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const uint32_t r = (block * B + i) * 256 + threadIdx.x;
+      if (r < slice.row_count) valid |= 1u << i;
+      row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
     }
-    (void)width;
-    const uint64_t null_lanes = __ballot(in && is_null);   // 64 consecutive rows = one bitmap word (slices start at multiples of 8192)
-    if (lane == 0 && r < ((slice.row_count + 63) & ~63u)) nulls[row >> 6] = null_lanes;
+    uint64_t x[B], y[B];
+    uint32_t x_nulls, y_nulls;
+    operand_rows<B>(a.left, slice.chunk, row, valid, x, &x_nulls);
+    operand_rows<B>(a.right, slice.chunk, row, valid, y, &y_nulls);
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const bool in = (valid >> i) & 1;
+      bool is_null = ((x_nulls | y_nulls) >> i) & 1;
+      Value result{false, 0, 0.0};
+      if (in && !is_null) is_null = arithmetic_cell(a.op, at, bt, rt, as_value(x[i], at), as_value(y[i], bt), &result);
+      if (in) {   // NULL cells hold T{} (value_segment.hpp)
+        switch (rt) {
+          case HY_TYPE_INT: reinterpret_cast<int32_t*>(values)[row[i]] = is_null ? 0 : static_cast<int32_t>(result.i); break;
+          case HY_TYPE_LONG: reinterpret_cast<int64_t*>(values)[row[i]] = is_null ? 0 : result.i; break;
+          case HY_TYPE_FLOAT: reinterpret_cast<float*>(values)[row[i]] = is_null ? 0.f : static_cast<float>(result.f); break;
+          default: reinterpret_cast<double*>(values)[row[i]] = is_null ? 0.0 : result.f; break;
+        }
+      }
+      const uint32_t r = (block * B + i) * 256 + threadIdx.x;
+      const uint64_t null_lanes = __ballot(in && is_null);   // slices start at multiples of 8192: 64 consecutive rows = one word
+      if (lane == 0 && r < ((slice.row_count + 63) & ~63u)) nulls[(slice.row_begin + r) >> 6] = null_lanes;
+    }
   }
 }
 
@@ -208,11 +235,12 @@ hy_status hy_projection_arithmetic(uint32_t op, const hy_operand* left, const hy
   const uint64_t values_bytes = value_base[n_chunks], null_words = null_base[n_chunks];
   const uint64_t tables_bytes = 16 * (uint64_t{n_chunks} + 1);
   char* arena = nullptr;
-  HY_HIP(hipMalloc(reinterpret_cast<void**>(&arena), values_bytes + 8 * null_words + tables_bytes + 256));
+  size_t arena_capacity = 0;
+  HY_TRY(pool_acquire(values_bytes + 8 * null_words + tables_bytes + 256, reinterpret_cast<void**>(&arena), &arena_capacity));
   uint64_t* d_nulls = reinterpret_cast<uint64_t*>(arena + values_bytes);
   uint64_t* d_value_base = reinterpret_cast<uint64_t*>(arena + values_bytes + 8 * null_words);
   uint64_t* d_null_base = d_value_base + n_chunks + 1;
-  auto release = [&](hy_status status) { (void)hipFree(arena); return status; };
+  auto release = [&](hy_status status) { pool_release(arena, arena_capacity); return status; };
   if (hipMemcpyAsync(d_value_base, value_base.data(), 8 * (size_t{n_chunks} + 1), hipMemcpyHostToDevice, stream) != hipSuccess ||
       hipMemcpyAsync(d_null_base, null_base.data(), 8 * (size_t{n_chunks} + 1), hipMemcpyHostToDevice, stream) != hipSuccess) {
     return release(fail(HY_ERR_DEVICE, "projection: upload of the chunk tables failed"));
@@ -251,7 +279,7 @@ hy_status hy_projection_arithmetic(uint32_t op, const hy_operand* left, const hy
   hy_column* column = nullptr;
   const hy_status status = hy_column_create(segments.data(), n_chunks, HY_MEM_DEVICE, &column);
   if (status != HY_OK) return release(status);
-  column->owned.push_back(arena);
+  column->pooled.emplace_back(arena_capacity, arena);
   *out = column;
   return HY_OK;
 }

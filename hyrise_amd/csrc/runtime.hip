@@ -79,29 +79,35 @@ struct BufferPool {
 };
 static thread_local BufferPool t_pool;
 
-hy_status DeviceBuffer::alloc(size_t bytes) {
+hy_status pool_acquire(size_t bytes, void** ptr, size_t* capacity) {
   size_t rounded = 4096;
   while (rounded < bytes) rounded <<= 1;
   for (size_t i = 0; i < t_pool.free_blocks.size(); ++i) {
     if (t_pool.free_blocks[i].first == rounded) {
-      ptr = t_pool.free_blocks[i].second;
-      capacity = rounded;
+      *ptr = t_pool.free_blocks[i].second;
+      *capacity = rounded;
       t_pool.free_blocks.erase(t_pool.free_blocks.begin() + i);
       return HY_OK;
     }
   }
-  hipError_t err = hipMalloc(&ptr, rounded);
+  hipError_t err = hipMalloc(ptr, rounded);
   if (err != hipSuccess) {   // release the pool and retry once
     for (auto& b : t_pool.free_blocks) (void)hipFree(b.second);
     t_pool.free_blocks.clear();
-    err = hipMalloc(&ptr, rounded);
+    err = hipMalloc(ptr, rounded);
   }
-  if (err != hipSuccess) { ptr = nullptr; return fail(HY_ERR_DEVICE, "hipMalloc(%zu) failed: %s", rounded, hipGetErrorString(err)); }
-  capacity = rounded;
+  if (err != hipSuccess) { *ptr = nullptr; return fail(HY_ERR_DEVICE, "hipMalloc(%zu) failed: %s", rounded, hipGetErrorString(err)); }
+  *capacity = rounded;
   return HY_OK;
 }
 
-DeviceBuffer::~DeviceBuffer() { if (ptr) t_pool.free_blocks.emplace_back(capacity, ptr); }
+void pool_release(void* ptr, size_t capacity) {
+  if (ptr) t_pool.free_blocks.emplace_back(capacity, ptr);
+}
+
+hy_status DeviceBuffer::alloc(size_t bytes) { return pool_acquire(bytes, &ptr, &capacity); }
+
+DeviceBuffer::~DeviceBuffer() { pool_release(ptr, capacity); }
 
 Scratch& scratch() { return t_scratch; }
 
@@ -501,6 +507,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
 hy_status hy_column_destroy(hy_column* column) {
   if (!column) return HY_OK;
   for (void* p : column->owned) (void)hipFree(p);
+  for (auto& block : column->pooled) pool_release(block.second, block.first);
   if (column->d_segments) (void)hipFree(column->d_segments);
   if (column->d_slices) (void)hipFree(column->d_slices);
   if (column->d_parts) (void)hipFree(column->d_parts);
