@@ -48,7 +48,7 @@ class Value(C.Union):
 class Predicate(C.Structure):
     _fields_ = [("condition", C.c_uint32), ("value_type", C.c_uint32), ("value", Value), ("value2", Value),
                 ("per_chunk_lower", C.c_void_p), ("per_chunk_upper", C.c_void_p), ("per_chunk_found", C.c_void_p),
-                ("column_is_nullable", C.c_uint32), ("reserved", C.c_uint32)]
+                ("column_is_nullable", C.c_uint32), ("reserved", C.c_uint32), ("match_words", C.c_void_p), ("match_word_offsets", C.c_void_p)]
 
 
 class ScanResult(C.Structure):

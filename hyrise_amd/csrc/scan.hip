@@ -32,7 +32,8 @@ namespace hy {
 // ---- per-chunk normalised predicate ---------------------------------------------------------------------------------
 enum : uint32_t { JOB_SCAN = 0, JOB_ALL = 1, JOB_NONE = 2 };
 enum : uint32_t { KIND_U32 = 0, KIND_I64 = 1, KIND_F32 = 2, KIND_F64 = 3, KIND_NULLTEST = 4,
-                  KIND_VISIBLE = 5 /* Validate: lo = snapshot commit id, span = our transaction id */ };
+                  KIND_VISIBLE = 5 /* Validate: lo = snapshot commit id, span = our transaction id */,
+                  KIND_VALUE_ID_SET = 6 /* LIKE family on dictionaries: lo = device address of the chunk's match bitmap */ };
 enum : uint32_t { JF_INVERT = 1, JF_LOWER_INCL = 2, JF_UPPER_INCL = 4, JF_NEVER = 8 };
 
 struct ScanJob {
@@ -52,6 +53,8 @@ struct PredicateArgs {
   const uint32_t* per_chunk_lower;
   const uint32_t* per_chunk_upper;
   const uint8_t* per_chunk_found;
+  const uint64_t* match_words;          // LIKE family: per data chunk a bitmap over the dictionary's value ids
+  const uint64_t* match_word_offsets;
   uint32_t column_is_nullable;
   uint32_t materialize_all;
 };
@@ -151,6 +154,17 @@ __device__ __forceinline__ void finish_job(const DevSegment& s, uint32_t c, cons
   job.lo = 0;
   job.span = 0;
   const uint32_t cond = p.condition;
+
+  if (cond >= HY_PRED_LIKE && cond <= HY_PRED_NOT_LIKE_INSENSITIVE) {   // column_like_table_scan_impl.cpp:69-121
+    const uint64_t* bitmap = p.match_words + p.match_word_offsets[c];
+    uint32_t matching = 0;
+    for (uint32_t w = 0; w < (s.aux_size + 63) / 64; ++w) matching += __popcll(bitmap[w]);
+    job.kind = KIND_VALUE_ID_SET;
+    job.null_vid = s.aux_size;
+    job.lo = reinterpret_cast<uint64_t>(bitmap);
+    if (matching == 0) job.mode = JOB_NONE;   // "LIKE matches no rows"; "matches all rows" still tests every row for NULL
+    return;
+  }
 
   if (cond == HY_PRED_IS_NULL || cond == HY_PRED_IS_NOT_NULL) {
     const bool is_null = cond == HY_PRED_IS_NULL;
@@ -380,6 +394,9 @@ __device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) 
   const bool invert = job.flags & JF_INVERT;
   if (s.encoding == HY_ENC_DICTIONARY) {
     const uint32_t vid = load_compressed(s.data, s.width, row);
+    if (job.kind == KIND_VALUE_ID_SET) {
+      return vid < job.null_vid && ((reinterpret_cast<const uint64_t*>(job.lo)[vid >> 6] >> (vid & 63)) & 1) != 0;
+    }
     const bool in = (vid - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
     return (in != invert) && vid != job.null_vid;   // null_vid is 0xFFFFFFFF for the NULL test itself
   }
@@ -449,6 +466,19 @@ __device__ __forceinline__ uint32_t eval8(const DevSegment& s, const ScanJob& jo
     return bits;
   }
   const uint32_t inv = (job.flags & JF_INVERT) ? 0xFFu : 0u;
+  if (s.encoding == HY_ENC_DICTIONARY && job.kind == KIND_VALUE_ID_SET) {
+    uint32_t x[8], bits = 0;
+    if (s.width == 2) load8<2>(s.data, row0, x);
+    else if (s.width == 1) load8<1>(s.data, row0, x);
+    else load8<4>(s.data, row0, x);
+    const uint64_t* bitmap = reinterpret_cast<const uint64_t*>(job.lo);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t vid = x[j] < job.null_vid ? x[j] : 0;   // the NULL id has no bit
+      bits |= ((x[j] < job.null_vid && ((bitmap[vid >> 6] >> (vid & 63)) & 1)) ? 1u : 0u) << j;
+    }
+    return bits;
+  }
   if (s.encoding == HY_ENC_DICTIONARY) {
     uint32_t bits, nullbits = 0;
     uint32_t x[8];
@@ -1213,8 +1243,16 @@ static uint32_t scan_grid(ScanKernel kernel, uint32_t n_parts) {
 static hy_status validate_predicate(const hy_column* column, const hy_predicate* p) {
   const uint32_t c = p->condition;
   const bool null_test = c == HY_PRED_IS_NULL || c == HY_PRED_IS_NOT_NULL;
-  if (!(c <= HY_PRED_BETWEEN_EXCLUSIVE || null_test)) return fail(HY_ERR_UNSUPPORTED, "predicate condition %u stays on the CPU path (Like/In/ExpressionEvaluator)", c);
+  const bool like = c >= HY_PRED_LIKE && c <= HY_PRED_NOT_LIKE_INSENSITIVE;
+  if (!(c <= HY_PRED_BETWEEN_EXCLUSIVE || null_test || like)) return fail(HY_ERR_UNSUPPORTED, "predicate condition %u stays on the CPU path (In / ExpressionEvaluator)", c);
   const hy_column* data_column = column->is_reference ? column->ref : column;
+  if (like) {
+    if (!p->match_words || !p->match_word_offsets) return fail(HY_ERR_INVALID, "LIKE scans need the per-chunk dictionary match bitmaps (hy_predicate.match_words)");
+    for (uint32_t chunk = 0; data_column && chunk < data_column->n_chunks; ++chunk) {
+      if (data_column->host_segments[chunk].encoding != HY_ENC_DICTIONARY) return fail(HY_ERR_UNSUPPORTED, "LIKE on unencoded string segments stays on the CPU path");
+    }
+    return HY_OK;
+  }
   if (!null_test) {
     if (data_column && data_column->has_dictionary_without_values) {
       if (!p->per_chunk_lower || !p->per_chunk_upper) return fail(HY_ERR_INVALID, "string dictionary scan needs per-chunk value ids (hy_predicate.per_chunk_lower/upper)");
@@ -1249,6 +1287,8 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
 
   // Scratch: jobs | per_chunk arrays | excluded | overflow flag | (host results) regions + dense copy + per-chunk arrays
   size_t need = sizeof(ScanJob) * (n_data_chunks + 1) + 3 * 4 * (size_t{n_data_chunks} + 64) + 4 * (size_t{n_excluded} + 64) + 1024;
+  const bool like = predicate && predicate->condition >= HY_PRED_LIKE && predicate->condition <= HY_PRED_NOT_LIKE_INSENSITIVE;
+  if (like) need += 8 * (size_t{n_data_chunks} + 2) + 8 * (predicate->match_word_offsets[n_data_chunks] + 2) + 1024;
   if (column->multi_chunk_reference) need += sizeof(hy_row_id) * (column->rows + 1) + 256;
   if (host_result) need += 2 * sizeof(hy_row_id) * (column->rows + 1) + 3 * 8 * (size_t{n_chunks} + 2) + 4 * (size_t{n_chunks} + 1) + n_chunks + 8192;
   HY_TRY(sc.reserve(need + 16 * 256));
@@ -1258,6 +1298,7 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   if (!right && column->stream_width == 1) kernel = scan_slices<1>;
   else if (!right && column->stream_width == 2) kernel = scan_slices<2>;
   else if (!right && column->stream_width == 4) kernel = scan_slices<4>;
+  if (like) kernel = scan_slices<0>;   // value-id sets are tested by the generic instantiation
 
   PredicateArgs pa;
   std::memset(&pa, 0, sizeof(pa));
@@ -1284,6 +1325,11 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     HY_TRY(stage(predicate->per_chunk_lower, 4 * size_t{n_data_chunks}, &d)); pa.per_chunk_lower = static_cast<const uint32_t*>(d);
     HY_TRY(stage(predicate->per_chunk_upper, 4 * size_t{n_data_chunks}, &d)); pa.per_chunk_upper = static_cast<const uint32_t*>(d);
     HY_TRY(stage(predicate->per_chunk_found, size_t{n_data_chunks}, &d)); pa.per_chunk_found = static_cast<const uint8_t*>(d);
+    if (predicate->match_words && predicate->match_word_offsets) {
+      const uint64_t total_words = predicate->match_word_offsets[n_data_chunks];
+      HY_TRY(stage(predicate->match_word_offsets, 8 * (size_t{n_data_chunks} + 1), &d)); pa.match_word_offsets = static_cast<const uint64_t*>(d);
+      HY_TRY(stage(predicate->match_words, 8 * (total_words ? total_words : 1), &d)); pa.match_words = static_cast<const uint64_t*>(d);
+    }
     if (n_data_chunks) {
       hipLaunchKernelGGL(prepare_jobs, dim3(n_data_chunks), dim3(256), 0, stream, data_column->d_segments, n_data_chunks, pa, d_jobs, d_overflow);
     }

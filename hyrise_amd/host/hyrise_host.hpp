@@ -641,6 +641,42 @@ inline bool is_between(PredicateCondition c) { return c >= PredicateCondition::B
 
 // TableScan over `column <condition> value [AND value2]` / `column IS [NOT] NULL` / `column <condition> column2`
 // (the shapes create_impl maps to ColumnVsValue / ColumnBetween / ColumnIsNull / ColumnVsColumn, table_scan.cpp:312-452).
+// LikeMatcher (expression/evaluation/like_matcher.hpp): `%` any run of chars, `_` one char, the rest literal; the
+// *Insensitive conditions lower-case pattern and input.  Iterative two-pointer match instead of the reference's
+// token/regex variants -- same language, no std::regex.
+class LikeMatcher {
+ public:
+  LikeMatcher(std::string pattern, PredicateCondition condition) : _pattern(std::move(pattern)) {
+    Assert(condition == PredicateCondition::Like || condition == PredicateCondition::NotLike || condition == PredicateCondition::LikeInsensitive ||
+               condition == PredicateCondition::NotLikeInsensitive, "Expected PredicateCondition (Not)Like or (Not)LikeInsensitive.");
+    _insensitive = condition == PredicateCondition::LikeInsensitive || condition == PredicateCondition::NotLikeInsensitive;
+    _negated = condition == PredicateCondition::NotLike || condition == PredicateCondition::NotLikeInsensitive;
+    if (_insensitive) to_lower(_pattern);
+  }
+  bool operator()(const std::string& input) const {
+    if (!_insensitive) return matches(input) != _negated;
+    auto lowered = input;
+    to_lower(lowered);
+    return matches(lowered) != _negated;
+  }
+
+ private:
+  static void to_lower(std::string& s) { for (auto& c : s) if (c >= 'A' && c <= 'Z') c = static_cast<char>(c - 'A' + 'a'); }
+  bool matches(const std::string& text) const {
+    size_t t = 0, p = 0, star = std::string::npos, resume = 0;
+    while (t < text.size()) {
+      if (p < _pattern.size() && _pattern[p] == '%') { star = p++; resume = t; }
+      else if (p < _pattern.size() && (_pattern[p] == '_' || _pattern[p] == text[t])) { ++p; ++t; }
+      else if (star != std::string::npos) { p = star + 1; t = ++resume; }
+      else return false;
+    }
+    while (p < _pattern.size() && _pattern[p] == '%') ++p;
+    return p == _pattern.size();
+  }
+  std::string _pattern;
+  bool _insensitive = false, _negated = false;
+};
+
 class TableScan : public AbstractReadOnlyOperator {
  public:
   TableScan(std::shared_ptr<const AbstractOperator> in, ColumnID column_id, PredicateCondition condition, AllTypeVariant value = NullValue{},
@@ -677,7 +713,15 @@ class TableScan : public AbstractReadOnlyOperator {
       const bool null_test = _condition == PredicateCondition::IsNull || _condition == PredicateCondition::IsNotNull;
       std::vector<uint32_t> lower, upper;
       std::vector<uint8_t> found;
-      if (!null_test) {
+      const bool like = _condition == PredicateCondition::Like || _condition == PredicateCondition::NotLike ||
+                        _condition == PredicateCondition::LikeInsensitive || _condition == PredicateCondition::NotLikeInsensitive;
+      std::vector<uint64_t> match_words, match_word_offsets;
+      if (like) {
+        // ColumnLikeTableScanImpl (column_like_table_scan_impl.cpp:28-36)
+        Assert(in_table->column_data_type(_column_id) == DataType::String, "LIKE operator only applicable on string columns.");
+        Assert(std::holds_alternative<std::string>(_value), "Right parameter must be a string.");
+        find_matches_in_dictionaries(in_table, match_words, match_word_offsets, predicate);
+      } else if (!null_test) {
         // ColumnVsValueTableScanImpl asserts matching types (column_vs_value_table_scan_impl.cpp:34-36)
         Assert(data_type_from_all_type_variant(_value) == in_table->column_data_type(_column_id), "Cannot scan: column and value data type do not match.");
         predicate.value_type = static_cast<uint32_t>(data_type_from_all_type_variant(_value));
@@ -761,6 +805,34 @@ class TableScan : public AbstractReadOnlyOperator {
     predicate.per_chunk_lower = lower.data();
     predicate.per_chunk_upper = upper.data();
     predicate.per_chunk_found = found.data();
+  }
+
+  // _find_matches_in_dictionary per data chunk (column_like_table_scan_impl.cpp:142-159): bit i of chunk c's words says
+  // whether dictionary entry i satisfies the (possibly negated) pattern; the device tests value ids against it.
+  void find_matches_in_dictionaries(const std::shared_ptr<const Table>& in_table, std::vector<uint64_t>& words, std::vector<uint64_t>& word_offsets,
+                                    hy_predicate& predicate) const {
+    auto data_table = in_table;
+    auto column_id = _column_id;
+    if (in_table->type() == TableType::References && in_table->chunk_count()) {
+      const auto ref = std::static_pointer_cast<ReferenceSegment>(in_table->get_chunk(0)->get_segment(_column_id));
+      data_table = ref->referenced_table();
+      column_id = ref->referenced_column_id();
+    }
+    const LikeMatcher matcher(std::get<std::string>(_value), _condition);
+    word_offsets.push_back(0);
+    for (ChunkID c = 0; c < data_table->chunk_count(); ++c) {
+      const auto* dict = dynamic_cast<const DictionarySegment<std::string>*>(data_table->get_chunk(c)->get_segment(column_id).get());
+      Assert(dict, "unencoded string segments stay on the CPU path");
+      const auto& dictionary = dict->dictionary();
+      const size_t base = words.size();
+      words.resize(base + (dictionary.size() + 63) / 64, 0);
+      for (size_t i = 0; i < dictionary.size(); ++i) if (matcher(dictionary[i])) words[base + i / 64] |= uint64_t{1} << (i % 64);
+      word_offsets.push_back(words.size());
+    }
+    if (words.empty()) words.push_back(0);
+    predicate.value_type = HY_TYPE_STRING;
+    predicate.match_words = words.data();
+    predicate.match_word_offsets = word_offsets.data();
   }
 
   ColumnID _column_id;

@@ -8,7 +8,9 @@ from . import abi
 
 
 def make_predicate(condition, data_type=abi.TYPE_INT, value=None, value2=None, nullable=False, per_chunk_lower=None,
-                   per_chunk_upper=None, per_chunk_found=None):
+                   per_chunk_upper=None, per_chunk_found=None, dictionary_matches=None):
+    """dictionary_matches (LIKE family): per data chunk a bool array over the chunk's dictionary -- what
+    ColumnLikeTableScanImpl::_find_matches_in_dictionary computes."""
     p = abi.Predicate()
     p.condition = condition
     p.value_type = data_type
@@ -32,6 +34,19 @@ def make_predicate(condition, data_type=abi.TYPE_INT, value=None, value2=None, n
             arr = np.ascontiguousarray(arr, dtype=dt)
             keep.append(arr)
             setattr(p, name, arr.ctypes.data)
+    if dictionary_matches is not None:
+        words, offsets = [], [0]
+        for matches in dictionary_matches:
+            bits = np.zeros(((len(matches) + 63) // 64) * 64, dtype=np.uint8)
+            bits[:len(matches)] = np.asarray(matches, dtype=bool)
+            words.append(np.packbits(bits, bitorder="little").view(np.uint64))
+            offsets.append(offsets[-1] + len(words[-1]))
+        flat = np.ascontiguousarray(np.concatenate(words) if words else np.zeros(0, dtype=np.uint64))
+        if len(flat) == 0:
+            flat = np.zeros(1, dtype=np.uint64)
+        starts = np.array(offsets, dtype=np.uint64)
+        keep += [flat, starts]
+        p.match_words, p.match_word_offsets = flat.ctypes.data, starts.ctypes.data
     p._keepalive = keep
     return p
 

@@ -94,6 +94,21 @@ def encode_segment(values, nulls, encoding, data_type=None):
     raise ValueError(f"encoding {encoding}")
 
 
+def encode_string_dictionary(values, nulls=None):
+    """DictionarySegment<pmr_string> of one chunk: the attribute vector goes to the device, the (byte-wise sorted,
+    distinct) dictionary stays with the host, which resolves literals and LIKE patterns against it per chunk
+    (dictionary_encoder.hpp:44-98).  Returns (HostSegment, dictionary as a list of bytes)."""
+    raw = [v if isinstance(v, bytes) else str(v).encode("utf-8") for v in values]
+    n = len(raw)
+    mask = np.asarray(nulls, dtype=bool) if nulls is not None else np.zeros(n, dtype=bool)
+    dictionary = sorted({v for v, is_null in zip(raw, mask) if not is_null})
+    value_id = {v: i for i, v in enumerate(dictionary)}
+    d = len(dictionary)
+    width = fixed_width(d)
+    av = np.array([d if is_null else value_id[v] for v, is_null in zip(raw, mask)], dtype=_UINT[width])
+    return HostSegment(abi.ENC_DICTIONARY, abi.TYPE_STRING, n, width, av, aux=None, aux_size=d), dictionary
+
+
 class HostColumn:
     """A column of a table, chunk by chunk."""
 

@@ -140,6 +140,14 @@ typedef struct hy_predicate {
   const uint8_t* per_chunk_found;
   uint32_t column_is_nullable; /* Table::column_is_nullable(); matters for dictionary "matches all" early-outs */
   uint32_t reserved;
+  /* HY_PRED_LIKE / NOT_LIKE / LIKE_INSENSITIVE / NOT_LIKE_INSENSITIVE on dictionary (incl. FixedString) segments
+   * (ColumnLikeTableScanImpl::_scan_dictionary_segment, column_like_table_scan_impl.cpp:69-140): the adapter runs Hyrise's
+   * LikeMatcher over every chunk's dictionary (`_find_matches_in_dictionary`, small host work) and passes the result as
+   * bitmaps: bit v of the words starting at match_words[match_word_offsets[c]] says whether value id v of data chunk c
+   * satisfies the predicate (the matcher already applies NOT); match_word_offsets has one entry per data chunk plus the
+   * end.  The device scans the attribute vectors against the bitmaps; the NULL value id never matches. */
+  const uint64_t* match_words;
+  const uint64_t* match_word_offsets;
 } hy_predicate;
 
 /* Per-chunk classification the scan reports (TableScan::PerformanceData counters, table_scan.hpp:56-69). */

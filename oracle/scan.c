@@ -234,6 +234,26 @@ static int scan_vs_value_dictionary(const hy_segment* s, uint32_t data_chunk_id,
   return 0;
 }
 
+/* ---- ColumnLike on dictionary segments (column_like_table_scan_impl.cpp:69-121) -------------------------------- */
+static int scan_like_dictionary(const hy_segment* s, uint32_t data_chunk_id, uint32_t out_chunk_id, const hy_predicate* p,
+                                const positions_t* pos, hy_row_id* matches, int64_t* n, uint8_t* state) {
+  if (!p->match_words || !p->match_word_offsets) return -1;
+  const uint64_t* dictionary_matches = p->match_words + p->match_word_offsets[data_chunk_id]; /* _find_matches_in_dictionary */
+  const uint32_t d = s->aux_size;
+  uint32_t match_count = 0;
+  for (uint32_t v = 0; v < d; ++v) match_count += (uint32_t)bitmap_get(dictionary_matches, v);
+  if (match_count == 0) { /* "LIKE matches no rows" (:108-112) */
+    if (state) *state = HY_CHUNK_NONE_MATCH;
+    return 0;
+  }
+  /* match_count == d: "LIKE matches all rows, but we still need to check for NULL" (:96-106) -- the same loop */
+  for (uint32_t i = 0; i < pos->count; ++i) {
+    const uint32_t vid = load_compressed(s->data, s->width, pos_offset(pos, i));
+    if (vid < d && bitmap_get(dictionary_matches, vid)) emit(matches, n, out_chunk_id, i);
+  }
+  return 0;
+}
+
 static int scan_vs_value_generic(const hy_segment* s, uint32_t out_chunk_id, const hy_predicate* p,
                                  const positions_t* pos, hy_row_id* matches, int64_t* n) {
   /* _scan_generic_segment (:64-87): _scan_with_iterators<true>(cmp(value, typed_value)) */
@@ -372,6 +392,10 @@ static int scan_non_reference_segment(const hy_segment* s, uint32_t data_chunk_i
                                       uint8_t* state) {
   const uint32_t c = p->condition;
   if (c == HY_PRED_IS_NULL || c == HY_PRED_IS_NOT_NULL) return scan_is_null(s, out_chunk_id, p, pos, matches, n, state);
+  if (c >= HY_PRED_LIKE && c <= HY_PRED_NOT_LIKE_INSENSITIVE) {
+    if (s->encoding != HY_ENC_DICTIONARY) return -1; /* unencoded strings: LikeMatcher per row, not restated */
+    return scan_like_dictionary(s, data_chunk_id, out_chunk_id, p, pos, matches, n, state);
+  }
   if (is_between(c)) {
     if (s->encoding == HY_ENC_DICTIONARY)
       return scan_between_dictionary(s, data_chunk_id, out_chunk_id, p, pos, matches, n, state);

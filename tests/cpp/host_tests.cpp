@@ -163,6 +163,49 @@ static void test_string_dictionary_scan() {   // the l_shipdate case: Dictionary
   }
 }
 
+static void test_like_on_dictionary_segments() {   // table_scan_string_test.cpp:112-327 (the *OnDictSegment / OnReferencedDictSegment cases)
+  struct Case { PredicateCondition condition; const char* pattern; const char* expected; };
+  const Case cases[] = {{PredicateCondition::Like, "%", "int_string_like_without_null.tbl"}, {PredicateCondition::Like, "Dampf%", "int_string_like_starting.tbl"},
+                        {PredicateCondition::Like, "%gesellschaft", "int_string_like_ending.tbl"}, {PredicateCondition::Like, "%schifffahrtsgesellschaft%", "int_string_like_containing.tbl"},
+                        {PredicateCondition::Like, "Schiff%schaft", "int_string_like_containing_wildcard.tbl"}, {PredicateCondition::Like, "%D%_m_f%", "int_string_like_starting.tbl"},
+                        {PredicateCondition::Like, "%not_there%", nullptr}, {PredicateCondition::NotLike, "%", nullptr},
+                        {PredicateCondition::NotLike, "%foo%", "int_string_like_without_null.tbl"}, {PredicateCondition::NotLike, "D_m_f%", "int_string_like_not_starting.tbl"},
+                        {PredicateCondition::LikeInsensitive, "dampf%", "int_string_like_starting.tbl"}};
+  const auto wrapper = load_and_encode("int_string_like.tbl", 5, EncodingType::Dictionary);
+  for (const auto& c : cases) {
+    for (const bool referenced : {false, true}) {
+      std::shared_ptr<const AbstractOperator> input = wrapper;
+      if (referenced) {
+        auto first = std::make_shared<TableScan>(wrapper, ColumnID{0}, PredicateCondition::GreaterThan, AllTypeVariant{int32_t{0}});
+        first->execute();
+        input = first;
+      }
+      auto scan = std::make_shared<TableScan>(input, ColumnID{1}, c.condition, AllTypeVariant{std::string(c.pattern)});
+      scan->execute();
+      if (!c.expected) { EXPECT_TRUE(scan->get_output()->row_count() == 0); if (!referenced) EXPECT_TRUE(scan->num_chunks_with_early_out == 2); continue; }
+      EXPECT_TRUE(tables_equal_unordered(scan->get_output(), load_table(g_tbl + "/" + c.expected, 1)));
+    }
+  }
+  // special characters are literals (:193-219)
+  const auto special = load_and_encode("int_string_like_special_chars.tbl", 2, EncodingType::Dictionary);
+  const std::pair<const char*, const char*> special_cases[] = {{"%2^2%", "int_string_like_special_chars_1.tbl"}, {"%$%$%", "int_string_like_special_chars_1.tbl"},
+      {"%(%)%", "int_string_like_special_chars_2.tbl"}, {"%la\\.^$+?)({}.*__bl%", "int_string_like_special_chars_3.tbl"}};
+  for (const auto& [pattern, expected] : special_cases) {
+    auto scan = std::make_shared<TableScan>(special, ColumnID{1}, PredicateCondition::Like, AllTypeVariant{std::string(pattern)});
+    scan->execute();
+    EXPECT_TRUE(tables_equal_unordered(scan->get_output(), load_table(g_tbl + "/" + expected, 1)));
+  }
+  // LIKE on a non-string column / with a non-string pattern throws (:91-101)
+  bool thrown = false;
+  try { auto s = std::make_shared<TableScan>(load_and_encode("int_float.tbl", 2, EncodingType::Dictionary), ColumnID{0}, PredicateCondition::Like, AllTypeVariant{std::string("%test")}); s->execute(); }
+  catch (const std::logic_error&) { thrown = true; }
+  EXPECT_TRUE(thrown);
+  thrown = false;
+  try { auto s = std::make_shared<TableScan>(wrapper, ColumnID{1}, PredicateCondition::Like, AllTypeVariant{int32_t{1234}}); s->execute(); }
+  catch (const std::logic_error&) { thrown = true; }
+  EXPECT_TRUE(thrown);
+}
+
 static void test_type_mismatch_throws() {   // table_scan_test.cpp:383-405 (EXPECT_THROW std::logic_error)
   const auto wrapper = load_and_encode("int_float.tbl", 2, EncodingType::Unencoded);
   auto scan = std::make_shared<TableScan>(wrapper, ColumnID{0}, PredicateCondition::Equals, AllTypeVariant{std::string("x")});
@@ -298,6 +341,7 @@ int main(int argc, char** argv) {
   run("TableScan.SingleScan / DoubleScan / Between", test_single_and_double_scan);
   run("TableScan.ScanForNullValues", test_scan_for_null_values);
   run("TableScan.DictionarySegment<string>", test_string_dictionary_scan);
+  run("TableScan.LikeOnDictionarySegments", test_like_on_dictionary_segments);
   run("TableScan.TypeMismatchThrowsLogicError", test_type_mismatch_throws);
   run("Validate.Visibility truth table, reference input, chunk shortcut", test_validate_visibility);
   run("JoinHash vs nested loop (Inner/Semi/AntiNullAsFalse/Left)", test_join_against_nested_loop);

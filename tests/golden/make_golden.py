@@ -20,6 +20,12 @@ FILES = [
     "int_int_shuffled.tbl", "int_int_shuffled_2.tbl", "int_sorted.tbl", "int_int_w_null_8_rows.tbl",
     "int_int3.tbl", "int_int_int.tbl", "int_string_like.tbl", "int_float_null_1.tbl", "int_float_null_2.tbl",
     "int_float4.tbl", "int_float_double_string.tbl", "float_int.tbl", "int.tbl", "int2.tbl", "int3.tbl",
+    # LIKE on dictionary segments: inputs and expected outputs of src/test/lib/operators/table_scan_string_test.cpp:66-327
+    "int_string_like_starting.tbl", "int_string_like_ending.tbl", "int_string_like_containing.tbl",
+    "int_string_like_containing_wildcard.tbl", "int_string_like_without_null.tbl", "int_string_like_not_starting.tbl",
+    "int_string_like_equals.tbl", "int_string_like_not_equals.tbl", "int_string_like_less_than.tbl",
+    "int_string_like_special_chars.tbl", "int_string_like_special_chars_1.tbl", "int_string_like_special_chars_2.tbl",
+    "int_string_like_special_chars_3.tbl",
     # JoinHash: differential-testing inputs (src/test/lib/operators/join_test_runner.cpp:656-791)
     "join_test_runner/input_table_left_0.tbl", "join_test_runner/input_table_left_10.tbl",
     "join_test_runner/input_table_left_15.tbl", "join_test_runner/input_table_right_0.tbl",
