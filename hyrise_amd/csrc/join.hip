@@ -277,6 +277,18 @@ __device__ __forceinline__ uint64_t match_any(uint32_t digit, bool valid, uint32
   return valid ? peers : 0;
 }
 
+// The same with all eight digit bits, unrolled (bits a digit never has: every lane agrees, the step changes nothing).
+__device__ __forceinline__ uint64_t match_any8(uint32_t digit, bool valid) {
+  uint64_t peers = __ballot(valid);
+#pragma unroll
+  for (uint32_t b = 0; b < 8; ++b) {
+    const bool bit = (digit >> b) & 1;
+    const uint64_t m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;   // (of a lane that is not valid: meaningless)
+}
+
 __global__ __launch_bounds__(256) void sort_scatter(const uint64_t* keys_in, const hy_row_id* rows_in, uint64_t* keys_out, hy_row_id* rows_out,
                                                     uint64_t n, uint32_t shift, const uint64_t* bases, uint32_t n_tiles) {
   __shared__ uint32_t s_wave_hist[4][256];   // per-wave digit counts, then per-wave running positions (relative to the tile's base)
@@ -394,6 +406,7 @@ struct Directory {
   const uint64_t* keys;      // sorted (unsigned order of the sign-extended bits)
   const uint32_t* keys32;    // int32 build columns: the low halves of `keys` (same order), padded by four entries; else nullptr
   const hy_row_id* row_ids;  // same order
+  const uint32_t* ids32;     // row_ids packed as chunk_id << 16 | chunk_offset when every build RowID fits (probe_emit_cached), else nullptr
   const uint32_t* dir;       // [n_buckets + 1] first position of every bucket
   uint64_t n;
   uint64_t key_min;
@@ -402,9 +415,14 @@ struct Directory {
   uint32_t n_buckets;
 };
 
-__global__ void directory_fill(const uint64_t* keys, uint64_t n, uint64_t key_min, uint32_t shift, uint32_t n_buckets, uint32_t* dir, uint32_t* keys32) {
+__global__ void directory_fill(const uint64_t* keys, uint64_t n, uint64_t key_min, uint32_t shift, uint32_t n_buckets, uint32_t* dir, uint32_t* keys32,
+                               const hy_row_id* row_ids, uint32_t* ids32) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (ids32) {
+    const hy_row_id id = row_ids[i];
+    ids32[i] = id.chunk_id << 16 | id.chunk_offset;
+  }
   if (keys32) {   // int32 build columns: the low halves, same order, padded by four entries
     keys32[i] = static_cast<uint32_t>(keys[i]);
     if (i + 1 == n) { keys32[n] = 0; keys32[n + 1] = 0; keys32[n + 2] = 0; keys32[n + 3] = 0; }
@@ -477,9 +495,15 @@ struct ProbeArgs {
   hy_row_id* build_out;           // may be nullptr (Semi/Anti)
   hy_row_id* probe_out;
   uint64_t* slice_offsets;
-  uint32_t* row_cache;            // [n_tiles][JOIN_TILE] pass 1 -> pass 2 (see cached_rows), or nullptr
-  uint32_t* tile_uncached;        // [n_tiles] set by pass 1 when a tile's rows do not fit the cache word
+  uint32_t* row_partner;          // [n_tiles][JOIN_TILE] pass 1 -> pass 2: build position of the row's partner, or nullptr
+  uint32_t* row_meta;             // [n_tiles][JOIN_WAVES][JOIN_ROUNDS / 2][64] pass 1 -> pass 2: partition and flags (ROW_*) of a lane's rows, two rounds per word
+  uint32_t* tile_uncached;        // [n_tiles] set by pass 1 when a tile has a row with several partners (pass 2 evaluates it again)
+  uint32_t* n_uncached;           // number of such tiles
+  uint32_t* xcd_tickets;          // [8] probe_emit_cached: next tile of every XCD's share
   uint32_t* error;                // set when a probe row matches >= 2^22 build rows (the staging record cannot hold it)
+  uint64_t* trace;                // debug (HY_JOIN_TRACE): 6 wall-clock stamps per probe_emit tile, else nullptr
+  uint32_t debug_plain_stores;
+  uint32_t pack_build_ids;        // dir.ids32 exists: probe_emit_cached stages the partner's packed RowID, not its position
 };
 
 struct ProbeRow {
@@ -616,34 +640,11 @@ __device__ __forceinline__ void decode_keys(const ProbeArgs& a, uint32_t chunk, 
   }
 }
 
-// The probe's second pass re-reads what the first pass found: one word per probe row,
-//   [31] materialised  [30] one output pair  [29] its partner is NULL_ROW_ID  [28:0] build position of the partner.
-// A tile with a row that does not fit (several partners, a position >= 2^29) is flagged and evaluated again instead.
-constexpr uint32_t CACHE_MATERIALISED = 1u << 31, CACHE_EMIT = 1u << 30, CACHE_NULL_PARTNER = 1u << 29, CACHE_POSITION = (1u << 29) - 1;
-
-__device__ __forceinline__ void cached_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
-                                            uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&start)[JOIN_ROUNDS]) {
-#pragma unroll
-  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) { meta[k] = INVALID_PARTITION; start[k] = 0; }
-  if (row_count == 0) return;
-  uint32_t row[JOIN_ROUNDS], word[JOIN_ROUNDS], index[JOIN_ROUNDS];
-  bool in[JOIN_ROUNDS], is_null[JOIN_ROUNDS];
-  int64_t key[JOIN_ROUNDS];
-#pragma unroll
-  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
-    const uint32_t r = wave * JOIN_WAVE_ROWS + k * 64 + lane;
-    index[k] = r < row_count ? r : 0;
-  }
-  load_rows<uint32_t>(a.row_cache + static_cast<size_t>(blockIdx.x) * JOIN_TILE, index, word);
-  decode_keys(a, chunk, row_begin, row_count, wave, lane, row, in, is_null, key);
-#pragma unroll
-  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
-    if (!in[k] || !(word[k] & CACHE_MATERIALISED)) continue;
-    const uint32_t partition = a.radix_bits ? static_cast<uint32_t>(static_cast<uint64_t>(key[k]) & ((1u << a.radix_bits) - 1)) : 0;
-    meta[k] = ((word[k] & CACHE_EMIT) ? 1u << 10 : 0u) | ((word[k] & CACHE_NULL_PARTNER) ? 0x200u : 0u) | partition;
-    start[k] = word[k] & CACHE_POSITION;
-  }
-}
+// What pass 1 leaves behind for pass 2, per probe row: a 16-bit word
+//   [7:0] radix partition  [8] materialised  [9] one output pair  [10] its build side is NULL_ROW_ID
+// (stored lane-major, the words of rounds 2j and 2j+1 of a lane in one 32-bit word) and the partner's position in the
+// sorted build side.  A tile with a row that has several partners is flagged and evaluated again by probe_emit_generic.
+constexpr uint32_t ROW_PARTITION = 0xFF, ROW_MATERIALISED = 0x100, ROW_EMIT = 0x200, ROW_NULL_PARTNER = 0x400;
 
 // meta[k] = emit << 10 | null_partner << 9 | partition (INVALID_PARTITION: not materialised); start[k] = first build position
 __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
@@ -760,6 +761,12 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
   }
 }
 
+// Workgroup -> tile.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): XCD x takes the x-th eighth
+// of the tiles, so neighbouring tiles -- whose (tile, partition) output runs are neighbours in memory and whose directory
+// and build-key lines overlap -- meet in the same L2 at about the same time.  The grid is 8 * ceil(n_tiles / 8).
+__host__ __device__ constexpr uint32_t probe_grid(uint32_t n_tiles) { return 8 * ((n_tiles + 7) / 8); }
+__device__ __forceinline__ uint32_t block_tile(uint32_t n_tiles) { return (blockIdx.x & 7) * ((n_tiles + 7) / 8) + (blockIdx.x >> 3); }
+
 __device__ __forceinline__ void tile_rows(const ProbeArgs& a, uint32_t tile, uint32_t* chunk, uint32_t* row_begin, uint32_t* row_count) {
   const Slice slice = a.slices[tile / (SLICE_ROWS / JOIN_TILE)];
   const uint32_t offset = (tile % (SLICE_ROWS / JOIN_TILE)) * JOIN_TILE;
@@ -771,14 +778,17 @@ __device__ __forceinline__ void tile_rows(const ProbeArgs& a, uint32_t tile, uin
 // Pass 1: per tile (4096 consecutive probe rows) and radix partition, the number of materialised probe elements and of
 // output pairs.  Wave w owns rows [w*512, (w+1)*512) of the tile, 64 consecutive rows per round.
 __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
-  __shared__ uint32_t s_elements[MAX_PARTITIONS + 1];   // + 1: "a row of this tile does not fit the cache word"
+  __shared__ uint32_t s_elements[MAX_PARTITIONS + 1];   // + 1: "a row of this tile has several partners"
   __shared__ uint32_t s_pairs[MAX_PARTITIONS];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t partitions = 1u << a.radix_bits;
+  const uint32_t tile = block_tile(a.n_tiles);
+  if (tile >= a.n_tiles) return;
   if (tid < MAX_PARTITIONS) { s_elements[tid] = 0; s_pairs[tid] = 0; }
+  if (tid == 0) s_elements[MAX_PARTITIONS] = 0;
   __syncthreads();
   uint32_t chunk, row_begin, row_count;
-  tile_rows(a, blockIdx.x, &chunk, &row_begin, &row_count);
+  tile_rows(a, tile, &chunk, &row_begin, &row_count);
   uint32_t meta[JOIN_ROUNDS], start[JOIN_ROUNDS];
   evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
   bool fits = true;
@@ -790,25 +800,264 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
       atomicAdd(&s_elements[partition], 1u);
       if (emit) atomicAdd(&s_pairs[partition], emit);
     }
-    if (a.row_cache) {
-      const uint32_t r = wave * JOIN_WAVE_ROWS + round * 64 + lane;
-      fits = fits && emit <= 1 && start[round] <= CACHE_POSITION;
-      const uint32_t word = partition == INVALID_PARTITION ? 0u
-                                                           : CACHE_MATERIALISED | (emit ? CACHE_EMIT : 0u) | ((meta[round] & 0x200u) ? CACHE_NULL_PARTNER : 0u) | (start[round] & CACHE_POSITION);
-      if (r < row_count) __builtin_nontemporal_store(word, a.row_cache + static_cast<size_t>(blockIdx.x) * JOIN_TILE + r);
-    }
+    fits = fits && emit <= 1;
   }
-  if (a.row_cache) {
-    const bool all_fit = __all(fits);
-    if (tid == 0) s_elements[MAX_PARTITIONS] = 0;
-    __syncthreads();
-    if (!all_fit && lane == 0) s_elements[MAX_PARTITIONS] = 1;
+  if (a.row_meta) {
+    uint32_t word[JOIN_ROUNDS];
+#pragma unroll
+    for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
+      const uint32_t partition = meta[round] & 0x1FF;
+      word[round] = partition == INVALID_PARTITION ? 0u
+                                                   : partition | ROW_MATERIALISED | ((meta[round] >> 10) ? ROW_EMIT : 0u) | ((meta[round] & 0x200u) ? ROW_NULL_PARTNER : 0u);
+      if (word[round] & ROW_EMIT) __builtin_nontemporal_store(start[round], a.row_partner + static_cast<size_t>(tile) * JOIN_TILE + wave * JOIN_WAVE_ROWS + round * 64 + lane);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < JOIN_ROUNDS / 2; ++j)   // (rows past the tile's end: 0, pass 2 loads whole tiles)
+      __builtin_nontemporal_store(word[2 * j] | word[2 * j + 1] << 16, a.row_meta + static_cast<size_t>(tile) * (JOIN_TILE / 2) + (wave * (JOIN_ROUNDS / 2) + j) * 64 + lane);
+    if (!__all(fits) && lane == 0) s_elements[MAX_PARTITIONS] = 1;
   }
   __syncthreads();
-  if (a.row_cache && tid == 0) a.tile_uncached[blockIdx.x] = s_elements[MAX_PARTITIONS];
+  if (a.row_meta && tid == 0) {
+    a.tile_uncached[tile] = s_elements[MAX_PARTITIONS];
+    if (s_elements[MAX_PARTITIONS]) atomicAdd(a.n_uncached, 1u);
+  }
   if (tid < partitions) {
-    a.hist_elements[static_cast<size_t>(tid) * a.n_tiles + blockIdx.x] = s_elements[tid];
-    a.hist_pairs[static_cast<size_t>(tid) * a.n_tiles + blockIdx.x] = s_pairs[tid];
+    a.hist_elements[static_cast<size_t>(tid) * a.n_tiles + tile] = s_elements[tid];
+    a.hist_pairs[static_cast<size_t>(tid) * a.n_tiles + tile] = s_pairs[tid];
+  }
+}
+
+// ---- pass 2, common case: every row of the tile has at most one partner ------------------------------------------------
+// Persistent workgroups (three per CU), each walking its share of an XCD's tiles with the NEXT tile's loads in flight:
+// pass 1 left a 16-bit word and the partner per row, so a tile is two plain coalesced loads per row -- no segment
+// descriptors, no key decoding, no directory.  Ranking: a pair's slot inside (tile, partition) is
+//   pairs of the partition in earlier waves + in earlier rounds of this wave + in lower lanes of this round.
+// The middle term comes from one byte counter per (wave, partition, round) -- eight rounds = one 8-byte LDS word, filled
+// with LDS atomics that return nothing, summed below a round with v_sad_u8 -- so no round waits for another one.  The
+// tile's pairs are laid out partition by partition in LDS and copied out: a (tile, partition) cell is one contiguous run
+// of nontemporal RowID stores.  The 131 070-element PosList cuts (one per ~32 tiles) are probe_cuts' business.
+//
+// LDS, in 4-byte words: staged pairs | byte counters | per-(wave, partition) pairs of earlier waves | first slot per
+// partition (+ total) | output base per partition | wave totals.
+__host__ __device__ constexpr size_t probe_emit_cached_lds_words(uint32_t partitions) {
+  return 2 * size_t{JOIN_TILE} + 2 * size_t{JOIN_WAVES} * partitions + size_t{JOIN_WAVES} * partitions + (partitions + 2) + 2 * size_t{partitions} + 16;
+}
+
+// Sum of the byte counters of rounds 0 .. round-1 (round is a constant after unrolling).
+__device__ __forceinline__ uint32_t pairs_of_earlier_rounds(u32x2_t counters, uint32_t round) {
+  if (round == 0) return 0;
+  if (round < 4) return __builtin_amdgcn_sad_u8(counters.x & ((1u << (8 * round)) - 1), 0u, 0u);
+  if (round == 4) return __builtin_amdgcn_sad_u8(counters.x, 0u, 0u);
+  return __builtin_amdgcn_sad_u8(counters.x, 0u, __builtin_amdgcn_sad_u8(counters.y & ((1u << (8 * (round - 4))) - 1), 0u, 0u));
+}
+
+struct TileLoads {   // what is loaded one tile ahead
+  uint32_t meta[JOIN_ROUNDS / 2];
+  uint32_t position[JOIN_ROUNDS];
+  uint32_t pairs;      // thread = partition: pairs of the tile's cell
+  uint32_t uncached;
+};
+
+__device__ __forceinline__ void issue_tile_loads(const ProbeArgs& a, uint32_t tile, uint32_t partitions, uint32_t tid, TileLoads& t) {
+  const uint32_t* meta = a.row_meta + static_cast<size_t>(tile) * (JOIN_TILE / 2) + (tid >> 6) * (JOIN_ROUNDS / 2 * 64) + (tid & 63);
+#pragma unroll
+  for (uint32_t j = 0; j < JOIN_ROUNDS / 2; ++j) t.meta[j] = meta[j * 64];
+  const uint32_t* position = a.row_partner + static_cast<size_t>(tile) * JOIN_TILE + (tid >> 6) * JOIN_WAVE_ROWS + (tid & 63);
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) t.position[k] = position[k * 64];   // (rows without a pair: never written, never used)
+  t.pairs = a.hist_pairs[static_cast<size_t>(tid < partitions ? tid : 0) * a.n_tiles + tile];
+  t.uncached = a.tile_uncached[tile];
+}
+
+__global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void probe_emit_cached(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
+  const uint32_t partitions = 1u << a.radix_bits;
+  u32x2_t* s_stage = reinterpret_cast<u32x2_t*>(join_smem);                            // [JOIN_TILE] row | partition << 12 | null << 21 , partner
+  u32x2_t* s_round_pairs = s_stage + JOIN_TILE;                                        // [JOIN_WAVES][partitions] 8 byte counters, one per round
+  uint32_t* s_wave_pairs = reinterpret_cast<uint32_t*>(s_round_pairs + JOIN_WAVES * partitions);   // [JOIN_WAVES][partitions] pairs of earlier waves
+  uint32_t* s_tile_offset = s_wave_pairs + JOIN_WAVES * partitions;                    // [partitions + 1] first staged slot of every partition
+  uint64_t* s_out_base = reinterpret_cast<uint64_t*>(s_tile_offset + partitions + 2 - (partitions & 1 ? 1 : 0));   // [partitions] global pair index of slot 0 of the partition's run, minus that slot
+  uint32_t* s_scratch = reinterpret_cast<uint32_t*>(s_out_base + partitions);         // [JOIN_WAVES] wave totals of the partition scan, [2] tickets
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave index in an SGPR)
+  const uint32_t scan_waves = partitions > 64 ? partitions / 64 : 1;
+
+  // this workgroup's tiles: XCD x = blockIdx % 8 owns the x-th eighth of the tiles; its workgroups draw them one at a time
+  // from the XCD's ticket counter (workgroups differ in speed by a third: equal shares leave the chip half idle at the
+  // end), two tickets ahead -- the next tile's loads are in flight while this one is ranked.
+  const uint32_t per_xcd = (a.n_tiles + 7) / 8, xcd = blockIdx.x & 7;
+  const uint32_t xcd_begin = xcd * per_xcd, xcd_end = (xcd + 1) * per_xcd < a.n_tiles ? (xcd + 1) * per_xcd : a.n_tiles;
+  if (tid == 0) {
+    s_scratch[JOIN_WAVES] = atomicAdd(a.xcd_tickets + xcd, 1u);
+    s_scratch[JOIN_WAVES + 1] = atomicAdd(a.xcd_tickets + xcd, 1u);
+  }
+  __syncthreads();
+  uint32_t tile = xcd_begin + s_scratch[JOIN_WAVES], tile_after = xcd_begin + s_scratch[JOIN_WAVES + 1];
+  __syncthreads();
+  if (tile >= xcd_end) return;
+  TileLoads next;
+  issue_tile_loads(a, tile, partitions, tid, next);
+  for (uint32_t iteration = 0; tile < xcd_end; ++iteration) {
+    // what arrived for this tile (one explicit vmcnt(0): everything in flight here is this tile's prefetch, and the waits
+    // the compiler derives for single registers across the loop edge would later also cover this iteration's gathers)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // (Two things would make the wave wait for the ticket right here: an initial value to merge the atomic's result with,
+    // and an address the compiler can see to be uniform -- it then aggregates the add over the wave and needs the result
+    // at once to hand out the lanes' shares.  Hence the undefined start and the laundered zero offset.)
+    uint32_t ticket, opaque_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+    asm volatile("" : "=v"(ticket));
+    if (tid == 0) ticket = atomicAdd(a.xcd_tickets + xcd + opaque_zero, 1u);   // the tile after the next one
+    uint32_t cur_meta[JOIN_ROUNDS / 2];
+#pragma unroll
+    for (uint32_t j = 0; j < JOIN_ROUNDS / 2; ++j) cur_meta[j] = next.meta[j];
+    const uint32_t cur_pairs = next.pairs, cur_uncached = next.uncached;
+    const uint32_t cur_tile = tile;
+    tile = tile_after;
+    // this tile's remaining loads, needed two or three barriers from here: the partners' RowIDs (d) -- fetched HERE, where
+    // consecutive lanes hold consecutive probe rows (sorted probe keys: nearly consecutive build positions, a line or two
+    // per wave), not in the copy-out, whose consecutive slots are rows of one partition = build positions a partition
+    // count apart = one line per slot -- and the cell's base (c) ...
+    uint32_t partner[JOIN_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+      const uint32_t meta = k & 1 ? cur_meta[k / 2] >> 16 : cur_meta[k / 2];
+      const bool has_partner = (meta & ROW_EMIT) && !(meta & ROW_NULL_PARTNER);
+      partner[k] = a.pack_build_ids ? a.dir.ids32[has_partner ? next.position[k] : 0] : next.position[k];
+    }
+    const uint64_t cell_base_pairs = a.base_pairs[static_cast<size_t>(tid < partitions ? tid : 0) * a.n_tiles + cur_tile];
+    uint32_t chunk, row_begin, row_count;
+    tile_rows(a, cur_tile, &chunk, &row_begin, &row_count);
+    // ... and, behind them, the next tile's first loads (unconditionally -- after the last tile: this tile's again -- so that
+    // the wait counts in front of this tile's loads can leave them in flight)
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would issue them first)
+    issue_tile_loads(a, tile < xcd_end ? tile : cur_tile, partitions, tid, next);
+    if (!cur_uncached) {   // (else: probe_emit_generic's tile)
+    if (a.trace && tid == 0) a.trace[cur_tile * 6 + 0] = wall_clock64();
+    // (a) clear the byte counters; the tile's first slot per partition from pass 1's pair counts (scan inside each wave
+    //     now, across waves in (c))
+    for (uint32_t i = tid; i < JOIN_WAVES * partitions; i += JOIN_THREADS) s_round_pairs[i] = u32x2_t{0, 0};
+    if (wave < scan_waves) {
+      const uint32_t mine = tid < partitions ? cur_pairs : 0;
+      const uint32_t inclusive = join_wave_inclusive_scan(mine);
+      if (tid < partitions) s_tile_offset[tid] = inclusive - mine;
+      if (lane == 63) s_scratch[wave] = inclusive;
+    }
+    __syncthreads();
+    // (b) count: one byte per (wave, partition, round)
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+      const uint32_t meta = k & 1 ? cur_meta[k / 2] >> 16 : cur_meta[k / 2] & 0xFFFFu;
+      if (meta & ROW_EMIT) atomicAdd(reinterpret_cast<uint32_t*>(s_round_pairs + wave * partitions + (meta & ROW_PARTITION)) + (k >> 2), 1u << (8 * (k & 3)));
+    }
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[cur_tile * 6 + 1] = wall_clock64();
+    // (c) thread = partition: pairs of earlier waves, first slot, output base
+    if (tid < partitions) {
+      uint32_t run = 0;
+#pragma unroll 1   // (unrolled, the eight LDS addresses are hoisted out of the tile loop and spilled)
+      for (uint32_t w = 0; w < JOIN_WAVES; ++w) {
+        const u32x2_t counters = s_round_pairs[w * partitions + tid];
+        s_wave_pairs[w * partitions + tid] = run;
+        run += __builtin_amdgcn_sad_u8(counters.x, 0u, 0u) + __builtin_amdgcn_sad_u8(counters.y, 0u, 0u);
+      }
+      uint32_t first = s_tile_offset[tid];   // (at most four waves hold partitions)
+      first += (wave > 0 ? s_scratch[0] : 0u) + (wave > 1 ? s_scratch[1] : 0u) + (wave > 2 ? s_scratch[2] : 0u);
+      s_tile_offset[tid] = first;
+      s_out_base[tid] = cell_base_pairs - first;
+      if (tid == partitions - 1) s_tile_offset[partitions] = first + cur_pairs;
+    }
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[cur_tile * 6 + 2] = wall_clock64();
+    // (d) ranking: no round depends on another one
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+      const uint32_t meta = k & 1 ? cur_meta[k / 2] >> 16 : cur_meta[k / 2] & 0xFFFFu;
+      const uint32_t partition = meta & ROW_PARTITION;
+      const bool emit = meta & ROW_EMIT;
+      const uint64_t peers = match_any8(partition, emit);
+      if (emit) {
+        const u32x2_t counters = s_round_pairs[wave * partitions + partition];
+        const uint32_t earlier_rounds = pairs_of_earlier_rounds(counters, k);
+        const uint32_t lower_peers = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(peers >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(peers), 0u));
+        const uint32_t slot = s_tile_offset[partition] + s_wave_pairs[wave * partitions + partition] + earlier_rounds + lower_peers;
+        const uint32_t r = wave * JOIN_WAVE_ROWS + k * 64 + lane;
+        s_stage[slot] = u32x2_t{r | (partition << 12) | ((meta & ROW_NULL_PARTNER) ? 1u << 21 : 0u), partner[k]};
+      }
+      __builtin_amdgcn_sched_barrier(0);   // one round at a time: several in flight do not fit the registers
+    }
+    if (a.trace && tid == 0) a.trace[cur_tile * 6 + 3] = wall_clock64();
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[cur_tile * 6 + 4] = wall_clock64();
+    // (e) copy out: slot s of partition p is pair  base_pairs[p][tile] + (s - first slot of p)
+    const uint32_t tile_pairs = s_tile_offset[partitions];
+    for (uint32_t slot = tid; slot < tile_pairs; slot += JOIN_THREADS) {
+      const u32x2_t record = s_stage[slot];
+      const uint32_t tag = record.x, partner = record.y;
+      const uint64_t pair_pos = s_out_base[(tag >> 12) & 0x1FF] + slot;
+      const u32x2_t probe_id = {chunk, row_begin + (tag & 0xFFFu)};
+      if (a.debug_plain_stores) reinterpret_cast<u32x2_t*>(a.probe_out)[pair_pos] = probe_id;
+      else __builtin_nontemporal_store(probe_id, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
+      if (a.build_out) {
+        u32x2_t build_id = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (!(tag & (1u << 21))) {
+          if (a.pack_build_ids) build_id = u32x2_t{partner >> 16, partner & 0xFFFFu};
+          else build_id = reinterpret_cast<const u32x2_t*>(a.dir.row_ids)[partner];
+        }
+        if (a.debug_plain_stores) reinterpret_cast<u32x2_t*>(a.build_out)[pair_pos] = build_id;
+        else __builtin_nontemporal_store(build_id, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+      }
+    }
+    if (a.trace && tid == 0) a.trace[cur_tile * 6 + 5] = wall_clock64();
+    }
+    if (tid == 0) s_scratch[JOIN_WAVES + (iteration & 1)] = ticket;
+    __syncthreads();   // the next tile clears what this one still reads
+    tile_after = xcd_begin + s_scratch[JOIN_WAVES + (iteration & 1)];
+  }
+}
+
+// The 131 070-element cuts of the tiles probe_emit_cached handles (join_hash_steps.hpp:655-660): output PosList s of
+// group g (radix partition, or probe chunk without radix partitioning) starts at the pair index where the group's
+// element number (s - first PosList of g) * 131 070 stands.  One wave per PosList: binary search for the cell holding that
+// element in the scanned element counts, then a walk over the tile's 16-bit row words.
+__global__ __launch_bounds__(64) void probe_cuts(ProbeArgs a, const uint64_t* group_first_cell, uint32_t n_groups, uint32_t n_slices) {
+  const uint32_t slice = blockIdx.x, lane = threadIdx.x;
+  uint32_t lo = 0, hi = n_groups;   // last group whose first PosList is <= slice
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) / 2;
+    if (a.partition_slice_base[mid] <= slice) lo = mid; else hi = mid;
+  }
+  const uint32_t group = lo;
+  const uint64_t first_cell = group_first_cell[group], end_cell = group_first_cell[group + 1];
+  const uint64_t target = a.base_elements[first_cell] + static_cast<uint64_t>(slice - a.partition_slice_base[group]) * PROBE_SIZE_PER_CHUNK;
+  uint64_t cell = first_cell, cell_end = end_cell;   // last cell of the group whose first element is <= target: it holds the element
+  while (cell_end - cell > 1) {
+    const uint64_t mid = (cell + cell_end) / 2;
+    if (a.base_elements[mid] <= target) cell = mid; else cell_end = mid;
+  }
+  const uint32_t tile = static_cast<uint32_t>(a.radix_bits ? cell - static_cast<uint64_t>(group) * a.n_tiles : cell);
+  if (a.tile_uncached[tile]) return;   // probe_emit_generic records the cuts of its tiles
+  const uint32_t partition = a.radix_bits ? group : 0;
+  uint32_t cut_rank = static_cast<uint32_t>(target - a.base_elements[cell]), pairs_before = 0;
+  const uint64_t lower_lanes = (1ull << lane) - 1;
+  const uint32_t* meta = a.row_meta + static_cast<size_t>(tile) * (JOIN_TILE / 2) + lane;   // word (wave, j) holds rounds 2j and 2j+1 of the wave: row order
+#pragma unroll 1
+  for (uint32_t batch = 0; batch < JOIN_TILE / 128; batch += 16) {
+    uint32_t word[16];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) word[k] = meta[(batch + k) * 64];
+#pragma unroll
+    for (uint32_t k = 0; k < 32; ++k) {
+      const uint32_t row_word = k & 1 ? word[k / 2] >> 16 : word[k / 2] & 0xFFFFu;
+      const bool member = (row_word & ROW_MATERIALISED) && (row_word & ROW_PARTITION) == partition;
+      const uint64_t members = __ballot(member), emitters = __ballot(member && (row_word & ROW_EMIT));
+      const uint32_t n = __popcll(members);
+      if (cut_rank < n) {
+        if (member && __popcll(members & lower_lanes) == cut_rank) a.slice_offsets[slice] = a.base_pairs[cell] + pairs_before + __popcll(emitters & lower_lanes);
+        return;
+      }
+      cut_rank -= n;
+      pairs_before += __popcll(emitters);
+    }
   }
 }
 
@@ -818,16 +1067,14 @@ __host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
   return 2 * size_t{JOIN_STAGE} + JOIN_THREADS + 2 * size_t{JOIN_WAVES} * partitions + (partitions + 1) + 6 * size_t{partitions} + 8;
 }
 
-// Pass 2: every tile knows, from the scanned histograms, where its pairs of every partition go.  A lane keeps the lookup
-// results of its eight rows in registers (CACHED: re-read from pass 1's word per row; otherwise -- tiles whose rows did
-// not fit that word -- evaluated again by a second launch of this kernel, so that the common instantiation needs few
-// enough registers for three workgroups per CU), a wave-level match-any ranking gives every row its stable rank inside
-// (partition, tile), and the pairs are first laid out partition by partition in LDS and then copied out, so that a run of
-// consecutive lanes writes a run of consecutive RowIDs: a (tile, partition) cell is one contiguous piece of the output.
-// Tiles whose pairs do not fit the staging buffer (build keys with many duplicates) write their pairs directly.
-template <bool CACHED>
-__global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void probe_emit(ProbeArgs a) {
-  if ((a.tile_uncached[blockIdx.x] == 0) != CACHED) return;   // the other instantiation's tile
+// Pass 2 for the tiles pass 1 flagged (a row with several partners: build keys with duplicates): the tile is evaluated
+// again, a lane keeps the lookup results of its eight rows in registers, a wave-level match-any ranking with running
+// per-(wave, partition) counters gives every row its stable rank inside (partition, tile), and the pairs are first laid
+// out partition by partition in LDS and then copied out.  Tiles whose pairs do not fit the staging buffer (many
+// duplicates) write their pairs directly.  One workgroup per tile; tiles probe_emit_cached handles return at once.
+__global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) {
+  const uint32_t tile = block_tile(a.n_tiles);
+  if (tile >= a.n_tiles || a.tile_uncached[tile] == 0) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
   const uint32_t partitions = 1u << a.radix_bits;
   uint32_t* s_stage = join_smem;                                     // [JOIN_STAGE][2] row | partition << 12 | null << 21 , build position
@@ -842,12 +1089,12 @@ __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6)
   for (uint32_t i = tid; i < 2 * JOIN_WAVES * partitions; i += JOIN_THREADS) s_run_elements[i] = 0;
   __syncthreads();
   uint32_t chunk, row_begin, row_count;
-  tile_rows(a, blockIdx.x, &chunk, &row_begin, &row_count);
+  tile_rows(a, tile, &chunk, &row_begin, &row_count);
   // thread = partition: the cell's global bases, requested now and used after the tile has been evaluated
   uint64_t cell_base_pairs = 0, cell_first_element = 0;
   uint32_t cell_slice_base = 0;
   if (tid < partitions) {
-    const size_t cell = static_cast<size_t>(tid) * a.n_tiles + blockIdx.x;
+    const size_t cell = static_cast<size_t>(tid) * a.n_tiles + tile;
     const uint32_t group = a.radix_bits ? tid : chunk;
     cell_base_pairs = a.base_pairs[cell];
     cell_first_element = a.base_elements[cell] - a.partition_element_origin[group];
@@ -856,8 +1103,7 @@ __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6)
 
   // (a) the lookup results of the lane's rows (row  wave*512 + round*64 + lane  <->  index round)
   uint32_t row_meta[JOIN_ROUNDS], row_start[JOIN_ROUNDS];
-  if constexpr (CACHED) cached_rows(a, chunk, row_begin, row_count, wave, lane, row_meta, row_start);
-  else evaluate_rows(a, chunk, row_begin, row_count, wave, lane, row_meta, row_start);
+  evaluate_rows(a, chunk, row_begin, row_count, wave, lane, row_meta, row_start);
 #pragma unroll
   for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
     const uint32_t partition = row_meta[round] & 0x1FF;
@@ -1022,7 +1268,7 @@ static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, h
 static bool is_integer_column(const hy_column* c) { return (c->data_type == HY_TYPE_INT || c->data_type == HY_TYPE_LONG) && !c->is_mvcc && !(c->ref && c->ref->is_mvcc); }
 
 struct BuildSide {
-  DeviceBuffer keys, rows, keys_tmp, rows_tmp, keys32, dir, bloom, flags;
+  DeviceBuffer keys, rows, keys_tmp, rows_tmp, keys32, ids32, dir, bloom, flags;
   uint64_t n = 0;
   Directory directory{};
   bool any_null = false;
@@ -1031,7 +1277,7 @@ struct BuildSide {
 
 // Materialise + (sort) + directory.  `bloom_in` (device) filters the build side (no observable effect, kept for the
 // reference's element counts); `bloom_out` receives the build side's filter if wanted.
-static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, BuildSide& b, hipStream_t stream) {
+static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, BuildSide& b, hipStream_t stream) {
   const uint32_t n_slices = build->n_slices;
   DeviceBuffer counts, offsets;
   HY_TRY(counts.alloc(4 * size_t{n_slices + 1}));
@@ -1140,6 +1386,11 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     HY_TRY(b.keys32.alloc(4 * (total + 4)));
     d.keys32 = b.keys32.as<uint32_t>();   // filled by directory_fill
   }
+  d.ids32 = nullptr;
+  if (total && want_ids32) {
+    HY_TRY(b.ids32.alloc(4 * total));
+    d.ids32 = b.ids32.as<uint32_t>();     // filled by directory_fill
+  }
   d.key_min = d.key_max = 0;
   d.shift = 0;
   d.n_buckets = 1;
@@ -1163,12 +1414,24 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   HY_TRY(b.dir.alloc(4 * (size_t{d.n_buckets} + 2)));
   d.dir = b.dir.as<uint32_t>();
   if (total) {
-    hipLaunchKernelGGL(directory_fill, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, stream, d.keys, total, d.key_min, d.shift, d.n_buckets, b.dir.as<uint32_t>(), const_cast<uint32_t*>(d.keys32));
+    hipLaunchKernelGGL(directory_fill, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, stream, d.keys, total, d.key_min, d.shift, d.n_buckets, b.dir.as<uint32_t>(), const_cast<uint32_t*>(d.keys32),
+                       d.row_ids, const_cast<uint32_t*>(d.ids32));
   } else {
     HY_HIP(hipMemsetAsync(b.dir.ptr, 0, 4 * (size_t{d.n_buckets} + 2), stream));
   }
   return HY_OK;
 }
+
+static uint32_t device_cu_count() {
+  int device = 0, cus = 256;
+  (void)hipGetDevice(&device);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  return static_cast<uint32_t>(cus);
+}
+
+constexpr uint32_t JOIN_TRACE_TILES = 1u << 15;
+static uint64_t* g_join_trace = nullptr;
+static uint32_t g_join_trace_tiles = 0;
 
 static hy_status run_join(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result, bool count_only, uint64_t* count_out) {
   if (mode == HY_JOIN_FULL_OUTER || mode == HY_JOIN_CROSS || mode > HY_JOIN_ANTI_NULL_AS_FALSE) return fail(HY_ERR_UNSUPPORTED, "JoinHash does not support join mode %u (join_hash.cpp:38-44)", mode);
@@ -1189,8 +1452,11 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
 
   // build side; its Bloom filter is applied to the probe side only when the build side is materialised first
   const bool probe_filtered = build->rows < probe->rows && !keep_nulls_probe;   // join_hash.cpp:365-381
+  // RowID -> chunk_id << 16 | chunk_offset needs both below 2^16 (every table with Hyrise's default chunk size)
+  bool pack_build_ids = !semi_anti && !count_only && build->n_chunks <= 65536;
+  for (uint32_t c = 0; c < build->n_chunks && pack_build_ids; ++c) pack_build_ids = build->host_segments[c].size <= 65536;
   BuildSide b;
-  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, b, stream));
+  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, b, stream));
 
   if (result) {
     result->radix_bits = radix_bits;
@@ -1224,19 +1490,30 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.build_rows_zero = build->rows == 0;
   a.build_bloom = probe_filtered ? b.bloom.as<uint8_t>() : nullptr;
   a.dir = b.directory;
+  a.trace = nullptr;
+  if (getenv("HY_JOIN_TRACE")) {
+    static uint64_t* trace_buffer = nullptr;
+    if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 6 * JOIN_TRACE_TILES);
+    if (n_tiles <= JOIN_TRACE_TILES) { a.trace = trace_buffer; g_join_trace = trace_buffer; g_join_trace_tiles = n_tiles; }
+  }
+  a.pack_build_ids = b.directory.ids32 ? 1 : 0;
   a.hist_elements = hist_e.as<uint32_t>();
   a.hist_pairs = hist_p.as<uint32_t>();
-  DeviceBuffer d_cache, d_uncached;
-  if (!count_only && n_tiles) {   // pass 2 follows: let pass 1 leave its lookup results behind (4 B per probe row)
-    HY_TRY(d_cache.alloc(4 * size_t{n_tiles} * JOIN_TILE));
+  DeviceBuffer d_partner, d_meta, d_uncached;
+  if (!count_only && n_tiles) {   // pass 2 follows: let pass 1 leave its lookup results behind (6 B per probe row)
+    HY_TRY(d_partner.alloc(4 * size_t{n_tiles} * JOIN_TILE));
+    HY_TRY(d_meta.alloc(2 * size_t{n_tiles} * JOIN_TILE));
     HY_TRY(d_uncached.alloc(4 * size_t{n_tiles}));
-    a.row_cache = d_cache.as<uint32_t>();
+    a.row_partner = d_partner.as<uint32_t>();
+    a.row_meta = d_meta.as<uint32_t>();
     a.tile_uncached = d_uncached.as<uint32_t>();
   }
   DeviceBuffer d_error;
   HY_TRY(d_error.alloc(256));
-  HY_HIP(hipMemsetAsync(d_error.ptr, 0, 4, stream));
+  HY_HIP(hipMemsetAsync(d_error.ptr, 0, 64, stream));
   a.error = d_error.as<uint32_t>();
+  a.n_uncached = d_error.as<uint32_t>() + 1;
+  a.xcd_tickets = d_error.as<uint32_t>() + 8;
   // Which scanned positions the host needs: the start of every partition (radix) or of every probe chunk
   // (radix_bits == 0: "partitions" are the probe chunks), plus the grand totals.
   const uint32_t n_groups = radix_bits ? partitions : probe->n_chunks;
@@ -1254,17 +1531,19 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   }
   std::vector<uint64_t> group_origin(size_t{n_groups} + 1, 0);
   uint64_t n_pairs = 0;
+  uint32_t n_uncached = 0;   // tiles with a row that has several partners
   DeviceBuffer d_index, d_origin;
   HY_TRY(d_index.alloc(8 * (size_t{n_groups} + 1)));
   HY_TRY(d_origin.alloc(8 * (size_t{n_groups} + 1)));
   if (n_tiles) {
-    hipLaunchKernelGGL(probe_count, dim3(n_tiles), dim3(JOIN_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(probe_count, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
     HY_TRY(exclusive_scan(hist_e.as<uint32_t>(), base_e.as<uint64_t>(), uint64_t{cells}, stream));
     HY_TRY(exclusive_scan(hist_p.as<uint32_t>(), base_p.as<uint64_t>(), uint64_t{cells}, stream));
     HY_HIP(hipMemcpyAsync(d_index.ptr, group_first_cell.data(), 8 * (size_t{n_groups} + 1), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(gather_u64, dim3((n_groups + 256) / 256), dim3(256), 0, stream, base_e.as<uint64_t>(), d_index.as<uint64_t>(), d_origin.as<uint64_t>(), n_groups + 1);
     HY_HIP(hipMemcpyAsync(group_origin.data(), d_origin.ptr, 8 * (size_t{n_groups} + 1), hipMemcpyDeviceToHost, stream));
     HY_HIP(hipMemcpyAsync(&n_pairs, base_p.as<uint64_t>() + cells, 8, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipMemcpyAsync(&n_uncached, a.n_uncached, 4, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
   }
   if (count_out) *count_out = n_pairs;
@@ -1309,17 +1588,29 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.probe_out = dev_probe;
   a.slice_offsets = dev_slice_offsets;
   if (n_tiles) {
-    const size_t lds_bytes = 4 * probe_emit_lds_words(partitions);
     static bool lds_raised = false;
+    static uint32_t workgroups_per_cu = 1;
     if (!lds_raised) {
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_cached), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_cached_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
       lds_raised = true;
     }
+    {
+      int per_cu = 0;
+      HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(probe_emit_cached), JOIN_THREADS, 4 * probe_emit_cached_lds_words(partitions)));
+      workgroups_per_cu = per_cu > 0 ? static_cast<uint32_t>(per_cu) : 1;
+    }
+    a.debug_plain_stores = getenv("HY_JOIN_PLAIN_STORES") ? 1 : 0;
+    if (getenv("HY_JOIN_TRACE")) fprintf(stderr, "probe_emit_cached: %u workgroups per CU, %zu LDS bytes\n", workgroups_per_cu, 4 * probe_emit_cached_lds_words(partitions));
+    if (const char* env = getenv("HY_JOIN_WGS_PER_CU")) workgroups_per_cu = static_cast<uint32_t>(atoi(env));
+    // persistent workgroups: as many as fit the device at once (a multiple of the 8 XCDs), never more than tiles
+    const uint32_t resident = device_cu_count() * workgroups_per_cu / 8 * 8;
+    const uint32_t cached_grid = std::max<uint32_t>(8, std::min<uint32_t>(resident, probe_grid(n_tiles)));
     profile_begin(stream);
-    hipLaunchKernelGGL(probe_emit<true>, dim3(n_tiles), dim3(JOIN_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL(probe_emit_cached, dim3(cached_grid), dim3(JOIN_THREADS), 4 * probe_emit_cached_lds_words(partitions), stream, a);
     profile_end(stream);
-    hipLaunchKernelGGL(probe_emit<false>, dim3(n_tiles), dim3(JOIN_THREADS), lds_bytes, stream, a);   // tiles pass 1 flagged (rare)
+    if (n_slices) hipLaunchKernelGGL(probe_cuts, dim3(static_cast<uint32_t>(n_slices)), dim3(64), 0, stream, a, d_index.as<uint64_t>(), n_groups, static_cast<uint32_t>(n_slices));
+    if (n_uncached) hipLaunchKernelGGL(probe_emit_generic, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
   }
   HY_HIP(hipMemcpyAsync(dev_slice_offsets + n_slices, &result->n_pairs, 8, hipMemcpyHostToDevice, stream));
   HY_HIP(hipGetLastError());
@@ -1358,6 +1649,15 @@ hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint
   if (!radix_bits) return fail(HY_ERR_INVALID, "hy_join_hash_radix_bits: null argument");
   *radix_bits = calculate_radix_bits(build_rows);
   return HY_OK;
+}
+
+// debug only (HY_JOIN_TRACE): the per-tile phase stamps of the last join's probe_emit; not part of the public header
+int hy_debug_join_trace(uint64_t* out, uint32_t capacity_tiles) {
+  if (!g_join_trace) return 0;
+  const uint32_t n = g_join_trace_tiles < capacity_tiles ? g_join_trace_tiles : capacity_tiles;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(out, g_join_trace, size_t{n} * 48, hipMemcpyDeviceToHost);
+  return static_cast<int>(n);
 }
 
 }  // extern "C"

@@ -20,3 +20,20 @@ for i in range(3):
     abi.check(lib.hy_join_hash(do.handle, dl.handle, abi.JOIN_INNER, C.byref(r)))
     torch.cuda.synchronize(); dt=time.perf_counter()-t
     print("join ms", dt*1e3, "pairs", r.n_pairs, "slices", r.n_slices, "radix", r.radix_bits, "rows/s %.3g" % ((data.n_orders+n)/dt))
+if os.environ.get("HY_JOIN_TRACE"):
+    lib.hy_debug_join_trace.argtypes = [C.c_void_p, C.c_uint32]; lib.hy_debug_join_trace.restype = C.c_int
+    buf = np.zeros((1 << 15, 6), dtype=np.uint64)
+    nt = lib.hy_debug_join_trace(buf.ctypes.data, 1 << 15)
+    t = buf[:nt].astype(np.int64)
+    t = t[t[:, 5] > 0]
+    d = np.diff(t, axis=1) / 100.0   # us
+    names = ["loads+count", "prefix", "ranking", "sync", "copy-out"]
+    print("probe_emit tiles", len(t), "kernel span us", (t[:, 5].max() - t[:, 0].min()) / 100.0)
+    for i, nme in enumerate(names):
+        print(f"  {nme:12s} mean {d[:, i].mean():7.2f} p50 {np.percentile(d[:, i], 50):7.2f} p90 {np.percentile(d[:, i], 90):7.2f}")
+    print("  total        mean %.2f" % ((t[:, 5] - t[:, 0]).mean() / 100.0))
+    per = (nt + 7) // 8
+    for x in range(8):   # tiles are handed out per XCD (tickets): when does each XCD finish its share?
+        sel = t[(np.arange(nt)[buf[:nt, 5] > 0] // per) == x]
+        print("  xcd %d: %5d tiles, first start %.1f last end %.1f us, tile mean %.2f" % (x, len(sel), (sel[:, 0].min() - t[:, 0].min()) / 100.0,
+              (sel[:, 5].max() - t[:, 0].min()) / 100.0, (sel[:, 5] - sel[:, 0]).mean() / 100.0))
