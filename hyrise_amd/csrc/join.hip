@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 
 namespace hy {
@@ -85,6 +86,18 @@ __device__ __forceinline__ bool bloom_test(const uint8_t* bloom, uint64_t hash) 
   return bloom[static_cast<uint32_t>(hash) & (BLOOM_BITS - 1)] != 0;
 }
 
+// The build side keeps its keys and RowIDs as narrow as the join allows: int32 columns as 32-bit keys (their unsigned
+// order is the unsigned order of the sign-extended 64-bit keys), RowIDs packed into 32 bits when every chunk id and chunk
+// offset of the build table is below 2^16 (Hyrise's default chunk size: always) -- half the bytes to write, sort and read.
+template <bool KEY32> struct BuildKey { using type = uint64_t; };
+template <> struct BuildKey<true> { using type = uint32_t; };
+template <bool ID32> struct BuildRow { using type = hy_row_id; };
+template <> struct BuildRow<true> { using type = uint32_t; };
+template <bool ID32> __device__ __forceinline__ typename BuildRow<ID32>::type make_build_row(uint32_t chunk, uint32_t offset) {
+  if constexpr (ID32) return chunk << 16 | offset;
+  else return hy_row_id{chunk, offset};
+}
+
 // ---- build side: materialise -------------------------------------------------------------------------------------------
 // One workgroup per 8192-row slice; rows are visited as row = k * 256 + tid (k = 0..31) so that compaction order is
 // row order.  MODE 0 counts, MODE 1 writes.
@@ -97,12 +110,13 @@ struct MaterializeArgs {
   uint8_t* bloom_out;             // may be nullptr
   uint32_t* slice_counts;         // [n_slices]
   const uint64_t* slice_offsets;  // MODE 1
-  uint64_t* keys;                 // MODE 1: sign-extended key bits
-  hy_row_id* row_ids;             // MODE 1
+  void* keys;                     // MODE 1: uint32_t (int32 columns: KEY32) or uint64_t sign-extended key bits
+  void* row_ids;                  // MODE 1: uint32_t chunk_id << 16 | chunk_offset (ID32) or hy_row_id
   uint32_t* any_null;             // set to 1 if a NULL was materialised (AntiNullAsTrue early-out)
+  const uint64_t* row_base;       // dense: [n_chunks + 1] first row of every chunk
 };
 
-template <int MODE>
+template <int MODE, bool KEY32, bool ID32>
 __global__ __launch_bounds__(256) void join_materialize(MaterializeArgs a) {
   __shared__ uint32_t s_count[32][4];
   __shared__ uint32_t s_offset[32][4];
@@ -140,8 +154,8 @@ __global__ __launch_bounds__(256) void join_materialize(MaterializeArgs a) {
       int64_t key;
       const bool is_null = column_key(a.segments, slice.chunk, slice.row_begin + r, &key);
       const uint64_t pos = base + s_offset[k][wave] + __popcll(ballot & ((1ull << lane) - 1));
-      a.keys[pos] = static_cast<uint64_t>(key);
-      a.row_ids[pos] = hy_row_id{slice.chunk, slice.row_begin + r};
+      static_cast<typename BuildKey<KEY32>::type*>(a.keys)[pos] = static_cast<typename BuildKey<KEY32>::type>(key);
+      static_cast<typename BuildRow<ID32>::type*>(a.row_ids)[pos] = make_build_row<ID32>(slice.chunk, slice.row_begin + r);
       if (is_null && a.any_null) *a.any_null = 1;
       if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(key) & (BLOOM_BITS - 1)] = 1;
     }
@@ -150,11 +164,12 @@ __global__ __launch_bounds__(256) void join_materialize(MaterializeArgs a) {
 
 // Build columns that cannot hold NULLs (value / FrameOfReference segments without a null vector): every row is
 // materialised at its own row number -- no counting, no ballots, eight rows of a lane in flight at a time.
+template <bool KEY32, bool ID32>
 __global__ __launch_bounds__(256) void join_materialize_dense(MaterializeArgs a) {
   const uint32_t tid = threadIdx.x;
   const Slice slice = a.slices[blockIdx.x];
   const DevSegment s = a.segments[slice.chunk];
-  const uint64_t base = a.slice_offsets[blockIdx.x];
+  const uint64_t base = a.row_base[slice.chunk] + slice.row_begin;   // every row is materialised: offsets are row numbers
   constexpr uint32_t BATCH = 8;
 #pragma unroll 1
   for (uint32_t block = 0; block < SLICE_ROWS / 256 / BATCH; ++block) {
@@ -175,8 +190,8 @@ __global__ __launch_bounds__(256) void join_materialize_dense(MaterializeArgs a)
 #pragma unroll
     for (uint32_t i = 0; i < BATCH; ++i) {
       if (r[i] >= slice.row_count) continue;
-      a.keys[base + r[i]] = static_cast<uint64_t>(key[i]);
-      a.row_ids[base + r[i]] = hy_row_id{slice.chunk, slice.row_begin + r[i]};
+      static_cast<typename BuildKey<KEY32>::type*>(a.keys)[base + r[i]] = static_cast<typename BuildKey<KEY32>::type>(key[i]);
+      static_cast<typename BuildRow<ID32>::type*>(a.row_ids)[base + r[i]] = make_build_row<ID32>(slice.chunk, slice.row_begin + r[i]);
       if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(key[i]) & (BLOOM_BITS - 1)] = 1;
     }
   }
@@ -204,7 +219,8 @@ __global__ __launch_bounds__(1024) void scan_counts(const uint32_t* counts, uint
 
 // keys sorted ascending (unsigned bit order)?  Also OR-reduces all keys (significant bytes for the radix sort):
 // one atomic per 1024-thread workgroup, at most 1024 workgroups (atomics on one word retire at ~88 per microsecond).
-__global__ __launch_bounds__(1024) void check_sorted(const uint64_t* keys, uint64_t n, uint32_t* unsorted, unsigned long long* key_or) {
+template <typename K>
+__global__ __launch_bounds__(1024) void check_sorted(const K* keys, uint64_t n, uint32_t* unsorted, unsigned long long* key_or) {
   __shared__ uint64_t s_bits[16];
   __shared__ uint32_t s_unsorted;
   if (threadIdx.x == 0) s_unsorted = 0;
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(1024) void check_sorted(const uint64_t* keys, uint6
   uint64_t bits = 0;
   bool unsorted_here = false;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-    const uint64_t key = keys[i];
+    const K key = keys[i];
     bits |= key;
     if (i + 1 < n && key > keys[i + 1]) unsorted_here = true;
   }
@@ -232,7 +248,8 @@ __global__ __launch_bounds__(1024) void check_sorted(const uint64_t* keys, uint6
 // ---- stable LSD radix sort of (key, RowID) pairs, 8 bits per pass ---------------------------------------------------
 // histogram: [256][tiles] (digit-major so that one exclusive scan over the flat array yields scatter bases)
 constexpr uint32_t SORT_TILE = 2048;
-__global__ __launch_bounds__(256) void sort_histogram(const uint64_t* keys, uint64_t n, uint32_t shift, uint32_t* hist, uint32_t n_tiles) {
+template <typename K>
+__global__ __launch_bounds__(256) void sort_histogram(const K* keys, uint64_t n, uint32_t shift, uint32_t* hist, uint32_t n_tiles) {
   __shared__ uint32_t s_hist[256];
   const uint32_t tid = threadIdx.x;
   s_hist[tid] = 0;
@@ -289,7 +306,8 @@ __device__ __forceinline__ uint64_t match_any8(uint32_t digit, bool valid) {
   return peers;   // (of a lane that is not valid: meaningless)
 }
 
-__global__ __launch_bounds__(256) void sort_scatter(const uint64_t* keys_in, const hy_row_id* rows_in, uint64_t* keys_out, hy_row_id* rows_out,
+template <typename K, typename R>
+__global__ __launch_bounds__(256) void sort_scatter(const K* keys_in, const R* rows_in, K* keys_out, R* rows_out,
                                                     uint64_t n, uint32_t shift, const uint64_t* bases, uint32_t n_tiles) {
   __shared__ uint32_t s_wave_hist[4][256];   // per-wave digit counts, then per-wave running positions (relative to the tile's base)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -348,8 +366,11 @@ __global__ __launch_bounds__(256) void scan_block_sums(const uint32_t* in, uint6
   if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 }
 
-__global__ __launch_bounds__(1024) void scan_block_offsets(uint64_t* block_sums, uint32_t n_blocks, uint64_t* total_out) {
+// `restart`: index of the block at which the running sum starts again from zero (two arrays scanned by one set of
+// launches, the second one laid out from a block boundary), or 0xFFFFFFFF.  *total_out = the (last) segment's total.
+__global__ __launch_bounds__(1024) void scan_block_offsets(uint64_t* block_sums, uint32_t n_blocks, uint32_t restart, uint64_t* total_out) {
   __shared__ uint64_t s_partial[1024];
+  __shared__ uint64_t s_first_segment;
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (n_blocks + 1023) / 1024;
   const uint32_t begin = tid * per < n_blocks ? tid * per : n_blocks, end = begin + per < n_blocks ? begin + per : n_blocks;
@@ -360,11 +381,17 @@ __global__ __launch_bounds__(1024) void scan_block_offsets(uint64_t* block_sums,
   if (tid == 0) {
     uint64_t run = 0;
     for (uint32_t i = 0; i < 1024; ++i) { const uint64_t v = s_partial[i]; s_partial[i] = run; run += v; }
-    *total_out = run;
+    *total_out = run;   // (with a restart: corrected below)
   }
   __syncthreads();
   uint64_t run = s_partial[tid];
   for (uint32_t i = begin; i < end; ++i) { const uint64_t v = block_sums[i]; block_sums[i] = run; run += v; }
+  if (restart >= n_blocks) return;
+  __syncthreads();
+  if (tid == 0) s_first_segment = block_sums[restart];   // everything in front of the second segment
+  __syncthreads();
+  for (uint32_t i = begin > restart ? begin : restart; i < end; ++i) block_sums[i] -= s_first_segment;
+  if (tid == 0) *total_out -= s_first_segment;
 }
 
 __global__ __launch_bounds__(256) void scan_blocks(const uint32_t* in, uint64_t n, const uint64_t* block_offsets, uint64_t* out) {
@@ -403,10 +430,10 @@ __global__ void gather_u64(const uint64_t* src, const uint64_t* index, uint64_t*
 
 // ---- bucket directory over the sorted build keys ------------------------------------------------------------------------
 struct Directory {
-  const uint64_t* keys;      // sorted (unsigned order of the sign-extended bits)
-  const uint32_t* keys32;    // int32 build columns: the low halves of `keys` (same order), padded by four entries; else nullptr
-  const hy_row_id* row_ids;  // same order
-  const uint32_t* ids32;     // row_ids packed as chunk_id << 16 | chunk_offset when every build RowID fits (probe_emit_cached), else nullptr
+  const uint64_t* keys;      // sorted (unsigned order of the sign-extended bits); nullptr when the keys are 32-bit
+  const uint32_t* keys32;    // int32 build columns instead: the keys' low halves (same order), padded by four entries
+  const hy_row_id* row_ids;  // same order; nullptr when the RowIDs are packed
+  const uint32_t* ids32;     // ... chunk_id << 16 | chunk_offset instead (every build RowID fits)
   const uint32_t* dir;       // [n_buckets + 1] first position of every bucket
   uint64_t n;
   uint64_t key_min;
@@ -415,20 +442,24 @@ struct Directory {
   uint32_t n_buckets;
 };
 
-__global__ void directory_fill(const uint64_t* keys, uint64_t n, uint64_t key_min, uint32_t shift, uint32_t n_buckets, uint32_t* dir, uint32_t* keys32,
-                               const hy_row_id* row_ids, uint32_t* ids32) {
+__device__ __forceinline__ uint64_t directory_key(const Directory& d, uint32_t i) {
+  return d.keys32 ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(d.keys32[i]))) : d.keys[i];
+}
+__device__ __forceinline__ hy_row_id directory_row_id(const Directory& d, uint32_t i) {
+  if (d.ids32) { const uint32_t id = d.ids32[i]; return hy_row_id{id >> 16, id & 0xFFFFu}; }
+  return d.row_ids[i];
+}
+template <typename K> __device__ __forceinline__ uint64_t key_bits(K key) {   // the 64-bit (sign-extended) key of a stored build key
+  if constexpr (sizeof(K) == 4) return static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(key)));
+  else return key;
+}
+
+template <typename K>
+__global__ void directory_fill(const K* keys, uint64_t n, uint64_t key_min, uint32_t shift, uint32_t n_buckets, uint32_t* dir) {
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (ids32) {
-    const hy_row_id id = row_ids[i];
-    ids32[i] = id.chunk_id << 16 | id.chunk_offset;
-  }
-  if (keys32) {   // int32 build columns: the low halves, same order, padded by four entries
-    keys32[i] = static_cast<uint32_t>(keys[i]);
-    if (i + 1 == n) { keys32[n] = 0; keys32[n + 1] = 0; keys32[n + 2] = 0; keys32[n + 3] = 0; }
-  }
-  const uint64_t bucket = (keys[i] - key_min) >> shift;
-  const int64_t previous = i == 0 ? -1 : static_cast<int64_t>((keys[i - 1] - key_min) >> shift);
+  const uint64_t bucket = (key_bits(keys[i]) - key_min) >> shift;
+  const int64_t previous = i == 0 ? -1 : static_cast<int64_t>((key_bits(keys[i - 1]) - key_min) >> shift);
   for (int64_t b = previous + 1; b <= static_cast<int64_t>(bucket); ++b) dir[b] = static_cast<uint32_t>(i);
   if (i + 1 == n) {
     for (uint64_t b = bucket + 1; b <= n_buckets; ++b) dir[b] = static_cast<uint32_t>(n);
@@ -445,8 +476,8 @@ __device__ __forceinline__ void directory_lookup(const Directory& d, uint64_t ke
   uint32_t lo = d.dir[bucket], hi = d.dir[bucket + 1];
   if (hi - lo <= 4) {
     const uint32_t last = static_cast<uint32_t>(d.n - 1);
-    const uint64_t k0 = d.keys[lo < last ? lo : last], k1 = d.keys[lo + 1 < last ? lo + 1 : last], k2 = d.keys[lo + 2 < last ? lo + 2 : last],
-                   k3 = d.keys[lo + 3 < last ? lo + 3 : last];
+    const uint64_t k0 = directory_key(d, lo < last ? lo : last), k1 = directory_key(d, lo + 1 < last ? lo + 1 : last), k2 = directory_key(d, lo + 2 < last ? lo + 2 : last),
+                   k3 = directory_key(d, lo + 3 < last ? lo + 3 : last);
     const uint32_t size = hi - lo;
     const uint32_t equal = (size > 0 && k0 == key ? 1u : 0u) | (size > 1 && k1 == key ? 2u : 0u) | (size > 2 && k2 == key ? 4u : 0u) | (size > 3 && k3 == key ? 8u : 0u);
     if (equal) {   // equal keys are adjacent
@@ -458,16 +489,16 @@ __device__ __forceinline__ void directory_lookup(const Directory& d, uint64_t ke
   const uint32_t bucket_end = hi;
   while (lo < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
-    if (d.keys[mid] < key) lo = mid + 1; else hi = mid;
+    if (directory_key(d, mid) < key) lo = mid + 1; else hi = mid;
   }
-  if (lo == bucket_end || d.keys[lo] != key) return;
+  if (lo == bucket_end || directory_key(d, lo) != key) return;
   *start = lo;
   uint32_t end = lo + 1;
-  if (end < bucket_end && d.keys[end] == key) {   // duplicates: upper bound inside the bucket
+  if (end < bucket_end && directory_key(d, end) == key) {   // duplicates: upper bound inside the bucket
     uint32_t l = end, h = bucket_end;
     while (l < h) {
       const uint32_t mid = l + (h - l) / 2;
-      if (d.keys[mid] <= key) l = mid + 1; else h = mid;
+      if (directory_key(d, mid) <= key) l = mid + 1; else h = mid;
     }
     end = l;
   }
@@ -475,6 +506,10 @@ __device__ __forceinline__ void directory_lookup(const Directory& d, uint64_t ke
 }
 
 // ---- probe side ------------------------------------------------------------------------------------------------------
+struct JoinPlan {   // written by plan_output between the probe passes: what pass 2's kernels need to know
+  uint32_t fits, n_slices;   // the result buffers hold the pairs and PosLists | number of output PosLists
+};
+
 struct ProbeArgs {
   const DevSegment* segments;     // probe column
   const Slice* slices;            // 8192-row slices; a tile is a quarter of a slice
@@ -500,6 +535,7 @@ struct ProbeArgs {
   uint32_t* tile_uncached;        // [n_tiles] set by pass 1 when a tile has a row with several partners (pass 2 evaluates it again)
   uint32_t* n_uncached;           // number of such tiles
   uint32_t* xcd_tickets;          // [8] probe_emit_cached: next tile of every XCD's share
+  const JoinPlan* plan;           // pass 2: does the result fit its buffers, how many output PosLists
   uint32_t* error;                // set when a probe row matches >= 2^22 build rows (the staging record cannot hold it)
   uint64_t* trace;                // debug (HY_JOIN_TRACE): 6 wall-clock stamps per probe_emit tile, else nullptr
   uint32_t debug_plain_stores;
@@ -886,6 +922,7 @@ __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6)
   // end), two tickets ahead -- the next tile's loads are in flight while this one is ranked.
   const uint32_t per_xcd = (a.n_tiles + 7) / 8, xcd = blockIdx.x & 7;
   const uint32_t xcd_begin = xcd * per_xcd, xcd_end = (xcd + 1) * per_xcd < a.n_tiles ? (xcd + 1) * per_xcd : a.n_tiles;
+  if (!a.plan->fits) return;
   if (tid == 0) {
     s_scratch[JOIN_WAVES] = atomicAdd(a.xcd_tickets + xcd, 1u);
     s_scratch[JOIN_WAVES + 1] = atomicAdd(a.xcd_tickets + xcd, 1u);
@@ -1019,15 +1056,17 @@ __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6)
 // group g (radix partition, or probe chunk without radix partitioning) starts at the pair index where the group's
 // element number (s - first PosList of g) * 131 070 stands.  One wave per PosList: binary search for the cell holding that
 // element in the scanned element counts, then a walk over the tile's 16-bit row words.
-__global__ __launch_bounds__(64) void probe_cuts(ProbeArgs a, const uint64_t* group_first_cell, uint32_t n_groups, uint32_t n_slices) {
+__global__ __launch_bounds__(64) void probe_cuts(ProbeArgs a, const uint64_t* group_first_cell, uint32_t n_groups) {
   const uint32_t slice = blockIdx.x, lane = threadIdx.x;
+  if (!a.plan->fits || slice >= a.plan->n_slices) return;
   uint32_t lo = 0, hi = n_groups;   // last group whose first PosList is <= slice
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) / 2;
     if (a.partition_slice_base[mid] <= slice) lo = mid; else hi = mid;
   }
   const uint32_t group = lo;
-  const uint64_t first_cell = group_first_cell[group], end_cell = group_first_cell[group + 1];
+  const uint64_t first_cell = group_first_cell ? group_first_cell[group] : static_cast<uint64_t>(group) * a.n_tiles;
+  const uint64_t end_cell = group_first_cell ? group_first_cell[group + 1] : static_cast<uint64_t>(group + 1) * a.n_tiles;
   const uint64_t target = a.base_elements[first_cell] + static_cast<uint64_t>(slice - a.partition_slice_base[group]) * PROBE_SIZE_PER_CHUNK;
   uint64_t cell = first_cell, cell_end = end_cell;   // last cell of the group whose first element is <= target: it holds the element
   while (cell_end - cell > 1) {
@@ -1074,7 +1113,7 @@ __host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
 // duplicates) write their pairs directly.  One workgroup per tile; tiles probe_emit_cached handles return at once.
 __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) {
   const uint32_t tile = block_tile(a.n_tiles);
-  if (tile >= a.n_tiles || a.tile_uncached[tile] == 0) return;
+  if (tile >= a.n_tiles || a.tile_uncached[tile] == 0 || !a.plan->fits) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
   const uint32_t partitions = 1u << a.radix_bits;
   uint32_t* s_stage = join_smem;                                     // [JOIN_STAGE][2] row | partition << 12 | null << 21 , build position
@@ -1208,7 +1247,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
 #pragma unroll 1
           for (uint32_t t = 0; t < emit; ++t) {
             a.probe_out[pair_pos + t] = probe_id;
-            if (a.build_out) a.build_out[pair_pos + t] = null_partner ? null_row : a.dir.row_ids[start + t];
+            if (a.build_out) a.build_out[pair_pos + t] = null_partner ? null_row : directory_row_id(a.dir, start + t);
           }
         }
       }
@@ -1232,7 +1271,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
     __builtin_nontemporal_store(probe_id, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
     if (a.build_out) {
       u32x2_t build_id = {0xFFFFFFFFu, 0xFFFFFFFFu};
-      if (!(tag & (1u << 21))) build_id = reinterpret_cast<const u32x2_t*>(a.dir.row_ids)[position];
+      if (!(tag & (1u << 21))) { const hy_row_id id = directory_row_id(a.dir, position); build_id = u32x2_t{id.chunk_id, id.chunk_offset}; }
       __builtin_nontemporal_store(build_id, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
     }
   }
@@ -1247,10 +1286,11 @@ static uint32_t calculate_radix_bits(uint64_t build_rows) {   // join_hash.cpp:7
   return static_cast<uint32_t>(std::min<size_t>(8, static_cast<size_t>(std::ceil(std::log2(cluster_count)))));
 }
 
-static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t stream);
-
-// out[0..n) = exclusive prefix sums of in, out[n] = total
-static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t stream) {
+// out[0..n) = exclusive prefix sums of in, out[n] = total.  With `second_at` (a multiple of SCAN_BLOCK): in[second_at..n)
+// is a second array with its own sums (out[second_at + i]); the first array must end with at least one zero so that
+// out[its length] is its total.  The block-sum buffer goes back to the pool of this thread's stream on return: whoever
+// gets it next runs behind these kernels.
+static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, hipStream_t stream, uint64_t second_at = ~0ull) {
   const uint32_t n_blocks = static_cast<uint32_t>((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   if (n_blocks == 0) {
     HY_HIP(hipMemsetAsync(out, 0, 8, stream));
@@ -1258,21 +1298,113 @@ static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, h
   }
   DeviceBuffer sums;
   HY_TRY(sums.alloc(8 * size_t{n_blocks}));
+  const uint32_t restart = second_at == ~0ull ? 0xFFFFFFFFu : static_cast<uint32_t>(second_at / SCAN_BLOCK);
   hipLaunchKernelGGL(scan_block_sums, dim3(n_blocks), dim3(256), 0, stream, in, n, sums.as<uint64_t>());
-  hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(1024), 0, stream, sums.as<uint64_t>(), n_blocks, out + n);
+  hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(1024), 0, stream, sums.as<uint64_t>(), n_blocks, restart, out + n);
   hipLaunchKernelGGL(scan_blocks, dim3(n_blocks), dim3(256), 0, stream, in, n, sums.as<uint64_t>(), out);
-  HY_HIP(hipStreamSynchronize(stream));   // `sums` is freed on return
   return HY_OK;
 }
 
 static bool is_integer_column(const hy_column* c) { return (c->data_type == HY_TYPE_INT || c->data_type == HY_TYPE_LONG) && !c->is_mvcc && !(c->ref && c->ref->is_mvcc); }
 
+// ---- what the host learns from the device during a join ----------------------------------------------------------------
+// A pinned, device-mapped block per thread: small kernels store into it, the host reads it after a stream synchronise.
+// (A hipMemcpyAsync into pageable memory is a blit kernel plus a host round trip each: ~20 us of idle GPU per value.)
+struct JoinMailbox {
+  uint64_t key_or, first_key, last_key;   // build side
+  uint32_t unsorted, any_null;
+  uint64_t n_pairs;                       // after pass 1
+  uint32_t n_slices, n_uncached, fits;    // fits: the result's capacities hold n_pairs / n_slices
+  uint32_t error;                         // pass 2: a probe row with >= 2^22 partners
+};
+static thread_local JoinMailbox* t_mailbox = nullptr;      // host address
+static thread_local JoinMailbox* t_mailbox_dev = nullptr;  // device address of the same memory
+
+static hy_status join_mailbox(JoinMailbox** host, JoinMailbox** device) {
+  if (!t_mailbox) {
+    HY_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_mailbox), sizeof(JoinMailbox), hipHostMallocMapped));
+    HY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_mailbox_dev), t_mailbox, 0));
+  }
+  std::memset(t_mailbox, 0, sizeof(JoinMailbox));
+  *host = t_mailbox;
+  *device = t_mailbox_dev;
+  return HY_OK;
+}
+
+// flags: [0] unsorted, [2] any NULL materialised, [4..5] OR of all keys (prepare_build)
+template <typename K>
+__global__ void publish_build_flags(const uint32_t* flags, const K* keys, uint64_t n, JoinMailbox* mailbox) {
+  mailbox->unsorted = flags[0];
+  mailbox->any_null = flags[2];
+  mailbox->key_or = *reinterpret_cast<const uint64_t*>(flags + 4);
+  mailbox->first_key = n ? key_bits(keys[0]) : 0;
+  mailbox->last_key = n ? key_bits(keys[n - 1]) : 0;
+  __threadfence_system();
+}
+
+// Between the two probe passes, on the device (the host only reads the outcome at the end of the join, or -- host-memory
+// results -- before it allocates the staging buffers): where every group's elements start (group = radix partition, or
+// probe chunk without radix partitioning), the first output PosList of every group (a new PosList every 131 070
+// materialised probe elements of a group, join_hash_steps.hpp:655-660), the totals, whether the result buffers hold them.
+__global__ __launch_bounds__(256) void plan_output(const uint64_t* base_elements, const uint64_t* base_pairs, const uint64_t* group_first_cell, uint32_t n_groups,
+                                                   uint32_t n_tiles, uint64_t cells, uint64_t capacity, uint32_t slice_capacity, uint64_t* origin, uint32_t* slice_base,
+                                                   uint64_t* slice_offsets, const uint32_t* n_uncached, JoinPlan* plan, JoinMailbox* mailbox) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_running;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_running = 0;
+  __syncthreads();
+  for (uint32_t begin = 0; begin < n_groups; begin += 256) {
+    const uint32_t g = begin + tid;
+    uint32_t slices = 0;
+    if (g < n_groups) {
+      const uint64_t first = group_first_cell ? group_first_cell[g] : static_cast<uint64_t>(g) * n_tiles;
+      const uint64_t next = group_first_cell ? group_first_cell[g + 1] : static_cast<uint64_t>(g + 1) * n_tiles;
+      const uint64_t from = base_elements[first], to = base_elements[next];
+      origin[g] = from;
+      if (g + 1 == n_groups) origin[n_groups] = to;
+      slices = static_cast<uint32_t>((to - from + PROBE_SIZE_PER_CHUNK - 1) / PROBE_SIZE_PER_CHUNK);
+    }
+    const uint32_t inclusive = join_wave_inclusive_scan(slices);
+    if (lane == 63) s_wave[wave] = inclusive;
+    __syncthreads();
+    uint32_t before = s_running;
+    for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+    if (g < n_groups) slice_base[g] = before + inclusive - slices;
+    __syncthreads();
+    if (tid == 255) s_running = before + inclusive;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint64_t n_pairs = base_pairs[cells];
+    const uint32_t n_slices = s_running;
+    const uint32_t fits = n_pairs <= capacity && n_slices <= slice_capacity ? 1u : 0u;
+    if (n_groups == 0) origin[0] = 0;
+    plan->fits = fits;
+    plan->n_slices = n_slices;
+    if (fits && slice_offsets) slice_offsets[n_slices] = n_pairs;
+    mailbox->n_pairs = n_pairs;
+    mailbox->n_slices = n_slices;
+    mailbox->n_uncached = n_uncached ? *n_uncached : 0;
+    mailbox->fits = fits;
+    __threadfence_system();
+  }
+}
+
+// HY_JOIN_TIMING=1: host-side wall clock at the join's synchronisation points (debug aid)
+struct StageClock {
+  bool on = getenv("HY_JOIN_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (on) fprintf(stderr, "  join %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - start).count());
+  }
+};
+
 struct BuildSide {
-  DeviceBuffer keys, rows, keys_tmp, rows_tmp, keys32, ids32, dir, bloom, flags;
+  DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags;
   uint64_t n = 0;
   Directory directory{};
   bool any_null = false;
-  std::vector<uint64_t> host_slice_offsets;   // source of an asynchronous upload: lives as long as the join
 };
 
 // Materialise + (sort) + directory.  `bloom_in` (device) filters the build side (no observable effect, kept for the
@@ -1306,91 +1438,106 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     dense = (seg.encoding == HY_ENC_UNENCODED || seg.encoding == HY_ENC_FRAME_OF_REFERENCE) && seg.nulls == nullptr;
   }
   if (n_slices && dense) {
-    std::vector<uint64_t>& slice_offsets = b.host_slice_offsets;
-    slice_offsets.clear();
-    slice_offsets.reserve(size_t{n_slices} + 1);
-    for (uint32_t c = 0; c < build->n_chunks; ++c) {
-      uint32_t begin = 0;
-      do {   // the same cuts as hy_column_create
-        slice_offsets.push_back(build->row_base[c] + begin);
-        begin += SLICE_ROWS;
-      } while (begin < build->host_segments[c].size);
-    }
-    slice_offsets.push_back(build->rows);
-    if (slice_offsets.size() != size_t{n_slices} + 1) return fail(HY_ERR_DEVICE, "slice table mismatch (internal error)");
-    HY_HIP(hipMemcpyAsync(offsets.ptr, slice_offsets.data(), 8 * slice_offsets.size(), hipMemcpyHostToDevice, stream));
+    m.row_base = build->d_row_base;
     total = build->rows;
   } else if (n_slices) {
-    hipLaunchKernelGGL(join_materialize<0>, dim3(n_slices), dim3(256), 0, stream, m);
+    hipLaunchKernelGGL((join_materialize<0, false, false>), dim3(n_slices), dim3(256), 0, stream, m);
     hipLaunchKernelGGL(scan_counts, dim3(1), dim3(1024), 0, stream, counts.as<uint32_t>(), offsets.as<uint64_t>(), n_slices);
     HY_HIP(hipMemcpyAsync(&total, offsets.as<uint64_t>() + n_slices, 8, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
   }
   b.n = total;
+  const bool key32 = build->data_type == HY_TYPE_INT, id32 = want_ids32;
+  const size_t key_bytes = key32 ? 4 : 8, row_bytes = id32 ? 4 : 8;
   uint64_t first_key = 0, last_key = 0;
   bool keys_were_sorted = false;
-  HY_TRY(b.keys.alloc(8 * total));
-  HY_TRY(b.rows.alloc(8 * total));
+  HY_TRY(b.keys.alloc(key_bytes * (total + 4)));   // (32-bit keys: four entries of padding for the probe's 16-byte loads)
+  HY_TRY(b.rows.alloc(row_bytes * total));
+  // one instantiation per (key width, RowID width)
+#define HY_JOIN_BUILD_KERNEL(KERNEL, GRID, BLOCK, ...)                                                                  \
+  do {                                                                                                                  \
+    if (key32 && id32) hipLaunchKernelGGL((KERNEL<true, true>), GRID, BLOCK, 0, stream, __VA_ARGS__);                 \
+    else if (key32) hipLaunchKernelGGL((KERNEL<true, false>), GRID, BLOCK, 0, stream, __VA_ARGS__);                   \
+    else if (id32) hipLaunchKernelGGL((KERNEL<false, true>), GRID, BLOCK, 0, stream, __VA_ARGS__);                    \
+    else hipLaunchKernelGGL((KERNEL<false, false>), GRID, BLOCK, 0, stream, __VA_ARGS__);                             \
+  } while (0)
   if (total) {
     m.slice_offsets = offsets.as<uint64_t>();
-    m.keys = b.keys.as<uint64_t>();
-    m.row_ids = b.rows.as<hy_row_id>();
-    if (dense) hipLaunchKernelGGL(join_materialize_dense, dim3(n_slices), dim3(256), 0, stream, m);
-    else hipLaunchKernelGGL(join_materialize<1>, dim3(n_slices), dim3(256), 0, stream, m);
+    m.keys = b.keys.ptr;
+    m.row_ids = b.rows.ptr;
+    if (dense) {
+      HY_JOIN_BUILD_KERNEL(join_materialize_dense, dim3(n_slices), dim3(256), m);
+    } else if (key32 && id32) {
+      hipLaunchKernelGGL((join_materialize<1, true, true>), dim3(n_slices), dim3(256), 0, stream, m);
+    } else if (key32) {
+      hipLaunchKernelGGL((join_materialize<1, true, false>), dim3(n_slices), dim3(256), 0, stream, m);
+    } else if (id32) {
+      hipLaunchKernelGGL((join_materialize<1, false, true>), dim3(n_slices), dim3(256), 0, stream, m);
+    } else {
+      hipLaunchKernelGGL((join_materialize<1, false, false>), dim3(n_slices), dim3(256), 0, stream, m);
+    }
+    if (key32) HY_HIP(hipMemsetAsync(b.keys.as<uint32_t>() + total, 0, 16, stream));
     uint32_t* unsorted = b.flags.as<uint32_t>();
     unsigned long long* key_or = reinterpret_cast<unsigned long long*>(b.flags.as<uint32_t>() + 4);
-    hipLaunchKernelGGL(check_sorted, dim3(static_cast<uint32_t>(std::min<uint64_t>((total + 1023) / 1024, 1024))), dim3(1024), 0, stream, b.keys.as<uint64_t>(), total, unsorted, key_or);
-    uint32_t host_flags[8];
-    HY_HIP(hipMemcpyAsync(host_flags, b.flags.ptr, 32, hipMemcpyDeviceToHost, stream));
-    HY_HIP(hipMemcpyAsync(&first_key, b.keys.ptr, 8, hipMemcpyDeviceToHost, stream));   // min / max if the keys are already sorted
-    HY_HIP(hipMemcpyAsync(&last_key, b.keys.as<uint64_t>() + (total - 1), 8, hipMemcpyDeviceToHost, stream));
+    JoinMailbox* mailbox = nullptr;
+    JoinMailbox* mailbox_dev = nullptr;
+    HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
+    const dim3 check_grid(static_cast<uint32_t>(std::min<uint64_t>((total + 1023) / 1024, 1024)));
+    if (key32) {
+      hipLaunchKernelGGL(check_sorted<uint32_t>, check_grid, dim3(1024), 0, stream, b.keys.as<uint32_t>(), total, unsorted, key_or);
+      hipLaunchKernelGGL(publish_build_flags<uint32_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint32_t>(), total, mailbox_dev);
+    } else {
+      hipLaunchKernelGGL(check_sorted<uint64_t>, check_grid, dim3(1024), 0, stream, b.keys.as<uint64_t>(), total, unsorted, key_or);
+      hipLaunchKernelGGL(publish_build_flags<uint64_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint64_t>(), total, mailbox_dev);
+    }
     HY_HIP(hipStreamSynchronize(stream));
-    b.any_null = host_flags[2] != 0;
-    keys_were_sorted = host_flags[0] == 0;
-    if (host_flags[0]) {   // not sorted: stable LSD radix sort, only over the bytes that are not constant zero
-      uint64_t key_bits;
-      std::memcpy(&key_bits, &host_flags[4], 8);
-      HY_TRY(b.keys_tmp.alloc(8 * total));
-      HY_TRY(b.rows_tmp.alloc(8 * total));
+    b.any_null = mailbox->any_null != 0;
+    keys_were_sorted = mailbox->unsorted == 0;
+    first_key = mailbox->first_key;   // min / max if the keys are already sorted
+    last_key = mailbox->last_key;
+    if (mailbox->unsorted) {   // not sorted: stable LSD radix sort, only over the bytes that are not constant zero
+      const uint64_t key_bits_or = mailbox->key_or;
+      HY_TRY(b.keys_tmp.alloc(key_bytes * (total + 4)));
+      HY_TRY(b.rows_tmp.alloc(row_bytes * total));
       const uint32_t n_tiles = static_cast<uint32_t>((total + SORT_TILE - 1) / SORT_TILE);
       DeviceBuffer hist, bases;
       HY_TRY(hist.alloc(4 * size_t{256} * n_tiles));
       HY_TRY(bases.alloc(8 * (size_t{256} * n_tiles + 1)));
-      uint64_t* src_keys = b.keys.as<uint64_t>();
-      hy_row_id* src_rows = b.rows.as<hy_row_id>();
-      uint64_t* dst_keys = b.keys_tmp.as<uint64_t>();
-      hy_row_id* dst_rows = b.rows_tmp.as<hy_row_id>();
-      for (uint32_t shift = 0; shift < 64; shift += 8) {
-        if (((key_bits >> shift) & 0xFF) == 0 && !(key_bits >> 63)) continue;   // byte is zero in every key
-        hipLaunchKernelGGL(sort_histogram, dim3(n_tiles), dim3(256), 0, stream, src_keys, total, shift, hist.as<uint32_t>(), n_tiles);
+      void* src_keys = b.keys.ptr;
+      void* src_rows = b.rows.ptr;
+      void* dst_keys = b.keys_tmp.ptr;
+      void* dst_rows = b.rows_tmp.ptr;
+      for (uint32_t shift = 0; shift < (key32 ? 32u : 64u); shift += 8) {
+        // a byte that is zero in every key does not move anything (64-bit keys: unless one is negative -- then the sign
+        // extension is part of the order)
+        if (((key_bits_or >> shift) & 0xFF) == 0 && (key32 || !(key_bits_or >> 63))) continue;
+        if (key32) hipLaunchKernelGGL(sort_histogram<uint32_t>, dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint32_t*>(src_keys), total, shift, hist.as<uint32_t>(), n_tiles);
+        else hipLaunchKernelGGL(sort_histogram<uint64_t>, dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint64_t*>(src_keys), total, shift, hist.as<uint32_t>(), n_tiles);
         HY_TRY(exclusive_scan(hist.as<uint32_t>(), bases.as<uint64_t>(), uint64_t{256} * n_tiles, stream));
-        hipLaunchKernelGGL(sort_scatter, dim3(n_tiles), dim3(256), 0, stream, src_keys, src_rows, dst_keys, dst_rows, total, shift, bases.as<uint64_t>(), n_tiles);
+        if (key32 && id32) hipLaunchKernelGGL((sort_scatter<uint32_t, uint32_t>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint32_t*>(src_keys), static_cast<const uint32_t*>(src_rows), static_cast<uint32_t*>(dst_keys), static_cast<uint32_t*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
+        else if (key32) hipLaunchKernelGGL((sort_scatter<uint32_t, hy_row_id>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint32_t*>(src_keys), static_cast<const hy_row_id*>(src_rows), static_cast<uint32_t*>(dst_keys), static_cast<hy_row_id*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
+        else if (id32) hipLaunchKernelGGL((sort_scatter<uint64_t, uint32_t>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint64_t*>(src_keys), static_cast<const uint32_t*>(src_rows), static_cast<uint64_t*>(dst_keys), static_cast<uint32_t*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
+        else hipLaunchKernelGGL((sort_scatter<uint64_t, hy_row_id>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint64_t*>(src_keys), static_cast<const hy_row_id*>(src_rows), static_cast<uint64_t*>(dst_keys), static_cast<hy_row_id*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
         std::swap(src_keys, dst_keys);
         std::swap(src_rows, dst_rows);
       }
-      if (src_keys != b.keys.as<uint64_t>()) {
+      if (src_keys != b.keys.ptr) {
         std::swap(b.keys.ptr, b.keys_tmp.ptr);
         std::swap(b.keys.capacity, b.keys_tmp.capacity);
         std::swap(b.rows.ptr, b.rows_tmp.ptr);
         std::swap(b.rows.capacity, b.rows_tmp.capacity);
       }
+      if (key32) HY_HIP(hipMemsetAsync(b.keys.as<uint32_t>() + total, 0, 16, stream));
     }
   }
+#undef HY_JOIN_BUILD_KERNEL
   // directory
   Directory& d = b.directory;
-  d.keys = b.keys.as<uint64_t>();
-  d.keys32 = nullptr;
-  d.row_ids = b.rows.as<hy_row_id>();
+  d.keys = key32 ? nullptr : b.keys.as<uint64_t>();
+  d.keys32 = key32 ? b.keys.as<uint32_t>() : nullptr;
+  d.row_ids = id32 ? nullptr : b.rows.as<hy_row_id>();
+  d.ids32 = id32 ? b.rows.as<uint32_t>() : nullptr;
   d.n = total;
-  if (total && build->data_type == HY_TYPE_INT) {
-    HY_TRY(b.keys32.alloc(4 * (total + 4)));
-    d.keys32 = b.keys32.as<uint32_t>();   // filled by directory_fill
-  }
-  d.ids32 = nullptr;
-  if (total && want_ids32) {
-    HY_TRY(b.ids32.alloc(4 * total));
-    d.ids32 = b.ids32.as<uint32_t>();     // filled by directory_fill
-  }
   d.key_min = d.key_max = 0;
   d.shift = 0;
   d.n_buckets = 1;
@@ -1398,10 +1545,15 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     if (keys_were_sorted) {
       d.key_min = first_key;
       d.key_max = last_key;
-    } else {
-      HY_HIP(hipMemcpyAsync(&d.key_min, d.keys, 8, hipMemcpyDeviceToHost, stream));
-      HY_HIP(hipMemcpyAsync(&d.key_max, d.keys + (total - 1), 8, hipMemcpyDeviceToHost, stream));
+    } else {   // the ends of the sorted keys
+      JoinMailbox* mailbox = nullptr;
+      JoinMailbox* mailbox_dev = nullptr;
+      HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
+      if (key32) hipLaunchKernelGGL(publish_build_flags<uint32_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint32_t>(), total, mailbox_dev);
+      else hipLaunchKernelGGL(publish_build_flags<uint64_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint64_t>(), total, mailbox_dev);
       HY_HIP(hipStreamSynchronize(stream));
+      d.key_min = mailbox->first_key;
+      d.key_max = mailbox->last_key;
     }
     uint32_t buckets = 1;
     while (buckets < total && buckets < (1u << 27)) buckets <<= 1;   // 1-2 keys per bucket on uniform keys: one probe of four keys
@@ -1414,8 +1566,9 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   HY_TRY(b.dir.alloc(4 * (size_t{d.n_buckets} + 2)));
   d.dir = b.dir.as<uint32_t>();
   if (total) {
-    hipLaunchKernelGGL(directory_fill, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, stream, d.keys, total, d.key_min, d.shift, d.n_buckets, b.dir.as<uint32_t>(), const_cast<uint32_t*>(d.keys32),
-                       d.row_ids, const_cast<uint32_t*>(d.ids32));
+    const dim3 grid(static_cast<uint32_t>((total + 255) / 256));
+    if (key32) hipLaunchKernelGGL(directory_fill<uint32_t>, grid, dim3(256), 0, stream, d.keys32, total, d.key_min, d.shift, d.n_buckets, b.dir.as<uint32_t>());
+    else hipLaunchKernelGGL(directory_fill<uint64_t>, grid, dim3(256), 0, stream, d.keys, total, d.key_min, d.shift, d.n_buckets, b.dir.as<uint32_t>());
   } else {
     HY_HIP(hipMemsetAsync(b.dir.ptr, 0, 4 * (size_t{d.n_buckets} + 2), stream));
   }
@@ -1456,7 +1609,9 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   bool pack_build_ids = !semi_anti && !count_only && build->n_chunks <= 65536;
   for (uint32_t c = 0; c < build->n_chunks && pack_build_ids; ++c) pack_build_ids = build->host_segments[c].size <= 65536;
   BuildSide b;
+  StageClock clock;
   HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, b, stream));
+  clock.mark("build side launched");
 
   if (result) {
     result->radix_bits = radix_bits;
@@ -1475,11 +1630,12 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   const uint32_t n_tiles = probe->n_slices * (SLICE_ROWS / JOIN_TILE);
   const uint32_t partitions = 1u << radix_bits;
   const size_t cells = size_t{partitions} * n_tiles;
-  DeviceBuffer hist_e, hist_p, base_e, base_p;
-  HY_TRY(hist_e.alloc(4 * (cells + 1)));
-  HY_TRY(hist_p.alloc(4 * (cells + 1)));
-  HY_TRY(base_e.alloc(8 * (cells + 2)));
-  HY_TRY(base_p.alloc(8 * (cells + 2)));
+  // pass 1's per-(partition, tile) counts: elements | zeros up to a scan-block boundary | pairs -- one buffer, one scan
+  const uint64_t second_at = (uint64_t{cells} + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK * SCAN_BLOCK;
+  DeviceBuffer hist, base;
+  HY_TRY(hist.alloc(4 * (second_at + cells + 1)));
+  HY_TRY(base.alloc(8 * (second_at + cells + 2)));
+  HY_HIP(hipMemsetAsync(hist.as<uint32_t>() + cells, 0, 4 * (second_at - cells), stream));
   ProbeArgs a{};
   a.segments = probe->d_segments;
   a.slices = probe->d_slices;
@@ -1497,8 +1653,10 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     if (n_tiles <= JOIN_TRACE_TILES) { a.trace = trace_buffer; g_join_trace = trace_buffer; g_join_trace_tiles = n_tiles; }
   }
   a.pack_build_ids = b.directory.ids32 ? 1 : 0;
-  a.hist_elements = hist_e.as<uint32_t>();
-  a.hist_pairs = hist_p.as<uint32_t>();
+  a.hist_elements = hist.as<uint32_t>();
+  a.hist_pairs = hist.as<uint32_t>() + second_at;
+  a.base_elements = base.as<uint64_t>();
+  a.base_pairs = base.as<uint64_t>() + second_at;
   DeviceBuffer d_partner, d_meta, d_uncached;
   if (!count_only && n_tiles) {   // pass 2 follows: let pass 1 leave its lookup results behind (6 B per probe row)
     HY_TRY(d_partner.alloc(4 * size_t{n_tiles} * JOIN_TILE));
@@ -1508,19 +1666,28 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     a.row_meta = d_meta.as<uint32_t>();
     a.tile_uncached = d_uncached.as<uint32_t>();
   }
-  DeviceBuffer d_error;
-  HY_TRY(d_error.alloc(256));
-  HY_HIP(hipMemsetAsync(d_error.ptr, 0, 64, stream));
-  a.error = d_error.as<uint32_t>();
-  a.n_uncached = d_error.as<uint32_t>() + 1;
-  a.xcd_tickets = d_error.as<uint32_t>() + 8;
-  // Which scanned positions the host needs: the start of every partition (radix) or of every probe chunk
-  // (radix_bits == 0: "partitions" are the probe chunks), plus the grand totals.
+  JoinMailbox* mailbox = nullptr;
+  JoinMailbox* mailbox_dev = nullptr;
+  HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
+  DeviceBuffer d_words;   // [0] pass 1's error flag (unused), [1] tiles with multi-partner rows, [8..15] XCD tickets, [16..17] JoinPlan
+  HY_TRY(d_words.alloc(256));
+  HY_HIP(hipMemsetAsync(d_words.ptr, 0, 128, stream));
+  a.error = &mailbox_dev->error;
+  a.n_uncached = d_words.as<uint32_t>() + 1;
+  a.xcd_tickets = d_words.as<uint32_t>() + 8;
+  JoinPlan* d_plan = reinterpret_cast<JoinPlan*>(d_words.as<uint32_t>() + 16);
+  a.plan = d_plan;
+
+  // Groups of the output: the radix partitions, or -- no radix partitioning -- the probe chunks (their tiles are
+  // consecutive).  Every 131 070 materialised elements of a group start a new output PosList.
   const uint32_t n_groups = radix_bits ? partitions : probe->n_chunks;
-  std::vector<uint64_t> group_first_cell(size_t{n_groups} + 1, cells);
-  if (radix_bits) {
-    for (uint32_t p = 0; p <= partitions; ++p) group_first_cell[p] = size_t{p} * n_tiles;
-  } else {
+  DeviceBuffer d_first_cell, d_origin, d_slice_base;
+  HY_TRY(d_origin.alloc(8 * (size_t{n_groups} + 1)));
+  HY_TRY(d_slice_base.alloc(4 * (size_t{n_groups} + 1)));
+  std::vector<uint64_t> group_first_cell;   // (source of an asynchronous upload: lives until the join returns)
+  const uint64_t* dev_first_cell = nullptr;   // radix partitions: group g starts at cell g * n_tiles
+  if (!radix_bits) {
+    group_first_cell.assign(size_t{n_groups} + 1, 0);
     uint64_t tile = 0;
     for (uint32_t c = 0; c < probe->n_chunks; ++c) {
       const uint32_t chunk_slices = (probe->host_segments[c].size + SLICE_ROWS - 1) / SLICE_ROWS;
@@ -1528,66 +1695,62 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
       tile += (chunk_slices ? chunk_slices : 1) * (SLICE_ROWS / JOIN_TILE);   // the tiles of each of its slices, consecutive
     }
     group_first_cell[n_groups] = tile;
+    HY_TRY(d_first_cell.alloc(8 * (size_t{n_groups} + 1)));
+    HY_HIP(hipMemcpyAsync(d_first_cell.ptr, group_first_cell.data(), 8 * (size_t{n_groups} + 1), hipMemcpyHostToDevice, stream));
+    dev_first_cell = d_first_cell.as<uint64_t>();
   }
-  std::vector<uint64_t> group_origin(size_t{n_groups} + 1, 0);
-  uint64_t n_pairs = 0;
-  uint32_t n_uncached = 0;   // tiles with a row that has several partners
-  DeviceBuffer d_index, d_origin;
-  HY_TRY(d_index.alloc(8 * (size_t{n_groups} + 1)));
-  HY_TRY(d_origin.alloc(8 * (size_t{n_groups} + 1)));
-  if (n_tiles) {
-    hipLaunchKernelGGL(probe_count, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
-    HY_TRY(exclusive_scan(hist_e.as<uint32_t>(), base_e.as<uint64_t>(), uint64_t{cells}, stream));
-    HY_TRY(exclusive_scan(hist_p.as<uint32_t>(), base_p.as<uint64_t>(), uint64_t{cells}, stream));
-    HY_HIP(hipMemcpyAsync(d_index.ptr, group_first_cell.data(), 8 * (size_t{n_groups} + 1), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(gather_u64, dim3((n_groups + 256) / 256), dim3(256), 0, stream, base_e.as<uint64_t>(), d_index.as<uint64_t>(), d_origin.as<uint64_t>(), n_groups + 1);
-    HY_HIP(hipMemcpyAsync(group_origin.data(), d_origin.ptr, 8 * (size_t{n_groups} + 1), hipMemcpyDeviceToHost, stream));
-    HY_HIP(hipMemcpyAsync(&n_pairs, base_p.as<uint64_t>() + cells, 8, hipMemcpyDeviceToHost, stream));
-    HY_HIP(hipMemcpyAsync(&n_uncached, a.n_uncached, 4, hipMemcpyDeviceToHost, stream));
-    HY_HIP(hipStreamSynchronize(stream));
+  const uint32_t max_slices = static_cast<uint32_t>(probe->rows / PROBE_SIZE_PER_CHUNK) + n_groups + 1;   // what the host knows without asking
+
+  // the caller's buffers
+  hy_row_id* user_build = nullptr;
+  hy_row_id* user_probe = nullptr;
+  if (!count_only) {
+    user_build = result->left_is_build ? result->left_pos : result->right_pos;
+    user_probe = result->left_is_build ? result->right_pos : result->left_pos;
+    if (!user_probe && result->capacity) return fail(HY_ERR_INVALID, "join result: PosList buffer for the probe side missing");
+    if (!semi_anti && !user_build && result->capacity) return fail(HY_ERR_INVALID, "join result: PosList buffer for the build side missing");
+    if (!result->slice_offsets) return fail(HY_ERR_INVALID, "join result: slice_offsets missing");
   }
-  if (count_out) *count_out = n_pairs;
-  if (count_only) return HY_OK;
-
-  // slices: every 131 070 materialised elements of a group start a new output PosList
-  std::vector<uint32_t> slice_base(n_groups ? n_groups : 1, 0);
-  uint64_t n_slices = 0;
-  for (uint32_t g = 0; g < n_groups; ++g) {
-    slice_base[g] = static_cast<uint32_t>(n_slices);
-    n_slices += (group_origin[g + 1] - group_origin[g] + PROBE_SIZE_PER_CHUNK - 1) / PROBE_SIZE_PER_CHUNK;
-  }
-  result->n_slices = static_cast<uint32_t>(n_slices);
-  result->n_pairs = n_pairs;
-  if (n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %llu output PosLists, slice capacity is %u", static_cast<unsigned long long>(n_slices), result->slice_capacity);
-  if (n_pairs > result->capacity) return fail(HY_ERR_CAPACITY, "join produces %llu pairs, capacity is %llu", static_cast<unsigned long long>(n_pairs), static_cast<unsigned long long>(result->capacity));
-
-  hy_row_id* user_build = result->left_is_build ? result->left_pos : result->right_pos;
-  hy_row_id* user_probe = result->left_is_build ? result->right_pos : result->left_pos;
-  if (!user_probe && n_pairs) return fail(HY_ERR_INVALID, "join result: PosList buffer for the probe side missing");
-  if (!semi_anti && !user_build && n_pairs) return fail(HY_ERR_INVALID, "join result: PosList buffer for the build side missing");
-  if (!result->slice_offsets) return fail(HY_ERR_INVALID, "join result: slice_offsets missing");
-
-  DeviceBuffer d_slice_base, d_build_out, d_probe_out, d_slice_offsets;
-  HY_TRY(d_slice_base.alloc(4 * slice_base.size()));
-  HY_HIP(hipMemcpyAsync(d_slice_base.ptr, slice_base.data(), 4 * slice_base.size(), hipMemcpyHostToDevice, stream));
-  hy_row_id* dev_build = user_build;
-  hy_row_id* dev_probe = user_probe;
-  uint64_t* dev_slice_offsets = result->slice_offsets;
-  if (host_result) {
-    if (!semi_anti) { HY_TRY(d_build_out.alloc(8 * n_pairs)); dev_build = d_build_out.as<hy_row_id>(); }
-    HY_TRY(d_probe_out.alloc(8 * n_pairs));
-    dev_probe = d_probe_out.as<hy_row_id>();
-    HY_TRY(d_slice_offsets.alloc(8 * (n_slices + 2)));
+  DeviceBuffer d_build_out, d_probe_out, d_slice_offsets;
+  uint64_t* dev_slice_offsets = count_only ? nullptr : result->slice_offsets;
+  if (!count_only && host_result) {
+    HY_TRY(d_slice_offsets.alloc(8 * (size_t{max_slices} + 2)));
     dev_slice_offsets = d_slice_offsets.as<uint64_t>();
   }
-  a.base_elements = base_e.as<uint64_t>();
-  a.base_pairs = base_p.as<uint64_t>();
+
+  // pass 1, the scan of its counts, the plan of the output -- no host round trip in between
+  if (n_tiles) {
+    hipLaunchKernelGGL(probe_count, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
+    HY_TRY(exclusive_scan(hist.as<uint32_t>(), base.as<uint64_t>(), second_at + cells, stream, second_at));
+  } else {
+    HY_HIP(hipMemsetAsync(base.ptr, 0, 8 * (second_at + cells + 2), stream));
+  }
+  hipLaunchKernelGGL(plan_output, dim3(1), dim3(256), 0, stream, a.base_elements, a.base_pairs, dev_first_cell, n_groups, n_tiles, uint64_t{cells},
+                     count_only ? ~0ull : result->capacity, count_only ? 0xFFFFFFFFu : result->slice_capacity, d_origin.as<uint64_t>(), d_slice_base.as<uint32_t>(),
+                     dev_slice_offsets, n_tiles && a.row_meta ? a.n_uncached : nullptr, d_plan, mailbox_dev);
+  clock.mark("pass 1 launched");
+  if (count_only) {
+    HY_HIP(hipStreamSynchronize(stream));
+    if (count_out) *count_out = mailbox->n_pairs;
+    return HY_OK;
+  }
+  hy_row_id* dev_build = user_build;
+  hy_row_id* dev_probe = user_probe;
+  if (host_result) {   // the staging buffers are sized by the pair count: ask now
+    HY_HIP(hipStreamSynchronize(stream));
+    clock.mark("pass 1 done");
+    if (mailbox->fits) {
+      if (!semi_anti) { HY_TRY(d_build_out.alloc(8 * mailbox->n_pairs)); dev_build = d_build_out.as<hy_row_id>(); }
+      HY_TRY(d_probe_out.alloc(8 * mailbox->n_pairs));
+      dev_probe = d_probe_out.as<hy_row_id>();
+    }
+  }
   a.partition_element_origin = d_origin.as<uint64_t>();
   a.partition_slice_base = d_slice_base.as<uint32_t>();
   a.build_out = semi_anti ? nullptr : dev_build;
   a.probe_out = dev_probe;
   a.slice_offsets = dev_slice_offsets;
-  if (n_tiles) {
+  if (n_tiles) {   // (every pass 2 kernel returns at once if the plan says that the result does not fit)
     static bool lds_raised = false;
     static uint32_t workgroups_per_cu = 1;
     if (!lds_raised) {
@@ -1601,7 +1764,6 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
       workgroups_per_cu = per_cu > 0 ? static_cast<uint32_t>(per_cu) : 1;
     }
     a.debug_plain_stores = getenv("HY_JOIN_PLAIN_STORES") ? 1 : 0;
-    if (getenv("HY_JOIN_TRACE")) fprintf(stderr, "probe_emit_cached: %u workgroups per CU, %zu LDS bytes\n", workgroups_per_cu, 4 * probe_emit_cached_lds_words(partitions));
     if (const char* env = getenv("HY_JOIN_WGS_PER_CU")) workgroups_per_cu = static_cast<uint32_t>(atoi(env));
     // persistent workgroups: as many as fit the device at once (a multiple of the 8 XCDs), never more than tiles
     const uint32_t resident = device_cu_count() * workgroups_per_cu / 8 * 8;
@@ -1609,22 +1771,27 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     profile_begin(stream);
     hipLaunchKernelGGL(probe_emit_cached, dim3(cached_grid), dim3(JOIN_THREADS), 4 * probe_emit_cached_lds_words(partitions), stream, a);
     profile_end(stream);
-    if (n_slices) hipLaunchKernelGGL(probe_cuts, dim3(static_cast<uint32_t>(n_slices)), dim3(64), 0, stream, a, d_index.as<uint64_t>(), n_groups, static_cast<uint32_t>(n_slices));
-    if (n_uncached) hipLaunchKernelGGL(probe_emit_generic, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
+    const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
+    if (cut_grid) hipLaunchKernelGGL(probe_cuts, dim3(cut_grid), dim3(64), 0, stream, a, dev_first_cell, n_groups);
+    // (device results: the host does not know whether a tile needs it; every workgroup of it looks at its tile's flag)
+    if (!host_result || mailbox->n_uncached) hipLaunchKernelGGL(probe_emit_generic, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
   }
-  HY_HIP(hipMemcpyAsync(dev_slice_offsets + n_slices, &result->n_pairs, 8, hipMemcpyHostToDevice, stream));
   HY_HIP(hipGetLastError());
+  clock.mark("pass 2 launched");
   if (host_result) {
-    if (n_pairs) {
-      HY_HIP(hipMemcpyAsync(user_probe, dev_probe, 8 * n_pairs, hipMemcpyDeviceToHost, stream));
-      if (!semi_anti) HY_HIP(hipMemcpyAsync(user_build, dev_build, 8 * n_pairs, hipMemcpyDeviceToHost, stream));
+    if (mailbox->fits && mailbox->n_pairs) {
+      HY_HIP(hipMemcpyAsync(user_probe, dev_probe, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
+      if (!semi_anti) HY_HIP(hipMemcpyAsync(user_build, dev_build, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
     }
-    HY_HIP(hipMemcpyAsync(result->slice_offsets, dev_slice_offsets, 8 * (n_slices + 1), hipMemcpyDeviceToHost, stream));
+    if (mailbox->fits) HY_HIP(hipMemcpyAsync(result->slice_offsets, dev_slice_offsets, 8 * (size_t{mailbox->n_slices} + 1), hipMemcpyDeviceToHost, stream));
   }
-  uint32_t probe_error = 0;
-  HY_HIP(hipMemcpyAsync(&probe_error, d_error.ptr, 4, hipMemcpyDeviceToHost, stream));
   HY_HIP(hipStreamSynchronize(stream));   // the temporaries above are freed on return
-  if (probe_error) return fail(HY_ERR_UNSUPPORTED, "a probe row matches more than 4 194 303 build rows");
+  clock.mark("pass 2 done");
+  result->n_slices = mailbox->n_slices;
+  result->n_pairs = mailbox->n_pairs;
+  if (mailbox->n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %u output PosLists, slice capacity is %u", mailbox->n_slices, result->slice_capacity);
+  if (mailbox->n_pairs > result->capacity) return fail(HY_ERR_CAPACITY, "join produces %llu pairs, capacity is %llu", static_cast<unsigned long long>(mailbox->n_pairs), static_cast<unsigned long long>(result->capacity));
+  if (mailbox->error) return fail(HY_ERR_UNSUPPORTED, "a probe row matches more than 4 194 303 build rows");
   return HY_OK;
 }
 
