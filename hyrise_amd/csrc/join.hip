@@ -376,22 +376,36 @@ __global__ __launch_bounds__(1024) void scan_block_offsets(uint64_t* block_sums,
   const uint32_t begin = tid * per < n_blocks ? tid * per : n_blocks, end = begin + per < n_blocks ? begin + per : n_blocks;
   uint64_t sum = 0;
   for (uint32_t i = begin; i < end; ++i) sum += block_sums[i];
-  s_partial[tid] = sum;
+  // exclusive prefix of the 1024 partial sums: inside every wave, then over the 16 wave totals
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  uint64_t inclusive = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up(inclusive, d, 64);
+    if (lane >= static_cast<uint32_t>(d)) inclusive += t;
+  }
+  if (lane == 63) s_partial[wave] = inclusive;
   __syncthreads();
-  if (tid == 0) {
-    uint64_t run = 0;
-    for (uint32_t i = 0; i < 1024; ++i) { const uint64_t v = s_partial[i]; s_partial[i] = run; run += v; }
-    *total_out = run;   // (with a restart: corrected below)
+  if (wave == 0) {
+    const uint64_t total = lane < 16 ? s_partial[lane] : 0;
+    uint64_t scanned = total;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint64_t t = __shfl_up(scanned, d, 64);
+      if (lane >= static_cast<uint32_t>(d)) scanned += t;
+    }
+    if (lane < 16) s_partial[16 + lane] = scanned - total;
+    if (lane == 15) *total_out = scanned;   // (with a restart: corrected below)
   }
   __syncthreads();
-  uint64_t run = s_partial[tid];
+  uint64_t run = s_partial[16 + wave] + inclusive - sum;
   for (uint32_t i = begin; i < end; ++i) { const uint64_t v = block_sums[i]; block_sums[i] = run; run += v; }
   if (restart >= n_blocks) return;
   __syncthreads();
   if (tid == 0) s_first_segment = block_sums[restart];   // everything in front of the second segment
   __syncthreads();
   for (uint32_t i = begin > restart ? begin : restart; i < end; ++i) block_sums[i] -= s_first_segment;
-  if (tid == 0) *total_out -= s_first_segment;
+  if (tid == 15) *total_out -= s_first_segment;   // (the lane that wrote it)
 }
 
 __global__ __launch_bounds__(256) void scan_blocks(const uint32_t* in, uint64_t n, const uint64_t* block_offsets, uint64_t* out) {
@@ -534,6 +548,7 @@ struct ProbeArgs {
   uint32_t* row_meta;             // [n_tiles][JOIN_WAVES][JOIN_ROUNDS / 2][64] pass 1 -> pass 2: partition and flags (ROW_*) of a lane's rows, two rounds per word
   uint32_t* tile_uncached;        // [n_tiles] set by pass 1 when a tile has a row with several partners (pass 2 evaluates it again)
   uint32_t* n_uncached;           // number of such tiles
+  uint32_t* uncached_tiles;       // [n_tiles] ... and which (in no particular order)
   uint32_t* xcd_tickets;          // [8] probe_emit_cached: next tile of every XCD's share
   const JoinPlan* plan;           // pass 2: does the result fit its buffers, how many output PosLists
   uint32_t* error;                // set when a probe row matches >= 2^22 build rows (the staging record cannot hold it)
@@ -855,7 +870,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
   __syncthreads();
   if (a.row_meta && tid == 0) {
     a.tile_uncached[tile] = s_elements[MAX_PARTITIONS];
-    if (s_elements[MAX_PARTITIONS]) atomicAdd(a.n_uncached, 1u);
+    if (s_elements[MAX_PARTITIONS]) a.uncached_tiles[atomicAdd(a.n_uncached, 1u)] = tile;   // probe_emit_generic's work list
   }
   if (tid < partitions) {
     a.hist_elements[static_cast<size_t>(tid) * a.n_tiles + tile] = s_elements[tid];
@@ -1059,10 +1074,13 @@ __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6)
 __global__ __launch_bounds__(64) void probe_cuts(ProbeArgs a, const uint64_t* group_first_cell, uint32_t n_groups) {
   const uint32_t slice = blockIdx.x, lane = threadIdx.x;
   if (!a.plan->fits || slice >= a.plan->n_slices) return;
+  // Both searches: the wave looks at 64 evenly spaced entries per step (three steps for 15 000 entries, not fourteen).
   uint32_t lo = 0, hi = n_groups;   // last group whose first PosList is <= slice
   while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) / 2;
-    if (a.partition_slice_base[mid] <= slice) lo = mid; else hi = mid;
+    const uint32_t step = (hi - lo + 63) / 64, at = lo + lane * step;
+    const uint32_t below = __popcll(__ballot(at < hi && a.partition_slice_base[at] <= slice));   // (monotone: the first `below` lanes)
+    lo += (below - 1) * step;
+    hi = lo + step < hi ? lo + step : hi;
   }
   const uint32_t group = lo;
   const uint64_t first_cell = group_first_cell ? group_first_cell[group] : static_cast<uint64_t>(group) * a.n_tiles;
@@ -1070,8 +1088,10 @@ __global__ __launch_bounds__(64) void probe_cuts(ProbeArgs a, const uint64_t* gr
   const uint64_t target = a.base_elements[first_cell] + static_cast<uint64_t>(slice - a.partition_slice_base[group]) * PROBE_SIZE_PER_CHUNK;
   uint64_t cell = first_cell, cell_end = end_cell;   // last cell of the group whose first element is <= target: it holds the element
   while (cell_end - cell > 1) {
-    const uint64_t mid = (cell + cell_end) / 2;
-    if (a.base_elements[mid] <= target) cell = mid; else cell_end = mid;
+    const uint64_t step = (cell_end - cell + 63) / 64, at = cell + lane * step;
+    const uint32_t below = __popcll(__ballot(at < cell_end && a.base_elements[at] <= target));
+    cell += (below - 1) * step;
+    cell_end = cell + step < cell_end ? cell + step : cell_end;
   }
   const uint32_t tile = static_cast<uint32_t>(a.radix_bits ? cell - static_cast<uint64_t>(group) * a.n_tiles : cell);
   if (a.tile_uncached[tile]) return;   // probe_emit_generic records the cuts of its tiles
@@ -1110,10 +1130,10 @@ __host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
 // again, a lane keeps the lookup results of its eight rows in registers, a wave-level match-any ranking with running
 // per-(wave, partition) counters gives every row its stable rank inside (partition, tile), and the pairs are first laid
 // out partition by partition in LDS and then copied out.  Tiles whose pairs do not fit the staging buffer (many
-// duplicates) write their pairs directly.  One workgroup per tile; tiles probe_emit_cached handles return at once.
+// duplicates) write their pairs directly.  Two workgroups per CU walk pass 1's list of such tiles.
 __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) {
-  const uint32_t tile = block_tile(a.n_tiles);
-  if (tile >= a.n_tiles || a.tile_uncached[tile] == 0 || !a.plan->fits) return;
+  const uint32_t n_listed = *a.n_uncached;
+  if (n_listed == 0 || !a.plan->fits) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
   const uint32_t partitions = 1u << a.radix_bits;
   uint32_t* s_stage = join_smem;                                     // [JOIN_STAGE][2] row | partition << 12 | null << 21 , build position
@@ -1125,6 +1145,9 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
   uint32_t* s_cut_rank = reinterpret_cast<uint32_t*>(s_base_pairs + partitions);   // [partitions] rank (in the tile) of the element that starts a new output PosList
   uint32_t* s_cut_slice = s_cut_rank + partitions;                   // [partitions] ... and the index of that PosList
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll 1
+  for (uint32_t listed = blockIdx.x; listed < n_listed; listed += gridDim.x) {
+  const uint32_t tile = a.uncached_tiles[listed];
   for (uint32_t i = tid; i < 2 * JOIN_WAVES * partitions; i += JOIN_THREADS) s_run_elements[i] = 0;
   __syncthreads();
   uint32_t chunk, row_begin, row_count;
@@ -1259,10 +1282,9 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (!staged) return;
   __syncthreads();
   // (e) copy out: slot s of partition p is pair  base_pairs[p][tile] + (s - first slot of p)
-  for (uint32_t s = tid; s < tile_pairs; s += JOIN_THREADS) {
+  for (uint32_t s = tid; staged && s < tile_pairs; s += JOIN_THREADS) {
     const u32x2_t record = reinterpret_cast<const u32x2_t*>(s_stage)[s];
     const uint32_t tag = record.x, position = record.y;
     const uint32_t partition = (tag >> 12) & 0x1FF;
@@ -1274,6 +1296,8 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
       if (!(tag & (1u << 21))) { const hy_row_id id = directory_row_id(a.dir, position); build_id = u32x2_t{id.chunk_id, id.chunk_offset}; }
       __builtin_nontemporal_store(build_id, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
     }
+  }
+  __syncthreads();   // the next listed tile reuses the staging area and the counters
   }
 }
 
@@ -1661,7 +1685,8 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   if (!count_only && n_tiles) {   // pass 2 follows: let pass 1 leave its lookup results behind (6 B per probe row)
     HY_TRY(d_partner.alloc(4 * size_t{n_tiles} * JOIN_TILE));
     HY_TRY(d_meta.alloc(2 * size_t{n_tiles} * JOIN_TILE));
-    HY_TRY(d_uncached.alloc(4 * size_t{n_tiles}));
+    HY_TRY(d_uncached.alloc(4 * size_t{n_tiles} * 2));   // flags | work list of probe_emit_generic
+    a.uncached_tiles = d_uncached.as<uint32_t>() + n_tiles;
     a.row_partner = d_partner.as<uint32_t>();
     a.row_meta = d_meta.as<uint32_t>();
     a.tile_uncached = d_uncached.as<uint32_t>();
@@ -1773,8 +1798,8 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     profile_end(stream);
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
     if (cut_grid) hipLaunchKernelGGL(probe_cuts, dim3(cut_grid), dim3(64), 0, stream, a, dev_first_cell, n_groups);
-    // (device results: the host does not know whether a tile needs it; every workgroup of it looks at its tile's flag)
-    if (!host_result || mailbox->n_uncached) hipLaunchKernelGGL(probe_emit_generic, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
+    // the tiles pass 1 listed (usually none: the workgroups read the list's length and leave)
+    if (!host_result || mailbox->n_uncached) hipLaunchKernelGGL(probe_emit_generic, dim3(std::min<uint32_t>(n_tiles, device_cu_count() * 2)), dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
   }
   HY_HIP(hipGetLastError());
   clock.mark("pass 2 launched");
