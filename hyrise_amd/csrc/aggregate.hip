@@ -275,6 +275,12 @@ __device__ __forceinline__ void row_tuple(const AggArgs& a, uint32_t chunk, uint
 //   pass 3  only if the slice has more groups: the remaining rows use LDS atomics per row -- the more groups, the fewer
 //           conflicts -- and rows whose group does not fit the LDS table go to the global table directly.
 //   merge   the slice's groups go to the global table with agent-scope atomics.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// Row k (0..31) of thread `tid` inside its 8192-row slice: four consecutive rows per lane and step, so that the loads of
+// rows 4m .. 4m+3 of a value / attribute-vector column are one wide load (16 bytes of floats, a dword of byte value ids).
+__device__ __forceinline__ uint32_t slice_row(uint32_t k, uint32_t tid) { return ((k >> 2) * 256 + tid) * 4 + (k & 3); }
+
 __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t words = a.n_groupby + 1;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   uint32_t* s_n_groups = s_slot_of_dense + DENSE_GROUPS;
   uint64_t* s_cell_value = reinterpret_cast<uint64_t*>(s_n_groups + 4);                     // [DENSE_GROUPS][256] thread-private accumulators
   uint32_t* s_cell_count = reinterpret_cast<uint32_t*>(s_cell_value + DENSE_GROUPS * 256);   // [DENSE_GROUPS][256]
-  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_cell_count + DENSE_GROUPS * 256);       // [SLICE_ROWS]
+  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_cell_count + DENSE_GROUPS * 256);       // [32][256] LDS slot of row k of thread tid
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   for (uint32_t s = tid; s < LDS_SLOTS; s += 256) {
     s_tags[s] = TAG_EMPTY;
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     uint32_t row[GB], valid = 0;
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const uint32_t r = (block * GB + i) * 256 + tid;
+      const uint32_t r = slice_row(block * GB + i, tid);
       if (r < slice.row_count) valid |= 1u << i;
       row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
     }
@@ -350,8 +356,19 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
       if (g >= a.n_groupby || !((local_keys >> g) & 1)) continue;
       const DevSegment& seg = a.groupby[g].segments[slice.chunk];
+      // the block's four rows are consecutive and start at a multiple of four: one aligned load of all four value ids
+      // (not for the group that straddles the end of the chunk: nothing may be read behind a caller's buffer)
+      if (seg.width == 1 && valid == 0xF) {
+        const uint32_t four = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(seg.data) + row[0]);
 #pragma unroll
-      for (int i = 0; i < GB; ++i) vid[g][i] = aload_compressed(seg.data, seg.width, row[i]);
+        for (int i = 0; i < GB; ++i) vid[g][i] = (four >> (8 * i)) & 0xFF;
+      } else if (seg.width == 2 && valid == 0xF) {
+        const u32x2 four = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(seg.data) + row[0]);
+        vid[g][0] = four.x & 0xFFFF; vid[g][1] = four.x >> 16; vid[g][2] = four.y & 0xFFFF; vid[g][3] = four.y >> 16;
+      } else {
+#pragma unroll
+        for (int i = 0; i < GB; ++i) vid[g][i] = aload_compressed(seg.data, seg.width, row[i]);
+      }
     }
 #pragma unroll
     for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
@@ -466,9 +483,9 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) { first[j] = 0xFFFFFFFFu; last[j] = 0; }
 #pragma unroll
     for (uint32_t k = 0; k < ROWS; ++k) {
-      const uint32_t r = k * 256 + tid;
+      const uint32_t r = slice_row(k, tid);
       if (r < slice.row_count && ((in_table >> k) & 1)) {
-        const uint32_t dense = s_dense_of_slot[s_row_slot[r]];
+        const uint32_t dense = s_dense_of_slot[s_row_slot[k * 256 + tid]];
         if (dense < DENSE_GROUPS) {
           is_dense |= 1u << k;
           if (k < 16) dense_lo |= dense << (2 * k); else dense_hi |= dense << (2 * (k - 16));
@@ -526,7 +543,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         uint32_t row[AB];
 #pragma unroll
         for (int i = 0; i < AB; ++i) {
-          const uint32_t r = (half * AB + i) * 256 + tid;
+          const uint32_t r = slice_row(half * AB + i, tid);
           row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
         }
         decode_rows<AB>(c.segments, slice.chunk, row, members, bits, &nulls);
@@ -592,12 +609,12 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   if (n_groups > DENSE_GROUPS) {
 #pragma unroll 1
     for (uint32_t k = 0; k < ROWS; ++k) {
-      const uint32_t r = k * 256 + tid;
+      const uint32_t r = slice_row(k, tid);
       if (r >= slice.row_count || ((is_dense >> k) & 1)) continue;
       const uint32_t row = slice.row_begin + r;
       const uint64_t global_row = chunk_base + row;
       const bool found = (in_table >> k) & 1;
-      const uint32_t slot = s_row_slot[r];
+      const uint32_t slot = s_row_slot[k * 256 + tid];
       uint32_t gslot = 0xFFFFFFFFu;
       if (!found) {
         uint64_t tuple[MAX_GROUPBY + 1];
@@ -648,20 +665,45 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   }
 }
 
+// The groups of the table, densely.  The first `staged_capacity` of them also go straight into pinned host memory (same
+// five arrays, `staged_capacity` rows each, behind a 64-byte header): few groups -- the usual case -- cost no copy at all.
+struct StagedGroups {
+  uint64_t* keys;
+  uint64_t* first;
+  uint64_t* last;
+  uint64_t* values;
+  uint64_t* counts;
+  uint32_t capacity;
+};
 __global__ void compact_groups(AggArgs a, uint32_t* counter, uint64_t* out_keys, uint64_t* out_first, uint64_t* out_last, uint64_t* out_values,
-                               uint64_t* out_counts, uint32_t out_capacity) {
+                               uint64_t* out_counts, uint32_t out_capacity, StagedGroups staged) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= a.capacity || a.tags[slot] == TAG_EMPTY) return;
   const uint32_t idx = atomicAdd(counter, 1u);
   if (idx >= out_capacity) return;
   const uint32_t words = a.n_groupby + 1;
-  for (uint32_t w = 0; w < words; ++w) out_keys[static_cast<size_t>(idx) * words + w] = a.keys[static_cast<size_t>(slot) * words + w];
+  const bool stage = idx < staged.capacity;
+  for (uint32_t w = 0; w < words; ++w) {
+    const uint64_t v = a.keys[static_cast<size_t>(slot) * words + w];
+    out_keys[static_cast<size_t>(idx) * words + w] = v;
+    if (stage) staged.keys[static_cast<size_t>(idx) * words + w] = v;
+  }
   out_first[idx] = a.first_row[slot];
   out_last[idx] = a.last_row[slot];
+  if (stage) { staged.first[idx] = a.first_row[slot]; staged.last[idx] = a.last_row[slot]; }
   for (uint32_t g = 0; g < a.n_aggregates; ++g) {
-    out_values[static_cast<size_t>(idx) * a.n_aggregates + g] = a.values[static_cast<size_t>(slot) * a.n_aggregates + g];
-    out_counts[static_cast<size_t>(idx) * a.n_aggregates + g] = a.counts[static_cast<size_t>(slot) * a.n_aggregates + g];
+    const uint64_t v = a.values[static_cast<size_t>(slot) * a.n_aggregates + g], c = a.counts[static_cast<size_t>(slot) * a.n_aggregates + g];
+    out_values[static_cast<size_t>(idx) * a.n_aggregates + g] = v;
+    out_counts[static_cast<size_t>(idx) * a.n_aggregates + g] = c;
+    if (stage) { staged.values[static_cast<size_t>(idx) * a.n_aggregates + g] = v; staged.counts[static_cast<size_t>(idx) * a.n_aggregates + g] = c; }
   }
+}
+
+// flags: [0] the group table overflowed, [1] number of groups -> the header of the pinned block
+__global__ void publish_group_flags(const uint32_t* flags, uint32_t* header) {
+  header[0] = flags[0];
+  header[1] = flags[1];
+  __threadfence_system();
 }
 
 // ANY(): value of the column at each group's representative row.
@@ -743,10 +785,28 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     HY_TRY(c_last.alloc(8 * size_t{out_capacity}));
     HY_TRY(c_values.alloc(8 * size_t{out_capacity} * (n_aggregates ? n_aggregates : 1)));
     HY_TRY(c_counts.alloc(8 * size_t{out_capacity} * (n_aggregates ? n_aggregates : 1)));
+    // pinned block: header | keys | first | last | values | counts for up to STAGED_GROUPS groups
+    constexpr uint32_t STAGED_GROUPS = 4096;
+    const uint32_t per_group = n_aggregates ? n_aggregates : 1;
+    const size_t staged_bytes = 64 + 8 * size_t{STAGED_GROUPS} * (words + 2 + 2 * per_group);
+    void* pinned_host = nullptr;
+    void* pinned_dev = nullptr;
+    HY_TRY(pinned_staging(staged_bytes, &pinned_host, &pinned_dev));
+    auto staged_arrays = [&](void* base) {
+      StagedGroups g;
+      g.keys = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(base) + 64);
+      g.first = g.keys + size_t{STAGED_GROUPS} * words;
+      g.last = g.first + STAGED_GROUPS;
+      g.values = g.last + STAGED_GROUPS;
+      g.counts = g.values + size_t{STAGED_GROUPS} * per_group;
+      g.capacity = STAGED_GROUPS;
+      return g;
+    };
     hipLaunchKernelGGL(compact_groups, dim3(static_cast<uint32_t>((capacity + 255) / 256)), dim3(256), 0, stream, a, flags.as<uint32_t>() + 1, c_keys.as<uint64_t>(),
-                       c_first.as<uint64_t>(), c_last.as<uint64_t>(), c_values.as<uint64_t>(), c_counts.as<uint64_t>(), out_capacity);
-    HY_HIP(hipMemcpyAsync(host_flags, flags.ptr, 8, hipMemcpyDeviceToHost, stream));
+                       c_first.as<uint64_t>(), c_last.as<uint64_t>(), c_values.as<uint64_t>(), c_counts.as<uint64_t>(), out_capacity, staged_arrays(pinned_dev));
+    hipLaunchKernelGGL(publish_group_flags, dim3(1), dim3(1), 0, stream, flags.as<uint32_t>(), static_cast<uint32_t*>(pinned_dev));
     HY_HIP(hipStreamSynchronize(stream));
+    std::memcpy(host_flags, pinned_host, 8);
     if (host_flags[0]) continue;   // table overflow: retry with a larger one
     const uint32_t n_groups = host_flags[1];
     out.n_groups = n_groups;
@@ -755,7 +815,16 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     out.last.resize(n_groups);
     out.values.resize(size_t{n_groups} * (n_aggregates ? n_aggregates : 1));
     out.counts.resize(size_t{n_groups} * (n_aggregates ? n_aggregates : 1));
-    if (n_groups) {
+    if (n_groups && n_groups <= STAGED_GROUPS) {   // everything is already here
+      const StagedGroups staged = staged_arrays(pinned_host);
+      std::memcpy(out.keys.data(), staged.keys, 8 * out.keys.size());
+      std::memcpy(out.first.data(), staged.first, 8 * size_t{n_groups});
+      std::memcpy(out.last.data(), staged.last, 8 * size_t{n_groups});
+      if (n_aggregates) {
+        std::memcpy(out.values.data(), staged.values, 8 * out.values.size());
+        std::memcpy(out.counts.data(), staged.counts, 8 * out.counts.size());
+      }
+    } else if (n_groups) {
       HY_HIP(hipMemcpyAsync(out.keys.data(), c_keys.ptr, 8 * out.keys.size(), hipMemcpyDeviceToHost, stream));
       HY_HIP(hipMemcpyAsync(out.first.data(), c_first.ptr, 8 * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
       HY_HIP(hipMemcpyAsync(out.last.data(), c_last.ptr, 8 * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
@@ -811,6 +880,16 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     if (spec.function == HY_AGG_COUNT_DISTINCT) {
       if (n_groupby + 1 > MAX_GROUPBY) return fail(HY_ERR_UNSUPPORTED, "COUNT(DISTINCT) with %u GROUP BY columns stays on the CPU path", n_groupby);
       continue;
+    }
+    // SUM and AVG of one floating-point column are the same accumulator (a double sum in row order and a count of the
+    // non-NULL rows): TPC-H Q1 asks for both of l_quantity and of l_extendedprice.  (Integer columns: SUM adds int64,
+    // AVG adds doubles -- two accumulators.)
+    const bool float_column = spec.column && (spec.column->data_type == HY_TYPE_FLOAT || spec.column->data_type == HY_TYPE_DOUBLE);
+    if (float_column && (spec.function == HY_AGG_SUM || spec.function == HY_AGG_AVG)) {
+      for (uint32_t earlier = 0; earlier < g && primary[g] < 0; ++earlier) {
+        if (specs[earlier].column == spec.column && (specs[earlier].function == HY_AGG_SUM || specs[earlier].function == HY_AGG_AVG)) primary[g] = primary[earlier];
+      }
+      if (primary[g] >= 0) continue;
     }
     const uint32_t wanted = spec.function == HY_AGG_STDDEV_SAMP ? 2 : 1;
     if (n_device + wanted > MAX_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "more than %u device accumulators stay on the CPU path", MAX_AGGREGATES);

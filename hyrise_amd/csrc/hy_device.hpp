@@ -102,6 +102,10 @@ hy_status fail(hy_status code, const char* fmt, ...);
 
 hipStream_t current_stream();
 
+// Pinned, device-mapped host memory of this thread (grow-only): small results that kernels store straight into host
+// memory, read by the host after a stream synchronise -- instead of one blit kernel and host round trip per hipMemcpyAsync.
+hy_status pinned_staging(size_t bytes, void** host, void** device);
+
 // Optional HIP-event bracket around the dominant kernel of an operator call (hy_set_profiling / hy_last_kernel_ms).
 void profile_begin(hipStream_t stream);
 void profile_end(hipStream_t stream);

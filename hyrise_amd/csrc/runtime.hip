@@ -109,6 +109,29 @@ hy_status DeviceBuffer::alloc(size_t bytes) { return pool_acquire(bytes, &ptr, &
 
 DeviceBuffer::~DeviceBuffer() { pool_release(ptr, capacity); }
 
+struct PinnedStaging {
+  void* host = nullptr;
+  void* device = nullptr;
+  size_t bytes = 0;
+  ~PinnedStaging() { if (host) (void)hipHostFree(host); }
+};
+static thread_local PinnedStaging t_staging;
+
+hy_status pinned_staging(size_t bytes, void** host, void** device) {
+  if (bytes > t_staging.bytes) {
+    if (t_staging.host) (void)hipHostFree(t_staging.host);
+    t_staging = PinnedStaging{};
+    size_t rounded = 1 << 16;
+    while (rounded < bytes) rounded <<= 1;
+    HY_HIP(hipHostMalloc(&t_staging.host, rounded, hipHostMallocMapped));
+    HY_HIP(hipHostGetDevicePointer(&t_staging.device, t_staging.host, 0));
+    t_staging.bytes = rounded;
+  }
+  *host = t_staging.host;
+  *device = t_staging.device;
+  return HY_OK;
+}
+
 Scratch& scratch() { return t_scratch; }
 
 hy_status Scratch::reserve(size_t bytes) {
