@@ -64,6 +64,7 @@ struct AggArgs {
   uint64_t* values;           // [capacity][n_aggregates]
   uint64_t* counts;           // [capacity][n_aggregates]
   uint32_t* overflow;
+  uint64_t* trace;            // debug (HY_AGG_TRACE): 12 wall-clock stamps per slice, else nullptr
 };
 
 // order-preserving map double -> int64 (so MIN/MAX of floating point values can use integer atomics)
@@ -276,6 +277,8 @@ __device__ __forceinline__ void row_tuple(const AggArgs& a, uint32_t chunk, uint
 //           conflicts -- and rows whose group does not fit the LDS table go to the global table directly.
 //   merge   the slice's groups go to the global table with agent-scope atomics.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) uint32_t global_u32;   // (pointers read from a segment descriptor are generic to the compiler: flat loads)
+typedef __attribute__((address_space(1))) u32x2 global_u32x2;
 
 // Row k (0..31) of thread `tid` inside its 8192-row slice: four consecutive rows per lane and step, so that the loads of
 // rows 4m .. 4m+3 of a value / attribute-vector column are one wide load (16 bytes of floats, a dword of byte value ids).
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   uint32_t* s_n_groups = s_slot_of_dense + DENSE_GROUPS;
   uint64_t* s_cell_value = reinterpret_cast<uint64_t*>(s_n_groups + 4);                     // [DENSE_GROUPS][256] thread-private accumulators
   uint32_t* s_cell_count = reinterpret_cast<uint32_t*>(s_cell_value + DENSE_GROUPS * 256);   // [DENSE_GROUPS][256]
-  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_cell_count + DENSE_GROUPS * 256);       // [32][256] LDS slot of row k of thread tid
+  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_cell_count + DENSE_GROUPS * 256);       // [SLICE_ROWS] LDS slot of every row of the slice (a thread's four consecutive rows: one word)
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   for (uint32_t s = tid; s < LDS_SLOTS; s += 256) {
     s_tags[s] = TAG_EMPTY;
@@ -311,33 +314,153 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
 
   const Slice slice = a.slices[blockIdx.x];
   const uint64_t chunk_base = a.row_base[slice.chunk];
+  uint64_t* stamps = a.trace ? a.trace + size_t{blockIdx.x} * 12 : nullptr;
+  if (stamps && tid == 0) stamps[0] = wall_clock64();
   constexpr uint32_t ROWS = SLICE_ROWS / 256;
   if (slice.row_count == 0) return;
   uint32_t in_table = 0;   // bit k: row k found its group in the LDS table
 
+  // What pass 1 needs of the GROUP BY columns' segment descriptors, once (read through the pointer they are a dependent
+  // global load in front of every block's attribute-vector loads: three round trips per block instead of one).
+  const void* key_data[MAX_GROUPBY];
+  uint32_t key_width[MAX_GROUPBY], key_dictionary_size[MAX_GROUPBY];
   uint32_t local_keys = 0;   // bit g: GROUP BY column g is a dictionary segment in this chunk (keyed by value id inside the slice)
-  for (uint32_t g = 0; g < a.n_groupby; ++g) {
-    if (a.groupby[g].segments[slice.chunk].encoding == HY_ENC_DICTIONARY) local_keys |= 1u << g;
+  bool keys_unaligned = false;
+#pragma unroll
+  for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+    key_data[g] = nullptr;
+    key_width[g] = key_dictionary_size[g] = 0;
+    if (g < a.n_groupby) {
+      const DevSegment& seg = a.groupby[g].segments[slice.chunk];
+      key_data[g] = seg.data;
+      key_width[g] = seg.width;
+      key_dictionary_size[g] = seg.aux_size;
+      if (seg.encoding == HY_ENC_DICTIONARY) local_keys |= 1u << g;
+      if (seg.flags & SEG_UNALIGNED) keys_unaligned = true;
+    }
   }
   // direct-mapped table?
   uint32_t direct_size[MAX_GROUPBY] = {1, 1, 1, 1}, direct_stride[MAX_GROUPBY] = {0, 0, 0, 0};
-  bool direct = a.n_groupby > 0 && local_keys == (1u << a.n_groupby) - 1;
+  bool direct = a.n_groupby > 0 && local_keys == (1u << a.n_groupby) - 1 && !keys_unaligned;   // (aligned: the wide loads of pass 1 stay inside the word that holds a chunk's last value id)
   {
     uint64_t product = 1;
 #pragma unroll
     for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
       if (g < a.n_groupby && direct) {
-        direct_size[g] = a.groupby[g].segments[slice.chunk].aux_size + 1;   // + 1: NULL
+        direct_size[g] = key_dictionary_size[g] + 1;   // + 1: NULL
         direct_stride[g] = static_cast<uint32_t>(product);
         product *= direct_size[g];
         if (product > LDS_SLOTS) direct = false;
       }
     }
   }
+  if (stamps && tid == 0) stamps[11] = wall_clock64();
   // ---- pass 1: group lookup, 4 rows at a time -----------------------------------------------------------------------------
   constexpr int GB = 4;
+  if (direct) {
+    // Every GROUP BY column is a dictionary segment and the product of (dictionary size + 1) fits the table: the combined
+    // value-id code IS the slot -- no hash, no probing, no key comparison, and no table traffic per row either: the rows
+    // only mark their code in a presence bitmap (codes below 32 through a register first), the groups are entered after
+    // the loop by the thread that owns the code.  All attribute-vector loads of the slice are in flight at once.
+    uint32_t* s_present = s_cell_count;   // [8] one bit per code
+    if (tid < 8) s_present[tid] = 0;
+    __syncthreads();
+    uint32_t seen_low = 0;
+    constexpr uint32_t BLOCKS = ROWS / GB;
+    uint32_t codes[BLOCKS];   // the codes of a block's four rows, one byte each
+#pragma unroll
+    for (uint32_t block = 0; block < BLOCKS; ++block) codes[block] = 0;
+    // column by column: the eight blocks' loads of a column are issued back to back, the width is decided once
+#pragma unroll
+    for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+      if (g >= a.n_groupby) continue;
+      const uint32_t size = key_dictionary_size[g], stride = direct_stride[g];
+      uint32_t vid[BLOCKS][GB];
+      if (key_width[g] == 1) {
+        const global_u32* base = reinterpret_cast<const global_u32*>(reinterpret_cast<uintptr_t>(key_data[g]));
+        uint32_t word[BLOCKS];
+#pragma unroll
+        for (uint32_t block = 0; block < BLOCKS; ++block) {
+          const uint32_t r0 = slice_row(block * GB, tid);
+          word[block] = base[(slice.row_begin + (r0 < slice.row_count ? r0 : 0)) / 4];
+        }
+#pragma unroll
+        for (uint32_t block = 0; block < BLOCKS; ++block) {
+#pragma unroll
+          for (int i = 0; i < GB; ++i) vid[block][i] = (word[block] >> (8 * i)) & 0xFF;
+        }
+      } else if (key_width[g] == 2) {
+        const global_u32x2* base = reinterpret_cast<const global_u32x2*>(reinterpret_cast<uintptr_t>(key_data[g]));
+        u32x2 word[BLOCKS];
+#pragma unroll
+        for (uint32_t block = 0; block < BLOCKS; ++block) {
+          const uint32_t r0 = slice_row(block * GB, tid);
+          word[block] = base[(slice.row_begin + (r0 < slice.row_count ? r0 : 0)) / 4];
+        }
+#pragma unroll
+        for (uint32_t block = 0; block < BLOCKS; ++block) {
+          vid[block][0] = word[block].x & 0xFFFF; vid[block][1] = word[block].x >> 16; vid[block][2] = word[block].y & 0xFFFF; vid[block][3] = word[block].y >> 16;
+        }
+      } else {
+        const global_u32* base = reinterpret_cast<const global_u32*>(reinterpret_cast<uintptr_t>(key_data[g]));
+#pragma unroll
+        for (uint32_t block = 0; block < BLOCKS; ++block) {
+          const uint32_t r0 = slice_row(block * GB, tid);
+#pragma unroll
+          for (int i = 0; i < GB; ++i) vid[block][i] = base[slice.row_begin + (r0 + i < slice.row_count ? r0 + i : 0)];
+        }
+      }
+#pragma unroll
+      for (uint32_t block = 0; block < BLOCKS; ++block) {
+#pragma unroll
+        for (int i = 0; i < GB; ++i) codes[block] += ((vid[block][i] < size ? vid[block][i] : size) * stride) << (8 * i);   // NULL: the last digit.  (A code is below 256: no carry.)
+      }
+    }
+#pragma unroll
+    for (uint32_t block = 0; block < BLOCKS; ++block) {
+      const uint32_t r0 = slice_row(block * GB, tid);
+      const uint32_t valid = r0 + 3 < slice.row_count ? 0xFu : (r0 < slice.row_count ? (1u << (slice.row_count - r0)) - 1 : 0u);
+      in_table |= valid << (block * GB);
+      reinterpret_cast<uint32_t*>(s_row_slot)[block * 256 + tid] = codes[block];   // = s_row_slot[slice_row(block * 4 + i, tid)], i = 0..3
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        if (!((valid >> i) & 1)) continue;
+        const uint32_t code = (codes[block] >> (8 * i)) & 0xFF;
+        if (code < 32) seen_low |= 1u << code;
+        else atomicOr(&s_present[code >> 5], 1u << (code & 31));
+      }
+    }
+    if (seen_low) atomicOr(&s_present[0], seen_low);
+    __syncthreads();
+    {   // thread = code: enter the group; its dense index is its rank among the codes present
+      uint32_t before = 0, total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < 8; ++w) {
+        const uint32_t bits = s_present[w];
+        total += __popc(bits);
+        if (w < (tid >> 5)) before += __popc(bits);
+        else if (w == (tid >> 5)) before += __popc(bits & ((1u << (tid & 31)) - 1));
+      }
+      if (tid < LDS_SLOTS && ((s_present[tid >> 5] >> (tid & 31)) & 1)) {
+        uint64_t null_mask = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+          if (g >= a.n_groupby) continue;
+          const uint32_t digit = (tid / direct_stride[g]) % direct_size[g];
+          const bool is_null = digit == direct_size[g] - 1;
+          if (is_null) null_mask |= 1ull << g;
+          s_keys[tid * words + g + 1] = is_null ? 0 : digit;
+        }
+        s_keys[tid * words] = null_mask;
+        s_dense_of_slot[tid] = before;
+        if (before < DENSE_GROUPS) s_slot_of_dense[before] = tid;
+        s_tags[tid] = 0x80000000u;
+      }
+      if (tid == 0) *s_n_groups = total;
+    }
+  }
 #pragma unroll 1
-  for (uint32_t block = 0; block < ROWS / GB; ++block) {
+  for (uint32_t block = direct ? ROWS / GB : 0; block < ROWS / GB; ++block) {
     uint32_t row[GB], valid = 0;
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
@@ -355,19 +478,18 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
 #pragma unroll
     for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
       if (g >= a.n_groupby || !((local_keys >> g) & 1)) continue;
-      const DevSegment& seg = a.groupby[g].segments[slice.chunk];
       // the block's four rows are consecutive and start at a multiple of four: one aligned load of all four value ids
       // (not for the group that straddles the end of the chunk: nothing may be read behind a caller's buffer)
-      if (seg.width == 1 && valid == 0xF) {
-        const uint32_t four = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(seg.data) + row[0]);
+      if (key_width[g] == 1 && valid == 0xF) {
+        const uint32_t four = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(key_data[g]) + row[0]);
 #pragma unroll
         for (int i = 0; i < GB; ++i) vid[g][i] = (four >> (8 * i)) & 0xFF;
-      } else if (seg.width == 2 && valid == 0xF) {
-        const u32x2 four = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(seg.data) + row[0]);
+      } else if (key_width[g] == 2 && valid == 0xF) {
+        const u32x2 four = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(key_data[g]) + row[0]);
         vid[g][0] = four.x & 0xFFFF; vid[g][1] = four.x >> 16; vid[g][2] = four.y & 0xFFFF; vid[g][3] = four.y >> 16;
       } else {
 #pragma unroll
-        for (int i = 0; i < GB; ++i) vid[g][i] = aload_compressed(seg.data, seg.width, row[i]);
+        for (int i = 0; i < GB; ++i) vid[g][i] = aload_compressed(key_data[g], key_width[g], row[i]);
       }
     }
 #pragma unroll
@@ -378,7 +500,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         continue;
       }
       if ((local_keys >> g) & 1) {
-        const uint32_t dictionary_size = a.groupby[g].segments[slice.chunk].aux_size;
+        const uint32_t dictionary_size = key_dictionary_size[g];
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
           const bool is_null = vid[g][i] >= dictionary_size;
@@ -398,34 +520,6 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         tuple[i][g + 1] = word;
       }
     }
-    if (direct) {
-      // every GROUP BY column is a dictionary segment and the product of (dictionary size + 1) fits the table: the
-      // combined value-id code IS the slot -- no hash, no probing, no key comparison
-#pragma unroll
-      for (int i = 0; i < GB; ++i) {
-        if (!((valid >> i) & 1)) continue;
-        const uint32_t k = block * GB + i;
-        uint32_t slot = 0;
-#pragma unroll
-        for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
-          if (g < a.n_groupby) slot += (((tuple[i][0] >> g) & 1) ? direct_size[g] - 1 : static_cast<uint32_t>(tuple[i][g + 1])) * direct_stride[g];
-        }
-        if (__hip_atomic_load(&s_tags[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == TAG_EMPTY) {
-          if (atomicCAS(&s_tags[slot], TAG_EMPTY, TAG_LOCKED) == TAG_EMPTY) {   // first row of this group in the slice
-#pragma unroll
-            for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) { if (w < words) s_keys[slot * words + w] = tuple[i][w]; }
-            const uint32_t dense = atomicAdd(s_n_groups, 1u);
-            s_dense_of_slot[slot] = dense;
-            if (dense < DENSE_GROUPS) s_slot_of_dense[dense] = slot;
-            __threadfence_block();
-            atomicExch(&s_tags[slot], 0x80000000u);
-          }
-        }
-        in_table |= 1u << k;
-        s_row_slot[k * 256 + tid] = static_cast<uint8_t>(slot);
-      }
-      continue;
-    }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
       if (!((valid >> i) & 1)) continue;
@@ -438,7 +532,11 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       uint32_t probes = 0;
       bool done = false;
       while (!done) {
-        const uint32_t tag = __hip_atomic_load(&s_tags[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);   // a plain ds_read: 256 threads reading 4 hot tags with an atomic RMW serialise
+        // A plain ds_read (256 threads reading 4 hot tags with an atomic RMW serialise), relaxed: LDS operations of a wave
+        // execute in order, so the key words read below are the ones written before the tag was published; the signal
+        // fence keeps the compiler from moving those reads up.  (An acquire load waits for every outstanding load.)
+        const uint32_t tag = __hip_atomic_load(&s_tags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __atomic_signal_fence(__ATOMIC_ACQUIRE);
         if (tag == TAG_EMPTY) {
           if (atomicCAS(&s_tags[slot], TAG_EMPTY, TAG_LOCKED) == TAG_EMPTY) {
 #pragma unroll
@@ -467,10 +565,11 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         }
       }
       if (found) in_table |= 1u << k;
-      s_row_slot[k * 256 + tid] = static_cast<uint8_t>(slot);
+      s_row_slot[slice_row(k, tid)] = static_cast<uint8_t>(slot);
     }
   }
   __syncthreads();
+  if (stamps && tid == 0) stamps[1] = wall_clock64();
   const uint32_t n_groups = *s_n_groups;
   const uint32_t n_dense = n_groups < DENSE_GROUPS ? n_groups : DENSE_GROUPS;
 
@@ -478,23 +577,37 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   uint32_t dense_lo = 0, dense_hi = 0;   // dense index of every row, two bits per row (rows 0-15 | 16-31); 3 = not dense when n_dense < 4 ...
   uint32_t is_dense = 0;                 // ... so the membership is kept separately
   {
-    uint32_t first[DENSE_GROUPS], last[DENSE_GROUPS];
+    uint32_t slots[ROWS / 4];
 #pragma unroll
-    for (uint32_t j = 0; j < DENSE_GROUPS; ++j) { first[j] = 0xFFFFFFFFu; last[j] = 0; }
+    for (uint32_t m = 0; m < ROWS / 4; ++m) slots[m] = reinterpret_cast<const uint32_t*>(s_row_slot)[m * 256 + tid];   // rows 4m .. 4m+3 of the thread
 #pragma unroll
     for (uint32_t k = 0; k < ROWS; ++k) {
       const uint32_t r = slice_row(k, tid);
       if (r < slice.row_count && ((in_table >> k) & 1)) {
-        const uint32_t dense = s_dense_of_slot[s_row_slot[k * 256 + tid]];
+        const uint32_t dense = s_dense_of_slot[(slots[k / 4] >> (8 * (k & 3))) & 0xFF];
         if (dense < DENSE_GROUPS) {
           is_dense |= 1u << k;
           if (k < 16) dense_lo |= dense << (2 * k); else dense_hi |= dense << (2 * (k - 16));
-#pragma unroll
-          for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
-            if (dense == j) { first[j] = min(first[j], r); last[j] = max(last[j], r); }
-          }
         }
       }
+    }
+    // A thread's rows ascend with k: the first / last row of a group is the lowest / highest set bit of the group's
+    // membership mask (the two-bit codes of 16 rows compared at once, the even bits of the match squeezed together).
+    uint32_t first[DENSE_GROUPS], last[DENSE_GROUPS];
+    auto squeeze = [](uint32_t x) {   // bits 0, 2, 4 ... 30 -> bits 0 .. 15
+      x &= 0x55555555u;
+      x = (x | x >> 1) & 0x33333333u;
+      x = (x | x >> 2) & 0x0F0F0F0Fu;
+      x = (x | x >> 4) & 0x00FF00FFu;
+      return (x | x >> 8) & 0xFFFFu;
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+      const uint32_t want_low = (j & 1) ? 0xFFFFFFFFu : 0u, want_high = (j & 2) ? 0xFFFFFFFFu : 0u;
+      const uint32_t match_lo = ~(dense_lo ^ want_low) & ~((dense_lo >> 1) ^ want_high), match_hi = ~(dense_hi ^ want_low) & ~((dense_hi >> 1) ^ want_high);
+      const uint32_t members = (squeeze(match_lo) | squeeze(match_hi) << 16) & is_dense;
+      first[j] = members ? slice_row(static_cast<uint32_t>(__ffs(static_cast<int>(members))) - 1, tid) : 0xFFFFFFFFu;
+      last[j] = members ? slice_row(31u - static_cast<uint32_t>(__clz(static_cast<int>(members))), tid) : 0u;
     }
 #pragma unroll
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {   // representative rows: smallest / largest row of the group
@@ -514,9 +627,12 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     }
   }
   constexpr int AB = 16;
+  if (stamps && tid == 0) stamps[2] = wall_clock64();
 #pragma unroll 1
   for (uint32_t g = 0; g < a.n_aggregates; ++g) {
+    if (stamps && tid == 0 && g < 6) stamps[3 + g] = wall_clock64();
     const AggColumn c = a.aggregates[g];
+    const DevSegment value_segment = c.segments ? c.segments[slice.chunk] : DevSegment{};
     // what the accumulators do, decided once per aggregate (not per row)
     enum : uint32_t { ACC_NONE, ACC_MIN, ACC_MAX, ACC_ADD_INT, ACC_ADD_DOUBLE };
     uint32_t kind = ACC_NONE;
@@ -528,10 +644,11 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     const bool int_to_double = c.function == HY_AGG_AVG && !c.is_float;
     // One private cell per (dense group, thread): the LDS read-modify-write instructions below never conflict, a row
     // costs one ds_add / ds_min / ds_max on the value cell and one ds_add on the count cell.
+    uint32_t cell_count[DENSE_GROUPS];   // the thread's non-NULL rows of every dense group: population counts, no LDS traffic
 #pragma unroll
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
       s_cell_value[j * 256 + tid] = initial_value(c.function);
-      s_cell_count[j * 256 + tid] = 0;
+      cell_count[j] = 0;
     }
 #pragma unroll 1
     for (uint32_t half = 0; half < ROWS / AB; ++half) {
@@ -546,7 +663,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
           const uint32_t r = slice_row(half * AB + i, tid);
           row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
         }
-        decode_rows<AB>(c.segments, slice.chunk, row, members, bits, &nulls);
+        decode_rows<AB>(value_segment, c.segments, slice.chunk, row, members, bits, &nulls);
         if (to_ordered) {
 #pragma unroll
           for (int i = 0; i < AB; ++i) bits[i] = static_cast<uint64_t>(ordered_bits(__longlong_as_double(static_cast<long long>(bits[i]))));
@@ -566,9 +683,18 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       // read-modify-write here: the latter makes every row of a group wait for the previous row's LDS round trip.
       uint32_t cell[AB];
 #pragma unroll
-      for (int i = 0; i < AB; ++i) {
-        cell[i] = ((dense_bits >> (2 * i)) & 3) * 256 + tid;
-        if ((take >> i) & 1) atomicAdd(&s_cell_count[cell[i]], 1u);
+      for (int i = 0; i < AB; ++i) cell[i] = ((dense_bits >> (2 * i)) & 3) * 256 + tid;
+      {   // rows taken per dense group: `take` spread to the even bit positions, against the group's two-bit codes
+        uint32_t spread = take;
+        spread = (spread | spread << 8) & 0x00FF00FFu;
+        spread = (spread | spread << 4) & 0x0F0F0F0Fu;
+        spread = (spread | spread << 2) & 0x33333333u;
+        spread = (spread | spread << 1) & 0x55555555u;
+        const uint32_t low = dense_bits & 0x55555555u, high = (dense_bits >> 1) & 0x55555555u;
+        cell_count[0] += __popc(spread & ~low & ~high);
+        cell_count[1] += __popc(spread & low & ~high);
+        cell_count[2] += __popc(spread & ~low & high);
+        cell_count[3] += __popc(spread & low & high);
       }
       switch (kind) {   // one loop per kind: the row loop itself stays free of scalar branches
         case ACC_MIN:
@@ -594,7 +720,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
       if (j >= n_dense) break;
       const uint64_t value = wave_combine(c, s_cell_value[j * 256 + tid]);
-      uint32_t count = s_cell_count[j * 256 + tid];
+      uint32_t count = cell_count[j];
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d, 64);
       if (lane == 0 && count != 0) {
@@ -605,6 +731,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     }
   }
 
+  if (stamps && tid == 0) stamps[9] = wall_clock64();
   // ---- pass 3: rows of the other groups (slices with more than DENSE_GROUPS groups only) ----------------------------------
   if (n_groups > DENSE_GROUPS) {
 #pragma unroll 1
@@ -614,7 +741,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       const uint32_t row = slice.row_begin + r;
       const uint64_t global_row = chunk_base + row;
       const bool found = (in_table >> k) & 1;
-      const uint32_t slot = s_row_slot[k * 256 + tid];
+      const uint32_t slot = s_row_slot[slice_row(k, tid)];
       uint32_t gslot = 0xFFFFFFFFu;
       if (!found) {
         uint64_t tuple[MAX_GROUPBY + 1];
@@ -662,6 +789,10 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     atomicMin(reinterpret_cast<unsigned long long*>(&a.first_row[gslot]), static_cast<unsigned long long>(s_first[s]));
     atomicMax(reinterpret_cast<unsigned long long*>(&a.last_row[gslot]), static_cast<unsigned long long>(s_last[s]));
     for (uint32_t g = 0; g < a.n_aggregates; ++g) merge_global(a, gslot, g, s_values[s * a.n_aggregates + g], s_counts[s * a.n_aggregates + g]);
+  }
+  if (stamps) {
+    __syncthreads();
+    if (tid == 0) stamps[10] = wall_clock64();
   }
 }
 
@@ -742,6 +873,9 @@ struct DeviceGroups {
 
 // Runs aggregate_rows + compact_groups for the columns wired into `a` (GROUP BY and device accumulators), retrying with a
 // larger global table when it overflows.
+static uint64_t* g_agg_trace = nullptr;
+static uint32_t g_agg_trace_slices = 0;
+
 static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out) {
   hipStream_t stream = current_stream();
   const uint32_t words = a.n_groupby + 1;
@@ -771,6 +905,15 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     a.values = values.as<uint64_t>();
     a.counts = counts.as<uint64_t>();
     a.overflow = flags.as<uint32_t>();
+    a.trace = nullptr;
+    if (getenv("HY_AGG_TRACE") && shape->n_slices <= (1u << 14)) {
+      static uint64_t* trace_buffer = nullptr;
+      if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 12 * size_t{1u << 14});
+      (void)hipMemsetAsync(trace_buffer, 0, 8 * 12 * size_t{shape->n_slices}, stream);
+      a.trace = trace_buffer;
+      g_agg_trace = trace_buffer;
+      g_agg_trace_slices = shape->n_slices;
+    }
     if (shape->n_slices && shape->rows) {
       profile_begin(stream);
       hipLaunchKernelGGL(aggregate_rows, dim3(shape->n_slices), dim3(256), lds_bytes, stream, a);
@@ -1058,6 +1201,15 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
   if (!result || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_aggregate_hash: null argument");
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_aggregate_hash: result columns missing");
   return run_aggregate(groupby_columns, n_groupby, aggregates, n_aggregates, result);
+}
+
+// debug only (HY_AGG_TRACE): the per-slice phase stamps of the last aggregate_rows launch; not part of the public header
+int hy_debug_aggregate_trace(uint64_t* out, uint32_t capacity_slices) {
+  if (!g_agg_trace) return 0;
+  const uint32_t n = g_agg_trace_slices < capacity_slices ? g_agg_trace_slices : capacity_slices;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(out, g_agg_trace, size_t{n} * 96, hipMemcpyDeviceToHost);
+  return static_cast<int>(n);
 }
 
 }  // extern "C"

@@ -54,9 +54,11 @@ __device__ inline Value column_value(const DevSegment* segments, uint32_t chunk,
 
 // ---- batched decoding: B rows of one column per call, the loads of all rows issued before any is used ----------------
 // bits[i]: the value as int64 (integer columns) or as the bits of a double (float/double columns); null bit i set for NULL.
+// `s` = segments[chunk], loaded by the caller (once for all the calls on one chunk: the descriptor is a dependent load in
+// front of the data loads).
 template <int B>
-__device__ __forceinline__ void decode_rows(const DevSegment* segments, uint32_t chunk, const uint32_t (&row)[B], uint32_t valid, uint64_t (&bits)[B], uint32_t* nulls) {
-  const DevSegment s = segments[chunk];
+__device__ __forceinline__ void decode_rows(const DevSegment& s, const DevSegment* segments, uint32_t chunk, const uint32_t (&row)[B], uint32_t valid, uint64_t (&bits)[B],
+                                            uint32_t* nulls) {
   *nulls = 0;
   if (s.encoding == HY_ENC_REFERENCE) {
 #pragma unroll 1
@@ -147,6 +149,12 @@ __device__ __forceinline__ void decode_rows(const DevSegment* segments, uint32_t
       for (int i = 0; i < B; ++i) bits[i] = static_cast<const uint64_t*>(values)[index[i]];
       break;
   }
+}
+
+template <int B>
+__device__ __forceinline__ void decode_rows(const DevSegment* segments, uint32_t chunk, const uint32_t (&row)[B], uint32_t valid, uint64_t (&bits)[B], uint32_t* nulls) {
+  const DevSegment s = segments[chunk];
+  decode_rows<B>(s, segments, chunk, row, valid, bits, nulls);
 }
 
 }  // namespace hy

@@ -38,3 +38,20 @@ for i in range(4):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
     print(f"aggregate ms {dt * 1e3:.3f} groups {result.n_groups} rows/s {n / dt:.3g} algorithmic GB/s {n * bytes_per_row / dt / 1e9:.0f}")
+if os.environ.get("HY_AGG_TRACE"):
+    lib.hy_debug_aggregate_trace.argtypes = [C.c_void_p, C.c_uint32]
+    lib.hy_debug_aggregate_trace.restype = C.c_int
+    buf = np.zeros((1 << 14, 12), dtype=np.uint64)
+    ns = lib.hy_debug_aggregate_trace(buf.ctypes.data, 1 << 14)
+    t = buf[:ns].astype(np.int64)
+    t = t[t[:, 10] > 0]
+    n_acc = int(((t[0, 3:9]) > 0).sum())
+    marks = [0, 1, 2] + [3 + g for g in range(n_acc)] + [9, 10]
+    names = ["pass 1 (keys)", "dense prep"] + [f"accumulator {g}" for g in range(n_acc)] + ["pass 3 + merge"]
+    names = ["pass 1 (keys)", "dense prep", "(loop entry)"] + [f"accumulator {g}" for g in range(n_acc)] + ["pass 3 + merge"]
+    print("aggregate_rows slices", len(t), "span us", (t[:, 10].max() - t[:, 0].min()) / 100.0)
+    for i in range(len(marks) - 1):
+        d = (t[:, marks[i + 1]] - t[:, marks[i]]) / 100.0
+        print(f"  {names[i]:16s} mean {d.mean():7.2f} p50 {np.percentile(d, 50):7.2f} p90 {np.percentile(d, 90):7.2f}")
+    print("  total            mean %.2f" % ((t[:, 10] - t[:, 0]).mean() / 100.0))
+    print("  (pass 1: setup before the row loop mean %.2f)" % ((t[:, 11] - t[:, 0]).mean() / 100.0))
