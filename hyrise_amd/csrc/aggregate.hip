@@ -223,10 +223,38 @@ __device__ __forceinline__ void accumulate_lds(const AggColumn& c, uint64_t* tar
   }
 }
 
-__device__ __forceinline__ uint64_t wave_combine(const AggColumn& c, uint64_t v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = combine(c, v, static_cast<uint64_t>(__shfl_xor(static_cast<long long>(v), d, 64)));
+// Reductions over the 64 lanes of a wave with DPP moves (a few cycles each; __shfl_xor is a ds_bpermute round trip through
+// the LDS crossbar per step -- the eleven reductions per accumulator used to cost more than the accumulation itself).
+// Scan-shaped: row_shr 1, 2, 4, 8 inside every row of 16 lanes, then row_bcast 15 / 31; the result is in LANE 63.  Lanes
+// without a source (and rows a broadcast does not reach) combine with `identity`.
+template <typename Combine>
+__device__ __forceinline__ uint64_t wave_reduce_to_lane63(uint64_t v, uint64_t identity, Combine combine_values) {
+  const int id_lo = static_cast<int>(static_cast<uint32_t>(identity)), id_hi = static_cast<int>(static_cast<uint32_t>(identity >> 32));
+#define HY_DPP_STEP(CTRL, ROW_MASK)                                                                                         \
+  {                                                                                                                        \
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id_lo, static_cast<int>(static_cast<uint32_t>(v)), CTRL, ROW_MASK, 0xF, false));       \
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id_hi, static_cast<int>(static_cast<uint32_t>(v >> 32)), CTRL, ROW_MASK, 0xF, false)); \
+    v = combine_values(v, static_cast<uint64_t>(hi) << 32 | lo);                                                            \
+  }
+  HY_DPP_STEP(0x111, 0xF)   // row_shr:1
+  HY_DPP_STEP(0x112, 0xF)   // row_shr:2
+  HY_DPP_STEP(0x114, 0xF)   // row_shr:4
+  HY_DPP_STEP(0x118, 0xF)   // row_shr:8
+  HY_DPP_STEP(0x142, 0xA)   // row_bcast:15 into rows 1 and 3
+  HY_DPP_STEP(0x143, 0xC)   // row_bcast:31 into rows 2 and 3
+#undef HY_DPP_STEP
   return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_u32_to_lane63(uint32_t v, uint32_t identity, bool take_min, bool take_max) {
+  return static_cast<uint32_t>(wave_reduce_to_lane63(v, identity, [=](uint64_t a, uint64_t b) {
+    const uint32_t x = static_cast<uint32_t>(a), y = static_cast<uint32_t>(b);
+    return static_cast<uint64_t>(take_min ? min(x, y) : take_max ? max(x, y) : x + y);
+  }));
+}
+
+__device__ __forceinline__ uint64_t wave_combine(const AggColumn& c, uint64_t v) {   // result in lane 63
+  return wave_reduce_to_lane63(v, initial_value(c.function), [&](uint64_t a, uint64_t b) { return combine(c, a, b); });
 }
 
 // Aggregate input of one row (generic, one row at a time): false for NULL (NULL inputs leave the aggregate unchanged,
@@ -296,9 +324,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   uint32_t* s_dense_of_slot = s_tags + LDS_SLOTS;                                            // [LDS_SLOTS]
   uint32_t* s_slot_of_dense = s_dense_of_slot + LDS_SLOTS;                                   // [DENSE_GROUPS]
   uint32_t* s_n_groups = s_slot_of_dense + DENSE_GROUPS;
-  uint64_t* s_cell_value = reinterpret_cast<uint64_t*>(s_n_groups + 4);                     // [DENSE_GROUPS][256] thread-private accumulators
-  uint32_t* s_cell_count = reinterpret_cast<uint32_t*>(s_cell_value + DENSE_GROUPS * 256);   // [DENSE_GROUPS][256]
-  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_cell_count + DENSE_GROUPS * 256);       // [SLICE_ROWS] LDS slot of every row of the slice (a thread's four consecutive rows: one word)
+  uint32_t* s_present = s_n_groups + 4;                                                      // [8] direct-mapped pass 1: one bit per code met in the slice
+  uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_present + 12);                          // [SLICE_ROWS] LDS slot of every row of the slice (a thread's four consecutive rows: one word)
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   for (uint32_t s = tid; s < LDS_SLOTS; s += 256) {
     s_tags[s] = TAG_EMPTY;
@@ -362,7 +389,6 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     // value-id code IS the slot -- no hash, no probing, no key comparison, and no table traffic per row either: the rows
     // only mark their code in a presence bitmap (codes below 32 through a register first), the groups are entered after
     // the loop by the thread that owns the code.  All attribute-vector loads of the slice are in flight at once.
-    uint32_t* s_present = s_cell_count;   // [8] one bit per code
     if (tid < 8) s_present[tid] = 0;
     __syncthreads();
     uint32_t seen_low = 0;
@@ -413,7 +439,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
 #pragma unroll
       for (uint32_t block = 0; block < BLOCKS; ++block) {
 #pragma unroll
-        for (int i = 0; i < GB; ++i) codes[block] += ((vid[block][i] < size ? vid[block][i] : size) * stride) << (8 * i);   // NULL: the last digit.  (A code is below 256: no carry.)
+        for (int i = 0; i < GB; ++i) codes[block] += __umul24(vid[block][i] < size ? vid[block][i] : size, stride) << (8 * i);   // NULL: the last digit.  (A code is below 256: no carry; 24-bit multiply: full rate.)
       }
     }
 #pragma unroll
@@ -612,14 +638,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
 #pragma unroll
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {   // representative rows: smallest / largest row of the group
       if (j >= n_dense) break;
-      uint32_t lowest = first[j], highest = last[j];
-      const bool any = lowest != 0xFFFFFFFFu;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) {
-        lowest = min(lowest, static_cast<uint32_t>(__shfl_xor(static_cast<int>(lowest), d, 64)));
-        highest = max(highest, static_cast<uint32_t>(__shfl_xor(static_cast<int>(highest), d, 64)));
-      }
-      if (__any(any) && lane == 0) {
+      const uint32_t lowest = wave_reduce_u32_to_lane63(first[j], 0xFFFFFFFFu, true, false), highest = wave_reduce_u32_to_lane63(last[j], 0u, false, true);
+      if (lane == 63 && lowest != 0xFFFFFFFFu) {
         const uint32_t slot = s_slot_of_dense[j];
         atomicMin(reinterpret_cast<unsigned long long*>(&s_first[slot]), static_cast<unsigned long long>(chunk_base + slice.row_begin + lowest));
         atomicMax(reinterpret_cast<unsigned long long*>(&s_last[slot]), static_cast<unsigned long long>(chunk_base + slice.row_begin + highest));
@@ -642,12 +662,15 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     else if (c.function == HY_AGG_AVG || c.function == AGG_SUM_SQUARES) kind = ACC_ADD_DOUBLE;
     const bool to_ordered = (kind == ACC_MIN || kind == ACC_MAX) && c.is_float;   // MIN/MAX of doubles on order-preserving int64
     const bool int_to_double = c.function == HY_AGG_AVG && !c.is_float;
-    // One private cell per (dense group, thread): the LDS read-modify-write instructions below never conflict, a row
-    // costs one ds_add / ds_min / ds_max on the value cell and one ds_add on the count cell.
-    uint32_t cell_count[DENSE_GROUPS];   // the thread's non-NULL rows of every dense group: population counts, no LDS traffic
+    // One private accumulator per (dense group, thread), in registers: a row updates the accumulator of its group through
+    // selects (for every group: combine, keep the old value unless the row belongs to it).  That is four combines per row
+    // instead of one, and still several times faster than one LDS atomic per row into a private cell: ds_add_f64 retires
+    // about one lane per cycle.
+    uint64_t cell_value[DENSE_GROUPS];
+    uint32_t cell_count[DENSE_GROUPS];   // the thread's non-NULL rows of every dense group: population counts
 #pragma unroll
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
-      s_cell_value[j * 256 + tid] = initial_value(c.function);
+      cell_value[j] = initial_value(c.function);
       cell_count[j] = 0;
     }
 #pragma unroll 1
@@ -679,11 +702,6 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         for (int i = 0; i < AB; ++i) bits[i] = 0;   // COUNT(*)
       }
       const uint32_t take = members & ~nulls;
-      // The cells are private to the thread, yet LDS atomics (no return value, nothing waits for them) beat a plain
-      // read-modify-write here: the latter makes every row of a group wait for the previous row's LDS round trip.
-      uint32_t cell[AB];
-#pragma unroll
-      for (int i = 0; i < AB; ++i) cell[i] = ((dense_bits >> (2 * i)) & 3) * 256 + tid;
       {   // rows taken per dense group: `take` spread to the even bit positions, against the group's two-bit codes
         uint32_t spread = take;
         spread = (spread | spread << 8) & 0x00FF00FFu;
@@ -696,22 +714,58 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         cell_count[2] += __popc(spread & ~low & high);
         cell_count[3] += __popc(spread & low & high);
       }
+      // the rows of group j among the sixteen: bit i of mine[j]
+      uint32_t mine[DENSE_GROUPS];
+      {
+        auto squeeze = [](uint32_t x) {   // bits 0, 2, 4 ... 30 -> bits 0 .. 15
+          x = (x | x >> 1) & 0x33333333u;
+          x = (x | x >> 2) & 0x0F0F0F0Fu;
+          x = (x | x >> 4) & 0x00FF00FFu;
+          return (x | x >> 8) & 0xFFFFu;
+        };
+        const uint32_t low = dense_bits & 0x55555555u, high = (dense_bits >> 1) & 0x55555555u;
+        mine[0] = squeeze(~low & ~high & 0x55555555u) & take;
+        mine[1] = squeeze(low & ~high) & take;
+        mine[2] = squeeze(~low & high) & take;
+        mine[3] = squeeze(low & high) & take;
+      }
       switch (kind) {   // one loop per kind: the row loop itself stays free of scalar branches
         case ACC_MIN:
 #pragma unroll
-          for (int i = 0; i < AB; ++i) if ((take >> i) & 1) atomicMin(reinterpret_cast<long long*>(&s_cell_value[cell[i]]), static_cast<long long>(bits[i]));
+          for (int i = 0; i < AB; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+              const long long smaller = min(static_cast<long long>(cell_value[j]), static_cast<long long>(bits[i]));
+              cell_value[j] = ((mine[j] >> i) & 1) ? static_cast<uint64_t>(smaller) : cell_value[j];
+            }
+          }
           break;
         case ACC_MAX:
 #pragma unroll
-          for (int i = 0; i < AB; ++i) if ((take >> i) & 1) atomicMax(reinterpret_cast<long long*>(&s_cell_value[cell[i]]), static_cast<long long>(bits[i]));
+          for (int i = 0; i < AB; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
+              const long long larger = max(static_cast<long long>(cell_value[j]), static_cast<long long>(bits[i]));
+              cell_value[j] = ((mine[j] >> i) & 1) ? static_cast<uint64_t>(larger) : cell_value[j];
+            }
+          }
           break;
         case ACC_ADD_INT:
 #pragma unroll
-          for (int i = 0; i < AB; ++i) if ((take >> i) & 1) atomicAdd(reinterpret_cast<unsigned long long*>(&s_cell_value[cell[i]]), static_cast<unsigned long long>(bits[i]));
+          for (int i = 0; i < AB; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) cell_value[j] += ((mine[j] >> i) & 1) ? bits[i] : 0ull;
+          }
           break;
         case ACC_ADD_DOUBLE:
 #pragma unroll
-          for (int i = 0; i < AB; ++i) if ((take >> i) & 1) atomicAdd(reinterpret_cast<double*>(&s_cell_value[cell[i]]), __longlong_as_double(static_cast<long long>(bits[i])));
+          for (int i = 0; i < AB; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {   // (+ 0.0 for the other groups' rows: exact)
+              const double addend = ((mine[j] >> i) & 1) ? __longlong_as_double(static_cast<long long>(bits[i])) : 0.0;
+              cell_value[j] = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(cell_value[j])) + addend));
+            }
+          }
           break;
         default: break;
       }
@@ -719,11 +773,9 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
 #pragma unroll
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
       if (j >= n_dense) break;
-      const uint64_t value = wave_combine(c, s_cell_value[j * 256 + tid]);
-      uint32_t count = cell_count[j];
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d, 64);
-      if (lane == 0 && count != 0) {
+      const uint64_t value = wave_combine(c, cell_value[j]);
+      const uint32_t count = wave_reduce_u32_to_lane63(cell_count[j], 0u, false, false);
+      if (lane == 63 && count != 0) {
         const uint32_t slot = s_slot_of_dense[j];
         accumulate_lds(c, &s_values[slot * a.n_aggregates + g], value);
         atomicAdd(&s_counts[slot * a.n_aggregates + g], count);
@@ -880,7 +932,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   hipStream_t stream = current_stream();
   const uint32_t words = a.n_groupby + 1;
   const uint32_t n_aggregates = a.n_aggregates;
-  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + size_t{DENSE_GROUPS} * 256 * 12 + SLICE_ROWS;
+  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + 64 + SLICE_ROWS;
   uint64_t capacity = 1u << 16;
   while (capacity < 2 * uint64_t{LDS_SLOTS}) capacity <<= 1;
   for (int attempt = 0; attempt < 3; ++attempt) {
