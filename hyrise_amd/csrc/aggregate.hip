@@ -307,6 +307,8 @@ __device__ __forceinline__ void row_tuple(const AggArgs& a, uint32_t chunk, uint
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) uint32_t global_u32;   // (pointers read from a segment descriptor are generic to the compiler: flat loads)
 typedef __attribute__((address_space(1))) u32x2 global_u32x2;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 global_u32x4;
 
 // Row k (0..31) of thread `tid` inside its 8192-row slice: four consecutive rows per lane and step, so that the loads of
 // rows 4m .. 4m+3 of a value / attribute-vector column are one wide load (16 bytes of floats, a dword of byte value ids).
@@ -666,6 +668,9 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     // selects (for every group: combine, keep the old value unless the row belongs to it).  That is four combines per row
     // instead of one, and still several times faster than one LDS atomic per row into a private cell: ds_add_f64 retires
     // about one lane per cycle.
+    // The usual aggregate column -- an unencoded, aligned 4-byte segment without NULLs -- skips the generic decoder.
+    const bool plain4 = c.segments && value_segment.encoding == HY_ENC_UNENCODED && !value_segment.nulls && !(value_segment.flags & SEG_UNALIGNED) &&
+                        (value_segment.data_type == HY_TYPE_INT || value_segment.data_type == HY_TYPE_FLOAT);
     uint64_t cell_value[DENSE_GROUPS];
     uint32_t cell_count[DENSE_GROUPS];   // the thread's non-NULL rows of every dense group: population counts
 #pragma unroll
@@ -686,7 +691,20 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
           const uint32_t r = slice_row(half * AB + i, tid);
           row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
         }
-        decode_rows<AB>(value_segment, c.segments, slice.chunk, row, members, bits, &nulls);
+        if (plain4) {   // four aligned 16-byte loads instead of sixteen decoded rows
+          const global_u32x4* base = reinterpret_cast<const global_u32x4*>(reinterpret_cast<uintptr_t>(value_segment.data));
+          u32x4 raw[AB / 4];
+#pragma unroll
+          for (int m = 0; m < AB / 4; ++m) raw[m] = base[row[4 * m] / 4];   // (rows past the slice's end were clamped to row 0 of the slice: their values are not taken)
+          const bool is_float = value_segment.data_type == HY_TYPE_FLOAT;
+#pragma unroll
+          for (int i = 0; i < AB; ++i) {
+            const uint32_t word = raw[i / 4][i & 3];
+            bits[i] = is_float ? static_cast<uint64_t>(__double_as_longlong(static_cast<double>(__uint_as_float(word)))) : static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(word)));
+          }
+        } else {
+          decode_rows<AB>(value_segment, c.segments, slice.chunk, row, members, bits, &nulls);
+        }
         if (to_ordered) {
 #pragma unroll
           for (int i = 0; i < AB; ++i) bits[i] = static_cast<uint64_t>(ordered_bits(__longlong_as_double(static_cast<long long>(bits[i]))));
