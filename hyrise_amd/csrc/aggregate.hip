@@ -458,7 +458,10 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         else atomicOr(&s_present[code >> 5], 1u << (code & 31));
       }
     }
-    if (seen_low) atomicOr(&s_present[0], seen_low);
+    {   // one LDS atomic per wave, not per thread: 256 atomics on one word are 256 serial operations
+      const uint32_t wave_seen = static_cast<uint32_t>(wave_reduce_to_lane63(seen_low, 0, [](uint64_t x, uint64_t y) { return x | y; }));
+      if (lane == 63 && wave_seen) atomicOr(&s_present[0], wave_seen);
+    }
     __syncthreads();
     {   // thread = code: enter the group; its dense index is its rank among the codes present
       uint32_t before = 0, total = 0;
