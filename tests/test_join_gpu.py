@@ -1,10 +1,12 @@
 """Parity of the HIP JoinHash with the CPU oracle: the concatenated PosList pairs and the 131 070-element slice
 boundaries must be bit-identical (1 GPU: identical order, not just identical multisets)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
 from hyrise_amd import abi, storage
-from hyrise_amd.operators import join_hash
+from hyrise_amd.operators import join_hash, join_hash_count
 from hyrise_amd.storage import DeviceColumn
 from support import build_column, load_tbl, oracle_join
 
@@ -126,3 +128,83 @@ def test_join_tpch_orders_lineitem(device):
     got = check(orders, lineitem, abi.JOIN_INNER, None, "orders x lineitem")
     assert got.n_pairs == data.n_lineitems
     assert got.c.left_is_build == 1
+
+
+def _device_buffer(lib, shape, dtype, fill):
+    """A device buffer through the C ABI, pre-filled (to see what a join leaves untouched)."""
+    host = np.full(shape, fill, dtype=dtype)
+    pointer = C.c_void_p()
+    abi.check(lib.hy_device_malloc(C.byref(pointer), max(host.nbytes, 256)))
+    abi.check(lib.hy_memcpy_h2d(pointer.value, host.ctypes.data, host.nbytes))
+    return pointer.value, host
+
+
+def _read_back(lib, pointer, like):
+    out = np.empty_like(like)
+    abi.check(lib.hy_memcpy_d2h(out.ctypes.data, pointer, out.nbytes))
+    return out
+
+
+@pytest.mark.parametrize("mode", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_SEMI])
+def test_join_device_memory_result_equals_host_memory_result(device, mode):
+    """Device-memory results take the path without a host round trip between the probe passes (the plan of the output is
+    made on the device): same pairs, same PosList cuts as the host-memory result."""
+    rng = np.random.default_rng(31)
+    left_host = build_column(rng.integers(0, 40_000, 300_000).astype(np.int32), rng.random(300_000) < 0.02, 65_535, abi.ENC_DICTIONARY)
+    right_host = build_column(rng.integers(0, 40_000, 50_000).astype(np.int32), None, 20_000, abi.ENC_UNENCODED)
+    left, right = DeviceColumn(left_host), DeviceColumn(right_host)
+    want = join_hash(left, right, mode)
+    n, slices = want.n_pairs, int(want.c.n_slices)
+    p_left, like_pairs = _device_buffer(device, (n + 8, 2), np.uint32, 0xABABABAB)
+    p_right, _ = _device_buffer(device, (n + 8, 2), np.uint32, 0xABABABAB)
+    p_offsets, like_offsets = _device_buffer(device, (slices + 8,), np.uint64, 0xCDCDCDCDCDCDCDCD)
+    r = abi.JoinResult()
+    r.mem, r.radix_bits = abi.MEM_DEVICE, int(want.c.radix_bits)
+    r.left_pos, r.right_pos, r.capacity = p_left, p_right, n
+    r.slice_offsets, r.slice_capacity = p_offsets, slices
+    abi.check(device.hy_join_hash(left.handle, right.handle, mode, C.byref(r)))
+    assert int(r.n_pairs) == n and int(r.n_slices) == slices and int(r.left_is_build) == int(want.c.left_is_build)
+    got_left, got_right, got_offsets = _read_back(device, p_left, like_pairs), _read_back(device, p_right, like_pairs), _read_back(device, p_offsets, like_offsets)
+    build_is_left = bool(want.c.left_is_build)
+    semi = mode == abi.JOIN_SEMI
+    if not (semi and build_is_left):
+        assert got_left[:n].tobytes() == want.left[:n].tobytes()
+    if not (semi and not build_is_left):
+        assert got_right[:n].tobytes() == want.right[:n].tobytes()
+    assert got_offsets[:slices + 1].tobytes() == want.slice_offsets[:slices + 1].tobytes()
+    assert (got_left[n:] == 0xABABABAB).all() and (got_right[n:] == 0xABABABAB).all()   # nothing behind the pairs
+    for p in (p_left, p_right, p_offsets):
+        device.hy_device_free(p)
+
+
+@pytest.mark.parametrize("mem", [abi.MEM_HOST, abi.MEM_DEVICE])
+def test_join_capacity_errors_leave_the_buffers_alone(device, mem):
+    """A result that does not fit is HY_ERR_CAPACITY with the needed sizes reported -- decided on the device between the
+    probe passes: pass 2 must not write a single pair."""
+    rng = np.random.default_rng(32)
+    left_host = build_column(rng.integers(0, 1_000, 100_000).astype(np.int32), None, 65_535, abi.ENC_UNENCODED)
+    right_host = build_column(np.arange(1_000, dtype=np.int32), None, 65_535, abi.ENC_UNENCODED)
+    left, right = DeviceColumn(left_host), DeviceColumn(right_host)
+    n = join_hash_count(left, right, abi.JOIN_INNER)
+    assert n == 100_000
+    for capacity, slice_capacity in ((n - 1, 64), (n, 0)):
+        r = abi.JoinResult()
+        r.mem, r.radix_bits, r.capacity, r.slice_capacity = mem, 0xFFFFFFFF, capacity, slice_capacity
+        if mem == abi.MEM_HOST:
+            left_pos, right_pos = np.full((n, 2), 0xABABABAB, dtype=np.uint32), np.full((n, 2), 0xABABABAB, dtype=np.uint32)
+            offsets = np.full(80, 0xCDCDCDCDCDCDCDCD, dtype=np.uint64)
+            r.left_pos, r.right_pos, r.slice_offsets = left_pos.ctypes.data, right_pos.ctypes.data, offsets.ctypes.data
+        else:
+            p_left, like_pairs = _device_buffer(device, (n, 2), np.uint32, 0xABABABAB)
+            p_right, _ = _device_buffer(device, (n, 2), np.uint32, 0xABABABAB)
+            p_offsets, like_offsets = _device_buffer(device, (80,), np.uint64, 0xCDCDCDCDCDCDCDCD)
+            r.left_pos, r.right_pos, r.slice_offsets = p_left, p_right, p_offsets
+        status = device.hy_join_hash(left.handle, right.handle, abi.JOIN_INNER, C.byref(r))
+        assert status == abi.ERR_CAPACITY
+        assert int(r.n_pairs) == n and int(r.n_slices) >= 1   # what the caller needs to retry
+        if mem == abi.MEM_DEVICE:
+            left_pos, right_pos, offsets = _read_back(device, p_left, like_pairs), _read_back(device, p_right, like_pairs), _read_back(device, p_offsets, like_offsets)
+            for p in (p_left, p_right, p_offsets):
+                device.hy_device_free(p)
+        assert (left_pos == 0xABABABAB).all() and (right_pos == 0xABABABAB).all()
+        assert (offsets == 0xCDCDCDCDCDCDCDCD).all()
