@@ -132,3 +132,34 @@ def test_count_distinct_and_stddev(device):
         run_both([ka, kb], aggregates, f"distinct/stddev chunk {chunk} enc {encoding}")
         run_both([ka], aggregates[:4], f"distinct/stddev one key chunk {chunk} enc {encoding}")
         run_both([], aggregates[:4], f"distinct/stddev no GROUP BY chunk {chunk} enc {encoding}")
+
+
+@pytest.mark.parametrize("n", [300_001, 65_535 * 2 + 3])
+def test_direct_mapped_groups_and_plain_value_columns(device, n):
+    """The fast paths of aggregate_rows: every GROUP BY column a dictionary segment with a small combined domain (the
+    combined value-id code is the slot; codes above 31 take the LDS bitmap, more than four groups per slice take pass 3),
+    NULL keys, chunk ends that are no multiple of four rows, and unencoded 4-byte aggregate columns without NULLs (wide
+    loads) next to nullable / 8-byte ones (generic decoder)."""
+    rng = np.random.default_rng(n)
+    chunk = 65_535
+    k1 = rng.integers(0, 40, n).astype(np.int32) * 3
+    k2 = rng.integers(0, 5, n).astype(np.int64)
+    k1_null, k2_null = rng.random(n) < 0.01, rng.random(n) < 0.02
+    g1 = build_column(k1, k1_null, chunk, abi.ENC_DICTIONARY)     # 41 x 6 codes = 246 <= 256: direct-mapped
+    g2 = build_column(k2, k2_null, chunk, abi.ENC_DICTIONARY)
+    few = build_column(rng.integers(0, 2, n).astype(np.int32), None, chunk, abi.ENC_DICTIONARY)   # 3 x ... : at most four groups with `few` alone
+    ints = build_column(rng.integers(-50_000, 50_000, n).astype(np.int32), None, chunk, abi.ENC_UNENCODED)
+    floats = build_column((rng.random(n) * 100).astype(np.float32), None, chunk, abi.ENC_UNENCODED)
+    nullable = build_column((rng.random(n) * 100).astype(np.float32), rng.random(n) < 0.1, chunk, abi.ENC_UNENCODED)
+    doubles = build_column(rng.normal(0.0, 1e3, n), None, chunk, abi.ENC_UNENCODED)
+    longs = build_column(rng.integers(-10**14, 10**14, n).astype(np.int64), None, chunk, abi.ENC_UNENCODED)
+    aggregates = [(abi.AGG_SUM, ints), (abi.AGG_AVG, ints), (abi.AGG_MIN, ints), (abi.AGG_MAX, floats), (abi.AGG_SUM, floats), (abi.AGG_AVG, floats),
+                  (abi.AGG_SUM, nullable), (abi.AGG_COUNT, nullable)]
+    more = [(abi.AGG_MIN, floats), (abi.AGG_MAX, ints), (abi.AGG_SUM, doubles), (abi.AGG_MAX, longs), (abi.AGG_STDDEV_SAMP, floats), (abi.AGG_COUNT, None)]
+    got = run_both([g1, g2], aggregates, "246 codes")
+    assert got.n_groups == 41 * 6
+    run_both([g2, g1], more, "246 codes, other aggregates")
+    got = run_both([few], aggregates, "two groups")
+    assert got.n_groups == 2
+    run_both([few, g2], more, "12 codes")
+    run_both([g2], aggregates[:6] + more[:2], "six groups: two of them behind the dense four")
