@@ -64,6 +64,12 @@ class JoinResult(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class JoinPredicate(C.Structure):
+    """hy_join_predicate: left_column <condition> right_column, evaluated on the pairs the primary equality finds."""
+    _fields_ = [("left_column", C.c_void_p), ("right_column", C.c_void_p), ("condition", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+MAX_SECONDARY_PREDICATES = 4
 ARITH_ADD, ARITH_SUB, ARITH_MUL, ARITH_DIV, ARITH_MOD = range(5)
 
 
@@ -111,6 +117,7 @@ SYMBOLS = [
     ("hy_column_chunk_rows", C.c_uint32, [C.c_void_p, C.c_uint32]),
     ("hy_validate", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ScanResult)]),
     ("hy_join_hash", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinResult)]),
+    ("hy_join_hash_predicates", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinPredicate), C.c_uint32, C.POINTER(JoinResult)]),
     ("hy_join_hash_radix_bits", C.c_int32, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),
     ("hy_join_hash_count", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("hy_aggregate_hash", C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(AggregateSpec), C.c_uint32,
@@ -132,10 +139,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("HY_LIBRARY", LIB_PATH)   # (another build of the same library: A/B timing)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). hyrise_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = restype

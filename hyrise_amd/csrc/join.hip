@@ -23,6 +23,7 @@
 // arrays are ever written.  The Bloom filters of the reference are reproduced only where they are observable: the
 // build side's filter decides which probe elements count as "materialised" (it shifts the 131 070-element cuts).
 #include "hy_device.hpp"
+#include "hy_decode.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -524,6 +525,15 @@ struct JoinPlan {   // written by plan_output between the probe passes: what pas
   uint32_t fits, n_slices;   // the result buffers hold the pairs and PosLists | number of output PosLists
 };
 
+// A secondary join predicate as the probe sees it:  build_value <condition> probe_value  (the caller's
+// left <condition> right, flipped when the build side is the right input: join_hash.cpp:158-165).
+struct SecondaryPredicate {
+  const DevSegment* build;
+  const DevSegment* probe;
+  uint32_t condition;
+  uint32_t reserved;
+};
+
 struct ProbeArgs {
   const DevSegment* segments;     // probe column
   const Slice* slices;            // 8192-row slices; a tile is a quarter of a slice
@@ -551,6 +561,8 @@ struct ProbeArgs {
   uint32_t* uncached_tiles;       // [n_tiles] ... and which (in no particular order)
   uint32_t* xcd_tickets;          // [8] probe_emit_cached: next tile of every XCD's share
   const JoinPlan* plan;           // pass 2: does the result fit its buffers, how many output PosLists
+  uint32_t n_secondary;           // secondary predicates: every partner the key lookup finds is tested against them
+  SecondaryPredicate secondary[HY_MAX_SECONDARY_PREDICATES];
   uint32_t* error;                // set when a probe row matches >= 2^22 build rows (the staging record cannot hold it)
   uint64_t* trace;                // debug (HY_JOIN_TRACE): 6 wall-clock stamps per probe_emit tile, else nullptr
   uint32_t debug_plain_stores;
@@ -593,6 +605,43 @@ __device__ __forceinline__ ProbeRow probe_row(const ProbeArgs& a, uint32_t chunk
   out.start = start;
   out.emit = pairs_of(a, is_null, count, &out.null_partner);
   return out;
+}
+
+// ---- secondary predicates (MultiPredicateJoinEvaluator, multi_predicate_join_evaluator.hpp:30-61) -------------------------
+// x <condition> y in the common C++ type of the two column types: the reference's comparator functors are generic
+// lambdas, the usual arithmetic conversions apply (int64 against float compares as float).
+__device__ __forceinline__ bool compare_typed(uint32_t condition, const Value& x, uint32_t xt, const Value& y, uint32_t yt) {
+  const bool x_float = xt == HY_TYPE_FLOAT || xt == HY_TYPE_DOUBLE, y_float = yt == HY_TYPE_FLOAT || yt == HY_TYPE_DOUBLE;
+  bool less, equal;
+  if (xt == HY_TYPE_DOUBLE || yt == HY_TYPE_DOUBLE) {
+    const double p = x_float ? x.f : static_cast<double>(x.i), q = y_float ? y.f : static_cast<double>(y.i);
+    less = p < q; equal = p == q;
+  } else if (xt == HY_TYPE_FLOAT || yt == HY_TYPE_FLOAT) {
+    const float p = x_float ? static_cast<float>(x.f) : static_cast<float>(x.i), q = y_float ? static_cast<float>(y.f) : static_cast<float>(y.i);
+    less = p < q; equal = p == q;
+  } else {
+    less = x.i < y.i; equal = x.i == y.i;
+  }
+  switch (condition) {
+    case HY_PRED_EQUALS: return equal;
+    case HY_PRED_NOT_EQUALS: return !equal;
+    case HY_PRED_LESS_THAN: return less;
+    case HY_PRED_LESS_THAN_EQUALS: return less || equal;
+    case HY_PRED_GREATER_THAN: return !less && !equal;
+    default: return !less;   // HY_PRED_GREATER_THAN_EQUALS
+  }
+}
+
+// Does the pair (build row, probe row) satisfy every secondary predicate?  A NULL on either side does not (:50-52).
+__device__ __forceinline__ bool satisfies_secondary(const ProbeArgs& a, hy_row_id build_row, uint32_t probe_chunk, uint32_t probe_row) {
+  for (uint32_t p = 0; p < a.n_secondary; ++p) {
+    const SecondaryPredicate& predicate = a.secondary[p];
+    const Value x = column_value(predicate.build, build_row.chunk_id, build_row.chunk_offset);
+    const Value y = column_value(predicate.probe, probe_chunk, probe_row);
+    if (x.is_null || y.is_null) return false;
+    if (!compare_typed(predicate.condition, x, predicate.build[build_row.chunk_id].data_type, y, predicate.probe[probe_chunk].data_type)) return false;
+  }
+  return true;
 }
 
 // ---- batched evaluation: the JOIN_ROUNDS rows of a lane, phase by phase --------------------------------------------------
@@ -698,13 +747,18 @@ __device__ __forceinline__ void decode_keys(const ProbeArgs& a, uint32_t chunk, 
 constexpr uint32_t ROW_PARTITION = 0xFF, ROW_MATERIALISED = 0x100, ROW_EMIT = 0x200, ROW_NULL_PARTNER = 0x400;
 
 // meta[k] = emit << 10 | null_partner << 9 | partition (INVALID_PARTITION: not materialised); start[k] = first build position
+template <bool SECONDARY>   // instantiated with and without secondary predicates: the plain join pays nothing for them
 __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
-                                              uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&start)[JOIN_ROUNDS]) {
+                                              uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&start)[JOIN_ROUNDS], uint32_t (&partners)[JOIN_ROUNDS]) {
   uint32_t row[JOIN_ROUNDS];
   bool in[JOIN_ROUNDS], is_null[JOIN_ROUNDS];
   int64_t key[JOIN_ROUNDS];
 #pragma unroll
-  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) { meta[k] = INVALID_PARTITION; start[k] = 0; }
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    meta[k] = INVALID_PARTITION;
+    start[k] = 0;
+    if constexpr (SECONDARY) partners[k] = 0;   // (only read with secondary predicates)
+  }
   if (row_count == 0) return;
   decode_keys(a, chunk, row_begin, row_count, wave, lane, row, in, is_null, key);
   // ---- phase 2: which rows are materialised by the NULL policy (the Bloom filter follows the lookup, see phase 4)
@@ -800,13 +854,30 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
       for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) valid[k] = valid[k] && !(count[k] == 0 && hit[k] == 0);
     }
   }
+  // ---- secondary predicates: of the partners the key found, the ones that also satisfy them (join_hash_steps.hpp:727-747,
+  //      869-876).  partners[] keeps the key's partner count: pass 2 walks them again and writes the ones that pass.
+  uint32_t passing[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) passing[k] = count[k];
+  if constexpr (SECONDARY) {
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) partners[k] = count[k];
+#pragma unroll 1
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+      uint32_t n = 0;
+      if (valid[k] && !is_null[k]) {
+        for (uint32_t t = 0; t < count[k]; ++t) n += satisfies_secondary(a, directory_row_id(d, start[k] + t), chunk, row[k]) ? 1u : 0u;
+      }
+      passing[k] = n;
+    }
+  }
   // ---- phase 5: pairs per mode
 #pragma unroll
   for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
     if (!valid[k]) continue;
     const uint32_t partition = a.radix_bits ? static_cast<uint32_t>(static_cast<uint64_t>(key[k]) & ((1u << a.radix_bits) - 1)) : 0;
     bool null_partner = false;
-    uint32_t emit = pairs_of(a, is_null[k], count[k], &null_partner);
+    uint32_t emit = pairs_of(a, is_null[k], passing[k], &null_partner);
     if (emit >= (1u << 22)) { *a.error = 1; emit = (1u << 22) - 1; }
     meta[k] = (emit << 10) | (null_partner ? 0x200u : 0u) | partition;
   }
@@ -828,6 +899,7 @@ __device__ __forceinline__ void tile_rows(const ProbeArgs& a, uint32_t tile, uin
 
 // Pass 1: per tile (4096 consecutive probe rows) and radix partition, the number of materialised probe elements and of
 // output pairs.  Wave w owns rows [w*512, (w+1)*512) of the tile, 64 consecutive rows per round.
+template <bool SECONDARY>
 __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
   __shared__ uint32_t s_elements[MAX_PARTITIONS + 1];   // + 1: "a row of this tile has several partners"
   __shared__ uint32_t s_pairs[MAX_PARTITIONS];
@@ -840,9 +912,9 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_count(ProbeArgs a) {
   __syncthreads();
   uint32_t chunk, row_begin, row_count;
   tile_rows(a, tile, &chunk, &row_begin, &row_count);
-  uint32_t meta[JOIN_ROUNDS], start[JOIN_ROUNDS];
-  evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, start);
-  bool fits = true;
+  uint32_t meta[JOIN_ROUNDS], start[JOIN_ROUNDS], partners[JOIN_ROUNDS];
+  evaluate_rows<SECONDARY>(a, chunk, row_begin, row_count, wave, lane, meta, start, partners);
+  bool fits = !SECONDARY;   // (with secondary predicates pass 2 has to test the partners again: probe_emit_generic)
 #pragma unroll
   for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
     const uint32_t partition = meta[round] & 0x1FF;
@@ -1131,6 +1203,7 @@ __host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
 // per-(wave, partition) counters gives every row its stable rank inside (partition, tile), and the pairs are first laid
 // out partition by partition in LDS and then copied out.  Tiles whose pairs do not fit the staging buffer (many
 // duplicates) write their pairs directly.  Two workgroups per CU walk pass 1's list of such tiles.
+template <bool SECONDARY>
 __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) {
   const uint32_t n_listed = *a.n_uncached;
   if (n_listed == 0 || !a.plan->fits) return;
@@ -1164,8 +1237,8 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
   }
 
   // (a) the lookup results of the lane's rows (row  wave*512 + round*64 + lane  <->  index round)
-  uint32_t row_meta[JOIN_ROUNDS], row_start[JOIN_ROUNDS];
-  evaluate_rows(a, chunk, row_begin, row_count, wave, lane, row_meta, row_start);
+  uint32_t row_meta[JOIN_ROUNDS], row_start[JOIN_ROUNDS], row_partners[JOIN_ROUNDS];
+  evaluate_rows<SECONDARY>(a, chunk, row_begin, row_count, wave, lane, row_meta, row_start, row_partners);
 #pragma unroll
   for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
     const uint32_t partition = row_meta[round] & 0x1FF;
@@ -1259,18 +1332,40 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
       if (emit) {
         const bool null_partner = meta & 0x200u;
         const uint32_t start = row_start[round];
-        if (staged) {
-          const uint32_t slot = s_tile_offset[partition] + pair_rank;
-          const uint32_t tag = r | (partition << 12) | (null_partner ? 1u << 21 : 0u);
-          reinterpret_cast<u32x2_t*>(s_stage)[slot] = u32x2_t{tag, start};
+        if constexpr (!SECONDARY) {
+          if (staged) {
+            const uint32_t slot = s_tile_offset[partition] + pair_rank;
+            const uint32_t tag = r | (partition << 12) | (null_partner ? 1u << 21 : 0u);
+            reinterpret_cast<u32x2_t*>(s_stage)[slot] = u32x2_t{tag, start};
 #pragma unroll 1
-          for (uint32_t t = 1; t < emit; ++t) reinterpret_cast<u32x2_t*>(s_stage)[slot + t] = u32x2_t{tag, start + t};   // several partners: rare
+            for (uint32_t t = 1; t < emit; ++t) reinterpret_cast<u32x2_t*>(s_stage)[slot + t] = u32x2_t{tag, start + t};   // several partners: rare
+          } else {
+            const hy_row_id probe_id{chunk, row_begin + r};
+#pragma unroll 1
+            for (uint32_t t = 0; t < emit; ++t) {
+              a.probe_out[pair_pos + t] = probe_id;
+              if (a.build_out) a.build_out[pair_pos + t] = null_partner ? null_row : directory_row_id(a.dir, start + t);
+            }
+          }
         } else {
+          // of the key's partners, the `emit` that satisfy the secondary predicates (a NULL partner: one pair, no build
+          // row; semi / anti joins: the predicates already decided whether the probe row is written, once)
+          const bool filter = !null_partner && a.build_out != nullptr;
+          const uint32_t candidates = filter ? row_partners[round] : emit;
+          const uint32_t tag = r | (partition << 12) | (null_partner ? 1u << 21 : 0u);
           const hy_row_id probe_id{chunk, row_begin + r};
+          uint32_t slot = s_tile_offset[partition] + pair_rank;
+          uint64_t at = pair_pos;
 #pragma unroll 1
-          for (uint32_t t = 0; t < emit; ++t) {
-            a.probe_out[pair_pos + t] = probe_id;
-            if (a.build_out) a.build_out[pair_pos + t] = null_partner ? null_row : directory_row_id(a.dir, start + t);
+          for (uint32_t t = 0; t < candidates; ++t) {
+            if (filter && !satisfies_secondary(a, directory_row_id(a.dir, start + t), chunk, row_begin + r)) continue;
+            if (staged) {
+              reinterpret_cast<u32x2_t*>(s_stage)[slot++] = u32x2_t{tag, start + t};
+            } else {
+              a.probe_out[at] = probe_id;
+              if (a.build_out) a.build_out[at] = null_partner ? null_row : directory_row_id(a.dir, start + t);
+              ++at;
+            }
           }
         }
       }
@@ -1610,8 +1705,38 @@ constexpr uint32_t JOIN_TRACE_TILES = 1u << 15;
 static uint64_t* g_join_trace = nullptr;
 static uint32_t g_join_trace_tiles = 0;
 
-static hy_status run_join(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result, bool count_only, uint64_t* count_out) {
+static bool same_chunk_layout(const hy_column* a, const hy_column* b) {
+  if (a->n_chunks != b->n_chunks) return false;
+  for (uint32_t c = 0; c < a->n_chunks; ++c) if (a->host_segments[c].size != b->host_segments[c].size) return false;
+  return true;
+}
+
+static uint32_t flip_condition(uint32_t condition) {   // flip_predicate_condition (types.cpp)
+  switch (condition) {
+    case HY_PRED_LESS_THAN: return HY_PRED_GREATER_THAN;
+    case HY_PRED_LESS_THAN_EQUALS: return HY_PRED_GREATER_THAN_EQUALS;
+    case HY_PRED_GREATER_THAN: return HY_PRED_LESS_THAN;
+    case HY_PRED_GREATER_THAN_EQUALS: return HY_PRED_LESS_THAN_EQUALS;
+    default: return condition;
+  }
+}
+
+static hy_status run_join(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result, bool count_only, uint64_t* count_out,
+                          const hy_join_predicate* secondary = nullptr, uint32_t n_secondary = 0) {
   if (mode == HY_JOIN_FULL_OUTER || mode == HY_JOIN_CROSS || mode > HY_JOIN_ANTI_NULL_AS_FALSE) return fail(HY_ERR_UNSUPPORTED, "JoinHash does not support join mode %u (join_hash.cpp:38-44)", mode);
+  if (n_secondary > HY_MAX_SECONDARY_PREDICATES) return fail(HY_ERR_UNSUPPORTED, "more than %u secondary join predicates stay on the CPU path", HY_MAX_SECONDARY_PREDICATES);
+  if (n_secondary && mode == HY_JOIN_ANTI_NULL_AS_TRUE) return fail(HY_ERR_UNSUPPORTED, "JoinHash does not support secondary predicates with AntiNullAsTrue (join_hash.cpp:39-44)");
+  for (uint32_t p = 0; p < n_secondary; ++p) {
+    const hy_join_predicate& predicate = secondary[p];
+    if (!predicate.left_column || !predicate.right_column) return fail(HY_ERR_INVALID, "secondary join predicate %u: column missing", p);
+    if (predicate.condition > HY_PRED_GREATER_THAN_EQUALS) return fail(HY_ERR_INVALID, "secondary join predicate %u: condition %u is no comparison", p, predicate.condition);
+    for (const hy_column* column : {predicate.left_column, predicate.right_column}) {
+      if (column->is_mvcc || (column->ref && column->ref->is_mvcc)) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
+      if (column->data_type < HY_TYPE_INT || column->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "secondary join predicates on strings stay on the CPU path");
+    }
+    if (!same_chunk_layout(predicate.left_column, left) || !same_chunk_layout(predicate.right_column, right))
+      return fail(HY_ERR_INVALID, "secondary join predicate %u: the columns do not have the chunk layout of the join's input tables", p);
+  }
   if (!is_integer_column(left) || !is_integer_column(right)) return fail(HY_ERR_UNSUPPORTED, "only int32/int64 join keys run on the device (std::hash of float/string keys is not pinned)");
   hipStream_t stream = current_stream();
   // side selection (join_hash.cpp:139-155)
@@ -1677,6 +1802,12 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     if (n_tiles <= JOIN_TRACE_TILES) { a.trace = trace_buffer; g_join_trace = trace_buffer; g_join_trace_tiles = n_tiles; }
   }
   a.pack_build_ids = b.directory.ids32 ? 1 : 0;
+  a.n_secondary = n_secondary;
+  for (uint32_t p = 0; p < n_secondary; ++p) {   // as the probe sees them: build <condition> probe (join_hash.cpp:158-165)
+    a.secondary[p].build = (build_right ? secondary[p].right_column : secondary[p].left_column)->d_segments;
+    a.secondary[p].probe = (build_right ? secondary[p].left_column : secondary[p].right_column)->d_segments;
+    a.secondary[p].condition = build_right ? flip_condition(secondary[p].condition) : secondary[p].condition;
+  }
   a.hist_elements = hist.as<uint32_t>();
   a.hist_pairs = hist.as<uint32_t>() + second_at;
   a.base_elements = base.as<uint64_t>();
@@ -1745,7 +1876,8 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
 
   // pass 1, the scan of its counts, the plan of the output -- no host round trip in between
   if (n_tiles) {
-    hipLaunchKernelGGL(probe_count, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
+    if (n_secondary) hipLaunchKernelGGL(probe_count<true>, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL(probe_count<false>, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
     HY_TRY(exclusive_scan(hist.as<uint32_t>(), base.as<uint64_t>(), second_at + cells, stream, second_at));
   } else {
     HY_HIP(hipMemsetAsync(base.ptr, 0, 8 * (second_at + cells + 2), stream));
@@ -1780,7 +1912,8 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     static uint32_t workgroups_per_cu = 1;
     if (!lds_raised) {
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_cached), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_cached_lds_words(MAX_PARTITIONS)));
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
       lds_raised = true;
     }
     {
@@ -1799,7 +1932,11 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
     if (cut_grid) hipLaunchKernelGGL(probe_cuts, dim3(cut_grid), dim3(64), 0, stream, a, dev_first_cell, n_groups);
     // the tiles pass 1 listed (usually none: the workgroups read the list's length and leave)
-    if (!host_result || mailbox->n_uncached) hipLaunchKernelGGL(probe_emit_generic, dim3(std::min<uint32_t>(n_tiles, device_cu_count() * 2)), dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
+    if (!host_result || mailbox->n_uncached) {
+      const dim3 generic_grid(std::min<uint32_t>(n_tiles, device_cu_count() * 2));
+      if (n_secondary) hipLaunchKernelGGL(probe_emit_generic<true>, generic_grid, dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
+      else hipLaunchKernelGGL(probe_emit_generic<false>, generic_grid, dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
+    }
   }
   HY_HIP(hipGetLastError());
   clock.mark("pass 2 launched");
@@ -1829,6 +1966,12 @@ extern "C" {
 hy_status hy_join_hash(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result) {
   if (!left || !right || !result) return fail(HY_ERR_INVALID, "hy_join_hash: null argument");
   return run_join(left, right, mode, result, false, nullptr);
+}
+
+hy_status hy_join_hash_predicates(const hy_column* left, const hy_column* right, uint32_t mode, const hy_join_predicate* secondary, uint32_t n_secondary,
+                                  hy_join_result* result) {
+  if (!left || !right || !result || (n_secondary && !secondary)) return fail(HY_ERR_INVALID, "hy_join_hash_predicates: null argument");
+  return run_join(left, right, mode, result, false, nullptr, secondary, n_secondary);
 }
 
 hy_status hy_join_hash_count(const hy_column* left, const hy_column* right, uint32_t mode, uint64_t* n_pairs) {

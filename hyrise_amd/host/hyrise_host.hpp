@@ -967,11 +967,17 @@ class Validate : public AbstractReadOnlyOperator {
 
 using ColumnIDPair = std::pair<ColumnID, ColumnID>;
 
+struct OperatorJoinPredicate {   // operators/operator_join_predicate.hpp: left column <condition> right column
+  ColumnIDPair column_ids;
+  PredicateCondition predicate_condition;
+};
+
 class JoinHash : public AbstractReadOnlyOperator {   // operators/join_hash.hpp:33-36 (primary predicate: Equals)
  public:
   JoinHash(std::shared_ptr<const AbstractOperator> left, std::shared_ptr<const AbstractOperator> right, JoinMode mode, ColumnIDPair column_ids,
-           std::optional<size_t> radix_bits = std::nullopt)
-      : AbstractReadOnlyOperator(std::move(left), std::move(right)), _mode(mode), _column_ids(column_ids), _radix_bits(radix_bits) {}
+           std::optional<size_t> radix_bits = std::nullopt, std::vector<OperatorJoinPredicate> secondary_predicates = {})
+      : AbstractReadOnlyOperator(std::move(left), std::move(right)), _mode(mode), _column_ids(column_ids), _radix_bits(radix_bits),
+        _secondary_predicates(std::move(secondary_predicates)) {}
   const std::string& name() const override { static const std::string n = "JoinHash"; return n; }
   size_t radix_bits = 0;
   bool left_input_is_build_side = false;   // JoinHash::PerformanceData
@@ -980,8 +986,19 @@ class JoinHash : public AbstractReadOnlyOperator {   // operators/join_hash.hpp:
   std::shared_ptr<const Table> _on_execute() override {
     const auto left = left_input_table(), right = right_input_table();
     const auto left_column = device_column(left, _column_ids.first), right_column = device_column(right, _column_ids.second);
+    // JoinHash::supports (join_hash.cpp:39-44)
+    Assert(_mode != JoinMode::AntiNullAsTrue || _secondary_predicates.empty(), "JoinHash does not support secondary predicates with AntiNullAsTrue");
+    std::vector<hy_join_predicate> secondary;
+    std::vector<std::shared_ptr<DeviceColumn>> secondary_columns;   // (keeps the handles alive)
+    for (const auto& predicate : _secondary_predicates) {
+      const auto l = device_column(left, predicate.column_ids.first), r = device_column(right, predicate.column_ids.second);
+      secondary_columns.push_back(l);
+      secondary_columns.push_back(r);
+      secondary.push_back(hy_join_predicate{l->handle, r->handle, static_cast<uint32_t>(predicate.predicate_condition), 0});
+    }
     uint64_t pair_count = 0;
     check_status(hy_join_hash_count(left_column->handle, right_column->handle, static_cast<uint32_t>(_mode), &pair_count));
+    if (!secondary.empty()) pair_count += std::max(left->row_count(), right->row_count());   // outer joins: a NULL partner per probe row at most
     std::vector<RowID> left_positions(std::max<uint64_t>(1, pair_count)), right_positions(std::max<uint64_t>(1, pair_count));
     const uint32_t slice_capacity = static_cast<uint32_t>(std::max(left->row_count(), right->row_count()) / 131070 + std::max(left->chunk_count(), right->chunk_count()) + 300);
     std::vector<uint64_t> slice_offsets(slice_capacity + 2);
@@ -993,7 +1010,7 @@ class JoinHash : public AbstractReadOnlyOperator {   // operators/join_hash.hpp:
     result.capacity = pair_count;
     result.slice_offsets = slice_offsets.data();
     result.slice_capacity = slice_capacity;
-    check_status(hy_join_hash(left_column->handle, right_column->handle, static_cast<uint32_t>(_mode), &result));
+    check_status(hy_join_hash_predicates(left_column->handle, right_column->handle, static_cast<uint32_t>(_mode), secondary.data(), static_cast<uint32_t>(secondary.size()), &result));
     radix_bits = result.radix_bits;
     left_input_is_build_side = result.left_is_build;
     const bool semi_anti = _mode == JoinMode::Semi || _mode == JoinMode::AntiNullAsTrue || _mode == JoinMode::AntiNullAsFalse;
@@ -1039,6 +1056,7 @@ class JoinHash : public AbstractReadOnlyOperator {   // operators/join_hash.hpp:
   JoinMode _mode;
   ColumnIDPair _column_ids;
   std::optional<size_t> _radix_bits;
+  std::vector<OperatorJoinPredicate> _secondary_predicates;
 };
 
 struct AggregateDefinition {   // WindowFunctionExpression over a PQPColumnExpression (INVALID_COLUMN_ID: COUNT(*))

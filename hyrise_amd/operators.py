@@ -205,12 +205,28 @@ def join_hash_count(left, right, mode):
     return int(n.value)
 
 
-def join_hash(left, right, mode, radix_bits=None):
-    """hy_join_hash with a host-memory result sized by hy_join_hash_count."""
+def join_predicates(secondary):
+    """[(left DeviceColumn, condition, right DeviceColumn), ...] -> (ctypes array or None, count)"""
+    if not secondary:
+        return None, 0
+    array = (abi.JoinPredicate * len(secondary))()
+    for i, (left_column, condition, right_column) in enumerate(secondary):
+        array[i].left_column, array[i].right_column, array[i].condition = left_column.handle, right_column.handle, condition
+    return array, len(secondary)
+
+
+def join_hash(left, right, mode, radix_bits=None, secondary=None):
+    """hy_join_hash (hy_join_hash_predicates with secondary predicates) with a host-memory result.  Sized by
+    hy_join_hash_count: secondary predicates only remove pairs of the equi-join (outer joins: never more than
+    count + probe rows)."""
     lib = abi.load_library()
-    n_pairs = join_hash_count(left, right, mode)
+    n_pairs = join_hash_count(left, right, mode) + (max(left.rows, right.rows) if secondary else 0)
     result = HostJoinResult(n_pairs, max(left.rows, right.rows) // 131070 + max(left.n_chunks, right.n_chunks) + 600, radix_bits)
-    abi.check(lib.hy_join_hash(left.handle, right.handle, mode, C.byref(result.c)))
+    predicates, n = join_predicates(secondary)
+    if n:
+        abi.check(lib.hy_join_hash_predicates(left.handle, right.handle, mode, predicates, n, C.byref(result.c)))
+    else:
+        abi.check(lib.hy_join_hash(left.handle, right.handle, mode, C.byref(result.c)))
     return result
 
 

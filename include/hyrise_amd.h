@@ -279,6 +279,23 @@ typedef struct hy_join_result {
 /* Equi-join of two int32/int64 columns.  Pair order == the CPU operator's concatenated probe() output
  * (join_hash_steps.hpp:624-792): by radix partition, then probe row, then build-side insertion order. */
 hy_status hy_join_hash(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result);
+
+/* A secondary join predicate  left_column <condition> right_column  (OperatorJoinPredicate, operator_join_predicate.hpp;
+ * evaluated like MultiPredicateJoinEvaluator::satisfies_all_predicates, multi_predicate_join_evaluator.hpp:44-54, on every
+ * pair the primary equality finds: join_hash_steps.hpp:727-747, 869-876).  The columns are columns of the join's LEFT and
+ * RIGHT input table (same chunk layout as the respective key column), numeric, of any two types: the values are compared
+ * in their common C++ type like the reference's comparator functors; a NULL on either side fails the predicate. */
+typedef struct hy_join_predicate {
+  const hy_column* left_column;
+  const hy_column* right_column;
+  uint32_t condition;             /* HY_PRED_EQUALS .. HY_PRED_GREATER_THAN_EQUALS */
+  uint32_t reserved;
+} hy_join_predicate;
+#define HY_MAX_SECONDARY_PREDICATES 4
+/* hy_join_hash with secondary predicates (n_secondary = 0: the same join).  HY_JOIN_ANTI_NULL_AS_TRUE with secondary
+ * predicates is HY_ERR_UNSUPPORTED, as in JoinHash::supports (join_hash.cpp:39-44). */
+hy_status hy_join_hash_predicates(const hy_column* left, const hy_column* right, uint32_t mode, const hy_join_predicate* secondary,
+                                  uint32_t n_secondary, hy_join_result* result);
 hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint32_t* radix_bits);
 /* Upper bound for result->capacity without running the join (Semi/Anti: probe rows; others: exact pair count). */
 hy_status hy_join_hash_count(const hy_column* left, const hy_column* right, uint32_t mode, uint64_t* n_pairs);

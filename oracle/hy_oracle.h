@@ -66,6 +66,9 @@ int32_t hyo_table_scan_columns(const hyo_column* left, const hyo_column* right, 
 /* ---- JoinHash ------------------------------------------------------------------------------------------------- */
 int32_t hyo_join_hash(const hyo_column* left, const hyo_column* right, uint32_t mode, hy_join_result* result,
                       int threads);
+/* With secondary predicates (the hy_join_predicate's columns are hyo_column pointers here). */
+int32_t hyo_join_hash_predicates(const hyo_column* left, const hyo_column* right, uint32_t mode, const hy_join_predicate* secondary,
+                                 uint32_t n_secondary, hy_join_result* result, int threads);
 uint32_t hyo_calculate_radix_bits(uint64_t build_rows, uint64_t probe_rows);
 /* Step-level entry points pinned by join_hash_steps_test.cpp. */
 /* materialize_input: writes (row_id,value) elements of one column in chunk order; returns element count.

@@ -82,6 +82,95 @@ static int column_value(const hyo_column* col, uint32_t c, uint32_t i, int64_t* 
   return data_value(&referenced->segments[r.chunk_id], r.chunk_offset, out);
 }
 
+/* ---- secondary predicates: MultiPredicateJoinEvaluator (multi_predicate_join_evaluator.hpp:30-61) ----------------------- */
+typedef struct { int is_null; int64_t i; double f; } typed_value_t;   /* .i for int / long, .f for float (widened) / double */
+
+static typed_value_t data_typed_value(const hy_segment* s, uint32_t i) {
+  typed_value_t v = {0, 0, 0.0};
+  const void* values = s->data;
+  uint32_t index = i;
+  if (s->encoding == HY_ENC_DICTIONARY) {
+    const uint32_t vid = load_compressed(s->data, s->width, i);
+    if (vid >= s->aux_size) { v.is_null = 1; return v; }
+    values = s->aux;
+    index = vid;
+  } else {
+    if (s->nulls && ((s->nulls[i / 64] >> (i % 64)) & 1)) { v.is_null = 1; return v; }
+    if (s->encoding == HY_ENC_FRAME_OF_REFERENCE) {
+      v.i = (int32_t)(load_compressed(s->data, s->width, i) + (uint32_t)((const int32_t*)s->aux)[i / HY_FOR_BLOCK_SIZE]);
+      return v;
+    }
+  }
+  switch (s->data_type) {
+    case HY_TYPE_INT: v.i = ((const int32_t*)values)[index]; break;
+    case HY_TYPE_LONG: v.i = ((const int64_t*)values)[index]; break;
+    case HY_TYPE_FLOAT: v.f = ((const float*)values)[index]; break;
+    default: v.f = ((const double*)values)[index]; break;
+  }
+  return v;
+}
+
+static typed_value_t column_typed_value(const hyo_column* col, hy_row_id id, uint32_t* type) {
+  const hy_segment* s = &col->segments[id.chunk_id];
+  *type = s->data_type;
+  if (s->encoding != HY_ENC_REFERENCE) return data_typed_value(s, id.chunk_offset);
+  const hyo_column* referenced = (const hyo_column*)s->ref;
+  hy_row_id r;
+  if (s->data) r = ((const hy_row_id*)s->data)[id.chunk_offset];
+  else { r.chunk_id = s->ref_chunk_id; r.chunk_offset = id.chunk_offset; }
+  typed_value_t null_value = {1, 0, 0.0};
+  if (r.chunk_offset == 0xFFFFFFFFu) return null_value;
+  return data_typed_value(&referenced->segments[r.chunk_id], r.chunk_offset);
+}
+
+static int is_float_type(uint32_t t) { return t == HY_TYPE_FLOAT || t == HY_TYPE_DOUBLE; }
+
+/* x <condition> y in the common C++ type of the two column types (the comparator functors of type_comparison.hpp are
+ * generic lambdas: the usual arithmetic conversions apply -- int64 against float compares as float) */
+static int compare_values(uint32_t condition, typed_value_t x, uint32_t xt, typed_value_t y, uint32_t yt) {
+  int less, equal;
+  if (xt == HY_TYPE_DOUBLE || yt == HY_TYPE_DOUBLE) {
+    const double a = is_float_type(xt) ? x.f : (double)x.i, b = is_float_type(yt) ? y.f : (double)y.i;
+    less = a < b; equal = a == b;
+  } else if (xt == HY_TYPE_FLOAT || yt == HY_TYPE_FLOAT) {
+    const float a = is_float_type(xt) ? (float)x.f : (float)x.i, b = is_float_type(yt) ? (float)y.f : (float)y.i;
+    less = a < b; equal = a == b;
+  } else {
+    less = x.i < y.i; equal = x.i == y.i;
+  }
+  switch (condition) {
+    case HY_PRED_EQUALS: return equal;
+    case HY_PRED_NOT_EQUALS: return !equal;
+    case HY_PRED_LESS_THAN: return less;
+    case HY_PRED_LESS_THAN_EQUALS: return less || equal;
+    case HY_PRED_GREATER_THAN: return !less && !equal;
+    case HY_PRED_GREATER_THAN_EQUALS: return !less;
+    default: return 0;
+  }
+}
+
+typedef struct { const hyo_column* build; const hyo_column* probe; uint32_t condition; } secondary_t;   /* build <condition> probe */
+
+static int satisfies_all_predicates(const secondary_t* predicates, uint32_t n, hy_row_id build_row, hy_row_id probe_row) {
+  for (uint32_t p = 0; p < n; ++p) {
+    uint32_t bt, pt;
+    const typed_value_t b = column_typed_value(predicates[p].build, build_row, &bt), q = column_typed_value(predicates[p].probe, probe_row, &pt);
+    if (b.is_null || q.is_null) return 0;   /* :50-52 (AntiNullAsTrue is not supported with secondary predicates) */
+    if (!compare_values(predicates[p].condition, b, bt, q, pt)) return 0;
+  }
+  return 1;
+}
+
+static uint32_t flip_condition(uint32_t c) {   /* flip_predicate_condition, types.cpp */
+  switch (c) {
+    case HY_PRED_LESS_THAN: return HY_PRED_GREATER_THAN;
+    case HY_PRED_LESS_THAN_EQUALS: return HY_PRED_GREATER_THAN_EQUALS;
+    case HY_PRED_GREATER_THAN: return HY_PRED_LESS_THAN;
+    case HY_PRED_GREATER_THAN_EQUALS: return HY_PRED_LESS_THAN_EQUALS;
+    default: return c;
+  }
+}
+
 static inline int bloom_get(const uint64_t* bloom, uint64_t hash) {
   const uint32_t bit = (uint32_t)(hash & BLOOM_MASK);
   return (int)((bloom[bit / 64] >> (bit % 64)) & 1);
@@ -321,6 +410,7 @@ typedef struct {
   uint64_t build_rows;
   struct { uint32_t partition; uint64_t begin, end; } * slices;
   pos_pair_t* out;
+  const secondary_t* secondary; uint32_t n_secondary;
 } probe_ctx_t;
 
 static const hy_row_id NULL_ROW = {0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -345,7 +435,17 @@ static void probe_job(void* arg, uint64_t s) {
       const uint32_t id = table_find(table, e->value);
       if (id != 0xFFFFFFFFu) {
         if (is_null) { pair_push(out, NULL_ROW, e->row_id, 1); continue; }
-        for (uint64_t m = table->offsets[id]; m < table->offsets[id + 1]; ++m) pair_push(out, table->pos_list[m], e->row_id, 1);
+        if (!p->n_secondary) {
+          for (uint64_t m = table->offsets[id]; m < table->offsets[id + 1]; ++m) pair_push(out, table->pos_list[m], e->row_id, 1);
+        } else { /* :727-747 */
+          int match_found = 0;
+          for (uint64_t m = table->offsets[id]; m < table->offsets[id + 1]; ++m) {
+            if (!satisfies_all_predicates(p->secondary, p->n_secondary, table->pos_list[m], e->row_id)) continue;
+            pair_push(out, table->pos_list[m], e->row_id, 1);
+            match_found = 1;
+          }
+          if (p->keep_nulls && !match_found) pair_push(out, NULL_ROW, e->row_id, 1);
+        }
       } else if (p->keep_nulls) {
         pair_push(out, NULL_ROW, e->row_id, 1);
       }
@@ -358,7 +458,17 @@ static void probe_job(void* arg, uint64_t s) {
       if (mode == HY_JOIN_SEMI) { if (e->row_id.chunk_offset == 0xFFFFFFFFu) continue; }
       else if (mode == HY_JOIN_ANTI_NULL_AS_FALSE) { if (is_null) { pair_push(out, NULL_ROW, e->row_id, 0); continue; } }
       else if (is_null) continue;
-      const int matches = table_find(table, e->value) != 0xFFFFFFFFu;
+      int matches;
+      if (!p->n_secondary) {
+        matches = table_find(table, e->value) != 0xFFFFFFFFu;
+      } else { /* :869-876 */
+        matches = 0;
+        const uint32_t id = table_find(table, e->value);
+        if (id != 0xFFFFFFFFu) {
+          for (uint64_t m = table->offsets[id]; m < table->offsets[id + 1] && !matches; ++m)
+            matches = satisfies_all_predicates(p->secondary, p->n_secondary, table->pos_list[m], e->row_id);
+        }
+      }
       if ((mode == HY_JOIN_SEMI && matches) || (mode != HY_JOIN_SEMI && !matches)) pair_push(out, NULL_ROW, e->row_id, 0);
     }
   }
@@ -373,7 +483,13 @@ static void build_job(void* arg, uint64_t r) {
 
 int32_t hyo_join_hash(const hyo_column* left, const hyo_column* right, uint32_t mode, hy_join_result* result,
                       int threads) {
+  return hyo_join_hash_predicates(left, right, mode, NULL, 0, result, threads);
+}
+
+int32_t hyo_join_hash_predicates(const hyo_column* left, const hyo_column* right, uint32_t mode, const hy_join_predicate* secondary_in,
+                                 uint32_t n_secondary, hy_join_result* result, int threads) {
   if (mode == HY_JOIN_FULL_OUTER || mode == HY_JOIN_CROSS || mode > HY_JOIN_ANTI_NULL_AS_FALSE) return HY_ERR_UNSUPPORTED;
+  if (n_secondary > HY_MAX_SECONDARY_PREDICATES || (n_secondary && mode == HY_JOIN_ANTI_NULL_AS_TRUE)) return HY_ERR_UNSUPPORTED;   /* join_hash.cpp:39-44 */
   uint64_t left_rows = 0, right_rows = 0;
   for (uint32_t c = 0; c < left->n_chunks; ++c) left_rows += left->segments[c].size;
   for (uint32_t c = 0; c < right->n_chunks; ++c) right_rows += right->segments[c].size;
@@ -418,8 +534,19 @@ int32_t hyo_join_hash(const hyo_column* left, const hyo_column* right, uint32_t 
   }
   free(hist_build); free(hist_probe);
 
-  /* build (:426-507) */
-  const int all_positions = !semi_anti;
+  /* secondary predicates follow the side swap (join_hash.cpp:158-165) */
+  secondary_t secondary[HY_MAX_SECONDARY_PREDICATES];
+  for (uint32_t p = 0; p < n_secondary; ++p) {
+    const hyo_column* l = (const hyo_column*)secondary_in[p].left_column;
+    const hyo_column* r = (const hyo_column*)secondary_in[p].right_column;
+    if (secondary_in[p].condition > HY_PRED_GREATER_THAN_EQUALS) return HY_ERR_INVALID;
+    secondary[p].build = build_right ? r : l;
+    secondary[p].probe = build_right ? l : r;
+    secondary[p].condition = build_right ? flip_condition(secondary_in[p].condition) : secondary_in[p].condition;
+  }
+
+  /* build (:426-507); semi / anti joins with secondary predicates need every position (join_hash.cpp:445-453) */
+  const int all_positions = !semi_anti || n_secondary != 0;
   uint32_t n_tables = 0;
   hash_table_t* tables = NULL;
   if (n_build_parts > 0) {
@@ -451,6 +578,7 @@ int32_t hyo_join_hash(const hyo_column* left, const hyo_column* right, uint32_t 
     memset(&pctx, 0, sizeof(pctx));
     pctx.probe_partitions = radix_probe; pctx.tables = tables; pctx.n_tables = n_tables; pctx.mode = mode;
     pctx.keep_nulls = keep_nulls_probe; pctx.build_rows = build_rows;
+    pctx.secondary = secondary; pctx.n_secondary = n_secondary;
     pctx.slices = malloc(sizeof(*pctx.slices) * (n_slices ? n_slices : 1));
     pctx.out = (pos_pair_t*)calloc(n_slices ? n_slices : 1, sizeof(pos_pair_t));
     uint64_t s = 0;

@@ -248,6 +248,51 @@ static void test_join_against_nested_loop() {   // join_test_runner.cpp:656-791 
   }
 }
 
+static void test_join_with_secondary_predicates() {   // join_test_runner.cpp:207-211, 464-480: {0,0} <, >=, != as secondary predicates
+  const auto left = load_and_encode("join_test_runner/input_table_left_15.tbl", 3, EncodingType::Dictionary);
+  const auto right = load_and_encode("join_test_runner/input_table_right_10.tbl", 10, EncodingType::Unencoded);
+  const auto lrows = left->get_output()->get_rows(), rrows = right->get_output()->get_rows();
+  const ColumnID key{6};   // l_long / r_long: few distinct values, several partners per row
+  for (const auto condition : {PredicateCondition::LessThan, PredicateCondition::GreaterThanEquals, PredicateCondition::NotEquals}) {
+    const auto holds = [&](int32_t x, int32_t y) {
+      return condition == PredicateCondition::LessThan ? x < y : condition == PredicateCondition::GreaterThanEquals ? x >= y : x != y;
+    };
+    size_t inner = 0, semi = 0, anti = 0;
+    for (const auto& l : lrows) {
+      bool any = false;
+      for (const auto& r : rrows) {
+        if (variant_is_null(l[key]) || variant_is_null(r[key]) || std::get<int64_t>(l[key]) != std::get<int64_t>(r[key])) continue;
+        if (!holds(std::get<int32_t>(l[0]), std::get<int32_t>(r[0]))) continue;
+        ++inner;
+        any = true;
+      }
+      semi += any;
+      anti += !any;
+    }
+    const std::vector<OperatorJoinPredicate> secondary{{ColumnIDPair{ColumnID{0}, ColumnID{0}}, condition}};
+    auto join = std::make_shared<JoinHash>(left, right, JoinMode::Inner, ColumnIDPair{key, key}, std::nullopt, secondary);
+    join->execute();
+    EXPECT_TRUE(join->get_output()->row_count() == inner);
+    for (const auto& row : join->get_output()->get_rows()) {
+      EXPECT_TRUE(cells_equal(row[key], row[lrows[0].size() + key]));
+      EXPECT_TRUE(holds(std::get<int32_t>(row[0]), std::get<int32_t>(row[lrows[0].size()])));
+    }
+    auto semi_join = std::make_shared<JoinHash>(left, right, JoinMode::Semi, ColumnIDPair{key, key}, 2, secondary);
+    semi_join->execute();
+    EXPECT_TRUE(semi_join->get_output()->row_count() == semi);
+    auto anti_join = std::make_shared<JoinHash>(left, right, JoinMode::AntiNullAsFalse, ColumnIDPair{key, key}, std::nullopt, secondary);
+    anti_join->execute();
+    EXPECT_TRUE(anti_join->get_output()->row_count() == anti);
+    auto left_join = std::make_shared<JoinHash>(left, right, JoinMode::Left, ColumnIDPair{key, key}, std::nullopt, secondary);
+    left_join->execute();
+    EXPECT_TRUE(left_join->get_output()->row_count() == inner + anti);
+    bool thrown = false;   // JoinHash::supports: no secondary predicates with AntiNullAsTrue
+    try { auto j = std::make_shared<JoinHash>(left, right, JoinMode::AntiNullAsTrue, ColumnIDPair{key, key}, std::nullopt, secondary); j->execute(); }
+    catch (const std::logic_error&) { thrown = true; }
+    EXPECT_TRUE(thrown);
+  }
+}
+
 static void test_aggregates_against_fixtures() {   // aggregate_test.cpp: test_output<>(input, aggregates, group by, expected)
   struct Case { std::string input; std::vector<AggregateDefinition> aggregates; std::vector<ColumnID> groupby; std::string expected; };
   const std::string d1 = "aggregateoperator/groupby_int_1gb_1agg/", d2 = "aggregateoperator/groupby_int_1gb_2agg/", d21 = "aggregateoperator/groupby_int_2gb_1agg/";
@@ -345,6 +390,7 @@ int main(int argc, char** argv) {
   run("TableScan.TypeMismatchThrowsLogicError", test_type_mismatch_throws);
   run("Validate.Visibility truth table, reference input, chunk shortcut", test_validate_visibility);
   run("JoinHash vs nested loop (Inner/Semi/AntiNullAsFalse/Left)", test_join_against_nested_loop);
+  run("JoinHash with secondary predicates vs nested loop", test_join_with_secondary_predicates);
   run("AggregateHash vs .tbl fixtures (+ CannotSumStringColumns)", test_aggregates_against_fixtures);
   hy_shutdown();
   std::printf("%s\n", g_failures ? "HOST TESTS FAILED" : "HOST TESTS PASSED");

@@ -305,6 +305,9 @@ class HostJoinResult:
 def _bind_join(lib):
     lib.hyo_join_hash.restype = C.c_int32
     lib.hyo_join_hash.argtypes = [C.POINTER(OracleColumn), C.POINTER(OracleColumn), C.c_uint32, C.POINTER(abi.JoinResult), C.c_int]
+    lib.hyo_join_hash_predicates.restype = C.c_int32
+    lib.hyo_join_hash_predicates.argtypes = [C.POINTER(OracleColumn), C.POINTER(OracleColumn), C.c_uint32, C.POINTER(abi.JoinPredicate), C.c_uint32,
+                                             C.POINTER(abi.JoinResult), C.c_int]
     lib.hyo_calculate_radix_bits.restype = C.c_uint32
     lib.hyo_calculate_radix_bits.argtypes = [C.c_uint64, C.c_uint64]
     lib.hyo_join_materialize.restype = C.c_uint64
@@ -312,16 +315,21 @@ def _bind_join(lib):
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 
 
-def oracle_join(left, right, mode, radix_bits=None, threads=1, capacity=None):
+def oracle_join(left, right, mode, radix_bits=None, threads=1, capacity=None, secondary=None):
+    """secondary: [(left HostColumn, condition, right HostColumn), ...]"""
     lib = oracle()
     _bind_join(lib)
     lcol, rcol = OracleCol(left), OracleCol(right)
+    extra = [(OracleCol(l), c, OracleCol(r)) for l, c, r in (secondary or [])]
+    predicates = (abi.JoinPredicate * max(1, len(extra)))()
+    for i, (l, c, r) in enumerate(extra):
+        predicates[i].left_column, predicates[i].right_column, predicates[i].condition = C.addressof(l.c), C.addressof(r.c), c
     if capacity is None:
         capacity = max(left.rows, right.rows, 1) * 4 + 1024
     slice_capacity = (max(left.rows, right.rows) // 131070) + 600
     while True:
         result = HostJoinResult(capacity, slice_capacity, radix_bits)
-        status = lib.hyo_join_hash(C.byref(lcol.c), C.byref(rcol.c), mode, C.byref(result.c), threads)
+        status = lib.hyo_join_hash_predicates(C.byref(lcol.c), C.byref(rcol.c), mode, predicates, len(extra), C.byref(result.c), threads)
         if status == abi.ERR_CAPACITY:
             capacity *= 8
             continue
@@ -352,9 +360,63 @@ def row_ids_of(host_column):
     return rows
 
 
-def verification_join(left, right, mode):
+_NP_OF_TYPE = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}
+
+
+def cxx_compare(condition, x, x_type, y, y_type):
+    """x <condition> y the way C++ compares an x_type with a y_type value (usual arithmetic conversions: the comparator
+    functors of type_comparison.hpp are generic lambdas) -- int64 against float compares as float."""
+    if abi.TYPE_DOUBLE in (x_type, y_type):
+        common = np.float64
+    elif abi.TYPE_FLOAT in (x_type, y_type):
+        common = np.float32
+    else:
+        common = np.int64
+    a, b = common(_NP_OF_TYPE[x_type](x)), common(_NP_OF_TYPE[y_type](y))
+    return {abi.PRED_EQUALS: a == b, abi.PRED_NOT_EQUALS: a != b, abi.PRED_LESS_THAN: a < b, abi.PRED_LESS_THAN_EQUALS: a <= b,
+            abi.PRED_GREATER_THAN: a > b, abi.PRED_GREATER_THAN_EQUALS: a >= b}[condition]
+
+
+def _verification_join_general(left, right, mode, secondary):
+    """The nested loops themselves, with secondary predicates (join_verification.cpp:60-184): a pair matches if the keys
+    are equal and every secondary predicate holds (NULL on either side: it does not)."""
+    lv, rv = column_values(left), column_values(right)
+    lrows, rrows = row_ids_of(left), row_ids_of(right)
+    extra = [(column_values(l), l.data_type, c, column_values(r), r.data_type) for l, c, r in secondary]
+
+    def matches(i, j):
+        if lv[i] is None or rv[j] is None or lv[i] != rv[j]:
+            return False
+        for xs, xt, c, ys, yt in extra:
+            if xs[i] is None or ys[j] is None or not cxx_compare(c, xs[i], xt, ys[j], yt):
+                return False
+        return True
+
+    out = []
+    if mode == abi.JOIN_INNER:
+        out = [(lrows[i], rrows[j]) for i in range(len(lv)) for j in range(len(rv)) if matches(i, j)]
+    elif mode == abi.JOIN_LEFT:
+        for i in range(len(lv)):
+            found = [(lrows[i], rrows[j]) for j in range(len(rv)) if matches(i, j)]
+            out += found or [(lrows[i], None)]
+    elif mode == abi.JOIN_RIGHT:
+        for j in range(len(rv)):
+            found = [(lrows[i], rrows[j]) for i in range(len(lv)) if matches(i, j)]
+            out += found or [(None, rrows[j])]
+    elif mode == abi.JOIN_SEMI:
+        out = [(lrows[i], None) for i in range(len(lv)) if any(matches(i, j) for j in range(len(rv)))]
+    elif mode == abi.JOIN_ANTI_NULL_AS_FALSE:
+        out = [(lrows[i], None) for i in range(len(lv)) if not any(matches(i, j) for j in range(len(rv)))]
+    else:
+        raise ValueError("AntiNullAsTrue has no secondary predicates in JoinHash")
+    return sorted(out, key=lambda p: (p[0] is None, p[0] or (0, 0), p[1] is None, p[1] or (0, 0)))
+
+
+def verification_join(left, right, mode, secondary=None):
     """Nested-loop reference of the join semantics (JoinVerification, operators/join_verification.cpp:60-184), as a
     sorted multiset of ((left chunk, left offset) | None, (right chunk, right offset) | None)."""
+    if secondary:
+        return _verification_join_general(left, right, mode, secondary)
     lv, rv = column_values(left), column_values(right)
     lrows, rrows = row_ids_of(left), row_ids_of(right)
     out = []

@@ -208,3 +208,70 @@ def test_join_capacity_errors_leave_the_buffers_alone(device, mem):
                 device.hy_device_free(p)
         assert (left_pos == 0xABABABAB).all() and (right_pos == 0xABABABAB).all()
         assert (offsets == 0xCDCDCDCDCDCDCDCD).all()
+
+
+SECONDARY_MODES = [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_FALSE]
+
+
+@pytest.mark.parametrize("mode", SECONDARY_MODES)
+def test_join_with_secondary_predicates_runner_tables(device, mode):
+    """Multi-predicate joins on the reference's join_test_runner inputs (join_test_runner.cpp:207-211, 464-480): the
+    secondary predicates filter the partners the key finds, inside the probe -- same pairs in the same order as the
+    oracle (which agrees with the nested loops of JoinVerification: tests/test_oracle_join.py)."""
+    from test_oracle_join import SECONDARY_SETS, runner_tables, secondary_columns
+    for lsize, rsize in ((10, 15), (15, 10), (15, 15), (0, 10), (10, 0)):
+        lt, rt = runner_tables(lsize, 0)[0], runner_tables(rsize, 0)[1]
+        for key in ("int", "long_null"):
+            lvals, lnull = lt.column("l_" + key)
+            rvals, rnull = rt.column("r_" + key)
+            for chunk, encoding in ((10, abi.ENC_UNENCODED), (3, abi.ENC_DICTIONARY)):
+                left, right = build_column(lvals, lnull, chunk, encoding), build_column(rvals, rnull, chunk, encoding)
+                ldev, rdev = DeviceColumn(left), DeviceColumn(right)
+                for predicate_set in SECONDARY_SETS:
+                    secondary = secondary_columns(lt, rt, predicate_set, chunk, encoding)
+                    on_device = [(DeviceColumn(l), c, DeviceColumn(r)) for l, c, r in secondary]
+                    for radix_bits in (None, 2):
+                        got = join_hash(ldev, rdev, mode, radix_bits, secondary=on_device)
+                        want = oracle_join(left, right, mode, radix_bits, secondary=secondary)
+                        assert_join_equal(got, want, mode, f"key {key} sizes {lsize},{rsize} chunk {chunk} predicates {predicate_set} radix {radix_bits}")
+
+
+@pytest.mark.parametrize("mode", SECONDARY_MODES)
+def test_join_with_secondary_predicates_random(device, mode):
+    """Many partners per key, two secondary predicates on columns of mixed types and encodings, NULLs on all sides, several
+    chunks and radix partitions: the device against the oracle, pair by pair."""
+    rng = np.random.default_rng(41 + mode)
+    n_left, n_right, chunk = 60_000, 9_000, 20_000
+    lkey = build_column(rng.integers(0, 500, n_left).astype(np.int32), rng.random(n_left) < 0.02, chunk, abi.ENC_DICTIONARY)
+    rkey = build_column(rng.integers(0, 500, n_right).astype(np.int32), rng.random(n_right) < 0.02, chunk, abi.ENC_UNENCODED)
+    la = build_column(rng.integers(-50, 50, n_left).astype(np.int64), rng.random(n_left) < 0.05, chunk, abi.ENC_UNENCODED)
+    ra = build_column((rng.random(n_right) * 100 - 50).astype(np.float32), None, chunk, abi.ENC_DICTIONARY)
+    lb = build_column(rng.integers(0, 1000, n_left).astype(np.int32), None, chunk, abi.ENC_FRAME_OF_REFERENCE)
+    rb = build_column(rng.random(n_right) * 1000, rng.random(n_right) < 0.05, chunk, abi.ENC_UNENCODED)
+    secondary = [(la, abi.PRED_LESS_THAN, ra), (lb, abi.PRED_NOT_EQUALS, rb)]
+    ldev, rdev = DeviceColumn(lkey), DeviceColumn(rkey)
+    on_device = [(DeviceColumn(l), c, DeviceColumn(r)) for l, c, r in secondary]
+    for radix_bits in (None, 3):
+        got = join_hash(ldev, rdev, mode, radix_bits, secondary=on_device)
+        want = oracle_join(lkey, rkey, mode, radix_bits, secondary=secondary)
+        assert_join_equal(got, want, mode, f"random, radix {radix_bits}")
+        assert 0 < got.n_pairs
+    plain = join_hash(ldev, rdev, mode, None)
+    if mode == abi.JOIN_INNER:
+        assert got.n_pairs < plain.n_pairs
+
+
+def test_join_secondary_predicate_rejections(device):
+    """AntiNullAsTrue with secondary predicates, string or mis-shaped columns, non-comparisons: rejected like
+    JoinHash::supports (join_hash.cpp:39-44) / the evaluator's type check."""
+    a = DeviceColumn(build_column(np.arange(10, dtype=np.int32), None, 5, abi.ENC_UNENCODED))
+    b = DeviceColumn(build_column(np.arange(10, dtype=np.int32), None, 5, abi.ENC_UNENCODED))
+    other_layout = DeviceColumn(build_column(np.arange(10, dtype=np.int32), None, 4, abi.ENC_UNENCODED))
+    with pytest.raises(Exception):
+        join_hash(a, b, abi.JOIN_ANTI_NULL_AS_TRUE, secondary=[(a, abi.PRED_LESS_THAN, b)])
+    with pytest.raises(Exception):
+        join_hash(a, b, abi.JOIN_INNER, secondary=[(other_layout, abi.PRED_LESS_THAN, b)])
+    with pytest.raises(Exception):
+        join_hash(a, b, abi.JOIN_INNER, secondary=[(a, abi.PRED_IS_NULL, b)])
+    with pytest.raises(Exception):
+        join_hash(a, b, abi.JOIN_INNER, secondary=[(a, abi.PRED_EQUALS, b)] * 5)

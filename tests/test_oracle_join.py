@@ -136,3 +136,68 @@ def test_probe_slices_of_131070_elements():
     assert got1.c.n_slices == 2
     offsets = got1.slice_offsets[:3].tolist()
     assert offsets == [0, 131070, 150000]
+
+
+SECONDARY_SETS = [   # join_test_runner.cpp:207-211: the secondary predicate compares the first columns of the two tables ...
+    [("int", abi.PRED_LESS_THAN, "int")], [("int", abi.PRED_GREATER_THAN_EQUALS, "int")], [("int", abi.PRED_NOT_EQUALS, "int")],
+    # ... and, beyond the reference's sets: nullable columns, mixed types (compared in the common C++ type), two predicates
+    [("int_null", abi.PRED_LESS_THAN_EQUALS, "long_null")], [("float", abi.PRED_GREATER_THAN, "long")], [("double_null", abi.PRED_EQUALS, "float_null")],
+    [("int", abi.PRED_NOT_EQUALS, "int"), ("double", abi.PRED_LESS_THAN, "double")],
+]
+SECONDARY_MODES = [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_FALSE]
+
+
+def secondary_columns(lt, rt, predicate_set, chunk, encoding):
+    out = []
+    for left_name, condition, right_name in predicate_set:
+        lvals, lnull = lt.column("l_" + left_name)
+        rvals, rnull = rt.column("r_" + right_name)
+        out.append((build_column(lvals, lnull, chunk, encoding), condition, build_column(rvals, rnull, chunk, encoding)))
+    return out
+
+
+@pytest.mark.parametrize("mode", SECONDARY_MODES)
+def test_join_with_secondary_predicates_against_verification(mode):
+    """Multi-predicate joins (join_test_runner.cpp:464-480): the primary equality on a key column with few distinct values,
+    secondary predicates on other columns of the two tables, every join mode JoinHash supports with them, against the
+    nested loops of JoinVerification -- as multisets, like the reference compares (:786-791)."""
+    for lsize, rsize in ((10, 15), (15, 10), (15, 15), (0, 10), (10, 0)):
+        lt, rt = runner_tables(lsize, 0)[0], runner_tables(rsize, 0)[1]
+        for key in ("int", "long_null"):
+            lvals, lnull = lt.column("l_" + key)
+            rvals, rnull = rt.column("r_" + key)
+            for chunk, encoding in ((10, abi.ENC_UNENCODED), (3, abi.ENC_DICTIONARY)):
+                left, right = build_column(lvals, lnull, chunk, encoding), build_column(rvals, rnull, chunk, encoding)
+                for predicate_set in SECONDARY_SETS:
+                    secondary = secondary_columns(lt, rt, predicate_set, chunk, encoding)
+                    for radix_bits in (None, 2):
+                        got = oracle_join(left, right, mode, radix_bits, secondary=secondary)
+                        assert join_result_multiset(got, mode) == verification_join(left, right, mode, secondary), \
+                            f"key {key} sizes {lsize},{rsize} chunk {chunk} predicates {predicate_set} radix {radix_bits}"
+
+
+def test_secondary_predicates_keep_the_join_order_and_reject_anti_null_as_true():
+    """With secondary predicates the surviving pairs keep the order of the equi-join (they are a filter inside probe());
+    AntiNullAsTrue with secondary predicates is unsupported (join_hash.cpp:39-44)."""
+    lt, rt = runner_tables(15, 0)[0], runner_tables(15, 0)[1]
+    lvals, lnull = lt.column("l_int")
+    rvals, rnull = rt.column("r_int")
+    left, right = build_column(lvals, lnull, 3, abi.ENC_UNENCODED), build_column(rvals, rnull, 3, abi.ENC_UNENCODED)
+    secondary = secondary_columns(lt, rt, [("double", abi.PRED_LESS_THAN, "double")], 3, abi.ENC_UNENCODED)
+    plain = oracle_join(left, right, abi.JOIN_INNER, 1)
+    filtered = oracle_join(left, right, abi.JOIN_INNER, 1, secondary=secondary)
+    pairs = [(tuple(l), tuple(r)) for l, r in zip(plain.left[:plain.n_pairs].tolist(), plain.right[:plain.n_pairs].tolist())]
+    kept = [(tuple(l), tuple(r)) for l, r in zip(filtered.left[:filtered.n_pairs].tolist(), filtered.right[:filtered.n_pairs].tolist())]
+    assert 0 < len(kept) < len(pairs)
+    iterator = iter(pairs)
+    assert all(pair in iterator for pair in kept)   # a subsequence
+    from support import HostJoinResult, OracleCol, _bind_join, oracle
+    import ctypes as C
+    lib = oracle()
+    _bind_join(lib)
+    result = HostJoinResult(1000, 100)
+    lcol, rcol = OracleCol(left), OracleCol(right)
+    l2, r2 = OracleCol(secondary[0][0]), OracleCol(secondary[0][2])
+    predicates = (abi.JoinPredicate * 1)()
+    predicates[0].left_column, predicates[0].right_column, predicates[0].condition = C.addressof(l2.c), C.addressof(r2.c), abi.PRED_LESS_THAN
+    assert lib.hyo_join_hash_predicates(C.byref(lcol.c), C.byref(rcol.c), abi.JOIN_ANTI_NULL_AS_TRUE, predicates, 1, C.byref(result.c), 1) == abi.ERR_UNSUPPORTED
