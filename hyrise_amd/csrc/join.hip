@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6)
   // end), two tickets ahead -- the next tile's loads are in flight while this one is ranked.
   const uint32_t per_xcd = (a.n_tiles + 7) / 8, xcd = blockIdx.x & 7;
   const uint32_t xcd_begin = xcd * per_xcd, xcd_end = (xcd + 1) * per_xcd < a.n_tiles ? (xcd + 1) * per_xcd : a.n_tiles;
-  if (!a.plan->fits) return;
+  if (!a.plan->fits || *a.n_uncached == a.n_tiles) return;   // (every tile is probe_emit_generic's: nothing to walk)
   if (tid == 0) {
     s_scratch[JOIN_WAVES] = atomicAdd(a.xcd_tickets + xcd, 1u);
     s_scratch[JOIN_WAVES + 1] = atomicAdd(a.xcd_tickets + xcd, 1u);
@@ -1201,8 +1201,8 @@ __host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
 // Pass 2 for the tiles pass 1 flagged (a row with several partners: build keys with duplicates): the tile is evaluated
 // again, a lane keeps the lookup results of its eight rows in registers, a wave-level match-any ranking with running
 // per-(wave, partition) counters gives every row its stable rank inside (partition, tile), and the pairs are first laid
-// out partition by partition in LDS and then copied out.  Tiles whose pairs do not fit the staging buffer (many
-// duplicates) write their pairs directly.  Two workgroups per CU walk pass 1's list of such tiles.
+// out partition by partition in LDS and then copied out, one staging buffer of pairs at a time.  Two workgroups per CU walk
+// pass 1's list of such tiles.
 template <bool SECONDARY>
 __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) {
   const uint32_t n_listed = *a.n_uncached;
@@ -1290,14 +1290,11 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
   }
   __syncthreads();
   const uint32_t tile_pairs = s_tile_offset[partitions];
-  const bool staged = tile_pairs <= JOIN_STAGE;
 
-  // (d) stable ranking inside the wave, round by round
-  const hy_row_id null_row{0xFFFFFFFFu, 0xFFFFFFFFu};
+  // (d) stable ranking inside the wave, round by round: the first staged slot of every row's pairs
+  uint32_t first_slot[JOIN_ROUNDS];
 #pragma unroll
   for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
-    const uint32_t round_base = wave * JOIN_WAVE_ROWS + round * 64;
-    const uint32_t r = round_base + lane;
     const uint32_t meta = row_meta[round];
     const uint32_t partition = meta & 0x1FF;
     const uint32_t emit = meta >> 10;
@@ -1310,6 +1307,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
       __builtin_amdgcn_wave_barrier();
     }
     uint32_t pairs_before = 0, pairs_total = 0;
+    first_slot[round] = 0;
     if (valid) {
       if (many == 0) {
         pairs_before = __popcll(lower & one);
@@ -1327,48 +1325,8 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
       }
       const uint32_t element_rank = s_run_elements[wave * partitions + partition] + __popcll(lower);
       const uint32_t pair_rank = s_run_pairs[wave * partitions + partition] + pairs_before;
-      const uint64_t pair_pos = s_base_pairs[partition] + pair_rank;
-      if (element_rank == s_cut_rank[partition]) a.slice_offsets[s_cut_slice[partition]] = pair_pos;
-      if (emit) {
-        const bool null_partner = meta & 0x200u;
-        const uint32_t start = row_start[round];
-        if constexpr (!SECONDARY) {
-          if (staged) {
-            const uint32_t slot = s_tile_offset[partition] + pair_rank;
-            const uint32_t tag = r | (partition << 12) | (null_partner ? 1u << 21 : 0u);
-            reinterpret_cast<u32x2_t*>(s_stage)[slot] = u32x2_t{tag, start};
-#pragma unroll 1
-            for (uint32_t t = 1; t < emit; ++t) reinterpret_cast<u32x2_t*>(s_stage)[slot + t] = u32x2_t{tag, start + t};   // several partners: rare
-          } else {
-            const hy_row_id probe_id{chunk, row_begin + r};
-#pragma unroll 1
-            for (uint32_t t = 0; t < emit; ++t) {
-              a.probe_out[pair_pos + t] = probe_id;
-              if (a.build_out) a.build_out[pair_pos + t] = null_partner ? null_row : directory_row_id(a.dir, start + t);
-            }
-          }
-        } else {
-          // of the key's partners, the `emit` that satisfy the secondary predicates (a NULL partner: one pair, no build
-          // row; semi / anti joins: the predicates already decided whether the probe row is written, once)
-          const bool filter = !null_partner && a.build_out != nullptr;
-          const uint32_t candidates = filter ? row_partners[round] : emit;
-          const uint32_t tag = r | (partition << 12) | (null_partner ? 1u << 21 : 0u);
-          const hy_row_id probe_id{chunk, row_begin + r};
-          uint32_t slot = s_tile_offset[partition] + pair_rank;
-          uint64_t at = pair_pos;
-#pragma unroll 1
-          for (uint32_t t = 0; t < candidates; ++t) {
-            if (filter && !satisfies_secondary(a, directory_row_id(a.dir, start + t), chunk, row_begin + r)) continue;
-            if (staged) {
-              reinterpret_cast<u32x2_t*>(s_stage)[slot++] = u32x2_t{tag, start + t};
-            } else {
-              a.probe_out[at] = probe_id;
-              if (a.build_out) a.build_out[at] = null_partner ? null_row : directory_row_id(a.dir, start + t);
-              ++at;
-            }
-          }
-        }
-      }
+      if (element_rank == s_cut_rank[partition]) a.slice_offsets[s_cut_slice[partition]] = s_base_pairs[partition] + pair_rank;
+      first_slot[round] = s_tile_offset[partition] + pair_rank;
     }
     __builtin_amdgcn_wave_barrier();
     if (valid && (peers >> lane) >> 1 == 0) {   // highest peer advances the running counters of its partition
@@ -1377,19 +1335,56 @@ __global__ __launch_bounds__(JOIN_THREADS) void probe_emit_generic(ProbeArgs a) 
     }
     __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();
-  // (e) copy out: slot s of partition p is pair  base_pairs[p][tile] + (s - first slot of p)
-  for (uint32_t s = tid; staged && s < tile_pairs; s += JOIN_THREADS) {
-    const u32x2_t record = reinterpret_cast<const u32x2_t*>(s_stage)[s];
-    const uint32_t tag = record.x, position = record.y;
-    const uint32_t partition = (tag >> 12) & 0x1FF;
-    const uint64_t pair_pos = s_base_pairs[partition] + (s - s_tile_offset[partition]);
-    const u32x2_t probe_id = {chunk, row_begin + (tag & 0xFFFu)};
-    __builtin_nontemporal_store(probe_id, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
-    if (a.build_out) {
-      u32x2_t build_id = {0xFFFFFFFFu, 0xFFFFFFFFu};
-      if (!(tag & (1u << 21))) { const hy_row_id id = directory_row_id(a.dir, position); build_id = u32x2_t{id.chunk_id, id.chunk_offset}; }
-      __builtin_nontemporal_store(build_id, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+  // (e) the tile's pairs leave through the staging buffer, JOIN_STAGE slots at a time (a tile of 4096 probe rows with four
+  //     partners each is four windows): every window is laid out partition by partition in LDS by the rows whose pairs
+  //     fall into it and copied out with consecutive lanes writing consecutive RowIDs.
+#pragma unroll 1
+  for (uint32_t window = 0; window < tile_pairs; window += JOIN_STAGE) {
+    const uint32_t window_pairs = tile_pairs - window < JOIN_STAGE ? tile_pairs - window : JOIN_STAGE;
+    if (window) __syncthreads();   // the previous window has been copied out
+#pragma unroll
+    for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
+      const uint32_t meta = row_meta[round];
+      const uint32_t emit = meta >> 10;
+      if ((meta & 0x1FF) == INVALID_PARTITION || emit == 0) continue;
+      const uint32_t slot = first_slot[round];
+      if (slot >= window + window_pairs || slot + emit <= window) continue;   // none of this row's pairs in the window
+      const uint32_t from = slot < window ? window - slot : 0, to = slot + emit < window + window_pairs ? emit : window + window_pairs - slot;   // its pairs [from, to)
+      const bool null_partner = meta & 0x200u;
+      const uint32_t r = wave * JOIN_WAVE_ROWS + round * 64 + lane;
+      const uint32_t tag = r | ((meta & 0x1FF) << 12) | (null_partner ? 1u << 21 : 0u);
+      const uint32_t start = row_start[round];
+      if constexpr (!SECONDARY) {
+#pragma unroll 1
+        for (uint32_t j = from; j < to; ++j) reinterpret_cast<u32x2_t*>(s_stage)[slot + j - window] = u32x2_t{tag, start + j};
+      } else {
+        // of the key's partners, the ones that satisfy the secondary predicates are the row's pairs (a NULL partner: one
+        // pair, no build row; semi / anti joins: the predicates already decided whether the probe row is written, once)
+        const bool filter = !null_partner && a.build_out != nullptr;
+        const uint32_t candidates = filter ? row_partners[round] : emit;
+        uint32_t j = 0;
+#pragma unroll 1
+        for (uint32_t t = 0; t < candidates && j < to; ++t) {
+          if (filter && !satisfies_secondary(a, directory_row_id(a.dir, start + t), chunk, row_begin + r)) continue;
+          if (j >= from) reinterpret_cast<u32x2_t*>(s_stage)[slot + j - window] = u32x2_t{tag, start + t};
+          ++j;
+        }
+      }
+    }
+    __syncthreads();
+    // copy out: slot s of partition p is pair  base_pairs[p][tile] + (s - first slot of p)
+    for (uint32_t s = tid; s < window_pairs; s += JOIN_THREADS) {
+      const u32x2_t record = reinterpret_cast<const u32x2_t*>(s_stage)[s];
+      const uint32_t tag = record.x, position = record.y;
+      const uint32_t partition = (tag >> 12) & 0x1FF;
+      const uint64_t pair_pos = s_base_pairs[partition] + (window + s - s_tile_offset[partition]);
+      const u32x2_t probe_id = {chunk, row_begin + (tag & 0xFFFu)};
+      __builtin_nontemporal_store(probe_id, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
+      if (a.build_out) {
+        u32x2_t build_id = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (!(tag & (1u << 21))) { const hy_row_id id = directory_row_id(a.dir, position); build_id = u32x2_t{id.chunk_id, id.chunk_offset}; }
+        __builtin_nontemporal_store(build_id, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+      }
     }
   }
   __syncthreads();   // the next listed tile reuses the staging area and the counters

@@ -275,3 +275,29 @@ def test_join_secondary_predicate_rejections(device):
         join_hash(a, b, abi.JOIN_INNER, secondary=[(a, abi.PRED_IS_NULL, b)])
     with pytest.raises(Exception):
         join_hash(a, b, abi.JOIN_INNER, secondary=[(a, abi.PRED_EQUALS, b)] * 5)
+
+
+@pytest.mark.parametrize("mode", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT])
+def test_join_many_partners_per_probe_row(device, mode):
+    """Eight partners per probe row and more: a 4096-row probe tile produces several staging buffers of pairs (the generic
+    pass 2 lays them out window by window), with and without a secondary predicate, radix partitioning on and off."""
+    rng = np.random.default_rng(51)
+    build_keys = np.repeat(np.arange(2_000, dtype=np.int32), 8)
+    rng.shuffle(build_keys)
+    build_keys[::97] = 7                       # one key with a few hundred partners
+    probe_keys = rng.integers(0, 2_100, 30_000).astype(np.int32)
+    small = build_column(build_keys, rng.random(len(build_keys)) < 0.01, 5_000, abi.ENC_UNENCODED)
+    large = build_column(probe_keys, rng.random(len(probe_keys)) < 0.01, 20_000, abi.ENC_DICTIONARY)
+    small_other = build_column(rng.integers(0, 100, len(build_keys)).astype(np.int32), None, 5_000, abi.ENC_UNENCODED)
+    large_other = build_column(rng.integers(0, 100, len(probe_keys)).astype(np.int64), None, 20_000, abi.ENC_UNENCODED)
+    left, right = (large, small) if mode != abi.JOIN_RIGHT else (small, large)   # the probe side is the large one
+    left_other, right_other = (large_other, small_other) if mode != abi.JOIN_RIGHT else (small_other, large_other)
+    ldev, rdev = DeviceColumn(left), DeviceColumn(right)
+    for radix_bits in (0, 3):
+        got = join_hash(ldev, rdev, mode, radix_bits)
+        assert_join_equal(got, oracle_join(left, right, mode, radix_bits), mode, f"many partners, radix {radix_bits}")
+        assert got.n_pairs > 8 * 25_000
+        secondary = [(left_other, abi.PRED_LESS_THAN, right_other)]
+        on_device = [(DeviceColumn(left_other), abi.PRED_LESS_THAN, DeviceColumn(right_other))]
+        got = join_hash(ldev, rdev, mode, radix_bits, secondary=on_device)
+        assert_join_equal(got, oracle_join(left, right, mode, radix_bits, secondary=secondary), mode, f"many partners + predicate, radix {radix_bits}")
