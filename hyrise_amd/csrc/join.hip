@@ -565,7 +565,6 @@ struct ProbeArgs {
   SecondaryPredicate secondary[HY_MAX_SECONDARY_PREDICATES];
   uint32_t* error;                // set when a probe row matches >= 2^22 build rows (the staging record cannot hold it)
   uint64_t* trace;                // debug (HY_JOIN_TRACE): 6 wall-clock stamps per probe_emit tile, else nullptr
-  uint32_t debug_plain_stores;
   uint32_t pack_build_ids;        // dir.ids32 exists: probe_emit_cached stages the partner's packed RowID, not its position
 };
 
@@ -1119,16 +1118,14 @@ __global__ __launch_bounds__(JOIN_THREADS) __attribute__((amdgpu_waves_per_eu(6)
       const uint32_t tag = record.x, partner = record.y;
       const uint64_t pair_pos = s_out_base[(tag >> 12) & 0x1FF] + slot;
       const u32x2_t probe_id = {chunk, row_begin + (tag & 0xFFFu)};
-      if (a.debug_plain_stores) reinterpret_cast<u32x2_t*>(a.probe_out)[pair_pos] = probe_id;
-      else __builtin_nontemporal_store(probe_id, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
+      __builtin_nontemporal_store(probe_id, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
       if (a.build_out) {
         u32x2_t build_id = {0xFFFFFFFFu, 0xFFFFFFFFu};
         if (!(tag & (1u << 21))) {
           if (a.pack_build_ids) build_id = u32x2_t{partner >> 16, partner & 0xFFFFu};
           else build_id = reinterpret_cast<const u32x2_t*>(a.dir.row_ids)[partner];
         }
-        if (a.debug_plain_stores) reinterpret_cast<u32x2_t*>(a.build_out)[pair_pos] = build_id;
-        else __builtin_nontemporal_store(build_id, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+        __builtin_nontemporal_store(build_id, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
       }
     }
     if (a.trace && tid == 0) a.trace[cur_tile * 6 + 5] = wall_clock64();
@@ -1916,7 +1913,6 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
       HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(probe_emit_cached), JOIN_THREADS, 4 * probe_emit_cached_lds_words(partitions)));
       workgroups_per_cu = per_cu > 0 ? static_cast<uint32_t>(per_cu) : 1;
     }
-    a.debug_plain_stores = getenv("HY_JOIN_PLAIN_STORES") ? 1 : 0;
     if (const char* env = getenv("HY_JOIN_WGS_PER_CU")) workgroups_per_cu = static_cast<uint32_t>(atoi(env));
     // persistent workgroups: as many as fit the device at once (a multiple of the 8 XCDs), never more than tiles
     const uint32_t resident = device_cu_count() * workgroups_per_cu / 8 * 8;
