@@ -791,10 +791,44 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         default: break;
       }
     }
+    if (stamps && tid == 0 && g == 0 && a.n_aggregates <= 5) stamps[8] = wall_clock64();   // (debug: end of the first accumulator's row loop)
+    // the wave's totals (lane 63): the combine is chosen ONCE per accumulator -- inside the DPP steps, a switch on the
+    // aggregate function was a dozen scalar branches per step, 48 steps per accumulator: more time than the rows took
+    uint64_t reduced[DENSE_GROUPS];
+    {
+      const uint64_t identity = initial_value(c.function);
+      switch (kind) {
+        case ACC_MIN:
+#pragma unroll
+          for (uint32_t j = 0; j < DENSE_GROUPS; ++j)
+            reduced[j] = wave_reduce_to_lane63(cell_value[j], identity, [](uint64_t x, uint64_t y) { return static_cast<uint64_t>(min(static_cast<long long>(x), static_cast<long long>(y))); });
+          break;
+        case ACC_MAX:
+#pragma unroll
+          for (uint32_t j = 0; j < DENSE_GROUPS; ++j)
+            reduced[j] = wave_reduce_to_lane63(cell_value[j], identity, [](uint64_t x, uint64_t y) { return static_cast<uint64_t>(max(static_cast<long long>(x), static_cast<long long>(y))); });
+          break;
+        case ACC_ADD_INT:
+#pragma unroll
+          for (uint32_t j = 0; j < DENSE_GROUPS; ++j) reduced[j] = wave_reduce_to_lane63(cell_value[j], identity, [](uint64_t x, uint64_t y) { return x + y; });
+          break;
+        case ACC_ADD_DOUBLE:
+#pragma unroll
+          for (uint32_t j = 0; j < DENSE_GROUPS; ++j)
+            reduced[j] = wave_reduce_to_lane63(cell_value[j], identity, [](uint64_t x, uint64_t y) {
+              return static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(x)) + __longlong_as_double(static_cast<long long>(y))));
+            });
+          break;
+        default:
+#pragma unroll
+          for (uint32_t j = 0; j < DENSE_GROUPS; ++j) reduced[j] = cell_value[j];
+          break;
+      }
+    }
 #pragma unroll
     for (uint32_t j = 0; j < DENSE_GROUPS; ++j) {
       if (j >= n_dense) break;
-      const uint64_t value = wave_combine(c, cell_value[j]);
+      const uint64_t value = reduced[j];
       const uint32_t count = wave_reduce_u32_to_lane63(cell_count[j], 0u, false, false);
       if (lane == 63 && count != 0) {
         const uint32_t slot = s_slot_of_dense[j];

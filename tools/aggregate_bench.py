@@ -45,7 +45,7 @@ if os.environ.get("HY_AGG_TRACE"):
     ns = lib.hy_debug_aggregate_trace(buf.ctypes.data, 1 << 14)
     t = buf[:ns].astype(np.int64)
     t = t[t[:, 10] > 0]
-    n_acc = int(((t[0, 3:9]) > 0).sum())
+    n_acc = int(((t[0, 3:8]) > 0).sum())   # (slot 8: end of the first accumulator's row loop)
     marks = [0, 1, 2] + [3 + g for g in range(n_acc)] + [9, 10]
     names = ["pass 1 (keys)", "dense prep"] + [f"accumulator {g}" for g in range(n_acc)] + ["pass 3 + merge"]
     names = ["pass 1 (keys)", "dense prep", "(loop entry)"] + [f"accumulator {g}" for g in range(n_acc)] + ["pass 3 + merge"]
@@ -55,3 +55,5 @@ if os.environ.get("HY_AGG_TRACE"):
         print(f"  {names[i]:16s} mean {d.mean():7.2f} p50 {np.percentile(d, 50):7.2f} p90 {np.percentile(d, 90):7.2f}")
     print("  total            mean %.2f" % ((t[:, 10] - t[:, 0]).mean() / 100.0))
     print("  (pass 1: setup before the row loop mean %.2f)" % ((t[:, 11] - t[:, 0]).mean() / 100.0))
+    if n_acc <= 5:
+        print("  (accumulator 0: rows %.2f, reductions + merge into the slice's table %.2f)" % ((t[:, 8] - t[:, 3]).mean() / 100.0, (t[:, 4] - t[:, 8]).mean() / 100.0))
