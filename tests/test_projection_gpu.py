@@ -119,3 +119,28 @@ def test_tpch_q6_pipeline_stays_on_device(device):
     products = data.l_extendedprice[keep] * data.l_discount[keep]            # float32 products, like the reference
     assert total.column(1)[0] == int(keep.sum()) > 100
     assert abs(total.column(0)[0] - float(products.astype(np.float64).sum())) <= 1e-9 * abs(float(products.astype(np.float64).sum()))
+
+
+def test_plain_operands_all_type_pairs(device):
+    """The fast path of projection_rows: + - * over unencoded value segments without NULLs and literals (wide loads, the
+    cell arithmetic instantiated per type pair), chunk sizes that are no multiple of four rows, every type pair and literal
+    side -- bit for bit what the oracle computes, no NULL in the result."""
+    rng = np.random.default_rng(62)
+    n, chunk = 40_003, 9_001
+    raw = {abi.TYPE_INT: rng.integers(-2**31, 2**31 - 1, n).astype(np.int32), abi.TYPE_LONG: rng.integers(-2**62, 2**62, n).astype(np.int64),
+           abi.TYPE_FLOAT: (rng.normal(0, 1e6, n)).astype(np.float32), abi.TYPE_DOUBLE: rng.normal(0, 1e12, n)}
+    devs = {t: DeviceColumn(build_column(values, None, chunk, abi.ENC_UNENCODED)) for t, values in raw.items()}
+    literal = {abi.TYPE_INT: -7, abi.TYPE_LONG: 5_000_000_000, abi.TYPE_FLOAT: 0.3, abi.TYPE_DOUBLE: 1.0 - 0.05}
+    for op in (abi.ARITH_ADD, abi.ARITH_SUB, abi.ARITH_MUL):
+        for lt in raw:
+            for rt in raw:
+                got = projection_arithmetic(op, devs[lt], devs[rt])
+                assert_same(got, oracle_arithmetic(op, (raw[lt], None), (raw[rt], None)), f"plain op {op} types {lt},{rt}")
+            for rt, value in literal.items():
+                assert_same(projection_arithmetic(op, devs[lt], (rt, value)), oracle_arithmetic(op, (raw[lt], None), (rt, value)), f"plain op {op} {lt} x literal {rt}")
+                assert_same(projection_arithmetic(op, (rt, value), devs[lt]), oracle_arithmetic(op, (rt, value), (raw[lt], None)), f"plain op {op} literal {rt} x {lt}")
+    # a result column (pooled device buffers) as an operand of the next projection: l_extendedprice * (1 - l_discount)
+    one_minus = projection_arithmetic(abi.ARITH_SUB, (abi.TYPE_INT, 1), devs[abi.TYPE_FLOAT])
+    chained = projection_arithmetic(abi.ARITH_MUL, devs[abi.TYPE_DOUBLE], one_minus)
+    inner_values, _ = oracle_arithmetic(abi.ARITH_SUB, (abi.TYPE_INT, 1), (raw[abi.TYPE_FLOAT], None))
+    assert_same(chained, oracle_arithmetic(abi.ARITH_MUL, (raw[abi.TYPE_DOUBLE], None), (inner_values, None)), "chained plain projections")
