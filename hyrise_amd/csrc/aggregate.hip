@@ -36,6 +36,7 @@ namespace hy {
 constexpr uint32_t MAX_GROUPBY = 4;
 constexpr uint32_t MAX_AGGREGATES = 8;
 constexpr uint32_t LDS_SLOTS = 256;
+constexpr uint32_t MAX_GLOBAL_PROBES = 512;   // linear probing in the global group table: longer sequences count as overflow
 constexpr uint32_t DENSE_GROUPS = 4;   // slices with at most this many groups accumulate in thread-private LDS cells
 constexpr uint32_t TAG_EMPTY = 0, TAG_LOCKED = 1;   // ready tags have bit 31 set
 constexpr uint32_t AGG_SUM_SQUARES = 100;           // device-internal: sum of x*x as double (second accumulator of STDDEV_SAMP)
@@ -125,7 +126,12 @@ __device__ uint32_t global_slot(const AggArgs& a, const uint64_t* tuple, uint32_
   uint32_t result = 0xFFFFFFFFu;
   bool done = false;
   while (!done) {
-    uint32_t tag = __hip_atomic_load(&a.tags[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    // Relaxed, like the key words below: agent-scope atomic loads are served by the L2, which already holds the key
+    // words when it shows a published tag (the publisher's release store waits for them), and a wave's loads return in
+    // order; the signal fence keeps the compiler from moving the key loads up.  An acquire load here costs an L1
+    // invalidation per probe -- per ROW on the many-groups path.
+    uint32_t tag = __hip_atomic_load(&a.tags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_signal_fence(__ATOMIC_ACQUIRE);
     if (tag == TAG_EMPTY) {
       uint32_t expected = TAG_EMPTY;
       if (__hip_atomic_compare_exchange_strong(&a.tags[slot], &expected, TAG_LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -151,7 +157,9 @@ __device__ uint32_t global_slot(const AggArgs& a, const uint64_t* tuple, uint32_
         done = true;
       } else {
         slot = (slot + 1) & (a.capacity - 1);
-        if (++probes >= a.capacity) done = true;   // table full
+        // a probe sequence this long means a table that is (nearly) full: report overflow, the host retries with a larger
+        // one -- walking a 95 % full table of millions of slots group by group takes minutes
+        if (++probes >= (a.capacity < MAX_GLOBAL_PROBES ? a.capacity : MAX_GLOBAL_PROBES)) done = true;
       }
     } else {
       __builtin_amdgcn_s_sleep(1);   // locked by someone else: retry
@@ -845,6 +853,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     for (uint32_t k = 0; k < ROWS; ++k) {
       const uint32_t r = slice_row(k, tid);
       if (r >= slice.row_count || ((is_dense >> k) & 1)) continue;
+      if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // the table is too small: the host starts over with a larger one, no point in walking the full one
       const uint32_t row = slice.row_begin + r;
       const uint64_t global_row = chunk_base + row;
       const bool found = (in_table >> k) & 1;
@@ -875,6 +884,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   // merge the workgroup's groups into the global table
   for (uint32_t s = tid; s < LDS_SLOTS; s += 256) {
     if (s_tags[s] == TAG_EMPTY) continue;
+    if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     uint64_t tuple[MAX_GROUPBY + 1];
     for (uint32_t w = 0; w < words; ++w) tuple[w] = s_keys[s * words + w];
     for (uint32_t g = 0; g < a.n_groupby; ++g) {   // value ids -> values
@@ -990,9 +1000,13 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + 64 + SLICE_ROWS;
   uint64_t capacity = 1u << 16;
   while (capacity < 2 * uint64_t{LDS_SLOTS}) capacity <<= 1;
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    if (attempt == 1) { capacity = 1u << 22; }
-    if (attempt == 2) { capacity = 1024; while (capacity < 2 * shape->rows + 1024) capacity <<= 1; }
+  // the number of groups is not known: 64 Ki slots, then 2 Mi, then 32 Mi, then two slots per row (never overflows)
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    uint64_t two_per_row = 1024;
+    while (two_per_row < 2 * shape->rows + 1024) two_per_row <<= 1;
+    if (attempt == 1) capacity = 1u << 21;
+    if (attempt == 2) capacity = 1u << 25;
+    if (attempt == 3 || capacity > two_per_row) capacity = two_per_row;
     if (capacity > (1ull << 31)) return fail(HY_ERR_UNSUPPORTED, "too many rows for the device group table");
     DeviceBuffer tags, keys, first, last, values, counts, flags;
     HY_TRY(tags.alloc(4 * capacity));
