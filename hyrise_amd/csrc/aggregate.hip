@@ -261,10 +261,6 @@ __device__ __forceinline__ uint32_t wave_reduce_u32_to_lane63(uint32_t v, uint32
   }));
 }
 
-__device__ __forceinline__ uint64_t wave_combine(const AggColumn& c, uint64_t v) {   // result in lane 63
-  return wave_reduce_to_lane63(v, initial_value(c.function), [&](uint64_t a, uint64_t b) { return combine(c, a, b); });
-}
-
 // Aggregate input of one row (generic, one row at a time): false for NULL (NULL inputs leave the aggregate unchanged,
 // aggregate_hash.cpp:627-637).
 __device__ __forceinline__ bool contribution_of(const AggColumn& c, uint32_t chunk, uint32_t row, uint64_t* contribution) {

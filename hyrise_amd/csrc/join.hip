@@ -437,12 +437,6 @@ __global__ __launch_bounds__(256) void scan_blocks(const uint32_t* in, uint64_t 
   }
 }
 
-// out[i] = src[index[i]]
-__global__ void gather_u64(const uint64_t* src, const uint64_t* index, uint64_t* out, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = src[index[i]];
-}
-
 // ---- bucket directory over the sorted build keys ------------------------------------------------------------------------
 struct Directory {
   const uint64_t* keys;      // sorted (unsigned order of the sign-extended bits); nullptr when the keys are 32-bit
@@ -568,13 +562,6 @@ struct ProbeArgs {
   uint32_t pack_build_ids;        // dir.ids32 exists: probe_emit_cached stages the partner's packed RowID, not its position
 };
 
-struct ProbeRow {
-  uint32_t partition;   // INVALID_PARTITION if not materialised
-  uint32_t emit;        // output pairs
-  uint32_t start;       // first build position (emit real partners) -- unused when null_partner
-  bool null_partner;    // emit NULL_ROW_ID as the build side
-};
-
 // Output pairs of one probe row per join mode (probe / probe_semi_anti, join_hash_steps.hpp:575-922).
 __device__ __forceinline__ uint32_t pairs_of(const ProbeArgs& a, bool is_null, uint32_t count, bool* null_partner) {
   // Selects on the (uniform) mode instead of a switch: this runs per probe row, eight times unrolled -- a switch is half
@@ -589,21 +576,6 @@ __device__ __forceinline__ uint32_t pairs_of(const ProbeArgs& a, bool is_null, u
          : mode == HY_JOIN_SEMI ? (count > 0 ? 1u : 0u)
          : mode == HY_JOIN_ANTI_NULL_AS_FALSE ? (none ? 1u : 0u)
          : anti_null_as_true;
-}
-
-__device__ __forceinline__ ProbeRow probe_row(const ProbeArgs& a, uint32_t chunk, uint32_t row) {
-  ProbeRow out{INVALID_PARTITION, 0, 0, false};
-  int64_t key;
-  const bool is_null = column_key(a.segments, chunk, row, &key);
-  if (is_null && !a.keep_nulls) return out;
-  const uint64_t hash = static_cast<uint64_t>(key);
-  if (!is_null && !a.keep_nulls && a.build_bloom && !bloom_test(a.build_bloom, hash)) return out;   // join_hash_steps.hpp:354-358
-  out.partition = a.radix_bits ? static_cast<uint32_t>(hash & ((1u << a.radix_bits) - 1)) : 0;
-  uint32_t start = 0, count = 0;
-  if (!is_null) directory_lookup(a.dir, hash, &start, &count);
-  out.start = start;
-  out.emit = pairs_of(a, is_null, count, &out.null_partner);
-  return out;
 }
 
 // ---- secondary predicates (MultiPredicateJoinEvaluator, multi_predicate_join_evaluator.hpp:30-61) -------------------------
