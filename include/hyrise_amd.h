@@ -277,7 +277,11 @@ typedef struct hy_join_result {
 } hy_join_result;
 
 /* Equi-join of two int32/int64 columns.  Pair order == the CPU operator's concatenated probe() output
- * (join_hash_steps.hpp:624-792): by radix partition, then probe row, then build-side insertion order. */
+ * (join_hash_steps.hpp:624-792): by radix partition, then probe row, then build-side insertion order.
+ * A result that does not fit `capacity` / `slice_capacity` is HY_ERR_CAPACITY: nothing is written to the PosList or
+ * slice_offsets buffers (device-memory results included -- the check happens on the device between the two probe passes),
+ * n_pairs and n_slices report what the join needs.  With mem = HY_MEM_DEVICE the PosLists stay in HBM for the next
+ * operator and the call makes no host round trip between the passes. */
 hy_status hy_join_hash(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result);
 
 /* A secondary join predicate  left_column <condition> right_column  (OperatorJoinPredicate, operator_join_predicate.hpp;
