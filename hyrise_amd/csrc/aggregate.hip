@@ -356,16 +356,19 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   // What pass 1 needs of the GROUP BY columns' segment descriptors, once (read through the pointer they are a dependent
   // global load in front of every block's attribute-vector loads: three round trips per block instead of one).
   const void* key_data[MAX_GROUPBY];
-  uint32_t key_width[MAX_GROUPBY], key_dictionary_size[MAX_GROUPBY];
+  const void* key_dictionary[MAX_GROUPBY];
+  uint32_t key_width[MAX_GROUPBY], key_dictionary_size[MAX_GROUPBY], key_type[MAX_GROUPBY];
   uint32_t local_keys = 0;   // bit g: GROUP BY column g is a dictionary segment in this chunk (keyed by value id inside the slice)
   bool keys_unaligned = false;
 #pragma unroll
   for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
-    key_data[g] = nullptr;
-    key_width[g] = key_dictionary_size[g] = 0;
+    key_data[g] = key_dictionary[g] = nullptr;
+    key_width[g] = key_dictionary_size[g] = key_type[g] = 0;
     if (g < a.n_groupby) {
       const DevSegment& seg = a.groupby[g].segments[slice.chunk];
       key_data[g] = seg.data;
+      key_dictionary[g] = seg.aux;
+      key_type[g] = seg.data_type;
       key_width[g] = seg.width;
       key_dictionary_size[g] = seg.aux_size;
       if (seg.encoding == HY_ENC_DICTIONARY) local_keys |= 1u << g;
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     for (uint32_t k = 0; k < ROWS; ++k) {
       const uint32_t r = slice_row(k, tid);
       if (r < slice.row_count && ((in_table >> k) & 1)) {
-        const uint32_t dense = s_dense_of_slot[(slots[k / 4] >> (8 * (k & 3))) & 0xFF];
+        const uint32_t dense = s_dense_of_slot[(slots[k / 4] >> (8 * (k & 3))) & 0xFF];   // (a table lookup: computing the rank of the code from the presence bits costs more)
         if (dense < DENSE_GROUPS) {
           is_dense |= 1u << k;
           if (k < 16) dense_lo |= dense << (2 * k); else dense_hi |= dense << (2 * (k - 16));
@@ -883,16 +886,16 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     uint64_t tuple[MAX_GROUPBY + 1];
     for (uint32_t w = 0; w < words; ++w) tuple[w] = s_keys[s * words + w];
-    for (uint32_t g = 0; g < a.n_groupby; ++g) {   // value ids -> values
-      if (!((local_keys >> g) & 1) || ((tuple[0] >> g) & 1)) continue;
-      const DevSegment& seg = a.groupby[g].segments[slice.chunk];
+#pragma unroll
+    for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {   // value ids -> values (the dictionary pointers were read with the other descriptor fields)
+      if (g >= a.n_groupby || !((local_keys >> g) & 1) || ((tuple[0] >> g) & 1)) continue;
       const uint32_t id = static_cast<uint32_t>(tuple[g + 1]);
       uint64_t bits;
-      switch (seg.data_type) {
-        case HY_TYPE_INT: bits = static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int32_t*>(seg.aux)[id])); break;
-        case HY_TYPE_LONG: bits = static_cast<const uint64_t*>(seg.aux)[id]; break;
-        case HY_TYPE_FLOAT: bits = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<const float*>(seg.aux)[id]))); break;
-        default: bits = static_cast<const uint64_t*>(seg.aux)[id]; break;
+      switch (key_type[g]) {
+        case HY_TYPE_INT: bits = static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int32_t*>(key_dictionary[g])[id])); break;
+        case HY_TYPE_LONG: bits = static_cast<const uint64_t*>(key_dictionary[g])[id]; break;
+        case HY_TYPE_FLOAT: bits = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<const float*>(key_dictionary[g])[id]))); break;
+        default: bits = static_cast<const uint64_t*>(key_dictionary[g])[id]; break;
       }
       if (a.groupby[g].is_float && __longlong_as_double(static_cast<long long>(bits)) == 0.0) bits = 0;
       tuple[g + 1] = bits;
