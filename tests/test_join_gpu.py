@@ -301,3 +301,31 @@ def test_join_many_partners_per_probe_row(device, mode):
         on_device = [(DeviceColumn(left_other), abi.PRED_LESS_THAN, DeviceColumn(right_other))]
         got = join_hash(ldev, rdev, mode, radix_bits, secondary=on_device)
         assert_join_equal(got, oracle_join(left, right, mode, radix_bits, secondary=secondary), mode, f"many partners + predicate, radix {radix_bits}")
+
+
+def test_join_secondary_predicates_on_reference_inputs(device):
+    """Secondary predicates over reference tables: the predicate columns are reference segments with the key columns' pos
+    lists (all columns of a reference table's chunk share one pos list), NULL_ROW_IDs included."""
+    rng = np.random.default_rng(18)
+    n_l, n_r = 6000, 9000
+    base_lkey = build_column(rng.integers(0, 200, n_l).astype(np.int32), rng.random(n_l) < 0.05, 1000, abi.ENC_DICTIONARY)
+    base_rkey = build_column(rng.integers(0, 200, n_r).astype(np.int32), None, 1500, abi.ENC_UNENCODED)
+    base_lval = build_column(rng.integers(0, 50, n_l).astype(np.int64), rng.random(n_l) < 0.05, 1000, abi.ENC_UNENCODED)
+    base_rval = build_column((rng.random(n_r) * 50).astype(np.float32), None, 1500, abi.ENC_DICTIONARY)
+    pos_l = [np.stack([np.full(400, c, dtype=np.uint32), np.sort(rng.choice(1000, 400, replace=False)).astype(np.uint32)], axis=1)
+             for c in range(base_lkey.n_chunks)]
+    mixed = np.stack([rng.integers(0, base_rkey.n_chunks, 2500).astype(np.uint32), rng.integers(0, 1500, 2500).astype(np.uint32)], axis=1)
+    mixed[::97] = 0xFFFFFFFF
+    single = list(range(base_lkey.n_chunks))
+    ref_lkey = storage.make_reference_column(base_lkey, pos_l, single)
+    ref_lval = storage.make_reference_column(base_lval, pos_l, single)
+    ref_rkey = storage.make_reference_column(base_rkey, [mixed, 2], [None, 2])
+    ref_rval = storage.make_reference_column(base_rval, [mixed, 2], [None, 2])
+    bases = {id(c): DeviceColumn(c) for c in (base_lkey, base_rkey, base_lval, base_rval)}
+    dev = {name: DeviceColumn(col, refs={id(base): bases[id(base)]})
+           for name, col, base in (("lkey", ref_lkey, base_lkey), ("lval", ref_lval, base_lval), ("rkey", ref_rkey, base_rkey), ("rval", ref_rval, base_rval))}
+    for mode in SECONDARY_MODES:
+        for radix_bits in (0, 2):
+            got = join_hash(dev["lkey"], dev["rkey"], mode, radix_bits, secondary=[(dev["lval"], abi.PRED_GREATER_THAN_EQUALS, dev["rval"])])
+            want = oracle_join(ref_lkey, ref_rkey, mode, radix_bits, secondary=[(ref_lval, abi.PRED_GREATER_THAN_EQUALS, ref_rval)])
+            assert_join_equal(got, want, mode, f"reference inputs + secondary predicate, mode {mode} radix {radix_bits}")
