@@ -137,9 +137,8 @@ inline T* carve(Scratch& s, size_t count) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 
-// Temporary device buffers come from a per-thread pool of power-of-two blocks that is reused across calls
-// (hipMalloc/hipFree cost ~100 us each and synchronise the device).
-// Pool of power-of-two device blocks (per thread): acquire / release without hipMalloc / hipFree in the steady state.
+// Temporary device buffers come from a per-thread pool of power-of-two blocks that is reused across calls in stream
+// order (hipMalloc/hipFree cost ~100 us each and synchronise the device); hy_shutdown releases the calling thread's pool.
 hy_status pool_acquire(size_t bytes, void** ptr, size_t* capacity);
 void pool_release(void* ptr, size_t capacity);
 

@@ -120,7 +120,8 @@ static thread_local PinnedStaging t_staging;
 hy_status pinned_staging(size_t bytes, void** host, void** device) {
   if (bytes > t_staging.bytes) {
     if (t_staging.host) (void)hipHostFree(t_staging.host);
-    t_staging = PinnedStaging{};
+    t_staging.host = t_staging.device = nullptr;
+    t_staging.bytes = 0;
     size_t rounded = 1 << 16;
     while (rounded < bytes) rounded <<= 1;
     HY_HIP(hipHostMalloc(&t_staging.host, rounded, hipHostMallocMapped));
@@ -251,17 +252,29 @@ hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches) {
   return HY_OK;
 }
 
+// Releases what the CALLING thread holds between calls: its scratch arena, its pool of temporary blocks and its pinned
+// staging area (all of them are thread-local and grow on demand, so calling the library again afterwards is fine).
 hy_status hy_shutdown(void) {
+  (void)hipStreamSynchronize(t_stream);
   Scratch& s = scratch();
   if (s.base) (void)hipFree(s.base);
   if (s.ticket) (void)hipFree(s.ticket);
   if (s.status) (void)hipFree(s.status);
   s = Scratch{};
+  for (auto& block : t_pool.free_blocks) (void)hipFree(block.second);
+  t_pool.free_blocks.clear();
+  if (t_staging.host) (void)hipHostFree(t_staging.host);
+  t_staging.host = t_staging.device = nullptr;
+  t_staging.bytes = 0;
   return HY_OK;
 }
 
+// The thread's temporaries (scratch arena, pooled blocks) are reused from call to call in stream order, so work still
+// queued on the old stream has to finish before launches on a different stream may touch them.
 hy_status hy_set_stream(void* hip_stream) {
-  t_stream = static_cast<hipStream_t>(hip_stream);
+  const auto stream = static_cast<hipStream_t>(hip_stream);
+  if (stream != t_stream) (void)hipStreamSynchronize(t_stream);   // (the old handle may already be destroyed: then nothing is queued)
+  t_stream = stream;
   return HY_OK;
 }
 
