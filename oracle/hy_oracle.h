@@ -74,6 +74,9 @@ uint32_t hyo_calculate_radix_bits(uint64_t build_rows, uint64_t probe_rows);
 /* materialize_input: writes (row_id,value) elements of one column in chunk order; returns element count.
  * bloom_in may be NULL (all-true); bloom_out 2^20 bits = 16384 u64 words (zeroed by the caller).
  * histograms_out [n_chunks << radix_bits] */
+/* std::hash<HashedType>{}(key) as libstdc++ computes it; key: an integer, or the bit pattern of a float (zero-extended) /
+ * double with -0.0 given as +0.0.  hashed_type: HY_TYPE_*. */
+uint64_t hyo_std_hash(int64_t key, uint32_t hashed_type);
 uint64_t hyo_join_materialize(const hyo_column* column, int keep_nulls, uint32_t radix_bits, const uint64_t* bloom_in,
                               uint64_t* bloom_out, hy_row_id* row_ids_out, int64_t* values_out, uint8_t* nulls_out,
                               uint64_t* chunk_element_counts_out, uint64_t* histograms_out);

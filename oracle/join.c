@@ -10,8 +10,12 @@
  *   partition_by_radix                                join_hash_steps.hpp:509-617
  *   build + PosHashTable                              join_hash_steps.hpp:97-236, 426-507
  *   probe / probe_semi_anti                           join_hash_steps.hpp:624-922
- * Integer keys only (int32/int64): std::hash is the identity there (pinned by join_hash_steps_test.cpp:169-188);
- * std::hash<float/double> is implementation-defined, so float-keyed joins stay on the CPU path.
+ * Keys: int32/int64 -- std::hash is the identity there (pinned by join_hash_steps_test.cpp:169-188) -- and float/double,
+ * also mixed with integers (JoinHashTraits, join_hash_traits.hpp:15-40: both sides are cast to one HashedType first).
+ * std::hash<float/double> is implementation-defined; this file restates libstdc++'s (GCC is the reference's primary
+ * compiler): 0 for +-0.0, otherwise _Hash_bytes (libsupc++/hash_bytes.cc, the 64-bit Murmur-style function, seed
+ * 0xc70f6907) over the value's 4 / 8 bytes.  tests/test_oracle_join.py pins hyo_std_hash against the std::hash of the g++
+ * installed here.  String keys stay on the CPU path.
  * Secondary predicates are not part of the device ABI and therefore not restated.
  *
  * Result: the concatenation of probe()'s per-slice PosLists, in the order the slices are created
@@ -190,6 +194,75 @@ uint32_t hyo_calculate_radix_bits(uint64_t build_rows, uint64_t probe_rows) {
   return bits > 8.0 ? 8u : (uint32_t)bits;                                       /* :113 */
 }
 
+/* ---- HashedType (join_hash_traits.hpp:15-40) and its std::hash ------------------------------------------------------------- */
+/* One join at a time (test infrastructure): the type both sides are cast to before hashing and comparing.  Integer joins keep
+ * the element's value; float joins keep the bit pattern of the HashedType value (float: zero-extended), -0.0 as +0.0 (they
+ * compare equal and both hash to 0), so that equal bits <=> equal keys -- except NaN, which equals nothing. */
+static uint32_t g_hashed_type = HY_TYPE_LONG;
+
+static uint32_t hashed_type_of(uint32_t l, uint32_t r) {
+  const int lf = is_float_type(l), rf = is_float_type(r);
+  if (lf && rf) return (l == HY_TYPE_DOUBLE || r == HY_TYPE_DOUBLE) ? HY_TYPE_DOUBLE : HY_TYPE_FLOAT;   /* the larger one */
+  if (!lf && !rf) return (l == HY_TYPE_LONG || r == HY_TYPE_LONG) ? HY_TYPE_LONG : HY_TYPE_INT;
+  return lf ? l : r;                                                                                   /* the floating one */
+}
+
+/* libstdc++ _Hash_bytes, size_t = 64 bits (libsupc++/hash_bytes.cc) */
+static uint64_t shift_mix(uint64_t v) { return v ^ (v >> 47); }
+static uint64_t libstdcxx_hash_bytes(const void* ptr, uint64_t len) {
+  const uint64_t mul = (((uint64_t)0xc6a4a793UL) << 32) + (uint64_t)0x5bd1e995UL;
+  const unsigned char* buf = (const unsigned char*)ptr;
+  const uint64_t len_aligned = len & ~(uint64_t)7;
+  uint64_t hash = (uint64_t)0xc70f6907UL ^ (len * mul);
+  for (uint64_t p = 0; p < len_aligned; p += 8) {
+    uint64_t word;
+    memcpy(&word, buf + p, 8);
+    hash ^= shift_mix(word * mul) * mul;
+    hash *= mul;
+  }
+  if (len & 7) {
+    uint64_t data = 0;
+    for (int n = (int)(len & 7) - 1; n >= 0; --n) data = (data << 8) + buf[len_aligned + (uint64_t)n];
+    hash ^= data;
+    hash *= mul;
+  }
+  hash = shift_mix(hash) * mul;
+  return shift_mix(hash);
+}
+
+/* std::hash<HashedType>{}(key) for a key in this file's representation (functional_hash.h: 0 for 0.0 and -0.0) */
+uint64_t hyo_std_hash(int64_t key, uint32_t hashed_type) {
+  if (hashed_type == HY_TYPE_FLOAT) {
+    const uint32_t bits = (uint32_t)key;
+    return bits == 0 ? 0 : libstdcxx_hash_bytes(&bits, 4);
+  }
+  if (hashed_type == HY_TYPE_DOUBLE) return key == 0 ? 0 : libstdcxx_hash_bytes(&key, 8);
+  return (uint64_t)key;   /* std::hash<integral> is the identity */
+}
+
+static int key_is_nan(int64_t key) {
+  if (g_hashed_type == HY_TYPE_FLOAT) return ((uint32_t)key & 0x7FFFFFFFu) > 0x7F800000u;
+  if (g_hashed_type == HY_TYPE_DOUBLE) return ((uint64_t)key & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull;
+  return 0;
+}
+
+/* static_cast<HashedType>(value) in this file's key representation */
+static int64_t key_of(typed_value_t v, uint32_t column_type) {
+  if (g_hashed_type == HY_TYPE_FLOAT) {
+    const float f = is_float_type(column_type) ? (float)v.f : (float)v.i;
+    uint32_t bits;
+    memcpy(&bits, &f, 4);
+    return f == 0.0f ? 0 : (int64_t)bits;
+  }
+  if (g_hashed_type == HY_TYPE_DOUBLE) {
+    const double d = is_float_type(column_type) ? v.f : (double)v.i;
+    int64_t bits;
+    memcpy(&bits, &d, 8);
+    return d == 0.0 ? 0 : bits;
+  }
+  return v.i;
+}
+
 /* materialize_input<T, HashedType, keep_null_values> for one chunk (join_hash_steps.hpp:306-410). */
 static void materialize_chunk(const hyo_column* col, uint32_t chunk_id, int keep_nulls, uint32_t radix_bits,
                               const uint64_t* bloom_in, uint64_t* bloom_out, partition_t* out, uint64_t* histogram) {
@@ -200,9 +273,18 @@ static void materialize_chunk(const hyo_column* col, uint32_t chunk_id, int keep
   uint64_t count = 0;
   for (uint32_t i = 0; i < n; ++i) {
     int64_t value;
-    const int is_null = column_value(col, chunk_id, i, &value);
+    int is_null;
+    if (is_float_type(g_hashed_type)) {
+      uint32_t column_type;
+      const hy_row_id id = {chunk_id, i};
+      const typed_value_t v = column_typed_value(col, id, &column_type);
+      is_null = v.is_null;
+      value = is_null ? 0 : key_of(v, column_type);
+    } else {
+      is_null = column_value(col, chunk_id, i, &value);
+    }
     if (is_null && !keep_nulls) continue;
-    const uint64_t hash = (uint64_t)value; /* std::hash<integral> is the identity */
+    const uint64_t hash = hyo_std_hash(value, g_hashed_type);
     if (!is_null && bloom_in && !bloom_get(bloom_in, hash) && !keep_nulls) continue; /* :354-358 */
     bloom_set(bloom_out, hash);                                                      /* :362 */
     out->elements[count].row_id.chunk_id = chunk_id;  /* reference segments: index in the segment (:364-371) */
@@ -220,6 +302,7 @@ uint64_t hyo_join_materialize(const hyo_column* column, int keep_nulls, uint32_t
                               uint64_t* chunk_element_counts_out, uint64_t* histograms_out) {
   const uint64_t partitions = (uint64_t)1 << radix_bits;
   uint64_t total = 0;
+  g_hashed_type = HY_TYPE_LONG;   /* the step-level entry point is for integer columns */
   for (uint32_t c = 0; c < column->n_chunks; ++c) {
     partition_t p;
     uint64_t* hist = (uint64_t*)calloc(partitions, sizeof(uint64_t));
@@ -271,7 +354,7 @@ typedef struct {
 static uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; return x; }
 
 static uint32_t table_find(const hash_table_t* t, int64_t key) {
-  if (!t->exists || t->capacity == 0) return 0xFFFFFFFFu;
+  if (!t->exists || t->capacity == 0 || key_is_nan(key)) return 0xFFFFFFFFu;
   uint64_t slot = mix((uint64_t)key) & (t->capacity - 1);
   while (t->used[slot]) {
     if (t->keys[slot] == key) return t->ids[slot];
@@ -299,7 +382,8 @@ static void table_build(hash_table_t* t, const partition_t* parts, uint32_t n_pa
     for (uint64_t i = 0; i < parts[p].size; ++i, ++e) {
       const int64_t key = parts[p].elements[i].value;
       element_ids[e] = 0xFFFFFFFFu;
-      if (!bloom_get(probe_bloom, (uint64_t)key)) continue;   /* :476-479 */
+      if (!bloom_get(probe_bloom, hyo_std_hash(key, g_hashed_type))) continue;   /* :476-479 */
+      if (key_is_nan(key)) continue;   /* (the reference adds an entry that no lookup ever finds) */
       uint64_t slot = mix((uint64_t)key) & (cap - 1);
       while (t->used[slot] && t->keys[slot] != key) slot = (slot + 1) & (cap - 1);
       if (!t->used[slot]) { t->used[slot] = 1; t->keys[slot] = key; t->ids[slot] = t->distinct++; }
@@ -377,7 +461,7 @@ static partition_t* partition_by_radix(const partition_t* in, uint32_t n_in, con
   }
   for (uint32_t c = 0; c < n_in; ++c) {
     for (uint64_t i = 0; i < in[c].size; ++i) {
-      const uint64_t r = (uint64_t)in[c].elements[i].value & mask;
+      const uint64_t r = hyo_std_hash(in[c].elements[i].value, g_hashed_type) & mask;
       const uint64_t idx = offsets[(uint64_t)c * partitions + r]++;
       out[r].elements[idx] = in[c].elements[i];
       if (keep_nulls) out[r].nulls[idx] = in[c].nulls[i];
@@ -490,6 +574,12 @@ int32_t hyo_join_hash_predicates(const hyo_column* left, const hyo_column* right
                                  uint32_t n_secondary, hy_join_result* result, int threads) {
   if (mode == HY_JOIN_FULL_OUTER || mode == HY_JOIN_CROSS || mode > HY_JOIN_ANTI_NULL_AS_FALSE) return HY_ERR_UNSUPPORTED;
   if (n_secondary > HY_MAX_SECONDARY_PREDICATES || (n_secondary && mode == HY_JOIN_ANTI_NULL_AS_TRUE)) return HY_ERR_UNSUPPORTED;   /* join_hash.cpp:39-44 */
+  {
+    const uint32_t left_type = left->n_chunks ? left->segments[0].data_type : HY_TYPE_LONG;
+    const uint32_t right_type = right->n_chunks ? right->segments[0].data_type : left_type;
+    if (left_type < HY_TYPE_INT || left_type > HY_TYPE_DOUBLE || right_type < HY_TYPE_INT || right_type > HY_TYPE_DOUBLE) return HY_ERR_UNSUPPORTED;
+    g_hashed_type = hashed_type_of(left->n_chunks ? left_type : right_type, right_type);
+  }
   uint64_t left_rows = 0, right_rows = 0;
   for (uint32_t c = 0; c < left->n_chunks; ++c) left_rows += left->segments[c].size;
   for (uint32_t c = 0; c < right->n_chunks; ++c) right_rows += right->segments[c].size;

@@ -384,8 +384,8 @@ def _verification_join_general(left, right, mode, secondary):
     lrows, rrows = row_ids_of(left), row_ids_of(right)
     extra = [(column_values(l), l.data_type, c, column_values(r), r.data_type) for l, c, r in secondary]
 
-    def matches(i, j):
-        if lv[i] is None or rv[j] is None or lv[i] != rv[j]:
+    def matches(i, j):   # the keys compare like C++ compares the two column types (= after JoinHash's cast to its HashedType)
+        if lv[i] is None or rv[j] is None or not cxx_compare(abi.PRED_EQUALS, lv[i], left.data_type, rv[j], right.data_type):
             return False
         for xs, xt, c, ys, yt in extra:
             if xs[i] is None or ys[j] is None or not cxx_compare(c, xs[i], xt, ys[j], yt):
@@ -407,6 +407,10 @@ def _verification_join_general(left, right, mode, secondary):
         out = [(lrows[i], None) for i in range(len(lv)) if any(matches(i, j) for j in range(len(rv)))]
     elif mode == abi.JOIN_ANTI_NULL_AS_FALSE:
         out = [(lrows[i], None) for i in range(len(lv)) if not any(matches(i, j) for j in range(len(rv)))]
+    elif not secondary:   # AntiNullAsTrue: a NULL on either side counts as a match
+        def maybe(i, j):
+            return lv[i] is None or rv[j] is None or matches(i, j)
+        out = [(lrows[i], None) for i in range(len(lv)) if not any(maybe(i, j) for j in range(len(rv)))]
     else:
         raise ValueError("AntiNullAsTrue has no secondary predicates in JoinHash")
     return sorted(out, key=lambda p: (p[0] is None, p[0] or (0, 0), p[1] is None, p[1] or (0, 0)))
@@ -415,8 +419,9 @@ def _verification_join_general(left, right, mode, secondary):
 def verification_join(left, right, mode, secondary=None):
     """Nested-loop reference of the join semantics (JoinVerification, operators/join_verification.cpp:60-184), as a
     sorted multiset of ((left chunk, left offset) | None, (right chunk, right offset) | None)."""
-    if secondary:
-        return _verification_join_general(left, right, mode, secondary)
+    floating = (abi.TYPE_FLOAT, abi.TYPE_DOUBLE)
+    if secondary or left.data_type in floating or right.data_type in floating:
+        return _verification_join_general(left, right, mode, secondary or [])
     lv, rv = column_values(left), column_values(right)
     lrows, rrows = row_ids_of(left), row_ids_of(right)
     out = []

@@ -201,3 +201,95 @@ def test_secondary_predicates_keep_the_join_order_and_reject_anti_null_as_true()
     predicates = (abi.JoinPredicate * 1)()
     predicates[0].left_column, predicates[0].right_column, predicates[0].condition = C.addressof(l2.c), C.addressof(r2.c), abi.PRED_LESS_THAN
     assert lib.hyo_join_hash_predicates(C.byref(lcol.c), C.byref(rcol.c), abi.JOIN_ANTI_NULL_AS_TRUE, predicates, 1, C.byref(result.c), 1) == abi.ERR_UNSUPPORTED
+
+
+# ---- float / double keys, also mixed with integers (JoinHashTraits) ---------------------------------------------------------
+NUMERIC_COLUMNS = ("int", "int_null", "long", "long_null", "float", "float_null", "double", "double_null")
+
+
+def test_std_hash_restatement_against_the_installed_libstdcxx(tmp_path):
+    """hyo_std_hash (oracle/join.c: libstdc++'s _Hash_bytes, 0 for +-0.0) against std::hash<float> / std::hash<double> of
+    the g++ installed here -- the radix partition, and with it the pair order, of float-keyed joins hangs on it."""
+    import subprocess
+    source = tmp_path / "std_hash.cpp"
+    source.write_text('''#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+int main() {
+  unsigned type; unsigned long long bits;
+  while (std::scanf("%u %llx", &type, &bits) == 2) {
+    unsigned long long hash;
+    if (type == 3) { float f; const uint32_t b = static_cast<uint32_t>(bits); std::memcpy(&f, &b, 4); hash = std::hash<float>{}(f); }
+    else { double d; std::memcpy(&d, &bits, 8); hash = std::hash<double>{}(d); }
+    std::printf("%llx\\n", hash);
+  }
+}
+''')
+    binary = tmp_path / "std_hash"
+    subprocess.check_call(["g++", "-O1", "-o", str(binary), str(source)])
+    rng = np.random.default_rng(3)
+    doubles = np.concatenate([np.array([0.0, -0.0, 1.0, -1.0, 1338.0, 4294968633.0, 0.1, np.inf, -np.inf, 1e-310, 724.3]), rng.normal(size=200) * 1e6,
+                              rng.integers(-10**6, 10**6, 100).astype(np.float64)])
+    floats = doubles.astype(np.float32)
+    cases = [(abi.TYPE_DOUBLE, int(b)) for b in doubles.view(np.uint64)] + [(abi.TYPE_FLOAT, int(b)) for b in floats.view(np.uint32)]
+    lines = "".join(f"{t} {b:x}\n" for t, b in cases)
+    want = [int(x, 16) for x in subprocess.run([str(binary)], input=lines.encode(), stdout=subprocess.PIPE, check=True).stdout.split()]
+    lib = oracle()
+    lib.hyo_std_hash.restype = C.c_uint64
+    lib.hyo_std_hash.argtypes = [C.c_int64, C.c_uint32]
+    assert len(want) == len(cases)
+    for (t, b), w in zip(cases, want):
+        negative_zero = b == (1 << 63) if t == abi.TYPE_DOUBLE else b == (1 << 31)
+        key = 0 if negative_zero else (b - (1 << 64) if b >= (1 << 63) else b)   # the oracle's key: the bits, -0.0 as +0.0
+        assert lib.hyo_std_hash(key, t) == w, (t, hex(b))
+    assert lib.hyo_std_hash(-5, abi.TYPE_LONG) == (1 << 64) - 5 and lib.hyo_std_hash(7, abi.TYPE_INT) == 7
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_join_on_all_numeric_type_pairs_of_the_runner_tables(mode):
+    """join_test_runner.cpp:183-193 joins every data type with every other one: both sides are cast to JoinHashTraits'
+    HashedType (int x float -> float, long x double -> double ...) and compared there, like C++ compares the two types."""
+    lt, rt = runner_tables(15, 0)[0], runner_tables(10, 0)[1]
+    for left_name in NUMERIC_COLUMNS:
+        for right_name in NUMERIC_COLUMNS:
+            if "float" not in left_name + right_name and "double" not in left_name + right_name:
+                continue   # (the integer pairs: test_join_against_verification_on_runner_tables)
+            lvals, lnull = lt.column("l_" + left_name)
+            rvals, rnull = rt.column("r_" + right_name)
+            for chunk, encoding, radix_bits in ((10, abi.ENC_UNENCODED, None), (3, abi.ENC_DICTIONARY, 2), (4, abi.ENC_DICTIONARY, 0)):
+                left = build_column(lvals, lnull, chunk, encoding)
+                right = build_column(rvals, rnull, chunk, encoding)
+                got = oracle_join(left, right, mode, radix_bits)
+                assert join_result_multiset(got, mode) == verification_join(left, right, mode), f"{left_name} x {right_name} chunk {chunk} radix {radix_bits}"
+
+
+FLOAT_KEY_DOMAIN = [0.0, -0.0, 1.0, -1.0, 0.5, 16777216.0, 16777217.0, 16777218.0, 1e30, -1e30, float("inf"), float("-inf"), float("nan"), 3.25, 1338.0]
+
+
+def float_key_column(rng, data_type, n, chunk, null_fraction=0.15):
+    """Keys that collide after the cast to the HashedType: 16777217 is not a float, +-0.0 are one key, NaN is none."""
+    np_type = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}[data_type]
+    if data_type in (abi.TYPE_INT, abi.TYPE_LONG):
+        domain = np.array([0, 1, -1, 16777216, 16777217, 16777218, 3, 1338], dtype=np_type)
+    else:
+        domain = np.array(FLOAT_KEY_DOMAIN, dtype=np_type)
+    values = domain[rng.integers(0, len(domain), n)]
+    nulls = rng.random(n) < null_fraction
+    encoding = abi.ENC_UNENCODED if (np_type in (np.float32, np.float64) and np.isnan(values).any()) or rng.random() < 0.5 else abi.ENC_DICTIONARY
+    return build_column(values, nulls, chunk, encoding)   # (a dictionary cannot hold NaN: it is not ordered)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_float_key_joins_against_verification(mode):
+    rng = np.random.default_rng(17)
+    types = (abi.TYPE_INT, abi.TYPE_LONG, abi.TYPE_FLOAT, abi.TYPE_DOUBLE)
+    for left_type in types:
+        for right_type in types:
+            if left_type in (abi.TYPE_INT, abi.TYPE_LONG) and right_type in (abi.TYPE_INT, abi.TYPE_LONG):
+                continue
+            for n_left, n_right, chunk, radix_bits in ((40, 25, 7, 3), (12, 60, 100, None), (30, 30, 5, 0)):
+                left = float_key_column(rng, left_type, n_left, chunk)
+                right = float_key_column(rng, right_type, n_right, chunk)
+                got = oracle_join(left, right, mode, radix_bits)
+                assert join_result_multiset(got, mode) == verification_join(left, right, mode), f"{left_type} x {right_type} rows {n_left},{n_right} radix {radix_bits}"
