@@ -87,6 +87,55 @@ __device__ __forceinline__ bool bloom_test(const uint8_t* bloom, uint64_t hash) 
   return bloom[static_cast<uint32_t>(hash) & (BLOOM_BITS - 1)] != 0;
 }
 
+// ---- float / double keys, also joined with integer columns -----------------------------------------------------------------
+// JoinHashTraits (join_hash_traits.hpp:15-40): both sides are cast to one HashedType -- the larger floating type, or THE
+// floating type of an integer x floating join -- hashed with std::hash<HashedType> and compared there.  Such a join keeps
+// the BIT PATTERN of the HashedType value as its 64-bit key (float: zero-extended; -0.0 as +0.0, they compare equal and
+// both hash to 0): equal bits <=> equal keys, except NaN, which finds nothing.  The radix partition and the Bloom filter
+// take std::hash of the value, which libstdc++ defines as 0 for zero and _Hash_bytes (libsupc++/hash_bytes.cc, seed
+// 0xc70f6907) over the 4 / 8 bytes otherwise -- restated here, pinned in tests/test_oracle_join.py.
+// hashed_type: 0 (integer keys, std::hash is the identity) | HY_TYPE_FLOAT | HY_TYPE_DOUBLE.
+__device__ __forceinline__ uint64_t join_hash(uint64_t key, uint32_t hashed_type) {
+  if (hashed_type == 0 || key == 0) return key;
+  constexpr uint64_t mul = (0xc6a4a793ull << 32) + 0x5bd1e995ull;
+  auto shift_mix = [](uint64_t v) { return v ^ (v >> 47); };
+  uint64_t hash;
+  if (hashed_type == HY_TYPE_FLOAT) {
+    hash = 0xc70f6907ull ^ (4 * mul);
+    hash ^= key;   // the four bytes, little endian
+    hash *= mul;
+  } else {
+    hash = 0xc70f6907ull ^ (8 * mul);
+    hash ^= shift_mix(key * mul) * mul;
+    hash *= mul;
+  }
+  hash = shift_mix(hash) * mul;
+  return shift_mix(hash);
+}
+
+__device__ __forceinline__ bool key_is_nan(uint64_t key, uint32_t hashed_type) {
+  if (hashed_type == HY_TYPE_FLOAT) return (static_cast<uint32_t>(key) & 0x7FFFFFFFu) > 0x7F800000u;
+  if (hashed_type == HY_TYPE_DOUBLE) return (key & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull;
+  return false;
+}
+
+// static_cast<HashedType>(value) of a row of any numeric column (data or reference segments), as the key above; true if NULL.
+__device__ __forceinline__ bool hashed_key(const DevSegment* segments, uint32_t chunk, uint32_t row, uint32_t hashed_type, int64_t* key) {
+  *key = 0;
+  const Value v = column_value(segments, chunk, row);
+  if (v.is_null) return true;
+  const uint32_t type = segments[chunk].data_type;
+  const bool is_float = type == HY_TYPE_FLOAT || type == HY_TYPE_DOUBLE;
+  if (hashed_type == HY_TYPE_FLOAT) {
+    const float f = is_float ? static_cast<float>(v.f) : static_cast<float>(v.i);
+    *key = f == 0.0f ? 0 : static_cast<int64_t>(__float_as_uint(f));
+  } else {
+    const double d = is_float ? v.f : static_cast<double>(v.i);
+    *key = d == 0.0 ? 0 : __double_as_longlong(d);
+  }
+  return false;
+}
+
 // The build side keeps its keys and RowIDs as narrow as the join allows: int32 columns as 32-bit keys (their unsigned
 // order is the unsigned order of the sign-extended 64-bit keys), RowIDs packed into 32 bits when every chunk id and chunk
 // offset of the build table is below 2^16 (Hyrise's default chunk size: always) -- half the bytes to write, sort and read.
@@ -115,6 +164,7 @@ struct MaterializeArgs {
   void* row_ids;                  // MODE 1: uint32_t chunk_id << 16 | chunk_offset (ID32) or hy_row_id
   uint32_t* any_null;             // set to 1 if a NULL was materialised (AntiNullAsTrue early-out)
   const uint64_t* row_base;       // dense: [n_chunks + 1] first row of every chunk
+  uint32_t hashed_type;           // 0: integer keys | HY_TYPE_FLOAT | HY_TYPE_DOUBLE (see join_hash)
 };
 
 template <int MODE, bool KEY32, bool ID32>
@@ -129,9 +179,9 @@ __global__ __launch_bounds__(256) void join_materialize(MaterializeArgs a) {
     bool keep = false;
     if (r < slice.row_count) {
       int64_t key;
-      const bool is_null = column_key(a.segments, slice.chunk, slice.row_begin + r, &key);
+      const bool is_null = a.hashed_type ? hashed_key(a.segments, slice.chunk, slice.row_begin + r, a.hashed_type, &key) : column_key(a.segments, slice.chunk, slice.row_begin + r, &key);
       keep = !is_null || a.keep_nulls;
-      if (keep && !is_null && a.bloom_in && !a.keep_nulls) keep = bloom_test(a.bloom_in, static_cast<uint64_t>(key));
+      if (keep && !is_null && a.bloom_in && !a.keep_nulls) keep = bloom_test(a.bloom_in, join_hash(static_cast<uint64_t>(key), a.hashed_type));
     }
     const uint64_t ballot = __ballot(keep);
     if (lane == 0) s_count[k][wave] = __popcll(ballot);
@@ -153,12 +203,12 @@ __global__ __launch_bounds__(256) void join_materialize(MaterializeArgs a) {
     if (keep) {
       const uint32_t r = k * 256 + tid;
       int64_t key;
-      const bool is_null = column_key(a.segments, slice.chunk, slice.row_begin + r, &key);
+      const bool is_null = a.hashed_type ? hashed_key(a.segments, slice.chunk, slice.row_begin + r, a.hashed_type, &key) : column_key(a.segments, slice.chunk, slice.row_begin + r, &key);
       const uint64_t pos = base + s_offset[k][wave] + __popcll(ballot & ((1ull << lane) - 1));
       static_cast<typename BuildKey<KEY32>::type*>(a.keys)[pos] = static_cast<typename BuildKey<KEY32>::type>(key);
       static_cast<typename BuildRow<ID32>::type*>(a.row_ids)[pos] = make_build_row<ID32>(slice.chunk, slice.row_begin + r);
       if (is_null && a.any_null) *a.any_null = 1;
-      if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(key) & (BLOOM_BITS - 1)] = 1;
+      if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(join_hash(static_cast<uint64_t>(key), a.hashed_type)) & (BLOOM_BITS - 1)] = 1;
     }
   }
 }
@@ -560,6 +610,7 @@ struct ProbeArgs {
   uint32_t* error;                // set when a probe row matches >= 2^22 build rows (the staging record cannot hold it)
   uint64_t* trace;                // debug (HY_JOIN_TRACE): 6 wall-clock stamps per probe_emit tile, else nullptr
   uint32_t pack_build_ids;        // dir.ids32 exists: probe_emit_cached stages the partner's packed RowID, not its position
+  uint32_t hashed_type;           // 0: integer keys | HY_TYPE_FLOAT | HY_TYPE_DOUBLE (join_hash); only the <true> instantiations look at it
 };
 
 // Output pairs of one probe row per join mode (probe / probe_semi_anti, join_hash_steps.hpp:575-922).
@@ -643,6 +694,7 @@ __device__ __forceinline__ void load_compressed_rows(const void* data, uint32_t 
 }
 
 // Phase 1 of a probe: the keys of the lane's JOIN_ROUNDS rows (NULL rows: key 0, a kept NULL lands in partition 0).
+template <bool GENERAL>   // the general instantiation also reads float / double keys, and integer keys cast to them
 __device__ __forceinline__ void decode_keys(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
                                             uint32_t (&row)[JOIN_ROUNDS], bool (&in)[JOIN_ROUNDS], bool (&is_null)[JOIN_ROUNDS], int64_t (&key)[JOIN_ROUNDS]) {
 #pragma unroll
@@ -652,6 +704,15 @@ __device__ __forceinline__ void decode_keys(const ProbeArgs& a, uint32_t chunk, 
     row[k] = row_begin + (in[k] ? r : 0);   // row_count > 0: the tile's first row exists
     is_null[k] = false;
     key[k] = 0;
+  }
+  if constexpr (GENERAL) {
+    if (a.hashed_type) {
+#pragma unroll 1
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+        if (in[k]) is_null[k] = hashed_key(a.segments, chunk, row[k], a.hashed_type, &key[k]);
+      }
+      return;
+    }
   }
   const DevSegment s = a.segments[chunk];
   if (s.encoding == HY_ENC_REFERENCE) {
@@ -718,7 +779,7 @@ __device__ __forceinline__ void decode_keys(const ProbeArgs& a, uint32_t chunk, 
 constexpr uint32_t ROW_PARTITION = 0xFF, ROW_MATERIALISED = 0x100, ROW_EMIT = 0x200, ROW_NULL_PARTNER = 0x400;
 
 // meta[k] = emit << 10 | null_partner << 9 | partition (INVALID_PARTITION: not materialised); start[k] = first build position
-template <bool SECONDARY>   // instantiated with and without secondary predicates: the plain join pays nothing for them
+template <bool SECONDARY>   // the general instantiation (<true>: secondary predicates, float / double keys) and the plain one, which pays nothing for them
 __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
                                               uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&start)[JOIN_ROUNDS], uint32_t (&partners)[JOIN_ROUNDS]) {
   uint32_t row[JOIN_ROUNDS];
@@ -731,7 +792,9 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
     if constexpr (SECONDARY) partners[k] = 0;   // (only read with secondary predicates)
   }
   if (row_count == 0) return;
-  decode_keys(a, chunk, row_begin, row_count, wave, lane, row, in, is_null, key);
+  decode_keys<SECONDARY>(a, chunk, row_begin, row_count, wave, lane, row, in, is_null, key);
+  uint32_t hashed_type = 0;   // (constant 0 in the plain instantiation: std::hash is the identity and nothing below changes)
+  if constexpr (SECONDARY) hashed_type = a.hashed_type;
   // ---- phase 2: which rows are materialised by the NULL policy (the Bloom filter follows the lookup, see phase 4)
   bool valid[JOIN_ROUNDS];
 #pragma unroll
@@ -749,7 +812,7 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
 #pragma unroll
     for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
       const uint64_t hash = static_cast<uint64_t>(key[k]);
-      look[k] = valid[k] && !is_null[k] && hash >= d.key_min && hash <= d.key_max;
+      look[k] = valid[k] && !is_null[k] && hash >= d.key_min && hash <= d.key_max && !key_is_nan(hash, hashed_type);
       const uint64_t bucket = look[k] ? (hash - d.key_min) >> d.shift : 0;
       const u32x2_t entry = *reinterpret_cast<const u32x2_t __attribute__((aligned(4)))*>(d.dir + bucket);
       lo[k] = entry.x;
@@ -819,7 +882,7 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
       uint32_t index[JOIN_ROUNDS];
       uint8_t hit[JOIN_ROUNDS];
 #pragma unroll
-      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) index[k] = static_cast<uint32_t>(key[k]) & (BLOOM_BITS - 1);
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) index[k] = static_cast<uint32_t>(join_hash(static_cast<uint64_t>(key[k]), hashed_type)) & (BLOOM_BITS - 1);
       load_rows<uint8_t>(a.build_bloom, index, hit);
 #pragma unroll
       for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) valid[k] = valid[k] && !(count[k] == 0 && hit[k] == 0);
@@ -846,7 +909,7 @@ __device__ __forceinline__ void evaluate_rows(const ProbeArgs& a, uint32_t chunk
 #pragma unroll
   for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
     if (!valid[k]) continue;
-    const uint32_t partition = a.radix_bits ? static_cast<uint32_t>(static_cast<uint64_t>(key[k]) & ((1u << a.radix_bits) - 1)) : 0;
+    const uint32_t partition = a.radix_bits ? static_cast<uint32_t>(join_hash(static_cast<uint64_t>(key[k]), hashed_type) & ((1u << a.radix_bits) - 1)) : 0;
     bool null_partner = false;
     uint32_t emit = pairs_of(a, is_null[k], passing[k], &null_partner);
     if (emit >= (1u << 22)) { *a.error = 1; emit = (1u << 22) - 1; }
@@ -1388,7 +1451,6 @@ static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, h
   return HY_OK;
 }
 
-static bool is_integer_column(const hy_column* c) { return (c->data_type == HY_TYPE_INT || c->data_type == HY_TYPE_LONG) && !c->is_mvcc && !(c->ref && c->ref->is_mvcc); }
 
 // ---- what the host learns from the device during a join ----------------------------------------------------------------
 // A pinned, device-mapped block per thread: small kernels store into it, the host reads it after a stream synchronise.
@@ -1492,7 +1554,7 @@ struct BuildSide {
 
 // Materialise + (sort) + directory.  `bloom_in` (device) filters the build side (no observable effect, kept for the
 // reference's element counts); `bloom_out` receives the build side's filter if wanted.
-static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, BuildSide& b, hipStream_t stream) {
+static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, uint32_t hashed_type, BuildSide& b, hipStream_t stream) {
   const uint32_t n_slices = build->n_slices;
   DeviceBuffer counts, offsets;
   HY_TRY(counts.alloc(4 * size_t{n_slices + 1}));
@@ -1512,10 +1574,11 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   m.bloom_out = want_bloom ? b.bloom.as<uint8_t>() : nullptr;
   m.slice_counts = counts.as<uint32_t>();
   m.any_null = b.flags.as<uint32_t>() + 2;
+  m.hashed_type = hashed_type;
   uint64_t total = 0;
   // A column whose segments cannot hold NULLs (value / FrameOfReference segments without a null vector) materialises
   // every row: slice offsets are row numbers, no counting pass and no host round trip.
-  bool dense = true;
+  bool dense = hashed_type == 0;   // (float / double keys go through the generic decoder)
   for (uint32_t c = 0; c < build->n_chunks && dense; ++c) {
     const hy_segment& seg = build->host_segments[c];
     dense = (seg.encoding == HY_ENC_UNENCODED || seg.encoding == HY_ENC_FRAME_OF_REFERENCE) && seg.nulls == nullptr;
@@ -1530,7 +1593,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     HY_HIP(hipStreamSynchronize(stream));
   }
   b.n = total;
-  const bool key32 = build->data_type == HY_TYPE_INT, id32 = want_ids32;
+  const bool key32 = build->data_type == HY_TYPE_INT && hashed_type == 0, id32 = want_ids32;
   const size_t key_bytes = key32 ? 4 : 8, row_bytes = id32 ? 4 : 8;
   uint64_t first_key = 0, last_key = 0;
   bool keys_were_sorted = false;
@@ -1701,7 +1764,19 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     if (!same_chunk_layout(predicate.left_column, left) || !same_chunk_layout(predicate.right_column, right))
       return fail(HY_ERR_INVALID, "secondary join predicate %u: the columns do not have the chunk layout of the join's input tables", p);
   }
-  if (!is_integer_column(left) || !is_integer_column(right)) return fail(HY_ERR_UNSUPPORTED, "only int32/int64 join keys run on the device (std::hash of float/string keys is not pinned)");
+  for (const hy_column* column : {left, right}) {
+    if (column->is_mvcc || (column->ref && column->ref->is_mvcc)) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
+    if (column->data_type < HY_TYPE_INT || column->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "string join keys stay on the CPU path");
+  }
+  // JoinHashTraits (join_hash_traits.hpp:15-40): the type both sides are cast to; 0 = an integer type (std::hash is the identity)
+  uint32_t hashed_type = 0;
+  {
+    const uint32_t l = left->data_type, r = right->data_type;
+    const bool l_float = l == HY_TYPE_FLOAT || l == HY_TYPE_DOUBLE, r_float = r == HY_TYPE_FLOAT || r == HY_TYPE_DOUBLE;
+    if (l_float && r_float) hashed_type = (l == HY_TYPE_DOUBLE || r == HY_TYPE_DOUBLE) ? HY_TYPE_DOUBLE : HY_TYPE_FLOAT;
+    else if (l_float || r_float) hashed_type = l_float ? l : r;
+  }
+  const bool general = n_secondary != 0 || hashed_type != 0;   // the <true> instantiations of the probe kernels
   hipStream_t stream = current_stream();
   // side selection (join_hash.cpp:139-155)
   const bool build_right = mode == HY_JOIN_LEFT || mode == HY_JOIN_ANTI_NULL_AS_TRUE || mode == HY_JOIN_ANTI_NULL_AS_FALSE || mode == HY_JOIN_SEMI ||
@@ -1723,7 +1798,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   for (uint32_t c = 0; c < build->n_chunks && pack_build_ids; ++c) pack_build_ids = build->host_segments[c].size <= 65536;
   BuildSide b;
   StageClock clock;
-  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, b, stream));
+  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, b, stream));
   clock.mark("build side launched");
 
   if (result) {
@@ -1766,6 +1841,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     if (n_tiles <= JOIN_TRACE_TILES) { a.trace = trace_buffer; g_join_trace = trace_buffer; g_join_trace_tiles = n_tiles; }
   }
   a.pack_build_ids = b.directory.ids32 ? 1 : 0;
+  a.hashed_type = hashed_type;
   a.n_secondary = n_secondary;
   for (uint32_t p = 0; p < n_secondary; ++p) {   // as the probe sees them: build <condition> probe (join_hash.cpp:158-165)
     a.secondary[p].build = (build_right ? secondary[p].right_column : secondary[p].left_column)->d_segments;
@@ -1840,7 +1916,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
 
   // pass 1, the scan of its counts, the plan of the output -- no host round trip in between
   if (n_tiles) {
-    if (n_secondary) hipLaunchKernelGGL(probe_count<true>, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
+    if (general) hipLaunchKernelGGL(probe_count<true>, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
     else hipLaunchKernelGGL(probe_count<false>, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
     HY_TRY(exclusive_scan(hist.as<uint32_t>(), base.as<uint64_t>(), second_at + cells, stream, second_at));
   } else {
@@ -1897,7 +1973,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     // the tiles pass 1 listed (usually none: the workgroups read the list's length and leave)
     if (!host_result || mailbox->n_uncached) {
       const dim3 generic_grid(std::min<uint32_t>(n_tiles, device_cu_count() * 2));
-      if (n_secondary) hipLaunchKernelGGL(probe_emit_generic<true>, generic_grid, dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
+      if (general) hipLaunchKernelGGL(probe_emit_generic<true>, generic_grid, dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
       else hipLaunchKernelGGL(probe_emit_generic<false>, generic_grid, dim3(JOIN_THREADS), 4 * probe_emit_lds_words(partitions), stream, a);
     }
   }

@@ -276,8 +276,12 @@ typedef struct hy_join_result {
   uint32_t reserved;
 } hy_join_result;
 
-/* Equi-join of two int32/int64 columns.  Pair order == the CPU operator's concatenated probe() output
- * (join_hash_steps.hpp:624-792): by radix partition, then probe row, then build-side insertion order.
+/* Equi-join of two numeric columns (int32 / int64 / float / double, any two: both sides are cast to JoinHashTraits'
+ * HashedType first, join_hash_traits.hpp:15-40 -- the larger integer type, the larger floating type, or THE floating
+ * type of an integer x floating join -- and compared there; NaN keys find nothing).  String keys: HY_ERR_UNSUPPORTED.
+ * Pair order == the CPU operator's concatenated probe() output (join_hash_steps.hpp:624-792): by radix partition
+ * (std::hash<HashedType> of the key -- the identity for integers, libstdc++'s for float / double), then probe row, then
+ * build-side insertion order.
  * A result that does not fit `capacity` / `slice_capacity` is HY_ERR_CAPACITY: nothing is written to the PosList or
  * slice_offsets buffers (device-memory results included -- the check happens on the device between the two probe passes),
  * n_pairs and n_slices report what the join needs.  With mem = HY_MEM_DEVICE the PosLists stay in HBM for the next

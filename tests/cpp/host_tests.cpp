@@ -248,6 +248,40 @@ static void test_join_against_nested_loop() {   // join_test_runner.cpp:656-791 
   }
 }
 
+static bool cxx_equal(const AllTypeVariant& x, const AllTypeVariant& y) {   // x == y as C++ compares the two alternatives' types
+  return std::visit([](const auto& a, const auto& b) -> bool {
+    using A = std::decay_t<decltype(a)>;
+    using B = std::decay_t<decltype(b)>;
+    if constexpr (std::is_arithmetic_v<A> && std::is_arithmetic_v<B>) return a == b;
+    else return false;
+  }, x, y);
+}
+
+static void test_join_on_mixed_numeric_key_types() {   // join_test_runner.cpp:183-193: every data type against every other one
+  const auto left = load_and_encode("join_test_runner/input_table_left_15.tbl", 4, EncodingType::Dictionary);
+  const auto right = load_and_encode("join_test_runner/input_table_right_10.tbl", 3, EncodingType::Unencoded);
+  const auto lrows = left->get_output()->get_rows(), rrows = right->get_output()->get_rows();
+  for (ColumnID lc{0}; lc < 8; ++lc) {     // int, int_null, float, float_null, double, double_null, long, long_null
+    for (ColumnID rc{0}; rc < 8; ++rc) {
+      size_t inner = 0, anti = 0;
+      for (const auto& l : lrows) {
+        bool any = false;
+        for (const auto& r : rrows) {
+          if (cxx_equal(l[lc], r[rc])) { ++inner; any = true; }
+        }
+        anti += !any;
+      }
+      auto join = std::make_shared<JoinHash>(left, right, JoinMode::Inner, ColumnIDPair{lc, rc});
+      join->execute();
+      EXPECT_TRUE(join->get_output()->row_count() == inner);
+      for (const auto& row : join->get_output()->get_rows()) EXPECT_TRUE(cxx_equal(row[lc], row[lrows[0].size() + rc]));
+      auto left_join = std::make_shared<JoinHash>(left, right, JoinMode::Left, ColumnIDPair{lc, rc}, 2);
+      left_join->execute();
+      EXPECT_TRUE(left_join->get_output()->row_count() == inner + anti);
+    }
+  }
+}
+
 static void test_join_with_secondary_predicates() {   // join_test_runner.cpp:207-211, 464-480: {0,0} <, >=, != as secondary predicates
   const auto left = load_and_encode("join_test_runner/input_table_left_15.tbl", 3, EncodingType::Dictionary);
   const auto right = load_and_encode("join_test_runner/input_table_right_10.tbl", 10, EncodingType::Unencoded);
@@ -390,6 +424,7 @@ int main(int argc, char** argv) {
   run("TableScan.TypeMismatchThrowsLogicError", test_type_mismatch_throws);
   run("Validate.Visibility truth table, reference input, chunk shortcut", test_validate_visibility);
   run("JoinHash vs nested loop (Inner/Semi/AntiNullAsFalse/Left)", test_join_against_nested_loop);
+  run("JoinHash on every pair of numeric key types vs nested loop", test_join_on_mixed_numeric_key_types);
   run("JoinHash with secondary predicates vs nested loop", test_join_with_secondary_predicates);
   run("AggregateHash vs .tbl fixtures (+ CannotSumStringColumns)", test_aggregates_against_fixtures);
   hy_shutdown();

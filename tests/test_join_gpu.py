@@ -329,3 +329,88 @@ def test_join_secondary_predicates_on_reference_inputs(device):
             got = join_hash(dev["lkey"], dev["rkey"], mode, radix_bits, secondary=[(dev["lval"], abi.PRED_GREATER_THAN_EQUALS, dev["rval"])])
             want = oracle_join(ref_lkey, ref_rkey, mode, radix_bits, secondary=[(ref_lval, abi.PRED_GREATER_THAN_EQUALS, ref_rval)])
             assert_join_equal(got, want, mode, f"reference inputs + secondary predicate, mode {mode} radix {radix_bits}")
+
+
+# ---- float / double keys, also mixed with integers (JoinHashTraits: both sides are cast to one HashedType) -----------------
+NUMERIC_COLUMNS = ("int", "int_null", "long", "long_null", "float", "float_null", "double", "double_null")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_join_all_numeric_type_pairs_of_the_runner_tables(device, mode):
+    """join_test_runner.cpp:183-193: every data type against every other one; pair order and slices as the oracle's
+    (partition = std::hash<HashedType> of the cast key, libstdc++'s, restated in oracle/join.c and csrc/join.hip)."""
+    lt = load_tbl("join_test_runner/input_table_left_15.tbl")
+    rt = load_tbl("join_test_runner/input_table_right_10.tbl")
+    for left_name in NUMERIC_COLUMNS:
+        for right_name in NUMERIC_COLUMNS:
+            if "float" not in left_name + right_name and "double" not in left_name + right_name:
+                continue
+            lvals, lnull = lt.column("l_" + left_name)
+            rvals, rnull = rt.column("r_" + right_name)
+            for chunk, encoding, radix_bits in ((10, abi.ENC_UNENCODED, None), (3, abi.ENC_DICTIONARY, 2), (4, abi.ENC_DICTIONARY, 0)):
+                check(build_column(lvals, lnull, chunk, encoding), build_column(rvals, rnull, chunk, encoding), mode, radix_bits,
+                      f"mode {mode} {left_name} x {right_name} chunk {chunk} radix {radix_bits}")
+
+
+def _float_key_column(rng, data_type, n, chunk):
+    """Keys that collide after the cast to the HashedType (2^24 + 1 is not a float, 2^53 + 1 not a double), +-0.0 (one key),
+    NaN (no key), infinities; NULLs; a dictionary cannot hold NaN (not ordered), so those columns stay unencoded."""
+    np_type = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}[data_type]
+    if data_type == abi.TYPE_INT:
+        domain = np.array([0, 1, -1, 16777216, 16777217, 16777218, 3, 1338, 2147483647, -2147483648], dtype=np_type)
+    elif data_type == abi.TYPE_LONG:
+        domain = np.array([0, 1, -1, 16777216, 16777217, 3, 1338, 2**40, 2**40 + 1, 2**53, 2**53 + 1, -2**53 - 1, 2**63 - 1], dtype=np_type)
+    else:
+        domain = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 16777216.0, 16777217.0, 16777218.0, 2.0**40, 2.0**53, 1e30, -1e30, np.inf, -np.inf, np.nan, 3.0, 1338.0,
+                           2147483648.0, -2147483648.0, 9.223372036854775807e18], dtype=np_type)
+    values = domain[rng.integers(0, len(domain), n)]
+    nulls = rng.random(n) < 0.15
+    has_nan = np_type in (np.float32, np.float64) and bool(np.isnan(values).any())
+    encoding = abi.ENC_UNENCODED if has_nan or rng.random() < 0.5 else abi.ENC_DICTIONARY
+    return build_column(values, nulls, chunk, encoding)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_join_float_keys_random(device, mode):
+    rng = np.random.default_rng(23)
+    types = (abi.TYPE_INT, abi.TYPE_LONG, abi.TYPE_FLOAT, abi.TYPE_DOUBLE)
+    for left_type in types:
+        for right_type in types:
+            if left_type in (abi.TYPE_INT, abi.TYPE_LONG) and right_type in (abi.TYPE_INT, abi.TYPE_LONG):
+                continue
+            for n_left, n_right, chunk, radix_bits in ((400, 250, 70, 3), (120, 6000, 1000, None), (9000, 5000, 4096, 0), (5000, 9000, 65535, 5)):
+                check(_float_key_column(rng, left_type, n_left, chunk), _float_key_column(rng, right_type, n_right, chunk), mode, radix_bits,
+                      f"mode {mode} types {left_type} x {right_type} rows {n_left},{n_right} radix {radix_bits}")
+
+
+def test_join_double_keys_many_tiles(device):
+    """300 000 probe rows (74 tiles) of doubles with a few thousand distinct values against 40 000 build rows with about a
+    dozen rows per key (millions of pairs), then an int64 probe column against the same doubles."""
+    rng = np.random.default_rng(29)
+    build_values = np.round(rng.normal(size=40000) * 50, 1)
+    probe_values = np.round(rng.normal(size=300000) * 50, 1)
+    build = build_column(build_values, rng.random(40000) < 0.02, 65535, abi.ENC_DICTIONARY)
+    probe = build_column(probe_values.astype(np.float32).astype(np.float64), None, 65535, abi.ENC_UNENCODED)
+    for mode in (abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_SEMI):
+        got = check(probe, build, mode, None, f"doubles mode {mode}")
+    assert got.n_pairs > 1000
+    longs = build_column(rng.integers(-300, 300, 300000).astype(np.int64), rng.random(300000) < 0.05, 65535, abi.ENC_UNENCODED)
+    got = check(longs, build, abi.JOIN_INNER, None, "long x double")
+    assert got.n_pairs > 100000
+
+
+@pytest.mark.parametrize("mode", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_FALSE])
+def test_join_float_keys_with_secondary_predicates(device, mode):
+    """Float / double keys and secondary predicates share the general probe kernels: both at once."""
+    rng = np.random.default_rng(31)
+    for left_type, right_type in ((abi.TYPE_DOUBLE, abi.TYPE_INT), (abi.TYPE_FLOAT, abi.TYPE_DOUBLE), (abi.TYPE_LONG, abi.TYPE_FLOAT)):
+        n_left, n_right, chunk = 3000, 5000, 700
+        left, right = _float_key_column(rng, left_type, n_left, chunk), _float_key_column(rng, right_type, n_right, chunk)
+        left_extra = build_column(rng.integers(0, 10, n_left).astype(np.int32), rng.random(n_left) < 0.1, chunk, abi.ENC_DICTIONARY)
+        right_extra = build_column(rng.integers(0, 10, n_right).astype(np.float32), None, chunk, abi.ENC_UNENCODED)
+        ldev, rdev = DeviceColumn(left), DeviceColumn(right)
+        lx, rx = DeviceColumn(left_extra), DeviceColumn(right_extra)
+        for condition in (abi.PRED_LESS_THAN, abi.PRED_NOT_EQUALS):
+            got = join_hash(ldev, rdev, mode, 3, secondary=[(lx, condition, rx)])
+            want = oracle_join(left, right, mode, 3, secondary=[(left_extra, condition, right_extra)])
+            assert_join_equal(got, want, mode, f"mode {mode} types {left_type} x {right_type} condition {condition}")
