@@ -117,6 +117,26 @@ def test_join_reference_inputs(device):
             assert_join_equal(got, want, mode, f"reference inputs mode {mode} radix {radix_bits}")
 
 
+def test_join_reference_inputs_with_float_keys(device):
+    """The same shape of reference tables, a float column against an int64 one (HashedType float)."""
+    rng = np.random.default_rng(9)
+    base_l = build_column((rng.integers(0, 300, 6000) / 2).astype(np.float32), rng.random(6000) < 0.1, 1000, abi.ENC_DICTIONARY)
+    base_r = build_column(rng.integers(0, 150, 9000).astype(np.int64), None, 1500, abi.ENC_UNENCODED)
+    pos_l = [np.stack([np.full(400, c, dtype=np.uint32), np.sort(rng.choice(1000, 400, replace=False)).astype(np.uint32)], axis=1)
+             for c in range(base_l.n_chunks)]
+    mixed = np.stack([rng.integers(0, base_r.n_chunks, 2500).astype(np.uint32), rng.integers(0, 1500, 2500).astype(np.uint32)], axis=1)
+    mixed[::97] = 0xFFFFFFFF   # NULL_ROW_IDs from an outer join
+    ref_l = storage.make_reference_column(base_l, pos_l, list(range(base_l.n_chunks)))
+    ref_r = storage.make_reference_column(base_r, [mixed, 2], [None, 2])
+    bl, br = DeviceColumn(base_l), DeviceColumn(base_r)
+    dl, dr = DeviceColumn(ref_l, refs={id(base_l): bl}), DeviceColumn(ref_r, refs={id(base_r): br})
+    for mode in MODES:
+        got = join_hash(dl, dr, mode, 2)
+        want = oracle_join(ref_l, ref_r, mode, 2)
+        assert_join_equal(got, want, mode, f"float reference inputs mode {mode}")
+    assert join_hash(dl, dr, abi.JOIN_INNER, 2).n_pairs > 1000
+
+
 def test_join_tpch_orders_lineitem(device):
     """lineitem x orders on the order key at SF 0.1 shape: unique sparse build keys (unencoded), FoR-encoded probe keys,
     every probe row has exactly one partner (config 3 of BASELINE.json, scaled down)."""
