@@ -20,6 +20,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <optional>
 #include <sstream>
@@ -494,8 +495,11 @@ struct DeviceColumn {
   ~DeviceColumn() { if (handle) hy_column_destroy(handle); }
 };
 
+// How a DictionarySegment<pmr_string> is presented to the device: the value ids alone (scans), or with a dictionary of int64
+// stand-ins for the strings -- AggregateKey names (GROUP BY) or join ids (JoinHash).
+enum class StringKeys { None, AggregateKeyNames, JoinIds };
 struct ColumnCache {
-  std::map<std::pair<ColumnID, bool>, std::shared_ptr<DeviceColumn>> columns;
+  std::map<std::pair<ColumnID, StringKeys>, std::shared_ptr<DeviceColumn>> columns;
 };
 inline Table::~Table() = default;
 
@@ -517,10 +521,48 @@ inline int64_t string_key_name(const std::string& s, std::map<std::string, int64
   }
 }
 
-// `as_key_names`: present string dictionary columns as dictionaries of int64 AggregateKey names (GROUP BY).
-inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const Table>& table, ColumnID column_id, bool as_key_names = false) {
+// JoinHash on pmr_string keys.  The reference hashes them with std::hash (join_hash_steps.hpp:282,352,573: Bloom index =
+// hash % 2^20, radix partition = hash & mask) and compares them in the hash table; the device joins 64-bit integers whose
+// partition and Bloom index are their low bits.  So every distinct string gets the id  unique number << 20 | hash & 0xFFFFF:
+// equal ids <=> equal strings, id & mask == hash & mask for radix_bits <= 8, id % 2^20 == the Bloom index -- the join over the
+// ids is the reference's join over the strings (same partitions, probe-row order, build-side insertion order).  The hash is
+// libstdc++'s (_Hash_bytes, libsupc++/hash_bytes.cc, seed 0xc70f6907), spelled out so that the ids do not depend on the
+// standard library this file is compiled with (same restatement as hyrise_amd/join_keys.py, pinned in tests/test_oracle_join.py).
+inline uint64_t libstdcxx_hash_bytes(const void* data, size_t length) {
+  const uint64_t mul = (uint64_t{0xc6a4a793} << 32) + uint64_t{0x5bd1e995};
+  const auto shift_mix = [](uint64_t v) { return v ^ (v >> 47); };
+  const auto* bytes = static_cast<const unsigned char*>(data);
+  const size_t aligned = length & ~size_t{7};
+  uint64_t hash = uint64_t{0xc70f6907} ^ (length * mul);
+  for (size_t p = 0; p < aligned; p += 8) {
+    uint64_t word;
+    std::memcpy(&word, bytes + p, 8);
+    hash ^= shift_mix(word * mul) * mul;
+    hash *= mul;
+  }
+  if (length & 7) {
+    uint64_t tail = 0;
+    for (size_t n = length & 7; n-- > 0;) tail = (tail << 8) + bytes[aligned + n];
+    hash ^= tail;
+    hash *= mul;
+  }
+  hash = shift_mix(hash) * mul;
+  return shift_mix(hash);
+}
+
+inline int64_t string_join_id(const std::string& s) {   // one registry for all tables: cached columns stay valid across joins
+  static std::mutex mutex;
+  static std::map<std::string, int64_t> ids;
+  const std::lock_guard<std::mutex> lock(mutex);
+  const auto [it, inserted] = ids.emplace(s, 0);
+  if (inserted) it->second = static_cast<int64_t>(ids.size() << 20 | (libstdcxx_hash_bytes(s.data(), s.size()) & 0xFFFFF));
+  return it->second;
+}
+
+// `string_keys`: what a string dictionary column's dictionary is replaced with (see StringKeys).
+inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const Table>& table, ColumnID column_id, StringKeys string_keys = StringKeys::None) {
   if (!table->device_columns) table->device_columns = std::make_shared<ColumnCache>();
-  auto& slot = table->device_columns->columns[{column_id, as_key_names}];
+  auto& slot = table->device_columns->columns[{column_id, string_keys}];
   if (slot) return slot;
   auto column = std::make_shared<DeviceColumn>();
   const auto chunk_count = table->chunk_count();
@@ -557,8 +599,9 @@ inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const T
     else if (const auto* s = dynamic_cast<const DictionarySegment<std::string>*>(segment.get())) {
       d.encoding = HY_ENC_DICTIONARY; d.width = s->attribute_vector().width; d.data = s->attribute_vector().bytes.data();
       d.aux_size = s->unique_values_count();
-      if (as_key_names) {   // GROUP BY: the dictionary becomes the int64 key names
-        for (const auto& entry : s->dictionary()) column->key_names[chunk_id].push_back(string_key_name(entry, long_strings));
+      if (string_keys != StringKeys::None) {   // GROUP BY / join key: the dictionary becomes int64 key names / join ids
+        for (const auto& entry : s->dictionary())
+          column->key_names[chunk_id].push_back(string_keys == StringKeys::JoinIds ? string_join_id(entry) : string_key_name(entry, long_strings));
         d.aux = column->key_names[chunk_id].data();
         d.data_type = HY_TYPE_LONG;
       } else {
@@ -571,9 +614,9 @@ inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const T
       d.nulls = s->has_nulls() ? s->null_words().data() : nullptr;
       ok = true;
     } else if (const auto* s = dynamic_cast<const ReferenceSegment*>(segment.get())) {
-      if (!referenced) referenced = device_column(s->referenced_table(), s->referenced_column_id(), as_key_names);
+      if (!referenced) referenced = device_column(s->referenced_table(), s->referenced_column_id(), string_keys);
       d.encoding = HY_ENC_REFERENCE; d.width = 8; d.ref = referenced->handle;
-      if (as_key_names && s->data_type() == DataType::String) d.data_type = HY_TYPE_LONG;
+      if (string_keys != StringKeys::None && s->data_type() == DataType::String) d.data_type = HY_TYPE_LONG;
       if (const auto* entire = dynamic_cast<const EntireChunkPosList*>(s->pos_list().get())) {
         d.data = nullptr; d.ref_chunk_id = entire->common_chunk_id();
       } else {
@@ -985,7 +1028,11 @@ class JoinHash : public AbstractReadOnlyOperator {   // operators/join_hash.hpp:
  protected:
   std::shared_ptr<const Table> _on_execute() override {
     const auto left = left_input_table(), right = right_input_table();
-    const auto left_column = device_column(left, _column_ids.first), right_column = device_column(right, _column_ids.second);
+    // string keys join as ids (see string_join_id); a string against a number stays with the stock operator
+    const bool string_keys = left->column_data_type(_column_ids.first) == DataType::String;
+    Assert(string_keys == (right->column_data_type(_column_ids.second) == DataType::String), "JoinHash: a string key against a numeric key is not run on the device");
+    const auto keys = string_keys ? StringKeys::JoinIds : StringKeys::None;
+    const auto left_column = device_column(left, _column_ids.first, keys), right_column = device_column(right, _column_ids.second, keys);
     // JoinHash::supports (join_hash.cpp:39-44)
     Assert(_mode != JoinMode::AntiNullAsTrue || _secondary_predicates.empty(), "JoinHash does not support secondary predicates with AntiNullAsTrue");
     std::vector<hy_join_predicate> secondary;
@@ -1075,7 +1122,7 @@ class AggregateHash : public AbstractReadOnlyOperator {   // operators/aggregate
     const auto input = left_input_table();
     std::vector<std::shared_ptr<DeviceColumn>> keep;
     std::vector<const hy_column*> groupby;
-    for (const auto id : _groupby) { keep.push_back(device_column(input, id, input->column_data_type(id) == DataType::String)); groupby.push_back(keep.back()->handle); }
+    for (const auto id : _groupby) { keep.push_back(device_column(input, id, input->column_data_type(id) == DataType::String ? StringKeys::AggregateKeyNames : StringKeys::None)); groupby.push_back(keep.back()->handle); }
     std::vector<hy_aggregate_spec> specs;
     for (const auto& aggregate : _aggregates) {
       hy_aggregate_spec spec{};

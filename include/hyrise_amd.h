@@ -278,7 +278,10 @@ typedef struct hy_join_result {
 
 /* Equi-join of two numeric columns (int32 / int64 / float / double, any two: both sides are cast to JoinHashTraits'
  * HashedType first, join_hash_traits.hpp:15-40 -- the larger integer type, the larger floating type, or THE floating
- * type of an integer x floating join -- and compared there; NaN keys find nothing).  String keys: HY_ERR_UNSUPPORTED.
+ * type of an integer x floating join -- and compared there; NaN keys find nothing).  String columns: HY_ERR_UNSUPPORTED
+ * here -- the adapter joins them as DictionarySegment<int64> views whose dictionaries hold one id per distinct string,
+ * unique << 20 | std::hash(string) & 0xFFFFF, which this join partitions and filters exactly like the strings
+ * (INTEGRATION.md section 3).
  * Pair order == the CPU operator's concatenated probe() output (join_hash_steps.hpp:624-792): by radix partition
  * (std::hash<HashedType> of the key -- the identity for integers, libstdc++'s for float / double), then probe row, then
  * build-side insertion order.

@@ -77,6 +77,7 @@ uint32_t hyo_calculate_radix_bits(uint64_t build_rows, uint64_t probe_rows);
 /* std::hash<HashedType>{}(key) as libstdc++ computes it; key: an integer, or the bit pattern of a float (zero-extended) /
  * double with -0.0 given as +0.0.  hashed_type: HY_TYPE_*. */
 uint64_t hyo_std_hash(int64_t key, uint32_t hashed_type);
+uint64_t hyo_std_hash_bytes(const void* data, uint64_t length);   /* std::hash<std::string / pmr_string> over the bytes */
 uint64_t hyo_join_materialize(const hyo_column* column, int keep_nulls, uint32_t radix_bits, const uint64_t* bloom_in,
                               uint64_t* bloom_out, hy_row_id* row_ids_out, int64_t* values_out, uint8_t* nulls_out,
                               uint64_t* chunk_element_counts_out, uint64_t* histograms_out);

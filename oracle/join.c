@@ -230,6 +230,8 @@ static uint64_t libstdcxx_hash_bytes(const void* ptr, uint64_t len) {
   return shift_mix(hash);
 }
 
+uint64_t hyo_std_hash_bytes(const void* data, uint64_t length) { return libstdcxx_hash_bytes(data, length); }   /* std::hash<std::string> */
+
 /* std::hash<HashedType>{}(key) for a key in this file's representation (functional_hash.h: 0 for 0.0 and -0.0) */
 uint64_t hyo_std_hash(int64_t key, uint32_t hashed_type) {
   if (hashed_type == HY_TYPE_FLOAT) {

@@ -282,6 +282,42 @@ static void test_join_on_mixed_numeric_key_types() {   // join_test_runner.cpp:1
   }
 }
 
+static void test_join_on_string_keys() {   // join_test_runner.cpp:183-193 (string x string); ids from string_join_id
+  for (const auto chunk : {ChunkOffset{4}, ChunkOffset{10}}) {
+    const auto left = load_and_encode("join_test_runner/input_table_left_15.tbl", chunk, EncodingType::Dictionary);
+    const auto right = load_and_encode("join_test_runner/input_table_right_10.tbl", 3, EncodingType::Dictionary);
+    const auto lrows = left->get_output()->get_rows(), rrows = right->get_output()->get_rows();
+    for (const ColumnID column : {ColumnID{8}, ColumnID{9}}) {   // string, string_null
+      size_t inner = 0, semi = 0;
+      for (const auto& l : lrows) {
+        bool any = false;
+        for (const auto& r : rrows) {
+          if (!variant_is_null(l[column]) && !variant_is_null(r[column]) && std::get<std::string>(l[column]) == std::get<std::string>(r[column])) { ++inner; any = true; }
+        }
+        semi += any;
+      }
+      auto join = std::make_shared<JoinHash>(left, right, JoinMode::Inner, ColumnIDPair{column, column}, 3);
+      join->execute();
+      EXPECT_TRUE(inner > 0 && join->get_output()->row_count() == inner);
+      for (const auto& row : join->get_output()->get_rows()) EXPECT_TRUE(cells_equal(row[column], row[lrows[0].size() + column]));
+      auto semi_join = std::make_shared<JoinHash>(left, right, JoinMode::Semi, ColumnIDPair{column, column});
+      semi_join->execute();
+      EXPECT_TRUE(semi_join->get_output()->row_count() == semi);
+      auto right_join = std::make_shared<JoinHash>(left, right, JoinMode::Right, ColumnIDPair{column, column});
+      right_join->execute();
+      size_t unmatched_right = 0;
+      for (const auto& r : rrows) {
+        bool any = false;
+        for (const auto& l : lrows) any = any || (!variant_is_null(l[column]) && !variant_is_null(r[column]) && std::get<std::string>(l[column]) == std::get<std::string>(r[column]));
+        unmatched_right += !any;
+      }
+      EXPECT_TRUE(right_join->get_output()->row_count() == inner + unmatched_right);
+    }
+  }
+  // libstdc++'s std::hash<std::string>, spelled out -- and this binary is built with libstdc++
+  for (const std::string s : {"", "a", "abcdefgh", "Dampfschifffahrtsgesellschaft"}) EXPECT_TRUE(libstdcxx_hash_bytes(s.data(), s.size()) == std::hash<std::string>{}(s));
+}
+
 static void test_join_with_secondary_predicates() {   // join_test_runner.cpp:207-211, 464-480: {0,0} <, >=, != as secondary predicates
   const auto left = load_and_encode("join_test_runner/input_table_left_15.tbl", 3, EncodingType::Dictionary);
   const auto right = load_and_encode("join_test_runner/input_table_right_10.tbl", 10, EncodingType::Unencoded);
@@ -425,6 +461,7 @@ int main(int argc, char** argv) {
   run("Validate.Visibility truth table, reference input, chunk shortcut", test_validate_visibility);
   run("JoinHash vs nested loop (Inner/Semi/AntiNullAsFalse/Left)", test_join_against_nested_loop);
   run("JoinHash on every pair of numeric key types vs nested loop", test_join_on_mixed_numeric_key_types);
+  run("JoinHash on string keys (join ids) vs nested loop", test_join_on_string_keys);
   run("JoinHash with secondary predicates vs nested loop", test_join_with_secondary_predicates);
   run("AggregateHash vs .tbl fixtures (+ CannotSumStringColumns)", test_aggregates_against_fixtures);
   hy_shutdown();

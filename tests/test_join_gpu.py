@@ -434,3 +434,29 @@ def test_join_float_keys_with_secondary_predicates(device, mode):
             got = join_hash(ldev, rdev, mode, 3, secondary=[(lx, condition, rx)])
             want = oracle_join(left, right, mode, 3, secondary=[(left_extra, condition, right_extra)])
             assert_join_equal(got, want, mode, f"mode {mode} types {left_type} x {right_type} condition {condition}")
+
+
+@pytest.mark.parametrize("mode", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE])
+def test_join_string_keys_as_join_ids(device, mode):
+    """String keys join as the adapter's ids (hyrise_amd/join_keys.py: unique << 20 | std::hash & 0xFFFFF): runner tables,
+    and 20 000 x 50 000 random words; the pairs are checked against the strings themselves."""
+    from test_oracle_join import string_key_columns
+    lt = load_tbl("join_test_runner/input_table_left_15.tbl")
+    rt = load_tbl("join_test_runner/input_table_right_10.tbl")
+    for name in ("string", "string_null"):
+        lvals, lnull = lt.column("l_" + name)
+        rvals, rnull = rt.column("r_" + name)
+        for chunk, radix_bits in ((10, None), (3, 2), (1, 8)):
+            left, right, _, _ = string_key_columns(lvals, lnull, rvals, rnull, chunk)
+            check(left, right, mode, radix_bits, f"strings {name} mode {mode} chunk {chunk} radix {radix_bits}")
+    rng = np.random.default_rng(37)
+    words = np.array(["w%d" % i + "x" * int(i % 9) for i in range(3000)], dtype=object)
+    lvals, rvals = words[rng.integers(0, 3000, 20000)], words[rng.integers(0, 2500, 50000)]
+    lnull, rnull = rng.random(20000) < 0.05, rng.random(50000) < 0.05
+    left, right, _, _ = string_key_columns(lvals, lnull, rvals, rnull, 4096)
+    got = check(left, right, mode, None, f"random words mode {mode}")
+    if mode == abi.JOIN_INNER:
+        assert got.n_pairs > 100000
+        for k in rng.integers(0, got.n_pairs, 200):
+            l, r = got.left[k], got.right[k]
+            assert lvals[int(l[0]) * 4096 + int(l[1])] == rvals[int(r[0]) * 4096 + int(r[1])]

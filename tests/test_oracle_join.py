@@ -293,3 +293,66 @@ def test_float_key_joins_against_verification(mode):
                 right = float_key_column(rng, right_type, n_right, chunk)
                 got = oracle_join(left, right, mode, radix_bits)
                 assert join_result_multiset(got, mode) == verification_join(left, right, mode), f"{left_type} x {right_type} rows {n_left},{n_right} radix {radix_bits}"
+
+
+# ---- string keys: ids made by the adapter (hyrise_amd/join_keys.py), joined as int64 -------------------------------------------
+def string_key_columns(lvals, lnull, rvals, rnull, chunk):
+    """-> (left, right) int64 HostColumns over the strings' join ids, and the same columns over independent codes."""
+    from hyrise_amd.join_keys import StringJoinKeys
+    keys = StringJoinKeys()
+    codes = {}
+    out = []
+    for values, nulls in ((lvals, lnull), (rvals, rnull)):
+        raw = [v.encode() for v in values]
+        segments, dictionaries = [], []
+        for begin in range(0, len(raw), chunk):
+            segment, dictionary = storage.encode_string_dictionary(raw[begin:begin + chunk], None if nulls is None else nulls[begin:begin + chunk])
+            segments.append(segment)
+            dictionaries.append(dictionary)
+        independent = np.array([codes.setdefault(v, len(codes)) for v in raw], dtype=np.int64)
+        out.append((keys.column(segments, dictionaries), build_column(independent, nulls, chunk, abi.ENC_UNENCODED)))
+    return out[0][0], out[1][0], out[0][1], out[1][1]
+
+
+def test_std_hash_of_strings_against_the_installed_libstdcxx(tmp_path):
+    import subprocess
+    from hyrise_amd.join_keys import std_hash_bytes
+    source = tmp_path / "string_hash.cpp"
+    source.write_text('''#include <cstdio>
+#include <functional>
+#include <iostream>
+#include <string>
+int main() { std::string line; while (std::getline(std::cin, line)) std::printf("%llx\\n", static_cast<unsigned long long>(std::hash<std::string>{}(line))); }
+''')
+    binary = tmp_path / "string_hash"
+    subprocess.check_call(["g++", "-O1", "-o", str(binary), str(source)])
+    rng = np.random.default_rng(4)
+    cases = [b"", b"a", b"m", b"abcdefg", b"abcdefgh", b"abcdefghi", b"Dampfschifffahrtsgesellschaft", "kapit\u00e4n".encode()]
+    cases += [bytes(rng.integers(32, 127, int(n)).astype(np.uint8)) for n in rng.integers(0, 70, 200)]
+    want = [int(x, 16) for x in subprocess.run([str(binary)], input=b"".join(c + b"\n" for c in cases), stdout=subprocess.PIPE, check=True).stdout.split()]
+    lib = oracle()
+    lib.hyo_std_hash_bytes.restype = C.c_uint64
+    lib.hyo_std_hash_bytes.argtypes = [C.c_char_p, C.c_uint64]
+    assert len(want) == len(cases)
+    for c, w in zip(cases, want):
+        assert std_hash_bytes(c) == w and lib.hyo_std_hash_bytes(c, len(c)) == w, c
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_string_key_joins_on_runner_tables(mode):
+    """The join over the adapter's string ids is the join over the strings: same pairs as the nested loop over independent
+    codes, and in radix-partition order of std::hash(string) (the low bits of an id ARE the hash's)."""
+    from hyrise_amd.join_keys import std_hash_bytes
+    lt, rt = runner_tables(15, 0)[0], runner_tables(10, 0)[1]
+    for name in ("string", "string_null"):
+        lvals, lnull = lt.column("l_" + name)
+        rvals, rnull = rt.column("r_" + name)
+        for chunk, radix_bits in ((10, None), (3, 2), (4, 0), (1, 8)):
+            left, right, left_codes, right_codes = string_key_columns(lvals, lnull, rvals, rnull, chunk)
+            got = oracle_join(left, right, mode, radix_bits)
+            assert join_result_multiset(got, mode) == verification_join(left_codes, right_codes, mode), f"{name} chunk {chunk} radix {radix_bits}"
+            bits = got.c.radix_bits
+            if bits and mode == abi.JOIN_INNER:
+                side, values = (got.right, rvals) if got.c.left_is_build else (got.left, lvals)   # the probe side's strings, in output order
+                partitions = [std_hash_bytes(values[int(c) * chunk + int(o)].encode()) & ((1 << bits) - 1) for c, o in side[:got.n_pairs]]
+                assert partitions == sorted(partitions) and got.n_pairs > 0
