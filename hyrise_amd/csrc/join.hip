@@ -26,6 +26,7 @@
 #include "hy_decode.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstring>
@@ -1948,13 +1949,13 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.probe_out = dev_probe;
   a.slice_offsets = dev_slice_offsets;
   if (n_tiles) {   // (every pass 2 kernel returns at once if the plan says that the result does not fit)
-    static bool lds_raised = false;
-    static uint32_t workgroups_per_cu = 1;
-    if (!lds_raised) {
+    static std::atomic<bool> lds_raised{false};   // (joins run from any thread; setting the attributes twice is harmless)
+    uint32_t workgroups_per_cu = 1;
+    if (!lds_raised.load(std::memory_order_acquire)) {
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_cached), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_cached_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
-      lds_raised = true;
+      lds_raised.store(true, std::memory_order_release);
     }
     {
       int per_cu = 0;
