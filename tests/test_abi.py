@@ -48,3 +48,24 @@ def test_calls_without_a_device_fail_loudly():
     status = lib.hy_init(0)
     assert status == abi.ERR_DEVICE
     assert lib.hy_last_error()
+
+
+def test_header_is_valid_c_and_cxx_and_ctypes_layouts_match(tmp_path):
+    """The boundary is a C ABI: include/hyrise_amd.h must compile as C11 and as C++17 on its own, and the ctypes mirror of
+    every struct (hyrise_amd/abi.py) must have the size the C compiler gives it."""
+    import ctypes as C
+    import subprocess
+    header = os.path.join(ROOT, "include", "hyrise_amd.h")
+    for compiler, flags in (("gcc", ["-std=c11", "-x", "c"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        subprocess.check_call([compiler] + flags + ["-Wall", "-Wextra", "-Werror", "-fsyntax-only", header])
+    structs = {"hy_row_id": abi.RowID, "hy_segment": abi.Segment, "hy_value": abi.Value, "hy_predicate": abi.Predicate,
+               "hy_scan_result": abi.ScanResult, "hy_join_predicate": abi.JoinPredicate, "hy_join_result": abi.JoinResult, "hy_operand": abi.Operand,
+               "hy_aggregate_spec": abi.AggregateSpec, "hy_aggregate_column": abi.AggregateColumn, "hy_aggregate_result": abi.AggregateResult}
+    source = tmp_path / "sizes.c"
+    source.write_text('#include <stdio.h>\n#include "hyrise_amd.h"\nint main(void) {\n' +
+                      "".join(f'  printf("{name} %zu\\n", sizeof({name}));\n' for name in structs) + "  return 0;\n}\n")
+    binary = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(binary), str(source)])
+    sizes = dict(line.split() for line in subprocess.run([str(binary)], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines())
+    for name, mirror in structs.items():
+        assert int(sizes[name]) == C.sizeof(mirror), f"{name}: C says {sizes[name]}, ctypes {C.sizeof(mirror)}"
