@@ -62,10 +62,14 @@ def test_header_is_valid_c_and_cxx_and_ctypes_layouts_match(tmp_path):
                "hy_scan_result": abi.ScanResult, "hy_join_predicate": abi.JoinPredicate, "hy_join_result": abi.JoinResult, "hy_operand": abi.Operand,
                "hy_aggregate_spec": abi.AggregateSpec, "hy_aggregate_column": abi.AggregateColumn, "hy_aggregate_result": abi.AggregateResult}
     source = tmp_path / "sizes.c"
-    source.write_text('#include <stdio.h>\n#include "hyrise_amd.h"\nint main(void) {\n' +
-                      "".join(f'  printf("{name} %zu\\n", sizeof({name}));\n' for name in structs) + "  return 0;\n}\n")
+    lines = [f'  printf("{name} %zu\\n", sizeof({name}));\n' for name in structs]
+    for name, mirror in structs.items():   # ... and every field sits where the C compiler puts it (same field names on both sides)
+        lines += [f'  printf("{name}.{field[0]} %zu\\n", offsetof({name}, {field[0]}));\n' for field in mirror._fields_]
+    source.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "hyrise_amd.h"\nint main(void) {\n' + "".join(lines) + "  return 0;\n}\n")
     binary = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(binary), str(source)])
     sizes = dict(line.split() for line in subprocess.run([str(binary)], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines())
     for name, mirror in structs.items():
         assert int(sizes[name]) == C.sizeof(mirror), f"{name}: C says {sizes[name]}, ctypes {C.sizeof(mirror)}"
+        for field in mirror._fields_:
+            assert int(sizes[f"{name}.{field[0]}"]) == getattr(mirror, field[0]).offset, f"{name}.{field[0]}"
