@@ -13,7 +13,8 @@ N x SF10 table (chunks shard naturally, no data-path collective: SURVEY.md secti
 
 Prints ONE JSON line on rank 0: rows/s over the whole job, plus `roofline` (scan_slices kernel: algorithmic bytes /
 HIP-event duration vs. the 8 TB/s HBM peak) and `cpu_baseline` (the CPU restatement of the Hyrise operator on the
-host cores, rank 0, N=1 only).
+host cores, rank 0, N=1 only).  At N=1 the line also carries `join` and `aggregate` objects: the SF10 orders x lineitem
+JoinHash and the TPC-H Q1-core AggregateHash on the same GPU (configs 3 and 4 of BASELINE.json), outside the timed region.
 """
 import argparse
 import ctypes as C
@@ -276,11 +277,11 @@ def main():
                                  "kernel_GBps": bytes_case / (km.value / max(1, ln.value) * 1e-3) / 1e9}
 
     join_info = None
-    if rank == 0 and not args.no_join and not args.rows:
+    if rank == 0 and world == 1 and not args.no_join and not args.rows:   # (single-GPU legs: the N > 1 runs time the sharded scan only)
         join_info = join_leg(lib, torch, dev, args.steps)
 
     aggregate_info = None
-    if rank == 0 and not args.no_aggregate and not args.rows:
+    if rank == 0 and world == 1 and not args.no_aggregate and not args.rows:
         aggregate_info = aggregate_leg(lib, torch, args.steps)
 
     if rank == 0:
