@@ -169,7 +169,6 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import numpy as np
     import torch
     from hyrise_amd import abi, tpch
     from hyrise_amd.operators import make_predicate

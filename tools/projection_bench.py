@@ -7,7 +7,6 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 from hyrise_amd import abi, storage, tpch
 from hyrise_amd.operators import projection_arithmetic

@@ -4,7 +4,6 @@ unencoded int32 value segment and as FrameOfReference, predicate selectivity ~43
 import ctypes as C
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
