@@ -40,6 +40,18 @@ struct Slice {
   uint32_t first_of_chunk;     // 1 if row_begin == 0
 };
 
+// What a kernel that runs AHEAD of its data needs to know about a slice, in one 32-byte record (one scalar load instead of
+// the slice -> segment descriptor -> data chain): where the rows' stored words are and how to read them.
+struct SliceView {
+  const void* data;            // the chunk's values / offsets (VIEW_GENERIC: unused, the kernel goes through DevSegment)
+  const void* aux;             // FrameOfReference: block minima
+  uint32_t chunk;
+  uint32_t row_begin;
+  uint32_t row_count;
+  uint32_t kind;               // VIEW_*
+};
+enum : uint32_t { VIEW_GENERIC = 0, VIEW_INT32 = 1, VIEW_FOR8 = 2, VIEW_FOR16 = 3, VIEW_FOR32 = 4 };   // int32 values | FoR offsets of 1 / 2 / 4 bytes, no NULLs
+
 // A part: at most PART_SLICES consecutive slices of ONE chunk -- the unit a scan workgroup owns.  A Hyrise chunk
 // (<= 65 535 rows) is exactly one part, so its PosList is produced by one workgroup without any inter-workgroup traffic.
 struct Part {
@@ -76,6 +88,7 @@ struct hy_column {
   std::vector<uint64_t> row_base;           // [n_chunks + 1] prefix sum of sizes
   hy::DevSegment* d_segments = nullptr;
   hy::Slice* d_slices = nullptr;
+  hy::SliceView* d_slice_views = nullptr;   // [n_slices]
   uint32_t n_slices = 0;
   hy::Part* d_parts = nullptr;
   uint32_t n_parts = 0;

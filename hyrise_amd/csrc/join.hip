@@ -149,6 +149,10 @@ template <bool ID32> __device__ __forceinline__ typename BuildRow<ID32>::type ma
   else return hy_row_id{chunk, offset};
 }
 
+// the 64-bit (sign-extended) key of a stored build key
+__device__ __forceinline__ uint64_t key_bits_of(uint32_t key) { return static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(key))); }
+__device__ __forceinline__ uint64_t key_bits_of(uint64_t key) { return key; }
+
 // ---- build side: materialise -------------------------------------------------------------------------------------------
 // One workgroup per 8192-row slice; rows are visited as row = k * 256 + tid (k = 0..31) so that compaction order is
 // row order.  MODE 0 counts, MODE 1 writes.
@@ -249,6 +253,251 @@ __global__ __launch_bounds__(256) void join_materialize_dense(MaterializeArgs a)
   }
 }
 
+// ---- dense build columns read in place ------------------------------------------------------------------------------------
+// A dense build column (above) that turns out to be sorted and duplicate-free -- a primary key -- needs neither a key array
+// nor a RowID array: the rank table is filled from the column itself and a key's rank is its row number.  Two passes over
+// the column: the statistics that decide (order, equal neighbours, smallest / largest key: the flags of check_sorted), then
+// the table.  Rows are visited as row = k * 256 + tid: consecutive lanes hold consecutive rows.
+__device__ __forceinline__ int64_t dense_key(const DevSegment& s, uint32_t row) {
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) return static_cast<int32_t>(jload_compressed(s.data, s.width, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]));
+  if (s.data_type == HY_TYPE_INT) return static_cast<const int32_t*>(s.data)[row];
+  return static_cast<const int64_t*>(s.data)[row];
+}
+
+// The key that follows the slice's last row (the first row of the next slice that has rows), or `fallback`.
+__device__ __forceinline__ int64_t key_after_slice(const MaterializeArgs& a, uint32_t slice_index, int64_t fallback, bool* exists) {
+  *exists = false;
+  for (uint32_t next = slice_index + 1; next < a.n_slices; ++next) {
+    const Slice after = a.slices[next];
+    if (after.row_count == 0) continue;
+    *exists = true;
+    return dense_key(a.segments[after.chunk], after.row_begin);
+  }
+  return fallback;
+}
+
+__global__ __launch_bounds__(256) void dense_key_stats(MaterializeArgs a, uint64_t* partials) {   // partials: [n_slices][4] OR | min ^ sign | max ^ sign | flags
+  __shared__ uint64_t s_bits[4], s_min[4], s_max[4];
+  __shared__ uint32_t s_flags[3];
+  const uint32_t tid = threadIdx.x;
+  const Slice slice = a.slices[blockIdx.x];
+  if (slice.row_count == 0) {
+    if (tid == 0) { uint64_t* record = partials + 4 * size_t{blockIdx.x}; record[0] = 0; record[1] = ~0ull; record[2] = 0; record[3] = 0; }
+    return;
+  }
+  if (tid < 3) s_flags[tid] = 0;
+  __syncthreads();
+  const DevSegment s = a.segments[slice.chunk];
+  constexpr uint64_t SIGN = 1ull << 63;
+  uint64_t bits = 0, lowest = ~0ull, highest = 0;
+  bool unsorted = false, equal = false, unsorted_signed = false;
+  if (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !(s.flags & SEG_UNALIGNED)) {
+    // int32 values: four consecutive rows per lane and load (16 bytes), all eight loads of the slice in flight, plus the one
+    // value behind each group; everything in 32-bit arithmetic (signed order; the unsigned order of the sign-extended keys
+    // is the unsigned order of the 32-bit patterns)
+    const int32_t* values = static_cast<const int32_t*>(s.data) + slice.row_begin;
+    constexpr uint32_t GROUPS = SLICE_ROWS / 1024;
+    u32x4_t group[GROUPS];
+    int32_t after[GROUPS];
+#pragma unroll
+    for (uint32_t i = 0; i < GROUPS; ++i) {
+      const uint32_t first = i * 1024 + tid * 4;
+      group[i] = *reinterpret_cast<const u32x4_t*>(values + (first < slice.row_count ? first : 0));
+      after[i] = values[first + 4 < slice.row_count ? first + 4 : 0];
+    }
+    int32_t low32 = 0x7FFFFFFF, high32 = static_cast<int32_t>(0x80000000u);
+    uint32_t or32 = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < GROUPS; ++i) {
+      const uint32_t first = i * 1024 + tid * 4;
+      const int32_t k[5] = {static_cast<int32_t>(group[i].x), static_cast<int32_t>(group[i].y), static_cast<int32_t>(group[i].z), static_cast<int32_t>(group[i].w), after[i]};
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e) {
+        if (first + e >= slice.row_count) continue;
+        or32 |= static_cast<uint32_t>(k[e]);
+        low32 = k[e] < low32 ? k[e] : low32;
+        high32 = k[e] > high32 ? k[e] : high32;
+        bool has_next = first + e + 1 < slice.row_count;
+        int32_t next = k[e + 1];
+        if (!has_next) next = static_cast<int32_t>(key_after_slice(a, blockIdx.x, 0, &has_next));   // (one thread per slice)
+        if (has_next) {
+          if (static_cast<uint32_t>(k[e]) > static_cast<uint32_t>(next)) unsorted = true;
+          if (k[e] == next) equal = true;
+          if (k[e] > next) unsorted_signed = true;
+        }
+      }
+    }
+    if (low32 <= high32) {
+      bits = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(or32)));   // (sign-extended like the keys: only its low half is looked at for 32-bit keys)
+      lowest = static_cast<uint64_t>(static_cast<int64_t>(low32)) ^ SIGN;
+      highest = static_cast<uint64_t>(static_cast<int64_t>(high32)) ^ SIGN;
+    }
+  } else {
+    constexpr uint32_t BATCH = 8;
+#pragma unroll 1
+    for (uint32_t block = 0; block < SLICE_ROWS / 256 / BATCH; ++block) {
+      if (block * BATCH * 256 >= slice.row_count) break;
+      int64_t key[BATCH], next[BATCH];
+#pragma unroll
+      for (uint32_t i = 0; i < BATCH; ++i) {
+        const uint32_t r = (block * BATCH + i) * 256 + tid;
+        const uint32_t row = slice.row_begin + (r < slice.row_count ? r : 0);
+        const uint32_t row_after = slice.row_begin + (r + 1 < slice.row_count ? r + 1 : 0);
+        key[i] = dense_key(s, row);
+        next[i] = dense_key(s, row_after);
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < BATCH; ++i) {
+        const uint32_t r = (block * BATCH + i) * 256 + tid;
+        if (r >= slice.row_count) continue;
+        const uint64_t wide = static_cast<uint64_t>(key[i]);
+        bits |= wide;
+        lowest = (wide ^ SIGN) < lowest ? (wide ^ SIGN) : lowest;
+        highest = (wide ^ SIGN) > highest ? (wide ^ SIGN) : highest;
+        bool has_next = r + 1 < slice.row_count;
+        int64_t after = next[i];
+        if (!has_next) after = key_after_slice(a, blockIdx.x, 0, &has_next);   // (one thread per slice)
+        if (has_next) {
+          if (wide > static_cast<uint64_t>(after)) unsorted = true;
+          if (key[i] == after) equal = true;
+          if (key[i] > after) unsorted_signed = true;
+        }
+      }
+    }
+  }
+  if (unsorted) s_flags[0] = 1;
+  if (equal) s_flags[1] = 1;
+  if (unsorted_signed) s_flags[2] = 1;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    bits |= __shfl_xor(bits, d, 64);
+    const uint64_t other_low = __shfl_xor(lowest, d, 64), other_high = __shfl_xor(highest, d, 64);
+    lowest = other_low < lowest ? other_low : lowest;
+    highest = other_high > highest ? other_high : highest;
+  }
+  if ((tid & 63) == 0) { s_bits[tid >> 6] = bits; s_min[tid >> 6] = lowest; s_max[tid >> 6] = highest; }
+  __syncthreads();
+  if (tid == 0) {   // one record per slice (thousands of atomics on three words would take longer than the column: ~88 per microsecond)
+    uint64_t all = 0, low = ~0ull, high = 0;
+    for (uint32_t w = 0; w < 4; ++w) { all |= s_bits[w]; low = s_min[w] < low ? s_min[w] : low; high = s_max[w] > high ? s_max[w] : high; }
+    uint64_t* record = partials + 4 * size_t{blockIdx.x};
+    record[0] = all;
+    record[1] = low;
+    record[2] = high;
+    record[3] = (s_flags[0] ? 1u : 0u) | (s_flags[1] ? 2u : 0u) | (s_flags[2] ? 4u : 0u);
+  }
+}
+
+// The rank table of a sorted, duplicate-free dense column, from the column.  A slice's keys are consecutive keys of the
+// column, so they fill a contiguous run of table words: the workgroup assembles the run in LDS (ds_or per key; the first
+// key of a word also notes its row number -- the entry's base) and stores it with coalesced 8-byte writes.  Only the
+// run's first and last word can hold keys of a neighbouring slice: those two go to the (zeroed) table with an atomic OR.
+// A slice whose keys span more words than the LDS holds (a sparse stretch) sets its bits with one global atomic per key.
+constexpr uint32_t FILL_WORDS = 4096;
+typedef uint32_t u32x2_entry_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void rank_table_fill_dense(MaterializeArgs a, uint64_t key_min, u32x2_entry_t* entries) {
+  __shared__ uint32_t s_bits[FILL_WORDS], s_base[FILL_WORDS];
+  const uint32_t tid = threadIdx.x;
+  const Slice slice = a.slices[blockIdx.x];
+  if (slice.row_count == 0) return;
+  const DevSegment s = a.segments[slice.chunk];
+  const uint64_t first_row = a.row_base[slice.chunk] + slice.row_begin;   // rank of the slice's first key
+  const uint64_t first_word = (static_cast<uint64_t>(dense_key(s, slice.row_begin)) - key_min) >> 5;
+  const uint64_t last_word = (static_cast<uint64_t>(dense_key(s, slice.row_begin + slice.row_count - 1)) - key_min) >> 5;
+  const uint64_t span = last_word - first_word + 1;
+  const bool staged = span <= FILL_WORDS;
+  // the key in front of the slice (the last row of the nearest earlier slice with rows): its word
+  uint64_t word_before = ~0ull;
+  if (tid == 0) {
+    for (uint32_t before = blockIdx.x; before-- > 0;) {
+      const Slice earlier = a.slices[before];
+      if (earlier.row_count == 0) continue;
+      word_before = (static_cast<uint64_t>(dense_key(a.segments[earlier.chunk], earlier.row_begin + earlier.row_count - 1)) - key_min) >> 5;
+      break;
+    }
+  }
+  if (staged) {
+    for (uint32_t i = tid; i < span; i += 256) { s_bits[i] = 0; s_base[i] = 0; }
+    __syncthreads();
+  }
+  auto place = [&](int64_t key, uint64_t previous_word, uint32_t r) {   // row r of the slice
+    const uint64_t rel = static_cast<uint64_t>(key) - key_min;
+    const uint64_t word = rel >> 5;
+    const uint32_t bit = 1u << (rel & 31);
+    const bool leader = previous_word != word;   // no earlier row shares the word: its row number is the entry's base
+    if (staged) {
+      atomicOr(&s_bits[word - first_word], bit);
+      if (leader) s_base[word - first_word] = static_cast<uint32_t>(first_row + r) + 1u;   // (+ 1: 0 = the word's first key is not in this slice)
+    } else {
+      atomicOr(reinterpret_cast<uint32_t*>(entries + word), bit);
+      if (leader) reinterpret_cast<uint32_t*>(entries + word)[1] = static_cast<uint32_t>(first_row + r);
+    }
+    if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(key) & (BLOOM_BITS - 1)] = 1;
+  };
+  if (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !(s.flags & SEG_UNALIGNED)) {
+    // int32 values: four consecutive rows per lane and load, all eight loads in flight, plus the value in front of each group
+    const int32_t* values = static_cast<const int32_t*>(s.data) + slice.row_begin;
+    constexpr uint32_t GROUPS = SLICE_ROWS / 1024;
+    u32x4_t group[GROUPS];
+    int32_t front[GROUPS];
+#pragma unroll
+    for (uint32_t i = 0; i < GROUPS; ++i) {
+      const uint32_t first = i * 1024 + tid * 4;
+      group[i] = *reinterpret_cast<const u32x4_t*>(values + (first < slice.row_count ? first : 0));
+      front[i] = values[first > 0 && first < slice.row_count ? first - 1 : 0];
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < GROUPS; ++i) {
+      const uint32_t first = i * 1024 + tid * 4;
+      const int32_t k[5] = {front[i], static_cast<int32_t>(group[i].x), static_cast<int32_t>(group[i].y), static_cast<int32_t>(group[i].z), static_cast<int32_t>(group[i].w)};
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e) {
+        if (first + e >= slice.row_count) continue;
+        const uint64_t previous = first + e == 0 ? word_before : (static_cast<uint64_t>(static_cast<int64_t>(k[e])) - key_min) >> 5;
+        place(k[e + 1], previous, first + e);
+      }
+    }
+  } else {
+  constexpr uint32_t BATCH = 8;
+#pragma unroll 1
+  for (uint32_t block = 0; block < SLICE_ROWS / 256 / BATCH; ++block) {
+    if (block * BATCH * 256 >= slice.row_count) break;
+    int64_t key[BATCH], before[BATCH];
+#pragma unroll
+    for (uint32_t i = 0; i < BATCH; ++i) {
+      const uint32_t r = (block * BATCH + i) * 256 + tid;
+      const uint32_t row = slice.row_begin + (r < slice.row_count ? r : 0);
+      key[i] = dense_key(s, row);
+      before[i] = dense_key(s, row > slice.row_begin ? row - 1 : row);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < BATCH; ++i) {
+      const uint32_t r = (block * BATCH + i) * 256 + tid;
+      if (r >= slice.row_count) continue;
+      place(key[i], r == 0 ? word_before : (static_cast<uint64_t>(before[i]) - key_min) >> 5, r);
+    }
+  }
+  }
+  if (!staged) return;
+  __syncthreads();
+  for (uint32_t i = tid; i < span; i += 256) {
+    const uint32_t bits = s_bits[i], base = s_base[i];
+    if (i == 0 || i + 1 == span) {   // may be shared with a neighbouring slice: add the bits; the base comes from the slice with the word's first key
+      if (bits) atomicOr(reinterpret_cast<uint32_t*>(entries + first_word + i), bits);
+      if (base) reinterpret_cast<uint32_t*>(entries + first_word + i)[1] = base - 1u;
+    } else {
+      entries[first_word + i] = u32x2_entry_t{bits, base ? base - 1u : 0u};
+    }
+  }
+}
+
+// Two small regions zeroed by one launch (a hipMemsetAsync each is ~5 us of stream time).
+__global__ __launch_bounds__(256) void zero_two(uint32_t* first, size_t first_words, uint32_t* second, size_t second_words) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < first_words + second_words; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    if (i < first_words) first[i] = 0; else second[i - first_words] = 0;
+  }
+}
+
 // Single-workgroup exclusive scan of u32 counts into u64 offsets (n is a few thousand); offsets[n] = total.
 __global__ __launch_bounds__(1024) void scan_counts(const uint32_t* counts, uint64_t* offsets, uint32_t n) {
   __shared__ uint64_t s_partial[1024];
@@ -269,31 +518,57 @@ __global__ __launch_bounds__(1024) void scan_counts(const uint32_t* counts, uint
   for (uint32_t i = begin; i < end; ++i) { offsets[i] = run; run += counts[i]; }
 }
 
-// keys sorted ascending (unsigned bit order)?  Also OR-reduces all keys (significant bytes for the radix sort):
-// one atomic per 1024-thread workgroup, at most 1024 workgroups (atomics on one word retire at ~88 per microsecond).
+// keys sorted ascending (unsigned bit order)?  Also: are two neighbours equal (a sorted column with duplicates), the OR of
+// all keys (significant bytes for the radix sort) and the smallest / largest key in the order of the 64-bit key bits
+// (the rank table's origin and extent): one round of atomics per 1024-thread workgroup, at most 1024 workgroups
+// (atomics on one word retire at ~88 per microsecond).
+// The directory keeps the keys in the unsigned order of their 64-bit bits; the rank table wants the SIGNED order (a key
+// column with negative and positive values is dense there, not 2^63 apart): min / max are kept biased by the sign bit.
+// flags (u32 words): [0] unsorted  [1] equal neighbours  [2] any NULL materialised  [3] unsorted in signed order
+//                    [4..5] OR  [6..7] min ^ sign  [8..9] max ^ sign
 template <typename K>
-__global__ __launch_bounds__(1024) void check_sorted(const K* keys, uint64_t n, uint32_t* unsorted, unsigned long long* key_or) {
-  __shared__ uint64_t s_bits[16];
-  __shared__ uint32_t s_unsorted;
-  if (threadIdx.x == 0) s_unsorted = 0;
+__global__ __launch_bounds__(1024) void check_sorted(const K* keys, uint64_t n, uint32_t* flags) {
+  __shared__ uint64_t s_bits[16], s_min[16], s_max[16];
+  __shared__ uint32_t s_unsorted, s_equal, s_unsorted_signed;
+  if (threadIdx.x == 0) { s_unsorted = 0; s_equal = 0; s_unsorted_signed = 0; }
   __syncthreads();
-  uint64_t bits = 0;
-  bool unsorted_here = false;
+  uint64_t bits = 0, lowest = ~0ull, highest = 0;
+  bool unsorted_here = false, equal_here = false, unsorted_signed_here = false;
+  constexpr uint64_t SIGN = 1ull << 63;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     const K key = keys[i];
     bits |= key;
-    if (i + 1 < n && key > keys[i + 1]) unsorted_here = true;
+    const uint64_t wide = key_bits_of(key) ^ SIGN;
+    lowest = wide < lowest ? wide : lowest;
+    highest = wide > highest ? wide : highest;
+    if (i + 1 < n) {
+      const K next = keys[i + 1];
+      if (key > next) unsorted_here = true;
+      if (key == next) equal_here = true;
+      if (wide > (key_bits_of(next) ^ SIGN)) unsorted_signed_here = true;
+    }
   }
   if (unsorted_here) s_unsorted = 1;
+  if (equal_here) s_equal = 1;
+  if (unsorted_signed_here) s_unsorted_signed = 1;
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) bits |= __shfl_xor(bits, d, 64);
-  if ((threadIdx.x & 63) == 0) s_bits[threadIdx.x >> 6] = bits;
+  for (int d = 32; d > 0; d >>= 1) {
+    bits |= __shfl_xor(bits, d, 64);
+    const uint64_t other_low = __shfl_xor(lowest, d, 64), other_high = __shfl_xor(highest, d, 64);
+    lowest = other_low < lowest ? other_low : lowest;
+    highest = other_high > highest ? other_high : highest;
+  }
+  if ((threadIdx.x & 63) == 0) { s_bits[threadIdx.x >> 6] = bits; s_min[threadIdx.x >> 6] = lowest; s_max[threadIdx.x >> 6] = highest; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint64_t all = 0;
-    for (uint32_t w = 0; w < 16; ++w) all |= s_bits[w];
-    if (all) atomicOr(key_or, static_cast<unsigned long long>(all));
-    if (s_unsorted) *unsorted = 1;
+    uint64_t all = 0, low = ~0ull, high = 0;
+    for (uint32_t w = 0; w < 16; ++w) { all |= s_bits[w]; low = s_min[w] < low ? s_min[w] : low; high = s_max[w] > high ? s_max[w] : high; }
+    if (all) atomicOr(reinterpret_cast<unsigned long long*>(flags + 4), static_cast<unsigned long long>(all));
+    atomicMin(reinterpret_cast<unsigned long long*>(flags + 6), static_cast<unsigned long long>(low));
+    atomicMax(reinterpret_cast<unsigned long long*>(flags + 8), static_cast<unsigned long long>(high));
+    if (s_unsorted) flags[0] = 1;
+    if (s_equal) flags[1] = 1;
+    if (s_unsorted_signed) flags[3] = 1;
   }
 }
 
@@ -565,6 +840,103 @@ __device__ __forceinline__ void directory_lookup(const Directory& d, uint64_t ke
   *count = end - lo;
 }
 
+// ---- rank table over the build keys ------------------------------------------------------------------------------------
+// Integer build keys that are unique and not too sparse (primary keys: TPC-H o_orderkey uses 8 of every 32 integers, SSB's
+// dimension keys are dense) get a succinct rank dictionary instead of the bucket directory: one 8-byte entry per 32
+// consecutive key values, {bit per value present, number of build keys below the entry's first value}.  A probe is ONE
+// dependent 8-byte load: the key is a build key iff its bit is set, and its rank among the build keys -- its position in
+// the key-ordered build side -- is base + popcount(bits below).  No key is ever compared, so the sorted key array is not
+// read by the probe at all; the table (range / 4 bytes: 15 MB for SF10 orders) stays in the L2s / Infinity Cache where
+// the directory and its key array (120 MB) cannot.  The same open-addressing idea as the directory with a hash function
+// that is the key itself.
+struct RankTable {
+  const u32x2_t* entries;    // [(range >> 5) + 1]
+  uint64_t key_min;
+  uint64_t range;            // key_max - key_min
+  uint32_t identity_rows;    // != 0: the build row of rank r is RowID{r / identity_rows, r % identity_rows} (a dense, sorted build
+  uint32_t reserved;         //       column whose chunks all hold identity_rows rows): no RowID array at all
+  double identity_inverse;   // 1.0 / identity_rows
+};
+
+// Sorted, duplicate-free keys: the first key of every 32-value word collects the word's bits (its followers are the next
+// <= 31 keys) and stores the entry -- no atomics, no scan; words without a key keep their zeros.
+template <typename K>
+__global__ __launch_bounds__(256) void rank_table_fill_sorted(const K* keys, uint64_t n, uint64_t key_min, u32x2_t* entries) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t rel = key_bits_of(keys[i]) - key_min;
+  const uint64_t word = rel >> 5;
+  if (i != 0 && ((key_bits_of(keys[i - 1]) - key_min) >> 5) == word) return;
+  uint32_t bits = 1u << (rel & 31);
+  for (uint64_t j = i + 1; j < n && j < i + 32; ++j) {
+    const uint64_t other = key_bits_of(keys[j]) - key_min;
+    if ((other >> 5) != word) break;
+    bits |= 1u << (other & 31);
+  }
+  entries[word] = u32x2_t{bits, static_cast<uint32_t>(i)};
+}
+
+// Unsorted keys: every key sets its bit (a bit that is already set: the keys are not unique, the join falls back to the
+// sorted directory), a scan over the words' population counts gives the bases, and the RowIDs are scattered to their
+// keys' ranks -- which is all the "sort" a unique build side needs.
+template <typename K>
+__global__ __launch_bounds__(256) void rank_table_mark(const K* keys, uint64_t n, uint64_t key_min, u32x2_t* entries, uint32_t* duplicate) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t rel = key_bits_of(keys[i]) - key_min;
+  const uint32_t bit = 1u << (rel & 31);
+  const uint32_t old = atomicOr(reinterpret_cast<uint32_t*>(entries + (rel >> 5)), bit);
+  if (old & bit) *duplicate = 1;
+}
+
+constexpr uint32_t RANK_BLOCK = 4096;   // table words per workgroup of the base scan
+__global__ __launch_bounds__(256) void rank_table_block_sums(const u32x2_t* entries, uint64_t words, uint64_t* block_sums) {
+  __shared__ uint32_t s_wave[4];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * RANK_BLOCK;
+  uint32_t sum = 0;
+  for (uint32_t k = 0; k < RANK_BLOCK / 256; ++k) {
+    const uint64_t w = base + k * 256 + threadIdx.x;
+    if (w < words) sum += __popc(entries[w].x);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = uint64_t{s_wave[0]} + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+__global__ __launch_bounds__(256) void rank_table_bases(u32x2_t* entries, uint64_t words, const uint64_t* block_offsets) {
+  __shared__ uint32_t s_wave[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * RANK_BLOCK + static_cast<uint64_t>(tid) * (RANK_BLOCK / 256);
+  uint32_t counts[RANK_BLOCK / 256];
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < RANK_BLOCK / 256; ++k) {
+    counts[k] = first + k < words ? __popc(entries[first + k].x) : 0;
+    sum += counts[k];
+  }
+  const uint32_t inclusive = join_wave_inclusive_scan(sum);
+  if (lane == 63) s_wave[wave] = inclusive;
+  __syncthreads();
+  uint32_t run = static_cast<uint32_t>(block_offsets[blockIdx.x]) + inclusive - sum;
+  for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+  for (uint32_t k = 0; k < RANK_BLOCK / 256; ++k) {
+    if (first + k < words) reinterpret_cast<uint32_t*>(entries + first + k)[1] = run;
+    run += counts[k];
+  }
+}
+
+template <typename K, typename R>
+__global__ __launch_bounds__(256) void rank_table_scatter_rows(const K* keys, const R* rows_in, R* rows_out, uint64_t n, uint64_t key_min, const u32x2_t* entries) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t rel = key_bits_of(keys[i]) - key_min;
+  const u32x2_t entry = entries[rel >> 5];
+  rows_out[entry.y + __popc(entry.x & ((1u << (rel & 31)) - 1))] = rows_in[i];
+}
+
 // ---- probe side ------------------------------------------------------------------------------------------------------
 struct JoinPlan {   // written by plan_output between the probe passes: what pass 2's kernels need to know
   uint32_t fits, n_slices;   // the result buffers hold the pairs and PosLists | number of output PosLists
@@ -581,7 +953,8 @@ struct SecondaryPredicate {
 
 struct ProbeArgs {
   const DevSegment* segments;     // probe column
-  const Slice* slices;            // 8192-row slices; a tile is a quarter of a slice
+  const Slice* slices;            // 8192-row slices; a tile is half a slice
+  const SliceView* views;         // the same slices for the kernels that fetch ahead (rt_probe_count / rt_probe_emit)
   uint32_t n_tiles;
   uint32_t mode;                  // HY_JOIN_*
   uint32_t radix_bits;
@@ -589,6 +962,7 @@ struct ProbeArgs {
   uint32_t build_rows_zero;       // build table has no rows (AntiNullAsTrue special case)
   const uint8_t* build_bloom;     // filter applied to the probe side, or nullptr
   Directory dir;
+  RankTable rank;                 // rank.entries != nullptr: the rt_* kernels look keys up here (dir then only carries the RowIDs by rank)
   // pass 1 out / pass 2 in
   uint32_t* hist_elements;        // [P][n_tiles]  (P = 1 << radix_bits, or 1)
   uint32_t* hist_pairs;           // [P][n_tiles]
@@ -1225,6 +1599,425 @@ __global__ __launch_bounds__(64) void probe_cuts(ProbeArgs a, const uint64_t* gr
   }
 }
 
+// ---- the probe passes over a rank table ------------------------------------------------------------------------------------
+// Unique integer build keys (RankTable above): a probe row has at most one partner and finding it is one 8-byte load, so
+// pass 2 evaluates the rows again instead of reading what pass 1 found -- pass 1 writes nothing per row (the 6 bytes per
+// probe row it left behind for probe_emit_cached were 0.73 GB of the 2.1 GB a config-3 join moved), no tile is ever
+// "uncached", and the 131 070-element cuts re-evaluate the one tile they fall into.
+// meta[k] = emit << 10 | null_partner << 9 | partition (INVALID_PARTITION: not materialised); rank[k] = the partner's rank.
+__device__ __forceinline__ void rt_evaluate_rows(const ProbeArgs& a, uint32_t chunk, uint32_t row_begin, uint32_t row_count, uint32_t wave, uint32_t lane,
+                                                 uint32_t (&meta)[JOIN_ROUNDS], uint32_t (&rank)[JOIN_ROUNDS]) {
+  uint32_t row[JOIN_ROUNDS];
+  bool in[JOIN_ROUNDS], is_null[JOIN_ROUNDS];
+  int64_t key[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    meta[k] = INVALID_PARTITION;
+    rank[k] = 0;
+  }
+  if (row_count == 0) return;
+  decode_keys<false>(a, chunk, row_begin, row_count, wave, lane, row, in, is_null, key);
+  const RankTable& t = a.rank;
+  bool valid[JOIN_ROUNDS], look[JOIN_ROUNDS];
+  uint32_t rel[JOIN_ROUNDS], low[JOIN_ROUNDS];
+  u32x2_t entry[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    valid[k] = in[k] && !(is_null[k] && !a.keep_nulls);
+    const uint64_t distance = static_cast<uint64_t>(key[k]) - t.key_min;
+    look[k] = valid[k] && !is_null[k] && distance <= t.range;
+    rel[k] = look[k] ? static_cast<uint32_t>(distance) : 0u;
+    low[k] = static_cast<uint32_t>(key[k]);   // std::hash of an integer key is the key: radix partition and Bloom index are its low bits
+    entry[k] = t.entries[rel[k] >> 5];
+  }
+  bool found[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    const uint32_t bit = 1u << (rel[k] & 31);
+    found[k] = look[k] && (entry[k].x & bit);
+    rank[k] = entry[k].y + __popc(entry[k].x & (bit - 1));
+  }
+  // the build side's Bloom filter decides which partner-less probe rows count as materialised (join_hash_steps.hpp:354-358)
+  if (a.build_bloom && !a.keep_nulls) {
+    bool any = false;
+#pragma unroll
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) any = any || (valid[k] && !found[k]);
+    if (__any(any)) {
+      uint32_t index[JOIN_ROUNDS];
+      uint8_t hit[JOIN_ROUNDS];
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) index[k] = low[k] & (BLOOM_BITS - 1);
+      load_rows<uint8_t>(a.build_bloom, index, hit);
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) valid[k] = valid[k] && !(!found[k] && hit[k] == 0);
+    }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    if (!valid[k]) continue;
+    const uint32_t partition = a.radix_bits ? low[k] & ((1u << a.radix_bits) - 1) : 0;
+    bool null_partner = false;
+    const uint32_t emit = pairs_of(a, is_null[k], found[k] ? 1u : 0u, &null_partner);
+    meta[k] = (emit << 10) | (null_partner ? 0x200u : 0u) | partition;
+  }
+}
+
+// ---- pass 1 over a rank table ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_view(const ProbeArgs& a, uint32_t tile, SliceView* view, uint32_t* row_begin, uint32_t* row_count) {
+  *view = a.views[tile / (SLICE_ROWS / JOIN_TILE)];
+  const uint32_t offset = (tile % (SLICE_ROWS / JOIN_TILE)) * JOIN_TILE;
+  *row_begin = view->row_begin + offset;
+  *row_count = view->row_count > offset ? (view->row_count - offset < JOIN_TILE ? view->row_count - offset : JOIN_TILE) : 0;
+}
+
+// The (tile, partition) counts and nothing else, one tile per workgroup (probe columns of any kind; columns of plain int32 /
+// FrameOfReference segments take rt_stream_count below).  One LDS atomic per row: materialised elements in the low half of a
+// 32-bit cell, pairs (at most one per row) in the high half; eight copies of the cells, chosen by the lane, because
+// neighbouring rows share their key (four lineitems per order) and same-address LDS atomics serialise.
+constexpr uint32_t COUNT_COPIES = 8;
+__global__ __launch_bounds__(JOIN_THREADS) void rt_probe_count(ProbeArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cells[MAX_PARTITIONS * COUNT_COPIES];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t partitions = 1u << a.radix_bits;
+  const uint32_t tile = block_tile(a.n_tiles);
+  if (tile >= a.n_tiles) return;
+  for (uint32_t i = tid; i < partitions * COUNT_COPIES; i += JOIN_THREADS) s_cells[i] = 0;
+  __syncthreads();
+  uint32_t chunk, row_begin, row_count;
+  tile_rows(a, tile, &chunk, &row_begin, &row_count);
+  uint32_t meta[JOIN_ROUNDS], rank[JOIN_ROUNDS];
+  rt_evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, rank);
+#pragma unroll
+  for (uint32_t round = 0; round < JOIN_ROUNDS; ++round) {
+    const uint32_t partition = meta[round] & 0x1FF;
+    if (partition != INVALID_PARTITION) atomicAdd(&s_cells[partition * COUNT_COPIES + (lane & (COUNT_COPIES - 1))], (meta[round] >> 10) ? 0x10001u : 1u);
+  }
+  __syncthreads();
+  if (tid < partitions) {
+    const u32x4_t low = *reinterpret_cast<const u32x4_t*>(s_cells + tid * COUNT_COPIES), high = *reinterpret_cast<const u32x4_t*>(s_cells + tid * COUNT_COPIES + 4);
+    const uint32_t sum = low.x + low.y + low.z + low.w + high.x + high.y + high.z + high.w;
+    a.hist_elements[static_cast<size_t>(tid) * a.n_tiles + tile] = sum & 0xFFFFu;
+    a.hist_pairs[static_cast<size_t>(tid) * a.n_tiles + tile] = sum >> 16;
+  }
+}
+
+// RowID of the build row of rank r.
+__device__ __forceinline__ u32x2_t rank_row_id(const ProbeArgs& a, uint32_t r) {
+  if (a.rank.identity_rows) {
+    uint32_t chunk = static_cast<uint32_t>(static_cast<double>(r) * a.rank.identity_inverse);
+    if (chunk * a.rank.identity_rows > r) --chunk;   // (the product is within one ulp of the quotient)
+    uint32_t offset = r - chunk * a.rank.identity_rows;
+    if (offset >= a.rank.identity_rows) { ++chunk; offset -= a.rank.identity_rows; }
+    return u32x2_t{chunk, offset};
+  }
+  if (a.dir.ids32) { const uint32_t id = a.dir.ids32[r]; return u32x2_t{id >> 16, id & 0xFFFFu}; }
+  return reinterpret_cast<const u32x2_t*>(a.dir.row_ids)[r];
+}
+
+// LDS of rt_probe_emit, in 4-byte words: staged pairs (one spare slot per partition, see below) | pairs per (wave, partition),
+// then pairs of earlier waves | first slot per partition (+ total) | output base per partition | wave totals.
+__host__ __device__ constexpr size_t rt_probe_emit_lds_words(uint32_t partitions) {
+  return 2 * (size_t{JOIN_TILE} + partitions + 2) + size_t{JOIN_WAVES} * partitions + (partitions + 2) + 2 * size_t{partitions} + 16;
+}
+
+// Pass 2 over a rank table, persistent like pass 1 (the keys of the following tile in flight while this one is ranked and
+// written).  Ranking: a pair's slot inside (tile, partition) is  pairs of earlier waves + pairs of earlier rounds of the
+// wave + pairs in lower lanes of the round.  The wave keeps one running counter per partition in LDS: in every round the
+// lowest lane of each group of rows with the same partition (wave-level match-any) adds the group's size with ONE returning
+// atomic -- LDS operations of a wave execute in order, so what it gets back are the pairs of the earlier rounds -- and the
+// group reads it from that lane.  After the rounds the counters are the wave totals; thread = partition turns them into
+// pairs of earlier waves.  No counting pass, no byte counters.
+// The copy-out writes 16 bytes per lane and stream: the chip retires 8-byte stores at ~5 B / clock / CU (a whole tile of
+// them took 5 us even with every run sequential), 16-byte stores at twice that.  To make the two pairs of a lane one
+// aligned 16-byte store, partition p's run starts at a staging slot of the parity of its first global pair index -- every
+// non-empty partition reserves one spare slot for that, marked invalid.
+constexpr uint32_t STAGE_INVALID = 0xFFFFFFFFu;
+__global__ __launch_bounds__(JOIN_THREADS) void rt_probe_emit(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
+  const uint32_t partitions = 1u << a.radix_bits;
+  const uint32_t stage_slots = JOIN_TILE + partitions + 2;
+  u32x2_t* s_stage = reinterpret_cast<u32x2_t*>(join_smem);                            // [stage_slots] row | partition << 12 | null << 21 , partner's rank
+  uint32_t* s_wave_pairs = reinterpret_cast<uint32_t*>(s_stage + stage_slots);         // [JOIN_WAVES][partitions] running pairs of a wave, then pairs of earlier waves
+  uint32_t* s_tile_offset = s_wave_pairs + JOIN_WAVES * partitions;                    // [partitions + 1] first staged slot of every partition, total
+  uint64_t* s_out_base = reinterpret_cast<uint64_t*>(s_tile_offset + partitions + 2 - (partitions & 1 ? 1 : 0));   // [partitions] global pair index of staging slot 0
+  uint32_t* s_scratch = reinterpret_cast<uint32_t*>(s_out_base + partitions);         // [JOIN_WAVES] wave totals of the partition scan
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t scan_waves = partitions > 64 ? partitions / 64 : 1;
+  const uint32_t tile = block_tile(a.n_tiles);
+  if (tile >= a.n_tiles || !a.plan->fits) return;
+  if (a.trace && tid == 0) a.trace[tile * 6 + 0] = wall_clock64();
+  for (uint32_t i = tid; i < JOIN_WAVES * partitions; i += JOIN_THREADS) s_wave_pairs[i] = 0;
+  uint32_t chunk, tile_row_begin, tile_row_count;
+  tile_rows(a, tile, &chunk, &tile_row_begin, &tile_row_count);
+  // thread = partition: the cell's pairs and its first global pair index
+  const size_t cell = static_cast<size_t>(tid < partitions ? tid : 0) * a.n_tiles + tile;
+  const uint32_t cell_pairs = tid < partitions ? a.hist_pairs[cell] : 0;
+  const uint64_t cell_base = a.base_pairs[cell];
+  uint32_t meta[JOIN_ROUNDS], rank[JOIN_ROUNDS];
+  rt_evaluate_rows(a, chunk, tile_row_begin, tile_row_count, wave, lane, meta, rank);
+  if (a.trace && tid == 0) a.trace[tile * 6 + 1] = wall_clock64();
+  // (a) reserve pairs + 1 slots per non-empty partition: scan inside each wave now, across waves in (c)
+  const uint32_t reserve = cell_pairs ? cell_pairs + 1 : 0;
+  uint32_t first_in_wave = 0;
+  if (wave < scan_waves) {
+    const uint32_t inclusive = join_wave_inclusive_scan(reserve);
+    first_in_wave = inclusive - reserve;
+    if (lane == 63) s_scratch[wave] = inclusive;
+  }
+  __syncthreads();   // the counters are zero
+  // (b) rank inside the wave, four rounds at a time (their atomics in flight together); the rank moves into meta[k] bits 11..
+#pragma unroll
+  for (uint32_t half = 0; half < JOIN_ROUNDS; half += 4) {
+    uint32_t before[4], who[4];   // who: leader lane | pairs in lower lanes << 8
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t k = half + j;
+      const uint32_t partition = meta[k] & 0xFF;
+      const bool emit = (meta[k] >> 10) != 0;
+      const uint64_t peers = match_any8(partition, emit);
+      const uint32_t leader = emit ? static_cast<uint32_t>(__ffsll(static_cast<long long>(peers))) - 1u : lane;
+      who[j] = leader | __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(peers >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(peers), 0u)) << 8;
+      before[j] = 0;
+      if (emit && leader == lane) before[j] = atomicAdd(&s_wave_pairs[wave * partitions + partition], static_cast<uint32_t>(__popcll(peers)));
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) meta[half + j] |= (__shfl(before[j], static_cast<int>(who[j] & 0xFF), 64) + (who[j] >> 8)) << 11;
+  }
+  __syncthreads();
+  if (a.trace && tid == 0) a.trace[tile * 6 + 2] = wall_clock64();
+  // (c) thread = partition: pairs of earlier waves, first slot (parity of the first global pair), output base
+  if (tid < partitions) {
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < JOIN_WAVES; ++w) {
+      const uint32_t pairs = s_wave_pairs[w * partitions + tid];
+      s_wave_pairs[w * partitions + tid] = run;
+      run += pairs;
+    }
+    uint32_t first = first_in_wave + (wave > 0 ? s_scratch[0] : 0u) + (wave > 1 ? s_scratch[1] : 0u) + (wave > 2 ? s_scratch[2] : 0u);
+    if (reserve) {
+      const uint32_t shift = (first ^ static_cast<uint32_t>(cell_base)) & 1u;
+      s_stage[shift ? first : first + cell_pairs].x = STAGE_INVALID;   // the spare slot
+      first += shift;
+    }
+    s_tile_offset[tid] = first;
+    s_out_base[tid] = cell_base - first;
+    if (tid == 0) s_tile_offset[partitions] = s_scratch[0] + (scan_waves > 1 ? s_scratch[1] : 0u) + (scan_waves > 2 ? s_scratch[2] : 0u) + (scan_waves > 3 ? s_scratch[3] : 0u);   // every reserved slot
+  }
+  __syncthreads();
+  if (a.trace && tid == 0) a.trace[tile * 6 + 3] = wall_clock64();
+  // (d) stage: slot = first slot of the partition + pairs of earlier waves + rank inside the wave
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    if (!((meta[k] >> 10) & 1)) continue;
+    const uint32_t partition = meta[k] & 0xFF;
+    const uint32_t slot = s_tile_offset[partition] + s_wave_pairs[wave * partitions + partition] + (meta[k] >> 11);
+    const uint32_t r = wave * JOIN_WAVE_ROWS + k * 64 + lane;
+    s_stage[slot] = u32x2_t{r | (partition << 12) | ((meta[k] & 0x200u) ? 1u << 21 : 0u), rank[k]};
+  }
+  __syncthreads();
+  if (a.trace && tid == 0) a.trace[tile * 6 + 4] = wall_clock64();
+  // (e) copy out, two staging slots (= two consecutive pairs of one partition, or a run's end and the next one's spare) per lane
+  const uint32_t reserved = s_tile_offset[partitions];
+  for (uint32_t slot = 2 * tid; slot < reserved; slot += 2 * JOIN_THREADS) {
+    const u32x4_t records = *reinterpret_cast<const u32x4_t*>(s_stage + slot);
+    const uint32_t tag0 = records.x, tag1 = slot + 1 < reserved ? records.z : STAGE_INVALID;
+    const bool valid0 = tag0 != STAGE_INVALID, valid1 = tag1 != STAGE_INVALID;
+    const uint32_t partition0 = (tag0 >> 12) & 0x1FF, partition1 = (tag1 >> 12) & 0x1FF;
+    const u32x2_t probe0 = {chunk, tile_row_begin + (tag0 & 0xFFFu)}, probe1 = {chunk, tile_row_begin + (tag1 & 0xFFFu)};
+    u32x2_t build0 = {0xFFFFFFFFu, 0xFFFFFFFFu}, build1 = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (a.build_out) {
+      if (valid0 && !(tag0 & (1u << 21))) build0 = rank_row_id(a, records.y);
+      if (valid1 && !(tag1 & (1u << 21))) build1 = rank_row_id(a, records.w);
+    }
+    if (valid0 && valid1 && partition0 == partition1) {   // both pairs of one run: its first global index has the slot's parity -> aligned
+      const uint64_t pair_pos = s_out_base[partition0] + slot;
+      __builtin_nontemporal_store(u32x4_t{probe0.x, probe0.y, probe1.x, probe1.y}, reinterpret_cast<u32x4_t*>(reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos));
+      if (a.build_out) __builtin_nontemporal_store(u32x4_t{build0.x, build0.y, build1.x, build1.y}, reinterpret_cast<u32x4_t*>(reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos));
+    } else {
+      if (valid0) {
+        const uint64_t pair_pos = s_out_base[partition0] + slot;
+        __builtin_nontemporal_store(probe0, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
+        if (a.build_out) __builtin_nontemporal_store(build0, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+      }
+      if (valid1) {
+        const uint64_t pair_pos = s_out_base[partition1] + slot + 1;
+        __builtin_nontemporal_store(probe1, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
+        if (a.build_out) __builtin_nontemporal_store(build1, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+      }
+    }
+  }
+  if (a.trace && tid == 0) a.trace[tile * 6 + 5] = wall_clock64();
+}
+
+// ---- pass 1, one wave per tile -------------------------------------------------------------------------------------------------
+// Counting needs no workgroup and no row order: a WAVE takes a tile, requests all of its stored words at once with 16-byte
+// loads (eight batches of 512 rows, a lane holds eight consecutive rows of each: 8 KB in flight per wave -- with the 2-byte
+// loads of the workgroup kernels a CU never had more than ~25 KB in flight and the column arrived at 1.5 TB/s), then looks
+// the batches up one after the other, the next batch's table entries in flight, and counts in private LDS cells.  No
+// barriers; 24+ independent streams per CU.
+constexpr uint32_t STREAM_WAVES = 4;   // waves per workgroup (they share nothing but the launch)
+__host__ __device__ constexpr size_t stream_count_lds_words(uint32_t partitions) { return size_t{STREAM_WAVES} * partitions * COUNT_COPIES; }
+
+template <uint32_t WIDTH>   // bytes per stored word: FrameOfReference offsets of 1 / 2 / 4 bytes, int32 values
+__device__ __forceinline__ void load_batch_words(const char* base, uint32_t first_row, u32x4_t (&words)[2]) {
+  // the lane's eight consecutive words (first_row is a multiple of eight: the loads are aligned)
+  words[0] = words[1] = u32x4_t{0, 0, 0, 0};
+  if constexpr (WIDTH == 1) {
+    const u32x2_t v = *reinterpret_cast<const u32x2_t*>(base + first_row);
+    words[0].x = v.x; words[0].y = v.y;
+  } else if constexpr (WIDTH == 2) {
+    words[0] = *reinterpret_cast<const u32x4_t*>(base + first_row * 2u);
+  } else {
+    words[0] = *reinterpret_cast<const u32x4_t*>(base + first_row * 4u);
+    words[1] = *reinterpret_cast<const u32x4_t*>(base + first_row * 4u + 16u);
+  }
+}
+template <uint32_t WIDTH>
+__device__ __forceinline__ uint32_t batch_word(const u32x4_t (&words)[2], uint32_t j) {   // j = 0..7, constant after unrolling
+  if constexpr (WIDTH == 1) { const uint32_t w = j < 4 ? words[0].x : words[0].y; return (w >> (8 * (j & 3))) & 0xFFu; }
+  else if constexpr (WIDTH == 2) { const uint32_t w = j < 2 ? words[0].x : j < 4 ? words[0].y : j < 6 ? words[0].z : words[0].w; return (w >> (16 * (j & 1))) & 0xFFFFu; }
+  else { const u32x4_t v = j < 4 ? words[0] : words[1]; return (j & 3) == 0 ? v.x : (j & 3) == 1 ? v.y : (j & 3) == 2 ? v.z : v.w; }
+}
+
+template <uint32_t WIDTH>
+__device__ __forceinline__ void count_tile_wide(const ProbeArgs& a, const SliceView& view, uint32_t row_begin, uint32_t row_count, uint32_t lane, uint32_t* cells) {
+  const char* base = static_cast<const char*>(view.data);
+  u32x4_t words[JOIN_WAVES][2];
+  uint32_t bias[JOIN_WAVES];
+#pragma unroll
+  for (uint32_t b = 0; b < JOIN_WAVES; ++b) {
+    const uint32_t first = b * JOIN_WAVE_ROWS + lane * 8;
+    load_batch_words<WIDTH>(base, row_begin + (first < row_count ? first : 0), words[b]);
+    bias[b] = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(row_begin + (b * JOIN_WAVE_ROWS < row_count ? b * JOIN_WAVE_ROWS : 0)) / HY_FOR_BLOCK_SIZE]);
+  }
+  const RankTable& table = a.rank;
+  const uint32_t origin = static_cast<uint32_t>(table.key_min);
+#pragma unroll
+  for (uint32_t b = 0; b < JOIN_WAVES; ++b) {
+    uint32_t low[JOIN_ROUNDS];
+    u32x2_t entry[JOIN_ROUNDS];
+    uint32_t valid = 0, look = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < JOIN_ROUNDS; ++j) {
+      const bool in = b * JOIN_WAVE_ROWS + lane * 8 + j < row_count;
+      const int64_t key = static_cast<int32_t>(batch_word<WIDTH>(words[b], j) + bias[b]);
+      const uint64_t distance = static_cast<uint64_t>(key) - table.key_min;
+      const bool looked = in && distance <= table.range;
+      low[j] = static_cast<uint32_t>(key);
+      entry[j] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(table.entries) + (looked ? (static_cast<uint32_t>(distance) >> 5) * 8u : 0u));
+      valid |= (in ? 1u : 0u) << j;
+      look |= (looked ? 1u : 0u) << j;
+    }
+    uint32_t found = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < JOIN_ROUNDS; ++j) {
+      if (((look >> j) & 1) && (entry[j].x & (1u << ((low[j] - origin) & 31)))) found |= 1u << j;
+    }
+    if (a.build_bloom && !a.keep_nulls && __any((valid & ~found) != 0)) {   // partner-less rows: materialised only if the build side's filter has their bit
+      uint32_t miss = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < JOIN_ROUNDS; ++j) {
+        if (((valid & ~found) >> j) & 1) miss |= (a.build_bloom[low[j] & (BLOOM_BITS - 1)] == 0 ? 1u : 0u) << j;
+      }
+      valid &= ~miss;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < JOIN_ROUNDS; ++j) {
+      if (!((valid >> j) & 1)) continue;
+      const uint32_t partition = a.radix_bits ? low[j] & ((1u << a.radix_bits) - 1) : 0;
+      bool null_partner = false;
+      const uint32_t emit = pairs_of(a, false, (found >> j) & 1, &null_partner);
+      atomicAdd(&cells[partition * COUNT_COPIES + ((lane + j) & (COUNT_COPIES - 1))], emit ? 0x10001u : 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * STREAM_WAVES) void rt_stream_count(ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
+  const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t partitions = 1u << a.radix_bits;
+  uint32_t* cells = join_smem + wave * partitions * COUNT_COPIES;   // this wave's: [partitions][COUNT_COPIES]
+  // the tiles of a wave: XCD x = blockIdx % 8 owns the x-th eighth of the tiles, its waves take them interleaved
+  const uint32_t per_xcd = (a.n_tiles + 7) / 8, xcd = blockIdx.x & 7;
+  const uint32_t end = (xcd + 1) * per_xcd < a.n_tiles ? (xcd + 1) * per_xcd : a.n_tiles, step = (gridDim.x >> 3) * STREAM_WAVES;
+  for (uint32_t i = lane; i < partitions * COUNT_COPIES; i += 64) cells[i] = 0;
+#pragma unroll 1
+  for (uint32_t tile = xcd * per_xcd + (blockIdx.x >> 3) * STREAM_WAVES + wave; tile < end; tile += step) {
+    SliceView view;
+    uint32_t row_begin, row_count;
+    tile_view(a, tile, &view, &row_begin, &row_count);
+    if (row_count) {
+      if (view.kind == VIEW_FOR8) count_tile_wide<1>(a, view, row_begin, row_count, lane, cells);
+      else if (view.kind == VIEW_FOR16) count_tile_wide<2>(a, view, row_begin, row_count, lane, cells);
+      else count_tile_wide<4>(a, view, row_begin, row_count, lane, cells);
+    }
+    // the tile's cells leave, zeroed for the next one (LDS operations of a wave execute in order: no barrier)
+    for (uint32_t partition = lane; partition < partitions; partition += 64) {
+      u32x4_t* mine = reinterpret_cast<u32x4_t*>(cells + partition * COUNT_COPIES);
+      const u32x4_t low = mine[0], high = mine[1];
+      mine[0] = u32x4_t{0, 0, 0, 0};
+      mine[1] = u32x4_t{0, 0, 0, 0};
+      const uint32_t sum = low.x + low.y + low.z + low.w + high.x + high.y + high.z + high.w;
+      a.hist_elements[static_cast<size_t>(partition) * a.n_tiles + tile] = sum & 0xFFFFu;
+      a.hist_pairs[static_cast<size_t>(partition) * a.n_tiles + tile] = sum >> 16;
+    }
+  }
+}
+
+// The 131 070-element cuts over a rank table: one workgroup per output PosList finds the cell that holds the PosList's first
+// element (the searches of probe_cuts), evaluates that tile once more and locates the element among its rows.
+__global__ __launch_bounds__(JOIN_THREADS) void rt_probe_cuts(ProbeArgs a, const uint64_t* group_first_cell, uint32_t n_groups) {
+  __shared__ uint32_t s_members[JOIN_WAVES * JOIN_ROUNDS], s_emitters[JOIN_WAVES * JOIN_ROUNDS];
+  const uint32_t slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!a.plan->fits || slice >= a.plan->n_slices) return;
+  uint32_t lo = 0, hi = n_groups;   // last group whose first PosList is <= slice (every wave searches: the results are uniform)
+  while (hi - lo > 1) {
+    const uint32_t step = (hi - lo + 63) / 64, at = lo + lane * step;
+    const uint32_t below = __popcll(__ballot(at < hi && a.partition_slice_base[at] <= slice));
+    lo += (below - 1) * step;
+    hi = lo + step < hi ? lo + step : hi;
+  }
+  const uint32_t group = lo;
+  const uint64_t first_cell = group_first_cell ? group_first_cell[group] : static_cast<uint64_t>(group) * a.n_tiles;
+  const uint64_t end_cell = group_first_cell ? group_first_cell[group + 1] : static_cast<uint64_t>(group + 1) * a.n_tiles;
+  const uint64_t target = a.base_elements[first_cell] + static_cast<uint64_t>(slice - a.partition_slice_base[group]) * PROBE_SIZE_PER_CHUNK;
+  uint64_t cell = first_cell, cell_end = end_cell;   // last cell of the group whose first element is <= target: it holds the element
+  while (cell_end - cell > 1) {
+    const uint64_t step = (cell_end - cell + 63) / 64, at = cell + lane * step;
+    const uint32_t below = __popcll(__ballot(at < cell_end && a.base_elements[at] <= target));
+    cell += (below - 1) * step;
+    cell_end = cell + step < cell_end ? cell + step : cell_end;
+  }
+  const uint32_t tile = static_cast<uint32_t>(a.radix_bits ? cell - static_cast<uint64_t>(group) * a.n_tiles : cell);
+  const uint32_t partition = a.radix_bits ? group : 0;
+  const uint32_t cut_rank = static_cast<uint32_t>(target - a.base_elements[cell]);
+  uint32_t chunk, row_begin, row_count;
+  tile_rows(a, tile, &chunk, &row_begin, &row_count);
+  uint32_t meta[JOIN_ROUNDS], rank[JOIN_ROUNDS];
+  rt_evaluate_rows(a, chunk, row_begin, row_count, wave, lane, meta, rank);
+  uint64_t members[JOIN_ROUNDS], emitters[JOIN_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    const bool member = (meta[k] & 0x1FF) == partition;   // (INVALID_PARTITION is no partition)
+    members[k] = __ballot(member);
+    emitters[k] = __ballot(member && (meta[k] >> 10));
+    if (lane == 0) { s_members[wave * JOIN_ROUNDS + k] = __popcll(members[k]); s_emitters[wave * JOIN_ROUNDS + k] = __popcll(emitters[k]); }
+  }
+  __syncthreads();
+  // rows come wave by wave, round by round, lane by lane: members / emitters in front of this wave's first round
+  uint32_t members_before = 0, emitters_before = 0;
+  for (uint32_t i = 0; i < wave * JOIN_ROUNDS; ++i) { members_before += s_members[i]; emitters_before += s_emitters[i]; }
+  const uint64_t lower_lanes = (1ull << lane) - 1;
+#pragma unroll
+  for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+    const bool member = (members[k] >> lane) & 1;
+    if (member && members_before + __popcll(members[k] & lower_lanes) == cut_rank) a.slice_offsets[slice] = a.base_pairs[cell] + emitters_before + __popcll(emitters[k] & lower_lanes);
+    members_before += __popcll(members[k]);
+    emitters_before += __popcll(emitters[k]);
+  }
+}
+
 // LDS of probe_emit, in 4-byte words: staged pairs | the pair counts of a wave's current round | per-(wave, partition)
 // running counters | per-partition offsets inside the tile | global bases of the tile's cells.
 __host__ __device__ constexpr size_t probe_emit_lds_words(uint32_t partitions) {
@@ -1458,7 +2251,9 @@ static hy_status exclusive_scan(const uint32_t* in, uint64_t* out, uint64_t n, h
 // (A hipMemcpyAsync into pageable memory is a blit kernel plus a host round trip each: ~20 us of idle GPU per value.)
 struct JoinMailbox {
   uint64_t key_or, first_key, last_key;   // build side
-  uint32_t unsorted, any_null;
+  uint64_t key_min, key_max;              // ... smallest / largest key as signed 64-bit values
+  uint32_t unsorted, any_null, equal_neighbours, duplicate;   // duplicate: rank_table_mark met a key twice
+  uint32_t unsorted_signed, reserved;
   uint64_t n_pairs;                       // after pass 1
   uint32_t n_slices, n_uncached, fits;    // fits: the result's capacities hold n_pairs / n_slices
   uint32_t error;                         // pass 2: a probe row with >= 2^22 partners
@@ -1477,14 +2272,58 @@ static hy_status join_mailbox(JoinMailbox** host, JoinMailbox** device) {
   return HY_OK;
 }
 
-// flags: [0] unsorted, [2] any NULL materialised, [4..5] OR of all keys (prepare_build)
+// flags: see check_sorted; [10] a key met twice by rank_table_mark
 template <typename K>
 __global__ void publish_build_flags(const uint32_t* flags, const K* keys, uint64_t n, JoinMailbox* mailbox) {
   mailbox->unsorted = flags[0];
+  mailbox->equal_neighbours = flags[1];
   mailbox->any_null = flags[2];
+  mailbox->duplicate = flags[10];
   mailbox->key_or = *reinterpret_cast<const uint64_t*>(flags + 4);
-  mailbox->first_key = n ? key_bits(keys[0]) : 0;
-  mailbox->last_key = n ? key_bits(keys[n - 1]) : 0;
+  mailbox->unsorted_signed = flags[3];
+  mailbox->key_min = *reinterpret_cast<const uint64_t*>(flags + 6) ^ (1ull << 63);   // in signed order
+  mailbox->key_max = *reinterpret_cast<const uint64_t*>(flags + 8) ^ (1ull << 63);
+  mailbox->first_key = n ? key_bits_of(keys[0]) : 0;
+  mailbox->last_key = n ? key_bits_of(keys[n - 1]) : 0;
+  __threadfence_system();
+}
+
+// The same for a dense column read in place (dense_key_stats): first / last key = first row of the first / last row of the
+// last slice that has rows.
+__global__ __launch_bounds__(256) void publish_dense_flags(const uint64_t* partials, MaterializeArgs a, uint32_t first_slice, uint32_t last_slice, JoinMailbox* mailbox) {
+  __shared__ uint64_t s_all[4], s_low[4], s_high[4], s_bits[4];
+  const uint32_t tid = threadIdx.x;
+  uint64_t all = 0, low = ~0ull, high = 0, bits = 0;
+  for (uint32_t i = tid; i < a.n_slices; i += 256) {
+    const uint64_t* record = partials + 4 * size_t{i};
+    all |= record[0];
+    low = record[1] < low ? record[1] : low;
+    high = record[2] > high ? record[2] : high;
+    bits |= record[3];
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    all |= __shfl_xor(all, d, 64);
+    bits |= __shfl_xor(bits, d, 64);
+    const uint64_t other_low = __shfl_xor(low, d, 64), other_high = __shfl_xor(high, d, 64);
+    low = other_low < low ? other_low : low;
+    high = other_high > high ? other_high : high;
+  }
+  if ((tid & 63) == 0) { s_all[tid >> 6] = all; s_low[tid >> 6] = low; s_high[tid >> 6] = high; s_bits[tid >> 6] = bits; }
+  __syncthreads();
+  if (tid != 0) return;
+  for (uint32_t i = 1; i < 4; ++i) { all |= s_all[i]; low = s_low[i] < low ? s_low[i] : low; high = s_high[i] > high ? s_high[i] : high; bits |= s_bits[i]; }
+  mailbox->unsorted = bits & 1 ? 1 : 0;
+  mailbox->equal_neighbours = bits & 2 ? 1 : 0;
+  mailbox->unsorted_signed = bits & 4 ? 1 : 0;
+  mailbox->any_null = 0;
+  mailbox->duplicate = 0;
+  mailbox->key_or = all;
+  mailbox->key_min = low ^ (1ull << 63);
+  mailbox->key_max = high ^ (1ull << 63);
+  const Slice first = a.slices[first_slice], last = a.slices[last_slice];
+  mailbox->first_key = static_cast<uint64_t>(dense_key(a.segments[first.chunk], first.row_begin));
+  mailbox->last_key = static_cast<uint64_t>(dense_key(a.segments[last.chunk], last.row_begin + last.row_count - 1));
   __threadfence_system();
 }
 
@@ -1547,21 +2386,22 @@ struct StageClock {
 };
 
 struct BuildSide {
-  DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags;
+  DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags, rank_entries;
   uint64_t n = 0;
   Directory directory{};
+  RankTable rank{};            // rank.entries != nullptr: unique integer keys, looked up in the rank table (directory.dir is not built)
   bool any_null = false;
 };
 
 // Materialise + (sort) + directory.  `bloom_in` (device) filters the build side (no observable effect, kept for the
 // reference's element counts); `bloom_out` receives the build side's filter if wanted.
-static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, uint32_t hashed_type, BuildSide& b, hipStream_t stream) {
+static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, uint32_t hashed_type, bool allow_rank_table, BuildSide& b,
+                               hipStream_t stream) {
   const uint32_t n_slices = build->n_slices;
   DeviceBuffer counts, offsets;
   HY_TRY(counts.alloc(4 * size_t{n_slices + 1}));
   HY_TRY(offsets.alloc(8 * size_t{n_slices + 2}));
   HY_TRY(b.flags.alloc(64));
-  HY_HIP(hipMemsetAsync(b.flags.ptr, 0, 64, stream));
   if (want_bloom) {
     HY_TRY(b.bloom.alloc(BLOOM_BITS));
     HY_HIP(hipMemsetAsync(b.bloom.ptr, 0, BLOOM_BITS, stream));
@@ -1594,6 +2434,59 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     HY_HIP(hipStreamSynchronize(stream));
   }
   b.n = total;
+  // A dense column that may be a primary key: look at it in place first (statistics), and if it is sorted, duplicate-free
+  // and not too sparse fill the rank table from it -- no key array, no RowID array (a key's rank is its row number).
+  bool uniform_chunks = dense && build->n_chunks > 0;
+  for (uint32_t c = 1; c < build->n_chunks && uniform_chunks; ++c) {
+    const uint32_t size = build->host_segments[c].size, first_size = build->host_segments[0].size;
+    uniform_chunks = first_size > 0 && (c + 1 == build->n_chunks ? size <= first_size : size == first_size);
+  }
+  if (dense && total && uniform_chunks && build->host_segments[0].size > 0 && allow_rank_table && !getenv("HY_JOIN_NO_RANK_TABLE") && !getenv("HY_JOIN_NO_IDENTITY")) {
+    uint32_t first_slice = 0, last_slice = 0;   // slices with rows (the host knows the chunk sizes: slices are per chunk, in order)
+    {
+      std::vector<uint32_t> rows_of_slice;
+      for (uint32_t c = 0; c < build->n_chunks; ++c) {
+        const uint32_t size = build->host_segments[c].size;
+        const uint32_t chunk_slices = (size + SLICE_ROWS - 1) / SLICE_ROWS;
+        for (uint32_t i = 0; i < (chunk_slices ? chunk_slices : 1); ++i) rows_of_slice.push_back(size > i * SLICE_ROWS ? std::min(SLICE_ROWS, size - i * SLICE_ROWS) : 0);
+      }
+      if (rows_of_slice.size() != n_slices) return fail(HY_ERR_DEVICE, "join: slice table of the build column is inconsistent");
+      first_slice = n_slices;
+      for (uint32_t i = 0; i < n_slices; ++i) if (rows_of_slice[i]) { if (first_slice == n_slices) first_slice = i; last_slice = i; }
+    }
+    JoinMailbox* mailbox = nullptr;
+    JoinMailbox* mailbox_dev = nullptr;
+    HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
+    DeviceBuffer partials;
+    HY_TRY(partials.alloc(32 * size_t{n_slices}));
+    hipLaunchKernelGGL(dense_key_stats, dim3(n_slices), dim3(256), 0, stream, m, partials.as<uint64_t>());
+    hipLaunchKernelGGL(publish_dense_flags, dim3(1), dim3(256), 0, stream, partials.as<uint64_t>(), m, first_slice, last_slice, mailbox_dev);
+    HY_HIP(hipStreamSynchronize(stream));
+    const uint64_t key_min = mailbox->key_min, range = mailbox->key_max - mailbox->key_min;
+    const uint64_t words = (range >> 5) + 1;
+    if (getenv("HY_JOIN_TIMING")) fprintf(stderr, "  dense stats: min %lld max %lld unsorted %u signed %u equal %u total %llu\n", (long long)mailbox->key_min, (long long)mailbox->key_max, mailbox->unsorted, mailbox->unsorted_signed, mailbox->equal_neighbours, (unsigned long long)total);
+    if (!mailbox->unsorted_signed && !mailbox->equal_neighbours && range < 0xFFFFFF00ull && words <= 2 * total + 4096) {
+      HY_TRY(b.rank_entries.alloc(8 * (words + 1)));
+      u32x2_t* entries = b.rank_entries.as<u32x2_t>();
+      HY_HIP(hipMemsetAsync(entries, 0, 8 * (words + 1), stream));
+      hipLaunchKernelGGL(rank_table_fill_dense, dim3(n_slices), dim3(256), 0, stream, m, key_min, entries);
+      b.rank.entries = entries;
+      b.rank.key_min = key_min;
+      b.rank.range = range;
+      b.rank.identity_rows = build->host_segments[0].size;
+      b.rank.identity_inverse = 1.0 / static_cast<double>(b.rank.identity_rows);
+      Directory& d = b.directory;   // nothing but the extent: the probe needs neither keys nor RowIDs
+      d = Directory{};
+      d.n = total;
+      d.key_min = mailbox->key_min;
+      d.key_max = mailbox->key_max;
+      d.n_buckets = 1;
+      return HY_OK;
+    }
+    // (not a primary key after all: materialise as usual)
+  }
+  HY_HIP(hipMemsetAsync(b.flags.ptr, 0, 64, stream));
+  HY_HIP(hipMemsetAsync(b.flags.as<uint32_t>() + 6, 0xFF, 8, stream));   // the running minimum
   const bool key32 = build->data_type == HY_TYPE_INT && hashed_type == 0, id32 = want_ids32;
   const size_t key_bytes = key32 ? 4 : 8, row_bytes = id32 ? 4 : 8;
   uint64_t first_key = 0, last_key = 0;
@@ -1624,17 +2517,15 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       hipLaunchKernelGGL((join_materialize<1, false, false>), dim3(n_slices), dim3(256), 0, stream, m);
     }
     if (key32) HY_HIP(hipMemsetAsync(b.keys.as<uint32_t>() + total, 0, 16, stream));
-    uint32_t* unsorted = b.flags.as<uint32_t>();
-    unsigned long long* key_or = reinterpret_cast<unsigned long long*>(b.flags.as<uint32_t>() + 4);
     JoinMailbox* mailbox = nullptr;
     JoinMailbox* mailbox_dev = nullptr;
     HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
     const dim3 check_grid(static_cast<uint32_t>(std::min<uint64_t>((total + 1023) / 1024, 1024)));
     if (key32) {
-      hipLaunchKernelGGL(check_sorted<uint32_t>, check_grid, dim3(1024), 0, stream, b.keys.as<uint32_t>(), total, unsorted, key_or);
+      hipLaunchKernelGGL(check_sorted<uint32_t>, check_grid, dim3(1024), 0, stream, b.keys.as<uint32_t>(), total, b.flags.as<uint32_t>());
       hipLaunchKernelGGL(publish_build_flags<uint32_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint32_t>(), total, mailbox_dev);
     } else {
-      hipLaunchKernelGGL(check_sorted<uint64_t>, check_grid, dim3(1024), 0, stream, b.keys.as<uint64_t>(), total, unsorted, key_or);
+      hipLaunchKernelGGL(check_sorted<uint64_t>, check_grid, dim3(1024), 0, stream, b.keys.as<uint64_t>(), total, b.flags.as<uint32_t>());
       hipLaunchKernelGGL(publish_build_flags<uint64_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint64_t>(), total, mailbox_dev);
     }
     HY_HIP(hipStreamSynchronize(stream));
@@ -1642,6 +2533,79 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     keys_were_sorted = mailbox->unsorted == 0;
     first_key = mailbox->first_key;   // min / max if the keys are already sorted
     last_key = mailbox->last_key;
+    // Unique integer keys that are not too sparse: the rank table (struct RankTable) instead of sort + directory.
+    bool rank_table = false;
+    {
+      const uint64_t key_min = mailbox->key_min, range = mailbox->key_max - mailbox->key_min;
+      const uint64_t words = (range >> 5) + 1;
+      if (allow_rank_table && hashed_type == 0 && !b.any_null && !mailbox->equal_neighbours && range < 0xFFFFFF00ull && words <= 2 * total + 4096 &&
+          !getenv("HY_JOIN_NO_RANK_TABLE")) {
+        HY_TRY(b.rank_entries.alloc(8 * (words + 1)));
+        u32x2_t* entries = b.rank_entries.as<u32x2_t>();
+        HY_HIP(hipMemsetAsync(entries, 0, 8 * (words + 1), stream));
+        const dim3 key_grid(static_cast<uint32_t>((total + 255) / 256));
+        const bool sorted_signed = mailbox->unsorted_signed == 0;
+        if (sorted_signed) {
+          if (key32) hipLaunchKernelGGL(rank_table_fill_sorted<uint32_t>, key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), total, key_min, entries);
+          else hipLaunchKernelGGL(rank_table_fill_sorted<uint64_t>, key_grid, dim3(256), 0, stream, b.keys.as<uint64_t>(), total, key_min, entries);
+          rank_table = true;
+        } else {
+          if (key32) {
+            hipLaunchKernelGGL(rank_table_mark<uint32_t>, key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), total, key_min, entries, b.flags.as<uint32_t>() + 10);
+            hipLaunchKernelGGL(publish_build_flags<uint32_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint32_t>(), total, mailbox_dev);
+          } else {
+            hipLaunchKernelGGL(rank_table_mark<uint64_t>, key_grid, dim3(256), 0, stream, b.keys.as<uint64_t>(), total, key_min, entries, b.flags.as<uint32_t>() + 10);
+            hipLaunchKernelGGL(publish_build_flags<uint64_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint64_t>(), total, mailbox_dev);
+          }
+          HY_HIP(hipStreamSynchronize(stream));
+          if (!mailbox->duplicate) {   // bases by a scan over the words' population counts, then every RowID goes to its key's rank
+            const uint32_t n_blocks = static_cast<uint32_t>((words + RANK_BLOCK - 1) / RANK_BLOCK);
+            DeviceBuffer sums;
+            HY_TRY(sums.alloc(8 * (size_t{n_blocks} + 1)));
+            hipLaunchKernelGGL(rank_table_block_sums, dim3(n_blocks), dim3(256), 0, stream, entries, words, sums.as<uint64_t>());
+            hipLaunchKernelGGL(scan_block_offsets, dim3(1), dim3(1024), 0, stream, sums.as<uint64_t>(), n_blocks, 0xFFFFFFFFu, sums.as<uint64_t>() + n_blocks);
+            hipLaunchKernelGGL(rank_table_bases, dim3(n_blocks), dim3(256), 0, stream, entries, words, sums.as<uint64_t>());
+            HY_TRY(b.rows_tmp.alloc(row_bytes * total));
+            if (key32 && id32) hipLaunchKernelGGL((rank_table_scatter_rows<uint32_t, uint32_t>), key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), b.rows.as<uint32_t>(), b.rows_tmp.as<uint32_t>(), total, key_min, entries);
+            else if (key32) hipLaunchKernelGGL((rank_table_scatter_rows<uint32_t, hy_row_id>), key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), b.rows.as<hy_row_id>(), b.rows_tmp.as<hy_row_id>(), total, key_min, entries);
+            else if (id32) hipLaunchKernelGGL((rank_table_scatter_rows<uint64_t, uint32_t>), key_grid, dim3(256), 0, stream, b.keys.as<uint64_t>(), b.rows.as<uint32_t>(), b.rows_tmp.as<uint32_t>(), total, key_min, entries);
+            else hipLaunchKernelGGL((rank_table_scatter_rows<uint64_t, hy_row_id>), key_grid, dim3(256), 0, stream, b.keys.as<uint64_t>(), b.rows.as<hy_row_id>(), b.rows_tmp.as<hy_row_id>(), total, key_min, entries);
+            std::swap(b.rows.ptr, b.rows_tmp.ptr);
+            std::swap(b.rows.capacity, b.rows_tmp.capacity);
+            rank_table = true;
+          }
+        }
+        if (rank_table) {
+          b.rank.entries = entries;
+          b.rank.key_min = key_min;
+          b.rank.range = range;
+          // a dense, sorted build column with equally sized chunks: the build row of rank r is row r of the table
+          bool uniform = dense && sorted_signed && build->n_chunks > 0 && build->host_segments[0].size > 0;
+          for (uint32_t c = 1; c < build->n_chunks && uniform; ++c) {
+            const uint32_t size = build->host_segments[c].size, first_size = build->host_segments[0].size;
+            uniform = c + 1 == build->n_chunks ? size <= first_size : size == first_size;
+          }
+          if (uniform && !getenv("HY_JOIN_NO_IDENTITY")) {
+            b.rank.identity_rows = build->host_segments[0].size;
+            b.rank.identity_inverse = 1.0 / static_cast<double>(b.rank.identity_rows);
+          }
+        }
+      }
+    }
+    if (rank_table) {
+      Directory& d = b.directory;   // only the RowIDs by rank
+      d.keys = nullptr;
+      d.keys32 = nullptr;
+      d.row_ids = id32 ? nullptr : b.rows.as<hy_row_id>();
+      d.ids32 = id32 ? b.rows.as<uint32_t>() : nullptr;
+      d.n = total;
+      d.key_min = mailbox->key_min;
+      d.key_max = mailbox->key_max;
+      d.shift = 0;
+      d.n_buckets = 1;
+      d.dir = nullptr;
+      return HY_OK;
+    }
     if (mailbox->unsorted) {   // not sorted: stable LSD radix sort, only over the bytes that are not constant zero
       const uint64_t key_bits_or = mailbox->key_or;
       HY_TRY(b.keys_tmp.alloc(key_bytes * (total + 4)));
@@ -1722,6 +2686,17 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   return HY_OK;
 }
 
+static uint32_t device_cu_count();
+// Persistent waves that take one tile at a time (rt_stream_count), STREAM_WAVES per workgroup: as many as fit the device at once
+// (a multiple of the 8 XCDs), never more than there are tiles.
+static uint32_t stream_grid(uint32_t n_tiles, int workgroups_per_cu) {
+  uint32_t per_cu = workgroups_per_cu > 0 ? static_cast<uint32_t>(workgroups_per_cu) : 1;
+  if (const char* env = getenv("HY_JOIN_WGS_PER_CU")) per_cu = static_cast<uint32_t>(atoi(env));
+  const uint32_t resident = device_cu_count() * per_cu / 8 * 8;
+  const uint32_t needed = 8 * (((n_tiles + 7) / 8 + STREAM_WAVES - 1) / STREAM_WAVES);   // a wave per tile of every XCD's share
+  return std::max<uint32_t>(8, std::min<uint32_t>(resident, needed));
+}
+
 static uint32_t device_cu_count() {
   int device = 0, cus = 256;
   (void)hipGetDevice(&device);
@@ -1729,6 +2704,7 @@ static uint32_t device_cu_count() {
   return static_cast<uint32_t>(cus);
 }
 
+static thread_local int t_last_join_used_rank_table = 0;   // debug / tests: which lookup structure the thread's last join built
 constexpr uint32_t JOIN_TRACE_TILES = 1u << 15;
 static uint64_t* g_join_trace = nullptr;
 static uint32_t g_join_trace_tiles = 0;
@@ -1799,7 +2775,16 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   for (uint32_t c = 0; c < build->n_chunks && pack_build_ids; ++c) pack_build_ids = build->host_segments[c].size <= 65536;
   BuildSide b;
   StageClock clock;
-  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, b, stream));
+  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, b, stream));
+  const bool rank_path = b.rank.entries != nullptr;
+  // the probe column's segments are all ones a SliceView describes (int32 values / FrameOfReference offsets, no NULLs): the
+  // pipelined instantiations of the rank-table passes
+  bool fetch_ahead = rank_path && !probe->is_reference && !getenv("HY_JOIN_NO_FETCH_AHEAD");
+  for (uint32_t c = 0; c < probe->n_chunks && fetch_ahead; ++c) {
+    const hy_segment& seg = probe->host_segments[c];
+    fetch_ahead = !seg.nulls && ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
+  }
+  t_last_join_used_rank_table = rank_path ? (b.rank.identity_rows ? 2 : 1) : 0;
   clock.mark("build side launched");
 
   if (result) {
@@ -1824,10 +2809,10 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   DeviceBuffer hist, base;
   HY_TRY(hist.alloc(4 * (second_at + cells + 1)));
   HY_TRY(base.alloc(8 * (second_at + cells + 2)));
-  HY_HIP(hipMemsetAsync(hist.as<uint32_t>() + cells, 0, 4 * (second_at - cells), stream));
   ProbeArgs a{};
   a.segments = probe->d_segments;
   a.slices = probe->d_slices;
+  a.views = probe->d_slice_views;
   a.n_tiles = n_tiles;
   a.mode = mode;
   a.radix_bits = radix_bits;
@@ -1835,6 +2820,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.build_rows_zero = build->rows == 0;
   a.build_bloom = probe_filtered ? b.bloom.as<uint8_t>() : nullptr;
   a.dir = b.directory;
+  a.rank = b.rank;
   a.trace = nullptr;
   if (getenv("HY_JOIN_TRACE")) {
     static uint64_t* trace_buffer = nullptr;
@@ -1854,7 +2840,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.base_elements = base.as<uint64_t>();
   a.base_pairs = base.as<uint64_t>() + second_at;
   DeviceBuffer d_partner, d_meta, d_uncached;
-  if (!count_only && n_tiles) {   // pass 2 follows: let pass 1 leave its lookup results behind (6 B per probe row)
+  if (!count_only && n_tiles && !rank_path) {   // pass 2 follows: let pass 1 leave its lookup results behind (6 B per probe row; a rank table is looked up again)
     HY_TRY(d_partner.alloc(4 * size_t{n_tiles} * JOIN_TILE));
     HY_TRY(d_meta.alloc(2 * size_t{n_tiles} * JOIN_TILE));
     HY_TRY(d_uncached.alloc(4 * size_t{n_tiles} * 2));   // flags | work list of probe_emit_generic
@@ -1868,7 +2854,8 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
   DeviceBuffer d_words;   // [0] pass 1's error flag (unused), [1] tiles with multi-partner rows, [8..15] XCD tickets, [16..17] JoinPlan
   HY_TRY(d_words.alloc(256));
-  HY_HIP(hipMemsetAsync(d_words.ptr, 0, 128, stream));
+  hipLaunchKernelGGL(zero_two, dim3(static_cast<uint32_t>(std::min<uint64_t>(64, (second_at - cells + 32 + 255) / 256))), dim3(256), 0, stream, hist.as<uint32_t>() + cells, size_t{second_at - cells},
+                     d_words.as<uint32_t>(), size_t{32});   // the zeros between pass 1's two count arrays | the words above
   a.error = &mailbox_dev->error;
   a.n_uncached = d_words.as<uint32_t>() + 1;
   a.xcd_tickets = d_words.as<uint32_t>() + 8;
@@ -1917,7 +2904,13 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
 
   // pass 1, the scan of its counts, the plan of the output -- no host round trip in between
   if (n_tiles) {
-    if (general) hipLaunchKernelGGL(probe_count<true>, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
+    if (rank_path && fetch_ahead) {
+      int per_cu = 0;
+      HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rt_stream_count), 64 * STREAM_WAVES, 4 * stream_count_lds_words(partitions)));
+      hipLaunchKernelGGL(rt_stream_count, dim3(stream_grid(n_tiles, per_cu)), dim3(64 * STREAM_WAVES), 4 * stream_count_lds_words(partitions), stream, a);
+    } else if (rank_path) {
+      hipLaunchKernelGGL(rt_probe_count, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
+    } else if (general) hipLaunchKernelGGL(probe_count<true>, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
     else hipLaunchKernelGGL(probe_count<false>, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 0, stream, a);
     HY_TRY(exclusive_scan(hist.as<uint32_t>(), base.as<uint64_t>(), second_at + cells, stream, second_at));
   } else {
@@ -1948,15 +2941,22 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   a.build_out = semi_anti ? nullptr : dev_build;
   a.probe_out = dev_probe;
   a.slice_offsets = dev_slice_offsets;
-  if (n_tiles) {   // (every pass 2 kernel returns at once if the plan says that the result does not fit)
-    static std::atomic<bool> lds_raised{false};   // (joins run from any thread; setting the attributes twice is harmless)
+  static std::atomic<bool> lds_raised{false};   // (joins run from any thread; setting the attributes twice is harmless)
+  if (n_tiles && !lds_raised.load(std::memory_order_acquire)) {
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_cached), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_cached_lds_words(MAX_PARTITIONS)));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rt_probe_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * rt_probe_emit_lds_words(MAX_PARTITIONS)));
+    lds_raised.store(true, std::memory_order_release);
+  }
+  if (n_tiles && rank_path) {   // (every pass 2 kernel returns at once if the plan says that the result does not fit)
+    profile_begin(stream);
+    hipLaunchKernelGGL(rt_probe_emit, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * rt_probe_emit_lds_words(partitions), stream, a);
+    profile_end(stream);
+    const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
+    if (cut_grid) hipLaunchKernelGGL(rt_probe_cuts, dim3(cut_grid), dim3(JOIN_THREADS), 0, stream, a, dev_first_cell, n_groups);
+  } else if (n_tiles) {
     uint32_t workgroups_per_cu = 1;
-    if (!lds_raised.load(std::memory_order_acquire)) {
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_cached), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_cached_lds_words(MAX_PARTITIONS)));
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
-      lds_raised.store(true, std::memory_order_release);
-    }
     {
       int per_cu = 0;
       HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(probe_emit_cached), JOIN_THREADS, 4 * probe_emit_cached_lds_words(partitions)));
@@ -2025,6 +3025,9 @@ hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint
   *radix_bits = calculate_radix_bits(build_rows);
   return HY_OK;
 }
+
+// debug / tests only: 0 = the last join of this thread probed the sorted directory, 1 = a rank table, 2 = a rank table whose ranks are row numbers
+int hy_debug_join_used_rank_table(void) { return t_last_join_used_rank_table; }
 
 // debug only (HY_JOIN_TRACE): the per-tile phase stamps of the last join's probe_emit; not part of the public header
 int hy_debug_join_trace(uint64_t* out, uint32_t capacity_tiles) {

@@ -531,6 +531,21 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   if (err == hipSuccess) err = hipMemcpy(column->d_segments, dev.data(), sizeof(DevSegment) * dev.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_slices), sizeof(Slice) * (slices.size() + 1));
   if (err == hipSuccess && !slices.empty()) err = hipMemcpy(column->d_slices, slices.data(), sizeof(Slice) * slices.size(), hipMemcpyHostToDevice);
+  std::vector<SliceView> views(slices.size());
+  for (size_t i = 0; i < slices.size(); ++i) {
+    const hy_segment& s = column->host_segments[slices[i].chunk];
+    SliceView& v = views[i];
+    v.data = s.data;
+    v.aux = s.aux;
+    v.chunk = slices[i].chunk;
+    v.row_begin = slices[i].row_begin;
+    v.row_count = slices[i].row_count;
+    v.kind = VIEW_GENERIC;
+    if (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !s.nulls) v.kind = VIEW_INT32;
+    if (s.encoding == HY_ENC_FRAME_OF_REFERENCE && !s.nulls) v.kind = s.width == 1 ? VIEW_FOR8 : s.width == 2 ? VIEW_FOR16 : VIEW_FOR32;
+  }
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_slice_views), sizeof(SliceView) * (views.size() + 1));
+  if (err == hipSuccess && !views.empty()) err = hipMemcpy(column->d_slice_views, views.data(), sizeof(SliceView) * views.size(), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_row_base), 8 * (size_t{n_chunks} + 1));
   if (err == hipSuccess) err = hipMemcpy(column->d_row_base, column->row_base.data(), 8 * (size_t{n_chunks} + 1), hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_parts), sizeof(Part) * (parts.size() + 1));
@@ -546,6 +561,7 @@ hy_status hy_column_destroy(hy_column* column) {
   for (auto& block : column->pooled) pool_release(block.second, block.first);
   if (column->d_segments) (void)hipFree(column->d_segments);
   if (column->d_slices) (void)hipFree(column->d_slices);
+  if (column->d_slice_views) (void)hipFree(column->d_slice_views);
   if (column->d_parts) (void)hipFree(column->d_parts);
   if (column->d_row_base) (void)hipFree(column->d_row_base);
   delete column;

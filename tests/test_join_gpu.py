@@ -460,3 +460,89 @@ def test_join_string_keys_as_join_ids(device, mode):
         for k in rng.integers(0, got.n_pairs, 200):
             l, r = got.left[k], got.right[k]
             assert lvals[int(l[0]) * 4096 + int(l[1])] == rvals[int(r[0]) * 4096 + int(r[1])]
+
+
+def used_rank_table():
+    lib = abi.load_library()
+    lib.hy_debug_join_used_rank_table.restype = C.c_int
+    return int(lib.hy_debug_join_used_rank_table())
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_join_unique_build_keys_take_the_rank_table(device, mode):
+    """Unique integer build keys (primary keys) are looked up in the rank table (csrc/join.hip: RankTable): sorted and
+    shuffled build sides, sparse keys (TPC-H's 8 of every 32), negative keys, probe NULLs and probe keys outside the build
+    range, every radix setting; pairs and 131 070-element cuts bit-identical to the oracle."""
+    rng = np.random.default_rng(100 + mode)
+    n_build, n_probe = 20000, 150000
+    i = np.arange(1, n_build + 1, dtype=np.int64)
+    sparse = (((i >> 3) << 5) | (i & 7)).astype(np.int32)
+    dense_negative = (np.arange(n_build, dtype=np.int32) - 7000)
+    for name, keys in (("sparse", sparse), ("dense_negative", dense_negative)):
+        probe_values = rng.choice(keys, n_probe).astype(np.int32)
+        outside = rng.random(n_probe) < 0.03
+        probe_values[outside] = rng.integers(int(keys.min()) - 500, int(keys.max()) + 500, int(outside.sum())).astype(np.int32)
+        probe_nulls = rng.random(n_probe) < 0.02
+        sorted_probe = np.sort(probe_values)
+        for shuffled in (False, True):
+            build_values = rng.permutation(keys) if shuffled else keys
+            for build_encoding, probe_encoding, chunk in ((abi.ENC_UNENCODED, abi.ENC_FRAME_OF_REFERENCE, 4096), (abi.ENC_DICTIONARY, abi.ENC_UNENCODED, 3000)):
+                build = build_column(build_values, None, chunk, build_encoding)
+                for pname, pvalues, pnulls in (("random", probe_values, probe_nulls), ("sorted", sorted_probe, None)):
+                    probe = build_column(pvalues, pnulls, 65535, probe_encoding)
+                    for radix_bits in (None, 0, 3, 8):
+                        context = f"mode {mode} {name} shuffled {shuffled} enc {build_encoding} probe {pname} radix {radix_bits}"
+                        if mode in SEMI or mode == abi.JOIN_LEFT:
+                            check(probe, build, mode, radix_bits, context)
+                        else:
+                            check(build, probe, mode, radix_bits, context)
+                        assert used_rank_table() in (1, 2), context
+                        if build_encoding == abi.ENC_UNENCODED and not shuffled and mode == abi.JOIN_INNER:
+                            assert used_rank_table() == 2, context   # dense, sorted, equally sized chunks: ranks are row numbers
+
+
+def test_join_rank_table_int64_and_reference_build(device):
+    rng = np.random.default_rng(77)
+    keys = (np.arange(5000, dtype=np.int64) * 3 + 10_000_000_000)
+    build = build_column(rng.permutation(keys), None, 1000, abi.ENC_UNENCODED)
+    probe = build_column(rng.choice(keys, 40000) + rng.integers(0, 2, 40000), rng.random(40000) < 0.05, 7000, abi.ENC_DICTIONARY)
+    for mode in MODES:
+        if mode in SEMI or mode == abi.JOIN_LEFT:
+            check(probe, build, mode, 2, f"int64 mode {mode}")
+        else:
+            check(build, probe, mode, 2, f"int64 mode {mode}")
+        assert used_rank_table() == 1
+    # a filtered dimension table as the build side: reference segments over unique keys, ascending
+    base = build_column(np.arange(0, 9000, 3, dtype=np.int32), None, 1000, abi.ENC_UNENCODED)
+    pos = [np.stack([np.full(300, c, dtype=np.uint32), np.sort(rng.choice(1000, 300, replace=False)).astype(np.uint32)], axis=1) for c in range(base.n_chunks)]
+    ref = storage.make_reference_column(base, pos, list(range(base.n_chunks)))
+    fact = build_column(rng.integers(0, 9000, 50000).astype(np.int32), None, 65535, abi.ENC_UNENCODED)
+    db, df = DeviceColumn(base), DeviceColumn(fact)
+    dr = DeviceColumn(ref, refs={id(base): db})
+    for mode in (abi.JOIN_INNER, abi.JOIN_RIGHT):
+        got = join_hash(dr, df, mode, None)
+        want = oracle_join(ref, fact, mode, None)
+        assert_join_equal(got, want, mode, f"reference build mode {mode}")
+        assert used_rank_table() == 1
+
+
+def test_join_rank_table_falls_back(device, monkeypatch):
+    """Duplicate build keys (found while the table is marked) and sparse key ranges use the sorted directory; so does
+    HY_JOIN_NO_RANK_TABLE, with identical results."""
+    rng = np.random.default_rng(5)
+    keys = rng.permutation(np.arange(3000, dtype=np.int32))
+    keys[17] = keys[2900]   # one duplicate, far apart
+    build = build_column(keys, None, 500, abi.ENC_UNENCODED)
+    probe = build_column(rng.integers(0, 3000, 20000).astype(np.int32), None, 4000, abi.ENC_UNENCODED)
+    check(build, probe, abi.JOIN_INNER, 2, "duplicate")
+    assert used_rank_table() == 0
+    sparse = build_column((np.arange(2000, dtype=np.int64) * 1_000_003).astype(np.int32), None, 500, abi.ENC_UNENCODED)
+    check(sparse, probe, abi.JOIN_INNER, 2, "sparse")
+    assert used_rank_table() == 0
+    unique = build_column(np.arange(3000, dtype=np.int32), None, 500, abi.ENC_UNENCODED)
+    a = check(unique, probe, abi.JOIN_INNER, 2, "rank table")
+    assert used_rank_table() == 2
+    monkeypatch.setenv("HY_JOIN_NO_RANK_TABLE", "1")
+    b = check(unique, probe, abi.JOIN_INNER, 2, "directory")
+    assert used_rank_table() == 0
+    assert a.left[:a.n_pairs].tobytes() == b.left[:b.n_pairs].tobytes() and a.right[:a.n_pairs].tobytes() == b.right[:b.n_pairs].tobytes()

@@ -14,7 +14,7 @@ dev = torch.device("cuda")
 n = data.n_lineitems
 left = torch.empty((n,2), dtype=torch.int32, device=dev); right = torch.empty((n,2), dtype=torch.int32, device=dev)
 so = torch.zeros(2000, dtype=torch.int64, device=dev)
-r = abi.JoinResult(); r.mem = abi.MEM_DEVICE; r.radix_bits = 0xFFFFFFFF; r.left_pos = left.data_ptr(); r.right_pos = right.data_ptr(); r.capacity = n; r.slice_offsets = so.data_ptr(); r.slice_capacity = 1990
+r = abi.JoinResult(); r.mem = abi.MEM_DEVICE; r.radix_bits = int(os.environ.get('RADIX', '0xFFFFFFFF'), 0); r.left_pos = left.data_ptr(); r.right_pos = right.data_ptr(); r.capacity = n; r.slice_offsets = so.data_ptr(); r.slice_capacity = 1990
 for i in range(3):
     torch.cuda.synchronize(); t=time.perf_counter()
     abi.check(lib.hy_join_hash(do.handle, dl.handle, abi.JOIN_INNER, C.byref(r)))
@@ -27,7 +27,7 @@ if os.environ.get("HY_JOIN_TRACE"):
     t = buf[:nt].astype(np.int64)
     t = t[t[:, 5] > 0]
     d = np.diff(t, axis=1) / 100.0   # us
-    names = ["loads+count", "prefix", "ranking", "sync", "copy-out"]
+    names = ["evaluate", "clear+count", "prefix", "ranking+sync", "copy-out"] if os.environ.get("HY_JOIN_NO_RANK_TABLE") is None else ["loads+count", "prefix", "ranking", "sync", "copy-out"]
     print("probe_emit tiles", len(t), "kernel span us", (t[:, 5].max() - t[:, 0].min()) / 100.0)
     for i, nme in enumerate(names):
         print(f"  {nme:12s} mean {d[:, i].mean():7.2f} p50 {np.percentile(d[:, i], 50):7.2f} p90 {np.percentile(d[:, i], 90):7.2f}")
