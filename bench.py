@@ -4,17 +4,21 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload at every N: config 2 of BASELINE.json -- TableScan ColumnVsValue on a TPC-H SF10 lineitem `l_shipdate`
+Timed workload at every N: config 2 of BASELINE.json -- TableScan ColumnVsValue on a TPC-H SF10 lineitem `l_shipdate`
 column (59 986 052 rows, 916 chunks of 65 535, DictionarySegment<int32> + FixedWidthInteger u16 attribute vectors),
 predicate `l_shipdate < 1995-01-01` (the reference's own micro-benchmark predicate,
 src/benchmark/tpch_data_micro_benchmark.cpp:65-67).  One step = one hy_table_scan over the whole column with the
-column resident in HBM and the PosLists written to HBM.  With N GPUs every rank scans its own SF10-shaped shard of an
-N x SF10 table (chunks shard naturally, no data-path collective: SURVEY.md section 8(e)) -> weak scaling.
+column resident in HBM and the PosLists written to HBM; the steps rotate over three copies of the column (3 x 120 MB +
+480 MB of PosLists: nothing the kernel touches is still in the 256 MiB Infinity Cache when it comes round again).  With N
+GPUs every rank scans its own SF10-shaped shard of an N x SF10 table (chunks shard naturally, no data-path collective:
+SURVEY.md section 8(e)) -> weak scaling; the line then also carries the strong-scaling scan (ONE SF10 table split over the
+ranks), the sharded AggregateHash (per-rank partials + one all-reduce over RCCL) and the sharded JoinHash (broadcast-build
+by all-gather, and hash repartition by all-to-all) -- `multi_gpu` object, hyrise_amd/distributed.py.
 
-Prints ONE JSON line on rank 0: rows/s over the whole job, plus `roofline` (scan_slices kernel: algorithmic bytes /
-HIP-event duration vs. the 8 TB/s HBM peak) and `cpu_baseline` (the CPU restatement of the Hyrise operator on the
-host cores, rank 0, N=1 only).  At N=1 the line also carries `join` and `aggregate` objects: the SF10 orders x lineitem
-JoinHash and the TPC-H Q1-core AggregateHash on the same GPU (configs 3 and 4 of BASELINE.json), outside the timed region.
+Prints ONE JSON line on rank 0: rows/s over the whole job, `roofline` (scan_slices: algorithmic bytes / HIP-event duration
+vs. the 8 TB/s HBM peak) and `cpu_baseline` (the CPU restatement of the Hyrise operator on the host cores, rank 0, N=1
+only).  At N=1 the line also carries `join` and `aggregate` objects -- configs 3 and 4 of BASELINE.json on the same GPU, each
+with its own roofline and cpu_baseline -- and `cases`: the other predicates / encodings / key orders SURVEY.md 8(d) lists.
 """
 import argparse
 import ctypes as C
@@ -28,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PROFILE_EVERY = 4               # every 4th scan of the timed region carries the HIP event pair (a timed launch costs ~7 us of stream time)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+COLUMN_COPIES = 3               # > 256 MiB of column data in rotation
 
 
 def parse_args():
@@ -37,50 +42,90 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=0, help="override row count (debug); 0 = SF10 lineitem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cases", action="store_true", help="also time the Q1/Q6/point predicates (extra JSON field)")
-    ap.add_argument("--no-join", action="store_true", help="skip the JoinHash orders x lineitem leg (extra JSON field)")
-    ap.add_argument("--no-aggregate", action="store_true", help="skip the AggregateHash Q1-core leg (extra JSON field)")
+    ap.add_argument("--no-cases", action="store_true", help="skip the extra scan / join cases (N = 1)")
+    ap.add_argument("--no-join", action="store_true", help="skip the JoinHash orders x lineitem leg")
+    ap.add_argument("--no-aggregate", action="store_true", help="skip the AggregateHash Q1-core leg")
+    ap.add_argument("--no-multi", action="store_true", help="N > 1: skip the strong-scaling / aggregate / join legs")
     return ap.parse_args()
 
 
-def cpu_baseline(host_column, predicate, rows, budget_s=12.0):
-    """CPU restatement of the Hyrise TableScan (oracle/, kind 'port'), all host cores, one job per chunk range
-    (table_scan.cpp:223-229).  The ONLY place bench.py touches the oracle: a reported baseline, never the product."""
+def oracle_support():
+    """tests/support.py: the ctypes side of the CPU oracle.  The ONLY use of oracle/ in this file is the cpu_baseline
+    objects: reported baselines, never the product."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import support
+    return support
+
+
+def median_time(run, budget_s, min_runs=3, max_runs=25):
+    run()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < min_runs or (time.perf_counter() < t_end and len(times) < max_runs):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], len(times)
+
+
+def cpu_baseline_scan(host_column, predicate, rows, budget_s=10.0):
+    """CPU restatement of the Hyrise TableScan (oracle/, kind 'port'), all host cores, one job per chunk range
+    (table_scan.cpp:223-229)."""
+    support = oracle_support()
     from hyrise_amd.operators import HostScanResult
     cores = os.cpu_count() or 1
     # column descriptors and the PosList buffers are set up once (a Hyrise operator writes into pooled memory, it does not
-    # page-fault 480 MB of fresh output per scan); the first call below touches every page
+    # page-fault 480 MB of fresh output per scan); the first call touches every page
     column = support.OracleCol(host_column)
     result = HostScanResult(host_column.n_chunks, host_column.rows, 0)
     scan = support.oracle().hyo_table_scan
 
     def run():
-        status = scan(C.byref(column.c), C.byref(predicate), C.byref(result.c), cores)
-        if status != 0:
-            raise SystemExit(f"oracle scan failed with {status}")
+        if scan(C.byref(column.c), C.byref(predicate), C.byref(result.c), cores) != 0:
+            raise SystemExit("oracle scan failed")
 
     run()
-    run()
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 25):
-        t0 = time.perf_counter()
-        run()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    median = times[len(times) // 2]
+    median, n = median_time(run, budget_s)
     return {"value": rows / median, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": f"full {rows}-row l_shipdate column, same predicate, median of {len(times)} runs "
-                      f"({median * 1e3:.1f} ms each), CPU restatement of Hyrise's TableScan (not Hyrise itself)"}
+            "sample": f"full {rows}-row l_shipdate column, same predicate, median of {n} runs ({median * 1e3:.1f} ms each), "
+                      "CPU restatement of Hyrise's TableScan (not Hyrise itself)"}
 
 
-def committed_traffic():
-    """HBM bytes per scan_slices launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled as
-    the gfx950 guide prescribes, + WRITE_SIZE; collected by tools/profile_scan.sh on the same command).  None when no
-    profile of this round is committed."""
-    path = os.path.join(ROOT, "profiles", "scan_pmc.json")
+def cpu_baseline_join(orders, lineitem, rows, budget_s=12.0):
+    """The oracle's JoinHash (materialise -> radix-partition -> build -> probe with the reference's radix_bits, one job per
+    chunk / partition: join_hash.cpp:270-572), all host cores."""
+    support = oracle_support()
+    from hyrise_amd import abi
+    cores = os.cpu_count() or 1
+
+    def run():
+        support.oracle_join(orders, lineitem, abi.JOIN_INNER, None, threads=cores, capacity=lineitem.rows + 1024)
+
+    median, n = median_time(run, budget_s, min_runs=2, max_runs=5)
+    return {"value": rows / median, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": f"full SF10 orders x lineitem Inner join, median of {n} runs ({median * 1e3:.0f} ms each, fresh output buffers each run), "
+                      "CPU restatement of Hyrise's JoinHash"}
+
+
+def cpu_baseline_aggregate(groupby, aggregates, rows, budget_s=12.0):
+    """The oracle's AggregateHash: sequential over chunks and rows like the reference (aggregate_hash.cpp:1016-1176), one core."""
+    support = oracle_support()
+
+    def run():
+        support.oracle_aggregate(groupby, aggregates, group_capacity=64)
+
+    median, n = median_time(run, budget_s, min_runs=1, max_runs=3)
+    return {"value": rows / median, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"full SF10 lineitem Q1 core (string keys as key names, dictionary-encoded float measures), median of {n} runs "
+                      f"({median * 1e3:.0f} ms each), sequential like the reference's AggregateHash"}
+
+
+def committed_traffic(kind):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (collected by
+    tools/profile_*.sh on the same workload; FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).  None when no
+    profile of this round is committed.  (rocprofv3 cannot run inside this process: the counters are not measured live.)"""
+    path = os.path.join(ROOT, "profiles", f"r02_{kind}_pmc.json")
     if not os.path.exists(path):
         return None
     try:
@@ -90,75 +135,193 @@ def committed_traffic():
         return None
 
 
-def join_leg(lib, torch, dev, steps):
-    """Config 3 of BASELINE.json: JoinHash(orders, lineitem) on the order key, SF10 -- o_orderkey unencoded int32 (build),
-    l_orderkey FrameOfReference + u16 offsets (probe); PosList pairs written to HBM.  Reported beside the scan."""
-    from hyrise_amd import abi, storage, tpch
-    from hyrise_amd.storage import DeviceColumn
-    data = tpch.TpchData(scale_factor=10.0, seed=42)
-    orders = DeviceColumn(storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED))
-    lineitem = DeviceColumn(storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE))
-    n = data.n_lineitems
-    left = torch.empty((n, 2), dtype=torch.int32, device=dev)
-    right = torch.empty((n, 2), dtype=torch.int32, device=dev)
-    slice_offsets = torch.zeros(4096, dtype=torch.int64, device=dev)
-    r = abi.JoinResult()
-    r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
-    r.left_pos, r.right_pos, r.capacity = left.data_ptr(), right.data_ptr(), n
-    r.slice_offsets, r.slice_capacity = slice_offsets.data_ptr(), 4000
-    steps = max(3, min(steps, 10))
+def timed_kernel(lib, torch, run, steps, every=1):
+    """(seconds per call, kernel ms per timed launch): `run` repeated `steps` times after two warm-up calls."""
+    from hyrise_amd import abi
     for _ in range(2):
-        abi.check(lib.hy_join_hash(orders.handle, lineitem.handle, abi.JOIN_INNER, C.byref(r)))
-    abi.check(lib.hy_set_profiling(1))
+        run()
+    abi.check(lib.hy_set_profiling(every))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        abi.check(lib.hy_join_hash(orders.handle, lineitem.handle, abi.JOIN_INNER, C.byref(r)))
+        run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     km, ln = C.c_float(0), C.c_uint32(0)
     abi.check(lib.hy_profile_read(C.byref(km), C.byref(ln)))
     abi.check(lib.hy_set_profiling(0))
+    return dt, km.value / max(1, ln.value)
+
+
+def roofline_object(kernel, algorithmic_bytes, kernel_ms, traffic=None):
+    achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": kernel, "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms}
+
+
+def device_join(lib, torch, dev, left, right, pairs_capacity):
+    """One hy_join_hash with device-memory PosLists; returns (callable, result struct)."""
+    from hyrise_amd import abi
+    left_pos = torch.empty((pairs_capacity, 2), dtype=torch.int32, device=dev)
+    right_pos = torch.empty((pairs_capacity, 2), dtype=torch.int32, device=dev)
+    slice_offsets = torch.zeros(8192, dtype=torch.int64, device=dev)
+    r = abi.JoinResult()
+    r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
+    r.left_pos, r.right_pos, r.capacity = left_pos.data_ptr(), right_pos.data_ptr(), pairs_capacity
+    r.slice_offsets, r.slice_capacity = slice_offsets.data_ptr(), 8000
+    keep = (left_pos, right_pos, slice_offsets)
+
+    def run():
+        abi.check(lib.hy_join_hash(left.handle, right.handle, abi.JOIN_INNER, C.byref(r)))
+
+    return run, r, keep
+
+
+def join_leg(lib, torch, dev, steps, with_cases, with_cpu):
+    """Config 3 of BASELINE.json: JoinHash(orders, lineitem) on the order key, SF10 -- o_orderkey unencoded int32 (build),
+    l_orderkey FrameOfReference + u16 offsets (probe); PosList pairs written to HBM."""
+    import numpy as np
+    from hyrise_amd import abi, storage, tpch
+    from hyrise_amd.storage import DeviceColumn
+    data = tpch.TpchData(scale_factor=10.0, seed=42)
+    orders_host = storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED)
+    lineitem_host = storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE)
+    orders, lineitem = DeviceColumn(orders_host), DeviceColumn(lineitem_host)
+    n = data.n_lineitems
+    steps = max(3, min(steps, 10))
+    run, r, keep = device_join(lib, torch, dev, orders, lineitem, n)
+    dt, kernel_ms = timed_kernel(lib, torch, run, steps)
     algorithmic = data.n_orders * 4 + n * 2 + int(r.n_pairs) * 16      # SURVEY.md 8(d): build keys + probe keys + 16 B/pair
-    return {"workload": "configs[2]: JoinHash orders x lineitem on the order key, SF10, Inner", "rows_per_s": (data.n_orders + n) / dt,
-            "ms_per_join": dt * 1e3, "pairs": int(r.n_pairs), "radix_bits": int(r.radix_bits), "output_pos_lists": int(r.n_slices),
-            "algorithmic_bytes": algorithmic, "achieved_GBps_whole_join": algorithmic / dt / 1e9,
-            "probe_emit_kernel_ms": km.value / max(1, ln.value)}
+    emit_bytes = n * 2 + int(r.n_pairs) * 16                             # the dominant kernel's share: probe keys in, pairs out
+    info = {"workload": "configs[2]: JoinHash orders x lineitem on the order key, SF10, Inner (o_orderkey int32 values, l_orderkey FrameOfReference u16)",
+            "rows_per_s": (data.n_orders + n) / dt, "ms_per_join": dt * 1e3, "pairs": int(r.n_pairs), "radix_bits": int(r.radix_bits),
+            "output_pos_lists": int(r.n_slices), "algorithmic_bytes": algorithmic,
+            "roofline": dict(roofline_object("whole operator (all kernels of one hy_join_hash, host-timed)", algorithmic, dt * 1e3, committed_traffic("join")),
+                             dominant_kernel=roofline_object("rt_probe_emit", emit_bytes, kernel_ms))}
+    del keep
+    if with_cases:
+        cases = {}
+        rng = np.random.default_rng(7)
+        # probe side in random order: FrameOfReference offsets widen to 4 bytes, no locality in the lookups
+        shuffled = DeviceColumn(storage.make_column(data.l_orderkey[rng.permutation(n)], None, abi.ENC_FRAME_OF_REFERENCE))
+        run_s, r_s, keep_s = device_join(lib, torch, dev, orders, shuffled, n)
+        dt_s, _ = timed_kernel(lib, torch, run_s, 3)
+        cases["shuffled_probe"] = {"ms_per_join": dt_s * 1e3, "rows_per_s": (data.n_orders + n) / dt_s, "pairs": int(r_s.n_pairs),
+                                   "GBps_on_algorithmic_bytes": (data.n_orders * 4 + n * 4 + int(r_s.n_pairs) * 16) / dt_s / 1e9}
+        del keep_s, shuffled
+        # build side in random order (still unique): no sort, the rank table is filled by atomics + a scan
+        build_shuffled = DeviceColumn(storage.make_column(data.o_orderkey[rng.permutation(data.n_orders)], None, abi.ENC_UNENCODED))
+        run_b, r_b, keep_b = device_join(lib, torch, dev, build_shuffled, lineitem, n)
+        dt_b, _ = timed_kernel(lib, torch, run_b, 3)
+        cases["shuffled_build"] = {"ms_per_join": dt_b * 1e3, "rows_per_s": (data.n_orders + n) / dt_b, "pairs": int(r_b.n_pairs)}
+        del keep_b, build_shuffled
+        # duplicate build keys (every key four times, random order): radix sort + bucket directory, several partners per probe row
+        dup_keys = np.repeat(data.o_orderkey[:3_750_000], 4)[rng.permutation(15_000_000)]
+        dup_build = DeviceColumn(storage.make_column(dup_keys, None, abi.ENC_UNENCODED))
+        probe_rows = 16_000_000
+        dup_probe = DeviceColumn(storage.make_column(data.l_orderkey[:probe_rows], None, abi.ENC_FRAME_OF_REFERENCE))
+        run_d, r_d, keep_d = device_join(lib, torch, dev, dup_build, dup_probe, probe_rows * 4 + 1024)
+        dt_d, _ = timed_kernel(lib, torch, run_d, 3)
+        cases["duplicate_build_x4"] = {"ms_per_join": dt_d * 1e3, "rows_per_s": (15_000_000 + probe_rows) / dt_d, "pairs": int(r_d.n_pairs),
+                                       "pairs_per_s": int(r_d.n_pairs) / dt_d,
+                                       "GBps_on_algorithmic_bytes": (15_000_000 * 4 + probe_rows * 2 + int(r_d.n_pairs) * 16) / dt_d / 1e9}
+        del keep_d, dup_build, dup_probe
+        info["cases"] = cases
+    if with_cpu:
+        info["cpu_baseline"] = cpu_baseline_join(orders_host, lineitem_host, data.n_orders + n)
+    return info
 
 
-def aggregate_leg(lib, torch, steps):
-    """Config 4 of BASELINE.json on one GPU: AggregateHash, TPC-H Q1 core -- GROUP BY l_returnflag, l_linestatus (dictionary
-    segments, u8 attribute vectors) with SUM / AVG over l_quantity, l_extendedprice, l_discount (float value segments) and
-    COUNT(*), SF10 lineitem.  Reported beside the scan."""
+def aggregate_leg(lib, torch, steps, with_cases, with_cpu):
+    """Config 4 of BASELINE.json on one GPU, as SURVEY.md 8(d) specifies it: AggregateHash, TPC-H Q1 core -- GROUP BY
+    l_returnflag, l_linestatus (string dictionary columns, u8 value ids, passed as their AggregateKey names) with SUM / AVG
+    over l_quantity, l_extendedprice, l_discount (DictionarySegment<float>: u8 / u16 / u8 value ids) and COUNT(*), SF10."""
     from hyrise_amd import abi, storage, tpch
     from hyrise_amd.operators import aggregate_hash
     from hyrise_amd.storage import DeviceColumn
     data = tpch.TpchData(scale_factor=10.0, seed=42)
     n = data.n_lineitems
-    flag = DeviceColumn(storage.make_column(data.l_returnflag, None, abi.ENC_DICTIONARY))
-    status = DeviceColumn(storage.make_column(data.l_linestatus, None, abi.ENC_DICTIONARY))
-    quantity = DeviceColumn(storage.make_column(data.l_quantity, None, abi.ENC_UNENCODED))
-    price = DeviceColumn(storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED))
-    discount = DeviceColumn(storage.make_column(data.l_discount, None, abi.ENC_UNENCODED))
-    aggregates = [(abi.AGG_SUM, quantity), (abi.AGG_SUM, price), (abi.AGG_AVG, quantity), (abi.AGG_AVG, price), (abi.AGG_AVG, discount),
-                  (abi.AGG_COUNT, None)]
+    groupby_host, measures_host, algorithmic = tpch.q1_core_columns(data)
+    groupby = [DeviceColumn(c) for c in groupby_host]
+    measures = {name: DeviceColumn(c) for name, c in measures_host.items()}
+
+    def spec(columns):
+        return [(abi.AGG_SUM, columns["l_quantity"]), (abi.AGG_SUM, columns["l_extendedprice"]), (abi.AGG_AVG, columns["l_quantity"]),
+                (abi.AGG_AVG, columns["l_extendedprice"]), (abi.AGG_AVG, columns["l_discount"]), (abi.AGG_COUNT, None)]
+
     steps = max(3, min(steps, 10))
-    for _ in range(2):
-        result = aggregate_hash([flag, status], aggregates, group_capacity=64)
-    abi.check(lib.hy_set_profiling(1))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        result = aggregate_hash([flag, status], aggregates, group_capacity=64)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    km, ln = C.c_float(0), C.c_uint32(0)
-    abi.check(lib.hy_profile_read(C.byref(km), C.byref(ln)))
-    abi.check(lib.hy_set_profiling(0))
-    algorithmic = n * (1 + 1 + 4 + 4 + 4)   # two u8 attribute vectors + three float columns, each read once
-    return {"workload": "configs[3] on one GPU: AggregateHash Q1 core, GROUP BY l_returnflag, l_linestatus, SF10 lineitem",
-            "rows_per_s": n / dt, "ms_per_aggregate": dt * 1e3, "groups": int(result.n_groups), "algorithmic_bytes": algorithmic,
-            "achieved_GBps_whole_operator": algorithmic / dt / 1e9, "aggregate_rows_kernel_ms": km.value / max(1, ln.value)}
+    holder = {}
+
+    def run():
+        holder["result"] = aggregate_hash(groupby, spec(measures), group_capacity=64)
+
+    dt, kernel_ms = timed_kernel(lib, torch, run, steps)
+    info = {"workload": "configs[3] on one GPU: AggregateHash Q1 core, GROUP BY l_returnflag, l_linestatus (string dictionaries as key names, u8), "
+                        "SUM/AVG over DictionarySegment<float> l_quantity (u8), l_extendedprice (u16), l_discount (u8), COUNT(*), SF10 lineitem",
+            "rows_per_s": n / dt, "ms_per_aggregate": dt * 1e3, "groups": int(holder["result"].n_groups), "algorithmic_bytes": algorithmic,
+            "roofline": dict(roofline_object("whole operator (host-timed)", algorithmic, dt * 1e3, committed_traffic("aggregate")),
+                             dominant_kernel=roofline_object("aggregate_rows", algorithmic, kernel_ms))}
+    if with_cases:   # the same query over unencoded float value segments (round 1's bench shape): 4-byte measures, no dictionary gather
+        plain = {name: DeviceColumn(storage.make_column(getattr(data, name), None, abi.ENC_UNENCODED)) for name in ("l_quantity", "l_extendedprice", "l_discount")}
+
+        def run_plain():
+            holder["plain"] = aggregate_hash(groupby, spec(plain), group_capacity=64)
+
+        dt_p, kernel_p = timed_kernel(lib, torch, run_plain, steps)
+        bytes_p = n * (1 + 1 + 4 + 4 + 4)
+        info["cases"] = {"float_value_segments": {"ms_per_aggregate": dt_p * 1e3, "rows_per_s": n / dt_p, "kernel_ms": kernel_p,
+                                                  "kernel_GBps": bytes_p / (kernel_p * 1e-3) / 1e9 if kernel_p else None, "algorithmic_bytes": bytes_p}}
+    if with_cpu:
+        aggregates_host = spec(measures_host)
+        info["cpu_baseline"] = cpu_baseline_aggregate(groupby_host, aggregates_host, n)
+    return info
+
+
+def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, width):
+    """The other scans SURVEY.md 8(d) lists for config 2, same column unless stated."""
+    import numpy as np
+    from hyrise_amd import abi, storage, tpch
+    from hyrise_amd.operators import make_predicate
+    from hyrise_amd.storage import DeviceColumn
+    out = {}
+
+    def measure(run, bytes_of):
+        dt, km = timed_kernel(lib, torch, run, steps, PROFILE_EVERY)
+        m = int(counts.sum().item())
+        return {"rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "matches": m, "kernel_ms": km,
+                "kernel_GBps": bytes_of(m) / (km * 1e-3) / 1e9 if km else None}
+
+    for name, pred in (("q1_le_1998-09-02", make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, tpch.DAY_1998_09_02)),
+                       ("q6_between_1994", make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, tpch.DAY_1994_01_01, tpch.DAY_1995_01_01)),
+                       ("point_eq_1995-06-17", make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, tpch.CURRENT_DATE)),
+                       ("is_null", make_predicate(abi.PRED_IS_NULL, abi.TYPE_INT))):
+        out[name] = measure(lambda p=pred: step_fn(p, column), lambda m: rows * width + m * 8)
+    # the same dates as unencoded int32 values (ValueSegment<int32>: the 4-byte streaming instantiation)
+    values = DeviceColumn(storage.make_column(days, None, abi.ENC_UNENCODED))
+    pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
+    out["int32_value_segments_lt_1995"] = measure(lambda: step_fn(pred, values), lambda m: rows * 4 + m * 8)
+    del values
+    # ColumnVsColumn (Q4 / Q12): l_commitdate < l_receiptdate, both dictionary-encoded with u16 value ids
+    rng = np.random.default_rng(43)
+    orderdate = rng.integers(0, tpch.LAST_ORDERDATE + 1, rows, dtype=np.int32)
+    commit = DeviceColumn(storage.make_column((orderdate + rng.integers(30, 91, rows, dtype=np.int32)).astype(np.int32), None, abi.ENC_DICTIONARY))
+    receipt = DeviceColumn(storage.make_column((orderdate + rng.integers(2, 152, rows, dtype=np.int32)).astype(np.int32), None, abi.ENC_DICTIONARY))
+    matches = torch.empty((rows, 2), dtype=torch.int32, device=dev)
+    offsets = torch.zeros(commit.n_chunks + 1, dtype=torch.int64, device=dev)
+    counts2 = torch.zeros(commit.n_chunks, dtype=torch.int32, device=dev)
+    result = abi.ScanResult()
+    result.mem, result.flags = abi.MEM_DEVICE, abi.SCAN_CHUNK_REGIONS
+    result.matches, result.capacity = matches.data_ptr(), rows
+    result.offsets, result.counts = offsets.data_ptr(), counts2.data_ptr()
+
+    def run_columns():
+        abi.check(lib.hy_table_scan_columns(commit.handle, receipt.handle, abi.PRED_LESS_THAN, C.byref(result)))
+
+    dt, km = timed_kernel(lib, torch, run_columns, steps, PROFILE_EVERY)
+    m = int(counts2.sum().item())
+    out["column_vs_column_commit_lt_receipt"] = {"rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "matches": m, "kernel_ms": km,
+                                                  "kernel_GBps": (rows * 4 + m * 8) / (km * 1e-3) / 1e9 if km else None}
+    return out
 
 
 def main():
@@ -196,7 +359,7 @@ def main():
     # ---- data: this rank's SF10-shaped shard (seed differs per rank), encoded like Hyrise, uploaded once -------------
     rows = args.rows or tpch.LINEITEM_ROWS_SF10
     days, host_column = tpch.shipdate_column(rows, seed=42 + rank)
-    column = DeviceColumn(host_column)
+    columns = [DeviceColumn(host_column) for _ in range(COLUMN_COPIES)]
     n_chunks = host_column.n_chunks
     predicate = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
 
@@ -209,8 +372,12 @@ def main():
     counts = torch.zeros(n_chunks, dtype=torch.int32, device=dev)
     result.flags = abi.SCAN_CHUNK_REGIONS  # chunk c's PosList at matches[offsets[c] : offsets[c] + counts[c]]
     result.offsets, result.counts = offsets.data_ptr(), counts.data_ptr()
+    turn = [0]
 
-    def step(pred=predicate):
+    def step(pred=predicate, column=None):
+        if column is None:
+            column = columns[turn[0] % COLUMN_COPIES]
+            turn[0] += 1
         abi.check(lib.hy_table_scan(column.handle, C.byref(pred), None, 0, C.byref(result)))
 
     def barrier():
@@ -248,40 +415,19 @@ def main():
     # roofline of the dominant kernel (scan_slices): algorithmic bytes per launch = attribute vector + RowIDs written
     width = host_column.segments[0].width
     algorithmic_bytes = rows * width + n_matches * 8
-    kernel_s = (kernel_ms.value / max(1, launches.value)) * 1e-3
-    achieved = algorithmic_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    kernel_ms_per_launch = kernel_ms.value / max(1, launches.value)
+    single = rank == 0 and world == 1 and not args.rows
 
     extra_cases = None
-    if args.cases and rank == 0:
-        extra_cases = {}
-        for name, pred in (("q1_le_1998-09-02", make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, tpch.DAY_1998_09_02)),
-                           ("q6_between_1994", make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, tpch.DAY_1994_01_01, tpch.DAY_1995_01_01)),
-                           ("point_eq_1995-06-17", make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, tpch.CURRENT_DATE))):
-            for _ in range(3):
-                step(pred)
-            abi.check(lib.hy_set_profiling(PROFILE_EVERY))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step(pred)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / args.steps
-            km, ln = C.c_float(0), C.c_uint32(0)
-            abi.check(lib.hy_profile_read(C.byref(km), C.byref(ln)))
-            abi.check(lib.hy_set_profiling(0))
-            m = int(counts.sum().item())
-            bytes_case = rows * width + m * 8
-            extra_cases[name] = {"rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "matches": m,
-                                 "kernel_ms": km.value / max(1, ln.value),
-                                 "kernel_GBps": bytes_case / (km.value / max(1, ln.value) * 1e-3) / 1e9}
+    if single and not args.no_cases:
+        extra_cases = scan_cases(lib, torch, dev, args.steps, days, columns[0], step, counts, rows, width)
+    join_info = join_leg(lib, torch, dev, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_join else None
+    aggregate_info = aggregate_leg(lib, torch, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_aggregate else None
 
-    join_info = None
-    if rank == 0 and world == 1 and not args.no_join and not args.rows:   # (single-GPU legs: the N > 1 runs time the sharded scan only)
-        join_info = join_leg(lib, torch, dev, args.steps)
-
-    aggregate_info = None
-    if rank == 0 and world == 1 and not args.no_aggregate and not args.rows:
-        aggregate_info = aggregate_leg(lib, torch, args.steps)
+    multi = None
+    if world > 1 and not args.no_multi and not args.rows:
+        from hyrise_amd import distributed
+        multi = distributed.bench_legs(lib, torch, dist, dev, rank, world, share_gpu, steps=max(3, min(args.steps, 10)))
 
     if rank == 0:
         line = {
@@ -290,13 +436,11 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "configs[1]: TableScan ColumnVsValue, SF10 lineitem l_shipdate, DictionarySegment<int32> "
-                                   "+ u16 attribute vectors, 916 chunks x 65535 rows, column and PosLists resident in HBM",
+                                   "+ u16 attribute vectors, 916 chunks x 65535 rows, column and PosLists resident in HBM, "
+                                   f"{COLUMN_COPIES} copies of the column scanned in rotation",
                        "rows_per_gpu": rows, "chunks_per_gpu": n_chunks, "selectivity": n_matches / rows,
                        "parallelism": f"chunk-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "scan_slices",
-                         "algorithmic_bytes_per_launch": algorithmic_bytes,
-                         "kernel_ms": kernel_s * 1e3, "launches_timed": int(launches.value)},
+            "roofline": dict(roofline_object("scan_slices", algorithmic_bytes, kernel_ms_per_launch, committed_traffic("scan")), launches_timed=int(launches.value)),
         }
         if extra_cases:
             line["cases"] = extra_cases
@@ -304,9 +448,10 @@ def main():
             line["join"] = join_info
         if aggregate_info:
             line["aggregate"] = aggregate_info
-        line["roofline"]["traffic"] = committed_traffic()
+        if multi:
+            line["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host_column, predicate, rows)
+            line["cpu_baseline"] = cpu_baseline_scan(host_column, predicate, rows)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -85,3 +85,27 @@ def shipdate_column(n_rows=LINEITEM_ROWS_SF10, seed=42, chunk_size=abi.CHUNK_DEF
     rng = np.random.default_rng(seed)
     days = (rng.integers(0, LAST_ORDERDATE + 1, n_rows, dtype=np.int32) + rng.integers(1, 122, n_rows, dtype=np.int32))
     return days.astype(np.int32), storage.make_column(days.astype(np.int32), None, abi.ENC_DICTIONARY, chunk_size)
+
+
+def string_key_column(char_codes, chunk_size=abi.CHUNK_DEFAULT_SIZE):
+    """A column of one-character strings (l_returnflag, l_linestatus) as AggregateHash's GROUP BY takes it from the adapter:
+    DictionarySegment<pmr_string> per chunk -- attribute vector of value ids (u8: a handful of distinct flags) over the
+    byte-ordered dictionary -- whose dictionary entries are replaced by their AggregateKeyEntry names, 2 + the character
+    (aggregate_hash.cpp:852-900, hyrise_amd/string_keys.py).  `char_codes`: the characters as integers."""
+    column = storage.make_column(np.ascontiguousarray(char_codes, dtype=np.int32), None, abi.ENC_DICTIONARY, chunk_size)
+    segments = [storage.HostSegment(abi.ENC_DICTIONARY, abi.TYPE_LONG, s.size, s.width, s.data, aux=(s.aux.astype(np.int64) + 2), aux_size=s.aux_size)
+                for s in column.segments]
+    return storage.HostColumn(segments, abi.TYPE_LONG)
+
+
+def q1_core_columns(data, chunk_size=abi.CHUNK_DEFAULT_SIZE):
+    """Config 4 as SURVEY.md 8(d) specifies it: GROUP BY l_returnflag, l_linestatus (string dictionaries, u8 value ids) and
+    the measures as DictionarySegment<float> (l_quantity u8, l_extendedprice u16 with ~60 k entries per chunk, l_discount u8).
+    Returns (group-by columns, {name: column}, algorithmic bytes: attribute vectors + dictionaries, each read once)."""
+    groupby = [string_key_column(data.l_returnflag, chunk_size), string_key_column(data.l_linestatus, chunk_size)]
+    measures = {name: storage.make_column(getattr(data, name), None, abi.ENC_DICTIONARY, chunk_size) for name in ("l_quantity", "l_extendedprice", "l_discount")}
+    total = 0
+    for column in groupby + list(measures.values()):
+        for s in column.segments:
+            total += s.size * s.width + s.aux_size * s.aux.dtype.itemsize
+    return groupby, measures, total

@@ -533,3 +533,80 @@ def oracle_aggregate(groupby_columns, aggregates, group_capacity=None):
     assert status == 0, f"oracle aggregate failed with {status}"
     result._keep = (gcols, acols)
     return result
+
+
+# ---- aggregate fixtures with string columns ------------------------------------------------------------------------------
+class AggregateCase:
+    """The columns of one aggregate_test.cpp case as the device / oracle take them.  String columns travel as int64
+    stand-ins (hyrise_amd/string_keys.py): AggregateKeyEntry names where they are GROUP BY columns, order-preserving
+    ranks where they are aggregate arguments; `output_rows` maps the result back to the table the reference expects."""
+
+    def __init__(self, case):
+        from hyrise_amd import string_keys
+        self.case = case
+        table = load_tbl(case["input"])
+        self.table = table
+        encoding = abi.ENC_DICTIONARY if case["encoded"] else abi.ENC_UNENCODED
+        chunk = case["chunk_size"]
+        self.plain = {}
+
+        def numeric(i):
+            if i not in self.plain:
+                self.plain[i] = build_column(table.columns[i], table.nulls[i] if table.nullable[i] else None, chunk, encoding)
+            return self.plain[i]
+
+        def string_column(i, keys):
+            values, nulls = table.columns[i], (table.nulls[i] if table.nullable[i] else None)
+            if case["encoded"]:
+                segments, dictionaries = string_keys.encode_string_column(values, nulls, chunk)
+                return keys.dictionary_column(segments, dictionaries)
+            return keys.value_column(values, nulls, chunk)
+
+        self.groupby, self.group_strings = [], []
+        for g in case["groupby"]:
+            if table.types[g] == abi.TYPE_STRING:
+                self.groupby.append(string_column(g, string_keys.AggregateKeyNames()))
+            else:
+                self.groupby.append(numeric(g))
+        self.aggregates, self.ranks = [], []
+        for c, f in case["aggregates"]:
+            ranks = None
+            if c is None:
+                column = None
+            elif table.types[c] == abi.TYPE_STRING:
+                ranks = string_keys.StringRanks(table.columns[c], table.nulls[c] if table.nullable[c] else None)
+                column = string_column(c, ranks)
+            else:
+                column = numeric(c)
+            self.aggregates.append((AGG_BY_NAME[f], column))
+            self.ranks.append(ranks if AGG_BY_NAME[f] in (abi.AGG_MIN, abi.AGG_MAX, abi.AGG_ANY) else None)
+
+    @property
+    def runnable(self):
+        return bool(self.groupby) or any(c is not None for _, c in self.aggregates)
+
+    def output_rows(self, result):
+        """GROUP BY columns (the values of the representative rows, strings as strings), then one cell per aggregate."""
+        table, case = self.table, self.case
+        flat_index, offset = {}, 0
+        shape = (self.groupby[0] if self.groupby else next(c for _, c in self.aggregates if c is not None))
+        for chunk, seg in enumerate(shape.segments):
+            for i in range(seg.size):
+                flat_index[(chunk, i)] = offset + i
+            offset += seg.size
+        rows = []
+        for g in range(result.n_groups):
+            rid = tuple(int(x) for x in result.row_ids[g])
+            row = []
+            for column_id in case["groupby"]:
+                is_null = table.nullable[column_id] and table.nulls[column_id][flat_index[rid]]
+                value = table.columns[column_id][flat_index[rid]]
+                row.append(None if is_null else (value if table.types[column_id] == abi.TYPE_STRING else value.item()))
+            rows.append(row)
+        for a in range(len(self.aggregates)):
+            cells = result.column(a)
+            if self.ranks[a] is not None:
+                cells = self.ranks[a].strings_of(cells)
+            for g, v in enumerate(cells):
+                rows[g].append(v)
+        return rows

@@ -10,11 +10,11 @@ import pytest
 from hyrise_amd import abi, storage, tpch
 from hyrise_amd.operators import aggregate_hash
 from hyrise_amd.storage import DeviceColumn
-from support import AGG_BY_NAME, GOLDEN, build_column, load_tbl, oracle_aggregate
+from support import GOLDEN, AggregateCase, build_column, oracle_aggregate
 
 pytestmark = pytest.mark.gpu
 FLOAT_TOLERANCE = 1e-9
-CASES = [c for c in json.load(open(os.path.join(os.path.dirname(GOLDEN), "aggregate_cases.json")))["cases"] if "string" not in c["input"]]
+CASES = json.load(open(os.path.join(os.path.dirname(GOLDEN), "aggregate_cases.json")))["cases"]   # all 79 (string columns as key names / ranks: hyrise_amd/string_keys.py)
 
 
 def assert_aggregate_equal(got, want, n_aggregates, context=""):
@@ -48,13 +48,10 @@ def run_both(groupby_hosts, aggregate_hosts, context=""):
 
 @pytest.mark.parametrize("case", CASES, ids=[f"L{c['line']}" for c in CASES])
 def test_reference_aggregate_fixture_on_device(device, case):
-    table = load_tbl(case["input"])
-    encoding = abi.ENC_DICTIONARY if case["encoded"] else abi.ENC_UNENCODED
-    columns = [build_column(table.columns[i], table.nulls[i] if table.nullable[i] else None, case["chunk_size"], encoding)
-               for i in range(len(table.names))]
-    groupby = [columns[g] for g in case["groupby"]]
-    aggregates = [(AGG_BY_NAME[f], columns[c] if c is not None else None) for c, f in case["aggregates"]]
-    run_both(groupby, aggregates, f"aggregate_test.cpp:{case['line']}")
+    columns = AggregateCase(case)
+    if not columns.runnable:
+        pytest.skip("COUNT(*) without GROUP BY and without a column to take the table's shape from")
+    run_both(columns.groupby, columns.aggregates, f"aggregate_test.cpp:{case['line']}")
 
 
 def test_group_order_and_immediate_key(device):
