@@ -122,6 +122,10 @@ SYMBOLS = [
     ("hy_join_hash_count", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("hy_aggregate_hash", C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(AggregateSpec), C.c_uint32,
                                       C.POINTER(AggregateResult)]),
+    ("hy_column_export", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("hy_repartition_count", C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("hy_repartition_pack", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("hy_gather_row_ids", C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
 ]
 
 

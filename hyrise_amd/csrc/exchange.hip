@@ -1,0 +1,282 @@
+// exchange.hip -- what the multi-GPU execution needs from one GPU: the reference is a single
+// process; sharding its operators over GPUs adds one exchange step per operator, and the data of that step is produced and
+// consumed here, on the device, so that the collective (RCCL over xGMI, driven by the host plumbing in
+// hyrise_amd/distributed.py) moves device buffers and nothing crosses PCIe.
+//
+//   hy_column_export      a column's values decoded into one flat device array (+ NULL bytes): the build side of a
+//                         broadcast-build join before its all-gather; any operator result handed to another library
+//   hy_repartition_count  rows per destination of a hash repartition:  destination = std::hash(key) % parts  (std::hash of an
+//   hy_repartition_pack   integer is the integer: JoinHash's own hash, join_hash_steps.hpp:352); then the (key, RowID) tuples
+//                         grouped by destination, stable in (chunk, row) order -- the send buffer of the all-to-all
+//   hy_gather_row_ids     positions in a received tuple array -> the RowIDs that travelled with the keys (the local join of a
+//                         repartitioned join speaks positions of the received arrays)
+#include "hy_device.hpp"
+#include "hy_decode.hpp"
+
+#include <algorithm>
+
+namespace hy {
+
+struct ExportArgs {
+  const DevSegment* segments;
+  const Slice* slices;
+  const uint64_t* row_base;
+  void* values;        // [rows] of the column's type
+  uint8_t* nulls;      // [rows] or nullptr
+  uint32_t width;      // bytes per value
+  uint32_t is_float;   // the column holds float / double (the decoder returns them as doubles)
+};
+
+__global__ __launch_bounds__(256) void export_rows(ExportArgs a) {
+  const Slice slice = a.slices[blockIdx.x];
+  if (slice.row_count == 0) return;
+  const DevSegment s = a.segments[slice.chunk];
+  const uint64_t base = a.row_base[slice.chunk] + slice.row_begin;
+  constexpr int BATCH = 8;
+#pragma unroll 1
+  for (uint32_t block = 0; block < SLICE_ROWS / 256 / BATCH; ++block) {
+    if (block * BATCH * 256 >= slice.row_count) break;
+    uint32_t row[BATCH], r[BATCH], valid = 0;
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      r[i] = (block * BATCH + i) * 256 + threadIdx.x;
+      if (r[i] < slice.row_count) valid |= 1u << i;
+      row[i] = slice.row_begin + (r[i] < slice.row_count ? r[i] : 0);
+    }
+    uint64_t bits[BATCH];
+    uint32_t nulls = 0;
+    decode_rows<BATCH>(s, a.segments, slice.chunk, row, valid, bits, &nulls);
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      if (!((valid >> i) & 1)) continue;
+      const uint64_t at = base + r[i];
+      const bool is_null = (nulls >> i) & 1;
+      if (a.width == 4) {
+        uint32_t word = static_cast<uint32_t>(bits[i]);
+        if (a.is_float) word = __float_as_uint(static_cast<float>(__longlong_as_double(static_cast<long long>(bits[i]))));
+        static_cast<uint32_t*>(a.values)[at] = is_null ? 0u : word;
+      } else {
+        static_cast<uint64_t*>(a.values)[at] = is_null ? 0ull : bits[i];
+      }
+      if (a.nulls) a.nulls[at] = is_null ? 1 : 0;
+    }
+  }
+}
+
+// ---- hash repartition ------------------------------------------------------------------------------------------------------
+constexpr uint32_t MAX_PARTS = 16;
+struct RepartitionArgs {
+  const DevSegment* segments;
+  const Slice* slices;
+  uint32_t n_slices;
+  uint32_t parts;
+  uint32_t chunk_id_offset;       // added to the chunk ids of the RowIDs that travel (the shard's first chunk in the whole table)
+  uint32_t key_width;             // 4: int32 keys travel as int32, 8: int64
+  uint32_t* slice_counts;         // [n_slices][parts]
+  const uint64_t* slice_offsets;  // pack: [parts][n_slices] flattened destination-major exclusive scan (+ total)
+  void* keys_out;
+  hy_row_id* rows_out;
+};
+
+__device__ __forceinline__ bool repartition_key(const RepartitionArgs& a, const DevSegment& s, uint32_t chunk, uint32_t row, int64_t* key) {
+  const Value v = column_value(a.segments, chunk, row);
+  *key = v.i;
+  return !v.is_null;   // NULL keys never find a partner: they stay home (Inner / Semi joins)
+}
+
+// One workgroup per slice, rows visited as row = k * 256 + tid so that compaction order is row order.  MODE 0 counts the
+// slice's rows per destination, MODE 1 writes them behind the scanned offsets.
+template <int MODE>
+__global__ __launch_bounds__(256) void repartition_rows(RepartitionArgs a) {
+  __shared__ uint32_t s_count[32][4][MAX_PARTS];   // [k][wave][destination]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const Slice slice = a.slices[blockIdx.x];
+  const DevSegment s = a.segments[slice.chunk];
+#pragma unroll 1
+  for (uint32_t k = 0; k < 32; ++k) {
+    const uint32_t r = k * 256 + tid;
+    uint32_t dest = 0;   // + 1
+    if (r < slice.row_count) {
+      int64_t key;
+      if (repartition_key(a, s, slice.chunk, slice.row_begin + r, &key)) dest = static_cast<uint32_t>(static_cast<uint64_t>(key) % a.parts) + 1;
+    }
+    for (uint32_t d = 0; d < a.parts; ++d) {
+      const uint64_t mask = __ballot(dest == d + 1);
+      if (lane == 0) s_count[k][wave][d] = __popcll(mask);
+    }
+  }
+  __syncthreads();
+  if (MODE == 0) {
+    if (tid < a.parts) {
+      uint32_t sum = 0;
+      for (uint32_t k = 0; k < 32; ++k)
+        for (uint32_t w = 0; w < 4; ++w) sum += s_count[k][w][tid];
+      a.slice_counts[static_cast<size_t>(blockIdx.x) * a.parts + tid] = sum;
+    }
+    return;
+  }
+  if (tid < a.parts) {   // exclusive prefix over (k, wave) for this destination
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < 32; ++k)
+      for (uint32_t w = 0; w < 4; ++w) { const uint32_t c = s_count[k][w][tid]; s_count[k][w][tid] = run; run += c; }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (uint32_t k = 0; k < 32; ++k) {
+    const uint32_t r = k * 256 + tid;
+    uint32_t dest = 0;   // + 1 (the key is read again: cheaper than keeping 32 destinations per thread)
+    int64_t key = 0;
+    if (r < slice.row_count && repartition_key(a, s, slice.chunk, slice.row_begin + r, &key)) dest = static_cast<uint32_t>(static_cast<uint64_t>(key) % a.parts) + 1;
+    for (uint32_t d = 0; d < a.parts; ++d) {
+      const uint64_t mask = __ballot(dest == d + 1);
+      if (dest != d + 1) continue;
+      const uint64_t pos = a.slice_offsets[static_cast<size_t>(d) * a.n_slices + blockIdx.x] + s_count[k][wave][d] + __popcll(mask & ((1ull << lane) - 1));
+      if (a.key_width == 4) static_cast<int32_t*>(a.keys_out)[pos] = static_cast<int32_t>(key);
+      else static_cast<int64_t*>(a.keys_out)[pos] = key;
+      a.rows_out[pos] = hy_row_id{slice.chunk + a.chunk_id_offset, slice.row_begin + r};
+    }
+  }
+}
+
+// slice_counts [n_slices][parts] -> offsets [parts][n_slices] (destination-major exclusive scan), totals[parts]; one workgroup
+// (shards have a few thousand slices).
+__global__ __launch_bounds__(1024) void repartition_scan(const uint32_t* slice_counts, uint32_t n_slices, uint32_t parts, uint64_t* offsets, uint64_t* totals) {
+  __shared__ uint64_t s_partial[1024];
+  __shared__ uint64_t s_base;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const uint32_t per = (n_slices + 1023) / 1024;
+  for (uint32_t d = 0; d < parts; ++d) {
+    const uint32_t begin = tid * per < n_slices ? tid * per : n_slices, end = begin + per < n_slices ? begin + per : n_slices;
+    uint64_t sum = 0;
+    for (uint32_t i = begin; i < end; ++i) sum += slice_counts[static_cast<size_t>(i) * parts + d];
+    s_partial[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      uint64_t run = s_base;
+      for (uint32_t i = 0; i < 1024; ++i) { const uint64_t v = s_partial[i]; s_partial[i] = run; run += v; }
+      totals[d] = run - s_base;
+      s_base = run;
+    }
+    __syncthreads();
+    uint64_t run = s_partial[tid];
+    for (uint32_t i = begin; i < end; ++i) { offsets[static_cast<size_t>(d) * n_slices + i] = run; run += slice_counts[static_cast<size_t>(i) * parts + d]; }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_row_ids(const hy_row_id* table, uint64_t table_rows, uint32_t chunk_rows, const hy_row_id* positions, uint64_t n, hy_row_id* out) {
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const hy_row_id p = positions[i];
+    hy_row_id r{0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (p.chunk_offset != 0xFFFFFFFFu) {
+      const uint64_t at = static_cast<uint64_t>(p.chunk_id) * chunk_rows + p.chunk_offset;
+      if (at < table_rows) r = table[at];
+    }
+    out[i] = r;
+  }
+}
+
+}  // namespace hy
+
+using namespace hy;
+
+extern "C" {
+
+hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls) {
+  if (!column || !values) return fail(HY_ERR_INVALID, "hy_column_export: null argument");
+  if (column->is_mvcc) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
+  if (column->data_type < HY_TYPE_INT || column->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "hy_column_export: numeric columns only");
+  if (column->has_dictionary_without_values) return fail(HY_ERR_UNSUPPORTED, "hy_column_export: the dictionary values are not on the device");
+  if (!column->n_slices || !column->rows) return HY_OK;
+  hipStream_t stream = current_stream();
+  ExportArgs a{};
+  a.segments = column->d_segments;
+  a.slices = column->d_slices;
+  a.row_base = column->d_row_base;
+  a.values = values;
+  a.nulls = nulls;
+  a.width = (column->data_type == HY_TYPE_INT || column->data_type == HY_TYPE_FLOAT) ? 4 : 8;
+  a.is_float = (column->data_type == HY_TYPE_FLOAT || column->data_type == HY_TYPE_DOUBLE) ? 1 : 0;
+  hipLaunchKernelGGL(export_rows, dim3(column->n_slices), dim3(256), 0, stream, a);
+  HY_HIP(hipGetLastError());
+  return HY_OK;
+}
+
+static hy_status repartition_check(const hy_column* column, uint32_t parts) {
+  if (!column) return fail(HY_ERR_INVALID, "hy_repartition: null column");
+  if (parts == 0 || parts > MAX_PARTS) return fail(HY_ERR_INVALID, "hy_repartition: 1..%u destinations", MAX_PARTS);
+  if (column->is_mvcc) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
+  if (column->data_type != HY_TYPE_INT && column->data_type != HY_TYPE_LONG) return fail(HY_ERR_UNSUPPORTED, "hy_repartition: integer join keys (std::hash of a float is not its value)");
+  if (column->has_dictionary_without_values) return fail(HY_ERR_UNSUPPORTED, "hy_repartition: the dictionary values are not on the device");
+  return HY_OK;
+}
+
+hy_status hy_repartition_count(const hy_column* column, uint32_t parts, uint64_t* counts) {
+  HY_TRY(repartition_check(column, parts));
+  if (!counts) return fail(HY_ERR_INVALID, "hy_repartition_count: counts missing");
+  for (uint32_t d = 0; d < parts; ++d) counts[d] = 0;
+  if (!column->n_slices || !column->rows) return HY_OK;
+  hipStream_t stream = current_stream();
+  DeviceBuffer slice_counts, offsets, totals;
+  HY_TRY(slice_counts.alloc(4 * size_t{column->n_slices} * parts));
+  HY_TRY(offsets.alloc(8 * size_t{column->n_slices} * parts));
+  HY_TRY(totals.alloc(8 * size_t{MAX_PARTS}));
+  RepartitionArgs a{};
+  a.segments = column->d_segments;
+  a.slices = column->d_slices;
+  a.n_slices = column->n_slices;
+  a.parts = parts;
+  a.slice_counts = slice_counts.as<uint32_t>();
+  hipLaunchKernelGGL(repartition_rows<0>, dim3(column->n_slices), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(repartition_scan, dim3(1), dim3(1024), 0, stream, slice_counts.as<uint32_t>(), column->n_slices, parts, offsets.as<uint64_t>(), totals.as<uint64_t>());
+  HY_HIP(hipMemcpyAsync(counts, totals.ptr, 8 * size_t{parts}, hipMemcpyDeviceToHost, stream));
+  HY_HIP(hipStreamSynchronize(stream));
+  return HY_OK;
+}
+
+hy_status hy_repartition_pack(const hy_column* column, uint32_t parts, uint32_t chunk_id_offset, void* keys_out, hy_row_id* row_ids_out, uint64_t capacity,
+                              uint64_t* counts) {
+  HY_TRY(repartition_check(column, parts));
+  if (!counts || (capacity && (!keys_out || !row_ids_out))) return fail(HY_ERR_INVALID, "hy_repartition_pack: output buffer missing");
+  for (uint32_t d = 0; d < parts; ++d) counts[d] = 0;
+  if (!column->n_slices || !column->rows) return HY_OK;
+  hipStream_t stream = current_stream();
+  DeviceBuffer slice_counts, offsets, totals;
+  HY_TRY(slice_counts.alloc(4 * size_t{column->n_slices} * parts));
+  HY_TRY(offsets.alloc(8 * size_t{column->n_slices} * parts));
+  HY_TRY(totals.alloc(8 * size_t{MAX_PARTS}));
+  RepartitionArgs a{};
+  a.segments = column->d_segments;
+  a.slices = column->d_slices;
+  a.n_slices = column->n_slices;
+  a.parts = parts;
+  a.chunk_id_offset = chunk_id_offset;
+  a.key_width = column->data_type == HY_TYPE_INT ? 4 : 8;
+  a.slice_counts = slice_counts.as<uint32_t>();
+  a.slice_offsets = offsets.as<uint64_t>();
+  a.keys_out = keys_out;
+  a.rows_out = row_ids_out;
+  hipLaunchKernelGGL(repartition_rows<0>, dim3(column->n_slices), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(repartition_scan, dim3(1), dim3(1024), 0, stream, slice_counts.as<uint32_t>(), column->n_slices, parts, offsets.as<uint64_t>(), totals.as<uint64_t>());
+  HY_HIP(hipMemcpyAsync(counts, totals.ptr, 8 * size_t{parts}, hipMemcpyDeviceToHost, stream));
+  HY_HIP(hipStreamSynchronize(stream));
+  uint64_t total = 0;
+  for (uint32_t d = 0; d < parts; ++d) total += counts[d];
+  if (total > capacity) return fail(HY_ERR_CAPACITY, "hy_repartition_pack: %llu tuples, capacity %llu", static_cast<unsigned long long>(total), static_cast<unsigned long long>(capacity));
+  hipLaunchKernelGGL(repartition_rows<1>, dim3(column->n_slices), dim3(256), 0, stream, a);
+  HY_HIP(hipGetLastError());
+  return HY_OK;
+}
+
+hy_status hy_gather_row_ids(const hy_row_id* table, uint64_t table_rows, uint32_t chunk_rows, const hy_row_id* positions, uint64_t n, hy_row_id* out) {
+  if (n && (!table || !positions || !out || !chunk_rows)) return fail(HY_ERR_INVALID, "hy_gather_row_ids: null argument");
+  if (!n) return HY_OK;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 16384));
+  hipLaunchKernelGGL(gather_row_ids, dim3(grid), dim3(256), 0, current_stream(), table, table_rows, chunk_rows, positions, n, out);
+  HY_HIP(hipGetLastError());
+  return HY_OK;
+}
+
+}  // extern "C"

@@ -2777,12 +2777,13 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   StageClock clock;
   HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, b, stream));
   const bool rank_path = b.rank.entries != nullptr;
-  // the probe column's segments are all ones a SliceView describes (int32 values / FrameOfReference offsets, no NULLs): the
-  // pipelined instantiations of the rank-table passes
+  // the probe column's segments are all ones a SliceView describes (int32 values / FrameOfReference offsets, no NULLs, 16-byte
+  // aligned): pass 1 is the wave-per-tile kernel with wide loads
   bool fetch_ahead = rank_path && !probe->is_reference && !getenv("HY_JOIN_NO_FETCH_AHEAD");
   for (uint32_t c = 0; c < probe->n_chunks && fetch_ahead; ++c) {
     const hy_segment& seg = probe->host_segments[c];
-    fetch_ahead = !seg.nulls && ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
+    fetch_ahead = !seg.nulls && reinterpret_cast<uintptr_t>(seg.data) % 16 == 0 &&
+                  ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
   }
   t_last_join_used_rank_table = rank_path ? (b.rank.identity_rows ? 2 : 1) : 0;
   clock.mark("build side launched");

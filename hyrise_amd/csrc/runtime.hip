@@ -541,8 +541,9 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     v.row_begin = slices[i].row_begin;
     v.row_count = slices[i].row_count;
     v.kind = VIEW_GENERIC;
-    if (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !s.nulls) v.kind = VIEW_INT32;
-    if (s.encoding == HY_ENC_FRAME_OF_REFERENCE && !s.nulls) v.kind = s.width == 1 ? VIEW_FOR8 : s.width == 2 ? VIEW_FOR16 : VIEW_FOR32;
+    const bool aligned = reinterpret_cast<uintptr_t>(s.data) % 16 == 0;   // the kernels that use views read 16 bytes per lane
+    if (aligned && s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !s.nulls) v.kind = VIEW_INT32;
+    if (aligned && s.encoding == HY_ENC_FRAME_OF_REFERENCE && !s.nulls) v.kind = s.width == 1 ? VIEW_FOR8 : s.width == 2 ? VIEW_FOR16 : VIEW_FOR32;
   }
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_slice_views), sizeof(SliceView) * (views.size() + 1));
   if (err == hipSuccess && !views.empty()) err = hipMemcpy(column->d_slice_views, views.data(), sizeof(SliceView) * views.size(), hipMemcpyHostToDevice);

@@ -1,21 +1,36 @@
-"""Multi-GPU execution: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm, "gloo" in
-the CPU tests).  The reference is single-process; this is what SURVEY.md section 8(e) adds:
+"""Multi-GPU execution: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the
+CPU tests and in the two-ranks-on-one-GPU debug mode).  The reference is single-process; this is what SURVEY.md section 8(e)
+adds -- one exchange step per operator, on device buffers:
 
   TableScan      chunks shard naturally: rank r owns a contiguous chunk range, scans it alone, NO collective.
-  AggregateHash  every rank aggregates its chunk range into partial (key, SUM, COUNT, MIN, MAX, first row) groups; ONE
-                 all-gather of those few bytes (Q1: 4 groups x 6 aggregates) and a local, deterministic merge that
-                 restores the reference's first-occurrence order (global first row = min over ranks).
-  JoinHash       broadcast-build: the build side's join column is all-gathered (15 M keys x 4 B = 60 MB at SF10, arriving
-                 over all 7 xGMI links at once), every rank builds the same table, the probe side stays chunk-sharded
-                 and each rank emits the pairs of its probe chunks.  Pair order across ranks is the per-rank reference
-                 order; the multi-GPU parity check is therefore on multisets (as the reference's own join tests are).
+  AggregateHash  every rank aggregates its chunk range (hy_aggregate_hash) into per-group partials -- SUM and COUNT (AVG is
+                 their quotient), MIN, MAX, the group's first row.  Small canonical key domains (TPC-H Q1: 4 groups) go into
+                 FIXED SLOTS, slot = mixed-radix index of the key tuple in the all-reduced key ranges, and the partial arrays
+                 are combined by all-reduce (SUM / MIN / MAX): a few hundred bytes, latency-bound.  Otherwise the groups'
+                 (key, partial) arrays are all-gathered and merged locally.  The reference's group order is restored from the
+                 all-reduced first rows (first occurrence) or keys (immediate-key shortcut, aggregate_hash.cpp:770-804).
+  JoinHash (A)   broadcast-build: the build side's join column is decoded on the device (hy_column_export), all-gathered
+                 (15 M keys x 4 B = 60 MB at SF10, arriving over all 7 xGMI links at once), every rank joins the whole build
+                 side with its probe chunks.
+  JoinHash (B)   hash repartition: both sides send every (key, RowID) to GPU  key % G  (hy_repartition_pack -> all-to-all),
+                 every GPU joins what it received and maps the positions back to the RowIDs that travelled
+                 (hy_gather_row_ids).  For build sides that do not fit one GPU; BASELINE.json names it for the SSB star join.
+  Pair order across ranks is per-rank reference order (ranks in order); the N > 1 parity checks are on multisets, as the
+  reference's own join tests are (join_test_runner.cpp:786).
 
-The per-rank work is done by an *executor* (the HIP library in production; the CPU oracle in the gloo tests, where no
-GPU exists) -- this module only partitions, exchanges and merges.
+The per-rank work is done by an *executor*: `HipExecutor` (the C ABI on this rank's GPU) in production and in the GPU tests,
+an oracle-backed one in the CPU tests (tests/test_distributed_cpu.py), where no GPU exists.  This module only partitions,
+exchanges and merges; collectives move torch tensors that live where the executor's buffers live.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import abi
+
+FIXED_SLOT_LIMIT = 4096      # key domains up to this many slots are combined by all-reduce
+REPARTITION_CHUNK = 65535    # received tuple arrays are presented as columns of this chunk size (Chunk::DEFAULT_SIZE)
+_NULL_ROW = -1               # 0xFFFFFFFF as int32
 
 
 def chunk_range(n_chunks, world_size, rank):
@@ -26,142 +41,569 @@ def chunk_range(n_chunks, world_size, rank):
 
 
 def shard_column(host_column, world_size, rank):
-    """The rank's chunks of a HostColumn (a view: segments are shared, not copied)."""
+    """The rank's chunks of a HostColumn (a view: segments are shared, not copied) and its first chunk id."""
     from .storage import HostColumn
     begin, end = chunk_range(host_column.n_chunks, world_size, rank)
     return HostColumn(host_column.segments[begin:end], host_column.data_type), begin
 
 
-def _all_gather_arrays(dist, array, device=None):
-    """all_gather of a variable-length 1-D numpy array (lengths first, then padded payloads)."""
-    import torch
-    world = dist.get_world_size()
-    dev = device if device is not None else "cpu"
-    length = torch.tensor([array.size], dtype=torch.int64, device=dev)
-    lengths = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(lengths, length)
-    lengths = [int(x.item()) for x in lengths]
-    padded = np.zeros(max(lengths + [1]), dtype=array.dtype)
-    padded[:array.size] = array
-    local = torch.from_numpy(padded.view(np.uint8).copy()).to(dev)
-    parts = [torch.zeros_like(local) for _ in range(world)]
-    dist.all_gather(parts, local)
-    return [p.cpu().numpy().view(array.dtype)[:n] for p, n in zip(parts, lengths)]
+# ---- collectives -----------------------------------------------------------------------------------------------------
+class Comm:
+    """torch.distributed with the two things the operators need on top: variable-length all-gather / all-to-all, and -- for
+    the gloo backend over CUDA tensors (several ranks sharing one GPU in the debug mode) -- staging through host memory."""
+
+    def __init__(self, dist):
+        import torch
+        self.dist, self.torch = dist, torch
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.staged = dist.get_backend() == "gloo"
+
+    def _in(self, t):
+        return t.cpu() if self.staged and t.is_cuda else t
+
+    def all_reduce(self, t, op):
+        """In place; op: "sum" | "min" | "max"."""
+        reduce_op = {"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}[op]
+        staged = self._in(t)
+        self.dist.all_reduce(staged, op=reduce_op)
+        if staged is not t:
+            t.copy_(staged)
+        return t
+
+    def all_gather_counts(self, n):
+        torch = self.torch
+        mine = torch.tensor([int(n)], dtype=torch.int64)
+        if not self.staged:
+            mine = mine.to(self._device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [int(x.item()) for x in out]
+
+    def bind(self, device):
+        self._device = device
+        return self
+
+    def all_gather_var(self, t):
+        """Every rank's 1-D (or [n, k]) tensor, in rank order."""
+        torch = self.torch
+        counts = self.all_gather_counts(t.shape[0])
+        width = max(counts + [1])
+        staged = self._in(t)
+        padded = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=staged.device)
+        padded[:t.shape[0]] = staged
+        parts = [torch.zeros_like(padded) for _ in range(self.world)]
+        self.dist.all_gather(parts, padded)
+        return [p[:n].to(t.device) for p, n in zip(parts, counts)]
+
+    def all_to_all_var(self, send, send_counts):
+        """send: rows grouped by destination (send_counts[d] rows for rank d).  Returns (received rows grouped by source,
+        counts per source)."""
+        torch = self.torch
+        counts = torch.tensor([int(c) for c in send_counts], dtype=torch.int64)
+        if not self.staged:
+            counts = counts.to(self._device)
+        received = torch.zeros_like(counts)
+        self.dist.all_to_all_single(received, counts)
+        recv_counts = [int(x) for x in received.cpu().tolist()]
+        staged = self._in(send).contiguous()
+        out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=staged.device)
+        self.dist.all_to_all_single(out, staged, output_split_sizes=recv_counts, input_split_sizes=[int(c) for c in send_counts])
+        return out.to(send.device), recv_counts
+
+
+# ---- the per-rank executor over the C ABI ---------------------------------------------------------------------------------
+class DeviceValueColumn:
+    """An hy_column over a torch tensor of values in device memory (HY_MEM_DEVICE: nothing is copied), chunked like a table
+    with `chunk_rows` rows per chunk; keeps the tensor(s) alive."""
+
+    def __init__(self, lib, values, chunk_rows, data_type, null_bytes=None):
+        import torch
+        self.lib, self.values, self.data_type = lib, values, data_type
+        self.rows = int(values.shape[0])
+        width = values.element_size()
+        self.null_words = None
+        if null_bytes is not None and bool(null_bytes.any().item()):
+            bits = null_bytes.to(torch.uint8)
+            padded = torch.zeros(((self.rows + 63) // 64) * 64, dtype=torch.uint8, device=bits.device)
+            padded[:self.rows] = bits
+        else:
+            padded = None
+        n_chunks = (self.rows + chunk_rows - 1) // chunk_rows
+        self.n_chunks = n_chunks
+        segments = (abi.Segment * max(1, n_chunks))()
+        self._null_chunks = []
+        for c in range(n_chunks):
+            begin, end = c * chunk_rows, min(self.rows, (c + 1) * chunk_rows)
+            s = segments[c]
+            s.encoding, s.data_type, s.size, s.width = abi.ENC_UNENCODED, data_type, end - begin, width
+            s.data = values.data_ptr() + begin * width
+            s.ref_chunk_id = abi.INVALID_CHUNK_ID
+            if padded is not None:   # the chunk's bits as libstdc++ vector<bool> words (little endian bytes of LSB-first bits)
+                chunk_bits = torch.zeros(((end - begin + 63) // 64) * 64, dtype=torch.uint8, device=bits.device)
+                chunk_bits[:end - begin] = bits[begin:end]
+                weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=bits.device)
+                packed = (chunk_bits.view(-1, 8).to(torch.int32) * weights).sum(dim=1).to(torch.uint8).contiguous()
+                self._null_chunks.append(packed)
+                s.nulls = packed.data_ptr()
+        self._segments = segments
+        handle = C.c_void_p()
+        abi.check(lib.hy_column_create(segments, n_chunks, abi.MEM_DEVICE, C.byref(handle)))
+        self.handle = handle
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hy_column_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipExecutor:
+    """Everything a rank computes, through libhyrise_amd.so on its GPU.  Columns are DeviceColumn / DeviceValueColumn."""
+    _TORCH = None
+
+    def __init__(self, device):
+        import torch
+        self.torch, self.device = torch, device
+        self.lib = abi.load_library()
+        self._types = {abi.TYPE_INT: torch.int32, abi.TYPE_LONG: torch.int64, abi.TYPE_FLOAT: torch.float32, abi.TYPE_DOUBLE: torch.float64}
+
+    def column(self, host_column):
+        from .storage import DeviceColumn
+        return DeviceColumn(host_column)
+
+    def rows_of(self, column):
+        return column.rows
+
+    def aggregate(self, groupby, aggregates):
+        from .operators import aggregate_hash
+        return aggregate_hash(groupby, aggregates)
+
+    def export(self, column, with_nulls=True):
+        torch = self.torch
+        values = torch.empty(column.rows, dtype=self._types[column.data_type], device=self.device)
+        nulls = torch.zeros(column.rows, dtype=torch.uint8, device=self.device) if with_nulls else None
+        abi.check(self.lib.hy_column_export(column.handle, values.data_ptr(), nulls.data_ptr() if nulls is not None else None))
+        return values, nulls
+
+    def value_column(self, values, chunk_rows, null_bytes=None):
+        data_type = {v: k for k, v in self._types.items()}[values.dtype]
+        return DeviceValueColumn(self.lib, values.contiguous(), chunk_rows, data_type, null_bytes)
+
+    def join(self, left, right, mode):
+        """-> (left positions [n, 2] int32, right positions [n, 2] int32 or None for semi / anti joins), device tensors"""
+        torch = self.torch
+        capacity = max(1, left.rows, right.rows)   # enough for a key / foreign-key join; otherwise the join says what it needs
+        slice_capacity = max(left.rows, right.rows) // 131070 + max(left.n_chunks, right.n_chunks) + 600
+        slice_offsets = torch.zeros(slice_capacity + 2, dtype=torch.int64, device=self.device)
+        while True:
+            left_pos = torch.empty((capacity, 2), dtype=torch.int32, device=self.device)
+            right_pos = torch.empty((capacity, 2), dtype=torch.int32, device=self.device)
+            r = abi.JoinResult()
+            r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
+            r.left_pos, r.right_pos, r.capacity = left_pos.data_ptr(), right_pos.data_ptr(), capacity
+            r.slice_offsets, r.slice_capacity = slice_offsets.data_ptr(), slice_capacity
+            status = self.lib.hy_join_hash(left.handle, right.handle, mode, C.byref(r))
+            if status == abi.ERR_CAPACITY and int(r.n_pairs) > capacity:   # (one pass 1 wasted: only joins that multiply rows)
+                capacity = int(r.n_pairs)
+                continue
+            abi.check(status)
+            break
+        pairs = int(r.n_pairs)
+        semi = mode in (abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_ANTI_NULL_AS_FALSE)
+        return left_pos[:pairs], (None if semi else right_pos[:pairs])
+
+    def repartition(self, column, parts, first_chunk):
+        """-> (keys tensor, RowIDs [n, 2] int32, tuples per destination)"""
+        torch = self.torch
+        counts = (C.c_uint64 * parts)()
+        keys = torch.empty(max(1, column.rows), dtype=self._types[column.data_type], device=self.device)
+        rows = torch.empty((max(1, column.rows), 2), dtype=torch.int32, device=self.device)
+        abi.check(self.lib.hy_repartition_pack(column.handle, parts, first_chunk, keys.data_ptr(), rows.data_ptr(), column.rows, counts))
+        abi.check(self.lib.hy_synchronize())
+        per = [int(c) for c in counts]
+        total = sum(per)
+        return keys[:total], rows[:total], per
+
+    def gather_row_ids(self, table, chunk_rows, positions):
+        torch = self.torch
+        out = torch.empty_like(positions)
+        if positions.shape[0]:
+            table = table.contiguous()
+            abi.check(self.lib.hy_gather_row_ids(table.data_ptr(), table.shape[0], chunk_rows, positions.contiguous().data_ptr(), positions.shape[0], out.data_ptr()))
+        return out
+
+    def synchronize(self):
+        abi.check(self.lib.hy_synchronize())
 
 
 # ---- AggregateHash ---------------------------------------------------------------------------------------------------
-def partial_aggregates(functions):
-    """Per-rank aggregate list that carries enough to merge: AVG -> SUM(as double) + COUNT; everything else itself."""
-    plan = []
-    for f in functions:
-        if f == abi.AGG_AVG:
-            plan.append((abi.AGG_AVG, ("sum_as_double", "count")))
-        else:
-            plan.append((f, None))
-    return plan
+_MERGEABLE = (abi.AGG_MIN, abi.AGG_MAX, abi.AGG_SUM, abi.AGG_AVG, abi.AGG_COUNT, abi.AGG_ANY)
+_INT_TYPES = (abi.TYPE_INT, abi.TYPE_LONG)
 
 
-def merge_group_partials(parts, functions):
-    """parts: per rank dict(keys=[tuple], first=[(global_chunk, offset)], values=[[per aggregate (value, count)]]).
-    Returns merged groups in the reference's order (first occurrence over the whole table).  Deterministic: ranks are
-    merged in rank order, so floating-point sums do not depend on arrival order."""
-    merged = {}
-    for part in parts:
-        for key, first, values in zip(part["keys"], part["first"], part["values"]):
-            entry = merged.get(key)
-            if entry is None:
-                merged[key] = {"first": first, "last": part.get("last", {}).get(key, first), "values": [list(v) for v in values]}
-                continue
-            entry["first"] = min(entry["first"], first)
-            for a, (value, count) in enumerate(values):
-                cur_value, cur_count = entry["values"][a]
-                f = functions[a]
-                if count == 0:
-                    continue
-                if cur_count == 0:
-                    entry["values"][a] = [value, count]
-                elif f == abi.AGG_MIN:
-                    entry["values"][a] = [min(cur_value, value), cur_count + count]
-                elif f == abi.AGG_MAX:
-                    entry["values"][a] = [max(cur_value, value), cur_count + count]
-                elif f in (abi.AGG_SUM, abi.AGG_AVG):
-                    entry["values"][a] = [cur_value + value, cur_count + count]
-                else:  # COUNT
-                    entry["values"][a] = [0, cur_count + count]
-    order = sorted(merged.items(), key=lambda kv: kv[1]["first"])
-    return [(key, entry) for key, entry in order]
+MAX_AGGREGATES_PER_CALL = 8   # hy_aggregate_hash's limit
 
 
-def sharded_aggregate(dist, executor, groupby_columns, aggregates, device=None):
-    """groupby_columns / aggregates refer to the FULL table's HostColumns; every rank runs `executor` on its chunk range
-    and the partials are exchanged with one all-gather.  executor(groupby, [(function, column)]) must return an object
-    with n_groups, row_ids (representative = first row of the group in the shard), column(a) values and, for the
-    merge, be called with SUM+COUNT for AVG (done here)."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    shards = {}
+def _local_partials(ex, groupby, aggregates):
+    """The shard's groups: per group the key values, the first row and per aggregate (value, count of non-NULL inputs).
+    The partial aggregates (each distinct (function, column) once, plus ANY of every GROUP BY column for the key values) run
+    in as few executor calls as the per-call limit allows; the calls group the same rows in the same order."""
+    plan, index = [], {}
 
-    def shard(col):
-        if col is None:
-            return None
-        if id(col) not in shards:
-            shards[id(col)] = shard_column(col, world, rank)
-        return shards[id(col)][0]
+    def want(function, column):
+        key = (function, id(column))
+        if key not in index:
+            index[key] = len(plan)
+            plan.append((function, column))
+        return index[key]
 
-    shape = groupby_columns[0] if groupby_columns else next(c for _, c in aggregates if c is not None)
-    chunk_begin, _ = chunk_range(shape.n_chunks, world, rank)
-    # local plan: every aggregate also needs its COUNT of non-NULL inputs; AVG is carried as SUM
-    local = []
-    for f, c in aggregates:
-        local.append((abi.AGG_SUM if f == abi.AGG_AVG else f, shard(c)))
-        local.append((abi.AGG_COUNT, shard(c)))
-    gcols = [shard(c) for c in groupby_columns]
-    rows_here = sum(s.size for s in (gcols[0].segments if gcols else next(c for _, c in local if c is not None).segments))
-    keys, firsts, values = [], [], []
-    if rows_here:
-        # the group's key values are read back through ANY(group-by column)
-        result = executor(gcols, local + [(abi.AGG_ANY, g) for g in gcols])
-        n = result.n_groups
-        cols = [result.column(i) for i in range(len(local) + len(gcols))]
-        for g in range(n):
-            key = tuple(cols[len(local) + k][g] for k in range(len(gcols)))
-            keys.append(key)
-            firsts.append((int(result.row_ids[g][0]) + chunk_begin, int(result.row_ids[g][1])))
-            row = []
-            for a, (f, _) in enumerate(aggregates):
-                value, count = cols[2 * a][g], cols[2 * a + 1][g]
-                if f == abi.AGG_AVG and value is not None:
-                    value = float(value)
-                row.append([0 if value is None else value, 0 if count is None else count])
-            values.append(row)
-    # exchange: one all-gather of a flat float64/int64 encoding (keys may be None -> flag)
-    import pickle
-    payload = np.frombuffer(pickle.dumps({"keys": keys, "first": firsts, "values": values}), dtype=np.uint8).copy()
-    parts = [pickle.loads(p.tobytes()) for p in _all_gather_arrays(dist, payload, device)]
+    cells = []
+    for function, column in aggregates:
+        if function not in _MERGEABLE:
+            raise NotImplementedError(f"aggregate function {function} has no cross-rank merge rule here (COUNT DISTINCT needs the value sets, "
+                                      "STDDEV_SAMP the (n, mean, M2) triple): run it on one GPU")
+        cells.append((want(abi.AGG_SUM if function == abi.AGG_AVG else function, column), want(abi.AGG_COUNT, column)))
+    key_cells = [want(abi.AGG_ANY, g) for g in groupby]
+    shape = groupby[0] if groupby else next((c for _, c in aggregates if c is not None), None)
+    if shape is None or ex.rows_of(shape) == 0:
+        return [], [], []
+    columns, first = [], None
+    for begin in range(0, len(plan), MAX_AGGREGATES_PER_CALL):
+        result = ex.aggregate(groupby, plan[begin:begin + MAX_AGGREGATES_PER_CALL])
+        if first is None:
+            first = result
+        assert result.n_groups == first.n_groups
+        columns += [result.column(i) for i in range(len(plan[begin:begin + MAX_AGGREGATES_PER_CALL]))]
+    n = first.n_groups
+    keys = [tuple(columns[c][g] for c in key_cells) for g in range(n)]
+    rows = [(int(first.row_ids[g][0]), int(first.row_ids[g][1])) for g in range(n)]
+    values = [[(columns[v][g], columns[c][g]) for v, c in cells] for g in range(n)]
+    return keys, rows, values
+
+
+def _aggregate_is_float(function, column):
+    return column is not None and column.data_type in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE) and function != abi.AGG_COUNT
+
+
+def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hint=None):
+    """groupby / aggregates: THIS RANK's chunk range of the columns (executor columns); first_chunk: the range's first chunk
+    id in the whole table.  Every rank returns the same list of (key tuple, [aggregate values]) in the reference's group
+    order.  SUM / AVG over floating-point columns: double additions in a different order than the sequential reference
+    (1e-9 relative, as on one GPU); everything else exact."""
+    torch = comm.torch
     functions = [f for f, _ in aggregates]
-    merged = merge_group_partials(parts, functions)
-    out_rows = []
-    for key, entry in merged:
-        row = list(key)
-        for a, f in enumerate(functions):
-            value, count = entry["values"][a]
-            if f == abi.AGG_COUNT:
-                row.append(count)
-            elif count == 0:
-                row.append(None)
-            elif f == abi.AGG_AVG:
-                row.append(value / count)
+    keys, rows, values = _local_partials(ex, groupby, aggregates)
+    n_aggregates, n_keys = len(aggregates), len(groupby)
+    device = comm._device
+    first_rows = [((chunk + first_chunk) << 32) | offset for chunk, offset in rows]
+    shape = groupby[0] if groupby else next((c for _, c in aggregates if c is not None), None)
+    local_rows = ex.rows_of(shape) if shape is not None else 0
+
+    # ---- key ranges (integer GROUP BY columns only): decide between fixed slots and the general merge, on every rank alike
+    integer_keys = all(g.data_type in _INT_TYPES for g in groupby)
+    BIG = 1 << 62
+    low = torch.full((max(1, n_keys),), BIG, dtype=torch.int64, device=device)
+    high = torch.full((max(1, n_keys),), -BIG, dtype=torch.int64, device=device)
+    if integer_keys and keys:
+        for k in range(n_keys):
+            present = [key[k] for key in keys if key[k] is not None]
+            if present:
+                low[k], high[k] = min(present), max(present)
+    totals = torch.tensor([local_rows], dtype=torch.int64, device=device)
+    comm.all_reduce(low, "min")
+    comm.all_reduce(high, "max")
+    comm.all_reduce(totals, "sum")
+    total_rows = int(totals.item())
+    low_l, high_l = [int(x) for x in low.cpu().tolist()], [int(x) for x in high.cpu().tolist()]
+    spans = [max(0, h - l + 1) + 1 for l, h in zip(low_l, high_l)][:n_keys]   # + 1: slot 0 of every column is NULL
+    slots = 1
+    for s in spans:
+        slots *= s
+    fixed = integer_keys and slots <= FIXED_SLOT_LIMIT
+
+    merged = {}   # key tuple -> [first row, last row, [[value, count], ...]]
+    if fixed:
+        def slot_of(key):
+            index = 0
+            for k in range(n_keys):
+                index = index * spans[k] + (0 if key[k] is None else int(key[k]) - low_l[k] + 1)
+            return index
+
+        isum = torch.zeros((slots, 2 * n_aggregates + 1), dtype=torch.int64, device="cpu")     # integer SUMs | counts | group present
+        fsum = torch.zeros((slots, max(1, n_aggregates)), dtype=torch.float64, device="cpu")
+        imin = torch.full((slots, n_aggregates + 1), BIG, dtype=torch.int64, device="cpu")      # integer MINs | first row
+        imax = torch.full((slots, n_aggregates + 1), -BIG, dtype=torch.int64, device="cpu")     # integer MAXs | last row
+        fmin = torch.full((slots, max(1, n_aggregates)), float("inf"), dtype=torch.float64, device="cpu")
+        fmax = torch.full((slots, max(1, n_aggregates)), float("-inf"), dtype=torch.float64, device="cpu")
+        for key, first, row in zip(keys, first_rows, values):
+            s = slot_of(key)
+            isum[s, 2 * n_aggregates] = 1
+            imin[s, n_aggregates] = first
+            imax[s, n_aggregates] = first
+            for a, (value, count) in enumerate(row):
+                count = 0 if count is None else int(count)
+                isum[s, n_aggregates + a] = count
+                if value is None or (count == 0 and functions[a] != abi.AGG_COUNT):
+                    continue
+                is_float = _aggregate_is_float(functions[a], aggregates[a][1])
+                if functions[a] in (abi.AGG_SUM, abi.AGG_AVG):
+                    if is_float:
+                        fsum[s, a] = float(value)
+                    else:
+                        isum[s, a] = int(value)
+                elif functions[a] in (abi.AGG_MIN, abi.AGG_ANY):
+                    if is_float:
+                        fmin[s, a] = float(value)
+                    else:
+                        imin[s, a] = int(value)
+                elif functions[a] == abi.AGG_MAX:
+                    if is_float:
+                        fmax[s, a] = float(value)
+                    else:
+                        imax[s, a] = int(value)
+        tensors = [(isum, "sum"), (fsum, "sum"), (imin, "min"), (fmin, "min"), (imax, "max"), (fmax, "max")]
+        on_device = [(t.to(device), op) for t, op in tensors]
+        for t, op in on_device:   # the exchange: all-reduce over RCCL, device buffers
+            comm.all_reduce(t, op)
+        isum, fsum, imin, fmin, imax, fmax = [t.cpu() for t, _ in on_device]
+        for s in torch.nonzero(isum[:, 2 * n_aggregates]).flatten().tolist():
+            key, rest = [], s
+            for k in reversed(range(n_keys)):
+                digit = rest % spans[k]
+                rest //= spans[k]
+                key.append(None if digit == 0 else digit - 1 + low_l[k])
+            key = tuple(reversed(key))
+            row = []
+            for a in range(n_aggregates):
+                count = int(isum[s, n_aggregates + a])
+                is_float = _aggregate_is_float(functions[a], aggregates[a][1])
+                if functions[a] in (abi.AGG_SUM, abi.AGG_AVG):
+                    value = float(fsum[s, a]) if is_float else int(isum[s, a])
+                elif functions[a] in (abi.AGG_MIN, abi.AGG_ANY):
+                    value = float(fmin[s, a]) if is_float else int(imin[s, a])
+                elif functions[a] == abi.AGG_MAX:
+                    value = float(fmax[s, a]) if is_float else int(imax[s, a])
+                else:
+                    value = 0
+                row.append([value, count])
+            merged[key] = [int(imin[s, n_aggregates]), int(imax[s, n_aggregates]), row]
+    else:
+        # general merge: every rank's groups, all-gathered as arrays (keys as doubles' / integers' bits in int64 + NULL flags)
+        def bits(value, column):
+            if value is None:
+                return 0
+            if column.data_type in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE):
+                return int(np.float64(value).view(np.int64))
+            return int(value)
+
+        g = len(keys)
+        table = np.zeros((g, 2 * n_keys + 1 + 3 * n_aggregates), dtype=np.int64)
+        for i, (key, first, row) in enumerate(zip(keys, first_rows, values)):
+            for k in range(n_keys):
+                table[i, 2 * k] = bits(key[k], groupby[k])
+                table[i, 2 * k + 1] = 1 if key[k] is None else 0
+            table[i, 2 * n_keys] = first
+            for a, (value, count) in enumerate(row):
+                base = 2 * n_keys + 1 + 3 * a
+                table[i, base] = 0 if count is None else int(count)
+                table[i, base + 1] = 0 if value is None else 1
+                if value is not None:
+                    is_float = _aggregate_is_float(functions[a], aggregates[a][1])
+                    table[i, base + 2] = int(np.float64(value).view(np.int64)) if is_float else int(value)
+        parts = comm.all_gather_var(torch.from_numpy(table).to(device))
+        for part in parts:   # rank order: deterministic floating-point sums
+            for line in part.cpu().numpy():
+                key = []
+                for k in range(n_keys):
+                    if line[2 * k + 1]:
+                        key.append(None)
+                    elif groupby[k].data_type in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE):
+                        key.append(float(np.int64(line[2 * k]).view(np.float64)))
+                    else:
+                        key.append(int(line[2 * k]))
+                key = tuple(key)
+                first = int(line[2 * n_keys])
+                entry = merged.get(key)
+                if entry is None:
+                    entry = merged[key] = [first, first, [[None, 0] for _ in range(n_aggregates)]]
+                entry[0], entry[1] = min(entry[0], first), max(entry[1], first)
+                for a in range(n_aggregates):
+                    base = 2 * n_keys + 1 + 3 * a
+                    count, has_value = int(line[base]), bool(line[base + 1])
+                    is_float = _aggregate_is_float(functions[a], aggregates[a][1])
+                    value = (float(np.int64(line[base + 2]).view(np.float64)) if is_float else int(line[base + 2])) if has_value else None
+                    cur = entry[2][a]
+                    cur[1] += count
+                    if value is None:
+                        continue
+                    if cur[0] is None:
+                        cur[0] = value
+                    elif functions[a] in (abi.AGG_SUM, abi.AGG_AVG):
+                        cur[0] = cur[0] + value
+                    elif functions[a] == abi.AGG_MIN:
+                        cur[0] = min(cur[0], value)
+                    elif functions[a] == abi.AGG_MAX:
+                        cur[0] = max(cur[0], value)
+    # ---- the reference's group order: ascending key with NULL first under the immediate-key shortcut (one int32 GROUP BY
+    #      column whose key range is below 1.2 x rows, aggregate_hash.cpp:770-804), else first occurrence (:388-401)
+    immediate = False
+    if n_keys == 1 and groupby[0].data_type == abi.TYPE_INT and merged:
+        present = [key[0] for key in merged if key[0] is not None]
+        if present and (max(present) - min(present)) < total_rows * 1.2:
+            immediate = True
+    if immediate:
+        order = sorted(merged.items(), key=lambda kv: (kv[0][0] is not None, kv[0][0] if kv[0][0] is not None else 0))
+    else:
+        order = sorted(merged.items(), key=lambda kv: kv[1][0])
+    out = []
+    for key, (first, last, row) in order:
+        cells = []
+        for a, function in enumerate(functions):
+            value, count = row[a]
+            if function == abi.AGG_COUNT:
+                cells.append(count)
+            elif count == 0 or value is None:
+                cells.append(None)
+            elif function == abi.AGG_AVG:
+                cells.append(float(value) / count)
             else:
-                row.append(value)
-        out_rows.append((entry["first"], row))
-    return out_rows
+                cells.append(value)
+        out.append((key, cells))
+    return out
 
 
 # ---- JoinHash --------------------------------------------------------------------------------------------------------
-def gather_build_column(dist, build_values, build_nulls, device=None):
-    """all-gather the build side's (decoded) join column: every rank ends up with the full build column, in rank order
-    == chunk order."""
-    values = _all_gather_arrays(dist, np.ascontiguousarray(build_values), device)
-    nulls = None
-    if build_nulls is not None:
-        nulls = np.concatenate(_all_gather_arrays(dist, np.ascontiguousarray(build_nulls, dtype=np.uint8), device)).astype(bool)
-    return np.concatenate(values), nulls
+def _offset_chunks(torch, positions, first_chunk):
+    """RowIDs [n, 2] int32 of a shard -> of the whole table (NULL_ROW_ID stays)."""
+    if positions is None or first_chunk == 0 or positions.shape[0] == 0:
+        return positions
+    out = positions.clone()
+    valid = out[:, 1] != _NULL_ROW
+    out[:, 0] = torch.where(valid, out[:, 0] + first_chunk, out[:, 0])
+    return out
+
+
+def sharded_join_broadcast(comm, ex, build, probe, mode, first_probe_chunk, build_chunk_rows, build_is_left=True):
+    """Broadcast-build: `build` is this rank's chunk range of the build table's join column, `probe` of the probe table's.
+    Returns this rank's (build RowIDs, probe RowIDs) as device tensors [n, 2] int32, RowIDs of the WHOLE tables.  The shards
+    of the build column must be whole chunks of `build_chunk_rows` rows (all but the table's last): gathered in rank order
+    they are the table."""
+    torch = comm.torch
+    values, nulls = ex.export(build)
+    gathered = torch.cat(comm.all_gather_var(values))
+    gathered_nulls = torch.cat(comm.all_gather_var(nulls)) if nulls is not None else None
+    whole = ex.value_column(gathered, build_chunk_rows, gathered_nulls)
+    if build_is_left:
+        left_pos, right_pos = ex.join(whole, probe, mode)
+        return left_pos, _offset_chunks(torch, right_pos, first_probe_chunk)
+    left_pos, right_pos = ex.join(probe, whole, mode)
+    return right_pos, _offset_chunks(torch, left_pos, first_probe_chunk)
+
+
+def sharded_join_repartition(comm, ex, left, right, first_left_chunk, first_right_chunk, mode=abi.JOIN_INNER):
+    """Hash repartition: both sides' (key, RowID) tuples go to rank  key % G  (one all-to-all per side), every rank joins
+    what it received.  Inner and Semi joins (NULL keys are not sent).  Returns (left RowIDs, right RowIDs or None) of the
+    whole tables, device tensors."""
+    if mode not in (abi.JOIN_INNER, abi.JOIN_SEMI):
+        raise NotImplementedError("the repartitioned join sends no NULL keys: Inner and Semi joins")
+    received = []
+    for column, first_chunk in ((left, first_left_chunk), (right, first_right_chunk)):
+        keys, rows, counts = ex.repartition(column, comm.world, first_chunk)
+        recv_keys, _ = comm.all_to_all_var(keys, counts)
+        recv_rows, _ = comm.all_to_all_var(rows, counts)
+        received.append((recv_keys, recv_rows))
+    (left_keys, left_rows), (right_keys, right_rows) = received
+    left_column = ex.value_column(left_keys, REPARTITION_CHUNK)
+    right_column = ex.value_column(right_keys, REPARTITION_CHUNK)
+    left_pos, right_pos = ex.join(left_column, right_column, mode)
+    out_left = ex.gather_row_ids(left_rows, REPARTITION_CHUNK, left_pos)
+    out_right = ex.gather_row_ids(right_rows, REPARTITION_CHUNK, right_pos) if right_pos is not None else None
+    return out_left, out_right
+
+
+# ---- bench.py --gpus N: the legs beside the weak-scaling scan ---------------------------------------------------------
+def bench_legs(lib, torch, dist, device, rank, world, share_gpu, steps=5):
+    """Strong-scaling scan, sharded Q1-core aggregate and both sharded joins on ONE SF10 table split over the ranks.
+    Returns a dict on rank 0 (None elsewhere): every time is the maximum over the ranks."""
+    import time
+    from . import tpch, storage
+    from .operators import make_predicate
+    from .storage import DeviceColumn
+    comm = Comm(dist).bind(torch.device("cpu") if share_gpu else device)
+    ex = HipExecutor(device)
+    data = tpch.TpchData(scale_factor=10.0, seed=42)   # the same table on every rank; each keeps its chunk range
+
+    def timed(run, repeats=steps):
+        run()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            run()
+        torch.cuda.synchronize()
+        elapsed = torch.tensor([(time.perf_counter() - t0) / repeats], dtype=torch.float64, device=comm._device)
+        comm.all_reduce(elapsed, "max")
+        return float(elapsed.item())
+
+    out = {}
+    # -- scan, strong scaling: one SF10 l_shipdate column, chunk ranges per rank, no collective in the data path
+    days, whole = tpch.shipdate_column(tpch.LINEITEM_ROWS_SF10, seed=42)
+    shard, first_chunk = shard_column(whole, world, rank)
+    column = DeviceColumn(shard)
+    matches = torch.empty((max(1, shard.rows), 2), dtype=torch.int32, device=device)
+    offsets = torch.zeros(shard.n_chunks + 1, dtype=torch.int64, device=device)
+    counts = torch.zeros(max(1, shard.n_chunks), dtype=torch.int32, device=device)
+    result = abi.ScanResult()
+    result.mem, result.flags = abi.MEM_DEVICE, abi.SCAN_CHUNK_REGIONS
+    result.matches, result.capacity, result.offsets, result.counts = matches.data_ptr(), shard.rows, offsets.data_ptr(), counts.data_ptr()
+    predicate = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
+    seconds = timed(lambda: abi.check(lib.hy_table_scan(column.handle, C.byref(predicate), None, 0, C.byref(result))), repeats=max(steps, 20))
+    found = torch.tensor([int(counts.sum().item())], dtype=torch.int64, device=comm._device)
+    comm.all_reduce(found, "sum")
+    out["scan_strong"] = {"rows": whole.rows, "ms": seconds * 1e3, "rows_per_s": whole.rows / seconds, "matches": int(found.item()),
+                          "expected_matches": int((days < tpch.DAY_1995_01_01).sum())}
+    del column, matches
+    # -- aggregate: Q1 core as specified, per-rank partials + fixed-slot all-reduce
+    groupby_host, measures_host, _ = tpch.q1_core_columns(data)
+    groupby = [DeviceColumn(shard_column(c, world, rank)[0]) for c in groupby_host]
+    measures = {name: DeviceColumn(shard_column(c, world, rank)[0]) for name, c in measures_host.items()}
+    first_chunk = shard_column(groupby_host[0], world, rank)[1]
+    aggregates = [(abi.AGG_SUM, measures["l_quantity"]), (abi.AGG_SUM, measures["l_extendedprice"]), (abi.AGG_AVG, measures["l_quantity"]),
+                  (abi.AGG_AVG, measures["l_extendedprice"]), (abi.AGG_AVG, measures["l_discount"]), (abi.AGG_COUNT, None)]
+    holder = {}
+
+    def run_aggregate():
+        holder["groups"] = sharded_aggregate(comm, ex, groupby, aggregates, first_chunk)
+
+    seconds = timed(run_aggregate)
+    out["aggregate_q1"] = {"rows": data.n_lineitems, "ms": seconds * 1e3, "rows_per_s": data.n_lineitems / seconds, "groups": len(holder["groups"]),
+                           "count_star_total": int(sum(cells[5] for _, cells in holder["groups"])), "exchange": "fixed-slot all-reduce (sum / min / max)"}
+    del groupby, measures
+    # -- joins: orders x lineitem on the order key, both tables chunk-sharded
+    orders_host = storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED)
+    lineitem_host = storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE)
+    orders_shard, first_orders = shard_column(orders_host, world, rank)
+    lineitem_shard, first_lineitem = shard_column(lineitem_host, world, rank)
+    orders, lineitem = DeviceColumn(orders_shard), DeviceColumn(lineitem_shard)
+    total = data.n_orders + data.n_lineitems
+    pairs = {}
+
+    def run_broadcast():
+        build_pos, probe_pos = sharded_join_broadcast(comm, ex, orders, lineitem, abi.JOIN_INNER, first_lineitem, abi.CHUNK_DEFAULT_SIZE)
+        pairs["broadcast"] = build_pos.shape[0]
+
+    def run_repartition():
+        left_pos, right_pos = sharded_join_repartition(comm, ex, orders, lineitem, first_orders, first_lineitem)
+        pairs["repartition"] = left_pos.shape[0]
+
+    for name, run in (("join_broadcast_build", run_broadcast), ("join_repartition", run_repartition)):
+        seconds = timed(run, repeats=min(steps, 3))
+        n_pairs = torch.tensor([pairs["broadcast" if "broadcast" in name else "repartition"]], dtype=torch.int64, device=comm._device)
+        comm.all_reduce(n_pairs, "sum")
+        out[name] = {"rows": total, "ms": seconds * 1e3, "rows_per_s": total / seconds, "pairs": int(n_pairs.item()), "expected_pairs": data.n_lineitems}
+    return out if rank == 0 else None

@@ -338,6 +338,27 @@ typedef struct hy_aggregate_result {
 hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby,
                             const hy_aggregate_spec* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
 
+/* ---- multi-GPU exchange (the reference is one process: these have no counterpart there) ----------------
+ * Sharding an operator over GPUs adds one exchange step per operator (hyrise_amd/distributed.py: one process per GPU, RCCL):
+ * the broadcast-build JoinHash all-gathers the build side's join column, the repartitioned JoinHash sends every (key, RowID)
+ * to the GPU  std::hash(key) % parts  (the integer itself: JoinHash's own hash function, join_hash_steps.hpp:352), the
+ * sharded AggregateHash all-reduces per-group partials.  The buffers of those collectives are produced and consumed on the
+ * device by the entry points below; all pointers are DEVICE pointers unless stated. */
+/* The column's values decoded into values[rows] (the column's type; NULL rows: 0) and, if nulls is not NULL, nulls[rows] bytes. */
+hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls);
+/* Rows per destination of a hash repartition of an integer join column (NULL keys never find a partner: they are not sent).
+ * counts[parts] is a HOST array. */
+hy_status hy_repartition_count(const hy_column* column, uint32_t parts, uint64_t* counts);
+/* The (key, RowID) tuples grouped by destination, (chunk, row) order inside each: keys_out (int32 for an int column, int64 for a
+ * long column) and row_ids_out hold the tuples of destination 0, then 1, ...; counts[parts] (HOST) as above.  The RowIDs carry
+ * chunk_id + chunk_id_offset (the shard's first chunk in the whole table). */
+hy_status hy_repartition_pack(const hy_column* column, uint32_t parts, uint32_t chunk_id_offset, void* keys_out, hy_row_id* row_ids_out,
+                              uint64_t capacity, uint64_t* counts);
+/* out[i] = table[positions[i].chunk_id * chunk_rows + positions[i].chunk_offset] (NULL_ROW_ID stays): the PosList of a join over
+ * received tuple arrays (presented as a column of chunk_rows-row chunks) back to the RowIDs that travelled with the keys. */
+hy_status hy_gather_row_ids(const hy_row_id* table, uint64_t table_rows, uint32_t chunk_rows, const hy_row_id* positions, uint64_t n,
+                            hy_row_id* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,63 @@
+"""The per-rank executor of the CPU tests: the same interface as hyrise_amd.distributed.HipExecutor, computed by the CPU
+oracle and numpy on host tensors (test infrastructure: there is no GPU in the CPU test environment)."""
+import numpy as np
+import torch
+
+from hyrise_amd import abi
+from support import build_column, column_values, oracle_aggregate, oracle_join
+
+_NP = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}
+
+
+class OracleExecutor:
+    def column(self, host_column):
+        return host_column
+
+    def rows_of(self, column):
+        return column.rows
+
+    def aggregate(self, groupby, aggregates):
+        return oracle_aggregate(groupby, aggregates)
+
+    def export(self, column, with_nulls=True):
+        cells = column_values(column)
+        nulls = np.array([c is None for c in cells], dtype=np.uint8)
+        values = np.array([0 if c is None else c for c in cells], dtype=_NP[column.data_type])
+        return torch.from_numpy(values), (torch.from_numpy(nulls) if with_nulls else None)
+
+    def value_column(self, values, chunk_rows, null_bytes=None):
+        nulls = null_bytes.numpy().astype(bool) if null_bytes is not None and bool(null_bytes.any()) else None
+        return build_column(values.numpy(), nulls, chunk_rows, abi.ENC_UNENCODED)
+
+    def join(self, left, right, mode):
+        result = oracle_join(left, right, mode)
+        n = result.n_pairs
+        semi = mode in (abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_ANTI_NULL_AS_FALSE)
+        left_pos = torch.from_numpy(result.left[:n].astype(np.int64).astype(np.uint32).view(np.int32).copy())
+        right_pos = None if semi else torch.from_numpy(result.right[:n].view(np.int32).copy())
+        return left_pos, right_pos
+
+    def repartition(self, column, parts, first_chunk):
+        cells = column_values(column)
+        rows = []
+        for c, seg in enumerate(column.segments):
+            rows.extend((c + first_chunk, i) for i in range(seg.size))
+        keep = [i for i, cell in enumerate(cells) if cell is not None]
+        keys = np.array([cells[i] for i in keep], dtype=_NP[column.data_type])
+        row_ids = np.array([rows[i] for i in keep], dtype=np.uint32).reshape(-1, 2)
+        dest = (keys.astype(np.int64).view(np.uint64) % np.uint64(parts)).astype(np.int64)
+        order = np.argsort(dest, kind="stable")
+        counts = [int((dest == p).sum()) for p in range(parts)]
+        return torch.from_numpy(keys[order].copy()), torch.from_numpy(row_ids[order].view(np.int32).copy()), counts
+
+    def gather_row_ids(self, table, chunk_rows, positions):
+        t = table.numpy().view(np.uint32)
+        p = positions.numpy().view(np.uint32)
+        out = np.full_like(p, 0xFFFFFFFF)
+        valid = p[:, 1] != 0xFFFFFFFF
+        flat = p[valid, 0].astype(np.int64) * chunk_rows + p[valid, 1].astype(np.int64)
+        out[valid] = t[flat]
+        return torch.from_numpy(out.view(np.int32).copy())
+
+    def synchronize(self):
+        pass
