@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--no-join", action="store_true", help="skip the JoinHash orders x lineitem leg")
     ap.add_argument("--no-aggregate", action="store_true", help="skip the AggregateHash Q1-core leg")
     ap.add_argument("--no-multi", action="store_true", help="N > 1: skip the strong-scaling / aggregate / join legs")
+    ap.add_argument("--no-ssb", action="store_true", help="skip the SSB SF30 star-join leg (config 5)")
     return ap.parse_args()
 
 
@@ -428,6 +429,11 @@ def main():
     if world > 1 and not args.no_multi and not args.rows:
         from hyrise_amd import distributed
         multi = distributed.bench_legs(lib, torch, dist, dev, rank, world, share_gpu, steps=max(3, min(args.steps, 10)))
+    ssb_info = None
+    if not args.no_ssb and not args.rows:   # config 5: SSB SF30 star joins, lineorder chunk-sharded over the ranks
+        del columns, matches
+        from hyrise_amd import ssb
+        ssb_info = ssb.bench(30.0, 3, world, rank, dist, share_gpu, local_rank)
 
     if rank == 0:
         line = {
@@ -450,6 +456,9 @@ def main():
             line["aggregate"] = aggregate_info
         if multi:
             line["multi_gpu"] = multi
+        if ssb_info:
+            line["ssb"] = dict(ssb_info, workload="configs[4]: SSB SF30 Q2.1 / Q4.1 star joins (dimension scans, one JoinHash per dimension over device-resident "
+                                                   "PosLists, AggregateHash), synthetic tables per the SSB specification")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_scan(host_column, predicate, rows)
         print(json.dumps(line))

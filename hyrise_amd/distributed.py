@@ -162,8 +162,50 @@ class DeviceValueColumn:
             pass
 
 
+class DeviceReferenceColumn:
+    """A column of a reference table in device memory: `rows` ([n, 2] int32 RowIDs into `base`, a data column) presented as
+    ReferenceSegments of `chunk_rows` rows each (HY_MEM_DEVICE: the PosList a join or scan just wrote is read in place)."""
+
+    def __init__(self, lib, base, rows, chunk_rows):
+        import torch
+        self.lib, self.base, self.data_type = lib, base, base.data_type
+        if rows.shape[0] == 0:   # an empty table still has a type: one empty chunk
+            rows = torch.zeros((1, 2), dtype=torch.int32, device=rows.device)
+            self.rows = 0
+        else:
+            rows = rows.contiguous()
+            self.rows = int(rows.shape[0])
+        self.pos = rows
+        n_chunks = max(1, (self.rows + chunk_rows - 1) // chunk_rows)
+        self.n_chunks = n_chunks
+        segments = (abi.Segment * n_chunks)()
+        for c in range(n_chunks):
+            begin, end = c * chunk_rows, min(self.rows, (c + 1) * chunk_rows)
+            s = segments[c]
+            s.encoding, s.data_type, s.size, s.width = abi.ENC_REFERENCE, base.data_type, max(0, end - begin), 8
+            s.data = rows.data_ptr() + begin * 8
+            s.ref = base.handle
+            s.ref_chunk_id = abi.INVALID_CHUNK_ID
+        self._segments = segments
+        handle = C.c_void_p()
+        abi.check(lib.hy_column_create(segments, n_chunks, abi.MEM_DEVICE, C.byref(handle)))
+        self.handle = handle
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hy_column_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipExecutor:
-    """Everything a rank computes, through libhyrise_amd.so on its GPU.  Columns are DeviceColumn / DeviceValueColumn."""
+    """Everything a rank computes, through libhyrise_amd.so on its GPU.  Columns are DeviceColumn / DeviceValueColumn /
+    DeviceReferenceColumn / operators.ResultColumn."""
     _TORCH = None
 
     def __init__(self, device):
@@ -181,7 +223,27 @@ class HipExecutor:
 
     def aggregate(self, groupby, aggregates):
         from .operators import aggregate_hash
-        return aggregate_hash(groupby, aggregates)
+        shape = groupby[0] if groupby else next(c for _, c in aggregates if c is not None)
+        try:   # few groups are the rule; a result that does not fit says so
+            return aggregate_hash(groupby, aggregates, group_capacity=min(shape.rows + 1, 4096))
+        except abi.HyriseAmdError as error:
+            if error.status != abi.ERR_CAPACITY:
+                raise
+        return aggregate_hash(groupby, aggregates, group_capacity=shape.rows + 1)
+
+    def scan(self, column, predicate):
+        """RowIDs of the matching rows, one flat device PosList (dimension tables: the per-chunk PosLists come back through
+        host memory; a fact-table scan keeps its chunk regions on the device, hy_table_scan with HY_MEM_DEVICE)."""
+        from .operators import table_scan
+        result = table_scan(column, predicate, flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
+        return self.torch.from_numpy(result.matches[:result.total].view(np.int32).copy()).to(self.device)
+
+    def reference_column(self, base, rows, chunk_rows):
+        return DeviceReferenceColumn(self.lib, base, rows, chunk_rows)
+
+    def projection(self, op, left, right):
+        from .operators import projection_arithmetic
+        return projection_arithmetic(op, left, right)
 
     def export(self, column, with_nulls=True):
         torch = self.torch
@@ -284,6 +346,25 @@ def _local_partials(ex, groupby, aggregates):
     rows = [(int(first.row_ids[g][0]), int(first.row_ids[g][1])) for g in range(n)]
     values = [[(columns[v][g], columns[c][g]) for v, c in cells] for g in range(n)]
     return keys, rows, values
+
+
+def aggregate_groups(ex, groupby, aggregates):
+    """One GPU: [(key tuple, [aggregate values])] in the reference's group order (the executor's)."""
+    keys, _, values = _local_partials(ex, groupby, aggregates)
+    out = []
+    for key, row in zip(keys, values):
+        cells = []
+        for (function, _), (value, count) in zip(aggregates, row):
+            if function == abi.AGG_COUNT:
+                cells.append(count)
+            elif value is None or not count:
+                cells.append(None)
+            elif function == abi.AGG_AVG:
+                cells.append(float(value) / count)
+            else:
+                cells.append(value)
+        out.append((key, cells))
+    return out
 
 
 def _aggregate_is_float(function, column):

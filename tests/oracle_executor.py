@@ -19,6 +19,26 @@ class OracleExecutor:
     def aggregate(self, groupby, aggregates):
         return oracle_aggregate(groupby, aggregates)
 
+    def scan(self, column, predicate):
+        from support import oracle_scan
+        result = oracle_scan(column, predicate, flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
+        return torch.from_numpy(result.matches[:result.total].view(np.int32).copy())
+
+    def reference_column(self, base, rows, chunk_rows):
+        from hyrise_amd import storage
+        pos = rows.numpy().view(np.uint32).reshape(-1, 2)
+        chunks = [pos[begin:begin + chunk_rows] for begin in range(0, len(pos), chunk_rows)] or [pos[:0]]
+        return storage.make_reference_column(base, chunks)
+
+    def projection(self, op, left, right):
+        a, b = column_values(left), column_values(right)
+        assert op == abi.ARITH_SUB
+        nulls = np.array([x is None or y is None for x, y in zip(a, b)], dtype=bool)
+        values = np.array([0 if (x is None or y is None) else x - y for x, y in zip(a, b)], dtype=_NP[left.data_type])
+        sizes = [s.size for s in left.segments]
+        chunk = max(sizes + [1])
+        return build_column(values, nulls if nulls.any() else None, chunk, abi.ENC_UNENCODED)
+
     def export(self, column, with_nulls=True):
         cells = column_values(column)
         nulls = np.array([c is None for c in cells], dtype=np.uint8)

@@ -1,0 +1,30 @@
+"""Config 5 (SSB star joins) on the device: the plans of hyrise_amd/ssb.py through the C ABI -- dimension scans, one JoinHash per
+dimension over device-resident PosLists (reference columns in HBM, hy_gather_row_ids dereferencing), projection, AggregateHash --
+against SQLite and against the same plan executed by the CPU oracle."""
+import pytest
+import torch
+
+from hyrise_amd import ssb
+from hyrise_amd.distributed import HipExecutor, aggregate_groups
+from oracle_executor import OracleExecutor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("query,sql", [("2.1", ssb.Q2_1_SQL), ("4.1", ssb.Q4_1_SQL)])
+def test_ssb_query_on_device(device, query, sql):
+    data = ssb.SsbData(scale_factor=0.05, seed=9, lineorder_rows=300_000)
+    host = data.host_columns()
+    ex = HipExecutor(torch.device("cuda", 0))
+    columns = {name: ex.column(c) for name, c in host.items()}
+    groupby, aggregates, joined = ssb.run_query(ex, columns, query)
+    got = ssb.result_rows(aggregate_groups(ex, groupby, aggregates))
+    oracle = OracleExecutor()
+    o_groupby, o_aggregates, o_joined = ssb.run_query(oracle, host, query)
+    want = ssb.result_rows(aggregate_groups(oracle, o_groupby, o_aggregates))
+    assert joined == o_joined and got == want
+    if query == "2.1":
+        sqlite = sorted(((year, brand), total) for total, year, brand in data.sqlite_result(sql))
+    else:
+        sqlite = sorted(((year, nation), profit) for year, nation, profit in data.sqlite_result(sql))
+    assert got == sqlite
