@@ -39,7 +39,8 @@ constexpr uint32_t LDS_SLOTS = 256;
 constexpr uint32_t MAX_GLOBAL_PROBES = 512;   // linear probing in the global group table: longer sequences count as overflow
 constexpr uint32_t DENSE_GROUPS = 4;   // slices with at most this many groups accumulate in thread-private LDS cells
 constexpr uint32_t TAG_EMPTY = 0, TAG_LOCKED = 1;   // ready tags have bit 31 set
-constexpr uint32_t AGG_SUM_SQUARES = 100;           // device-internal: sum of x*x as double (second accumulator of STDDEV_SAMP)
+constexpr uint32_t AGG_SUM_SQUARES = 100;           // device-internal: sum of (x - pivot)^2 as double (second accumulator of STDDEV_SAMP)
+constexpr uint32_t AGG_SUM_SHIFTED = 101;           // device-internal: sum of (x - pivot) as double + count (first accumulator of STDDEV_SAMP)
 
 struct AggColumn {
   const DevSegment* segments;
@@ -47,6 +48,7 @@ struct AggColumn {
   uint32_t data_type;    // HY_TYPE_*
   uint32_t is_float;     // accumulate as double
   uint32_t reserved;
+  double pivot;          // AGG_SUM_SHIFTED / AGG_SUM_SQUARES: a value of the column, subtracted before accumulating (see STDDEV_SAMP below)
 };
 
 struct AggArgs {
@@ -177,6 +179,7 @@ __device__ __forceinline__ void merge_global(const AggArgs& a, uint32_t slot, ui
     case HY_AGG_MAX: atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(value)); break;
     case HY_AGG_SUM:
     case HY_AGG_AVG:
+    case AGG_SUM_SHIFTED:
     case AGG_SUM_SQUARES:
       if (c.is_float || c.function != HY_AGG_SUM) atomicAdd(reinterpret_cast<double*>(target), __longlong_as_double(static_cast<long long>(value)));
       else atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(value));
@@ -193,6 +196,7 @@ __device__ __forceinline__ uint64_t combine(const AggColumn& c, uint64_t accumul
     case HY_AGG_MAX: return static_cast<uint64_t>(max(static_cast<long long>(accumulator), static_cast<long long>(contribution)));
     case HY_AGG_SUM:
     case HY_AGG_AVG:
+    case AGG_SUM_SHIFTED:
     case AGG_SUM_SQUARES:
       if (c.is_float || c.function != HY_AGG_SUM) {
         return static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(accumulator)) + __longlong_as_double(static_cast<long long>(contribution))));
@@ -209,9 +213,10 @@ __device__ __forceinline__ uint64_t contribution_from(const AggColumn& c, uint64
     case HY_AGG_MAX: return c.is_float ? static_cast<uint64_t>(ordered_bits(__longlong_as_double(static_cast<long long>(bits)))) : bits;
     case HY_AGG_SUM: return bits;
     case HY_AGG_AVG: return c.is_float ? bits : static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<int64_t>(bits))));
+    case AGG_SUM_SHIFTED:
     case AGG_SUM_SQUARES: {
-      const double x = c.is_float ? __longlong_as_double(static_cast<long long>(bits)) : static_cast<double>(static_cast<int64_t>(bits));
-      return static_cast<uint64_t>(__double_as_longlong(x * x));
+      const double x = (c.is_float ? __longlong_as_double(static_cast<long long>(bits)) : static_cast<double>(static_cast<int64_t>(bits))) - c.pivot;
+      return static_cast<uint64_t>(__double_as_longlong(c.function == AGG_SUM_SQUARES ? x * x : x));
     }
     default: return 0;
   }
@@ -223,6 +228,7 @@ __device__ __forceinline__ void accumulate_lds(const AggColumn& c, uint64_t* tar
     case HY_AGG_MAX: atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(contribution)); break;
     case HY_AGG_SUM:
     case HY_AGG_AVG:
+    case AGG_SUM_SHIFTED:
     case AGG_SUM_SQUARES:
       if (c.is_float || c.function != HY_AGG_SUM) atomicAdd(reinterpret_cast<double*>(target), __longlong_as_double(static_cast<long long>(contribution)));
       else atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(contribution));
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     if (c.function == HY_AGG_MIN) kind = ACC_MIN;
     else if (c.function == HY_AGG_MAX) kind = ACC_MAX;
     else if (c.function == HY_AGG_SUM) kind = c.is_float ? ACC_ADD_DOUBLE : ACC_ADD_INT;
-    else if (c.function == HY_AGG_AVG || c.function == AGG_SUM_SQUARES) kind = ACC_ADD_DOUBLE;
+    else if (c.function == HY_AGG_AVG || c.function == AGG_SUM_SQUARES || c.function == AGG_SUM_SHIFTED) kind = ACC_ADD_DOUBLE;
     const bool to_ordered = (kind == ACC_MIN || kind == ACC_MAX) && c.is_float;   // MIN/MAX of doubles on order-preserving int64
     const bool int_to_double = c.function == HY_AGG_AVG && !c.is_float;
     // One private accumulator per (dense group, thread), in registers: a row updates the accumulator of its group through
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
         } else if (int_to_double) {
 #pragma unroll
           for (int i = 0; i < AB; ++i) bits[i] = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(static_cast<int64_t>(bits[i]))));
-        } else if (c.function == AGG_SUM_SQUARES) {
+        } else if (c.function == AGG_SUM_SQUARES || c.function == AGG_SUM_SHIFTED) {
 #pragma unroll
           for (int i = 0; i < AB; ++i) bits[i] = contribution_from(c, bits[i]);
         }
@@ -1102,6 +1108,40 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   return fail(HY_ERR_DEVICE, "the device group table overflowed at every size (internal error)");
 }
 
+
+// Some value of a column (its first non-NULL one among the first rows of the chunks), as a double: STDDEV_SAMP accumulates
+// sum(x - pivot) and sum((x - pivot)^2).  The reference runs Welford's recurrence (abstract_aggregate_operator.hpp:83-113);
+// plain sums of x and x^2 cancel catastrophically when |mean| >> spread (values 1e9 + {0, 1, 2}: x^2 ~ 1e18, one ulp 128),
+// shifted by a value of the data they do not: the variance formula is shift-invariant and the shifted terms are of the
+// size of the spread.  out[0] = pivot, out[1] = 1 if one was found.
+__global__ __launch_bounds__(256) void column_pivot(const DevSegment* segments, uint32_t n_chunks, double* out) {
+  __shared__ double s_value;
+  __shared__ uint32_t s_found;
+  if (threadIdx.x == 0) s_found = 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t chunk = 0; chunk < n_chunks; ++chunk) {
+    const uint32_t size = segments[chunk].size;
+    for (uint32_t begin = 0; begin < size && begin < 16384; begin += 256) {
+      const uint32_t row = begin + threadIdx.x;
+      Value v{true, 0, 0.0};
+      if (row < size) v = column_value(segments, chunk, row);
+      if (!v.is_null) atomicMin(&s_found, threadIdx.x);
+      __syncthreads();
+      if (s_found != 0xFFFFFFFFu) {
+        if (threadIdx.x == s_found) {
+          const uint32_t type = segments[chunk].data_type;
+          s_value = (type == HY_TYPE_FLOAT || type == HY_TYPE_DOUBLE) ? v.f : static_cast<double>(v.i);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { out[0] = s_value; out[1] = 1.0; }
+        return;
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; }
+}
+
 static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_groupby, const hy_aggregate_spec* specs, uint32_t n_aggregates,
                                hy_aggregate_result* result) {
   if (n_groupby > MAX_GROUPBY) return fail(HY_ERR_UNSUPPORTED, "more than %u GROUP BY columns stay on the CPU path", MAX_GROUPBY);
@@ -1128,7 +1168,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     if (groupby[g]->data_type == HY_TYPE_STRING) return fail(HY_ERR_UNSUPPORTED, "string GROUP BY columns must be passed as dictionary segments of int64 key names (INTEGRATION.md)");
     wire(a.groupby[g], groupby[g], 0);
   }
-  // Device accumulators.  STDDEV_SAMP takes two (sum as double + count, sum of squares); COUNT(DISTINCT) takes none: it
+  // Device accumulators.  STDDEV_SAMP takes two (sum of x - pivot as double + count, sum of (x - pivot)^2); COUNT(DISTINCT) takes none: it
   // is a second grouping by (GROUP BY columns, aggregate column) whose groups are counted per outer group.
   std::vector<int> primary(n_aggregates, -1), secondary(n_aggregates, -1);
   uint32_t n_device = 0;
@@ -1157,10 +1197,19 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     const uint32_t wanted = spec.function == HY_AGG_STDDEV_SAMP ? 2 : 1;
     if (n_device + wanted > MAX_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "more than %u device accumulators stay on the CPU path", MAX_AGGREGATES);
     primary[g] = static_cast<int>(n_device);
-    wire(a.aggregates[n_device++], spec.column, spec.function == HY_AGG_STDDEV_SAMP ? static_cast<uint32_t>(HY_AGG_AVG) : spec.function);
+    wire(a.aggregates[n_device++], spec.column, spec.function == HY_AGG_STDDEV_SAMP ? AGG_SUM_SHIFTED : spec.function);
     if (spec.function == HY_AGG_STDDEV_SAMP) {
       secondary[g] = static_cast<int>(n_device);
       wire(a.aggregates[n_device++], spec.column, AGG_SUM_SQUARES);
+      double* pivot_host = nullptr;   // a value of the column to shift by (column_pivot above)
+      double* pivot_dev = nullptr;
+      HY_TRY(pinned_staging(16, reinterpret_cast<void**>(&pivot_host), reinterpret_cast<void**>(&pivot_dev)));
+      pivot_host[0] = pivot_host[1] = 0.0;
+      if (spec.column->n_chunks) {
+        hipLaunchKernelGGL(column_pivot, dim3(1), dim3(256), 0, current_stream(), spec.column->d_segments, spec.column->n_chunks, pivot_dev);
+        HY_HIP(hipStreamSynchronize(current_stream()));
+      }
+      a.aggregates[n_device - 2].pivot = a.aggregates[n_device - 1].pivot = pivot_host[0];
     }
   }
   a.n_aggregates = n_device;
@@ -1265,7 +1314,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       switch (function) {
         case HY_AGG_COUNT: vi = static_cast<int64_t>(count); break;
         case HY_AGG_COUNT_DISTINCT: vi = have ? static_cast<int64_t>(distinct_counts[g][order[o]]) : 0; break;
-        case HY_AGG_STDDEV_SAMP:   // abstract_aggregate_operator.hpp:83-113 (Welford there; sums here: float tolerance)
+        case HY_AGG_STDDEV_SAMP:   // abstract_aggregate_operator.hpp:83-113 (Welford there; sums of the values shifted by a value of the column here)
           is_null = count <= 1;
           if (count > 1) {
             double sum, squares;

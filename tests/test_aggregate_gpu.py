@@ -160,3 +160,29 @@ def test_direct_mapped_groups_and_plain_value_columns(device, n):
     assert got.n_groups == 2
     run_both([few, g2], more, "12 codes")
     run_both([g2], aggregates[:6] + more[:2], "six groups: two of them behind the dense four")
+
+
+def test_stddev_of_large_values_with_a_small_spread(device):
+    """STDDEV_SAMP where |mean| >> spread (values around 1e9, spread 1): the plain sums of x and x^2 cancel catastrophically
+    (x^2 ~ 1e18: one ulp is 128).  The device accumulates values shifted by a value of the column and lands within 1e-9 of the
+    exact standard deviation; the reference's Welford recurrence (abstract_aggregate_operator.hpp:83-113, the oracle) rounds
+    its running mean at these magnitudes (1e-7 .. 1e-5 relative here), so both are checked against the exact value."""
+    rng = np.random.default_rng(12)
+    n = 200_000
+    keys = rng.integers(0, 5, n).astype(np.int32) * 1000
+    key_column = build_column(keys, None, 65535, abi.ENC_UNENCODED)
+    for values in ((1_000_000_000 + rng.integers(0, 3, n)).astype(np.int32), (1e9 + rng.random(n)).astype(np.float64),
+                   (5_000_000_000_000 + rng.integers(-2, 3, n)).astype(np.int64)):
+        nulls = rng.random(n) < 0.01
+        column = build_column(values, nulls, 65535, abi.ENC_UNENCODED)
+        got = aggregate_hash([DeviceColumn(key_column)], [(abi.AGG_STDDEV_SAMP, DeviceColumn(column))])
+        want = oracle_aggregate([key_column], [(abi.AGG_STDDEV_SAMP, column)])
+        assert got.n_groups == want.n_groups == 5
+        np.testing.assert_array_equal(got.row_ids[:5], want.row_ids[:5])
+        group_keys = [int(keys[int(r[0]) * 65535 + int(r[1])]) for r in want.row_ids[:5]]
+        for g, key in enumerate(group_keys):
+            member = (keys == key) & ~nulls
+            shifted = (values[member] - values[member][0]).astype(np.longdouble)   # exact: the differences are small
+            exact = float(np.sqrt(((shifted - shifted.mean()) ** 2).sum() / (member.sum() - 1)))
+            assert abs(got.column(0)[g] - exact) <= 1e-9 * exact, f"device {got.column(0)[g]} vs exact {exact}"
+            assert abs(want.column(0)[g] - exact) <= 1e-4 * exact, f"oracle {want.column(0)[g]} vs exact {exact}"   # (the reference tests tolerance)
