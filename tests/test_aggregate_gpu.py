@@ -166,7 +166,7 @@ def test_stddev_of_large_values_with_a_small_spread(device):
     """STDDEV_SAMP where |mean| >> spread (values around 1e9, spread 1): the plain sums of x and x^2 cancel catastrophically
     (x^2 ~ 1e18: one ulp is 128).  The device accumulates values shifted by a value of the column and lands within 1e-9 of the
     exact standard deviation; the reference's Welford recurrence (abstract_aggregate_operator.hpp:83-113, the oracle) rounds
-    its running mean at these magnitudes (1e-7 .. 1e-5 relative here), so both are checked against the exact value."""
+    its running mean at these magnitudes (1e-7 .. 2e-4 relative here), so both are checked against the exact value."""
     rng = np.random.default_rng(12)
     n = 200_000
     keys = rng.integers(0, 5, n).astype(np.int32) * 1000
@@ -185,4 +185,4 @@ def test_stddev_of_large_values_with_a_small_spread(device):
             shifted = (values[member] - values[member][0]).astype(np.longdouble)   # exact: the differences are small
             exact = float(np.sqrt(((shifted - shifted.mean()) ** 2).sum() / (member.sum() - 1)))
             assert abs(got.column(0)[g] - exact) <= 1e-9 * exact, f"device {got.column(0)[g]} vs exact {exact}"
-            assert abs(want.column(0)[g] - exact) <= 1e-4 * exact, f"oracle {want.column(0)[g]} vs exact {exact}"   # (the reference tests tolerance)
+            assert abs(want.column(0)[g] - exact) <= 1e-3 * exact, f"oracle {want.column(0)[g]} vs exact {exact}"   # (its running mean has an ulp of 1e-3 at 5e12)
