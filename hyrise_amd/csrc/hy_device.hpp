@@ -114,6 +114,7 @@ hy_status fail(hy_status code, const char* fmt, ...);
   } while (0)
 
 hipStream_t current_stream();
+void bind_thread_device();   // hipSetDevice(the device hy_init chose) once per thread
 
 // Pinned, device-mapped host memory of this thread (grow-only): small results that kernels store straight into host
 // memory, read by the host after a stream synchronise -- instead of one blit kernel and host round trip per hipMemcpyAsync.

@@ -2923,6 +2923,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   clock.mark("pass 1 launched");
   if (count_only) {
     HY_HIP(hipStreamSynchronize(stream));
+    if (mailbox->error) return fail(HY_ERR_UNSUPPORTED, "a probe row matches more than 4 194 303 build rows");   // (pass 1 clamped its count)
     if (count_out) *count_out = mailbox->n_pairs;
     return HY_OK;
   }

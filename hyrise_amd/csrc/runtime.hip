@@ -5,6 +5,7 @@
 // table_scan.cpp:129-131 -- here one call covers all chunks, and concurrent calls come from different threads).
 #include "hy_device.hpp"
 
+#include <atomic>
 #include <cstring>
 
 namespace hy {
@@ -23,7 +24,23 @@ hy_status fail(hy_status code, const char* fmt, ...) {
   return code;
 }
 
-hipStream_t current_stream() { return t_stream; }
+// The device hy_init chose, for every thread of the process: hipSetDevice only binds the CALLING thread, and the operators
+// run on Hyrise's scheduler workers (abstract_scheduler.cpp:53-63), not on the thread that loaded the plugin.  Every thread
+// binds itself the first time it reaches the library (all entry points pass through current_stream / the pools below).
+static std::atomic<int> g_device{-1};
+static thread_local int t_bound_device = -1;
+void bind_thread_device() {
+  const int device = g_device.load(std::memory_order_acquire);
+  if (device >= 0 && t_bound_device != device) {
+    (void)hipSetDevice(device);
+    t_bound_device = device;
+  }
+}
+
+hipStream_t current_stream() {
+  bind_thread_device();
+  return t_stream;
+}
 
 struct Profile {
   bool enabled = false;
@@ -80,6 +97,7 @@ struct BufferPool {
 static thread_local BufferPool t_pool;
 
 hy_status pool_acquire(size_t bytes, void** ptr, size_t* capacity) {
+  bind_thread_device();
   size_t rounded = 4096;
   while (rounded < bytes) rounded <<= 1;
   for (size_t i = 0; i < t_pool.free_blocks.size(); ++i) {
@@ -118,6 +136,7 @@ struct PinnedStaging {
 static thread_local PinnedStaging t_staging;
 
 hy_status pinned_staging(size_t bytes, void** host, void** device) {
+  bind_thread_device();
   if (bytes > t_staging.bytes) {
     if (t_staging.host) (void)hipHostFree(t_staging.host);
     t_staging.host = t_staging.device = nullptr;
@@ -133,7 +152,10 @@ hy_status pinned_staging(size_t bytes, void** host, void** device) {
   return HY_OK;
 }
 
-Scratch& scratch() { return t_scratch; }
+Scratch& scratch() {
+  bind_thread_device();
+  return t_scratch;
+}
 
 hy_status Scratch::reserve(size_t bytes) {
   bytes = align_up(bytes + 4096, 1 << 20);
@@ -216,6 +238,8 @@ hy_status hy_init(int32_t device) {
   if (n <= 0) return fail(HY_ERR_DEVICE, "hy_init: no HIP device visible -- the MI355X path has no CPU fallback");
   if (device < 0 || device >= n) return fail(HY_ERR_INVALID, "hy_init: device %d out of range [0,%d)", device, n);
   HY_HIP(hipSetDevice(device));
+  g_device.store(device, std::memory_order_release);   // (every other thread binds itself on its first call: bind_thread_device)
+  t_bound_device = device;
   hipDeviceProp_t prop;
   HY_HIP(hipGetDeviceProperties(&prop, device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("HY_ALLOW_ANY_ARCH")) {
@@ -285,6 +309,7 @@ hy_status hy_synchronize(void) {
 
 hy_status hy_device_malloc(void** ptr, size_t bytes) {
   if (!ptr) return fail(HY_ERR_INVALID, "hy_device_malloc: null argument");
+  bind_thread_device();
   HY_HIP(hipMalloc(ptr, bytes ? bytes : 256));
   return HY_OK;
 }
@@ -295,14 +320,16 @@ hy_status hy_device_free(void* ptr) {
 }
 
 hy_status hy_memcpy_h2d(void* dst, const void* src, size_t bytes) {
-  if (bytes) HY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, t_stream));
-  HY_HIP(hipStreamSynchronize(t_stream));
+  hipStream_t stream = current_stream();
+  if (bytes) HY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+  HY_HIP(hipStreamSynchronize(stream));
   return HY_OK;
 }
 
 hy_status hy_memcpy_d2h(void* dst, const void* src, size_t bytes) {
-  if (bytes) HY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t_stream));
-  HY_HIP(hipStreamSynchronize(t_stream));
+  hipStream_t stream = current_stream();
+  if (bytes) HY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+  HY_HIP(hipStreamSynchronize(stream));
   return HY_OK;
 }
 
@@ -374,6 +401,7 @@ static size_t null_bytes(const hy_segment& s) {
 
 hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32_t mem, hy_column** out) {
   if (!out) return fail(HY_ERR_INVALID, "hy_column_create: null output");
+  bind_thread_device();
   *out = nullptr;
   if (n_chunks && !segments) return fail(HY_ERR_INVALID, "hy_column_create: null segments");
   if (mem != HY_MEM_HOST && mem != HY_MEM_DEVICE) return fail(HY_ERR_INVALID, "hy_column_create: bad memory space %u", mem);

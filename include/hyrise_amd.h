@@ -183,7 +183,8 @@ typedef struct hy_scan_result {
 
 /* ---- runtime -------------------------------------------------------------------------------------------------- */
 int32_t hy_abi_version(void);
-hy_status hy_init(int32_t device);            /* selects the HIP device for the calling process (one process per GPU) */
+hy_status hy_init(int32_t device);            /* selects the HIP device of the process (one process per GPU): every thread that calls
+                                               * into the library afterwards is bound to it on its first call */
 hy_status hy_shutdown(void);
 const char* hy_last_error(void);              /* thread-local message of the last non-OK status */
 hy_status hy_set_stream(void* hip_stream);    /* thread-local stream used for all launches; NULL = default stream     */
