@@ -18,26 +18,30 @@ abi.check(lib.hy_init(0))
 sf = float(os.environ.get("SF", "10"))
 data = tpch.TpchData(scale_factor=sf, seed=42)
 n = data.n_lineitems
-cols = {
-    "l_returnflag": storage.make_column(data.l_returnflag, None, abi.ENC_DICTIONARY),
-    "l_linestatus": storage.make_column(data.l_linestatus, None, abi.ENC_DICTIONARY),
-    "l_quantity": storage.make_column(data.l_quantity, None, abi.ENC_UNENCODED),
-    "l_extendedprice": storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED),
-    "l_discount": storage.make_column(data.l_discount, None, abi.ENC_UNENCODED),
-}
+if os.environ.get("PLAIN"):   # round 1's shape: int32 dictionary keys, unencoded float measures
+    cols = {
+        "l_returnflag": storage.make_column(data.l_returnflag, None, abi.ENC_DICTIONARY),
+        "l_linestatus": storage.make_column(data.l_linestatus, None, abi.ENC_DICTIONARY),
+        "l_quantity": storage.make_column(data.l_quantity, None, abi.ENC_UNENCODED),
+        "l_extendedprice": storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED),
+        "l_discount": storage.make_column(data.l_discount, None, abi.ENC_UNENCODED),
+    }
+    bytes_total = n * (1 + 1 + 4 + 4 + 4)
+else:                         # config 4 as specified: string keys as key names, dictionary-encoded float measures
+    groupby_host, measures_host, bytes_total = tpch.q1_core_columns(data)
+    cols = dict(measures_host, l_returnflag=groupby_host[0], l_linestatus=groupby_host[1])
 dev = {k: DeviceColumn(v) for k, v in cols.items()}
 aggregates = [(abi.AGG_SUM, dev["l_quantity"]), (abi.AGG_SUM, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_quantity"]),
               (abi.AGG_AVG, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_discount"]), (abi.AGG_COUNT, None)]
 n_aggs = int(os.environ.get("AGGS", str(len(aggregates))))
 aggregates = aggregates[:n_aggs] if n_aggs else [(abi.AGG_COUNT, None)]
-bytes_per_row = 1 + 1 + 4 + 4 + 4
 for i in range(4):
     torch.cuda.synchronize()
     t = time.perf_counter()
     result = aggregate_hash([dev["l_returnflag"], dev["l_linestatus"]], aggregates, group_capacity=64)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
-    print(f"aggregate ms {dt * 1e3:.3f} groups {result.n_groups} rows/s {n / dt:.3g} algorithmic GB/s {n * bytes_per_row / dt / 1e9:.0f}")
+    print(f"aggregate ms {dt * 1e3:.3f} groups {result.n_groups} rows/s {n / dt:.3g} algorithmic GB/s {bytes_total / dt / 1e9:.0f}")
 if os.environ.get("HY_AGG_TRACE"):
     lib.hy_debug_aggregate_trace.argtypes = [C.c_void_p, C.c_uint32]
     lib.hy_debug_aggregate_trace.restype = C.c_int

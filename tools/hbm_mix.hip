@@ -48,19 +48,23 @@ __global__ __launch_bounds__(256) void mix(const u32x4* __restrict__ in, uint2* 
 int main(int argc, char** argv) {
   const unsigned n_parts = 916, rows = 65536;
   const double selectivities[] = {0.15, 0.43};
+  // argv[1] = number of input copies scanned in rotation (default 1: the 120 MB input stays in the 256 MiB Infinity Cache; 3: every
+  // launch reads its input from HBM, like bench.py's rotating column copies)
+  const int copies = argc > 1 ? atoi(argv[1]) : 1;
   u32x4* in;
   uint2* out;
   unsigned* sink;
-  CHECK(hipMalloc(&in, size_t{n_parts} * rows * 2));
+  CHECK(hipMalloc(&in, size_t{n_parts} * rows * 2 * copies));
   CHECK(hipMalloc(&out, size_t{n_parts + 1} * (rows + 4096) * 8));
   CHECK(hipMalloc(&sink, 4));
-  CHECK(hipMemset(in, 1, size_t{n_parts} * rows * 2));
+  CHECK(hipMemset(in, 1, size_t{n_parts} * rows * 2 * copies));
+  const size_t copy_words = size_t{n_parts} * rows * 2 / 16;
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   typedef void (*Kernel)(const u32x4*, uint2*, unsigned, unsigned, unsigned, unsigned*, unsigned);
   const Kernel kernels[8] = {mix<0>, mix<1>, mix<2>, mix<3>, mix<4>, mix<5>, mix<6>, mix<7>};
-  for (unsigned stride : {65536u, 65535u, 65536u + 1040u, 65536u - 2064u, 28192u, 32768u + 1040u})
+  for (unsigned stride : {65535u, 65536u + 1040u})
   for (unsigned mode : {3u}) {
     const unsigned grid = 916;
     printf("region stride %u RowIDs\n", stride);
@@ -73,7 +77,7 @@ int main(int argc, char** argv) {
       const int reps = 30;
       for (int i = 0; i < reps; ++i) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(mix, dim3(grid > n_parts ? n_parts : grid), dim3(256), 0, 0, in, out, rows, out_per_wg, n_parts, sink, stride);
+        hipLaunchKernelGGL(mix, dim3(grid > n_parts ? n_parts : grid), dim3(256), 0, 0, in + (i % copies) * copy_words, out, rows, out_per_wg, n_parts, sink, stride);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;

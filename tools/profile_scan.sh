@@ -10,8 +10,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o scan -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-join --no-aggregate > $OUT/bench_trace.log 2>&1 || true
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o scan -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-join --no-aggregate > $OUT/bench_fetch.log 2>&1 || true
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o scan -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-join --no-aggregate > $OUT/bench_write.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o scan -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-join --no-aggregate --no-cases --no-ssb > $OUT/bench_trace.log 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o scan -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-join --no-aggregate --no-cases --no-ssb > $OUT/bench_fetch.log 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o scan -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-join --no-aggregate --no-cases --no-ssb > $OUT/bench_write.log 2>&1 || true
 find $OUT -name '*.csv' | head -20
 python $R/tools/summarize_profile.py $OUT
