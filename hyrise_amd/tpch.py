@@ -13,6 +13,8 @@ dbgen implements) so that value ranges, dictionary sizes and vector-compression 
 Dates are int32 days since 1992-01-01 (the "int" twin of SURVEY.md section 8: a dictionary scan only ever sees value
 ids, so DictionarySegment<int32> of day numbers and DictionarySegment<pmr_string> of ISO dates run the same kernel).
 """
+import os
+
 import numpy as np
 
 from . import abi, storage
@@ -36,6 +38,21 @@ class TpchData:
     """Raw (unencoded) numpy columns of orders and lineitem at `scale_factor`."""
 
     def __init__(self, scale_factor=10.0, seed=42, lineitem_rows=None):
+        # HY_TPCH_CACHE=<directory>: the profiling scripts run the same generator many times in one session
+        cache = os.environ.get("HY_TPCH_CACHE")
+        path = os.path.join(cache, f"tpch_{scale_factor}_{seed}_{lineitem_rows}.npz") if cache else None
+        if path and os.path.exists(path):
+            with np.load(path) as arrays:
+                for name in arrays.files:
+                    setattr(self, name, arrays[name])
+            self.n_orders, self.n_lineitems = len(self.o_orderkey), len(self.l_orderkey)
+            return
+        self._generate(scale_factor, seed, lineitem_rows)
+        if path:
+            os.makedirs(cache, exist_ok=True)
+            np.savez(path, **{name: value for name, value in vars(self).items() if isinstance(value, np.ndarray)})
+
+    def _generate(self, scale_factor, seed, lineitem_rows):
         rng = np.random.default_rng(seed)
         n_orders = int(round(ORDERS_PER_SF * scale_factor))
         self.o_orderkey = sparse_orderkeys(n_orders)

@@ -1,7 +1,10 @@
-"""The BASELINE.json configurations at their FULL size (TPC-H SF10: 59 986 052 lineitem rows, 15 000 000 orders), checked
-through properties that do not need the oracle to process 60 M rows: counts against numpy, order invariants of the
-reference's output (PosLists ascending per chunk; join pairs grouped by radix partition and ascending in the probe
-row inside a partition), key equality of EVERY join pair, and aggregate totals within the stated float tolerance."""
+"""The BASELINE.json configurations at their FULL size (TPC-H SF10: 59 986 052 lineitem rows, 15 000 000 orders), compared
+BYTE FOR BYTE with the oracle run on the same columns (PosLists and counts of configuration 2; both pair arrays and the
+PosList cuts of configuration 3; the group rows and every aggregate value of configuration 4 as SURVEY.md 8(d) specifies it),
+and additionally through properties that do not depend on the oracle: counts against numpy, order invariants of the
+reference's output, key equality of EVERY join pair, aggregate totals within the stated float tolerance."""
+import os
+
 import ctypes as C
 
 import numpy as np
@@ -10,6 +13,10 @@ import pytest
 from hyrise_amd import abi, storage, tpch
 from hyrise_amd.operators import aggregate_hash, make_predicate
 from hyrise_amd.storage import DeviceColumn
+
+from support import oracle_aggregate, oracle_join, oracle_scan
+
+ORACLE_THREADS = max(1, min(32, os.cpu_count() or 1))
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +75,12 @@ def test_scan_sf10_shipdate(device, sf10):
         keep = (np.arange(rows) % chunk) < np.repeat(got_counts, chunk)[:rows]      # the filled prefix of every region
         got_rows = host_matches[keep]
         np.testing.assert_array_equal(got_rows[:, 0].astype(np.int64) * chunk + got_rows[:, 1], np.flatnonzero(expected))
+        # ... and the oracle's bytes: per-chunk counts, chunk states and every PosList, chunk by chunk
+        # (the oracle packs the PosLists back to back; the device wrote each into its chunk's region, `keep` is the same bytes)
+        want = oracle_scan(host, predicate, threads=ORACLE_THREADS)
+        assert want.n_chunks == host.n_chunks and int(got_counts.sum()) == int(want.c.total_matches) == want.total   # (device-memory results leave total_matches to the caller)
+        np.testing.assert_array_equal(got_counts, want.counts[:host.n_chunks].astype(np.int64))
+        assert want.matches[:want.total].tobytes() == np.ascontiguousarray(got_rows).tobytes()
 
 
 def test_join_sf10_orders_lineitem(device, sf10):
@@ -98,6 +111,12 @@ def test_join_sf10_orders_lineitem(device, sf10):
     assert cuts[0] == 0 and cuts[-1] == n and np.all(np.diff(cuts) > 0) and np.all(np.diff(cuts) <= 131070)
     per_partition = np.bincount(partition, minlength=128)
     assert r.n_slices == int(np.sum((per_partition + 131069) // 131070))           # a new PosList every 131 070 probe elements
+    # ... and the oracle's bytes: both pair arrays and every PosList cut
+    want = oracle_join(orders.host, lineitem.host, abi.JOIN_INNER, threads=ORACLE_THREADS, capacity=n)
+    assert want.n_pairs == n and int(want.c.radix_bits) == 7 and int(want.c.left_is_build) == 1 and int(want.c.n_slices) == r.n_slices
+    want_left, want_right = want.pairs()
+    assert want_left.tobytes() == left.numpy().tobytes() and want_right.tobytes() == right.numpy().tobytes()
+    np.testing.assert_array_equal(want.slice_offsets[:r.n_slices + 1].astype(np.int64), cuts)
 
 
 def test_aggregate_sf10_q1_core(device, sf10):
@@ -118,3 +137,38 @@ def test_aggregate_sf10_q1_core(device, sf10):
         total = float(sf10.l_quantity[members].astype(np.float64).sum())
         mean = float(sf10.l_extendedprice[members].astype(np.float64).mean())
         assert abs(got.column(0)[i] - total) <= 1e-9 * total and abs(got.column(1)[i] - mean) <= 1e-9 * mean
+
+
+def test_aggregate_sf10_q1_as_specified(device, sf10):
+    """Configuration 4 as SURVEY.md 8(d) specifies it: GROUP BY the two string columns (dictionary segments whose entries
+    are AggregateKeyEntry names, aggregate_hash.cpp:852-914) over DictionarySegment<float> measures with u8 / u16 / u8
+    attribute vectors -- against the oracle's bytes.  Byte-exact: the group rows (order of first occurrence), COUNT, ANY and
+    the sums whose double accumulation is exact in any order (l_quantity: whole numbers; l_discount: hundredths as float32,
+    49 significant bits at most).  SUM / AVG(l_extendedprice) need up to 60 bits, so they carry the stated 1e-9 relative
+    tolerance (the device adds in another order than the reference's single thread)."""
+    groupby, measures, _ = tpch.q1_core_columns(sf10)
+    assert [s.width for s in (groupby[0].segments[0], groupby[1].segments[0])] == [1, 1]
+    assert [measures[m].segments[0].width for m in ("l_quantity", "l_extendedprice", "l_discount")] == [1, 2, 1]
+    device_groupby = [DeviceColumn(c) for c in groupby]
+    device_measures = {name: DeviceColumn(c) for name, c in measures.items()}
+    functions = [(abi.AGG_SUM, "l_quantity"), (abi.AGG_SUM, "l_extendedprice"), (abi.AGG_SUM, "l_discount"), (abi.AGG_AVG, "l_quantity"),
+                 (abi.AGG_AVG, "l_extendedprice"), (abi.AGG_AVG, "l_discount"), (abi.AGG_COUNT, None)]
+    got = aggregate_hash(device_groupby, [(f, device_measures[m] if m else None) for f, m in functions], group_capacity=64)
+    want = oracle_aggregate(groupby, [(f, measures[m] if m else None) for f, m in functions], group_capacity=64)
+    groups = want.n_groups
+    assert got.n_groups == groups == 4
+    assert got.row_ids[:groups].tobytes() == want.row_ids[:groups].tobytes()         # the first row of every group, in group order
+    for a, (function, measure) in enumerate(functions):
+        assert got.columns[a].data_type == want.columns[a].data_type
+        assert got.nulls[a][:groups].tobytes() == want.nulls[a][:groups].tobytes()
+        if measure == "l_extendedprice":
+            np.testing.assert_allclose(got.raw[a][:groups].view(np.float64), want.raw[a][:groups].view(np.float64), rtol=1e-9, atol=0)
+        else:
+            assert got.raw[a][:groups].tobytes() == want.raw[a][:groups].tobytes(), (function, measure)
+    # independent of the oracle: the four (returnflag, linestatus) groups and their sizes from numpy
+    keys = sf10.l_returnflag.astype(np.int64) * 256 + sf10.l_linestatus
+    values, first, counts = np.unique(keys, return_index=True, return_counts=True)
+    order = np.argsort(first)
+    assert got.column(6) == counts[order].tolist()
+    chunk = abi.CHUNK_DEFAULT_SIZE
+    assert (got.row_ids[:groups, 0].astype(np.int64) * chunk + got.row_ids[:groups, 1]).tolist() == first[order].tolist()
