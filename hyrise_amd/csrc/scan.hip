@@ -1214,6 +1214,49 @@ __global__ void compact_regions(const hy_row_id* regions, const uint64_t* region
   for (uint64_t i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
 }
 
+
+// hy_poslist_translate: exclusive prefix sum of the per-chunk match counts (one workgroup; a column has thousands of chunks
+// at most) -> where every chunk's PosList begins in the back-to-back output, and the total behind the last one.
+__global__ __launch_bounds__(256) void region_prefix(const uint32_t* __restrict__ counts, uint32_t n_chunks, uint64_t* __restrict__ dense_offsets) {
+  __shared__ uint64_t s_sum[256];
+  const uint32_t per = (n_chunks + 255) / 256;
+  const uint32_t begin = min(n_chunks, threadIdx.x * per), end = min(n_chunks, begin + per);
+  uint64_t mine = 0;
+  for (uint32_t c = begin; c < end; ++c) mine += counts[c];
+  s_sum[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t running = 0;
+    for (uint32_t t = 0; t < 256; ++t) { const uint64_t v = s_sum[t]; s_sum[t] = running; running += v; }
+    dense_offsets[n_chunks] = running;
+  }
+  __syncthreads();
+  uint64_t running = s_sum[threadIdx.x];
+  for (uint32_t c = begin; c < end; ++c) { dense_offsets[c] = running; running += counts[c]; }
+}
+
+// hy_poslist_translate: chunk c's region -> its place in the back-to-back PosList; a match (c, o) of a scan over
+// ReferenceSegments becomes the RowID at position o of chunk c's PosList (table_scan.cpp:158-196), so that the output
+// references the data table and never a reference table.  blockIdx.x: chunk, blockIdx.y: quarter of its matches.
+__global__ __launch_bounds__(256) void translate_regions(const DevSegment* __restrict__ segments, const hy_row_id* __restrict__ regions, const uint64_t* __restrict__ region_offsets,
+                                                         const uint32_t* __restrict__ counts, const uint64_t* __restrict__ dense_offsets, hy_row_id* __restrict__ out,
+                                                         uint64_t capacity) {
+  const uint32_t c = blockIdx.x;
+  const uint32_t count = counts[c];
+  const uint64_t base = dense_offsets[c];
+  if (base + count > capacity) return;   // the host reports HY_ERR_CAPACITY from the total
+  const DevSegment seg = segments[c];
+  const uint2* src = reinterpret_cast<const uint2*>(regions + region_offsets[c]);
+  uint2* dst = reinterpret_cast<uint2*>(out + base);
+  const bool reference = seg.encoding == HY_ENC_REFERENCE;
+  const uint2* pos_list = static_cast<const uint2*>(seg.data);
+  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < count; i += 256 * gridDim.y) {
+    uint2 r = src[i];
+    if (reference) r = pos_list ? pos_list[r.y] : make_uint2(seg.ref_chunk_id, r.y);
+    dst[i] = r;
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 
 // Launch shape of the persistent scan kernel: min(parts, CUs x resident workgroups per CU).  Workgroups of a chunk
@@ -1484,6 +1527,34 @@ hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, u
   }
   if (left->data_type == HY_TYPE_STRING || right->data_type == HY_TYPE_STRING) return fail(HY_ERR_UNSUPPORTED, "string ColumnVsColumn scans stay on the CPU path");
   return run_scan(left, right, nullptr, condition, nullptr, 0, result);
+}
+
+hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* result, hy_row_id* out, uint64_t capacity, uint64_t* n_out) {
+  if (!scanned || !result || !n_out) return fail(HY_ERR_INVALID, "hy_poslist_translate: null argument");
+  *n_out = 0;
+  if (result->mem != HY_MEM_DEVICE) return fail(HY_ERR_INVALID, "hy_poslist_translate reads a device-memory scan result (host results are back to back already)");
+  if (!(result->flags & HY_SCAN_CHUNK_REGIONS) || !(result->flags & HY_SCAN_MATERIALIZE_ALL_MATCH)) {
+    return fail(HY_ERR_INVALID, "hy_poslist_translate: the scan must have run with HY_SCAN_CHUNK_REGIONS | HY_SCAN_MATERIALIZE_ALL_MATCH");
+  }
+  if (!result->matches || !result->offsets || !result->counts) return fail(HY_ERR_INVALID, "hy_poslist_translate: matches, offsets and counts of the scan result are needed");
+  if (capacity && !out) return fail(HY_ERR_INVALID, "hy_poslist_translate: output buffer missing");
+  const uint32_t n_chunks = scanned->n_chunks;
+  if (n_chunks == 0) return HY_OK;
+  hipStream_t stream = current_stream();
+  Scratch& sc = scratch();
+  HY_TRY(sc.reserve(8 * (size_t{n_chunks} + 2) + 4096));
+  uint64_t* d_dense_offsets = carve<uint64_t>(sc, size_t{n_chunks} + 2);
+  if (!d_dense_offsets) return fail(HY_ERR_DEVICE, "scratch arena exhausted");
+  hipLaunchKernelGGL(region_prefix, dim3(1), dim3(256), 0, stream, result->counts, n_chunks, d_dense_offsets);
+  hipLaunchKernelGGL(translate_regions, dim3(n_chunks, 4), dim3(256), 0, stream, scanned->d_segments, result->matches, result->offsets, result->counts, d_dense_offsets, out,
+                     capacity);
+  HY_HIP(hipGetLastError());
+  uint64_t total = 0;
+  HY_HIP(hipMemcpyAsync(&total, d_dense_offsets + n_chunks, 8, hipMemcpyDeviceToHost, stream));
+  HY_HIP(hipStreamSynchronize(stream));
+  *n_out = total;
+  if (total > capacity) return fail(HY_ERR_CAPACITY, "hy_poslist_translate: %llu RowIDs, capacity is %llu", static_cast<unsigned long long>(total), static_cast<unsigned long long>(capacity));
+  return HY_OK;
 }
 
 }  // extern "C"

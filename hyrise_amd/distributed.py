@@ -232,11 +232,24 @@ class HipExecutor:
         return aggregate_hash(groupby, aggregates, group_capacity=shape.rows + 1)
 
     def scan(self, column, predicate):
-        """RowIDs of the matching rows, one flat device PosList (dimension tables: the per-chunk PosLists come back through
-        host memory; a fact-table scan keeps its chunk regions on the device, hy_table_scan with HY_MEM_DEVICE)."""
-        from .operators import table_scan
-        result = table_scan(column, predicate, flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
-        return self.torch.from_numpy(result.matches[:result.total].view(np.int32).copy()).to(self.device)
+        """RowIDs of the matching rows as ONE flat device PosList that references the DATA table: hy_table_scan writes its
+        chunk regions to device memory, hy_poslist_translate packs them and -- when `column` is a reference column, i.e. the
+        output of an earlier scan or join -- replaces each match by the RowID it stands for (table_scan.cpp:158-196).  Eight
+        bytes (the match count) cross to the host; no PosList does."""
+        torch = self.torch
+        rows, n_chunks = max(1, column.rows), column.n_chunks
+        regions = torch.empty((rows, 2), dtype=torch.int32, device=self.device)
+        offsets = torch.empty(n_chunks + 1, dtype=torch.int64, device=self.device)
+        counts = torch.zeros(max(1, n_chunks), dtype=torch.int32, device=self.device)
+        result = abi.ScanResult()
+        result.mem, result.flags = abi.MEM_DEVICE, abi.SCAN_CHUNK_REGIONS | abi.SCAN_MATERIALIZE_ALL_MATCH
+        result.matches, result.capacity = regions.data_ptr(), rows
+        result.offsets, result.counts = offsets.data_ptr(), counts.data_ptr()
+        abi.check(self.lib.hy_table_scan(column.handle, C.byref(predicate), None, 0, C.byref(result)))
+        out = torch.empty((rows, 2), dtype=torch.int32, device=self.device)
+        written = C.c_uint64(0)
+        abi.check(self.lib.hy_poslist_translate(column.handle, C.byref(result), out.data_ptr(), rows, C.byref(written)))
+        return out[:int(written.value)]
 
     def reference_column(self, base, rows, chunk_rows):
         return DeviceReferenceColumn(self.lib, base, rows, chunk_rows)

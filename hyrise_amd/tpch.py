@@ -126,3 +126,37 @@ def q1_core_columns(data, chunk_size=abi.CHUNK_DEFAULT_SIZE):
         for s in column.segments:
             total += s.size * s.width + s.aux_size * s.aux.dtype.itemsize
     return groupby, measures, total
+
+
+# ---- TPC-H Q6 as an operator chain (configs[0]: the reference's own CPU-runnable case) -------------------------------------
+Q6_SQL = ("SELECT SUM(l_extendedprice * l_discount) AS revenue, COUNT(*) FROM lineitem WHERE l_shipdate >= :from AND l_shipdate < :to "
+          "AND l_discount BETWEEN :low AND :high AND l_quantity < :quantity")
+RESULT_CHUNK = 65535   # operator results are presented to the next operator as tables of this chunk size
+
+
+def q6_columns(data, chunk_size=abi.CHUNK_DEFAULT_SIZE):
+    """The four lineitem columns Q6 touches: l_shipdate / l_discount dictionary-encoded, l_quantity / l_extendedprice as
+    float value segments."""
+    return {"l_shipdate": storage.make_column(data.l_shipdate, None, abi.ENC_DICTIONARY, chunk_size),
+            "l_discount": storage.make_column(data.l_discount, None, abi.ENC_DICTIONARY, chunk_size),
+            "l_quantity": storage.make_column(data.l_quantity, None, abi.ENC_UNENCODED, chunk_size),
+            "l_extendedprice": storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED, chunk_size)}
+
+
+def run_q6(ex, columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discount=(0.05, 0.07), quantity=24.0):
+    """TPC-H Q6 (tpch_queries.cpp:206-210) the way the reference's plan runs it: three TableScans chained through reference
+    segments (the second and third scan read the PosList of the one before, table_scan.cpp:158-196), a Projection
+    l_extendedprice * l_discount over the survivors, AggregateHash SUM without GROUP BY.  `ex`: distributed.HipExecutor (every
+    intermediate -- PosLists, the product column -- stays in device memory) or the tests' oracle executor.
+    -> (revenue, qualifying rows)"""
+    from .operators import make_predicate
+    rows = ex.scan(columns["l_shipdate"], make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, date_from, date_to))
+    rows = ex.scan(ex.reference_column(columns["l_discount"], rows, RESULT_CHUNK),
+                   make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, np.float32(discount[0]), np.float32(discount[1])))
+    rows = ex.scan(ex.reference_column(columns["l_quantity"], rows, RESULT_CHUNK), make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, quantity))
+    if rows.shape[0] == 0:
+        return None, 0        # SUM over no rows is NULL
+    revenue = ex.projection(abi.ARITH_MUL, ex.reference_column(columns["l_extendedprice"], rows, RESULT_CHUNK),
+                            ex.reference_column(columns["l_discount"], rows, RESULT_CHUNK))
+    result = ex.aggregate([], [(abi.AGG_SUM, revenue), (abi.AGG_COUNT, None)])
+    return result.column(0)[0], result.column(1)[0]

@@ -235,6 +235,17 @@ hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, u
 hy_status hy_validate(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut,
                       hy_scan_result* result);
 
+/* The PosList a scan hands to the next operator, WITHOUT leaving device memory (replaces the output assembly of
+ * TableScan::_on_execute, table_scan.cpp:158-196: the matches of a scan over ReferenceSegments are translated through the
+ * input PosList, so the output always references the data table, never another reference table).
+ * `result`: a HY_MEM_DEVICE result of hy_table_scan / hy_table_scan_columns / hy_validate over `scanned`, produced with
+ * HY_SCAN_CHUNK_REGIONS | HY_SCAN_MATERIALIZE_ALL_MATCH.  Writes ONE back-to-back PosList to `out` (device memory, room for
+ * `capacity` RowIDs): the chunks' matches in chunk order; over a reference column a match (c, o) is replaced by the RowID at
+ * position o of chunk c's PosList ((ref_chunk_id, o) for an entire-chunk PosList), NULL RowIDs included as they are.
+ * *n_out (host): RowIDs written -- the one value that crosses to the host (8 bytes; the call waits for the stream).
+ * HY_ERR_CAPACITY with *n_out = the needed capacity if `out` is too small. */
+hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* result, hy_row_id* out, uint64_t capacity, uint64_t* n_out);
+
 /* ---- Projection arithmetic (the ArithmeticExpressions a Projection evaluates through the
  * ExpressionEvaluator, operators/projection.cpp + expression/evaluation/expression_functors.hpp:127-213) -------------------
  * result = left <op> right, element-wise over a table's rows; an operand is a column of the table (data or reference

@@ -14,32 +14,11 @@ from hyrise_amd import abi, storage, tpch
 from hyrise_amd.operators import aggregate_hash, make_predicate
 from hyrise_amd.storage import DeviceColumn
 
-from support import oracle_aggregate, oracle_join, oracle_scan
+from support import DeviceArray, oracle_aggregate, oracle_join, oracle_scan
 
 ORACLE_THREADS = max(1, min(32, os.cpu_count() or 1))
 
 pytestmark = pytest.mark.gpu
-
-
-class DeviceArray:
-    """A device buffer through the C ABI (hy_device_malloc / hy_memcpy_d2h): the tests need no torch."""
-
-    def __init__(self, lib, shape, dtype):
-        self.lib, self.shape, self.dtype = lib, shape, np.dtype(dtype)
-        self.nbytes = int(np.prod(shape)) * self.dtype.itemsize
-        pointer = C.c_void_p()
-        abi.check(lib.hy_device_malloc(C.byref(pointer), max(self.nbytes, 256)))
-        self.pointer = pointer.value
-
-    def numpy(self):
-        out = np.empty(self.shape, dtype=self.dtype)
-        abi.check(self.lib.hy_memcpy_d2h(out.ctypes.data, self.pointer, self.nbytes))
-        return out
-
-    def __del__(self):
-        if getattr(self, "pointer", None):
-            self.lib.hy_device_free(self.pointer)
-            self.pointer = None
 
 
 @pytest.fixture(scope="module")

@@ -79,46 +79,42 @@ def test_all_type_pairs(device):
                 "reference segments float - long")
 
 
-def test_tpch_q6_pipeline_stays_on_device(device):
+def test_tpch_q6_pipeline_stays_on_device(device, monkeypatch):
     """SELECT SUM(l_extendedprice * l_discount) FROM lineitem WHERE l_shipdate >= 1994-01-01 AND l_shipdate < 1995-01-01
-    AND l_discount BETWEEN 0.05 AND 0.07 AND l_quantity < 24 -- scans chained through reference segments (PosLists), the
-    product over the survivors, the sum: every intermediate is a device column; the check is plain numpy."""
+    AND l_discount BETWEEN 0.05 AND 0.07 AND l_quantity < 24 -- tpch.run_q6: three scans chained through reference segments,
+    the product over the survivors, the sum.  Every intermediate is a device buffer: the scans write chunk regions to HBM,
+    hy_poslist_translate packs / dereferences them there, the next operator reads them in place.  Proof: the host-result
+    classes are made unusable for the duration of the chain, and every PosList handed on is a CUDA tensor."""
+    import torch
+    from hyrise_amd import operators
+    from hyrise_amd.distributed import HipExecutor
     data = tpch.TpchData(scale_factor=0.05, seed=7)
-    n, chunk = data.n_lineitems, 20_000
-    hosts = {"shipdate": storage.make_column(data.l_shipdate, None, abi.ENC_DICTIONARY, chunk_size=chunk),
-             "discount": storage.make_column(data.l_discount, None, abi.ENC_DICTIONARY, chunk_size=chunk),
-             "quantity": storage.make_column(data.l_quantity, None, abi.ENC_UNENCODED, chunk_size=chunk),
-             "price": storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED, chunk_size=chunk)}
-    devs = {k: DeviceColumn(v) for k, v in hosts.items()}
+    columns = {name: DeviceColumn(column) for name, column in tpch.q6_columns(data, chunk_size=20_000).items()}
+    ex = HipExecutor(torch.device("cuda", 0))
+    handed_on = []
+    real_reference_column = ex.reference_column
 
-    def pos_lists(result, previous=None):
-        """A scan's output as reference segments over the base table (one pos list per non-empty input chunk)."""
-        lists = []
-        for c in range(result.n_chunks):
-            rows = result.pos_list(c) if result.chunk_state[c] != abi.CHUNK_ALL_MATCH else None
-            if rows is None:
-                size = previous[c].shape[0] if previous is not None else hosts["shipdate"].segments[c].size
-                rows = np.stack([np.full(size, c, dtype=np.uint32), np.arange(size, dtype=np.uint32)], axis=1)
-            lists.append(previous[c][rows[:, 1]] if previous is not None else rows.astype(np.uint32))
-        return lists
+    def reference_column(base, rows, chunk_rows):
+        handed_on.append(rows)
+        return real_reference_column(base, rows, chunk_rows)
 
-    def reference(name, lists):
-        host = storage.make_reference_column(hosts[name], lists, [None] * len(lists))
-        return DeviceColumn(host, refs={id(hosts[name]): devs[name]})
+    def forbidden(*args, **kwargs):
+        raise AssertionError("a PosList was read on the host")
 
-    first = table_scan(devs["shipdate"], make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, tpch.DAY_1994_01_01, tpch.DAY_1995_01_01))
-    lists = pos_lists(first)
-    second = table_scan(reference("discount", lists), make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, np.float32(0.05), np.float32(0.07)))
-    lists = pos_lists(second, lists)
-    third = table_scan(reference("quantity", lists), make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, 24.0))
-    lists = pos_lists(third, lists)
-    revenue = projection_arithmetic(abi.ARITH_MUL, reference("price", lists), reference("discount", lists))
-    total = aggregate_hash([], [(abi.AGG_SUM, revenue), (abi.AGG_COUNT, None)], group_capacity=4)
+    monkeypatch.setattr(ex, "reference_column", reference_column)
+    monkeypatch.setattr(operators.HostScanResult, "__init__", forbidden)      # no host-memory scan result may even be created
+    monkeypatch.setattr(operators.HostScanResult, "pos_list", forbidden)
+    revenue, qualifying = tpch.run_q6(ex, columns)
+    monkeypatch.undo()
+    assert len(handed_on) == 4 and all(rows.is_cuda and rows.dtype == torch.int32 for rows in handed_on)
     keep = (data.l_shipdate >= tpch.DAY_1994_01_01) & (data.l_shipdate < tpch.DAY_1995_01_01) & (data.l_discount >= np.float32(0.05)) & \
            (data.l_discount <= np.float32(0.07)) & (data.l_quantity < 24)
+    # the last PosList is exactly the qualifying rows, in table order, as RowIDs of the DATA table
+    final = handed_on[-1].cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(final[:, 0].astype(np.int64) * 20_000 + final[:, 1], np.flatnonzero(keep))
     products = data.l_extendedprice[keep] * data.l_discount[keep]            # float32 products, like the reference
-    assert total.column(1)[0] == int(keep.sum()) > 100
-    assert abs(total.column(0)[0] - float(products.astype(np.float64).sum())) <= 1e-9 * abs(float(products.astype(np.float64).sum()))
+    assert qualifying == int(keep.sum()) > 100
+    assert abs(revenue - float(products.astype(np.float64).sum())) <= 1e-9 * abs(float(products.astype(np.float64).sum()))
 
 
 def test_plain_operands_all_type_pairs(device):

@@ -1,5 +1,7 @@
 """Parity of the HIP TableScan with the CPU oracle: PosLists, per-chunk offsets/counts and early-out states must be
 bit-identical.  Every call goes through the C ABI (hy_table_scan / hy_table_scan_columns)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -7,7 +9,7 @@ from golden import known_answers as KA
 from hyrise_amd import abi, storage
 from hyrise_amd.operators import make_predicate, table_scan, table_scan_columns
 from hyrise_amd.storage import DeviceColumn
-from support import (assert_scan_equal, build_column, decode_rows, load_tbl, oracle_scan, oracle_scan_columns,
+from support import (DeviceArray, assert_scan_equal, build_column, decode_rows, load_tbl, oracle_scan, oracle_scan_columns,
                      result_rows)
 
 pytestmark = pytest.mark.gpu
@@ -283,3 +285,74 @@ def test_run_length_segments(device):
     sums = aggregate_hash([dev], [(abi.AGG_COUNT, None), (abi.AGG_SUM, dev)])
     expected = oracle_aggregate([host], [(abi.AGG_COUNT, None), (abi.AGG_SUM, host)])
     assert sums.n_groups == expected.n_groups and sums.column(0) == expected.column(0) and sums.column(1) == expected.column(1)
+
+
+def device_pos_list(lib, host_column, device_column, predicate):
+    """hy_table_scan into device memory + hy_poslist_translate: the PosList the next operator reads, copied back for the check."""
+    rows, n_chunks = max(1, host_column.rows), host_column.n_chunks
+    regions, offsets, counts = DeviceArray(lib, (rows, 2), np.uint32), DeviceArray(lib, (n_chunks + 1,), np.int64), DeviceArray(lib, (max(1, n_chunks),), np.int32)
+    result = abi.ScanResult()
+    result.mem, result.flags = abi.MEM_DEVICE, abi.SCAN_CHUNK_REGIONS | abi.SCAN_MATERIALIZE_ALL_MATCH
+    result.matches, result.capacity, result.offsets, result.counts = regions.pointer, rows, offsets.pointer, counts.pointer
+    abi.check(lib.hy_table_scan(device_column.handle, C.byref(predicate), None, 0, C.byref(result)))
+    out = DeviceArray(lib, (rows, 2), np.uint32)
+    written = C.c_uint64(0)
+    abi.check(lib.hy_poslist_translate(device_column.handle, C.byref(result), out.pointer, rows, C.byref(written)))
+    result._keep = (regions, offsets, counts)   # the device buffers live as long as the struct that points at them
+    return out.numpy()[:written.value], result
+
+
+def expected_pos_list(host_column, predicate):
+    """What TableScan::_on_execute assembles (table_scan.cpp:158-196): the oracle's matches, chunk after chunk, each replaced by
+    the RowID it stands for when the input is a reference table."""
+    want = oracle_scan(host_column, predicate, flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
+    out = []
+    for c, segment in enumerate(host_column.segments):
+        matches = want.pos_list(c)
+        if segment.encoding != abi.ENC_REFERENCE:
+            out.append(matches)
+        elif segment.data is None:
+            out.append(np.stack([np.full(len(matches), segment.ref_chunk_id, dtype=np.uint32), matches[:, 1]], axis=1))
+        else:
+            out.append(np.asarray(segment.data, dtype=np.uint32).reshape(-1, 2)[matches[:, 1]])
+    return np.concatenate(out) if out else np.zeros((0, 2), dtype=np.uint32)
+
+
+def test_poslist_translate(device):
+    """The device-resident hand-over between operators: data columns (packing only), single-chunk and entire-chunk PosLists,
+    PosLists over many chunks with NULL RowIDs, an empty table; and the capacity error."""
+    rng = np.random.default_rng(23)
+    n, chunk = 150_000, 9_000
+    values = rng.integers(0, 1000, n).astype(np.int32)
+    nulls = rng.random(n) < 0.05
+    for encoding in ENCODINGS:
+        base = build_column(values, nulls, chunk, encoding)
+        base_dev = DeviceColumn(base)
+        first = oracle_scan(base, make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 700, nullable=True), flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
+        single = [first.pos_list(c).copy() for c in range(base.n_chunks)] + [2]
+        single_host = storage.make_reference_column(base, single, list(range(base.n_chunks)) + [2])
+        many = []
+        for size in (0, 1, 65, 30_000, 65_535):
+            rows = rng.integers(0, n, size)
+            pos = np.stack([rows // chunk, rows % chunk], axis=1).astype(np.uint32)
+            pos[rng.random(size) < 0.03] = 0xFFFFFFFF
+            many.append(pos)
+        many_host = storage.make_reference_column(base, many, [None] * len(many))
+        for host, dev in ((base, base_dev), (single_host, DeviceColumn(single_host, refs={id(base): base_dev})),
+                          (many_host, DeviceColumn(many_host, refs={id(base): base_dev}))):
+            for condition in (abi.PRED_EQUALS, abi.PRED_LESS_THAN, abi.PRED_BETWEEN_INCLUSIVE, abi.PRED_IS_NULL, abi.PRED_IS_NOT_NULL):
+                p = make_predicate(condition, abi.TYPE_INT, 100, 400, nullable=True)
+                got, _ = device_pos_list(device, host, dev, p)
+                want = expected_pos_list(host, p)
+                assert got.tobytes() == want.tobytes(), f"enc {encoding} cond {condition}"
+    # too small an output buffer: the needed capacity comes back with HY_ERR_CAPACITY
+    p = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 500, nullable=True)
+    full, result = device_pos_list(device, base, base_dev, p)
+    small = DeviceArray(device, (16, 2), np.uint32)
+    written = C.c_uint64(0)
+    assert device.hy_poslist_translate(base_dev.handle, C.byref(result), small.pointer, 16, C.byref(written)) == abi.ERR_CAPACITY
+    assert written.value == len(full) > 16
+    # a host-memory result is refused
+    host_result = abi.ScanResult()
+    host_result.mem = abi.MEM_HOST
+    assert device.hy_poslist_translate(base_dev.handle, C.byref(host_result), small.pointer, 16, C.byref(written)) == abi.ERR_INVALID
