@@ -227,6 +227,15 @@ def join_leg(lib, torch, dev, steps, with_cases, with_cpu):
                                        "pairs_per_s": int(r_d.n_pairs) / dt_d,
                                        "GBps_on_algorithmic_bytes": (15_000_000 * 4 + probe_rows * 2 + int(r_d.n_pairs) * 16) / dt_d / 1e9}
         del keep_d, dup_build, dup_probe
+        # the boundary as the adapter uses it today: PosLists returned to HOST memory (0.96 GB over PCIe), one call
+        from hyrise_amd.operators import join_hash
+        join_hash(orders, lineitem, abi.JOIN_INNER)
+        t0 = time.perf_counter()
+        host = join_hash(orders, lineitem, abi.JOIN_INNER)
+        dt_h = time.perf_counter() - t0
+        cases["host_memory_result"] = {"ms_per_join": dt_h * 1e3, "rows_per_s": (data.n_orders + n) / dt_h, "pairs": host.n_pairs,
+                                       "note": "HY_MEM_HOST: includes the device-to-host copy of both PosLists and the host buffer allocation"}
+        del host
         info["cases"] = cases
     if with_cpu:
         info["cpu_baseline"] = cpu_baseline_join(orders_host, lineitem_host, data.n_orders + n)
@@ -297,6 +306,16 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
                        ("point_eq_1995-06-17", make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, tpch.CURRENT_DATE)),
                        ("is_null", make_predicate(abi.PRED_IS_NULL, abi.TYPE_INT))):
         out[name] = measure(lambda p=pred: step_fn(p, column), lambda m: rows * width + m * 8)
+    # the boundary as the adapter uses it today: PosLists returned to HOST memory (PCIe-inclusive, never the headline value)
+    from hyrise_amd.operators import table_scan
+    pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
+    table_scan(column, pred)
+    t0 = time.perf_counter()
+    host = table_scan(column, pred)
+    dt_h = time.perf_counter() - t0
+    out["host_memory_result_lt_1995"] = {"rows_per_s": rows / dt_h, "ms_per_step": dt_h * 1e3, "matches": host.total,
+                                         "note": "HY_MEM_HOST: includes packing the chunk regions, the device-to-host copy of the PosLists and the host buffer allocation"}
+    del host
     # the same dates as unencoded int32 values (ValueSegment<int32>: the 4-byte streaming instantiation)
     values = DeviceColumn(storage.make_column(days, None, abi.ENC_UNENCODED))
     pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)

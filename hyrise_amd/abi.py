@@ -116,6 +116,8 @@ SYMBOLS = [
     ("hy_column_data_type", C.c_uint32, [C.c_void_p]),
     ("hy_column_chunk_rows", C.c_uint32, [C.c_void_p, C.c_uint32]),
     ("hy_validate", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ScanResult)]),
+    ("hy_predicate_cast", C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Predicate)]),
+    ("hy_join_output_chunks", C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("hy_poslist_translate", C.c_int32, [C.c_void_p, C.POINTER(ScanResult), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("hy_join_hash", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinResult)]),
     ("hy_join_hash_predicates", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinPredicate), C.c_uint32, C.POINTER(JoinResult)]),

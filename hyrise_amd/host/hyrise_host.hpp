@@ -765,12 +765,23 @@ class TableScan : public AbstractReadOnlyOperator {
         Assert(std::holds_alternative<std::string>(_value), "Right parameter must be a string.");
         find_matches_in_dictionaries(in_table, match_words, match_word_offsets, predicate);
       } else if (!null_test) {
-        // ColumnVsValueTableScanImpl asserts matching types (column_vs_value_table_scan_impl.cpp:34-36)
-        Assert(data_type_from_all_type_variant(_value) == in_table->column_data_type(_column_id), "Cannot scan: column and value data type do not match.");
-        predicate.value_type = static_cast<uint32_t>(data_type_from_all_type_variant(_value));
-        predicate.value = to_hy_value(_value);
-        if (_value2) predicate.value2 = to_hy_value(*_value2);
-        if (in_table->column_data_type(_column_id) == DataType::String) resolve_string_literal(in_table, lower, upper, found, predicate);
+        const auto column_type = in_table->column_data_type(_column_id);
+        if (column_type == DataType::String) {
+          // ColumnVsValueTableScanImpl asserts matching types (column_vs_value_table_scan_impl.cpp:34-36)
+          Assert(data_type_from_all_type_variant(_value) == DataType::String, "Cannot scan: column and value data type do not match.");
+          predicate.value_type = static_cast<uint32_t>(DataType::String);
+          resolve_string_literal(in_table, lower, upper, found, predicate);
+        } else {
+          // TableScan::create_impl casts the literal(s) to the column's type, adjusting the condition where only that is
+          // lossless (table_scan.cpp:336-366, 406-448); where neither works the stock ExpressionEvaluator scan runs.
+          const hy_value first = to_hy_value(_value), second = _value2 ? to_hy_value(*_value2) : hy_value{};
+          hy_predicate cast{};
+          const auto status = hy_predicate_cast(static_cast<uint32_t>(_condition), static_cast<uint32_t>(column_type), static_cast<uint32_t>(data_type_from_all_type_variant(_value)),
+                                                &first, _value2 ? static_cast<uint32_t>(data_type_from_all_type_variant(*_value2)) : HY_TYPE_NULL, _value2 ? &second : nullptr, &cast);
+          Assert(status != HY_ERR_UNSUPPORTED, "Cannot scan: the literal has no lossless predicate cast to the column's data type (ExpressionEvaluator scan, stock operator).");
+          check_status(status);
+          predicate.condition = cast.condition, predicate.value_type = cast.value_type, predicate.value = cast.value, predicate.value2 = cast.value2;
+        }
       }
       check_status(hy_table_scan(column->handle, &predicate, excluded_chunk_ids.data(), static_cast<uint32_t>(excluded_chunk_ids.size()), &result));
     }
@@ -1043,33 +1054,48 @@ class JoinHash : public AbstractReadOnlyOperator {   // operators/join_hash.hpp:
       secondary_columns.push_back(r);
       secondary.push_back(hy_join_predicate{l->handle, r->handle, static_cast<uint32_t>(predicate.predicate_condition), 0});
     }
-    uint64_t pair_count = 0;
-    check_status(hy_join_hash_count(left_column->handle, right_column->handle, static_cast<uint32_t>(_mode), &pair_count));
-    if (!secondary.empty()) pair_count += std::max(left->row_count(), right->row_count());   // outer joins: a NULL partner per probe row at most
-    std::vector<RowID> left_positions(std::max<uint64_t>(1, pair_count)), right_positions(std::max<uint64_t>(1, pair_count));
-    const uint32_t slice_capacity = static_cast<uint32_t>(std::max(left->row_count(), right->row_count()) / 131070 + std::max(left->chunk_count(), right->chunk_count()) + 300);
-    std::vector<uint64_t> slice_offsets(slice_capacity + 2);
+    // One call: room for one partner per row of the larger input (every key / foreign-key join fits); a join that multiplies
+    // rows reports what it needs with HY_ERR_CAPACITY (nothing written) and runs once more with exactly that.
+    uint64_t capacity = std::max<uint64_t>(1, std::max(left->row_count(), right->row_count()));
+    uint32_t slice_capacity = static_cast<uint32_t>(capacity / 131070 + std::max(left->chunk_count(), right->chunk_count()) + 300);
+    std::vector<RowID> left_positions, right_positions;
+    std::vector<uint64_t> slice_offsets;
     hy_join_result result{};
-    result.mem = HY_MEM_HOST;
-    result.radix_bits = _radix_bits ? static_cast<uint32_t>(*_radix_bits) : 0xFFFFFFFFu;
-    result.left_pos = reinterpret_cast<hy_row_id*>(left_positions.data());
-    result.right_pos = reinterpret_cast<hy_row_id*>(right_positions.data());
-    result.capacity = pair_count;
-    result.slice_offsets = slice_offsets.data();
-    result.slice_capacity = slice_capacity;
-    check_status(hy_join_hash_predicates(left_column->handle, right_column->handle, static_cast<uint32_t>(_mode), secondary.data(), static_cast<uint32_t>(secondary.size()), &result));
+    for (int attempt = 0;; ++attempt) {
+      left_positions.resize(capacity);
+      right_positions.resize(capacity);
+      slice_offsets.assign(size_t{slice_capacity} + 2, 0);
+      result = hy_join_result{};
+      result.mem = HY_MEM_HOST;
+      result.radix_bits = _radix_bits ? static_cast<uint32_t>(*_radix_bits) : 0xFFFFFFFFu;
+      result.left_pos = reinterpret_cast<hy_row_id*>(left_positions.data());
+      result.right_pos = reinterpret_cast<hy_row_id*>(right_positions.data());
+      result.capacity = capacity;
+      result.slice_offsets = slice_offsets.data();
+      result.slice_capacity = slice_capacity;
+      const auto status = hy_join_hash_predicates(left_column->handle, right_column->handle, static_cast<uint32_t>(_mode), secondary.data(), static_cast<uint32_t>(secondary.size()), &result);
+      if (status == HY_ERR_CAPACITY && attempt == 0 && (result.n_pairs > capacity || result.n_slices > slice_capacity)) {
+        capacity = std::max<uint64_t>(capacity, result.n_pairs);
+        slice_capacity = std::max(slice_capacity, result.n_slices);
+        continue;
+      }
+      check_status(status);
+      break;
+    }
     radix_bits = result.radix_bits;
     left_input_is_build_side = result.left_is_build;
     const bool semi_anti = _mode == JoinMode::Semi || _mode == JoinMode::AntiNullAsTrue || _mode == JoinMode::AntiNullAsFalse;
-    // Output: one chunk per non-empty probe slice (write_output_chunks, join_output_writing.cpp:205-340; the 1000/4000
-    // merge of small PosLists is not applied here).  Columns: left input's, then right input's (Semi/Anti: left only).
+    // Output (write_output_chunks, join_output_writing.cpp:205-340): one chunk per non-empty PosList, small ones merged by the
+    // reference's 1000 / 4000 rule (hy_join_output_chunks).  Columns: left input's, then right input's (Semi/Anti: left only).
     TableColumnDefinitions definitions = left->column_definitions();
     if (!semi_anti) for (const auto& d : right->column_definitions()) definitions.push_back({d.name, d.data_type, d.nullable || _mode == JoinMode::Left});
     if (_mode == JoinMode::Right) for (ColumnID c = 0; c < left->column_count(); ++c) definitions[c].nullable = true;
+    std::vector<uint64_t> chunk_offsets(size_t{result.n_slices} + 1);
+    uint32_t n_output_chunks = 0;
+    check_status(hy_join_output_chunks(slice_offsets.data(), result.n_slices, chunk_offsets.data(), &n_output_chunks));
     std::vector<std::shared_ptr<Chunk>> chunks;
-    for (uint32_t s = 0; s < result.n_slices; ++s) {
-      const auto begin = slice_offsets[s], end = slice_offsets[s + 1];
-      if (begin == end) continue;
+    for (uint32_t k = 0; k < n_output_chunks; ++k) {
+      const auto begin = chunk_offsets[k], end = chunk_offsets[k + 1];
       Segments segments;
       append_side(segments, left, std::vector<RowID>(left_positions.begin() + begin, left_positions.begin() + end));
       if (!semi_anti) append_side(segments, right, std::vector<RowID>(right_positions.begin() + begin, right_positions.begin() + end));

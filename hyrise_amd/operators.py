@@ -51,6 +51,48 @@ def make_predicate(condition, data_type=abi.TYPE_INT, value=None, value2=None, n
     return p
 
 
+def _literal(data_type, value):
+    v = abi.Value()
+    C.memset(C.byref(v), 0, C.sizeof(v))
+    if data_type == abi.TYPE_INT:
+        v.i32 = int(value)
+    elif data_type == abi.TYPE_LONG:
+        v.i64 = int(value)
+    elif data_type == abi.TYPE_FLOAT:
+        v.f32 = float(value)
+    elif data_type == abi.TYPE_DOUBLE:
+        v.f64 = float(value)
+    return v
+
+
+def predicate_for_column(condition, column_type, literal_type, literal, literal2_type=None, literal2=None, nullable=False):
+    """The predicate of `column <condition> literal [AND literal2]` as the scan takes it: hy_predicate_cast applies
+    TableScan::create_impl's lossless predicate cast (table_scan.cpp:336-366, 406-448).  Returns None where the reference
+    falls back to its ExpressionEvaluator scan (HY_ERR_UNSUPPORTED)."""
+    lib = abi.load_library()
+    out = abi.Predicate()
+    first = _literal(literal_type, literal)
+    second = _literal(literal2_type, literal2) if literal2 is not None else None
+    status = lib.hy_predicate_cast(condition, column_type, literal_type, C.addressof(first), literal2_type if literal2 is not None else abi.TYPE_NULL,
+                                   C.addressof(second) if second is not None else None, C.byref(out))
+    if status == abi.ERR_UNSUPPORTED:
+        return None
+    abi.check(status)
+    out.column_is_nullable = 1 if nullable else 0
+    return out
+
+
+def join_output_chunks(slice_offsets, n_slices):
+    """Pair ranges of the output chunks JoinHash builds from a join result's PosLists (hy_join_output_chunks: write_output_chunks'
+    1000 / 4000 merge, join_output_writing.cpp:245-296) -> numpy uint64 array of n_chunks + 1 offsets."""
+    lib = abi.load_library()
+    offsets = np.ascontiguousarray(slice_offsets[:n_slices + 1], dtype=np.uint64)
+    out = np.zeros(n_slices + 1, dtype=np.uint64)
+    n = C.c_uint32(0)
+    abi.check(lib.hy_join_output_chunks(offsets.ctypes.data, n_slices, out.ctypes.data, C.byref(n)))
+    return out[:n.value + 1]
+
+
 class HostScanResult:
     """Scan result in host memory, numpy views."""
 
@@ -215,19 +257,23 @@ def join_predicates(secondary):
     return array, len(secondary)
 
 
-def join_hash(left, right, mode, radix_bits=None, secondary=None):
-    """hy_join_hash (hy_join_hash_predicates with secondary predicates) with a host-memory result.  Sized by
-    hy_join_hash_count: secondary predicates only remove pairs of the equi-join (outer joins: never more than
-    count + probe rows)."""
+def join_hash(left, right, mode, radix_bits=None, secondary=None, capacity=None):
+    """hy_join_hash (hy_join_hash_predicates with secondary predicates) with a host-memory result, in ONE call: the result is
+    sized for one partner per row of the larger input (every key / foreign-key join fits); a join that multiplies rows answers
+    HY_ERR_CAPACITY with what it needs (nothing written) and runs once more with exactly that -- never a counting call first."""
     lib = abi.load_library()
-    n_pairs = join_hash_count(left, right, mode) + (max(left.rows, right.rows) if secondary else 0)
-    result = HostJoinResult(n_pairs, max(left.rows, right.rows) // 131070 + max(left.n_chunks, right.n_chunks) + 600, radix_bits)
     predicates, n = join_predicates(secondary)
-    if n:
-        abi.check(lib.hy_join_hash_predicates(left.handle, right.handle, mode, predicates, n, C.byref(result.c)))
-    else:
-        abi.check(lib.hy_join_hash(left.handle, right.handle, mode, C.byref(result.c)))
-    return result
+    capacity = max(1, left.rows, right.rows) if capacity is None else capacity
+    slice_capacity = max(left.rows, right.rows) // 131070 + max(left.n_chunks, right.n_chunks) + 600
+    for attempt in (0, 1):
+        result = HostJoinResult(capacity, slice_capacity, radix_bits)
+        status = lib.hy_join_hash_predicates(left.handle, right.handle, mode, predicates, n, C.byref(result.c)) if n else \
+            lib.hy_join_hash(left.handle, right.handle, mode, C.byref(result.c))
+        if status == abi.ERR_CAPACITY and attempt == 0 and (result.n_pairs > capacity or int(result.c.n_slices) > slice_capacity):
+            capacity, slice_capacity = max(capacity, result.n_pairs), max(slice_capacity, int(result.c.n_slices))
+            continue
+        abi.check(status)
+        return result
 
 
 class HostAggregateResult:

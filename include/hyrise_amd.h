@@ -235,6 +235,17 @@ hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, u
 hy_status hy_validate(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut,
                       hy_scan_result* result);
 
+/* The literal handling TableScan::create_impl performs before it picks a scan implementation (table_scan.cpp:336-366 for
+ * `column OP literal`, :406-448 for `column BETWEEN a AND b`): each literal is cast to the column's type without loss
+ * (lossless_cast.hpp:32-187) or, where that is impossible but an equivalent predicate exists, the predicate is adjusted --
+ * `float_column < 3.1` becomes `float_column <= 3.0999999f` (lossless_predicate_cast.hpp:23-64, .cpp:14-73).  Pure host
+ * arithmetic, no device needed.  literal2 is NULL for the binary conditions.  On HY_OK out->condition / value_type / value /
+ * value2 are what hy_table_scan takes (the other fields are zeroed); HY_ERR_UNSUPPORTED where the reference falls back to its
+ * ExpressionEvaluator scan (`float_column = 3.1`, a NULL literal, a bound that does not fit the column type).  String literals
+ * are outside hy_value: against a string column they need no cast, against anything else there is none. */
+hy_status hy_predicate_cast(uint32_t condition, uint32_t column_type, uint32_t literal_type, const hy_value* literal, uint32_t literal2_type,
+                            const hy_value* literal2, hy_predicate* out);
+
 /* The PosList a scan hands to the next operator, WITHOUT leaving device memory (replaces the output assembly of
  * TableScan::_on_execute, table_scan.cpp:158-196: the matches of a scan over ReferenceSegments are translated through the
  * input PosList, so the output always references the data table, never another reference table).
@@ -322,6 +333,12 @@ hy_status hy_join_hash_predicates(const hy_column* left, const hy_column* right,
 hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint32_t* radix_bits);
 /* Upper bound for result->capacity without running the join (Semi/Anti: probe rows; others: exact pair count). */
 hy_status hy_join_hash_count(const hy_column* left, const hy_column* right, uint32_t mode, uint64_t* n_pairs);
+
+/* write_output_chunks' chunking of a join result (join_output_writing.cpp:245-296; JoinHash always allows the merge,
+ * join_hash.cpp:563): one output chunk per non-empty PosList of slice_offsets[0 .. n_slices], after merging a PosList of fewer
+ * than 1000 pairs with its successors while the sum stays below 4000.  chunk_offsets (room for n_slices + 1 values) receives
+ * the pair ranges of the output chunks, *n_chunks their number.  Host arrays; pure host arithmetic. */
+hy_status hy_join_output_chunks(const uint64_t* slice_offsets, uint32_t n_slices, uint64_t* chunk_offsets, uint32_t* n_chunks);
 
 /* ---- AggregateHash (replaces AggregateHash::_on_execute, aggregate_hash.cpp:1180-1372) -------------------------- */
 typedef struct hy_aggregate_spec {

@@ -52,6 +52,12 @@ int64_t hyo_scan_chunk_columns(const hyo_column* left, const hyo_column* right, 
 /* Whole-column driver with the ABI's result layout (host memory), single thread or `threads` pthreads over chunks
  * (JobTask fan-out, table_scan.cpp:223-229). */
 int32_t hyo_table_scan(const hyo_column* column, const hy_predicate* predicate, hy_scan_result* result, int threads);
+/* The literal handling in front of a TableScan (predicate_cast.c): lossless_predicate_cast.{hpp,cpp}, table_scan.cpp:336-448. */
+int hyo_next_float_towards(double value, double towards, float* out);
+int hyo_lossless_predicate_cast(uint32_t condition, uint32_t source_type, const hy_value* value, uint32_t target_type, uint32_t* out_condition,
+                                hy_value* out_value);
+int hyo_predicate_for_column(uint32_t condition, uint32_t column_type, uint32_t value_type, const hy_value* value, uint32_t value2_type,
+                             const hy_value* value2, hy_predicate* out);
 /* Projection arithmetic (projection.c). */
 uint32_t hyo_expression_common_type(uint32_t lhs, uint32_t rhs);
 int hyo_arithmetic_cell(uint32_t op, uint32_t a_type, const void* a, int a_null, uint32_t b_type, const void* b, int b_null, void* result);
@@ -70,6 +76,8 @@ int32_t hyo_join_hash(const hyo_column* left, const hyo_column* right, uint32_t 
 int32_t hyo_join_hash_predicates(const hyo_column* left, const hyo_column* right, uint32_t mode, const hy_join_predicate* secondary,
                                  uint32_t n_secondary, hy_join_result* result, int threads);
 uint32_t hyo_calculate_radix_bits(uint64_t build_rows, uint64_t probe_rows);
+/* write_output_chunks' chunking of the per-partition PosLists incl. the MIN_SIZE / MAX_SIZE merge (join_output_writing.cpp:245-296). */
+uint32_t hyo_write_output_chunks(const uint64_t* slice_offsets, uint32_t n_slices, int allow_partition_merge, uint64_t* chunk_offsets);
 /* Step-level entry points pinned by join_hash_steps_test.cpp. */
 /* materialize_input: writes (row_id,value) elements of one column in chunk order; returns element count.
  * bloom_in may be NULL (all-true); bloom_out 2^20 bits = 16384 u64 words (zeroed by the caller).

@@ -712,3 +712,33 @@ int32_t hyo_join_hash_predicates(const hyo_column* left, const hyo_column* right
   free(build_bloom); free(probe_bloom);
   return status;
 }
+
+/* ---- output chunking (join_output_writing.cpp:205-340) --------------------------------------------------------------
+ * write_output_chunks walks the per-partition PosLists (here: the slices of hy_join_result.slice_offsets) in order and emits
+ * one output chunk per non-empty PosList -- after merging, when allow_partition_merge is set (JoinHash always sets it,
+ * join_hash.cpp:563), a PosList smaller than MIN_SIZE = 1000 with its successors as long as the sum stays below
+ * MAX_SIZE = 4000 (:245-296).  chunk_offsets[k] .. chunk_offsets[k + 1] are the pairs of output chunk k; returns the number
+ * of chunks (chunk_offsets needs room for n_slices + 1 values). */
+uint32_t hyo_write_output_chunks(const uint64_t* slice_offsets, uint32_t n_slices, int allow_partition_merge, uint64_t* chunk_offsets) {
+  const uint64_t MIN_SIZE = 1000, MAX_SIZE = MIN_SIZE * 4;
+  uint32_t partition_id = 0, chunk_input_position = 0;
+  chunk_offsets[0] = 0;
+  while (partition_id < n_slices) {
+    uint64_t size = slice_offsets[partition_id + 1] - slice_offsets[partition_id];   /* right_side_pos_list->size() */
+    if (size == 0) {                                    /* :270-273 */
+      ++partition_id;
+      continue;
+    }
+    if (allow_partition_merge) {
+      while (partition_id + 1 < n_slices && size < MIN_SIZE &&
+             size + (slice_offsets[partition_id + 2] - slice_offsets[partition_id + 1]) < MAX_SIZE) {   /* :278-279 */
+        size += slice_offsets[partition_id + 2] - slice_offsets[partition_id + 1];
+        ++partition_id;
+      }
+    }
+    chunk_offsets[chunk_input_position + 1] = slice_offsets[partition_id + 1];
+    ++partition_id;
+    ++chunk_input_position;
+  }
+  return chunk_input_position;
+}

@@ -214,6 +214,61 @@ static void test_type_mismatch_throws() {   // table_scan_test.cpp:383-405 (EXPE
   EXPECT_TRUE(thrown);
 }
 
+static void test_literals_of_other_types_are_cast_without_loss() {   // table_scan.cpp:336-366, 406-448; lossless_predicate_cast_test.cpp
+  for (const auto encoding : {EncodingType::Unencoded, EncodingType::Dictionary}) {
+    const auto wrapper = load_and_encode("int_float.tbl", 2, encoding);   // b: 458.7f, 456.7f, 457.7f
+    const auto count = [&](ColumnID column, PredicateCondition condition, AllTypeVariant value, std::optional<AllTypeVariant> value2 = std::nullopt) {
+      auto scan = std::make_shared<TableScan>(wrapper, column, condition, std::move(value), std::move(value2));
+      scan->execute();
+      return scan->get_output()->row_count();
+    };
+    // a double literal against the float column: 457.7 (double) lies just below 457.7f, so < and <= both exclude that row,
+    // > and >= both include it
+    EXPECT_TRUE(static_cast<double>(457.7f) > 457.7);
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::LessThan, 457.7) == 1);
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::LessThanEquals, 457.7) == 1);
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::GreaterThan, 457.7) == 2);
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::GreaterThanEquals, 457.7) == 2);
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::GreaterThanEquals, static_cast<double>(457.7f)) == 2);   // exactly a float: no adjustment
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::GreaterThan, static_cast<double>(457.7f)) == 1);
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::BetweenExclusive, 456.7, 458.0) == 2);                   // (456.7, 458): 456.7f > 456.7 is inside
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::BetweenInclusive, int32_t{457}, int64_t{458}) == 1);
+    // long / double literals against the int column
+    EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::GreaterThan, int64_t{1000}) == 2);
+    EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::Equals, 123.0) == 1);
+    EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::Equals, 123.0f) == 1);
+    for (const AllTypeVariant& literal : {AllTypeVariant{123.5}, AllTypeVariant{int64_t{100'000'000'000}}}) {   // no int equals these: the stock evaluator scan
+      bool thrown = false;
+      try { count(ColumnID{0}, PredicateCondition::LessThan, literal); } catch (const std::logic_error&) { thrown = true; }
+      EXPECT_TRUE(thrown);
+    }
+    bool thrown = false;
+    try { count(ColumnID{1}, PredicateCondition::Equals, 457.7); } catch (const std::logic_error&) { thrown = true; }   // float = double that is no float
+    EXPECT_TRUE(thrown);
+  }
+}
+
+static void test_join_output_chunks_are_merged() {   // join_output_writing.cpp:245-296: PosLists below 1000 rows merge up to 4000
+  const auto left = load_and_encode("join_test_runner/input_table_left_15.tbl", 3, EncodingType::Unencoded);
+  const auto right = load_and_encode("join_test_runner/input_table_right_10.tbl", 3, EncodingType::Unencoded);
+  auto join = std::make_shared<JoinHash>(left, right, JoinMode::Inner, ColumnIDPair{ColumnID{0}, ColumnID{0}}, 4);   // 16 radix partitions
+  join->execute();
+  EXPECT_TRUE(join->radix_bits == 4);
+  EXPECT_TRUE(join->get_output()->row_count() > 0 && join->get_output()->chunk_count() == 1);   // a handful of rows: one merged chunk
+  // a result of several thousand rows: chunks of 1000 .. 3999 rows, none smaller except the last
+  auto big_left = std::make_shared<Table>(TableColumnDefinitions{{"a", DataType::Int, false}}, TableType::Data, ChunkOffset{1000});
+  auto big_right = std::make_shared<Table>(TableColumnDefinitions{{"a", DataType::Int, false}}, TableType::Data, ChunkOffset{1000});
+  for (int32_t i = 0; i < 6000; ++i) { big_left->append({AllTypeVariant{i}}); big_right->append({AllTypeVariant{(i * 7) % 6000}}); }
+  big_left->finalize();
+  big_right->finalize();
+  auto big = std::make_shared<JoinHash>(wrap(big_left), wrap(big_right), JoinMode::Inner, ColumnIDPair{ColumnID{0}, ColumnID{0}}, 5);   // 32 partitions of ~188 rows
+  big->execute();
+  const auto out = big->get_output();
+  EXPECT_TRUE(out->row_count() == 6000 && out->chunk_count() < 7 && out->chunk_count() >= 2);
+  for (ChunkID c = 0; c + 1 < out->chunk_count(); ++c) EXPECT_TRUE(out->get_chunk(c)->size() >= 1000 && out->get_chunk(c)->size() < 4000);
+  for (const auto& row : out->get_rows()) EXPECT_TRUE(cells_equal(row[0], row[1]));
+}
+
 static void test_join_against_nested_loop() {   // join_test_runner.cpp:656-791 (Inner / Semi / AntiNullAsFalse on int columns)
   for (const auto chunk : {ChunkOffset{10}, ChunkOffset{3}}) {
     for (const auto encoding : {EncodingType::Unencoded, EncodingType::Dictionary}) {
@@ -458,6 +513,8 @@ int main(int argc, char** argv) {
   run("TableScan.DictionarySegment<string>", test_string_dictionary_scan);
   run("TableScan.LikeOnDictionarySegments", test_like_on_dictionary_segments);
   run("TableScan.TypeMismatchThrowsLogicError", test_type_mismatch_throws);
+  run("TableScan: literals of another type go through the lossless predicate cast", test_literals_of_other_types_are_cast_without_loss);
+  run("JoinHash: small output PosLists are merged (1000 / 4000 rule)", test_join_output_chunks_are_merged);
   run("Validate.Visibility truth table, reference input, chunk shortcut", test_validate_visibility);
   run("JoinHash vs nested loop (Inner/Semi/AntiNullAsFalse/Left)", test_join_against_nested_loop);
   run("JoinHash on every pair of numeric key types vs nested loop", test_join_on_mixed_numeric_key_types);
