@@ -26,6 +26,7 @@
 #include "hy_decode.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -36,6 +37,7 @@ namespace hy {
 constexpr uint32_t MAX_GROUPBY = 4;
 constexpr uint32_t MAX_AGGREGATES = 8;
 constexpr uint32_t LDS_SLOTS = 256;
+constexpr uint32_t MAX_LDS_PROBES = 24;      // linear probing in a workgroup's table: rows that would walk further are handled like rows of a full table
 constexpr uint32_t MAX_GLOBAL_PROBES = 512;   // linear probing in the global group table: longer sequences count as overflow
 constexpr uint32_t DENSE_GROUPS = 4;   // slices with at most this many groups accumulate in thread-private LDS cells
 constexpr uint32_t TAG_EMPTY = 0, TAG_LOCKED = 1;   // ready tags have bit 31 set
@@ -66,9 +68,12 @@ struct AggArgs {
   uint64_t* last_row;         // [capacity]
   uint64_t* values;           // [capacity][n_aggregates]
   uint64_t* counts;           // [capacity][n_aggregates]
-  uint32_t* overflow;
+  uint32_t* overflow;         // flags: [0] the global table overflowed, [1] number of groups (compact_groups), [2] give up: too many rows left the
+                              //        LDS tables (the host switches to the partitioned path), [3] rows that left the LDS tables so far
+  uint32_t spill_limit;       // [3] above this sets [2]
   uint64_t* trace;            // debug (HY_AGG_TRACE): 12 wall-clock stamps per slice, else nullptr
 };
+enum : uint32_t { FLAG_OVERFLOW = 0, FLAG_GROUPS = 1, FLAG_GIVE_UP = 2, FLAG_SPILLED = 3 };
 
 // order-preserving map double -> int64 (so MIN/MAX of floating point values can use integer atomics)
 __device__ __forceinline__ int64_t ordered_bits(double d) {
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   uint32_t* s_slot_of_dense = s_dense_of_slot + LDS_SLOTS;                                   // [DENSE_GROUPS]
   uint32_t* s_n_groups = s_slot_of_dense + DENSE_GROUPS;
   uint32_t* s_present = s_n_groups + 4;                                                      // [8] direct-mapped pass 1: one bit per code met in the slice
+  uint32_t* s_spilled = s_present + 8;                                                       // rows of the slice that did not fit the LDS table | the give-up flag as the workgroup saw it
   uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_present + 12);                          // [SLICE_ROWS] LDS slot of every row of the slice (a thread's four consecutive rows: one word)
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   for (uint32_t s = tid; s < LDS_SLOTS; s += 256) {
@@ -348,8 +354,13 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       s_counts[s * a.n_aggregates + g] = 0;
     }
   }
-  if (tid == 0) *s_n_groups = 0;
+  if (tid == 0) {
+    *s_n_groups = 0;
+    s_spilled[0] = 0;
+    s_spilled[1] = __hip_atomic_load(&a.overflow[FLAG_GIVE_UP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
+  if (s_spilled[1]) return;   // the table has too many groups for this kernel: the partitioned path takes over (every thread sees the same word)
 
   const Slice slice = a.slices[blockIdx.x];
   const uint64_t chunk_base = a.row_base[slice.chunk];
@@ -604,7 +615,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
             done = true;
           } else {
             slot = (slot + 1) & (LDS_SLOTS - 1);
-            if (++probes >= LDS_SLOTS) done = true;   // LDS table full: this row goes to the global table
+            if (++probes >= MAX_LDS_PROBES) done = true;   // a crowded (or full) LDS table: this row goes to the global table -- wherever a group's rows
+                                                           // accumulate, they meet in the global table under the group's key
           }
         }
       }
@@ -616,6 +628,23 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   if (stamps && tid == 0) stamps[1] = wall_clock64();
   const uint32_t n_groups = *s_n_groups;
   const uint32_t n_dense = n_groups < DENSE_GROUPS ? n_groups : DENSE_GROUPS;
+  if (n_groups > LDS_SLOTS / 2) {   // a crowded LDS table: rows may have been left out.  Many of them in many slices = a table for the partitioned path
+    uint32_t outside = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < ROWS; ++k) outside += (slice_row(k, tid) < slice.row_count && !((in_table >> k) & 1)) ? 1u : 0u;
+    const uint32_t wave_outside = wave_reduce_u32_to_lane63(outside, 0u, false, false);
+    if (lane == 63 && wave_outside) atomicAdd(&s_spilled[0], wave_outside);
+    __syncthreads();
+    if (tid == 0) {
+      if (s_spilled[0]) {
+        const uint32_t before = atomicAdd(&a.overflow[FLAG_SPILLED], s_spilled[0]);
+        if (before + s_spilled[0] > a.spill_limit) __hip_atomic_store(&a.overflow[FLAG_GIVE_UP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_spilled[1] = __hip_atomic_load(&a.overflow[FLAG_GIVE_UP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_spilled[1]) return;   // the whole attempt is being abandoned: nothing this slice adds will be read
+  }
 
   // ---- pass 2: rows of the dense groups, registers --------------------------------------------------------------------------
   uint32_t dense_lo = 0, dense_hi = 0;   // dense index of every row, two bits per row (rows 0-15 | 16-31); 3 = not dense when n_dense < 4 ...
@@ -859,6 +888,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       const uint32_t r = slice_row(k, tid);
       if (r >= slice.row_count || ((is_dense >> k) & 1)) continue;
       if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // the table is too small: the host starts over with a larger one, no point in walking the full one
+      if (!((in_table >> k) & 1) && __hip_atomic_load(&a.overflow[FLAG_GIVE_UP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // ... or with the partitioned path
       const uint32_t row = slice.row_begin + r;
       const uint64_t global_row = chunk_base + row;
       const bool found = (in_table >> k) & 1;
@@ -918,6 +948,221 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   }
 }
 
+// ---- the partitioned path: tables with more groups than a slice's LDS table holds -------------------------------------------
+// aggregate_rows sends the rows of groups that do not fit its 256-slot table to the global table one device-scope atomic at a
+// time (a dozen G atomics/s for the whole device: 22 ms for 60 M rows in 1000 groups).  When that happens to more than a few
+// rows, the host starts over here (the reference partitions by the hash of the keys for the same reason, aggregate_hash.cpp:661-
+// 948: its partitions keep the hash tables in cache):
+//   partition_count    per part (<= 65 536 rows of one chunk): histogram of the rows' partitions -- the top bits of the tuple hash
+//   scan_*             exclusive prefix sum over (partition, part): where every part's rows of every partition go
+//   partition_scatter  the RowIDs, grouped by partition (a partition's rows: 8 bytes each, contiguous)
+//   aggregate_partitions  one workgroup per partition: ALL rows of a group are here, so the groups live in an LDS table for the
+//                      whole pass (LDS atomics per row) and reach the global table once, at the end.
+struct PartitionArgs {
+  const Part* parts;
+  uint32_t n_parts;
+  uint32_t bits;            // partitions = 1 << bits
+  uint32_t lds_slots;       // aggregate_partitions: slots of the workgroup's table (power of two)
+  uint32_t reserved;
+  uint32_t* offsets;        // [partitions][n_parts]: counts, then (after the scan) first output position
+  hy_row_id* rows;          // [total_rows]
+  uint64_t total_rows;
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void partition_rows(AggArgs a, PartitionArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* s_cell = reinterpret_cast<uint32_t*>(smem);   // count (SCATTER: next output position) of every partition
+  const uint32_t partitions = 1u << p.bits, tid = threadIdx.x, words = a.n_groupby + 1;
+  for (uint32_t i = tid; i < partitions; i += 256) s_cell[i] = SCATTER ? p.offsets[size_t{i} * p.n_parts + blockIdx.x] : 0u;
+  __syncthreads();
+  const Part part = p.parts[blockIdx.x];
+  for (uint32_t s = 0; s < part.n_slices; ++s) {
+    const Slice slice = a.slices[part.first_slice + s];
+#pragma unroll 2
+    for (uint32_t r = tid; r < slice.row_count; r += 256) {
+      const uint32_t row = slice.row_begin + r;
+      uint64_t tuple[MAX_GROUPBY + 1];
+      row_tuple(a, slice.chunk, row, tuple);
+      const uint32_t partition = static_cast<uint32_t>(hash_tuple(tuple, words) >> (64 - p.bits));
+      const uint32_t position = atomicAdd(&s_cell[partition], 1u);
+      if (SCATTER) p.rows[position] = hy_row_id{slice.chunk, row};
+    }
+  }
+  if (SCATTER) return;
+  __syncthreads();
+  for (uint32_t i = tid; i < partitions; i += 256) p.offsets[size_t{i} * p.n_parts + blockIdx.x] = s_cell[i];
+}
+
+// Exclusive prefix sum of `data[0 .. n)` in place, three launches: per block of 4096 (sums[b] = the block's total), the block
+// totals (one workgroup; sums[n_blocks] = the grand total), and the block offsets added back.
+constexpr uint32_t SCAN_BLOCK = 4096;
+__global__ __launch_bounds__(256) void scan_blocks(uint32_t* data, uint64_t n, uint32_t* sums) {
+  __shared__ uint32_t s_total[256];
+  const uint64_t begin = uint64_t{blockIdx.x} * SCAN_BLOCK + threadIdx.x * 16;
+  uint32_t v[16], total = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { v[i] = begin + i < n ? data[begin + i] : 0u; total += v[i]; }
+  s_total[threadIdx.x] = total;
+  __syncthreads();
+  for (uint32_t step = 1; step < 256; step <<= 1) {   // Hillis-Steele over the 256 thread totals
+    const uint32_t add = threadIdx.x >= step ? s_total[threadIdx.x - step] : 0u;
+    __syncthreads();
+    s_total[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t running = threadIdx.x ? s_total[threadIdx.x - 1] : 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { if (begin + i < n) data[begin + i] = running; running += v[i]; }
+  if (threadIdx.x == 255) sums[blockIdx.x] = s_total[255];
+}
+__global__ __launch_bounds__(256) void scan_sums(uint32_t* sums, uint32_t n_blocks) {
+  __shared__ uint32_t s_total[256];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_blocks; base += 256) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n_blocks ? sums[i] : 0u;
+    s_total[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t step = 1; step < 256; step <<= 1) {
+      const uint32_t add = threadIdx.x >= step ? s_total[threadIdx.x - step] : 0u;
+      __syncthreads();
+      s_total[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < n_blocks) sums[i] = s_carry + s_total[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry += s_total[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[n_blocks] = s_carry;
+}
+__global__ __launch_bounds__(256) void scan_add(uint32_t* data, uint64_t n, const uint32_t* sums) {
+  const uint32_t offset = sums[blockIdx.x];
+  const uint64_t begin = uint64_t{blockIdx.x} * SCAN_BLOCK;
+  for (uint32_t i = threadIdx.x; i < SCAN_BLOCK && begin + i < n; i += 256) data[begin + i] += offset;
+}
+
+// Find or insert `tuple` in a workgroup's LDS table (tags / keys as in aggregate_rows, same lock discipline as global_slot).
+// Returns the slot, or 0xFFFFFFFF when the table is full.
+__device__ __forceinline__ uint32_t lds_slot(uint32_t* s_tags, uint64_t* s_keys, uint32_t slots, uint32_t words, const uint64_t (&tuple)[MAX_GROUPBY + 1], uint64_t hash,
+                                             uint32_t* s_n_groups) {
+  const uint32_t ready = 0x80000000u | static_cast<uint32_t>(hash >> 33);
+  uint32_t slot = static_cast<uint32_t>(hash) & (slots - 1), probes = 0, result = 0xFFFFFFFFu;
+  bool done = false;
+  while (!done) {
+    const uint32_t tag = __hip_atomic_load(&s_tags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __atomic_signal_fence(__ATOMIC_ACQUIRE);
+    if (tag == TAG_EMPTY) {
+      if (atomicCAS(&s_tags[slot], TAG_EMPTY, TAG_LOCKED) == TAG_EMPTY) {
+#pragma unroll
+        for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) { if (w < words) s_keys[slot * words + w] = tuple[w]; }
+        atomicAdd(s_n_groups, 1u);
+        __threadfence_block();
+        atomicExch(&s_tags[slot], ready);
+        result = slot;
+        done = true;
+      }
+    } else if (tag != TAG_LOCKED) {
+      bool equal = tag == ready;
+      if (equal) {
+#pragma unroll
+        for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) { if (w < words) equal &= s_keys[slot * words + w] == tuple[w]; }
+      }
+      if (equal) {
+        result = slot;
+        done = true;
+      } else {
+        slot = (slot + 1) & (slots - 1);
+        if (++probes >= slots) done = true;
+      }
+    }
+  }
+  return result;
+}
+
+// LDS layout: keys[S][words] u64 | first[S] u64 | last[S] u64 | values[S][A] u64 | counts[S][A] u32 | tags[S] u32 | groups, spilled u32
+__global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, PartitionArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t words = a.n_groupby + 1, slots = p.lds_slots, tid = threadIdx.x;
+  uint64_t* s_keys = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* s_first = s_keys + size_t{slots} * words;
+  uint64_t* s_last = s_first + slots;
+  uint64_t* s_values = s_last + slots;
+  uint32_t* s_counts = reinterpret_cast<uint32_t*>(s_values + size_t{slots} * a.n_aggregates);
+  uint32_t* s_tags = s_counts + size_t{slots} * a.n_aggregates;
+  uint32_t* s_n_groups = s_tags + slots;   // [0] groups in the table, [1] rows that did not fit, [2] the give-up flag as the workgroup saw it
+  for (uint32_t s = tid; s < slots; s += 256) {
+    s_tags[s] = TAG_EMPTY;
+    s_first[s] = ~0ull;
+    s_last[s] = 0;
+    for (uint32_t g = 0; g < a.n_aggregates; ++g) {
+      s_values[s * a.n_aggregates + g] = initial_value(a.aggregates[g].function);
+      s_counts[s * a.n_aggregates + g] = 0;
+    }
+  }
+  if (tid == 0) {
+    s_n_groups[0] = s_n_groups[1] = 0;
+    s_n_groups[2] = __hip_atomic_load(&a.overflow[FLAG_GIVE_UP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | __hip_atomic_load(&a.overflow[FLAG_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_n_groups[2]) return;
+  const uint32_t partitions = 1u << p.bits;
+  const uint64_t begin = p.offsets[size_t{blockIdx.x} * p.n_parts];
+  const uint64_t end = blockIdx.x + 1 < partitions ? p.offsets[size_t{blockIdx.x + 1} * p.n_parts] : p.total_rows;
+#pragma unroll 1
+  for (uint64_t base = begin; base < end; base += 256) {
+    const uint64_t i = base + tid;
+    if (i >= end) continue;
+    const hy_row_id id = p.rows[i];
+    const uint64_t global_row = a.row_base[id.chunk_id] + id.chunk_offset;
+    uint64_t tuple[MAX_GROUPBY + 1];
+    row_tuple(a, id.chunk_id, id.chunk_offset, tuple);
+    const uint64_t hash = hash_tuple(tuple, words);
+    // (the partition took the hash's top bits; both tables index with its low bits)
+    const uint32_t slot = lds_slot(s_tags, s_keys, slots, words, tuple, hash, s_n_groups);
+    uint32_t gslot = 0xFFFFFFFFu;
+    if (slot == 0xFFFFFFFFu) {   // the partition has more groups than the table holds: this row goes to the global table directly
+      atomicAdd(&s_n_groups[1], 1u);
+      if (__hip_atomic_load(&a.overflow[FLAG_GIVE_UP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | __hip_atomic_load(&a.overflow[FLAG_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+      gslot = global_slot(a, tuple, words, hash);
+      if (gslot == 0xFFFFFFFFu) { a.overflow[FLAG_OVERFLOW] = 1; continue; }
+      atomicMin(reinterpret_cast<unsigned long long*>(&a.first_row[gslot]), static_cast<unsigned long long>(global_row));
+      atomicMax(reinterpret_cast<unsigned long long*>(&a.last_row[gslot]), static_cast<unsigned long long>(global_row));
+    } else {
+      atomicMin(reinterpret_cast<unsigned long long*>(&s_first[slot]), static_cast<unsigned long long>(global_row));
+      atomicMax(reinterpret_cast<unsigned long long*>(&s_last[slot]), static_cast<unsigned long long>(global_row));
+    }
+    for (uint32_t g = 0; g < a.n_aggregates; ++g) {
+      const AggColumn& c = a.aggregates[g];
+      uint64_t contribution;
+      if (!contribution_of(c, id.chunk_id, id.chunk_offset, &contribution)) continue;
+      if (slot == 0xFFFFFFFFu) { merge_global(a, gslot, g, contribution, 1); continue; }
+      accumulate_lds(c, &s_values[slot * a.n_aggregates + g], contribution);
+      atomicAdd(&s_counts[slot * a.n_aggregates + g], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && s_n_groups[1]) {
+    const uint32_t before = atomicAdd(&a.overflow[FLAG_SPILLED], s_n_groups[1]);
+    if (before + s_n_groups[1] > a.spill_limit) __hip_atomic_store(&a.overflow[FLAG_GIVE_UP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // the partition's groups: nobody else has them, every one is entered into the global table exactly once
+  for (uint32_t s = tid; s < slots; s += 256) {
+    if (s_tags[s] == TAG_EMPTY) continue;
+    if (__hip_atomic_load(&a.overflow[FLAG_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    uint64_t tuple[MAX_GROUPBY + 1];
+    for (uint32_t w = 0; w < words; ++w) tuple[w] = s_keys[s * words + w];
+    const uint32_t gslot = global_slot(a, tuple, words, hash_tuple(tuple, words));
+    if (gslot == 0xFFFFFFFFu) { a.overflow[FLAG_OVERFLOW] = 1; continue; }
+    atomicMin(reinterpret_cast<unsigned long long*>(&a.first_row[gslot]), static_cast<unsigned long long>(s_first[s]));
+    atomicMax(reinterpret_cast<unsigned long long*>(&a.last_row[gslot]), static_cast<unsigned long long>(s_last[s]));
+    for (uint32_t g = 0; g < a.n_aggregates; ++g) merge_global(a, gslot, g, s_values[s * a.n_aggregates + g], s_counts[s * a.n_aggregates + g]);
+  }
+}
+
 // The groups of the table, densely.  The first `staged_capacity` of them also go straight into pinned host memory (same
 // five arrays, `staged_capacity` rows each, behind a 64-byte header): few groups -- the usual case -- cost no copy at all.
 struct StagedGroups {
@@ -952,10 +1197,12 @@ __global__ void compact_groups(AggArgs a, uint32_t* counter, uint64_t* out_keys,
   }
 }
 
-// flags: [0] the group table overflowed, [1] number of groups -> the header of the pinned block
+// the flag words (FLAG_*) -> the header of the pinned block
 __global__ void publish_group_flags(const uint32_t* flags, uint32_t* header) {
   header[0] = flags[0];
   header[1] = flags[1];
+  header[2] = flags[2];
+  header[3] = flags[3];
   __threadfence_system();
 }
 
@@ -982,6 +1229,13 @@ static uint32_t result_type(uint32_t function, uint32_t input_type) {   // windo
 }
 
 static hy_row_id row_id_of(const hy_column* shape, uint64_t global_row) {
+  if (shape->n_chunks > 1) {   // chunks of one size (all but the last): a division instead of a search
+    const uint64_t size = shape->row_base[1];
+    const uint64_t chunk = size ? global_row / size : 0;
+    if (size && chunk < shape->n_chunks && shape->row_base[chunk] == chunk * size && global_row < shape->row_base[chunk + 1]) {
+      return hy_row_id{static_cast<uint32_t>(chunk), static_cast<uint32_t>(global_row - chunk * size)};
+    }
+  }
   const auto it = std::upper_bound(shape->row_base.begin(), shape->row_base.end(), global_row);
   const uint32_t chunk = static_cast<uint32_t>(it - shape->row_base.begin()) - 1;
   return hy_row_id{chunk, static_cast<uint32_t>(global_row - shape->row_base[chunk])};
@@ -998,20 +1252,41 @@ struct DeviceGroups {
 static uint64_t* g_agg_trace = nullptr;
 static uint32_t g_agg_trace_slices = 0;
 
+static uint32_t g_agg_path = 0;   // debug: 0 = aggregate_rows, otherwise the partition bits of the partitioned path (last call of this process)
+
 static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out) {
   hipStream_t stream = current_stream();
   const uint32_t words = a.n_groupby + 1;
   const uint32_t n_aggregates = a.n_aggregates;
   const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + 64 + SLICE_ROWS;
-  uint64_t capacity = 1u << 16;
-  while (capacity < 2 * uint64_t{LDS_SLOTS}) capacity <<= 1;
+  uint64_t two_per_row = 1024;
+  while (two_per_row < 2 * shape->rows + 1024) two_per_row <<= 1;
   // the number of groups is not known: 64 Ki slots, then 2 Mi, then 32 Mi, then two slots per row (never overflows)
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    uint64_t two_per_row = 1024;
-    while (two_per_row < 2 * shape->rows + 1024) two_per_row <<= 1;
-    if (attempt == 1) capacity = 1u << 21;
-    if (attempt == 2) capacity = 1u << 25;
-    if (attempt == 3 || capacity > two_per_row) capacity = two_per_row;
+  const uint64_t ladder[4] = {std::max<uint64_t>(1u << 16, 2 * uint64_t{LDS_SLOTS}), 1u << 21, 1u << 25, two_per_row};
+  int rung = 0;
+  // The partitioned path (tables with many groups): entered when aggregate_rows gives up; 2^bits partitions of about 16 Ki rows,
+  // then -- if even those hold more groups than a workgroup's table -- the most the partitioning kernels take.
+  constexpr uint32_t MAX_PARTITION_BITS = 14;
+  const bool can_partition = a.n_groupby > 0 && shape->rows < (1ull << 32) && shape->d_parts && shape->n_parts && !getenv("HY_AGG_NO_PARTITIONS");
+  uint32_t first_bits = 6;
+  while (first_bits < MAX_PARTITION_BITS && (shape->rows >> first_bits) > 16384) ++first_bits;
+  uint32_t partition_bits = 0;   // 0: aggregate_rows
+  if (can_partition && getenv("HY_AGG_PARTITION_BITS")) partition_bits = std::min<uint32_t>(MAX_PARTITION_BITS, std::max(1, atoi(getenv("HY_AGG_PARTITION_BITS"))));   // (tests: force the path)
+  bool unlimited = false, partitions_ready = false;
+  DeviceBuffer part_offsets, part_rows, part_sums;
+  PartitionArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  const bool timing = getenv("HY_AGG_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what, int round) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[aggregate]   round %d %-18s +%8.3f ms\n", round, what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  for (int round = 0; round < 12; ++round) {
+    if (partition_bits && rung == 0) rung = 1;   // many groups are a given on this path
+    const uint64_t capacity = std::min(ladder[rung], two_per_row);
     if (capacity > (1ull << 31)) return fail(HY_ERR_UNSUPPORTED, "too many rows for the device group table");
     DeviceBuffer tags, keys, first, last, values, counts, flags;
     HY_TRY(tags.alloc(4 * capacity));
@@ -1023,6 +1298,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     HY_TRY(flags.alloc(64));
     HY_HIP(hipMemsetAsync(tags.ptr, 0, 4 * capacity, stream));
     HY_HIP(hipMemsetAsync(flags.ptr, 0, 64, stream));
+    lap("table allocated", round);
     a.capacity = static_cast<uint32_t>(capacity);
     a.tags = tags.as<uint32_t>();
     a.keys = keys.as<uint64_t>();
@@ -1031,6 +1307,10 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     a.values = values.as<uint64_t>();
     a.counts = counts.as<uint64_t>();
     a.overflow = flags.as<uint32_t>();
+    // rows outside the LDS tables cost a handful of device-scope atomics each; the partitioned path costs about as much as one
+    // such row in sixteen.  (No limit where there is nothing to switch to.)
+    const bool last_resort = !can_partition || unlimited || (partition_bits && partition_bits >= MAX_PARTITION_BITS);
+    a.spill_limit = last_resort ? 0xFFFFFFFFu : static_cast<uint32_t>(std::max<uint64_t>(65536, shape->rows / 16));
     a.trace = nullptr;
     if (getenv("HY_AGG_TRACE") && shape->n_slices <= (1u << 14)) {
       static uint64_t* trace_buffer = nullptr;
@@ -1040,12 +1320,48 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       g_agg_trace = trace_buffer;
       g_agg_trace_slices = shape->n_slices;
     }
-    if (shape->n_slices && shape->rows) {
+    g_agg_path = partition_bits;
+    if (shape->n_slices && shape->rows && partition_bits == 0) {
       profile_begin(stream);
       hipLaunchKernelGGL(aggregate_rows, dim3(shape->n_slices), dim3(256), lds_bytes, stream, a);
       profile_end(stream);
+    } else if (shape->n_slices && shape->rows) {
+      const uint32_t partitions = 1u << partition_bits;
+      profile_begin(stream);
+      if (!partitions_ready) {
+        const uint64_t cells = uint64_t{partitions} * shape->n_parts;
+        const uint32_t n_blocks = static_cast<uint32_t>((cells + SCAN_BLOCK - 1) / SCAN_BLOCK);
+        HY_TRY(part_offsets.alloc(4 * cells));
+        HY_TRY(part_sums.alloc(4 * (size_t{n_blocks} + 1)));
+        HY_TRY(part_rows.alloc(sizeof(hy_row_id) * shape->rows));
+        pa.parts = shape->d_parts;
+        pa.n_parts = shape->n_parts;
+        pa.bits = partition_bits;
+        pa.offsets = part_offsets.as<uint32_t>();
+        pa.rows = part_rows.as<hy_row_id>();
+        pa.total_rows = shape->rows;
+        const size_t per_slot = 8 * words + 16 + 12 * n_aggregates + 4;
+        pa.lds_slots = 2048;
+        while (pa.lds_slots > 64 && pa.lds_slots * per_slot > 32768) pa.lds_slots >>= 1;
+        static const bool lds_raised = [] {   // 2^14 partitions: 64 KiB of counters, the most a workgroup gets without asking
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+          return true;
+        }();
+        (void)lds_raised;
+        hipLaunchKernelGGL(partition_rows<false>, dim3(shape->n_parts), dim3(256), 4 * size_t{partitions}, stream, a, pa);
+        hipLaunchKernelGGL(scan_blocks, dim3(n_blocks), dim3(256), 0, stream, pa.offsets, cells, part_sums.as<uint32_t>());
+        hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, part_sums.as<uint32_t>(), n_blocks);
+        hipLaunchKernelGGL(scan_add, dim3(n_blocks), dim3(256), 0, stream, pa.offsets, cells, part_sums.as<uint32_t>());
+        hipLaunchKernelGGL(partition_rows<true>, dim3(shape->n_parts), dim3(256), 4 * size_t{partitions}, stream, a, pa);
+        partitions_ready = true;
+      }
+      const size_t per_slot = 8 * words + 16 + 12 * n_aggregates + 4;
+      hipLaunchKernelGGL(aggregate_partitions, dim3(partitions), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa);
+      profile_end(stream);
     }
-    uint32_t host_flags[2] = {0, 0};
+    lap("kernels launched", round);
+    uint32_t host_flags[4] = {0, 0, 0, 0};
     // count groups, then compact
     DeviceBuffer c_keys, c_first, c_last, c_values, c_counts;
     const uint32_t out_capacity = static_cast<uint32_t>(std::min<uint64_t>(capacity, shape->rows + 1));
@@ -1071,13 +1387,26 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       g.capacity = STAGED_GROUPS;
       return g;
     };
-    hipLaunchKernelGGL(compact_groups, dim3(static_cast<uint32_t>((capacity + 255) / 256)), dim3(256), 0, stream, a, flags.as<uint32_t>() + 1, c_keys.as<uint64_t>(),
+    hipLaunchKernelGGL(compact_groups, dim3(static_cast<uint32_t>((capacity + 255) / 256)), dim3(256), 0, stream, a, flags.as<uint32_t>() + FLAG_GROUPS, c_keys.as<uint64_t>(),
                        c_first.as<uint64_t>(), c_last.as<uint64_t>(), c_values.as<uint64_t>(), c_counts.as<uint64_t>(), out_capacity, staged_arrays(pinned_dev));
     hipLaunchKernelGGL(publish_group_flags, dim3(1), dim3(1), 0, stream, flags.as<uint32_t>(), static_cast<uint32_t*>(pinned_dev));
+    lap("compact launched", round);
     HY_HIP(hipStreamSynchronize(stream));
-    std::memcpy(host_flags, pinned_host, 8);
-    if (host_flags[0]) continue;   // table overflow: retry with a larger one
-    const uint32_t n_groups = host_flags[1];
+    lap("device finished", round);
+    std::memcpy(host_flags, pinned_host, 16);
+    if (host_flags[FLAG_GIVE_UP]) {   // too many rows outside the LDS tables: partition (more finely)
+      if (partition_bits == 0) partition_bits = first_bits;
+      else if (partition_bits < MAX_PARTITION_BITS) partition_bits = MAX_PARTITION_BITS;
+      else unlimited = true;
+      partitions_ready = false;
+      continue;
+    }
+    if (host_flags[FLAG_OVERFLOW]) {   // table overflow: retry with a larger one
+      if (rung < 3) ++rung;
+      else return fail(HY_ERR_DEVICE, "the device group table overflowed at two slots per row (internal error)");
+      continue;
+    }
+    const uint32_t n_groups = host_flags[FLAG_GROUPS];
     out.n_groups = n_groups;
     out.keys.resize(size_t{n_groups} * words);
     out.first.resize(n_groups);
@@ -1103,9 +1432,10 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       }
       HY_HIP(hipStreamSynchronize(stream));
     }
+    lap("groups copied", round);
     return HY_OK;
   }
-  return fail(HY_ERR_DEVICE, "the device group table overflowed at every size (internal error)");
+  return fail(HY_ERR_DEVICE, "the device group table did not settle (internal error)");
 }
 
 
@@ -1218,8 +1548,14 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   hipStream_t stream = current_stream();
   const uint32_t words = n_groupby + 1;
 
+  const bool timing = getenv("HY_AGG_TIMING") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) std::fprintf(stderr, "[aggregate] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
   DeviceGroups main_groups;
   HY_TRY(device_groups(a, shape, main_groups));
+  lap("device groups on host");
   const uint32_t n_groups = main_groups.n_groups;
   const std::vector<uint64_t>&h_keys = main_groups.keys, &h_first = main_groups.first, &h_last = main_groups.last, &h_values = main_groups.values,
                              &h_counts = main_groups.counts;
@@ -1262,16 +1598,26 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     }
     immediate = max_key > 0 && static_cast<double>(max_key - min_key) < static_cast<double>(shape->rows) * 1.2;
   }
-  if (immediate) {
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-      const bool xn = h_keys[size_t{x} * words] & 1, yn = h_keys[size_t{y} * words] & 1;
-      if (xn != yn) return xn;
-      return static_cast<int64_t>(h_keys[size_t{x} * words + 1]) < static_cast<int64_t>(h_keys[size_t{y} * words + 1]);
-    });
-  } else {
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_first[x] < h_first[y]; });
+  {   // ascending key (NULL first) or first row: an LSD radix sort of (64-bit sort key, group) -- a comparison sort of 100 000 groups
+      // through an index costs more than the device spends on the whole table
+    std::vector<uint64_t> sort_key(n_groups);
+    uint64_t all_bits = 0;
+    for (uint32_t i = 0; i < n_groups; ++i) {
+      if (immediate) sort_key[i] = (h_keys[size_t{i} * words] & 1) ? 0 : static_cast<uint64_t>(static_cast<int64_t>(h_keys[size_t{i} * words + 1]) - static_cast<int64_t>(INT32_MIN)) + 1;
+      else sort_key[i] = h_first[i];
+      all_bits |= sort_key[i];
+    }
+    std::vector<uint32_t> scratch_order(n_groups);
+    for (uint32_t shift = 0; shift < 64 && (all_bits >> shift) != 0; shift += 16) {
+      std::vector<uint32_t> bucket(65537, 0);
+      for (uint32_t i = 0; i < n_groups; ++i) ++bucket[((sort_key[order[i]] >> shift) & 0xFFFF) + 1];
+      for (uint32_t b = 0; b < 65536; ++b) bucket[b + 1] += bucket[b];
+      for (uint32_t i = 0; i < n_groups; ++i) scratch_order[bucket[(sort_key[order[i]] >> shift) & 0xFFFF]++] = order[i];
+      order.swap(scratch_order);
+    }
   }
 
+  lap("groups ordered");
   const bool no_groupby_empty = n_groupby == 0 && n_groups == 0;   // one row of NULLs / zero counts (:1422-1432)
   const uint32_t out_groups = no_groupby_empty ? 1 : n_groups;
   result->n_groups = out_groups;
@@ -1356,6 +1702,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       }
     }
   }
+  lap("result written");
   return HY_OK;
 }
 
@@ -1371,6 +1718,9 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_aggregate_hash: result columns missing");
   return run_aggregate(groupby_columns, n_groupby, aggregates, n_aggregates, result);
 }
+
+// debug only: which path the last hy_aggregate_hash of this process took -- 0 aggregate_rows, else the partition bits; not part of the public header
+int hy_debug_aggregate_path(void) { return static_cast<int>(g_agg_path); }
 
 // debug only (HY_AGG_TRACE): the per-slice phase stamps of the last aggregate_rows launch; not part of the public header
 int hy_debug_aggregate_trace(uint64_t* out, uint32_t capacity_slices) {

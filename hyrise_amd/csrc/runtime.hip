@@ -123,7 +123,14 @@ void pool_release(void* ptr, size_t capacity) {
   if (ptr) t_pool.free_blocks.emplace_back(capacity, ptr);
 }
 
-hy_status DeviceBuffer::alloc(size_t bytes) { return pool_acquire(bytes, &ptr, &capacity); }
+hy_status DeviceBuffer::alloc(size_t bytes) {
+  if (ptr) {   // a buffer that is sized again gives its block back first
+    pool_release(ptr, capacity);
+    ptr = nullptr;
+    capacity = 0;
+  }
+  return pool_acquire(bytes, &ptr, &capacity);
+}
 
 DeviceBuffer::~DeviceBuffer() { pool_release(ptr, capacity); }
 

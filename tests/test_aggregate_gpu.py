@@ -186,3 +186,63 @@ def test_stddev_of_large_values_with_a_small_spread(device):
             exact = float(np.sqrt(((shifted - shifted.mean()) ** 2).sum() / (member.sum() - 1)))
             assert abs(got.column(0)[g] - exact) <= 1e-9 * exact, f"device {got.column(0)[g]} vs exact {exact}"
             assert abs(want.column(0)[g] - exact) <= 1e-3 * exact, f"oracle {want.column(0)[g]} vs exact {exact}"   # (its running mean has an ulp of 1e-3 at 5e12)
+
+
+def aggregate_path():
+    lib = abi.load_library()
+    lib.hy_debug_aggregate_path.restype = int
+    return lib.hy_debug_aggregate_path()
+
+
+@pytest.fixture
+def forced_partitions():
+    """HY_AGG_PARTITION_BITS: every aggregate of the test runs the partitioned path (partition -> LDS tables -> one merge)."""
+    os.environ["HY_AGG_PARTITION_BITS"] = "3"
+    yield
+    del os.environ["HY_AGG_PARTITION_BITS"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"L{c['line']}" for c in CASES])
+def test_reference_aggregate_fixture_on_the_partitioned_path(device, forced_partitions, case):
+    columns = AggregateCase(case)
+    if not columns.runnable:
+        pytest.skip("COUNT(*) without GROUP BY and without a column to take the table's shape from")
+    run_both(columns.groupby, columns.aggregates, f"aggregate_test.cpp:{case['line']} (partitioned)")
+    assert aggregate_path() == (3 if columns.groupby else 0)
+
+
+@pytest.mark.parametrize("n_groups,expected_path", [(100, 0), (5_000, 6), (150_000, 14)])
+def test_many_groups_take_the_partitioned_path(device, n_groups, expected_path):
+    """More groups than a slice's LDS table holds: aggregate_rows gives up after a few slices and the table is partitioned by
+    the hash of its keys (two GROUP BY columns, NULL keys, dictionary / unencoded / FrameOfReference inputs, every mergeable
+    function)."""
+    rng = np.random.default_rng(n_groups)
+    n, chunk = 700_000, 65535
+    k1 = (rng.integers(0, n_groups, n).astype(np.int64) * 1_000_003 - 17)            # sparse int64 keys
+    k2 = rng.integers(0, 2, n).astype(np.int32)
+    k1_null = rng.random(n) < 0.003
+    ints = rng.integers(-1000, 1000, n).astype(np.int32)
+    floats = (rng.random(n) * 1000).astype(np.float32)
+    doubles = rng.random(n) * 1e6
+    vnull = rng.random(n) < 0.05
+    groupby = [build_column(k1, k1_null, chunk, abi.ENC_DICTIONARY), build_column(k2, None, chunk, abi.ENC_UNENCODED)]
+    aggregates = [(abi.AGG_SUM, build_column(ints, vnull, chunk, abi.ENC_FRAME_OF_REFERENCE)), (abi.AGG_AVG, build_column(floats, None, chunk, abi.ENC_DICTIONARY)),
+                  (abi.AGG_MIN, build_column(doubles, vnull, chunk, abi.ENC_UNENCODED)), (abi.AGG_MAX, build_column(ints, None, chunk, abi.ENC_UNENCODED)),
+                  (abi.AGG_COUNT, None), (abi.AGG_SUM, build_column(doubles, None, chunk, abi.ENC_UNENCODED))]
+    got = run_both(groupby, aggregates, f"{n_groups} groups")
+    assert got.n_groups > n_groups * 0.9
+    assert aggregate_path() == expected_path
+
+
+def test_partitions_with_more_groups_than_their_tables(device):
+    """Every row its own group at 2^3 forced partitions: the partitions' LDS tables overflow, the rows go to the global table
+    directly, the path gives up and partitions more finely -- the result is the same."""
+    os.environ["HY_AGG_PARTITION_BITS"] = "3"
+    try:
+        n = 200_000
+        keys = np.random.default_rng(4).permutation(n).astype(np.int32) * 13
+        values = np.arange(n, dtype=np.int64)
+        got = run_both([build_column(keys, None, 65535, abi.ENC_UNENCODED)], [(abi.AGG_SUM, build_column(values, None, 65535, abi.ENC_UNENCODED)), (abi.AGG_COUNT, None)])
+        assert got.n_groups == n and aggregate_path() == 14
+    finally:
+        del os.environ["HY_AGG_PARTITION_BITS"]

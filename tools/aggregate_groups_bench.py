@@ -17,7 +17,7 @@ abi.check(lib.hy_init(0))
 rng = np.random.default_rng(9)
 n = int(os.environ.get("ROWS", "60000000"))
 values = DeviceColumn(storage.make_column(rng.random(n).astype(np.float32), None, abi.ENC_UNENCODED))
-for groups in (4, 64, 1000, 100_000, 4_000_000):
+for groups in [int(g) for g in os.environ.get("NGROUPS", "4,64,1000,100000,4000000").split(",")]:
     keys = DeviceColumn(storage.make_column(rng.integers(0, groups, n).astype(np.int32), None, abi.ENC_UNENCODED))
     for i in range(3):
         torch.cuda.synchronize()
