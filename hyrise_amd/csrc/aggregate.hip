@@ -516,6 +516,9 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   }
 #pragma unroll 1
   for (uint32_t block = direct ? ROWS / GB : 0; block < ROWS / GB; ++block) {
+    // A table that is full after a part of the slice: the rest of the rows would walk it in vain.  They count as rows left
+    // out (pass 3 sends them to the global table -- or, when that happens in many slices, the partitioned path takes the table).
+    if (__hip_atomic_load(s_n_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LDS_SLOTS) break;
     uint32_t row[GB], valid = 0;
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
@@ -953,40 +956,122 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
 // time (a dozen G atomics/s for the whole device: 22 ms for 60 M rows in 1000 groups).  When that happens to more than a few
 // rows, the host starts over here (the reference partitions by the hash of the keys for the same reason, aggregate_hash.cpp:661-
 // 948: its partitions keep the hash tables in cache):
-//   partition_count    per part (<= 65 536 rows of one chunk): histogram of the rows' partitions -- the top bits of the tuple hash
-//   scan_*             exclusive prefix sum over (partition, part): where every part's rows of every partition go
-//   partition_scatter  the RowIDs, grouped by partition (a partition's rows: 8 bytes each, contiguous)
+//   partition_count    per tile (one slice, or eight where there are very many partitions): histogram of the rows' partitions -- the
+//                      top bits of the tuple hash
+//   scan_*             exclusive prefix sum over (partition, tile): where every tile's rows of every partition go
+//   partition_scatter  one RECORD per row, grouped by partition: global row number + which aggregate inputs are non-NULL | the GROUP BY
+//                      tuple | the aggregates' contributions -- everything the next kernel needs, written and read back
+//                      sequentially.  (Carrying RowIDs and gathering the values again costs a 128-byte line per row and column.)
 //   aggregate_partitions  one workgroup per partition: ALL rows of a group are here, so the groups live in an LDS table for the
 //                      whole pass (LDS atomics per row) and reach the global table once, at the end.
 struct PartitionArgs {
-  const Part* parts;
-  uint32_t n_parts;
+  uint32_t tile_slices;     // a tile of the partitioning kernels: this many consecutive slices (one workgroup)
+  uint32_t n_slices;
+  uint32_t reserved;
+  uint32_t n_parts;         // number of tiles
   uint32_t bits;            // partitions = 1 << bits
   uint32_t lds_slots;       // aggregate_partitions: slots of the workgroup's table (power of two)
-  uint32_t reserved;
+  uint32_t split;           // aggregate_partitions: workgroups per partition (each takes a share of its rows; they meet in the global table)
   uint32_t* offsets;        // [partitions][n_parts]: counts, then (after the scan) first output position
-  hy_row_id* rows;          // [total_rows]
+  uint64_t* records;        // [total_rows][record_words]: row | present << 32, tuple[words], contribution of every aggregate with a column
   uint64_t total_rows;
+  uint32_t reserved2;
+  uint32_t record_words;    // even: records are written and read as 16-byte pairs
+  uint32_t carried;         // aggregates with a column (the first `carried` of AggArgs.aggregates): their contributions travel in the record
 };
 
-template <bool SCATTER>
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t MAX_RECORD_PAIRS = (2 + MAX_GROUPBY + 1 + MAX_AGGREGATES) / 2;   // head + tuple + contributions, rounded up to 16 bytes
+
+// WORDS = GROUP BY columns + 1 (the tuple's words): the record layout is static per instantiation, so a record is built in
+// registers and leaves as 16-byte stores (8-byte stores retire at half the rate).
+template <bool SCATTER, int WORDS>
 __global__ __launch_bounds__(256) void partition_rows(AggArgs a, PartitionArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_cell = reinterpret_cast<uint32_t*>(smem);   // count (SCATTER: next output position) of every partition
-  const uint32_t partitions = 1u << p.bits, tid = threadIdx.x, words = a.n_groupby + 1;
+  const uint32_t partitions = 1u << p.bits, tid = threadIdx.x;
   for (uint32_t i = tid; i < partitions; i += 256) s_cell[i] = SCATTER ? p.offsets[size_t{i} * p.n_parts + blockIdx.x] : 0u;
   __syncthreads();
-  const Part part = p.parts[blockIdx.x];
-  for (uint32_t s = 0; s < part.n_slices; ++s) {
-    const Slice slice = a.slices[part.first_slice + s];
+  const uint32_t pairs = p.record_words / 2, carried = p.carried;
+  const uint32_t first_slice = blockIdx.x * p.tile_slices, last_slice = min(p.n_slices, first_slice + p.tile_slices);
+  constexpr int R = 2;   // rows per thread and step: the loads of both (and, unrolled, of the next step) are in flight together
+  for (uint32_t s = first_slice; s < last_slice; ++s) {
+    const Slice slice = a.slices[s];
+    const uint64_t chunk_base = SCATTER ? a.row_base[slice.chunk] : 0;
 #pragma unroll 2
-    for (uint32_t r = tid; r < slice.row_count; r += 256) {
-      const uint32_t row = slice.row_begin + r;
-      uint64_t tuple[MAX_GROUPBY + 1];
-      row_tuple(a, slice.chunk, row, tuple);
-      const uint32_t partition = static_cast<uint32_t>(hash_tuple(tuple, words) >> (64 - p.bits));
-      const uint32_t position = atomicAdd(&s_cell[partition], 1u);
-      if (SCATTER) p.rows[position] = hy_row_id{slice.chunk, row};
+    for (uint32_t base = 0; base < slice.row_count; base += 256 * R) {
+      uint32_t row[R], valid = 0;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const uint32_t r = base + tid * R + i;
+        if (r < slice.row_count) valid |= 1u << i;
+        row[i] = slice.row_begin + (r < slice.row_count ? r : 0);
+      }
+      uint64_t tuple[R][MAX_GROUPBY + 1];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+#pragma unroll
+        for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) tuple[i][w] = 0;
+      }
+#pragma unroll
+      for (int g = 0; g < WORDS - 1; ++g) {
+        const DevSegment segment = a.groupby[g].segments[slice.chunk];
+        uint64_t bits[R];
+        uint32_t nulls;
+        decode_rows<R>(segment, a.groupby[g].segments, slice.chunk, row, valid, bits, &nulls);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          uint64_t word = bits[i];
+          if (a.groupby[g].is_float && __longlong_as_double(static_cast<long long>(word)) == 0.0) word = 0;   // -0.0 groups with 0.0
+          if ((nulls >> i) & 1) { tuple[i][0] |= 1ull << g; word = 0; }
+          tuple[i][g + 1] = word;
+        }
+      }
+      uint32_t position[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        position[i] = 0;
+        if ((valid >> i) & 1) position[i] = atomicAdd(&s_cell[static_cast<uint32_t>(hash_tuple(tuple[i], WORDS) >> (64 - p.bits))], 1u);
+      }
+      if (SCATTER) {
+        uint64_t contribution[MAX_AGGREGATES][R];
+        uint32_t present[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) present[i] = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < MAX_AGGREGATES; ++g) {   // the aggregates with a column come first (run_aggregate orders them)
+#pragma unroll
+          for (int i = 0; i < R; ++i) contribution[g][i] = 0;
+          if (g >= carried) continue;
+          const AggColumn c = a.aggregates[g];
+          const DevSegment segment = c.segments[slice.chunk];
+          uint64_t bits[R];
+          uint32_t nulls;
+          decode_rows<R>(segment, c.segments, slice.chunk, row, valid, bits, &nulls);
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            contribution[g][i] = contribution_from(c, bits[i]);
+            if (!((nulls >> i) & 1)) present[i] |= 1u << g;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          if (!((valid >> i) & 1)) continue;
+          uint64_t record[2 * MAX_RECORD_PAIRS];
+#pragma unroll
+          for (uint32_t k = 0; k < 2 * MAX_RECORD_PAIRS; ++k) record[k] = 0;
+          record[0] = (chunk_base + row[i]) | static_cast<uint64_t>(present[i]) << 32;
+#pragma unroll
+          for (int w = 0; w < WORDS; ++w) record[1 + w] = tuple[i][w];
+#pragma unroll
+          for (uint32_t g = 0; g < MAX_AGGREGATES; ++g) record[1 + WORDS + g] = contribution[g][i];
+          u64x2* out = reinterpret_cast<u64x2*>(p.records) + size_t{position[i]} * pairs;
+#pragma unroll
+          for (uint32_t k = 0; k < MAX_RECORD_PAIRS; ++k) {
+            if (k < pairs) { u64x2 v; v.x = record[2 * k]; v.y = record[2 * k + 1]; out[k] = v; }
+          }
+        }
+      }
     }
   }
   if (SCATTER) return;
@@ -1084,9 +1169,11 @@ __device__ __forceinline__ uint32_t lds_slot(uint32_t* s_tags, uint64_t* s_keys,
 }
 
 // LDS layout: keys[S][words] u64 | first[S] u64 | last[S] u64 | values[S][A] u64 | counts[S][A] u32 | tags[S] u32 | groups, spilled u32
+template <int WORDS>
 __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, PartitionArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t words = a.n_groupby + 1, slots = p.lds_slots, tid = threadIdx.x;
+  constexpr uint32_t words = WORDS;
+  const uint32_t slots = p.lds_slots, tid = threadIdx.x;
   uint64_t* s_keys = reinterpret_cast<uint64_t*>(smem);
   uint64_t* s_first = s_keys + size_t{slots} * words;
   uint64_t* s_last = s_first + slots;
@@ -1109,17 +1196,33 @@ __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, Partition
   }
   __syncthreads();
   if (s_n_groups[2]) return;
-  const uint32_t partitions = 1u << p.bits;
-  const uint64_t begin = p.offsets[size_t{blockIdx.x} * p.n_parts];
-  const uint64_t end = blockIdx.x + 1 < partitions ? p.offsets[size_t{blockIdx.x + 1} * p.n_parts] : p.total_rows;
+  const uint32_t partitions = 1u << p.bits, partition = blockIdx.x / p.split, share = blockIdx.x % p.split;
+  const uint64_t partition_begin = p.offsets[size_t{partition} * p.n_parts];
+  const uint64_t partition_end = partition + 1 < partitions ? p.offsets[size_t{partition + 1} * p.n_parts] : p.total_rows;
+  const uint64_t per_share = (partition_end - partition_begin + p.split - 1) / p.split;
+  const uint64_t begin = min(partition_end, partition_begin + share * per_share), end = min(partition_end, begin + per_share);
+  const uint32_t pairs = p.record_words / 2;
 #pragma unroll 1
   for (uint64_t base = begin; base < end; base += 256) {
     const uint64_t i = base + tid;
     if (i >= end) continue;
-    const hy_row_id id = p.rows[i];
-    const uint64_t global_row = a.row_base[id.chunk_id] + id.chunk_offset;
+    uint64_t record[2 * MAX_RECORD_PAIRS];
+    {
+      const u64x2* in = reinterpret_cast<const u64x2*>(p.records) + i * pairs;
+#pragma unroll
+      for (uint32_t k = 0; k < MAX_RECORD_PAIRS; ++k) {
+        u64x2 v; v.x = 0; v.y = 0;
+        if (k < pairs) v = in[k];
+        record[2 * k] = v.x;
+        record[2 * k + 1] = v.y;
+      }
+    }
+    const uint64_t head = record[0];
+    const uint64_t global_row = head & 0xFFFFFFFFull;
+    const uint32_t present = static_cast<uint32_t>(head >> 32);
     uint64_t tuple[MAX_GROUPBY + 1];
-    row_tuple(a, id.chunk_id, id.chunk_offset, tuple);
+#pragma unroll
+    for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) tuple[w] = w < words ? record[1 + w] : 0ull;
     const uint64_t hash = hash_tuple(tuple, words);
     // (the partition took the hash's top bits; both tables index with its low bits)
     const uint32_t slot = lds_slot(s_tags, s_keys, slots, words, tuple, hash, s_n_groups);
@@ -1135,10 +1238,15 @@ __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, Partition
       atomicMin(reinterpret_cast<unsigned long long*>(&s_first[slot]), static_cast<unsigned long long>(global_row));
       atomicMax(reinterpret_cast<unsigned long long*>(&s_last[slot]), static_cast<unsigned long long>(global_row));
     }
-    for (uint32_t g = 0; g < a.n_aggregates; ++g) {
+#pragma unroll
+    for (uint32_t g = 0; g < MAX_AGGREGATES; ++g) {
+      if (g >= a.n_aggregates) continue;
       const AggColumn& c = a.aggregates[g];
-      uint64_t contribution;
-      if (!contribution_of(c, id.chunk_id, id.chunk_offset, &contribution)) continue;
+      uint64_t contribution = 0;
+      if (g < p.carried) {
+        contribution = record[1 + words + g];
+        if (!((present >> g) & 1)) continue;   // NULL inputs leave the aggregate unchanged
+      }
       if (slot == 0xFFFFFFFFu) { merge_global(a, gslot, g, contribution, 1); continue; }
       accumulate_lds(c, &s_values[slot * a.n_aggregates + g], contribution);
       atomicAdd(&s_counts[slot * a.n_aggregates + g], 1u);
@@ -1252,6 +1360,30 @@ struct DeviceGroups {
 static uint64_t* g_agg_trace = nullptr;
 static uint32_t g_agg_trace_slices = 0;
 
+template <bool SCATTER, int WORDS>
+static void launch_partition_rows_as(uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
+  static const bool lds_raised = [] {   // 2^14 partitions: 64 KiB of counters, the most a workgroup gets without asking
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_rows<SCATTER, WORDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    return true;
+  }();
+  (void)lds_raised;
+  hipLaunchKernelGGL((partition_rows<SCATTER, WORDS>), dim3(grid), dim3(256), lds, stream, a, pa);
+}
+template <bool SCATTER>
+static void launch_partition_rows_of(uint32_t words, uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
+  switch (words) {
+    case 1: launch_partition_rows_as<SCATTER, 1>(grid, lds, stream, a, pa); break;
+    case 2: launch_partition_rows_as<SCATTER, 2>(grid, lds, stream, a, pa); break;
+    case 3: launch_partition_rows_as<SCATTER, 3>(grid, lds, stream, a, pa); break;
+    case 4: launch_partition_rows_as<SCATTER, 4>(grid, lds, stream, a, pa); break;
+    default: launch_partition_rows_as<SCATTER, 5>(grid, lds, stream, a, pa); break;
+  }
+}
+static void launch_partition_rows(bool scatter, uint32_t words, uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
+  if (scatter) launch_partition_rows_of<true>(words, grid, lds, stream, a, pa);
+  else launch_partition_rows_of<false>(words, grid, lds, stream, a, pa);
+}
+
 static uint32_t g_agg_path = 0;   // debug: 0 = aggregate_rows, otherwise the partition bits of the partitioned path (last call of this process)
 
 static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out) {
@@ -1264,12 +1396,12 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   // the number of groups is not known: 64 Ki slots, then 2 Mi, then 32 Mi, then two slots per row (never overflows)
   const uint64_t ladder[4] = {std::max<uint64_t>(1u << 16, 2 * uint64_t{LDS_SLOTS}), 1u << 21, 1u << 25, two_per_row};
   int rung = 0;
-  // The partitioned path (tables with many groups): entered when aggregate_rows gives up; 2^bits partitions of about 16 Ki rows,
+  // The partitioned path (tables with many groups): entered when aggregate_rows gives up; 2^bits partitions of about 64 Ki rows,
   // then -- if even those hold more groups than a workgroup's table -- the most the partitioning kernels take.
   constexpr uint32_t MAX_PARTITION_BITS = 14;
-  const bool can_partition = a.n_groupby > 0 && shape->rows < (1ull << 32) && shape->d_parts && shape->n_parts && !getenv("HY_AGG_NO_PARTITIONS");
+  const bool can_partition = a.n_groupby > 0 && shape->rows < (1ull << 32) && !getenv("HY_AGG_NO_PARTITIONS");
   uint32_t first_bits = 6;
-  while (first_bits < MAX_PARTITION_BITS && (shape->rows >> first_bits) > 16384) ++first_bits;
+  while (first_bits < MAX_PARTITION_BITS && (shape->rows >> first_bits) > 65536) ++first_bits;
   uint32_t partition_bits = 0;   // 0: aggregate_rows
   if (can_partition && getenv("HY_AGG_PARTITION_BITS")) partition_bits = std::min<uint32_t>(MAX_PARTITION_BITS, std::max(1, atoi(getenv("HY_AGG_PARTITION_BITS"))));   // (tests: force the path)
   bool unlimited = false, partitions_ready = false;
@@ -1329,35 +1461,46 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       const uint32_t partitions = 1u << partition_bits;
       profile_begin(stream);
       if (!partitions_ready) {
-        const uint64_t cells = uint64_t{partitions} * shape->n_parts;
+        pa.tile_slices = partition_bits <= 11 ? 1 : 8;   // (a tile's histogram is written and scanned: 2^bits cells per tile)
+        pa.n_slices = shape->n_slices;
+        pa.n_parts = (shape->n_slices + pa.tile_slices - 1) / pa.tile_slices;
+        const uint64_t cells = uint64_t{partitions} * pa.n_parts;
         const uint32_t n_blocks = static_cast<uint32_t>((cells + SCAN_BLOCK - 1) / SCAN_BLOCK);
         HY_TRY(part_offsets.alloc(4 * cells));
         HY_TRY(part_sums.alloc(4 * (size_t{n_blocks} + 1)));
-        HY_TRY(part_rows.alloc(sizeof(hy_row_id) * shape->rows));
-        pa.parts = shape->d_parts;
-        pa.n_parts = shape->n_parts;
+        uint32_t carried = 0;
+        while (carried < n_aggregates && a.aggregates[carried].segments) ++carried;   // (run_aggregate puts COUNT(*) last)
+        for (uint32_t g = carried; g < n_aggregates; ++g) if (a.aggregates[g].segments) return fail(HY_ERR_DEVICE, "aggregates with a column must come first (internal error)");
+        pa.carried = carried;
+        pa.record_words = (1 + words + carried + 1) / 2 * 2;
+        HY_TRY(part_rows.alloc(8 * size_t{pa.record_words} * shape->rows));
         pa.bits = partition_bits;
         pa.offsets = part_offsets.as<uint32_t>();
-        pa.rows = part_rows.as<hy_row_id>();
+        pa.records = part_rows.as<uint64_t>();
         pa.total_rows = shape->rows;
         const size_t per_slot = 8 * words + 16 + 12 * n_aggregates + 4;
         pa.lds_slots = 2048;
-        while (pa.lds_slots > 64 && pa.lds_slots * per_slot > 32768) pa.lds_slots >>= 1;
-        static const bool lds_raised = [] {   // 2^14 partitions: 64 KiB of counters, the most a workgroup gets without asking
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-          return true;
-        }();
-        (void)lds_raised;
-        hipLaunchKernelGGL(partition_rows<false>, dim3(shape->n_parts), dim3(256), 4 * size_t{partitions}, stream, a, pa);
+        const size_t lds_budget = getenv("HY_AGG_LDS_BUDGET") ? static_cast<size_t>(atoi(getenv("HY_AGG_LDS_BUDGET"))) : 32768;
+        while (pa.lds_slots > 64 && pa.lds_slots * per_slot > lds_budget) pa.lds_slots >>= 1;
+        launch_partition_rows(false, words, pa.n_parts, 4 * size_t{partitions}, stream, a, pa);
         hipLaunchKernelGGL(scan_blocks, dim3(n_blocks), dim3(256), 0, stream, pa.offsets, cells, part_sums.as<uint32_t>());
         hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, part_sums.as<uint32_t>(), n_blocks);
         hipLaunchKernelGGL(scan_add, dim3(n_blocks), dim3(256), 0, stream, pa.offsets, cells, part_sums.as<uint32_t>());
-        hipLaunchKernelGGL(partition_rows<true>, dim3(shape->n_parts), dim3(256), 4 * size_t{partitions}, stream, a, pa);
+        launch_partition_rows(true, words, pa.n_parts, 4 * size_t{partitions}, stream, a, pa);
         partitions_ready = true;
       }
       const size_t per_slot = 8 * words + 16 + 12 * n_aggregates + 4;
-      hipLaunchKernelGGL(aggregate_partitions, dim3(partitions), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa);
+      // about 16 Ki rows per workgroup: coarse partitions (long contiguous runs for the scatter) are shared by several
+      pa.split = 1;
+      while (pa.split < 64 && (shape->rows >> partition_bits) / pa.split > 16384) pa.split <<= 1;
+      if (const char* env = getenv("HY_AGG_SPLIT")) pa.split = std::max(1, atoi(env));
+      switch (words) {
+        case 1: hipLaunchKernelGGL(aggregate_partitions<1>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
+        case 2: hipLaunchKernelGGL(aggregate_partitions<2>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
+        case 3: hipLaunchKernelGGL(aggregate_partitions<3>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
+        case 4: hipLaunchKernelGGL(aggregate_partitions<4>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
+        default: hipLaunchKernelGGL(aggregate_partitions<5>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
+      }
       profile_end(stream);
     }
     lap("kernels launched", round);
@@ -1540,6 +1683,18 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
         HY_HIP(hipStreamSynchronize(current_stream()));
       }
       a.aggregates[n_device - 2].pivot = a.aggregates[n_device - 1].pivot = pivot_host[0];
+    }
+  }
+  {   // accumulators with a column first, COUNT(*) last: the partitioned path carries the contributions of a prefix
+    AggColumn wired[MAX_AGGREGATES];
+    uint32_t place[MAX_AGGREGATES], next = 0;
+    for (uint32_t d = 0; d < n_device; ++d) wired[d] = a.aggregates[d];
+    for (uint32_t d = 0; d < n_device; ++d) if (wired[d].segments) place[d] = next++;
+    for (uint32_t d = 0; d < n_device; ++d) if (!wired[d].segments) place[d] = next++;
+    for (uint32_t d = 0; d < n_device; ++d) a.aggregates[place[d]] = wired[d];
+    for (uint32_t g = 0; g < n_aggregates; ++g) {
+      if (primary[g] >= 0) primary[g] = static_cast<int>(place[primary[g]]);
+      if (secondary[g] >= 0) secondary[g] = static_cast<int>(place[secondary[g]]);
     }
   }
   a.n_aggregates = n_device;
