@@ -684,6 +684,42 @@ __device__ __forceinline__ void unpack_group(const RawGroup<W>& g, uint32_t (&x)
   }
 }
 
+// ---- ColumnVsColumn over 4-byte columns (TPC-H Q4 / Q12: l_commitdate < l_receiptdate) ------------------------------------------
+// A segment whose rows decode to one 4-byte word each -- unencoded int32 / float, a dictionary of such values, or
+// FrameOfReference -- and whose vector can be read in aligned groups of eight rows.
+__device__ __forceinline__ bool four_byte_rows(const DevSegment& s) {
+  if ((s.data_type != HY_TYPE_INT && s.data_type != HY_TYPE_FLOAT) || (s.flags & SEG_UNALIGNED)) return false;
+  if (s.encoding == HY_ENC_UNENCODED) return true;
+  if (s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE) return s.width == 1 || s.width == 2 || s.width == 4;
+  return false;
+}
+
+// Rows row0 .. row0 + 7 of such a segment (row0 a multiple of eight, at least one of the rows inside the segment): the eight
+// stored elements come with ONE aligned load; dictionary value ids are then looked up (the dictionaries of a chunk are a few
+// KiB: cache hits).  Bit j of *nulls: row j is NULL.
+__device__ __forceinline__ void fetch_four_byte_rows(const DevSegment& s, uint32_t row0, uint32_t (&word)[8], uint32_t* nulls) {
+  uint32_t x[8];
+  if (s.encoding == HY_ENC_UNENCODED || s.width == 4) unpack_group<4>(load_group<4>(s.data, row0), x);
+  else if (s.width == 2) unpack_group<2>(load_group<2>(s.data, row0), x);
+  else unpack_group<1>(load_group<1>(s.data, row0), x);
+  *nulls = 0;
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    const HY_GLOBAL uint32_t* dictionary = as_global<uint32_t>(s.aux);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool is_null = x[j] >= s.aux_size;
+      if (is_null) *nulls |= 1u << j;
+      word[j] = dictionary[is_null ? 0u : x[j]];   // (a NULL-only chunk has an empty dictionary: the word is never used, the load stays inside the allocation's page)
+    }
+    if (s.aux_size == 0) *nulls = 0xFF;
+    return;
+  }
+  if (s.nulls) *nulls = as_global<uint8_t>(s.nulls)[row0 >> 3];
+  const uint32_t bias = s.encoding == HY_ENC_FRAME_OF_REFERENCE ? as_global<uint32_t>(s.aux)[row0 / HY_FOR_BLOCK_SIZE] : 0u;   // (eight aligned rows never straddle a 2048-row block)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) word[j] = x[j] + bias;
+}
+
 // Persistent two-pass kernel.  gridDim.x workgroups, all co-resident; workgroup b owns the CONTIGUOUS slice range
 // [b * per_wg, (b+1) * per_wg) of each round (a round = gridDim.x * per_wg slices; SF10 lineitem is one round).
 //   pass 1  stream the range once: 32-bit match mask per lane and slice -> LDS (1 KiB per slice) plus the match count
@@ -700,7 +736,31 @@ __device__ __forceinline__ void unpack_group(const RawGroup<W>& g, uint32_t (&x)
 // i.e. (chunk, row) ascending: bit-identical to the CPU loop's appends.
 __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slice& slice, const DevSegment& seg, uint32_t wave, uint32_t lane) {
   uint32_t mask = 0;       // bit (8k + j) <-> row  wave*2048 + k*512 + lane*8 + j  of the slice
-  if (a.right) {
+  const DevSegment right_seg = a.right ? a.right[slice.chunk] : DevSegment{};
+  if (a.right && seg.data_type == right_seg.data_type && four_byte_rows(seg) && four_byte_rows(right_seg) && (seg.aux_size || seg.encoding != HY_ENC_DICTIONARY) &&
+      (right_seg.aux_size || right_seg.encoding != HY_ENC_DICTIONARY)) {
+    // ColumnVsColumn, both sides 4-byte rows of one type: eight rows per lane and step, each side one wide load (+ the
+    // dictionary lookups); int32 against int32 and float against float compare like the reference's typed comparator
+    // (column_vs_column_table_scan_impl.cpp:169-184)
+    const bool is_float = seg.data_type == HY_TYPE_FLOAT;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+      if (r0 >= slice.row_count) continue;
+      const uint32_t valid = (slice.row_count - r0 < 8) ? slice.row_count - r0 : 8;
+      uint32_t left[8], right[8], left_nulls, right_nulls;
+      fetch_four_byte_rows(seg, slice.row_begin + r0, left, &left_nulls);
+      fetch_four_byte_rows(right_seg, slice.row_begin + r0, right, &right_nulls);
+      uint32_t bits = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool m = is_float ? compare<float>(a.condition, __uint_as_float(left[j]), __uint_as_float(right[j]))
+                                : compare<int32_t>(a.condition, static_cast<int32_t>(left[j]), static_cast<int32_t>(right[j]));
+        bits |= (m ? 1u : 0u) << j;
+      }
+      mask |= (bits & ~(left_nulls | right_nulls) & ((1u << valid) - 1u)) << (8 * k);
+    }
+  } else if (a.right) {
     // ColumnVsColumn: both sides decoded per row (no SIMD path in the reference either, abstract_table_scan_impl.hpp:61-66)
 #pragma unroll 1
     for (uint32_t k = 0; k < 4; ++k) {

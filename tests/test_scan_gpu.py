@@ -181,6 +181,44 @@ def test_column_vs_column(device):
                     assert_scan_equal(got, want, f"col-vs-col {right.dtype} lenc {lenc} renc {renc} cond {condition}")
 
 
+def test_column_vs_column_four_byte_rows(device):
+    """The wide path of ColumnVsColumn: int32 against int32 and float against float, every pair of encodings (FrameOfReference on
+    either side of the ints; 1-, 2- and 4-byte value ids), NULLs on either side, no NULLs at all, negative values, NaNs, chunk
+    sizes that are no multiple of eight, a NULL-only chunk."""
+    rng = np.random.default_rng(29)
+    n, chunk = 150_001, 20_003
+    nulls = [(None, None), (rng.random(n) < 0.1, None), (rng.random(n) < 0.05, rng.random(n) < 0.2)]
+    for spread in (10, 300, 100_000):      # dictionary sizes: u8, u16 and u32 value ids
+        left, right = rng.integers(-spread, spread, n).astype(np.int32), rng.integers(-spread, spread, n).astype(np.int32)
+        for lnull, rnull in nulls:
+            if lnull is not None:
+                lnull = lnull.copy()
+                lnull[chunk:2 * chunk] = True                                   # chunk 1 of the left column: only NULLs
+            for lenc in ENCODINGS:
+                for renc in ENCODINGS:
+                    lcol, rcol = build_column(left, lnull, chunk, lenc), build_column(right, rnull, chunk, renc)
+                    ldev, rdev = DeviceColumn(lcol), DeviceColumn(rcol)
+                    for condition in CONDITIONS[:6]:
+                        assert_scan_equal(table_scan_columns(ldev, rdev, condition), oracle_scan_columns(lcol, rcol, condition),
+                                          f"int32 spread {spread} lenc {lenc} renc {renc} cond {condition}")
+    lf = (rng.integers(-50, 50, n) * 0.25).astype(np.float32)
+    rf = (rng.integers(-50, 50, n) * 0.25).astype(np.float32)
+    rf[rng.random(n) < 0.01] = -0.0
+    with_nan = lf.copy()
+    with_nan[rng.random(n) < 0.01] = np.nan                                      # (dictionaries cannot hold NaNs: unencoded only)
+    lcol, rcol = build_column(with_nan, None, chunk, abi.ENC_UNENCODED), build_column(rf, nulls[1][0], chunk, abi.ENC_UNENCODED)
+    for condition in CONDITIONS[:6]:
+        assert_scan_equal(table_scan_columns(DeviceColumn(lcol), DeviceColumn(rcol), condition), oracle_scan_columns(lcol, rcol, condition), f"float NaN cond {condition}")
+    for lnull, rnull in nulls:
+        for lenc in (abi.ENC_UNENCODED, abi.ENC_DICTIONARY):
+            for renc in (abi.ENC_UNENCODED, abi.ENC_DICTIONARY):
+                lcol, rcol = build_column(lf, lnull, chunk, lenc), build_column(rf, rnull, chunk, renc)
+                ldev, rdev = DeviceColumn(lcol), DeviceColumn(rcol)
+                for condition in CONDITIONS[:6]:
+                    assert_scan_equal(table_scan_columns(ldev, rdev, condition), oracle_scan_columns(lcol, rcol, condition),
+                                      f"float lenc {lenc} renc {renc} cond {condition}")
+
+
 def test_excluded_chunks(device):
     rng = np.random.default_rng(17)
     values = rng.integers(0, 100, 50_000).astype(np.int32)
