@@ -362,7 +362,12 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   __syncthreads();
   if (s_spilled[1]) return;   // the table has too many groups for this kernel: the partitioned path takes over (every thread sees the same word)
 
-  const Slice slice = a.slices[blockIdx.x];
+  // Workgroup b runs on XCD b % 8, and every XCD has its own L2.  In slice order the eight slices of a chunk would land on
+  // eight XCDs and each would fetch the chunk's dictionaries (240 KB for l_extendedprice) for itself; instead, of every 64
+  // consecutive slices -- eight chunks of eight slices -- XCD x takes slices 8x .. 8x + 7: one chunk, one L2.
+  uint32_t slice_index = blockIdx.x;
+  if ((blockIdx.x | 63u) < gridDim.x) slice_index = (blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u);
+  const Slice slice = a.slices[slice_index];
   const uint64_t chunk_base = a.row_base[slice.chunk];
   uint64_t* stamps = a.trace ? a.trace + size_t{blockIdx.x} * 12 : nullptr;
   if (stamps && tid == 0) stamps[0] = wall_clock64();
