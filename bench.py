@@ -136,6 +136,17 @@ def committed_traffic(kind):
         return None
 
 
+_SF10 = []
+
+
+def sf10_tables():
+    """The synthetic TPC-H SF10 orders / lineitem columns, generated once per process (join, aggregate and Q6 legs share them)."""
+    from hyrise_amd import tpch
+    if not _SF10:
+        _SF10.append(tpch.TpchData(scale_factor=10.0, seed=42))
+    return _SF10[0]
+
+
 def timed_kernel(lib, torch, run, steps, every=1):
     """(seconds per call, kernel ms per timed launch): `run` repeated `steps` times after two warm-up calls."""
     from hyrise_amd import abi
@@ -184,7 +195,7 @@ def join_leg(lib, torch, dev, steps, with_cases, with_cpu):
     import numpy as np
     from hyrise_amd import abi, storage, tpch
     from hyrise_amd.storage import DeviceColumn
-    data = tpch.TpchData(scale_factor=10.0, seed=42)
+    data = sf10_tables()
     orders_host = storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED)
     lineitem_host = storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE)
     orders, lineitem = DeviceColumn(orders_host), DeviceColumn(lineitem_host)
@@ -249,7 +260,7 @@ def aggregate_leg(lib, torch, steps, with_cases, with_cpu):
     from hyrise_amd import abi, storage, tpch
     from hyrise_amd.operators import aggregate_hash
     from hyrise_amd.storage import DeviceColumn
-    data = tpch.TpchData(scale_factor=10.0, seed=42)
+    data = sf10_tables()
     n = data.n_lineitems
     groupby_host, measures_host, algorithmic = tpch.q1_core_columns(data)
     groupby = [DeviceColumn(c) for c in groupby_host]
@@ -297,6 +308,37 @@ def aggregate_leg(lib, torch, steps, with_cases, with_cpu):
         aggregates_host = spec(measures_host)
         info["cpu_baseline"] = cpu_baseline_aggregate(groupby_host, aggregates_host, n)
     return info
+
+
+def q6_leg(torch, dev, steps):
+    """configs[0]'s query on the GPU: TPC-H Q6 at SF10 as the reference plans it -- three TableScans chained through device-resident
+    PosLists (hy_table_scan -> hy_poslist_translate -> reference column), Projection l_extendedprice * l_discount, AggregateHash SUM
+    (hyrise_amd/tpch.py run_q6); checked against numpy on every run."""
+    import numpy as np
+    from hyrise_amd import tpch
+    from hyrise_amd.distributed import HipExecutor
+    from hyrise_amd.storage import DeviceColumn
+    data = sf10_tables()
+    host = tpch.q6_columns(data)
+    columns = {name: DeviceColumn(column) for name, column in host.items()}
+    ex = HipExecutor(dev)
+    revenue, qualifying = tpch.run_q6(ex, columns)
+    keep = (data.l_shipdate >= tpch.DAY_1994_01_01) & (data.l_shipdate < tpch.DAY_1995_01_01) & (data.l_discount >= np.float32(0.05)) & \
+           (data.l_discount <= np.float32(0.07)) & (data.l_quantity < 24)
+    exact = float((data.l_extendedprice[keep] * data.l_discount[keep]).astype(np.float64).sum())
+    if qualifying != int(keep.sum()) or abs(revenue - exact) > 1e-9 * exact:
+        raise SystemExit(f"Q6 on the device: {qualifying} rows / {revenue}, numpy says {int(keep.sum())} / {exact}")
+    steps = max(3, min(steps, 10))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tpch.run_q6(ex, columns)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    read = sum(s.size * s.width + s.aux_size * 4 for s in host["l_shipdate"].segments)                       # first scan: the whole attribute vector
+    return {"workload": "configs[0] on one GPU: TPC-H Q6, SF10 lineitem, scan -> scan -> scan -> projection -> aggregate over device-resident PosLists",
+            "ms_per_query": dt * 1e3, "lineitem_rows_per_s": data.n_lineitems / dt, "qualifying_rows": qualifying, "revenue": revenue,
+            "first_scan_bytes": read, "note": "every intermediate stays in HBM; 8 bytes (a match count) per scan cross to the host"}
 
 
 def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, width):
@@ -456,6 +498,8 @@ def main():
     join_info = join_leg(lib, torch, dev, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_join else None
     aggregate_info = aggregate_leg(lib, torch, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_aggregate else None
 
+    q6_info = q6_leg(torch, dev, args.steps) if single and not args.no_cases else None
+
     multi = None
     if world > 1 and not args.no_multi and not args.rows:
         from hyrise_amd import distributed
@@ -485,6 +529,8 @@ def main():
             line["join"] = join_info
         if aggregate_info:
             line["aggregate"] = aggregate_info
+        if q6_info:
+            line["q6"] = q6_info
         if multi:
             line["multi_gpu"] = multi
         if ssb_info:

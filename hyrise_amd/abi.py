@@ -27,6 +27,7 @@ INVALID_CHUNK_ID = 0xFFFFFFFF
 FOR_BLOCK_SIZE = 2048
 SCAN_MATERIALIZE_ALL_MATCH = 1
 SCAN_CHUNK_REGIONS = 2
+POSLIST_DENSE, POSLIST_CHUNK_REGIONS = 0, 1
 CHUNK_DEFAULT_SIZE = 65535  # Chunk::DEFAULT_SIZE, storage/chunk.hpp:52
 
 
@@ -118,7 +119,7 @@ SYMBOLS = [
     ("hy_validate", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ScanResult)]),
     ("hy_predicate_cast", C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Predicate)]),
     ("hy_join_output_chunks", C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
-    ("hy_poslist_translate", C.c_int32, [C.c_void_p, C.POINTER(ScanResult), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("hy_poslist_translate", C.c_int32, [C.c_void_p, C.POINTER(ScanResult), C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("hy_join_hash", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinResult)]),
     ("hy_join_hash_predicates", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinPredicate), C.c_uint32, C.POINTER(JoinResult)]),
     ("hy_join_hash_radix_bits", C.c_int32, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),

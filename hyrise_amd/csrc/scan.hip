@@ -776,7 +776,30 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
   } else if (seg.encoding == HY_ENC_REFERENCE) {
     uint32_t mode = JOB_SCAN;
     if (seg.ref_chunk_id != 0xFFFFFFFFu) mode = a.jobs[seg.ref_chunk_id].mode;
-    if (mode == JOB_SCAN || (mode == JOB_ALL && a.materialize_all)) {
+    if ((mode == JOB_SCAN || (mode == JOB_ALL && a.materialize_all)) && seg.ref_chunk_id != 0xFFFFFFFFu) {
+      // A PosList that references ONE chunk (what a first TableScan, a Validate or a join's write_output_chunks guarantee,
+      // abstract_dereferenced_column_table_scan_impl.cpp:38-46): the referenced segment and its job are the same for every row --
+      // scalar registers instead of two descriptor loads per row -- and only the offsets of the RowIDs are read.
+      const DevSegment base = seg.ref[seg.ref_chunk_id];
+      const ScanJob job = a.jobs[seg.ref_chunk_id];
+      const HY_GLOBAL uint32_t* words = as_global<uint32_t>(seg.data);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
+        uint32_t offset[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+          const uint32_t row = slice.row_begin + (r0 + j < slice.row_count ? r0 + j : 0);
+          offset[j] = words ? words[2 * size_t{row} + 1] : row;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+          if (r0 + j >= slice.row_count) continue;
+          const bool m = offset[j] == 0xFFFFFFFFu ? a.is_null_scan != 0 : eval_row(base, job, offset[j]);
+          if (m) mask |= 1u << (8 * k + j);
+        }
+      }
+    } else if (mode == JOB_SCAN || (mode == JOB_ALL && a.materialize_all)) {
 #pragma unroll 1
       for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
@@ -1300,10 +1323,10 @@ __global__ __launch_bounds__(256) void region_prefix(const uint32_t* __restrict_
 // references the data table and never a reference table.  blockIdx.x: chunk, blockIdx.y: quarter of its matches.
 __global__ __launch_bounds__(256) void translate_regions(const DevSegment* __restrict__ segments, const hy_row_id* __restrict__ regions, const uint64_t* __restrict__ region_offsets,
                                                          const uint32_t* __restrict__ counts, const uint64_t* __restrict__ dense_offsets, hy_row_id* __restrict__ out,
-                                                         uint64_t capacity) {
+                                                         uint64_t capacity, uint32_t keep_regions) {
   const uint32_t c = blockIdx.x;
   const uint32_t count = counts[c];
-  const uint64_t base = dense_offsets[c];
+  const uint64_t base = keep_regions ? region_offsets[c] : dense_offsets[c];
   if (base + count > capacity) return;   // the host reports HY_ERR_CAPACITY from the total
   const DevSegment seg = segments[c];
   const uint2* src = reinterpret_cast<const uint2*>(regions + region_offsets[c]);
@@ -1589,8 +1612,10 @@ hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, u
   return run_scan(left, right, nullptr, condition, nullptr, 0, result);
 }
 
-hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* result, hy_row_id* out, uint64_t capacity, uint64_t* n_out) {
+hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* result, uint32_t layout, hy_row_id* out, uint64_t capacity, uint64_t* n_out) {
   if (!scanned || !result || !n_out) return fail(HY_ERR_INVALID, "hy_poslist_translate: null argument");
+  if (layout != HY_POSLIST_DENSE && layout != HY_POSLIST_CHUNK_REGIONS) return fail(HY_ERR_INVALID, "hy_poslist_translate: unknown layout %u", layout);
+  if (layout == HY_POSLIST_CHUNK_REGIONS && capacity < scanned->rows) return fail(HY_ERR_CAPACITY, "hy_poslist_translate: chunk regions need capacity >= %llu rows", static_cast<unsigned long long>(scanned->rows));
   *n_out = 0;
   if (result->mem != HY_MEM_DEVICE) return fail(HY_ERR_INVALID, "hy_poslist_translate reads a device-memory scan result (host results are back to back already)");
   if (!(result->flags & HY_SCAN_CHUNK_REGIONS) || !(result->flags & HY_SCAN_MATERIALIZE_ALL_MATCH)) {
@@ -1607,13 +1632,13 @@ hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* r
   if (!d_dense_offsets) return fail(HY_ERR_DEVICE, "scratch arena exhausted");
   hipLaunchKernelGGL(region_prefix, dim3(1), dim3(256), 0, stream, result->counts, n_chunks, d_dense_offsets);
   hipLaunchKernelGGL(translate_regions, dim3(n_chunks, 4), dim3(256), 0, stream, scanned->d_segments, result->matches, result->offsets, result->counts, d_dense_offsets, out,
-                     capacity);
+                     capacity, layout == HY_POSLIST_CHUNK_REGIONS ? 1u : 0u);
   HY_HIP(hipGetLastError());
   uint64_t total = 0;
   HY_HIP(hipMemcpyAsync(&total, d_dense_offsets + n_chunks, 8, hipMemcpyDeviceToHost, stream));
   HY_HIP(hipStreamSynchronize(stream));
   *n_out = total;
-  if (total > capacity) return fail(HY_ERR_CAPACITY, "hy_poslist_translate: %llu RowIDs, capacity is %llu", static_cast<unsigned long long>(total), static_cast<unsigned long long>(capacity));
+  if (layout == HY_POSLIST_DENSE && total > capacity) return fail(HY_ERR_CAPACITY, "hy_poslist_translate: %llu RowIDs, capacity is %llu", static_cast<unsigned long long>(total), static_cast<unsigned long long>(capacity));
   return HY_OK;
 }
 

@@ -203,6 +203,61 @@ class DeviceReferenceColumn:
             pass
 
 
+_SEGMENT_DTYPE = np.dtype([("encoding", np.uint32), ("data_type", np.uint32), ("size", np.uint32), ("width", np.uint32), ("data", np.uint64), ("aux", np.uint64),
+                           ("aux_size", np.uint32), ("ref_chunk_id", np.uint32), ("nulls", np.uint64), ("ref", np.uint64)])
+assert _SEGMENT_DTYPE.itemsize == C.sizeof(abi.Segment)
+
+
+class DevicePosLists:
+    """A scan's output in the reference's shape: one PosList per input chunk, in device memory (`rows`: [input rows, 2] int32,
+    chunk c's PosList at rows[begin[c] : begin[c] + count[c]], RowIDs of the DATA table `base_chunk[c]` -- the one chunk it
+    references -- or mixed when base_chunk[c] is INVALID_CHUNK_ID).  The counts are the only thing the host knows of it."""
+
+    def __init__(self, rows, begin, count, base_chunk):
+        self.rows, self.begin, self.count, self.base_chunk = rows, begin, count, base_chunk
+        self.total = int(count.sum())
+
+
+class DeviceChunkedReferenceColumn:
+    """Column `base` seen through DevicePosLists: one ReferenceSegment per non-empty PosList, read in place (HY_MEM_DEVICE), each
+    with the single-chunk guarantee the PosLists carry (ReferenceSegment + RowIDPosList::guarantee_single_chunk)."""
+
+    def __init__(self, lib, base, pos_lists):
+        self.lib, self.base, self.data_type, self.pos = lib, base, base.data_type, pos_lists
+        keep = np.flatnonzero(pos_lists.count)
+        self.chunk_of_segment = keep                      # output chunk k <- input chunk keep[k]
+        self.rows = pos_lists.total
+        self.n_chunks = max(1, len(keep))
+        # the hy_segment array, filled column-wise (one ctypes store per field and chunk costs more than the scan itself)
+        table = np.zeros(self.n_chunks, dtype=_SEGMENT_DTYPE)
+        table["encoding"], table["data_type"], table["width"] = abi.ENC_REFERENCE, base.data_type, 8
+        table["ref"] = base.handle.value if isinstance(base.handle, C.c_void_p) else int(base.handle)
+        if len(keep) == 0:   # an empty table still has a type: one empty chunk
+            self._empty = pos_lists.rows.new_zeros((1, 2))
+            table["data"], table["ref_chunk_id"] = self._empty.data_ptr(), abi.INVALID_CHUNK_ID
+        else:
+            table["size"] = pos_lists.count[keep]
+            table["data"] = pos_lists.rows.data_ptr() + pos_lists.begin[keep].astype(np.uint64) * 8
+            table["ref_chunk_id"] = pos_lists.base_chunk[keep]
+        segments = table.ctypes.data_as(C.POINTER(abi.Segment))
+        self._table = table
+        self._segments = segments
+        handle = C.c_void_p()
+        abi.check(lib.hy_column_create(segments, self.n_chunks, abi.MEM_DEVICE, C.byref(handle)))
+        self.handle = handle
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hy_column_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipExecutor:
     """Everything a rank computes, through libhyrise_amd.so on its GPU.  Columns are DeviceColumn / DeviceValueColumn /
     DeviceReferenceColumn / operators.ResultColumn."""
@@ -231,11 +286,8 @@ class HipExecutor:
                 raise
         return aggregate_hash(groupby, aggregates, group_capacity=shape.rows + 1)
 
-    def scan(self, column, predicate):
-        """RowIDs of the matching rows as ONE flat device PosList that references the DATA table: hy_table_scan writes its
-        chunk regions to device memory, hy_poslist_translate packs them and -- when `column` is a reference column, i.e. the
-        output of an earlier scan or join -- replaces each match by the RowID it stands for (table_scan.cpp:158-196).  Eight
-        bytes (the match count) cross to the host; no PosList does."""
+    def _device_scan(self, column, predicate, layout):
+        """hy_table_scan into device memory + hy_poslist_translate -> (RowID tensor, per-chunk region begins, counts tensor, total)"""
         torch = self.torch
         rows, n_chunks = max(1, column.rows), column.n_chunks
         regions = torch.empty((rows, 2), dtype=torch.int32, device=self.device)
@@ -248,8 +300,33 @@ class HipExecutor:
         abi.check(self.lib.hy_table_scan(column.handle, C.byref(predicate), None, 0, C.byref(result)))
         out = torch.empty((rows, 2), dtype=torch.int32, device=self.device)
         written = C.c_uint64(0)
-        abi.check(self.lib.hy_poslist_translate(column.handle, C.byref(result), out.data_ptr(), rows, C.byref(written)))
-        return out[:int(written.value)]
+        abi.check(self.lib.hy_poslist_translate(column.handle, C.byref(result), layout, out.data_ptr(), rows, C.byref(written)))
+        return out, offsets, counts, int(written.value)
+
+    def scan(self, column, predicate):
+        """RowIDs of the matching rows as ONE flat device PosList that references the DATA table: hy_table_scan writes its
+        chunk regions to device memory, hy_poslist_translate packs them and -- when `column` is a reference column, i.e. the
+        output of an earlier scan or join -- replaces each match by the RowID it stands for (table_scan.cpp:158-196).  Eight
+        bytes (the match count) cross to the host; no PosList does."""
+        out, _, _, total = self._device_scan(column, predicate, abi.POSLIST_DENSE)
+        return out[:total]
+
+    def scan_chunked(self, column, predicate):
+        """The same scan with the reference's output shape kept: one PosList per input chunk (DevicePosLists), each still
+        referencing the one data chunk its input chunk referenced.  The per-chunk counts (4 bytes per chunk) cross to the host."""
+        out, offsets, counts, _ = self._device_scan(column, predicate, abi.POSLIST_CHUNK_REGIONS)
+        begin = offsets[:column.n_chunks].cpu().numpy()
+        count = counts[:column.n_chunks].cpu().numpy().astype(np.int64)
+        if isinstance(column, DeviceChunkedReferenceColumn):
+            base_chunk = column.pos.base_chunk[column.chunk_of_segment] if len(column.chunk_of_segment) else np.full(column.n_chunks, abi.INVALID_CHUNK_ID, dtype=np.int64)
+        elif isinstance(column, DeviceReferenceColumn):
+            base_chunk = np.full(column.n_chunks, abi.INVALID_CHUNK_ID, dtype=np.int64)
+        else:
+            base_chunk = np.arange(column.n_chunks, dtype=np.int64)                # a data table: chunk c's matches are rows of chunk c
+        return DevicePosLists(out, begin, count, base_chunk)
+
+    def reference_column_chunked(self, base, pos_lists):
+        return DeviceChunkedReferenceColumn(self.lib, base, pos_lists)
 
     def reference_column(self, base, rows, chunk_rows):
         return DeviceReferenceColumn(self.lib, base, rows, chunk_rows)

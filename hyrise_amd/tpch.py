@@ -131,7 +131,6 @@ def q1_core_columns(data, chunk_size=abi.CHUNK_DEFAULT_SIZE):
 # ---- TPC-H Q6 as an operator chain (configs[0]: the reference's own CPU-runnable case) -------------------------------------
 Q6_SQL = ("SELECT SUM(l_extendedprice * l_discount) AS revenue, COUNT(*) FROM lineitem WHERE l_shipdate >= :from AND l_shipdate < :to "
           "AND l_discount BETWEEN :low AND :high AND l_quantity < :quantity")
-RESULT_CHUNK = 65535   # operator results are presented to the next operator as tables of this chunk size
 
 
 def q6_columns(data, chunk_size=abi.CHUNK_DEFAULT_SIZE):
@@ -150,13 +149,14 @@ def run_q6(ex, columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discou
     intermediate -- PosLists, the product column -- stays in device memory) or the tests' oracle executor.
     -> (revenue, qualifying rows)"""
     from .operators import make_predicate
-    rows = ex.scan(columns["l_shipdate"], make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, date_from, date_to))
-    rows = ex.scan(ex.reference_column(columns["l_discount"], rows, RESULT_CHUNK),
-                   make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, np.float32(discount[0]), np.float32(discount[1])))
-    rows = ex.scan(ex.reference_column(columns["l_quantity"], rows, RESULT_CHUNK), make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, quantity))
-    if rows.shape[0] == 0:
+    # the scans keep the reference's output shape -- one PosList per input chunk, each referencing one data chunk -- so the
+    # second and third scan take the single-chunk path of AbstractDereferencedColumnTableScanImpl (:38-46)
+    lists = ex.scan_chunked(columns["l_shipdate"], make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, date_from, date_to))
+    lists = ex.scan_chunked(ex.reference_column_chunked(columns["l_discount"], lists),
+                            make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, np.float32(discount[0]), np.float32(discount[1])))
+    lists = ex.scan_chunked(ex.reference_column_chunked(columns["l_quantity"], lists), make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, quantity))
+    if lists.total == 0:
         return None, 0        # SUM over no rows is NULL
-    revenue = ex.projection(abi.ARITH_MUL, ex.reference_column(columns["l_extendedprice"], rows, RESULT_CHUNK),
-                            ex.reference_column(columns["l_discount"], rows, RESULT_CHUNK))
+    revenue = ex.projection(abi.ARITH_MUL, ex.reference_column_chunked(columns["l_extendedprice"], lists), ex.reference_column_chunked(columns["l_discount"], lists))
     result = ex.aggregate([], [(abi.AGG_SUM, revenue), (abi.AGG_COUNT, None)])
     return result.column(0)[0], result.column(1)[0]

@@ -246,16 +246,21 @@ hy_status hy_validate(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot
 hy_status hy_predicate_cast(uint32_t condition, uint32_t column_type, uint32_t literal_type, const hy_value* literal, uint32_t literal2_type,
                             const hy_value* literal2, hy_predicate* out);
 
-/* The PosList a scan hands to the next operator, WITHOUT leaving device memory (replaces the output assembly of
+/* The PosLists a scan hands to the next operator, WITHOUT leaving device memory (replaces the output assembly of
  * TableScan::_on_execute, table_scan.cpp:158-196: the matches of a scan over ReferenceSegments are translated through the
  * input PosList, so the output always references the data table, never another reference table).
  * `result`: a HY_MEM_DEVICE result of hy_table_scan / hy_table_scan_columns / hy_validate over `scanned`, produced with
- * HY_SCAN_CHUNK_REGIONS | HY_SCAN_MATERIALIZE_ALL_MATCH.  Writes ONE back-to-back PosList to `out` (device memory, room for
- * `capacity` RowIDs): the chunks' matches in chunk order; over a reference column a match (c, o) is replaced by the RowID at
- * position o of chunk c's PosList ((ref_chunk_id, o) for an entire-chunk PosList), NULL RowIDs included as they are.
- * *n_out (host): RowIDs written -- the one value that crosses to the host (8 bytes; the call waits for the stream).
- * HY_ERR_CAPACITY with *n_out = the needed capacity if `out` is too small. */
-hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* result, hy_row_id* out, uint64_t capacity, uint64_t* n_out);
+ * HY_SCAN_CHUNK_REGIONS | HY_SCAN_MATERIALIZE_ALL_MATCH.  Over a reference column a match (c, o) is replaced by the RowID at
+ * position o of chunk c's PosList ((ref_chunk_id, o) for an entire-chunk PosList), NULL RowIDs included as they are; over a
+ * data column the RowIDs are copied.  `out` is device memory with room for `capacity` RowIDs:
+ *   HY_POSLIST_DENSE          ONE back-to-back PosList, the chunks' matches in chunk order.  HY_ERR_CAPACITY with *n_out = the
+ *                             needed capacity if `out` is too small.
+ *   HY_POSLIST_CHUNK_REGIONS  one PosList per input chunk, chunk c's at out + result->offsets[c] (result->counts[c] RowIDs): the
+ *                             reference's output shape -- an output chunk per input chunk, and a PosList that referenced one
+ *                             chunk still does (guarantee_single_chunk, table_scan.cpp:176-178).  capacity >= the column's rows.
+ * *n_out (host): RowIDs written in total -- the one value that crosses to the host (8 bytes; the call waits for the stream). */
+enum { HY_POSLIST_DENSE = 0, HY_POSLIST_CHUNK_REGIONS = 1 };
+hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* result, uint32_t layout, hy_row_id* out, uint64_t capacity, uint64_t* n_out);
 
 /* ---- Projection arithmetic (the ArithmeticExpressions a Projection evaluates through the
  * ExpressionEvaluator, operators/projection.cpp + expression/evaluation/expression_functors.hpp:127-213) -------------------

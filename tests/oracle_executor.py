@@ -9,6 +9,12 @@ from support import build_column, column_values, oracle_aggregate, oracle_join
 _NP = {abi.TYPE_INT: np.int32, abi.TYPE_LONG: np.int64, abi.TYPE_FLOAT: np.float32, abi.TYPE_DOUBLE: np.float64}
 
 
+class _HostPosLists:
+    def __init__(self, lists, base_chunk):
+        self.lists, self.base_chunk = lists, base_chunk
+        self.total = sum(len(rows) for rows in lists)
+
+
 class OracleExecutor:
     def column(self, host_column):
         return host_column
@@ -28,6 +34,30 @@ class OracleExecutor:
             pos = np.concatenate([np.asarray(s.data).reshape(-1, 2) for s in column.segments]) if column.rows else matches[:0]
             matches = pos[begins[matches[:, 0]] + matches[:, 1]].astype(np.uint32)
         return torch.from_numpy(np.ascontiguousarray(matches).view(np.int32).copy())
+
+    def scan_chunked(self, column, predicate):
+        """-> per input chunk the matching RowIDs of the DATA table (host arrays) + the one data chunk each list references"""
+        from support import oracle_scan
+        result = oracle_scan(column, predicate, flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
+        lists, base_chunk = [], []
+        for c, segment in enumerate(column.segments):
+            matches = result.pos_list(c).copy()
+            if segment.encoding == abi.ENC_REFERENCE:
+                matches = np.asarray(segment.data, dtype=np.uint32).reshape(-1, 2)[matches[:, 1]] if segment.data is not None else \
+                    np.stack([np.full(len(matches), segment.ref_chunk_id, dtype=np.uint32), matches[:, 1]], axis=1)
+                base_chunk.append(segment.ref_chunk_id)
+            else:
+                base_chunk.append(c)
+            lists.append(matches)
+        return _HostPosLists(lists, base_chunk)
+
+    def reference_column_chunked(self, base, pos_lists):
+        from hyrise_amd import storage
+        keep = [c for c, rows in enumerate(pos_lists.lists) if len(rows)]
+        if not keep:
+            return storage.make_reference_column(base, [np.zeros((0, 2), dtype=np.uint32)], [None])
+        return storage.make_reference_column(base, [pos_lists.lists[c] for c in keep],
+                                             [None if pos_lists.base_chunk[c] == abi.INVALID_CHUNK_ID else pos_lists.base_chunk[c] for c in keep])
 
     def reference_column(self, base, rows, chunk_rows):
         from hyrise_amd import storage

@@ -92,26 +92,32 @@ def test_tpch_q6_pipeline_stays_on_device(device, monkeypatch):
     columns = {name: DeviceColumn(column) for name, column in tpch.q6_columns(data, chunk_size=20_000).items()}
     ex = HipExecutor(torch.device("cuda", 0))
     handed_on = []
-    real_reference_column = ex.reference_column
+    real_reference_column = ex.reference_column_chunked
 
-    def reference_column(base, rows, chunk_rows):
-        handed_on.append(rows)
-        return real_reference_column(base, rows, chunk_rows)
+    def reference_column(base, pos_lists):
+        handed_on.append(pos_lists)
+        return real_reference_column(base, pos_lists)
 
     def forbidden(*args, **kwargs):
         raise AssertionError("a PosList was read on the host")
 
-    monkeypatch.setattr(ex, "reference_column", reference_column)
+    monkeypatch.setattr(ex, "reference_column_chunked", reference_column)
     monkeypatch.setattr(operators.HostScanResult, "__init__", forbidden)      # no host-memory scan result may even be created
     monkeypatch.setattr(operators.HostScanResult, "pos_list", forbidden)
     revenue, qualifying = tpch.run_q6(ex, columns)
     monkeypatch.undo()
-    assert len(handed_on) == 4 and all(rows.is_cuda and rows.dtype == torch.int32 for rows in handed_on)
+    assert len(handed_on) == 4 and all(lists.rows.is_cuda and lists.rows.dtype == torch.int32 for lists in handed_on)
     keep = (data.l_shipdate >= tpch.DAY_1994_01_01) & (data.l_shipdate < tpch.DAY_1995_01_01) & (data.l_discount >= np.float32(0.05)) & \
            (data.l_discount <= np.float32(0.07)) & (data.l_quantity < 24)
-    # the last PosList is exactly the qualifying rows, in table order, as RowIDs of the DATA table
-    final = handed_on[-1].cpu().numpy().view(np.uint32)
+    # the last PosLists are exactly the qualifying rows, chunk by chunk in table order, as RowIDs of the DATA table -- and every
+    # list still references the one chunk it came from
+    last = handed_on[-1]
+    everything = last.rows.cpu().numpy().view(np.uint32)
+    final = np.concatenate([everything[int(b):int(b) + int(n)] for b, n in zip(last.begin, last.count)])
     np.testing.assert_array_equal(final[:, 0].astype(np.int64) * 20_000 + final[:, 1], np.flatnonzero(keep))
+    assert last.base_chunk.tolist() == list(range(len(last.count)))
+    for c, (b, n) in enumerate(zip(last.begin, last.count)):
+        assert (everything[int(b):int(b) + int(n), 0] == c).all()
     products = data.l_extendedprice[keep] * data.l_discount[keep]            # float32 products, like the reference
     assert qualifying == int(keep.sum()) > 100
     assert abs(revenue - float(products.astype(np.float64).sum())) <= 1e-9 * abs(float(products.astype(np.float64).sum()))

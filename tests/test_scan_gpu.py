@@ -325,8 +325,9 @@ def test_run_length_segments(device):
     assert sums.n_groups == expected.n_groups and sums.column(0) == expected.column(0) and sums.column(1) == expected.column(1)
 
 
-def device_pos_list(lib, host_column, device_column, predicate):
-    """hy_table_scan into device memory + hy_poslist_translate: the PosList the next operator reads, copied back for the check."""
+def device_pos_list(lib, host_column, device_column, predicate, layout=abi.POSLIST_DENSE):
+    """hy_table_scan into device memory + hy_poslist_translate: the PosList the next operator reads, copied back for the check
+    (HY_POSLIST_CHUNK_REGIONS: the filled prefixes of the chunk regions, concatenated)."""
     rows, n_chunks = max(1, host_column.rows), host_column.n_chunks
     regions, offsets, counts = DeviceArray(lib, (rows, 2), np.uint32), DeviceArray(lib, (n_chunks + 1,), np.int64), DeviceArray(lib, (max(1, n_chunks),), np.int32)
     result = abi.ScanResult()
@@ -335,8 +336,13 @@ def device_pos_list(lib, host_column, device_column, predicate):
     abi.check(lib.hy_table_scan(device_column.handle, C.byref(predicate), None, 0, C.byref(result)))
     out = DeviceArray(lib, (rows, 2), np.uint32)
     written = C.c_uint64(0)
-    abi.check(lib.hy_poslist_translate(device_column.handle, C.byref(result), out.pointer, rows, C.byref(written)))
+    abi.check(lib.hy_poslist_translate(device_column.handle, C.byref(result), layout, out.pointer, rows, C.byref(written)))
     result._keep = (regions, offsets, counts)   # the device buffers live as long as the struct that points at them
+    if layout == abi.POSLIST_CHUNK_REGIONS:
+        begin, count, everything = offsets.numpy(), counts.numpy(), out.numpy()
+        parts = [everything[int(begin[c]):int(begin[c]) + int(count[c])] for c in range(n_chunks)]
+        assert sum(len(part) for part in parts) == written.value
+        return (np.concatenate(parts) if parts else everything[:0]), result
     return out.numpy()[:written.value], result
 
 
@@ -380,17 +386,20 @@ def test_poslist_translate(device):
                           (many_host, DeviceColumn(many_host, refs={id(base): base_dev}))):
             for condition in (abi.PRED_EQUALS, abi.PRED_LESS_THAN, abi.PRED_BETWEEN_INCLUSIVE, abi.PRED_IS_NULL, abi.PRED_IS_NOT_NULL):
                 p = make_predicate(condition, abi.TYPE_INT, 100, 400, nullable=True)
-                got, _ = device_pos_list(device, host, dev, p)
                 want = expected_pos_list(host, p)
-                assert got.tobytes() == want.tobytes(), f"enc {encoding} cond {condition}"
+                for layout in (abi.POSLIST_DENSE, abi.POSLIST_CHUNK_REGIONS):
+                    got, _ = device_pos_list(device, host, dev, p, layout)
+                    assert got.tobytes() == want.tobytes(), f"enc {encoding} cond {condition} layout {layout}"
     # too small an output buffer: the needed capacity comes back with HY_ERR_CAPACITY
     p = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 500, nullable=True)
     full, result = device_pos_list(device, base, base_dev, p)
     small = DeviceArray(device, (16, 2), np.uint32)
     written = C.c_uint64(0)
-    assert device.hy_poslist_translate(base_dev.handle, C.byref(result), small.pointer, 16, C.byref(written)) == abi.ERR_CAPACITY
+    assert device.hy_poslist_translate(base_dev.handle, C.byref(result), abi.POSLIST_DENSE, small.pointer, 16, C.byref(written)) == abi.ERR_CAPACITY
     assert written.value == len(full) > 16
+    assert device.hy_poslist_translate(base_dev.handle, C.byref(result), abi.POSLIST_CHUNK_REGIONS, small.pointer, 16, C.byref(written)) == abi.ERR_CAPACITY
+    assert device.hy_poslist_translate(base_dev.handle, C.byref(result), 7, small.pointer, 16, C.byref(written)) == abi.ERR_INVALID
     # a host-memory result is refused
     host_result = abi.ScanResult()
     host_result.mem = abi.MEM_HOST
-    assert device.hy_poslist_translate(base_dev.handle, C.byref(host_result), small.pointer, 16, C.byref(written)) == abi.ERR_INVALID
+    assert device.hy_poslist_translate(base_dev.handle, C.byref(host_result), abi.POSLIST_DENSE, small.pointer, 16, C.byref(written)) == abi.ERR_INVALID
