@@ -1,27 +1,36 @@
-// join.hip -- JoinHash on MI355X: equi-joins of int32/int64 columns, all JoinHash modes except secondary predicates.
+// join.hip -- JoinHash on MI355X: equi-joins of numeric columns (int32 / int64 / float / double, any two), all JoinHash modes,
+// up to four secondary predicates.
 //
 // What it replaces (reference, CPU):
 //   JoinHash::_on_execute / JoinHashImpl::_on_execute                 operators/join_hash.cpp:116-225, 270-572
 //   materialize_input / partition_by_radix / build / probe(_semi_anti) operators/join_hash/join_hash_steps.hpp:274-922
 //
 // The reference's output order is fully determined by its algorithm: pairs come radix partition by radix partition
-// (low `radix_bits` bits of the key; `radix_bits` == 0: probe chunk by probe chunk), inside a partition by probe row,
-// inside a probe row by build row (hash-table insertion order == (chunk, row) order), and every 131 070 materialised
+// (low `radix_bits` bits of the key's std::hash; `radix_bits` == 0: probe chunk by probe chunk), inside a partition by probe
+// row, inside a probe row by build row (hash-table insertion order == (chunk, row) order), and every 131 070 materialised
 // probe elements of a partition start a new output PosList.  The device code produces exactly that order without
-// materialising the partitions themselves:
-//   build side   materialise (key, RowID) in row order (count / write passes with ballot compaction), radix-sort it
-//                by key only if it is not already sorted (a primary-key column usually is), and lay an
-//                order-preserving bucket directory over the sorted keys: bucket = (key - min) >> shift, open-ended
-//                runs inside a bucket are resolved by a short binary search.  Equal keys are adjacent in build-row
-//                order, so a probe hit is just (start, count) into the sorted RowID array.
-//   probe side   two passes over the (still encoded) probe column, 2048-row tiles:
-//                1. histogram: per tile and partition, the number of materialised probe elements and of output pairs
-//                2. scatter: exclusive prefix sums of those histograms give every (partition, tile) its output range;
-//                   inside a tile a wave-level match-any ranking (ballots over the radix bits) keeps the order stable,
-//                   and every lane writes its pairs straight to their final positions.
-// HBM traffic: build keys + 2 x probe keys + 16 B per pair (+ the small histograms); no 12-byte PartitionedElement
-// arrays are ever written.  The Bloom filters of the reference are reproduced only where they are observable: the
-// build side's filter decides which probe elements count as "materialised" (it shifts the 131 070-element cuts).
+// materialising the partitions themselves.  Two build-side structures, chosen per join (prepare_build):
+//   rank table   unique integer build keys whose range is at most ~64 x their number (a primary key, dense or dbgen-sparse):
+//                one 8-byte entry {32 presence bits, rank of the word's first key} per 32 key values; a lookup is ONE dependent
+//                load, the partner's rank = base + popcount(bits below the key).  A dense, sorted build column of equal-sized
+//                chunks is read in place (dense_key_stats, rank_table_fill_dense: no key or RowID arrays at all) and the rank IS
+//                the row number; unsorted unique keys mark their bits with atomicOr (a bit that was already set = a
+//                duplicate -> fall back), block sums turn into bases, and a rank -> row array is scattered.
+//   directory    everything else (duplicate keys, sparse keys, float / double keys, secondary predicates): (key, RowID) in row
+//                order, an 8-bit LSD radix sort by key only if the keys are not already sorted, and an order-preserving
+//                bucket directory (key - min) >> shift over the sorted keys; equal keys are adjacent in build-row order, a
+//                probe hit is (start, count).
+// Probe side, two passes over the (still encoded) probe column in 4096-row tiles:
+//   1. count     per (tile, partition): materialised probe elements and output pairs (rt_stream_count: one wave per tile,
+//                16-byte loads; rt_probe_count / probe_count: one workgroup per tile for the general decoders)
+//      scans + plan_output (capacity check, PosList plan -- on the device) + probe_cuts (the 131 070-element cuts)
+//   2. emit      every (partition, tile) cell has its output range; rt_probe_emit re-evaluates the tile's rows (nothing is
+//                handed over from pass 1), ranks the pairs of a partition inside the tile (one returning LDS atomic per
+//                match-any group of a wave), stages them partition by partition in LDS and writes contiguous runs with
+//                16-byte nontemporal stores.  Tiles with multi-partner rows take probe_emit_generic.
+// HBM traffic at config 3: build keys (twice: statistics, fill) + 2 x probe keys + 16 B per pair + the rank table; no
+// 12-byte PartitionedElement arrays are ever written.  The Bloom filters of the reference are reproduced only where they are
+// observable: the build side's filter decides which probe elements count as "materialised" (it shifts the cuts).
 #include "hy_device.hpp"
 #include "hy_decode.hpp"
 

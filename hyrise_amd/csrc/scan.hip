@@ -720,20 +720,19 @@ __device__ __forceinline__ void fetch_four_byte_rows(const DevSegment& s, uint32
   for (int j = 0; j < 8; ++j) word[j] = x[j] + bias;
 }
 
-// Persistent two-pass kernel.  gridDim.x workgroups, all co-resident; workgroup b owns the CONTIGUOUS slice range
-// [b * per_wg, (b+1) * per_wg) of each round (a round = gridDim.x * per_wg slices; SF10 lineitem is one round).
-//   pass 1  stream the range once: 32-bit match mask per lane and slice -> LDS (1 KiB per slice) plus the match count
-//           of every (slice, wave).  In the streaming instantiations (W = 1/2/4: every segment of the column is a
-//           W-byte attribute vector / FoR offset vector / int32 value vector) the loads of slice s+1 are issued before
-//           slice s is evaluated, so every lane keeps 8 x 16 B in flight.
-//   exchange  publish the workgroup total as ONE epoch-tagged 8-byte word (agent-scope relaxed atomic: the word is the
-//           flag, no fence), then all 256 threads read the totals of the workgroups before it in parallel -- one
-//           L2 round trip instead of a serial look-back chain -- and reduce them to the global output offset
-//   pass 2  barrier-free: wave w owns rows [w*2048, (w+1)*2048) of every slice, i.e. a contiguous piece of the
-//           output; it derives its output offset from the (slice, wave) counts, expands its masks with one packed
-//           prefix sum, compacts row numbers through its private 4 KiB of LDS and writes coalesced 8-byte RowIDs.
-// The column is read from HBM exactly once and every RowID is written exactly once.  Output order is slice order,
-// i.e. (chunk, row) ascending: bit-identical to the CPU loop's appends.
+// scan_slices (below): persistent grid, one workgroup per PART (<= 8 slices of one chunk; a Hyrise chunk is one part), ONE fused
+// pass per 8192-row slice:
+//   evaluate  32-bit match mask per lane (rows wave*2048 + k*512 + lane*8 + j).  Streaming instantiations (W = 1 / 2 / 4: every
+//             segment of the column is a W-byte attribute vector / FoR offset vector / int32 value vector): the 16-byte loads of
+//             the next slice -- also across parts -- are issued before this slice is evaluated.  W = 0 (evaluate_slice): every
+//             other shape -- ColumnVsColumn, reference segments, 8-byte values, LIKE bitmaps, MVCC visibility.
+//   count     masks transposed inside the wave so that a lane holds 32 consecutive rows, one DPP prefix scan, the four wave
+//             totals meet in LDS (the only workgroup barrier per slice)
+//   emit      each wave compacts its row numbers through private LDS and writes RowID pairs with line-aligned nontemporal
+//             16-byte stores at the running offset of the chunk's region.
+// The column is read from HBM exactly once and every RowID is written exactly once.  Output order is (chunk, row) ascending:
+// bit-identical to the CPU loop's appends.  Chunks of more than one part chain their parts through one epoch-tagged status
+// word per part.
 __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slice& slice, const DevSegment& seg, uint32_t wave, uint32_t lane) {
   uint32_t mask = 0;       // bit (8k + j) <-> row  wave*2048 + k*512 + lane*8 + j  of the slice
   const DevSegment right_seg = a.right ? a.right[slice.chunk] : DevSegment{};
