@@ -995,6 +995,7 @@ struct ProbeArgs {
   uint64_t* trace;                // debug (HY_JOIN_TRACE): 6 wall-clock stamps per probe_emit tile, else nullptr
   uint32_t pack_build_ids;        // dir.ids32 exists: probe_emit_cached stages the partner's packed RowID, not its position
   uint32_t hashed_type;           // 0: integer keys | HY_TYPE_FLOAT | HY_TYPE_DOUBLE (join_hash); only the <true> instantiations look at it
+  uint32_t lane_ordered_atomics;  // rt_probe_emit: a returning LDS atomic hands the lanes of one instruction their values in lane order (probed once per process)
 };
 
 // Output pairs of one probe row per join mode (probe / probe_semi_anti, join_hash_steps.hpp:575-922).
@@ -1741,6 +1742,42 @@ __host__ __device__ constexpr size_t rt_probe_emit_lds_words(uint32_t partitions
 // aligned 16-byte store, partition p's run starts at a staging slot of the parity of its first global pair index -- every
 // non-empty partition reserves one spare slot for that, marked invalid.
 constexpr uint32_t STAGE_INVALID = 0xFFFFFFFFu;
+// Does a returning LDS atomic hand the lanes of one instruction their values in lane order?  Eight waves at once, four address
+// patterns each (one counter; two interleaved; 128 counters hit in runs of one to seven lanes like sorted foreign keys; a
+// pseudo-random spread), several rounds on the same counters: every lane compares what it got with the count of equal
+// addresses in lower lanes + earlier rounds.  failures[0] counts mismatches.
+__global__ __launch_bounds__(512) void lds_atomic_order_probe(uint32_t* failures, uint32_t seed) {
+  __shared__ uint32_t s_counter[8][128];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < 8 * 128; i += 512) (&s_counter[0][0])[i] = 0;
+  __syncthreads();
+  uint32_t wrong = 0;
+  for (uint32_t pattern = 0; pattern < 4; ++pattern) {
+    uint32_t seen[4] = {0, 0, 0, 0};   // this lane's address was hit this often by all lanes in earlier rounds (tracked per round below)
+    for (uint32_t round = 0; round < 4; ++round) {
+      uint32_t address;
+      if (pattern == 0) address = 0;
+      else if (pattern == 1) address = lane & 1;
+      else if (pattern == 2) address = ((lane + round * 64 + seed) / (1 + (seed + blockIdx.x) % 7)) & 127;
+      else address = ((lane * 2654435761u + round * 40503u + seed * 97u + blockIdx.x) >> 7) & 127;
+      const bool take = pattern < 2 || ((lane * 7 + round + seed) % 5) != 0;   // some lanes sit a round out
+      const uint64_t peers = match_any8(address, take);
+      const uint32_t lower = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(peers >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(peers), 0u));
+      // what the counter held before this instruction: read it back through the group's lowest lane after the fact
+      uint32_t got = 0;
+      if (take) got = atomicAdd(&s_counter[wave][address], 1u);
+      const uint32_t leader = take ? static_cast<uint32_t>(__ffsll(static_cast<long long>(peers))) - 1u : lane;
+      const uint32_t base = __shfl(got, static_cast<int>(leader), 64);      // the lowest lane must have seen the counter's old value ...
+      if (take && got != base + lower) ++wrong;                              // ... and every lane old value + equal addresses below it
+      (void)seen;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 8 * 128; i += 512) (&s_counter[0][0])[i] = 0;
+    __syncthreads();
+  }
+  if (wrong) atomicAdd(failures, wrong);
+}
+
 __global__ __launch_bounds__(JOIN_THREADS) void rt_probe_emit(ProbeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
   const uint32_t partitions = 1u << a.radix_bits;
@@ -1774,23 +1811,39 @@ __global__ __launch_bounds__(JOIN_THREADS) void rt_probe_emit(ProbeArgs a) {
     if (lane == 63) s_scratch[wave] = inclusive;
   }
   __syncthreads();   // the counters are zero
-  // (b) rank inside the wave, four rounds at a time (their atomics in flight together); the rank moves into meta[k] bits 11..
+  // (b) rank inside the wave; the rank moves into meta[k] bits 11..
+  if (a.lane_ordered_atomics) {
+    // One returning LDS atomic per pair: the LDS serves the lanes of one instruction that hit the same counter in lane order
+    // (and a wave's LDS instructions in program order), so the value a lane gets back is the number of pairs of its partition in
+    // lower lanes and earlier rounds -- its rank.  (Not an architectural promise: lds_atomic_order_probe checks it on the device
+    // the process runs on; where it does not hold, the match-any ranking below runs.)  All rounds' atomics are in flight together.
+    uint32_t before[JOIN_ROUNDS];
 #pragma unroll
-  for (uint32_t half = 0; half < JOIN_ROUNDS; half += 4) {
-    uint32_t before[4], who[4];   // who: leader lane | pairs in lower lanes << 8
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t k = half + j;
-      const uint32_t partition = meta[k] & 0xFF;
-      const bool emit = (meta[k] >> 10) != 0;
-      const uint64_t peers = match_any8(partition, emit);
-      const uint32_t leader = emit ? static_cast<uint32_t>(__ffsll(static_cast<long long>(peers))) - 1u : lane;
-      who[j] = leader | __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(peers >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(peers), 0u)) << 8;
-      before[j] = 0;
-      if (emit && leader == lane) before[j] = atomicAdd(&s_wave_pairs[wave * partitions + partition], static_cast<uint32_t>(__popcll(peers)));
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) {
+      before[k] = 0;
+      if ((meta[k] >> 10) != 0) before[k] = atomicAdd(&s_wave_pairs[wave * partitions + (meta[k] & 0xFF)], 1u);
     }
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) meta[half + j] |= (__shfl(before[j], static_cast<int>(who[j] & 0xFF), 64) + (who[j] >> 8)) << 11;
+    for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) meta[k] |= before[k] << 11;
+  } else {
+    // match-any groups, four rounds at a time (their atomics in flight together): the lowest lane of a group adds the group's pairs
+#pragma unroll
+    for (uint32_t half = 0; half < JOIN_ROUNDS; half += 4) {
+      uint32_t before[4], who[4];   // who: leader lane | pairs in lower lanes << 8
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t k = half + j;
+        const uint32_t partition = meta[k] & 0xFF;
+        const bool emit = (meta[k] >> 10) != 0;
+        const uint64_t peers = match_any8(partition, emit);
+        const uint32_t leader = emit ? static_cast<uint32_t>(__ffsll(static_cast<long long>(peers))) - 1u : lane;
+        who[j] = leader | __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(peers >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(peers), 0u)) << 8;
+        before[j] = 0;
+        if (emit && leader == lane) before[j] = atomicAdd(&s_wave_pairs[wave * partitions + partition], static_cast<uint32_t>(__popcll(peers)));
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) meta[half + j] |= (__shfl(before[j], static_cast<int>(who[j] & 0xFF), 64) + (who[j] >> 8)) << 11;
+    }
   }
   __syncthreads();
   if (a.trace && tid == 0) a.trace[tile * 6 + 2] = wall_clock64();
@@ -2734,6 +2787,28 @@ static uint32_t flip_condition(uint32_t condition) {   // flip_predicate_conditi
   }
 }
 
+// Probed once per process (on the device hy_init selected): 0 unknown, 1 lane-ordered, 2 not.
+static std::atomic<int> g_lds_atomic_order{0};
+static bool lds_atomics_are_lane_ordered(hipStream_t stream) {
+  int state = g_lds_atomic_order.load(std::memory_order_acquire);
+  if (state == 0) {
+    state = 2;
+    if (!getenv("HY_JOIN_NO_ORDERED_ATOMICS")) {
+      uint32_t* failures = nullptr;
+      if (hipMalloc(reinterpret_cast<void**>(&failures), 4) == hipSuccess) {
+        uint32_t host = 1;
+        bool ok = hipMemsetAsync(failures, 0, 4, stream) == hipSuccess;
+        for (uint32_t seed = 0; ok && seed < 4; ++seed) hipLaunchKernelGGL(lds_atomic_order_probe, dim3(512), dim3(512), 0, stream, failures, seed);
+        ok = ok && hipMemcpyAsync(&host, failures, 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+        (void)hipFree(failures);
+        if (ok && host == 0) state = 1;
+      }
+    }
+    g_lds_atomic_order.store(state, std::memory_order_release);
+  }
+  return state == 1;
+}
+
 static hy_status run_join(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result, bool count_only, uint64_t* count_out,
                           const hy_join_predicate* secondary = nullptr, uint32_t n_secondary = 0) {
   if (mode == HY_JOIN_FULL_OUTER || mode == HY_JOIN_CROSS || mode > HY_JOIN_ANTI_NULL_AS_FALSE) return fail(HY_ERR_UNSUPPORTED, "JoinHash does not support join mode %u (join_hash.cpp:38-44)", mode);
@@ -2961,6 +3036,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     lds_raised.store(true, std::memory_order_release);
   }
   if (n_tiles && rank_path) {   // (every pass 2 kernel returns at once if the plan says that the result does not fit)
+    a.lane_ordered_atomics = lds_atomics_are_lane_ordered(stream) ? 1u : 0u;
     profile_begin(stream);
     hipLaunchKernelGGL(rt_probe_emit, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * rt_probe_emit_lds_words(partitions), stream, a);
     profile_end(stream);
@@ -3038,6 +3114,9 @@ hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint
 }
 
 // debug / tests only: 0 = the last join of this thread probed the sorted directory, 1 = a rank table, 2 = a rank table whose ranks are row numbers
+// debug only: 1 if rt_probe_emit ranks with lane-ordered LDS atomics on this device, 2 if the probe said no, 0 before the first join
+int hy_debug_join_lane_ordered_atomics() { return g_lds_atomic_order.load(); }
+
 int hy_debug_join_used_rank_table(void) { return t_last_join_used_rank_table; }
 
 // debug only (HY_JOIN_TRACE): the per-tile phase stamps of the last join's probe_emit; not part of the public header

@@ -546,3 +546,24 @@ def test_join_rank_table_falls_back(device, monkeypatch):
     b = check(unique, probe, abi.JOIN_INNER, 2, "directory")
     assert used_rank_table() == 0
     assert a.left[:a.n_pairs].tobytes() == b.left[:b.n_pairs].tobytes() and a.right[:a.n_pairs].tobytes() == b.right[:b.n_pairs].tobytes()
+
+
+def test_rank_table_join_with_and_without_lane_ordered_atomics(device):
+    """rt_probe_emit ranks the pairs of a partition inside a wave either with one returning LDS atomic per pair (where the device
+    serves the lanes of one instruction in lane order -- probed once per process) or with match-any groups; both produce the
+    oracle's bytes.  The probe's verdict is reported."""
+    rng = np.random.default_rng(77)
+    build = np.arange(0, 400_000, dtype=np.int32) * 3
+    probe = np.sort(rng.integers(0, 1_200_000, 900_000).astype(np.int32))
+    lcol, rcol = build_column(build, None, 65_535, abi.ENC_UNENCODED), build_column(probe, None, 65_535, abi.ENC_FRAME_OF_REFERENCE)
+    left, right = DeviceColumn(lcol), DeviceColumn(rcol)
+    want = oracle_join(lcol, rcol, abi.JOIN_INNER)
+    got = join_hash(left, right, abi.JOIN_INNER)
+    assert used_rank_table() in (1, 2)
+    n = want.n_pairs
+    assert got.n_pairs == n and got.left[:n].tobytes() == want.left[:n].tobytes() and got.right[:n].tobytes() == want.right[:n].tobytes()
+    lib = abi.load_library()
+    lib.hy_debug_join_lane_ordered_atomics.restype = int
+    verdict = lib.hy_debug_join_lane_ordered_atomics()
+    assert verdict in (1, 2)
+    print("lane-ordered LDS atomics:", "yes" if verdict == 1 else "no (match-any ranking)")
