@@ -375,6 +375,18 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
     pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
     out["int32_value_segments_lt_1995"] = measure(lambda: step_fn(pred, values), lambda m: rows * 4 + m * 8)
     del values
+    # the other streaming instantiations: u8 value ids (l_returnflag = 'R': a dictionary of three strings, scanned as value ids) and
+    # FrameOfReference offsets (l_orderkey < literal: u16 offsets + one minimum per 2048-row block)
+    rng = np.random.default_rng(44)
+    flags = DeviceColumn(storage.make_column(rng.integers(0, 3, rows).astype(np.int32), None, abi.ENC_DICTIONARY))
+    pred = make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, 2)
+    out["u8_value_ids_returnflag_eq"] = measure(lambda: step_fn(pred, flags), lambda m: rows * 1 + m * 8)
+    del flags
+    order_keys = np.sort(rng.integers(1, 60_000_000, rows).astype(np.int32))
+    keys = DeviceColumn(storage.make_column(order_keys, None, abi.ENC_FRAME_OF_REFERENCE))
+    pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 20_000_000)
+    out["frame_of_reference_orderkey_lt"] = dict(measure(lambda: step_fn(pred, keys), lambda m: rows * keys.host.segments[0].width + m * 8), offset_width=int(keys.host.segments[0].width))
+    del keys, order_keys
     # ColumnVsColumn (Q4 / Q12): l_commitdate < l_receiptdate, both dictionary-encoded with u16 value ids
     rng = np.random.default_rng(43)
     orderdate = rng.integers(0, tpch.LAST_ORDERDATE + 1, rows, dtype=np.int32)

@@ -121,6 +121,7 @@ void bind_thread_device();   // hipSetDevice(the device hy_init chose) once per 
 hy_status pinned_staging(size_t bytes, void** host, void** device);
 
 // Optional HIP-event bracket around the dominant kernel of an operator call (hy_set_profiling / hy_last_kernel_ms).
+void release_thread_join_state();   // join.hip: frees the calling thread's pinned mailbox (hy_shutdown)
 void profile_begin(hipStream_t stream);
 void profile_end(hipStream_t stream);
 bool profile_events(hipEvent_t* start, hipEvent_t* stop);   // per-kernel pair for hipExtLaunchKernelGGL

@@ -2323,6 +2323,12 @@ struct JoinMailbox {
 static thread_local JoinMailbox* t_mailbox = nullptr;      // host address
 static thread_local JoinMailbox* t_mailbox_dev = nullptr;  // device address of the same memory
 
+// hy_shutdown: the calling thread's mailbox goes with its scratch arena and pools (the next join allocates a new one)
+void release_thread_join_state() {
+  if (t_mailbox) (void)hipHostFree(t_mailbox);
+  t_mailbox = t_mailbox_dev = nullptr;
+}
+
 static hy_status join_mailbox(JoinMailbox** host, JoinMailbox** device) {
   if (!t_mailbox) {
     HY_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_mailbox), sizeof(JoinMailbox), hipHostMallocMapped));

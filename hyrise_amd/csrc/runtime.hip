@@ -283,8 +283,10 @@ hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches) {
   return HY_OK;
 }
 
-// Releases what the CALLING thread holds between calls: its scratch arena, its pool of temporary blocks and its pinned
-// staging area (all of them are thread-local and grow on demand, so calling the library again afterwards is fine).
+// Releases what the CALLING thread holds between calls: its scratch arena, its pool of temporary blocks, its pinned
+// staging area, its join mailbox and its profiling events (all of them are thread-local and grow on demand, so calling the
+// library again afterwards is fine).  Worker threads that end should call it: HIP objects freed from a thread_local destructor at
+// process exit may outlive the runtime.
 hy_status hy_shutdown(void) {
   (void)hipStreamSynchronize(t_stream);
   Scratch& s = scratch();
@@ -297,6 +299,11 @@ hy_status hy_shutdown(void) {
   if (t_staging.host) (void)hipHostFree(t_staging.host);
   t_staging.host = t_staging.device = nullptr;
   t_staging.bytes = 0;
+  release_thread_join_state();
+  for (hipEvent_t event : t_profile.events) (void)hipEventDestroy(event);
+  t_profile.events.clear();
+  t_profile.used = 0;
+  t_profile.open = false;
   return HY_OK;
 }
 

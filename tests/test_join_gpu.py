@@ -567,3 +567,18 @@ def test_rank_table_join_with_and_without_lane_ordered_atomics(device):
     verdict = lib.hy_debug_join_lane_ordered_atomics()
     assert verdict in (1, 2)
     print("lane-ordered LDS atomics:", "yes" if verdict == 1 else "no (match-any ranking)")
+
+
+def test_shutdown_releases_the_thread_state_and_the_library_keeps_working(device):
+    """hy_shutdown frees what the calling thread holds (scratch, pools, pinned staging, the join mailbox, profiling events);
+    everything is allocated again on demand."""
+    rng = np.random.default_rng(5)
+    lcol = build_column(rng.integers(0, 5_000, 60_000).astype(np.int32), None, 20_000, abi.ENC_DICTIONARY)
+    rcol = build_column(rng.integers(0, 5_000, 90_000).astype(np.int32), None, 20_000, abi.ENC_UNENCODED)
+    left, right = DeviceColumn(lcol), DeviceColumn(rcol)
+    first = join_hash(left, right, abi.JOIN_INNER)
+    for _ in range(3):
+        abi.check(device.hy_shutdown())
+        again = join_hash(left, right, abi.JOIN_INNER)
+        n = first.n_pairs
+        assert again.n_pairs == n > 0 and again.left[:n].tobytes() == first.left[:n].tobytes() and again.right[:n].tobytes() == first.right[:n].tobytes()
