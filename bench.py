@@ -110,16 +110,33 @@ def cpu_baseline_join(orders, lineitem, rows, budget_s=12.0):
 
 
 def cpu_baseline_aggregate(groupby, aggregates, rows, budget_s=12.0):
-    """The oracle's AggregateHash: sequential over chunks and rows like the reference (aggregate_hash.cpp:1016-1176), one core."""
+    """The oracle's AggregateHash: sequential over chunks and rows like the reference (aggregate_hash.cpp:1016-1176), one core --
+    and, beside it, the per-thread-partial variant SURVEY.md 8(d) asks for: every host thread aggregates a contiguous chunk range
+    with the same code, the (few) partial groups are added up."""
     support = oracle_support()
+    from concurrent.futures import ThreadPoolExecutor
+    from hyrise_amd.distributed import shard_column
 
     def run():
         support.oracle_aggregate(groupby, aggregates, group_capacity=64)
 
     median, n = median_time(run, budget_s, min_runs=1, max_runs=3)
+    threads = max(1, min(os.cpu_count() or 1, 64, groupby[0].n_chunks))
+    shards = [([shard_column(c, threads, t)[0] for c in groupby], [(f, shard_column(c, threads, t)[0] if c is not None else None) for f, c in aggregates])
+              for t in range(threads)]
+
+    def run_partials():
+        with ThreadPoolExecutor(threads) as pool:   # (ctypes releases the GIL for the duration of the C call)
+            partials = list(pool.map(lambda shard: support.oracle_aggregate(shard[0], shard[1], group_capacity=64), shards))
+        return sum(p.n_groups for p in partials)
+
+    median_partials, n_partials = median_time(run_partials, budget_s / 2, min_runs=2, max_runs=5)
     return {"value": rows / median, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"full SF10 lineitem Q1 core (string keys as key names, dictionary-encoded float measures), median of {n} runs "
-                      f"({median * 1e3:.0f} ms each), sequential like the reference's AggregateHash"}
+                      f"({median * 1e3:.0f} ms each), sequential like the reference's AggregateHash",
+            "per_thread_partials": {"value": rows / median_partials, "unit": "rows/s", "cores": threads,
+                                    "sample": f"the same aggregate as {threads} chunk-range partials on {threads} threads, median of {n_partials} runs "
+                                              f"({median_partials * 1e3:.0f} ms each; merging the partial groups is not timed: a handful of additions)"}}
 
 
 def committed_traffic(kind):
