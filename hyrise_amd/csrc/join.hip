@@ -1724,6 +1724,58 @@ __device__ __forceinline__ u32x2_t rank_row_id(const ProbeArgs& a, uint32_t r) {
   return reinterpret_cast<const u32x2_t*>(a.dir.row_ids)[r];
 }
 
+constexpr uint32_t STAGE_INVALID = 0xFFFFFFFFu;   // tag of a staging slot that holds no pair (the spare slot of a run)
+enum : int { BUILD_NONE = 0, BUILD_IDENTITY = 1, BUILD_PACKED = 2, BUILD_ROW_IDS = 3 };
+
+template <int BUILD>
+__device__ __forceinline__ u32x2_t rank_row_id_as(const ProbeArgs& a, uint32_t r) {
+  if constexpr (BUILD == BUILD_IDENTITY) {
+    uint32_t chunk = static_cast<uint32_t>(static_cast<double>(r) * a.rank.identity_inverse);
+    if (chunk * a.rank.identity_rows > r) --chunk;   // (the product is within one ulp of the quotient)
+    uint32_t offset = r - chunk * a.rank.identity_rows;
+    if (offset >= a.rank.identity_rows) { ++chunk; offset -= a.rank.identity_rows; }
+    return u32x2_t{chunk, offset};
+  } else if constexpr (BUILD == BUILD_PACKED) {
+    const uint32_t id = a.dir.ids32[r];
+    return u32x2_t{id >> 16, id & 0xFFFFu};
+  } else {
+    return reinterpret_cast<const u32x2_t*>(a.dir.row_ids)[r];
+  }
+}
+
+template <int BUILD>
+__device__ __forceinline__ void rt_copy_out(const ProbeArgs& a, const u32x2_t* s_stage, const uint64_t* s_out_base, uint32_t reserved, uint32_t chunk, uint32_t tile_row_begin,
+                                            uint32_t tid) {
+  for (uint32_t slot = 2 * tid; slot < reserved; slot += 2 * JOIN_THREADS) {
+    const u32x4_t records = *reinterpret_cast<const u32x4_t*>(s_stage + slot);
+    const uint32_t tag0 = records.x, tag1 = slot + 1 < reserved ? records.z : STAGE_INVALID;
+    const bool valid0 = tag0 != STAGE_INVALID, valid1 = tag1 != STAGE_INVALID;
+    const uint32_t partition0 = (tag0 >> 12) & 0x1FF, partition1 = (tag1 >> 12) & 0x1FF;
+    const u32x2_t probe0 = {chunk, tile_row_begin + (tag0 & 0xFFFu)}, probe1 = {chunk, tile_row_begin + (tag1 & 0xFFFu)};
+    u32x2_t build0 = {0xFFFFFFFFu, 0xFFFFFFFFu}, build1 = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    if constexpr (BUILD != BUILD_NONE) {
+      if (valid0 && !(tag0 & (1u << 21))) build0 = rank_row_id_as<BUILD>(a, records.y);
+      if (valid1 && !(tag1 & (1u << 21))) build1 = rank_row_id_as<BUILD>(a, records.w);
+    }
+    if (valid0 && valid1 && partition0 == partition1) {   // both pairs of one run: its first global index has the slot's parity -> aligned
+      const uint64_t pair_pos = s_out_base[partition0] + slot;
+      __builtin_nontemporal_store(u32x4_t{probe0.x, probe0.y, probe1.x, probe1.y}, reinterpret_cast<u32x4_t*>(reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos));
+      if constexpr (BUILD != BUILD_NONE) __builtin_nontemporal_store(u32x4_t{build0.x, build0.y, build1.x, build1.y}, reinterpret_cast<u32x4_t*>(reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos));
+    } else {
+      if (valid0) {
+        const uint64_t pair_pos = s_out_base[partition0] + slot;
+        __builtin_nontemporal_store(probe0, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
+        if constexpr (BUILD != BUILD_NONE) __builtin_nontemporal_store(build0, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+      }
+      if (valid1) {
+        const uint64_t pair_pos = s_out_base[partition1] + slot + 1;
+        __builtin_nontemporal_store(probe1, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
+        if constexpr (BUILD != BUILD_NONE) __builtin_nontemporal_store(build1, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
+      }
+    }
+  }
+}
+
 // LDS of rt_probe_emit, in 4-byte words: staged pairs (one spare slot per partition, see below) | pairs per (wave, partition),
 // then pairs of earlier waves | first slot per partition (+ total) | output base per partition | wave totals.
 __host__ __device__ constexpr size_t rt_probe_emit_lds_words(uint32_t partitions) {
@@ -1741,7 +1793,7 @@ __host__ __device__ constexpr size_t rt_probe_emit_lds_words(uint32_t partitions
 // them took 5 us even with every run sequential), 16-byte stores at twice that.  To make the two pairs of a lane one
 // aligned 16-byte store, partition p's run starts at a staging slot of the parity of its first global pair index -- every
 // non-empty partition reserves one spare slot for that, marked invalid.
-constexpr uint32_t STAGE_INVALID = 0xFFFFFFFFu;
+
 // Does a returning LDS atomic hand the lanes of one instruction their values in lane order?  Eight waves at once, four address
 // patterns each (one counter; two interleaved; 128 counters hit in runs of one to seven lanes like sorted foreign keys; a
 // pseudo-random spread), several rounds on the same counters: every lane compares what it got with the count of equal
@@ -1879,36 +1931,15 @@ __global__ __launch_bounds__(JOIN_THREADS) void rt_probe_emit(ProbeArgs a) {
   }
   __syncthreads();
   if (a.trace && tid == 0) a.trace[tile * 6 + 4] = wall_clock64();
-  // (e) copy out, two staging slots (= two consecutive pairs of one partition, or a run's end and the next one's spare) per lane
+  // (e) copy out, two staging slots (= two consecutive pairs of one partition, or a run's end and the next one's spare) per lane.
+  // One loop per way of turning a partner's rank into its RowID -- chosen once, outside: the identity case (rank = row number) has
+  // no global load in it, so the compiler does not put an `s_waitcnt vmcnt(0)` (which also waits for every STORE in flight: loads and
+  // stores share the counter on gfx9) at the top of every iteration, as it did when the three cases shared one loop.
   const uint32_t reserved = s_tile_offset[partitions];
-  for (uint32_t slot = 2 * tid; slot < reserved; slot += 2 * JOIN_THREADS) {
-    const u32x4_t records = *reinterpret_cast<const u32x4_t*>(s_stage + slot);
-    const uint32_t tag0 = records.x, tag1 = slot + 1 < reserved ? records.z : STAGE_INVALID;
-    const bool valid0 = tag0 != STAGE_INVALID, valid1 = tag1 != STAGE_INVALID;
-    const uint32_t partition0 = (tag0 >> 12) & 0x1FF, partition1 = (tag1 >> 12) & 0x1FF;
-    const u32x2_t probe0 = {chunk, tile_row_begin + (tag0 & 0xFFFu)}, probe1 = {chunk, tile_row_begin + (tag1 & 0xFFFu)};
-    u32x2_t build0 = {0xFFFFFFFFu, 0xFFFFFFFFu}, build1 = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (a.build_out) {
-      if (valid0 && !(tag0 & (1u << 21))) build0 = rank_row_id(a, records.y);
-      if (valid1 && !(tag1 & (1u << 21))) build1 = rank_row_id(a, records.w);
-    }
-    if (valid0 && valid1 && partition0 == partition1) {   // both pairs of one run: its first global index has the slot's parity -> aligned
-      const uint64_t pair_pos = s_out_base[partition0] + slot;
-      __builtin_nontemporal_store(u32x4_t{probe0.x, probe0.y, probe1.x, probe1.y}, reinterpret_cast<u32x4_t*>(reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos));
-      if (a.build_out) __builtin_nontemporal_store(u32x4_t{build0.x, build0.y, build1.x, build1.y}, reinterpret_cast<u32x4_t*>(reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos));
-    } else {
-      if (valid0) {
-        const uint64_t pair_pos = s_out_base[partition0] + slot;
-        __builtin_nontemporal_store(probe0, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
-        if (a.build_out) __builtin_nontemporal_store(build0, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
-      }
-      if (valid1) {
-        const uint64_t pair_pos = s_out_base[partition1] + slot + 1;
-        __builtin_nontemporal_store(probe1, reinterpret_cast<u32x2_t*>(a.probe_out) + pair_pos);
-        if (a.build_out) __builtin_nontemporal_store(build1, reinterpret_cast<u32x2_t*>(a.build_out) + pair_pos);
-      }
-    }
-  }
+  if (!a.build_out) rt_copy_out<BUILD_NONE>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
+  else if (a.rank.identity_rows) rt_copy_out<BUILD_IDENTITY>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
+  else if (a.dir.ids32) rt_copy_out<BUILD_PACKED>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
+  else rt_copy_out<BUILD_ROW_IDS>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
   if (a.trace && tid == 0) a.trace[tile * 6 + 5] = wall_clock64();
 }
 
