@@ -392,6 +392,17 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
     pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
     out["int32_value_segments_lt_1995"] = measure(lambda: step_fn(pred, values), lambda m: rows * 4 + m * 8)
     del values
+    # l_shipdate as Hyrise's schema has it: DictionarySegment<pmr_string> of ISO dates -- the same attribute vectors, the literal resolved
+    # per chunk on the host (lower / upper bound in 916 string dictionaries: reported beside the scan as host_literal_resolution_ms)
+    from hyrise_amd.operators import string_predicate
+    strings_host, dictionaries = tpch.string_date_column(column.host)
+    strings = DeviceColumn(strings_host)
+    string_pred = string_predicate(abi.PRED_LESS_THAN, dictionaries, "1995-01-01")
+    out["string_dictionary_twin_lt_1995"] = measure(lambda: step_fn(string_pred, strings), lambda m: rows * width + m * 8)
+    t0 = time.perf_counter()
+    string_predicate(abi.PRED_LESS_THAN, dictionaries, "1995-01-01")
+    out["string_dictionary_twin_lt_1995"]["host_literal_resolution_ms"] = (time.perf_counter() - t0) * 1e3
+    del strings
     # the other streaming instantiations: u8 value ids (l_returnflag = 'R': a dictionary of three strings, scanned as value ids) and
     # FrameOfReference offsets (l_orderkey < literal: u16 offsets + one minimum per 2048-row block)
     rng = np.random.default_rng(44)

@@ -51,6 +51,36 @@ def make_predicate(condition, data_type=abi.TYPE_INT, value=None, value2=None, n
     return p
 
 
+def string_predicate(condition, dictionaries, value, value2=None, nullable=False):
+    """The predicate of `string_column <condition> 'literal'` over DictionarySegment<pmr_string> chunks: the literal(s) are
+    resolved against every chunk's (byte-wise sorted) dictionary on the host -- lower_bound / upper_bound, as
+    column_vs_value_table_scan_impl.cpp:211-226 and column_between_table_scan_impl.cpp:112-124 do per segment -- and the device
+    compares value ids.  `dictionaries`: per chunk the sorted list of bytes."""
+    import bisect
+
+    def encoded(x):
+        return x if isinstance(x, bytes) else str(x).encode("utf-8")
+
+    first, second = encoded(value), (encoded(value2) if value2 is not None else None)
+    between = abi.PRED_BETWEEN_INCLUSIVE <= condition <= abi.PRED_BETWEEN_EXCLUSIVE
+    lower_inclusive = condition in (abi.PRED_BETWEEN_INCLUSIVE, abi.PRED_BETWEEN_UPPER_EXCLUSIVE)
+    upper_inclusive = condition in (abi.PRED_BETWEEN_INCLUSIVE, abi.PRED_BETWEEN_LOWER_EXCLUSIVE)
+    lower, upper, found = [], [], []
+    for dictionary in dictionaries:
+        def bound(position):
+            return position if position < len(dictionary) else abi.INVALID_VALUE_ID
+        if between:
+            lower.append(bound(bisect.bisect_left(dictionary, first) if lower_inclusive else bisect.bisect_right(dictionary, first)))
+            upper.append(bound(bisect.bisect_right(dictionary, second) if upper_inclusive else bisect.bisect_left(dictionary, second)))
+            found.append(0)
+        else:
+            position = bisect.bisect_left(dictionary, first)
+            lower.append(bound(position))
+            upper.append(bound(bisect.bisect_right(dictionary, first)))
+            found.append(1 if position < len(dictionary) and dictionary[position] == first else 0)
+    return make_predicate(condition, abi.TYPE_STRING, nullable=nullable, per_chunk_lower=lower, per_chunk_upper=upper, per_chunk_found=found)
+
+
 def _literal(data_type, value):
     v = abi.Value()
     C.memset(C.byref(v), 0, C.sizeof(v))

@@ -104,6 +104,25 @@ def shipdate_column(n_rows=LINEITEM_ROWS_SF10, seed=42, chunk_size=abi.CHUNK_DEF
     return days.astype(np.int32), storage.make_column(days.astype(np.int32), None, abi.ENC_DICTIONARY, chunk_size)
 
 
+def iso_date(day):
+    """Day number (days since 1992-01-01) -> b'YYYY-MM-DD', the form TPC-H dates have in Hyrise's string columns."""
+    import datetime
+    return (datetime.date(1992, 1, 1) + datetime.timedelta(days=int(day))).isoformat().encode("ascii")
+
+
+def string_date_column(int_column):
+    """The DictionarySegment<pmr_string> twin of a dictionary-encoded column of day numbers -- what l_shipdate IS in Hyrise's
+    TPC-H schema (tpch_table_generator.cpp:46).  ISO dates sort like the days they name, so every chunk's attribute vector is the
+    int twin's, and its dictionary (kept on the host, like all string dictionaries) holds the same days as strings.
+    -> (HostColumn of type string, per-chunk dictionaries as sorted lists of bytes)"""
+    segments, dictionaries = [], []
+    for s in int_column.segments:
+        assert s.encoding == abi.ENC_DICTIONARY
+        dictionaries.append([iso_date(day) for day in np.asarray(s.aux)[:s.aux_size]])
+        segments.append(storage.HostSegment(abi.ENC_DICTIONARY, abi.TYPE_STRING, s.size, s.width, s.data, aux=None, aux_size=s.aux_size))
+    return storage.HostColumn(segments, abi.TYPE_STRING), dictionaries
+
+
 def string_key_column(char_codes, chunk_size=abi.CHUNK_DEFAULT_SIZE):
     """A column of one-character strings (l_returnflag, l_linestatus) as AggregateHash's GROUP BY takes it from the adapter:
     DictionarySegment<pmr_string> per chunk -- attribute vector of value ids (u8: a handful of distinct flags) over the

@@ -62,6 +62,29 @@ def test_scan_sf10_shipdate(device, sf10):
         assert want.matches[:want.total].tobytes() == np.ascontiguousarray(got_rows).tobytes()
 
 
+def test_scan_sf10_shipdate_string_twin(device, sf10):
+    """l_shipdate as Hyrise holds it -- DictionarySegment<pmr_string> of ISO dates (tpch_table_generator.cpp:46) -- against its int
+    twin: the host resolves the string literal per chunk (column_vs_value_table_scan_impl.cpp:211-226), the device compares value ids;
+    PosLists, counts and chunk states are the oracle's bytes and the int twin's."""
+    from hyrise_amd.operators import string_predicate, table_scan
+    ints = storage.make_column(sf10.l_shipdate, None, abi.ENC_DICTIONARY)
+    strings, dictionaries = tpch.string_date_column(ints)
+    int_column, string_column = DeviceColumn(ints), DeviceColumn(strings)
+    for condition, a, b, ia, ib in ((abi.PRED_LESS_THAN, "1995-01-01", None, tpch.DAY_1995_01_01, None),
+                                    (abi.PRED_LESS_THAN_EQUALS, "1998-09-02", None, tpch.DAY_1998_09_02, None),
+                                    (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, "1994-01-01", "1995-01-01", tpch.DAY_1994_01_01, tpch.DAY_1995_01_01),
+                                    (abi.PRED_EQUALS, "1995-06-17", None, tpch.CURRENT_DATE, None), (abi.PRED_GREATER_THAN, "1999-01-01", None, 2600, None)):
+        predicate = string_predicate(condition, dictionaries, a, b)
+        got = table_scan(string_column, predicate)
+        twin = table_scan(int_column, make_predicate(condition, abi.TYPE_INT, ia, ib))
+        want = oracle_scan(strings, predicate, threads=ORACLE_THREADS)
+        for other in (twin, want):
+            assert got.total == other.total
+            assert got.matches[:got.total].tobytes() == other.matches[:other.total].tobytes()
+            np.testing.assert_array_equal(got.counts, other.counts)
+            np.testing.assert_array_equal(got.chunk_state, other.chunk_state)
+
+
 def test_join_sf10_orders_lineitem(device, sf10):
     orders = DeviceColumn(storage.make_column(sf10.o_orderkey, None, abi.ENC_UNENCODED))
     lineitem = DeviceColumn(storage.make_column(sf10.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE))
