@@ -174,3 +174,49 @@ def test_aggregate_sf10_q1_as_specified(device, sf10):
     assert got.column(6) == counts[order].tolist()
     chunk = abi.CHUNK_DEFAULT_SIZE
     assert (got.row_ids[:groups, 0].astype(np.int64) * chunk + got.row_ids[:groups, 1]).tolist() == first[order].tolist()
+
+
+def test_join_large_unsorted_and_duplicate_builds(device):
+    """The other build-side structures at a size where every kernel runs thousands of workgroups, against the oracle's bytes: unique build
+    keys in random order (rank table filled with atomics + scattered rows), a shuffled probe side (random lookups, 4-byte FrameOfReference
+    offsets), and every build key four times (sorted directory, multi-partner tiles)."""
+    from hyrise_amd.operators import join_hash
+    rng = np.random.default_rng(123)
+    n_build, n_probe = 3_000_000, 12_000_000
+    keys = tpch.sparse_orderkeys(n_build)
+    probe_sorted = np.sort(keys[rng.integers(0, n_build, n_probe)])
+    cases = {"shuffled build": (keys[rng.permutation(n_build)], probe_sorted),
+             "shuffled probe": (keys, probe_sorted[rng.permutation(n_probe)]),
+             "duplicate build x4": (np.repeat(keys[:n_build // 4], 4)[rng.permutation(n_build // 4 * 4)], probe_sorted[:n_probe // 3])}
+    for name, (build, probe) in cases.items():
+        build_host = storage.make_column(build, None, abi.ENC_UNENCODED)
+        probe_host = storage.make_column(probe, None, abi.ENC_FRAME_OF_REFERENCE)
+        got = join_hash(DeviceColumn(build_host), DeviceColumn(probe_host), abi.JOIN_INNER)
+        want = oracle_join(build_host, probe_host, abi.JOIN_INNER, threads=ORACLE_THREADS, capacity=got.n_pairs + 16)
+        n = want.n_pairs
+        assert got.n_pairs == n > 0 and int(got.c.n_slices) == int(want.c.n_slices) and int(got.c.radix_bits) == int(want.c.radix_bits), name
+        assert got.left[:n].tobytes() == want.left[:n].tobytes() and got.right[:n].tobytes() == want.right[:n].tobytes(), name
+        np.testing.assert_array_equal(got.slice_offsets[:int(got.c.n_slices) + 1], want.slice_offsets[:int(want.c.n_slices) + 1], err_msg=name)
+
+
+def test_aggregate_many_groups_at_size(device):
+    """The hash-partitioned path at 20 M rows / 100 000 groups against the oracle: group rows and COUNT / integer SUM / MIN / MAX bytes,
+    float sums within the stated tolerance."""
+    rng = np.random.default_rng(321)
+    n = 20_000_000
+    keys = storage.make_column(rng.integers(0, 100_000, n).astype(np.int32) * 7 - 3, None, abi.ENC_UNENCODED)
+    ints = storage.make_column(rng.integers(-1000, 1000, n).astype(np.int32), None, abi.ENC_FRAME_OF_REFERENCE)
+    floats = storage.make_column((rng.random(n) * 100).astype(np.float32), None, abi.ENC_DICTIONARY)
+    aggregates = [(abi.AGG_SUM, ints), (abi.AGG_MIN, ints), (abi.AGG_MAX, floats), (abi.AGG_SUM, floats), (abi.AGG_COUNT, None)]
+    device_columns = {id(c): DeviceColumn(c) for c in (keys, ints, floats)}
+    got = aggregate_hash([device_columns[id(keys)]], [(f, device_columns[id(c)] if c is not None else None) for f, c in aggregates], group_capacity=100_016)
+    want = oracle_aggregate([keys], aggregates, group_capacity=100_016)
+    groups = want.n_groups
+    assert got.n_groups == groups == 100_000
+    assert got.row_ids[:groups].tobytes() == want.row_ids[:groups].tobytes()
+    for a in (0, 1, 2, 4):
+        assert got.raw[a][:groups].tobytes() == want.raw[a][:groups].tobytes(), a
+    np.testing.assert_allclose(got.raw[3][:groups].view(np.float64), want.raw[3][:groups].view(np.float64), rtol=1e-9, atol=0)
+    lib = abi.load_library()
+    lib.hy_debug_aggregate_path.restype = int
+    assert lib.hy_debug_aggregate_path() > 0
