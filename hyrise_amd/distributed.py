@@ -286,8 +286,9 @@ class HipExecutor:
                 raise
         return aggregate_hash(groupby, aggregates, group_capacity=shape.rows + 1)
 
-    def _device_scan(self, column, predicate, layout):
-        """hy_table_scan into device memory + hy_poslist_translate -> (RowID tensor, per-chunk region begins, counts tensor, total)"""
+    def _device_scan(self, column, predicate, layout, visibility=None):
+        """hy_table_scan (or, with visibility = (our_tid, snapshot commit id), hy_validate) into device memory + hy_poslist_translate
+        -> (RowID tensor, per-chunk region begins, counts tensor, total)"""
         torch = self.torch
         rows, n_chunks = max(1, column.rows), column.n_chunks
         regions = torch.empty((rows, 2), dtype=torch.int32, device=self.device)
@@ -297,7 +298,10 @@ class HipExecutor:
         result.mem, result.flags = abi.MEM_DEVICE, abi.SCAN_CHUNK_REGIONS | abi.SCAN_MATERIALIZE_ALL_MATCH
         result.matches, result.capacity = regions.data_ptr(), rows
         result.offsets, result.counts = offsets.data_ptr(), counts.data_ptr()
-        abi.check(self.lib.hy_table_scan(column.handle, C.byref(predicate), None, 0, C.byref(result)))
+        if visibility is None:
+            abi.check(self.lib.hy_table_scan(column.handle, C.byref(predicate), None, 0, C.byref(result)))
+        else:
+            abi.check(self.lib.hy_validate(column.handle, visibility[0], visibility[1], 1, C.byref(result)))
         out = torch.empty((rows, 2), dtype=torch.int32, device=self.device)
         written = C.c_uint64(0)
         abi.check(self.lib.hy_poslist_translate(column.handle, C.byref(result), layout, out.data_ptr(), rows, C.byref(written)))
@@ -324,6 +328,14 @@ class HipExecutor:
         else:
             base_chunk = np.arange(column.n_chunks, dtype=np.int64)                # a data table: chunk c's matches are rows of chunk c
         return DevicePosLists(out, begin, count, base_chunk)
+
+    def validate_chunked(self, mvcc_column, our_tid, snapshot_commit_id):
+        """Validate in front of the scans (what every SQL-driven plan has): the rows of the data table visible to
+        the transaction, one PosList per chunk, on the device."""
+        out, offsets, counts, _ = self._device_scan(mvcc_column, None, abi.POSLIST_CHUNK_REGIONS, visibility=(our_tid, snapshot_commit_id))
+        begin = offsets[:mvcc_column.n_chunks].cpu().numpy()
+        count = counts[:mvcc_column.n_chunks].cpu().numpy().astype(np.int64)
+        return DevicePosLists(out, begin, count, np.arange(mvcc_column.n_chunks, dtype=np.int64))
 
     def reference_column_chunked(self, base, pos_lists):
         return DeviceChunkedReferenceColumn(self.lib, base, pos_lists)

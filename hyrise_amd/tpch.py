@@ -161,16 +161,22 @@ def q6_columns(data, chunk_size=abi.CHUNK_DEFAULT_SIZE):
             "l_extendedprice": storage.make_column(data.l_extendedprice, None, abi.ENC_UNENCODED, chunk_size)}
 
 
-def run_q6(ex, columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discount=(0.05, 0.07), quantity=24.0):
+def run_q6(ex, columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discount=(0.05, 0.07), quantity=24.0, mvcc=None, transaction=(0, 0)):
     """TPC-H Q6 (tpch_queries.cpp:206-210) the way the reference's plan runs it: three TableScans chained through reference
     segments (the second and third scan read the PosList of the one before, table_scan.cpp:158-196), a Projection
     l_extendedprice * l_discount over the survivors, AggregateHash SUM without GROUP BY.  `ex`: distributed.HipExecutor (every
     intermediate -- PosLists, the product column -- stays in device memory) or the tests' oracle executor.
+    With `mvcc` (the table's MvccData as a column, storage.make_mvcc_column) the chain starts like every SQL-driven plan of the
+    reference: GetTable -> Validate -> the scans (sql_pipeline_builder.hpp:55, validate.cpp:275); `transaction` = (our tid,
+    snapshot commit id).
     -> (revenue, qualifying rows)"""
     from .operators import make_predicate
     # the scans keep the reference's output shape -- one PosList per input chunk, each referencing one data chunk -- so the
     # second and third scan take the single-chunk path of AbstractDereferencedColumnTableScanImpl (:38-46)
-    lists = ex.scan_chunked(columns["l_shipdate"], make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, date_from, date_to))
+    first = columns["l_shipdate"]
+    if mvcc is not None:
+        first = ex.reference_column_chunked(first, ex.validate_chunked(mvcc, transaction[0], transaction[1]))
+    lists = ex.scan_chunked(first, make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, date_from, date_to))
     lists = ex.scan_chunked(ex.reference_column_chunked(columns["l_discount"], lists),
                             make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, np.float32(discount[0]), np.float32(discount[1])))
     lists = ex.scan_chunked(ex.reference_column_chunked(columns["l_quantity"], lists), make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, quantity))

@@ -51,6 +51,11 @@ class OracleExecutor:
             lists.append(matches)
         return _HostPosLists(lists, base_chunk)
 
+    def validate_chunked(self, mvcc_column, our_tid, snapshot_commit_id):
+        from support import oracle_validate
+        result = oracle_validate(mvcc_column, our_tid, snapshot_commit_id, flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
+        return _HostPosLists([result.pos_list(c).copy() for c in range(mvcc_column.n_chunks)], list(range(mvcc_column.n_chunks)))
+
     def reference_column_chunked(self, base, pos_lists):
         from hyrise_amd import storage
         keep = [c for c, rows in enumerate(pos_lists.lists) if len(rows)]

@@ -52,6 +52,60 @@ def test_q6_no_qualifying_row_is_null():
     assert revenue is None and qualifying == 0
 
 
+def mvcc_for(data, rng, chunk_size):
+    """MvccData of a lineitem table that has seen some transactions: 3 % of the rows deleted before the snapshot, 2 % after it, 1 %
+    inserted after it, a few in-flight rows of our own and of another transaction.  -> (mvcc column, visible mask for tid 7 / snapshot 10)"""
+    from hyrise_amd import storage
+    n = data.n_lineitems
+    tids = np.zeros(n, dtype=np.uint32)
+    begin = np.full(n, 3, dtype=np.uint32)
+    end = np.full(n, storage.MAX_COMMIT_ID, dtype=np.uint32)
+    pick = rng.random(n)
+    end[pick < 0.03] = 8                                   # deleted before the snapshot: invisible
+    end[(pick >= 0.03) & (pick < 0.05)] = 12               # deleted after it: still visible
+    begin[(pick >= 0.05) & (pick < 0.06)] = 11             # inserted after it: invisible
+    ours = (pick >= 0.06) & (pick < 0.062)                 # our own uncommitted inserts: visible to us
+    begin[ours], tids[ours] = storage.MAX_COMMIT_ID, 7
+    theirs = (pick >= 0.062) & (pick < 0.064)              # somebody else's: invisible
+    begin[theirs], tids[theirs] = storage.MAX_COMMIT_ID, 9
+    snapshot, our_tid = 10, 7
+    visible = (snapshot < end) & ((snapshot >= begin) != (tids == our_tid))
+    return storage.make_mvcc_column(tids, begin, end, chunk_size), visible
+
+
+def numpy_q6_visible(data, visible):
+    keep = visible & (data.l_shipdate >= tpch.DAY_1994_01_01) & (data.l_shipdate < tpch.DAY_1995_01_01) & (data.l_discount >= np.float32(0.05)) & \
+           (data.l_discount <= np.float32(0.07)) & (data.l_quantity < 24)
+    return float((data.l_extendedprice[keep] * data.l_discount[keep]).astype(np.float64).sum()), int(keep.sum())
+
+
+def test_q6_behind_validate_on_the_oracle():
+    """GetTable -> Validate -> TableScan x3 -> Projection -> AggregateHash, the plan shape of hyriseBenchmarkTPCH."""
+    data = tpch.TpchData(scale_factor=0.01, seed=12)
+    mvcc, visible = mvcc_for(data, np.random.default_rng(1), 5000)
+    revenue, qualifying = tpch.run_q6(OracleExecutor(), tpch.q6_columns(data, chunk_size=5000), mvcc=mvcc, transaction=(7, 10))
+    exact_revenue, exact_rows = numpy_q6_visible(data, visible)
+    assert qualifying == exact_rows > 0 and qualifying < numpy_q6(data)[1]
+    assert abs(revenue - exact_revenue) <= 1e-9 * exact_revenue
+
+
+@pytest.mark.gpu
+def test_q6_behind_validate_on_device(device):
+    import torch
+    from hyrise_amd.distributed import HipExecutor
+    from hyrise_amd.storage import DeviceColumn
+    data = tpch.TpchData(scale_factor=0.5, seed=42)
+    mvcc, visible = mvcc_for(data, np.random.default_rng(2), 65_535)
+    host = tpch.q6_columns(data)
+    columns = {name: DeviceColumn(column) for name, column in host.items()}
+    revenue, qualifying = tpch.run_q6(HipExecutor(torch.device("cuda", 0)), columns, mvcc=DeviceColumn(mvcc), transaction=(7, 10))
+    exact_revenue, exact_rows = numpy_q6_visible(data, visible)
+    assert qualifying == exact_rows > 0
+    assert abs(revenue - exact_revenue) <= 1e-9 * exact_revenue
+    oracle_revenue, oracle_rows = tpch.run_q6(OracleExecutor(), host, mvcc=mvcc, transaction=(7, 10))
+    assert oracle_rows == qualifying and abs(oracle_revenue - revenue) <= 1e-9 * abs(oracle_revenue)
+
+
 @pytest.mark.gpu
 def test_q6_sf1_on_device_matches_sqlite(device):
     import torch
