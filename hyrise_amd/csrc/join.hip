@@ -1805,7 +1805,6 @@ __global__ __launch_bounds__(512) void lds_atomic_order_probe(uint32_t* failures
   __syncthreads();
   uint32_t wrong = 0;
   for (uint32_t pattern = 0; pattern < 4; ++pattern) {
-    uint32_t seen[4] = {0, 0, 0, 0};   // this lane's address was hit this often by all lanes in earlier rounds (tracked per round below)
     for (uint32_t round = 0; round < 4; ++round) {
       uint32_t address;
       if (pattern == 0) address = 0;
@@ -1815,13 +1814,11 @@ __global__ __launch_bounds__(512) void lds_atomic_order_probe(uint32_t* failures
       const bool take = pattern < 2 || ((lane * 7 + round + seed) % 5) != 0;   // some lanes sit a round out
       const uint64_t peers = match_any8(address, take);
       const uint32_t lower = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(peers >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(peers), 0u));
-      // what the counter held before this instruction: read it back through the group's lowest lane after the fact
       uint32_t got = 0;
       if (take) got = atomicAdd(&s_counter[wave][address], 1u);
       const uint32_t leader = take ? static_cast<uint32_t>(__ffsll(static_cast<long long>(peers))) - 1u : lane;
       const uint32_t base = __shfl(got, static_cast<int>(leader), 64);      // the lowest lane must have seen the counter's old value ...
       if (take && got != base + lower) ++wrong;                              // ... and every lane old value + equal addresses below it
-      (void)seen;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 8 * 128; i += 512) (&s_counter[0][0])[i] = 0;
