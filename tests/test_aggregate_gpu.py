@@ -246,3 +246,29 @@ def test_partitions_with_more_groups_than_their_tables(device):
         assert got.n_groups == n and aggregate_path() == 14
     finally:
         del os.environ["HY_AGG_PARTITION_BITS"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"L{c['line']}" for c in CASES])
+def test_reference_aggregate_fixture_on_a_reference_table(device, case):
+    """aggregate_test.cpp runs every case a second time on a reference table produced by a pass-through TableScan (:40-79): all columns
+    as ReferenceSegments -- explicit PosLists for the even chunks, EntireChunkPosLists for the odd ones -- over the data columns."""
+    columns = AggregateCase(case)
+    if not columns.runnable:
+        pytest.skip("COUNT(*) without GROUP BY and without a column to take the table's shape from")
+    devices, references = {}, {}
+
+    def reference_of(column):
+        if id(column) not in references:
+            lists = [np.stack([np.full(s.size, c, dtype=np.uint32), np.arange(s.size, dtype=np.uint32)], axis=1) if c % 2 == 0 else c for c, s in enumerate(column.segments)]
+            host = storage.make_reference_column(column, lists, list(range(column.n_chunks)))
+            devices[id(column)] = DeviceColumn(column)
+            references[id(column)] = (host, DeviceColumn(host, refs={id(column): devices[id(column)]}))
+        return references[id(column)]
+
+    groupby = [reference_of(c) for c in columns.groupby]
+    aggregates = [(f, reference_of(c) if c is not None else None) for f, c in columns.aggregates]
+    got = aggregate_hash([d for _, d in groupby], [(f, r[1] if r is not None else None) for f, r in aggregates])
+    want = oracle_aggregate(columns.groupby, columns.aggregates)                 # the data table's result: same groups, same order, same rows
+    on_references = oracle_aggregate([h for h, _ in groupby], [(f, r[0] if r is not None else None) for f, r in aggregates])
+    assert_aggregate_equal(on_references, want, len(aggregates), f"oracle, reference table, aggregate_test.cpp:{case['line']}")
+    assert_aggregate_equal(got, want, len(aggregates), f"device, reference table, aggregate_test.cpp:{case['line']}")

@@ -53,6 +53,24 @@ def test_reference_aggregate_fixture(case):
     run_case(case, oracle_aggregate)
 
 
+@pytest.mark.parametrize("case", CASES, ids=[f"L{c['line']}" for c in CASES])
+def test_reference_aggregate_fixture_on_a_reference_table(case):
+    """aggregate_test.cpp runs every case again on a reference table produced by a pass-through TableScan (:40-79): explicit PosLists
+    for the even chunks, EntireChunkPosLists for the odd ones."""
+    from hyrise_amd import storage
+    references = {}
+
+    def reference_of(column):
+        if column is None:
+            return None
+        if id(column) not in references:
+            lists = [np.stack([np.full(s.size, c, dtype=np.uint32), np.arange(s.size, dtype=np.uint32)], axis=1) if c % 2 == 0 else c for c, s in enumerate(column.segments)]
+            references[id(column)] = storage.make_reference_column(column, lists, list(range(column.n_chunks)))
+        return references[id(column)]
+
+    run_case(case, lambda groupby, aggregates: oracle_aggregate([reference_of(c) for c in groupby], [(f, reference_of(c)) for f, c in aggregates]))
+
+
 def test_string_group_keys_are_the_reference_names():
     """aggregate_hash.cpp:852-914: "" -> 1, 2 + byte, 258 + two bytes ..., map ids from 5 000 000 000 for five and more characters."""
     from hyrise_amd.string_keys import AggregateKeyNames
