@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <vector>
 
 namespace hy {
@@ -1341,18 +1342,32 @@ static uint32_t result_type(uint32_t function, uint32_t input_type) {   // windo
   }
 }
 
-static hy_row_id row_id_of(const hy_column* shape, uint64_t global_row) {
-  if (shape->n_chunks > 1) {   // chunks of one size (all but the last): a division instead of a search
-    const uint64_t size = shape->row_base[1];
-    const uint64_t chunk = size ? global_row / size : 0;
-    if (size && chunk < shape->n_chunks && shape->row_base[chunk] == chunk * size && global_row < shape->row_base[chunk + 1]) {
-      return hy_row_id{static_cast<uint32_t>(chunk), static_cast<uint32_t>(global_row - chunk * size)};
+// Global row number -> RowID.  Chunks of one size (all but the last) are the rule: then the chunk is a multiplication by the
+// reciprocal (+ a fix-up: the product is within one of the quotient) instead of a 64-bit division or a search per group.
+struct RowIdOf {
+  const hy_column* shape;
+  uint64_t size = 0;       // common chunk size, 0: search
+  double inverse = 0.0;
+  explicit RowIdOf(const hy_column* column) : shape(column) {
+    if (column->n_chunks > 1 && column->row_base[1] > 0 && column->rows < (1ull << 52)) {
+      size = column->row_base[1];
+      for (uint32_t c = 1; c < column->n_chunks && size; ++c) if (column->row_base[c] != c * size) size = 0;
+      if (size) inverse = 1.0 / static_cast<double>(size);
     }
   }
-  const auto it = std::upper_bound(shape->row_base.begin(), shape->row_base.end(), global_row);
-  const uint32_t chunk = static_cast<uint32_t>(it - shape->row_base.begin()) - 1;
-  return hy_row_id{chunk, static_cast<uint32_t>(global_row - shape->row_base[chunk])};
-}
+  hy_row_id operator()(uint64_t global_row) const {
+    if (size) {
+      uint64_t chunk = static_cast<uint64_t>(static_cast<double>(global_row) * inverse);
+      if (chunk * size > global_row) --chunk;
+      else if ((chunk + 1) * size <= global_row) ++chunk;
+      if (chunk >= shape->n_chunks) chunk = shape->n_chunks - 1;
+      return hy_row_id{static_cast<uint32_t>(chunk), static_cast<uint32_t>(global_row - chunk * size)};
+    }
+    const auto it = std::upper_bound(shape->row_base.begin(), shape->row_base.end(), global_row);
+    const uint32_t chunk = static_cast<uint32_t>(it - shape->row_base.begin()) - 1;
+    return hy_row_id{chunk, static_cast<uint32_t>(global_row - shape->row_base[chunk])};
+  }
+};
 
 // What the device table holds after one pass over the table: the groups' tuples, first / last rows and accumulators.
 struct DeviceGroups {
@@ -1620,6 +1635,21 @@ __global__ __launch_bounds__(256) void column_pivot(const DevSegment* segments, 
   if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; }
 }
 
+// Host loops over the result's groups: disjoint output ranges, so large results (the partitioned path hands back 10^5 .. 10^7
+// groups) are split over a few threads.
+template <typename Body>
+static void for_each_group_range(uint32_t n, Body body) {
+  const uint32_t threads = n < (1u << 19) ? 1u : std::min<uint32_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+  if (threads <= 1) { body(0u, n); return; }
+  std::vector<std::thread> workers;
+  const uint32_t per = (n + threads - 1) / threads;
+  for (uint32_t t = 0; t < threads; ++t) {
+    const uint32_t begin = std::min(n, t * per), end = std::min(n, begin + per);
+    if (begin < end) workers.emplace_back([=] { body(begin, end); });
+  }
+  for (auto& worker : workers) worker.join();
+}
+
 static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_groupby, const hy_aggregate_spec* specs, uint32_t n_aggregates,
                                hy_aggregate_result* result) {
   if (n_groupby > MAX_GROUPBY) return fail(HY_ERR_UNSUPPORTED, "more than %u GROUP BY columns stay on the CPU path", MAX_GROUPBY);
@@ -1784,8 +1814,16 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   if (out_groups > result->group_capacity) return fail(HY_ERR_CAPACITY, "aggregate produces %u groups, capacity is %u", out_groups, result->group_capacity);
   if (result->mem != HY_MEM_HOST) return fail(HY_ERR_UNSUPPORTED, "aggregate results are returned in host memory (they are ordered on the host)");
   std::vector<hy_row_id> representative(out_groups, hy_row_id{0, 0});
-  for (uint32_t o = 0; o < n_groups; ++o) representative[o] = row_id_of(shape, immediate ? h_last[order[o]] : h_first[order[o]]);
+  const RowIdOf row_id_of(shape);
+  for_each_group_range(n_groups, [&](uint32_t begin, uint32_t end) {
+    const uint64_t* rows_of_groups = immediate ? h_last.data() : h_first.data();
+    for (uint32_t o = begin; o < end; ++o) {
+      if (o + 16 < end) __builtin_prefetch(rows_of_groups + order[o + 16]);   // (the groups come in table order, the result in its own)
+      representative[o] = row_id_of(rows_of_groups[order[o]]);
+    }
+  });
   if (result->group_row_ids) std::memcpy(result->group_row_ids, representative.data(), sizeof(hy_row_id) * out_groups);
+  lap("representatives");
 
   for (uint32_t g = 0; g < n_aggregates; ++g) {
     hy_aggregate_column& col = result->columns[g];
@@ -1810,7 +1848,47 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       HY_HIP(hipMemcpyAsync(any_null.data(), d_null.ptr, n_groups, hipMemcpyDeviceToHost, stream));
       HY_HIP(hipStreamSynchronize(stream));
     }
-    for (uint32_t o = 0; o < out_groups; ++o) {
+    // the common shapes as tight loops (a result of 100 000 groups spends more time here than the device spends on the table):
+    // COUNT -> int64, SUM / AVG of a floating-point column or AVG of an integer one -> double, SUM of an integer column -> int64
+    const bool plain = out_groups == n_groups && primary[g] >= 0;
+    const uint64_t* group_values = h_values.data() + (primary[g] >= 0 ? primary[g] : 0);
+    const uint64_t* group_counts = h_counts.data() + (primary[g] >= 0 ? primary[g] : 0);
+    if (plain && function == HY_AGG_COUNT && col.data_type == HY_TYPE_LONG) {
+      for_each_group_range(out_groups, [&](uint32_t range_begin, uint32_t range_end) {
+        int64_t* out_values = static_cast<int64_t*>(col.values);
+        for (uint32_t o = range_begin; o < range_end; ++o) {
+          if (o + 16 < range_end) __builtin_prefetch(group_counts + size_t{order[o + 16]} * n_device);
+          out_values[o] = static_cast<int64_t>(group_counts[size_t{order[o]} * n_device]);
+        }
+        if (col.is_null) std::memset(col.is_null + range_begin, 0, range_end - range_begin);
+      });
+      continue;
+    }
+    if (plain && (function == HY_AGG_SUM || function == HY_AGG_AVG) && (col.data_type == HY_TYPE_DOUBLE || (function == HY_AGG_SUM && col.data_type == HY_TYPE_LONG))) {
+      const bool as_double = col.data_type == HY_TYPE_DOUBLE, divide = function == HY_AGG_AVG;
+      for_each_group_range(out_groups, [&](uint32_t range_begin, uint32_t range_end) {
+        for (uint32_t o = range_begin; o < range_end; ++o) {
+          if (o + 16 < range_end) {
+            __builtin_prefetch(group_values + size_t{order[o + 16]} * n_device);
+            __builtin_prefetch(group_counts + size_t{order[o + 16]} * n_device);
+          }
+          const size_t at = size_t{order[o]} * n_device;
+          const uint64_t bits = group_values[at], count = group_counts[at];
+          const bool is_null = count == 0;
+          if (col.is_null) col.is_null[o] = is_null;
+          if (as_double) {
+            double sum;
+            std::memcpy(&sum, &bits, 8);
+            static_cast<double*>(col.values)[o] = is_null ? 0.0 : (divide ? sum / static_cast<double>(count) : sum);
+          } else {
+            static_cast<int64_t*>(col.values)[o] = is_null ? 0 : static_cast<int64_t>(bits);
+          }
+        }
+      });
+      continue;
+    }
+    for_each_group_range(out_groups, [&](uint32_t range_begin, uint32_t range_end) {
+    for (uint32_t o = range_begin; o < range_end; ++o) {
       const bool have = o < n_groups;
       const uint64_t bits = have && primary[g] >= 0 ? h_values[size_t{order[o]} * n_device + primary[g]] : 0;
       const uint64_t count = have && primary[g] >= 0 ? h_counts[size_t{order[o]} * n_device + primary[g]] : 0;
@@ -1861,6 +1939,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
         default: static_cast<double*>(col.values)[o] = is_null ? 0.0 : vf; break;
       }
     }
+    });
   }
   lap("result written");
   return HY_OK;
