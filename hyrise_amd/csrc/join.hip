@@ -1134,14 +1134,32 @@ __device__ __forceinline__ void decode_keys(const ProbeArgs& a, uint32_t chunk, 
       for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) is_null[k] = (bits[k] >> (row[k] & 63)) & 1;
     }
     if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
-      uint32_t raw[JOIN_ROUNDS], block[JOIN_ROUNDS];
-      int32_t bias[JOIN_ROUNDS];
-      load_compressed_rows(s.data, s.width, row, raw);
+      uint32_t raw[JOIN_ROUNDS];
+      // A wave's rows (JOIN_WAVE_ROWS consecutive ones, starting at a multiple of JOIN_WAVE_ROWS inside the chunk: tiles are halves
+      // of 8192-row slices) lie in ONE 2048-row block: its minimum is a scalar load, not eight vector loads per lane.
+      static_assert(HY_FOR_BLOCK_SIZE % JOIN_WAVE_ROWS == 0 && JOIN_TILE % HY_FOR_BLOCK_SIZE == 0, "a wave's rows must not straddle FrameOfReference blocks");
+      const uint32_t wave_row = __builtin_amdgcn_readfirstlane(row_begin + (wave * JOIN_WAVE_ROWS < row_count ? wave * JOIN_WAVE_ROWS : 0u));
+      const uint32_t bias = static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[wave_row / HY_FOR_BLOCK_SIZE]);
+      if (row_count == JOIN_TILE) {   // a full tile: row k of the lane is 64 elements behind row k - 1 -- one address, immediate offsets
+        const uint32_t first = row_begin + wave * JOIN_WAVE_ROWS + lane;
+        if (s.width == 2) {
+          const uint16_t* base = static_cast<const uint16_t*>(s.data) + first;
 #pragma unroll
-      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) block[k] = row[k] / HY_FOR_BLOCK_SIZE;
-      load_rows<int32_t>(s.aux, block, bias);
+          for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) raw[k] = base[k * 64];
+        } else if (s.width == 1) {
+          const uint8_t* base = static_cast<const uint8_t*>(s.data) + first;
 #pragma unroll
-      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = static_cast<int32_t>(raw[k] + static_cast<uint32_t>(bias[k]));
+          for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) raw[k] = base[k * 64];
+        } else {
+          const uint32_t* base = static_cast<const uint32_t*>(s.data) + first;
+#pragma unroll
+          for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) raw[k] = base[k * 64];
+        }
+      } else {
+        load_compressed_rows(s.data, s.width, row, raw);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < JOIN_ROUNDS; ++k) key[k] = static_cast<int32_t>(raw[k] + bias);
     } else if (s.data_type == HY_TYPE_INT) {
       int32_t v[JOIN_ROUNDS];
       load_rows<int32_t>(s.data, row, v);
@@ -1725,11 +1743,18 @@ __device__ __forceinline__ u32x2_t rank_row_id(const ProbeArgs& a, uint32_t r) {
 }
 
 constexpr uint32_t STAGE_INVALID = 0xFFFFFFFFu;   // tag of a staging slot that holds no pair (the spare slot of a run)
-enum : int { BUILD_NONE = 0, BUILD_IDENTITY = 1, BUILD_PACKED = 2, BUILD_ROW_IDS = 3 };
+enum : int { BUILD_NONE = 0, BUILD_IDENTITY = 1, BUILD_PACKED = 2, BUILD_ROW_IDS = 3, BUILD_IDENTITY_65535 = 4 };
 
 template <int BUILD>
 __device__ __forceinline__ u32x2_t rank_row_id_as(const ProbeArgs& a, uint32_t r) {
-  if constexpr (BUILD == BUILD_IDENTITY) {
+  if constexpr (BUILD == BUILD_IDENTITY_65535) {
+    // chunks of 2^16 - 1 rows (Chunk::DEFAULT_SIZE): r = q * 65536 + low = q * 65535 + (q + low) -- shifts and adds instead of a
+    // double-precision reciprocal and two quarter-rate integer multiplies per RowID
+    uint32_t chunk = r >> 16, offset = (r & 0xFFFFu) + chunk;   // offset < 2^17
+    if (offset >= 65535u) { ++chunk; offset -= 65535u; }
+    if (offset >= 65535u) { ++chunk; offset -= 65535u; }
+    return u32x2_t{chunk, offset};
+  } else if constexpr (BUILD == BUILD_IDENTITY) {
     uint32_t chunk = static_cast<uint32_t>(static_cast<double>(r) * a.rank.identity_inverse);
     if (chunk * a.rank.identity_rows > r) --chunk;   // (the product is within one ulp of the quotient)
     uint32_t offset = r - chunk * a.rank.identity_rows;
@@ -1934,6 +1959,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void rt_probe_emit(ProbeArgs a) {
   // stores share the counter on gfx9) at the top of every iteration, as it did when the three cases shared one loop.
   const uint32_t reserved = s_tile_offset[partitions];
   if (!a.build_out) rt_copy_out<BUILD_NONE>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
+  else if (a.rank.identity_rows == 65535u) rt_copy_out<BUILD_IDENTITY_65535>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
   else if (a.rank.identity_rows) rt_copy_out<BUILD_IDENTITY>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
   else if (a.dir.ids32) rt_copy_out<BUILD_PACKED>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
   else rt_copy_out<BUILD_ROW_IDS>(a, s_stage, s_out_base, reserved, chunk, tile_row_begin, tid);
