@@ -7,9 +7,17 @@ buffers go to the device unchanged (`storage.DeviceColumn`), and columns encoded
 
 Handled: Unencoded (ValueSegment), Dictionary and FrameOfReference segments with FixedWidthInteger attribute / offset
 vectors and numeric RunLength segments, all five data types (string columns: parsed; only their dictionary-encoded form is
-scannable on the device; FixedStringDictionary segments are string dictionaries for it).  LZ4 and BitPacking vectors
-raise UnsupportedSegment (the adapter keeps such columns
-on the CPU path).
+scannable on the device; FixedStringDictionary segments are string dictionaries for it).
+
+LZ4 segments and BitPacking vectors are EXPANDED while reading, the way the residency cache expands RunLength segments: an
+LZ4Segment becomes the ValueSegment it was compressed from (the reference itself can only decompress such a segment block by
+block to scan it, lz4_segment.cpp:125-136), a BitPacking attribute / offset vector the FixedWidthInteger vector of the smallest
+width that holds its values.  The LZ4 block format is the published one (lz4.org, lz4_Block_format.md; the reference links
+liblz4, third_party/lz4: an absent submodule); the bit layout of the BitPacking container (compact::vector<uint32_t, 0, uint64_t>,
+bitpacking_vector_type.hpp:18; github.com/gmarcais/compact_vector, also absent) is a little-endian bit stream -- element i in
+bits [i b, (i + 1) b) of the 64-bit words -- PINNED here by files Hyrise wrote: the string offsets of every LZ4 string segment
+under tests/golden/bin (12 files) decode to the strings of their Unencoded twins, and LZ4MultipleBlocks.bin to the table
+binary_parser_test.cpp:247-268 spells out.
 """
 import struct
 
@@ -29,6 +37,66 @@ UINT_OF_WIDTH = {1: np.uint8, 2: np.uint16, 4: np.uint32}
 
 class UnsupportedSegment(Exception):
     pass
+
+
+def lz4_block_decode(block, size, history=b""):
+    """One LZ4 block (lz4_Block_format.md: token = literal length << 4 | match length - 4, 255-continued lengths, literals, 2-byte
+    little-endian match offset; the last sequence ends after its literals) -> `size` bytes.  `history`: the dictionary the block was
+    compressed with (LZ4_decompress_safe_usingDict, lz4_segment.cpp:217-220): matches may reach back into it."""
+    out = bytearray(history)
+    start, end, i, n = len(history), len(history) + size, 0, len(block)
+    while i < n:
+        token = block[i]
+        i += 1
+        literals = token >> 4
+        if literals == 15:
+            while True:
+                extra = block[i]
+                i += 1
+                literals += extra
+                if extra != 255:
+                    break
+        out += block[i:i + literals]
+        i += literals
+        if i >= n:
+            break                                   # the last sequence has no match
+        offset = block[i] | block[i + 1] << 8
+        i += 2
+        if offset == 0 or offset > len(out):
+            raise ValueError("corrupt LZ4 block: match offset outside the history")
+        length = (token & 15) + 4
+        if (token & 15) == 15:
+            while True:
+                extra = block[i]
+                i += 1
+                length += extra
+                if extra != 255:
+                    break
+        position = len(out) - offset
+        if offset >= length:
+            out += out[position:position + length]
+        else:                                       # overlapping match: the copied bytes feed the copy (run-length patterns)
+            for k in range(length):
+                out.append(out[position + k])
+    if len(out) != end:
+        raise ValueError(f"LZ4 block decoded to {len(out) - start} bytes, {size} expected")
+    return bytes(out[start:])
+
+
+def unpack_bits(words, bits, count):
+    """compact::vector<uint32_t, 0, uint64_t>: `count` elements of `bits` bits each, a little-endian bit stream over 64-bit words."""
+    if bits == 0 or count == 0:
+        return np.zeros(count, dtype=np.uint32)
+    stream = np.unpackbits(np.ascontiguousarray(words, dtype="<u8").view(np.uint8), bitorder="little")[:count * bits].reshape(count, bits)
+    weights = (np.uint64(1) << np.arange(bits, dtype=np.uint64))
+    return (stream.astype(np.uint64) * weights).sum(axis=1).astype(np.uint32)
+
+
+def fixed_width_of(values):
+    """(width, vector) of the FixedWidthInteger vector that holds `values` (fixed_width_integer_compressor.cpp:33-44)."""
+    top = int(values.max()) if len(values) else 0
+    width = 1 if top <= 0xFF else 2 if top <= 0xFFFF else 4
+    return width, values.astype(UINT_OF_WIDTH[width])
 
 
 class FixedStrings(list):
@@ -67,6 +135,18 @@ class _Reader:
         out = np.frombuffer(self.data, dtype=dtype, count=count, offset=self.pos).copy()
         self.pos += out.nbytes
         return out
+
+    def compact_vector(self, count):   # export_compact_vector (binary_writer.cpp:106-109): bit width, then the raw 64-bit words
+        bits = self.take("B")
+        words = (count * bits + 63) // 64
+        return unpack_bits(self.array(np.dtype("<u8"), words), bits, count)
+
+    def vector(self, vector_type, count):
+        """An attribute / offset vector of any CompressedVectorType -> (width, FixedWidthInteger values)."""
+        if vector_type == VECTOR_BIT_PACKING:
+            return fixed_width_of(self.compact_vector(count))
+        width = WIDTH_OF_VECTOR[vector_type]
+        return width, self.array(UINT_OF_WIDTH[width], count)
 
     def strings(self, count):   # export_string_values (binary_writer.cpp:48-76): size_t lengths, then the bytes back to back
         lengths = self.array(np.uint64, count)
@@ -124,10 +204,7 @@ def _read_segment(r, data_type, column_nullable, rows):
             dictionary = None
         else:
             dictionary = r.array(NUMPY_OF_TYPE[data_type], dictionary_size)
-        if vector_type not in WIDTH_OF_VECTOR:
-            raise UnsupportedSegment("BitPacking attribute vector")
-        width = WIDTH_OF_VECTOR[vector_type]
-        attribute_vector = r.array(UINT_OF_WIDTH[width], rows)
+        width, attribute_vector = r.vector(vector_type, rows)
         nulls = attribute_vector == dictionary_size     # NULL value id (dictionary_segment.cpp:139-141)
         return (HostSegment(abi.ENC_DICTIONARY, data_type, rows, width, attribute_vector, aux=dictionary, aux_size=dictionary_size), text,
                 nulls if nulls.any() else None)
@@ -137,10 +214,7 @@ def _read_segment(r, data_type, column_nullable, rows):
         raw = r.data[r.pos:r.pos + dictionary_size * length]
         r.pos += dictionary_size * length
         text = FixedStrings([raw[i * length:(i + 1) * length].rstrip(b"\0").decode("utf-8", errors="surrogateescape") for i in range(dictionary_size)], length)
-        if vector_type not in WIDTH_OF_VECTOR:
-            raise UnsupportedSegment("BitPacking attribute vector")
-        width = WIDTH_OF_VECTOR[vector_type]
-        attribute_vector = r.array(UINT_OF_WIDTH[width], rows)
+        width, attribute_vector = r.vector(vector_type, rows)
         nulls = attribute_vector == dictionary_size
         # for the device this IS a string dictionary segment: scans compare value ids the caller resolved
         return HostSegment(abi.ENC_DICTIONARY, data_type, rows, width, attribute_vector, aux=None, aux_size=dictionary_size), text, nulls if nulls.any() else None
@@ -149,10 +223,7 @@ def _read_segment(r, data_type, column_nullable, rows):
         blocks = r.take("I")
         minima = r.array(np.int32, blocks)
         nulls = r.array(np.uint8, rows).astype(bool) if r.take("B") else None
-        if vector_type not in WIDTH_OF_VECTOR:
-            raise UnsupportedSegment("BitPacking offset vector")
-        width = WIDTH_OF_VECTOR[vector_type]
-        offsets = r.array(UINT_OF_WIDTH[width], rows)
+        width, offsets = r.vector(vector_type, rows)
         words = pack_nulls(nulls) if nulls is not None else None
         return HostSegment(abi.ENC_FRAME_OF_REFERENCE, data_type, rows, width, offsets, aux=minima, aux_size=blocks, nulls=words), None, nulls
     if encoding == ENCODING_RUN_LENGTH:                  # binary_writer.hpp:146-160
@@ -166,7 +237,35 @@ def _read_segment(r, data_type, column_nullable, rows):
         width = 0 if is_string else run_values.dtype.itemsize
         return (HostSegment(abi.ENC_RUN_LENGTH, data_type, rows, width, run_values, aux=run_ends, aux_size=runs, nulls=run_nulls), text,
                 nulls if nulls.any() else None)
-    raise UnsupportedSegment({ENCODING_RUN_LENGTH: "RunLength", ENCODING_FIXED_STRING: "FixedStringDictionary", ENCODING_LZ4: "LZ4"}.get(encoding, f"encoding {encoding}"))
+    if encoding == ENCODING_LZ4:                         # binary_writer.hpp:194-223, binary_parser.cpp:263-305
+        elements, block_count, block_size, last_block_size = r.take("I"), r.take("I"), r.take("I"), r.take("I")
+        block_sizes = r.array(np.uint32, block_count)
+        blocks = []
+        for size in block_sizes:
+            blocks.append(bytes(r.data[r.pos:r.pos + int(size)]))
+            r.pos += int(size)
+        null_count = r.take("I")
+        nulls = r.array(np.uint8, null_count).astype(bool) if null_count else None
+        dictionary_bytes = r.take("I")
+        dictionary = bytes(r.data[r.pos:r.pos + dictionary_bytes])
+        r.pos += dictionary_bytes
+        offset_count = r.take("I")
+        offsets = r.compact_vector(rows) if offset_count else None
+        # every block was compressed on its own (with the dictionary, if there is one): lz4_segment.cpp:191-226
+        raw = b"".join(lz4_block_decode(block, block_size if b + 1 < block_count else last_block_size, dictionary) for b, block in enumerate(blocks))
+        if nulls is not None and not nulls.any():
+            nulls = None
+        if is_string:
+            if offsets is None:                          # only empty strings: nothing was compressed (lz4_segment.cpp:141-147)
+                values = [""] * rows
+            else:
+                ends = np.concatenate([offsets[1:].astype(np.int64), [len(raw)]])
+                values = [raw[int(b):int(e)].decode("utf-8", errors="surrogateescape") for b, e in zip(offsets, ends)]
+            return HostSegment(abi.ENC_UNENCODED, data_type, rows, 0, None), values, nulls
+        values = np.frombuffer(raw, dtype=NUMPY_OF_TYPE[data_type], count=elements).copy()
+        words = pack_nulls(nulls) if nulls is not None else None
+        return HostSegment(abi.ENC_UNENCODED, data_type, rows, values.dtype.itemsize, values, nulls=words), None, nulls
+    raise UnsupportedSegment(f"encoding {encoding}")
 
 
 def _write_strings(out, values):

@@ -43,7 +43,7 @@ BIN_REF = "/root/reference/resources/test_data/bin"
 BIN_FILES = ["SingleChunkFrameOfReferenceSegment.bin", "MultipleChunksFrameOfReferenceSegment.bin", "NullValuesFrameOfReferenceSegment.bin",
              "AllNullFrameOfReferenceSegment.bin", "SortColumnDefinitions.bin", "TwoColumnsNoValues.bin", "float.bin", "int_float.bin",
              "int_float_deleted.bin", "int_string2.bin", "FixedStringDictionarySingleChunk.bin", "FixedStringDictionaryNullValue.bin",
-             "FixedStringDictionaryMultipleChunks.bin"]
+             "FixedStringDictionaryMultipleChunks.bin", "LZ4MultipleBlocks.bin"]
 BIN_DIRS = ["AllTypesAllNullValues", "AllTypesMixColumn", "AllTypesNullValues", "AllTypesSegmentSorted", "AllTypesSegmentUnsorted",
             "EmptyStringsSegment", "MultipleChunkSingleFloatColumn", "RepeatedInt", "RunNullValues", "SingleChunkSingleFloatColumn", "StringSegment"]
 
