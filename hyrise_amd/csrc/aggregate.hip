@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     key_width[g] = key_dictionary_size[g] = key_type[g] = 0;
     if (g < a.n_groupby) {
       const DevSegment& seg = a.groupby[g].segments[slice.chunk];
+      if (seg.encoding == HY_ENC_REFERENCE) keys_unaligned = true;   // (rows behind a PosList: no direct table, no wide loads -- the hash path dereferences them)
       key_data[g] = seg.data;
       key_dictionary[g] = seg.aux;
       key_type[g] = seg.data_type;
@@ -575,7 +576,16 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       }
       uint64_t bits[GB];
       uint32_t nulls;
-      decode_rows<GB>(a.groupby[g].segments, slice.chunk, row, valid, bits, &nulls);
+      {
+        const uint32_t* pos_words;
+        const DevSegment key_segment = resolve_segment(a.groupby[g].segments[slice.chunk], &pos_words);
+        uint32_t key_row[GB];
+#pragma unroll
+        for (int i = 0; i < GB; ++i) key_row[i] = row[i];
+        const uint32_t null_rows = pos_words ? dereference_rows<GB>(pos_words, key_row) : 0u;
+        decode_rows<GB>(key_segment, a.groupby[g].segments, slice.chunk, key_row, valid, bits, &nulls);
+        nulls |= null_rows;
+      }
 #pragma unroll
       for (int i = 0; i < GB; ++i) {
         uint64_t word = bits[i];
@@ -708,7 +718,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   for (uint32_t g = 0; g < a.n_aggregates; ++g) {
     if (stamps && tid == 0 && g < 6) stamps[3 + g] = wall_clock64();
     const AggColumn c = a.aggregates[g];
-    const DevSegment value_segment = c.segments ? c.segments[slice.chunk] : DevSegment{};
+    const uint32_t* value_pos_words = nullptr;   // the slice's rows sit behind a single-chunk PosList: their offsets in the referenced segment
+    const DevSegment value_segment = c.segments ? resolve_segment(c.segments[slice.chunk], &value_pos_words) : DevSegment{};
     // what the accumulators do, decided once per aggregate (not per row)
     enum : uint32_t { ACC_NONE, ACC_MIN, ACC_MAX, ACC_ADD_INT, ACC_ADD_DOUBLE };
     uint32_t kind = ACC_NONE;
@@ -723,7 +734,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     // instead of one, and still several times faster than one LDS atomic per row into a private cell: ds_add_f64 retires
     // about one lane per cycle.
     // The usual aggregate column -- an unencoded, aligned 4-byte segment without NULLs -- skips the generic decoder.
-    const bool plain4 = c.segments && value_segment.encoding == HY_ENC_UNENCODED && !value_segment.nulls && !(value_segment.flags & SEG_UNALIGNED) &&
+    const bool plain4 = c.segments && !value_pos_words && value_segment.encoding == HY_ENC_UNENCODED && !value_segment.nulls && !(value_segment.flags & SEG_UNALIGNED) &&
                         (value_segment.data_type == HY_TYPE_INT || value_segment.data_type == HY_TYPE_FLOAT);
     uint64_t cell_value[DENSE_GROUPS];
     uint32_t cell_count[DENSE_GROUPS];   // the thread's non-NULL rows of every dense group: population counts
@@ -757,7 +768,9 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
             bits[i] = is_float ? static_cast<uint64_t>(__double_as_longlong(static_cast<double>(__uint_as_float(word)))) : static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(word)));
           }
         } else {
+          const uint32_t null_rows = value_pos_words ? dereference_rows<AB>(value_pos_words, row) : 0u;
           decode_rows<AB>(value_segment, c.segments, slice.chunk, row, members, bits, &nulls);
+          nulls |= null_rows;
         }
         if (to_ordered) {
 #pragma unroll
@@ -1021,10 +1034,16 @@ __global__ __launch_bounds__(256) void partition_rows(AggArgs a, PartitionArgs p
       }
 #pragma unroll
       for (int g = 0; g < WORDS - 1; ++g) {
-        const DevSegment segment = a.groupby[g].segments[slice.chunk];
+        const uint32_t* pos_words;
+        const DevSegment segment = resolve_segment(a.groupby[g].segments[slice.chunk], &pos_words);
+        uint32_t key_row[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) key_row[i] = row[i];
+        const uint32_t null_rows = pos_words ? dereference_rows<R>(pos_words, key_row) : 0u;
         uint64_t bits[R];
         uint32_t nulls;
-        decode_rows<R>(segment, a.groupby[g].segments, slice.chunk, row, valid, bits, &nulls);
+        decode_rows<R>(segment, a.groupby[g].segments, slice.chunk, key_row, valid, bits, &nulls);
+        nulls |= null_rows;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
           uint64_t word = bits[i];
@@ -1050,10 +1069,16 @@ __global__ __launch_bounds__(256) void partition_rows(AggArgs a, PartitionArgs p
           for (int i = 0; i < R; ++i) contribution[g][i] = 0;
           if (g >= carried) continue;
           const AggColumn c = a.aggregates[g];
-          const DevSegment segment = c.segments[slice.chunk];
+          const uint32_t* pos_words;
+          const DevSegment segment = resolve_segment(c.segments[slice.chunk], &pos_words);
+          uint32_t value_row[R];
+#pragma unroll
+          for (int i = 0; i < R; ++i) value_row[i] = row[i];
+          const uint32_t null_rows = pos_words ? dereference_rows<R>(pos_words, value_row) : 0u;
           uint64_t bits[R];
           uint32_t nulls;
-          decode_rows<R>(segment, c.segments, slice.chunk, row, valid, bits, &nulls);
+          decode_rows<R>(segment, c.segments, slice.chunk, value_row, valid, bits, &nulls);
+          nulls |= null_rows;
 #pragma unroll
           for (int i = 0; i < R; ++i) {
             contribution[g][i] = contribution_from(c, bits[i]);

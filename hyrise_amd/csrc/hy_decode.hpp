@@ -52,6 +52,31 @@ __device__ inline Value column_value(const DevSegment* segments, uint32_t chunk,
   return data_value(s.ref[r.chunk_id], r.chunk_offset);
 }
 
+// ---- ReferenceSegments whose PosList references ONE chunk (what scans, Validate and join output chunks guarantee) ------------
+// Resolved once per slice by the caller: the REFERENCED segment's descriptor (a uniform load: scalar registers) and the PosList,
+// whose offsets then replace the batch's row numbers (dereference_rows) before the batched decoder below runs on the referenced
+// segment.  *pos_words stays nullptr for data segments, for EntireChunkPosLists (rows map one to one) and for PosLists over
+// several chunks (those keep the segment as it is: the row-by-row path of decode_rows).
+__device__ __forceinline__ DevSegment resolve_segment(const DevSegment& s, const uint32_t** pos_words) {
+  *pos_words = nullptr;
+  if (s.encoding != HY_ENC_REFERENCE || s.ref_chunk_id == 0xFFFFFFFFu) return s;
+  *pos_words = static_cast<const uint32_t*>(s.data);
+  return s.ref[s.ref_chunk_id];
+}
+
+// row[i] <- chunk offset of RowID row[i] of the PosList; returns the mask of NULL RowIDs (their row becomes 0).
+template <int B>
+__device__ __forceinline__ uint32_t dereference_rows(const uint32_t* pos_words, uint32_t (&row)[B]) {
+  uint32_t null_rows = 0;
+#pragma unroll
+  for (int i = 0; i < B; ++i) row[i] = pos_words[2 * size_t{row[i]} + 1];
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    if (row[i] == 0xFFFFFFFFu) { null_rows |= 1u << i; row[i] = 0; }
+  }
+  return null_rows;
+}
+
 // ---- batched decoding: B rows of one column per call, the loads of all rows issued before any is used ----------------
 // bits[i]: the value as int64 (integer columns) or as the bits of a double (float/double columns); null bit i set for NULL.
 // `s` = segments[chunk], loaded by the caller (once for all the calls on one chunk: the descriptor is a dependent load in

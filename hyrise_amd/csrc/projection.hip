@@ -51,7 +51,15 @@ __device__ __forceinline__ uint32_t cxx_common_type(uint32_t a, uint32_t b) {
 template <int B>
 __device__ __forceinline__ void operand_rows(const Operand& o, uint32_t chunk, const uint32_t (&row)[B], uint32_t valid, uint64_t (&bits)[B], uint32_t* nulls) {
   if (o.segments) {
-    decode_rows<B>(o.segments, chunk, row, valid, bits, nulls);
+    // rows behind a single-chunk PosList (the output of a scan or a join) are read from the referenced segment at their offsets
+    const uint32_t* pos_words;
+    const DevSegment segment = resolve_segment(o.segments[chunk], &pos_words);
+    uint32_t operand_row[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) operand_row[i] = row[i];
+    const uint32_t null_rows = pos_words ? dereference_rows<B>(pos_words, operand_row) : 0u;
+    decode_rows<B>(segment, o.segments, chunk, operand_row, valid, bits, nulls);
+    *nulls |= null_rows;
     return;
   }
   uint64_t literal = 0;
