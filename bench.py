@@ -321,6 +321,25 @@ def aggregate_leg(lib, torch, steps, with_cases, with_cpu):
         info["cases"]["groups_100000"] = {"ms_per_aggregate": dt_m * 1e3, "rows_per_s": n / dt_m, "groups": int(holder["many"].n_groups), "device_ms": kernel_m,
                                           "note": "hash-partitioned path: count, scan, scatter of 32-byte records, one LDS table per partition; device_ms excludes the abandoned first attempt"}
         del many_keys
+    if with_cases:   # the plan shape of TPC-H Q1 in Hyrise: TableScan l_shipdate <= 1998-09-02, then AggregateHash over the REFERENCE table it produced
+        import torch as _torch
+        from hyrise_amd.distributed import HipExecutor
+        from hyrise_amd.operators import make_predicate
+        ex = HipExecutor(_torch.device("cuda", _torch.cuda.current_device()))
+        shipdate = DeviceColumn(storage.make_column(data.l_shipdate, None, abi.ENC_DICTIONARY))
+        predicate = make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, tpch.DAY_1998_09_02)
+
+        def run_behind_scan():
+            lists = ex.scan_chunked(shipdate, predicate)
+            keys = [ex.reference_column_chunked(c, lists) for c in groupby]
+            values = {name: ex.reference_column_chunked(c, lists) for name, c in measures.items()}
+            holder["behind_scan"] = (ex.aggregate(keys, spec(values)), lists.total)
+
+        dt_s, kernel_s = timed_kernel(lib, torch, run_behind_scan, 3)
+        info["cases"]["q1_behind_scan"] = {"ms_per_query": dt_s * 1e3, "rows_per_s": n / dt_s, "qualifying_rows": holder["behind_scan"][1],
+                                           "groups": int(holder["behind_scan"][0].n_groups), "aggregate_kernel_ms": kernel_s,
+                                           "note": "scan (PosLists stay in HBM) + five reference columns over them + aggregate through the PosLists"}
+        del shipdate
     if with_cpu:
         aggregates_host = spec(measures_host)
         info["cpu_baseline"] = cpu_baseline_aggregate(groupby_host, aggregates_host, n)
