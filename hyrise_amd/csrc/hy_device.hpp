@@ -93,6 +93,7 @@ struct hy_column {
   hy::Part* d_parts = nullptr;
   uint32_t n_parts = 0;
   uint64_t* d_row_base = nullptr;           // [n_chunks + 1] device copy of row_base
+  bool descriptors_pooled = false;          // the five descriptor tables above are pieces of ONE pooled block (column->pooled), uploaded with one copy
   std::vector<void*> owned;                 // device allocations freed with the column
   std::vector<std::pair<size_t, void*>> pooled;   // ... or handed back to the buffer pool (operator results)
 };

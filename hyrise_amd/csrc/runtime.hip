@@ -569,10 +569,6 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   column->n_slices = static_cast<uint32_t>(slices.size());
   column->n_parts = static_cast<uint32_t>(parts.size());
 
-  hipError_t err = hipMalloc(reinterpret_cast<void**>(&column->d_segments), sizeof(DevSegment) * dev.size());
-  if (err == hipSuccess) err = hipMemcpy(column->d_segments, dev.data(), sizeof(DevSegment) * dev.size(), hipMemcpyHostToDevice);
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_slices), sizeof(Slice) * (slices.size() + 1));
-  if (err == hipSuccess && !slices.empty()) err = hipMemcpy(column->d_slices, slices.data(), sizeof(Slice) * slices.size(), hipMemcpyHostToDevice);
   std::vector<SliceView> views(slices.size());
   for (size_t i = 0; i < slices.size(); ++i) {
     const hy_segment& s = column->host_segments[slices[i].chunk];
@@ -587,12 +583,32 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     if (aligned && s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !s.nulls) v.kind = VIEW_INT32;
     if (aligned && s.encoding == HY_ENC_FRAME_OF_REFERENCE && !s.nulls) v.kind = s.width == 1 ? VIEW_FOR8 : s.width == 2 ? VIEW_FOR16 : VIEW_FOR32;
   }
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_slice_views), sizeof(SliceView) * (views.size() + 1));
-  if (err == hipSuccess && !views.empty()) err = hipMemcpy(column->d_slice_views, views.data(), sizeof(SliceView) * views.size(), hipMemcpyHostToDevice);
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_row_base), 8 * (size_t{n_chunks} + 1));
-  if (err == hipSuccess) err = hipMemcpy(column->d_row_base, column->row_base.data(), 8 * (size_t{n_chunks} + 1), hipMemcpyHostToDevice);
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&column->d_parts), sizeof(Part) * (parts.size() + 1));
-  if (err == hipSuccess && !parts.empty()) err = hipMemcpy(column->d_parts, parts.data(), sizeof(Part) * parts.size(), hipMemcpyHostToDevice);
+  // The five descriptor tables travel as ONE block with ONE copy (operator chains create a reference column per operator and
+  // column: five allocations and five synchronous copies each were most of what a chain's step cost on the host).
+  auto aligned = [](size_t bytes) { return (bytes + 255) & ~size_t{255}; };
+  const size_t segments_bytes = sizeof(DevSegment) * dev.size(), slices_bytes = sizeof(Slice) * slices.size(), views_bytes = sizeof(SliceView) * views.size();
+  const size_t row_base_bytes = 8 * (size_t{n_chunks} + 1), parts_bytes = sizeof(Part) * parts.size();
+  const size_t at_slices = aligned(segments_bytes + sizeof(DevSegment)), at_views = at_slices + aligned(slices_bytes + sizeof(Slice));
+  const size_t at_row_base = at_views + aligned(views_bytes + sizeof(SliceView)), at_parts = at_row_base + aligned(row_base_bytes);
+  const size_t total = at_parts + aligned(parts_bytes + sizeof(Part));
+  std::vector<unsigned char> staging(total, 0);
+  if (segments_bytes) std::memcpy(staging.data(), dev.data(), segments_bytes);
+  if (slices_bytes) std::memcpy(staging.data() + at_slices, slices.data(), slices_bytes);
+  if (views_bytes) std::memcpy(staging.data() + at_views, views.data(), views_bytes);
+  std::memcpy(staging.data() + at_row_base, column->row_base.data(), row_base_bytes);
+  if (parts_bytes) std::memcpy(staging.data() + at_parts, parts.data(), parts_bytes);
+  void* block = nullptr;
+  size_t block_capacity = 0;
+  if (pool_acquire(total, &block, &block_capacity) != HY_OK) return cleanup(HY_ERR_DEVICE);
+  column->pooled.emplace_back(block_capacity, block);
+  column->descriptors_pooled = true;
+  unsigned char* base = static_cast<unsigned char*>(block);
+  column->d_segments = reinterpret_cast<DevSegment*>(base);
+  column->d_slices = reinterpret_cast<Slice*>(base + at_slices);
+  column->d_slice_views = reinterpret_cast<SliceView*>(base + at_views);
+  column->d_row_base = reinterpret_cast<uint64_t*>(base + at_row_base);
+  column->d_parts = reinterpret_cast<Part*>(base + at_parts);
+  const hipError_t err = hipMemcpy(block, staging.data(), total, hipMemcpyHostToDevice);
   if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "descriptor upload failed: %s", hipGetErrorString(err)));
   *out = column;
   return HY_OK;
@@ -600,13 +616,18 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
 
 hy_status hy_column_destroy(hy_column* column) {
   if (!column) return HY_OK;
+  // The descriptor block goes back to the pool and may be handed out again at once: wait for whatever still reads it (hipFree,
+  // which released the tables before they were pooled, waits for the device, too).
+  if (column->descriptors_pooled) (void)hipDeviceSynchronize();
   for (void* p : column->owned) (void)hipFree(p);
   for (auto& block : column->pooled) pool_release(block.second, block.first);
-  if (column->d_segments) (void)hipFree(column->d_segments);
-  if (column->d_slices) (void)hipFree(column->d_slices);
-  if (column->d_slice_views) (void)hipFree(column->d_slice_views);
-  if (column->d_parts) (void)hipFree(column->d_parts);
-  if (column->d_row_base) (void)hipFree(column->d_row_base);
+  if (!column->descriptors_pooled) {
+    if (column->d_segments) (void)hipFree(column->d_segments);
+    if (column->d_slices) (void)hipFree(column->d_slices);
+    if (column->d_slice_views) (void)hipFree(column->d_slice_views);
+    if (column->d_parts) (void)hipFree(column->d_parts);
+    if (column->d_row_base) (void)hipFree(column->d_row_base);
+  }
   delete column;
   return HY_OK;
 }
