@@ -258,6 +258,12 @@ class DeviceChunkedReferenceColumn:
             pass
 
 
+def _is_data_column(column):
+    """A DeviceColumn over data segments (not a reference table, not MvccData): its scan result needs no dereferencing."""
+    host = getattr(column, "host", None)
+    return host is not None and all(s.encoding not in (abi.ENC_REFERENCE, abi.ENC_MVCC) for s in host.segments)
+
+
 class HipExecutor:
     """Everything a rank computes, through libhyrise_amd.so on its GPU.  Columns are DeviceColumn / DeviceValueColumn /
     DeviceReferenceColumn / operators.ResultColumn."""
@@ -302,6 +308,10 @@ class HipExecutor:
             abi.check(self.lib.hy_table_scan(column.handle, C.byref(predicate), None, 0, C.byref(result)))
         else:
             abi.check(self.lib.hy_validate(column.handle, visibility[0], visibility[1], 1, C.byref(result)))
+        is_reference = isinstance(column, (DeviceReferenceColumn, DeviceChunkedReferenceColumn)) or getattr(getattr(column, "host", None), "is_reference", False)
+        if layout == abi.POSLIST_CHUNK_REGIONS and visibility is None and not is_reference and _is_data_column(column):
+            # a scan over a DATA table in the chunk-region layout already IS the output: chunk c's RowIDs of chunk c in its region
+            return regions, offsets, counts, None
         out = torch.empty((rows, 2), dtype=torch.int32, device=self.device)
         written = C.c_uint64(0)
         abi.check(self.lib.hy_poslist_translate(column.handle, C.byref(result), layout, out.data_ptr(), rows, C.byref(written)))
