@@ -381,22 +381,26 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   const void* key_data[MAX_GROUPBY];
   const void* key_dictionary[MAX_GROUPBY];
   uint32_t key_width[MAX_GROUPBY], key_dictionary_size[MAX_GROUPBY], key_type[MAX_GROUPBY];
+  const uint32_t* key_pos[MAX_GROUPBY];   // the slice's rows of column g sit behind a single-chunk PosList: value ids are GATHERED at its offsets
   uint32_t local_keys = 0;   // bit g: GROUP BY column g is a dictionary segment in this chunk (keyed by value id inside the slice)
   bool keys_unaligned = false;
 #pragma unroll
   for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
     key_data[g] = key_dictionary[g] = nullptr;
+    key_pos[g] = nullptr;
     key_width[g] = key_dictionary_size[g] = key_type[g] = 0;
     if (g < a.n_groupby) {
-      const DevSegment& seg = a.groupby[g].segments[slice.chunk];
-      if (seg.encoding == HY_ENC_REFERENCE) keys_unaligned = true;   // (rows behind a PosList: no direct table, no wide loads -- the hash path dereferences them)
+      // (a reference segment over one chunk is read as the referenced segment at the PosList's offsets; PosLists over several
+      //  chunks stay reference segments: hash path, row-by-row decoder)
+      const DevSegment seg = resolve_segment(a.groupby[g].segments[slice.chunk], &key_pos[g]);
+      if (seg.encoding == HY_ENC_REFERENCE) keys_unaligned = true;
       key_data[g] = seg.data;
       key_dictionary[g] = seg.aux;
       key_type[g] = seg.data_type;
       key_width[g] = seg.width;
       key_dictionary_size[g] = seg.aux_size;
       if (seg.encoding == HY_ENC_DICTIONARY) local_keys |= 1u << g;
-      if (seg.flags & SEG_UNALIGNED) keys_unaligned = true;
+      if ((seg.flags & SEG_UNALIGNED) && !key_pos[g]) keys_unaligned = true;   // (gathered value ids are read one by one: any alignment)
     }
   }
   // direct-mapped table?
@@ -435,7 +439,24 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       if (g >= a.n_groupby) continue;
       const uint32_t size = key_dictionary_size[g], stride = direct_stride[g];
       uint32_t vid[BLOCKS][GB];
-      if (key_width[g] == 1) {
+      if (key_pos[g]) {   // behind a PosList: the offsets of the thread's 32 rows (one batch of loads), then their value ids (another)
+        uint32_t offset[BLOCKS][GB];
+#pragma unroll
+        for (uint32_t block = 0; block < BLOCKS; ++block) {
+          const uint32_t r0 = slice_row(block * GB, tid);
+#pragma unroll
+          for (int i = 0; i < GB; ++i) offset[block][i] = key_pos[g][2 * size_t{slice.row_begin + (r0 + i < slice.row_count ? r0 + i : 0)} + 1];
+        }
+#pragma unroll
+        for (uint32_t block = 0; block < BLOCKS; ++block) {
+#pragma unroll
+          for (int i = 0; i < GB; ++i) {
+            const bool null_row = offset[block][i] == 0xFFFFFFFFu;   // NULL_ROW_ID (an outer join's output): a NULL key
+            const uint32_t id = aload_compressed(key_data[g], key_width[g], null_row ? 0u : offset[block][i]);
+            vid[block][i] = null_row ? size : id;
+          }
+        }
+      } else if (key_width[g] == 1) {
         const global_u32* base = reinterpret_cast<const global_u32*>(reinterpret_cast<uintptr_t>(key_data[g]));
         uint32_t word[BLOCKS];
 #pragma unroll
@@ -545,7 +566,13 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       if (g >= a.n_groupby || !((local_keys >> g) & 1)) continue;
       // the block's four rows are consecutive and start at a multiple of four: one aligned load of all four value ids
       // (not for the group that straddles the end of the chunk: nothing may be read behind a caller's buffer)
-      if (key_width[g] == 1 && valid == 0xF) {
+      if (key_pos[g]) {
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+          const uint32_t offset = key_pos[g][2 * size_t{row[i]} + 1];
+          vid[g][i] = offset == 0xFFFFFFFFu ? key_dictionary_size[g] : aload_compressed(key_data[g], key_width[g], offset);
+        }
+      } else if (key_width[g] == 1 && valid == 0xF) {
         const uint32_t four = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(key_data[g]) + row[0]);
 #pragma unroll
         for (int i = 0; i < GB; ++i) vid[g][i] = (four >> (8 * i)) & 0xFF;
