@@ -3097,9 +3097,9 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   }
   if (n_tiles && rank_path) {   // (every pass 2 kernel returns at once if the plan says that the result does not fit)
     a.lane_ordered_atomics = lds_atomics_are_lane_ordered(stream) ? 1u : 0u;
-    profile_begin(stream);
-    hipLaunchKernelGGL(rt_probe_emit, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * rt_probe_emit_lds_words(partitions), stream, a);
-    profile_end(stream);
+    hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself: event records around the launch add the gaps to its neighbours)
+    profile_events(&started, &stopped);
+    hipExtLaunchKernelGGL(rt_probe_emit, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * rt_probe_emit_lds_words(partitions), stream, started, stopped, 0, a);
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
     if (cut_grid) hipLaunchKernelGGL(rt_probe_cuts, dim3(cut_grid), dim3(JOIN_THREADS), 0, stream, a, dev_first_cell, n_groups);
   } else if (n_tiles) {
