@@ -161,3 +161,33 @@ def test_oracle_column_vs_column():
                            abi.PRED_GREATER_THAN: left > right, abi.PRED_GREATER_THAN_EQUALS: left >= right}
                     expected = expected_result_from_mask(ops[condition] & ~lnull & ~rnull, chunk)
                     np.testing.assert_array_equal(result.matches[:result.total], expected)
+
+
+def test_string_date_twin_scans_like_the_int_column():
+    """l_shipdate as DictionarySegment<pmr_string> of ISO dates (the reference's TPC-H schema, tpch_table_generator.cpp:46): the literal is
+    resolved per chunk on the host (operators.string_predicate: lower_bound / upper_bound in the chunk's dictionary,
+    column_vs_value_table_scan_impl.cpp:211-226, column_between_table_scan_impl.cpp:112-124) and the scan over value ids gives the
+    PosLists, counts and early-out states of the same scan over the int twin."""
+    from hyrise_amd import tpch
+    from hyrise_amd.operators import string_predicate
+    data = tpch.TpchData(scale_factor=0.05, seed=3)
+    ints = storage.make_column(data.l_shipdate, None, abi.ENC_DICTIONARY, 20_000)
+    strings, dictionaries = tpch.string_date_column(ints)
+    assert strings.data_type == abi.TYPE_STRING and dictionaries[0][0] < dictionaries[0][-1] and len(dictionaries[0][0]) == 10
+    cases = [(abi.PRED_LESS_THAN, "1995-01-01", None, tpch.DAY_1995_01_01, None), (abi.PRED_LESS_THAN_EQUALS, "1998-09-02", None, tpch.DAY_1998_09_02, None),
+             (abi.PRED_GREATER_THAN, "1995-06-17", None, tpch.CURRENT_DATE, None), (abi.PRED_GREATER_THAN_EQUALS, "1992-01-01", None, 0, None),
+             (abi.PRED_EQUALS, "1995-06-17", None, tpch.CURRENT_DATE, None), (abi.PRED_NOT_EQUALS, "1995-06-17", None, tpch.CURRENT_DATE, None),
+             (abi.PRED_EQUALS, "1995-06-17x", None, None, None),                                        # a literal that is in no dictionary
+             (abi.PRED_BETWEEN_INCLUSIVE, "1994-01-01", "1994-12-31", tpch.DAY_1994_01_01, tpch.DAY_1995_01_01 - 1),
+             (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, "1994-01-01", "1995-01-01", tpch.DAY_1994_01_01, tpch.DAY_1995_01_01),
+             (abi.PRED_BETWEEN_LOWER_EXCLUSIVE, "1993-12-31", "1994-12-31", tpch.DAY_1994_01_01 - 1, tpch.DAY_1995_01_01 - 1),
+             (abi.PRED_BETWEEN_EXCLUSIVE, "1993-12-31", "1995-01-01", tpch.DAY_1994_01_01 - 1, tpch.DAY_1995_01_01)]
+    for condition, a, b, ia, ib in cases:
+        got = oracle_scan(strings, string_predicate(condition, dictionaries, a, b))
+        if ia is None:
+            assert got.total == 0
+            continue
+        want = oracle_scan(ints, make_predicate(condition, abi.TYPE_INT, ia, ib))
+        assert got.total == want.total and got.matches[:got.total].tobytes() == want.matches[:want.total].tobytes(), condition
+        np.testing.assert_array_equal(got.counts, want.counts)
+        np.testing.assert_array_equal(got.chunk_state, want.chunk_state)
