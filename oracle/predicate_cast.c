@@ -68,18 +68,21 @@ static int lossless_cast(uint32_t source_type, const hy_value* in, uint32_t targ
   }
 }
 
-/* lossless_predicate_cast.cpp:14-38 */
+/* lossless_predicate_cast.cpp:14-38: the float next to the double `value` on the side of `towards` -- the rounded float itself when
+ * rounding already went that way, else its neighbour in that direction; nothing for values outside the float range, for
+ * value == towards, and when the neighbour is not finite. */
 int hyo_next_float_towards(double value, double towards, float* out) {
-  if (value > FLOAT_LIMIT || value < -FLOAT_LIMIT) return 0;
-  if (value == towards) return 0;
-  const float casted_value = (float)value;
-  if (((double)casted_value < value && towards < value) || ((double)casted_value > value && towards > value)) {
-    *out = casted_value;
+  if (value > FLOAT_LIMIT || value < -FLOAT_LIMIT || value == towards) return 0;
+  const float rounded = (float)value;
+  const int downwards = towards < value;
+  const int rounded_down = (double)rounded < value, rounded_up = (double)rounded > value;
+  if ((downwards && rounded_down) || (!downwards && rounded_up)) {
+    *out = rounded;
     return 1;
   }
-  const float next = nexttowardf(casted_value, (long double)towards);
-  if (!isfinite(next)) return 0;
-  *out = next;
+  const float neighbour = nexttowardf(rounded, (long double)towards);
+  if (!isfinite(neighbour)) return 0;
+  *out = neighbour;
   return 1;
 }
 
