@@ -68,3 +68,47 @@ SCAN_FOR_NULL_VALUES = {
 
 # table_scan_test.cpp:296-302  SingleScan: int_float.tbl `a >= 1234` == int_float_filtered2.tbl
 # table_scan_test.cpp:330-342 (DoubleScan): `a >= 1234` then `b < 457.9` == int_float_filtered.tbl
+
+# table_scan_between_test.cpp:194-243  (lower bound, upper bound, expected values of column b).  The table (set-up at
+# :40-96): column a = cast<ColumnType>(10.25 + 2 i) for i = 0..10 (30.25 - 2 i when sorted descending), column b = row
+# index, chunk size 6 with the first two chunks encoded and the last left unencoded; nullable + unsorted: every i with
+# i % 3 == 2 is NULL; nullable + sorted: three NULL rows in front.  Both bounds are cast to the column type (:146-147),
+# so an int column sees BETWEEN 12 AND 16 for (12.25, 16.75) -- the lists hold for int, long, float and double alike.
+BETWEEN_TESTS = {
+    abi.PRED_BETWEEN_INCLUSIVE: [
+        (12.25, 16.25, [1, 2, 3]), (12.0, 16.25, [1, 2, 3]), (12.25, 16.75, [1, 2, 3]), (12.0, 16.75, [1, 2, 3]),
+        (0.0, 16.75, [0, 1, 2, 3]), (16.0, 50.75, [3, 4, 5, 6, 7, 8, 9, 10]), (13.0, 16.25, [2, 3]),
+        (12.25, 15.0, [1, 2]), (0.25, 50.75, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]), (0.25, 0.75, []),
+    ],
+    abi.PRED_BETWEEN_LOWER_EXCLUSIVE: [(11.0, 16.25, [1, 2, 3]), (12.25, 16.25, [2, 3]), (13.0, 16.25, [2, 3])],
+    abi.PRED_BETWEEN_UPPER_EXCLUSIVE: [(12.25, 17.0, [1, 2, 3]), (12.25, 16.25, [1, 2]), (12.25, 15.0, [1, 2])],
+    abi.PRED_BETWEEN_EXCLUSIVE: [
+        (12.25, 16.25, [2]), (11.0, 16.25, [1, 2]), (12.25, 17.0, [2, 3]), (11.0, 17.0, [1, 2, 3]), (13.0, 16.25, [2]),
+        (12.25, 15.0, [2]), (13.0, 15.0, [2]),
+    ],
+}
+BETWEEN_SORT_MODES = ["unsorted", "ascending", "descending"]
+
+
+def between_table(np_type, sort_mode, nullable):
+    """(values of column a, NULL mask or None, values of column b): table_scan_between_test.cpp:40-78."""
+    import numpy as np
+    leading_nulls = 3 if (nullable and sort_mode != "unsorted") else 0
+    a, nulls, b = [0] * leading_nulls, [True] * leading_nulls, list(range(leading_nulls))
+    for i in range(11):
+        value = 30.25 - 2.0 * i if sort_mode == "descending" else 10.25 + 2.0 * i
+        null = nullable and sort_mode == "unsorted" and i % 3 == 2
+        a.append(0 if null else np_type(int(value)) if np.issubdtype(np_type, np.integer) else np_type(value))
+        nulls.append(null)
+        b.append(i + leading_nulls)
+    return np.array(a, dtype=np_type), (np.array(nulls, dtype=bool) if nullable else None), np.array(b, dtype=np.int32)
+
+
+def between_expected(expected, sort_mode, nullable):
+    """table_scan_between_test.cpp:167-191: the index lists above moved to where the rows are in this variant."""
+    leading_nulls = 3 if (nullable and sort_mode != "unsorted") else 0
+    if sort_mode == "descending":
+        return sorted(10 + leading_nulls - x for x in expected)
+    if sort_mode == "ascending":
+        return [x + leading_nulls for x in expected]
+    return [x for x in expected if not (nullable and x % 3 == 2)]

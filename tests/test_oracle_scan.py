@@ -191,3 +191,38 @@ def test_string_date_twin_scans_like_the_int_column():
         assert got.total == want.total and got.matches[:got.total].tobytes() == want.matches[:want.total].tobytes(), condition
         np.testing.assert_array_equal(got.counts, want.counts)
         np.testing.assert_array_equal(got.chunk_state, want.chunk_state)
+
+
+BETWEEN_TYPES = [np.int32, np.int64, np.float32, np.float64]
+
+
+def between_column(a, nulls, encoding, nullable):
+    """Chunk size 6, the two full chunks encoded, the third left as it was appended (table_scan_between_test.cpp:88-92).
+    RunLength segments are expanded the way the residency cache expands them on upload (the oracle reads plain segments)."""
+    if encoding != abi.ENC_RUN_LENGTH:
+        return build_column(a, nulls, 6, [encoding, encoding], nullable=nullable)
+    plain = build_column(a, nulls, 6, abi.ENC_UNENCODED, nullable=nullable)
+    runs = [storage.encode_run_length(a[c * 6:c * 6 + 6], None if nulls is None else nulls[c * 6:c * 6 + 6]) for c in range(2)]
+    return storage.expand_run_length(storage.HostColumn(runs + plain.segments[2:], plain.data_type))
+
+
+@pytest.mark.parametrize("np_type", BETWEEN_TYPES, ids=lambda t: t.__name__)
+@pytest.mark.parametrize("encoding", ENCODINGS + [abi.ENC_RUN_LENGTH], ids=ENC_IDS + ["RunLength"])
+@pytest.mark.parametrize("sort_mode", KA.BETWEEN_SORT_MODES)
+@pytest.mark.parametrize("nullable", [False, True], ids=["not_null", "nullable"])
+def test_between_known_answers(np_type, encoding, sort_mode, nullable):
+    """table_scan_between_test.cpp:194-243 (Inclusive / LowerExclusive / UpperExclusive / Exclusive) over its
+    create_test_params() grid of numeric types x encodings x sort modes x nullability."""
+    if encoding == abi.ENC_FRAME_OF_REFERENCE and np_type != np.int32:
+        pytest.skip("encoding_supports_data_type(): FrameOfReference holds int only")
+    a, nulls, b = KA.between_table(np_type, sort_mode, nullable)
+    column = between_column(a, nulls, encoding, nullable)
+    data_type = storage.TYPE_OF_NP[np.dtype(np_type)]
+    cast = (lambda x: np_type(int(x))) if np.issubdtype(np_type, np.integer) else np_type   # static_cast<ColumnDataType>
+    for condition, tests in KA.BETWEEN_TESTS.items():
+        for lower, upper, expected in tests:
+            p = make_predicate(condition, data_type, cast(lower), cast(upper), nullable=nullable)
+            rows = np.array([c * 6 + o for c, o in result_rows(oracle_scan(column, p))], dtype=np.int64)
+            assert sorted(b[rows].tolist()) == KA.between_expected(expected, sort_mode, nullable), \
+                f"condition {condition} BETWEEN {lower} AND {upper}"
+

@@ -403,3 +403,30 @@ def test_poslist_translate(device):
     host_result = abi.ScanResult()
     host_result.mem = abi.MEM_HOST
     assert device.hy_poslist_translate(base_dev.handle, C.byref(host_result), abi.POSLIST_DENSE, small.pointer, 16, C.byref(written)) == abi.ERR_INVALID
+
+
+@pytest.mark.parametrize("np_type", [np.int32, np.int64, np.float32, np.float64], ids=lambda t: t.__name__)
+@pytest.mark.parametrize("encoding", ENCODINGS + [abi.ENC_RUN_LENGTH], ids=["Unencoded", "Dictionary", "FrameOfReference", "RunLength"])
+@pytest.mark.parametrize("sort_mode", KA.BETWEEN_SORT_MODES)
+@pytest.mark.parametrize("nullable", [False, True], ids=["not_null", "nullable"])
+def test_between_known_answers(device, np_type, encoding, sort_mode, nullable):
+    """table_scan_between_test.cpp:194-243 on the device: the reference's expected row lists, and the oracle's PosLists."""
+    if encoding == abi.ENC_FRAME_OF_REFERENCE and np_type != np.int32:
+        pytest.skip("encoding_supports_data_type(): FrameOfReference holds int only")
+    a, nulls, b = KA.between_table(np_type, sort_mode, nullable)
+    if encoding == abi.ENC_RUN_LENGTH:   # uploaded as the ValueSegments they decode to (storage.expand_run_length)
+        plain = build_column(a, nulls, 6, abi.ENC_UNENCODED, nullable=nullable)
+        runs = [storage.encode_run_length(a[c * 6:c * 6 + 6], None if nulls is None else nulls[c * 6:c * 6 + 6]) for c in range(2)]
+        host = storage.expand_run_length(storage.HostColumn(runs + plain.segments[2:], plain.data_type))
+    else:
+        host = build_column(a, nulls, 6, [encoding, encoding], nullable=nullable)
+    dev = DeviceColumn(host)
+    data_type = storage.TYPE_OF_NP[np.dtype(np_type)]
+    cast = (lambda x: np_type(int(x))) if np.issubdtype(np_type, np.integer) else np_type
+    for condition, tests in KA.BETWEEN_TESTS.items():
+        for lower, upper, expected in tests:
+            p = make_predicate(condition, data_type, cast(lower), cast(upper), nullable=nullable)
+            got = check(host, p, dev, context=f"condition {condition} BETWEEN {lower} AND {upper}")
+            rows = np.array([c * 6 + o for c, o in result_rows(got)], dtype=np.int64)
+            assert sorted(b[rows].tolist()) == KA.between_expected(expected, sort_mode, nullable)
+
