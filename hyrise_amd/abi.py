@@ -82,6 +82,28 @@ class AggregateSpec(C.Structure):
     _fields_ = [("function", C.c_uint32), ("column", C.c_void_p)]
 
 
+EXPR_COLUMN, EXPR_LITERAL, EXPR_ARITHMETIC = range(3)
+MAX_EXPRESSION_NODES, MAX_FILTERS = 12, 4
+
+
+class ExpressionNode(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("op", C.c_uint32), ("column", C.c_void_p), ("literal_type", C.c_uint32), ("reserved", C.c_uint32),
+                ("literal", Value)]
+
+
+class Expression(C.Structure):
+    """hy_expression: postfix, at most three stack slots."""
+    _fields_ = [("n_nodes", C.c_uint32), ("reserved", C.c_uint32), ("nodes", ExpressionNode * MAX_EXPRESSION_NODES)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("column", C.c_void_p), ("predicate", Predicate)]
+
+
+class FusedAggregate(C.Structure):
+    _fields_ = [("function", C.c_uint32), ("reserved", C.c_uint32), ("input", C.POINTER(Expression))]
+
+
 class AggregateColumn(C.Structure):
     _fields_ = [("data_type", C.c_uint32), ("reserved", C.c_uint32), ("values", C.c_void_p), ("is_null", C.c_void_p)]
 
@@ -126,6 +148,8 @@ SYMBOLS = [
     ("hy_join_hash_count", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("hy_aggregate_hash", C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(AggregateSpec), C.c_uint32,
                                       C.POINTER(AggregateResult)]),
+    ("hy_scan_project_aggregate", C.c_int32, [C.POINTER(Filter), C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(FusedAggregate), C.c_uint32,
+                                              C.POINTER(AggregateResult)]),
     ("hy_column_export", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("hy_repartition_count", C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("hy_repartition_pack", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -24,12 +24,15 @@
 // sequential loop, so those results are compared with a stated tolerance (1e-9 relative); everything else is exact.
 #include "hy_device.hpp"
 #include "hy_decode.hpp"
+#include "hy_arithmetic.hpp"
+#include "hy_scan_job.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -98,6 +101,23 @@ __device__ __forceinline__ uint64_t hash_tuple(const uint64_t* tuple, uint32_t w
   return (static_cast<uint64_t>(h2) << 32) | h1;
 }
 
+// hash_tuple of a tuple held in registers (static indices only)
+__device__ __forceinline__ uint64_t hash_tuple_in_registers(const uint64_t (&tuple)[MAX_GROUPBY + 1], uint32_t words) {
+  uint32_t h1 = 0x9E3779B9u, h2 = 0x85EBCA6Bu;
+#pragma unroll
+  for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) {
+    if (w >= words) continue;
+    const uint32_t lo = static_cast<uint32_t>(tuple[w]), hi = static_cast<uint32_t>(tuple[w] >> 32);
+    h1 = (h1 ^ lo) * 0x9E3779B1u;
+    h1 = (h1 ^ (h1 >> 15) ^ hi) * 0x85EBCA77u;
+    h2 = (h2 ^ hi) * 0xC2B2AE3Du;
+    h2 = (h2 ^ (h2 >> 13) ^ lo) * 0x27D4EB2Fu;
+  }
+  h1 ^= h1 >> 16;
+  h2 ^= h2 >> 15;
+  return (static_cast<uint64_t>(h2) << 32) | h1;
+}
+
 // Hash for the workgroup's LDS table only (computed for every row): fold the words with rotates and xors, then two
 // multiplies -- 32-bit multiplies run at quarter rate, the per-word mixing of hash_tuple costs more than the lookup itself.
 // Structured tuples may collide here; that costs probes in a 256-slot table, never correctness.
@@ -127,7 +147,7 @@ __device__ __forceinline__ uint64_t initial_value(uint32_t function) {
 // lanes of one wave run in lockstep, so the holder could be masked off behind the spinning lane forever.  Every
 // iteration of the single retry loop either finishes the whole critical section (claim, initialise, publish) or makes
 // no blocking step at all; a lane that finds a slot locked simply goes around again.
-__device__ uint32_t global_slot(const AggArgs& a, const uint64_t* tuple, uint32_t words, uint64_t hash) {
+__device__ __forceinline__ uint32_t global_slot(const AggArgs& a, const uint64_t* tuple, uint32_t words, uint64_t hash) {
   const uint32_t ready = 0x80000000u | static_cast<uint32_t>(hash >> 33);
   uint32_t slot = static_cast<uint32_t>(hash) & (a.capacity - 1);
   uint32_t probes = 0;
@@ -1329,6 +1349,707 @@ __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, Partition
   }
 }
 
+// ---- fused TableScan(s) -> Projection -> AggregateHash (hy_scan_project_aggregate) ----------------------------------------------
+// One pass over a data table: a row is tested against every filter (the per-chunk jobs prepare_jobs normalised for hy_table_scan),
+// the aggregates' input expressions are evaluated for the rows that pass, and the results go to the accumulators of the
+// row's group -- a workgroup-private LDS table like aggregate_partitions', merged into the global table at the end of the
+// slice.  No PosList, no expression column: what the chain writes to HBM and reads back (8 bytes per surviving row and scan,
+// 4-8 bytes per row and expression, twice) never exists.  One workgroup per 8192-row slice; every wave owns a quarter of it:
+//   scan      the filters, in plan order, over the wave's 2048 rows at once: a lane takes rows k * 64 + lane (k = 0..31), the 32
+//             loads of a filter are in flight together (one memory round trip per filter and slice, not per row batch).
+//   compact   the surviving rows' numbers, in row order, into the wave's list in LDS (ballot + mbcnt: no atomics, no barrier).
+//             A selective plan (TPC-H Q6: 2 % of the rows) does everything below on full waves of SURVIVORS.
+//   rows      FUSED_ROWS list entries per lane and batch.  GROUP BY columns first -- all their loads issued before any is used
+//             (decode_columns) -- tuples of VALUES (a slice may hold any mix of encodings) into the workgroup's 256-slot table;
+//             rows whose group does not fit go to the global table directly.  Then the distinct columns the expressions read,
+//             decoded ONCE per batch the same way; the expressions run on registers.
+//   accumulate  a wave's rows of one i usually belong to a handful of groups (TPC-H Q1: four in the table; Q6: one): up to
+//             FUSED_LEADERS groups per wave and i are reduced across the wave with DPP moves and cost ONE LDS atomic per aggregate;
+//             further groups use LDS atomics per row (many groups: few conflicts).
+constexpr uint32_t FUSED_LDS_SLOTS = 128;
+constexpr int FUSED_ROWS = 2;
+constexpr int FUSED_COLUMNS = 6;                    // distinct columns the aggregates' inputs may read
+constexpr uint32_t FUSED_WAVE_ROWS = SLICE_ROWS / 4;   // 2048
+constexpr uint32_t FUSED_VIEWS = HY_MAX_FILTERS + MAX_GROUPBY + FUSED_COLUMNS;
+constexpr uint32_t FUSED_DENSE = 4;    // groups (the first the chunk meets) whose accumulators are spread over ...
+constexpr uint32_t FUSED_CELLS = 16;   // ... this many copies each
+constexpr int FUSED_WAVES = 4;         // waves per SIMD the register allocation aims at
+
+struct FusedNode {
+  uint64_t literal;             // HY_EXPR_LITERAL: the int64 value, the float's bits (low word) or the double's bits
+  uint32_t kind;                // HY_EXPR_*
+  uint32_t op;                  // HY_ARITH_*
+  uint32_t type;                // result type of the node (HY_TYPE_NULL: the NULL literal)
+  uint32_t column;              // HY_EXPR_COLUMN: index into FusedPlan::columns
+};
+struct FusedInput {             // input of one device accumulator, postfix
+  FusedNode nodes[HY_MAX_EXPRESSION_NODES];
+  uint32_t n_nodes;             // 0: COUNT(*)
+  uint32_t type;
+};
+struct FusedFilter {
+  const DevSegment* segments;
+  const ScanJob* jobs;          // [n_chunks]
+};
+struct FusedPlan {
+  FusedFilter filters[HY_MAX_FILTERS];
+  const DevSegment* columns[FUSED_COLUMNS];
+  FusedInput inputs[MAX_AGGREGATES];
+  uint32_t n_filters;
+  uint32_t n_columns;
+  uint32_t lds_slots;           // of the workgroup's group table: FUSED_LDS_SLOTS, or a handful without GROUP BY (one group)
+  uint32_t debug;               // HY_FUSED_DEBUG (timing experiments): 1 no accumulation, 2 no expressions, 4 no input columns, 8 no GROUP BY lookups, 16 scans only
+};
+enum : uint32_t { FLAG_PASSED = 4 };   // (two words: rows that passed the filters, the row count of the chain's aggregate input)
+
+// What the kernel needs of a data segment, staged in LDS once per workgroup (a slice is one chunk): read through the descriptor
+// tables in global memory these are vector loads of 48 bytes in front of every batch of data loads -- and twelve registers each.
+struct ColumnView {
+  const void* data;
+  const void* aux;
+  const uint64_t* nulls;
+  uint32_t aux_size;
+  uint8_t encoding, data_type, width, present;
+};
+__device__ __forceinline__ ColumnView view_of(const DevSegment& s) {
+  return ColumnView{s.data, s.aux, s.nulls, s.aux_size, s.encoding, s.data_type, s.width, 1};
+}
+// a value every lane holds alike, moved to a scalar register: branches on it are scalar branches
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+template <typename T>
+__device__ __forceinline__ const T* uniform(const T* p) {
+  const uint64_t bits = reinterpret_cast<uint64_t>(p);
+  return reinterpret_cast<const T*>(static_cast<uint64_t>(uniform(static_cast<uint32_t>(bits >> 32))) << 32 | uniform(static_cast<uint32_t>(bits)));
+}
+__device__ __forceinline__ ColumnView uniform(const ColumnView& v) {
+  const uint32_t shape = uniform(static_cast<uint32_t>(v.encoding) | static_cast<uint32_t>(v.data_type) << 8 | static_cast<uint32_t>(v.width) << 16 | static_cast<uint32_t>(v.present) << 24);
+  return ColumnView{uniform(v.data), uniform(v.aux), uniform(v.nulls), uniform(v.aux_size), static_cast<uint8_t>(shape), static_cast<uint8_t>(shape >> 8), static_cast<uint8_t>(shape >> 16),
+                    static_cast<uint8_t>(shape >> 24)};
+}
+__device__ __forceinline__ ScanJob uniform(const ScanJob& j) {
+  ScanJob u;
+  u.mode = uniform(j.mode); u.kind = uniform(j.kind); u.flags = uniform(j.flags); u.null_vid = uniform(j.null_vid);
+  u.lo = static_cast<uint64_t>(uniform(static_cast<uint32_t>(j.lo >> 32))) << 32 | uniform(static_cast<uint32_t>(j.lo));
+  u.span = static_cast<uint64_t>(uniform(static_cast<uint32_t>(j.span >> 32))) << 32 | uniform(static_cast<uint32_t>(j.span));
+  return u;
+}
+
+// One row of a data segment against its chunk's job (what eval_row of scan.hip decides for JOB_SCAN jobs of data segments).
+__device__ __forceinline__ bool filter_row(const ColumnView& s, const ScanJob& job, uint32_t row) {
+  const bool invert = job.flags & JF_INVERT;
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    const uint32_t vid = aload_compressed(s.data, s.width, row);
+    if (job.kind == KIND_VALUE_ID_SET) return vid < job.null_vid && ((reinterpret_cast<const uint64_t*>(job.lo)[vid >> 6] >> (vid & 63)) & 1) != 0;
+    const bool in = (vid - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+    return (in != invert) && vid != job.null_vid;   // (the NULL test itself: null_vid = 0xFFFFFFFF)
+  }
+  const bool is_null = s.nulls ? ((s.nulls[row >> 6] >> (row & 63)) & 1) != 0 : false;
+  if (job.kind == KIND_NULLTEST) return is_null != invert;
+  if (is_null) return false;   // NULL never matches a comparison
+  bool in;
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+    const uint32_t x = aload_compressed(s.data, s.width, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]);
+    in = (x - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+  } else if (job.kind == KIND_U32) {
+    in = (static_cast<const uint32_t*>(s.data)[row] - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+  } else if (job.kind == KIND_I64) {
+    in = (static_cast<const uint64_t*>(s.data)[row] - job.lo) <= job.span;
+  } else if (job.kind == KIND_F32) {
+    const float x = static_cast<const float*>(s.data)[row];
+    const float lower = __uint_as_float(static_cast<uint32_t>(job.lo)), upper = __uint_as_float(static_cast<uint32_t>(job.span));
+    in = ((job.flags & JF_LOWER_INCL) ? x >= lower : x > lower) && ((job.flags & JF_UPPER_INCL) ? x <= upper : x < upper);
+  } else {
+    const double x = static_cast<const double*>(s.data)[row];
+    const double lower = __longlong_as_double(static_cast<long long>(job.lo)), upper = __longlong_as_double(static_cast<long long>(job.span));
+    in = ((job.flags & JF_LOWER_INCL) ? x >= lower : x > lower) && ((job.flags & JF_UPPER_INCL) ? x <= upper : x < upper);
+  }
+  return in != invert;
+}
+
+// The filter over a wave's part of the slice: bit k = row first_row + k * 64 + lane matches (rows at or behind n_rows: undefined, the
+// caller masks them).  Stored words of at most four bytes -- value ids, FrameOfReference offsets, int / float values -- are loaded
+// sixteen rows at a time before the first is tested; 8-byte values and value-id sets go row by row.
+__device__ __forceinline__ uint32_t filter_wave_rows(const ColumnView& s, const ScanJob& job, uint32_t first_row, uint32_t lane, uint32_t n_rows) {
+  constexpr int K = static_cast<int>(FUSED_WAVE_ROWS / 64), B = 16;
+  const bool invert = job.flags & JF_INVERT;
+  const bool words = s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE || job.kind == KIND_U32 || job.kind == KIND_F32 || job.kind == KIND_NULLTEST;
+  uint32_t bits = 0;
+  if (!words || job.kind == KIND_VALUE_ID_SET) {
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const uint32_t r = static_cast<uint32_t>(k) * 64 + lane;
+      if (r < n_rows && filter_row(s, job, first_row + r)) bits |= 1u << k;
+    }
+    return bits;
+  }
+  const uint32_t width = (s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE) ? s.width : 4u;
+  const uint32_t lo = static_cast<uint32_t>(job.lo), span = static_cast<uint32_t>(job.span), null_vid = job.null_vid;
+  const float lower = __uint_as_float(lo), upper = __uint_as_float(span);
+  const bool lower_inclusive = job.flags & JF_LOWER_INCL, upper_inclusive = job.flags & JF_UPPER_INCL;
+#pragma unroll 1
+  for (int k0 = 0; k0 < K; k0 += B) {
+    if (static_cast<uint32_t>(k0) * 64 >= n_rows) break;
+    uint32_t row[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      const uint32_t r = static_cast<uint32_t>(k0 + k) * 64 + lane;
+      row[k] = first_row + (r < n_rows ? r : 0);
+    }
+    uint32_t null_bits = 0, round = 0;
+    if (s.encoding != HY_ENC_DICTIONARY && s.nulls) {
+      uint64_t word[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) word[k] = s.nulls[row[k] >> 6];
+#pragma unroll
+      for (int k = 0; k < B; ++k) null_bits |= static_cast<uint32_t>((word[k] >> (row[k] & 63)) & 1) << k;
+    }
+    if (job.kind == KIND_NULLTEST && s.encoding != HY_ENC_DICTIONARY) {
+      bits |= ((invert ? ~null_bits : null_bits) & 0xFFFFu) << k0;
+      continue;
+    }
+    uint32_t raw[B];
+    if (width == 1) {
+#pragma unroll
+      for (int k = 0; k < B; ++k) raw[k] = static_cast<const uint8_t*>(s.data)[row[k]];
+    } else if (width == 2) {
+#pragma unroll
+      for (int k = 0; k < B; ++k) raw[k] = static_cast<const uint16_t*>(s.data)[row[k]];
+    } else {
+#pragma unroll
+      for (int k = 0; k < B; ++k) raw[k] = static_cast<const uint32_t*>(s.data)[row[k]];
+    }
+    if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+      uint32_t bias[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) bias[k] = static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row[k] / HY_FOR_BLOCK_SIZE]);
+#pragma unroll
+      for (int k = 0; k < B; ++k) raw[k] += bias[k];
+    }
+    if (s.encoding == HY_ENC_DICTIONARY) {
+#pragma unroll
+      for (int k = 0; k < B; ++k) round |= ((((raw[k] - lo) <= span) != invert) && raw[k] != null_vid ? 1u : 0u) << k;
+    } else {
+      if (job.kind == KIND_F32) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+          const float x = __uint_as_float(raw[k]);
+          round |= (((lower_inclusive ? x >= lower : x > lower) && (upper_inclusive ? x <= upper : x < upper)) ? 1u : 0u) << k;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < B; ++k) round |= ((raw[k] - lo) <= span ? 1u : 0u) << k;
+      }
+      round = (invert ? ~round : round) & ~null_bits;
+    }
+    bits |= (round & 0xFFFFu) << k0;
+  }
+  return bits;
+}
+
+// What the stages of decode_columns must know of the staged views without loading them: bit v = view v ...
+struct ViewMasks {
+  uint32_t present;      // ... exists
+  uint32_t nullable;     // ... is a value / FrameOfReference segment with a null bitmap
+  uint32_t dictionary;   // ... is a dictionary segment
+  uint32_t frame;        // ... is a FrameOfReference segment
+  uint32_t is_int;       // ... holds int32 values
+  uint32_t is_float;     // ... holds float values
+};
+
+// N columns (views first .. first + N - 1) for FUSED_ROWS rows of a lane, stage by stage, so that the loads of ALL columns of a stage are in
+// flight together: the stored words (value ids / offsets / values), the null words of value segments, the dictionary entries.  Values
+// come out as int64 (int / long columns) or as the bits of the double; float columns as the bits of the double too (WIDEN: GROUP BY
+// keys, like decode_rows) or as the float's own bits in the low word (the expressions compute on those).  Data segments only.
+template <int N, bool WIDEN>
+__device__ __forceinline__ void decode_columns(const ColumnView* views, const ViewMasks& all, uint32_t first, const uint32_t (&row)[FUSED_ROWS], uint64_t (&value)[N][FUSED_ROWS],
+                                               uint32_t (&nulls)[N]) {
+  constexpr int R = FUSED_ROWS;
+  const uint32_t present = all.present >> first, nullable = all.nullable >> first, dictionary = all.dictionary >> first, frame = all.frame >> first, is_int = all.is_int >> first,
+                 is_float = all.is_float >> first;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {   // stage 1: stored words
+    nulls[c] = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) value[c][i] = 0;
+    if (!((present >> c) & 1)) continue;
+    const ColumnView s = uniform(views[first + c]);
+    if (s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+      if (s.width == 1) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) value[c][i] = static_cast<const uint8_t*>(s.data)[row[i]];
+      } else if (s.width == 2) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) value[c][i] = static_cast<const uint16_t*>(s.data)[row[i]];
+      } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) value[c][i] = static_cast<const uint32_t*>(s.data)[row[i]];
+      }
+      if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {   // the block minimum rides in the upper half
+#pragma unroll
+        for (int i = 0; i < R; ++i) value[c][i] |= static_cast<uint64_t>(static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row[i] / HY_FOR_BLOCK_SIZE])) << 32;
+      }
+    } else if (s.data_type == HY_TYPE_INT || s.data_type == HY_TYPE_FLOAT) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) value[c][i] = static_cast<const uint32_t*>(s.data)[row[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < R; ++i) value[c][i] = static_cast<const uint64_t*>(s.data)[row[i]];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c) {   // stage 1b: NULLs of value / FrameOfReference segments
+    if (!((nullable >> c) & 1)) continue;
+    const uint64_t* null_words = uniform(views[first + c].nulls);
+    uint64_t word[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) word[i] = null_words[row[i] >> 6];
+#pragma unroll
+    for (int i = 0; i < R; ++i) nulls[c] |= static_cast<uint32_t>((word[i] >> (row[i] & 63)) & 1) << i;
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c) {   // stage 2: dictionary entries
+    if (!((dictionary >> c) & 1)) continue;
+    const ColumnView s = uniform(views[first + c]);
+    uint32_t index[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      index[i] = static_cast<uint32_t>(value[c][i]);
+      if (index[i] >= s.aux_size) { nulls[c] |= 1u << i; index[i] = 0; }   // the NULL value id
+    }
+    if (s.aux_size == 0) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) value[c][i] = 0;
+    } else if (s.data_type == HY_TYPE_INT || s.data_type == HY_TYPE_FLOAT) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) value[c][i] = static_cast<const uint32_t*>(s.aux)[index[i]];
+    } else {
+#pragma unroll
+      for (int i = 0; i < R; ++i) value[c][i] = static_cast<const uint64_t*>(s.aux)[index[i]];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c) {   // stage 3: stored word -> value
+    if (!((present >> c) & 1)) continue;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const uint64_t raw = value[c][i];
+      if ((frame >> c) & 1) value[c][i] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(raw) + static_cast<uint32_t>(raw >> 32))));
+      else if ((is_int >> c) & 1) value[c][i] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(raw))));
+      else if (WIDEN && ((is_float >> c) & 1)) value[c][i] = static_cast<uint64_t>(__double_as_longlong(static_cast<double>(__uint_as_float(static_cast<uint32_t>(raw)))));
+    }
+  }
+}
+
+// A value on the expression stack (int64 | float bits in the low word | double bits) <-> the Value arithmetic_cell computes on
+__device__ __forceinline__ Value stack_value(uint64_t bits, uint32_t type) {
+  Value v{false, 0, 0.0};
+  if (type == HY_TYPE_FLOAT) v.f = static_cast<double>(__uint_as_float(static_cast<uint32_t>(bits)));
+  else if (type == HY_TYPE_DOUBLE) v.f = __longlong_as_double(static_cast<long long>(bits));
+  else v.i = static_cast<int64_t>(bits);
+  return v;
+}
+__device__ __forceinline__ uint64_t stack_bits(const Value& v, uint32_t type) {
+  if (type == HY_TYPE_FLOAT) return __float_as_uint(static_cast<float>(v.f));
+  if (type == HY_TYPE_DOUBLE) return static_cast<uint64_t>(__double_as_longlong(v.f));
+  return static_cast<uint64_t>(v.i);
+}
+
+// The input expression of one accumulator for FUSED_ROWS rows of a lane: a three-slot stack held in registers (slot 0 = top; push and
+// pop move the slots, nothing is indexed); column nodes take the batch's decoded columns.  + - * of two operands of the result's own
+// type (the host gives literals the type the operation converts them to anyway) are single IEEE / integer operations on the stack
+// words; everything else goes through arithmetic_cell -- the cell hy_projection_arithmetic computes.  Floats leave as double bits.
+__device__ __forceinline__ void evaluate_input(const FusedInput& input, const uint64_t (&columns)[FUSED_COLUMNS][FUSED_ROWS], const uint32_t (&column_nulls)[FUSED_COLUMNS], uint32_t valid,
+                                               uint64_t (&out)[FUSED_ROWS], uint32_t* out_nulls) {
+  uint64_t s0[FUSED_ROWS], s1[FUSED_ROWS], s2[FUSED_ROWS];
+  uint32_t n0 = 0, n1 = 0, n2 = 0, t0 = HY_TYPE_NULL, t1 = HY_TYPE_NULL, t2 = HY_TYPE_NULL;
+#pragma unroll
+  for (int i = 0; i < FUSED_ROWS; ++i) s0[i] = s1[i] = s2[i] = 0;
+  const uint32_t n_nodes = uniform(input.n_nodes);
+#pragma unroll 1
+  for (uint32_t k = 0; k < n_nodes; ++k) {
+    const FusedNode& node = input.nodes[k];
+    const uint32_t kind = uniform(node.kind), type = uniform(node.type);
+    if (kind == HY_EXPR_ARITHMETIC) {   // slot 1 <op> slot 0 -> slot 0; slot 2 moves up
+      const uint32_t op = uniform(node.op);
+      uint32_t nulls = n0 | n1;
+      if (op <= HY_ARITH_MUL && t0 == type && t1 == type) {
+        if (type == HY_TYPE_FLOAT) {
+#pragma unroll
+          for (int i = 0; i < FUSED_ROWS; ++i) {
+            const float x = __uint_as_float(static_cast<uint32_t>(s1[i])), y = __uint_as_float(static_cast<uint32_t>(s0[i]));
+            s0[i] = __float_as_uint(op == HY_ARITH_ADD ? __fadd_rn(x, y) : op == HY_ARITH_SUB ? __fsub_rn(x, y) : __fmul_rn(x, y));
+          }
+        } else if (type == HY_TYPE_DOUBLE) {
+#pragma unroll
+          for (int i = 0; i < FUSED_ROWS; ++i) {
+            const double x = __longlong_as_double(static_cast<long long>(s1[i])), y = __longlong_as_double(static_cast<long long>(s0[i]));
+            s0[i] = static_cast<uint64_t>(__double_as_longlong(op == HY_ARITH_ADD ? __dadd_rn(x, y) : op == HY_ARITH_SUB ? __dsub_rn(x, y) : __dmul_rn(x, y)));
+          }
+        } else if (type == HY_TYPE_LONG) {
+#pragma unroll
+          for (int i = 0; i < FUSED_ROWS; ++i) s0[i] = op == HY_ARITH_ADD ? s1[i] + s0[i] : op == HY_ARITH_SUB ? s1[i] - s0[i] : s1[i] * s0[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < FUSED_ROWS; ++i) {
+            const uint32_t x = static_cast<uint32_t>(s1[i]), y = static_cast<uint32_t>(s0[i]);
+            s0[i] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(op == HY_ARITH_ADD ? x + y : op == HY_ARITH_SUB ? x - y : x * y)));
+          }
+        }
+      } else if (op <= HY_ARITH_MUL) {   // + - * with conversions: the rows side by side, the operator a constant of each instance
+#pragma unroll
+        for (int i = 0; i < FUSED_ROWS; ++i) {
+          Value result{false, 0, 0.0};
+          if (((valid & ~nulls) >> i) & 1) {
+            const Value x = stack_value(s1[i], t1), y = stack_value(s0[i], t0);
+            if (op == HY_ARITH_ADD) arithmetic_cell(HY_ARITH_ADD, t1, t0, type, x, y, &result);
+            else if (op == HY_ARITH_SUB) arithmetic_cell(HY_ARITH_SUB, t1, t0, type, x, y, &result);
+            else arithmetic_cell(HY_ARITH_MUL, t1, t0, type, x, y, &result);
+          }
+          s0[i] = stack_bits(result, type);
+        }
+      } else {   // / and %: 64-bit division, fmod -- long instruction sequences with many live registers: ONE instance, the rows one after the other
+                 // (row i selected by comparisons: an index would put the stack into scratch memory)
+#pragma unroll 1
+        for (int i = 0; i < FUSED_ROWS; ++i) {
+          uint64_t x = s1[0], y = s0[0];
+#pragma unroll
+          for (int j = 1; j < FUSED_ROWS; ++j) { x = i == j ? s1[j] : x; y = i == j ? s0[j] : y; }
+          Value result{false, 0, 0.0};
+          bool is_null = true;
+          if (((valid & ~nulls) >> i) & 1) is_null = arithmetic_cell(op, t1, t0, type, stack_value(x, t1), stack_value(y, t0), &result);   // NULL: division / modulo by zero
+          if (is_null) nulls |= (valid & (1u << i));
+          const uint64_t bits = stack_bits(result, type);
+#pragma unroll
+          for (int j = 0; j < FUSED_ROWS; ++j) s0[j] = i == j ? bits : s0[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FUSED_ROWS; ++i) s1[i] = s2[i];
+      n0 = nulls; t0 = type;
+      n1 = n2; t1 = t2;
+    } else {                            // push
+#pragma unroll
+      for (int i = 0; i < FUSED_ROWS; ++i) { s2[i] = s1[i]; s1[i] = s0[i]; }
+      n2 = n1; t2 = t1;
+      n1 = n0; t1 = t0;
+      t0 = type;
+      if (kind == HY_EXPR_COLUMN) {
+        const uint32_t which = uniform(node.column);
+#pragma unroll
+        for (int c = 0; c < FUSED_COLUMNS; ++c) {
+          if (which != static_cast<uint32_t>(c)) continue;
+#pragma unroll
+          for (int i = 0; i < FUSED_ROWS; ++i) s0[i] = columns[c][i];
+          n0 = column_nulls[c];
+        }
+      } else {
+        const uint64_t literal = node.literal;
+#pragma unroll
+        for (int i = 0; i < FUSED_ROWS; ++i) s0[i] = literal;
+        n0 = type == HY_TYPE_NULL ? 0xFFFFFFFFu : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FUSED_ROWS; ++i) out[i] = t0 == HY_TYPE_FLOAT ? static_cast<uint64_t>(__double_as_longlong(static_cast<double>(__uint_as_float(static_cast<uint32_t>(s0[i]))))) : s0[i];
+  *out_nulls = n0;
+}
+
+// Find or insert `tuple` in the workgroup's table (lds_slot with one addition: a new group gets its arrival number -- its dense index).
+__device__ __forceinline__ uint32_t fused_lds_slot(uint32_t* s_tags, uint64_t* s_keys, uint32_t* s_dense_of_slot, uint32_t* s_slot_of_dense, uint32_t slots, uint32_t words,
+                                                   const uint64_t (&tuple)[MAX_GROUPBY + 1], uint64_t hash, uint32_t* s_n_groups) {
+  const uint32_t ready = 0x80000000u | static_cast<uint32_t>(hash >> 33);
+  uint32_t slot = static_cast<uint32_t>(hash) & (slots - 1), probes = 0, result = 0xFFFFFFFFu;
+  bool done = false;
+  while (!done) {
+    const uint32_t tag = __hip_atomic_load(&s_tags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __atomic_signal_fence(__ATOMIC_ACQUIRE);
+    if (tag == TAG_EMPTY) {
+      if (atomicCAS(&s_tags[slot], TAG_EMPTY, TAG_LOCKED) == TAG_EMPTY) {
+#pragma unroll
+        for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) { if (w < words) s_keys[slot * words + w] = tuple[w]; }
+        const uint32_t arrival = atomicAdd(s_n_groups, 1u);
+        s_dense_of_slot[slot] = arrival;
+        if (arrival < FUSED_DENSE) s_slot_of_dense[arrival] = slot;
+        __threadfence_block();
+        atomicExch(&s_tags[slot], ready);
+        result = slot;
+        done = true;
+      }
+    } else if (tag != TAG_LOCKED) {
+      bool equal = tag == ready;
+      if (equal) {
+#pragma unroll
+        for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) { if (w < words) equal &= s_keys[slot * words + w] == tuple[w]; }
+      }
+      if (equal) {
+        result = slot;
+        done = true;
+      } else {
+        slot = (slot + 1) & (slots - 1);
+        if (++probes >= slots) done = true;
+      }
+    }
+  }
+  return result;
+}
+
+// LDS layout: keys[S][words] u64 | first[S] u64 | last[S] u64 | values[S][A] u64 | counts[S][A] u32 | tags[S] u32 | dense index of a slot [S] u32 |
+//             groups, passed, stop, -, slot of a dense index [4], view masks [6] u32 (+ pad to 64 bytes) | the waves' lists of surviving rows [4][2048] u16 |
+//             this chunk's segment views [FUSED_VIEWS] | the filters' jobs [HY_MAX_FILTERS] | the input expressions [A] |
+//             the dense groups' cells: values [4][A + 2][16] u64 (the last two: first / last row) | counts [4][A][16] u32
+__global__ __launch_bounds__(256, FUSED_WAVES) void fused_rows(AggArgs a, const FusedPlan* __restrict__ plan, uint32_t n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int R = FUSED_ROWS;
+  const uint32_t slots = plan->lds_slots;
+  const uint32_t words = a.n_groupby + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_aggregates = a.n_aggregates;
+  uint64_t* s_keys = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* s_first = s_keys + size_t{slots} * words;
+  uint64_t* s_last = s_first + slots;
+  uint64_t* s_values = s_last + slots;
+  uint32_t* s_counts = reinterpret_cast<uint32_t*>(s_values + size_t{slots} * n_aggregates);
+  uint32_t* s_tags = s_counts + size_t{slots} * n_aggregates;
+  uint32_t* s_dense_of_slot = s_tags + slots;
+  uint32_t* s_n_groups = s_dense_of_slot + slots;   // [0] groups in the table, [1] rows that passed the filters, [2] the overflow flag as the workgroup saw it
+  uint32_t* s_slot_of_dense = s_n_groups + 4;       // [FUSED_DENSE]
+  uint16_t* s_list = reinterpret_cast<uint16_t*>(s_n_groups + 16) + size_t{wave} * FUSED_WAVE_ROWS;
+  ColumnView* s_views = reinterpret_cast<ColumnView*>(reinterpret_cast<uint16_t*>(s_n_groups + 16) + SLICE_ROWS);   // filters [0, 4) | GROUP BY [4, 8) | inputs' columns [8, 8 + C)
+  ScanJob* s_jobs = reinterpret_cast<ScanJob*>(s_views + FUSED_VIEWS);
+  ViewMasks* s_masks = reinterpret_cast<ViewMasks*>(s_n_groups + 8);
+  FusedInput* s_inputs = reinterpret_cast<FusedInput*>(s_jobs + HY_MAX_FILTERS);   // the accumulators' input expressions (read node by node for every batch: global memory is a round trip each)
+  // The cells of the first FUSED_DENSE groups the chunk meets: FUSED_CELLS copies of every accumulator, a lane adds to copy lane % FUSED_CELLS.  256 lanes
+  // adding to the four groups of TPC-H Q1 through ONE cell per group and aggregate serialise completely; sixteen copies take a sixteenth of that.
+  uint64_t* s_cell_values = reinterpret_cast<uint64_t*>(s_inputs + n_aggregates);                  // [FUSED_DENSE][A + 2][FUSED_CELLS]
+  uint32_t* s_cell_counts = reinterpret_cast<uint32_t*>(s_cell_values + FUSED_DENSE * (n_aggregates + 2) * FUSED_CELLS);   // [FUSED_DENSE][A][FUSED_CELLS]
+  const uint32_t chunk = blockIdx.x;
+  for (uint32_t s = tid; s < slots; s += 256) {
+    s_tags[s] = TAG_EMPTY;
+    s_first[s] = ~0ull;
+    s_last[s] = 0;
+    for (uint32_t g = 0; g < n_aggregates; ++g) {
+      s_values[s * n_aggregates + g] = initial_value(a.aggregates[g].function);
+      s_counts[s * n_aggregates + g] = 0;
+    }
+  }
+  for (uint32_t cell = tid; cell < FUSED_DENSE * (n_aggregates + 2) * FUSED_CELLS; cell += 256) {
+    const uint32_t g = (cell / FUSED_CELLS) % (n_aggregates + 2);
+    s_cell_values[cell] = g < n_aggregates ? initial_value(a.aggregates[g].function) : (g == n_aggregates ? ~0ull : 0ull);
+  }
+  for (uint32_t cell = tid; cell < FUSED_DENSE * n_aggregates * FUSED_CELLS; cell += 256) s_cell_counts[cell] = 0;
+  if (tid == 0) {
+    s_n_groups[0] = s_n_groups[1] = 0;
+    s_n_groups[2] = __hip_atomic_load(&a.overflow[FLAG_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {   // this chunk's descriptors and jobs, the input expressions -> LDS
+    const uint32_t n_filters = plan->n_filters, n_columns = plan->n_columns;
+    const DevSegment* segments = nullptr;
+#pragma unroll
+    for (uint32_t f = 0; f < HY_MAX_FILTERS; ++f) if (tid == f && f < n_filters) segments = plan->filters[f].segments;
+#pragma unroll
+    for (uint32_t g = 0; g < MAX_GROUPBY; ++g) if (tid == HY_MAX_FILTERS + g && g < a.n_groupby) segments = a.groupby[g].segments;
+#pragma unroll
+    for (uint32_t c = 0; c < static_cast<uint32_t>(FUSED_COLUMNS); ++c) if (tid == HY_MAX_FILTERS + MAX_GROUPBY + c && c < n_columns) segments = plan->columns[c];
+    const ColumnView view = segments ? view_of(segments[chunk]) : ColumnView{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+    if (tid < FUSED_VIEWS) s_views[tid] = view;
+    if (wave == 0) {   // (the views sit in lanes 0 .. FUSED_VIEWS - 1 of wave 0: a ballot per property)
+      const bool mine = tid < FUSED_VIEWS && view.present;
+      ViewMasks masks;
+      masks.present = static_cast<uint32_t>(__ballot(mine));
+      masks.nullable = static_cast<uint32_t>(__ballot(mine && view.encoding != HY_ENC_DICTIONARY && view.nulls != nullptr));
+      masks.dictionary = static_cast<uint32_t>(__ballot(mine && view.encoding == HY_ENC_DICTIONARY));
+      masks.frame = static_cast<uint32_t>(__ballot(mine && view.encoding == HY_ENC_FRAME_OF_REFERENCE));
+      masks.is_int = static_cast<uint32_t>(__ballot(mine && view.data_type == HY_TYPE_INT));
+      masks.is_float = static_cast<uint32_t>(__ballot(mine && view.data_type == HY_TYPE_FLOAT));
+      if (tid == 0) *s_masks = masks;
+    }
+    if (tid >= 64 && tid < 64 + n_filters) s_jobs[tid - 64] = plan->filters[tid - 64].jobs[chunk];
+    const uint64_t* plan_inputs = reinterpret_cast<const uint64_t*>(plan->inputs);
+    uint64_t* staged_inputs = reinterpret_cast<uint64_t*>(s_inputs);
+    for (uint32_t w = tid; w < n_aggregates * (sizeof(FusedInput) / 8); w += 256) staged_inputs[w] = plan_inputs[w];
+  }
+  __syncthreads();
+  if (s_n_groups[2]) return;   // the global table is too small: the host retries with a larger one
+  const uint64_t chunk_base = a.row_base[chunk];
+  const uint32_t chunk_rows = static_cast<uint32_t>(a.row_base[chunk + 1] - chunk_base);
+  const uint32_t debug = plan->debug;
+  const uint32_t n_filters = plan->n_filters;
+  uint32_t wave_passed = 0;
+  ViewMasks masks;
+  masks.present = uniform(s_masks->present); masks.nullable = uniform(s_masks->nullable); masks.dictionary = uniform(s_masks->dictionary);
+  masks.frame = uniform(s_masks->frame); masks.is_int = uniform(s_masks->is_int); masks.is_float = uniform(s_masks->is_float);
+
+  // The chunk, 8192 rows at a time; every wave takes a quarter of the piece (no barrier in here: the waves share the group table through
+  // LDS atomics only).
+#pragma unroll 1
+  for (uint32_t piece = 0; piece < chunk_rows; piece += SLICE_ROWS) {
+    const uint32_t first_row = piece + wave * FUSED_WAVE_ROWS;   // chunk offset of the wave's first row
+    if (first_row >= chunk_rows) break;
+    const uint32_t wave_rows = min(FUSED_WAVE_ROWS, chunk_rows - first_row);
+    const uint64_t wave_base = chunk_base + first_row;           // its global row number
+    uint32_t n_list = 0;
+    {
+      // ---- the scans: every filter over the wave's rows ---------------------------------------------------------------------------
+      uint32_t pass = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < FUSED_WAVE_ROWS / 64; ++k) pass |= (k * 64 + lane < wave_rows ? 1u : 0u) << k;
+#pragma unroll 1
+      for (uint32_t f = 0; f < n_filters; ++f) {
+        const ScanJob job = uniform(s_jobs[f]);
+        if (job.mode == JOB_ALL) continue;                                       // the chunk's early-out: every row matches
+        if (job.mode == JOB_NONE || (job.flags & JF_NEVER)) { pass = 0; break; }   // ... or none does
+        pass &= filter_wave_rows(uniform(s_views[f]), job, first_row, lane, wave_rows);
+        if (__ballot(pass != 0) == 0) break;
+      }
+      // ---- the survivors' row numbers (relative to the quarter), in row order -----------------------------------------------------
+#pragma unroll
+      for (uint32_t k = 0; k < FUSED_WAVE_ROWS / 64; ++k) {
+        const bool alive = (pass >> k) & 1;
+        const uint64_t lanes = __ballot(alive);
+        if (alive) s_list[n_list + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(lanes >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(lanes), 0u))] = static_cast<uint16_t>(k * 64 + lane);
+        n_list += static_cast<uint32_t>(__popcll(lanes));
+      }
+      wave_passed += n_list;
+    }
+    if (debug & 16) n_list = 0;
+
+#pragma unroll 1
+    for (uint32_t base = 0; base < n_list; base += 64 * R) {
+      uint32_t row[R], offset[R], pass = 0;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const uint32_t entry = base + static_cast<uint32_t>(i) * 64 + lane;
+        if (entry < n_list) pass |= 1u << i;
+        offset[i] = s_list[entry < n_list ? entry : base];
+        row[i] = first_row + offset[i];
+      }
+      // ---- GROUP BY tuples and their slots; `cell`: where the row's accumulators are ------------------------------------------------------
+      uint32_t slot[R], dense[R], in_global = 0;
+      {
+        uint64_t key[MAX_GROUPBY][R];
+        uint32_t key_nulls[MAX_GROUPBY];
+        decode_columns<static_cast<int>(MAX_GROUPBY), true>(s_views, masks, HY_MAX_FILTERS, row, key, key_nulls);
+        if (debug & 8) pass = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          slot[i] = 0xFFFFFFFFu;
+          dense[i] = 0xFFFFFFFFu;
+          uint64_t tuple[MAX_GROUPBY + 1];
+          tuple[0] = 0;
+#pragma unroll
+          for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+            tuple[g + 1] = 0;
+            if (g >= a.n_groupby) continue;
+            if ((key_nulls[g] >> i) & 1) { tuple[0] |= 1ull << g; continue; }
+            uint64_t bits = key[g][i];
+            if (a.groupby[g].is_float && __longlong_as_double(static_cast<long long>(bits)) == 0.0) bits = 0;   // -0.0 and 0.0 are one group
+            tuple[g + 1] = bits;
+          }
+          if (!((pass >> i) & 1)) continue;
+          const uint64_t global_row = wave_base + offset[i];
+          const uint64_t hash = hash_tuple_in_registers(tuple, words);
+          slot[i] = fused_lds_slot(s_tags, s_keys, s_dense_of_slot, s_slot_of_dense, slots, words, tuple, hash, s_n_groups);
+          if (slot[i] != 0xFFFFFFFFu) {
+            dense[i] = s_dense_of_slot[slot[i]];
+            // first / last row of the group: the dense groups' cells, or the slot itself
+            const bool is_dense = dense[i] < FUSED_DENSE;
+            uint64_t* first = is_dense ? &s_cell_values[(dense[i] * (n_aggregates + 2) + n_aggregates) * FUSED_CELLS + (lane % FUSED_CELLS)] : &s_first[slot[i]];
+            uint64_t* last = is_dense ? first + FUSED_CELLS : &s_last[slot[i]];
+            atomicMin(reinterpret_cast<unsigned long long*>(first), static_cast<unsigned long long>(global_row));
+            atomicMax(reinterpret_cast<unsigned long long*>(last), static_cast<unsigned long long>(global_row));
+            continue;
+          }
+          // the chunk has more groups than the table holds: this row goes to the global table directly
+          uint64_t spilled[MAX_GROUPBY + 1];   // (global_slot walks its tuple in memory: a copy made on this path only keeps `tuple` in registers)
+#pragma unroll
+          for (uint32_t w = 0; w <= MAX_GROUPBY; ++w) spilled[w] = tuple[w];
+          const uint32_t gslot = __hip_atomic_load(&a.overflow[FLAG_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0xFFFFFFFFu : global_slot(a, spilled, words, hash);
+          if (gslot == 0xFFFFFFFFu) {
+            a.overflow[FLAG_OVERFLOW] = 1;
+            pass &= ~(1u << i);   // (the whole pass is repeated with a larger table)
+            continue;
+          }
+          atomicMin(reinterpret_cast<unsigned long long*>(&a.first_row[gslot]), static_cast<unsigned long long>(global_row));
+          atomicMax(reinterpret_cast<unsigned long long*>(&a.last_row[gslot]), static_cast<unsigned long long>(global_row));
+          slot[i] = gslot;
+          in_global |= 1u << i;
+        }
+      }
+
+      // ---- the columns the expressions read, once per batch; then the aggregates: input expression, accumulators ------------------------
+      uint64_t column[FUSED_COLUMNS][R];
+      uint32_t column_nulls[FUSED_COLUMNS];
+      if (!(debug & 4)) decode_columns<FUSED_COLUMNS, false>(s_views, masks, HY_MAX_FILTERS + MAX_GROUPBY, row, column, column_nulls);
+      else {
+#pragma unroll
+        for (int c = 0; c < FUSED_COLUMNS; ++c) { column_nulls[c] = 0; for (int i = 0; i < R; ++i) column[c][i] = row[i]; }
+      }
+#pragma unroll 1
+      for (uint32_t g = 0; g < n_aggregates; ++g) {
+        const AggColumn& c = a.aggregates[g];
+        const FusedInput& input = s_inputs[g];
+        const uint32_t function = c.function;
+        const bool has_value = function == HY_AGG_MIN || function == HY_AGG_MAX || function == HY_AGG_SUM || function == HY_AGG_AVG;
+        uint64_t value[R];
+        uint32_t nulls = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) value[i] = 0;
+        if (uniform(input.n_nodes) && !(debug & 2)) evaluate_input(input, column, column_nulls, pass, value, &nulls);
+        if (debug & 1) continue;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          if (!(((pass & ~nulls) >> i) & 1)) continue;   // NULL inputs leave the aggregate unchanged
+          const uint64_t contribution = has_value ? contribution_from(c, value[i]) : 0;
+          if ((in_global >> i) & 1) { merge_global(a, slot[i], g, contribution, 1); continue; }
+          const bool is_dense = dense[i] < FUSED_DENSE;
+          uint64_t* target = is_dense ? &s_cell_values[(dense[i] * (n_aggregates + 2) + g) * FUSED_CELLS + (lane % FUSED_CELLS)] : &s_values[slot[i] * n_aggregates + g];
+          uint32_t* count = is_dense ? &s_cell_counts[(dense[i] * n_aggregates + g) * FUSED_CELLS + (lane % FUSED_CELLS)] : &s_counts[slot[i] * n_aggregates + g];
+          if (has_value) accumulate_lds(c, target, contribution);
+          atomicAdd(count, 1u);
+        }
+      }
+    }
+  }
+  if (lane == 0 && wave_passed) atomicAdd(&s_n_groups[1], wave_passed);
+  __syncthreads();
+  if (tid == 0 && s_n_groups[1]) atomicAdd(reinterpret_cast<unsigned long long*>(a.overflow + FLAG_PASSED), static_cast<unsigned long long>(s_n_groups[1]));
+  // the dense groups' cells -> their slots (one thread per group and accumulator; nobody else touches the table now)
+  {
+    const uint32_t n_dense = min(s_n_groups[0], FUSED_DENSE);
+    for (uint32_t item = tid; item < n_dense * (n_aggregates + 2); item += 256) {
+      const uint32_t d = item / (n_aggregates + 2), g = item % (n_aggregates + 2), slot = s_slot_of_dense[d];
+      const uint64_t* cells = &s_cell_values[(d * (n_aggregates + 2) + g) * FUSED_CELLS];
+      if (g < n_aggregates) {
+        const AggColumn& c = a.aggregates[g];
+        uint64_t value = s_values[slot * n_aggregates + g];
+        uint32_t count = s_counts[slot * n_aggregates + g];
+        for (uint32_t k = 0; k < FUSED_CELLS; ++k) {
+          value = combine(c, value, cells[k]);
+          count += s_cell_counts[(d * n_aggregates + g) * FUSED_CELLS + k];
+        }
+        s_values[slot * n_aggregates + g] = value;
+        s_counts[slot * n_aggregates + g] = count;
+      } else {
+        uint64_t row = g == n_aggregates ? s_first[slot] : s_last[slot];
+        for (uint32_t k = 0; k < FUSED_CELLS; ++k) row = g == n_aggregates ? min(row, cells[k]) : max(row, cells[k]);
+        if (g == n_aggregates) s_first[slot] = row; else s_last[slot] = row;
+      }
+    }
+  }
+  __syncthreads();
+  // the chunk's groups -> the global table
+  for (uint32_t s = tid; s < slots; s += 256) {
+    if (s_tags[s] == TAG_EMPTY) continue;
+    if (__hip_atomic_load(&a.overflow[FLAG_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    uint64_t tuple[MAX_GROUPBY + 1];
+    for (uint32_t w = 0; w < words; ++w) tuple[w] = s_keys[s * words + w];
+    const uint32_t gslot = global_slot(a, tuple, words, hash_tuple(tuple, words));
+    if (gslot == 0xFFFFFFFFu) { a.overflow[FLAG_OVERFLOW] = 1; continue; }
+    atomicMin(reinterpret_cast<unsigned long long*>(&a.first_row[gslot]), static_cast<unsigned long long>(s_first[s]));
+    atomicMax(reinterpret_cast<unsigned long long*>(&a.last_row[gslot]), static_cast<unsigned long long>(s_last[s]));
+    for (uint32_t g = 0; g < n_aggregates; ++g) merge_global(a, gslot, g, s_values[s * n_aggregates + g], s_counts[s * n_aggregates + g]);
+  }
+}
+
 // The groups of the table, densely.  The first `staged_capacity` of them also go straight into pinned host memory (same
 // five arrays, `staged_capacity` rows each, behind a 64-byte header): few groups -- the usual case -- cost no copy at all.
 struct StagedGroups {
@@ -1369,6 +2090,8 @@ __global__ void publish_group_flags(const uint32_t* flags, uint32_t* header) {
   header[1] = flags[1];
   header[2] = flags[2];
   header[3] = flags[3];
+  header[4] = flags[4];   // (FLAG_PASSED, two words: fused_rows only)
+  header[5] = flags[5];
   __threadfence_system();
 }
 
@@ -1424,6 +2147,7 @@ struct RowIdOf {
 // What the device table holds after one pass over the table: the groups' tuples, first / last rows and accumulators.
 struct DeviceGroups {
   uint32_t n_groups = 0;
+  uint64_t passed_rows = 0;   // fused_rows: rows that passed the filters
   std::vector<uint64_t> keys, first, last, values, counts;
 };
 
@@ -1458,7 +2182,11 @@ static void launch_partition_rows(bool scatter, uint32_t words, uint32_t grid, s
 
 static uint32_t g_agg_path = 0;   // debug: 0 = aggregate_rows, otherwise the partition bits of the partitioned path (last call of this process)
 
-static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out) {
+static uint32_t fused_lds_slots(uint32_t n_groupby) { return n_groupby ? FUSED_LDS_SLOTS : 8u; }
+
+// (`fused`: the device copy of a FusedPlan -- fused_rows takes the place of aggregate_rows; its accumulators' inputs are expressions, which
+//  the partitioned path cannot carry.)
+static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out, const FusedPlan* fused = nullptr) {
   hipStream_t stream = current_stream();
   const uint32_t words = a.n_groupby + 1;
   const uint32_t n_aggregates = a.n_aggregates;
@@ -1471,7 +2199,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   // The partitioned path (tables with many groups): entered when aggregate_rows gives up; 2^bits partitions of about 64 Ki rows,
   // then -- if even those hold more groups than a workgroup's table -- the most the partitioning kernels take.
   constexpr uint32_t MAX_PARTITION_BITS = 14;
-  const bool can_partition = a.n_groupby > 0 && shape->rows < (1ull << 32) && !getenv("HY_AGG_NO_PARTITIONS");
+  const bool can_partition = !fused && a.n_groupby > 0 && shape->rows < (1ull << 32) && !getenv("HY_AGG_NO_PARTITIONS");
   uint32_t first_bits = 6;
   while (first_bits < MAX_PARTITION_BITS && (shape->rows >> first_bits) > 65536) ++first_bits;
   uint32_t partition_bits = 0;   // 0: aggregate_rows
@@ -1525,7 +2253,13 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       g_agg_trace_slices = shape->n_slices;
     }
     g_agg_path = partition_bits;
-    if (shape->n_slices && shape->rows && partition_bits == 0) {
+    if (shape->n_slices && shape->rows && fused) {   // one workgroup per chunk
+      const size_t fused_lds = size_t{fused_lds_slots(a.n_groupby)} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 64 + 2 * size_t{SLICE_ROWS} + sizeof(ColumnView) * FUSED_VIEWS +
+                               sizeof(ScanJob) * HY_MAX_FILTERS + sizeof(FusedInput) * n_aggregates + size_t{FUSED_DENSE} * FUSED_CELLS * (8 * (n_aggregates + 2) + 4 * n_aggregates);
+      profile_begin(stream);
+      hipLaunchKernelGGL(fused_rows, dim3(shape->n_chunks), dim3(256), fused_lds, stream, a, fused, shape->n_chunks);
+      profile_end(stream);
+    } else if (shape->n_slices && shape->rows && partition_bits == 0) {
       profile_begin(stream);
       hipLaunchKernelGGL(aggregate_rows, dim3(shape->n_slices), dim3(256), lds_bytes, stream, a);
       profile_end(stream);
@@ -1576,7 +2310,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       profile_end(stream);
     }
     lap("kernels launched", round);
-    uint32_t host_flags[4] = {0, 0, 0, 0};
+    uint32_t host_flags[6] = {0, 0, 0, 0, 0, 0};
     // count groups, then compact
     DeviceBuffer c_keys, c_first, c_last, c_values, c_counts;
     const uint32_t out_capacity = static_cast<uint32_t>(std::min<uint64_t>(capacity, shape->rows + 1));
@@ -1608,7 +2342,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     lap("compact launched", round);
     HY_HIP(hipStreamSynchronize(stream));
     lap("device finished", round);
-    std::memcpy(host_flags, pinned_host, 16);
+    std::memcpy(host_flags, pinned_host, 24);
     if (host_flags[FLAG_GIVE_UP]) {   // too many rows outside the LDS tables: partition (more finely)
       if (partition_bits == 0) partition_bits = first_bits;
       else if (partition_bits < MAX_PARTITION_BITS) partition_bits = MAX_PARTITION_BITS;
@@ -1623,6 +2357,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     }
     const uint32_t n_groups = host_flags[FLAG_GROUPS];
     out.n_groups = n_groups;
+    out.passed_rows = static_cast<uint64_t>(host_flags[5]) << 32 | host_flags[4];
     out.keys.resize(size_t{n_groups} * words);
     out.first.resize(n_groups);
     out.last.resize(n_groups);
@@ -1702,13 +2437,31 @@ static void for_each_group_range(uint32_t n, Body body) {
   for (auto& worker : workers) worker.join();
 }
 
+// hy_scan_project_aggregate: the filters and the aggregates' input expressions, checked and typed by run_fused below.  The aggregate
+// specs then carry no columns -- input g is `inputs[g]` (n_nodes 0: COUNT(*)); inputs with the same `same_as` are one expression.
+struct FusedQuery {
+  const hy_column* shape;
+  const hy_filter* filters;
+  uint32_t n_filters;
+  const hy_column* columns[FUSED_COLUMNS];   // the distinct columns the expressions read (FusedNode::column indexes them)
+  uint32_t n_columns;
+  FusedInput inputs[MAX_AGGREGATES];
+  uint32_t same_as[MAX_AGGREGATES];
+};
+
 static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_groupby, const hy_aggregate_spec* specs, uint32_t n_aggregates,
-                               hy_aggregate_result* result) {
+                               hy_aggregate_result* result, const FusedQuery* fused = nullptr) {
   if (n_groupby > MAX_GROUPBY) return fail(HY_ERR_UNSUPPORTED, "more than %u GROUP BY columns stay on the CPU path", MAX_GROUPBY);
   if (n_aggregates > MAX_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "more than %u aggregates stay on the CPU path", MAX_AGGREGATES);
-  const hy_column* shape = n_groupby ? groupby[0] : nullptr;
+  const hy_column* shape = fused ? fused->shape : n_groupby ? groupby[0] : nullptr;
   for (uint32_t g = 0; g < n_aggregates && !shape; ++g) shape = specs[g].column;
   if (!shape) return fail(HY_ERR_INVALID, "hy_aggregate_hash needs at least one column (pass any column of the table for a lone COUNT(*))");
+  // what an aggregate reads: a column, or (fused) an expression -- known to the accumulators only by its type and by a non-null marker
+  static const DevSegment expression_marker{};
+  auto has_input = [&](uint32_t g) { return fused ? fused->inputs[g].n_nodes != 0 : specs[g].column != nullptr; };
+  auto input_type = [&](uint32_t g) -> uint32_t { return fused ? (fused->inputs[g].n_nodes ? fused->inputs[g].type : static_cast<uint32_t>(HY_TYPE_LONG))
+                                                                : (specs[g].column ? specs[g].column->data_type : static_cast<uint32_t>(HY_TYPE_LONG)); };
+  auto same_input = [&](uint32_t x, uint32_t y) { return fused ? fused->same_as[x] == fused->same_as[y] : specs[x].column == specs[y].column; };
   auto same_shape = [&](const hy_column* c) {
     if (c->n_chunks != shape->n_chunks || c->is_mvcc || (c->ref && c->ref->is_mvcc)) return false;
     for (uint32_t k = 0; k < c->n_chunks; ++k) if (c->host_segments[k].size != shape->host_segments[k].size) return false;
@@ -1718,6 +2471,12 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     slot.segments = column ? column->d_segments : nullptr;
     slot.data_type = column ? column->data_type : static_cast<uint32_t>(HY_TYPE_LONG);
     slot.is_float = column && (column->data_type == HY_TYPE_FLOAT || column->data_type == HY_TYPE_DOUBLE);
+    slot.function = function;
+  };
+  auto wire_expression = [&](AggColumn& slot, uint32_t g, uint32_t function) {
+    slot.segments = has_input(g) ? &expression_marker : nullptr;   // (never dereferenced: fused_rows evaluates FusedPlan::inputs)
+    slot.data_type = input_type(g);
+    slot.is_float = has_input(g) && (slot.data_type == HY_TYPE_FLOAT || slot.data_type == HY_TYPE_DOUBLE);
     slot.function = function;
   };
   AggArgs a;
@@ -1732,10 +2491,12 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   // is a second grouping by (GROUP BY columns, aggregate column) whose groups are counted per outer group.
   std::vector<int> primary(n_aggregates, -1), secondary(n_aggregates, -1);
   uint32_t n_device = 0;
+  uint32_t spec_of_device[MAX_AGGREGATES] = {0, 0, 0, 0, 0, 0, 0, 0};   // (fused: whose expression feeds the accumulator)
   for (uint32_t g = 0; g < n_aggregates; ++g) {
     const hy_aggregate_spec& spec = specs[g];
     if (spec.function > HY_AGG_ANY) return fail(HY_ERR_INVALID, "unknown aggregate function %u", spec.function);
-    if (!spec.column && spec.function != HY_AGG_COUNT) return fail(HY_ERR_INVALID, "only COUNT may omit its column (aggregate_hash.cpp:1002)");
+    if (!has_input(g) && spec.function != HY_AGG_COUNT) return fail(HY_ERR_INVALID, "only COUNT may omit its column (aggregate_hash.cpp:1002)");
+    if (fused && spec.function > HY_AGG_COUNT) return fail(HY_ERR_UNSUPPORTED, "hy_scan_project_aggregate: MIN / MAX / SUM / AVG / COUNT only -- run the operator chain for function %u", spec.function);
     if (spec.column) {
       if (!same_shape(spec.column)) return fail(HY_ERR_INVALID, "aggregate column %u does not have the table's chunk layout", g);
       if (spec.column->data_type == HY_TYPE_STRING && spec.function != HY_AGG_COUNT) return fail(HY_ERR_UNSUPPORTED, "string aggregates stay on the CPU path");
@@ -1747,16 +2508,21 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     // SUM and AVG of one floating-point column are the same accumulator (a double sum in row order and a count of the
     // non-NULL rows): TPC-H Q1 asks for both of l_quantity and of l_extendedprice.  (Integer columns: SUM adds int64,
     // AVG adds doubles -- two accumulators.)
-    const bool float_column = spec.column && (spec.column->data_type == HY_TYPE_FLOAT || spec.column->data_type == HY_TYPE_DOUBLE);
+    const bool float_column = has_input(g) && (input_type(g) == HY_TYPE_FLOAT || input_type(g) == HY_TYPE_DOUBLE);
     if (float_column && (spec.function == HY_AGG_SUM || spec.function == HY_AGG_AVG)) {
       for (uint32_t earlier = 0; earlier < g && primary[g] < 0; ++earlier) {
-        if (specs[earlier].column == spec.column && (specs[earlier].function == HY_AGG_SUM || specs[earlier].function == HY_AGG_AVG)) primary[g] = primary[earlier];
+        if (has_input(earlier) && same_input(earlier, g) && (specs[earlier].function == HY_AGG_SUM || specs[earlier].function == HY_AGG_AVG)) primary[g] = primary[earlier];
       }
       if (primary[g] >= 0) continue;
     }
     const uint32_t wanted = spec.function == HY_AGG_STDDEV_SAMP ? 2 : 1;
     if (n_device + wanted > MAX_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "more than %u device accumulators stay on the CPU path", MAX_AGGREGATES);
     primary[g] = static_cast<int>(n_device);
+    spec_of_device[n_device] = g;
+    if (fused) {
+      wire_expression(a.aggregates[n_device++], g, spec.function);
+      continue;
+    }
     wire(a.aggregates[n_device++], spec.column, spec.function == HY_AGG_STDDEV_SAMP ? AGG_SUM_SHIFTED : spec.function);
     if (spec.function == HY_AGG_STDDEV_SAMP) {
       secondary[g] = static_cast<int>(n_device);
@@ -1779,6 +2545,11 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     for (uint32_t d = 0; d < n_device; ++d) if (wired[d].segments) place[d] = next++;
     for (uint32_t d = 0; d < n_device; ++d) if (!wired[d].segments) place[d] = next++;
     for (uint32_t d = 0; d < n_device; ++d) a.aggregates[place[d]] = wired[d];
+    {
+      uint32_t moved[MAX_AGGREGATES];
+      for (uint32_t d = 0; d < n_device; ++d) moved[place[d]] = spec_of_device[d];
+      for (uint32_t d = 0; d < n_device; ++d) spec_of_device[d] = moved[d];
+    }
     for (uint32_t g = 0; g < n_aggregates; ++g) {
       if (primary[g] >= 0) primary[g] = static_cast<int>(place[primary[g]]);
       if (secondary[g] >= 0) secondary[g] = static_cast<int>(place[secondary[g]]);
@@ -1796,7 +2567,37 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     if (timing) std::fprintf(stderr, "[aggregate] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   };
   DeviceGroups main_groups;
-  HY_TRY(device_groups(a, shape, main_groups));
+  if (fused) {
+    // the plan in device memory: per filter the chunk jobs (prepare_jobs, like hy_table_scan), per accumulator its input expression
+    const uint32_t n_chunks = shape->n_chunks;
+    std::vector<size_t> staging_at(fused->n_filters + 1, 0);
+    for (uint32_t f = 0; f < fused->n_filters; ++f) staging_at[f + 1] = staging_at[f] + align_up(scan_jobs_staging_bytes(fused->filters[f].column, &fused->filters[f].predicate), 256);
+    const size_t jobs_bytes = align_up(sizeof(ScanJob) * (size_t{n_chunks} + 1), 256);
+    DeviceBuffer plan_buffer;
+    HY_TRY(plan_buffer.alloc(align_up(sizeof(FusedPlan), 256) + jobs_bytes * fused->n_filters + staging_at[fused->n_filters] + 256));
+    char* base = plan_buffer.as<char>();
+    char* jobs_base = base + align_up(sizeof(FusedPlan), 256);
+    char* staging_base = jobs_base + jobs_bytes * fused->n_filters;
+    FusedPlan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    plan.n_filters = fused->n_filters;
+    for (uint32_t f = 0; f < fused->n_filters; ++f) {
+      ScanJob* jobs = reinterpret_cast<ScanJob*>(jobs_base + jobs_bytes * f);
+      HY_TRY(prepare_scan_jobs(fused->filters[f].column, &fused->filters[f].predicate, jobs, staging_base + staging_at[f]));
+      plan.filters[f].segments = fused->filters[f].column->d_segments;
+      plan.filters[f].jobs = jobs;
+    }
+    plan.n_columns = fused->n_columns;
+    plan.lds_slots = fused_lds_slots(n_groupby);
+    plan.debug = getenv("HY_FUSED_DEBUG") ? static_cast<uint32_t>(atoi(getenv("HY_FUSED_DEBUG"))) : 0u;
+    for (uint32_t c = 0; c < fused->n_columns; ++c) plan.columns[c] = fused->columns[c]->d_segments;
+    for (uint32_t d = 0; d < n_device; ++d) plan.inputs[d] = fused->inputs[spec_of_device[d]];
+    HY_HIP(hipMemcpyAsync(base, &plan, sizeof(plan), hipMemcpyHostToDevice, stream));
+    HY_HIP(hipStreamSynchronize(stream));   // (`plan` is a stack object)
+    HY_TRY(device_groups(a, shape, main_groups, reinterpret_cast<const FusedPlan*>(base)));
+  } else {
+    HY_TRY(device_groups(a, shape, main_groups));
+  }
   lap("device groups on host");
   const uint32_t n_groups = main_groups.n_groups;
   const std::vector<uint64_t>&h_keys = main_groups.keys, &h_first = main_groups.first, &h_last = main_groups.last, &h_values = main_groups.values,
@@ -1838,7 +2639,8 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       min_key = std::min(min_key, k);
       max_key = std::max(max_key, k);
     }
-    immediate = max_key > 0 && static_cast<double>(max_key - min_key) < static_cast<double>(shape->rows) * 1.2;
+    // (the row count is that of the aggregate's INPUT: behind fused filters, the rows that passed them)
+    immediate = max_key > 0 && static_cast<double>(max_key - min_key) < static_cast<double>(fused ? main_groups.passed_rows : shape->rows) * 1.2;
   }
   {   // ascending key (NULL first) or first row: an LSD radix sort of (64-bit sort key, group) -- a comparison sort of 100 000 groups
       // through an index costs more than the device spends on the whole table
@@ -1880,7 +2682,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   for (uint32_t g = 0; g < n_aggregates; ++g) {
     hy_aggregate_column& col = result->columns[g];
     const uint32_t function = specs[g].function;
-    const uint32_t in_type = specs[g].column ? specs[g].column->data_type : HY_TYPE_LONG;
+    const uint32_t in_type = input_type(g);
     const bool is_float = in_type == HY_TYPE_FLOAT || in_type == HY_TYPE_DOUBLE;
     col.data_type = result_type(function, in_type);
     if (!col.values) return fail(HY_ERR_INVALID, "aggregate %u: values buffer missing", g);
@@ -1997,11 +2799,134 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   return HY_OK;
 }
 
+// hy_scan_project_aggregate: checks the plan, types the expressions (expression_common_type per arithmetic node, like
+// hy_projection_arithmetic per call) and runs the aggregate with fused_rows in the place of aggregate_rows.
+static hy_status run_fused(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby, uint32_t n_groupby, const hy_fused_aggregate* aggregates,
+                           uint32_t n_aggregates, hy_aggregate_result* result) {
+  if (n_filters > HY_MAX_FILTERS) return fail(HY_ERR_UNSUPPORTED, "more than %d fused filters: run the operator chain", static_cast<int>(HY_MAX_FILTERS));
+  if (n_aggregates > MAX_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "more than %u aggregates stay on the CPU path", MAX_AGGREGATES);
+  if (n_groupby > MAX_GROUPBY) return fail(HY_ERR_UNSUPPORTED, "more than %u GROUP BY columns stay on the CPU path", MAX_GROUPBY);
+  auto query = std::make_unique<FusedQuery>();
+  FusedQuery& q = *query;
+  std::memset(&q, 0, sizeof(q));
+  const hy_column* shape = nullptr;
+  auto table_column = [&](const hy_column* c, const char* what) -> hy_status {
+    if (!c) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: %s column missing", what);
+    if (c->is_reference || c->is_mvcc) return fail(HY_ERR_UNSUPPORTED, "hy_scan_project_aggregate reads the columns of a data table (%s column is a reference / MVCC column): run the operator chain", what);
+    if (!shape) { shape = c; return HY_OK; }
+    if (c->n_chunks != shape->n_chunks) return fail(HY_ERR_INVALID, "%s column does not belong to the table (chunk counts differ)", what);
+    for (uint32_t k = 0; k < c->n_chunks; ++k) {
+      if (c->host_segments[k].size != shape->host_segments[k].size) return fail(HY_ERR_INVALID, "%s column does not belong to the table (chunk %u)", what, k);
+    }
+    return HY_OK;
+  };
+  auto numeric = [](uint32_t t) { return t >= HY_TYPE_INT && t <= HY_TYPE_DOUBLE; };
+  for (uint32_t f = 0; f < n_filters; ++f) HY_TRY(table_column(filters[f].column, "filter"));
+  for (uint32_t g = 0; g < n_groupby; ++g) HY_TRY(table_column(groupby[g], "GROUP BY"));
+  for (uint32_t g = 0; g < n_aggregates; ++g) {
+    const hy_expression* e = aggregates[g].input;
+    FusedInput& input = q.inputs[g];
+    q.same_as[g] = g;
+    if (!e) continue;   // COUNT(*)
+    if (e->n_nodes == 0 || e->n_nodes > HY_MAX_EXPRESSION_NODES) return fail(HY_ERR_INVALID, "aggregate %u: an expression has 1 to %d nodes", g, static_cast<int>(HY_MAX_EXPRESSION_NODES));
+    uint32_t types[4] = {0, 0, 0, 0}, depth = 0;
+    int producers[4] = {-1, -1, -1, -1};   // the LITERAL node that put the stack entry there, else -1
+    for (uint32_t k = 0; k < e->n_nodes; ++k) {
+      const hy_expression_node& n = e->nodes[k];
+      FusedNode& out = input.nodes[k];
+      out.kind = n.kind;
+      if (n.kind == HY_EXPR_ARITHMETIC) {
+        if (n.op > HY_ARITH_MOD) return fail(HY_ERR_INVALID, "aggregate %u: unknown arithmetic operator %u", g, n.op);
+        if (depth < 2) return fail(HY_ERR_INVALID, "aggregate %u: node %u has no two operands below it (postfix order)", g, k);
+        const uint32_t left = types[depth - 2], right = types[depth - 1];
+        if (left == HY_TYPE_NULL && right == HY_TYPE_NULL) return fail(HY_ERR_INVALID, "Cannot deduce common type if both sides are NULL.");
+        out.op = n.op;
+        out.type = expression_common_type(left, right);
+        // A literal operand of + - * is converted to the operation's C++ type before anything is computed (arithmetic_cell): done here, once,
+        // so that the kernel finds two operands of the result's own type and takes its one-instruction path.
+        if (n.op <= HY_ARITH_MUL) {
+          for (int side = 0; side < 2; ++side) {
+            const uint32_t at = side == 0 ? left : right, other = side == 0 ? right : left;
+            const int producer = side == 0 ? producers[depth - 2] : producers[depth - 1];
+            if (producer < 0 || at == HY_TYPE_NULL || other == HY_TYPE_NULL) continue;
+            FusedNode& literal = input.nodes[producer];
+            const uint32_t common = (at == HY_TYPE_DOUBLE || other == HY_TYPE_DOUBLE) ? HY_TYPE_DOUBLE : (at == HY_TYPE_FLOAT || other == HY_TYPE_FLOAT) ? HY_TYPE_FLOAT
+                                    : (at == HY_TYPE_LONG || other == HY_TYPE_LONG) ? HY_TYPE_LONG : HY_TYPE_INT;   // std::common_type_t
+            if (common == at || common != out.type) continue;   // (int (op) long literal: the result type is the common type as well; long (op) float -> double is not)
+            double as_double = 0.0;
+            float as_float = 0.f;
+            int64_t as_integer = static_cast<int64_t>(literal.literal);
+            if (at == HY_TYPE_FLOAT) { uint32_t word = static_cast<uint32_t>(literal.literal); std::memcpy(&as_float, &word, 4); as_double = as_float; }
+            else as_double = static_cast<double>(as_integer);
+            if (common == HY_TYPE_DOUBLE) std::memcpy(&literal.literal, &as_double, 8);
+            else if (common == HY_TYPE_FLOAT) { as_float = static_cast<float>(as_double); uint32_t word; std::memcpy(&word, &as_float, 4); literal.literal = word; }   // (via double, like the device's convert())
+            else literal.literal = static_cast<uint64_t>(as_integer);   // int -> long
+            literal.type = common;
+          }
+        }
+        depth -= 1;
+        types[depth - 1] = out.type;
+        producers[depth - 1] = -1;
+        continue;
+      }
+      if (depth == 3) return fail(HY_ERR_UNSUPPORTED, "aggregate %u: the expression needs more than three stack slots: run the operator chain", g);
+      if (n.kind == HY_EXPR_COLUMN) {
+        HY_TRY(table_column(n.column, "expression"));
+        if (!numeric(n.column->data_type)) return fail(HY_ERR_UNSUPPORTED, "string expressions stay on the CPU path");
+        uint32_t which = 0;
+        while (which < q.n_columns && q.columns[which] != n.column) ++which;
+        if (which == q.n_columns) {
+          if (q.n_columns == static_cast<uint32_t>(FUSED_COLUMNS)) return fail(HY_ERR_UNSUPPORTED, "the expressions read more than %d distinct columns: run the operator chain", FUSED_COLUMNS);
+          q.columns[q.n_columns++] = n.column;
+        }
+        out.column = which;
+        out.type = n.column->data_type;
+      } else if (n.kind == HY_EXPR_LITERAL) {
+        if (n.literal_type != HY_TYPE_NULL && !numeric(n.literal_type)) return fail(HY_ERR_UNSUPPORTED, "string expressions stay on the CPU path");
+        out.type = n.literal_type;
+        double widened = 0.0;
+        switch (n.literal_type) {
+          case HY_TYPE_INT: out.literal = static_cast<uint64_t>(static_cast<int64_t>(n.literal.i32)); break;
+          case HY_TYPE_LONG: out.literal = static_cast<uint64_t>(n.literal.i64); break;
+          case HY_TYPE_FLOAT: { uint32_t word; std::memcpy(&word, &n.literal.f32, 4); out.literal = word; break; }   // (floats travel as their own bits)
+          case HY_TYPE_DOUBLE: widened = n.literal.f64; std::memcpy(&out.literal, &widened, 8); break;
+          default: break;
+        }
+      } else {
+        return fail(HY_ERR_INVALID, "aggregate %u: unknown expression node kind %u", g, n.kind);
+      }
+      producers[depth] = n.kind == HY_EXPR_LITERAL ? static_cast<int>(k) : -1;
+      types[depth++] = out.type;
+    }
+    if (depth != 1) return fail(HY_ERR_INVALID, "aggregate %u: the expression leaves %u results (postfix order)", g, depth);
+    if (types[0] == HY_TYPE_NULL) return fail(HY_ERR_UNSUPPORTED, "aggregate %u: an aggregate of the NULL literal stays on the CPU path", g);
+    input.n_nodes = e->n_nodes;
+    input.type = types[0];
+    for (uint32_t earlier = 0; earlier < g; ++earlier) {
+      if (std::memcmp(&q.inputs[earlier], &input, sizeof(FusedInput)) == 0) { q.same_as[g] = q.same_as[earlier]; break; }
+    }
+  }
+  if (!shape) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate needs at least one column");
+  q.shape = shape;
+  q.filters = filters;
+  q.n_filters = n_filters;
+  std::vector<hy_aggregate_spec> specs(n_aggregates ? n_aggregates : 1);
+  for (uint32_t g = 0; g < n_aggregates; ++g) specs[g] = hy_aggregate_spec{aggregates[g].function, nullptr};
+  return run_aggregate(groupby, n_groupby, specs.data(), n_aggregates, result, &q);
+}
+
 }  // namespace hy
 
 using namespace hy;
 
 extern "C" {
+
+hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
+                                    const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result) {
+  if (!result || (n_filters && !filters) || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: null argument");
+  if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: result columns missing");
+  return run_fused(filters, n_filters, groupby_columns, n_groupby, aggregates, n_aggregates, result);
+}
 
 hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates,
                             uint32_t n_aggregates, hy_aggregate_result* result) {

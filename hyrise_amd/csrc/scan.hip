@@ -22,42 +22,13 @@
 //   compact_regions  (host results only) packs the regions back to back.
 // HBM-bound integer work: no MFMA anywhere.
 #include "hy_device.hpp"
+#include "hy_scan_job.hpp"
 
 #include <cmath>
 #include <cstring>
 #include <limits>
 
 namespace hy {
-
-// ---- per-chunk normalised predicate ---------------------------------------------------------------------------------
-enum : uint32_t { JOB_SCAN = 0, JOB_ALL = 1, JOB_NONE = 2 };
-enum : uint32_t { KIND_U32 = 0, KIND_I64 = 1, KIND_F32 = 2, KIND_F64 = 3, KIND_NULLTEST = 4,
-                  KIND_VISIBLE = 5 /* Validate: lo = snapshot commit id, span = our transaction id */,
-                  KIND_VALUE_ID_SET = 6 /* LIKE family on dictionaries: lo = device address of the chunk's match bitmap */ };
-enum : uint32_t { JF_INVERT = 1, JF_LOWER_INCL = 2, JF_UPPER_INCL = 4, JF_NEVER = 8 };
-
-struct ScanJob {
-  uint32_t mode;       // JOB_*
-  uint32_t kind;       // KIND_*
-  uint32_t flags;      // JF_*
-  uint32_t null_vid;   // dictionary: value id that encodes NULL (aux_size); else 0xFFFFFFFF
-  uint64_t lo;         // integer lower bound (bit pattern) | float/double lower bound bits
-  uint64_t span;       // integer hi - lo                   | float/double upper bound bits
-};
-
-struct PredicateArgs {
-  uint32_t condition;
-  uint32_t value_type;
-  hy_value value;
-  hy_value value2;
-  const uint32_t* per_chunk_lower;
-  const uint32_t* per_chunk_upper;
-  const uint8_t* per_chunk_found;
-  const uint64_t* match_words;          // LIKE family: per data chunk a bitmap over the dictionary's value ids
-  const uint64_t* match_word_offsets;
-  uint32_t column_is_nullable;
-  uint32_t materialize_all;
-};
 
 __device__ __forceinline__ bool is_between(uint32_t c) { return c >= HY_PRED_BETWEEN_INCLUSIVE && c <= HY_PRED_BETWEEN_EXCLUSIVE; }
 __device__ __forceinline__ bool lower_inclusive(uint32_t c) { return c == HY_PRED_BETWEEN_INCLUSIVE || c == HY_PRED_BETWEEN_UPPER_EXCLUSIVE; }
@@ -1389,6 +1360,47 @@ static hy_status validate_predicate(const hy_column* column, const hy_predicate*
       return fail(HY_ERR_INVALID, "literal type %u differs from column type %u: use the lossless predicate cast first", p->value_type, column->data_type);
     }
   }
+  return HY_OK;
+}
+
+size_t scan_jobs_staging_bytes(const hy_column* column, const hy_predicate* predicate) {
+  size_t bytes = 4 * 256 + 9 * (size_t{column->n_chunks} + 64);   // prepare_jobs' status word | the per-chunk arrays, 256-byte aligned
+  if (predicate->match_words && predicate->match_word_offsets) bytes += 2 * 256 + 8 * (size_t{column->n_chunks} + 2) + 8 * (predicate->match_word_offsets[column->n_chunks] + 2);
+  return bytes;
+}
+
+// (what run_scan does for its own predicate, for callers that evaluate the jobs themselves)
+hy_status prepare_scan_jobs(const hy_column* column, const hy_predicate* predicate, ScanJob* jobs, void* staging) {
+  if (column->is_reference || column->is_mvcc) return fail(HY_ERR_INVALID, "prepare_scan_jobs: data columns only");
+  HY_TRY(validate_predicate(column, predicate));
+  const uint32_t n_chunks = column->n_chunks;
+  hipStream_t stream = current_stream();
+  PredicateArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.condition = predicate->condition;
+  pa.value_type = predicate->value_type;
+  pa.value = predicate->value;
+  pa.value2 = predicate->value2;
+  pa.column_is_nullable = predicate->column_is_nullable;
+  char* cursor = static_cast<char*>(staging) + 256;
+  auto stage = [&](const void* host, size_t bytes, const void** dev) -> hy_status {
+    *dev = nullptr;
+    if (!host) return HY_OK;
+    if (bytes) HY_HIP(hipMemcpyAsync(cursor, host, bytes, hipMemcpyHostToDevice, stream));
+    *dev = cursor;
+    cursor += align_up(bytes ? bytes : 4, 256);
+    return HY_OK;
+  };
+  const void* d;
+  HY_TRY(stage(predicate->per_chunk_lower, 4 * size_t{n_chunks}, &d)); pa.per_chunk_lower = static_cast<const uint32_t*>(d);
+  HY_TRY(stage(predicate->per_chunk_upper, 4 * size_t{n_chunks}, &d)); pa.per_chunk_upper = static_cast<const uint32_t*>(d);
+  HY_TRY(stage(predicate->per_chunk_found, size_t{n_chunks}, &d)); pa.per_chunk_found = static_cast<const uint8_t*>(d);
+  if (predicate->match_words && predicate->match_word_offsets) {
+    const uint64_t total_words = predicate->match_word_offsets[n_chunks];
+    HY_TRY(stage(predicate->match_word_offsets, 8 * (size_t{n_chunks} + 1), &d)); pa.match_word_offsets = static_cast<const uint64_t*>(d);
+    HY_TRY(stage(predicate->match_words, 8 * (total_words ? total_words : 1), &d)); pa.match_words = static_cast<const uint64_t*>(d);
+  }
+  if (n_chunks) hipLaunchKernelGGL(prepare_jobs, dim3(n_chunks), dim3(256), 0, stream, column->d_segments, n_chunks, pa, jobs, static_cast<uint32_t*>(staging));
   return HY_OK;
 }
 

@@ -348,3 +348,63 @@ def aggregate_hash(groupby_columns, aggregates, group_capacity=None):
     result = HostAggregateResult(len(aggregates), (shape.rows + 1) if group_capacity is None else group_capacity)
     abi.check(lib.hy_aggregate_hash(garr, len(groupby_columns), specs, len(aggregates), C.byref(result.c)))
     return result
+
+
+def expression(tree):
+    """An arithmetic expression as hy_expression (postfix).  tree: a column (DeviceColumn), a literal (HY_TYPE_*, value), None (the
+    NULL literal) or (abi.ARITH_*, left tree, right tree)."""
+    e = abi.Expression()
+    nodes = []
+
+    def walk(t):
+        n = abi.ExpressionNode()
+        if hasattr(t, "handle"):
+            n.kind, n.column = abi.EXPR_COLUMN, t.handle
+        elif t is None or len(t) == 2:
+            literal = _operand(t)
+            n.kind, n.literal_type, n.literal = abi.EXPR_LITERAL, literal.literal_type, literal.literal
+        else:
+            op, left, right = t
+            walk(left)
+            walk(right)
+            n.kind, n.op = abi.EXPR_ARITHMETIC, op
+        nodes.append(n)
+
+    walk(tree)
+    if len(nodes) > abi.MAX_EXPRESSION_NODES:
+        raise ValueError(f"an expression has at most {abi.MAX_EXPRESSION_NODES} nodes")
+    e.n_nodes = len(nodes)
+    for i, n in enumerate(nodes):
+        e.nodes[i] = n
+    return e
+
+
+def scan_project_aggregate(filters, groupby_columns, aggregates, group_capacity=None):
+    """hy_scan_project_aggregate: TableScan(s) -> Projection -> AggregateHash of one data table in one pass.
+    filters: [(DeviceColumn, predicate)], ANDed in order; aggregates: [(HY_AGG_*, expression tree or None for COUNT(*))]."""
+    lib = abi.load_library()
+    farr = (abi.Filter * max(1, len(filters)))()
+    for i, (column, predicate) in enumerate(filters):
+        farr[i].column = column.handle
+        farr[i].predicate = predicate          # (a copy of the struct; `filters` keeps the arrays it points to alive)
+    garr = (C.c_void_p * max(1, len(groupby_columns)))(*[c.handle for c in groupby_columns])
+    expressions = [expression(tree) if tree is not None or function != abi.AGG_COUNT else None for function, tree in aggregates]
+    specs = (abi.FusedAggregate * max(1, len(aggregates)))()
+    for i, (function, _) in enumerate(aggregates):
+        specs[i].function = function
+        if expressions[i] is not None:
+            specs[i].input = C.pointer(expressions[i])
+
+    def columns_of(tree):
+        if hasattr(tree, "handle"):
+            yield tree
+        elif tree is not None and len(tree) == 3:
+            yield from columns_of(tree[1])
+            yield from columns_of(tree[2])
+
+    table = [c for c, _ in filters] + list(groupby_columns) + [c for _, tree in aggregates for c in columns_of(tree)]
+    if not table:
+        raise ValueError("hy_scan_project_aggregate needs at least one column")
+    result = HostAggregateResult(len(aggregates), (table[0].rows + 1) if group_capacity is None else group_capacity)
+    abi.check(lib.hy_scan_project_aggregate(farr, len(filters), garr, len(groupby_columns), specs, len(aggregates), C.byref(result.c)))
+    return result

@@ -185,3 +185,58 @@ def run_q6(ex, columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discou
     revenue = ex.projection(abi.ARITH_MUL, ex.reference_column_chunked(columns["l_extendedprice"], lists), ex.reference_column_chunked(columns["l_discount"], lists))
     result = ex.aggregate([], [(abi.AGG_SUM, revenue), (abi.AGG_COUNT, None)])
     return result.column(0)[0], result.column(1)[0]
+
+
+def q6_fused(columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discount=(0.05, 0.07), quantity=24.0):
+    """The same Q6 in ONE pass over lineitem (hy_scan_project_aggregate): no PosList, no product column.  `columns`: DeviceColumns of the
+    data table.  -> (revenue, qualifying rows)"""
+    from .operators import make_predicate, scan_project_aggregate
+    result = scan_project_aggregate(
+        [(columns["l_shipdate"], make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, date_from, date_to)),
+         (columns["l_discount"], make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, np.float32(discount[0]), np.float32(discount[1]))),
+         (columns["l_quantity"], make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, quantity))],
+        [], [(abi.AGG_SUM, (abi.ARITH_MUL, columns["l_extendedprice"], columns["l_discount"])), (abi.AGG_COUNT, None)], group_capacity=4)
+    return result.column(0)[0], result.column(1)[0]
+
+
+# ---- TPC-H Q1, the whole query (tpch_queries.cpp:60-80): scan, two expressions, eight aggregates ---------------------------------------
+Q1_AGGREGATES = ("sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order")
+
+
+def q1_columns(data, chunk_size=abi.CHUNK_DEFAULT_SIZE):
+    """The seven lineitem columns Q1 reads, encoded like q1_core_columns (+ l_shipdate as a dictionary of days, l_tax)."""
+    groupby, measures, _ = q1_core_columns(data, chunk_size)
+    columns = dict(measures)
+    columns["l_returnflag"], columns["l_linestatus"] = groupby
+    columns["l_shipdate"] = storage.make_column(data.l_shipdate, None, abi.ENC_DICTIONARY, chunk_size)
+    columns["l_tax"] = storage.make_column(data.l_tax, None, abi.ENC_DICTIONARY, chunk_size)
+    return columns
+
+
+def _q1_aggregates(quantity, price, discount, disc_price, charge):
+    return [(abi.AGG_SUM, quantity), (abi.AGG_SUM, price), (abi.AGG_SUM, disc_price), (abi.AGG_SUM, charge), (abi.AGG_AVG, quantity), (abi.AGG_AVG, price),
+            (abi.AGG_AVG, discount), (abi.AGG_COUNT, None)]
+
+
+def run_q1(ex, columns, ship_to=DAY_1998_09_02):
+    """Q1 the way the reference's plan runs it: TableScan l_shipdate <= :to, Projection of l_extendedprice * (1 - l_discount) and of
+    that * (1 + l_tax) over the survivors (four ArithmeticExpressions, each materialised), AggregateHash GROUP BY l_returnflag,
+    l_linestatus.  -> aggregate result (the ORDER BY is not part of the path)"""
+    from .operators import make_predicate
+    lists = ex.scan_chunked(columns["l_shipdate"], make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, ship_to))
+    ref = {name: ex.reference_column_chunked(column, lists) for name, column in columns.items() if name != "l_shipdate"}
+    one = (abi.TYPE_INT, 1)
+    disc_price = ex.projection(abi.ARITH_MUL, ref["l_extendedprice"], ex.projection(abi.ARITH_SUB, one, ref["l_discount"]))
+    charge = ex.projection(abi.ARITH_MUL, disc_price, ex.projection(abi.ARITH_ADD, one, ref["l_tax"]))
+    return ex.aggregate([ref["l_returnflag"], ref["l_linestatus"]], _q1_aggregates(ref["l_quantity"], ref["l_extendedprice"], ref["l_discount"], disc_price, charge))
+
+
+def q1_fused(columns, ship_to=DAY_1998_09_02):
+    """The same Q1 in ONE pass over lineitem (hy_scan_project_aggregate)."""
+    from .operators import make_predicate, scan_project_aggregate
+    one = (abi.TYPE_INT, 1)
+    disc_price = (abi.ARITH_MUL, columns["l_extendedprice"], (abi.ARITH_SUB, one, columns["l_discount"]))
+    charge = (abi.ARITH_MUL, disc_price, (abi.ARITH_ADD, one, columns["l_tax"]))
+    return scan_project_aggregate([(columns["l_shipdate"], make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, ship_to))],
+                                  [columns["l_returnflag"], columns["l_linestatus"]],
+                                  _q1_aggregates(columns["l_quantity"], columns["l_extendedprice"], columns["l_discount"], disc_price, charge), group_capacity=4096)

@@ -372,6 +372,49 @@ typedef struct hy_aggregate_result {
 hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby,
                             const hy_aggregate_spec* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
 
+/* ---- fused TableScan(s) -> Projection -> AggregateHash over ONE data table --------------------
+ * The plan shape of TPC-H Q1 / Q6 (tpch_queries.cpp:60-80, 206-210): a chain of ColumnVsValue / Between / IsNull / LIKE scans
+ * on columns of one table (table_scan.cpp:97-240), a Projection of arithmetic expressions over the survivors
+ * (operators/projection.cpp, expression_functors.hpp:127-213) and an AggregateHash of them (aggregate_hash.cpp:1180-1372).
+ * The reference materialises a PosList per scan and an ExpressionResult vector per expression node; hy_table_scan ->
+ * hy_poslist_translate -> hy_projection_arithmetic -> hy_aggregate_hash do the same in HBM.  This entry point evaluates the
+ * whole chain in ONE pass over the table: a row is tested against every filter (the same normalised per-chunk tests
+ * hy_table_scan evaluates: NULL never matches), the expressions are computed for the rows that pass -- cell by cell with
+ * the types and NULL rules of hy_projection_arithmetic -- and fed to the accumulators of hy_aggregate_hash.  No PosList and
+ * no expression column is written.  Results are those of the chain: same groups, same group order, same values (sums
+ * of floating-point inputs within the tolerance hy_aggregate_hash states); group_row_ids name rows of the DATA table (the
+ * chain's name rows of its last intermediate table).
+ * Expressions are in postfix order over at most HY_MAX_EXPRESSION_NODES nodes and three stack slots:
+ * l_extendedprice * (1 - l_discount) is  COLUMN l_extendedprice, LITERAL 1, COLUMN l_discount, ARITHMETIC SUB, ARITHMETIC MUL.
+ * All columns are data columns (no reference segments) of one table.  HY_ERR_UNSUPPORTED: more than HY_MAX_FILTERS filters,
+ * aggregate functions other than MIN / MAX / SUM / AVG / COUNT, string expressions -- run the chain instead. */
+enum { HY_EXPR_COLUMN = 0, HY_EXPR_LITERAL = 1, HY_EXPR_ARITHMETIC = 2 };
+enum { HY_MAX_EXPRESSION_NODES = 12, HY_MAX_FILTERS = 4 };
+typedef struct hy_expression_node {
+  uint32_t kind;                  /* HY_EXPR_*                                                                         */
+  uint32_t op;                    /* HY_EXPR_ARITHMETIC: HY_ARITH_*, applied to the two results below it on the stack  */
+  const hy_column* column;        /* HY_EXPR_COLUMN                                                                    */
+  uint32_t literal_type;          /* HY_EXPR_LITERAL: HY_TYPE_* (HY_TYPE_NULL: the NULL literal)                       */
+  uint32_t reserved;
+  hy_value literal;
+} hy_expression_node;
+typedef struct hy_expression {
+  uint32_t n_nodes;
+  uint32_t reserved;
+  hy_expression_node nodes[HY_MAX_EXPRESSION_NODES];
+} hy_expression;
+typedef struct hy_filter {
+  const hy_column* column;
+  hy_predicate predicate;         /* as for hy_table_scan (literals already cast: hy_predicate_cast)                   */
+} hy_filter;
+typedef struct hy_fused_aggregate {
+  uint32_t function;              /* HY_AGG_MIN / MAX / SUM / AVG / COUNT                                              */
+  uint32_t reserved;
+  const hy_expression* input;     /* NULL for COUNT(*)                                                                 */
+} hy_fused_aggregate;
+hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
+                                    const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
+
 /* ---- multi-GPU exchange (the reference is one process: these have no counterpart there) ----------------
  * Sharding an operator over GPUs adds one exchange step per operator (hyrise_amd/distributed.py: one process per GPU, RCCL):
  * the broadcast-build JoinHash all-gathers the build side's join column, the repartitioned JoinHash sends every (key, RowID)

@@ -18,6 +18,11 @@ def pytest_configure(config):
 def device():
     """Initialised HIP device; GPU tests fail loudly (no skip, no fallback) when the library or device is missing."""
     from hyrise_amd import abi
+    try:   # tests that hand torch tensors to the library: PyTorch brings its own HIP runtime, which wants to find the device first
+        import torch
+        torch.cuda.init()
+    except Exception:
+        pass
     lib = abi.load_library()
     abi.check(lib.hy_init(0))
     yield lib

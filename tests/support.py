@@ -631,3 +631,68 @@ class AggregateCase:
             for g, v in enumerate(cells):
                 rows[g].append(v)
         return rows
+
+
+# ---- TableScan(s) -> Projection -> AggregateHash, operator by operator, on the CPU oracle ----------------------------------------
+def oracle_chain(filters, groupby, aggregates):
+    """What hy_scan_project_aggregate fuses, run the reference's way: every scan reads the PosLists of the one before
+    (table_scan.cpp:158-196), the expressions are materialised node by node over the survivors (oracle_arithmetic), the
+    aggregate runs on that reference table.  filters: [(HostColumn, predicate)]; aggregates: [(function, tree or None)], tree =
+    HostColumn | (HY_TYPE_*, value) | None | (ARITH_*, tree, tree).
+    -> (aggregate result, RowIDs of the data table behind the rows of the aggregate's input table)"""
+    from oracle_executor import OracleExecutor
+    ex = OracleExecutor()
+    lists = None
+    for column, predicate in filters:
+        lists = ex.scan_chunked(column if lists is None else ex.reference_column_chunked(column, lists), predicate)
+
+    def view(column):
+        return column if lists is None else ex.reference_column_chunked(column, lists)
+
+    table = [c for c, _ in filters] + list(groupby)
+
+    def columns_of(tree):
+        if hasattr(tree, "segments"):
+            yield tree
+        elif tree is not None and len(tree) == 3:
+            yield from columns_of(tree[1])
+            yield from columns_of(tree[2])
+
+    for _, tree in aggregates:
+        table.extend(columns_of(tree))
+    shape = view(table[0])
+    sizes = [s.size for s in shape.segments]
+    rows = int(sum(sizes))
+
+    def evaluate(tree):
+        if hasattr(tree, "segments"):
+            cells = column_values(view(tree))
+            nulls = np.array([c is None for c in cells], dtype=bool)
+            return np.array([0 if c is None else c for c in cells], dtype=_NP_OF_TYPE[tree.data_type]), (nulls if nulls.any() else None)
+        if tree is None or len(tree) == 2:
+            return tree
+        op, left, right = tree
+        values, nulls = oracle_arithmetic(op, evaluate(left), evaluate(right), n=rows)
+        return values, (nulls if nulls.any() else None)
+
+    def materialise(tree):
+        result = evaluate(tree)
+        assert result is not None and isinstance(result[0], np.ndarray), "an aggregate of a literal is not a case of these tests"
+        values, nulls = result
+        segments, begin = [], 0
+        for size in sizes:
+            segments.append(storage.encode_segment(values[begin:begin + size], None if nulls is None else nulls[begin:begin + size], abi.ENC_UNENCODED))
+            begin += size
+        return storage.HostColumn(segments, storage.TYPE_OF_NP[values.dtype])
+
+    inputs = [(function, materialise(tree) if tree is not None else None) for function, tree in aggregates]
+    if not groupby and all(c is None for _, c in inputs):   # a lone COUNT(*): the oracle wants one column for the table's shape
+        result = oracle_aggregate([], inputs + [(abi.AGG_COUNT, shape)])
+    else:
+        result = oracle_aggregate([view(c) for c in groupby], inputs)
+    if lists is None:
+        base_rows = np.array(row_ids_of(shape), dtype=np.uint32).reshape(-1, 2)
+    else:
+        kept = [rows_ for rows_ in lists.lists if len(rows_)]
+        base_rows = np.concatenate(kept).astype(np.uint32).reshape(-1, 2) if kept else np.zeros((0, 2), dtype=np.uint32)
+    return result, base_rows, sizes
