@@ -372,9 +372,53 @@ def q6_leg(torch, dev, steps):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     read = sum(s.size * s.width + s.aux_size * 4 for s in host["l_shipdate"].segments)                       # first scan: the whole attribute vector
+    # the same query in ONE pass (hy_scan_project_aggregate): no PosList, no product column
+    fused_revenue, fused_rows = tpch.q6_fused(columns)
+    if fused_rows != qualifying or abs(fused_revenue - exact) > 1e-9 * exact:
+        raise SystemExit(f"Q6 fused: {fused_rows} rows / {fused_revenue}, numpy says {int(keep.sum())} / {exact}")
+    lib = ex.lib
+    fused_dt, fused_kernel_ms = timed_kernel(lib, torch, lambda: tpch.q6_fused(columns), steps)
+    # what the fused kernel must read: the three filter columns in full (stored words), price and discount entries of the survivors
+    fused_bytes = sum(s.size * s.width for name in ("l_shipdate", "l_discount", "l_quantity") for s in host[name].segments) + qualifying * (4 + 4)
     return {"workload": "configs[0] on one GPU: TPC-H Q6, SF10 lineitem, scan -> scan -> scan -> projection -> aggregate over device-resident PosLists",
             "ms_per_query": dt * 1e3, "lineitem_rows_per_s": data.n_lineitems / dt, "qualifying_rows": qualifying, "revenue": revenue,
-            "first_scan_bytes": read, "note": "every intermediate stays in HBM; 8 bytes (a match count) per scan cross to the host"}
+            "first_scan_bytes": read, "note": "every intermediate stays in HBM; 8 bytes (a match count) per scan cross to the host",
+            "fused": {"workload": "the same query as ONE hy_scan_project_aggregate call (kernel fused_rows): three filters, l_extendedprice * l_discount, SUM + COUNT(*)",
+                      "ms_per_query": fused_dt * 1e3, "lineitem_rows_per_s": data.n_lineitems / fused_dt, "speedup_over_the_chain": dt / fused_dt,
+                      "roofline": roofline_object("fused_rows", fused_bytes, fused_kernel_ms)}}
+
+
+def q1_leg(lib, torch, dev, steps):
+    """TPC-H Q1, the whole query (tpch_queries.cpp:60-80) at SF10: the operator chain (scan, four ArithmeticExpressions materialised over the
+    reference table, AggregateHash of eight aggregates) beside the one-pass hy_scan_project_aggregate; the two results are compared."""
+    from hyrise_amd import tpch
+    from hyrise_amd.distributed import HipExecutor
+    from hyrise_amd.storage import DeviceColumn
+    data = sf10_tables()
+    host = tpch.q1_columns(data)
+    columns = {name: DeviceColumn(column) for name, column in host.items()}
+    ex = HipExecutor(dev)
+    chain, fused = tpch.run_q1(ex, columns), tpch.q1_fused(columns)
+    if chain.n_groups != fused.n_groups:
+        raise SystemExit("Q1: the fused pass and the operator chain disagree on the groups")
+    for a, name in enumerate(tpch.Q1_AGGREGATES):
+        for x, y in zip(chain.column(a), fused.column(a)):
+            if abs(x - y) > 1e-9 * max(1.0, abs(y)):
+                raise SystemExit(f"Q1 {name}: chain {x}, fused {y}")
+    steps = max(3, min(steps, 10))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tpch.run_q1(ex, columns)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fused_dt, fused_kernel_ms = timed_kernel(lib, torch, lambda: tpch.q1_fused(columns), steps)
+    fused_bytes = sum(s.size * s.width + s.aux_size * (s.aux.dtype.itemsize if s.aux is not None else 0) for column in host.values() for s in column.segments)
+    return {"workload": "TPC-H Q1 (the whole query: l_shipdate <= 1998-09-02, two expressions, eight aggregates, GROUP BY l_returnflag, l_linestatus), SF10 lineitem, "
+                        "columns encoded as config 4 specifies",
+            "chain_ms_per_query": dt * 1e3, "groups": fused.n_groups, "count_order": fused.column(7),
+            "fused": {"workload": "ONE hy_scan_project_aggregate call (kernel fused_rows)", "ms_per_query": fused_dt * 1e3, "lineitem_rows_per_s": data.n_lineitems / fused_dt,
+                      "speedup_over_the_chain": dt / fused_dt, "roofline": roofline_object("fused_rows", fused_bytes, fused_kernel_ms)}}
 
 
 def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, width):
@@ -558,6 +602,7 @@ def main():
     aggregate_info = aggregate_leg(lib, torch, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_aggregate else None
 
     q6_info = q6_leg(torch, dev, args.steps) if single and not args.no_cases else None
+    q1_info = q1_leg(lib, torch, dev, args.steps) if single and not args.no_cases else None
 
     multi = None
     if world > 1 and not args.no_multi and not args.rows:
@@ -590,6 +635,8 @@ def main():
             line["aggregate"] = aggregate_info
         if q6_info:
             line["q6"] = q6_info
+        if q1_info:
+            line["q1"] = q1_info
         if multi:
             line["multi_gpu"] = multi
         if ssb_info:

@@ -220,3 +220,44 @@ def test_aggregate_many_groups_at_size(device):
     lib = abi.load_library()
     lib.hy_debug_aggregate_path.restype = int
     assert lib.hy_debug_aggregate_path() > 0
+
+
+def test_fused_q6_and_q1_sf10(device, sf10):
+    """hy_scan_project_aggregate at full size: TPC-H Q6 against numpy (exact row count, revenue within the float tolerance) and Q1
+    against an independent numpy evaluation per group (float32 expressions node by node, sums in double) -- and both against the
+    operator chain run on the device."""
+    import torch
+    from hyrise_amd.distributed import HipExecutor
+    ex = HipExecutor(torch.device("cuda", 0))
+    q6 = {name: DeviceColumn(column) for name, column in tpch.q6_columns(sf10).items()}
+    revenue, qualifying = tpch.q6_fused(q6)
+    keep = (sf10.l_shipdate >= tpch.DAY_1994_01_01) & (sf10.l_shipdate < tpch.DAY_1995_01_01) & (sf10.l_discount >= np.float32(0.05)) & \
+           (sf10.l_discount <= np.float32(0.07)) & (sf10.l_quantity < 24)
+    exact = float((sf10.l_extendedprice[keep] * sf10.l_discount[keep]).astype(np.float64).sum())
+    assert qualifying == int(keep.sum())
+    assert abs(revenue - exact) <= 1e-9 * exact
+    chain_revenue, chain_rows = tpch.run_q6(ex, q6)
+    assert chain_rows == qualifying and abs(chain_revenue - revenue) <= 1e-9 * exact
+    del q6
+
+    q1 = {name: DeviceColumn(column) for name, column in tpch.q1_columns(sf10).items()}
+    fused = tpch.q1_fused(q1)
+    chain = tpch.run_q1(ex, q1)
+    assert fused.n_groups == chain.n_groups == 4
+    keep = sf10.l_shipdate <= tpch.DAY_1998_09_02
+    one = np.float32(1)
+    disc_price = (sf10.l_extendedprice * (one - sf10.l_discount)).astype(np.float32)
+    charge = (disc_price * (one + sf10.l_tax)).astype(np.float32)
+    chunk = abi.CHUNK_DEFAULT_SIZE
+    for g in range(4):
+        first = int(fused.row_ids[g][0]) * chunk + int(fused.row_ids[g][1])          # a row of the DATA table: the group's first row
+        members = keep & (sf10.l_returnflag == sf10.l_returnflag[first]) & (sf10.l_linestatus == sf10.l_linestatus[first])
+        assert members[first] and not members[:first].any()
+        n = int(members.sum())
+        want = [sf10.l_quantity[members].astype(np.float64).sum(), sf10.l_extendedprice[members].astype(np.float64).sum(), disc_price[members].astype(np.float64).sum(),
+                charge[members].astype(np.float64).sum(), None, None, None, n]
+        want[4], want[5], want[6] = want[0] / n, want[1] / n, sf10.l_discount[members].astype(np.float64).sum() / n
+        for a, w in enumerate(want):
+            got, through_chain = fused.column(a)[g], chain.column(a)[g]
+            assert abs(got - w) <= 1e-9 * max(1.0, abs(w)), f"group {g} {tpch.Q1_AGGREGATES[a]}: {got} vs numpy {w}"
+            assert abs(got - through_chain) <= 1e-9 * max(1.0, abs(w)), f"group {g} {tpch.Q1_AGGREGATES[a]}: {got} vs the chain's {through_chain}"

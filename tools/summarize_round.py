@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-DOMINANT = {"scan": "scan_slices", "join": "rt_probe_emit", "aggregate": "aggregate_rows"}
+DOMINANT = {"scan": "scan_slices", "join": "rt_probe_emit", "aggregate": "aggregate_rows", "fused": "fused_rows"}
 
 
 def short(name):
@@ -53,6 +53,8 @@ def main():
             kernels[name] = {"launches": max(f[1], w[1]), "FETCH_SIZE_KB_per_launch": f[0] / f[1] if f[1] else None,
                              "WRITE_SIZE_KB_per_launch": w[0] / w[1] if w[1] else None,
                              "hbm_bytes_per_launch": (f[0] / f[1] * 2048 if f[1] else 0) + (w[0] / w[1] * 1024 if w[1] else 0)}
+        if not kernels:   # (a leg collected without counter passes)
+            continue
         summary = {"leg": leg, "dominant_kernel": DOMINANT[leg], "kernels": kernels,
                    "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024; Infinity-Cache hits included"}
         dominant = [k for k in kernels if DOMINANT[leg] in k]
