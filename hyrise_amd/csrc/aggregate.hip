@@ -1353,19 +1353,21 @@ __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, Partition
 // One pass over a data table: a row is tested against every filter (the per-chunk jobs prepare_jobs normalised for hy_table_scan),
 // the aggregates' input expressions are evaluated for the rows that pass, and the results go to the accumulators of the
 // row's group -- a workgroup-private LDS table like aggregate_partitions', merged into the global table at the end of the
-// slice.  No PosList, no expression column: what the chain writes to HBM and reads back (8 bytes per surviving row and scan,
-// 4-8 bytes per row and expression, twice) never exists.  One workgroup per 8192-row slice; every wave owns a quarter of it:
-//   scan      the filters, in plan order, over the wave's 2048 rows at once: a lane takes rows k * 64 + lane (k = 0..31), the 32
-//             loads of a filter are in flight together (one memory round trip per filter and slice, not per row batch).
+// chunk.  No PosList, no expression column: what the chain writes to HBM and reads back (8 bytes per surviving row and scan,
+// 4-8 bytes per row and expression, twice) never exists.  One workgroup per CHUNK (its segment descriptors, jobs and input
+// expressions are staged in LDS once, its groups reach the global table once), 8192 rows at a time, a quarter per wave:
+//   scan      the filters, in plan order, over the wave's 2048 rows: a lane takes rows k * 64 + lane (k = 0..31), sixteen loads of a
+//             filter in flight together (two memory round trips per filter and 2048 rows, not one per row batch).
 //   compact   the surviving rows' numbers, in row order, into the wave's list in LDS (ballot + mbcnt: no atomics, no barrier).
 //             A selective plan (TPC-H Q6: 2 % of the rows) does everything below on full waves of SURVIVORS.
 //   rows      FUSED_ROWS list entries per lane and batch.  GROUP BY columns first -- all their loads issued before any is used
-//             (decode_columns) -- tuples of VALUES (a slice may hold any mix of encodings) into the workgroup's 256-slot table;
+//             (decode_columns) -- tuples of VALUES (a chunk may hold any mix of encodings) into the workgroup's table;
 //             rows whose group does not fit go to the global table directly.  Then the distinct columns the expressions read,
 //             decoded ONCE per batch the same way; the expressions run on registers.
-//   accumulate  a wave's rows of one i usually belong to a handful of groups (TPC-H Q1: four in the table; Q6: one): up to
-//             FUSED_LEADERS groups per wave and i are reduced across the wave with DPP moves and cost ONE LDS atomic per aggregate;
-//             further groups use LDS atomics per row (many groups: few conflicts).
+//   accumulate  the first FUSED_DENSE groups a chunk meets (TPC-H Q1 has four in the table, Q6 one) own FUSED_CELLS copies of every
+//             accumulator and a lane adds to copy lane % FUSED_CELLS: one cell per group and aggregate serialises all 256 lanes of the
+//             workgroup (measured: 5.8 ms of a 9.3 ms Q1 even with a wave reduction in front of every atomic).  Further groups use the
+//             table's own cells (many groups: few conflicts).  The copies are folded into the table before it is merged.
 constexpr uint32_t FUSED_LDS_SLOTS = 128;
 constexpr int FUSED_ROWS = 2;
 constexpr int FUSED_COLUMNS = 6;                    // distinct columns the aggregates' inputs may read

@@ -387,7 +387,8 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
  * Expressions are in postfix order over at most HY_MAX_EXPRESSION_NODES nodes and three stack slots:
  * l_extendedprice * (1 - l_discount) is  COLUMN l_extendedprice, LITERAL 1, COLUMN l_discount, ARITHMETIC SUB, ARITHMETIC MUL.
  * All columns are data columns (no reference segments) of one table.  HY_ERR_UNSUPPORTED: more than HY_MAX_FILTERS filters,
- * aggregate functions other than MIN / MAX / SUM / AVG / COUNT, string expressions -- run the chain instead. */
+ * aggregate functions other than MIN / MAX / SUM / AVG / COUNT, string expressions, expressions that read more than six
+ * distinct columns between them or need a fourth stack slot -- run the chain instead. */
 enum { HY_EXPR_COLUMN = 0, HY_EXPR_LITERAL = 1, HY_EXPR_ARITHMETIC = 2 };
 enum { HY_MAX_EXPRESSION_NODES = 12, HY_MAX_FILTERS = 4 };
 typedef struct hy_expression_node {
