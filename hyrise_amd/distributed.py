@@ -292,6 +292,17 @@ class HipExecutor:
                 raise
         return aggregate_hash(groupby, aggregates, group_capacity=shape.rows + 1)
 
+    def scan_project_aggregate(self, filters, groupby, aggregates):
+        """TableScan(s) -> Projection -> AggregateHash of this rank's chunks in one pass (hy_scan_project_aggregate); aggregates:
+        [(function, expression tree or None)], trees as operators.expression takes them."""
+        from .operators import scan_project_aggregate
+        try:
+            return scan_project_aggregate(filters, groupby, aggregates, group_capacity=4096)
+        except abi.HyriseAmdError as error:
+            if error.status != abi.ERR_CAPACITY:
+                raise
+        return scan_project_aggregate(filters, groupby, aggregates)
+
     def _device_scan(self, column, predicate, layout, visibility=None):
         """hy_table_scan (or, with visibility = (our_tid, snapshot commit id), hy_validate) into device memory + hy_poslist_translate
         -> (RowID tensor, per-chunk region begins, counts tensor, total)"""
@@ -488,17 +499,95 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
     id in the whole table.  Every rank returns the same list of (key tuple, [aggregate values]) in the reference's group
     order.  SUM / AVG over floating-point columns: double additions in a different order than the sequential reference
     (1e-9 relative, as on one GPU); everything else exact."""
-    torch = comm.torch
-    functions = [f for f, _ in aggregates]
     keys, rows, values = _local_partials(ex, groupby, aggregates)
-    n_aggregates, n_keys = len(aggregates), len(groupby)
-    device = comm._device
-    first_rows = [((chunk + first_chunk) << 32) | offset for chunk, offset in rows]
     shape = groupby[0] if groupby else next((c for _, c in aggregates if c is not None), None)
     local_rows = ex.rows_of(shape) if shape is not None else 0
+    return _merge_partials(comm, keys, rows, values, [f for f, _ in aggregates], [_aggregate_is_float(f, c) for f, c in aggregates],
+                           [g.data_type for g in groupby], local_rows, first_chunk)
+
+
+def expression_type(tree):
+    """Result type of an expression tree (operators.expression): expression_common_type, expression_utils.cpp:172-204."""
+    if hasattr(tree, "data_type"):
+        return tree.data_type
+    if tree is None:
+        return abi.TYPE_NULL
+    if len(tree) == 2:
+        return tree[0]
+    left, right = expression_type(tree[1]), expression_type(tree[2])
+    if left == abi.TYPE_NULL:
+        return right
+    if right == abi.TYPE_NULL:
+        return left
+    if abi.TYPE_DOUBLE in (left, right):
+        return abi.TYPE_DOUBLE
+    if abi.TYPE_LONG in (left, right):
+        return abi.TYPE_DOUBLE if abi.TYPE_FLOAT in (left, right) else abi.TYPE_LONG
+    return abi.TYPE_FLOAT if abi.TYPE_FLOAT in (left, right) else abi.TYPE_INT
+
+
+def _tree_key(tree):
+    if hasattr(tree, "data_type"):
+        return ("column", id(tree))
+    if tree is None or len(tree) == 2:
+        return ("literal", tree)
+    return (tree[0], _tree_key(tree[1]), _tree_key(tree[2]))
+
+
+def sharded_scan_project_aggregate(comm, ex, filters, groupby, aggregates, first_chunk):
+    """TableScan(s) -> Projection -> AggregateHash over a chunk-sharded table: every rank runs the fused pass
+    (ex.scan_project_aggregate) over ITS chunks of the columns -- filters [(column, predicate)], groupby [column], aggregates
+    [(MIN / MAX / SUM / AVG / COUNT, expression tree or None)] -- and the partial groups are merged like sharded_aggregate's
+    (same exchange, same group order; the immediate-key shortcut is decided on the rows that passed the filters on all ranks).
+    The key values travel as MIN(key column) of the group (all its rows hold the same value)."""
+    plan, index = [], {}
+
+    def want(function, tree):
+        key = (function, _tree_key(tree))
+        if key not in index:
+            index[key] = len(plan)
+            plan.append((function, tree))
+        return index[key]
+
+    cells = []
+    for function, tree in aggregates:
+        if function not in (abi.AGG_MIN, abi.AGG_MAX, abi.AGG_SUM, abi.AGG_AVG, abi.AGG_COUNT):
+            raise NotImplementedError(f"aggregate function {function} is not part of the fused pass: run the operator chain")
+        cells.append((want(abi.AGG_SUM if function == abi.AGG_AVG else function, tree), want(abi.AGG_COUNT, tree)))
+    key_cells = [want(abi.AGG_MIN, g) for g in groupby]
+    passed_cell = want(abi.AGG_COUNT, None)
+    columns, first = [], None
+    for begin in range(0, len(plan), MAX_AGGREGATES_PER_CALL):   # (every call is a pass over the shard; they group the same rows in the same order)
+        result = ex.scan_project_aggregate(filters, groupby, plan[begin:begin + MAX_AGGREGATES_PER_CALL])
+        if first is None:
+            first = result
+        assert result.n_groups == first.n_groups
+        columns += [result.column(i) if result.n_groups else [] for i in range(len(plan[begin:begin + MAX_AGGREGATES_PER_CALL]))]
+    n = first.n_groups
+    if not groupby and n == 1 and not columns[passed_cell][0]:
+        n = 0   # (no GROUP BY, nothing passed: the one row of NULLs / zero counts is produced after the merge, not by every rank)
+    keys = [tuple(columns[c][g] for c in key_cells) for g in range(n)]
+    rows = [(int(first.row_ids[g][0]), int(first.row_ids[g][1])) for g in range(n)]
+    values = [[(columns[v][g], columns[c][g]) for v, c in cells] for g in range(n)]
+    local_rows = sum(int(columns[passed_cell][g]) for g in range(n))
+    is_float = [tree is not None and function != abi.AGG_COUNT and expression_type(tree) in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE) for function, tree in aggregates]
+    merged = _merge_partials(comm, keys, rows, values, [f for f, _ in aggregates], is_float, [g.data_type for g in groupby], local_rows, first_chunk)
+    if not groupby and not merged:
+        merged = [((), [0 if f == abi.AGG_COUNT else None for f, _ in aggregates])]
+    return merged
+
+
+def _merge_partials(comm, keys, rows, values, functions, is_float_aggregate, key_types, local_rows, first_chunk):
+    """The exchange and the merge behind sharded_aggregate / sharded_scan_project_aggregate.  keys / rows / values: this rank's groups (key
+    tuple, first row as (chunk, offset) of the shard, per aggregate (value, count of non-NULL inputs)); local_rows: the rows of the
+    aggregate's input on this rank."""
+    torch = comm.torch
+    n_aggregates, n_keys = len(functions), len(key_types)
+    device = comm._device
+    first_rows = [((chunk + first_chunk) << 32) | offset for chunk, offset in rows]
 
     # ---- key ranges (integer GROUP BY columns only): decide between fixed slots and the general merge, on every rank alike
-    integer_keys = all(g.data_type in _INT_TYPES for g in groupby)
+    integer_keys = all(t in _INT_TYPES for t in key_types)
     BIG = 1 << 62
     low = torch.full((max(1, n_keys),), BIG, dtype=torch.int64, device=device)
     high = torch.full((max(1, n_keys),), -BIG, dtype=torch.int64, device=device)
@@ -543,7 +632,7 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
                 isum[s, n_aggregates + a] = count
                 if value is None or (count == 0 and functions[a] != abi.AGG_COUNT):
                     continue
-                is_float = _aggregate_is_float(functions[a], aggregates[a][1])
+                is_float = is_float_aggregate[a]
                 if functions[a] in (abi.AGG_SUM, abi.AGG_AVG):
                     if is_float:
                         fsum[s, a] = float(value)
@@ -574,7 +663,7 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
             row = []
             for a in range(n_aggregates):
                 count = int(isum[s, n_aggregates + a])
-                is_float = _aggregate_is_float(functions[a], aggregates[a][1])
+                is_float = is_float_aggregate[a]
                 if functions[a] in (abi.AGG_SUM, abi.AGG_AVG):
                     value = float(fsum[s, a]) if is_float else int(isum[s, a])
                 elif functions[a] in (abi.AGG_MIN, abi.AGG_ANY):
@@ -587,10 +676,10 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
             merged[key] = [int(imin[s, n_aggregates]), int(imax[s, n_aggregates]), row]
     else:
         # general merge: every rank's groups, all-gathered as arrays (keys as doubles' / integers' bits in int64 + NULL flags)
-        def bits(value, column):
+        def bits(value, key_type):
             if value is None:
                 return 0
-            if column.data_type in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE):
+            if key_type in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE):
                 return int(np.float64(value).view(np.int64))
             return int(value)
 
@@ -598,7 +687,7 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
         table = np.zeros((g, 2 * n_keys + 1 + 3 * n_aggregates), dtype=np.int64)
         for i, (key, first, row) in enumerate(zip(keys, first_rows, values)):
             for k in range(n_keys):
-                table[i, 2 * k] = bits(key[k], groupby[k])
+                table[i, 2 * k] = bits(key[k], key_types[k])
                 table[i, 2 * k + 1] = 1 if key[k] is None else 0
             table[i, 2 * n_keys] = first
             for a, (value, count) in enumerate(row):
@@ -606,7 +695,7 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
                 table[i, base] = 0 if count is None else int(count)
                 table[i, base + 1] = 0 if value is None else 1
                 if value is not None:
-                    is_float = _aggregate_is_float(functions[a], aggregates[a][1])
+                    is_float = is_float_aggregate[a]
                     table[i, base + 2] = int(np.float64(value).view(np.int64)) if is_float else int(value)
         parts = comm.all_gather_var(torch.from_numpy(table).to(device))
         for part in parts:   # rank order: deterministic floating-point sums
@@ -615,7 +704,7 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
                 for k in range(n_keys):
                     if line[2 * k + 1]:
                         key.append(None)
-                    elif groupby[k].data_type in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE):
+                    elif key_types[k] in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE):
                         key.append(float(np.int64(line[2 * k]).view(np.float64)))
                     else:
                         key.append(int(line[2 * k]))
@@ -628,7 +717,7 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
                 for a in range(n_aggregates):
                     base = 2 * n_keys + 1 + 3 * a
                     count, has_value = int(line[base]), bool(line[base + 1])
-                    is_float = _aggregate_is_float(functions[a], aggregates[a][1])
+                    is_float = is_float_aggregate[a]
                     value = (float(np.int64(line[base + 2]).view(np.float64)) if is_float else int(line[base + 2])) if has_value else None
                     cur = entry[2][a]
                     cur[1] += count
@@ -645,7 +734,7 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
     # ---- the reference's group order: ascending key with NULL first under the immediate-key shortcut (one int32 GROUP BY
     #      column whose key range is below 1.2 x rows, aggregate_hash.cpp:770-804), else first occurrence (:388-401)
     immediate = False
-    if n_keys == 1 and groupby[0].data_type == abi.TYPE_INT and merged:
+    if n_keys == 1 and key_types[0] == abi.TYPE_INT and merged:
         present = [key[0] for key in merged if key[0] is not None]
         if present and (max(present) - min(present)) < total_rows * 1.2:
             immediate = True

@@ -49,6 +49,32 @@ def aggregate_specs(d):
             "no_groupby": ([], full)}
 
 
+def fused_specs(d):
+    """Plans for the sharded fused pass: (filters [(column name, predicate)], GROUP BY names, aggregates [(function, tree over names)])."""
+    from hyrise_amd import abi
+    from hyrise_amd.operators import make_predicate
+    nullable = make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_INT, -400, 300, nullable=True)
+    floats = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, 80.0)
+    product = (abi.ARITH_MUL, "cf", (abi.ARITH_SUB, (abi.TYPE_INT, 1), "gf"))
+    full = [(abi.AGG_SUM, product), (abi.AGG_AVG, product), (abi.AGG_SUM, (abi.ARITH_ADD, "ci", (abi.TYPE_LONG, 7))), (abi.AGG_MIN, "ci"), (abi.AGG_MAX, "cf"),
+            (abi.AGG_COUNT, "ci"), (abi.AGG_COUNT, None)]
+    nothing = make_predicate(abi.PRED_GREATER_THAN, abi.TYPE_FLOAT, 1000.0)
+    return {"fused_two_keys_general": ([("ci", nullable), ("cf", floats)], ["g1", "g2"], full),
+            "fused_small_domain_slots": ([("cf", floats)], ["g3", "g2"], full),
+            "fused_immediate_key": ([("ci", nullable)], ["g3"], full[:4]),
+            "fused_no_groupby": ([("ci", nullable), ("cf", floats)], [], full),
+            "fused_nothing_passes": ([("cf", nothing)], [], full[:1] + full[-1:]),
+            "fused_nothing_passes_grouped": ([("cf", nothing)], ["g3"], full[-1:])}
+
+
+def bind_tree(tree, column_of):
+    if isinstance(tree, str):
+        return column_of(tree)
+    if tree is None or len(tree) == 2:
+        return tree
+    return (tree[0], bind_tree(tree[1], column_of), bind_tree(tree[2], column_of))
+
+
 def pairs_of(left_pos, right_pos):
     left = left_pos.cpu().numpy().astype(np.uint32)
     right = right_pos.cpu().numpy().astype(np.uint32) if right_pos is not None else None
@@ -94,6 +120,11 @@ def worker(rank, world, init_file, out_dir, executor_kind):
     for case, (keys, aggregates) in aggregate_specs(d).items():
         first_chunk = shard_column(d[keys[0] if keys else "ci"], world, rank)[1]
         out["aggregate"][case] = sharded_aggregate(comm, ex, [shard(k) for k in keys], [(f, shard(c)) for f, c in aggregates], first_chunk)
+    from hyrise_amd.distributed import sharded_scan_project_aggregate
+    first_chunk = shard_column(d["ci"], world, rank)[1]
+    for case, (filters, keys, aggregates) in fused_specs(d).items():
+        out["aggregate"][case] = sharded_scan_project_aggregate(comm, ex, [(shard(c), p) for c, p in filters], [shard(k) for k in keys],
+                                                                [(f, bind_tree(tree, shard)) for f, tree in aggregates], first_chunk)
     first_probe = shard_column(d["probe"], world, rank)[1]
     first_build = shard_column(d["build"], world, rank)[1]
     for mode in (abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_SEMI):
@@ -141,6 +172,30 @@ def check_results(results):
                     expected, got = want.column(a)[g], cells[a]
                     if expected is None:
                         assert got is None, (case, a)
+                    elif isinstance(expected, float):
+                        assert abs(got - expected) <= 1e-9 * max(1.0, abs(expected)), (case, a, got, expected)
+                    else:
+                        assert got == expected, (case, a, got, expected)
+
+    # the sharded fused pass against the single-process operator chain on the oracle
+    from support import oracle_chain
+    for case, (filters, keys, aggregates) in fused_specs(d).items():
+        want, base_rows, sizes = oracle_chain([(d[c], p) for c, p in filters], [d[k] for k in keys], [(f, bind_tree(tree, lambda name: d[name])) for f, tree in aggregates])
+        key_values = [column_values(d[k]) for k in keys]
+        first_of_chunk = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        for rank_rows in (r["aggregate"][case] for r in results):
+            assert len(rank_rows) == want.n_groups, case
+            for g, (key, cells) in enumerate(rank_rows):
+                if keys:
+                    in_chain = want.row_ids[g]
+                    base = base_rows[int(first_of_chunk[int(in_chain[0])]) + int(in_chain[1])]
+                    flat_row = int(base[0]) * d["chunk"] + int(base[1])
+                    expected_key = tuple(kv[flat_row] for kv in key_values)
+                    assert tuple(key) == expected_key, f"{case}: group {g} is {key}, the chain has {expected_key} there (group order)"
+                for a in range(len(aggregates)):
+                    expected, got = want.column(a)[g], cells[a]
+                    if expected is None:
+                        assert got is None, (case, a, got)
                     elif isinstance(expected, float):
                         assert abs(got - expected) <= 1e-9 * max(1.0, abs(expected)), (case, a, got, expected)
                     else:

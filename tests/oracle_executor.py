@@ -25,6 +25,18 @@ class OracleExecutor:
     def aggregate(self, groupby, aggregates):
         return oracle_aggregate(groupby, aggregates)
 
+    def scan_project_aggregate(self, filters, groupby, aggregates):
+        """The fused pass, run the reference's way (support.oracle_chain: scan -> scan -> ... -> arithmetic node by node -> aggregate);
+        the groups' representative rows are translated to rows of the data table, which is what hy_scan_project_aggregate returns."""
+        from support import oracle_chain
+        result, base_rows, sizes = oracle_chain(filters, groupby, aggregates)
+        n = result.n_groups
+        if n and len(base_rows):
+            first_of_chunk = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+            flat = first_of_chunk[result.row_ids[:n, 0].astype(np.int64)] + result.row_ids[:n, 1].astype(np.int64)
+            result.row_ids[:n] = base_rows[flat]
+        return result
+
     def scan(self, column, predicate):
         from support import oracle_scan
         result = oracle_scan(column, predicate, flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
