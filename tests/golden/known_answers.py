@@ -112,3 +112,56 @@ def between_expected(expected, sort_mode, nullable):
     if sort_mode == "ascending":
         return [x + leading_nulls for x in expected]
     return [x for x in expected if not (nullable and x % 3 == 2)]
+
+# table_scan_sorted_segment_search_test.cpp:106-171  (condition, value, second value, expected VALUES in position order on the ascending
+# segment 0, 0, 1, 1, 2, 2, 3, 3, 4, 4; descending segments hold 4, 4, ..., 0, 0 and expect the reversed list, :58-60).  The segment is a
+# ValueSegment<int32_t> with three NULLs in front (NullsFirst) or behind (NullsLast) when nullable, or three NULLs only (:64-90).
+# SortedSegmentSearch is the reference's shortcut for sorted chunks; a scan that ignores the sort flags must emit the same positions in
+# the same order -- which is what these vectors pin for the full scan here.
+SORTED_SEGMENT_SEARCH_TESTS = [
+    (abi.PRED_EQUALS, 2, None, [2, 2]),
+    (abi.PRED_NOT_EQUALS, 2, None, [0, 0, 1, 1, 3, 3, 4, 4]), (abi.PRED_NOT_EQUALS, 4, None, [0, 0, 1, 1, 2, 2, 3, 3]),
+    (abi.PRED_NOT_EQUALS, 0, None, [1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_NOT_EQUALS, 5, None, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_NOT_EQUALS, -1, None, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_LESS_THAN, -1, None, []), (abi.PRED_LESS_THAN, 0, None, []), (abi.PRED_LESS_THAN, 2, None, [0, 0, 1, 1]),
+    (abi.PRED_LESS_THAN, 5, None, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_LESS_THAN, 4, None, [0, 0, 1, 1, 2, 2, 3, 3]),
+    (abi.PRED_LESS_THAN_EQUALS, -1, None, []), (abi.PRED_LESS_THAN_EQUALS, 0, None, [0, 0]), (abi.PRED_LESS_THAN_EQUALS, 2, None, [0, 0, 1, 1, 2, 2]),
+    (abi.PRED_LESS_THAN_EQUALS, 5, None, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_LESS_THAN_EQUALS, 4, None, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_GREATER_THAN, -1, None, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_GREATER_THAN, 0, None, [1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_GREATER_THAN, 2, None, [3, 3, 4, 4]), (abi.PRED_GREATER_THAN, 5, None, []), (abi.PRED_GREATER_THAN, 4, None, []),
+    (abi.PRED_GREATER_THAN_EQUALS, -1, None, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_GREATER_THAN_EQUALS, 0, None, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_GREATER_THAN_EQUALS, 2, None, [2, 2, 3, 3, 4, 4]), (abi.PRED_GREATER_THAN_EQUALS, 5, None, []), (abi.PRED_GREATER_THAN_EQUALS, 4, None, [4, 4]),
+    (abi.PRED_BETWEEN_INCLUSIVE, -1, 5, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_BETWEEN_INCLUSIVE, 0, 4, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_BETWEEN_INCLUSIVE, 0, 3, [0, 0, 1, 1, 2, 2, 3, 3]), (abi.PRED_BETWEEN_INCLUSIVE, 2, 4, [2, 2, 3, 3, 4, 4]),
+    (abi.PRED_BETWEEN_INCLUSIVE, 1, 3, [1, 1, 2, 2, 3, 3]), (abi.PRED_BETWEEN_INCLUSIVE, 5, 10, []), (abi.PRED_BETWEEN_INCLUSIVE, -5, -1, []),
+    (abi.PRED_BETWEEN_EXCLUSIVE, -2, 6, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_BETWEEN_EXCLUSIVE, -1, 5, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_BETWEEN_EXCLUSIVE, -1, 4, [0, 0, 1, 1, 2, 2, 3, 3]), (abi.PRED_BETWEEN_EXCLUSIVE, 1, 5, [2, 2, 3, 3, 4, 4]),
+    (abi.PRED_BETWEEN_EXCLUSIVE, 0, 4, [1, 1, 2, 2, 3, 3]), (abi.PRED_BETWEEN_EXCLUSIVE, 4, 10, []), (abi.PRED_BETWEEN_EXCLUSIVE, -5, 0, []),
+    (abi.PRED_BETWEEN_LOWER_EXCLUSIVE, -2, 4, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_BETWEEN_LOWER_EXCLUSIVE, -1, 4, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_BETWEEN_LOWER_EXCLUSIVE, -1, 3, [0, 0, 1, 1, 2, 2, 3, 3]), (abi.PRED_BETWEEN_LOWER_EXCLUSIVE, 1, 4, [2, 2, 3, 3, 4, 4]),
+    (abi.PRED_BETWEEN_LOWER_EXCLUSIVE, 0, 3, [1, 1, 2, 2, 3, 3]), (abi.PRED_BETWEEN_LOWER_EXCLUSIVE, 4, 10, []), (abi.PRED_BETWEEN_LOWER_EXCLUSIVE, -5, -1, []),
+    (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, -1, 6, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]), (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, 0, 5, [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]),
+    (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, 0, 4, [0, 0, 1, 1, 2, 2, 3, 3]), (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, 2, 5, [2, 2, 3, 3, 4, 4]),
+    (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, 1, 4, [1, 1, 2, 2, 3, 3]), (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, 5, 10, []), (abi.PRED_BETWEEN_UPPER_EXCLUSIVE, -5, 0, []),
+]
+SORTED_SEGMENT_SORT_MODES = ["AscendingNullsFirst", "DescendingNullsFirst", "AscendingNullsLast", "DescendingNullsLast"]
+SORTED_SEGMENT_NULL_USAGES = ["WithoutNulls", "WithNulls", "OnlyNulls"]
+
+
+def sorted_search_segment(sort_mode, null_usage):
+    """(values, NULL mask or None): table_scan_sorted_segment_search_test.cpp:62-90."""
+    import numpy as np
+    ascending, nulls_last = sort_mode.startswith("Ascending"), sort_mode.endswith("NullsLast")
+    nullable, only_nulls = null_usage != "WithoutNulls", null_usage == "OnlyNulls"
+    values, nulls = [], []
+    if (nullable and not nulls_last) or only_nulls:
+        values += [0, 0, 0]
+        nulls += [True] * 3
+    if not only_nulls:
+        for row in range(5):
+            values += [row if ascending else 4 - row] * 2
+            nulls += [False, False]
+        if nullable and nulls_last:
+            values += [0, 0, 0]
+            nulls += [True] * 3
+    return np.array(values, dtype=np.int32), (np.array(nulls, dtype=bool) if nullable else None)

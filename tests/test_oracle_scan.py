@@ -226,3 +226,20 @@ def test_between_known_answers(np_type, encoding, sort_mode, nullable):
             assert sorted(b[rows].tolist()) == KA.between_expected(expected, sort_mode, nullable), \
                 f"condition {condition} BETWEEN {lower} AND {upper}"
 
+
+@pytest.mark.parametrize("sort_mode", KA.SORTED_SEGMENT_SORT_MODES)
+@pytest.mark.parametrize("null_usage", KA.SORTED_SEGMENT_NULL_USAGES)
+def test_sorted_segment_search_known_answers(sort_mode, null_usage):
+    """table_scan_sorted_segment_search_test.cpp:106-214: the full scan emits what SortedSegmentSearch emits, in the same order."""
+    values, nulls = KA.sorted_search_segment(sort_mode, null_usage)
+    column = build_column(values, nulls, len(values), abi.ENC_UNENCODED, nullable=nulls is not None)
+    for condition, value, value2, expected in KA.SORTED_SEGMENT_SEARCH_TESTS:
+        result = oracle_scan(column, make_predicate(condition, abi.TYPE_INT, value, value2, nullable=nulls is not None))
+        rows = [o for _, o in result_rows(result)]
+        if null_usage == "OnlyNulls":
+            assert rows == []
+            continue
+        assert not (nulls is not None and nulls[rows].any())
+        want = expected if sort_mode.startswith("Ascending") else expected[::-1]
+        assert values[rows].tolist() == want, f"condition {condition} value {value} / {value2}"
+

@@ -430,3 +430,17 @@ def test_between_known_answers(device, np_type, encoding, sort_mode, nullable):
             rows = np.array([c * 6 + o for c, o in result_rows(got)], dtype=np.int64)
             assert sorted(b[rows].tolist()) == KA.between_expected(expected, sort_mode, nullable)
 
+
+@pytest.mark.parametrize("sort_mode", KA.SORTED_SEGMENT_SORT_MODES)
+@pytest.mark.parametrize("null_usage", KA.SORTED_SEGMENT_NULL_USAGES)
+def test_sorted_segment_search_known_answers(device, sort_mode, null_usage):
+    """table_scan_sorted_segment_search_test.cpp:106-214 on the device (which never looks at sort flags): same positions, same order."""
+    values, nulls = KA.sorted_search_segment(sort_mode, null_usage)
+    host = build_column(values, nulls, len(values), abi.ENC_UNENCODED, nullable=nulls is not None)
+    dev = DeviceColumn(host)
+    for condition, value, value2, expected in KA.SORTED_SEGMENT_SEARCH_TESTS:
+        got = check(host, make_predicate(condition, abi.TYPE_INT, value, value2, nullable=nulls is not None), dev, context=f"condition {condition} value {value} / {value2}")
+        rows = [o for _, o in result_rows(got)]
+        want = [] if null_usage == "OnlyNulls" else (expected if sort_mode.startswith("Ascending") else expected[::-1])
+        assert values[rows].tolist() == want
+
