@@ -34,6 +34,8 @@ FILES = [
     "tpch/sf-0.001/lineitem.tbl", "tpch/sf-0.001/orders.tbl",
     # Projection arithmetic: the ExpressionEvaluator's series tests (src/test/lib/expression/expression_evaluator_to_values_test.cpp:38,244-256)
     "expression_evaluator/input_a.tbl",
+    # Projection: int_float.tbl's a + b (src/test/lib/operators/projection_test.cpp:59-64)
+    "projection/int_float_add.tbl",
 ]
 
 

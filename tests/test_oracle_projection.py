@@ -45,6 +45,17 @@ def test_arithmetics_series():   # :244-256
     assert series(abi.ARITH_ADD, (np.zeros(0, np.int32), None), (np.zeros(0, np.int32), None)) == []
 
 
+def test_projection_of_int_float_add():   # projection_test.cpp:59-64 (ExecutedOnAllChunks): int_float.tbl's a + b
+    t, expected = load_tbl("int_float.tbl"), load_tbl("projection/int_float_add.tbl")
+    values, nulls = oracle_arithmetic(abi.ARITH_ADD, t.column("a"), t.column("b"))
+    assert values.dtype == np.float32 and not nulls.any()
+    want = expected.columns[0]
+    assert expected.types[0] == abi.TYPE_FLOAT and len(values) == len(want)
+    # (the reference compares tables cell by cell with a float tolerance and ignores the row order, check_table_equal.cpp:34,109-115)
+    assert np.allclose(np.sort(values), np.sort(want), rtol=1e-6)
+    assert values.tolist() == (t.columns[0].astype(np.float32) + t.columns[1]).tolist()   # int + float computes in float
+
+
 def test_expression_common_type():   # expression_utils.cpp:172-204
     common = oracle().hyo_expression_common_type
     table = {(I, I): I, (I, L): L, (L, I): L, (I, F): F, (F, I): F, (L, F): D, (F, L): D, (I, D): D, (D, F): D, (F, F): F, (L, L): L, (L, D): D,

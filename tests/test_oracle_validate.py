@@ -1,5 +1,6 @@
 """Pins the CPU restatement of Validate (oracle/validate.c) against the reference's own known answers: the MVCC truth
-table of operators/validate_visibility_test.cpp:45-131 (our_tid = 2, snapshot = 2), and states the chunk shortcut and
+table of operators/validate_visibility_test.cpp:45-131 (our_tid = 2, snapshot = 2) and the four _is_entire_chunk_visible cases of
+operators/validate_test.cpp:163-214, and states the chunk shortcut and
 reference-segment rules of validate.cpp:57-68,164-314 as explicit contracts."""
 import numpy as np
 
@@ -10,6 +11,22 @@ from support import oracle_validate, result_rows
 TRUTH_TABLE = [("Impossible", 2, 2, 2, False), ("PastDelete", 42, 2, 2, False), ("Impossible2", 2, 4, 1, False),
                ("OwnDeleteUncommitted", 2, 1, 6, False), ("Impossible3", 50, 3, 1, False), ("OwnInsert", 2, 3, 3, True),
                ("PastInsertOrFutureDelete", 99, 2, 3, True), ("UncommittedInsertOrFutureInsert", 99, 3, 3, False)]
+
+
+# (name, begin_cid, mutable, invalid row count, entirely visible) at snapshot commit id 1 -- validate_test.cpp:163-214: one-row chunks of
+# MvccData(1, begin_cid) (tid 0, end_cid unset); a chunk that was never marked immutable has no max_begin_cid
+ENTIRE_CHUNK_VISIBLE = [("ChunkNotEntirelyVisibleWithoutMaxBeginCid", 0, True, 0, False), ("ChunkNotEntirelyVisibleWithLowerSnapshotCid", 2, False, 0, False),
+                        ("ChunkNotEntirelyVisibleWithInvalidRows", 0, False, 1, False), ("ChunkEntirelyVisible", 0, False, 0, True)]
+
+
+def entire_chunk_case(begin, mutable, invalid):
+    return storage.make_mvcc_column([0], [begin], [storage.MAX_COMMIT_ID], chunk_size=10, mutable_chunks=(0,) if mutable else (), invalid_row_counts=[invalid])
+
+
+def test_is_entire_chunk_visible_of_the_reference():
+    for name, begin, mutable, invalid, entirely_visible in ENTIRE_CHUNK_VISIBLE:
+        got = oracle_validate(entire_chunk_case(begin, mutable, invalid), our_tid=1, snapshot_commit_id=1)
+        assert (got.chunk_state[0] == abi.CHUNK_ALL_MATCH) == entirely_visible, name
 
 
 def numpy_visible(tids, begins, ends, our_tid, snapshot):
