@@ -84,6 +84,7 @@ uint32_t hyo_write_output_chunks(const uint64_t* slice_offsets, uint32_t n_slice
  * histograms_out [n_chunks << radix_bits] */
 /* std::hash<HashedType>{}(key) as libstdc++ computes it; key: an integer, or the bit pattern of a float (zero-extended) /
  * double with -0.0 given as +0.0.  hashed_type: HY_TYPE_*. */
+uint32_t hyo_join_hashed_type(uint32_t left_type, uint32_t right_type);   /* JoinHashTraits<L, R>::HashType, join_hash_traits.hpp:15-40 (numeric types) */
 uint64_t hyo_std_hash(int64_t key, uint32_t hashed_type);
 uint64_t hyo_std_hash_bytes(const void* data, uint64_t length);   /* std::hash<std::string / pmr_string> over the bytes */
 uint64_t hyo_join_materialize(const hyo_column* column, int keep_nulls, uint32_t radix_bits, const uint64_t* bloom_in,

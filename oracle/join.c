@@ -207,6 +207,8 @@ static uint32_t hashed_type_of(uint32_t l, uint32_t r) {
   return lf ? l : r;                                                                                   /* the floating one */
 }
 
+uint32_t hyo_join_hashed_type(uint32_t left_type, uint32_t right_type) { return hashed_type_of(left_type, right_type); }   /* (tests: join_hash_traits_test.cpp) */
+
 /* libstdc++ _Hash_bytes, size_t = 64 bits (libsupc++/hash_bytes.cc) */
 static uint64_t shift_mix(uint64_t v) { return v ^ (v >> 47); }
 static uint64_t libstdcxx_hash_bytes(const void* ptr, uint64_t len) {

@@ -49,6 +49,18 @@ def bloom_bits(words):
     return set(np.nonzero(np.unpackbits(words.view(np.uint8), bitorder="little"))[0].tolist())
 
 
+def test_hashed_type_of_the_reference():
+    """join_hash_traits_test.cpp (IntegerTraits, FloatingTraits, MixedNumberTraits): the type both sides are cast to before hashing."""
+    import ctypes as C
+    I, L, F, D = abi.TYPE_INT, abi.TYPE_LONG, abi.TYPE_FLOAT, abi.TYPE_DOUBLE
+    hashed = oracle().hyo_join_hashed_type
+    hashed.restype, hashed.argtypes = C.c_uint32, [C.c_uint32, C.c_uint32]
+    table = {(I, I): I, (L, L): L, (I, L): L, (L, I): L, (F, F): F, (D, D): D, (F, D): D, (D, F): D, (I, F): F, (F, I): F, (I, D): D, (D, I): D,
+             (L, F): F, (F, L): F, (L, D): D, (D, L): D}
+    for (left, right), expected in table.items():
+        assert hashed(left, right) == expected, (left, right)
+
+
 def test_materialize_bloom_filters():
     """join_hash_steps_test.cpp:169-220 on int_int4_with_null.tbl (chunk size 10)."""
     values = np.array([18, 7, 7, 9, 6, 0, 13, 0, 9, 7, 0], dtype=np.int32)      # column a, NULLs at rows 5 and 7
