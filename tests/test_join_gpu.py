@@ -582,3 +582,15 @@ def test_shutdown_releases_the_thread_state_and_the_library_keeps_working(device
         again = join_hash(left, right, abi.JOIN_INNER)
         n = first.n_pairs
         assert again.n_pairs == n > 0 and again.left[:n].tobytes() == first.left[:n].tobytes() and again.right[:n].tobytes() == first.right[:n].tobytes()
+
+
+@pytest.mark.parametrize("np_type", [np.int32, np.int64, np.float32, np.float64], ids=lambda t: t.__name__)
+def test_hash_map_inputs_of_the_reference(device, np_type):
+    """join_hash_types_test.cpp:57-76 as joins of a column with itself: 500 x the value 17 (250 000 pairs: every probe row has 500
+    partners) and i^3 for i < 500 (500 pairs) -- bytes equal to the oracle's."""
+    same = build_column(np.full(500, 17).astype(np_type), None, 500, abi.ENC_UNENCODED)
+    got = check(same, same, abi.JOIN_INNER, context="500 x 17")
+    assert got.n_pairs == 250_000
+    cubes = build_column((np.arange(500, dtype=np.float64) ** 3).astype(np_type), None, 500, abi.ENC_UNENCODED)
+    got = check(cubes, cubes, abi.JOIN_INNER, context="cubes")
+    assert got.n_pairs == 500 and (got.left[:500, 1] == got.right[:500, 1]).all()

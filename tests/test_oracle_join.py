@@ -61,6 +61,23 @@ def test_hashed_type_of_the_reference():
         assert hashed(left, right) == expected, (left, right)
 
 
+@pytest.mark.parametrize("np_type", [np.int32, np.int64, np.float32, np.float64], ids=lambda t: t.__name__)
+def test_hash_map_finds_every_row_of_the_reference_inputs(np_type):
+    """join_hash_types_test.cpp:57-76 (BuildSingleValueLargePosList: 500 x the value 17; BuildSingleRowIds: i^3 for i < 500) builds the
+    hash map and looks every row up by its key.  As a join of the column with itself: every row pairs with exactly the rows of its
+    key -- 500 x 500 pairs, and 500 pairs (i, i)."""
+    same = build_column(np.full(500, 17).astype(np_type), None, 500, abi.ENC_UNENCODED)
+    result = oracle_join(same, same, abi.JOIN_INNER, capacity=500 * 500 + 16)
+    assert result.n_pairs == 500 * 500
+    pairs = set(zip(result.left[:result.n_pairs, 1].tolist(), result.right[:result.n_pairs, 1].tolist()))
+    assert len(pairs) == 500 * 500
+    cubes = build_column((np.arange(500, dtype=np.float64) ** 3).astype(np_type), None, 500, abi.ENC_UNENCODED)
+    result = oracle_join(cubes, cubes, abi.JOIN_INNER)
+    n = result.n_pairs
+    assert n == 500 and sorted(result.left[:n, 1].tolist()) == list(range(500))
+    assert (result.left[:n, 1] == result.right[:n, 1]).all()
+
+
 def test_materialize_bloom_filters():
     """join_hash_steps_test.cpp:169-220 on int_int4_with_null.tbl (chunk size 10)."""
     values = np.array([18, 7, 7, 9, 6, 0, 13, 0, 9, 7, 0], dtype=np.int32)      # column a, NULLs at rows 5 and 7
