@@ -1368,14 +1368,27 @@ __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, Partition
 //             accumulator and a lane adds to copy lane % FUSED_CELLS: one cell per group and aggregate serialises all 256 lanes of the
 //             workgroup (measured: 5.8 ms of a 9.3 ms Q1 even with a wave reduction in front of every atomic).  Further groups use the
 //             table's own cells (many groups: few conflicts).  The copies are folded into the table before it is merged.
-constexpr uint32_t FUSED_LDS_SLOTS = 128;
-constexpr int FUSED_ROWS = 2;
+// (the -D overrides are for A/B builds: tools/fused_variants.sh compiles them side by side and times them through HY_LIBRARY)
+#ifndef HY_FUSED_LDS_SLOTS
+#define HY_FUSED_LDS_SLOTS 128
+#endif
+#ifndef HY_FUSED_ROWS
+#define HY_FUSED_ROWS 2
+#endif
+#ifndef HY_FUSED_WAVES
+#define HY_FUSED_WAVES 4
+#endif
+#ifndef HY_FUSED_CELLS
+#define HY_FUSED_CELLS 16
+#endif
+constexpr uint32_t FUSED_LDS_SLOTS = HY_FUSED_LDS_SLOTS;
+constexpr int FUSED_ROWS = HY_FUSED_ROWS;
 constexpr int FUSED_COLUMNS = 6;                    // distinct columns the aggregates' inputs may read
 constexpr uint32_t FUSED_WAVE_ROWS = SLICE_ROWS / 4;   // 2048
 constexpr uint32_t FUSED_VIEWS = HY_MAX_FILTERS + MAX_GROUPBY + FUSED_COLUMNS;
 constexpr uint32_t FUSED_DENSE = 4;    // groups (the first the chunk meets) whose accumulators are spread over ...
-constexpr uint32_t FUSED_CELLS = 16;   // ... this many copies each
-constexpr int FUSED_WAVES = 4;         // waves per SIMD the register allocation aims at
+constexpr uint32_t FUSED_CELLS = HY_FUSED_CELLS;   // ... this many copies each
+constexpr int FUSED_WAVES = HY_FUSED_WAVES;        // waves per SIMD the register allocation aims at
 
 struct FusedNode {
   uint64_t literal;             // HY_EXPR_LITERAL: the int64 value, the float's bits (low word) or the double's bits
