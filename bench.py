@@ -18,7 +18,9 @@ by all-gather, and hash repartition by all-to-all) -- `multi_gpu` object, hyrise
 Prints ONE JSON line on rank 0: rows/s over the whole job, `roofline` (scan_slices: algorithmic bytes / HIP-event duration
 vs. the 8 TB/s HBM peak) and `cpu_baseline` (the CPU restatement of the Hyrise operator on the host cores, rank 0, N=1
 only).  At N=1 the line also carries `join` and `aggregate` objects -- configs 3 and 4 of BASELINE.json on the same GPU, each
-with its own roofline and cpu_baseline -- and `cases`: the other predicates / encodings / key orders SURVEY.md 8(d) lists.
+with its own roofline and cpu_baseline -- `cases`: the other predicates / encodings / key orders SURVEY.md 8(d) lists, `q6` (configs[0]'s
+query as a device-resident operator chain, and `q6.fused`: the same query as one hy_scan_project_aggregate call), `q1` (the whole
+TPC-H Q1: chain and fused pass, compared with each other on every run) and `ssb` (config 5).
 """
 import argparse
 import ctypes as C
