@@ -83,16 +83,24 @@ class OracleExecutor:
         return storage.make_reference_column(base, chunks)
 
     def projection(self, op, left, right):
+        """left <op> right, operands: columns or literals ((HY_TYPE_*, value) / None), with the chunk layout of the column operand(s)."""
+        from hyrise_amd import storage
         from support import oracle_arithmetic
 
-        def operand(column):
-            cells = column_values(column)
+        def operand(x):
+            if x is None or not hasattr(x, "segments"):
+                return x
+            cells = column_values(x)
             nulls = np.array([c is None for c in cells], dtype=bool)
-            return np.array([0 if c is None else c for c in cells], dtype=_NP[column.data_type]), (nulls if nulls.any() else None)
+            return np.array([0 if c is None else c for c in cells], dtype=_NP[x.data_type]), (nulls if nulls.any() else None)
 
-        values, nulls = oracle_arithmetic(op, operand(left), operand(right))
-        chunk = max([s.size for s in left.segments] + [1])
-        return build_column(values, nulls if nulls.any() else None, chunk, abi.ENC_UNENCODED)
+        shape = left if hasattr(left, "segments") else right
+        values, nulls = oracle_arithmetic(op, operand(left), operand(right), n=shape.rows)
+        segments, begin = [], 0
+        for segment in shape.segments:
+            segments.append(storage.encode_segment(values[begin:begin + segment.size], nulls[begin:begin + segment.size] if nulls.any() else None, abi.ENC_UNENCODED))
+            begin += segment.size
+        return storage.HostColumn(segments, storage.TYPE_OF_NP[values.dtype])
 
     def export(self, column, with_nulls=True):
         cells = column_values(column)
