@@ -1,26 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- headline measurement of the MI355X hot path (BASELINE.json metric).
+"""bench.py -- headline measurement of the MI355X hot path (BASELINE.json metric: rows/sec TableScan+JoinHash, TPC-H SF10).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Timed workload at every N: config 2 of BASELINE.json -- TableScan ColumnVsValue on a TPC-H SF10 lineitem `l_shipdate`
-column (59 986 052 rows, 916 chunks of 65 535, DictionarySegment<int32> + FixedWidthInteger u16 attribute vectors),
-predicate `l_shipdate < 1995-01-01` (the reference's own micro-benchmark predicate,
-src/benchmark/tpch_data_micro_benchmark.cpp:65-67).  One step = one hy_table_scan over the whole column with the
-column resident in HBM and the PosLists written to HBM; the steps rotate over three copies of the column (3 x 120 MB +
-480 MB of PosLists: nothing the kernel touches is still in the 256 MiB Infinity Cache when it comes round again).  With N
-GPUs every rank scans its own SF10-shaped shard of an N x SF10 table (chunks shard naturally, no data-path collective:
-SURVEY.md section 8(e)) -> weak scaling; the line then also carries the strong-scaling scan (ONE SF10 table split over the
-ranks), the sharded AggregateHash (per-rank partials + one all-reduce over RCCL) and the sharded JoinHash (broadcast-build
-by all-gather, and hash repartition by all-to-all) -- `multi_gpu` object, hyrise_amd/distributed.py.
+One step = ONE TableScan + ONE JoinHash on the same GPU, inputs and outputs resident in HBM:
+  * TableScan ColumnVsValue (config 2): TPC-H SF10 lineitem `l_shipdate` (59 986 052 rows, 916 chunks of 65 535, DictionarySegment<int32>
+    + FixedWidthInteger u16 attribute vectors), predicate `l_shipdate < 1995-01-01` (the reference's own micro-benchmark predicate,
+    src/benchmark/tpch_data_micro_benchmark.cpp:65-67), PosLists written to HBM; the steps rotate over three copies of the column;
+  * JoinHash (config 3): orders x lineitem on the order key, Inner (o_orderkey ValueSegment<int32> = build side, 15 000 000 rows;
+    l_orderkey FrameOfReference + u16 offsets = probe side, 59 986 052 rows), both PosLists (0.96 GB) written to HBM.
+Each step moves > 1.4 GB through the memory-side cache (256 MiB): nothing it reads is still there when it comes round again.
+`value` = (scanned rows + build rows + probe rows) / step time.  With N GPUs every rank runs the step on its own SF10-shaped shard
+of an N x SF10 database (chunks shard naturally, orders and lineitem co-partitioned by order key range: no data-path collective,
+SURVEY.md section 8(e)) -> weak scaling; the line then also carries the strong-scaling scan (ONE SF10 table split over the ranks), the
+sharded AggregateHash (per-rank partials + one all-reduce over RCCL) and the sharded JoinHash (broadcast-build by all-gather, and
+hash repartition by all-to-all) -- `multi_gpu` object, hyrise_amd/distributed.py.
 
-Prints ONE JSON line on rank 0: rows/s over the whole job, `roofline` (scan_slices: algorithmic bytes / HIP-event duration
-vs. the 8 TB/s HBM peak) and `cpu_baseline` (the CPU restatement of the Hyrise operator on the host cores, rank 0, N=1
-only).  At N=1 the line also carries `join` and `aggregate` objects -- configs 3 and 4 of BASELINE.json on the same GPU, each
-with its own roofline and cpu_baseline -- `cases`: the other predicates / encodings / key orders SURVEY.md 8(d) lists, `q6` (configs[0]'s
-query as a device-resident operator chain, and `q6.fused`: the same query as one hy_scan_project_aggregate call), `q1` (the whole
-TPC-H Q1: chain and fused pass, compared with each other on every run) and `ssb` (config 5).
+Prints ONE JSON line on rank 0: `roofline` = the step's algorithmic bytes (scan 2 B/row + 8 B/match, join build
+keys + probe keys + 16 B/pair) over the step time vs. the 8 TB/s HBM peak, with the HIP-event durations of the step's kernels
+(`kernels`: scan_slices, pk_emit, pk_count, rank_table_fill_checked -- events taken INSIDE the timed region, every 4th step) and
+`dominant_kernel` = pk_emit; `cpu_baseline` = the CPU restatement of the two Hyrise operators on the host cores (rank 0, N = 1
+only).  At N = 1 the line also carries `scan` (config 2 alone), `join` (config 3 alone, + Semi legs + cases) and `aggregate`
+(config 4), each with its own roofline and cpu_baseline, `cases` (the other predicates / encodings SURVEY.md 8(d) lists), `q6`
+(configs[0]'s query as a device-resident operator chain, and `q6.fused`), `q1` and `ssb` (config 5).
 """
 import argparse
 import ctypes as C
@@ -95,6 +98,17 @@ def cpu_baseline_scan(host_column, predicate, rows, budget_s=10.0):
                       "CPU restatement of Hyrise's TableScan (not Hyrise itself)"}
 
 
+def cpu_baseline_step(host_column, predicate, rows, orders_host, lineitem_host):
+    """The headline's CPU baseline: the oracle's TableScan and the oracle's JoinHash, one after the other like a step, all host cores."""
+    scan = cpu_baseline_scan(host_column, predicate, rows, budget_s=6.0)
+    join_rows = orders_host.rows + lineitem_host.rows
+    join = cpu_baseline_join(orders_host, lineitem_host, join_rows, budget_s=10.0)
+    seconds = rows / scan["value"] + join_rows / join["value"]
+    return {"value": (rows + join_rows) / seconds, "unit": "rows/s", "cores": scan["cores"], "kind": "port",
+            "sample": "one full step on the host: " + scan["sample"] + " | then " + join["sample"],
+            "scan": scan, "join": join}
+
+
 def cpu_baseline_join(orders, lineitem, rows, budget_s=12.0):
     """The oracle's JoinHash (materialise -> radix-partition -> build -> probe with the reference's radix_bits, one job per
     chunk / partition: join_hash.cpp:270-572), all host cores."""
@@ -141,18 +155,43 @@ def cpu_baseline_aggregate(groupby, aggregates, rows, budget_s=12.0):
                                               f"({median_partials * 1e3:.0f} ms each; merging the partial groups is not timed: a handful of additions)"}}
 
 
-def committed_traffic(kind):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (collected by
-    tools/profile_*.sh on the same workload; FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).  None when no
-    profile of this round is committed.  (rocprofv3 cannot run inside this process: the counters are not measured live.)"""
-    path = os.path.join(ROOT, "profiles", f"r02_{kind}_pmc.json")
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes over THIS script that are committed under profiles/
+    (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate runs of `python bench.py`, FETCH_SIZE doubled as the gfx950
+    guide prescribes).  None when the committed profile does not list the kernel (rocprofv3 cannot run inside this process: the
+    counters are not measured live -- `traffic_source` in the line says which file and commit the figure is from)."""
+    path = os.path.join(ROOT, "profiles", "r03_bench_pmc.json")
     if not os.path.exists(path):
         return None
     try:
         with open(path) as fh:
-            return json.load(fh).get("hbm_bytes_per_launch")
+            entry = json.load(fh).get("kernels", {}).get(kernel)
+        return entry.get("hbm_bytes_per_launch") if entry else None
     except (OSError, ValueError):
         return None
+
+
+def traffic_source():
+    path = os.path.join(ROOT, "profiles", "r03_bench_pmc.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as fh:
+            return "profiles/r03_bench_pmc.json, " + str(json.load(fh).get("collected", ""))
+    except (OSError, ValueError):
+        return None
+
+
+def kernel_times(lib):
+    """{kernel kind: (ms per timed launch, timed launches)} of the current profiling session (hy_profile_read_kernel)."""
+    from hyrise_amd import abi
+    out = {}
+    for name, kind in (("scan", abi.KERNEL_SCAN), ("join_probe", abi.KERNEL_JOIN_PROBE), ("join_count", abi.KERNEL_JOIN_COUNT), ("join_build", abi.KERNEL_JOIN_BUILD),
+                       ("aggregate", abi.KERNEL_AGGREGATE)):
+        km, ln = C.c_float(0), C.c_uint32(0)
+        abi.check(lib.hy_profile_read_kernel(kind, C.byref(km), C.byref(ln)))
+        out[name] = (km.value / ln.value if ln.value else 0.0, int(ln.value))
+    return out
 
 
 _SF10 = []
@@ -166,8 +205,21 @@ def sf10_tables():
     return _SF10[0]
 
 
-def timed_kernel(lib, torch, run, steps, every=1):
-    """(seconds per call, kernel ms per timed launch): `run` repeated `steps` times after two warm-up calls."""
+def join_keys(rank, rows):
+    """(o_orderkey, l_orderkey) of this rank's SF10-shaped shard: rank 0 of a full run shares the tables of the other legs."""
+    from hyrise_amd import tpch
+    if rows:
+        data = tpch.TpchData(scale_factor=rows / 5_998_605.2, seed=42 + rank, keys_only=True)
+    elif rank == 0 and _SF10:
+        data = _SF10[0]
+    else:
+        data = tpch.TpchData(scale_factor=10.0, seed=42 + rank, keys_only=True)
+    return data.o_orderkey, data.l_orderkey
+
+
+def timed_kernel(lib, torch, run, steps, every=1, kind=None, all_kinds=False):
+    """(seconds per call, kernel ms per timed launch): `run` repeated `steps` times after two warm-up calls.  kind: the kernel whose
+    HIP-event time is returned (default: every timed kernel of the call summed / timed launches); all_kinds: the kernel_times dict."""
     from hyrise_amd import abi
     for _ in range(2):
         run()
@@ -178,9 +230,14 @@ def timed_kernel(lib, torch, run, steps, every=1):
         run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    kinds = kernel_times(lib)
     km, ln = C.c_float(0), C.c_uint32(0)
     abi.check(lib.hy_profile_read(C.byref(km), C.byref(ln)))
     abi.check(lib.hy_set_profiling(0))
+    if all_kinds:
+        return dt, kinds
+    if kind is not None:
+        return dt, kinds[kind][0]
     return dt, km.value / max(1, ln.value)
 
 
@@ -190,11 +247,12 @@ def roofline_object(kernel, algorithmic_bytes, kernel_ms, traffic=None):
             "kernel": kernel, "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms}
 
 
-def device_join(lib, torch, dev, left, right, pairs_capacity):
-    """One hy_join_hash with device-memory PosLists; returns (callable, result struct)."""
+def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None):
+    """One hy_join_hash with device-memory PosLists; returns (callable, result struct, buffers)."""
     from hyrise_amd import abi
+    mode = abi.JOIN_INNER if mode is None else mode
     left_pos = torch.empty((pairs_capacity, 2), dtype=torch.int32, device=dev)
-    right_pos = torch.empty((pairs_capacity, 2), dtype=torch.int32, device=dev)
+    right_pos = torch.empty((pairs_capacity, 2), dtype=torch.int32, device=dev) if mode == abi.JOIN_INNER else left_pos   # (Semi: one PosList)
     slice_offsets = torch.zeros(8192, dtype=torch.int64, device=dev)
     r = abi.JoinResult()
     r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
@@ -203,33 +261,62 @@ def device_join(lib, torch, dev, left, right, pairs_capacity):
     keep = (left_pos, right_pos, slice_offsets)
 
     def run():
-        abi.check(lib.hy_join_hash(left.handle, right.handle, abi.JOIN_INNER, C.byref(r)))
+        r.radix_bits = 0xFFFFFFFF
+        abi.check(lib.hy_join_hash(left.handle, right.handle, mode, C.byref(r)))
 
     return run, r, keep
 
 
-def join_leg(lib, torch, dev, steps, with_cases, with_cpu):
-    """Config 3 of BASELINE.json: JoinHash(orders, lineitem) on the order key, SF10 -- o_orderkey unencoded int32 (build),
-    l_orderkey FrameOfReference + u16 offsets (probe); PosList pairs written to HBM."""
+def join_kernels(kinds, n_orders, n, pairs, offset_width=2, pair_bytes=16):
+    """The timed kernels of one PK-FK join as roofline objects: HIP-event time per launch against the bytes each must move."""
+    out = {}
+    if kinds["join_probe"][1]:
+        out["pk_emit"] = roofline_object("pk_emit", n * offset_width + pairs * pair_bytes, kinds["join_probe"][0], committed_traffic("pk_emit"))
+    if kinds["join_count"][1]:
+        out["pk_count"] = roofline_object("pk_count", n * offset_width, kinds["join_count"][0], committed_traffic("pk_count"))
+    if kinds["join_build"][1]:
+        out["rank_table_fill_checked"] = roofline_object("rank_table_fill_checked", n_orders * 4, kinds["join_build"][0], committed_traffic("rank_table_fill_checked"))
+    return out
+
+
+def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem_host, orders, lineitem):
+    """Config 3 of BASELINE.json alone: JoinHash(orders, lineitem) on the order key, SF10 -- o_orderkey unencoded int32 (build),
+    l_orderkey FrameOfReference + u16 offsets (probe); PosList pairs written to HBM.  Also the reference's two Semi benchmarks
+    (tpch_data_micro_benchmark.cpp:299-316)."""
     import numpy as np
-    from hyrise_amd import abi, storage, tpch
+    from hyrise_amd import abi, storage
     from hyrise_amd.storage import DeviceColumn
     data = sf10_tables()
-    orders_host = storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED)
-    lineitem_host = storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE)
-    orders, lineitem = DeviceColumn(orders_host), DeviceColumn(lineitem_host)
     n = data.n_lineitems
     steps = max(3, min(steps, 10))
     run, r, keep = device_join(lib, torch, dev, orders, lineitem, n)
-    dt, kernel_ms = timed_kernel(lib, torch, run, steps)
+    dt, kinds = timed_kernel(lib, torch, run, steps, all_kinds=True)
     algorithmic = data.n_orders * 4 + n * 2 + int(r.n_pairs) * 16      # SURVEY.md 8(d): build keys + probe keys + 16 B/pair
-    emit_bytes = n * 2 + int(r.n_pairs) * 16                             # the dominant kernel's share: probe keys in, pairs out
+    kernels = join_kernels(kinds, data.n_orders, n, int(r.n_pairs))
     info = {"workload": "configs[2]: JoinHash orders x lineitem on the order key, SF10, Inner (o_orderkey int32 values, l_orderkey FrameOfReference u16)",
             "rows_per_s": (data.n_orders + n) / dt, "ms_per_join": dt * 1e3, "pairs": int(r.n_pairs), "radix_bits": int(r.radix_bits),
             "output_pos_lists": int(r.n_slices), "algorithmic_bytes": algorithmic,
-            "roofline": dict(roofline_object("whole operator (all kernels of one hy_join_hash, host-timed)", algorithmic, dt * 1e3, committed_traffic("join")),
-                             dominant_kernel=roofline_object("rt_probe_emit", emit_bytes, kernel_ms))}
+            "roofline": dict(roofline_object("whole operator (all kernels of one hy_join_hash, host-timed)", algorithmic, dt * 1e3, committed_traffic("hy_join_hash")),
+                             dominant_kernel=kernels.get("pk_emit"), kernels=kernels)}
     del keep
+    # Semi joins, both directions (BM_HashSemiProbeRelationLarger: lineitem semi-joins orders -- probe lineitem, build orders;
+    # BM_HashSemiProbeRelationSmaller: orders semi-joins lineitem -- probe orders, build lineitem with its duplicate keys)
+    semi = {}
+    run_l, r_l, keep_l = device_join(lib, torch, dev, lineitem, orders, n, abi.JOIN_SEMI)
+    dt_l, kinds_l = timed_kernel(lib, torch, run_l, steps, all_kinds=True)
+    bytes_l = data.n_orders * 4 + n * 2 + int(r_l.n_pairs) * 8
+    semi["probe_relation_larger"] = {"workload": "JoinHash(lineitem, orders, Semi): probe lineitem (FrameOfReference u16), build orders; one PosList of 8 B per match",
+                                     "ms_per_join": dt_l * 1e3, "rows_per_s": (data.n_orders + n) / dt_l, "matches": int(r_l.n_pairs), "algorithmic_bytes": bytes_l,
+                                     "roofline": dict(roofline_object("whole operator (host-timed)", bytes_l, dt_l * 1e3), kernels=join_kernels(kinds_l, data.n_orders, n, int(r_l.n_pairs), pair_bytes=8))}
+    del keep_l
+    run_s, r_s, keep_s = device_join(lib, torch, dev, orders, lineitem, data.n_orders, abi.JOIN_SEMI)
+    dt_s, kinds_s = timed_kernel(lib, torch, run_s, 3, all_kinds=True)
+    bytes_s = data.n_orders * 4 + n * 2 + int(r_s.n_pairs) * 8
+    semi["probe_relation_smaller"] = {"workload": "JoinHash(orders, lineitem, Semi): probe orders (int32 values), build lineitem (59 986 052 keys, four per order)",
+                                      "ms_per_join": dt_s * 1e3, "rows_per_s": (data.n_orders + n) / dt_s, "matches": int(r_s.n_pairs), "algorithmic_bytes": bytes_s,
+                                      "roofline": roofline_object("whole operator (host-timed)", bytes_s, dt_s * 1e3)}
+    del keep_s
+    info["semi"] = semi
     if with_cases:
         cases = {}
         rng = np.random.default_rng(7)
@@ -536,11 +623,21 @@ def main():
     abi.check(lib.hy_set_stream(C.c_void_p(stream.cuda_stream)))
 
     # ---- data: this rank's SF10-shaped shard (seed differs per rank), encoded like Hyrise, uploaded once -------------
+    from hyrise_amd import storage
     rows = args.rows or tpch.LINEITEM_ROWS_SF10
+    single = rank == 0 and world == 1 and not args.rows
+    if single and not (args.no_join and args.no_aggregate and args.no_cases):
+        sf10_tables()   # (the other legs need every column: generate once, the headline's join keys are two of them)
     days, host_column = tpch.shipdate_column(rows, seed=42 + rank)
     columns = [DeviceColumn(host_column) for _ in range(COLUMN_COPIES)]
     n_chunks = host_column.n_chunks
     predicate = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
+    o_orderkey, l_orderkey = join_keys(rank, args.rows)
+    n_orders, n_lineitems = len(o_orderkey), len(l_orderkey)
+    orders_host = storage.make_column(o_orderkey, None, abi.ENC_UNENCODED)
+    lineitem_host = storage.make_column(l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE)
+    orders, lineitem = DeviceColumn(orders_host), DeviceColumn(lineitem_host)
+    offset_width = int(lineitem_host.segments[0].width)
 
     dev = torch.device("cuda", local_rank)
     matches = torch.empty((rows, 2), dtype=torch.int32, device=dev)
@@ -551,20 +648,25 @@ def main():
     counts = torch.zeros(n_chunks, dtype=torch.int32, device=dev)
     result.flags = abi.SCAN_CHUNK_REGIONS  # chunk c's PosList at matches[offsets[c] : offsets[c] + counts[c]]
     result.offsets, result.counts = offsets.data_ptr(), counts.data_ptr()
+    run_join, join_result, join_buffers = device_join(lib, torch, dev, orders, lineitem, n_lineitems)
     turn = [0]
 
-    def step(pred=predicate, column=None):
+    def scan_step(pred=predicate, column=None):
         if column is None:
             column = columns[turn[0] % COLUMN_COPIES]
             turn[0] += 1
         abi.check(lib.hy_table_scan(column.handle, C.byref(pred), None, 0, C.byref(result)))
+
+    def step():
+        scan_step()
+        run_join()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2)):   # (the second join over a resident build column fills its rank table from the first one's key hint)
         step()
     abi.check(lib.hy_set_profiling(0 if os.environ.get("HY_BENCH_NO_EVENTS") else PROFILE_EVERY))
     barrier()
@@ -573,14 +675,16 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = C.c_float(0), C.c_uint32(0)
-    abi.check(lib.hy_profile_read(C.byref(kernel_ms), C.byref(launches)))
+    kinds = kernel_times(lib)
     abi.check(lib.hy_set_profiling(0))
 
     n_matches = int(counts.sum().item())
     expected = int((days < tpch.DAY_1995_01_01).sum())
     if n_matches != expected:
         raise SystemExit(f"rank {rank}: scan produced {n_matches} matches, numpy says {expected}")
+    n_pairs = int(join_result.n_pairs)
+    if n_pairs != n_lineitems:
+        raise SystemExit(f"rank {rank}: join produced {n_pairs} pairs, every one of the {n_lineitems} lineitems has exactly one order")
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
@@ -588,19 +692,30 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    total_rows = rows * world
-    value = total_rows / (elapsed / args.steps)
+    step_rows = rows + n_orders + n_lineitems
+    value = step_rows * world / (elapsed / args.steps)
 
-    # roofline of the dominant kernel (scan_slices): algorithmic bytes per launch = attribute vector + RowIDs written
+    # algorithmic bytes per step: attribute vector + RowIDs written | build keys + probe keys + 16 B per pair
     width = host_column.segments[0].width
-    algorithmic_bytes = rows * width + n_matches * 8
-    kernel_ms_per_launch = kernel_ms.value / max(1, launches.value)
-    single = rank == 0 and world == 1 and not args.rows
+    scan_bytes = rows * width + n_matches * 8
+    join_bytes = n_orders * 4 + n_lineitems * offset_width + n_pairs * 16
+    step_kernels = {"scan_slices": roofline_object("scan_slices", scan_bytes, kinds["scan"][0], committed_traffic("scan_slices"))}
+    step_kernels.update(join_kernels(kinds, n_orders, n_lineitems, n_pairs, offset_width))
 
+    # ---- the operators alone, the other configs (N = 1) ---------------------------------------------------------------
+    scan_info = None
+    if single:
+        dt_scan, scan_kernel_ms = timed_kernel(lib, torch, scan_step, args.steps, PROFILE_EVERY, kind="scan")
+        scan_info = {"workload": "configs[1] alone: TableScan ColumnVsValue, SF10 lineitem l_shipdate < 1995-01-01, three column copies in rotation",
+                     "rows_per_s": rows / dt_scan, "ms_per_scan": dt_scan * 1e3, "matches": n_matches, "algorithmic_bytes": scan_bytes,
+                     "roofline": dict(roofline_object("whole operator (host-timed)", scan_bytes, dt_scan * 1e3),
+                                      dominant_kernel=roofline_object("scan_slices", scan_bytes, scan_kernel_ms, committed_traffic("scan_slices")))}
     extra_cases = None
     if single and not args.no_cases:
-        extra_cases = scan_cases(lib, torch, dev, args.steps, days, columns[0], step, counts, rows, width)
-    join_info = join_leg(lib, torch, dev, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_join else None
+        extra_cases = scan_cases(lib, torch, dev, args.steps, days, columns[0], scan_step, counts, rows, width)
+    del join_buffers
+    join_info = (join_leg(lib, torch, dev, args.steps, not args.no_cases, not args.no_cpu_baseline, orders_host, lineitem_host, orders, lineitem)
+                 if single and not args.no_join else None)
     aggregate_info = aggregate_leg(lib, torch, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_aggregate else None
 
     q6_info = q6_leg(torch, dev, args.steps) if single and not args.no_cases else None
@@ -612,23 +727,31 @@ def main():
         multi = distributed.bench_legs(lib, torch, dist, dev, rank, world, share_gpu, steps=max(3, min(args.steps, 10)))
     ssb_info = None
     if not args.no_ssb and not args.rows:   # config 5: SSB SF30 star joins, lineorder chunk-sharded over the ranks
-        del columns, matches
+        del columns, matches, orders, lineitem
         from hyrise_amd import ssb
         ssb_info = ssb.bench(30.0, 3, world, rank, dist, share_gpu, local_rank)
 
     if rank == 0:
+        step_roofline = roofline_object("TableScan + JoinHash step: every kernel and launch gap of one hy_table_scan + one hy_join_hash, host-timed over the timed region",
+                                        scan_bytes + join_bytes, ms_per_step)
+        step_roofline.update(dominant_kernel=step_kernels.get("pk_emit") or step_kernels["scan_slices"], kernels=step_kernels,
+                             launches_timed={name: kinds[name][1] for name in ("scan", "join_probe", "join_count", "join_build")},
+                             traffic_source=traffic_source(), algorithmic_bytes={"scan": scan_bytes, "join": join_bytes})
+        step_roofline["traffic"] = committed_traffic("step")
         line = {
-            "metric": "rows/sec TableScan (ColumnVsValue, l_shipdate < 1995-01-01) on TPC-H SF10 lineitem",
+            "metric": "rows/sec TableScan+JoinHash, TPC-H SF10 lineitem (ColumnVsValue l_shipdate < 1995-01-01, then JoinHash orders x lineitem on the order key)",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "configs[1]: TableScan ColumnVsValue, SF10 lineitem l_shipdate, DictionarySegment<int32> "
-                                   "+ u16 attribute vectors, 916 chunks x 65535 rows, column and PosLists resident in HBM, "
-                                   f"{COLUMN_COPIES} copies of the column scanned in rotation",
-                       "rows_per_gpu": rows, "chunks_per_gpu": n_chunks, "selectivity": n_matches / rows,
-                       "parallelism": f"chunk-sharded x{world}, no collective"},
-            "roofline": dict(roofline_object("scan_slices", algorithmic_bytes, kernel_ms_per_launch, committed_traffic("scan")), launches_timed=int(launches.value)),
+            "config": {"workload": "configs[1] + configs[2] per step: TableScan ColumnVsValue on SF10 lineitem l_shipdate (DictionarySegment<int32> + u16 attribute vectors, "
+                                   f"916 chunks x 65535 rows, {COLUMN_COPIES} column copies in rotation) and JoinHash orders x lineitem on the order key (o_orderkey int32 values, "
+                                   "l_orderkey FrameOfReference u16; Inner); columns, PosLists and pair lists resident in HBM",
+                       "rows_per_step_per_gpu": step_rows, "scan_rows": rows, "build_rows": n_orders, "probe_rows": n_lineitems, "chunks_per_gpu": n_chunks,
+                       "scan_selectivity": n_matches / rows, "join_pairs": n_pairs, "parallelism": f"chunk-sharded x{world}, no collective"},
+            "roofline": step_roofline,
         }
+        if scan_info:
+            line["scan"] = scan_info
         if extra_cases:
             line["cases"] = extra_cases
         if join_info:
@@ -645,7 +768,7 @@ def main():
             line["ssb"] = dict(ssb_info, workload="configs[4]: SSB SF30 Q2.1 / Q4.1 star joins (dimension scans, one JoinHash per dimension over device-resident "
                                                    "PosLists, AggregateHash), synthetic tables per the SSB specification")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_scan(host_column, predicate, rows)
+            line["cpu_baseline"] = cpu_baseline_step(host_column, predicate, rows, orders_host, lineitem_host)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -71,6 +71,7 @@ class JoinPredicate(C.Structure):
 
 
 MAX_SECONDARY_PREDICATES = 4
+KERNEL_OTHER, KERNEL_SCAN, KERNEL_JOIN_PROBE, KERNEL_JOIN_COUNT, KERNEL_JOIN_BUILD, KERNEL_AGGREGATE, KERNEL_PROJECTION = range(7)   # hy_profile_read_kernel
 ARITH_ADD, ARITH_SUB, ARITH_MUL, ARITH_DIV, ARITH_MOD = range(5)
 
 
@@ -128,6 +129,7 @@ SYMBOLS = [
     ("hy_device_count", C.c_int32, [C.POINTER(C.c_int32)]),
     ("hy_set_profiling", C.c_int32, [C.c_int32]),
     ("hy_profile_read", C.c_int32, [C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    ("hy_profile_read_kernel", C.c_int32, [C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     ("hy_column_create", C.c_int32, [C.POINTER(Segment), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("hy_column_destroy", C.c_int32, [C.c_void_p]),
     ("hy_column_row_count", C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -2271,16 +2271,16 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     if (shape->n_slices && shape->rows && fused) {   // one workgroup per chunk
       const size_t fused_lds = size_t{fused_lds_slots(a.n_groupby)} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 64 + 2 * size_t{SLICE_ROWS} + sizeof(ColumnView) * FUSED_VIEWS +
                                sizeof(ScanJob) * HY_MAX_FILTERS + sizeof(FusedInput) * n_aggregates + size_t{FUSED_DENSE} * FUSED_CELLS * (8 * (n_aggregates + 2) + 4 * n_aggregates);
-      profile_begin(stream);
+      profile_begin(stream, HY_KERNEL_AGGREGATE);
       hipLaunchKernelGGL(fused_rows, dim3(shape->n_chunks), dim3(256), fused_lds, stream, a, fused, shape->n_chunks);
       profile_end(stream);
     } else if (shape->n_slices && shape->rows && partition_bits == 0) {
-      profile_begin(stream);
+      profile_begin(stream, HY_KERNEL_AGGREGATE);
       hipLaunchKernelGGL(aggregate_rows, dim3(shape->n_slices), dim3(256), lds_bytes, stream, a);
       profile_end(stream);
     } else if (shape->n_slices && shape->rows) {
       const uint32_t partitions = 1u << partition_bits;
-      profile_begin(stream);
+      profile_begin(stream, HY_KERNEL_AGGREGATE);
       if (!partitions_ready) {
         pa.tile_slices = partition_bits <= 11 ? 1 : 8;   // (a tile's histogram is written and scanned: 2^bits cells per tile)
         pa.n_slices = shape->n_slices;

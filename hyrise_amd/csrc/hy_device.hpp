@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -73,6 +74,15 @@ constexpr uint32_t SLICE_ROWS = WG_THREADS * ROWS_PER_THREAD;   // 8192
 
 }  // namespace hy
 
+// What the first JoinHash over a resident build column learned about its keys (join.hip: rank_table_fill_checked): later joins
+// fill their rank table in one pass sized by it and CHECK it in the same pass -- it saves no work on the keys, only a host round
+// trip and the second read.  state: 0 nothing known, 1 valid, 2 do not use (a check failed once).
+struct hy_join_key_hint {
+  std::atomic<uint32_t> state{0};
+  std::atomic<uint32_t> unique{0};          // no key twice (a column with duplicates still serves Semi / Anti joins: presence bits only)
+  std::atomic<uint64_t> key_min{0}, key_max{0};
+};
+
 // The opaque ABI type.
 struct hy_column {
   uint32_t n_chunks = 0;
@@ -93,9 +103,11 @@ struct hy_column {
   hy::Part* d_parts = nullptr;
   uint32_t n_parts = 0;
   uint64_t* d_row_base = nullptr;           // [n_chunks + 1] device copy of row_base
+  uint32_t* d_first_slice = nullptr;        // [n_chunks + 1] index of every chunk's first slice (the last entry: n_slices)
   bool descriptors_pooled = false;          // the five descriptor tables above are pieces of ONE pooled block (column->pooled), uploaded with one copy
   std::vector<void*> owned;                 // device allocations freed with the column
   std::vector<std::pair<size_t, void*>> pooled;   // ... or handed back to the buffer pool (operator results)
+  mutable hy_join_key_hint join_hint;
 };
 
 namespace hy {
@@ -123,9 +135,9 @@ hy_status pinned_staging(size_t bytes, void** host, void** device);
 
 // Optional HIP-event bracket around the dominant kernel of an operator call (hy_set_profiling / hy_last_kernel_ms).
 void release_thread_join_state();   // join.hip: frees the calling thread's pinned mailbox (hy_shutdown)
-void profile_begin(hipStream_t stream);
+void profile_begin(hipStream_t stream, uint32_t kind = HY_KERNEL_OTHER);   // kind: HY_KERNEL_* (hy_profile_read_kernel)
 void profile_end(hipStream_t stream);
-bool profile_events(hipEvent_t* start, hipEvent_t* stop);   // per-kernel pair for hipExtLaunchKernelGGL
+bool profile_events(hipEvent_t* start, hipEvent_t* stop, uint32_t kind = HY_KERNEL_OTHER);   // per-kernel pair for hipExtLaunchKernelGGL
 
 // ---- per-thread scratch (status words for decoupled look-back, job tables, temporaries) ----------------------------
 // Every operator call of a thread reuses one growing arena; thread-safe because it is thread-local, as are streams.

@@ -2377,6 +2377,16 @@ struct JoinMailbox {
 static thread_local JoinMailbox* t_mailbox = nullptr;      // host address
 static thread_local JoinMailbox* t_mailbox_dev = nullptr;  // device address of the same memory
 
+// What rank_table_fill_checked found out about a build column that was filled on the strength of a hint (below): read by the
+// host when the join's last kernel has finished.  It lives behind the mailbox in the same pinned block and is cleared only by
+// the launch that fills it (join_mailbox clears the mailbox several times per join).
+struct BuildVerdict {
+  uint64_t key_min, key_max;              // smallest / largest key as signed 64-bit values
+  uint32_t unsorted_signed, equal_neighbours, outside_hint, done;
+};
+static BuildVerdict* build_verdict_host() { return reinterpret_cast<BuildVerdict*>(reinterpret_cast<char*>(t_mailbox) + 256); }
+static BuildVerdict* build_verdict_device() { return reinterpret_cast<BuildVerdict*>(reinterpret_cast<char*>(t_mailbox_dev) + 256); }
+
 // hy_shutdown: the calling thread's mailbox goes with its scratch arena and pools (the next join allocates a new one)
 void release_thread_join_state() {
   if (t_mailbox) (void)hipHostFree(t_mailbox);
@@ -2385,13 +2395,190 @@ void release_thread_join_state() {
 
 static hy_status join_mailbox(JoinMailbox** host, JoinMailbox** device) {
   if (!t_mailbox) {
-    HY_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_mailbox), sizeof(JoinMailbox), hipHostMallocMapped));
+    static_assert(sizeof(JoinMailbox) <= 256, "the build verdict sits 256 bytes behind the mailbox");
+    HY_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_mailbox), 256 + sizeof(BuildVerdict), hipHostMallocMapped));
     HY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_mailbox_dev), t_mailbox, 0));
   }
   std::memset(t_mailbox, 0, sizeof(JoinMailbox));
   *host = t_mailbox;
   *device = t_mailbox_dev;
   return HY_OK;
+}
+
+// The same table AND the statistics of dense_key_stats in ONE pass over the build column, for a column whose extent is already
+// known: the first join over a resident column leaves its key range behind as a hint (hy_column::join_hint -- encoded segments
+// are immutable, abstract_encoded_segment.hpp:12-17), later joins size and fill the table from the hint while they check
+// every key against it (order, duplicates, smallest / largest key, keys outside the hinted range), and the host compares the
+// verdict with the hint when the join's last kernel has finished: no second read of the build keys, no host round trip between
+// the build and the probe.  A verdict that does not confirm the hint discards the join's output and runs the two-pass build.
+// partials: [n_slices][4] min ^ sign | max ^ sign | flags (1 unsorted, 2 equal neighbours, 4 outside the hint) | unused.
+__global__ __launch_bounds__(256) void rank_table_fill_checked(MaterializeArgs a, uint64_t key_min, uint64_t hint_range, u32x2_entry_t* entries, uint64_t* partials, uint32_t* ticket,
+                                                               BuildVerdict* verdict) {
+  __shared__ uint32_t s_bits[FILL_WORDS], s_base[FILL_WORDS];
+  __shared__ uint64_t s_min[4], s_max[4];
+  __shared__ uint32_t s_flags, s_last;
+  const uint32_t tid = threadIdx.x;
+  const Slice slice = a.slices[blockIdx.x];
+  constexpr uint64_t SIGN = 1ull << 63;
+  uint64_t lowest = ~0ull, highest = 0;
+  uint32_t flags = 0;
+  if (tid == 0) s_flags = 0;
+  if (slice.row_count != 0) {
+    const DevSegment s = a.segments[slice.chunk];
+    const uint64_t first_row = a.row_base[slice.chunk] + slice.row_begin;   // rank of the slice's first key
+    const uint64_t first_rel = static_cast<uint64_t>(dense_key(s, slice.row_begin)) - key_min, last_rel = static_cast<uint64_t>(dense_key(s, slice.row_begin + slice.row_count - 1)) - key_min;
+    const uint64_t first_word = first_rel >> 5;
+    // (an unsorted slice or one outside the hint: whatever it writes stays inside the table, and the verdict discards the join)
+    const bool staged = first_rel <= hint_range && last_rel <= hint_range && last_rel >= first_rel && (last_rel >> 5) - first_word < FILL_WORDS;
+    const uint64_t span = staged ? (last_rel >> 5) - first_word + 1 : 0;
+    // the key in front of the slice (the last row of the nearest earlier slice with rows)
+    int64_t key_before = 0;
+    bool has_before = false;
+    if (tid == 0) {
+      for (uint32_t before = blockIdx.x; before-- > 0;) {
+        const Slice earlier = a.slices[before];
+        if (earlier.row_count == 0) continue;
+        key_before = dense_key(a.segments[earlier.chunk], earlier.row_begin + earlier.row_count - 1);
+        has_before = true;
+        break;
+      }
+    }
+    if (staged) {
+      for (uint32_t i = tid; i < span; i += 256) { s_bits[i] = 0; s_base[i] = 0; }
+    }
+    __syncthreads();
+    auto place = [&](int64_t key, int64_t previous, bool has_previous, uint32_t r) {   // row r of the slice
+      const uint64_t wide = static_cast<uint64_t>(key);
+      lowest = (wide ^ SIGN) < lowest ? (wide ^ SIGN) : lowest;
+      highest = (wide ^ SIGN) > highest ? (wide ^ SIGN) : highest;
+      if (has_previous) {
+        if (previous > key) flags |= 1u;
+        if (previous == key) flags |= 2u;
+      }
+      const uint64_t rel = wide - key_min;
+      if (rel > hint_range) { flags |= 4u; return; }
+      const uint64_t word = rel >> 5;
+      const uint32_t bit = 1u << (rel & 31);
+      const bool leader = !has_previous || ((static_cast<uint64_t>(previous) - key_min) >> 5) != word;   // no earlier row shares the word: its row number is the entry's base
+      if (staged && word - first_word < span) {
+        atomicOr(&s_bits[word - first_word], bit);
+        if (leader) s_base[word - first_word] = static_cast<uint32_t>(first_row + r) + 1u;   // (+ 1: 0 = the word's first key is not in this slice)
+      } else {
+        atomicOr(reinterpret_cast<uint32_t*>(entries + word), bit);
+        if (leader) reinterpret_cast<uint32_t*>(entries + word)[1] = static_cast<uint32_t>(first_row + r);
+      }
+      if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(key) & (BLOOM_BITS - 1)] = 1;
+    };
+    if (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !(s.flags & SEG_UNALIGNED)) {
+      // int32 values: four consecutive rows per lane and load, all eight loads in flight, plus the value in front of each group
+      const int32_t* values = static_cast<const int32_t*>(s.data) + slice.row_begin;
+      constexpr uint32_t GROUPS = SLICE_ROWS / 1024;
+      u32x4_t group[GROUPS];
+      int32_t front[GROUPS];
+#pragma unroll
+      for (uint32_t i = 0; i < GROUPS; ++i) {
+        const uint32_t first = i * 1024 + tid * 4;
+        group[i] = *reinterpret_cast<const u32x4_t*>(values + (first < slice.row_count ? first : 0));
+        front[i] = values[first > 0 && first < slice.row_count ? first - 1 : 0];
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < GROUPS; ++i) {
+        const uint32_t first = i * 1024 + tid * 4;
+        const int32_t k[5] = {front[i], static_cast<int32_t>(group[i].x), static_cast<int32_t>(group[i].y), static_cast<int32_t>(group[i].z), static_cast<int32_t>(group[i].w)};
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+          if (first + e >= slice.row_count) continue;
+          const bool at_start = first + e == 0;
+          place(k[e + 1], at_start ? key_before : static_cast<int64_t>(k[e]), at_start ? has_before : true, first + e);
+        }
+      }
+    } else {
+      constexpr uint32_t BATCH = 8;
+#pragma unroll 1
+      for (uint32_t block = 0; block < SLICE_ROWS / 256 / BATCH; ++block) {
+        if (block * BATCH * 256 >= slice.row_count) break;
+        int64_t key[BATCH], before[BATCH];
+#pragma unroll
+        for (uint32_t i = 0; i < BATCH; ++i) {
+          const uint32_t r = (block * BATCH + i) * 256 + tid;
+          const uint32_t row = slice.row_begin + (r < slice.row_count ? r : 0);
+          key[i] = dense_key(s, row);
+          before[i] = dense_key(s, row > slice.row_begin ? row - 1 : row);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < BATCH; ++i) {
+          const uint32_t r = (block * BATCH + i) * 256 + tid;
+          if (r >= slice.row_count) continue;
+          place(key[i], r == 0 ? key_before : before[i], r == 0 ? has_before : true, r);
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < span; i += 256) {
+      const uint32_t bits = s_bits[i], base = s_base[i];
+      if (i == 0 || i + 1 == span) {   // may be shared with a neighbouring slice: add the bits; the base comes from the slice with the word's first key
+        if (bits) atomicOr(reinterpret_cast<uint32_t*>(entries + first_word + i), bits);
+        if (base) reinterpret_cast<uint32_t*>(entries + first_word + i)[1] = base - 1u;
+      } else {
+        entries[first_word + i] = u32x2_entry_t{bits, base ? base - 1u : 0u};
+      }
+    }
+  } else {
+    __syncthreads();
+  }
+  // the slice's record
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint64_t other_low = __shfl_xor(lowest, d, 64), other_high = __shfl_xor(highest, d, 64);
+    lowest = other_low < lowest ? other_low : lowest;
+    highest = other_high > highest ? other_high : highest;
+  }
+  if (flags) atomicOr(&s_flags, flags);
+  if ((tid & 63) == 0) { s_min[tid >> 6] = lowest; s_max[tid >> 6] = highest; }
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t low = ~0ull, high = 0;
+    for (uint32_t w = 0; w < 4; ++w) { low = s_min[w] < low ? s_min[w] : low; high = s_max[w] > high ? s_max[w] : high; }
+    uint64_t* record = partials + 4 * size_t{blockIdx.x};
+    record[0] = low;
+    record[1] = high;
+    record[2] = s_flags;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = arrived + 1 == gridDim.x ? 1u : 0u;
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // the workgroup that arrives last sees every slice's record: the verdict
+  uint64_t low = ~0ull, high = 0, bits = 0;
+  for (uint32_t i = tid; i < a.n_slices; i += 256) {
+    const uint64_t* record = partials + 4 * size_t{i};
+    low = record[0] < low ? record[0] : low;
+    high = record[1] > high ? record[1] : high;
+    bits |= record[2];
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    bits |= __shfl_xor(bits, d, 64);
+    const uint64_t other_low = __shfl_xor(low, d, 64), other_high = __shfl_xor(high, d, 64);
+    low = other_low < low ? other_low : low;
+    high = other_high > high ? other_high : high;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { s_min[tid >> 6] = low; s_max[tid >> 6] = high; atomicOr(&s_flags, static_cast<uint32_t>(bits)); }
+  __syncthreads();
+  if (tid != 0) return;
+  for (uint32_t w = 0; w < 4; ++w) { low = s_min[w] < low ? s_min[w] : low; high = s_max[w] > high ? s_max[w] : high; }
+  verdict->key_min = low ^ SIGN;
+  verdict->key_max = high ^ SIGN;
+  verdict->unsorted_signed = s_flags & 1u ? 1 : 0;
+  verdict->equal_neighbours = s_flags & 2u ? 1 : 0;
+  verdict->outside_hint = s_flags & 4u ? 1 : 0;
+  verdict->done = 1;
+  *ticket = 0;
+  __threadfence_system();
 }
 
 // flags: see check_sorted; [10] a key met twice by rank_table_mark
@@ -2498,6 +2685,8 @@ __global__ __launch_bounds__(256) void plan_output(const uint64_t* base_elements
   }
 }
 
+#include "join_pkfk.hpp"
+
 // HY_JOIN_TIMING=1: host-side wall clock at the join's synchronisation points (debug aid)
 struct StageClock {
   bool on = getenv("HY_JOIN_TIMING") != nullptr;
@@ -2508,7 +2697,10 @@ struct StageClock {
 };
 
 struct BuildSide {
-  DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags, rank_entries;
+  DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags, rank_entries, partials;
+  bool hint_allows_duplicates = false;
+  bool hinted = false;           // the rank table was filled from the column's key hint: the join must confirm build_verdict_host() at its end
+  uint64_t hint_min = 0, hint_max = 0;
   uint64_t n = 0;
   Directory directory{};
   RankTable rank{};            // rank.entries != nullptr: unique integer keys, looked up in the rank table (directory.dir is not built)
@@ -2517,8 +2709,11 @@ struct BuildSide {
 
 // Materialise + (sort) + directory.  `bloom_in` (device) filters the build side (no observable effect, kept for the
 // reference's element counts); `bloom_out` receives the build side's filter if wanted.
-static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, uint32_t hashed_type, bool allow_rank_table, BuildSide& b,
-                               hipStream_t stream) {
+// `existence_only`: the join only asks whether a key exists (Semi / Anti without secondary predicates -- the reference's
+// ExistenceOnly hash table, join_hash_steps.hpp:97-236): a sorted dense build column WITH duplicates still gets a rank table, of
+// which only the presence bits mean anything.
+static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, uint32_t hashed_type, bool allow_rank_table, bool existence_only,
+                               BuildSide& b, hipStream_t stream) {
   const uint32_t n_slices = build->n_slices;
   DeviceBuffer counts, offsets;
   HY_TRY(counts.alloc(4 * size_t{n_slices + 1}));
@@ -2579,6 +2774,41 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     JoinMailbox* mailbox = nullptr;
     JoinMailbox* mailbox_dev = nullptr;
     HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
+    auto identity_table = [&](u32x2_t* entries, uint64_t key_min, uint64_t key_max) {
+      b.rank.entries = entries;
+      b.rank.key_min = key_min;
+      b.rank.range = key_max - key_min;
+      b.rank.identity_rows = build->host_segments[0].size;
+      b.rank.identity_inverse = 1.0 / static_cast<double>(b.rank.identity_rows);
+      Directory& d = b.directory;   // nothing but the extent: the probe needs neither keys nor RowIDs
+      d = Directory{};
+      d.n = total;
+      d.key_min = key_min;
+      d.key_max = key_max;
+      d.n_buckets = 1;
+    };
+    if (build->join_hint.state.load(std::memory_order_acquire) == 1 && (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) && !getenv("HY_JOIN_NO_HINT")) {
+      // an earlier join over this column found a primary key in [key_min, key_max]: one pass fills the table and checks every key
+      const uint64_t key_min = build->join_hint.key_min.load(std::memory_order_relaxed);
+      uint64_t key_max = build->join_hint.key_max.load(std::memory_order_relaxed);
+      if (getenv("HY_JOIN_BREAK_HINT") && key_max - key_min > 64) key_max -= 64;   // tests: a hint that does not hold
+      const uint64_t words = ((key_max - key_min) >> 5) + 1;
+      HY_TRY(b.rank_entries.alloc(8 * (words + 1) + 16));
+      HY_TRY(b.partials.alloc(32 * size_t{n_slices}));
+      u32x2_t* entries = b.rank_entries.as<u32x2_t>();
+      HY_HIP(hipMemsetAsync(entries, 0, 8 * (words + 1) + 16, stream));   // the table | the arrival counter
+      build_verdict_host()->done = 0;
+      hipEvent_t fill_started = nullptr, fill_stopped = nullptr;
+      profile_events(&fill_started, &fill_stopped, HY_KERNEL_JOIN_BUILD);
+      hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, key_min, key_max - key_min, entries,
+                            b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 1), build_verdict_device());
+      identity_table(entries, key_min, key_max);
+      b.hinted = true;
+      b.hint_allows_duplicates = existence_only;
+      b.hint_min = key_min;
+      b.hint_max = key_max;
+      return HY_OK;
+    }
     DeviceBuffer partials;
     HY_TRY(partials.alloc(32 * size_t{n_slices}));
     hipLaunchKernelGGL(dense_key_stats, dim3(n_slices), dim3(256), 0, stream, m, partials.as<uint64_t>());
@@ -2587,22 +2817,18 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     const uint64_t key_min = mailbox->key_min, range = mailbox->key_max - mailbox->key_min;
     const uint64_t words = (range >> 5) + 1;
     if (getenv("HY_JOIN_TIMING")) fprintf(stderr, "  dense stats: min %lld max %lld unsorted %u signed %u equal %u total %llu\n", (long long)mailbox->key_min, (long long)mailbox->key_max, mailbox->unsorted, mailbox->unsorted_signed, mailbox->equal_neighbours, (unsigned long long)total);
-    if (!mailbox->unsorted_signed && !mailbox->equal_neighbours && range < 0xFFFFFF00ull && words <= 2 * total + 4096) {
+    if (!mailbox->unsorted_signed && (!mailbox->equal_neighbours || existence_only) && range < 0xFFFFFF00ull && words <= 2 * total + 4096) {
       HY_TRY(b.rank_entries.alloc(8 * (words + 1)));
       u32x2_t* entries = b.rank_entries.as<u32x2_t>();
       HY_HIP(hipMemsetAsync(entries, 0, 8 * (words + 1), stream));
       hipLaunchKernelGGL(rank_table_fill_dense, dim3(n_slices), dim3(256), 0, stream, m, key_min, entries);
-      b.rank.entries = entries;
-      b.rank.key_min = key_min;
-      b.rank.range = range;
-      b.rank.identity_rows = build->host_segments[0].size;
-      b.rank.identity_inverse = 1.0 / static_cast<double>(b.rank.identity_rows);
-      Directory& d = b.directory;   // nothing but the extent: the probe needs neither keys nor RowIDs
-      d = Directory{};
-      d.n = total;
-      d.key_min = mailbox->key_min;
-      d.key_max = mailbox->key_max;
-      d.n_buckets = 1;
+      identity_table(entries, mailbox->key_min, mailbox->key_max);
+      if (build->join_hint.state.load(std::memory_order_acquire) == 0) {   // the next join over this column fills its table in one pass
+        build->join_hint.key_min.store(mailbox->key_min, std::memory_order_relaxed);
+        build->join_hint.key_max.store(mailbox->key_max, std::memory_order_relaxed);
+        build->join_hint.unique.store(mailbox->equal_neighbours ? 0u : 1u, std::memory_order_relaxed);
+        build->join_hint.state.store(1, std::memory_order_release);
+      }
       return HY_OK;
     }
     // (not a primary key after all: materialise as usual)
@@ -2827,6 +3053,9 @@ static uint32_t device_cu_count() {
 }
 
 static thread_local int t_last_join_used_rank_table = 0;   // debug / tests: which lookup structure the thread's last join built
+static thread_local int t_last_join_used_pkfk = 0;         // ... and whether the kernels of join_pkfk.hpp probed it
+static thread_local int t_last_join_hinted_attempt = 0;
+static thread_local int t_last_join_hinted = 0;            // ... 1: the build side was filled from the column's key hint, 2: that attempt was discarded and the join ran again
 constexpr uint32_t JOIN_TRACE_TILES = 1u << 15;
 static uint64_t* g_join_trace = nullptr;
 static uint32_t g_join_trace_tiles = 0;
@@ -2869,8 +3098,8 @@ static bool lds_atomics_are_lane_ordered(hipStream_t stream) {
   return state == 1;
 }
 
-static hy_status run_join(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result, bool count_only, uint64_t* count_out,
-                          const hy_join_predicate* secondary = nullptr, uint32_t n_secondary = 0) {
+static hy_status run_join_once(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result, bool count_only, uint64_t* count_out,
+                               const hy_join_predicate* secondary, uint32_t n_secondary, bool* retry) {
   if (mode == HY_JOIN_FULL_OUTER || mode == HY_JOIN_CROSS || mode > HY_JOIN_ANTI_NULL_AS_FALSE) return fail(HY_ERR_UNSUPPORTED, "JoinHash does not support join mode %u (join_hash.cpp:38-44)", mode);
   if (n_secondary > HY_MAX_SECONDARY_PREDICATES) return fail(HY_ERR_UNSUPPORTED, "more than %u secondary join predicates stay on the CPU path", HY_MAX_SECONDARY_PREDICATES);
   if (n_secondary && mode == HY_JOIN_ANTI_NULL_AS_TRUE) return fail(HY_ERR_UNSUPPORTED, "JoinHash does not support secondary predicates with AntiNullAsTrue (join_hash.cpp:39-44)");
@@ -2919,8 +3148,17 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   for (uint32_t c = 0; c < build->n_chunks && pack_build_ids; ++c) pack_build_ids = build->host_segments[c].size <= 65536;
   BuildSide b;
   StageClock clock;
-  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, b, stream));
+  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, semi_anti && n_secondary == 0, b, stream));
   const bool rank_path = b.rank.entries != nullptr;
+  // A rank table filled from the build column's key hint (rank_table_fill_checked) is confirmed when the join's kernels have finished:
+  // if the column is not what the hint said, the hint is dropped, whatever the join wrote is discarded and the caller runs it again.
+  auto hint_confirmed = [&]() {
+    if (!b.hinted) return true;
+    const BuildVerdict* v = build_verdict_host();
+    const bool ok = v->done && !v->unsorted_signed && (!v->equal_neighbours || b.hint_allows_duplicates) && !v->outside_hint && v->key_min == b.hint_min && v->key_max == b.hint_max;
+    if (!ok) { build->join_hint.state.store(2, std::memory_order_release); *retry = true; }
+    return ok;
+  };
   // the probe column's segments are all ones a SliceView describes (int32 values / FrameOfReference offsets, no NULLs, 16-byte
   // aligned): pass 1 is the wave-per-tile kernel with wide loads
   bool fetch_ahead = rank_path && !probe->is_reference && !getenv("HY_JOIN_NO_FETCH_AHEAD");
@@ -2930,6 +3168,8 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
                   ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
   }
   t_last_join_used_rank_table = rank_path ? (b.rank.identity_rows ? 2 : 1) : 0;
+  t_last_join_used_pkfk = 0;
+  t_last_join_hinted_attempt = b.hinted ? 1 : 0;
   clock.mark("build side launched");
 
   if (result) {
@@ -2942,6 +3182,124 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     if (count_out) *count_out = 0;
     if (result && result->slice_offsets && host_result) result->slice_offsets[0] = 0;
     if (result && result->slice_offsets && !host_result) HY_HIP(hipMemsetAsync(result->slice_offsets, 0, 8, stream));
+    return HY_OK;
+  }
+
+  // The primary-key / foreign-key probe (join_pkfk.hpp): rank table, probe segments that SliceViews describe, keys of both sides
+  // int32 values (32-bit distances), counts and pair indices in 32 bits, lane-ordered LDS atomics.
+  const bool pk_path = rank_path && fetch_ahead && probe->n_slices > 0 && probe->rows < 0xFFFF0000ull && !getenv("HY_JOIN_NO_PKFK") &&
+                       static_cast<int64_t>(b.rank.key_min) >= INT32_MIN && static_cast<int64_t>(b.rank.key_min + b.rank.range) <= INT32_MAX &&
+                       (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
+  if (pk_path) {
+    const uint32_t n_tiles = probe->n_slices, partitions = 1u << radix_bits;
+    const uint32_t stride = (n_tiles + 1 + 3) & ~3u;
+    const uint32_t n_groups = radix_bits ? partitions : probe->n_chunks;
+    const uint32_t max_slices = static_cast<uint32_t>(probe->rows / PROBE_SIZE_PER_CHUNK) + n_groups + 1;
+    DeviceBuffer cells, small;
+    HY_TRY(cells.alloc(size_t{12} * partitions * stride));
+    const size_t at_origin = align_up(8 * size_t{partitions}, 8), at_slice_base = at_origin + 8 * (size_t{partitions} + 1), at_words = align_up(at_slice_base + 4 * (size_t{n_groups} + 1), 8);
+    HY_TRY(small.alloc(at_words + 64));
+    JoinMailbox* mailbox = nullptr;
+    JoinMailbox* mailbox_dev = nullptr;
+    HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
+    hy_row_id* user_build = nullptr;
+    hy_row_id* user_probe = nullptr;
+    if (!count_only) {
+      user_build = result->left_is_build ? result->left_pos : result->right_pos;
+      user_probe = result->left_is_build ? result->right_pos : result->left_pos;
+      if (!user_probe && result->capacity) return fail(HY_ERR_INVALID, "join result: PosList buffer for the probe side missing");
+      if (!semi_anti && !user_build && result->capacity) return fail(HY_ERR_INVALID, "join result: PosList buffer for the build side missing");
+      if (!result->slice_offsets) return fail(HY_ERR_INVALID, "join result: slice_offsets missing");
+    }
+    DeviceBuffer d_build_out, d_probe_out, d_slice_offsets;
+    uint64_t* dev_slice_offsets = count_only ? nullptr : result->slice_offsets;
+    if (!count_only && host_result) {
+      HY_TRY(d_slice_offsets.alloc(8 * (size_t{max_slices} + 2)));
+      dev_slice_offsets = d_slice_offsets.as<uint64_t>();
+    }
+    PkArgs k{};
+    k.views = probe->d_slice_views;
+    k.n_tiles = n_tiles;
+    k.stride = stride;
+    k.mode = mode;
+    k.radix_bits = radix_bits;
+    k.keep_nulls = keep_nulls_probe;
+    k.n_groups = n_groups;
+    k.build_bloom = probe_filtered ? b.bloom.as<uint8_t>() : nullptr;
+    k.rank = b.rank;
+    k.ids32 = b.directory.ids32;
+    k.row_ids = b.directory.row_ids;
+    k.counts = cells.as<uint32_t>();
+    k.rel_elements = k.counts + size_t{partitions} * stride;
+    k.rel_pairs = k.rel_elements + size_t{partitions} * stride;
+    char* small_base = small.as<char>();
+    k.totals = reinterpret_cast<uint32_t*>(small_base);
+    k.origin_pairs = reinterpret_cast<uint64_t*>(small_base + at_origin);
+    k.slice_base = reinterpret_cast<uint32_t*>(small_base + at_slice_base);
+    k.group_first_tile = probe->d_first_slice;
+    k.ticket = reinterpret_cast<uint32_t*>(small_base + at_words);
+    k.plan = reinterpret_cast<JoinPlan*>(small_base + at_words + 16);
+    k.mailbox = mailbox_dev;
+    k.capacity = count_only ? ~0ull : result->capacity;
+    k.slice_capacity = count_only ? 0xFFFFFFFFu : result->slice_capacity;
+    k.plain_stores = getenv("HY_JOIN_PLAIN_STORES") ? 1u : 0u;
+    k.slice_offsets = dev_slice_offsets;
+    const uint32_t tile_grid = 8 * ((n_tiles + 7) / 8);
+    {
+      hipEvent_t count_started = nullptr, count_stopped = nullptr;
+      profile_events(&count_started, &count_stopped, HY_KERNEL_JOIN_COUNT);
+      hipExtLaunchKernelGGL(pk_count, dim3(tile_grid), dim3(PK_COUNT_THREADS), 0, stream, count_started, count_stopped, 0, k);
+    }
+    hipLaunchKernelGGL(pk_scan, dim3(partitions), dim3(PK_SCAN_THREADS), 0, stream, k);
+    clock.mark("pass 1 launched");
+    if (count_only) {
+      HY_HIP(hipStreamSynchronize(stream));
+      if (!hint_confirmed()) return HY_OK;
+      if (count_out) *count_out = mailbox->n_pairs;
+      return HY_OK;
+    }
+    hy_row_id* dev_build = user_build;
+    hy_row_id* dev_probe = user_probe;
+    if (host_result) {   // the staging buffers are sized by the pair count: ask now
+      HY_HIP(hipStreamSynchronize(stream));
+      clock.mark("pass 1 done");
+      if (mailbox->fits) {
+        if (!semi_anti) { HY_TRY(d_build_out.alloc(8 * mailbox->n_pairs)); dev_build = d_build_out.as<hy_row_id>(); }
+        HY_TRY(d_probe_out.alloc(8 * mailbox->n_pairs));
+        dev_probe = d_probe_out.as<hy_row_id>();
+      }
+    }
+    k.build_out = semi_anti ? nullptr : dev_build;
+    k.probe_out = dev_probe;
+    static std::atomic<bool> pk_lds_raised{false};
+    if (!pk_lds_raised.load(std::memory_order_acquire)) {
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
+      pk_lds_raised.store(true, std::memory_order_release);
+    }
+    hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself)
+    profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
+    if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
+    else hipExtLaunchKernelGGL(pk_emit<false>, dim3(tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
+    const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
+    if (cut_grid) hipLaunchKernelGGL(pk_cuts, dim3(cut_grid), dim3(PK_THREADS), 0, stream, k);
+    HY_HIP(hipGetLastError());
+    clock.mark("pass 2 launched");
+    t_last_join_used_pkfk = 1;   // debug / tests: the primary-key / foreign-key kernels ran
+    if (host_result) {
+      if (mailbox->fits && mailbox->n_pairs) {
+        HY_HIP(hipMemcpyAsync(user_probe, dev_probe, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
+        if (!semi_anti) HY_HIP(hipMemcpyAsync(user_build, dev_build, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
+      }
+      if (mailbox->fits) HY_HIP(hipMemcpyAsync(result->slice_offsets, dev_slice_offsets, 8 * (size_t{mailbox->n_slices} + 1), hipMemcpyDeviceToHost, stream));
+    }
+    HY_HIP(hipStreamSynchronize(stream));   // the temporaries above are freed on return
+    clock.mark("pass 2 done");
+    if (!hint_confirmed()) return HY_OK;
+    result->n_slices = mailbox->n_slices;
+    result->n_pairs = mailbox->n_pairs;
+    if (mailbox->n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %u output PosLists, slice capacity is %u", mailbox->n_slices, result->slice_capacity);
+    if (mailbox->n_pairs > result->capacity) return fail(HY_ERR_CAPACITY, "join produces %llu pairs, capacity is %llu", static_cast<unsigned long long>(mailbox->n_pairs), static_cast<unsigned long long>(result->capacity));
     return HY_OK;
   }
 
@@ -3067,6 +3425,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   clock.mark("pass 1 launched");
   if (count_only) {
     HY_HIP(hipStreamSynchronize(stream));
+    if (!hint_confirmed()) return HY_OK;
     if (mailbox->error) return fail(HY_ERR_UNSUPPORTED, "a probe row matches more than 4 194 303 build rows");   // (pass 1 clamped its count)
     if (count_out) *count_out = mailbox->n_pairs;
     return HY_OK;
@@ -3098,7 +3457,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   if (n_tiles && rank_path) {   // (every pass 2 kernel returns at once if the plan says that the result does not fit)
     a.lane_ordered_atomics = lds_atomics_are_lane_ordered(stream) ? 1u : 0u;
     hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself: event records around the launch add the gaps to its neighbours)
-    profile_events(&started, &stopped);
+    profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
     hipExtLaunchKernelGGL(rt_probe_emit, dim3(probe_grid(n_tiles)), dim3(JOIN_THREADS), 4 * rt_probe_emit_lds_words(partitions), stream, started, stopped, 0, a);
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
     if (cut_grid) hipLaunchKernelGGL(rt_probe_cuts, dim3(cut_grid), dim3(JOIN_THREADS), 0, stream, a, dev_first_cell, n_groups);
@@ -3113,7 +3472,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     // persistent workgroups: as many as fit the device at once (a multiple of the 8 XCDs), never more than tiles
     const uint32_t resident = device_cu_count() * workgroups_per_cu / 8 * 8;
     const uint32_t cached_grid = std::max<uint32_t>(8, std::min<uint32_t>(resident, probe_grid(n_tiles)));
-    profile_begin(stream);
+    profile_begin(stream, HY_KERNEL_JOIN_PROBE);
     hipLaunchKernelGGL(probe_emit_cached, dim3(cached_grid), dim3(JOIN_THREADS), 4 * probe_emit_cached_lds_words(partitions), stream, a);
     profile_end(stream);
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
@@ -3136,12 +3495,28 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
   }
   HY_HIP(hipStreamSynchronize(stream));   // the temporaries above are freed on return
   clock.mark("pass 2 done");
+  if (!hint_confirmed()) return HY_OK;
   result->n_slices = mailbox->n_slices;
   result->n_pairs = mailbox->n_pairs;
   if (mailbox->n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %u output PosLists, slice capacity is %u", mailbox->n_slices, result->slice_capacity);
   if (mailbox->n_pairs > result->capacity) return fail(HY_ERR_CAPACITY, "join produces %llu pairs, capacity is %llu", static_cast<unsigned long long>(mailbox->n_pairs), static_cast<unsigned long long>(result->capacity));
   if (mailbox->error) return fail(HY_ERR_UNSUPPORTED, "a probe row matches more than 4 194 303 build rows");
   return HY_OK;
+}
+
+static hy_status run_join(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result, bool count_only, uint64_t* count_out,
+                          const hy_join_predicate* secondary = nullptr, uint32_t n_secondary = 0) {
+  const uint32_t radix_bits = result ? result->radix_bits : 0;   // (the first attempt overwrites the caller's request with what it used)
+  bool retry = false;
+  hy_status status = run_join_once(left, right, mode, result, count_only, count_out, secondary, n_secondary, &retry);
+  t_last_join_hinted = t_last_join_hinted_attempt ? 1 : 0;
+  if (status == HY_OK && retry) {   // the build column's key hint did not hold: it is dropped now, the two-pass build runs
+    if (result) result->radix_bits = radix_bits;
+    retry = false;
+    status = run_join_once(left, right, mode, result, count_only, count_out, secondary, n_secondary, &retry);
+    t_last_join_hinted = 2;
+  }
+  return status;
 }
 
 }  // namespace hy
@@ -3178,6 +3553,12 @@ hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint
 int hy_debug_join_lane_ordered_atomics() { return g_lds_atomic_order.load(); }
 
 int hy_debug_join_used_rank_table(void) { return t_last_join_used_rank_table; }
+
+// debug / tests only: see t_last_join_hinted
+int hy_debug_join_build_was_hinted(void) { return t_last_join_hinted; }
+
+// debug / tests only: 1 = the last join of this thread ran pk_count / pk_scan / pk_emit / pk_cuts (join_pkfk.hpp)
+int hy_debug_join_used_pkfk(void) { return t_last_join_used_pkfk; }
 
 // debug only (HY_JOIN_TRACE): the per-tile phase stamps of the last join's probe_emit; not part of the public header
 int hy_debug_join_trace(uint64_t* out, uint32_t capacity_tiles) {

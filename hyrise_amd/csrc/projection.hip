@@ -324,7 +324,7 @@ hy_status hy_projection_arithmetic(uint32_t op, const hy_operand* left, const hy
   a.nulls = d_nulls;
   a.null_base = d_null_base;
   if (shape->n_slices && shape->rows) {
-    profile_begin(stream);
+    profile_begin(stream, HY_KERNEL_PROJECTION);
     hipLaunchKernelGGL(projection_rows, dim3(shape->n_slices), dim3(256), 0, stream, a);
     profile_end(stream);
   }

@@ -44,10 +44,11 @@ hipStream_t current_stream() {
 
 struct Profile {
   bool enabled = false;
-  uint32_t period = 1;              // every period-th bracket is timed (timed launches cost ~7 us of stream time each)
-  uint32_t counter = 0;
+  uint32_t period = 1;              // every period-th bracket of a kernel is timed (timed launches cost ~7 us of stream time each)
+  uint32_t counter[HY_KERNEL_KINDS] = {};
   bool open = false;                // profile_begin recorded, profile_end pending
   std::vector<hipEvent_t> events;   // start/stop pairs, reused across profiling sessions
+  std::vector<uint8_t> kinds;       // [pair] which kernel the pair brackets (HY_KERNEL_*)
   size_t used = 0;
 };
 static thread_local Profile t_profile;
@@ -62,14 +63,18 @@ static hipEvent_t next_event() {
   return p.events[p.used++];
 }
 
-static bool sampled() {
+static bool sampled(uint32_t kind) {
   Profile& p = t_profile;
   if (!p.enabled || p.used >= 16384) return false;
-  return p.counter++ % p.period == 0;
+  if (kind >= HY_KERNEL_KINDS) kind = 0;
+  if (p.counter[kind]++ % p.period != 0) return false;
+  if (p.kinds.size() <= p.used / 2) p.kinds.resize(p.used / 2 + 1);
+  p.kinds[p.used / 2] = static_cast<uint8_t>(kind);
+  return true;
 }
 
-void profile_begin(hipStream_t stream) {
-  t_profile.open = sampled();
+void profile_begin(hipStream_t stream, uint32_t kind) {
+  t_profile.open = sampled(kind);
   if (t_profile.open) (void)hipEventRecord(next_event(), stream);
 }
 
@@ -81,9 +86,9 @@ void profile_end(hipStream_t stream) {
 
 // A start/stop pair for ONE kernel: handed to hipExtLaunchKernelGGL, which stamps them from the dispatch packet itself
 // (no extra barrier packets on the stream, unlike hipEventRecord before and after the launch).
-bool profile_events(hipEvent_t* start, hipEvent_t* stop) {
+bool profile_events(hipEvent_t* start, hipEvent_t* stop, uint32_t kind) {
   *start = *stop = nullptr;
-  if (!sampled()) return false;
+  if (!sampled(kind)) return false;
   *start = next_event();
   *stop = next_event();
   return true;
@@ -259,18 +264,19 @@ hy_status hy_init(int32_t device) {
 hy_status hy_set_profiling(int32_t enabled) {
   t_profile.enabled = enabled > 0;
   t_profile.period = enabled > 1 ? static_cast<uint32_t>(enabled) : 1;
-  t_profile.counter = 0;
+  for (uint32_t& c : t_profile.counter) c = 0;
   t_profile.open = false;
   t_profile.used = 0;
   return HY_OK;
 }
 
-hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches) {
-  if (!total_milliseconds || !launches) return fail(HY_ERR_INVALID, "hy_profile_read: null argument");
+// Sum and count of the recorded pairs of one kernel kind (HY_KERNEL_KINDS: all of them); waits for the events.
+static hy_status profile_sum(uint32_t kind, float* total_milliseconds, uint32_t* launches) {
   Profile& p = t_profile;
   float total = 0.f;
   uint32_t count = 0;
   for (size_t i = 0; i + 1 < p.used; i += 2) {
+    if (kind != HY_KERNEL_KINDS && (i / 2 >= p.kinds.size() || p.kinds[i / 2] != kind)) continue;
     float ms = 0.f;
     HY_HIP(hipEventSynchronize(p.events[i + 1]));
     HY_HIP(hipEventElapsedTime(&ms, p.events[i], p.events[i + 1]));
@@ -279,8 +285,20 @@ hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches) {
   }
   *total_milliseconds = total;
   *launches = count;
-  p.used = 0;
   return HY_OK;
+}
+
+hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches) {
+  if (!total_milliseconds || !launches) return fail(HY_ERR_INVALID, "hy_profile_read: null argument");
+  HY_TRY(profile_sum(HY_KERNEL_KINDS, total_milliseconds, launches));
+  t_profile.used = 0;
+  return HY_OK;
+}
+
+hy_status hy_profile_read_kernel(uint32_t kernel, float* total_milliseconds, uint32_t* launches) {
+  if (!total_milliseconds || !launches) return fail(HY_ERR_INVALID, "hy_profile_read_kernel: null argument");
+  if (kernel >= HY_KERNEL_KINDS) return fail(HY_ERR_INVALID, "hy_profile_read_kernel: unknown kernel kind %u", kernel);
+  return profile_sum(kernel, total_milliseconds, launches);
 }
 
 // Releases what the CALLING thread holds between calls: its scratch arena, its pool of temporary blocks, its pinned
@@ -590,13 +608,18 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   const size_t row_base_bytes = 8 * (size_t{n_chunks} + 1), parts_bytes = sizeof(Part) * parts.size();
   const size_t at_slices = aligned(segments_bytes + sizeof(DevSegment)), at_views = at_slices + aligned(slices_bytes + sizeof(Slice));
   const size_t at_row_base = at_views + aligned(views_bytes + sizeof(SliceView)), at_parts = at_row_base + aligned(row_base_bytes);
-  const size_t total = at_parts + aligned(parts_bytes + sizeof(Part));
+  const size_t at_first_slice = at_parts + aligned(parts_bytes + sizeof(Part));
+  const size_t total = at_first_slice + aligned(4 * (size_t{n_chunks} + 1));
+  std::vector<uint32_t> first_slice(size_t{n_chunks} + 1, 0);
+  for (size_t i = slices.size(); i-- > 0;) first_slice[slices[i].chunk] = static_cast<uint32_t>(i);   // (descending: the chunk's first slice is written last)
+  first_slice[n_chunks] = static_cast<uint32_t>(slices.size());
   std::vector<unsigned char> staging(total, 0);
   if (segments_bytes) std::memcpy(staging.data(), dev.data(), segments_bytes);
   if (slices_bytes) std::memcpy(staging.data() + at_slices, slices.data(), slices_bytes);
   if (views_bytes) std::memcpy(staging.data() + at_views, views.data(), views_bytes);
   std::memcpy(staging.data() + at_row_base, column->row_base.data(), row_base_bytes);
   if (parts_bytes) std::memcpy(staging.data() + at_parts, parts.data(), parts_bytes);
+  std::memcpy(staging.data() + at_first_slice, first_slice.data(), 4 * (size_t{n_chunks} + 1));
   void* block = nullptr;
   size_t block_capacity = 0;
   if (pool_acquire(total, &block, &block_capacity) != HY_OK) return cleanup(HY_ERR_DEVICE);
@@ -608,6 +631,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   column->d_slice_views = reinterpret_cast<SliceView*>(base + at_views);
   column->d_row_base = reinterpret_cast<uint64_t*>(base + at_row_base);
   column->d_parts = reinterpret_cast<Part*>(base + at_parts);
+  column->d_first_slice = reinterpret_cast<uint32_t*>(base + at_first_slice);
   const hipError_t err = hipMemcpy(block, staging.data(), total, hipMemcpyHostToDevice);
   if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "descriptor upload failed: %s", hipGetErrorString(err)));
   *out = column;

@@ -1526,7 +1526,7 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
       g_trace_grid = grid;
     }
     hipEvent_t started = nullptr, stopped = nullptr;
-    profile_events(&started, &stopped);
+    profile_events(&started, &stopped, HY_KERNEL_SCAN);
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(WG_THREADS), SCAN_LDS_BYTES, stream, started, stopped, 0, a.segments, a.right, a.slices, a.jobs,
                           column->d_parts, a);
   }

@@ -37,10 +37,12 @@ def sparse_orderkeys(n):
 class TpchData:
     """Raw (unencoded) numpy columns of orders and lineitem at `scale_factor`."""
 
-    def __init__(self, scale_factor=10.0, seed=42, lineitem_rows=None):
+    def __init__(self, scale_factor=10.0, seed=42, lineitem_rows=None, keys_only=False):
+        # keys_only: o_orderkey and l_orderkey alone (the join's inputs; the same keys the full generator produces)
         # HY_TPCH_CACHE=<directory>: the profiling scripts run the same generator many times in one session
+        self.keys_only = keys_only
         cache = os.environ.get("HY_TPCH_CACHE")
-        path = os.path.join(cache, f"tpch_{scale_factor}_{seed}_{lineitem_rows}.npz") if cache else None
+        path = os.path.join(cache, f"tpch_{scale_factor}_{seed}_{lineitem_rows}{'_keys' if keys_only else ''}.npz") if cache else None
         if path and os.path.exists(path):
             with np.load(path) as arrays:
                 for name in arrays.files:
@@ -78,6 +80,9 @@ class TpchData:
         n = int(counts.sum())
         order_index = np.repeat(np.arange(n_orders, dtype=np.int32), counts)
         self.l_orderkey = self.o_orderkey[order_index]
+        self.n_orders, self.n_lineitems = n_orders, n
+        if self.keys_only:
+            return
         orderdate = self.o_orderdate[order_index]
         self.l_shipdate = (orderdate + rng.integers(1, 122, n, dtype=np.int32)).astype(np.int32)
         self.l_commitdate = (orderdate + rng.integers(30, 91, n, dtype=np.int32)).astype(np.int32)

@@ -200,6 +200,11 @@ hy_status hy_device_count(int32_t* count);
  * summed elapsed time and the number of timed launches since profiling was (re-)enabled. */
 hy_status hy_set_profiling(int32_t enabled);
 hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches);
+/* The same per kernel, without resetting: an operator chain (bench.py's TableScan + JoinHash step) reads the time of each of its
+ * timed kernels separately before hy_profile_read() clears the session. */
+enum { HY_KERNEL_OTHER = 0, HY_KERNEL_SCAN = 1, HY_KERNEL_JOIN_PROBE = 2, HY_KERNEL_JOIN_COUNT = 3, HY_KERNEL_JOIN_BUILD = 4, HY_KERNEL_AGGREGATE = 5,
+       HY_KERNEL_PROJECTION = 6, HY_KERNEL_KINDS = 8 };
+hy_status hy_profile_read_kernel(uint32_t kernel, float* total_milliseconds, uint32_t* launches);
 
 /* ---- residency cache: a column made device-visible once (encoded segments are immutable,
  *      abstract_encoded_segment.hpp:12-17) ------------------------------------------------------------------------ */

@@ -594,3 +594,94 @@ def test_hash_map_inputs_of_the_reference(device, np_type):
     cubes = build_column((np.arange(500, dtype=np.float64) ** 3).astype(np_type), None, 500, abi.ENC_UNENCODED)
     got = check(cubes, cubes, abi.JOIN_INNER, context="cubes")
     assert got.n_pairs == 500 and (got.left[:500, 1] == got.right[:500, 1]).all()
+
+
+def used_pkfk():
+    lib = abi.load_library()
+    lib.hy_debug_join_used_pkfk.restype = C.c_int
+    return int(lib.hy_debug_join_used_pkfk())
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_primary_key_foreign_key_probe(device, mode, monkeypatch):
+    """The kernels of csrc/join_pkfk.hpp (pk_count / pk_scan / pk_emit / pk_cuts: 8192-row tiles, one launch for scan and plan):
+    a primary-key build side and a probe column of NULL-free int32 value / FrameOfReference segments (1-, 2- and 4-byte offsets),
+    sorted and random, with keys outside the build range, ragged chunks and every radix setting -- pairs and 131 070-element cuts
+    equal to the oracle's bytes, and equal to what the general kernels produce (HY_JOIN_NO_PKFK)."""
+    rng = np.random.default_rng(300 + mode)
+    n_build = 30000
+    i = np.arange(1, n_build + 1, dtype=np.int64)
+    sparse = (((i >> 3) << 5) | (i & 7)).astype(np.int32)
+    dense_negative = np.arange(n_build, dtype=np.int32) - 11000
+    for name, keys, n_probe in (("sparse", sparse, 300_000), ("dense_negative", dense_negative, 70_001)):
+        base = rng.choice(keys, n_probe).astype(np.int32)
+        outside = rng.random(n_probe) < 0.04
+        base[outside] = rng.integers(int(keys.min()) - 300, int(keys.max()) + 300, int(outside.sum())).astype(np.int32)
+        narrow = (np.sort(rng.choice(keys[:200], n_probe))).astype(np.int32)          # FrameOfReference offsets of one byte
+        for pname, pvalues, probe_encoding, chunk in (("sorted", np.sort(base), abi.ENC_FRAME_OF_REFERENCE, 65535), ("random", base, abi.ENC_FRAME_OF_REFERENCE, 20000),
+                                                      ("values", base, abi.ENC_UNENCODED, 65535), ("narrow", narrow, abi.ENC_FRAME_OF_REFERENCE, 8192 * 3 + 5)):
+            build = build_column(keys, None, 4096, abi.ENC_UNENCODED)
+            probe = build_column(pvalues, None, chunk, probe_encoding)
+            for radix_bits in (None, 0, 1, 5, 8):
+                context = f"pk mode {mode} {name} probe {pname} radix {radix_bits}"
+                args = (probe, build) if mode in SEMI or mode == abi.JOIN_LEFT else (build, probe)
+                got = check(*args, mode, radix_bits, context)
+                assert used_pkfk() == 1, context
+                if radix_bits in (None, 5):
+                    monkeypatch.setenv("HY_JOIN_NO_PKFK", "1")
+                    general = check(*args, mode, radix_bits, context + " general kernels")
+                    monkeypatch.delenv("HY_JOIN_NO_PKFK")
+                    assert used_pkfk() == 0
+                    n = got.n_pairs
+                    assert general.n_pairs == n and general.left[:n].tobytes() == got.left[:n].tobytes()
+
+
+def test_primary_key_hint(device, monkeypatch):
+    """The first join over a resident primary-key column leaves its key range behind (hy_column::join_hint); later joins fill the rank
+    table in ONE pass sized by the hint, check every key against it and confirm it when the join has finished.  Same bytes either way;
+    a hint that does not hold (HY_JOIN_BREAK_HINT shrinks it) is dropped and the join runs again with the two-pass build."""
+    rng = np.random.default_rng(8)
+    keys = (np.arange(100_000, dtype=np.int32) * 2 + 40)
+    build_host = build_column(keys, None, 65535, abi.ENC_UNENCODED)
+    probe_host = build_column(np.sort(rng.integers(0, 200_200, 500_000).astype(np.int32)), None, 65535, abi.ENC_FRAME_OF_REFERENCE)
+    want = oracle_join(build_host, probe_host, abi.JOIN_INNER)
+    lib = abi.load_library()
+    lib.hy_debug_join_build_was_hinted.restype = C.c_int
+    for broken in (False, True):
+        build, probe = DeviceColumn(build_host), DeviceColumn(probe_host)
+        first = join_hash(build, probe, abi.JOIN_INNER)
+        assert lib.hy_debug_join_build_was_hinted() == 0
+        assert_join_equal(first, want, abi.JOIN_INNER, "first join")
+        if broken:
+            monkeypatch.setenv("HY_JOIN_BREAK_HINT", "1")
+        second = join_hash(build, probe, abi.JOIN_INNER)
+        assert lib.hy_debug_join_build_was_hinted() == (2 if broken else 1)     # 2: the hinted attempt was discarded
+        assert_join_equal(second, want, abi.JOIN_INNER, f"second join, broken hint {broken}")
+        if broken:
+            monkeypatch.delenv("HY_JOIN_BREAK_HINT")
+        third = join_hash(build, probe, abi.JOIN_SEMI if False else abi.JOIN_INNER)
+        assert lib.hy_debug_join_build_was_hinted() == (0 if broken else 1)     # a dropped hint stays dropped
+        assert_join_equal(third, want, abi.JOIN_INNER, "third join")
+        assert join_hash_count(build, probe, abi.JOIN_INNER) == want.n_pairs
+
+
+@pytest.mark.parametrize("mode", SEMI)
+def test_semi_join_over_a_sorted_build_side_with_duplicates(device, mode):
+    """Semi / Anti joins without secondary predicates only ask whether a key exists (the reference's ExistenceOnly hash table,
+    join_hash_steps.hpp:97-236): a sorted, dense build column WITH duplicate keys -- lineitem's order keys, the build side of the
+    reference's BM_HashSemiProbeRelationSmaller -- still gets a rank table, of which only the presence bits are read."""
+    rng = np.random.default_rng(61)
+    orders = (np.arange(1, 40_001, dtype=np.int32) * 3)
+    lineitem = np.repeat(orders[rng.random(40_000) < 0.8], 3)        # four orders in five have lineitems, three each
+    probe = build_column(orders, None, 65535, abi.ENC_UNENCODED)
+    build = build_column(lineitem, None, 65535, abi.ENC_FRAME_OF_REFERENCE)
+    for radix_bits in (None, 0, 4):
+        got = check(probe, build, mode, radix_bits, f"existence only, mode {mode} radix {radix_bits}")
+        assert used_rank_table() == 2 and used_pkfk() == 1
+        assert got.n_pairs == (int((np.isin(orders, lineitem)).sum()) if mode == abi.JOIN_SEMI else int((~np.isin(orders, lineitem)).sum()))
+    again = DeviceColumn(probe), DeviceColumn(build)
+    for _ in range(2):   # the second join over the resident build column is filled from the key hint (duplicates allowed for Semi / Anti only)
+        got = join_hash(again[0], again[1], mode)
+        assert_join_equal(got, oracle_join(probe, build, mode), mode, "resident columns")
+    inner = join_hash(again[1], again[0], abi.JOIN_INNER)             # ... and an Inner join of the same columns must not use that table
+    assert_join_equal(inner, oracle_join(build, probe, abi.JOIN_INNER), abi.JOIN_INNER, "inner after semi")

@@ -18,9 +18,9 @@ __global__ __launch_bounds__(512) void stream(u32x4* out) {
 
 // run_vectors: 16-byte vectors per run (16 = 256 bytes); a tile writes 2 x 128 runs = 2 x 128 x run_vectors vectors
 template <int STORE>   // 0: nontemporal, 1: plain (write-back L2), 2: plain for the vectors of a run's first and last line, nontemporal inside
-__global__ __launch_bounds__(512) void runs(u32x4* left, u32x4* right, unsigned n_tiles, unsigned run_vectors) {
+__global__ __launch_bounds__(512) void runs(u32x4* left, u32x4* right, unsigned n_tiles, unsigned run_vectors, unsigned partitions = 128) {
   const unsigned tile = (blockIdx.x % 8) * (n_tiles / 8) + blockIdx.x / 8;          // XCD x works on the x-th eighth of the tiles
-  const unsigned per_tile = 128 * run_vectors;
+  const unsigned per_tile = partitions * run_vectors;
   for (unsigned i = threadIdx.x; i < per_tile; i += 512) {
     const unsigned partition = i / run_vectors, within = i % run_vectors;
     const size_t position = (static_cast<size_t>(partition) * n_tiles + tile) * run_vectors + within;
@@ -66,6 +66,17 @@ int main() {
     timed(name, [&](u32x4* b) { hipLaunchKernelGGL(runs<1>, dim3(n_tiles), dim3(512), 0, 0, b + 3, b + bytes / 32 + 3, n_tiles - 8, run_vectors); });
     snprintf(name, sizeof(name), "  ... off the grid, plain edge lines");
     timed(name, [&](u32x4* b) { hipLaunchKernelGGL(runs<2>, dim3(n_tiles), dim3(512), 0, 0, b + 3, b + bytes / 32 + 3, n_tiles - 8, run_vectors); });
+  }
+  // the shape of pk_emit at config 3: 32 populated partitions, 8192-row tiles -> 2 KB runs per array (and 4096 / 16384-row tiles)
+  for (unsigned run_bytes : {1024u, 2048u, 4096u}) {
+    const unsigned run_vectors = run_bytes / 16, partitions = 32;
+    const unsigned n_tiles = static_cast<unsigned>(bytes / 2 / (partitions * run_bytes)) / 8 * 8;
+    char name[96];
+    snprintf(name, sizeof(name), "32 partitions, runs of %u bytes, %u tiles", run_bytes, n_tiles);
+    timed(name, [&](u32x4* b) { hipLaunchKernelGGL(runs<0>, dim3(n_tiles), dim3(512), 0, 0, b, b + bytes / 32, n_tiles, run_vectors, partitions); });
+    timed("  ... 48 bytes off the line grid", [&](u32x4* b) { hipLaunchKernelGGL(runs<0>, dim3(n_tiles), dim3(512), 0, 0, b + 3, b + bytes / 32 + 3, n_tiles - 8, run_vectors, partitions); });
+    timed("  ... off the grid, plain stores", [&](u32x4* b) { hipLaunchKernelGGL(runs<1>, dim3(n_tiles), dim3(512), 0, 0, b + 3, b + bytes / 32 + 3, n_tiles - 8, run_vectors, partitions); });
+    timed("  ... off the grid, plain edge lines", [&](u32x4* b) { hipLaunchKernelGGL(runs<2>, dim3(n_tiles), dim3(512), 0, 0, b + 3, b + bytes / 32 + 3, n_tiles - 8, run_vectors, partitions); });
   }
   return 0;
 }
