@@ -39,6 +39,7 @@
 #include <cmath>
 #include <chrono>
 #include <cstring>
+#include <type_traits>
 
 namespace hy {
 
@@ -179,6 +180,7 @@ struct MaterializeArgs {
   uint32_t* any_null;             // set to 1 if a NULL was materialised (AntiNullAsTrue early-out)
   const uint64_t* row_base;       // dense: [n_chunks + 1] first row of every chunk
   uint32_t hashed_type;           // 0: integer keys | HY_TYPE_FLOAT | HY_TYPE_DOUBLE (see join_hash)
+  const SliceView* views;         // the same slices as one record each (rank_table_fill_checked)
 };
 
 template <int MODE, bool KEY32, bool ID32>
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(256) void dense_key_stats(MaterializeArgs a, uint64
 // run's first and last word can hold keys of a neighbouring slice: those two go to the (zeroed) table with an atomic OR.
 // A slice whose keys span more words than the LDS holds (a sparse stretch) sets its bits with one global atomic per key.
 constexpr uint32_t FILL_WORDS = 4096;
+constexpr uint32_t CHECKED_FILL_WORDS = 2048;   // rank_table_fill_checked: 16 KB of LDS, eight workgroups per CU (sparser slices set their bits in the table itself)
 typedef uint32_t u32x2_entry_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void rank_table_fill_dense(MaterializeArgs a, uint64_t key_min, u32x2_entry_t* entries) {
   __shared__ uint32_t s_bits[FILL_WORDS], s_base[FILL_WORDS];
@@ -497,6 +500,14 @@ __global__ __launch_bounds__(256) void rank_table_fill_dense(MaterializeArgs a, 
     } else {
       entries[first_word + i] = u32x2_entry_t{bits, base ? base - 1u : 0u};
     }
+  }
+}
+
+// Two regions zeroed by one launch with 16-byte stores (sizes in 16-byte vectors; pool blocks: aligned, and as long as their rounded
+// sizes): the rank table and the Bloom filter of a hinted build -- two hipMemsetAsync calls were two launches and ~20 us of gaps.
+__global__ __launch_bounds__(256) void zero_vectors(u32x4_t* first, size_t first_vectors, u32x4_t* second, size_t second_vectors) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < first_vectors + second_vectors; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    if (i < first_vectors) first[i] = u32x4_t{0, 0, 0, 0}; else second[i - first_vectors] = u32x4_t{0, 0, 0, 0};
   }
 }
 
@@ -2412,152 +2423,202 @@ static hy_status join_mailbox(JoinMailbox** host, JoinMailbox** device) {
 // verdict with the hint when the join's last kernel has finished: no second read of the build keys, no host round trip between
 // the build and the probe.  A verdict that does not confirm the hint discards the join's output and runs the two-pass build.
 // partials: [n_slices][4] min ^ sign | max ^ sign | flags (1 unsorted, 2 equal neighbours, 4 outside the hint) | unused.
-__global__ __launch_bounds__(256) void rank_table_fill_checked(MaterializeArgs a, uint64_t key_min, uint64_t hint_range, u32x2_entry_t* entries, uint64_t* partials, uint32_t* ticket,
-                                                               BuildVerdict* verdict) {
-  __shared__ uint32_t s_bits[FILL_WORDS], s_base[FILL_WORDS];
+// The keys of GROUP consecutive rows of a slice a SliceView describes (int32 values / FrameOfReference offsets of WIDTH bytes), one
+// 16-byte load where the width allows.
+template <uint32_t WIDTH> struct FillGroup { static constexpr uint32_t ROWS = WIDTH == 4 ? 4 : 8; };
+template <uint32_t WIDTH>
+__device__ __forceinline__ void load_group_words(const SliceView& view, uint32_t first, uint32_t (&word)[FillGroup<WIDTH>::ROWS]) {
+  const char* base = static_cast<const char*>(view.data);
+  if constexpr (WIDTH == 4) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + size_t{first} * 4);
+    word[0] = v.x; word[1] = v.y; word[2] = v.z; word[3] = v.w;
+  } else if constexpr (WIDTH == 2) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + size_t{first} * 2);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) word[j] = (w[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+  } else {
+    const u32x2_t v = *reinterpret_cast<const u32x2_t*>(base + first);
+    const uint32_t w[2] = {v.x, v.y};
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) word[j] = (w[j / 4] >> (8 * (j & 3))) & 0xFFu;
+  }
+}
+
+// Key of row `row` of the chunk a view describes (one row: the key in front of a wave's first group, or of the slice).
+__device__ __forceinline__ int32_t view_key(const SliceView& view, uint32_t row) {
+  if (view.kind == VIEW_INT32) return static_cast<const int32_t*>(view.data)[row];
+  const uint32_t stored = view.kind == VIEW_FOR8 ? static_cast<const uint8_t*>(view.data)[row] : view.kind == VIEW_FOR16 ? static_cast<const uint16_t*>(view.data)[row] : static_cast<const uint32_t*>(view.data)[row];
+  return static_cast<int32_t>(stored + static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[row / HY_FOR_BLOCK_SIZE]));
+}
+
+// One slice of a column of int32 keys (every segment one a SliceView describes, key_min an int32 value): 32-bit arithmetic
+// throughout -- the wrapped difference of two int32 values is their distance, or larger than any range.  The workgroup learns the
+// extent of its keys from the keys themselves (a wave reduction each, no dependent loads in front of the slice's eight), sets up its
+// run of table words in LDS, and the bits of a group's keys that share a word leave with ONE LDS atomic (sorted keys: four lineitems of
+// an order, eight dbgen order keys per word).
+template <uint32_t WIDTH>
+__device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, const SliceView& view, uint32_t origin, uint32_t range, u32x2_entry_t* entries, uint32_t* s_bits, uint32_t* s_base,
+                                                   int32_t* s_extent, uint32_t tid, int32_t* low_out, int32_t* high_out, uint32_t* flags_out) {
+  constexpr uint32_t GROUP = FillGroup<WIDTH>::ROWS, GROUPS = SLICE_ROWS / 256 / GROUP;
+  const uint32_t row_count = view.row_count, lane = tid & 63, wave = tid >> 6;
+  uint32_t word[GROUPS][GROUP];
+  int32_t front[GROUPS];
+#pragma unroll
+  for (uint32_t i = 0; i < GROUPS; ++i) {
+    const uint32_t first = (i * 256 + tid) * GROUP;
+    load_group_words<WIDTH>(view, view.row_begin + (first < row_count ? first : 0), word[i]);
+    front[i] = 0;
+    if (lane == 0 && first > 0 && first < row_count) front[i] = view_key(view, view.row_begin + first - 1);   // (the other lanes: from their neighbour)
+  }
+  // the key in front of the slice: the last row of the nearest earlier slice with rows (one thread)
+  int32_t key_before = 0;
+  bool has_before = false;
+  if (tid == 0) {
+    for (uint32_t before = blockIdx.x; before-- > 0;) {
+      const SliceView earlier = a.views[before];
+      if (earlier.row_count == 0) continue;
+      key_before = view_key(earlier, earlier.row_begin + earlier.row_count - 1);
+      has_before = true;
+      break;
+    }
+  }
+  int32_t low = 0x7FFFFFFF, high = static_cast<int32_t>(0x80000000u);
+  int32_t key[GROUPS][GROUP];
+#pragma unroll
+  for (uint32_t i = 0; i < GROUPS; ++i) {
+    const uint32_t first = (i * 256 + tid) * GROUP;
+    const uint32_t bias = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + (first < row_count ? first : 0)) / HY_FOR_BLOCK_SIZE]);   // (a group lies in one 2048-row block)
+#pragma unroll
+    for (uint32_t e = 0; e < GROUP; ++e) {
+      key[i][e] = static_cast<int32_t>(word[i][e] + bias);
+      if (first + e < row_count) { low = key[i][e] < low ? key[i][e] : low; high = key[i][e] > high ? key[i][e] : high; }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const int32_t other_low = __shfl_xor(low, d, 64), other_high = __shfl_xor(high, d, 64);
+    low = other_low < low ? other_low : low;
+    high = other_high > high ? other_high : high;
+  }
+  if (lane == 0) { s_extent[wave] = low; s_extent[4 + wave] = high; }
+  __syncthreads();
+  low = min(min(s_extent[0], s_extent[1]), min(s_extent[2], s_extent[3]));
+  high = max(max(s_extent[4], s_extent[5]), max(s_extent[6], s_extent[7]));
+  *low_out = low;
+  *high_out = high;
+  // the slice's run of table words, staged in LDS if it is short enough and inside the hinted range (keys outside are flagged and skipped)
+  const uint32_t low_rel = static_cast<uint32_t>(low) - origin, high_rel = static_cast<uint32_t>(high) - origin;
+  const bool staged = low_rel <= range && high_rel <= range && high_rel >= low_rel && (high_rel >> 5) - (low_rel >> 5) < CHECKED_FILL_WORDS;
+  const uint32_t first_word = low_rel >> 5, span = staged ? (high_rel >> 5) - first_word + 1 : 0;
+  for (uint32_t i = tid; i < span; i += 256) { s_bits[i] = 0; s_base[i] = 0; }
+  __syncthreads();
+  const uint32_t first_row = static_cast<uint32_t>(a.row_base[view.chunk]) + view.row_begin;   // rank of the slice's first key
+  uint32_t flags = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < GROUPS; ++i) {
+    const uint32_t first = (i * 256 + tid) * GROUP;
+    const int32_t neighbour = __shfl_up(key[i][GROUP - 1], 1, 64);
+    if (lane != 0) front[i] = neighbour;
+    uint32_t run_word = 0xFFFFFFFFu, run_bits = 0, run_row = 0;
+    bool run_leader = false;
+    auto flush = [&]() {
+      if (run_word == 0xFFFFFFFFu) return;
+      if (run_word - first_word < span) {
+        atomicOr(&s_bits[run_word - first_word], run_bits);
+        if (run_leader) s_base[run_word - first_word] = first_row + run_row + 1u;   // (+ 1: 0 = the word's first key is not in this slice)
+      } else {
+        atomicOr(reinterpret_cast<uint32_t*>(entries + run_word), run_bits);
+        if (run_leader) reinterpret_cast<uint32_t*>(entries + run_word)[1] = first_row + run_row;
+      }
+    };
+#pragma unroll
+    for (uint32_t e = 0; e < GROUP; ++e) {
+      if (first + e >= row_count) continue;
+      const bool at_start = first + e == 0;
+      const int32_t k = key[i][e], previous = at_start ? key_before : (e == 0 ? front[i] : key[i][e - 1]);
+      const bool has_previous = at_start ? has_before : true;
+      if (has_previous) {
+        if (previous > k) flags |= 1u;
+        if (previous == k) flags |= 2u;
+      }
+      if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(k) & (BLOOM_BITS - 1)] = 1;
+      const uint32_t rel = static_cast<uint32_t>(k) - origin;
+      if (rel > range) { flags |= 4u; continue; }
+      const uint32_t table_word = rel >> 5, bit = 1u << (rel & 31);
+      if (table_word == run_word) { run_bits |= bit; continue; }
+      flush();
+      run_word = table_word;
+      run_bits = bit;
+      run_row = first + e;
+      run_leader = !has_previous || ((static_cast<uint32_t>(previous) - origin) >> 5) != table_word;   // no earlier row shares the word: its row number is the entry's base
+    }
+    flush();
+  }
+  *flags_out = flags;
+  __syncthreads();
+  for (uint32_t i = tid; i < span; i += 256) {
+    const uint32_t bits = s_bits[i], base = s_base[i];
+    if (i == 0 || i + 1 == span) {   // may be shared with a neighbouring slice: add the bits; the base comes from the slice with the word's first key
+      if (bits) atomicOr(reinterpret_cast<uint32_t*>(entries + first_word + i), bits);
+      if (base) reinterpret_cast<uint32_t*>(entries + first_word + i)[1] = base - 1u;
+    } else {
+      entries[first_word + i] = u32x2_entry_t{bits, base ? base - 1u : 0u};
+    }
+  }
+}
+
+// The same table as rank_table_fill_dense AND the statistics of dense_key_stats in ONE pass over the build column, for a column
+// whose extent is already known: the first join over a resident column leaves its key range behind as a hint
+// (hy_column::join_hint -- encoded segments are immutable, abstract_encoded_segment.hpp:12-17), later joins size and fill the table
+// from the hint while they check every key against it (order, duplicates, smallest / largest key, keys outside the hinted range),
+// and the host compares the verdict with the hint when the join's last kernel has finished: no second read of the build keys, no
+// host round trip between the build and the probe.  A verdict that does not confirm the hint discards the join's output and runs the
+// two-pass build.  Only for columns of int32 keys whose segments SliceViews describe (the host checks).
+// partials: [n_slices][4] min ^ sign | max ^ sign | flags (1 unsorted, 2 equal neighbours, 4 outside the hint) | unused.
+__global__ __launch_bounds__(256, 5) void rank_table_fill_checked(MaterializeArgs a, uint64_t key_min, uint64_t hint_range, u32x2_entry_t* entries, uint64_t* partials, uint32_t* ticket,
+                                                                  BuildVerdict* verdict) {
+  __shared__ uint32_t s_bits[CHECKED_FILL_WORDS], s_base[CHECKED_FILL_WORDS];
+  __shared__ int32_t s_extent[8];
   __shared__ uint64_t s_min[4], s_max[4];
   __shared__ uint32_t s_flags, s_last;
   const uint32_t tid = threadIdx.x;
-  const Slice slice = a.slices[blockIdx.x];
   constexpr uint64_t SIGN = 1ull << 63;
-  uint64_t lowest = ~0ull, highest = 0;
+  const SliceView view = a.views[blockIdx.x];
+  int32_t low32 = 0x7FFFFFFF, high32 = static_cast<int32_t>(0x80000000u);
   uint32_t flags = 0;
   if (tid == 0) s_flags = 0;
-  if (slice.row_count != 0) {
-    const DevSegment s = a.segments[slice.chunk];
-    const uint64_t first_row = a.row_base[slice.chunk] + slice.row_begin;   // rank of the slice's first key
-    const uint64_t first_rel = static_cast<uint64_t>(dense_key(s, slice.row_begin)) - key_min, last_rel = static_cast<uint64_t>(dense_key(s, slice.row_begin + slice.row_count - 1)) - key_min;
-    const uint64_t first_word = first_rel >> 5;
-    // (an unsorted slice or one outside the hint: whatever it writes stays inside the table, and the verdict discards the join)
-    const bool staged = first_rel <= hint_range && last_rel <= hint_range && last_rel >= first_rel && (last_rel >> 5) - first_word < FILL_WORDS;
-    const uint64_t span = staged ? (last_rel >> 5) - first_word + 1 : 0;
-    // the key in front of the slice (the last row of the nearest earlier slice with rows)
-    int64_t key_before = 0;
-    bool has_before = false;
-    if (tid == 0) {
-      for (uint32_t before = blockIdx.x; before-- > 0;) {
-        const Slice earlier = a.slices[before];
-        if (earlier.row_count == 0) continue;
-        key_before = dense_key(a.segments[earlier.chunk], earlier.row_begin + earlier.row_count - 1);
-        has_before = true;
-        break;
-      }
-    }
-    if (staged) {
-      for (uint32_t i = tid; i < span; i += 256) { s_bits[i] = 0; s_base[i] = 0; }
-    }
-    __syncthreads();
-    auto place = [&](int64_t key, int64_t previous, bool has_previous, uint32_t r) {   // row r of the slice
-      const uint64_t wide = static_cast<uint64_t>(key);
-      lowest = (wide ^ SIGN) < lowest ? (wide ^ SIGN) : lowest;
-      highest = (wide ^ SIGN) > highest ? (wide ^ SIGN) : highest;
-      if (has_previous) {
-        if (previous > key) flags |= 1u;
-        if (previous == key) flags |= 2u;
-      }
-      const uint64_t rel = wide - key_min;
-      if (rel > hint_range) { flags |= 4u; return; }
-      const uint64_t word = rel >> 5;
-      const uint32_t bit = 1u << (rel & 31);
-      const bool leader = !has_previous || ((static_cast<uint64_t>(previous) - key_min) >> 5) != word;   // no earlier row shares the word: its row number is the entry's base
-      if (staged && word - first_word < span) {
-        atomicOr(&s_bits[word - first_word], bit);
-        if (leader) s_base[word - first_word] = static_cast<uint32_t>(first_row + r) + 1u;   // (+ 1: 0 = the word's first key is not in this slice)
-      } else {
-        atomicOr(reinterpret_cast<uint32_t*>(entries + word), bit);
-        if (leader) reinterpret_cast<uint32_t*>(entries + word)[1] = static_cast<uint32_t>(first_row + r);
-      }
-      if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(key) & (BLOOM_BITS - 1)] = 1;
-    };
-    if (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !(s.flags & SEG_UNALIGNED)) {
-      // int32 values: four consecutive rows per lane and load, all eight loads in flight, plus the value in front of each group
-      const int32_t* values = static_cast<const int32_t*>(s.data) + slice.row_begin;
-      constexpr uint32_t GROUPS = SLICE_ROWS / 1024;
-      u32x4_t group[GROUPS];
-      int32_t front[GROUPS];
-#pragma unroll
-      for (uint32_t i = 0; i < GROUPS; ++i) {
-        const uint32_t first = i * 1024 + tid * 4;
-        group[i] = *reinterpret_cast<const u32x4_t*>(values + (first < slice.row_count ? first : 0));
-        front[i] = values[first > 0 && first < slice.row_count ? first - 1 : 0];
-      }
-#pragma unroll
-      for (uint32_t i = 0; i < GROUPS; ++i) {
-        const uint32_t first = i * 1024 + tid * 4;
-        const int32_t k[5] = {front[i], static_cast<int32_t>(group[i].x), static_cast<int32_t>(group[i].y), static_cast<int32_t>(group[i].z), static_cast<int32_t>(group[i].w)};
-#pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-          if (first + e >= slice.row_count) continue;
-          const bool at_start = first + e == 0;
-          place(k[e + 1], at_start ? key_before : static_cast<int64_t>(k[e]), at_start ? has_before : true, first + e);
-        }
-      }
-    } else {
-      constexpr uint32_t BATCH = 8;
-#pragma unroll 1
-      for (uint32_t block = 0; block < SLICE_ROWS / 256 / BATCH; ++block) {
-        if (block * BATCH * 256 >= slice.row_count) break;
-        int64_t key[BATCH], before[BATCH];
-#pragma unroll
-        for (uint32_t i = 0; i < BATCH; ++i) {
-          const uint32_t r = (block * BATCH + i) * 256 + tid;
-          const uint32_t row = slice.row_begin + (r < slice.row_count ? r : 0);
-          key[i] = dense_key(s, row);
-          before[i] = dense_key(s, row > slice.row_begin ? row - 1 : row);
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < BATCH; ++i) {
-          const uint32_t r = (block * BATCH + i) * 256 + tid;
-          if (r >= slice.row_count) continue;
-          place(key[i], r == 0 ? key_before : before[i], r == 0 ? has_before : true, r);
-        }
-      }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < span; i += 256) {
-      const uint32_t bits = s_bits[i], base = s_base[i];
-      if (i == 0 || i + 1 == span) {   // may be shared with a neighbouring slice: add the bits; the base comes from the slice with the word's first key
-        if (bits) atomicOr(reinterpret_cast<uint32_t*>(entries + first_word + i), bits);
-        if (base) reinterpret_cast<uint32_t*>(entries + first_word + i)[1] = base - 1u;
-      } else {
-        entries[first_word + i] = u32x2_entry_t{bits, base ? base - 1u : 0u};
-      }
-    }
-  } else {
-    __syncthreads();
-  }
-  // the slice's record
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const uint64_t other_low = __shfl_xor(lowest, d, 64), other_high = __shfl_xor(highest, d, 64);
-    lowest = other_low < lowest ? other_low : lowest;
-    highest = other_high > highest ? other_high : highest;
+  if (view.row_count != 0) {
+    const uint32_t origin = static_cast<uint32_t>(key_min), range = static_cast<uint32_t>(hint_range);
+    if (view.kind == VIEW_FOR16) fill_checked_slice<2>(a, view, origin, range, entries, s_bits, s_base, s_extent, tid, &low32, &high32, &flags);
+    else if (view.kind == VIEW_FOR8) fill_checked_slice<1>(a, view, origin, range, entries, s_bits, s_base, s_extent, tid, &low32, &high32, &flags);
+    else fill_checked_slice<4>(a, view, origin, range, entries, s_bits, s_base, s_extent, tid, &low32, &high32, &flags);
   }
   if (flags) atomicOr(&s_flags, flags);
-  if ((tid & 63) == 0) { s_min[tid >> 6] = lowest; s_max[tid >> 6] = highest; }
   __syncthreads();
   if (tid == 0) {
-    uint64_t low = ~0ull, high = 0;
-    for (uint32_t w = 0; w < 4; ++w) { low = s_min[w] < low ? s_min[w] : low; high = s_max[w] > high ? s_max[w] : high; }
+    // The record leaves with agent-scope atomic stores (write-through, sc1) and is read by the last workgroup with agent-scope
+    // atomic loads: no release fence here -- a fence writes back the XCD's whole L2, which holds megabytes of freshly written table
+    // words (measured: 103 us for this kernel with a fence per workgroup, half of that without).
+    const uint64_t low = view.row_count ? static_cast<uint64_t>(static_cast<int64_t>(low32)) ^ SIGN : ~0ull, high = view.row_count ? static_cast<uint64_t>(static_cast<int64_t>(high32)) ^ SIGN : 0;
     uint64_t* record = partials + 4 * size_t{blockIdx.x};
-    record[0] = low;
-    record[1] = high;
-    record[2] = s_flags;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(record + 0, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(record + 1, high, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(record + 2, static_cast<uint64_t>(s_flags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = arrived + 1 == gridDim.x ? 1u : 0u;
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   if (!s_last) return;
   // the workgroup that arrives last sees every slice's record: the verdict
   uint64_t low = ~0ull, high = 0, bits = 0;
   for (uint32_t i = tid; i < a.n_slices; i += 256) {
-    const uint64_t* record = partials + 4 * size_t{i};
-    low = record[0] < low ? record[0] : low;
-    high = record[1] > high ? record[1] : high;
-    bits |= record[2];
+    uint64_t* record = partials + 4 * size_t{i};
+    const uint64_t record_low = __hip_atomic_load(record + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), record_high = __hip_atomic_load(record + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    low = record_low < low ? record_low : low;
+    high = record_high > high ? record_high : high;
+    bits |= __hip_atomic_load(record + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
@@ -2577,7 +2638,6 @@ __global__ __launch_bounds__(256) void rank_table_fill_checked(MaterializeArgs a
   verdict->equal_neighbours = s_flags & 2u ? 1 : 0;
   verdict->outside_hint = s_flags & 4u ? 1 : 0;
   verdict->done = 1;
-  *ticket = 0;
   __threadfence_system();
 }
 
@@ -2719,12 +2779,32 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   HY_TRY(counts.alloc(4 * size_t{n_slices + 1}));
   HY_TRY(offsets.alloc(8 * size_t{n_slices + 2}));
   HY_TRY(b.flags.alloc(64));
+  // (decided here, before anything is launched: a hinted build zeroes its table and the Bloom filter with one launch)
+  bool dense = hashed_type == 0;   // a column whose segments cannot hold NULLs; float / double keys go through the generic decoder
+  for (uint32_t c = 0; c < build->n_chunks && dense; ++c) {
+    const hy_segment& seg = build->host_segments[c];
+    dense = (seg.encoding == HY_ENC_UNENCODED || seg.encoding == HY_ENC_FRAME_OF_REFERENCE) && seg.nulls == nullptr;
+  }
+  bool uniform_chunks = dense && build->n_chunks > 0;
+  for (uint32_t c = 1; c < build->n_chunks && uniform_chunks; ++c) {
+    const uint32_t size = build->host_segments[c].size, first_size = build->host_segments[0].size;
+    uniform_chunks = first_size > 0 && (c + 1 == build->n_chunks ? size <= first_size : size == first_size);
+  }
+  const bool identity_candidate = dense && build->rows && uniform_chunks && build->host_segments[0].size > 0 && allow_rank_table && !getenv("HY_JOIN_NO_RANK_TABLE") &&
+                                  !getenv("HY_JOIN_NO_IDENTITY");
+  bool hinted = identity_candidate && build->join_hint.state.load(std::memory_order_acquire) == 1 &&
+                (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) && !getenv("HY_JOIN_NO_HINT");
+  for (uint32_t c = 0; c < build->n_chunks && hinted; ++c) {   // rank_table_fill_checked reads int32 keys through SliceViews, 16 bytes per load
+    const hy_segment& seg = build->host_segments[c];
+    hinted = reinterpret_cast<uintptr_t>(seg.data) % 16 == 0 && ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
+  }
   if (want_bloom) {
     HY_TRY(b.bloom.alloc(BLOOM_BITS));
-    HY_HIP(hipMemsetAsync(b.bloom.ptr, 0, BLOOM_BITS, stream));
+    if (!hinted) HY_HIP(hipMemsetAsync(b.bloom.ptr, 0, BLOOM_BITS, stream));
   }
   MaterializeArgs m{};
   m.segments = build->d_segments;
+  m.views = build->d_slice_views;
   m.slices = build->d_slices;
   m.n_slices = n_slices;
   m.keep_nulls = keep_nulls;
@@ -2736,11 +2816,6 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   uint64_t total = 0;
   // A column whose segments cannot hold NULLs (value / FrameOfReference segments without a null vector) materialises
   // every row: slice offsets are row numbers, no counting pass and no host round trip.
-  bool dense = hashed_type == 0;   // (float / double keys go through the generic decoder)
-  for (uint32_t c = 0; c < build->n_chunks && dense; ++c) {
-    const hy_segment& seg = build->host_segments[c];
-    dense = (seg.encoding == HY_ENC_UNENCODED || seg.encoding == HY_ENC_FRAME_OF_REFERENCE) && seg.nulls == nullptr;
-  }
   if (n_slices && dense) {
     m.row_base = build->d_row_base;
     total = build->rows;
@@ -2753,12 +2828,51 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   b.n = total;
   // A dense column that may be a primary key: look at it in place first (statistics), and if it is sorted, duplicate-free
   // and not too sparse fill the rank table from it -- no key array, no RowID array (a key's rank is its row number).
-  bool uniform_chunks = dense && build->n_chunks > 0;
-  for (uint32_t c = 1; c < build->n_chunks && uniform_chunks; ++c) {
-    const uint32_t size = build->host_segments[c].size, first_size = build->host_segments[0].size;
-    uniform_chunks = first_size > 0 && (c + 1 == build->n_chunks ? size <= first_size : size == first_size);
-  }
-  if (dense && total && uniform_chunks && build->host_segments[0].size > 0 && allow_rank_table && !getenv("HY_JOIN_NO_RANK_TABLE") && !getenv("HY_JOIN_NO_IDENTITY")) {
+  if (identity_candidate && total) {
+    auto identity_table = [&](u32x2_t* entries, uint64_t key_min, uint64_t key_max) {
+      b.rank.entries = entries;
+      b.rank.key_min = key_min;
+      b.rank.range = key_max - key_min;
+      b.rank.identity_rows = build->host_segments[0].size;
+      b.rank.identity_inverse = 1.0 / static_cast<double>(b.rank.identity_rows);
+      Directory& d = b.directory;   // nothing but the extent: the probe needs neither keys nor RowIDs
+      d = Directory{};
+      d.n = total;
+      d.key_min = key_min;
+      d.key_max = key_max;
+      d.n_buckets = 1;
+    };
+    if (hinted) {
+      // an earlier join over this column found a primary key in [key_min, key_max]: one pass fills the table and checks every key
+      {
+        JoinMailbox* unused_host = nullptr;
+        JoinMailbox* unused_device = nullptr;
+        HY_TRY(join_mailbox(&unused_host, &unused_device));   // (the verdict lives behind this thread's mailbox: make sure it exists)
+      }
+      const uint64_t key_min = build->join_hint.key_min.load(std::memory_order_relaxed);
+      uint64_t key_max = build->join_hint.key_max.load(std::memory_order_relaxed);
+      if (getenv("HY_JOIN_BREAK_HINT") && key_max - key_min > 64) key_max -= 64;   // tests: a hint that does not hold
+      const uint64_t words = ((key_max - key_min) >> 5) + 1;
+      HY_TRY(b.rank_entries.alloc(8 * (words + 1) + 16));
+      HY_TRY(b.partials.alloc(32 * size_t{n_slices}));
+      u32x2_t* entries = b.rank_entries.as<u32x2_t>();
+      {   // the table | the arrival counter, and the Bloom filter
+        const size_t table_vectors = (8 * (words + 1) + 16 + 15) / 16, bloom_vectors = want_bloom ? BLOOM_BITS / 16 : 0;
+        hipLaunchKernelGGL(zero_vectors, dim3(static_cast<uint32_t>(std::min<size_t>(2048, (table_vectors + bloom_vectors + 255) / 256))), dim3(256), 0, stream,
+                           reinterpret_cast<u32x4_t*>(entries), table_vectors, b.bloom.as<u32x4_t>(), bloom_vectors);
+      }
+      build_verdict_host()->done = 0;
+      hipEvent_t fill_started = nullptr, fill_stopped = nullptr;
+      profile_events(&fill_started, &fill_stopped, HY_KERNEL_JOIN_BUILD);
+      hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, key_min, key_max - key_min, entries,
+                            b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 1), build_verdict_device());
+      identity_table(entries, key_min, key_max);
+      b.hinted = true;
+      b.hint_allows_duplicates = existence_only;
+      b.hint_min = key_min;
+      b.hint_max = key_max;
+      return HY_OK;
+    }
     uint32_t first_slice = 0, last_slice = 0;   // slices with rows (the host knows the chunk sizes: slices are per chunk, in order)
     {
       std::vector<uint32_t> rows_of_slice;
@@ -2774,41 +2888,6 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     JoinMailbox* mailbox = nullptr;
     JoinMailbox* mailbox_dev = nullptr;
     HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
-    auto identity_table = [&](u32x2_t* entries, uint64_t key_min, uint64_t key_max) {
-      b.rank.entries = entries;
-      b.rank.key_min = key_min;
-      b.rank.range = key_max - key_min;
-      b.rank.identity_rows = build->host_segments[0].size;
-      b.rank.identity_inverse = 1.0 / static_cast<double>(b.rank.identity_rows);
-      Directory& d = b.directory;   // nothing but the extent: the probe needs neither keys nor RowIDs
-      d = Directory{};
-      d.n = total;
-      d.key_min = key_min;
-      d.key_max = key_max;
-      d.n_buckets = 1;
-    };
-    if (build->join_hint.state.load(std::memory_order_acquire) == 1 && (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) && !getenv("HY_JOIN_NO_HINT")) {
-      // an earlier join over this column found a primary key in [key_min, key_max]: one pass fills the table and checks every key
-      const uint64_t key_min = build->join_hint.key_min.load(std::memory_order_relaxed);
-      uint64_t key_max = build->join_hint.key_max.load(std::memory_order_relaxed);
-      if (getenv("HY_JOIN_BREAK_HINT") && key_max - key_min > 64) key_max -= 64;   // tests: a hint that does not hold
-      const uint64_t words = ((key_max - key_min) >> 5) + 1;
-      HY_TRY(b.rank_entries.alloc(8 * (words + 1) + 16));
-      HY_TRY(b.partials.alloc(32 * size_t{n_slices}));
-      u32x2_t* entries = b.rank_entries.as<u32x2_t>();
-      HY_HIP(hipMemsetAsync(entries, 0, 8 * (words + 1) + 16, stream));   // the table | the arrival counter
-      build_verdict_host()->done = 0;
-      hipEvent_t fill_started = nullptr, fill_stopped = nullptr;
-      profile_events(&fill_started, &fill_stopped, HY_KERNEL_JOIN_BUILD);
-      hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, key_min, key_max - key_min, entries,
-                            b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 1), build_verdict_device());
-      identity_table(entries, key_min, key_max);
-      b.hinted = true;
-      b.hint_allows_duplicates = existence_only;
-      b.hint_min = key_min;
-      b.hint_max = key_max;
-      return HY_OK;
-    }
     DeviceBuffer partials;
     HY_TRY(partials.alloc(32 * size_t{n_slices}));
     hipLaunchKernelGGL(dense_key_stats, dim3(n_slices), dim3(256), 0, stream, m, partials.as<uint64_t>());
@@ -3191,7 +3270,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
                        static_cast<int64_t>(b.rank.key_min) >= INT32_MIN && static_cast<int64_t>(b.rank.key_min + b.rank.range) <= INT32_MAX &&
                        (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
   if (pk_path) {
-    const uint32_t n_tiles = probe->n_slices, partitions = 1u << radix_bits;
+    const uint32_t n_tiles = probe->n_slices * PK_TILES_PER_SLICE, partitions = 1u << radix_bits;
     const uint32_t stride = (n_tiles + 1 + 3) & ~3u;
     const uint32_t n_groups = radix_bits ? partitions : probe->n_chunks;
     const uint32_t max_slices = static_cast<uint32_t>(probe->rows / PROBE_SIZE_PER_CHUNK) + n_groups + 1;
@@ -3242,7 +3321,13 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     k.mailbox = mailbox_dev;
     k.capacity = count_only ? ~0ull : result->capacity;
     k.slice_capacity = count_only ? 0xFFFFFFFFu : result->slice_capacity;
-    k.plain_stores = getenv("HY_JOIN_PLAIN_STORES") ? 1u : 0u;
+    k.plain_stores = 2;   // pk_copy_out: write-back stores for the lines a run shares with its neighbours, nontemporal ones in between
+    if (const char* env = getenv("HY_JOIN_STORES")) k.plain_stores = static_cast<uint32_t>(atoi(env));   // A/B: 0 nontemporal, 1 write-back
+    if (getenv("HY_JOIN_TRACE")) {
+      static uint64_t* trace_buffer = nullptr;
+      if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 6 * JOIN_TRACE_TILES);
+      if (n_tiles <= JOIN_TRACE_TILES) { k.trace = trace_buffer; g_join_trace = trace_buffer; g_join_trace_tiles = n_tiles; }
+    }
     k.slice_offsets = dev_slice_offsets;
     const uint32_t tile_grid = 8 * ((n_tiles + 7) / 8);
     {
@@ -3279,10 +3364,10 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     }
     hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself)
     profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
-    if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
-    else hipExtLaunchKernelGGL(pk_emit<false>, dim3(tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
-    if (cut_grid) hipLaunchKernelGGL(pk_cuts, dim3(cut_grid), dim3(PK_THREADS), 0, stream, k);
+    k.cut_blocks = (cut_grid + 7) / 8 * 8;   // (pk_cut_slice returns at once for slices the plan does not have)
+    if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
+    else hipExtLaunchKernelGGL(pk_emit<false>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     HY_HIP(hipGetLastError());
     clock.mark("pass 2 launched");
     t_last_join_used_pkfk = 1;   // debug / tests: the primary-key / foreign-key kernels ran

@@ -22,21 +22,29 @@
 // HBM traffic at config 3: 2 x probe keys + 16 B per pair + 3 x 4 B per (partition, tile) cell.
 #pragma once
 
-constexpr uint32_t PK_TILE = SLICE_ROWS;                 // 8192 rows: a probe tile is a slice
-constexpr uint32_t PK_THREADS = 512;
+#ifndef HY_PK_TILE
+#define HY_PK_TILE 8192
+#endif
+#ifndef HY_PK_WAVES_PER_SIMD
+#define HY_PK_WAVES_PER_SIMD 4   // pk_emit: workgroups per CU x waves per workgroup / 4 (the register budget: 512 / this)
+#endif
+constexpr uint32_t PK_TILE = HY_PK_TILE;                 // rows per probe tile: a slice (8192) or half a slice (-DHY_PK_TILE=4096: A/B builds)
+constexpr uint32_t PK_TILES_PER_SLICE = SLICE_ROWS / PK_TILE;
+constexpr uint32_t PK_ROUNDS = 16;                       // rows per lane
+constexpr uint32_t PK_THREADS = PK_TILE / PK_ROUNDS;     // 512
 constexpr uint32_t PK_WAVES = PK_THREADS / 64;           // 8
 constexpr uint32_t PK_WAVE_ROWS = PK_TILE / PK_WAVES;    // 1024 consecutive rows per wave
-constexpr uint32_t PK_ROUNDS = PK_WAVE_ROWS / 64;        // 16 rows per lane
-constexpr uint32_t PK_COUNT_THREADS = 256;
-constexpr uint32_t PK_COUNT_WAVE_ROWS = PK_TILE / (PK_COUNT_THREADS / 64);   // 2048: one FrameOfReference block per wave
+constexpr uint32_t PK_COUNT_WAVE_ROWS = 2048;            // pk_count: one FrameOfReference block per wave
+constexpr uint32_t PK_COUNT_THREADS = 64 * (PK_TILE / PK_COUNT_WAVE_ROWS);   // 256
 constexpr uint32_t PK_COUNT_BATCHES = PK_COUNT_WAVE_ROWS / 512;              // 4 batches of 512 rows, eight consecutive rows per lane
 constexpr uint32_t PK_SCAN_THREADS = 256;
 constexpr uint32_t PK_SCAN_CHUNK = 4096;                 // tiles per pass of pk_scan's loop
-static_assert(HY_FOR_BLOCK_SIZE % PK_WAVE_ROWS == 0 && HY_FOR_BLOCK_SIZE == PK_COUNT_WAVE_ROWS, "a wave's rows must lie in one FrameOfReference block");
+static_assert(SLICE_ROWS % PK_TILE == 0 && HY_FOR_BLOCK_SIZE % PK_WAVE_ROWS == 0 && HY_FOR_BLOCK_SIZE == PK_COUNT_WAVE_ROWS && PK_TILE % PK_COUNT_WAVE_ROWS == 0,
+              "a wave's rows must lie in one FrameOfReference block");
 static_assert(PK_TILE <= (1u << 13), "a staged pair keeps its row in 13 bits");
 
 struct PkArgs {
-  const SliceView* views;          // [n_tiles] the probe column's slices
+  const SliceView* views;          // the probe column's slices; a tile is a slice or (PK_TILES_PER_SLICE == 2) half of one
   uint32_t n_tiles;
   uint32_t stride;                 // row stride of the [P][stride] arrays below (> n_tiles: entry n_tiles of a row is its total)
   uint32_t mode;                   // HY_JOIN_*
@@ -59,11 +67,25 @@ struct PkArgs {
   JoinMailbox* mailbox;
   uint64_t capacity;
   uint32_t slice_capacity;
-  uint32_t plain_stores;           // debug (HY_JOIN_PLAIN_STORES): write-back stores instead of nontemporal ones in pk_emit
+  uint32_t plain_stores;           // pk_copy_out's STORES
   hy_row_id* build_out;            // nullptr: Semi / Anti
   hy_row_id* probe_out;
   uint64_t* slice_offsets;
+  uint32_t cut_blocks;             // pk_emit: its first cut_blocks workgroups compute the PosList cuts (pk_cut_slice)
+  uint32_t reserved;
+  uint64_t* trace;                 // debug (HY_JOIN_TRACE): 6 wall-clock stamps per pk_emit tile, else nullptr
 };
+
+// The rows of tile `tile`: its slice's view, narrowed to the tile.
+__device__ __forceinline__ SliceView pk_tile_view(const PkArgs& a, uint32_t tile) {
+  SliceView view = a.views[tile / PK_TILES_PER_SLICE];
+  if constexpr (PK_TILES_PER_SLICE > 1) {
+    const uint32_t offset = (tile % PK_TILES_PER_SLICE) * PK_TILE;
+    view.row_begin += offset;
+    view.row_count = view.row_count > offset ? (view.row_count - offset < PK_TILE ? view.row_count - offset : PK_TILE) : 0;
+  }
+  return view;
+}
 
 // XCD x = blockIdx % 8 takes the x-th eighth of the tiles (block_tile in join.hip): neighbouring tiles, whose output runs are
 // neighbours in memory, meet in one L2.
@@ -94,45 +116,58 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
   const uint32_t bias = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + wave_first) / HY_FOR_BLOCK_SIZE]);
   const uint32_t origin = static_cast<uint32_t>(a.rank.key_min), range = static_cast<uint32_t>(a.rank.range);
   const uint32_t mask = a.radix_bits ? (1u << a.radix_bits) - 1 : 0u;
+  // Two groups of 1024 rows: a group's sixteen lookups per lane are in flight together (counting only needs an entry's presence bits,
+  // its first word), and the kernel stays below 64 registers -- eight workgroups per CU hide each other's round trips.
 #pragma unroll
-  for (uint32_t b = 0; b < PK_COUNT_BATCHES; ++b) {
-    uint32_t low[8];
-    u32x2_t entry[8];
-    uint32_t valid = 0, look = 0;
+  for (uint32_t g = 0; g < PK_COUNT_BATCHES; g += 2) {
+    uint32_t bits[2][8];
 #pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
-      const bool in = wave_first + b * 512 + lane * 8 + j < row_count;
-      low[j] = batch_word<WIDTH>(words[b], j) + bias;
-      const uint32_t distance = low[j] - origin;   // (32-bit: both sides' keys are int32 values, see pk_path_applies)
-      const bool looked = in && distance <= range;
-      entry[j] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(a.rank.entries) + (looked ? (distance >> 5) * 8u : 0u));
-      valid |= (in ? 1u : 0u) << j;
-      look |= (looked ? 1u : 0u) << j;
-    }
-    uint32_t found = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
-      if (((look >> j) & 1) && ((entry[j].x >> ((low[j] - origin) & 31)) & 1)) found |= 1u << j;
-    }
-    if (a.build_bloom && !a.keep_nulls && __any((valid & ~found) != 0)) {   // partner-less rows: materialised only if the build side's filter has their bit
-      uint32_t miss = 0;
+    for (uint32_t b = 0; b < 2; ++b) {
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
-        if (((valid & ~found) >> j) & 1) miss |= (a.build_bloom[low[j] & (BLOOM_BITS - 1)] == 0 ? 1u : 0u) << j;
+        const uint32_t distance = batch_word<WIDTH>(words[g + b], j) + bias - origin;   // (32-bit: both sides' keys are int32 values, pk_path in run_join)
+        bits[b][j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
       }
-      valid &= ~miss;
     }
 #pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
-      if (!((valid >> j) & 1)) continue;
-      bool null_partner;
-      const bool emit = pk_emits<false>(a.mode, (found >> j) & 1, &null_partner);
-      atomicAdd(&cells[(low[j] & mask) * COUNT_COPIES + ((lane + j) & (COUNT_COPIES - 1))], emit ? 0x10001u : 1u);
+    for (uint32_t b = 0; b < 2; ++b) {
+      uint32_t valid = 0, found = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t distance = batch_word<WIDTH>(words[g + b], j) + bias - origin;
+        const bool in = wave_first + (g + b) * 512 + lane * 8 + j < row_count;
+        valid |= (in ? 1u : 0u) << j;
+        found |= (in && distance <= range && ((bits[b][j] >> (distance & 31)) & 1) ? 1u : 0u) << j;
+      }
+      if (a.build_bloom && !a.keep_nulls && __any((valid & ~found) != 0)) {   // partner-less rows: materialised only if the build side's filter has their bit
+        uint32_t miss = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+          if (((valid & ~found) >> j) & 1) miss |= (a.build_bloom[(batch_word<WIDTH>(words[g + b], j) + bias) & (BLOOM_BITS - 1)] == 0 ? 1u : 0u) << j;
+        }
+        valid &= ~miss;
+      }
+      // neighbouring rows share their key (four lineitems per order): the lane's eight consecutive rows leave as one LDS atomic per RUN
+      // of equal partitions (same-address atomics serialise)
+      uint32_t run_partition = 0xFFFFFFFFu, run_value = 0;
+      const uint32_t copy = ((lane >> 4) & 3) | ((lane & 1) << 2);   // (lanes 16 apart -- 32 orders, the period of dbgen's sparse keys mod 128 -- meet in one partition: they use different copies)
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        if (!((valid >> j) & 1)) continue;
+        bool null_partner;
+        const bool emit = pk_emits<false>(a.mode, (found >> j) & 1, &null_partner);
+        const uint32_t partition = (batch_word<WIDTH>(words[g + b], j) + bias) & mask, value = emit ? 0x10001u : 1u;
+        if (partition == run_partition) { run_value += value; continue; }
+        if (run_value) atomicAdd(&cells[run_partition * COUNT_COPIES + copy], run_value);
+        run_partition = partition;
+        run_value = value;
+      }
+      if (run_value) atomicAdd(&cells[run_partition * COUNT_COPIES + copy], run_value);
     }
   }
 }
 
-__global__ __launch_bounds__(PK_COUNT_THREADS) void pk_count(PkArgs a) {
+__global__ __launch_bounds__(PK_COUNT_THREADS, 8 * PK_COUNT_THREADS / 256) void pk_count(PkArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cells[MAX_PARTITIONS * COUNT_COPIES];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t partitions = 1u << a.radix_bits;
@@ -141,7 +176,7 @@ __global__ __launch_bounds__(PK_COUNT_THREADS) void pk_count(PkArgs a) {
   if (tile >= a.n_tiles) return;
   for (uint32_t i = tid; i < partitions * COUNT_COPIES; i += PK_COUNT_THREADS) s_cells[i] = 0;
   __syncthreads();
-  const SliceView view = a.views[tile];
+  const SliceView view = pk_tile_view(a, tile);
   if (view.kind == VIEW_FOR8) pk_count_wave<1>(a, view, wave, lane, s_cells);
   else if (view.kind == VIEW_FOR16) pk_count_wave<2>(a, view, wave, lane, s_cells);
   else pk_count_wave<4>(a, view, wave, lane, s_cells);
@@ -181,7 +216,8 @@ __device__ void pk_plan(const PkArgs& a, uint64_t* s_tmp, uint32_t tid) {
   uint64_t n_pairs = 0;
   uint32_t n_slices = 0;
   if (a.radix_bits) {   // groups = partitions (<= 256 = PK_SCAN_THREADS)
-    const uint64_t elements = tid < partitions ? a.totals[tid] : 0, pairs = tid < partitions ? a.totals[partitions + tid] : 0;
+    const uint64_t elements = tid < partitions ? __hip_atomic_load(a.totals + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const uint64_t pairs = tid < partitions ? __hip_atomic_load(a.totals + partitions + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     uint64_t total = 0;
     const uint64_t pairs_before = pk_block_exclusive_scan64(pairs, s_tmp, tid, &total);
     n_pairs = total;
@@ -194,13 +230,13 @@ __device__ void pk_plan(const PkArgs& a, uint64_t* s_tmp, uint32_t tid) {
     }
     if (tid == 0) { a.origin_pairs[partitions] = n_pairs; a.slice_base[partitions] = n_slices; }
   } else {   // groups = probe chunks: their tiles are consecutive in the one row of counts
-    n_pairs = a.totals[1];
+    n_pairs = __hip_atomic_load(a.totals + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (one workgroup: its own stores, the prefixes below included)
     uint64_t running = 0;
     for (uint32_t begin = 0; begin < a.n_groups; begin += PK_SCAN_THREADS) {
       const uint32_t g = begin + tid;
       uint64_t slices = 0;
       if (g < a.n_groups) {
-        const uint32_t elements = a.rel_elements[a.group_first_tile[g + 1]] - a.rel_elements[a.group_first_tile[g]];
+        const uint32_t elements = a.rel_elements[a.group_first_tile[g + 1] * PK_TILES_PER_SLICE] - a.rel_elements[a.group_first_tile[g] * PK_TILES_PER_SLICE];
         slices = (elements + PROBE_SIZE_PER_CHUNK - 1) / PROBE_SIZE_PER_CHUNK;
       }
       uint64_t total = 0;
@@ -265,89 +301,119 @@ __global__ __launch_bounds__(PK_SCAN_THREADS) void pk_scan(PkArgs a) {
     carry += total;
     __syncthreads();
   }
+  // The workgroup that arrives last plans the output.  It needs the partitions' totals (and, without radix partitioning, its own
+  // row of prefixes): they leave with agent-scope atomic stores (write-through) and are read back with agent-scope atomic loads --
+  // no release fence, which would write back the whole L2.
   if (tid == 0) {
     rel_elements[a.n_tiles] = static_cast<uint32_t>(carry);
     rel_pairs[a.n_tiles] = static_cast<uint32_t>(carry >> 32);
-    a.totals[partition] = static_cast<uint32_t>(carry);
-    a.totals[gridDim.x + partition] = static_cast<uint32_t>(carry >> 32);
-  }
-  // the workgroup that arrives last sees every partition's totals: it plans the output
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(a.totals + partition, static_cast<uint32_t>(carry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.totals + gridDim.x + partition, static_cast<uint32_t>(carry >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t arrived = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = arrived + 1 == gridDim.x ? 1u : 0u;
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   if (!s_last) return;
   pk_plan(a, s_tmp, tid);
 }
 
-// ---- evaluation of a tile's rows (pass 2, cuts) ----------------------------------------------------------------------------------
-// Wave w owns rows [1024 w, 1024 (w + 1)) of the tile, row k * 64 + lane in round k: row order = (wave, round, lane).
+// The stored words of a wave's 1024 rows, requested with 16-byte loads: lane l asks for the words of rows [16 l, 16 l + 16) of the
+// wave's block -- one piece of 16 bytes for 1-byte offsets, two for 2-byte offsets, four for 4-byte words -- and pk_rows_of_words
+// hands every lane ITS rows (row k * 64 + lane in round k: the order the ranking needs) through a wave-private LDS block.  Two
+// coalesced loads per lane instead of sixteen 2-byte ones, and a prefetched tile costs eight to sixteen registers.
+// A piece is loaded if its first row exists (a partial tile's last piece reads < 16 bytes past the rows: inside the segment's padding).
+struct PkWords { u32x4_t piece[4]; };
+__device__ __forceinline__ void pk_load_words(const SliceView& view, uint32_t wave, uint32_t lane, PkWords& words) {
+  const uint32_t width = view.kind == VIEW_FOR8 ? 1u : view.kind == VIEW_FOR16 ? 2u : 4u;
+  const uint32_t first = wave * PK_WAVE_ROWS + lane * PK_ROUNDS;          // of the lane's 16 rows, in the tile
+  const char* base = static_cast<const char*>(view.data) + static_cast<size_t>(view.row_begin + first) * width;
+  const uint32_t rows_per_piece = 16 / width;
+#pragma unroll
+  for (uint32_t p = 0; p < 4; ++p) {
+    words.piece[p] = u32x4_t{0, 0, 0, 0};
+    // (global, not flat: a flat load also counts on lgkmcnt)
+    typedef const __attribute__((address_space(1))) u32x4_t* global_words;
+    if (p < width && first + p * rows_per_piece < view.row_count) words.piece[p] = *(global_words)(base + p * 16);
+  }
+}
+
+// The lane's words go into the wave's LDS block (`block`: 4 KB that belong to this wave for the moment) ...
+__device__ __forceinline__ void pk_words_to_block(const SliceView& view, const PkWords& words, uint32_t* block, uint32_t lane) {
+  const uint32_t width = view.kind == VIEW_FOR8 ? 1u : view.kind == VIEW_FOR16 ? 2u : 4u;
+  u32x4_t* mine = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(block) + lane * PK_ROUNDS * width);
+#pragma unroll
+  for (uint32_t p = 0; p < 4; ++p) {
+    if (p < width) mine[p] = words.piece[p];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ... and come back as the stored words of the lane's rows: row k * 64 + lane of the wave's block in round k.
+__device__ __forceinline__ uint32_t pk_block_word(const SliceView& view, const uint32_t* block, uint32_t lane, uint32_t k) {
+  if (view.kind == VIEW_FOR16) return reinterpret_cast<const uint16_t*>(block)[k * 64 + lane];
+  if (view.kind == VIEW_FOR8) return reinterpret_cast<const uint8_t*>(block)[k * 64 + lane];
+  return block[k * 64 + lane];
+}
+
+// Keys, rank-table entries, the rows' fate -- HALVES == 2: eight rows at a time (two table round trips instead of one, half the
+// registers at the peak).
 // meta[k] = partition | null_partner << 9 | emit << 10 (INVALID_PARTITION: the row is not materialised); rank[k] = the partner's rank.
-template <bool INNER>
-__device__ __forceinline__ void pk_evaluate(const PkArgs& a, const SliceView& view, uint32_t wave, uint32_t lane, uint32_t (&meta)[PK_ROUNDS], uint32_t (&rank)[PK_ROUNDS]) {
+template <bool INNER, uint32_t HALVES>
+__device__ __forceinline__ void pk_lookup_rows(const PkArgs& a, const SliceView& view, const uint32_t* block, uint32_t wave, uint32_t lane, uint32_t (&meta)[PK_ROUNDS],
+                                               uint32_t (&rank)[PK_ROUNDS]) {
+  constexpr uint32_t N = PK_ROUNDS / HALVES;
   const uint32_t row_count = view.row_count;
   const uint32_t wave_first = wave * PK_WAVE_ROWS;
-  uint32_t raw[PK_ROUNDS];
-  if (row_count == PK_TILE) {   // a full tile: one address per lane, immediate offsets
-    const uint32_t first = view.row_begin + wave_first + lane;
-    if (view.kind == VIEW_FOR16) {
-      const uint16_t* base = static_cast<const uint16_t*>(view.data) + first;
-#pragma unroll
-      for (uint32_t k = 0; k < PK_ROUNDS; ++k) raw[k] = base[k * 64];
-    } else if (view.kind == VIEW_FOR8) {
-      const uint8_t* base = static_cast<const uint8_t*>(view.data) + first;
-#pragma unroll
-      for (uint32_t k = 0; k < PK_ROUNDS; ++k) raw[k] = base[k * 64];
-    } else {
-      const uint32_t* base = static_cast<const uint32_t*>(view.data) + first;
-#pragma unroll
-      for (uint32_t k = 0; k < PK_ROUNDS; ++k) raw[k] = base[k * 64];
-    }
-  } else {
-#pragma unroll
-    for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
-      const uint32_t r = wave_first + k * 64 + lane;
-      const uint32_t index = view.row_begin + (r < row_count ? r : 0);
-      raw[k] = view.kind == VIEW_FOR16 ? static_cast<const uint16_t*>(view.data)[index] : view.kind == VIEW_FOR8 ? static_cast<const uint8_t*>(view.data)[index] : static_cast<const uint32_t*>(view.data)[index];
-    }
-  }
   const uint32_t bias = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + (wave_first < row_count ? wave_first : 0u)) / HY_FOR_BLOCK_SIZE]);
   const uint32_t origin = static_cast<uint32_t>(a.rank.key_min), range = static_cast<uint32_t>(a.rank.range);
   const uint32_t mask = a.radix_bits ? (1u << a.radix_bits) - 1 : 0u;
-  u32x2_t entry[PK_ROUNDS];
 #pragma unroll
-  for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
-    raw[k] += bias;                                  // the key's low 32 bits
-    const uint32_t distance = raw[k] - origin;
-    entry[k] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
-  }
-  uint32_t valid = 0, found = 0;
+  for (uint32_t h = 0; h < HALVES; ++h) {
+    uint32_t raw[N];
+    u32x2_t entry[N];
 #pragma unroll
-  for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
-    const uint32_t distance = raw[k] - origin;
-    const uint32_t bit = distance & 31;
-    const bool in = wave_first + k * 64 + lane < row_count;
-    if (in) valid |= 1u << k;
-    if (in && distance <= range && ((entry[k].x >> bit) & 1)) found |= 1u << k;
-    rank[k] = entry[k].y + __popc(entry[k].x & ((1u << bit) - 1));
-  }
-  if (a.build_bloom && !a.keep_nulls && __any((valid & ~found) != 0)) {   // join_hash_steps.hpp:354-358
-#pragma unroll
-    for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
-      if (((valid & ~found) >> k) & 1) { if (a.build_bloom[raw[k] & (BLOOM_BITS - 1)] == 0) valid &= ~(1u << k); }
+    for (uint32_t j = 0; j < N; ++j) {
+      raw[j] = pk_block_word(view, block, lane, h * N + j) + bias;   // the key's low 32 bits
+      const uint32_t distance = raw[j] - origin;                     // (32-bit: both sides' keys are int32 values, pk_path in run_join)
+      entry[j] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
     }
-  }
+    uint32_t valid = 0, found = 0;
 #pragma unroll
-  for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
-    bool null_partner;
-    const bool emit = pk_emits<INNER>(a.mode, (found >> k) & 1, &null_partner);
-    meta[k] = (valid >> k) & 1 ? (raw[k] & mask) | (null_partner ? 0x200u : 0u) | (emit ? 0x400u : 0u) : INVALID_PARTITION;
+    for (uint32_t j = 0; j < N; ++j) {
+      const uint32_t distance = raw[j] - origin;
+      const uint32_t bit = distance & 31;
+      const bool in = wave_first + (h * N + j) * 64 + lane < row_count;
+      if (in) valid |= 1u << j;
+      if (in && distance <= range && ((entry[j].x >> bit) & 1)) found |= 1u << j;
+      rank[h * N + j] = entry[j].y + __popc(entry[j].x & ((1u << bit) - 1));
+    }
+    if (a.build_bloom && !a.keep_nulls && __any((valid & ~found) != 0)) {   // join_hash_steps.hpp:354-358
+#pragma unroll
+      for (uint32_t j = 0; j < N; ++j) {
+        if (((valid & ~found) >> j) & 1) { if (a.build_bloom[raw[j] & (BLOOM_BITS - 1)] == 0) valid &= ~(1u << j); }
+      }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+      bool null_partner;
+      const bool emit = pk_emits<INNER>(a.mode, (found >> j) & 1, &null_partner);
+      meta[h * N + j] = (valid >> j) & 1 ? (raw[j] & mask) | (null_partner ? 0x200u : 0u) | (emit ? 0x400u : 0u) : INVALID_PARTITION;
+    }
+    if (h + 1 < HALVES) __builtin_amdgcn_sched_barrier(0);   // (the second half's loads must not move up: that is the point)
   }
+}
+
+// ---- evaluation of a tile's rows (cuts) --------------------------------------------------------------------------------------
+// Wave w owns rows [1024 w, 1024 (w + 1)) of the tile, row k * 64 + lane in round k: row order = (wave, round, lane).
+template <bool INNER>
+__device__ __forceinline__ void pk_evaluate(const PkArgs& a, const SliceView& view, uint32_t* block, uint32_t wave, uint32_t lane, uint32_t (&meta)[PK_ROUNDS], uint32_t (&rank)[PK_ROUNDS]) {
+  PkWords words;
+  pk_load_words(view, wave, lane, words);
+  pk_words_to_block(view, words, block, lane);
+  pk_lookup_rows<INNER, 1>(a, view, block, wave, lane, meta, rank);
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------------------------------------------
@@ -356,11 +422,16 @@ __device__ __forceinline__ void pk_evaluate(const PkArgs& a, const SliceView& vi
 // staging slot 0 per partition | wave totals of the partition scan, reserved slots.
 constexpr uint32_t PK_STAGE_ROW = 0x1FFF, PK_STAGE_PARTITION_SHIFT = 13, PK_STAGE_NULL = 1u << 21;
 __host__ __device__ constexpr size_t pk_emit_lds_words(uint32_t partitions) {
-  return 2 * (size_t{PK_TILE} + partitions + 2) + size_t{PK_WAVES} * partitions + partitions + 16;
+  return 2 * (size_t{PK_TILE} + partitions + 2) + size_t{PK_WAVES} * partitions + 3 * size_t{partitions} + 32;
 }
 
-template <int BUILD, bool PLAIN>
-__device__ __forceinline__ void pk_copy_out(const PkArgs& a, const u32x2_t* s_stage, const uint32_t* s_out_base, uint32_t reserved, uint32_t chunk, uint32_t tile_row_begin, uint32_t tid) {
+// STORES: 0 nontemporal | 1 write-back | 2 write-back for the two pairs that share a 128-byte line with a NEIGHBOURING tile's pairs (a
+// run's first and last line: the partial lines merge in the XCD's L2 instead of reaching HBM as two masked writes each), nontemporal
+// for the full lines in between (nothing of the 0.96 GB stays behind in the L2 for the next kernel to evict).  tools/hbm_write.hip:
+// 246 us / 187 us / 188 us for config 3's layout.  s_edge: [2][partitions] first and last line of every run.
+template <int BUILD, int STORES>
+__device__ __forceinline__ void pk_copy_out(const PkArgs& a, const u32x2_t* s_stage, const uint32_t* s_out_base, const uint32_t* s_edge, uint32_t partitions, uint32_t reserved,
+                                            uint32_t chunk, uint32_t tile_row_begin, uint32_t tid) {
   u32x2_t* probe_out = reinterpret_cast<u32x2_t*>(a.probe_out);
   u32x2_t* build_out = reinterpret_cast<u32x2_t*>(a.build_out);
   auto rank_row = [&](uint32_t r) -> u32x2_t {
@@ -382,11 +453,8 @@ __device__ __forceinline__ void pk_copy_out(const PkArgs& a, const u32x2_t* s_st
       return reinterpret_cast<const u32x2_t*>(a.row_ids)[r];
     }
   };
-  auto store4 = [&](u32x4_t v, u32x2_t* at) {
-    if constexpr (PLAIN) *reinterpret_cast<u32x4_t*>(at) = v; else __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(at));
-  };
-  auto store2 = [&](u32x2_t v, u32x2_t* at) {
-    if constexpr (PLAIN) *at = v; else __builtin_nontemporal_store(v, at);
+  auto store2 = [&](u32x2_t v, u32x2_t* at) {   // (a run's first or last pair)
+    if constexpr (STORES != 0) *at = v; else __builtin_nontemporal_store(v, at);
   };
   for (uint32_t slot = 2 * tid; slot < reserved; slot += 2 * PK_THREADS) {
     const u32x4_t records = *reinterpret_cast<const u32x4_t*>(s_stage + slot);
@@ -400,9 +468,18 @@ __device__ __forceinline__ void pk_copy_out(const PkArgs& a, const u32x2_t* s_st
       if (valid1 && !(tag1 & PK_STAGE_NULL)) build1 = rank_row(records.w);
     }
     if (valid0 && valid1 && partition0 == partition1) {   // both pairs of one run: its first global index has the slot's parity -> aligned
-      const size_t pair_pos = static_cast<uint32_t>(s_out_base[partition0] + slot);
-      store4(u32x4_t{probe0.x, probe0.y, probe1.x, probe1.y}, probe_out + pair_pos);
-      if constexpr (BUILD != BUILD_NONE) store4(u32x4_t{build0.x, build0.y, build1.x, build1.y}, build_out + pair_pos);
+      const uint32_t pair_index = s_out_base[partition0] + slot;
+      const size_t pair_pos = pair_index;
+      const u32x4_t probe_pairs = {probe0.x, probe0.y, probe1.x, probe1.y}, build_pairs = {build0.x, build0.y, build1.x, build1.y};
+      bool write_back = STORES == 1;
+      if constexpr (STORES == 2) write_back = (pair_index >> 4) == s_edge[partition0] || (pair_index >> 4) == s_edge[partitions + partition0];
+      if (write_back) {
+        *reinterpret_cast<u32x4_t*>(probe_out + pair_pos) = probe_pairs;
+        if constexpr (BUILD != BUILD_NONE) *reinterpret_cast<u32x4_t*>(build_out + pair_pos) = build_pairs;
+      } else {
+        __builtin_nontemporal_store(probe_pairs, reinterpret_cast<u32x4_t*>(probe_out + pair_pos));
+        if constexpr (BUILD != BUILD_NONE) __builtin_nontemporal_store(build_pairs, reinterpret_cast<u32x4_t*>(build_out + pair_pos));
+      }
     } else {
       if (valid0) {
         const size_t pair_pos = static_cast<uint32_t>(s_out_base[partition0] + slot);
@@ -418,28 +495,25 @@ __device__ __forceinline__ void pk_copy_out(const PkArgs& a, const u32x2_t* s_st
   }
 }
 
+// One tile from its stored words to its pairs in the output.  The five phases are separated by four workgroup barriers.
 template <bool INNER>
-__global__ __launch_bounds__(PK_THREADS, 4) void pk_emit(PkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
+__device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, const SliceView& view, const PkWords& words, uint32_t cell_pairs, uint32_t cell_base,
+                                             uint32_t* join_smem, uint32_t tid, uint32_t lane, uint32_t wave) {
   const uint32_t partitions = 1u << a.radix_bits;
   const uint32_t stage_slots = PK_TILE + partitions + 2;
   u32x2_t* s_stage = reinterpret_cast<u32x2_t*>(join_smem);                      // [stage_slots]
   uint32_t* s_wave_pairs = reinterpret_cast<uint32_t*>(s_stage + stage_slots);   // [PK_WAVES][partitions]
   uint32_t* s_out_base = s_wave_pairs + PK_WAVES * partitions;                   // [partitions]
-  uint32_t* s_scratch = s_out_base + partitions;                                 // [4] wave totals of the partition scan, [8] reserved slots
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t* s_edge = s_out_base + partitions;                                    // [2][partitions] first / last 128-byte line of the partition's run
+  uint32_t* s_scratch = s_edge + 2 * partitions;                                 // [4] wave totals of the partition scan, [8] reserved slots, [16 + wave] a counter for rows without a pair
   const uint32_t scan_waves = partitions > 64 ? partitions / 64 : 1;
-  const uint32_t tile = pk_block_tile(a.n_tiles);
-  if (tile >= a.n_tiles || !a.plan->fits) return;
-  const SliceView view = a.views[tile];
-  if (view.row_count == 0) return;
+  if (a.trace && tid == 0) a.trace[tile * 6 + 0] = wall_clock64();
   for (uint32_t i = tid; i < PK_WAVES * partitions; i += PK_THREADS) s_wave_pairs[i] = 0;
-  // thread = partition: the cell's pairs and its first global pair index (fits 32 bits: pk_path_applies)
-  const size_t cell = static_cast<size_t>(tid < partitions ? tid : 0) * a.stride + tile;
-  const uint32_t cell_pairs = tid < partitions ? a.counts[cell] >> 16 : 0;
-  const uint32_t cell_base = static_cast<uint32_t>(a.origin_pairs[tid < partitions ? tid : 0]) + a.rel_pairs[cell];
   uint32_t meta[PK_ROUNDS], rank[PK_ROUNDS];
-  pk_evaluate<INNER>(a, view, wave, lane, meta, rank);
+  pk_words_to_block(view, words, join_smem + wave * 1024, lane);   // (the staging area is not in use yet: 4 KB of it per wave)
+  pk_lookup_rows<INNER, 1>(a, view, join_smem + wave * 1024, wave, lane, meta, rank);
+  __builtin_amdgcn_wave_barrier();
+  if (a.trace && tid == 0) a.trace[tile * 6 + 1] = wall_clock64();
   // (a) reserve pairs + 1 slots per non-empty partition: scan inside each wave now, across waves in (c)
   const uint32_t reserve = cell_pairs ? cell_pairs + 1 : 0;
   uint32_t first_in_wave = 0;
@@ -454,16 +528,17 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pk_emit(PkArgs a) {
   // host takes the general kernels where it does not hold), so a lane gets back the pairs of its partition in lower lanes and
   // earlier rounds.  The rank moves into meta[k] bits 11..
   {
+    // (rows without a pair count on a spare counter of the wave: sixteen atomics back to back, no branch around any of them)
     uint32_t before[PK_ROUNDS];
+    uint32_t* mine = s_wave_pairs + wave * partitions;
+    uint32_t* spare = s_scratch + 16 + wave;
 #pragma unroll
-    for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
-      before[k] = 0;
-      if (meta[k] & 0x400u) before[k] = atomicAdd(&s_wave_pairs[wave * partitions + (meta[k] & 0xFF)], 1u);
-    }
+    for (uint32_t k = 0; k < PK_ROUNDS; ++k) before[k] = atomicAdd((meta[k] & 0x400u) ? mine + (meta[k] & 0xFF) : spare, 1u);
 #pragma unroll
-    for (uint32_t k = 0; k < PK_ROUNDS; ++k) meta[k] |= before[k] << 11;
+    for (uint32_t k = 0; k < PK_ROUNDS; ++k) meta[k] |= (meta[k] & 0x400u) ? before[k] << 11 : 0u;
   }
   __syncthreads();
+  if (a.trace && tid == 0) a.trace[tile * 6 + 2] = wall_clock64();
   // (c) thread = partition: first slot of every (wave, partition) = first slot of the partition (parity of its first global pair
   // index) + pairs of earlier waves; output base
   if (tid < partitions) {
@@ -474,6 +549,8 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pk_emit(PkArgs a) {
       first += shift;
     }
     s_out_base[tid] = cell_base - first;
+    s_edge[tid] = cell_base >> 4;
+    s_edge[partitions + tid] = (cell_base + cell_pairs - (cell_pairs ? 1u : 0u)) >> 4;
     uint32_t run = first;
 #pragma unroll
     for (uint32_t w = 0; w < PK_WAVES; ++w) {
@@ -484,24 +561,27 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pk_emit(PkArgs a) {
     if (tid == 0) s_scratch[8] = s_scratch[0] + (scan_waves > 1 ? s_scratch[1] : 0u) + (scan_waves > 2 ? s_scratch[2] : 0u) + (scan_waves > 3 ? s_scratch[3] : 0u);   // every reserved slot
   }
   __syncthreads();
+  if (a.trace && tid == 0) a.trace[tile * 6 + 3] = wall_clock64();
   // (d) stage
+  // (rows without a pair write the slot behind every run: no branch here either)
 #pragma unroll
   for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
-    if (!(meta[k] & 0x400u)) continue;
     const uint32_t partition = meta[k] & 0xFF;
-    const uint32_t slot = s_wave_pairs[wave * partitions + partition] + (meta[k] >> 11);
+    const uint32_t slot = (meta[k] & 0x400u) ? s_wave_pairs[wave * partitions + partition] + (meta[k] >> 11) : stage_slots - 1;
     const uint32_t r = wave * PK_WAVE_ROWS + k * 64 + lane;
     s_stage[slot] = u32x2_t{r | (partition << PK_STAGE_PARTITION_SHIFT) | ((meta[k] & 0x200u) ? PK_STAGE_NULL : 0u), rank[k]};
   }
   __syncthreads();
+  if (a.trace && tid == 0) a.trace[tile * 6 + 4] = wall_clock64();
   // (e) copy out: one loop per way of turning a partner's rank into its RowID (the identity cases have no global load in the loop:
   // no `s_waitcnt vmcnt(0)` per iteration, which would also wait for every store in flight)
   const uint32_t reserved = s_scratch[8];
   const uint32_t chunk = view.chunk, row_begin = view.row_begin;
-#define HY_PK_COPY(BUILD)                                                                                        \
-  do {                                                                                                           \
-    if (a.plain_stores) pk_copy_out<BUILD, true>(a, s_stage, s_out_base, reserved, chunk, row_begin, tid);    \
-    else pk_copy_out<BUILD, false>(a, s_stage, s_out_base, reserved, chunk, row_begin, tid);                  \
+#define HY_PK_COPY(BUILD)                                                                                                              \
+  do {                                                                                                                                 \
+    if (a.plain_stores == 1) pk_copy_out<BUILD, 1>(a, s_stage, s_out_base, s_edge, partitions, reserved, chunk, row_begin, tid);    \
+    else if (a.plain_stores == 2) pk_copy_out<BUILD, 2>(a, s_stage, s_out_base, s_edge, partitions, reserved, chunk, row_begin, tid); \
+    else pk_copy_out<BUILD, 0>(a, s_stage, s_out_base, s_edge, partitions, reserved, chunk, row_begin, tid);                         \
   } while (0)
   if (!a.build_out) HY_PK_COPY(BUILD_NONE);
   else if (a.rank.identity_rows == 65535u) HY_PK_COPY(BUILD_IDENTITY_65535);
@@ -509,14 +589,17 @@ __global__ __launch_bounds__(PK_THREADS, 4) void pk_emit(PkArgs a) {
   else if (a.ids32) HY_PK_COPY(BUILD_PACKED);
   else HY_PK_COPY(BUILD_ROW_IDS);
 #undef HY_PK_COPY
+  if (a.trace && tid == 0) a.trace[tile * 6 + 5] = wall_clock64();
 }
 
 // ---- the 131 070-element cuts ------------------------------------------------------------------------------------------------
 // One workgroup per output PosList: its group (partition or probe chunk), the tile that holds the PosList's first element
 // (64-ary searches over the scanned counts), then the tile's rows once more.
-__global__ __launch_bounds__(PK_THREADS) void pk_cuts(PkArgs a) {
-  __shared__ uint32_t s_members[PK_WAVES * PK_ROUNDS], s_emitters[PK_WAVES * PK_ROUNDS];
-  const uint32_t slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// smem: PK_WAVES * 1024 + 2 * PK_WAVES * PK_ROUNDS words.
+__device__ __forceinline__ void pk_cut_slice(const PkArgs& a, uint32_t slice, uint32_t* smem, uint32_t tid, uint32_t lane, uint32_t wave) {
+  uint32_t* s_rows = smem;
+  uint32_t* s_members = smem + PK_WAVES * 1024;
+  uint32_t* s_emitters = s_members + PK_WAVES * PK_ROUNDS;
   if (!a.plan->fits || slice >= a.plan->n_slices) return;
   uint32_t lo = 0, hi = a.n_groups;   // last group whose first PosList is <= slice (every wave searches: the results are uniform)
   while (hi - lo > 1) {
@@ -528,7 +611,7 @@ __global__ __launch_bounds__(PK_THREADS) void pk_cuts(PkArgs a) {
   const uint32_t group = lo;
   const uint32_t partition = a.radix_bits ? group : 0;
   const uint32_t* rel_elements = a.rel_elements + static_cast<size_t>(partition) * a.stride;
-  const uint32_t first_tile = a.radix_bits ? 0 : a.group_first_tile[group], end_tile = a.radix_bits ? a.n_tiles : a.group_first_tile[group + 1];
+  const uint32_t first_tile = a.radix_bits ? 0 : a.group_first_tile[group] * PK_TILES_PER_SLICE, end_tile = a.radix_bits ? a.n_tiles : a.group_first_tile[group + 1] * PK_TILES_PER_SLICE;
   const uint32_t target = rel_elements[first_tile] + (slice - a.slice_base[group]) * PROBE_SIZE_PER_CHUNK;
   uint32_t tile = first_tile, tile_end = end_tile;   // last tile of the group whose first element is <= target: it holds the element
   while (tile_end - tile > 1) {
@@ -538,9 +621,9 @@ __global__ __launch_bounds__(PK_THREADS) void pk_cuts(PkArgs a) {
     tile_end = tile + step < tile_end ? tile + step : tile_end;
   }
   const uint32_t cut_rank = target - rel_elements[tile];
-  const SliceView view = a.views[tile];
+  const SliceView view = pk_tile_view(a, tile);
   uint32_t meta[PK_ROUNDS], rank[PK_ROUNDS];
-  pk_evaluate<false>(a, view, wave, lane, meta, rank);
+  pk_evaluate<false>(a, view, s_rows + wave * 1024, wave, lane, meta, rank);
   uint64_t members[PK_ROUNDS], emitters[PK_ROUNDS];
 #pragma unroll
   for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
@@ -562,3 +645,33 @@ __global__ __launch_bounds__(PK_THREADS) void pk_cuts(PkArgs a) {
     emitters_before += __popcll(emitters[k]);
   }
 }
+
+__global__ __launch_bounds__(PK_THREADS) void pk_cuts(PkArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cut[PK_WAVES * 1024 + 2 * PK_WAVES * PK_ROUNDS];
+  const uint32_t tid = threadIdx.x;
+  pk_cut_slice(a, blockIdx.x, s_cut, tid, tid & 63, __builtin_amdgcn_readfirstlane(tid >> 6));
+}
+
+// One tile per workgroup (2 workgroups per CU overlap each other's phases).
+template <bool INNER>
+__global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
+  const uint32_t partitions = 1u << a.radix_bits;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The first cut_blocks workgroups (a multiple of 8: the others keep their XCD) find the PosList cuts while the rest emits: a launch
+  // of its own behind this kernel was 13 us of an otherwise idle device.
+  if (blockIdx.x < a.cut_blocks) { pk_cut_slice(a, blockIdx.x, join_smem, tid, lane, wave); return; }
+  const uint32_t block = blockIdx.x - a.cut_blocks;
+  const uint32_t tile = (block & 7) * ((a.n_tiles + 7) / 8) + (block >> 3);
+  if (tile >= a.n_tiles || !a.plan->fits) return;
+  const SliceView view = pk_tile_view(a, tile);
+  if (view.row_count == 0) return;
+  // thread = partition: the cell's pairs and its first global pair index (fits 32 bits: pk_path in run_join)
+  const size_t cell = static_cast<size_t>(tid < partitions ? tid : 0) * a.stride + tile;
+  const uint32_t cell_pairs = tid < partitions ? a.counts[cell] >> 16 : 0;
+  const uint32_t cell_base = static_cast<uint32_t>(a.origin_pairs[tid < partitions ? tid : 0]) + a.rel_pairs[cell];
+  PkWords words;
+  pk_load_words(view, wave, lane, words);
+  pk_emit_tile<INNER>(a, tile, view, words, cell_pairs, cell_base, join_smem, tid, lane, wave);
+}
+

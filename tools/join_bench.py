@@ -23,7 +23,8 @@ def main():
     orders = DeviceColumn(storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED))
     lineitem = DeviceColumn(storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE))
     n = data.n_lineitems
-    variants = [("default", {}), ("plain stores", {"HY_JOIN_PLAIN_STORES": "1"}), ("no key hint (two-pass build)", {"HY_JOIN_NO_HINT": "1"}),
+    variants = [("default (edge lines write-back)", {}), ("nontemporal stores", {"HY_JOIN_STORES": "0"}), ("write-back stores", {"HY_JOIN_STORES": "1"}),
+                ("no key hint (two-pass build)", {"HY_JOIN_NO_HINT": "1"}),
                 ("general rank-table kernels (round 2)", {"HY_JOIN_NO_PKFK": "1", "HY_JOIN_NO_HINT": "1"}), ("default again", {})]
     for name, env in variants:
         for k, v in env.items():
@@ -33,6 +34,19 @@ def main():
         print(f"{name:40s} {dt * 1e3:7.3f} ms/join  pairs {int(r.n_pairs)}  " + "  ".join(f"{k} {v[0] * 1e3:6.1f} us" for k, v in kinds.items() if v[1]), flush=True)
         for k in env:
             del os.environ[k]
+        del keep
+    if os.environ.get("HY_JOIN_TRACE"):   # per-tile phase stamps of pk_emit of the last join (wall clock, 100 MHz)
+        import numpy as np
+        lib.hy_debug_join_trace.restype = C.c_int
+        run, r, keep = bench.device_join(lib, torch, dev, orders, lineitem, n)
+        run()
+        stamps = np.zeros((1 << 15, 6), dtype=np.uint64)
+        tiles = lib.hy_debug_join_trace(stamps.ctypes.data_as(C.c_void_p), C.c_uint32(1 << 15))
+        t = stamps[:tiles].astype(np.float64) / 100.0   # us
+        t = t[t[:, 5] > 0]
+        phases = ("evaluate", "reserve + rank", "prefix", "stage", "copy out")
+        print(f"pk_emit trace over {len(t)} tiles: span {t[:, 5].max() - t[:, 0].min():.1f} us, per tile " +
+              ", ".join(f"{name} {np.median(t[:, i + 1] - t[:, i]):.2f}" for i, name in enumerate(phases)) + f", total {np.median(t[:, 5] - t[:, 0]):.2f} us (medians)")
         del keep
     for name, left, right, capacity in (("semi: probe lineitem, build orders", lineitem, orders, n), ("semi: probe orders, build lineitem", orders, lineitem, data.n_orders)):
         run, r, keep = bench.device_join(lib, torch, dev, left, right, capacity, abi.JOIN_SEMI)
