@@ -182,15 +182,33 @@ def traffic_source():
         return None
 
 
+_EVENT_OVERHEAD = []
+
+
+def event_overhead_ms(lib):
+    """What an event pair handed to the launch measures beyond the kernel (hy_profile_event_overhead: an empty kernel, median of 32)."""
+    from hyrise_amd import abi
+    if not _EVENT_OVERHEAD:
+        ms = C.c_float(0)
+        abi.check(lib.hy_profile_event_overhead(C.byref(ms)))
+        _EVENT_OVERHEAD.append(0.0 if os.environ.get("HY_BENCH_RAW_EVENTS") else float(ms.value))
+    return _EVENT_OVERHEAD[0]
+
+
 def kernel_times(lib):
-    """{kernel kind: (ms per timed launch, timed launches)} of the current profiling session (hy_profile_read_kernel)."""
+    """{kernel kind: (ms per timed launch, timed launches)} of the current profiling session (hy_profile_read_kernel).  The scan and
+    join kernels are timed by event pairs stamped from their dispatch packets: the elapsed time of an empty kernel measured the same way
+    (a few microseconds, `event_overhead_ms` in the line) is taken off every one of them, which is what makes these durations comparable
+    with a profiler's per-kernel begin / end timestamps (profiles/r03_bench_kernel_stats.csv)."""
     from hyrise_amd import abi
     out = {}
-    for name, kind in (("scan", abi.KERNEL_SCAN), ("join_probe", abi.KERNEL_JOIN_PROBE), ("join_count", abi.KERNEL_JOIN_COUNT), ("join_build", abi.KERNEL_JOIN_BUILD),
-                       ("aggregate", abi.KERNEL_AGGREGATE)):
+    overhead = event_overhead_ms(lib)
+    for name, kind, packet_events in (("scan", abi.KERNEL_SCAN, True), ("join_probe", abi.KERNEL_JOIN_PROBE, True), ("join_count", abi.KERNEL_JOIN_COUNT, True),
+                                      ("join_build", abi.KERNEL_JOIN_BUILD, True), ("aggregate", abi.KERNEL_AGGREGATE, False)):
         km, ln = C.c_float(0), C.c_uint32(0)
         abi.check(lib.hy_profile_read_kernel(kind, C.byref(km), C.byref(ln)))
-        out[name] = (km.value / ln.value if ln.value else 0.0, int(ln.value))
+        per_launch = km.value / ln.value if ln.value else 0.0
+        out[name] = (max(per_launch - overhead, 0.0) if packet_events and ln.value else per_launch, int(ln.value))
     return out
 
 
@@ -736,7 +754,7 @@ def main():
                                         scan_bytes + join_bytes, ms_per_step)
         step_roofline.update(dominant_kernel=step_kernels.get("pk_emit") or step_kernels["scan_slices"], kernels=step_kernels,
                              launches_timed={name: kinds[name][1] for name in ("scan", "join_probe", "join_count", "join_build")},
-                             traffic_source=traffic_source(), algorithmic_bytes={"scan": scan_bytes, "join": join_bytes})
+                             traffic_source=traffic_source(), algorithmic_bytes={"scan": scan_bytes, "join": join_bytes}, event_overhead_ms=event_overhead_ms(lib))
         step_roofline["traffic"] = committed_traffic("step")
         line = {
             "metric": "rows/sec TableScan+JoinHash, TPC-H SF10 lineitem (ColumnVsValue l_shipdate < 1995-01-01, then JoinHash orders x lineitem on the order key)",

@@ -130,6 +130,7 @@ SYMBOLS = [
     ("hy_set_profiling", C.c_int32, [C.c_int32]),
     ("hy_profile_read", C.c_int32, [C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     ("hy_profile_read_kernel", C.c_int32, [C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    ("hy_profile_event_overhead", C.c_int32, [C.POINTER(C.c_float)]),
     ("hy_column_create", C.c_int32, [C.POINTER(Segment), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("hy_column_destroy", C.c_int32, [C.c_void_p]),
     ("hy_column_row_count", C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256) void dense_key_stats(MaterializeArgs a, uint64
 // run's first and last word can hold keys of a neighbouring slice: those two go to the (zeroed) table with an atomic OR.
 // A slice whose keys span more words than the LDS holds (a sparse stretch) sets its bits with one global atomic per key.
 constexpr uint32_t FILL_WORDS = 4096;
+constexpr uint32_t CHECKED_FILL_TICKETS = 32;   // second-level arrival counters of rank_table_fill_checked, 128 bytes apart behind the first
 constexpr uint32_t CHECKED_FILL_WORDS = 2048;   // rank_table_fill_checked: 16 KB of LDS, eight workgroups per CU (sparser slices set their bits in the table itself)
 typedef uint32_t u32x2_entry_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void rank_table_fill_dense(MaterializeArgs a, uint64_t key_min, u32x2_entry_t* entries) {
@@ -2452,7 +2453,7 @@ __device__ __forceinline__ int32_t view_key(const SliceView& view, uint32_t row)
   return static_cast<int32_t>(stored + static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[row / HY_FOR_BLOCK_SIZE]));
 }
 
-// One slice of a column of int32 keys (every segment one a SliceView describes, key_min an int32 value): 32-bit arithmetic
+// One slice of a column of int32 keys (every segment one a SliceView describes, `origin` an int32 value and a multiple of 32): 32-bit arithmetic
 // throughout -- the wrapped difference of two int32 values is their distance, or larger than any range.  The workgroup learns the
 // extent of its keys from the keys themselves (a wave reduction each, no dependent loads in front of the slice's eight), sets up its
 // run of table words in LDS, and the bits of a group's keys that share a word leave with ONE LDS atomic (sorted keys: four lineitems of
@@ -2513,7 +2514,14 @@ __device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, con
   const uint32_t first_word = low_rel >> 5, span = staged ? (high_rel >> 5) - first_word + 1 : 0;
   for (uint32_t i = tid; i < span; i += 256) { s_bits[i] = 0; s_base[i] = 0; }
   __syncthreads();
+  if (a.keep_nulls == 0xFFFFFFFFu) { *flags_out = 0; return; }   // (HY_JOIN_FILL_DEBUG=2: loads and extent only)
   const uint32_t first_row = static_cast<uint32_t>(a.row_base[view.chunk]) + view.row_begin;   // rank of the slice's first key
+  // The Bloom filter of the build side (bit = key & 0xFFFFF, join_hash_steps.hpp:252,362) as 2^20 BITS: the table's origin is a
+  // multiple of 32, so a key's bit inside its table word is its bit inside its filter word, and a table word's presence bits are
+  // OR-ed into filter word (table word + origin / 32) mod 2^15 -- one atomic per table word instead of one byte store per key
+  // (15 M scattered byte stores were 25 us of this kernel's 60).
+  uint32_t* bloom_words = reinterpret_cast<uint32_t*>(a.bloom_out);
+  const uint32_t origin_word = origin >> 5;
   uint32_t flags = 0;
 #pragma unroll
   for (uint32_t i = 0; i < GROUPS; ++i) {
@@ -2530,6 +2538,7 @@ __device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, con
       } else {
         atomicOr(reinterpret_cast<uint32_t*>(entries + run_word), run_bits);
         if (run_leader) reinterpret_cast<uint32_t*>(entries + run_word)[1] = first_row + run_row;
+        if (bloom_words) atomicOr(bloom_words + ((run_word + origin_word) & (BLOOM_BITS / 32 - 1)), run_bits);
       }
     };
 #pragma unroll
@@ -2542,7 +2551,6 @@ __device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, con
         if (previous > k) flags |= 1u;
         if (previous == k) flags |= 2u;
       }
-      if (a.bloom_out) a.bloom_out[static_cast<uint32_t>(k) & (BLOOM_BITS - 1)] = 1;
       const uint32_t rel = static_cast<uint32_t>(k) - origin;
       if (rel > range) { flags |= 4u; continue; }
       const uint32_t table_word = rel >> 5, bit = 1u << (rel & 31);
@@ -2559,6 +2567,7 @@ __device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, con
   __syncthreads();
   for (uint32_t i = tid; i < span; i += 256) {
     const uint32_t bits = s_bits[i], base = s_base[i];
+    if (bits && bloom_words) atomicOr(bloom_words + ((first_word + i + origin_word) & (BLOOM_BITS / 32 - 1)), bits);
     if (i == 0 || i + 1 == span) {   // may be shared with a neighbouring slice: add the bits; the base comes from the slice with the word's first key
       if (bits) atomicOr(reinterpret_cast<uint32_t*>(entries + first_word + i), bits);
       if (base) reinterpret_cast<uint32_t*>(entries + first_word + i)[1] = base - 1u;
@@ -2606,8 +2615,14 @@ __global__ __launch_bounds__(256, 5) void rank_table_fill_checked(MaterializeArg
     __hip_atomic_store(record + 1, high, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(record + 2, static_cast<uint64_t>(s_flags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = arrived + 1 == gridDim.x ? 1u : 0u;
+    // Arrival in two levels -- 32 counters (one 128-byte line each), then one: agent-scope atomics on ONE word retire at ~88 per
+    // microsecond, and 1 831 workgroups queueing on it were 22 us of this kernel.
+    const uint32_t lanes = gridDim.x < CHECKED_FILL_TICKETS ? gridDim.x : CHECKED_FILL_TICKETS, mine = blockIdx.x % lanes;
+    const uint32_t quota = gridDim.x / lanes + (mine < gridDim.x % lanes ? 1u : 0u);
+    uint32_t last = 0;
+    if (__hip_atomic_fetch_add(ticket + 32 * (1 + mine), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == quota)
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == lanes ? 1u : 0u;
+    s_last = last;
   }
   __syncthreads();
   if (!s_last) return;
@@ -2759,6 +2774,7 @@ struct StageClock {
 struct BuildSide {
   DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags, rank_entries, partials;
   bool hint_allows_duplicates = false;
+  bool bloom_is_bits = false;    // the filter is 2^20 BITS (rank_table_fill_checked folds the table's presence words into it), not one byte per bit
   bool hinted = false;           // the rank table was filled from the column's key hint: the join must confirm build_verdict_host() at its end
   uint64_t hint_min = 0, hint_max = 0;
   uint64_t n = 0;
@@ -2772,8 +2788,10 @@ struct BuildSide {
 // `existence_only`: the join only asks whether a key exists (Semi / Anti without secondary predicates -- the reference's
 // ExistenceOnly hash table, join_hash_steps.hpp:97-236): a sorted dense build column WITH duplicates still gets a rank table, of
 // which only the presence bits mean anything.
+// `bit_filter_ok`: whoever probes reads the Bloom filter as 2^20 bits (the kernels of join_pkfk.hpp) -- what the one-pass hinted build
+// produces; everything else reads one byte per bit.
 static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, uint32_t hashed_type, bool allow_rank_table, bool existence_only,
-                               BuildSide& b, hipStream_t stream) {
+                               bool bit_filter_ok, BuildSide& b, hipStream_t stream) {
   const uint32_t n_slices = build->n_slices;
   DeviceBuffer counts, offsets;
   HY_TRY(counts.alloc(4 * size_t{n_slices + 1}));
@@ -2792,7 +2810,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   }
   const bool identity_candidate = dense && build->rows && uniform_chunks && build->host_segments[0].size > 0 && allow_rank_table && !getenv("HY_JOIN_NO_RANK_TABLE") &&
                                   !getenv("HY_JOIN_NO_IDENTITY");
-  bool hinted = identity_candidate && build->join_hint.state.load(std::memory_order_acquire) == 1 &&
+  bool hinted = identity_candidate && bit_filter_ok && build->join_hint.state.load(std::memory_order_acquire) == 1 &&
                 (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) && !getenv("HY_JOIN_NO_HINT");
   for (uint32_t c = 0; c < build->n_chunks && hinted; ++c) {   // rank_table_fill_checked reads int32 keys through SliceViews, 16 bytes per load
     const hy_segment& seg = build->host_segments[c];
@@ -2843,6 +2861,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       d.n_buckets = 1;
     };
     if (hinted) {
+      const MaterializeArgs& m_in = m;
       // an earlier join over this column found a primary key in [key_min, key_max]: one pass fills the table and checks every key
       {
         JoinMailbox* unused_host = nullptr;
@@ -2852,21 +2871,30 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       const uint64_t key_min = build->join_hint.key_min.load(std::memory_order_relaxed);
       uint64_t key_max = build->join_hint.key_max.load(std::memory_order_relaxed);
       if (getenv("HY_JOIN_BREAK_HINT") && key_max - key_min > 64) key_max -= 64;   // tests: a hint that does not hold
-      const uint64_t words = ((key_max - key_min) >> 5) + 1;
-      HY_TRY(b.rank_entries.alloc(8 * (words + 1) + 16));
+      const uint64_t origin = key_min & ~uint64_t{31};   // (the table starts at a multiple of 32: a key's bit in its table word is its bit in the Bloom filter's word)
+      const uint64_t words = ((key_max - origin) >> 5) + 1;
+      const size_t ticket_bytes = 128 * (size_t{CHECKED_FILL_TICKETS} + 1);
+      HY_TRY(b.rank_entries.alloc(8 * (words + 2) + ticket_bytes));
       HY_TRY(b.partials.alloc(32 * size_t{n_slices}));
       u32x2_t* entries = b.rank_entries.as<u32x2_t>();
       {   // the table | the arrival counter, and the Bloom filter
-        const size_t table_vectors = (8 * (words + 1) + 16 + 15) / 16, bloom_vectors = want_bloom ? BLOOM_BITS / 16 : 0;
+        const size_t table_vectors = (8 * (words + 2) + ticket_bytes + 15) / 16, bloom_vectors = want_bloom ? BLOOM_BITS / 8 / 16 : 0;   // (the filter as bits: 128 KB)
         hipLaunchKernelGGL(zero_vectors, dim3(static_cast<uint32_t>(std::min<size_t>(2048, (table_vectors + bloom_vectors + 255) / 256))), dim3(256), 0, stream,
                            reinterpret_cast<u32x4_t*>(entries), table_vectors, b.bloom.as<u32x4_t>(), bloom_vectors);
       }
       build_verdict_host()->done = 0;
+      MaterializeArgs m = m_in;
+      if (const char* debug = getenv("HY_JOIN_FILL_DEBUG")) {   // timing experiments only (results are wrong): 1 no filter, 2 no table either
+        m.bloom_out = nullptr;
+        if (atoi(debug) >= 2) m.keep_nulls = 0xFFFFFFFFu;
+      }
       hipEvent_t fill_started = nullptr, fill_stopped = nullptr;
       profile_events(&fill_started, &fill_stopped, HY_KERNEL_JOIN_BUILD);
-      hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, key_min, key_max - key_min, entries,
-                            b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 1), build_verdict_device());
-      identity_table(entries, key_min, key_max);
+      hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries,
+                            b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 2), build_verdict_device());
+      identity_table(entries, origin, key_max);
+      b.directory.key_min = key_min;
+      b.bloom_is_bits = want_bloom;
       b.hinted = true;
       b.hint_allows_duplicates = existence_only;
       b.hint_min = key_min;
@@ -3227,7 +3255,18 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   for (uint32_t c = 0; c < build->n_chunks && pack_build_ids; ++c) pack_build_ids = build->host_segments[c].size <= 65536;
   BuildSide b;
   StageClock clock;
-  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, semi_anti && n_secondary == 0, b, stream));
+  // Will the probe side take the kernels of join_pkfk.hpp if the build side turns out to be a rank table?  (Everything that does not
+  // depend on the build side: probe segments that SliceViews describe -- int32 values / FrameOfReference offsets, no NULLs, 16-byte
+  // aligned --, counts and pair indices in 32 bits, lane-ordered LDS atomics.)
+  bool probe_views = !probe->is_reference && probe->n_slices > 0 && !getenv("HY_JOIN_NO_FETCH_AHEAD");
+  for (uint32_t c = 0; c < probe->n_chunks && probe_views; ++c) {
+    const hy_segment& seg = probe->host_segments[c];
+    probe_views = !seg.nulls && reinterpret_cast<uintptr_t>(seg.data) % 16 == 0 &&
+                  ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
+  }
+  const bool probe_takes_pk = probe_views && hashed_type == 0 && n_secondary == 0 && probe->rows < 0xFFFF0000ull && !getenv("HY_JOIN_NO_PKFK") &&
+                              (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
+  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, semi_anti && n_secondary == 0, probe_takes_pk, b, stream));
   const bool rank_path = b.rank.entries != nullptr;
   // A rank table filled from the build column's key hint (rank_table_fill_checked) is confirmed when the join's kernels have finished:
   // if the column is not what the hint said, the hint is dropped, whatever the join wrote is discarded and the caller runs it again.
@@ -3238,14 +3277,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     if (!ok) { build->join_hint.state.store(2, std::memory_order_release); *retry = true; }
     return ok;
   };
-  // the probe column's segments are all ones a SliceView describes (int32 values / FrameOfReference offsets, no NULLs, 16-byte
-  // aligned): pass 1 is the wave-per-tile kernel with wide loads
-  bool fetch_ahead = rank_path && !probe->is_reference && !getenv("HY_JOIN_NO_FETCH_AHEAD");
-  for (uint32_t c = 0; c < probe->n_chunks && fetch_ahead; ++c) {
-    const hy_segment& seg = probe->host_segments[c];
-    fetch_ahead = !seg.nulls && reinterpret_cast<uintptr_t>(seg.data) % 16 == 0 &&
-                  ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
-  }
+  const bool fetch_ahead = rank_path && probe_views;   // pass 1 of the general rank-table kernels is the wave-per-tile kernel with wide loads
   t_last_join_used_rank_table = rank_path ? (b.rank.identity_rows ? 2 : 1) : 0;
   t_last_join_used_pkfk = 0;
   t_last_join_hinted_attempt = b.hinted ? 1 : 0;
@@ -3266,9 +3298,8 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
 
   // The primary-key / foreign-key probe (join_pkfk.hpp): rank table, probe segments that SliceViews describe, keys of both sides
   // int32 values (32-bit distances), counts and pair indices in 32 bits, lane-ordered LDS atomics.
-  const bool pk_path = rank_path && fetch_ahead && probe->n_slices > 0 && probe->rows < 0xFFFF0000ull && !getenv("HY_JOIN_NO_PKFK") &&
-                       static_cast<int64_t>(b.rank.key_min) >= INT32_MIN && static_cast<int64_t>(b.rank.key_min + b.rank.range) <= INT32_MAX &&
-                       (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
+  const bool pk_path = rank_path && probe_takes_pk && static_cast<int64_t>(b.rank.key_min) >= INT32_MIN && static_cast<int64_t>(b.rank.key_min + b.rank.range) <= INT32_MAX;
+  if (b.bloom_is_bits && !pk_path) return fail(HY_ERR_DEVICE, "join: a bit filter was built for kernels that do not run");   // (cannot happen: a hinted build has int32 keys)
   if (pk_path) {
     const uint32_t n_tiles = probe->n_slices * PK_TILES_PER_SLICE, partitions = 1u << radix_bits;
     const uint32_t stride = (n_tiles + 1 + 3) & ~3u;
@@ -3305,6 +3336,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     k.keep_nulls = keep_nulls_probe;
     k.n_groups = n_groups;
     k.build_bloom = probe_filtered ? b.bloom.as<uint8_t>() : nullptr;
+    k.bloom_is_bits = b.bloom_is_bits ? 1u : 0u;
     k.rank = b.rank;
     k.ids32 = b.directory.ids32;
     k.row_ids = b.directory.row_ids;

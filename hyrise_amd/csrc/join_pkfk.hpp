@@ -72,7 +72,7 @@ struct PkArgs {
   hy_row_id* probe_out;
   uint64_t* slice_offsets;
   uint32_t cut_blocks;             // pk_emit: its first cut_blocks workgroups compute the PosList cuts (pk_cut_slice)
-  uint32_t reserved;
+  uint32_t bloom_is_bits;          // build_bloom holds 2^20 bits (a hinted build, rank_table_fill_checked), not one byte per bit
   uint64_t* trace;                 // debug (HY_JOIN_TRACE): 6 wall-clock stamps per pk_emit tile, else nullptr
 };
 
@@ -85,6 +85,14 @@ __device__ __forceinline__ SliceView pk_tile_view(const PkArgs& a, uint32_t tile
     view.row_count = view.row_count > offset ? (view.row_count - offset < PK_TILE ? view.row_count - offset : PK_TILE) : 0;
   }
   return view;
+}
+
+// Is the bit of `key` set in the build side's Bloom filter (join_hash_steps.hpp:354-358: index = hash & 0xFFFFF, the hash of an integer
+// key is the key)?
+__device__ __forceinline__ bool pk_bloom_test(const PkArgs& a, uint32_t key) {
+  const uint32_t index = key & (BLOOM_BITS - 1);
+  if (a.bloom_is_bits) return (reinterpret_cast<const uint32_t*>(a.build_bloom)[index >> 5] >> (index & 31)) & 1;
+  return a.build_bloom[index] != 0;
 }
 
 // XCD x = blockIdx % 8 takes the x-th eighth of the tiles (block_tile in join.hip): neighbouring tiles, whose output runs are
@@ -101,6 +109,12 @@ __device__ __forceinline__ bool pk_emits(uint32_t mode, bool found, bool* null_p
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------------------------------
+// One workgroup per tile; a wave owns 2048 rows of it (one FrameOfReference block): four batches of 512 rows, a lane holds eight
+// consecutive rows of each (16-byte loads).  Where the 50 us go (measured by switching parts off): 43 are the tile's words arriving --
+// a plain read of the column in this launch shape takes 23 (tools/hbm_read.hip); a workgroup spends two dependent round trips, the
+// tile's view and then its words, of its short life waiting -- lookups and LDS atomics are the other 7.  Persistent workgroups that
+// request their next tile's words ahead were SLOWER (76 us): loads return in order (one counter, vmcnt), so either the lookups queue
+// behind the prefetch or the prefetch costs 48 more live registers.
 template <uint32_t WIDTH>
 __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& view, uint32_t wave, uint32_t lane, uint32_t* cells) {
   const char* base = static_cast<const char*>(view.data);
@@ -116,8 +130,9 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
   const uint32_t bias = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + wave_first) / HY_FOR_BLOCK_SIZE]);
   const uint32_t origin = static_cast<uint32_t>(a.rank.key_min), range = static_cast<uint32_t>(a.rank.range);
   const uint32_t mask = a.radix_bits ? (1u << a.radix_bits) - 1 : 0u;
+  const uint32_t copy = ((lane >> 4) & 3) | ((lane & 1) << 2);   // (lanes 16 apart -- 32 orders, the period of dbgen's sparse keys mod 128 -- meet in one partition: they use different copies)
   // Two groups of 1024 rows: a group's sixteen lookups per lane are in flight together (counting only needs an entry's presence bits,
-  // its first word), and the kernel stays below 64 registers -- eight workgroups per CU hide each other's round trips.
+  // its first word), and the kernel stays at 64 registers -- eight workgroups per CU hide each other's round trips.
 #pragma unroll
   for (uint32_t g = 0; g < PK_COUNT_BATCHES; g += 2) {
     uint32_t bits[2][8];
@@ -143,14 +158,13 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
         uint32_t miss = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 8; ++j) {
-          if (((valid & ~found) >> j) & 1) miss |= (a.build_bloom[(batch_word<WIDTH>(words[g + b], j) + bias) & (BLOOM_BITS - 1)] == 0 ? 1u : 0u) << j;
+          if (((valid & ~found) >> j) & 1) miss |= (pk_bloom_test(a, batch_word<WIDTH>(words[g + b], j) + bias) ? 0u : 1u) << j;
         }
         valid &= ~miss;
       }
       // neighbouring rows share their key (four lineitems per order): the lane's eight consecutive rows leave as one LDS atomic per RUN
       // of equal partitions (same-address atomics serialise)
       uint32_t run_partition = 0xFFFFFFFFu, run_value = 0;
-      const uint32_t copy = ((lane >> 4) & 3) | ((lane & 1) << 2);   // (lanes 16 apart -- 32 orders, the period of dbgen's sparse keys mod 128 -- meet in one partition: they use different copies)
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
         if (!((valid >> j) & 1)) continue;
@@ -393,7 +407,7 @@ __device__ __forceinline__ void pk_lookup_rows(const PkArgs& a, const SliceView&
     if (a.build_bloom && !a.keep_nulls && __any((valid & ~found) != 0)) {   // join_hash_steps.hpp:354-358
 #pragma unroll
       for (uint32_t j = 0; j < N; ++j) {
-        if (((valid & ~found) >> j) & 1) { if (a.build_bloom[raw[j] & (BLOOM_BITS - 1)] == 0) valid &= ~(1u << j); }
+        if (((valid & ~found) >> j) & 1) { if (!pk_bloom_test(a, raw[j])) valid &= ~(1u << j); }
       }
     }
 #pragma unroll

@@ -205,6 +205,9 @@ hy_status hy_profile_read(float* total_milliseconds, uint32_t* launches);
 enum { HY_KERNEL_OTHER = 0, HY_KERNEL_SCAN = 1, HY_KERNEL_JOIN_PROBE = 2, HY_KERNEL_JOIN_COUNT = 3, HY_KERNEL_JOIN_BUILD = 4, HY_KERNEL_AGGREGATE = 5,
        HY_KERNEL_PROJECTION = 6, HY_KERNEL_KINDS = 8 };
 hy_status hy_profile_read_kernel(uint32_t kernel, float* total_milliseconds, uint32_t* launches);
+/* What such an event pair measures beyond the kernel itself (the pair is stamped from the dispatch packet): the elapsed time of an
+ * empty kernel, median of 32 launches, measured once per process.  A profiler's per-kernel duration is shorter by about this much. */
+hy_status hy_profile_event_overhead(float* milliseconds);
 
 /* ---- residency cache: a column made device-visible once (encoded segments are immutable,
  *      abstract_encoded_segment.hpp:12-17) ------------------------------------------------------------------------ */

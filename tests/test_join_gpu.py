@@ -663,6 +663,22 @@ def test_primary_key_hint(device, monkeypatch):
         assert lib.hy_debug_join_build_was_hinted() == (0 if broken else 1)     # a dropped hint stays dropped
         assert_join_equal(third, want, abi.JOIN_INNER, "third join")
         assert join_hash_count(build, probe, abi.JOIN_INNER) == want.n_pairs
+    # The build side's Bloom filter decides which partner-less probe rows count as materialised (they move the 131 070-element cuts,
+    # join_hash_steps.hpp:354-358).  The two-pass build keeps it as one byte per bit, the hinted one-pass build folds the rank table's
+    # presence words into 2^20 bits: probe keys that are no build keys but share their low 20 bits with one, and keys that do not.
+    keys = np.arange(450_000, dtype=np.int32) * 3 + 40                 # 40 .. 1 350 037: more than 2^20 apart
+    alias = keys[:90_000] + (1 << 20)                                  # (2^20 mod 3 == 1: none of them is a build key, each has a build key's filter bit)
+    probe_values = np.sort(np.concatenate([rng.choice(keys, 400_000), rng.choice(alias, 200_000), rng.integers(41, 1_350_000, 100_000).astype(np.int32)]).astype(np.int32))
+    build_host = build_column(keys, None, 65535, abi.ENC_UNENCODED)
+    probe_host = build_column(probe_values, None, 65535, abi.ENC_FRAME_OF_REFERENCE)
+    build, probe = DeviceColumn(build_host), DeviceColumn(probe_host)
+    for radix_bits in (1, None):
+        want = oracle_join(build_host, probe_host, abi.JOIN_INNER, radix_bits)
+        assert want.c.n_slices > (1 << int(want.c.radix_bits))        # (partitions with cuts inside)
+        for attempt in range(2):
+            got = join_hash(build, probe, abi.JOIN_INNER, radix_bits)
+            assert lib.hy_debug_join_build_was_hinted() == (0 if radix_bits == 1 and attempt == 0 else 1)
+            assert_join_equal(got, want, abi.JOIN_INNER, f"filter aliases, radix {radix_bits}, attempt {attempt}")
 
 
 @pytest.mark.parametrize("mode", SEMI)

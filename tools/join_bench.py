@@ -25,6 +25,7 @@ def main():
     n = data.n_lineitems
     variants = [("default (edge lines write-back)", {}), ("nontemporal stores", {"HY_JOIN_STORES": "0"}), ("write-back stores", {"HY_JOIN_STORES": "1"}),
                 ("no key hint (two-pass build)", {"HY_JOIN_NO_HINT": "1"}),
+                ("debug: checked fill without the filter", {"HY_JOIN_FILL_DEBUG": "1"}), ("debug: checked fill, loads and extent only", {"HY_JOIN_FILL_DEBUG": "2"}),
                 ("general rank-table kernels (round 2)", {"HY_JOIN_NO_PKFK": "1", "HY_JOIN_NO_HINT": "1"}), ("default again", {})]
     for name, env in variants:
         for k, v in env.items():

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Summarises the rocprofv3 runs of tools/collect_profiles.sh over `python bench.py` itself into the files committed under profiles/:
+  r03_bench_kernel_stats.csv   per (kernel, grid size): launches, average / min / max duration -- from the kernel trace of ONE bench.py
+                               process, whose own JSON line (HIP-event kernel_ms measured inside that process) is r03_bench_traced.json
+  r03_bench_pmc.json           per kernel (the launch shape of the headline step = the shape with most launches): FETCH_SIZE / WRITE_SIZE per
+                               launch and hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE doubled: gfx950 tallies the 128-byte
+                               requests of wide coalesced reads at 64 bytes, MI355X_MICROARCH.md "HBM"; WRITE_SIZE as reported); "step" = the
+                               kernels of one TableScan + JoinHash step added up, "hy_join_hash" = the join's.  bench.py reads this file for
+                               roofline.traffic.
+usage: summarize_bench_profile.py <dir with trace/ fetch/ write/> <commit>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+STEP = ("scan_slices", "prepare_jobs", "zero_vectors", "rank_table_fill_checked", "pk_count", "pk_scan", "pk_emit")
+JOIN = STEP[2:]
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("void ", "").replace("hy::", "").strip()
+
+
+def base(name):
+    return short(name).split("<")[0]
+
+
+def main():
+    root, commit = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
+    groups = collections.defaultdict(list)
+    for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if "hy::" in row["Kernel_Name"]:
+                    groups[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    with open(os.path.join(root, "r03_bench_kernel_stats.csv"), "w", newline="") as fh:
+        writer = csv.writer(fh)
+        writer.writerow(["kernel", "grid_size_x", "launches", "average_us", "min_us", "max_us", "total_ms"])
+        for (name, grid), durations in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            writer.writerow([name, grid, len(durations), f"{sum(durations) / len(durations) / 1e3:.2f}", f"{min(durations) / 1e3:.2f}", f"{max(durations) / 1e3:.2f}", f"{sum(durations) / 1e6:.3f}"])
+    # the headline shape of every kernel: the (name, grid) with most launches
+    headline = {}
+    for (name, grid), durations in groups.items():
+        if base(name) not in headline or len(durations) > headline[base(name)][2]:
+            headline[base(name)] = (name, grid, len(durations), sum(durations) / len(durations) / 1e3)
+    for name in STEP:
+        if name in headline:
+            print(f"{headline[name][0]:40s} grid {headline[name][1]:9d} launches {headline[name][2]:5d} avg {headline[name][3]:8.1f} us")
+
+    def counters(leg, counter):
+        per = collections.defaultdict(lambda: [0.0, 0])
+        for path in glob.glob(os.path.join(root, leg, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get("Counter_Name") == counter and "hy::" in row.get("Kernel_Name", ""):
+                        cell = per[(short(row["Kernel_Name"]), int(row["Grid_Size"]) if "Grid_Size" in row else int(row.get("Grid_Size_X", 0)))]
+                        cell[0] += float(row["Counter_Value"])
+                        cell[1] += 1
+        return per
+
+    fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
+    kernels = {}
+    for name, (full, grid, launches, average) in headline.items():
+        f, w = fetch.get((full, grid), [0.0, 0]), write.get((full, grid), [0.0, 0])
+        if not f[1] and not w[1]:
+            continue
+        kernels[name] = {"kernel": full, "grid_size_x": grid, "launches_counted": max(f[1], w[1]), "FETCH_SIZE_KB_per_launch": f[0] / f[1] if f[1] else None,
+                         "WRITE_SIZE_KB_per_launch": w[0] / w[1] if w[1] else None,
+                         "hbm_bytes_per_launch": (f[0] / f[1] * 2048 if f[1] else 0) + (w[0] / w[1] * 1024 if w[1] else 0), "average_us_traced": average}
+    for total, members in (("step", STEP), ("hy_join_hash", JOIN)):
+        if all(m in kernels for m in members if m not in ("prepare_jobs", "zero_vectors")):
+            kernels[total] = {"kernels": [m for m in members if m in kernels], "hbm_bytes_per_launch": sum(kernels[m]["hbm_bytes_per_launch"] for m in members if m in kernels)}
+    summary = {"collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) over `python bench.py`, commit {commit}", "kernels": kernels,
+               "note": "bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024 per launch of the kernel's headline shape (the grid size with most launches); memory-side cache hits included"}
+    with open(os.path.join(root, "r03_bench_pmc.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    for name in ("scan_slices", "pk_emit", "pk_count", "rank_table_fill_checked", "step", "hy_join_hash"):
+        if name in kernels:
+            print(f"{name:28s} hbm bytes per launch {kernels[name]['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
