@@ -666,7 +666,11 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   column->d_row_base = reinterpret_cast<uint64_t*>(base + at_row_base);
   column->d_parts = reinterpret_cast<Part*>(base + at_parts);
   column->d_first_slice = reinterpret_cast<uint32_t*>(base + at_first_slice);
-  const hipError_t err = hipMemcpy(block, staging.data(), total, hipMemcpyHostToDevice);
+  // The block comes from this thread's pool: whoever held it before may have released it while kernels on the thread's stream still
+  // read it (pool blocks are recycled in STREAM order).  The upload therefore goes onto that stream -- a copy on the NULL stream is not
+  // ordered behind a non-blocking stream -- and the host waits for it (`staging` dies with this call).
+  hipError_t err = hipMemcpyAsync(block, staging.data(), total, hipMemcpyHostToDevice, t_stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(t_stream);
   if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "descriptor upload failed: %s", hipGetErrorString(err)));
   *out = column;
   return HY_OK;
@@ -674,9 +678,10 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
 
 hy_status hy_column_destroy(hy_column* column) {
   if (!column) return HY_OK;
-  // The descriptor block goes back to the pool and may be handed out again at once: wait for whatever still reads it (hipFree,
-  // which released the tables before they were pooled, waits for the device, too).
-  if (column->descriptors_pooled) (void)hipDeviceSynchronize();
+  // The descriptor block goes back to this thread's pool and is handed out again in the order of this thread's stream: wait for that
+  // stream only (a column that other threads still use must not be destroyed: the caller's contract, as for any shared object) --
+  // a device-wide synchronise here stalled every thread's stream at every step of an operator chain.
+  if (column->descriptors_pooled) (void)hipStreamSynchronize(t_stream);
   for (void* p : column->owned) (void)hipFree(p);
   for (auto& block : column->pooled) pool_release(block.second, block.first);
   if (!column->descriptors_pooled) {

@@ -428,6 +428,10 @@ class HipExecutor:
 
 # ---- AggregateHash ---------------------------------------------------------------------------------------------------
 _MERGEABLE = (abi.AGG_MIN, abi.AGG_MAX, abi.AGG_SUM, abi.AGG_AVG, abi.AGG_COUNT, abi.AGG_ANY)
+# STDDEV_SAMP travels as two cells: (SUM, COUNT) and (M2 = sum of squared deviations from the rank's mean, COUNT); two partials combine
+# as  M2 = M2_a + M2_b + (mean_b - mean_a)^2 * n_a * n_b / (n_a + n_b)  (the pairwise update of Chan, Golub, LeVeque; the reference's own
+# per-row update, abstract_aggregate_operator.hpp:83-113, is its n_b == 1 case).  COUNT(DISTINCT) has its own exchange (sharded_aggregate).
+_MOMENT_SUM, _MOMENT_M2 = 1000, 1001
 _INT_TYPES = (abi.TYPE_INT, abi.TYPE_LONG)
 
 
@@ -449,9 +453,14 @@ def _local_partials(ex, groupby, aggregates):
 
     cells = []
     for function, column in aggregates:
+        if function == _MOMENT_M2:     # (value = the rank's STDDEV_SAMP, turned into M2 below)
+            cells.append((want(abi.AGG_STDDEV_SAMP, column), want(abi.AGG_COUNT, column)))
+            continue
+        if function == _MOMENT_SUM:
+            function = abi.AGG_SUM
         if function not in _MERGEABLE:
-            raise NotImplementedError(f"aggregate function {function} has no cross-rank merge rule here (COUNT DISTINCT needs the value sets, "
-                                      "STDDEV_SAMP the (n, mean, M2) triple): run it on one GPU")
+            raise NotImplementedError(f"aggregate function {function} has no cross-rank merge rule in this helper (sharded_aggregate splits COUNT DISTINCT "
+                                      "and STDDEV_SAMP into mergeable parts first)")
         cells.append((want(abi.AGG_SUM if function == abi.AGG_AVG else function, column), want(abi.AGG_COUNT, column)))
     key_cells = [want(abi.AGG_ANY, g) for g in groupby]
     shape = groupby[0] if groupby else next((c for _, c in aggregates if c is not None), None)
@@ -468,6 +477,11 @@ def _local_partials(ex, groupby, aggregates):
     keys = [tuple(columns[c][g] for c in key_cells) for g in range(n)]
     rows = [(int(first.row_ids[g][0]), int(first.row_ids[g][1])) for g in range(n)]
     values = [[(columns[v][g], columns[c][g]) for v, c in cells] for g in range(n)]
+    for a, (function, _) in enumerate(aggregates):
+        if function == _MOMENT_M2:   # s -> M2 = s^2 (n - 1); one row: 0
+            for g in range(n):
+                deviation, count = values[g][a]
+                values[g][a] = (0.0 if deviation is None else float(deviation) ** 2 * (int(count) - 1), count)
     return keys, rows, values
 
 
@@ -494,16 +508,98 @@ def _aggregate_is_float(function, column):
     return column is not None and column.data_type in (abi.TYPE_FLOAT, abi.TYPE_DOUBLE) and function != abi.AGG_COUNT
 
 
-def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hint=None):
+def shared_long_strings(comm, local_strings):
+    """The distinct strings of five or more bytes of a string GROUP BY column over ALL ranks, in one order on every rank (rank by
+    rank, first appearance inside a rank): what string_keys.AggregateKeyNames(shared_long_strings=...) needs to hand out the same
+    id for the same string everywhere.  local_strings: this rank's strings (any iterable of str / bytes; short ones are ignored)."""
+    seen, mine = set(), []
+    for value in local_strings:
+        data = value if isinstance(value, bytes) else str(value).encode("utf-8")
+        if len(data) >= 5 and data not in seen:
+            seen.add(data)
+            mine.append(data)
+    gathered = [None] * comm.world
+    comm.dist.all_gather_object(gathered, mine)
+    out, seen = [], set()
+    for part in gathered:
+        for data in part:
+            if data not in seen:
+                seen.add(data)
+                out.append(data)
+    return out
+
+
+def _check_key_names(key_names):
+    """AggregateKeyNames of strings of five or more bytes are ids in order of first appearance (aggregate_hash.cpp:903-914): names
+    inside one process.  Merging groups across ranks by key VALUE needs ids every rank agrees on."""
+    for names in key_names or ():
+        if names is not None and names.has_long_strings and not names.shared:
+            raise NotImplementedError("GROUP BY a string column with entries of five or more bytes across ranks needs shared key names: "
+                                      "string_keys.AggregateKeyNames(shared_long_strings=distributed.shared_long_strings(comm, strings))")
+
+
+def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hint=None, key_names=None):
     """groupby / aggregates: THIS RANK's chunk range of the columns (executor columns); first_chunk: the range's first chunk
     id in the whole table.  Every rank returns the same list of (key tuple, [aggregate values]) in the reference's group
     order.  SUM / AVG over floating-point columns: double additions in a different order than the sequential reference
-    (1e-9 relative, as on one GPU); everything else exact."""
-    keys, rows, values = _local_partials(ex, groupby, aggregates)
+    (1e-9 relative, as on one GPU); everything else exact.  key_names: per GROUP BY column the string_keys.AggregateKeyNames its
+    values came from, or None for numeric columns (string columns MUST be declared: see _check_key_names)."""
+    _check_key_names(key_names)
+    # STDDEV_SAMP -> (sum, count) + (M2, count); COUNT(DISTINCT x) -> its own exchange of the distinct (group, x) tuples
+    internal, layout = [], []   # layout[a] = ("plain", index) | ("stddev", index of the sum cell) | ("distinct", column)
+    for function, column in aggregates:
+        if function == abi.AGG_STDDEV_SAMP:
+            layout.append(("stddev", len(internal)))
+            internal += [(_MOMENT_SUM, column), (_MOMENT_M2, column)]
+        elif function == abi.AGG_COUNT_DISTINCT:
+            layout.append(("distinct", column))
+        else:
+            layout.append(("plain", len(internal)))
+            internal.append((function, column))
+    keys, rows, values = _local_partials(ex, groupby, internal)
     shape = groupby[0] if groupby else next((c for _, c in aggregates if c is not None), None)
     local_rows = ex.rows_of(shape) if shape is not None else 0
-    return _merge_partials(comm, keys, rows, values, [f for f, _ in aggregates], [_aggregate_is_float(f, c) for f, c in aggregates],
-                           [g.data_type for g in groupby], local_rows, first_chunk)
+    key_types = [g.data_type for g in groupby]
+    merged = _merge_partials(comm, keys, rows, values, [f for f, _ in internal], [f in (_MOMENT_SUM, _MOMENT_M2) or _aggregate_is_float(f, c) for f, c in internal],
+                             key_types, local_rows, first_chunk, raw_cells=True)
+    distinct = {}
+    for a, (kind, column) in enumerate(layout):
+        if kind != "distinct":
+            continue
+        if len(groupby) + 1 > 4:
+            raise NotImplementedError("COUNT(DISTINCT) across ranks groups by the GROUP BY columns and the counted column: at most three GROUP BY columns")
+        # the rank's distinct (group key, value) tuples = the groups of GROUP BY (keys..., value) (DISTINCT is a GROUP BY without aggregates,
+        # aggregate_hash.cpp:1024-1061); merged across the ranks like any groups; NULL values are not counted
+        tuple_keys, tuple_rows, tuple_values = _local_partials(ex, list(groupby) + [column], [(abi.AGG_COUNT, None)])
+        tuples = _merge_partials(comm, tuple_keys, tuple_rows, tuple_values, [abi.AGG_COUNT], [False], key_types + [column.data_type], local_rows, first_chunk,
+                                 force_general=True)
+        tally = {}
+        for key, _ in tuples:
+            if key[-1] is not None:
+                tally[key[:-1]] = tally.get(key[:-1], 0) + 1
+        distinct[a] = tally
+    out = []
+    for key, cells in merged:
+        row = []
+        for a, (kind, where) in enumerate(layout):
+            if kind == "distinct":
+                row.append(distinct[a].get(key, 0))
+            elif kind == "stddev":
+                (total, count), (m2, _) = cells[where], cells[where + 1]
+                row.append(None if count < 2 or m2 is None else float(np.sqrt(m2 / (count - 1))))
+            else:
+                value, count = cells[where]
+                function = aggregates[a][0]
+                if function == abi.AGG_COUNT:
+                    row.append(count)
+                elif count == 0 or value is None:
+                    row.append(None)
+                elif function == abi.AGG_AVG:
+                    row.append(float(value) / count)
+                else:
+                    row.append(value)
+        out.append((key, row))
+    return out
 
 
 def expression_type(tree):
@@ -534,12 +630,13 @@ def _tree_key(tree):
     return (tree[0], _tree_key(tree[1]), _tree_key(tree[2]))
 
 
-def sharded_scan_project_aggregate(comm, ex, filters, groupby, aggregates, first_chunk):
+def sharded_scan_project_aggregate(comm, ex, filters, groupby, aggregates, first_chunk, key_names=None):
     """TableScan(s) -> Projection -> AggregateHash over a chunk-sharded table: every rank runs the fused pass
     (ex.scan_project_aggregate) over ITS chunks of the columns -- filters [(column, predicate)], groupby [column], aggregates
     [(MIN / MAX / SUM / AVG / COUNT, expression tree or None)] -- and the partial groups are merged like sharded_aggregate's
     (same exchange, same group order; the immediate-key shortcut is decided on the rows that passed the filters on all ranks).
     The key values travel as MIN(key column) of the group (all its rows hold the same value)."""
+    _check_key_names(key_names)
     plan, index = [], {}
 
     def want(function, tree):
@@ -577,7 +674,7 @@ def sharded_scan_project_aggregate(comm, ex, filters, groupby, aggregates, first
     return merged
 
 
-def _merge_partials(comm, keys, rows, values, functions, is_float_aggregate, key_types, local_rows, first_chunk):
+def _merge_partials(comm, keys, rows, values, functions, is_float_aggregate, key_types, local_rows, first_chunk, raw_cells=False, force_general=False):
     """The exchange and the merge behind sharded_aggregate / sharded_scan_project_aggregate.  keys / rows / values: this rank's groups (key
     tuple, first row as (chunk, offset) of the shard, per aggregate (value, count of non-NULL inputs)); local_rows: the rows of the
     aggregate's input on this rank."""
@@ -606,7 +703,7 @@ def _merge_partials(comm, keys, rows, values, functions, is_float_aggregate, key
     slots = 1
     for s in spans:
         slots *= s
-    fixed = integer_keys and slots <= FIXED_SLOT_LIMIT
+    fixed = integer_keys and slots <= FIXED_SLOT_LIMIT and not force_general and _MOMENT_M2 not in functions   # (moments merge pairwise: the general path)
 
     merged = {}   # key tuple -> [first row, last row, [[value, count], ...]]
     if fixed:
@@ -714,18 +811,29 @@ def _merge_partials(comm, keys, rows, values, functions, is_float_aggregate, key
                 if entry is None:
                     entry = merged[key] = [first, first, [[None, 0] for _ in range(n_aggregates)]]
                 entry[0], entry[1] = min(entry[0], first), max(entry[1], first)
-                for a in range(n_aggregates):
+                for a in reversed(range(n_aggregates)):   # (descending: an M2 cell sits behind its sum cell and needs that cell's OLD value)
                     base = 2 * n_keys + 1 + 3 * a
                     count, has_value = int(line[base]), bool(line[base + 1])
                     is_float = is_float_aggregate[a]
                     value = (float(np.int64(line[base + 2]).view(np.float64)) if is_float else int(line[base + 2])) if has_value else None
                     cur = entry[2][a]
+                    if functions[a] == _MOMENT_M2 and count:
+                        # pairwise update: (n_a, sum_a, M2_a) so far, (n_b, sum_b, M2_b) arriving; the sum cell is a - 1
+                        sum_base = 2 * n_keys + 1 + 3 * (a - 1)
+                        n_b, sum_b = count, float(np.int64(line[sum_base + 2]).view(np.float64)) if line[sum_base + 1] else 0.0
+                        n_a, sum_a = entry[2][a - 1][1], entry[2][a - 1][0] or 0.0
+                        m2 = (cur[0] or 0.0) + (value or 0.0)
+                        if n_a and n_b:
+                            delta = sum_b / n_b - sum_a / n_a
+                            m2 += delta * delta * n_a * n_b / (n_a + n_b)
+                        cur[0], cur[1] = m2, cur[1] + count
+                        continue
                     cur[1] += count
                     if value is None:
                         continue
                     if cur[0] is None:
                         cur[0] = value
-                    elif functions[a] in (abi.AGG_SUM, abi.AGG_AVG):
+                    elif functions[a] in (abi.AGG_SUM, abi.AGG_AVG, _MOMENT_SUM):
                         cur[0] = cur[0] + value
                     elif functions[a] == abi.AGG_MIN:
                         cur[0] = min(cur[0], value)
@@ -742,6 +850,8 @@ def _merge_partials(comm, keys, rows, values, functions, is_float_aggregate, key
         order = sorted(merged.items(), key=lambda kv: (kv[0][0] is not None, kv[0][0] if kv[0][0] is not None else 0))
     else:
         order = sorted(merged.items(), key=lambda kv: kv[1][0])
+    if raw_cells:
+        return [(key, [tuple(cell) for cell in row]) for key, (first, last, row) in order]
     out = []
     for key, (first, last, row) in order:
         cells = []
@@ -775,6 +885,14 @@ def sharded_join_broadcast(comm, ex, build, probe, mode, first_probe_chunk, buil
     Returns this rank's (build RowIDs, probe RowIDs) as device tensors [n, 2] int32, RowIDs of the WHOLE tables.  The shards
     of the build column must be whole chunks of `build_chunk_rows` rows (all but the table's last): gathered in rank order
     they are the table."""
+    # hy_join_hash picks the build side by mode (join_hash.cpp:139-155): Left, Semi and Anti* build on the right input, Right on the
+    # left one.  The gathered table must be THAT side -- as the probe or outer side it would be probed / emitted by every rank, and
+    # the union over the ranks would hold its unmatched (Left, Anti*) or matched (Semi) rows once per rank.
+    allowed = {abi.JOIN_INNER: (True, False), abi.JOIN_LEFT: (False,), abi.JOIN_SEMI: (False,), abi.JOIN_ANTI_NULL_AS_TRUE: (False,),
+               abi.JOIN_ANTI_NULL_AS_FALSE: (False,), abi.JOIN_RIGHT: (True,)}
+    if build_is_left not in allowed.get(mode, ()):
+        raise NotImplementedError(f"broadcast-build join: mode {mode} builds on the {'right' if mode != abi.JOIN_RIGHT else 'left'} input -- "
+                                  f"the gathered column must be that side (build_is_left={not build_is_left})")
     torch = comm.torch
     values, nulls = ex.export(build)
     gathered = torch.cat(comm.all_gather_var(values))
@@ -789,10 +907,15 @@ def sharded_join_broadcast(comm, ex, build, probe, mode, first_probe_chunk, buil
 
 def sharded_join_repartition(comm, ex, left, right, first_left_chunk, first_right_chunk, mode=abi.JOIN_INNER):
     """Hash repartition: both sides' (key, RowID) tuples go to rank  key % G  (one all-to-all per side), every rank joins
-    what it received.  Inner and Semi joins (NULL keys are not sent).  Returns (left RowIDs, right RowIDs or None) of the
-    whole tables, device tensors."""
-    if mode not in (abi.JOIN_INNER, abi.JOIN_SEMI):
-        raise NotImplementedError("the repartitioned join sends no NULL keys: Inner and Semi joins")
+    what it received with `mode`.  NULL keys are not sent -- a NULL meets no partner anywhere -- so the modes that keep rows with
+    NULL keys (join_hash.cpp:284-286) get them from the rank that holds them:
+      Left / Right         the outer side's NULL-key rows leave with a NULL partner, once, from their own rank
+      AntiNullAsFalse      the left side's NULL-key rows are part of the result
+      AntiNullAsTrue       NULL = x is not false: a NULL key on the RIGHT side empties the result (join_hash.cpp:483-494), a NULL key on
+                           the left side is kept only when the right table has no rows at all (ranks agree through two all-reduces)
+    Returns (left RowIDs, right RowIDs or None) of the whole tables, device tensors; rows of different ranks in rank order."""
+    torch = comm.torch
+    semi = mode in (abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_ANTI_NULL_AS_FALSE)
     received = []
     for column, first_chunk in ((left, first_left_chunk), (right, first_right_chunk)):
         keys, rows, counts = ex.repartition(column, comm.world, first_chunk)
@@ -805,7 +928,33 @@ def sharded_join_repartition(comm, ex, left, right, first_left_chunk, first_righ
     left_pos, right_pos = ex.join(left_column, right_column, mode)
     out_left = ex.gather_row_ids(left_rows, REPARTITION_CHUNK, left_pos)
     out_right = ex.gather_row_ids(right_rows, REPARTITION_CHUNK, right_pos) if right_pos is not None else None
-    return out_left, out_right
+    if mode in (abi.JOIN_INNER, abi.JOIN_SEMI):
+        return out_left, out_right
+
+    from .operators import make_predicate
+    def null_key_rows(column, first_chunk):
+        rows = ex.scan(column, make_predicate(abi.PRED_IS_NULL, column.data_type))
+        return _offset_chunks(torch, rows.to(out_left.device), first_chunk)
+
+    null_partner = lambda n: torch.full((n, 2), -1, dtype=torch.int32, device=out_left.device)   # NULL_ROW_ID
+    if mode == abi.JOIN_LEFT:
+        mine = null_key_rows(left, first_left_chunk)
+        return torch.cat([out_left, mine]), torch.cat([out_right, null_partner(mine.shape[0])])
+    if mode == abi.JOIN_RIGHT:
+        mine = null_key_rows(right, first_right_chunk)
+        return torch.cat([out_left, null_partner(mine.shape[0])]), torch.cat([out_right, mine])
+    mine = null_key_rows(left, first_left_chunk)
+    if mode == abi.JOIN_ANTI_NULL_AS_FALSE:
+        return torch.cat([out_left, mine]), None
+    # AntiNullAsTrue
+    flags = torch.tensor([ex.rows_of(right), int(null_key_rows(right, first_right_chunk).shape[0])], dtype=torch.int64, device=comm._device)
+    comm.all_reduce(flags, "sum")
+    right_rows_total, right_nulls_total = int(flags[0].item()), int(flags[1].item())
+    if right_nulls_total:
+        return out_left[:0], None
+    if right_rows_total == 0:
+        return torch.cat([out_left, mine]), None
+    return out_left, None
 
 
 # ---- bench.py --gpus N: the legs beside the weak-scaling scan ---------------------------------------------------------

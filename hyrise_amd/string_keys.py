@@ -29,8 +29,18 @@ class AggregateKeyNames:
     """AggregateKeyEntry of strings; one instance per GROUP BY column of one operator run (the map ids of long strings
     follow the order of first appearance, like the reference's id_map)."""
 
-    def __init__(self):
+    def __init__(self, shared_long_strings=None):
+        # shared_long_strings: the distinct strings of five or more bytes of the WHOLE column, in an order every rank agrees on
+        # (distributed.shared_long_strings): their ids are then the same on every rank, which a cross-rank merge by key value needs.
+        # Without it the ids are names inside ONE process only (`shared` stays False and the sharded operators refuse long strings).
         self._long = {}
+        self.shared = shared_long_strings is not None
+        for data in shared_long_strings or ():
+            self._long.setdefault(_bytes(data), LONG_STRING_IDS_FROM + len(self._long))
+
+    @property
+    def has_long_strings(self):
+        return bool(self._long)
 
     def name(self, value):
         data = _bytes(value)

@@ -34,6 +34,7 @@ def make_data():
     d["probe_values"] = rng.integers(0, 30000, 50_000).astype(np.int32)
     d["build"] = build_column(d["build_values"], None, chunk, abi.ENC_UNENCODED)
     d["probe"] = build_column(d["probe_values"], None, 4096, abi.ENC_FRAME_OF_REFERENCE)
+    d["nullable_probe"] = build_column(d["probe_values"][:30_000], rng.random(30_000) < 0.04, 4096, abi.ENC_DICTIONARY)   # NULL keys on the outer side
     dup_values = rng.integers(0, 2000, 9000).astype(np.int32)                           # duplicate keys on both sides
     d["dup_build"] = build_column(dup_values, rng.random(9000) < 0.03, chunk, abi.ENC_UNENCODED)
     return d
@@ -46,7 +47,11 @@ def aggregate_specs(d):
             "small_domain_slots": (["g3", "g2"], full),      # 5 x 3 keys -> fixed slots, all-reduce
             "immediate_key": (["g3"], full[:3]),             # one dense int32 key: key order, NULL first
             "float_key": (["gf"], full[:2]),                 # floating-point GROUP BY column -> general merge
-            "no_groupby": ([], full)}
+            "no_groupby": ([], full),
+            # COUNT(DISTINCT) and STDDEV_SAMP across ranks: the distinct (group, value) tuples all-gathered, (n, sum, M2) merged pairwise
+            "distinct_and_stddev_slots": (["g3"], [(abi.AGG_COUNT_DISTINCT, "ci"), (abi.AGG_STDDEV_SAMP, "cf"), (abi.AGG_SUM, "ci"), (abi.AGG_STDDEV_SAMP, "ci")]),
+            "distinct_and_stddev_general": (["g1", "g2"], [(abi.AGG_STDDEV_SAMP, "cf"), (abi.AGG_COUNT_DISTINCT, "g3"), (abi.AGG_AVG, "cf")]),
+            "stddev_no_groupby": ([], [(abi.AGG_STDDEV_SAMP, "cf"), (abi.AGG_COUNT_DISTINCT, "ci")])}
 
 
 def fused_specs(d):
@@ -141,6 +146,20 @@ def worker(rank, world, init_file, out_dir, executor_kind):
     out["joins"][("repartition_duplicates", abi.JOIN_INNER)] = pairs_of(l, r)
     l, r = sharded_join_repartition(comm, ex, shard("probe"), shard("dup_build"), first_probe, first_dup, abi.JOIN_SEMI)
     out["joins"][("repartition_semi", abi.JOIN_SEMI)] = pairs_of(l, r)
+    # the modes that keep rows with NULL keys: NULL-key rows never travel, their own rank emits them
+    first_nullable = shard_column(d["nullable_probe"], world, rank)[1]
+    for mode in (abi.JOIN_LEFT, abi.JOIN_ANTI_NULL_AS_FALSE, abi.JOIN_ANTI_NULL_AS_TRUE):
+        l, r = sharded_join_repartition(comm, ex, shard("nullable_probe"), shard("build"), first_nullable, first_build, mode)
+        out["joins"][("repartition_outer", mode)] = pairs_of(l, r)
+    l, r = sharded_join_repartition(comm, ex, shard("build"), shard("nullable_probe"), first_build, first_nullable, abi.JOIN_RIGHT)
+    out["joins"][("repartition_outer", abi.JOIN_RIGHT)] = pairs_of(l, r)
+    l, r = sharded_join_repartition(comm, ex, shard("nullable_probe"), shard("dup_build"), first_nullable, first_dup, abi.JOIN_ANTI_NULL_AS_TRUE)
+    out["joins"][("repartition_anti_null_build", abi.JOIN_ANTI_NULL_AS_TRUE)] = pairs_of(l, r)
+    try:   # a broadcast of the side hy_join_hash would PROBE with is refused (every rank would emit the gathered side's rows)
+        sharded_join_broadcast(comm, ex, shard("build"), shard("probe"), abi.JOIN_LEFT, first_probe, d["chunk"], build_is_left=True)
+        out["broadcast_refused"] = False
+    except NotImplementedError:
+        out["broadcast_refused"] = True
     with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as fh:
         pickle.dump(out, fh)
     dist.barrier()
@@ -217,3 +236,11 @@ def check_results(results):
     assert multiset("repartition_duplicates", abi.JOIN_INNER) == join_result_multiset(dup, abi.JOIN_INNER)
     semi = oracle_join(d["probe"], d["dup_build"], abi.JOIN_SEMI)
     assert multiset("repartition_semi", abi.JOIN_SEMI) == join_result_multiset(semi, abi.JOIN_SEMI)
+    for mode in (abi.JOIN_LEFT, abi.JOIN_ANTI_NULL_AS_FALSE, abi.JOIN_ANTI_NULL_AS_TRUE):
+        whole = oracle_join(d["nullable_probe"], d["build"], mode)
+        assert multiset("repartition_outer", mode) == join_result_multiset(whole, mode), f"repartitioned join, mode {mode}"
+    whole = oracle_join(d["build"], d["nullable_probe"], abi.JOIN_RIGHT)
+    assert multiset("repartition_outer", abi.JOIN_RIGHT) == join_result_multiset(whole, abi.JOIN_RIGHT)
+    whole = oracle_join(d["nullable_probe"], d["dup_build"], abi.JOIN_ANTI_NULL_AS_TRUE)   # (a NULL key on the right side: nothing qualifies)
+    assert whole.n_pairs == 0 and multiset("repartition_anti_null_build", abi.JOIN_ANTI_NULL_AS_TRUE) == []
+    assert all(r["broadcast_refused"] for r in results)

@@ -40,10 +40,17 @@ def test_two_rank_aggregate_and_joins_match_single_process():
     distributed_workload.check_results(results)
 
 
-def test_unmergeable_aggregates_are_refused():
-    """COUNT DISTINCT / STDDEV_SAMP have no cross-rank merge rule here: the sharded aggregate raises instead of returning zeros."""
-    from hyrise_amd.distributed import _local_partials
+def test_string_keys_across_ranks_need_shared_names():
+    """AggregateKeyNames of strings of five or more bytes are ids in order of first appearance inside ONE process; the sharded operators
+    refuse them unless the names were built from a list every rank agrees on (distributed.shared_long_strings)."""
+    from hyrise_amd.distributed import _check_key_names
+    from hyrise_amd.string_keys import AggregateKeyNames
+    local = AggregateKeyNames()
+    assert local.name("N") == 2 + ord("N")          # short strings: the bytes themselves, the same everywhere
+    _check_key_names([local, None])
+    local.name("BUILDING")
     with pytest.raises(NotImplementedError):
-        _local_partials(None, [], [(abi.AGG_COUNT_DISTINCT, None)])
-    with pytest.raises(NotImplementedError):
-        _local_partials(None, [], [(abi.AGG_STDDEV_SAMP, None)])
+        _check_key_names([local])
+    rank0, rank1 = AggregateKeyNames(shared_long_strings=[b"MACHINERY", b"BUILDING"]), AggregateKeyNames(shared_long_strings=[b"MACHINERY", b"BUILDING"])
+    assert rank1.name("BUILDING") == rank0.name("BUILDING") == 5_000_000_001 and rank0.name("MACHINERY") == 5_000_000_000
+    _check_key_names([rank0])
