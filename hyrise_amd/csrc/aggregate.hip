@@ -1017,6 +1017,8 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   }
 }
 
+#include "aggregate_small.hpp"
+
 // ---- the partitioned path: tables with more groups than a slice's LDS table holds -------------------------------------------
 // aggregate_rows sends the rows of groups that do not fit its 256-slot table to the global table one device-scope atomic at a
 // time (a dozen G atomics/s for the whole device: 22 ms for 60 M rows in 1000 groups).  When that happens to more than a few
@@ -2196,12 +2198,13 @@ static void launch_partition_rows(bool scatter, uint32_t words, uint32_t grid, s
 }
 
 static uint32_t g_agg_path = 0;   // debug: 0 = aggregate_rows, otherwise the partition bits of the partitioned path (last call of this process)
+static uint32_t g_agg_small = 0;  // debug: 1 = the last call's groups came from aggregate_small_domain
 
 static uint32_t fused_lds_slots(uint32_t n_groupby) { return n_groupby ? FUSED_LDS_SLOTS : 8u; }
 
 // (`fused`: the device copy of a FusedPlan -- fused_rows takes the place of aggregate_rows; its accumulators' inputs are expressions, which
 //  the partitioned path cannot carry.)
-static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out, const FusedPlan* fused = nullptr) {
+static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out, const FusedPlan* fused = nullptr, const SmallDomainPlan* small = nullptr) {
   hipStream_t stream = current_stream();
   const uint32_t words = a.n_groupby + 1;
   const uint32_t n_aggregates = a.n_aggregates;
@@ -2268,11 +2271,21 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       g_agg_trace_slices = shape->n_slices;
     }
     g_agg_path = partition_bits;
+    g_agg_small = small && partition_bits == 0 && !fused ? 1u : 0u;
     if (shape->n_slices && shape->rows && fused) {   // one workgroup per chunk
       const size_t fused_lds = size_t{fused_lds_slots(a.n_groupby)} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 64 + 2 * size_t{SLICE_ROWS} + sizeof(ColumnView) * FUSED_VIEWS +
                                sizeof(ScanJob) * HY_MAX_FILTERS + sizeof(FusedInput) * n_aggregates + size_t{FUSED_DENSE} * FUSED_CELLS * (8 * (n_aggregates + 2) + 4 * n_aggregates);
       profile_begin(stream, HY_KERNEL_AGGREGATE);
       hipLaunchKernelGGL(fused_rows, dim3(shape->n_chunks), dim3(256), fused_lds, stream, a, fused, shape->n_chunks);
+      profile_end(stream);
+    } else if (shape->n_slices && shape->rows && partition_bits == 0 && small) {   // a handful of groups over dictionary columns: one workgroup per chunk (aggregate_small.hpp)
+      profile_begin(stream, HY_KERNEL_AGGREGATE);
+      static std::atomic<bool> raised{false};
+      if (!raised.load(std::memory_order_acquire)) {
+        HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_small_domain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sd_lds_bytes())));
+        raised.store(true, std::memory_order_release);
+      }
+      hipLaunchKernelGGL(aggregate_small_domain, dim3(shape->n_chunks), dim3(SD_THREADS), sd_lds_bytes(), stream, a, *small, shape->n_chunks);
       profile_end(stream);
     } else if (shape->n_slices && shape->rows && partition_bits == 0) {
       profile_begin(stream, HY_KERNEL_AGGREGATE);
@@ -2611,7 +2624,51 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     HY_HIP(hipStreamSynchronize(stream));   // (`plan` is a stack object)
     HY_TRY(device_groups(a, shape, main_groups, reinterpret_cast<const FusedPlan*>(base)));
   } else {
-    HY_TRY(device_groups(a, shape, main_groups));
+    // The TPC-H Q1 shape -- a handful of groups over dictionary columns, SUM / AVG / COUNT over dictionary-encoded floating-point
+    // columns with 1- or 2-byte value ids -- has a kernel of its own (aggregate_small.hpp); everything else takes aggregate_rows.
+    SmallDomainPlan small;
+    std::memset(&small, 0, sizeof(small));
+    auto dictionary_column = [&](const hy_column* column, uint32_t* width) {   // every chunk a dictionary segment with its values on the device, one id width, aligned
+      if (!column || column->is_reference || column->has_dictionary_without_values || column->n_chunks == 0) return false;
+      *width = column->host_segments[0].width;
+      if (*width != 1 && *width != 2) return false;
+      for (uint32_t k = 0; k < column->n_chunks; ++k) {
+        const hy_segment& seg = column->host_segments[k];
+        if (seg.encoding != HY_ENC_DICTIONARY || seg.width != *width || (!seg.aux && seg.aux_size) || reinterpret_cast<uintptr_t>(seg.data) % 16 != 0 || (*width == 1 && seg.aux_size > 255)) return false;
+      }
+      return true;
+    };
+    bool lean = !getenv("HY_AGG_NO_SMALL_DOMAIN") && shape->rows > 0 && n_groupby <= MAX_GROUPBY;
+    for (uint32_t g = 0; g < n_groupby && lean; ++g) lean = dictionary_column(groupby[g], &small.key_width[g]);
+    for (uint32_t k = 0; k < shape->n_chunks && lean; ++k) {
+      uint64_t product = 1;
+      for (uint32_t g = 0; g < n_groupby; ++g) product *= uint64_t{groupby[g]->host_segments[k].aux_size} + 1;
+      lean = product <= SD_CODES;
+    }
+    std::vector<const hy_column*> inputs;   // distinct input columns, 1-byte ids first
+    for (int pass = 0; pass < 2 && lean; ++pass) {
+      for (uint32_t d = 0; d < n_device && lean; ++d) {
+        const hy_column* column = specs[spec_of_device[d]].column;
+        const uint32_t function = a.aggregates[d].function;
+        lean = function == HY_AGG_SUM || function == HY_AGG_AVG || function == HY_AGG_COUNT;
+        if (!column || !lean) continue;
+        uint32_t width = 0;
+        lean = (column->data_type == HY_TYPE_FLOAT || column->data_type == HY_TYPE_DOUBLE) && dictionary_column(column, &width);
+        if (lean && width == (pass == 0 ? 1u : 2u) && std::find(inputs.begin(), inputs.end(), column) == inputs.end()) inputs.push_back(column);
+      }
+      if (pass == 0) small.n_narrow = static_cast<uint32_t>(inputs.size());
+    }
+    lean = lean && small.n_narrow <= SD_NARROW && inputs.size() - small.n_narrow <= SD_WIDE;
+    if (lean) {
+      if (const char* debug = getenv("HY_AGG_SMALL_DEBUG")) small.debug = static_cast<uint32_t>(atoi(debug));   // timing experiments only
+      small.n_columns = static_cast<uint32_t>(inputs.size());
+      for (uint32_t c = 0; c < small.n_columns; ++c) small.column[c] = inputs[c]->d_segments;
+      for (uint32_t d = 0; d < n_device; ++d) {
+        const hy_column* column = specs[spec_of_device[d]].column;
+        small.column_of_aggregate[d] = column ? static_cast<uint32_t>(std::find(inputs.begin(), inputs.end(), column) - inputs.begin()) : 0xFFFFFFFFu;
+      }
+    }
+    HY_TRY(device_groups(a, shape, main_groups, nullptr, lean ? &small : nullptr));
   }
   lap("device groups on host");
   const uint32_t n_groups = main_groups.n_groups;
@@ -2952,6 +3009,9 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
 
 // debug only: which path the last hy_aggregate_hash of this process took -- 0 aggregate_rows, else the partition bits; not part of the public header
 int hy_debug_aggregate_path(void) { return static_cast<int>(g_agg_path); }
+
+// debug / tests only: 1 = the last hy_aggregate_hash of this process ran aggregate_small_domain (aggregate_small.hpp)
+int hy_debug_aggregate_small_domain(void) { return static_cast<int>(g_agg_small); }
 
 // debug only (HY_AGG_TRACE): the per-slice phase stamps of the last aggregate_rows launch; not part of the public header
 int hy_debug_aggregate_trace(uint64_t* out, uint32_t capacity_slices) {

@@ -272,3 +272,63 @@ def test_reference_aggregate_fixture_on_a_reference_table(device, case):
     on_references = oracle_aggregate([h for h, _ in groupby], [(f, r[0] if r is not None else None) for f, r in aggregates])
     assert_aggregate_equal(on_references, want, len(aggregates), f"oracle, reference table, aggregate_test.cpp:{case['line']}")
     assert_aggregate_equal(got, want, len(aggregates), f"device, reference table, aggregate_test.cpp:{case['line']}")
+
+
+def used_small_domain():
+    lib = abi.load_library()
+    lib.hy_debug_aggregate_small_domain.restype = int
+    return lib.hy_debug_aggregate_small_domain()
+
+
+def test_small_domain_kernel(device, monkeypatch):
+    """aggregate_small_domain (csrc/aggregate_small.hpp): a handful of groups over dictionary GROUP BY columns, SUM / AVG / COUNT over
+    dictionary-encoded float / double columns with 1- and 2-byte value ids -- the TPC-H Q1 shape.  Against the oracle: 1 - 3 GROUP BY
+    columns, NULLs in keys and inputs, more than four groups per chunk (the shared-cell path), ragged chunks, one-row chunks, and
+    the same answers as the generic kernel (HY_AGG_NO_SMALL_DOMAIN)."""
+    rng = np.random.default_rng(91)
+    for n, chunk in ((200_000, 65535), (70_001, 8192), (5, 2), (40_000, 40_000), (150_000, 100_000)):   # (the last: chunks of more than one 65520-row span)
+        flags = rng.integers(0, 3, n).astype(np.int32)                       # 3 distinct
+        status = rng.integers(0, 2, n).astype(np.int64)                      # 2 distinct
+        third = (rng.integers(0, 2, n) * 7).astype(np.int32)
+        flag_nulls = rng.random(n) < 0.01
+        quantity = rng.integers(1, 51, n).astype(np.float32)                 # 1-byte value ids
+        discount = (rng.integers(0, 11, n) / 100.0).astype(np.float64)       # 1-byte value ids, double
+        price = (rng.integers(0, min(60_000, max(300, n)), n) * 1.37 + 900.0).astype(np.float32)   # 2-byte value ids where the chunk is large enough
+        wide_double = rng.integers(0, max(300, n // 3), n).astype(np.float64) * 0.25
+        price_nulls = rng.random(n) < 0.02
+        g1 = build_column(flags, flag_nulls, chunk, abi.ENC_DICTIONARY)
+        g2 = build_column(status, None, chunk, abi.ENC_DICTIONARY)
+        g3 = build_column(third, None, chunk, abi.ENC_DICTIONARY)
+        q = build_column(quantity, None, chunk, abi.ENC_DICTIONARY)
+        d = build_column(discount, rng.random(n) < 0.03, chunk, abi.ENC_DICTIONARY)
+        p = build_column(price, price_nulls, chunk, abi.ENC_DICTIONARY)
+        w = build_column(wide_double, None, chunk, abi.ENC_DICTIONARY)
+        q1 = [(abi.AGG_SUM, q), (abi.AGG_SUM, p), (abi.AGG_AVG, q), (abi.AGG_AVG, p), (abi.AGG_AVG, d), (abi.AGG_COUNT, None)]
+        for name, groupby, aggregates in (("q1 shape", [g1, g2], q1), ("one key", [g2], q1[:3] + [(abi.AGG_COUNT, p)]),
+                                          ("three keys, 36 codes: the generic kernel", [g1, g2, g3], [(abi.AGG_SUM, w), (abi.AGG_AVG, p), (abi.AGG_COUNT, d), (abi.AGG_COUNT, None)]),
+                                          ("two keys, up to nine groups", [g2, g3, g2], [(abi.AGG_SUM, w), (abi.AGG_AVG, p), (abi.AGG_COUNT, d), (abi.AGG_COUNT, None)]),
+                                          ("twelve groups with NULL keys", [g1, g3], [(abi.AGG_SUM, w), (abi.AGG_AVG, p), (abi.AGG_COUNT, d), (abi.AGG_COUNT, None)]),
+                                          ("no group by", [], [(abi.AGG_SUM, q), (abi.AGG_AVG, w), (abi.AGG_COUNT, None)])):
+            context = f"small domain, {n} rows in chunks of {chunk}, {name}"
+            got = run_both(groupby, aggregates, context)
+            widths = {c.segments[0].width for _, c in aggregates if c is not None} | {c.segments[0].width for c in groupby}
+            codes = max((int(np.prod([g.segments[k].aux_size + 1 for g in groupby])) for k in range(q.n_chunks)), default=1)
+            inputs = {id(c): c.segments[0].width for _, c in aggregates if c is not None}
+            narrow, wide = sum(1 for v in inputs.values() if v == 1), sum(1 for v in inputs.values() if v == 2)
+            assert used_small_domain() == (1 if widths <= {1, 2} and codes <= 16 and narrow <= 2 and wide <= 2 else 0), context
+            monkeypatch.setenv("HY_AGG_NO_SMALL_DOMAIN", "1")
+            generic = run_both(groupby, aggregates, context + " (generic kernel)")
+            monkeypatch.delenv("HY_AGG_NO_SMALL_DOMAIN")
+            assert used_small_domain() == 0
+            np.testing.assert_array_equal(got.row_ids[:got.n_groups], generic.row_ids[:generic.n_groups])
+    # a shape the kernel does not take: an integer input column, a GROUP BY column with too many distinct values
+    ints = build_column(rng.integers(0, 9, 1000).astype(np.int32), None, 500, abi.ENC_DICTIONARY)
+    many = build_column(rng.integers(0, 40, 1000).astype(np.int32), None, 500, abi.ENC_DICTIONARY)
+    few = build_column(rng.integers(0, 2, 1000).astype(np.int32), None, 500, abi.ENC_DICTIONARY)
+    floats = build_column(rng.integers(0, 9, 1000).astype(np.float32), None, 500, abi.ENC_DICTIONARY)
+    run_both([few], [(abi.AGG_SUM, ints)], "integer input")
+    assert used_small_domain() == 0
+    run_both([many], [(abi.AGG_SUM, floats)], "forty groups")
+    assert used_small_domain() == 0
+    run_both([few], [(abi.AGG_SUM, floats), (abi.AGG_MIN, floats)], "MIN")
+    assert used_small_domain() == 0

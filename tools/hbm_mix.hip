@@ -46,48 +46,51 @@ __global__ __launch_bounds__(256) void mix(const u32x4* __restrict__ in, uint2* 
 }
 
 int main(int argc, char** argv) {
-  const unsigned n_parts = 916, rows = 65536;
-  const double selectivities[] = {0.15, 0.43};
-  // argv[1] = number of input copies scanned in rotation (default 1: the 120 MB input stays in the 256 MiB Infinity Cache; 3: every
-  // launch reads its input from HBM, like bench.py's rotating column copies)
-  const int copies = argc > 1 ? atoi(argv[1]) : 1;
+  // argv[1] = number of input copies scanned in rotation (default 3: every launch reads its input from HBM, like bench.py's rotating
+  // column copies; 1: the 120 MB input stays in the 256 MiB memory-side cache)
+  const int copies = argc > 1 ? atoi(argv[1]) : 3;
+  const unsigned total_rows = 916u * 65536u;
   u32x4* in;
   uint2* out;
   unsigned* sink;
-  CHECK(hipMalloc(&in, size_t{n_parts} * rows * 2 * copies));
-  CHECK(hipMalloc(&out, size_t{n_parts + 1} * (rows + 4096) * 8));
+  CHECK(hipMalloc(&in, size_t{total_rows} * 2 * copies));
+  CHECK(hipMalloc(&out, (size_t{total_rows} + 4096u * 3665u) * 8));
   CHECK(hipMalloc(&sink, 4));
-  CHECK(hipMemset(in, 1, size_t{n_parts} * rows * 2 * copies));
-  const size_t copy_words = size_t{n_parts} * rows * 2 / 16;
+  CHECK(hipMemset(in, 1, size_t{total_rows} * 2 * copies));
+  const size_t copy_words = size_t{total_rows} * 2 / 16;
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   typedef void (*Kernel)(const u32x4*, uint2*, unsigned, unsigned, unsigned, unsigned*, unsigned);
   const Kernel kernels[8] = {mix<0>, mix<1>, mix<2>, mix<3>, mix<4>, mix<5>, mix<6>, mix<7>};
-  for (unsigned stride : {65535u, 65536u + 1040u})
-  for (unsigned mode : {3u}) {
-    const unsigned grid = 916;
-    printf("region stride %u RowIDs\n", stride);
-    const Kernel mix = kernels[mode];
-    for (double sel : selectivities) {
-      const unsigned out_per_wg = static_cast<unsigned>(rows * sel) / 8 * 8;
-      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(mix, dim3(grid > n_parts ? n_parts : grid), dim3(256), 0, 0, in, out, rows, out_per_wg, n_parts, sink, stride);
-      CHECK(hipDeviceSynchronize());
-      float best = 1e9f, sum = 0;
-      const int reps = 30;
-      for (int i = 0; i < reps; ++i) {
-        CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(mix, dim3(grid > n_parts ? n_parts : grid), dim3(256), 0, 0, in + (i % copies) * copy_words, out, rows, out_per_wg, n_parts, sink, stride);
-        CHECK(hipEventRecord(e1));
-        CHECK(hipEventSynchronize(e1));
-        float ms;
-        CHECK(hipEventElapsedTime(&ms, e0, e1));
-        best = ms < best ? ms : best;
-        sum += ms;
+  const char* mode_names[8] = {"8 B write-back stores", "16 B write-back stores", "8 B nontemporal stores", "16 B nontemporal stores", "8 B write-back stores, nontemporal loads",
+                               "16 B write-back stores, nontemporal loads", "8 B nontemporal stores, nontemporal loads", "16 B nontemporal stores, nontemporal loads"};
+  // the scan's traffic (2 B read per row, 8 B written per match) for three selectivities, workgroups that own 65536 / 32768 / 16384 rows
+  // (one, two, four per Hyrise chunk), every store flavour
+  for (double sel : {0.15, 0.43, 0.986}) {
+    for (unsigned rows : {65536u, 32768u, 16384u}) {
+      const unsigned n_parts = total_rows / rows, stride = rows + 1040u;
+      for (unsigned mode : {3u, 1u, 2u, 7u}) {
+        const Kernel mix = kernels[mode];
+        const unsigned out_per_wg = static_cast<unsigned>(rows * sel) / 8 * 8;
+        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(mix, dim3(n_parts), dim3(256), 0, 0, in + (i % copies) * copy_words, out, rows, out_per_wg, n_parts, sink, stride);
+        CHECK(hipDeviceSynchronize());
+        float best = 1e9f, sum = 0;
+        const int reps = 16;
+        for (int i = 0; i < reps; ++i) {
+          CHECK(hipEventRecord(e0));
+          hipLaunchKernelGGL(mix, dim3(n_parts), dim3(256), 0, 0, in + (i % copies) * copy_words, out, rows, out_per_wg, n_parts, sink, stride);
+          CHECK(hipEventRecord(e1));
+          CHECK(hipEventSynchronize(e1));
+          float ms;
+          CHECK(hipEventElapsedTime(&ms, e0, e1));
+          best = ms < best ? ms : best;
+          sum += ms;
+        }
+        const double bytes = double(n_parts) * (rows * 2.0 + out_per_wg * 8.0);
+        printf("selectivity %.3f  %5u workgroups x %5u rows  %-44s %6.1f MB  avg %6.1f us (%4.0f GB/s)  best %6.1f us (%4.0f GB/s)\n", sel, n_parts, rows, mode_names[mode], bytes / 1e6,
+               sum / reps * 1e3, bytes / (sum / reps * 1e-3) / 1e9, best * 1e3, bytes / (best * 1e-3) / 1e9);
       }
-      const double bytes = double(n_parts) * (rows * 2.0 + out_per_wg * 8.0);
-      printf("mode %u  selectivity %.4f  bytes %.1f MB  avg %.1f us (%.0f GB/s)  best %.1f us (%.0f GB/s)\n", grid, sel, bytes / 1e6, sum / reps * 1e3,
-             bytes / (sum / reps * 1e-3) / 1e9, best * 1e3, bytes / (best * 1e-3) / 1e9);
     }
   }
   return 0;

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Config 2 (TableScan l_shipdate < 1995-01-01, SF10, three column copies in rotation) under the scan's debug switches, one process:
+ms per scan and the HIP-event time of scan_slices.  Usage: python tools/scan_ab.py [steps]   (not part of the product)"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    import torch
+    from hyrise_amd import abi, tpch
+    from hyrise_amd.operators import make_predicate
+    from hyrise_amd.storage import DeviceColumn
+    lib = abi.load_library()
+    abi.check(lib.hy_init(0))
+    dev = torch.device("cuda", 0)
+    rows = tpch.LINEITEM_ROWS_SF10
+    days, host = tpch.shipdate_column(rows, seed=42)
+    columns = [DeviceColumn(host) for _ in range(3)]
+    matches = torch.empty((rows, 2), dtype=torch.int32, device=dev)
+    offsets = torch.zeros(host.n_chunks + 1, dtype=torch.int64, device=dev)
+    counts = torch.zeros(host.n_chunks, dtype=torch.int32, device=dev)
+    result = abi.ScanResult()
+    result.mem, result.flags = abi.MEM_DEVICE, abi.SCAN_CHUNK_REGIONS
+    result.matches, result.capacity = matches.data_ptr(), rows
+    result.offsets, result.counts = offsets.data_ptr(), counts.data_ptr()
+    turn = [0]
+    for name, pred in (("l_shipdate < 1995-01-01 (sel 0.43)", make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)),
+                       ("Q6 between (sel 0.15)", make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, tpch.DAY_1994_01_01, tpch.DAY_1995_01_01)),
+                       ("Q1 <= 1998-09-02 (sel 0.99)", make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, tpch.DAY_1998_09_02))):
+        def step():
+            abi.check(lib.hy_table_scan(columns[turn[0] % 3].handle, C.byref(pred), None, 0, C.byref(result)))
+            turn[0] += 1
+        for variant, env in (("default", {}),):
+            os.environ.update(env)
+            dt, km = bench.timed_kernel(lib, torch, step, steps, 4, kind="scan")
+            m = int(counts.sum().item())
+            print(f"{name:36s} {variant:24s} {dt * 1e6:7.1f} us/scan  scan_slices {km * 1e3:6.1f} us  {(rows * 2 + m * 8) / (km * 1e-3) / 1e9:6.0f} GB/s on algorithmic bytes", flush=True)
+            for k in env:
+                del os.environ[k]
+
+
+if __name__ == "__main__":
+    main()
