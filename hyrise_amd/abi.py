@@ -131,6 +131,17 @@ SYMBOLS = [
     ("hy_profile_read", C.c_int32, [C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     ("hy_profile_read_kernel", C.c_int32, [C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     ("hy_profile_event_overhead", C.c_int32, [C.POINTER(C.c_float)]),
+    ("hy_bind_device", C.c_int32, [C.c_int32]),
+    ("hy_comm_unique_id", C.c_int32, [C.c_void_p]),
+    ("hy_comm_init_rank", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("hy_comm_init_all", C.c_int32, [C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("hy_comm_destroy", C.c_int32, [C.c_void_p]),
+    ("hy_comm_rank", C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("hy_comm_group_begin", C.c_int32, []),
+    ("hy_comm_group_end", C.c_int32, []),
+    ("hy_comm_all_reduce", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]),
+    ("hy_comm_all_gather", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    ("hy_comm_all_to_all_v", C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64)]),
     ("hy_column_create", C.c_int32, [C.POINTER(Segment), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("hy_column_destroy", C.c_int32, [C.c_void_p]),
     ("hy_column_row_count", C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -3004,6 +3004,8 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
                             uint32_t n_aggregates, hy_aggregate_result* result) {
   if (!result || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_aggregate_hash: null argument");
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_aggregate_hash: result columns missing");
+  for (uint32_t i = 0; i < n_groupby; ++i) HY_TRY(on_this_device(groupby_columns[i], "hy_aggregate_hash"));
+  for (uint32_t i = 0; i < n_aggregates; ++i) HY_TRY(on_this_device(aggregates[i].column, "hy_aggregate_hash"));
   return run_aggregate(groupby_columns, n_groupby, aggregates, n_aggregates, result);
 }
 

@@ -206,6 +206,7 @@ hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls
 
 static hy_status repartition_check(const hy_column* column, uint32_t parts) {
   if (!column) return fail(HY_ERR_INVALID, "hy_repartition: null column");
+  HY_TRY(on_this_device(column, "hy_repartition"));
   if (parts == 0 || parts > MAX_PARTS) return fail(HY_ERR_INVALID, "hy_repartition: 1..%u destinations", MAX_PARTS);
   if (column->is_mvcc) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
   if (column->data_type != HY_TYPE_INT && column->data_type != HY_TYPE_LONG) return fail(HY_ERR_UNSUPPORTED, "hy_repartition: integer join keys (std::hash of a float is not its value)");

@@ -88,6 +88,7 @@ struct hy_column {
   uint32_t n_chunks = 0;
   uint32_t data_type = HY_TYPE_NULL;
   uint64_t rows = 0;
+  int device = 0;                           // the device of the thread that created it: operators refuse a column of another device
   bool is_reference = false;
   bool is_mvcc = false;                     // HY_ENC_MVCC segments: a table's MvccData, only hy_validate reads it
   bool multi_chunk_reference = false;       // some pos list spans several referenced chunks
@@ -114,6 +115,7 @@ namespace hy {
 
 // ---- errors ---------------------------------------------------------------------------------------------------------
 hy_status fail(hy_status code, const char* fmt, ...);
+hy_status on_this_device(const hy_column* column, const char* entry_point);   // runtime.hip: the calling thread's device holds the column
 #define HY_HIP(expr)                                                                                      \
   do {                                                                                                    \
     hipError_t err__ = (expr);                                                                            \

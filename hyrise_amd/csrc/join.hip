@@ -3644,17 +3644,27 @@ extern "C" {
 
 hy_status hy_join_hash(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result) {
   if (!left || !right || !result) return fail(HY_ERR_INVALID, "hy_join_hash: null argument");
+  HY_TRY(on_this_device(left, "hy_join_hash"));
+  HY_TRY(on_this_device(right, "hy_join_hash"));
   return run_join(left, right, mode, result, false, nullptr);
 }
 
 hy_status hy_join_hash_predicates(const hy_column* left, const hy_column* right, uint32_t mode, const hy_join_predicate* secondary, uint32_t n_secondary,
                                   hy_join_result* result) {
   if (!left || !right || !result || (n_secondary && !secondary)) return fail(HY_ERR_INVALID, "hy_join_hash_predicates: null argument");
+  HY_TRY(on_this_device(left, "hy_join_hash_predicates"));
+  HY_TRY(on_this_device(right, "hy_join_hash_predicates"));
+  for (uint32_t i = 0; i < n_secondary; ++i) {
+    HY_TRY(on_this_device(secondary[i].left_column, "hy_join_hash_predicates"));
+    HY_TRY(on_this_device(secondary[i].right_column, "hy_join_hash_predicates"));
+  }
   return run_join(left, right, mode, result, false, nullptr, secondary, n_secondary);
 }
 
 hy_status hy_join_hash_count(const hy_column* left, const hy_column* right, uint32_t mode, uint64_t* n_pairs) {
   if (!left || !right || !n_pairs) return fail(HY_ERR_INVALID, "hy_join_hash_count: null argument");
+  HY_TRY(on_this_device(left, "hy_join_hash_count"));
+  HY_TRY(on_this_device(right, "hy_join_hash_count"));
   return run_join(left, right, mode, nullptr, true, n_pairs);
 }
 

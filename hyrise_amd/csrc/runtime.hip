@@ -30,12 +30,28 @@ hy_status fail(hy_status code, const char* fmt, ...) {
 // binds itself the first time it reaches the library (all entry points pass through current_stream / the pools below).
 static std::atomic<int> g_device{-1};
 static thread_local int t_bound_device = -1;
+static thread_local int t_own_device = -1;   // hy_bind_device: this thread's device (one worker thread per GPU in a multi-GPU process), else hy_init's
 void bind_thread_device() {
-  const int device = g_device.load(std::memory_order_acquire);
+  const int device = t_own_device >= 0 ? t_own_device : g_device.load(std::memory_order_acquire);
   if (device >= 0 && t_bound_device != device) {
     (void)hipSetDevice(device);
     t_bound_device = device;
   }
+}
+
+// hy_bind_device (comm.hip): everything thread-local -- stream, buffer pool, scratch arena, pinned staging -- was created on the device the
+// thread was bound to, so a thread may only change its device while it holds none of it (a fresh worker, or after hy_shutdown).
+hy_status on_this_device(const hy_column* column, const char* entry_point) {
+  if (!column) return HY_OK;
+  bind_thread_device();
+  const int here = t_bound_device >= 0 ? t_bound_device : 0;
+  if (column->device != here) return fail(HY_ERR_INVALID, "%s: the column lives on device %d, the calling thread works on device %d (hy_bind_device)", entry_point, column->device, here);
+  return on_this_device(column->ref, entry_point);
+}
+
+void bind_thread_to(int device) {
+  t_own_device = device;
+  bind_thread_device();
 }
 
 hipStream_t current_stream() {
@@ -476,6 +492,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
 
   auto column = new hy_column();
   column->n_chunks = n_chunks;
+  column->device = t_bound_device >= 0 ? t_bound_device : 0;
   column->data_type = column_type;
   column->host_segments.assign(segments, segments + n_chunks);
   column->row_base.resize(size_t{n_chunks} + 1, 0);

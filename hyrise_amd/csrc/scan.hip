@@ -1590,6 +1590,7 @@ int hy_debug_scan_trace(uint64_t* out, uint32_t capacity_wgs) {
 hy_status hy_table_scan(const hy_column* column, const hy_predicate* predicate, const uint32_t* excluded_chunks,
                         uint32_t n_excluded, hy_scan_result* result) {
   if (!column || !predicate || !result) return fail(HY_ERR_INVALID, "hy_table_scan: null argument");
+  HY_TRY(on_this_device(column, "hy_table_scan"));
   if (n_excluded && !excluded_chunks) return fail(HY_ERR_INVALID, "hy_table_scan: excluded chunk list missing");
   for (uint32_t i = 0; i < n_excluded; ++i) {
     if (excluded_chunks[i] >= column->n_chunks) return fail(HY_ERR_INVALID, "excluded chunk id %u out of range", excluded_chunks[i]);
@@ -1613,6 +1614,8 @@ hy_status hy_validate(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot
 hy_status hy_table_scan_columns(const hy_column* left, const hy_column* right, uint32_t condition,
                                 hy_scan_result* result) {
   if (!left || !right || !result) return fail(HY_ERR_INVALID, "hy_table_scan_columns: null argument");
+  HY_TRY(on_this_device(left, "hy_table_scan_columns"));
+  HY_TRY(on_this_device(right, "hy_table_scan_columns"));
   if (left->is_mvcc || right->is_mvcc || (left->ref && left->ref->is_mvcc) || (right->ref && right->ref->is_mvcc)) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
   if (condition > HY_PRED_GREATER_THAN_EQUALS) return fail(HY_ERR_INVALID, "ColumnVsColumn supports binary comparisons only");
   if (left->n_chunks != right->n_chunks) return fail(HY_ERR_INVALID, "columns of one table must have the same chunk count");

@@ -302,6 +302,7 @@ class Table : public std::enable_shared_from_this<Table> {   // storage/table.hp
   const std::string& column_name(ColumnID id) const { return _definitions.at(id).name; }
   TableType type() const { return _type; }
   ChunkID chunk_count() const { return static_cast<ChunkID>(_chunks.size()); }
+  ChunkOffset target_chunk_size() const { return _target_chunk_size; }
   const std::shared_ptr<Chunk>& get_chunk(ChunkID id) const { return _chunks.at(id); }
   uint64_t row_count() const { uint64_t n = 0; for (const auto& c : _chunks) n += c->size(); return n; }
   void append_chunk(Segments segments) { _chunks.push_back(std::make_shared<Chunk>(std::move(segments))); }
@@ -560,18 +561,21 @@ inline int64_t string_join_id(const std::string& s) {   // one registry for all 
 }
 
 // `string_keys`: what a string dictionary column's dictionary is replaced with (see StringKeys).
-inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const Table>& table, ColumnID column_id, StringKeys string_keys = StringKeys::None) {
-  if (!table->device_columns) table->device_columns = std::make_shared<ColumnCache>();
-  auto& slot = table->device_columns->columns[{column_id, string_keys}];
-  if (slot) return slot;
+inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const Table>& table, ColumnID column_id, StringKeys string_keys = StringKeys::None);
+
+// The chunks [chunk_begin, chunk_end) of one column on the CALLING THREAD's device (not cached: the residency cache of a table holds
+// whole columns on the process's device; the shards of a DeviceGroup worker, multi_gpu.hpp, belong to that worker).
+inline std::shared_ptr<DeviceColumn> device_column_of_chunks(const std::shared_ptr<const Table>& table, ColumnID column_id, StringKeys string_keys, ChunkID chunk_begin,
+                                                             ChunkID chunk_end) {
   auto column = std::make_shared<DeviceColumn>();
-  const auto chunk_count = table->chunk_count();
+  const auto chunk_count = chunk_end - chunk_begin;
   column->descriptors.assign(chunk_count, hy_segment{});
   column->key_names.resize(chunk_count);
   std::map<std::string, int64_t> long_strings;
   std::shared_ptr<DeviceColumn> referenced;
-  for (ChunkID chunk_id = 0; chunk_id < chunk_count; ++chunk_id) {
-    const auto segment = table->get_chunk(chunk_id)->get_segment(column_id);
+  for (ChunkID table_chunk = chunk_begin; table_chunk < chunk_end; ++table_chunk) {
+    const ChunkID chunk_id = table_chunk - chunk_begin;
+    const auto segment = table->get_chunk(table_chunk)->get_segment(column_id);
     hy_segment& d = column->descriptors[chunk_id];
     d.size = segment->size();
     d.data_type = static_cast<uint32_t>(segment->data_type());
@@ -629,8 +633,14 @@ inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const T
     if (!ok) Fail("segment kind not handled by the device path (the Hyrise adapter keeps the stock operator here)");
   }
   check_status(hy_column_create(column->descriptors.data(), chunk_count, HY_MEM_HOST, &column->handle));
-  slot = column;
   return column;
+}
+
+inline std::shared_ptr<DeviceColumn> device_column(const std::shared_ptr<const Table>& table, ColumnID column_id, StringKeys string_keys) {
+  if (!table->device_columns) table->device_columns = std::make_shared<ColumnCache>();
+  auto& slot = table->device_columns->columns[{column_id, string_keys}];
+  if (!slot) slot = device_column_of_chunks(table, column_id, string_keys, 0, table->chunk_count());
+  return slot;
 }
 
 // ---- operators ---------------------------------------------------------------------------------------------------------

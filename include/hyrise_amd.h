@@ -209,6 +209,33 @@ hy_status hy_profile_read_kernel(uint32_t kernel, float* total_milliseconds, uin
  * empty kernel, median of 32 launches, measured once per process.  A profiler's per-kernel duration is shorter by about this much. */
 hy_status hy_profile_event_overhead(float* milliseconds);
 
+/* ---- several GPUs in one process, and the collectives between them (csrc/comm.hip: RCCL over xGMI) ----------------------------
+ * Hyrise is one process whose operators run on scheduler workers (scheduler/operator_task.cpp:163-200): the multi-GPU shape is one
+ * worker thread per GPU.  hy_bind_device makes the CALLING thread work on `device` (its stream, pools and every column it creates
+ * belong to that device; threads that never call it use hy_init's device).  hy_comm_init_all creates one communicator per device of
+ * the process (RCCL's single-process mode, ncclCommInitAll); hy_comm_init_rank one per process (id from hy_comm_unique_id, carried to
+ * the other processes by the caller).  The collectives run on the calling thread's stream like a kernel launch (hy_synchronize waits
+ * for them).  A thread that drives several devices' communicators brackets each collective for all of them with hy_comm_group_begin /
+ * hy_comm_group_end.  What the sharded operators exchange: fixed-slot partial aggregates (all_reduce), (key, partial)
+ * tables and build-side columns (all_gather), (key, RowID) tuples by key % G (all_to_all_v: grouped ncclSend / ncclRecv).
+ * A device list that names ONE device n times (worker threads that share a GPU; RCCL refuses such a list) gets communicators that
+ * exchange through that GPU's memory: same entry points, same results. */
+typedef struct hy_comm hy_comm;
+enum { HY_COMM_SUM = 0, HY_COMM_MIN = 1, HY_COMM_MAX = 2 };
+enum { HY_COMM_ID_BYTES = 128 };
+hy_status hy_bind_device(int32_t device);
+hy_status hy_comm_unique_id(void* id_128_bytes);
+hy_status hy_comm_init_rank(const void* id_128_bytes, uint32_t world, uint32_t rank, hy_comm** comm);
+hy_status hy_comm_init_all(const int32_t* devices, uint32_t n_devices, hy_comm** comms /* [n_devices] */);
+hy_status hy_comm_destroy(hy_comm* comm);
+hy_status hy_comm_rank(const hy_comm* comm, uint32_t* rank, uint32_t* world);
+hy_status hy_comm_group_begin(void);
+hy_status hy_comm_group_end(void);
+hy_status hy_comm_all_reduce(hy_comm* comm, const void* send, void* recv, uint64_t count, uint32_t data_type /* HY_TYPE_INT / LONG / FLOAT / DOUBLE */, uint32_t op);
+hy_status hy_comm_all_gather(hy_comm* comm, const void* send, void* recv /* world x bytes_per_rank */, uint64_t bytes_per_rank);
+/* send / recv: the bytes for / from rank 0, rank 1, ... back to back */
+hy_status hy_comm_all_to_all_v(hy_comm* comm, const void* send, const uint64_t* send_bytes, void* recv, const uint64_t* recv_bytes);
+
 /* ---- residency cache: a column made device-visible once (encoded segments are immutable,
  *      abstract_encoded_segment.hpp:12-17) ------------------------------------------------------------------------ */
 /* mem == HY_MEM_HOST: segment buffers are copied to HBM and owned by the hy_column.
