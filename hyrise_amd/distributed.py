@@ -435,7 +435,20 @@ _MOMENT_SUM, _MOMENT_M2 = 1000, 1001
 _INT_TYPES = (abi.TYPE_INT, abi.TYPE_LONG)
 
 
-MAX_AGGREGATES_PER_CALL = 8   # hy_aggregate_hash's limit
+MAX_AGGREGATES_PER_CALL = 8   # hy_aggregate_hash's limit: device accumulators per call (STDDEV_SAMP takes two)
+
+
+def _calls_of(plan):
+    """The plan cut into executor calls of at most MAX_AGGREGATES_PER_CALL device accumulators each."""
+    calls, weight = [[]], 0
+    for function, column in plan:
+        cost = 2 if function == abi.AGG_STDDEV_SAMP else 1
+        if weight + cost > MAX_AGGREGATES_PER_CALL:
+            calls.append([])
+            weight = 0
+        calls[-1].append((function, column))
+        weight += cost
+    return [call for call in calls if call]
 
 
 def _local_partials(ex, groupby, aggregates):
@@ -467,12 +480,12 @@ def _local_partials(ex, groupby, aggregates):
     if shape is None or ex.rows_of(shape) == 0:
         return [], [], []
     columns, first = [], None
-    for begin in range(0, len(plan), MAX_AGGREGATES_PER_CALL):
-        result = ex.aggregate(groupby, plan[begin:begin + MAX_AGGREGATES_PER_CALL])
+    for call in _calls_of(plan):
+        result = ex.aggregate(groupby, call)
         if first is None:
             first = result
         assert result.n_groups == first.n_groups
-        columns += [result.column(i) for i in range(len(plan[begin:begin + MAX_AGGREGATES_PER_CALL]))]
+        columns += [result.column(i) for i in range(len(call))]
     n = first.n_groups
     keys = [tuple(columns[c][g] for c in key_cells) for g in range(n)]
     rows = [(int(first.row_ids[g][0]), int(first.row_ids[g][1])) for g in range(n)]
@@ -654,12 +667,12 @@ def sharded_scan_project_aggregate(comm, ex, filters, groupby, aggregates, first
     key_cells = [want(abi.AGG_MIN, g) for g in groupby]
     passed_cell = want(abi.AGG_COUNT, None)
     columns, first = [], None
-    for begin in range(0, len(plan), MAX_AGGREGATES_PER_CALL):   # (every call is a pass over the shard; they group the same rows in the same order)
-        result = ex.scan_project_aggregate(filters, groupby, plan[begin:begin + MAX_AGGREGATES_PER_CALL])
+    for call in _calls_of(plan):   # (every call is a pass over the shard; they group the same rows in the same order)
+        result = ex.scan_project_aggregate(filters, groupby, call)
         if first is None:
             first = result
         assert result.n_groups == first.n_groups
-        columns += [result.column(i) if result.n_groups else [] for i in range(len(plan[begin:begin + MAX_AGGREGATES_PER_CALL]))]
+        columns += [result.column(i) if result.n_groups else [] for i in range(len(call))]
     n = first.n_groups
     if not groupby and n == 1 and not columns[passed_cell][0]:
         n = 0   # (no GROUP BY, nothing passed: the one row of NULLs / zero counts is produced after the merge, not by every rank)
