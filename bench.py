@@ -155,6 +155,28 @@ def cpu_baseline_aggregate(groupby, aggregates, rows, budget_s=12.0):
                                               f"({median_partials * 1e3:.0f} ms each; merging the partial groups is not timed: a handful of additions)"}}
 
 
+def cpu_baseline_ssb(sample_rows=30_000_000):
+    """Config 5 on the host cores: the plans of hyrise_amd/ssb.py on the CPU restatement of the operators (tests/oracle_executor.py), SF30
+    dimensions and a bounded sample of lineorder (a sixth of SF30's 180 M rows), one run per query."""
+    oracle_support()
+    from oracle_executor import OracleExecutor
+    from hyrise_amd import ssb
+    from hyrise_amd.distributed import aggregate_groups
+    data = ssb.SsbData(scale_factor=30.0, seed=7, lineorder_rows=sample_rows)
+    columns = data.host_columns()
+    ex = OracleExecutor()
+    out = {}
+    for query in ("2.1", "4.1"):
+        t0 = time.perf_counter()
+        groupby, aggregates, joined = ssb.run_query(ex, columns, query)
+        groups = aggregate_groups(ex, groupby, aggregates)
+        dt = time.perf_counter() - t0
+        out[f"q{query}"] = {"value": sample_rows / dt, "unit": "lineorder rows/s", "cores": 1, "kind": "port",
+                            "sample": f"SF30 dimensions, {sample_rows} of SF30's 180000000 lineorder rows, one run ({dt:.1f} s): scan -> JoinHash per dimension -> AggregateHash on the "
+                                      f"CPU restatement of Hyrise's operators, single-threaded; {joined} joined rows, {len(groups)} groups"}
+    return out
+
+
 def committed_traffic(kernel):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes over THIS script that are committed under profiles/
     (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate runs of `python bench.py`, FETCH_SIZE doubled as the gfx950
@@ -748,6 +770,11 @@ def main():
         del columns, matches, orders, lineitem
         from hyrise_amd import ssb
         ssb_info = ssb.bench(30.0, 3, world, rank, dist, share_gpu, local_rank)
+        for query in ("q2.1", "q4.1"):   # the whole query against the HBM roofline: its algorithmic bytes over its host-timed duration
+            ssb_info[query]["roofline"] = roofline_object("whole query (dimension scans, one JoinHash per dimension, gathers, AggregateHash; host-timed)",
+                                                          ssb_info[query]["algorithmic_bytes"], ssb_info[query]["ms"])
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            ssb_info["cpu_baseline"] = cpu_baseline_ssb()
 
     if rank == 0:
         step_roofline = roofline_object("TableScan + JoinHash step: every kernel and launch gap of one hy_table_scan + one hy_join_hash, host-timed over the timed region",

@@ -20,6 +20,7 @@ TYPE_NULL, TYPE_INT, TYPE_LONG, TYPE_FLOAT, TYPE_DOUBLE, TYPE_STRING = range(6)
  JOIN_ANTI_NULL_AS_FALSE) = range(8)
 AGG_MIN, AGG_MAX, AGG_SUM, AGG_AVG, AGG_COUNT, AGG_COUNT_DISTINCT, AGG_STDDEV_SAMP, AGG_ANY = range(8)
 ENC_UNENCODED, ENC_DICTIONARY, ENC_FRAME_OF_REFERENCE, ENC_REFERENCE, ENC_MVCC, ENC_RUN_LENGTH = range(6)
+SORT_NONE, SORT_ASCENDING_NULLS_FIRST, SORT_DESCENDING_NULLS_FIRST, SORT_ASCENDING_NULLS_LAST, SORT_DESCENDING_NULLS_LAST = range(5)   # hyrise::SortMode + 1
 MEM_HOST, MEM_DEVICE = 0, 1
 CHUNK_SCANNED, CHUNK_ALL_MATCH, CHUNK_NONE_MATCH = 0, 1, 2
 INVALID_VALUE_ID = 0xFFFFFFFF
@@ -38,7 +39,7 @@ class RowID(C.Structure):
 class Segment(C.Structure):
     _fields_ = [("encoding", C.c_uint32), ("data_type", C.c_uint32), ("size", C.c_uint32), ("width", C.c_uint32),
                 ("data", C.c_void_p), ("aux", C.c_void_p), ("aux_size", C.c_uint32), ("ref_chunk_id", C.c_uint32),
-                ("nulls", C.c_void_p), ("ref", C.c_void_p)]
+                ("nulls", C.c_void_p), ("ref", C.c_void_p), ("sorted_by", C.c_uint32), ("bits", C.c_uint32)]
 
 
 class Value(C.Union):

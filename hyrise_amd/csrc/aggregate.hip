@@ -77,7 +77,8 @@ struct AggArgs {
   uint32_t spill_limit;       // [3] above this sets [2]
   uint64_t* trace;            // debug (HY_AGG_TRACE): 12 wall-clock stamps per slice, else nullptr
 };
-enum : uint32_t { FLAG_OVERFLOW = 0, FLAG_GROUPS = 1, FLAG_GIVE_UP = 2, FLAG_SPILLED = 3 };
+enum : uint32_t { FLAG_OVERFLOW = 0, FLAG_GROUPS = 1, FLAG_GIVE_UP = 2, FLAG_SPILLED = 3, /* 4, 5: FLAG_PASSED */
+                  FLAG_SMALL_REFUSED = 6 /* aggregate_small_domain: a 4-bit counter overflowed, run aggregate_rows */ };
 
 // order-preserving map double -> int64 (so MIN/MAX of floating point values can use integer atomics)
 __device__ __forceinline__ int64_t ordered_bits(double d) {
@@ -2109,6 +2110,7 @@ __global__ void publish_group_flags(const uint32_t* flags, uint32_t* header) {
   header[3] = flags[3];
   header[4] = flags[4];   // (FLAG_PASSED, two words: fused_rows only)
   header[5] = flags[5];
+  header[6] = flags[6];
   __threadfence_system();
 }
 
@@ -2338,7 +2340,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       profile_end(stream);
     }
     lap("kernels launched", round);
-    uint32_t host_flags[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t host_flags[7] = {0, 0, 0, 0, 0, 0, 0};
     // count groups, then compact
     DeviceBuffer c_keys, c_first, c_last, c_values, c_counts;
     const uint32_t out_capacity = static_cast<uint32_t>(std::min<uint64_t>(capacity, shape->rows + 1));
@@ -2370,7 +2372,11 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     lap("compact launched", round);
     HY_HIP(hipStreamSynchronize(stream));
     lap("device finished", round);
-    std::memcpy(host_flags, pinned_host, 24);
+    std::memcpy(host_flags, pinned_host, 28);
+    if (host_flags[FLAG_SMALL_REFUSED] && small) {   // (a value met sixteen times in one group of one chunk)
+      small = nullptr;
+      continue;
+    }
     if (host_flags[FLAG_GIVE_UP]) {   // too many rows outside the LDS tables: partition (more finely)
       if (partition_bits == 0) partition_bits = first_bits;
       else if (partition_bits < MAX_PARTITION_BITS) partition_bits = MAX_PARTITION_BITS;
@@ -2638,8 +2644,11 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       }
       return true;
     };
-    bool lean = !getenv("HY_AGG_NO_SMALL_DOMAIN") && shape->rows > 0 && n_groupby <= MAX_GROUPBY;
-    for (uint32_t g = 0; g < n_groupby && lean; ++g) lean = dictionary_column(groupby[g], &small.key_width[g]);
+    bool lean = !getenv("HY_AGG_NO_SMALL_DOMAIN") && shape->rows > 0 && n_groupby <= SD_KEYS;
+    for (uint32_t g = 0; g < n_groupby && lean; ++g) {
+      uint32_t key_width = 0;
+      lean = dictionary_column(groupby[g], &key_width) && key_width == 1;
+    }
     for (uint32_t k = 0; k < shape->n_chunks && lean; ++k) {
       uint64_t product = 1;
       for (uint32_t g = 0; g < n_groupby; ++g) product *= uint64_t{groupby[g]->host_segments[k].aux_size} + 1;
@@ -2997,7 +3006,22 @@ hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters
                                     const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result) {
   if (!result || (n_filters && !filters) || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: null argument");
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: result columns missing");
-  return run_fused(filters, n_filters, groupby_columns, n_groupby, aggregates, n_aggregates, result);
+  // run-length / bit-packed segments: the decoded twins (hy_device.hpp)
+  std::vector<hy_filter> plain_filters(filters, filters + n_filters);
+  for (hy_filter& filter : plain_filters) HY_TRY(plain_column(filter.column, &filter.column));
+  std::vector<const hy_column*> plain_groupby(groupby_columns, groupby_columns + n_groupby);
+  for (const hy_column*& column : plain_groupby) HY_TRY(plain_column(column, &column));
+  std::vector<hy_fused_aggregate> plain_aggregates(aggregates, aggregates + n_aggregates);
+  std::vector<hy_expression> plain_inputs(n_aggregates);
+  for (uint32_t g = 0; g < n_aggregates; ++g) {
+    if (!aggregates[g].input) continue;
+    plain_inputs[g] = *aggregates[g].input;
+    for (uint32_t k = 0; k < plain_inputs[g].n_nodes && k < HY_MAX_EXPRESSION_NODES; ++k) {
+      if (plain_inputs[g].nodes[k].kind == HY_EXPR_COLUMN) HY_TRY(plain_column(plain_inputs[g].nodes[k].column, &plain_inputs[g].nodes[k].column));
+    }
+    plain_aggregates[g].input = &plain_inputs[g];
+  }
+  return run_fused(plain_filters.data(), n_filters, plain_groupby.data(), n_groupby, plain_aggregates.data(), n_aggregates, result);
 }
 
 hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates,
@@ -3006,7 +3030,11 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_aggregate_hash: result columns missing");
   for (uint32_t i = 0; i < n_groupby; ++i) HY_TRY(on_this_device(groupby_columns[i], "hy_aggregate_hash"));
   for (uint32_t i = 0; i < n_aggregates; ++i) HY_TRY(on_this_device(aggregates[i].column, "hy_aggregate_hash"));
-  return run_aggregate(groupby_columns, n_groupby, aggregates, n_aggregates, result);
+  std::vector<const hy_column*> plain_groupby(groupby_columns, groupby_columns + n_groupby);   // run-length / bit-packed segments: the decoded twins
+  for (const hy_column*& column : plain_groupby) HY_TRY(plain_column(column, &column));
+  std::vector<hy_aggregate_spec> plain_aggregates(aggregates, aggregates + n_aggregates);
+  for (hy_aggregate_spec& spec : plain_aggregates) HY_TRY(plain_column(spec.column, &spec.column));
+  return run_aggregate(plain_groupby.data(), n_groupby, plain_aggregates.data(), n_aggregates, result);
 }
 
 // debug only: which path the last hy_aggregate_hash of this process took -- 0 aggregate_rows, else the partition bits; not part of the public header

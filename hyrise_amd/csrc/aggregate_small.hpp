@@ -5,17 +5,19 @@
 // GROUP BY l_returnflag, l_linestatus (dictionary segments, a few distinct values) with SUM / AVG / COUNT over DictionarySegment<float>
 // columns.  aggregate_rows handles every encoding x type x function in one 150 KB body at 167 registers and ran this shape at 11 %
 // of the HBM roofline; this kernel takes the shape and nothing else:
-//   * every GROUP BY column is a dictionary segment in every chunk, the product of their (dictionary size + 1) is at most 16: a
-//     row's group is the mixed-radix CODE of its value ids; the first four codes a chunk meets are its DENSE groups (Q1 has four),
+//   * at most two GROUP BY columns, each a dictionary segment with 1-byte value ids in every chunk, the product of their (dictionary
+//     size + 1) at most 16: a row's group is the mixed-radix CODE of its value ids; the first four codes a chunk meets are its DENSE
+//     groups (Q1 has four),
 //   * every aggregate is SUM / AVG / COUNT over a dictionary-encoded float / double column with 1- or 2-byte value ids (or COUNT(*)),
-//   * 1-byte value ids (l_quantity, l_discount): the rows are COUNTED per (dense group, value id) in an LDS histogram -- one LDS
+//   * 1-byte value ids (l_quantity, l_discount): the rows are COUNTED per (value id, dense group) in an LDS histogram -- one LDS
 //     atomic per row and column, no dictionary gather at all -- and the counts are weighted with the dictionary once per chunk
 //     (the double sums are exact for these columns' products count x value in any order),
-//   * 2-byte value ids (l_extendedprice, 240 KB of dictionary per chunk): one gather per row from the chunk's dictionary (one XCD
-//     works on one chunk: the dictionary stays in its L2) into four register accumulators selected by the row's dense group.
-// One workgroup per chunk, sixteen consecutive rows per lane and step (16-byte loads of 1-byte ids, two for 2-byte ids).  Rows of a
-// fifth, sixth ... group of a chunk take LDS atomics on shared cells.  The chunk's groups are merged into the global table like
-// aggregate_rows' (global_slot / merge_global): result order, representative rows and values are those of the generic kernel.
+//   * 2-byte value ids (l_extendedprice, 240 KB of dictionary per chunk): counted as well, in one 4-bit counter per (value id, dense
+//     group) -- 128 KB of LDS -- and weighted with the dictionary, which is read once, coalesced (see the kernel's comment).
+// One workgroup of 1024 threads per chunk, sixteen consecutive rows per lane and step (16-byte loads of 1-byte ids, two for 2-byte ids),
+// a step's loads issued one step ahead.  Rows of a fifth, sixth ... group of a chunk take LDS atomics on shared cells.  The chunk's
+// groups are merged into the global table like aggregate_rows' (global_slot / merge_global): result order, representative rows and
+// values are those of the generic kernel.
 // SUM / AVG: double additions in a different order than the reference's row loop -- the stated 1e-9 relative tolerance.
 #pragma once
 
@@ -23,8 +25,9 @@ constexpr uint32_t SD_CODES = 16;       // product of (dictionary size + 1) over
 constexpr uint32_t SD_DENSE = 4;        // groups of a chunk with register / histogram accumulators
 constexpr uint32_t SD_COLUMNS = 4;      // distinct aggregate input columns
 constexpr uint32_t SD_NARROW = 2;       // ... of which with 1-byte value ids, at most
-constexpr uint32_t SD_WIDE = 2;         // ... and with 2-byte value ids
+constexpr uint32_t SD_WIDE = 1;         // ... and with 2-byte value ids
 constexpr uint32_t SD_ROWS = 16;        // consecutive rows of a lane per step
+constexpr uint32_t SD_KEYS = 2;         // GROUP BY columns, at most (1-byte value ids: their dictionaries have fewer than sixteen entries)
 typedef __attribute__((address_space(1))) float global_f32;    // (pointers read from a segment descriptor are generic to the compiler: flat loads, which also count on lgkmcnt)
 typedef __attribute__((address_space(1))) double global_f64;
 
@@ -32,8 +35,7 @@ struct SmallDomainPlan {
   uint32_t n_columns, n_narrow;                   // distinct input columns; the first n_narrow have 1-byte value ids, the others 2-byte ones
   const DevSegment* column[SD_COLUMNS];
   uint32_t column_of_aggregate[MAX_AGGREGATES];   // 0xFFFFFFFF: COUNT(*)
-  uint32_t key_width[MAX_GROUPBY];                // bytes per value id of the GROUP BY columns (1 or 2; the same in every chunk)
-  uint32_t debug;                                 // HY_AGG_SMALL_DEBUG (timing experiments, wrong results): 1 no histograms, 2 no phase 2, 4 phase 2 without the LDS gathers and adds, 8 no dense lookup
+  uint32_t debug;                                 // HY_AGG_SMALL_DEBUG (timing experiments, wrong results): 1 no histograms, 2 no 2-byte columns, 8 no dense lookup
 };
 
 // value id of row j (0..15) of a lane's sixteen consecutive ids loaded as 16 bytes (WIDTH 1) or 2 x 16 bytes (WIDTH 2)
@@ -61,25 +63,38 @@ __device__ __forceinline__ void sd_load_ids(const void* data, uint32_t width, ui
   }
 }
 
-constexpr uint32_t SD_THREADS = 512;                        // one workgroup per chunk, two workgroups per CU (each takes half of the CU's LDS)
-constexpr uint32_t SD_STEPS = 8;                            // steps of 16 rows per lane and span
-constexpr uint32_t SD_SPAN = SD_THREADS * SD_ROWS * SD_STEPS - SD_ROWS;   // 65520: where the next span of a chunk with more than 65535 rows starts (a span has fewer than 2^16 rows: see phase 2)
-constexpr uint32_t SD_DICT_BYTES = 64 * 1024;               // LDS for a window of a wide column's (dense group, value id) counters, 16 bits each
-constexpr uint32_t SD_WINDOW_IDS = SD_DICT_BYTES / 2 / SD_DENSE;   // 8192 value ids per window
-__host__ __device__ constexpr size_t sd_lds_bytes() { return SD_DICT_BYTES + size_t{SD_NARROW} * SD_DENSE * 256 * 4 + size_t{SD_NARROW} * 256 * 8; }
+constexpr uint32_t SD_THREADS = 1024;                       // one workgroup per chunk and CU (it takes most of the CU's LDS): 16 waves
+constexpr uint32_t SD_STEPS = 4;                            // steps of 16 rows per lane and span
+constexpr uint32_t SD_SPAN = SD_THREADS * SD_ROWS * SD_STEPS;   // 65536 rows: a Hyrise chunk (at most 65535 rows) is one span
+constexpr uint32_t SD_WIDE_BYTES = 128 * 1024;              // one 16-bit cell per value id of a wide column: four 4-bit counters, one per dense group
+constexpr uint32_t SD_COPIES = 2;                           // copies of the narrow columns' histograms (even / odd lanes)
+__host__ __device__ constexpr size_t sd_lds_bytes() { return SD_WIDE_BYTES + size_t{SD_COPIES} * SD_NARROW * 256 * SD_DENSE * 4 + size_t{SD_NARROW} * 256 * 8; }
 
-// The 2-byte value ids' dictionary does not fit a CU's L1 (240 KB for l_extendedprice), and 60 M gathers that each pull a 128-byte line
-// out of the L2 for four bytes were 700 of this kernel's first version's 980 us (and what bounds aggregate_rows).  Staging the
-// dictionary in LDS windows and gathering there cut that to 270 us (four windows x a compare, an LDS read and four select-adds in double
-// precision per row).  What runs now does no gather at all: see phase 2.  The rows' dense groups are kept in registers (four bits per
-// row) between the windows; only the 2-byte ids are read again, out of the L2.
-__global__ __launch_bounds__(SD_THREADS, 4) void aggregate_small_domain(AggArgs a, SmallDomainPlan plan, uint32_t n_chunks) {
+// What a lane asks for per step: sixteen consecutive rows of every column (16 bytes of 1-byte ids, 2 x 16 bytes of 2-byte ids).
+struct SdStep {
+  u32x4 key[SD_KEYS];
+  u32x4 narrow[SD_NARROW];
+  u32x4 wide[2];
+};
+
+// History of the 2-byte column (l_extendedprice, 240 KB of dictionary per chunk -- more than a CU's L1, and 60 M gathers that each pull
+// a 128-byte line out of the L2 for four bytes were 700 of the first version's 980 us and are what bounds aggregate_rows): gathers from
+// dictionary windows staged in LDS, 550 us; rows COUNTED per (dense group, value id) in 16-bit LDS counters, eight windows of 8192 ids,
+// 520 us -- 316 of them the windows: 64 dependent round trips per chunk (eight windows x (zero, ids from the L2 twice, dictionary from
+// HBM twice)) with two workgroups per CU to hide them.  Now ONE window: a 4-bit counter per (dense group, value id) -- 128 KB of LDS
+// for 65536 ids -- so a row costs one LDS atomic and the chunk is read once; the dictionary is read once, coalesced, when the counts
+// are weighted.  A counter that meets a sixteenth row carries into its neighbour; every carry lowers the sum of all counters, which is
+// compared with the rows counted in registers: a chunk that fails the comparison (sixteen rows of one group with one price in 65535
+// rows) raises FLAG_SMALL_REFUSED and the host runs aggregate_rows instead.
+__global__ __launch_bounds__(SD_THREADS) void aggregate_small_domain(AggArgs a, SmallDomainPlan plan, uint32_t n_chunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sd_smem[];
-  uint32_t (*s_hist)[SD_DENSE][256] = reinterpret_cast<uint32_t (*)[SD_DENSE][256]>(sd_smem + SD_DICT_BYTES);                   // [narrow column][dense group][value id] rows
-  double (*s_dict)[256] = reinterpret_cast<double (*)[256]>(sd_smem + SD_DICT_BYTES + size_t{SD_NARROW} * SD_DENSE * 256 * 4);   // narrow columns' dictionaries as doubles
+  uint32_t* s_wide = reinterpret_cast<uint32_t*>(sd_smem);                                                        // [32768] two 16-bit cells each
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(sd_smem + SD_WIDE_BYTES);                                         // [copy][narrow column][value id][dense group] rows
+  double (*s_dict)[256] = reinterpret_cast<double (*)[256]>(sd_smem + SD_WIDE_BYTES + size_t{SD_COPIES} * SD_NARROW * 256 * SD_DENSE * 4);   // narrow columns' dictionaries as doubles
   __shared__ uint32_t s_dense_of_code[SD_CODES];               // 0xFF unassigned, 0xFE being assigned, else the dense index (may be >= SD_DENSE: a shared-cell group)
   __shared__ uint32_t s_code_of_dense[SD_CODES];
   __shared__ uint32_t s_n_dense;
+  __shared__ uint32_t s_check;                                 // counters summed - rows counted (wide columns): not zero = a counter overflowed
   __shared__ __attribute__((aligned(8))) uint32_t s_dense_map[4];   // [0..1] sixteen nibbles: dense index of code c | [2] bit c: the nibble is valid
   __shared__ double s_sum[SD_CODES][SD_COLUMNS];               // per dense index (all of them) and column
   __shared__ uint32_t s_nonnull[SD_CODES][SD_COLUMNS];
@@ -91,11 +106,11 @@ __global__ __launch_bounds__(SD_THREADS, 4) void aggregate_small_domain(AggArgs 
   const uint64_t chunk_base = a.row_base[chunk];
 
   // ---- descriptors ---------------------------------------------------------------------------------------------------------
-  const void* key_data[MAX_GROUPBY];
-  uint32_t key_stride[MAX_GROUPBY], key_size[MAX_GROUPBY];
+  const void* key_data[SD_KEYS];
+  uint32_t key_stride[SD_KEYS], key_size[SD_KEYS];
   uint32_t rows_in_chunk = 0, product = 1;
 #pragma unroll
-  for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
+  for (uint32_t g = 0; g < SD_KEYS; ++g) {
     key_data[g] = nullptr;
     key_stride[g] = 0;
     key_size[g] = 0;
@@ -124,7 +139,40 @@ __global__ __launch_bounds__(SD_THREADS, 4) void aggregate_small_domain(AggArgs 
       if (a.n_groupby == 0) rows_in_chunk = seg.size;
     }
   }
-  for (uint32_t i = tid; i < SD_NARROW * SD_DENSE * 256; i += SD_THREADS) (&s_hist[0][0][0])[i] = 0;
+  const uint32_t n_wide = plan.n_columns - plan.n_narrow;
+  const void* wide_data = nullptr;       // the 2-byte column (selected with static indices: an array indexed at run time would live in scratch memory)
+  const void* wide_dictionary = nullptr;
+  uint32_t wide_size = 0;
+  bool wide_is_float = false;
+#pragma unroll
+  for (uint32_t c = 0; c < SD_COLUMNS; ++c) {
+    if (n_wide && c == plan.n_narrow) { wide_data = column_data[c]; wide_dictionary = column_dictionary[c]; wide_size = column_size[c]; wide_is_float = column_type[c] == HY_TYPE_FLOAT; }
+  }
+
+  // The loads of a step: issued one step ahead of their use (volatile: the compiler would sink them down to it).
+  auto load_step = [&](uint32_t span, uint32_t span_end, uint32_t step, SdStep& s) {
+    typedef const volatile __attribute__((address_space(1))) u32x4 global_u32x4_now;
+    const uint32_t first = span + (step * SD_THREADS + tid) * SD_ROWS;
+    const uint32_t row = first < span_end ? first : span;   // (a lane without rows reads the span's first ids)
+#pragma unroll
+    for (uint32_t g = 0; g < SD_KEYS; ++g) {
+      s.key[g] = u32x4{0, 0, 0, 0};
+      if (g < a.n_groupby) s.key[g] = *(global_u32x4_now*)(static_cast<const char*>(key_data[g]) + row);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < SD_NARROW; ++c) {
+      s.narrow[c] = u32x4{0, 0, 0, 0};
+      if (c < plan.n_narrow) s.narrow[c] = *(global_u32x4_now*)(static_cast<const char*>(column_data[c]) + row);
+    }
+    s.wide[0] = s.wide[1] = u32x4{0, 0, 0, 0};
+    if (n_wide) {
+      const char* at = static_cast<const char*>(wide_data) + size_t{row} * 2;
+      s.wide[0] = *(global_u32x4_now*)at;
+      if (row + 8 < rows_in_chunk) s.wide[1] = *(global_u32x4_now*)(at + 16);   // (a load starts at an existing row: it ends inside the padding every uploaded buffer has)
+    }
+  };
+
+  for (uint32_t i = tid; i < SD_COPIES * SD_NARROW * 256 * SD_DENSE; i += SD_THREADS) s_hist[i] = 0;
 #pragma unroll
   for (uint32_t c = 0; c < SD_NARROW; ++c) {
     if (c >= plan.n_narrow || tid >= 256) continue;   // (a narrow column's dictionary has at most 255 entries)
@@ -140,46 +188,40 @@ __global__ __launch_bounds__(SD_THREADS, 4) void aggregate_small_domain(AggArgs 
     s_last[tid] = 0;
     for (uint32_t c = 0; c < SD_COLUMNS; ++c) { s_sum[tid][c] = 0.0; s_nonnull[tid][c] = 0; }
   }
-  if (tid == 0) s_n_dense = 0;
+  if (tid == 0) { s_n_dense = 0; s_check = 0; }
   if (tid < 4) s_dense_map[tid] = 0;
-  __syncthreads();
 
-  const uint32_t n_wide = plan.n_columns - plan.n_narrow;
   uint32_t rows_of[SD_DENSE], first_of[SD_DENSE], last_of[SD_DENSE];
 #pragma unroll
   for (uint32_t k = 0; k < SD_DENSE; ++k) { rows_of[k] = 0; first_of[k] = 0xFFFFFFFFu; last_of[k] = 0; }
+  const uint32_t copy = lane & (SD_COPIES - 1);
   uint32_t span_end = 0;
 #pragma unroll 1
   for (uint32_t span = 0; span < rows_in_chunk; span = span_end) {
-    span_end = rows_in_chunk - span <= 65535u ? rows_in_chunk : span + SD_SPAN;   // a Hyrise chunk (at most 65535 rows) is one span
-    // ---- phase 1: the rows' groups (kept for phase 2), their bookkeeping, the 1-byte columns' histograms ---------------------------------
-    uint64_t dense0 = 0, dense1 = 0, dense2 = 0, dense3 = 0, dense4 = 0, dense5 = 0, dense6 = 0, dense7 = 0;   // (named registers, selected by the step: an array indexed by a loop counter would live in scratch memory)
-    static_assert(SD_STEPS == 8, "dense0 .. dense7");
+    span_end = rows_in_chunk - span <= SD_SPAN ? rows_in_chunk : span + SD_SPAN;
+    SdStep current;
+    load_step(span, span_end, 0, current);
+    if (span != 0) __syncthreads();   // (the span before has been weighted: its counters may go)
+    if (n_wide) {
+      for (uint32_t i = tid; i < SD_WIDE_BYTES / 16; i += SD_THREADS) reinterpret_cast<u32x4*>(sd_smem)[i] = u32x4{0, 0, 0, 0};
+    }
+    __syncthreads();   // (the tables are set up; an earlier span's counters have been weighted)
+    uint32_t wide_rows = 0;   // rows this lane counted into the wide column's counters
+    // ---- the rows: groups, bookkeeping, histograms of the 1-byte columns, counters of the first 2-byte column ---------------------------
 #pragma unroll 1
     for (uint32_t step = 0; step < SD_STEPS; ++step) {
       const uint32_t first = span + (step * SD_THREADS + tid) * SD_ROWS;
-      const uint32_t load_row = first < span_end ? first : span;   // (a lane without rows reads the chunk's first ids)
-      u32x4 key_ids[MAX_GROUPBY][2], narrow_ids[SD_NARROW];
-#pragma unroll
-      for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
-        key_ids[g][0] = key_ids[g][1] = u32x4{0, 0, 0, 0};
-        if (g < a.n_groupby) sd_load_ids(key_data[g], plan.key_width[g], load_row, rows_in_chunk, key_ids[g]);
-      }
-#pragma unroll
-      for (uint32_t c = 0; c < SD_NARROW; ++c) {
-        narrow_ids[c] = u32x4{0, 0, 0, 0};
-        if (c < plan.n_narrow) narrow_ids[c] = *(const global_u32x4*)(static_cast<const char*>(column_data[c]) + load_row);
-      }
+      SdStep next = current;
+      if (step + 1 < SD_STEPS && span + (step + 1) * SD_THREADS * SD_ROWS < span_end) load_step(span, span_end, step + 1, next);
       uint64_t codes = 0;   // the rows' codes, four bits each
 #pragma unroll
       for (uint32_t j = 0; j < SD_ROWS; ++j) {
         uint32_t code = 0;
 #pragma unroll
-        for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
-          if (g < a.n_groupby) {
-            const uint32_t id = sd_id(key_ids[g], plan.key_width[g], j);
-            code += (id < key_size[g] ? id : key_size[g]) * key_stride[g];
-          }
+        for (uint32_t g = 0; g < SD_KEYS; ++g) {   // (a GROUP BY column that is not there: ids 0, stride 0)
+          const u32x4 ids[2] = {current.key[g], u32x4{0, 0, 0, 0}};
+          const uint32_t id = sd_id(ids, 1u, j);
+          code += (id < key_size[g] ? id : key_size[g]) * key_stride[g];
         }
         codes |= static_cast<uint64_t>(code & 0xFu) << (4 * j);
       }
@@ -220,8 +262,6 @@ __global__ __launch_bounds__(SD_THREADS, 4) void aggregate_small_domain(AggArgs 
           dense |= static_cast<uint64_t>(first + j < span_end ? d : 0xFu) << (4 * j);   // (rows that do not exist match no group)
         }
       }
-      if (step == 0) dense0 = dense; else if (step == 1) dense1 = dense; else if (step == 2) dense2 = dense; else if (step == 3) dense3 = dense;
-      else if (step == 4) dense4 = dense; else if (step == 5) dense5 = dense; else if (step == 6) dense6 = dense; else dense7 = dense;
       // rows, first and last row per dense group: nibble arithmetic on the sixteen dense indices (a zero nibble of dense ^ k * 0x1111...
       // is a row of group k; the classic zero-in-word test marks it in the nibble's top bit)
 #pragma unroll
@@ -259,105 +299,110 @@ __global__ __launch_bounds__(SD_THREADS, 4) void aggregate_small_domain(AggArgs 
           }
         }
       }
-      // 1-byte value ids: count the row in the histogram of its (dense group, value id) -- NULL ids are counted like the others and
-      // left out when the counts are weighted; rows of other groups and rows that do not exist count in a spare row
+      // 1-byte value ids: count the row in the histogram of its (value id, dense group) -- NULL ids are counted like the others and
+      // left out when the counts are weighted; rows of other groups and rows that do not exist count in a spare row.  Cells of one
+      // value id are neighbours (a column with eleven values, l_discount, would otherwise meet in eleven of the LDS's banks) and even
+      // and odd lanes have their own copy.
 #pragma unroll
       for (uint32_t c = 0; c < SD_NARROW; ++c) {
         if (c >= plan.n_narrow || (plan.debug & 1)) continue;
-        const u32x4 ids[2] = {narrow_ids[c], u32x4{0, 0, 0, 0}};
+        const u32x4 ids[2] = {current.narrow[c], u32x4{0, 0, 0, 0}};
+        uint32_t* cells = s_hist + (copy * SD_NARROW + c) * 256 * SD_DENSE;
 #pragma unroll
         for (uint32_t j = 0; j < SD_ROWS; ++j) {
           const uint32_t d = static_cast<uint32_t>(dense >> (4 * j)) & 0xFu;
           const uint32_t id = sd_id(ids, 1u, j);
-          atomicAdd(d < SD_DENSE ? &s_hist[c][d][id] : &s_spare[id & 63u], 1u);
+          atomicAdd(d < SD_DENSE ? &cells[id * SD_DENSE + d] : &s_spare[id & 63u], 1u);
         }
       }
+      // the first 2-byte column: one 4-bit counter per (value id, dense group); NULL ids (the dictionary's size) are not counted
+      if (n_wide && !(plan.debug & 2)) {
+#pragma unroll
+        for (uint32_t j = 0; j < SD_ROWS; ++j) {
+          const uint32_t d = static_cast<uint32_t>(dense >> (4 * j)) & 0xFu;
+          const uint32_t id = sd_id(current.wide, 2u, j);
+          if (d < SD_DENSE && id < wide_size) {
+            atomicAdd(&s_wide[id >> 1], 1u << (16 * (id & 1) + 4 * d));
+            wide_rows += 1;
+          }
+        }
+      }
+      current = next;
     }
-    // ---- phase 2: the 2-byte columns, one window of value ids at a time ------------------------------------------------------------------
-    // The rows of a window are COUNTED per (dense group, value id) in 16-bit LDS counters -- one LDS atomic per row on a packed pair;
-    // a span has fewer than 2^16 rows, so a counter cannot carry into its neighbour -- and the counts are weighted with the window's
-    // dictionary entries, read once, coalesced: no gather anywhere, and no floating-point work per row.
+    // ---- the 2-byte columns' counters x their dictionaries -------------------------------------------------------------------------------
 #pragma unroll 1
     for (uint32_t w = 0; w < ((plan.debug & 2) ? 0u : n_wide); ++w) {
       const uint32_t c = plan.n_narrow + w;
-      const void* data = w == 0 ? column_data[plan.n_narrow < SD_COLUMNS ? plan.n_narrow : 0] : column_data[plan.n_narrow + 1 < SD_COLUMNS ? plan.n_narrow + 1 : 0];
-      const void* dictionary = w == 0 ? column_dictionary[plan.n_narrow < SD_COLUMNS ? plan.n_narrow : 0] : column_dictionary[plan.n_narrow + 1 < SD_COLUMNS ? plan.n_narrow + 1 : 0];
-      const uint32_t size = w == 0 ? column_size[plan.n_narrow < SD_COLUMNS ? plan.n_narrow : 0] : column_size[plan.n_narrow + 1 < SD_COLUMNS ? plan.n_narrow + 1 : 0];
-      const bool is_float = (w == 0 ? column_type[plan.n_narrow < SD_COLUMNS ? plan.n_narrow : 0] : column_type[plan.n_narrow + 1 < SD_COLUMNS ? plan.n_narrow + 1 : 0]) == HY_TYPE_FLOAT;
-      uint32_t* s_window = reinterpret_cast<uint32_t*>(sd_smem);   // [SD_DENSE][SD_WINDOW_IDS / 2] pairs of 16-bit counters
+      const void* dictionary = wide_dictionary;
+      const uint32_t size = wide_size;
+      const bool is_float = wide_is_float;
       double acc[SD_DENSE] = {0.0, 0.0, 0.0, 0.0};
       uint32_t counted[SD_DENSE] = {0, 0, 0, 0};   // non-NULL inputs per dense group
-#pragma unroll 1
-      for (uint32_t origin = 0; origin < size; origin += SD_WINDOW_IDS) {
-        const uint32_t here = size - origin < SD_WINDOW_IDS ? size - origin : SD_WINDOW_IDS;
-        __syncthreads();   // (the previous window has been weighted)
-        for (uint32_t i = tid; i < SD_DICT_BYTES / 16; i += SD_THREADS) reinterpret_cast<u32x4*>(sd_smem)[i] = u32x4{0, 0, 0, 0};
-        __syncthreads();
-        // four steps' ids in flight at once (one after the other, sixty-four dependent L2 round trips per chunk -- eight windows x eight
-        // steps -- bound this phase)
-#pragma unroll 1
-        for (uint32_t group = 0; group < SD_STEPS; group += 4) {
-          u32x4 ids[4][2];
+      // Thread t takes the value ids t, t + SD_THREADS, ...: 32 dictionary entries (16 for doubles) requested at once -- they come from
+      // HBM, coalesced, and one request after the other, eight round trips per chunk, was a sixth of this kernel -- and the first batch
+      // is requested BEFORE the barrier that ends the counting (the dictionary does not depend on it).
+      bool counting_done = false;
+      auto weigh = [&](uint32_t i, double value) {
+        const uint32_t cell = i < size ? (s_wide[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
 #pragma unroll
-          for (uint32_t s4 = 0; s4 < 4; ++s4) {
-            const uint32_t first = span + ((group + s4) * SD_THREADS + tid) * SD_ROWS;
-            sd_load_ids(data, 2u, first < span_end ? first : span, rows_in_chunk, ids[s4]);
-          }
-#pragma unroll
-          for (uint32_t s4 = 0; s4 < 4; ++s4) {
-            const uint64_t dense = group == 0 ? (s4 == 0 ? dense0 : s4 == 1 ? dense1 : s4 == 2 ? dense2 : dense3) : (s4 == 0 ? dense4 : s4 == 1 ? dense5 : s4 == 2 ? dense6 : dense7);
-            if (plan.debug & 4) { acc[0] += static_cast<double>(ids[s4][0].x ^ ids[s4][1].w); continue; }
-#pragma unroll
-            for (uint32_t j = 0; j < SD_ROWS; ++j) {
-              const uint32_t local = sd_id(ids[s4], 2u, j) - origin;
-              const uint32_t d = static_cast<uint32_t>(dense >> (4 * j)) & 0xFu;
-              // (unsigned: ids below the window wrap around; the NULL id, size, is in no window; rows of a fifth ... group and rows that
-              // do not exist have d >= 4)
-              if (local < here && d < SD_DENSE) atomicAdd(&s_window[d * (SD_WINDOW_IDS / 2) + (local >> 1)], 1u << (16 * (local & 1)));
-            }
-          }
+        for (uint32_t k = 0; k < SD_DENSE; ++k) {
+          const uint32_t count = (cell >> (4 * k)) & 0xFu;
+          acc[k] += static_cast<double>(count) * value;
+          counted[k] += count;
         }
-        __syncthreads();
-        // weights: thread t takes the window's entries t, t + SD_THREADS, ... -- all of its dictionary loads in flight at once (they come
-        // from HBM: one after the other, sixteen round trips per window were most of this kernel)
+      };
+      if (is_float) {
+        constexpr uint32_t BATCH = 32;
 #pragma unroll 1
-        for (uint32_t batch = 0; batch < SD_WINDOW_IDS / SD_THREADS; batch += 8) {
-          if (batch * SD_THREADS >= here) break;
-          double value[8];
+        for (uint32_t batch = 0; batch < 65536 / SD_THREADS; batch += BATCH) {
+          if (batch * SD_THREADS >= size) break;
+          float value[BATCH];
 #pragma unroll
-          for (uint32_t n = 0; n < 8; ++n) {
+          for (uint32_t n = 0; n < BATCH; ++n) {
             const uint32_t i = (batch + n) * SD_THREADS + tid;
-            const uint32_t at = origin + (i < here ? i : 0u);
-            value[n] = is_float ? static_cast<double>(((const global_f32*)dictionary)[at]) : ((const global_f64*)dictionary)[at];
+            value[n] = ((const global_f32*)dictionary)[i < size ? i : 0u];
           }
+          if (!counting_done) { __syncthreads(); counting_done = true; }
 #pragma unroll
-          for (uint32_t n = 0; n < 8; ++n) {
+          for (uint32_t n = 0; n < BATCH; ++n) weigh((batch + n) * SD_THREADS + tid, static_cast<double>(value[n]));
+        }
+      } else {
+        constexpr uint32_t BATCH = 16;
+#pragma unroll 1
+        for (uint32_t batch = 0; batch < 65536 / SD_THREADS; batch += BATCH) {
+          if (batch * SD_THREADS >= size) break;
+          double value[BATCH];
+#pragma unroll
+          for (uint32_t n = 0; n < BATCH; ++n) {
             const uint32_t i = (batch + n) * SD_THREADS + tid;
-#pragma unroll
-            for (uint32_t k = 0; k < SD_DENSE; ++k) {
-              const uint32_t count = i < here ? (s_window[k * (SD_WINDOW_IDS / 2) + (i >> 1)] >> (16 * (i & 1))) & 0xFFFFu : 0u;
-              acc[k] += static_cast<double>(count) * value[n];
-              counted[k] += count;
-            }
+            value[n] = ((const global_f64*)dictionary)[i < size ? i : 0u];
           }
+          if (!counting_done) { __syncthreads(); counting_done = true; }
+#pragma unroll
+          for (uint32_t n = 0; n < BATCH; ++n) weigh((batch + n) * SD_THREADS + tid, value[n]);
         }
       }
-      __syncthreads();
-      // the column's sums -> LDS cells (a wave reduction each, then one LDS atomic per wave)
+      if (!counting_done) __syncthreads();   // (an empty dictionary: every row NULL)
+      // the column's sums -> LDS cells (a wave reduction each, then one LDS atomic per wave); counters summed against rows counted
+      uint32_t all_counted = 0;
 #pragma unroll
       for (uint32_t k = 0; k < SD_DENSE; ++k) {
         const uint64_t sum = wave_reduce_to_lane63(static_cast<uint64_t>(__double_as_longlong(acc[k])), 0ull, [](uint64_t x, uint64_t y) {
           return static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(x)) + __longlong_as_double(static_cast<long long>(y))));
         });
         const uint32_t inputs = wave_reduce_u32_to_lane63(counted[k], 0u, false, false);
+        all_counted += inputs;
         if (lane == 63) {
           atomicAdd(&s_sum[k][c], __longlong_as_double(static_cast<long long>(sum)));
           atomicAdd(&s_nonnull[k][c], inputs);
         }
       }
+      const uint32_t expected = wave_reduce_u32_to_lane63(wide_rows, 0u, false, false);
+      if (lane == 63 && all_counted != expected) atomicAdd(&s_check, all_counted - expected);
     }
   }
   __syncthreads();
+  if (tid == 0 && s_check != 0) __hip_atomic_store(&a.overflow[FLAG_SMALL_REFUSED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // ---- the chunk's groups --------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -376,7 +421,10 @@ __global__ __launch_bounds__(SD_THREADS, 4) void aggregate_small_domain(AggArgs 
     if (c >= plan.n_narrow || tid >= 256) continue;
 #pragma unroll
     for (uint32_t k = 0; k < SD_DENSE; ++k) {
-      const uint32_t count = tid < column_size[c] ? s_hist[c][k][tid] : 0u;
+      uint32_t count = 0;
+#pragma unroll
+      for (uint32_t copy_index = 0; copy_index < SD_COPIES; ++copy_index) count += s_hist[((copy_index * SD_NARROW + c) * 256 + tid) * SD_DENSE + k];
+      if (tid >= column_size[c]) count = 0;
       const uint64_t sum = wave_reduce_to_lane63(static_cast<uint64_t>(__double_as_longlong(static_cast<double>(count) * s_dict[c][tid])), 0ull, [](uint64_t x, uint64_t y) {
         return static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(x)) + __longlong_as_double(static_cast<long long>(y))));
       });
@@ -399,9 +447,9 @@ __global__ __launch_bounds__(SD_THREADS, 4) void aggregate_small_domain(AggArgs 
 #pragma unroll
   for (uint32_t g = 0; g < MAX_GROUPBY; ++g) {
     tuple[g + 1] = 0;
-    if (g >= a.n_groupby) continue;
-    const uint32_t id = (code / key_stride[g]) % (key_size[g] + 1);
-    if (id >= key_size[g]) { tuple[0] |= 1ull << g; continue; }
+    if (g >= a.n_groupby || g >= SD_KEYS) continue;
+    const uint32_t id = (code / key_stride[g < SD_KEYS ? g : 0]) % (key_size[g < SD_KEYS ? g : 0] + 1);
+    if (id >= key_size[g < SD_KEYS ? g : 0]) { tuple[0] |= 1ull << g; continue; }
     const DevSegment seg = a.groupby[g].segments[chunk];
     uint64_t bits;
     switch (seg.data_type) {

@@ -190,6 +190,7 @@ hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls
   if (column->data_type < HY_TYPE_INT || column->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "hy_column_export: numeric columns only");
   if (column->has_dictionary_without_values) return fail(HY_ERR_UNSUPPORTED, "hy_column_export: the dictionary values are not on the device");
   if (!column->n_slices || !column->rows) return HY_OK;
+  HY_TRY(plain_column(column, &column));
   hipStream_t stream = current_stream();
   ExportArgs a{};
   a.segments = column->d_segments;
@@ -216,6 +217,7 @@ static hy_status repartition_check(const hy_column* column, uint32_t parts) {
 
 hy_status hy_repartition_count(const hy_column* column, uint32_t parts, uint64_t* counts) {
   HY_TRY(repartition_check(column, parts));
+  HY_TRY(plain_column(column, &column));
   if (!counts) return fail(HY_ERR_INVALID, "hy_repartition_count: counts missing");
   for (uint32_t d = 0; d < parts; ++d) counts[d] = 0;
   if (!column->n_slices || !column->rows) return HY_OK;
@@ -240,6 +242,7 @@ hy_status hy_repartition_count(const hy_column* column, uint32_t parts, uint64_t
 hy_status hy_repartition_pack(const hy_column* column, uint32_t parts, uint32_t chunk_id_offset, void* keys_out, hy_row_id* row_ids_out, uint64_t capacity,
                               uint64_t* counts) {
   HY_TRY(repartition_check(column, parts));
+  HY_TRY(plain_column(column, &column));
   if (!counts || (capacity && (!keys_out || !row_ids_out))) return fail(HY_ERR_INVALID, "hy_repartition_pack: output buffer missing");
   for (uint32_t d = 0; d < parts; ++d) counts[d] = 0;
   if (!column->n_slices || !column->rows) return HY_OK;

@@ -30,6 +30,9 @@ struct DevSegment {
   uint8_t data_type;
   uint8_t width;
   uint8_t flags;               // SEG_*
+  uint8_t sorted_by;           // HY_SORT_*
+  uint8_t bits;                // width == 0: bits per element of the bit-packed attribute / offset vector in `data`
+  uint8_t reserved[6];
 };
 enum : uint8_t { SEG_UNALIGNED = 1 };
 
@@ -109,6 +112,12 @@ struct hy_column {
   std::vector<void*> owned;                 // device allocations freed with the column
   std::vector<std::pair<size_t, void*>> pooled;   // ... or handed back to the buffer pool (operator results)
   mutable hy_join_key_hint join_hint;
+  // RunLength segments and bit-packed vectors stay compressed in device memory; TableScan reads them in place.  The operators that
+  // gather rows (joins, aggregates, projections, exchanges, reference columns) read `plain`: the same column as Value / FixedWidthInteger
+  // segments, decoded ON THE DEVICE from the resident compressed buffers the first time one of them asks (plain_column, runtime.hip).
+  bool has_compressed = false;
+  mutable std::mutex plain_mutex;
+  mutable hy_column* plain = nullptr;       // owned
 };
 
 namespace hy {
@@ -116,6 +125,7 @@ namespace hy {
 // ---- errors ---------------------------------------------------------------------------------------------------------
 hy_status fail(hy_status code, const char* fmt, ...);
 hy_status on_this_device(const hy_column* column, const char* entry_point);   // runtime.hip: the calling thread's device holds the column
+hy_status plain_column(const hy_column* column, const hy_column** plain);      // runtime.hip: `column` itself, or its decoded twin (see hy_column::plain)
 #define HY_HIP(expr)                                                                                      \
   do {                                                                                                    \
     hipError_t err__ = (expr);                                                                            \

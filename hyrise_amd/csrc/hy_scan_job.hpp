@@ -6,7 +6,8 @@
 namespace hy {
 
 // ---- per-chunk normalised predicate ---------------------------------------------------------------------------------
-enum : uint32_t { JOB_SCAN = 0, JOB_ALL = 1, JOB_NONE = 2 };
+enum : uint32_t { JOB_SCAN = 0, JOB_ALL = 1, JOB_NONE = 2,
+                  JOB_RANGE = 3 /* a sorted chunk: the rows [range_begin, range_end) without [hole_begin, hole_end) match, nothing is read */ };
 enum : uint32_t { KIND_U32 = 0, KIND_I64 = 1, KIND_F32 = 2, KIND_F64 = 3, KIND_NULLTEST = 4,
                   KIND_VISIBLE = 5 /* Validate: lo = snapshot commit id, span = our transaction id */,
                   KIND_VALUE_ID_SET = 6 /* LIKE family on dictionaries: lo = device address of the chunk's match bitmap */ };
@@ -19,6 +20,8 @@ struct ScanJob {
   uint32_t null_vid;   // dictionary: value id that encodes NULL (aux_size); else 0xFFFFFFFF
   uint64_t lo;         // integer lower bound (bit pattern) | float/double lower bound bits
   uint64_t span;       // integer hi - lo                   | float/double upper bound bits
+  uint32_t range_begin, range_end;   // JOB_RANGE (sorted_segment_search.hpp): chunk offsets
+  uint32_t hole_begin, hole_end;     // ... NotEquals leaves two ranges (:259-320)
 };
 
 struct PredicateArgs {
@@ -33,6 +36,7 @@ struct PredicateArgs {
   const uint64_t* match_word_offsets;
   uint32_t column_is_nullable;
   uint32_t materialize_all;
+  uint32_t no_ranges;                   // the caller evaluates the jobs itself and knows JOB_SCAN / JOB_ALL / JOB_NONE only (fused_rows)
 };
 
 // scan.hip: checks `predicate` for `column` (a data column) like hy_table_scan does, uploads its per-chunk arrays into

@@ -3646,6 +3646,8 @@ hy_status hy_join_hash(const hy_column* left, const hy_column* right, uint32_t m
   if (!left || !right || !result) return fail(HY_ERR_INVALID, "hy_join_hash: null argument");
   HY_TRY(on_this_device(left, "hy_join_hash"));
   HY_TRY(on_this_device(right, "hy_join_hash"));
+  HY_TRY(plain_column(left, &left));   // (run-length / bit-packed segments: the decoded twin, hy_device.hpp)
+  HY_TRY(plain_column(right, &right));
   return run_join(left, right, mode, result, false, nullptr);
 }
 
@@ -3658,13 +3660,22 @@ hy_status hy_join_hash_predicates(const hy_column* left, const hy_column* right,
     HY_TRY(on_this_device(secondary[i].left_column, "hy_join_hash_predicates"));
     HY_TRY(on_this_device(secondary[i].right_column, "hy_join_hash_predicates"));
   }
-  return run_join(left, right, mode, result, false, nullptr, secondary, n_secondary);
+  HY_TRY(plain_column(left, &left));
+  HY_TRY(plain_column(right, &right));
+  std::vector<hy_join_predicate> plain_secondary(secondary, secondary + n_secondary);
+  for (hy_join_predicate& predicate : plain_secondary) {
+    HY_TRY(plain_column(predicate.left_column, &predicate.left_column));
+    HY_TRY(plain_column(predicate.right_column, &predicate.right_column));
+  }
+  return run_join(left, right, mode, result, false, nullptr, plain_secondary.data(), n_secondary);
 }
 
 hy_status hy_join_hash_count(const hy_column* left, const hy_column* right, uint32_t mode, uint64_t* n_pairs) {
   if (!left || !right || !n_pairs) return fail(HY_ERR_INVALID, "hy_join_hash_count: null argument");
   HY_TRY(on_this_device(left, "hy_join_hash_count"));
   HY_TRY(on_this_device(right, "hy_join_hash_count"));
+  HY_TRY(plain_column(left, &left));
+  HY_TRY(plain_column(right, &right));
   return run_join(left, right, mode, nullptr, true, n_pairs);
 }
 

@@ -270,6 +270,11 @@ hy_status hy_projection_arithmetic(uint32_t op, const hy_operand* left, const hy
   if (!left || !right || !out) return fail(HY_ERR_INVALID, "hy_projection_arithmetic: null argument");
   *out = nullptr;
   if (op > HY_ARITH_MOD) return fail(HY_ERR_INVALID, "unknown arithmetic operator %u", op);
+  hy_operand plain_left = *left, plain_right = *right;   // run-length / bit-packed segments: the decoded twins (hy_device.hpp)
+  HY_TRY(plain_column(plain_left.column, &plain_left.column));
+  HY_TRY(plain_column(plain_right.column, &plain_right.column));
+  left = &plain_left;
+  right = &plain_right;
   const hy_column* shape = left->column ? left->column : right->column;
   if (!shape) return fail(HY_ERR_INVALID, "hy_projection_arithmetic: at least one operand must be a column");
   for (const hy_operand* o : {left, right}) {
@@ -354,6 +359,7 @@ hy_status hy_projection_arithmetic(uint32_t op, const hy_operand* left, const hy
 hy_status hy_column_read_chunk(const hy_column* column, uint32_t chunk, void* values, uint64_t* null_words) {
   if (!column || !values) return fail(HY_ERR_INVALID, "hy_column_read_chunk: null argument");
   if (chunk >= column->n_chunks) return fail(HY_ERR_INVALID, "chunk %u out of range", chunk);
+  HY_TRY(plain_column(column, &column));
   const hy_segment& s = column->host_segments[chunk];
   if (s.encoding != HY_ENC_UNENCODED) return fail(HY_ERR_UNSUPPORTED, "hy_column_read_chunk reads unencoded value segments");
   hipStream_t stream = current_stream();

@@ -437,13 +437,15 @@ static hy_status validate_segment(const hy_segment& s, uint32_t chunk, uint32_t 
       if (s.size && !s.data) return fail(HY_ERR_INVALID, "chunk %u: null data pointer", chunk);
       break;
     case HY_ENC_DICTIONARY:
-      if (s.width != 1 && s.width != 2 && s.width != 4) return fail(HY_ERR_INVALID, "chunk %u: attribute vector width %u", chunk, s.width);
+      if (s.width == 0 && (s.bits < 1 || s.bits > 32)) return fail(HY_ERR_INVALID, "chunk %u: bit-packed attribute vector of %u bits per element", chunk, s.bits);
+      if (s.width != 0 && s.width != 1 && s.width != 2 && s.width != 4) return fail(HY_ERR_INVALID, "chunk %u: attribute vector width %u", chunk, s.width);
       if (s.size && !s.data) return fail(HY_ERR_INVALID, "chunk %u: null attribute vector", chunk);
       if (s.data_type != HY_TYPE_STRING && s.aux_size && !s.aux) return fail(HY_ERR_INVALID, "chunk %u: dictionary missing", chunk);
       break;
     case HY_ENC_FRAME_OF_REFERENCE:
       if (s.data_type != HY_TYPE_INT) return fail(HY_ERR_INVALID, "chunk %u: FrameOfReference is int32 only", chunk);
-      if (s.width != 1 && s.width != 2 && s.width != 4) return fail(HY_ERR_INVALID, "chunk %u: offset width %u", chunk, s.width);
+      if (s.width == 0 && (s.bits < 1 || s.bits > 32)) return fail(HY_ERR_INVALID, "chunk %u: bit-packed offset vector of %u bits per element", chunk, s.bits);
+      if (s.width != 0 && s.width != 1 && s.width != 2 && s.width != 4) return fail(HY_ERR_INVALID, "chunk %u: offset width %u", chunk, s.width);
       if (s.size && (!s.data || !s.aux)) return fail(HY_ERR_INVALID, "chunk %u: FrameOfReference buffers missing", chunk);
       if (s.aux_size != (s.size + HY_FOR_BLOCK_SIZE - 1) / HY_FOR_BLOCK_SIZE) return fail(HY_ERR_INVALID, "chunk %u: %u block minima for %u rows", chunk, s.aux_size, s.size);
       break;
@@ -464,13 +466,20 @@ static hy_status validate_segment(const hy_segment& s, uint32_t chunk, uint32_t 
       break;
     default: return fail(HY_ERR_UNSUPPORTED, "chunk %u: encoding %u stays on the CPU path", chunk, s.encoding);
   }
+  if (s.sorted_by > HY_SORT_DESCENDING_NULLS_LAST) return fail(HY_ERR_INVALID, "chunk %u: sort mode %u", chunk, s.sorted_by);
   return HY_OK;
 }
 
+static bool bit_packed(const hy_segment& s) { return (s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE) && s.width == 0; }
+static bool compressed(const hy_segment& s) { return s.encoding == HY_ENC_RUN_LENGTH || bit_packed(s); }
+
 static size_t data_bytes(const hy_segment& s) {
+  if (s.encoding == HY_ENC_RUN_LENGTH) return size_t{s.width} * s.aux_size;                 // one value per run
+  if (bit_packed(s)) return 8 * ((size_t{s.size} * s.bits + 63) / 64);                       // compact::vector: whole 64-bit words
   return s.encoding == HY_ENC_REFERENCE ? (s.data ? size_t{8} * s.size : 0) : size_t{s.width} * s.size;
 }
 static size_t aux_bytes(const hy_segment& s) {
+  if (s.encoding == HY_ENC_RUN_LENGTH) return size_t{4} * s.aux_size;                        // inclusive end positions
   if (s.encoding == HY_ENC_DICTIONARY) return s.aux ? type_width(s.data_type) * s.aux_size : 0;
   if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) return size_t{4} * s.aux_size;
   if (s.encoding == HY_ENC_MVCC) return size_t{4} * s.size;
@@ -478,6 +487,7 @@ static size_t aux_bytes(const hy_segment& s) {
 }
 static size_t null_bytes(const hy_segment& s) {
   if (s.encoding == HY_ENC_MVCC) return size_t{4} * s.size;   // the end commit ids travel in the `nulls` slot
+  if (s.encoding == HY_ENC_RUN_LENGTH) return s.nulls ? size_t{s.aux_size} : 0;   // one byte per run
   return (s.nulls && s.encoding != HY_ENC_REFERENCE) ? size_t{8} * ((s.size + 63) / 64) : 0;
 }
 
@@ -501,40 +511,20 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     return st;
   };
 
-  // RunLengthSegments are expanded once, here: the kernels see a ValueSegment (values + null bitmap).  The expansion of
-  // RunLengthSegmentIterable (run_length_segment_iterable.hpp): row r belongs to the first run whose end position >= r.
-  std::vector<std::vector<unsigned char>> expanded_values(n_chunks);
-  std::vector<std::vector<uint64_t>> expanded_nulls(n_chunks);
+  // RunLengthSegments and bit-packed vectors travel and stay as they are (TableScan reads them in place; plain_column decodes a twin
+  // on the device for the operators that gather rows).  Their runs are checked here, on the host, while they still are host memory.
   for (uint32_t c = 0; c < n_chunks; ++c) {
-    hy_segment& s = column->host_segments[c];
-    if (s.encoding != HY_ENC_RUN_LENGTH) continue;
-    if (mem != HY_MEM_HOST) return cleanup(fail(HY_ERR_UNSUPPORTED, "chunk %u: run-length segments are expanded on upload (HY_MEM_HOST only)", c));
-    const auto* run_values = static_cast<const unsigned char*>(s.data);
+    const hy_segment& s = segments[c];
+    if (compressed(s)) column->has_compressed = true;
+    if (s.encoding != HY_ENC_RUN_LENGTH || mem != HY_MEM_HOST) continue;
     const auto* run_ends = static_cast<const uint32_t*>(s.aux);
-    const auto* run_nulls = reinterpret_cast<const uint8_t*>(s.nulls);
-    auto& values = expanded_values[c];
-    auto& nulls = expanded_nulls[c];
-    values.assign(size_t{s.width} * s.size, 0);
-    bool any_null = false;
-    for (uint32_t run = 0; run < s.aux_size && run_nulls; ++run) any_null = any_null || run_nulls[run] != 0;
-    if (any_null) nulls.assign((size_t{s.size} + 63) / 64, 0);
     uint32_t row = 0;
     for (uint32_t run = 0; run < s.aux_size; ++run) {
       if (run_ends[run] >= s.size || run_ends[run] < row) return cleanup(fail(HY_ERR_INVALID, "chunk %u: run %u ends at %u (rows: %u)", c, run, run_ends[run], s.size));
-      const bool is_null = run_nulls && run_nulls[run] != 0;
-      for (; row <= run_ends[run]; ++row) {
-        if (is_null) nulls[row >> 6] |= 1ull << (row & 63);
-        else std::memcpy(&values[size_t{row} * s.width], run_values + size_t{run} * s.width, s.width);
-      }
+      row = run_ends[run] + 1;
     }
     if (row != s.size) return cleanup(fail(HY_ERR_INVALID, "chunk %u: runs cover %u of %u rows", c, row, s.size));
-    s.encoding = HY_ENC_UNENCODED;
-    s.data = values.data();
-    s.aux = nullptr;
-    s.aux_size = 0;
-    s.nulls = any_null ? nulls.data() : nullptr;
   }
-  segments = column->host_segments.data();   // from here on: the expanded descriptors
 
   // One arena for every buffer of the column: 916 chunks x 3 buffers would otherwise be ~2.7k hipMallocs.
   size_t arena_bytes = 0;
@@ -592,12 +582,17 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     d.data_type = static_cast<uint8_t>(s.data_type);
     d.width = static_cast<uint8_t>(s.width);
     d.flags = 0;
+    d.sorted_by = static_cast<uint8_t>(s.sorted_by);
+    d.bits = static_cast<uint8_t>(bit_packed(s) ? s.bits : 0);
     if (reinterpret_cast<uintptr_t>(s.data) % 16 != 0 || reinterpret_cast<uintptr_t>(s.nulls) % 8 != 0) d.flags |= SEG_UNALIGNED;
     if (s.encoding == HY_ENC_REFERENCE) {
       column->is_reference = true;
       if (column->ref && column->ref != s.ref) return cleanup(fail(HY_ERR_INVALID, "chunk %u references a different table than chunk 0", c));
       column->ref = s.ref;
-      d.ref = s.ref->d_segments;
+      const hy_column* referenced = nullptr;   // (a referenced column with run-length / bit-packed segments is read through its decoded twin)
+      const hy_status plain_status = plain_column(s.ref, &referenced);
+      if (plain_status != HY_OK) return cleanup(plain_status);
+      d.ref = referenced->d_segments;
       if (s.data && s.ref_chunk_id == 0xFFFFFFFFu) column->multi_chunk_reference = true;
     } else if (column->is_reference) {
       return cleanup(fail(HY_ERR_INVALID, "chunk %u: data and reference segments mixed in one column", c));
@@ -629,7 +624,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     const hy_segment& s = column->host_segments[c];
     const bool kind_ok = s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE ||
                          (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT);
-    if (!kind_ok || (dev[c].flags & SEG_UNALIGNED)) streamable = false;
+    if (!kind_ok || (dev[c].flags & SEG_UNALIGNED) || compressed(s)) streamable = false;
     else if (stream_width == 0) stream_width = s.width;
     else if (stream_width != s.width) streamable = false;
   }
@@ -650,7 +645,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     v.kind = VIEW_GENERIC;
     const bool aligned = reinterpret_cast<uintptr_t>(s.data) % 16 == 0;   // the kernels that use views read 16 bytes per lane
     if (aligned && s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT && !s.nulls) v.kind = VIEW_INT32;
-    if (aligned && s.encoding == HY_ENC_FRAME_OF_REFERENCE && !s.nulls) v.kind = s.width == 1 ? VIEW_FOR8 : s.width == 2 ? VIEW_FOR16 : VIEW_FOR32;
+    if (aligned && s.encoding == HY_ENC_FRAME_OF_REFERENCE && !s.nulls && s.width != 0) v.kind = s.width == 1 ? VIEW_FOR8 : s.width == 2 ? VIEW_FOR16 : VIEW_FOR32;
   }
   // The five descriptor tables travel as ONE block with ONE copy (operator chains create a reference column per operator and
   // column: five allocations and five synchronous copies each were most of what a chain's step cost on the host).
@@ -693,12 +688,132 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   return HY_OK;
 }
 
+}  // extern "C"
+
+namespace hy {
+
+// ---- decoded twins of run-length / bit-packed segments (hy_column::plain) -------------------------------------------------------------
+// The compressed buffers are resident; these kernels write what RunLengthSegmentIterable (run_length_segment_iterable.hpp:100-160: row r
+// belongs to the first run whose inclusive end position is >= r) and the BitPacking decompressor (bitpacking_decompressor.hpp:35-37:
+// element i = bits [i * b, (i + 1) * b) of the little-endian word stream) hand out, once, into buffers the twin column owns.
+struct ExpandTarget {
+  void* values;        // RunLength: T values[size]; bit-packed: FixedWidthInteger vector of `width` bytes per element
+  uint64_t* nulls;     // RunLength with NULL runs: the ValueSegment's null bitmap, else nullptr
+  uint32_t width;
+};
+
+__global__ __launch_bounds__(256) void expand_compressed(const DevSegment* segments, const ExpandTarget* targets, uint32_t n_chunks) {
+  const uint32_t chunk = blockIdx.x;
+  if (chunk >= n_chunks) return;
+  const DevSegment s = segments[chunk];
+  const ExpandTarget t = targets[chunk];
+  if (!t.values) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  if (s.encoding == HY_ENC_RUN_LENGTH) {
+    const uint32_t* ends = static_cast<const uint32_t*>(s.aux);
+    const uint8_t* run_is_null = reinterpret_cast<const uint8_t*>(s.nulls);
+    for (uint32_t base = 0; base < s.size; base += 256) {   // (whole waves: the ballot below needs every lane)
+      const uint32_t row = base + tid;
+      bool is_null = false;
+      if (row < s.size) {
+        uint32_t low = 0, high = s.aux_size - 1;   // first run with ends[run] >= row
+        while (low < high) {
+          const uint32_t middle = (low + high) / 2;
+          if (ends[middle] >= row) high = middle; else low = middle + 1;
+        }
+        is_null = run_is_null && run_is_null[low] != 0;
+        if (s.width == 8) static_cast<uint64_t*>(t.values)[row] = is_null ? 0ull : static_cast<const uint64_t*>(s.data)[low];
+        else static_cast<uint32_t*>(t.values)[row] = is_null ? 0u : static_cast<const uint32_t*>(s.data)[low];
+      }
+      const uint64_t word = __ballot(is_null);
+      if (t.nulls && lane == 0 && base + (tid & ~63u) < s.size) t.nulls[(base + tid) >> 6] = word;
+    }
+    return;
+  }
+  const uint64_t* words = static_cast<const uint64_t*>(s.data);
+  const uint32_t bits = s.bits;
+  const uint64_t mask = bits == 64 ? ~0ull : (1ull << bits) - 1;
+  for (uint32_t row = tid; row < s.size; row += 256) {
+    const uint64_t at = uint64_t{row} * bits;
+    const uint32_t shift = static_cast<uint32_t>(at & 63);
+    uint64_t value = words[at >> 6] >> shift;
+    if (shift + bits > 64) value |= words[(at >> 6) + 1] << (64 - shift);
+    value &= mask;
+    if (t.width == 1) static_cast<uint8_t*>(t.values)[row] = static_cast<uint8_t>(value);
+    else if (t.width == 2) static_cast<uint16_t*>(t.values)[row] = static_cast<uint16_t>(value);
+    else static_cast<uint32_t*>(t.values)[row] = static_cast<uint32_t>(value);
+  }
+}
+
+hy_status plain_column(const hy_column* column, const hy_column** plain) {
+  *plain = column;
+  if (!column || !column->has_compressed) return HY_OK;
+  std::lock_guard<std::mutex> lock(column->plain_mutex);
+  if (column->plain) { *plain = column->plain; return HY_OK; }
+  bind_thread_device();
+  const uint32_t n_chunks = column->n_chunks;
+  std::vector<hy_segment> segments(column->host_segments);
+  std::vector<ExpandTarget> targets(n_chunks, ExpandTarget{nullptr, nullptr, 0});
+  size_t arena_bytes = 0;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const hy_segment& s = segments[c];
+    if (s.encoding == HY_ENC_RUN_LENGTH) arena_bytes += align_up(size_t{s.width} * s.size + 16, 256) + (s.nulls ? align_up(8 * ((size_t{s.size} + 63) / 64) + 16, 256) : 0);
+    else if (compressed(s)) arena_bytes += align_up(size_t{s.bits <= 8 ? 1u : s.bits <= 16 ? 2u : 4u} * s.size + 16, 256);
+  }
+  char* arena = nullptr;
+  DeviceBuffer d_targets;
+  HY_TRY(d_targets.alloc(sizeof(ExpandTarget) * n_chunks));
+  HY_HIP(hipMalloc(reinterpret_cast<void**>(&arena), arena_bytes ? arena_bytes : 256));
+  size_t cursor = 0;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    hy_segment& s = segments[c];
+    if (!compressed(s)) continue;
+    ExpandTarget& t = targets[c];
+    if (s.encoding == HY_ENC_RUN_LENGTH) {
+      t.width = s.width;
+      t.values = arena + cursor;
+      cursor += align_up(size_t{s.width} * s.size + 16, 256);
+      if (s.nulls) { t.nulls = reinterpret_cast<uint64_t*>(arena + cursor); cursor += align_up(8 * ((size_t{s.size} + 63) / 64) + 16, 256); }
+      s.encoding = HY_ENC_UNENCODED;
+      s.data = t.values;
+      s.aux = nullptr;
+      s.aux_size = 0;
+      s.nulls = t.nulls;
+    } else {
+      t.width = s.bits <= 8 ? 1u : s.bits <= 16 ? 2u : 4u;
+      t.values = arena + cursor;
+      cursor += align_up(size_t{t.width} * s.size + 16, 256);
+      s.width = t.width;
+      s.bits = 0;
+      s.data = t.values;
+    }
+  }
+  hipStream_t stream = current_stream();
+  hipError_t err = hipMemcpyAsync(d_targets.ptr, targets.data(), sizeof(ExpandTarget) * n_chunks, hipMemcpyHostToDevice, stream);
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(expand_compressed, dim3(n_chunks), dim3(256), 0, stream, column->d_segments, d_targets.as<ExpandTarget>(), n_chunks);
+    err = hipStreamSynchronize(stream);   // (`targets` dies with this call; other threads may read the twin as soon as it is published)
+  }
+  hy_column* twin = nullptr;
+  hy_status status = err == hipSuccess ? hy_column_create(segments.data(), n_chunks, HY_MEM_DEVICE, &twin) : fail(HY_ERR_DEVICE, "decoding a compressed column failed: %s", hipGetErrorString(err));
+  if (status != HY_OK) { (void)hipFree(arena); return status; }
+  twin->owned.push_back(arena);
+  column->plain = twin;
+  *plain = twin;
+  return HY_OK;
+}
+
+}  // namespace hy
+
+extern "C" {
+
 hy_status hy_column_destroy(hy_column* column) {
   if (!column) return HY_OK;
   // The descriptor block goes back to this thread's pool and is handed out again in the order of this thread's stream: wait for that
   // stream only (a column that other threads still use must not be destroyed: the caller's contract, as for any shared object) --
   // a device-wide synchronise here stalled every thread's stream at every step of an operator chain.
   if (column->descriptors_pooled) (void)hipStreamSynchronize(t_stream);
+  if (column->plain) (void)hy_column_destroy(column->plain);
   for (void* p : column->owned) (void)hipFree(p);
   for (auto& block : column->pooled) pool_release(block.second, block.first);
   if (!column->descriptors_pooled) {

@@ -124,6 +124,7 @@ __device__ __forceinline__ void finish_job(const DevSegment& s, uint32_t c, cons
   job.null_vid = 0xFFFFFFFFu;
   job.lo = 0;
   job.span = 0;
+  job.range_begin = job.range_end = job.hole_begin = job.hole_end = 0;
   const uint32_t cond = p.condition;
 
   if (cond >= HY_PRED_LIKE && cond <= HY_PRED_NOT_LIKE_INSENSITIVE) {   // column_like_table_scan_impl.cpp:69-121
@@ -293,9 +294,84 @@ __device__ __forceinline__ void finish_job(const DevSegment& s, uint32_t c, cons
   }
 }
 
+// ---- sorted chunks: SortedSegmentSearch (sorted_segment_search.hpp:20-384, used by column_vs_value_table_scan_impl.cpp:46-55,182-209 and
+// column_between_table_scan_impl.cpp:60-110 when the chunk is flagged as sorted by the scanned column) -----------------------------------
+// The reference narrows [begin, end) with lower_bound / upper_bound on the segment's values and writes the positions in between (two
+// ranges for NotEquals).  Here: the chunk's normalised job classifies a row as below / inside / above the predicate's value range, a
+// wave finds the ends of the NULL block and of the inside block with 64-ary searches (three dependent loads for 65 535 rows), and the
+// job becomes JOB_RANGE: the scan kernel emits the positions without reading the segment.  The rows are the reference's: on a chunk
+// that is sorted as flagged, "the rows between the bounds" and "the rows that satisfy the predicate" are the same set.
+__device__ __forceinline__ uint32_t load_element(const DevSegment& s, uint32_t i);   // (defined with the row evaluation below)
+__device__ __forceinline__ uint32_t run_of_row(const DevSegment& s, uint32_t row);
+__device__ __forceinline__ bool sorted_row_is_null(const DevSegment& s, uint32_t row) {
+  if (s.encoding == HY_ENC_DICTIONARY) return load_element(s, row) >= s.aux_size;
+  if (s.encoding == HY_ENC_RUN_LENGTH) return s.nulls && reinterpret_cast<const uint8_t*>(s.nulls)[run_of_row(s, row)] != 0;
+  return s.nulls && ((s.nulls[row >> 6] >> (row & 63)) & 1) != 0;
+}
+
+// -1: the row's value lies below the job's range, 0: inside, +1: above (the row is not NULL).
+__device__ __forceinline__ int sorted_row_side(const DevSegment& s, const ScanJob& job, uint32_t row) {
+  if (s.encoding == HY_ENC_DICTIONARY) {   // value ids: unsigned, ordered like the values
+    const uint64_t x = load_element(s, row), lo = static_cast<uint32_t>(job.lo), hi = lo + static_cast<uint32_t>(job.span);
+    return x < lo ? -1 : x > hi ? 1 : 0;
+  }
+  const void* values = s.data;
+  uint32_t index = row;
+  if (s.encoding == HY_ENC_RUN_LENGTH) index = run_of_row(s, row);
+  switch (job.kind) {
+    case KIND_U32: {   // int32 values
+      const int64_t v = s.encoding == HY_ENC_FRAME_OF_REFERENCE ? static_cast<int32_t>(load_element(s, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]))
+                                                                : static_cast<const int32_t*>(values)[index];
+      const int64_t lo = static_cast<int32_t>(static_cast<uint32_t>(job.lo)), hi = lo + static_cast<uint32_t>(job.span);
+      return v < lo ? -1 : v > hi ? 1 : 0;
+    }
+    case KIND_I64: {
+      const int64_t v = static_cast<const int64_t*>(values)[index], lo = static_cast<int64_t>(job.lo);
+      return v < lo ? -1 : static_cast<uint64_t>(v) - job.lo > job.span ? 1 : 0;
+    }
+    case KIND_F32: {
+      const float x = static_cast<const float*>(values)[index], a = __uint_as_float(static_cast<uint32_t>(job.lo)), b = __uint_as_float(static_cast<uint32_t>(job.span));
+      if (!((job.flags & JF_LOWER_INCL) ? x >= a : x > a)) return -1;
+      return ((job.flags & JF_UPPER_INCL) ? x <= b : x < b) ? 0 : 1;
+    }
+    default: {
+      const double x = static_cast<const double*>(values)[index], a = __longlong_as_double(static_cast<long long>(job.lo)), b = __longlong_as_double(static_cast<long long>(job.span));
+      if (!((job.flags & JF_LOWER_INCL) ? x >= a : x > a)) return -1;
+      return ((job.flags & JF_UPPER_INCL) ? x <= b : x < b) ? 0 : 1;
+    }
+  }
+}
+
+// The end of the prefix of [begin, end) whose rows satisfy `pred` (true for a prefix, false behind it), found by one wave: every round
+// probes 64 rows and keeps the 1/64 of the range in which the prefix ends.
+template <typename Pred>
+__device__ __forceinline__ uint32_t wave_prefix_end(uint32_t begin, uint32_t end, uint32_t lane, Pred pred) {
+  while (end - begin > 64) {
+    const uint32_t step = (end - begin + 63) / 64;
+    const uint32_t probe = begin + lane * step;
+    const unsigned long long holds = __ballot(probe < end && pred(probe));
+    const uint32_t first_false = ~holds ? static_cast<uint32_t>(__ffsll(static_cast<long long>(~holds)) - 1) : 64u;
+    if (first_false == 0) return begin;
+    const uint32_t known_false = begin + first_false * step;   // (beyond `end` if every probe held)
+    begin += (first_false - 1) * step + 1;                     // the last probe that held, plus one
+    if (first_false < 64 && known_false < end) end = known_false;
+  }
+  const unsigned long long holds = __ballot(begin + lane < end && pred(begin + lane));
+  const uint32_t first_false = ~holds ? static_cast<uint32_t>(__ffsll(static_cast<long long>(~holds)) - 1) : 64u;
+  return begin + first_false;
+}
+
+__device__ __forceinline__ bool job_takes_sorted_search(const DevSegment& seg, const PredicateArgs& p, const ScanJob& job) {
+  const uint32_t cond = p.condition;
+  return seg.sorted_by != HY_SORT_NONE && !p.no_ranges && seg.size != 0 && job.mode == JOB_SCAN && !(job.flags & JF_NEVER) && cond <= HY_PRED_BETWEEN_EXCLUSIVE &&
+         job.kind != KIND_NULLTEST && job.kind != KIND_VALUE_ID_SET;
+}
+
 // One 256-thread workgroup per DATA chunk of the scanned column (for reference columns: of the referenced column).
 __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, uint32_t n_chunks, PredicateArgs p, ScanJob* jobs, uint32_t* overflow) {
   __shared__ uint32_t s_bound[4];
+  __shared__ ScanJob s_job;
+  __shared__ uint32_t s_range[2];
   const uint32_t c = blockIdx.x;
   if (c == 0 && threadIdx.x == 0) *overflow = 0;
   if (c >= n_chunks) return;
@@ -306,10 +382,55 @@ __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, 
     if (lane == 0) s_bound[wave] = r;
   }
   __syncthreads();
+  if (seg.sorted_by == HY_SORT_NONE) {   // (uniform: the common case leaves here)
+    if (threadIdx.x != 0) return;
+    ScanJob job;
+    finish_job(seg, c, p, s_bound, job);
+    jobs[c] = job;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    ScanJob job;
+    finish_job(seg, c, p, s_bound, job);
+    s_job = job;
+  }
+  __syncthreads();
+  const ScanJob job = s_job;
+  if (!job_takes_sorted_search(seg, p, job)) {
+    if (threadIdx.x == 0) jobs[c] = job;
+    return;
+  }
+  if (wave < 2) {   // wave 0: where the inside block begins, wave 1: where it ends; both find the NULL block first
+    const bool ascending = seg.sorted_by == HY_SORT_ASCENDING_NULLS_FIRST || seg.sorted_by == HY_SORT_ASCENDING_NULLS_LAST;
+    const bool nulls_last = seg.sorted_by == HY_SORT_ASCENDING_NULLS_LAST || seg.sorted_by == HY_SORT_DESCENDING_NULLS_LAST;
+    uint32_t begin = 0, end = seg.size;
+    if (seg.encoding == HY_ENC_DICTIONARY || seg.nulls) {
+      if (nulls_last) end = wave_prefix_end(0, seg.size, lane, [&](uint32_t row) { return !sorted_row_is_null(seg, row); });
+      else begin = wave_prefix_end(0, seg.size, lane, [&](uint32_t row) { return sorted_row_is_null(seg, row); });
+    }
+    // ascending: below | inside | above; descending: above | inside | below
+    const int before = ascending ? -1 : 1;
+    uint32_t bound;
+    if (wave == 0) bound = wave_prefix_end(begin, end, lane, [&](uint32_t row) { return sorted_row_side(seg, job, row) == before; });
+    else bound = wave_prefix_end(begin, end, lane, [&](uint32_t row) { return sorted_row_side(seg, job, row) != -before; });
+    if (lane == 0) s_range[wave] = bound;
+    if (wave == 0 && lane == 0) { s_bound[0] = begin; s_bound[1] = end; }
+  }
+  __syncthreads();
   if (threadIdx.x != 0) return;
-  ScanJob job;
-  finish_job(seg, c, p, s_bound, job);
-  jobs[c] = job;
+  ScanJob ranged = job;
+  ranged.mode = JOB_RANGE;
+  const uint32_t inside_begin = s_range[0], inside_end = s_range[1] < s_range[0] ? s_range[0] : s_range[1];
+  if (job.flags & JF_INVERT) {   // NotEquals: the non-NULL rows without the inside block
+    ranged.range_begin = s_bound[0];
+    ranged.range_end = s_bound[1];
+    ranged.hole_begin = inside_begin;
+    ranged.hole_end = inside_end;
+  } else {
+    ranged.range_begin = inside_begin;
+    ranged.range_end = inside_end;
+  }
+  jobs[c] = ranged;
 }
 
 // Validate: one job per chunk of the MVCC column.  Entirely visible chunks (validate.cpp:57-68) need no row test.
@@ -339,6 +460,23 @@ __device__ __forceinline__ uint32_t load_compressed(const void* data, uint32_t w
   return static_cast<const uint32_t*>(data)[i];
 }
 
+// Element `i` of a segment's attribute / offset vector: FixedWidthInteger, or (width 0) a BitPackingVector -- compact::vector<uint32_t, 0,
+// uint64_t>: bits [i * b, (i + 1) * b) of a little-endian stream of 64-bit words, unpacked in registers (bitpacking_decompressor.hpp:35-37).
+__device__ __forceinline__ uint32_t load_element(const DevSegment& s, uint32_t i) {
+  if (s.width != 0) return load_compressed(s.data, s.width, i);
+  const uint64_t* words = static_cast<const uint64_t*>(s.data);
+  const uint64_t at = uint64_t{i} * s.bits;
+  const uint32_t shift = static_cast<uint32_t>(at & 63);
+  uint64_t value = words[at >> 6] >> shift;
+  if (shift + s.bits > 64) value |= words[(at >> 6) + 1] << (64 - shift);
+  return static_cast<uint32_t>(value & ((1ull << s.bits) - 1));
+}
+
+// A row against a JOB_RANGE job (a sorted chunk's matching rows, found by prepare_jobs).
+__device__ __forceinline__ bool row_in_job_range(const ScanJob& job, uint32_t row) {
+  return row - job.range_begin < job.range_end - job.range_begin && !(row - job.hole_begin < job.hole_end - job.hole_begin);
+}
+
 __device__ __forceinline__ bool float_in_range(float x, const ScanJob& job) {
   const float a = __uint_as_float(static_cast<uint32_t>(job.lo)), b = __uint_as_float(static_cast<uint32_t>(job.span));
   const bool lower_ok = (job.flags & JF_LOWER_INCL) ? x >= a : x > a;
@@ -352,10 +490,39 @@ __device__ __forceinline__ bool double_in_range(double x, const ScanJob& job) {
   return lower_ok && upper_ok;
 }
 
+// values[index] of an unencoded vector (a ValueSegment's values, a RunLengthSegment's run values) against the job's range.
+__device__ __forceinline__ bool value_in_job(const void* values, uint32_t index, const ScanJob& job) {
+  switch (job.kind) {
+    case KIND_U32: return (static_cast<const uint32_t*>(values)[index] - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+    case KIND_I64: return (static_cast<const uint64_t*>(values)[index] - job.lo) <= job.span;
+    case KIND_F32: return float_in_range(static_cast<const float*>(values)[index], job);
+    default: return double_in_range(static_cast<const double*>(values)[index], job);
+  }
+}
+
+// RunLengthSegment: the run of `row` = the first run whose inclusive end position is >= row (run_length_segment_iterable.hpp:100-160).
+__device__ __forceinline__ uint32_t run_of_row(const DevSegment& s, uint32_t row) {
+  const uint32_t* ends = static_cast<const uint32_t*>(s.aux);
+  uint32_t low = 0, high = s.aux_size - 1;
+  while (low < high) {
+    const uint32_t middle = (low + high) / 2;
+    if (ends[middle] >= row) high = middle; else low = middle + 1;
+  }
+  return low;
+}
+__device__ __forceinline__ bool eval_run(const DevSegment& s, const ScanJob& job, uint32_t run) {
+  const bool is_null = s.nulls && reinterpret_cast<const uint8_t*>(s.nulls)[run] != 0;
+  const bool invert = job.flags & JF_INVERT;
+  if (job.kind == KIND_NULLTEST) return is_null != invert;
+  return !is_null && value_in_job(s.data, run, job) != invert;
+}
+
 // Scalar evaluation of one row of a DATA segment: tails, unaligned buffers and pos-list gathers.
 __device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) {
   if (job.mode == JOB_ALL) return true;
   if (job.mode == JOB_NONE || (job.flags & JF_NEVER)) return false;
+  if (job.mode == JOB_RANGE) return row_in_job_range(job, row);
+  if (s.encoding == HY_ENC_RUN_LENGTH) return eval_run(s, job, run_of_row(s, row));
   if (s.encoding == HY_ENC_MVCC) {   // Validate::is_row_visible (validate.cpp:47-55)
     const uint32_t snapshot = static_cast<uint32_t>(job.lo), our_tid = static_cast<uint32_t>(job.span);
     const uint32_t tid = static_cast<const uint32_t*>(s.data)[row], begin = static_cast<const uint32_t*>(s.aux)[row];
@@ -364,7 +531,7 @@ __device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) 
   }
   const bool invert = job.flags & JF_INVERT;
   if (s.encoding == HY_ENC_DICTIONARY) {
-    const uint32_t vid = load_compressed(s.data, s.width, row);
+    const uint32_t vid = load_element(s, row);
     if (job.kind == KIND_VALUE_ID_SET) {
       return vid < job.null_vid && ((reinterpret_cast<const uint64_t*>(job.lo)[vid >> 6] >> (vid & 63)) & 1) != 0;
     }
@@ -376,15 +543,10 @@ __device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) 
   if (is_null) return false;
   bool in;
   if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
-    const uint32_t x = load_compressed(s.data, s.width, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]);
+    const uint32_t x = load_element(s, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]);
     in = (x - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
   } else {
-    switch (job.kind) {
-      case KIND_U32: in = (static_cast<const uint32_t*>(s.data)[row] - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span); break;
-      case KIND_I64: in = (static_cast<const uint64_t*>(s.data)[row] - job.lo) <= job.span; break;
-      case KIND_F32: in = float_in_range(static_cast<const float*>(s.data)[row], job); break;
-      default: in = double_in_range(static_cast<const double*>(s.data)[row], job); break;
-    }
+    in = value_in_job(s.data, row, job);
   }
   return in != invert;
 }
@@ -420,7 +582,23 @@ __device__ __forceinline__ uint32_t eval8_u32(const DevSegment& s, const ScanJob
 
 // Match bits of 8 rows [row0, row0+8) of a data segment; rows >= size are masked off by the caller.
 __device__ __forceinline__ uint32_t eval8(const DevSegment& s, const ScanJob& job, uint32_t row0, uint32_t valid) {
-  if (valid < 8 || (s.flags & SEG_UNALIGNED)) {
+  if (job.mode == JOB_RANGE) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) bits |= (j < valid && row_in_job_range(job, row0 + j) ? 1u : 0u) << j;
+    return bits;
+  }
+  if (s.encoding == HY_ENC_RUN_LENGTH) {   // one search of the end positions, then the runs are walked
+    const uint32_t* ends = static_cast<const uint32_t*>(s.aux);
+    uint32_t run = run_of_row(s, row0), bits = 0;
+    bool matches = eval_run(s, job, run);
+    for (uint32_t j = 0; j < valid; ++j) {
+      if (row0 + j > ends[run]) { ++run; matches = eval_run(s, job, run); }
+      bits |= (matches ? 1u : 0u) << j;
+    }
+    return bits;
+  }
+  if (valid < 8 || (s.flags & SEG_UNALIGNED) || s.width == 0) {
     uint32_t bits = 0;
     for (uint32_t j = 0; j < valid; ++j) bits |= (eval_row(s, job, row0 + j) ? 1u : 0u) << j;
     return bits;
@@ -746,7 +924,7 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
   } else if (seg.encoding == HY_ENC_REFERENCE) {
     uint32_t mode = JOB_SCAN;
     if (seg.ref_chunk_id != 0xFFFFFFFFu) mode = a.jobs[seg.ref_chunk_id].mode;
-    if ((mode == JOB_SCAN || (mode == JOB_ALL && a.materialize_all)) && seg.ref_chunk_id != 0xFFFFFFFFu) {
+    if ((mode == JOB_SCAN || mode == JOB_RANGE || (mode == JOB_ALL && a.materialize_all)) && seg.ref_chunk_id != 0xFFFFFFFFu) {
       // A PosList that references ONE chunk (what a first TableScan, a Validate or a join's write_output_chunks guarantee,
       // abstract_dereferenced_column_table_scan_impl.cpp:38-46): the referenced segment and its job are the same for every row --
       // scalar registers instead of two descriptor loads per row -- and only the offsets of the RowIDs are read.
@@ -769,7 +947,7 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
           if (m) mask |= 1u << (8 * k + j);
         }
       }
-    } else if (mode == JOB_SCAN || (mode == JOB_ALL && a.materialize_all)) {
+    } else if (mode == JOB_SCAN || mode == JOB_RANGE || (mode == JOB_ALL && a.materialize_all)) {
 #pragma unroll 1
       for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
@@ -787,7 +965,7 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
     }
   } else {
     const ScanJob job = a.jobs[slice.chunk];
-    if (job.mode == JOB_SCAN && !(job.flags & JF_NEVER)) {
+    if ((job.mode == JOB_SCAN || job.mode == JOB_RANGE) && !(job.flags & JF_NEVER)) {
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
@@ -900,6 +1078,16 @@ __device__ __forceinline__ uint32_t evaluate_loaded(const SliceLoad<W>& ld, cons
     }
   }
   if (job.mode == JOB_ALL) return materialize_all ? valid : 0u;
+  if (job.mode == JOB_RANGE) {   // a sorted chunk: the matching rows are known, nothing was loaded
+    uint32_t mask = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t row0 = slice.row_begin + wave * 2048 + k * 512 + lane * 8;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) mask |= (row_in_job_range(job, row0 + j) ? 1u : 0u) << (8 * k + j);
+    }
+    return mask & valid;
+  }
   if (job.mode != JOB_SCAN || (job.flags & JF_NEVER)) return 0u;
 
   const bool invert = job.flags & JF_INVERT;
@@ -1382,6 +1570,7 @@ hy_status prepare_scan_jobs(const hy_column* column, const hy_predicate* predica
   pa.value = predicate->value;
   pa.value2 = predicate->value2;
   pa.column_is_nullable = predicate->column_is_nullable;
+  pa.no_ranges = 1;   // (fused_rows evaluates JOB_SCAN / JOB_ALL / JOB_NONE)
   char* cursor = static_cast<char*>(staging) + 256;
   auto stage = [&](const void* host, size_t bytes, const void** dev) -> hy_status {
     *dev = nullptr;
@@ -1410,8 +1599,16 @@ struct VisibilityArgs {   // hy_validate
 
 static hy_status run_scan(const hy_column* column, const hy_column* right, const hy_predicate* predicate, uint32_t condition,
                           const uint32_t* excluded, uint32_t n_excluded, hy_scan_result* result, const VisibilityArgs* visibility = nullptr) {
+  // Run-length / bit-packed segments are read in place by a ColumnVsValue / Between / IsNull / Like scan of the data column itself; the
+  // two-column scan and the scan through reference segments read the decoded twins (hy_device.hpp) -- a reference segment's `ref`
+  // already points at the twin's descriptors, so the jobs are prepared from the twin as well.
+  if (right) {
+    HY_TRY(plain_column(column, &column));
+    HY_TRY(plain_column(right, &right));
+  }
   const uint32_t n_chunks = column->n_chunks;
   const hy_column* data_column = column->is_reference ? column->ref : column;
+  if (column->is_reference) HY_TRY(plain_column(data_column, &data_column));
   const uint32_t n_data_chunks = data_column ? data_column->n_chunks : 0;
   const bool host_result = result->mem == HY_MEM_HOST;
   if (!result->offsets) return fail(HY_ERR_INVALID, "scan result: offsets array missing");

@@ -204,7 +204,7 @@ class DeviceReferenceColumn:
 
 
 _SEGMENT_DTYPE = np.dtype([("encoding", np.uint32), ("data_type", np.uint32), ("size", np.uint32), ("width", np.uint32), ("data", np.uint64), ("aux", np.uint64),
-                           ("aux_size", np.uint32), ("ref_chunk_id", np.uint32), ("nulls", np.uint64), ("ref", np.uint64)])
+                           ("aux_size", np.uint32), ("ref_chunk_id", np.uint32), ("nulls", np.uint64), ("ref", np.uint64), ("sorted_by", np.uint32), ("bits", np.uint32)])
 assert _SEGMENT_DTYPE.itemsize == C.sizeof(abi.Segment)
 
 

@@ -49,6 +49,12 @@ enum class JoinMode : uint8_t { Inner, Left, Right, FullOuter, Cross, Semi, Anti
 enum class WindowFunction : uint8_t { Min, Max, Sum, Avg, Count, CountDistinct, StandardDeviationSample, Any };
 enum class EncodingType : uint8_t { Unencoded, Dictionary, FrameOfReference };
 enum class TableType : uint8_t { Data, References };
+enum class SortMode : uint8_t { AscendingNullsFirst, DescendingNullsFirst, AscendingNullsLast, DescendingNullsLast };   // types.hpp:219
+struct SortColumnDefinition {   // types.hpp:245-251
+  explicit SortColumnDefinition(ColumnID init_column, SortMode init_sort_mode = SortMode::AscendingNullsFirst) : column(init_column), sort_mode(init_sort_mode) {}
+  ColumnID column;
+  SortMode sort_mode;
+};
 
 struct NullValue {};
 using AllTypeVariant = std::variant<NullValue, int32_t, int64_t, float, double, std::string>;
@@ -271,9 +277,14 @@ class Chunk {   // storage/chunk.hpp:38-218
   const std::shared_ptr<AbstractSegment>& get_segment(ColumnID column_id) const { return _segments.at(column_id); }
   void replace_segment(ColumnID column_id, std::shared_ptr<AbstractSegment> segment) { _segments.at(column_id) = std::move(segment); }
   ColumnID column_count() const { return static_cast<ColumnID>(_segments.size()); }
+  // chunk.hpp:160-176: the scan of a column the chunk is flagged as sorted by takes the SortedSegmentSearch path (HY_SORT_* on the descriptor)
+  const std::vector<SortColumnDefinition>& individually_sorted_by() const { return _sorted_by; }
+  void set_individually_sorted_by(const SortColumnDefinition& sorted_by) { _sorted_by = {sorted_by}; }
+  void set_individually_sorted_by(const std::vector<SortColumnDefinition>& sorted_by) { _sorted_by = sorted_by; }
 
  private:
   Segments _segments;
+  std::vector<SortColumnDefinition> _sorted_by;
   std::shared_ptr<MvccData> _mvcc_data;
   bool _is_mutable = true;
   uint32_t _invalid_row_count = 0;
@@ -580,6 +591,9 @@ inline std::shared_ptr<DeviceColumn> device_column_of_chunks(const std::shared_p
     d.size = segment->size();
     d.data_type = static_cast<uint32_t>(segment->data_type());
     d.ref_chunk_id = 0xFFFFFFFFu;
+    for (const auto& sorted_by : table->get_chunk(table_chunk)->individually_sorted_by()) {   // column_vs_value_table_scan_impl.cpp:46-55
+      if (sorted_by.column == column_id) d.sorted_by = static_cast<uint32_t>(sorted_by.sort_mode) + 1;   // HY_SORT_* = SortMode + 1
+    }
     bool ok = false;
     const auto describe_value = [&](auto* typed) {
       using T = std::decay_t<decltype(typed->values()[0])>;

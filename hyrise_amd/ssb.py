@@ -124,9 +124,46 @@ def _join_dimension(ex, build_column, fact_key_column, carried):
     return build_pos, {name: ex.gather_row_ids(rows, VIRTUAL_CHUNK, probe_pos) for name, rows in carried.items()}
 
 
-def run_query(ex, columns, query, fact_first_chunk=0):
+def _join_dimension_repartitioned(comm, ex, key_column, dimension_rows, fact_key_column, carried):
+    """The same join as a HASH-REPARTITIONED one (configs[4]: "hash repartition over xGMI"): rank r builds over the filtered dimension
+    rows whose key hashes to r -- every rank holds the dimension tables, so its partition is a local cut of the scan's output -- every
+    (key, position) of this rank's fact table travels to the rank that owns the key (one all-to-all of keys, one of positions:
+    hy_repartition_pack groups them by destination on the device), is joined there against 1 / G of the build side, and every match
+    travels back to the rank its fact row came from together with the dimension row it met (the second all-to-all pair).  Returns
+    (base RowIDs of the dimension rows, carried RowID arrays) like _join_dimension; pair ORDER differs from the single-process join
+    (the aggregate above does not depend on it)."""
+    from .distributed import REPARTITION_CHUNK
+    torch = comm.torch
+    world, me = comm.world, comm.rank
+    build_table = ex.reference_column(key_column, dimension_rows, VIRTUAL_CHUNK)
+    keys, positions, counts = ex.repartition(build_table, world, 0)
+    begin = sum(counts[:me])
+    build_keys = keys[begin:begin + counts[me]]
+    build_rows = ex.gather_row_ids(dimension_rows, VIRTUAL_CHUNK, positions[begin:begin + counts[me]])   # base RowIDs of this rank's partition
+    fact_keys, fact_positions, fact_counts = ex.repartition(fact_key_column, world, 0)
+    received_keys, received_counts = comm.all_to_all_var(fact_keys, fact_counts)
+    received_positions, _ = comm.all_to_all_var(fact_positions, fact_counts)
+    build_pos, probe_pos = ex.join(ex.value_column(build_keys, REPARTITION_CHUNK), ex.value_column(received_keys, REPARTITION_CHUNK), abi.JOIN_INNER)
+    matched_dimension = ex.gather_row_ids(build_rows, REPARTITION_CHUNK, build_pos)
+    matched_fact = ex.gather_row_ids(received_positions, REPARTITION_CHUNK, probe_pos)
+    # the way back: a received tuple's source is the block of the receive buffer it sits in
+    flat = probe_pos[:, 0].to(torch.int64) * REPARTITION_CHUNK + probe_pos[:, 1].to(torch.int64)
+    bounds = torch.cumsum(torch.tensor(received_counts, dtype=torch.int64, device=flat.device), 0)
+    source = torch.bucketize(flat, bounds, right=True)
+    order = torch.argsort(source, stable=True)
+    back_counts = [int(c) for c in torch.bincount(source, minlength=world).cpu().tolist()]
+    dimension_home, _ = comm.all_to_all_var(matched_dimension[order].contiguous(), back_counts)
+    fact_home, _ = comm.all_to_all_var(matched_fact[order].contiguous(), back_counts)
+    if carried is None:
+        return dimension_home, {"lineorder": fact_home}
+    return dimension_home, {name: ex.gather_row_ids(rows, VIRTUAL_CHUNK, fact_home) for name, rows in carried.items()}
+
+
+def run_query(ex, columns, query, fact_first_chunk=0, comm=None, repartitioned=()):
     """columns: {name: executor column} (the fact table's may be one rank's chunk range).  Returns (group-by columns, aggregates)
-    ready for ex.aggregate / sharded_aggregate, as executor columns over the join result, plus the number of joined rows."""
+    ready for ex.aggregate / sharded_aggregate, as executor columns over the join result, plus the number of joined rows.
+    comm + repartitioned: the dimensions in `repartitioned` ("customer", "part": the large ones) are joined by hash repartition
+    (_join_dimension_repartitioned) instead of against a full replica."""
     if query == "2.1":
         dims = [("part", "p_partkey", "p_category", abi.PRED_EQUALS, 12, None, "lo_partkey"),
                 ("supplier", "s_suppkey", "s_region", abi.PRED_EQUALS, AMERICA, None, "lo_suppkey")]
@@ -140,6 +177,10 @@ def run_query(ex, columns, query, fact_first_chunk=0):
     for table, key, filter_column, condition, value, value2, fact_key in dims:
         build, dimension_rows = _dimension(ex, columns, key, filter_column, condition, value, value2)
         fact_column = columns[fact_key] if carried is None else ex.reference_column(columns[fact_key], carried["lineorder"], VIRTUAL_CHUNK)
+        if comm is not None and table in repartitioned:
+            carried_dimension, carried = _join_dimension_repartitioned(comm, ex, columns[key], dimension_rows, fact_column, carried)
+            carried[table] = carried_dimension
+            continue
         build_pos, carried = _join_dimension(ex, build, fact_column, carried)
         carried[table] = ex.gather_row_ids(dimension_rows, VIRTUAL_CHUNK, build_pos)
     # the date dimension is not filtered: build = the whole d_datekey column
@@ -172,8 +213,9 @@ def result_rows(groups):
 
 # ---- measurement (bench.py, tools/ssb_bench.py) -----------------------------------------------------------------------------
 def bench(sf=30.0, steps=3, world=1, rank=0, dist=None, share_gpu=False, local_rank=0, verify=False):
-    """Q2.1 and Q4.1 at `sf` on this rank's GPU (world > 1: lineorder chunk-sharded, dimensions replicated, groups combined by the
-    sharded AggregateHash); times are per query, maximum over the ranks.  Returns a dict (meaningful on rank 0)."""
+    """Q2.1 and Q4.1 at `sf` on this rank's GPU (world > 1: lineorder chunk-sharded, groups combined by the sharded AggregateHash; timed
+    twice: every dimension replicated, and `customer` / `part` joined by hash repartition); times are per query, maximum over the
+    ranks.  Returns a dict (meaningful on rank 0)."""
     import time
     import torch
     from .distributed import Comm, HipExecutor, aggregate_groups, shard_column, sharded_aggregate
@@ -197,34 +239,47 @@ def bench(sf=30.0, steps=3, world=1, rank=0, dist=None, share_gpu=False, local_r
     for query in ("2.1", "4.1"):
         holder = {}
 
-        def once():
-            groupby, aggregates, joined = run_query(ex, columns, query)
-            if comm is None:
-                holder["groups"] = aggregate_groups(ex, groupby, aggregates)
-            else:
-                holder["groups"] = sharded_aggregate(comm, ex, groupby, aggregates, first_chunk)
-            holder["joined"] = joined
+        def timed(repartitioned):
+            def once():
+                groupby, aggregates, joined = run_query(ex, columns, query, comm=comm, repartitioned=repartitioned)
+                if comm is None:
+                    holder["groups"] = aggregate_groups(ex, groupby, aggregates)
+                else:
+                    holder["groups"] = sharded_aggregate(comm, ex, groupby, aggregates, first_chunk)
+                holder["joined"] = joined
 
-        once()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
             once()
-        torch.cuda.synchronize()
-        seconds = (time.perf_counter() - t0) / steps
-        joined = holder["joined"]
-        if comm is not None:
-            t = torch.tensor([seconds], dtype=torch.float64, device=comm._device)
-            comm.all_reduce(t, "max")
-            seconds = float(t.item())
-            j = torch.tensor([joined], dtype=torch.int64, device=comm._device)
-            comm.all_reduce(j, "sum")
-            joined = int(j.item())
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                once()
+            torch.cuda.synchronize()
+            seconds = (time.perf_counter() - t0) / steps
+            joined = holder["joined"]
+            if comm is not None:
+                t = torch.tensor([seconds], dtype=torch.float64, device=comm._device)
+                comm.all_reduce(t, "max")
+                seconds = float(t.item())
+                j = torch.tensor([joined], dtype=torch.int64, device=comm._device)
+                comm.all_reduce(j, "sum")
+                joined = int(j.item())
+            return seconds, joined
+
+        seconds, joined = timed(())
         algorithmic = referenced_bytes(data, query)
         entry = {"ms": seconds * 1e3, "lineorder_rows_per_s": data.n_lineorder / seconds, "joined_rows": joined, "groups": len(holder["groups"]),
                  "algorithmic_bytes": algorithmic, "GBps_on_algorithmic_bytes": algorithmic / seconds / 1e9}
+        if comm is not None:   # the same query with `customer` / `part` joined by hash repartition (tuples to the key's rank and back)
+            entry["plan"] = "lineorder chunk-sharded, dimensions replicated, groups all-reduced"
+            try:
+                repartition_seconds, repartition_joined = timed(("customer", "part"))
+                entry["repartitioned"] = {"plan": "customer and part joined by hash repartition (two all-to-all pairs per join), the other dimensions replicated",
+                                          "ms": repartition_seconds * 1e3, "lineorder_rows_per_s": data.n_lineorder / repartition_seconds,
+                                          "joined_rows": repartition_joined, "groups": len(holder["groups"])}
+            except Exception as error:   # (reported, not fatal: the replicated plan's numbers above stand on their own)
+                entry["repartitioned"] = {"error": f"{type(error).__name__}: {error}"}
         if verify and rank == 0:
             sql = Q2_1_SQL if query == "2.1" else Q4_1_SQL
             rows = data.sqlite_result(sql)

@@ -43,10 +43,12 @@ class HostSegment:
     """One segment with its buffers as numpy arrays (kept alive for as long as descriptors point at them)."""
 
     def __init__(self, encoding, data_type, size, width, data, aux=None, aux_size=0, nulls=None, ref=None,
-                 ref_chunk_id=abi.INVALID_CHUNK_ID):
+                 ref_chunk_id=abi.INVALID_CHUNK_ID, sorted_by=0, bits=0):
         self.encoding, self.data_type, self.size, self.width = encoding, data_type, int(size), int(width)
         self.data, self.aux, self.aux_size, self.nulls = data, aux, int(aux_size), nulls
         self.ref, self.ref_chunk_id = ref, int(ref_chunk_id)
+        self.sorted_by = int(sorted_by)   # abi.SORT_*: Chunk::individually_sorted_by names this column
+        self.bits = int(bits)             # width == 0: `data` is a BitPackingVector of `bits` bits per element (uint64 words)
 
 
 def encode_segment(values, nulls, encoding, data_type=None):
@@ -137,6 +139,7 @@ class HostColumn:
             d.ref_chunk_id = s.ref_chunk_id
             d.nulls = s.nulls.ctypes.data if s.nulls is not None else None
             d.ref = resolve_ref(s.ref) if s.ref is not None else None
+            d.sorted_by, d.bits = s.sorted_by, s.bits
         return arr
 
 
@@ -186,13 +189,44 @@ def encode_run_length(values, nulls=None):
                        nulls=mask[starts].astype(np.uint8))
 
 
-def expand_run_length(host_column):
-    """The same column with every RunLength segment replaced by the ValueSegment it decodes to (what the residency cache
-    does on upload; the CPU oracle reads plain segments only)."""
-    if not any(s.encoding == abi.ENC_RUN_LENGTH for s in host_column.segments):
+def pack_bits(values, bits):
+    """BitPackingVector (compact::vector<uint32_t, 0, uint64_t>, bitpacking_vector_type.hpp:18): element i in bits
+    [i * bits, (i + 1) * bits) of a little-endian stream of 64-bit words (the layout tests/test_binary_tables.py pins on files
+    Hyrise wrote)."""
+    values = np.asarray(values, dtype=np.uint64)
+    n = len(values)
+    words = (n * bits + 63) // 64
+    stream = np.zeros(max(1, words) * 64, dtype=np.uint8)
+    if n:
+        stream[:n * bits] = ((values[:, None] >> np.arange(bits, dtype=np.uint64)) & np.uint64(1)).astype(np.uint8).reshape(-1)
+    return np.packbits(stream, bitorder="little").view(np.uint64)[:max(1, words)].copy()
+
+
+def bit_pack_segment(segment):
+    """The same Dictionary / FrameOfReference segment with its FixedWidthInteger vector as a BitPackingVector of the fewest bits
+    that hold its largest element (bitpacking_compressor.cpp:14-30: at least one bit)."""
+    assert segment.encoding in (abi.ENC_DICTIONARY, abi.ENC_FRAME_OF_REFERENCE) and segment.width != 0
+    top = int(segment.data.max()) if segment.size else 0
+    bits = max(1, top.bit_length())
+    return HostSegment(segment.encoding, segment.data_type, segment.size, 0, pack_bits(segment.data, bits), aux=segment.aux, aux_size=segment.aux_size,
+                       nulls=segment.nulls, sorted_by=segment.sorted_by, bits=bits)
+
+
+def expand_compressed(host_column):
+    """The same column with every RunLength segment replaced by the ValueSegment it decodes to and every BitPackingVector by the
+    FixedWidthInteger vector of the same elements (what the device decodes for the operators that gather rows; the CPU oracle
+    reads plain segments only)."""
+    if not any(s.encoding == abi.ENC_RUN_LENGTH or (s.width == 0 and s.bits) for s in host_column.segments):
         return host_column
     segments = []
     for s in host_column.segments:
+        if s.width == 0 and s.bits and s.encoding != abi.ENC_RUN_LENGTH:
+            from .binary import unpack_bits
+            elements = unpack_bits(s.data, s.bits, s.size)
+            width = 1 if s.bits <= 8 else 2 if s.bits <= 16 else 4
+            segments.append(HostSegment(s.encoding, s.data_type, s.size, width, elements.astype(_UINT[width]), aux=s.aux, aux_size=s.aux_size, nulls=s.nulls,
+                                        sorted_by=s.sorted_by))
+            continue
         if s.encoding != abi.ENC_RUN_LENGTH:
             segments.append(s)
             continue
@@ -200,8 +234,11 @@ def expand_run_length(host_column):
         mask = np.repeat(np.asarray(s.nulls, dtype=bool), lengths)
         values = np.repeat(s.data, lengths)
         values[mask] = 0
-        segments.append(HostSegment(abi.ENC_UNENCODED, s.data_type, s.size, s.width, values, nulls=pack_nulls(mask) if mask.any() else None))
+        segments.append(HostSegment(abi.ENC_UNENCODED, s.data_type, s.size, s.width, values, nulls=pack_nulls(mask) if mask.any() else None, sorted_by=s.sorted_by))
     return HostColumn(segments, host_column.data_type)
+
+
+expand_run_length = expand_compressed   # (the name the tests of round 2 use)
 
 
 MVCC_MUTABLE = 1 << 31

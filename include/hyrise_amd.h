@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HY_ABI_VERSION 1
+#define HY_ABI_VERSION 2   /* 2: hy_segment carries sorted_by and bits */
 
 typedef int32_t hy_status;
 enum {
@@ -69,7 +69,15 @@ enum { HY_ENC_UNENCODED = 0, HY_ENC_DICTIONARY = 1, HY_ENC_FRAME_OF_REFERENCE = 
        HY_ENC_MVCC = 4 /* not a column encoding: a chunk's MvccData, see hy_validate */,
        HY_ENC_RUN_LENGTH = 5 /* RunLengthSegment<T> (run_length_segment.hpp): data = run values (T[aux_size]), aux = inclusive end
                               * positions (uint32_t[aux_size]), nulls = per-run NULL flags as BYTES (uint8_t[aux_size], cast), width =
-                              * sizeof(T).  HY_MEM_HOST only: the residency cache expands the runs once, on upload. */ };
+                              * sizeof(T).  The runs stay runs in device memory: hy_table_scan reads them in place (one search of
+                              * the end positions per eight rows, run_length_segment_iterable.hpp:100-160); the other operators read a
+                              * ValueSegment twin that a device kernel decodes from them the first time one of them asks. */ };
+
+/* hy_segment::sorted_by: the chunk is individually sorted by this column (Chunk::individually_sorted_by, chunk.hpp:160-176;
+ * HY_SORT_* = hyrise::SortMode + 1, types.hpp:219).  ColumnVsValue / ColumnBetween scans then find the matching row range with
+ * binary searches instead of reading the segment (sorted_segment_search.hpp:20-384, column_vs_value_table_scan_impl.cpp:46-55). */
+enum { HY_SORT_NONE = 0, HY_SORT_ASCENDING_NULLS_FIRST = 1, HY_SORT_DESCENDING_NULLS_FIRST = 2, HY_SORT_ASCENDING_NULLS_LAST = 3,
+       HY_SORT_DESCENDING_NULLS_LAST = 4 };
 
 /* Where the pointers of a descriptor / result live. */
 enum { HY_MEM_HOST = 0, HY_MEM_DEVICE = 1 };
@@ -88,10 +96,14 @@ typedef struct hy_column hy_column; /* opaque: one column of a table, chunk by c
 /*
  * One segment (= one column of one chunk).  Plain views of what Hyrise keeps in pmr_vectors.
  *   UNENCODED          data = T values[size]                       width = sizeof(T)
- *   DICTIONARY         data = attribute vector (value ids)          width = 1|2|4
+ *   DICTIONARY         data = attribute vector (value ids)          width = 1|2|4 (FixedWidthInteger), or width = 0 and
+ *                      bits = 1..32: a BitPackingVector (bitpacking_vector_type.hpp:18) -- compact::vector<uint32_t, 0, uint64_t>:
+ *                      element i occupies bits [i * bits, (i + 1) * bits) of a little-endian stream of 64-bit words.  It stays
+ *                      packed in device memory: hy_table_scan unpacks in registers (bitpacking_decompressor.hpp:35-37), the other
+ *                      operators read a FixedWidthInteger twin unpacked on the device on first use
  *                      aux  = T dictionary[aux_size] sorted unique; may be NULL for HY_TYPE_STRING
  *                      (then comparisons must be passed as pre-resolved value ids, see hy_predicate)
- *   FRAME_OF_REFERENCE data = offset values                         width = 1|2|4
+ *   FRAME_OF_REFERENCE data = offset values                         width = 1|2|4, or bit-packed (width = 0, bits) like DICTIONARY
  *                      aux  = int32 block_minima[aux_size]
  *   REFERENCE          data = hy_row_id pos_list[size]  (NULL => EntireChunkPosList{ref_chunk_id,size})
  *                      ref  = the referenced column (data segments only; reference_segment.hpp:36-38)
@@ -109,6 +121,8 @@ typedef struct hy_segment {
   uint32_t ref_chunk_id;     /* REFERENCE: common chunk id if the pos list references a single chunk, else ~0u */
   const uint64_t* nulls;
   const hy_column* ref;      /* REFERENCE only */
+  uint32_t sorted_by;        /* HY_SORT_*: 0 unless the chunk is flagged as sorted by this column */
+  uint32_t bits;             /* bits per element of a BitPackingVector in `data` (width == 0), else 0 */
 } hy_segment;
 
 /* A literal as the scan implementations receive it after the lossless cast (table_scan.cpp:312-452). */

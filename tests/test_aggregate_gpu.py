@@ -315,12 +315,25 @@ def test_small_domain_kernel(device, monkeypatch):
             codes = max((int(np.prod([g.segments[k].aux_size + 1 for g in groupby])) for k in range(q.n_chunks)), default=1)
             inputs = {id(c): c.segments[0].width for _, c in aggregates if c is not None}
             narrow, wide = sum(1 for v in inputs.values() if v == 1), sum(1 for v in inputs.values() if v == 2)
-            assert used_small_domain() == (1 if widths <= {1, 2} and codes <= 16 and narrow <= 2 and wide <= 2 else 0), context
+            assert used_small_domain() == (1 if widths <= {1, 2} and codes <= 16 and narrow <= 2 and wide <= 1 and len(groupby) <= 2 else 0), context
             monkeypatch.setenv("HY_AGG_NO_SMALL_DOMAIN", "1")
             generic = run_both(groupby, aggregates, context + " (generic kernel)")
             monkeypatch.delenv("HY_AGG_NO_SMALL_DOMAIN")
             assert used_small_domain() == 0
             np.testing.assert_array_equal(got.row_ids[:got.n_groups], generic.row_ids[:generic.n_groups])
+    # a 2-byte column's value that sixteen rows of one group share inside one chunk: its 4-bit counter overflows, the kernel notices
+    # (the counters' sum falls short of the rows counted) and the generic kernel answers
+    n = 60_000
+    price = (np.arange(n) % 50_000 * 1.37 + 900.0).astype(np.float32)
+    price[rng.choice(n, 40, replace=False)] = 123.5
+    key = build_column(np.zeros(n, np.int32), None, 65535, abi.ENC_DICTIONARY)
+    repeated = build_column(price, None, 65535, abi.ENC_DICTIONARY)
+    assert repeated.segments[0].width == 2
+    run_both([key], [(abi.AGG_SUM, repeated), (abi.AGG_COUNT, None)], "a value forty times in one group of one chunk")
+    assert used_small_domain() == 0
+    price[price == 123.5] = 77.25 + np.arange(40, dtype=np.float32)   # (the same column without the repeated value: the kernel keeps it)
+    run_both([key], [(abi.AGG_SUM, build_column(price, None, 65535, abi.ENC_DICTIONARY)), (abi.AGG_COUNT, None)], "no value sixteen times")
+    assert used_small_domain() == 1
     # a shape the kernel does not take: an integer input column, a GROUP BY column with too many distinct values
     ints = build_column(rng.integers(0, 9, 1000).astype(np.int32), None, 500, abi.ENC_DICTIONARY)
     many = build_column(rng.integers(0, 40, 1000).astype(np.int32), None, 500, abi.ENC_DICTIONARY)

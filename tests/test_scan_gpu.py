@@ -405,21 +405,39 @@ def test_poslist_translate(device):
     assert device.hy_poslist_translate(base_dev.handle, C.byref(host_result), abi.POSLIST_DENSE, small.pointer, 16, C.byref(written)) == abi.ERR_INVALID
 
 
+SORT_OF = {"AscendingNullsFirst": abi.SORT_ASCENDING_NULLS_FIRST, "DescendingNullsFirst": abi.SORT_DESCENDING_NULLS_FIRST,
+           "AscendingNullsLast": abi.SORT_ASCENDING_NULLS_LAST, "DescendingNullsLast": abi.SORT_DESCENDING_NULLS_LAST}
+SEGMENT_KINDS = ["Unencoded", "Dictionary", "FrameOfReference", "RunLength", "BitPackedDictionary", "BitPackedFrameOfReference"]
+
+
+def encode_chunk(values, nulls, kind, nullable):
+    """One chunk in one of the layouts the device reads IN PLACE: RunLength segments and BitPackingVectors stay compressed in device
+    memory (the scan unpacks them in registers; csrc/scan.hip load_element / run_of_row)."""
+    if kind == "RunLength":
+        return storage.encode_run_length(values, nulls)
+    base = {"Unencoded": abi.ENC_UNENCODED, "Dictionary": abi.ENC_DICTIONARY, "FrameOfReference": abi.ENC_FRAME_OF_REFERENCE,
+            "BitPackedDictionary": abi.ENC_DICTIONARY, "BitPackedFrameOfReference": abi.ENC_FRAME_OF_REFERENCE}[kind]
+    segment = build_column(values, nulls, max(1, len(values)), base, nullable=nullable).segments[0] if len(values) else storage.encode_segment(values, nulls, base)
+    return storage.bit_pack_segment(segment) if kind.startswith("BitPacked") else segment
+
+
 @pytest.mark.parametrize("np_type", [np.int32, np.int64, np.float32, np.float64], ids=lambda t: t.__name__)
-@pytest.mark.parametrize("encoding", ENCODINGS + [abi.ENC_RUN_LENGTH], ids=["Unencoded", "Dictionary", "FrameOfReference", "RunLength"])
+@pytest.mark.parametrize("kind", SEGMENT_KINDS)
 @pytest.mark.parametrize("sort_mode", KA.BETWEEN_SORT_MODES)
 @pytest.mark.parametrize("nullable", [False, True], ids=["not_null", "nullable"])
-def test_between_known_answers(device, np_type, encoding, sort_mode, nullable):
-    """table_scan_between_test.cpp:194-243 on the device: the reference's expected row lists, and the oracle's PosLists."""
-    if encoding == abi.ENC_FRAME_OF_REFERENCE and np_type != np.int32:
+def test_between_known_answers(device, np_type, kind, sort_mode, nullable):
+    """table_scan_between_test.cpp:194-243 on the device, on the ENCODED segments (the first two chunks encoded, the last a ValueSegment,
+    :40-96) and with the chunks flagged as sorted where the reference flags them: the reference's expected row lists, and the oracle's
+    PosLists."""
+    if kind.endswith("FrameOfReference") and np_type != np.int32:
         pytest.skip("encoding_supports_data_type(): FrameOfReference holds int only")
     a, nulls, b = KA.between_table(np_type, sort_mode, nullable)
-    if encoding == abi.ENC_RUN_LENGTH:   # uploaded as the ValueSegments they decode to (storage.expand_run_length)
-        plain = build_column(a, nulls, 6, abi.ENC_UNENCODED, nullable=nullable)
-        runs = [storage.encode_run_length(a[c * 6:c * 6 + 6], None if nulls is None else nulls[c * 6:c * 6 + 6]) for c in range(2)]
-        host = storage.expand_run_length(storage.HostColumn(runs + plain.segments[2:], plain.data_type))
-    else:
-        host = build_column(a, nulls, 6, [encoding, encoding], nullable=nullable)
+    plain = build_column(a, nulls, 6, abi.ENC_UNENCODED, nullable=nullable)
+    encoded = [encode_chunk(a[c * 6:c * 6 + 6], None if nulls is None else nulls[c * 6:c * 6 + 6], kind, nullable) for c in range(2)]
+    host = storage.HostColumn(encoded + plain.segments[2:], plain.data_type)
+    if sort_mode != "unsorted":   # (NULLs in front, :75)
+        for segment in host.segments:
+            segment.sorted_by = abi.SORT_ASCENDING_NULLS_FIRST if sort_mode == "ascending" else abi.SORT_DESCENDING_NULLS_FIRST
     dev = DeviceColumn(host)
     data_type = storage.TYPE_OF_NP[np.dtype(np_type)]
     cast = (lambda x: np_type(int(x))) if np.issubdtype(np_type, np.integer) else np_type
@@ -433,10 +451,16 @@ def test_between_known_answers(device, np_type, encoding, sort_mode, nullable):
 
 @pytest.mark.parametrize("sort_mode", KA.SORTED_SEGMENT_SORT_MODES)
 @pytest.mark.parametrize("null_usage", KA.SORTED_SEGMENT_NULL_USAGES)
-def test_sorted_segment_search_known_answers(device, sort_mode, null_usage):
-    """table_scan_sorted_segment_search_test.cpp:106-214 on the device (which never looks at sort flags): same positions, same order."""
+@pytest.mark.parametrize("kind", SEGMENT_KINDS)
+@pytest.mark.parametrize("flagged", [True, False], ids=["flagged", "not_flagged"])
+def test_sorted_segment_search_known_answers(device, sort_mode, null_usage, kind, flagged):
+    """table_scan_sorted_segment_search_test.cpp:106-214 on the device, every segment layout: with the chunk's sort flag the scan finds
+    the rows with binary searches (prepare_jobs: JOB_RANGE) and reads nothing, without it every row is tested -- same positions, same
+    order, either way."""
     values, nulls = KA.sorted_search_segment(sort_mode, null_usage)
-    host = build_column(values, nulls, len(values), abi.ENC_UNENCODED, nullable=nulls is not None)
+    host = storage.HostColumn([encode_chunk(values, nulls, kind, nulls is not None)], abi.TYPE_INT)
+    if flagged:
+        host.segments[0].sorted_by = SORT_OF[sort_mode]
     dev = DeviceColumn(host)
     for condition, value, value2, expected in KA.SORTED_SEGMENT_SEARCH_TESTS:
         got = check(host, make_predicate(condition, abi.TYPE_INT, value, value2, nullable=nulls is not None), dev, context=f"condition {condition} value {value} / {value2}")
@@ -444,3 +468,73 @@ def test_sorted_segment_search_known_answers(device, sort_mode, null_usage):
         want = [] if null_usage == "OnlyNulls" else (expected if sort_mode.startswith("Ascending") else expected[::-1])
         assert values[rows].tolist() == want
 
+
+@pytest.mark.parametrize("np_type", [np.int32, np.int64, np.float32, np.float64], ids=lambda t: t.__name__)
+@pytest.mark.parametrize("sort_mode", KA.SORTED_SEGMENT_SORT_MODES)
+def test_sorted_chunks_of_full_size(device, np_type, sort_mode):
+    """Chunks of 65 535 rows, each sorted on its own and flagged (Chunk::individually_sorted_by): the 64-ary searches of prepare_jobs
+    against the oracle's full scan -- every condition, literals below / at / between / above the chunk's values, NULL blocks of
+    different lengths (none, some, a whole chunk), every layout, through the streaming and the generic kernel."""
+    rng = np.random.default_rng(77)
+    ascending, nulls_last = sort_mode.startswith("Ascending"), sort_mode.endswith("NullsLast")
+    data_type = storage.TYPE_OF_NP[np.dtype(np_type)]
+    sizes = [65535, 65535, 40_000, 1, 64, 65]
+    null_counts = [0, 1000, 40_000, 0, 64, 1]
+    chunks = []
+    for size, n_null in zip(sizes, null_counts):
+        body = np.sort(rng.integers(-500, 500, size - n_null) * 2).astype(np_type)   # even values: odd literals fall between them
+        if not ascending:
+            body = body[::-1]
+        filler = np.zeros(n_null, np_type)
+        values = np.concatenate([body, filler] if nulls_last else [filler, body])
+        mask = np.concatenate([np.zeros(len(body), bool), np.ones(n_null, bool)] if nulls_last else [np.ones(n_null, bool), np.zeros(len(body), bool)])
+        chunks.append((values, mask))
+    kinds = [k for k in SEGMENT_KINDS if np_type == np.int32 or not k.endswith("FrameOfReference")]
+    for kind in kinds:
+        host = storage.HostColumn([encode_chunk(v, m, kind, True) for v, m in chunks], data_type)
+        for segment in host.segments:
+            segment.sorted_by = SORT_OF[sort_mode]
+        dev = DeviceColumn(host)
+        for condition in CONDITIONS[:10]:
+            for value, value2 in ((-2000, 2000), (-1000, 998), (0, 0), (-301, 299), (300, -300), (7, 7), (999, 1001), (-1002, -1001), (-600, 601)):
+                for flags in (0, abi.SCAN_MATERIALIZE_ALL_MATCH):
+                    p = make_predicate(condition, data_type, np_type(value), np_type(value2), nullable=True)
+                    check(host, p, dev, flags, context=f"sorted {sort_mode} {kind} {np_type.__name__} cond {condition} lit {value},{value2} flags {flags}")
+
+
+def test_compressed_segments_through_every_operator(device):
+    """RunLength segments and BitPackingVectors stay compressed in device memory; a scan reads them in place, every other operator reads
+    the twin a device kernel decodes once (runtime.hip plain_column): a join, an aggregate, a projection, a ColumnVsColumn scan and a
+    scan through reference segments over such columns answer like the oracle over the decoded columns."""
+    from hyrise_amd.operators import aggregate_hash, join_hash
+    from support import oracle_aggregate, oracle_join
+    rng = np.random.default_rng(29)
+    n, chunk = 150_000, 40_000
+    keys = np.repeat(rng.integers(0, 300, n // 20 + 1), 20)[:n].astype(np.int32)
+    nulls = np.repeat(rng.random(n // 50 + 1) < 0.05, 50)[:n]
+    measures = rng.integers(0, 5000, n).astype(np.int32)
+    for kind in ("RunLength", "BitPackedDictionary", "BitPackedFrameOfReference"):
+        host = storage.HostColumn([encode_chunk(keys[b:b + chunk], nulls[b:b + chunk], kind, True) for b in range(0, n, chunk)], abi.TYPE_INT)
+        packed = storage.HostColumn([encode_chunk(measures[b:b + chunk], None, "BitPackedDictionary", False) for b in range(0, n, chunk)], abi.TYPE_INT)
+        assert kind == "RunLength" or (host.segments[0].width == 0 and 1 <= host.segments[0].bits <= 16)
+        dev, packed_dev = DeviceColumn(host), DeviceColumn(packed)
+        for condition in CONDITIONS:
+            check(host, make_predicate(condition, abi.TYPE_INT, 100, 200, nullable=True), dev, context=f"{kind} cond {condition}")
+        other_host = build_column(rng.integers(0, 400, 2_000).astype(np.int32), None, 700, abi.ENC_DICTIONARY)
+        other = DeviceColumn(other_host)
+        got, want = join_hash(other, dev, abi.JOIN_INNER), oracle_join(other_host, host, abi.JOIN_INNER)
+        assert got.n_pairs == want.n_pairs and got.left[:got.n_pairs].tobytes() == want.left[:want.n_pairs].tobytes()
+        assert got.right[:got.n_pairs].tobytes() == want.right[:want.n_pairs].tobytes()
+        spec = [(abi.AGG_COUNT, None), (abi.AGG_SUM, packed_dev), (abi.AGG_MAX, packed_dev)]
+        sums = aggregate_hash([dev], spec)
+        expected = oracle_aggregate([host], [(abi.AGG_COUNT, None), (abi.AGG_SUM, packed), (abi.AGG_MAX, packed)])
+        assert sums.n_groups == expected.n_groups
+        for column in range(3):
+            assert sums.column(column) == expected.column(column), f"{kind}: aggregate column {column}"
+        got_columns = table_scan_columns(dev, packed_dev, abi.PRED_LESS_THAN)
+        assert_scan_equal(got_columns, oracle_scan_columns(host, packed, abi.PRED_LESS_THAN), f"{kind}: ColumnVsColumn")
+        # a reference table over the compressed column (an EntireChunkPosList per chunk), scanned
+        reference_host = storage.make_reference_column(host, list(range(host.n_chunks)))
+        reference = DeviceColumn(reference_host, refs={id(host): dev})
+        p = make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_INT, 50, 250, nullable=True)
+        assert_scan_equal(table_scan(reference, p), oracle_scan(reference_host, p), f"{kind}: reference segments")

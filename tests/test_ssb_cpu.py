@@ -38,3 +38,19 @@ def test_table_shapes_follow_the_specification():
     assert len(d.c_custkey) == 60_000 and len(d.s_suppkey) == 4_000 and len(d.p_partkey) == 400_000
     assert set(np.unique(d.p_category // 10)) == {1, 2, 3, 4, 5} and d.p_brand1.min() >= 1101 and d.p_brand1.max() <= 5540
     assert ssb.referenced_bytes(d, "2.1") == 4 * (4 * 1000 + 2 * 400_000 + 2 * 4_000 + 2 * 2557)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_replicated_and_repartitioned_plans_match_sqlite():
+    """gloo, two processes, the oracle as the per-rank executor: lineorder chunk-sharded; Q2.1 / Q4.1 with the dimensions replicated and
+    with `customer` / `part` joined by hash repartition (tuples to the key's rank and back) -- both SQLite's rows on every rank."""
+    import os
+    import pickle
+    import tempfile
+    import torch.multiprocessing as mp
+    import ssb_workload
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(ssb_workload.worker, args=(world, os.path.join(tmp, "init"), tmp, "oracle"), nprocs=world, join=True)
+        results = [pickle.load(open(os.path.join(tmp, f"rank{r}.pkl"), "rb")) for r in range(world)]
+    ssb_workload.check_results(results)

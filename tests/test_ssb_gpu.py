@@ -28,3 +28,20 @@ def test_ssb_query_on_device(device, query, sql):
     else:
         sqlite = sorted(((year, nation), profit) for year, nation, profit in data.sqlite_result(sql))
     assert got == sqlite
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_replicated_and_repartitioned_plans(device):
+    """Two processes share the test box's GPU (gloo carries the exchanges through host memory; on a multi-GPU node the same code runs one
+    rank per GPU over RCCL): lineorder chunk-sharded, Q2.1 / Q4.1 with the dimensions replicated and with customer / part joined by hash
+    repartition (hy_repartition_pack, hy_join_hash over the received tuples, hy_gather_row_ids) -- SQLite's rows on every rank."""
+    import os
+    import pickle
+    import tempfile
+    import torch.multiprocessing as mp
+    import ssb_workload
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(ssb_workload.worker, args=(world, os.path.join(tmp, "init"), tmp, "hip"), nprocs=world, join=True)
+        results = [pickle.load(open(os.path.join(tmp, f"rank{r}.pkl"), "rb")) for r in range(world)]
+    ssb_workload.check_results(results)

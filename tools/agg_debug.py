@@ -9,8 +9,8 @@ data = tpch.TpchData(10.0, 42)
 g, m, _ = tpch.q1_core_columns(data)
 gd = [DeviceColumn(c) for c in g]; md = {k: DeviceColumn(v) for k, v in m.items()}
 spec = [(abi.AGG_SUM, md["l_quantity"]), (abi.AGG_SUM, md["l_extendedprice"]), (abi.AGG_AVG, md["l_quantity"]), (abi.AGG_AVG, md["l_extendedprice"]), (abi.AGG_AVG, md["l_discount"]), (abi.AGG_COUNT, None)]
-for name, env in (("default", {}), ("no histograms", {"HY_AGG_SMALL_DEBUG": "1"}), ("no phase 2", {"HY_AGG_SMALL_DEBUG": "2"}), ("phase 2: staging and id loads only", {"HY_AGG_SMALL_DEBUG": "4"}),
-                  ("no dense lookup", {"HY_AGG_SMALL_DEBUG": "8"}), ("no histograms, no phase 2, no dense lookup", {"HY_AGG_SMALL_DEBUG": "11"}), ("generic kernel", {"HY_AGG_NO_SMALL_DOMAIN": "1"})):
+for name, env in (("default", {}), ("no histograms", {"HY_AGG_SMALL_DEBUG": "1"}), ("no 2-byte column", {"HY_AGG_SMALL_DEBUG": "2"}),
+                  ("no dense lookup", {"HY_AGG_SMALL_DEBUG": "8"}), ("no histograms, no 2-byte column, no dense lookup", {"HY_AGG_SMALL_DEBUG": "11"}), ("generic kernel", {"HY_AGG_NO_SMALL_DOMAIN": "1"})):
     os.environ.update(env)
     dt, km = bench.timed_kernel(lib, torch, lambda: aggregate_hash(gd, spec, group_capacity=64), 5, kind="aggregate")
     print(f"{name:24s} {dt*1e3:7.3f} ms/call  kernel {km*1e3:7.1f} us", flush=True)

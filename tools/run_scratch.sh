@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-timeout 300 tests/cpp/multi_gpu_tests 0 0 > gpurun_out/mg2.log 2>&1; echo "rc=$?" >> gpurun_out/mg2.log
-timeout 300 tests/cpp/multi_gpu_tests 0 0 0 > gpurun_out/mg3.log 2>&1; echo "rc=$?" >> gpurun_out/mg3.log
-tail -20 gpurun_out/mg2.log; tail -8 gpurun_out/mg3.log
-timeout 600 python -m pytest tests/test_multi_gpu_cpp_gpu.py tests/test_host_mirror_gpu.py -q -m gpu 2>&1 | tail -5
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/gputest.log 2>&1; echo "rc=$?" >> gpurun_out/gputest.log
+tail -6 gpurun_out/gputest.log
+timeout 300 python tools/agg_debug.py > gpurun_out/agg_debug.log 2>&1; cat gpurun_out/agg_debug.log
+bash tools/run_ssb_profile.sh > gpurun_out/ssb_profile.txt 2>&1; tail -40 gpurun_out/ssb_profile.txt
