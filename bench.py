@@ -584,6 +584,44 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
     pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
     out["int32_value_segments_lt_1995"] = measure(lambda: step_fn(pred, values), lambda m: rows * 4 + m * 8)
     del values
+    # Sorted chunks (Chunk::individually_sorted_by; hyriseBenchmarkTPCH --clustering sorts lineitem by l_shipdate, tpch_benchmark.cpp:61-64):
+    # the reference's SortedSegmentSearch, here prepare_jobs' binary searches -- the kernel writes the positions and reads no row.
+    #   clustered table: the chunks follow each other in date order, all but the chunk that holds 1995-01-01 match entirely or not at all
+    #   per-chunk sorted: every chunk spans all dates and is sorted on its own (every chunk emits a range)
+    def flagged(values_of_chunks):
+        host = storage.make_column(values_of_chunks, None, abi.ENC_DICTIONARY)
+        for segment in host.segments:
+            segment.sorted_by = abi.SORT_ASCENDING_NULLS_FIRST
+        return DeviceColumn(host)
+    pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
+    clustered = flagged(np.sort(days))
+    out["sorted_clustered_table_lt_1995"] = dict(measure(lambda: step_fn(pred, clustered), lambda m: m * 8),
+                                                 note="bytes counted: the RowIDs written; the column's value ids are not read (one chunk is searched)")
+    del clustered
+    chunk_rows = abi.CHUNK_DEFAULT_SIZE
+    per_chunk = days.copy()
+    for begin in range(0, rows, chunk_rows):
+        per_chunk[begin:begin + chunk_rows].sort()
+    sorted_chunks = flagged(per_chunk)
+    out["sorted_chunks_lt_1995"] = dict(measure(lambda: step_fn(pred, sorted_chunks), lambda m: m * 8),
+                                        note="every chunk: two 64-ary searches (three dependent loads each), then its range of positions is written; no row is read")
+    del sorted_chunks, per_chunk
+    # Compressed layouts scanned in place: l_shipdate's value ids need 12 bits (2 526 dates + the NULL id): a BitPackingVector of 12 bits per
+    # row instead of FixedWidthInteger<2> (vector_compression/bitpacking), and RunLengthSegment<int32> over the clustered dates
+    packed_host = storage.make_column(days, None, abi.ENC_DICTIONARY)
+    packed_host = storage.HostColumn([storage.bit_pack_segment(segment) for segment in packed_host.segments], packed_host.data_type)
+    packed_bits = int(packed_host.segments[0].bits)
+    packed = DeviceColumn(packed_host)
+    out["bit_packed_value_ids_lt_1995"] = dict(measure(lambda: step_fn(pred, packed), lambda m: rows * packed_bits // 8 + m * 8), bits_per_value_id=packed_bits,
+                                               note="the generic instantiation unpacks the value ids in registers; bytes counted: bits / 8 per row + 8 per match")
+    del packed, packed_host
+    clustered_days = np.sort(days)
+    runs_host = storage.HostColumn([storage.encode_run_length(clustered_days[begin:begin + chunk_rows]) for begin in range(0, rows, chunk_rows)], abi.TYPE_INT)
+    n_runs = sum(segment.aux_size for segment in runs_host.segments)
+    runs = DeviceColumn(runs_host)
+    out["run_length_clustered_dates_lt_1995"] = dict(measure(lambda: step_fn(pred, runs), lambda m: n_runs * 8 + m * 8), runs=n_runs,
+                                                     note="RunLengthSegment<int32> read in place: one search of the end positions per eight rows; bytes counted: 8 per run + 8 per match")
+    del runs, runs_host, clustered_days
     # l_shipdate as Hyrise's schema has it: DictionarySegment<pmr_string> of ISO dates -- the same attribute vectors, the literal resolved
     # per chunk on the host (lower / upper bound in 916 string dictionaries: reported beside the scan as host_literal_resolution_ms)
     from hyrise_amd.operators import string_predicate

@@ -28,13 +28,14 @@ struct DevSegment {
   uint32_t ref_chunk_id;
   uint8_t encoding;
   uint8_t data_type;
-  uint8_t width;
-  uint8_t flags;               // SEG_*
-  uint8_t sorted_by;           // HY_SORT_*
-  uint8_t bits;                // width == 0: bits per element of the bit-packed attribute / offset vector in `data`
-  uint8_t reserved[6];
+  uint8_t width;               // bytes per element of `data`; SEG_PACKED | b: a bit-packed attribute / offset vector of b bits per element
+  uint8_t flags;               // SEG_UNALIGNED | HY_SORT_* << SEG_SORT_SHIFT
 };
-enum : uint8_t { SEG_UNALIGNED = 1 };
+enum : uint8_t { SEG_UNALIGNED = 1, SEG_SORT_SHIFT = 4, SEG_PACKED = 0x80 };
+// (the struct stays 48 bytes -- three 16-byte scalar loads, and the streaming scan keeps two of them in scalar registers)
+__host__ __device__ inline bool seg_is_packed(const DevSegment& s) { return (s.width & SEG_PACKED) != 0; }
+__host__ __device__ inline uint32_t seg_bits(const DevSegment& s) { return s.width & 0x7Fu; }
+__host__ __device__ inline uint32_t seg_sorted_by(const DevSegment& s) { return s.flags >> SEG_SORT_SHIFT; }
 
 // A contiguous run of at most SLICE_ROWS rows of one chunk: the unit of work of the scan / materialise kernels.
 struct Slice {
@@ -116,6 +117,7 @@ struct hy_column {
   // gather rows (joins, aggregates, projections, exchanges, reference columns) read `plain`: the same column as Value / FixedWidthInteger
   // segments, decoded ON THE DEVICE from the resident compressed buffers the first time one of them asks (plain_column, runtime.hip).
   bool has_compressed = false;
+  bool has_sorted = false;                  // some chunk is flagged as sorted by this column (hy_segment::sorted_by): its scan may take JOB_RANGE jobs
   mutable std::mutex plain_mutex;
   mutable hy_column* plain = nullptr;       // owned
 };

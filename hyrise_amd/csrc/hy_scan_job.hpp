@@ -20,9 +20,13 @@ struct ScanJob {
   uint32_t null_vid;   // dictionary: value id that encodes NULL (aux_size); else 0xFFFFFFFF
   uint64_t lo;         // integer lower bound (bit pattern) | float/double lower bound bits
   uint64_t span;       // integer hi - lo                   | float/double upper bound bits
-  uint32_t range_begin, range_end;   // JOB_RANGE (sorted_segment_search.hpp): chunk offsets
-  uint32_t hole_begin, hole_end;     // ... NotEquals leaves two ranges (:259-320)
+  // JOB_RANGE (sorted_segment_search.hpp): lo = range_begin | range_end << 32, span = hole_begin | hole_end << 32 (chunk offsets;
+  // NotEquals leaves two ranges, :259-320) -- the struct stays 32 bytes: the streaming scan keeps two of them in scalar registers
 };
+__host__ __device__ inline uint32_t job_range_begin(const ScanJob& job) { return static_cast<uint32_t>(job.lo); }
+__host__ __device__ inline uint32_t job_range_end(const ScanJob& job) { return static_cast<uint32_t>(job.lo >> 32); }
+__host__ __device__ inline uint32_t job_hole_begin(const ScanJob& job) { return static_cast<uint32_t>(job.span); }
+__host__ __device__ inline uint32_t job_hole_end(const ScanJob& job) { return static_cast<uint32_t>(job.span >> 32); }
 
 struct PredicateArgs {
   uint32_t condition;

@@ -516,6 +516,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   for (uint32_t c = 0; c < n_chunks; ++c) {
     const hy_segment& s = segments[c];
     if (compressed(s)) column->has_compressed = true;
+    if (s.sorted_by != HY_SORT_NONE) column->has_sorted = true;
     if (s.encoding != HY_ENC_RUN_LENGTH || mem != HY_MEM_HOST) continue;
     const auto* run_ends = static_cast<const uint32_t*>(s.aux);
     uint32_t row = 0;
@@ -524,7 +525,13 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
       row = run_ends[run] + 1;
     }
     if (row != s.size) return cleanup(fail(HY_ERR_INVALID, "chunk %u: runs cover %u of %u rows", c, row, s.size));
+    // A segment without a NULL run travels without its flags: IS NULL / IS NOT NULL then take the early-outs of a ValueSegment without a
+    // null vector (column_is_null_table_scan_impl.cpp:197-251) -- what the decoded twin of the segment is.
+    bool any_null = false;
+    for (uint32_t run = 0; run < s.aux_size && s.nulls; ++run) any_null = any_null || reinterpret_cast<const uint8_t*>(s.nulls)[run] != 0;
+    if (!any_null) column->host_segments[c].nulls = nullptr;
   }
+  segments = column->host_segments.data();
 
   // One arena for every buffer of the column: 916 chunks x 3 buffers would otherwise be ~2.7k hipMallocs.
   size_t arena_bytes = 0;
@@ -580,10 +587,8 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     d.ref_chunk_id = s.ref_chunk_id;
     d.encoding = static_cast<uint8_t>(s.encoding);
     d.data_type = static_cast<uint8_t>(s.data_type);
-    d.width = static_cast<uint8_t>(s.width);
-    d.flags = 0;
-    d.sorted_by = static_cast<uint8_t>(s.sorted_by);
-    d.bits = static_cast<uint8_t>(bit_packed(s) ? s.bits : 0);
+    d.width = static_cast<uint8_t>(bit_packed(s) ? SEG_PACKED | s.bits : s.width);
+    d.flags = static_cast<uint8_t>(s.sorted_by << SEG_SORT_SHIFT);
     if (reinterpret_cast<uintptr_t>(s.data) % 16 != 0 || reinterpret_cast<uintptr_t>(s.nulls) % 8 != 0) d.flags |= SEG_UNALIGNED;
     if (s.encoding == HY_ENC_REFERENCE) {
       column->is_reference = true;
@@ -731,8 +736,8 @@ __global__ __launch_bounds__(256) void expand_compressed(const DevSegment* segme
     return;
   }
   const uint64_t* words = static_cast<const uint64_t*>(s.data);
-  const uint32_t bits = s.bits;
-  const uint64_t mask = bits == 64 ? ~0ull : (1ull << bits) - 1;
+  const uint32_t bits = seg_bits(s);
+  const uint64_t mask = (1ull << bits) - 1;
   for (uint32_t row = tid; row < s.size; row += 256) {
     const uint64_t at = uint64_t{row} * bits;
     const uint32_t shift = static_cast<uint32_t>(at & 63);

@@ -124,7 +124,6 @@ __device__ __forceinline__ void finish_job(const DevSegment& s, uint32_t c, cons
   job.null_vid = 0xFFFFFFFFu;
   job.lo = 0;
   job.span = 0;
-  job.range_begin = job.range_end = job.hole_begin = job.hole_end = 0;
   const uint32_t cond = p.condition;
 
   if (cond >= HY_PRED_LIKE && cond <= HY_PRED_NOT_LIKE_INSENSITIVE) {   // column_like_table_scan_impl.cpp:69-121
@@ -301,10 +300,11 @@ __device__ __forceinline__ void finish_job(const DevSegment& s, uint32_t c, cons
 // wave finds the ends of the NULL block and of the inside block with 64-ary searches (three dependent loads for 65 535 rows), and the
 // job becomes JOB_RANGE: the scan kernel emits the positions without reading the segment.  The rows are the reference's: on a chunk
 // that is sorted as flagged, "the rows between the bounds" and "the rows that satisfy the predicate" are the same set.
+template <bool COMPRESSED>
 __device__ __forceinline__ uint32_t load_element(const DevSegment& s, uint32_t i);   // (defined with the row evaluation below)
 __device__ __forceinline__ uint32_t run_of_row(const DevSegment& s, uint32_t row);
 __device__ __forceinline__ bool sorted_row_is_null(const DevSegment& s, uint32_t row) {
-  if (s.encoding == HY_ENC_DICTIONARY) return load_element(s, row) >= s.aux_size;
+  if (s.encoding == HY_ENC_DICTIONARY) return load_element<true>(s, row) >= s.aux_size;
   if (s.encoding == HY_ENC_RUN_LENGTH) return s.nulls && reinterpret_cast<const uint8_t*>(s.nulls)[run_of_row(s, row)] != 0;
   return s.nulls && ((s.nulls[row >> 6] >> (row & 63)) & 1) != 0;
 }
@@ -312,7 +312,7 @@ __device__ __forceinline__ bool sorted_row_is_null(const DevSegment& s, uint32_t
 // -1: the row's value lies below the job's range, 0: inside, +1: above (the row is not NULL).
 __device__ __forceinline__ int sorted_row_side(const DevSegment& s, const ScanJob& job, uint32_t row) {
   if (s.encoding == HY_ENC_DICTIONARY) {   // value ids: unsigned, ordered like the values
-    const uint64_t x = load_element(s, row), lo = static_cast<uint32_t>(job.lo), hi = lo + static_cast<uint32_t>(job.span);
+    const uint64_t x = load_element<true>(s, row), lo = static_cast<uint32_t>(job.lo), hi = lo + static_cast<uint32_t>(job.span);
     return x < lo ? -1 : x > hi ? 1 : 0;
   }
   const void* values = s.data;
@@ -320,7 +320,7 @@ __device__ __forceinline__ int sorted_row_side(const DevSegment& s, const ScanJo
   if (s.encoding == HY_ENC_RUN_LENGTH) index = run_of_row(s, row);
   switch (job.kind) {
     case KIND_U32: {   // int32 values
-      const int64_t v = s.encoding == HY_ENC_FRAME_OF_REFERENCE ? static_cast<int32_t>(load_element(s, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]))
+      const int64_t v = s.encoding == HY_ENC_FRAME_OF_REFERENCE ? static_cast<int32_t>(load_element<true>(s, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]))
                                                                 : static_cast<const int32_t*>(values)[index];
       const int64_t lo = static_cast<int32_t>(static_cast<uint32_t>(job.lo)), hi = lo + static_cast<uint32_t>(job.span);
       return v < lo ? -1 : v > hi ? 1 : 0;
@@ -363,7 +363,7 @@ __device__ __forceinline__ uint32_t wave_prefix_end(uint32_t begin, uint32_t end
 
 __device__ __forceinline__ bool job_takes_sorted_search(const DevSegment& seg, const PredicateArgs& p, const ScanJob& job) {
   const uint32_t cond = p.condition;
-  return seg.sorted_by != HY_SORT_NONE && !p.no_ranges && seg.size != 0 && job.mode == JOB_SCAN && !(job.flags & JF_NEVER) && cond <= HY_PRED_BETWEEN_EXCLUSIVE &&
+  return seg_sorted_by(seg) != HY_SORT_NONE && !p.no_ranges && seg.size != 0 && job.mode == JOB_SCAN && !(job.flags & JF_NEVER) && cond <= HY_PRED_BETWEEN_EXCLUSIVE &&
          job.kind != KIND_NULLTEST && job.kind != KIND_VALUE_ID_SET;
 }
 
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, 
     if (lane == 0) s_bound[wave] = r;
   }
   __syncthreads();
-  if (seg.sorted_by == HY_SORT_NONE) {   // (uniform: the common case leaves here)
+  if (seg_sorted_by(seg) == HY_SORT_NONE) {   // (uniform: the common case leaves here)
     if (threadIdx.x != 0) return;
     ScanJob job;
     finish_job(seg, c, p, s_bound, job);
@@ -401,8 +401,9 @@ __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, 
     return;
   }
   if (wave < 2) {   // wave 0: where the inside block begins, wave 1: where it ends; both find the NULL block first
-    const bool ascending = seg.sorted_by == HY_SORT_ASCENDING_NULLS_FIRST || seg.sorted_by == HY_SORT_ASCENDING_NULLS_LAST;
-    const bool nulls_last = seg.sorted_by == HY_SORT_ASCENDING_NULLS_LAST || seg.sorted_by == HY_SORT_DESCENDING_NULLS_LAST;
+    const uint32_t sorted_by = seg_sorted_by(seg);
+    const bool ascending = sorted_by == HY_SORT_ASCENDING_NULLS_FIRST || sorted_by == HY_SORT_ASCENDING_NULLS_LAST;
+    const bool nulls_last = sorted_by == HY_SORT_ASCENDING_NULLS_LAST || sorted_by == HY_SORT_DESCENDING_NULLS_LAST;
     uint32_t begin = 0, end = seg.size;
     if (seg.encoding == HY_ENC_DICTIONARY || seg.nulls) {
       if (nulls_last) end = wave_prefix_end(0, seg.size, lane, [&](uint32_t row) { return !sorted_row_is_null(seg, row); });
@@ -422,13 +423,11 @@ __global__ __launch_bounds__(256) void prepare_jobs(const DevSegment* segments, 
   ranged.mode = JOB_RANGE;
   const uint32_t inside_begin = s_range[0], inside_end = s_range[1] < s_range[0] ? s_range[0] : s_range[1];
   if (job.flags & JF_INVERT) {   // NotEquals: the non-NULL rows without the inside block
-    ranged.range_begin = s_bound[0];
-    ranged.range_end = s_bound[1];
-    ranged.hole_begin = inside_begin;
-    ranged.hole_end = inside_end;
+    ranged.lo = static_cast<uint64_t>(s_bound[0]) | static_cast<uint64_t>(s_bound[1]) << 32;
+    ranged.span = static_cast<uint64_t>(inside_begin) | static_cast<uint64_t>(inside_end) << 32;
   } else {
-    ranged.range_begin = inside_begin;
-    ranged.range_end = inside_end;
+    ranged.lo = static_cast<uint64_t>(inside_begin) | static_cast<uint64_t>(inside_end) << 32;
+    ranged.span = 0;
   }
   jobs[c] = ranged;
 }
@@ -462,19 +461,40 @@ __device__ __forceinline__ uint32_t load_compressed(const void* data, uint32_t w
 
 // Element `i` of a segment's attribute / offset vector: FixedWidthInteger, or (width 0) a BitPackingVector -- compact::vector<uint32_t, 0,
 // uint64_t>: bits [i * b, (i + 1) * b) of a little-endian stream of 64-bit words, unpacked in registers (bitpacking_decompressor.hpp:35-37).
-__device__ __forceinline__ uint32_t load_element(const DevSegment& s, uint32_t i) {
-  if (s.width != 0) return load_compressed(s.data, s.width, i);
-  const uint64_t* words = static_cast<const uint64_t*>(s.data);
-  const uint64_t at = uint64_t{i} * s.bits;
+__device__ __noinline__ uint32_t load_packed_element(const uint64_t* words, uint32_t bits, uint32_t i) {   // (not inlined: the rare layout must not cost the common ones registers)
+  const uint64_t at = uint64_t{i} * bits;
   const uint32_t shift = static_cast<uint32_t>(at & 63);
   uint64_t value = words[at >> 6] >> shift;
-  if (shift + s.bits > 64) value |= words[(at >> 6) + 1] << (64 - shift);
-  return static_cast<uint32_t>(value & ((1ull << s.bits) - 1));
+  if (shift + bits > 64) value |= words[(at >> 6) + 1] << (64 - shift);
+  return static_cast<uint32_t>(value & ((1ull << bits) - 1));
+}
+// COMPRESSED = false: the caller knows the column holds no bit-packed vector and no run-length segment (the instantiations of the
+// scan kernel that every ordinary column takes carry none of that code).
+template <bool COMPRESSED = true>
+__device__ __forceinline__ uint32_t load_element(const DevSegment& s, uint32_t i) {
+  if (!COMPRESSED || !seg_is_packed(s)) return load_compressed(s.data, s.width, i);
+  return load_packed_element(static_cast<const uint64_t*>(s.data), seg_bits(s), i);
 }
 
 // A row against a JOB_RANGE job (a sorted chunk's matching rows, found by prepare_jobs).
 __device__ __forceinline__ bool row_in_job_range(const ScanJob& job, uint32_t row) {
-  return row - job.range_begin < job.range_end - job.range_begin && !(row - job.hole_begin < job.hole_end - job.hole_begin);
+  return row - job_range_begin(job) < job_range_end(job) - job_range_begin(job) && !(row - job_hole_begin(job) < job_hole_end(job) - job_hole_begin(job));
+}
+// The rows [row0, row0 + 8) against [begin, end): one bit per row.
+__device__ __forceinline__ uint32_t rows_in_range8(uint32_t row0, uint32_t begin, uint32_t end) {
+  const uint32_t first = begin > row0 ? (begin - row0 < 8 ? begin - row0 : 8u) : 0u, last = end > row0 ? (end - row0 < 8 ? end - row0 : 8u) : 0u;
+  return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
+}
+// The 32 rows a lane owns in a slice of a JOB_RANGE chunk (the streaming instantiations' layout: four groups of eight rows).
+__device__ __forceinline__ uint32_t job_range_mask(uint64_t range, uint64_t hole, uint32_t first_row) {
+  uint32_t mask = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t row0 = first_row + k * 512;
+    mask |= (rows_in_range8(row0, static_cast<uint32_t>(range), static_cast<uint32_t>(range >> 32)) &
+             ~rows_in_range8(row0, static_cast<uint32_t>(hole), static_cast<uint32_t>(hole >> 32))) << (8 * k);
+  }
+  return mask;
 }
 
 __device__ __forceinline__ bool float_in_range(float x, const ScanJob& job) {
@@ -501,15 +521,15 @@ __device__ __forceinline__ bool value_in_job(const void* values, uint32_t index,
 }
 
 // RunLengthSegment: the run of `row` = the first run whose inclusive end position is >= row (run_length_segment_iterable.hpp:100-160).
-__device__ __forceinline__ uint32_t run_of_row(const DevSegment& s, uint32_t row) {
-  const uint32_t* ends = static_cast<const uint32_t*>(s.aux);
-  uint32_t low = 0, high = s.aux_size - 1;
+__device__ __noinline__ uint32_t run_of_position(const uint32_t* ends, uint32_t n_runs, uint32_t row) {
+  uint32_t low = 0, high = n_runs - 1;
   while (low < high) {
     const uint32_t middle = (low + high) / 2;
     if (ends[middle] >= row) high = middle; else low = middle + 1;
   }
   return low;
 }
+__device__ __forceinline__ uint32_t run_of_row(const DevSegment& s, uint32_t row) { return run_of_position(static_cast<const uint32_t*>(s.aux), s.aux_size, row); }
 __device__ __forceinline__ bool eval_run(const DevSegment& s, const ScanJob& job, uint32_t run) {
   const bool is_null = s.nulls && reinterpret_cast<const uint8_t*>(s.nulls)[run] != 0;
   const bool invert = job.flags & JF_INVERT;
@@ -518,11 +538,12 @@ __device__ __forceinline__ bool eval_run(const DevSegment& s, const ScanJob& job
 }
 
 // Scalar evaluation of one row of a DATA segment: tails, unaligned buffers and pos-list gathers.
+template <bool COMPRESSED>
 __device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) {
   if (job.mode == JOB_ALL) return true;
   if (job.mode == JOB_NONE || (job.flags & JF_NEVER)) return false;
   if (job.mode == JOB_RANGE) return row_in_job_range(job, row);
-  if (s.encoding == HY_ENC_RUN_LENGTH) return eval_run(s, job, run_of_row(s, row));
+  if (COMPRESSED && s.encoding == HY_ENC_RUN_LENGTH) return eval_run(s, job, run_of_row(s, row));
   if (s.encoding == HY_ENC_MVCC) {   // Validate::is_row_visible (validate.cpp:47-55)
     const uint32_t snapshot = static_cast<uint32_t>(job.lo), our_tid = static_cast<uint32_t>(job.span);
     const uint32_t tid = static_cast<const uint32_t*>(s.data)[row], begin = static_cast<const uint32_t*>(s.aux)[row];
@@ -531,7 +552,7 @@ __device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) 
   }
   const bool invert = job.flags & JF_INVERT;
   if (s.encoding == HY_ENC_DICTIONARY) {
-    const uint32_t vid = load_element(s, row);
+    const uint32_t vid = load_element<COMPRESSED>(s, row);
     if (job.kind == KIND_VALUE_ID_SET) {
       return vid < job.null_vid && ((reinterpret_cast<const uint64_t*>(job.lo)[vid >> 6] >> (vid & 63)) & 1) != 0;
     }
@@ -543,7 +564,7 @@ __device__ bool eval_row(const DevSegment& s, const ScanJob& job, uint32_t row) 
   if (is_null) return false;
   bool in;
   if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
-    const uint32_t x = load_element(s, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]);
+    const uint32_t x = load_element<COMPRESSED>(s, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]);
     in = (x - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
   } else {
     in = value_in_job(s.data, row, job);
@@ -580,27 +601,28 @@ __device__ __forceinline__ uint32_t eval8_u32(const DevSegment& s, const ScanJob
   return bits;
 }
 
+// RunLengthSegment: one search of the end positions, then the runs are walked (run_length_segment_iterable.hpp:100-160).
+__device__ __forceinline__ uint32_t eval8_run_length(const DevSegment& s, const ScanJob& job, uint32_t row0, uint32_t valid) {
+  const uint32_t* ends = static_cast<const uint32_t*>(s.aux);
+  uint32_t run = run_of_row(s, row0), bits = 0;
+  bool matches = eval_run(s, job, run);
+  for (uint32_t j = 0; j < valid; ++j) {
+    if (row0 + j > ends[run]) { ++run; matches = eval_run(s, job, run); }
+    bits |= (matches ? 1u : 0u) << j;
+  }
+  return bits;
+}
+
 // Match bits of 8 rows [row0, row0+8) of a data segment; rows >= size are masked off by the caller.
+template <bool COMPRESSED>
 __device__ __forceinline__ uint32_t eval8(const DevSegment& s, const ScanJob& job, uint32_t row0, uint32_t valid) {
   if (job.mode == JOB_RANGE) {
-    uint32_t bits = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) bits |= (j < valid && row_in_job_range(job, row0 + j) ? 1u : 0u) << j;
-    return bits;
+    return rows_in_range8(row0, job_range_begin(job), job_range_end(job)) & ~rows_in_range8(row0, job_hole_begin(job), job_hole_end(job)) & ((1u << valid) - 1u);
   }
-  if (s.encoding == HY_ENC_RUN_LENGTH) {   // one search of the end positions, then the runs are walked
-    const uint32_t* ends = static_cast<const uint32_t*>(s.aux);
-    uint32_t run = run_of_row(s, row0), bits = 0;
-    bool matches = eval_run(s, job, run);
-    for (uint32_t j = 0; j < valid; ++j) {
-      if (row0 + j > ends[run]) { ++run; matches = eval_run(s, job, run); }
-      bits |= (matches ? 1u : 0u) << j;
-    }
-    return bits;
-  }
-  if (valid < 8 || (s.flags & SEG_UNALIGNED) || s.width == 0) {
+  if (COMPRESSED && s.encoding == HY_ENC_RUN_LENGTH) return eval8_run_length(s, job, row0, valid);
+  if (valid < 8 || (s.flags & SEG_UNALIGNED) || (COMPRESSED && seg_is_packed(s))) {
     uint32_t bits = 0;
-    for (uint32_t j = 0; j < valid; ++j) bits |= (eval_row(s, job, row0 + j) ? 1u : 0u) << j;
+    for (uint32_t j = 0; j < valid; ++j) bits |= (eval_row<COMPRESSED>(s, job, row0 + j) ? 1u : 0u) << j;
     return bits;
   }
   if (s.encoding == HY_ENC_MVCC) {   // eight rows: 2 x 16 B of each of the three arrays
@@ -882,6 +904,7 @@ __device__ __forceinline__ void fetch_four_byte_rows(const DevSegment& s, uint32
 // The column is read from HBM exactly once and every RowID is written exactly once.  Output order is (chunk, row) ascending:
 // bit-identical to the CPU loop's appends.  Chunks of more than one part chain their parts through one epoch-tagged status
 // word per part.
+template <bool COMPRESSED>
 __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slice& slice, const DevSegment& seg, uint32_t wave, uint32_t lane) {
   uint32_t mask = 0;       // bit (8k + j) <-> row  wave*2048 + k*512 + lane*8 + j  of the slice
   const DevSegment right_seg = a.right ? a.right[slice.chunk] : DevSegment{};
@@ -943,7 +966,7 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
 #pragma unroll
         for (uint32_t j = 0; j < 8; ++j) {
           if (r0 + j >= slice.row_count) continue;
-          const bool m = offset[j] == 0xFFFFFFFFu ? a.is_null_scan != 0 : eval_row(base, job, offset[j]);
+          const bool m = offset[j] == 0xFFFFFFFFu ? a.is_null_scan != 0 : eval_row<false>(base, job, offset[j]);   // (a reference segment points at the decoded twin)
           if (m) mask |= 1u << (8 * k + j);
         }
       }
@@ -958,7 +981,7 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
           else { r.chunk_id = seg.ref_chunk_id; r.chunk_offset = row; }
           bool m;
           if (r.chunk_offset == 0xFFFFFFFFu) m = a.is_null_scan != 0;   // NULL_ROW_ID: only IS NULL matches
-          else m = eval_row(seg.ref[r.chunk_id], a.jobs[r.chunk_id], r.chunk_offset);
+          else m = eval_row<false>(seg.ref[r.chunk_id], a.jobs[r.chunk_id], r.chunk_offset);
           if (m) mask |= 1u << (8 * k + j);
         }
       }
@@ -971,7 +994,7 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
         const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
         if (r0 < slice.row_count) {
           const uint32_t valid = (slice.row_count - r0 < 8) ? slice.row_count - r0 : 8;
-          mask |= eval8(seg, job, slice.row_begin + r0, valid) << (8 * k);
+          mask |= eval8<COMPRESSED>(seg, job, slice.row_begin + r0, valid) << (8 * k);
         }
       }
     } else if (job.mode == JOB_ALL && a.materialize_all) {
@@ -1064,7 +1087,9 @@ __device__ __forceinline__ uint32_t two_groups(const RawGroup<W>& g0, const RawG
   return (acc | (acc >> 15)) & 0xFFFFu;
 }
 
-template <int W>
+// RANGES: the column has chunks flagged as sorted (their jobs may be JOB_RANGE); the instantiations every other column takes carry none
+// of that code.
+template <int W, bool RANGES>
 __device__ __forceinline__ uint32_t evaluate_loaded(const SliceLoad<W>& ld, const DevSegment& seg, const ScanJob& job, const Slice& slice,
                                                     uint32_t materialize_all, uint32_t wave, uint32_t lane) {
   uint32_t valid = 0xFFFFFFFFu;   // rows of the lane's groups that exist
@@ -1078,16 +1103,7 @@ __device__ __forceinline__ uint32_t evaluate_loaded(const SliceLoad<W>& ld, cons
     }
   }
   if (job.mode == JOB_ALL) return materialize_all ? valid : 0u;
-  if (job.mode == JOB_RANGE) {   // a sorted chunk: the matching rows are known, nothing was loaded
-    uint32_t mask = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-      const uint32_t row0 = slice.row_begin + wave * 2048 + k * 512 + lane * 8;
-#pragma unroll
-      for (uint32_t j = 0; j < 8; ++j) mask |= (row_in_job_range(job, row0 + j) ? 1u : 0u) << (8 * k + j);
-    }
-    return mask & valid;
-  }
+  if (RANGES && job.mode == JOB_RANGE) return job_range_mask(job.lo, job.span, slice.row_begin + wave * 2048 + lane * 8) & valid;   // a sorted chunk: nothing was loaded
   if (job.mode != JOB_SCAN || (job.flags & JF_NEVER)) return 0u;
 
   const bool invert = job.flags & JF_INVERT;
@@ -1190,7 +1206,7 @@ __device__ __forceinline__ Slice part_slice(const Part& part, const DevSegment& 
 // the earlier parts of its chunk in parallel (they belong to workgroups that are resident and never wait for later
 // parts, so this cannot deadlock as long as the grid is co-resident).
 // Every RowID is written exactly once, in (chunk, row) order: bit-identical to the CPU loop's appends.
-template <int W>
+template <int W, bool RANGES = false>
 __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict__ segments_in, const DevSegment* __restrict__ right_in,
                                                    const Slice* __restrict__ slices_in, const ScanJob* __restrict__ jobs_in,
                                                    const Part* __restrict__ parts, ScanArgs a) {
@@ -1209,7 +1225,8 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 0] = wall_clock64();   // (reading HW_ID here with s_getreg makes the register allocator spill)
 
-  constexpr int LW = W == 0 ? 1 : W;
+  constexpr bool GENERIC = W == 0 || W == 8;   // W == 8: the generic instantiation that also reads run-length segments and bit-packed vectors in place
+  constexpr int LW = GENERIC ? 1 : W;
   SliceLoad<LW> next;   // streaming state: loads of the next slice to evaluate (possibly of the next part)
   uint32_t part_id = blockIdx.x;
   Part part{};
@@ -1218,7 +1235,7 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
   if (part_id < a.n_parts) {
     part = parts[part_id];
     seg = a.segments[part.chunk];
-    if constexpr (W != 0) {
+    if constexpr (!GENERIC) {
       job = a.jobs[part.chunk];
       issue_loads<W>(next, seg, job, part_slice(part, seg, 0), wave, lane);
     }
@@ -1233,7 +1250,7 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
     if (next_part_id < a.n_parts) {   // one part ahead: these scalar loads complete long before they are needed
       next_part = parts[next_part_id];
       next_seg = a.segments[next_part.chunk];
-      if constexpr (W != 0) next_job = a.jobs[next_part.chunk];
+      if constexpr (!GENERIC) next_job = a.jobs[next_part.chunk];
     }
 
     // ---- chunks larger than one part: matches in the earlier parts of the same chunk -------------------------------------
@@ -1242,12 +1259,12 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
       uint32_t mine = 0;
       for (uint32_t i = 0; i < part.n_slices; ++i) {
         const Slice slice = part_slice(part, seg, i);
-        if constexpr (W == 0) {
-          mine += __popc(evaluate_slice(a, slice, seg, wave, lane));
+        if constexpr (GENERIC) {
+          mine += __popc(evaluate_slice<W == 8>(a, slice, seg, wave, lane));
         } else {
           SliceLoad<W> again;
           issue_loads<W>(again, seg, job, slice, wave, lane);
-          mine += __popc(evaluate_loaded<W>(again, seg, job, slice, a.materialize_all, wave, lane));
+          mine += __popc(evaluate_loaded<W, RANGES>(again, seg, job, slice, a.materialize_all, wave, lane));
         }
       }
       mine = __builtin_amdgcn_readlane(wave_inclusive_scan_u32(mine), 63);
@@ -1271,7 +1288,7 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
 
     // ---- per-chunk outputs ------------------------------------------------------------------------------------------------
     uint32_t mode = JOB_SCAN;
-    if constexpr (W != 0) {
+    if constexpr (!GENERIC) {
       mode = job.mode;
     } else if (!a.right) {
       if (seg.encoding != HY_ENC_REFERENCE) mode = a.jobs[part.chunk].mode;
@@ -1290,13 +1307,13 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
     for (uint32_t i = 0; i < part.n_slices; ++i) {
       const Slice slice = part_slice(part, seg, i);
       uint32_t mask;
-      if constexpr (W == 0) {
-        mask = evaluate_slice(a, slice, seg, wave, lane);
+      if constexpr (GENERIC) {
+        mask = evaluate_slice<W == 8>(a, slice, seg, wave, lane);
       } else {
         const SliceLoad<W> current = next;
         if (i + 1 < part.n_slices) issue_loads<W>(next, seg, job, part_slice(part, seg, i + 1), wave, lane);
         else if (next_part_id < a.n_parts) issue_loads<W>(next, next_seg, next_job, part_slice(next_part, next_seg, 0), wave, lane);
-        mask = evaluate_loaded<W>(current, seg, job, slice, a.materialize_all, wave, lane);
+        mask = evaluate_loaded<W, RANGES>(current, seg, job, slice, a.materialize_all, wave, lane);
       }
       // Transpose the masks inside the wave so that lane L holds the 32 CONSECUTIVE rows [32 L, 32 L + 32) of the wave's
       // 2048: byte k of lane l goes to byte k*64 + l of the wave's 256-byte scratch, lane L reads dword L.  A lane's
@@ -1628,11 +1645,11 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   HY_TRY(sc.reserve(need + 16 * 256));
   ScanJob* d_jobs = carve<ScanJob>(sc, n_data_chunks + 1);
   uint32_t* d_overflow = sc.ticket + 16;   // persistent word, zero unless a scan overflowed (an internal error)
-  ScanKernel kernel = scan_slices<0>;
-  if (!right && column->stream_width == 1) kernel = scan_slices<1>;
-  else if (!right && column->stream_width == 2) kernel = scan_slices<2>;
-  else if (!right && column->stream_width == 4) kernel = scan_slices<4>;
-  if (like) kernel = scan_slices<0>;   // value-id sets are tested by the generic instantiation
+  ScanKernel kernel = !right && column->has_compressed ? scan_slices<8> : scan_slices<0>;
+  if (!right && column->stream_width == 1) kernel = column->has_sorted ? scan_slices<1, true> : scan_slices<1>;
+  else if (!right && column->stream_width == 2) kernel = column->has_sorted ? scan_slices<2, true> : scan_slices<2>;
+  else if (!right && column->stream_width == 4) kernel = column->has_sorted ? scan_slices<4, true> : scan_slices<4>;
+  if (like) kernel = column->has_compressed ? scan_slices<8> : scan_slices<0>;   // value-id sets are tested by the generic instantiations
 
   PredicateArgs pa;
   std::memset(&pa, 0, sizeof(pa));

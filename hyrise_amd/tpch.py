@@ -245,3 +245,76 @@ def q1_fused(columns, ship_to=DAY_1998_09_02):
     return scan_project_aggregate([(columns["l_shipdate"], make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, ship_to))],
                                   [columns["l_returnflag"], columns["l_linestatus"]],
                                   _q1_aggregates(columns["l_quantity"], columns["l_extendedprice"], columns["l_discount"], disc_price, charge), group_capacity=4096)
+
+
+# ---- rows of the reference's own generator --------------------------------------------------------------------------------
+def convert_money(cents):
+    """tpch_table_generator.cpp:90-94: float(dollars) + float(cents) / 100.0f, in float32 arithmetic."""
+    cents = np.asarray(cents, dtype=np.int64)
+    return (cents // 100).astype(np.float32) + (cents % 100).astype(np.float32) / np.float32(100.0)
+
+
+def _days_of_iso(dates):
+    """char[n][10] 'YYYY-MM-DD' -> int32 days since 1992-01-01"""
+    text = np.ascontiguousarray(dates).view("S10").reshape(-1)
+    return (text.astype("U10").astype("datetime64[D]") - np.datetime64("1992-01-01")).astype(np.int32)
+
+
+class DbgenData:
+    """orders / lineitem rows as the reference's vendored dbgen generates them (third_party/tpch-dbgen driven like
+    TPCHTableGenerator::generate, oracle/dbgen/tpch_rows.c), with TpchData's attributes -- so the same plans, encoders and tests run on
+    them -- and in Hyrise's column types (tpch_table_generator.cpp:34-47): keys int32, l_quantity / l_extendedprice / l_discount / l_tax
+    float through convert_money, flags and dates strings (dates kept as day numbers; string_date_column makes the string twin).
+    Sources: the binary file tpch_rows writes (oracle/_ref: built where the reference tree is), or the committed fixture
+    tests/golden/dbgen/*.npz that tools/make_dbgen_fixture.py derives from such a file."""
+
+    def __init__(self, arrays):
+        self.o_orderkey = arrays["o_orderkey"].astype(np.int32)
+        self.l_orderkey = arrays["l_orderkey"].astype(np.int32)
+        self.l_quantity = arrays["l_quantity"].astype(np.float32)
+        self.l_extendedprice = convert_money(arrays["l_extendedprice_cents"])
+        self.l_discount = convert_money(arrays["l_discount_cents"])
+        self.l_tax = convert_money(arrays["l_tax_cents"])
+        self.l_returnflag = arrays["l_returnflag"].astype(np.int32)     # the character's code, like TpchData
+        self.l_linestatus = arrays["l_linestatus"].astype(np.int32)
+        self.l_shipdate = arrays["l_shipdate"].astype(np.int32)
+        self.l_commitdate = arrays["l_commitdate"].astype(np.int32)
+        self.l_receiptdate = arrays["l_receiptdate"].astype(np.int32)
+        self.n_orders, self.n_lineitems = len(self.o_orderkey), len(self.l_orderkey)
+        self.keys_only = False
+
+    @staticmethod
+    def read_rows_file(path):
+        """The arrays of a file written by oracle/_ref/tpch_rows (layout: oracle/dbgen/tpch_rows.c)."""
+        with open(path, "rb") as fh:
+            assert fh.read(8) == b"HYDBGEN1", "not a tpch_rows file"
+            n_orders, n = (int(x) for x in np.frombuffer(fh.read(16), dtype="<u8"))
+
+            def take(dtype, count, width=1):
+                return np.frombuffer(fh.read(np.dtype(dtype).itemsize * count * width), dtype=dtype)
+
+            arrays = {"o_orderkey": take("<i4", n_orders), "l_orderkey": take("<i4", n), "l_quantity": take("<i4", n), "l_extendedprice_cents": take("<i8", n),
+                      "l_discount_cents": take("<i4", n), "l_tax_cents": take("<i4", n), "l_returnflag": take("u1", n), "l_linestatus": take("u1", n)}
+            for name in ("l_shipdate", "l_commitdate", "l_receiptdate"):
+                arrays[name] = _days_of_iso(take("u1", n, 10).reshape(n, 10))
+        return arrays
+
+    @classmethod
+    def from_rows_file(cls, path):
+        return cls(cls.read_rows_file(path))
+
+    @classmethod
+    def from_fixture(cls, path):
+        with np.load(path) as arrays:
+            return cls({name: arrays[name] for name in arrays.files})
+
+    @classmethod
+    def generate(cls, scale_factor, binary, scratch_directory):
+        """Runs the generator (`binary` = oracle/_ref/tpch_rows) at `scale_factor`."""
+        import subprocess
+        path = os.path.join(scratch_directory, f"tpch_rows_{scale_factor}.bin")
+        subprocess.check_call([binary, str(scale_factor), path], stderr=subprocess.DEVNULL)
+        try:
+            return cls.from_rows_file(path)
+        finally:
+            os.remove(path)
