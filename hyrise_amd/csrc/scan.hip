@@ -793,6 +793,7 @@ struct ScanArgs {
   uint8_t* chunk_state;            // [n_chunks] or nullptr
   uint32_t* overflow;              // set to 1 if capacity was exceeded (a persistent, normally-zero word of the scratch)
   uint64_t* trace;                 // debug: 4 wall-clock stamps per workgroup (HY_SCAN_TRACE), else nullptr
+  uint32_t plain_stores;           // write-back stores for the RowIDs (the default; HY_SCAN_NT_STORES=1: nontemporal ones, for A/B runs with tools/scan_ab.py)
 };
 
 __device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v, uint32_t lane) {
@@ -1362,10 +1363,18 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
           HY_GLOBAL u32x4* out = (HY_GLOBAL u32x4*)(a.matches + (first - skew));
           const uint32_t* pairs = reinterpret_cast<const uint32_t*>(my_rows);
           const uint32_t pair_begin = (skew + 1) / 2, pair_end = end / 2;
-          for (uint32_t q = lane < pair_begin ? lane + 64 : lane; q < pair_end; q += 64) {
-            const uint32_t two = pairs[q];
-            const u32x4 v = {part.chunk, slice.row_begin + (two & 0xFFFFu), part.chunk, slice.row_begin + (two >> 16)};
-            __builtin_nontemporal_store(v, out + q);
+          if (a.plain_stores) {
+            for (uint32_t q = lane < pair_begin ? lane + 64 : lane; q < pair_end; q += 64) {
+              const uint32_t two = pairs[q];
+              const u32x4 v = {part.chunk, slice.row_begin + (two & 0xFFFFu), part.chunk, slice.row_begin + (two >> 16)};
+              out[q] = v;
+            }
+          } else {
+            for (uint32_t q = lane < pair_begin ? lane + 64 : lane; q < pair_end; q += 64) {
+              const uint32_t two = pairs[q];
+              const u32x4 v = {part.chunk, slice.row_begin + (two & 0xFFFFu), part.chunk, slice.row_begin + (two >> 16)};
+              __builtin_nontemporal_store(v, out + q);
+            }
           }
           HY_GLOBAL u32x2* single = (HY_GLOBAL u32x2*)out;
           if (lane == 0 && (skew & 1)) { const u32x2 v = {part.chunk, slice.row_begin + my_rows[skew]}; __builtin_nontemporal_store(v, single + skew); }
@@ -1732,6 +1741,9 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     a.chunk_state = d_state;
     a.overflow = d_overflow;
     a.trace = nullptr;
+    // Write-back stores: on this part a 37 : 63 read : write stream runs 13 % faster through the L2 than around it (nontemporal) --
+    // tools/hbm_mix.hip shows it for the bare traffic pattern, tools/scan_ab.py for this kernel (profiles/r03_scan_stores.txt).
+    a.plain_stores = getenv("HY_SCAN_NT_STORES") ? 0u : 1u;
     if (getenv("HY_SCAN_TRACE")) {
       static uint64_t* trace_buffer = nullptr;
       if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 4 * 4096);

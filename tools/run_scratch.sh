@@ -1,7 +1,3 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/gputest.log 2>&1; echo "rc=$?" >> gpurun_out/gputest.log
-tail -5 gpurun_out/gputest.log
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; tail -3 gpurun_out/bench.err
-bash tools/collect_profiles.sh "$1"
-timeout 300 tools/hbm_mix_bin 3 > gpurun_out/hbm_mix.txt 2>&1; tail -3 gpurun_out/hbm_mix.txt
-timeout 300 tools/hbm_write_bin > gpurun_out/hbm_write.txt 2>&1; tail -3 gpurun_out/hbm_write.txt
+timeout 600 python tools/scan_ab.py 40 2>&1 | grep -v amdgpu.ids > gpurun_out/scan_ab.txt; cat gpurun_out/scan_ab.txt
+timeout 600 python tools/join_bench.py 10 2>&1 | grep -v amdgpu.ids > gpurun_out/join_bench.txt; cat gpurun_out/join_bench.txt

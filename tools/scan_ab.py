@@ -36,7 +36,7 @@ def main():
         def step():
             abi.check(lib.hy_table_scan(columns[turn[0] % 3].handle, C.byref(pred), None, 0, C.byref(result)))
             turn[0] += 1
-        for variant, env in (("default", {}),):
+        for variant, env in (("write-back stores (default)", {}), ("nontemporal stores", {"HY_SCAN_NT_STORES": "1"}), ("write-back again", {}), ("nontemporal again", {"HY_SCAN_NT_STORES": "1"})):
             os.environ.update(env)
             dt, km = bench.timed_kernel(lib, torch, step, steps, 4, kind="scan")
             m = int(counts.sum().item())
