@@ -86,6 +86,7 @@ class AggregateSpec(C.Structure):
 
 EXPR_COLUMN, EXPR_LITERAL, EXPR_ARITHMETIC = range(3)
 MAX_EXPRESSION_NODES, MAX_FILTERS = 12, 4
+FILTER_VALIDATE = 0x100   # hy_filter.predicate.condition of a Validate filter (hy_scan_project_aggregate)
 
 
 class ExpressionNode(C.Structure):

@@ -45,51 +45,63 @@ def lz4_block_decode(block, size, history=b""):
     compressed with (LZ4_decompress_safe_usingDict, lz4_segment.cpp:217-220): matches may reach back into it."""
     out = bytearray(history)
     start, end, i, n = len(history), len(history) + size, 0, len(block)
+
+    def continued(value, at):   # a length field of 15 continues in bytes of 255 ... < 255
+        while True:
+            if at >= n:
+                raise ValueError("corrupt LZ4 block: a length runs past the end of the block")
+            extra = block[at]
+            at += 1
+            value += extra
+            if extra != 255:
+                return value, at
+
     while i < n:
         token = block[i]
         i += 1
         literals = token >> 4
         if literals == 15:
-            while True:
-                extra = block[i]
-                i += 1
-                literals += extra
-                if extra != 255:
-                    break
+            literals, i = continued(literals, i)
+        if i + literals > n:
+            raise ValueError("corrupt LZ4 block: literals run past the end of the block")   # (a slice past the end would silently be shorter)
         out += block[i:i + literals]
         i += literals
         if i >= n:
             break                                   # the last sequence has no match
+        if i + 2 > n:
+            raise ValueError("corrupt LZ4 block: truncated match offset")
         offset = block[i] | block[i + 1] << 8
         i += 2
         if offset == 0 or offset > len(out):
             raise ValueError("corrupt LZ4 block: match offset outside the history")
         length = (token & 15) + 4
         if (token & 15) == 15:
-            while True:
-                extra = block[i]
-                i += 1
-                length += extra
-                if extra != 255:
-                    break
+            length, i = continued(length, i)
+        if len(out) + length > end:
+            raise ValueError("corrupt LZ4 block: a match runs past the decoded size")
         position = len(out) - offset
         if offset >= length:
             out += out[position:position + length]
-        else:                                       # overlapping match: the copied bytes feed the copy (run-length patterns)
-            for k in range(length):
-                out.append(out[position + k])
+        else:                                       # overlapping match: the copied bytes feed the copy -- the last `offset` bytes repeat
+            pattern = bytes(out[position:])
+            out += (pattern * (length // offset + 1))[:length]
     if len(out) != end:
         raise ValueError(f"LZ4 block decoded to {len(out) - start} bytes, {size} expected")
     return bytes(out[start:])
 
 
 def unpack_bits(words, bits, count):
-    """compact::vector<uint32_t, 0, uint64_t>: `count` elements of `bits` bits each, a little-endian bit stream over 64-bit words."""
+    """compact::vector<uint32_t, 0, uint64_t>: `count` elements of `bits` bits each, a little-endian bit stream over 64-bit words.
+    Element i = bits [i * bits, (i + 1) * bits): the low part from word i * bits / 64, the rest (if it straddles) from the next word."""
     if bits == 0 or count == 0:
         return np.zeros(count, dtype=np.uint32)
-    stream = np.unpackbits(np.ascontiguousarray(words, dtype="<u8").view(np.uint8), bitorder="little")[:count * bits].reshape(count, bits)
-    weights = (np.uint64(1) << np.arange(bits, dtype=np.uint64))
-    return (stream.astype(np.uint64) * weights).sum(axis=1).astype(np.uint32)
+    words = np.concatenate([np.ascontiguousarray(words, dtype="<u8").astype(np.uint64), np.zeros(1, dtype=np.uint64)])   # (a spare word for the last element's "next word")
+    at = np.arange(count, dtype=np.uint64) * np.uint64(bits)
+    index, shift = (at >> np.uint64(6)).astype(np.int64), at & np.uint64(63)
+    low = words[index] >> shift
+    spill = shift + np.uint64(bits) > np.uint64(64)
+    high = np.where(spill, words[index + 1] << ((np.uint64(64) - shift) & np.uint64(63)), np.uint64(0))
+    return ((low | high) & np.uint64((1 << bits) - 1)).astype(np.uint32)
 
 
 def fixed_width_of(values):

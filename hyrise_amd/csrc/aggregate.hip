@@ -1454,6 +1454,11 @@ __device__ __forceinline__ ScanJob uniform(const ScanJob& j) {
 
 // One row of a data segment against its chunk's job (what eval_row of scan.hip decides for JOB_SCAN jobs of data segments).
 __device__ __forceinline__ bool filter_row(const ColumnView& s, const ScanJob& job, uint32_t row) {
+  if (s.encoding == HY_ENC_MVCC) {   // a Validate filter: Validate::is_row_visible (validate.cpp:47-55) on the chunk's tids / begin cids / end cids
+    const uint32_t snapshot = static_cast<uint32_t>(job.lo), our_tid = static_cast<uint32_t>(job.span);
+    const uint32_t tid = static_cast<const uint32_t*>(s.data)[row], begin = static_cast<const uint32_t*>(s.aux)[row], end = reinterpret_cast<const uint32_t*>(s.nulls)[row];
+    return snapshot < end && ((snapshot >= begin) != (tid == our_tid));
+  }
   const bool invert = job.flags & JF_INVERT;
   if (s.encoding == HY_ENC_DICTIONARY) {
     const uint32_t vid = aload_compressed(s.data, s.width, row);
@@ -1490,7 +1495,7 @@ __device__ __forceinline__ bool filter_row(const ColumnView& s, const ScanJob& j
 __device__ __forceinline__ uint32_t filter_wave_rows(const ColumnView& s, const ScanJob& job, uint32_t first_row, uint32_t lane, uint32_t n_rows) {
   constexpr int K = static_cast<int>(FUSED_WAVE_ROWS / 64), B = 16;
   const bool invert = job.flags & JF_INVERT;
-  const bool words = s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE || job.kind == KIND_U32 || job.kind == KIND_F32 || job.kind == KIND_NULLTEST;
+  const bool words = s.encoding != HY_ENC_MVCC && (s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE || job.kind == KIND_U32 || job.kind == KIND_F32 || job.kind == KIND_NULLTEST);
   uint32_t bits = 0;
   if (!words || job.kind == KIND_VALUE_ID_SET) {
 #pragma unroll 1
@@ -2605,7 +2610,10 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     // the plan in device memory: per filter the chunk jobs (prepare_jobs, like hy_table_scan), per accumulator its input expression
     const uint32_t n_chunks = shape->n_chunks;
     std::vector<size_t> staging_at(fused->n_filters + 1, 0);
-    for (uint32_t f = 0; f < fused->n_filters; ++f) staging_at[f + 1] = staging_at[f] + align_up(scan_jobs_staging_bytes(fused->filters[f].column, &fused->filters[f].predicate), 256);
+    for (uint32_t f = 0; f < fused->n_filters; ++f) {
+      const bool validate = fused->filters[f].predicate.condition == HY_FILTER_VALIDATE;
+      staging_at[f + 1] = staging_at[f] + (validate ? 256 : align_up(scan_jobs_staging_bytes(fused->filters[f].column, &fused->filters[f].predicate), 256));
+    }
     const size_t jobs_bytes = align_up(sizeof(ScanJob) * (size_t{n_chunks} + 1), 256);
     DeviceBuffer plan_buffer;
     HY_TRY(plan_buffer.alloc(align_up(sizeof(FusedPlan), 256) + jobs_bytes * fused->n_filters + staging_at[fused->n_filters] + 256));
@@ -2617,7 +2625,9 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     plan.n_filters = fused->n_filters;
     for (uint32_t f = 0; f < fused->n_filters; ++f) {
       ScanJob* jobs = reinterpret_cast<ScanJob*>(jobs_base + jobs_bytes * f);
-      HY_TRY(prepare_scan_jobs(fused->filters[f].column, &fused->filters[f].predicate, jobs, staging_base + staging_at[f]));
+      const hy_predicate& predicate = fused->filters[f].predicate;
+      if (predicate.condition == HY_FILTER_VALIDATE) HY_TRY(prepare_visibility_scan_jobs(fused->filters[f].column, predicate.value.value_id, predicate.value2.value_id, predicate.column_is_nullable, jobs, staging_base + staging_at[f]));
+      else HY_TRY(prepare_scan_jobs(fused->filters[f].column, &predicate, jobs, staging_base + staging_at[f]));
       plan.filters[f].segments = fused->filters[f].column->d_segments;
       plan.filters[f].jobs = jobs;
     }
@@ -2902,7 +2912,16 @@ static hy_status run_fused(const hy_filter* filters, uint32_t n_filters, const h
     return HY_OK;
   };
   auto numeric = [](uint32_t t) { return t >= HY_TYPE_INT && t <= HY_TYPE_DOUBLE; };
-  for (uint32_t f = 0; f < n_filters; ++f) HY_TRY(table_column(filters[f].column, "filter"));
+  for (uint32_t f = 0; f < n_filters; ++f) {
+    if (filters[f].predicate.condition == HY_FILTER_VALIDATE) {   // the table's MvccData: same chunk layout, checked like a column
+      const hy_column* mvcc = filters[f].column;
+      if (!mvcc || !mvcc->is_mvcc || mvcc->is_reference) return fail(HY_ERR_INVALID, "a Validate filter needs the table's column of HY_ENC_MVCC segments");
+      if (shape && mvcc->n_chunks != shape->n_chunks) return fail(HY_ERR_INVALID, "the MvccData does not belong to the table (chunk counts differ)");
+      if (!shape) shape = mvcc;
+      continue;
+    }
+    HY_TRY(table_column(filters[f].column, "filter"));
+  }
   for (uint32_t g = 0; g < n_groupby; ++g) HY_TRY(table_column(groupby[g], "GROUP BY"));
   for (uint32_t g = 0; g < n_aggregates; ++g) {
     const hy_expression* e = aggregates[g].input;

@@ -48,5 +48,7 @@ struct PredicateArgs {
 // jobs[c] = the normalised test of chunk c.
 size_t scan_jobs_staging_bytes(const hy_column* column, const hy_predicate* predicate);
 hy_status prepare_scan_jobs(const hy_column* column, const hy_predicate* predicate, ScanJob* jobs, void* staging);
+// ... the same for Validate (hy_validate's jobs over a column of HY_ENC_MVCC segments): KIND_VISIBLE, or JOB_ALL for entirely visible chunks
+hy_status prepare_visibility_scan_jobs(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut, ScanJob* jobs, void* staging);
 
 }  // namespace hy

@@ -1619,6 +1619,14 @@ hy_status prepare_scan_jobs(const hy_column* column, const hy_predicate* predica
   return HY_OK;
 }
 
+hy_status prepare_visibility_scan_jobs(const hy_column* mvcc, uint32_t our_tid, uint32_t snapshot_commit_id, uint32_t can_use_chunk_shortcut, ScanJob* jobs, void* staging) {
+  if (!mvcc || !mvcc->is_mvcc || mvcc->is_reference) return fail(HY_ERR_INVALID, "a Validate filter needs the table's column of HY_ENC_MVCC segments");
+  const uint32_t n_chunks = mvcc->n_chunks;
+  if (n_chunks) hipLaunchKernelGGL(prepare_visibility_jobs, dim3((n_chunks + 255) / 256), dim3(256), 0, current_stream(), mvcc->d_segments, n_chunks, our_tid, snapshot_commit_id, can_use_chunk_shortcut,
+                                   jobs, static_cast<uint32_t*>(staging));
+  return HY_OK;
+}
+
 struct VisibilityArgs {   // hy_validate
   uint32_t our_tid, snapshot, can_use_chunk_shortcut;
 };

@@ -771,6 +771,7 @@ class TableScan : public AbstractReadOnlyOperator {
     result.offsets = offsets.data();
     result.counts = counts.data();
     result.chunk_state = states.data();
+    bool evaluated_on_host = false;
     if (_right_column_id) {
       check_status(hy_table_scan_columns(column->handle, device_column(in_table, *_right_column_id)->handle, static_cast<uint32_t>(_condition), &result));
     } else {
@@ -802,12 +803,22 @@ class TableScan : public AbstractReadOnlyOperator {
           hy_predicate cast{};
           const auto status = hy_predicate_cast(static_cast<uint32_t>(_condition), static_cast<uint32_t>(column_type), static_cast<uint32_t>(data_type_from_all_type_variant(_value)),
                                                 &first, _value2 ? static_cast<uint32_t>(data_type_from_all_type_variant(*_value2)) : HY_TYPE_NULL, _value2 ? &second : nullptr, &cast);
-          Assert(status != HY_ERR_UNSUPPORTED, "Cannot scan: the literal has no lossless predicate cast to the column's data type (ExpressionEvaluator scan, stock operator).");
-          check_status(status);
-          predicate.condition = cast.condition, predicate.value_type = cast.value_type, predicate.value = cast.value, predicate.value2 = cast.value2;
+          const auto numeric_literal = [](const AllTypeVariant& v) { return v.index() >= 1 && v.index() <= 4; };
+          // a string literal against a numeric column is an invalid plan, not a scan for the evaluator (table_scan_test.cpp:383-405: std::logic_error)
+          Assert(status != HY_ERR_UNSUPPORTED || (numeric_literal(_value) && (!_value2 || numeric_literal(*_value2))), "Cannot scan: column and value data type do not match.");
+          if (status == HY_ERR_UNSUPPORTED) {
+            // No lossless cast (`float_column = 3.1`, `int_column < 3.5`, a literal outside the column type's range): the reference falls
+            // back to its ExpressionEvaluator scan (table_scan.cpp:346-366, 450), and so does the adapter -- the stock operator runs.
+            // The mirror's stand-in for it: every row compared with the literal in the common type (expression_functors.hpp).
+            evaluate_on_host(in_table, matches, offsets, counts, states);
+            evaluated_on_host = true;
+          } else {
+            check_status(status);
+            predicate.condition = cast.condition, predicate.value_type = cast.value_type, predicate.value = cast.value, predicate.value2 = cast.value2;
+          }
         }
       }
-      check_status(hy_table_scan(column->handle, &predicate, excluded_chunk_ids.data(), static_cast<uint32_t>(excluded_chunk_ids.size()), &result));
+      if (!evaluated_on_host) check_status(hy_table_scan(column->handle, &predicate, excluded_chunk_ids.data(), static_cast<uint32_t>(excluded_chunk_ids.size()), &result));
     }
     // ---- output assembly, table_scan.cpp:129-220 ----
     std::vector<std::shared_ptr<Chunk>> output_chunks;
@@ -850,6 +861,52 @@ class TableScan : public AbstractReadOnlyOperator {
   }
 
  private:
+  // The stock scan's stand-in (see _on_execute): a numeric column against numeric literals, row by row, both sides in the common type
+  // (two integers: int64; otherwise double -- what the ExpressionEvaluator's comparison functors promote to).  NULL matches nothing.
+  void evaluate_on_host(const std::shared_ptr<const Table>& in_table, std::vector<RowID>& matches, std::vector<uint64_t>& offsets, std::vector<uint32_t>& counts,
+                        std::vector<uint8_t>& states) const {
+    const auto as_double = [](const AllTypeVariant& v) {
+      return std::visit([](const auto& x) -> double { if constexpr (std::is_arithmetic_v<std::decay_t<decltype(x)>>) return static_cast<double>(x); else return 0.0; }, v);
+    };
+    const auto integral = [](const AllTypeVariant& v) { return v.index() == 1 || v.index() == 2; };
+    const auto as_long = [](const AllTypeVariant& v) { return v.index() == 1 ? static_cast<int64_t>(std::get<int32_t>(v)) : std::get<int64_t>(v); };
+    const auto compare = [&](const AllTypeVariant& cell, const AllTypeVariant& literal) {   // -1, 0, 1
+      if (integral(cell) && integral(literal)) { const int64_t a = as_long(cell), b = as_long(literal); return a < b ? -1 : a > b ? 1 : 0; }
+      const double a = as_double(cell), b = as_double(literal);
+      return a < b ? -1 : a > b ? 1 : 0;
+    };
+    const auto matches_row = [&](const AllTypeVariant& cell) {
+      if (variant_is_null(cell)) return false;
+      const int first = compare(cell, _value);
+      switch (_condition) {
+        case PredicateCondition::Equals: return first == 0;
+        case PredicateCondition::NotEquals: return first != 0;
+        case PredicateCondition::LessThan: return first < 0;
+        case PredicateCondition::LessThanEquals: return first <= 0;
+        case PredicateCondition::GreaterThan: return first > 0;
+        case PredicateCondition::GreaterThanEquals: return first >= 0;
+        default: break;
+      }
+      Assert(_value2.has_value(), "BETWEEN needs two literals.");
+      const int second = compare(cell, *_value2);
+      const bool lower_inclusive = _condition == PredicateCondition::BetweenInclusive || _condition == PredicateCondition::BetweenUpperExclusive;
+      const bool upper_inclusive = _condition == PredicateCondition::BetweenInclusive || _condition == PredicateCondition::BetweenLowerExclusive;
+      return (lower_inclusive ? first >= 0 : first > 0) && (upper_inclusive ? second <= 0 : second < 0);
+    };
+    uint64_t written = 0;
+    for (ChunkID chunk_id = 0; chunk_id < in_table->chunk_count(); ++chunk_id) {
+      const auto segment = in_table->get_chunk(chunk_id)->get_segment(_column_id);
+      offsets[chunk_id] = written;
+      const bool excluded = std::find(excluded_chunk_ids.begin(), excluded_chunk_ids.end(), chunk_id) != excluded_chunk_ids.end();
+      for (ChunkOffset offset = 0; !excluded && offset < segment->size(); ++offset) {
+        if (matches_row((*segment)[offset])) matches[written++] = RowID{chunk_id, offset};
+      }
+      counts[chunk_id] = static_cast<uint32_t>(written - offsets[chunk_id]);
+      states[chunk_id] = HY_CHUNK_SCANNED;
+    }
+    offsets[in_table->chunk_count()] = written;
+  }
+
   // DictionarySegment<pmr_string>: resolve the literal per chunk like _get_search_value_id
   // (column_vs_value_table_scan_impl.cpp:211-226) and column_between_table_scan_impl.cpp:112-124.
   void resolve_string_literal(const std::shared_ptr<const Table>& in_table, std::vector<uint32_t>& lower, std::vector<uint32_t>& upper,
@@ -1248,6 +1305,151 @@ class AggregateHash : public AbstractReadOnlyOperator {   // operators/aggregate
  private:
   std::vector<AggregateDefinition> _aggregates;
   std::vector<ColumnID> _groupby;
+};
+
+// ---- TableScan(s) -> Projection -> AggregateHash of one data table in ONE pass (hy_scan_project_aggregate) --------------------------------
+// What the adapter substitutes for the plan  GetTable -> [Validate ->] TableScan ... -> Projection -> AggregateHash  when every scan is a
+// ColumnVsValue / Between / IsNull scan of a numeric column of the stored table and every aggregate a MIN / MAX / SUM / AVG / COUNT of an
+// arithmetic expression over its columns (tpch_queries.cpp:60-80, 206-210: Q1, Q6).  Expressions are given in postfix order, like
+// hy_expression:  l_extendedprice * (1 - l_discount)  =  column, literal 1, column, Subtraction, Multiplication.
+enum class ArithmeticOperator : uint8_t { Addition, Subtraction, Multiplication, Division, Modulo };   // expression/arithmetic_expression.hpp:12
+struct ExpressionNode {
+  static ExpressionNode column(ColumnID id) { ExpressionNode n; n.kind = HY_EXPR_COLUMN; n.column_id = id; return n; }
+  static ExpressionNode literal(AllTypeVariant v) { ExpressionNode n; n.kind = HY_EXPR_LITERAL; n.value = std::move(v); return n; }
+  static ExpressionNode arithmetic(ArithmeticOperator op) { ExpressionNode n; n.kind = HY_EXPR_ARITHMETIC; n.op = op; return n; }
+  uint32_t kind = HY_EXPR_COLUMN;
+  ColumnID column_id = INVALID_COLUMN_ID;
+  AllTypeVariant value;
+  ArithmeticOperator op = ArithmeticOperator::Addition;
+};
+struct ScanPredicate {   // column <condition> value [AND value2]
+  ColumnID column_id;
+  PredicateCondition condition;
+  AllTypeVariant value;
+  std::optional<AllTypeVariant> value2;
+};
+struct ExpressionAggregate {   // WindowFunctionExpression over an arithmetic expression (no nodes: COUNT(*))
+  WindowFunction function;
+  std::vector<ExpressionNode> input;
+};
+
+class ScanProjectAggregate : public AbstractReadOnlyOperator {
+ public:
+  ScanProjectAggregate(std::shared_ptr<const AbstractOperator> in, std::vector<ScanPredicate> predicates, std::vector<ColumnID> groupby_column_ids, std::vector<ExpressionAggregate> aggregates)
+      : AbstractReadOnlyOperator(std::move(in)), _predicates(std::move(predicates)), _groupby(std::move(groupby_column_ids)), _aggregates(std::move(aggregates)) {}
+  const std::string& name() const override { static const std::string n = "ScanProjectAggregate"; return n; }
+  // with a context, Validate is the pass's first filter (sql_pipeline_builder.hpp:55: every SQL-driven plan validates behind GetTable)
+  void set_transaction_context(std::shared_ptr<TransactionContext> context) { _context = std::move(context); }
+
+ protected:
+  std::shared_ptr<const Table> _on_execute() override {
+    const auto input = left_input_table();
+    Assert(input->type() == TableType::Data, "ScanProjectAggregate reads a stored table: run the operator chain on reference tables.");
+    std::vector<std::shared_ptr<DeviceColumn>> keep;
+    std::vector<hy_filter> filters;
+    if (_context) {
+      keep.push_back(mvcc_column(input));
+      hy_filter filter{};
+      filter.column = keep.back()->handle;
+      filter.predicate.condition = HY_FILTER_VALIDATE;
+      filter.predicate.value.value_id = _context->transaction_id();
+      filter.predicate.value2.value_id = _context->snapshot_commit_id();
+      filter.predicate.column_is_nullable = _context->has_in_flight_delete() ? 0u : 1u;   // can_use_chunk_shortcut (validate.cpp:116-127)
+      filters.push_back(filter);
+    }
+    for (const auto& predicate : _predicates) {
+      const auto column_type = input->column_data_type(predicate.column_id);
+      Assert(column_type != DataType::String, "ScanProjectAggregate: string predicates run as the operator chain.");
+      keep.push_back(device_column(input, predicate.column_id));
+      hy_filter filter{};
+      filter.column = keep.back()->handle;
+      filter.predicate.condition = static_cast<uint32_t>(predicate.condition);
+      filter.predicate.column_is_nullable = input->column_is_nullable(predicate.column_id);
+      if (predicate.condition != PredicateCondition::IsNull && predicate.condition != PredicateCondition::IsNotNull) {
+        const hy_value first = to_hy_value(predicate.value), second = predicate.value2 ? to_hy_value(*predicate.value2) : hy_value{};
+        hy_predicate cast{};
+        const auto status = hy_predicate_cast(static_cast<uint32_t>(predicate.condition), static_cast<uint32_t>(column_type), static_cast<uint32_t>(data_type_from_all_type_variant(predicate.value)), &first,
+                                              predicate.value2 ? static_cast<uint32_t>(data_type_from_all_type_variant(*predicate.value2)) : HY_TYPE_NULL, predicate.value2 ? &second : nullptr, &cast);
+        Assert(status != HY_ERR_UNSUPPORTED, "ScanProjectAggregate: the literal has no lossless predicate cast -- run the operator chain.");
+        check_status(status);
+        filter.predicate.condition = cast.condition, filter.predicate.value_type = cast.value_type, filter.predicate.value = cast.value, filter.predicate.value2 = cast.value2;
+      }
+      filters.push_back(filter);
+    }
+    std::vector<const hy_column*> groupby;
+    for (const auto id : _groupby) {
+      keep.push_back(device_column(input, id, input->column_data_type(id) == DataType::String ? StringKeys::AggregateKeyNames : StringKeys::None));
+      groupby.push_back(keep.back()->handle);
+    }
+    std::vector<hy_expression> expressions(_aggregates.size());
+    std::vector<hy_fused_aggregate> specs(_aggregates.size());
+    for (size_t a = 0; a < _aggregates.size(); ++a) {
+      specs[a].function = static_cast<uint32_t>(_aggregates[a].function);
+      const auto& nodes = _aggregates[a].input;
+      if (nodes.empty()) { Assert(_aggregates[a].function == WindowFunction::Count, "Only COUNT may omit its argument."); continue; }
+      Assert(nodes.size() <= HY_MAX_EXPRESSION_NODES, "ScanProjectAggregate: expression too long -- run the operator chain.");
+      expressions[a].n_nodes = static_cast<uint32_t>(nodes.size());
+      for (size_t k = 0; k < nodes.size(); ++k) {
+        hy_expression_node& out = expressions[a].nodes[k];
+        out.kind = nodes[k].kind;
+        if (nodes[k].kind == HY_EXPR_COLUMN) {
+          keep.push_back(device_column(input, nodes[k].column_id));
+          out.column = keep.back()->handle;
+        } else if (nodes[k].kind == HY_EXPR_LITERAL) {
+          out.literal_type = static_cast<uint32_t>(data_type_from_all_type_variant(nodes[k].value));
+          if (!variant_is_null(nodes[k].value)) out.literal = to_hy_value(nodes[k].value);
+        } else {
+          out.op = static_cast<uint32_t>(nodes[k].op);
+        }
+      }
+      specs[a].input = &expressions[a];
+    }
+    const uint32_t capacity = static_cast<uint32_t>(input->row_count() + 1);
+    std::vector<RowID> group_rows(capacity);
+    std::vector<std::vector<uint64_t>> values(specs.size(), std::vector<uint64_t>(capacity));
+    std::vector<std::vector<uint8_t>> nulls(specs.size(), std::vector<uint8_t>(capacity));
+    std::vector<hy_aggregate_column> columns(std::max<size_t>(1, specs.size()));
+    for (size_t a = 0; a < specs.size(); ++a) { columns[a].values = values[a].data(); columns[a].is_null = nulls[a].data(); }
+    hy_aggregate_result result{};
+    result.mem = HY_MEM_HOST;
+    result.group_capacity = capacity;
+    result.group_row_ids = reinterpret_cast<hy_row_id*>(group_rows.data());
+    result.columns = columns.data();
+    check_status(hy_scan_project_aggregate(filters.data(), static_cast<uint32_t>(filters.size()), groupby.data(), static_cast<uint32_t>(groupby.size()), specs.data(),
+                                           static_cast<uint32_t>(specs.size()), &result));
+    // output like AggregateHash's: GROUP BY values through the representative rows (rows of the stored table), then the aggregates
+    TableColumnDefinitions definitions;
+    for (const auto id : _groupby) definitions.push_back(input->column_definitions()[id]);
+    static const char* names[] = {"MIN", "MAX", "SUM", "AVG", "COUNT", "COUNT DISTINCT", "STDDEV_SAMP", "ANY"};
+    for (size_t a = 0; a < specs.size(); ++a) {
+      const bool needs_null = _aggregates[a].function != WindowFunction::Count;
+      definitions.push_back({std::string(names[static_cast<int>(_aggregates[a].function)]) + "(" + (_aggregates[a].input.empty() ? "*" : "expression " + std::to_string(a)) + ")",
+                             static_cast<DataType>(columns[a].data_type), needs_null});
+    }
+    auto output = std::make_shared<Table>(definitions, TableType::Data, Chunk::DEFAULT_SIZE);
+    for (uint32_t g = 0; g < result.n_groups; ++g) {
+      std::vector<AllTypeVariant> row;
+      for (const auto id : _groupby) row.push_back((*input->get_chunk(group_rows[g].chunk_id)->get_segment(id))[group_rows[g].chunk_offset]);
+      for (size_t a = 0; a < specs.size(); ++a) {
+        if (nulls[a][g]) { row.emplace_back(NullValue{}); continue; }
+        switch (static_cast<DataType>(columns[a].data_type)) {
+          case DataType::Int: row.emplace_back(reinterpret_cast<const int32_t*>(values[a].data())[g]); break;
+          case DataType::Long: row.emplace_back(reinterpret_cast<const int64_t*>(values[a].data())[g]); break;
+          case DataType::Float: row.emplace_back(reinterpret_cast<const float*>(values[a].data())[g]); break;
+          default: row.emplace_back(reinterpret_cast<const double*>(values[a].data())[g]); break;
+        }
+      }
+      output->append(std::move(row));
+    }
+    output->finalize();
+    return output;
+  }
+
+ private:
+  std::vector<ScanPredicate> _predicates;
+  std::vector<ColumnID> _groupby;
+  std::vector<ExpressionAggregate> _aggregates;
+  std::shared_ptr<TransactionContext> _context;
 };
 
 }  // namespace hyrise_amd

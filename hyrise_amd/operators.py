@@ -379,6 +379,15 @@ def expression(tree):
     return e
 
 
+def validate_filter(mvcc_column, our_tid, snapshot_commit_id, can_use_chunk_shortcut=True):
+    """Validate as a filter of hy_scan_project_aggregate: (the table's MvccData as a DeviceColumn, its predicate)."""
+    predicate = abi.Predicate()
+    predicate.condition = abi.FILTER_VALIDATE
+    predicate.value.value_id, predicate.value2.value_id = int(our_tid), int(snapshot_commit_id)
+    predicate.column_is_nullable = 1 if can_use_chunk_shortcut else 0
+    return mvcc_column, predicate
+
+
 def scan_project_aggregate(filters, groupby_columns, aggregates, group_capacity=None):
     """hy_scan_project_aggregate: TableScan(s) -> Projection -> AggregateHash of one data table in one pass.
     filters: [(DeviceColumn, predicate)], ANDed in order; aggregates: [(HY_AGG_*, expression tree or None for COUNT(*))]."""

@@ -192,11 +192,13 @@ def run_q6(ex, columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discou
     return result.column(0)[0], result.column(1)[0]
 
 
-def q6_fused(columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discount=(0.05, 0.07), quantity=24.0):
+def q6_fused(columns, date_from=DAY_1994_01_01, date_to=DAY_1995_01_01, discount=(0.05, 0.07), quantity=24.0, mvcc=None, transaction=(0, 0)):
     """The same Q6 in ONE pass over lineitem (hy_scan_project_aggregate): no PosList, no product column.  `columns`: DeviceColumns of the
-    data table.  -> (revenue, qualifying rows)"""
-    from .operators import make_predicate, scan_project_aggregate
+    data table; `mvcc` (a DeviceColumn of the table's MvccData): Validate is the pass's first filter, like in run_q6.
+    -> (revenue, qualifying rows)"""
+    from .operators import make_predicate, scan_project_aggregate, validate_filter
     result = scan_project_aggregate(
+        ([validate_filter(mvcc, transaction[0], transaction[1])] if mvcc is not None else []) +
         [(columns["l_shipdate"], make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, date_from, date_to)),
          (columns["l_discount"], make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, np.float32(discount[0]), np.float32(discount[1]))),
          (columns["l_quantity"], make_predicate(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, quantity))],

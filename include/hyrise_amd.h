@@ -435,11 +435,16 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
  * chain's name rows of its last intermediate table).
  * Expressions are in postfix order over at most HY_MAX_EXPRESSION_NODES nodes and three stack slots:
  * l_extendedprice * (1 - l_discount) is  COLUMN l_extendedprice, LITERAL 1, COLUMN l_discount, ARITHMETIC SUB, ARITHMETIC MUL.
+ * Validate as a filter (the plan shape of a SQL pipeline: GetTable -> Validate -> scans -> Projection -> Aggregate): a filter whose
+ * `column` is the table's MvccData (HY_ENC_MVCC segments, see hy_validate) with predicate.condition = HY_FILTER_VALIDATE,
+ * predicate.value.value_id = our transaction id, predicate.value2.value_id = the snapshot commit id and
+ * predicate.column_is_nullable = can_use_chunk_shortcut keeps the rows hy_validate keeps (validate.cpp:47-68).
  * All columns are data columns (no reference segments) of one table.  HY_ERR_UNSUPPORTED: more than HY_MAX_FILTERS filters,
  * aggregate functions other than MIN / MAX / SUM / AVG / COUNT, string expressions, expressions that read more than six
  * distinct columns between them or need a fourth stack slot -- run the chain instead. */
 enum { HY_EXPR_COLUMN = 0, HY_EXPR_LITERAL = 1, HY_EXPR_ARITHMETIC = 2 };
 enum { HY_MAX_EXPRESSION_NODES = 12, HY_MAX_FILTERS = 4 };
+enum { HY_FILTER_VALIDATE = 0x100 /* hy_filter.predicate.condition of a Validate filter; not a PredicateCondition */ };
 typedef struct hy_expression_node {
   uint32_t kind;                  /* HY_EXPR_*                                                                         */
   uint32_t op;                    /* HY_EXPR_ARITHMETIC: HY_ARITH_*, applied to the two results below it on the stack  */

@@ -237,15 +237,96 @@ static void test_literals_of_other_types_are_cast_without_loss() {   // table_sc
     EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::GreaterThan, int64_t{1000}) == 2);
     EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::Equals, 123.0) == 1);
     EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::Equals, 123.0f) == 1);
-    for (const AllTypeVariant& literal : {AllTypeVariant{123.5}, AllTypeVariant{int64_t{100'000'000'000}}}) {   // no int equals these: the stock evaluator scan
-      bool thrown = false;
-      try { count(ColumnID{0}, PredicateCondition::LessThan, literal); } catch (const std::logic_error&) { thrown = true; }
-      EXPECT_TRUE(thrown);
-    }
-    bool thrown = false;
-    try { count(ColumnID{1}, PredicateCondition::Equals, 457.7); } catch (const std::logic_error&) { thrown = true; }   // float = double that is no float
-    EXPECT_TRUE(thrown);
+    // No lossless cast: the reference runs its ExpressionEvaluator scan (table_scan.cpp:346-366, 450) -- the adapter the stock operator,
+    // this mirror its row-by-row stand-in; queries that run on stock Hyrise run through the adapter (a: 12345, 123, 1234).
+    EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::LessThan, 123.5) == 1);
+    EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::GreaterThanEquals, 123.5) == 2);
+    EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::Equals, 123.5) == 0);
+    EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::LessThan, int64_t{100'000'000'000}) == 3);
+    EXPECT_TRUE(count(ColumnID{0}, PredicateCondition::BetweenInclusive, 122.5, 1234.5) == 2);
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::Equals, 457.7) == 0);      // float_column = a double that is no float: no row
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::NotEquals, 457.7) == 3);
+    EXPECT_TRUE(count(ColumnID{1}, PredicateCondition::Equals, 3.1) == 0);
   }
+}
+
+static void test_scan_project_aggregate() {   // the fused pass behind the operator interface: Q6's shape, with and without Validate
+  // a: 0 .. 99, b = a % 7 as float, c = 0.5 * a as double, key = a % 3; chunks of 32 rows
+  auto table = std::make_shared<Table>(TableColumnDefinitions{{"a", DataType::Int, false}, {"b", DataType::Float, false}, {"c", DataType::Double, true}, {"key", DataType::Int, false}},
+                                       TableType::Data, ChunkOffset{32});
+  for (ChunkID chunk = 0; chunk * 32 < 100; ++chunk) {
+    std::vector<int32_t> a, key;
+    std::vector<float> b;
+    std::vector<double> c;
+    std::vector<bool> c_null;
+    for (int32_t i = static_cast<int32_t>(chunk) * 32; i < std::min<int32_t>(100, (static_cast<int32_t>(chunk) + 1) * 32); ++i) {
+      a.push_back(i); key.push_back(i % 3); b.push_back(static_cast<float>(i % 7)); c.push_back(0.5 * i); c_null.push_back(i % 10 == 9);
+    }
+    const auto rows = a.size();
+    table->append_chunk({std::make_shared<ValueSegment<int32_t>>(a, std::nullopt), std::make_shared<ValueSegment<float>>(b, std::nullopt),
+                         std::make_shared<ValueSegment<double>>(c, c_null), std::make_shared<ValueSegment<int32_t>>(key, std::nullopt)}, std::make_shared<MvccData>(rows));
+  }
+  // SELECT key, SUM(b * (1 - c)), COUNT(*), MIN(a) FROM t WHERE a BETWEEN 10 AND 89 AND b < 5 GROUP BY key    (rows with c NULL: NULL product, not summed)
+  const auto expected = [&](const std::function<bool(int32_t)>& visible) {
+    std::map<int32_t, std::tuple<double, int64_t, int32_t, bool>> groups;   // sum, count, min, any non-NULL product
+    std::vector<int32_t> order;
+    for (int32_t i = 0; i < 100; ++i) {
+      if (!visible(i) || i < 10 || i > 89 || static_cast<float>(i % 7) >= 5.0f) continue;
+      if (!groups.count(i % 3)) { groups[i % 3] = {0.0, 0, i, false}; order.push_back(i % 3); }
+      auto& [sum, count, minimum, any] = groups[i % 3];
+      if (i % 10 != 9) { sum += static_cast<double>(static_cast<float>(i % 7)) * (1.0 - 0.5 * i); any = true; }
+      count += 1;
+      minimum = std::min(minimum, i);
+    }
+    return std::make_pair(groups, order);
+  };
+  const std::vector<ScanPredicate> predicates = {{ColumnID{0}, PredicateCondition::BetweenInclusive, AllTypeVariant{int32_t{10}}, AllTypeVariant{int64_t{89}}},
+                                                 {ColumnID{1}, PredicateCondition::LessThan, AllTypeVariant{5.0}, std::nullopt}};
+  const std::vector<ExpressionAggregate> aggregates = {
+      {WindowFunction::Sum, {ExpressionNode::column(ColumnID{1}), ExpressionNode::literal(int32_t{1}), ExpressionNode::column(ColumnID{2}), ExpressionNode::arithmetic(ArithmeticOperator::Subtraction),
+                             ExpressionNode::arithmetic(ArithmeticOperator::Multiplication)}},
+      {WindowFunction::Count, {}}, {WindowFunction::Min, {ExpressionNode::column(ColumnID{0})}}};
+  const auto check = [&](const std::shared_ptr<const Table>& out, const std::function<bool(int32_t)>& visible) {
+    const auto [groups, order] = expected(visible);
+    EXPECT_TRUE(out->row_count() == groups.size());
+    int32_t previous_key = -1;
+    for (uint64_t g = 0; g < out->row_count() && g < order.size(); ++g) {   // one int32 GROUP BY column: the immediate-key shortcut, key order (aggregate_hash.cpp:770-804)
+      const auto row = out->get_rows()[g];
+      const int32_t key = std::get<int32_t>(row[0]);
+      EXPECT_TRUE(groups.count(key) == 1 && key > previous_key);
+      previous_key = key;
+      if (!groups.count(key)) continue;
+      const auto& [sum, count, minimum, any] = groups.at(key);
+      EXPECT_TRUE(any ? std::abs(std::get<double>(row[1]) - sum) <= 1e-9 * std::max(1.0, std::abs(sum)) : variant_is_null(row[1]));
+      EXPECT_TRUE(std::get<int64_t>(row[2]) == count);
+      EXPECT_TRUE(std::get<int32_t>(row[3]) == minimum);
+    }
+  };
+  auto fused = std::make_shared<ScanProjectAggregate>(wrap(table), predicates, std::vector<ColumnID>{ColumnID{3}}, aggregates);
+  fused->execute();
+  check(fused->get_output(), [](int32_t) { return true; });
+  // behind Validate: rows 20 .. 39 were deleted before the snapshot, rows 50 .. 54 are another transaction's uncommitted inserts
+  for (int32_t i = 0; i < 100; ++i) {
+    const auto& mvcc = table->get_chunk(static_cast<ChunkID>(i / 32))->mvcc_data();
+    mvcc->set_begin_cid(static_cast<ChunkOffset>(i % 32), 1);
+    if (i >= 20 && i < 40) mvcc->set_end_cid(static_cast<ChunkOffset>(i % 32), 3);
+    if (i >= 50 && i < 55) { mvcc->set_begin_cid(static_cast<ChunkOffset>(i % 32), MAX_COMMIT_ID); mvcc->set_tid(static_cast<ChunkOffset>(i % 32), 9); }
+  }
+  auto validated = std::make_shared<ScanProjectAggregate>(wrap(table), predicates, std::vector<ColumnID>{ColumnID{3}}, aggregates);
+  validated->set_transaction_context(std::make_shared<TransactionContext>(7, 5));
+  validated->execute();
+  check(validated->get_output(), [](int32_t i) { return !(i >= 20 && i < 40) && !(i >= 50 && i < 55); });
+  // ... and equal to the chain Validate -> TableScan -> TableScan on the survivors' count
+  auto validate = std::make_shared<Validate>(wrap(table));
+  validate->set_transaction_context(std::make_shared<TransactionContext>(7, 5));
+  validate->execute();
+  auto first = std::make_shared<TableScan>(validate, ColumnID{0}, PredicateCondition::BetweenInclusive, AllTypeVariant{int32_t{10}}, AllTypeVariant{int32_t{89}});
+  first->execute();
+  auto second = std::make_shared<TableScan>(first, ColumnID{1}, PredicateCondition::LessThan, AllTypeVariant{5.0f});
+  second->execute();
+  int64_t counted = 0;
+  for (const auto& row : validated->get_output()->get_rows()) counted += std::get<int64_t>(row[2]);
+  EXPECT_TRUE(static_cast<uint64_t>(counted) == second->get_output()->row_count());
 }
 
 static void test_join_output_chunks_are_merged() {   // join_output_writing.cpp:245-296: PosLists below 1000 rows merge up to 4000
@@ -521,6 +602,7 @@ int main(int argc, char** argv) {
   run("JoinHash on string keys (join ids) vs nested loop", test_join_on_string_keys);
   run("JoinHash with secondary predicates vs nested loop", test_join_with_secondary_predicates);
   run("AggregateHash vs .tbl fixtures (+ CannotSumStringColumns)", test_aggregates_against_fixtures);
+  run("ScanProjectAggregate (fused pass) with and without Validate", test_scan_project_aggregate);
   hy_shutdown();
   std::printf("%s\n", g_failures ? "HOST TESTS FAILED" : "HOST TESTS PASSED");
   return g_failures ? 1 : 0;

@@ -183,3 +183,21 @@ def test_bit_packing_layout():
                 stream[i * bits + b] = (int(v) >> b) & 1
         words = np.packbits(stream, bitorder="little").view("<u8")
         np.testing.assert_array_equal(binary.unpack_bits(words, bits, 1000), values.astype(np.uint32))
+
+
+def test_lz4_decoder_refuses_truncated_blocks_and_replicates_overlapping_matches():
+    """lz4_block_decode checks every length against the block (a truncated block used to raise IndexError or silently copy a short
+    literal run) and copies an overlapping match by repeating the offset-sized pattern (RLE-like blocks at interpreter speed before)."""
+    # 4 literals "abcd", then a match of 20 bytes at offset 4 (overlapping: abcdabcd...), then the last literals "xy"
+    block = bytes([0x4F]) + b"abcd" + bytes([4, 0]) + bytes([20 - 4 - 15]) + bytes([0x20]) + b"xy"
+    want = b"abcd" + b"abcd" * 5 + b"xy"
+    assert binary.lz4_block_decode(block, len(want)) == want
+    run = bytes([0x1F]) + b"z" + bytes([1, 0]) + bytes([255, 255, 10]) + bytes([0x00])      # one literal, then 'z' 539 more times (offset 1)
+    assert binary.lz4_block_decode(run, 1 + 4 + 15 + 255 + 255 + 10) == b"z" * 540
+    for cut in (1, 3, 5, 6, 7):                                                              # every truncation is refused, never mis-decoded
+        with pytest.raises(ValueError):
+            binary.lz4_block_decode(block[:cut], len(want))
+    with pytest.raises(ValueError):
+        binary.lz4_block_decode(block, len(want) - 3)                                        # a match past the decoded size
+    with pytest.raises(ValueError):
+        binary.lz4_block_decode(bytes([0x00, 9, 0]), 4)                                      # offset outside the history

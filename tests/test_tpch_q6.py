@@ -73,6 +73,12 @@ def mvcc_for(data, rng, chunk_size):
     return storage.make_mvcc_column(tids, begin, end, chunk_size), visible
 
 
+def storage_mvcc_all_visible(n, chunk_size=65_535):
+    """MvccData of a table nobody has touched since it was loaded: every chunk immutable and entirely visible (validate.cpp:57-68)."""
+    from hyrise_amd import storage
+    return storage.make_mvcc_column(np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.full(n, storage.MAX_COMMIT_ID, np.uint32), chunk_size)
+
+
 def numpy_q6_visible(data, visible):
     keep = visible & (data.l_shipdate >= tpch.DAY_1994_01_01) & (data.l_shipdate < tpch.DAY_1995_01_01) & (data.l_discount >= np.float32(0.05)) & \
            (data.l_discount <= np.float32(0.07)) & (data.l_quantity < 24)
@@ -98,12 +104,30 @@ def test_q6_behind_validate_on_device(device):
     mvcc, visible = mvcc_for(data, np.random.default_rng(2), 65_535)
     host = tpch.q6_columns(data)
     columns = {name: DeviceColumn(column) for name, column in host.items()}
-    revenue, qualifying = tpch.run_q6(HipExecutor(torch.device("cuda", 0)), columns, mvcc=DeviceColumn(mvcc), transaction=(7, 10))
+    mvcc_device = DeviceColumn(mvcc)
+    revenue, qualifying = tpch.run_q6(HipExecutor(torch.device("cuda", 0)), columns, mvcc=mvcc_device, transaction=(7, 10))
     exact_revenue, exact_rows = numpy_q6_visible(data, visible)
     assert qualifying == exact_rows > 0
     assert abs(revenue - exact_revenue) <= 1e-9 * exact_revenue
     oracle_revenue, oracle_rows = tpch.run_q6(OracleExecutor(), host, mvcc=mvcc, transaction=(7, 10))
     assert oracle_rows == qualifying and abs(oracle_revenue - revenue) <= 1e-9 * abs(oracle_revenue)
+    # the same plan in ONE pass: Validate is the first filter of hy_scan_project_aggregate (HY_FILTER_VALIDATE)
+    fused_revenue, fused_rows = tpch.q6_fused(columns, mvcc=mvcc_device, transaction=(7, 10))
+    assert fused_rows == qualifying and abs(fused_revenue - revenue) <= 1e-9 * abs(revenue)
+    # ... for another transaction (nobody's uncommitted rows are ours), and with the entirely-visible-chunk shortcut taken by every chunk
+    for our_tid, snapshot in ((3, 10), (7, 2)):
+        chain = tpch.run_q6(HipExecutor(torch.device("cuda", 0)), columns, mvcc=mvcc_device, transaction=(our_tid, snapshot))
+        fused = tpch.q6_fused(columns, mvcc=mvcc_device, transaction=(our_tid, snapshot))
+        assert fused[1] == chain[1] and (chain[0] is None) == (fused[0] is None)
+        if chain[0] is not None:
+            assert abs(fused[0] - chain[0]) <= 1e-9 * abs(chain[0])
+    n = data.n_lineitems
+    clean = DeviceColumn(storage_mvcc_all_visible(n))
+    assert tpch.q6_fused(columns, mvcc=clean, transaction=(7, 10))[1] == numpy_q6(data)[1]
+    from hyrise_amd import abi
+    short = DeviceColumn(storage_mvcc_all_visible(1000))   # the MvccData of some other table
+    with pytest.raises(abi.HyriseAmdError):
+        tpch.q6_fused(columns, mvcc=short, transaction=(7, 10))
 
 
 @pytest.mark.gpu
