@@ -3019,6 +3019,40 @@ static hy_status run_fused(const hy_filter* filters, uint32_t n_filters, const h
 
 using namespace hy;
 
+// HY_MEM_DEVICE results: the groups are ordered on the host (the reference's order is a host-side sort of a few groups), so the
+// operator runs against a host shadow of the caller's buffers and the filled prefix is uploaded -- what the caller gets is a result a
+// next operator can read without the values crossing to the host's address space of the CALLER (an operator chain that ends on the device).
+template <typename Run>
+static hy_status run_with_result_memory(hy_aggregate_result* result, uint32_t n_aggregates, Run run) {
+  if (result->mem == HY_MEM_HOST) return run(result);
+  if (result->mem != HY_MEM_DEVICE) return fail(HY_ERR_INVALID, "aggregate result: bad memory space %u", result->mem);
+  const size_t capacity = result->group_capacity;
+  std::vector<hy_row_id> rows(capacity ? capacity : 1);
+  std::vector<std::vector<uint64_t>> values(n_aggregates, std::vector<uint64_t>(capacity ? capacity : 1));
+  std::vector<std::vector<uint8_t>> nulls(n_aggregates, std::vector<uint8_t>(capacity ? capacity : 1));
+  std::vector<hy_aggregate_column> columns(n_aggregates ? n_aggregates : 1);
+  for (uint32_t a = 0; a < n_aggregates; ++a) { columns[a].values = values[a].data(); columns[a].is_null = result->columns[a].is_null ? nulls[a].data() : nullptr; }
+  hy_aggregate_result shadow = *result;
+  shadow.mem = HY_MEM_HOST;
+  shadow.group_row_ids = result->group_row_ids ? rows.data() : nullptr;
+  shadow.columns = columns.data();
+  const hy_status status = run(&shadow);
+  result->n_groups = shadow.n_groups;
+  if (status != HY_OK) return status;
+  hipStream_t stream = current_stream();
+  const size_t n = shadow.n_groups;
+  if (result->group_row_ids && n) HY_HIP(hipMemcpyAsync(result->group_row_ids, rows.data(), sizeof(hy_row_id) * n, hipMemcpyHostToDevice, stream));
+  for (uint32_t a = 0; a < n_aggregates; ++a) {
+    result->columns[a].data_type = columns[a].data_type;
+    const size_t width = columns[a].data_type == HY_TYPE_INT || columns[a].data_type == HY_TYPE_FLOAT ? 4 : 8;
+    if (!result->columns[a].values) return fail(HY_ERR_INVALID, "aggregate %u: values buffer missing", a);
+    if (n) HY_HIP(hipMemcpyAsync(result->columns[a].values, values[a].data(), width * n, hipMemcpyHostToDevice, stream));
+    if (result->columns[a].is_null && n) HY_HIP(hipMemcpyAsync(result->columns[a].is_null, nulls[a].data(), n, hipMemcpyHostToDevice, stream));
+  }
+  HY_HIP(hipStreamSynchronize(stream));   // (the shadows die with this call)
+  return HY_OK;
+}
+
 extern "C" {
 
 hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
@@ -3040,7 +3074,9 @@ hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters
     }
     plain_aggregates[g].input = &plain_inputs[g];
   }
-  return run_fused(plain_filters.data(), n_filters, plain_groupby.data(), n_groupby, plain_aggregates.data(), n_aggregates, result);
+  return run_with_result_memory(result, n_aggregates, [&](hy_aggregate_result* out) {
+    return run_fused(plain_filters.data(), n_filters, plain_groupby.data(), n_groupby, plain_aggregates.data(), n_aggregates, out);
+  });
 }
 
 hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates,
@@ -3053,7 +3089,9 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
   for (const hy_column*& column : plain_groupby) HY_TRY(plain_column(column, &column));
   std::vector<hy_aggregate_spec> plain_aggregates(aggregates, aggregates + n_aggregates);
   for (hy_aggregate_spec& spec : plain_aggregates) HY_TRY(plain_column(spec.column, &spec.column));
-  return run_aggregate(plain_groupby.data(), n_groupby, plain_aggregates.data(), n_aggregates, result);
+  return run_with_result_memory(result, n_aggregates, [&](hy_aggregate_result* out) {
+    return run_aggregate(plain_groupby.data(), n_groupby, plain_aggregates.data(), n_aggregates, out);
+  });
 }
 
 // debug only: which path the last hy_aggregate_hash of this process took -- 0 aggregate_rows, else the partition bits; not part of the public header

@@ -3362,7 +3362,26 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     }
     k.slice_offsets = dev_slice_offsets;
     const uint32_t tile_grid = 8 * ((n_tiles + 7) / 8);
-    {
+    // The build side staged in LDS (pk_count_lds, join_pkfk.hpp): a rank table over fewer than 2^20 key values, enough tiles for
+    // persistent workgroups to pay for staging it once per CU.
+    DeviceBuffer row_masks;
+    const bool build_in_lds = b.rank.range < PK_LDS_KEYS && partitions <= PK_LDS_MAX_PARTITIONS && n_tiles >= (getenv("HY_JOIN_LDS_BUILD_TILES") ? static_cast<uint32_t>(atoi(getenv("HY_JOIN_LDS_BUILD_TILES"))) : 2048u) && !getenv("HY_JOIN_NO_LDS_BUILD");   // (tests lower the bar)
+    if (build_in_lds) {
+      HY_TRY(row_masks.alloc(size_t{n_tiles} * (2 * PK_TILE / 8)));
+      k.row_masks = row_masks.as<uint8_t>();
+      static std::atomic<bool> count_lds_raised{false};
+      if (!count_lds_raised.load(std::memory_order_acquire)) {
+        HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_count_lds), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pk_count_lds_bytes(PK_LDS_KEYS - 1, PK_LDS_MAX_PARTITIONS))));
+        count_lds_raised.store(true, std::memory_order_release);
+      }
+      int device = 0, cus = 256;
+      (void)hipGetDevice(&device);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      const uint32_t groups = std::min<uint32_t>(static_cast<uint32_t>(cus), (n_tiles + PK_LDS_SUBTILES - 1) / PK_LDS_SUBTILES);
+      hipEvent_t count_started = nullptr, count_stopped = nullptr;
+      profile_events(&count_started, &count_stopped, HY_KERNEL_JOIN_COUNT);
+      hipExtLaunchKernelGGL(pk_count_lds, dim3(groups), dim3(1024), pk_count_lds_bytes(b.rank.range, partitions), stream, count_started, count_stopped, 0, k);
+    } else {
       hipEvent_t count_started = nullptr, count_stopped = nullptr;
       profile_events(&count_started, &count_stopped, HY_KERNEL_JOIN_COUNT);
       hipExtLaunchKernelGGL(pk_count, dim3(tile_grid), dim3(PK_COUNT_THREADS), 0, stream, count_started, count_stopped, 0, k);
@@ -3392,17 +3411,22 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     if (!pk_lds_raised.load(std::memory_order_acquire)) {
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       pk_lds_raised.store(true, std::memory_order_release);
     }
     hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself)
     profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
     k.cut_blocks = (cut_grid + 7) / 8 * 8;   // (pk_cut_slice returns at once for slices the plan does not have)
-    if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
+    if (build_in_lds) {   // (pass 2 reads the rows' found / materialised bits pass 1 left behind)
+      if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL((pk_emit<true, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
+      else hipExtLaunchKernelGGL((pk_emit<false, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
+    } else if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     else hipExtLaunchKernelGGL(pk_emit<false>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     HY_HIP(hipGetLastError());
     clock.mark("pass 2 launched");
-    t_last_join_used_pkfk = 1;   // debug / tests: the primary-key / foreign-key kernels ran
+    t_last_join_used_pkfk = build_in_lds ? 2 : 1;   // debug / tests: the primary-key / foreign-key kernels ran (2: with the build side's bits staged in LDS)
     if (host_result) {
       if (mailbox->fits && mailbox->n_pairs) {
         HY_HIP(hipMemcpyAsync(user_probe, dev_probe, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
@@ -3695,7 +3719,7 @@ int hy_debug_join_used_rank_table(void) { return t_last_join_used_rank_table; }
 // debug / tests only: see t_last_join_hinted
 int hy_debug_join_build_was_hinted(void) { return t_last_join_hinted; }
 
-// debug / tests only: 1 = the last join of this thread ran pk_count / pk_scan / pk_emit / pk_cuts (join_pkfk.hpp)
+// debug / tests only: 1 = the last join of this thread ran pk_count / pk_scan / pk_emit / pk_cuts (join_pkfk.hpp), 2 = pk_count_lds / pk_emit<., true>
 int hy_debug_join_used_pkfk(void) { return t_last_join_used_pkfk; }
 
 // debug only (HY_JOIN_TRACE): the per-tile phase stamps of the last join's probe_emit; not part of the public header

@@ -74,7 +74,16 @@ struct PkArgs {
   uint32_t cut_blocks;             // pk_emit: its first cut_blocks workgroups compute the PosList cuts (pk_cut_slice)
   uint32_t bloom_is_bits;          // build_bloom holds 2^20 bits (a hinted build, rank_table_fill_checked), not one byte per bit
   uint64_t* trace;                 // debug (HY_JOIN_TRACE): 6 wall-clock stamps per pk_emit tile, else nullptr
+  // The build side staged in LDS (pk_count_lds): a rank table of at most PK_LDS_KEYS key values -- a filtered dimension of a star join --
+  // is 128 KB of presence bits; pass 1 looks every probe row up THERE and leaves two bits per row behind for pass 2.
+  uint8_t* row_masks;              // [n_tiles][2][PK_TILE / 8] found | materialised, or nullptr (the classic kernels)
 };
+constexpr uint32_t PK_LDS_KEYS = 1u << 20;                       // the table's range must be smaller: then the Bloom filter (bit = key & 0xFFFFF) is the presence bit
+constexpr uint32_t PK_LDS_WORDS = PK_LDS_KEYS / 32;              // 32 768 presence words = 128 KB
+constexpr uint32_t PK_LDS_SUBTILES = 4;                          // tiles a 1024-thread workgroup of pk_count_lds counts at once
+constexpr uint32_t PK_LDS_MAX_PARTITIONS = 128;                 // (the workgroup's cells: 4 tiles x partitions x 8 copies -- 16 KB beside the 128 KB of bits)
+__host__ __device__ inline uint32_t pk_lds_presence_words(uint64_t range) { return (static_cast<uint32_t>(range >> 5) + 1 + 3) & ~3u; }   // (16-byte aligned cells behind them)
+__host__ __device__ inline size_t pk_count_lds_bytes(uint64_t range, uint32_t partitions) { return 4 * (size_t{pk_lds_presence_words(range)} + size_t{PK_LDS_SUBTILES} * partitions * COUNT_COPIES); }
 
 // The rows of tile `tile`: its slice's view, narrowed to the tile.
 __device__ __forceinline__ SliceView pk_tile_view(const PkArgs& a, uint32_t tile) {
@@ -115,8 +124,12 @@ __device__ __forceinline__ bool pk_emits(uint32_t mode, bool found, bool* null_p
 // tile's view and then its words, of its short life waiting -- lookups and LDS atomics are the other 7.  Persistent workgroups that
 // request their next tile's words ahead were SLOWER (76 us): loads return in order (one counter, vmcnt), so either the lookups queue
 // behind the prefetch or the prefetch costs 48 more live registers.
-template <uint32_t WIDTH>
-__device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& view, uint32_t wave, uint32_t lane, uint32_t* cells) {
+// LDS: the presence words come from `presence` (LDS, the whole table), partner-less rows ask the same words instead of the Bloom
+// filter (exact for a range below 2^20: the one key value of the range that shares the row's filter bit), and the rows' found /
+// materialised bits are left in `masks` (the tile's 2 x 1 KB) for pass 2.
+template <uint32_t WIDTH, bool LDS = false>
+__device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& view, uint32_t wave, uint32_t lane, uint32_t* cells, const uint32_t* presence = nullptr,
+                                              uint8_t* masks = nullptr) {
   const char* base = static_cast<const char*>(view.data);
   const uint32_t row_count = view.row_count;
   const uint32_t wave_first = wave * PK_COUNT_WAVE_ROWS;
@@ -141,7 +154,8 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
         const uint32_t distance = batch_word<WIDTH>(words[g + b], j) + bias - origin;   // (32-bit: both sides' keys are int32 values, pk_path in run_join)
-        bits[b][j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
+        if constexpr (LDS) bits[b][j] = presence[distance <= range ? distance >> 5 : 0u];
+        else bits[b][j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
       }
     }
 #pragma unroll
@@ -158,9 +172,22 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
         uint32_t miss = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 8; ++j) {
-          if (((valid & ~found) >> j) & 1) miss |= (pk_bloom_test(a, batch_word<WIDTH>(words[g + b], j) + bias) ? 0u : 1u) << j;
+          if (!(((valid & ~found) >> j) & 1)) continue;
+          bool filter_bit;
+          if constexpr (LDS) {   // range < 2^20: the filter's bit of a key is the presence bit of the one key of the range congruent to it
+            const uint32_t candidate = (batch_word<WIDTH>(words[g + b], j) + bias - origin) & (BLOOM_BITS - 1);
+            filter_bit = candidate <= range && ((presence[candidate >> 5] >> (candidate & 31)) & 1);
+          } else {
+            filter_bit = pk_bloom_test(a, batch_word<WIDTH>(words[g + b], j) + bias);
+          }
+          miss |= (filter_bit ? 0u : 1u) << j;
         }
         valid &= ~miss;
+      }
+      if constexpr (LDS) {   // the lane's eight rows are consecutive: one byte each of the tile's found / materialised bits
+        const uint32_t at = (wave_first + (g + b) * 512) / 8 + lane;
+        masks[at] = static_cast<uint8_t>(found);
+        masks[PK_TILE / 8 + at] = static_cast<uint8_t>(valid);
       }
       // neighbouring rows share their key (four lineitems per order): the lane's eight consecutive rows leave as one LDS atomic per RUN
       // of equal partitions (same-address atomics serialise)
@@ -198,6 +225,48 @@ __global__ __launch_bounds__(PK_COUNT_THREADS, 8 * PK_COUNT_THREADS / 256) void 
   for (uint32_t partition = tid; partition < partitions; partition += PK_COUNT_THREADS) {
     const u32x4_t low = *reinterpret_cast<const u32x4_t*>(s_cells + partition * COUNT_COPIES), high = *reinterpret_cast<const u32x4_t*>(s_cells + partition * COUNT_COPIES + 4);
     a.counts[static_cast<size_t>(partition) * a.stride + tile] = low.x + low.y + low.z + low.w + high.x + high.y + high.z + high.w;
+  }
+}
+
+// Pass 1 with the build side staged in LDS -- what north_star asks of JoinHash ("build side staged in LDS", per-wave probing) where it
+// fits: a rank table over fewer than 2^20 key values (the filtered dimension of a star join: SSB's part has 1 M keys) is 128 KB of
+// presence bits.  A probe row of the classic kernel pulls a 128-byte line of the table out of the L2 for one bit -- with unclustered
+// foreign keys (SSB lineorder) that line traffic, not HBM, bounds both passes (pk_count 1.0 ms for 180 M rows).  Here every CU stages
+// the bits once, persistent 1024-thread workgroups walk the tiles four at a time, and pass 2 gets the rows' two bits from a mask
+// instead of looking non-partners up again (pk_emit<INNER, true>).
+__global__ __launch_bounds__(1024) void pk_count_lds(PkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t pk_lds[];
+  uint32_t* s_presence = pk_lds;                                        // [range / 32 + 1]
+  uint32_t* s_cells = pk_lds + pk_lds_presence_words(a.rank.range);     // [PK_LDS_SUBTILES][partitions * COUNT_COPIES]
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t sub = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), local = tid & 255;
+  const uint32_t partitions = 1u << a.radix_bits;
+  if (blockIdx.x == 0 && tid == 0) *a.ticket = 0;   // pk_scan's arrival counter (pk_scan runs behind this kernel)
+  const uint32_t words = static_cast<uint32_t>(a.rank.range >> 5) + 1;
+  for (uint32_t i = tid; i < words; i += 1024) s_presence[i] = a.rank.entries[i].x;
+  uint32_t* cells = s_cells + sub * partitions * COUNT_COPIES;
+  for (uint32_t first = blockIdx.x * PK_LDS_SUBTILES; first < a.n_tiles; first += gridDim.x * PK_LDS_SUBTILES) {
+    const uint32_t tile = first + sub;
+    for (uint32_t i = local; i < partitions * COUNT_COPIES; i += 256) cells[i] = 0;
+    __syncthreads();   // (the bits are staged; the cells are zero)
+    if (tile < a.n_tiles) {
+      const SliceView view = pk_tile_view(a, tile);
+      uint8_t* masks = a.row_masks + static_cast<size_t>(tile) * (2 * PK_TILE / 8);
+      // (a partial tile: the bits of rows that do not exist are written as zeros by the waves that have rows; waves without rows clear theirs)
+      if (wave * PK_COUNT_WAVE_ROWS >= view.row_count) {
+        for (uint32_t i = lane; i < PK_COUNT_WAVE_ROWS / 8; i += 64) { masks[wave * PK_COUNT_WAVE_ROWS / 8 + i] = 0; masks[PK_TILE / 8 + wave * PK_COUNT_WAVE_ROWS / 8 + i] = 0; }
+      } else if (view.kind == VIEW_FOR8) pk_count_wave<1, true>(a, view, wave, lane, cells, s_presence, masks);
+      else if (view.kind == VIEW_FOR16) pk_count_wave<2, true>(a, view, wave, lane, cells, s_presence, masks);
+      else pk_count_wave<4, true>(a, view, wave, lane, cells, s_presence, masks);
+    }
+    __syncthreads();
+    if (tile < a.n_tiles) {
+      for (uint32_t partition = local; partition < partitions; partition += 256) {
+        const u32x4_t low = *reinterpret_cast<const u32x4_t*>(cells + partition * COUNT_COPIES), high = *reinterpret_cast<const u32x4_t*>(cells + partition * COUNT_COPIES + 4);
+        a.counts[static_cast<size_t>(partition) * a.stride + tile] = low.x + low.y + low.z + low.w + high.x + high.y + high.z + high.w;
+      }
+    }
+    __syncthreads();   // (the cells are read before the next round clears them)
   }
 }
 
@@ -375,26 +444,53 @@ __device__ __forceinline__ uint32_t pk_block_word(const SliceView& view, const u
 // Keys, rank-table entries, the rows' fate -- HALVES == 2: eight rows at a time (two table round trips instead of one, half the
 // registers at the peak).
 // meta[k] = partition | null_partner << 9 | emit << 10 (INVALID_PARTITION: the row is not materialised); rank[k] = the partner's rank.
-template <bool INNER, uint32_t HALVES>
+// MASKS: pass 1 was pk_count_lds -- a row's found / materialised bits come from `tile_masks` (the tile's 2 x PK_TILE / 8 bytes), only rows
+// with a partner read their table entry (the others read entry 0: one line for all of them), the Bloom filter is not asked again.
+template <bool INNER, uint32_t HALVES, bool MASKS = false>
 __device__ __forceinline__ void pk_lookup_rows(const PkArgs& a, const SliceView& view, const uint32_t* block, uint32_t wave, uint32_t lane, uint32_t (&meta)[PK_ROUNDS],
-                                               uint32_t (&rank)[PK_ROUNDS]) {
+                                               uint32_t (&rank)[PK_ROUNDS], const uint8_t* tile_masks = nullptr) {
   constexpr uint32_t N = PK_ROUNDS / HALVES;
   const uint32_t row_count = view.row_count;
   const uint32_t wave_first = wave * PK_WAVE_ROWS;
   const uint32_t bias = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + (wave_first < row_count ? wave_first : 0u)) / HY_FOR_BLOCK_SIZE]);
   const uint32_t origin = static_cast<uint32_t>(a.rank.key_min), range = static_cast<uint32_t>(a.rank.range);
   const uint32_t mask = a.radix_bits ? (1u << a.radix_bits) - 1 : 0u;
+  // MASKS: the wave's 1024 rows are 32 words of found bits and 32 of materialised bits; lane l < 32 holds found word l, lane 32 + l
+  // materialised word l; row k * 64 + lane sits in word 2 k + lane / 32, bit lane % 32
+  uint32_t mask_word = 0;
+  if constexpr (MASKS) mask_word = reinterpret_cast<const uint32_t*>(tile_masks + (lane < 32 ? 0u : PK_TILE / 8))[wave * (PK_WAVE_ROWS / 32) + (lane & 31)];
 #pragma unroll
   for (uint32_t h = 0; h < HALVES; ++h) {
     uint32_t raw[N];
     u32x2_t entry[N];
+    uint32_t valid = 0, found = 0;
+    if constexpr (MASKS) {
+#pragma unroll
+      for (uint32_t j = 0; j < N; ++j) {
+        const uint32_t k = h * N + j;
+        const uint32_t found_word = lane < 32 ? __builtin_amdgcn_readlane(mask_word, 2 * k) : __builtin_amdgcn_readlane(mask_word, 2 * k + 1);
+        const uint32_t valid_word = lane < 32 ? __builtin_amdgcn_readlane(mask_word, 32 + 2 * k) : __builtin_amdgcn_readlane(mask_word, 32 + 2 * k + 1);
+        found |= ((found_word >> (lane & 31)) & 1u) << j;
+        valid |= ((valid_word >> (lane & 31)) & 1u) << j;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < N; ++j) {
+        raw[j] = pk_block_word(view, block, lane, h * N + j) + bias;
+        const uint32_t distance = raw[j] - origin;
+        entry[j] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(a.rank.entries) + (((found >> j) & 1) ? (distance >> 5) * 8u : 0u));
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < N; ++j) {
+        const uint32_t bit = (raw[j] - origin) & 31;
+        rank[h * N + j] = entry[j].y + __popc(entry[j].x & ((1u << bit) - 1));
+      }
+    } else {
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) {
       raw[j] = pk_block_word(view, block, lane, h * N + j) + bias;   // the key's low 32 bits
       const uint32_t distance = raw[j] - origin;                     // (32-bit: both sides' keys are int32 values, pk_path in run_join)
       entry[j] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
     }
-    uint32_t valid = 0, found = 0;
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) {
       const uint32_t distance = raw[j] - origin;
@@ -410,6 +506,7 @@ __device__ __forceinline__ void pk_lookup_rows(const PkArgs& a, const SliceView&
         if (((valid & ~found) >> j) & 1) { if (!pk_bloom_test(a, raw[j])) valid &= ~(1u << j); }
       }
     }
+    }
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) {
       bool null_partner;
@@ -422,12 +519,13 @@ __device__ __forceinline__ void pk_lookup_rows(const PkArgs& a, const SliceView&
 
 // ---- evaluation of a tile's rows (cuts) --------------------------------------------------------------------------------------
 // Wave w owns rows [1024 w, 1024 (w + 1)) of the tile, row k * 64 + lane in round k: row order = (wave, round, lane).
-template <bool INNER>
-__device__ __forceinline__ void pk_evaluate(const PkArgs& a, const SliceView& view, uint32_t* block, uint32_t wave, uint32_t lane, uint32_t (&meta)[PK_ROUNDS], uint32_t (&rank)[PK_ROUNDS]) {
+template <bool INNER, bool MASKS = false>
+__device__ __forceinline__ void pk_evaluate(const PkArgs& a, const SliceView& view, uint32_t* block, uint32_t wave, uint32_t lane, uint32_t (&meta)[PK_ROUNDS], uint32_t (&rank)[PK_ROUNDS],
+                                            const uint8_t* tile_masks = nullptr) {
   PkWords words;
   pk_load_words(view, wave, lane, words);
   pk_words_to_block(view, words, block, lane);
-  pk_lookup_rows<INNER, 1>(a, view, block, wave, lane, meta, rank);
+  pk_lookup_rows<INNER, 1, MASKS>(a, view, block, wave, lane, meta, rank, tile_masks);
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------------------------------------------
@@ -510,7 +608,7 @@ __device__ __forceinline__ void pk_copy_out(const PkArgs& a, const u32x2_t* s_st
 }
 
 // One tile from its stored words to its pairs in the output.  The five phases are separated by four workgroup barriers.
-template <bool INNER>
+template <bool INNER, bool MASKS = false>
 __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, const SliceView& view, const PkWords& words, uint32_t cell_pairs, uint32_t cell_base,
                                              uint32_t* join_smem, uint32_t tid, uint32_t lane, uint32_t wave) {
   const uint32_t partitions = 1u << a.radix_bits;
@@ -525,7 +623,7 @@ __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, con
   for (uint32_t i = tid; i < PK_WAVES * partitions; i += PK_THREADS) s_wave_pairs[i] = 0;
   uint32_t meta[PK_ROUNDS], rank[PK_ROUNDS];
   pk_words_to_block(view, words, join_smem + wave * 1024, lane);   // (the staging area is not in use yet: 4 KB of it per wave)
-  pk_lookup_rows<INNER, 1>(a, view, join_smem + wave * 1024, wave, lane, meta, rank);
+  pk_lookup_rows<INNER, 1, MASKS>(a, view, join_smem + wave * 1024, wave, lane, meta, rank, MASKS ? a.row_masks + static_cast<size_t>(tile) * (2 * PK_TILE / 8) : nullptr);
   __builtin_amdgcn_wave_barrier();
   if (a.trace && tid == 0) a.trace[tile * 6 + 1] = wall_clock64();
   // (a) reserve pairs + 1 slots per non-empty partition: scan inside each wave now, across waves in (c)
@@ -546,8 +644,14 @@ __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, con
     uint32_t before[PK_ROUNDS];
     uint32_t* mine = s_wave_pairs + wave * partitions;
     uint32_t* spare = s_scratch + 16 + wave;
+    if constexpr (MASKS) {   // (a selective join: most rows have no pair -- on one spare counter their atomics would serialise, 64 lanes deep)
+#pragma unroll
+      for (uint32_t k = 0; k < PK_ROUNDS; ++k) { before[k] = 0; if (meta[k] & 0x400u) before[k] = atomicAdd(mine + (meta[k] & 0xFF), 1u); }
+      (void)spare;
+    } else {
 #pragma unroll
     for (uint32_t k = 0; k < PK_ROUNDS; ++k) before[k] = atomicAdd((meta[k] & 0x400u) ? mine + (meta[k] & 0xFF) : spare, 1u);
+    }
 #pragma unroll
     for (uint32_t k = 0; k < PK_ROUNDS; ++k) meta[k] |= (meta[k] & 0x400u) ? before[k] << 11 : 0u;
   }
@@ -610,6 +714,7 @@ __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, con
 // One workgroup per output PosList: its group (partition or probe chunk), the tile that holds the PosList's first element
 // (64-ary searches over the scanned counts), then the tile's rows once more.
 // smem: PK_WAVES * 1024 + 2 * PK_WAVES * PK_ROUNDS words.
+template <bool MASKS = false>
 __device__ __forceinline__ void pk_cut_slice(const PkArgs& a, uint32_t slice, uint32_t* smem, uint32_t tid, uint32_t lane, uint32_t wave) {
   uint32_t* s_rows = smem;
   uint32_t* s_members = smem + PK_WAVES * 1024;
@@ -637,7 +742,7 @@ __device__ __forceinline__ void pk_cut_slice(const PkArgs& a, uint32_t slice, ui
   const uint32_t cut_rank = target - rel_elements[tile];
   const SliceView view = pk_tile_view(a, tile);
   uint32_t meta[PK_ROUNDS], rank[PK_ROUNDS];
-  pk_evaluate<false>(a, view, s_rows + wave * 1024, wave, lane, meta, rank);
+  pk_evaluate<false, MASKS>(a, view, s_rows + wave * 1024, wave, lane, meta, rank, MASKS ? a.row_masks + static_cast<size_t>(tile) * (2 * PK_TILE / 8) : nullptr);
   uint64_t members[PK_ROUNDS], emitters[PK_ROUNDS];
 #pragma unroll
   for (uint32_t k = 0; k < PK_ROUNDS; ++k) {
@@ -667,14 +772,14 @@ __global__ __launch_bounds__(PK_THREADS) void pk_cuts(PkArgs a) {
 }
 
 // One tile per workgroup (2 workgroups per CU overlap each other's phases).
-template <bool INNER>
+template <bool INNER, bool MASKS = false>
 __global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
   const uint32_t partitions = 1u << a.radix_bits;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // The first cut_blocks workgroups (a multiple of 8: the others keep their XCD) find the PosList cuts while the rest emits: a launch
   // of its own behind this kernel was 13 us of an otherwise idle device.
-  if (blockIdx.x < a.cut_blocks) { pk_cut_slice(a, blockIdx.x, join_smem, tid, lane, wave); return; }
+  if (blockIdx.x < a.cut_blocks) { pk_cut_slice<MASKS>(a, blockIdx.x, join_smem, tid, lane, wave); return; }
   const uint32_t block = blockIdx.x - a.cut_blocks;
   const uint32_t tile = (block & 7) * ((a.n_tiles + 7) / 8) + (block >> 3);
   if (tile >= a.n_tiles || !a.plan->fits) return;
@@ -686,6 +791,6 @@ __global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkAr
   const uint32_t cell_base = static_cast<uint32_t>(a.origin_pairs[tid < partitions ? tid : 0]) + a.rel_pairs[cell];
   PkWords words;
   pk_load_words(view, wave, lane, words);
-  pk_emit_tile<INNER>(a, tile, view, words, cell_pairs, cell_base, join_smem, tid, lane, wave);
+  pk_emit_tile<INNER, MASKS>(a, tile, view, words, cell_pairs, cell_base, join_smem, tid, lane, wave);
 }
 

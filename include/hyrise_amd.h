@@ -408,7 +408,9 @@ typedef struct hy_aggregate_column {
 } hy_aggregate_column;
 
 typedef struct hy_aggregate_result {
-  uint32_t mem;
+  uint32_t mem;                   /* HY_MEM_HOST, or HY_MEM_DEVICE: group_row_ids / values / is_null are device buffers (the
+                                   * groups are ordered on the host either way; a device result is uploaded once, so that an
+                                   * operator chain can end on the device)                                              */
   uint32_t group_capacity;
   uint32_t n_groups;              /* out */
   uint32_t reserved;

@@ -16,7 +16,8 @@
  * compiler): 0 for +-0.0, otherwise _Hash_bytes (libsupc++/hash_bytes.cc, the 64-bit Murmur-style function, seed
  * 0xc70f6907) over the value's 4 / 8 bytes.  tests/test_oracle_join.py pins hyo_std_hash against the std::hash of the g++
  * installed here.  String keys stay on the CPU path.
- * Secondary predicates are not part of the device ABI and therefore not restated.
+ * Secondary predicates (MultiPredicateJoinEvaluator, join_hash_steps.hpp:563-591: every candidate pair is tested against the
+ * additional column comparisons before it is emitted) are restated below (hyo_join_hash_predicates).
  *
  * Result: the concatenation of probe()'s per-slice PosLists, in the order the slices are created
  * (partition, then 131 070-element slice), plus the slice boundaries; write_output_chunks

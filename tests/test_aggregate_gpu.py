@@ -345,3 +345,46 @@ def test_small_domain_kernel(device, monkeypatch):
     assert used_small_domain() == 0
     run_both([few], [(abi.AGG_SUM, floats), (abi.AGG_MIN, floats)], "MIN")
     assert used_small_domain() == 0
+
+
+def test_aggregate_result_in_device_memory(device):
+    """hy_aggregate_result.mem = HY_MEM_DEVICE: the group rows, values and NULL flags arrive in the caller's device buffers (an operator
+    chain that ends on the device) and are the host-memory result's bytes; a result that does not fit reports the groups it needs."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(17)
+    n = 50_000
+    keys = build_column(rng.integers(0, 300, n).astype(np.int32), rng.random(n) < 0.01, 7000, abi.ENC_DICTIONARY)
+    ints = build_column(rng.integers(-1000, 1000, n).astype(np.int32), rng.random(n) < 0.1, 7000, abi.ENC_FRAME_OF_REFERENCE)
+    floats = build_column(rng.random(n).astype(np.float32), None, 7000, abi.ENC_UNENCODED)
+    devices = {id(c): DeviceColumn(c) for c in (keys, ints, floats)}
+    spec = [(abi.AGG_SUM, ints), (abi.AGG_AVG, floats), (abi.AGG_MIN, ints), (abi.AGG_MAX, floats), (abi.AGG_COUNT, None)]
+    want = aggregate_hash([devices[id(keys)]], [(f, devices[id(c)] if c is not None else None) for f, c in spec])
+    lib = abi.load_library()
+    capacity = 512
+    dev = torch.device("cuda", 0)
+    rows = torch.zeros((capacity, 2), dtype=torch.int32, device=dev)
+    values = [torch.zeros(capacity, dtype=torch.int64, device=dev) for _ in spec]
+    nulls = [torch.zeros(capacity, dtype=torch.uint8, device=dev) for _ in spec]
+    columns = (abi.AggregateColumn * len(spec))()
+    for a in range(len(spec)):
+        columns[a].values, columns[a].is_null = values[a].data_ptr(), nulls[a].data_ptr()
+    result = abi.AggregateResult()
+    result.mem, result.group_capacity, result.group_row_ids, result.columns = abi.MEM_DEVICE, capacity, rows.data_ptr(), columns
+    garr = (C.c_void_p * 1)(devices[id(keys)].handle)
+    specs = (abi.AggregateSpec * len(spec))()
+    for i, (function, column) in enumerate(spec):
+        specs[i].function = function
+        specs[i].column = devices[id(column)].handle if column is not None else None
+    abi.check(lib.hy_aggregate_hash(garr, 1, specs, len(spec), C.byref(result)))
+    torch.cuda.synchronize()
+    groups = int(result.n_groups)
+    assert groups == want.n_groups == 301
+    assert rows[:groups].cpu().numpy().view(np.uint32).tobytes() == want.row_ids[:groups].tobytes()
+    for a in range(len(spec)):
+        assert columns[a].data_type == want.columns[a].data_type
+        width = 4 if columns[a].data_type in (abi.TYPE_INT, abi.TYPE_FLOAT) else 8
+        assert values[a].cpu().numpy().tobytes()[:width * groups] == want.raw[a].tobytes()[:width * groups], f"aggregate {a}"
+        assert nulls[a][:groups].cpu().numpy().tobytes() == want.nulls[a][:groups].tobytes()
+    result.group_capacity = 100   # too small: nothing is promised about the buffers, the group count is reported
+    assert lib.hy_aggregate_hash(garr, 1, specs, len(spec), C.byref(result)) == abi.ERR_CAPACITY and int(result.n_groups) == 301
