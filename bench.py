@@ -564,11 +564,25 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
         return {"rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "matches": m, "kernel_ms": km,
                 "kernel_GBps": bytes_of(m) / (km * 1e-3) / 1e9 if km else None}
 
+    class Rotating:
+        """COLUMN_COPIES device copies of a column, scanned in rotation: like the headline's, a case's input comes from HBM, not from the
+        256 MiB Infinity Cache a single repeated scan of a 60 - 240 MB column would partly live in (profiles/r03_scan_stores.txt shows what
+        that residency is worth -- and that it decides which store flavour wins)."""
+
+        def __init__(self, host):
+            self.host = host
+            self.copies = [DeviceColumn(host) for _ in range(COLUMN_COPIES)]
+            self.turn = 0
+
+        def scan(self, pred):
+            step_fn(pred, self.copies[self.turn % COLUMN_COPIES])
+            self.turn += 1
+
     for name, pred in (("q1_le_1998-09-02", make_predicate(abi.PRED_LESS_THAN_EQUALS, abi.TYPE_INT, tpch.DAY_1998_09_02)),
                        ("q6_between_1994", make_predicate(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, tpch.DAY_1994_01_01, tpch.DAY_1995_01_01)),
                        ("point_eq_1995-06-17", make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, tpch.CURRENT_DATE)),
                        ("is_null", make_predicate(abi.PRED_IS_NULL, abi.TYPE_INT))):
-        out[name] = measure(lambda p=pred: step_fn(p, column), lambda m: rows * width + m * 8)
+        out[name] = measure(lambda p=pred: step_fn(p, None), lambda m: rows * width + m * 8)   # (None: the headline's copies in rotation)
     # the boundary as the adapter uses it today: PosLists returned to HOST memory (PCIe-inclusive, never the headline value)
     from hyrise_amd.operators import table_scan
     pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
@@ -580,9 +594,9 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
                                          "note": "HY_MEM_HOST: includes packing the chunk regions, the device-to-host copy of the PosLists and the host buffer allocation"}
     del host
     # the same dates as unencoded int32 values (ValueSegment<int32>: the 4-byte streaming instantiation)
-    values = DeviceColumn(storage.make_column(days, None, abi.ENC_UNENCODED))
+    values = Rotating(storage.make_column(days, None, abi.ENC_UNENCODED))
     pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
-    out["int32_value_segments_lt_1995"] = measure(lambda: step_fn(pred, values), lambda m: rows * 4 + m * 8)
+    out["int32_value_segments_lt_1995"] = measure(lambda: values.scan(pred), lambda m: rows * 4 + m * 8)
     del values
     # Sorted chunks (Chunk::individually_sorted_by; hyriseBenchmarkTPCH --clustering sorts lineitem by l_shipdate, tpch_benchmark.cpp:61-64):
     # the reference's SortedSegmentSearch, here prepare_jobs' binary searches -- the kernel writes the positions and reads no row.
@@ -611,8 +625,8 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
     packed_host = storage.make_column(days, None, abi.ENC_DICTIONARY)
     packed_host = storage.HostColumn([storage.bit_pack_segment(segment) for segment in packed_host.segments], packed_host.data_type)
     packed_bits = int(packed_host.segments[0].bits)
-    packed = DeviceColumn(packed_host)
-    out["bit_packed_value_ids_lt_1995"] = dict(measure(lambda: step_fn(pred, packed), lambda m: rows * packed_bits // 8 + m * 8), bits_per_value_id=packed_bits,
+    packed = Rotating(packed_host)
+    out["bit_packed_value_ids_lt_1995"] = dict(measure(lambda: packed.scan(pred), lambda m: rows * packed_bits // 8 + m * 8), bits_per_value_id=packed_bits,
                                                note="the generic instantiation unpacks the value ids in registers; bytes counted: bits / 8 per row + 8 per match")
     del packed, packed_host
     clustered_days = np.sort(days)
@@ -626,9 +640,9 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
     # per chunk on the host (lower / upper bound in 916 string dictionaries: reported beside the scan as host_literal_resolution_ms)
     from hyrise_amd.operators import string_predicate
     strings_host, dictionaries = tpch.string_date_column(column.host)
-    strings = DeviceColumn(strings_host)
+    strings = Rotating(strings_host)
     string_pred = string_predicate(abi.PRED_LESS_THAN, dictionaries, "1995-01-01")
-    out["string_dictionary_twin_lt_1995"] = measure(lambda: step_fn(string_pred, strings), lambda m: rows * width + m * 8)
+    out["string_dictionary_twin_lt_1995"] = measure(lambda: strings.scan(string_pred), lambda m: rows * width + m * 8)
     t0 = time.perf_counter()
     string_predicate(abi.PRED_LESS_THAN, dictionaries, "1995-01-01")
     out["string_dictionary_twin_lt_1995"]["host_literal_resolution_ms"] = (time.perf_counter() - t0) * 1e3
@@ -636,14 +650,14 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
     # the other streaming instantiations: u8 value ids (l_returnflag = 'R': a dictionary of three strings, scanned as value ids) and
     # FrameOfReference offsets (l_orderkey < literal: u16 offsets + one minimum per 2048-row block)
     rng = np.random.default_rng(44)
-    flags = DeviceColumn(storage.make_column(rng.integers(0, 3, rows).astype(np.int32), None, abi.ENC_DICTIONARY))
+    flags = Rotating(storage.make_column(rng.integers(0, 3, rows).astype(np.int32), None, abi.ENC_DICTIONARY))
     pred = make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, 2)
-    out["u8_value_ids_returnflag_eq"] = measure(lambda: step_fn(pred, flags), lambda m: rows * 1 + m * 8)
+    out["u8_value_ids_returnflag_eq"] = measure(lambda: flags.scan(pred), lambda m: rows * 1 + m * 8)
     del flags
     order_keys = np.sort(rng.integers(1, 60_000_000, rows).astype(np.int32))
-    keys = DeviceColumn(storage.make_column(order_keys, None, abi.ENC_FRAME_OF_REFERENCE))
+    keys = Rotating(storage.make_column(order_keys, None, abi.ENC_FRAME_OF_REFERENCE))
     pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 20_000_000)
-    out["frame_of_reference_orderkey_lt"] = dict(measure(lambda: step_fn(pred, keys), lambda m: rows * keys.host.segments[0].width + m * 8), offset_width=int(keys.host.segments[0].width))
+    out["frame_of_reference_orderkey_lt"] = dict(measure(lambda: keys.scan(pred), lambda m: rows * keys.host.segments[0].width + m * 8), offset_width=int(keys.host.segments[0].width))
     del keys, order_keys
     # ColumnVsColumn (Q4 / Q12): l_commitdate < l_receiptdate, both dictionary-encoded with u16 value ids
     rng = np.random.default_rng(43)

@@ -1,3 +1,2 @@
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_join_gpu.py -m gpu -q -x -k "primary_key" > gpurun_out/gputest_small.log 2>&1; tail -3 gpurun_out/gputest_small.log
-timeout 600 python tools/ssb_bench.py --sf 30 2>&1 | grep -v amdgpu.ids | tail -2
+timeout 600 python tools/scan_ab.py 40 3 2>&1 | grep -v amdgpu.ids > gpurun_out/scan_ab.txt; grep -v "u16 value ids" gpurun_out/scan_ab.txt
