@@ -629,9 +629,11 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     const hy_segment& s = column->host_segments[c];
     const bool kind_ok = s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE ||
                          (s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT);
-    if (!kind_ok || (dev[c].flags & SEG_UNALIGNED) || compressed(s)) streamable = false;
-    else if (stream_width == 0) stream_width = s.width;
-    else if (stream_width != s.width) streamable = false;
+    // (width class 16: a BitPackingVector of at most 16 bits per element -- the streaming kernel unpacks eight elements from 20 bytes)
+    const uint32_t width_class = bit_packed(s) ? (s.bits <= 16 ? 16u : 0u) : s.width;
+    if (!kind_ok || (dev[c].flags & SEG_UNALIGNED) || s.encoding == HY_ENC_RUN_LENGTH || width_class == 0) streamable = false;
+    else if (stream_width == 0) stream_width = width_class;
+    else if (stream_width != width_class) streamable = false;
   }
   column->stream_width = streamable ? stream_width : 0;
   column->rows = column->row_base[n_chunks];

@@ -820,6 +820,9 @@ struct RawGroup;   // 8 rows of W-byte elements as loaded from HBM
 template <> struct RawGroup<1> { u32x2 v; };
 template <> struct RawGroup<2> { u32x4 v; };
 template <> struct RawGroup<4> { u32x4 v0, v1; };
+// W = 16: a BitPackingVector of at most 16 bits per element -- the group's b bytes start at byte (row0 / 8) * b of the word stream: the 20
+// bytes from the 4-byte boundary below it hold them all
+template <> struct RawGroup<16> { u32x4 v; uint32_t tail; uint32_t shift; };
 
 // Segment buffers are always global memory: say so, or the compiler emits flat loads (which also tick lgkmcnt).
 #define HY_GLOBAL __attribute__((address_space(1)))
@@ -841,6 +844,30 @@ __device__ __forceinline__ RawGroup<W> load_group(const void* data, uint32_t row
     g.v1 = *(const HY_GLOBAL u32x4*)(base + 16);
   }
   return g;
+}
+
+__device__ __forceinline__ RawGroup<16> load_packed_group(const void* data, uint32_t row0, uint32_t bits) {
+  RawGroup<16> g;
+  const uint32_t byte_offset = (row0 >> 3) * bits;   // (eight rows are `bits` whole bytes)
+  const HY_GLOBAL uint8_t* base = as_global<uint8_t>(data) + (byte_offset & ~3u);
+  g.v = *(const HY_GLOBAL u32x4*)(base);
+  g.tail = *(const HY_GLOBAL uint32_t*)(base + 16);
+  g.shift = (byte_offset & 3u) * 8;
+  return g;
+}
+// Eight elements of `bits` bits each (1 .. 16, the same for every lane): the window is shifted down to the group's first bit, then
+// element j sits at bit j * bits -- a position every lane shares, so the word selects are scalar (bitpacking_decompressor.hpp:35-37).
+__device__ __forceinline__ void unpack_packed_group(const RawGroup<16>& g, uint32_t bits, uint32_t (&x)[8]) {
+  const uint32_t a0 = __builtin_amdgcn_alignbit(g.v.y, g.v.x, g.shift), a1 = __builtin_amdgcn_alignbit(g.v.z, g.v.y, g.shift);
+  const uint32_t a2 = __builtin_amdgcn_alignbit(g.v.w, g.v.z, g.shift), a3 = __builtin_amdgcn_alignbit(g.tail, g.v.w, g.shift);
+  const uint32_t mask = (1u << bits) - 1u;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    const uint32_t position = j * bits, word = position >> 5, shift = position & 31;
+    const uint32_t low = word == 0 ? a0 : word == 1 ? a1 : word == 2 ? a2 : a3;
+    const uint32_t high = word == 0 ? a1 : word == 1 ? a2 : word == 2 ? a3 : 0u;
+    x[j] = __builtin_amdgcn_alignbit(high, low, shift) & mask;
+  }
 }
 
 template <int W>
@@ -1022,11 +1049,13 @@ struct SliceLoad {
   RawGroup<W> raw[4];
   uint32_t null_byte[4];
   uint32_t bias;          // FrameOfReference: minimum of the wave's 2048-row block (a wave's rows never straddle blocks)
+  uint32_t bits;          // W = 16: bits per element of the segment's BitPackingVector
 };
 
 template <int W>
 __device__ __forceinline__ void issue_loads(SliceLoad<W>& ld, const DevSegment& seg, const ScanJob& job, const Slice& slice, uint32_t wave, uint32_t lane) {
   ld.bias = 0;
+  ld.bits = seg_bits(seg);
 #pragma unroll
   for (uint32_t k = 0; k < 4; ++k) ld.null_byte[k] = 0;
   if (job.mode != JOB_SCAN || (job.flags & JF_NEVER) || slice.row_count == 0) return;
@@ -1037,7 +1066,8 @@ __device__ __forceinline__ void issue_loads(SliceLoad<W>& ld, const DevSegment& 
     uint32_t r0 = wave * 2048 + k * 512 + lane * 8;
     if (slice.row_count != SLICE_ROWS) r0 = r0 < last_group ? r0 : last_group;   // groups past the end re-read the last one
     const uint32_t row = slice.row_begin + r0;
-    ld.raw[k] = load_group<W>(seg.data, row);
+    if constexpr (W == 16) ld.raw[k] = load_packed_group(seg.data, row, seg_bits(seg));
+    else ld.raw[k] = load_group<W>(seg.data, row);
     if (has_bitmap) ld.null_byte[k] = as_global<uint8_t>(seg.nulls)[row >> 3];
   }
   if (seg.encoding == HY_ENC_FRAME_OF_REFERENCE) {
@@ -1114,13 +1144,14 @@ __device__ __forceinline__ uint32_t evaluate_loaded(const SliceLoad<W>& ld, cons
   const bool is_dict = seg.encoding == HY_ENC_DICTIONARY;
   uint32_t inside;   // rows whose value lies in [lo, lo + span]
   uint32_t not_null = ~null_bits;
-  if constexpr (W == 4) {
+  if constexpr (W == 4 || W == 16) {
     const uint32_t lo = static_cast<uint32_t>(job.lo) - ld.bias, span = static_cast<uint32_t>(job.span);
     inside = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
       uint32_t x[8];
-      unpack_group<W>(ld.raw[k], x);
+      if constexpr (W == 16) unpack_packed_group(ld.raw[k], ld.bits, x);
+      else unpack_group<W>(ld.raw[k], x);
       inside |= range_bits8(x, lo, span) << (8 * k);
       if (is_dict && invert) {
 #pragma unroll
@@ -1663,7 +1694,8 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   ScanJob* d_jobs = carve<ScanJob>(sc, n_data_chunks + 1);
   uint32_t* d_overflow = sc.ticket + 16;   // persistent word, zero unless a scan overflowed (an internal error)
   ScanKernel kernel = !right && column->has_compressed ? scan_slices<8> : scan_slices<0>;
-  if (!right && column->stream_width == 1) kernel = column->has_sorted ? scan_slices<1, true> : scan_slices<1>;
+  if (!right && column->stream_width == 16) kernel = column->has_sorted ? scan_slices<16, true> : scan_slices<16>;   // bit-packed vectors of at most 16 bits
+  else if (!right && column->stream_width == 1) kernel = column->has_sorted ? scan_slices<1, true> : scan_slices<1>;
   else if (!right && column->stream_width == 2) kernel = column->has_sorted ? scan_slices<2, true> : scan_slices<2>;
   else if (!right && column->stream_width == 4) kernel = column->has_sorted ? scan_slices<4, true> : scan_slices<4>;
   if (like) kernel = column->has_compressed ? scan_slices<8> : scan_slices<0>;   // value-id sets are tested by the generic instantiations

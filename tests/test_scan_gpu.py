@@ -538,3 +538,37 @@ def test_compressed_segments_through_every_operator(device):
         reference = DeviceColumn(reference_host, refs={id(host): dev})
         p = make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_INT, 50, 250, nullable=True)
         assert_scan_equal(table_scan(reference, p), oracle_scan(reference_host, p), f"{kind}: reference segments")
+
+
+@pytest.mark.parametrize("bits", [1, 2, 3, 5, 7, 8, 9, 11, 12, 13, 15, 16])
+def test_bit_packed_vectors_stream(device, bits):
+    """A column whose chunks all hold BitPackingVectors of at most 16 bits takes the streaming instantiation scan_slices<16>: eight elements
+    are unpacked from the 20 bytes around the group's `bits` bytes (any byte alignment), dictionary value ids with NULLs and FrameOfReference
+    offsets, ragged chunks, every condition -- PosLists equal to the oracle's over the unpacked column."""
+    rng = np.random.default_rng(1000 + bits)
+    chunk = 20_000 if bits <= 13 else 65_535                # (a chunk holds all 2^bits - 1 values)
+    n = 3 * chunk + chunk // 2 + 3
+    distinct = max(1, (1 << bits) - 1)                      # the NULL value id is `distinct`: it needs exactly `bits` bits
+    values = (rng.integers(0, distinct, n) * 3 - 50).astype(np.int32)
+    values[:distinct] = np.arange(distinct, dtype=np.int32) * 3 - 50   # (every value occurs in the first chunk at least)
+    nulls = rng.random(n) < 0.03
+    nulls[:chunk] |= np.arange(chunk) == 17
+    for kind, with_nulls in (("BitPackedDictionary", True), ("BitPackedDictionary", False), ("BitPackedFrameOfReference", True)):
+        mask = nulls if with_nulls else None
+        if kind == "BitPackedFrameOfReference":              # offsets below 2^bits inside every 2048-row block
+            bases = (rng.integers(-1000, 1000, n // chunk + 1) * 7)[np.arange(n) // chunk]   # one base per chunk: every 2048-row block of a chunk has offsets below 2^bits
+            column_values = (bases + rng.integers(0, 1 << bits, n)).astype(np.int32)
+        else:
+            column_values = values
+        segments = [encode_chunk(column_values[b:b + chunk], None if mask is None else mask[b:b + chunk], kind, with_nulls) for b in range(0, n, chunk)]
+        assert all(s.width == 0 and s.bits <= 16 for s in segments)
+        if kind == "BitPackedDictionary" and with_nulls:
+            assert segments[0].bits == bits
+        host = storage.HostColumn(segments, abi.TYPE_INT)
+        dev = DeviceColumn(host)
+        low, high = int(np.percentile(column_values, 30)), int(np.percentile(column_values, 70))
+        for condition in CONDITIONS:
+            for value, value2 in ((low, high), (int(column_values[5]), int(column_values[5])), (-10_000, 10_000)):
+                for flags in (0, abi.SCAN_MATERIALIZE_ALL_MATCH):
+                    p = make_predicate(condition, abi.TYPE_INT, value, value2, nullable=with_nulls)
+                    check(host, p, dev, flags, context=f"{kind} {bits} bits nulls {with_nulls} cond {condition} lit {value},{value2} flags {flags}")

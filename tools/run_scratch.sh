@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-timeout 600 python tools/scan_ab.py 40 3 2>&1 | grep -v amdgpu.ids > gpurun_out/scan_ab.txt; grep -v "u16 value ids" gpurun_out/scan_ab.txt
+timeout 1200 python -m pytest tests/test_scan_gpu.py -m gpu -q -x -k "bit_packed" > gpurun_out/gputest_small.log 2>&1; tail -5 gpurun_out/gputest_small.log
