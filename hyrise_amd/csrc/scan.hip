@@ -1336,14 +1336,24 @@ __global__ __launch_bounds__(256) void scan_slices(const DevSegment* __restrict_
     uint32_t emitted = before;   // matches of this chunk before the current slice
     uint16_t* my_rows = s_rows + wave * (2048 + ROW_PAD);
     uint8_t* my_bytes = s_bytes + wave * 256;
-    for (uint32_t i = 0; i < part.n_slices; ++i) {
+    uint32_t n_slices = part.n_slices;
+    if constexpr (!GENERIC) {
+      // A chunk with an early-out (no row can match, or every row matches and all-match chunks own no RowIDs) has nothing to evaluate
+      // and nothing to emit: its eight rounds of transposition, scan and barrier were 25 us of a scan whose chunks all take one
+      // (IS NULL on a column without NULLs, a clustered table).  Only the next part's first loads are still requested here.
+      if (mode == JOB_NONE || (job.flags & JF_NEVER) || (mode == JOB_ALL && !a.materialize_all)) {
+        if (next_part_id < a.n_parts) issue_loads<W>(next, next_seg, next_job, part_slice(next_part, next_seg, 0), wave, lane);
+        n_slices = 0;
+      }
+    }
+    for (uint32_t i = 0; i < n_slices; ++i) {
       const Slice slice = part_slice(part, seg, i);
       uint32_t mask;
       if constexpr (GENERIC) {
         mask = evaluate_slice<W == 8>(a, slice, seg, wave, lane);
       } else {
         const SliceLoad<W> current = next;
-        if (i + 1 < part.n_slices) issue_loads<W>(next, seg, job, part_slice(part, seg, i + 1), wave, lane);
+        if (i + 1 < n_slices) issue_loads<W>(next, seg, job, part_slice(part, seg, i + 1), wave, lane);
         else if (next_part_id < a.n_parts) issue_loads<W>(next, next_seg, next_job, part_slice(next_part, next_seg, 0), wave, lane);
         mask = evaluate_loaded<W, RANGES>(current, seg, job, slice, a.materialize_all, wave, lane);
       }
