@@ -291,14 +291,18 @@ def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None):
     """One hy_join_hash with device-memory PosLists; returns (callable, result struct, buffers)."""
     from hyrise_amd import abi
     mode = abi.JOIN_INNER if mode is None else mode
-    left_pos = torch.empty((pairs_capacity, 2), dtype=torch.int32, device=dev)
-    right_pos = torch.empty((pairs_capacity, 2), dtype=torch.int32, device=dev) if mode == abi.JOIN_INNER else left_pos   # (Semi: one PosList)
+    from hyrise_amd.operators import pair_lists
+    # (the adapter's result-buffer policy: both PosLists from one allocation, 1.25 MiB apart modulo 2 MiB -- two streams written at the same
+    #  index then use different memory channels, INTEGRATION.md section 3; Semi joins write one PosList)
+    left_pos, right_pos, arena = pair_lists(torch, dev, pairs_capacity)
+    if mode != abi.JOIN_INNER:
+        right_pos = left_pos
     slice_offsets = torch.zeros(8192, dtype=torch.int64, device=dev)
     r = abi.JoinResult()
     r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
     r.left_pos, r.right_pos, r.capacity = left_pos.data_ptr(), right_pos.data_ptr(), pairs_capacity
     r.slice_offsets, r.slice_capacity = slice_offsets.data_ptr(), 8000
-    keep = (left_pos, right_pos, slice_offsets)
+    keep = (left_pos, right_pos, slice_offsets, arena)
 
     def run():
         r.radix_bits = 0xFFFFFFFF

@@ -386,8 +386,8 @@ class HipExecutor:
         slice_capacity = max(left.rows, right.rows) // 131070 + max(left.n_chunks, right.n_chunks) + 600
         slice_offsets = torch.zeros(slice_capacity + 2, dtype=torch.int64, device=self.device)
         while True:
-            left_pos = torch.empty((capacity, 2), dtype=torch.int32, device=self.device)
-            right_pos = torch.empty((capacity, 2), dtype=torch.int32, device=self.device)
+            from .operators import pair_lists
+            left_pos, right_pos, _arena = pair_lists(torch, self.device, capacity)   # (one allocation, the lists 1.25 MiB apart modulo 2 MiB)
             r = abi.JoinResult()
             r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
             r.left_pos, r.right_pos, r.capacity = left_pos.data_ptr(), right_pos.data_ptr(), capacity

@@ -379,6 +379,25 @@ def expression(tree):
     return e
 
 
+PAIR_LIST_PERIOD = 2 << 20          # the two output PosLists of a join are written at the same pair index at the same time: when their
+PAIR_LIST_OFFSET = 5 << 18          # addresses are congruent modulo 2 MiB the two streams meet in the same memory channels -- pk_emit takes
+                                    # 306 - 315 us; 1.25 MiB apart (mod 2 MiB) 274 - 283 us (tools/join_placement.py, profiles/r03_join_placement.txt)
+
+
+def pair_lists(torch, device, capacity):
+    """Device buffers for a join's two output PosLists ([capacity, 2] int32 each), carved out of ONE allocation so that the second starts
+    1.25 MiB past a 2 MiB boundary when the first starts on one -- the result-buffer policy of the adapter.
+    -> (left, right, the allocation: keep it alive)"""
+    list_bytes = 8 * max(1, int(capacity))
+    arena = torch.empty(2 * list_bytes + 3 * PAIR_LIST_PERIOD, dtype=torch.uint8, device=device)
+    first = -arena.data_ptr() % PAIR_LIST_PERIOD
+    second = (first + list_bytes + PAIR_LIST_PERIOD - 1) // PAIR_LIST_PERIOD * PAIR_LIST_PERIOD + PAIR_LIST_OFFSET
+    rows = max(1, int(capacity))
+    left = arena[first:first + list_bytes].view(torch.int32).view(rows, 2)
+    right = arena[second:second + list_bytes].view(torch.int32).view(rows, 2)
+    return left, right, arena
+
+
 def validate_filter(mvcc_column, our_tid, snapshot_commit_id, can_use_chunk_shortcut=True):
     """Validate as a filter of hy_scan_project_aggregate: (the table's MvccData as a DeviceColumn, its predicate)."""
     predicate = abi.Predicate()

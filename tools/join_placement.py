@@ -29,7 +29,26 @@ def main():
     base = (arena.data_ptr() + (2 << 20) - 1) // (2 << 20) * (2 << 20)   # 2 MiB aligned
     slice_offsets = torch.zeros(8192, dtype=torch.int64, device=dev)
     print(f"arena at {arena.data_ptr():#x}, first list at {base:#x}, lists of {list_bytes} bytes")
-    for skew in (0, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 1 << 18, 1 << 20, (1 << 20) + 4096, 3 << 20, (32 << 20) + 2048):
+    skews = [k << 18 for k in range(0, 17)] + [5 << 20, 7 << 20, 9 << 20, 17 << 20, 33 << 20, 63 << 20]
+    if len(sys.argv) > 2 and sys.argv[2] == "absolute":   # both lists moved together, 1.25 MiB apart (mod 2 MiB): does the absolute position matter?
+        origin = base
+        for shift in [k << 18 for k in range(0, 33, 2)] + [(16 << 20) + (k << 20) for k in (0, 1, 3, 8, 16, 31)]:
+            first = origin + shift
+            second = (first + list_bytes + (2 << 20) - 1) // (2 << 20) * (2 << 20) + (shift & ((2 << 20) - 1)) + (5 << 18)
+            r = abi.JoinResult()
+            r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
+            r.left_pos, r.right_pos, r.capacity = first, second, n
+            r.slice_offsets, r.slice_capacity = slice_offsets.data_ptr(), 8000
+
+            def run_shifted():
+                r.radix_bits = 0xFFFFFFFF
+                abi.check(lib.hy_join_hash(orders.handle, lineitem.handle, abi.JOIN_INNER, C.byref(r)))
+            dt, kinds = bench.timed_kernel(lib, torch, run_shifted, steps, all_kinds=True)
+            print(f"both lists + {shift:9d} B: {dt * 1e3:7.3f} ms/join  " + "  ".join(f"{k} {v[0] * 1e3:6.1f} us" for k, v in kinds.items() if v[1]), flush=True)
+        return
+    if len(sys.argv) > 2:
+        base += int(sys.argv[2]) << 18   # (the first list itself off the 2 MiB grid, in units of 256 KiB)
+    for skew in skews:
         second = (base + list_bytes + (2 << 20) - 1) // (2 << 20) * (2 << 20) + skew   # 2 MiB aligned + skew
         r = abi.JoinResult()
         r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
