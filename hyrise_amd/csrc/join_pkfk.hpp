@@ -37,8 +37,8 @@ constexpr uint32_t PK_WAVE_ROWS = PK_TILE / PK_WAVES;    // 1024 consecutive row
 constexpr uint32_t PK_COUNT_WAVE_ROWS = 2048;            // pk_count: one FrameOfReference block per wave
 constexpr uint32_t PK_COUNT_THREADS = 64 * (PK_TILE / PK_COUNT_WAVE_ROWS);   // 256
 constexpr uint32_t PK_COUNT_BATCHES = PK_COUNT_WAVE_ROWS / 512;              // 4 batches of 512 rows, eight consecutive rows per lane
-constexpr uint32_t PK_SCAN_THREADS = 256;
-constexpr uint32_t PK_SCAN_CHUNK = 4096;                 // tiles per pass of pk_scan's loop
+constexpr uint32_t PK_SCAN_THREADS = 512;
+constexpr uint32_t PK_SCAN_CHUNK = 8192;                 // tiles per pass of pk_scan's loop (config 3's 7 323 tiles: one pass)
 static_assert(SLICE_ROWS % PK_TILE == 0 && HY_FOR_BLOCK_SIZE % PK_WAVE_ROWS == 0 && HY_FOR_BLOCK_SIZE == PK_COUNT_WAVE_ROWS && PK_TILE % PK_COUNT_WAVE_ROWS == 0,
               "a wave's rows must lie in one FrameOfReference block");
 static_assert(PK_TILE <= (1u << 13), "a staged pair keeps its row in 13 bits");

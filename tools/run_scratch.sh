@@ -1,2 +1,3 @@
 mkdir -p gpurun_out
-timeout 600 python tools/join_placement.py 8 absolute 2>&1 | grep -v amdgpu.ids > gpurun_out/join_placement_c.txt; cut -c1-100 gpurun_out/join_placement_c.txt
+timeout 900 python -m pytest tests/test_join_gpu.py -m gpu -q -x -k "primary_key or pk or hint" 2>&1 | tail -3
+timeout 600 python tools/join_bench.py 10 2>&1 | grep -v amdgpu.ids | head -3
