@@ -2681,6 +2681,10 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     if (lean) {
       if (const char* debug = getenv("HY_AGG_SMALL_DEBUG")) small.debug = static_cast<uint32_t>(atoi(debug));   // timing experiments only
       small.n_columns = static_cast<uint32_t>(inputs.size());
+      small.joint = small.n_narrow == 2 && !getenv("HY_AGG_NO_JOINT_HISTOGRAM") ? 1u : 0u;
+      for (uint32_t k = 0; k < shape->n_chunks && small.joint; ++k) {
+        if ((uint64_t{inputs[0]->host_segments[k].aux_size} + 1) * (uint64_t{inputs[1]->host_segments[k].aux_size} + 1) > SD_JOINT_CELLS) small.joint = 0;
+      }
       for (uint32_t c = 0; c < small.n_columns; ++c) small.column[c] = inputs[c]->d_segments;
       for (uint32_t d = 0; d < n_device; ++d) {
         const hy_column* column = specs[spec_of_device[d]].column;

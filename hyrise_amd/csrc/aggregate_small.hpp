@@ -26,6 +26,7 @@ constexpr uint32_t SD_DENSE = 4;        // groups of a chunk with register / his
 constexpr uint32_t SD_COLUMNS = 4;      // distinct aggregate input columns
 constexpr uint32_t SD_NARROW = 2;       // ... of which with 1-byte value ids, at most
 constexpr uint32_t SD_WIDE = 1;         // ... and with 2-byte value ids
+constexpr uint32_t SD_JOINT_CELLS = 1024; // (value id, value id) pairs of two 1-byte columns counted in one histogram (the two single histograms' LDS)
 constexpr uint32_t SD_ROWS = 16;        // consecutive rows of a lane per step
 constexpr uint32_t SD_KEYS = 2;         // GROUP BY columns, at most (1-byte value ids: their dictionaries have fewer than sixteen entries)
 typedef __attribute__((address_space(1))) float global_f32;    // (pointers read from a segment descriptor are generic to the compiler: flat loads, which also count on lgkmcnt)
@@ -35,6 +36,7 @@ struct SmallDomainPlan {
   uint32_t n_columns, n_narrow;                   // distinct input columns; the first n_narrow have 1-byte value ids, the others 2-byte ones
   const DevSegment* column[SD_COLUMNS];
   uint32_t column_of_aggregate[MAX_AGGREGATES];   // 0xFFFFFFFF: COUNT(*)
+  uint32_t joint;                                 // two 1-byte columns whose (dictionary size + 1)s multiply to at most SD_JOINT_CELLS in every chunk: ONE histogram over the pair
   uint32_t debug;                                 // HY_AGG_SMALL_DEBUG (timing experiments, wrong results): 1 no histograms, 2 no 2-byte columns, 8 no dense lookup
 };
 
@@ -303,6 +305,19 @@ __global__ __launch_bounds__(SD_THREADS) void aggregate_small_domain(AggArgs a, 
       // left out when the counts are weighted; rows of other groups and rows that do not exist count in a spare row.  Cells of one
       // value id are neighbours (a column with eleven values, l_discount, would otherwise meet in eleven of the LDS's banks) and even
       // and odd lanes have their own copy.
+      if (plan.joint && !(plan.debug & 1)) {
+        // Two 1-byte columns (l_quantity x l_discount: 51 x 12 pairs): the row counts ONCE, in the cell of its pair of value ids -- one LDS
+        // atomic instead of two; the pair counts are summed into each column's histogram when the chunk is done.
+        const u32x4 first_ids[2] = {current.narrow[0], u32x4{0, 0, 0, 0}}, second_ids[2] = {current.narrow[1], u32x4{0, 0, 0, 0}};
+        const uint32_t second_domain = column_size[1] + 1;
+#pragma unroll
+        for (uint32_t j = 0; j < SD_ROWS; ++j) {
+          const uint32_t d = static_cast<uint32_t>(dense >> (4 * j)) & 0xFu;
+          const uint32_t id0 = sd_id(first_ids, 1u, j), id1 = sd_id(second_ids, 1u, j);
+          const uint32_t cell = (id0 < column_size[0] ? id0 : column_size[0]) * second_domain + (id1 < column_size[1] ? id1 : column_size[1]);
+          atomicAdd(d < SD_DENSE ? &s_hist[cell * SD_DENSE + d] : &s_spare[cell & 63u], 1u);
+        }
+      } else {
 #pragma unroll
       for (uint32_t c = 0; c < SD_NARROW; ++c) {
         if (c >= plan.n_narrow || (plan.debug & 1)) continue;
@@ -314,6 +329,7 @@ __global__ __launch_bounds__(SD_THREADS) void aggregate_small_domain(AggArgs a, 
           const uint32_t id = sd_id(ids, 1u, j);
           atomicAdd(d < SD_DENSE ? &cells[id * SD_DENSE + d] : &s_spare[id & 63u], 1u);
         }
+      }
       }
       // the first 2-byte column: one 4-bit counter per (value id, dense group); NULL ids (the dictionary's size) are not counted
       if (n_wide && !(plan.debug & 2)) {
@@ -422,8 +438,14 @@ __global__ __launch_bounds__(SD_THREADS) void aggregate_small_domain(AggArgs a, 
 #pragma unroll
     for (uint32_t k = 0; k < SD_DENSE; ++k) {
       uint32_t count = 0;
+      if (plan.joint) {   // the column's histogram = the pair histogram summed over the other column's value ids (its NULL id included)
+        const uint32_t second_domain = column_size[1] + 1;
+        if (c == 0) { for (uint32_t other = 0; other < second_domain && tid < column_size[0]; ++other) count += s_hist[(tid * second_domain + other) * SD_DENSE + k]; }
+        else { for (uint32_t other = 0; other <= column_size[0] && tid < column_size[1]; ++other) count += s_hist[(other * second_domain + tid) * SD_DENSE + k]; }
+      } else {
 #pragma unroll
-      for (uint32_t copy_index = 0; copy_index < SD_COPIES; ++copy_index) count += s_hist[((copy_index * SD_NARROW + c) * 256 + tid) * SD_DENSE + k];
+        for (uint32_t copy_index = 0; copy_index < SD_COPIES; ++copy_index) count += s_hist[((copy_index * SD_NARROW + c) * 256 + tid) * SD_DENSE + k];
+      }
       if (tid >= column_size[c]) count = 0;
       const uint64_t sum = wave_reduce_to_lane63(static_cast<uint64_t>(__double_as_longlong(static_cast<double>(count) * s_dict[c][tid])), 0ull, [](uint64_t x, uint64_t y) {
         return static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(x)) + __longlong_as_double(static_cast<long long>(y))));
