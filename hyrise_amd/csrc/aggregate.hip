@@ -2073,6 +2073,8 @@ __global__ __launch_bounds__(256, FUSED_WAVES) void fused_rows(AggArgs a, const 
   }
 }
 
+#include "fused_small.hpp"
+
 // The groups of the table, densely.  The first `staged_capacity` of them also go straight into pinned host memory (same
 // five arrays, `staged_capacity` rows each, behind a 64-byte header): few groups -- the usual case -- cost no copy at all.
 struct StagedGroups {
@@ -2211,7 +2213,8 @@ static uint32_t fused_lds_slots(uint32_t n_groupby) { return n_groupby ? FUSED_L
 
 // (`fused`: the device copy of a FusedPlan -- fused_rows takes the place of aggregate_rows; its accumulators' inputs are expressions, which
 //  the partitioned path cannot carry.)
-static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out, const FusedPlan* fused = nullptr, const SmallDomainPlan* small = nullptr) {
+static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& out, const FusedPlan* fused = nullptr, const SmallDomainPlan* small = nullptr,
+                               const FusedSmallPlan* fused_small = nullptr) {
   hipStream_t stream = current_stream();
   const uint32_t words = a.n_groupby + 1;
   const uint32_t n_aggregates = a.n_aggregates;
@@ -2279,7 +2282,17 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     }
     g_agg_path = partition_bits;
     g_agg_small = small && partition_bits == 0 && !fused ? 1u : 0u;
-    if (shape->n_slices && shape->rows && fused) {   // one workgroup per chunk
+    g_agg_small = fused && fused_small ? 2u : g_agg_small;
+    if (shape->n_slices && shape->rows && fused && fused_small) {   // the Q1 shape: one workgroup of 1024 threads per chunk (fused_small.hpp)
+      profile_begin(stream, HY_KERNEL_AGGREGATE);
+      static std::atomic<bool> raised{false};
+      if (!raised.load(std::memory_order_acquire)) {
+        HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_small_domain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fs_lds_bytes())));
+        raised.store(true, std::memory_order_release);
+      }
+      hipLaunchKernelGGL(fused_small_domain, dim3(shape->n_chunks), dim3(FS_THREADS), fs_lds_bytes(), stream, a, fused, *fused_small, shape->n_chunks);
+      profile_end(stream);
+    } else if (shape->n_slices && shape->rows && fused) {   // one workgroup per chunk
       const size_t fused_lds = size_t{fused_lds_slots(a.n_groupby)} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 64 + 2 * size_t{SLICE_ROWS} + sizeof(ColumnView) * FUSED_VIEWS +
                                sizeof(ScanJob) * HY_MAX_FILTERS + sizeof(FusedInput) * n_aggregates + size_t{FUSED_DENSE} * FUSED_CELLS * (8 * (n_aggregates + 2) + 4 * n_aggregates);
       profile_begin(stream, HY_KERNEL_AGGREGATE);
@@ -2380,6 +2393,10 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     std::memcpy(host_flags, pinned_host, 28);
     if (host_flags[FLAG_SMALL_REFUSED] && small) {   // (a value met sixteen times in one group of one chunk)
       small = nullptr;
+      continue;
+    }
+    if (host_flags[FLAG_SMALL_REFUSED] && fused_small) {   // (a fifth group in a chunk, a NULL input: fused_rows)
+      fused_small = nullptr;
       continue;
     }
     if (host_flags[FLAG_GIVE_UP]) {   // too many rows outside the LDS tables: partition (more finely)
@@ -2605,6 +2622,40 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   auto lap = [&](const char* what) {
     if (timing) std::fprintf(stderr, "[aggregate] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   };
+  auto dictionary_column = [&](const hy_column* column, uint32_t* width) {   // every chunk a dictionary segment with its values on the device, one id width, aligned
+    if (!column || column->is_reference || column->has_dictionary_without_values || column->n_chunks == 0) return false;
+    *width = column->host_segments[0].width;
+    if (*width != 1 && *width != 2) return false;
+    for (uint32_t k = 0; k < column->n_chunks; ++k) {
+      const hy_segment& seg = column->host_segments[k];
+      if (seg.encoding != HY_ENC_DICTIONARY || seg.width != *width || (!seg.aux && seg.aux_size) || reinterpret_cast<uintptr_t>(seg.data) % 16 != 0 || (*width == 1 && seg.aux_size > 255)) return false;
+    }
+    return true;
+  };
+  // every chunk a dictionary segment, one width of 1 or 2 bytes per value id, aligned (the dictionary's values may be anywhere: filters test ids)
+  auto value_id_column = [&](const hy_column* column, uint32_t* width) {
+    if (!column || column->is_reference || column->n_chunks == 0) return false;
+    *width = column->host_segments[0].width;
+    if (*width != 1 && *width != 2) return false;
+    for (uint32_t k = 0; k < column->n_chunks; ++k) {
+      const hy_segment& seg = column->host_segments[k];
+      if (seg.encoding != HY_ENC_DICTIONARY || seg.width != *width || reinterpret_cast<uintptr_t>(seg.data) % 16 != 0) return false;
+    }
+    return true;
+  };
+  auto few_codes = [&]() {   // the GROUP BY columns of the small-domain kernels: 1-byte value ids, at most SD_CODES combinations per chunk
+    if (n_groupby > SD_KEYS) return false;
+    for (uint32_t g = 0; g < n_groupby; ++g) {
+      uint32_t key_width = 0;
+      if (!dictionary_column(groupby[g], &key_width) || key_width != 1) return false;
+    }
+    for (uint32_t k = 0; k < shape->n_chunks; ++k) {
+      uint64_t product = 1;
+      for (uint32_t g = 0; g < n_groupby; ++g) product *= uint64_t{groupby[g]->host_segments[k].aux_size} + 1;
+      if (product > SD_CODES) return false;
+    }
+    return true;
+  };
   DeviceGroups main_groups;
   if (fused) {
     // the plan in device memory: per filter the chunk jobs (prepare_jobs, like hy_table_scan), per accumulator its input expression
@@ -2638,32 +2689,73 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     for (uint32_t d = 0; d < n_device; ++d) plan.inputs[d] = fused->inputs[spec_of_device[d]];
     HY_HIP(hipMemcpyAsync(base, &plan, sizeof(plan), hipMemcpyHostToDevice, stream));
     HY_HIP(hipStreamSynchronize(stream));   // (`plan` is a stack object)
-    HY_TRY(device_groups(a, shape, main_groups, reinterpret_cast<const FusedPlan*>(base)));
+    // The TPC-H Q1 shape -- a handful of groups, filters on value ids, float expressions over dictionary columns -- has a kernel of its
+    // own (fused_small.hpp); everything else, and whatever that kernel refuses at run time, takes fused_rows.
+    FusedSmallPlan small_plan;
+    std::memset(&small_plan, 0, sizeof(small_plan));
+    for (uint32_t c = 0; c < FS_COLUMNS; ++c) small_plan.column_of_slot[c] = 0xFFFFFFFFu;
+    bool lean = !getenv("HY_FUSED_NO_SMALL_DOMAIN") && shape->rows > 0 && fused->n_filters <= FS_FILTERS && fused->n_columns <= FS_COLUMNS && few_codes();
+    for (uint32_t k = 0; k < shape->n_chunks && lean; ++k) lean = shape->host_segments[k].size <= FS_SPAN;
+    for (uint32_t f = 0; f < fused->n_filters && lean; ++f) {
+      const uint32_t condition = fused->filters[f].predicate.condition;
+      lean = condition != HY_FILTER_VALIDATE && !(condition >= HY_PRED_IN && condition <= HY_PRED_NOT_LIKE_INSENSITIVE) && value_id_column(fused->filters[f].column, &small_plan.filter_width[f]);
+    }
+    uint32_t n_narrow = 0;
+    for (uint32_t c = 0; c < fused->n_columns && lean; ++c) {   // 1-byte value ids: slots 0 .. FS_NARROW - 1; 2-byte value ids: the last slot
+      uint32_t width = 0;
+      lean = fused->columns[c]->data_type == HY_TYPE_FLOAT && dictionary_column(fused->columns[c], &width);
+      if (!lean) break;
+      uint32_t slot = FS_NARROW;
+      if (width == 1) {
+        lean = n_narrow < FS_NARROW;
+        slot = n_narrow++;
+      } else {
+        lean = small_plan.column_of_slot[FS_NARROW] == 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < shape->n_chunks && lean; ++k) lean = reinterpret_cast<uintptr_t>(fused->columns[c]->host_segments[k].aux) % 16 == 0;   // (staged with 16-byte loads)
+      }
+      if (lean) { small_plan.column_of_slot[slot] = c; small_plan.slot_of_column[c] = slot; }
+    }
+    uint32_t n_literals = 0;
+    for (uint32_t d = 0; d < n_device && lean; ++d) {
+      const FusedInput& input = plan.inputs[d];
+      const uint32_t function = a.aggregates[d].function;
+      lean = function == HY_AGG_SUM || function == HY_AGG_AVG || function == HY_AGG_COUNT;
+      if (input.n_nodes == 0) continue;   // COUNT(*): behind the accumulators with an expression
+      lean = lean && d < FS_INPUTS && input.type == HY_TYPE_FLOAT;
+      for (uint32_t n = 0; n < input.n_nodes && lean; ++n) {
+        const FusedNode& node = input.nodes[n];
+        lean = node.type == HY_TYPE_FLOAT && (node.kind == HY_EXPR_COLUMN || node.kind == HY_EXPR_LITERAL || (node.kind == HY_EXPR_ARITHMETIC && node.op <= HY_ARITH_MUL));
+      }
+      small_plan.n_inputs = d + 1;
+      // the program: five bits per node, literals by their index in a table of FS_LITERALS
+      for (uint32_t n = 0; n < input.n_nodes && lean; ++n) {
+        const FusedNode& node = input.nodes[n];
+        uint64_t code = 0;
+        if (node.kind == HY_EXPR_COLUMN) {
+          lean = node.column < fused->n_columns;
+          code = FS_PUSH_COLUMN + small_plan.slot_of_column[lean ? node.column : 0];
+        } else if (node.kind == HY_EXPR_LITERAL) {
+          uint32_t index = 0;
+          while (index < n_literals && small_plan.literal[index] != static_cast<uint32_t>(node.literal)) ++index;
+          if (index == n_literals) {
+            lean = n_literals < FS_LITERALS;
+            if (lean) small_plan.literal[n_literals++] = static_cast<uint32_t>(node.literal);
+          }
+          code = FS_PUSH_LITERAL + index;
+        } else {
+          code = node.op == HY_ARITH_ADD ? FS_ADD : node.op == HY_ARITH_SUB ? FS_SUB : FS_MUL;
+        }
+        small_plan.program[d] |= code << (5 * n);
+      }
+      small_plan.n_nodes |= input.n_nodes << (4 * d);
+    }
+    HY_TRY(device_groups(a, shape, main_groups, reinterpret_cast<const FusedPlan*>(base), nullptr, lean ? &small_plan : nullptr));
   } else {
     // The TPC-H Q1 shape -- a handful of groups over dictionary columns, SUM / AVG / COUNT over dictionary-encoded floating-point
     // columns with 1- or 2-byte value ids -- has a kernel of its own (aggregate_small.hpp); everything else takes aggregate_rows.
     SmallDomainPlan small;
     std::memset(&small, 0, sizeof(small));
-    auto dictionary_column = [&](const hy_column* column, uint32_t* width) {   // every chunk a dictionary segment with its values on the device, one id width, aligned
-      if (!column || column->is_reference || column->has_dictionary_without_values || column->n_chunks == 0) return false;
-      *width = column->host_segments[0].width;
-      if (*width != 1 && *width != 2) return false;
-      for (uint32_t k = 0; k < column->n_chunks; ++k) {
-        const hy_segment& seg = column->host_segments[k];
-        if (seg.encoding != HY_ENC_DICTIONARY || seg.width != *width || (!seg.aux && seg.aux_size) || reinterpret_cast<uintptr_t>(seg.data) % 16 != 0 || (*width == 1 && seg.aux_size > 255)) return false;
-      }
-      return true;
-    };
-    bool lean = !getenv("HY_AGG_NO_SMALL_DOMAIN") && shape->rows > 0 && n_groupby <= SD_KEYS;
-    for (uint32_t g = 0; g < n_groupby && lean; ++g) {
-      uint32_t key_width = 0;
-      lean = dictionary_column(groupby[g], &key_width) && key_width == 1;
-    }
-    for (uint32_t k = 0; k < shape->n_chunks && lean; ++k) {
-      uint64_t product = 1;
-      for (uint32_t g = 0; g < n_groupby; ++g) product *= uint64_t{groupby[g]->host_segments[k].aux_size} + 1;
-      lean = product <= SD_CODES;
-    }
+    bool lean = !getenv("HY_AGG_NO_SMALL_DOMAIN") && shape->rows > 0 && few_codes();
     std::vector<const hy_column*> inputs;   // distinct input columns, 1-byte ids first
     for (int pass = 0; pass < 2 && lean; ++pass) {
       for (uint32_t d = 0; d < n_device && lean; ++d) {
