@@ -2727,8 +2727,14 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
         lean = node.type == HY_TYPE_FLOAT && (node.kind == HY_EXPR_COLUMN || node.kind == HY_EXPR_LITERAL || (node.kind == HY_EXPR_ARITHMETIC && node.op <= HY_ARITH_MUL));
       }
       small_plan.n_inputs = d + 1;
-      // the program: five bits per node, literals by their index in a table of FS_LITERALS
-      for (uint32_t n = 0; n < input.n_nodes && lean; ++n) {
+      // the program: five bits per node, literals by their index in a table of FS_LITERALS.  An input that begins with the whole of the
+      // input before it (Q1: l_extendedprice, then l_extendedprice * (1 - l_discount), then that * (1 + l_tax)) continues on its stack.
+      uint32_t skipped = 0;
+      if (d > 0 && plan.inputs[d - 1].n_nodes > 0 && plan.inputs[d - 1].n_nodes < input.n_nodes &&
+          std::memcmp(plan.inputs[d - 1].nodes, input.nodes, sizeof(FusedNode) * plan.inputs[d - 1].n_nodes) == 0 && !getenv("HY_FUSED_NO_SHARED_PREFIX")) {
+        skipped = plan.inputs[d - 1].n_nodes;
+      }
+      for (uint32_t n = skipped; n < input.n_nodes && lean; ++n) {
         const FusedNode& node = input.nodes[n];
         uint64_t code = 0;
         if (node.kind == HY_EXPR_COLUMN) {
@@ -2745,9 +2751,9 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
         } else {
           code = node.op == HY_ARITH_ADD ? FS_ADD : node.op == HY_ARITH_SUB ? FS_SUB : FS_MUL;
         }
-        small_plan.program[d] |= code << (5 * n);
+        small_plan.program[d] |= code << (5 * (n - skipped));
       }
-      small_plan.n_nodes |= input.n_nodes << (4 * d);
+      small_plan.n_nodes |= (input.n_nodes - skipped) << (4 * d);
     }
     HY_TRY(device_groups(a, shape, main_groups, reinterpret_cast<const FusedPlan*>(base), nullptr, lean ? &small_plan : nullptr));
   } else {

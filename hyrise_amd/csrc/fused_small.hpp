@@ -35,7 +35,8 @@ struct FusedSmallPlan {
   uint32_t slot_of_column[FS_COLUMNS];   // ... and back (FusedNode::column -> slot)
   uint32_t filter_width[FS_FILTERS];     // bytes per value id
   uint32_t n_inputs;                     // accumulators 0 .. n_inputs - 1 have an expression; the others are COUNT(*)
-  uint32_t n_nodes;                      // four bits per input
+  uint32_t n_nodes;                      // four bits per input: the nodes of program[d] -- without its first nodes where those are the whole of input d - 1:
+                                         // the inputs are evaluated in order on one stack, input d then starts on what input d - 1 left
   uint32_t literal[FS_LITERALS];         // float bits
   uint64_t program[FS_INPUTS];           // the input's postfix nodes, five bits each (FS_*), first node lowest -- kernel arguments: scalar registers
 };
@@ -275,10 +276,10 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
 #pragma unroll
         for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) {
           id[i] = fs_id16(wide_ids, i);
-          if (group[i] != 0xFu && id[i] >= wide_size) bad = 1;
           far[i] = 0.0f;
           if (id[i] >= in_window && id[i] < wide_size) far[i] = ((const global_f32*)wide_dictionary)[id[i]];
         }
+        if (max(max(id[0], id[1]), max(id[2], id[3])) >= wide_size) bad |= pass;   // a NULL (rows that do not count included: a refusal costs time, nothing else)
 #pragma unroll
         for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) {
           const float near = s_window[id[i] < in_window ? id[i] : 0u];
@@ -290,34 +291,43 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
       }
 #pragma unroll
       for (uint32_t c = 0; c < FS_NARROW; ++c) {
+        uint32_t largest = 0;
 #pragma unroll
         for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) {
           value[c][i] = 0.0f;
           if (!narrow_data[c]) continue;
           const uint32_t id = fs_id8(narrow_ids[c], i);
-          if (group[i] != 0xFu && id >= narrow_size[c]) bad = 1;
+          largest = max(largest, id);
           value[c][i] = s_dict[c][id];
         }
+        if (narrow_data[c] && largest >= narrow_size[c]) bad |= pass;
       }
       // ---- the expressions -----------------------------------------------------------------------------------------------------------
+      // a three-slot stack in registers (slot 0 = top), as evaluate_input's -- floats only
+      float s0[FS_ROWS], s1[FS_ROWS], s2[FS_ROWS];
+#pragma unroll
+      for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = s1[i] = s2[i] = 0.0f;
 #pragma unroll
       for (uint32_t d = 0; d < FS_INPUTS; ++d) {
         if (d >= n_inputs) continue;
-        // a three-slot stack in registers (slot 0 = top), as evaluate_input's -- floats only
-        float s0[FS_ROWS], s1[FS_ROWS], s2[FS_ROWS];
-#pragma unroll
-        for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = s1[i] = s2[i] = 0.0f;
         const uint32_t n_nodes = (lean.n_nodes >> (4 * d)) & 0xFu;
         uint64_t program = lean.program[d];
 #pragma unroll 1
         for (uint32_t n = 0; n < n_nodes; ++n, program >>= 5) {
           const uint32_t node = static_cast<uint32_t>(program) & 31u;
           if (node >= FS_ADD) {
+            if (node == FS_ADD) {
 #pragma unroll
-            for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) {
-              s0[i] = node == FS_ADD ? __fadd_rn(s1[i], s0[i]) : node == FS_SUB ? __fsub_rn(s1[i], s0[i]) : __fmul_rn(s1[i], s0[i]);
-              s1[i] = s2[i];
+              for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = __fadd_rn(s1[i], s0[i]);
+            } else if (node == FS_SUB) {
+#pragma unroll
+              for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = __fsub_rn(s1[i], s0[i]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = __fmul_rn(s1[i], s0[i]);
             }
+#pragma unroll
+            for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s1[i] = s2[i];
           } else {
 #pragma unroll
             for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) { s2[i] = s1[i]; s1[i] = s0[i]; }
