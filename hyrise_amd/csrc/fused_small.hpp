@@ -279,7 +279,10 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
           far[i] = 0.0f;
           if (id[i] >= in_window && id[i] < wide_size) far[i] = ((const global_f32*)wide_dictionary)[id[i]];
         }
-        if (max(max(id[0], id[1]), max(id[2], id[3])) >= wide_size) bad |= pass;   // a NULL (rows that do not count included: a refusal costs time, nothing else)
+        if (max(max(id[0], id[1]), max(id[2], id[3])) >= wide_size) {   // a NULL id? (rare: the four ids are looked at one by one only then)
+#pragma unroll
+          for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) bad |= ((pass >> i) & 1) && id[i] >= wide_size ? 1u : 0u;   // (rows behind the chunk's end read padding)
+        }
 #pragma unroll
         for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) {
           const float near = s_window[id[i] < in_window ? id[i] : 0u];
@@ -300,7 +303,10 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
           largest = max(largest, id);
           value[c][i] = s_dict[c][id];
         }
-        if (narrow_data[c] && largest >= narrow_size[c]) bad |= pass;
+        if (narrow_data[c] && largest >= narrow_size[c]) {
+#pragma unroll
+          for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) bad |= ((pass >> i) & 1) && fs_id8(narrow_ids[c], i) >= narrow_size[c] ? 1u : 0u;
+        }
       }
       // ---- the expressions -----------------------------------------------------------------------------------------------------------
       // a three-slot stack in registers (slot 0 = top), as evaluate_input's -- floats only
