@@ -78,7 +78,9 @@ struct AggArgs {
   uint64_t* trace;            // debug (HY_AGG_TRACE): 12 wall-clock stamps per slice, else nullptr
 };
 enum : uint32_t { FLAG_OVERFLOW = 0, FLAG_GROUPS = 1, FLAG_GIVE_UP = 2, FLAG_SPILLED = 3, /* 4, 5: FLAG_PASSED */
-                  FLAG_SMALL_REFUSED = 6 /* aggregate_small_domain: a 4-bit counter overflowed, run aggregate_rows */ };
+                  FLAG_SMALL_REFUSED = 6 /* aggregate_small_domain: a 4-bit counter overflowed, run aggregate_rows */,
+                  FLAG_CROWDED = 7 /* aggregate_rows: slices most of whose rows found no place in the LDS table */ };
+constexpr uint32_t CROWDED_SLICES = 8;   // ... this many of them end the attempt at once
 
 // order-preserving map double -> int64 (so MIN/MAX of floating point values can use integer atomics)
 __device__ __forceinline__ int64_t ordered_bits(double d) {
@@ -704,8 +706,14 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     __syncthreads();
     if (tid == 0) {
       if (s_spilled[0]) {
+        // Two ways to learn that the table has too many groups for this kernel: slices most of whose rows are outside their LDS table
+        // (thousands of groups: the first few such slices say so before any of them has paid for its rows -- waiting for a share of ALL
+        // rows to spill made the abandoned attempt cost more than the partitioned path that follows), and the sum of the rows outside
+        // (a few groups more than the table holds, SSB Q2.1's 280: those rows take device-scope atomics, up to the limit).
         const uint32_t before = atomicAdd(&a.overflow[FLAG_SPILLED], s_spilled[0]);
-        if (before + s_spilled[0] > a.spill_limit) __hip_atomic_store(&a.overflow[FLAG_GIVE_UP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool give_up = before + s_spilled[0] > a.spill_limit;
+        if (a.spill_limit != 0xFFFFFFFFu && 2 * s_spilled[0] > slice.row_count) give_up |= atomicAdd(&a.overflow[FLAG_CROWDED], 1u) >= CROWDED_SLICES;
+        if (give_up) __hip_atomic_store(&a.overflow[FLAG_GIVE_UP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       s_spilled[1] = __hip_atomic_load(&a.overflow[FLAG_GIVE_UP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -2268,9 +2276,13 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     a.counts = counts.as<uint64_t>();
     a.overflow = flags.as<uint32_t>();
     // rows outside the LDS tables cost a handful of device-scope atomics each; the partitioned path costs about as much as one
-    // such row in sixteen.  (No limit where there is nothing to switch to.)
+    // such row in sixteen -- plus the attempt it abandons: aggregate_rows goes on up to one row in eight (tables with thousands of
+    // groups are recognised by their first slices, FLAG_CROWDED); partitions too coarse for their tables are refined at one in sixteen.
+    // (No limit where there is nothing to switch to.)
     const bool last_resort = !can_partition || unlimited || (partition_bits && partition_bits >= MAX_PARTITION_BITS);
-    a.spill_limit = last_resort ? 0xFFFFFFFFu : static_cast<uint32_t>(std::max<uint64_t>(65536, shape->rows / 16));
+    // (SSB Q2.1 at SF30: 280 groups, 9 % of 1.4 M rows outside the 256-slot tables -- 3.9 ms with them, 4.5 ms through the give-up at rows / 16)
+    const int spill_shift = getenv("HY_AGG_SPILL_SHIFT") ? std::max(0, std::min(8, atoi(getenv("HY_AGG_SPILL_SHIFT")))) : 3;
+    a.spill_limit = last_resort ? 0xFFFFFFFFu : static_cast<uint32_t>(std::max<uint64_t>(65536, shape->rows >> (partition_bits ? 4 : spill_shift)));
     a.trace = nullptr;
     if (getenv("HY_AGG_TRACE") && shape->n_slices <= (1u << 14)) {
       static uint64_t* trace_buffer = nullptr;
