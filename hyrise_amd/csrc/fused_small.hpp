@@ -30,6 +30,20 @@ constexpr uint32_t FS_WINDOW = 38912;    // entries of the 2-byte column's dicti
 constexpr uint32_t FS_LITERALS = 4;      // distinct literals of the expressions
 enum : uint32_t { FS_PUSH_COLUMN = 0 /* + slot */, FS_PUSH_LITERAL = 4 /* + index */, FS_ADD = 8, FS_SUB = 9, FS_MUL = 10 };   // a node of a program: five bits
 
+// The expression stack's cell: two rows' floats side by side (packed float instructions), or -- HY_FS_SCALAR_STACK, for timing -- one.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef HY_FS_SCALAR_STACK
+typedef float fs_cell;
+constexpr int FS_CELLS = static_cast<int>(FS_ROWS);
+__device__ __forceinline__ fs_cell fs_cell_of(float v) { return v; }
+#define FS_ROW(cells, i) ((cells)[i])
+#else
+typedef f32x2 fs_cell;
+constexpr int FS_CELLS = static_cast<int>(FS_ROWS) / 2;
+__device__ __forceinline__ fs_cell fs_cell_of(float v) { return f32x2{v, v}; }
+#define FS_ROW(cells, i) ((cells)[(i) / 2][(i) % 2])
+#endif
+
 struct FusedSmallPlan {
   uint32_t column_of_slot[FS_COLUMNS];   // index into FusedPlan::columns, 0xFFFFFFFF: the slot is empty
   uint32_t slot_of_column[FS_COLUMNS];   // ... and back (FusedNode::column -> slot)
@@ -43,8 +57,13 @@ struct FusedSmallPlan {
 __host__ __device__ constexpr size_t fs_lds_bytes() { return size_t{FS_WINDOW} * 4 + size_t{FS_NARROW} * 256 * 4; }
 
 // four consecutive value ids as loaded (1-byte ids: x; 2-byte ids: x, y)
+#ifndef HY_FS_CACHED_IDS   // value ids are read once: nontemporal loads leave the L2 to the dictionary lines of the gathers (0.569 -> 0.552 ms; the switch is for timing)
+__device__ __forceinline__ uint32_t fs_load_ids8(const void* data, uint32_t row) { return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(static_cast<const char*>(data) + row)); }
+__device__ __forceinline__ u32x2 fs_load_ids16(const void* data, uint32_t row) { return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(static_cast<const char*>(data) + size_t{row} * 2)); }
+#else
 __device__ __forceinline__ uint32_t fs_load_ids8(const void* data, uint32_t row) { return *(const __attribute__((address_space(1))) uint32_t*)(static_cast<const char*>(data) + row); }
 __device__ __forceinline__ u32x2 fs_load_ids16(const void* data, uint32_t row) { return *(const global_u32x2*)(static_cast<const char*>(data) + size_t{row} * 2); }
+#endif
 __device__ __forceinline__ uint32_t fs_id8(uint32_t v, int j) { return (v >> (8 * j)) & 0xFFu; }
 __device__ __forceinline__ uint32_t fs_id16(const u32x2& v, int j) { return ((j < 2 ? v.x : v.y) >> (16 * (j & 1))) & 0xFFFFu; }
 
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
         }
       }
       // ---- the columns' values: dictionaries in LDS --------------------------------------------------------------------------------
-      float value[FS_COLUMNS][FS_ROWS];
+      fs_cell value[FS_COLUMNS][FS_CELLS];
       if (has_wide) {
         uint32_t id[FS_ROWS];
         float far[FS_ROWS];
@@ -286,22 +305,22 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
 #pragma unroll
         for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) {
           const float near = s_window[id[i] < in_window ? id[i] : 0u];
-          value[FS_NARROW][i] = id[i] < in_window ? near : far[i];
+          FS_ROW(value[FS_NARROW], i) = id[i] < in_window ? near : far[i];
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) value[FS_NARROW][i] = 0.0f;
+        for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) FS_ROW(value[FS_NARROW], i) = 0.0f;
       }
 #pragma unroll
       for (uint32_t c = 0; c < FS_NARROW; ++c) {
         uint32_t largest = 0;
 #pragma unroll
         for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) {
-          value[c][i] = 0.0f;
+          FS_ROW(value[c], i) = 0.0f;
           if (!narrow_data[c]) continue;
           const uint32_t id = fs_id8(narrow_ids[c], i);
           largest = max(largest, id);
-          value[c][i] = s_dict[c][id];
+          FS_ROW(value[c], i) = s_dict[c][id];
         }
         if (narrow_data[c] && largest >= narrow_size[c]) {
 #pragma unroll
@@ -309,10 +328,10 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
         }
       }
       // ---- the expressions -----------------------------------------------------------------------------------------------------------
-      // a three-slot stack in registers (slot 0 = top), as evaluate_input's -- floats only
-      float s0[FS_ROWS], s1[FS_ROWS], s2[FS_ROWS];
+      // a three-slot stack in registers (slot 0 = top), as evaluate_input's -- floats only, two rows to a cell (v_pk_add_f32 / v_pk_mul_f32)
+      fs_cell s0[FS_CELLS], s1[FS_CELLS], s2[FS_CELLS];
 #pragma unroll
-      for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = s1[i] = s2[i] = 0.0f;
+      for (int h = 0; h < FS_CELLS; ++h) s0[h] = s1[h] = s2[h] = fs_cell_of(0.0f);
 #pragma unroll
       for (uint32_t d = 0; d < FS_INPUTS; ++d) {
         if (d >= n_inputs) continue;
@@ -324,37 +343,37 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
           if (node >= FS_ADD) {
             if (node == FS_ADD) {
 #pragma unroll
-              for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = __fadd_rn(s1[i], s0[i]);
+              for (int h = 0; h < FS_CELLS; ++h) s0[h] = s1[h] + s0[h];
             } else if (node == FS_SUB) {
 #pragma unroll
-              for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = __fsub_rn(s1[i], s0[i]);
+              for (int h = 0; h < FS_CELLS; ++h) s0[h] = s1[h] - s0[h];
             } else {
 #pragma unroll
-              for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = __fmul_rn(s1[i], s0[i]);
+              for (int h = 0; h < FS_CELLS; ++h) s0[h] = s1[h] * s0[h];
             }
 #pragma unroll
-            for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s1[i] = s2[i];
+            for (int h = 0; h < FS_CELLS; ++h) s1[h] = s2[h];
           } else {
 #pragma unroll
-            for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) { s2[i] = s1[i]; s1[i] = s0[i]; }
+            for (int h = 0; h < FS_CELLS; ++h) { s2[h] = s1[h]; s1[h] = s0[h]; }
             if (node < FS_PUSH_LITERAL) {
 #pragma unroll
               for (uint32_t c = 0; c < FS_COLUMNS; ++c) {
                 if (node != c) continue;
 #pragma unroll
-                for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = value[c][i];
+                for (int h = 0; h < FS_CELLS; ++h) s0[h] = value[c][h];
               }
             } else {
               const uint32_t which = node - FS_PUSH_LITERAL;
               const float literal = __uint_as_float(which == 0 ? lean.literal[0] : which == 1 ? lean.literal[1] : which == 2 ? lean.literal[2] : lean.literal[3]);
 #pragma unroll
-              for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) s0[i] = literal;
+              for (int h = 0; h < FS_CELLS; ++h) s0[h] = fs_cell_of(literal);
             }
           }
         }
 #pragma unroll
         for (int i = 0; i < static_cast<int>(FS_ROWS); ++i) {
-          const double x = static_cast<double>(s0[i]);
+          const double x = static_cast<double>(FS_ROW(s0, i));
 #pragma unroll
           for (uint32_t k = 0; k < SD_DENSE; ++k) acc[d][k] += group[i] == k ? x : 0.0;
         }
