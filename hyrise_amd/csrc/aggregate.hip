@@ -2192,11 +2192,12 @@ static uint32_t g_agg_trace_slices = 0;
 
 template <bool SCATTER, int WORDS>
 static void launch_partition_rows_as(uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
-  static const bool lds_raised = [] {   // 2^14 partitions: 64 KiB of counters, the most a workgroup gets without asking
+  static OncePerDevice lds_raised;   // 2^14 partitions: 64 KiB of counters, the most a workgroup gets without asking
+  uint64_t device_bit = 0;
+  if (lds_raised.pending(&device_bit)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_rows<SCATTER, WORDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    return true;
-  }();
-  (void)lds_raised;
+    lds_raised.done(device_bit);
+  }
   hipLaunchKernelGGL((partition_rows<SCATTER, WORDS>), dim3(grid), dim3(256), lds, stream, a, pa);
 }
 template <bool SCATTER>
@@ -2297,10 +2298,11 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     g_agg_small = fused && fused_small ? 2u : g_agg_small;
     if (shape->n_slices && shape->rows && fused && fused_small) {   // the Q1 shape: one workgroup of 1024 threads per chunk (fused_small.hpp)
       profile_begin(stream, HY_KERNEL_AGGREGATE);
-      static std::atomic<bool> raised{false};
-      if (!raised.load(std::memory_order_acquire)) {
+      static OncePerDevice raised;
+      uint64_t device_bit = 0;
+      if (raised.pending(&device_bit)) {
         HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_small_domain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fs_lds_bytes())));
-        raised.store(true, std::memory_order_release);
+        raised.done(device_bit);
       }
       hipLaunchKernelGGL(fused_small_domain, dim3(shape->n_chunks), dim3(FS_THREADS), fs_lds_bytes(), stream, a, fused, *fused_small, shape->n_chunks);
       profile_end(stream);
@@ -2312,10 +2314,11 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       profile_end(stream);
     } else if (shape->n_slices && shape->rows && partition_bits == 0 && small) {   // a handful of groups over dictionary columns: one workgroup per chunk (aggregate_small.hpp)
       profile_begin(stream, HY_KERNEL_AGGREGATE);
-      static std::atomic<bool> raised{false};
-      if (!raised.load(std::memory_order_acquire)) {
+      static OncePerDevice raised;
+      uint64_t device_bit = 0;
+      if (raised.pending(&device_bit)) {
         HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_small_domain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sd_lds_bytes())));
-        raised.store(true, std::memory_order_release);
+        raised.done(device_bit);
       }
       hipLaunchKernelGGL(aggregate_small_domain, dim3(shape->n_chunks), dim3(SD_THREADS), sd_lds_bytes(), stream, a, *small, shape->n_chunks);
       profile_end(stream);

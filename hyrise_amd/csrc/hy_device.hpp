@@ -76,6 +76,23 @@ constexpr uint32_t WG_THREADS = 256;
 constexpr uint32_t ROWS_PER_THREAD = 32;
 constexpr uint32_t SLICE_ROWS = WG_THREADS * ROWS_PER_THREAD;   // 8192
 
+// hipFuncSetAttribute applies to the calling thread's current device: a kernel that asks for more dynamic LDS than a workgroup gets by default
+// is registered once per DEVICE and call site (a process-wide flag would leave the second GPU of a one-process plan -- hy_bind_device, one
+// worker thread per GPU -- with the default limit and its launches failing).
+class OncePerDevice {
+ public:
+  bool pending(uint64_t* bit) const {
+    int device = 0;
+    (void)hipGetDevice(&device);
+    *bit = 1ull << (static_cast<unsigned>(device) & 63u);
+    return (done_.load(std::memory_order_acquire) & *bit) == 0;
+  }
+  void done(uint64_t bit) { done_.fetch_or(bit, std::memory_order_release); }
+
+ private:
+  std::atomic<uint64_t> done_{0};
+};
+
 }  // namespace hy
 
 // What the first JoinHash over a resident build column learned about its keys (join.hip: rank_table_fill_checked): later joins

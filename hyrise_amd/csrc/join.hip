@@ -3369,10 +3369,11 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     if (build_in_lds) {
       HY_TRY(row_masks.alloc(size_t{n_tiles} * (2 * PK_TILE / 8)));
       k.row_masks = row_masks.as<uint8_t>();
-      static std::atomic<bool> count_lds_raised{false};
-      if (!count_lds_raised.load(std::memory_order_acquire)) {
+      static OncePerDevice count_lds_raised;
+      uint64_t device_bit = 0;
+      if (count_lds_raised.pending(&device_bit)) {
         HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_count_lds), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pk_count_lds_bytes(PK_LDS_KEYS - 1, PK_LDS_MAX_PARTITIONS))));
-        count_lds_raised.store(true, std::memory_order_release);
+        count_lds_raised.done(device_bit);
       }
       int device = 0, cus = 256;
       (void)hipGetDevice(&device);
@@ -3407,13 +3408,14 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     }
     k.build_out = semi_anti ? nullptr : dev_build;
     k.probe_out = dev_probe;
-    static std::atomic<bool> pk_lds_raised{false};
-    if (!pk_lds_raised.load(std::memory_order_acquire)) {
+    static OncePerDevice pk_lds_raised;
+    uint64_t pk_device_bit = 0;
+    if (pk_lds_raised.pending(&pk_device_bit)) {
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
-      pk_lds_raised.store(true, std::memory_order_release);
+      pk_lds_raised.done(pk_device_bit);
     }
     hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself)
     profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
@@ -3587,13 +3589,14 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   a.build_out = semi_anti ? nullptr : dev_build;
   a.probe_out = dev_probe;
   a.slice_offsets = dev_slice_offsets;
-  static std::atomic<bool> lds_raised{false};   // (joins run from any thread; setting the attributes twice is harmless)
-  if (n_tiles && !lds_raised.load(std::memory_order_acquire)) {
+  static OncePerDevice lds_raised;   // (joins run from any thread; setting the attributes twice is harmless)
+  uint64_t lds_device_bit = 0;
+  if (n_tiles && lds_raised.pending(&lds_device_bit)) {
     HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_cached), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_cached_lds_words(MAX_PARTITIONS)));
     HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
     HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_emit_generic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * probe_emit_lds_words(MAX_PARTITIONS)));
     HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rt_probe_emit), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * rt_probe_emit_lds_words(MAX_PARTITIONS)));
-    lds_raised.store(true, std::memory_order_release);
+    lds_raised.done(lds_device_bit);
   }
   if (n_tiles && rank_path) {   // (every pass 2 kernel returns at once if the plan says that the result does not fit)
     a.lane_ordered_atomics = lds_atomics_are_lane_ordered(stream) ? 1u : 0u;
