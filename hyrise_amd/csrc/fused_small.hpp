@@ -8,9 +8,9 @@
 //   * every aggregate is SUM / AVG / COUNT over a float expression (+ - * over float columns and literals) or COUNT(*); the
 //     expressions read at most four columns, all DictionarySegment<float>, at most one of them with 2-byte value ids.
 // fused_rows serves every shape from one body: its survivors' list, the decoded 64-bit stack words and sixteen copies of LDS accumulator
-// cells per dense group run Q1 at 3.0 ms.  Here a lane takes four consecutive rows per step (4- and 8-byte loads of ids), tests the
+// cells per dense group run Q1 at 3.0 ms (SF10); this kernel at 0.55 ms.  Here a lane takes four consecutive rows per step (4- and 8-byte loads of ids), tests the
 // filters on the ids, takes the float values from dictionaries in LDS (the 1-byte columns' dictionaries whole; of the 2-byte column's --
-// 240 KB per chunk for l_extendedprice -- the first 39000 entries, the others are gathered through the L2), interprets the postfix
+// 240 KB per chunk for l_extendedprice -- the first 38912 entries, the others are gathered through the L2), interprets the postfix
 // expressions on float registers (the programs are kernel arguments: five bits per node in scalar registers) and adds the results to
 // per-lane double accumulators, one per (accumulator, dense group), selected by the row's group.  One workgroup of 1024 threads per chunk.
 // What the kernel does not take -- a fifth group in a chunk, a NULL in an input column, a LIKE filter's value-id set -- raises
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
         }
         codes |= (code & 0xFu) << (4 * j);
       }
-      uint32_t group[FS_ROWS];    // dense index of the row, 0xF: not counted (in this pass)
+      uint32_t group[FS_ROWS];    // dense index of the row, 0xF: not counted
       {
         uint32_t assigned = *reinterpret_cast<volatile uint32_t*>(&s_dense_map[2]);
         uint32_t wanted = 0;   // codes of this lane's rows that passed
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
           group[j] = ((pass >> j) & 1) && d < SD_DENSE ? d : 0xFu;
         }
       }
-      // ---- rows, first and last row per dense group (once: in the first window's pass) --------------------------------------------
+      // ---- rows, first and last row per dense group ------------------------------------------------------------------------------------
       {
 #pragma unroll
         for (uint32_t k = 0; k < SD_DENSE; ++k) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
           }
         }
       }
-      // ---- the columns' values: dictionaries in LDS --------------------------------------------------------------------------------
+      // ---- the columns' values: dictionaries in LDS, the 2-byte column's entries behind the window through the L2 ---------------------
       fs_cell value[FS_COLUMNS][FS_CELLS];
       if (has_wide) {
         uint32_t id[FS_ROWS];
