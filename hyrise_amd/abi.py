@@ -63,7 +63,16 @@ class JoinResult(C.Structure):
     _fields_ = [("mem", C.c_uint32), ("radix_bits", C.c_uint32), ("left_pos", C.c_void_p), ("right_pos", C.c_void_p),
                 ("capacity", C.c_uint64), ("slice_offsets", C.c_void_p), ("slice_capacity", C.c_uint32),
                 ("n_slices", C.c_uint32), ("n_pairs", C.c_uint64), ("left_is_build", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("status", C.c_void_p)]
+
+
+JOIN_ASYNC = 1
+
+
+class JoinStatus(C.Structure):
+    """hy_join_status: what a HY_JOIN_ASYNC join leaves in device memory."""
+    _fields_ = [("n_pairs", C.c_uint64), ("n_slices", C.c_uint32), ("fits", C.c_uint32), ("build_confirmed", C.c_uint32), ("error", C.c_uint32),
+                ("reserved", C.c_uint64)]
 
 
 class JoinPredicate(C.Structure):
@@ -72,6 +81,11 @@ class JoinPredicate(C.Structure):
 
 
 MAX_SECONDARY_PREDICATES = 4
+# hy_set_option (include/hyrise_amd.h HY_OPT_*): equivalent paths / launch shapes; every setting gives the same results
+(OPT_ALLOW_ANY_ARCH, OPT_SCAN_WGS_PER_CU, OPT_SCAN_NT_STORES, OPT_PART_SLICES, OPT_JOIN_RANK_TABLE, OPT_JOIN_IDENTITY, OPT_JOIN_HINT, OPT_JOIN_BREAK_HINT,
+ OPT_JOIN_FETCH_AHEAD, OPT_JOIN_PKFK, OPT_JOIN_LDS_BUILD, OPT_JOIN_LDS_BUILD_TILES, OPT_JOIN_ORDERED_ATOMICS, OPT_JOIN_STORES, OPT_JOIN_WGS_PER_CU,
+ OPT_AGG_PARTITIONS, OPT_AGG_PARTITION_BITS, OPT_AGG_SPILL_SHIFT, OPT_AGG_LDS_BUDGET, OPT_AGG_SPLIT, OPT_AGG_SMALL_DOMAIN, OPT_AGG_JOINT_HISTOGRAM,
+ OPT_FUSED_SMALL_DOMAIN, OPT_FUSED_SHARED_PREFIX, OPT_JOIN_LDS_HASH, OPT_HOST_RESULT_TILES) = range(26)
 KERNEL_OTHER, KERNEL_SCAN, KERNEL_JOIN_PROBE, KERNEL_JOIN_COUNT, KERNEL_JOIN_BUILD, KERNEL_AGGREGATE, KERNEL_PROJECTION = range(7)   # hy_profile_read_kernel
 ARITH_ADD, ARITH_SUB, ARITH_MUL, ARITH_DIV, ARITH_MOD = range(5)
 
@@ -120,6 +134,8 @@ class AggregateResult(C.Structure):
 SYMBOLS = [
     ("hy_abi_version", C.c_int32, []),
     ("hy_init", C.c_int32, [C.c_int32]),
+    ("hy_set_option", C.c_int32, [C.c_uint32, C.c_int64]),
+    ("hy_get_option", C.c_int32, [C.c_uint32, C.POINTER(C.c_int64)]),
     ("hy_shutdown", C.c_int32, []),
     ("hy_last_error", C.c_char_p, []),
     ("hy_set_stream", C.c_int32, [C.c_void_p]),
@@ -159,6 +175,7 @@ SYMBOLS = [
     ("hy_join_output_chunks", C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("hy_poslist_translate", C.c_int32, [C.c_void_p, C.POINTER(ScanResult), C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("hy_join_hash", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinResult)]),
+    ("hy_join_hash_finish", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinResult)]),
     ("hy_join_hash_predicates", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(JoinPredicate), C.c_uint32, C.POINTER(JoinResult)]),
     ("hy_join_hash_radix_bits", C.c_int32, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),
     ("hy_join_hash_count", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
@@ -203,3 +220,65 @@ def load_library():
 def check(status):
     if status != OK:
         raise HyriseAmdError(status, load_library().hy_last_error().decode("utf-8", "replace"))
+
+
+class option:
+    """`with abi.option(abi.OPT_JOIN_PKFK, 0): ...` -- one of the library's options set for the block (tests force paths, tools A/B them)."""
+
+    def __init__(self, option_id, value):
+        self.option_id, self.value, self.before = option_id, value, C.c_int64(0)
+
+    def __enter__(self):
+        lib = load_library()
+        check(lib.hy_get_option(self.option_id, C.byref(self.before)))
+        check(lib.hy_set_option(self.option_id, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        check(load_library().hy_set_option(self.option_id, self.before.value))
+        return False
+
+
+# The switches the tools/ scripts name (DESIGN.md section 6) -> (option, value when the switch is "1" / its integer value otherwise).
+_SWITCHES = {
+    "HY_SCAN_NT_STORES": (OPT_SCAN_NT_STORES, None), "HY_SCAN_WGS_PER_CU": (OPT_SCAN_WGS_PER_CU, None), "HY_PART_SLICES": (OPT_PART_SLICES, None),
+    "HY_JOIN_NO_RANK_TABLE": (OPT_JOIN_RANK_TABLE, 0), "HY_JOIN_NO_IDENTITY": (OPT_JOIN_IDENTITY, 0), "HY_JOIN_NO_HINT": (OPT_JOIN_HINT, 0),
+    "HY_JOIN_BREAK_HINT": (OPT_JOIN_BREAK_HINT, None), "HY_JOIN_NO_FETCH_AHEAD": (OPT_JOIN_FETCH_AHEAD, 0), "HY_JOIN_NO_PKFK": (OPT_JOIN_PKFK, 0),
+    "HY_JOIN_NO_LDS_BUILD": (OPT_JOIN_LDS_BUILD, 0), "HY_JOIN_LDS_BUILD_TILES": (OPT_JOIN_LDS_BUILD_TILES, None),
+    "HY_JOIN_NO_ORDERED_ATOMICS": (OPT_JOIN_ORDERED_ATOMICS, 0), "HY_JOIN_STORES": (OPT_JOIN_STORES, None), "HY_JOIN_WGS_PER_CU": (OPT_JOIN_WGS_PER_CU, None),
+    "HY_JOIN_NO_LDS_HASH": (OPT_JOIN_LDS_HASH, 0),
+    "HY_AGG_NO_PARTITIONS": (OPT_AGG_PARTITIONS, 0), "HY_AGG_PARTITION_BITS": (OPT_AGG_PARTITION_BITS, None), "HY_AGG_SPILL_SHIFT": (OPT_AGG_SPILL_SHIFT, None),
+    "HY_AGG_LDS_BUDGET": (OPT_AGG_LDS_BUDGET, None), "HY_AGG_SPLIT": (OPT_AGG_SPLIT, None), "HY_AGG_NO_SMALL_DOMAIN": (OPT_AGG_SMALL_DOMAIN, 0),
+    "HY_AGG_NO_JOINT_HISTOGRAM": (OPT_AGG_JOINT_HISTOGRAM, 0), "HY_FUSED_NO_SMALL_DOMAIN": (OPT_FUSED_SMALL_DOMAIN, 0),
+    "HY_FUSED_NO_SHARED_PREFIX": (OPT_FUSED_SHARED_PREFIX, 0), "HY_NO_HOST_RESULT_TILES": (OPT_HOST_RESULT_TILES, 0),
+}
+
+
+class switches:
+    """`with abi.switches({"HY_JOIN_NO_PKFK": "1"}): ...` -- the tools' named switches as options for the block.  Names that are not options
+    (HY_*_TRACE, HY_*_TIMING, HY_*_DEBUG) are debug aids of a -DHY_DEBUG_SWITCHES build: they go into the environment."""
+
+    def __init__(self, named):
+        self.named, self.stack, self.env = dict(named), [], []
+
+    def __enter__(self):
+        for name, value in self.named.items():
+            if name in _SWITCHES:
+                option_id, fixed = _SWITCHES[name]
+                o = option(option_id, fixed if fixed is not None else int(value))
+                o.__enter__()
+                self.stack.append(o)
+            else:
+                self.env.append((name, os.environ.get(name)))
+                os.environ[name] = str(value)
+        return self
+
+    def __exit__(self, *exc):
+        for o in reversed(self.stack):
+            o.__exit__(*exc)
+        for name, before in self.env:
+            if before is None:
+                del os.environ[name]
+            else:
+                os.environ[name] = before
+        return False

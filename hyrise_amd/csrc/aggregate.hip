@@ -2236,16 +2236,16 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   // The partitioned path (tables with many groups): entered when aggregate_rows gives up; 2^bits partitions of about 64 Ki rows,
   // then -- if even those hold more groups than a workgroup's table -- the most the partitioning kernels take.
   constexpr uint32_t MAX_PARTITION_BITS = 14;
-  const bool can_partition = !fused && a.n_groupby > 0 && shape->rows < (1ull << 32) && !getenv("HY_AGG_NO_PARTITIONS");
+  const bool can_partition = !fused && a.n_groupby > 0 && shape->rows < (1ull << 32) && option(HY_OPT_AGG_PARTITIONS);
   uint32_t first_bits = 6;
   while (first_bits < MAX_PARTITION_BITS && (shape->rows >> first_bits) > 65536) ++first_bits;
   uint32_t partition_bits = 0;   // 0: aggregate_rows
-  if (can_partition && getenv("HY_AGG_PARTITION_BITS")) partition_bits = std::min<uint32_t>(MAX_PARTITION_BITS, std::max(1, atoi(getenv("HY_AGG_PARTITION_BITS"))));   // (tests: force the path)
+  if (can_partition && option(HY_OPT_AGG_PARTITION_BITS) > 0) partition_bits = std::min<uint32_t>(MAX_PARTITION_BITS, static_cast<uint32_t>(option(HY_OPT_AGG_PARTITION_BITS)));   // (tests: force the path)
   bool unlimited = false, partitions_ready = false;
   DeviceBuffer part_offsets, part_rows, part_sums;
   PartitionArgs pa;
   std::memset(&pa, 0, sizeof(pa));
-  const bool timing = getenv("HY_AGG_TIMING") != nullptr;
+  const bool timing = HY_DEBUG_ENV("HY_AGG_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what, int round) {
     if (!timing) return;
@@ -2282,10 +2282,10 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     // (No limit where there is nothing to switch to.)
     const bool last_resort = !can_partition || unlimited || (partition_bits && partition_bits >= MAX_PARTITION_BITS);
     // (SSB Q2.1 at SF30: 280 groups, 9 % of 1.4 M rows outside the 256-slot tables -- 3.9 ms with them, 4.5 ms through the give-up at rows / 16)
-    const int spill_shift = getenv("HY_AGG_SPILL_SHIFT") ? std::max(0, std::min(8, atoi(getenv("HY_AGG_SPILL_SHIFT")))) : 3;
+    const int spill_shift = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(8, option(HY_OPT_AGG_SPILL_SHIFT))));
     a.spill_limit = last_resort ? 0xFFFFFFFFu : static_cast<uint32_t>(std::max<uint64_t>(65536, shape->rows >> (partition_bits ? 4 : spill_shift)));
     a.trace = nullptr;
-    if (getenv("HY_AGG_TRACE") && shape->n_slices <= (1u << 14)) {
+    if (HY_DEBUG_ENV("HY_AGG_TRACE") && shape->n_slices <= (1u << 14)) {
       static uint64_t* trace_buffer = nullptr;
       if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 12 * size_t{1u << 14});
       (void)hipMemsetAsync(trace_buffer, 0, 8 * 12 * size_t{shape->n_slices}, stream);
@@ -2349,7 +2349,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
         pa.total_rows = shape->rows;
         const size_t per_slot = 8 * words + 16 + 12 * n_aggregates + 4;
         pa.lds_slots = 2048;
-        const size_t lds_budget = getenv("HY_AGG_LDS_BUDGET") ? static_cast<size_t>(atoi(getenv("HY_AGG_LDS_BUDGET"))) : 32768;
+        const size_t lds_budget = static_cast<size_t>(std::max<int64_t>(1024, option(HY_OPT_AGG_LDS_BUDGET)));
         while (pa.lds_slots > 64 && pa.lds_slots * per_slot > lds_budget) pa.lds_slots >>= 1;
         launch_partition_rows(false, words, pa.n_parts, 4 * size_t{partitions}, stream, a, pa);
         hipLaunchKernelGGL(scan_blocks, dim3(n_blocks), dim3(256), 0, stream, pa.offsets, cells, part_sums.as<uint32_t>());
@@ -2362,7 +2362,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       // about 16 Ki rows per workgroup: coarse partitions (long contiguous runs for the scatter) are shared by several
       pa.split = 1;
       while (pa.split < 64 && (shape->rows >> partition_bits) / pa.split > 16384) pa.split <<= 1;
-      if (const char* env = getenv("HY_AGG_SPLIT")) pa.split = std::max(1, atoi(env));
+      if (option(HY_OPT_AGG_SPLIT) > 0) pa.split = static_cast<uint32_t>(option(HY_OPT_AGG_SPLIT));
       switch (words) {
         case 1: hipLaunchKernelGGL(aggregate_partitions<1>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
         case 2: hipLaunchKernelGGL(aggregate_partitions<2>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
@@ -2632,7 +2632,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
   hipStream_t stream = current_stream();
   const uint32_t words = n_groupby + 1;
 
-  const bool timing = getenv("HY_AGG_TIMING") != nullptr;
+  const bool timing = HY_DEBUG_ENV("HY_AGG_TIMING") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (timing) std::fprintf(stderr, "[aggregate] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
@@ -2699,7 +2699,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     }
     plan.n_columns = fused->n_columns;
     plan.lds_slots = fused_lds_slots(n_groupby);
-    plan.debug = getenv("HY_FUSED_DEBUG") ? static_cast<uint32_t>(atoi(getenv("HY_FUSED_DEBUG"))) : 0u;
+    plan.debug = HY_DEBUG_ENV("HY_FUSED_DEBUG") ? static_cast<uint32_t>(atoi(HY_DEBUG_ENV("HY_FUSED_DEBUG"))) : 0u;
     for (uint32_t c = 0; c < fused->n_columns; ++c) plan.columns[c] = fused->columns[c]->d_segments;
     for (uint32_t d = 0; d < n_device; ++d) plan.inputs[d] = fused->inputs[spec_of_device[d]];
     HY_HIP(hipMemcpyAsync(base, &plan, sizeof(plan), hipMemcpyHostToDevice, stream));
@@ -2709,7 +2709,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     FusedSmallPlan small_plan;
     std::memset(&small_plan, 0, sizeof(small_plan));
     for (uint32_t c = 0; c < FS_COLUMNS; ++c) small_plan.column_of_slot[c] = 0xFFFFFFFFu;
-    bool lean = !getenv("HY_FUSED_NO_SMALL_DOMAIN") && shape->rows > 0 && fused->n_filters <= FS_FILTERS && fused->n_columns <= FS_COLUMNS && few_codes();
+    bool lean = option(HY_OPT_FUSED_SMALL_DOMAIN) && shape->rows > 0 && fused->n_filters <= FS_FILTERS && fused->n_columns <= FS_COLUMNS && few_codes();
     for (uint32_t k = 0; k < shape->n_chunks && lean; ++k) lean = shape->host_segments[k].size <= FS_SPAN;
     for (uint32_t f = 0; f < fused->n_filters && lean; ++f) {
       const uint32_t condition = fused->filters[f].predicate.condition;
@@ -2746,7 +2746,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       // input before it (Q1: l_extendedprice, then l_extendedprice * (1 - l_discount), then that * (1 + l_tax)) continues on its stack.
       uint32_t skipped = 0;
       if (d > 0 && plan.inputs[d - 1].n_nodes > 0 && plan.inputs[d - 1].n_nodes < input.n_nodes &&
-          std::memcmp(plan.inputs[d - 1].nodes, input.nodes, sizeof(FusedNode) * plan.inputs[d - 1].n_nodes) == 0 && !getenv("HY_FUSED_NO_SHARED_PREFIX")) {
+          std::memcmp(plan.inputs[d - 1].nodes, input.nodes, sizeof(FusedNode) * plan.inputs[d - 1].n_nodes) == 0 && option(HY_OPT_FUSED_SHARED_PREFIX)) {
         skipped = plan.inputs[d - 1].n_nodes;
       }
       for (uint32_t n = skipped; n < input.n_nodes && lean; ++n) {
@@ -2776,7 +2776,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     // columns with 1- or 2-byte value ids -- has a kernel of its own (aggregate_small.hpp); everything else takes aggregate_rows.
     SmallDomainPlan small;
     std::memset(&small, 0, sizeof(small));
-    bool lean = !getenv("HY_AGG_NO_SMALL_DOMAIN") && shape->rows > 0 && few_codes();
+    bool lean = option(HY_OPT_AGG_SMALL_DOMAIN) && shape->rows > 0 && few_codes();
     std::vector<const hy_column*> inputs;   // distinct input columns, 1-byte ids first
     for (int pass = 0; pass < 2 && lean; ++pass) {
       for (uint32_t d = 0; d < n_device && lean; ++d) {
@@ -2792,9 +2792,9 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     }
     lean = lean && small.n_narrow <= SD_NARROW && inputs.size() - small.n_narrow <= SD_WIDE;
     if (lean) {
-      if (const char* debug = getenv("HY_AGG_SMALL_DEBUG")) small.debug = static_cast<uint32_t>(atoi(debug));   // timing experiments only
+      if (const char* debug = HY_DEBUG_ENV("HY_AGG_SMALL_DEBUG")) small.debug = static_cast<uint32_t>(atoi(debug));   // timing experiments only
       small.n_columns = static_cast<uint32_t>(inputs.size());
-      small.joint = small.n_narrow == 2 && !getenv("HY_AGG_NO_JOINT_HISTOGRAM") ? 1u : 0u;
+      small.joint = small.n_narrow == 2 && option(HY_OPT_AGG_JOINT_HISTOGRAM) ? 1u : 0u;
       for (uint32_t k = 0; k < shape->n_chunks && small.joint; ++k) {
         if ((uint64_t{inputs[0]->host_segments[k].aux_size} + 1) * (uint64_t{inputs[1]->host_segments[k].aux_size} + 1) > SD_JOINT_CELLS) small.joint = 0;
       }

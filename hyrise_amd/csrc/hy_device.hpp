@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/hyrise_amd.h"
+#include "hy_options.hpp"
 
 namespace hy {
 

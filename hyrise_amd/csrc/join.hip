@@ -2381,7 +2381,7 @@ struct JoinMailbox {
   uint64_t key_or, first_key, last_key;   // build side
   uint64_t key_min, key_max;              // ... smallest / largest key as signed 64-bit values
   uint32_t unsorted, any_null, equal_neighbours, duplicate;   // duplicate: rank_table_mark met a key twice
-  uint32_t unsorted_signed, reserved;
+  uint32_t unsorted_signed, build_unconfirmed;   // build_unconfirmed: the build column contradicted its key hint (pk_plan): nothing was written
   uint64_t n_pairs;                       // after pass 1
   uint32_t n_slices, n_uncached, fits;    // fits: the result's capacities hold n_pairs / n_slices
   uint32_t error;                         // pass 2: a probe row with >= 2^22 partners
@@ -2389,15 +2389,14 @@ struct JoinMailbox {
 static thread_local JoinMailbox* t_mailbox = nullptr;      // host address
 static thread_local JoinMailbox* t_mailbox_dev = nullptr;  // device address of the same memory
 
-// What rank_table_fill_checked found out about a build column that was filled on the strength of a hint (below): read by the
-// host when the join's last kernel has finished.  It lives behind the mailbox in the same pinned block and is cleared only by
-// the launch that fills it (join_mailbox clears the mailbox several times per join).
+// What rank_table_fill_checked found out about a build column that was filled on the strength of a hint (below).  Device memory
+// behind the table's arrival counters (zeroed with them); the kernel that plans the join's output (pk_plan) compares it with the
+// hint: a build column that contradicts its hint makes the plan say "does not fit" -- nothing is written -- and the host, when it
+// reads the mailbox (or, HY_JOIN_ASYNC, hy_join_status), drops the hint and runs the join again.
 struct BuildVerdict {
   uint64_t key_min, key_max;              // smallest / largest key as signed 64-bit values
   uint32_t unsorted_signed, equal_neighbours, outside_hint, done;
 };
-static BuildVerdict* build_verdict_host() { return reinterpret_cast<BuildVerdict*>(reinterpret_cast<char*>(t_mailbox) + 256); }
-static BuildVerdict* build_verdict_device() { return reinterpret_cast<BuildVerdict*>(reinterpret_cast<char*>(t_mailbox_dev) + 256); }
 
 // hy_shutdown: the calling thread's mailbox goes with its scratch arena and pools (the next join allocates a new one)
 void release_thread_join_state() {
@@ -2407,8 +2406,8 @@ void release_thread_join_state() {
 
 static hy_status join_mailbox(JoinMailbox** host, JoinMailbox** device) {
   if (!t_mailbox) {
-    static_assert(sizeof(JoinMailbox) <= 256, "the build verdict sits 256 bytes behind the mailbox");
-    HY_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_mailbox), 256 + sizeof(BuildVerdict), hipHostMallocMapped));
+    static_assert(sizeof(JoinMailbox) <= 256, "the mailbox is a 256-byte pinned block");
+    HY_HIP(hipHostMalloc(reinterpret_cast<void**>(&t_mailbox), 256, hipHostMallocMapped));
     HY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&t_mailbox_dev), t_mailbox, 0));
   }
   std::memset(t_mailbox, 0, sizeof(JoinMailbox));
@@ -2581,9 +2580,9 @@ __device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, con
 // whose extent is already known: the first join over a resident column leaves its key range behind as a hint
 // (hy_column::join_hint -- encoded segments are immutable, abstract_encoded_segment.hpp:12-17), later joins size and fill the table
 // from the hint while they check every key against it (order, duplicates, smallest / largest key, keys outside the hinted range),
-// and the host compares the verdict with the hint when the join's last kernel has finished: no second read of the build keys, no
-// host round trip between the build and the probe.  A verdict that does not confirm the hint discards the join's output and runs the
-// two-pass build.  Only for columns of int32 keys whose segments SliceViews describe (the host checks).
+// and the kernel that plans the output (pk_plan) compares the verdict with the hint: no second read of the build keys, no host round
+// trip between the build and the probe.  A verdict that does not confirm the hint writes no output and the host runs the two-pass
+// build.  Only for columns of int32 keys whose segments SliceViews describe (the host checks).
 // partials: [n_slices][4] min ^ sign | max ^ sign | flags (1 unsorted, 2 equal neighbours, 4 outside the hint) | unused.
 __global__ __launch_bounds__(256, 5) void rank_table_fill_checked(MaterializeArgs a, uint64_t key_min, uint64_t hint_range, u32x2_entry_t* entries, uint64_t* partials, uint32_t* ticket,
                                                                   BuildVerdict* verdict) {
@@ -2762,9 +2761,18 @@ __global__ __launch_bounds__(256) void plan_output(const uint64_t* base_elements
 
 #include "join_pkfk.hpp"
 
+__global__ void publish_join_status(hy_join_status* status, uint64_t n_pairs, uint32_t n_slices, uint32_t fits) {
+  status->n_pairs = n_pairs;
+  status->n_slices = n_slices;
+  status->fits = fits;
+  status->build_confirmed = 1;
+  status->error = 0;
+  status->reserved = 0;
+}
+
 // HY_JOIN_TIMING=1: host-side wall clock at the join's synchronisation points (debug aid)
 struct StageClock {
-  bool on = getenv("HY_JOIN_TIMING") != nullptr;
+  bool on = HY_DEBUG_ENV("HY_JOIN_TIMING") != nullptr;
   std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
   void mark(const char* what) {
     if (on) fprintf(stderr, "  join %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - start).count());
@@ -2775,8 +2783,9 @@ struct BuildSide {
   DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags, rank_entries, partials;
   bool hint_allows_duplicates = false;
   bool bloom_is_bits = false;    // the filter is 2^20 BITS (rank_table_fill_checked folds the table's presence words into it), not one byte per bit
-  bool hinted = false;           // the rank table was filled from the column's key hint: the join must confirm build_verdict_host() at its end
+  bool hinted = false;           // the rank table was filled from the column's key hint: pk_plan confirms `verdict` against the hint
   uint64_t hint_min = 0, hint_max = 0;
+  const BuildVerdict* verdict = nullptr;   // (device memory, behind the table's arrival counters)
   uint64_t n = 0;
   Directory directory{};
   RankTable rank{};            // rank.entries != nullptr: unique integer keys, looked up in the rank table (directory.dir is not built)
@@ -2808,10 +2817,10 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     const uint32_t size = build->host_segments[c].size, first_size = build->host_segments[0].size;
     uniform_chunks = first_size > 0 && (c + 1 == build->n_chunks ? size <= first_size : size == first_size);
   }
-  const bool identity_candidate = dense && build->rows && uniform_chunks && build->host_segments[0].size > 0 && allow_rank_table && !getenv("HY_JOIN_NO_RANK_TABLE") &&
-                                  !getenv("HY_JOIN_NO_IDENTITY");
+  const bool identity_candidate = dense && build->rows && uniform_chunks && build->host_segments[0].size > 0 && allow_rank_table && option(HY_OPT_JOIN_RANK_TABLE) &&
+                                  option(HY_OPT_JOIN_IDENTITY);
   bool hinted = identity_candidate && bit_filter_ok && build->join_hint.state.load(std::memory_order_acquire) == 1 &&
-                (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) && !getenv("HY_JOIN_NO_HINT");
+                (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) && option(HY_OPT_JOIN_HINT);
   for (uint32_t c = 0; c < build->n_chunks && hinted; ++c) {   // rank_table_fill_checked reads int32 keys through SliceViews, 16 bytes per load
     const hy_segment& seg = build->host_segments[c];
     hinted = reinterpret_cast<uintptr_t>(seg.data) % 16 == 0 && ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
@@ -2863,35 +2872,31 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     if (hinted) {
       const MaterializeArgs& m_in = m;
       // an earlier join over this column found a primary key in [key_min, key_max]: one pass fills the table and checks every key
-      {
-        JoinMailbox* unused_host = nullptr;
-        JoinMailbox* unused_device = nullptr;
-        HY_TRY(join_mailbox(&unused_host, &unused_device));   // (the verdict lives behind this thread's mailbox: make sure it exists)
-      }
       const uint64_t key_min = build->join_hint.key_min.load(std::memory_order_relaxed);
       uint64_t key_max = build->join_hint.key_max.load(std::memory_order_relaxed);
-      if (getenv("HY_JOIN_BREAK_HINT") && key_max - key_min > 64) key_max -= 64;   // tests: a hint that does not hold
+      if (option(HY_OPT_JOIN_BREAK_HINT) && key_max - key_min > 64) key_max -= 64;   // tests: a hint that does not hold
       const uint64_t origin = key_min & ~uint64_t{31};   // (the table starts at a multiple of 32: a key's bit in its table word is its bit in the Bloom filter's word)
       const uint64_t words = ((key_max - origin) >> 5) + 1;
       const size_t ticket_bytes = 128 * (size_t{CHECKED_FILL_TICKETS} + 1);
-      HY_TRY(b.rank_entries.alloc(8 * (words + 2) + ticket_bytes));
+      HY_TRY(b.rank_entries.alloc(8 * (words + 2) + ticket_bytes + 64));   // the table | the arrival counters | the verdict
       HY_TRY(b.partials.alloc(32 * size_t{n_slices}));
       u32x2_t* entries = b.rank_entries.as<u32x2_t>();
       {   // the table | the arrival counter, and the Bloom filter
-        const size_t table_vectors = (8 * (words + 2) + ticket_bytes + 15) / 16, bloom_vectors = want_bloom ? BLOOM_BITS / 8 / 16 : 0;   // (the filter as bits: 128 KB)
+        const size_t table_vectors = (8 * (words + 2) + ticket_bytes + 64 + 15) / 16, bloom_vectors = want_bloom ? BLOOM_BITS / 8 / 16 : 0;   // (the filter as bits: 128 KB)
         hipLaunchKernelGGL(zero_vectors, dim3(static_cast<uint32_t>(std::min<size_t>(2048, (table_vectors + bloom_vectors + 255) / 256))), dim3(256), 0, stream,
                            reinterpret_cast<u32x4_t*>(entries), table_vectors, b.bloom.as<u32x4_t>(), bloom_vectors);
       }
-      build_verdict_host()->done = 0;
+      BuildVerdict* verdict = reinterpret_cast<BuildVerdict*>(reinterpret_cast<char*>(entries + words + 2) + ticket_bytes);
       MaterializeArgs m = m_in;
-      if (const char* debug = getenv("HY_JOIN_FILL_DEBUG")) {   // timing experiments only (results are wrong): 1 no filter, 2 no table either
+      if (const char* debug = HY_DEBUG_ENV("HY_JOIN_FILL_DEBUG")) {   // timing experiments only (results are wrong): 1 no filter, 2 no table either
         m.bloom_out = nullptr;
         if (atoi(debug) >= 2) m.keep_nulls = 0xFFFFFFFFu;
       }
       hipEvent_t fill_started = nullptr, fill_stopped = nullptr;
       profile_events(&fill_started, &fill_stopped, HY_KERNEL_JOIN_BUILD);
       hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries,
-                            b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 2), build_verdict_device());
+                            b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 2), verdict);
+      b.verdict = verdict;
       identity_table(entries, origin, key_max);
       b.directory.key_min = key_min;
       b.bloom_is_bits = want_bloom;
@@ -2923,7 +2928,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     HY_HIP(hipStreamSynchronize(stream));
     const uint64_t key_min = mailbox->key_min, range = mailbox->key_max - mailbox->key_min;
     const uint64_t words = (range >> 5) + 1;
-    if (getenv("HY_JOIN_TIMING")) fprintf(stderr, "  dense stats: min %lld max %lld unsorted %u signed %u equal %u total %llu\n", (long long)mailbox->key_min, (long long)mailbox->key_max, mailbox->unsorted, mailbox->unsorted_signed, mailbox->equal_neighbours, (unsigned long long)total);
+    if (HY_DEBUG_ENV("HY_JOIN_TIMING")) fprintf(stderr, "  dense stats: min %lld max %lld unsorted %u signed %u equal %u total %llu\n", (long long)mailbox->key_min, (long long)mailbox->key_max, mailbox->unsorted, mailbox->unsorted_signed, mailbox->equal_neighbours, (unsigned long long)total);
     if (!mailbox->unsorted_signed && (!mailbox->equal_neighbours || existence_only) && range < 0xFFFFFF00ull && words <= 2 * total + 4096) {
       HY_TRY(b.rank_entries.alloc(8 * (words + 1)));
       u32x2_t* entries = b.rank_entries.as<u32x2_t>();
@@ -2994,7 +2999,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       const uint64_t key_min = mailbox->key_min, range = mailbox->key_max - mailbox->key_min;
       const uint64_t words = (range >> 5) + 1;
       if (allow_rank_table && hashed_type == 0 && !b.any_null && !mailbox->equal_neighbours && range < 0xFFFFFF00ull && words <= 2 * total + 4096 &&
-          !getenv("HY_JOIN_NO_RANK_TABLE")) {
+          option(HY_OPT_JOIN_RANK_TABLE)) {
         HY_TRY(b.rank_entries.alloc(8 * (words + 1)));
         u32x2_t* entries = b.rank_entries.as<u32x2_t>();
         HY_HIP(hipMemsetAsync(entries, 0, 8 * (words + 1), stream));
@@ -3040,7 +3045,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
             const uint32_t size = build->host_segments[c].size, first_size = build->host_segments[0].size;
             uniform = c + 1 == build->n_chunks ? size <= first_size : size == first_size;
           }
-          if (uniform && !getenv("HY_JOIN_NO_IDENTITY")) {
+          if (uniform && option(HY_OPT_JOIN_IDENTITY)) {
             b.rank.identity_rows = build->host_segments[0].size;
             b.rank.identity_inverse = 1.0 / static_cast<double>(b.rank.identity_rows);
           }
@@ -3146,7 +3151,7 @@ static uint32_t device_cu_count();
 // (a multiple of the 8 XCDs), never more than there are tiles.
 static uint32_t stream_grid(uint32_t n_tiles, int workgroups_per_cu) {
   uint32_t per_cu = workgroups_per_cu > 0 ? static_cast<uint32_t>(workgroups_per_cu) : 1;
-  if (const char* env = getenv("HY_JOIN_WGS_PER_CU")) per_cu = static_cast<uint32_t>(atoi(env));
+  if (option(HY_OPT_JOIN_WGS_PER_CU) > 0) per_cu = static_cast<uint32_t>(option(HY_OPT_JOIN_WGS_PER_CU));
   const uint32_t resident = device_cu_count() * per_cu / 8 * 8;
   const uint32_t needed = 8 * (((n_tiles + 7) / 8 + STREAM_WAVES - 1) / STREAM_WAVES);   // a wave per tile of every XCD's share
   return std::max<uint32_t>(8, std::min<uint32_t>(resident, needed));
@@ -3163,6 +3168,7 @@ static thread_local int t_last_join_used_rank_table = 0;   // debug / tests: whi
 static thread_local int t_last_join_used_pkfk = 0;         // ... and whether the kernels of join_pkfk.hpp probed it
 static thread_local int t_last_join_hinted_attempt = 0;
 static thread_local int t_last_join_hinted = 0;            // ... 1: the build side was filled from the column's key hint, 2: that attempt was discarded and the join ran again
+static thread_local bool t_join_returned_async = false;    // run_join_once returned with its kernels queued (HY_JOIN_ASYNC)
 constexpr uint32_t JOIN_TRACE_TILES = 1u << 15;
 static uint64_t* g_join_trace = nullptr;
 static uint32_t g_join_trace_tiles = 0;
@@ -3189,7 +3195,7 @@ static bool lds_atomics_are_lane_ordered(hipStream_t stream) {
   int state = g_lds_atomic_order.load(std::memory_order_acquire);
   if (state == 0) {
     state = 2;
-    if (!getenv("HY_JOIN_NO_ORDERED_ATOMICS")) {
+    if (option(HY_OPT_JOIN_ORDERED_ATOMICS)) {
       uint32_t* failures = nullptr;
       if (hipMalloc(reinterpret_cast<void**>(&failures), 4) == hipSuccess) {
         uint32_t host = 1;
@@ -3258,24 +3264,23 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   // Will the probe side take the kernels of join_pkfk.hpp if the build side turns out to be a rank table?  (Everything that does not
   // depend on the build side: probe segments that SliceViews describe -- int32 values / FrameOfReference offsets, no NULLs, 16-byte
   // aligned --, counts and pair indices in 32 bits, lane-ordered LDS atomics.)
-  bool probe_views = !probe->is_reference && probe->n_slices > 0 && !getenv("HY_JOIN_NO_FETCH_AHEAD");
+  bool probe_views = !probe->is_reference && probe->n_slices > 0 && option(HY_OPT_JOIN_FETCH_AHEAD);
   for (uint32_t c = 0; c < probe->n_chunks && probe_views; ++c) {
     const hy_segment& seg = probe->host_segments[c];
     probe_views = !seg.nulls && reinterpret_cast<uintptr_t>(seg.data) % 16 == 0 &&
                   ((seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || seg.encoding == HY_ENC_FRAME_OF_REFERENCE);
   }
-  const bool probe_takes_pk = probe_views && hashed_type == 0 && n_secondary == 0 && probe->rows < 0xFFFF0000ull && !getenv("HY_JOIN_NO_PKFK") &&
+  const bool probe_takes_pk = probe_views && hashed_type == 0 && n_secondary == 0 && probe->rows < 0xFFFF0000ull && option(HY_OPT_JOIN_PKFK) &&
                               (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
   HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, semi_anti && n_secondary == 0, probe_takes_pk, b, stream));
   const bool rank_path = b.rank.entries != nullptr;
   // A rank table filled from the build column's key hint (rank_table_fill_checked) is confirmed when the join's kernels have finished:
   // if the column is not what the hint said, the hint is dropped, whatever the join wrote is discarded and the caller runs it again.
-  auto hint_confirmed = [&]() {
-    if (!b.hinted) return true;
-    const BuildVerdict* v = build_verdict_host();
-    const bool ok = v->done && !v->unsorted_signed && (!v->equal_neighbours || b.hint_allows_duplicates) && !v->outside_hint && v->key_min == b.hint_min && v->key_max == b.hint_max;
-    if (!ok) { build->join_hint.state.store(2, std::memory_order_release); *retry = true; }
-    return ok;
+  auto hint_confirmed = [&](const JoinMailbox* mailbox) {   // (after the stream synchronise that makes pk_plan's mailbox visible)
+    if (!b.hinted || !mailbox->build_unconfirmed) return true;
+    build->join_hint.state.store(2, std::memory_order_release);
+    *retry = true;
+    return false;
   };
   const bool fetch_ahead = rank_path && probe_views;   // pass 1 of the general rank-table kernels is the wave-per-tile kernel with wide loads
   t_last_join_used_rank_table = rank_path ? (b.rank.identity_rows ? 2 : 1) : 0;
@@ -3353,19 +3358,25 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     k.mailbox = mailbox_dev;
     k.capacity = count_only ? ~0ull : result->capacity;
     k.slice_capacity = count_only ? 0xFFFFFFFFu : result->slice_capacity;
-    k.plain_stores = 2;   // pk_copy_out: write-back stores for the lines a run shares with its neighbours, nontemporal ones in between
-    if (const char* env = getenv("HY_JOIN_STORES")) k.plain_stores = static_cast<uint32_t>(atoi(env));   // A/B: 0 nontemporal, 1 write-back
-    if (getenv("HY_JOIN_TRACE")) {
+    k.plain_stores = static_cast<uint32_t>(option(HY_OPT_JOIN_STORES));   // pk_copy_out: 2 = write-back stores for the lines a run shares with its neighbours, nontemporal ones in between
+    if (HY_DEBUG_ENV("HY_JOIN_TRACE")) {
       static uint64_t* trace_buffer = nullptr;
       if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 6 * JOIN_TRACE_TILES);
       if (n_tiles <= JOIN_TRACE_TILES) { k.trace = trace_buffer; g_join_trace = trace_buffer; g_join_trace_tiles = n_tiles; }
     }
     k.slice_offsets = dev_slice_offsets;
+    // HY_JOIN_ASYNC: no host round trip at all -- pk_plan leaves in device memory what the host would read from the mailbox
+    const bool async = !count_only && !host_result && (result->flags & HY_JOIN_ASYNC) && result->status;
+    k.status = async ? result->status : nullptr;
+    k.verdict = b.hinted ? b.verdict : nullptr;
+    k.hint_min = b.hint_min;
+    k.hint_max = b.hint_max;
+    k.hint_allows_duplicates = b.hint_allows_duplicates ? 1u : 0u;
     const uint32_t tile_grid = 8 * ((n_tiles + 7) / 8);
     // The build side staged in LDS (pk_count_lds, join_pkfk.hpp): a rank table over fewer than 2^20 key values, enough tiles for
     // persistent workgroups to pay for staging it once per CU.
     DeviceBuffer row_masks;
-    const bool build_in_lds = b.rank.range < PK_LDS_KEYS && partitions <= PK_LDS_MAX_PARTITIONS && n_tiles >= (getenv("HY_JOIN_LDS_BUILD_TILES") ? static_cast<uint32_t>(atoi(getenv("HY_JOIN_LDS_BUILD_TILES"))) : 2048u) && !getenv("HY_JOIN_NO_LDS_BUILD");   // (tests lower the bar)
+    const bool build_in_lds = b.rank.range < PK_LDS_KEYS && partitions <= PK_LDS_MAX_PARTITIONS && n_tiles >= static_cast<uint64_t>(option(HY_OPT_JOIN_LDS_BUILD_TILES)) && option(HY_OPT_JOIN_LDS_BUILD);   // (tests lower the bar)
     if (build_in_lds) {
       HY_TRY(row_masks.alloc(size_t{n_tiles} * (2 * PK_TILE / 8)));
       k.row_masks = row_masks.as<uint8_t>();
@@ -3391,7 +3402,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     clock.mark("pass 1 launched");
     if (count_only) {
       HY_HIP(hipStreamSynchronize(stream));
-      if (!hint_confirmed()) return HY_OK;
+      if (!hint_confirmed(mailbox)) return HY_OK;
       if (count_out) *count_out = mailbox->n_pairs;
       return HY_OK;
     }
@@ -3436,9 +3447,13 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       }
       if (mailbox->fits) HY_HIP(hipMemcpyAsync(result->slice_offsets, dev_slice_offsets, 8 * (size_t{mailbox->n_slices} + 1), hipMemcpyDeviceToHost, stream));
     }
+    if (async) {   // the temporaries go back to this thread's pool: whatever takes them next is queued behind these kernels on the same stream
+      t_join_returned_async = true;
+      return HY_OK;
+    }
     HY_HIP(hipStreamSynchronize(stream));   // the temporaries above are freed on return
     clock.mark("pass 2 done");
-    if (!hint_confirmed()) return HY_OK;
+    if (!hint_confirmed(mailbox)) return HY_OK;
     result->n_slices = mailbox->n_slices;
     result->n_pairs = mailbox->n_pairs;
     if (mailbox->n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %u output PosLists, slice capacity is %u", mailbox->n_slices, result->slice_capacity);
@@ -3468,7 +3483,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   a.dir = b.directory;
   a.rank = b.rank;
   a.trace = nullptr;
-  if (getenv("HY_JOIN_TRACE")) {
+  if (HY_DEBUG_ENV("HY_JOIN_TRACE")) {
     static uint64_t* trace_buffer = nullptr;
     if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 6 * JOIN_TRACE_TILES);
     if (n_tiles <= JOIN_TRACE_TILES) { a.trace = trace_buffer; g_join_trace = trace_buffer; g_join_trace_tiles = n_tiles; }
@@ -3568,7 +3583,6 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   clock.mark("pass 1 launched");
   if (count_only) {
     HY_HIP(hipStreamSynchronize(stream));
-    if (!hint_confirmed()) return HY_OK;
     if (mailbox->error) return fail(HY_ERR_UNSUPPORTED, "a probe row matches more than 4 194 303 build rows");   // (pass 1 clamped its count)
     if (count_out) *count_out = mailbox->n_pairs;
     return HY_OK;
@@ -3612,7 +3626,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(probe_emit_cached), JOIN_THREADS, 4 * probe_emit_cached_lds_words(partitions)));
       workgroups_per_cu = per_cu > 0 ? static_cast<uint32_t>(per_cu) : 1;
     }
-    if (const char* env = getenv("HY_JOIN_WGS_PER_CU")) workgroups_per_cu = static_cast<uint32_t>(atoi(env));
+    if (option(HY_OPT_JOIN_WGS_PER_CU) > 0) workgroups_per_cu = static_cast<uint32_t>(option(HY_OPT_JOIN_WGS_PER_CU));
     // persistent workgroups: as many as fit the device at once (a multiple of the 8 XCDs), never more than tiles
     const uint32_t resident = device_cu_count() * workgroups_per_cu / 8 * 8;
     const uint32_t cached_grid = std::max<uint32_t>(8, std::min<uint32_t>(resident, probe_grid(n_tiles)));
@@ -3639,7 +3653,6 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   }
   HY_HIP(hipStreamSynchronize(stream));   // the temporaries above are freed on return
   clock.mark("pass 2 done");
-  if (!hint_confirmed()) return HY_OK;
   result->n_slices = mailbox->n_slices;
   result->n_pairs = mailbox->n_pairs;
   if (mailbox->n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %u output PosLists, slice capacity is %u", mailbox->n_slices, result->slice_capacity);
@@ -3652,6 +3665,7 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
                           const hy_join_predicate* secondary = nullptr, uint32_t n_secondary = 0) {
   const uint32_t radix_bits = result ? result->radix_bits : 0;   // (the first attempt overwrites the caller's request with what it used)
   bool retry = false;
+  t_join_returned_async = false;
   hy_status status = run_join_once(left, right, mode, result, count_only, count_out, secondary, n_secondary, &retry);
   t_last_join_hinted = t_last_join_hinted_attempt ? 1 : 0;
   if (status == HY_OK && retry) {   // the build column's key hint did not hold: it is dropped now, the two-pass build runs
@@ -3659,6 +3673,11 @@ static hy_status run_join(const hy_column* left, const hy_column* right, uint32_
     retry = false;
     status = run_join_once(left, right, mode, result, count_only, count_out, secondary, n_secondary, &retry);
     t_last_join_hinted = 2;
+  }
+  // HY_JOIN_ASYNC on a shape that ran synchronously: the status block is filled all the same (a following kernel may read it)
+  if (result && !count_only && result->mem == HY_MEM_DEVICE && (result->flags & HY_JOIN_ASYNC) && result->status && !t_join_returned_async &&
+      (status == HY_OK || status == HY_ERR_CAPACITY)) {
+    hipLaunchKernelGGL(publish_join_status, dim3(1), dim3(1), 0, current_stream(), result->status, result->n_pairs, result->n_slices, status == HY_OK ? 1u : 0u);
   }
   return status;
 }
@@ -3676,6 +3695,43 @@ hy_status hy_join_hash(const hy_column* left, const hy_column* right, uint32_t m
   HY_TRY(plain_column(left, &left));   // (run-length / bit-packed segments: the decoded twin, hy_device.hpp)
   HY_TRY(plain_column(right, &right));
   return run_join(left, right, mode, result, false, nullptr);
+}
+
+hy_status hy_join_hash_finish(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result) {
+  if (!left || !right || !result) return fail(HY_ERR_INVALID, "hy_join_hash_finish: null argument");
+  if (!(result->flags & HY_JOIN_ASYNC) || !result->status || result->mem != HY_MEM_DEVICE) return HY_OK;
+  HY_TRY(on_this_device(left, "hy_join_hash_finish"));
+  HY_TRY(on_this_device(right, "hy_join_hash_finish"));
+  hipStream_t stream = current_stream();
+  void* host = nullptr;
+  void* device = nullptr;
+  HY_TRY(pinned_staging(sizeof(hy_join_status), &host, &device));
+  HY_HIP(hipMemcpyAsync(host, result->status, sizeof(hy_join_status), hipMemcpyDeviceToHost, stream));
+  HY_HIP(hipStreamSynchronize(stream));
+  const hy_join_status seen = *static_cast<const hy_join_status*>(host);
+  if (!seen.build_confirmed) {   // the build column contradicted its key hint: nothing was written -- drop the hint, run the join again (two-pass build)
+    HY_TRY(plain_column(left, &left));
+    HY_TRY(plain_column(right, &right));
+    const bool build_right = mode == HY_JOIN_LEFT || mode == HY_JOIN_ANTI_NULL_AS_TRUE || mode == HY_JOIN_ANTI_NULL_AS_FALSE || mode == HY_JOIN_SEMI ||
+                             (mode == HY_JOIN_INNER && left->rows > right->rows);   // (side selection of run_join_once)
+    (build_right ? right : left)->join_hint.state.store(2, std::memory_order_release);
+    const uint32_t flags = result->flags;
+    result->flags = flags & ~HY_JOIN_ASYNC;   // (radix_bits: the first attempt left the value it used)
+    const hy_status status = run_join(left, right, mode, result, false, nullptr);
+    result->flags = flags;
+    t_last_join_hinted = 2;
+    if (status == HY_OK || status == HY_ERR_CAPACITY) {
+      hipLaunchKernelGGL(publish_join_status, dim3(1), dim3(1), 0, stream, result->status, result->n_pairs, result->n_slices, status == HY_OK ? 1u : 0u);
+      HY_HIP(hipStreamSynchronize(stream));
+    }
+    return status;
+  }
+  result->n_pairs = seen.n_pairs;
+  result->n_slices = seen.n_slices;
+  if (seen.error) return fail(HY_ERR_UNSUPPORTED, "a probe row matches more than 4 194 303 build rows");
+  if (seen.n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %u output PosLists, slice capacity is %u", seen.n_slices, result->slice_capacity);
+  if (seen.n_pairs > result->capacity) return fail(HY_ERR_CAPACITY, "join produces %llu pairs, capacity is %llu", static_cast<unsigned long long>(seen.n_pairs), static_cast<unsigned long long>(result->capacity));
+  return HY_OK;
 }
 
 hy_status hy_join_hash_predicates(const hy_column* left, const hy_column* right, uint32_t mode, const hy_join_predicate* secondary, uint32_t n_secondary,

@@ -77,6 +77,12 @@ struct PkArgs {
   // The build side staged in LDS (pk_count_lds): a rank table of at most PK_LDS_KEYS key values -- a filtered dimension of a star join --
   // is 128 KB of presence bits; pass 1 looks every probe row up THERE and leaves two bits per row behind for pass 2.
   uint8_t* row_masks;              // [n_tiles][2][PK_TILE / 8] found | materialised, or nullptr (the classic kernels)
+  // A build side filled on the strength of the column's key hint (rank_table_fill_checked): pk_plan confirms the fill's verdict
+  // against the hint -- a column that contradicts it gets the plan "does not fit": nothing is written, the host runs the join again.
+  const BuildVerdict* verdict;     // nullptr: the build side was not hinted
+  uint64_t hint_min, hint_max;
+  uint32_t hint_allows_duplicates;
+  hy_join_status* status;          // HY_JOIN_ASYNC: what the host would read from the mailbox, in device memory; else nullptr
 };
 constexpr uint32_t PK_LDS_KEYS = 1u << 20;                       // the table's range must be smaller: then the Bloom filter (bit = key & 0xFFFFF) is the presence bit
 constexpr uint32_t PK_LDS_WORDS = PK_LDS_KEYS / 32;              // 32 768 presence words = 128 KB
@@ -331,14 +337,28 @@ __device__ void pk_plan(const PkArgs& a, uint64_t* s_tmp, uint32_t tid) {
     if (tid == 0) { a.origin_pairs[0] = 0; a.origin_pairs[1] = n_pairs; a.slice_base[a.n_groups] = n_slices; }
   }
   if (tid == 0) {
-    const uint32_t fits = n_pairs <= a.capacity && n_slices <= a.slice_capacity ? 1u : 0u;
+    bool confirmed = true;
+    if (a.verdict) {   // (written by an earlier kernel of this stream)
+      const BuildVerdict v = *a.verdict;
+      confirmed = v.done && !v.unsorted_signed && (!v.equal_neighbours || a.hint_allows_duplicates) && !v.outside_hint && v.key_min == a.hint_min && v.key_max == a.hint_max;
+    }
+    const uint32_t fits = confirmed && n_pairs <= a.capacity && n_slices <= a.slice_capacity ? 1u : 0u;
     a.plan->fits = fits;
     a.plan->n_slices = n_slices;
     if (fits && a.slice_offsets) a.slice_offsets[n_slices] = n_pairs;
+    if (a.status) {
+      a.status->n_pairs = n_pairs;
+      a.status->n_slices = n_slices;
+      a.status->fits = fits;
+      a.status->build_confirmed = confirmed ? 1u : 0u;
+      a.status->error = 0;
+      a.status->reserved = 0;
+    }
     a.mailbox->n_pairs = n_pairs;
     a.mailbox->n_slices = n_slices;
     a.mailbox->n_uncached = 0;
     a.mailbox->fits = fits;
+    a.mailbox->build_unconfirmed = confirmed ? 0u : 1u;
     __threadfence_system();
   }
 }

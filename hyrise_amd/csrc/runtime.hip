@@ -12,6 +12,37 @@
 namespace hy {
 
 static thread_local std::string t_error;
+// The options of include/hyrise_amd.h (HY_OPT_*) with their defaults; hy_set_option stores, the operators load (hy_options.hpp).
+std::atomic<int64_t> g_options[HY_OPT_COUNT];
+namespace {
+struct OptionDefaults {
+  OptionDefaults() {
+    for (auto& v : g_options) v.store(0, std::memory_order_relaxed);
+    auto set = [](uint32_t id, int64_t v) { g_options[id].store(v, std::memory_order_relaxed); };
+    set(HY_OPT_SCAN_WGS_PER_CU, 8);
+    set(HY_OPT_JOIN_RANK_TABLE, 1);
+    set(HY_OPT_JOIN_IDENTITY, 1);
+    set(HY_OPT_JOIN_HINT, 1);
+    set(HY_OPT_JOIN_FETCH_AHEAD, 1);
+    set(HY_OPT_JOIN_PKFK, 1);
+    set(HY_OPT_JOIN_LDS_BUILD, 1);
+    set(HY_OPT_JOIN_LDS_BUILD_TILES, 2048);
+    set(HY_OPT_JOIN_ORDERED_ATOMICS, 1);
+    set(HY_OPT_JOIN_STORES, 2);
+    set(HY_OPT_AGG_PARTITIONS, 1);
+    set(HY_OPT_AGG_SPILL_SHIFT, 3);
+    set(HY_OPT_AGG_LDS_BUDGET, 32768);
+    set(HY_OPT_AGG_SMALL_DOMAIN, 1);
+    set(HY_OPT_AGG_JOINT_HISTOGRAM, 1);
+    set(HY_OPT_FUSED_SMALL_DOMAIN, 1);
+    set(HY_OPT_FUSED_SHARED_PREFIX, 1);
+    set(HY_OPT_JOIN_LDS_HASH, 1);
+    set(HY_OPT_HOST_RESULT_TILES, 1);
+  }
+};
+OptionDefaults g_option_defaults;   // (static initialisation: before any entry point can run)
+}  // namespace
+
 static thread_local hipStream_t t_stream = nullptr;
 static thread_local Scratch t_scratch;
 
@@ -261,6 +292,18 @@ hy_status hy_device_count(int32_t* count) {
   return HY_OK;
 }
 
+hy_status hy_set_option(uint32_t option_id, int64_t value) {
+  if (option_id >= HY_OPT_COUNT) return fail(HY_ERR_INVALID, "hy_set_option: no option %u", option_id);
+  g_options[option_id].store(value, std::memory_order_relaxed);
+  return HY_OK;
+}
+
+hy_status hy_get_option(uint32_t option_id, int64_t* value) {
+  if (option_id >= HY_OPT_COUNT || !value) return fail(HY_ERR_INVALID, "hy_get_option: no option %u", option_id);
+  *value = option(option_id);
+  return HY_OK;
+}
+
 hy_status hy_init(int32_t device) {
   int n = 0;
   HY_HIP(hipGetDeviceCount(&n));
@@ -271,7 +314,7 @@ hy_status hy_init(int32_t device) {
   t_bound_device = device;
   hipDeviceProp_t prop;
   HY_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("HY_ALLOW_ANY_ARCH")) {
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !option(HY_OPT_ALLOW_ANY_ARCH)) {
     return fail(HY_ERR_DEVICE, "hy_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                 prop.gcnArchName);
   }
@@ -562,7 +605,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   std::vector<Slice> slices;
   std::vector<Part> parts;
   uint32_t part_slices = PART_SLICES;   // slices per part: one Hyrise chunk (65 535 rows) = one part = one workgroup
-  if (const char* env = getenv("HY_PART_SLICES")) part_slices = static_cast<uint32_t>(atoi(env));
+  if (option(HY_OPT_PART_SLICES) > 0) part_slices = static_cast<uint32_t>(option(HY_OPT_PART_SLICES));
   if (part_slices < 1) part_slices = 1;
   if (part_slices > PART_SLICES) part_slices = PART_SLICES;
   for (uint32_t c = 0; c < n_chunks; ++c) {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HY_ABI_VERSION 2   /* 2: hy_segment carries sorted_by and bits */
+#define HY_ABI_VERSION 3   /* 2: hy_segment carries sorted_by and bits; 3: hy_join_result flags / status (HY_JOIN_ASYNC), hy_set_option */
 
 typedef int32_t hy_status;
 enum {
@@ -223,6 +223,43 @@ hy_status hy_profile_read_kernel(uint32_t kernel, float* total_milliseconds, uin
  * empty kernel, median of 32 launches, measured once per process.  A profiler's per-kernel duration is shorter by about this much. */
 hy_status hy_profile_event_overhead(float* milliseconds);
 
+/* ---- options: which of several equivalent paths / launch shapes an operator takes ---------------------------------------------
+ * Process-wide integers with the defaults below.  EVERY setting produces the same results: the tests force each path with them and
+ * compare it with the oracle, the tools time one path against another in one process.  The library reads no environment variable
+ * (a build with -DHY_DEBUG_SWITCHES adds the trace / timing / parts-switched-off aids of DESIGN.md section 6; release builds do not
+ * contain them). */
+enum {
+  HY_OPT_ALLOW_ANY_ARCH = 0,         /* 0    hy_init accepts a device that is not gfx950 (nothing is tuned for it)                    */
+  HY_OPT_SCAN_WGS_PER_CU = 1,        /* 8    resident scan workgroups per CU (upper bound)                                            */
+  HY_OPT_SCAN_NT_STORES = 2,         /* 0    scan_slices writes its RowIDs with nontemporal instead of write-back stores              */
+  HY_OPT_PART_SLICES = 3,            /* 0    slices per scan part, 0 = one part per chunk                                             */
+  HY_OPT_JOIN_RANK_TABLE = 4,        /* 1    unique dense-ish integer build keys get a rank table                                     */
+  HY_OPT_JOIN_IDENTITY = 5,          /* 1    ... read in place when the build column is sorted (rank = row number)                    */
+  HY_OPT_JOIN_HINT = 6,              /* 1    later joins over a resident build column fill the table in one checked pass              */
+  HY_OPT_JOIN_BREAK_HINT = 7,        /* 0    tests: hand the checked fill a hint that does not hold (the join must notice and rerun)   */
+  HY_OPT_JOIN_FETCH_AHEAD = 8,       /* 1    probe segments read through SliceViews (wide loads)                                      */
+  HY_OPT_JOIN_PKFK = 9,              /* 1    the primary-key / foreign-key probe kernels (join_pkfk.hpp)                              */
+  HY_OPT_JOIN_LDS_BUILD = 10,        /* 1    rank tables below 2^20 key values are staged in LDS ...                                  */
+  HY_OPT_JOIN_LDS_BUILD_TILES = 11,  /* 2048 ... from this many probe tiles on                                                        */
+  HY_OPT_JOIN_ORDERED_ATOMICS = 12,  /* 1    rank pairs with one returning LDS atomic each where the LDS serves lanes in order         */
+  HY_OPT_JOIN_STORES = 13,           /* 2    pk_emit's stores: 0 nontemporal, 1 write-back, 2 write-back for the lines runs share      */
+  HY_OPT_JOIN_WGS_PER_CU = 14,       /* 0    probe workgroups per CU of the persistent probe kernels, 0 = what the occupancy query says */
+  HY_OPT_AGG_PARTITIONS = 15,        /* 1    many groups take the hash-partitioned path                                               */
+  HY_OPT_AGG_PARTITION_BITS = 16,    /* 0    partition bits of that path, 0 = derived from the row count; > 0 also forces the path     */
+  HY_OPT_AGG_SPILL_SHIFT = 17,       /* 3    aggregate_rows gives up when rows >> shift left its LDS tables                           */
+  HY_OPT_AGG_LDS_BUDGET = 18,        /* 32768 bytes of LDS a partition table may take                                                 */
+  HY_OPT_AGG_SPLIT = 19,             /* 0    workgroups per partition, 0 = derived                                                    */
+  HY_OPT_AGG_SMALL_DOMAIN = 20,      /* 1    aggregate_small_domain for the shapes it accepts                                         */
+  HY_OPT_AGG_JOINT_HISTOGRAM = 21,   /* 1    ... with two 1-byte measure columns counted in one pair histogram                        */
+  HY_OPT_FUSED_SMALL_DOMAIN = 22,    /* 1    fused_small_domain for the shapes it accepts                                             */
+  HY_OPT_FUSED_SHARED_PREFIX = 23,   /* 1    fused inputs that begin with an earlier input continue on its stack                      */
+  HY_OPT_JOIN_LDS_HASH = 24,         /* 1    general builds (duplicates, unsorted, sparse, float keys): radix partitions + LDS hash tables */
+  HY_OPT_HOST_RESULT_TILES = 25,     /* 1    host-memory results leave through pinned staging tiles that overlap the kernels          */
+  HY_OPT_COUNT = 32
+};
+hy_status hy_set_option(uint32_t option, int64_t value);
+hy_status hy_get_option(uint32_t option, int64_t* value);
+
 /* ---- several GPUs in one process, and the collectives between them (csrc/comm.hip: RCCL over xGMI) ----------------------------
  * Hyrise is one process whose operators run on scheduler workers (scheduler/operator_task.cpp:163-200): the multi-GPU shape is one
  * worker thread per GPU.  hy_bind_device makes the CALLING thread work on `device` (its stream, pools and every column it creates
@@ -350,8 +387,26 @@ typedef struct hy_join_result {
   uint32_t n_slices;              /* out */
   uint64_t n_pairs;               /* out */
   uint32_t left_is_build;         /* out: JoinHash::PerformanceData::left_input_is_build_side                          */
-  uint32_t reserved;
+  uint32_t flags;                 /* in: HY_JOIN_ASYNC or 0                                                            */
+  struct hy_join_status* status;  /* in: HY_JOIN_ASYNC: device memory the join's last planning kernel writes; else unused */
 } hy_join_result;
+
+/* HY_JOIN_ASYNC (mem == HY_MEM_DEVICE only): the call returns as soon as the join's kernels are queued on the calling thread's
+ * stream -- no host round trip, so a chain (the next scan, the next join) is queued while this one runs.  What the host normally
+ * learns -- the pair count, the number of output PosLists, whether they fit the capacities (a join that does not fit writes
+ * nothing), whether the build column still is what its key hint said (hy_join_hash below; if not, nothing is written either) --
+ * goes to `status` in DEVICE memory, where a following kernel can read it; n_pairs / n_slices of the result are NOT valid until
+ * hy_join_hash_finish has run.  Shapes whose build side needs a host decision (the first join over a column, duplicate or unsorted
+ * build keys) run synchronously as always and fill `status` at the end: the flag is a permission, not a promise. */
+#define HY_JOIN_ASYNC 1u
+typedef struct hy_join_status {
+  uint64_t n_pairs;
+  uint32_t n_slices;
+  uint32_t fits;                  /* 1: n_pairs <= capacity and n_slices <= slice_capacity, the PosLists are written        */
+  uint32_t build_confirmed;       /* 0: the build column contradicted its key hint -- hy_join_hash_finish runs the join again */
+  uint32_t error;                 /* a probe row with more than 4 194 303 partners (HY_ERR_UNSUPPORTED)                      */
+  uint64_t reserved;
+} hy_join_status;
 
 /* Equi-join of two numeric columns (int32 / int64 / float / double, any two: both sides are cast to JoinHashTraits'
  * HashedType first, join_hash_traits.hpp:15-40 -- the larger integer type, the larger floating type, or THE floating
@@ -367,6 +422,11 @@ typedef struct hy_join_result {
  * n_pairs and n_slices report what the join needs.  With mem = HY_MEM_DEVICE the PosLists stay in HBM for the next
  * operator and the call makes no host round trip between the passes. */
 hy_status hy_join_hash(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result);
+/* Completes a HY_JOIN_ASYNC join (same arguments): waits for the calling thread's stream, reads result->status, fills n_pairs /
+ * n_slices and returns what the synchronous call would have returned (HY_ERR_CAPACITY with the needed sizes; a build column that
+ * contradicted its hint: the hint is dropped and the join runs again, synchronously, before this call returns).  A no-op for a
+ * result without the flag. */
+hy_status hy_join_hash_finish(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result);
 
 /* A secondary join predicate  left_column <condition> right_column  (OperatorJoinPredicate, operator_join_predicate.hpp;
  * evaluated like MultiPredicateJoinEvaluator::satisfies_all_predicates, multi_predicate_join_evaluator.hpp:44-54, on every

@@ -195,11 +195,10 @@ def aggregate_path():
 
 
 @pytest.fixture
-def forced_partitions():
-    """HY_AGG_PARTITION_BITS: every aggregate of the test runs the partitioned path (partition -> LDS tables -> one merge)."""
-    os.environ["HY_AGG_PARTITION_BITS"] = "3"
+def forced_partitions(options):
+    """HY_OPT_AGG_PARTITION_BITS: every aggregate of the test runs the partitioned path (partition -> LDS tables -> one merge)."""
+    options.set(abi.OPT_AGG_PARTITION_BITS, 3)
     yield
-    del os.environ["HY_AGG_PARTITION_BITS"]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"L{c['line']}" for c in CASES])
@@ -234,10 +233,10 @@ def test_many_groups_take_the_partitioned_path(device, n_groups, expected_path):
     assert aggregate_path() == expected_path
 
 
-def test_partitions_with_more_groups_than_their_tables(device):
+def test_partitions_with_more_groups_than_their_tables(device, options):
     """Every row its own group at 2^3 forced partitions: the partitions' LDS tables overflow, the rows go to the global table
     directly, the path gives up and partitions more finely -- the result is the same."""
-    os.environ["HY_AGG_PARTITION_BITS"] = "3"
+    options.set(abi.OPT_AGG_PARTITION_BITS, 3)
     try:
         n = 200_000
         keys = np.random.default_rng(4).permutation(n).astype(np.int32) * 13
@@ -245,7 +244,7 @@ def test_partitions_with_more_groups_than_their_tables(device):
         got = run_both([build_column(keys, None, 65535, abi.ENC_UNENCODED)], [(abi.AGG_SUM, build_column(values, None, 65535, abi.ENC_UNENCODED)), (abi.AGG_COUNT, None)])
         assert got.n_groups == n and aggregate_path() == 14
     finally:
-        del os.environ["HY_AGG_PARTITION_BITS"]
+        options.reset()
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"L{c['line']}" for c in CASES])
@@ -280,11 +279,11 @@ def used_small_domain():
     return lib.hy_debug_aggregate_small_domain()
 
 
-def test_small_domain_kernel(device, monkeypatch):
+def test_small_domain_kernel(device, options):
     """aggregate_small_domain (csrc/aggregate_small.hpp): a handful of groups over dictionary GROUP BY columns, SUM / AVG / COUNT over
     dictionary-encoded float / double columns with 1- and 2-byte value ids -- the TPC-H Q1 shape.  Against the oracle: 1 - 3 GROUP BY
     columns, NULLs in keys and inputs, more than four groups per chunk (the shared-cell path), ragged chunks, one-row chunks, and
-    the same answers as the generic kernel (HY_AGG_NO_SMALL_DOMAIN)."""
+    the same answers as the generic kernel (HY_OPT_AGG_SMALL_DOMAIN = 0)."""
     rng = np.random.default_rng(91)
     for n, chunk in ((200_000, 65535), (70_001, 8192), (5, 2), (40_000, 40_000), (150_000, 100_000)):   # (the last: chunks of more than one 65520-row span)
         flags = rng.integers(0, 3, n).astype(np.int32)                       # 3 distinct
@@ -316,9 +315,9 @@ def test_small_domain_kernel(device, monkeypatch):
             inputs = {id(c): c.segments[0].width for _, c in aggregates if c is not None}
             narrow, wide = sum(1 for v in inputs.values() if v == 1), sum(1 for v in inputs.values() if v == 2)
             assert used_small_domain() == (1 if widths <= {1, 2} and codes <= 16 and narrow <= 2 and wide <= 1 and len(groupby) <= 2 else 0), context
-            monkeypatch.setenv("HY_AGG_NO_SMALL_DOMAIN", "1")
+            options.set(abi.OPT_AGG_SMALL_DOMAIN, 0)
             generic = run_both(groupby, aggregates, context + " (generic kernel)")
-            monkeypatch.delenv("HY_AGG_NO_SMALL_DOMAIN")
+            options.reset(abi.OPT_AGG_SMALL_DOMAIN)
             assert used_small_domain() == 0
             np.testing.assert_array_equal(got.row_ids[:got.n_groups], generic.row_ids[:generic.n_groups])
     # a 2-byte column's value that sixteen rows of one group share inside one chunk: its 4-bit counter overflows, the kernel notices

@@ -88,11 +88,11 @@ def test_what_the_kernel_refuses_falls_back(device):
             assert_matches_chain(got, chain, len(plan.aggregates), f"plan {plan.name}, {what}")
 
 
-def test_the_switch_that_turns_the_kernel_off(device, monkeypatch):
+def test_the_switch_that_turns_the_kernel_off(device, options):
     lib = abi.load_library()
     hosts = table(25_000, 10_000)
     plan = plans()[0]
-    monkeypatch.setenv("HY_FUSED_NO_SMALL_DOMAIN", "1")
+    options.set(abi.OPT_FUSED_SMALL_DOMAIN, 0)
     got, kernel = run(lib, hosts, plan)
     assert kernel == 0
     assert_matches_chain(got, oracle_chain(*plan.on(hosts)), len(plan.aggregates), "fused_rows")

@@ -197,6 +197,100 @@ def test_join_device_memory_result_equals_host_memory_result(device, mode):
         device.hy_device_free(p)
 
 
+def test_join_async_leaves_its_status_on_the_device(device, options):
+    """HY_JOIN_ASYNC: the call returns with its kernels queued, the pair count / PosList count / fit flag / hint verdict go to
+    hy_join_status in device memory and hy_join_hash_finish reports what the synchronous call reports.  Three joins are queued back
+    to back before the first finish (the temporaries of one are the next one's, in stream order); a shape that needs a host decision
+    (duplicate build keys) runs synchronously under the flag and fills the status all the same; a result that does not fit writes
+    nothing; a build column that contradicts its hint writes nothing and finish runs the join again."""
+    rng = np.random.default_rng(77)
+    keys = (np.arange(120_000, dtype=np.int32) * 3 + 7)
+    build_host = build_column(keys, None, 65535, abi.ENC_UNENCODED)
+    probe_host = build_column(np.sort(rng.integers(0, 360_100, 700_000).astype(np.int32)), None, 65535, abi.ENC_FRAME_OF_REFERENCE)
+    duplicate_host = build_column(np.repeat(np.arange(50_000, dtype=np.int32), 2), None, 65535, abi.ENC_UNENCODED)
+    build, probe, duplicate = DeviceColumn(build_host), DeviceColumn(probe_host), DeviceColumn(duplicate_host)
+    want = join_hash(build, probe, abi.JOIN_INNER)          # (the first join over `build`: leaves the key hint behind)
+    n, slices = want.n_pairs, int(want.c.n_slices)
+
+    class Run:
+        def __init__(self, left, right, capacity, slice_capacity):
+            self.left, self.right = left, right
+            self.p_left, self.like = _device_buffer(device, (capacity + 8, 2), np.uint32, 0xABABABAB)
+            self.p_right, _ = _device_buffer(device, (capacity + 8, 2), np.uint32, 0xABABABAB)
+            self.p_offsets, self.like_offsets = _device_buffer(device, (slice_capacity + 8,), np.uint64, 0xCDCDCDCDCDCDCDCD)
+            self.p_status, self.like_status = _device_buffer(device, (4,), np.uint64, 0xEEEEEEEEEEEEEEEE)
+            r = abi.JoinResult()
+            r.mem, r.radix_bits, r.flags, r.status = abi.MEM_DEVICE, 0xFFFFFFFF, abi.JOIN_ASYNC, self.p_status
+            r.left_pos, r.right_pos, r.capacity = self.p_left, self.p_right, capacity
+            r.slice_offsets, r.slice_capacity = self.p_offsets, slice_capacity
+            self.r = r
+
+        def start(self):
+            return device.hy_join_hash(self.left.handle, self.right.handle, abi.JOIN_INNER, C.byref(self.r))
+
+        def finish(self):
+            return device.hy_join_hash_finish(self.left.handle, self.right.handle, abi.JOIN_INNER, C.byref(self.r))
+
+        def pairs(self):
+            return _read_back(device, self.p_left, self.like), _read_back(device, self.p_right, self.like), _read_back(device, self.p_offsets, self.like_offsets)
+
+        def status(self):
+            words = _read_back(device, self.p_status, self.like_status)
+            return int(words[0]), int(words[1] & 0xFFFFFFFF), int(words[1] >> 32), int(words[2] & 0xFFFFFFFF), int(words[2] >> 32)   # n_pairs, n_slices, fits, build_confirmed, error
+
+        def free(self):
+            for p in (self.p_left, self.p_right, self.p_offsets, self.p_status):
+                device.hy_device_free(p)
+
+    runs = [Run(build, probe, n, slices) for _ in range(3)]
+    for run in runs:
+        abi.check(run.start())
+        assert device.hy_debug_join_build_was_hinted() == 1 and device.hy_debug_join_used_pkfk() == 1
+    for run in runs:
+        abi.check(run.finish())
+        assert int(run.r.n_pairs) == n and int(run.r.n_slices) == slices
+        assert run.status() == (n, slices, 1, 1, 0)
+        got_left, got_right, got_offsets = run.pairs()
+        assert got_left[:n].tobytes() == want.left[:n].tobytes() and got_right[:n].tobytes() == want.right[:n].tobytes()
+        assert got_offsets[:slices + 1].tobytes() == want.slice_offsets[:slices + 1].tobytes()
+        assert (got_left[n:] == 0xABABABAB).all() and (got_right[n:] == 0xABABABAB).all()
+        run.free()
+    # does not fit: nothing written, finish reports the needed sizes
+    small = Run(build, probe, n - 1, slices)
+    abi.check(small.start())
+    assert small.finish() == abi.ERR_CAPACITY and int(small.r.n_pairs) == n
+    assert small.status()[:3] == (n, slices, 0)
+    got_left, got_right, got_offsets = small.pairs()
+    assert (got_left == 0xABABABAB).all() and (got_right == 0xABABABAB).all() and (got_offsets == 0xCDCDCDCDCDCDCDCD).all()
+    small.free()
+    # duplicate build keys: the sorted directory needs host decisions -- synchronous under the flag, status filled all the same
+    want_duplicate = join_hash(duplicate, probe, abi.JOIN_INNER)
+    m, m_slices = want_duplicate.n_pairs, int(want_duplicate.c.n_slices)
+    sync = Run(duplicate, probe, m, m_slices)
+    abi.check(sync.start())
+    assert int(sync.r.n_pairs) == m          # (already known: the call was synchronous)
+    abi.check(sync.finish())
+    assert sync.status() == (m, m_slices, 1, 1, 0)
+    got_left, got_right, _ = sync.pairs()
+    assert got_left[:m].tobytes() == want_duplicate.left[:m].tobytes() and got_right[:m].tobytes() == want_duplicate.right[:m].tobytes()
+    sync.free()
+    # a hint that does not hold: the device notices (nothing written, build_confirmed = 0), finish drops the hint and runs the join again
+    options.set(abi.OPT_JOIN_BREAK_HINT, 1)
+    broken = Run(build, probe, n, slices)
+    abi.check(broken.start())
+    device.hy_synchronize()
+    assert broken.status()[2:4] == (0, 0)
+    got_left, _, _ = broken.pairs()
+    assert (got_left == 0xABABABAB).all()
+    abi.check(broken.finish())
+    assert device.hy_debug_join_build_was_hinted() == 2 and int(broken.r.n_pairs) == n
+    assert broken.status() == (n, slices, 1, 1, 0)
+    got_left, got_right, got_offsets = broken.pairs()
+    assert got_left[:n].tobytes() == want.left[:n].tobytes() and got_right[:n].tobytes() == want.right[:n].tobytes()
+    assert got_offsets[:slices + 1].tobytes() == want.slice_offsets[:slices + 1].tobytes()
+    broken.free()
+
+
 @pytest.mark.parametrize("mem", [abi.MEM_HOST, abi.MEM_DEVICE])
 def test_join_capacity_errors_leave_the_buffers_alone(device, mem):
     """A result that does not fit is HY_ERR_CAPACITY with the needed sizes reported -- decided on the device between the
@@ -526,9 +620,9 @@ def test_join_rank_table_int64_and_reference_build(device):
         assert used_rank_table() == 1
 
 
-def test_join_rank_table_falls_back(device, monkeypatch):
+def test_join_rank_table_falls_back(device, options):
     """Duplicate build keys (found while the table is marked) and sparse key ranges use the sorted directory; so does
-    HY_JOIN_NO_RANK_TABLE, with identical results."""
+    HY_OPT_JOIN_RANK_TABLE = 0, with identical results."""
     rng = np.random.default_rng(5)
     keys = rng.permutation(np.arange(3000, dtype=np.int32))
     keys[17] = keys[2900]   # one duplicate, far apart
@@ -542,7 +636,7 @@ def test_join_rank_table_falls_back(device, monkeypatch):
     unique = build_column(np.arange(3000, dtype=np.int32), None, 500, abi.ENC_UNENCODED)
     a = check(unique, probe, abi.JOIN_INNER, 2, "rank table")
     assert used_rank_table() == 2
-    monkeypatch.setenv("HY_JOIN_NO_RANK_TABLE", "1")
+    options.set(abi.OPT_JOIN_RANK_TABLE, 0)
     b = check(unique, probe, abi.JOIN_INNER, 2, "directory")
     assert used_rank_table() == 0
     assert a.left[:a.n_pairs].tobytes() == b.left[:b.n_pairs].tobytes() and a.right[:a.n_pairs].tobytes() == b.right[:b.n_pairs].tobytes()
@@ -604,16 +698,16 @@ def used_pkfk():
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("build_in_lds", [False, True], ids=["table_in_l2", "bits_in_lds"])
-def test_primary_key_foreign_key_probe(device, mode, build_in_lds, monkeypatch):
+def test_primary_key_foreign_key_probe(device, mode, build_in_lds, options):
     """The kernels of csrc/join_pkfk.hpp (pk_count / pk_scan / pk_emit / pk_cuts: 8192-row tiles, one launch for scan and plan):
     a primary-key build side and a probe column of NULL-free int32 value / FrameOfReference segments (1-, 2- and 4-byte offsets),
     sorted and random, with keys outside the build range, ragged chunks and every radix setting -- pairs and 131 070-element cuts
-    equal to the oracle's bytes, and equal to what the general kernels produce (HY_JOIN_NO_PKFK).
+    equal to the oracle's bytes, and equal to what the general kernels produce (HY_OPT_JOIN_PKFK = 0).
     bits_in_lds: the same joins with the build side's presence bits staged in LDS (pk_count_lds: persistent workgroups, the Bloom filter
     answered from the same bits, found / materialised masks handed to pk_emit<., true>) -- a path large probes against small tables
     take on their own (star joins), forced here for small ones."""
     if build_in_lds:
-        monkeypatch.setenv("HY_JOIN_LDS_BUILD_TILES", "1")
+        options.set(abi.OPT_JOIN_LDS_BUILD_TILES, 1)
     rng = np.random.default_rng(300 + mode)
     n_build = 30000
     i = np.arange(1, n_build + 1, dtype=np.int64)
@@ -636,18 +730,18 @@ def test_primary_key_foreign_key_probe(device, mode, build_in_lds, monkeypatch):
                 got = check(*args, mode, radix_bits, context)
                 assert used_pkfk() == (2 if build_in_lds and radix_bits != 8 else 1), context   # (256 partitions: the workgroup's cells would not fit beside the bits)
                 if radix_bits in (None, 5) and not build_in_lds:
-                    monkeypatch.setenv("HY_JOIN_NO_PKFK", "1")
+                    options.set(abi.OPT_JOIN_PKFK, 0)
                     general = check(*args, mode, radix_bits, context + " general kernels")
-                    monkeypatch.delenv("HY_JOIN_NO_PKFK")
+                    options.reset(abi.OPT_JOIN_PKFK)
                     assert used_pkfk() == 0
                     n = got.n_pairs
                     assert general.n_pairs == n and general.left[:n].tobytes() == got.left[:n].tobytes()
 
 
-def test_primary_key_hint(device, monkeypatch):
+def test_primary_key_hint(device, options):
     """The first join over a resident primary-key column leaves its key range behind (hy_column::join_hint); later joins fill the rank
     table in ONE pass sized by the hint, check every key against it and confirm it when the join has finished.  Same bytes either way;
-    a hint that does not hold (HY_JOIN_BREAK_HINT shrinks it) is dropped and the join runs again with the two-pass build."""
+    a hint that does not hold (HY_OPT_JOIN_BREAK_HINT shrinks it) is dropped and the join runs again with the two-pass build."""
     rng = np.random.default_rng(8)
     keys = (np.arange(100_000, dtype=np.int32) * 2 + 40)
     build_host = build_column(keys, None, 65535, abi.ENC_UNENCODED)
@@ -661,12 +755,12 @@ def test_primary_key_hint(device, monkeypatch):
         assert lib.hy_debug_join_build_was_hinted() == 0
         assert_join_equal(first, want, abi.JOIN_INNER, "first join")
         if broken:
-            monkeypatch.setenv("HY_JOIN_BREAK_HINT", "1")
+            options.set(abi.OPT_JOIN_BREAK_HINT, 1)
         second = join_hash(build, probe, abi.JOIN_INNER)
         assert lib.hy_debug_join_build_was_hinted() == (2 if broken else 1)     # 2: the hinted attempt was discarded
         assert_join_equal(second, want, abi.JOIN_INNER, f"second join, broken hint {broken}")
         if broken:
-            monkeypatch.delenv("HY_JOIN_BREAK_HINT")
+            options.reset(abi.OPT_JOIN_BREAK_HINT)
         third = join_hash(build, probe, abi.JOIN_SEMI if False else abi.JOIN_INNER)
         assert lib.hy_debug_join_build_was_hinted() == (0 if broken else 1)     # a dropped hint stays dropped
         assert_join_equal(third, want, abi.JOIN_INNER, "third join")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config 3 (JoinHash orders x lineitem, SF10) under the library's debug switches, one process: ms per join and the HIP-event time of
-the timed kernels.  Usage: python tools/join_bench.py [steps]   (not part of the product; the switches are documented in DESIGN.md section 6)"""
+the timed kernels.  Usage: python tools/join_bench.py [steps]   (not part of the product; the switches are options, include/hyrise_amd.h HY_OPT_*; the "debug:" variants and HY_JOIN_TRACE need a -DHY_DEBUG_SWITCHES build)"""
 import ctypes as C
 import os
 import sys
@@ -28,13 +28,12 @@ def main():
                 ("debug: checked fill without the filter", {"HY_JOIN_FILL_DEBUG": "1"}), ("debug: checked fill, loads and extent only", {"HY_JOIN_FILL_DEBUG": "2"}),
                 ("general rank-table kernels (round 2)", {"HY_JOIN_NO_PKFK": "1", "HY_JOIN_NO_HINT": "1"}), ("default again", {})]
     for name, env in variants:
-        for k, v in env.items():
-            os.environ[k] = v
+        switches = abi.switches(env)
+        switches.__enter__()
         run, r, keep = bench.device_join(lib, torch, dev, orders, lineitem, n)
         dt, kinds = bench.timed_kernel(lib, torch, run, steps, all_kinds=True)
         print(f"{name:40s} {dt * 1e3:7.3f} ms/join  pairs {int(r.n_pairs)}  " + "  ".join(f"{k} {v[0] * 1e3:6.1f} us" for k, v in kinds.items() if v[1]), flush=True)
-        for k in env:
-            del os.environ[k]
+        switches.__exit__(None, None, None)
         del keep
     if os.environ.get("HY_JOIN_TRACE"):   # per-tile phase stamps of pk_emit of the last join (wall clock, 100 MHz)
         import numpy as np

@@ -20,13 +20,13 @@ def main():
     columns = {name: DeviceColumn(column) for name, column in tpch.q1_columns(data).items()}
     results = {}
     for label, env in (("fused_small_domain", {}), ("fused_rows", {"HY_FUSED_NO_SMALL_DOMAIN": "1"})):
-        os.environ.update(env)
+        _switches = abi.switches(env)
+        _switches.__enter__()
         results[label] = tpch.q1_fused(columns)
         which = lib.hy_debug_aggregate_small_domain()
         dt, km = bench.timed_kernel(lib, torch, lambda: tpch.q1_fused(columns), steps)
         print(f"{label:20s} kernel flag {which}  {dt * 1e3:7.3f} ms/query  kernel {km:7.3f} ms", flush=True)
-        for k in env:
-            del os.environ[k]
+        _switches.__exit__(None, None, None)
     a, b = results["fused_small_domain"], results["fused_rows"]
     assert a.n_groups == b.n_groups, (a.n_groups, b.n_groups)
     assert (a.row_ids[:a.n_groups] == b.row_ids[:b.n_groups]).all(), "group order / representative rows"

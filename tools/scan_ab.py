@@ -54,12 +54,12 @@ def main():
                 abi.check(lib.hy_table_scan(copies[turn[0] % len(copies)].handle, C.byref(pred), None, 0, C.byref(result)))
                 turn[0] += 1
             for variant, env in (("write-back stores (default)", {}), ("nontemporal stores", {"HY_SCAN_NT_STORES": "1"}), ("write-back again", {}), ("nontemporal again", {"HY_SCAN_NT_STORES": "1"})):
-                os.environ.update(env)
+                _switches = abi.switches(env)
+                _switches.__enter__()
                 dt, km = bench.timed_kernel(lib, torch, step, steps, 4, kind="scan")
                 m = int(counts.sum().item())
                 print(f"{label:24s} {name:9s} {variant:28s} {dt * 1e6:7.1f} us/scan  scan_slices {km * 1e3:6.1f} us  {(rows * width + m * 8) / (km * 1e-3) / 1e9:6.0f} GB/s on algorithmic bytes", flush=True)
-                for k in env:
-                    del os.environ[k]
+                _switches.__exit__(None, None, None)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ def main():
     columns = {name: ex.column(column) for name, column in data.host_columns().items()}
     reference = {}
     for shift in ("4", "3", "2", "4"):
-        os.environ["HY_AGG_SPILL_SHIFT"] = shift
+        abi.check(lib.hy_set_option(abi.OPT_AGG_SPILL_SHIFT, int(shift)))
         for query in ("2.1", "4.1"):
             def once():
                 groupby, aggregates, joined = ssb.run_query(ex, columns, query)
