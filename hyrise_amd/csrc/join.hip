@@ -2457,38 +2457,61 @@ __device__ __forceinline__ int32_t view_key(const SliceView& view, uint32_t row)
 // extent of its keys from the keys themselves (a wave reduction each, no dependent loads in front of the slice's eight), sets up its
 // run of table words in LDS, and the bits of a group's keys that share a word leave with ONE LDS atomic (sorted keys: four lineitems of
 // an order, eight dbgen order keys per word).
+// A slice's stored words in registers: what rank_table_fill_checked loads at the top of a slice, and what rank_table_fill_stream
+// requests one slice AHEAD of the one it is working on.
 template <uint32_t WIDTH>
-__device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, const SliceView& view, uint32_t origin, uint32_t range, u32x2_entry_t* entries, uint32_t* s_bits, uint32_t* s_base,
-                                                   int32_t* s_extent, uint32_t tid, int32_t* low_out, int32_t* high_out, uint32_t* flags_out) {
-  constexpr uint32_t GROUP = FillGroup<WIDTH>::ROWS, GROUPS = SLICE_ROWS / 256 / GROUP;
-  const uint32_t row_count = view.row_count, lane = tid & 63, wave = tid >> 6;
+struct FillWords {
+  static constexpr uint32_t GROUP = FillGroup<WIDTH>::ROWS, GROUPS = SLICE_ROWS / 256 / GROUP;
   uint32_t word[GROUPS][GROUP];
-  int32_t front[GROUPS];
+  int32_t front[GROUPS];      // lane 0 of a wave: the key in front of the group's first row
+  uint32_t bias[GROUPS];      // FrameOfReference: the minimum of the group's block (a group lies in one 2048-row block)
+  int32_t key_before;         // thread 0: the key in front of the slice (the last row of the nearest earlier slice with rows) ...
+  bool has_before;            // ... if there is one
+};
+
+template <uint32_t WIDTH>
+__device__ __forceinline__ void load_fill_words(const MaterializeArgs& a, const SliceView& view, uint32_t slice_index, uint32_t tid, FillWords<WIDTH>& w) {
+  constexpr uint32_t GROUP = FillWords<WIDTH>::GROUP, GROUPS = FillWords<WIDTH>::GROUPS;
+  const uint32_t row_count = view.row_count, lane = tid & 63;
 #pragma unroll
   for (uint32_t i = 0; i < GROUPS; ++i) {
     const uint32_t first = (i * 256 + tid) * GROUP;
-    load_group_words<WIDTH>(view, view.row_begin + (first < row_count ? first : 0), word[i]);
-    front[i] = 0;
-    if (lane == 0 && first > 0 && first < row_count) front[i] = view_key(view, view.row_begin + first - 1);   // (the other lanes: from their neighbour)
+    load_group_words<WIDTH>(view, view.row_begin + (first < row_count ? first : 0), w.word[i]);
+    w.front[i] = 0;
+    if (lane == 0 && first > 0 && first < row_count) w.front[i] = view_key(view, view.row_begin + first - 1);   // (the other lanes: from their neighbour)
+    w.bias[i] = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + (first < row_count ? first : 0)) / HY_FOR_BLOCK_SIZE]);
   }
   // the key in front of the slice: the last row of the nearest earlier slice with rows (one thread)
-  int32_t key_before = 0;
-  bool has_before = false;
+  w.key_before = 0;
+  w.has_before = false;
   if (tid == 0) {
-    for (uint32_t before = blockIdx.x; before-- > 0;) {
+    for (uint32_t before = slice_index; before-- > 0;) {
       const SliceView earlier = a.views[before];
       if (earlier.row_count == 0) continue;
-      key_before = view_key(earlier, earlier.row_begin + earlier.row_count - 1);
-      has_before = true;
+      w.key_before = view_key(earlier, earlier.row_begin + earlier.row_count - 1);
+      w.has_before = true;
       break;
     }
   }
+}
+
+template <uint32_t WIDTH>
+__device__ __forceinline__ void fill_checked_process(const MaterializeArgs& a, const SliceView& view, const FillWords<WIDTH>& w, uint32_t origin, uint32_t range, u32x2_entry_t* entries,
+                                                     uint32_t* s_bits, uint32_t* s_base, int32_t* s_extent, uint32_t tid, int32_t* low_out, int32_t* high_out, uint32_t* flags_out) {
+  constexpr uint32_t GROUP = FillGroup<WIDTH>::ROWS, GROUPS = SLICE_ROWS / 256 / GROUP;
+  const uint32_t row_count = view.row_count, lane = tid & 63, wave = tid >> 6;
+  const auto& word = w.word;
+  int32_t front[GROUPS];
+#pragma unroll
+  for (uint32_t i = 0; i < GROUPS; ++i) front[i] = w.front[i];
+  const int32_t key_before = w.key_before;
+  const bool has_before = w.has_before;
   int32_t low = 0x7FFFFFFF, high = static_cast<int32_t>(0x80000000u);
   int32_t key[GROUPS][GROUP];
 #pragma unroll
   for (uint32_t i = 0; i < GROUPS; ++i) {
     const uint32_t first = (i * 256 + tid) * GROUP;
-    const uint32_t bias = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + (first < row_count ? first : 0)) / HY_FOR_BLOCK_SIZE]);   // (a group lies in one 2048-row block)
+    const uint32_t bias = w.bias[i];
 #pragma unroll
     for (uint32_t e = 0; e < GROUP; ++e) {
       key[i][e] = static_cast<int32_t>(word[i][e] + bias);
@@ -2576,6 +2599,14 @@ __device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, con
   }
 }
 
+template <uint32_t WIDTH>
+__device__ __forceinline__ void fill_checked_slice(const MaterializeArgs& a, const SliceView& view, uint32_t origin, uint32_t range, u32x2_entry_t* entries, uint32_t* s_bits, uint32_t* s_base,
+                                                   int32_t* s_extent, uint32_t tid, int32_t* low_out, int32_t* high_out, uint32_t* flags_out) {
+  FillWords<WIDTH> words;
+  load_fill_words<WIDTH>(a, view, blockIdx.x, tid, words);
+  fill_checked_process<WIDTH>(a, view, words, origin, range, entries, s_bits, s_base, s_extent, tid, low_out, high_out, flags_out);
+}
+
 // The same table as rank_table_fill_dense AND the statistics of dense_key_stats in ONE pass over the build column, for a column
 // whose extent is already known: the first join over a resident column leaves its key range behind as a hint
 // (hy_column::join_hint -- encoded segments are immutable, abstract_encoded_segment.hpp:12-17), later joins size and fill the table
@@ -2628,6 +2659,95 @@ __global__ __launch_bounds__(256, 5) void rank_table_fill_checked(MaterializeArg
   // the workgroup that arrives last sees every slice's record: the verdict
   uint64_t low = ~0ull, high = 0, bits = 0;
   for (uint32_t i = tid; i < a.n_slices; i += 256) {
+    uint64_t* record = partials + 4 * size_t{i};
+    const uint64_t record_low = __hip_atomic_load(record + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), record_high = __hip_atomic_load(record + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    low = record_low < low ? record_low : low;
+    high = record_high > high ? record_high : high;
+    bits |= __hip_atomic_load(record + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    bits |= __shfl_xor(bits, d, 64);
+    const uint64_t other_low = __shfl_xor(low, d, 64), other_high = __shfl_xor(high, d, 64);
+    low = other_low < low ? other_low : low;
+    high = other_high > high ? other_high : high;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { s_min[tid >> 6] = low; s_max[tid >> 6] = high; atomicOr(&s_flags, static_cast<uint32_t>(bits)); }
+  __syncthreads();
+  if (tid != 0) return;
+  for (uint32_t w = 0; w < 4; ++w) { low = s_min[w] < low ? s_min[w] : low; high = s_max[w] > high ? s_max[w] : high; }
+  verdict->key_min = low ^ SIGN;
+  verdict->key_max = high ^ SIGN;
+  verdict->unsorted_signed = s_flags & 1u ? 1 : 0;
+  verdict->equal_neighbours = s_flags & 2u ? 1 : 0;
+  verdict->outside_hint = s_flags & 4u ? 1 : 0;
+  verdict->done = 1;
+  __threadfence_system();
+}
+
+// The same pass with workgroups that STAY: workgroup b takes `slices_per_group` consecutive slices and requests a slice's words while it
+// builds the table words of the slice before (rank_table_fill_checked's 1 831 workgroups for SF10 orders live about 25 us each --
+// descriptors, then words, then two dependent agent-scope round trips to hand in their record -- in 1.4 rounds of residency; here
+// the loads of slice s + 1 are in flight during the LDS work of slice s, and a workgroup hands in ONE record at its end).  The host picks
+// slices_per_group so that all workgroups are resident at once and every one of them has the same number of slices (+- 1 at the end).
+// Columns whose segments all have stored words of WIDTH bytes (hy_column::stream_width); partials: [gridDim.x][4].
+template <uint32_t WIDTH>
+__global__ __launch_bounds__(256, 3) void rank_table_fill_stream(MaterializeArgs a, uint64_t key_min, uint64_t hint_range, u32x2_entry_t* entries, uint64_t* partials, uint32_t* ticket,
+                                                                 BuildVerdict* verdict, uint32_t slices_per_group) {
+  __shared__ uint32_t s_bits[CHECKED_FILL_WORDS], s_base[CHECKED_FILL_WORDS];
+  __shared__ int32_t s_extent[8];
+  __shared__ uint64_t s_min[4], s_max[4];
+  __shared__ uint32_t s_flags, s_last;
+  const uint32_t tid = threadIdx.x;
+  constexpr uint64_t SIGN = 1ull << 63;
+  const uint32_t begin = blockIdx.x * slices_per_group, end = begin + slices_per_group < a.n_slices ? begin + slices_per_group : a.n_slices;
+  const uint32_t origin = static_cast<uint32_t>(key_min), range = static_cast<uint32_t>(hint_range);
+  int32_t low32 = 0x7FFFFFFF, high32 = static_cast<int32_t>(0x80000000u);
+  uint32_t flags = 0;
+  bool any_rows = false;
+  if (tid == 0) s_flags = 0;
+  FillWords<WIDTH> current, ahead;
+  SliceView view = a.views[begin < a.n_slices ? begin : 0];
+  if (begin < end && view.row_count != 0) load_fill_words<WIDTH>(a, view, begin, tid, current);
+  for (uint32_t slice = begin; slice < end; ++slice) {
+    SliceView next_view = view;
+    if (slice + 1 < end) {
+      next_view = a.views[slice + 1];
+      if (next_view.row_count != 0) load_fill_words<WIDTH>(a, next_view, slice + 1, tid, ahead);
+    }
+    if (view.row_count != 0) {
+      int32_t low = 0, high = 0;
+      uint32_t slice_flags = 0;
+      fill_checked_process<WIDTH>(a, view, current, origin, range, entries, s_bits, s_base, s_extent, tid, &low, &high, &slice_flags);
+      low32 = low < low32 ? low : low32;
+      high32 = high > high32 ? high : high32;
+      flags |= slice_flags;
+      any_rows = true;
+    }
+    current = ahead;
+    view = next_view;
+  }
+  if (flags) atomicOr(&s_flags, flags);
+  __syncthreads();
+  if (tid == 0) {   // (the record and the arrival: as in rank_table_fill_checked, once per workgroup)
+    const uint64_t low = any_rows ? static_cast<uint64_t>(static_cast<int64_t>(low32)) ^ SIGN : ~0ull, high = any_rows ? static_cast<uint64_t>(static_cast<int64_t>(high32)) ^ SIGN : 0;
+    uint64_t* record = partials + 4 * size_t{blockIdx.x};
+    __hip_atomic_store(record + 0, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(record + 1, high, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(record + 2, static_cast<uint64_t>(s_flags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t lanes = gridDim.x < CHECKED_FILL_TICKETS ? gridDim.x : CHECKED_FILL_TICKETS, mine = blockIdx.x % lanes;
+    const uint32_t quota = gridDim.x / lanes + (mine < gridDim.x % lanes ? 1u : 0u);
+    uint32_t last = 0;
+    if (__hip_atomic_fetch_add(ticket + 32 * (1 + mine), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == quota)
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == lanes ? 1u : 0u;
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  uint64_t low = ~0ull, high = 0, bits = 0;
+  for (uint32_t i = tid; i < gridDim.x; i += 256) {
     uint64_t* record = partials + 4 * size_t{i};
     const uint64_t record_low = __hip_atomic_load(record + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), record_high = __hip_atomic_load(record + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     low = record_low < low ? record_low : low;
@@ -2779,6 +2899,8 @@ struct StageClock {
   }
 };
 
+static uint32_t device_cu_count();
+
 struct BuildSide {
   DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags, rank_entries, partials;
   bool hint_allows_duplicates = false;
@@ -2894,6 +3016,16 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       }
       hipEvent_t fill_started = nullptr, fill_stopped = nullptr;
       profile_events(&fill_started, &fill_stopped, HY_KERNEL_JOIN_BUILD);
+      // rank_table_fill_stream: as many workgroups as stay resident (option: per CU), each with the same number of consecutive slices
+      const uint32_t fill_capacity = device_cu_count() * static_cast<uint32_t>(std::max<int64_t>(0, std::min<int64_t>(3, option(HY_OPT_JOIN_FILL_WGS_PER_CU))));
+      const uint32_t stream_width = build->stream_width == 1 || build->stream_width == 2 || build->stream_width == 4 ? build->stream_width : 0;
+      if (fill_capacity && stream_width && m.keep_nulls != 0xFFFFFFFFu) {
+        const uint32_t slices_per_group = (n_slices + fill_capacity - 1) / fill_capacity, groups = (n_slices + slices_per_group - 1) / slices_per_group;
+        uint32_t* tickets = reinterpret_cast<uint32_t*>(entries + words + 2);
+        if (stream_width == 4) hipExtLaunchKernelGGL(rank_table_fill_stream<4>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), tickets, verdict, slices_per_group);
+        else if (stream_width == 2) hipExtLaunchKernelGGL(rank_table_fill_stream<2>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), tickets, verdict, slices_per_group);
+        else hipExtLaunchKernelGGL(rank_table_fill_stream<1>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), tickets, verdict, slices_per_group);
+      } else
       hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries,
                             b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 2), verdict);
       b.verdict = verdict;
@@ -3146,7 +3278,6 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   return HY_OK;
 }
 
-static uint32_t device_cu_count();
 // Persistent waves that take one tile at a time (rt_stream_count), STREAM_WAVES per workgroup: as many as fit the device at once
 // (a multiple of the 8 XCDs), never more than there are tiles.
 static uint32_t stream_grid(uint32_t n_tiles, int workgroups_per_cu) {

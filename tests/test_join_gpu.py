@@ -783,6 +783,68 @@ def test_primary_key_hint(device, options):
             assert_join_equal(got, want, abi.JOIN_INNER, f"filter aliases, radix {radix_bits}, attempt {attempt}")
 
 
+@pytest.mark.parametrize("workgroups_per_cu", [0, 1, 3])
+def test_hinted_fill_kernels(device, options, workgroups_per_cu):
+    """The one-pass checked fill of a hinted build side, as short-lived workgroups (one per slice, HY_OPT_JOIN_FILL_WGS_PER_CU = 0) and as
+    persistent ones that read a slice ahead (rank_table_fill_stream<1 | 2 | 4>): int32 values and FrameOfReference offsets of every
+    width, ragged chunks (slices of 3 and 8191 rows), sparse stretches (slices whose keys span more table words than the LDS window),
+    more slices than workgroups -- and a column that is NOT sorted although an (invented) hint says so: the verdict must catch it."""
+    options.set(abi.OPT_JOIN_FILL_WGS_PER_CU, workgroups_per_cu)
+    lib = abi.load_library()
+    rng = np.random.default_rng(400 + workgroups_per_cu)
+    n = 3_300_000 if workgroups_per_cu == 1 else 700_000   # (1 per CU: 256 workgroups for 400+ slices -- two slices each)
+    dense = np.arange(n, dtype=np.int32) * 2 - 50_000                                   # 4-byte values; as FoR: 2-byte offsets
+    stepped = (np.arange(n, dtype=np.int64) // 8 * 32 + np.arange(n) % 8).astype(np.int32)   # dbgen's sparse keys: 8 of every 32
+    sparse_tail = np.concatenate([np.arange(n - 20_000, dtype=np.int64), (n - 20_000) + np.arange(20_000, dtype=np.int64) * 37]).astype(np.int32)   # the last slices: 37 key values per key
+    small = np.arange(200_000, dtype=np.int32) % 120 + np.arange(200_000, dtype=np.int32) // 120 * 128    # 1-byte FoR offsets (blocks of 2048 rows span < 256)... keys ascending
+    cases = [("dense int32", dense, abi.ENC_UNENCODED, 65535), ("dense FoR", dense, abi.ENC_FRAME_OF_REFERENCE, 65535), ("stepped int32", stepped, abi.ENC_UNENCODED, 65535),
+             ("ragged chunks", dense[:500_000], abi.ENC_UNENCODED, 8195), ("sparse tail", sparse_tail, abi.ENC_UNENCODED, 65535),
+             ("wide FoR", sparse_tail, abi.ENC_FRAME_OF_REFERENCE, 65535)]
+    for name, keys, encoding, chunk in cases:
+        build_host = build_column(keys, None, chunk, encoding)
+        probe_keys = np.sort(np.concatenate([rng.choice(keys, 300_000), rng.integers(int(keys[0]) - 100, int(keys[-1]) + 100, 50_000).astype(np.int32)]).astype(np.int32))
+        probe_host = build_column(probe_keys, None, 65535, abi.ENC_FRAME_OF_REFERENCE)
+        build, probe = DeviceColumn(build_host), DeviceColumn(probe_host)
+        want = oracle_join(build_host, probe_host, abi.JOIN_INNER)
+        for attempt in range(3):
+            got = join_hash(build, probe, abi.JOIN_INNER)
+            assert lib.hy_debug_join_build_was_hinted() == (0 if attempt == 0 else 1), name
+            assert_join_equal(got, want, abi.JOIN_INNER, f"{name}, attempt {attempt}, fill workgroups per CU {workgroups_per_cu}")
+    # a column that stops being sorted behind its hint: the build column lives in CALLER-owned device memory (HY_MEM_DEVICE), the first
+    # join leaves the hint, then two keys swap places in that memory (what "encoded segments are immutable" rules out -- the check
+    # must hold anyway): the verdict says unsorted, nothing is written, the join runs again on the two-pass build
+    keys = np.arange(600_000, dtype=np.int32) * 2
+    chunk = 65520   # (chunk buffers 16-byte aligned inside the one allocation: the checked fill reads 16 bytes per load)
+    probe_host = build_column(np.sort(rng.choice(keys, 400_000)).astype(np.int32), None, 65535, abi.ENC_FRAME_OF_REFERENCE)
+    probe = DeviceColumn(probe_host)
+    pointer, _ = _device_buffer(lib, keys.shape, np.int32, 0)
+    abi.check(lib.hy_memcpy_h2d(pointer, keys.ctypes.data, keys.nbytes))
+    n_chunks = (len(keys) + chunk - 1) // chunk
+    segments = (abi.Segment * n_chunks)()
+    for c in range(n_chunks):
+        rows = min(chunk, len(keys) - c * chunk)
+        segments[c].encoding, segments[c].data_type, segments[c].size, segments[c].width = abi.ENC_UNENCODED, abi.TYPE_INT, rows, 4
+        segments[c].data = pointer + 4 * c * chunk
+    handle = C.c_void_p()
+    abi.check(lib.hy_column_create(segments, n_chunks, abi.MEM_DEVICE, C.byref(handle)))
+
+    class Handle:   # (what join_hash wants of a DeviceColumn)
+        pass
+    build = Handle()
+    build.handle, build.rows, build.n_chunks = handle, len(keys), n_chunks
+    sorted_host = build_column(keys, None, chunk, abi.ENC_UNENCODED)
+    first = join_hash(build, probe, abi.JOIN_INNER)
+    assert_join_equal(first, oracle_join(sorted_host, probe_host, abi.JOIN_INNER), abi.JOIN_INNER, "caller-owned build column")
+    swapped = keys.copy()
+    swapped[[123_456, 400_000]] = swapped[[400_000, 123_456]]
+    abi.check(lib.hy_memcpy_h2d(pointer, swapped.ctypes.data, swapped.nbytes))
+    got = join_hash(build, probe, abi.JOIN_INNER)
+    assert lib.hy_debug_join_build_was_hinted() == 2          # the hinted attempt was discarded
+    assert_join_equal(got, oracle_join(build_column(swapped, None, chunk, abi.ENC_UNENCODED), probe_host, abi.JOIN_INNER), abi.JOIN_INNER, "unsorted column behind a sorted column's hint")
+    abi.check(lib.hy_column_destroy(handle))
+    lib.hy_device_free(pointer)
+
+
 @pytest.mark.parametrize("mode", SEMI)
 def test_semi_join_over_a_sorted_build_side_with_duplicates(device, mode):
     """Semi / Anti joins without secondary predicates only ask whether a key exists (the reference's ExistenceOnly hash table,
