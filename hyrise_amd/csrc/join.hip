@@ -2686,93 +2686,314 @@ __global__ __launch_bounds__(256, 5) void rank_table_fill_checked(MaterializeArg
   __threadfence_system();
 }
 
-// The same pass with workgroups that STAY: workgroup b takes `slices_per_group` consecutive slices and requests a slice's words while it
-// builds the table words of the slice before (rank_table_fill_checked's 1 831 workgroups for SF10 orders live about 25 us each --
-// descriptors, then words, then two dependent agent-scope round trips to hand in their record -- in 1.4 rounds of residency; here
-// the loads of slice s + 1 are in flight during the LDS work of slice s, and a workgroup hands in ONE record at its end).  The host picks
-// slices_per_group so that all workgroups are resident at once and every one of them has the same number of slices (+- 1 at the end).
-// Columns whose segments all have stored words of WIDTH bytes (hy_column::stream_width); partials: [gridDim.x][4].
-template <uint32_t WIDTH>
-__global__ __launch_bounds__(256, 3) void rank_table_fill_stream(MaterializeArgs a, uint64_t key_min, uint64_t hint_range, u32x2_entry_t* entries, uint64_t* partials, uint32_t* ticket,
-                                                                 BuildVerdict* verdict, uint32_t slices_per_group) {
-  __shared__ uint32_t s_bits[CHECKED_FILL_WORDS], s_base[CHECKED_FILL_WORDS];
-  __shared__ int32_t s_extent[8];
-  __shared__ uint64_t s_min[4], s_max[4];
-  __shared__ uint32_t s_flags, s_last;
-  const uint32_t tid = threadIdx.x;
-  constexpr uint64_t SIGN = 1ull << 63;
-  const uint32_t begin = blockIdx.x * slices_per_group, end = begin + slices_per_group < a.n_slices ? begin + slices_per_group : a.n_slices;
-  const uint32_t origin = static_cast<uint32_t>(key_min), range = static_cast<uint32_t>(hint_range);
-  int32_t low32 = 0x7FFFFFFF, high32 = static_cast<int32_t>(0x80000000u);
-  uint32_t flags = 0;
+// The same pass, wave by wave: rank_table_fill_checked spends ~130 vector instructions per key (runs of keys per table word found
+// with per-key branches, five workgroup barriers per slice) and is bound by exactly that -- its time falls with the number of resident
+// workgroups, not with the loads' latency (tools/join_bench.py: 1 / 2 / 3 persistent workgroups per CU 102 / 60 / 47 us).  Here a wave
+// owns a run of consecutive 512-row steps (eight consecutive rows per lane: one or two 16-byte loads, requested a step ahead) and builds
+// a step's table words in a window of LDS that belongs to it alone: a key is ONE ds_or (its bit) and ONE ds_min (its rank: the smallest
+// rank of a word is its base) -- no run detection, no workgroup barrier, uniform control flow.  The window is [word of the step's first
+// key, word of its last key]: sorted keys stay inside, and a step whose keys are not sorted (or span more than FW_WINDOW words: a very
+// sparse stretch) takes one global atomic per key instead.  A step's first and last word may be shared with the neighbouring steps: their
+// bits leave with a global atomicOr, and the base is written by the step that holds the word's first key.  The checks of
+// rank_table_fill_checked (order, equal neighbours, extent, keys outside the hint) run on the same registers; a workgroup hands in one
+// record.  Columns whose segments all have stored words of WIDTH bytes (hy_column::stream_width); partials: [gridDim.x][4].
+constexpr uint32_t FW_STEP = 512;                        // rows per step: eight consecutive rows per lane
+constexpr uint32_t FW_STEPS_PER_SLICE = SLICE_ROWS / FW_STEP;
+constexpr uint32_t FW_WINDOW = 2048;                     // table words a batch (or a step) may span to be built in LDS (8 KB per wave)
+static_assert(HY_FOR_BLOCK_SIZE % FW_STEP == 0, "a step lies in one FrameOfReference block");
+
+constexpr uint32_t FW_BATCH = 4;                          // steps a wave builds in one window and requests at once, a batch ahead (2 x 8 loads of 16 bytes per lane in flight for 4-byte keys)
+
+// What a wave carries from step to step (all of it uniform).
+struct FillWaveState {
+  uint64_t unsorted = 0, equal = 0, outside = 0;   // ballots: some lane met a key below / equal to its predecessor / outside the hinted range
+  int32_t low = 0x7FFFFFFF, high = static_cast<int32_t>(0x80000000u);   // first and last key of the wave's rows: the extent if they are sorted
   bool any_rows = false;
-  if (tid == 0) s_flags = 0;
-  FillWords<WIDTH> current, ahead;
-  SliceView view = a.views[begin < a.n_slices ? begin : 0];
-  if (begin < end && view.row_count != 0) load_fill_words<WIDTH>(a, view, begin, tid, current);
-  for (uint32_t slice = begin; slice < end; ++slice) {
-    SliceView next_view = view;
-    if (slice + 1 < end) {
-      next_view = a.views[slice + 1];
-      if (next_view.row_count != 0) load_fill_words<WIDTH>(a, next_view, slice + 1, tid, ahead);
+  int32_t carry = 0;           // the key in front of the next step ...
+  bool has_carry = false;      // ... if there is one
+};
+
+template <uint32_t WIDTH>
+__device__ __forceinline__ int32_t fill_step_key(const u32x4_t& a, const u32x4_t& b, uint32_t bias, uint32_t j) {
+  uint32_t stored;
+  if constexpr (WIDTH == 4) stored = j < 4 ? a[j] : b[j - 4];
+  else if constexpr (WIDTH == 2) stored = (a[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+  else stored = (a[j / 4] >> (8 * (j & 3))) & 0xFFu;
+  return static_cast<int32_t>(stored + bias);
+}
+
+// The key in front of step `step` (the last row before it that exists), for the first step of a wave: one lane asks.
+__device__ __forceinline__ bool key_in_front_of_step(const MaterializeArgs& a, uint32_t step, int32_t* key) {
+  uint32_t slice = step / FW_STEPS_PER_SLICE;
+  const uint32_t offset = (step % FW_STEPS_PER_SLICE) * FW_STEP;
+  if (offset > 0) {   // (the slice has rows in front of the step, or the step has none itself)
+    const SliceView view = a.views[slice];
+    if (view.row_count > 0) { *key = view_key(view, view.row_begin + (offset <= view.row_count ? offset : view.row_count) - 1); return true; }
+  }
+  while (slice-- > 0) {
+    const SliceView earlier = a.views[slice];
+    if (earlier.row_count == 0) continue;
+    *key = view_key(earlier, earlier.row_begin + earlier.row_count - 1);
+    return true;
+  }
+  return false;
+}
+
+// K consecutive steps from registers (K = 1: one step; K = FW_BATCH: a wave's batch -- one window for all of them, a quarter of the LDS
+// round trips and of the shared edge words): step k has rows[k] rows (uniform; the steps with rows come first, a step with fewer than
+// FW_STEP rows is the last with rows) whose first has rank first_rank[k]; the lane's eight consecutive keys of step k are a[k] / b[k] +
+// bias[k].  Returns false -- nothing done -- if the keys of K > 1 steps do not fit one window (the caller then takes them step by step).
+template <uint32_t WIDTH, uint32_t K>
+__device__ __forceinline__ bool fill_process_steps(FillWaveState& w, const u32x4_t (&a)[K], const u32x4_t (&b)[K], const uint32_t (&bias)[K], const uint32_t (&rows)[K],
+                                                   const uint32_t (&first_rank)[K], uint32_t lane, uint32_t origin, uint32_t range, u32x2_entry_t* entries, uint32_t* bloom_words,
+                                                   uint32_t* bits_window, uint32_t debug) {
+  // (debug: timing experiments of a -DHY_DEBUG_SWITCHES build, results are wrong then -- 2 no table stores, 4 no LDS work, 8 keys are only looked at)
+  const uint32_t origin_word = origin >> 5;
+  if (rows[0] == 0) return true;
+  int32_t key[K][8];
+  uint32_t lane_rows[K];
+  int32_t first_key = 0, last_key = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < K; ++k) {
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) key[k][j] = fill_step_key<WIDTH>(a[k], b[k], bias[k], j);
+    lane_rows[k] = lane * 8 < rows[k] ? (rows[k] - lane * 8 < 8 ? rows[k] - lane * 8 : 8) : 0;   // rows of this lane (8 unless the step is the last of its slice)
+    if (rows[k] != 0) {   // the step's last key (uniform): lane (rows - 1) / 8, element (rows - 1) % 8
+      const uint32_t last_lane = (rows[k] - 1) >> 3, last_j = (rows[k] - 1) & 7;
+      int32_t mine = key[k][0];
+#pragma unroll
+      for (uint32_t j = 1; j < 8; ++j) mine = last_j == j ? key[k][j] : mine;
+      last_key = __builtin_amdgcn_readlane(mine, last_lane);
     }
-    if (view.row_count != 0) {
-      int32_t low = 0, high = 0;
-      uint32_t slice_flags = 0;
-      fill_checked_process<WIDTH>(a, view, current, origin, range, entries, s_bits, s_base, s_extent, tid, &low, &high, &slice_flags);
-      low32 = low < low32 ? low : low32;
-      high32 = high > high32 ? high : high32;
-      flags |= slice_flags;
-      any_rows = true;
+    if (k == 0) first_key = __builtin_amdgcn_readfirstlane(key[0][0]);
+  }
+  // the window of table words: [word of the first key, word of the last key]
+  const uint32_t first_rel = static_cast<uint32_t>(first_key) - origin, last_rel = static_cast<uint32_t>(last_key) - origin;
+  const uint32_t first_word = first_rel >> 5;
+  const bool windowed = first_rel <= range && last_rel <= range && last_rel >= first_rel && (last_rel >> 5) - first_word < FW_WINDOW;
+  if (K > 1 && !windowed) return false;
+  const uint32_t span = windowed ? (last_rel >> 5) - first_word + 1 : 0;
+  if (!w.any_rows) w.low = first_key;
+  w.high = last_key;
+  w.any_rows = true;
+  // order: every key against its predecessor (lane 0's first key of a step against the last key of the step before)
+  int32_t before[K];
+  bool first_has_before[K];
+  {
+    int32_t carry = w.carry;
+    bool has_carry = w.has_carry;
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+      before[k] = __shfl_up(key[k][7], 1, 64);
+      if (lane == 0) before[k] = carry;
+      first_has_before[k] = lane != 0 || has_carry;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const int32_t previous = j == 0 ? before[k] : key[k][j - 1];
+        const bool checked = j < lane_rows[k] && (j != 0 || first_has_before[k]);
+        w.unsorted |= __ballot(checked && key[k][j] < previous);
+        w.equal |= __ballot(checked && key[k][j] == previous);
+      }
+      if (rows[k] != 0) {   // (a full step's last key sits in lane 63; only the last step with rows may be shorter, and nothing follows it)
+        carry = __builtin_amdgcn_readlane(key[k][7], 63);
+        has_carry = true;
+      }
+    }
+  }
+  // does the batch hold the first key of its first word?  (else an earlier step writes that word's base)
+  const uint32_t carry_rel = static_cast<uint32_t>(w.carry) - origin;
+  const bool first_is_leader = !w.has_carry || carry_rel > range || (carry_rel >> 5) != first_word;
+  w.carry = last_key;
+  w.has_carry = true;
+  // keys outside the hinted range: sorted keys lie between the first and the last (and keys that are not sorted are flagged above)
+  if (first_rel > range || last_rel > range) w.outside = 1;
+#ifdef HY_DEBUG_SWITCHES
+  if (debug & 8) return true;
+#endif
+  if (windowed) {
+#ifdef HY_DEBUG_SWITCHES
+    if (debug & 4) return true;
+#endif
+    for (uint32_t i = lane; i < span; i += 64) bits_window[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t rel = static_cast<uint32_t>(key[k][j]) - origin;
+        const uint32_t at = (rel >> 5) - first_word;
+        // (at >= span: the keys are not sorted -- flagged above, the join will not use this table; at < span: the word lies inside the table)
+        if (j < lane_rows[k] && at < span) atomicOr(&bits_window[at], 1u << (rel & 31));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // A word's base is the rank of its first key: the batch's rows are consecutive and its keys ascend without repeats (anything else is
+    // flagged above and ends the use of this table; a table for existence-only joins, which may hold repeats, is never asked for a base),
+    // so that rank is the batch's first rank plus the keys of the batch in the words before -- a running sum of population counts.
+    uint32_t keys_before = 0;
+    for (uint32_t begin = 0; begin < span; begin += 64) {
+      const uint32_t i = begin + lane;
+      const uint32_t bits = i < span ? bits_window[i] : 0u;
+      const uint32_t count = __popc(bits);
+      uint32_t inclusive = count;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t other = __shfl_up(inclusive, d, 64);
+        if (lane >= static_cast<uint32_t>(d)) inclusive += other;
+      }
+      const uint32_t base = first_rank[0] + keys_before + inclusive - count;
+      keys_before += __builtin_amdgcn_readlane(inclusive, 63);
+      if (i >= span) continue;
+      const uint32_t table_word = first_word + i;
+      if (bits && bloom_words) atomicOr(bloom_words + ((table_word + origin_word) & (BLOOM_BITS / 32 - 1)), bits);
+#ifdef HY_DEBUG_SWITCHES
+      if (debug & 2) { if (bits == 0xDEADBEEFu && base == 0x12345678u) entries[0] = u32x2_entry_t{bits, base}; continue; }
+#endif
+      if (i == 0 || i + 1 == span) {   // may be shared with a neighbouring batch: add the bits; the base comes from the batch with the word's first key
+        if (bits) atomicOr(reinterpret_cast<uint32_t*>(entries + table_word), bits);
+        if (bits && (i != 0 || first_is_leader)) reinterpret_cast<uint32_t*>(entries + table_word)[1] = base;
+      } else {
+        entries[table_word] = u32x2_entry_t{bits, bits ? base : 0u};
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // (the window is read before the next batch clears it)
+  } else {
+    // a step outside any window (K == 1): one global atomic per key; a key that starts a table word writes the word's base
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+      const uint32_t lane_rank = first_rank[k] + lane * 8;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t rel = static_cast<uint32_t>(key[k][j]) - origin;
+        const int32_t previous = j == 0 ? before[k] : key[k][j - 1];
+        const bool has_previous = j != 0 || first_has_before[k];
+        w.outside |= __ballot(j < lane_rows[k] && rel > range);
+        if (j < lane_rows[k] && rel <= range) {
+          const uint32_t table_word = rel >> 5, bits = 1u << (rel & 31);
+          atomicOr(reinterpret_cast<uint32_t*>(entries + table_word), bits);
+          const uint32_t previous_rel = static_cast<uint32_t>(previous) - origin;
+          if (!has_previous || previous_rel > range || (previous_rel >> 5) != table_word) reinterpret_cast<uint32_t*>(entries + table_word)[1] = lane_rank + j;
+          if (bloom_words) atomicOr(bloom_words + ((table_word + origin_word) & (BLOOM_BITS / 32 - 1)), bits);
+        }
+      }
+    }
+  }
+  return true;
+}
+
+// What a wave requests at once: the stored words of FW_BATCH steps and what it needs to know about them.
+template <uint32_t WIDTH>
+struct FillBatch {
+  u32x4_t a[FW_BATCH], b[FW_BATCH];
+  uint32_t bias[FW_BATCH], rows[FW_BATCH], first_rank[FW_BATCH];
+};
+
+template <uint32_t WIDTH>
+__device__ __forceinline__ void load_fill_batch(const MaterializeArgs& a, uint32_t batch_step, uint32_t end_step, uint32_t chunk_rows, uint32_t lane, FillBatch<WIDTH>& batch) {
+  typedef const __attribute__((address_space(1))) u32x4_t* global_x4;
+  typedef const __attribute__((address_space(1))) u32x2_t* global_x2;
+  // the batch's steps lie in at most two slices (FW_BATCH divides the steps of a slice: in one, in fact -- two keeps the code independent of that)
+  const uint32_t slice0 = batch_step / FW_STEPS_PER_SLICE;
+  const SliceView view0 = a.views[slice0];
+  const SliceView view1 = a.views[slice0 + 1 < a.n_slices ? slice0 + 1 : slice0];
+  // (every chunk but the last holds chunk_rows rows -- rank_table_fill_waves serves identity tables -- so a chunk's first rank needs no load)
+  const uint32_t rank0 = view0.chunk * chunk_rows + view0.row_begin, rank1 = view1.chunk * chunk_rows + view1.row_begin;
+#pragma unroll
+  for (uint32_t k = 0; k < FW_BATCH; ++k) {
+    const uint32_t step = batch_step + k;
+    const bool second = step / FW_STEPS_PER_SLICE != slice0;
+    const SliceView& view = second ? view1 : view0;
+    const uint32_t offset = (step % FW_STEPS_PER_SLICE) * FW_STEP;
+    batch.rows[k] = step < end_step && view.row_count > offset ? (view.row_count - offset < FW_STEP ? view.row_count - offset : FW_STEP) : 0;
+    batch.first_rank[k] = (second ? rank1 : rank0) + offset;
+    batch.a[k] = u32x4_t{0, 0, 0, 0};
+    batch.b[k] = u32x4_t{0, 0, 0, 0};
+    batch.bias[k] = 0;
+    if (batch.rows[k] != 0) {
+      const uint32_t row = view.row_begin + offset + (lane * 8 < batch.rows[k] ? lane * 8 : 0);   // (a lane without rows reads the step's first rows again)
+      const char* base = static_cast<const char*>(view.data);
+      if constexpr (WIDTH == 4) {
+        batch.a[k] = *(global_x4)(base + size_t{row} * 4);
+        batch.b[k] = *(global_x4)(base + size_t{row} * 4 + 16);
+      } else if constexpr (WIDTH == 2) {
+        batch.a[k] = *(global_x4)(base + size_t{row} * 2);
+      } else {
+        const u32x2_t v = *(global_x2)(base + row);
+        batch.a[k].x = v.x;
+        batch.a[k].y = v.y;
+      }
+      if (view.kind != VIEW_INT32) batch.bias[k] = static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + offset) / HY_FOR_BLOCK_SIZE]);
+    }
+  }
+}
+
+template <uint32_t WIDTH>
+__global__ __launch_bounds__(256, 4) void rank_table_fill_waves(MaterializeArgs a, uint64_t key_min, uint64_t hint_range, u32x2_entry_t* entries, uint64_t* partials, uint32_t chunk_rows,
+                                                             uint32_t batches_per_wave, uint32_t n_steps, uint32_t debug) {
+  __shared__ uint32_t s_window[4][FW_WINDOW];   // per wave: the presence bits of the batch's table words
+  __shared__ uint64_t s_min[4], s_max[4];
+  __shared__ uint32_t s_flags;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr uint64_t SIGN = 1ull << 63;
+  const uint32_t origin = static_cast<uint32_t>(key_min), range = static_cast<uint32_t>(hint_range);
+  uint32_t* bloom_words = reinterpret_cast<uint32_t*>(a.bloom_out);
+  uint32_t* bits_window = s_window[wave];
+  const uint32_t steps_per_wave = batches_per_wave * FW_BATCH;
+  const uint32_t first_step = (blockIdx.x * 4 + wave) * steps_per_wave;
+  const uint32_t end_step = first_step + steps_per_wave < n_steps ? first_step + steps_per_wave : n_steps;
+  if (tid == 0) s_flags = 0;
+  FillWaveState w;
+  FillBatch<WIDTH> current, ahead;
+  if (first_step < end_step) {
+    load_fill_batch<WIDTH>(a, first_step, end_step, chunk_rows, lane, current);
+    int32_t front = 0;
+    uint32_t has_front = 0;
+    if (lane == 0) has_front = key_in_front_of_step(a, first_step, &front) ? 1u : 0u;
+    w.carry = __builtin_amdgcn_readfirstlane(front);
+    w.has_carry = __builtin_amdgcn_readfirstlane(has_front) != 0;
+  }
+  for (uint32_t batch_step = first_step; batch_step < end_step; batch_step += FW_BATCH) {
+    if (batch_step + FW_BATCH < end_step) load_fill_batch<WIDTH>(a, batch_step + FW_BATCH, end_step, chunk_rows, lane, ahead);   // (in flight while this batch is built)
+    // steps with rows come first inside a slice; a batch that straddles two slices (never, as FW_BATCH divides a slice's steps) or whose
+    // keys do not fit one window goes step by step
+    bool packed = true;
+#pragma unroll
+    for (uint32_t k = 1; k < FW_BATCH; ++k) packed = packed && (current.rows[k] == 0 || current.rows[k - 1] == FW_STEP);
+    if (!packed || !fill_process_steps<WIDTH, FW_BATCH>(w, current.a, current.b, current.bias, current.rows, current.first_rank, lane, origin, range, entries, bloom_words, bits_window,
+                                                        debug)) {
+#pragma unroll
+      for (uint32_t k = 0; k < FW_BATCH; ++k) {
+        const u32x4_t one_a[1] = {current.a[k]}, one_b[1] = {current.b[k]};
+        const uint32_t one_bias[1] = {current.bias[k]}, one_rows[1] = {current.rows[k]}, one_rank[1] = {current.first_rank[k]};
+        fill_process_steps<WIDTH, 1>(w, one_a, one_b, one_bias, one_rows, one_rank, lane, origin, range, entries, bloom_words, bits_window, debug);
+      }
     }
     current = ahead;
-    view = next_view;
   }
-  if (flags) atomicOr(&s_flags, flags);
+  const uint64_t unsorted = w.unsorted, equal = w.equal, outside = w.outside;
+  const int32_t low = w.low, high = w.high;
+  const bool any_rows = w.any_rows;
+  // the workgroup's record: extent and flags of its four waves.  No arrival counter, no verdict here: the kernel that plans the join's
+  // output (pk_plan) reads the records -- rank_table_fill_checked's workgroups queue on two dependent agent-scope round trips for that
+  const uint32_t flags = (unsorted ? 1u : 0u) | (equal ? 2u : 0u) | (outside ? 4u : 0u);
+  if (lane == 0) {
+    s_min[wave] = any_rows ? static_cast<uint64_t>(static_cast<int64_t>(low)) ^ SIGN : ~0ull;
+    s_max[wave] = any_rows ? static_cast<uint64_t>(static_cast<int64_t>(high)) ^ SIGN : 0;
+  }
   __syncthreads();
-  if (tid == 0) {   // (the record and the arrival: as in rank_table_fill_checked, once per workgroup)
-    const uint64_t low = any_rows ? static_cast<uint64_t>(static_cast<int64_t>(low32)) ^ SIGN : ~0ull, high = any_rows ? static_cast<uint64_t>(static_cast<int64_t>(high32)) ^ SIGN : 0;
+  if (lane == 0 && flags) atomicOr(&s_flags, flags);
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t group_low = ~0ull, group_high = 0;
+    for (uint32_t v = 0; v < 4; ++v) { group_low = s_min[v] < group_low ? s_min[v] : group_low; group_high = s_max[v] > group_high ? s_max[v] : group_high; }
     uint64_t* record = partials + 4 * size_t{blockIdx.x};
-    __hip_atomic_store(record + 0, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(record + 1, high, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(record + 2, static_cast<uint64_t>(s_flags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t lanes = gridDim.x < CHECKED_FILL_TICKETS ? gridDim.x : CHECKED_FILL_TICKETS, mine = blockIdx.x % lanes;
-    const uint32_t quota = gridDim.x / lanes + (mine < gridDim.x % lanes ? 1u : 0u);
-    uint32_t last = 0;
-    if (__hip_atomic_fetch_add(ticket + 32 * (1 + mine), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == quota)
-      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == lanes ? 1u : 0u;
-    s_last = last;
+    record[0] = group_low;
+    record[1] = group_high;
+    record[2] = s_flags;
   }
-  __syncthreads();
-  if (!s_last) return;
-  uint64_t low = ~0ull, high = 0, bits = 0;
-  for (uint32_t i = tid; i < gridDim.x; i += 256) {
-    uint64_t* record = partials + 4 * size_t{i};
-    const uint64_t record_low = __hip_atomic_load(record + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), record_high = __hip_atomic_load(record + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    low = record_low < low ? record_low : low;
-    high = record_high > high ? record_high : high;
-    bits |= __hip_atomic_load(record + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    bits |= __shfl_xor(bits, d, 64);
-    const uint64_t other_low = __shfl_xor(low, d, 64), other_high = __shfl_xor(high, d, 64);
-    low = other_low < low ? other_low : low;
-    high = other_high > high ? other_high : high;
-  }
-  __syncthreads();
-  if ((tid & 63) == 0) { s_min[tid >> 6] = low; s_max[tid >> 6] = high; atomicOr(&s_flags, static_cast<uint32_t>(bits)); }
-  __syncthreads();
-  if (tid != 0) return;
-  for (uint32_t w = 0; w < 4; ++w) { low = s_min[w] < low ? s_min[w] : low; high = s_max[w] > high ? s_max[w] : high; }
-  verdict->key_min = low ^ SIGN;
-  verdict->key_max = high ^ SIGN;
-  verdict->unsorted_signed = s_flags & 1u ? 1 : 0;
-  verdict->equal_neighbours = s_flags & 2u ? 1 : 0;
-  verdict->outside_hint = s_flags & 4u ? 1 : 0;
-  verdict->done = 1;
-  __threadfence_system();
 }
 
 // flags: see check_sorted; [10] a key met twice by rank_table_mark
@@ -2907,7 +3128,9 @@ struct BuildSide {
   bool bloom_is_bits = false;    // the filter is 2^20 BITS (rank_table_fill_checked folds the table's presence words into it), not one byte per bit
   bool hinted = false;           // the rank table was filled from the column's key hint: pk_plan confirms `verdict` against the hint
   uint64_t hint_min = 0, hint_max = 0;
-  const BuildVerdict* verdict = nullptr;   // (device memory, behind the table's arrival counters)
+  const BuildVerdict* verdict = nullptr;   // (device memory, behind the table's arrival counters: rank_table_fill_checked)
+  const uint64_t* fill_records = nullptr;  // ... or one record per workgroup of rank_table_fill_waves: [n_fill_records][4] smallest key | largest key (both ^ sign) | flags
+  uint32_t n_fill_records = 0;
   uint64_t n = 0;
   Directory directory{};
   RankTable rank{};            // rank.entries != nullptr: unique integer keys, looked up in the rank table (directory.dir is not built)
@@ -3001,7 +3224,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       const uint64_t words = ((key_max - origin) >> 5) + 1;
       const size_t ticket_bytes = 128 * (size_t{CHECKED_FILL_TICKETS} + 1);
       HY_TRY(b.rank_entries.alloc(8 * (words + 2) + ticket_bytes + 64));   // the table | the arrival counters | the verdict
-      HY_TRY(b.partials.alloc(32 * size_t{n_slices}));
+      HY_TRY(b.partials.alloc(32 * (size_t{n_slices} * FW_STEPS_PER_SLICE / 4 + 1)));   // one record per workgroup: per slice (rank_table_fill_checked), or per four waves of >= 1 step (rank_table_fill_waves)
       u32x2_t* entries = b.rank_entries.as<u32x2_t>();
       {   // the table | the arrival counter, and the Bloom filter
         const size_t table_vectors = (8 * (words + 2) + ticket_bytes + 64 + 15) / 16, bloom_vectors = want_bloom ? BLOOM_BITS / 8 / 16 : 0;   // (the filter as bits: 128 KB)
@@ -3011,24 +3234,33 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       BuildVerdict* verdict = reinterpret_cast<BuildVerdict*>(reinterpret_cast<char*>(entries + words + 2) + ticket_bytes);
       MaterializeArgs m = m_in;
       if (const char* debug = HY_DEBUG_ENV("HY_JOIN_FILL_DEBUG")) {   // timing experiments only (results are wrong): 1 no filter, 2 no table either
-        m.bloom_out = nullptr;
-        if (atoi(debug) >= 2) m.keep_nulls = 0xFFFFFFFFu;
+        if (atoi(debug) & 1) m.bloom_out = nullptr;
+        if (atoi(debug) >= 2 && !option(HY_OPT_JOIN_FILL_WGS_PER_CU)) m.keep_nulls = 0xFFFFFFFFu;   // (rank_table_fill_checked: loads and extent only)
       }
       hipEvent_t fill_started = nullptr, fill_stopped = nullptr;
       profile_events(&fill_started, &fill_stopped, HY_KERNEL_JOIN_BUILD);
-      // rank_table_fill_stream: as many workgroups as stay resident (option: per CU), each with the same number of consecutive slices
-      const uint32_t fill_capacity = device_cu_count() * static_cast<uint32_t>(std::max<int64_t>(0, std::min<int64_t>(3, option(HY_OPT_JOIN_FILL_WGS_PER_CU))));
+      // rank_table_fill_waves: as many waves as stay resident (at most the option's workgroups per CU), each with the same number of consecutive batches
       const uint32_t stream_width = build->stream_width == 1 || build->stream_width == 2 || build->stream_width == 4 ? build->stream_width : 0;
-      if (fill_capacity && stream_width && m.keep_nulls != 0xFFFFFFFFu) {
-        const uint32_t slices_per_group = (n_slices + fill_capacity - 1) / fill_capacity, groups = (n_slices + slices_per_group - 1) / slices_per_group;
-        uint32_t* tickets = reinterpret_cast<uint32_t*>(entries + words + 2);
-        if (stream_width == 4) hipExtLaunchKernelGGL(rank_table_fill_stream<4>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), tickets, verdict, slices_per_group);
-        else if (stream_width == 2) hipExtLaunchKernelGGL(rank_table_fill_stream<2>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), tickets, verdict, slices_per_group);
-        else hipExtLaunchKernelGGL(rank_table_fill_stream<1>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), tickets, verdict, slices_per_group);
+      uint32_t fill_waves = 0;
+      if (stream_width && option(HY_OPT_JOIN_FILL_WGS_PER_CU) > 0) {
+        int per_cu = 0;
+        const void* kernel = stream_width == 4 ? reinterpret_cast<const void*>(rank_table_fill_waves<4>) : stream_width == 2 ? reinterpret_cast<const void*>(rank_table_fill_waves<2>) : reinterpret_cast<const void*>(rank_table_fill_waves<1>);
+        HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+        fill_waves = 4 * device_cu_count() * static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(per_cu, option(HY_OPT_JOIN_FILL_WGS_PER_CU))));
+      }
+      const uint32_t fill_debug = HY_DEBUG_ENV("HY_JOIN_FILL_DEBUG") ? static_cast<uint32_t>(atoi(HY_DEBUG_ENV("HY_JOIN_FILL_DEBUG"))) : 0u;   // (wave kernel: 1 no filter, 2 no table stores, 4 no LDS work, 8 loads and checks only)
+      if (fill_waves) {
+        const uint32_t n_steps = n_slices * FW_STEPS_PER_SLICE, n_batches = (n_steps + FW_BATCH - 1) / FW_BATCH;
+        const uint32_t batches_per_wave = (n_batches + fill_waves - 1) / fill_waves, waves = (n_batches + batches_per_wave - 1) / batches_per_wave, groups = (waves + 3) / 4;
+        b.fill_records = b.partials.as<uint64_t>();
+        b.n_fill_records = groups;
+        if (stream_width == 4) hipExtLaunchKernelGGL(rank_table_fill_waves<4>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), build->host_segments[0].size, batches_per_wave, n_steps, fill_debug);
+        else if (stream_width == 2) hipExtLaunchKernelGGL(rank_table_fill_waves<2>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), build->host_segments[0].size, batches_per_wave, n_steps, fill_debug);
+        else hipExtLaunchKernelGGL(rank_table_fill_waves<1>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), build->host_segments[0].size, batches_per_wave, n_steps, fill_debug);
       } else
       hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries,
                             b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 2), verdict);
-      b.verdict = verdict;
+      b.verdict = b.n_fill_records ? nullptr : verdict;
       identity_table(entries, origin, key_max);
       b.directory.key_min = key_min;
       b.bloom_is_bits = want_bloom;
@@ -3500,6 +3732,8 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     const bool async = !count_only && !host_result && (result->flags & HY_JOIN_ASYNC) && result->status;
     k.status = async ? result->status : nullptr;
     k.verdict = b.hinted ? b.verdict : nullptr;
+    k.fill_records = b.hinted ? b.fill_records : nullptr;
+    k.n_fill_records = b.hinted ? b.n_fill_records : 0;
     k.hint_min = b.hint_min;
     k.hint_max = b.hint_max;
     k.hint_allows_duplicates = b.hint_allows_duplicates ? 1u : 0u;

@@ -79,7 +79,9 @@ struct PkArgs {
   uint8_t* row_masks;              // [n_tiles][2][PK_TILE / 8] found | materialised, or nullptr (the classic kernels)
   // A build side filled on the strength of the column's key hint (rank_table_fill_checked): pk_plan confirms the fill's verdict
   // against the hint -- a column that contradicts it gets the plan "does not fit": nothing is written, the host runs the join again.
-  const BuildVerdict* verdict;     // nullptr: the build side was not hinted
+  const BuildVerdict* verdict;     // rank_table_fill_checked's; nullptr: the build side was not hinted, or ...
+  const uint64_t* fill_records;    // ... rank_table_fill_waves filled it: [n_fill_records][4] smallest key | largest key (both ^ sign) | flags, one per workgroup
+  uint32_t n_fill_records;
   uint64_t hint_min, hint_max;
   uint32_t hint_allows_duplicates;
   hy_join_status* status;          // HY_JOIN_ASYNC: what the host would read from the mailbox, in device memory; else nullptr
@@ -336,9 +338,37 @@ __device__ void pk_plan(const PkArgs& a, uint64_t* s_tmp, uint32_t tid) {
     n_slices = static_cast<uint32_t>(running);
     if (tid == 0) { a.origin_pairs[0] = 0; a.origin_pairs[1] = n_pairs; a.slice_base[a.n_groups] = n_slices; }
   }
+  // The records of rank_table_fill_waves' workgroups (written by an earlier kernel of this stream): extent and flags of the build column.
+  uint64_t build_low = ~0ull, build_high = 0, build_flags = 0;
+  if (a.fill_records) {
+    for (uint32_t i = tid; i < a.n_fill_records; i += PK_SCAN_THREADS) {
+      const uint64_t* record = a.fill_records + 4 * size_t{i};
+      build_low = record[0] < build_low ? record[0] : build_low;
+      build_high = record[1] > build_high ? record[1] : build_high;
+      build_flags |= record[2];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      build_flags |= __shfl_xor(build_flags, d, 64);
+      const uint64_t other_low = __shfl_xor(build_low, d, 64), other_high = __shfl_xor(build_high, d, 64);
+      build_low = other_low < build_low ? other_low : build_low;
+      build_high = other_high > build_high ? other_high : build_high;
+    }
+    __syncthreads();   // (s_tmp may still be read from the scans above)
+    if ((tid & 63) == 0) { s_tmp[tid >> 6] = build_low; s_tmp[8 + (tid >> 6)] = build_high; s_tmp[16 + (tid >> 6)] = build_flags; }
+    __syncthreads();
+  }
   if (tid == 0) {
     bool confirmed = true;
-    if (a.verdict) {   // (written by an earlier kernel of this stream)
+    if (a.fill_records) {
+      for (uint32_t v = 0; v < PK_SCAN_THREADS / 64; ++v) {
+        build_low = s_tmp[v] < build_low ? s_tmp[v] : build_low;
+        build_high = s_tmp[8 + v] > build_high ? s_tmp[8 + v] : build_high;
+        build_flags |= s_tmp[16 + v];
+      }
+      constexpr uint64_t SIGN = 1ull << 63;
+      confirmed = !(build_flags & 1) && (!(build_flags & 2) || a.hint_allows_duplicates) && !(build_flags & 4) && (build_low ^ SIGN) == a.hint_min && (build_high ^ SIGN) == a.hint_max;
+    } else if (a.verdict) {   // (written by an earlier kernel of this stream)
       const BuildVerdict v = *a.verdict;
       confirmed = v.done && !v.unsorted_signed && (!v.equal_neighbours || a.hint_allows_duplicates) && !v.outside_hint && v.key_min == a.hint_min && v.key_max == a.hint_max;
     }
@@ -367,7 +397,7 @@ __global__ __launch_bounds__(PK_SCAN_THREADS) void pk_scan(PkArgs a) {
   // element i of a chunk sits at i + i / 16: a thread's 16 consecutive elements start 17 words apart -> no bank conflicts
   constexpr uint32_t PER_THREAD = PK_SCAN_CHUNK / PK_SCAN_THREADS, PADDED = PK_SCAN_CHUNK + PK_SCAN_CHUNK / PER_THREAD;
   __shared__ uint32_t s_elements[PADDED], s_pairs[PADDED];
-  __shared__ uint64_t s_tmp[8];
+  __shared__ uint64_t s_tmp[24];   // (scans: 8 wave totals; pk_plan's reduction of the build side's records: 3 x 8)
   __shared__ uint32_t s_last;
   const uint32_t tid = threadIdx.x, partition = blockIdx.x;
   const uint32_t* counts = a.counts + static_cast<size_t>(partition) * a.stride;

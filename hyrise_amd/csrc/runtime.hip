@@ -38,7 +38,7 @@ struct OptionDefaults {
     set(HY_OPT_FUSED_SHARED_PREFIX, 1);
     set(HY_OPT_JOIN_LDS_HASH, 1);
     set(HY_OPT_HOST_RESULT_TILES, 1);
-    set(HY_OPT_JOIN_FILL_WGS_PER_CU, 3);
+    set(HY_OPT_JOIN_FILL_WGS_PER_CU, 4);
   }
 };
 OptionDefaults g_option_defaults;   // (static initialisation: before any entry point can run)

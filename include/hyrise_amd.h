@@ -255,8 +255,8 @@ enum {
   HY_OPT_FUSED_SHARED_PREFIX = 23,   /* 1    fused inputs that begin with an earlier input continue on its stack                      */
   HY_OPT_JOIN_LDS_HASH = 24,         /* 1    general builds (duplicates, unsorted, sparse, float keys): radix partitions + LDS hash tables */
   HY_OPT_HOST_RESULT_TILES = 25,     /* 1    host-memory results leave through pinned staging tiles that overlap the kernels          */
-  HY_OPT_JOIN_FILL_WGS_PER_CU = 26,  /* 3    the checked one-pass fill with persistent workgroups (this many per CU, <= 3) that read a slice
-                                      *      ahead; 0 = one short-lived workgroup per slice                                           */
+  HY_OPT_JOIN_FILL_WGS_PER_CU = 26,  /* 4    the checked one-pass fill wave by wave (rank_table_fill_waves: this many resident workgroups per
+                                      *      CU, <= 8); 0 = one short-lived workgroup per slice (rank_table_fill_checked)              */
   HY_OPT_COUNT = 32
 };
 hy_status hy_set_option(uint32_t option, int64_t value);

@@ -783,16 +783,17 @@ def test_primary_key_hint(device, options):
             assert_join_equal(got, want, abi.JOIN_INNER, f"filter aliases, radix {radix_bits}, attempt {attempt}")
 
 
-@pytest.mark.parametrize("workgroups_per_cu", [0, 1, 3])
+@pytest.mark.parametrize("workgroups_per_cu", [0, 1, 4])
 def test_hinted_fill_kernels(device, options, workgroups_per_cu):
     """The one-pass checked fill of a hinted build side, as short-lived workgroups (one per slice, HY_OPT_JOIN_FILL_WGS_PER_CU = 0) and as
-    persistent ones that read a slice ahead (rank_table_fill_stream<1 | 2 | 4>): int32 values and FrameOfReference offsets of every
-    width, ragged chunks (slices of 3 and 8191 rows), sparse stretches (slices whose keys span more table words than the LDS window),
-    more slices than workgroups -- and a column that is NOT sorted although an (invented) hint says so: the verdict must catch it."""
+    wave by wave (rank_table_fill_waves<1 | 2 | 4>: every wave a run of 512-row steps, read a step ahead, built in its own LDS window):
+    int32 values and FrameOfReference offsets of every width, ragged chunks (steps of 3 and 511 rows), sparse stretches (steps whose
+    keys span more table words than the window), one step and several steps per wave -- and a column that is NOT sorted although its
+    hint says so: the verdict must catch it."""
     options.set(abi.OPT_JOIN_FILL_WGS_PER_CU, workgroups_per_cu)
     lib = abi.load_library()
     rng = np.random.default_rng(400 + workgroups_per_cu)
-    n = 3_300_000 if workgroups_per_cu == 1 else 700_000   # (1 per CU: 256 workgroups for 400+ slices -- two slices each)
+    n = 3_300_000 if workgroups_per_cu else 700_000   # (6 464 steps: seven per wave with one workgroup per CU, two with four)
     dense = np.arange(n, dtype=np.int32) * 2 - 50_000                                   # 4-byte values; as FoR: 2-byte offsets
     stepped = (np.arange(n, dtype=np.int64) // 8 * 32 + np.arange(n) % 8).astype(np.int32)   # dbgen's sparse keys: 8 of every 32
     sparse_tail = np.concatenate([np.arange(n - 20_000, dtype=np.int64), (n - 20_000) + np.arange(20_000, dtype=np.int64) * 37]).astype(np.int32)   # the last slices: 37 key values per key
@@ -802,7 +803,7 @@ def test_hinted_fill_kernels(device, options, workgroups_per_cu):
              ("wide FoR", sparse_tail, abi.ENC_FRAME_OF_REFERENCE, 65535)]
     for name, keys, encoding, chunk in cases:
         build_host = build_column(keys, None, chunk, encoding)
-        probe_keys = np.sort(np.concatenate([rng.choice(keys, 300_000), rng.integers(int(keys[0]) - 100, int(keys[-1]) + 100, 50_000).astype(np.int32)]).astype(np.int32))
+        probe_keys = np.sort(np.concatenate([rng.choice(keys, len(keys) + 50_000), rng.integers(int(keys[0]) - 100, int(keys[-1]) + 100, 50_000).astype(np.int32)]).astype(np.int32))   # (more probe rows than build rows: JoinHash builds over the smaller side)
         probe_host = build_column(probe_keys, None, 65535, abi.ENC_FRAME_OF_REFERENCE)
         build, probe = DeviceColumn(build_host), DeviceColumn(probe_host)
         want = oracle_join(build_host, probe_host, abi.JOIN_INNER)
@@ -815,7 +816,7 @@ def test_hinted_fill_kernels(device, options, workgroups_per_cu):
     # must hold anyway): the verdict says unsorted, nothing is written, the join runs again on the two-pass build
     keys = np.arange(600_000, dtype=np.int32) * 2
     chunk = 65520   # (chunk buffers 16-byte aligned inside the one allocation: the checked fill reads 16 bytes per load)
-    probe_host = build_column(np.sort(rng.choice(keys, 400_000)).astype(np.int32), None, 65535, abi.ENC_FRAME_OF_REFERENCE)
+    probe_host = build_column(np.sort(rng.choice(keys, 700_000)).astype(np.int32), None, 65535, abi.ENC_FRAME_OF_REFERENCE)   # (more probe rows than build rows)
     probe = DeviceColumn(probe_host)
     pointer, _ = _device_buffer(lib, keys.shape, np.int32, 0)
     abi.check(lib.hy_memcpy_h2d(pointer, keys.ctypes.data, keys.nbytes))
