@@ -152,6 +152,52 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
   const uint32_t origin = static_cast<uint32_t>(a.rank.key_min), range = static_cast<uint32_t>(a.rank.range);
   const uint32_t mask = a.radix_bits ? (1u << a.radix_bits) - 1 : 0u;
   const uint32_t copy = ((lane >> 4) & 3) | ((lane & 1) << 2);   // (lanes 16 apart -- 32 orders, the period of dbgen's sparse keys mod 128 -- meet in one partition: they use different copies)
+  uint32_t counted = 0;   // (uniform) bit b: batch b was counted by the lean loop
+  // The lean loop -- Inner / Semi joins, a wave whose 2048 rows all exist, the table in global memory: about a dozen vector instructions
+  // per row (the general loop below spends twice that on masks for rows that do not exist and on merging runs of equal partitions, and
+  // is bound by it: 38 of pk_count's 47 us at SF10 were instruction issue).  A key outside the table's range reads the empty entry behind
+  // the table (distance clamped to range + 32: every build path allocates and clears that entry), so a row is one unpack, one add, one
+  // clamp, a shift and a mask for the address, one bit test -- and ONE LDS atomic, no run detection: with eight copies per cell the
+  // lanes of an instruction rarely meet.  A batch in which some row has no partner goes to the general loop (the Bloom filter decides
+  // about such rows), as does every other mode.
+  if constexpr (!LDS) {
+    if ((a.mode == HY_JOIN_INNER || a.mode == HY_JOIN_SEMI) && wave_first + PK_COUNT_WAVE_ROWS <= row_count) {
+      const uint32_t delta = bias - origin, beyond = range + 32;
+      const char* table = reinterpret_cast<const char*>(a.rank.entries);
+      uint32_t counted_here = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < PK_COUNT_BATCHES; g += 2) {
+        uint32_t bits[2][8];
+#pragma unroll
+        for (uint32_t b = 0; b < 2; ++b) {
+#pragma unroll
+          for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t distance = batch_word<WIDTH>(words[g + b], j) + delta;
+            const uint32_t clamped = distance < beyond ? distance : beyond;
+            bits[b][j] = *reinterpret_cast<const uint32_t*>(table + ((clamped >> 2) & ~7u));
+          }
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < 2; ++b) {
+          uint32_t found = 0;
+#pragma unroll
+          for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t distance = batch_word<WIDTH>(words[g + b], j) + delta;
+            found |= (distance <= range ? (bits[b][j] >> (distance & 31)) & 1u : 0u) << j;
+          }
+          if (__any(found != 0xFFu)) continue;   // (uniform: the batch is counted by the general loop)
+#pragma unroll
+          for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t partition = (batch_word<WIDTH>(words[g + b], j) + bias) & mask;
+            atomicAdd(&cells[partition * COUNT_COPIES + copy], 0x10001u);
+          }
+          counted_here |= 1u << (g + b);
+        }
+      }
+      counted = counted_here;
+      if (counted == (1u << PK_COUNT_BATCHES) - 1) return;
+    }
+  }
   // Two groups of 1024 rows: a group's sixteen lookups per lane are in flight together (counting only needs an entry's presence bits,
   // its first word), and the kernel stays at 64 registers -- eight workgroups per CU hide each other's round trips.
 #pragma unroll
@@ -168,6 +214,7 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
     }
 #pragma unroll
     for (uint32_t b = 0; b < 2; ++b) {
+      if ((counted >> (g + b)) & 1) continue;
       uint32_t valid = 0, found = 0;
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
