@@ -696,6 +696,87 @@ __global__ __launch_bounds__(256) void sort_scatter(const K* keys_in, const R* r
   }
 }
 
+// The same pass over 8192-element tiles with the tile's elements staged in LDS digit by digit: a digit's elements of a tile leave as one
+// run per array (32 elements on average: whole 128-byte lines) instead of one scattered 4-byte store each -- sort_scatter's 2048-element
+// tiles wrote 15 M keys and 15 M RowIDs per pass at 0.75 TB/s.  The rank inside (wave, digit) is one returning LDS atomic per element
+// (lane-ordered: lds_atomic_order_probe; the host keeps sort_scatter where that does not hold).  uint32 keys and packed RowIDs.
+constexpr uint32_t SORT_BIG_TILE = 8192, SORT_BIG_THREADS = 512, SORT_BIG_WAVES = SORT_BIG_THREADS / 64, SORT_BIG_ROUNDS = SORT_BIG_TILE / SORT_BIG_THREADS;
+__global__ __launch_bounds__(SORT_BIG_THREADS) void sort_histogram_big(const uint32_t* keys, uint64_t n, uint32_t shift, uint32_t* hist, uint32_t n_tiles) {
+  __shared__ uint32_t s_hist[4][256];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < 4 * 256; i += SORT_BIG_THREADS) (&s_hist[0][0])[i] = 0;
+  __syncthreads();
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SORT_BIG_TILE;
+#pragma unroll
+  for (uint32_t k = 0; k < SORT_BIG_ROUNDS; ++k) {
+    const uint64_t i = base + k * SORT_BIG_THREADS + tid;
+    if (i < n) atomicAdd(&s_hist[tid & 3][(keys[i] >> shift) & 0xFF], 1u);
+  }
+  __syncthreads();
+  if (tid < 256) hist[static_cast<size_t>(tid) * n_tiles + blockIdx.x] = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
+}
+
+__global__ __launch_bounds__(SORT_BIG_THREADS) void sort_scatter_staged(const uint32_t* keys_in, const uint32_t* rows_in, uint32_t* keys_out, uint32_t* rows_out, uint64_t n, uint32_t shift,
+                                                                         const uint64_t* bases, uint32_t n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sort_smem[];
+  u32x2_t* s_stage = reinterpret_cast<u32x2_t*>(sort_smem);                 // [SORT_BIG_TILE]
+  uint32_t* s_wave = sort_smem + 2 * SORT_BIG_TILE;                           // [SORT_BIG_WAVES][256]
+  uint32_t* s_first = s_wave + SORT_BIG_WAVES * 256;                          // [256]
+  uint64_t* s_base = reinterpret_cast<uint64_t*>(s_first + 256);              // [256]
+  uint32_t* s_totals = reinterpret_cast<uint32_t*>(s_base + 256);             // [8]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint64_t tile_base = static_cast<uint64_t>(blockIdx.x) * SORT_BIG_TILE;
+  const uint32_t count = n - tile_base < SORT_BIG_TILE ? static_cast<uint32_t>(n - tile_base) : SORT_BIG_TILE;
+  for (uint32_t i = tid; i < SORT_BIG_WAVES * 256; i += SORT_BIG_THREADS) s_wave[i] = 0;
+  // wave w owns elements [w * 1024, (w + 1) * 1024) of the tile, element w * 1024 + k * 64 + lane in round k: element order = (wave, round, lane)
+  uint32_t key[SORT_BIG_ROUNDS], row[SORT_BIG_ROUNDS], before[SORT_BIG_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < SORT_BIG_ROUNDS; ++k) {
+    const uint32_t e = wave * (SORT_BIG_TILE / SORT_BIG_WAVES) + k * 64 + lane;
+    key[k] = e < count ? keys_in[tile_base + e] : 0u;
+    row[k] = e < count ? rows_in[tile_base + e] : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < SORT_BIG_ROUNDS; ++k) {
+    const uint32_t e = wave * (SORT_BIG_TILE / SORT_BIG_WAVES) + k * 64 + lane;
+    before[k] = 0;
+    if (e < count) before[k] = atomicAdd(&s_wave[wave * 256 + ((key[k] >> shift) & 0xFF)], 1u);
+  }
+  __syncthreads();
+  uint32_t total = 0;
+  if (tid < 256) {
+#pragma unroll
+    for (uint32_t w = 0; w < SORT_BIG_WAVES; ++w) { const uint32_t c = s_wave[w * 256 + tid]; s_wave[w * 256 + tid] = total; total += c; }
+  }
+  const uint32_t inclusive = join_wave_inclusive_scan(total);
+  if (lane == 63) s_totals[wave] = inclusive;
+  __syncthreads();
+  uint32_t earlier_waves = 0;
+  for (uint32_t w = 0; w < wave; ++w) earlier_waves += s_totals[w];
+  if (tid < 256) {
+    const uint32_t first = earlier_waves + inclusive - total;
+    s_first[tid] = first;
+    s_base[tid] = bases[static_cast<size_t>(tid) * n_tiles + blockIdx.x] - first;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < SORT_BIG_ROUNDS; ++k) {
+    const uint32_t e = wave * (SORT_BIG_TILE / SORT_BIG_WAVES) + k * 64 + lane;
+    if (e >= count) continue;
+    const uint32_t digit = (key[k] >> shift) & 0xFF;
+    s_stage[s_first[digit] + s_wave[wave * 256 + digit] + before[k]] = u32x2_t{key[k], row[k]};
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < count; i += SORT_BIG_THREADS) {
+    const u32x2_t element = s_stage[i];
+    const uint64_t at = s_base[(element.x >> shift) & 0xFF] + i;
+    keys_out[at] = element.x;
+    rows_out[at] = element.y;
+  }
+}
+__host__ __device__ constexpr size_t sort_staged_lds_bytes() { return 4 * (2 * size_t{SORT_BIG_TILE} + SORT_BIG_WAVES * 256 + 256 + 2 * 256 + 8); }
+
 // Exclusive scan of a long u32 array into u64: per-block sums (4096 elements per workgroup), a single-workgroup scan
 // of the block sums, then per-block scans with the block's offset.  out[n] = total.
 constexpr uint32_t SCAN_BLOCK = 4096;
@@ -3101,6 +3182,7 @@ __global__ __launch_bounds__(256) void plan_output(const uint64_t* base_elements
 }
 
 #include "join_pkfk.hpp"
+#include "join_hp.hpp"
 
 __global__ void publish_join_status(hy_join_status* status, uint64_t n_pairs, uint32_t n_slices, uint32_t fits) {
   status->n_pairs = n_pairs;
@@ -3121,6 +3203,7 @@ struct StageClock {
 };
 
 static uint32_t device_cu_count();
+static bool lds_atomics_are_lane_ordered(hipStream_t stream);
 
 struct BuildSide {
   DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags, rank_entries, partials;
@@ -3131,6 +3214,11 @@ struct BuildSide {
   const BuildVerdict* verdict = nullptr;   // (device memory, behind the table's arrival counters: rank_table_fill_checked)
   const uint64_t* fill_records = nullptr;  // ... or one record per workgroup of rank_table_fill_waves: [n_fill_records][4] smallest key | largest key (both ^ sign) | flags
   uint32_t n_fill_records = 0;
+  // The radix-partitioned path (join_hp.hpp) should run instead of anything prepared here: unique int32 keys in [hp_min, hp_max] (or, existence
+  // only, keys with repeats), a build column that is not sorted or a probe side without locality; nothing of the build side has been launched.
+  bool hp_wanted = false;
+  bool hp_extent_from_column = false;   // the extent was remembered by the column (no host round trip happened)
+  uint64_t hp_min = 0, hp_max = 0;
   uint64_t n = 0;
   Directory directory{};
   RankTable rank{};            // rank.entries != nullptr: unique integer keys, looked up in the rank table (directory.dir is not built)
@@ -3144,8 +3232,10 @@ struct BuildSide {
 // which only the presence bits mean anything.
 // `bit_filter_ok`: whoever probes reads the Bloom filter as 2^20 bits (the kernels of join_pkfk.hpp) -- what the one-pass hinted build
 // produces; everything else reads one byte per bit.
+// `hp_radix_bits` < 0xFFFFFFFF: the caller could run the radix-partitioned path with that many radix bits (join_hp.hpp; both columns fit it);
+// `probe_scattered`: the probe keys have no locality (a rank table read in place would be read at random).
 static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, uint32_t hashed_type, bool allow_rank_table, bool existence_only,
-                               bool bit_filter_ok, BuildSide& b, hipStream_t stream) {
+                               bool bit_filter_ok, uint32_t hp_radix_bits, bool probe_scattered, BuildSide& b, hipStream_t stream) {
   const uint32_t n_slices = build->n_slices;
   DeviceBuffer counts, offsets;
   HY_TRY(counts.alloc(4 * size_t{n_slices + 1}));
@@ -3164,6 +3254,29 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
   }
   const bool identity_candidate = dense && build->rows && uniform_chunks && build->host_segments[0].size > 0 && allow_rank_table && option(HY_OPT_JOIN_RANK_TABLE) &&
                                   option(HY_OPT_JOIN_IDENTITY);
+  // Would the partition tables of the radix-partitioned path fit LDS for keys in [key_min, key_max]?
+  auto hp_fits = [&](uint64_t key_min, uint64_t key_max) {
+    if (hp_radix_bits == 0xFFFFFFFFu || !identity_candidate || build->join_hint.hp_refused.load(std::memory_order_relaxed)) return false;
+    if (static_cast<int64_t>(key_min) < INT32_MIN || static_cast<int64_t>(key_max) > INT32_MAX) return false;
+    const uint64_t origin = key_min & ~((uint64_t{1} << hp_radix_bits) - 1), slots = ((key_max - origin) >> hp_radix_bits) + 1;
+    return (slots + 31) / 32 <= HP_MAX_TABLE_WORDS;
+  };
+  // a column that an earlier join found sorted and unique (its key hint), probed at random: the partitioned path, with no look at the keys
+  if (probe_scattered && build->join_hint.state.load(std::memory_order_acquire) == 1 && (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) &&
+      option(HY_OPT_JOIN_HINT) && hp_fits(build->join_hint.key_min.load(std::memory_order_relaxed), build->join_hint.key_max.load(std::memory_order_relaxed))) {
+    b.hp_wanted = b.hp_extent_from_column = true;
+    b.hp_min = build->join_hint.key_min.load(std::memory_order_relaxed);
+    b.hp_max = build->join_hint.key_max.load(std::memory_order_relaxed);
+    return HY_OK;
+  }
+  // ... or one that an earlier partitioned join found unique without being sorted
+  if (build->join_hint.hp_state.load(std::memory_order_acquire) == 1 && option(HY_OPT_JOIN_HINT) &&
+      hp_fits(build->join_hint.hp_min.load(std::memory_order_relaxed), build->join_hint.hp_max.load(std::memory_order_relaxed))) {
+    b.hp_wanted = b.hp_extent_from_column = true;
+    b.hp_min = build->join_hint.hp_min.load(std::memory_order_relaxed);
+    b.hp_max = build->join_hint.hp_max.load(std::memory_order_relaxed);
+    return HY_OK;
+  }
   bool hinted = identity_candidate && bit_filter_ok && build->join_hint.state.load(std::memory_order_acquire) == 1 &&
                 (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) && option(HY_OPT_JOIN_HINT);
   for (uint32_t c = 0; c < build->n_chunks && hinted; ++c) {   // rank_table_fill_checked reads int32 keys through SliceViews, 16 bytes per load
@@ -3248,7 +3361,8 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
         HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
         fill_waves = 4 * device_cu_count() * static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(per_cu, option(HY_OPT_JOIN_FILL_WGS_PER_CU))));
       }
-      const uint32_t fill_debug = HY_DEBUG_ENV("HY_JOIN_FILL_DEBUG") ? static_cast<uint32_t>(atoi(HY_DEBUG_ENV("HY_JOIN_FILL_DEBUG"))) : 0u;   // (wave kernel: 1 no filter, 2 no table stores, 4 no LDS work, 8 loads and checks only)
+      uint32_t fill_debug = 0;
+      if (const char* debug = HY_DEBUG_ENV("HY_JOIN_FILL_DEBUG")) fill_debug = static_cast<uint32_t>(atoi(debug));   // (wave kernel: 1 no filter, 2 no table stores, 4 no LDS work, 8 loads and checks only)
       if (fill_waves) {
         const uint32_t n_steps = n_slices * FW_STEPS_PER_SLICE, n_batches = (n_steps + FW_BATCH - 1) / FW_BATCH;
         const uint32_t batches_per_wave = (n_batches + fill_waves - 1) / fill_waves, waves = (n_batches + batches_per_wave - 1) / batches_per_wave, groups = (waves + 3) / 4;
@@ -3292,8 +3406,18 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     HY_HIP(hipStreamSynchronize(stream));
     const uint64_t key_min = mailbox->key_min, range = mailbox->key_max - mailbox->key_min;
     const uint64_t words = (range >> 5) + 1;
+    // The radix-partitioned path instead: the keys are not sorted (a rank table read in place would be filled with one random atomic per
+    // key), or they are and the probe side has no locality -- if the keys could be unique (sorted keys: no equal neighbours; keys that are
+    // not sorted: hp_table finds out) and the table is one a rank table would be.  (A small key range is always one: 64 Ki entries.)
+    if ((mailbox->unsorted_signed || probe_scattered) && (mailbox->unsorted_signed || !mailbox->equal_neighbours || existence_only) && range < 0xFFFFFF00ull &&
+        (words <= 2 * total + 4096 || words <= 65536) && hp_fits(mailbox->key_min, mailbox->key_max)) {
+      b.hp_wanted = true;
+      b.hp_min = mailbox->key_min;
+      b.hp_max = mailbox->key_max;
+      return HY_OK;
+    }
     if (HY_DEBUG_ENV("HY_JOIN_TIMING")) fprintf(stderr, "  dense stats: min %lld max %lld unsorted %u signed %u equal %u total %llu\n", (long long)mailbox->key_min, (long long)mailbox->key_max, mailbox->unsorted, mailbox->unsorted_signed, mailbox->equal_neighbours, (unsigned long long)total);
-    if (!mailbox->unsorted_signed && (!mailbox->equal_neighbours || existence_only) && range < 0xFFFFFF00ull && words <= 2 * total + 4096) {
+    if (!mailbox->unsorted_signed && (!mailbox->equal_neighbours || existence_only) && range < 0xFFFFFF00ull && (words <= 2 * total + 4096 || words <= 65536)) {
       HY_TRY(b.rank_entries.alloc(8 * (words + 1)));
       u32x2_t* entries = b.rank_entries.as<u32x2_t>();
       HY_HIP(hipMemsetAsync(entries, 0, 8 * (words + 1), stream));
@@ -3362,8 +3486,8 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     {
       const uint64_t key_min = mailbox->key_min, range = mailbox->key_max - mailbox->key_min;
       const uint64_t words = (range >> 5) + 1;
-      if (allow_rank_table && hashed_type == 0 && !b.any_null && !mailbox->equal_neighbours && range < 0xFFFFFF00ull && words <= 2 * total + 4096 &&
-          option(HY_OPT_JOIN_RANK_TABLE)) {
+      if (allow_rank_table && hashed_type == 0 && !b.any_null && !mailbox->equal_neighbours && range < 0xFFFFFF00ull && (words <= 2 * total + 4096 || words <= 65536) &&
+          option(HY_OPT_JOIN_RANK_TABLE) && !build->join_hint.has_duplicates.load(std::memory_order_relaxed)) {   // (a column in which an earlier join met a key twice: no second try)
         HY_TRY(b.rank_entries.alloc(8 * (words + 1)));
         u32x2_t* entries = b.rank_entries.as<u32x2_t>();
         HY_HIP(hipMemsetAsync(entries, 0, 8 * (words + 1), stream));
@@ -3382,6 +3506,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
             hipLaunchKernelGGL(publish_build_flags<uint64_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint64_t>(), total, mailbox_dev);
           }
           HY_HIP(hipStreamSynchronize(stream));
+          if (mailbox->duplicate) build->join_hint.has_duplicates.store(1, std::memory_order_relaxed);
           if (!mailbox->duplicate) {   // bases by a scan over the words' population counts, then every RowID goes to its key's rank
             const uint32_t n_blocks = static_cast<uint32_t>((words + RANK_BLOCK - 1) / RANK_BLOCK);
             DeviceBuffer sums;
@@ -3434,7 +3559,16 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       const uint64_t key_bits_or = mailbox->key_or;
       HY_TRY(b.keys_tmp.alloc(key_bytes * (total + 4)));
       HY_TRY(b.rows_tmp.alloc(row_bytes * total));
-      const uint32_t n_tiles = static_cast<uint32_t>((total + SORT_TILE - 1) / SORT_TILE);
+      const bool staged = key32 && id32 && lds_atomics_are_lane_ordered(stream);   // (sort_scatter_staged: 8192-element tiles, runs instead of scattered stores)
+      const uint32_t n_tiles = static_cast<uint32_t>(staged ? (total + SORT_BIG_TILE - 1) / SORT_BIG_TILE : (total + SORT_TILE - 1) / SORT_TILE);
+      if (staged) {
+        static OncePerDevice sort_lds_raised;
+        uint64_t sort_device_bit = 0;
+        if (sort_lds_raised.pending(&sort_device_bit)) {
+          HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sort_staged_lds_bytes())));
+          sort_lds_raised.done(sort_device_bit);
+        }
+      }
       DeviceBuffer hist, bases;
       HY_TRY(hist.alloc(4 * size_t{256} * n_tiles));
       HY_TRY(bases.alloc(8 * (size_t{256} * n_tiles + 1)));
@@ -3446,10 +3580,12 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
         // a byte that is zero in every key does not move anything (64-bit keys: unless one is negative -- then the sign
         // extension is part of the order)
         if (((key_bits_or >> shift) & 0xFF) == 0 && (key32 || !(key_bits_or >> 63))) continue;
-        if (key32) hipLaunchKernelGGL(sort_histogram<uint32_t>, dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint32_t*>(src_keys), total, shift, hist.as<uint32_t>(), n_tiles);
+        if (staged) hipLaunchKernelGGL(sort_histogram_big, dim3(n_tiles), dim3(SORT_BIG_THREADS), 0, stream, static_cast<const uint32_t*>(src_keys), total, shift, hist.as<uint32_t>(), n_tiles);
+        else if (key32) hipLaunchKernelGGL(sort_histogram<uint32_t>, dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint32_t*>(src_keys), total, shift, hist.as<uint32_t>(), n_tiles);
         else hipLaunchKernelGGL(sort_histogram<uint64_t>, dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint64_t*>(src_keys), total, shift, hist.as<uint32_t>(), n_tiles);
         HY_TRY(exclusive_scan(hist.as<uint32_t>(), bases.as<uint64_t>(), uint64_t{256} * n_tiles, stream));
-        if (key32 && id32) hipLaunchKernelGGL((sort_scatter<uint32_t, uint32_t>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint32_t*>(src_keys), static_cast<const uint32_t*>(src_rows), static_cast<uint32_t*>(dst_keys), static_cast<uint32_t*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
+        if (staged) hipLaunchKernelGGL(sort_scatter_staged, dim3(n_tiles), dim3(SORT_BIG_THREADS), sort_staged_lds_bytes(), stream, static_cast<const uint32_t*>(src_keys), static_cast<const uint32_t*>(src_rows), static_cast<uint32_t*>(dst_keys), static_cast<uint32_t*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
+        else if (key32 && id32) hipLaunchKernelGGL((sort_scatter<uint32_t, uint32_t>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint32_t*>(src_keys), static_cast<const uint32_t*>(src_rows), static_cast<uint32_t*>(dst_keys), static_cast<uint32_t*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
         else if (key32) hipLaunchKernelGGL((sort_scatter<uint32_t, hy_row_id>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint32_t*>(src_keys), static_cast<const hy_row_id*>(src_rows), static_cast<uint32_t*>(dst_keys), static_cast<hy_row_id*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
         else if (id32) hipLaunchKernelGGL((sort_scatter<uint64_t, uint32_t>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint64_t*>(src_keys), static_cast<const uint32_t*>(src_rows), static_cast<uint64_t*>(dst_keys), static_cast<uint32_t*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
         else hipLaunchKernelGGL((sort_scatter<uint64_t, hy_row_id>), dim3(n_tiles), dim3(256), 0, stream, static_cast<const uint64_t*>(src_keys), static_cast<const hy_row_id*>(src_rows), static_cast<uint64_t*>(dst_keys), static_cast<hy_row_id*>(dst_rows), total, shift, bases.as<uint64_t>(), n_tiles);
@@ -3574,6 +3710,224 @@ static bool lds_atomics_are_lane_ordered(hipStream_t stream) {
   return state == 1;
 }
 
+
+// Can the radix-partitioned path (join_hp.hpp) read this column?  int32 values / FrameOfReference segments without NULLs (what a SliceView
+// describes), RowIDs that pack into 32 bits.
+static bool hp_reads(const hy_column* column) {
+  if (column->is_reference || column->n_slices == 0 || column->n_chunks > 65536 || column->rows >= (1ull << 29)) return false;
+  for (uint32_t c = 0; c < column->n_chunks; ++c) {
+    const hy_segment& seg = column->host_segments[c];
+    const bool plain = (seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || (seg.encoding == HY_ENC_FRAME_OF_REFERENCE && (seg.width == 1 || seg.width == 2 || seg.width == 4));
+    if (!plain || seg.nulls || seg.size > 65536) return false;
+  }
+  return true;
+}
+
+// Do the probe keys lack locality as far as the host can tell?  FrameOfReference blocks of 1- or 2-byte offsets span at most 65 536 key
+// values per 2048 rows (TPC-H lineitem's order keys); 4-byte offsets and unencoded values say nothing -- foreign keys of a fact table
+// (SSB lineorder) are random.
+static bool probe_keys_scattered(const hy_column* probe) {
+  for (uint32_t c = 0; c < probe->n_chunks; ++c) {
+    const hy_segment& seg = probe->host_segments[c];
+    if (!(seg.encoding == HY_ENC_FRAME_OF_REFERENCE && seg.width <= 2)) return true;
+  }
+  return false;
+}
+
+static thread_local int t_last_join_used_hp = 0;   // debug / tests: the thread's last join ran the kernels of join_hp.hpp
+
+// The radix-partitioned join (join_hp.hpp) over keys in [key_min, key_max].  *refused: the build side has a key twice -- nothing was
+// written, the column is marked and the caller runs the join again on the general kernels.
+static hy_status run_join_hp(const hy_column* build, const hy_column* probe, uint32_t mode, uint32_t radix_bits, uint64_t key_min, uint64_t key_max, bool remember_extent,
+                             bool existence_only, bool semi_anti, bool keep_nulls_probe, bool probe_filtered, hy_join_result* result, bool count_only, uint64_t* count_out,
+                             bool* refused, hipStream_t stream) {
+  const uint32_t partitions = 1u << radix_bits;
+  const bool host_result = !result || result->mem == HY_MEM_HOST;
+  auto side = [&](const hy_column* column, HpSide& s, DeviceBuffer& counts, DeviceBuffer& bases, DeviceBuffer& tuples) -> hy_status {
+    s.views = column->d_slice_views;
+    s.n_tiles = column->n_slices;
+    s.stride = (column->n_slices + 1 + 3) & ~3u;
+    s.radix_bits = radix_bits;
+    const size_t cells = size_t{partitions} * s.stride;
+    HY_TRY(counts.alloc(4 * cells));
+    HY_TRY(bases.alloc(8 * (cells + 1)));
+    HY_TRY(tuples.alloc(8 * std::max<uint64_t>(column->rows, 1)));
+    HY_HIP(hipMemsetAsync(counts.ptr, 0, 4 * cells, stream));   // (the cells behind a row's tiles stay zero)
+    s.counts = counts.as<uint32_t>();
+    s.bases = bases.as<uint64_t>();
+    s.tuples = tuples.as<u32x2_t>();
+    hipLaunchKernelGGL(hp_hist, dim3(s.n_tiles), dim3(HP_THREADS), 0, stream, s);
+    HY_TRY(exclusive_scan(s.counts, bases.as<uint64_t>(), cells, stream));
+    hipLaunchKernelGGL(hp_scatter, dim3(s.n_tiles), dim3(HP_THREADS), 4 * hp_scatter_lds_words(partitions), stream, s);
+    return HY_OK;
+  };
+  static OncePerDevice lds_raised;
+  uint64_t device_bit = 0;
+  if (lds_raised.pending(&device_bit)) {
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hp_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * hp_scatter_lds_words(MAX_PARTITIONS)));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hp_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * HP_MAX_TABLE_WORDS));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hp_mark), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (HP_MAX_TABLE_WORDS + HP_BLOOM_LDS_WORDS)));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hp_ranks), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HP_MAX_TABLE_WORDS));
+    lds_raised.done(device_bit);
+  }
+  HpSide build_side{}, probe_side{};
+  DeviceBuffer build_counts, build_bases, build_tuples, probe_counts, probe_bases, probe_tuples;
+  HY_TRY(side(build, build_side, build_counts, build_bases, build_tuples));
+  HY_TRY(side(probe, probe_side, probe_counts, probe_bases, probe_tuples));
+  // layout | table
+  const uint64_t origin = key_min & ~((uint64_t{1} << radix_bits) - 1);   // (two's complement: rounds towards minus infinity)
+  const uint32_t words = static_cast<uint32_t>(((((key_max - origin) >> radix_bits) + 1) + 31) / 32);
+  // groups of the output: the partitions, or -- no radix partitioning -- the probe chunks (join_hash_steps.hpp:655-760: a PosList per chunk)
+  const uint32_t n_groups = radix_bits ? partitions : probe->n_chunks;
+  const uint32_t max_steps = static_cast<uint32_t>(probe->rows / HP_STEP) + n_groups + 1;
+  DeviceBuffer small, entries, ids, bloom, results, steps, step_info, partial_bits, partial_bloom;
+  const uint32_t mark_groups = 2 * device_cu_count(), mark_grid = (mark_groups + partitions + 7) / 8 * 8;   // hp_mark / hp_ids: workgroups hp_layout hands out | the most it can
+  const size_t group_words = 4 * (size_t{n_groups} + 1);
+  const size_t at_probe_off = 4 * (size_t{partitions} + 1), at_first_step = at_probe_off + group_words, at_slice_base = at_first_step + group_words, at_group_elements = at_slice_base + group_words,
+               at_mark_first = at_group_elements + group_words, at_plan = align_up(at_mark_first + 4 * (size_t{partitions} + 1), 16), at_flags = at_plan + 16;
+  HY_TRY(small.alloc(at_flags + 16));
+  HY_HIP(hipMemsetAsync(small.as<char>() + at_flags, 0, 16, stream));
+  HY_TRY(entries.alloc(8 * size_t{partitions} * words));
+  HY_TRY(step_info.alloc(32 * size_t{max_steps}));
+  HY_TRY(partial_bits.alloc(4 * size_t{mark_grid} * words));
+  HY_TRY(ids.alloc(4 * std::max<uint64_t>(build->rows, 1)));
+  HY_TRY(results.alloc(4 * std::max<uint64_t>(probe->rows, 1)));
+  HY_TRY(steps.alloc(4 * 3 * size_t{max_steps}));
+  HpLayout layout{};
+  layout.build_off = small.as<uint32_t>();
+  layout.probe_off = reinterpret_cast<uint32_t*>(small.as<char>() + at_probe_off);
+  layout.first_step = reinterpret_cast<uint32_t*>(small.as<char>() + at_first_step);
+  layout.n_groups = n_groups;
+  layout.steps = step_info.as<u32x4_t>();
+  layout.mark_first = reinterpret_cast<uint32_t*>(small.as<char>() + at_mark_first);
+  layout.mark_groups = mark_groups;
+  hipLaunchKernelGGL(hp_layout, dim3(1), dim3(HP_PROBE_THREADS), 0, stream, build_side, probe_side, probe->d_row_base, layout);
+  HpTable table{};
+  table.entries = entries.as<u32x2_t>();
+  table.words = words;
+  table.origin = static_cast<uint32_t>(origin);
+  table.range = static_cast<uint32_t>(key_max - origin);
+  table.radix_bits = radix_bits;
+  table.existence_only = existence_only ? 1u : 0u;
+  table.ids = existence_only ? nullptr : ids.as<uint32_t>();
+  table.flags = reinterpret_cast<uint32_t*>(small.as<char>() + at_flags);
+  table.partial_bits = partial_bits.as<uint32_t>();
+  const uint32_t bloom_words = hp_bloom_words(radix_bits);
+  const bool bloom_in_lds = probe_filtered && bloom_words <= HP_BLOOM_LDS_WORDS;
+  if (probe_filtered) {
+    HY_TRY(bloom.alloc(4 * size_t{partitions} * bloom_words));
+    if (!bloom_in_lds) HY_HIP(hipMemsetAsync(bloom.ptr, 0, 4 * size_t{partitions} * bloom_words, stream));   // (else hp_ranks writes every word)
+    table.bloom_bits = bloom.as<uint32_t>();
+    if (bloom_in_lds) {
+      HY_TRY(partial_bloom.alloc(4 * size_t{mark_grid} * bloom_words));
+      table.partial_bloom = partial_bloom.as<uint32_t>();
+    }
+  }
+  hipLaunchKernelGGL(hp_mark, dim3(mark_grid), dim3(HP_PROBE_THREADS), 4 * (size_t{words} + (bloom_in_lds ? bloom_words : 0)), stream, build_side, layout, table);
+  hipLaunchKernelGGL(hp_ranks, dim3(partitions), dim3(HP_PROBE_THREADS), 4 * size_t{words}, stream, layout, table);
+  if (table.ids) hipLaunchKernelGGL(hp_ids, dim3(mark_grid), dim3(HP_PROBE_THREADS), 0, stream, build_side, layout, table);
+  JoinMailbox* mailbox = nullptr;
+  JoinMailbox* mailbox_dev = nullptr;
+  HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
+  hy_row_id* user_build = nullptr;
+  hy_row_id* user_probe = nullptr;
+  if (!count_only) {
+    user_build = result->left_is_build ? result->left_pos : result->right_pos;
+    user_probe = result->left_is_build ? result->right_pos : result->left_pos;
+    if (!user_probe && result->capacity) return fail(HY_ERR_INVALID, "join result: PosList buffer for the probe side missing");
+    if (!semi_anti && !user_build && result->capacity) return fail(HY_ERR_INVALID, "join result: PosList buffer for the build side missing");
+    if (!result->slice_offsets) return fail(HY_ERR_INVALID, "join result: slice_offsets missing");
+  }
+  const uint32_t max_slices = static_cast<uint32_t>(probe->rows / PROBE_SIZE_PER_CHUNK) + n_groups + 1;
+  DeviceBuffer d_build_out, d_probe_out, d_slice_offsets;
+  uint64_t* dev_slice_offsets = count_only ? nullptr : result->slice_offsets;
+  if (!count_only && host_result) {
+    HY_TRY(d_slice_offsets.alloc(8 * (size_t{max_slices} + 2)));
+    dev_slice_offsets = d_slice_offsets.as<uint64_t>();
+  }
+  const bool async = !count_only && !host_result && (result->flags & HY_JOIN_ASYNC) && result->status && remember_extent;   // (an extent the column remembered: no host read has happened)
+  HpProbe a{};
+  a.tuples = probe_side.tuples;
+  a.layout = layout;
+  a.table = table;
+  a.mode = mode;
+  a.keep_nulls = keep_nulls_probe ? 1u : 0u;
+  a.shares = std::max<uint32_t>(8, std::min<uint32_t>(device_cu_count(), max_steps) / 8 * 8);   // hp_probe's workgroups: one per CU (a partition's table fills its LDS), a multiple of 8
+  a.bloom_bits = probe_filtered ? bloom.as<uint32_t>() : nullptr;
+  a.results = results.as<uint32_t>();
+  a.step_counts = steps.as<uint32_t>();
+  a.pair_base = a.step_counts + max_steps;
+  a.element_base = a.pair_base + max_steps;
+  a.slice_base = reinterpret_cast<uint32_t*>(small.as<char>() + at_slice_base);
+  a.group_elements = reinterpret_cast<uint32_t*>(small.as<char>() + at_group_elements);
+  a.plan = reinterpret_cast<JoinPlan*>(small.as<char>() + at_plan);
+  a.mailbox = mailbox_dev;
+  a.status = async ? result->status : nullptr;
+  a.capacity = count_only ? ~0ull : result->capacity;
+  a.slice_capacity = count_only ? 0xFFFFFFFFu : result->slice_capacity;
+  a.slice_offsets = dev_slice_offsets;
+  a.max_steps = max_steps;
+  hipEvent_t count_started = nullptr, count_stopped = nullptr;
+  profile_events(&count_started, &count_stopped, HY_KERNEL_JOIN_COUNT);
+  hipExtLaunchKernelGGL(hp_probe, dim3(a.shares), dim3(HP_PROBE_THREADS), 8 * size_t{words}, stream, count_started, count_stopped, 0, a);
+  hipLaunchKernelGGL(hp_plan, dim3(1), dim3(HP_PROBE_THREADS), 0, stream, a);
+  t_last_join_used_hp = 1;
+  auto settle = [&]() -> bool {   // (after a stream synchronise) the build side: a key twice?  else remember what was learnt about the column
+    if (mailbox->duplicate) {
+      build->join_hint.hp_refused.store(1, std::memory_order_release);
+      *refused = true;
+      return false;
+    }
+    if (!remember_extent && !existence_only && build->join_hint.hp_state.load(std::memory_order_acquire) == 0) {
+      build->join_hint.hp_min.store(key_min, std::memory_order_relaxed);
+      build->join_hint.hp_max.store(key_max, std::memory_order_relaxed);
+      build->join_hint.hp_state.store(1, std::memory_order_release);
+    }
+    return true;
+  };
+  if (count_only) {
+    HY_HIP(hipStreamSynchronize(stream));
+    if (!settle()) return HY_OK;
+    if (count_out) *count_out = mailbox->n_pairs;
+    return HY_OK;
+  }
+  hy_row_id* dev_build = user_build;
+  hy_row_id* dev_probe = user_probe;
+  if (host_result) {   // the staging buffers are sized by the pair count: ask now
+    HY_HIP(hipStreamSynchronize(stream));
+    if (!settle()) return HY_OK;
+    if (mailbox->fits) {
+      if (!semi_anti) { HY_TRY(d_build_out.alloc(8 * std::max<uint64_t>(mailbox->n_pairs, 1))); dev_build = d_build_out.as<hy_row_id>(); }
+      HY_TRY(d_probe_out.alloc(8 * std::max<uint64_t>(mailbox->n_pairs, 1)));
+      dev_probe = d_probe_out.as<hy_row_id>();
+    }
+  }
+  a.build_out = semi_anti ? nullptr : dev_build;
+  a.probe_out = dev_probe;
+  hipEvent_t started = nullptr, stopped = nullptr;
+  profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
+  hipExtLaunchKernelGGL(hp_emit, dim3(std::max<uint32_t>(8, std::min<uint32_t>(2 * device_cu_count(), max_steps) / 8 * 8)), dim3(HP_PROBE_THREADS), 0, stream, started, stopped, 0, a);
+  HY_HIP(hipGetLastError());
+  if (host_result) {
+    if (mailbox->fits && mailbox->n_pairs) {
+      HY_HIP(hipMemcpyAsync(user_probe, dev_probe, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
+      if (!semi_anti) HY_HIP(hipMemcpyAsync(user_build, dev_build, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
+    }
+    if (mailbox->fits) HY_HIP(hipMemcpyAsync(result->slice_offsets, dev_slice_offsets, 8 * (size_t{mailbox->n_slices} + 1), hipMemcpyDeviceToHost, stream));
+  }
+  if (async) {
+    t_join_returned_async = true;
+    return HY_OK;
+  }
+  HY_HIP(hipStreamSynchronize(stream));
+  if (!host_result && !settle()) return HY_OK;
+  result->n_slices = mailbox->n_slices;
+  result->n_pairs = mailbox->n_pairs;
+  if (mailbox->n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %u output PosLists, slice capacity is %u", mailbox->n_slices, result->slice_capacity);
+  if (mailbox->n_pairs > result->capacity) return fail(HY_ERR_CAPACITY, "join produces %llu pairs, capacity is %llu", static_cast<unsigned long long>(mailbox->n_pairs), static_cast<unsigned long long>(result->capacity));
+  return HY_OK;
+}
+
 static hy_status run_join_once(const hy_column* left, const hy_column* right, uint32_t mode, hy_join_result* result, bool count_only, uint64_t* count_out,
                                const hy_join_predicate* secondary, uint32_t n_secondary, bool* retry) {
   if (mode == HY_JOIN_FULL_OUTER || mode == HY_JOIN_CROSS || mode > HY_JOIN_ANTI_NULL_AS_FALSE) return fail(HY_ERR_UNSUPPORTED, "JoinHash does not support join mode %u (join_hash.cpp:38-44)", mode);
@@ -3635,7 +3989,26 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   }
   const bool probe_takes_pk = probe_views && hashed_type == 0 && n_secondary == 0 && probe->rows < 0xFFFF0000ull && option(HY_OPT_JOIN_PKFK) &&
                               (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
-  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, semi_anti && n_secondary == 0, probe_takes_pk, b, stream));
+  // The radix-partitioned path (join_hp.hpp) is possible for int32 columns without NULLs and without secondary predicates; prepare_build
+  // decides whether it is wanted (a build column that is not sorted, a probe side without locality).
+  const bool hp_possible = option(HY_OPT_JOIN_LDS_HASH) && hashed_type == 0 && n_secondary == 0 && hp_reads(build) && hp_reads(probe) &&
+                           (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
+  t_last_join_used_hp = 0;
+  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, semi_anti && n_secondary == 0, probe_takes_pk,
+                       hp_possible ? radix_bits : 0xFFFFFFFFu, hp_possible && probe_keys_scattered(probe), b, stream));
+  if (b.hp_wanted) {
+    if (result) {
+      result->radix_bits = radix_bits;
+      result->left_is_build = build_right ? 0 : 1;
+      result->n_slices = 0;
+      result->n_pairs = 0;
+    }
+    t_last_join_used_rank_table = 0;
+    t_last_join_used_pkfk = 0;
+    t_last_join_hinted_attempt = 0;
+    return run_join_hp(build, probe, mode, radix_bits, b.hp_min, b.hp_max, b.hp_extent_from_column, semi_anti && n_secondary == 0, semi_anti, keep_nulls_probe, probe_filtered, result,
+                       count_only, count_out, retry, stream);
+  }
   const bool rank_path = b.rank.entries != nullptr;
   // A rank table filled from the build column's key hint (rank_table_fill_checked) is confirmed when the join's kernels have finished:
   // if the column is not what the hint said, the hint is dropped, whatever the join wrote is discarded and the caller runs it again.
@@ -4080,6 +4453,7 @@ hy_status hy_join_hash_finish(const hy_column* left, const hy_column* right, uin
     const bool build_right = mode == HY_JOIN_LEFT || mode == HY_JOIN_ANTI_NULL_AS_TRUE || mode == HY_JOIN_ANTI_NULL_AS_FALSE || mode == HY_JOIN_SEMI ||
                              (mode == HY_JOIN_INNER && left->rows > right->rows);   // (side selection of run_join_once)
     (build_right ? right : left)->join_hint.state.store(2, std::memory_order_release);
+    (build_right ? right : left)->join_hint.hp_refused.store(1, std::memory_order_release);   // (whichever path ran: neither is taken again)
     const uint32_t flags = result->flags;
     result->flags = flags & ~HY_JOIN_ASYNC;   // (radix_bits: the first attempt left the value it used)
     const hy_status status = run_join(left, right, mode, result, false, nullptr);
@@ -4139,6 +4513,9 @@ hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint
 int hy_debug_join_lane_ordered_atomics() { return g_lds_atomic_order.load(); }
 
 int hy_debug_join_used_rank_table(void) { return t_last_join_used_rank_table; }
+
+// debug / tests only: 1 = the last join of this thread ran the radix-partitioned kernels (join_hp.hpp)
+int hy_debug_join_used_hp(void) { return t_last_join_used_hp; }
 
 // debug / tests only: see t_last_join_hinted
 int hy_debug_join_build_was_hinted(void) { return t_last_join_hinted; }
