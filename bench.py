@@ -184,8 +184,8 @@ def committed_traffic(kernel):
     (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate runs of `python bench.py`, FETCH_SIZE doubled as the gfx950
     guide prescribes).  None when the committed profile does not list the kernel (rocprofv3 cannot run inside this process: the
     counters are not measured live -- `traffic_source` in the line says which file and commit the figure is from)."""
-    path = os.path.join(ROOT, "profiles", "r03_bench_pmc.json")
-    if not os.path.exists(path):
+    path = pmc_file()
+    if not path:
         return None
     try:
         with open(path) as fh:
@@ -195,15 +195,50 @@ def committed_traffic(kernel):
         return None
 
 
+def pmc_file():
+    """The newest committed PMC summary of this script (profiles/rNN_bench_pmc.json, tools/collect_profiles.sh)."""
+    for round_ in (4, 3):
+        path = os.path.join(ROOT, "profiles", f"r{round_:02d}_bench_pmc.json")
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def traffic_source():
-    path = os.path.join(ROOT, "profiles", "r03_bench_pmc.json")
-    if not os.path.exists(path):
+    path = pmc_file()
+    if not path:
         return None
     try:
         with open(path) as fh:
-            return "profiles/r03_bench_pmc.json, " + str(json.load(fh).get("collected", ""))
+            return "profiles/" + os.path.basename(path) + ", " + str(json.load(fh).get("collected", ""))
     except (OSError, ValueError):
         return None
+
+
+PCIE_PEAK_GBS = 63.0           # PCIe 5.0 x16, one direction: 32 GT/s x 16 lanes x 128/130
+
+
+def pcie_roofline(what, payload_bytes, seconds):
+    """A result (or an upload) that crosses the host link: payload bytes over the call's wall time against the link's peak."""
+    achieved = payload_bytes / seconds / 1e9 if seconds > 0 else 0.0
+    return {"bound": "pcie", "achieved": achieved, "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": achieved / PCIE_PEAK_GBS, "traffic": None, "kernel": what,
+            "algorithmic_bytes_per_launch": payload_bytes, "kernel_ms": seconds * 1e3}
+
+
+def timed_upload(name, host_column, uploads):
+    """DeviceColumn(host_column) with its H2D time on record: `uploads[name]` = bytes, ms, GB/s of hy_column_create (pageable host buffers ->
+    one arena in HBM; resident-column runs -- everything else in this file -- start behind it)."""
+    from hyrise_amd.storage import DeviceColumn
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    column = DeviceColumn(host_column)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    payload = sum(sum(int(a.nbytes) for a in (seg.data, seg.aux, seg.nulls) if a is not None and hasattr(a, "nbytes")) for seg in host_column.segments)
+    if name not in uploads and payload:
+        uploads[name] = dict(pcie_roofline(f"hy_column_create({name}): host segments -> HBM, one call", payload, dt), bytes=payload, ms=dt * 1e3)
+    return column
 
 
 _EVENT_OVERHEAD = []
@@ -408,18 +443,37 @@ def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem
                                        "GBps_on_algorithmic_bytes": (15_000_000 * 4 + probe_rows * 2 + int(r_d.n_pairs) * 16) / dt_d / 1e9}
         del keep_d, dup_build, dup_probe
         # the boundary as the adapter uses it today: PosLists returned to HOST memory (0.96 GB over PCIe), one call
-        from hyrise_amd.operators import join_hash
-        join_hash(orders, lineitem, abi.JOIN_INNER)
+        from hyrise_amd.operators import HostJoinResult, join_hash
         t0 = time.perf_counter()
-        host = join_hash(orders, lineitem, abi.JOIN_INNER)
-        dt_h = time.perf_counter() - t0
+        fresh = join_hash(orders, lineitem, abi.JOIN_INNER)
+        dt_fresh = time.perf_counter() - t0
+        del fresh
+        host = HostJoinResult(n, n // 131070 + 1000)
+        host.left[:] = 1
+        host.right[:] = 1          # (the pages exist: the adapter writes into pooled PosList memory)
+        times = []
+        for _ in range(3):
+            host.c.radix_bits = 0xFFFFFFFF
+            t0 = time.perf_counter()
+            abi.check(lib.hy_join_hash(orders.handle, lineitem.handle, abi.JOIN_INNER, C.byref(host.c)))
+            times.append(time.perf_counter() - t0)
+        dt_h = sorted(times)[1]
         cases["host_memory_result"] = {"ms_per_join": dt_h * 1e3, "rows_per_s": (data.n_orders + n) / dt_h, "pairs": host.n_pairs,
-                                       "note": "HY_MEM_HOST: includes the device-to-host copy of both PosLists and the host buffer allocation"}
+                                       "roofline": pcie_roofline("hy_join_hash with HY_MEM_HOST PosLists: the join's kernels, then both PosLists over the link", host.n_pairs * 16, dt_h),
+                                       "ms_into_fresh_buffers": dt_fresh * 1e3,
+                                       "note": "HY_MEM_HOST into result buffers whose pages exist (median of 3); ms_into_fresh_buffers: one call that also allocates "
+                                               "0.96 GB of numpy memory and takes its first-touch page faults inside the copy (round 3's 56 ms)"}
         del host
         info["cases"] = cases
     if with_cpu:
         info["cpu_baseline"] = cpu_baseline_join(orders_host, lineitem_host, data.n_orders + n)
     return info
+
+
+def aggregate_kernel_name(lib):
+    """Which kernel answered the thread's last hy_aggregate_hash (the library's debug accessor): the Q1 shape takes aggregate_small_domain."""
+    lib.hy_debug_aggregate_small_domain.restype = C.c_int
+    return "aggregate_small_domain" if lib.hy_debug_aggregate_small_domain() else "aggregate_rows"
 
 
 def aggregate_leg(lib, torch, steps, with_cases, with_cpu):
@@ -449,8 +503,8 @@ def aggregate_leg(lib, torch, steps, with_cases, with_cpu):
     info = {"workload": "configs[3] on one GPU: AggregateHash Q1 core, GROUP BY l_returnflag, l_linestatus (string dictionaries as key names, u8), "
                         "SUM/AVG over DictionarySegment<float> l_quantity (u8), l_extendedprice (u16), l_discount (u8), COUNT(*), SF10 lineitem",
             "rows_per_s": n / dt, "ms_per_aggregate": dt * 1e3, "groups": int(holder["result"].n_groups), "algorithmic_bytes": algorithmic,
-            "roofline": dict(roofline_object("whole operator (host-timed)", algorithmic, dt * 1e3, committed_traffic("aggregate")),
-                             dominant_kernel=roofline_object("aggregate_rows", algorithmic, kernel_ms))}
+            "roofline": dict(roofline_object("whole operator (host-timed)", algorithmic, dt * 1e3, committed_traffic("hy_aggregate_hash")),
+                             dominant_kernel=roofline_object(aggregate_kernel_name(lib), algorithmic, kernel_ms, committed_traffic(aggregate_kernel_name(lib))))}
     if with_cases:   # the same query over unencoded float value segments (round 1's bench shape): 4-byte measures, no dictionary gather
         plain = {name: DeviceColumn(storage.make_column(getattr(data, name), None, abi.ENC_UNENCODED)) for name in ("l_quantity", "l_extendedprice", "l_discount")}
 
@@ -608,14 +662,24 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
                        ("is_null", make_predicate(abi.PRED_IS_NULL, abi.TYPE_INT))):
         out[name] = measure(lambda p=pred: step_fn(p, None), lambda m: rows * width + m * 8)   # (None: the headline's copies in rotation)
     # the boundary as the adapter uses it today: PosLists returned to HOST memory (PCIe-inclusive, never the headline value)
-    from hyrise_amd.operators import table_scan
+    from hyrise_amd.operators import HostScanResult, table_scan
     pred = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
-    table_scan(column, pred)
     t0 = time.perf_counter()
-    host = table_scan(column, pred)
-    dt_h = time.perf_counter() - t0
+    fresh = table_scan(column, pred)
+    dt_fresh = time.perf_counter() - t0
+    del fresh
+    host = HostScanResult(column.n_chunks, rows, 0)
+    host.matches[:] = 1            # (the pages exist)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        abi.check(lib.hy_table_scan(column.handle, C.byref(pred), None, 0, C.byref(host.c)))
+        times.append(time.perf_counter() - t0)
+    dt_h = sorted(times)[1]
     out["host_memory_result_lt_1995"] = {"rows_per_s": rows / dt_h, "ms_per_step": dt_h * 1e3, "matches": host.total,
-                                         "note": "HY_MEM_HOST: includes packing the chunk regions, the device-to-host copy of the PosLists and the host buffer allocation"}
+                                         "roofline": pcie_roofline("hy_table_scan with HY_MEM_HOST PosLists: scan, packing the chunk regions, the PosLists over the link", host.total * 8, dt_h),
+                                         "ms_into_fresh_buffers": dt_fresh * 1e3,
+                                         "note": "HY_MEM_HOST into a result buffer whose pages exist (median of 3); ms_into_fresh_buffers: one call that also allocates the numpy buffer"}
     del host
     # the same dates as unencoded int32 values (ValueSegment<int32>: the 4-byte streaming instantiation)
     values = Rotating(storage.make_column(days, None, abi.ENC_UNENCODED))
@@ -751,7 +815,8 @@ def main():
     if single and not (args.no_join and args.no_aggregate and args.no_cases):
         sf10_tables()   # (the other legs need every column: generate once, the headline's join keys are two of them)
     days, host_column = tpch.shipdate_column(rows, seed=42 + rank)
-    columns = [DeviceColumn(host_column) for _ in range(COLUMN_COPIES)]
+    uploads = {}
+    columns = [timed_upload("l_shipdate (DictionarySegment<int32>, u16 value ids)", host_column, uploads) for _ in range(COLUMN_COPIES)]
     n_chunks = host_column.n_chunks
     predicate = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, tpch.DAY_1995_01_01)
     o_orderkey, l_orderkey = join_keys(rank, args.rows)
@@ -759,8 +824,8 @@ def main():
     orders_host = storage.make_column(o_orderkey, None, abi.ENC_UNENCODED)
     lineitem_host = storage.make_column(l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE)
     # like the scanned column, the join's inputs exist COLUMN_COPIES times and the steps take them in rotation (540 MB of keys)
-    orders_copies = [DeviceColumn(orders_host) for _ in range(COLUMN_COPIES)]
-    lineitem_copies = [DeviceColumn(lineitem_host) for _ in range(COLUMN_COPIES)]
+    orders_copies = [timed_upload("o_orderkey (ValueSegment<int32>)", orders_host, uploads) for _ in range(COLUMN_COPIES)]
+    lineitem_copies = [timed_upload("l_orderkey (FrameOfReference, u16 offsets)", lineitem_host, uploads) for _ in range(COLUMN_COPIES)]
     orders, lineitem = orders_copies[0], lineitem_copies[0]
     offset_width = int(lineitem_host.segments[0].width)
 
@@ -885,6 +950,8 @@ def main():
                        "rows_per_step_per_gpu": step_rows, "scan_rows": rows, "build_rows": n_orders, "probe_rows": n_lineitems, "chunks_per_gpu": n_chunks,
                        "scan_selectivity": n_matches / rows, "join_pairs": n_pairs, "parallelism": f"chunk-sharded x{world}, no collective"},
             "roofline": step_roofline,
+            # H2D once per column (reported apart from the resident-column runs -- every other figure in this line starts behind it)
+            "upload": uploads,
         }
         if scan_info:
             line["scan"] = scan_info
@@ -900,6 +967,11 @@ def main():
             line["q1"] = q1_info
         if multi:
             line["multi_gpu"] = multi
+            # ONE SF10 database split over the ranks -- the strong-scaling figures, next to the (weak-scaling) `value`: rows/s of the whole job
+            line["strong_scaling"] = {name: {"rows_per_s": leg["rows_per_s"], "ms": leg["ms"]} for name, leg in multi.items() if isinstance(leg, dict) and "rows_per_s" in leg}
+            line["strong_scaling"]["n_gpus"] = world
+            line["strong_scaling"]["note"] = ("scan_strong: the SF10 l_shipdate scan, chunks sharded, no collective; aggregate_q1: per-rank partials + one RCCL all-reduce; "
+                                              "join_broadcast_build: all-gather of the build column; join_repartition: all-to-all of (key, RowID) tuples by key % G and back")
         if ssb_info:
             line["ssb"] = dict(ssb_info, workload="configs[4]: SSB SF30 Q2.1 / Q4.1 star joins (dimension scans, one JoinHash per dimension over device-resident "
                                                    "PosLists, AggregateHash), synthetic tables per the SSB specification")

@@ -36,7 +36,6 @@ struct OptionDefaults {
     set(HY_OPT_AGG_JOINT_HISTOGRAM, 1);
     set(HY_OPT_FUSED_SMALL_DOMAIN, 1);
     set(HY_OPT_FUSED_SHARED_PREFIX, 1);
-    set(HY_OPT_HOST_RESULT_TILES, 1);
     set(HY_OPT_JOIN_FILL_WGS_PER_CU, 4);
   }
 };
