@@ -3176,6 +3176,15 @@ hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters
                                     const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result) {
   if (!result || (n_filters && !filters) || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: null argument");
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: result columns missing");
+  // every column of the plan lives on the calling thread's device (hy_bind_device: one worker thread per GPU) -- checked before a compressed
+  // column's twin is decoded, which would happen on the wrong device with this thread's pool
+  for (uint32_t f = 0; f < n_filters; ++f) HY_TRY(on_this_device(filters[f].column, "hy_scan_project_aggregate"));
+  for (uint32_t i = 0; i < n_groupby; ++i) HY_TRY(on_this_device(groupby_columns[i], "hy_scan_project_aggregate"));
+  for (uint32_t g = 0; g < n_aggregates; ++g) {
+    if (!aggregates[g].input) continue;
+    for (uint32_t k = 0; k < aggregates[g].input->n_nodes && k < HY_MAX_EXPRESSION_NODES; ++k)
+      if (aggregates[g].input->nodes[k].kind == HY_EXPR_COLUMN) HY_TRY(on_this_device(aggregates[g].input->nodes[k].column, "hy_scan_project_aggregate"));
+  }
   // run-length / bit-packed segments: the decoded twins (hy_device.hpp)
   std::vector<hy_filter> plain_filters(filters, filters + n_filters);
   for (hy_filter& filter : plain_filters) HY_TRY(plain_column(filter.column, &filter.column));

@@ -16,6 +16,9 @@
 // a single-GPU user never touches it, and a process that already holds an RCCL (PyTorch's) shares that copy.
 #include "hy_device.hpp"
 
+#include <atomic>
+#include <string>
+
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -55,6 +58,7 @@ struct Rccl {
 
 static Rccl g_rccl;
 static std::once_flag g_rccl_once;
+static std::string g_rccl_why;   // why librccl is not usable, captured once (dlerror() clears itself when read)
 
 static hy_status rccl(Rccl** out) {
   std::call_once(g_rccl_once, [] {
@@ -65,7 +69,11 @@ static hy_status rccl(Rccl** out) {
       if (handle) break;
     }
     if (!handle) handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!handle) return;
+    if (!handle) {
+      const char* why = dlerror();
+      g_rccl_why = why ? why : "dlopen failed";
+      return;
+    }
     Rccl r;
     r.handle = handle;
 #define HY_RCCL_SYMBOL(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(handle, name))
@@ -83,8 +91,10 @@ static hy_status rccl(Rccl** out) {
 #undef HY_RCCL_SYMBOL
     if (r.get_unique_id && r.comm_init_rank && r.comm_init_all && r.comm_destroy && r.all_reduce && r.all_gather && r.send && r.recv && r.group_start && r.group_end && r.error_string)
       g_rccl = r;
+    else
+      g_rccl_why = "a collective's symbol is missing";
   });
-  if (!g_rccl.handle) return fail(HY_ERR_DEVICE, "librccl.so could not be loaded (%s): the collectives of the multi-GPU path need RCCL", dlerror() ? dlerror() : "symbols missing");
+  if (!g_rccl.handle) return fail(HY_ERR_DEVICE, "librccl.so could not be loaded (%s): the collectives of the multi-GPU path need RCCL", g_rccl_why.c_str());
   *out = &g_rccl;
   return HY_OK;
 }
@@ -132,6 +142,9 @@ struct LocalExchange {
   uint64_t round = 0;
   std::vector<const void*> send;
   std::vector<const uint64_t*> send_bytes;
+  // A rank that fails (its stream, an argument) still takes part in both meetings of a collective and raises this flag before the first:
+  // the others skip the exchange and report the failure too, instead of waiting for the rank that left (cleared by the last rank to leave).
+  std::atomic<uint32_t> failed{0};
 };
 
 template <typename T>
@@ -142,11 +155,12 @@ static void reduce_cells(T* into, const T* from, uint64_t count, uint32_t op) {
 static hy_status local_all_reduce(hy_comm* comm, const void* send, void* recv, uint64_t count, uint32_t data_type, size_t width, uint32_t op) {
   LocalExchange& x = *comm->local;
   hipStream_t stream = current_stream();
-  HY_HIP(hipStreamSynchronize(stream));
+  hy_status status = HY_OK;
+  if (hipStreamSynchronize(stream) != hipSuccess) { status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: this rank's stream failed"); x.failed.store(1); }
   x.send[comm->rank] = send;
   x.meet();
+  if (status == HY_OK && x.failed.load()) status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: a co-located rank failed");
   std::vector<unsigned char> total(count * width), piece(count * width);
-  hy_status status = HY_OK;
   for (uint32_t peer = 0; peer < x.world && status == HY_OK; ++peer) {
     if (hipMemcpyAsync(peer == 0 ? total.data() : piece.data(), x.send[peer], count * width, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
       status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: reading a co-located rank's cells failed");
@@ -161,6 +175,7 @@ static hy_status local_all_reduce(hy_comm* comm, const void* send, void* recv, u
     }
   }
   x.meet();   // everyone has read every send buffer: recv may alias send
+  if (comm->rank == 0) x.failed.store(0);   // (every rank has looked at the flag before the meeting above)
   if (status == HY_OK && count && (hipMemcpyAsync(recv, total.data(), count * width, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess))
     status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: writing the reduced cells failed");
   return status;
@@ -171,11 +186,12 @@ template <typename Offset, typename Bytes>
 static hy_status local_collect(hy_comm* comm, const void* send, const uint64_t* send_bytes, void* recv, Offset from_peer, Bytes bytes) {
   LocalExchange& x = *comm->local;
   hipStream_t stream = current_stream();
-  HY_HIP(hipStreamSynchronize(stream));
+  hy_status status = HY_OK;
+  if (hipStreamSynchronize(stream) != hipSuccess) { status = fail(HY_ERR_DEVICE, "this rank's stream failed before a collective"); x.failed.store(1); }
   x.send[comm->rank] = send;
   x.send_bytes[comm->rank] = send_bytes;
   x.meet();
-  hy_status status = HY_OK;
+  if (status == HY_OK && x.failed.load()) status = fail(HY_ERR_DEVICE, "a co-located rank failed before a collective");
   uint64_t at = 0;
   for (uint32_t peer = 0; peer < x.world; ++peer) {
     const uint64_t n = bytes(peer);
@@ -185,6 +201,7 @@ static hy_status local_collect(hy_comm* comm, const void* send, const uint64_t* 
   }
   if (hipStreamSynchronize(stream) != hipSuccess && status == HY_OK) status = fail(HY_ERR_DEVICE, "copying a co-located rank's bytes failed");
   x.meet();   // the send buffers (and the callers' send_bytes arrays) may go now
+  if (comm->rank == 0) x.failed.store(0);
   return status;
 }
 
@@ -292,11 +309,17 @@ hy_status hy_comm_group_end(void) {
 }
 
 hy_status hy_comm_all_reduce(hy_comm* comm, const void* send, void* recv, uint64_t count, uint32_t data_type, uint32_t op) {
-  if (!comm || (count && (!send || !recv))) return fail(HY_ERR_INVALID, "hy_comm_all_reduce: null argument");
-  ncclDataType_t type;
-  size_t width;
-  if (!nccl_type(data_type, &type, &width)) return fail(HY_ERR_INVALID, "hy_comm_all_reduce: data type %u", data_type);
-  if (op > HY_COMM_MAX) return fail(HY_ERR_INVALID, "hy_comm_all_reduce: operation %u", op);
+  if (!comm) return fail(HY_ERR_INVALID, "hy_comm_all_reduce: null argument");
+  ncclDataType_t type = ncclInt8;
+  size_t width = 0;
+  const bool bad = (count && (!send || !recv)) || !nccl_type(data_type, &type, &width) || op > HY_COMM_MAX;
+  if (bad && comm->local) {   // (the co-located ranks are waiting at the meeting points: go there, with the failure flag up)
+    comm->local->failed.store(1);
+    comm->local->meet();
+    comm->local->meet();
+    if (comm->rank == 0) comm->local->failed.store(0);
+  }
+  if (bad) return fail(HY_ERR_INVALID, "hy_comm_all_reduce: null argument, data type %u or operation %u", data_type, op);
   if (comm->local) return local_all_reduce(comm, send, recv, count, data_type, width, op);
   Rccl* r = nullptr;
   HY_TRY(rccl(&r));
@@ -329,14 +352,19 @@ hy_status hy_comm_all_to_all_v(hy_comm* comm, const void* send, const uint64_t* 
   HY_TRY(rccl(&r));
   hipStream_t stream = current_stream();
   HY_RCCL(r, r->group_start());
+  // (a send or recv that fails must not leave the thread's group open -- later collectives would queue behind it and never start:
+  //  the group is always closed, the first error is reported)
+  ncclResult_t first_error = ncclSuccess;
   uint64_t send_at = 0, recv_at = 0;
-  for (uint32_t peer = 0; peer < comm->world; ++peer) {
-    if (send_bytes[peer]) HY_RCCL(r, r->send(static_cast<const char*>(send) + send_at, send_bytes[peer], ncclInt8, static_cast<int>(peer), comm->comm, stream));
-    if (recv_bytes[peer]) HY_RCCL(r, r->recv(static_cast<char*>(recv) + recv_at, recv_bytes[peer], ncclInt8, static_cast<int>(peer), comm->comm, stream));
+  for (uint32_t peer = 0; peer < comm->world && first_error == ncclSuccess; ++peer) {
+    if (send_bytes[peer]) first_error = r->send(static_cast<const char*>(send) + send_at, send_bytes[peer], ncclInt8, static_cast<int>(peer), comm->comm, stream);
+    if (recv_bytes[peer] && first_error == ncclSuccess) first_error = r->recv(static_cast<char*>(recv) + recv_at, recv_bytes[peer], ncclInt8, static_cast<int>(peer), comm->comm, stream);
     send_at += send_bytes[peer];
     recv_at += recv_bytes[peer];
   }
-  HY_RCCL(r, r->group_end());
+  const ncclResult_t closed = r->group_end();
+  if (first_error == ncclSuccess) first_error = closed;
+  if (first_error != ncclSuccess) return fail(HY_ERR_DEVICE, "hy_comm_all_to_all_v failed: %s", r->error_string(first_error));
   return HY_OK;
 }
 

@@ -186,6 +186,7 @@ extern "C" {
 
 hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls) {
   if (!column || !values) return fail(HY_ERR_INVALID, "hy_column_export: null argument");
+  HY_TRY(on_this_device(column, "hy_column_export"));
   if (column->is_mvcc) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
   if (column->data_type < HY_TYPE_INT || column->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "hy_column_export: numeric columns only");
   if (column->has_dictionary_without_values) return fail(HY_ERR_UNSUPPORTED, "hy_column_export: the dictionary values are not on the device");
@@ -275,7 +276,8 @@ hy_status hy_repartition_pack(const hy_column* column, uint32_t parts, uint32_t 
 }
 
 hy_status hy_gather_row_ids(const hy_row_id* table, uint64_t table_rows, uint32_t chunk_rows, const hy_row_id* positions, uint64_t n, hy_row_id* out) {
-  if (n && (!table || !positions || !out || !chunk_rows)) return fail(HY_ERR_INVALID, "hy_gather_row_ids: null argument");
+  // (an empty table -- a rank that received no tuples of the other side -- has no buffer: every position then is out of range and yields the NULL RowID)
+  if (n && ((!table && table_rows) || !positions || !out || !chunk_rows)) return fail(HY_ERR_INVALID, "hy_gather_row_ids: null argument");
   if (!n) return HY_OK;
   const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 16384));
   hipLaunchKernelGGL(gather_row_ids, dim3(grid), dim3(256), 0, current_stream(), table, table_rows, chunk_rows, positions, n, out);

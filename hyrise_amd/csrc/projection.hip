@@ -270,6 +270,8 @@ hy_status hy_projection_arithmetic(uint32_t op, const hy_operand* left, const hy
   if (!left || !right || !out) return fail(HY_ERR_INVALID, "hy_projection_arithmetic: null argument");
   *out = nullptr;
   if (op > HY_ARITH_MOD) return fail(HY_ERR_INVALID, "unknown arithmetic operator %u", op);
+  HY_TRY(on_this_device(left->column, "hy_projection_arithmetic"));
+  HY_TRY(on_this_device(right->column, "hy_projection_arithmetic"));
   hy_operand plain_left = *left, plain_right = *right;   // run-length / bit-packed segments: the decoded twins (hy_device.hpp)
   HY_TRY(plain_column(plain_left.column, &plain_left.column));
   HY_TRY(plain_column(plain_right.column, &plain_right.column));

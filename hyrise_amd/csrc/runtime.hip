@@ -861,10 +861,18 @@ hy_status hy_column_destroy(hy_column* column) {
   // The descriptor block goes back to this thread's pool and is handed out again in the order of this thread's stream: wait for that
   // stream only (a column that other threads still use must not be destroyed: the caller's contract, as for any shared object) --
   // a device-wide synchronise here stalled every thread's stream at every step of an operator chain.
-  if (column->descriptors_pooled) (void)hipStreamSynchronize(t_stream);
+  // A column of ANOTHER device (one process, one worker thread per GPU: multi_gpu.hpp's shards die on the coordinator's thread): its
+  // pooled blocks must not enter this thread's pool -- the pool hands blocks out for kernels of this thread's device -- and the stream to
+  // wait for is not this thread's: free them (hipFree waits for the device's work).
+  bind_thread_device();
+  const bool foreign = t_bound_device >= 0 && column->device != t_bound_device;
+  if (column->descriptors_pooled && !foreign) (void)hipStreamSynchronize(t_stream);
   if (column->plain) (void)hy_column_destroy(column->plain);
   for (void* p : column->owned) (void)hipFree(p);
-  for (auto& block : column->pooled) pool_release(block.second, block.first);
+  for (auto& block : column->pooled) {
+    if (foreign) (void)hipFree(block.second);
+    else pool_release(block.second, block.first);
+  }
   if (!column->descriptors_pooled) {
     if (column->d_segments) (void)hipFree(column->d_segments);
     if (column->d_slices) (void)hipFree(column->d_slices);

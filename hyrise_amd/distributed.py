@@ -128,7 +128,7 @@ class DeviceValueColumn:
             padded[:self.rows] = bits
         else:
             padded = None
-        n_chunks = (self.rows + chunk_rows - 1) // chunk_rows
+        n_chunks = max(1, (self.rows + chunk_rows - 1) // chunk_rows)   # (no rows: ONE empty chunk, so that the column still has its data type)
         self.n_chunks = n_chunks
         segments = (abi.Segment * max(1, n_chunks))()
         self._null_chunks = []

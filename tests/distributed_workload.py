@@ -37,6 +37,9 @@ def make_data():
     d["nullable_probe"] = build_column(d["probe_values"][:30_000], rng.random(30_000) < 0.04, 4096, abi.ENC_DICTIONARY)   # NULL keys on the outer side
     dup_values = rng.integers(0, 2000, 9000).astype(np.int32)                           # duplicate keys on both sides
     d["dup_build"] = build_column(dup_values, rng.random(9000) < 0.03, chunk, abi.ENC_UNENCODED)
+    # a small dimension whose keys are all even: with two ranks, rank 1 (key % 2 == 1) receives NO build tuples -- its local join has an
+    # empty side, and the modes that emit rows without a partner must still answer (round-3 advisor finding)
+    d["even_build"] = build_column((np.arange(40, dtype=np.int32) * 2), None, chunk, abi.ENC_UNENCODED)
     return d
 
 
@@ -155,6 +158,12 @@ def worker(rank, world, init_file, out_dir, executor_kind):
     out["joins"][("repartition_outer", abi.JOIN_RIGHT)] = pairs_of(l, r)
     l, r = sharded_join_repartition(comm, ex, shard("nullable_probe"), shard("dup_build"), first_nullable, first_dup, abi.JOIN_ANTI_NULL_AS_TRUE)
     out["joins"][("repartition_anti_null_build", abi.JOIN_ANTI_NULL_AS_TRUE)] = pairs_of(l, r)
+    first_even = shard_column(d["even_build"], world, rank)[1]
+    for mode in (abi.JOIN_LEFT, abi.JOIN_ANTI_NULL_AS_FALSE, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_SEMI):
+        l, r = sharded_join_repartition(comm, ex, shard("probe"), shard("even_build"), first_probe, first_even, mode)
+        out["joins"][("repartition_empty_side", mode)] = pairs_of(l, r)
+    l, r = sharded_join_repartition(comm, ex, shard("even_build"), shard("probe"), first_even, first_probe, abi.JOIN_RIGHT)
+    out["joins"][("repartition_empty_side", abi.JOIN_RIGHT)] = pairs_of(l, r)
     try:   # a broadcast of the side hy_join_hash would PROBE with is refused (every rank would emit the gathered side's rows)
         sharded_join_broadcast(comm, ex, shard("build"), shard("probe"), abi.JOIN_LEFT, first_probe, d["chunk"], build_is_left=True)
         out["broadcast_refused"] = False
@@ -243,4 +252,9 @@ def check_results(results):
     assert multiset("repartition_outer", abi.JOIN_RIGHT) == join_result_multiset(whole, abi.JOIN_RIGHT)
     whole = oracle_join(d["nullable_probe"], d["dup_build"], abi.JOIN_ANTI_NULL_AS_TRUE)   # (a NULL key on the right side: nothing qualifies)
     assert whole.n_pairs == 0 and multiset("repartition_anti_null_build", abi.JOIN_ANTI_NULL_AS_TRUE) == []
+    for mode in (abi.JOIN_LEFT, abi.JOIN_ANTI_NULL_AS_FALSE, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_SEMI):
+        whole = oracle_join(d["probe"], d["even_build"], mode)
+        assert multiset("repartition_empty_side", mode) == join_result_multiset(whole, mode), f"a rank without build tuples, mode {mode}"
+    whole = oracle_join(d["even_build"], d["probe"], abi.JOIN_RIGHT)
+    assert multiset("repartition_empty_side", abi.JOIN_RIGHT) == join_result_multiset(whole, abi.JOIN_RIGHT)
     assert all(r["broadcast_refused"] for r in results)
