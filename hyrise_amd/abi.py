@@ -19,7 +19,7 @@ TYPE_NULL, TYPE_INT, TYPE_LONG, TYPE_FLOAT, TYPE_DOUBLE, TYPE_STRING = range(6)
 (JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL_OUTER, JOIN_CROSS, JOIN_SEMI, JOIN_ANTI_NULL_AS_TRUE,
  JOIN_ANTI_NULL_AS_FALSE) = range(8)
 AGG_MIN, AGG_MAX, AGG_SUM, AGG_AVG, AGG_COUNT, AGG_COUNT_DISTINCT, AGG_STDDEV_SAMP, AGG_ANY = range(8)
-ENC_UNENCODED, ENC_DICTIONARY, ENC_FRAME_OF_REFERENCE, ENC_REFERENCE, ENC_MVCC, ENC_RUN_LENGTH = range(6)
+ENC_UNENCODED, ENC_DICTIONARY, ENC_FRAME_OF_REFERENCE, ENC_REFERENCE, ENC_MVCC, ENC_RUN_LENGTH, ENC_LZ4 = range(7)
 SORT_NONE, SORT_ASCENDING_NULLS_FIRST, SORT_DESCENDING_NULLS_FIRST, SORT_ASCENDING_NULLS_LAST, SORT_DESCENDING_NULLS_LAST = range(5)   # hyrise::SortMode + 1
 MEM_HOST, MEM_DEVICE = 0, 1
 CHUNK_SCANNED, CHUNK_ALL_MATCH, CHUNK_NONE_MATCH = 0, 1, 2
@@ -40,6 +40,12 @@ class Segment(C.Structure):
     _fields_ = [("encoding", C.c_uint32), ("data_type", C.c_uint32), ("size", C.c_uint32), ("width", C.c_uint32),
                 ("data", C.c_void_p), ("aux", C.c_void_p), ("aux_size", C.c_uint32), ("ref_chunk_id", C.c_uint32),
                 ("nulls", C.c_void_p), ("ref", C.c_void_p), ("sorted_by", C.c_uint32), ("bits", C.c_uint32)]
+
+
+class Lz4Blocks(C.Structure):
+    """hy_lz4_blocks: what an LZ4Segment<T> holds -- its blocks, compressed one by one against the dictionary."""
+    _fields_ = [("blocks", C.POINTER(C.c_void_p)), ("block_bytes", C.POINTER(C.c_uint32)), ("block_count", C.c_uint32), ("block_size", C.c_uint32),
+                ("last_block_size", C.c_uint32), ("dictionary_bytes", C.c_uint32), ("dictionary", C.c_void_p)]
 
 
 class Value(C.Union):

@@ -169,7 +169,9 @@ class _Reader:
         return out
 
 
-def read_table(path):
+def read_table(path, keep_lz4=False):
+    """keep_lz4: numeric LZ4 segments stay compressed (abi.ENC_LZ4: the library decompresses them on the device); their decoded twin is kept
+    in `segment.decoded` for comparison."""
     with open(path, "rb") as fh:
         r = _Reader(fh.read())
     chunk_size, chunk_count, column_count = r.take("I"), r.take("I"), r.take("H")
@@ -184,7 +186,7 @@ def read_table(path):
         rows = r.take("I")
         sort_definitions.append([r.take("HB") for _ in range(r.take("I"))])   # SortColumnDefinition: ColumnID (2) + SortMode (1)
         for c in range(column_count):
-            segment, text, nulls = _read_segment(r, types[c], nullable[c], rows)
+            segment, text, nulls = _read_segment(r, types[c], nullable[c], rows, keep_lz4)
             segments[c].append(segment)
             strings[c].append(text)
             null_masks[c].append(nulls)
@@ -194,7 +196,7 @@ def read_table(path):
     return BinaryTable(names, types, nullable, chunk_size, columns, strings, null_masks, sort_definitions)
 
 
-def _read_segment(r, data_type, column_nullable, rows):
+def _read_segment(r, data_type, column_nullable, rows, keep_lz4=False):
     encoding = r.take("B")
     is_string = data_type == abi.TYPE_STRING
     if encoding == ENCODING_UNENCODED:                   # binary_writer.hpp:56-76
@@ -276,6 +278,11 @@ def _read_segment(r, data_type, column_nullable, rows):
             return HostSegment(abi.ENC_UNENCODED, data_type, rows, 0, None), values, nulls
         values = np.frombuffer(raw, dtype=NUMPY_OF_TYPE[data_type], count=elements).copy()
         words = pack_nulls(nulls) if nulls is not None else None
+        if keep_lz4:   # the segment as Hyrise holds it: the library's device decoder gets the blocks
+            segment = HostSegment(abi.ENC_LZ4, data_type, rows, values.dtype.itemsize, None, nulls=words)
+            segment.lz4 = (blocks, block_size, last_block_size, dictionary)
+            segment.decoded = values
+            return segment, None, nulls
         return HostSegment(abi.ENC_UNENCODED, data_type, rows, values.dtype.itemsize, values, nulls=words), None, nulls
     raise UnsupportedSegment(f"encoding {encoding}")
 

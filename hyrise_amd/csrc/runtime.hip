@@ -469,6 +469,8 @@ static size_t type_width(uint32_t data_type) {
   }
 }
 
+constexpr uint32_t LZ4_MAX_BLOCK = 65536;   // decompressed bytes of an LZ4 block: its output is staged in LDS (Hyrise's blocks are 16 KB)
+
 static hy_status validate_segment(const hy_segment& s, uint32_t chunk, uint32_t column_type) {
   if (s.data_type != column_type) return fail(HY_ERR_INVALID, "chunk %u: data type %u differs from chunk 0's %u", chunk, s.data_type, column_type);
   if (s.data_type < HY_TYPE_INT || s.data_type > HY_TYPE_STRING) return fail(HY_ERR_INVALID, "chunk %u: bad data type %u", chunk, s.data_type);
@@ -506,6 +508,18 @@ static hy_status validate_segment(const hy_segment& s, uint32_t chunk, uint32_t 
       if (!s.data && s.ref_chunk_id >= s.ref->n_chunks) return fail(HY_ERR_INVALID, "chunk %u: EntireChunkPosList chunk id out of range", chunk);
       if (s.data && s.ref_chunk_id != 0xFFFFFFFFu && s.ref_chunk_id >= s.ref->n_chunks) return fail(HY_ERR_INVALID, "chunk %u: common chunk id out of range", chunk);
       break;
+    case HY_ENC_LZ4: {
+      if (s.data_type == HY_TYPE_STRING) return fail(HY_ERR_UNSUPPORTED, "chunk %u: LZ4 string segments stay on the CPU path", chunk);
+      if (s.width != type_width(s.data_type)) return fail(HY_ERR_INVALID, "chunk %u: value width %u does not match type %u", chunk, s.width, s.data_type);
+      const auto* lz4 = static_cast<const hy_lz4_blocks*>(s.data);
+      if (!lz4) return fail(HY_ERR_INVALID, "chunk %u: LZ4 segment without its block descriptor", chunk);
+      if (lz4->block_count && (!lz4->blocks || !lz4->block_bytes)) return fail(HY_ERR_INVALID, "chunk %u: LZ4 blocks missing", chunk);
+      if (lz4->block_size > LZ4_MAX_BLOCK || lz4->last_block_size > lz4->block_size) return fail(HY_ERR_UNSUPPORTED, "chunk %u: LZ4 blocks of %u bytes (at most %u)", chunk, lz4->block_size, LZ4_MAX_BLOCK);
+      const uint64_t decoded = lz4->block_count ? uint64_t{lz4->block_count - 1} * lz4->block_size + lz4->last_block_size : 0;
+      if (decoded != uint64_t{s.size} * s.width) return fail(HY_ERR_INVALID, "chunk %u: LZ4 blocks decode to %llu bytes, %u rows of %u bytes expected", chunk, static_cast<unsigned long long>(decoded), s.size, s.width);
+      if (lz4->dictionary_bytes && !lz4->dictionary) return fail(HY_ERR_INVALID, "chunk %u: LZ4 dictionary missing", chunk);
+      break;
+    }
     default: return fail(HY_ERR_UNSUPPORTED, "chunk %u: encoding %u stays on the CPU path", chunk, s.encoding);
   }
   if (s.sorted_by > HY_SORT_DESCENDING_NULLS_LAST) return fail(HY_ERR_INVALID, "chunk %u: sort mode %u", chunk, s.sorted_by);
@@ -513,6 +527,158 @@ static hy_status validate_segment(const hy_segment& s, uint32_t chunk, uint32_t 
 }
 
 static bool bit_packed(const hy_segment& s) { return (s.encoding == HY_ENC_DICTIONARY || s.encoding == HY_ENC_FRAME_OF_REFERENCE) && s.width == 0; }
+}  // extern "C"
+
+namespace hy {
+
+// ---- LZ4 blocks, decompressed on the device (lz4_Block_format.md; LZ4_decompress_safe_usingDict, lz4_segment.cpp:191-226) ---------------
+// A block is a chain of sequences -- token (literal length << 4 | match length - 4, both continued in bytes of 255), the literals, a 2-byte
+// match offset -- each of which copies bytes that are already there: one wavefront per block walks the chain with uniform (scalar) reads
+// and copies with all 64 lanes, the block's output in LDS (an LDS instruction of a wave sees what its earlier ones wrote; global memory
+// promises that only behind a wait for every store), which leaves as one coalesced copy.  A match may reach back in front of the block,
+// into the segment's dictionary, and may overlap its own output (offset < length: the last `offset` bytes repeat).
+struct Lz4Block {
+  uint64_t source, target, dictionary;   // byte offsets: the compressed block and the dictionary inside `compressed`, the output inside `decoded`
+  uint32_t source_bytes, target_bytes, dictionary_bytes, reserved;
+};
+
+__global__ __launch_bounds__(64) void lz4_decode_blocks(const uint8_t* compressed, uint8_t* decoded, const Lz4Block* blocks, uint32_t* error) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_out[];   // [target_bytes, rounded up to 16] the output | [source_bytes] the compressed block
+  const uint32_t lane = threadIdx.x;
+  const Lz4Block block = blocks[blockIdx.x];
+  const uint8_t* dictionary = compressed + block.dictionary;
+  const uint32_t n = block.source_bytes, size = block.target_bytes, history = block.dictionary_bytes;
+  // the compressed block into LDS first (one coalesced read): the chain below reads it byte by byte, each read waiting for the one before
+  uint8_t* in = s_out + ((size + 15) & ~15u);
+  for (uint32_t k = lane; k < n; k += 64) in[k] = compressed[block.source + k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint32_t i = 0, o = 0;
+  bool corrupt = false;
+  while (i < n && !corrupt) {
+    const uint32_t token = in[i++];
+    uint32_t literals = token >> 4;
+    if (literals == 15) {
+      uint32_t extra;
+      do {
+        if (i >= n) { corrupt = true; break; }
+        extra = in[i++];
+        literals += extra;
+      } while (extra == 255);
+    }
+    if (corrupt || i + literals > n || o + literals > size) { corrupt = true; break; }
+    for (uint32_t k = lane; k < literals; k += 64) s_out[o + k] = in[i + k];
+    i += literals;
+    o += literals;
+    if (i >= n) break;   // the last sequence ends after its literals
+    if (i + 2 > n) { corrupt = true; break; }
+    const uint32_t offset = in[i] | static_cast<uint32_t>(in[i + 1]) << 8;
+    i += 2;
+    uint32_t length = (token & 15) + 4;
+    if ((token & 15) == 15) {
+      uint32_t extra;
+      do {
+        if (i >= n) { corrupt = true; break; }
+        extra = in[i++];
+        length += extra;
+      } while (extra == 255);
+    }
+    if (corrupt || offset == 0 || offset > o + history || o + length > size) { corrupt = true; break; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // byte k of the match is byte (k mod offset) of the `offset` bytes in front of the output position -- which may begin in the dictionary
+    for (uint32_t k = lane; k < length; k += 64) {
+      const int64_t from = static_cast<int64_t>(o) - offset + (k % offset);
+      s_out[o + k] = from >= 0 ? s_out[from] : dictionary[history + from];
+    }
+    o += length;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (corrupt || o != size) { if (lane == 0) atomicOr(error, 1u); return; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint8_t* out = decoded + block.target;
+  if (size % 4 == 0) { for (uint32_t k = lane; k < size / 4; k += 64) reinterpret_cast<uint32_t*>(out)[k] = reinterpret_cast<const uint32_t*>(s_out)[k]; }
+  else { for (uint32_t k = lane; k < size; k += 64) out[k] = s_out[k]; }
+}
+
+// The LZ4 segments of a column that is being created: their blocks go to the device as they are, lz4_decode_blocks writes the values into a
+// buffer the column owns, and the segments become the ValueSegments they were compressed from (data = device memory: on_device[c] = 1).
+static hy_status decode_lz4_segments(hy_column* column, std::vector<uint8_t>& on_device) {
+  std::vector<Lz4Block> blocks;
+  std::vector<uint8_t> staged;
+  size_t decoded_bytes = 0;
+  std::vector<size_t> segment_target(column->n_chunks, 0);
+  for (uint32_t c = 0; c < column->n_chunks; ++c) {
+    const hy_segment& s = column->host_segments[c];
+    if (s.encoding != HY_ENC_LZ4) continue;
+    const auto* lz4 = static_cast<const hy_lz4_blocks*>(s.data);
+    const size_t dictionary_at = staged.size();
+    if (lz4->dictionary_bytes) staged.insert(staged.end(), static_cast<const uint8_t*>(lz4->dictionary), static_cast<const uint8_t*>(lz4->dictionary) + lz4->dictionary_bytes);
+    segment_target[c] = decoded_bytes;
+    for (uint32_t b = 0; b < lz4->block_count; ++b) {
+      Lz4Block block{};
+      block.source = staged.size();
+      block.source_bytes = lz4->block_bytes[b];
+      block.dictionary = dictionary_at;
+      block.dictionary_bytes = lz4->dictionary_bytes;
+      block.target = decoded_bytes + size_t{b} * lz4->block_size;
+      block.target_bytes = b + 1 < lz4->block_count ? lz4->block_size : lz4->last_block_size;
+      staged.insert(staged.end(), static_cast<const uint8_t*>(lz4->blocks[b]), static_cast<const uint8_t*>(lz4->blocks[b]) + lz4->block_bytes[b]);
+      blocks.push_back(block);
+    }
+    decoded_bytes += align_up(size_t{s.size} * s.width + 16, 256);   // (+ 16: vector loads of the last partial group stay inside)
+  }
+  if (decoded_bytes == 0) return HY_OK;
+  hipStream_t stream = current_stream();
+  char* decoded = nullptr;
+  HY_HIP(hipMalloc(reinterpret_cast<void**>(&decoded), decoded_bytes));
+  column->owned.push_back(decoded);
+  if (!blocks.empty()) {
+    DeviceBuffer d_staged, d_blocks, d_error;
+    HY_TRY(d_staged.alloc(staged.size() + 16));
+    HY_TRY(d_blocks.alloc(sizeof(Lz4Block) * blocks.size()));
+    HY_TRY(d_error.alloc(4));
+    HY_HIP(hipMemcpyAsync(d_staged.ptr, staged.data(), staged.size(), hipMemcpyHostToDevice, stream));
+    HY_HIP(hipMemcpyAsync(d_blocks.ptr, blocks.data(), sizeof(Lz4Block) * blocks.size(), hipMemcpyHostToDevice, stream));
+    HY_HIP(hipMemsetAsync(d_error.ptr, 0, 4, stream));
+    static OncePerDevice lds_raised;
+    uint64_t device_bit = 0;
+    if (lds_raised.pending(&device_bit)) {
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_decode_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LZ4_MAX_BLOCK + 4096));
+      lds_raised.done(device_bit);
+    }
+    uint32_t largest = 0;   // LDS per block: its output and its compressed bytes
+    for (const Lz4Block& block : blocks) largest = std::max(largest, ((block.target_bytes + 15) & ~15u) + block.source_bytes);
+    if (largest > 2 * LZ4_MAX_BLOCK + 4096) return fail(HY_ERR_UNSUPPORTED, "an LZ4 block of %u bytes (compressed + decompressed) does not fit LDS", largest);
+    hipLaunchKernelGGL(lz4_decode_blocks, dim3(static_cast<uint32_t>(blocks.size())), dim3(64), (largest + 15) & ~15u, stream, d_staged.as<uint8_t>(),
+                       reinterpret_cast<uint8_t*>(decoded), d_blocks.as<Lz4Block>(), d_error.as<uint32_t>());
+    uint32_t error = 0;
+    HY_HIP(hipMemcpyAsync(&error, d_error.ptr, 4, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipStreamSynchronize(stream));   // (the staged blocks and the host vectors above live until here)
+    if (error) return fail(HY_ERR_INVALID, "an LZ4 block is corrupt (its sequences do not decode to the block's size)");
+  }
+  for (uint32_t c = 0; c < column->n_chunks; ++c) {
+    hy_segment& s = column->host_segments[c];
+    if (s.encoding != HY_ENC_LZ4) continue;
+    s.encoding = HY_ENC_UNENCODED;
+    s.data = decoded + segment_target[c];
+    s.aux = nullptr;
+    s.aux_size = 0;
+    on_device[c] = 1;
+  }
+  return HY_OK;
+}
+
+}  // namespace hy
+
+extern "C" {
+
 static bool compressed(const hy_segment& s) { return s.encoding == HY_ENC_RUN_LENGTH || bit_packed(s); }
 
 static size_t data_bytes(const hy_segment& s) {
@@ -573,6 +739,15 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     for (uint32_t run = 0; run < s.aux_size && s.nulls; ++run) any_null = any_null || reinterpret_cast<const uint8_t*>(s.nulls)[run] != 0;
     if (!any_null) column->host_segments[c].nulls = nullptr;
   }
+  // LZ4 segments: decompressed on the device, ValueSegments from here on (their values are device memory already)
+  std::vector<uint8_t> on_device(n_chunks, 0);
+  bool any_lz4 = false;
+  for (uint32_t c = 0; c < n_chunks; ++c) any_lz4 = any_lz4 || segments[c].encoding == HY_ENC_LZ4;
+  if (any_lz4) {
+    if (mem != HY_MEM_HOST) return cleanup(fail(HY_ERR_INVALID, "LZ4 segments are handed over as host memory (HY_MEM_HOST)"));
+    const hy_status decoded = decode_lz4_segments(column, on_device);
+    if (decoded != HY_OK) return cleanup(decoded);
+  }
   segments = column->host_segments.data();
 
   // One arena for every buffer of the column: 916 chunks x 3 buffers would otherwise be ~2.7k hipMallocs.
@@ -581,7 +756,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     for (uint32_t c = 0; c < n_chunks; ++c) {
       const hy_segment& s = segments[c];
       // +16: vector loads of the last partial group never leave the allocation
-      arena_bytes += align_up(data_bytes(s) + 16, 256) + align_up(aux_bytes(s) + 16, 256) + align_up(null_bytes(s) + 16, 256);
+      arena_bytes += (on_device[c] ? 0 : align_up(data_bytes(s) + 16, 256)) + align_up(aux_bytes(s) + 16, 256) + align_up(null_bytes(s) + 16, 256);
     }
   }
   char* arena = nullptr;
@@ -612,8 +787,8 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     DevSegment& d = dev[c];
     std::memset(&d, 0, sizeof(d));
     if (mem == HY_MEM_HOST) {
-      const void *p_data = nullptr, *p_aux = nullptr, *p_nulls = nullptr;
-      hipError_t err = upload(s.data, data_bytes(s), &p_data);
+      const void *p_data = on_device[c] ? s.data : nullptr, *p_aux = nullptr, *p_nulls = nullptr;
+      hipError_t err = on_device[c] ? hipSuccess : upload(s.data, data_bytes(s), &p_data);
       if (err == hipSuccess) err = upload(s.aux, aux_bytes(s), &p_aux);
       if (err == hipSuccess) err = upload(s.nulls, null_bytes(s), &p_nulls);
       if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "chunk %u upload failed: %s", c, hipGetErrorString(err)));

@@ -47,7 +47,7 @@ enum class PredicateCondition : uint8_t {
 };
 enum class JoinMode : uint8_t { Inner, Left, Right, FullOuter, Cross, Semi, AntiNullAsTrue, AntiNullAsFalse };
 enum class WindowFunction : uint8_t { Min, Max, Sum, Avg, Count, CountDistinct, StandardDeviationSample, Any };
-enum class EncodingType : uint8_t { Unencoded, Dictionary, FrameOfReference };
+enum class EncodingType : uint8_t { Unencoded, Dictionary, FrameOfReference, LZ4 };
 enum class TableType : uint8_t { Data, References };
 enum class SortMode : uint8_t { AscendingNullsFirst, DescendingNullsFirst, AscendingNullsLast, DescendingNullsLast };   // types.hpp:219
 struct SortColumnDefinition {   // types.hpp:245-251
@@ -224,6 +224,73 @@ class FrameOfReferenceSegment : public AbstractSegment {   // storage/frame_of_r
   std::optional<std::vector<bool>> _nulls;
   std::vector<uint64_t> _null_words;
   ChunkOffset _size;
+};
+
+// LZ4Segment<T> of a numeric type (storage/lz4_segment.hpp:25-118): the values' bytes in blocks of BLOCK_SIZE, every block compressed on its
+// own.  The device path takes the blocks as they are (HY_ENC_LZ4 + hy_lz4_blocks) and decompresses them with a kernel.
+template <typename T>
+class LZ4Segment : public AbstractSegment {
+ public:
+  static constexpr size_t BLOCK_SIZE = 16384;   // lz4_encoder.hpp:61
+  LZ4Segment(std::vector<std::vector<char>> blocks, std::optional<std::vector<bool>> nulls, std::vector<char> dictionary, size_t block_size, size_t last_block_size, ChunkOffset size)
+      : AbstractSegment(data_type_of<T>()), _blocks(std::move(blocks)), _nulls(std::move(nulls)), _dictionary(std::move(dictionary)), _block_size(block_size),
+        _last_block_size(last_block_size), _size(size) {
+    if (_nulls) _null_words = pack_null_words(*_nulls);
+    for (const auto& block : _blocks) { _block_pointers.push_back(block.data()); _block_bytes.push_back(static_cast<uint32_t>(block.size())); }
+    _descriptor.blocks = _block_pointers.data();
+    _descriptor.block_bytes = _block_bytes.data();
+    _descriptor.block_count = static_cast<uint32_t>(_blocks.size());
+    _descriptor.block_size = static_cast<uint32_t>(_block_size);
+    _descriptor.last_block_size = static_cast<uint32_t>(_last_block_size);
+    _descriptor.dictionary_bytes = static_cast<uint32_t>(_dictionary.size());
+    _descriptor.dictionary = _dictionary.empty() ? nullptr : _dictionary.data();
+  }
+  ChunkOffset size() const override { return _size; }
+  AllTypeVariant operator[](ChunkOffset offset) const override {   // (the mirror's own decoder: decompress(), lz4_segment.cpp:125-136)
+    if (_nulls && (*_nulls)[offset]) return NullValue{};
+    return decompress()[offset];
+  }
+  std::vector<T> decompress() const {
+    std::vector<char> bytes;
+    for (size_t b = 0; b < _blocks.size(); ++b) {
+      const auto& in = _blocks[b];
+      const size_t start = bytes.size();
+      size_t i = 0;
+      while (i < in.size()) {
+        const auto token = static_cast<uint8_t>(in[i++]);
+        size_t literals = token >> 4;
+        if (literals == 15) { uint8_t extra; do { extra = static_cast<uint8_t>(in[i++]); literals += extra; } while (extra == 255); }
+        bytes.insert(bytes.end(), in.begin() + i, in.begin() + i + literals);
+        i += literals;
+        if (i >= in.size()) break;
+        const size_t offset = static_cast<uint8_t>(in[i]) | static_cast<size_t>(static_cast<uint8_t>(in[i + 1])) << 8;
+        i += 2;
+        size_t length = (token & 15) + 4;
+        if ((token & 15) == 15) { uint8_t extra; do { extra = static_cast<uint8_t>(in[i++]); length += extra; } while (extra == 255); }
+        for (size_t k = 0; k < length; ++k) {
+          const ptrdiff_t from = static_cast<ptrdiff_t>(bytes.size() - start) - static_cast<ptrdiff_t>(offset);
+          bytes.push_back(from >= 0 ? bytes[start + from] : _dictionary[_dictionary.size() + from]);
+        }
+      }
+    }
+    std::vector<T> values(_size);
+    std::memcpy(values.data(), bytes.data(), std::min(bytes.size(), sizeof(T) * _size));
+    return values;
+  }
+  const hy_lz4_blocks& descriptor() const { return _descriptor; }
+  bool has_nulls() const { return _nulls.has_value(); }
+  const std::vector<uint64_t>& null_words() const { return _null_words; }
+
+ private:
+  std::vector<std::vector<char>> _blocks;
+  std::optional<std::vector<bool>> _nulls;
+  std::vector<char> _dictionary;
+  size_t _block_size, _last_block_size;
+  ChunkOffset _size;
+  std::vector<uint64_t> _null_words;
+  std::vector<const void*> _block_pointers;
+  std::vector<uint32_t> _block_bytes;
+  hy_lz4_blocks _descriptor{};
 };
 
 class ReferenceSegment : public AbstractSegment {   // storage/reference_segment.hpp:20-48
@@ -477,6 +544,54 @@ struct ChunkEncoder {
     return std::make_shared<FrameOfReferenceSegment>(std::move(minima), CompressedVector::compress(offsets, max_offset),
                                                      any_null ? std::optional<std::vector<bool>>(std::move(nulls)) : std::nullopt, n);
   }
+  // One LZ4 block (lz4_Block_format.md) by a greedy matcher over 4-byte words -- enough to produce what liblz4 would also accept; the
+  // mirror has no zstd dictionary trainer, so its blocks are compressed without one (each still decompresses on its own).
+  static std::vector<char> lz4_compress_block(const char* in, size_t n) {
+    std::vector<char> out;
+    std::vector<int32_t> last(1 << 12, -1);
+    size_t anchor = 0, i = 0;
+    auto emit = [&](size_t literal_end, size_t offset, size_t length) {   // length 0: the closing literals
+      const size_t literals = literal_end - anchor;
+      out.push_back(static_cast<char>((std::min<size_t>(literals, 15) << 4) | (length ? std::min<size_t>(length - 4, 15) : 0)));
+      if (literals >= 15) { size_t rest = literals - 15; while (rest >= 255) { out.push_back(static_cast<char>(255)); rest -= 255; } out.push_back(static_cast<char>(rest)); }
+      out.insert(out.end(), in + anchor, in + literal_end);
+      if (!length) return;
+      out.push_back(static_cast<char>(offset & 0xFF));
+      out.push_back(static_cast<char>(offset >> 8));
+      if (length - 4 >= 15) { size_t rest = length - 4 - 15; while (rest >= 255) { out.push_back(static_cast<char>(255)); rest -= 255; } out.push_back(static_cast<char>(rest)); }
+    };
+    while (i + 12 < n) {   // (the format wants the last five bytes as literals and no match within the last twelve)
+      uint32_t word;
+      std::memcpy(&word, in + i, 4);
+      const uint32_t slot = (word * 2654435761u) >> 20;
+      const int32_t candidate = last[slot];
+      last[slot] = static_cast<int32_t>(i);
+      uint32_t there = 0;
+      if (candidate >= 0) std::memcpy(&there, in + candidate, 4);
+      if (candidate < 0 || there != word || i - candidate > 65535) { ++i; continue; }
+      size_t length = 4;
+      while (i + length + 5 < n && in[candidate + length] == in[i + length]) ++length;
+      emit(i, i - candidate, length);
+      i += length;
+      anchor = i;
+    }
+    emit(n, 0, 0);
+    return out;
+  }
+  template <typename T>
+  static std::shared_ptr<AbstractSegment> encode_lz4(const ValueSegment<T>& segment) {
+    const auto n = segment.size();
+    std::vector<T> values(segment.values().begin(), segment.values().end());
+    std::vector<bool> nulls(n, false);
+    bool any_null = false;
+    for (ChunkOffset i = 0; i < n; ++i) { nulls[i] = segment.is_null(i); any_null |= nulls[i]; if (nulls[i]) values[i] = T{}; }
+    const auto* bytes = reinterpret_cast<const char*>(values.data());
+    const size_t total = sizeof(T) * n, block_size = LZ4Segment<T>::BLOCK_SIZE;
+    std::vector<std::vector<char>> blocks;
+    for (size_t begin = 0; begin < total; begin += block_size) blocks.push_back(lz4_compress_block(bytes + begin, std::min(block_size, total - begin)));
+    const size_t last_block_size = total == 0 ? 0 : (total % block_size ? total % block_size : block_size);
+    return std::make_shared<LZ4Segment<T>>(std::move(blocks), any_null ? std::optional<std::vector<bool>>(std::move(nulls)) : std::nullopt, std::vector<char>{}, block_size, last_block_size, n);
+  }
   // encode_all_chunks(table, SegmentEncodingSpec{type}); unsupported (type, data type) pairs stay unencoded like
   // load_and_encode_table in table_scan_test.cpp:63-75.
   static void encode_all_chunks(const std::shared_ptr<Table>& table, EncodingType type) {
@@ -488,6 +603,12 @@ struct ChunkEncoder {
         std::shared_ptr<AbstractSegment> encoded;
         if (type == EncodingType::FrameOfReference) {
           if (const auto* ints = dynamic_cast<const ValueSegment<int32_t>*>(segment.get())) encoded = encode_frame_of_reference(*ints);
+        } else if (type == EncodingType::LZ4) {   // (LZ4 string segments stay on the CPU path: strings keep their dictionary encoding here)
+          if (const auto* i32 = dynamic_cast<const ValueSegment<int32_t>*>(segment.get())) encoded = encode_lz4(*i32);
+          else if (const auto* i64 = dynamic_cast<const ValueSegment<int64_t>*>(segment.get())) encoded = encode_lz4(*i64);
+          else if (const auto* f32 = dynamic_cast<const ValueSegment<float>*>(segment.get())) encoded = encode_lz4(*f32);
+          else if (const auto* f64 = dynamic_cast<const ValueSegment<double>*>(segment.get())) encoded = encode_lz4(*f64);
+          else if (const auto* str = dynamic_cast<const ValueSegment<std::string>*>(segment.get())) encoded = encode_dictionary(*str);
         } else if (const auto* i32 = dynamic_cast<const ValueSegment<int32_t>*>(segment.get())) encoded = encode_dictionary(*i32);
         else if (const auto* i64 = dynamic_cast<const ValueSegment<int64_t>*>(segment.get())) encoded = encode_dictionary(*i64);
         else if (const auto* f32 = dynamic_cast<const ValueSegment<float>*>(segment.get())) encoded = encode_dictionary(*f32);
@@ -601,6 +722,12 @@ inline std::shared_ptr<DeviceColumn> device_column_of_chunks(const std::shared_p
       d.nulls = typed->is_nullable() ? typed->null_words().data() : nullptr;
       ok = true;
     };
+    const auto describe_lz4 = [&](auto* typed) {   // the blocks as they are: the library decompresses them on the device
+      using T = std::decay_t<decltype(typed->decompress()[0])>;
+      d.encoding = HY_ENC_LZ4; d.width = sizeof(T); d.data = &typed->descriptor();
+      d.nulls = typed->has_nulls() ? typed->null_words().data() : nullptr;
+      ok = true;
+    };
     const auto describe_dictionary = [&](auto* typed) {
       d.encoding = HY_ENC_DICTIONARY; d.width = typed->attribute_vector().width; d.data = typed->attribute_vector().bytes.data();
       d.aux = typed->dictionary().data(); d.aux_size = typed->unique_values_count();
@@ -610,6 +737,10 @@ inline std::shared_ptr<DeviceColumn> device_column_of_chunks(const std::shared_p
     else if (const auto* s = dynamic_cast<const ValueSegment<int64_t>*>(segment.get())) describe_value(s);
     else if (const auto* s = dynamic_cast<const ValueSegment<float>*>(segment.get())) describe_value(s);
     else if (const auto* s = dynamic_cast<const ValueSegment<double>*>(segment.get())) describe_value(s);
+    else if (const auto* s = dynamic_cast<const LZ4Segment<int32_t>*>(segment.get())) describe_lz4(s);
+    else if (const auto* s = dynamic_cast<const LZ4Segment<int64_t>*>(segment.get())) describe_lz4(s);
+    else if (const auto* s = dynamic_cast<const LZ4Segment<float>*>(segment.get())) describe_lz4(s);
+    else if (const auto* s = dynamic_cast<const LZ4Segment<double>*>(segment.get())) describe_lz4(s);
     else if (const auto* s = dynamic_cast<const DictionarySegment<int32_t>*>(segment.get())) describe_dictionary(s);
     else if (const auto* s = dynamic_cast<const DictionarySegment<int64_t>*>(segment.get())) describe_dictionary(s);
     else if (const auto* s = dynamic_cast<const DictionarySegment<float>*>(segment.get())) describe_dictionary(s);

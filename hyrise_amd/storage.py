@@ -49,6 +49,23 @@ class HostSegment:
         self.ref, self.ref_chunk_id = ref, int(ref_chunk_id)
         self.sorted_by = int(sorted_by)   # abi.SORT_*: Chunk::individually_sorted_by names this column
         self.bits = int(bits)             # width == 0: `data` is a BitPackingVector of `bits` bits per element (uint64 words)
+        self.lz4 = None                   # ENC_LZ4: (blocks as bytes objects, block_size, last_block_size, dictionary bytes) -- see lz4_descriptor
+
+    def lz4_descriptor(self):
+        """abi.Lz4Blocks over this segment's compressed blocks (and everything that must stay alive with it)."""
+        import ctypes as C
+        blocks, block_size, last_block_size, dictionary = self.lz4
+        buffers = [np.frombuffer(b, dtype=np.uint8) if len(b) else np.zeros(1, dtype=np.uint8) for b in blocks]
+        pointers = (C.c_void_p * max(1, len(blocks)))(*[b.ctypes.data for b in buffers])
+        sizes = (C.c_uint32 * max(1, len(blocks)))(*[len(b) for b in blocks])
+        dictionary_buffer = np.frombuffer(dictionary, dtype=np.uint8) if dictionary else None
+        d = abi.Lz4Blocks()
+        d.blocks, d.block_bytes = C.cast(pointers, C.POINTER(C.c_void_p)), C.cast(sizes, C.POINTER(C.c_uint32))
+        d.block_count, d.block_size, d.last_block_size = len(blocks), block_size, last_block_size
+        d.dictionary_bytes = len(dictionary) if dictionary else 0
+        d.dictionary = dictionary_buffer.ctypes.data if dictionary_buffer is not None else None
+        self._lz4_alive = (buffers, pointers, sizes, dictionary_buffer, d)
+        return d
 
 
 def encode_segment(values, nulls, encoding, data_type=None):
@@ -133,7 +150,11 @@ class HostColumn:
         for i, s in enumerate(self.segments):
             d = arr[i]
             d.encoding, d.data_type, d.size, d.width = s.encoding, s.data_type, s.size, s.width
-            d.data = s.data.ctypes.data if s.data is not None else None
+            if s.encoding == abi.ENC_LZ4:
+                import ctypes as C
+                d.data = C.addressof(s.lz4_descriptor())
+            else:
+                d.data = s.data.ctypes.data if s.data is not None else None
             d.aux = s.aux.ctypes.data if s.aux is not None else None
             d.aux_size = s.aux_size
             d.ref_chunk_id = s.ref_chunk_id

@@ -73,6 +73,23 @@ enum { HY_ENC_UNENCODED = 0, HY_ENC_DICTIONARY = 1, HY_ENC_FRAME_OF_REFERENCE = 
                               * the end positions per eight rows, run_length_segment_iterable.hpp:100-160); the other operators read a
                               * ValueSegment twin that a device kernel decodes from them the first time one of them asks. */ };
 
+/* HY_ENC_LZ4 = 6: an LZ4Segment<T> of a numeric type (lz4_segment.hpp:25-60, lz4_segment.cpp:125-226): `data` points at ONE hy_lz4_blocks
+ * (host memory: such a segment is handed over with HY_MEM_HOST), width = sizeof(T), nulls = the optional null bitmap like a ValueSegment's.
+ * The blocks -- compressed one by one with LZ4_compress_*_usingDict against the segment's dictionary, so that each decompresses on its own --
+ * travel to the device as they are and a kernel decompresses them there (one wavefront per block, the block's output staged in LDS); the
+ * column then holds the ValueSegment the segment was compressed from (the reference, too, decompresses an LZ4Segment to scan it).
+ * LZ4 string segments stay with the host like every string payload. */
+enum { HY_ENC_LZ4 = 6 };
+typedef struct hy_lz4_blocks {
+  const void* const* blocks;      /* [block_count] the compressed blocks (pmr_vector<pmr_vector<char>>: one buffer each)             */
+  const uint32_t* block_bytes;    /* [block_count] their compressed sizes                                                           */
+  uint32_t block_count;
+  uint32_t block_size;            /* decompressed bytes of every block but the last (LZ4Encoder::BLOCK_SIZE = 16 384), at most 65 536  */
+  uint32_t last_block_size;       /* ... of the last                                                                                */
+  uint32_t dictionary_bytes;      /* 0: a single block, compressed without a dictionary                                            */
+  const void* dictionary;
+} hy_lz4_blocks;
+
 /* hy_segment::sorted_by: the chunk is individually sorted by this column (Chunk::individually_sorted_by, chunk.hpp:160-176;
  * HY_SORT_* = hyrise::SortMode + 1, types.hpp:219).  ColumnVsValue / ColumnBetween scans then find the matching row range with
  * binary searches instead of reading the segment (sorted_segment_search.hpp:20-384, column_vs_value_table_scan_impl.cpp:46-55). */

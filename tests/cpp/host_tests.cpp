@@ -75,7 +75,7 @@ static void run(const char* name, const std::function<void()>& test) {
   std::printf("[%s] %s\n", g_failures == before ? "  OK  " : "FAILED", name);
 }
 
-static const EncodingType ENCODINGS[] = {EncodingType::Unencoded, EncodingType::Dictionary, EncodingType::FrameOfReference};
+static const EncodingType ENCODINGS[] = {EncodingType::Unencoded, EncodingType::Dictionary, EncodingType::FrameOfReference, EncodingType::LZ4};
 
 static void test_scan_on_compressed_segments() {   // table_scan_test.cpp:407-431, 486-534
   using PC = PredicateCondition;

@@ -59,7 +59,7 @@ def test_header_is_valid_c_and_cxx_and_ctypes_layouts_match(tmp_path):
     for compiler, flags in (("gcc", ["-std=c11", "-x", "c"]), ("g++", ["-std=c++17", "-x", "c++"])):
         subprocess.check_call([compiler] + flags + ["-Wall", "-Wextra", "-Werror", "-fsyntax-only", header])
     structs = {"hy_row_id": abi.RowID, "hy_segment": abi.Segment, "hy_value": abi.Value, "hy_predicate": abi.Predicate,
-               "hy_scan_result": abi.ScanResult, "hy_join_predicate": abi.JoinPredicate, "hy_join_result": abi.JoinResult, "hy_join_status": abi.JoinStatus, "hy_operand": abi.Operand,
+               "hy_scan_result": abi.ScanResult, "hy_join_predicate": abi.JoinPredicate, "hy_join_result": abi.JoinResult, "hy_join_status": abi.JoinStatus, "hy_lz4_blocks": abi.Lz4Blocks, "hy_operand": abi.Operand,
                "hy_aggregate_spec": abi.AggregateSpec, "hy_aggregate_column": abi.AggregateColumn, "hy_aggregate_result": abi.AggregateResult,
                "hy_expression_node": abi.ExpressionNode, "hy_expression": abi.Expression, "hy_filter": abi.Filter, "hy_fused_aggregate": abi.FusedAggregate}
     source = tmp_path / "sizes.c"

@@ -300,6 +300,86 @@ def test_scan_hyrise_binary_tables(device):
     assert scanned > 300
 
 
+def test_lz4_segments_are_decompressed_on_the_device(device):
+    """LZ4Segments exactly as Hyrise wrote them (tests/golden/bin/*/LZ4.bin, LZ4MultipleBlocks.bin: blocks compressed one by one against a
+    zstd-trained dictionary) cross the C ABI COMPRESSED (HY_ENC_LZ4 + hy_lz4_blocks) and are decompressed by the library's kernel: the
+    column reads back as the values of the file's Unencoded twin (hyrise_amd/binary.py's decoder, itself pinned by those files) and scans
+    like a ValueSegment.  Synthetic blocks add what the fixtures lack: literal runs with 255-continued lengths, matches that overlap their
+    own output, a match that begins in the dictionary and ends in the block; a corrupt block is refused."""
+    import glob
+    import os
+    from hyrise_amd import binary
+    from hyrise_amd.storage import HostColumn, HostSegment
+    from support import GOLDEN
+    lib = device
+    root = os.path.join(os.path.dirname(GOLDEN), "bin")
+    checked = 0
+    for path in sorted(glob.glob(os.path.join(root, "**", "LZ4*.bin"), recursive=True)):
+        table = binary.read_table(path, keep_lz4=True)
+        for c, data_type in enumerate(table.types):
+            if data_type == abi.TYPE_STRING or table.chunk_count == 0:
+                continue
+            column = table.columns[c]
+            if not any(segment.encoding == abi.ENC_LZ4 for segment in column.segments):
+                continue
+            dev = DeviceColumn(column)
+            for chunk, segment in enumerate(column.segments):
+                if segment.encoding != abi.ENC_LZ4:
+                    continue
+                got = np.zeros(segment.size, dtype=segment.decoded.dtype)
+                null_words = np.zeros((segment.size + 63) // 64 + 1, dtype=np.uint64)
+                abi.check(lib.hy_column_read_chunk(dev.handle, chunk, got.ctypes.data, null_words.ctypes.data))
+                nulls = table.null_masks[c][chunk]
+                keep = slice(None) if nulls is None else ~nulls
+                assert got[keep].tobytes() == segment.decoded[keep].tobytes(), f"{os.path.relpath(path, root)} column {c} chunk {chunk}"
+                checked += 1
+            dev.close()
+    assert checked >= 20
+
+    def encode(literal_runs_and_matches, dictionary=b""):   # a hand-made LZ4 block: [(literals, match offset or None, match length)]
+        out = bytearray()
+        for literals, offset, length in literal_runs_and_matches:
+            token_literals, token_match = min(len(literals), 15), 0 if offset is None else min(length - 4, 15)
+            out.append(token_literals << 4 | token_match)
+            rest = len(literals) - 15
+            while len(literals) >= 15 and rest >= 0:
+                out.append(min(rest, 255))
+                if rest < 255:
+                    break
+                rest -= 255
+            out += literals
+            if offset is None:
+                break
+            out += bytes([offset & 0xFF, offset >> 8])
+            rest = length - 4 - 15
+            while length - 4 >= 15 and rest >= 0:
+                out.append(min(rest, 255))
+                if rest < 255:
+                    break
+                rest -= 255
+        return bytes(out)
+
+    dictionary = bytes(range(200)) * 6                                                # 1200 bytes of history
+    sequences = [(bytes(range(7)) * 100, 1, 900),                                       # 700 literals (continued length), then the last byte 900 times
+                 (b"", 1200 + 1600 - 100, 300),                                         # 300 bytes out of the dictionary (it lies 1600 output bytes back, the match starts 100 bytes into it)
+                 (b"xy", 2, 2000), (b"tail" * 25 + b"zz", None, 0)]                      # "xyxyxy...": a match that overlaps its own output; the last sequence: literals only
+    block = encode(sequences, dictionary)
+    expected = binary.lz4_block_decode(block, 700 + 900 + 300 + 2 + 2000 + 102, dictionary)
+    assert len(expected) % 4 == 0 and expected[1600:1604] == dictionary[100:104]
+    values = np.frombuffer(expected, dtype=np.int32)
+    segment = HostSegment(abi.ENC_LZ4, abi.TYPE_INT, len(values), 4, None)
+    segment.lz4 = ([block], len(expected), len(expected), dictionary)
+    dev = DeviceColumn(HostColumn([segment], abi.TYPE_INT))
+    got = np.zeros(len(values), dtype=np.int32)
+    abi.check(lib.hy_column_read_chunk(dev.handle, 0, got.ctypes.data, None))
+    assert got.tobytes() == expected
+    dev.close()
+    corrupt = HostSegment(abi.ENC_LZ4, abi.TYPE_INT, len(values), 4, None)
+    corrupt.lz4 = ([block[:-7]], len(expected), len(expected), dictionary)
+    with pytest.raises(abi.HyriseAmdError):
+        DeviceColumn(HostColumn([corrupt], abi.TYPE_INT))
+
+
 def test_run_length_segments(device):
     """RunLengthSegment<T> columns (expanded once by the residency cache) behave like the ValueSegments they decode to:
     scans, a join and an aggregate over long runs with NULL runs."""
