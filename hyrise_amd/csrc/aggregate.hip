@@ -3215,8 +3215,37 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
   for (const hy_column*& column : plain_groupby) HY_TRY(plain_column(column, &column));
   std::vector<hy_aggregate_spec> plain_aggregates(aggregates, aggregates + n_aggregates);
   for (hy_aggregate_spec& spec : plain_aggregates) HY_TRY(plain_column(spec.column, &spec.column));
-  return run_with_result_memory(result, n_aggregates, [&](hy_aggregate_result* out) {
-    return run_aggregate(plain_groupby.data(), n_groupby, plain_aggregates.data(), n_aggregates, out);
+  return run_with_result_memory(result, n_aggregates, [&](hy_aggregate_result* out) -> hy_status {
+    // More aggregates than one pass has accumulators for (eight; STDDEV_SAMP takes two) run in several passes over the same GROUP BY
+    // columns: the groups and their order -- first occurrence, or key order -- do not depend on the aggregates, so pass k just fills its
+    // own result columns (aggregate_hash.cpp:1016-1176 has one context per aggregate as well).  Each pass takes what fits.
+    auto accumulators_of = [&](const hy_aggregate_spec& spec) -> uint32_t {
+      return spec.function == HY_AGG_STDDEV_SAMP ? 2u : spec.function == HY_AGG_COUNT_DISTINCT ? 0u : 1u;
+    };
+    uint32_t needed = 0;
+    for (uint32_t g = 0; g < n_aggregates; ++g) needed += accumulators_of(plain_aggregates[g]);
+    if (needed <= MAX_AGGREGATES && n_aggregates <= MAX_AGGREGATES) return run_aggregate(plain_groupby.data(), n_groupby, plain_aggregates.data(), n_aggregates, out);
+    uint32_t n_groups = 0;
+    std::vector<hy_row_id> first_pass_rows;
+    for (uint32_t begin = 0; begin < n_aggregates;) {
+      uint32_t end = begin, taken = 0;
+      while (end < n_aggregates && end - begin < MAX_AGGREGATES && taken + accumulators_of(plain_aggregates[end]) <= MAX_AGGREGATES) taken += accumulators_of(plain_aggregates[end++]);
+      hy_aggregate_result pass = *out;
+      pass.columns = out->columns + begin;
+      std::vector<hy_row_id> rows;
+      if (begin != 0) {   // (later passes: their representative rows only confirm that the groups came in the same order)
+        rows.resize(out->group_capacity ? out->group_capacity : 1);
+        pass.group_row_ids = out->group_row_ids ? rows.data() : nullptr;
+      }
+      const hy_status status = run_aggregate(plain_groupby.data(), n_groupby, plain_aggregates.data() + begin, end - begin, &pass);
+      out->n_groups = pass.n_groups;
+      if (status != HY_OK) return status;
+      if (begin == 0) n_groups = pass.n_groups;
+      else if (pass.n_groups != n_groups || (out->group_row_ids && n_groups && std::memcmp(rows.data(), out->group_row_ids, sizeof(hy_row_id) * n_groups) != 0))
+        return fail(HY_ERR_DEVICE, "hy_aggregate_hash: two passes over the same GROUP BY columns disagree about the groups");
+      begin = end;
+    }
+    return HY_OK;
   });
 }
 

@@ -194,6 +194,23 @@ def aggregate_path():
     return lib.hy_debug_aggregate_path()
 
 
+def test_more_aggregates_than_one_pass_has_accumulators(device):
+    """Eight device accumulators per pass (STDDEV_SAMP takes two): a plan with more -- AggregateHash takes any number,
+    aggregate_hash.cpp:1016-1176 -- runs in several passes over the same GROUP BY columns; the groups, their order and every column equal the
+    oracle's.  Few groups (LDS tables) and many (the partitioned path), with NULLs."""
+    rng = np.random.default_rng(12)
+    n = 150_000
+    for distinct in (7, 20_000):
+        keys = build_column(rng.integers(0, distinct, n).astype(np.int32), rng.random(n) < 0.01, 65535, abi.ENC_DICTIONARY)
+        a = build_column(rng.integers(-1000, 1000, n).astype(np.int32), rng.random(n) < 0.05, 65535, abi.ENC_UNENCODED)
+        b = build_column(rng.random(n).astype(np.float64) * 100, None, 65535, abi.ENC_UNENCODED)
+        c = build_column(rng.integers(0, 50, n).astype(np.int64), None, 65535, abi.ENC_DICTIONARY)
+        aggregates = [(abi.AGG_SUM, a), (abi.AGG_AVG, a), (abi.AGG_MIN, a), (abi.AGG_MAX, a), (abi.AGG_COUNT, a), (abi.AGG_STDDEV_SAMP, a), (abi.AGG_SUM, b), (abi.AGG_MIN, b), (abi.AGG_MAX, b),
+                      (abi.AGG_STDDEV_SAMP, b), (abi.AGG_SUM, c), (abi.AGG_AVG, c), (abi.AGG_MAX, c), (abi.AGG_COUNT_DISTINCT, c), (abi.AGG_COUNT, None), (abi.AGG_ANY, a), (abi.AGG_MIN, c)]
+        got = run_both([keys], aggregates, f"{len(aggregates)} aggregates, {distinct} distinct keys")
+        assert distinct * 0.99 < got.n_groups <= distinct + 1   # (run_both compared the groups themselves with the oracle's)
+
+
 @pytest.fixture
 def forced_partitions(options):
     """HY_OPT_AGG_PARTITION_BITS: every aggregate of the test runs the partitioned path (partition -> LDS tables -> one merge)."""
