@@ -1052,7 +1052,7 @@ struct PartitionArgs {
   uint32_t* offsets;        // [partitions][n_parts]: counts, then (after the scan) first output position
   uint64_t* records;        // [total_rows][record_words]: row | present << 32, tuple[words], contribution of every aggregate with a column
   uint64_t total_rows;
-  uint32_t reserved2;
+  uint32_t narrow;          // 1: NARROW records (below)
   uint32_t record_words;    // even: records are written and read as 16-byte pairs
   uint32_t carried;         // aggregates with a column (the first `carried` of AggArgs.aggregates): their contributions travel in the record
 };
@@ -1060,9 +1060,20 @@ struct PartitionArgs {
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 constexpr uint32_t MAX_RECORD_PAIRS = (2 + MAX_GROUPBY + 1 + MAX_AGGREGATES) / 2;   // head + tuple + contributions, rounded up to 16 bytes
 
+// NARROW records: every GROUP BY column and every carried aggregate input is a 4-byte type (int32 / float32 -- order keys, part keys, dates,
+// prices): the record is 32-bit words -- row | present + NULL mask << 16 | the keys' values | the inputs' values -- padded to 16 bytes.  One int32
+// key and one float input: 16 bytes a row instead of 32; the two kernels that write and read the records move half the bytes.
+constexpr uint32_t MAX_NARROW_QUADS = (2 + MAX_GROUPBY + MAX_AGGREGATES + 3) / 4;
+__device__ __forceinline__ uint32_t narrow_word(uint64_t bits, bool is_float) {   // the decoded word of a 4-byte column (aggregate_contribution)
+  return is_float ? __float_as_uint(static_cast<float>(__longlong_as_double(static_cast<long long>(bits)))) : static_cast<uint32_t>(bits);
+}
+__device__ __forceinline__ uint64_t widen_word(uint32_t word, bool is_float) {
+  return is_float ? static_cast<uint64_t>(__double_as_longlong(static_cast<double>(__uint_as_float(word)))) : static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(word)));
+}
+
 // WORDS = GROUP BY columns + 1 (the tuple's words): the record layout is static per instantiation, so a record is built in
 // registers and leaves as 16-byte stores (8-byte stores retire at half the rate).
-template <bool SCATTER, int WORDS>
+template <bool SCATTER, int WORDS, bool NARROW>
 __global__ __launch_bounds__(256) void partition_rows(AggArgs a, PartitionArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* s_cell = reinterpret_cast<uint32_t*>(smem);   // count (SCATTER: next output position) of every partition
@@ -1139,9 +1150,30 @@ __global__ __launch_bounds__(256) void partition_rows(AggArgs a, PartitionArgs p
           nulls |= null_rows;
 #pragma unroll
           for (int i = 0; i < R; ++i) {
-            contribution[g][i] = contribution_from(c, bits[i]);
+            contribution[g][i] = NARROW ? static_cast<uint64_t>(narrow_word(bits[i], c.is_float)) : contribution_from(c, bits[i]);
             if (!((nulls >> i) & 1)) present[i] |= 1u << g;
           }
+        }
+        if (NARROW) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            if (!((valid >> i) & 1)) continue;
+            uint32_t record[4 * MAX_NARROW_QUADS];
+#pragma unroll
+            for (uint32_t k = 0; k < 4 * MAX_NARROW_QUADS; ++k) record[k] = 0;
+            record[0] = static_cast<uint32_t>(chunk_base + row[i]);
+            record[1] = present[i] | static_cast<uint32_t>(tuple[i][0]) << 16;
+#pragma unroll
+            for (int w = 1; w < WORDS; ++w) record[1 + w] = narrow_word(tuple[i][w], a.groupby[w - 1].is_float);
+#pragma unroll
+            for (uint32_t g = 0; g < MAX_AGGREGATES; ++g) record[1 + WORDS + g] = static_cast<uint32_t>(contribution[g][i]);
+            u32x4* out = reinterpret_cast<u32x4*>(p.records) + size_t{position[i]} * pairs;
+#pragma unroll
+            for (uint32_t k = 0; k < MAX_NARROW_QUADS; ++k) {
+              if (k < pairs) { u32x4 v; v.x = record[4 * k]; v.y = record[4 * k + 1]; v.z = record[4 * k + 2]; v.w = record[4 * k + 3]; out[k] = v; }
+            }
+          }
+          continue;
         }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -1258,7 +1290,7 @@ __device__ __forceinline__ uint32_t lds_slot(uint32_t* s_tags, uint64_t* s_keys,
 }
 
 // LDS layout: keys[S][words] u64 | first[S] u64 | last[S] u64 | values[S][A] u64 | counts[S][A] u32 | tags[S] u32 | groups, spilled u32
-template <int WORDS>
+template <int WORDS, bool NARROW>
 __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, PartitionArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t words = WORDS;
@@ -1296,7 +1328,26 @@ __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, Partition
     const uint64_t i = base + tid;
     if (i >= end) continue;
     uint64_t record[2 * MAX_RECORD_PAIRS];
-    {
+    if (NARROW) {   // widened into the layout of the 64-bit records: head, tuple, the inputs' decoded words (contribution_from below)
+      const u32x4* in = reinterpret_cast<const u32x4*>(p.records) + i * pairs;
+      uint32_t narrow[4 * MAX_NARROW_QUADS];
+#pragma unroll
+      for (uint32_t k = 0; k < MAX_NARROW_QUADS; ++k) {
+        u32x4 v; v.x = 0; v.y = 0; v.z = 0; v.w = 0;
+        if (k < pairs) v = in[k];
+        narrow[4 * k] = v.x; narrow[4 * k + 1] = v.y; narrow[4 * k + 2] = v.z; narrow[4 * k + 3] = v.w;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 2 * MAX_RECORD_PAIRS; ++k) record[k] = 0;
+      record[0] = narrow[0] | static_cast<uint64_t>(narrow[1] & 0xFFFFu) << 32;
+      record[1] = narrow[1] >> 16;
+#pragma unroll
+      for (int w = 1; w < WORDS; ++w) record[1 + w] = widen_word(narrow[1 + w], a.groupby[w - 1].is_float);
+#pragma unroll
+      for (uint32_t g = 0; g < MAX_AGGREGATES; ++g) {
+        if (g < p.carried) record[1 + words + g] = contribution_from(a.aggregates[g], widen_word(narrow[1 + words + g], a.aggregates[g].is_float));
+      }
+    } else {
       const u64x2* in = reinterpret_cast<const u64x2*>(p.records) + i * pairs;
 #pragma unroll
       for (uint32_t k = 0; k < MAX_RECORD_PAIRS; ++k) {
@@ -2093,11 +2144,24 @@ struct StagedGroups {
   uint64_t* counts;
   uint32_t capacity;
 };
-__global__ void compact_groups(AggArgs a, uint32_t* counter, uint64_t* out_keys, uint64_t* out_first, uint64_t* out_last, uint64_t* out_values,
-                               uint64_t* out_counts, uint32_t out_capacity, StagedGroups staged) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= a.capacity || a.tags[slot] == TAG_EMPTY) return;
-  const uint32_t idx = atomicAdd(counter, 1u);
+// (One atomic on the group counter per workgroup: one per group serialises at its L2 channel -- 100 000 groups took 0.36 ms that way.)
+constexpr uint32_t COMPACT_THREADS = 1024;
+__global__ __launch_bounds__(COMPACT_THREADS) void compact_groups(AggArgs a, uint32_t* counter, uint64_t* out_keys, uint64_t* out_first, uint64_t* out_last, uint64_t* out_values,
+                                                                  uint64_t* out_counts, uint32_t out_capacity, StagedGroups staged) {
+  __shared__ uint32_t s_wave_base[COMPACT_THREADS / 64 + 1];
+  const uint32_t slot = blockIdx.x * COMPACT_THREADS + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool taken = slot < a.capacity && a.tags[slot] != TAG_EMPTY;
+  const uint64_t peers = __ballot(taken);
+  if (lane == 0) s_wave_base[wave] = static_cast<uint32_t>(__popcll(peers));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < COMPACT_THREADS / 64; ++w) { const uint32_t count = s_wave_base[w]; s_wave_base[w] = total; total += count; }
+    s_wave_base[COMPACT_THREADS / 64] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  if (!taken) return;
+  const uint32_t idx = s_wave_base[COMPACT_THREADS / 64] + s_wave_base[wave] + static_cast<uint32_t>(__popcll(peers & ((1ull << lane) - 1)));
   if (idx >= out_capacity) return;
   const uint32_t words = a.n_groupby + 1;
   const bool stage = idx < staged.capacity;
@@ -2136,6 +2200,131 @@ __global__ void gather_values(const DevSegment* segments, const hy_row_id* rows,
   const Value v = column_value(segments, rows[i].chunk_id, rows[i].chunk_offset);
   is_null[i] = v.is_null;
   bits[i] = is_float ? static_cast<uint64_t>(__double_as_longlong(v.f)) : static_cast<uint64_t>(v.i);
+}
+
+// ---- large results are finished where they are ------------------------------------------------------------------------
+// A result of 10^5 .. 10^7 groups used to come to the host as five arrays, be ordered there and be rewritten column by column: 3.5 of the
+// 5 ms of a 100 000-group aggregate over 60 M rows, 220 of the 240 ms of a 4 M-group one.  The same steps as kernels: the extent of the
+// keys (is the immediate-key shortcut taken?), one 32-bit sort key per group, the radix sort of join.hip, RowIDs and result columns written
+// in result order -- and one copy per output array.
+struct GroupExtent {
+  unsigned long long key_min, key_max;   // over the groups with a value: biased key + 1 (as run_aggregate's host loop)
+  unsigned long long row_max;            // largest first row
+};
+// (`partial`: device memory, {~0, 0, 0} and a zero counter behind it; the last workgroup publishes it into the pinned `out` -- atomics on
+//  pinned host memory cross PCIe one by one.)
+__global__ __launch_bounds__(256) void finish_extent(const uint64_t* keys, const uint64_t* first, uint32_t n_groups, uint32_t words, uint32_t int_key, GroupExtent* partial,
+                                                     GroupExtent* out) {
+  __shared__ unsigned long long s_min, s_max, s_row;
+  if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0; s_row = 0; }
+  __syncthreads();
+  unsigned long long low = ~0ull, high = 0, row = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_groups; i += gridDim.x * 256) {
+    row = first[i] > row ? first[i] : row;
+    if (int_key && !(keys[size_t{i} * words] & 1)) {
+      const unsigned long long k = static_cast<unsigned long long>(static_cast<int64_t>(keys[size_t{i} * words + 1]) - static_cast<int64_t>(INT32_MIN)) + 1;
+      low = k < low ? k : low;
+      high = k > high ? k : high;
+    }
+  }
+  for (int step = 32; step > 0; step >>= 1) {   // (64-bit LDS atomics of every lane on three words: 1.3 ms for 100 000 groups)
+    const unsigned long long other_low = __shfl_xor(low, step), other_high = __shfl_xor(high, step), other_row = __shfl_xor(row, step);
+    low = other_low < low ? other_low : low;
+    high = other_high > high ? other_high : high;
+    row = other_row > row ? other_row : row;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&s_min, low);
+    atomicMax(&s_max, high);
+    atomicMax(&s_row, row);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&partial->key_min, s_min);
+    atomicMax(&partial->key_max, s_max);
+    atomicMax(&partial->row_max, s_row);
+    __threadfence();
+    if (atomicAdd(reinterpret_cast<uint32_t*>(partial + 1), 1u) + 1 == gridDim.x) {
+      __threadfence();
+      out->key_min = __hip_atomic_load(&partial->key_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out->key_max = __hip_atomic_load(&partial->key_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out->row_max = __hip_atomic_load(&partial->row_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+    }
+  }
+}
+
+// sort key of group i: its first row, or (immediate keys) 0 for the NULL group and key - smallest key + 1 otherwise
+__global__ __launch_bounds__(256) void finish_sort_keys(const uint64_t* keys, const uint64_t* first, uint32_t n_groups, uint32_t words, uint32_t immediate, uint64_t key_min,
+                                                        uint32_t* sort_keys, uint32_t* ids) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_groups) return;
+  uint32_t key = static_cast<uint32_t>(first[i]);
+  if (immediate) {
+    const uint64_t k = static_cast<uint64_t>(static_cast<int64_t>(keys[size_t{i} * words + 1]) - static_cast<int64_t>(INT32_MIN)) + 1;
+    key = (keys[size_t{i} * words] & 1) ? 0u : static_cast<uint32_t>(k - key_min) + 1u;
+  }
+  sort_keys[i] = key;
+  ids[i] = i;
+}
+
+// RowID of every result row's representative row (rows_of_groups: the groups' first rows, or their last ones: aggregate_hash.cpp:388-401)
+__global__ __launch_bounds__(256) void finish_row_ids(const uint32_t* order, const uint64_t* rows_of_groups, uint32_t n_groups, const uint64_t* row_base, uint32_t n_chunks,
+                                                      uint32_t uniform_size, hy_row_id* out) {
+  const uint32_t o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_groups) return;
+  const uint64_t row = rows_of_groups[order[o]];
+  uint32_t chunk;
+  if (uniform_size) {
+    chunk = static_cast<uint32_t>(row) / uniform_size;
+    if (chunk >= n_chunks) chunk = n_chunks - 1;
+  } else {
+    uint32_t low = 0, high = n_chunks;   // the last chunk whose base is <= row
+    while (high - low > 1) {
+      const uint32_t middle = (low + high) / 2;
+      if (row_base[middle] <= row) low = middle; else high = middle;
+    }
+    chunk = low;
+  }
+  out[o] = hy_row_id{chunk, static_cast<uint32_t>(row - row_base[chunk])};
+}
+
+// One result column in result order: COUNT / SUM / AVG / MIN / MAX from accumulator `primary` (the switch of run_aggregate's host loop).
+struct FinishColumn {
+  uint32_t function, out_type, is_float, primary;
+};
+__global__ __launch_bounds__(256) void finish_column(const uint32_t* order, const uint64_t* values, const uint64_t* counts, uint32_t n_groups, uint32_t n_device, FinishColumn c,
+                                                     void* out_values, uint8_t* out_null) {
+  const uint32_t o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_groups) return;
+  const size_t at = size_t{order[o]} * n_device + c.primary;
+  const uint64_t bits = values[at], count = counts[at];
+  bool is_null = count == 0;
+  int64_t vi = 0;
+  double vf = 0.0;
+  switch (c.function) {
+    case HY_AGG_COUNT: vi = static_cast<int64_t>(count); is_null = false; break;
+    case HY_AGG_SUM:
+      if (c.is_float) vf = __longlong_as_double(static_cast<long long>(bits)); else vi = static_cast<int64_t>(bits);
+      break;
+    case HY_AGG_AVG:
+      if (count) vf = __longlong_as_double(static_cast<long long>(bits)) / static_cast<double>(count);   // aggregate_hash.cpp:166
+      break;
+    default:   // MIN / MAX
+      if (c.is_float) {
+        int64_t ordered = static_cast<int64_t>(bits);
+        if (ordered < 0) ordered ^= 0x7FFFFFFFFFFFFFFFll;
+        vf = __longlong_as_double(ordered);
+      } else vi = static_cast<int64_t>(bits);
+      break;
+  }
+  if (out_null) out_null[o] = is_null;
+  switch (c.out_type) {
+    case HY_TYPE_INT: static_cast<int32_t*>(out_values)[o] = is_null ? 0 : static_cast<int32_t>(vi); break;
+    case HY_TYPE_LONG: static_cast<int64_t*>(out_values)[o] = is_null ? 0 : vi; break;
+    case HY_TYPE_FLOAT: static_cast<float*>(out_values)[o] = is_null ? 0.f : static_cast<float>(vf); break;
+    default: static_cast<double*>(out_values)[o] = is_null ? 0.0 : vf; break;
+  }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -2183,39 +2372,79 @@ struct DeviceGroups {
   uint32_t n_groups = 0;
   uint64_t passed_rows = 0;   // fused_rows: rows that passed the filters
   std::vector<uint64_t> keys, first, last, values, counts;
+  // Large results whose caller finishes them on the device (finish_groups_on_device): the same five arrays stay in device memory.
+  bool keep_on_device = false;   // in: leave more than STAGED_GROUPS groups where they are
+  bool on_device = false;        // out
+  DeviceBuffer d_keys, d_first, d_last, d_values, d_counts;
+  // in: the column whose aggregate_hint remembers the path (nullptr: none) and the signature of this GROUP BY
+  const hy_column* hint_owner = nullptr;
+  uint64_t hint_signature = 0;
 };
+
+// DeviceGroups::on_device -> the host vectors (the host finish after all)
+static hy_status download_groups(DeviceGroups& groups, uint32_t words, uint32_t n_aggregates, hipStream_t stream) {
+  const uint32_t n_groups = groups.n_groups;
+  const size_t per_group = n_aggregates ? n_aggregates : 1;
+  groups.keys.resize(size_t{n_groups} * words);
+  groups.first.resize(n_groups);
+  groups.last.resize(n_groups);
+  groups.values.resize(n_groups * per_group);
+  groups.counts.resize(n_groups * per_group);
+  HY_HIP(hipMemcpyAsync(groups.keys.data(), groups.d_keys.ptr, 8 * groups.keys.size(), hipMemcpyDeviceToHost, stream));
+  HY_HIP(hipMemcpyAsync(groups.first.data(), groups.d_first.ptr, 8 * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
+  HY_HIP(hipMemcpyAsync(groups.last.data(), groups.d_last.ptr, 8 * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
+  if (n_aggregates) {
+    HY_HIP(hipMemcpyAsync(groups.values.data(), groups.d_values.ptr, 8 * groups.values.size(), hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipMemcpyAsync(groups.counts.data(), groups.d_counts.ptr, 8 * groups.counts.size(), hipMemcpyDeviceToHost, stream));
+  }
+  HY_HIP(hipStreamSynchronize(stream));
+  groups.on_device = false;
+  return HY_OK;
+}
 
 // Runs aggregate_rows + compact_groups for the columns wired into `a` (GROUP BY and device accumulators), retrying with a
 // larger global table when it overflows.
 static uint64_t* g_agg_trace = nullptr;
 static uint32_t g_agg_trace_slices = 0;
 
-template <bool SCATTER, int WORDS>
+template <bool SCATTER, int WORDS, bool NARROW>
 static void launch_partition_rows_as(uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
   static OncePerDevice lds_raised;   // 2^14 partitions: 64 KiB of counters, the most a workgroup gets without asking
   uint64_t device_bit = 0;
   if (lds_raised.pending(&device_bit)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_rows<SCATTER, WORDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_rows<SCATTER, WORDS, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     lds_raised.done(device_bit);
   }
-  hipLaunchKernelGGL((partition_rows<SCATTER, WORDS>), dim3(grid), dim3(256), lds, stream, a, pa);
+  hipLaunchKernelGGL((partition_rows<SCATTER, WORDS, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa);
 }
-template <bool SCATTER>
+template <bool SCATTER, bool NARROW>
 static void launch_partition_rows_of(uint32_t words, uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
   switch (words) {
-    case 1: launch_partition_rows_as<SCATTER, 1>(grid, lds, stream, a, pa); break;
-    case 2: launch_partition_rows_as<SCATTER, 2>(grid, lds, stream, a, pa); break;
-    case 3: launch_partition_rows_as<SCATTER, 3>(grid, lds, stream, a, pa); break;
-    case 4: launch_partition_rows_as<SCATTER, 4>(grid, lds, stream, a, pa); break;
-    default: launch_partition_rows_as<SCATTER, 5>(grid, lds, stream, a, pa); break;
+    case 1: launch_partition_rows_as<SCATTER, 1, NARROW>(grid, lds, stream, a, pa); break;
+    case 2: launch_partition_rows_as<SCATTER, 2, NARROW>(grid, lds, stream, a, pa); break;
+    case 3: launch_partition_rows_as<SCATTER, 3, NARROW>(grid, lds, stream, a, pa); break;
+    case 4: launch_partition_rows_as<SCATTER, 4, NARROW>(grid, lds, stream, a, pa); break;
+    default: launch_partition_rows_as<SCATTER, 5, NARROW>(grid, lds, stream, a, pa); break;
   }
 }
 static void launch_partition_rows(bool scatter, uint32_t words, uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
-  if (scatter) launch_partition_rows_of<true>(words, grid, lds, stream, a, pa);
-  else launch_partition_rows_of<false>(words, grid, lds, stream, a, pa);
+  if (!scatter) launch_partition_rows_of<false, false>(words, grid, lds, stream, a, pa);   // (counting does not build records)
+  else if (pa.narrow) launch_partition_rows_of<true, true>(words, grid, lds, stream, a, pa);
+  else launch_partition_rows_of<true, false>(words, grid, lds, stream, a, pa);
+}
+template <bool NARROW>
+static void launch_aggregate_partitions(uint32_t words, uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
+  switch (words) {
+    case 1: hipLaunchKernelGGL((aggregate_partitions<1, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
+    case 2: hipLaunchKernelGGL((aggregate_partitions<2, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
+    case 3: hipLaunchKernelGGL((aggregate_partitions<3, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
+    case 4: hipLaunchKernelGGL((aggregate_partitions<4, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
+    default: hipLaunchKernelGGL((aggregate_partitions<5, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
+  }
 }
 
 static uint32_t g_agg_path = 0;   // debug: 0 = aggregate_rows, otherwise the partition bits of the partitioned path (last call of this process)
+static uint32_t g_agg_finished_on_device = 0;   // debug: 1 = the last call's result was ordered and written by the finish kernels
 static uint32_t g_agg_small = 0;  // debug: 1 = the last call's groups came from aggregate_small_domain
 
 static uint32_t fused_lds_slots(uint32_t n_groupby) { return n_groupby ? FUSED_LDS_SLOTS : 8u; }
@@ -2241,6 +2470,13 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   while (first_bits < MAX_PARTITION_BITS && (shape->rows >> first_bits) > 65536) ++first_bits;
   uint32_t partition_bits = 0;   // 0: aggregate_rows
   if (can_partition && option(HY_OPT_AGG_PARTITION_BITS) > 0) partition_bits = std::min<uint32_t>(MAX_PARTITION_BITS, static_cast<uint32_t>(option(HY_OPT_AGG_PARTITION_BITS)));   // (tests: force the path)
+  // A GROUP BY over the same columns ended on the partitioned path before: start there (the attempt aggregate_rows abandons at one row in
+  // eight outside its tables costs about as much as the partitioned path itself; columns do not change, neither does the outcome).
+  const bool hinted = can_partition && partition_bits == 0 && out.hint_owner && !small;
+  if (hinted) {
+    const uint64_t hint = out.hint_owner->aggregate_hint.load(std::memory_order_relaxed);
+    if (hint >> 8 == out.hint_signature >> 8 && (hint & 0xFF) > 1) partition_bits = std::min<uint32_t>(MAX_PARTITION_BITS, static_cast<uint32_t>(hint & 0xFF) - 1);
+  }
   bool unlimited = false, partitions_ready = false;
   DeviceBuffer part_offsets, part_rows, part_sums;
   PartitionArgs pa;
@@ -2342,6 +2578,10 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
         for (uint32_t g = carried; g < n_aggregates; ++g) if (a.aggregates[g].segments) return fail(HY_ERR_DEVICE, "aggregates with a column must come first (internal error)");
         pa.carried = carried;
         pa.record_words = (1 + words + carried + 1) / 2 * 2;
+        pa.narrow = 1;   // every key and every carried input a 4-byte type: 32-bit words (partition_rows)
+        for (uint32_t g = 0; g + 1 < words; ++g) if (a.groupby[g].data_type != HY_TYPE_INT && a.groupby[g].data_type != HY_TYPE_FLOAT) pa.narrow = 0;
+        for (uint32_t g = 0; g < carried; ++g) if (a.aggregates[g].data_type != HY_TYPE_INT && a.aggregates[g].data_type != HY_TYPE_FLOAT) pa.narrow = 0;
+        if (pa.narrow) pa.record_words = (2 + (words - 1) + carried + 3) / 4 * 2;   // (16-byte units either way)
         HY_TRY(part_rows.alloc(8 * size_t{pa.record_words} * shape->rows));
         pa.bits = partition_bits;
         pa.offsets = part_offsets.as<uint32_t>();
@@ -2363,13 +2603,8 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       pa.split = 1;
       while (pa.split < 64 && (shape->rows >> partition_bits) / pa.split > 16384) pa.split <<= 1;
       if (option(HY_OPT_AGG_SPLIT) > 0) pa.split = static_cast<uint32_t>(option(HY_OPT_AGG_SPLIT));
-      switch (words) {
-        case 1: hipLaunchKernelGGL(aggregate_partitions<1>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
-        case 2: hipLaunchKernelGGL(aggregate_partitions<2>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
-        case 3: hipLaunchKernelGGL(aggregate_partitions<3>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
-        case 4: hipLaunchKernelGGL(aggregate_partitions<4>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
-        default: hipLaunchKernelGGL(aggregate_partitions<5>, dim3(partitions * pa.split), dim3(256), pa.lds_slots * per_slot + 64, stream, a, pa); break;
-      }
+      if (pa.narrow) launch_aggregate_partitions<true>(words, partitions * pa.split, pa.lds_slots * per_slot + 64, stream, a, pa);
+      else launch_aggregate_partitions<false>(words, partitions * pa.split, pa.lds_slots * per_slot + 64, stream, a, pa);
       profile_end(stream);
     }
     lap("kernels launched", round);
@@ -2399,7 +2634,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       g.capacity = STAGED_GROUPS;
       return g;
     };
-    hipLaunchKernelGGL(compact_groups, dim3(static_cast<uint32_t>((capacity + 255) / 256)), dim3(256), 0, stream, a, flags.as<uint32_t>() + FLAG_GROUPS, c_keys.as<uint64_t>(),
+    hipLaunchKernelGGL(compact_groups, dim3(static_cast<uint32_t>((capacity + COMPACT_THREADS - 1) / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, stream, a, flags.as<uint32_t>() + FLAG_GROUPS, c_keys.as<uint64_t>(),
                        c_first.as<uint64_t>(), c_last.as<uint64_t>(), c_values.as<uint64_t>(), c_counts.as<uint64_t>(), out_capacity, staged_arrays(pinned_dev));
     hipLaunchKernelGGL(publish_group_flags, dim3(1), dim3(1), 0, stream, flags.as<uint32_t>(), static_cast<uint32_t*>(pinned_dev));
     lap("compact launched", round);
@@ -2429,6 +2664,17 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     const uint32_t n_groups = host_flags[FLAG_GROUPS];
     out.n_groups = n_groups;
     out.passed_rows = static_cast<uint64_t>(host_flags[5]) << 32 | host_flags[4];
+    if (out.hint_owner && can_partition && !small && option(HY_OPT_AGG_PARTITION_BITS) <= 0) out.hint_owner->aggregate_hint.store((out.hint_signature >> 8) << 8 | (partition_bits + 1), std::memory_order_relaxed);
+    if (out.keep_on_device && n_groups > STAGED_GROUPS) {
+      std::swap(out.d_keys.ptr, c_keys.ptr);     std::swap(out.d_keys.capacity, c_keys.capacity);
+      std::swap(out.d_first.ptr, c_first.ptr);   std::swap(out.d_first.capacity, c_first.capacity);
+      std::swap(out.d_last.ptr, c_last.ptr);     std::swap(out.d_last.capacity, c_last.capacity);
+      std::swap(out.d_values.ptr, c_values.ptr); std::swap(out.d_values.capacity, c_values.capacity);
+      std::swap(out.d_counts.ptr, c_counts.ptr); std::swap(out.d_counts.capacity, c_counts.capacity);
+      out.on_device = true;
+      lap("groups stay", round);
+      return HY_OK;
+    }
     out.keys.resize(size_t{n_groups} * words);
     out.first.resize(n_groups);
     out.last.resize(n_groups);
@@ -2672,6 +2918,20 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     return true;
   };
   DeviceGroups main_groups;
+  {   // a large result of plain aggregates is finished on the device (finish kernels above); everything else comes to the host
+    bool plain_functions = n_groupby > 0 && result->mem == HY_MEM_HOST && shape->rows < (1ull << 32);
+    for (uint32_t g = 0; g < n_aggregates && plain_functions; ++g) {
+      const uint32_t f = specs[g].function;
+      plain_functions = primary[g] >= 0 && (f == HY_AGG_COUNT || f == HY_AGG_SUM || f == HY_AGG_AVG || f == HY_AGG_MIN || f == HY_AGG_MAX) && result->columns[g].values;
+    }
+    main_groups.keep_on_device = plain_functions;
+    if (!fused && n_groupby) {
+      uint64_t signature = 0x9E3779B97F4A7C15ull * (n_groupby + 1);
+      for (uint32_t g = 0; g < n_groupby; ++g) signature = (signature ^ reinterpret_cast<uintptr_t>(groupby[g])) * 0xD6E8FEB86659FD93ull;
+      main_groups.hint_owner = groupby[0];
+      main_groups.hint_signature = signature | 0x100;   // (never zero above the path byte)
+    }
+  }
   if (fused) {
     // the plan in device memory: per filter the chunk jobs (prepare_jobs, like hy_table_scan), per accumulator its input expression
     const uint32_t n_chunks = shape->n_chunks;
@@ -2807,6 +3067,93 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     HY_TRY(device_groups(a, shape, main_groups, nullptr, lean ? &small : nullptr));
   }
   lap("device groups on host");
+  if (main_groups.on_device) {
+    const uint32_t n_groups = main_groups.n_groups;
+    result->n_groups = n_groups;
+    if (n_groups > result->group_capacity) return fail(HY_ERR_CAPACITY, "aggregate produces %u groups, capacity is %u", n_groups, result->group_capacity);
+    const bool int_key = n_groupby == 1 && groupby[0]->data_type == HY_TYPE_INT;
+    GroupExtent* extent_host = nullptr;
+    GroupExtent* extent_dev = nullptr;
+    HY_TRY(pinned_staging(sizeof(GroupExtent), reinterpret_cast<void**>(&extent_host), reinterpret_cast<void**>(&extent_dev)));
+    const uint32_t blocks = (n_groups + 255) / 256;
+    DeviceBuffer extent_partial;
+    HY_TRY(extent_partial.alloc(sizeof(GroupExtent) + 8));
+    HY_HIP(hipMemsetAsync(extent_partial.ptr, 0, sizeof(GroupExtent) + 8, stream));
+    HY_HIP(hipMemsetAsync(extent_partial.ptr, 0xFF, 8, stream));   // key_min
+    hipLaunchKernelGGL(finish_extent, dim3(std::min(blocks, 1024u)), dim3(256), 0, stream, main_groups.d_keys.as<uint64_t>(), main_groups.d_first.as<uint64_t>(), n_groups, words, int_key ? 1u : 0u,
+                       extent_partial.as<GroupExtent>(), extent_dev);
+    HY_HIP(hipStreamSynchronize(stream));
+    const uint64_t min_key = extent_host->key_min, max_key = extent_host->key_max;
+    // the immediate-key shortcut, as below (aggregate_hash.cpp:388-401)
+    const bool immediate = int_key && max_key > 0 && static_cast<double>(max_key - min_key) < static_cast<double>(fused ? main_groups.passed_rows : shape->rows) * 1.2;
+    const uint64_t largest_sort_key = immediate ? max_key - min_key + 1 : extent_host->row_max;
+    if (largest_sort_key >= (1ull << 32)) HY_TRY(download_groups(main_groups, words, n_device, stream));   // (keys spread over more than 2^32 values with more rows than that to justify it: never)
+    else {
+      uint32_t key_bits = 1;
+      while (key_bits < 32 && (largest_sort_key >> key_bits) != 0) ++key_bits;
+      DeviceBuffer sort_keys, sort_ids, sort_keys_tmp, sort_ids_tmp;
+      HY_TRY(sort_keys.alloc(4 * size_t{n_groups}));
+      HY_TRY(sort_ids.alloc(4 * size_t{n_groups}));
+      HY_TRY(sort_keys_tmp.alloc(4 * size_t{n_groups}));
+      HY_TRY(sort_ids_tmp.alloc(4 * size_t{n_groups}));
+      hipLaunchKernelGGL(finish_sort_keys, dim3(blocks), dim3(256), 0, stream, main_groups.d_keys.as<uint64_t>(), main_groups.d_first.as<uint64_t>(), n_groups, words, immediate ? 1u : 0u, min_key,
+                         sort_keys.as<uint32_t>(), sort_ids.as<uint32_t>());
+      uint32_t* sorted_keys = sort_keys.as<uint32_t>();
+      uint32_t* order = sort_ids.as<uint32_t>();
+      HY_TRY(sort_pairs_u32(&sorted_keys, &order, sort_keys_tmp.as<uint32_t>(), sort_ids_tmp.as<uint32_t>(), n_groups, key_bits, stream));
+      // Results up to 16 MiB are written straight into pinned host memory by the kernels and copied out by the host (every hipMemcpyAsync
+      // into pageable memory is a staged copy with ~0.2 ms of host work around it: five of them cost more than the kernels); larger ones
+      // go through device arrays and one copy each.
+      const RowIdOf row_id_of(shape);
+      size_t value_bytes[MAX_AGGREGATES], values_at[MAX_AGGREGATES], nulls_at[MAX_AGGREGATES];
+      size_t staged_bytes = result->group_row_ids ? align_up(sizeof(hy_row_id) * size_t{n_groups}, 256) : 0;
+      for (uint32_t g = 0; g < n_aggregates; ++g) {
+        hy_aggregate_column& col = result->columns[g];
+        col.data_type = result_type(specs[g].function, input_type(g));
+        value_bytes[g] = (col.data_type == HY_TYPE_INT || col.data_type == HY_TYPE_FLOAT) ? 4 : 8;
+        values_at[g] = staged_bytes;
+        staged_bytes += align_up(value_bytes[g] * n_groups, 256);
+        nulls_at[g] = staged_bytes;
+        if (col.is_null) staged_bytes += align_up(size_t{n_groups}, 256);
+      }
+      const bool through_pinned = staged_bytes <= (size_t{16} << 20);
+      unsigned char* staged_host = nullptr;
+      unsigned char* staged_dev = nullptr;
+      DeviceBuffer staged_device_memory;
+      if (through_pinned) HY_TRY(pinned_staging(staged_bytes, reinterpret_cast<void**>(&staged_host), reinterpret_cast<void**>(&staged_dev)));
+      else {
+        HY_TRY(staged_device_memory.alloc(staged_bytes));
+        staged_dev = staged_device_memory.as<unsigned char>();
+      }
+      if (result->group_row_ids) {
+        hipLaunchKernelGGL(finish_row_ids, dim3(blocks), dim3(256), 0, stream, order, immediate ? main_groups.d_last.as<uint64_t>() : main_groups.d_first.as<uint64_t>(), n_groups, shape->d_row_base,
+                           shape->n_chunks, static_cast<uint32_t>(row_id_of.size), reinterpret_cast<hy_row_id*>(staged_dev));
+        if (!through_pinned) HY_HIP(hipMemcpyAsync(result->group_row_ids, staged_dev, sizeof(hy_row_id) * size_t{n_groups}, hipMemcpyDeviceToHost, stream));
+      }
+      for (uint32_t g = 0; g < n_aggregates; ++g) {
+        hy_aggregate_column& col = result->columns[g];
+        const uint32_t in_type = input_type(g);
+        const FinishColumn c{specs[g].function, col.data_type, (in_type == HY_TYPE_FLOAT || in_type == HY_TYPE_DOUBLE) ? 1u : 0u, static_cast<uint32_t>(primary[g])};
+        hipLaunchKernelGGL(finish_column, dim3(blocks), dim3(256), 0, stream, order, main_groups.d_values.as<uint64_t>(), main_groups.d_counts.as<uint64_t>(), n_groups, n_device, c, staged_dev + values_at[g],
+                           col.is_null ? staged_dev + nulls_at[g] : nullptr);
+        if (through_pinned) continue;
+        HY_HIP(hipMemcpyAsync(col.values, staged_dev + values_at[g], value_bytes[g] * n_groups, hipMemcpyDeviceToHost, stream));
+        if (col.is_null) HY_HIP(hipMemcpyAsync(col.is_null, staged_dev + nulls_at[g], n_groups, hipMemcpyDeviceToHost, stream));
+      }
+      HY_HIP(hipStreamSynchronize(stream));
+      if (through_pinned) {
+        if (result->group_row_ids) std::memcpy(result->group_row_ids, staged_host, sizeof(hy_row_id) * size_t{n_groups});
+        for (uint32_t g = 0; g < n_aggregates; ++g) {
+          std::memcpy(result->columns[g].values, staged_host + values_at[g], value_bytes[g] * n_groups);
+          if (result->columns[g].is_null) std::memcpy(result->columns[g].is_null, staged_host + nulls_at[g], n_groups);
+        }
+      }
+      g_agg_finished_on_device = 1;
+      lap("finished on the device");
+      return HY_OK;
+    }
+  }
+  g_agg_finished_on_device = 0;
   const uint32_t n_groups = main_groups.n_groups;
   const std::vector<uint64_t>&h_keys = main_groups.keys, &h_first = main_groups.first, &h_last = main_groups.last, &h_values = main_groups.values,
                              &h_counts = main_groups.counts;
@@ -3251,6 +3598,9 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
 
 // debug only: which path the last hy_aggregate_hash of this process took -- 0 aggregate_rows, else the partition bits; not part of the public header
 int hy_debug_aggregate_path(void) { return static_cast<int>(g_agg_path); }
+
+// debug / tests only: 1 = the last aggregate of this process was ordered and written by the finish kernels (large results of plain functions)
+int hy_debug_aggregate_finished_on_device(void) { return static_cast<int>(g_agg_finished_on_device); }
 
 // debug / tests only: 1 = the last hy_aggregate_hash of this process ran aggregate_small_domain (aggregate_small.hpp)
 int hy_debug_aggregate_small_domain(void) { return static_cast<int>(g_agg_small); }

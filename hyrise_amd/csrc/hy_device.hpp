@@ -136,6 +136,7 @@ struct hy_column {
   std::vector<void*> owned;                 // device allocations freed with the column
   std::vector<std::pair<size_t, void*>> pooled;   // ... or handed back to the buffer pool (operator results)
   mutable hy_join_key_hint join_hint;
+  mutable std::atomic<uint64_t> aggregate_hint{0};   // aggregate.hip: which path the last GROUP BY led by this column ended on (signature of the column set << 8 | partition bits + 1)
   // RunLength segments and bit-packed vectors stay compressed in device memory; TableScan reads them in place.  The operators that
   // gather rows (joins, aggregates, projections, exchanges, reference columns) read `plain`: the same column as Value / FixedWidthInteger
   // segments, decoded ON THE DEVICE from the resident compressed buffers the first time one of them asks (plain_column, runtime.hip).
@@ -169,6 +170,9 @@ void bind_thread_device();   // hipSetDevice(the device hy_init chose) once per 
 // Pinned, device-mapped host memory of this thread (grow-only): small results that kernels store straight into host
 // memory, read by the host after a stream synchronise -- instead of one blit kernel and host round trip per hipMemcpyAsync.
 hy_status pinned_staging(size_t bytes, void** host, void** device);
+
+// join.hip: stable LSD radix sort of (key, id) pairs by key (see there)
+hy_status sort_pairs_u32(uint32_t** keys, uint32_t** ids, uint32_t* keys_tmp, uint32_t* ids_tmp, uint64_t n, uint32_t key_bits, hipStream_t stream);
 
 // Optional HIP-event bracket around the dominant kernel of an operator call (hy_set_profiling / hy_last_kernel_ms).
 void release_thread_join_state();   // join.hip: frees the calling thread's pinned mailbox (hy_shutdown)

@@ -3711,6 +3711,39 @@ static bool lds_atomics_are_lane_ordered(hipStream_t stream) {
 }
 
 
+// The LSD radix sort above for other operators (aggregate.hip orders the groups of a large result by it): (key, id) pairs of 32 bits each,
+// ascending by key, stable; only the bytes below `key_bits` move anything.  *keys / *ids point at the sorted arrays on return (the inputs
+// or the temporaries).
+hy_status sort_pairs_u32(uint32_t** keys, uint32_t** ids, uint32_t* keys_tmp, uint32_t* ids_tmp, uint64_t n, uint32_t key_bits, hipStream_t stream) {
+  if (n < 2) return HY_OK;
+  const bool staged = lds_atomics_are_lane_ordered(stream);
+  const uint32_t n_tiles = static_cast<uint32_t>(staged ? (n + SORT_BIG_TILE - 1) / SORT_BIG_TILE : (n + SORT_TILE - 1) / SORT_TILE);
+  if (staged) {
+    static OncePerDevice lds_raised;
+    uint64_t device_bit = 0;
+    if (lds_raised.pending(&device_bit)) {
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_scatter_staged), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sort_staged_lds_bytes())));
+      lds_raised.done(device_bit);
+    }
+  }
+  DeviceBuffer hist, bases;
+  HY_TRY(hist.alloc(4 * size_t{256} * n_tiles));
+  HY_TRY(bases.alloc(8 * (size_t{256} * n_tiles + 1)));
+  uint32_t *src_keys = *keys, *src_ids = *ids, *dst_keys = keys_tmp, *dst_ids = ids_tmp;
+  for (uint32_t shift = 0; shift < 32 && shift < key_bits; shift += 8) {
+    if (staged) hipLaunchKernelGGL(sort_histogram_big, dim3(n_tiles), dim3(SORT_BIG_THREADS), 0, stream, src_keys, n, shift, hist.as<uint32_t>(), n_tiles);
+    else hipLaunchKernelGGL(sort_histogram<uint32_t>, dim3(n_tiles), dim3(256), 0, stream, src_keys, n, shift, hist.as<uint32_t>(), n_tiles);
+    HY_TRY(exclusive_scan(hist.as<uint32_t>(), bases.as<uint64_t>(), uint64_t{256} * n_tiles, stream));
+    if (staged) hipLaunchKernelGGL(sort_scatter_staged, dim3(n_tiles), dim3(SORT_BIG_THREADS), sort_staged_lds_bytes(), stream, src_keys, src_ids, dst_keys, dst_ids, n, shift, bases.as<uint64_t>(), n_tiles);
+    else hipLaunchKernelGGL((sort_scatter<uint32_t, uint32_t>), dim3(n_tiles), dim3(256), 0, stream, src_keys, src_ids, dst_keys, dst_ids, n, shift, bases.as<uint64_t>(), n_tiles);
+    std::swap(src_keys, dst_keys);
+    std::swap(src_ids, dst_ids);
+  }
+  *keys = src_keys;
+  *ids = src_ids;
+  return HY_OK;
+}
+
 // Can the radix-partitioned path (join_hp.hpp) read this column?  int32 values / FrameOfReference segments without NULLs (what a SliceView
 // describes), RowIDs that pack into 32 bits.
 static bool hp_reads(const hy_column* column) {

@@ -248,6 +248,81 @@ def test_many_groups_take_the_partitioned_path(device, n_groups, expected_path):
     got = run_both(groupby, aggregates, f"{n_groups} groups")
     assert got.n_groups > n_groups * 0.9
     assert aggregate_path() == expected_path
+    assert finished_on_device() == (1 if got.n_groups > 4096 else 0)
+
+
+def finished_on_device():
+    lib = abi.load_library()
+    lib.hy_debug_aggregate_finished_on_device.restype = int
+    return lib.hy_debug_aggregate_finished_on_device()
+
+
+def ragged_column(values, nulls, sizes, encoding):
+    """Chunks of the given sizes (a table behind deletes / a partial last chunk in the middle after a merge): RowIDs by search."""
+    segments, begin = [], 0
+    for size in sizes:
+        segments.append(storage.encode_segment(values[begin:begin + size], None if nulls is None else nulls[begin:begin + size], encoding))
+        begin += size
+    assert begin == len(values)
+    return storage.HostColumn(segments, storage.TYPE_OF_NP[values.dtype])
+
+
+@pytest.mark.parametrize("order", ["first_row", "immediate_key"])
+@pytest.mark.parametrize("chunks", ["uniform", "ragged"])
+def test_large_results_are_finished_on_the_device(device, order, chunks):
+    """More than 4096 groups of COUNT / SUM / AVG / MIN / MAX: ordered (by first row, or by key with the NULL group first:
+    aggregate_hash.cpp:388-401, 770-804), turned into RowIDs and typed columns by kernels -- byte for byte the oracle's result; the second
+    call over the same columns starts on the path the first one ended on and returns the same."""
+    rng = np.random.default_rng(77)
+    n, distinct = 400_000, 30_000
+    sizes = [65535] * (n // 65535) + [n % 65535] if chunks == "uniform" else [50_000, 1, 65_535, 120_000, 999, n - 50_000 - 1 - 65_535 - 120_000 - 999]
+    keys = rng.integers(0, distinct, n).astype(np.int32)
+    keys = keys - 15_000 if order == "immediate_key" else keys * 50_021 - (1 << 30)   # dense: the key is the order; sparse: the first row is
+    key_nulls = rng.random(n) < 0.002
+    ints = rng.integers(-1000, 1000, n).astype(np.int32)
+    longs = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+    floats = (rng.random(n) * 100 - 50).astype(np.float32)
+    doubles = rng.random(n) * 1e6 - 5e5
+    vnull = rng.random(n) < 0.3
+    groupby = [ragged_column(keys, key_nulls, sizes, abi.ENC_UNENCODED)]
+    aggregates = [(abi.AGG_SUM, ragged_column(ints, vnull, sizes, abi.ENC_UNENCODED)), (abi.AGG_AVG, ragged_column(ints, vnull, sizes, abi.ENC_UNENCODED)),
+                  (abi.AGG_MIN, ragged_column(ints, vnull, sizes, abi.ENC_UNENCODED)), (abi.AGG_MAX, ragged_column(floats, None, sizes, abi.ENC_DICTIONARY)),
+                  (abi.AGG_MIN, ragged_column(doubles, vnull, sizes, abi.ENC_UNENCODED)), (abi.AGG_SUM, ragged_column(longs, None, sizes, abi.ENC_UNENCODED)),
+                  (abi.AGG_COUNT, ragged_column(doubles, vnull, sizes, abi.ENC_UNENCODED)), (abi.AGG_COUNT, None)]
+    cache = {}
+
+    def dev(col):
+        return cache.setdefault(id(col), DeviceColumn(col))
+
+    want = oracle_aggregate(groupby, aggregates)
+    for attempt in range(2):
+        got = aggregate_hash([dev(c) for c in groupby], [(f, dev(c) if c is not None else None) for f, c in aggregates])
+        assert_aggregate_equal(got, want, len(aggregates), f"{order}, {chunks} chunks, call {attempt}")
+        assert finished_on_device() == 1 and aggregate_path() > 0
+    assert got.n_groups > 29_000
+
+
+def test_four_byte_columns_travel_in_narrow_records(device):
+    """Every GROUP BY column and every aggregate input an int32 / float32 column: the partitioned path's records are 32-bit words
+    (partition_rows NARROW).  Negative keys and values, -0.0 and 0.0 float keys in one group, NULL keys and inputs, every function."""
+    rng = np.random.default_rng(5)
+    n, chunk = 500_000, 65535
+    k1 = rng.integers(-20_000, 20_000, n).astype(np.int32)
+    k2 = rng.choice(np.array([-0.0, 0.0, 1.5, -2.25], dtype=np.float32), n)
+    k1_null = rng.random(n) < 0.004
+    k2_null = rng.random(n) < 0.01
+    ints = rng.integers(-(1 << 31), (1 << 31) - 1, n).astype(np.int32)
+    floats = ((rng.random(n) - 0.5) * 1e6).astype(np.float32)
+    vnull = rng.random(n) < 0.2
+    int_column = build_column(ints, vnull, chunk, abi.ENC_FRAME_OF_REFERENCE)
+    float_column = build_column(floats, vnull, chunk, abi.ENC_DICTIONARY)
+    groupby = [build_column(k1, k1_null, chunk, abi.ENC_DICTIONARY), build_column(k2, k2_null, chunk, abi.ENC_UNENCODED)]
+    aggregates = [(abi.AGG_SUM, int_column), (abi.AGG_MIN, int_column), (abi.AGG_MAX, float_column), (abi.AGG_AVG, float_column), (abi.AGG_MIN, float_column), (abi.AGG_COUNT, int_column),
+                  (abi.AGG_COUNT, None)]
+    got = run_both(groupby, aggregates, "narrow records")
+    assert got.n_groups > 100_000 and aggregate_path() > 0 and finished_on_device() == 1
+    got = run_both(groupby[:1], [(abi.AGG_STDDEV_SAMP, float_column), (abi.AGG_AVG, int_column)], "narrow records, host finish")
+    assert aggregate_path() > 0 and finished_on_device() == 0
 
 
 def test_partitions_with_more_groups_than_their_tables(device, options):
