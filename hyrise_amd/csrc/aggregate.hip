@@ -1041,6 +1041,26 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
 //                      sequentially.  (Carrying RowIDs and gathering the values again costs a 128-byte line per row and column.)
 //   aggregate_partitions  one workgroup per partition: ALL rows of a group are here, so the groups live in an LDS table for the
 //                      whole pass (LDS atomics per row) and reach the global table once, at the end.
+// The groups of the table, densely.  The first `staged_capacity` of them also go straight into pinned host memory (same
+// five arrays, `staged_capacity` rows each, behind a 64-byte header): few groups -- the usual case -- cost no copy at all.
+struct StagedGroups {
+  uint64_t* keys;
+  uint64_t* first;
+  uint64_t* last;
+  uint64_t* values;
+  uint64_t* counts;
+  uint32_t capacity;
+};
+// aggregate_partitions with one workgroup per partition owns its groups: they go from its LDS table straight into the compacted arrays (a range
+// reserved with one atomic on the group counter) -- not group by group through the global table: 4 M groups were 28 M scattered device-scope
+// atomics into a 2 GB table, 9 of the call's 14 ms on the device.  (Rows that did not fit the LDS table still meet in the global table;
+// compact_groups appends its groups behind these.)
+struct DirectGroups {
+  uint32_t enabled, out_capacity;
+  uint32_t* counter;
+  uint64_t *keys, *first, *last, *values, *counts;
+  StagedGroups staged;
+};
 struct PartitionArgs {
   uint32_t tile_slices;     // a tile of the partitioning kernels: this many consecutive slices (one workgroup)
   uint32_t n_slices;
@@ -1291,7 +1311,7 @@ __device__ __forceinline__ uint32_t lds_slot(uint32_t* s_tags, uint64_t* s_keys,
 
 // LDS layout: keys[S][words] u64 | first[S] u64 | last[S] u64 | values[S][A] u64 | counts[S][A] u32 | tags[S] u32 | groups, spilled u32
 template <int WORDS, bool NARROW>
-__global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, PartitionArgs p) {
+__global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, PartitionArgs p, DirectGroups direct) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t words = WORDS;
   const uint32_t slots = p.lds_slots, tid = threadIdx.x;
@@ -1396,6 +1416,50 @@ __global__ __launch_bounds__(256) void aggregate_partitions(AggArgs a, Partition
   if (tid == 0 && s_n_groups[1]) {
     const uint32_t before = atomicAdd(&a.overflow[FLAG_SPILLED], s_n_groups[1]);
     if (before + s_n_groups[1] > a.spill_limit) __hip_atomic_store(&a.overflow[FLAG_GIVE_UP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (direct.enabled) {
+    __shared__ uint32_t s_direct[8];   // [0] first index of this workgroup's groups, [1] groups written so far, [2] refused, [4..7] per wave
+    if (tid == 0) {
+      const uint32_t n = s_n_groups[0];
+      const uint32_t base = n ? atomicAdd(direct.counter, n) : 0u;
+      s_direct[0] = base;
+      s_direct[1] = 0;
+      s_direct[2] = uint64_t{base} + n > direct.out_capacity;
+      if (s_direct[2]) a.overflow[FLAG_OVERFLOW] = 1;
+    }
+    __syncthreads();
+    if (s_direct[2]) return;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    for (uint32_t begin = 0; begin < slots; begin += 256) {
+      const uint32_t s = begin + tid;
+      const bool taken = s < slots && s_tags[s] != TAG_EMPTY;
+      const uint64_t peers = __ballot(taken);
+      if (lane == 0) s_direct[4 + wave] = static_cast<uint32_t>(__popcll(peers));
+      __syncthreads();
+      uint32_t before = s_direct[1];
+      for (uint32_t w = 0; w < wave; ++w) before += s_direct[4 + w];
+      const uint32_t step_total = s_direct[4] + s_direct[5] + s_direct[6] + s_direct[7];
+      __syncthreads();
+      if (tid == 0) s_direct[1] += step_total;
+      if (!taken) continue;
+      const size_t idx = size_t{s_direct[0]} + before + static_cast<uint32_t>(__popcll(peers & ((1ull << lane) - 1)));
+      const bool stage = idx < direct.staged.capacity;
+      for (uint32_t w = 0; w < words; ++w) {
+        const uint64_t v = s_keys[s * words + w];
+        direct.keys[idx * words + w] = v;
+        if (stage) direct.staged.keys[idx * words + w] = v;
+      }
+      direct.first[idx] = s_first[s];
+      direct.last[idx] = s_last[s];
+      if (stage) { direct.staged.first[idx] = s_first[s]; direct.staged.last[idx] = s_last[s]; }
+      for (uint32_t g = 0; g < a.n_aggregates; ++g) {
+        const uint64_t v = s_values[s * a.n_aggregates + g], c = s_counts[s * a.n_aggregates + g];
+        direct.values[idx * a.n_aggregates + g] = v;
+        direct.counts[idx * a.n_aggregates + g] = c;
+        if (stage) { direct.staged.values[idx * a.n_aggregates + g] = v; direct.staged.counts[idx * a.n_aggregates + g] = c; }
+      }
+    }
+    return;
   }
   // the partition's groups: nobody else has them, every one is entered into the global table exactly once
   for (uint32_t s = tid; s < slots; s += 256) {
@@ -2134,16 +2198,6 @@ __global__ __launch_bounds__(256, FUSED_WAVES) void fused_rows(AggArgs a, const 
 
 #include "fused_small.hpp"
 
-// The groups of the table, densely.  The first `staged_capacity` of them also go straight into pinned host memory (same
-// five arrays, `staged_capacity` rows each, behind a 64-byte header): few groups -- the usual case -- cost no copy at all.
-struct StagedGroups {
-  uint64_t* keys;
-  uint64_t* first;
-  uint64_t* last;
-  uint64_t* values;
-  uint64_t* counts;
-  uint32_t capacity;
-};
 // (One atomic on the group counter per workgroup: one per group serialises at its L2 channel -- 100 000 groups took 0.36 ms that way.)
 constexpr uint32_t COMPACT_THREADS = 1024;
 __global__ __launch_bounds__(COMPACT_THREADS) void compact_groups(AggArgs a, uint32_t* counter, uint64_t* out_keys, uint64_t* out_first, uint64_t* out_last, uint64_t* out_values,
@@ -2433,13 +2487,13 @@ static void launch_partition_rows(bool scatter, uint32_t words, uint32_t grid, s
   else launch_partition_rows_of<true, false>(words, grid, lds, stream, a, pa);
 }
 template <bool NARROW>
-static void launch_aggregate_partitions(uint32_t words, uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
+static void launch_aggregate_partitions(uint32_t words, uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa, const DirectGroups& direct) {
   switch (words) {
-    case 1: hipLaunchKernelGGL((aggregate_partitions<1, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
-    case 2: hipLaunchKernelGGL((aggregate_partitions<2, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
-    case 3: hipLaunchKernelGGL((aggregate_partitions<3, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
-    case 4: hipLaunchKernelGGL((aggregate_partitions<4, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
-    default: hipLaunchKernelGGL((aggregate_partitions<5, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa); break;
+    case 1: hipLaunchKernelGGL((aggregate_partitions<1, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+    case 2: hipLaunchKernelGGL((aggregate_partitions<2, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+    case 3: hipLaunchKernelGGL((aggregate_partitions<3, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+    case 4: hipLaunchKernelGGL((aggregate_partitions<4, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+    default: hipLaunchKernelGGL((aggregate_partitions<5, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
   }
 }
 
@@ -2529,6 +2583,32 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       g_agg_trace = trace_buffer;
       g_agg_trace_slices = shape->n_slices;
     }
+    // where the groups go, densely (compact_groups; aggregate_partitions with DirectGroups)
+    DeviceBuffer c_keys, c_first, c_last, c_values, c_counts;
+    // (the partitioned path's groups mostly bypass the global table: room for 8 Mi of them whatever its size)
+    const uint32_t out_capacity = static_cast<uint32_t>(std::min<uint64_t>(partition_bits ? std::max<uint64_t>(capacity, 1u << 23) : capacity, shape->rows + 1));
+    HY_TRY(c_keys.alloc(8 * size_t{out_capacity} * words));
+    HY_TRY(c_first.alloc(8 * size_t{out_capacity}));
+    HY_TRY(c_last.alloc(8 * size_t{out_capacity}));
+    HY_TRY(c_values.alloc(8 * size_t{out_capacity} * (n_aggregates ? n_aggregates : 1)));
+    HY_TRY(c_counts.alloc(8 * size_t{out_capacity} * (n_aggregates ? n_aggregates : 1)));
+    // pinned block: header | keys | first | last | values | counts for up to STAGED_GROUPS groups
+    constexpr uint32_t STAGED_GROUPS = 4096;
+    const uint32_t per_group = n_aggregates ? n_aggregates : 1;
+    const size_t staged_bytes = 64 + 8 * size_t{STAGED_GROUPS} * (words + 2 + 2 * per_group);
+    void* pinned_host = nullptr;
+    void* pinned_dev = nullptr;
+    HY_TRY(pinned_staging(staged_bytes, &pinned_host, &pinned_dev));
+    auto staged_arrays = [&](void* base) {
+      StagedGroups g;
+      g.keys = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(base) + 64);
+      g.first = g.keys + size_t{STAGED_GROUPS} * words;
+      g.last = g.first + STAGED_GROUPS;
+      g.values = g.last + STAGED_GROUPS;
+      g.counts = g.values + size_t{STAGED_GROUPS} * per_group;
+      g.capacity = STAGED_GROUPS;
+      return g;
+    };
     g_agg_path = partition_bits;
     g_agg_small = small && partition_bits == 0 && !fused ? 1u : 0u;
     g_agg_small = fused && fused_small ? 2u : g_agg_small;
@@ -2603,37 +2683,23 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       pa.split = 1;
       while (pa.split < 64 && (shape->rows >> partition_bits) / pa.split > 16384) pa.split <<= 1;
       if (option(HY_OPT_AGG_SPLIT) > 0) pa.split = static_cast<uint32_t>(option(HY_OPT_AGG_SPLIT));
-      if (pa.narrow) launch_aggregate_partitions<true>(words, partitions * pa.split, pa.lds_slots * per_slot + 64, stream, a, pa);
-      else launch_aggregate_partitions<false>(words, partitions * pa.split, pa.lds_slots * per_slot + 64, stream, a, pa);
+      DirectGroups direct;
+      std::memset(&direct, 0, sizeof(direct));
+      direct.enabled = pa.split == 1 ? 1u : 0u;
+      direct.out_capacity = out_capacity;
+      direct.counter = flags.as<uint32_t>() + FLAG_GROUPS;
+      direct.keys = c_keys.as<uint64_t>();
+      direct.first = c_first.as<uint64_t>();
+      direct.last = c_last.as<uint64_t>();
+      direct.values = c_values.as<uint64_t>();
+      direct.counts = c_counts.as<uint64_t>();
+      direct.staged = staged_arrays(pinned_dev);
+      if (pa.narrow) launch_aggregate_partitions<true>(words, partitions * pa.split, pa.lds_slots * per_slot + 64, stream, a, pa, direct);
+      else launch_aggregate_partitions<false>(words, partitions * pa.split, pa.lds_slots * per_slot + 64, stream, a, pa, direct);
       profile_end(stream);
     }
     lap("kernels launched", round);
     uint32_t host_flags[7] = {0, 0, 0, 0, 0, 0, 0};
-    // count groups, then compact
-    DeviceBuffer c_keys, c_first, c_last, c_values, c_counts;
-    const uint32_t out_capacity = static_cast<uint32_t>(std::min<uint64_t>(capacity, shape->rows + 1));
-    HY_TRY(c_keys.alloc(8 * size_t{out_capacity} * words));
-    HY_TRY(c_first.alloc(8 * size_t{out_capacity}));
-    HY_TRY(c_last.alloc(8 * size_t{out_capacity}));
-    HY_TRY(c_values.alloc(8 * size_t{out_capacity} * (n_aggregates ? n_aggregates : 1)));
-    HY_TRY(c_counts.alloc(8 * size_t{out_capacity} * (n_aggregates ? n_aggregates : 1)));
-    // pinned block: header | keys | first | last | values | counts for up to STAGED_GROUPS groups
-    constexpr uint32_t STAGED_GROUPS = 4096;
-    const uint32_t per_group = n_aggregates ? n_aggregates : 1;
-    const size_t staged_bytes = 64 + 8 * size_t{STAGED_GROUPS} * (words + 2 + 2 * per_group);
-    void* pinned_host = nullptr;
-    void* pinned_dev = nullptr;
-    HY_TRY(pinned_staging(staged_bytes, &pinned_host, &pinned_dev));
-    auto staged_arrays = [&](void* base) {
-      StagedGroups g;
-      g.keys = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(base) + 64);
-      g.first = g.keys + size_t{STAGED_GROUPS} * words;
-      g.last = g.first + STAGED_GROUPS;
-      g.values = g.last + STAGED_GROUPS;
-      g.counts = g.values + size_t{STAGED_GROUPS} * per_group;
-      g.capacity = STAGED_GROUPS;
-      return g;
-    };
     hipLaunchKernelGGL(compact_groups, dim3(static_cast<uint32_t>((capacity + COMPACT_THREADS - 1) / COMPACT_THREADS)), dim3(COMPACT_THREADS), 0, stream, a, flags.as<uint32_t>() + FLAG_GROUPS, c_keys.as<uint64_t>(),
                        c_first.as<uint64_t>(), c_last.as<uint64_t>(), c_values.as<uint64_t>(), c_counts.as<uint64_t>(), out_capacity, staged_arrays(pinned_dev));
     hipLaunchKernelGGL(publish_group_flags, dim3(1), dim3(1), 0, stream, flags.as<uint32_t>(), static_cast<uint32_t*>(pinned_dev));
@@ -2662,6 +2728,11 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       continue;
     }
     const uint32_t n_groups = host_flags[FLAG_GROUPS];
+    if (n_groups > out_capacity) {   // (direct groups + the global table's: more than the arrays hold)
+      if (rung < 3) ++rung;
+      else return fail(HY_ERR_DEVICE, "more groups than rows (internal error)");
+      continue;
+    }
     out.n_groups = n_groups;
     out.passed_rows = static_cast<uint64_t>(host_flags[5]) << 32 | host_flags[4];
     if (out.hint_owner && can_partition && !small && option(HY_OPT_AGG_PARTITION_BITS) <= 0) out.hint_owner->aggregate_hint.store((out.hint_signature >> 8) << 8 | (partition_bits + 1), std::memory_order_relaxed);

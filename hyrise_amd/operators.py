@@ -336,8 +336,10 @@ class HostAggregateResult:
         return [None if self.nulls[a][i] else values[i].item() for i in range(n)]
 
 
-def aggregate_hash(groupby_columns, aggregates, group_capacity=None):
-    """aggregates: list of (HY_AGG_*, DeviceColumn or None for COUNT(*))."""
+def aggregate_hash(groupby_columns, aggregates, group_capacity=None, result=None):
+    """aggregates: list of (HY_AGG_*, DeviceColumn or None for COUNT(*)).  result: a HostAggregateResult of an earlier call with the same
+    aggregates and capacity, written again (a caller that runs the plan repeatedly keeps its buffers; fresh numpy arrays are first touched --
+    one page fault per 4 KiB -- while the result is copied into them)."""
     lib = abi.load_library()
     garr = (C.c_void_p * max(1, len(groupby_columns)))(*[c.handle for c in groupby_columns])
     specs = (abi.AggregateSpec * max(1, len(aggregates)))()
@@ -345,7 +347,8 @@ def aggregate_hash(groupby_columns, aggregates, group_capacity=None):
         specs[i].function = function
         specs[i].column = column.handle if column is not None else None
     shape = groupby_columns[0] if groupby_columns else next(c for _, c in aggregates if c is not None)
-    result = HostAggregateResult(len(aggregates), (shape.rows + 1) if group_capacity is None else group_capacity)
+    if result is None:
+        result = HostAggregateResult(len(aggregates), (shape.rows + 1) if group_capacity is None else group_capacity)
     abi.check(lib.hy_aggregate_hash(garr, len(groupby_columns), specs, len(aggregates), C.byref(result.c)))
     return result
 

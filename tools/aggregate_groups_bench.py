@@ -19,10 +19,11 @@ n = int(os.environ.get("ROWS", "60000000"))
 values = DeviceColumn(storage.make_column(rng.random(n).astype(np.float32), None, abi.ENC_UNENCODED))
 for groups in [int(g) for g in os.environ.get("NGROUPS", "4,64,1000,100000,4000000").split(",")]:
     keys = DeviceColumn(storage.make_column(rng.integers(0, groups, n).astype(np.int32), None, abi.ENC_UNENCODED))
-    for i in range(3):
+    result = None
+    for i in range(4):
         torch.cuda.synchronize()
         t = time.perf_counter()
-        result = aggregate_hash([keys], [(abi.AGG_SUM, values), (abi.AGG_COUNT, None)], group_capacity=groups + 16)
+        result = aggregate_hash([keys], [(abi.AGG_SUM, values), (abi.AGG_COUNT, None)], group_capacity=groups + 16, result=result if os.environ.get("FRESH") is None else None)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
     print(f"groups {groups:8d}: {dt * 1e3:8.3f} ms  {n / dt:.3g} rows/s  ({result.n_groups} groups)", flush=True)
