@@ -739,7 +739,8 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
     n_runs = sum(segment.aux_size for segment in runs_host.segments)
     runs = DeviceColumn(runs_host)
     out["run_length_clustered_dates_lt_1995"] = dict(measure(lambda: step_fn(pred, runs), lambda m: n_runs * 8 + m * 8), runs=n_runs,
-                                                     note="RunLengthSegment<int32> read in place: one search of the end positions per eight rows; bytes counted: 8 per run + 8 per match")
+                                                     note="RunLengthSegment<int32> read in place, run by run: one search of the end positions per wave (2048 rows), every run tested once; bytes counted: 8 per run + 8 per match "
+                                                          "(sorted_chunks_lt_1995 writes the same positions without reading anything: the floor of this case)")
     del runs, runs_host, clustered_days
     # l_shipdate as Hyrise's schema has it: DictionarySegment<pmr_string> of ISO dates -- the same attribute vectors, the literal resolved
     # per chunk on the host (lower / upper bound in 916 string dictionaries: reported beside the scan as host_literal_resolution_ms)

@@ -1016,7 +1016,31 @@ __device__ __forceinline__ uint32_t evaluate_slice(const ScanArgs& a, const Slic
     }
   } else {
     const ScanJob job = a.jobs[slice.chunk];
-    if ((job.mode == JOB_SCAN || job.mode == JOB_RANGE) && !(job.flags & JF_NEVER)) {
+    bool walked = false;
+    if (COMPRESSED && job.mode == JOB_SCAN && !(job.flags & JF_NEVER) && seg.encoding == HY_ENC_RUN_LENGTH && wave * 2048 < slice.row_count) {
+      // RunLengthSegment, run by run (run_length_segment_iterable.hpp:100-160 walks the runs; so does the wave): the runs that overlap the
+      // wave's 2048 rows are found with one search of the end positions for the whole wave (scalar loads), each is tested once, and a
+      // lane marks the rows of its four groups that lie in a matching run -- no lane reads anything.  (Clustered dates, 17 000 rows per run:
+      // one search per eight rows was 98 us for 60 M rows, of which the 206 MB of positions take 49.)  Segments with short runs -- more
+      // than 64 under one wave -- keep the search per group below.
+      const uint32_t* ends = static_cast<const uint32_t*>(seg.aux);
+      const uint32_t first = __builtin_amdgcn_readfirstlane(slice.row_begin + wave * 2048);
+      const uint32_t end = __builtin_amdgcn_readfirstlane(slice.row_begin + (slice.row_count < wave * 2048 + 2048 ? slice.row_count : wave * 2048 + 2048));
+      uint32_t run = __builtin_amdgcn_readfirstlane(run_of_position(ends, seg.aux_size, first));
+      uint32_t cursor = first, walked_mask = 0;
+      for (uint32_t step = 0; step < 64 && cursor < end; ++step, ++run) {
+        const uint32_t run_end = ends[run] + 1 < end ? ends[run] + 1 : end;   // (exclusive)
+        if (eval_run(seg, job, run)) {
+#pragma unroll
+          for (uint32_t k = 0; k < 4; ++k) walked_mask |= rows_in_range8(first + k * 512 + lane * 8, cursor, run_end) << (8 * k);
+        }
+        cursor = run_end;
+      }
+      walked = cursor >= end;
+      if (walked) mask = walked_mask;
+    }
+    if (walked) {
+    } else if ((job.mode == JOB_SCAN || job.mode == JOB_RANGE) && !(job.flags & JF_NEVER)) {
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t r0 = wave * 2048 + k * 512 + lane * 8;

@@ -395,6 +395,15 @@ def test_run_length_segments(device):
     dev = DeviceColumn(host)
     for condition in CONDITIONS:
         check(host, make_predicate(condition, abi.TYPE_INT, 10, 30, nullable=True), dev, context=f"run length cond {condition}")
+    # runs of 1 .. 6000 rows (a wave's 2048 rows lie in one run, in a few, or in more than the 64 it walks), NULL runs, ragged chunks
+    lengths = np.concatenate([rng.integers(1, 6_000, 60), rng.integers(1, 12, 3_000), rng.integers(500, 3_000, 40)])
+    mixed = np.repeat(rng.integers(0, 50, len(lengths)), lengths).astype(np.int32)
+    mixed_nulls = np.repeat(rng.random(len(lengths)) < 0.15, lengths)
+    bounds = [0, 65_535, 65_535 + 2_048, 65_535 + 2_048 + 40_001, len(mixed)]
+    mixed_host = storage.HostColumn([storage.encode_run_length(mixed[b:e], mixed_nulls[b:e]) for b, e in zip(bounds[:-1], bounds[1:]) if e > b], abi.TYPE_INT)
+    mixed_dev = DeviceColumn(mixed_host)
+    for condition in CONDITIONS:
+        check(mixed_host, make_predicate(condition, abi.TYPE_INT, 10, 30, nullable=True), mixed_dev, context=f"run length (mixed runs) cond {condition}")
     other_host = build_column(rng.integers(0, 60, 3_000).astype(np.int32), None, 1_000, abi.ENC_DICTIONARY)
     other = DeviceColumn(other_host)
     got, want = join_hash(other, dev, abi.JOIN_INNER), oracle_join(other_host, host, abi.JOIN_INNER)
