@@ -21,7 +21,7 @@ hash repartition by all-to-all) -- `multi_gpu` object, hyrise_amd/distributed.py
 
 Prints ONE JSON line on rank 0: `roofline` = the step's algorithmic bytes (scan 2 B/row + 8 B/match, join build
 keys + probe keys + 16 B/pair) over the step time vs. the 8 TB/s HBM peak, with the HIP-event durations of the step's kernels
-(`kernels`: scan_slices, pk_emit, pk_count, rank_table_fill_checked -- events taken INSIDE the timed region, every 4th step) and
+(`kernels`: scan_slices, pk_emit, pk_count, rank_table_fill_waves -- events taken INSIDE the timed region, every 4th step) and
 `dominant_kernel` = pk_emit; `cpu_baseline` = the CPU restatement of the two Hyrise operators on the host cores (rank 0, N = 1
 only).  At N = 1 the line also carries `scan` (config 2 alone), `join` (config 3 alone, + Semi legs + cases) and `aggregate`
 (config 4), each with its own roofline and cpu_baseline, `cases` (the other predicates / encodings SURVEY.md 8(d) lists), `q6`
@@ -258,7 +258,7 @@ def kernel_times(lib):
     """{kernel kind: (ms per timed launch, timed launches)} of the current profiling session (hy_profile_read_kernel).  The scan and
     join kernels are timed by event pairs stamped from their dispatch packets: the elapsed time of an empty kernel measured the same way
     (a few microseconds, `event_overhead_ms` in the line) is taken off every one of them, which is what makes these durations comparable
-    with a profiler's per-kernel begin / end timestamps (profiles/r03_bench_kernel_stats.csv)."""
+    with a profiler's per-kernel begin / end timestamps (profiles/r04_bench_kernel_stats.csv)."""
     from hyrise_amd import abi
     out = {}
     overhead = event_overhead_ms(lib)
@@ -373,7 +373,7 @@ def join_kernels(kinds, n_orders, n, pairs, offset_width=2, pair_bytes=16):
     if kinds["join_count"][1]:
         out["pk_count"] = roofline_object("pk_count", n * offset_width, kinds["join_count"][0], committed_traffic("pk_count"))
     if kinds["join_build"][1]:
-        out["rank_table_fill_checked"] = roofline_object("rank_table_fill_checked", n_orders * 4, kinds["join_build"][0], committed_traffic("rank_table_fill_checked"))
+        out["rank_table_fill_waves"] = roofline_object("rank_table_fill_waves", n_orders * 4, kinds["join_build"][0], committed_traffic("rank_table_fill_waves"))
     return out
 
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Summarises the rocprofv3 runs of tools/collect_profiles.sh over `python bench.py` itself into the files committed under profiles/:
-  r03_bench_kernel_stats.csv   per (kernel, grid size): launches, average / min / max duration -- from the kernel trace of ONE bench.py
-                               process, whose own JSON line (HIP-event kernel_ms measured inside that process) is r03_bench_traced.json
-  r03_bench_pmc.json           per kernel (the launch shape of the headline step = the shape with most launches): FETCH_SIZE / WRITE_SIZE per
+  r04_bench_kernel_stats.csv   per (kernel, grid size): launches, average / min / max duration -- from the kernel trace of ONE bench.py
+                               process, whose own JSON line (HIP-event kernel_ms measured inside that process) is r04_bench_traced.json
+  r04_bench_pmc.json           per kernel (the launch shape of the headline step = the shape with most launches): FETCH_SIZE / WRITE_SIZE per
                                launch and hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE doubled: gfx950 tallies the 128-byte
                                requests of wide coalesced reads at 64 bytes, MI355X_MICROARCH.md "HBM"; WRITE_SIZE as reported); "step" = the
                                kernels of one TableScan + JoinHash step added up, "hy_join_hash" = the join's.  bench.py reads this file for
@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-STEP = ("scan_slices", "prepare_jobs", "zero_vectors", "rank_table_fill_checked", "pk_count", "pk_scan", "pk_emit")
+STEP = ("scan_slices", "prepare_jobs", "zero_vectors", "rank_table_fill_waves", "pk_count", "pk_scan", "pk_plan", "pk_emit")
 JOIN = STEP[2:]
 
 
@@ -28,6 +28,32 @@ def base(name):
     return short(name).split("<")[0]
 
 
+def timeline(root):
+    """r04_bench_step_timeline.txt: the kernels of three consecutive headline steps in the middle of the timed region, with the idle time
+    before each (launch gaps) -- what separates the sum of the kernels from the step's wall time."""
+    rows = []
+    for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        with open(path) as fh:
+            rows += [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(fh)]
+    rows.sort()
+    emits = [i for i, r in enumerate(rows) if base(r[2]) == "pk_emit"]
+    scans = [i for i, r in enumerate(rows) if base(r[2]) == "scan_slices"]
+    if len(emits) < 12:
+        return
+    # the longest stretch of alternating scan / join launches is the timed region: take three steps from its middle
+    middle = emits[len(emits) // 2]
+    begin = max(i for i in scans if i < middle)
+    steps_begin = max([i for i in scans if i < begin][-2:-1] or [begin])
+    end = emits[min(len(emits) - 1, len(emits) // 2 + 1)]
+    with open(os.path.join(root, "r04_bench_step_timeline.txt"), "w") as fh:
+        fh.write("offset_us  idle_before_us  duration_us  kernel\n")
+        origin, previous_end = rows[steps_begin][0], None
+        for start, stop, name in rows[steps_begin:end + 1]:
+            idle = (start - previous_end) / 1e3 if previous_end is not None else 0.0
+            fh.write(f"{(start - origin) / 1e3:9.1f}  {idle:14.1f}  {(stop - start) / 1e3:11.1f}  {name[:70]}\n")
+            previous_end = max(stop, previous_end or stop)
+
+
 def main():
     root, commit = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
     groups = collections.defaultdict(list)
@@ -36,7 +62,8 @@ def main():
             for row in csv.DictReader(fh):
                 if "hy::" in row["Kernel_Name"]:
                     groups[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-    with open(os.path.join(root, "r03_bench_kernel_stats.csv"), "w", newline="") as fh:
+    timeline(root)
+    with open(os.path.join(root, "r04_bench_kernel_stats.csv"), "w", newline="") as fh:
         writer = csv.writer(fh)
         writer.writerow(["kernel", "grid_size_x", "launches", "average_us", "min_us", "max_us", "total_ms"])
         for (name, grid), durations in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
@@ -71,13 +98,13 @@ def main():
                          "WRITE_SIZE_KB_per_launch": w[0] / w[1] if w[1] else None,
                          "hbm_bytes_per_launch": (f[0] / f[1] * 2048 if f[1] else 0) + (w[0] / w[1] * 1024 if w[1] else 0), "average_us_traced": average}
     for total, members in (("step", STEP), ("hy_join_hash", JOIN)):
-        if all(m in kernels for m in members if m not in ("prepare_jobs", "zero_vectors")):
+        if all(m in kernels for m in members if m not in ("prepare_jobs", "zero_vectors", "pk_plan")):
             kernels[total] = {"kernels": [m for m in members if m in kernels], "hbm_bytes_per_launch": sum(kernels[m]["hbm_bytes_per_launch"] for m in members if m in kernels)}
     summary = {"collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) over `python bench.py`, commit {commit}", "kernels": kernels,
                "note": "bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024 per launch of the kernel's headline shape (the grid size with most launches); memory-side cache hits included"}
-    with open(os.path.join(root, "r03_bench_pmc.json"), "w") as fh:
+    with open(os.path.join(root, "r04_bench_pmc.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
-    for name in ("scan_slices", "pk_emit", "pk_count", "rank_table_fill_checked", "step", "hy_join_hash"):
+    for name in ("scan_slices", "pk_emit", "pk_count", "rank_table_fill_waves", "step", "hy_join_hash"):
         if name in kernels:
             print(f"{name:28s} hbm bytes per launch {kernels[name]['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
 
