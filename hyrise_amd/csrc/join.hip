@@ -4202,6 +4202,11 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself)
     profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
+    {
+      const int64_t group = option(HY_OPT_JOIN_EMIT_TILE_GROUP);
+      k.emit_group_shift = 32;
+      if (group > 0) { k.emit_group_shift = 0; while (k.emit_group_shift < 16 && (int64_t{1} << (k.emit_group_shift + 1)) <= group) ++k.emit_group_shift; }
+    }
     k.cut_blocks = (cut_grid + 7) / 8 * 8;   // (pk_cut_slice returns at once for slices the plan does not have)
     if (build_in_lds) {   // (pass 2 reads the rows' found / materialised bits pass 1 left behind)
       if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL((pk_emit<true, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);

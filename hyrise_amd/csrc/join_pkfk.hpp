@@ -71,6 +71,7 @@ struct PkArgs {
   hy_row_id* build_out;            // nullptr: Semi / Anti
   hy_row_id* probe_out;
   uint64_t* slice_offsets;
+  uint32_t emit_group_shift;       // pk_emit: log2 of the consecutive tiles an XCD takes (32: every XCD its own eighth of the tiles)
   uint32_t cut_blocks;             // pk_emit: its first cut_blocks workgroups compute the PosList cuts (pk_cut_slice)
   uint32_t bloom_is_bits;          // build_bloom holds 2^20 bits (a hinted build, rank_table_fill_checked), not one byte per bit
   uint64_t* trace;                 // debug (HY_JOIN_TRACE): 6 wall-clock stamps per pk_emit tile, else nullptr
@@ -878,7 +879,17 @@ __global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkAr
   // of its own behind this kernel was 13 us of an otherwise idle device.
   if (blockIdx.x < a.cut_blocks) { pk_cut_slice<MASKS>(a, blockIdx.x, join_smem, tid, lane, wave); return; }
   const uint32_t block = blockIdx.x - a.cut_blocks;
-  const uint32_t tile = (block & 7) * ((a.n_tiles + 7) / 8) + (block >> 3);
+  // Which tile: the device works on one front of tiles that moves through the probe side -- workgroups arrive at the XCDs in turn (block b
+  // on XCD b % 8), an XCD takes 2^emit_group_shift consecutive tiles of every 8 x 2^emit_group_shift (the partial lines two neighbouring
+  // tiles share meet in one L2).  One front per XCD (every XCD its own eighth of the tiles: emit_group_shift = 32) is eight times as many
+  // places written at the same time: the same write pattern alone runs 209 us that way and 187 us on one front (tools/write_fronts.hip),
+  // pk_emit itself 265 .. 285 us instead of 285 .. 300 in the allocations where it is slow.
+  uint32_t tile;
+  if (a.emit_group_shift < 32) {
+    const uint32_t xcd = block & 7, j = block >> 3, shift = a.emit_group_shift;
+    const uint32_t whole = ((a.n_tiles + 7) / 8) >> shift << shift;   // (the grid: 8 x ceil(n_tiles / 8) tile blocks)
+    tile = j < whole ? ((j >> shift) << (shift + 3)) + (xcd << shift) + (j & ((1u << shift) - 1)) : whole * 8 + (j - whole) * 8 + xcd;
+  } else tile = (block & 7) * ((a.n_tiles + 7) / 8) + (block >> 3);
   if (tile >= a.n_tiles || !a.plan->fits) return;
   const SliceView view = pk_tile_view(a, tile);
   if (view.row_count == 0) return;

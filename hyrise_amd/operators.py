@@ -392,9 +392,18 @@ def pair_lists(torch, device, capacity):
     1.25 MiB past a 2 MiB boundary when the first starts on one -- the result-buffer policy of the adapter.
     -> (left, right, the allocation: keep it alive)"""
     list_bytes = 8 * max(1, int(capacity))
-    arena = torch.empty(2 * list_bytes + 3 * PAIR_LIST_PERIOD, dtype=torch.uint8, device=device)
-    first = -arena.data_ptr() % PAIR_LIST_PERIOD
-    second = (first + list_bytes + PAIR_LIST_PERIOD - 1) // PAIR_LIST_PERIOD * PAIR_LIST_PERIOD + PAIR_LIST_OFFSET
+    import os
+    align = int(os.environ.get("HY_PAIR_ALIGN", "0"))          # experiments (tools/emit_lottery.py): both lists from an `align`-aligned address,
+    offset = int(os.environ.get("HY_PAIR_OFFSET", str(PAIR_LIST_OFFSET)))   # the second `offset` past the next multiple of `align`
+    if align:
+        span = (list_bytes + align - 1) // align * align
+        arena = torch.empty(2 * span + align + offset, dtype=torch.uint8, device=device)
+        first = -arena.data_ptr() % align
+        second = first + span + offset
+    else:
+        arena = torch.empty(2 * list_bytes + 3 * PAIR_LIST_PERIOD, dtype=torch.uint8, device=device)
+        first = -arena.data_ptr() % PAIR_LIST_PERIOD
+        second = (first + list_bytes + PAIR_LIST_PERIOD - 1) // PAIR_LIST_PERIOD * PAIR_LIST_PERIOD + offset
     rows = max(1, int(capacity))
     left = arena[first:first + list_bytes].view(torch.int32).view(rows, 2)
     right = arena[second:second + list_bytes].view(torch.int32).view(rows, 2)

@@ -273,7 +273,8 @@ enum {
   HY_OPT_JOIN_LDS_HASH = 24,         /* 0    1: unique int32 build keys that are not sorted, or probed without locality, take the radix-partitioned
                                       *      path (csrc/join_hp.hpp: tuples partition by partition, per-partition tables probed in LDS).  Off: at SF10 it
                                       *      runs 1.9 - 2.05 ms where the rank table read in place runs 1.65 - 1.92 ms          */
-  HY_OPT_RESERVED_25 = 25,
+  HY_OPT_JOIN_EMIT_TILE_GROUP = 25,  /* 64   pk_emit: consecutive tiles per XCD, a power of two (the device works on ONE front of 8 x this many tiles
+                                      *      that moves through the probe side); 0 = every XCD works through its own eighth of the tiles        */
   HY_OPT_JOIN_FILL_WGS_PER_CU = 26,  /* 4    the checked one-pass fill wave by wave (rank_table_fill_waves: this many resident workgroups per
                                       *      CU, <= 8); 0 = one short-lived workgroup per slice (rank_table_fill_checked)              */
   HY_OPT_COUNT = 32

@@ -24,10 +24,18 @@ def main():
     data = tpch.TpchData(10.0, 42, keys_only=True)
     orders_host = storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED)
     lineitem_host = storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE)
-    orders = [DeviceColumn(orders_host) for _ in range(3)]
-    lineitem = [DeviceColumn(lineitem_host) for _ in range(3)]
     n = data.n_lineitems
-    joins = [bench.device_join(lib, torch, dev, orders, lineitem, n) for _ in range(arenas)]
+    orders, lineitem = [], []
+    if os.environ.get("ARENAS_FIRST"):   # the output arenas before anything else is in device memory
+        joins = [bench.device_join(lib, torch, dev, orders, lineitem, n) for _ in range(arenas)]
+    orders += [DeviceColumn(orders_host) for _ in range(3)]
+    lineitem += [DeviceColumn(lineitem_host) for _ in range(3)]
+    if not os.environ.get("ARENAS_FIRST"):
+        joins = [bench.device_join(lib, torch, dev, orders, lineitem, n) for _ in range(arenas)]
+    if os.environ.get("SHARE_SMALL"):   # every join writes its PosList offsets and its status into the buffers of join number SHARE_SMALL
+        donor = joins[int(os.environ["SHARE_SMALL"])][1]
+        for run, r, keep in joins:
+            r.slice_offsets, r.status = donor.slice_offsets, donor.status
     for run, r, keep in joins:
         for _ in range(6):
             run()
@@ -39,6 +47,11 @@ def main():
             out.append(kinds["join_probe"][0] * 1e3)
         print(f"{label:44s} pk_emit per arena: " + "  ".join(f"{v:6.1f}" for v in out) + f"   (arena addresses mod 1 GiB: " + " ".join(f"{(k[3].data_ptr() >> 21) & 511}" for _, _, k in joins) + ")", flush=True)
 
+    if os.environ.get("TILE_GROUPS"):   # HY_OPT_JOIN_EMIT_TILE_GROUP: the same arenas under every setting
+        for group in [int(g) for g in os.environ["TILE_GROUPS"].split(",")] * 2:
+            abi.check(lib.hy_set_option(abi.OPT_JOIN_EMIT_TILE_GROUP, group))
+            measure(f"tile group {group}")
+        return
     measure("as allocated")
     measure("again")
     # the library's temporaries: hy_shutdown releases this thread's pool, the next join allocates anew
