@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU-box session: the -m gpu suite, the bench line, then bench.py profiled as one process (tools/collect_profiles.sh), the kernel
 # traces of the SSB star joins (tools/run_ssb_profile.sh) and of TPC-H Q1 through hy_scan_project_aggregate (tools/q1_fused_time.py).
+# Every step under its own timeout.  usage: bash tools/run_round.sh <commit>
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/gputest.log 2>&1; echo "rc=$?" >> gpurun_out/gputest.log
 tail -4 gpurun_out/gputest.log
