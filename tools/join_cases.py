@@ -27,6 +27,8 @@ def main():
     abi.check(lib.hy_init(0))
     if "--no-partitioned" in sys.argv:
         abi.check(lib.hy_set_option(abi.OPT_JOIN_LDS_HASH, 0))
+    if "--partitioned" in sys.argv:   # the radix-partitioned path for unique int32 keys (join_hp.hpp; off by default)
+        abi.check(lib.hy_set_option(abi.OPT_JOIN_LDS_HASH, 1))
     dev = torch.device("cuda", 0)
     data = tpch.TpchData(10.0, 42, keys_only=True)
     n = data.n_lineitems
