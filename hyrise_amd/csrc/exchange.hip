@@ -63,6 +63,80 @@ __global__ __launch_bounds__(256) void export_rows(ExportArgs a) {
   }
 }
 
+// The same for a REFERENCE column (an operator result read through its PosLists: the foreign key of a join result, the columns an
+// aggregate reads behind three joins).  decode_rows takes such rows one at a time -- RowID, then the referenced segment's descriptor, then
+// its NULL word, its vector, its dictionary or block minimum: five dependent loads a row, nothing in flight beside them (36 M foreign keys
+// of SSB Q4.1: 432 us).  Here eight rows per lane go through every level together: the RowIDs, then the descriptors' words, then the
+// first-level elements, then the second-level ones.
+__global__ __launch_bounds__(256) void export_reference_rows(ExportArgs a) {
+  const Slice slice = a.slices[blockIdx.x];
+  if (slice.row_count == 0) return;
+  const DevSegment s = a.segments[slice.chunk];
+  const hy_row_id* pos = static_cast<const hy_row_id*>(s.data);
+  const uint64_t base = a.row_base[slice.chunk] + slice.row_begin;
+  constexpr int BATCH = 8;
+#pragma unroll 1
+  for (uint32_t block = 0; block * BATCH * 256 < slice.row_count; ++block) {
+    uint32_t r[BATCH], chunk[BATCH], offset[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      r[i] = (block * BATCH + i) * 256 + threadIdx.x;
+      chunk[i] = s.ref_chunk_id;
+      offset[i] = 0xFFFFFFFFu;
+      if (r[i] < slice.row_count) {
+        if (pos) { const hy_row_id rid = pos[slice.row_begin + r[i]]; chunk[i] = rid.chunk_id; offset[i] = rid.chunk_offset; }
+        else offset[i] = slice.row_begin + r[i];   // (EntireChunkPosList)
+      }
+    }
+    const void* data[BATCH];
+    const void* aux[BATCH];
+    const uint64_t* null_words[BATCH];
+    uint32_t aux_size[BATCH], kind[BATCH];   // kind: encoding | data_type << 8 | width << 16
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      data[i] = aux[i] = nullptr;
+      null_words[i] = nullptr;
+      aux_size[i] = kind[i] = 0;
+      if (offset[i] == 0xFFFFFFFFu) continue;   // NULL_ROW_ID (or past the slice)
+      const DevSegment* b = s.ref + chunk[i];
+      data[i] = b->data;
+      aux[i] = b->aux;
+      null_words[i] = b->nulls;
+      aux_size[i] = b->aux_size;
+      kind[i] = static_cast<uint32_t>(b->encoding) | static_cast<uint32_t>(b->data_type) << 8 | static_cast<uint32_t>(b->width) << 16;
+    }
+    uint64_t first[BATCH], null_word[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      first[i] = null_word[i] = 0;
+      if (offset[i] == 0xFFFFFFFFu) continue;
+      const uint32_t encoding = kind[i] & 0xFF, type = (kind[i] >> 8) & 0xFF, width = kind[i] >> 16;
+      if (encoding == HY_ENC_DICTIONARY || encoding == HY_ENC_FRAME_OF_REFERENCE) first[i] = aload_compressed(data[i], width, offset[i]);
+      else if (type == HY_TYPE_INT || type == HY_TYPE_FLOAT) first[i] = static_cast<const uint32_t*>(data[i])[offset[i]];
+      else first[i] = static_cast<const uint64_t*>(data[i])[offset[i]];
+      if (encoding != HY_ENC_DICTIONARY && null_words[i]) null_word[i] = null_words[i][offset[i] >> 6];
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      if (r[i] >= slice.row_count) continue;
+      const uint32_t encoding = kind[i] & 0xFF, type = (kind[i] >> 8) & 0xFF;
+      bool is_null = offset[i] == 0xFFFFFFFFu || ((null_word[i] >> (offset[i] & 63)) & 1);
+      uint64_t word = first[i];   // the value's own bits: 4 bytes of an int32 / float, 8 of an int64 / double
+      if (!is_null && encoding == HY_ENC_DICTIONARY) {
+        if (first[i] >= aux_size[i]) is_null = true;
+        else if (type == HY_TYPE_INT || type == HY_TYPE_FLOAT) word = static_cast<const uint32_t*>(aux[i])[first[i]];
+        else word = static_cast<const uint64_t*>(aux[i])[first[i]];
+      } else if (!is_null && encoding == HY_ENC_FRAME_OF_REFERENCE) {
+        word = static_cast<uint32_t>(first[i]) + static_cast<uint32_t>(static_cast<const int32_t*>(aux[i])[offset[i] / HY_FOR_BLOCK_SIZE]);
+      }
+      const uint64_t at = base + r[i];
+      if (a.width == 4) static_cast<uint32_t*>(a.values)[at] = is_null ? 0u : static_cast<uint32_t>(word);
+      else static_cast<uint64_t*>(a.values)[at] = is_null ? 0ull : word;
+      if (a.nulls) a.nulls[at] = is_null ? 1 : 0;
+    }
+  }
+}
+
 // ---- hash repartition ------------------------------------------------------------------------------------------------------
 constexpr uint32_t MAX_PARTS = 16;
 struct RepartitionArgs {
@@ -178,6 +252,35 @@ __global__ __launch_bounds__(256) void gather_row_ids(const hy_row_id* table, ui
   }
 }
 
+// The same, four positions per thread and step as two 16-byte loads and stores (both arrays on 16-byte boundaries): 36 M positions of an
+// SSB join result took 275 us one RowID at a time -- 2.1 TB/s for an access pattern that is two streams and a small table.
+typedef uint32_t gather_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gather_row_ids_wide(const hy_row_id* table, uint64_t table_rows, uint32_t chunk_rows, const hy_row_id* positions, uint64_t n, hy_row_id* out) {
+  const gather_u32x4* in = reinterpret_cast<const gather_u32x4*>(positions);
+  gather_u32x4* wide_out = reinterpret_cast<gather_u32x4*>(out);
+  const uint64_t n_vectors = n / 2;
+  auto lookup = [&](uint32_t chunk_id, uint32_t chunk_offset) -> hy_row_id {
+    hy_row_id r{0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (chunk_offset != 0xFFFFFFFFu) {
+      const uint64_t at = static_cast<uint64_t>(chunk_id) * chunk_rows + chunk_offset;
+      if (at < table_rows) r = table[at];
+    }
+    return r;
+  };
+  for (uint64_t v = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * 2; v < n_vectors; v += static_cast<uint64_t>(gridDim.x) * 512) {
+    const bool second = v + 1 < n_vectors;
+    const gather_u32x4 p0 = __builtin_nontemporal_load(in + v);
+    const gather_u32x4 p1 = second ? __builtin_nontemporal_load(in + v + 1) : gather_u32x4{0, 0xFFFFFFFFu, 0, 0xFFFFFFFFu};
+    const hy_row_id a0 = lookup(p0.x, p0.y), a1 = lookup(p0.z, p0.w), b0 = lookup(p1.x, p1.y), b1 = lookup(p1.z, p1.w);
+    __builtin_nontemporal_store(gather_u32x4{a0.chunk_id, a0.chunk_offset, a1.chunk_id, a1.chunk_offset}, wide_out + v);
+    if (second) __builtin_nontemporal_store(gather_u32x4{b0.chunk_id, b0.chunk_offset, b1.chunk_id, b1.chunk_offset}, wide_out + v + 1);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+    const hy_row_id p = positions[n - 1];
+    out[n - 1] = lookup(p.chunk_id, p.chunk_offset);
+  }
+}
+
 }  // namespace hy
 
 using namespace hy;
@@ -201,7 +304,8 @@ hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls
   a.nulls = nulls;
   a.width = (column->data_type == HY_TYPE_INT || column->data_type == HY_TYPE_FLOAT) ? 4 : 8;
   a.is_float = (column->data_type == HY_TYPE_FLOAT || column->data_type == HY_TYPE_DOUBLE) ? 1 : 0;
-  hipLaunchKernelGGL(export_rows, dim3(column->n_slices), dim3(256), 0, stream, a);
+  if (column->is_reference) hipLaunchKernelGGL(export_reference_rows, dim3(column->n_slices), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(export_rows, dim3(column->n_slices), dim3(256), 0, stream, a);
   HY_HIP(hipGetLastError());
   return HY_OK;
 }
@@ -279,8 +383,10 @@ hy_status hy_gather_row_ids(const hy_row_id* table, uint64_t table_rows, uint32_
   // (an empty table -- a rank that received no tuples of the other side -- has no buffer: every position then is out of range and yields the NULL RowID)
   if (n && ((!table && table_rows) || !positions || !out || !chunk_rows)) return fail(HY_ERR_INVALID, "hy_gather_row_ids: null argument");
   if (!n) return HY_OK;
-  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 16384));
-  hipLaunchKernelGGL(gather_row_ids, dim3(grid), dim3(256), 0, current_stream(), table, table_rows, chunk_rows, positions, n, out);
+  const bool wide = n >= 4096 && reinterpret_cast<uintptr_t>(positions) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n / (wide ? 4 : 1) + 255) / 256, 16384));
+  if (wide) hipLaunchKernelGGL(gather_row_ids_wide, dim3(grid), dim3(256), 0, current_stream(), table, table_rows, chunk_rows, positions, n, out);
+  else hipLaunchKernelGGL(gather_row_ids, dim3(grid), dim3(256), 0, current_stream(), table, table_rows, chunk_rows, positions, n, out);
   HY_HIP(hipGetLastError());
   return HY_OK;
 }

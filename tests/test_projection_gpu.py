@@ -146,3 +146,64 @@ def test_plain_operands_all_type_pairs(device):
     chained = projection_arithmetic(abi.ARITH_MUL, devs[abi.TYPE_DOUBLE], one_minus)
     inner_values, _ = oracle_arithmetic(abi.ARITH_SUB, (abi.TYPE_INT, 1), (raw[abi.TYPE_FLOAT], None))
     assert_same(chained, oracle_arithmetic(abi.ARITH_MUL, (raw[abi.TYPE_DOUBLE], None), (inner_values, None)), "chained plain projections")
+
+
+@pytest.mark.parametrize("np_type", [np.int32, np.int64, np.float32, np.float64], ids=lambda t: t.__name__)
+def test_export_through_pos_lists(device, np_type):
+    """hy_column_export of a reference column (the foreign key of a join result, materialised for the next join): PosLists over several
+    chunks in random order with NULL RowIDs, and an EntireChunk / single-chunk PosList per chunk (scan output), over Unencoded /
+    Dictionary / FrameOfReference base segments with NULLs -- the values and NULL bytes of the referenced cells."""
+    import torch
+    from hyrise_amd.distributed import DevicePosLists, HipExecutor
+    rng = np.random.default_rng(5)
+    n, chunk = 200_000, 30_000
+    values = (rng.integers(-5000, 5000, n) if np.issubdtype(np_type, np.integer) else rng.random(n) * 1000 - 500).astype(np_type)
+    nulls = rng.random(n) < 0.05
+    encodings = [abi.ENC_UNENCODED, abi.ENC_DICTIONARY, abi.ENC_FRAME_OF_REFERENCE, abi.ENC_DICTIONARY, abi.ENC_UNENCODED, abi.ENC_FRAME_OF_REFERENCE, abi.ENC_DICTIONARY]
+    ex = HipExecutor(torch.device("cuda", 0))
+    for with_nulls in (False, True):
+        base = DeviceColumn(build_column(values, nulls if with_nulls else None, chunk, encodings))
+        picks = rng.integers(0, n, 500_000)
+        rows = np.stack([picks // chunk, picks % chunk], axis=1).astype(np.uint32)
+        null_rows = rng.random(len(picks)) < 0.01
+        rows[null_rows] = 0xFFFFFFFF                                   # NULL_ROW_ID (outer joins)
+        through = ex.reference_column(base, torch.from_numpy(rows.view(np.int32)).to("cuda"), 65535)
+        got_values, got_nulls = ex.export(through)
+        want_null = null_rows | (nulls[picks] if with_nulls else False)
+        np.testing.assert_array_equal(got_nulls.cpu().numpy().astype(bool), want_null)
+        want = np.where(want_null, np_type(0), values[picks])
+        assert got_values.cpu().numpy().tobytes() == want.astype(np_type).tobytes()
+        # one PosList per base chunk (what a scan hands on): every second row of the chunk, the last chunk whole
+        counts = [(min(n, (c + 1) * chunk) - c * chunk + 1) // 2 for c in range((n + chunk - 1) // chunk)]
+        offsets = np.concatenate([np.arange(0, min(n, (c + 1) * chunk) - c * chunk, 2) for c in range(len(counts))])
+        chunk_ids = np.concatenate([np.full(count, c) for c, count in enumerate(counts)])
+        lists = np.stack([chunk_ids, offsets], axis=1).astype(np.uint32)
+        begin = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        pos_lists = DevicePosLists(torch.from_numpy(lists.view(np.int32)).to("cuda"), begin, np.array(counts), np.arange(len(counts)))
+        chunked = ex.reference_column_chunked(base, pos_lists)
+        got_values, got_nulls = ex.export(chunked)
+        flat = chunk_ids.astype(np.int64) * chunk + offsets
+        want_null = nulls[flat] if with_nulls else np.zeros(len(flat), dtype=bool)
+        np.testing.assert_array_equal(got_nulls.cpu().numpy().astype(bool), want_null)
+        assert got_values.cpu().numpy().tobytes() == np.where(want_null, np_type(0), values[flat]).astype(np_type).tobytes()
+
+
+@pytest.mark.parametrize("n", [0, 1, 4095, 100_001, 1_000_000])
+def test_gather_row_ids(device, n):
+    """hy_gather_row_ids: positions (chunk, offset) of a table of RowIDs presented in chunks -> the RowIDs there; NULL positions and
+    positions past the table give the NULL RowID.  Small and odd counts (one RowID per thread) and large ones (four per thread)."""
+    import torch
+    from hyrise_amd.distributed import HipExecutor
+    rng = np.random.default_rng(n)
+    ex = HipExecutor(torch.device("cuda", 0))
+    table_rows, chunk_rows = 70_001, 65_536
+    table = rng.integers(0, 1 << 31, (table_rows, 2)).astype(np.int32)
+    flat = rng.integers(0, table_rows + 500, n)                       # (some past the end)
+    positions = np.stack([flat // chunk_rows, flat % chunk_rows], axis=1).astype(np.uint32)
+    null_positions = rng.random(n) < 0.02
+    positions[null_positions] = 0xFFFFFFFF
+    got = ex.gather_row_ids(torch.from_numpy(table).to("cuda"), chunk_rows, torch.from_numpy(positions.view(np.int32)).to("cuda")).cpu().numpy()
+    want = np.full((n, 2), -1, dtype=np.int32)
+    ok = ~null_positions & (flat < table_rows)
+    want[ok] = table[flat[ok]]
+    np.testing.assert_array_equal(got.reshape(n, 2), want)
