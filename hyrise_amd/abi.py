@@ -136,6 +136,22 @@ class AggregateResult(C.Structure):
                 ("reserved", C.c_uint32), ("group_row_ids", C.c_void_p), ("columns", C.POINTER(AggregateColumn))]
 
 
+STAR_NO_OP = 0xFFFFFFFF
+MAX_STAR_DIMENSIONS, MAX_STAR_AGGREGATES = 8, 8
+
+
+class StarDimension(C.Structure):
+    _fields_ = [("key", C.c_void_p), ("filter_column", C.c_void_p), ("predicate", Predicate), ("fact_key", C.c_void_p)]
+
+
+class StarColumn(C.Structure):
+    _fields_ = [("table", C.c_uint32), ("reserved", C.c_uint32), ("column", C.c_void_p)]
+
+
+class StarAggregate(C.Structure):
+    _fields_ = [("function", C.c_uint32), ("op", C.c_uint32), ("left", StarColumn), ("right", StarColumn)]
+
+
 # every symbol include/hyrise_amd.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("hy_abi_version", C.c_int32, []),
@@ -187,6 +203,8 @@ SYMBOLS = [
     ("hy_join_hash_count", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("hy_aggregate_hash", C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(AggregateSpec), C.c_uint32,
                                       C.POINTER(AggregateResult)]),
+    ("hy_star_join_aggregate", C.c_int32, [C.POINTER(StarDimension), C.c_uint32, C.POINTER(StarColumn), C.c_uint32, C.POINTER(StarAggregate), C.c_uint32,
+                                           C.POINTER(AggregateResult), C.POINTER(C.c_uint64)]),
     ("hy_scan_project_aggregate", C.c_int32, [C.POINTER(Filter), C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(FusedAggregate), C.c_uint32,
                                               C.POINTER(AggregateResult)]),
     ("hy_column_export", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,0 +1,269 @@
+// plan.hip -- a star join as ONE call over the operator entry points (BASELINE.json configs[4]: the SSB star joins).
+//
+// Hyrise runs such a query as an operator tree: a TableScan per filtered dimension, one JoinHash per dimension with the filtered dimension as
+// build side and the join result so far as probe side, a Projection for the aggregates' expressions, an AggregateHash.  Between the
+// operators the reference hands reference tables on (PosLists); here the intermediates stay in HBM, and this function is the adapter's
+// plan for that shape: nothing but calls of hy_table_scan / hy_poslist_translate / hy_column_create / hy_column_export / hy_join_hash /
+// hy_gather_row_ids / hy_projection_arithmetic / hy_aggregate_hash, in the order hyrise_amd/ssb.py run_query makes them -- without an
+// interpreter, a tensor allocation and a ctypes marshalling between two of them (a quarter of an SSB query was idle device between
+// operator calls).  Intermediates are presented to the next operator as tables of DENSE_CHUNK rows:
+//   * a filtered dimension's keys, the foreign keys of the join result and the columns the aggregate reads are MATERIALISED
+//     (hy_column_export through the PosLists: JoinHash materialises its inputs anyway, join_hash_steps.hpp:274-330) into plain value
+//     columns, which the primary-key / foreign-key join kernels and the aggregate's streaming decoders read with wide loads;
+//   * per joined table the base RowIDs of every surviving row are carried along (hy_gather_row_ids with the probe positions).
+#include "hy_device.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+namespace hy {
+
+constexpr uint32_t DENSE_CHUNK = 65536;   // rows per chunk of an intermediate table (chunks start on 16-byte boundaries for every type)
+
+struct ColumnHandle {   // an hy_column this plan created
+  hy_column* column = nullptr;
+  ColumnHandle() = default;
+  ColumnHandle(const ColumnHandle&) = delete;
+  ColumnHandle& operator=(const ColumnHandle&) = delete;
+  ~ColumnHandle() { reset(); }
+  void reset() { if (column) (void)hy_column_destroy(column); column = nullptr; }
+};
+
+static size_t type_bytes(uint32_t data_type) { return (data_type == HY_TYPE_INT || data_type == HY_TYPE_FLOAT) ? 4 : 8; }
+
+// `rows` RowIDs into the data column `base`, presented as ReferenceSegments of DENSE_CHUNK rows (read in place)
+static hy_status reference_column(const hy_column* base, const hy_row_id* rows, uint64_t n, ColumnHandle& out) {
+  const uint32_t n_chunks = static_cast<uint32_t>(std::max<uint64_t>(1, (n + DENSE_CHUNK - 1) / DENSE_CHUNK));
+  std::vector<hy_segment> segments(n_chunks);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    hy_segment& s = segments[c];
+    std::memset(&s, 0, sizeof(s));
+    const uint64_t begin = uint64_t{c} * DENSE_CHUNK, end = std::min<uint64_t>(n, begin + DENSE_CHUNK);
+    s.encoding = HY_ENC_REFERENCE;
+    s.data_type = base->data_type;
+    s.size = static_cast<uint32_t>(end > begin ? end - begin : 0);
+    s.width = 8;
+    s.data = rows + begin;
+    s.ref = base;
+    s.ref_chunk_id = 0xFFFFFFFFu;
+  }
+  return hy_column_create(segments.data(), n_chunks, HY_MEM_DEVICE, &out.column);
+}
+
+// `values` (n elements of `data_type`, device memory, no NULLs) as ValueSegments of DENSE_CHUNK rows
+static hy_status value_column(const void* values, uint64_t n, uint32_t data_type, ColumnHandle& out) {
+  const uint32_t n_chunks = static_cast<uint32_t>(std::max<uint64_t>(1, (n + DENSE_CHUNK - 1) / DENSE_CHUNK));
+  const size_t width = type_bytes(data_type);
+  std::vector<hy_segment> segments(n_chunks);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    hy_segment& s = segments[c];
+    std::memset(&s, 0, sizeof(s));
+    const uint64_t begin = uint64_t{c} * DENSE_CHUNK, end = std::min<uint64_t>(n, begin + DENSE_CHUNK);
+    s.encoding = HY_ENC_UNENCODED;
+    s.data_type = data_type;
+    s.size = static_cast<uint32_t>(end > begin ? end - begin : 0);
+    s.width = static_cast<uint32_t>(width);
+    s.data = static_cast<const char*>(values) + begin * width;
+    s.ref_chunk_id = 0xFFFFFFFFu;
+  }
+  return hy_column_create(segments.data(), n_chunks, HY_MEM_DEVICE, &out.column);
+}
+
+// column `base` at the rows `rows` as a plain value column (values in `storage`)
+static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint64_t n, DeviceBuffer& storage, ColumnHandle& out) {
+  if (base->data_type < HY_TYPE_INT || base->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "hy_star_join_aggregate: numeric columns only");
+  HY_TRY(storage.alloc(type_bytes(base->data_type) * std::max<uint64_t>(n, 1) + 16));
+  if (n) {
+    ColumnHandle through;
+    HY_TRY(reference_column(base, rows, n, through));
+    HY_TRY(hy_column_export(through.column, storage.ptr, nullptr));
+  }
+  return value_column(storage.ptr, n, base->data_type, out);
+}
+
+// The rows of `filter_column` that satisfy the predicate, as one dense PosList in device memory
+static hy_status filtered_rows(const hy_column* filter_column, const hy_predicate* predicate, DeviceBuffer& rows, uint64_t* n_rows) {
+  DeviceBuffer regions, offsets, counts;
+  const uint64_t capacity = std::max<uint64_t>(1, filter_column->rows);
+  HY_TRY(regions.alloc(sizeof(hy_row_id) * capacity));
+  HY_TRY(offsets.alloc(8 * (size_t{filter_column->n_chunks} + 1)));
+  HY_TRY(counts.alloc(4 * std::max<size_t>(1, filter_column->n_chunks)));
+  HY_TRY(rows.alloc(sizeof(hy_row_id) * capacity));
+  hy_scan_result scan;
+  std::memset(&scan, 0, sizeof(scan));
+  scan.mem = HY_MEM_DEVICE;
+  scan.flags = HY_SCAN_CHUNK_REGIONS | HY_SCAN_MATERIALIZE_ALL_MATCH;
+  scan.matches = regions.as<hy_row_id>();
+  scan.capacity = capacity;
+  scan.offsets = offsets.as<uint64_t>();
+  scan.counts = counts.as<uint32_t>();
+  HY_TRY(hy_table_scan(filter_column, predicate, nullptr, 0, &scan));
+  return hy_poslist_translate(filter_column, &scan, HY_POSLIST_DENSE, rows.as<hy_row_id>(), capacity, n_rows);
+}
+
+struct JoinOutput {
+  DeviceBuffer arena, slice_offsets;
+  hy_row_id* left = nullptr;
+  hy_row_id* right = nullptr;
+  uint64_t n_pairs = 0;
+};
+
+// build x probe (Inner), PosLists in device memory: both from one allocation, the second 1.25 MiB past a 2 MiB boundary
+static hy_status join_inner(const hy_column* build, const hy_column* probe, JoinOutput& out) {
+  constexpr size_t PERIOD = size_t{2} << 20, OFFSET = size_t{5} << 18;
+  uint64_t capacity = std::max<uint64_t>({1, build->rows, probe->rows});
+  const uint64_t slice_capacity = std::max(build->rows, probe->rows) / 131070 + std::max(build->n_chunks, probe->n_chunks) + 600;
+  HY_TRY(out.slice_offsets.alloc(8 * (slice_capacity + 2)));
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t list_bytes = sizeof(hy_row_id) * capacity;
+    HY_TRY(out.arena.alloc(2 * list_bytes + 3 * PERIOD));
+    char* base = out.arena.as<char>();
+    char* first = base + (PERIOD - reinterpret_cast<uintptr_t>(base) % PERIOD) % PERIOD;
+    char* second = first + (list_bytes + PERIOD - 1) / PERIOD * PERIOD + OFFSET;
+    out.left = reinterpret_cast<hy_row_id*>(first);
+    out.right = reinterpret_cast<hy_row_id*>(second);
+    hy_join_result r;
+    std::memset(&r, 0, sizeof(r));
+    r.mem = HY_MEM_DEVICE;
+    r.radix_bits = 0xFFFFFFFFu;
+    r.left_pos = out.left;
+    r.right_pos = out.right;
+    r.capacity = capacity;
+    r.slice_offsets = out.slice_offsets.as<uint64_t>();
+    r.slice_capacity = slice_capacity;
+    const hy_status status = hy_join_hash(build, probe, HY_JOIN_INNER, &r);
+    if (status == HY_ERR_CAPACITY && attempt == 0 && r.n_pairs > capacity) { capacity = r.n_pairs; continue; }
+    HY_TRY(status);
+    out.n_pairs = r.n_pairs;
+    return HY_OK;
+  }
+  return fail(HY_ERR_CAPACITY, "hy_star_join_aggregate: a join did not fit the capacity it asked for");
+}
+
+}  // namespace hy
+
+using namespace hy;
+
+extern "C" {
+
+hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n_dimensions, const hy_star_column* groupby, uint32_t n_groupby,
+                                 const hy_star_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result, uint64_t* joined_rows) {
+  if (!dimensions || !n_dimensions || n_dimensions > HY_MAX_STAR_DIMENSIONS) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: 1 .. %d dimensions", static_cast<int>(HY_MAX_STAR_DIMENSIONS));
+  if ((n_groupby && !groupby) || (n_aggregates && !aggregates) || !result) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: null argument");
+  if (n_aggregates > HY_MAX_STAR_AGGREGATES || n_groupby > HY_MAX_STAR_AGGREGATES) return fail(HY_ERR_UNSUPPORTED, "hy_star_join_aggregate: at most %d GROUP BY columns / aggregates", static_cast<int>(HY_MAX_STAR_AGGREGATES));
+  auto table_ok = [&](const hy_star_column& c) { return c.column != nullptr && c.table <= n_dimensions; };
+  for (uint32_t g = 0; g < n_groupby; ++g) if (!table_ok(groupby[g])) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: GROUP BY column %u names no table of the join", g);
+  for (uint32_t a = 0; a < n_aggregates; ++a) {
+    const hy_star_aggregate& spec = aggregates[a];
+    if (spec.left.column && !table_ok(spec.left)) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: aggregate %u names no table of the join", a);
+    if (spec.op != HY_STAR_NO_OP && (!spec.left.column || !table_ok(spec.right))) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: aggregate %u: an expression needs two columns", a);
+  }
+  for (uint32_t d = 0; d < n_dimensions; ++d) {
+    if (!dimensions[d].key || !dimensions[d].fact_key) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: dimension %u: key columns missing", d);
+    HY_TRY(on_this_device(dimensions[d].key, "hy_star_join_aggregate"));
+    HY_TRY(on_this_device(dimensions[d].fact_key, "hy_star_join_aggregate"));
+  }
+
+  // carried[t]: base RowIDs of table t (0 = the fact table, d + 1 = dimension d) per row of the join result so far
+  std::vector<std::unique_ptr<DeviceBuffer>> carried(n_dimensions + 1);
+  std::vector<const hy_row_id*> carried_rows(n_dimensions + 1, nullptr);
+  std::vector<std::unique_ptr<JoinOutput>> joins;   // (the PosLists a carried pointer may still point into)
+  uint64_t n_rows = 0;
+  for (uint32_t d = 0; d < n_dimensions; ++d) {
+    const hy_star_dimension& dimension = dimensions[d];
+    // build side: the dimension's keys, of the rows that pass its filter
+    DeviceBuffer dimension_rows, build_keys;
+    uint64_t n_dimension_rows = 0;
+    ColumnHandle build;
+    const hy_column* build_column = dimension.key;
+    if (dimension.filter_column) {
+      HY_TRY(filtered_rows(dimension.filter_column, &dimension.predicate, dimension_rows, &n_dimension_rows));
+      HY_TRY(materialise(dimension.key, dimension_rows.as<hy_row_id>(), n_dimension_rows, build_keys, build));
+      build_column = build.column;
+    }
+    // probe side: the fact table's foreign key, of the rows still in the join
+    DeviceBuffer probe_keys;
+    ColumnHandle probe;
+    const hy_column* probe_column = dimension.fact_key;
+    if (d > 0) {
+      HY_TRY(materialise(dimension.fact_key, carried_rows[0], n_rows, probe_keys, probe));
+      probe_column = probe.column;
+    }
+    joins.push_back(std::make_unique<JoinOutput>());
+    JoinOutput& join = *joins.back();
+    HY_TRY(join_inner(build_column, probe_column, join));
+    const uint64_t n_pairs = join.n_pairs;
+    // what every surviving row is made of
+    std::vector<std::unique_ptr<DeviceBuffer>> next(n_dimensions + 1);
+    std::vector<const hy_row_id*> next_rows(n_dimensions + 1, nullptr);
+    if (d == 0) next_rows[0] = join.right;   // (positions in the fact table ARE its RowIDs: the probe column is the data column)
+    for (uint32_t t = 0; t <= d; ++t) {
+      if (d == 0 || (t > 0 && !carried_rows[t])) continue;
+      next[t] = std::make_unique<DeviceBuffer>();
+      HY_TRY(next[t]->alloc(sizeof(hy_row_id) * std::max<uint64_t>(1, n_pairs)));
+      HY_TRY(hy_gather_row_ids(carried_rows[t], n_rows, DENSE_CHUNK, join.right, n_pairs, next[t]->as<hy_row_id>()));
+      next_rows[t] = next[t]->as<hy_row_id>();
+    }
+    if (dimension.filter_column) {
+      next[d + 1] = std::make_unique<DeviceBuffer>();
+      HY_TRY(next[d + 1]->alloc(sizeof(hy_row_id) * std::max<uint64_t>(1, n_pairs)));
+      HY_TRY(hy_gather_row_ids(dimension_rows.as<hy_row_id>(), n_dimension_rows, DENSE_CHUNK, join.left, n_pairs, next[d + 1]->as<hy_row_id>()));
+      next_rows[d + 1] = next[d + 1]->as<hy_row_id>();
+    } else next_rows[d + 1] = join.left;   // (an unfiltered dimension is joined as the data column itself)
+    // The kernels that read this round's inputs are queued on this thread's stream; the buffers released here go back to its pool and are
+    // handed out again in stream order.
+    carried.swap(next);
+    carried_rows.swap(next_rows);
+    n_rows = n_pairs;
+    // join outputs nobody points into any more
+    for (auto& earlier : joins) {
+      if (!earlier) continue;
+      bool used = false;
+      for (const hy_row_id* rows : carried_rows) used = used || rows == earlier->left || rows == earlier->right;
+      if (!used) earlier.reset();
+    }
+  }
+  if (joined_rows) *joined_rows = n_rows;
+
+  // the columns the aggregate reads, materialised at the surviving rows (each (table, column) once)
+  struct Output { hy_star_column source; DeviceBuffer values; ColumnHandle column; };
+  std::vector<std::unique_ptr<Output>> outputs;
+  auto output_of = [&](const hy_star_column& source, const hy_column** column) -> hy_status {
+    for (auto& o : outputs) if (o->source.table == source.table && o->source.column == source.column) { *column = o->column.column; return HY_OK; }
+    outputs.push_back(std::make_unique<Output>());
+    Output& o = *outputs.back();
+    o.source = source;
+    if (!carried_rows[source.table]) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: no rows carried for table %u (internal error)", source.table);
+    HY_TRY(materialise(source.column, carried_rows[source.table], n_rows, o.values, o.column));
+    *column = o.column.column;
+    return HY_OK;
+  };
+  std::vector<const hy_column*> groupby_columns(n_groupby ? n_groupby : 1, nullptr);
+  for (uint32_t g = 0; g < n_groupby; ++g) HY_TRY(output_of(groupby[g], &groupby_columns[g]));
+  std::vector<hy_aggregate_spec> specs(n_aggregates ? n_aggregates : 1);
+  std::vector<std::unique_ptr<ColumnHandle>> expressions;
+  for (uint32_t a = 0; a < n_aggregates; ++a) {
+    specs[a].function = aggregates[a].function;
+    specs[a].column = nullptr;
+    if (!aggregates[a].left.column) continue;   // COUNT(*)
+    const hy_column* left = nullptr;
+    HY_TRY(output_of(aggregates[a].left, &left));
+    if (aggregates[a].op == HY_STAR_NO_OP) { specs[a].column = left; continue; }
+    const hy_column* right = nullptr;
+    HY_TRY(output_of(aggregates[a].right, &right));
+    hy_operand l, r;
+    std::memset(&l, 0, sizeof(l));
+    std::memset(&r, 0, sizeof(r));
+    l.column = left;
+    r.column = right;
+    expressions.push_back(std::make_unique<ColumnHandle>());
+    HY_TRY(hy_projection_arithmetic(aggregates[a].op, &l, &r, &expressions.back()->column));
+    specs[a].column = expressions.back()->column;
+  }
+  if (n_groupby == 0 && n_aggregates == 0) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: nothing to aggregate");
+  return hy_aggregate_hash(groupby_columns.data(), n_groupby, specs.data(), n_aggregates, result);
+}
+
+}  // extern "C"

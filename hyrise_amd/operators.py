@@ -353,6 +353,35 @@ def aggregate_hash(groupby_columns, aggregates, group_capacity=None, result=None
     return result
 
 
+def star_join_aggregate(dimensions, groupby, aggregates, group_capacity=4096, result=None):
+    """hy_star_join_aggregate: the star join fact x dimensions -> GROUP BY -> aggregates as one call (csrc/plan.hip).
+    dimensions: [(key column, filter column or None, predicate or None, fact foreign-key column)]; groupby: [(table, column)] with table 0 =
+    the fact table, d + 1 = dimension d; aggregates: [(function, (table, column) or None for COUNT(*), op or None, (table, column) or None)].
+    -> (HostAggregateResult, rows of the join result)"""
+    lib = abi.load_library()
+    dims = (abi.StarDimension * len(dimensions))()
+    for d, (key, filter_column, predicate, fact_key) in enumerate(dimensions):
+        dims[d].key, dims[d].fact_key = key.handle, fact_key.handle
+        dims[d].filter_column = filter_column.handle if filter_column is not None else None
+        if predicate is not None:
+            dims[d].predicate = predicate
+    groups = (abi.StarColumn * max(1, len(groupby)))()
+    for g, (table, column) in enumerate(groupby):
+        groups[g].table, groups[g].column = table, column.handle
+    specs = (abi.StarAggregate * max(1, len(aggregates)))()
+    for a, (function, left, op, right) in enumerate(aggregates):
+        specs[a].function, specs[a].op = function, abi.STAR_NO_OP if op is None else op
+        if left is not None:
+            specs[a].left.table, specs[a].left.column = left[0], left[1].handle
+        if right is not None:
+            specs[a].right.table, specs[a].right.column = right[0], right[1].handle
+    if result is None:
+        result = HostAggregateResult(len(aggregates), group_capacity)
+    joined = C.c_uint64(0)
+    abi.check(lib.hy_star_join_aggregate(dims, len(dimensions), groups, len(groupby), specs, len(aggregates), C.byref(result.c), C.byref(joined)))
+    return result, int(joined.value)
+
+
 def expression(tree):
     """An arithmetic expression as hy_expression (postfix).  tree: a column (DeviceColumn), a literal (HY_TYPE_*, value), None (the
     NULL literal) or (abi.ARITH_*, left tree, right tree)."""

@@ -215,6 +215,36 @@ def run_query(ex, columns, query, fact_first_chunk=0, comm=None, repartitioned=(
     return [through("d_year", "date"), through("c_nation", "customer")], [(abi.AGG_SUM, profit)], joined
 
 
+def star_plan(columns, query):
+    """The same two queries as arguments of hy_star_join_aggregate (operators.star_join_aggregate): the plan of run_query + the aggregate
+    made by ONE call of the library (csrc/plan.hip) -- single GPU, every dimension against its full replica."""
+    from .operators import make_predicate
+    if query == "2.1":
+        dimensions = [(columns["p_partkey"], columns["p_category"], make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, 12), columns["lo_partkey"]),
+                      (columns["s_suppkey"], columns["s_region"], make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, AMERICA), columns["lo_suppkey"]),
+                      (columns["d_datekey"], None, None, columns["lo_orderdate"])]
+        groupby = [(3, columns["d_year"]), (1, columns["p_brand1"])]
+        return dimensions, groupby, [(abi.AGG_SUM, (0, columns["lo_revenue"]), None, None)] + [(abi.AGG_MIN, g, None, None) for g in groupby]
+    if query == "4.1":
+        dimensions = [(columns["s_suppkey"], columns["s_region"], make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, AMERICA), columns["lo_suppkey"]),
+                      (columns["c_custkey"], columns["c_region"], make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, AMERICA), columns["lo_custkey"]),
+                      (columns["p_partkey"], columns["p_mfgr"], make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_INT, 1, 2), columns["lo_partkey"]),
+                      (columns["d_datekey"], None, None, columns["lo_orderdate"])]
+        groupby = [(4, columns["d_year"]), (2, columns["c_nation"])]
+        return dimensions, groupby, [(abi.AGG_SUM, (0, columns["lo_revenue"]), abi.ARITH_SUB, (0, columns["lo_supplycost"]))] + [(abi.AGG_MIN, g, None, None) for g in groupby]
+    raise ValueError(query)
+
+
+def star_groups(result, n_groupby_columns):
+    """hy_star_join_aggregate's result in the shape aggregate_groups returns: [(key tuple, [aggregate cells])].  The result names
+    representative rows of an intermediate table the caller never sees, so star_plan asks for the GROUP BY values as MIN() aggregates of
+    the columns themselves (the last n_groupby_columns result columns)."""
+    n_cells = len(result.raw) - n_groupby_columns
+    keys = [result.column(n_cells + g) for g in range(n_groupby_columns)]
+    cells = [result.column(a) for a in range(n_cells)]
+    return [(tuple(int(k[i]) for k in keys), [c[i] for c in cells]) for i in range(result.n_groups)]
+
+
 def referenced_bytes(data, query):
     """Algorithmic bytes: referenced lineorder columns x 4 B x N + dimension keys + filter columns."""
     fact = {"2.1": 4, "4.1": 6}[query]   # lo_partkey, lo_suppkey, lo_orderdate, lo_revenue (+ lo_custkey, lo_supplycost)
@@ -288,6 +318,27 @@ def bench(sf=30.0, steps=3, world=1, rank=0, dist=None, share_gpu=False, local_r
         algorithmic = referenced_bytes(data, query)
         entry = {"ms": seconds * 1e3, "lineorder_rows_per_s": data.n_lineorder / seconds, "joined_rows": joined, "groups": len(holder["groups"]),
                  "algorithmic_bytes": algorithmic, "GBps_on_algorithmic_bytes": algorithmic / seconds / 1e9}
+        if comm is None:   # the same plan made by ONE call of the library (hy_star_join_aggregate): no interpreter between the operator calls
+            from .operators import star_join_aggregate
+            dimensions, star_groupby, star_aggregates = star_plan(columns, query)
+            star = {}
+
+            def one_call():
+                star["result"], star["joined"] = star_join_aggregate(dimensions, star_groupby, star_aggregates, result=star.get("result"))
+
+            one_call()
+            if result_rows(star_groups(star["result"], len(star_groupby))) != result_rows(holder["groups"]) or star["joined"] != joined:
+                raise RuntimeError(f"SSB Q{query}: hy_star_join_aggregate and the operator chain disagree")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one_call()
+            torch.cuda.synchronize()
+            star_seconds = (time.perf_counter() - t0) / steps
+            entry["operator_calls_from_python_ms"] = entry["ms"]
+            entry.update({"ms": star_seconds * 1e3, "lineorder_rows_per_s": data.n_lineorder / star_seconds, "GBps_on_algorithmic_bytes": algorithmic / star_seconds / 1e9,
+                          "plan": "hy_star_join_aggregate: scan -> JoinHash per dimension -> projection -> AggregateHash as one call of the library (csrc/plan.hip); "
+                                  "operator_calls_from_python_ms: the same calls made one by one through ctypes (hyrise_amd/ssb.py run_query)"})
         if comm is not None:   # the same query with `customer` / `part` joined by hash repartition (tuples to the key's rank and back)
             entry["plan"] = "lineorder chunk-sharded, dimensions replicated, groups all-reduced"
             try:

@@ -554,6 +554,37 @@ typedef struct hy_fused_aggregate {
 hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
                                     const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
 
+/* ---- a star join as one call (BASELINE.json configs[4], the SSB star joins; csrc/plan.hip) ------------------------------------
+ * The operator tree Hyrise runs for   fact JOIN dim_1 ... JOIN dim_k  GROUP BY ...  -- a TableScan per filtered dimension, one JoinHash
+ * per dimension (the filtered dimension as build side, the join result so far as probe side, in the order given), a Projection for
+ * the aggregates' arithmetic, an AggregateHash -- made by ONE function: exactly the calls of the entry points above an adapter would
+ * make (hy_table_scan, hy_poslist_translate, hy_column_create, hy_column_export, hy_join_hash, hy_gather_row_ids,
+ * hy_projection_arithmetic, hy_aggregate_hash), with every intermediate in device memory and no interpreter between them.  No
+ * counterpart in the reference (its scheduler runs the operators one by one); results are those of the operator chain.
+ * Columns are named as (table, column): table 0 = the fact table, d + 1 = dimension d; every column is a DATA column (numeric, or a
+ * dictionary of key names / join ids) of its table.  An aggregate reads `left` alone (op = HY_STAR_NO_OP), `left <op> right`
+ * (HY_ARITH_*: hy_projection_arithmetic), or nothing (left.column = NULL: COUNT(*)).  *joined_rows: rows of the join result. */
+enum { HY_MAX_STAR_DIMENSIONS = 8, HY_MAX_STAR_AGGREGATES = 8 };
+#define HY_STAR_NO_OP 0xFFFFFFFFu
+typedef struct hy_star_dimension {
+  const hy_column* key;            /* the dimension's key column: the build side of its join                                     */
+  const hy_column* filter_column;  /* a column of the dimension that `predicate` tests; NULL: the dimension is not filtered        */
+  hy_predicate predicate;
+  const hy_column* fact_key;       /* the fact table's foreign key to this dimension                                             */
+} hy_star_dimension;
+typedef struct hy_star_column {
+  uint32_t table;                  /* 0 = the fact table, d + 1 = dimension d                                                    */
+  uint32_t reserved;
+  const hy_column* column;
+} hy_star_column;
+typedef struct hy_star_aggregate {
+  uint32_t function;               /* HY_AGG_*                                                                                   */
+  uint32_t op;                     /* HY_STAR_NO_OP or HY_ARITH_*                                                                */
+  hy_star_column left, right;
+} hy_star_aggregate;
+hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n_dimensions, const hy_star_column* groupby, uint32_t n_groupby,
+                                 const hy_star_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result, uint64_t* joined_rows);
+
 /* ---- multi-GPU exchange (the reference is one process: these have no counterpart there) ----------------
  * Sharding an operator over GPUs adds one exchange step per operator (hyrise_amd/distributed.py: one process per GPU, RCCL):
  * the broadcast-build JoinHash all-gathers the build side's join column, the repartitioned JoinHash sends every (key, RowID)

@@ -28,6 +28,11 @@ def test_ssb_query_on_device(device, query, sql):
     else:
         sqlite = sorted(((year, nation), profit) for year, nation, profit in data.sqlite_result(sql))
     assert got == sqlite
+    # the same query as ONE call of the library (hy_star_join_aggregate, csrc/plan.hip): the rows and the size of the join result
+    from hyrise_amd.operators import star_join_aggregate
+    dimensions, star_groupby, star_aggregates = ssb.star_plan(columns, query)
+    result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
+    assert star_joined == joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == sqlite
 
 
 @pytest.mark.timeout(900)
