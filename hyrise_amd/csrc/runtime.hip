@@ -195,6 +195,28 @@ struct PinnedStaging {
 };
 static thread_local PinnedStaging t_staging;
 
+// Descriptor tables of columns over DEVICE memory (operator results: a reference column per operator and column of a plan) travel through
+// a ring of pinned slots: the copy is queued on the thread's stream and nobody waits for it -- the slot is written again only after its
+// event has passed (sixteen uploads later).  A synchronise per created column was 20 - 30 us of idle device, a dozen times per SSB join.
+struct DescriptorRing {
+  static constexpr uint32_t SLOTS = 16;
+  static constexpr size_t SLOT_BYTES = size_t{1} << 19;
+  unsigned char* host = nullptr;
+  hipEvent_t sent[SLOTS] = {};
+  bool busy[SLOTS] = {};
+  uint32_t next = 0;
+  void release() {
+    for (uint32_t i = 0; i < SLOTS; ++i) {
+      if (sent[i]) (void)hipEventDestroy(sent[i]);
+      sent[i] = nullptr;
+      busy[i] = false;
+    }
+    if (host) (void)hipHostFree(host);
+    host = nullptr;
+  }
+};
+static thread_local DescriptorRing t_descriptor_ring;
+
 hy_status pinned_staging(size_t bytes, void** host, void** device) {
   bind_thread_device();
   if (bytes > t_staging.bytes) {
@@ -410,6 +432,7 @@ hy_status hy_shutdown(void) {
   if (t_staging.host) (void)hipHostFree(t_staging.host);
   t_staging.host = t_staging.device = nullptr;
   t_staging.bytes = 0;
+  t_descriptor_ring.release();
   release_thread_join_state();
   for (hipEvent_t event : t_profile.events) (void)hipEventDestroy(event);
   t_profile.events.clear();
@@ -927,13 +950,34 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   std::vector<uint32_t> first_slice(size_t{n_chunks} + 1, 0);
   for (size_t i = slices.size(); i-- > 0;) first_slice[slices[i].chunk] = static_cast<uint32_t>(i);   // (descending: the chunk's first slice is written last)
   first_slice[n_chunks] = static_cast<uint32_t>(slices.size());
-  std::vector<unsigned char> staging(total, 0);
-  if (segments_bytes) std::memcpy(staging.data(), dev.data(), segments_bytes);
-  if (slices_bytes) std::memcpy(staging.data() + at_slices, slices.data(), slices_bytes);
-  if (views_bytes) std::memcpy(staging.data() + at_views, views.data(), views_bytes);
-  std::memcpy(staging.data() + at_row_base, column->row_base.data(), row_base_bytes);
-  if (parts_bytes) std::memcpy(staging.data() + at_parts, parts.data(), parts_bytes);
-  std::memcpy(staging.data() + at_first_slice, first_slice.data(), 4 * (size_t{n_chunks} + 1));
+  // where the tables are put together: a slot of the pinned ring (columns over device memory whose tables fit one), else a vector
+  std::vector<unsigned char> staging_vector;
+  unsigned char* staging = nullptr;
+  int ring_slot = -1;
+  if (mem == HY_MEM_DEVICE && total <= DescriptorRing::SLOT_BYTES) {
+    DescriptorRing& ring = t_descriptor_ring;
+    if (!ring.host && hipHostMalloc(reinterpret_cast<void**>(&ring.host), DescriptorRing::SLOTS * DescriptorRing::SLOT_BYTES, hipHostMallocDefault) != hipSuccess) ring.host = nullptr;
+    if (ring.host) {
+      ring_slot = static_cast<int>(ring.next);
+      ring.next = (ring.next + 1) % DescriptorRing::SLOTS;
+      if (!ring.sent[ring_slot] && hipEventCreateWithFlags(&ring.sent[ring_slot], hipEventDisableTiming) != hipSuccess) ring_slot = -1;
+      else if (ring.busy[ring_slot]) { (void)hipEventSynchronize(ring.sent[ring_slot]); ring.busy[ring_slot] = false; }
+    }
+    if (ring_slot >= 0) {
+      staging = ring.host + size_t{static_cast<uint32_t>(ring_slot)} * DescriptorRing::SLOT_BYTES;
+      std::memset(staging, 0, total);
+    }
+  }
+  if (!staging) {
+    staging_vector.assign(total, 0);
+    staging = staging_vector.data();
+  }
+  if (segments_bytes) std::memcpy(staging, dev.data(), segments_bytes);
+  if (slices_bytes) std::memcpy(staging + at_slices, slices.data(), slices_bytes);
+  if (views_bytes) std::memcpy(staging + at_views, views.data(), views_bytes);
+  std::memcpy(staging + at_row_base, column->row_base.data(), row_base_bytes);
+  if (parts_bytes) std::memcpy(staging + at_parts, parts.data(), parts_bytes);
+  std::memcpy(staging + at_first_slice, first_slice.data(), 4 * (size_t{n_chunks} + 1));
   void* block = nullptr;
   size_t block_capacity = 0;
   if (pool_acquire(total, &block, &block_capacity) != HY_OK) return cleanup(HY_ERR_DEVICE);
@@ -949,8 +993,13 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   // The block comes from this thread's pool: whoever held it before may have released it while kernels on the thread's stream still
   // read it (pool blocks are recycled in STREAM order).  The upload therefore goes onto that stream -- a copy on the NULL stream is not
   // ordered behind a non-blocking stream -- and the host waits for it (`staging` dies with this call).
-  hipError_t err = hipMemcpyAsync(block, staging.data(), total, hipMemcpyHostToDevice, t_stream);
-  if (err == hipSuccess) err = hipStreamSynchronize(t_stream);
+  // (From the ring nobody waits: the slot outlives the copy.  From the vector -- and for every column that was uploaded from host memory
+  // above -- the host waits: `staging_vector` dies with this call, and the caller's buffers are his again when it returns.)
+  hipError_t err = hipMemcpyAsync(block, staging, total, hipMemcpyHostToDevice, t_stream);
+  if (err == hipSuccess && ring_slot >= 0) {
+    err = hipEventRecord(t_descriptor_ring.sent[ring_slot], t_stream);
+    t_descriptor_ring.busy[ring_slot] = err == hipSuccess;
+  } else if (err == hipSuccess) err = hipStreamSynchronize(t_stream);
   if (err != hipSuccess) return cleanup(fail(HY_ERR_DEVICE, "descriptor upload failed: %s", hipGetErrorString(err)));
   *out = column;
   return HY_OK;

@@ -312,7 +312,10 @@ hy_status hy_comm_all_to_all_v(hy_comm* comm, const void* send, const uint64_t* 
 /* ---- residency cache: a column made device-visible once (encoded segments are immutable,
  *      abstract_encoded_segment.hpp:12-17) ------------------------------------------------------------------------ */
 /* mem == HY_MEM_HOST: segment buffers are copied to HBM and owned by the hy_column.
- * mem == HY_MEM_DEVICE: pointers are device pointers and stay owned by the caller. */
+ * mem == HY_MEM_DEVICE: pointers are device pointers and stay owned by the caller; the call does not wait for the device: the column's
+ *                       descriptor tables are complete in the order of the calling thread's stream (every entry point this thread calls
+ *                       afterwards sees them; another thread synchronises with this one first -- hy_synchronize -- like for the data
+ *                       the pointers name). */
 hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32_t mem, hy_column** out);
 hy_status hy_column_destroy(hy_column* column);
 hy_status hy_column_row_count(const hy_column* column, uint64_t* rows);
