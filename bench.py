@@ -157,25 +157,30 @@ def cpu_baseline_aggregate(groupby, aggregates, rows, budget_s=12.0):
                                               f"({median_partials * 1e3:.0f} ms each; merging the partial groups is not timed: a handful of additions)"}}
 
 
-def cpu_baseline_ssb(sample_rows=30_000_000):
-    """Config 5 on the host cores: the plans of hyrise_amd/ssb.py on the CPU restatement of the operators (tests/oracle_executor.py), SF30
-    dimensions and a bounded sample of lineorder (a sixth of SF30's 180 M rows), one run per query."""
+def cpu_baseline_ssb(threads=None, runs=3):
+    """Config 5 on the host cores: the plans of hyrise_amd/ssb.py on the CPU restatement of the operators (tests/oracle_executor.py) over
+    the FULL SF30 tables, scans and joins on every core (chunk ranges / radix partitions per thread; the aggregate is sequential like the
+    reference's AggregateHash), median of `runs` runs per query."""
     oracle_support()
     from oracle_executor import OracleExecutor
     from hyrise_amd import ssb
     from hyrise_amd.distributed import aggregate_groups
-    data = ssb.SsbData(scale_factor=30.0, seed=7, lineorder_rows=sample_rows)
+    threads = threads or max(1, os.cpu_count() or 1)
+    data = ssb.SsbData(scale_factor=30.0, seed=7)
     columns = data.host_columns()
-    ex = OracleExecutor()
+    ex = OracleExecutor(threads=threads)
     out = {}
     for query in ("2.1", "4.1"):
-        t0 = time.perf_counter()
-        groupby, aggregates, joined = ssb.run_query(ex, columns, query)
-        groups = aggregate_groups(ex, groupby, aggregates)
-        dt = time.perf_counter() - t0
-        out[f"q{query}"] = {"value": sample_rows / dt, "unit": "lineorder rows/s", "cores": 1, "kind": "port",
-                            "sample": f"SF30 dimensions, {sample_rows} of SF30's 180000000 lineorder rows, one run ({dt:.1f} s): scan -> JoinHash per dimension -> AggregateHash on the "
-                                      f"CPU restatement of Hyrise's operators, single-threaded; {joined} joined rows, {len(groups)} groups"}
+        times = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            groupby, aggregates, joined = ssb.run_query(ex, columns, query)
+            groups = aggregate_groups(ex, groupby, aggregates)
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
+        out[f"q{query}"] = {"value": data.n_lineorder / dt, "unit": "lineorder rows/s", "cores": threads, "kind": "port",
+                            "sample": f"full SF30 ({data.n_lineorder} lineorder rows), median of {runs} runs ({dt:.2f} s each): scan -> JoinHash per dimension -> AggregateHash on the "
+                                      f"CPU restatement of Hyrise's operators, scans and joins on {threads} threads, numpy gathers between them; {joined} joined rows, {len(groups)} groups"}
     return out
 
 

@@ -15,7 +15,73 @@ class _HostPosLists:
         self.total = sum(len(rows) for rows in lists)
 
 
+def _null_bits(segment, n):
+    if segment.nulls is None:
+        return np.zeros(n, dtype=bool)
+    return np.unpackbits(np.ascontiguousarray(segment.nulls).view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def _decode_data_column(column):
+    """(values, NULL flags) of a DATA column as flat numpy arrays (Unencoded / Dictionary / FrameOfReference segments; None otherwise);
+    remembered on the column object (columns do not change)."""
+    cached = getattr(column, "_decoded_flat", None)
+    if cached is not None:
+        return cached
+    values, nulls = [], []
+    for segment in column.segments:
+        n = segment.size
+        if segment.encoding == abi.ENC_DICTIONARY and getattr(segment, "bits", 0) == 0:
+            ids = np.asarray(segment.data[:n]).astype(np.int64)
+            is_null = ids >= segment.aux_size
+            dictionary = np.asarray(segment.aux) if segment.aux_size else np.zeros(1, dtype=_NP[column.data_type])
+            values.append(dictionary[np.where(is_null, 0, ids)])
+            nulls.append(is_null)
+        elif segment.encoding == abi.ENC_FRAME_OF_REFERENCE and getattr(segment, "bits", 0) == 0:
+            raw = np.asarray(segment.data[:n]).astype(np.int64)
+            minima = np.asarray(segment.aux).astype(np.int64)[np.arange(n) // abi.FOR_BLOCK_SIZE] if n else np.zeros(0, dtype=np.int64)
+            values.append((raw + minima).astype(np.int32))
+            nulls.append(_null_bits(segment, n))
+        elif segment.encoding == abi.ENC_UNENCODED:
+            values.append(np.asarray(segment.data[:n]))
+            nulls.append(_null_bits(segment, n))
+        else:
+            return None
+    flat = (np.concatenate(values) if values else np.zeros(0, dtype=_NP[column.data_type]), np.concatenate(nulls) if nulls else np.zeros(0, dtype=bool))
+    try:
+        column._decoded_flat = flat
+    except AttributeError:
+        pass
+    return flat
+
+
+def _decode_column(column):
+    """... of a data column or of a reference column over one (numpy gathers instead of a Python loop per cell: the SSB plans export
+    millions of cells per query)."""
+    if not column.segments or column.segments[0].encoding != abi.ENC_REFERENCE:
+        return _decode_data_column(column)
+    base = column.segments[0].ref
+    decoded = _decode_data_column(base)
+    if decoded is None or any(s.encoding != abi.ENC_REFERENCE or s.ref is not base for s in column.segments):
+        return None
+    begins = np.concatenate([[0], np.cumsum([s.size for s in base.segments])]).astype(np.int64)
+    rows = []
+    for segment in column.segments:
+        if segment.data is None:
+            rows.append(np.stack([np.full(segment.size, segment.ref_chunk_id, dtype=np.uint32), np.arange(segment.size, dtype=np.uint32)], axis=1))
+        else:
+            rows.append(np.asarray(segment.data).reshape(-1, 2)[:segment.size].astype(np.uint32))
+    rows = np.concatenate(rows) if rows else np.zeros((0, 2), dtype=np.uint32)
+    null_row = rows[:, 1] == 0xFFFFFFFF
+    flat = np.where(null_row, 0, begins[np.where(null_row, 0, rows[:, 0]).astype(np.int64)] + rows[:, 1].astype(np.int64))
+    if len(decoded[0]) == 0:
+        return np.zeros(len(rows), dtype=_NP[column.data_type]), np.ones(len(rows), dtype=bool)
+    return decoded[0][flat], decoded[1][flat] | null_row
+
+
 class OracleExecutor:
+    def __init__(self, threads=1):
+        self.threads = threads   # of the oracle's scan and join (chunk ranges / radix partitions per thread); the aggregate is sequential like the reference's
+
     def column(self, host_column):
         return host_column
 
@@ -39,7 +105,7 @@ class OracleExecutor:
 
     def scan(self, column, predicate):
         from support import oracle_scan
-        result = oracle_scan(column, predicate, flags=abi.SCAN_MATERIALIZE_ALL_MATCH)
+        result = oracle_scan(column, predicate, flags=abi.SCAN_MATERIALIZE_ALL_MATCH, threads=self.threads)
         matches = result.matches[:result.total].copy()
         if column.segments and column.segments[0].encoding == abi.ENC_REFERENCE:   # (c, o) -> the RowID at position o of chunk c's PosList
             begins = np.concatenate([[0], np.cumsum([s.size for s in column.segments])])
@@ -103,17 +169,23 @@ class OracleExecutor:
         return storage.HostColumn(segments, storage.TYPE_OF_NP[values.dtype])
 
     def export(self, column, with_nulls=True):
-        cells = column_values(column)
-        nulls = np.array([c is None for c in cells], dtype=np.uint8)
-        values = np.array([0 if c is None else c for c in cells], dtype=_NP[column.data_type])
-        return torch.from_numpy(values), (torch.from_numpy(nulls) if with_nulls else None)
+        decoded = _decode_column(column)
+        if decoded is None:   # (layouts the vectorised decoder below does not cover: cell by cell)
+            cells = column_values(column)
+            nulls = np.array([c is None for c in cells], dtype=np.uint8)
+            values = np.array([0 if c is None else c for c in cells], dtype=_NP[column.data_type])
+        else:
+            values, is_null = decoded
+            values = np.where(is_null, np.zeros(1, dtype=values.dtype), values).astype(_NP[column.data_type])
+            nulls = is_null.astype(np.uint8)
+        return torch.from_numpy(np.ascontiguousarray(values)), (torch.from_numpy(nulls) if with_nulls else None)
 
     def value_column(self, values, chunk_rows, null_bytes=None):
         nulls = null_bytes.numpy().astype(bool) if null_bytes is not None and bool(null_bytes.any()) else None
         return build_column(values.numpy(), nulls, chunk_rows, abi.ENC_UNENCODED)
 
     def join(self, left, right, mode):
-        result = oracle_join(left, right, mode)
+        result = oracle_join(left, right, mode, threads=self.threads)
         n = result.n_pairs
         semi = mode in (abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_ANTI_NULL_AS_FALSE)
         left_pos = torch.from_numpy(result.left[:n].astype(np.int64).astype(np.uint32).view(np.int32).copy())
