@@ -347,15 +347,19 @@ def oracle_join(left, right, mode, radix_bits=None, threads=1, capacity=None, se
         predicates[i].left_column, predicates[i].right_column, predicates[i].condition = C.addressof(l.c), C.addressof(r.c), c
     if capacity is None:
         capacity = max(left.rows, right.rows, 1) * 4 + 1024
-    slice_capacity = (max(left.rows, right.rows) // 131070) + 600
-    while True:
+    slice_capacity = (max(left.rows, right.rows) // 131070) + max(len(left.segments), len(right.segments)) + 600   # (without radix partitioning: a PosList per probe chunk)
+    for attempt in range(6):
         result = HostJoinResult(capacity, slice_capacity, radix_bits)
         status = lib.hyo_join_hash_predicates(C.byref(lcol.c), C.byref(rcol.c), mode, predicates, len(extra), C.byref(result.c), threads)
-        if status == abi.ERR_CAPACITY:
-            capacity *= 8
+        if status == abi.ERR_CAPACITY:   # (the oracle does not say which: first more PosLists -- a partial one per radix partition --, then more pairs)
+            if attempt == 0:
+                slice_capacity += 1 << 17
+            else:
+                capacity *= 8
             continue
         assert status == 0, f"oracle join failed with {status}"
         return result
+    raise AssertionError("oracle join: the result does not fit")
 
 
 def column_values(host_column):
