@@ -50,3 +50,62 @@ def test_two_ranks_on_one_gpu_replicated_and_repartitioned_plans(device):
         mp.spawn(ssb_workload.worker, args=(world, os.path.join(tmp, "init"), tmp, "hip"), nprocs=world, join=True)
         results = [pickle.load(open(os.path.join(tmp, f"rank{r}.pkl"), "rb")) for r in range(world)]
     ssb_workload.check_results(results)
+
+
+@pytest.mark.parametrize("case", ["filtered", "nothing_survives", "first_dimension_unfiltered", "dangling_foreign_keys"])
+def test_star_join_aggregate_small_tables(device, case):
+    """hy_star_join_aggregate on tables small enough to join with numpy: two dimensions (either may be unfiltered), foreign keys without a
+    partner, a filter nothing passes (an empty join result: no groups), GROUP BY a column of each dimension, SUM of a fact column,
+    SUM of an expression over two fact columns, COUNT(*)."""
+    import numpy as np
+    from hyrise_amd import abi, storage
+    from hyrise_amd.operators import make_predicate, star_join_aggregate
+    from hyrise_amd.storage import DeviceColumn
+    rng = np.random.default_rng(len(case))
+    n_fact, n_a, n_b = 200_000, 3_000, 500
+    a_key = np.arange(1, n_a + 1, dtype=np.int32) * 3                       # sparse unique keys
+    a_group = rng.integers(0, 7, n_a).astype(np.int32)
+    a_filter = rng.integers(0, 10, n_a).astype(np.int32)
+    b_key = rng.permutation(n_b).astype(np.int32) + 100                     # unsorted unique keys
+    b_group = rng.integers(0, 5, n_b).astype(np.int32)
+    b_filter = rng.integers(0, 4, n_b).astype(np.int32)
+    fk_a = a_key[rng.integers(0, n_a, n_fact)].copy()
+    fk_b = b_key[rng.integers(0, n_b, n_fact)].copy()
+    if case == "dangling_foreign_keys":
+        fk_a[rng.random(n_fact) < 0.3] = 1                                   # no such key
+        fk_b[rng.random(n_fact) < 0.2] = 99
+    x = rng.integers(-1000, 1000, n_fact).astype(np.int32)
+    y = rng.integers(0, 50, n_fact).astype(np.int32)
+    column = lambda values, encoding=abi.ENC_UNENCODED, chunk=20_000: DeviceColumn(storage.make_column(values, None, encoding, chunk))
+    c = {"a_key": column(a_key, chunk=1_000), "a_group": column(a_group, abi.ENC_DICTIONARY, 1_000), "a_filter": column(a_filter, abi.ENC_FRAME_OF_REFERENCE, 1_000),
+         "b_key": column(b_key, chunk=200), "b_group": column(b_group, abi.ENC_FRAME_OF_REFERENCE, 200), "b_filter": column(b_filter, abi.ENC_DICTIONARY, 200),
+         "fk_a": column(fk_a, abi.ENC_FRAME_OF_REFERENCE), "fk_b": column(fk_b, abi.ENC_FRAME_OF_REFERENCE), "x": column(x, abi.ENC_FRAME_OF_REFERENCE), "y": column(y, abi.ENC_DICTIONARY)}
+    a_value = 99 if case == "nothing_survives" else 3
+    a_predicate = None if case == "first_dimension_unfiltered" else make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, a_value) if case != "nothing_survives" else make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, 99)
+    dimensions = [(c["a_key"], None if a_predicate is None else c["a_filter"], a_predicate, c["fk_a"]),
+                  (c["b_key"], c["b_filter"], make_predicate(abi.PRED_NOT_EQUALS, abi.TYPE_INT, 2), c["fk_b"])]
+    groupby = [(1, c["a_group"]), (2, c["b_group"])]
+    aggregates = [(abi.AGG_SUM, (0, c["x"]), None, None), (abi.AGG_SUM, (0, c["x"]), abi.ARITH_MUL, (0, c["y"])), (abi.AGG_COUNT, None, None, None),
+                  (abi.AGG_MIN, groupby[0], None, None), (abi.AGG_MIN, groupby[1], None, None)]
+    result, joined = star_join_aggregate(dimensions, groupby, aggregates)
+    # numpy: positions of the partners, then the filters
+    a_of = {int(k): i for i, k in enumerate(a_key)}
+    b_of = {int(k): i for i, k in enumerate(b_key)}
+    ia = np.array([a_of.get(int(k), -1) for k in fk_a])
+    ib = np.array([b_of.get(int(k), -1) for k in fk_b])
+    keep = (ia >= 0) & (ib >= 0)
+    if case == "nothing_survives":
+        keep &= False
+    elif case != "first_dimension_unfiltered":
+        keep &= a_filter[np.maximum(ia, 0)] < 3
+    keep &= b_filter[np.maximum(ib, 0)] != 2
+    assert joined == int(keep.sum())
+    want = {}
+    for ga, gb, xv, yv in zip(a_group[ia[keep]], b_group[ib[keep]], x[keep].astype(np.int64), y[keep].astype(np.int64)):
+        cell = want.setdefault((int(ga), int(gb)), [0, 0, 0])
+        cell[0] += int(xv)
+        cell[1] += int(xv) * int(yv)
+        cell[2] += 1
+    n = result.n_groups
+    got = {(result.column(3)[i], result.column(4)[i]): [result.column(0)[i], result.column(1)[i], result.column(2)[i]] for i in range(n)}
+    assert got == want and (case != "nothing_survives" or n == 0)
