@@ -4197,10 +4197,6 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit_resident<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit_resident<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit_resident<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
-      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit_resident<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       pk_lds_raised.done(pk_device_bit);
     }
     hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself)
@@ -4212,17 +4208,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       if (group > 0) { k.emit_group_shift = 0; while (k.emit_group_shift < 16 && (int64_t{1} << (k.emit_group_shift + 1)) <= group) ++k.emit_group_shift; }
     }
     k.cut_blocks = (cut_grid + 7) / 8 * 8;   // (pk_cut_slice returns at once for slices the plan does not have)
-    // resident workgroups (HY_OPT_JOIN_EMIT_RESIDENT per CU, a multiple of 8 of them) that walk the tiles, or a workgroup per tile
-    uint32_t workers = 0;
-    if (option(HY_OPT_JOIN_EMIT_RESIDENT) > 0) workers = std::min<uint32_t>(tile_grid, device_cu_count() * static_cast<uint32_t>(std::min<int64_t>(2, option(HY_OPT_JOIN_EMIT_RESIDENT))) / 8 * 8);
-    if (workers) {
-      const dim3 grid(k.cut_blocks + workers), threads(PK_THREADS);
-      const size_t lds = 4 * pk_emit_lds_words(partitions);
-      if (build_in_lds && mode == HY_JOIN_INNER) hipExtLaunchKernelGGL((pk_emit_resident<true, true>), grid, threads, lds, stream, started, stopped, 0, k);
-      else if (build_in_lds) hipExtLaunchKernelGGL((pk_emit_resident<false, true>), grid, threads, lds, stream, started, stopped, 0, k);
-      else if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit_resident<true>, grid, threads, lds, stream, started, stopped, 0, k);
-      else hipExtLaunchKernelGGL(pk_emit_resident<false>, grid, threads, lds, stream, started, stopped, 0, k);
-    } else if (build_in_lds) {   // (pass 2 reads the rows' found / materialised bits pass 1 left behind)
+    if (build_in_lds) {   // (pass 2 reads the rows' found / materialised bits pass 1 left behind)
       if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL((pk_emit<true, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
       else hipExtLaunchKernelGGL((pk_emit<false, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     } else if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);

@@ -706,11 +706,9 @@ __device__ __forceinline__ void pk_copy_out(const PkArgs& a, const u32x2_t* s_st
 }
 
 // One tile from its stored words to its pairs in the output.  The five phases are separated by four workgroup barriers.
-// `before_copy_out` runs when the tile's pairs are staged and before they leave: a workgroup that goes on to another tile asks for that
-// tile's words there (pk_emit_resident) -- the registers of the lookup phases are free by then.
-template <bool INNER, bool MASKS = false, typename BeforeCopyOut>
+template <bool INNER, bool MASKS = false>
 __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, const SliceView& view, const PkWords& words, uint32_t cell_pairs, uint32_t cell_base,
-                                             uint32_t* join_smem, uint32_t tid, uint32_t lane, uint32_t wave, BeforeCopyOut before_copy_out) {
+                                             uint32_t* join_smem, uint32_t tid, uint32_t lane, uint32_t wave) {
   const uint32_t partitions = 1u << a.radix_bits;
   const uint32_t stage_slots = PK_TILE + partitions + 2;
   u32x2_t* s_stage = reinterpret_cast<u32x2_t*>(join_smem);                      // [stage_slots]
@@ -791,7 +789,6 @@ __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, con
   }
   __syncthreads();
   if (a.trace && tid == 0) a.trace[tile * 6 + 4] = wall_clock64();
-  before_copy_out();
   // (e) copy out: one loop per way of turning a partner's rank into its RowID (the identity cases have no global load in the loop:
   // no `s_waitcnt vmcnt(0)` per iteration, which would also wait for every store in flight)
   const uint32_t reserved = s_scratch[8];
@@ -902,60 +899,6 @@ __global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkAr
   const uint32_t cell_base = static_cast<uint32_t>(a.origin_pairs[tid < partitions ? tid : 0]) + a.rel_pairs[cell];
   PkWords words;
   pk_load_words(view, wave, lane, words);
-  pk_emit_tile<INNER, MASKS>(a, tile, view, words, cell_pairs, cell_base, join_smem, tid, lane, wave, []() {});
-}
-
-// The same tiles by workgroups that STAY (two per CU) and walk them: round r of the `workers` resident workgroups takes the tiles
-// [r * workers, (r + 1) * workers) -- one front for the device, XCD x the x-th eighth of every round (the partial lines two neighbouring
-// tiles share meet in one L2) --, and a workgroup has the next tile's view and cells on their way while it works on this one and asks for
-// the next tile's words before it copies this one's pairs out.  With a workgroup per tile, a tile's five phases took 11.9 us of the 19 us
-// its place on the CU was held (HY_JOIN_TRACE): the rest was the launch of 512 threads with 67 KB of LDS and three dependent round trips
-// (view, cells, words) before the first phase could start.
-template <bool INNER, bool MASKS = false>
-__global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit_resident(PkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
-  const uint32_t partitions = 1u << a.radix_bits;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (blockIdx.x < a.cut_blocks) { pk_cut_slice<MASKS>(a, blockIdx.x, join_smem, tid, lane, wave); return; }
-  if (!a.plan->fits) return;
-  const uint32_t block = blockIdx.x - a.cut_blocks, workers = gridDim.x - a.cut_blocks;   // (a multiple of 8)
-  const uint32_t place = (block & 7) * (workers >> 3) + (block >> 3);
-  uint32_t tile = place;
-  if (tile >= a.n_tiles) return;
-  const uint32_t my_partition = tid < partitions ? tid : 0;
-  const uint32_t origin = static_cast<uint32_t>(a.origin_pairs[my_partition]);
-  auto cell_of = [&](uint32_t t, uint32_t* pairs, uint32_t* base) {   // thread = partition: the cell's pairs and its first global pair index
-    const size_t cell = static_cast<size_t>(my_partition) * a.stride + t;
-    *pairs = tid < partitions ? a.counts[cell] >> 16 : 0;
-    *base = origin + a.rel_pairs[cell];
-  };
-  SliceView view = pk_tile_view(a, tile);
-  uint32_t cell_pairs, cell_base;
-  cell_of(tile, &cell_pairs, &cell_base);
-  PkWords words;
-  pk_load_words(view, wave, lane, words);
-  for (;;) {
-    const uint32_t next = tile + workers;
-    const bool more = next < a.n_tiles;
-    SliceView next_view = view;
-    uint32_t next_pairs = 0, next_base = 0;
-    if (more) {
-      next_view = pk_tile_view(a, next);
-      cell_of(next, &next_pairs, &next_base);
-    }
-    PkWords next_words;
-#pragma unroll
-    for (uint32_t p = 0; p < 4; ++p) next_words.piece[p] = u32x4_t{0, 0, 0, 0};
-    auto request_next = [&]() { if (more) pk_load_words(next_view, wave, lane, next_words); };
-    if (view.row_count) pk_emit_tile<INNER, MASKS>(a, tile, view, words, cell_pairs, cell_base, join_smem, tid, lane, wave, request_next);
-    else request_next();
-    if (!more) break;
-    __syncthreads();   // (the copy-out has read the staging area)
-    tile = next;
-    view = next_view;
-    cell_pairs = next_pairs;
-    cell_base = next_base;
-    words = next_words;
-  }
+  pk_emit_tile<INNER, MASKS>(a, tile, view, words, cell_pairs, cell_base, join_smem, tid, lane, wave);
 }
 

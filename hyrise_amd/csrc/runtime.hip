@@ -38,7 +38,6 @@ struct OptionDefaults {
     set(HY_OPT_FUSED_SHARED_PREFIX, 1);
     set(HY_OPT_JOIN_FILL_WGS_PER_CU, 4);
     set(HY_OPT_JOIN_EMIT_TILE_GROUP, 64);
-    set(HY_OPT_JOIN_EMIT_RESIDENT, 0);
   }
 };
 OptionDefaults g_option_defaults;   // (static initialisation: before any entry point can run)

@@ -277,8 +277,6 @@ enum {
                                       *      that moves through the probe side); 0 = every XCD works through its own eighth of the tiles        */
   HY_OPT_JOIN_FILL_WGS_PER_CU = 26,  /* 4    the checked one-pass fill wave by wave (rank_table_fill_waves: this many resident workgroups per
                                       *      CU, <= 8); 0 = one short-lived workgroup per slice (rank_table_fill_checked)              */
-  HY_OPT_JOIN_EMIT_RESIDENT = 27,    /* 2    pk_emit: workgroups per CU that stay and walk the tiles (1 | 2), the next tile's words requested before
-                                      *      this tile's pairs are copied out; 0 = one short-lived workgroup per tile                          */
   HY_OPT_COUNT = 32
 };
 hy_status hy_set_option(uint32_t option, int64_t value);

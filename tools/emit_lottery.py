@@ -52,11 +52,6 @@ def main():
             abi.check(lib.hy_set_option(abi.OPT_JOIN_EMIT_TILE_GROUP, group))
             measure(f"tile group {group}")
         return
-    if os.environ.get("RESIDENT"):   # HY_OPT_JOIN_EMIT_RESIDENT: the same arenas with workgroups per tile (0) and resident ones (1, 2 per CU)
-        for resident in [int(g) for g in os.environ["RESIDENT"].split(",")] * 2:
-            abi.check(lib.hy_set_option(abi.OPT_JOIN_EMIT_RESIDENT, resident))
-            measure(f"resident workgroups per CU: {resident}")
-        return
     measure("as allocated")
     measure("again")
     # the library's temporaries: hy_shutdown releases this thread's pool, the next join allocates anew
