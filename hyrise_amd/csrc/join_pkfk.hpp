@@ -890,9 +890,10 @@ __global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkAr
     const uint32_t whole = ((a.n_tiles + 7) / 8) >> shift << shift;   // (the grid: 8 x ceil(n_tiles / 8) tile blocks)
     tile = j < whole ? ((j >> shift) << (shift + 3)) + (xcd << shift) + (j & ((1u << shift) - 1)) : whole * 8 + (j - whole) * 8 + xcd;
   } else tile = (block & 7) * ((a.n_tiles + 7) / 8) + (block >> 3);
-  if (tile >= a.n_tiles || !a.plan->fits) return;
+  if (tile >= a.n_tiles) return;
   const SliceView view = pk_tile_view(a, tile);
-  if (view.row_count == 0) return;
+  const uint32_t fits = a.plan->fits;   // (asked for together with the view: one round trip, not two, before the words can be requested)
+  if (!fits || view.row_count == 0) return;
   // thread = partition: the cell's pairs and its first global pair index (fits 32 bits: pk_path in run_join)
   const size_t cell = static_cast<size_t>(tid < partitions ? tid : 0) * a.stride + tile;
   const uint32_t cell_pairs = tid < partitions ? a.counts[cell] >> 16 : 0;

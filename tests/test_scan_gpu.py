@@ -661,3 +661,17 @@ def test_bit_packed_vectors_stream(device, bits):
                 for flags in (0, abi.SCAN_MATERIALIZE_ALL_MATCH):
                     p = make_predicate(condition, abi.TYPE_INT, value, value2, nullable=with_nulls)
                     check(host, p, dev, flags, context=f"{kind} {bits} bits nulls {with_nulls} cond {condition} lit {value},{value2} flags {flags}")
+
+
+def test_upload_windows(device):
+    """hy_column_create moves host buffers through 32 MiB windows of pinned memory: a column of many small buffers that fill several
+    windows (dictionary segments: three buffers a chunk), and chunks larger than a window (they go straight from the caller's memory) --
+    the scans of both equal the oracle's."""
+    rng = np.random.default_rng(8)
+    many = rng.integers(0, 3000, 24_000_000).astype(np.int32)                # 367 chunks x (attribute vector + dictionary): ~50 MB, two windows
+    host = build_column(many, None, 65535, abi.ENC_DICTIONARY)
+    check(host, make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 1200), context="many buffers")
+    big = rng.integers(-1000, 1000, 21_000_000).astype(np.int32)             # two chunks of 42 MB each: larger than a window
+    nulls = rng.random(len(big)) < 0.01
+    host = build_column(big, nulls, 10_500_000, abi.ENC_UNENCODED)
+    check(host, make_predicate(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_INT, -5, 700, nullable=True), context="chunks larger than a window")
