@@ -978,6 +978,12 @@ __global__ __launch_bounds__(256) void rank_table_fill_sorted(const K* keys, uin
   entries[word] = u32x2_t{bits, static_cast<uint32_t>(i)};
 }
 
+// keys[i] <- keys[i] + delta (uint32 arithmetic): a build side's keys as distances from the smallest one and back
+__global__ __launch_bounds__(256) void shift_keys(uint32_t* keys, uint64_t n, uint32_t delta) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] += delta;
+}
+
 // Unsorted keys: every key sets its bit (a bit that is already set: the keys are not unique, the join falls back to the
 // sorted directory), a scan over the words' population counts gives the bases, and the RowIDs are scattered to their
 // keys' ranks -- which is all the "sort" a unique build side needs.
@@ -3497,6 +3503,45 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
           if (key32) hipLaunchKernelGGL(rank_table_fill_sorted<uint32_t>, key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), total, key_min, entries);
           else hipLaunchKernelGGL(rank_table_fill_sorted<uint64_t>, key_grid, dim3(256), 0, stream, b.keys.as<uint64_t>(), total, key_min, entries);
           rank_table = true;
+        } else if (key32 && id32 && range < 0xFFFFFFF0ull && total >= 65536 && lds_atomics_are_lane_ordered(stream)) {
+          // Unsorted 32-bit keys, many of them: SORT the (key - smallest key, RowID) pairs (the LSD radix sort below: tiles staged in LDS, runs
+          // instead of scattered stores) and fill the table from the sorted keys -- the RowIDs then already stand in rank order.  Marking
+          // 15 M shuffled keys with device-scope atomicOr and scattering their RowIDs to their ranks took 0.56 + 0.41 ms.
+          uint32_t key_bits = 1;
+          while (key_bits < 32 && (range >> key_bits) != 0) ++key_bits;
+          HY_TRY(b.keys_tmp.alloc(key_bytes * (total + 4)));
+          HY_TRY(b.rows_tmp.alloc(row_bytes * total));
+          hipLaunchKernelGGL(shift_keys, key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), total, 0u - static_cast<uint32_t>(key_min));
+          uint32_t* sorted_keys = b.keys.as<uint32_t>();
+          uint32_t* sorted_rows = b.rows.as<uint32_t>();
+          HY_TRY(sort_pairs_u32(&sorted_keys, &sorted_rows, b.keys_tmp.as<uint32_t>(), b.rows_tmp.as<uint32_t>(), total, key_bits, stream));
+          if (sorted_keys != b.keys.as<uint32_t>()) {
+            std::swap(b.keys.ptr, b.keys_tmp.ptr);
+            std::swap(b.keys.capacity, b.keys_tmp.capacity);
+            std::swap(b.rows.ptr, b.rows_tmp.ptr);
+            std::swap(b.rows.capacity, b.rows_tmp.capacity);
+          }
+          HY_HIP(hipMemsetAsync(b.flags.ptr, 0, 64, stream));
+          hipLaunchKernelGGL(check_sorted<uint32_t>, check_grid, dim3(1024), 0, stream, b.keys.as<uint32_t>(), total, b.flags.as<uint32_t>());
+          hipLaunchKernelGGL(publish_build_flags<uint32_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint32_t>(), total, mailbox_dev);
+          const uint64_t remembered_min = mailbox->key_min, remembered_max = mailbox->key_max, remembered_or = mailbox->key_or;
+          HY_HIP(hipStreamSynchronize(stream));
+          const bool duplicates = mailbox->equal_neighbours != 0;
+          mailbox->key_min = remembered_min;   // (the second look saw distances, not keys)
+          mailbox->key_max = remembered_max;
+          mailbox->key_or = remembered_or;
+          if (duplicates) {   // not unique after all: the keys again as they were, for the directory below -- which wants them in the order of
+            // their sign-extended bits (negative keys last): sorted already if there is no negative key, else its own sort runs (stable: equal
+            // keys keep the build-row order they have now)
+            build->join_hint.has_duplicates.store(1, std::memory_order_relaxed);
+            hipLaunchKernelGGL(shift_keys, key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), total, static_cast<uint32_t>(key_min));
+            HY_HIP(hipMemsetAsync(b.keys.as<uint32_t>() + total, 0, 16, stream));
+            mailbox->unsorted = static_cast<int64_t>(key_min) < 0 ? 1 : 0;
+            mailbox->equal_neighbours = 1;
+          } else {
+            hipLaunchKernelGGL(rank_table_fill_sorted<uint32_t>, key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), total, uint64_t{0}, entries);
+            rank_table = true;
+          }
         } else {
           if (key32) {
             hipLaunchKernelGGL(rank_table_mark<uint32_t>, key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), total, key_min, entries, b.flags.as<uint32_t>() + 10);

@@ -595,6 +595,36 @@ def test_join_unique_build_keys_take_the_rank_table(device, mode):
                             assert used_rank_table() == 2, context   # dense, sorted, equally sized chunks: ranks are row numbers
 
 
+@pytest.mark.parametrize("mode", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE])
+def test_join_large_shuffled_build_keys_are_sorted_into_the_rank_table(device, mode):
+    """65 536 and more shuffled 32-bit build keys: the (key - smallest key, RowID) pairs are radix-sorted and the rank table filled from the
+    sorted keys (the atomicOr marking stays for small and 64-bit builds).  Negative keys, sparse keys, a probe side with NULLs and keys
+    outside the range; and a build side that turns out to have duplicates after the sort: the sorted directory takes over with the pairs
+    in build-row order.  Pairs and PosList cuts bit-identical to the oracle."""
+    rng = np.random.default_rng(5 + mode)
+    n_build, n_probe = 150_000, 400_000
+    keys = (np.arange(n_build, dtype=np.int64) * 5 - 300_000).astype(np.int32)       # sparse (one in five), negative and positive
+    positive = keys + 300_007
+    for name, keys, build_values in (("unique", keys, rng.permutation(keys)), ("duplicates", keys, rng.permutation(np.concatenate([keys, keys[:5000]]))),
+                                     ("duplicates, no negative key", positive, rng.permutation(np.concatenate([positive, positive[-5000:]])))):
+        probe_values = rng.choice(keys, n_probe).astype(np.int32)
+        outside = rng.random(n_probe) < 0.03
+        probe_values[outside] = rng.integers(int(keys.min()) - 500, int(keys.max()) + 500, int(outside.sum())).astype(np.int32)
+        probe_nulls = rng.random(n_probe) < 0.02
+        build = build_column(build_values, None, 65535, abi.ENC_UNENCODED)
+        probe = build_column(probe_values, probe_nulls, 65535, abi.ENC_FRAME_OF_REFERENCE)
+        for radix_bits in (None, 0, 4):
+            context = f"mode {mode} {name} radix {radix_bits}"
+            if mode in SEMI or mode == abi.JOIN_LEFT:
+                check(probe, build, mode, radix_bits, context)
+            else:
+                check(build, probe, mode, radix_bits, context)
+            if name == "unique":
+                assert used_rank_table() == 1, context
+            elif mode == abi.JOIN_INNER:   # (Semi / Anti joins keep presence bits only: duplicates still serve them)
+                assert used_rank_table() == 0, context
+
+
 def test_join_rank_table_int64_and_reference_build(device):
     rng = np.random.default_rng(77)
     keys = (np.arange(5000, dtype=np.int64) * 3 + 10_000_000_000)
