@@ -4191,7 +4191,8 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     const uint32_t tile_grid = 8 * ((n_tiles + 7) / 8);
     // The build side staged in LDS (pk_count_lds, join_pkfk.hpp): a rank table over fewer than 2^20 key values, enough tiles for
     // persistent workgroups to pay for staging it once per CU.
-    DeviceBuffer row_masks;
+    DeviceBuffer row_masks, row_ranks;
+    bool hand_over_ranks = false;
     const bool build_in_lds = b.rank.range < PK_LDS_KEYS && partitions <= PK_LDS_MAX_PARTITIONS && n_tiles >= static_cast<uint64_t>(option(HY_OPT_JOIN_LDS_BUILD_TILES)) && option(HY_OPT_JOIN_LDS_BUILD);   // (tests lower the bar)
     if (build_in_lds) {
       HY_TRY(row_masks.alloc(size_t{n_tiles} * (2 * PK_TILE / 8)));
@@ -4212,7 +4213,14 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     } else {
       hipEvent_t count_started = nullptr, count_stopped = nullptr;
       profile_events(&count_started, &count_stopped, HY_KERNEL_JOIN_COUNT);
-      hipExtLaunchKernelGGL(pk_count, dim3(tile_grid), dim3(PK_COUNT_THREADS), 0, stream, count_started, count_stopped, 0, k);
+      // Probe keys without locality, an Inner join over a million rows or more: pass 1 hands every row's partner rank to pass 2 (pk_count_wave RANKS)
+      hand_over_ranks = mode == HY_JOIN_INNER && !count_only && probe_keys_scattered(probe) && option(HY_OPT_JOIN_HAND_OVER_RANKS) > 0 &&
+                        probe->rows >= static_cast<uint64_t>(option(HY_OPT_JOIN_HAND_OVER_RANKS));
+      if (hand_over_ranks) {
+        HY_TRY(row_ranks.alloc(4 * size_t{n_tiles} * PK_TILE));
+        k.row_ranks = row_ranks.as<uint32_t>();
+        hipExtLaunchKernelGGL(pk_count<true>, dim3(tile_grid), dim3(PK_COUNT_THREADS), 0, stream, count_started, count_stopped, 0, k);
+      } else hipExtLaunchKernelGGL(pk_count<false>, dim3(tile_grid), dim3(PK_COUNT_THREADS), 0, stream, count_started, count_stopped, 0, k);
     }
     hipLaunchKernelGGL(pk_scan, dim3(partitions), dim3(PK_SCAN_THREADS), 0, stream, k);
     clock.mark("pass 1 launched");
@@ -4242,6 +4250,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk_emit<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pk_emit_lds_words(MAX_PARTITIONS)));
       pk_lds_raised.done(pk_device_bit);
     }
     hipEvent_t started = nullptr, stopped = nullptr;   // (stamped from the dispatch packet itself)
@@ -4256,7 +4265,8 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     if (build_in_lds) {   // (pass 2 reads the rows' found / materialised bits pass 1 left behind)
       if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL((pk_emit<true, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
       else hipExtLaunchKernelGGL((pk_emit<false, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
-    } else if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
+    } else if (hand_over_ranks) hipExtLaunchKernelGGL((pk_emit<true, false, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
+    else if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     else hipExtLaunchKernelGGL(pk_emit<false>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     HY_HIP(hipGetLastError());
     clock.mark("pass 2 launched");

@@ -72,6 +72,7 @@ struct PkArgs {
   hy_row_id* probe_out;
   uint64_t* slice_offsets;
   uint32_t emit_group_shift;       // pk_emit: log2 of the consecutive tiles an XCD takes (32: every XCD its own eighth of the tiles)
+  uint32_t* row_ranks;             // probe keys without locality (Inner): pass 1 leaves every row's partner rank here (PK_NO_RANK: none), pass 2 reads it back
   uint32_t cut_blocks;             // pk_emit: its first cut_blocks workgroups compute the PosList cuts (pk_cut_slice)
   uint32_t bloom_is_bits;          // build_bloom holds 2^20 bits (a hinted build, rank_table_fill_checked), not one byte per bit
   uint64_t* trace;                 // debug (HY_JOIN_TRACE): 6 wall-clock stamps per pk_emit tile, else nullptr
@@ -136,9 +137,13 @@ __device__ __forceinline__ bool pk_emits(uint32_t mode, bool found, bool* null_p
 // LDS: the presence words come from `presence` (LDS, the whole table), partner-less rows ask the same words instead of the Bloom
 // filter (exact for a range below 2^20: the one key value of the range that shares the row's filter bit), and the rows' found /
 // materialised bits are left in `masks` (the tile's 2 x 1 KB) for pass 2.
-template <uint32_t WIDTH, bool LDS = false>
+// RANKS: probe keys without locality (shuffled foreign keys against a table of megabytes): every lookup is a sector out of the L2 or the
+// memory-side cache, and pass 2 would make every one of them again.  Pass 1 then reads the whole entry, computes the partner's rank and
+// leaves it in `tile_ranks` (4 bytes a row, written and read back sequentially): 60 M shuffled probe rows 0.81 + 1.02 ms -> see DESIGN.md 4.2.
+constexpr uint32_t PK_NO_RANK = 0xFFFFFFFFu;
+template <uint32_t WIDTH, bool LDS = false, bool RANKS = false>
 __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& view, uint32_t wave, uint32_t lane, uint32_t* cells, const uint32_t* presence = nullptr,
-                                              uint8_t* masks = nullptr) {
+                                              uint8_t* masks = nullptr, uint32_t* tile_ranks = nullptr) {
   const char* base = static_cast<const char*>(view.data);
   const uint32_t row_count = view.row_count;
   const uint32_t wave_first = wave * PK_COUNT_WAVE_ROWS;
@@ -161,7 +166,7 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
   // clamp, a shift and a mask for the address, one bit test -- and ONE LDS atomic, no run detection: with eight copies per cell the
   // lanes of an instruction rarely meet.  A batch in which some row has no partner goes to the general loop (the Bloom filter decides
   // about such rows), as does every other mode.
-  if constexpr (!LDS) {
+  if constexpr (!LDS && !RANKS) {
     if ((a.mode == HY_JOIN_INNER || a.mode == HY_JOIN_SEMI) && wave_first + PK_COUNT_WAVE_ROWS <= row_count) {
       const uint32_t delta = bias - origin, beyond = range + 32;
       const char* table = reinterpret_cast<const char*>(a.rank.entries);
@@ -204,13 +209,36 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
 #pragma unroll
   for (uint32_t g = 0; g < PK_COUNT_BATCHES; g += 2) {
     uint32_t bits[2][8];
+    uint32_t bases[RANKS ? 2 : 1][RANKS ? 8 : 1];
 #pragma unroll
     for (uint32_t b = 0; b < 2; ++b) {
 #pragma unroll
       for (uint32_t j = 0; j < 8; ++j) {
         const uint32_t distance = batch_word<WIDTH>(words[g + b], j) + bias - origin;   // (32-bit: both sides' keys are int32 values, pk_path in run_join)
         if constexpr (LDS) bits[b][j] = presence[distance <= range ? distance >> 5 : 0u];
-        else bits[b][j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
+        else if constexpr (RANKS) {
+          const u32x2_t entry = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
+          bits[b][j] = entry.x;
+          bases[b][j] = entry.y;
+        } else bits[b][j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.rank.entries) + (distance <= range ? (distance >> 5) * 8u : 0u));
+      }
+    }
+    if constexpr (RANKS) {   // the lane's eight consecutive rows of both batches: 32 bytes each, two 16-byte stores
+#pragma unroll
+      for (uint32_t b = 0; b < 2; ++b) {
+        uint32_t ranks[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+          const uint32_t distance = batch_word<WIDTH>(words[g + b], j) + bias - origin;
+          const bool has = distance <= range && ((bits[b][j] >> (distance & 31)) & 1);
+          ranks[j] = has ? bases[b][j] + __popc(bits[b][j] & ((1u << (distance & 31)) - 1)) : PK_NO_RANK;
+        }
+        const uint32_t first = wave_first + (g + b) * 512 + lane * 8;
+        if (first < row_count) {   // (a partial tile's last lanes write ranks of rows that do not exist: inside the tile's PK_TILE words)
+          u32x4_t* out = reinterpret_cast<u32x4_t*>(tile_ranks + first);
+          out[0] = u32x4_t{ranks[0], ranks[1], ranks[2], ranks[3]};
+          out[1] = u32x4_t{ranks[4], ranks[5], ranks[6], ranks[7]};
+        }
       }
     }
 #pragma unroll
@@ -264,7 +292,8 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
   }
 }
 
-__global__ __launch_bounds__(PK_COUNT_THREADS, 8 * PK_COUNT_THREADS / 256) void pk_count(PkArgs a) {
+template <bool RANKS = false>
+__global__ __launch_bounds__(PK_COUNT_THREADS, (RANKS ? 4 : 8) * PK_COUNT_THREADS / 256) void pk_count(PkArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cells[MAX_PARTITIONS * COUNT_COPIES];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t partitions = 1u << a.radix_bits;
@@ -274,9 +303,10 @@ __global__ __launch_bounds__(PK_COUNT_THREADS, 8 * PK_COUNT_THREADS / 256) void 
   for (uint32_t i = tid; i < partitions * COUNT_COPIES; i += PK_COUNT_THREADS) s_cells[i] = 0;
   __syncthreads();
   const SliceView view = pk_tile_view(a, tile);
-  if (view.kind == VIEW_FOR8) pk_count_wave<1>(a, view, wave, lane, s_cells);
-  else if (view.kind == VIEW_FOR16) pk_count_wave<2>(a, view, wave, lane, s_cells);
-  else pk_count_wave<4>(a, view, wave, lane, s_cells);
+  uint32_t* tile_ranks = RANKS ? a.row_ranks + static_cast<size_t>(tile) * PK_TILE : nullptr;
+  if (view.kind == VIEW_FOR8) pk_count_wave<1, false, RANKS>(a, view, wave, lane, s_cells, nullptr, nullptr, tile_ranks);
+  else if (view.kind == VIEW_FOR16) pk_count_wave<2, false, RANKS>(a, view, wave, lane, s_cells, nullptr, nullptr, tile_ranks);
+  else pk_count_wave<4, false, RANKS>(a, view, wave, lane, s_cells, nullptr, nullptr, tile_ranks);
   __syncthreads();
   for (uint32_t partition = tid; partition < partitions; partition += PK_COUNT_THREADS) {
     const u32x4_t low = *reinterpret_cast<const u32x4_t*>(s_cells + partition * COUNT_COPIES), high = *reinterpret_cast<const u32x4_t*>(s_cells + partition * COUNT_COPIES + 4);
@@ -544,9 +574,11 @@ __device__ __forceinline__ uint32_t pk_block_word(const SliceView& view, const u
 // meta[k] = partition | null_partner << 9 | emit << 10 (INVALID_PARTITION: the row is not materialised); rank[k] = the partner's rank.
 // MASKS: pass 1 was pk_count_lds -- a row's found / materialised bits come from `tile_masks` (the tile's 2 x PK_TILE / 8 bytes), only rows
 // with a partner read their table entry (the others read entry 0: one line for all of them), the Bloom filter is not asked again.
-template <bool INNER, uint32_t HALVES, bool MASKS = false>
+// RANKS (Inner joins): pass 1 was pk_count<true> -- a row's rank (or PK_NO_RANK) comes from `tile_ranks`, no table entry is read; a row
+// without a partner emits nothing in an Inner join, whether it counted as materialised is pass 1's business.
+template <bool INNER, uint32_t HALVES, bool MASKS = false, bool RANKS = false>
 __device__ __forceinline__ void pk_lookup_rows(const PkArgs& a, const SliceView& view, const uint32_t* block, uint32_t wave, uint32_t lane, uint32_t (&meta)[PK_ROUNDS],
-                                               uint32_t (&rank)[PK_ROUNDS], const uint8_t* tile_masks = nullptr) {
+                                               uint32_t (&rank)[PK_ROUNDS], const uint8_t* tile_masks = nullptr, const uint32_t* tile_ranks = nullptr) {
   constexpr uint32_t N = PK_ROUNDS / HALVES;
   const uint32_t row_count = view.row_count;
   const uint32_t wave_first = wave * PK_WAVE_ROWS;
@@ -562,7 +594,20 @@ __device__ __forceinline__ void pk_lookup_rows(const PkArgs& a, const SliceView&
     uint32_t raw[N];
     u32x2_t entry[N];
     uint32_t valid = 0, found = 0;
-    if constexpr (MASKS) {
+    if constexpr (RANKS) {
+      static_assert(INNER && !MASKS, "ranks are handed over by Inner joins on the global-table kernels");
+#pragma unroll
+      for (uint32_t j = 0; j < N; ++j) {
+        const uint32_t r = wave_first + (h * N + j) * 64 + lane;
+        raw[j] = pk_block_word(view, block, lane, h * N + j) + bias;
+        rank[h * N + j] = r < row_count ? tile_ranks[r] : PK_NO_RANK;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < N; ++j) {
+        if (wave_first + (h * N + j) * 64 + lane < row_count) valid |= 1u << j;
+        if (rank[h * N + j] != PK_NO_RANK) found |= 1u << j;
+      }
+    } else if constexpr (MASKS) {
 #pragma unroll
       for (uint32_t j = 0; j < N; ++j) {
         const uint32_t k = h * N + j;
@@ -706,7 +751,7 @@ __device__ __forceinline__ void pk_copy_out(const PkArgs& a, const u32x2_t* s_st
 }
 
 // One tile from its stored words to its pairs in the output.  The five phases are separated by four workgroup barriers.
-template <bool INNER, bool MASKS = false>
+template <bool INNER, bool MASKS = false, bool RANKS = false>
 __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, const SliceView& view, const PkWords& words, uint32_t cell_pairs, uint32_t cell_base,
                                              uint32_t* join_smem, uint32_t tid, uint32_t lane, uint32_t wave) {
   const uint32_t partitions = 1u << a.radix_bits;
@@ -721,7 +766,8 @@ __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, con
   for (uint32_t i = tid; i < PK_WAVES * partitions; i += PK_THREADS) s_wave_pairs[i] = 0;
   uint32_t meta[PK_ROUNDS], rank[PK_ROUNDS];
   pk_words_to_block(view, words, join_smem + wave * 1024, lane);   // (the staging area is not in use yet: 4 KB of it per wave)
-  pk_lookup_rows<INNER, 1, MASKS>(a, view, join_smem + wave * 1024, wave, lane, meta, rank, MASKS ? a.row_masks + static_cast<size_t>(tile) * (2 * PK_TILE / 8) : nullptr);
+  pk_lookup_rows<INNER, 1, MASKS, RANKS>(a, view, join_smem + wave * 1024, wave, lane, meta, rank, MASKS ? a.row_masks + static_cast<size_t>(tile) * (2 * PK_TILE / 8) : nullptr,
+                                         RANKS ? a.row_ranks + static_cast<size_t>(tile) * PK_TILE : nullptr);
   __builtin_amdgcn_wave_barrier();
   if (a.trace && tid == 0) a.trace[tile * 6 + 1] = wall_clock64();
   // (a) reserve pairs + 1 slots per non-empty partition: scan inside each wave now, across waves in (c)
@@ -870,7 +916,7 @@ __global__ __launch_bounds__(PK_THREADS) void pk_cuts(PkArgs a) {
 }
 
 // One tile per workgroup (2 workgroups per CU overlap each other's phases).
-template <bool INNER, bool MASKS = false>
+template <bool INNER, bool MASKS = false, bool RANKS = false>
 __global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t join_smem[];
   const uint32_t partitions = 1u << a.radix_bits;
@@ -900,6 +946,6 @@ __global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkAr
   const uint32_t cell_base = static_cast<uint32_t>(a.origin_pairs[tid < partitions ? tid : 0]) + a.rel_pairs[cell];
   PkWords words;
   pk_load_words(view, wave, lane, words);
-  pk_emit_tile<INNER, MASKS>(a, tile, view, words, cell_pairs, cell_base, join_smem, tid, lane, wave);
+  pk_emit_tile<INNER, MASKS, RANKS>(a, tile, view, words, cell_pairs, cell_base, join_smem, tid, lane, wave);
 }
 

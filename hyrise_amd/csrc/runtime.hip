@@ -38,6 +38,7 @@ struct OptionDefaults {
     set(HY_OPT_FUSED_SHARED_PREFIX, 1);
     set(HY_OPT_JOIN_FILL_WGS_PER_CU, 4);
     set(HY_OPT_JOIN_EMIT_TILE_GROUP, 64);
+    set(HY_OPT_JOIN_HAND_OVER_RANKS, 1 << 20);
   }
 };
 OptionDefaults g_option_defaults;   // (static initialisation: before any entry point can run)

@@ -625,6 +625,26 @@ def test_join_large_shuffled_build_keys_are_sorted_into_the_rank_table(device, m
                 assert used_rank_table() == 0, context
 
 
+@pytest.mark.parametrize("radix_bits", [None, 0, 5])
+def test_join_scattered_probe_keys_hand_their_ranks_over(device, options, radix_bits):
+    """Inner PK-FK joins whose probe keys have no locality (unencoded int32 / 4-byte FrameOfReference offsets): pass 1 leaves every probe
+    row's partner rank behind and pass 2 reads it back (pk_count_wave RANKS; forced here for a small probe side).  Keys outside the
+    build range, probe rows without a partner inside it (sparse build keys), a partial last tile, NULL-free probe columns of both
+    layouts; pairs and PosList cuts bit-identical to the oracle, with and without the hand-over."""
+    rng = np.random.default_rng(31)
+    n_build, n_probe = 40_000, 300_011
+    build_keys = (np.arange(n_build, dtype=np.int64) * 3 - 20_000).astype(np.int32)
+    probe_values = rng.integers(int(build_keys.min()) - 300, int(build_keys.max()) + 300, n_probe).astype(np.int32)
+    build = build_column(build_keys, None, 65535, abi.ENC_UNENCODED)
+    for encoding in (abi.ENC_UNENCODED, abi.ENC_FRAME_OF_REFERENCE):
+        probe = build_column(probe_values, None, 65535, encoding)
+        for threshold in (1, 0):
+            options.set(abi.OPT_JOIN_HAND_OVER_RANKS, threshold)
+            options.set(abi.OPT_JOIN_LDS_BUILD, 0)    # (the build side's bits staged in LDS is another path: not this test's)
+            check(build, probe, abi.JOIN_INNER, radix_bits, f"encoding {encoding} threshold {threshold} radix {radix_bits}")
+            assert used_rank_table() in (1, 2)
+
+
 def test_join_rank_table_int64_and_reference_build(device):
     rng = np.random.default_rng(77)
     keys = (np.arange(5000, dtype=np.int64) * 3 + 10_000_000_000)
