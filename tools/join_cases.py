@@ -27,6 +27,8 @@ def main():
     abi.check(lib.hy_init(0))
     if "--no-partitioned" in sys.argv:
         abi.check(lib.hy_set_option(abi.OPT_JOIN_LDS_HASH, 0))
+    if "--no-hand-over" in sys.argv:   # pass 2 looks every probe key up again
+        abi.check(lib.hy_set_option(abi.OPT_JOIN_HAND_OVER_RANKS, 0))
     if "--partitioned" in sys.argv:   # the radix-partitioned path for unique int32 keys (join_hp.hpp; off by default)
         abi.check(lib.hy_set_option(abi.OPT_JOIN_LDS_HASH, 1))
     dev = torch.device("cuda", 0)
