@@ -423,14 +423,14 @@ def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem
     if with_cases:
         cases = {}
         rng = np.random.default_rng(7)
-        # probe side in random order: FrameOfReference offsets widen to 4 bytes, no locality in the lookups
+        # probe side in random order: FrameOfReference offsets widen to 4 bytes, no locality in the lookups (pass 1 hands the ranks to pass 2)
         shuffled = DeviceColumn(storage.make_column(data.l_orderkey[rng.permutation(n)], None, abi.ENC_FRAME_OF_REFERENCE))
         run_s, r_s, keep_s = device_join(lib, torch, dev, orders, shuffled, n)
         dt_s, _ = timed_kernel(lib, torch, run_s, 3)
         cases["shuffled_probe"] = {"ms_per_join": dt_s * 1e3, "rows_per_s": (data.n_orders + n) / dt_s, "pairs": int(r_s.n_pairs),
                                    "GBps_on_algorithmic_bytes": (data.n_orders * 4 + n * 4 + int(r_s.n_pairs) * 16) / dt_s / 1e9}
         del keep_s, shuffled
-        # build side in random order (still unique): no sort, the rank table is filled by atomics + a scan
+        # build side in random order (still unique): the (key, RowID) pairs are radix-sorted and the rank table filled from the sorted keys
         build_shuffled = DeviceColumn(storage.make_column(data.o_orderkey[rng.permutation(data.n_orders)], None, abi.ENC_UNENCODED))
         run_b, r_b, keep_b = device_join(lib, torch, dev, build_shuffled, lineitem, n)
         dt_b, _ = timed_kernel(lib, torch, run_b, 3)
@@ -447,6 +447,19 @@ def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem
                                        "pairs_per_s": int(r_d.n_pairs) / dt_d,
                                        "GBps_on_algorithmic_bytes": (15_000_000 * 4 + probe_rows * 2 + int(r_d.n_pairs) * 16) / dt_d / 1e9}
         del keep_d, dup_build, dup_probe
+        # a selective dimension build (the first join of an SSB star plan): 1 000 of a dimension's 1 000 000 keys survive its filter, 180 M
+        # fact rows carry random foreign keys -- a key range of 31 250 table words takes the rank table, its bits are staged in LDS
+        sel_keys = np.sort(rng.choice(np.arange(1, 1_000_001, dtype=np.int32), 1000, replace=False))
+        sel_fact = rng.integers(1, 1_000_001, 180_000_000).astype(np.int32)
+        sel_build = DeviceColumn(storage.make_column(sel_keys, None, abi.ENC_UNENCODED))
+        sel_probe = DeviceColumn(storage.make_column(sel_fact, None, abi.ENC_UNENCODED))
+        run_s, r_s, keep_s = device_join(lib, torch, dev, sel_build, sel_probe, 1_000_000)
+        dt_s, _ = timed_kernel(lib, torch, run_s, 3)
+        lib.hy_debug_join_used_rank_table.restype = C.c_int
+        cases["selective_dimension_build"] = {"ms_per_join": dt_s * 1e3, "rows_per_s": (1000 + 180_000_000) / dt_s, "pairs": int(r_s.n_pairs),
+                                              "rank_table": bool(lib.hy_debug_join_used_rank_table()), "GBps_on_algorithmic_bytes": (180_000_000 * 4 + int(r_s.n_pairs) * 16) / dt_s / 1e9,
+                                              "note": "1 000 of 1 000 000 dimension keys against 180 M unencoded int32 foreign keys: rank table (not the sorted directory), pk_count_lds / pk_emit<., true>"}
+        del keep_s, sel_build, sel_probe, sel_fact
         # the boundary as the adapter uses it today: PosLists returned to HOST memory (0.96 GB over PCIe), one call
         from hyrise_amd.operators import HostJoinResult, join_hash
         t0 = time.perf_counter()
