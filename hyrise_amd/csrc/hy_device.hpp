@@ -108,6 +108,7 @@ struct hy_join_key_hint {
   std::atomic<uint32_t> hp_state{0}, hp_refused{0};
   std::atomic<uint32_t> has_duplicates{0};  // rank_table_mark met a key twice: later joins over the column go straight to the sorted directory
   std::atomic<uint64_t> hp_min{0}, hp_max{0};
+  std::atomic<uint32_t> probe_locality{0};  // as a PROBE side: 0 not looked at, 1 neighbouring rows hold neighbouring keys, 2 they do not (probe_key_locality, join.hip)
 };
 
 // The opaque ABI type.

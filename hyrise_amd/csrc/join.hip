@@ -3812,6 +3812,45 @@ static bool probe_keys_scattered(const hy_column* probe) {
   return false;
 }
 
+// ... and where the layout says nothing (4-byte values / offsets), a look at the keys themselves: 1 024 samples of 64 consecutive rows, spread over
+// the column; a sample is LOCAL when its keys span fewer than 2^16 key values (their table entries lie within 16 KB).  Shuffled foreign keys:
+// no sample is; TPC-H's l_orderkey as a ValueSegment: every one.  The answer stays with the column (it does not change).
+__global__ __launch_bounds__(64) void sample_key_spans(const SliceView* views, uint32_t n_slices, uint32_t* local_samples) {
+  const uint32_t slice = static_cast<uint32_t>((static_cast<uint64_t>(blockIdx.x) * n_slices) / gridDim.x);
+  const SliceView view = views[slice];
+  if (view.row_count < 64 || (view.kind != VIEW_INT32 && view.kind != VIEW_FOR32)) return;
+  const uint32_t row = view.row_begin + ((blockIdx.x * 2654435761u) % (view.row_count - 63)) + threadIdx.x;
+  uint32_t key = static_cast<const uint32_t*>(view.data)[row];
+  if (view.kind == VIEW_FOR32) key += static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[row / HY_FOR_BLOCK_SIZE]);
+  int32_t low = static_cast<int32_t>(key), high = static_cast<int32_t>(key);
+  for (int d = 32; d > 0; d >>= 1) {
+    const int32_t other_low = __shfl_xor(low, d), other_high = __shfl_xor(high, d);
+    low = other_low < low ? other_low : low;
+    high = other_high > high ? other_high : high;
+  }
+  if (threadIdx.x == 0 && static_cast<int64_t>(high) - static_cast<int64_t>(low) < 65536) atomicAdd(local_samples, 1u);
+}
+
+// true: the probe column's neighbouring rows do NOT hold neighbouring keys (pass 1 of an Inner join hands the ranks to pass 2)
+static hy_status probe_keys_lack_locality(const hy_column* probe, hipStream_t stream, bool* scattered) {
+  *scattered = false;
+  if (!probe_keys_scattered(probe) || !probe->d_slice_views || probe->n_slices == 0) return HY_OK;   // (1- and 2-byte offsets: local by construction)
+  uint32_t known = probe->join_hint.probe_locality.load(std::memory_order_relaxed);
+  if (known == 0) {
+    constexpr uint32_t SAMPLES = 1024;
+    uint32_t* host = nullptr;
+    uint32_t* device = nullptr;
+    HY_TRY(pinned_staging(64, reinterpret_cast<void**>(&host), reinterpret_cast<void**>(&device)));
+    *host = 0;
+    hipLaunchKernelGGL(sample_key_spans, dim3(SAMPLES), dim3(64), 0, stream, probe->d_slice_views, probe->n_slices, device);
+    HY_HIP(hipStreamSynchronize(stream));
+    known = *host * 4 >= SAMPLES * 3 ? 1u : 2u;   // three samples in four local: clustered
+    probe->join_hint.probe_locality.store(known, std::memory_order_relaxed);
+  }
+  *scattered = known == 2;
+  return HY_OK;
+}
+
 static thread_local int t_last_join_used_hp = 0;   // debug / tests: the thread's last join ran the kernels of join_hp.hpp
 
 // The radix-partitioned join (join_hp.hpp) over keys in [key_min, key_max].  *refused: the build side has a key twice -- nothing was
@@ -4214,8 +4253,8 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       hipEvent_t count_started = nullptr, count_stopped = nullptr;
       profile_events(&count_started, &count_stopped, HY_KERNEL_JOIN_COUNT);
       // Probe keys without locality, an Inner join over a million rows or more: pass 1 hands every row's partner rank to pass 2 (pk_count_wave RANKS)
-      hand_over_ranks = mode == HY_JOIN_INNER && !count_only && probe_keys_scattered(probe) && option(HY_OPT_JOIN_HAND_OVER_RANKS) > 0 &&
-                        probe->rows >= static_cast<uint64_t>(option(HY_OPT_JOIN_HAND_OVER_RANKS));
+      if (mode == HY_JOIN_INNER && !count_only && option(HY_OPT_JOIN_HAND_OVER_RANKS) > 0 && probe->rows >= static_cast<uint64_t>(option(HY_OPT_JOIN_HAND_OVER_RANKS)))
+        HY_TRY(probe_keys_lack_locality(probe, stream, &hand_over_ranks));
       if (hand_over_ranks) {
         HY_TRY(row_ranks.alloc(4 * size_t{n_tiles} * PK_TILE));
         k.row_ranks = row_ranks.as<uint32_t>();

@@ -58,6 +58,8 @@ def main():
         elif case == "duplicate_build_x4":
             dup_keys = np.repeat(data.o_orderkey[:3_750_000], 4)[rng.permutation(15_000_000)]
             measure(case, column(dup_keys, abi.ENC_UNENCODED), column(data.l_orderkey[:16_000_000], abi.ENC_FRAME_OF_REFERENCE), 16_000_000 * 4 + 1024)
+        elif case == "unencoded_probe":   # the headline's join with the foreign keys as a ValueSegment<int32>: clustered, but nothing in the layout says so
+            measure(case, column(data.o_orderkey, abi.ENC_UNENCODED), column(data.l_orderkey, abi.ENC_UNENCODED), n)
         elif case == "selective_dimension":
             # an SSB-shaped star join: 1 000 of a dimension's 1 000 000 keys survive its filter, 180 M fact rows carry random foreign keys
             keys = np.sort(rng.choice(np.arange(1, 1_000_001, dtype=np.int32), 1000, replace=False))
