@@ -49,6 +49,16 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         print(f"{name:22s} {dt * 1e3:7.3f} ms/join  pairs {int(r.n_pairs)}  rank table {lib.hy_debug_join_used_rank_table()}  pkfk {lib.hy_debug_join_used_pkfk()}  partitioned {lib.hy_debug_join_used_hp()}", flush=True)
+        if os.environ.get("HY_JOIN_TRACE"):   # (a -DHY_DEBUG_SWITCHES build: per-tile phase stamps of pk_emit, wall clock at 100 MHz)
+            lib.hy_debug_join_trace.restype = C.c_int
+            stamps = np.zeros((1 << 15, 6), dtype=np.uint64)
+            tiles = lib.hy_debug_join_trace(stamps.ctypes.data_as(C.c_void_p), C.c_uint32(1 << 15))
+            t = stamps[:tiles].astype(np.float64) / 100.0
+            t = t[t[:, 5] > 0]
+            phases = ("evaluate", "reserve + rank", "prefix", "stage", "copy out")
+            if len(t):
+                print(f"   pk_emit trace over {len(t)} tiles: span {t[:, 5].max() - t[:, 0].min():.1f} us, per tile " +
+                      ", ".join(f"{p} {np.median(t[:, i + 1] - t[:, i]):.2f}" for i, p in enumerate(phases)) + f", total {np.median(t[:, 5] - t[:, 0]):.2f} us (medians)")
 
     for case in cases:
         if case == "shuffled_probe":
