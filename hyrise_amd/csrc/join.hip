@@ -3839,10 +3839,13 @@ static hy_status probe_keys_lack_locality(const hy_column* probe, hipStream_t st
   if (known == 0) {
     constexpr uint32_t SAMPLES = 1024;
     uint32_t* host = nullptr;
-    uint32_t* device = nullptr;
-    HY_TRY(pinned_staging(64, reinterpret_cast<void**>(&host), reinterpret_cast<void**>(&device)));
-    *host = 0;
-    hipLaunchKernelGGL(sample_key_spans, dim3(SAMPLES), dim3(64), 0, stream, probe->d_slice_views, probe->n_slices, device);
+    uint32_t* mapped = nullptr;
+    HY_TRY(pinned_staging(64, reinterpret_cast<void**>(&host), reinterpret_cast<void**>(&mapped)));
+    DeviceBuffer counter;   // (the samples' atomics go to device memory: a thousand atomics on pinned host memory cross PCIe one by one, 0.75 ms)
+    HY_TRY(counter.alloc(64));
+    HY_HIP(hipMemsetAsync(counter.ptr, 0, 4, stream));
+    hipLaunchKernelGGL(sample_key_spans, dim3(SAMPLES), dim3(64), 0, stream, probe->d_slice_views, probe->n_slices, counter.as<uint32_t>());
+    HY_HIP(hipMemcpyAsync(host, counter.ptr, 4, hipMemcpyDeviceToHost, stream));
     HY_HIP(hipStreamSynchronize(stream));
     known = *host * 4 >= SAMPLES * 3 ? 1u : 2u;   // three samples in four local: clustered
     probe->join_hint.probe_locality.store(known, std::memory_order_relaxed);
@@ -4253,7 +4256,9 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       hipEvent_t count_started = nullptr, count_stopped = nullptr;
       profile_events(&count_started, &count_stopped, HY_KERNEL_JOIN_COUNT);
       // Probe keys without locality, an Inner join over a million rows or more: pass 1 hands every row's partner rank to pass 2 (pk_count_wave RANKS)
-      if (mode == HY_JOIN_INNER && !count_only && option(HY_OPT_JOIN_HAND_OVER_RANKS) > 0 && probe->rows >= static_cast<uint64_t>(option(HY_OPT_JOIN_HAND_OVER_RANKS)))
+      // (... and a table of a megabyte or more: random lookups in a smaller one stay in the L2)
+      if (mode == HY_JOIN_INNER && !count_only && option(HY_OPT_JOIN_HAND_OVER_RANKS) > 0 && probe->rows >= static_cast<uint64_t>(option(HY_OPT_JOIN_HAND_OVER_RANKS)) &&
+          (b.rank.range >> 5) * 8 >= (option(HY_OPT_JOIN_HAND_OVER_RANKS) == 1 ? 0u : (1u << 20)))
         HY_TRY(probe_keys_lack_locality(probe, stream, &hand_over_ranks));
       if (hand_over_ranks) {
         HY_TRY(row_ranks.alloc(4 * size_t{n_tiles} * PK_TILE));

@@ -277,9 +277,9 @@ enum {
                                       *      that moves through the probe side); 0 = every XCD works through its own eighth of the tiles        */
   HY_OPT_JOIN_FILL_WGS_PER_CU = 26,  /* 4    the checked one-pass fill wave by wave (rank_table_fill_waves: this many resident workgroups per
                                       *      CU, <= 8); 0 = one short-lived workgroup per slice (rank_table_fill_checked)              */
-  HY_OPT_JOIN_HAND_OVER_RANKS = 27,  /* 2^20 Inner PK-FK joins whose probe keys have no locality and whose probe side has at least this many rows: pass 1
-                                      *      leaves the partners' ranks behind (4 bytes a probe row), pass 2 reads them back instead of looking every
-                                      *      key up again; 0 = never                                                                          */
+  HY_OPT_JOIN_HAND_OVER_RANKS = 27,  /* 2^20 Inner PK-FK joins whose probe keys have no locality, whose probe side has at least this many rows and whose
+                                      *      rank table has a megabyte or more: pass 1 leaves the partners' ranks behind (4 bytes a probe row), pass 2
+                                      *      reads them back instead of looking every key up again; 0 = never, 1 = whenever the keys lack locality */
   HY_OPT_COUNT = 32
 };
 hy_status hy_set_option(uint32_t option, int64_t value);
