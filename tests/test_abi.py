@@ -61,7 +61,8 @@ def test_header_is_valid_c_and_cxx_and_ctypes_layouts_match(tmp_path):
     structs = {"hy_row_id": abi.RowID, "hy_segment": abi.Segment, "hy_value": abi.Value, "hy_predicate": abi.Predicate,
                "hy_scan_result": abi.ScanResult, "hy_join_predicate": abi.JoinPredicate, "hy_join_result": abi.JoinResult, "hy_join_status": abi.JoinStatus, "hy_lz4_blocks": abi.Lz4Blocks, "hy_operand": abi.Operand,
                "hy_aggregate_spec": abi.AggregateSpec, "hy_aggregate_column": abi.AggregateColumn, "hy_aggregate_result": abi.AggregateResult,
-               "hy_expression_node": abi.ExpressionNode, "hy_expression": abi.Expression, "hy_filter": abi.Filter, "hy_fused_aggregate": abi.FusedAggregate}
+               "hy_expression_node": abi.ExpressionNode, "hy_expression": abi.Expression, "hy_filter": abi.Filter, "hy_fused_aggregate": abi.FusedAggregate,
+               "hy_star_dimension": abi.StarDimension, "hy_star_column": abi.StarColumn, "hy_star_aggregate": abi.StarAggregate}
     source = tmp_path / "sizes.c"
     lines = [f'  printf("{name} %zu\\n", sizeof({name}));\n' for name in structs]
     for name, mirror in structs.items():   # ... and every field sits where the C compiler puts it (same field names on both sides)
