@@ -1583,4 +1583,132 @@ class ScanProjectAggregate : public AbstractReadOnlyOperator {
   std::shared_ptr<TransactionContext> _context;
 };
 
+// ---- a star join as one operator (hy_star_join_aggregate, csrc/plan.hip) ---------------------------------------------------------------
+// fact JOIN dimension_1 ... JOIN dimension_k (Inner, one key each, in this order) -> GROUP BY columns of any of the tables -> aggregates
+// over fact / dimension columns or over `left <op> right`: the subtree TableScan(s) -> JoinHash(es) -> Projection -> AggregateHash that
+// Hyrise's optimizer produces for SSB, handed to the library as ONE call.  Inputs are stored tables; the output is AggregateHash's: the
+// GROUP BY columns, then one column per aggregate.
+struct StarDimension {
+  std::shared_ptr<const AbstractOperator> table;
+  ColumnID key;
+  std::optional<ScanPredicate> filter;   // on a column of the dimension; none: the dimension is joined whole
+  ColumnID fact_key;
+};
+struct StarColumn { size_t table; ColumnID column; };   // table 0 = the fact table, d + 1 = dimension d
+struct StarAggregate {
+  WindowFunction function;
+  std::optional<StarColumn> left;                    // none: COUNT(*)
+  std::optional<ArithmeticOperator> op;              // with `right`: the aggregate of  left <op> right
+  std::optional<StarColumn> right;
+};
+
+class StarJoinAggregate : public AbstractReadOnlyOperator {
+ public:
+  StarJoinAggregate(std::shared_ptr<const AbstractOperator> fact, std::vector<StarDimension> dimensions, std::vector<StarColumn> groupby, std::vector<StarAggregate> aggregates)
+      : AbstractReadOnlyOperator(std::move(fact)), _dimensions(std::move(dimensions)), _groupby(std::move(groupby)), _aggregates(std::move(aggregates)) {}
+  const std::string& name() const override { static const std::string n = "StarJoinAggregate"; return n; }
+  uint64_t joined_rows = 0;
+
+ protected:
+  std::shared_ptr<const Table> _on_execute() override {
+    const auto fact = left_input_table();
+    std::vector<std::shared_ptr<const Table>> tables{fact};
+    for (const auto& dimension : _dimensions) tables.push_back(dimension.table->get_output());   // (executed by the caller, like every input)
+    for (const auto& table : tables) Assert(table->type() == TableType::Data, "StarJoinAggregate reads stored tables.");
+    std::vector<std::shared_ptr<DeviceColumn>> keep;
+    auto column_of = [&](const StarColumn& c) -> const hy_column* {
+      Assert(c.table < tables.size(), "StarJoinAggregate: no such table.");
+      Assert(tables[c.table]->column_data_type(c.column) != DataType::String, "StarJoinAggregate: string columns run as the operator chain.");
+      keep.push_back(device_column(tables[c.table], c.column));
+      return keep.back()->handle;
+    };
+    std::vector<hy_star_dimension> dims(_dimensions.size());
+    for (size_t d = 0; d < _dimensions.size(); ++d) {
+      std::memset(&dims[d], 0, sizeof(dims[d]));
+      dims[d].key = column_of({d + 1, _dimensions[d].key});
+      dims[d].fact_key = column_of({0, _dimensions[d].fact_key});
+      if (!_dimensions[d].filter) continue;
+      const ScanPredicate& predicate = *_dimensions[d].filter;
+      const auto column_type = tables[d + 1]->column_data_type(predicate.column_id);
+      dims[d].filter_column = column_of({d + 1, predicate.column_id});
+      dims[d].predicate.condition = static_cast<uint32_t>(predicate.condition);
+      dims[d].predicate.column_is_nullable = tables[d + 1]->column_is_nullable(predicate.column_id);
+      if (predicate.condition != PredicateCondition::IsNull && predicate.condition != PredicateCondition::IsNotNull) {
+        const hy_value first = to_hy_value(predicate.value), second = predicate.value2 ? to_hy_value(*predicate.value2) : hy_value{};
+        hy_predicate cast{};
+        const auto status = hy_predicate_cast(static_cast<uint32_t>(predicate.condition), static_cast<uint32_t>(column_type), static_cast<uint32_t>(data_type_from_all_type_variant(predicate.value)), &first,
+                                              predicate.value2 ? static_cast<uint32_t>(data_type_from_all_type_variant(*predicate.value2)) : HY_TYPE_NULL, predicate.value2 ? &second : nullptr, &cast);
+        Assert(status != HY_ERR_UNSUPPORTED, "StarJoinAggregate: the literal has no lossless predicate cast -- run the operator chain.");
+        check_status(status);
+        dims[d].predicate.condition = cast.condition, dims[d].predicate.value_type = cast.value_type, dims[d].predicate.value = cast.value, dims[d].predicate.value2 = cast.value2;
+      }
+    }
+    std::vector<hy_star_column> groupby(_groupby.size());
+    for (size_t g = 0; g < _groupby.size(); ++g) groupby[g] = hy_star_column{static_cast<uint32_t>(_groupby[g].table), 0, column_of(_groupby[g])};
+    // the caller's aggregates, then MIN of every GROUP BY column: the groups' representative rows are rows of an intermediate table
+    std::vector<hy_star_aggregate> specs(_aggregates.size() + _groupby.size());
+    for (size_t a = 0; a < _aggregates.size(); ++a) {
+      std::memset(&specs[a], 0, sizeof(specs[a]));
+      specs[a].function = static_cast<uint32_t>(_aggregates[a].function);
+      specs[a].op = HY_STAR_NO_OP;
+      if (!_aggregates[a].left) { Assert(_aggregates[a].function == WindowFunction::Count, "Only COUNT may omit its argument."); continue; }
+      specs[a].left = hy_star_column{static_cast<uint32_t>(_aggregates[a].left->table), 0, column_of(*_aggregates[a].left)};
+      if (_aggregates[a].op) {
+        Assert(_aggregates[a].right.has_value(), "StarJoinAggregate: an expression needs two columns.");
+        specs[a].op = static_cast<uint32_t>(*_aggregates[a].op);
+        specs[a].right = hy_star_column{static_cast<uint32_t>(_aggregates[a].right->table), 0, column_of(*_aggregates[a].right)};
+      }
+    }
+    for (size_t g = 0; g < _groupby.size(); ++g) {
+      std::memset(&specs[_aggregates.size() + g], 0, sizeof(hy_star_aggregate));
+      specs[_aggregates.size() + g].function = HY_AGG_MIN;
+      specs[_aggregates.size() + g].op = HY_STAR_NO_OP;
+      specs[_aggregates.size() + g].left = groupby[g];
+    }
+    Assert(specs.size() <= HY_MAX_STAR_AGGREGATES, "StarJoinAggregate: too many aggregates and GROUP BY columns for one call.");
+    const uint32_t capacity = static_cast<uint32_t>(std::min<uint64_t>(fact->row_count() + 1, 1u << 20));
+    std::vector<RowID> group_rows(capacity);
+    std::vector<std::vector<uint64_t>> values(specs.size(), std::vector<uint64_t>(capacity));
+    std::vector<std::vector<uint8_t>> nulls(specs.size(), std::vector<uint8_t>(capacity));
+    std::vector<hy_aggregate_column> columns(std::max<size_t>(1, specs.size()));
+    for (size_t a = 0; a < specs.size(); ++a) { columns[a].values = values[a].data(); columns[a].is_null = nulls[a].data(); }
+    hy_aggregate_result result{};
+    result.mem = HY_MEM_HOST;
+    result.group_capacity = capacity;
+    result.group_row_ids = reinterpret_cast<hy_row_id*>(group_rows.data());
+    result.columns = columns.data();
+    check_status(hy_star_join_aggregate(dims.data(), static_cast<uint32_t>(dims.size()), groupby.data(), static_cast<uint32_t>(groupby.size()), specs.data(), static_cast<uint32_t>(specs.size()),
+                                        &result, &joined_rows));
+    TableColumnDefinitions definitions;
+    for (const auto& g : _groupby) definitions.push_back(tables[g.table]->column_definitions()[g.column]);
+    static const char* names[] = {"MIN", "MAX", "SUM", "AVG", "COUNT", "COUNT DISTINCT", "STDDEV_SAMP", "ANY"};
+    for (size_t a = 0; a < _aggregates.size(); ++a)
+      definitions.push_back({std::string(names[static_cast<int>(_aggregates[a].function)]) + "(" + (_aggregates[a].left ? "expression " + std::to_string(a) : "*") + ")", static_cast<DataType>(columns[a].data_type),
+                             _aggregates[a].function != WindowFunction::Count});
+    auto cell = [&](size_t a, uint32_t g) -> AllTypeVariant {
+      if (nulls[a][g]) return NullValue{};
+      switch (static_cast<DataType>(columns[a].data_type)) {
+        case DataType::Int: return reinterpret_cast<const int32_t*>(values[a].data())[g];
+        case DataType::Long: return reinterpret_cast<const int64_t*>(values[a].data())[g];
+        case DataType::Float: return reinterpret_cast<const float*>(values[a].data())[g];
+        default: return reinterpret_cast<const double*>(values[a].data())[g];
+      }
+    };
+    auto output = std::make_shared<Table>(definitions, TableType::Data, Chunk::DEFAULT_SIZE);
+    for (uint32_t g = 0; g < result.n_groups; ++g) {
+      std::vector<AllTypeVariant> row;
+      for (size_t k = 0; k < _groupby.size(); ++k) row.push_back(cell(_aggregates.size() + k, g));
+      for (size_t a = 0; a < _aggregates.size(); ++a) row.push_back(cell(a, g));
+      output->append(std::move(row));
+    }
+    output->finalize();
+    return output;
+  }
+
+ private:
+  std::vector<StarDimension> _dimensions;
+  std::vector<StarColumn> _groupby;
+  std::vector<StarAggregate> _aggregates;
+};
+
 }  // namespace hyrise_amd

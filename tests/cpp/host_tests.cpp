@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <functional>
 #include <iostream>
+#include <map>
+#include <random>
+#include <array>
 
 #include "../../hyrise_amd/host/hyrise_host.hpp"
 
@@ -329,6 +332,56 @@ static void test_scan_project_aggregate() {   // the fused pass behind the opera
   EXPECT_TRUE(static_cast<uint64_t>(counted) == second->get_output()->row_count());
 }
 
+static void test_star_join_aggregate() {   // SSB's plan shape as one operator, against nested loops over the same tables
+  std::mt19937 rng(17);
+  const auto make = [](std::vector<std::string> names, ChunkOffset chunk) {
+    TableColumnDefinitions definitions;
+    for (auto& name : names) definitions.push_back({name, DataType::Int, false});
+    return std::make_shared<Table>(definitions, TableType::Data, chunk);
+  };
+  auto part = make({"p_key", "p_brand", "p_category"}, 40);        // filtered dimension, sparse keys
+  auto date = make({"d_key", "d_year"}, 16);                       // unfiltered dimension
+  auto fact = make({"f_part", "f_date", "f_revenue", "f_cost"}, 700);
+  std::vector<std::array<int32_t, 3>> parts;
+  for (int32_t i = 0; i < 300; ++i) { parts.push_back({i * 7 + 3, static_cast<int32_t>(rng() % 9), static_cast<int32_t>(rng() % 5)}); part->append({parts.back()[0], parts.back()[1], parts.back()[2]}); }
+  std::vector<std::array<int32_t, 2>> dates;
+  for (int32_t i = 0; i < 50; ++i) { dates.push_back({19920101 + i, 1992 + i / 10}); date->append({dates.back()[0], dates.back()[1]}); }
+  struct Cell { int64_t revenue = 0, profit = 0, count = 0; };
+  std::map<std::pair<int32_t, int32_t>, Cell> expected;
+  uint64_t joined = 0;
+  for (int32_t i = 0; i < 5000; ++i) {
+    const bool dangling = rng() % 10 == 0;
+    const int32_t p = dangling ? 1 : parts[rng() % parts.size()][0], d = dates[rng() % dates.size()][0];
+    const int32_t revenue = static_cast<int32_t>(rng() % 10000), cost = static_cast<int32_t>(rng() % 6000);
+    fact->append({p, d, revenue, cost});
+    for (const auto& row : parts) {
+      if (row[0] != p || row[2] != 2) continue;   // p_category = 2
+      auto& cell = expected[std::make_pair(dates[static_cast<size_t>(d - 19920101)][1], row[1])];
+      cell.revenue += revenue; cell.profit += revenue - cost; ++cell.count; ++joined;
+    }
+  }
+  part->finalize(); date->finalize(); fact->finalize();
+  for (const auto encoding : {EncodingType::Unencoded, EncodingType::FrameOfReference, EncodingType::Dictionary}) {
+    ChunkEncoder::encode_all_chunks(fact, encoding);
+    ChunkEncoder::encode_all_chunks(part, encoding);
+    const std::vector<StarDimension> dimensions = {{wrap(part), ColumnID{0}, ScanPredicate{ColumnID{2}, PredicateCondition::Equals, AllTypeVariant{int64_t{2}}, std::nullopt}, ColumnID{0}},
+                                                   {wrap(date), ColumnID{0}, std::nullopt, ColumnID{1}}};
+    auto star = std::make_shared<StarJoinAggregate>(wrap(fact), dimensions, std::vector<StarColumn>{{2, ColumnID{1}}, {1, ColumnID{1}}},
+                                                    std::vector<StarAggregate>{{WindowFunction::Sum, StarColumn{0, ColumnID{2}}, std::nullopt, std::nullopt},
+                                                                               {WindowFunction::Sum, StarColumn{0, ColumnID{2}}, ArithmeticOperator::Subtraction, StarColumn{0, ColumnID{3}}},
+                                                                               {WindowFunction::Count, std::nullopt, std::nullopt, std::nullopt}});
+    star->execute();
+    const auto out = star->get_output();
+    EXPECT_TRUE(star->joined_rows == joined && out->row_count() == expected.size());
+    for (const auto& row : out->get_rows()) {
+      const auto it = expected.find(std::make_pair(std::get<int32_t>(row[0]), std::get<int32_t>(row[1])));
+      EXPECT_TRUE(it != expected.end());
+      if (it == expected.end()) continue;
+      EXPECT_TRUE(std::get<int64_t>(row[2]) == it->second.revenue && std::get<int64_t>(row[3]) == it->second.profit && std::get<int64_t>(row[4]) == it->second.count);
+    }
+  }
+}
+
 static void test_join_output_chunks_are_merged() {   // join_output_writing.cpp:245-296: PosLists below 1000 rows merge up to 4000
   const auto left = load_and_encode("join_test_runner/input_table_left_15.tbl", 3, EncodingType::Unencoded);
   const auto right = load_and_encode("join_test_runner/input_table_right_10.tbl", 3, EncodingType::Unencoded);
@@ -603,6 +656,7 @@ int main(int argc, char** argv) {
   run("JoinHash with secondary predicates vs nested loop", test_join_with_secondary_predicates);
   run("AggregateHash vs .tbl fixtures (+ CannotSumStringColumns)", test_aggregates_against_fixtures);
   run("ScanProjectAggregate (fused pass) with and without Validate", test_scan_project_aggregate);
+  run("StarJoinAggregate (hy_star_join_aggregate) against nested loops", test_star_join_aggregate);
   hy_shutdown();
   std::printf("%s\n", g_failures ? "HOST TESTS FAILED" : "HOST TESTS PASSED");
   return g_failures ? 1 : 0;
