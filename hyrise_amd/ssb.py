@@ -245,6 +245,29 @@ def star_groups(result, n_groupby_columns):
     return [(tuple(int(k[i]) for k in keys), [c[i] for c in cells]) for i in range(result.n_groups)]
 
 
+def sharded_star_groups(comm, columns, query, result=None):
+    """N > 1: every rank runs hy_star_join_aggregate over ITS chunks of the fact table (the dimensions are replicated), the ranks' partial
+    groups -- a key tuple and the partial SUM each -- are all-gathered and added up per key: integer sums, exact in any order.
+    -> ([(key tuple, [sum])] as aggregate_groups returns it, this rank's joined rows, the result object for the next call)"""
+    import numpy as np
+    from .operators import star_join_aggregate
+    torch = comm.torch
+    dimensions, groupby, aggregates = star_plan(columns, query)
+    result, joined = star_join_aggregate(dimensions, groupby, aggregates, result=result)
+    n, n_keys = result.n_groups, len(groupby)
+    cells = np.zeros((n, 1 + n_keys), dtype=np.int64)
+    if n:
+        cells[:, 0] = np.frombuffer(result.raw[0].tobytes(), dtype=np.int64)[:n]                      # SUM: int64
+        for g in range(n_keys):
+            cells[:, 1 + g] = np.frombuffer(result.raw[1 + g].tobytes(), dtype=np.int32)[:n]          # MIN of an int32 GROUP BY column
+    totals = {}
+    for part in comm.all_gather_var(torch.from_numpy(cells)):
+        for row in part.numpy().tolist():
+            key = tuple(row[1:])
+            totals[key] = totals.get(key, 0) + row[0]
+    return [(key, [total]) for key, total in totals.items()], joined, result
+
+
 def referenced_bytes(data, query):
     """Algorithmic bytes: referenced lineorder columns x 4 B x N + dimension keys + filter columns."""
     fact = {"2.1": 4, "4.1": 6}[query]   # lo_partkey, lo_suppkey, lo_orderdate, lo_revenue (+ lo_custkey, lo_supplycost)
@@ -339,8 +362,29 @@ def bench(sf=30.0, steps=3, world=1, rank=0, dist=None, share_gpu=False, local_r
             entry.update({"ms": star_seconds * 1e3, "lineorder_rows_per_s": data.n_lineorder / star_seconds, "GBps_on_algorithmic_bytes": algorithmic / star_seconds / 1e9,
                           "plan": "hy_star_join_aggregate: scan -> JoinHash per dimension -> projection -> AggregateHash as one call of the library (csrc/plan.hip); "
                                   "operator_calls_from_python_ms: the same calls made one by one through ctypes (hyrise_amd/ssb.py run_query)"})
+        if comm is not None:   # every rank's shard as ONE hy_star_join_aggregate call, the ranks' partial groups added up
+            star = {}
+
+            def one_call_per_rank():
+                star["groups"], star["joined"], star["result"] = sharded_star_groups(comm, columns, query, star.get("result"))
+
+            one_call_per_rank()
+            if result_rows(star["groups"]) != result_rows(holder["groups"]):
+                raise RuntimeError(f"SSB Q{query}: the ranks' hy_star_join_aggregate results and the operator chain disagree")
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one_call_per_rank()
+            torch.cuda.synchronize()
+            star_seconds = (time.perf_counter() - t0) / steps
+            t = torch.tensor([star_seconds], dtype=torch.float64, device=comm._device)
+            comm.all_reduce(t, "max")
+            star_seconds = float(t.item())
+            entry["operator_calls_from_python_ms"] = entry["ms"]
+            entry.update({"ms": star_seconds * 1e3, "lineorder_rows_per_s": data.n_lineorder / star_seconds, "GBps_on_algorithmic_bytes": algorithmic / star_seconds / 1e9})
         if comm is not None:   # the same query with `customer` / `part` joined by hash repartition (tuples to the key's rank and back)
-            entry["plan"] = "lineorder chunk-sharded, dimensions replicated, groups all-reduced"
+            entry["plan"] = "lineorder chunk-sharded, dimensions replicated: hy_star_join_aggregate per rank, the partial groups all-gathered and added (operator_calls_from_python_ms: the operator chain per rank, groups all-reduced)"
             try:
                 repartition_seconds, repartition_joined = timed(("customer", "part"))
                 entry["repartitioned"] = {"plan": "customer and part joined by hash repartition (two all-to-all pairs per join), the other dimensions replicated",
