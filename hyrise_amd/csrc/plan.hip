@@ -71,14 +71,44 @@ static hy_status value_column(const void* values, uint64_t n, uint32_t data_type
   return hy_column_create(segments.data(), n_chunks, HY_MEM_DEVICE, &out.column);
 }
 
-// column `base` at the rows `rows` as a plain value column (values in `storage`)
+// Could a cell of the column be NULL as far as its layout tells?  (Value / FrameOfReference segments without a null vector cannot; a dictionary
+// segment's NULL is a value id, which only the data shows.)
+static bool may_hold_nulls(const hy_column* column) {
+  for (const hy_segment& s : column->host_segments) {
+    if (s.nulls != nullptr || (s.encoding != HY_ENC_UNENCODED && s.encoding != HY_ENC_FRAME_OF_REFERENCE)) return true;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void any_null_byte(const uint8_t* bytes, uint64_t n, uint32_t* found) {
+  bool any = false;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) any = any || bytes[i] != 0;
+  if (__any(any) && (threadIdx.x & 63) == 0) *found = 1;
+}
+
+// column `base` at the rows `rows` as a plain value column (values in `storage`).  The intermediate tables of this plan carry no null vectors:
+// a column whose cells at these rows include a NULL (a nullable foreign key, a GROUP BY column with NULLs) sends the caller to the operator chain.
 static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint64_t n, DeviceBuffer& storage, ColumnHandle& out) {
   if (base->data_type < HY_TYPE_INT || base->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "hy_star_join_aggregate: numeric columns only");
   HY_TRY(storage.alloc(type_bytes(base->data_type) * std::max<uint64_t>(n, 1) + 16));
   if (n) {
     ColumnHandle through;
     HY_TRY(reference_column(base, rows, n, through));
-    HY_TRY(hy_column_export(through.column, storage.ptr, nullptr));
+    if (may_hold_nulls(base)) {
+      DeviceBuffer null_bytes, found;
+      HY_TRY(null_bytes.alloc(n));
+      HY_TRY(found.alloc(64));
+      hipStream_t stream = current_stream();
+      HY_HIP(hipMemsetAsync(found.ptr, 0, 4, stream));
+      HY_TRY(hy_column_export(through.column, storage.ptr, null_bytes.as<uint8_t>()));
+      hipLaunchKernelGGL(any_null_byte, dim3(static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 2048))), dim3(256), 0, stream, null_bytes.as<uint8_t>(), n, found.as<uint32_t>());
+      uint32_t any = 0;
+      HY_HIP(hipMemcpyAsync(&any, found.ptr, 4, hipMemcpyDeviceToHost, stream));
+      HY_HIP(hipStreamSynchronize(stream));
+      if (any) return fail(HY_ERR_UNSUPPORTED, "hy_star_join_aggregate: a column of the join result holds NULLs -- run the operator chain");
+    } else {
+      HY_TRY(hy_column_export(through.column, storage.ptr, nullptr));
+    }
   }
   return value_column(storage.ptr, n, base->data_type, out);
 }

@@ -109,3 +109,30 @@ def test_star_join_aggregate_small_tables(device, case):
     n = result.n_groups
     got = {(result.column(3)[i], result.column(4)[i]): [result.column(0)[i], result.column(1)[i], result.column(2)[i]] for i in range(n)}
     assert got == want and (case != "nothing_survives" or n == 0)
+
+
+def test_star_join_aggregate_refuses_null_cells(device):
+    """The plan's intermediate tables carry no null vectors: a foreign key that is NULL in a row that survives the first join, or an
+    aggregate input with NULLs, sends the caller to the operator chain (HY_ERR_UNSUPPORTED) -- it is not joined as key 0."""
+    import numpy as np
+    from hyrise_amd import abi, storage
+    from hyrise_amd.operators import star_join_aggregate
+    from hyrise_amd.storage import DeviceColumn
+    rng = np.random.default_rng(3)
+    n = 50_000
+    a_key = np.arange(0, 200, dtype=np.int32)
+    b_key = np.arange(0, 50, dtype=np.int32)                                  # (key 0 exists: a NULL exported as 0 would find it)
+    fk_a = rng.integers(0, 200, n).astype(np.int32)
+    fk_b = rng.integers(0, 50, n).astype(np.int32)
+    x = rng.integers(0, 100, n).astype(np.int32)
+    nulls = rng.random(n) < 0.1
+    column = lambda values, null=None, chunk=8_000: DeviceColumn(storage.make_column(values, null, abi.ENC_UNENCODED, chunk))
+    a, b, fa, x_plain = column(a_key, None, 64), column(b_key, None, 64), column(fk_a), column(x)
+    dimensions = lambda second_key: [(a, None, None, fa), (b, None, None, second_key)]
+    groupby = [(1, a)]
+    for second_key, measure in ((column(fk_b, nulls), x_plain), (column(fk_b), column(x, nulls))):
+        with pytest.raises(abi.HyriseAmdError) as error:
+            star_join_aggregate(dimensions(second_key), groupby, [(abi.AGG_SUM, (0, measure), None, None), (abi.AGG_MIN, groupby[0], None, None)])
+        assert error.value.status == abi.ERR_UNSUPPORTED
+    result, joined = star_join_aggregate(dimensions(column(fk_b)), groupby, [(abi.AGG_SUM, (0, x_plain), None, None), (abi.AGG_MIN, groupby[0], None, None)])
+    assert joined == n and result.n_groups == 200
