@@ -397,6 +397,7 @@ def bench(sf=30.0, steps=3, world=1, rank=0, dist=None, share_gpu=False, local_r
             rows = data.sqlite_result(sql)
             want = sorted(((r[1], r[2]), r[0]) for r in rows) if query == "2.1" else sorted(((r[0], r[1]), r[2]) for r in rows)
             entry["matches_sqlite"] = result_rows(holder["groups"]) == want
+        entry["_rows"] = result_rows(holder["groups"])   # (for the caller's parity check against the CPU oracle; bench.py drops it from its output)
         out[f"q{query}"] = entry
     return out
 

@@ -33,6 +33,9 @@ def main():
     from hyrise_amd import ssb
     out = ssb.bench(args.sf, args.steps, world, rank, dist, share_gpu, local_rank, args.verify)
     if rank == 0:
+        for entry in out.values():
+            if isinstance(entry, dict):
+                entry.pop("_rows", None)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
