@@ -36,9 +36,25 @@
 #include <thread>
 #include <vector>
 
-namespace hy {
+// Two builds of this file: GROUP BY over at most 4 columns (this translation unit: a tuple is five 64-bit words in registers -- every
+// kernel below is tuned at that size) and, for the plans with more (TPC-H Q10 groups by seven columns, Q18 by five; the reference takes any
+// number: aggregate_hash.cpp:1184-1198, AggregateKeySmallVector), the same code with tuples of nine words (aggregate_wide.hip includes this
+// file with HY_MAX_GROUPBY 8; its entry points carry the suffix _wide and the ones below hand wider GROUP BYs over to them).
+#ifndef HY_MAX_GROUPBY
+#define HY_MAX_GROUPBY 4
+#endif
+#if HY_MAX_GROUPBY == 4
+#define HY_AGG_NAMESPACE narrow_keys
+#define HY_AGG_ENTRY(name) name
+#else
+#define HY_AGG_NAMESPACE wide_keys
+#define HY_AGG_ENTRY(name) name##_wide
+#endif
 
-constexpr uint32_t MAX_GROUPBY = 4;
+namespace hy {
+inline namespace HY_AGG_NAMESPACE {
+
+constexpr uint32_t MAX_GROUPBY = HY_MAX_GROUPBY;
 constexpr uint32_t MAX_AGGREGATES = 8;
 constexpr uint32_t LDS_SLOTS = 256;
 constexpr uint32_t MAX_LDS_PROBES = 24;      // linear probing in a workgroup's table: rows that would walk further are handled like rows of a full table
@@ -427,7 +443,9 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     }
   }
   // direct-mapped table?
-  uint32_t direct_size[MAX_GROUPBY] = {1, 1, 1, 1}, direct_stride[MAX_GROUPBY] = {0, 0, 0, 0};
+  uint32_t direct_size[MAX_GROUPBY], direct_stride[MAX_GROUPBY];
+#pragma unroll
+  for (uint32_t g = 0; g < MAX_GROUPBY; ++g) { direct_size[g] = 1; direct_stride[g] = 0; }
   bool direct = a.n_groupby > 0 && local_keys == (1u << a.n_groupby) - 1 && !keys_unaligned;   // (aligned: the wide loads of pass 1 stay inside the word that holds a chunk's last value id)
   {
     uint64_t product = 1;
@@ -2478,7 +2496,13 @@ static void launch_partition_rows_of(uint32_t words, uint32_t grid, size_t lds, 
     case 2: launch_partition_rows_as<SCATTER, 2, NARROW>(grid, lds, stream, a, pa); break;
     case 3: launch_partition_rows_as<SCATTER, 3, NARROW>(grid, lds, stream, a, pa); break;
     case 4: launch_partition_rows_as<SCATTER, 4, NARROW>(grid, lds, stream, a, pa); break;
-    default: launch_partition_rows_as<SCATTER, 5, NARROW>(grid, lds, stream, a, pa); break;
+#if HY_MAX_GROUPBY > 4
+    case 5: launch_partition_rows_as<SCATTER, 5, NARROW>(grid, lds, stream, a, pa); break;
+    case 6: launch_partition_rows_as<SCATTER, 6, NARROW>(grid, lds, stream, a, pa); break;
+    case 7: launch_partition_rows_as<SCATTER, 7, NARROW>(grid, lds, stream, a, pa); break;
+    case 8: launch_partition_rows_as<SCATTER, 8, NARROW>(grid, lds, stream, a, pa); break;
+#endif
+    default: launch_partition_rows_as<SCATTER, MAX_GROUPBY + 1, NARROW>(grid, lds, stream, a, pa); break;
   }
 }
 static void launch_partition_rows(bool scatter, uint32_t words, uint32_t grid, size_t lds, hipStream_t stream, const AggArgs& a, const PartitionArgs& pa) {
@@ -2493,7 +2517,13 @@ static void launch_aggregate_partitions(uint32_t words, uint32_t grid, size_t ld
     case 2: hipLaunchKernelGGL((aggregate_partitions<2, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
     case 3: hipLaunchKernelGGL((aggregate_partitions<3, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
     case 4: hipLaunchKernelGGL((aggregate_partitions<4, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
-    default: hipLaunchKernelGGL((aggregate_partitions<5, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+#if HY_MAX_GROUPBY > 4
+    case 5: hipLaunchKernelGGL((aggregate_partitions<5, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+    case 6: hipLaunchKernelGGL((aggregate_partitions<6, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+    case 7: hipLaunchKernelGGL((aggregate_partitions<7, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+    case 8: hipLaunchKernelGGL((aggregate_partitions<8, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
+#endif
+    default: hipLaunchKernelGGL((aggregate_partitions<MAX_GROUPBY + 1, NARROW>), dim3(grid), dim3(256), lds, stream, a, pa, direct); break;
   }
 }
 
@@ -3550,6 +3580,7 @@ static hy_status run_fused(const hy_filter* filters, uint32_t n_filters, const h
   return run_aggregate(groupby, n_groupby, specs.data(), n_aggregates, result, &q);
 }
 
+}  // namespace HY_AGG_NAMESPACE
 }  // namespace hy
 
 using namespace hy;
@@ -3590,8 +3621,24 @@ static hy_status run_with_result_memory(hy_aggregate_result* result, uint32_t n_
 
 extern "C" {
 
-hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
-                                    const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result) {
+#if HY_MAX_GROUPBY == 4
+// aggregate_wide.hip: this file again, with nine-word tuples
+hy_status hy_scan_project_aggregate_wide(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
+                                         const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
+hy_status hy_aggregate_hash_wide(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates, uint32_t n_aggregates,
+                                 hy_aggregate_result* result);
+int hy_debug_aggregate_path_wide(void);
+int hy_debug_aggregate_finished_on_device_wide(void);
+int hy_debug_aggregate_small_domain_wide(void);
+static bool g_last_aggregate_was_wide = false;   // debug accessors: which build answered the last call of this process
+#endif
+
+hy_status HY_AGG_ENTRY(hy_scan_project_aggregate)(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
+                                                  const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result) {
+#if HY_MAX_GROUPBY == 4
+  g_last_aggregate_was_wide = n_groupby > MAX_GROUPBY;
+  if (n_groupby > MAX_GROUPBY) return hy_scan_project_aggregate_wide(filters, n_filters, groupby_columns, n_groupby, aggregates, n_aggregates, result);
+#endif
   if (!result || (n_filters && !filters) || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: null argument");
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: result columns missing");
   // every column of the plan lives on the calling thread's device (hy_bind_device: one worker thread per GPU) -- checked before a compressed
@@ -3623,8 +3670,16 @@ hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters
   });
 }
 
-hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates,
-                            uint32_t n_aggregates, hy_aggregate_result* result) {
+hy_status HY_AGG_ENTRY(hy_aggregate_hash)(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates,
+                                          uint32_t n_aggregates, hy_aggregate_result* result) {
+#if HY_MAX_GROUPBY == 4
+  {   // (COUNT(DISTINCT x) groups by the GROUP BY columns and x: one more key word)
+    uint32_t key_columns = n_groupby;
+    for (uint32_t i = 0; aggregates && i < n_aggregates; ++i) if (aggregates[i].function == HY_AGG_COUNT_DISTINCT) key_columns = n_groupby + 1;
+    g_last_aggregate_was_wide = key_columns > MAX_GROUPBY;
+    if (g_last_aggregate_was_wide) return hy_aggregate_hash_wide(groupby_columns, n_groupby, aggregates, n_aggregates, result);
+  }
+#endif
   if (!result || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_aggregate_hash: null argument");
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_aggregate_hash: result columns missing");
   for (uint32_t i = 0; i < n_groupby; ++i) HY_TRY(on_this_device(groupby_columns[i], "hy_aggregate_hash"));
@@ -3668,16 +3723,21 @@ hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_
 }
 
 // debug only: which path the last hy_aggregate_hash of this process took -- 0 aggregate_rows, else the partition bits; not part of the public header
-int hy_debug_aggregate_path(void) { return static_cast<int>(g_agg_path); }
+#if HY_MAX_GROUPBY == 4
+#define HY_AGG_DEBUG(name, value) int name(void) { return g_last_aggregate_was_wide ? name##_wide() : static_cast<int>(value); }
+#else
+#define HY_AGG_DEBUG(name, value) int name##_wide(void) { return static_cast<int>(value); }
+#endif
+HY_AGG_DEBUG(hy_debug_aggregate_path, g_agg_path)
 
 // debug / tests only: 1 = the last aggregate of this process was ordered and written by the finish kernels (large results of plain functions)
-int hy_debug_aggregate_finished_on_device(void) { return static_cast<int>(g_agg_finished_on_device); }
+HY_AGG_DEBUG(hy_debug_aggregate_finished_on_device, g_agg_finished_on_device)
 
 // debug / tests only: 1 = the last hy_aggregate_hash of this process ran aggregate_small_domain (aggregate_small.hpp)
-int hy_debug_aggregate_small_domain(void) { return static_cast<int>(g_agg_small); }
+HY_AGG_DEBUG(hy_debug_aggregate_small_domain, g_agg_small)
 
 // debug only (HY_AGG_TRACE): the per-slice phase stamps of the last aggregate_rows launch; not part of the public header
-int hy_debug_aggregate_trace(uint64_t* out, uint32_t capacity_slices) {
+int HY_AGG_ENTRY(hy_debug_aggregate_trace)(uint64_t* out, uint32_t capacity_slices) {
   if (!g_agg_trace) return 0;
   const uint32_t n = g_agg_trace_slices < capacity_slices ? g_agg_trace_slices : capacity_slices;
   (void)hipDeviceSynchronize();

@@ -3511,6 +3511,8 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
           while (key_bits < 32 && (range >> key_bits) != 0) ++key_bits;
           HY_TRY(b.keys_tmp.alloc(key_bytes * (total + 4)));
           HY_TRY(b.rows_tmp.alloc(row_bytes * total));
+          // (read BEFORE anything below is queued: publish_build_flags writes these pinned fields again, with distances instead of keys)
+          const uint64_t remembered_min = mailbox->key_min, remembered_max = mailbox->key_max, remembered_or = mailbox->key_or;
           hipLaunchKernelGGL(shift_keys, key_grid, dim3(256), 0, stream, b.keys.as<uint32_t>(), total, 0u - static_cast<uint32_t>(key_min));
           uint32_t* sorted_keys = b.keys.as<uint32_t>();
           uint32_t* sorted_rows = b.rows.as<uint32_t>();
@@ -3524,7 +3526,6 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
           HY_HIP(hipMemsetAsync(b.flags.ptr, 0, 64, stream));
           hipLaunchKernelGGL(check_sorted<uint32_t>, check_grid, dim3(1024), 0, stream, b.keys.as<uint32_t>(), total, b.flags.as<uint32_t>());
           hipLaunchKernelGGL(publish_build_flags<uint32_t>, dim3(1), dim3(1), 0, stream, b.flags.as<uint32_t>(), b.keys.as<uint32_t>(), total, mailbox_dev);
-          const uint64_t remembered_min = mailbox->key_min, remembered_max = mailbox->key_max, remembered_or = mailbox->key_or;
           HY_HIP(hipStreamSynchronize(stream));
           const bool duplicates = mailbox->equal_neighbours != 0;
           mailbox->key_min = remembered_min;   // (the second look saw distances, not keys)
