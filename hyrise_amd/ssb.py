@@ -99,11 +99,14 @@ class SsbData:
     def sqlite_result(self, sql):
         """The query's rows from SQLite over the same tables (the reference's own verification practice)."""
         import sqlite3
-        db = sqlite3.connect(":memory:")
-        for table, names in self.TABLES.items():
-            db.execute(f'create table "{table}" ({", ".join(n + " integer" for n in names)})')
-            rows = list(zip(*[getattr(self, n).tolist() for n in names]))
-            db.executemany(f'insert into "{table}" values ({", ".join("?" for _ in names)})', rows)
+        db = getattr(self, "_sqlite", None)
+        if db is None:   # (loaded once per data set: at scale factor 1 the inserts take half a minute)
+            db = sqlite3.connect(":memory:")
+            for table, names in self.TABLES.items():
+                db.execute(f'create table "{table}" ({", ".join(n + " integer" for n in names)})')
+                rows = list(zip(*[getattr(self, n).tolist() for n in names]))
+                db.executemany(f'insert into "{table}" values ({", ".join("?" for _ in names)})', rows)
+            self._sqlite = db
         return [tuple(r) for r in db.execute(sql).fetchall()]
 
 

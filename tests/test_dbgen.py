@@ -133,8 +133,7 @@ def test_q1_on_dbgen_rows_matches_numpy(data):
     check_q1(data, result)
 
 
-@pytest.mark.gpu
-def test_dbgen_rows_on_device(device, data):
+def check_on_device(data, with_sqlite=True):
     """Config 2's two forms, config 3 and config 4 on real dbgen rows, through the C ABI: PosLists / pairs / groups are the oracle's."""
     import torch
     from hyrise_amd.distributed import HipExecutor
@@ -167,6 +166,30 @@ def test_dbgen_rows_on_device(device, data):
             assert abs(x - y) <= 1e-9 * abs(y)
     ex = HipExecutor(torch.device("cuda", 0))
     revenue, qualifying = tpch.run_q6(ex, {name: DeviceColumn(column) for name, column in tpch.q6_columns(data).items()})
-    check_q6(data, revenue, qualifying)
+    if with_sqlite:
+        check_q6(data, revenue, qualifying)
+    else:   # (at scale: numpy and the oracle's plan; loading six million rows into SQLite takes longer than everything else here)
+        from test_tpch_q6 import numpy_q6
+        exact_revenue, exact_rows = numpy_q6(data)
+        oracle_revenue, oracle_rows = tpch.run_q6(OracleExecutor(threads=os.cpu_count() or 1), tpch.q6_columns(data))
+        assert qualifying == exact_rows == oracle_rows > 0 and abs(revenue - exact_revenue) <= 1e-9 * exact_revenue and abs(revenue - oracle_revenue) <= 1e-9 * exact_revenue
     check_q1(data, tpch.run_q1(ex, {name: DeviceColumn(column) for name, column in tpch.q1_columns(data).items()}))
     check_q1(data, tpch.q1_fused({name: DeviceColumn(column) for name, column in tpch.q1_columns(data).items()}))
+
+
+@pytest.mark.gpu
+def test_dbgen_rows_on_device(device, data):
+    check_on_device(data)
+
+
+@pytest.mark.gpu
+@needs_generator
+@pytest.mark.timeout(600)
+def test_dbgen_scale_factor_one_on_device(device):
+    """The same checks on the reference generator's scale factor 1 (1 500 000 orders, 6 001 215 lineitems, 92 chunks): string-date PosLists,
+    orders x lineitem pair bytes (Inner and Semi), the Q1 core groups, Q6 and Q1 -- generated on the spot by oracle/_ref/tpch_rows (the
+    reference's dbgen, compiled from the reference tree; skipped where the binary did not travel)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        sf1 = tpch.DbgenData.generate(1, GENERATOR, tmp)
+    assert (sf1.n_orders, sf1.n_lineitems) == (1_500_000, 6_001_215)
+    check_on_device(sf1, with_sqlite=False)

@@ -35,6 +35,33 @@ def test_ssb_query_on_device(device, query, sql):
     assert star_joined == joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == sqlite
 
 
+@pytest.mark.timeout(600)
+def test_ssb_scale_factor_one_on_device(device):
+    """Config 5 at scale factor 1 (6 000 000 lineorder rows, 92 chunks; part 200 000, customer 30 000, supplier 2 000 rows): the operator
+    chain and the one-call plan on the device against the same plans on the CPU oracle (every thread) and against SQLite -- group rows,
+    sums and joined-row counts are integers: equal, not close.  (SF30 itself is checked by bench.py against the oracle on every run.)"""
+    import os
+    from hyrise_amd.operators import star_join_aggregate
+    data = ssb.SsbData(scale_factor=1.0, seed=11)
+    assert data.n_lineorder == 6_000_000
+    host = data.host_columns()
+    ex = HipExecutor(torch.device("cuda", 0))
+    columns = {name: ex.column(c) for name, c in host.items()}
+    oracle = OracleExecutor(threads=os.cpu_count() or 1)
+    for query, sql in (("2.1", ssb.Q2_1_SQL), ("4.1", ssb.Q4_1_SQL)):
+        groupby, aggregates, joined = ssb.run_query(ex, columns, query)
+        got = ssb.result_rows(aggregate_groups(ex, groupby, aggregates))
+        o_groupby, o_aggregates, o_joined = ssb.run_query(oracle, host, query)
+        want = ssb.result_rows(aggregate_groups(oracle, o_groupby, o_aggregates))
+        assert joined == o_joined and got == want, f"Q{query}: operator chain on the device vs the CPU oracle"
+        dimensions, star_groupby, star_aggregates = ssb.star_plan(columns, query)
+        result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
+        assert star_joined == o_joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == want, f"Q{query}: hy_star_join_aggregate vs the CPU oracle"
+        rows = data.sqlite_result(sql)
+        sqlite = sorted(((r[1], r[2]), r[0]) for r in rows) if query == "2.1" else sorted(((r[0], r[1]), r[2]) for r in rows)
+        assert got == sqlite, f"Q{query}: SQLite"
+
+
 @pytest.mark.timeout(900)
 def test_two_ranks_on_one_gpu_replicated_and_repartitioned_plans(device):
     """Two processes share the test box's GPU (gloo carries the exchanges through host memory; on a multi-GPU node the same code runs one
