@@ -2485,10 +2485,35 @@ struct BuildVerdict {
   uint32_t unsorted_signed, equal_neighbours, outside_hint, done;
 };
 
+// The rank table and the filter of a hinted build must start out as zeros (whole words are stored, the words two waves share and the
+// filter's words are OR-ed with atomics): zero_vectors in front of every fill was a launch of 6 us.  A thread keeps TWO blocks instead
+// and hands them out alternately, zeroed: the LAST kernel of join n (pk_emit, bound by its 0.96 GB of stores: 4 MB more do not show; in the
+// fill kernel's prologue they cost what zero_vectors did) clears -- one 16-byte store per thread of its first workgroups -- the block join
+// n - 1 used, which nothing reads any more when join n's kernels run (same stream).  A block is `clean` from the moment such
+// a launch is queued; `dirty_*` = what its last user may have written (table words, arrival counters, verdict; the filter's 128 KB).
+struct ZeroedBlocks {
+  void* table = nullptr;
+  size_t table_capacity = 0;
+  void* filter = nullptr;   // BLOOM_BITS / 8 bytes
+  size_t dirty_table = 0, dirty_filter = 0;
+  bool clean = false;
+  hipStream_t stream = nullptr;
+};
+static thread_local ZeroedBlocks t_zeroed[2];
+
+static void free_zeroed_blocks() {
+  for (ZeroedBlocks& z : t_zeroed) {
+    if (z.table) (void)hipFree(z.table);
+    if (z.filter) (void)hipFree(z.filter);
+    z = ZeroedBlocks{};
+  }
+}
+
 // hy_shutdown: the calling thread's mailbox goes with its scratch arena and pools (the next join allocates a new one)
 void release_thread_join_state() {
   if (t_mailbox) (void)hipHostFree(t_mailbox);
   t_mailbox = t_mailbox_dev = nullptr;
+  free_zeroed_blocks();
 }
 
 static hy_status join_mailbox(JoinMailbox** host, JoinMailbox** device) {
@@ -2826,6 +2851,40 @@ __device__ __forceinline__ bool key_in_front_of_step(const MaterializeArgs& a, u
   return false;
 }
 
+// The window of a batch's table words goes out: presence bits, and for every word the rank of its first key.
+// A word's base is the rank of its first key: the batch's rows are consecutive and its keys ascend without repeats (anything else is
+// flagged and ends the use of this table; a table for existence-only joins, which may hold repeats, is never asked for a base),
+// so that rank is the batch's first rank plus the keys of the batch in the words before -- a running sum of population counts.
+__device__ __forceinline__ void fill_flush_window(const uint32_t* bits_window, uint32_t span, uint32_t first_word, uint32_t origin_word, uint32_t first_rank, bool first_is_leader, uint32_t lane,
+                                                  u32x2_entry_t* entries, uint32_t* bloom_words, uint32_t debug) {
+  uint32_t keys_before = 0;
+  for (uint32_t begin = 0; begin < span; begin += 64) {
+    const uint32_t i = begin + lane;
+    const uint32_t bits = i < span ? bits_window[i] : 0u;
+    const uint32_t count = __popc(bits);
+    uint32_t inclusive = count;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t other = __shfl_up(inclusive, d, 64);
+      if (lane >= static_cast<uint32_t>(d)) inclusive += other;
+    }
+    const uint32_t base = first_rank + keys_before + inclusive - count;
+    keys_before += __builtin_amdgcn_readlane(inclusive, 63);
+    if (i >= span) continue;
+    const uint32_t table_word = first_word + i;
+    if (bits && bloom_words) atomicOr(bloom_words + ((table_word + origin_word) & (BLOOM_BITS / 32 - 1)), bits);
+#ifdef HY_DEBUG_SWITCHES
+    if (debug & 2) { if (bits == 0xDEADBEEFu && base == 0x12345678u) entries[0] = u32x2_entry_t{bits, base}; continue; }
+#endif
+    if (i == 0 || i + 1 == span) {   // may be shared with a neighbouring batch: add the bits; the base comes from the batch with the word's first key
+      if (bits) atomicOr(reinterpret_cast<uint32_t*>(entries + table_word), bits);
+      if (bits && (i != 0 || first_is_leader)) reinterpret_cast<uint32_t*>(entries + table_word)[1] = base;
+    } else {
+      entries[table_word] = u32x2_entry_t{bits, bits ? base : 0u};
+    }
+  }
+}
+
 // K consecutive steps from registers (K = 1: one step; K = FW_BATCH: a wave's batch -- one window for all of them, a quarter of the LDS
 // round trips and of the shared edge words): step k has rows[k] rows (uniform; the steps with rows come first, a step with fewer than
 // FW_STEP rows is the last with rows) whose first has rank first_rank[k]; the lane's eight consecutive keys of step k are a[k] / b[k] +
@@ -2917,35 +2976,7 @@ __device__ __forceinline__ bool fill_process_steps(FillWaveState& w, const u32x4
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // A word's base is the rank of its first key: the batch's rows are consecutive and its keys ascend without repeats (anything else is
-    // flagged above and ends the use of this table; a table for existence-only joins, which may hold repeats, is never asked for a base),
-    // so that rank is the batch's first rank plus the keys of the batch in the words before -- a running sum of population counts.
-    uint32_t keys_before = 0;
-    for (uint32_t begin = 0; begin < span; begin += 64) {
-      const uint32_t i = begin + lane;
-      const uint32_t bits = i < span ? bits_window[i] : 0u;
-      const uint32_t count = __popc(bits);
-      uint32_t inclusive = count;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t other = __shfl_up(inclusive, d, 64);
-        if (lane >= static_cast<uint32_t>(d)) inclusive += other;
-      }
-      const uint32_t base = first_rank[0] + keys_before + inclusive - count;
-      keys_before += __builtin_amdgcn_readlane(inclusive, 63);
-      if (i >= span) continue;
-      const uint32_t table_word = first_word + i;
-      if (bits && bloom_words) atomicOr(bloom_words + ((table_word + origin_word) & (BLOOM_BITS / 32 - 1)), bits);
-#ifdef HY_DEBUG_SWITCHES
-      if (debug & 2) { if (bits == 0xDEADBEEFu && base == 0x12345678u) entries[0] = u32x2_entry_t{bits, base}; continue; }
-#endif
-      if (i == 0 || i + 1 == span) {   // may be shared with a neighbouring batch: add the bits; the base comes from the batch with the word's first key
-        if (bits) atomicOr(reinterpret_cast<uint32_t*>(entries + table_word), bits);
-        if (bits && (i != 0 || first_is_leader)) reinterpret_cast<uint32_t*>(entries + table_word)[1] = base;
-      } else {
-        entries[table_word] = u32x2_entry_t{bits, bits ? base : 0u};
-      }
-    }
+    fill_flush_window(bits_window, span, first_word, origin_word, first_rank[0], first_is_leader, lane, entries, bloom_words, debug);
     __builtin_amdgcn_wave_barrier();   // (the window is read before the next batch clears it)
   } else {
     // a step outside any window (K == 1): one global atomic per key; a key that starts a table word writes the word's base
@@ -3016,6 +3047,12 @@ __device__ __forceinline__ void load_fill_batch(const MaterializeArgs& a, uint32
     }
   }
 }
+
+struct FillCleaning {   // two regions this launch leaves zeroed (16-byte vectors): the blocks of the join before (ZeroedBlocks)
+  u32x4_t* first;
+  u32x4_t* second;
+  uint32_t first_vectors, second_vectors;
+};
 
 template <uint32_t WIDTH>
 __global__ __launch_bounds__(256, 4) void rank_table_fill_waves(MaterializeArgs a, uint64_t key_min, uint64_t hint_range, u32x2_entry_t* entries, uint64_t* partials, uint32_t chunk_rows,
@@ -3213,6 +3250,8 @@ static bool lds_atomics_are_lane_ordered(hipStream_t stream);
 
 struct BuildSide {
   DeviceBuffer keys, rows, keys_tmp, rows_tmp, dir, bloom, flags, rank_entries, partials;
+  FillCleaning cleaning{nullptr, nullptr, 0, 0};   // the thread's other zeroed block (ZeroedBlocks), for the join's last kernel to clear ...
+  ZeroedBlocks* cleaned = nullptr;                 // ... and to mark clean when that kernel is queued
   bool hint_allows_duplicates = false;
   bool bloom_is_bits = false;    // the filter is 2^20 BITS (rank_table_fill_checked folds the table's presence words into it), not one byte per bit
   bool hinted = false;           // the rank table was filled from the column's key hint: pk_plan confirms `verdict` against the hint
@@ -3342,14 +3381,63 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       const uint64_t origin = key_min & ~uint64_t{31};   // (the table starts at a multiple of 32: a key's bit in its table word is its bit in the Bloom filter's word)
       const uint64_t words = ((key_max - origin) >> 5) + 1;
       const size_t ticket_bytes = 128 * (size_t{CHECKED_FILL_TICKETS} + 1);
-      HY_TRY(b.rank_entries.alloc(8 * (words + 2) + ticket_bytes + 64));   // the table | the arrival counters | the verdict
+      const size_t table_bytes = 8 * (words + 2) + ticket_bytes + 64;   // the table | the arrival counters | the verdict
+      const size_t table_vectors = (table_bytes + 15) / 16, bloom_vectors = want_bloom ? BLOOM_BITS / 8 / 16 : 0;   // (the filter as bits: 128 KB)
+      const uint32_t stream_width = build->stream_width == 1 || build->stream_width == 2 || build->stream_width == 4 ? build->stream_width : 0;
+      const bool wave_fill = stream_width && option(HY_OPT_JOIN_FILL_WGS_PER_CU) > 0;
       HY_TRY(b.partials.alloc(32 * (size_t{n_slices} * FW_STEPS_PER_SLICE / 4 + 1)));   // one record per workgroup: per slice (rank_table_fill_checked), or per four waves of >= 1 step (rank_table_fill_waves)
-      u32x2_t* entries = b.rank_entries.as<u32x2_t>();
-      {   // the table | the arrival counter, and the Bloom filter
-        const size_t table_vectors = (8 * (words + 2) + ticket_bytes + 64 + 15) / 16, bloom_vectors = want_bloom ? BLOOM_BITS / 8 / 16 : 0;   // (the filter as bits: 128 KB)
-        hipLaunchKernelGGL(zero_vectors, dim3(static_cast<uint32_t>(std::min<size_t>(2048, (table_vectors + bloom_vectors + 255) / 256))), dim3(256), 0, stream,
-                           reinterpret_cast<u32x4_t*>(entries), table_vectors, b.bloom.as<u32x4_t>(), bloom_vectors);
+      // The table and the filter: one of the thread's two zeroed blocks (ZeroedBlocks), whose partner this join's pk_emit clears -- or,
+      // where that does not apply (the first joins of a thread, a table that outgrew its block, the per-slice fill kernel), a block
+      // zeroed by a launch of its own.
+      FillCleaning cleaning{nullptr, nullptr, 0, 0};
+      ZeroedBlocks* cleaned = nullptr;
+      bool zeroed = false;
+      if (wave_fill && option(HY_OPT_JOIN_CLEAN_TABLES) && table_vectors + bloom_vectors < (1ull << 31)) {
+        if ((t_zeroed[0].table && t_zeroed[0].stream != stream) || (t_zeroed[1].table && t_zeroed[1].stream != stream)) {   // another stream: start over
+          HY_HIP(hipDeviceSynchronize());
+          free_zeroed_blocks();
+        }
+        int mine = -1;
+        for (int i = 0; i < 2; ++i) if (t_zeroed[i].clean && t_zeroed[i].table_capacity >= 16 * table_vectors) mine = i;
+        if (mine < 0) {   // a block that is not waiting to be cleaned by this launch: (re)allocate it, zeroed by zero_vectors below
+          mine = !t_zeroed[0].table ? 0 : !t_zeroed[1].table ? 1 : t_zeroed[1].clean && !t_zeroed[0].clean ? 1 : 0;   // (both in use and neither cleared -- the join before took other kernels: block 0, cleared by a launch)
+          if (mine >= 0 && t_zeroed[mine].table_capacity < 16 * table_vectors) {
+            ZeroedBlocks& z = t_zeroed[mine];
+            if (z.table) { HY_HIP(hipStreamSynchronize(stream)); HY_HIP(hipFree(z.table)); z.table = nullptr; }
+            z.table_capacity = (16 * table_vectors * 5 / 4 + 4095) & ~size_t{4095};
+            HY_HIP(hipMalloc(&z.table, z.table_capacity));
+            if (!z.filter) HY_HIP(hipMalloc(&z.filter, BLOOM_BITS / 8));
+            z.stream = stream;
+            z.clean = false;
+            z.dirty_table = z.table_capacity;   // (never written: all of it is cleared once)
+            z.dirty_filter = BLOOM_BITS / 8;
+          }
+        }
+        if (mine >= 0) {
+          ZeroedBlocks& z = t_zeroed[mine];
+          ZeroedBlocks& other = t_zeroed[1 - mine];
+          if (!z.clean) {
+            hipLaunchKernelGGL(zero_vectors, dim3(static_cast<uint32_t>(std::min<size_t>(2048, (z.dirty_table / 16 + z.dirty_filter / 16 + 255) / 256))), dim3(256), 0, stream,
+                               static_cast<u32x4_t*>(z.table), z.dirty_table / 16, static_cast<u32x4_t*>(z.filter), z.dirty_filter / 16);
+          }
+          if (other.table && !other.clean) {   // this join's pk_emit clears what the join before left in the other block
+            cleaning = FillCleaning{static_cast<u32x4_t*>(other.table), static_cast<u32x4_t*>(other.filter), static_cast<uint32_t>(other.dirty_table / 16), static_cast<uint32_t>(other.dirty_filter / 16)};
+            cleaned = &other;   // (clean once the fill kernel is queued, below)
+          }
+          z.clean = false;
+          z.dirty_table = 16 * table_vectors;
+          z.dirty_filter = 16 * bloom_vectors;
+          b.rank_entries.borrow(z.table);
+          if (want_bloom) { b.bloom.borrow(z.filter); m.bloom_out = b.bloom.as<uint8_t>(); }
+          zeroed = true;
+        }
       }
+      if (!zeroed) {
+        HY_TRY(b.rank_entries.alloc(table_bytes));
+        hipLaunchKernelGGL(zero_vectors, dim3(static_cast<uint32_t>(std::min<size_t>(2048, (table_vectors + bloom_vectors + 255) / 256))), dim3(256), 0, stream,
+                           b.rank_entries.as<u32x4_t>(), table_vectors, b.bloom.as<u32x4_t>(), bloom_vectors);
+      }
+      u32x2_t* entries = b.rank_entries.as<u32x2_t>();
       BuildVerdict* verdict = reinterpret_cast<BuildVerdict*>(reinterpret_cast<char*>(entries + words + 2) + ticket_bytes);
       MaterializeArgs m = m_in;
       if (const char* debug = HY_DEBUG_ENV("HY_JOIN_FILL_DEBUG")) {   // timing experiments only (results are wrong): 1 no filter, 2 no table either
@@ -3359,9 +3447,8 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       hipEvent_t fill_started = nullptr, fill_stopped = nullptr;
       profile_events(&fill_started, &fill_stopped, HY_KERNEL_JOIN_BUILD);
       // rank_table_fill_waves: as many waves as stay resident (at most the option's workgroups per CU), each with the same number of consecutive batches
-      const uint32_t stream_width = build->stream_width == 1 || build->stream_width == 2 || build->stream_width == 4 ? build->stream_width : 0;
       uint32_t fill_waves = 0;
-      if (stream_width && option(HY_OPT_JOIN_FILL_WGS_PER_CU) > 0) {
+      if (wave_fill) {
         int per_cu = 0;
         const void* kernel = stream_width == 4 ? reinterpret_cast<const void*>(rank_table_fill_waves<4>) : stream_width == 2 ? reinterpret_cast<const void*>(rank_table_fill_waves<2>) : reinterpret_cast<const void*>(rank_table_fill_waves<1>);
         HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
@@ -3377,6 +3464,8 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
         if (stream_width == 4) hipExtLaunchKernelGGL(rank_table_fill_waves<4>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), build->host_segments[0].size, batches_per_wave, n_steps, fill_debug);
         else if (stream_width == 2) hipExtLaunchKernelGGL(rank_table_fill_waves<2>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), build->host_segments[0].size, batches_per_wave, n_steps, fill_debug);
         else hipExtLaunchKernelGGL(rank_table_fill_waves<1>, dim3(groups), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries, b.partials.as<uint64_t>(), build->host_segments[0].size, batches_per_wave, n_steps, fill_debug);
+        b.cleaning = cleaning;   // (pk_emit clears the other block: run_join_once marks it clean when that launch is queued)
+        b.cleaned = cleaned;
       } else
       hipExtLaunchKernelGGL(rank_table_fill_checked, dim3(n_slices), dim3(256), 0, stream, fill_started, fill_stopped, 0, m, origin, key_max - origin, entries,
                             b.partials.as<uint64_t>(), reinterpret_cast<uint32_t*>(entries + words + 2), verdict);
@@ -4307,6 +4396,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       if (group > 0) { k.emit_group_shift = 0; while (k.emit_group_shift < 16 && (int64_t{1} << (k.emit_group_shift + 1)) <= group) ++k.emit_group_shift; }
     }
     k.cut_blocks = (cut_grid + 7) / 8 * 8;   // (pk_cut_slice returns at once for slices the plan does not have)
+    k.cleaning = b.cleaning;
     if (build_in_lds) {   // (pass 2 reads the rows' found / materialised bits pass 1 left behind)
       if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL((pk_emit<true, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
       else hipExtLaunchKernelGGL((pk_emit<false, true>), dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
@@ -4314,6 +4404,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     else if (mode == HY_JOIN_INNER) hipExtLaunchKernelGGL(pk_emit<true>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     else hipExtLaunchKernelGGL(pk_emit<false>, dim3(k.cut_blocks + tile_grid), dim3(PK_THREADS), 4 * pk_emit_lds_words(partitions), stream, started, stopped, 0, k);
     HY_HIP(hipGetLastError());
+    if (b.cleaned) { b.cleaned->clean = true; b.cleaned->dirty_table = b.cleaned->dirty_filter = 0; }
     clock.mark("pass 2 launched");
     t_last_join_used_pkfk = build_in_lds ? 2 : 1;   // debug / tests: the primary-key / foreign-key kernels ran (2: with the build side's bits staged in LDS)
     if (host_result) {

@@ -87,6 +87,7 @@ struct PkArgs {
   uint64_t hint_min, hint_max;
   uint32_t hint_allows_duplicates;
   hy_join_status* status;          // HY_JOIN_ASYNC: what the host would read from the mailbox, in device memory; else nullptr
+  FillCleaning cleaning;           // pk_emit: two regions its first workgroups zero (the rank table and filter of the join BEFORE: ZeroedBlocks in join.hip)
 };
 constexpr uint32_t PK_LDS_KEYS = 1u << 20;                       // the table's range must be smaller: then the Bloom filter (bit = key & 0xFFFFF) is the presence bit
 constexpr uint32_t PK_LDS_WORDS = PK_LDS_KEYS / 32;              // 32 768 presence words = 128 KB
@@ -292,8 +293,11 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
   }
 }
 
+#ifndef HY_PK_COUNT_WGS_PER_CU
+#define HY_PK_COUNT_WGS_PER_CU 8   // pk_count<false>: resident workgroups per CU the register budget is cut for (A/B builds: 5, 6)
+#endif
 template <bool RANKS = false>
-__global__ __launch_bounds__(PK_COUNT_THREADS, (RANKS ? 4 : 8) * PK_COUNT_THREADS / 256) void pk_count(PkArgs a) {
+__global__ __launch_bounds__(PK_COUNT_THREADS, (RANKS ? 4 : HY_PK_COUNT_WGS_PER_CU) * PK_COUNT_THREADS / 256) void pk_count(PkArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cells[MAX_PARTITIONS * COUNT_COPIES];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t partitions = 1u << a.radix_bits;
@@ -461,13 +465,15 @@ __device__ void pk_plan(const PkArgs& a, uint64_t* s_tmp, uint32_t tid) {
       a.status->build_confirmed = confirmed ? 1u : 0u;
       a.status->error = 0;
       a.status->reserved = 0;
+    } else {   // (a synchronous join: the host reads the pinned mailbox when the stream has drained; HY_JOIN_ASYNC never looks at it -- no
+               //  writes across the host link and no system-scope fence at the end of every asynchronous join's plan)
+      a.mailbox->n_pairs = n_pairs;
+      a.mailbox->n_slices = n_slices;
+      a.mailbox->n_uncached = 0;
+      a.mailbox->fits = fits;
+      a.mailbox->build_unconfirmed = confirmed ? 0u : 1u;
+      __threadfence_system();
     }
-    a.mailbox->n_pairs = n_pairs;
-    a.mailbox->n_slices = n_slices;
-    a.mailbox->n_uncached = 0;
-    a.mailbox->fits = fits;
-    a.mailbox->build_unconfirmed = confirmed ? 0u : 1u;
-    __threadfence_system();
   }
 }
 
@@ -923,6 +929,9 @@ __global__ __launch_bounds__(PK_THREADS, HY_PK_WAVES_PER_SIMD) void pk_emit(PkAr
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // The first cut_blocks workgroups (a multiple of 8: the others keep their XCD) find the PosList cuts while the rest emits: a launch
   // of its own behind this kernel was 13 us of an otherwise idle device.
+  for (uint32_t i = blockIdx.x * PK_THREADS + tid; i < a.cleaning.first_vectors + a.cleaning.second_vectors; i += gridDim.x * PK_THREADS) {
+    if (i < a.cleaning.first_vectors) a.cleaning.first[i] = u32x4_t{0, 0, 0, 0}; else a.cleaning.second[i - a.cleaning.first_vectors] = u32x4_t{0, 0, 0, 0};
+  }
   if (blockIdx.x < a.cut_blocks) { pk_cut_slice<MASKS>(a, blockIdx.x, join_smem, tid, lane, wave); return; }
   const uint32_t block = blockIdx.x - a.cut_blocks;
   // Which tile: the device works on one front of tiles that moves through the probe side -- workgroups arrive at the XCDs in turn (block b

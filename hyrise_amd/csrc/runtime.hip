@@ -39,6 +39,8 @@ struct OptionDefaults {
     set(HY_OPT_JOIN_FILL_WGS_PER_CU, 4);
     set(HY_OPT_JOIN_EMIT_TILE_GROUP, 64);
     set(HY_OPT_JOIN_HAND_OVER_RANKS, 1 << 20);
+    set(HY_OPT_SCAN_JOB_CACHE, 1);
+    set(HY_OPT_JOIN_CLEAN_TABLES, 1);
   }
 };
 OptionDefaults g_option_defaults;   // (static initialisation: before any entry point can run)
@@ -179,14 +181,22 @@ void pool_release(void* ptr, size_t capacity) {
 
 hy_status DeviceBuffer::alloc(size_t bytes) {
   if (ptr) {   // a buffer that is sized again gives its block back first
-    pool_release(ptr, capacity);
+    if (!borrowed) pool_release(ptr, capacity);
     ptr = nullptr;
     capacity = 0;
   }
+  borrowed = false;
   return pool_acquire(bytes, &ptr, &capacity);
 }
 
-DeviceBuffer::~DeviceBuffer() { pool_release(ptr, capacity); }
+void DeviceBuffer::borrow(void* block) {
+  if (ptr && !borrowed) pool_release(ptr, capacity);
+  ptr = block;
+  capacity = 0;
+  borrowed = true;
+}
+
+DeviceBuffer::~DeviceBuffer() { if (!borrowed) pool_release(ptr, capacity); }
 
 struct PinnedStaging {
   void* host = nullptr;

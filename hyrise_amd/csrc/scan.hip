@@ -1642,6 +1642,46 @@ static hy_status validate_predicate(const hy_column* column, const hy_predicate*
   return HY_OK;
 }
 
+// The column's remembered job table for `pa` (hy_scan_job_cache, hy_device.hpp): *jobs = the table -- prepared here, on `stream`, if the
+// predicate is new to the column -- or nullptr when the caller should prepare its own (the table was made on another stream).
+static hy_status cached_scan_jobs(const hy_column* column, const PredicateArgs& pa, hipStream_t stream, ScanJob** jobs) {
+  *jobs = nullptr;
+  hy_scan_job_cache& cache = column->scan_jobs;
+  uint8_t key[sizeof(hy_scan_job_cache::Entry::key)];
+  std::memset(key, 0, sizeof(key));
+  std::memcpy(key, &pa.condition, 4);
+  std::memcpy(key + 4, &pa.value_type, 4);
+  std::memcpy(key + 8, &pa.value, 8);
+  std::memcpy(key + 16, &pa.value2, 8);
+  std::memcpy(key + 24, &pa.column_is_nullable, 4);
+  std::memcpy(key + 28, &pa.materialize_all, 4);
+  std::memcpy(key + 32, &pa.no_ranges, 4);
+  std::lock_guard<std::mutex> lock(cache.mutex);
+  hy_scan_job_cache::Entry* victim = &cache.entries[0];
+  for (hy_scan_job_cache::Entry& entry : cache.entries) {
+    if (entry.jobs && std::memcmp(entry.key, key, sizeof(key)) == 0) {
+      if (entry.stream != stream) return HY_OK;   // (ordered behind its preparation only on the stream that prepared it)
+      entry.used = ++cache.clock;
+      *jobs = static_cast<ScanJob*>(entry.jobs);
+      return HY_OK;
+    }
+    if (!entry.jobs ? victim->jobs != nullptr : (victim->jobs && entry.used < victim->used)) victim = &entry;
+  }
+  // new to the column: the least recently used table is overwritten -- behind, in stream order, every scan of this stream that read it;
+  // a table another stream may still be reading is left alone (the caller prepares its own jobs this time)
+  if (victim->jobs && victim->stream != stream) return HY_OK;
+  if (!victim->jobs) {
+    HY_HIP(hipMalloc(&victim->jobs, sizeof(ScanJob) * (size_t{column->n_chunks} + 1)));
+    const_cast<hy_column*>(column)->owned.push_back(victim->jobs);   // (under the cache's lock: nothing else appends to a finished column)
+  }
+  std::memcpy(victim->key, key, sizeof(key));
+  victim->stream = stream;
+  victim->used = ++cache.clock;
+  hipLaunchKernelGGL(prepare_jobs, dim3(column->n_chunks), dim3(256), 0, stream, column->d_segments, column->n_chunks, pa, static_cast<ScanJob*>(victim->jobs), scratch().ticket + 16);
+  *jobs = static_cast<ScanJob*>(victim->jobs);
+  return HY_OK;
+}
+
 size_t scan_jobs_staging_bytes(const hy_column* column, const hy_predicate* predicate) {
   size_t bytes = 4 * 256 + 9 * (size_t{column->n_chunks} + 64);   // prepare_jobs' status word | the per-chunk arrays, 256-byte aligned
   if (predicate->match_words && predicate->match_word_offsets) bytes += 2 * 256 + 8 * (size_t{column->n_chunks} + 2) + 8 * (predicate->match_word_offsets[column->n_chunks] + 2);
@@ -1764,7 +1804,14 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
       HY_TRY(stage(predicate->match_word_offsets, 8 * (size_t{n_data_chunks} + 1), &d)); pa.match_word_offsets = static_cast<const uint64_t*>(d);
       HY_TRY(stage(predicate->match_words, 8 * (total_words ? total_words : 1), &d)); pa.match_words = static_cast<const uint64_t*>(d);
     }
-    if (n_data_chunks) {
+    // a literal predicate over a data column whose jobs this column remembers (hy_scan_job_cache): no launch
+    const bool cacheable = option(HY_OPT_SCAN_JOB_CACHE) && !visibility && !n_excluded && n_data_chunks && !pa.per_chunk_lower && !pa.per_chunk_upper && !pa.per_chunk_found &&
+                           !pa.match_words && !pa.match_word_offsets;
+    ScanJob* cached = nullptr;
+    if (cacheable) HY_TRY(cached_scan_jobs(data_column, pa, stream, &cached));
+    if (cached) {
+      d_jobs = cached;
+    } else if (n_data_chunks) {
       hipLaunchKernelGGL(prepare_jobs, dim3(n_data_chunks), dim3(256), 0, stream, data_column->d_segments, n_data_chunks, pa, d_jobs, d_overflow);
     }
   }

@@ -280,6 +280,10 @@ enum {
   HY_OPT_JOIN_HAND_OVER_RANKS = 27,  /* 2^20 Inner PK-FK joins whose probe keys have no locality, whose probe side has at least this many rows and whose
                                       *      rank table has a megabyte or more: pass 1 leaves the partners' ranks behind (4 bytes a probe row), pass 2
                                       *      reads them back instead of looking every key up again; 0 = never, 1 = whenever the keys lack locality */
+  HY_OPT_SCAN_JOB_CACHE = 28,        /* 1    a data column remembers the per-chunk jobs (dictionary bound searches, early-outs) of the last four literal
+                                      *      predicates it was scanned with; 0 = every scan prepares its jobs (one more launch)                     */
+  HY_OPT_JOIN_CLEAN_TABLES = 29,     /* 1    the rank table and filter of a hinted build come from two per-thread blocks that are handed out ZEROED: a join's
+                                      *      fill kernel clears the block the join before it used, instead of a launch that zeroes its own; 0 = zero_vectors */
   HY_OPT_COUNT = 32
 };
 hy_status hy_set_option(uint32_t option, int64_t value);

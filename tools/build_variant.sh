@@ -9,7 +9,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 mkdir -p "$R/hyrise_amd/variants" /tmp/hy_variant_objs
 objs=()
-for f in runtime scan join aggregate projection exchange boundary comm plan; do
+for f in runtime scan join aggregate aggregate_wide projection exchange boundary comm plan; do
   o=/tmp/hy_variant_objs/${f}_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wall -Wno-unused-function "$@" "$R/hyrise_amd/csrc/$f.hip" -o "$o" &
   objs+=("$o")

@@ -1,0 +1,10 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the headline step only (bench.py --headline-only): per-kernel average durations -> gpurun_out/$1/headline_stats.txt
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/$1/trace
+rm -rf $OUT && mkdir -p $OUT
+(cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o h -- python $R/bench.py --headline-only --steps 40 --warmup 5 --details /tmp/d.json > $OUT/line.json 2> $OUT/log.txt)
+python $R/tools/kernel_stats.py $OUT 14 > $R/gpurun_out/$1/headline_stats.txt 2>&1
+python $R/tools/ab_line.py < $OUT/line.json >> $R/gpurun_out/$1/headline_stats.txt 2>&1
+rm -rf $OUT
+cat $R/gpurun_out/$1/headline_stats.txt
