@@ -219,6 +219,26 @@ def test_column_vs_column_four_byte_rows(device):
                                       f"float lenc {lenc} renc {renc} cond {condition}")
 
 
+@pytest.mark.parametrize("two_columns", [1, 0], ids=["two_stream_kernel", "generic_instantiation"])
+def test_column_vs_column_dates(device, options, two_columns):
+    """TPC-H Q4 / Q12's l_commitdate < l_receiptdate: two dictionary columns with u16 value ids (the chunks' dictionaries staged in LDS by
+    scan_two_columns), a FrameOfReference twin, full and ragged chunks -- and the same scans with the kernel switched off (the generic
+    instantiation every other shape takes): both against the oracle."""
+    options.set(abi.OPT_SCAN_TWO_COLUMNS, two_columns)
+    rng = np.random.default_rng(412)
+    n = 65_535 * 3 + 4_321
+    orderdate = rng.integers(0, 2406, n, dtype=np.int32)
+    commit = (orderdate + rng.integers(30, 91, n, dtype=np.int32)).astype(np.int32)
+    receipt = (orderdate + rng.integers(2, 152, n, dtype=np.int32)).astype(np.int32)
+    receipt_nulls = rng.random(n) < 0.02
+    for chunk in (65_535, 20_000):
+        for lenc, renc in ((abi.ENC_DICTIONARY, abi.ENC_DICTIONARY), (abi.ENC_DICTIONARY, abi.ENC_FRAME_OF_REFERENCE), (abi.ENC_FRAME_OF_REFERENCE, abi.ENC_FRAME_OF_REFERENCE)):
+            lcol, rcol = build_column(commit, None, chunk, lenc), build_column(receipt, receipt_nulls, chunk, renc)
+            ldev, rdev = DeviceColumn(lcol), DeviceColumn(rcol)
+            for condition in CONDITIONS[:6]:
+                assert_scan_equal(table_scan_columns(ldev, rdev, condition), oracle_scan_columns(lcol, rcol, condition), f"dates chunk {chunk} lenc {lenc} renc {renc} cond {condition}")
+
+
 def test_excluded_chunks(device):
     rng = np.random.default_rng(17)
     values = rng.integers(0, 100, 50_000).astype(np.int32)
