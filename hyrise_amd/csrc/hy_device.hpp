@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -242,5 +243,21 @@ struct DeviceBuffer {
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
   template <typename T> T* as() const { return static_cast<T*>(ptr); }
 };
+
+
+// ---- join_star.hpp (join.hip): the probes of a star join fused into one pass over the fact table (hy_star_join_aggregate, plan.hip) ------
+struct StarProbeDimension {
+  const hy_column* key;        // the dimension's key column (int32, unique among `rows`)
+  const hy_row_id* rows;       // the dimension rows that take part (device memory): the rows that pass its filter, or all of them
+  uint64_t n_rows;
+  const hy_column* fact_key;   // the fact table's foreign key to this dimension
+  bool want_rows;              // the caller reads columns of this dimension at the surviving rows
+};
+// fact_rows / dimension_rows[d]: the RowIDs of the fact table and of dimension d per row of fact JOIN dim_1 ... JOIN dim_k (Inner), in the
+// fact table's row order.  *applicable = false: this shape is not for the fused probe (keys that are not int32 / not unique / too
+// sparse, foreign-key segments the probe does not stream) -- nothing was produced.
+hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimensions, DeviceBuffer& fact_rows, std::vector<std::unique_ptr<DeviceBuffer>>& dimension_rows,
+                          uint64_t* n_rows, bool* applicable);
+hy_status star_all_rows_of(const hy_column* column, DeviceBuffer& rows);   // every row of a data column's table as a PosList
 
 }  // namespace hy

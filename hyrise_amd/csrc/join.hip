@@ -3798,6 +3798,8 @@ static uint32_t device_cu_count() {
   return static_cast<uint32_t>(cus);
 }
 
+#include "join_star.hpp"
+
 static thread_local int t_last_join_used_rank_table = 0;   // debug / tests: which lookup structure the thread's last join built
 static thread_local int t_last_join_used_pkfk = 0;         // ... and whether the kernels of join_pkfk.hpp probed it
 static thread_local int t_last_join_hinted_attempt = 0;

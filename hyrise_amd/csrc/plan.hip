@@ -20,6 +20,8 @@
 
 namespace hy {
 
+static thread_local int t_last_star_was_fused = 0;   // debug / tests: the thread's last hy_star_join_aggregate took the fused probe
+
 constexpr uint32_t DENSE_CHUNK = 65536;   // rows per chunk of an intermediate table (chunks start on 16-byte boundaries for every type)
 
 struct ColumnHandle {   // an hy_column this plan created
@@ -144,9 +146,9 @@ struct JoinOutput {
 static hy_status join_inner(const hy_column* build, const hy_column* probe, JoinOutput& out) {
   constexpr size_t PERIOD = size_t{2} << 20, OFFSET = size_t{5} << 18;
   uint64_t capacity = std::max<uint64_t>({1, build->rows, probe->rows});
-  const uint64_t slice_capacity = std::max(build->rows, probe->rows) / 131070 + std::max(build->n_chunks, probe->n_chunks) + 600;
-  HY_TRY(out.slice_offsets.alloc(8 * (slice_capacity + 2)));
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  uint64_t slice_capacity = std::max(build->rows, probe->rows) / 131070 + std::max(build->n_chunks, probe->n_chunks) + 600;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    HY_TRY(out.slice_offsets.alloc(8 * (slice_capacity + 2)));
     const size_t list_bytes = sizeof(hy_row_id) * capacity;
     HY_TRY(out.arena.alloc(2 * list_bytes + 3 * PERIOD));
     char* base = out.arena.as<char>();
@@ -164,7 +166,12 @@ static hy_status join_inner(const hy_column* build, const hy_column* probe, Join
     r.slice_offsets = out.slice_offsets.as<uint64_t>();
     r.slice_capacity = slice_capacity;
     const hy_status status = hy_join_hash(build, probe, HY_JOIN_INNER, &r);
-    if (status == HY_ERR_CAPACITY && attempt == 0 && r.n_pairs > capacity) { capacity = r.n_pairs; continue; }
+    // (the result did not fit what was offered: the call says what it needs -- pairs, output PosLists, or both; like operators.join, once each)
+    if (status == HY_ERR_CAPACITY && attempt < 2 && (r.n_pairs > capacity || r.n_slices > slice_capacity)) {
+      capacity = std::max<uint64_t>(capacity, r.n_pairs);
+      slice_capacity = std::max<uint64_t>(slice_capacity, r.n_slices);
+      continue;
+    }
     HY_TRY(status);
     out.n_pairs = r.n_pairs;
     return HY_OK;
@@ -194,6 +201,30 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
     if (!dimensions[d].key || !dimensions[d].fact_key) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: dimension %u: key columns missing", d);
     HY_TRY(on_this_device(dimensions[d].key, "hy_star_join_aggregate"));
     HY_TRY(on_this_device(dimensions[d].fact_key, "hy_star_join_aggregate"));
+    if (dimensions[d].filter_column) HY_TRY(on_this_device(dimensions[d].filter_column, "hy_star_join_aggregate"));
+  }
+  // RowIDs found in one column of a table index the others: the columns named for a table must agree in their chunks (the fact table: with
+  // its first foreign key; dimension d: with its key) -- a mismatch would be read out of bounds by the kernels that dereference them
+  auto same_table = [](const hy_column* x, const hy_column* y) {
+    if (x->n_chunks != y->n_chunks || x->rows != y->rows) return false;
+    for (uint32_t c = 0; c < x->n_chunks; ++c) if (x->host_segments[c].size != y->host_segments[c].size) return false;
+    return true;
+  };
+  auto table_column = [&](uint32_t table) { return table == 0 ? dimensions[0].fact_key : dimensions[table - 1].key; };
+  for (uint32_t d = 0; d < n_dimensions; ++d) {
+    if (!same_table(dimensions[d].fact_key, dimensions[0].fact_key)) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: dimension %u: its foreign key is not a column of the fact table the others name", d);
+    if (dimensions[d].filter_column && !same_table(dimensions[d].filter_column, dimensions[d].key)) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: dimension %u: filter and key column are not columns of one table", d);
+  }
+  auto check_column = [&](const hy_star_column& c, const char* what, uint32_t index) -> hy_status {
+    if (!c.column) return HY_OK;
+    HY_TRY(on_this_device(c.column, "hy_star_join_aggregate"));
+    if (!same_table(c.column, table_column(c.table))) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: %s %u is not a column of table %u", what, index, c.table);
+    return HY_OK;
+  };
+  for (uint32_t g = 0; g < n_groupby; ++g) HY_TRY(check_column(groupby[g], "GROUP BY column", g));
+  for (uint32_t a = 0; a < n_aggregates; ++a) {
+    HY_TRY(check_column(aggregates[a].left, "the input of aggregate", a));
+    if (aggregates[a].op != HY_STAR_NO_OP) HY_TRY(check_column(aggregates[a].right, "the second input of aggregate", a));
   }
 
   // carried[t]: base RowIDs of table t (0 = the fact table, d + 1 = dimension d) per row of the join result so far
@@ -201,7 +232,46 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
   std::vector<const hy_row_id*> carried_rows(n_dimensions + 1, nullptr);
   std::vector<std::unique_ptr<JoinOutput>> joins;   // (the PosLists a carried pointer may still point into)
   uint64_t n_rows = 0;
-  for (uint32_t d = 0; d < n_dimensions; ++d) {
+  // The fused probe (csrc/join_star.hpp): every dimension's filtered keys become a direct table, ONE pass over the fact table's foreign keys
+  // finds the rows that have a partner in every dimension, and only those rows' RowIDs are written -- no pair lists, no RowIDs gathered
+  // through them from join to join.  The rows come in the fact table's order (the chain: in the order its last JoinHash leaves them in);
+  // the groups and their cells are the same, the ORDER of the groups follows the rows'.
+  bool fused = false;
+  t_last_star_was_fused = 0;
+  {
+    std::vector<std::unique_ptr<DeviceBuffer>> dimension_rows(n_dimensions);
+    std::vector<StarProbeDimension> probes(n_dimensions);
+    bool shape_ok = true;
+    for (uint32_t d = 0; d < n_dimensions && shape_ok; ++d) {
+      const hy_star_dimension& dimension = dimensions[d];
+      if (dimension.key->is_reference || dimension.key->data_type != HY_TYPE_INT || dimension.fact_key->data_type != HY_TYPE_INT) { shape_ok = false; break; }
+      dimension_rows[d] = std::make_unique<DeviceBuffer>();
+      uint64_t n_dimension_rows = dimension.key->rows;
+      if (dimension.filter_column) {
+        HY_TRY(filtered_rows(dimension.filter_column, &dimension.predicate, *dimension_rows[d], &n_dimension_rows));
+      } else HY_TRY(star_all_rows_of(dimension.key, *dimension_rows[d]));
+      bool wanted = false;
+      for (uint32_t g = 0; g < n_groupby; ++g) wanted = wanted || groupby[g].table == d + 1;
+      for (uint32_t a = 0; a < n_aggregates; ++a) wanted = wanted || (aggregates[a].left.column && aggregates[a].left.table == d + 1) || (aggregates[a].op != HY_STAR_NO_OP && aggregates[a].right.table == d + 1);
+      probes[d] = StarProbeDimension{dimension.key, dimension_rows[d]->as<hy_row_id>(), n_dimension_rows, dimension.fact_key, wanted};
+    }
+    if (shape_ok) {
+      auto fact_rows = std::make_unique<DeviceBuffer>();
+      std::vector<std::unique_ptr<DeviceBuffer>> rows_of_dimension;
+      HY_TRY(star_probe_rows(probes.data(), n_dimensions, *fact_rows, rows_of_dimension, &n_rows, &fused));
+      t_last_star_was_fused = fused ? 1 : 0;
+      if (fused) {
+        carried[0] = std::move(fact_rows);
+        carried_rows[0] = carried[0]->as<hy_row_id>();
+        for (uint32_t d = 0; d < n_dimensions; ++d) {
+          if (!rows_of_dimension[d]) continue;
+          carried[d + 1] = std::move(rows_of_dimension[d]);
+          carried_rows[d + 1] = carried[d + 1]->as<hy_row_id>();
+        }
+      } else n_rows = 0;
+    }
+  }
+  for (uint32_t d = 0; d < n_dimensions && !fused; ++d) {
     const hy_star_dimension& dimension = dimensions[d];
     // build side: the dimension's keys, of the rows that pass its filter
     DeviceBuffer dimension_rows, build_keys;
@@ -295,5 +365,8 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
   if (n_groupby == 0 && n_aggregates == 0) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: nothing to aggregate");
   return hy_aggregate_hash(groupby_columns.data(), n_groupby, specs.data(), n_aggregates, result);
 }
+
+// debug / tests only: 1 = the calling thread's last hy_star_join_aggregate probed every dimension in one pass (csrc/join_star.hpp)
+int hy_debug_star_fused(void) { return t_last_star_was_fused; }
 
 }  // extern "C"

@@ -42,6 +42,7 @@ struct OptionDefaults {
     set(HY_OPT_SCAN_JOB_CACHE, 1);
     set(HY_OPT_JOIN_CLEAN_TABLES, 1);
     set(HY_OPT_SCAN_TWO_COLUMNS, 1);
+    set(HY_OPT_STAR_FUSED_PROBE, 1);
   }
 };
 OptionDefaults g_option_defaults;   // (static initialisation: before any entry point can run)

@@ -285,6 +285,8 @@ enum {
   HY_OPT_JOIN_CLEAN_TABLES = 29,     /* 1    the rank table and filter of a hinted build come from two per-thread blocks that are handed out ZEROED: a join's
                                       *      fill kernel clears the block the join before it used, instead of a launch that zeroes its own; 0 = zero_vectors */
   HY_OPT_SCAN_TWO_COLUMNS = 30,      /* 1    ColumnVsColumn over two data columns of W-byte vectors: the two-stream kernel with the chunks' dictionaries in LDS */
+  HY_OPT_STAR_FUSED_PROBE = 31,      /* 1    hy_star_join_aggregate probes every dimension in ONE pass over the fact table (csrc/join_star.hpp) where the
+                                      *      shape allows; 0 = one hy_join_hash per dimension                                                      */
   HY_OPT_COUNT = 32
 };
 hy_status hy_set_option(uint32_t option, int64_t value);

@@ -33,6 +33,11 @@ def test_ssb_query_on_device(device, query, sql):
     dimensions, star_groupby, star_aggregates = ssb.star_plan(columns, query)
     result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
     assert star_joined == joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == sqlite
+    assert star_was_fused() == 1   # (one pass over lineorder: csrc/join_star.hpp) ... and dimension by dimension:
+    from hyrise_amd import abi
+    with abi.option(abi.OPT_STAR_FUSED_PROBE, 0):
+        result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
+    assert star_was_fused() == 0 and star_joined == joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == sqlite
 
 
 @pytest.mark.timeout(600)
@@ -41,6 +46,7 @@ def test_ssb_scale_factor_one_on_device(device):
     chain and the one-call plan on the device against the same plans on the CPU oracle (every thread) and against SQLite -- group rows,
     sums and joined-row counts are integers: equal, not close.  (SF30 itself is checked by bench.py against the oracle on every run.)"""
     import os
+    from hyrise_amd import abi
     from hyrise_amd.operators import star_join_aggregate
     data = ssb.SsbData(scale_factor=1.0, seed=11)
     assert data.n_lineorder == 6_000_000
@@ -55,8 +61,11 @@ def test_ssb_scale_factor_one_on_device(device):
         want = ssb.result_rows(aggregate_groups(oracle, o_groupby, o_aggregates))
         assert joined == o_joined and got == want, f"Q{query}: operator chain on the device vs the CPU oracle"
         dimensions, star_groupby, star_aggregates = ssb.star_plan(columns, query)
-        result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
-        assert star_joined == o_joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == want, f"Q{query}: hy_star_join_aggregate vs the CPU oracle"
+        for fused in (1, 0):
+            with abi.option(abi.OPT_STAR_FUSED_PROBE, fused):
+                result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
+            assert star_was_fused() == fused
+            assert star_joined == o_joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == want, f"Q{query}: hy_star_join_aggregate (fused {fused}) vs the CPU oracle"
         rows = data.sqlite_result(sql)
         sqlite = sorted(((r[1], r[2]), r[0]) for r in rows) if query == "2.1" else sorted(((r[0], r[1]), r[2]) for r in rows)
         assert got == sqlite, f"Q{query}: SQLite"
@@ -79,8 +88,16 @@ def test_two_ranks_on_one_gpu_replicated_and_repartitioned_plans(device):
     ssb_workload.check_results(results)
 
 
+def star_was_fused():
+    from hyrise_amd import abi
+    lib = abi.load_library()
+    lib.hy_debug_star_fused.restype = int
+    return lib.hy_debug_star_fused()
+
+
+@pytest.mark.parametrize("fused", [1, 0], ids=["fused_probe", "join_by_join"])
 @pytest.mark.parametrize("case", ["filtered", "nothing_survives", "first_dimension_unfiltered", "dangling_foreign_keys"])
-def test_star_join_aggregate_small_tables(device, case):
+def test_star_join_aggregate_small_tables(device, options, case, fused):
     """hy_star_join_aggregate on tables small enough to join with numpy: two dimensions (either may be unfiltered), foreign keys without a
     partner, a filter nothing passes (an empty join result: no groups), GROUP BY a column of each dimension, SUM of a fact column,
     SUM of an expression over two fact columns, COUNT(*)."""
@@ -114,7 +131,9 @@ def test_star_join_aggregate_small_tables(device, case):
     groupby = [(1, c["a_group"]), (2, c["b_group"])]
     aggregates = [(abi.AGG_SUM, (0, c["x"]), None, None), (abi.AGG_SUM, (0, c["x"]), abi.ARITH_MUL, (0, c["y"])), (abi.AGG_COUNT, None, None, None),
                   (abi.AGG_MIN, groupby[0], None, None), (abi.AGG_MIN, groupby[1], None, None)]
+    options.set(abi.OPT_STAR_FUSED_PROBE, fused)
     result, joined = star_join_aggregate(dimensions, groupby, aggregates)
+    assert star_was_fused() == fused   # (these tables are the fused probe's shape: int32 keys, unique per dimension, FrameOfReference foreign keys)
     # numpy: positions of the partners, then the filters
     a_of = {int(k): i for i, k in enumerate(a_key)}
     b_of = {int(k): i for i, k in enumerate(b_key)}
@@ -163,3 +182,60 @@ def test_star_join_aggregate_refuses_null_cells(device):
         assert error.value.status == abi.ERR_UNSUPPORTED
     result, joined = star_join_aggregate(dimensions(column(fk_b)), groupby, [(abi.AGG_SUM, (0, x_plain), None, None), (abi.AGG_MIN, groupby[0], None, None)])
     assert joined == n and result.n_groups == 200
+
+
+def test_star_join_shapes_the_fused_probe_leaves_to_the_joins(device):
+    """A dimension whose key comes twice (not a primary key: every partner counts, JoinHash's business), a dimension with a key range of
+    2^27 values (no direct table), and more dimensions than fit LDS at once with one of them asked in global memory: the first two run
+    join by join, the last fused -- all against numpy."""
+    import numpy as np
+    from hyrise_amd import abi, storage
+    from hyrise_amd.operators import make_predicate, star_join_aggregate
+    from hyrise_amd.storage import DeviceColumn
+    rng = np.random.default_rng(5)
+    n_fact = 150_000
+    column = lambda values, encoding=abi.ENC_UNENCODED, chunk=20_000: DeviceColumn(storage.make_column(np.ascontiguousarray(values), None, encoding, chunk))
+
+    def run(dim_keys, dim_groups, foreign):
+        dims = [(column(k, chunk=5_000), None, None, column(f, abi.ENC_FRAME_OF_REFERENCE)) for k, f in zip(dim_keys, foreign)]
+        group_columns = [column(g, abi.ENC_FRAME_OF_REFERENCE, 5_000) for g in dim_groups]
+        groupby = [(d + 1, g) for d, g in enumerate(group_columns)]
+        result, joined = star_join_aggregate(dims, groupby, [(abi.AGG_COUNT, None, None, None)] + [(abi.AGG_MIN, g, None, None) for g in groupby])
+        got = {tuple(result.column(1 + d)[i] for d in range(len(dims))): result.column(0)[i] for i in range(result.n_groups)}
+        return got, joined
+
+    def expected(dim_keys, dim_groups, foreign):
+        partners = []
+        for keys, groups, fk in zip(dim_keys, dim_groups, foreign):
+            of = {}
+            for k, g in zip(keys.tolist(), groups.tolist()):
+                of.setdefault(k, []).append(g)
+            partners.append([of.get(k, []) for k in fk.tolist()])
+        want, joined = {}, 0
+        for row in range(n_fact):
+            combos = [()]
+            for p in partners:
+                combos = [c + (g,) for c in combos for g in p[row]]
+            for c in combos:
+                want[c] = want.get(c, 0) + 1
+                joined += 1
+        return want, joined
+
+    # a key twice
+    keys = [np.concatenate([np.arange(1, 400, dtype=np.int32), np.array([7, 7, 9], dtype=np.int32)]), np.arange(1, 50, dtype=np.int32)]
+    groups = [rng.integers(0, 4, len(keys[0])).astype(np.int32), rng.integers(0, 3, len(keys[1])).astype(np.int32)]
+    foreign = [rng.integers(1, 420, n_fact).astype(np.int32), rng.integers(1, 55, n_fact).astype(np.int32)]
+    assert run(keys, groups, foreign) == expected(keys, groups, foreign) and star_was_fused() == 0
+    # a sparse key range
+    keys = [np.array(sorted(rng.choice(1 << 27, 300, replace=False)), dtype=np.int32), np.arange(1, 50, dtype=np.int32)]
+    groups = [rng.integers(0, 4, 300).astype(np.int32), rng.integers(0, 3, 49).astype(np.int32)]
+    foreign = [keys[0][rng.integers(0, 300, n_fact)], rng.integers(1, 55, n_fact).astype(np.int32)]
+    assert run(keys, groups, foreign) == expected(keys, groups, foreign) and star_was_fused() == 0
+    # five dimensions, one of them with 1.5 M key values (more than the others leave of LDS): fused, that one asked in global memory
+    sizes = [1_500_000, 1_000, 300, 50, 7]
+    keys = [np.arange(10, 10 + n, dtype=np.int32) for n in sizes]
+    keep = rng.random(sizes[0]) < 0.5
+    keys[0] = keys[0][keep]                      # (half of the big dimension's keys exist)
+    groups = [(k % 3).astype(np.int32) for k in keys]
+    foreign = [rng.integers(5, 15 + n, n_fact).astype(np.int32) for n in sizes]
+    assert run(keys, groups, foreign) == expected(keys, groups, foreign) and star_was_fused() == 1
