@@ -14,7 +14,7 @@
 //                                     keys arrive with 16-byte loads (eight consecutive rows per lane), a row survives if every
 //                                     dimension has its key; dimensions whose bits did not fit are asked in global memory, for the rows
 //                                     that survived the others only.  Leaves one byte per eight rows and a count per 8192-row tile.
-//   scan_counts                       where every tile's survivors go
+//   star_scan_counts                  where every tile's survivors go
 //   star_emit_rows                    the survivors' RowIDs, in FACT-TABLE ROW ORDER: the fact row's, and per dimension the RowID its
 //                                     table holds for the row's key (only survivors' keys are read again)
 // HBM traffic: every foreign-key column once + 1 bit per row + 8 bytes x (1 + dimensions) per surviving row.
@@ -53,9 +53,24 @@ __global__ __launch_bounds__(256) void star_all_rows(const uint64_t* row_base, u
   for (uint64_t i = begin + threadIdx.x; i < end; i += 256) rows[i] = hy_row_id{chunk, static_cast<uint32_t>(i - begin)};
 }
 
-// extent[0] = smallest key ^ sign, extent[1] = largest key ^ sign of the dimension's rows (NULL keys join nothing: skipped)
-__global__ __launch_bounds__(256) void star_dim_extent(const DevSegment* segments, const hy_row_id* rows, uint64_t n, unsigned long long* extent) {
+// What the two kernels below need of every dimension (blockIdx.y = dimension: all dimensions in ONE launch each -- a launch per dimension was
+// 30 us apiece for tables of a million rows and less, one after the other).
+struct StarDimensionJobs {
+  const DevSegment* segments[HY_MAX_STAR_DIMENSIONS];   // the key column
+  const hy_row_id* rows[HY_MAX_STAR_DIMENSIONS];        // the dimension's rows that take part
+  uint64_t n[HY_MAX_STAR_DIMENSIONS];
+  int64_t key_min[HY_MAX_STAR_DIMENSIONS];              // star_dim_fill
+  uint32_t* bits[HY_MAX_STAR_DIMENSIONS];
+  uint32_t* ids[HY_MAX_STAR_DIMENSIONS];
+};
+
+// extent[2 d] = smallest key ^ sign, extent[2 d + 1] = largest key ^ sign of dimension d's rows (NULL keys join nothing: skipped)
+__global__ __launch_bounds__(256) void star_dim_extent(StarDimensionJobs jobs, unsigned long long* extent) {
   constexpr uint64_t SIGN = 1ull << 63;
+  const uint32_t d = blockIdx.y;
+  const DevSegment* segments = jobs.segments[d];
+  const hy_row_id* rows = jobs.rows[d];
+  const uint64_t n = jobs.n[d];
   uint64_t low = ~0ull, high = 0;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) {
     const Value v = column_value(segments, rows[i].chunk_id, rows[i].chunk_offset);
@@ -65,16 +80,31 @@ __global__ __launch_bounds__(256) void star_dim_extent(const DevSegment* segment
     high = biased > high ? biased : high;
   }
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const uint64_t other_low = __shfl_xor(low, d, 64), other_high = __shfl_xor(high, d, 64);
+  for (int s = 32; s > 0; s >>= 1) {
+    const uint64_t other_low = __shfl_xor(low, s, 64), other_high = __shfl_xor(high, s, 64);
     low = other_low < low ? other_low : low;
     high = other_high > high ? other_high : high;
   }
-  if ((threadIdx.x & 63) == 0 && low <= high) { atomicMin(extent, static_cast<unsigned long long>(low)); atomicMax(extent + 1, static_cast<unsigned long long>(high)); }
+  // one pair of atomics per workgroup (atomics on one word retire one after the other: a pair per wave of 2 000 waves was 46 us per dimension)
+  __shared__ uint64_t s_low[4], s_high[4];
+  if ((threadIdx.x & 63) == 0) { s_low[threadIdx.x >> 6] = low; s_high[threadIdx.x >> 6] = high; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t w = 1; w < 4; ++w) { low = s_low[w] < low ? s_low[w] : low; high = s_high[w] > high ? s_high[w] : high; }
+    if (low <= high) { atomicMin(extent + 2 * d, static_cast<unsigned long long>(low)); atomicMax(extent + 2 * d + 1, static_cast<unsigned long long>(high)); }
+  }
 }
 
-// The dimension's direct table: bit and packed RowID of every key; *duplicate = 1 if a key comes twice.
-__global__ __launch_bounds__(256) void star_dim_fill(const DevSegment* segments, const hy_row_id* rows, uint64_t n, int64_t key_min, uint32_t* bits, uint32_t* ids, uint32_t* duplicate) {
+// The dimensions' direct tables: bit and packed RowID of every key; *duplicate = 1 if a key comes twice.  (A dimension without a table
+// -- no rows -- has n = 0.)
+__global__ __launch_bounds__(256) void star_dim_fill(StarDimensionJobs jobs, uint32_t* duplicate) {
+  const uint32_t d = blockIdx.y;
+  const DevSegment* segments = jobs.segments[d];
+  const hy_row_id* rows = jobs.rows[d];
+  const uint64_t n = jobs.n[d];
+  const int64_t key_min = jobs.key_min[d];
+  uint32_t* bits = jobs.bits[d];
+  uint32_t* ids = jobs.ids[d];
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) {
     const hy_row_id row = rows[i];
     const Value v = column_value(segments, row.chunk_id, row.chunk_offset);
@@ -169,13 +199,67 @@ __global__ __launch_bounds__(STAR_THREADS) void star_probe_mask(StarArgs a) {
   }
 }
 
-// One workgroup per tile with survivors: thread t holds the rows 32 t .. 32 t + 31 (four mask bytes).
+// Exclusive prefix of the tiles' survivor counts (n is tens of thousands): base[i] = survivors of the tiles before i, base[n] = all of them.
+// Blocks of 16 384 counts go through LDS: coalesced loads and stores, sixteen consecutive counts per thread in between.
+__global__ __launch_bounds__(1024) void star_scan_counts(const uint32_t* counts, uint64_t* base, uint32_t n) {
+  constexpr uint32_t PER = 16, BLOCK = 1024 * PER;
+  __shared__ uint32_t s_counts[BLOCK + BLOCK / PER];   // (element i at i + i / 16: a thread's sixteen start seventeen words apart)
+  __shared__ uint64_t s_wave[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint64_t carry = 0;
+  for (uint32_t begin = 0; begin < n; begin += BLOCK) {
+    const uint32_t m = n - begin < BLOCK ? n - begin : BLOCK;
+    for (uint32_t i = tid; i < BLOCK; i += 1024) s_counts[i + i / PER] = i < m ? counts[begin + i] : 0u;
+    __syncthreads();
+    uint32_t* mine = s_counts + tid * (PER + 1);
+    uint64_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) sum += mine[k];
+    uint64_t inclusive = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t other = __shfl_up(inclusive, d, 64);
+      if (lane >= static_cast<uint32_t>(d)) inclusive += other;
+    }
+    if (lane == 63) s_wave[wave] = inclusive;
+    __syncthreads();
+    uint64_t run = carry + inclusive - sum, total = 0;
+    for (uint32_t w = 0; w < 16; ++w) { if (w < wave) run += s_wave[w]; total += s_wave[w]; }
+    // (the prefixes leave as 64-bit words: a thread writes its sixteen -- 128 bytes, one line)
+    for (uint32_t k = 0; k < PER; ++k) { if (tid * PER + k < m) base[begin + tid * PER + k] = run; run += mine[k]; }
+    carry += total;
+    __syncthreads();
+  }
+  if (tid == 0) base[n] = carry;
+}
+
+// The survivors' RowIDs.  One workgroup per STAR_EMIT_TILES consecutive tiles: the set bits of their masks become a list of (tile, row)
+// in LDS -- in row order, a thread owns 256 consecutive rows -- and the list is worked off one survivor per thread: the output stores of a
+// wave are consecutive, and the dependent loads of a survivor (its stored word and block minimum per dimension, the dimension's RowID)
+// are in flight for a whole list at once instead of one tile's handful per workgroup (22 000 workgroups of a few dozen survivors each
+// took 145 us at SSB SF30).
+constexpr uint32_t STAR_EMIT_TILES = 8;
+constexpr uint32_t STAR_EMIT_LIST = 8192;   // survivors per pass over a workgroup's tiles
 __global__ __launch_bounds__(256) void star_emit_rows(StarArgs a) {
+  __shared__ uint32_t s_list[STAR_EMIT_LIST];   // tile in group << 13 | row in tile
   __shared__ uint32_t s_wave[4];
-  const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (a.counts[tile] == 0) return;   // (uniform)
-  uint32_t mask = reinterpret_cast<const uint32_t*>(a.masks + static_cast<size_t>(tile) * STAR_THREADS)[tid];
-  const uint32_t mine = __popc(mask);
+  __shared__ SliceView s_views[STAR_EMIT_TILES][HY_MAX_STAR_DIMENSIONS];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t first_tile = blockIdx.x * STAR_EMIT_TILES;
+  const uint32_t n_tiles = a.n_tiles - first_tile < STAR_EMIT_TILES ? a.n_tiles - first_tile : STAR_EMIT_TILES;
+  const uint64_t group_base = a.base[first_tile];
+  const uint32_t total = static_cast<uint32_t>(a.base[first_tile + n_tiles] - group_base);
+  if (total == 0) return;   // (uniform)
+  for (uint32_t i = tid; i < n_tiles * a.n_tables; i += 256) s_views[i / a.n_tables][i % a.n_tables] = a.table[i % a.n_tables].views[first_tile + i / a.n_tables];
+  // the thread's 256 consecutive rows: eight mask words
+  const uint32_t* words = reinterpret_cast<const uint32_t*>(a.masks + static_cast<size_t>(first_tile) * STAR_THREADS);
+  uint32_t mask[8], mine = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    const uint32_t w = tid * 8 + k;
+    mask[k] = w < n_tiles * (STAR_THREADS / 4) ? words[w] : 0u;
+    mine += __popc(mask[k]);
+  }
   uint32_t inclusive = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -186,21 +270,34 @@ __global__ __launch_bounds__(256) void star_emit_rows(StarArgs a) {
   __syncthreads();
   uint32_t before = inclusive - mine;
   for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
-  uint64_t out = a.base[tile] + before;
-  const SliceView fact = a.table[0].views[tile];
-  while (mask) {
-    const uint32_t j = __ffs(mask) - 1;
-    mask &= mask - 1;
-    const uint32_t row = 32 * tid + j;
-    a.fact_rows[out] = hy_row_id{fact.chunk, fact.row_begin + row};
-    for (uint32_t d = 0; d < a.n_tables; ++d) {
-      if (!a.table_rows[d]) continue;
-      const StarTable& table = a.table[d];
-      const SliceView view = table.views[tile];
-      const uint32_t id = table.ids[static_cast<uint32_t>(view_key(view, view.row_begin + row)) - table.key_min];
-      a.table_rows[d][out] = hy_row_id{id >> 16, id & 0xFFFFu};
+  for (uint32_t pass_begin = 0; pass_begin < total; pass_begin += STAR_EMIT_LIST) {
+    if (pass_begin) __syncthreads();   // (the list of the pass before has been worked off)
+    uint32_t rank = before;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+      uint32_t bits = mask[k];
+      const uint32_t row0 = (tid * 8 + k) * 32;   // row of bit 0, counted from the group's first row: tile = row0 / 8192
+      while (bits) {
+        const uint32_t j = __ffs(bits) - 1;
+        bits &= bits - 1;
+        if (rank - pass_begin < STAR_EMIT_LIST) s_list[rank - pass_begin] = row0 + j;   // (unsigned: ranks of earlier passes wrap to huge values)
+        ++rank;
+      }
     }
-    ++out;
+    __syncthreads();
+    const uint32_t in_pass = total - pass_begin < STAR_EMIT_LIST ? total - pass_begin : STAR_EMIT_LIST;
+    for (uint32_t i = tid; i < in_pass; i += 256) {
+      const uint32_t entry = s_list[i], tile = entry >> 13, row = entry & 8191u;
+      const uint64_t out = group_base + pass_begin + i;
+      const SliceView& fact = s_views[tile][0];
+      a.fact_rows[out] = hy_row_id{fact.chunk, fact.row_begin + row};
+      for (uint32_t d = 0; d < a.n_tables; ++d) {
+        if (!a.table_rows[d]) continue;
+        const SliceView& view = s_views[tile][d];
+        const uint32_t id = a.table[d].ids[static_cast<uint32_t>(view_key(view, view.row_begin + row)) - a.table[d].key_min];
+        a.table_rows[d][out] = hy_row_id{id >> 16, id & 0xFFFFu};
+      }
+    }
   }
 }
 
@@ -238,12 +335,17 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   std::vector<uint64_t> initial(2 * size_t{n_dimensions});
   for (uint32_t d = 0; d < n_dimensions; ++d) { initial[2 * d] = ~0ull; initial[2 * d + 1] = 0; }
   HY_HIP(hipMemcpyAsync(extents.ptr, initial.data(), 16 * size_t{n_dimensions}, hipMemcpyHostToDevice, stream));
+  StarDimensionJobs jobs;
+  std::memset(&jobs, 0, sizeof(jobs));
+  uint64_t most_rows = 0;
   for (uint32_t d = 0; d < n_dimensions; ++d) {
-    const StarProbeDimension& dim = dimensions[d];
-    if (!dim.n_rows) continue;
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((dim.n_rows + 255) / 256, 1024));
-    hipLaunchKernelGGL(star_dim_extent, dim3(grid), dim3(256), 0, stream, dim.key->d_segments, dim.rows, dim.n_rows, extents.as<unsigned long long>() + 2 * d);
+    jobs.segments[d] = dimensions[d].key->d_segments;
+    jobs.rows[d] = dimensions[d].rows;
+    jobs.n[d] = dimensions[d].n_rows;
+    most_rows = std::max(most_rows, dimensions[d].n_rows);
   }
+  const uint32_t job_grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((most_rows + 1023) / 1024, 256)));
+  hipLaunchKernelGGL(star_dim_extent, dim3(job_grid, n_dimensions), dim3(256), 0, stream, jobs, extents.as<unsigned long long>());
   std::vector<uint64_t> extent(2 * size_t{n_dimensions});
   HY_HIP(hipMemcpyAsync(extent.data(), extents.ptr, 16 * size_t{n_dimensions}, hipMemcpyDeviceToHost, stream));
   HY_HIP(hipStreamSynchronize(stream));
@@ -267,10 +369,12 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     HY_TRY(b.bits.alloc(4 * size_t{b.words} + 16));
     HY_TRY(b.ids.alloc(4 * (b.range + 1) + 16));
     HY_HIP(hipMemsetAsync(b.bits.ptr, 0, 4 * size_t{b.words}, stream));
-    const StarProbeDimension& dim = dimensions[d];
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((dim.n_rows + 255) / 256, 2048));
-    hipLaunchKernelGGL(star_dim_fill, dim3(grid), dim3(256), 0, stream, dim.key->d_segments, dim.rows, dim.n_rows, b.key_min, b.bits.as<uint32_t>(), b.ids.as<uint32_t>(), duplicate.as<uint32_t>());
+    jobs.key_min[d] = b.key_min;
+    jobs.bits[d] = b.bits.as<uint32_t>();
+    jobs.ids[d] = b.ids.as<uint32_t>();
   }
+  for (uint32_t d = 0; d < n_dimensions; ++d) if (built[d]->empty) jobs.n[d] = 0;
+  if (!nothing_joins) hipLaunchKernelGGL(star_dim_fill, dim3(job_grid, n_dimensions), dim3(256), 0, stream, jobs, duplicate.as<uint32_t>());
   dimension_rows.clear();
   dimension_rows.resize(n_dimensions);
   if (nothing_joins) {   // (still "applicable": the join result is empty)
@@ -331,7 +435,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   profile_begin(stream, HY_KERNEL_JOIN_PROBE);
   hipLaunchKernelGGL(star_probe_mask, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a);
   profile_end(stream);
-  hipLaunchKernelGGL(scan_counts, dim3(1), dim3(1024), 0, stream, counts.as<uint32_t>(), base.as<uint64_t>(), a.n_tiles);
+  hipLaunchKernelGGL(star_scan_counts, dim3(1), dim3(1024), 0, stream, counts.as<uint32_t>(), base.as<uint64_t>(), a.n_tiles);
   uint64_t total = 0;
   uint32_t key_twice = 0;
   HY_HIP(hipMemcpyAsync(&total, base.as<uint64_t>() + a.n_tiles, 8, hipMemcpyDeviceToHost, stream));
@@ -347,7 +451,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     HY_TRY(dimension_rows[d]->alloc(sizeof(hy_row_id) * std::max<uint64_t>(1, total)));
     a.table_rows[slot_of[d]] = dimension_rows[d]->as<hy_row_id>();
   }
-  if (total) hipLaunchKernelGGL(star_emit_rows, dim3(a.n_tiles), dim3(256), 0, stream, a);
+  if (total) hipLaunchKernelGGL(star_emit_rows, dim3((a.n_tiles + STAR_EMIT_TILES - 1) / STAR_EMIT_TILES), dim3(256), 0, stream, a);
   HY_HIP(hipGetLastError());
   *n_rows = total;
   *applicable = true;

@@ -22,7 +22,17 @@ namespace hy {
 
 static thread_local int t_last_star_was_fused = 0;   // debug / tests: the thread's last hy_star_join_aggregate took the fused probe
 
-constexpr uint32_t DENSE_CHUNK = 65536;   // rows per chunk of an intermediate table (chunks start on 16-byte boundaries for every type)
+constexpr uint32_t DENSE_CHUNK = 65536;   // rows per chunk of an intermediate table, at most (chunks start on 16-byte boundaries for every type)
+
+// Rows per chunk of an intermediate table of n rows.  The operators split their input chunk by chunk into slices of at most 8192 rows
+// and give a workgroup one slice: a join result of a million rows in chunks of 65 536 is 176 slices -- fewer than the device has CUs, and
+// AggregateHash's workgroups then take 0.3 - 0.5 ms for their 8192 rows each with nobody to overlap with.  About 2 000 slices instead:
+// chunks of 1024 rows and more, a power of two (the chunks of ONE table all have the same size: RowIDs are positions / chunk size).
+static uint32_t dense_chunk_rows(uint64_t n) {
+  uint32_t rows = 1024;
+  while (rows < DENSE_CHUNK && uint64_t{rows} * 2048 < n) rows <<= 1;
+  return rows;
+}
 
 struct ColumnHandle {   // an hy_column this plan created
   hy_column* column = nullptr;
@@ -36,13 +46,13 @@ struct ColumnHandle {   // an hy_column this plan created
 static size_t type_bytes(uint32_t data_type) { return (data_type == HY_TYPE_INT || data_type == HY_TYPE_FLOAT) ? 4 : 8; }
 
 // `rows` RowIDs into the data column `base`, presented as ReferenceSegments of DENSE_CHUNK rows (read in place)
-static hy_status reference_column(const hy_column* base, const hy_row_id* rows, uint64_t n, ColumnHandle& out) {
-  const uint32_t n_chunks = static_cast<uint32_t>(std::max<uint64_t>(1, (n + DENSE_CHUNK - 1) / DENSE_CHUNK));
+static hy_status reference_column(const hy_column* base, const hy_row_id* rows, uint64_t n, ColumnHandle& out, uint32_t chunk_rows = DENSE_CHUNK) {
+  const uint32_t n_chunks = static_cast<uint32_t>(std::max<uint64_t>(1, (n + chunk_rows - 1) / chunk_rows));
   std::vector<hy_segment> segments(n_chunks);
   for (uint32_t c = 0; c < n_chunks; ++c) {
     hy_segment& s = segments[c];
     std::memset(&s, 0, sizeof(s));
-    const uint64_t begin = uint64_t{c} * DENSE_CHUNK, end = std::min<uint64_t>(n, begin + DENSE_CHUNK);
+    const uint64_t begin = uint64_t{c} * chunk_rows, end = std::min<uint64_t>(n, begin + chunk_rows);
     s.encoding = HY_ENC_REFERENCE;
     s.data_type = base->data_type;
     s.size = static_cast<uint32_t>(end > begin ? end - begin : 0);
@@ -55,14 +65,14 @@ static hy_status reference_column(const hy_column* base, const hy_row_id* rows, 
 }
 
 // `values` (n elements of `data_type`, device memory, no NULLs) as ValueSegments of DENSE_CHUNK rows
-static hy_status value_column(const void* values, uint64_t n, uint32_t data_type, ColumnHandle& out) {
-  const uint32_t n_chunks = static_cast<uint32_t>(std::max<uint64_t>(1, (n + DENSE_CHUNK - 1) / DENSE_CHUNK));
+static hy_status value_column(const void* values, uint64_t n, uint32_t data_type, ColumnHandle& out, uint32_t chunk_rows = DENSE_CHUNK) {
+  const uint32_t n_chunks = static_cast<uint32_t>(std::max<uint64_t>(1, (n + chunk_rows - 1) / chunk_rows));
   const size_t width = type_bytes(data_type);
   std::vector<hy_segment> segments(n_chunks);
   for (uint32_t c = 0; c < n_chunks; ++c) {
     hy_segment& s = segments[c];
     std::memset(&s, 0, sizeof(s));
-    const uint64_t begin = uint64_t{c} * DENSE_CHUNK, end = std::min<uint64_t>(n, begin + DENSE_CHUNK);
+    const uint64_t begin = uint64_t{c} * chunk_rows, end = std::min<uint64_t>(n, begin + chunk_rows);
     s.encoding = HY_ENC_UNENCODED;
     s.data_type = data_type;
     s.size = static_cast<uint32_t>(end > begin ? end - begin : 0);
@@ -90,12 +100,12 @@ __global__ __launch_bounds__(256) void any_null_byte(const uint8_t* bytes, uint6
 
 // column `base` at the rows `rows` as a plain value column (values in `storage`).  The intermediate tables of this plan carry no null vectors:
 // a column whose cells at these rows include a NULL (a nullable foreign key, a GROUP BY column with NULLs) sends the caller to the operator chain.
-static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint64_t n, DeviceBuffer& storage, ColumnHandle& out) {
+static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint64_t n, DeviceBuffer& storage, ColumnHandle& out, uint32_t chunk_rows = DENSE_CHUNK) {
   if (base->data_type < HY_TYPE_INT || base->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "hy_star_join_aggregate: numeric columns only");
   HY_TRY(storage.alloc(type_bytes(base->data_type) * std::max<uint64_t>(n, 1) + 16));
   if (n) {
     ColumnHandle through;
-    HY_TRY(reference_column(base, rows, n, through));
+    HY_TRY(reference_column(base, rows, n, through, chunk_rows));
     if (may_hold_nulls(base)) {
       DeviceBuffer null_bytes, found;
       HY_TRY(null_bytes.alloc(n));
@@ -112,7 +122,7 @@ static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint6
       HY_TRY(hy_column_export(through.column, storage.ptr, nullptr));
     }
   }
-  return value_column(storage.ptr, n, base->data_type, out);
+  return value_column(storage.ptr, n, base->data_type, out, chunk_rows);
 }
 
 // The rows of `filter_column` that satisfy the predicate, as one dense PosList in device memory
@@ -336,7 +346,7 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
     Output& o = *outputs.back();
     o.source = source;
     if (!carried_rows[source.table]) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: no rows carried for table %u (internal error)", source.table);
-    HY_TRY(materialise(source.column, carried_rows[source.table], n_rows, o.values, o.column));
+    HY_TRY(materialise(source.column, carried_rows[source.table], n_rows, o.values, o.column, dense_chunk_rows(n_rows)));   // (the aggregate's input table: many small slices)
     *column = o.column.column;
     return HY_OK;
   };
