@@ -209,7 +209,7 @@ def committed_traffic(kernel):
 
 def pmc_file():
     """The newest committed PMC summary of this script (profiles/rNN_bench_pmc.json, tools/collect_profiles.sh)."""
-    for round_ in (4, 3):
+    for round_ in (5, 4, 3):
         path = os.path.join(ROOT, "profiles", f"r{round_:02d}_bench_pmc.json")
         if os.path.exists(path):
             return path

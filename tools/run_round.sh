@@ -9,6 +9,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpu
 bash tools/collect_profiles.sh "$1"
 ls gpurun_out/round
 bash tools/run_ssb_profile.sh > gpurun_out/ssb_profile.txt 2>&1
+bash tools/run_star_profile.sh round > /dev/null 2>&1   # hy_star_join_aggregate alone, per query: gpurun_out/round/star_q*.txt
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/q1prof
 rm -rf $OUT && mkdir -p $OUT

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Summarises the rocprofv3 runs of tools/collect_profiles.sh over `python bench.py` itself into the files committed under profiles/:
-  r04_bench_kernel_stats.csv   per (kernel, grid size): launches, average / min / max duration -- from the kernel trace of ONE bench.py
-                               process, whose own JSON line (HIP-event kernel_ms measured inside that process) is r04_bench_traced.json
-  r04_bench_pmc.json           per kernel (the launch shape of the headline step = the shape with most launches): FETCH_SIZE / WRITE_SIZE per
+  r05_bench_kernel_stats.csv   per (kernel, grid size): launches, average / min / max duration -- from the kernel trace of ONE bench.py
+                               process, whose own JSON line (HIP-event kernel_ms measured inside that process) is r05_bench_traced.json
+  r05_bench_pmc.json           per kernel (the launch shape of the headline step = the shape with most launches): FETCH_SIZE / WRITE_SIZE per
                                launch and hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE doubled: gfx950 tallies the 128-byte
                                requests of wide coalesced reads at 64 bytes, MI355X_MICROARCH.md "HBM"; WRITE_SIZE as reported); "step" = the
                                kernels of one TableScan + JoinHash step added up, "hy_join_hash" = the join's.  bench.py reads this file for
@@ -29,7 +29,7 @@ def base(name):
 
 
 def timeline(root):
-    """r04_bench_step_timeline.txt: the kernels of three consecutive headline steps in the middle of the timed region, with the idle time
+    """r05_bench_step_timeline.txt: the kernels of three consecutive headline steps in the middle of the timed region, with the idle time
     before each (launch gaps) -- what separates the sum of the kernels from the step's wall time."""
     rows = []
     for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
@@ -45,7 +45,7 @@ def timeline(root):
     begin = max(i for i in scans if i < middle)
     steps_begin = max([i for i in scans if i < begin][-2:-1] or [begin])
     end = emits[min(len(emits) - 1, len(emits) // 2 + 1)]
-    with open(os.path.join(root, "r04_bench_step_timeline.txt"), "w") as fh:
+    with open(os.path.join(root, "r05_bench_step_timeline.txt"), "w") as fh:
         fh.write("offset_us  idle_before_us  duration_us  kernel\n")
         origin, previous_end = rows[steps_begin][0], None
         for start, stop, name in rows[steps_begin:end + 1]:
@@ -63,7 +63,7 @@ def main():
                 if "hy::" in row["Kernel_Name"]:
                     groups[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     timeline(root)
-    with open(os.path.join(root, "r04_bench_kernel_stats.csv"), "w", newline="") as fh:
+    with open(os.path.join(root, "r05_bench_kernel_stats.csv"), "w", newline="") as fh:
         writer = csv.writer(fh)
         writer.writerow(["kernel", "grid_size_x", "launches", "average_us", "min_us", "max_us", "total_ms"])
         for (name, grid), durations in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
@@ -102,7 +102,7 @@ def main():
             kernels[total] = {"kernels": [m for m in members if m in kernels], "hbm_bytes_per_launch": sum(kernels[m]["hbm_bytes_per_launch"] for m in members if m in kernels)}
     summary = {"collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) over `python bench.py`, commit {commit}", "kernels": kernels,
                "note": "bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024 per launch of the kernel's headline shape (the grid size with most launches); memory-side cache hits included"}
-    with open(os.path.join(root, "r04_bench_pmc.json"), "w") as fh:
+    with open(os.path.join(root, "r05_bench_pmc.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     for name in ("scan_slices", "pk_emit", "pk_count", "rank_table_fill_waves", "step", "hy_join_hash"):
         if name in kernels:
