@@ -245,6 +245,13 @@ struct DeviceBuffer {
 };
 
 
+// ---- aggregate.hip: which path a GROUP BY should take, for callers whose input columns do not live long enough to remember it themselves
+// (hy_column::aggregate_hint does that for resident columns; the intermediate tables of hy_star_join_aggregate are new in every call).
+// t_aggregate_recommended: after a hy_aggregate_hash of this thread -- 0: aggregate_rows is fine, b + 1: start on the partitioned path with b
+// bits next time (the call ended there, or it met more groups than a workgroup's LDS table holds in an input of a few million rows).
+// t_aggregate_next_path: set before a call -- b + 1 starts that call on the partitioned path with b bits (consumed by the call).
+extern thread_local uint32_t t_aggregate_recommended, t_aggregate_next_path;
+
 // ---- join_star.hpp (join.hip): the probes of a star join fused into one pass over the fact table (hy_star_join_aggregate, plan.hip) ------
 struct StarProbeDimension {
   const hy_column* key;        // the dimension's key column (int32, unique among `rows`)

@@ -19,6 +19,8 @@ def main():
     from hyrise_amd.operators import star_join_aggregate
     lib = abi.load_library()
     abi.check(lib.hy_init(0))
+    named = {k: v for k, v in os.environ.items() if k in abi._SWITCHES}   # A/B: the library's named switches from the environment
+    abi.switches(named).__enter__()
     ex = HipExecutor(torch.device("cuda", 0))
     data = ssb.SsbData(scale_factor=sf, seed=7)
     columns = {name: ex.column(c) for name, c in data.host_columns().items()}
@@ -29,7 +31,8 @@ def main():
     for _ in range(steps):
         result, joined = star_join_aggregate(dimensions, groupby, aggregates, result=result)
     torch.cuda.synchronize()
-    print(f"Q{query} SF{sf:g}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per query, {joined} joined rows, {result.n_groups} groups")
+    lib.hy_debug_aggregate_path.restype = int
+    print(f"Q{query} SF{sf:g}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per query, {joined} joined rows, {result.n_groups} groups, switches {named}, aggregate path {lib.hy_debug_aggregate_path()}")
 
 
 if __name__ == "__main__":

@@ -38,13 +38,16 @@ def timeline(root):
     rows.sort()
     emits = [i for i, r in enumerate(rows) if base(r[2]) == "pk_emit"]
     scans = [i for i, r in enumerate(rows) if base(r[2]) == "scan_slices"]
-    if len(emits) < 12:
+    if len(emits) < 12 or len(scans) < 8:
         return
-    # the longest stretch of alternating scan / join launches is the timed region: take three steps from its middle
-    middle = emits[len(emits) // 2]
-    begin = max(i for i in scans if i < middle)
-    steps_begin = max([i for i in scans if i < begin][-2:-1] or [begin])
-    end = emits[min(len(emits) - 1, len(emits) // 2 + 1)]
+    # the timed region is where scan and join launches alternate (the joins in front of it -- placement calibration, setup -- come without
+    # scans): three steps around the middle SCAN launch
+    mid = len(scans) // 2
+    steps_begin = scans[mid - 1]
+    later = [i for i in emits if i > scans[min(len(scans) - 1, mid + 1)]]
+    if not later:
+        return
+    end = later[0]
     with open(os.path.join(root, "r05_bench_step_timeline.txt"), "w") as fh:
         fh.write("offset_us  idle_before_us  duration_us  kernel\n")
         origin, previous_end = rows[steps_begin][0], None
