@@ -256,7 +256,8 @@ extern thread_local uint32_t t_aggregate_recommended, t_aggregate_next_path;
 struct StarProbeDimension {
   const hy_column* key;        // the dimension's key column (int32, unique among `rows`)
   const hy_row_id* rows;       // the dimension rows that take part (device memory): the rows that pass its filter, or all of them
-  uint64_t n_rows;
+  uint64_t n_rows;             // how many -- or, with d_n_rows, at most how many
+  const uint64_t* d_n_rows;    // the count in device memory (a scan's total that no host has read), or nullptr
   const hy_column* fact_key;   // the fact table's foreign key to this dimension
   bool want_rows;              // the caller reads columns of this dimension at the surviving rows
 };
@@ -266,5 +267,8 @@ struct StarProbeDimension {
 hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimensions, DeviceBuffer& fact_rows, std::vector<std::unique_ptr<DeviceBuffer>>& dimension_rows,
                           uint64_t* n_rows, bool* applicable);
 hy_status star_all_rows_of(const hy_column* column, DeviceBuffer& rows);   // every row of a data column's table as a PosList
+// scan.hip: the kernels of hy_poslist_translate queued on the current stream, nothing read back -- dense_offsets: [n_chunks + 1] device words,
+// the last of them the number of RowIDs written
+hy_status poslist_translate_queued(const hy_column* scanned, const hy_scan_result* result, uint32_t layout, hy_row_id* out, uint64_t capacity, uint64_t* dense_offsets);
 
 }  // namespace hy

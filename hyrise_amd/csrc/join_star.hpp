@@ -59,6 +59,7 @@ struct StarDimensionJobs {
   const DevSegment* segments[HY_MAX_STAR_DIMENSIONS];   // the key column
   const hy_row_id* rows[HY_MAX_STAR_DIMENSIONS];        // the dimension's rows that take part
   uint64_t n[HY_MAX_STAR_DIMENSIONS];
+  const uint64_t* n_in_memory[HY_MAX_STAR_DIMENSIONS];  // ... or where their number stands (a scan's total that never went to the host)
   int64_t key_min[HY_MAX_STAR_DIMENSIONS];              // star_dim_fill
   uint32_t* bits[HY_MAX_STAR_DIMENSIONS];
   uint32_t* ids[HY_MAX_STAR_DIMENSIONS];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void star_dim_extent(StarDimensionJobs jobs, u
   const uint32_t d = blockIdx.y;
   const DevSegment* segments = jobs.segments[d];
   const hy_row_id* rows = jobs.rows[d];
-  const uint64_t n = jobs.n[d];
+  const uint64_t n = jobs.n_in_memory[d] ? *jobs.n_in_memory[d] : jobs.n[d];
   uint64_t low = ~0ull, high = 0;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) {
     const Value v = column_value(segments, rows[i].chunk_id, rows[i].chunk_offset);
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void star_dim_fill(StarDimensionJobs jobs, uin
   const uint32_t d = blockIdx.y;
   const DevSegment* segments = jobs.segments[d];
   const hy_row_id* rows = jobs.rows[d];
-  const uint64_t n = jobs.n[d];
+  const uint64_t n = jobs.n_in_memory[d] ? *jobs.n_in_memory[d] : jobs.n[d];
   const int64_t key_min = jobs.key_min[d];
   uint32_t* bits = jobs.bits[d];
   uint32_t* ids = jobs.ids[d];
@@ -342,6 +343,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     jobs.segments[d] = dimensions[d].key->d_segments;
     jobs.rows[d] = dimensions[d].rows;
     jobs.n[d] = dimensions[d].n_rows;
+    jobs.n_in_memory[d] = dimensions[d].d_n_rows;
     most_rows = std::max(most_rows, dimensions[d].n_rows);
   }
   const uint32_t job_grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((most_rows + 1023) / 1024, 256)));
@@ -373,7 +375,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     jobs.bits[d] = b.bits.as<uint32_t>();
     jobs.ids[d] = b.ids.as<uint32_t>();
   }
-  for (uint32_t d = 0; d < n_dimensions; ++d) if (built[d]->empty) jobs.n[d] = 0;
+  for (uint32_t d = 0; d < n_dimensions; ++d) if (built[d]->empty) { jobs.n[d] = 0; jobs.n_in_memory[d] = nullptr; }
   if (!nothing_joins) hipLaunchKernelGGL(star_dim_fill, dim3(job_grid, n_dimensions), dim3(256), 0, stream, jobs, duplicate.as<uint32_t>());
   dimension_rows.clear();
   dimension_rows.resize(n_dimensions);

@@ -126,7 +126,7 @@ static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint6
 }
 
 // The rows of `filter_column` that satisfy the predicate, as one dense PosList in device memory
-static hy_status filtered_rows(const hy_column* filter_column, const hy_predicate* predicate, DeviceBuffer& rows, uint64_t* n_rows) {
+static hy_status filtered_rows(const hy_column* filter_column, const hy_predicate* predicate, DeviceBuffer& rows, uint64_t* n_rows, DeviceBuffer* count_in_memory = nullptr) {
   DeviceBuffer regions, offsets, counts;
   const uint64_t capacity = std::max<uint64_t>(1, filter_column->rows);
   HY_TRY(regions.alloc(sizeof(hy_row_id) * capacity));
@@ -142,7 +142,11 @@ static hy_status filtered_rows(const hy_column* filter_column, const hy_predicat
   scan.offsets = offsets.as<uint64_t>();
   scan.counts = counts.as<uint32_t>();
   HY_TRY(hy_table_scan(filter_column, predicate, nullptr, 0, &scan));
-  return hy_poslist_translate(filter_column, &scan, HY_POSLIST_DENSE, rows.as<hy_row_id>(), capacity, n_rows);
+  if (!count_in_memory) return hy_poslist_translate(filter_column, &scan, HY_POSLIST_DENSE, rows.as<hy_row_id>(), capacity, n_rows);
+  // (the fused probe: the kernels that read the rows read their number from device memory too -- no host in between)
+  HY_TRY(count_in_memory->alloc(8 * (size_t{filter_column->n_chunks} + 2)));
+  *n_rows = capacity;
+  return poslist_translate_queued(filter_column, &scan, HY_POSLIST_DENSE, rows.as<hy_row_id>(), capacity, count_in_memory->as<uint64_t>());
 }
 
 struct JoinOutput {
@@ -249,7 +253,7 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
   bool fused = false;
   t_last_star_was_fused = 0;
   {
-    std::vector<std::unique_ptr<DeviceBuffer>> dimension_rows(n_dimensions);
+    std::vector<std::unique_ptr<DeviceBuffer>> dimension_rows(n_dimensions), counts(n_dimensions);
     std::vector<StarProbeDimension> probes(n_dimensions);
     bool shape_ok = true;
     for (uint32_t d = 0; d < n_dimensions && shape_ok; ++d) {
@@ -257,13 +261,16 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
       if (dimension.key->is_reference || dimension.key->data_type != HY_TYPE_INT || dimension.fact_key->data_type != HY_TYPE_INT) { shape_ok = false; break; }
       dimension_rows[d] = std::make_unique<DeviceBuffer>();
       uint64_t n_dimension_rows = dimension.key->rows;
+      const uint64_t* count_in_memory = nullptr;
       if (dimension.filter_column) {
-        HY_TRY(filtered_rows(dimension.filter_column, &dimension.predicate, *dimension_rows[d], &n_dimension_rows));
+        counts[d] = std::make_unique<DeviceBuffer>();
+        HY_TRY(filtered_rows(dimension.filter_column, &dimension.predicate, *dimension_rows[d], &n_dimension_rows, counts[d].get()));
+        count_in_memory = counts[d]->as<uint64_t>() + dimension.filter_column->n_chunks;
       } else HY_TRY(star_all_rows_of(dimension.key, *dimension_rows[d]));
       bool wanted = false;
       for (uint32_t g = 0; g < n_groupby; ++g) wanted = wanted || groupby[g].table == d + 1;
       for (uint32_t a = 0; a < n_aggregates; ++a) wanted = wanted || (aggregates[a].left.column && aggregates[a].left.table == d + 1) || (aggregates[a].op != HY_STAR_NO_OP && aggregates[a].right.table == d + 1);
-      probes[d] = StarProbeDimension{dimension.key, dimension_rows[d]->as<hy_row_id>(), n_dimension_rows, dimension.fact_key, wanted};
+      probes[d] = StarProbeDimension{dimension.key, dimension_rows[d]->as<hy_row_id>(), n_dimension_rows, count_in_memory, dimension.fact_key, wanted};
     }
     if (shape_ok) {
       auto fact_rows = std::make_unique<DeviceBuffer>();

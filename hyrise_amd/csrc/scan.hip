@@ -2112,6 +2112,17 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
   return HY_OK;
 }
 
+// hy_poslist_translate's kernels, queued on the current stream (hy_device.hpp): dense_offsets[n_chunks] = the total, in device memory.
+hy_status poslist_translate_queued(const hy_column* scanned, const hy_scan_result* result, uint32_t layout, hy_row_id* out, uint64_t capacity, uint64_t* dense_offsets) {
+  const uint32_t n_chunks = scanned->n_chunks;
+  hipStream_t stream = current_stream();
+  hipLaunchKernelGGL(region_prefix, dim3(1), dim3(256), 0, stream, result->counts, n_chunks, dense_offsets);
+  hipLaunchKernelGGL(translate_regions, dim3(n_chunks, 4), dim3(256), 0, stream, scanned->d_segments, result->matches, result->offsets, result->counts, dense_offsets, out,
+                     capacity, layout == HY_POSLIST_CHUNK_REGIONS ? 1u : 0u);
+  HY_HIP(hipGetLastError());
+  return HY_OK;
+}
+
 }  // namespace hy
 
 using namespace hy;
@@ -2184,10 +2195,7 @@ hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* r
   HY_TRY(sc.reserve(8 * (size_t{n_chunks} + 2) + 4096));
   uint64_t* d_dense_offsets = carve<uint64_t>(sc, size_t{n_chunks} + 2);
   if (!d_dense_offsets) return fail(HY_ERR_DEVICE, "scratch arena exhausted");
-  hipLaunchKernelGGL(region_prefix, dim3(1), dim3(256), 0, stream, result->counts, n_chunks, d_dense_offsets);
-  hipLaunchKernelGGL(translate_regions, dim3(n_chunks, 4), dim3(256), 0, stream, scanned->d_segments, result->matches, result->offsets, result->counts, d_dense_offsets, out,
-                     capacity, layout == HY_POSLIST_CHUNK_REGIONS ? 1u : 0u);
-  HY_HIP(hipGetLastError());
+  HY_TRY(poslist_translate_queued(scanned, result, layout, out, capacity, d_dense_offsets));
   uint64_t total = 0;
   HY_HIP(hipMemcpyAsync(&total, d_dense_offsets + n_chunks, 8, hipMemcpyDeviceToHost, stream));
   HY_HIP(hipStreamSynchronize(stream));
