@@ -287,16 +287,40 @@ __global__ __launch_bounds__(256) void star_emit_rows(StarArgs a) {
     }
     __syncthreads();
     const uint32_t in_pass = total - pass_begin < STAR_EMIT_LIST ? total - pass_begin : STAR_EMIT_LIST;
-    for (uint32_t i = tid; i < in_pass; i += 256) {
-      const uint32_t entry = s_list[i], tile = entry >> 13, row = entry & 8191u;
-      const uint64_t out = group_base + pass_begin + i;
-      const SliceView& fact = s_views[tile][0];
-      a.fact_rows[out] = hy_row_id{fact.chunk, fact.row_begin + row};
+    // eight survivors per thread at a time, table by table: their eight stored words are requested together, then their eight RowIDs, then
+    // the eight stores leave -- loads and stores share one counter on this hardware, a loop that stores after every load waits for each store
+    constexpr uint32_t AT_ONCE = 8;
+    for (uint32_t first = 0; first < in_pass; first += 256 * AT_ONCE) {
+      uint32_t tile[AT_ONCE], row[AT_ONCE];
+      bool there[AT_ONCE];
+#pragma unroll
+      for (uint32_t k = 0; k < AT_ONCE; ++k) {
+        const uint32_t i = first + k * 256 + tid;
+        there[k] = i < in_pass;
+        const uint32_t entry = s_list[there[k] ? i : 0u];
+        tile[k] = entry >> 13;
+        row[k] = entry & 8191u;
+      }
+      const uint64_t out = group_base + pass_begin + first + tid;
+#pragma unroll
+      for (uint32_t k = 0; k < AT_ONCE; ++k) {
+        const SliceView& fact = s_views[tile[k]][0];
+        if (there[k]) a.fact_rows[out + k * 256] = hy_row_id{fact.chunk, fact.row_begin + row[k]};
+      }
       for (uint32_t d = 0; d < a.n_tables; ++d) {
         if (!a.table_rows[d]) continue;
-        const SliceView& view = s_views[tile][d];
-        const uint32_t id = a.table[d].ids[static_cast<uint32_t>(view_key(view, view.row_begin + row)) - a.table[d].key_min];
-        a.table_rows[d][out] = hy_row_id{id >> 16, id & 0xFFFFu};
+        uint32_t key[AT_ONCE], id[AT_ONCE];
+#pragma unroll
+        for (uint32_t k = 0; k < AT_ONCE; ++k) {
+          const SliceView& view = s_views[tile[k]][d];
+          key[k] = static_cast<uint32_t>(view_key(view, view.row_begin + row[k]));   // (a thread without a survivor reads the list's first once more)
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < AT_ONCE; ++k) id[k] = a.table[d].ids[key[k] - a.table[d].key_min];
+#pragma unroll
+        for (uint32_t k = 0; k < AT_ONCE; ++k) {
+          if (there[k]) a.table_rows[d][out + k * 256] = hy_row_id{id[k] >> 16, id[k] & 0xFFFFu};
+        }
       }
     }
   }
