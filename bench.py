@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--no-ssb", action="store_true", help="skip the SSB SF30 star-join leg (config 5)")
     ap.add_argument("--switch", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: one of the library's named switches (hyrise_amd/abi.py _SWITCHES, e.g. HY_SCAN_NO_JOB_CACHE=1) for the whole run")
-    ap.add_argument("--placements", type=int, default=6, help="result-buffer placements the join's output pool is calibrated over before the timed region (1 = take the first)")
+    ap.add_argument("--placements", type=int, default=8, help="result-buffer placements the join's output pool is calibrated over before the timed region (1 = take the first)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed TableScan + JoinHash step (no legs, no CPU baselines)")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
                     help="file the full result object goes to (every leg, every case, prose); stdout gets the compact line only")
@@ -256,7 +256,8 @@ def timed_upload(name, host_column, uploads):
 def write_details(line, path):
     """The full result object (every leg, case and note) as indented JSON: `path`, and gpurun_out/ beside it when that exists (it travels back)."""
     text = json.dumps(line, indent=1)
-    targets = [path] + ([os.path.join(ROOT, "gpurun_out", os.path.basename(path))] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])
+    default = os.path.join(ROOT, "bench_details.json")   # (the default file is mirrored into gpurun_out/, which travels back from the GPU box; a named file is not)
+    targets = [path] + ([os.path.join(ROOT, "gpurun_out", "bench_details.json")] if path == default and os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])
     for target in targets:
         try:
             with open(target, "w") as fh:

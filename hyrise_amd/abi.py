@@ -266,7 +266,7 @@ class option:
 
 # The switches the tools/ scripts name -> (option, value when the switch is "1" / its integer value otherwise).
 _SWITCHES = {
-    "HY_SCAN_NO_JOB_CACHE": (OPT_SCAN_JOB_CACHE, 0), "HY_JOIN_NO_CLEAN_TABLES": (OPT_JOIN_CLEAN_TABLES, 0), "HY_SCAN_NO_TWO_COLUMNS": (OPT_SCAN_TWO_COLUMNS, 0), "HY_STAR_NO_FUSED_PROBE": (OPT_STAR_FUSED_PROBE, 0), "HY_SCAN_NT_STORES": (OPT_SCAN_NT_STORES, None), "HY_SCAN_WGS_PER_CU": (OPT_SCAN_WGS_PER_CU, None), "HY_PART_SLICES": (OPT_PART_SLICES, None),
+    "HY_SCAN_NO_JOB_CACHE": (OPT_SCAN_JOB_CACHE, 0), "HY_JOIN_NO_CLEAN_TABLES": (OPT_JOIN_CLEAN_TABLES, 0), "HY_JOIN_EMIT_TILE_GROUP": (OPT_JOIN_EMIT_TILE_GROUP, None), "HY_SCAN_NO_TWO_COLUMNS": (OPT_SCAN_TWO_COLUMNS, 0), "HY_STAR_NO_FUSED_PROBE": (OPT_STAR_FUSED_PROBE, 0), "HY_SCAN_NT_STORES": (OPT_SCAN_NT_STORES, None), "HY_SCAN_WGS_PER_CU": (OPT_SCAN_WGS_PER_CU, None), "HY_PART_SLICES": (OPT_PART_SLICES, None),
     "HY_JOIN_NO_RANK_TABLE": (OPT_JOIN_RANK_TABLE, 0), "HY_JOIN_NO_IDENTITY": (OPT_JOIN_IDENTITY, 0), "HY_JOIN_NO_HINT": (OPT_JOIN_HINT, 0),
     "HY_JOIN_BREAK_HINT": (OPT_JOIN_BREAK_HINT, None), "HY_JOIN_NO_FETCH_AHEAD": (OPT_JOIN_FETCH_AHEAD, 0), "HY_JOIN_NO_PKFK": (OPT_JOIN_PKFK, 0),
     "HY_JOIN_NO_LDS_BUILD": (OPT_JOIN_LDS_BUILD, 0), "HY_JOIN_LDS_BUILD_TILES": (OPT_JOIN_LDS_BUILD_TILES, None),

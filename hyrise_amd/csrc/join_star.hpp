@@ -224,10 +224,14 @@ __global__ __launch_bounds__(1024) void star_scan_counts(const uint32_t* counts,
     }
     if (lane == 63) s_wave[wave] = inclusive;
     __syncthreads();
-    uint64_t run = carry + inclusive - sum, total = 0;
+    uint64_t run = inclusive - sum, total = 0;   // (relative to the block: a block holds 16 384 tiles of at most 8192 survivors, 32 bits)
     for (uint32_t w = 0; w < 16; ++w) { if (w < wave) run += s_wave[w]; total += s_wave[w]; }
-    // (the prefixes leave as 64-bit words: a thread writes its sixteen -- 128 bytes, one line)
-    for (uint32_t k = 0; k < PER; ++k) { if (tid * PER + k < m) base[begin + tid * PER + k] = run; run += mine[k]; }
+    // the prefixes go back into the thread's sixteen LDS words and leave coalesced (a thread that stores its own sixteen 64-bit words writes a
+    // line of its own per instruction: 16 000 transactions from one CU were most of this kernel's 25 us)
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) { const uint32_t count = mine[k]; mine[k] = static_cast<uint32_t>(run); run += count; }
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += 1024) base[begin + i] = carry + s_counts[i + i / PER];
     carry += total;
     __syncthreads();
   }

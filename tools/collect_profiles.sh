@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/round
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp
-cmd="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cases --no-ssb --no-multi"
+cmd="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cases --no-ssb --no-multi --details /tmp/bench_details_profiled.json"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $cmd > $OUT/r05_bench_traced.json 2> $OUT/trace.log || tail -3 $OUT/trace.log
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $cmd > $OUT/fetch.json 2> $OUT/fetch.log || tail -3 $OUT/fetch.log
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $cmd > $OUT/write.json 2> $OUT/write.log || tail -3 $OUT/write.log
