@@ -514,7 +514,8 @@ typedef struct hy_aggregate_result {
 } hy_aggregate_result;
 
 /* Group order == the CPU operator's: first occurrence, or ascending key under the immediate-key shortcut
- * (aggregate_hash.cpp:388-401, 770-804). */
+ * (aggregate_hash.cpp:388-401, 770-804).  Up to eight GROUP BY columns (the reference: any number, aggregate_hash.cpp:1184-1198); more
+ * answer HY_ERR_UNSUPPORTED. */
 hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby,
                             const hy_aggregate_spec* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
 
@@ -573,7 +574,11 @@ hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters
  * the aggregates' arithmetic, an AggregateHash -- made by ONE function: exactly the calls of the entry points above an adapter would
  * make (hy_table_scan, hy_poslist_translate, hy_column_create, hy_column_export, hy_join_hash, hy_gather_row_ids,
  * hy_projection_arithmetic, hy_aggregate_hash), with every intermediate in device memory and no interpreter between them.  No
- * counterpart in the reference (its scheduler runs the operators one by one); results are those of the operator chain.
+ * counterpart in the reference (its scheduler runs the operators one by one); the groups and their cells are those of the operator chain.
+ * Where the shape allows (int32 primary keys with a range of at most 2^26 values, foreign keys as int32 values / FrameOfReference offsets
+ * without NULLs) every dimension is probed in ONE pass over the fact table instead (csrc/join_star.hpp, HY_OPT_STAR_FUSED_PROBE): the join
+ * result's rows -- and with them the groups, ordered by their first row -- then come in the fact table's row order, not in the order the
+ * last JoinHash of the chain would leave them in.
  * Columns are named as (table, column): table 0 = the fact table, d + 1 = dimension d; every column is a DATA column (numeric, or a
  * dictionary of key names / join ids) of its table.  An aggregate reads `left` alone (op = HY_STAR_NO_OP), `left <op> right`
  * (HY_ARITH_*: hy_projection_arithmetic), or nothing (left.column = NULL: COUNT(*)).  *joined_rows: rows of the join result.
