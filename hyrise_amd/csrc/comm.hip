@@ -35,6 +35,7 @@ struct hy_comm {
   std::shared_ptr<hy::LocalExchange> local;        // ... ranks that share ONE device (RCCL refuses those): copies inside its HBM
   int device = 0;
   uint32_t world = 1, rank = 0;
+  uint64_t collectives = 0;                        // this rank's collectives over `local` so far (LocalExchange::failed)
 };
 
 namespace hy {
@@ -142,9 +143,12 @@ struct LocalExchange {
   uint64_t round = 0;
   std::vector<const void*> send;
   std::vector<const uint64_t*> send_bytes;
-  // A rank that fails (its stream, an argument) still takes part in both meetings of a collective and raises this flag before the first:
-  // the others skip the exchange and report the failure too, instead of waiting for the rank that left (cleared by the last rank to leave).
-  std::atomic<uint32_t> failed{0};
+  // A rank that fails (its stream, an argument) still takes part in both meetings of a collective and raises the collective's flag before the
+  // first: the others skip the exchange and report the failure too, instead of waiting for the rank that left.  Two flags, taken in turn
+  // (every rank counts its collectives: hy_comm::collectives): collective k uses failed[k & 1], and rank 0 clears the OTHER one between k's
+  // two meetings -- nobody can be in collective k + 1 yet, and everybody has long finished reading k - 1's.  (One flag cleared after the
+  // last meeting could erase what a faster rank had already raised for the next collective.)
+  std::atomic<uint32_t> failed[2] = {{0}, {0}};
 };
 
 template <typename T>
@@ -156,10 +160,14 @@ static hy_status local_all_reduce(hy_comm* comm, const void* send, void* recv, u
   LocalExchange& x = *comm->local;
   hipStream_t stream = current_stream();
   hy_status status = HY_OK;
-  if (hipStreamSynchronize(stream) != hipSuccess) { status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: this rank's stream failed"); x.failed.store(1); }
+  std::atomic<uint32_t>& failed = x.failed[comm->collectives & 1];
+  std::atomic<uint32_t>& next_failed = x.failed[(comm->collectives + 1) & 1];
+  ++comm->collectives;
+  if (hipStreamSynchronize(stream) != hipSuccess) { status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: this rank's stream failed"); failed.store(1); }
   x.send[comm->rank] = send;
   x.meet();
-  if (status == HY_OK && x.failed.load()) status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: a co-located rank failed");
+  if (comm->rank == 0) next_failed.store(0);
+  if (status == HY_OK && failed.load()) status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: a co-located rank failed");
   std::vector<unsigned char> total(count * width), piece(count * width);
   for (uint32_t peer = 0; peer < x.world && status == HY_OK; ++peer) {
     if (hipMemcpyAsync(peer == 0 ? total.data() : piece.data(), x.send[peer], count * width, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
@@ -175,7 +183,6 @@ static hy_status local_all_reduce(hy_comm* comm, const void* send, void* recv, u
     }
   }
   x.meet();   // everyone has read every send buffer: recv may alias send
-  if (comm->rank == 0) x.failed.store(0);   // (every rank has looked at the flag before the meeting above)
   if (status == HY_OK && count && (hipMemcpyAsync(recv, total.data(), count * width, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess))
     status = fail(HY_ERR_DEVICE, "hy_comm_all_reduce: writing the reduced cells failed");
   return status;
@@ -187,11 +194,15 @@ static hy_status local_collect(hy_comm* comm, const void* send, const uint64_t* 
   LocalExchange& x = *comm->local;
   hipStream_t stream = current_stream();
   hy_status status = HY_OK;
-  if (hipStreamSynchronize(stream) != hipSuccess) { status = fail(HY_ERR_DEVICE, "this rank's stream failed before a collective"); x.failed.store(1); }
+  std::atomic<uint32_t>& failed = x.failed[comm->collectives & 1];
+  std::atomic<uint32_t>& next_failed = x.failed[(comm->collectives + 1) & 1];
+  ++comm->collectives;
+  if (hipStreamSynchronize(stream) != hipSuccess) { status = fail(HY_ERR_DEVICE, "this rank's stream failed before a collective"); failed.store(1); }
   x.send[comm->rank] = send;
   x.send_bytes[comm->rank] = send_bytes;
   x.meet();
-  if (status == HY_OK && x.failed.load()) status = fail(HY_ERR_DEVICE, "a co-located rank failed before a collective");
+  if (comm->rank == 0) next_failed.store(0);
+  if (status == HY_OK && failed.load()) status = fail(HY_ERR_DEVICE, "a co-located rank failed before a collective");
   uint64_t at = 0;
   for (uint32_t peer = 0; peer < x.world; ++peer) {
     const uint64_t n = bytes(peer);
@@ -201,7 +212,6 @@ static hy_status local_collect(hy_comm* comm, const void* send, const uint64_t* 
   }
   if (hipStreamSynchronize(stream) != hipSuccess && status == HY_OK) status = fail(HY_ERR_DEVICE, "copying a co-located rank's bytes failed");
   x.meet();   // the send buffers (and the callers' send_bytes arrays) may go now
-  if (comm->rank == 0) x.failed.store(0);
   return status;
 }
 
@@ -314,10 +324,11 @@ hy_status hy_comm_all_reduce(hy_comm* comm, const void* send, void* recv, uint64
   size_t width = 0;
   const bool bad = (count && (!send || !recv)) || !nccl_type(data_type, &type, &width) || op > HY_COMM_MAX;
   if (bad && comm->local) {   // (the co-located ranks are waiting at the meeting points: go there, with the failure flag up)
-    comm->local->failed.store(1);
+    const uint64_t k = comm->collectives++;
+    comm->local->failed[k & 1].store(1);
     comm->local->meet();
+    if (comm->rank == 0) comm->local->failed[(k + 1) & 1].store(0);
     comm->local->meet();
-    if (comm->rank == 0) comm->local->failed.store(0);
   }
   if (bad) return fail(HY_ERR_INVALID, "hy_comm_all_reduce: null argument, data type %u or operation %u", data_type, op);
   if (comm->local) return local_all_reduce(comm, send, recv, count, data_type, width, op);
