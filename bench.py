@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--no-ssb", action="store_true", help="skip the SSB SF30 star-join leg (config 5)")
     ap.add_argument("--switch", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: one of the library's named switches (hyrise_amd/abi.py _SWITCHES, e.g. HY_SCAN_NO_JOB_CACHE=1) for the whole run")
-    ap.add_argument("--placements", type=int, default=8, help="result-buffer placements the join's output pool is calibrated over before the timed region (1 = take the first)")
+    ap.add_argument("--placements", type=int, default=12, help="result-buffer placements the join's output pool is calibrated over before the timed region (1 = take the first)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed TableScan + JoinHash step (no legs, no CPU baselines)")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
                     help="file the full result object goes to (every leg, every case, prose); stdout gets the compact line only")
@@ -447,10 +447,10 @@ def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None, asynchr
     hy_join_hash_finish waits, reads them and fails like the synchronous call would."""
     from hyrise_amd import abi
     mode = abi.JOIN_INNER if mode is None else mode
-    from hyrise_amd.operators import pair_lists
+    from hyrise_amd.operators import pair_list_candidates, pair_lists
     # (the adapter's result-buffer policy: both PosLists from one allocation, 1.25 MiB apart modulo 2 MiB -- two streams written at the same
     #  index then use different memory channels, INTEGRATION.md section 3; Semi joins write one PosList)
-    candidates = [pair_lists(torch, dev, pairs_capacity) for _ in range(max(1, placements))]
+    candidates = pair_list_candidates(torch, dev, pairs_capacity, placements) if placements > 1 else [pair_lists(torch, dev, pairs_capacity)]
     left_pos, right_pos, arena = candidates[0]
     if mode != abi.JOIN_INNER:
         right_pos = left_pos

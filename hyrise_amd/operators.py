@@ -439,6 +439,24 @@ def pair_lists(torch, device, capacity):
     return left, right, arena
 
 
+def pair_list_candidates(torch, device, capacity, n):
+    """n candidate placements of a join's two output PosLists for a calibrated result-buffer pool: every list an
+    allocation of its own (2 n allocations: which stretch of device memory an allocation lands in decides pk_emit's speed by up to 15 %, and it
+    takes only ONE of the two lists in a good stretch -- profiles/r05_placement_probe.txt), the second list of a pair 1.25 MiB past the 2 MiB
+    grid the first starts on.  -> [(left, right, (the two allocations: keep them alive))]"""
+    list_bytes = 8 * max(1, int(capacity))
+    rows = max(1, int(capacity))
+    out = []
+    for _ in range(n):
+        arenas = [torch.empty(list_bytes + 2 * PAIR_LIST_PERIOD, dtype=torch.uint8, device=device) for _ in range(2)]
+        first = -arenas[0].data_ptr() % PAIR_LIST_PERIOD
+        second = -arenas[1].data_ptr() % PAIR_LIST_PERIOD + PAIR_LIST_OFFSET
+        left = arenas[0][first:first + list_bytes].view(torch.int32).view(rows, 2)
+        right = arenas[1][second:second + list_bytes].view(torch.int32).view(rows, 2)
+        out.append((left, right, tuple(arenas)))
+    return out
+
+
 def validate_filter(mvcc_column, our_tid, snapshot_commit_id, can_use_chunk_shortcut=True):
     """Validate as a filter of hy_scan_project_aggregate: (the table's MvccData as a DeviceColumn, its predicate)."""
     predicate = abi.Predicate()
