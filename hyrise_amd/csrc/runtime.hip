@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <cstring>
+#include <thread>
 
 namespace hy {
 
@@ -815,8 +816,36 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
     hipEvent_t* events;
     ~WindowEvents() { for (int i = 0; i < 2; ++i) if (events[i]) (void)hipEventDestroy(events[i]); }
   } window_events{window_sent};
+  // The copies into the window are collected and made by several threads when the window is sent: one thread moves pageable memory into
+  // the pinned block at 16 - 20 GB/s, a third of what the link takes.
+  struct WindowCopy { char* to; const void* from; size_t bytes; };
+  std::vector<WindowCopy> window_copies;
+  auto copy_window = [&]() {
+    size_t total = 0;
+    for (const WindowCopy& c : window_copies) total += c.bytes;
+    const unsigned helpers = total >= (size_t{4} << 20) ? std::min(4u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    auto work = [&](unsigned t) {   // contiguous shares of about total / helpers bytes
+      const size_t share_begin = total * t / helpers, share_end = total * (t + 1) / helpers;
+      size_t at = 0;
+      for (const WindowCopy& c : window_copies) {
+        const size_t begin = std::max(at, share_begin), end = std::min(at + c.bytes, share_end);
+        if (begin < end) std::memcpy(c.to + (begin - at), static_cast<const char*>(c.from) + (begin - at), end - begin);
+        at += c.bytes;
+        if (at >= share_end) break;
+      }
+    };
+    if (helpers == 1) work(0);
+    else {
+      std::vector<std::thread> threads;
+      for (unsigned t = 1; t < helpers; ++t) threads.emplace_back(work, t);
+      work(0);
+      for (std::thread& thread : threads) thread.join();
+    }
+    window_copies.clear();
+  };
   auto flush = [&]() -> hipError_t {
     if (cursor == window_begin) return hipSuccess;
+    copy_window();
     hipError_t err = hipMemcpyAsync(arena + window_begin, pinned + half * UPLOAD_WINDOW, cursor - window_begin, hipMemcpyHostToDevice, t_stream);
     if (err == hipSuccess) err = hipEventRecord(window_sent[half], t_stream);
     window_busy[half] = true;
@@ -846,7 +875,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
       window_begin = cursor;
       return err;
     }
-    if (err == hipSuccess) std::memcpy(pinned + half * UPLOAD_WINDOW + (cursor - window_begin), src, bytes);
+    if (err == hipSuccess) window_copies.push_back(WindowCopy{pinned + half * UPLOAD_WINDOW + (cursor - window_begin), src, bytes});
     cursor += padded;
     return err;
   };
