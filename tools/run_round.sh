@@ -3,8 +3,10 @@
 # traces of the SSB star joins (tools/run_ssb_profile.sh) and of TPC-H Q1 through hy_scan_project_aggregate (tools/q1_fused_time.py).
 # Every step under its own timeout.  usage: bash tools/run_round.sh <commit>
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/gputest.log 2>&1; echo "rc=$?" >> gpurun_out/gputest.log
-tail -4 gpurun_out/gputest.log
+if [ -z "$SKIP_TESTS" ]; then   # (SKIP_TESTS=1: the suite has passed at this commit in an earlier session)
+  timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/gputest.log 2>&1; echo "rc=$?" >> gpurun_out/gputest.log
+  tail -4 gpurun_out/gputest.log
+fi
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
 bash tools/collect_profiles.sh "$1"
 ls gpurun_out/round

@@ -60,17 +60,31 @@ def timeline(root):
 def main():
     root, commit = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
     groups = collections.defaultdict(list)
+    launches = []
     for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 if "hy::" in row["Kernel_Name"]:
-                    groups[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                    key = (short(row["Kernel_Name"]), int(row["Grid_Size_X"]))
+                    groups[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                    launches.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), key))
     timeline(root)
+    # The step's kernels INSIDE the stretch where scans and joins alternate (warm-up, the timed region and the scan-alone leg behind it): the
+    # joins in front of it run into the calibration's candidate placements (bench.py --placements) and the join legs behind it into buffers
+    # of their own -- the same kernels, slower or faster with where their output lies -- and would blur the step's averages.
+    scans = sorted(start for start, _, key in launches if base(key[0]) == "scan_slices")
+    in_step = collections.defaultdict(list)
+    if scans:
+        for start, stop, key in launches:
+            if scans[0] <= start <= scans[-1] and base(key[0]) in STEP:
+                in_step[key].append(stop - start)
     with open(os.path.join(root, "r05_bench_kernel_stats.csv"), "w", newline="") as fh:
         writer = csv.writer(fh)
-        writer.writerow(["kernel", "grid_size_x", "launches", "average_us", "min_us", "max_us", "total_ms"])
+        writer.writerow(["kernel", "grid_size_x", "launches", "average_us", "min_us", "max_us", "total_ms", "launches_in_step_region", "average_us_in_step_region"])
         for (name, grid), durations in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
-            writer.writerow([name, grid, len(durations), f"{sum(durations) / len(durations) / 1e3:.2f}", f"{min(durations) / 1e3:.2f}", f"{max(durations) / 1e3:.2f}", f"{sum(durations) / 1e6:.3f}"])
+            inside = in_step.get((name, grid), [])
+            writer.writerow([name, grid, len(durations), f"{sum(durations) / len(durations) / 1e3:.2f}", f"{min(durations) / 1e3:.2f}", f"{max(durations) / 1e3:.2f}", f"{sum(durations) / 1e6:.3f}",
+                             len(inside), f"{sum(inside) / len(inside) / 1e3:.2f}" if inside else ""])
     # the headline shape of every kernel: the (name, grid) with most launches
     headline = {}
     for (name, grid), durations in groups.items():
