@@ -22,17 +22,14 @@ namespace hy {
 
 static thread_local int t_last_star_was_fused = 0;   // debug / tests: the thread's last hy_star_join_aggregate took the fused probe
 
-constexpr uint32_t DENSE_CHUNK = 65536;   // rows per chunk of an intermediate table, at most (chunks start on 16-byte boundaries for every type)
+constexpr uint32_t DENSE_CHUNK = 65536;   // rows per chunk of an intermediate table (chunks start on 16-byte boundaries for every type; smaller chunks -- more,
+                                          // smaller slices for the aggregate -- were tried: 2048-row chunks cost more on the host, 700 descriptors per column, than they gave)
 
-// Rows per chunk of an intermediate table of n rows.  The operators split their input chunk by chunk into slices of at most 8192 rows
-// and give a workgroup one slice: a join result of a million rows in chunks of 65 536 is 176 slices -- fewer than the device has CUs, and
-// AggregateHash's workgroups then take 0.3 - 0.5 ms for their 8192 rows each with nobody to overlap with.  About 2 000 slices instead:
-// chunks of 1024 rows and more, a power of two (the chunks of ONE table all have the same size: RowIDs are positions / chunk size).
-static uint32_t dense_chunk_rows(uint64_t n) {
-  uint32_t rows = 1024;
-  while (rows < DENSE_CHUNK && uint64_t{rows} * 2048 < n) rows <<= 1;
-  return rows;
-}
+struct ColumnHandle;
+// Columns a step of the plan is done with: hy_column_destroy waits for the thread's stream (their descriptor blocks go back to the pool),
+// which -- right behind the launch that reads them -- kept the host from queueing the next step until the device had caught up (a third
+// of an SSB query was such waits).  They are kept until the plan's last kernel is queued and go together.
+static thread_local std::vector<std::unique_ptr<ColumnHandle>>* t_plan_done_with = nullptr;
 
 struct ColumnHandle {   // an hy_column this plan created
   hy_column* column = nullptr;
@@ -104,7 +101,12 @@ static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint6
   if (base->data_type < HY_TYPE_INT || base->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "hy_star_join_aggregate: numeric columns only");
   HY_TRY(storage.alloc(type_bytes(base->data_type) * std::max<uint64_t>(n, 1) + 16));
   if (n) {
-    ColumnHandle through;
+    auto through_owner = std::make_unique<ColumnHandle>();
+    ColumnHandle& through = *through_owner;
+    struct Later {   // (on every way out of this block)
+      std::unique_ptr<ColumnHandle>& owner;
+      ~Later() { if (t_plan_done_with) t_plan_done_with->push_back(std::move(owner)); }
+    } later{through_owner};
     HY_TRY(reference_column(base, rows, n, through, chunk_rows));
     if (may_hold_nulls(base)) {
       DeviceBuffer null_bytes, found;
@@ -241,6 +243,11 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
     if (aggregates[a].op != HY_STAR_NO_OP) HY_TRY(check_column(aggregates[a].right, "the second input of aggregate", a));
   }
 
+  std::vector<std::unique_ptr<ColumnHandle>> done_with;   // (destroyed when this function returns, after everything below)
+  struct DoneWith {
+    explicit DoneWith(std::vector<std::unique_ptr<ColumnHandle>>* list) { t_plan_done_with = list; }
+    ~DoneWith() { t_plan_done_with = nullptr; }
+  } done_with_scope{&done_with};
   // carried[t]: base RowIDs of table t (0 = the fact table, d + 1 = dimension d) per row of the join result so far
   std::vector<std::unique_ptr<DeviceBuffer>> carried(n_dimensions + 1);
   std::vector<const hy_row_id*> carried_rows(n_dimensions + 1, nullptr);
@@ -353,7 +360,7 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
     Output& o = *outputs.back();
     o.source = source;
     if (!carried_rows[source.table]) return fail(HY_ERR_INVALID, "hy_star_join_aggregate: no rows carried for table %u (internal error)", source.table);
-    HY_TRY(materialise(source.column, carried_rows[source.table], n_rows, o.values, o.column, dense_chunk_rows(n_rows)));   // (the aggregate's input table: many small slices)
+    HY_TRY(materialise(source.column, carried_rows[source.table], n_rows, o.values, o.column));
     *column = o.column.column;
     return HY_OK;
   };
