@@ -156,6 +156,10 @@ struct hy_column {
   std::vector<std::pair<size_t, void*>> pooled;   // ... or handed back to the buffer pool (operator results)
   mutable hy_join_key_hint join_hint;
   mutable hy_scan_job_cache scan_jobs;
+  // smallest / largest non-NULL value of an int32 data column (join_star.hpp: the range a dimension's direct table spans): computed once --
+  // the segments are immutable -- by the first star join that uses the column as a dimension key.  state 1: valid, 2: the column holds no value
+  mutable std::atomic<uint32_t> extent_state{0};
+  mutable std::atomic<int64_t> extent_min{0}, extent_max{0};
   mutable std::atomic<uint64_t> aggregate_hint{0};   // aggregate.hip: which path the last GROUP BY led by this column ended on (signature of the column set << 8 | partition bits + 1)
   // RunLength segments and bit-packed vectors stay compressed in device memory; TableScan reads them in place.  The operators that
   // gather rows (joins, aggregates, projections, exchanges, reference columns) read `plain`: the same column as Value / FixedWidthInteger

@@ -6,7 +6,7 @@
 // As an operator chain every join writes its pairs, and the carried RowIDs of every table are gathered through them for the next
 // join: 39 % of an SSB query's device time was materialising intermediates that a star probe never needs (profiles/r04_ssb_kernel_stats.txt).
 // Here:
-//   star_dim_extent / star_dim_fill   per dimension: smallest / largest key of its filtered rows, then a direct table over that range --
+//   star_column_extent / star_dim_fill   per dimension: smallest / largest key of its key column (once per column: remembered), then a direct table over that range --
 //                                     one presence bit and one packed RowID (chunk << 16 | offset) per key value; a key met twice is
 //                                     reported (not a primary key: the caller runs the operator chain)
 //   star_probe_mask                   persistent 1024-thread workgroups, the dimensions' presence bits staged in LDS where they fit
@@ -65,16 +65,14 @@ struct StarDimensionJobs {
   uint32_t* ids[HY_MAX_STAR_DIMENSIONS];
 };
 
-// extent[2 d] = smallest key ^ sign, extent[2 d + 1] = largest key ^ sign of dimension d's rows (NULL keys join nothing: skipped)
-__global__ __launch_bounds__(256) void star_dim_extent(StarDimensionJobs jobs, unsigned long long* extent) {
+// extent[0] = smallest value ^ sign, extent[1] = largest value ^ sign of a data column (NULLs skipped); one workgroup per chunk
+__global__ __launch_bounds__(256) void star_column_extent(const DevSegment* segments, unsigned long long* extent) {
   constexpr uint64_t SIGN = 1ull << 63;
-  const uint32_t d = blockIdx.y;
-  const DevSegment* segments = jobs.segments[d];
-  const hy_row_id* rows = jobs.rows[d];
-  const uint64_t n = jobs.n_in_memory[d] ? *jobs.n_in_memory[d] : jobs.n[d];
+  const uint32_t chunk = blockIdx.x;
+  const uint32_t size = segments[chunk].size;
   uint64_t low = ~0ull, high = 0;
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) {
-    const Value v = column_value(segments, rows[i].chunk_id, rows[i].chunk_offset);
+  for (uint32_t row = threadIdx.x; row < size; row += 256) {
+    const Value v = column_value(segments, chunk, row);
     if (v.is_null) continue;
     const uint64_t biased = static_cast<uint64_t>(v.i) ^ SIGN;
     low = biased < low ? biased : low;
@@ -86,13 +84,12 @@ __global__ __launch_bounds__(256) void star_dim_extent(StarDimensionJobs jobs, u
     low = other_low < low ? other_low : low;
     high = other_high > high ? other_high : high;
   }
-  // one pair of atomics per workgroup (atomics on one word retire one after the other: a pair per wave of 2 000 waves was 46 us per dimension)
   __shared__ uint64_t s_low[4], s_high[4];
   if ((threadIdx.x & 63) == 0) { s_low[threadIdx.x >> 6] = low; s_high[threadIdx.x >> 6] = high; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (uint32_t w = 1; w < 4; ++w) { low = s_low[w] < low ? s_low[w] : low; high = s_high[w] > high ? s_high[w] : high; }
-    if (low <= high) { atomicMin(extent + 2 * d, static_cast<unsigned long long>(low)); atomicMax(extent + 2 * d + 1, static_cast<unsigned long long>(high)); }
+    if (low <= high) { atomicMin(extent, static_cast<unsigned long long>(low)); atomicMax(extent + 1, static_cast<unsigned long long>(high)); }
   }
 }
 
@@ -358,12 +355,41 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     for (const hy_segment& s : rows_of->host_segments) if (s.size > 65536) return HY_OK;
   }
   hipStream_t stream = current_stream();
-  // ---- the dimensions' extents (one host read for all of them) ---------------------------------------------------------------
-  DeviceBuffer extents;
-  HY_TRY(extents.alloc(16 * size_t{n_dimensions} + 64));
-  std::vector<uint64_t> initial(2 * size_t{n_dimensions});
-  for (uint32_t d = 0; d < n_dimensions; ++d) { initial[2 * d] = ~0ull; initial[2 * d + 1] = 0; }
-  HY_HIP(hipMemcpyAsync(extents.ptr, initial.data(), 16 * size_t{n_dimensions}, hipMemcpyHostToDevice, stream));
+  // ---- the dimensions' key ranges: the extent of the whole key column (a superset of its filtered rows' keys), remembered by the column --
+  // one look at the keys and one host read the first time a column serves as a dimension key, none afterwards ------------------------------
+  std::vector<uint64_t> extent(2 * size_t{n_dimensions});
+  constexpr uint64_t SIGN = 1ull << 63;
+  {
+    DeviceBuffer extents;
+    std::vector<uint32_t> asked;
+    for (uint32_t d = 0; d < n_dimensions; ++d) if (dimensions[d].key->extent_state.load(std::memory_order_acquire) == 0) asked.push_back(d);
+    if (!asked.empty()) {
+      HY_TRY(extents.alloc(16 * asked.size() + 64));
+      std::vector<uint64_t> initial(2 * asked.size());
+      for (size_t i = 0; i < asked.size(); ++i) { initial[2 * i] = ~0ull; initial[2 * i + 1] = 0; }
+      HY_HIP(hipMemcpyAsync(extents.ptr, initial.data(), 16 * asked.size(), hipMemcpyHostToDevice, stream));
+      for (size_t i = 0; i < asked.size(); ++i) {
+        const hy_column* key = dimensions[asked[i]].key;
+        if (key->n_chunks) hipLaunchKernelGGL(star_column_extent, dim3(key->n_chunks), dim3(256), 0, stream, key->d_segments, extents.as<unsigned long long>() + 2 * i);
+      }
+      std::vector<uint64_t> found(2 * asked.size());
+      HY_HIP(hipMemcpyAsync(found.data(), extents.ptr, 16 * asked.size(), hipMemcpyDeviceToHost, stream));
+      HY_HIP(hipStreamSynchronize(stream));
+      for (size_t i = 0; i < asked.size(); ++i) {
+        const hy_column* key = dimensions[asked[i]].key;
+        const bool any = found[2 * i] <= found[2 * i + 1];
+        key->extent_min.store(any ? static_cast<int64_t>(found[2 * i] ^ SIGN) : 0, std::memory_order_relaxed);
+        key->extent_max.store(any ? static_cast<int64_t>(found[2 * i + 1] ^ SIGN) : 0, std::memory_order_relaxed);
+        key->extent_state.store(any ? 1u : 2u, std::memory_order_release);
+      }
+    }
+    for (uint32_t d = 0; d < n_dimensions; ++d) {
+      const hy_column* key = dimensions[d].key;
+      const bool any = key->extent_state.load(std::memory_order_acquire) == 1 && dimensions[d].n_rows != 0;
+      extent[2 * d] = any ? static_cast<uint64_t>(key->extent_min.load(std::memory_order_relaxed)) ^ SIGN : ~0ull;
+      extent[2 * d + 1] = any ? static_cast<uint64_t>(key->extent_max.load(std::memory_order_relaxed)) ^ SIGN : 0;
+    }
+  }
   StarDimensionJobs jobs;
   std::memset(&jobs, 0, sizeof(jobs));
   uint64_t most_rows = 0;
@@ -375,12 +401,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     most_rows = std::max(most_rows, dimensions[d].n_rows);
   }
   const uint32_t job_grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((most_rows + 1023) / 1024, 256)));
-  hipLaunchKernelGGL(star_dim_extent, dim3(job_grid, n_dimensions), dim3(256), 0, stream, jobs, extents.as<unsigned long long>());
-  std::vector<uint64_t> extent(2 * size_t{n_dimensions});
-  HY_HIP(hipMemcpyAsync(extent.data(), extents.ptr, 16 * size_t{n_dimensions}, hipMemcpyDeviceToHost, stream));
-  HY_HIP(hipStreamSynchronize(stream));
   // ---- the direct tables -------------------------------------------------------------------------------------------------------
-  constexpr uint64_t SIGN = 1ull << 63;
   struct Built { DeviceBuffer bits, ids; int64_t key_min = 0; uint64_t range = 0; uint32_t words = 0; bool empty = false; };
   std::vector<std::unique_ptr<Built>> built(n_dimensions);
   DeviceBuffer duplicate;
