@@ -34,6 +34,7 @@
 #include <map>
 #include <memory>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 // Two builds of this file: GROUP BY over at most 4 columns (this translation unit: a tuple is five 64-bit words in registers -- every
@@ -3145,7 +3146,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     }
     HY_TRY(device_groups(a, shape, main_groups, reinterpret_cast<const FusedPlan*>(base), nullptr, lean ? &small_plan : nullptr));
   } else {
-    // The TPC-H Q1 shape -- a handful of groups over dictionary columns, SUM / AVG / COUNT over dictionary-encoded floating-point
+    // The TPC-H Q1 shape -- a handful of groups over dictionary columns, SUM / AVG / COUNT / MIN / MAX over dictionary-encoded numeric
     // columns with 1- or 2-byte value ids -- has a kernel of its own (aggregate_small.hpp); everything else takes aggregate_rows.
     SmallDomainPlan small;
     std::memset(&small, 0, sizeof(small));
@@ -3155,10 +3156,10 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       for (uint32_t d = 0; d < n_device && lean; ++d) {
         const hy_column* column = specs[spec_of_device[d]].column;
         const uint32_t function = a.aggregates[d].function;
-        lean = function == HY_AGG_SUM || function == HY_AGG_AVG || function == HY_AGG_COUNT;
+        lean = function == HY_AGG_SUM || function == HY_AGG_AVG || function == HY_AGG_COUNT || function == HY_AGG_MIN || function == HY_AGG_MAX;
         if (!column || !lean) continue;
         uint32_t width = 0;
-        lean = (column->data_type == HY_TYPE_FLOAT || column->data_type == HY_TYPE_DOUBLE) && dictionary_column(column, &width);
+        lean = (column->data_type == HY_TYPE_INT || column->data_type == HY_TYPE_LONG || column->data_type == HY_TYPE_FLOAT || column->data_type == HY_TYPE_DOUBLE) && dictionary_column(column, &width);
         if (lean && width == (pass == 0 ? 1u : 2u) && std::find(inputs.begin(), inputs.end(), column) == inputs.end()) inputs.push_back(column);
       }
       if (pass == 0) small.n_narrow = static_cast<uint32_t>(inputs.size());
@@ -3175,6 +3176,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       for (uint32_t d = 0; d < n_device; ++d) {
         const hy_column* column = specs[spec_of_device[d]].column;
         small.column_of_aggregate[d] = column ? static_cast<uint32_t>(std::find(inputs.begin(), inputs.end(), column) - inputs.begin()) : 0xFFFFFFFFu;
+        if (column && (a.aggregates[d].function == HY_AGG_MIN || a.aggregates[d].function == HY_AGG_MAX)) small.extremes |= 1u << small.column_of_aggregate[d];
       }
     }
     HY_TRY(device_groups(a, shape, main_groups, nullptr, lean ? &small : nullptr));

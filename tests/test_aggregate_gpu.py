@@ -372,10 +372,10 @@ def used_small_domain():
 
 
 def test_small_domain_kernel(device, options):
-    """aggregate_small_domain (csrc/aggregate_small.hpp): a handful of groups over dictionary GROUP BY columns, SUM / AVG / COUNT over
-    dictionary-encoded float / double columns with 1- and 2-byte value ids -- the TPC-H Q1 shape.  Against the oracle: 1 - 3 GROUP BY
-    columns, NULLs in keys and inputs, more than four groups per chunk (the shared-cell path), ragged chunks, one-row chunks, and
-    the same answers as the generic kernel (HY_OPT_AGG_SMALL_DOMAIN = 0)."""
+    """aggregate_small_domain (csrc/aggregate_small.hpp): a handful of groups over dictionary GROUP BY columns, SUM / AVG / COUNT / MIN /
+    MAX over dictionary-encoded int / long / float / double columns with 1- and 2-byte value ids -- the TPC-H Q1 shape and its
+    neighbours.  Against the oracle: 1 - 3 GROUP BY columns, NULLs in keys and inputs, more than four groups per chunk (the shared-cell
+    path), ragged chunks, one-row chunks, negative integers, and the same answers as the generic kernel (HY_OPT_AGG_SMALL_DOMAIN = 0)."""
     rng = np.random.default_rng(91)
     for n, chunk in ((200_000, 65535), (70_001, 8192), (5, 2), (40_000, 40_000), (150_000, 100_000)):   # (the last: chunks of more than one 65520-row span)
         flags = rng.integers(0, 3, n).astype(np.int32)                       # 3 distinct
@@ -394,12 +394,24 @@ def test_small_domain_kernel(device, options):
         d = build_column(discount, rng.random(n) < 0.03, chunk, abi.ENC_DICTIONARY)
         p = build_column(price, price_nulls, chunk, abi.ENC_DICTIONARY)
         w = build_column(wide_double, None, chunk, abi.ENC_DICTIONARY)
+        qi = build_column(rng.integers(-40, 41, n).astype(np.int32), rng.random(n) < 0.05, chunk, abi.ENC_DICTIONARY)                 # int, 1-byte value ids
+        ql = build_column(rng.integers(-3, 4, n).astype(np.int64) * (1 << 40), None, chunk, abi.ENC_DICTIONARY)                       # long, 1-byte value ids, sums beyond 2^53
+        pi = build_column(rng.integers(-30_000, 30_000, n).astype(np.int32) * 1000, rng.random(n) < 0.02, chunk, abi.ENC_DICTIONARY)  # int, 2-byte value ids where the chunk is large enough
+        pl = build_column(rng.integers(-20_000, 20_000, n).astype(np.int64) * (1 << 33) - 5, None, chunk, abi.ENC_DICTIONARY)         # long, 2-byte value ids
         q1 = [(abi.AGG_SUM, q), (abi.AGG_SUM, p), (abi.AGG_AVG, q), (abi.AGG_AVG, p), (abi.AGG_AVG, d), (abi.AGG_COUNT, None)]
         for name, groupby, aggregates in (("q1 shape", [g1, g2], q1), ("one key", [g2], q1[:3] + [(abi.AGG_COUNT, p)]),
                                           ("three keys, 36 codes: the generic kernel", [g1, g2, g3], [(abi.AGG_SUM, w), (abi.AGG_AVG, p), (abi.AGG_COUNT, d), (abi.AGG_COUNT, None)]),
                                           ("two keys, up to nine groups", [g2, g3, g2], [(abi.AGG_SUM, w), (abi.AGG_AVG, p), (abi.AGG_COUNT, d), (abi.AGG_COUNT, None)]),
                                           ("twelve groups with NULL keys", [g1, g3], [(abi.AGG_SUM, w), (abi.AGG_AVG, p), (abi.AGG_COUNT, d), (abi.AGG_COUNT, None)]),
-                                          ("no group by", [], [(abi.AGG_SUM, q), (abi.AGG_AVG, w), (abi.AGG_COUNT, None)])):
+                                          ("no group by", [], [(abi.AGG_SUM, q), (abi.AGG_AVG, w), (abi.AGG_COUNT, None)]),
+                                          ("integers and extremes", [g1, g2], [(abi.AGG_SUM, qi), (abi.AGG_AVG, qi), (abi.AGG_MIN, qi), (abi.AGG_MAX, pi), (abi.AGG_SUM, pi), (abi.AGG_MIN, d),
+                                                                               (abi.AGG_MAX, d), (abi.AGG_COUNT, None)]),
+                                          ("longs", [g2], [(abi.AGG_SUM, ql), (abi.AGG_AVG, ql), (abi.AGG_MAX, ql), (abi.AGG_SUM, pl), (abi.AGG_MIN, pl), (abi.AGG_MAX, pl), (abi.AGG_AVG, pl), (abi.AGG_COUNT, pl)]),
+                                          ("extremes of floats", [g1], [(abi.AGG_MIN, p), (abi.AGG_MAX, p), (abi.AGG_MIN, q), (abi.AGG_MAX, q), (abi.AGG_AVG, p)]),
+                                          ("extremes of a wide double, no group by", [], [(abi.AGG_MIN, w), (abi.AGG_MAX, w), (abi.AGG_SUM, w)]),
+                                          ("twelve groups, integers and extremes", [g1, g3], [(abi.AGG_MIN, p), (abi.AGG_MAX, p), (abi.AGG_SUM, qi), (abi.AGG_AVG, qi), (abi.AGG_MAX, qi), (abi.AGG_MIN, d),
+                                                                                              (abi.AGG_COUNT, p)]),
+                                          ("twelve groups, a wide long", [g1, g3], [(abi.AGG_SUM, pl), (abi.AGG_MIN, pl), (abi.AGG_MAX, pl), (abi.AGG_SUM, ql), (abi.AGG_MIN, ql)])):
             context = f"small domain, {n} rows in chunks of {chunk}, {name}"
             got = run_both(groupby, aggregates, context)
             widths = {c.segments[0].width for _, c in aggregates if c is not None} | {c.segments[0].width for c in groupby}
@@ -425,16 +437,20 @@ def test_small_domain_kernel(device, options):
     price[price == 123.5] = 77.25 + np.arange(40, dtype=np.float32)   # (the same column without the repeated value: the kernel keeps it)
     run_both([key], [(abi.AGG_SUM, build_column(price, None, 65535, abi.ENC_DICTIONARY)), (abi.AGG_COUNT, None)], "no value sixteen times")
     assert used_small_domain() == 1
-    # a shape the kernel does not take: an integer input column, a GROUP BY column with too many distinct values
+    # shapes the kernel does not take: a GROUP BY column with too many distinct values, STDDEV_SAMP, an unencoded input -- and two it takes now
     ints = build_column(rng.integers(0, 9, 1000).astype(np.int32), None, 500, abi.ENC_DICTIONARY)
     many = build_column(rng.integers(0, 40, 1000).astype(np.int32), None, 500, abi.ENC_DICTIONARY)
     few = build_column(rng.integers(0, 2, 1000).astype(np.int32), None, 500, abi.ENC_DICTIONARY)
     floats = build_column(rng.integers(0, 9, 1000).astype(np.float32), None, 500, abi.ENC_DICTIONARY)
     run_both([few], [(abi.AGG_SUM, ints)], "integer input")
-    assert used_small_domain() == 0
+    assert used_small_domain() == 1
     run_both([many], [(abi.AGG_SUM, floats)], "forty groups")
     assert used_small_domain() == 0
     run_both([few], [(abi.AGG_SUM, floats), (abi.AGG_MIN, floats)], "MIN")
+    assert used_small_domain() == 1
+    run_both([few], [(abi.AGG_STDDEV_SAMP, floats)], "STDDEV_SAMP")
+    assert used_small_domain() == 0
+    run_both([few], [(abi.AGG_SUM, build_column(rng.integers(0, 9, 1000).astype(np.int32), None, 500, abi.ENC_UNENCODED))], "unencoded input")
     assert used_small_domain() == 0
 
 

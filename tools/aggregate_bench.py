@@ -33,6 +33,9 @@ else:                         # config 4 as specified: string keys as key names,
 dev = {k: DeviceColumn(v) for k, v in cols.items()}
 aggregates = [(abi.AGG_SUM, dev["l_quantity"]), (abi.AGG_SUM, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_quantity"]),
               (abi.AGG_AVG, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_discount"]), (abi.AGG_COUNT, None)]
+if os.environ.get("EXTREMES"):   # the kernel's round-5 widening: MIN / MAX (the smallest / largest value id a group counted) next to the sums
+    aggregates = [(abi.AGG_SUM, dev["l_quantity"]), (abi.AGG_MIN, dev["l_extendedprice"]), (abi.AGG_MAX, dev["l_extendedprice"]), (abi.AGG_AVG, dev["l_extendedprice"]),
+                  (abi.AGG_MIN, dev["l_discount"]), (abi.AGG_MAX, dev["l_quantity"]), (abi.AGG_COUNT, None)]
 n_aggs = int(os.environ.get("AGGS", str(len(aggregates))))
 aggregates = aggregates[:n_aggs] if n_aggs else [(abi.AGG_COUNT, None)]
 for i in range(4):
@@ -41,7 +44,8 @@ for i in range(4):
     result = aggregate_hash([dev["l_returnflag"], dev["l_linestatus"]], aggregates, group_capacity=64)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
-    print(f"aggregate ms {dt * 1e3:.3f} groups {result.n_groups} rows/s {n / dt:.3g} algorithmic GB/s {bytes_total / dt / 1e9:.0f}")
+    lib.hy_debug_aggregate_small_domain.restype = int
+    print(f"aggregate ms {dt * 1e3:.3f} groups {result.n_groups} rows/s {n / dt:.3g} algorithmic GB/s {bytes_total / dt / 1e9:.0f} small-domain kernel {lib.hy_debug_aggregate_small_domain()}")
 if os.environ.get("HY_AGG_TRACE"):
     lib.hy_debug_aggregate_trace.argtypes = [C.c_void_p, C.c_uint32]
     lib.hy_debug_aggregate_trace.restype = C.c_int
