@@ -441,7 +441,7 @@ def roofline_object(kernel, algorithmic_bytes, kernel_ms, traffic=None):
             "kernel": kernel, "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms}
 
 
-def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None, asynchronous=False, placements=1):
+def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None, asynchronous=False, placements=1, pool=None):
     """One hy_join_hash with device-memory PosLists; returns (callable, result struct, buffers).  asynchronous: HY_JOIN_ASYNC -- the call
     returns with its kernels queued (pair count, PosList count and fit flag stay in device memory, hy_join_status); `run.finish()` =
     hy_join_hash_finish waits, reads them and fails like the synchronous call would."""
@@ -450,7 +450,8 @@ def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None, asynchr
     from hyrise_amd.operators import pair_list_candidates, pair_lists
     # (the adapter's result-buffer policy: both PosLists from one allocation, 1.25 MiB apart modulo 2 MiB -- two streams written at the same
     #  index then use different memory channels; Semi joins write one PosList)
-    candidates = pair_list_candidates(torch, dev, pairs_capacity, placements) if placements > 1 else [pair_lists(torch, dev, pairs_capacity)]
+    # pool: (left list, right list, allocation) of an earlier call -- the calibrated result-buffer pool of this process, used again
+    candidates = [pool] if pool is not None else pair_list_candidates(torch, dev, pairs_capacity, placements) if placements > 1 else [pair_lists(torch, dev, pairs_capacity)]
     left_pos, right_pos, arena = candidates[0]
     if mode != abi.JOIN_INNER:
         right_pos = left_pos
@@ -521,7 +522,7 @@ def join_kernels(kinds, n_orders, n, pairs, offset_width=2, pair_bytes=16):
     return out
 
 
-def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem_host, orders, lineitem):
+def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem_host, orders, lineitem, pool=None):
     """Config 3 of BASELINE.json alone: JoinHash(orders, lineitem) on the order key, SF10 -- o_orderkey unencoded int32 (build),
     l_orderkey FrameOfReference + u16 offsets (probe); PosList pairs written to HBM.  Also the reference's two Semi benchmarks
     (tpch_data_micro_benchmark.cpp:299-316)."""
@@ -531,11 +532,12 @@ def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem
     data = sf10_tables()
     n = data.n_lineitems
     steps = max(3, min(steps, 10))
-    run, r, keep = device_join(lib, torch, dev, orders, lineitem, n)
+    run, r, keep = device_join(lib, torch, dev, orders, lineitem, n, pool=pool)   # (pool: the headline's calibrated result buffers)
     dt, kinds = timed_kernel(lib, torch, run, steps, all_kinds=True)
     algorithmic = data.n_orders * 4 + n * 2 + int(r.n_pairs) * 16      # build keys + probe keys + 16 B/pair
     kernels = join_kernels(kinds, data.n_orders, n, int(r.n_pairs))
-    info = {"workload": "configs[2]: JoinHash orders x lineitem on the order key, SF10, Inner (o_orderkey int32 values, l_orderkey FrameOfReference u16)",
+    info = {"workload": "configs[2]: JoinHash orders x lineitem on the order key, SF10, Inner (o_orderkey int32 values, l_orderkey FrameOfReference u16)"
+                        + ("; PosLists in the process's calibrated result-buffer pool (config.output_placement)" if pool is not None else ""),
             "rows_per_s": (data.n_orders + n) / dt, "ms_per_join": dt * 1e3, "pairs": int(r.n_pairs), "radix_bits": int(r.radix_bits),
             "output_pos_lists": int(r.n_slices), "algorithmic_bytes": algorithmic,
             "roofline": dict(roofline_object("whole operator (all kernels of one hy_join_hash, host-timed)", algorithmic, dt * 1e3, committed_traffic("hy_join_hash")),
@@ -1099,9 +1101,11 @@ def main():
     extra_cases = None
     if single and not args.no_cases:
         extra_cases = scan_cases(lib, torch, dev, args.steps, days, columns[0], scan_step, counts, rows, width)
+    join_pool = (join_buffers[0], join_buffers[1], join_buffers[3]) if run_join.placement else None   # (the calibrated pool serves the join leg too)
     del join_buffers, orders_copies[1:], lineitem_copies[1:]
-    join_info = (join_leg(lib, torch, dev, args.steps, not args.no_cases, not args.no_cpu_baseline, orders_host, lineitem_host, orders, lineitem)
+    join_info = (join_leg(lib, torch, dev, args.steps, not args.no_cases, not args.no_cpu_baseline, orders_host, lineitem_host, orders, lineitem, pool=join_pool)
                  if single and not args.no_join else None)
+    del join_pool
     aggregate_info = aggregate_leg(lib, torch, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_aggregate else None
 
     q6_info = q6_leg(torch, dev, args.steps) if single and not args.no_cases else None
