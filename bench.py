@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 COLUMN_COPIES = 3               # > 256 MiB of column data in rotation
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--headline-only", action="store_true", help="only the timed TableScan + JoinHash step (no legs, no CPU baselines)")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
                     help="file the full result object goes to (every leg, every case, prose); stdout gets the compact line only")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def oracle_support():
@@ -300,7 +300,9 @@ def compact_line(line, details_path=None):
                      "chunks_per_gpu": cfg["chunks_per_gpu"], "scan_selectivity": _short(cfg["scan_selectivity"], 4), "join_pairs": cfg["join_pairs"], "parallelism": cfg["parallelism"]}
     if cfg.get("output_placement"):
         out["config"]["output_placement"] = cfg["output_placement"]
-        out["config"]["workload"] += ", result-buffer pool calibrated over %d placements before the timed region" % cfg["output_placement"]["candidates"]
+        out["config"]["workload"] += (", PosLists in the library's result-buffer pool, calibrated over %d placements before the timed region (hy_result_pool_calibrate); "
+                                      "ms_per_step_median_placement: the same step in the median candidate") % cfg["output_placement"]["candidates"]
+        out["config"]["output_placement"] = {k: v for k, v in cfg["output_placement"].items() if k != "by"}
     r = line["roofline"]
     roof = compact_roofline(r, "TableScan+JoinHash step, host-timed")
     roof["dominant_kernel"] = compact_roofline(r.get("dominant_kernel"))
@@ -346,6 +348,14 @@ def compact_line(line, details_path=None):
                 legs["ssb_sf30"][q]["cpu_rows_per_s"] = _short(s["cpu_baseline"][q]["value"])
     if legs:
         out["legs"] = legs
+    if "ms_per_step_median_placement" in line:
+        out["ms_per_step_median_placement"] = _short(line["ms_per_step_median_placement"], 6)
+    if "rccl_ranks" in line:
+        out["rccl_ranks"] = line["rccl_ranks"]
+    if "cpp_operator_chain_ms" in line:
+        chain = line["cpp_operator_chain_ms"]
+        legs = out.setdefault("legs", {})
+        legs["cpp_operator_chain_ms"] = {k: _short(v) for k, v in chain.items() if isinstance(v, (int, float, bool, str)) and k not in ("pool_candidates", "pool_chosen")}
     if "upload" in line and line["upload"]:
         out["upload_GBps"] = _short(max(u["achieved"] for u in line["upload"].values()), 4)
     if "multi_gpu" in line:
@@ -441,32 +451,63 @@ def roofline_object(kernel, algorithmic_bytes, kernel_ms, traffic=None):
             "kernel": kernel, "algorithmic_bytes_per_launch": algorithmic_bytes, "kernel_ms": kernel_ms}
 
 
-def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None, asynchronous=False, placements=1, pool=None):
-    """One hy_join_hash with device-memory PosLists; returns (callable, result struct, buffers).  asynchronous: HY_JOIN_ASYNC -- the call
-    returns with its kernels queued (pair count, PosList count and fit flag stay in device memory, hy_join_status); `run.finish()` =
-    hy_join_hash_finish waits, reads them and fails like the synchronous call would."""
+class PoolPair:
+    """Two PosLists of the library's result-buffer pool (hy_result_pool_acquire_pair): given back on release() / when collected."""
+
+    def __init__(self, lib, rows):
+        from hyrise_amd import abi
+        self.lib, self.left, self.right = lib, C.c_void_p(), C.c_void_p()
+        abi.check(lib.hy_result_pool_acquire_pair(rows, C.byref(self.left), C.byref(self.right)))
+
+    def release(self):
+        for side in ("left", "right"):
+            pointer = getattr(self, side)
+            if pointer is not None and pointer.value:
+                self.lib.hy_result_pool_release(pointer)
+            setattr(self, side, None)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None, asynchronous=False, placements=1):
+    """One hy_join_hash with device-memory PosLists from the LIBRARY's result-buffer pool (hy_result_pool_*: what the C++ adapter's JoinHash
+    uses too, hyrise_amd/host/hyrise_host.hpp); returns (callable, result struct, buffers).  asynchronous: HY_JOIN_ASYNC -- the call returns
+    with its kernels queued (pair count, PosList count and fit flag stay in device memory, hy_join_status); `run.finish()` =
+    hy_join_hash_finish waits, reads them and fails like the synchronous call would.  placements > 1: the pool is calibrated first
+    (hy_result_pool_calibrate, outside any timed region: `placements` candidate pairs, the fastest is what the pool hands out from then on,
+    the median one stays as well -- `run.use_median()` points the join at it)."""
     from hyrise_amd import abi
     mode = abi.JOIN_INNER if mode is None else mode
-    from hyrise_amd.operators import pair_list_candidates, pair_lists
-    # (the adapter's result-buffer policy: both PosLists from one allocation, 1.25 MiB apart modulo 2 MiB -- two streams written at the same
-    #  index then use different memory channels, INTEGRATION.md section 3; Semi joins write one PosList)
-    # pool: (left list, right list, allocation) of an earlier call -- the calibrated result-buffer pool of this process, used again
-    candidates = [pool] if pool is not None else pair_list_candidates(torch, dev, pairs_capacity, placements) if placements > 1 else [pair_lists(torch, dev, pairs_capacity)]
-    left_pos, right_pos, arena = candidates[0]
-    if mode != abi.JOIN_INNER:
-        right_pos = left_pos
+    # `left` / `right`: a column each, or equally long lists of copies that the calls take in rotation (inputs that come from HBM, not
+    # from what the previous call left in the 256 MiB memory-side cache)
+    lefts, rights = (left if isinstance(left, (list, tuple)) else [left]), (right if isinstance(right, (list, tuple)) else [right])
+    placement = None
+    if placements > 1:
+        times = (C.c_float * placements)()
+        chosen = C.c_uint32(0)
+        abi.check(lib.hy_result_pool_calibrate(lefts[0].handle, rights[0].handle, mode, pairs_capacity, placements, abi.POOL_KEEP_MEDIAN, times, C.byref(chosen)))
+        placement = {"candidates": placements, "join_ms_per_candidate": [float(f"{t:.4g}") for t in times], "chosen": int(chosen.value),
+                     "by": "hy_result_pool_calibrate (the library's result-buffer pool; the C++ adapter's JoinHash draws from the same pool)"}
+    best = PoolPair(lib, pairs_capacity)                        # (the calibrated pair if there is one, else a fresh pair placed by the pool's policy)
+    median = PoolPair(lib, pairs_capacity) if placement else None   # (second in line: the median candidate)
     slice_offsets = torch.zeros(8192, dtype=torch.int64, device=dev)
     status = torch.zeros(4, dtype=torch.int64, device=dev)
     r = abi.JoinResult()
     r.mem, r.radix_bits = abi.MEM_DEVICE, 0xFFFFFFFF
-    r.left_pos, r.right_pos, r.capacity = left_pos.data_ptr(), right_pos.data_ptr(), pairs_capacity
+    r.capacity = pairs_capacity
     r.slice_offsets, r.slice_capacity = slice_offsets.data_ptr(), 8000
     if asynchronous:
         r.flags, r.status = abi.JOIN_ASYNC, status.data_ptr()
 
-    # `left` / `right`: a column each, or equally long lists of copies that the calls take in rotation (inputs that come from HBM, not
-    # from what the previous call left in the 256 MiB memory-side cache)
-    lefts, rights = (left if isinstance(left, (list, tuple)) else [left]), (right if isinstance(right, (list, tuple)) else [right])
+    def use(pair):
+        r.left_pos = pair.left.value
+        r.right_pos = pair.right.value if mode == abi.JOIN_INNER else pair.left.value
+
+    use(best)
     turn = [0]
 
     def run():
@@ -480,33 +521,10 @@ def device_join(lib, torch, dev, left, right, pairs_capacity, mode=None, asynchr
         abi.check(lib.hy_join_hash_finish(lefts[i].handle, rights[i].handle, mode, C.byref(r)))
 
     run.finish = finish
-    run.placement = None
-    if len(candidates) > 1:
-        # Where the two output lists lie in HBM decides pk_emit's speed by up to 20 % (profiles/r04_join_placement.txt: per
-        # allocation, reproducibly, cause not understood).  The adapter's result-buffer pool is therefore CALIBRATED once, outside any timed region:
-        # `placements` allocations of the pool's size, a few joins into each, the fastest is kept.
-        trial_ms = []
-        for left_c, right_c, _ in candidates:
-            r.left_pos, r.right_pos = left_c.data_ptr(), (right_c if mode == abi.JOIN_INNER else left_c).data_ptr()
-            for _ in range(2 * len(lefts)):   # (also leaves the build columns' key hints behind)
-                run()
-            started, stopped = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            started.record()
-            for _ in range(2 * len(lefts)):
-                run()
-            stopped.record()
-            if asynchronous:
-                finish()
-            torch.cuda.synchronize()
-            trial_ms.append(started.elapsed_time(stopped) / (2 * len(lefts)))
-        best = min(range(len(candidates)), key=lambda i: trial_ms[i])
-        left_pos, right_pos, arena = candidates[best]
-        if mode != abi.JOIN_INNER:
-            right_pos = left_pos
-        r.left_pos, r.right_pos = left_pos.data_ptr(), right_pos.data_ptr()
-        run.placement = {"candidates": len(candidates), "join_ms_per_candidate": [float(f"{t:.4g}") for t in trial_ms], "chosen": best}
-        del candidates
-    keep = (left_pos, right_pos, slice_offsets, arena, status)
+    run.placement = placement
+    run.use_median = (lambda: use(median)) if median else None
+    run.use_best = lambda: use(best)
+    keep = (best, median, slice_offsets, status)
     return run, r, keep
 
 
@@ -522,7 +540,7 @@ def join_kernels(kinds, n_orders, n, pairs, offset_width=2, pair_bytes=16):
     return out
 
 
-def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem_host, orders, lineitem, pool=None):
+def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem_host, orders, lineitem):
     """Config 3 of BASELINE.json alone: JoinHash(orders, lineitem) on the order key, SF10 -- o_orderkey unencoded int32 (build),
     l_orderkey FrameOfReference + u16 offsets (probe); PosList pairs written to HBM.  Also the reference's two Semi benchmarks
     (tpch_data_micro_benchmark.cpp:299-316)."""
@@ -532,12 +550,12 @@ def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem
     data = sf10_tables()
     n = data.n_lineitems
     steps = max(3, min(steps, 10))
-    run, r, keep = device_join(lib, torch, dev, orders, lineitem, n, pool=pool)   # (pool: the headline's calibrated result buffers)
+    run, r, keep = device_join(lib, torch, dev, orders, lineitem, n)   # (the library's result-buffer pool: the pair the headline's calibration left in it)
     dt, kinds = timed_kernel(lib, torch, run, steps, all_kinds=True)
     algorithmic = data.n_orders * 4 + n * 2 + int(r.n_pairs) * 16      # build keys + probe keys + 16 B/pair
     kernels = join_kernels(kinds, data.n_orders, n, int(r.n_pairs))
     info = {"workload": "configs[2]: JoinHash orders x lineitem on the order key, SF10, Inner (o_orderkey int32 values, l_orderkey FrameOfReference u16)"
-                        + ("; PosLists in the process's calibrated result-buffer pool (config.output_placement)" if pool is not None else ""),
+                        + "; PosLists from the library's result-buffer pool (calibrated once per process: config.output_placement)",
             "rows_per_s": (data.n_orders + n) / dt, "ms_per_join": dt * 1e3, "pairs": int(r.n_pairs), "radix_bits": int(r.radix_bits),
             "output_pos_lists": int(r.n_slices), "algorithmic_bytes": algorithmic,
             "roofline": dict(roofline_object("whole operator (all kernels of one hy_join_hash, host-timed)", algorithmic, dt * 1e3, committed_traffic("hy_join_hash")),
@@ -947,6 +965,54 @@ def scan_cases(lib, torch, dev, steps, days, column, step_fn, counts, rows, widt
     return out
 
 
+def device_identity(torch, local_rank):
+    """A 64-bit identity of the GPU this rank computes on: PCI domain / bus / device where the runtime tells, else the device's UUID bytes."""
+    import hashlib
+    props = torch.cuda.get_device_properties(local_rank)
+    text = "|".join(str(getattr(props, name, "")) for name in ("pci_domain_id", "pci_bus_id", "pci_device_id", "uuid", "name")) + "|" + str(torch.cuda.current_device())
+    return int.from_bytes(hashlib.sha256((os.uname().nodename + "|" + text).encode()).digest()[:7], "little")
+
+
+def count_distinct(identities):
+    return len(set(int(x) for x in identities))
+
+
+def require_distinct_gpus(rccl_ranks, world, share_gpu):
+    """`--gpus N` is a claim about hardware: N ranks on fewer than N GPUs is not an N-GPU measurement (HY_BENCH_SHARE_GPU: the debug mode that
+    says so itself -- gloo, control flow only)."""
+    if rccl_ranks < world and not share_gpu:
+        raise SystemExit(f"--gpus {world}: the {world} ranks run on {rccl_ranks} distinct GPU(s) (HY_BENCH_SHARE_GPU=1 exercises the control flow on one GPU)")
+
+
+def distinct_devices(torch, dist, local_rank, world, share_gpu):
+    """all-gather of every rank's device identity over the job's backend (RCCL unless the ranks share a GPU) -> number of distinct GPUs."""
+    mine = torch.tensor([device_identity(torch, local_rank)], dtype=torch.int64, device="cpu" if share_gpu else torch.device("cuda", local_rank))
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    return count_distinct(int(g.item()) for g in gathered)
+
+
+def cpp_operator_chain(placements):
+    """tests/cpp/operator_chain --time: TableScan -> JoinHash [-> AggregateHash] and JoinHash alone through `_on_execute()` of the C++ adapter
+    (hyrise_amd/host/hyrise_host.hpp) at SF10 size, with the intermediates as DevicePosLists in HBM and -- beside it -- with host-memory results
+    (the boundary as rounds 1-5 used it).  The binary is a separate process: its own tables (same shapes), its own calibration of the library's
+    result-buffer pool.  It is timed WITHOUT the oracle (that is --oracle, the tests' business)."""
+    import subprocess
+    binary = os.path.join(ROOT, "tests", "cpp", "operator_chain")
+    if not os.path.exists(binary):
+        return {"error": "tests/cpp/operator_chain missing: run __graft_entry__.build()"}
+    try:
+        proc = subprocess.run([binary, "--time", "7", "--calibrate", str(max(1, min(placements, 12)))], capture_output=True, text=True, timeout=600)
+    except subprocess.TimeoutExpired:
+        return {"error": "tests/cpp/operator_chain timed out"}
+    for text in reversed(proc.stdout.splitlines()):
+        if text.startswith("{"):
+            out = json.loads(text)["cpp_operator_chain_ms"]
+            out["ok"] = proc.returncode == 0 and "OPERATOR CHAIN OK" in proc.stdout
+            return out
+    return {"error": (proc.stdout + proc.stderr)[-400:]}
+
+
 def main():
     args = parse_args()
     if args.headline_only:
@@ -1051,6 +1117,23 @@ def main():
     run_join.finish()   # (the last join's pair count and fit flag: device memory until now)
     kinds = kernel_times(lib)
     abi.check(lib.hy_set_profiling(0))
+    # The same timed region with the join's PosLists in the MEDIAN candidate of the calibration -- what a pool that is not calibrated gets on
+    # average (`ms_per_step` is the calibrated placement, this is the honest second number)
+    elapsed_median = None
+    if run_join.use_median:
+        run_join.use_median()
+        for _ in range(max(2, args.warmup)):
+            step()
+        abi.check(lib.hy_set_profiling(0 if os.environ.get("HY_BENCH_NO_EVENTS") else PROFILE_EVERY))   # (the same event pairs on the stream as above)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed_median = time.perf_counter() - t0
+        run_join.finish()
+        abi.check(lib.hy_set_profiling(0))
+        run_join.use_best()
 
     n_matches = int(counts.sum().item())
     expected = int((days < tpch.DAY_1995_01_01).sum())
@@ -1060,12 +1143,19 @@ def main():
     if n_pairs != n_lineitems:
         raise SystemExit(f"rank {rank}: join produced {n_pairs} pairs, every one of the {n_lineitems} lineitems has exactly one order")
 
+    rccl_ranks = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
+        t = torch.tensor([elapsed, elapsed_median or 0.0], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if elapsed_median is not None:
+            elapsed_median = float(t[1].item())
+        # how many DISTINCT GPUs carry the ranks (all-gathered PCI bus ids): a run that claims N GPUs must have N
+        rccl_ranks = distinct_devices(torch, dist, local_rank, world, share_gpu)
+        require_distinct_gpus(rccl_ranks, world, share_gpu)
 
     ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step_median_placement = elapsed_median / args.steps * 1e3 if elapsed_median is not None else None
     step_rows = rows + n_orders + n_lineitems
     value = step_rows * world / (elapsed / args.steps)
 
@@ -1101,16 +1191,21 @@ def main():
     extra_cases = None
     if single and not args.no_cases:
         extra_cases = scan_cases(lib, torch, dev, args.steps, days, columns[0], scan_step, counts, rows, width)
-    join_pool = (join_buffers[0], join_buffers[1], join_buffers[3]) if run_join.placement else None   # (the calibrated pool serves the join leg too)
+    for pair in join_buffers[:2]:   # (back to the library's pool: the join leg and the C++ operator chain draw the calibrated pair from it)
+        if pair is not None:
+            pair.release()
     del join_buffers, orders_copies[1:], lineitem_copies[1:]
-    join_info = (join_leg(lib, torch, dev, args.steps, not args.no_cases, not args.no_cpu_baseline, orders_host, lineitem_host, orders, lineitem, pool=join_pool)
+    join_info = (join_leg(lib, torch, dev, args.steps, not args.no_cases, not args.no_cpu_baseline, orders_host, lineitem_host, orders, lineitem)
                  if single and not args.no_join else None)
-    del join_pool
     aggregate_info = aggregate_leg(lib, torch, args.steps, not args.no_cases, not args.no_cpu_baseline) if single and not args.no_aggregate else None
 
     q6_info = q6_leg(torch, dev, args.steps) if single and not args.no_cases else None
     q1_info = q1_leg(lib, torch, dev, args.steps) if single and not args.no_cases else None
 
+    cpp_chain = None
+    if single and not args.no_cases:
+        abi.check(lib.hy_result_pool_trim())   # (this process's pooled PosLists: the binary is another process on the same GPU)
+        cpp_chain = cpp_operator_chain(args.placements)
     multi = None
     if world > 1 and not args.no_multi and not args.rows:
         from hyrise_amd import distributed
@@ -1182,6 +1277,12 @@ def main():
             line["cpu_baseline"] = cpu_baseline_step(host_column, predicate, rows, orders_host, lineitem_host)
         if run_join.placement:
             line["config"]["output_placement"] = run_join.placement
+        if ms_per_step_median_placement is not None:
+            line["ms_per_step_median_placement"] = ms_per_step_median_placement
+        if rccl_ranks is not None:
+            line["rccl_ranks"] = rccl_ranks
+        if cpp_chain is not None:
+            line["cpp_operator_chain_ms"] = cpp_chain
         if first_join_no_hint_ms is not None:
             line.setdefault("join", {})["first_join_no_hint_ms"] = first_join_no_hint_ms
         # the reference's benchmark runner writes its detailed results to a file (-o) and prints a summary

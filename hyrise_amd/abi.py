@@ -29,6 +29,7 @@ FOR_BLOCK_SIZE = 2048
 SCAN_MATERIALIZE_ALL_MATCH = 1
 SCAN_CHUNK_REGIONS = 2
 POSLIST_DENSE, POSLIST_CHUNK_REGIONS = 0, 1
+POOL_KEEP_MEDIAN = 1
 CHUNK_DEFAULT_SIZE = 65535  # Chunk::DEFAULT_SIZE, storage/chunk.hpp:52
 
 
@@ -212,6 +213,13 @@ SYMBOLS = [
     ("hy_repartition_count", C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("hy_repartition_pack", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("hy_gather_row_ids", C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("hy_poslist_gather", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("hy_result_pool_acquire", C.c_int32, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    ("hy_result_pool_acquire_pair", C.c_int32, [C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("hy_result_pool_release", C.c_int32, [C.c_void_p]),
+    ("hy_result_pool_calibrate", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    ("hy_result_pool_trim", C.c_int32, []),
+    ("hy_result_pool_stats", C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
 ]
 
 

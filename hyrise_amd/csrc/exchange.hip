@@ -281,6 +281,32 @@ __global__ __launch_bounds__(256) void gather_row_ids_wide(const hy_row_id* tabl
   }
 }
 
+// positions (c, o) of a reference table -> the RowIDs its pos lists hold there: write_output_segments' dereferencing of a reference input
+// (join_output_writing.cpp:95-200: `(*input_pos_list)[row.chunk_offset]` per pair, NULL RowIDs stay NULL), two positions per thread and step.
+__global__ __launch_bounds__(256) void gather_through_pos_lists(const DevSegment* segments, uint32_t n_chunks, const hy_row_id* positions, uint64_t n, hy_row_id* out) {
+  auto lookup = [&](uint32_t chunk_id, uint32_t chunk_offset) -> hy_row_id {
+    hy_row_id r{0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (chunk_offset == 0xFFFFFFFFu || chunk_id >= n_chunks) return r;
+    const DevSegment& s = segments[chunk_id];
+    if (chunk_offset >= s.size) return r;
+    if (!s.data) return hy_row_id{s.ref_chunk_id, chunk_offset};   // EntireChunkPosList
+    return static_cast<const hy_row_id*>(s.data)[chunk_offset];
+  };
+  const bool wide = reinterpret_cast<uintptr_t>(positions) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  if (wide) {
+    const gather_u32x4* in = reinterpret_cast<const gather_u32x4*>(positions);
+    gather_u32x4* wide_out = reinterpret_cast<gather_u32x4*>(out);
+    for (uint64_t v = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; v < n / 2; v += static_cast<uint64_t>(gridDim.x) * 256) {
+      const gather_u32x4 p = __builtin_nontemporal_load(in + v);
+      const hy_row_id a = lookup(p.x, p.y), b = lookup(p.z, p.w);
+      __builtin_nontemporal_store(gather_u32x4{a.chunk_id, a.chunk_offset, b.chunk_id, b.chunk_offset}, wide_out + v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) out[n - 1] = lookup(positions[n - 1].chunk_id, positions[n - 1].chunk_offset);
+  } else {
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) out[i] = lookup(positions[i].chunk_id, positions[i].chunk_offset);
+  }
+}
+
 }  // namespace hy
 
 using namespace hy;
@@ -387,6 +413,17 @@ hy_status hy_gather_row_ids(const hy_row_id* table, uint64_t table_rows, uint32_
   const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n / (wide ? 4 : 1) + 255) / 256, 16384));
   if (wide) hipLaunchKernelGGL(gather_row_ids_wide, dim3(grid), dim3(256), 0, current_stream(), table, table_rows, chunk_rows, positions, n, out);
   else hipLaunchKernelGGL(gather_row_ids, dim3(grid), dim3(256), 0, current_stream(), table, table_rows, chunk_rows, positions, n, out);
+  HY_HIP(hipGetLastError());
+  return HY_OK;
+}
+
+hy_status hy_poslist_gather(const hy_column* reference, const hy_row_id* positions, uint64_t n, hy_row_id* out) {
+  if (!reference || (n && (!positions || !out))) return fail(HY_ERR_INVALID, "hy_poslist_gather: null argument");
+  HY_TRY(on_this_device(reference, "hy_poslist_gather"));
+  if (!reference->is_reference) return fail(HY_ERR_INVALID, "hy_poslist_gather: a column of reference segments is needed (a data table's positions ARE its RowIDs)");
+  if (!n) return HY_OK;
+  const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n / 2 + 255) / 256 + 1, 16384));
+  hipLaunchKernelGGL(gather_through_pos_lists, dim3(grid), dim3(256), 0, current_stream(), reference->d_segments, reference->n_chunks, positions, n, out);
   HY_HIP(hipGetLastError());
   return HY_OK;
 }

@@ -161,6 +161,7 @@ struct hy_column {
   mutable std::atomic<uint32_t> extent_state{0};
   mutable std::atomic<int64_t> extent_min{0}, extent_max{0};
   mutable std::atomic<uint64_t> aggregate_hint{0};   // aggregate.hip: which path the last GROUP BY led by this column ended on (signature of the column set << 8 | partition bits + 1)
+  mutable std::atomic<uint64_t> star_aggregate_hint{0};   // plan.hip: the same for the GROUP BY of a star join whose first GROUP BY column this is (its aggregate reads intermediate columns)
   // RunLength segments and bit-packed vectors stay compressed in device memory; TableScan reads them in place.  The operators that
   // gather rows (joins, aggregates, projections, exchanges, reference columns) read `plain`: the same column as Value / FixedWidthInteger
   // segments, decoded ON THE DEVICE from the resident compressed buffers the first time one of them asks (plain_column, runtime.hip).

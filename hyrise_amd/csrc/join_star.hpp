@@ -332,6 +332,7 @@ static bool star_reads_fact_key(const hy_column* column) {
   if (!column || column->is_reference || column->is_mvcc || column->has_compressed || column->data_type != HY_TYPE_INT) return false;
   for (const hy_segment& s : column->host_segments) {
     if (reinterpret_cast<uintptr_t>(s.data) % 16 != 0 || s.nulls) return false;
+    if (s.size == 0 || !s.data) return false;   // (a tile of an empty chunk would load from its null buffers)
     if (!((s.encoding == HY_ENC_UNENCODED && s.data_type == HY_TYPE_INT) || (s.encoding == HY_ENC_FRAME_OF_REFERENCE && (s.width == 1 || s.width == 2 || s.width == 4)))) return false;
   }
   return true;
@@ -347,6 +348,10 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   for (uint32_t d = 0; d < n_dimensions; ++d) {
     const StarProbeDimension& dim = dimensions[d];
     if (!star_reads_fact_key(dim.fact_key) || !dim.key || dim.key->data_type != HY_TYPE_INT || dim.key->is_mvcc) return HY_OK;
+    // the dimension's keys are read cell by cell through column_value: RunLength segments, bit-packed vectors and dictionaries whose values
+    // are not on the device are not decoded there -- such a key column keeps the join-by-join chain (hy_join_hash reads its decoded twin)
+    const hy_column* key_data = dim.key->is_reference ? dim.key->ref : dim.key;
+    if (dim.key->has_compressed || dim.key->has_dictionary_without_values || (key_data && (key_data->has_compressed || key_data->has_dictionary_without_values))) return HY_OK;
     if (dim.fact_key->n_chunks != shape->n_chunks || dim.fact_key->n_slices != shape->n_slices || dim.fact_key->rows != shape->rows) return HY_OK;
     for (uint32_t c = 0; c < shape->n_chunks; ++c) if (dim.fact_key->host_segments[c].size != shape->host_segments[c].size) return HY_OK;
     // a dimension row's RowID is packed into 32 bits

@@ -391,15 +391,19 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
   // caller's first GROUP BY column -- a data column that stays -- under the signature of the plan's columns.
   uint64_t signature = 0x51A9E5B1ull * (n_groupby + 1) + n_dimensions;
   for (uint32_t g = 0; g < n_groupby; ++g) signature = (signature ^ reinterpret_cast<uintptr_t>(groupby[g].column)) * 0xD6E8FEB86659FD93ull;
-  for (uint32_t d = 0; d < n_dimensions; ++d) signature = (signature ^ reinterpret_cast<uintptr_t>(dimensions[d].key) ^ dimensions[d].predicate.value.i64) * 0xD6E8FEB86659FD93ull;
+  for (uint32_t d = 0; d < n_dimensions; ++d) {
+    const uint64_t literal = dimensions[d].filter_column ? static_cast<uint64_t>(dimensions[d].predicate.value.i64) ^ (uint64_t{dimensions[d].predicate.condition} << 56) : 0;   // (no filter: the predicate is not read)
+    signature = (signature ^ reinterpret_cast<uintptr_t>(dimensions[d].key) ^ literal) * 0xD6E8FEB86659FD93ull;
+  }
   signature |= 0x100;
   const hy_column* hint_owner = n_groupby ? groupby[0].column : nullptr;
   if (hint_owner) {
-    const uint64_t hint = hint_owner->aggregate_hint.load(std::memory_order_relaxed);
+    const uint64_t hint = hint_owner->star_aggregate_hint.load(std::memory_order_relaxed);
     if (hint >> 8 == signature >> 8) t_aggregate_next_path = static_cast<uint32_t>(hint & 0xFF);
   }
   const hy_status status = hy_aggregate_hash(groupby_columns.data(), n_groupby, specs.data(), n_aggregates, result);
-  if (status == HY_OK && hint_owner && n_groupby <= 4) hint_owner->aggregate_hint.store((signature >> 8) << 8 | (t_aggregate_recommended & 0xFF), std::memory_order_relaxed);
+  t_aggregate_next_path = 0;   // (a call that returned before it consumed the hint must not leave it to the thread's next aggregate)
+  if (status == HY_OK && hint_owner && n_groupby <= 4) hint_owner->star_aggregate_hint.store((signature >> 8) << 8 | (t_aggregate_recommended & 0xFF), std::memory_order_relaxed);
   return status;
 }
 

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define HY_ABI_VERSION 3   /* 2: hy_segment carries sorted_by and bits; 3: hy_join_result flags / status (HY_JOIN_ASYNC), hy_set_option */
+#define HY_ABI_VERSION 4   /* 2: hy_segment carries sorted_by and bits; 3: hy_join_result flags / status (HY_JOIN_ASYNC), hy_set_option;
+                            * 4: hy_result_pool_*, hy_poslist_gather (device-resident PosLists behind _on_execute()) */
 
 typedef int32_t hy_status;
 enum {
@@ -240,6 +241,35 @@ hy_status hy_profile_read_kernel(uint32_t kernel, float* total_milliseconds, uin
  * empty kernel, median of 32 launches, measured once per process.  A profiler's per-kernel duration is shorter by about this much. */
 hy_status hy_profile_event_overhead(float* milliseconds);
 
+/* ---- result-buffer pool: device memory for PosLists that outlive the call that wrote them -----------------------------------------
+ * The reference's operators hand their results on as tables whose ReferenceSegments share PosLists (AbstractPosList,
+ * storage/pos_lists/abstract_pos_list.hpp:18-75; reference_segment.hpp:36-38; table_scan.cpp:207-210; join_output_writing.cpp:95-200): a PosList
+ * lives as long as a table references it.  An adapter that keeps operator chains in HBM (DevicePosList in hyrise_amd/host/hyrise_host.hpp,
+ * INTEGRATION.md section 3) takes the memory of such PosLists from this pool and gives it back when the PosList object dies; blocks are
+ * handed out again in stream order (the next owner's stream waits for what the last owner's stream still had queued), hipMalloc runs only when
+ * nothing fits.  Process-wide per device, thread-safe.
+ *   hy_result_pool_acquire       one buffer of at least `bytes` bytes (a scan's PosLists, a gathered PosList)
+ *   hy_result_pool_acquire_pair  the two PosLists of a join with `rows` RowIDs each: every list an allocation of its own, the first starting on
+ *                                a 2 MiB boundary, the second 1.25 MiB past one -- two streams written at the same index at the same time then
+ *                                use different memory channels; prefers the pair a calibration kept
+ *   hy_result_pool_release       either kind, one pointer at a time (NULL: nothing)
+ *   hy_result_pool_calibrate     where a join's output lists lie in HBM decides the emit kernel's speed by up to 20 %, reproducibly per allocation
+ *                                (profiles/r04_join_placement.txt, r05_placement_probe.txt): `candidates` fresh pairs for `rows` RowIDs are
+ *                                allocated, the join left x right (mode) runs a few times into each (HIP events on the calling thread's stream),
+ *                                the fastest pair stays in the pool as the one hy_result_pool_acquire_pair hands out first (with
+ *                                HY_POOL_KEEP_MEDIAN the median candidate stays too, second in line -- what an uncalibrated pool gets on
+ *                                average), the others are freed.  ms_per_candidate ([candidates], may be NULL): milliseconds per join;
+ *                                *chosen: the fastest.  Run it once, outside any timed region, when the process knows its largest join.
+ *   hy_result_pool_trim          frees every buffer of the calling thread's device that nobody holds (waits for the thread's stream) */
+#define HY_POOL_KEEP_MEDIAN 1u
+hy_status hy_result_pool_acquire(uint64_t bytes, void** ptr);
+hy_status hy_result_pool_acquire_pair(uint64_t rows, hy_row_id** left, hy_row_id** right);
+hy_status hy_result_pool_release(void* ptr);
+hy_status hy_result_pool_calibrate(const hy_column* left, const hy_column* right, uint32_t mode, uint64_t rows, uint32_t candidates, uint32_t flags,
+                                   float* ms_per_candidate, uint32_t* chosen);
+hy_status hy_result_pool_trim(void);
+hy_status hy_result_pool_stats(uint64_t* held_bytes, uint64_t* in_use_bytes, uint32_t* calibrated_pairs);
+
 /* ---- options: which of several equivalent paths / launch shapes an operator takes ---------------------------------------------
  * Process-wide integers with the defaults below.  EVERY setting produces the same results: the tests force each path with them and
  * compare it with the oracle, the tools time one path against another in one process.  The library reads no environment variable
@@ -382,6 +412,14 @@ hy_status hy_predicate_cast(uint32_t condition, uint32_t column_type, uint32_t l
  * *n_out (host): RowIDs written in total -- the one value that crosses to the host (8 bytes; the call waits for the stream). */
 enum { HY_POSLIST_DENSE = 0, HY_POSLIST_CHUNK_REGIONS = 1 };
 hy_status hy_poslist_translate(const hy_column* scanned, const hy_scan_result* result, uint32_t layout, hy_row_id* out, uint64_t capacity, uint64_t* n_out);
+
+/* The RowIDs a join hands on when an input was a reference table (write_output_segments, join_output_writing.cpp:95-200: the positions a
+ * join finds in a reference table are dereferenced through the input's PosLists, so the output references the data table), WITHOUT leaving
+ * device memory: out[i] = the RowID at position positions[i] = (chunk c, offset o) of `reference` -- a column of HY_ENC_REFERENCE segments
+ * (any column of the input table that shares the PosLists in question) -- i.e. pos_list(c)[o], (ref_chunk_id, o) for an entire-chunk
+ * PosList; a NULL position (outer joins) stays NULL_ROW_ID.  positions / out: device memory, n RowIDs each; queued on the calling thread's
+ * stream. */
+hy_status hy_poslist_gather(const hy_column* reference, const hy_row_id* positions, uint64_t n, hy_row_id* out);
 
 /* ---- Projection arithmetic (the ArithmeticExpressions a Projection evaluates through the
  * ExpressionEvaluator, operators/projection.cpp + expression/evaluation/expression_functors.hpp:127-213) -------------------

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_abi_version_and_struct_sizes():
     lib = abi.load_library()
-    assert lib.hy_abi_version() == 3
+    assert lib.hy_abi_version() == 4
     import ctypes as C
     assert C.sizeof(abi.RowID) == 8          # types.hpp:97-117
     assert C.sizeof(abi.Segment) == 64

@@ -66,3 +66,46 @@ def test_details_file_holds_the_full_object(tmp_path):
     bench.write_details(line, path)
     with open(path) as fh:
         assert json.load(fh) == line
+
+
+def test_multi_gpu_runs_count_their_distinct_gpus():
+    """`--gpus N` must be N GPUs: the ranks all-gather their device identities (`rccl_ranks` in the line) and the run refuses fewer than N
+    unless HY_BENCH_SHARE_GPU says it is the one-GPU debug mode."""
+    import pytest
+    import bench
+    assert bench.count_distinct([11, 12, 13, 14]) == 4 and bench.count_distinct([11, 11, 12, 12]) == 2
+    bench.require_distinct_gpus(8, 8, False)
+    bench.require_distinct_gpus(1, 2, True)
+    with pytest.raises(SystemExit):
+        bench.require_distinct_gpus(1, 2, False)
+    line = full_line()
+    for key in ("scan", "cases", "join", "aggregate", "q6", "q1", "cpu_baseline"):
+        line.pop(key, None)
+    line["n_gpus"], line["rccl_ranks"] = 4, 4
+    assert check(bench.compact_line(line))["rccl_ranks"] == 4
+
+
+def test_single_gpu_scale_line_has_the_bench_config():
+    """The driver's SCALE run at N = 1 is the BENCH command: the line's `config` (and metric / unit / dtype / scaling) may not depend on the
+    step counts or on anything but the workload, so the two lines describe the same configuration."""
+    import bench
+    a, b = full_line(), full_line()
+    b["steps"], b["warmup"], b["ms_per_step"], b["value"] = 7, 1, a["ms_per_step"] * 1.01, a["value"] / 1.01
+    ca, cb = bench.compact_line(a), bench.compact_line(b)
+    for key in ("metric", "unit", "dtype", "scaling", "data", "higher_is_better", "config", "n_gpus"):
+        assert ca[key] == cb[key], key
+    defaults, explicit = bench.parse_args([]), bench.parse_args(["--gpus", "1"])
+    assert vars(defaults) == vars(explicit) and defaults.gpus == 1
+
+
+def test_line_carries_median_placement_and_the_cpp_operator_chain():
+    import bench
+    line = full_line()
+    line["ms_per_step_median_placement"] = 0.4321
+    line["config"]["output_placement"] = {"candidates": 12, "join_ms_per_candidate": [0.33] * 12, "chosen": 3, "by": "hy_result_pool_calibrate"}
+    line["cpp_operator_chain_ms"] = {"scan_join_aggregate_device_resident": 2.5, "scan_join_device_resident": 1.8, "scan_join_host_result": 536.0,
+                                     "join_orders_lineitem_device_resident": 0.64, "join_orders_lineitem_host_result": 374.0, "scan_device_resident": 0.43,
+                                     "scan_host_result": 117.0, "rows": {"orders": 1}, "pool_candidates": 6, "pool_chosen": 0, "ok": True}
+    parsed = check(bench.compact_line(line))
+    assert parsed["ms_per_step_median_placement"] == 0.4321
+    assert parsed["legs"]["cpp_operator_chain_ms"]["join_orders_lineitem_device_resident"] == 0.64 and "hy_result_pool_calibrate" in parsed["config"]["workload"]

@@ -239,3 +239,42 @@ def test_star_join_shapes_the_fused_probe_leaves_to_the_joins(device):
     groups = [(k % 3).astype(np.int32) for k in keys]
     foreign = [rng.integers(5, 15 + n, n_fact).astype(np.int32) for n in sizes]
     assert run(keys, groups, foreign) == expected(keys, groups, foreign) and star_was_fused() == 1
+
+
+@pytest.mark.parametrize("key_layout", ["bit_packed_dictionary", "run_length", "bit_packed_frame_of_reference"])
+def test_star_join_with_a_compressed_dimension_key_takes_the_join_chain(device, key_layout):
+    """A dimension key held as a RunLength segment or a BitPackingVector is not decoded by the fused probe's cell reader: such a plan must
+    run join by join (hy_join_hash reads the key's decoded twin) and give numpy's groups -- not garbage keys."""
+    import numpy as np
+    from hyrise_amd import abi, storage
+    from hyrise_amd.operators import star_join_aggregate
+    from hyrise_amd.storage import DeviceColumn, HostColumn
+    rng = np.random.default_rng(11)
+    n_fact, n_a, n_b = 120_000, 2_000, 300
+    a_key = np.arange(5, 5 + n_a, dtype=np.int32)
+    a_group = rng.integers(0, 6, n_a).astype(np.int32)
+    b_key = np.arange(1, n_b + 1, dtype=np.int32)
+    fk_a = rng.integers(0, n_a + 40, n_fact).astype(np.int32)               # some foreign keys without a partner
+    fk_b = rng.integers(1, n_b + 1, n_fact).astype(np.int32)
+    x = rng.integers(0, 1000, n_fact).astype(np.int32)
+    if key_layout == "run_length":
+        host_key = HostColumn([storage.encode_run_length(a_key[i:i + 500], None) for i in range(0, n_a, 500)], abi.TYPE_INT)
+    else:
+        plain = storage.make_column(a_key, None, abi.ENC_DICTIONARY if key_layout == "bit_packed_dictionary" else abi.ENC_FRAME_OF_REFERENCE, 500)
+        host_key = HostColumn([storage.bit_pack_segment(s) for s in plain.segments], abi.TYPE_INT)
+    column = lambda values, encoding=abi.ENC_UNENCODED, chunk=20_000: DeviceColumn(storage.make_column(values, None, encoding, chunk))
+    a, a_g, b = DeviceColumn(host_key), column(a_group, abi.ENC_DICTIONARY, 500), column(b_key, chunk=100)
+    dimensions = [(a, None, None, column(fk_a, abi.ENC_FRAME_OF_REFERENCE)), (b, None, None, column(fk_b, abi.ENC_FRAME_OF_REFERENCE))]
+    groupby = [(1, a_g)]
+    result, joined = star_join_aggregate(dimensions, groupby, [(abi.AGG_SUM, (0, column(x)), None, None), (abi.AGG_COUNT, None, None, None), (abi.AGG_MIN, groupby[0], None, None)])
+    assert star_was_fused() == 0
+    ia = fk_a - 5
+    keep = (ia >= 0) & (ia < n_a)
+    assert joined == int(keep.sum())
+    want = {}
+    for g, xv in zip(a_group[ia[keep]], x[keep].astype(np.int64)):
+        cell = want.setdefault(int(g), [0, 0])
+        cell[0] += int(xv)
+        cell[1] += 1
+    got = {result.column(2)[i]: [result.column(0)[i], result.column(1)[i]] for i in range(result.n_groups)}
+    assert got == want
