@@ -2584,7 +2584,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
     if (partition_bits && rung == 0) rung = 1;   // many groups are a given on this path
     const uint64_t capacity = std::min(ladder[rung], two_per_row);
     if (capacity > (1ull << 31)) return fail(HY_ERR_UNSUPPORTED, "too many rows for the device group table");
-    DeviceBuffer tags, keys, first, last, values, counts, flags;
+    DeviceBuffer tags, keys, first, last, values, counts, flags, small_nibbles, small_slots;
     HY_TRY(tags.alloc(4 * capacity));
     HY_TRY(keys.alloc(8 * capacity * words));
     HY_TRY(first.alloc(8 * capacity));
@@ -2665,15 +2665,29 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       profile_begin(stream, HY_KERNEL_AGGREGATE);
       hipLaunchKernelGGL(fused_rows, dim3(shape->n_chunks), dim3(256), fused_lds, stream, a, fused, shape->n_chunks);
       profile_end(stream);
-    } else if (shape->n_slices && shape->rows && partition_bits == 0 && small) {   // a handful of groups over dictionary columns: one workgroup per chunk (aggregate_small.hpp)
-      profile_begin(stream, HY_KERNEL_AGGREGATE);
-      static OncePerDevice raised;
-      uint64_t device_bit = 0;
-      if (raised.pending(&device_bit)) {
-        HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_small_domain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sd_lds_bytes())));
-        raised.done(device_bit);
+    } else if (shape->n_slices && shape->rows && partition_bits == 0 && small) {   // a handful of groups over dictionary columns (aggregate_small.hpp)
+      // two launches: the GROUP BY ids and 1-byte columns per chunk, then the 2-byte column per (chunk, part of the value-id range); between
+      // them a nibble per row (its dense group) and the chunks' global-table slots
+      SmallDomainPlan plan = *small;
+      const bool has_wide = plan.n_columns > plan.n_narrow;
+      if (has_wide) {
+        HY_TRY(small_nibbles.alloc(size_t{shape->n_chunks} * SD_NIBBLE_BYTES));
+        HY_TRY(small_slots.alloc(4 * size_t{shape->n_chunks} * SD_DENSE));
+        plan.nibbles = small_nibbles.as<uint8_t>();
+        plan.chunk_slots = small_slots.as<uint32_t>();
       }
-      hipLaunchKernelGGL(aggregate_small_domain, dim3(shape->n_chunks), dim3(SD_THREADS), sd_lds_bytes(), stream, a, *small, shape->n_chunks);
+      profile_begin(stream, HY_KERNEL_AGGREGATE);
+      hipLaunchKernelGGL(sd_groups, dim3(shape->n_chunks), dim3(SD_THREADS), 0, stream, a, plan, shape->n_chunks);
+      if (has_wide && !(plan.debug & 2)) {
+        static OncePerDevice raised;
+        uint64_t device_bit = 0;
+        if (raised.pending(&device_bit)) {
+          HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sd_wide), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sd_wide_lds_bytes())));
+          raised.done(device_bit);
+        }
+        const uint32_t blocks = (shape->n_chunks + 7) / 8 * 8 * SD_WIDE_PARTS;
+        hipLaunchKernelGGL(sd_wide, dim3(blocks), dim3(SD_WIDE_THREADS), sd_wide_lds_bytes(), stream, a, plan, shape->n_chunks);
+      }
       profile_end(stream);
     } else if (shape->n_slices && shape->rows && partition_bits == 0) {
       profile_begin(stream, HY_KERNEL_AGGREGATE);
@@ -3151,6 +3165,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     SmallDomainPlan small;
     std::memset(&small, 0, sizeof(small));
     bool lean = option(HY_OPT_AGG_SMALL_DOMAIN) && shape->rows > 0 && few_codes();
+    for (uint32_t k = 0; k < shape->n_chunks && lean; ++k) lean = shape->host_segments[k].size <= SD_MAX_CHUNK_ROWS;   // (a chunk is one pass of either kernel)
     std::vector<const hy_column*> inputs;   // distinct input columns, 1-byte ids first
     for (int pass = 0; pass < 2 && lean; ++pass) {
       for (uint32_t d = 0; d < n_device && lean; ++d) {

@@ -372,12 +372,12 @@ def used_small_domain():
 
 
 def test_small_domain_kernel(device, options):
-    """aggregate_small_domain (csrc/aggregate_small.hpp): a handful of groups over dictionary GROUP BY columns, SUM / AVG / COUNT / MIN /
+    """sd_groups / sd_wide (csrc/aggregate_small.hpp): a handful of groups over dictionary GROUP BY columns, SUM / AVG / COUNT / MIN /
     MAX over dictionary-encoded int / long / float / double columns with 1- and 2-byte value ids -- the TPC-H Q1 shape and its
     neighbours.  Against the oracle: 1 - 3 GROUP BY columns, NULLs in keys and inputs, more than four groups per chunk (the shared-cell
     path), ragged chunks, one-row chunks, negative integers, and the same answers as the generic kernel (HY_OPT_AGG_SMALL_DOMAIN = 0)."""
     rng = np.random.default_rng(91)
-    for n, chunk in ((200_000, 65535), (70_001, 8192), (5, 2), (40_000, 40_000), (150_000, 100_000)):   # (the last: chunks of more than one 65520-row span)
+    for n, chunk in ((200_000, 65535), (70_001, 8192), (5, 2), (40_000, 40_000), (150_000, 100_000)):   # (the last: chunks of more than 65536 rows -- not the small-domain kernels' shape, the generic kernel answers)
         flags = rng.integers(0, 3, n).astype(np.int32)                       # 3 distinct
         status = rng.integers(0, 2, n).astype(np.int64)                      # 2 distinct
         third = (rng.integers(0, 2, n) * 7).astype(np.int32)
@@ -418,7 +418,7 @@ def test_small_domain_kernel(device, options):
             codes = max((int(np.prod([g.segments[k].aux_size + 1 for g in groupby])) for k in range(q.n_chunks)), default=1)
             inputs = {id(c): c.segments[0].width for _, c in aggregates if c is not None}
             narrow, wide = sum(1 for v in inputs.values() if v == 1), sum(1 for v in inputs.values() if v == 2)
-            assert used_small_domain() == (1 if widths <= {1, 2} and codes <= 16 and narrow <= 2 and wide <= 1 and len(groupby) <= 2 else 0), context
+            assert used_small_domain() == (1 if widths <= {1, 2} and codes <= 16 and narrow <= 2 and wide <= 1 and len(groupby) <= 2 and chunk <= 65536 else 0), context
             options.set(abi.OPT_AGG_SMALL_DOMAIN, 0)
             generic = run_both(groupby, aggregates, context + " (generic kernel)")
             options.reset(abi.OPT_AGG_SMALL_DOMAIN)
