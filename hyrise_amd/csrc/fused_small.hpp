@@ -243,7 +243,7 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
       }
       uint32_t group[FS_ROWS];    // dense index of the row, 0xF: not counted
       {
-        uint32_t assigned = *reinterpret_cast<volatile uint32_t*>(&s_dense_map[2]);
+        uint32_t assigned = __hip_atomic_load(&s_dense_map[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (not a volatile read: that waits for every outstanding load, aggregate_small.hpp)
         uint32_t wanted = 0;   // codes of this lane's rows that passed
 #pragma unroll
         for (int j = 0; j < static_cast<int>(FS_ROWS); ++j) {
@@ -263,9 +263,10 @@ __global__ __launch_bounds__(FS_THREADS) void fused_small_domain(AggArgs a, cons
               __hip_atomic_fetch_or(&s_dense_map[2], 1u << code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
-          assigned = *reinterpret_cast<volatile uint32_t*>(&s_dense_map[2]);
+          assigned = __hip_atomic_load(&s_dense_map[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        const uint64_t map = *reinterpret_cast<volatile uint64_t*>(&s_dense_map[0]);
+        const uint64_t map = static_cast<uint64_t>(__hip_atomic_load(&s_dense_map[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
+                             static_cast<uint64_t>(__hip_atomic_load(&s_dense_map[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32;
 #pragma unroll
         for (int j = 0; j < static_cast<int>(FS_ROWS); ++j) {
           const uint32_t code = (codes >> (4 * j)) & 0xFu;
