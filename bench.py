@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-multi", action="store_true", help="N > 1: skip the strong-scaling / aggregate / join legs")
     ap.add_argument("--no-ssb", action="store_true", help="skip the SSB SF30 star-join leg (config 5)")
     ap.add_argument("--switch", action="append", default=[], metavar="NAME=VALUE",
-                    help="A/B: one of the library's named switches (hyrise_amd/abi.py _SWITCHES, e.g. HY_SCAN_NO_JOB_CACHE=1) for the whole run")
+                    help="A/B: one of the library's named switches (hyrise_amd/abi.py _SWITCHES, e.g. HY_JOIN_NO_HINT=1) for the whole run")
     ap.add_argument("--placements", type=int, default=12, help="result-buffer placements the join's output pool is calibrated over before the timed region (1 = take the first)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed TableScan + JoinHash step (no legs, no CPU baselines)")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),

@@ -89,11 +89,8 @@ class JoinPredicate(C.Structure):
 
 MAX_SECONDARY_PREDICATES = 4
 # hy_set_option (include/hyrise_amd.h HY_OPT_*): equivalent paths / launch shapes; every setting gives the same results
-(OPT_ALLOW_ANY_ARCH, OPT_SCAN_WGS_PER_CU, OPT_SCAN_NT_STORES, OPT_PART_SLICES, OPT_JOIN_RANK_TABLE, OPT_JOIN_IDENTITY, OPT_JOIN_HINT, OPT_JOIN_BREAK_HINT,
- OPT_JOIN_FETCH_AHEAD, OPT_JOIN_PKFK, OPT_JOIN_LDS_BUILD, OPT_JOIN_LDS_BUILD_TILES, OPT_JOIN_ORDERED_ATOMICS, OPT_JOIN_STORES, OPT_JOIN_WGS_PER_CU,
- OPT_AGG_PARTITIONS, OPT_AGG_PARTITION_BITS, OPT_AGG_SPILL_SHIFT, OPT_AGG_LDS_BUDGET, OPT_AGG_SPLIT, OPT_AGG_SMALL_DOMAIN, OPT_AGG_JOINT_HISTOGRAM,
- OPT_FUSED_SMALL_DOMAIN, OPT_FUSED_SHARED_PREFIX, OPT_JOIN_LDS_HASH, OPT_JOIN_EMIT_TILE_GROUP, OPT_JOIN_FILL_WGS_PER_CU, OPT_JOIN_HAND_OVER_RANKS,
- OPT_SCAN_JOB_CACHE, OPT_JOIN_CLEAN_TABLES, OPT_SCAN_TWO_COLUMNS, OPT_STAR_FUSED_PROBE) = range(32)
+(OPT_ALLOW_ANY_ARCH, OPT_JOIN_RANK_TABLE, OPT_JOIN_HINT, OPT_JOIN_BREAK_HINT, OPT_JOIN_PKFK, OPT_JOIN_LDS_BUILD, OPT_JOIN_LDS_BUILD_TILES, OPT_JOIN_FILL_WGS_PER_CU,
+ OPT_JOIN_HAND_OVER_RANKS, OPT_AGG_PARTITION_BITS, OPT_AGG_SPILL_SHIFT, OPT_AGG_SMALL_DOMAIN, OPT_FUSED_SMALL_DOMAIN, OPT_SCAN_TWO_COLUMNS, OPT_STAR_FUSED_PROBE) = range(15)
 KERNEL_OTHER, KERNEL_SCAN, KERNEL_JOIN_PROBE, KERNEL_JOIN_COUNT, KERNEL_JOIN_BUILD, KERNEL_AGGREGATE, KERNEL_PROJECTION = range(7)   # hy_profile_read_kernel
 ARITH_ADD, ARITH_SUB, ARITH_MUL, ARITH_DIV, ARITH_MOD = range(5)
 
@@ -274,16 +271,12 @@ class option:
 
 # The switches the tools/ scripts name -> (option, value when the switch is "1" / its integer value otherwise).
 _SWITCHES = {
-    "HY_SCAN_NO_JOB_CACHE": (OPT_SCAN_JOB_CACHE, 0), "HY_JOIN_NO_CLEAN_TABLES": (OPT_JOIN_CLEAN_TABLES, 0), "HY_JOIN_EMIT_TILE_GROUP": (OPT_JOIN_EMIT_TILE_GROUP, None), "HY_SCAN_NO_TWO_COLUMNS": (OPT_SCAN_TWO_COLUMNS, 0), "HY_STAR_NO_FUSED_PROBE": (OPT_STAR_FUSED_PROBE, 0), "HY_SCAN_NT_STORES": (OPT_SCAN_NT_STORES, None), "HY_SCAN_WGS_PER_CU": (OPT_SCAN_WGS_PER_CU, None), "HY_PART_SLICES": (OPT_PART_SLICES, None),
-    "HY_JOIN_NO_RANK_TABLE": (OPT_JOIN_RANK_TABLE, 0), "HY_JOIN_NO_IDENTITY": (OPT_JOIN_IDENTITY, 0), "HY_JOIN_NO_HINT": (OPT_JOIN_HINT, 0),
-    "HY_JOIN_BREAK_HINT": (OPT_JOIN_BREAK_HINT, None), "HY_JOIN_NO_FETCH_AHEAD": (OPT_JOIN_FETCH_AHEAD, 0), "HY_JOIN_NO_PKFK": (OPT_JOIN_PKFK, 0),
-    "HY_JOIN_NO_LDS_BUILD": (OPT_JOIN_LDS_BUILD, 0), "HY_JOIN_LDS_BUILD_TILES": (OPT_JOIN_LDS_BUILD_TILES, None),
-    "HY_JOIN_NO_ORDERED_ATOMICS": (OPT_JOIN_ORDERED_ATOMICS, 0), "HY_JOIN_STORES": (OPT_JOIN_STORES, None), "HY_JOIN_WGS_PER_CU": (OPT_JOIN_WGS_PER_CU, None),
-    "HY_JOIN_NO_LDS_HASH": (OPT_JOIN_LDS_HASH, 0), "HY_JOIN_FILL_WGS_PER_CU": (OPT_JOIN_FILL_WGS_PER_CU, None),
-    "HY_AGG_NO_PARTITIONS": (OPT_AGG_PARTITIONS, 0), "HY_AGG_PARTITION_BITS": (OPT_AGG_PARTITION_BITS, None), "HY_AGG_SPILL_SHIFT": (OPT_AGG_SPILL_SHIFT, None),
-    "HY_AGG_LDS_BUDGET": (OPT_AGG_LDS_BUDGET, None), "HY_AGG_SPLIT": (OPT_AGG_SPLIT, None), "HY_AGG_NO_SMALL_DOMAIN": (OPT_AGG_SMALL_DOMAIN, 0),
-    "HY_AGG_NO_JOINT_HISTOGRAM": (OPT_AGG_JOINT_HISTOGRAM, 0), "HY_FUSED_NO_SMALL_DOMAIN": (OPT_FUSED_SMALL_DOMAIN, 0),
-    "HY_FUSED_NO_SHARED_PREFIX": (OPT_FUSED_SHARED_PREFIX, 0)
+    "HY_SCAN_NO_TWO_COLUMNS": (OPT_SCAN_TWO_COLUMNS, 0), "HY_STAR_NO_FUSED_PROBE": (OPT_STAR_FUSED_PROBE, 0),
+    "HY_JOIN_NO_RANK_TABLE": (OPT_JOIN_RANK_TABLE, 0), "HY_JOIN_NO_HINT": (OPT_JOIN_HINT, 0), "HY_JOIN_BREAK_HINT": (OPT_JOIN_BREAK_HINT, None),
+    "HY_JOIN_NO_PKFK": (OPT_JOIN_PKFK, 0), "HY_JOIN_NO_LDS_BUILD": (OPT_JOIN_LDS_BUILD, 0), "HY_JOIN_LDS_BUILD_TILES": (OPT_JOIN_LDS_BUILD_TILES, None),
+    "HY_JOIN_FILL_WGS_PER_CU": (OPT_JOIN_FILL_WGS_PER_CU, None), "HY_JOIN_HAND_OVER_RANKS": (OPT_JOIN_HAND_OVER_RANKS, None),
+    "HY_AGG_PARTITION_BITS": (OPT_AGG_PARTITION_BITS, None), "HY_AGG_SPILL_SHIFT": (OPT_AGG_SPILL_SHIFT, None), "HY_AGG_NO_SMALL_DOMAIN": (OPT_AGG_SMALL_DOMAIN, 0),
+    "HY_FUSED_NO_SMALL_DOMAIN": (OPT_FUSED_SMALL_DOMAIN, 0)
 }
 
 

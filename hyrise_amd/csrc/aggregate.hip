@@ -2553,7 +2553,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   // The partitioned path (tables with many groups): entered when aggregate_rows gives up; 2^bits partitions of about 64 Ki rows,
   // then -- if even those hold more groups than a workgroup's table -- the most the partitioning kernels take.
   constexpr uint32_t MAX_PARTITION_BITS = 14;
-  const bool can_partition = !fused && a.n_groupby > 0 && shape->rows < (1ull << 32) && option(HY_OPT_AGG_PARTITIONS);
+  const bool can_partition = !fused && a.n_groupby > 0 && shape->rows < (1ull << 32) && FIXED_AGG_PARTITIONS;
   uint32_t first_bits = 6;
   while (first_bits < MAX_PARTITION_BITS && (shape->rows >> first_bits) > 65536) ++first_bits;
   uint32_t partition_bits = 0;   // 0: aggregate_rows
@@ -2720,7 +2720,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
         pa.total_rows = shape->rows;
         const size_t per_slot = 8 * words + 16 + 12 * n_aggregates + 4;
         pa.lds_slots = 2048;
-        const size_t lds_budget = static_cast<size_t>(std::max<int64_t>(1024, option(HY_OPT_AGG_LDS_BUDGET)));
+        const size_t lds_budget = static_cast<size_t>(std::max<int64_t>(1024, FIXED_AGG_LDS_BUDGET));
         while (pa.lds_slots > 64 && pa.lds_slots * per_slot > lds_budget) pa.lds_slots >>= 1;
         launch_partition_rows(false, words, pa.n_parts, 4 * size_t{partitions}, stream, a, pa);
         hipLaunchKernelGGL(scan_blocks, dim3(n_blocks), dim3(256), 0, stream, pa.offsets, cells, part_sums.as<uint32_t>());
@@ -2733,7 +2733,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       // about 16 Ki rows per workgroup: coarse partitions (long contiguous runs for the scatter) are shared by several
       pa.split = 1;
       while (pa.split < 64 && (shape->rows >> partition_bits) / pa.split > 16384) pa.split <<= 1;
-      if (option(HY_OPT_AGG_SPLIT) > 0) pa.split = static_cast<uint32_t>(option(HY_OPT_AGG_SPLIT));
+      if (FIXED_AGG_SPLIT > 0) pa.split = static_cast<uint32_t>(FIXED_AGG_SPLIT);
       DirectGroups direct;
       std::memset(&direct, 0, sizeof(direct));
       direct.enabled = pa.split == 1 ? 1u : 0u;
@@ -3134,7 +3134,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       // input before it (Q1: l_extendedprice, then l_extendedprice * (1 - l_discount), then that * (1 + l_tax)) continues on its stack.
       uint32_t skipped = 0;
       if (d > 0 && plan.inputs[d - 1].n_nodes > 0 && plan.inputs[d - 1].n_nodes < input.n_nodes &&
-          std::memcmp(plan.inputs[d - 1].nodes, input.nodes, sizeof(FusedNode) * plan.inputs[d - 1].n_nodes) == 0 && option(HY_OPT_FUSED_SHARED_PREFIX)) {
+          std::memcmp(plan.inputs[d - 1].nodes, input.nodes, sizeof(FusedNode) * plan.inputs[d - 1].n_nodes) == 0 && FIXED_FUSED_SHARED_PREFIX) {
         skipped = plan.inputs[d - 1].n_nodes;
       }
       for (uint32_t n = skipped; n < input.n_nodes && lean; ++n) {
@@ -3183,7 +3183,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     if (lean) {
       if (const char* debug = HY_DEBUG_ENV("HY_AGG_SMALL_DEBUG")) small.debug = static_cast<uint32_t>(atoi(debug));   // timing experiments only
       small.n_columns = static_cast<uint32_t>(inputs.size());
-      small.joint = small.n_narrow == 2 && option(HY_OPT_AGG_JOINT_HISTOGRAM) ? 1u : 0u;
+      small.joint = small.n_narrow == 2 && FIXED_AGG_JOINT_HISTOGRAM ? 1u : 0u;
       for (uint32_t k = 0; k < shape->n_chunks && small.joint; ++k) {
         if ((uint64_t{inputs[0]->host_segments[k].aux_size} + 1) * (uint64_t{inputs[1]->host_segments[k].aux_size} + 1) > SD_JOINT_CELLS) small.joint = 0;
       }

@@ -104,11 +104,7 @@ struct hy_join_key_hint {
   std::atomic<uint32_t> state{0};
   std::atomic<uint32_t> unique{0};          // no key twice (a column with duplicates still serves Semi / Anti joins: presence bits only)
   std::atomic<uint64_t> key_min{0}, key_max{0};
-  // The radix-partitioned path (join_hp.hpp): hp_state 1 = a join found the column's keys unique in [hp_min, hp_max] without their being
-  // sorted (later joins skip the look at the keys); hp_refused: its table met a key twice -- the column keeps the general kernels.
-  std::atomic<uint32_t> hp_state{0}, hp_refused{0};
   std::atomic<uint32_t> has_duplicates{0};  // rank_table_mark met a key twice: later joins over the column go straight to the sorted directory
-  std::atomic<uint64_t> hp_min{0}, hp_max{0};
   std::atomic<uint32_t> probe_locality{0};  // as a PROBE side: 0 not looked at, 1 neighbouring rows hold neighbouring keys, 2 they do not (probe_key_locality, join.hip)
 };
 

@@ -3225,7 +3225,6 @@ __global__ __launch_bounds__(256) void plan_output(const uint64_t* base_elements
 }
 
 #include "join_pkfk.hpp"
-#include "join_hp.hpp"
 
 __global__ void publish_join_status(hy_join_status* status, uint64_t n_pairs, uint32_t n_slices, uint32_t fits) {
   status->n_pairs = n_pairs;
@@ -3259,11 +3258,6 @@ struct BuildSide {
   const BuildVerdict* verdict = nullptr;   // (device memory, behind the table's arrival counters: rank_table_fill_checked)
   const uint64_t* fill_records = nullptr;  // ... or one record per workgroup of rank_table_fill_waves: [n_fill_records][4] smallest key | largest key (both ^ sign) | flags
   uint32_t n_fill_records = 0;
-  // The radix-partitioned path (join_hp.hpp) should run instead of anything prepared here: unique int32 keys in [hp_min, hp_max] (or, existence
-  // only, keys with repeats), a build column that is not sorted or a probe side without locality; nothing of the build side has been launched.
-  bool hp_wanted = false;
-  bool hp_extent_from_column = false;   // the extent was remembered by the column (no host round trip happened)
-  uint64_t hp_min = 0, hp_max = 0;
   uint64_t n = 0;
   Directory directory{};
   RankTable rank{};            // rank.entries != nullptr: unique integer keys, looked up in the rank table (directory.dir is not built)
@@ -3277,10 +3271,8 @@ struct BuildSide {
 // which only the presence bits mean anything.
 // `bit_filter_ok`: whoever probes reads the Bloom filter as 2^20 bits (the kernels of join_pkfk.hpp) -- what the one-pass hinted build
 // produces; everything else reads one byte per bit.
-// `hp_radix_bits` < 0xFFFFFFFF: the caller could run the radix-partitioned path with that many radix bits (join_hp.hpp; both columns fit it);
-// `probe_scattered`: the probe keys have no locality (a rank table read in place would be read at random).
 static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool want_bloom, bool want_ids32, uint32_t hashed_type, bool allow_rank_table, bool existence_only,
-                               bool bit_filter_ok, uint32_t hp_radix_bits, bool probe_scattered, BuildSide& b, hipStream_t stream) {
+                               bool bit_filter_ok, BuildSide& b, hipStream_t stream) {
   const uint32_t n_slices = build->n_slices;
   DeviceBuffer counts, offsets;
   HY_TRY(counts.alloc(4 * size_t{n_slices + 1}));
@@ -3298,30 +3290,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     uniform_chunks = first_size > 0 && (c + 1 == build->n_chunks ? size <= first_size : size == first_size);
   }
   const bool identity_candidate = dense && build->rows && uniform_chunks && build->host_segments[0].size > 0 && allow_rank_table && option(HY_OPT_JOIN_RANK_TABLE) &&
-                                  option(HY_OPT_JOIN_IDENTITY);
-  // Would the partition tables of the radix-partitioned path fit LDS for keys in [key_min, key_max]?
-  auto hp_fits = [&](uint64_t key_min, uint64_t key_max) {
-    if (hp_radix_bits == 0xFFFFFFFFu || !identity_candidate || build->join_hint.hp_refused.load(std::memory_order_relaxed)) return false;
-    if (static_cast<int64_t>(key_min) < INT32_MIN || static_cast<int64_t>(key_max) > INT32_MAX) return false;
-    const uint64_t origin = key_min & ~((uint64_t{1} << hp_radix_bits) - 1), slots = ((key_max - origin) >> hp_radix_bits) + 1;
-    return (slots + 31) / 32 <= HP_MAX_TABLE_WORDS;
-  };
-  // a column that an earlier join found sorted and unique (its key hint), probed at random: the partitioned path, with no look at the keys
-  if (probe_scattered && build->join_hint.state.load(std::memory_order_acquire) == 1 && (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) &&
-      option(HY_OPT_JOIN_HINT) && hp_fits(build->join_hint.key_min.load(std::memory_order_relaxed), build->join_hint.key_max.load(std::memory_order_relaxed))) {
-    b.hp_wanted = b.hp_extent_from_column = true;
-    b.hp_min = build->join_hint.key_min.load(std::memory_order_relaxed);
-    b.hp_max = build->join_hint.key_max.load(std::memory_order_relaxed);
-    return HY_OK;
-  }
-  // ... or one that an earlier partitioned join found unique without being sorted
-  if (build->join_hint.hp_state.load(std::memory_order_acquire) == 1 && option(HY_OPT_JOIN_HINT) &&
-      hp_fits(build->join_hint.hp_min.load(std::memory_order_relaxed), build->join_hint.hp_max.load(std::memory_order_relaxed))) {
-    b.hp_wanted = b.hp_extent_from_column = true;
-    b.hp_min = build->join_hint.hp_min.load(std::memory_order_relaxed);
-    b.hp_max = build->join_hint.hp_max.load(std::memory_order_relaxed);
-    return HY_OK;
-  }
+                                  FIXED_JOIN_IDENTITY;
   bool hinted = identity_candidate && bit_filter_ok && build->join_hint.state.load(std::memory_order_acquire) == 1 &&
                 (existence_only || build->join_hint.unique.load(std::memory_order_relaxed)) && option(HY_OPT_JOIN_HINT);
   for (uint32_t c = 0; c < build->n_chunks && hinted; ++c) {   // rank_table_fill_checked reads int32 keys through SliceViews, 16 bytes per load
@@ -3392,7 +3361,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
       FillCleaning cleaning{nullptr, nullptr, 0, 0};
       ZeroedBlocks* cleaned = nullptr;
       bool zeroed = false;
-      if (wave_fill && option(HY_OPT_JOIN_CLEAN_TABLES) && table_vectors + bloom_vectors < (1ull << 31)) {
+      if (wave_fill && FIXED_JOIN_CLEAN_TABLES && table_vectors + bloom_vectors < (1ull << 31)) {
         if ((t_zeroed[0].table && t_zeroed[0].stream != stream) || (t_zeroed[1].table && t_zeroed[1].stream != stream)) {   // another stream: start over
           HY_HIP(hipDeviceSynchronize());
           free_zeroed_blocks();
@@ -3501,16 +3470,6 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
     HY_HIP(hipStreamSynchronize(stream));
     const uint64_t key_min = mailbox->key_min, range = mailbox->key_max - mailbox->key_min;
     const uint64_t words = (range >> 5) + 1;
-    // The radix-partitioned path instead: the keys are not sorted (a rank table read in place would be filled with one random atomic per
-    // key), or they are and the probe side has no locality -- if the keys could be unique (sorted keys: no equal neighbours; keys that are
-    // not sorted: hp_table finds out) and the table is one a rank table would be.  (A small key range is always one: 64 Ki entries.)
-    if ((mailbox->unsorted_signed || probe_scattered) && (mailbox->unsorted_signed || !mailbox->equal_neighbours || existence_only) && range < 0xFFFFFF00ull &&
-        (words <= 2 * total + 4096 || words <= 65536) && hp_fits(mailbox->key_min, mailbox->key_max)) {
-      b.hp_wanted = true;
-      b.hp_min = mailbox->key_min;
-      b.hp_max = mailbox->key_max;
-      return HY_OK;
-    }
     if (HY_DEBUG_ENV("HY_JOIN_TIMING")) fprintf(stderr, "  dense stats: min %lld max %lld unsorted %u signed %u equal %u total %llu\n", (long long)mailbox->key_min, (long long)mailbox->key_max, mailbox->unsorted, mailbox->unsorted_signed, mailbox->equal_neighbours, (unsigned long long)total);
     if (!mailbox->unsorted_signed && (!mailbox->equal_neighbours || existence_only) && range < 0xFFFFFF00ull && (words <= 2 * total + 4096 || words <= 65536)) {
       HY_TRY(b.rank_entries.alloc(8 * (words + 1)));
@@ -3669,7 +3628,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
             const uint32_t size = build->host_segments[c].size, first_size = build->host_segments[0].size;
             uniform = c + 1 == build->n_chunks ? size <= first_size : size == first_size;
           }
-          if (uniform && option(HY_OPT_JOIN_IDENTITY)) {
+          if (uniform && FIXED_JOIN_IDENTITY) {
             b.rank.identity_rows = build->host_segments[0].size;
             b.rank.identity_inverse = 1.0 / static_cast<double>(b.rank.identity_rows);
           }
@@ -3785,7 +3744,7 @@ static hy_status prepare_build(const hy_column* build, bool keep_nulls, bool wan
 // (a multiple of the 8 XCDs), never more than there are tiles.
 static uint32_t stream_grid(uint32_t n_tiles, int workgroups_per_cu) {
   uint32_t per_cu = workgroups_per_cu > 0 ? static_cast<uint32_t>(workgroups_per_cu) : 1;
-  if (option(HY_OPT_JOIN_WGS_PER_CU) > 0) per_cu = static_cast<uint32_t>(option(HY_OPT_JOIN_WGS_PER_CU));
+  if (FIXED_JOIN_WGS_PER_CU > 0) per_cu = static_cast<uint32_t>(FIXED_JOIN_WGS_PER_CU);
   const uint32_t resident = device_cu_count() * per_cu / 8 * 8;
   const uint32_t needed = 8 * (((n_tiles + 7) / 8 + STREAM_WAVES - 1) / STREAM_WAVES);   // a wave per tile of every XCD's share
   return std::max<uint32_t>(8, std::min<uint32_t>(resident, needed));
@@ -3831,7 +3790,7 @@ static bool lds_atomics_are_lane_ordered(hipStream_t stream) {
   int state = g_lds_atomic_order.load(std::memory_order_acquire);
   if (state == 0) {
     state = 2;
-    if (option(HY_OPT_JOIN_ORDERED_ATOMICS)) {
+    if (FIXED_JOIN_ORDERED_ATOMICS) {
       uint32_t* failures = nullptr;
       if (hipMalloc(reinterpret_cast<void**>(&failures), 4) == hipSuccess) {
         uint32_t host = 1;
@@ -3879,18 +3838,6 @@ hy_status sort_pairs_u32(uint32_t** keys, uint32_t** ids, uint32_t* keys_tmp, ui
   *keys = src_keys;
   *ids = src_ids;
   return HY_OK;
-}
-
-// Can the radix-partitioned path (join_hp.hpp) read this column?  int32 values / FrameOfReference segments without NULLs (what a SliceView
-// describes), RowIDs that pack into 32 bits.
-static bool hp_reads(const hy_column* column) {
-  if (column->is_reference || column->n_slices == 0 || column->n_chunks > 65536 || column->rows >= (1ull << 29)) return false;
-  for (uint32_t c = 0; c < column->n_chunks; ++c) {
-    const hy_segment& seg = column->host_segments[c];
-    const bool plain = (seg.encoding == HY_ENC_UNENCODED && seg.data_type == HY_TYPE_INT) || (seg.encoding == HY_ENC_FRAME_OF_REFERENCE && (seg.width == 1 || seg.width == 2 || seg.width == 4));
-    if (!plain || seg.nulls || seg.size > 65536) return false;
-  }
-  return true;
 }
 
 // Do the probe keys lack locality as far as the host can tell?  FrameOfReference blocks of 1- or 2-byte offsets span at most 65 536 key
@@ -3943,200 +3890,6 @@ static hy_status probe_keys_lack_locality(const hy_column* probe, hipStream_t st
     probe->join_hint.probe_locality.store(known, std::memory_order_relaxed);
   }
   *scattered = known == 2;
-  return HY_OK;
-}
-
-static thread_local int t_last_join_used_hp = 0;   // debug / tests: the thread's last join ran the kernels of join_hp.hpp
-
-// The radix-partitioned join (join_hp.hpp) over keys in [key_min, key_max].  *refused: the build side has a key twice -- nothing was
-// written, the column is marked and the caller runs the join again on the general kernels.
-static hy_status run_join_hp(const hy_column* build, const hy_column* probe, uint32_t mode, uint32_t radix_bits, uint64_t key_min, uint64_t key_max, bool remember_extent,
-                             bool existence_only, bool semi_anti, bool keep_nulls_probe, bool probe_filtered, hy_join_result* result, bool count_only, uint64_t* count_out,
-                             bool* refused, hipStream_t stream) {
-  const uint32_t partitions = 1u << radix_bits;
-  const bool host_result = !result || result->mem == HY_MEM_HOST;
-  auto side = [&](const hy_column* column, HpSide& s, DeviceBuffer& counts, DeviceBuffer& bases, DeviceBuffer& tuples) -> hy_status {
-    s.views = column->d_slice_views;
-    s.n_tiles = column->n_slices;
-    s.stride = (column->n_slices + 1 + 3) & ~3u;
-    s.radix_bits = radix_bits;
-    const size_t cells = size_t{partitions} * s.stride;
-    HY_TRY(counts.alloc(4 * cells));
-    HY_TRY(bases.alloc(8 * (cells + 1)));
-    HY_TRY(tuples.alloc(8 * std::max<uint64_t>(column->rows, 1)));
-    HY_HIP(hipMemsetAsync(counts.ptr, 0, 4 * cells, stream));   // (the cells behind a row's tiles stay zero)
-    s.counts = counts.as<uint32_t>();
-    s.bases = bases.as<uint64_t>();
-    s.tuples = tuples.as<u32x2_t>();
-    hipLaunchKernelGGL(hp_hist, dim3(s.n_tiles), dim3(HP_THREADS), 0, stream, s);
-    HY_TRY(exclusive_scan(s.counts, bases.as<uint64_t>(), cells, stream));
-    hipLaunchKernelGGL(hp_scatter, dim3(s.n_tiles), dim3(HP_THREADS), 4 * hp_scatter_lds_words(partitions), stream, s);
-    return HY_OK;
-  };
-  static OncePerDevice lds_raised;
-  uint64_t device_bit = 0;
-  if (lds_raised.pending(&device_bit)) {
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hp_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * hp_scatter_lds_words(MAX_PARTITIONS)));
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hp_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * HP_MAX_TABLE_WORDS));
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hp_mark), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (HP_MAX_TABLE_WORDS + HP_BLOOM_LDS_WORDS)));
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hp_ranks), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HP_MAX_TABLE_WORDS));
-    lds_raised.done(device_bit);
-  }
-  HpSide build_side{}, probe_side{};
-  DeviceBuffer build_counts, build_bases, build_tuples, probe_counts, probe_bases, probe_tuples;
-  HY_TRY(side(build, build_side, build_counts, build_bases, build_tuples));
-  HY_TRY(side(probe, probe_side, probe_counts, probe_bases, probe_tuples));
-  // layout | table
-  const uint64_t origin = key_min & ~((uint64_t{1} << radix_bits) - 1);   // (two's complement: rounds towards minus infinity)
-  const uint32_t words = static_cast<uint32_t>(((((key_max - origin) >> radix_bits) + 1) + 31) / 32);
-  // groups of the output: the partitions, or -- no radix partitioning -- the probe chunks (join_hash_steps.hpp:655-760: a PosList per chunk)
-  const uint32_t n_groups = radix_bits ? partitions : probe->n_chunks;
-  const uint32_t max_steps = static_cast<uint32_t>(probe->rows / HP_STEP) + n_groups + 1;
-  DeviceBuffer small, entries, ids, bloom, results, steps, step_info, partial_bits, partial_bloom;
-  const uint32_t mark_groups = 2 * device_cu_count(), mark_grid = (mark_groups + partitions + 7) / 8 * 8;   // hp_mark / hp_ids: workgroups hp_layout hands out | the most it can
-  const size_t group_words = 4 * (size_t{n_groups} + 1);
-  const size_t at_probe_off = 4 * (size_t{partitions} + 1), at_first_step = at_probe_off + group_words, at_slice_base = at_first_step + group_words, at_group_elements = at_slice_base + group_words,
-               at_mark_first = at_group_elements + group_words, at_plan = align_up(at_mark_first + 4 * (size_t{partitions} + 1), 16), at_flags = at_plan + 16;
-  HY_TRY(small.alloc(at_flags + 16));
-  HY_HIP(hipMemsetAsync(small.as<char>() + at_flags, 0, 16, stream));
-  HY_TRY(entries.alloc(8 * size_t{partitions} * words));
-  HY_TRY(step_info.alloc(32 * size_t{max_steps}));
-  HY_TRY(partial_bits.alloc(4 * size_t{mark_grid} * words));
-  HY_TRY(ids.alloc(4 * std::max<uint64_t>(build->rows, 1)));
-  HY_TRY(results.alloc(4 * std::max<uint64_t>(probe->rows, 1)));
-  HY_TRY(steps.alloc(4 * 3 * size_t{max_steps}));
-  HpLayout layout{};
-  layout.build_off = small.as<uint32_t>();
-  layout.probe_off = reinterpret_cast<uint32_t*>(small.as<char>() + at_probe_off);
-  layout.first_step = reinterpret_cast<uint32_t*>(small.as<char>() + at_first_step);
-  layout.n_groups = n_groups;
-  layout.steps = step_info.as<u32x4_t>();
-  layout.mark_first = reinterpret_cast<uint32_t*>(small.as<char>() + at_mark_first);
-  layout.mark_groups = mark_groups;
-  hipLaunchKernelGGL(hp_layout, dim3(1), dim3(HP_PROBE_THREADS), 0, stream, build_side, probe_side, probe->d_row_base, layout);
-  HpTable table{};
-  table.entries = entries.as<u32x2_t>();
-  table.words = words;
-  table.origin = static_cast<uint32_t>(origin);
-  table.range = static_cast<uint32_t>(key_max - origin);
-  table.radix_bits = radix_bits;
-  table.existence_only = existence_only ? 1u : 0u;
-  table.ids = existence_only ? nullptr : ids.as<uint32_t>();
-  table.flags = reinterpret_cast<uint32_t*>(small.as<char>() + at_flags);
-  table.partial_bits = partial_bits.as<uint32_t>();
-  const uint32_t bloom_words = hp_bloom_words(radix_bits);
-  const bool bloom_in_lds = probe_filtered && bloom_words <= HP_BLOOM_LDS_WORDS;
-  if (probe_filtered) {
-    HY_TRY(bloom.alloc(4 * size_t{partitions} * bloom_words));
-    if (!bloom_in_lds) HY_HIP(hipMemsetAsync(bloom.ptr, 0, 4 * size_t{partitions} * bloom_words, stream));   // (else hp_ranks writes every word)
-    table.bloom_bits = bloom.as<uint32_t>();
-    if (bloom_in_lds) {
-      HY_TRY(partial_bloom.alloc(4 * size_t{mark_grid} * bloom_words));
-      table.partial_bloom = partial_bloom.as<uint32_t>();
-    }
-  }
-  hipLaunchKernelGGL(hp_mark, dim3(mark_grid), dim3(HP_PROBE_THREADS), 4 * (size_t{words} + (bloom_in_lds ? bloom_words : 0)), stream, build_side, layout, table);
-  hipLaunchKernelGGL(hp_ranks, dim3(partitions), dim3(HP_PROBE_THREADS), 4 * size_t{words}, stream, layout, table);
-  if (table.ids) hipLaunchKernelGGL(hp_ids, dim3(mark_grid), dim3(HP_PROBE_THREADS), 0, stream, build_side, layout, table);
-  JoinMailbox* mailbox = nullptr;
-  JoinMailbox* mailbox_dev = nullptr;
-  HY_TRY(join_mailbox(&mailbox, &mailbox_dev));
-  hy_row_id* user_build = nullptr;
-  hy_row_id* user_probe = nullptr;
-  if (!count_only) {
-    user_build = result->left_is_build ? result->left_pos : result->right_pos;
-    user_probe = result->left_is_build ? result->right_pos : result->left_pos;
-    if (!user_probe && result->capacity) return fail(HY_ERR_INVALID, "join result: PosList buffer for the probe side missing");
-    if (!semi_anti && !user_build && result->capacity) return fail(HY_ERR_INVALID, "join result: PosList buffer for the build side missing");
-    if (!result->slice_offsets) return fail(HY_ERR_INVALID, "join result: slice_offsets missing");
-  }
-  const uint32_t max_slices = static_cast<uint32_t>(probe->rows / PROBE_SIZE_PER_CHUNK) + n_groups + 1;
-  DeviceBuffer d_build_out, d_probe_out, d_slice_offsets;
-  uint64_t* dev_slice_offsets = count_only ? nullptr : result->slice_offsets;
-  if (!count_only && host_result) {
-    HY_TRY(d_slice_offsets.alloc(8 * (size_t{max_slices} + 2)));
-    dev_slice_offsets = d_slice_offsets.as<uint64_t>();
-  }
-  const bool async = !count_only && !host_result && (result->flags & HY_JOIN_ASYNC) && result->status && remember_extent;   // (an extent the column remembered: no host read has happened)
-  HpProbe a{};
-  a.tuples = probe_side.tuples;
-  a.layout = layout;
-  a.table = table;
-  a.mode = mode;
-  a.keep_nulls = keep_nulls_probe ? 1u : 0u;
-  a.shares = std::max<uint32_t>(8, std::min<uint32_t>(device_cu_count(), max_steps) / 8 * 8);   // hp_probe's workgroups: one per CU (a partition's table fills its LDS), a multiple of 8
-  a.bloom_bits = probe_filtered ? bloom.as<uint32_t>() : nullptr;
-  a.results = results.as<uint32_t>();
-  a.step_counts = steps.as<uint32_t>();
-  a.pair_base = a.step_counts + max_steps;
-  a.element_base = a.pair_base + max_steps;
-  a.slice_base = reinterpret_cast<uint32_t*>(small.as<char>() + at_slice_base);
-  a.group_elements = reinterpret_cast<uint32_t*>(small.as<char>() + at_group_elements);
-  a.plan = reinterpret_cast<JoinPlan*>(small.as<char>() + at_plan);
-  a.mailbox = mailbox_dev;
-  a.status = async ? result->status : nullptr;
-  a.capacity = count_only ? ~0ull : result->capacity;
-  a.slice_capacity = count_only ? 0xFFFFFFFFu : result->slice_capacity;
-  a.slice_offsets = dev_slice_offsets;
-  a.max_steps = max_steps;
-  hipEvent_t count_started = nullptr, count_stopped = nullptr;
-  profile_events(&count_started, &count_stopped, HY_KERNEL_JOIN_COUNT);
-  hipExtLaunchKernelGGL(hp_probe, dim3(a.shares), dim3(HP_PROBE_THREADS), 8 * size_t{words}, stream, count_started, count_stopped, 0, a);
-  hipLaunchKernelGGL(hp_plan, dim3(1), dim3(HP_PROBE_THREADS), 0, stream, a);
-  t_last_join_used_hp = 1;
-  auto settle = [&]() -> bool {   // (after a stream synchronise) the build side: a key twice?  else remember what was learnt about the column
-    if (mailbox->duplicate) {
-      build->join_hint.hp_refused.store(1, std::memory_order_release);
-      *refused = true;
-      return false;
-    }
-    if (!remember_extent && !existence_only && build->join_hint.hp_state.load(std::memory_order_acquire) == 0) {
-      build->join_hint.hp_min.store(key_min, std::memory_order_relaxed);
-      build->join_hint.hp_max.store(key_max, std::memory_order_relaxed);
-      build->join_hint.hp_state.store(1, std::memory_order_release);
-    }
-    return true;
-  };
-  if (count_only) {
-    HY_HIP(hipStreamSynchronize(stream));
-    if (!settle()) return HY_OK;
-    if (count_out) *count_out = mailbox->n_pairs;
-    return HY_OK;
-  }
-  hy_row_id* dev_build = user_build;
-  hy_row_id* dev_probe = user_probe;
-  if (host_result) {   // the staging buffers are sized by the pair count: ask now
-    HY_HIP(hipStreamSynchronize(stream));
-    if (!settle()) return HY_OK;
-    if (mailbox->fits) {
-      if (!semi_anti) { HY_TRY(d_build_out.alloc(8 * std::max<uint64_t>(mailbox->n_pairs, 1))); dev_build = d_build_out.as<hy_row_id>(); }
-      HY_TRY(d_probe_out.alloc(8 * std::max<uint64_t>(mailbox->n_pairs, 1)));
-      dev_probe = d_probe_out.as<hy_row_id>();
-    }
-  }
-  a.build_out = semi_anti ? nullptr : dev_build;
-  a.probe_out = dev_probe;
-  hipEvent_t started = nullptr, stopped = nullptr;
-  profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
-  hipExtLaunchKernelGGL(hp_emit, dim3(std::max<uint32_t>(8, std::min<uint32_t>(2 * device_cu_count(), max_steps) / 8 * 8)), dim3(HP_PROBE_THREADS), 0, stream, started, stopped, 0, a);
-  HY_HIP(hipGetLastError());
-  if (host_result) {
-    if (mailbox->fits && mailbox->n_pairs) {
-      HY_HIP(hipMemcpyAsync(user_probe, dev_probe, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
-      if (!semi_anti) HY_HIP(hipMemcpyAsync(user_build, dev_build, 8 * mailbox->n_pairs, hipMemcpyDeviceToHost, stream));
-    }
-    if (mailbox->fits) HY_HIP(hipMemcpyAsync(result->slice_offsets, dev_slice_offsets, 8 * (size_t{mailbox->n_slices} + 1), hipMemcpyDeviceToHost, stream));
-  }
-  if (async) {
-    t_join_returned_async = true;
-    return HY_OK;
-  }
-  HY_HIP(hipStreamSynchronize(stream));
-  if (!host_result && !settle()) return HY_OK;
-  result->n_slices = mailbox->n_slices;
-  result->n_pairs = mailbox->n_pairs;
-  if (mailbox->n_slices > result->slice_capacity) return fail(HY_ERR_CAPACITY, "join produces %u output PosLists, slice capacity is %u", mailbox->n_slices, result->slice_capacity);
-  if (mailbox->n_pairs > result->capacity) return fail(HY_ERR_CAPACITY, "join produces %llu pairs, capacity is %llu", static_cast<unsigned long long>(mailbox->n_pairs), static_cast<unsigned long long>(result->capacity));
   return HY_OK;
 }
 
@@ -4193,7 +3946,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   // Will the probe side take the kernels of join_pkfk.hpp if the build side turns out to be a rank table?  (Everything that does not
   // depend on the build side: probe segments that SliceViews describe -- int32 values / FrameOfReference offsets, no NULLs, 16-byte
   // aligned --, counts and pair indices in 32 bits, lane-ordered LDS atomics.)
-  bool probe_views = !probe->is_reference && probe->n_slices > 0 && option(HY_OPT_JOIN_FETCH_AHEAD);
+  bool probe_views = !probe->is_reference && probe->n_slices > 0 && FIXED_JOIN_FETCH_AHEAD;
   for (uint32_t c = 0; c < probe->n_chunks && probe_views; ++c) {
     const hy_segment& seg = probe->host_segments[c];
     probe_views = !seg.nulls && reinterpret_cast<uintptr_t>(seg.data) % 16 == 0 &&
@@ -4201,26 +3954,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
   }
   const bool probe_takes_pk = probe_views && hashed_type == 0 && n_secondary == 0 && probe->rows < 0xFFFF0000ull && option(HY_OPT_JOIN_PKFK) &&
                               (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
-  // The radix-partitioned path (join_hp.hpp) is possible for int32 columns without NULLs and without secondary predicates; prepare_build
-  // decides whether it is wanted (a build column that is not sorted, a probe side without locality).
-  const bool hp_possible = option(HY_OPT_JOIN_LDS_HASH) && hashed_type == 0 && n_secondary == 0 && hp_reads(build) && hp_reads(probe) &&
-                           (count_only || result->capacity <= 0xFFFFFFFFull) && lds_atomics_are_lane_ordered(stream);
-  t_last_join_used_hp = 0;
-  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, semi_anti && n_secondary == 0, probe_takes_pk,
-                       hp_possible ? radix_bits : 0xFFFFFFFFu, hp_possible && probe_keys_scattered(probe), b, stream));
-  if (b.hp_wanted) {
-    if (result) {
-      result->radix_bits = radix_bits;
-      result->left_is_build = build_right ? 0 : 1;
-      result->n_slices = 0;
-      result->n_pairs = 0;
-    }
-    t_last_join_used_rank_table = 0;
-    t_last_join_used_pkfk = 0;
-    t_last_join_hinted_attempt = 0;
-    return run_join_hp(build, probe, mode, radix_bits, b.hp_min, b.hp_max, b.hp_extent_from_column, semi_anti && n_secondary == 0, semi_anti, keep_nulls_probe, probe_filtered, result,
-                       count_only, count_out, retry, stream);
-  }
+  HY_TRY(prepare_build(build, keep_nulls_build, probe_filtered, pack_build_ids, hashed_type, n_secondary == 0, semi_anti && n_secondary == 0, probe_takes_pk, b, stream));
   const bool rank_path = b.rank.entries != nullptr;
   // A rank table filled from the build column's key hint (rank_table_fill_checked) is confirmed when the join's kernels have finished:
   // if the column is not what the hint said, the hint is dropped, whatever the join wrote is discarded and the caller runs it again.
@@ -4306,7 +4040,6 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     k.mailbox = mailbox_dev;
     k.capacity = count_only ? ~0ull : result->capacity;
     k.slice_capacity = count_only ? 0xFFFFFFFFu : result->slice_capacity;
-    k.plain_stores = static_cast<uint32_t>(option(HY_OPT_JOIN_STORES));   // pk_copy_out: 2 = write-back stores for the lines a run shares with its neighbours, nontemporal ones in between
     if (HY_DEBUG_ENV("HY_JOIN_TRACE")) {
       static uint64_t* trace_buffer = nullptr;
       if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 6 * JOIN_TRACE_TILES);
@@ -4393,7 +4126,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
     profile_events(&started, &stopped, HY_KERNEL_JOIN_PROBE);
     const uint32_t cut_grid = std::min<uint32_t>(max_slices, result->slice_capacity);
     {
-      const int64_t group = option(HY_OPT_JOIN_EMIT_TILE_GROUP);
+      const int64_t group = FIXED_JOIN_EMIT_TILE_GROUP;
       k.emit_group_shift = 32;
       if (group > 0) { k.emit_group_shift = 0; while (k.emit_group_shift < 16 && (int64_t{1} << (k.emit_group_shift + 1)) <= group) ++k.emit_group_shift; }
     }
@@ -4595,7 +4328,7 @@ static hy_status run_join_once(const hy_column* left, const hy_column* right, ui
       HY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(probe_emit_cached), JOIN_THREADS, 4 * probe_emit_cached_lds_words(partitions)));
       workgroups_per_cu = per_cu > 0 ? static_cast<uint32_t>(per_cu) : 1;
     }
-    if (option(HY_OPT_JOIN_WGS_PER_CU) > 0) workgroups_per_cu = static_cast<uint32_t>(option(HY_OPT_JOIN_WGS_PER_CU));
+    if (FIXED_JOIN_WGS_PER_CU > 0) workgroups_per_cu = static_cast<uint32_t>(FIXED_JOIN_WGS_PER_CU);
     // persistent workgroups: as many as fit the device at once (a multiple of the 8 XCDs), never more than tiles
     const uint32_t resident = device_cu_count() * workgroups_per_cu / 8 * 8;
     const uint32_t cached_grid = std::max<uint32_t>(8, std::min<uint32_t>(resident, probe_grid(n_tiles)));
@@ -4684,7 +4417,6 @@ hy_status hy_join_hash_finish(const hy_column* left, const hy_column* right, uin
     const bool build_right = mode == HY_JOIN_LEFT || mode == HY_JOIN_ANTI_NULL_AS_TRUE || mode == HY_JOIN_ANTI_NULL_AS_FALSE || mode == HY_JOIN_SEMI ||
                              (mode == HY_JOIN_INNER && left->rows > right->rows);   // (side selection of run_join_once)
     (build_right ? right : left)->join_hint.state.store(2, std::memory_order_release);
-    (build_right ? right : left)->join_hint.hp_refused.store(1, std::memory_order_release);   // (whichever path ran: neither is taken again)
     const uint32_t flags = result->flags;
     result->flags = flags & ~HY_JOIN_ASYNC;   // (radix_bits: the first attempt left the value it used)
     const hy_status status = run_join(left, right, mode, result, false, nullptr);
@@ -4744,9 +4476,6 @@ hy_status hy_join_hash_radix_bits(uint64_t build_rows, uint64_t probe_rows, uint
 int hy_debug_join_lane_ordered_atomics() { return g_lds_atomic_order.load(); }
 
 int hy_debug_join_used_rank_table(void) { return t_last_join_used_rank_table; }
-
-// debug / tests only: 1 = the last join of this thread ran the radix-partitioned kernels (join_hp.hpp)
-int hy_debug_join_used_hp(void) { return t_last_join_used_hp; }
 
 // debug / tests only: see t_last_join_hinted
 int hy_debug_join_build_was_hinted(void) { return t_last_join_hinted; }

@@ -67,7 +67,6 @@ struct PkArgs {
   JoinMailbox* mailbox;
   uint64_t capacity;
   uint32_t slice_capacity;
-  uint32_t plain_stores;           // pk_copy_out's STORES
   hy_row_id* build_out;            // nullptr: Semi / Anti
   hy_row_id* probe_out;
   uint64_t* slice_offsets;
@@ -845,12 +844,9 @@ __device__ __forceinline__ void pk_emit_tile(const PkArgs& a, uint32_t tile, con
   // no `s_waitcnt vmcnt(0)` per iteration, which would also wait for every store in flight)
   const uint32_t reserved = s_scratch[8];
   const uint32_t chunk = view.chunk, row_begin = view.row_begin;
-#define HY_PK_COPY(BUILD)                                                                                                              \
-  do {                                                                                                                                 \
-    if (a.plain_stores == 1) pk_copy_out<BUILD, 1>(a, s_stage, s_out_base, s_edge, partitions, reserved, chunk, row_begin, tid);    \
-    else if (a.plain_stores == 2) pk_copy_out<BUILD, 2>(a, s_stage, s_out_base, s_edge, partitions, reserved, chunk, row_begin, tid); \
-    else pk_copy_out<BUILD, 0>(a, s_stage, s_out_base, s_edge, partitions, reserved, chunk, row_begin, tid);                         \
-  } while (0)
+  // (STORES = 2: the flavour the A/Bs of rounds 3-5 kept -- all nontemporal 356 us, all write-back 294 us but 25 us more in the kernels behind it,
+  //  mixed 302 us, profiles/r04_join_variants.txt)
+#define HY_PK_COPY(BUILD) pk_copy_out<BUILD, static_cast<int>(FIXED_JOIN_STORES)>(a, s_stage, s_out_base, s_edge, partitions, reserved, chunk, row_begin, tid)
   if (!a.build_out) HY_PK_COPY(BUILD_NONE);
   else if (a.rank.identity_rows == 65535u) HY_PK_COPY(BUILD_IDENTITY_65535);
   else if (a.rank.identity_rows) HY_PK_COPY(BUILD_IDENTITY);

@@ -20,28 +20,16 @@ struct OptionDefaults {
   OptionDefaults() {
     for (auto& v : g_options) v.store(0, std::memory_order_relaxed);
     auto set = [](uint32_t id, int64_t v) { g_options[id].store(v, std::memory_order_relaxed); };
-    set(HY_OPT_SCAN_WGS_PER_CU, 8);
     set(HY_OPT_JOIN_RANK_TABLE, 1);
-    set(HY_OPT_JOIN_IDENTITY, 1);
     set(HY_OPT_JOIN_HINT, 1);
-    set(HY_OPT_JOIN_FETCH_AHEAD, 1);
     set(HY_OPT_JOIN_PKFK, 1);
     set(HY_OPT_JOIN_LDS_BUILD, 1);
     set(HY_OPT_JOIN_LDS_BUILD_TILES, 2048);
-    set(HY_OPT_JOIN_ORDERED_ATOMICS, 1);
-    set(HY_OPT_JOIN_STORES, 2);
-    set(HY_OPT_AGG_PARTITIONS, 1);
-    set(HY_OPT_AGG_SPILL_SHIFT, 3);
-    set(HY_OPT_AGG_LDS_BUDGET, 32768);
-    set(HY_OPT_AGG_SMALL_DOMAIN, 1);
-    set(HY_OPT_AGG_JOINT_HISTOGRAM, 1);
-    set(HY_OPT_FUSED_SMALL_DOMAIN, 1);
-    set(HY_OPT_FUSED_SHARED_PREFIX, 1);
     set(HY_OPT_JOIN_FILL_WGS_PER_CU, 4);
-    set(HY_OPT_JOIN_EMIT_TILE_GROUP, 64);
     set(HY_OPT_JOIN_HAND_OVER_RANKS, 1 << 20);
-    set(HY_OPT_SCAN_JOB_CACHE, 1);
-    set(HY_OPT_JOIN_CLEAN_TABLES, 1);
+    set(HY_OPT_AGG_SPILL_SHIFT, 3);
+    set(HY_OPT_AGG_SMALL_DOMAIN, 1);
+    set(HY_OPT_FUSED_SMALL_DOMAIN, 1);
     set(HY_OPT_SCAN_TWO_COLUMNS, 1);
     set(HY_OPT_STAR_FUSED_PROBE, 1);
   }
@@ -884,7 +872,7 @@ hy_status hy_column_create(const hy_segment* segments, uint32_t n_chunks, uint32
   std::vector<Slice> slices;
   std::vector<Part> parts;
   uint32_t part_slices = PART_SLICES;   // slices per part: one Hyrise chunk (65 535 rows) = one part = one workgroup
-  if (option(HY_OPT_PART_SLICES) > 0) part_slices = static_cast<uint32_t>(option(HY_OPT_PART_SLICES));
+  if (FIXED_PART_SLICES > 0) part_slices = static_cast<uint32_t>(FIXED_PART_SLICES);
   if (part_slices < 1) part_slices = 1;
   if (part_slices > PART_SLICES) part_slices = PART_SLICES;
   for (uint32_t c = 0; c < n_chunks; ++c) {

@@ -1761,7 +1761,7 @@ static uint32_t scan_grid(ScanKernel kernel, uint32_t n_parts) {
   (void)hipGetDevice(&device);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
   int want = 8;
-  if (option(HY_OPT_SCAN_WGS_PER_CU) > 0) want = static_cast<int>(option(HY_OPT_SCAN_WGS_PER_CU));
+  if (FIXED_SCAN_WGS_PER_CU > 0) want = static_cast<int>(FIXED_SCAN_WGS_PER_CU);
   int per_cu = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WG_THREADS, SCAN_LDS_BYTES);
   // The over-report only happens where SGPRs are the limiter (API 7-8 blocks per CU); a VGPR- or LDS-limited answer
@@ -1963,7 +1963,7 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
       HY_TRY(stage(predicate->match_words, 8 * (total_words ? total_words : 1), &d)); pa.match_words = static_cast<const uint64_t*>(d);
     }
     // a literal predicate over a data column whose jobs this column remembers (hy_scan_job_cache): no launch
-    const bool cacheable = option(HY_OPT_SCAN_JOB_CACHE) && !visibility && !n_excluded && n_data_chunks && !pa.per_chunk_lower && !pa.per_chunk_upper && !pa.per_chunk_found &&
+    const bool cacheable = FIXED_SCAN_JOB_CACHE && !visibility && !n_excluded && n_data_chunks && !pa.per_chunk_lower && !pa.per_chunk_upper && !pa.per_chunk_found &&
                            !pa.match_words && !pa.match_word_offsets;
     ScanJob* cached = nullptr;
     if (cacheable) HY_TRY(cached_scan_jobs(data_column, pa, stream, &cached));
@@ -2022,7 +2022,7 @@ static hy_status run_scan(const hy_column* column, const hy_column* right, const
     a.trace = nullptr;
     // Write-back stores: on this part a 37 : 63 read : write stream runs 13 % faster through the L2 than around it (nontemporal) --
     // tools/hbm_mix.hip shows it for the bare traffic pattern, tools/scan_ab.py for this kernel (profiles/r03_scan_stores.txt).
-    a.plain_stores = option(HY_OPT_SCAN_NT_STORES) ? 0u : 1u;
+    a.plain_stores = FIXED_SCAN_NT_STORES ? 0u : 1u;
     if (HY_DEBUG_ENV("HY_SCAN_TRACE")) {
       static uint64_t* trace_buffer = nullptr;
       if (!trace_buffer) (void)hipMalloc(reinterpret_cast<void**>(&trace_buffer), 8 * 4 * 4096);

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define HY_ABI_VERSION 4   /* 2: hy_segment carries sorted_by and bits; 3: hy_join_result flags / status (HY_JOIN_ASYNC), hy_set_option;
-                            * 4: hy_result_pool_*, hy_poslist_gather (device-resident PosLists behind _on_execute()) */
+                            * 4: hy_result_pool_*, hy_poslist_gather (device-resident PosLists behind _on_execute()), 15 options (were 33) */
 
 typedef int32_t hy_status;
 enum {
@@ -277,47 +277,27 @@ hy_status hy_result_pool_stats(uint64_t* held_bytes, uint64_t* in_use_bytes, uin
  * contain them). */
 enum {
   HY_OPT_ALLOW_ANY_ARCH = 0,         /* 0    hy_init accepts a device that is not gfx950 (nothing is tuned for it)                    */
-  HY_OPT_SCAN_WGS_PER_CU = 1,        /* 8    resident scan workgroups per CU (upper bound)                                            */
-  HY_OPT_SCAN_NT_STORES = 2,         /* 0    scan_slices writes its RowIDs with nontemporal instead of write-back stores              */
-  HY_OPT_PART_SLICES = 3,            /* 0    slices per scan part, 0 = one part per chunk                                             */
-  HY_OPT_JOIN_RANK_TABLE = 4,        /* 1    unique dense-ish integer build keys get a rank table                                     */
-  HY_OPT_JOIN_IDENTITY = 5,          /* 1    ... read in place when the build column is sorted (rank = row number)                    */
-  HY_OPT_JOIN_HINT = 6,              /* 1    later joins over a resident build column fill the table in one checked pass              */
-  HY_OPT_JOIN_BREAK_HINT = 7,        /* 0    tests: hand the checked fill a hint that does not hold (the join must notice and rerun)   */
-  HY_OPT_JOIN_FETCH_AHEAD = 8,       /* 1    probe segments read through SliceViews (wide loads)                                      */
-  HY_OPT_JOIN_PKFK = 9,              /* 1    the primary-key / foreign-key probe kernels (join_pkfk.hpp)                              */
-  HY_OPT_JOIN_LDS_BUILD = 10,        /* 1    rank tables below 2^20 key values are staged in LDS ...                                  */
-  HY_OPT_JOIN_LDS_BUILD_TILES = 11,  /* 2048 ... from this many probe tiles on                                                        */
-  HY_OPT_JOIN_ORDERED_ATOMICS = 12,  /* 1    rank pairs with one returning LDS atomic each where the LDS serves lanes in order         */
-  HY_OPT_JOIN_STORES = 13,           /* 2    pk_emit's stores: 0 nontemporal, 1 write-back, 2 write-back for the lines runs share      */
-  HY_OPT_JOIN_WGS_PER_CU = 14,       /* 0    probe workgroups per CU of the persistent probe kernels, 0 = what the occupancy query says */
-  HY_OPT_AGG_PARTITIONS = 15,        /* 1    many groups take the hash-partitioned path                                               */
-  HY_OPT_AGG_PARTITION_BITS = 16,    /* 0    partition bits of that path, 0 = derived from the row count; > 0 also forces the path     */
-  HY_OPT_AGG_SPILL_SHIFT = 17,       /* 3    aggregate_rows gives up when rows >> shift left its LDS tables                           */
-  HY_OPT_AGG_LDS_BUDGET = 18,        /* 32768 bytes of LDS a partition table may take                                                 */
-  HY_OPT_AGG_SPLIT = 19,             /* 0    workgroups per partition, 0 = derived                                                    */
-  HY_OPT_AGG_SMALL_DOMAIN = 20,      /* 1    aggregate_small_domain for the shapes it accepts                                         */
-  HY_OPT_AGG_JOINT_HISTOGRAM = 21,   /* 1    ... with two 1-byte measure columns counted in one pair histogram                        */
-  HY_OPT_FUSED_SMALL_DOMAIN = 22,    /* 1    fused_small_domain for the shapes it accepts                                             */
-  HY_OPT_FUSED_SHARED_PREFIX = 23,   /* 1    fused inputs that begin with an earlier input continue on its stack                      */
-  HY_OPT_JOIN_LDS_HASH = 24,         /* 0    1: unique int32 build keys that are not sorted, or probed without locality, take the radix-partitioned
-                                      *      path (csrc/join_hp.hpp: tuples partition by partition, per-partition tables probed in LDS).  Off: at SF10 it
-                                      *      runs 1.9 - 2.05 ms where the rank table read in place runs 1.65 - 1.92 ms          */
-  HY_OPT_JOIN_EMIT_TILE_GROUP = 25,  /* 64   pk_emit: consecutive tiles per XCD, a power of two (the device works on ONE front of 8 x this many tiles
-                                      *      that moves through the probe side); 0 = every XCD works through its own eighth of the tiles        */
-  HY_OPT_JOIN_FILL_WGS_PER_CU = 26,  /* 4    the checked one-pass fill wave by wave (rank_table_fill_waves: this many resident workgroups per
+  HY_OPT_JOIN_RANK_TABLE = 1,        /* 1    unique dense-ish integer build keys get a rank table (else: the sorted directory)          */
+  HY_OPT_JOIN_HINT = 2,              /* 1    later joins over a resident build column fill the table in one checked pass              */
+  HY_OPT_JOIN_BREAK_HINT = 3,        /* 0    tests: hand the checked fill a hint that does not hold (the join must notice and rerun)   */
+  HY_OPT_JOIN_PKFK = 4,              /* 1    the primary-key / foreign-key probe kernels (join_pkfk.hpp)                              */
+  HY_OPT_JOIN_LDS_BUILD = 5,         /* 1    rank tables below 2^20 key values are staged in LDS ...                                  */
+  HY_OPT_JOIN_LDS_BUILD_TILES = 6,   /* 2048 ... from this many probe tiles on                                                        */
+  HY_OPT_JOIN_FILL_WGS_PER_CU = 7,   /* 4    the checked one-pass fill wave by wave (rank_table_fill_waves: this many resident workgroups per
                                       *      CU, <= 8); 0 = one short-lived workgroup per slice (rank_table_fill_checked)              */
-  HY_OPT_JOIN_HAND_OVER_RANKS = 27,  /* 2^20 Inner PK-FK joins whose probe keys have no locality, whose probe side has at least this many rows and whose
+  HY_OPT_JOIN_HAND_OVER_RANKS = 8,   /* 2^20 Inner PK-FK joins whose probe keys have no locality, whose probe side has at least this many rows and whose
                                       *      rank table has a megabyte or more: pass 1 leaves the partners' ranks behind (4 bytes a probe row), pass 2
                                       *      reads them back instead of looking every key up again; 0 = never, 1 = whenever the keys lack locality */
-  HY_OPT_SCAN_JOB_CACHE = 28,        /* 1    a data column remembers the per-chunk jobs (dictionary bound searches, early-outs) of the last four literal
-                                      *      predicates it was scanned with; 0 = every scan prepares its jobs (one more launch)                     */
-  HY_OPT_JOIN_CLEAN_TABLES = 29,     /* 1    the rank table and filter of a hinted build come from two per-thread blocks that are handed out ZEROED: a join's
-                                      *      fill kernel clears the block the join before it used, instead of a launch that zeroes its own; 0 = zero_vectors */
-  HY_OPT_SCAN_TWO_COLUMNS = 30,      /* 1    ColumnVsColumn over two data columns of W-byte vectors: the two-stream kernel with the chunks' dictionaries in LDS */
-  HY_OPT_STAR_FUSED_PROBE = 31,      /* 1    hy_star_join_aggregate probes every dimension in ONE pass over the fact table (csrc/join_star.hpp) where the
+  HY_OPT_AGG_PARTITION_BITS = 9,     /* 0    partition bits of the many-groups path, 0 = derived from the row count; > 0 also forces the path */
+  HY_OPT_AGG_SPILL_SHIFT = 10,       /* 3    aggregate_rows gives up when rows >> shift left its LDS tables                           */
+  HY_OPT_AGG_SMALL_DOMAIN = 11,      /* 1    sd_groups / sd_wide (aggregate_small.hpp) for the shapes they accept                     */
+  HY_OPT_FUSED_SMALL_DOMAIN = 12,    /* 1    fused_small_domain for the shapes it accepts                                             */
+  HY_OPT_SCAN_TWO_COLUMNS = 13,      /* 1    ColumnVsColumn over two data columns of W-byte vectors: the two-stream kernel with the chunks' dictionaries in LDS */
+  HY_OPT_STAR_FUSED_PROBE = 14,      /* 1    hy_star_join_aggregate probes every dimension in ONE pass over the fact table (csrc/join_star.hpp) where the
                                       *      shape allows; 0 = one hy_join_hash per dimension                                                      */
-  HY_OPT_COUNT = 32
+  HY_OPT_COUNT = 15
+  /* (rounds 4-5 had 33: launch shapes and store flavours whose A/B timings were flat twice are constants now -- csrc/hy_options.hpp --,
+   *  the radix-partitioned join path, which lost to the rank table read in place by 1.7 x, is gone) */
 };
 hy_status hy_set_option(uint32_t option, int64_t value);
 hy_status hy_get_option(uint32_t option, int64_t* value);

@@ -833,112 +833,6 @@ def test_primary_key_hint(device, options):
             assert_join_equal(got, want, abi.JOIN_INNER, f"filter aliases, radix {radix_bits}, attempt {attempt}")
 
 
-def used_hp():
-    lib = abi.load_library()
-    lib.hy_debug_join_used_hp.restype = C.c_int
-    return int(lib.hy_debug_join_used_hp())
-
-
-HP_MODES = [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_ANTI_NULL_AS_FALSE]
-
-
-@pytest.mark.parametrize("mode", HP_MODES)
-def test_radix_partitioned_join(device, mode, options):
-    """The radix-partitioned path (csrc/join_hp.hpp: both sides as tuples partition by partition, per-partition tables built and probed in
-    LDS): a unique int32 build side that is NOT sorted, or a sorted one probed at random -- pairs and 131 070-element cuts equal to the
-    oracle's bytes in every join mode and radix setting, with probe keys outside the build range, keys that share a build key's Bloom-filter
-    bit, ragged chunks, FrameOfReference and value segments on both sides, negative keys, partitions without rows -- and equal to what the
-    kernels it is an alternative to produce (HY_OPT_JOIN_LDS_HASH = 0, the default: DESIGN.md section 4.2 has the timings)."""
-    options.set(abi.OPT_JOIN_LDS_HASH, 1)
-    rng = np.random.default_rng(900 + mode)
-    n_build = 90_000
-    sparse = (((np.arange(1, n_build + 1, dtype=np.int64) >> 3) << 5) | (np.arange(1, n_build + 1) & 7)).astype(np.int32)   # dbgen's order keys: a quarter of the partitions
-    cases = [("shuffled sparse build", rng.permutation(sparse), "sorted"), ("shuffled dense negative build", rng.permutation(np.arange(n_build, dtype=np.int32) * 2 - 70_001), "random"),
-             ("sorted build, random probe", np.arange(n_build, dtype=np.int32) * 3 + 5, "random"), ("few keys", rng.permutation(np.arange(300, dtype=np.int32) * 7), "random")]
-    outer_is_probe = mode in (abi.JOIN_LEFT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_TRUE, abi.JOIN_ANTI_NULL_AS_FALSE)   # (these modes build over the RIGHT input whatever its size)
-    for name, keys, probe_order in cases:
-        low, high = int(keys.min()), int(keys.max())
-        n_probe = 400_000 if len(keys) > 1000 else 30_000
-        probe_keys = np.concatenate([rng.choice(keys, n_probe * 3 // 4), rng.integers(low - 500, high + 500, n_probe // 4).astype(np.int32),
-                                     (rng.choice(keys, 2000).astype(np.int64) + (1 << 20)).astype(np.int32)])   # misses, keys outside the range, Bloom-filter aliases
-        probe_keys = np.sort(probe_keys) if probe_order == "sorted" else rng.permutation(probe_keys)
-        for build_encoding, probe_encoding, chunk in ((abi.ENC_UNENCODED, abi.ENC_FRAME_OF_REFERENCE, 65535), (abi.ENC_FRAME_OF_REFERENCE, abi.ENC_UNENCODED, 8195)):
-            build_host = build_column(keys.astype(np.int32), None, chunk if len(keys) > chunk else 65535, build_encoding)
-            probe_host = build_column(probe_keys.astype(np.int32), None, chunk, probe_encoding)
-            left, right = (probe_host, build_host) if outer_is_probe or mode == abi.JOIN_INNER else (build_host, probe_host)   # (Right: builds over the left input)
-            for radix_bits in (None, 0, 3, 8):
-                context = f"{name}, {build_encoding}/{probe_encoding}, chunk {chunk}, mode {mode}, radix {radix_bits}"
-                got = check(left, right, mode, radix_bits, context)
-                assert used_hp() == 1, context
-                if radix_bits in (None, 3) and chunk == 65535:
-                    options.set(abi.OPT_JOIN_LDS_HASH, 0)
-                    general = check(left, right, mode, radix_bits, context + " general kernels")
-                    options.set(abi.OPT_JOIN_LDS_HASH, 1)
-                    assert used_hp() == 0
-                    n = got.n_pairs
-                    assert general.n_pairs == n and general.left[:n].tobytes() == got.left[:n].tobytes() and general.right[:n].tobytes() == got.right[:n].tobytes()
-
-
-def test_radix_partitioned_join_falls_back_and_remembers(device, options):
-    """A build side with a key twice is noticed by the partition that meets it (nothing written), the column is marked and the general
-    kernels answer -- now and for every later join; a unique one is remembered too: its second join does not look at the keys first (and may
-    run HY_JOIN_ASYNC).  Count-only calls, device-memory results and capacity errors go through the same kernels."""
-    options.set(abi.OPT_JOIN_LDS_HASH, 1)
-    lib = abi.load_library()
-    rng = np.random.default_rng(77)
-    keys = rng.permutation(np.arange(200_000, dtype=np.int32) * 2 + 11)
-    twice = keys.copy()
-    twice[150_000] = twice[3]
-    probe_host = build_column(rng.integers(0, 400_100, 600_000).astype(np.int32), None, 65535, abi.ENC_UNENCODED)
-    probe = DeviceColumn(probe_host)
-    build_host = build_column(twice, None, 65535, abi.ENC_UNENCODED)
-    build = DeviceColumn(build_host)
-    want = oracle_join(build_host, probe_host, abi.JOIN_INNER)
-    for attempt in range(2):
-        got = join_hash(build, probe, abi.JOIN_INNER)
-        assert used_hp() == 0, attempt            # (the first attempt ran them, refused, and the general kernels answered)
-        assert_join_equal(got, want, abi.JOIN_INNER, f"a key twice, attempt {attempt}")
-    semi = join_hash(probe, build, abi.JOIN_SEMI)                                      # existence only: repeats are fine
-    assert_join_equal(semi, oracle_join(probe_host, build_host, abi.JOIN_SEMI), abi.JOIN_SEMI, "semi join over a build side with repeats")
-    unique_host = build_column(keys, None, 65535, abi.ENC_UNENCODED)
-    unique = DeviceColumn(unique_host)
-    want = oracle_join(unique_host, probe_host, abi.JOIN_INNER)
-    for attempt in range(3):
-        got = join_hash(unique, probe, abi.JOIN_INNER)
-        assert used_hp() == 1
-        assert_join_equal(got, want, abi.JOIN_INNER, f"unique build side, attempt {attempt}")
-    assert join_hash_count(unique, probe, abi.JOIN_INNER) == want.n_pairs and used_hp() == 1
-    n, slices = want.n_pairs, int(want.c.n_slices)
-    p_left, like_pairs = _device_buffer(lib, (n + 8, 2), np.uint32, 0xABABABAB)
-    p_right, _ = _device_buffer(lib, (n + 8, 2), np.uint32, 0xABABABAB)
-    p_offsets, like_offsets = _device_buffer(lib, (slices + 8,), np.uint64, 0xCDCDCDCDCDCDCDCD)
-    p_status, like_status = _device_buffer(lib, (4,), np.uint64, 0xEEEEEEEEEEEEEEEE)
-    for flags, capacity in ((0, n), (abi.JOIN_ASYNC, n), (0, n - 1), (abi.JOIN_ASYNC, n - 1)):
-        untouched = np.full(like_pairs.shape, 0xABABABAB, dtype=like_pairs.dtype)
-        for p in (p_left, p_right):
-            abi.check(lib.hy_memcpy_h2d(p, untouched.ctypes.data, untouched.nbytes))
-        r = abi.JoinResult()
-        r.mem, r.radix_bits, r.flags, r.status = abi.MEM_DEVICE, 0xFFFFFFFF, flags, p_status
-        r.left_pos, r.right_pos, r.capacity = p_left, p_right, capacity
-        r.slice_offsets, r.slice_capacity = p_offsets, slices
-        status = lib.hy_join_hash(unique.handle, probe.handle, abi.JOIN_INNER, C.byref(r))
-        if flags:
-            assert status == abi.OK
-            status = lib.hy_join_hash_finish(unique.handle, probe.handle, abi.JOIN_INNER, C.byref(r))
-        assert used_hp() == 1
-        got_left, got_right = _read_back(lib, p_left, like_pairs), _read_back(lib, p_right, like_pairs)
-        if capacity < n:
-            assert status == abi.ERR_CAPACITY and int(r.n_pairs) == n
-            assert (got_left == 0xABABABAB).all() and (got_right == 0xABABABAB).all()
-        else:
-            assert status == abi.OK and int(r.n_pairs) == n and int(r.n_slices) == slices
-            assert got_left[:n].tobytes() == want.left[:n].tobytes() and got_right[:n].tobytes() == want.right[:n].tobytes()
-            assert (got_left[n:] == 0xABABABAB).all()
-            assert _read_back(lib, p_offsets, like_offsets)[:slices + 1].tobytes() == want.slice_offsets[:slices + 1].tobytes()
-    for p in (p_left, p_right, p_offsets, p_status):
-        lib.hy_device_free(p)
-
-
 @pytest.mark.parametrize("workgroups_per_cu", [0, 1, 4])
 def test_hinted_fill_kernels(device, options, workgroups_per_cu):
     """The one-pass checked fill of a hinted build side, as short-lived workgroups (one per slice, HY_OPT_JOIN_FILL_WGS_PER_CU = 0) and as

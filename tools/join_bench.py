@@ -23,9 +23,8 @@ def main():
     orders = DeviceColumn(storage.make_column(data.o_orderkey, None, abi.ENC_UNENCODED))
     lineitem = DeviceColumn(storage.make_column(data.l_orderkey, None, abi.ENC_FRAME_OF_REFERENCE))
     n = data.n_lineitems
-    variants = [("default (edge lines write-back)", {}), ("nontemporal stores", {"HY_JOIN_STORES": "0"}), ("write-back stores", {"HY_JOIN_STORES": "1"}),
-                ("no key hint (two-pass build)", {"HY_JOIN_NO_HINT": "1"}), ("fill: one workgroup per slice", {"HY_JOIN_FILL_WGS_PER_CU": "0"}), ("fill: waves, 1 workgroup per CU", {"HY_JOIN_FILL_WGS_PER_CU": "1"}), ("fill: waves, 2 per CU", {"HY_JOIN_FILL_WGS_PER_CU": "2"}), ("fill: waves, 4 per CU", {"HY_JOIN_FILL_WGS_PER_CU": "4"}), ("fill: waves, 8 per CU", {"HY_JOIN_FILL_WGS_PER_CU": "8"}), ("fill: one workgroup per slice", {"HY_JOIN_FILL_WGS_PER_CU": "0"}),
-                ("debug: checked fill without the filter", {"HY_JOIN_FILL_DEBUG": "1"}), ("debug: checked fill, loads and extent only", {"HY_JOIN_FILL_DEBUG": "2"}),
+    variants = [("default", {}), ("no key hint (two-pass build)", {"HY_JOIN_NO_HINT": "1"}), ("fill: one workgroup per slice", {"HY_JOIN_FILL_WGS_PER_CU": "0"}),
+                ("fill: waves, 2 per CU", {"HY_JOIN_FILL_WGS_PER_CU": "2"}), ("fill: waves, 8 per CU", {"HY_JOIN_FILL_WGS_PER_CU": "8"}),
                 ("general rank-table kernels (round 2)", {"HY_JOIN_NO_PKFK": "1", "HY_JOIN_NO_HINT": "1"}), ("default again", {})]
     for name, env in variants:
         switches = abi.switches(env)

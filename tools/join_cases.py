@@ -25,12 +25,8 @@ def main():
     from hyrise_amd.storage import DeviceColumn
     lib = abi.load_library()
     abi.check(lib.hy_init(0))
-    if "--no-partitioned" in sys.argv:
-        abi.check(lib.hy_set_option(abi.OPT_JOIN_LDS_HASH, 0))
     if "--no-hand-over" in sys.argv:   # pass 2 looks every probe key up again
         abi.check(lib.hy_set_option(abi.OPT_JOIN_HAND_OVER_RANKS, 0))
-    if "--partitioned" in sys.argv:   # the radix-partitioned path for unique int32 keys (join_hp.hpp; off by default)
-        abi.check(lib.hy_set_option(abi.OPT_JOIN_LDS_HASH, 1))
     dev = torch.device("cuda", 0)
     data = tpch.TpchData(10.0, 42, keys_only=True)
     n = data.n_lineitems
@@ -48,7 +44,7 @@ def main():
             run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        print(f"{name:22s} {dt * 1e3:7.3f} ms/join  pairs {int(r.n_pairs)}  rank table {lib.hy_debug_join_used_rank_table()}  pkfk {lib.hy_debug_join_used_pkfk()}  partitioned {lib.hy_debug_join_used_hp()}", flush=True)
+        print(f"{name:22s} {dt * 1e3:7.3f} ms/join  pairs {int(r.n_pairs)}  rank table {lib.hy_debug_join_used_rank_table()}  pkfk {lib.hy_debug_join_used_pkfk()}", flush=True)
         if os.environ.get("HY_JOIN_TRACE"):   # (a -DHY_DEBUG_SWITCHES build: per-tile phase stamps of pk_emit, wall clock at 100 MHz)
             lib.hy_debug_join_trace.restype = C.c_int
             stamps = np.zeros((1 << 15, 6), dtype=np.uint64)
