@@ -209,7 +209,7 @@ def committed_traffic(kernel):
 
 def pmc_file():
     """The newest committed PMC summary of this script (profiles/rNN_bench_pmc.json, tools/collect_profiles.sh)."""
-    for round_ in (5, 4, 3):
+    for round_ in (6, 5, 4, 3):
         path = os.path.join(ROOT, "profiles", f"r{round_:02d}_bench_pmc.json")
         if os.path.exists(path):
             return path
@@ -648,9 +648,10 @@ def join_leg(lib, torch, dev, steps, with_cases, with_cpu, orders_host, lineitem
 
 
 def aggregate_kernel_name(lib):
-    """Which kernel answered the thread's last hy_aggregate_hash (the library's debug accessor): the Q1 shape takes aggregate_small_domain."""
+    """Which kernels answered the thread's last hy_aggregate_hash (the library's debug accessor): the Q1 shape takes the two launches of
+    csrc/aggregate_small.hpp (their HIP-event bracket spans both)."""
     lib.hy_debug_aggregate_small_domain.restype = C.c_int
-    return "aggregate_small_domain" if lib.hy_debug_aggregate_small_domain() else "aggregate_rows"
+    return "sd_groups + sd_wide" if lib.hy_debug_aggregate_small_domain() else "aggregate_rows"
 
 
 def aggregate_leg(lib, torch, steps, with_cases, with_cpu):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Summarises the rocprofv3 runs of tools/collect_profiles.sh over `python bench.py` itself into the files committed under profiles/:
-  r05_bench_kernel_stats.csv   per (kernel, grid size): launches, average / min / max duration -- from the kernel trace of ONE bench.py
-                               process, whose own JSON line (HIP-event kernel_ms measured inside that process) is r05_bench_traced.json
-  r05_bench_pmc.json           per kernel (the launch shape of the headline step = the shape with most launches): FETCH_SIZE / WRITE_SIZE per
+  r06_bench_kernel_stats.csv   per (kernel, grid size): launches, average / min / max duration -- from the kernel trace of ONE bench.py
+                               process, whose own JSON line (HIP-event kernel_ms measured inside that process) is r06_bench_traced.json
+  r06_bench_pmc.json           per kernel (the launch shape of the headline step = the shape with most launches): FETCH_SIZE / WRITE_SIZE per
                                launch and hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE doubled: gfx950 tallies the 128-byte
                                requests of wide coalesced reads at 64 bytes, MI355X_MICROARCH.md "HBM"; WRITE_SIZE as reported); "step" = the
                                kernels of one TableScan + JoinHash step added up, "hy_join_hash" = the join's.  bench.py reads this file for
@@ -29,7 +29,7 @@ def base(name):
 
 
 def timeline(root):
-    """r05_bench_step_timeline.txt: the kernels of three consecutive headline steps in the middle of the timed region, with the idle time
+    """r06_bench_step_timeline.txt: the kernels of three consecutive headline steps in the middle of the timed region, with the idle time
     before each (launch gaps) -- what separates the sum of the kernels from the step's wall time."""
     rows = []
     for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
@@ -48,7 +48,7 @@ def timeline(root):
     if not later:
         return
     end = later[0]
-    with open(os.path.join(root, "r05_bench_step_timeline.txt"), "w") as fh:
+    with open(os.path.join(root, "r06_bench_step_timeline.txt"), "w") as fh:
         fh.write("offset_us  idle_before_us  duration_us  kernel\n")
         origin, previous_end = rows[steps_begin][0], None
         for start, stop, name in rows[steps_begin:end + 1]:
@@ -78,7 +78,7 @@ def main():
         for start, stop, key in launches:
             if scans[0] <= start <= scans[-1] and base(key[0]) in STEP:
                 in_step[key].append(stop - start)
-    with open(os.path.join(root, "r05_bench_kernel_stats.csv"), "w", newline="") as fh:
+    with open(os.path.join(root, "r06_bench_kernel_stats.csv"), "w", newline="") as fh:
         writer = csv.writer(fh)
         writer.writerow(["kernel", "grid_size_x", "launches", "average_us", "min_us", "max_us", "total_ms", "launches_in_step_region", "average_us_in_step_region"])
         for (name, grid), durations in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
@@ -114,14 +114,18 @@ def main():
         kernels[name] = {"kernel": full, "grid_size_x": grid, "launches_counted": max(f[1], w[1]), "FETCH_SIZE_KB_per_launch": f[0] / f[1] if f[1] else None,
                          "WRITE_SIZE_KB_per_launch": w[0] / w[1] if w[1] else None,
                          "hbm_bytes_per_launch": (f[0] / f[1] * 2048 if f[1] else 0) + (w[0] / w[1] * 1024 if w[1] else 0), "average_us_traced": average}
+    if "sd_groups" in kernels:   # config 4: the two launches of the Q1-shaped AggregateHash (bench.py names them together)
+        members = [m for m in ("sd_groups", "sd_wide") if m in kernels]
+        kernels["sd_groups + sd_wide"] = {"kernels": members, "hbm_bytes_per_launch": sum(kernels[m]["hbm_bytes_per_launch"] for m in members),
+                                          "average_us_traced": sum(kernels[m]["average_us_traced"] for m in members)}
     for total, members in (("step", STEP), ("hy_join_hash", JOIN)):
         if all(m in kernels for m in members if m not in ("prepare_jobs", "zero_vectors", "pk_plan")):
             kernels[total] = {"kernels": [m for m in members if m in kernels], "hbm_bytes_per_launch": sum(kernels[m]["hbm_bytes_per_launch"] for m in members if m in kernels)}
     summary = {"collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) over `python bench.py`, commit {commit}", "kernels": kernels,
                "note": "bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024 per launch of the kernel's headline shape (the grid size with most launches); memory-side cache hits included"}
-    with open(os.path.join(root, "r05_bench_pmc.json"), "w") as fh:
+    with open(os.path.join(root, "r06_bench_pmc.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
-    for name in ("scan_slices", "pk_emit", "pk_count", "rank_table_fill_waves", "step", "hy_join_hash"):
+    for name in ("scan_slices", "pk_emit", "pk_count", "rank_table_fill_waves", "step", "hy_join_hash", "sd_groups", "sd_wide", "sd_groups + sd_wide"):
         if name in kernels:
             print(f"{name:28s} hbm bytes per launch {kernels[name]['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
 
