@@ -418,43 +418,17 @@ PAIR_LIST_OFFSET = 5 << 18          # addresses are congruent modulo 2 MiB the t
 
 def pair_lists(torch, device, capacity):
     """Device buffers for a join's two output PosLists ([capacity, 2] int32 each), carved out of ONE allocation so that the second starts
-    1.25 MiB past a 2 MiB boundary when the first starts on one -- the result-buffer policy of the adapter.
+    1.25 MiB past a 2 MiB boundary when the first starts on one (callers that hold torch tensors; the C++ adapter and bench.py take
+    their lists from the library's pool, hy_result_pool_acquire_pair, which applies the same rule).
     -> (left, right, the allocation: keep it alive)"""
     list_bytes = 8 * max(1, int(capacity))
-    import os
-    align = int(os.environ.get("HY_PAIR_ALIGN", "0"))          # experiments (tools/emit_lottery.py): both lists from an `align`-aligned address,
-    offset = int(os.environ.get("HY_PAIR_OFFSET", str(PAIR_LIST_OFFSET)))   # the second `offset` past the next multiple of `align`
-    if align:
-        span = (list_bytes + align - 1) // align * align
-        arena = torch.empty(2 * span + align + offset, dtype=torch.uint8, device=device)
-        first = -arena.data_ptr() % align
-        second = first + span + offset
-    else:
-        arena = torch.empty(2 * list_bytes + 3 * PAIR_LIST_PERIOD, dtype=torch.uint8, device=device)
-        first = -arena.data_ptr() % PAIR_LIST_PERIOD
-        second = (first + list_bytes + PAIR_LIST_PERIOD - 1) // PAIR_LIST_PERIOD * PAIR_LIST_PERIOD + offset
+    arena = torch.empty(2 * list_bytes + 3 * PAIR_LIST_PERIOD, dtype=torch.uint8, device=device)
+    first = -arena.data_ptr() % PAIR_LIST_PERIOD
+    second = (first + list_bytes + PAIR_LIST_PERIOD - 1) // PAIR_LIST_PERIOD * PAIR_LIST_PERIOD + PAIR_LIST_OFFSET
     rows = max(1, int(capacity))
     left = arena[first:first + list_bytes].view(torch.int32).view(rows, 2)
     right = arena[second:second + list_bytes].view(torch.int32).view(rows, 2)
     return left, right, arena
-
-
-def pair_list_candidates(torch, device, capacity, n):
-    """n candidate placements of a join's two output PosLists for a calibrated result-buffer pool: every list an
-    allocation of its own (2 n allocations: which stretch of device memory an allocation lands in decides pk_emit's speed by up to 15 %, and it
-    takes only ONE of the two lists in a good stretch -- profiles/r05_placement_probe.txt), the second list of a pair 1.25 MiB past the 2 MiB
-    grid the first starts on.  -> [(left, right, (the two allocations: keep them alive))]"""
-    list_bytes = 8 * max(1, int(capacity))
-    rows = max(1, int(capacity))
-    out = []
-    for _ in range(n):
-        arenas = [torch.empty(list_bytes + 2 * PAIR_LIST_PERIOD, dtype=torch.uint8, device=device) for _ in range(2)]
-        first = -arenas[0].data_ptr() % PAIR_LIST_PERIOD
-        second = -arenas[1].data_ptr() % PAIR_LIST_PERIOD + PAIR_LIST_OFFSET
-        left = arenas[0][first:first + list_bytes].view(torch.int32).view(rows, 2)
-        right = arenas[1][second:second + list_bytes].view(torch.int32).view(rows, 2)
-        out.append((left, right, tuple(arenas)))
-    return out
 
 
 def validate_filter(mvcc_column, our_tid, snapshot_commit_id, can_use_chunk_shortcut=True):
