@@ -90,7 +90,7 @@ class JoinPredicate(C.Structure):
 MAX_SECONDARY_PREDICATES = 4
 # hy_set_option (include/hyrise_amd.h HY_OPT_*): equivalent paths / launch shapes; every setting gives the same results
 (OPT_ALLOW_ANY_ARCH, OPT_JOIN_RANK_TABLE, OPT_JOIN_HINT, OPT_JOIN_BREAK_HINT, OPT_JOIN_PKFK, OPT_JOIN_LDS_BUILD, OPT_JOIN_LDS_BUILD_TILES, OPT_JOIN_FILL_WGS_PER_CU,
- OPT_JOIN_HAND_OVER_RANKS, OPT_AGG_PARTITION_BITS, OPT_AGG_SPILL_SHIFT, OPT_AGG_SMALL_DOMAIN, OPT_FUSED_SMALL_DOMAIN, OPT_SCAN_TWO_COLUMNS, OPT_STAR_FUSED_PROBE) = range(15)
+ OPT_JOIN_HAND_OVER_RANKS, OPT_AGG_PARTITION_BITS, OPT_AGG_SPILL_SHIFT, OPT_AGG_SMALL_DOMAIN, OPT_FUSED_SMALL_DOMAIN, OPT_SCAN_TWO_COLUMNS, OPT_STAR_FUSED_PROBE, OPT_STAR_FUSED_FINISH) = range(16)
 KERNEL_OTHER, KERNEL_SCAN, KERNEL_JOIN_PROBE, KERNEL_JOIN_COUNT, KERNEL_JOIN_BUILD, KERNEL_AGGREGATE, KERNEL_PROJECTION = range(7)   # hy_profile_read_kernel
 ARITH_ADD, ARITH_SUB, ARITH_MUL, ARITH_DIV, ARITH_MOD = range(5)
 
@@ -271,7 +271,7 @@ class option:
 
 # The switches the tools/ scripts name -> (option, value when the switch is "1" / its integer value otherwise).
 _SWITCHES = {
-    "HY_SCAN_NO_TWO_COLUMNS": (OPT_SCAN_TWO_COLUMNS, 0), "HY_STAR_NO_FUSED_PROBE": (OPT_STAR_FUSED_PROBE, 0),
+    "HY_SCAN_NO_TWO_COLUMNS": (OPT_SCAN_TWO_COLUMNS, 0), "HY_STAR_NO_FUSED_PROBE": (OPT_STAR_FUSED_PROBE, 0), "HY_STAR_NO_FUSED_FINISH": (OPT_STAR_FUSED_FINISH, 0),
     "HY_JOIN_NO_RANK_TABLE": (OPT_JOIN_RANK_TABLE, 0), "HY_JOIN_NO_HINT": (OPT_JOIN_HINT, 0), "HY_JOIN_BREAK_HINT": (OPT_JOIN_BREAK_HINT, None),
     "HY_JOIN_NO_PKFK": (OPT_JOIN_PKFK, 0), "HY_JOIN_NO_LDS_BUILD": (OPT_JOIN_LDS_BUILD, 0), "HY_JOIN_LDS_BUILD_TILES": (OPT_JOIN_LDS_BUILD_TILES, None),
     "HY_JOIN_FILL_WGS_PER_CU": (OPT_JOIN_FILL_WGS_PER_CU, None), "HY_JOIN_HAND_OVER_RANKS": (OPT_JOIN_HAND_OVER_RANKS, None),

@@ -265,8 +265,22 @@ struct StarProbeDimension {
 // fact_rows / dimension_rows[d]: the RowIDs of the fact table and of dimension d per row of fact JOIN dim_1 ... JOIN dim_k (Inner), in the
 // fact table's row order.  *applicable = false: this shape is not for the fused probe (keys that are not int32 / not unique / too
 // sparse, foreign-key segments the probe does not stream) -- nothing was produced.
+// The plan's Projection + AggregateHash inside the join (star_finish, join_star.hpp): asked for with `finish`, answered in `groups` --
+// groups->done: the join result was grouped where it was found (no RowIDs were written); otherwise the RowIDs are there as without it.
+struct StarFinishColumnSpec { uint32_t table; const hy_column* column; };   // table 0 = the fact table, d + 1 = dimension d; column nullptr: none
+struct StarFinishRequest {
+  uint32_t n_groupby, n_aggregates;
+  StarFinishColumnSpec groupby[4];
+  struct { uint32_t function, op; StarFinishColumnSpec left, right; } aggregates[8];
+};
+struct StarFinishGroups {
+  bool done = false;
+  uint32_t n_groups = 0;
+  uint32_t input_type[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // type of every aggregate's input value (HY_TYPE_INT / HY_TYPE_LONG)
+  std::vector<uint64_t> keys, first, last, values, counts;   // [n][4], [n], [n], [n][8], [n]: first / last = row numbers of the join result
+};
 hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimensions, DeviceBuffer& fact_rows, std::vector<std::unique_ptr<DeviceBuffer>>& dimension_rows,
-                          uint64_t* n_rows, bool* applicable);
+                          uint64_t* n_rows, bool* applicable, const StarFinishRequest* finish = nullptr, StarFinishGroups* groups = nullptr);
 hy_status star_all_rows_of(const hy_column* column, DeviceBuffer& rows);   // every row of a data column's table as a PosList
 // scan.hip: the kernels of hy_poslist_translate queued on the current stream, nothing read back -- dense_offsets: [n_chunks + 1] device words,
 // the last of them the number of RowIDs written

@@ -33,6 +33,7 @@
 // observable: the build side's filter decides which probe elements count as "materialised" (it shifts the cuts).
 #include "hy_device.hpp"
 #include "hy_decode.hpp"
+#include "hy_arithmetic.hpp"
 
 #include <algorithm>
 #include <atomic>

@@ -17,6 +17,9 @@
 //   star_scan_counts                  where every tile's survivors go
 //   star_emit_rows                    the survivors' RowIDs, in FACT-TABLE ROW ORDER: the fact row's, and per dimension the RowID its
 //                                     table holds for the row's key (only survivors' keys are read again)
+//   star_finish / star_finish_compact the plan's Projection + AggregateHash inside the join (round 6): where every GROUP BY column and
+//                                     every aggregate input is an int / long column of a joined table, the survivors are grouped where
+//                                     they are found -- no RowIDs written, no columns exported, no second pass by hy_aggregate_hash
 // HBM traffic: every foreign-key column once + 1 bit per row + 8 bytes x (1 + dimensions) per surviving row.
 #pragma once
 
@@ -327,6 +330,447 @@ __global__ __launch_bounds__(256) void star_emit_rows(StarArgs a) {
   }
 }
 
+// ---- the finish inside the join -----------------------------------------------------------------------------------------------------
+// What it replaces: star_emit_rows, one hy_column_export per column the aggregate reads, hy_projection_arithmetic for the aggregates'
+// expressions (operators/projection.cpp) and hy_aggregate_hash over the result (aggregate_hash.cpp:317-403, 605-655) -- for plans whose GROUP
+// BY columns and aggregate inputs are int / long columns (any encoding column_value reads) of the fact table or of a dimension.  Survivors
+// are 0.8 - 1.6 % of an SSB fact table: their cells are gathered once, by the workgroup that holds their mask, and meet in a hash table in
+// LDS that the (persistent) workgroup merges into a small global table when it has seen its last tile.
+// The groups carry sums / extremes / one count (no NULL input is accepted: a NULL cell raises FLAG_REFUSED and the caller takes the
+// RowID path) and their first and last survivor as (tile << 13 | row in tile) -- monotone in the fact table's row order, i.e. in the order
+// of the join result's rows; star_finish_compact turns them into the survivors' ranks = the row numbers hy_aggregate_hash would have seen.
+constexpr uint32_t STAR_FINISH_KEYS = 4, STAR_FINISH_AGGREGATES = HY_MAX_STAR_AGGREGATES;
+constexpr uint32_t STAR_FINISH_THREADS = 512;
+constexpr uint32_t STAR_FINISH_SLOTS = 512;            // a workgroup's table in LDS
+constexpr uint32_t STAR_FINISH_GLOBAL_SLOTS = 1u << 14;
+constexpr uint32_t STAR_FINISH_MAX_GROUPS = 4096;      // what the compacted result holds (more: the RowID path)
+constexpr uint32_t STAR_FACT_TABLE = 0xFFFFFFFFu;
+enum : uint32_t { STAR_FLAG_REFUSED = 0, STAR_FLAG_GROUPS = 1 };
+
+constexpr uint32_t STAR_FINISH_FACT_COLUMNS = 4;   // distinct fact-table columns the aggregate reads (their slices' views are staged per tile)
+constexpr uint32_t STAR_FINISH_ATTRIBUTES = 4;     // distinct dimension columns it reads (one attribute table each)
+enum : uint32_t { STAR_COLUMN_NONE = 0, STAR_COLUMN_FACT = 1, STAR_COLUMN_DIMENSION = 2 };
+
+// A column of the join result as star_finish reads it.  FACT: the fact table's column `index` of StarFinishArgs::fact (its slice's view, or cell by
+// cell where the view says VIEW_GENERIC).  DIMENSION: attribute table `index` -- the column's value per KEY of its dimension (star_dim_attributes),
+// asked with the fact row's foreign key to the table in slot `table`: one load behind the key instead of RowID -> descriptor -> value id -> value.
+struct StarFinishColumn {
+  uint32_t kind;
+  uint32_t index;
+  uint32_t table;
+  uint32_t data_type;           // HY_TYPE_INT / HY_TYPE_LONG
+};
+struct StarFinishAggregate {
+  StarFinishColumn left, right;
+  uint32_t function, op;        // HY_AGG_*; HY_STAR_NO_OP or HY_ARITH_*
+  uint32_t type;                // type of the value that is aggregated (expression_common_type of the operands)
+  uint32_t reserved;
+};
+struct StarFinishArgs {
+  StarFinishColumn groupby[STAR_FINISH_KEYS];
+  StarFinishAggregate aggregates[STAR_FINISH_AGGREGATES];
+  uint32_t n_groupby, n_aggregates;
+  uint32_t n_fact, n_attributes;
+  // the fact table's columns the aggregate reads: fact_slot[c] = c for c < n_fact, else 0 (a load that repeats column 0's)
+  const SliceView* fact_views[STAR_FINISH_FACT_COLUMNS];
+  const DevSegment* fact_segments[STAR_FINISH_FACT_COLUMNS];
+  uint32_t fact_slot[STAR_FINISH_FACT_COLUMNS];
+  uint32_t fact_generic;        // bit c: some slices of column c have no view (VIEW_GENERIC): read cell by cell
+  // the dimensions' columns it reads, as attribute tables [range + 1] of int64; entries past n_attributes repeat entry 0
+  const int64_t* attributes[STAR_FINISH_ATTRIBUTES];
+  uint32_t attribute_slot[STAR_FINISH_ATTRIBUTES];     // slot in StarArgs::table of the dimension whose key indexes the table
+  uint32_t attribute_key_min[STAR_FINISH_ATTRIBUTES];
+  uint32_t attribute_mask[STAR_FINISH_ATTRIBUTES];     // all ones; 0 where the plan reads no dimension column at all (entry 0 of a stand-in table)
+  uint32_t capacity;            // global table (power of two)
+  uint32_t* tags;
+  uint64_t* keys;               // [capacity][STAR_FINISH_KEYS]
+  uint64_t* values;             // [capacity][STAR_FINISH_AGGREGATES]
+  uint32_t* counts;             // [capacity]
+  uint32_t* first;              // [capacity] tile << 13 | row
+  uint32_t* last;
+  uint32_t* flags;              // STAR_FLAG_*
+};
+struct StarFinishHeader {       // what the host reads after the plan's last kernel (pinned memory)
+  uint32_t refused, n_groups, key_twice, reserved;
+  uint64_t total;               // rows of the join result
+};
+
+// The attribute tables: per dimension column the aggregate reads, its value at every key of the dimension's rows (blockIdx.y = attribute).
+// A NULL cell raises *null_met (the finish carries no NULLs: the caller takes the RowID path).
+struct StarAttributeJobs {
+  const DevSegment* key_segments[STAR_FINISH_ATTRIBUTES];
+  const DevSegment* segments[STAR_FINISH_ATTRIBUTES];
+  const hy_row_id* rows[STAR_FINISH_ATTRIBUTES];
+  uint64_t n[STAR_FINISH_ATTRIBUTES];
+  const uint64_t* n_in_memory[STAR_FINISH_ATTRIBUTES];
+  int64_t key_min[STAR_FINISH_ATTRIBUTES];
+  int64_t* out[STAR_FINISH_ATTRIBUTES];
+};
+__global__ __launch_bounds__(256) void star_dim_attributes(StarAttributeJobs jobs, uint32_t* null_met) {
+  const uint32_t k = blockIdx.y;
+  const hy_row_id* rows = jobs.rows[k];
+  const uint64_t n = jobs.n_in_memory[k] ? *jobs.n_in_memory[k] : jobs.n[k];
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) {
+    const hy_row_id row = rows[i];
+    const Value key = column_value(jobs.key_segments[k], row.chunk_id, row.chunk_offset);
+    if (key.is_null) continue;
+    const Value v = column_value(jobs.segments[k], row.chunk_id, row.chunk_offset);
+    if (v.is_null) { *null_met = 1; continue; }
+    const uint32_t rel = static_cast<uint32_t>(key.i - jobs.key_min[k]);
+    jobs.out[k][rel] = v.i;
+  }
+}
+
+// Row `row` of the chunk a view describes, without a branch on the view's kind and without a conditional load (the loads of a survivor's
+// columns are all requested before the first is looked at): the aligned word that holds the stored value, shifted and masked, and the block
+// minimum -- for plain int32 values the word at the front of the data, not used.  A VIEW_GENERIC slice reads its first word (not used either).
+__device__ __forceinline__ int32_t star_view_value(const SliceView& view, uint32_t row) {
+  const uint32_t width = view.kind == VIEW_FOR8 ? 1u : view.kind == VIEW_FOR16 ? 2u : 4u;
+  const uint32_t byte = view.kind == VIEW_GENERIC ? 0u : row * width;
+  const bool biased = view.kind != VIEW_INT32 && view.kind != VIEW_GENERIC;
+  // (pointers out of a descriptor are generic to the compiler: flat loads, which count as LDS traffic too -- every wait for the next view's words
+  //  would wait for them; global-address-space loads do not)
+  typedef __attribute__((address_space(1))) const uint32_t global_word;
+  global_word* minima = (global_word*)(biased ? view.aux : view.data);
+  global_word* words = (global_word*)(static_cast<const char*>(view.data) + (byte & ~3u));
+  const uint32_t word = *words;
+  const uint32_t minimum = minima[biased ? row / HY_FOR_BLOCK_SIZE : 0u];
+  const uint32_t stored = width == 4 ? word : (word >> ((byte & 3u) * 8)) & (width == 1 ? 0xFFu : 0xFFFFu);
+  return static_cast<int32_t>(stored + (biased ? minimum : 0u));
+}
+
+__device__ __forceinline__ uint64_t star_initial_value(uint32_t function) {
+  return function == HY_AGG_MIN ? static_cast<uint64_t>(INT64_MAX) : function == HY_AGG_MAX ? static_cast<uint64_t>(INT64_MIN) : 0ull;
+}
+
+__device__ __forceinline__ uint32_t star_tuple_hash(const uint64_t (&tuple)[STAR_FINISH_KEYS], uint32_t words) {
+  uint32_t h = 0x9E3779B9u;
+#pragma unroll
+  for (uint32_t w = 0; w < STAR_FINISH_KEYS; ++w) {
+    if (w >= words) continue;
+    h = (h ^ static_cast<uint32_t>(tuple[w])) * 0x85EBCA77u;
+    h = (h ^ (h >> 15) ^ static_cast<uint32_t>(tuple[w] >> 32)) * 0xC2B2AE3Du;
+  }
+  return h ^ (h >> 13);
+}
+
+// Find or insert in the workgroup's LDS table; 0xFFFFFFFF: no place within the probe limit.  One retry loop whose every iteration either
+// completes claim + initialise + publish or takes no blocking step (lanes of a wave run in lockstep: a lane must never spin on a slot a
+// masked-off neighbour holds) -- the discipline of aggregate.hip's tables.
+__device__ __forceinline__ uint32_t star_lds_slot(uint32_t* s_tags, uint64_t* s_keys, uint64_t* s_values, uint32_t* s_counts, uint32_t* s_first, uint32_t* s_last, const StarFinishArgs& f,
+                                                 const uint64_t (&tuple)[STAR_FINISH_KEYS], uint32_t hash) {
+  const uint32_t ready = 0x80000000u | (hash >> 1);
+  uint32_t slot = hash & (STAR_FINISH_SLOTS - 1), probes = 0, result = 0xFFFFFFFFu;
+  bool done = false;
+  while (!done) {
+    const uint32_t tag = __hip_atomic_load(&s_tags[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (tag == 0) {
+      uint32_t expected = 0;
+      if (__hip_atomic_compare_exchange_strong(&s_tags[slot], &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+#pragma unroll
+        for (uint32_t w = 0; w < STAR_FINISH_KEYS; ++w) s_keys[slot * STAR_FINISH_KEYS + w] = tuple[w];
+        for (uint32_t g = 0; g < f.n_aggregates; ++g) s_values[slot * f.n_aggregates + g] = star_initial_value(f.aggregates[g].function);
+        s_counts[slot] = 0;
+        s_first[slot] = 0xFFFFFFFFu;
+        s_last[slot] = 0;
+        __hip_atomic_store(&s_tags[slot], ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        result = slot;
+        done = true;
+      }
+    } else if (tag != 1u) {
+      bool equal = tag == ready;
+#pragma unroll
+      for (uint32_t w = 0; w < STAR_FINISH_KEYS; ++w) equal = equal && (w >= f.n_groupby || s_keys[slot * STAR_FINISH_KEYS + w] == tuple[w]);
+      if (equal) { result = slot; done = true; }
+      else {
+        slot = (slot + 1) & (STAR_FINISH_SLOTS - 1);
+        if (++probes >= 64) done = true;
+      }
+    } else __builtin_amdgcn_s_sleep(1);
+  }
+  return result;
+}
+
+// The same in the global table (agent scope); 0xFFFFFFFF: full.
+__device__ __forceinline__ uint32_t star_global_slot(const StarFinishArgs& f, const uint64_t (&tuple)[STAR_FINISH_KEYS], uint32_t hash) {
+  const uint32_t ready = 0x80000000u | (hash >> 1);
+  uint32_t slot = hash & (f.capacity - 1), probes = 0, result = 0xFFFFFFFFu;
+  bool done = false;
+  while (!done) {
+    const uint32_t tag = __hip_atomic_load(&f.tags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_signal_fence(__ATOMIC_ACQUIRE);
+    if (tag == 0) {
+      uint32_t expected = 0;
+      if (__hip_atomic_compare_exchange_strong(&f.tags[slot], &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        for (uint32_t w = 0; w < STAR_FINISH_KEYS; ++w) __hip_atomic_store(&f.keys[size_t{slot} * STAR_FINISH_KEYS + w], tuple[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t g = 0; g < STAR_FINISH_AGGREGATES; ++g) {
+          __hip_atomic_store(&f.values[size_t{slot} * STAR_FINISH_AGGREGATES + g], g < f.n_aggregates ? star_initial_value(f.aggregates[g].function) : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(&f.counts[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&f.first[slot], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&f.last[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&f.tags[slot], ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        result = slot;
+        done = true;
+      }
+    } else if (tag != 1u) {
+      bool equal = tag == ready;
+      if (equal) {
+        for (uint32_t w = 0; w < f.n_groupby; ++w) equal = equal && __hip_atomic_load(&f.keys[size_t{slot} * STAR_FINISH_KEYS + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tuple[w];
+      }
+      if (equal) { result = slot; done = true; }
+      else {
+        slot = (slot + 1) & (f.capacity - 1);
+        if (++probes >= 512) done = true;
+      }
+    } else __builtin_amdgcn_s_sleep(1);
+  }
+  return result;
+}
+
+// (a slot's accumulators lie n_aggregates words apart: up to four aggregates leave room for two workgroups per CU)
+constexpr size_t star_finish_lds_bytes(uint32_t n_aggregates) {
+  return 4 * size_t{STAR_EMIT_LIST} + sizeof(SliceView) * STAR_EMIT_TILES * (HY_MAX_STAR_DIMENSIONS + STAR_FINISH_FACT_COLUMNS) +
+         8 * size_t{STAR_FINISH_SLOTS} * (STAR_FINISH_KEYS + (n_aggregates ? n_aggregates : 1)) + 4 * size_t{STAR_FINISH_SLOTS} * 4 + 64;
+}
+
+__global__ __launch_bounds__(STAR_FINISH_THREADS, 4) void star_finish(StarArgs a, StarFinishArgs f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_star_finish[];
+  uint64_t* s_keys = reinterpret_cast<uint64_t*>(s_star_finish);
+  SliceView* s_views = reinterpret_cast<SliceView*>(s_keys + size_t{STAR_FINISH_SLOTS} * STAR_FINISH_KEYS);   // [tile][dimension]: the foreign keys' slices
+  SliceView* s_fact_views = s_views + STAR_EMIT_TILES * HY_MAX_STAR_DIMENSIONS;                                 // [tile][fact column]
+  uint32_t* s_list = reinterpret_cast<uint32_t*>(s_fact_views + STAR_EMIT_TILES * STAR_FINISH_FACT_COLUMNS);
+  uint32_t* s_tags = s_list + STAR_EMIT_LIST;
+  uint32_t* s_counts = s_tags + STAR_FINISH_SLOTS;
+  uint32_t* s_first = s_counts + STAR_FINISH_SLOTS;
+  uint32_t* s_last = s_first + STAR_FINISH_SLOTS;
+  uint32_t* s_wave = s_last + STAR_FINISH_SLOTS;   // [8] + [1] the workgroup gave up
+  uint64_t* s_values = reinterpret_cast<uint64_t*>(s_wave + 16);   // [STAR_FINISH_SLOTS][n_aggregates]
+  constexpr uint32_t WAVES = STAR_FINISH_THREADS / 64, WORDS = STAR_EMIT_TILES * SLICE_ROWS / 32 / STAR_FINISH_THREADS;   // mask words per thread: 4
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint32_t i = tid; i < STAR_FINISH_SLOTS; i += STAR_FINISH_THREADS) s_tags[i] = 0;
+  if (tid == 0) s_wave[WAVES] = 0;
+  const uint32_t n_groups_of_tiles = (a.n_tiles + STAR_EMIT_TILES - 1) / STAR_EMIT_TILES;
+  for (uint32_t group = blockIdx.x; group < n_groups_of_tiles; group += gridDim.x) {
+    const uint32_t first_tile = group * STAR_EMIT_TILES;
+    const uint32_t n_tiles = a.n_tiles - first_tile < STAR_EMIT_TILES ? a.n_tiles - first_tile : STAR_EMIT_TILES;
+    __syncthreads();   // (the list and the views of the group before are done with; the tags are cleared)
+    for (uint32_t i = tid; i < n_tiles * a.n_tables; i += STAR_FINISH_THREADS) s_views[(i / a.n_tables) * HY_MAX_STAR_DIMENSIONS + i % a.n_tables] = a.table[i % a.n_tables].views[first_tile + i / a.n_tables];
+    for (uint32_t i = tid; i < n_tiles * f.n_fact; i += STAR_FINISH_THREADS) s_fact_views[(i / f.n_fact) * STAR_FINISH_FACT_COLUMNS + i % f.n_fact] = f.fact_views[i % f.n_fact][first_tile + i / f.n_fact];
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(a.masks + static_cast<size_t>(first_tile) * STAR_THREADS);
+    uint32_t mask[WORDS], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < WORDS; ++k) {
+      const uint32_t w = tid * WORDS + k;
+      mask[k] = w < n_tiles * (STAR_THREADS / 4) ? words[w] : 0u;
+      mine += __popc(mask[k]);
+    }
+    uint32_t inclusive = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t other = __shfl_up(inclusive, d, 64);
+      if (lane >= static_cast<uint32_t>(d)) inclusive += other;
+    }
+    if (lane == 63) s_wave[wave] = inclusive;
+    __syncthreads();
+    uint32_t before = inclusive - mine, total = 0;
+    for (uint32_t w = 0; w < WAVES; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
+    for (uint32_t pass_begin = 0; pass_begin < total; pass_begin += STAR_EMIT_LIST) {
+      if (pass_begin) __syncthreads();
+      uint32_t rank = before;
+#pragma unroll
+      for (uint32_t k = 0; k < WORDS; ++k) {
+        uint32_t bits = mask[k];
+        const uint32_t row0 = (tid * WORDS + k) * 32;
+        while (bits) {
+          const uint32_t j = __ffs(bits) - 1;
+          bits &= bits - 1;
+          if (rank - pass_begin < STAR_EMIT_LIST) s_list[rank - pass_begin] = row0 + j;
+          ++rank;
+        }
+      }
+      __syncthreads();
+      const uint32_t in_pass = total - pass_begin < STAR_EMIT_LIST ? total - pass_begin : STAR_EMIT_LIST;
+      for (uint32_t i = tid; i < in_pass; i += STAR_FINISH_THREADS) {
+        const uint32_t entry = s_list[i];
+        const uint32_t tile = entry >> 13, row = entry & 8191u;
+        const SliceView* views = s_views + tile * HY_MAX_STAR_DIMENSIONS;
+        const SliceView* fact_views = s_fact_views + tile * STAR_FINISH_FACT_COLUMNS;
+        // round trip 1: the row's foreign keys to the dimensions somebody reads, and its cells of the fact table's columns.  Every load below is
+        // unconditional (entries past the plan's repeat entry 0: the same address once more) -- a load on some control-flow paths only makes the
+        // compiler wait for everything in flight where the paths meet, and the row's dozen loads would go one round trip at a time.
+        uint32_t rel[STAR_FINISH_ATTRIBUTES];
+#pragma unroll
+        for (uint32_t k = 0; k < STAR_FINISH_ATTRIBUTES; ++k) {
+          const SliceView& view = views[f.attribute_slot[k]];
+          rel[k] = (static_cast<uint32_t>(star_view_value(view, view.row_begin + row)) - f.attribute_key_min[k]) & f.attribute_mask[k];
+        }
+        int64_t fact[STAR_FINISH_FACT_COLUMNS];
+#pragma unroll
+        for (uint32_t c = 0; c < STAR_FINISH_FACT_COLUMNS; ++c) {
+          const SliceView& view = fact_views[f.fact_slot[c]];
+          fact[c] = star_view_value(view, view.row_begin + row);
+        }
+        // round trip 2: the dimensions' attributes at those keys
+        int64_t attribute[STAR_FINISH_ATTRIBUTES];
+#pragma unroll
+        for (uint32_t k = 0; k < STAR_FINISH_ATTRIBUTES; ++k) attribute[k] = f.attributes[k][rel[k]];
+        bool refuse = false;
+        if (f.fact_generic) {   // columns with slices no view describes (dictionary segments, nullable ones, int64): those rows cell by cell
+#pragma unroll
+          for (uint32_t c = 0; c < STAR_FINISH_FACT_COLUMNS; ++c) {
+            if (!((f.fact_generic >> c) & 1)) continue;
+            const SliceView& view = fact_views[c];
+            if (view.kind != VIEW_GENERIC) continue;
+            const Value v = column_value(f.fact_segments[c], view.chunk, view.row_begin + row);
+            refuse = refuse || v.is_null;
+            fact[c] = v.i;
+          }
+        }
+        auto cell = [&](const StarFinishColumn& column) -> int64_t {
+          int64_t v = 0;
+          if (column.kind == STAR_COLUMN_FACT) {
+#pragma unroll
+            for (uint32_t c = 0; c < STAR_FINISH_FACT_COLUMNS; ++c) v = column.index == c ? fact[c] : v;
+          } else {
+#pragma unroll
+            for (uint32_t k = 0; k < STAR_FINISH_ATTRIBUTES; ++k) v = column.index == k ? attribute[k] : v;
+          }
+          return v;
+        };
+        uint64_t tuple[STAR_FINISH_KEYS];
+#pragma unroll
+        for (uint32_t g = 0; g < STAR_FINISH_KEYS; ++g) tuple[g] = g < f.n_groupby ? static_cast<uint64_t>(cell(f.groupby[g])) : 0ull;
+        // an aggregate's input at this row; *null_cell: the expression's cell is NULL (division by zero) -- the plan goes to the RowID path
+        auto input_of = [&](uint32_t g, bool* null_cell) -> uint64_t {
+          const StarFinishAggregate& spec = f.aggregates[g];
+          Value v{false, cell(spec.left), 0.0};
+          if (spec.op != HY_STAR_NO_OP) {
+            const Value right{false, cell(spec.right), 0.0};
+            Value out{false, 0, 0.0};
+            *null_cell = arithmetic_cell(spec.op, spec.left.data_type, spec.right.data_type, spec.type, v, right, &out) || *null_cell;
+            v = out;
+          }
+          return static_cast<uint64_t>(v.i);
+        };
+        const uint32_t hash = star_tuple_hash(tuple, f.n_groupby);
+        const uint32_t position = first_tile * SLICE_ROWS + entry;   // (tile << 13 | row, tiles counted from the table's first)
+        const uint32_t slot = star_lds_slot(s_tags, s_keys, s_values, s_counts, s_first, s_last, f, tuple, hash);
+        if (slot != 0xFFFFFFFFu) {
+          for (uint32_t g = 0; g < f.n_aggregates; ++g) {
+            if (f.aggregates[g].left.kind == STAR_COLUMN_NONE) continue;
+            const uint32_t function = f.aggregates[g].function;
+            const uint64_t input = input_of(g, &refuse);
+            uint64_t* target = &s_values[slot * f.n_aggregates + g];
+            if (function == HY_AGG_MIN) atomicMin(reinterpret_cast<long long*>(target), static_cast<long long>(input));
+            else if (function == HY_AGG_MAX) atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(input));
+            else if (function != HY_AGG_COUNT) atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(input));
+          }
+          atomicAdd(&s_counts[slot], 1u);
+          if (position < s_first[slot]) atomicMin(&s_first[slot], position);
+          if (position > s_last[slot]) atomicMax(&s_last[slot], position);
+        } else {   // the workgroup's table has no place for this group: the row goes to the global table itself
+          const uint32_t global = star_global_slot(f, tuple, hash);
+          if (global == 0xFFFFFFFFu) { s_wave[WAVES] = 1; continue; }
+          for (uint32_t g = 0; g < f.n_aggregates; ++g) {
+            if (f.aggregates[g].left.kind == STAR_COLUMN_NONE) continue;
+            const uint32_t function = f.aggregates[g].function;
+            const uint64_t input = input_of(g, &refuse);
+            uint64_t* target = &f.values[size_t{global} * STAR_FINISH_AGGREGATES + g];
+            if (function == HY_AGG_MIN) atomicMin(reinterpret_cast<long long*>(target), static_cast<long long>(input));
+            else if (function == HY_AGG_MAX) atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(input));
+            else if (function != HY_AGG_COUNT) atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(input));
+          }
+          atomicAdd(&f.counts[global], 1u);
+          atomicMin(&f.first[global], position);
+          atomicMax(&f.last[global], position);
+        }
+        if (refuse) s_wave[WAVES] = 1;   // (a NULL cell: what this row left in the tables does not matter, the result is discarded)
+      }
+    }
+  }
+  __syncthreads();
+  // the workgroup's groups -> the global table
+  bool gave_up = s_wave[WAVES] != 0;
+  for (uint32_t slot = tid; slot < STAR_FINISH_SLOTS; slot += STAR_FINISH_THREADS) {
+    if (s_tags[slot] == 0) continue;
+    uint64_t tuple[STAR_FINISH_KEYS];
+#pragma unroll
+    for (uint32_t w = 0; w < STAR_FINISH_KEYS; ++w) tuple[w] = s_keys[slot * STAR_FINISH_KEYS + w];
+    const uint32_t global = star_global_slot(f, tuple, star_tuple_hash(tuple, f.n_groupby));
+    if (global == 0xFFFFFFFFu) { gave_up = true; continue; }
+    for (uint32_t g = 0; g < f.n_aggregates; ++g) {
+      if (f.aggregates[g].left.kind == STAR_COLUMN_NONE) continue;
+      const uint32_t function = f.aggregates[g].function;
+      uint64_t* target = &f.values[size_t{global} * STAR_FINISH_AGGREGATES + g];
+      const uint64_t value = s_values[slot * f.n_aggregates + g];
+      if (function == HY_AGG_MIN) atomicMin(reinterpret_cast<long long*>(target), static_cast<long long>(value));
+      else if (function == HY_AGG_MAX) atomicMax(reinterpret_cast<long long*>(target), static_cast<long long>(value));
+      else if (function != HY_AGG_COUNT) atomicAdd(reinterpret_cast<unsigned long long*>(target), static_cast<unsigned long long>(value));
+    }
+    atomicAdd(&f.counts[global], s_counts[slot]);
+    atomicMin(&f.first[global], s_first[slot]);
+    atomicMax(&f.last[global], s_last[slot]);
+  }
+  if (gave_up) f.flags[STAR_FLAG_REFUSED] = 1;
+}
+
+// The global table's groups, densely, into the block the host reads (pinned memory): keys, first / last as RANKS among the survivors (the row
+// numbers of the join result: survivors of the tiles before + set mask bits in front of the row), values, counts; the workgroup that finishes
+// last writes the header.  One slot per thread; flags[STAR_FLAG_GROUPS] hands out the places (the host orders the groups anyway).
+constexpr uint32_t STAR_FLAG_TICKET = 2, STAR_FLAG_NULL_ATTRIBUTE = 3;
+__global__ __launch_bounds__(256) void star_finish_compact(StarArgs a, StarFinishArgs f, const uint32_t* duplicate, StarFinishHeader* header, uint64_t* out_keys, uint64_t* out_first,
+                                                           uint64_t* out_last, uint64_t* out_values, uint64_t* out_counts) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  auto rank_of = [&](uint32_t position) -> uint64_t {
+    const uint32_t tile = position >> 13, row = position & 8191u;
+    const u32x4_t* quads = reinterpret_cast<const u32x4_t*>(a.masks + static_cast<size_t>(tile) * STAR_THREADS);
+    uint32_t bits = 0;
+    const uint32_t full = row / 128;   // whole 16-byte pieces in front of the row: up to 63, four loads in flight
+    for (uint32_t q = 0; q < full; q += 4) {
+      u32x4_t piece[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) piece[k] = quads[q + k < full ? q + k : q];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) if (q + k < full) bits += __popc(piece[k].x) + __popc(piece[k].y) + __popc(piece[k].z) + __popc(piece[k].w);
+    }
+    const u32x4_t last_piece = quads[full];
+    const uint32_t in_piece = row & 127u;
+    const uint32_t w[4] = {last_piece.x, last_piece.y, last_piece.z, last_piece.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      if (in_piece >= 32 * (k + 1)) bits += __popc(w[k]);
+      else if (in_piece > 32 * k) bits += __popc(w[k] & ((1u << (in_piece - 32 * k)) - 1u));
+    }
+    return a.base[tile] + bits;
+  };
+  const uint32_t slot = blockIdx.x * 256 + tid;
+  const bool taken = slot < f.capacity && f.tags[slot] != 0;
+  const uint64_t peers = __ballot(taken);
+  uint32_t place = 0;
+  if (peers) {
+    if (lane == static_cast<uint32_t>(__ffsll(static_cast<long long>(peers)) - 1)) place = atomicAdd(&f.flags[STAR_FLAG_GROUPS], static_cast<uint32_t>(__popcll(peers)));
+    place = __shfl(place, __ffsll(static_cast<long long>(peers)) - 1, 64) + static_cast<uint32_t>(__popcll(peers & ((1ull << lane) - 1)));
+  }
+  if (taken && place < STAR_FINISH_MAX_GROUPS) {
+    for (uint32_t w = 0; w < STAR_FINISH_KEYS; ++w) out_keys[size_t{place} * STAR_FINISH_KEYS + w] = f.keys[size_t{slot} * STAR_FINISH_KEYS + w];
+    for (uint32_t g = 0; g < STAR_FINISH_AGGREGATES; ++g) out_values[size_t{place} * STAR_FINISH_AGGREGATES + g] = f.values[size_t{slot} * STAR_FINISH_AGGREGATES + g];
+    out_counts[place] = f.counts[slot];
+    out_first[place] = rank_of(f.first[slot]);
+    out_last[place] = rank_of(f.last[slot]);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0 && atomicAdd(&f.flags[STAR_FLAG_TICKET], 1u) == gridDim.x - 1) {
+    const uint32_t n_groups = atomicAdd(&f.flags[STAR_FLAG_GROUPS], 0u);
+    header->refused = atomicAdd(&f.flags[STAR_FLAG_REFUSED], 0u) | atomicAdd(&f.flags[STAR_FLAG_NULL_ATTRIBUTE], 0u) | (n_groups > STAR_FINISH_MAX_GROUPS ? 1u : 0u);
+    header->n_groups = n_groups;
+    header->key_twice = *duplicate;
+    header->total = a.base[a.n_tiles];
+    __threadfence_system();
+  }
+}
+
 // Can the probe kernels read this column as a fact table's foreign key (int32 keys, every segment one a SliceView describes)?
 static bool star_reads_fact_key(const hy_column* column) {
   if (!column || column->is_reference || column->is_mvcc || column->has_compressed || column->data_type != HY_TYPE_INT) return false;
@@ -339,10 +783,34 @@ static bool star_reads_fact_key(const hy_column* column) {
 }
 
 // star_probe_rows (hy_device.hpp): see the top of this file.  *applicable = false: nothing was produced, the caller joins dimension by dimension.
+// Can star_finish read this column cell by cell (column_value), as an integer?
+static bool star_finish_reads(const hy_column* column) {
+  if (!column || column->is_reference || column->is_mvcc || column->has_compressed || column->has_dictionary_without_values) return false;
+  return column->data_type == HY_TYPE_INT || column->data_type == HY_TYPE_LONG;
+}
+
+// Is the plan's aggregate one star_finish computes?  (MIN / MAX / SUM / AVG / COUNT over int / long cells, one to four int / long GROUP BY columns)
+static bool star_finish_applies(const StarFinishRequest* finish, uint32_t n_dimensions, const hy_column* fact_shape) {
+  if (!finish || !option(HY_OPT_STAR_FUSED_FINISH)) return false;
+  if (finish->n_groupby == 0 || finish->n_groupby > STAR_FINISH_KEYS || finish->n_aggregates > STAR_FINISH_AGGREGATES) return false;
+  if (fact_shape->rows >= (1ull << 31) || fact_shape->n_slices >= (1u << 19)) return false;   // (positions are tile << 13 | row in 32 bits, counts 32 bits)
+  auto column_ok = [&](const StarFinishColumnSpec& c) { return c.table <= n_dimensions && star_finish_reads(c.column); };
+  for (uint32_t g = 0; g < finish->n_groupby; ++g) if (!column_ok(finish->groupby[g])) return false;
+  for (uint32_t g = 0; g < finish->n_aggregates; ++g) {
+    const auto& spec = finish->aggregates[g];
+    if (spec.function != HY_AGG_MIN && spec.function != HY_AGG_MAX && spec.function != HY_AGG_SUM && spec.function != HY_AGG_AVG && spec.function != HY_AGG_COUNT) return false;
+    if (!spec.left.column) { if (spec.function != HY_AGG_COUNT || spec.op != HY_STAR_NO_OP) return false; continue; }
+    if (!column_ok(spec.left)) return false;
+    if (spec.op != HY_STAR_NO_OP && (spec.op > HY_ARITH_MOD || !column_ok(spec.right))) return false;
+  }
+  return true;
+}
+
 hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimensions, DeviceBuffer& fact_rows, std::vector<std::unique_ptr<DeviceBuffer>>& dimension_rows, uint64_t* n_rows,
-                          bool* applicable) {
+                          bool* applicable, const StarFinishRequest* finish, StarFinishGroups* groups) {
   *applicable = false;
   *n_rows = 0;
+  if (groups) { groups->done = false; groups->n_groups = 0; }
   if (!option(HY_OPT_STAR_FUSED_PROBE) || n_dimensions == 0 || n_dimensions > HY_MAX_STAR_DIMENSIONS) return HY_OK;
   const hy_column* shape = dimensions[0].fact_key;
   for (uint32_t d = 0; d < n_dimensions; ++d) {
@@ -360,6 +828,35 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     for (const hy_segment& s : rows_of->host_segments) if (s.size > 65536) return HY_OK;
   }
   hipStream_t stream = current_stream();
+  // ---- the aggregate inside the join (star_finish): which columns it reads ----------------------------------------------------------------
+  struct FinishPlan {
+    bool on = false;
+    std::vector<const hy_column*> fact;                                  // distinct fact-table columns
+    std::vector<std::pair<uint32_t, const hy_column*>> attributes;       // distinct (dimension, column)
+    std::vector<std::unique_ptr<DeviceBuffer>> attribute_tables;
+    DeviceBuffer table;                                                  // flags | tags | counts | first | last | keys | values
+  } plan;
+  plan.on = groups && star_finish_applies(finish, n_dimensions, shape);
+  auto plan_column = [&](const StarFinishColumnSpec& c) {
+    if (!c.column) return;
+    if (c.table == 0) { if (std::find(plan.fact.begin(), plan.fact.end(), c.column) == plan.fact.end()) plan.fact.push_back(c.column); }
+    else if (std::find(plan.attributes.begin(), plan.attributes.end(), std::make_pair(c.table - 1, c.column)) == plan.attributes.end()) plan.attributes.emplace_back(c.table - 1, c.column);
+  };
+  if (plan.on) {
+    for (uint32_t g = 0; g < finish->n_groupby; ++g) plan_column(finish->groupby[g]);
+    for (uint32_t g = 0; g < finish->n_aggregates; ++g) {
+      plan_column(finish->aggregates[g].left);
+      if (finish->aggregates[g].op != HY_STAR_NO_OP) plan_column(finish->aggregates[g].right);
+    }
+    plan.on = plan.fact.size() <= STAR_FINISH_FACT_COLUMNS && plan.attributes.size() <= STAR_FINISH_ATTRIBUTES;
+    for (const hy_column* c : plan.fact) plan.on = plan.on && c->n_slices == shape->n_slices;
+  }
+  constexpr size_t FINISH_TAGS_BYTES = 4 * size_t{STAR_FINISH_GLOBAL_SLOTS}, FINISH_KEYS_BYTES = 8 * size_t{STAR_FINISH_GLOBAL_SLOTS} * STAR_FINISH_KEYS;
+  constexpr size_t FINISH_VALUES_BYTES = 8 * size_t{STAR_FINISH_GLOBAL_SLOTS} * STAR_FINISH_AGGREGATES;
+  if (plan.on) {
+    HY_TRY(plan.table.alloc(64 + 4 * FINISH_TAGS_BYTES + FINISH_KEYS_BYTES + FINISH_VALUES_BYTES));
+    HY_HIP(hipMemsetAsync(plan.table.ptr, 0, 64 + FINISH_TAGS_BYTES, stream));   // flags and tags
+  }
   // ---- the dimensions' key ranges: the extent of the whole key column (a superset of its filtered rows' keys), remembered by the column --
   // one look at the keys and one host read the first time a column serves as a dimension key, none afterwards ------------------------------
   std::vector<uint64_t> extent(2 * size_t{n_dimensions});
@@ -431,9 +928,38 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   }
   for (uint32_t d = 0; d < n_dimensions; ++d) if (built[d]->empty) { jobs.n[d] = 0; jobs.n_in_memory[d] = nullptr; }
   if (!nothing_joins) hipLaunchKernelGGL(star_dim_fill, dim3(job_grid, n_dimensions), dim3(256), 0, stream, jobs, duplicate.as<uint32_t>());
+  if (!nothing_joins && plan.on && !plan.attributes.empty()) {   // what the aggregate reads of the dimensions, per key
+    StarAttributeJobs attribute_jobs;
+    std::memset(&attribute_jobs, 0, sizeof(attribute_jobs));
+    for (size_t k = 0; k < plan.attributes.size(); ++k) {
+      const uint32_t d = plan.attributes[k].first;
+      const hy_column* column = plan.attributes[k].second;
+      plan.attribute_tables.push_back(std::make_unique<DeviceBuffer>());
+      HY_TRY(plan.attribute_tables.back()->alloc(8 * (built[d]->range + 1) + 16));
+      attribute_jobs.key_segments[k] = jobs.segments[d];
+      attribute_jobs.segments[k] = column->d_segments;
+      attribute_jobs.rows[k] = jobs.rows[d];
+      attribute_jobs.n[k] = jobs.n[d];
+      attribute_jobs.n_in_memory[k] = jobs.n_in_memory[d];
+      attribute_jobs.key_min[k] = jobs.key_min[d];
+      attribute_jobs.out[k] = plan.attribute_tables.back()->as<int64_t>();
+    }
+    hipLaunchKernelGGL(star_dim_attributes, dim3(job_grid, static_cast<uint32_t>(plan.attributes.size())), dim3(256), 0, stream, attribute_jobs,
+                       reinterpret_cast<uint32_t*>(plan.table.ptr) + STAR_FLAG_NULL_ATTRIBUTE);
+  }
   dimension_rows.clear();
   dimension_rows.resize(n_dimensions);
   if (nothing_joins) {   // (still "applicable": the join result is empty)
+    if (plan.on) {   // ... and so is the aggregate's
+      for (uint32_t g = 0; g < finish->n_aggregates; ++g) {
+        const auto& spec = finish->aggregates[g];
+        groups->input_type[g] = !spec.left.column ? static_cast<uint32_t>(HY_TYPE_LONG) : spec.op == HY_STAR_NO_OP ? spec.left.column->data_type : expression_common_type(spec.left.column->data_type, spec.right.column->data_type);
+      }
+      groups->keys.clear(); groups->first.clear(); groups->last.clear(); groups->values.clear(); groups->counts.clear();
+      groups->done = true;
+      *applicable = true;
+      return HY_OK;
+    }
     HY_TRY(fact_rows.alloc(sizeof(hy_row_id)));
     for (uint32_t d = 0; d < n_dimensions; ++d) { dimension_rows[d] = std::make_unique<DeviceBuffer>(); HY_TRY(dimension_rows[d]->alloc(sizeof(hy_row_id))); }
     *applicable = true;
@@ -494,10 +1020,120 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   hipLaunchKernelGGL(star_scan_counts, dim3(1), dim3(1024), 0, stream, counts.as<uint32_t>(), base.as<uint64_t>(), a.n_tiles);
   uint64_t total = 0;
   uint32_t key_twice = 0;
-  HY_HIP(hipMemcpyAsync(&total, base.as<uint64_t>() + a.n_tiles, 8, hipMemcpyDeviceToHost, stream));
-  HY_HIP(hipMemcpyAsync(&key_twice, duplicate.ptr, 4, hipMemcpyDeviceToHost, stream));
-  HY_HIP(hipStreamSynchronize(stream));
-  if (key_twice) return HY_OK;   // a dimension key that is not unique: JoinHash's business
+  if (plan.on) {
+    // ---- the aggregate, where the survivors are (star_finish): one host read for the whole plan -------------------------------------------
+    StarFinishArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.n_groupby = finish->n_groupby;
+    f.n_aggregates = finish->n_aggregates;
+    f.n_fact = static_cast<uint32_t>(plan.fact.size());
+    f.n_attributes = static_cast<uint32_t>(plan.attributes.size());
+    // (entries past the plan's repeat entry 0 -- or, where the plan reads no fact column / no dimension column, the first foreign key and the
+    //  finish's own table: loads that go somewhere valid and whose result nobody looks at)
+    for (uint32_t c = 0; c < STAR_FINISH_FACT_COLUMNS; ++c) {
+      const hy_column* column = plan.fact.empty() ? shape : plan.fact[c < plan.fact.size() ? c : 0];
+      f.fact_views[c] = column->d_slice_views;
+      f.fact_segments[c] = column->d_segments;
+      f.fact_slot[c] = c < plan.fact.size() ? c : 0;
+      if (c < plan.fact.size() && !star_reads_fact_key(column)) f.fact_generic |= 1u << c;
+    }
+    if (plan.fact.empty()) f.n_fact = 1;   // (the views of the first foreign key are staged in its place)
+    for (uint32_t k = 0; k < STAR_FINISH_ATTRIBUTES; ++k) {
+      if (plan.attributes.empty()) { f.attributes[k] = reinterpret_cast<const int64_t*>(plan.table.ptr); f.attribute_slot[k] = 0; f.attribute_key_min[k] = a.table[0].key_min; f.attribute_mask[k] = 0; continue; }
+      const size_t from = k < plan.attributes.size() ? k : 0;
+      f.attributes[k] = plan.attribute_tables[from]->as<int64_t>();
+      f.attribute_slot[k] = slot_of[plan.attributes[from].first];
+      f.attribute_key_min[k] = a.table[f.attribute_slot[k]].key_min;
+      f.attribute_mask[k] = 0xFFFFFFFFu;
+    }
+    auto wire = [&](StarFinishColumn& out, const StarFinishColumnSpec& in) {
+      out.kind = STAR_COLUMN_NONE;
+      out.data_type = in.column ? in.column->data_type : static_cast<uint32_t>(HY_TYPE_LONG);
+      if (!in.column) return;
+      if (in.table == 0) {
+        out.kind = STAR_COLUMN_FACT;
+        out.index = static_cast<uint32_t>(std::find(plan.fact.begin(), plan.fact.end(), in.column) - plan.fact.begin());
+      } else {
+        out.kind = STAR_COLUMN_DIMENSION;
+        out.index = static_cast<uint32_t>(std::find(plan.attributes.begin(), plan.attributes.end(), std::make_pair(in.table - 1, in.column)) - plan.attributes.begin());
+        out.table = slot_of[in.table - 1];
+      }
+    };
+    for (uint32_t g = 0; g < f.n_groupby; ++g) wire(f.groupby[g], finish->groupby[g]);
+    for (uint32_t g = 0; g < f.n_aggregates; ++g) {
+      const auto& spec = finish->aggregates[g];
+      StarFinishAggregate& out = f.aggregates[g];
+      out.function = spec.function;
+      out.op = spec.left.column ? spec.op : HY_STAR_NO_OP;
+      wire(out.left, spec.left);
+      if (out.op != HY_STAR_NO_OP) wire(out.right, spec.right);
+      out.type = !spec.left.column ? static_cast<uint32_t>(HY_TYPE_LONG) : out.op == HY_STAR_NO_OP ? spec.left.column->data_type : expression_common_type(spec.left.column->data_type, spec.right.column->data_type);
+      groups->input_type[g] = out.type;
+    }
+    f.capacity = STAR_FINISH_GLOBAL_SLOTS;
+    char* at = plan.table.as<char>();
+    f.flags = reinterpret_cast<uint32_t*>(at);                at += 64;
+    f.tags = reinterpret_cast<uint32_t*>(at);                 at += FINISH_TAGS_BYTES;
+    f.counts = reinterpret_cast<uint32_t*>(at);               at += FINISH_TAGS_BYTES;
+    f.first = reinterpret_cast<uint32_t*>(at);                at += FINISH_TAGS_BYTES;
+    f.last = reinterpret_cast<uint32_t*>(at);                 at += FINISH_TAGS_BYTES;
+    f.keys = reinterpret_cast<uint64_t*>(at);                 at += FINISH_KEYS_BYTES;
+    f.values = reinterpret_cast<uint64_t*>(at);
+    constexpr size_t G = STAR_FINISH_MAX_GROUPS;
+    const size_t staged_bytes = 64 + 8 * G * (STAR_FINISH_KEYS + STAR_FINISH_AGGREGATES + 3);
+    unsigned char* staged_host = nullptr;
+    unsigned char* staged_dev = nullptr;
+    HY_TRY(pinned_staging(staged_bytes, reinterpret_cast<void**>(&staged_host), reinterpret_cast<void**>(&staged_dev)));
+    auto arrays = [&](unsigned char* block, uint64_t** keys, uint64_t** first, uint64_t** last, uint64_t** values, uint64_t** group_counts) {
+      *keys = reinterpret_cast<uint64_t*>(block + 64);
+      *first = *keys + G * STAR_FINISH_KEYS;
+      *last = *first + G;
+      *values = *last + G;
+      *group_counts = *values + G * STAR_FINISH_AGGREGATES;
+    };
+    static OncePerDevice finish_lds_raised;
+    uint64_t finish_bit = 0;
+    if (finish_lds_raised.pending(&finish_bit)) {
+      HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_finish), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(star_finish_lds_bytes(STAR_FINISH_AGGREGATES))));
+      finish_lds_raised.done(finish_bit);
+    }
+    const uint32_t tile_groups = (a.n_tiles + STAR_EMIT_TILES - 1) / STAR_EMIT_TILES;
+    profile_begin(stream, HY_KERNEL_AGGREGATE);
+    hipLaunchKernelGGL(star_finish, dim3(std::max(1u, std::min(tile_groups, 2 * device_cu_count()))), dim3(STAR_FINISH_THREADS), star_finish_lds_bytes(f.n_aggregates), stream, a, f);
+    profile_end(stream);
+    uint64_t *d_keys, *d_first, *d_last, *d_values, *d_counts;
+    arrays(staged_dev, &d_keys, &d_first, &d_last, &d_values, &d_counts);
+    hipLaunchKernelGGL(star_finish_compact, dim3(f.capacity / 256), dim3(256), 0, stream, a, f, duplicate.as<uint32_t>(), reinterpret_cast<StarFinishHeader*>(staged_dev), d_keys, d_first, d_last, d_values, d_counts);
+    HY_HIP(hipGetLastError());
+    HY_HIP(hipStreamSynchronize(stream));
+    StarFinishHeader header;
+    std::memcpy(&header, staged_host, sizeof(header));
+    if (header.key_twice) return HY_OK;   // a dimension key that is not unique: JoinHash's business
+    total = header.total;
+    if (!header.refused) {
+      uint64_t *h_keys, *h_first, *h_last, *h_values, *h_counts;
+      arrays(staged_host, &h_keys, &h_first, &h_last, &h_values, &h_counts);
+      const size_t n = header.n_groups;
+      groups->n_groups = header.n_groups;
+      groups->keys.assign(h_keys, h_keys + n * STAR_FINISH_KEYS);
+      groups->first.assign(h_first, h_first + n);
+      groups->last.assign(h_last, h_last + n);
+      groups->values.assign(h_values, h_values + n * STAR_FINISH_AGGREGATES);
+      groups->counts.assign(h_counts, h_counts + n);
+      groups->done = true;
+      dimension_rows.clear();
+      dimension_rows.resize(n_dimensions);
+      *n_rows = total;
+      *applicable = true;
+      return HY_OK;
+    }
+    // (a NULL cell, a division by zero, more groups than the tables hold: the RowIDs after all)
+  } else {
+    HY_HIP(hipMemcpyAsync(&total, base.as<uint64_t>() + a.n_tiles, 8, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipMemcpyAsync(&key_twice, duplicate.ptr, 4, hipMemcpyDeviceToHost, stream));
+    HY_HIP(hipStreamSynchronize(stream));
+    if (key_twice) return HY_OK;   // a dimension key that is not unique: JoinHash's business
+  }
   // ---- the survivors' RowIDs -------------------------------------------------------------------------------------------------------
   HY_TRY(fact_rows.alloc(sizeof(hy_row_id) * std::max<uint64_t>(1, total)));
   a.fact_rows = fact_rows.as<hy_row_id>();

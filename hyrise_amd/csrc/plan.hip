@@ -20,7 +20,7 @@
 
 namespace hy {
 
-static thread_local int t_last_star_was_fused = 0;   // debug / tests: the thread's last hy_star_join_aggregate took the fused probe
+static thread_local int t_last_star_was_fused = 0;   // debug / tests: the thread's last hy_star_join_aggregate took the fused probe (2: and grouped inside it)
 
 constexpr uint32_t DENSE_CHUNK = 65536;   // rows per chunk of an intermediate table (chunks start on 16-byte boundaries for every type; smaller chunks -- more,
                                           // smaller slices for the aggregate -- were tried: 2048-row chunks cost more on the host, 700 descriptors per column, than they gave)
@@ -195,6 +195,48 @@ static hy_status join_inner(const hy_column* build, const hy_column* probe, Join
   return fail(HY_ERR_CAPACITY, "hy_star_join_aggregate: a join did not fit the capacity it asked for");
 }
 
+// The groups star_finish left (join_star.hpp) -> the aggregate's result, by AggregateHash's rules as hy_aggregate_hash applies them to the
+// join result (aggregate.hip run_aggregate): rows ordered by the groups' first rows, or by ascending key under the immediate-key shortcut
+// (one int GROUP BY column whose key range is below 1.2 x the rows, aggregate_hash.cpp:388-401, 770-804: the representative row is then the
+// group's LAST row); representative rows as RowIDs of the intermediate table the chain would have aggregated (DENSE_CHUNK rows per chunk);
+// result types of window_function_traits.hpp:11-77.  No cell is NULL (star_finish refuses NULL inputs).
+static hy_status write_star_groups(const StarFinishGroups& groups, const hy_star_column* groupby, uint32_t n_groupby, const hy_star_aggregate* aggregates, uint32_t n_aggregates,
+                                   uint64_t n_rows, hy_aggregate_result* result) {
+  const uint32_t n = groups.n_groups;
+  result->n_groups = n;
+  if (n > result->group_capacity) return fail(HY_ERR_CAPACITY, "aggregate produces %u groups, capacity is %u", n, result->group_capacity);
+  bool immediate = false;
+  auto sort_key_of = [&](uint32_t i) { return static_cast<uint64_t>(static_cast<int64_t>(groups.keys[size_t{i} * 4]) - static_cast<int64_t>(INT32_MIN)) + 1; };
+  if (n_groupby == 1 && groupby[0].column->data_type == HY_TYPE_INT && n) {
+    uint64_t min_key = ~0ull, max_key = 0;
+    for (uint32_t i = 0; i < n; ++i) { min_key = std::min(min_key, sort_key_of(i)); max_key = std::max(max_key, sort_key_of(i)); }
+    immediate = max_key > 0 && static_cast<double>(max_key - min_key) < static_cast<double>(n_rows) * 1.2;
+  }
+  std::vector<uint32_t> order(n);
+  for (uint32_t i = 0; i < n; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return immediate ? sort_key_of(x) < sort_key_of(y) : groups.first[x] < groups.first[y]; });
+  for (uint32_t o = 0; o < n && result->group_row_ids; ++o) {
+    const uint64_t row = immediate ? groups.last[order[o]] : groups.first[order[o]];
+    result->group_row_ids[o] = hy_row_id{static_cast<uint32_t>(row / DENSE_CHUNK), static_cast<uint32_t>(row % DENSE_CHUNK)};
+  }
+  for (uint32_t g = 0; g < n_aggregates; ++g) {
+    hy_aggregate_column& col = result->columns[g];
+    const uint32_t function = aggregates[g].function, in_type = groups.input_type[g];
+    col.data_type = function == HY_AGG_COUNT ? static_cast<uint32_t>(HY_TYPE_LONG) : function == HY_AGG_AVG ? static_cast<uint32_t>(HY_TYPE_DOUBLE) : function == HY_AGG_SUM ? static_cast<uint32_t>(HY_TYPE_LONG) : in_type;
+    if (!col.values) return fail(HY_ERR_INVALID, "aggregate %u: values buffer missing", g);
+    for (uint32_t o = 0; o < n; ++o) {
+      const int64_t value = static_cast<int64_t>(groups.values[size_t{order[o]} * 8 + g]);
+      const uint64_t count = groups.counts[order[o]];
+      if (col.is_null) col.is_null[o] = 0;
+      if (function == HY_AGG_COUNT) static_cast<int64_t*>(col.values)[o] = static_cast<int64_t>(count);
+      else if (function == HY_AGG_AVG) static_cast<double*>(col.values)[o] = static_cast<double>(value) / static_cast<double>(count);   // (the chain adds doubles of integers: exact below 2^53)
+      else if (col.data_type == HY_TYPE_INT) static_cast<int32_t*>(col.values)[o] = static_cast<int32_t>(value);
+      else static_cast<int64_t*>(col.values)[o] = value;
+    }
+  }
+  return HY_OK;
+}
+
 }  // namespace hy
 
 using namespace hy;
@@ -282,8 +324,28 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
     if (shape_ok) {
       auto fact_rows = std::make_unique<DeviceBuffer>();
       std::vector<std::unique_ptr<DeviceBuffer>> rows_of_dimension;
-      HY_TRY(star_probe_rows(probes.data(), n_dimensions, *fact_rows, rows_of_dimension, &n_rows, &fused));
-      t_last_star_was_fused = fused ? 1 : 0;
+      // the aggregate inside the join, where its shape allows (star_finish, join_star.hpp; star_probe_rows checks the columns)
+      StarFinishRequest finish;
+      std::memset(&finish, 0, sizeof(finish));
+      StarFinishGroups finished;
+      const bool ask = result->mem == HY_MEM_HOST && n_groupby >= 1 && n_groupby <= 4 && n_aggregates <= 8;
+      if (ask) {
+        finish.n_groupby = n_groupby;
+        finish.n_aggregates = n_aggregates;
+        for (uint32_t g = 0; g < n_groupby; ++g) finish.groupby[g] = StarFinishColumnSpec{groupby[g].table, groupby[g].column};
+        for (uint32_t g = 0; g < n_aggregates; ++g) {
+          finish.aggregates[g].function = aggregates[g].function;
+          finish.aggregates[g].op = aggregates[g].op;
+          finish.aggregates[g].left = StarFinishColumnSpec{aggregates[g].left.table, aggregates[g].left.column};
+          finish.aggregates[g].right = StarFinishColumnSpec{aggregates[g].right.table, aggregates[g].op != HY_STAR_NO_OP ? aggregates[g].right.column : nullptr};
+        }
+      }
+      HY_TRY(star_probe_rows(probes.data(), n_dimensions, *fact_rows, rows_of_dimension, &n_rows, &fused, ask ? &finish : nullptr, ask ? &finished : nullptr));
+      t_last_star_was_fused = fused ? (finished.done ? 2 : 1) : 0;
+      if (fused && finished.done) {
+        if (joined_rows) *joined_rows = n_rows;
+        return write_star_groups(finished, groupby, n_groupby, aggregates, n_aggregates, n_rows, result);
+      }
       if (fused) {
         carried[0] = std::move(fact_rows);
         carried_rows[0] = carried[0]->as<hy_row_id>();
@@ -407,7 +469,8 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
   return status;
 }
 
-// debug / tests only: 1 = the calling thread's last hy_star_join_aggregate probed every dimension in one pass (csrc/join_star.hpp)
+// debug / tests only: 1 = the calling thread's last hy_star_join_aggregate probed every dimension in one pass (csrc/join_star.hpp), 2 = and grouped
+// the survivors inside that pass (star_finish)
 int hy_debug_star_fused(void) { return t_last_star_was_fused; }
 
 }  // extern "C"

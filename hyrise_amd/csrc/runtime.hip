@@ -32,6 +32,7 @@ struct OptionDefaults {
     set(HY_OPT_FUSED_SMALL_DOMAIN, 1);
     set(HY_OPT_SCAN_TWO_COLUMNS, 1);
     set(HY_OPT_STAR_FUSED_PROBE, 1);
+    set(HY_OPT_STAR_FUSED_FINISH, 1);
   }
 };
 OptionDefaults g_option_defaults;   // (static initialisation: before any entry point can run)

@@ -295,7 +295,9 @@ enum {
   HY_OPT_SCAN_TWO_COLUMNS = 13,      /* 1    ColumnVsColumn over two data columns of W-byte vectors: the two-stream kernel with the chunks' dictionaries in LDS */
   HY_OPT_STAR_FUSED_PROBE = 14,      /* 1    hy_star_join_aggregate probes every dimension in ONE pass over the fact table (csrc/join_star.hpp) where the
                                       *      shape allows; 0 = one hy_join_hash per dimension                                                      */
-  HY_OPT_COUNT = 15
+  HY_OPT_STAR_FUSED_FINISH = 15,     /* 1    ... and groups the survivors where it finds them (star_finish) where every GROUP BY column and aggregate input
+                                      *      is an int / long column: no RowIDs, exports, projection, hy_aggregate_hash; 0 = those four steps     */
+  HY_OPT_COUNT = 16
   /* (rounds 4-5 had 33: launch shapes and store flavours whose A/B timings were flat twice are constants now -- csrc/hy_options.hpp --,
    *  the radix-partitioned join path, which lost to the rank table read in place by 1.7 x, is gone) */
 };
@@ -596,7 +598,10 @@ hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters
  * Where the shape allows (int32 primary keys with a range of at most 2^26 values, foreign keys as int32 values / FrameOfReference offsets
  * without NULLs) every dimension is probed in ONE pass over the fact table instead (csrc/join_star.hpp, HY_OPT_STAR_FUSED_PROBE): the join
  * result's rows -- and with them the groups, ordered by their first row -- then come in the fact table's row order, not in the order the
- * last JoinHash of the chain would leave them in.
+ * last JoinHash of the chain would leave them in.  Where, in addition, every GROUP BY column (one to four) and every aggregate input (at most
+ * four aggregates: MIN / MAX / SUM / AVG / COUNT) is an int / long column, the Projection and the AggregateHash happen inside that join
+ * (HY_OPT_STAR_FUSED_FINISH): the rows that survive every dimension are grouped where they are found; same groups, order, cells and
+ * representative rows as the steps it replaces.
  * Columns are named as (table, column): table 0 = the fact table, d + 1 = dimension d; every column is a DATA column (numeric, or a
  * dictionary of key names / join ids) of its table.  An aggregate reads `left` alone (op = HY_STAR_NO_OP), `left <op> right`
  * (HY_ARITH_*: hy_projection_arithmetic), or nothing (left.column = NULL: COUNT(*)).  *joined_rows: rows of the join result.

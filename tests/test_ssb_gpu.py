@@ -33,9 +33,13 @@ def test_ssb_query_on_device(device, query, sql):
     dimensions, star_groupby, star_aggregates = ssb.star_plan(columns, query)
     result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
     assert star_joined == joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == sqlite
-    assert star_was_fused() == 1   # (one pass over lineorder: csrc/join_star.hpp) ... and dimension by dimension:
+    assert star_was_fused() == 2   # (one pass over lineorder, the survivors grouped inside it: csrc/join_star.hpp star_finish) ...
     from hyrise_amd import abi
-    with abi.option(abi.OPT_STAR_FUSED_PROBE, 0):
+    finished = result_bytes(result, len(star_aggregates))
+    with abi.option(abi.OPT_STAR_FUSED_FINISH, 0):   # ... the survivors' RowIDs written and hy_aggregate_hash over the exported columns: the same bytes
+        result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
+    assert star_was_fused() == 1 and star_joined == joined and result_bytes(result, len(star_aggregates)) == finished
+    with abi.option(abi.OPT_STAR_FUSED_PROBE, 0):    # ... and dimension by dimension (the groups in the order of the last join's rows)
         result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
     assert star_was_fused() == 0 and star_joined == joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == sqlite
 
@@ -61,11 +65,14 @@ def test_ssb_scale_factor_one_on_device(device):
         want = ssb.result_rows(aggregate_groups(oracle, o_groupby, o_aggregates))
         assert joined == o_joined and got == want, f"Q{query}: operator chain on the device vs the CPU oracle"
         dimensions, star_groupby, star_aggregates = ssb.star_plan(columns, query)
-        for fused in (1, 0):
-            with abi.option(abi.OPT_STAR_FUSED_PROBE, fused):
+        same = {}
+        for fused in (2, 1, 0):
+            with abi.option(abi.OPT_STAR_FUSED_PROBE, 1 if fused else 0), abi.option(abi.OPT_STAR_FUSED_FINISH, 1 if fused == 2 else 0):
                 result, star_joined = star_join_aggregate(dimensions, star_groupby, star_aggregates)
             assert star_was_fused() == fused
             assert star_joined == o_joined and ssb.result_rows(ssb.star_groups(result, len(star_groupby))) == want, f"Q{query}: hy_star_join_aggregate (fused {fused}) vs the CPU oracle"
+            same[fused] = result_bytes(result, len(star_aggregates))
+        assert same[2] == same[1], f"Q{query}: grouped inside the join vs hy_aggregate_hash over the exported survivors: group order, representative rows, cells"
         rows = data.sqlite_result(sql)
         sqlite = sorted(((r[1], r[2]), r[0]) for r in rows) if query == "2.1" else sorted(((r[0], r[1]), r[2]) for r in rows)
         assert got == sqlite, f"Q{query}: SQLite"
@@ -89,13 +96,20 @@ def test_two_ranks_on_one_gpu_replicated_and_repartitioned_plans(device):
 
 
 def star_was_fused():
+    """0: one hy_join_hash per dimension; 1: every dimension probed in one pass; 2: ... and the survivors grouped inside it"""
     from hyrise_amd import abi
     lib = abi.load_library()
     lib.hy_debug_star_fused.restype = int
     return lib.hy_debug_star_fused()
 
 
-@pytest.mark.parametrize("fused", [1, 0], ids=["fused_probe", "join_by_join"])
+def result_bytes(result, n_aggregates):
+    """Everything hy_star_join_aggregate wrote: the groups in their order, representative RowIDs, every cell with its type and NULL flag."""
+    n = result.n_groups
+    return (n, result.row_ids[:n].tobytes(), [(result.columns[a].data_type, result.raw[a][:n].tobytes(), result.nulls[a][:n].tobytes()) for a in range(n_aggregates)])
+
+
+@pytest.mark.parametrize("fused", [2, 1, 0], ids=["fused_finish", "fused_probe", "join_by_join"])
 @pytest.mark.parametrize("case", ["filtered", "nothing_survives", "first_dimension_unfiltered", "dangling_foreign_keys"])
 def test_star_join_aggregate_small_tables(device, options, case, fused):
     """hy_star_join_aggregate on tables small enough to join with numpy: two dimensions (either may be unfiltered), foreign keys without a
@@ -131,9 +145,14 @@ def test_star_join_aggregate_small_tables(device, options, case, fused):
     groupby = [(1, c["a_group"]), (2, c["b_group"])]
     aggregates = [(abi.AGG_SUM, (0, c["x"]), None, None), (abi.AGG_SUM, (0, c["x"]), abi.ARITH_MUL, (0, c["y"])), (abi.AGG_COUNT, None, None, None),
                   (abi.AGG_MIN, groupby[0], None, None), (abi.AGG_MIN, groupby[1], None, None)]
-    options.set(abi.OPT_STAR_FUSED_PROBE, fused)
+    options.set(abi.OPT_STAR_FUSED_PROBE, 1 if fused else 0)
+    options.set(abi.OPT_STAR_FUSED_FINISH, 1 if fused == 2 else 0)
     result, joined = star_join_aggregate(dimensions, groupby, aggregates)
     assert star_was_fused() == fused   # (these tables are the fused probe's shape: int32 keys, unique per dimension, FrameOfReference foreign keys)
+    if fused == 2:   # the same bytes as hy_aggregate_hash over the exported survivors: group order, representative rows, types, cells
+        options.set(abi.OPT_STAR_FUSED_FINISH, 0)
+        other, _ = star_join_aggregate(dimensions, groupby, aggregates)
+        assert star_was_fused() == 1 and result_bytes(other, len(aggregates)) == result_bytes(result, len(aggregates))
     # numpy: positions of the partners, then the filters
     a_of = {int(k): i for i, k in enumerate(a_key)}
     b_of = {int(k): i for i, k in enumerate(b_key)}
@@ -181,7 +200,7 @@ def test_star_join_aggregate_refuses_null_cells(device):
             star_join_aggregate(dimensions(second_key), groupby, [(abi.AGG_SUM, (0, measure), None, None), (abi.AGG_MIN, groupby[0], None, None)])
         assert error.value.status == abi.ERR_UNSUPPORTED
     result, joined = star_join_aggregate(dimensions(column(fk_b)), groupby, [(abi.AGG_SUM, (0, x_plain), None, None), (abi.AGG_MIN, groupby[0], None, None)])
-    assert joined == n and result.n_groups == 200
+    assert joined == n and result.n_groups == 200 and star_was_fused() == 2
 
 
 def test_star_join_shapes_the_fused_probe_leaves_to_the_joins(device):
@@ -238,7 +257,80 @@ def test_star_join_shapes_the_fused_probe_leaves_to_the_joins(device):
     keys[0] = keys[0][keep]                      # (half of the big dimension's keys exist)
     groups = [(k % 3).astype(np.int32) for k in keys]
     foreign = [rng.integers(5, 15 + n, n_fact).astype(np.int32) for n in sizes]
-    assert run(keys, groups, foreign) == expected(keys, groups, foreign) and star_was_fused() == 1
+    assert run(keys, groups, foreign) == expected(keys, groups, foreign) and star_was_fused() == 1   # (five GROUP BY columns: not star_finish's shape)
+
+
+@pytest.mark.parametrize("case", ["immediate_key", "three_thousand_groups", "six_thousand_groups", "long_columns", "division_by_zero"])
+def test_star_finish_shapes(device, options, case):
+    """star_finish (the aggregate inside the fused probe) against hy_aggregate_hash over the exported survivors -- the same bytes -- and numpy:
+    one int GROUP BY column with a dense key range (the immediate-key shortcut: ascending keys, the LAST row represents a group), more
+    groups than a workgroup's LDS table holds (rows go to the global table), more than the compacted result holds (refused: the RowID
+    path answers), int64 columns, and an expression whose cell is NULL (x / 0: refused, the RowID path answers)."""
+    import numpy as np
+    from hyrise_amd import abi, storage
+    from hyrise_amd.operators import make_predicate, star_join_aggregate
+    from hyrise_amd.storage import DeviceColumn
+    rng = np.random.default_rng(len(case))
+    n_fact, n_a, n_b = 400_000, 8_000, 40
+    column = lambda values, encoding=abi.ENC_UNENCODED, chunk=30_000: DeviceColumn(storage.make_column(np.ascontiguousarray(values), None, encoding, chunk))
+    n_groups = {"immediate_key": 25, "three_thousand_groups": 1_000, "six_thousand_groups": 2_000}.get(case, 300)
+    wide = np.int64 if case == "long_columns" else np.int32
+    a_key = rng.permutation(n_a).astype(np.int32) + 17
+    a_group = (rng.integers(0, n_groups, n_a).astype(wide) - 3) * (1 << 33 if case == "long_columns" else 1)
+    a_filter = rng.integers(0, 10, n_a).astype(np.int32)
+    b_key = np.arange(n_b, dtype=np.int32) * 2
+    b_group = rng.integers(0, 3, n_b).astype(np.int32)
+    fk_a = a_key[rng.integers(0, n_a, n_fact)]
+    fk_b = rng.integers(0, 2 * n_b, n_fact).astype(np.int32)              # odd keys have no partner
+    x = (rng.integers(-50_000, 50_000, n_fact).astype(wide)) * (1 << 20 if case == "long_columns" else 1)
+    y = rng.integers(0 if case == "division_by_zero" else 1, 60, n_fact).astype(np.int32)
+    c = {"a_key": column(a_key, chunk=1_000), "a_group": column(a_group, abi.ENC_DICTIONARY if wide is np.int32 else abi.ENC_UNENCODED, 1_000), "a_filter": column(a_filter, abi.ENC_DICTIONARY, 1_000),
+         "b_key": column(b_key, chunk=16), "b_group": column(b_group, abi.ENC_FRAME_OF_REFERENCE, 16), "fk_a": column(fk_a, abi.ENC_FRAME_OF_REFERENCE), "fk_b": column(fk_b),
+         "x": column(x, abi.ENC_UNENCODED if wide is np.int64 else abi.ENC_FRAME_OF_REFERENCE), "y": column(y, abi.ENC_DICTIONARY)}
+    dimensions = [(c["a_key"], c["a_filter"], make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 8), c["fk_a"]), (c["b_key"], None, None, c["fk_b"])]
+    groupby = [(1, c["a_group"])] if case in ("immediate_key", "long_columns") else [(1, c["a_group"]), (2, c["b_group"])]
+    op = abi.ARITH_DIV if case == "division_by_zero" else abi.ARITH_SUB
+    aggregates = [(abi.AGG_SUM, (0, c["x"]), op, (0, c["y"])), (abi.AGG_MIN, (0, c["x"]), None, None), (abi.AGG_MAX, (0, c["y"]), None, None), (abi.AGG_AVG, (0, c["x"]), None, None),
+                  (abi.AGG_COUNT, (0, c["y"]), None, None), (abi.AGG_COUNT, None, None, None), (abi.AGG_MIN, (1, c["a_group"]), None, None), (abi.AGG_MAX, (2, c["b_group"]), None, None)]
+    capacity = 32_768
+    result, joined = star_join_aggregate(dimensions, groupby, aggregates, group_capacity=capacity)
+    assert star_was_fused() == (1 if case in ("six_thousand_groups", "division_by_zero") else 2)   # (refused: the RowID path answered)
+    options.set(abi.OPT_STAR_FUSED_FINISH, 0)
+    other, other_joined = star_join_aggregate(dimensions, groupby, aggregates, group_capacity=capacity)
+    assert star_was_fused() == 1 and other_joined == joined and result_bytes(other, len(aggregates)) == result_bytes(result, len(aggregates))
+    if case == "division_by_zero":   # (x / 0 is a NULL cell the chain's SUM skips; star_finish carries no NULLs and leaves the plan to the chain)
+        assert result.n_groups > 0
+        return
+    # numpy
+    ia = np.full(int(a_key.max()) + 1, -1, dtype=np.int64)
+    ia[a_key] = np.arange(n_a)
+    rows_a = ia[fk_a]
+    keep = (a_filter[rows_a] < 8) & (fk_b % 2 == 0)
+    assert joined == int(keep.sum())
+    ga, gb = a_group[rows_a][keep].astype(np.int64), b_group[fk_b[keep] // 2].astype(np.int64)
+    key = ga if len(groupby) == 1 else ga * 8 + gb
+    xs, ys = x[keep].astype(np.int64), y[keep].astype(np.int64)
+    diff = (x[keep] - y[keep].astype(wide)).astype(np.int64)               # (int - int is computed in int32: these values do not wrap)
+    want = {}
+    for k, d, xv, yv, gav, gbv in zip(key.tolist(), diff.tolist(), xs.tolist(), ys.tolist(), ga.tolist(), gb.tolist()):
+        cell = want.setdefault(k, [0, xv, yv, 0, 0, 0, gav, gbv])
+        cell[0] += d
+        cell[1] = min(cell[1], xv)
+        cell[2] = max(cell[2], yv)
+        cell[3] += xv
+        cell[4] += 1
+        cell[5] += 1
+        cell[7] = max(cell[7], gbv)
+    n = result.n_groups
+    assert n == len(want)
+    columns = [result.column(a) for a in range(len(aggregates))]
+    for i in range(n):
+        k = columns[6][i] if len(groupby) == 1 else columns[6][i] * 8 + columns[7][i]
+        w = want[k]
+        assert [columns[a][i] for a in (0, 1, 2, 4, 5, 6)] == [w[0], w[1], w[2], w[4], w[5], w[6]] and columns[3][i] == w[3] / w[4]
+        assert len(groupby) == 1 or columns[7][i] == w[7]
+    if case == "immediate_key":
+        assert columns[6] == sorted(columns[6])                            # ascending keys
 
 
 @pytest.mark.parametrize("key_layout", ["bit_packed_dictionary", "run_length", "bit_packed_frame_of_reference"])
