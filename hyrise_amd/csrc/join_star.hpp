@@ -141,62 +141,114 @@ __device__ __forceinline__ uint32_t star_test_words(const u32x4_t (&words)[2], u
   return found;
 }
 
+// A tile's stored words of every LDS-resident dimension's foreign key, requested without a branch and without a load under a condition (what
+// the kernel below asks for one tile AHEAD: a load on some control-flow paths only makes the compiler wait for everything in flight where the
+// paths meet -- the prefetch would be waited for where it is issued).  Words as load_batch_words leaves them.  1-byte offsets: sixteen bytes
+// from eight rows back (the lane's are the upper half) or, for the slice's first rows, from the front; 2-byte offsets: the sixteen bytes; 4-byte
+// words: two loads -- the narrower kinds repeat their first.  The block minimum: of the lane's first row; plain int32 values read the word at
+// the front of the data instead, not used.
+struct StarTileWords {
+  u32x4_t words[STAR_LDS_DIMENSIONS][2];
+  uint32_t bias[STAR_LDS_DIMENSIONS];
+};
+// A view every lane reads alike, through the scalar cache (constant address space: the tables are written by hy_column_create, long before) --
+// as a vector load it would queue behind the tile's data loads and waiting for it would wait for them.
+__device__ __forceinline__ SliceView star_uniform_view(const SliceView* view) {
+  typedef __attribute__((address_space(4))) const uint64_t constant_u64;
+  const uint64_t address = reinterpret_cast<uint64_t>(view);
+  constant_u64* q = (constant_u64*)(static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(address >> 32)))) << 32 |
+                                    static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(address))));
+  const uint64_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+  SliceView v;
+  v.data = reinterpret_cast<const void*>(w0);
+  v.aux = reinterpret_cast<const void*>(w1);
+  v.chunk = static_cast<uint32_t>(w2);
+  v.row_begin = static_cast<uint32_t>(w2 >> 32);
+  v.row_count = static_cast<uint32_t>(w3);
+  v.kind = static_cast<uint32_t>(w3 >> 32);
+  return v;
+}
+__device__ __forceinline__ void star_request_tile(const StarArgs& a, uint32_t tile, uint32_t first, StarTileWords& t, uint32_t (&kind)[STAR_LDS_DIMENSIONS], uint32_t* rows) {
+  typedef __attribute__((address_space(1))) const u32x4_t global_quad;
+  typedef __attribute__((address_space(1))) const uint32_t global_word;
+  *rows = star_uniform_view(a.table[0].views + tile).row_count;
+#pragma unroll
+  for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
+    const SliceView view = star_uniform_view(a.table[d < a.n_lds ? d : 0].views + tile);
+    kind[d] = view.kind;
+    const uint32_t width = view.kind == VIEW_FOR8 ? 1u : view.kind == VIEW_FOR16 ? 2u : 4u;
+    const uint32_t row = view.row_begin + (first < view.row_count ? first : 0u);
+    const uint32_t back = width == 1 && row >= 8 ? 8u : 0u;
+    const char* at = static_cast<const char*>(view.data) + row * width - back;
+    const u32x4_t v0 = *(global_quad*)at;
+    const u32x4_t v1 = *(global_quad*)(at + (width == 4 ? 16 : 0));
+    const bool biased = view.kind != VIEW_INT32;
+    global_word* minima = (global_word*)(biased ? view.aux : view.data);
+    t.bias[d] = minima[biased ? row / HY_FOR_BLOCK_SIZE : 0u];
+    t.words[d][0] = back ? u32x4_t{v0.z, v0.w, 0, 0} : v0;
+    t.words[d][1] = v1;
+  }
+}
+
+// Which of the tile's rows survive every dimension -> masks[tile], counts[tile] (two barriers)
+__device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile, uint32_t tid, uint32_t first, const StarTileWords& t, const uint32_t (&kind)[STAR_LDS_DIMENSIONS], uint32_t rows,
+                                                const uint32_t* s_star_bits, uint32_t* s_count) {
+  const uint32_t lane = tid & 63;
+  if (tid == 0) *s_count = 0;
+  __syncthreads();   // (the bits are staged; the count of the tile before has been written)
+  uint32_t alive = first >= rows ? 0u : (rows - first < 8 ? (1u << (rows - first)) - 1u : 0xFFu);
+#pragma unroll
+  for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
+    if (d >= a.n_lds) continue;
+    const uint32_t* bits = s_star_bits + a.table[d].lds_word;
+    const uint32_t bias = kind[d] == VIEW_INT32 ? 0u : t.bias[d];
+    alive &= kind[d] == VIEW_FOR8 ? star_test_words<1>(t.words[d], bias, a.table[d], bits) : kind[d] == VIEW_FOR16 ? star_test_words<2>(t.words[d], bias, a.table[d], bits)
+                                                                                                                   : star_test_words<4>(t.words[d], bias, a.table[d], bits);
+  }
+  // the dimensions whose bits did not fit: asked in global memory, the rows that are still alive only
+  for (uint32_t d = a.n_lds; d < a.n_tables; ++d) {
+    if (!__any(alive != 0)) break;
+    const StarTable& table = a.table[d];
+    const SliceView view = table.views[tile];
+    uint32_t pending = alive;
+    while (pending) {
+      const uint32_t j = __ffs(pending) - 1;
+      pending &= pending - 1;
+      const uint32_t rel = static_cast<uint32_t>(view_key(view, view.row_begin + first + j)) - table.key_min;
+      if (rel > table.range || !((table.bits[rel >> 5] >> (rel & 31)) & 1u)) alive &= ~(1u << j);
+    }
+  }
+  a.masks[static_cast<size_t>(tile) * STAR_THREADS + tid] = static_cast<uint8_t>(alive);
+  uint32_t survivors = __popc(alive);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) survivors += __shfl_xor(survivors, d, 64);
+  if (lane == 0 && survivors) atomicAdd(s_count, survivors);
+  __syncthreads();
+  if (tid == 0) a.counts[tile] = *s_count;
+}
+
+// Persistent workgroups, a tile's words requested while the tile before is looked up (two fixed sets of registers, the loop unrolled by two:
+// rotating one set into the other would wait for the loads just issued).
 __global__ __launch_bounds__(STAR_THREADS) void star_probe_mask(StarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_star_bits[];
   __shared__ uint32_t s_count;
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t tid = threadIdx.x;
   for (uint32_t d = 0; d < a.n_lds; ++d) {
     const StarTable& table = a.table[d];
     for (uint32_t i = tid; i < table.words; i += STAR_THREADS) s_star_bits[table.lds_word + i] = table.bits[i];
   }
   const uint32_t first = tid * 8;
-  for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    if (tid == 0) s_count = 0;
-    __syncthreads();   // (the bits are staged; the count of the tile before has been written)
-    // the tile's stored words of every LDS-resident dimension's foreign key, all requested before the first is looked at
-    u32x4_t words[STAR_LDS_DIMENSIONS][2];
-    uint32_t bias[STAR_LDS_DIMENSIONS], kind[STAR_LDS_DIMENSIONS];
-    uint32_t rows = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
-      words[d][0] = words[d][1] = u32x4_t{0, 0, 0, 0};
-      bias[d] = kind[d] = 0;
-      if (d < a.n_lds) {
-        const SliceView view = a.table[d].views[tile];
-        star_load_words(view, first, words[d], &bias[d]);
-        kind[d] = view.kind;
-        rows = view.row_count;
-      }
-    }
-    if (a.n_lds == 0) rows = a.table[0].views[tile].row_count;
-    uint32_t alive = first >= rows ? 0u : (rows - first < 8 ? (1u << (rows - first)) - 1u : 0xFFu);
-#pragma unroll
-    for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
-      if (d >= a.n_lds) continue;
-      const uint32_t* bits = s_star_bits + a.table[d].lds_word;
-      alive &= kind[d] == VIEW_FOR8 ? star_test_words<1>(words[d], bias[d], a.table[d], bits) : kind[d] == VIEW_FOR16 ? star_test_words<2>(words[d], bias[d], a.table[d], bits)
-                                                                                                                     : star_test_words<4>(words[d], bias[d], a.table[d], bits);
-    }
-    // the dimensions whose bits did not fit: asked in global memory, the rows that are still alive only
-    for (uint32_t d = a.n_lds; d < a.n_tables; ++d) {
-      if (!__any(alive != 0)) break;
-      const StarTable& table = a.table[d];
-      const SliceView view = table.views[tile];
-      uint32_t pending = alive;
-      while (pending) {
-        const uint32_t j = __ffs(pending) - 1;
-        pending &= pending - 1;
-        const uint32_t rel = static_cast<uint32_t>(view_key(view, view.row_begin + first + j)) - table.key_min;
-        if (rel > table.range || !((table.bits[rel >> 5] >> (rel & 31)) & 1u)) alive &= ~(1u << j);
-      }
-    }
-    a.masks[static_cast<size_t>(tile) * STAR_THREADS + tid] = static_cast<uint8_t>(alive);
-    uint32_t survivors = __popc(alive);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) survivors += __shfl_xor(survivors, d, 64);
-    if (lane == 0 && survivors) atomicAdd(&s_count, survivors);
-    __syncthreads();
-    if (tid == 0) a.counts[tile] = s_count;
+  const uint32_t last_tile = a.n_tiles - 1;   // (a tile past the last: the last one's words once more, not used)
+  StarTileWords even, odd;
+  uint32_t kind_even[STAR_LDS_DIMENSIONS], kind_odd[STAR_LDS_DIMENSIONS], rows_even = 0, rows_odd = 0;
+  if (blockIdx.x < a.n_tiles) star_request_tile(a, blockIdx.x, first, even, kind_even, &rows_even);
+  for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += 2 * gridDim.x) {
+    const uint32_t next = tile + gridDim.x, after = tile + 2 * gridDim.x;
+    star_request_tile(a, next < a.n_tiles ? next : last_tile, first, odd, kind_odd, &rows_odd);
+    star_probe_tile(a, tile, tid, first, even, kind_even, rows_even, s_star_bits, &s_count);
+    if (next >= a.n_tiles) break;
+    star_request_tile(a, after < a.n_tiles ? after : last_tile, first, even, kind_even, &rows_even);
+    star_probe_tile(a, next, tid, first, odd, kind_odd, rows_odd, s_star_bits, &s_count);
   }
 }
 
@@ -340,7 +392,11 @@ __global__ __launch_bounds__(256) void star_emit_rows(StarArgs a) {
 // RowID path) and their first and last survivor as (tile << 13 | row in tile) -- monotone in the fact table's row order, i.e. in the order
 // of the join result's rows; star_finish_compact turns them into the survivors' ranks = the row numbers hy_aggregate_hash would have seen.
 constexpr uint32_t STAR_FINISH_KEYS = 4, STAR_FINISH_AGGREGATES = HY_MAX_STAR_AGGREGATES;
-constexpr uint32_t STAR_FINISH_THREADS = 512;
+#ifndef HY_STAR_FINISH_THREADS
+#define HY_STAR_FINISH_THREADS 256
+#endif
+constexpr uint32_t STAR_FINISH_THREADS = HY_STAR_FINISH_THREADS;          // four workgroups per CU: their phases (masks, keys, attributes: a round trip each) overlap
+constexpr uint32_t STAR_FINISH_LIST = 2048;            // survivors of a group of tiles looked at per pass
 constexpr uint32_t STAR_FINISH_SLOTS = 512;            // a workgroup's table in LDS
 constexpr uint32_t STAR_FINISH_GLOBAL_SLOTS = 1u << 14;
 constexpr uint32_t STAR_FINISH_MAX_GROUPS = 4096;      // what the compacted result holds (more: the RowID path)
@@ -354,6 +410,7 @@ enum : uint32_t { STAR_COLUMN_NONE = 0, STAR_COLUMN_FACT = 1, STAR_COLUMN_DIMENS
 // A column of the join result as star_finish reads it.  FACT: the fact table's column `index` of StarFinishArgs::fact (its slice's view, or cell by
 // cell where the view says VIEW_GENERIC).  DIMENSION: attribute table `index` -- the column's value per KEY of its dimension (star_dim_attributes),
 // asked with the fact row's foreign key to the table in slot `table`: one load behind the key instead of RowID -> descriptor -> value id -> value.
+struct StarDirectPlan;
 struct StarFinishColumn {
   uint32_t kind;
   uint32_t index;
@@ -380,6 +437,7 @@ struct StarFinishArgs {
   const int64_t* attributes[STAR_FINISH_ATTRIBUTES];
   uint32_t attribute_slot[STAR_FINISH_ATTRIBUTES];     // slot in StarArgs::table of the dimension whose key indexes the table
   uint32_t attribute_key_min[STAR_FINISH_ATTRIBUTES];
+  uint32_t debug;               // timing experiments (HY_DEBUG_SWITCHES builds, HY_STAR_DEBUG): 1 no survivor is looked at, 2 no table work, 4 no cells loaded
   uint32_t attribute_mask[STAR_FINISH_ATTRIBUTES];     // all ones; 0 where the plan reads no dimension column at all (entry 0 of a stand-in table)
   uint32_t capacity;            // global table (power of two)
   uint32_t* tags;
@@ -389,6 +447,8 @@ struct StarFinishArgs {
   uint32_t* first;              // [capacity] tile << 13 | row
   uint32_t* last;
   uint32_t* flags;              // STAR_FLAG_*
+  const long long* extent;      // star_dim_attributes' [attribute][2]
+  struct StarDirectPlan* direct;   // star_finish_plan's answer
 };
 struct StarFinishHeader {       // what the host reads after the plan's last kernel (pinned memory)
   uint32_t refused, n_groups, key_twice, reserved;
@@ -405,11 +465,13 @@ struct StarAttributeJobs {
   const uint64_t* n_in_memory[STAR_FINISH_ATTRIBUTES];
   int64_t key_min[STAR_FINISH_ATTRIBUTES];
   int64_t* out[STAR_FINISH_ATTRIBUTES];
+  long long* extent;            // [STAR_FINISH_ATTRIBUTES][2] smallest / largest value of every attribute (star_finish_plan: the direct-mapped groups)
 };
 __global__ __launch_bounds__(256) void star_dim_attributes(StarAttributeJobs jobs, uint32_t* null_met) {
   const uint32_t k = blockIdx.y;
   const hy_row_id* rows = jobs.rows[k];
   const uint64_t n = jobs.n_in_memory[k] ? *jobs.n_in_memory[k] : jobs.n[k];
+  long long low = INT64_MAX, high = INT64_MIN;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) {
     const hy_row_id row = rows[i];
     const Value key = column_value(jobs.key_segments[k], row.chunk_id, row.chunk_offset);
@@ -418,7 +480,16 @@ __global__ __launch_bounds__(256) void star_dim_attributes(StarAttributeJobs job
     if (v.is_null) { *null_met = 1; continue; }
     const uint32_t rel = static_cast<uint32_t>(key.i - jobs.key_min[k]);
     jobs.out[k][rel] = v.i;
+    low = v.i < low ? v.i : low;
+    high = v.i > high ? v.i : high;
   }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const long long other_low = __shfl_xor(low, d, 64), other_high = __shfl_xor(high, d, 64);
+    low = other_low < low ? other_low : low;
+    high = other_high > high ? other_high : high;
+  }
+  if ((threadIdx.x & 63) == 0 && low <= high) { atomicMin(jobs.extent + 2 * k, low); atomicMax(jobs.extent + 2 * k + 1, high); }
 }
 
 // Row `row` of the chunk a view describes, without a branch on the view's kind and without a conditional load (the loads of a survivor's
@@ -441,6 +512,48 @@ __device__ __forceinline__ int32_t star_view_value(const SliceView& view, uint32
 
 __device__ __forceinline__ uint64_t star_initial_value(uint32_t function) {
   return function == HY_AGG_MIN ? static_cast<uint64_t>(INT64_MAX) : function == HY_AGG_MAX ? static_cast<uint64_t>(INT64_MIN) : 0ull;
+}
+
+// Direct-mapped groups: where every GROUP BY column is a dimension's attribute and the product of the attributes' value ranges (of the rows
+// that pass the dimensions' filters: star_dim_attributes) is at most STAR_FINISH_SLOTS, a group's place in the tables IS the mixed-radix code of
+// its values -- no hash, no key comparison, no slot to claim (SSB Q2.1: 7 years x 40 brands, Q4.1: 7 years x 5 nations).  Decided on the
+// device (one workgroup, between the attribute tables and star_finish; nothing comes to the host): the answer, and the global table's
+// slots 0 .. n_codes - 1 initialised with their keys.
+struct StarDirectPlan {
+  uint32_t direct, n_codes;
+  uint32_t stride[STAR_FINISH_KEYS], range[STAR_FINISH_KEYS];
+  long long low[STAR_FINISH_KEYS];
+};
+__global__ __launch_bounds__(256) void star_finish_plan(StarFinishArgs f) {
+  __shared__ StarDirectPlan s_plan;
+  if (threadIdx.x == 0) {
+    StarDirectPlan p;
+    p.direct = 1;
+    uint64_t codes = 1;
+    for (uint32_t g = 0; g < STAR_FINISH_KEYS; ++g) {
+      p.stride[g] = 0; p.range[g] = 1; p.low[g] = 0;
+      if (g >= f.n_groupby) continue;
+      if (f.groupby[g].kind != STAR_COLUMN_DIMENSION) { p.direct = 0; continue; }
+      const long long low = f.extent[2 * f.groupby[g].index], high = f.extent[2 * f.groupby[g].index + 1];
+      if (low > high || static_cast<unsigned long long>(high - low) >= STAR_FINISH_SLOTS) { p.direct = 0; continue; }
+      p.low[g] = low;
+      p.range[g] = static_cast<uint32_t>(high - low) + 1;
+      p.stride[g] = static_cast<uint32_t>(codes);
+      codes *= p.range[g];
+      if (codes > STAR_FINISH_SLOTS) { p.direct = 0; codes = 1; }
+    }
+    p.n_codes = p.direct ? static_cast<uint32_t>(codes) : 0u;
+    s_plan = p;
+    *f.direct = p;
+  }
+  __syncthreads();
+  for (uint32_t code = threadIdx.x; code < s_plan.n_codes; code += 256) {
+    for (uint32_t g = 0; g < STAR_FINISH_KEYS; ++g) f.keys[size_t{code} * STAR_FINISH_KEYS + g] = g < f.n_groupby ? static_cast<uint64_t>(s_plan.low[g] + (code / s_plan.stride[g]) % s_plan.range[g]) : 0ull;
+    for (uint32_t g = 0; g < STAR_FINISH_AGGREGATES; ++g) f.values[size_t{code} * STAR_FINISH_AGGREGATES + g] = g < f.n_aggregates ? star_initial_value(f.aggregates[g].function) : 0ull;
+    f.counts[code] = 0;
+    f.first[code] = 0xFFFFFFFFu;
+    f.last[code] = 0;   // (the tags: zeroed with the flags)
+  }
 }
 
 __device__ __forceinline__ uint32_t star_tuple_hash(const uint64_t (&tuple)[STAR_FINISH_KEYS], uint32_t words) {
@@ -530,7 +643,7 @@ __device__ __forceinline__ uint32_t star_global_slot(const StarFinishArgs& f, co
 
 // (a slot's accumulators lie n_aggregates words apart: up to four aggregates leave room for two workgroups per CU)
 constexpr size_t star_finish_lds_bytes(uint32_t n_aggregates) {
-  return 4 * size_t{STAR_EMIT_LIST} + sizeof(SliceView) * STAR_EMIT_TILES * (HY_MAX_STAR_DIMENSIONS + STAR_FINISH_FACT_COLUMNS) +
+  return 4 * size_t{STAR_FINISH_LIST} + sizeof(SliceView) * STAR_EMIT_TILES * (HY_MAX_STAR_DIMENSIONS + STAR_FINISH_FACT_COLUMNS) +
          8 * size_t{STAR_FINISH_SLOTS} * (STAR_FINISH_KEYS + (n_aggregates ? n_aggregates : 1)) + 4 * size_t{STAR_FINISH_SLOTS} * 4 + 64;
 }
 
@@ -540,31 +653,82 @@ __global__ __launch_bounds__(STAR_FINISH_THREADS, 4) void star_finish(StarArgs a
   SliceView* s_views = reinterpret_cast<SliceView*>(s_keys + size_t{STAR_FINISH_SLOTS} * STAR_FINISH_KEYS);   // [tile][dimension]: the foreign keys' slices
   SliceView* s_fact_views = s_views + STAR_EMIT_TILES * HY_MAX_STAR_DIMENSIONS;                                 // [tile][fact column]
   uint32_t* s_list = reinterpret_cast<uint32_t*>(s_fact_views + STAR_EMIT_TILES * STAR_FINISH_FACT_COLUMNS);
-  uint32_t* s_tags = s_list + STAR_EMIT_LIST;
+  uint32_t* s_tags = s_list + STAR_FINISH_LIST;
   uint32_t* s_counts = s_tags + STAR_FINISH_SLOTS;
   uint32_t* s_first = s_counts + STAR_FINISH_SLOTS;
   uint32_t* s_last = s_first + STAR_FINISH_SLOTS;
-  uint32_t* s_wave = s_last + STAR_FINISH_SLOTS;   // [8] + [1] the workgroup gave up
+  uint32_t* s_wave = s_last + STAR_FINISH_SLOTS;   // [waves] + [1] the workgroup gave up
   uint64_t* s_values = reinterpret_cast<uint64_t*>(s_wave + 16);   // [STAR_FINISH_SLOTS][n_aggregates]
-  constexpr uint32_t WAVES = STAR_FINISH_THREADS / 64, WORDS = STAR_EMIT_TILES * SLICE_ROWS / 32 / STAR_FINISH_THREADS;   // mask words per thread: 4
+  constexpr uint32_t WAVES = STAR_FINISH_THREADS / 64, WORDS = STAR_EMIT_TILES * SLICE_ROWS / 32 / STAR_FINISH_THREADS;   // mask words per thread: 8
+  static_assert(WORDS % 4 == 0 && STAR_EMIT_TILES * (HY_MAX_STAR_DIMENSIONS + STAR_FINISH_FACT_COLUMNS) <= STAR_FINISH_THREADS, "a thread's mask words are 16-byte pieces; one view per thread");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (uint32_t i = tid; i < STAR_FINISH_SLOTS; i += STAR_FINISH_THREADS) s_tags[i] = 0;
+  // direct-mapped groups (star_finish_plan) or the hash table
+  const uint32_t n_codes = f.direct->n_codes;
+  const bool direct = f.direct->direct != 0;
+  uint32_t stride[STAR_FINISH_KEYS];
+  long long low[STAR_FINISH_KEYS];
+#pragma unroll
+  for (uint32_t g = 0; g < STAR_FINISH_KEYS; ++g) { stride[g] = f.direct->stride[g]; low[g] = f.direct->low[g]; }
+  for (uint32_t i = tid; i < STAR_FINISH_SLOTS; i += STAR_FINISH_THREADS) {
+    s_tags[i] = 0;
+    if (direct && i < n_codes) {
+      s_counts[i] = 0;
+      s_first[i] = 0xFFFFFFFFu;
+      s_last[i] = 0;
+      for (uint32_t g = 0; g < f.n_aggregates; ++g) s_values[i * f.n_aggregates + g] = star_initial_value(f.aggregates[g].function);
+    }
+  }
   if (tid == 0) s_wave[WAVES] = 0;
   const uint32_t n_groups_of_tiles = (a.n_tiles + STAR_EMIT_TILES - 1) / STAR_EMIT_TILES;
+  // A group of tiles costs a round trip for its masks and views before the first survivor is known: the NEXT group's are requested while this
+  // one's survivors are worked on.  Thread t < 64 stages the foreign-key view (tile t / 8, dimension t % 8), thread 64 <= t < 96 a fact column's.
+  const bool stages_key = tid < STAR_EMIT_TILES * HY_MAX_STAR_DIMENSIONS && (tid % HY_MAX_STAR_DIMENSIONS) < a.n_tables;
+  const uint32_t fact_index = tid - STAR_EMIT_TILES * HY_MAX_STAR_DIMENSIONS;
+  const bool stages_fact = fact_index < STAR_EMIT_TILES * STAR_FINISH_FACT_COLUMNS && (fact_index % STAR_FINISH_FACT_COLUMNS) < f.n_fact;
+  const uint32_t my_tile = stages_key ? tid / HY_MAX_STAR_DIMENSIONS : stages_fact ? fact_index / STAR_FINISH_FACT_COLUMNS : 0u;
+  const SliceView* my_views = a.table[0].views;   // (every thread loads a view -- the others the first tile's first, nobody's: no load under a condition)
+#pragma unroll
+  for (uint32_t d = 0; d < HY_MAX_STAR_DIMENSIONS; ++d) my_views = stages_key && tid % HY_MAX_STAR_DIMENSIONS == d ? a.table[d].views : my_views;
+#pragma unroll
+  for (uint32_t c = 0; c < STAR_FINISH_FACT_COLUMNS; ++c) my_views = stages_fact && fact_index % STAR_FINISH_FACT_COLUMNS == c ? f.fact_views[c] : my_views;
+  SliceView* my_place = stages_key ? s_views + tid : stages_fact ? s_fact_views + fact_index : nullptr;
+  u32x4_t next_mask[WORDS / 4];
+  const void* next_data = nullptr;     // (the view's six words one by one: a struct the compiler may not keep in registers)
+  const void* next_aux = nullptr;
+  uint32_t next_chunk = 0, next_row_begin = 0, next_row_count = 0, next_kind = 0;
+#define HY_STAR_REQUEST(GROUP)                                                                                                       \
+  {   /* (a group past the last: the first tile's, not used) */                                                                      \
+    const uint32_t r_first = (GROUP) * STAR_EMIT_TILES < a.n_tiles ? (GROUP) * STAR_EMIT_TILES : 0u;                                 \
+    const uint32_t r_tiles = a.n_tiles - r_first < STAR_EMIT_TILES ? a.n_tiles - r_first : STAR_EMIT_TILES;                          \
+    const u32x4_t* r_pieces = reinterpret_cast<const u32x4_t*>(a.masks + static_cast<size_t>(r_first) * STAR_THREADS);               \
+    _Pragma("unroll") for (uint32_t k = 0; k < WORDS / 4; ++k) {                                                                     \
+      const uint32_t piece = tid * (WORDS / 4) + k;                                                                                  \
+      next_mask[k] = r_pieces[piece < r_tiles * (STAR_THREADS / 16) ? piece : 0u];                                                   \
+    }                                                                                                                                \
+    const SliceView* r_view = my_views + r_first + (my_tile < r_tiles ? my_tile : 0u);                                               \
+    next_data = r_view->data;                                                                                                        \
+    next_aux = r_view->aux;                                                                                                          \
+    next_chunk = r_view->chunk;                                                                                                      \
+    next_row_begin = r_view->row_begin;                                                                                              \
+    next_row_count = r_view->row_count;                                                                                              \
+    next_kind = r_view->kind;                                                                                                        \
+  }
+  HY_STAR_REQUEST(blockIdx.x)
   for (uint32_t group = blockIdx.x; group < n_groups_of_tiles; group += gridDim.x) {
     const uint32_t first_tile = group * STAR_EMIT_TILES;
     const uint32_t n_tiles = a.n_tiles - first_tile < STAR_EMIT_TILES ? a.n_tiles - first_tile : STAR_EMIT_TILES;
     __syncthreads();   // (the list and the views of the group before are done with; the tags are cleared)
-    for (uint32_t i = tid; i < n_tiles * a.n_tables; i += STAR_FINISH_THREADS) s_views[(i / a.n_tables) * HY_MAX_STAR_DIMENSIONS + i % a.n_tables] = a.table[i % a.n_tables].views[first_tile + i / a.n_tables];
-    for (uint32_t i = tid; i < n_tiles * f.n_fact; i += STAR_FINISH_THREADS) s_fact_views[(i / f.n_fact) * STAR_FINISH_FACT_COLUMNS + i % f.n_fact] = f.fact_views[i % f.n_fact][first_tile + i / f.n_fact];
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(a.masks + static_cast<size_t>(first_tile) * STAR_THREADS);
+    if (my_place) { my_place->data = next_data; my_place->aux = next_aux; my_place->chunk = next_chunk; my_place->row_begin = next_row_begin; my_place->row_count = next_row_count; my_place->kind = next_kind; }
     uint32_t mask[WORDS], mine = 0;
 #pragma unroll
     for (uint32_t k = 0; k < WORDS; ++k) {
-      const uint32_t w = tid * WORDS + k;
-      mask[k] = w < n_tiles * (STAR_THREADS / 4) ? words[w] : 0u;
+      const uint32_t piece = tid * (WORDS / 4) + k / 4;
+      const u32x4_t words = next_mask[k / 4];
+      const uint32_t word = k % 4 == 0 ? words.x : k % 4 == 1 ? words.y : k % 4 == 2 ? words.z : words.w;
+      mask[k] = piece < n_tiles * (STAR_THREADS / 16) ? word : 0u;
       mine += __popc(mask[k]);
     }
+    HY_STAR_REQUEST(group + gridDim.x)
     uint32_t inclusive = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -575,7 +739,7 @@ __global__ __launch_bounds__(STAR_FINISH_THREADS, 4) void star_finish(StarArgs a
     __syncthreads();
     uint32_t before = inclusive - mine, total = 0;
     for (uint32_t w = 0; w < WAVES; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
-    for (uint32_t pass_begin = 0; pass_begin < total; pass_begin += STAR_EMIT_LIST) {
+    for (uint32_t pass_begin = 0; pass_begin < total; pass_begin += STAR_FINISH_LIST) {
       if (pass_begin) __syncthreads();
       uint32_t rank = before;
 #pragma unroll
@@ -585,16 +749,17 @@ __global__ __launch_bounds__(STAR_FINISH_THREADS, 4) void star_finish(StarArgs a
         while (bits) {
           const uint32_t j = __ffs(bits) - 1;
           bits &= bits - 1;
-          if (rank - pass_begin < STAR_EMIT_LIST) s_list[rank - pass_begin] = row0 + j;
+          if (rank - pass_begin < STAR_FINISH_LIST) s_list[rank - pass_begin] = row0 + j;
           ++rank;
         }
       }
       __syncthreads();
-      const uint32_t in_pass = total - pass_begin < STAR_EMIT_LIST ? total - pass_begin : STAR_EMIT_LIST;
+      const uint32_t in_pass = total - pass_begin < STAR_FINISH_LIST ? total - pass_begin : STAR_FINISH_LIST;
       for (uint32_t i = tid; i < in_pass; i += STAR_FINISH_THREADS) {
+        if (f.debug & 1) break;
         const uint32_t entry = s_list[i];
-        const uint32_t tile = entry >> 13, row = entry & 8191u;
-        const SliceView* views = s_views + tile * HY_MAX_STAR_DIMENSIONS;
+        const uint32_t tile = entry >> 13, row = f.debug & 4 ? 0u : entry & 8191u;
+        const SliceView* views = s_views + (f.debug & 4 ? 0u : tile) * HY_MAX_STAR_DIMENSIONS;
         const SliceView* fact_views = s_fact_views + tile * STAR_FINISH_FACT_COLUMNS;
         // round trip 1: the row's foreign keys to the dimensions somebody reads, and its cells of the fact table's columns.  Every load below is
         // unconditional (entries past the plan's repeat entry 0: the same address once more) -- a load on some control-flow paths only makes the
@@ -655,7 +820,15 @@ __global__ __launch_bounds__(STAR_FINISH_THREADS, 4) void star_finish(StarArgs a
         };
         const uint32_t hash = star_tuple_hash(tuple, f.n_groupby);
         const uint32_t position = first_tile * SLICE_ROWS + entry;   // (tile << 13 | row, tiles counted from the table's first)
-        const uint32_t slot = star_lds_slot(s_tags, s_keys, s_values, s_counts, s_first, s_last, f, tuple, hash);
+        if (f.debug & 2) { if (hash == 0x12345u) s_wave[WAVES] = 1; continue; }
+        uint32_t slot = 0xFFFFFFFFu;
+        if (direct) {   // the mixed-radix code of the row's values is its group's place
+          uint32_t code = 0;
+#pragma unroll
+          for (uint32_t g = 0; g < STAR_FINISH_KEYS; ++g) code += static_cast<uint32_t>(static_cast<long long>(tuple[g]) - low[g]) * stride[g];
+          if (code < n_codes) slot = code;
+          else { s_wave[WAVES] = 1; continue; }   // (a value outside the extent its attribute table was built with: cannot happen)
+        } else slot = star_lds_slot(s_tags, s_keys, s_values, s_counts, s_first, s_last, f, tuple, hash);
         if (slot != 0xFFFFFFFFu) {
           for (uint32_t g = 0; g < f.n_aggregates; ++g) {
             if (f.aggregates[g].left.kind == STAR_COLUMN_NONE) continue;
@@ -693,11 +866,17 @@ __global__ __launch_bounds__(STAR_FINISH_THREADS, 4) void star_finish(StarArgs a
   // the workgroup's groups -> the global table
   bool gave_up = s_wave[WAVES] != 0;
   for (uint32_t slot = tid; slot < STAR_FINISH_SLOTS; slot += STAR_FINISH_THREADS) {
-    if (s_tags[slot] == 0) continue;
-    uint64_t tuple[STAR_FINISH_KEYS];
+    uint32_t global = slot;
+    if (direct) {   // the global table is direct-mapped too: its keys are in place (star_finish_plan)
+      if (slot >= n_codes || s_counts[slot] == 0) continue;
+      f.tags[slot] = 0x80000000u;
+    } else {
+      if (s_tags[slot] == 0) continue;
+      uint64_t tuple[STAR_FINISH_KEYS];
 #pragma unroll
-    for (uint32_t w = 0; w < STAR_FINISH_KEYS; ++w) tuple[w] = s_keys[slot * STAR_FINISH_KEYS + w];
-    const uint32_t global = star_global_slot(f, tuple, star_tuple_hash(tuple, f.n_groupby));
+      for (uint32_t w = 0; w < STAR_FINISH_KEYS; ++w) tuple[w] = s_keys[slot * STAR_FINISH_KEYS + w];
+      global = star_global_slot(f, tuple, star_tuple_hash(tuple, f.n_groupby));
+    }
     if (global == 0xFFFFFFFFu) { gave_up = true; continue; }
     for (uint32_t g = 0; g < f.n_aggregates; ++g) {
       if (f.aggregates[g].left.kind == STAR_COLUMN_NONE) continue;
@@ -714,6 +893,8 @@ __global__ __launch_bounds__(STAR_FINISH_THREADS, 4) void star_finish(StarArgs a
   }
   if (gave_up) f.flags[STAR_FLAG_REFUSED] = 1;
 }
+
+#undef HY_STAR_REQUEST
 
 // The global table's groups, densely, into the block the host reads (pinned memory): keys, first / last as RANKS among the survivors (the row
 // numbers of the join result: survivors of the tiles before + set mask bits in front of the row), values, counts; the workgroup that finishes
@@ -835,6 +1016,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     std::vector<std::pair<uint32_t, const hy_column*>> attributes;       // distinct (dimension, column)
     std::vector<std::unique_ptr<DeviceBuffer>> attribute_tables;
     DeviceBuffer table;                                                  // flags | tags | counts | first | last | keys | values
+    DeviceBuffer extents;                                                // [STAR_FINISH_ATTRIBUTES][2] smallest / largest attribute value | StarDirectPlan
   } plan;
   plan.on = groups && star_finish_applies(finish, n_dimensions, shape);
   auto plan_column = [&](const StarFinishColumnSpec& c) {
@@ -856,6 +1038,10 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   if (plan.on) {
     HY_TRY(plan.table.alloc(64 + 4 * FINISH_TAGS_BYTES + FINISH_KEYS_BYTES + FINISH_VALUES_BYTES));
     HY_HIP(hipMemsetAsync(plan.table.ptr, 0, 64 + FINISH_TAGS_BYTES, stream));   // flags and tags
+    HY_TRY(plan.extents.alloc(16 * STAR_FINISH_ATTRIBUTES + sizeof(StarDirectPlan) + 64));
+    long long nothing[2 * STAR_FINISH_ATTRIBUTES];
+    for (uint32_t k = 0; k < STAR_FINISH_ATTRIBUTES; ++k) { nothing[2 * k] = INT64_MAX; nothing[2 * k + 1] = INT64_MIN; }
+    HY_HIP(hipMemcpyAsync(plan.extents.ptr, nothing, sizeof(nothing), hipMemcpyHostToDevice, stream));   // (pageable memory: copied before the call returns)
   }
   // ---- the dimensions' key ranges: the extent of the whole key column (a superset of its filtered rows' keys), remembered by the column --
   // one look at the keys and one host read the first time a column serves as a dimension key, none afterwards ------------------------------
@@ -944,6 +1130,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
       attribute_jobs.key_min[k] = jobs.key_min[d];
       attribute_jobs.out[k] = plan.attribute_tables.back()->as<int64_t>();
     }
+    attribute_jobs.extent = plan.extents.as<long long>();
     hipLaunchKernelGGL(star_dim_attributes, dim3(job_grid, static_cast<uint32_t>(plan.attributes.size())), dim3(256), 0, stream, attribute_jobs,
                        reinterpret_cast<uint32_t*>(plan.table.ptr) + STAR_FLAG_NULL_ATTRIBUTE);
   }
@@ -1070,6 +1257,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
       out.type = !spec.left.column ? static_cast<uint32_t>(HY_TYPE_LONG) : out.op == HY_STAR_NO_OP ? spec.left.column->data_type : expression_common_type(spec.left.column->data_type, spec.right.column->data_type);
       groups->input_type[g] = out.type;
     }
+    if (const char* debug = HY_DEBUG_ENV("HY_STAR_DEBUG")) f.debug = static_cast<uint32_t>(atoi(debug));   // timing experiments only
     f.capacity = STAR_FINISH_GLOBAL_SLOTS;
     char* at = plan.table.as<char>();
     f.flags = reinterpret_cast<uint32_t*>(at);                at += 64;
@@ -1079,6 +1267,8 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     f.last = reinterpret_cast<uint32_t*>(at);                 at += FINISH_TAGS_BYTES;
     f.keys = reinterpret_cast<uint64_t*>(at);                 at += FINISH_KEYS_BYTES;
     f.values = reinterpret_cast<uint64_t*>(at);
+    f.extent = plan.extents.as<long long>();
+    f.direct = reinterpret_cast<StarDirectPlan*>(plan.extents.as<char>() + 16 * STAR_FINISH_ATTRIBUTES);
     constexpr size_t G = STAR_FINISH_MAX_GROUPS;
     const size_t staged_bytes = 64 + 8 * G * (STAR_FINISH_KEYS + STAR_FINISH_AGGREGATES + 3);
     unsigned char* staged_host = nullptr;
@@ -1098,8 +1288,9 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
       finish_lds_raised.done(finish_bit);
     }
     const uint32_t tile_groups = (a.n_tiles + STAR_EMIT_TILES - 1) / STAR_EMIT_TILES;
+    hipLaunchKernelGGL(star_finish_plan, dim3(1), dim3(256), 0, stream, f);
     profile_begin(stream, HY_KERNEL_AGGREGATE);
-    hipLaunchKernelGGL(star_finish, dim3(std::max(1u, std::min(tile_groups, 2 * device_cu_count()))), dim3(STAR_FINISH_THREADS), star_finish_lds_bytes(f.n_aggregates), stream, a, f);
+    hipLaunchKernelGGL(star_finish, dim3(std::max(1u, std::min(tile_groups, (1024 / STAR_FINISH_THREADS) * device_cu_count()))), dim3(STAR_FINISH_THREADS), star_finish_lds_bytes(f.n_aggregates), stream, a, f);
     profile_end(stream);
     uint64_t *d_keys, *d_first, *d_last, *d_values, *d_counts;
     arrays(staged_dev, &d_keys, &d_first, &d_last, &d_values, &d_counts);
