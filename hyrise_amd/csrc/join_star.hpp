@@ -393,9 +393,9 @@ __global__ __launch_bounds__(256) void star_emit_rows(StarArgs a) {
 // of the join result's rows; star_finish_compact turns them into the survivors' ranks = the row numbers hy_aggregate_hash would have seen.
 constexpr uint32_t STAR_FINISH_KEYS = 4, STAR_FINISH_AGGREGATES = HY_MAX_STAR_AGGREGATES;
 #ifndef HY_STAR_FINISH_THREADS
-#define HY_STAR_FINISH_THREADS 256
+#define HY_STAR_FINISH_THREADS 512
 #endif
-constexpr uint32_t STAR_FINISH_THREADS = HY_STAR_FINISH_THREADS;          // four workgroups per CU: their phases (masks, keys, attributes: a round trip each) overlap
+constexpr uint32_t STAR_FINISH_THREADS = HY_STAR_FINISH_THREADS;   // two workgroups per CU (256 threads x 4: 189 / 319 us against 135 / 244)
 constexpr uint32_t STAR_FINISH_LIST = 2048;            // survivors of a group of tiles looked at per pass
 constexpr uint32_t STAR_FINISH_SLOTS = 512;            // a workgroup's table in LDS
 constexpr uint32_t STAR_FINISH_GLOBAL_SLOTS = 1u << 14;

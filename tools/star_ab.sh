@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out/star_ab
 for v in default "$@"; do
 for q in 2.1 4.1; do
   OUT=$R/gpurun_out/star_ab/t; rm -rf $OUT; mkdir -p $OUT
-  lib=""; [ "$v" != default ] && lib=$R/hyrise_amd/variants/lib_$v.so
+  lib=$R/hyrise_amd/libhyrise_amd.so; [ "$v" != default ] && lib=$R/hyrise_amd/variants/lib_$v.so
   (cd /tmp && HY_LIBRARY=$lib timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python $R/tools/ssb_star_time.py $q 10 > $OUT/log.txt 2>&1)
   echo "== $v Q$q" >> $R/gpurun_out/star_ab/summary.txt
   python $R/tools/kernel_stats.py $OUT 8 | grep -E 'star_finish\(|star_probe' | cut -c1-130 >> $R/gpurun_out/star_ab/summary.txt
