@@ -99,21 +99,46 @@ __global__ __launch_bounds__(256) void star_column_extent(const DevSegment* segm
 // The dimensions' direct tables: bit and packed RowID of every key; *duplicate = 1 if a key comes twice.  (A dimension without a table
 // -- no rows -- has n = 0.)
 __global__ __launch_bounds__(256) void star_dim_fill(StarDimensionJobs jobs, uint32_t* duplicate) {
-  const uint32_t d = blockIdx.y;
+  const uint32_t d = blockIdx.y, lane = threadIdx.x & 63;
   const DevSegment* segments = jobs.segments[d];
   const hy_row_id* rows = jobs.rows[d];
   const uint64_t n = jobs.n_in_memory[d] ? *jobs.n_in_memory[d] : jobs.n[d];
   const int64_t key_min = jobs.key_min[d];
   uint32_t* bits = jobs.bits[d];
   uint32_t* ids = jobs.ids[d];
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) {
-    const hy_row_id row = rows[i];
-    const Value v = column_value(segments, row.chunk_id, row.chunk_offset);
-    if (v.is_null) continue;
-    const uint32_t rel = static_cast<uint32_t>(v.i - key_min);
-    const uint32_t bit = 1u << (rel & 31);
-    if (atomicOr(&bits[rel >> 5], bit) & bit) *duplicate = 1;
-    ids[rel] = row.chunk_id << 16 | row.chunk_offset;
+  // (the loop's trip count is the wave's: the lanes of a wave merge their bits before they go to memory -- a dimension's rows come in key order
+  //  more often than not, 64 of them meet in two or three words, and an atomic per row on those words was most of this kernel)
+  for (uint64_t first = (static_cast<uint64_t>(blockIdx.x) * 256 + (threadIdx.x & ~63u)); first < n; first += static_cast<uint64_t>(gridDim.x) * 256) {
+    const uint64_t i = first + lane;
+    bool valid = i < n;
+    uint32_t rel = 0;
+    if (valid) {
+      const hy_row_id row = rows[i];
+      const Value v = column_value(segments, row.chunk_id, row.chunk_offset);
+      valid = !v.is_null;
+      rel = static_cast<uint32_t>(v.i - key_min);
+      if (valid) ids[rel] = row.chunk_id << 16 | row.chunk_offset;
+    }
+    const uint32_t word = rel >> 5, bit = 1u << (rel & 31);
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+      const uint32_t w = static_cast<uint32_t>(__shfl(static_cast<int>(word), leader, 64));
+      const bool mine = valid && word == w;
+      const uint64_t same = __ballot(mine);
+      uint32_t merged = mine ? bit : 0u;
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) merged |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(merged), s, 64));
+      if (static_cast<int>(lane) == leader) {
+        const uint32_t before = atomicOr(&bits[w], merged);
+        if ((before & merged) || __popc(merged) != __popcll(same)) *duplicate = 1;   // a key another wave has set, or two lanes of this one
+      }
+      todo &= ~same;
+      if (__popcll(same) <= 2 && todo) {   // (rows that passed a selective filter: their keys are far apart -- an atomic each, no more merging)
+        if ((todo >> lane) & 1) { if (atomicOr(&bits[word], bit) & bit) *duplicate = 1; }
+        break;
+      }
+    }
   }
 }
 
@@ -489,7 +514,13 @@ __global__ __launch_bounds__(256) void star_dim_attributes(StarAttributeJobs job
     low = other_low < low ? other_low : low;
     high = other_high > high ? other_high : high;
   }
-  if ((threadIdx.x & 63) == 0 && low <= high) { atomicMin(jobs.extent + 2 * k, low); atomicMax(jobs.extent + 2 * k + 1, high); }
+  __shared__ long long s_low[4], s_high[4];   // (one pair of atomics per workgroup: thousands of waves on two words took longer than the table)
+  if ((threadIdx.x & 63) == 0) { s_low[threadIdx.x >> 6] = low; s_high[threadIdx.x >> 6] = high; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t w = 1; w < 4; ++w) { low = s_low[w] < low ? s_low[w] : low; high = s_high[w] > high ? s_high[w] : high; }
+    if (low <= high) { atomicMin(jobs.extent + 2 * k, low); atomicMax(jobs.extent + 2 * k + 1, high); }
+  }
 }
 
 // Row `row` of the chunk a view describes, without a branch on the view's kind and without a conditional load (the loads of a survivor's
@@ -1088,14 +1119,14 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     jobs.n_in_memory[d] = dimensions[d].d_n_rows;
     most_rows = std::max(most_rows, dimensions[d].n_rows);
   }
-  const uint32_t job_grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((most_rows + 1023) / 1024, 256)));
+  // (a row per thread: a row is three dependent round trips and an atomic that is waited for -- 256 workgroups walking a million rows spent 59 us on it)
+  const uint32_t job_grid = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((most_rows + 255) / 256, 8192)));
   // ---- the direct tables -------------------------------------------------------------------------------------------------------
-  struct Built { DeviceBuffer bits, ids; int64_t key_min = 0; uint64_t range = 0; uint32_t words = 0; bool empty = false; };
+  struct Built { uint32_t* bits = nullptr; DeviceBuffer ids; int64_t key_min = 0; uint64_t range = 0; uint32_t words = 0; bool empty = false; };
   std::vector<std::unique_ptr<Built>> built(n_dimensions);
-  DeviceBuffer duplicate;
-  HY_TRY(duplicate.alloc(64));
-  HY_HIP(hipMemsetAsync(duplicate.ptr, 0, 4, stream));
+  DeviceBuffer duplicate;   // [16 words of flags] | every dimension's presence words: ONE buffer, one memset
   bool nothing_joins = false;
+  size_t all_words = 16;
   for (uint32_t d = 0; d < n_dimensions; ++d) {
     built[d] = std::make_unique<Built>();
     Built& b = *built[d];
@@ -1105,12 +1136,22 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     b.key_min = low;
     b.range = static_cast<uint64_t>(high - low);
     b.words = static_cast<uint32_t>(b.range >> 5) + 1;
-    HY_TRY(b.bits.alloc(4 * size_t{b.words} + 16));
-    HY_TRY(b.ids.alloc(4 * (b.range + 1) + 16));
-    HY_HIP(hipMemsetAsync(b.bits.ptr, 0, 4 * size_t{b.words}, stream));
-    jobs.key_min[d] = b.key_min;
-    jobs.bits[d] = b.bits.as<uint32_t>();
-    jobs.ids[d] = b.ids.as<uint32_t>();
+    all_words += (size_t{b.words} + 7) & ~size_t{7};
+  }
+  HY_TRY(duplicate.alloc(4 * all_words + 64));
+  HY_HIP(hipMemsetAsync(duplicate.ptr, 0, 4 * all_words, stream));
+  {
+    size_t at = 16;
+    for (uint32_t d = 0; d < n_dimensions; ++d) {
+      Built& b = *built[d];
+      if (b.empty) continue;
+      b.bits = duplicate.as<uint32_t>() + at;
+      at += (size_t{b.words} + 7) & ~size_t{7};
+      HY_TRY(b.ids.alloc(4 * (b.range + 1) + 16));
+      jobs.key_min[d] = b.key_min;
+      jobs.bits[d] = b.bits;
+      jobs.ids[d] = b.ids.as<uint32_t>();
+    }
   }
   for (uint32_t d = 0; d < n_dimensions; ++d) if (built[d]->empty) { jobs.n[d] = 0; jobs.n_in_memory[d] = nullptr; }
   if (!nothing_joins) hipLaunchKernelGGL(star_dim_fill, dim3(job_grid, n_dimensions), dim3(256), 0, stream, jobs, duplicate.as<uint32_t>());
@@ -1131,7 +1172,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
       attribute_jobs.out[k] = plan.attribute_tables.back()->as<int64_t>();
     }
     attribute_jobs.extent = plan.extents.as<long long>();
-    hipLaunchKernelGGL(star_dim_attributes, dim3(job_grid, static_cast<uint32_t>(plan.attributes.size())), dim3(256), 0, stream, attribute_jobs,
+    hipLaunchKernelGGL(star_dim_attributes, dim3(std::min(job_grid, 1024u), static_cast<uint32_t>(plan.attributes.size())), dim3(256), 0, stream, attribute_jobs,
                        reinterpret_cast<uint32_t*>(plan.table.ptr) + STAR_FLAG_NULL_ATTRIBUTE);
   }
   dimension_rows.clear();
@@ -1180,7 +1221,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   for (uint32_t d = 0; d < n_dimensions; ++d) {
     StarTable& t = a.table[slot_of[d]];
     t.views = dimensions[d].fact_key->d_slice_views;
-    t.bits = built[d]->bits.as<uint32_t>();
+    t.bits = built[d]->bits;
     t.ids = built[d]->ids.as<uint32_t>();
     t.key_min = static_cast<uint32_t>(static_cast<int32_t>(built[d]->key_min));
     t.range = static_cast<uint32_t>(built[d]->range);
