@@ -2078,15 +2078,19 @@ __host__ __device__ constexpr size_t stream_count_lds_words(uint32_t partitions)
 template <uint32_t WIDTH>   // bytes per stored word: FrameOfReference offsets of 1 / 2 / 4 bytes, int32 values
 __device__ __forceinline__ void load_batch_words(const char* base, uint32_t first_row, u32x4_t (&words)[2]) {
   // the lane's eight consecutive words (first_row is a multiple of eight: the loads are aligned)
+  // (global-address-space loads: `base` comes out of a descriptor and is a generic pointer to the compiler -- flat loads, which count as LDS
+  //  traffic too, so that the first wait for an LDS atomic would wait for the column as well)
+  typedef __attribute__((address_space(1))) const u32x4_t global_quad;
+  typedef __attribute__((address_space(1))) const u32x2_t global_pair;
   words[0] = words[1] = u32x4_t{0, 0, 0, 0};
   if constexpr (WIDTH == 1) {
-    const u32x2_t v = *reinterpret_cast<const u32x2_t*>(base + first_row);
+    const u32x2_t v = *(global_pair*)(base + first_row);
     words[0].x = v.x; words[0].y = v.y;
   } else if constexpr (WIDTH == 2) {
-    words[0] = *reinterpret_cast<const u32x4_t*>(base + first_row * 2u);
+    words[0] = *(global_quad*)(base + first_row * 2u);
   } else {
-    words[0] = *reinterpret_cast<const u32x4_t*>(base + first_row * 4u);
-    words[1] = *reinterpret_cast<const u32x4_t*>(base + first_row * 4u + 16u);
+    words[0] = *(global_quad*)(base + first_row * 4u);
+    words[1] = *(global_quad*)(base + first_row * 4u + 16u);
   }
 }
 template <uint32_t WIDTH>
@@ -3223,6 +3227,24 @@ __global__ __launch_bounds__(256) void plan_output(const uint64_t* base_elements
     mailbox->fits = fits;
     __threadfence_system();
   }
+}
+
+// A SliceView every lane of the workgroup reads alike, through the scalar cache (constant address space: the tables are written by
+// hy_column_create, long before the kernel): as a vector load it is a round trip of its own in front of the tile's words.
+__device__ __forceinline__ SliceView uniform_view(const SliceView* view) {
+  typedef __attribute__((address_space(4))) const uint64_t constant_u64;
+  const uint64_t address = reinterpret_cast<uint64_t>(view);
+  constant_u64* q = (constant_u64*)(static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(address >> 32)))) << 32 |
+                                    static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(address))));
+  const uint64_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+  SliceView v;
+  v.data = reinterpret_cast<const void*>(w0);
+  v.aux = reinterpret_cast<const void*>(w1);
+  v.chunk = static_cast<uint32_t>(w2);
+  v.row_begin = static_cast<uint32_t>(w2 >> 32);
+  v.row_count = static_cast<uint32_t>(w3);
+  v.kind = static_cast<uint32_t>(w3 >> 32);
+  return v;
 }
 
 #include "join_pkfk.hpp"

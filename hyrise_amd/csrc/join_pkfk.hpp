@@ -97,7 +97,7 @@ __host__ __device__ inline size_t pk_count_lds_bytes(uint64_t range, uint32_t pa
 
 // The rows of tile `tile`: its slice's view, narrowed to the tile.
 __device__ __forceinline__ SliceView pk_tile_view(const PkArgs& a, uint32_t tile) {
-  SliceView view = a.views[tile / PK_TILES_PER_SLICE];
+  SliceView view = uniform_view(a.views + tile / PK_TILES_PER_SLICE);   // (tile: the same for every lane of the workgroup)
   if constexpr (PK_TILES_PER_SLICE > 1) {
     const uint32_t offset = (tile % PK_TILES_PER_SLICE) * PK_TILE;
     view.row_begin += offset;
@@ -154,7 +154,9 @@ __device__ __forceinline__ void pk_count_wave(const PkArgs& a, const SliceView& 
     const uint32_t first = wave_first + b * 512 + lane * 8;
     load_batch_words<WIDTH>(base, view.row_begin + (first < row_count ? first : 0), words[b]);
   }
-  const uint32_t bias = view.kind == VIEW_INT32 ? 0u : static_cast<uint32_t>(static_cast<const int32_t*>(view.aux)[(view.row_begin + wave_first) / HY_FOR_BLOCK_SIZE]);
+  // (the wave's block minimum: one value for all lanes, through the scalar cache -- immutable like the views)
+  typedef __attribute__((address_space(4))) const uint32_t constant_word;
+  const uint32_t bias = view.kind == VIEW_INT32 ? 0u : ((constant_word*)view.aux)[__builtin_amdgcn_readfirstlane(static_cast<int>((view.row_begin + wave_first) / HY_FOR_BLOCK_SIZE))];
   const uint32_t origin = static_cast<uint32_t>(a.rank.key_min), range = static_cast<uint32_t>(a.rank.range);
   const uint32_t mask = a.radix_bits ? (1u << a.radix_bits) - 1 : 0u;
   const uint32_t copy = ((lane >> 4) & 3) | ((lane & 1) << 2);   // (lanes 16 apart -- 32 orders, the period of dbgen's sparse keys mod 128 -- meet in one partition: they use different copies)
@@ -303,9 +305,9 @@ __global__ __launch_bounds__(PK_COUNT_THREADS, (RANKS ? 4 : HY_PK_COUNT_WGS_PER_
   const uint32_t tile = pk_block_tile(a.n_tiles);
   if (blockIdx.x == 0 && tid == 0) *a.ticket = 0;   // pk_scan's arrival counter (pk_scan runs behind this kernel)
   if (tile >= a.n_tiles) return;
+  const SliceView view = pk_tile_view(a, tile);
   for (uint32_t i = tid; i < partitions * COUNT_COPIES; i += PK_COUNT_THREADS) s_cells[i] = 0;
   __syncthreads();
-  const SliceView view = pk_tile_view(a, tile);
   uint32_t* tile_ranks = RANKS ? a.row_ranks + static_cast<size_t>(tile) * PK_TILE : nullptr;
   if (view.kind == VIEW_FOR8) pk_count_wave<1, false, RANKS>(a, view, wave, lane, s_cells, nullptr, nullptr, tile_ranks);
   else if (view.kind == VIEW_FOR16) pk_count_wave<2, false, RANKS>(a, view, wave, lane, s_cells, nullptr, nullptr, tile_ranks);

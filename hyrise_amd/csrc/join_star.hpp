@@ -176,30 +176,13 @@ struct StarTileWords {
   u32x4_t words[STAR_LDS_DIMENSIONS][2];
   uint32_t bias[STAR_LDS_DIMENSIONS];
 };
-// A view every lane reads alike, through the scalar cache (constant address space: the tables are written by hy_column_create, long before) --
-// as a vector load it would queue behind the tile's data loads and waiting for it would wait for them.
-__device__ __forceinline__ SliceView star_uniform_view(const SliceView* view) {
-  typedef __attribute__((address_space(4))) const uint64_t constant_u64;
-  const uint64_t address = reinterpret_cast<uint64_t>(view);
-  constant_u64* q = (constant_u64*)(static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(address >> 32)))) << 32 |
-                                    static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(address))));
-  const uint64_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
-  SliceView v;
-  v.data = reinterpret_cast<const void*>(w0);
-  v.aux = reinterpret_cast<const void*>(w1);
-  v.chunk = static_cast<uint32_t>(w2);
-  v.row_begin = static_cast<uint32_t>(w2 >> 32);
-  v.row_count = static_cast<uint32_t>(w3);
-  v.kind = static_cast<uint32_t>(w3 >> 32);
-  return v;
-}
 __device__ __forceinline__ void star_request_tile(const StarArgs& a, uint32_t tile, uint32_t first, StarTileWords& t, uint32_t (&kind)[STAR_LDS_DIMENSIONS], uint32_t* rows) {
   typedef __attribute__((address_space(1))) const u32x4_t global_quad;
   typedef __attribute__((address_space(1))) const uint32_t global_word;
-  *rows = star_uniform_view(a.table[0].views + tile).row_count;
+  *rows = uniform_view(a.table[0].views + tile).row_count;
 #pragma unroll
   for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
-    const SliceView view = star_uniform_view(a.table[d < a.n_lds ? d : 0].views + tile);
+    const SliceView view = uniform_view(a.table[d < a.n_lds ? d : 0].views + tile);
     kind[d] = view.kind;
     const uint32_t width = view.kind == VIEW_FOR8 ? 1u : view.kind == VIEW_FOR16 ? 2u : 4u;
     const uint32_t row = view.row_begin + (first < view.row_count ? first : 0u);
