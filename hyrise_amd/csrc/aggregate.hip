@@ -40,16 +40,22 @@
 // Two builds of this file: GROUP BY over at most 4 columns (this translation unit: a tuple is five 64-bit words in registers -- every
 // kernel below is tuned at that size) and, for the plans with more (TPC-H Q10 groups by seven columns, Q18 by five; the reference takes any
 // number: aggregate_hash.cpp:1184-1198, AggregateKeySmallVector), the same code with tuples of nine words (aggregate_wide.hip includes this
-// file with HY_MAX_GROUPBY 8; its entry points carry the suffix _wide and the ones below hand wider GROUP BYs over to them).
+// file with HY_MAX_GROUPBY 8; its entry points carry the suffix _wide and the ones below hand wider GROUP BYs over to them), and for nine to
+// sixteen columns a third time with seventeen words (aggregate_widest.hip, suffix _widest).
 #ifndef HY_MAX_GROUPBY
 #define HY_MAX_GROUPBY 4
 #endif
 #if HY_MAX_GROUPBY == 4
 #define HY_AGG_NAMESPACE narrow_keys
 #define HY_AGG_ENTRY(name) name
-#else
+#define HY_AGG_NEXT(name) name##_wide       // the build that takes what this one does not
+#elif HY_MAX_GROUPBY == 8
 #define HY_AGG_NAMESPACE wide_keys
 #define HY_AGG_ENTRY(name) name##_wide
+#define HY_AGG_NEXT(name) name##_widest     // (aggregate_widest.hip: nine to sixteen GROUP BY columns, seventeen-word tuples)
+#else
+#define HY_AGG_NAMESPACE widest_keys
+#define HY_AGG_ENTRY(name) name##_widest
 #endif
 
 namespace hy {
@@ -2553,7 +2559,9 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   // The partitioned path (tables with many groups): entered when aggregate_rows gives up; 2^bits partitions of about 64 Ki rows,
   // then -- if even those hold more groups than a workgroup's table -- the most the partitioning kernels take.
   constexpr uint32_t MAX_PARTITION_BITS = 14;
-  const bool can_partition = !fused && a.n_groupby > 0 && shape->rows < (1ull << 32) && FIXED_AGG_PARTITIONS;
+  // (the seventeen-word build -- nine to sixteen GROUP BY columns -- keeps to aggregate_rows and the global table: the partitioning kernels
+  //  are instantiated per tuple size, and eight more sizes of them for plans this rare would double the library's build time)
+  const bool can_partition = !fused && a.n_groupby > 0 && shape->rows < (1ull << 32) && FIXED_AGG_PARTITIONS && MAX_GROUPBY <= 8;
   uint32_t first_bits = 6;
   while (first_bits < MAX_PARTITION_BITS && (shape->rows >> first_bits) > 65536) ++first_bits;
   uint32_t partition_bits = 0;   // 0: aggregate_rows
@@ -2663,6 +2671,14 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       const size_t fused_lds = size_t{fused_lds_slots(a.n_groupby)} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 64 + 2 * size_t{SLICE_ROWS} + sizeof(ColumnView) * FUSED_VIEWS +
                                sizeof(ScanJob) * HY_MAX_FILTERS + sizeof(FusedInput) * n_aggregates + size_t{FUSED_DENSE} * FUSED_CELLS * (8 * (n_aggregates + 2) + 4 * n_aggregates);
       profile_begin(stream, HY_KERNEL_AGGREGATE);
+      if (fused_lds > 65536) {
+        static OncePerDevice fused_lds_raised;
+        uint64_t device_bit = 0;
+        if (fused_lds_raised.pending(&device_bit)) {
+          HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          fused_lds_raised.done(device_bit);
+        }
+      }
       hipLaunchKernelGGL(fused_rows, dim3(shape->n_chunks), dim3(256), fused_lds, stream, a, fused, shape->n_chunks);
       profile_end(stream);
     } else if (shape->n_slices && shape->rows && partition_bits == 0 && small) {   // a handful of groups over dictionary columns (aggregate_small.hpp)
@@ -2691,6 +2707,14 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
       profile_end(stream);
     } else if (shape->n_slices && shape->rows && partition_bits == 0) {
       profile_begin(stream, HY_KERNEL_AGGREGATE);
+      if (lds_bytes > 65536) {   // (seventeen-word tuples: 256 slots of them exceed what a workgroup gets without asking)
+        static OncePerDevice rows_lds_raised;
+        uint64_t device_bit = 0;
+        if (rows_lds_raised.pending(&device_bit)) {
+          HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          rows_lds_raised.done(device_bit);
+        }
+      }
       hipLaunchKernelGGL(aggregate_rows, dim3(shape->n_slices), dim3(256), lds_bytes, stream, a);
       profile_end(stream);
     } else if (shape->n_slices && shape->rows) {
@@ -3650,23 +3674,23 @@ static hy_status run_with_result_memory(hy_aggregate_result* result, uint32_t n_
 
 extern "C" {
 
-#if HY_MAX_GROUPBY == 4
-// aggregate_wide.hip: this file again, with nine-word tuples
-hy_status hy_scan_project_aggregate_wide(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
-                                         const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
-hy_status hy_aggregate_hash_wide(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates, uint32_t n_aggregates,
-                                 hy_aggregate_result* result);
-int hy_debug_aggregate_path_wide(void);
-int hy_debug_aggregate_finished_on_device_wide(void);
-int hy_debug_aggregate_small_domain_wide(void);
-static bool g_last_aggregate_was_wide = false;   // debug accessors: which build answered the last call of this process
+#ifdef HY_AGG_NEXT
+// aggregate_wide.hip / aggregate_widest.hip: this file again, with nine- / seventeen-word tuples
+hy_status HY_AGG_NEXT(hy_scan_project_aggregate)(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
+                                                 const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);
+hy_status HY_AGG_NEXT(hy_aggregate_hash)(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates, uint32_t n_aggregates,
+                                         hy_aggregate_result* result);
+int HY_AGG_NEXT(hy_debug_aggregate_path)(void);
+int HY_AGG_NEXT(hy_debug_aggregate_finished_on_device)(void);
+int HY_AGG_NEXT(hy_debug_aggregate_small_domain)(void);
+static bool g_last_aggregate_was_wide = false;   // debug accessors: the next build answered the last call of this process
 #endif
 
 hy_status HY_AGG_ENTRY(hy_scan_project_aggregate)(const hy_filter* filters, uint32_t n_filters, const hy_column* const* groupby_columns, uint32_t n_groupby,
                                                   const hy_fused_aggregate* aggregates, uint32_t n_aggregates, hy_aggregate_result* result) {
-#if HY_MAX_GROUPBY == 4
+#ifdef HY_AGG_NEXT
   g_last_aggregate_was_wide = n_groupby > MAX_GROUPBY;
-  if (n_groupby > MAX_GROUPBY) return hy_scan_project_aggregate_wide(filters, n_filters, groupby_columns, n_groupby, aggregates, n_aggregates, result);
+  if (n_groupby > MAX_GROUPBY) return HY_AGG_NEXT(hy_scan_project_aggregate)(filters, n_filters, groupby_columns, n_groupby, aggregates, n_aggregates, result);
 #endif
   if (!result || (n_filters && !filters) || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: null argument");
   if (n_aggregates && !result->columns) return fail(HY_ERR_INVALID, "hy_scan_project_aggregate: result columns missing");
@@ -3701,12 +3725,12 @@ hy_status HY_AGG_ENTRY(hy_scan_project_aggregate)(const hy_filter* filters, uint
 
 hy_status HY_AGG_ENTRY(hy_aggregate_hash)(const hy_column* const* groupby_columns, uint32_t n_groupby, const hy_aggregate_spec* aggregates,
                                           uint32_t n_aggregates, hy_aggregate_result* result) {
-#if HY_MAX_GROUPBY == 4
+#ifdef HY_AGG_NEXT
   {   // (COUNT(DISTINCT x) groups by the GROUP BY columns and x: one more key word)
     uint32_t key_columns = n_groupby;
     for (uint32_t i = 0; aggregates && i < n_aggregates; ++i) if (aggregates[i].function == HY_AGG_COUNT_DISTINCT) key_columns = n_groupby + 1;
     g_last_aggregate_was_wide = key_columns > MAX_GROUPBY;
-    if (g_last_aggregate_was_wide) return hy_aggregate_hash_wide(groupby_columns, n_groupby, aggregates, n_aggregates, result);
+    if (g_last_aggregate_was_wide) return HY_AGG_NEXT(hy_aggregate_hash)(groupby_columns, n_groupby, aggregates, n_aggregates, result);
   }
 #endif
   if (!result || (n_groupby && !groupby_columns) || (n_aggregates && !aggregates)) return fail(HY_ERR_INVALID, "hy_aggregate_hash: null argument");
@@ -3752,10 +3776,10 @@ hy_status HY_AGG_ENTRY(hy_aggregate_hash)(const hy_column* const* groupby_column
 }
 
 // debug only: which path the last hy_aggregate_hash of this process took -- 0 aggregate_rows, else the partition bits; not part of the public header
-#if HY_MAX_GROUPBY == 4
-#define HY_AGG_DEBUG(name, value) int name(void) { return g_last_aggregate_was_wide ? name##_wide() : static_cast<int>(value); }
+#ifdef HY_AGG_NEXT
+#define HY_AGG_DEBUG(name, value) int HY_AGG_ENTRY(name)(void) { return g_last_aggregate_was_wide ? HY_AGG_NEXT(name)() : static_cast<int>(value); }
 #else
-#define HY_AGG_DEBUG(name, value) int name##_wide(void) { return static_cast<int>(value); }
+#define HY_AGG_DEBUG(name, value) int HY_AGG_ENTRY(name)(void) { return static_cast<int>(value); }
 #endif
 HY_AGG_DEBUG(hy_debug_aggregate_path, g_agg_path)
 

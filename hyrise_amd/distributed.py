@@ -579,7 +579,7 @@ def sharded_aggregate(comm, ex, groupby, aggregates, first_chunk, total_rows_hin
     for a, (kind, column) in enumerate(layout):
         if kind != "distinct":
             continue
-        if len(groupby) + 1 > 8:
+        if len(groupby) + 1 > 16:
             raise NotImplementedError("COUNT(DISTINCT) across ranks groups by the GROUP BY columns and the counted column: at most seven GROUP BY columns")
         # the rank's distinct (group key, value) tuples = the groups of GROUP BY (keys..., value) (DISTINCT is a GROUP BY without aggregates,
         # aggregate_hash.cpp:1024-1061); merged across the ranks like any groups; NULL values are not counted

@@ -534,7 +534,7 @@ typedef struct hy_aggregate_result {
 } hy_aggregate_result;
 
 /* Group order == the CPU operator's: first occurrence, or ascending key under the immediate-key shortcut
- * (aggregate_hash.cpp:388-401, 770-804).  Up to eight GROUP BY columns (the reference: any number, aggregate_hash.cpp:1184-1198); more
+ * (aggregate_hash.cpp:388-401, 770-804).  Up to sixteen GROUP BY columns (the reference: any number, aggregate_hash.cpp:1184-1198); more
  * answer HY_ERR_UNSUPPORTED. */
 hy_status hy_aggregate_hash(const hy_column* const* groupby_columns, uint32_t n_groupby,
                             const hy_aggregate_spec* aggregates, uint32_t n_aggregates, hy_aggregate_result* result);

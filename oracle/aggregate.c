@@ -23,7 +23,7 @@
 
 #include "hy_oracle.h"
 
-#define MAX_GROUPBY 8
+#define MAX_GROUPBY 16
 
 static inline uint32_t load_compressed(const void* data, uint32_t width, uint32_t i) {
   if (width == 1) return ((const uint8_t*)data)[i];

@@ -1,7 +1,8 @@
 """AggregateHash over more than four GROUP BY columns (the reference takes any number: aggregate_hash.cpp:1184-1198 dispatches one to four
 columns to fixed-size keys and everything else to AggregateKeySmallVector; key construction :661-948).  TPC-H Q10 groups by seven
-columns, Q18 by five.  The device runs these plans on the nine-word build of its aggregate kernels (csrc/aggregate_wide.hip); groups,
-their order and representative rows are compared with the CPU oracle byte for byte, SUM / AVG of floats within 1e-9."""
+columns, Q18 by five.  The device runs these plans on the nine-word build of its aggregate kernels (csrc/aggregate_wide.hip), nine to
+sixteen columns on the seventeen-word build (csrc/aggregate_widest.hip); groups, their order and representative rows are compared with the
+CPU oracle byte for byte, SUM / AVG of floats within 1e-9."""
 import json
 import os
 
@@ -73,7 +74,7 @@ def test_q18_shaped_five_columns(device):
 
 @pytest.mark.parametrize("n_columns", [5, 6, 8])
 def test_groups_that_differ_in_the_last_column_only(device, n_columns):
-    """Tuples equal in every column but the last; eight columns = the most the device takes (more is HY_ERR_UNSUPPORTED, below)."""
+    """Tuples equal in every column but the last; eight columns = the most the nine-word build takes."""
     rng = np.random.default_rng(n_columns)
     n = 100_000
     constant = [build_column(np.full(n, 5 + g, dtype=np.int32 if g % 2 else np.int64), None, 30_000, abi.ENC_DICTIONARY if g % 3 == 0 else abi.ENC_UNENCODED) for g in range(n_columns - 1)]
@@ -142,8 +143,62 @@ def test_fused_scan_project_aggregate_over_five_columns(device):
     assert_matches_chain(got, chain, 3, "fused, five GROUP BY columns")
 
 
-def test_nine_columns_are_refused(device):
+@pytest.mark.parametrize("n_customers", [40, 3_000], ids=["lds", "global"])
+def test_q10_shape_padded_to_twelve_columns(device, n_customers):
+    """TPC-H Q10's seven GROUP BY columns and five more of the customer's (the reference takes any number, aggregate_hash.cpp:1184-1198):
+    nine to sixteen columns run on the seventeen-word build of the kernels (csrc/aggregate_widest.hip) -- groups, order, representative
+    rows and cells against the CPU oracle, like the narrower plans."""
+    rng = np.random.default_rng(1200 + n_customers)
+    n, chunk = 300_000, 65_535
+    table = customers(rng, n_customers)
+    for extra in range(5):
+        table[f"c_extra{extra}"] = rng.integers(0, 4, n_customers).astype(np.int32 if extra % 2 else np.int64) - 1
+    of_row = rng.integers(0, n_customers, n)
+    columns = {name: values[of_row].copy() for name, values in table.items()}
+    columns["c_extra4"][rng.random(n) < 0.02] = 9       # (groups that differ in the twelfth column only)
+    nulls = {"c_acctbal": rng.random(n) < 0.01, "c_extra2": rng.random(n) < 0.01}
+    names = ["c_custkey", "c_name", "c_acctbal", "c_phone", "n_name", "c_address", "c_comment"] + [f"c_extra{e}" for e in range(5)]
+    groupby = [build_column(columns[name], nulls.get(name), chunk, abi.ENC_DICTIONARY if name in ("n_name", "c_comment", "c_acctbal", "c_extra1") else abi.ENC_UNENCODED) for name in names]
+    revenue = (rng.random(n) * 1e4).astype(np.float32)
+    quantity = rng.integers(1, 51, n).astype(np.int32)
+    aggregates = [(abi.AGG_SUM, build_column(revenue, None, chunk, abi.ENC_UNENCODED)), (abi.AGG_COUNT, None),
+                  (abi.AGG_MIN, build_column(quantity, rng.random(n) < 0.05, chunk, abi.ENC_FRAME_OF_REFERENCE)), (abi.AGG_AVG, build_column(quantity, None, chunk, abi.ENC_DICTIONARY))]
+    got = run_both(groupby, aggregates, f"Q10 shape + five columns, {n_customers} customers")
+    assert got.n_groups > n_customers
+    run_both(groupby, [], "DISTINCT over twelve columns")
+
+
+def test_sixteen_columns_and_count_distinct_behind_fifteen(device):
+    """Sixteen GROUP BY columns = the most the device takes; COUNT(DISTINCT x) behind fifteen is a sixteen-column key."""
+    rng = np.random.default_rng(16)
+    n = 80_000
+    keys = [build_column(rng.integers(0, 2, n).astype(np.int32 if g % 2 else np.int64), rng.random(n) < 0.01 if g == 11 else None, 30_000, abi.ENC_DICTIONARY if g % 3 == 0 else abi.ENC_UNENCODED)
+            for g in range(16)]
+    x = build_column(rng.integers(0, 20, n).astype(np.int32), rng.random(n) < 0.1, 30_000, abi.ENC_UNENCODED)
+    run_both(keys, [(abi.AGG_SUM, x), (abi.AGG_COUNT, None), (abi.AGG_MAX, x)], "sixteen columns")
+    run_both(keys[:15], [(abi.AGG_COUNT_DISTINCT, x), (abi.AGG_SUM, x)], "COUNT(DISTINCT), fifteen GROUP BY columns")
+
+
+def test_fused_scan_project_aggregate_over_ten_columns(device):
+    """hy_scan_project_aggregate with a ten-column GROUP BY against the operator chain on the CPU oracle."""
+    rng = np.random.default_rng(1010)
+    n, chunk = 120_000, 40_000
+    hosts = {f"k{g}": build_column(rng.integers(0, 2, n).astype(np.int32), rng.random(n) < 0.01 if g == 7 else None, chunk, abi.ENC_DICTIONARY if g % 2 else abi.ENC_UNENCODED) for g in range(10)}
+    hosts["date"] = build_column(rng.integers(0, 2000, n).astype(np.int32), None, chunk, abi.ENC_DICTIONARY)
+    hosts["price"] = build_column((rng.random(n) * 1000).astype(np.float32), None, chunk, abi.ENC_UNENCODED)
+    devices = {name: DeviceColumn(column) for name, column in hosts.items()}
+    predicate = make_predicate(abi.PRED_LESS_THAN, abi.TYPE_INT, 1200)
+
+    def plan(columns):
+        return ([(columns["date"], predicate)], [columns[f"k{g}"] for g in range(10)], [(abi.AGG_SUM, columns["price"]), (abi.AGG_COUNT, None), (abi.AGG_MAX, columns["price"])])
+
+    chain = oracle_chain(*plan(hosts))
+    got = scan_project_aggregate(*plan(devices), group_capacity=4096)
+    assert_matches_chain(got, chain, 3, "fused, ten GROUP BY columns")
+
+
+def test_seventeen_columns_are_refused(device):
     column = DeviceColumn(build_column(np.arange(100, dtype=np.int32), None, 50, abi.ENC_UNENCODED))
     with pytest.raises(abi.HyriseAmdError) as error:
-        aggregate_hash([column] * 9, [(abi.AGG_COUNT, None)])
+        aggregate_hash([column] * 17, [(abi.AGG_COUNT, None)])
     assert error.value.status == abi.ERR_UNSUPPORTED

@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; files=$2; shift 2
 mkdir -p "$R/hyrise_amd/variants" /tmp/hy_variant_objs
 objs=()
-for f in runtime scan join aggregate aggregate_wide projection exchange boundary comm plan result_pool; do
+for f in runtime scan join aggregate aggregate_wide aggregate_widest projection exchange boundary comm plan result_pool; do
   if [[ " $files " == *" $f.hip "* ]]; then
     o=/tmp/hy_variant_objs/${f}_$name.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wall -Wno-unused-function "$@" "$R/hyrise_amd/csrc/$f.hip" -o "$o" &
