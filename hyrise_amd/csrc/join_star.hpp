@@ -198,12 +198,11 @@ __device__ __forceinline__ void star_request_tile(const StarArgs& a, uint32_t ti
   }
 }
 
-// Which of the tile's rows survive every dimension -> masks[tile], counts[tile] (two barriers)
+// Which of the tile's rows survive every dimension -> masks[tile], counts[tile] (zeroed by the host; a wave adds its survivors: no barrier --
+// the sixteen waves of the workgroup run their tiles' loads and lookups independently of each other)
 __device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile, uint32_t tid, uint32_t first, const StarTileWords& t, const uint32_t (&kind)[STAR_LDS_DIMENSIONS], uint32_t rows,
-                                                const uint32_t* s_star_bits, uint32_t* s_count) {
+                                                const uint32_t* s_star_bits) {
   const uint32_t lane = tid & 63;
-  if (tid == 0) *s_count = 0;
-  __syncthreads();   // (the bits are staged; the count of the tile before has been written)
   uint32_t alive = first >= rows ? 0u : (rows - first < 8 ? (1u << (rows - first)) - 1u : 0xFFu);
 #pragma unroll
   for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
@@ -230,21 +229,19 @@ __device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile
   uint32_t survivors = __popc(alive);
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) survivors += __shfl_xor(survivors, d, 64);
-  if (lane == 0 && survivors) atomicAdd(s_count, survivors);
-  __syncthreads();
-  if (tid == 0) a.counts[tile] = *s_count;
+  if (lane == 0 && survivors) atomicAdd(&a.counts[tile], survivors);
 }
 
 // Persistent workgroups, a tile's words requested while the tile before is looked up (two fixed sets of registers, the loop unrolled by two:
 // rotating one set into the other would wait for the loads just issued).
 __global__ __launch_bounds__(STAR_THREADS) void star_probe_mask(StarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_star_bits[];
-  __shared__ uint32_t s_count;
   const uint32_t tid = threadIdx.x;
   for (uint32_t d = 0; d < a.n_lds; ++d) {
     const StarTable& table = a.table[d];
     for (uint32_t i = tid; i < table.words; i += STAR_THREADS) s_star_bits[table.lds_word + i] = table.bits[i];
   }
+  __syncthreads();   // (the bits are staged: the only barrier)
   const uint32_t first = tid * 8;
   const uint32_t last_tile = a.n_tiles - 1;   // (a tile past the last: the last one's words once more, not used)
   StarTileWords even, odd;
@@ -253,10 +250,10 @@ __global__ __launch_bounds__(STAR_THREADS) void star_probe_mask(StarArgs a) {
   for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += 2 * gridDim.x) {
     const uint32_t next = tile + gridDim.x, after = tile + 2 * gridDim.x;
     star_request_tile(a, next < a.n_tiles ? next : last_tile, first, odd, kind_odd, &rows_odd);
-    star_probe_tile(a, tile, tid, first, even, kind_even, rows_even, s_star_bits, &s_count);
+    star_probe_tile(a, tile, tid, first, even, kind_even, rows_even, s_star_bits);
     if (next >= a.n_tiles) break;
     star_request_tile(a, after < a.n_tiles ? after : last_tile, first, even, kind_even, &rows_even);
-    star_probe_tile(a, next, tid, first, odd, kind_odd, rows_odd, s_star_bits, &s_count);
+    star_probe_tile(a, next, tid, first, odd, kind_odd, rows_odd, s_star_bits);
   }
 }
 
@@ -1214,6 +1211,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   DeviceBuffer masks, counts, base;
   HY_TRY(masks.alloc(size_t{a.n_tiles} * STAR_THREADS + 16));
   HY_TRY(counts.alloc(4 * (size_t{a.n_tiles} + 1)));
+  HY_HIP(hipMemsetAsync(counts.ptr, 0, 4 * (size_t{a.n_tiles} + 1), stream));   // (the probe's waves ADD their survivors)
   HY_TRY(base.alloc(8 * (size_t{a.n_tiles} + 2)));
   a.masks = masks.as<uint8_t>();
   a.counts = counts.as<uint32_t>();
