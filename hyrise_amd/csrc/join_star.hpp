@@ -918,13 +918,13 @@ __global__ __launch_bounds__(256) void star_finish_compact(StarArgs a, StarFinis
     const uint32_t tile = position >> 13, row = position & 8191u;
     const u32x4_t* quads = reinterpret_cast<const u32x4_t*>(a.masks + static_cast<size_t>(tile) * STAR_THREADS);
     uint32_t bits = 0;
-    const uint32_t full = row / 128;   // whole 16-byte pieces in front of the row: up to 63, four loads in flight
-    for (uint32_t q = 0; q < full; q += 4) {
-      u32x4_t piece[4];
+    const uint32_t full = row / 128;   // whole 16-byte pieces in front of the row: up to 63, sixteen loads in flight
+    for (uint32_t q = 0; q < full; q += 16) {
+      u32x4_t piece[16];
 #pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) piece[k] = quads[q + k < full ? q + k : q];
+      for (uint32_t k = 0; k < 16; ++k) piece[k] = quads[q + k < full ? q + k : q];
 #pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) if (q + k < full) bits += __popc(piece[k].x) + __popc(piece[k].y) + __popc(piece[k].z) + __popc(piece[k].w);
+      for (uint32_t k = 0; k < 16; ++k) if (q + k < full) bits += __popc(piece[k].x) + __popc(piece[k].y) + __popc(piece[k].z) + __popc(piece[k].w);
     }
     const u32x4_t last_piece = quads[full];
     const uint32_t in_piece = row & 127u;
