@@ -256,8 +256,11 @@ extern thread_local uint32_t t_aggregate_recommended, t_aggregate_next_path;
 // ---- join_star.hpp (join.hip): the probes of a star join fused into one pass over the fact table (hy_star_join_aggregate, plan.hip) ------
 struct StarProbeDimension {
   const hy_column* key;        // the dimension's key column (int32, unique among `rows`)
-  const hy_row_id* rows;       // the dimension rows that take part (device memory): the rows that pass its filter, or all of them
-  uint64_t n_rows;             // how many -- or, with d_n_rows, at most how many
+  const hy_row_id* rows;       // the dimension rows that take part (device memory): the rows that pass its filter, or all of them -- or nullptr:
+                               // every row of the key column's table that passes `filter` (tested by the kernels that build the dimension's tables)
+  const hy_column* filter;     // rows == nullptr: the column the filter tests (a data column of the dimension's table), or nullptr: no filter
+  const struct ScanJob* filter_jobs;   // ... and its per-chunk jobs in device memory (prepare_scan_jobs)
+  uint64_t n_rows;             // how many -- or, with d_n_rows / a filter, at most how many
   const uint64_t* d_n_rows;    // the count in device memory (a scan's total that no host has read), or nullptr
   const hy_column* fact_key;   // the fact table's foreign key to this dimension
   bool want_rows;              // the caller reads columns of this dimension at the surviving rows

@@ -34,6 +34,7 @@
 #include "hy_device.hpp"
 #include "hy_decode.hpp"
 #include "hy_arithmetic.hpp"
+#include "hy_scan_job.hpp"
 
 #include <algorithm>
 #include <atomic>

@@ -66,7 +66,61 @@ struct StarDimensionJobs {
   int64_t key_min[HY_MAX_STAR_DIMENSIONS];              // star_dim_fill
   uint32_t* bits[HY_MAX_STAR_DIMENSIONS];
   uint32_t* ids[HY_MAX_STAR_DIMENSIONS];
+  // rows == nullptr: EVERY row of the table, tested here against the dimension's filter (round 6: a TableScan, a prefix and a translation per
+  // dimension -- three launches over a table of a few thousand to a million rows -- were a tenth of an SSB query) -- or against none
+  const uint64_t* row_base[HY_MAX_STAR_DIMENSIONS];     // [n_chunks + 1] first row of every chunk of the table
+  uint32_t n_chunks[HY_MAX_STAR_DIMENSIONS];
+  uint32_t chunk_rows[HY_MAX_STAR_DIMENSIONS];          // rows of every chunk but the last where they agree, else 0
+  const DevSegment* filter_segments[HY_MAX_STAR_DIMENSIONS];   // nullptr: no filter
+  const ScanJob* filter_jobs[HY_MAX_STAR_DIMENSIONS];          // [n_chunks] the filter's normalised test per chunk (prepare_scan_jobs)
 };
+
+// One row of a data segment against its chunk's job -- what scan_slices decides for the row (hy_scan_job.hpp; JOB_RANGE does not occur:
+// prepare_scan_jobs asks for none).  NULL never matches a comparison.
+__device__ __forceinline__ bool star_filter_row(const DevSegment& s, const ScanJob& job, uint32_t row) {
+  if (job.mode == JOB_ALL) return true;
+  if (job.mode == JOB_NONE) return false;
+  const bool invert = job.flags & JF_INVERT;
+  if (s.encoding == HY_ENC_DICTIONARY) {
+    const uint32_t vid = aload_compressed(s.data, s.width, row);
+    if (job.kind == KIND_VALUE_ID_SET) return vid < job.null_vid && ((reinterpret_cast<const uint64_t*>(job.lo)[vid >> 6] >> (vid & 63)) & 1) != 0;
+    if (job.kind == KIND_NULLTEST) return (vid == s.aux_size) != invert;
+    const bool in = (vid - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+    return (in != invert) && vid != job.null_vid;
+  }
+  const bool is_null = s.nulls ? ((s.nulls[row >> 6] >> (row & 63)) & 1) != 0 : false;
+  if (job.kind == KIND_NULLTEST) return is_null != invert;
+  if (is_null) return false;
+  bool in;
+  if (s.encoding == HY_ENC_FRAME_OF_REFERENCE) {
+    const uint32_t x = aload_compressed(s.data, s.width, row) + static_cast<uint32_t>(static_cast<const int32_t*>(s.aux)[row / HY_FOR_BLOCK_SIZE]);
+    in = (x - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+  } else if (job.kind == KIND_U32) {
+    in = (static_cast<const uint32_t*>(s.data)[row] - static_cast<uint32_t>(job.lo)) <= static_cast<uint32_t>(job.span);
+  } else if (job.kind == KIND_I64) {
+    in = (static_cast<const uint64_t*>(s.data)[row] - job.lo) <= job.span;
+  } else if (job.kind == KIND_F32) {
+    const float x = static_cast<const float*>(s.data)[row];
+    const float lower = __uint_as_float(static_cast<uint32_t>(job.lo)), upper = __uint_as_float(static_cast<uint32_t>(job.span));
+    in = ((job.flags & JF_LOWER_INCL) ? x >= lower : x > lower) && ((job.flags & JF_UPPER_INCL) ? x <= upper : x < upper);
+  } else {
+    const double x = static_cast<const double*>(s.data)[row];
+    const double lower = __longlong_as_double(static_cast<long long>(job.lo)), upper = __longlong_as_double(static_cast<long long>(job.span));
+    in = ((job.flags & JF_LOWER_INCL) ? x >= lower : x > lower) && ((job.flags & JF_UPPER_INCL) ? x <= upper : x < upper);
+  }
+  return in != invert;
+}
+
+// Row i of a table (rows counted through its chunks) -> RowID: the chunk whose first row is the last at or below i
+__device__ __forceinline__ hy_row_id star_row_of_table(const uint64_t* row_base, uint32_t n_chunks, uint32_t chunk_rows, uint64_t i) {
+  if (chunk_rows) { const uint32_t chunk = static_cast<uint32_t>(i / chunk_rows); return hy_row_id{chunk, static_cast<uint32_t>(i - uint64_t{chunk} * chunk_rows)}; }   // (chunks of one size, the last may be shorter)
+  uint32_t low = 0, high = n_chunks;   // row_base[low] <= i < row_base[high]
+  while (high - low > 1) {
+    const uint32_t middle = (low + high) / 2;
+    if (row_base[middle] <= i) low = middle; else high = middle;
+  }
+  return hy_row_id{low, static_cast<uint32_t>(i - row_base[low])};
+}
 
 // extent[0] = smallest value ^ sign, extent[1] = largest value ^ sign of a data column (NULLs skipped); one workgroup per chunk
 __global__ __launch_bounds__(256) void star_column_extent(const DevSegment* segments, unsigned long long* extent) {
@@ -113,11 +167,14 @@ __global__ __launch_bounds__(256) void star_dim_fill(StarDimensionJobs jobs, uin
     bool valid = i < n;
     uint32_t rel = 0;
     if (valid) {
-      const hy_row_id row = rows[i];
+      const hy_row_id row = rows ? rows[i] : star_row_of_table(jobs.row_base[d], jobs.n_chunks[d], jobs.chunk_rows[d], i);
+      if (!rows && jobs.filter_segments[d]) valid = star_filter_row(jobs.filter_segments[d][row.chunk_id], jobs.filter_jobs[d][row.chunk_id], row.chunk_offset);
+    if (valid) {
       const Value v = column_value(segments, row.chunk_id, row.chunk_offset);
       valid = !v.is_null;
       rel = static_cast<uint32_t>(v.i - key_min);
       if (valid) ids[rel] = row.chunk_id << 16 | row.chunk_offset;
+    }
     }
     const uint32_t word = rel >> 5, bit = 1u << (rel & 31);
     uint64_t todo = __ballot(valid);
@@ -463,27 +520,22 @@ struct StarFinishHeader {       // what the host reads after the plan's last ker
 // The attribute tables: per dimension column the aggregate reads, its value at every key of the dimension's rows (blockIdx.y = attribute).
 // A NULL cell raises *null_met (the finish carries no NULLs: the caller takes the RowID path).
 struct StarAttributeJobs {
-  const DevSegment* key_segments[STAR_FINISH_ATTRIBUTES];
+  const uint32_t* bits[STAR_FINISH_ATTRIBUTES];   // the dimension's direct table (star_dim_fill): presence bit and packed RowID per key
+  const uint32_t* ids[STAR_FINISH_ATTRIBUTES];
+  uint64_t keys[STAR_FINISH_ATTRIBUTES];          // range + 1
   const DevSegment* segments[STAR_FINISH_ATTRIBUTES];
-  const hy_row_id* rows[STAR_FINISH_ATTRIBUTES];
-  uint64_t n[STAR_FINISH_ATTRIBUTES];
-  const uint64_t* n_in_memory[STAR_FINISH_ATTRIBUTES];
-  int64_t key_min[STAR_FINISH_ATTRIBUTES];
   int64_t* out[STAR_FINISH_ATTRIBUTES];
   long long* extent;            // [STAR_FINISH_ATTRIBUTES][2] smallest / largest value of every attribute (star_finish_plan: the direct-mapped groups)
 };
+// A thread per key VALUE of the dimension: where the key is present, the column's cell at the row the table names.
 __global__ __launch_bounds__(256) void star_dim_attributes(StarAttributeJobs jobs, uint32_t* null_met) {
   const uint32_t k = blockIdx.y;
-  const hy_row_id* rows = jobs.rows[k];
-  const uint64_t n = jobs.n_in_memory[k] ? *jobs.n_in_memory[k] : jobs.n[k];
   long long low = INT64_MAX, high = INT64_MIN;
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) {
-    const hy_row_id row = rows[i];
-    const Value key = column_value(jobs.key_segments[k], row.chunk_id, row.chunk_offset);
-    if (key.is_null) continue;
-    const Value v = column_value(jobs.segments[k], row.chunk_id, row.chunk_offset);
+  for (uint64_t rel = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; rel < jobs.keys[k]; rel += static_cast<uint64_t>(gridDim.x) * 256) {
+    if (!((jobs.bits[k][rel >> 5] >> (rel & 31)) & 1)) continue;
+    const uint32_t id = jobs.ids[k][rel];
+    const Value v = column_value(jobs.segments[k], id >> 16, id & 0xFFFFu);
     if (v.is_null) { *null_met = 1; continue; }
-    const uint32_t rel = static_cast<uint32_t>(key.i - jobs.key_min[k]);
     jobs.out[k][rel] = v.i;
     low = v.i < low ? v.i : low;
     high = v.i > high ? v.i : high;
@@ -494,12 +546,17 @@ __global__ __launch_bounds__(256) void star_dim_attributes(StarAttributeJobs job
     low = other_low < low ? other_low : low;
     high = other_high > high ? other_high : high;
   }
-  __shared__ long long s_low[4], s_high[4];   // (one pair of atomics per workgroup: thousands of waves on two words took longer than the table)
+  __shared__ long long s_low[4], s_high[4];
   if ((threadIdx.x & 63) == 0) { s_low[threadIdx.x >> 6] = low; s_high[threadIdx.x >> 6] = high; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (uint32_t w = 1; w < 4; ++w) { low = s_low[w] < low ? s_low[w] : low; high = s_high[w] > high ? s_high[w] : high; }
-    if (low <= high) { atomicMin(jobs.extent + 2 * k, low); atomicMax(jobs.extent + 2 * k + 1, high); }
+    // (an atomic only where the workgroup's values widen what is there: a dimension's attribute takes a handful of values, and thousands of
+    //  workgroups on two words took longer than the table)
+    if (low <= high) {
+      if (low < __hip_atomic_load(jobs.extent + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(jobs.extent + 2 * k, low);
+      if (high > __hip_atomic_load(jobs.extent + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(jobs.extent + 2 * k + 1, high);
+    }
   }
 }
 
@@ -1097,6 +1154,17 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     jobs.rows[d] = dimensions[d].rows;
     jobs.n[d] = dimensions[d].n_rows;
     jobs.n_in_memory[d] = dimensions[d].d_n_rows;
+    jobs.row_base[d] = dimensions[d].key->d_row_base;
+    jobs.n_chunks[d] = dimensions[d].key->n_chunks;
+    {   // chunks of one size (all but the last): the row -> RowID arithmetic needs no search
+      const hy_column* key = dimensions[d].key;
+      uint32_t size = key->n_chunks ? key->host_segments[0].size : 0;
+      for (uint32_t c = 0; c + 1 < key->n_chunks && size; ++c) if (key->host_segments[c].size != size) size = 0;
+      if (key->n_chunks && key->host_segments[key->n_chunks - 1].size > size) size = 0;
+      jobs.chunk_rows[d] = size;
+    }
+    jobs.filter_segments[d] = dimensions[d].filter ? dimensions[d].filter->d_segments : nullptr;
+    jobs.filter_jobs[d] = dimensions[d].filter_jobs;
     most_rows = std::max(most_rows, dimensions[d].n_rows);
   }
   // (a row per thread: a row is three dependent round trips and an atomic that is waited for -- 256 workgroups walking a million rows spent 59 us on it)
@@ -1138,21 +1206,23 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   if (!nothing_joins && plan.on && !plan.attributes.empty()) {   // what the aggregate reads of the dimensions, per key
     StarAttributeJobs attribute_jobs;
     std::memset(&attribute_jobs, 0, sizeof(attribute_jobs));
+    uint64_t most_keys = 1;
     for (size_t k = 0; k < plan.attributes.size(); ++k) {
       const uint32_t d = plan.attributes[k].first;
       const hy_column* column = plan.attributes[k].second;
       plan.attribute_tables.push_back(std::make_unique<DeviceBuffer>());
       HY_TRY(plan.attribute_tables.back()->alloc(8 * (built[d]->range + 1) + 16));
-      attribute_jobs.key_segments[k] = jobs.segments[d];
+      attribute_jobs.bits[k] = jobs.bits[d];
+      attribute_jobs.ids[k] = jobs.ids[d];
+      attribute_jobs.keys[k] = built[d]->range + 1;
       attribute_jobs.segments[k] = column->d_segments;
-      attribute_jobs.rows[k] = jobs.rows[d];
-      attribute_jobs.n[k] = jobs.n[d];
-      attribute_jobs.n_in_memory[k] = jobs.n_in_memory[d];
-      attribute_jobs.key_min[k] = jobs.key_min[d];
+      most_keys = std::max(most_keys, built[d]->range + 1);
       attribute_jobs.out[k] = plan.attribute_tables.back()->as<int64_t>();
     }
     attribute_jobs.extent = plan.extents.as<long long>();
-    hipLaunchKernelGGL(star_dim_attributes, dim3(std::min(job_grid, 1024u), static_cast<uint32_t>(plan.attributes.size())), dim3(256), 0, stream, attribute_jobs,
+    const uint64_t attribute_blocks = (most_keys + 255) / 256;
+    const dim3 attribute_grid(static_cast<uint32_t>(attribute_blocks < 512 ? attribute_blocks : 512), static_cast<uint32_t>(plan.attributes.size()));   // (keys without a row cost a coalesced word: a few per thread)
+    hipLaunchKernelGGL(star_dim_attributes, attribute_grid, dim3(256), 0, stream, attribute_jobs,
                        reinterpret_cast<uint32_t*>(plan.table.ptr) + STAR_FLAG_NULL_ATTRIBUTE);
   }
   dimension_rows.clear();

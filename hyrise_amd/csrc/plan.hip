@@ -12,6 +12,7 @@
 //     columns, which the primary-key / foreign-key join kernels and the aggregate's streaming decoders read with wide loads;
 //   * per joined table the base RowIDs of every surviving row are carried along (hy_gather_row_ids with the probe positions).
 #include "hy_device.hpp"
+#include "hy_scan_job.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -311,15 +312,36 @@ hy_status hy_star_join_aggregate(const hy_star_dimension* dimensions, uint32_t n
       dimension_rows[d] = std::make_unique<DeviceBuffer>();
       uint64_t n_dimension_rows = dimension.key->rows;
       const uint64_t* count_in_memory = nullptr;
-      if (dimension.filter_column) {
-        counts[d] = std::make_unique<DeviceBuffer>();
-        HY_TRY(filtered_rows(dimension.filter_column, &dimension.predicate, *dimension_rows[d], &n_dimension_rows, counts[d].get()));
-        count_in_memory = counts[d]->as<uint64_t>() + dimension.filter_column->n_chunks;
-      } else HY_TRY(star_all_rows_of(dimension.key, *dimension_rows[d]));
+      const hy_row_id* rows = nullptr;
+      const ScanJob* filter_jobs = nullptr;
+      // The kernels that build a dimension's tables walk the table itself and test its filter row by row (join_star.hpp: no TableScan, no
+      // PosList for a table of a few thousand to a million rows) where its columns are plain data columns; otherwise: the rows a scan leaves.
+      const bool in_place = !dimension.key->has_compressed && !dimension.key->is_mvcc &&
+                            (!dimension.filter_column || (!dimension.filter_column->is_reference && !dimension.filter_column->is_mvcc && !dimension.filter_column->has_compressed));
+      bool tested_in_place = in_place && !dimension.filter_column;
+      if (in_place && dimension.filter_column) {
+        const uint32_t n_chunks = dimension.filter_column->n_chunks;
+        const size_t jobs_bytes = (sizeof(ScanJob) * (size_t{n_chunks} + 1) + 255) & ~size_t{255};
+        counts[d] = std::make_unique<DeviceBuffer>();   // (the jobs and what prepare_jobs stages of the predicate)
+        HY_TRY(counts[d]->alloc(jobs_bytes + scan_jobs_staging_bytes(dimension.filter_column, &dimension.predicate) + 512));
+        ScanJob* jobs = counts[d]->as<ScanJob>();
+        if (prepare_scan_jobs(dimension.filter_column, &dimension.predicate, jobs, counts[d]->as<char>() + jobs_bytes) == HY_OK) {
+          filter_jobs = jobs;
+          tested_in_place = true;
+        }   // (a predicate the scan refuses: hy_table_scan below says why)
+      }
+      if (!tested_in_place) {
+        if (dimension.filter_column) {
+          counts[d] = std::make_unique<DeviceBuffer>();
+          HY_TRY(filtered_rows(dimension.filter_column, &dimension.predicate, *dimension_rows[d], &n_dimension_rows, counts[d].get()));
+          count_in_memory = counts[d]->as<uint64_t>() + dimension.filter_column->n_chunks;
+        } else HY_TRY(star_all_rows_of(dimension.key, *dimension_rows[d]));
+        rows = dimension_rows[d]->as<hy_row_id>();
+      }
       bool wanted = false;
       for (uint32_t g = 0; g < n_groupby; ++g) wanted = wanted || groupby[g].table == d + 1;
       for (uint32_t a = 0; a < n_aggregates; ++a) wanted = wanted || (aggregates[a].left.column && aggregates[a].left.table == d + 1) || (aggregates[a].op != HY_STAR_NO_OP && aggregates[a].right.table == d + 1);
-      probes[d] = StarProbeDimension{dimension.key, dimension_rows[d]->as<hy_row_id>(), n_dimension_rows, count_in_memory, dimension.fact_key, wanted};
+      probes[d] = StarProbeDimension{dimension.key, rows, filter_jobs ? dimension.filter_column : nullptr, filter_jobs, n_dimension_rows, count_in_memory, dimension.fact_key, wanted};
     }
     if (shape_ok) {
       auto fact_rows = std::make_unique<DeviceBuffer>();
