@@ -313,7 +313,14 @@ using namespace hy;
 
 extern "C" {
 
-hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls) {
+hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls) { return hy::export_column_at(column, values, nulls, nullptr); }
+
+}  // extern "C"
+
+namespace hy {
+// hy_column_export with the chunks' first rows given (device array [n_chunks], in elements): row r of chunk c goes to values[row_base[c] + r]
+// -- join.hip materialises reference inputs chunk by chunk on 16-byte boundaries.  nullptr: the column's own (back to back).
+hy_status export_column_at(const hy_column* column, void* values, uint8_t* nulls, const uint64_t* d_row_base) {
   if (!column || !values) return fail(HY_ERR_INVALID, "hy_column_export: null argument");
   HY_TRY(on_this_device(column, "hy_column_export"));
   if (column->is_mvcc) return fail(HY_ERR_INVALID, "MVCC columns are read by hy_validate only");
@@ -325,7 +332,7 @@ hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls
   ExportArgs a{};
   a.segments = column->d_segments;
   a.slices = column->d_slices;
-  a.row_base = column->d_row_base;
+  a.row_base = d_row_base ? d_row_base : column->d_row_base;
   a.values = values;
   a.nulls = nulls;
   a.width = (column->data_type == HY_TYPE_INT || column->data_type == HY_TYPE_FLOAT) ? 4 : 8;
@@ -335,6 +342,9 @@ hy_status hy_column_export(const hy_column* column, void* values, uint8_t* nulls
   HY_HIP(hipGetLastError());
   return HY_OK;
 }
+}  // namespace hy
+
+extern "C" {
 
 static hy_status repartition_check(const hy_column* column, uint32_t parts) {
   if (!column) return fail(HY_ERR_INVALID, "hy_repartition: null column");

@@ -253,6 +253,9 @@ struct DeviceBuffer {
 // t_aggregate_next_path: set before a call -- b + 1 starts that call on the partitioned path with b bits (consumed by the call).
 extern thread_local uint32_t t_aggregate_recommended, t_aggregate_next_path;
 
+// exchange.hip: hy_column_export with the chunks' first rows given (device array [n_chunks], in elements; nullptr: the column's own)
+hy_status export_column_at(const hy_column* column, void* values, uint8_t* nulls, const uint64_t* d_row_base);
+
 // ---- join_star.hpp (join.hip): the probes of a star join fused into one pass over the fact table (hy_star_join_aggregate, plan.hip) ------
 struct StarProbeDimension {
   const hy_column* key;        // the dimension's key column (int32, unique among `rows`)

@@ -117,6 +117,37 @@ def test_join_reference_inputs(device):
             assert_join_equal(got, want, mode, f"reference inputs mode {mode} radix {radix_bits}")
 
 
+@pytest.mark.parametrize("with_nulls", [False, True], ids=["no_nulls", "null_row_ids"])
+def test_join_large_reference_inputs_are_materialised(device, with_nulls):
+    """Reference inputs of 131 072 rows and more are read through their PosLists once, into a plain int32 column with the input's chunk layout
+    (JoinHash materialises its inputs, join_hash_steps.hpp:274-330), and the join runs on that -- unless a key is NULL (a NULL RowID of an
+    outer join, a NULL cell), which keeps the reference column.  The pairs are positions in the INPUT tables either way: oracle's bytes."""
+    rng = np.random.default_rng(131 + with_nulls)
+    n_keys, n_l, n_r = 40_000, 150_000, 260_000
+    base_l = build_column(rng.permutation(n_keys).astype(np.int32), None, 7_000, abi.ENC_UNENCODED)                      # unique keys: a rank table
+    base_r = build_column(rng.integers(0, n_keys + 500, 300_000).astype(np.int32), None, 50_000, abi.ENC_FRAME_OF_REFERENCE)
+    pos_l = [np.stack([np.full(5_000, c, dtype=np.uint32), np.sort(rng.choice(7_000 if c + 1 < base_l.n_chunks else n_keys - 7_000 * (base_l.n_chunks - 1), 5_000, replace=False)).astype(np.uint32)], axis=1)
+             for c in range(base_l.n_chunks)]
+    # the right input: chunks of irregular sizes (what a join's output looks like), positions all over the base table
+    sizes = [1, 33_333, 100_001, n_r - 133_335]
+    pos_r = []
+    for size in sizes:
+        p = np.stack([rng.integers(0, base_r.n_chunks, size).astype(np.uint32), rng.integers(0, 50_000, size).astype(np.uint32)], axis=1)
+        if with_nulls:
+            p[::1013] = 0xFFFFFFFF
+        pos_r.append(p)
+    ref_l = storage.make_reference_column(base_l, pos_l, list(range(base_l.n_chunks)))
+    ref_r = storage.make_reference_column(base_r, pos_r, [None] * len(sizes))
+    assert sum(len(p) for p in pos_l) < 131_072 <= sum(sizes)
+    bl, br = DeviceColumn(base_l), DeviceColumn(base_r)
+    dl, dr = DeviceColumn(ref_l, refs={id(base_l): bl}), DeviceColumn(ref_r, refs={id(base_r): br})
+    for mode in (abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_SEMI, abi.JOIN_ANTI_NULL_AS_FALSE):
+        for left, right, host_l, host_r in ((dl, dr, ref_l, ref_r), (dr, dl, ref_r, ref_l)):
+            got = join_hash(left, right, mode, None)
+            want = oracle_join(host_l, host_r, mode, None)
+            assert_join_equal(got, want, mode, f"large reference inputs, mode {mode}, nulls {with_nulls}")
+
+
 def test_join_reference_inputs_with_float_keys(device):
     """The same shape of reference tables, a float column against an int64 one (HashedType float)."""
     rng = np.random.default_rng(9)
