@@ -363,7 +363,8 @@ def bench(sf=30.0, steps=3, world=1, rank=0, dist=None, share_gpu=False, local_r
             star_seconds = (time.perf_counter() - t0) / steps
             entry["operator_calls_from_python_ms"] = entry["ms"]
             entry.update({"ms": star_seconds * 1e3, "lineorder_rows_per_s": data.n_lineorder / star_seconds, "GBps_on_algorithmic_bytes": algorithmic / star_seconds / 1e9,
-                          "plan": "hy_star_join_aggregate: scan -> JoinHash per dimension -> projection -> AggregateHash as one call of the library (csrc/plan.hip); "
+                          "plan": "hy_star_join_aggregate: scan -> JoinHash per dimension -> projection -> AggregateHash as one call of the library (csrc/plan.hip, join_star.hpp: "
+                                  "every dimension probed in one pass over lineorder, the survivors grouped inside it); "
                                   "operator_calls_from_python_ms: the same calls made one by one through ctypes (hyrise_amd/ssb.py run_query)"})
         if comm is not None:   # every rank's shard as ONE hy_star_join_aggregate call, the ranks' partial groups added up
             star = {}
