@@ -22,7 +22,7 @@ constexpr uint32_t FS_THREADS = 1024;
 constexpr uint32_t FS_ROWS = 4;          // consecutive rows of a lane per step (their expressions are evaluated side by side)
 constexpr uint32_t FS_STEPS = 16;        // steps per span
 constexpr uint32_t FS_SPAN = FS_THREADS * FS_ROWS * FS_STEPS;   // 65536 rows: a Hyrise chunk (at most 65535 rows) is one span; the host sends no larger chunk here
-constexpr uint32_t FS_FILTERS = 3;        // (TPC-H Q6 tests three columns)
+constexpr uint32_t FS_FILTERS = 2;
 constexpr uint32_t FS_NARROW = 3;        // columns with 1-byte value ids the expressions read: slots 0 .. 2
 constexpr uint32_t FS_COLUMNS = FS_NARROW + 1;   // slot 3: the column with 2-byte value ids
 constexpr uint32_t FS_INPUTS = 5;        // accumulators with an expression

@@ -49,9 +49,6 @@ def plans():
         # no GROUP BY: one group; Q6's expression behind two of its filters
         Plan("no_groups", [("l_shipdate", p(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, 731, 1096)), ("l_discount", p(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, F32(0.05), F32(0.07)))],
              [], [(abi.AGG_SUM, (MUL, "l_extendedprice", "l_discount")), (abi.AGG_COUNT, None)]),
-        # TPC-H Q6 whole: three filters (round 6: the kernel takes three), its one expression, no GROUP BY
-        Plan("q6", [("l_shipdate", p(abi.PRED_BETWEEN_UPPER_EXCLUSIVE, abi.TYPE_INT, 731, 1096)), ("l_discount", p(abi.PRED_BETWEEN_INCLUSIVE, abi.TYPE_FLOAT, F32(0.05), F32(0.07))),
-                    ("l_quantity", p(abi.PRED_LESS_THAN, abi.TYPE_FLOAT, 24.0))], [], [(abi.AGG_SUM, (MUL, "l_extendedprice", "l_discount")), (abi.AGG_COUNT, None)]),
         # a filter that empties some chunks' jobs and an inverted range
         Plan("not_equals", [("l_tax", p(abi.PRED_NOT_EQUALS, abi.TYPE_FLOAT, F32(0.04)))], ["l_returnflag"], [(abi.AGG_AVG, "l_extendedprice"), (abi.AGG_SUM, (SUB, "l_extendedprice", "l_quantity"))]),
         Plan("nothing_passes", [("l_shipdate", p(abi.PRED_GREATER_THAN, abi.TYPE_INT, 5000))], ["l_returnflag"], [(abi.AGG_SUM, "l_quantity"), (abi.AGG_COUNT, None)]),
