@@ -294,14 +294,14 @@ def compact_line(line, details_path=None):
     out["value"], out["ms_per_step"] = _short(line["value"], 6), _short(line["ms_per_step"], 6)
     cfg = line["config"]
     out["config"] = {"workload": "configs[1]+configs[2] per step: TableScan l_shipdate<1995-01-01 (Dictionary int32, u16 ids) + JoinHash orders x lineitem Inner "
-                                 "(o_orderkey int32 build, l_orderkey FoR u16 probe), SF10, HBM-resident, 3 column copies in rotation, HY_JOIN_ASYNC, "
+                                 "(o_orderkey int32 build, l_orderkey FoR u16 probe), SF10, in HBM, 3 column copies in rotation, HY_JOIN_ASYNC, "
                                  "build-key hint from an earlier join",
                      "rows_per_step_per_gpu": cfg["rows_per_step_per_gpu"], "scan_rows": cfg["scan_rows"], "build_rows": cfg["build_rows"], "probe_rows": cfg["probe_rows"],
-                     "chunks_per_gpu": cfg["chunks_per_gpu"], "scan_selectivity": _short(cfg["scan_selectivity"], 4), "join_pairs": cfg["join_pairs"], "parallelism": cfg["parallelism"]}
+                     "chunks_per_gpu": cfg["chunks_per_gpu"], "scan_selectivity": _short(cfg["scan_selectivity"], 4), "parallelism": cfg["parallelism"]}   # (join_pairs = probe_rows: in the details)
     if cfg.get("output_placement"):
         out["config"]["output_placement"] = cfg["output_placement"]
-        out["config"]["workload"] += (", PosLists in the library's result-buffer pool, calibrated over %d placements before the timed region (hy_result_pool_calibrate); "
-                                      "ms_per_step_median_placement: the same step in the median candidate") % cfg["output_placement"]["candidates"]
+        out["config"]["workload"] += (", PosLists from the library's pool (hy_result_pool_calibrate over %d placements before the timed region); "
+                                      "ms_per_step_median_placement: the step in the median candidate") % cfg["output_placement"]["candidates"]
         out["config"]["output_placement"] = {k: v for k, v in cfg["output_placement"].items() if k != "by"}
     r = line["roofline"]
     roof = compact_roofline(r, "TableScan+JoinHash step, host-timed")
@@ -312,7 +312,7 @@ def compact_line(line, details_path=None):
     out["roofline"] = roof
     if "cpu_baseline" in line:
         c = line["cpu_baseline"]
-        out["cpu_baseline"] = compact_cpu_baseline(c, "full SF10 step on the host cores: oracle TableScan (median) then oracle JoinHash (median), all threads")
+        out["cpu_baseline"] = compact_cpu_baseline(c, "full SF10 step on the host: oracle scan then oracle join (medians), all threads")
         out["cpu_baseline"]["scan"] = _short(c["scan"]["value"])
         out["cpu_baseline"]["join"] = _short(c["join"]["value"])
     legs = {}
@@ -342,7 +342,7 @@ def compact_line(line, details_path=None):
     if "ssb" in line:
         s = line["ssb"]
         legs["ssb_sf30"] = {q: {"ms": _short(s[q]["ms"]), "frac": _short(s[q]["roofline"]["frac"], 4), "groups": s[q]["groups"], "joined_rows": s[q]["joined_rows"],
-                                "oracle_parity": s[q].get("oracle_parity")} for q in ("q2.1", "q4.1") if q in s}
+                                "oracle_parity": "equal" if s[q].get("oracle_parity") else None} for q in ("q2.1", "q4.1") if q in s}   # (the sentence: bench_details.json; the run fails on a difference)
         if "cpu_baseline" in s:
             for q in ("q2.1", "q4.1"):
                 legs["ssb_sf30"][q]["cpu_rows_per_s"] = _short(s["cpu_baseline"][q]["value"])

@@ -18,7 +18,7 @@ def full_line():
 
 def check(compact):
     text = json.dumps(compact, separators=(",", ":"))
-    assert "\n" not in text and len(text) < 6000, len(text)
+    assert "\n" not in text and len(text) < 4096, len(text)
     parsed = json.loads(text)
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "dominant_kernel", "kernels"):
         assert key in parsed["roofline"], key
