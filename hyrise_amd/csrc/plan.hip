@@ -62,8 +62,9 @@ static hy_status reference_column(const hy_column* base, const hy_row_id* rows, 
   return hy_column_create(segments.data(), n_chunks, HY_MEM_DEVICE, &out.column);
 }
 
-// `values` (n elements of `data_type`, device memory, no NULLs) as ValueSegments of DENSE_CHUNK rows
-static hy_status value_column(const void* values, uint64_t n, uint32_t data_type, ColumnHandle& out, uint32_t chunk_rows = DENSE_CHUNK) {
+// `values` (n elements of `data_type`, device memory) as ValueSegments of DENSE_CHUNK rows; null_words: one bit per row (bit r & 63 of word
+// r >> 6: a ValueSegment's null vector, chunk after chunk -- chunk_rows is a multiple of 64), or nullptr: no NULLs
+static hy_status value_column(const void* values, uint64_t n, uint32_t data_type, ColumnHandle& out, uint32_t chunk_rows = DENSE_CHUNK, const uint64_t* null_words = nullptr) {
   const uint32_t n_chunks = static_cast<uint32_t>(std::max<uint64_t>(1, (n + chunk_rows - 1) / chunk_rows));
   const size_t width = type_bytes(data_type);
   std::vector<hy_segment> segments(n_chunks);
@@ -76,6 +77,7 @@ static hy_status value_column(const void* values, uint64_t n, uint32_t data_type
     s.size = static_cast<uint32_t>(end > begin ? end - begin : 0);
     s.width = static_cast<uint32_t>(width);
     s.data = static_cast<const char*>(values) + begin * width;
+    s.nulls = null_words ? null_words + begin / 64 : nullptr;
     s.ref_chunk_id = 0xFFFFFFFFu;
   }
   return hy_column_create(segments.data(), n_chunks, HY_MEM_DEVICE, &out.column);
@@ -96,11 +98,25 @@ __global__ __launch_bounds__(256) void any_null_byte(const uint8_t* bytes, uint6
   if (__any(any) && (threadIdx.x & 63) == 0) *found = 1;
 }
 
-// column `base` at the rows `rows` as a plain value column (values in `storage`).  The intermediate tables of this plan carry no null vectors:
-// a column whose cells at these rows include a NULL (a nullable foreign key, a GROUP BY column with NULLs) sends the caller to the operator chain.
+// one bit per row out of one byte per row (hy_column_export's NULL flags -> a ValueSegment's null vector); n: a multiple of 64 rows are written
+__global__ __launch_bounds__(256) void null_bytes_to_words(const uint8_t* bytes, uint64_t n, uint64_t* words) {
+  const uint64_t padded = (n + 63) & ~uint64_t{63};
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < padded; i += static_cast<uint64_t>(gridDim.x) * 256) {
+    const uint64_t lanes = __ballot(i < n && bytes[i] != 0);
+    if ((threadIdx.x & 63) == 0) words[i >> 6] = lanes;
+  }
+}
+
+// column `base` at the rows `rows` as a plain value column (values -- and, where a cell is NULL, the null vector -- in `storage`): a nullable
+// foreign key whose NULL finds no partner, a GROUP BY column whose NULLs are a group of their own, an aggregate input whose NULLs are skipped
+// (round 6; before, a NULL cell sent the whole plan back to the caller's operator chain)
 static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint64_t n, DeviceBuffer& storage, ColumnHandle& out, uint32_t chunk_rows = DENSE_CHUNK) {
   if (base->data_type < HY_TYPE_INT || base->data_type > HY_TYPE_DOUBLE) return fail(HY_ERR_UNSUPPORTED, "hy_star_join_aggregate: numeric columns only");
-  HY_TRY(storage.alloc(type_bytes(base->data_type) * std::max<uint64_t>(n, 1) + 16));
+  const size_t values_bytes = (type_bytes(base->data_type) * std::max<uint64_t>(n, 1) + 16 + 255) & ~size_t{255};
+  const size_t words_bytes = 8 * ((std::max<uint64_t>(n, 1) + 63) / 64) + 64;
+  const bool nullable = n != 0 && may_hold_nulls(base);
+  HY_TRY(storage.alloc(values_bytes + (nullable ? words_bytes : 0)));
+  const uint64_t* null_words = nullptr;
   if (n) {
     auto through_owner = std::make_unique<ColumnHandle>();
     ColumnHandle& through = *through_owner;
@@ -120,12 +136,16 @@ static hy_status materialise(const hy_column* base, const hy_row_id* rows, uint6
       uint32_t any = 0;
       HY_HIP(hipMemcpyAsync(&any, found.ptr, 4, hipMemcpyDeviceToHost, stream));
       HY_HIP(hipStreamSynchronize(stream));
-      if (any) return fail(HY_ERR_UNSUPPORTED, "hy_star_join_aggregate: a column of the join result holds NULLs -- run the operator chain");
+      if (any) {
+        uint64_t* words = reinterpret_cast<uint64_t*>(storage.as<char>() + values_bytes);
+        hipLaunchKernelGGL(null_bytes_to_words, dim3(static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 2048))), dim3(256), 0, stream, null_bytes.as<uint8_t>(), n, words);
+        null_words = words;   // (null_bytes goes back to this thread's pool when the block ends: handed out again in stream order, behind this kernel)
+      }
     } else {
       HY_TRY(hy_column_export(through.column, storage.ptr, nullptr));
     }
   }
-  return value_column(storage.ptr, n, base->data_type, out, chunk_rows);
+  return value_column(storage.ptr, n, base->data_type, out, chunk_rows, null_words);
 }
 
 // The rows of `filter_column` that satisfy the predicate, as one dense PosList in device memory

@@ -605,8 +605,8 @@ hy_status hy_scan_project_aggregate(const hy_filter* filters, uint32_t n_filters
  * Columns are named as (table, column): table 0 = the fact table, d + 1 = dimension d; every column is a DATA column (numeric, or a
  * dictionary of key names / join ids) of its table.  An aggregate reads `left` alone (op = HY_STAR_NO_OP), `left <op> right`
  * (HY_ARITH_*: hy_projection_arithmetic), or nothing (left.column = NULL: COUNT(*)).  *joined_rows: rows of the join result.
- * The intermediate tables carry no null vectors: HY_ERR_UNSUPPORTED if a cell the plan reads after the first join is NULL (a nullable foreign
- * key in a surviving row, a GROUP BY or aggregate column with NULLs) -- run the operator chain. */
+ * NULLs: a foreign key that is NULL finds no partner, a NULL aggregate input is skipped, NULL GROUP BY cells are a group of their own -- as in
+ * the operator chain (the plan's intermediate tables carry null vectors where a cell is NULL; such plans keep to the join-by-join / RowID paths). */
 enum { HY_MAX_STAR_DIMENSIONS = 8, HY_MAX_STAR_AGGREGATES = 8 };
 #define HY_STAR_NO_OP 0xFFFFFFFFu
 typedef struct hy_star_dimension {

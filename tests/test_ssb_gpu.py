@@ -176,9 +176,11 @@ def test_star_join_aggregate_small_tables(device, options, case, fused):
     assert got == want and (case != "nothing_survives" or n == 0)
 
 
-def test_star_join_aggregate_refuses_null_cells(device):
-    """The plan's intermediate tables carry no null vectors: a foreign key that is NULL in a row that survives the first join, or an
-    aggregate input with NULLs, sends the caller to the operator chain (HY_ERR_UNSUPPORTED) -- it is not joined as key 0."""
+def test_star_join_aggregate_with_null_cells(device):
+    """NULLs in what the plan reads (round 6: the plan's intermediate tables carry null vectors; before, such a plan was refused): a foreign key
+    that is NULL finds no partner -- it is not joined as key 0 --, a NULL aggregate input is skipped, a NULL GROUP BY cell is a group of its
+    own.  The fused probe does not read nullable foreign keys and star_finish carries no NULLs: these plans run join by join / on the RowID
+    path by themselves.  Against numpy."""
     import numpy as np
     from hyrise_amd import abi, storage
     from hyrise_amd.operators import star_join_aggregate
@@ -186,6 +188,8 @@ def test_star_join_aggregate_refuses_null_cells(device):
     rng = np.random.default_rng(3)
     n = 50_000
     a_key = np.arange(0, 200, dtype=np.int32)
+    a_group = rng.integers(0, 6, 200).astype(np.int32)
+    a_group_nulls = rng.random(200) < 0.1
     b_key = np.arange(0, 50, dtype=np.int32)                                  # (key 0 exists: a NULL exported as 0 would find it)
     fk_a = rng.integers(0, 200, n).astype(np.int32)
     fk_b = rng.integers(0, 50, n).astype(np.int32)
@@ -193,14 +197,33 @@ def test_star_join_aggregate_refuses_null_cells(device):
     nulls = rng.random(n) < 0.1
     column = lambda values, null=None, chunk=8_000: DeviceColumn(storage.make_column(values, null, abi.ENC_UNENCODED, chunk))
     a, b, fa, x_plain = column(a_key, None, 64), column(b_key, None, 64), column(fk_a), column(x)
+    group_plain, group_nullable = column(a_group, None, 64), column(a_group, a_group_nulls, 64)
     dimensions = lambda second_key: [(a, None, None, fa), (b, None, None, second_key)]
-    groupby = [(1, a)]
-    for second_key, measure in ((column(fk_b, nulls), x_plain), (column(fk_b), column(x, nulls))):
-        with pytest.raises(abi.HyriseAmdError) as error:
-            star_join_aggregate(dimensions(second_key), groupby, [(abi.AGG_SUM, (0, measure), None, None), (abi.AGG_MIN, groupby[0], None, None)])
-        assert error.value.status == abi.ERR_UNSUPPORTED
-    result, joined = star_join_aggregate(dimensions(column(fk_b)), groupby, [(abi.AGG_SUM, (0, x_plain), None, None), (abi.AGG_MIN, groupby[0], None, None)])
-    assert joined == n and result.n_groups == 200 and star_was_fused() == 2
+
+    def run(second_key, measure, group):
+        groupby = [(1, group)]
+        result, joined = star_join_aggregate(dimensions(second_key), groupby, [(abi.AGG_SUM, (0, measure), None, None), (abi.AGG_COUNT, (0, measure), None, None), (abi.AGG_COUNT, None, None, None),
+                                                                                (abi.AGG_MIN, groupby[0], None, None)])
+        return {result.column(3)[i]: (result.column(0)[i], result.column(1)[i], result.column(2)[i]) for i in range(result.n_groups)}, joined
+
+    def expected(key_nulls, measure_nulls, group_nulls):
+        keep = ~key_nulls if key_nulls is not None else np.ones(n, dtype=bool)
+        want = {}
+        for row in np.flatnonzero(keep):
+            g = None if group_nulls is not None and group_nulls[fk_a[row]] else int(a_group[fk_a[row]])
+            cell = want.setdefault(g, [None, 0, 0])
+            cell[2] += 1
+            if measure_nulls is None or not measure_nulls[row]:
+                cell[0] = (cell[0] or 0) + int(x[row])
+                cell[1] += 1
+        return {g: tuple(c) for g, c in want.items()}, int(keep.sum())
+
+    assert run(column(fk_b, nulls), x_plain, group_plain) == expected(nulls, None, None) and star_was_fused() == 0   # a nullable foreign key: join by join
+    assert run(column(fk_b), column(x, nulls), group_plain) == expected(None, nulls, None) and star_was_fused() == 1  # NULL inputs: star_finish hands over to the RowID path
+    assert run(column(fk_b), x_plain, group_nullable) == expected(None, None, a_group_nulls) and star_was_fused() == 1   # a NULL group
+    assert run(column(fk_b, nulls), column(x, nulls), group_nullable) == expected(nulls, nulls, a_group_nulls)
+    got, joined = run(column(fk_b), x_plain, group_plain)
+    assert joined == n and len(got) == 6 and star_was_fused() == 2
 
 
 def test_star_join_shapes_the_fused_probe_leaves_to_the_joins(device):
