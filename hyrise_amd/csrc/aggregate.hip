@@ -3361,6 +3361,10 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
       all_bits |= sort_key[i];
     }
     std::vector<uint32_t> scratch_order(n_groups);
+    if (n_groups <= 2048) {   // (a handful of groups -- TPC-H Q1 has four: two passes over 65 536 buckets cost 17 us of a 0.28 ms call)
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return sort_key[x] < sort_key[y]; });
+      all_bits = 0;
+    }
     for (uint32_t shift = 0; shift < 64 && (all_bits >> shift) != 0; shift += 16) {
       std::vector<uint32_t> bucket(65537, 0);
       for (uint32_t i = 0; i < n_groups; ++i) ++bucket[((sort_key[order[i]] >> shift) & 0xFFFF) + 1];
