@@ -3114,8 +3114,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     plan.debug = HY_DEBUG_ENV("HY_FUSED_DEBUG") ? static_cast<uint32_t>(atoi(HY_DEBUG_ENV("HY_FUSED_DEBUG"))) : 0u;
     for (uint32_t c = 0; c < fused->n_columns; ++c) plan.columns[c] = fused->columns[c]->d_segments;
     for (uint32_t d = 0; d < n_device; ++d) plan.inputs[d] = fused->inputs[spec_of_device[d]];
-    HY_HIP(hipMemcpyAsync(base, &plan, sizeof(plan), hipMemcpyHostToDevice, stream));
-    HY_HIP(hipStreamSynchronize(stream));   // (`plan` is a stack object)
+    HY_HIP(hipMemcpyAsync(base, &plan, sizeof(plan), hipMemcpyHostToDevice, stream));   // (`plan` lives until device_groups below has waited for the stream)
     // The TPC-H Q1 shape -- a handful of groups, filters on value ids, float expressions over dictionary columns -- has a kernel of its
     // own (fused_small.hpp); everything else, and whatever that kernel refuses at run time, takes fused_rows.
     FusedSmallPlan small_plan;
