@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-ssb", action="store_true", help="skip the SSB SF30 star-join leg (config 5)")
     ap.add_argument("--switch", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: one of the library's named switches (hyrise_amd/abi.py _SWITCHES, e.g. HY_JOIN_NO_HINT=1) for the whole run")
-    ap.add_argument("--placements", type=int, default=12, help="result-buffer placements the join's output pool is calibrated over before the timed region (1 = take the first)")
+    ap.add_argument("--placements", type=int, default=32, help="result-buffer placements the join's output pool is calibrated over before the timed region (1 = take the first)")
     ap.add_argument("--headline-only", action="store_true", help="only the timed TableScan + JoinHash step (no legs, no CPU baselines)")
     ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
                     help="file the full result object goes to (every leg, every case, prose); stdout gets the compact line only")
@@ -302,7 +302,10 @@ def compact_line(line, details_path=None):
         out["config"]["output_placement"] = cfg["output_placement"]
         out["config"]["workload"] += (", PosLists from the library's pool (hy_result_pool_calibrate over %d placements before the timed region); "
                                       "ms_per_step_median_placement: the step in the median candidate") % cfg["output_placement"]["candidates"]
-        out["config"]["output_placement"] = {k: v for k, v in cfg["output_placement"].items() if k != "by"}
+        placement = cfg["output_placement"]
+        times = sorted(placement.get("join_ms_per_candidate") or [0.0])   # (every candidate's time: bench_details.json)
+        out["config"]["output_placement"] = {"candidates": placement["candidates"], "chosen": placement.get("chosen"), "join_ms_fastest": times[0],
+                                             "join_ms_median": times[len(times) // 2], "join_ms_slowest": times[-1]}
     r = line["roofline"]
     roof = compact_roofline(r, "TableScan+JoinHash step, host-timed")
     roof["dominant_kernel"] = compact_roofline(r.get("dominant_kernel"))
