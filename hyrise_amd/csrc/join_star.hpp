@@ -212,13 +212,16 @@ __device__ __forceinline__ void star_load_words(const SliceView& view, uint32_t 
 // Which of the lane's eight rows have their key in the table (bits: the table's presence words, LDS)?
 template <uint32_t WIDTH>
 __device__ __forceinline__ uint32_t star_test_words(const u32x4_t (&words)[2], uint32_t bias, const StarTable& table, const uint32_t* bits) {
+  // (32-bit: the wrapped difference of two int32 values is their distance, or larger than any range.  A key outside the table asks bit
+  //  range + 1, which the host keeps zero -- one v_min instead of two compares and two selects per row: the kernel is bound by its
+  //  instructions, 117 M vector ones per SF30 pass, profiles/r06_star_traffic.txt)
   uint32_t found = 0;
-  const uint32_t delta = bias - table.key_min;
+  const uint32_t delta = bias - table.key_min, beyond = table.range + 1;
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j) {
-    const uint32_t rel = batch_word<WIDTH>(words, j) + delta;   // (32-bit: the wrapped difference of two int32 values is their distance, or larger than any range)
-    const uint32_t word = bits[rel <= table.range ? rel >> 5 : 0u];
-    found |= (rel <= table.range ? (word >> (rel & 31)) & 1u : 0u) << j;
+    const uint32_t distance = batch_word<WIDTH>(words, j) + delta;
+    const uint32_t rel = distance < beyond ? distance : beyond;
+    found |= ((bits[rel >> 5] >> (rel & 31)) & 1u) << j;
   }
   return found;
 }
@@ -233,13 +236,16 @@ struct StarTileWords {
   u32x4_t words[STAR_LDS_DIMENSIONS][2];
   uint32_t bias[STAR_LDS_DIMENSIONS];
 };
+template <uint32_t N_LDS>
 __device__ __forceinline__ void star_request_tile(const StarArgs& a, uint32_t tile, uint32_t first, StarTileWords& t, uint32_t (&kind)[STAR_LDS_DIMENSIONS], uint32_t* rows) {
   typedef __attribute__((address_space(1))) const u32x4_t global_quad;
   typedef __attribute__((address_space(1))) const uint32_t global_word;
   *rows = uniform_view(a.table[0].views + tile).row_count;
 #pragma unroll
   for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
-    const SliceView view = uniform_view(a.table[d < a.n_lds ? d : 0].views + tile);
+    kind[d] = 0;
+    if (d >= N_LDS) continue;   // (compile time: the kernel is instantiated per number of LDS-resident dimensions -- no load is under a run-time condition)
+    const SliceView view = uniform_view(a.table[d].views + tile);
     kind[d] = view.kind;
     const uint32_t width = view.kind == VIEW_FOR8 ? 1u : view.kind == VIEW_FOR16 ? 2u : 4u;
     const uint32_t row = view.row_begin + (first < view.row_count ? first : 0u);
@@ -257,20 +263,21 @@ __device__ __forceinline__ void star_request_tile(const StarArgs& a, uint32_t ti
 
 // Which of the tile's rows survive every dimension -> masks[tile], counts[tile] (zeroed by the host; a wave adds its survivors: no barrier --
 // the sixteen waves of the workgroup run their tiles' loads and lookups independently of each other)
+template <uint32_t N_LDS>
 __device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile, uint32_t tid, uint32_t first, const StarTileWords& t, const uint32_t (&kind)[STAR_LDS_DIMENSIONS], uint32_t rows,
                                                 const uint32_t* s_star_bits) {
   const uint32_t lane = tid & 63;
   uint32_t alive = first >= rows ? 0u : (rows - first < 8 ? (1u << (rows - first)) - 1u : 0xFFu);
 #pragma unroll
   for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
-    if (d >= a.n_lds) continue;
+    if (d >= N_LDS) continue;
     const uint32_t* bits = s_star_bits + a.table[d].lds_word;
     const uint32_t bias = kind[d] == VIEW_INT32 ? 0u : t.bias[d];
     alive &= kind[d] == VIEW_FOR8 ? star_test_words<1>(t.words[d], bias, a.table[d], bits) : kind[d] == VIEW_FOR16 ? star_test_words<2>(t.words[d], bias, a.table[d], bits)
                                                                                                                    : star_test_words<4>(t.words[d], bias, a.table[d], bits);
   }
   // the dimensions whose bits did not fit: asked in global memory, the rows that are still alive only
-  for (uint32_t d = a.n_lds; d < a.n_tables; ++d) {
+  for (uint32_t d = N_LDS; d < a.n_tables; ++d) {
     if (!__any(alive != 0)) break;
     const StarTable& table = a.table[d];
     const SliceView view = table.views[tile];
@@ -291,10 +298,11 @@ __device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile
 
 // Persistent workgroups, a tile's words requested while the tile before is looked up (two fixed sets of registers, the loop unrolled by two:
 // rotating one set into the other would wait for the loads just issued).
+template <uint32_t N_LDS>
 __global__ __launch_bounds__(STAR_THREADS) void star_probe_mask(StarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_star_bits[];
   const uint32_t tid = threadIdx.x;
-  for (uint32_t d = 0; d < a.n_lds; ++d) {
+  for (uint32_t d = 0; d < N_LDS; ++d) {
     const StarTable& table = a.table[d];
     for (uint32_t i = tid; i < table.words; i += STAR_THREADS) s_star_bits[table.lds_word + i] = table.bits[i];
   }
@@ -303,14 +311,14 @@ __global__ __launch_bounds__(STAR_THREADS) void star_probe_mask(StarArgs a) {
   const uint32_t last_tile = a.n_tiles - 1;   // (a tile past the last: the last one's words once more, not used)
   StarTileWords even, odd;
   uint32_t kind_even[STAR_LDS_DIMENSIONS], kind_odd[STAR_LDS_DIMENSIONS], rows_even = 0, rows_odd = 0;
-  if (blockIdx.x < a.n_tiles) star_request_tile(a, blockIdx.x, first, even, kind_even, &rows_even);
+  if (blockIdx.x < a.n_tiles) star_request_tile<N_LDS>(a, blockIdx.x, first, even, kind_even, &rows_even);
   for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += 2 * gridDim.x) {
     const uint32_t next = tile + gridDim.x, after = tile + 2 * gridDim.x;
-    star_request_tile(a, next < a.n_tiles ? next : last_tile, first, odd, kind_odd, &rows_odd);
-    star_probe_tile(a, tile, tid, first, even, kind_even, rows_even, s_star_bits);
+    star_request_tile<N_LDS>(a, next < a.n_tiles ? next : last_tile, first, odd, kind_odd, &rows_odd);
+    star_probe_tile<N_LDS>(a, tile, tid, first, even, kind_even, rows_even, s_star_bits);
     if (next >= a.n_tiles) break;
-    star_request_tile(a, after < a.n_tiles ? after : last_tile, first, even, kind_even, &rows_even);
-    star_probe_tile(a, next, tid, first, odd, kind_odd, rows_odd, s_star_bits);
+    star_request_tile<N_LDS>(a, after < a.n_tiles ? after : last_tile, first, even, kind_even, &rows_even);
+    star_probe_tile<N_LDS>(a, next, tid, first, odd, kind_odd, rows_odd, s_star_bits);
   }
 }
 
@@ -1183,7 +1191,7 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
     if (low < INT32_MIN || high > INT32_MAX || static_cast<uint64_t>(high - low) > STAR_MAX_RANGE) return HY_OK;   // (a sparse key: the rank table / directory of hy_join_hash)
     b.key_min = low;
     b.range = static_cast<uint64_t>(high - low);
-    b.words = static_cast<uint32_t>(b.range >> 5) + 1;
+    b.words = static_cast<uint32_t>((b.range + 1) >> 5) + 1;   // (one bit more than the range: what keys outside it ask, always zero)
     all_words += (size_t{b.words} + 7) & ~size_t{7};
   }
   HY_TRY(duplicate.alloc(4 * all_words + 64));
@@ -1289,12 +1297,22 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   static OncePerDevice lds_raised;
   uint64_t device_bit = 0;
   if (lds_raised.pending(&device_bit)) {
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
+    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
     lds_raised.done(device_bit);
   }
   const uint32_t probe_grid = std::max(1u, std::min(a.n_tiles, device_cu_count()));
   profile_begin(stream, HY_KERNEL_JOIN_PROBE);
-  hipLaunchKernelGGL(star_probe_mask, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a);
+  switch (a.n_lds) {   // (instantiated per number of LDS-resident dimensions: the kernel requests exactly their words, unconditionally)
+    case 0: hipLaunchKernelGGL(star_probe_mask<0>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
+    case 1: hipLaunchKernelGGL(star_probe_mask<1>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
+    case 2: hipLaunchKernelGGL(star_probe_mask<2>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
+    case 3: hipLaunchKernelGGL(star_probe_mask<3>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
+    default: hipLaunchKernelGGL(star_probe_mask<4>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
+  }
   profile_end(stream);
   hipLaunchKernelGGL(star_scan_counts, dim3(1), dim3(1024), 0, stream, counts.as<uint32_t>(), base.as<uint64_t>(), a.n_tiles);
   uint64_t total = 0;
