@@ -215,14 +215,23 @@ __device__ __forceinline__ uint32_t star_test_words(const u32x4_t (&words)[2], u
   // (32-bit: the wrapped difference of two int32 values is their distance, or larger than any range.  A key outside the table asks bit
   //  range + 1, which the host keeps zero -- one v_min instead of two compares and two selects per row: the kernel is bound by its
   //  instructions, 117 M vector ones per SF30 pass, profiles/r06_star_traffic.txt)
-  uint32_t found = 0;
+  //  Six vector instructions a lookup: unpack + add, clamp, word index (a bit-field extract, so that the compiler keeps index x 4 + base as
+  //  one shift-add), the LDS read, the bit (a bit-field extract at a variable offset), shift-or into the result.
+  typedef __attribute__((address_space(3))) const uint32_t lds_word;
   const uint32_t delta = bias - table.key_min, beyond = table.range + 1;
+  const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_word*)bits));
+  uint32_t rel[8], word[8];
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j) {
     const uint32_t distance = batch_word<WIDTH>(words, j) + delta;
-    const uint32_t rel = distance < beyond ? distance : beyond;
-    found |= ((bits[rel >> 5] >> (rel & 31)) & 1u) << j;
+    rel[j] = distance < beyond ? distance : beyond;
+    uint32_t index;   // (opaque to the optimiser, which otherwise rewrites (rel >> 5) * 4 + base as shift, mask, add)
+    asm("v_lshrrev_b32 %0, 5, %1" : "=v"(index) : "v"(rel[j]));
+    word[j] = *(lds_word*)static_cast<uintptr_t>(index * 4u + base);
   }
+  uint32_t found = 0;
+#pragma unroll
+  for (int j = 7; j >= 0; --j) found = (found << 1) | __builtin_amdgcn_ubfe(word[j], rel[j], 1);
   return found;
 }
 

@@ -20,7 +20,7 @@ for q in ("2.1", "4.1"):
     for d in ("f", "w", "s"):
         for f in glob.glob("$OUT/%s%s/**/*counter_collection.csv" % (d, q), recursive=True):
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0].replace("hy::", "")[:40]
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hy::", "")[:40]
                 if not k.startswith("star_"): continue
                 acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
     for k, v in sorted(acc.items()):
