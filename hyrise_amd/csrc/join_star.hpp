@@ -245,7 +245,7 @@ struct StarTileWords {
   u32x4_t words[STAR_LDS_DIMENSIONS][2];
   uint32_t bias[STAR_LDS_DIMENSIONS];
 };
-template <uint32_t N_LDS>
+template <uint32_t N_WORDS>
 __device__ __forceinline__ void star_request_tile(const StarArgs& a, uint32_t tile, uint32_t first, StarTileWords& t, uint32_t (&kind)[STAR_LDS_DIMENSIONS], uint32_t* rows) {
   typedef __attribute__((address_space(1))) const u32x4_t global_quad;
   typedef __attribute__((address_space(1))) const uint32_t global_word;
@@ -253,7 +253,7 @@ __device__ __forceinline__ void star_request_tile(const StarArgs& a, uint32_t ti
 #pragma unroll
   for (uint32_t d = 0; d < STAR_LDS_DIMENSIONS; ++d) {
     kind[d] = 0;
-    if (d >= N_LDS) continue;   // (compile time: the kernel is instantiated per number of LDS-resident dimensions -- no load is under a run-time condition)
+    if (d >= N_WORDS) continue;   // (compile time: the kernel is instantiated per number of dimensions whose words it streams -- no load is under a run-time condition)
     const SliceView view = uniform_view(a.table[d].views + tile);
     kind[d] = view.kind;
     const uint32_t width = view.kind == VIEW_FOR8 ? 1u : view.kind == VIEW_FOR16 ? 2u : 4u;
@@ -272,7 +272,7 @@ __device__ __forceinline__ void star_request_tile(const StarArgs& a, uint32_t ti
 
 // Which of the tile's rows survive every dimension -> masks[tile], counts[tile] (zeroed by the host; a wave adds its survivors: no barrier --
 // the sixteen waves of the workgroup run their tiles' loads and lookups independently of each other)
-template <uint32_t N_LDS>
+template <uint32_t N_LDS, uint32_t N_STREAM>
 __device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile, uint32_t tid, uint32_t first, const StarTileWords& t, const uint32_t (&kind)[STAR_LDS_DIMENSIONS], uint32_t rows,
                                                 const uint32_t* s_star_bits) {
   const uint32_t lane = tid & 63;
@@ -285,8 +285,44 @@ __device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile
     alive &= kind[d] == VIEW_FOR8 ? star_test_words<1>(t.words[d], bias, a.table[d], bits) : kind[d] == VIEW_FOR16 ? star_test_words<2>(t.words[d], bias, a.table[d], bits)
                                                                                                                    : star_test_words<4>(t.words[d], bias, a.table[d], bits);
   }
-  // the dimensions whose bits did not fit: asked in global memory, the rows that are still alive only
-  for (uint32_t d = N_LDS; d < a.n_tables; ++d) {
+  // The first dimension whose bits did not fit LDS, where a word slot is free (N_STREAM): its foreign keys are streamed like the others'
+  // -- coalesced, requested a tile ahead -- and only the bits of the rows that are still alive are asked in global memory (the table stays in
+  // the L2).  Reading those rows' keys one by one instead pulled a 128-byte line per 4-byte key: at SSB Q4.1's 4 % of surviving rows more
+  // bytes than the whole column, behind two dependent round trips per row (SSB Q4.1's probe 457 -> 390 us).
+#pragma unroll
+  for (uint32_t d = N_LDS; d < N_LDS + N_STREAM; ++d) {
+    if (!__any(alive != 0)) break;
+    const StarTable& table = a.table[d];
+    const uint32_t bias = kind[d] == VIEW_INT32 ? 0u : t.bias[d];
+    const uint32_t delta = bias - table.key_min;
+    const uint32_t width = kind[d] == VIEW_FOR8 ? 1u : kind[d] == VIEW_FOR16 ? 2u : 4u;
+    const uint32_t w[8] = {t.words[d][0].x, t.words[d][0].y, t.words[d][0].z, t.words[d][0].w, t.words[d][1].x, t.words[d][1].y, t.words[d][1].z, t.words[d][1].w};
+    typedef __attribute__((address_space(1))) const uint32_t global_word;
+    global_word* bits = (global_word*)table.bits;
+    const uint32_t beyond = table.range + 1;   // (a clear bit behind the table's last, as in LDS)
+    // (asked row by row, under the condition that the row is alive: asking a lane's first two survivors at once without a condition -- or all
+    //  eight rows -- was measured slower, 480 / 433 against 390 us: every lane then issues its loads and the pass is bound by their number)
+#define HY_STAR_STREAMED_KEY(J, REL)                                                                                                    \
+  {                                                                                                                                      \
+    const uint32_t byte = (J) * width, i = byte >> 2;                                                                                    \
+    const uint32_t a0 = i & 1 ? w[1] : w[0], a1 = i & 1 ? w[3] : w[2], a2 = i & 1 ? w[5] : w[4], a3 = i & 1 ? w[7] : w[6];               \
+    const uint32_t b0 = i & 2 ? a1 : a0, b1 = i & 2 ? a3 : a2; /* (w[i] without an indexed register file) */                             \
+    const uint32_t dword = i & 4 ? b1 : b0;                                                                                              \
+    const uint32_t distance = (width == 4 ? dword : (dword >> ((byte & 3u) * 8)) & (width == 1 ? 0xFFu : 0xFFFFu)) + delta;              \
+    REL = distance < beyond ? distance : beyond;                                                                                         \
+  }
+    uint32_t pending = alive;
+    while (pending) {
+      const uint32_t j = __ffs(pending) - 1;
+      pending &= pending - 1;
+      uint32_t rel;
+      HY_STAR_STREAMED_KEY(j, rel)
+      if (!__builtin_amdgcn_ubfe(bits[rel >> 5], rel, 1)) alive &= ~(1u << j);
+    }
+#undef HY_STAR_STREAMED_KEY
+  }
+  // the other dimensions whose bits did not fit: keys and bits asked in global memory, the rows that are still alive only
+  for (uint32_t d = N_LDS + N_STREAM; d < a.n_tables; ++d) {
     if (!__any(alive != 0)) break;
     const StarTable& table = a.table[d];
     const SliceView view = table.views[tile];
@@ -307,7 +343,7 @@ __device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile
 
 // Persistent workgroups, a tile's words requested while the tile before is looked up (two fixed sets of registers, the loop unrolled by two:
 // rotating one set into the other would wait for the loads just issued).
-template <uint32_t N_LDS>
+template <uint32_t N_LDS, uint32_t N_STREAM>
 __global__ __launch_bounds__(STAR_THREADS) void star_probe_mask(StarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_star_bits[];
   const uint32_t tid = threadIdx.x;
@@ -320,14 +356,14 @@ __global__ __launch_bounds__(STAR_THREADS) void star_probe_mask(StarArgs a) {
   const uint32_t last_tile = a.n_tiles - 1;   // (a tile past the last: the last one's words once more, not used)
   StarTileWords even, odd;
   uint32_t kind_even[STAR_LDS_DIMENSIONS], kind_odd[STAR_LDS_DIMENSIONS], rows_even = 0, rows_odd = 0;
-  if (blockIdx.x < a.n_tiles) star_request_tile<N_LDS>(a, blockIdx.x, first, even, kind_even, &rows_even);
+  if (blockIdx.x < a.n_tiles) star_request_tile<N_LDS + N_STREAM>(a, blockIdx.x, first, even, kind_even, &rows_even);
   for (uint32_t tile = blockIdx.x; tile < a.n_tiles; tile += 2 * gridDim.x) {
     const uint32_t next = tile + gridDim.x, after = tile + 2 * gridDim.x;
-    star_request_tile<N_LDS>(a, next < a.n_tiles ? next : last_tile, first, odd, kind_odd, &rows_odd);
-    star_probe_tile<N_LDS>(a, tile, tid, first, even, kind_even, rows_even, s_star_bits);
+    star_request_tile<N_LDS + N_STREAM>(a, next < a.n_tiles ? next : last_tile, first, odd, kind_odd, &rows_odd);
+    star_probe_tile<N_LDS, N_STREAM>(a, tile, tid, first, even, kind_even, rows_even, s_star_bits);
     if (next >= a.n_tiles) break;
-    star_request_tile<N_LDS>(a, after < a.n_tiles ? after : last_tile, first, even, kind_even, &rows_even);
-    star_probe_tile<N_LDS>(a, next, tid, first, odd, kind_odd, rows_odd, s_star_bits);
+    star_request_tile<N_LDS + N_STREAM>(a, after < a.n_tiles ? after : last_tile, first, even, kind_even, &rows_even);
+    star_probe_tile<N_LDS, N_STREAM>(a, next, tid, first, odd, kind_odd, rows_odd, s_star_bits);
   }
 }
 
@@ -1306,22 +1342,30 @@ hy_status star_probe_rows(const StarProbeDimension* dimensions, uint32_t n_dimen
   static OncePerDevice lds_raised;
   uint64_t device_bit = 0;
   if (lds_raised.pending(&device_bit)) {
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
-    HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
+#define HY_STAR_RAISE(L, S) HY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(star_probe_mask<L, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAR_LDS_WORDS));
+    HY_STAR_RAISE(0, 0) HY_STAR_RAISE(1, 0) HY_STAR_RAISE(2, 0) HY_STAR_RAISE(3, 0) HY_STAR_RAISE(4, 0)
+    HY_STAR_RAISE(0, 1) HY_STAR_RAISE(1, 1) HY_STAR_RAISE(2, 1) HY_STAR_RAISE(3, 1)
+#undef HY_STAR_RAISE
     lds_raised.done(device_bit);
   }
   const uint32_t probe_grid = std::max(1u, std::min(a.n_tiles, device_cu_count()));
   profile_begin(stream, HY_KERNEL_JOIN_PROBE);
-  switch (a.n_lds) {   // (instantiated per number of LDS-resident dimensions: the kernel requests exactly their words, unconditionally)
-    case 0: hipLaunchKernelGGL(star_probe_mask<0>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
-    case 1: hipLaunchKernelGGL(star_probe_mask<1>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
-    case 2: hipLaunchKernelGGL(star_probe_mask<2>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
-    case 3: hipLaunchKernelGGL(star_probe_mask<3>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
-    default: hipLaunchKernelGGL(star_probe_mask<4>, dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a); break;
+  // (instantiated per number of LDS-resident dimensions, and with or without a streamed one behind them -- the first dimension asked in
+  //  global memory, if a word slot is left: the kernel requests exactly their words, unconditionally)
+  const uint32_t streamed = a.n_lds < STAR_LDS_DIMENSIONS && a.n_lds < a.n_tables ? 1u : 0u;
+#define HY_STAR_LAUNCH(L, S) hipLaunchKernelGGL((star_probe_mask<L, S>), dim3(probe_grid), dim3(STAR_THREADS), 4 * size_t{lds_words}, stream, a)
+  switch (a.n_lds * 2 + streamed) {
+    case 0: HY_STAR_LAUNCH(0, 0); break;
+    case 1: HY_STAR_LAUNCH(0, 1); break;
+    case 2: HY_STAR_LAUNCH(1, 0); break;
+    case 3: HY_STAR_LAUNCH(1, 1); break;
+    case 4: HY_STAR_LAUNCH(2, 0); break;
+    case 5: HY_STAR_LAUNCH(2, 1); break;
+    case 6: HY_STAR_LAUNCH(3, 0); break;
+    case 7: HY_STAR_LAUNCH(3, 1); break;
+    default: HY_STAR_LAUNCH(4, 0); break;
   }
+#undef HY_STAR_LAUNCH
   profile_end(stream);
   hipLaunchKernelGGL(star_scan_counts, dim3(1), dim3(1024), 0, stream, counts.as<uint32_t>(), base.as<uint64_t>(), a.n_tiles);
   uint64_t total = 0;

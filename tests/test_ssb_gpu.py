@@ -283,6 +283,54 @@ def test_star_join_shapes_the_fused_probe_leaves_to_the_joins(device):
     assert run(keys, groups, foreign) == expected(keys, groups, foreign) and star_was_fused() == 1   # (five GROUP BY columns: not star_finish's shape)
 
 
+@pytest.mark.parametrize("layout", ["int32", "for32", "for16", "for8", "two_in_memory"])
+def test_star_join_streams_the_first_dimension_that_does_not_fit_lds(device, layout):
+    """Three dimensions, one with 1.5 M key values (its presence bits do not fit beside the others'): the probe streams its foreign keys with the
+    LDS-resident dimensions' and asks the surviving rows' bits in global memory -- per width of the stored foreign keys (plain int32; frame of
+    reference with 4-, 2- and 1-byte offsets: keys clustered per block narrow the offsets) and with a second such dimension behind it (that one
+    asked row by row).  A ragged last tile; against numpy."""
+    import numpy as np
+    from hyrise_amd import abi, storage
+    from hyrise_amd.operators import star_join_aggregate
+    from hyrise_amd.storage import DeviceColumn
+    rng = np.random.default_rng(11)
+    n_fact = 150_001
+    column = lambda values, encoding=abi.ENC_UNENCODED, chunk=20_000: DeviceColumn(storage.make_column(np.ascontiguousarray(values), None, encoding, chunk))
+    sizes = [1_500_000, 1_500_000, 300] if layout == "two_in_memory" else [1_500_000, 1_000, 300]
+    keys = [np.arange(10, 10 + n, dtype=np.int32) for n in sizes]
+    for d, n in enumerate(sizes):
+        if n > 100_000:
+            keys[d] = keys[d][rng.random(n) < 0.5]     # (half of a big dimension's keys exist)
+    groups = [(k % 3).astype(np.int32) for k in keys]
+    foreign = [rng.integers(5, 15 + n, n_fact).astype(np.int32) for n in sizes]
+    if layout in ("for16", "for8"):                    # (ascending with small steps: a block of 2048 rows spans < 65536 / < 256 values)
+        step = 9 if layout == "for16" else 0.1
+        foreign[0] = (5 + np.floor(np.arange(n_fact) * step) + rng.integers(0, 20, n_fact)).astype(np.int32)
+    encoding = abi.ENC_UNENCODED if layout == "int32" else abi.ENC_FRAME_OF_REFERENCE
+    dims = [(column(k, chunk=50_000), None, None, column(f, encoding)) for k, f in zip(keys, foreign)]
+    if layout in ("for16", "for8"):
+        stored = storage.make_column(np.ascontiguousarray(foreign[0]), None, abi.ENC_FRAME_OF_REFERENCE, 20_000)
+        widths = {segment.width for segment in stored.segments}
+        assert widths == {2 if layout == "for16" else 1}, widths
+    group_columns = [column(g, abi.ENC_FRAME_OF_REFERENCE, 50_000) for g in groups]
+    groupby = [(d + 1, g) for d, g in enumerate(group_columns)]
+    result, joined = star_join_aggregate(dims, groupby, [(abi.AGG_COUNT, None, None, None)])
+    assert star_was_fused() == 2
+    got = {tuple(int(result.column(1 + d)[i]) for d in range(3)): int(result.column(0)[i]) for i in range(result.n_groups)}
+    alive = np.ones(n_fact, dtype=bool)
+    codes = []
+    for k, fk in zip(keys, foreign):
+        position = np.searchsorted(k, fk)
+        found = (position < len(k)) & (k[np.minimum(position, len(k) - 1)] == fk)
+        alive &= found
+        codes.append(fk % 3)
+    want = {}
+    for c in zip(*(code[alive].tolist() for code in codes)):
+        want[c] = want.get(c, 0) + 1
+    assert joined == int(alive.sum()) and joined > 1000
+    assert got == want
+
+
 @pytest.mark.parametrize("case", ["immediate_key", "three_thousand_groups", "six_thousand_groups", "long_columns", "division_by_zero"])
 def test_star_finish_shapes(device, options, case):
     """star_finish (the aggregate inside the fused probe) against hy_aggregate_hash over the exported survivors -- the same bytes -- and numpy:
