@@ -314,7 +314,7 @@ def test_star_join_streams_the_first_dimension_that_does_not_fit_lds(device, lay
         assert widths == {2 if layout == "for16" else 1}, widths
     group_columns = [column(g, abi.ENC_FRAME_OF_REFERENCE, 50_000) for g in groups]
     groupby = [(d + 1, g) for d, g in enumerate(group_columns)]
-    result, joined = star_join_aggregate(dims, groupby, [(abi.AGG_COUNT, None, None, None)])
+    result, joined = star_join_aggregate(dims, groupby, [(abi.AGG_COUNT, None, None, None)] + [(abi.AGG_MIN, g, None, None) for g in groupby])
     assert star_was_fused() == 2
     got = {tuple(int(result.column(1 + d)[i]) for d in range(3)): int(result.column(0)[i]) for i in range(result.n_groups)}
     alive = np.ones(n_fact, dtype=bool)
