@@ -425,18 +425,24 @@ def join_keys(rank, rows):
 
 
 def timed_kernel(lib, torch, run, steps, every=1, kind=None, all_kinds=False):
-    """(seconds per call, kernel ms per timed launch): `run` repeated `steps` times after two warm-up calls.  kind: the kernel whose
+    """(seconds per call, kernel ms per timed launch): `run` repeated `steps` times after two warm-up calls, in up to five batches whose
+    median mean is the figure (the secondary legs only: the headline step is timed as one region, main()).  kind: the kernel whose
     HIP-event time is returned (default: every timed kernel of the call summed / timed launches); all_kinds: the kernel_times dict."""
     from hyrise_amd import abi
     for _ in range(2):
         run()
     abi.check(lib.hy_set_profiling(every))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    batches = min(5, steps)   # (the median of up to five batch means: one descheduled call of twenty otherwise decides a leg's figure)
+    means = []
+    for b in range(batches):
+        calls = steps // batches + (1 if b < steps % batches else 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            run()
+        torch.cuda.synchronize()
+        means.append((time.perf_counter() - t0) / calls)
+    dt = sorted(means)[len(means) // 2]
     kinds = kernel_times(lib)
     km, ln = C.c_float(0), C.c_uint32(0)
     abi.check(lib.hy_profile_read(C.byref(km), C.byref(ln)))
