@@ -102,6 +102,7 @@ struct AggArgs {
                               //        LDS tables (the host switches to the partitioned path), [3] rows that left the LDS tables so far
   uint32_t spill_limit;       // [3] above this sets [2]
   uint64_t* trace;            // debug (HY_AGG_TRACE): 12 wall-clock stamps per slice, else nullptr
+  uint32_t pos_cache;         // aggregate_rows: some column is a reference column -- the launch carries LDS for the slice's PosList offsets
 };
 enum : uint32_t { FLAG_OVERFLOW = 0, FLAG_GROUPS = 1, FLAG_GIVE_UP = 2, FLAG_SPILLED = 3, /* 4, 5: FLAG_PASSED */
                   FLAG_SMALL_REFUSED = 6 /* aggregate_small_domain: a 4-bit counter overflowed, run aggregate_rows */,
@@ -379,6 +380,16 @@ typedef __attribute__((address_space(1))) u32x4 global_u32x4;
 // rows 4m .. 4m+3 of a value / attribute-vector column are one wide load (16 bytes of floats, a dword of byte value ids).
 __device__ __forceinline__ uint32_t slice_row(uint32_t k, uint32_t tid) { return ((k >> 2) * 256 + tid) * 4 + (k & 3); }
 
+// aggregate_rows' PosList cache: the offsets of a thread's four consecutive rows in one LDS word -- the first offset (16 bits) and three
+// steps of at most 31 (what a scan's ascending PosList over one chunk gives; anything else -- a NULL RowID, a join's order, a chunk of more
+// than 65 536 rows -- is not encodable and the slice reads its PosLists from memory as before).
+__device__ __forceinline__ void cached_offsets(uint32_t word, uint32_t (&offset)[4]) {
+  offset[0] = word & 0xFFFFu;
+  offset[1] = offset[0] + ((word >> 16) & 31u);
+  offset[2] = offset[1] + ((word >> 21) & 31u);
+  offset[3] = offset[2] + (word >> 26);
+}
+
 __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t words = a.n_groupby + 1;
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
   uint32_t* s_present = s_n_groups + 4;                                                      // [8] direct-mapped pass 1: one bit per code met in the slice
   uint32_t* s_spilled = s_present + 8;                                                       // rows of the slice that did not fit the LDS table | the give-up flag as the workgroup saw it
   uint8_t* s_row_slot = reinterpret_cast<uint8_t*>(s_present + 12);                          // [SLICE_ROWS] LDS slot of every row of the slice (a thread's four consecutive rows: one word)
+  uint32_t* s_pos = reinterpret_cast<uint32_t*>(s_row_slot + SLICE_ROWS);                      // [SLICE_ROWS / 4] a.pos_cache: the PosList offsets of a thread's four consecutive rows (stage_pos_offsets)
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   for (uint32_t s = tid; s < LDS_SLOTS; s += 256) {
     s_tags[s] = TAG_EMPTY;
@@ -408,6 +420,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     *s_n_groups = 0;
     s_spilled[0] = 0;
     s_spilled[1] = __hip_atomic_load(&a.overflow[FLAG_GIVE_UP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_spilled[2] = 0;   // stage_pos_offsets: some block of four rows is not encodable
   }
   __syncthreads();
   if (s_spilled[1]) return;   // the table has too many groups for this kernel: the partitioned path takes over (every thread sees the same word)
@@ -452,6 +465,39 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       if ((seg.flags & SEG_UNALIGNED) && !key_pos[g]) keys_unaligned = true;   // (gathered value ids are read one by one: any alignment)
     }
   }
+  // ---- the slice's PosList, read ONCE ---------------------------------------------------------------------------------------------------
+  // The columns of a reference table share their PosList, and every column's pass over the slice used to read it again: 64 KB per slice and
+  // column, with a reuse distance of all the resident workgroups' slices -- more than an L2 holds, so TPC-H Q1 behind its scan read the
+  // 472 MB list five times (profiles/r06_q1_chain_launches.txt: 3.35 GB per launch).  Now the first referenced column's offsets are staged in
+  // LDS (a thread reads back only what it wrote: no barrier for the data) and every column behind the same list takes them from there.
+  const uint32_t* cached_pos = nullptr;
+  if (a.pos_cache) {
+#pragma unroll
+    for (uint32_t g = 0; g < MAX_GROUPBY; ++g) if (!cached_pos && key_pos[g]) cached_pos = key_pos[g];
+    for (uint32_t g = 0; g < a.n_aggregates && !cached_pos; ++g) {
+      const uint32_t* pos_words = nullptr;
+      if (a.aggregates[g].segments) resolve_segment(a.aggregates[g].segments[slice.chunk], &pos_words);
+      cached_pos = pos_words;
+    }
+    if (cached_pos) {
+      const global_u32* pos = reinterpret_cast<const global_u32*>(reinterpret_cast<uintptr_t>(cached_pos));
+      bool encodable = true;
+#pragma unroll
+      for (uint32_t k = 0; k < ROWS / 4; ++k) {
+        const uint32_t r0 = slice_row(k * 4, tid);
+        const uint32_t n = r0 < slice.row_count ? (slice.row_count - r0 < 4 ? slice.row_count - r0 : 4u) : 0u;
+        uint32_t offset[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) offset[i] = pos[2 * (size_t{slice.row_begin} + (n ? r0 + (i < n ? i : n - 1) : 0u)) + 1];   // (rows past the end: the last row's once more)
+        const uint32_t d1 = offset[1] - offset[0], d2 = offset[2] - offset[1], d3 = offset[3] - offset[2];
+        if (n && (offset[0] > 0xFFFFu || d1 > 31u || d2 > 31u || d3 > 31u)) encodable = false;
+        s_pos[k * 256 + tid] = n ? offset[0] | d1 << 16 | d2 << 21 | d3 << 26 : 0u;
+      }
+      if (!encodable) s_spilled[2] = 1;
+    }
+    __syncthreads();
+    if (s_spilled[2]) cached_pos = nullptr;
+  }
   // direct-mapped table?
   uint32_t direct_size[MAX_GROUPBY], direct_stride[MAX_GROUPBY];
 #pragma unroll
@@ -492,11 +538,16 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       uint32_t vid[BLOCKS][GB];
       if (key_pos[g]) {   // behind a PosList: the offsets of the thread's 32 rows (one batch of loads), then their value ids (another)
         uint32_t offset[BLOCKS][GB];
+        if (key_pos[g] == cached_pos) {
 #pragma unroll
-        for (uint32_t block = 0; block < BLOCKS; ++block) {
-          const uint32_t r0 = slice_row(block * GB, tid);
+          for (uint32_t block = 0; block < BLOCKS; ++block) cached_offsets(s_pos[block * 256 + tid], offset[block]);
+        } else {
 #pragma unroll
-          for (int i = 0; i < GB; ++i) offset[block][i] = key_pos[g][2 * size_t{slice.row_begin + (r0 + i < slice.row_count ? r0 + i : 0)} + 1];
+          for (uint32_t block = 0; block < BLOCKS; ++block) {
+            const uint32_t r0 = slice_row(block * GB, tid);
+#pragma unroll
+            for (int i = 0; i < GB; ++i) offset[block][i] = key_pos[g][2 * size_t{slice.row_begin + (r0 + i < slice.row_count ? r0 + i : 0)} + 1];
+          }
         }
 #pragma unroll
         for (uint32_t block = 0; block < BLOCKS; ++block) {
@@ -618,11 +669,15 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
       // the block's four rows are consecutive and start at a multiple of four: one aligned load of all four value ids
       // (not for the group that straddles the end of the chunk: nothing may be read behind a caller's buffer)
       if (key_pos[g]) {
+        uint32_t offset[GB];
+        if (key_pos[g] == cached_pos) {
+          cached_offsets(s_pos[block * 256 + tid], offset);
+        } else {
 #pragma unroll
-        for (int i = 0; i < GB; ++i) {
-          const uint32_t offset = key_pos[g][2 * size_t{row[i]} + 1];
-          vid[g][i] = offset == 0xFFFFFFFFu ? key_dictionary_size[g] : aload_compressed(key_data[g], key_width[g], offset);
+          for (int i = 0; i < GB; ++i) offset[i] = key_pos[g][2 * size_t{row[i]} + 1];
         }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) vid[g][i] = offset[i] == 0xFFFFFFFFu ? key_dictionary_size[g] : aload_compressed(key_data[g], key_width[g], offset[i]);
       } else if (key_width[g] == 1 && valid == 0xF) {
         const uint32_t four = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(key_data[g]) + row[0]);
 #pragma unroll
@@ -852,7 +907,18 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
             bits[i] = is_float ? static_cast<uint64_t>(__double_as_longlong(static_cast<double>(__uint_as_float(word)))) : static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(word)));
           }
         } else {
-          const uint32_t null_rows = value_pos_words ? dereference_rows<AB>(value_pos_words, row) : 0u;
+          uint32_t null_rows = 0;
+          if (value_pos_words && value_pos_words == cached_pos) {
+#pragma unroll
+            for (int m = 0; m < AB / 4; ++m) {
+              uint32_t offset[4];
+              cached_offsets(s_pos[(half * (AB / 4) + m) * 256 + tid], offset);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) row[4 * m + i] = offset[i];
+            }
+          } else if (value_pos_words) {
+            null_rows = dereference_rows<AB>(value_pos_words, row);
+          }
           decode_rows<AB>(value_segment, c.segments, slice.chunk, row, members, bits, &nulls);
           nulls |= null_rows;
         }
@@ -2550,7 +2616,7 @@ static hy_status device_groups(AggArgs a, const hy_column* shape, DeviceGroups& 
   hipStream_t stream = current_stream();
   const uint32_t words = a.n_groupby + 1;
   const uint32_t n_aggregates = a.n_aggregates;
-  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + 64 + SLICE_ROWS;
+  const size_t lds_bytes = size_t{LDS_SLOTS} * (8 * words + 16 + 12 * n_aggregates + 4 + 4) + 4 * DENSE_GROUPS + 64 + 64 + SLICE_ROWS + (a.pos_cache ? SLICE_ROWS : 0);   // (+ aggregate_rows' PosList offsets, one word per four rows)
   uint64_t two_per_row = 1024;
   while (two_per_row < 2 * shape->rows + 1024) two_per_row <<= 1;
   // the number of groups is not known: 64 Ki slots, then 2 Mi, then 32 Mi, then two slots per row (never overflows)
@@ -2936,7 +3002,9 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     for (uint32_t k = 0; k < c->n_chunks; ++k) if (c->host_segments[k].size != shape->host_segments[k].size) return false;
     return true;
   };
-  auto wire = [](AggColumn& slot, const hy_column* column, uint32_t function) {
+  bool reads_references = false;
+  auto wire = [&reads_references](AggColumn& slot, const hy_column* column, uint32_t function) {
+    if (column && column->is_reference) reads_references = true;
     slot.segments = column ? column->d_segments : nullptr;
     slot.data_type = column ? column->data_type : static_cast<uint32_t>(HY_TYPE_LONG);
     slot.is_float = column && (column->data_type == HY_TYPE_FLOAT || column->data_type == HY_TYPE_DOUBLE);
@@ -3217,6 +3285,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
         if (column && (a.aggregates[d].function == HY_AGG_MIN || a.aggregates[d].function == HY_AGG_MAX)) small.extremes |= 1u << small.column_of_aggregate[d];
       }
     }
+    a.pos_cache = reads_references ? 1u : 0u;
     HY_TRY(device_groups(a, shape, main_groups, nullptr, lean ? &small : nullptr));
   }
   lap("device groups on host");
@@ -3319,6 +3388,7 @@ static hy_status run_aggregate(const hy_column* const* groupby, uint32_t n_group
     inner.n_groupby = n_groupby + 1;
     inner.n_aggregates = 0;
     wire(inner.groupby[n_groupby], specs[g].column, 0);
+    inner.pos_cache = reads_references ? 1u : 0u;
     DeviceGroups combos;
     HY_TRY(device_groups(inner, shape, combos));
     std::map<std::vector<uint64_t>, uint32_t> group_of_key;

@@ -206,7 +206,13 @@ __device__ __forceinline__ bool plain_operand(const Operand& o, uint32_t chunk, 
 // One workgroup per 8192-row slice; a thread owns rows k*256 + tid (k = 0..31), decoded eight at a time (the loads of both
 // operands first).  Row r of a wave's round lands in bit (r % 64) of one bitmap word: the null words are one ballot each.
 __global__ __launch_bounds__(256) void projection_rows(ProjectionArgs a) {
-  const Slice slice = a.slices[blockIdx.x];
+  // Workgroup b runs on XCD b % 8, each with its own L2: of every 64 consecutive slices -- eight chunks of eight slices -- XCD x takes slices
+  // 8x .. 8x + 7, one chunk, so that a chunk's dictionary is fetched into ONE L2 (aggregate_rows' mapping).  In slice order all eight L2s
+  // gather from every chunk in flight: l_extendedprice's 240 KB dictionaries, 130 chunks at a time, do not fit, and the Q1 projection over
+  // that column read 5.97 GB for 0.78 GB of operands (profiles/r06_q1_chain_launches.txt: 860 us against the other three's 350-400).
+  uint32_t slice_index = blockIdx.x;
+  if ((blockIdx.x | 63u) < gridDim.x) slice_index = (blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u);
+  const Slice slice = a.slices[slice_index];
   const uint32_t lane = threadIdx.x & 63;
   char* values = static_cast<char*>(a.values) + a.value_base[slice.chunk];
   uint64_t* nulls = a.nulls + a.null_base[slice.chunk];

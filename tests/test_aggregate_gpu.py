@@ -495,3 +495,46 @@ def test_aggregate_result_in_device_memory(device):
         assert nulls[a][:groups].cpu().numpy().tobytes() == want.nulls[a][:groups].tobytes()
     result.group_capacity = 100   # too small: nothing is promised about the buffers, the group count is reported
     assert lib.hy_aggregate_hash(garr, 1, specs, len(spec), C.byref(result)) == abi.ERR_CAPACITY and int(result.n_groups) == 301
+
+
+@pytest.mark.parametrize("selectivity", [0.99, 0.5, 0.02])
+def test_aggregate_behind_a_scan_reads_the_shared_pos_list_once(device, selectivity):
+    """AggregateHash over the reference table a TableScan leaves (every column behind the SAME per-chunk PosList, as tpch.run_q1 builds it):
+    aggregate_rows stages a slice's offsets in LDS -- sixteen bits and three steps of at most 31 per four rows -- when the list is ascending and
+    dense enough (0.99, 0.5), and reads the list from memory per column when a step does not fit (0.02: steps of 50 on average).  Both against
+    numpy; a ragged last chunk; a second group of columns behind ANOTHER list of the same shape (compared by pointer: not the cached one)."""
+    import torch
+    from hyrise_amd.distributed import HipExecutor
+    from hyrise_amd.operators import make_predicate
+    rng = np.random.default_rng(int(selectivity * 100))
+    n, chunk = 150_001, 40_000
+    flag = rng.integers(0, 3, n).astype(np.int32)
+    other = rng.integers(0, 5, n).astype(np.int32)
+    value = rng.integers(-1000, 1000, n).astype(np.int32)
+    price = rng.integers(0, 50_000, n).astype(np.int32)
+    pick = (rng.random(n) < selectivity).astype(np.int32)
+    host = {"flag": storage.make_column(flag, None, abi.ENC_DICTIONARY, chunk), "other": storage.make_column(other, None, abi.ENC_DICTIONARY, chunk),
+            "value": storage.make_column(value, None, abi.ENC_UNENCODED, chunk), "price": storage.make_column(price, None, abi.ENC_DICTIONARY, chunk),
+            "pick": storage.make_column(pick, None, abi.ENC_UNENCODED, chunk)}
+    columns = {name: DeviceColumn(column) for name, column in host.items()}
+    ex = HipExecutor(torch.device("cuda:0"))
+    predicate = make_predicate(abi.PRED_EQUALS, abi.TYPE_INT, 1)
+    lists = ex.scan_chunked(columns["pick"], predicate)
+    again = ex.scan_chunked(columns["pick"], predicate)                       # the same rows in another buffer
+    ref = {name: ex.reference_column_chunked(column, lists) for name, column in columns.items()}
+    ref_again = {name: ex.reference_column_chunked(column, again) for name, column in columns.items()}
+    keep = pick == 1
+
+    def expected(keys):
+        want = {}
+        for row in np.flatnonzero(keep):
+            k = tuple(int(c[row]) for c in keys)
+            count, total, top, cheapest = want.get(k, (0, 0, -(1 << 40), 1 << 40))
+            want[k] = (count + 1, total + int(value[row]), max(top, int(price[row])), min(cheapest, int(value[row])))
+        return want
+
+    for groupby, keys, source in (([ref["flag"], ref["other"]], [flag, other], ref), ([ref["flag"]], [flag], ref_again), ([ref_again["other"]], [other], ref)):
+        aggregates = [(abi.AGG_COUNT, None), (abi.AGG_SUM, source["value"]), (abi.AGG_MAX, source["price"]), (abi.AGG_MIN, ref_again["value"])]
+        result = aggregate_hash(groupby, aggregates + [(abi.AGG_MIN, g) for g in groupby], group_capacity=64)
+        got = {tuple(result.column(4 + g)[i] for g in range(len(groupby))): tuple(result.column(a)[i] for a in range(4)) for i in range(result.n_groups)}
+        assert got == expected(keys)
