@@ -129,77 +129,142 @@ __host__ __device__ constexpr uint32_t common_type_of(uint32_t lhs, uint32_t rhs
   return HY_TYPE_INT;
 }
 
+// The stored words of four consecutive rows (row0 a multiple of four, all four inside the chunk): one 16-byte load, two for 8-byte types --
+// unconditional, so that a thread's loads of several groups and of both operands are in flight together (a load under a condition makes the
+// compiler wait for everything in flight where the paths meet: with one group per trip a wave had 16 bytes per lane in flight and the pass
+// ran at 1.9 TB/s, profiles/r06_q1_chain_launches.txt).
+struct RawFour { pu32x4 lo, hi; };
+struct PlainNulls { const uint8_t *x, *y; };   // the operands' null bitmaps as bytes (nullptr: the operand has no NULL)
+template <uint32_t TYPE>
+__device__ __forceinline__ RawFour raw_four(const void* data, uint32_t row0) {
+  RawFour r{};
+  if (!data) return r;   // (a literal: uniform for the whole launch)
+  if (TYPE == HY_TYPE_INT || TYPE == HY_TYPE_FLOAT) {
+    r.lo = reinterpret_cast<const global_pu32x4*>(reinterpret_cast<uintptr_t>(data))[row0 / 4];
+  } else {
+    r.lo = reinterpret_cast<const global_pu32x4*>(reinterpret_cast<uintptr_t>(data))[row0 / 2];
+    r.hi = reinterpret_cast<const global_pu32x4*>(reinterpret_cast<uintptr_t>(data))[row0 / 2 + 1];
+  }
+  return r;
+}
+template <uint32_t TYPE>
+__device__ __forceinline__ void values_of(const RawFour& r, Value (&out)[4]) {
+  const uint64_t wide[4] = {static_cast<uint64_t>(r.lo[1]) << 32 | r.lo[0], static_cast<uint64_t>(r.lo[3]) << 32 | r.lo[2], static_cast<uint64_t>(r.hi[1]) << 32 | r.hi[0],
+                            static_cast<uint64_t>(r.hi[3]) << 32 | r.hi[2]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[i] = Value{false, 0, 0.0};
+    if (TYPE == HY_TYPE_INT) out[i].i = static_cast<int32_t>(r.lo[i]);
+    else if (TYPE == HY_TYPE_FLOAT) out[i].f = static_cast<double>(__uint_as_float(r.lo[i]));
+    else if (TYPE == HY_TYPE_LONG) out[i].i = static_cast<int64_t>(wide[i]);
+    else out[i].f = __longlong_as_double(static_cast<long long>(wide[i]));
+  }
+}
+
 template <uint32_t OP, uint32_t AT, uint32_t BT>
-__device__ __forceinline__ void plain_slice(const ProjectionArgs& a, const Slice& slice, const void* x_data, const void* y_data, char* values) {
+__device__ __forceinline__ void plain_slice(const ProjectionArgs& a, const Slice& slice, const void* x_data, const void* y_data, char* values, const PlainNulls& operand_nulls) {
   constexpr uint32_t RT = common_type_of(AT, BT);
   constexpr bool WIDE = RT == HY_TYPE_LONG || RT == HY_TYPE_DOUBLE;
-#pragma unroll 2
-  for (uint32_t block = 0; block < SLICE_ROWS / 1024; ++block) {
-    const uint32_t r0 = (block * 256 + threadIdx.x) * 4;
-    if (r0 >= slice.row_count) continue;
-    const uint32_t row0 = slice.row_begin + r0;
-    Value x[4], y[4];
-    const uint32_t n_valid = slice.row_count - r0 < 4 ? slice.row_count - r0 : 4;
-    load_four<AT>(x_data, row0, n_valid, a.left.literal, x_data == nullptr, x);
-    load_four<BT>(y_data, row0, n_valid, a.right.literal, y_data == nullptr, y);
-    uint64_t bits[4];
+  constexpr uint32_t GROUPS = 4;   // groups of four rows a thread has in flight
+#pragma unroll 1
+  for (uint32_t base = 0; base < SLICE_ROWS / 1024; base += GROUPS) {
+    RawFour x_raw[GROUPS], y_raw[GROUPS];
+    uint32_t null_four[GROUPS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      Value result{false, 0, 0.0};
-      arithmetic_cell(OP, AT, BT, RT, x[i], y[i], &result);
-      if (RT == HY_TYPE_INT) bits[i] = static_cast<uint32_t>(static_cast<int32_t>(result.i));
-      else if (RT == HY_TYPE_LONG) bits[i] = static_cast<uint64_t>(result.i);
-      else if (RT == HY_TYPE_FLOAT) bits[i] = __float_as_uint(static_cast<float>(result.f));
-      else bits[i] = static_cast<uint64_t>(__double_as_longlong(result.f));
+    for (uint32_t g = 0; g < GROUPS; ++g) {   // the group that straddles the end of the chunk and the groups behind it ask the slice's first group (if that one is whole): nothing is read behind the buffer
+      const uint32_t r0 = ((base + g) * 256 + threadIdx.x) * 4;
+      const uint32_t from = slice.row_begin + (r0 + 3 < slice.row_count ? r0 : 0u);
+      const bool readable = slice.row_count >= 4;
+      x_raw[g] = raw_four<AT>(readable ? x_data : nullptr, from);
+      y_raw[g] = raw_four<BT>(readable ? y_data : nullptr, from);
+      typedef __attribute__((address_space(1))) const uint8_t global_byte;
+      uint32_t null_byte = 0;   // the four rows' bits: one nibble of a byte of each bitmap (from is a multiple of four)
+      if (operand_nulls.x) null_byte |= reinterpret_cast<global_byte*>(reinterpret_cast<uintptr_t>(operand_nulls.x))[from / 8];
+      if (operand_nulls.y) null_byte |= reinterpret_cast<global_byte*>(reinterpret_cast<uintptr_t>(operand_nulls.y))[from / 8];
+      null_four[g] = (null_byte >> (from & 4u)) & 0xFu;
     }
-    const bool whole = r0 + 3 < slice.row_count;
-    if (whole) {   // (the value buffers are 256-byte aligned per chunk, row0 is a multiple of four)
-      if (WIDE) {
-        pu32x4* out = reinterpret_cast<pu32x4*>(values) + row0 / 2;
-        __builtin_nontemporal_store(pu32x4{static_cast<uint32_t>(bits[0]), static_cast<uint32_t>(bits[0] >> 32), static_cast<uint32_t>(bits[1]), static_cast<uint32_t>(bits[1] >> 32)}, out);
-        __builtin_nontemporal_store(pu32x4{static_cast<uint32_t>(bits[2]), static_cast<uint32_t>(bits[2] >> 32), static_cast<uint32_t>(bits[3]), static_cast<uint32_t>(bits[3] >> 32)}, out + 1);
-      } else {
-        __builtin_nontemporal_store(pu32x4{static_cast<uint32_t>(bits[0]), static_cast<uint32_t>(bits[1]), static_cast<uint32_t>(bits[2]), static_cast<uint32_t>(bits[3])},
-                                    reinterpret_cast<pu32x4*>(values) + row0 / 4);
+#pragma unroll
+    for (uint32_t g = 0; g < GROUPS; ++g) {
+      const uint32_t r0 = ((base + g) * 256 + threadIdx.x) * 4;
+      if (r0 >= slice.row_count) continue;
+      const uint32_t row0 = slice.row_begin + r0;
+      Value x[4], y[4];
+      const uint32_t n_valid = slice.row_count - r0 < 4 ? slice.row_count - r0 : 4;
+      if (n_valid == 4) {
+        if (x_data) values_of<AT>(x_raw[g], x);
+        else load_four<AT>(x_data, row0, n_valid, a.left.literal, true, x);
+        if (y_data) values_of<BT>(y_raw[g], y);
+        else load_four<BT>(y_data, row0, n_valid, a.right.literal, true, y);
+      } else {   // (one group per chunk at most: row by row)
+        load_four<AT>(x_data, row0, n_valid, a.left.literal, x_data == nullptr, x);
+        load_four<BT>(y_data, row0, n_valid, a.right.literal, y_data == nullptr, y);
+        uint32_t null_byte = 0;
+        if (operand_nulls.x) null_byte |= operand_nulls.x[row0 / 8];
+        if (operand_nulls.y) null_byte |= operand_nulls.y[row0 / 8];
+        null_four[g] = (null_byte >> (row0 & 4u)) & 0xFu;
       }
-    } else {
+      uint64_t bits[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (r0 + i >= slice.row_count) break;
-        if (WIDE) reinterpret_cast<uint64_t*>(values)[row0 + i] = bits[i];
-        else reinterpret_cast<uint32_t*>(values)[row0 + i] = static_cast<uint32_t>(bits[i]);
+        Value result{false, 0, 0.0};
+        arithmetic_cell(OP, AT, BT, RT, x[i], y[i], &result);
+        if (RT == HY_TYPE_INT) bits[i] = static_cast<uint32_t>(static_cast<int32_t>(result.i));
+        else if (RT == HY_TYPE_LONG) bits[i] = static_cast<uint64_t>(result.i);
+        else if (RT == HY_TYPE_FLOAT) bits[i] = __float_as_uint(static_cast<float>(result.f));
+        else bits[i] = static_cast<uint64_t>(__double_as_longlong(result.f));
+        if ((null_four[g] >> i) & 1u) bits[i] = 0;   // NULL cells hold T{} (value_segment.hpp)
+      }
+      const bool whole = r0 + 3 < slice.row_count;
+      if (whole) {   // (the value buffers are 256-byte aligned per chunk, row0 is a multiple of four)
+        if (WIDE) {
+          pu32x4* out = reinterpret_cast<pu32x4*>(values) + row0 / 2;
+          __builtin_nontemporal_store(pu32x4{static_cast<uint32_t>(bits[0]), static_cast<uint32_t>(bits[0] >> 32), static_cast<uint32_t>(bits[1]), static_cast<uint32_t>(bits[1] >> 32)}, out);
+          __builtin_nontemporal_store(pu32x4{static_cast<uint32_t>(bits[2]), static_cast<uint32_t>(bits[2] >> 32), static_cast<uint32_t>(bits[3]), static_cast<uint32_t>(bits[3] >> 32)}, out + 1);
+        } else {
+          __builtin_nontemporal_store(pu32x4{static_cast<uint32_t>(bits[0]), static_cast<uint32_t>(bits[1]), static_cast<uint32_t>(bits[2]), static_cast<uint32_t>(bits[3])},
+                                      reinterpret_cast<pu32x4*>(values) + row0 / 4);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (r0 + i >= slice.row_count) break;
+          if (WIDE) reinterpret_cast<uint64_t*>(values)[row0 + i] = bits[i];
+          else reinterpret_cast<uint32_t*>(values)[row0 + i] = static_cast<uint32_t>(bits[i]);
+        }
       }
     }
   }
 }
 
 template <uint32_t OP, uint32_t AT>
-__device__ __forceinline__ void plain_slice_by_right(const ProjectionArgs& a, const Slice& slice, const void* x, const void* y, char* values) {
+__device__ __forceinline__ void plain_slice_by_right(const ProjectionArgs& a, const Slice& slice, const void* x, const void* y, char* values, const PlainNulls& n) {
   switch (a.right.type) {
-    case HY_TYPE_INT: plain_slice<OP, AT, HY_TYPE_INT>(a, slice, x, y, values); break;
-    case HY_TYPE_LONG: plain_slice<OP, AT, HY_TYPE_LONG>(a, slice, x, y, values); break;
-    case HY_TYPE_FLOAT: plain_slice<OP, AT, HY_TYPE_FLOAT>(a, slice, x, y, values); break;
-    default: plain_slice<OP, AT, HY_TYPE_DOUBLE>(a, slice, x, y, values); break;
+    case HY_TYPE_INT: plain_slice<OP, AT, HY_TYPE_INT>(a, slice, x, y, values, n); break;
+    case HY_TYPE_LONG: plain_slice<OP, AT, HY_TYPE_LONG>(a, slice, x, y, values, n); break;
+    case HY_TYPE_FLOAT: plain_slice<OP, AT, HY_TYPE_FLOAT>(a, slice, x, y, values, n); break;
+    default: plain_slice<OP, AT, HY_TYPE_DOUBLE>(a, slice, x, y, values, n); break;
   }
 }
 
 template <uint32_t OP>
-__device__ __forceinline__ void plain_slice_by_types(const ProjectionArgs& a, const Slice& slice, const void* x, const void* y, char* values) {
+__device__ __forceinline__ void plain_slice_by_types(const ProjectionArgs& a, const Slice& slice, const void* x, const void* y, char* values, const PlainNulls& n) {
   switch (a.left.type) {
-    case HY_TYPE_INT: plain_slice_by_right<OP, HY_TYPE_INT>(a, slice, x, y, values); break;
-    case HY_TYPE_LONG: plain_slice_by_right<OP, HY_TYPE_LONG>(a, slice, x, y, values); break;
-    case HY_TYPE_FLOAT: plain_slice_by_right<OP, HY_TYPE_FLOAT>(a, slice, x, y, values); break;
-    default: plain_slice_by_right<OP, HY_TYPE_DOUBLE>(a, slice, x, y, values); break;
+    case HY_TYPE_INT: plain_slice_by_right<OP, HY_TYPE_INT>(a, slice, x, y, values, n); break;
+    case HY_TYPE_LONG: plain_slice_by_right<OP, HY_TYPE_LONG>(a, slice, x, y, values, n); break;
+    case HY_TYPE_FLOAT: plain_slice_by_right<OP, HY_TYPE_FLOAT>(a, slice, x, y, values, n); break;
+    default: plain_slice_by_right<OP, HY_TYPE_DOUBLE>(a, slice, x, y, values, n); break;
   }
 }
 
-// operand of the fast path?  *data = its values in this chunk (nullptr: literal)
-__device__ __forceinline__ bool plain_operand(const Operand& o, uint32_t chunk, const void** data) {
+// operand of the fast path?  *data = its values in this chunk (nullptr: literal), *null_words = its bitmap (nullptr: none)
+__device__ __forceinline__ bool plain_operand(const Operand& o, uint32_t chunk, const void** data, const uint64_t** null_words) {
   *data = nullptr;
+  *null_words = nullptr;
   if (!o.segments) return o.type >= HY_TYPE_INT && o.type <= HY_TYPE_DOUBLE;   // (a NULL literal makes every cell NULL: generic path)
   const DevSegment& s = o.segments[chunk];
-  if (s.encoding != HY_ENC_UNENCODED || s.nulls || (s.flags & SEG_UNALIGNED)) return false;
+  if (s.encoding != HY_ENC_UNENCODED || (s.flags & SEG_UNALIGNED)) return false;
   *data = s.data;
+  *null_words = s.nulls;   // (what an earlier projection leaves always carries a bitmap: Q1's charge = disc_price * (1 + l_tax) reads two of them)
   return true;
 }
 
@@ -219,12 +284,17 @@ __global__ __launch_bounds__(256) void projection_rows(ProjectionArgs a) {
   const uint32_t at = a.left.type, bt = a.right.type, rt = a.result_type;
   if (a.op <= HY_ARITH_MUL) {
     const void *x_data, *y_data;
-    if (plain_operand(a.left, slice.chunk, &x_data) && plain_operand(a.right, slice.chunk, &y_data)) {
-      if (threadIdx.x < (slice.row_count + 63) / 64) nulls[slice.row_begin / 64 + threadIdx.x] = 0;   // + - * of non-NULL values: no NULL
+    const uint64_t *x_nulls, *y_nulls;
+    if (plain_operand(a.left, slice.chunk, &x_data, &x_nulls) && plain_operand(a.right, slice.chunk, &y_data, &y_nulls)) {
+      if (threadIdx.x < (slice.row_count + 63) / 64) {   // + - * make no NULL of their own: a cell is NULL where an operand's is (slices start at multiples of 8192: whole words)
+        const uint32_t word = slice.row_begin / 64 + threadIdx.x;
+        nulls[word] = (x_nulls ? x_nulls[word] : 0ull) | (y_nulls ? y_nulls[word] : 0ull);
+      }
+      const PlainNulls operand_nulls{reinterpret_cast<const uint8_t*>(x_nulls), reinterpret_cast<const uint8_t*>(y_nulls)};
       switch (a.op) {
-        case HY_ARITH_ADD: plain_slice_by_types<HY_ARITH_ADD>(a, slice, x_data, y_data, values); break;
-        case HY_ARITH_SUB: plain_slice_by_types<HY_ARITH_SUB>(a, slice, x_data, y_data, values); break;
-        default: plain_slice_by_types<HY_ARITH_MUL>(a, slice, x_data, y_data, values); break;
+        case HY_ARITH_ADD: plain_slice_by_types<HY_ARITH_ADD>(a, slice, x_data, y_data, values, operand_nulls); break;
+        case HY_ARITH_SUB: plain_slice_by_types<HY_ARITH_SUB>(a, slice, x_data, y_data, values, operand_nulls); break;
+        default: plain_slice_by_types<HY_ARITH_MUL>(a, slice, x_data, y_data, values, operand_nulls); break;
       }
       return;
     }

@@ -148,6 +148,32 @@ def test_plain_operands_all_type_pairs(device):
     assert_same(chained, oracle_arithmetic(abi.ARITH_MUL, (raw[abi.TYPE_DOUBLE], None), (inner_values, None)), "chained plain projections")
 
 
+def test_plain_operands_with_null_bitmaps(device):
+    """The same fast path over unencoded value segments that carry a null bitmap (what an earlier projection leaves, always): a cell is NULL
+    where an operand's is and holds T{}; chunk sizes that are no multiple of four rows (the group that straddles a chunk's end is read row
+    by row), every type pair, a NULL-free partner and a literal -- bit for bit the oracle's."""
+    rng = np.random.default_rng(63)
+    n, chunk = 40_003, 9_001
+    raw = {abi.TYPE_INT: rng.integers(-2**31, 2**31 - 1, n).astype(np.int32), abi.TYPE_LONG: rng.integers(-2**62, 2**62, n).astype(np.int64),
+           abi.TYPE_FLOAT: (rng.normal(0, 1e6, n)).astype(np.float32), abi.TYPE_DOUBLE: rng.normal(0, 1e12, n)}
+    nulls = {t: rng.random(n) < 0.07 for t in raw}
+    nulls[abi.TYPE_INT][-3:] = [True, False, True]   # (in the straddling group)
+    with_nulls = {t: DeviceColumn(build_column(values, nulls[t], chunk, abi.ENC_UNENCODED)) for t, values in raw.items()}
+    without = {t: DeviceColumn(build_column(values, None, chunk, abi.ENC_UNENCODED)) for t, values in raw.items()}
+    for op in (abi.ARITH_ADD, abi.ARITH_SUB, abi.ARITH_MUL):
+        for lt in raw:
+            for rt in raw:
+                assert_same(projection_arithmetic(op, with_nulls[lt], with_nulls[rt]), oracle_arithmetic(op, (raw[lt], nulls[lt]), (raw[rt], nulls[rt])), f"op {op} types {lt},{rt}, both nullable")
+                assert_same(projection_arithmetic(op, without[lt], with_nulls[rt]), oracle_arithmetic(op, (raw[lt], None), (raw[rt], nulls[rt])), f"op {op} types {lt},{rt}, right nullable")
+            assert_same(projection_arithmetic(op, with_nulls[lt], (abi.TYPE_INT, 3)), oracle_arithmetic(op, (raw[lt], nulls[lt]), (abi.TYPE_INT, 3)), f"op {op} {lt} nullable x literal")
+    # results as operands: (1 - x) * (1 + y), NULL where x or y is
+    left = projection_arithmetic(abi.ARITH_SUB, (abi.TYPE_INT, 1), with_nulls[abi.TYPE_FLOAT])
+    right = projection_arithmetic(abi.ARITH_ADD, (abi.TYPE_INT, 1), with_nulls[abi.TYPE_DOUBLE])
+    left_values, left_nulls = oracle_arithmetic(abi.ARITH_SUB, (abi.TYPE_INT, 1), (raw[abi.TYPE_FLOAT], nulls[abi.TYPE_FLOAT]))
+    right_values, right_nulls = oracle_arithmetic(abi.ARITH_ADD, (abi.TYPE_INT, 1), (raw[abi.TYPE_DOUBLE], nulls[abi.TYPE_DOUBLE]))
+    assert_same(projection_arithmetic(abi.ARITH_MUL, left, right), oracle_arithmetic(abi.ARITH_MUL, (left_values, left_nulls), (right_values, right_nulls)), "chained nullable projections")
+
+
 @pytest.mark.parametrize("np_type", [np.int32, np.int64, np.float32, np.float64], ids=lambda t: t.__name__)
 def test_export_through_pos_lists(device, np_type):
     """hy_column_export of a reference column (the foreign key of a join result, materialised for the next join): PosLists over several
