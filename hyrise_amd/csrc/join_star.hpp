@@ -287,8 +287,8 @@ __device__ __forceinline__ void star_probe_tile(const StarArgs& a, uint32_t tile
   }
   // The first dimension whose bits did not fit LDS, where a word slot is free (N_STREAM): its foreign keys are streamed like the others'
   // -- coalesced, requested a tile ahead -- and only the bits of the rows that are still alive are asked in global memory (the table stays in
-  // the L2).  Reading those rows' keys one by one instead pulled a 128-byte line per 4-byte key: at SSB Q4.1's 4 % of surviving rows more
-  // bytes than the whole column, behind two dependent round trips per row (SSB Q4.1's probe 457 -> 390 us).
+  // the L2).  Reading those rows' keys one by one instead cost a 128-byte line per 4-byte key -- at SSB Q4.1's 4 % of surviving rows nearly the
+  // column's bytes -- behind two dependent round trips per row (the probe 481 -> 389 us; traffic 2.04 -> 2.22 GB, profiles/r06_star_traffic.txt).
 #pragma unroll
   for (uint32_t d = N_LDS; d < N_LDS + N_STREAM; ++d) {
     if (!__any(alive != 0)) break;
