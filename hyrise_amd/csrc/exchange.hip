@@ -28,7 +28,10 @@ struct ExportArgs {
 };
 
 __global__ __launch_bounds__(256) void export_rows(ExportArgs a) {
-  const Slice slice = a.slices[blockIdx.x];
+  // (a chunk's eight slices on one XCD, so that one L2 fetches the chunk's dictionary: projection_rows' mapping)
+  uint32_t slice_index = blockIdx.x;
+  if ((blockIdx.x | 63u) < gridDim.x) slice_index = (blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u);
+  const Slice slice = a.slices[slice_index];
   if (slice.row_count == 0) return;
   const DevSegment s = a.segments[slice.chunk];
   const uint64_t base = a.row_base[slice.chunk] + slice.row_begin;
