@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
     // instead of one, and still several times faster than one LDS atomic per row into a private cell: ds_add_f64 retires
     // about one lane per cycle.
     // The usual aggregate column -- an unencoded, aligned 4-byte segment without NULLs -- skips the generic decoder.
-    const bool plain4 = c.segments && !value_pos_words && value_segment.encoding == HY_ENC_UNENCODED && !value_segment.nulls && !(value_segment.flags & SEG_UNALIGNED) &&
+    const bool plain4 = c.segments && !value_pos_words && value_segment.encoding == HY_ENC_UNENCODED && !(value_segment.flags & SEG_UNALIGNED) &&   // (with or without a null bitmap: a projection's result always has one)
                         (value_segment.data_type == HY_TYPE_INT || value_segment.data_type == HY_TYPE_FLOAT);
     uint64_t cell_value[DENSE_GROUPS];
     uint32_t cell_count[DENSE_GROUPS];   // the thread's non-NULL rows of every dense group: population counts
@@ -900,6 +900,15 @@ __global__ __launch_bounds__(256) void aggregate_rows(AggArgs a) {
           u32x4 raw[AB / 4];
 #pragma unroll
           for (int m = 0; m < AB / 4; ++m) raw[m] = base[row[4 * m] / 4];   // (rows past the slice's end were clamped to row 0 of the slice: their values are not taken)
+          if (value_segment.nulls) {   // the four rows' bits: a nibble of one byte of the bitmap (row[4 m] is a multiple of four)
+            typedef __attribute__((address_space(1))) const uint8_t global_byte;
+            global_byte* null_bytes = reinterpret_cast<global_byte*>(reinterpret_cast<uintptr_t>(value_segment.nulls));
+            uint32_t null_byte[AB / 4];
+#pragma unroll
+            for (int m = 0; m < AB / 4; ++m) null_byte[m] = null_bytes[row[4 * m] / 8];
+#pragma unroll
+            for (int m = 0; m < AB / 4; ++m) nulls |= ((null_byte[m] >> (row[4 * m] & 4u)) & 0xFu) << (4 * m);
+          }
           const bool is_float = value_segment.data_type == HY_TYPE_FLOAT;
 #pragma unroll
           for (int i = 0; i < AB; ++i) {

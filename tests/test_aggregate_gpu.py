@@ -135,8 +135,8 @@ def test_count_distinct_and_stddev(device):
 def test_direct_mapped_groups_and_plain_value_columns(device, n):
     """The fast paths of aggregate_rows: every GROUP BY column a dictionary segment with a small combined domain (the
     combined value-id code is the slot; codes above 31 take the LDS bitmap, more than four groups per slice take pass 3),
-    NULL keys, chunk ends that are no multiple of four rows, and unencoded 4-byte aggregate columns without NULLs (wide
-    loads) next to nullable / 8-byte ones (generic decoder)."""
+    NULL keys, chunk ends that are no multiple of four rows, and unencoded 4-byte aggregate columns with and without a null
+    bitmap (wide loads, the four rows' NULL bits from one byte of the bitmap) next to 8-byte ones (generic decoder)."""
     rng = np.random.default_rng(n)
     chunk = 65_535
     k1 = rng.integers(0, 40, n).astype(np.int32) * 3
@@ -148,11 +148,13 @@ def test_direct_mapped_groups_and_plain_value_columns(device, n):
     ints = build_column(rng.integers(-50_000, 50_000, n).astype(np.int32), None, chunk, abi.ENC_UNENCODED)
     floats = build_column((rng.random(n) * 100).astype(np.float32), None, chunk, abi.ENC_UNENCODED)
     nullable = build_column((rng.random(n) * 100).astype(np.float32), rng.random(n) < 0.1, chunk, abi.ENC_UNENCODED)
+    nullable_ints = build_column(rng.integers(-9_000, 9_000, n).astype(np.int32), rng.random(n) < 0.3, chunk, abi.ENC_UNENCODED)
     doubles = build_column(rng.normal(0.0, 1e3, n), None, chunk, abi.ENC_UNENCODED)
     longs = build_column(rng.integers(-10**14, 10**14, n).astype(np.int64), None, chunk, abi.ENC_UNENCODED)
     aggregates = [(abi.AGG_SUM, ints), (abi.AGG_AVG, ints), (abi.AGG_MIN, ints), (abi.AGG_MAX, floats), (abi.AGG_SUM, floats), (abi.AGG_AVG, floats),
                   (abi.AGG_SUM, nullable), (abi.AGG_COUNT, nullable)]
-    more = [(abi.AGG_MIN, floats), (abi.AGG_MAX, ints), (abi.AGG_SUM, doubles), (abi.AGG_MAX, longs), (abi.AGG_STDDEV_SAMP, floats), (abi.AGG_COUNT, None)]
+    more = [(abi.AGG_MIN, floats), (abi.AGG_MAX, ints), (abi.AGG_SUM, doubles), (abi.AGG_MAX, longs), (abi.AGG_STDDEV_SAMP, floats), (abi.AGG_COUNT, None),
+            (abi.AGG_MIN, nullable_ints)]
     got = run_both([g1, g2], aggregates, "246 codes")
     assert got.n_groups == 41 * 6
     run_both([g2, g1], more, "246 codes, other aggregates")
